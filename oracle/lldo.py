@@ -1,0 +1,188 @@
+"""ctypes binding of the CPU oracle (oracle/lld_oracle.c) and helpers to run the
+real reference binary (oracle/_ref/SMILExtract).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. The product (opensmile_amd/, include/) never
+imports this module.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+import wave
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+LIB_PATH = os.path.join(HERE, "liblld_oracle.so")
+
+WIN = {"rect": 0, "hann": 1, "ham": 2, "gauss": 3, "sine": 4, "tri": 5,
+       "bartlett": 6, "lanczos": 7}
+
+
+class MfccCfg(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_double), ("frame_size_sec", C.c_double),
+        ("frame_step_sec", C.c_double),
+        ("preemph_enable", C.c_int), ("preemph_k", C.c_float), ("preemph_de", C.c_int),
+        ("win_func", C.c_int), ("win_sigma", C.c_double), ("win_gain", C.c_double),
+        ("win_offset", C.c_double),
+        ("zero_pad_symmetric", C.c_int),
+        ("n_bands", C.c_int), ("lofreq", C.c_float), ("hifreq", C.c_float),
+        ("use_power", C.c_int), ("mel_htk_compatible", C.c_int),
+        ("first_mfcc", C.c_int), ("last_mfcc", C.c_int), ("cep_lifter", C.c_float),
+        ("mfcc_htk_compatible", C.c_int), ("melfloor", C.c_float),
+        ("n_delta", C.c_int), ("delta_win", C.c_int),
+    ]
+
+
+class Geom(C.Structure):
+    _fields_ = [("N", C.c_long), ("H", C.c_long), ("Nfft", C.c_long), ("K", C.c_long),
+                ("frame_size_sec_fft", C.c_double)]
+
+
+def build():
+    """(Re)build liblld_oracle.so (and oracle/_ref when /root/reference exists)."""
+    subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True)
+    if os.path.isdir("/root/reference/src"):
+        subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref"], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref_dsp = None
+_hook_keepalive = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        f32p = C.POINTER(C.c_float)
+        L.lldo_default_mfcc12_cfg.argtypes = [C.POINTER(MfccCfg)]
+        L.lldo_geometry.argtypes = [C.POINTER(MfccCfg), C.POINTER(Geom)]
+        L.lldo_num_frames.restype = C.c_long
+        L.lldo_num_frames.argtypes = [C.c_long, C.c_long, C.c_long]
+        L.lldo_mfcc_chain.restype = C.c_long
+        L.lldo_mfcc_chain.argtypes = [C.POINTER(MfccCfg), C.c_void_p, C.c_long, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lldo_delta_regression.restype = C.c_long
+        L.lldo_delta_regression.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p]
+        L.lldo_set_rfft_hook.argtypes = [C.c_void_p]
+        L.lldo_pcm16_to_float.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.lldo_window_table.argtypes = [C.c_int, C.c_long, C.c_double, C.c_double, C.c_void_p]
+        L.lldo_window_table.restype = C.c_int
+        L.lldo_rfft_frame.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(REF_DIR, "SMILExtract"))
+
+
+def use_reference_fft(enable=True):
+    """Plug the reference's own Ooura rdft (oracle/_ref/libref_dsp.so, compiled
+    from src/dspcore/fftsg.c) into the restatement -- pins every non-FFT stage
+    bit-for-bit against the real binary."""
+    global _ref_dsp
+    if not enable:
+        lib().lldo_set_rfft_hook(None)
+        return True
+    p = os.path.join(REF_DIR, "libref_dsp.so")
+    if not os.path.exists(p):
+        return False
+    if _ref_dsp is None:
+        _ref_dsp = C.CDLL(p)
+    lib().lldo_set_rfft_hook(C.cast(_ref_dsp.rdft, C.c_void_p))
+    return True
+
+
+def default_cfg():
+    c = MfccCfg()
+    lib().lldo_default_mfcc12_cfg(C.byref(c))
+    return c
+
+
+def geometry(cfg):
+    g = Geom()
+    lib().lldo_geometry(C.byref(cfg), C.byref(g))
+    return g
+
+
+def mfcc_chain(cfg, pcm, taps=False):
+    """pcm: int16 1-D array. Returns (T x Dtot) float32 [, dict of taps]."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    g = geometry(cfg)
+    T = lib().lldo_num_frames(len(pcm), g.N, g.H)
+    D = (cfg.last_mfcc - cfg.first_mfcc + 1) * (1 + cfg.n_delta)
+    out = np.zeros((max(T, 0), D), dtype=np.float32)
+    if T <= 0:
+        return (out, {}) if taps else out
+    tp = {}
+    ptrs = [None] * 4
+    if taps:
+        tp = {"win": np.zeros((T, g.N), np.float32), "fft": np.zeros((T, g.Nfft), np.float32),
+              "mag": np.zeros((T, g.K), np.float32), "mel": np.zeros((T, cfg.n_bands), np.float32)}
+        ptrs = [tp[k].ctypes.data for k in ("win", "fft", "mag", "mel")]
+    lib().lldo_mfcc_chain(C.byref(cfg), pcm.ctypes.data, len(pcm), out.ctypes.data, *ptrs)
+    return (out, tp) if taps else out
+
+
+def delta_regression(x, W):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    T, D = x.shape
+    y = np.zeros((T + W, D), np.float32)
+    lib().lldo_delta_regression(x.ctypes.data, T, D, W, y.ctypes.data)
+    return y
+
+
+# ------------------------------------------------------------ real reference
+def write_wav(path, pcm, fs=16000):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(fs)
+        w.writeframes(np.ascontiguousarray(pcm, dtype="<i2").tobytes())
+
+
+def read_htk(path):
+    """HTK parameter file as written by cHtkSink (src/iocore/htkSink.cpp:93-105,
+    183-202): 12-byte big-endian header + big-endian float32 rows."""
+    b = open(path, "rb").read()
+    n, period, size, kind = struct.unpack(">IIHH", b[:12])
+    a = np.frombuffer(b[12:], dtype=">f4").astype(np.float32)
+    return a.reshape(n, size // 4), period, kind
+
+
+def run_reference(conf_rel, pcm, fs=16000, extra_args=()):
+    """Run the real SMILExtract (oracle/_ref) on one utterance; returns the HTK
+    output matrix. conf_rel is relative to the reference's config/ directory."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    conf = os.path.join(REF_DIR, "config", conf_rel)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        out = os.path.join(td, "out.htk")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "0", "-nologfile",
+                        *extra_args], check=True, cwd=td,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if not os.path.exists(out):
+            return np.zeros((0, 0), np.float32)
+        return read_htk(out)[0]
+
+
+def delta_chain(x, W, n_orders):
+    """Tick-accurate delta chain; returns array (n_orders, T, D)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    T, D = x.shape
+    y = np.zeros((n_orders, T, D), np.float32)
+    L = lib()
+    L.lldo_delta_chain.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p]
+    L.lldo_delta_chain.restype = None
+    L.lldo_delta_chain(x.ctypes.data, T, D, W, n_orders, y.ctypes.data)
+    return y

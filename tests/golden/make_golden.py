@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference
+binary (oracle/_ref/SMILExtract, built from /root/reference by oracle/Makefile)
+on inputs from the synthetic-corpus contract (opensmile_amd/synth.py).
+
+Run from the repo root in a container that has /root/reference:
+    python tests/golden/make_golden.py
+The .npz files are committed; the GPU box only reads them.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import lldo  # noqa: E402
+from opensmile_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    lldo.build()
+    assert lldo.have_ref(), "oracle/_ref/SMILExtract missing (needs /root/reference)"
+    # config 2 shape, shortened: utterances 0 (zeros), 1 (square), 2, 3 (voiced), 10 (noise)
+    # at 1.0 s, plus ragged lengths around the frame boundary (399/400/401/559/560/561 samples)
+    cases = {}
+    for u in (0, 1, 2, 3, 10):
+        pcm = synth.utterance(u, 16000)
+        cases[f"u{u}_16000"] = pcm
+    for n in (399, 400, 401, 559, 560, 561, 1000):
+        cases[f"u7_{n}"] = synth.utterance(7, n)
+    ref = {}
+    for k, pcm in cases.items():
+        y = lldo.run_reference("mfcc/MFCC12_0_D_A.conf", pcm)
+        ref["pcm_" + k] = pcm
+        ref["out_" + k] = y
+        print(k, y.shape)
+    np.savez_compressed(os.path.join(OUT, "mfcc12_0_d_a_synth.npz"), **ref)
+
+    # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
+    import wave
+    wav = os.path.join(lldo.REF_DIR, "opensmile.wav")
+    with wave.open(wav, "rb") as w:
+        fs = w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()
+    y = lldo.run_reference("mfcc/MFCC12_0_D_A.conf", pcm, fs=fs)
+    print("config1", fs, pcm.shape, y.shape, y[0, :3])
+    np.savez_compressed(os.path.join(OUT, "mfcc12_0_d_a_config1.npz"), out=y, fs=fs,
+                        n_samples=len(pcm))
+
+
+if __name__ == "__main__":
+    main()
