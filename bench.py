@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config 2.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the fused LLD chain (MFCC12_0_D_A: int16 PCM ->
+13 MFCC + delta + accel) over one batch of synthetic audio: 1000 utterances x
+10 s, 16 kHz mono, 25 ms / 10 ms => 998 000 frames per GPU (configs[1]). PCM is
+resident in HBM before the timed region starts; outputs stay in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): utterances shard
+embarrassingly, every rank runs its own 1000 x 10 s batch ("weak" scaling, no
+data-path collective); the only collective in the path -- the gather of the
+feature matrices to rank 0 -- is opensmile_amd/gather.py and is reported
+separately (gather_ms) outside the timed region's `value`.
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+  roofline     -- dominant kernel (fused MFCC): algorithmic bytes per launch
+                  (372 B/frame) / average launch duration
+                  measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline -- the REAL reference (oracle/_ref/SMILExtract) timed on this
+                  box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_UTT = 1000          # config 2: 1000 x 10 s
+UTT_SAMPLES = 160000
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3
+ALG_BYTES_PER_FRAME_MAIN = 2 * 160 + 4 * 13      # int16 hop in + 13 f32 out
+ALG_BYTES_PER_FRAME_CHAIN = 2 * 160 + 4 * 39     # incl. delta/accel columns
+ALG_FLOP_PER_FRAME = 1.52e4
+
+
+def cpu_baseline(max_seconds=25.0):
+    """Time the real reference binary (one process per 10 s file, HTK output to
+    /dev/shm, log level 0) on all host cores; bounded sample, scaled to frames/s."""
+    from oracle import lldo
+    from opensmile_amd import synth
+    exe = os.path.join(lldo.REF_DIR, "SMILExtract")
+    conf = os.path.join(lldo.REF_DIR, "config", "mfcc", "MFCC12_0_D_A.conf")
+    cores = os.cpu_count() or 1
+    if not os.path.exists(exe):
+        # fall back to the C restatement ("port"), single thread
+        cfg = lldo.default_cfg()
+        pcm = synth.utterance(2, UTT_SAMPLES)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(max_seconds, 10.0):
+            lldo.mfcc_chain(cfg, pcm)
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"value": n * 998 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"{n} x 10 s utterances through oracle/lld_oracle.c (1 thread)"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as td:
+        n_unique = 8
+        for i in range(n_unique):
+            lldo.write_wav(os.path.join(td, f"u{i}.wav"), synth.utterance(2 + i, UTT_SAMPLES))
+        # calibrate on a few files, 1 core
+        t0 = time.perf_counter()
+        n_cal = 8
+        for i in range(n_cal):
+            subprocess.run([exe, "-C", conf, "-I", os.path.join(td, f"u{i % n_unique}.wav"),
+                            "-O", os.path.join(td, "cal.htk"), "-l", "0", "-nologfile"],
+                           cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        per_file = (time.perf_counter() - t0) / n_cal
+        one_core = 998 / per_file
+        n_files = int(max(cores * 4, min(2000, (max_seconds * 0.6) / per_file * cores)))
+        jobs = "\n".join(f"{i % n_unique} {i}" for i in range(n_files))
+        cmd = (f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {td}/u$0.wav -O {td}/o$1.htk "
+               f"-l 0 -nologfile >/dev/null 2>&1'")
+        t0 = time.perf_counter()
+        subprocess.run(cmd, shell=True, input=jobs.encode(), cwd=td, check=True)
+        dt = time.perf_counter() - t0
+        done = sum(1 for f in os.listdir(td) if f.startswith("o") and f.endswith(".htk"))
+    return {"value": done * 998 / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": (f"{done} x 10 s files, one SMILExtract process per file, {cores} in parallel "
+                       f"(xargs -P), -O /dev/shm/*.htk -l 0; {dt:.1f} s wall"),
+            "one_core_value": one_core}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--utts", type=int, default=N_UTT, help="utterances per GPU (default: config 2)")
+    args = ap.parse_args()
+
+    import torch
+    from opensmile_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    ctx = capi.Context(dev)
+    plan = capi.Plan(ctx)                       # MFCC12_0_D_A
+    n_out = plan.geometry.n_out
+    # this rank's shard of the corpus: utterances [rank*utts, (rank+1)*utts)
+    pcm, off = synth.corpus_tiled(args.utts, UTT_SAMPLES, n_unique=32)
+    batch = capi.Batch(plan, off)
+    frames = batch.total_frames
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_out = torch.empty((frames, n_out), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    plan.set_timing(True)                        # HIP events around each launch, same stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_main, ms_delta = plan.last_timing()
+    plan.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        fr = torch.tensor([frames], dtype=torch.int64, device="cuda")
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        total_frames = int(fr.item())
+    else:
+        total_frames = frames
+
+    # the path's one collective: gather feature matrices to rank 0 (outside `value`)
+    gather_ms = None
+    if world > 1:
+        from opensmile_amd import gather
+        barrier()
+        g0 = time.perf_counter()
+        gather.gather_features(d_out, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        value = total_frames * args.steps / dt
+        alg_bytes = ALG_BYTES_PER_FRAME_MAIN * frames
+        achieved = alg_bytes / (ms_main * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "MFCC frames/sec (16kHz, 25ms/10ms)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MFCC12_0_D_A (13 MFCC + delta + accel) on 1000 x 10 s synthetic 16 kHz mono "
+                                   "int16 per GPU, 25 ms / 10 ms, PCM resident in HBM",
+                       "utterances_per_gpu": args.utts, "frames_per_gpu": frames, "out_cols": n_out,
+                       "parallelism": f"utterance-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "fused MFCC (R0-R7)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME_MAIN,
+                         "kernel_ms": ms_main, "delta_kernel_ms": ms_delta,
+                         "fp32_valu_frac": (ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3)) / (FP32_PEAK_TFLOPS * 1e12)},
+        }
+        if gather_ms is not None:
+            res["gather_ms"] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the bench line down
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

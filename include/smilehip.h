@@ -1,0 +1,226 @@
+/*
+ * smilehip.h -- C ABI of libsmilehip.so: openSMILE's per-frame LLD hot path
+ * (framing -> pre-emphasis -> window -> real FFT -> magnitude -> mel bank ->
+ * log/DCT/lifter -> delta regression) as hand-written HIP kernels for
+ * MI355X (gfx950).
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only, no C++ or
+ * torch types. The openSMILE-side adapter (opensmile_amd/plugin/, a
+ * plugins/NAME.so registering components under the built-in names, see
+ * INTEGRATION.md) and the Python host mirror (opensmile_amd/capi.py) both bind
+ * exactly these symbols.
+ *
+ * Every entry point names the reference interface it replaces
+ * (paths relative to the audeering/opensmile v3.0.2 tree).
+ *
+ * Conventions
+ *  - All functions return SMILEHIP_OK (0) or a negative smilehip_status; they
+ *    never throw. smilehip_last_error() gives the message for the calling
+ *    thread's last failure (the C++ component turns it into COMP_ERR,
+ *    src/include/core/exceptions.hpp:137).
+ *  - Pointers named d_* are DEVICE pointers (HIP), h_* are host pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream). All
+ *    kernels are enqueued on it; nothing synchronises unless stated.
+ *  - Frame matrices are frame-major ("column-major by frame" in the reference's
+ *    words, cMatrix data[n + t*N], src/include/core/dataMemoryLevel.hpp:152-217):
+ *    element n of frame t is at base[t*ld + n].
+ *  - FLOAT_DMEM = float (src/include/core/smileTypes.h:28).
+ */
+#ifndef SMILEHIP_H
+#define SMILEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMILEHIP_VERSION 0x000100
+
+typedef enum smilehip_status {
+  SMILEHIP_OK = 0,
+  SMILEHIP_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+  SMILEHIP_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+  SMILEHIP_ERR_HIP = -3,         /* a HIP runtime call failed */
+  SMILEHIP_ERR_NOMEM = -4
+} smilehip_status;
+
+/* winFunc ids; names as cWindower's `winFunc` option accepts them
+ * (src/dspcore/windower.cpp:26-58, winFuncToInt in smileUtil.c) */
+typedef enum smilehip_winfunc {
+  SMILEHIP_WIN_RECT = 0, SMILEHIP_WIN_HANN = 1, SMILEHIP_WIN_HAMM = 2,
+  SMILEHIP_WIN_GAUSS = 3, SMILEHIP_WIN_SINE = 4, SMILEHIP_WIN_TRI = 5,
+  SMILEHIP_WIN_BARTLETT = 6, SMILEHIP_WIN_LANCZOS = 7
+} smilehip_winfunc;
+
+/* Parameters of the MFCC chain. Each group carries exactly the options the
+ * corresponding reference component reads in myFetchConfig(). */
+typedef struct smilehip_lld_config {
+  uint32_t struct_size;        /* = sizeof(smilehip_lld_config) */
+  /* cWaveSource (src/iocore/waveSource.cpp:190) + cFramer
+   * (src/core/winToVecProcessor.cpp:435-456): frameMode=fixed,
+   * frameCenterSpecial=left, noPostEOIprocessing=1 */
+  double sample_rate;
+  double frame_size_sec;
+  double frame_step_sec;
+  /* cVectorPreemphasis (src/dspcore/vectorPreemphasis.cpp:55,89-107);
+   * preemph=0: component not in the chain */
+  int32_t preemph;
+  float   preemph_k;
+  int32_t preemph_de;
+  /* cWindower (src/dspcore/windower.cpp:66-118) */
+  int32_t win_func;
+  double  win_sigma;
+  double  win_gain;
+  double  win_offset;
+  /* cTransformFFT (src/dspcore/transformFft.cpp:55-64) */
+  int32_t zero_pad_symmetric;
+  /* cMelspec (src/lldcore/melspec.cpp:66-136), specScale=mel, bwMethod=lr */
+  int32_t n_bands;
+  float   lofreq;
+  float   hifreq;
+  int32_t use_power;
+  int32_t mel_htk_compatible;
+  /* cMfcc (src/lldcore/mfcc.cpp:64-96) */
+  int32_t first_mfcc;
+  int32_t last_mfcc;
+  float   cep_lifter;
+  int32_t mfcc_htk_compatible;
+  float   melfloor;
+  /* cDeltaRegression x n_delta (src/dspcore/deltaRegression.cpp:58-91):
+   * 0 = static only, 1 = +delta, 2 = +delta+accel (cVectorConcat order) */
+  int32_t n_delta;
+  int32_t delta_win;
+} smilehip_lld_config;
+
+/* Integer geometry derived from the config -- the part of the contract that
+ * must be bit-exact. */
+typedef struct smilehip_geometry {
+  int64_t frame_size;      /* N  = frameSizeFrames */
+  int64_t frame_step;      /* H  = frameStepFrames */
+  int64_t fft_size;        /* Nfft */
+  int64_t n_bins;          /* K = Nfft/2+1 */
+  int32_t n_static;        /* lastMfcc-firstMfcc+1 */
+  int32_t n_out;           /* n_static*(1+n_delta): columns of the output */
+  double  frame_period;    /* seconds between frames: level period after cFramer */
+  double  fft_frame_size_sec; /* frameSizeSec after cTransformFFT (transformFft.cpp:66-96) */
+} smilehip_geometry;
+
+typedef struct smilehip_context smilehip_context;
+typedef struct smilehip_plan smilehip_plan;
+typedef struct smilehip_batch smilehip_batch;
+
+/* ------------------------------------------------------------ life cycle */
+int  smilehip_version(void);
+/* thread-local message of the last failing call (never NULL) */
+const char *smilehip_last_error(void);
+/* Opens HIP device `device`; fails (SMILEHIP_ERR_NO_DEVICE) unless it is a
+ * gfx950 part. There is NO CPU fallback anywhere in this library. */
+int  smilehip_init(int device, smilehip_context **ctx);
+void smilehip_shutdown(smilehip_context *ctx);
+int  smilehip_device_name(smilehip_context *ctx, char *buf, int buflen);
+
+/* fills c with config/mfcc/MFCC12_0_D_A.conf's values */
+void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c);
+
+/* Replaces the configure/finalise phase of the chain's components
+ * (cDataProcessor::myFinaliseInstance, src/core/dataProcessor.cpp:548-596 ->
+ * cWindower::precomputeWinFunc windower.cpp:159, cMelspec::computeFilters
+ * melspec.cpp:184, cMfcc::initTables mfcc.cpp:136): builds all tables on the
+ * host with the reference's double->float rounding and uploads them once. */
+int  smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_config *cfg, smilehip_plan **plan);
+/* Tables and geometry only, no device needed (table-level parity tests, config
+ * validation on a host without a GPU). Every compute entry point refuses such
+ * a plan with SMILEHIP_ERR_NO_DEVICE. */
+int  smilehip_plan_create_host_only(const smilehip_lld_config *cfg, smilehip_plan **plan);
+void smilehip_plan_destroy(smilehip_plan *plan);
+int  smilehip_plan_geometry(const smilehip_plan *plan, smilehip_geometry *g);
+/* cWinToVecProcessor framing rule: T = floor((S-N)/H)+1, 0 if S<N
+ * (src/core/winToVecProcessor.cpp:872-877) */
+int64_t smilehip_num_frames(const smilehip_plan *plan, int64_t n_samples);
+/* frame t's time stamp = t*H/fs (cMatrix::squashTimeMeta,
+ * src/core/dataMemoryLevel.cpp:617-626) and vIdx = t */
+double  smilehip_frame_time(const smilehip_plan *plan, int64_t t);
+/* host copies of the generated tables (for table-level parity tests); each
+ * returns the element count or a negative status. out may be NULL. */
+int64_t smilehip_plan_get_window(const smilehip_plan *plan, float *out, int64_t cap);
+int64_t smilehip_plan_get_mel_weights(const smilehip_plan *plan, float *out, int64_t cap);
+int64_t smilehip_plan_get_mel_chanmap(const smilehip_plan *plan, int32_t *out, int64_t cap);
+int64_t smilehip_plan_get_dct(const smilehip_plan *plan, float *out, int64_t cap);
+int64_t smilehip_plan_get_lifter(const smilehip_plan *plan, float *out, int64_t cap);
+
+/* ------------------------------------------------------- batched hot path */
+/* A batch = a set of utterances packed back to back in one int16 buffer.
+ * h_sample_offsets[n_utt+1]: utterance u occupies samples
+ * [off[u], off[u+1]) of the PCM buffer. The batch object owns the device-side
+ * work tables (utterance/frame offsets, tile table) and may be reused for any
+ * PCM buffer with the same layout. This replaces the reference's per-tick
+ * control flow (cComponentManager::tick, componentManager.cpp:1233-1261): the
+ * batch dimension the GPU needs does not exist there. */
+int  smilehip_batch_create(smilehip_plan *plan, const int64_t *h_sample_offsets, int32_t n_utt,
+                           smilehip_batch **batch);
+void smilehip_batch_destroy(smilehip_batch *batch);
+int64_t smilehip_batch_total_frames(const smilehip_batch *batch);
+/* h_frame_offsets[n_utt+1]: row range of utterance u in the output matrix */
+int  smilehip_batch_frame_offsets(const smilehip_batch *batch, int64_t *h_frame_offsets);
+
+/* The fused chain: R0 smilePcm_convertSamples (smileUtil.c:2527-2535) ->
+ * R1 cFramer -> R2 cVectorPreemphasis::processVector -> R3
+ * cWindower::processVector -> R4 cTransformFFT::processVector -> R5
+ * cFFTmagphase::processVector -> R6 cMelspec::processVector -> R7
+ * cMfcc::processVector -> R13 cDeltaRegression x n_delta + cVectorConcat.
+ * d_pcm: int16 mono samples (device). d_out: total_frames x ld_out floats,
+ * ld_out >= n_out; row = frame, columns [static | delta | accel].
+ * Asynchronous on `stream`. */
+int  smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *batch, const int16_t *d_pcm,
+                       float *d_out, int64_t ld_out, void *stream);
+
+/* Convenience for hosts that hold plain memory (the plugin / batch driver):
+ * H2D, run, D2H, synchronises. h_out must hold total_frames*n_out floats. */
+int  smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *batch, const int16_t *h_pcm,
+                            int64_t n_samples, float *h_out);
+
+/* HIP-event timing of smilehip_mfcc_run on this plan, per kernel (ms):
+ * smilehip_plan_set_timing(plan,1) resets the counters and makes every run
+ * record events on its stream before/after each launch;
+ * smilehip_plan_last_timing returns the AVERAGE launch duration over the runs
+ * recorded since (at most the last 128) -- call it after synchronising. */
+int  smilehip_plan_set_timing(smilehip_plan *plan, int enable);
+int  smilehip_plan_last_timing(smilehip_plan *plan, float *ms_main, float *ms_delta);
+
+/* ------------------------------------- per-component batched entry points */
+/* Same arithmetic, one reference component at a time, over n_frames frames;
+ * used by the plugin in per-component mode and by the stage-level parity
+ * tests. src/dst are device pointers, frame-major with leading dimensions. */
+
+/* R0: smilePcm_convertSamples, 16-bit mono (smileUtil.c:2527-2535) */
+int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t n, float *d_out, void *stream);
+/* R2: cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107) */
+int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
+                                int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream);
+/* R3: cWindower::processVector (windower.cpp:221-229); window of the plan */
+int smilehip_window_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
+                           int64_t ld_dst, int64_t n_frames, void *stream);
+/* R4: cTransformFFT::processVector forward (transformFft.cpp:165-223):
+ * N -> Nfft floats in Ooura's packed layout (fftsg.c:103-135) */
+int smilehip_rfft_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
+                         int64_t ld_dst, int64_t n_frames, void *stream);
+/* R5: cFFTmagphase::processVector magnitude branch (fftmagphase.cpp:215-221) */
+int smilehip_fftmag_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
+                           int64_t ld_dst, int64_t n_frames, void *stream);
+/* R6: cMelspec::processVector (melspec.cpp:519-570) */
+int smilehip_melspec_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
+                            int64_t ld_dst, int64_t n_frames, void *stream);
+/* R7: cMfcc::processVector (mfcc.cpp:239-273) */
+int smilehip_mfcc_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
+                         int64_t ld_dst, int64_t n_frames, void *stream);
+/* R13: n_orders chained cDeltaRegression::processBuffer (deltaRegression.cpp:
+ * 113-170) with the reference's end-of-input semantics, per utterance of the
+ * batch; reads columns [0,D) of d_io rows, writes columns [D, D*(1+n_orders)). */
+int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *batch, float *d_io, int64_t ld,
+                         int32_t D, int32_t W, int32_t n_orders, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMILEHIP_H */

@@ -1,0 +1,256 @@
+"""ctypes binding of libsmilehip.so's C ABI (include/smilehip.h).
+
+Python host mirror of the boundary: names and argument meaning follow the
+reference's component options (cFramer / cVectorPreemphasis / cWindower /
+cTransformFFT / cMelspec / cMfcc / cDeltaRegression). There is no CPU path in
+here: if the HIP library is missing or no gfx950 device is present every
+compute entry point raises SmileHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmilehip.so")
+
+WINFUNC = {"rec": 0, "rect": 0, "han": 1, "hann": 1, "ham": 2, "hamming": 2, "gau": 3,
+           "gauss": 3, "sin": 4, "sine": 4, "tri": 5, "bar": 6, "bartlett": 6, "lac": 7}
+
+
+class SmileHipError(RuntimeError):
+    pass
+
+
+class LldConfig(C.Structure):
+    """smilehip_lld_config"""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("sample_rate", C.c_double), ("frame_size_sec", C.c_double), ("frame_step_sec", C.c_double),
+        ("preemph", C.c_int32), ("preemph_k", C.c_float), ("preemph_de", C.c_int32),
+        ("win_func", C.c_int32), ("win_sigma", C.c_double), ("win_gain", C.c_double),
+        ("win_offset", C.c_double),
+        ("zero_pad_symmetric", C.c_int32),
+        ("n_bands", C.c_int32), ("lofreq", C.c_float), ("hifreq", C.c_float),
+        ("use_power", C.c_int32), ("mel_htk_compatible", C.c_int32),
+        ("first_mfcc", C.c_int32), ("last_mfcc", C.c_int32), ("cep_lifter", C.c_float),
+        ("mfcc_htk_compatible", C.c_int32), ("melfloor", C.c_float),
+        ("n_delta", C.c_int32), ("delta_win", C.c_int32),
+    ]
+
+
+class Geometry(C.Structure):
+    """smilehip_geometry"""
+    _fields_ = [("frame_size", C.c_int64), ("frame_step", C.c_int64), ("fft_size", C.c_int64),
+                ("n_bins", C.c_int64), ("n_static", C.c_int32), ("n_out", C.c_int32),
+                ("frame_period", C.c_double), ("fft_frame_size_sec", C.c_double)]
+
+
+# every symbol include/smilehip.h declares: (restype, argtypes)
+_vp, _i32, _i64, _f32, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+SYMBOLS = {
+    "smilehip_version": (C.c_int, []),
+    "smilehip_last_error": (C.c_char_p, []),
+    "smilehip_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "smilehip_shutdown": (None, [_vp]),
+    "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "smilehip_config_mfcc12_0_d_a": (None, [C.POINTER(LldConfig)]),
+    "smilehip_plan_create": (C.c_int, [_vp, C.POINTER(LldConfig), C.POINTER(_vp)]),
+    "smilehip_plan_create_host_only": (C.c_int, [C.POINTER(LldConfig), C.POINTER(_vp)]),
+    "smilehip_plan_destroy": (None, [_vp]),
+    "smilehip_plan_geometry": (C.c_int, [_vp, C.POINTER(Geometry)]),
+    "smilehip_num_frames": (_i64, [_vp, _i64]),
+    "smilehip_frame_time": (_dbl, [_vp, _i64]),
+    "smilehip_plan_get_window": (_i64, [_vp, _vp, _i64]),
+    "smilehip_plan_get_mel_weights": (_i64, [_vp, _vp, _i64]),
+    "smilehip_plan_get_mel_chanmap": (_i64, [_vp, _vp, _i64]),
+    "smilehip_plan_get_dct": (_i64, [_vp, _vp, _i64]),
+    "smilehip_plan_get_lifter": (_i64, [_vp, _vp, _i64]),
+    "smilehip_batch_create": (C.c_int, [_vp, _vp, _i32, C.POINTER(_vp)]),
+    "smilehip_batch_destroy": (None, [_vp]),
+    "smilehip_batch_total_frames": (_i64, [_vp]),
+    "smilehip_batch_frame_offsets": (C.c_int, [_vp, _vp]),
+    "smilehip_mfcc_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "smilehip_mfcc_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "smilehip_plan_set_timing": (C.c_int, [_vp, C.c_int]),
+    "smilehip_plan_last_timing": (C.c_int, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
+    "smilehip_pcm16_to_float": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "smilehip_preemphasis_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, C.c_int, _vp]),
+    "smilehip_window_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_rfft_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_fftmag_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_melspec_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_mfcc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_delta_chain": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsmilehip.so and bind every declared symbol. Raises if the
+    library has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmileHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C opensmile_amd/csrc). libsmilehip has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SmileHipError(f"smilehip error {rc}: {load().smilehip_last_error().decode()}")
+
+
+def mfcc12_0_d_a_config():
+    c = LldConfig()
+    load().smilehip_config_mfcc12_0_d_a(C.byref(c))
+    return c
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = _vp()
+        _check(load().smilehip_init(device, C.byref(self._h)))
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        _check(load().smilehip_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            load().smilehip_shutdown(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Configured chain (tables resident on the device)."""
+
+    def __init__(self, ctx, cfg=None):
+        self.ctx = ctx
+        self.cfg = cfg if cfg is not None else mfcc12_0_d_a_config()
+        self._h = _vp()
+        if ctx is None:      # host-only: tables + geometry, compute entry points refuse it
+            _check(load().smilehip_plan_create_host_only(C.byref(self.cfg), C.byref(self._h)))
+        else:
+            _check(load().smilehip_plan_create(ctx._h, C.byref(self.cfg), C.byref(self._h)))
+        g = Geometry()
+        _check(load().smilehip_plan_geometry(self._h, C.byref(g)))
+        self.geometry = g
+
+    def num_frames(self, n_samples):
+        return int(load().smilehip_num_frames(self._h, n_samples))
+
+    def frame_time(self, t):
+        return float(load().smilehip_frame_time(self._h, t))
+
+    def _table(self, fn, dtype):
+        n = fn(self._h, None, 0)
+        a = np.zeros(n, dtype)
+        fn(self._h, a.ctypes.data, n)
+        return a
+
+    def window(self):
+        return self._table(load().smilehip_plan_get_window, np.float32)
+
+    def mel_weights(self):
+        return self._table(load().smilehip_plan_get_mel_weights, np.float32)
+
+    def mel_chanmap(self):
+        return self._table(load().smilehip_plan_get_mel_chanmap, np.int32)
+
+    def dct(self):
+        g = self.geometry
+        return self._table(load().smilehip_plan_get_dct, np.float32).reshape(g.n_static, self.cfg.n_bands)
+
+    def lifter(self):
+        return self._table(load().smilehip_plan_get_lifter, np.float32)
+
+    def set_timing(self, on=True):
+        _check(load().smilehip_plan_set_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        a, b = _f32(), _f32()
+        _check(load().smilehip_plan_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            load().smilehip_plan_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A packed set of utterances (sample offsets) prepared for a plan."""
+
+    def __init__(self, plan, sample_offsets):
+        self.plan = plan
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        assert off.ndim == 1 and len(off) >= 1
+        self.n_utt = len(off) - 1
+        self.sample_offsets = off
+        self._h = _vp()
+        _check(load().smilehip_batch_create(plan._h, off.ctypes.data, self.n_utt, C.byref(self._h)))
+        self.total_frames = int(load().smilehip_batch_total_frames(self._h))
+        fo = np.zeros(self.n_utt + 1, np.int64)
+        _check(load().smilehip_batch_frame_offsets(self._h, fo.ctypes.data))
+        self.frame_offsets = fo
+
+    def run_device(self, d_pcm_ptr, d_out_ptr, ld_out, stream=None):
+        """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int)."""
+        _check(load().smilehip_mfcc_run(self.plan._h, self._h, d_pcm_ptr, d_out_ptr, ld_out, stream))
+
+    def run_host(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = np.zeros((self.total_frames, self.plan.geometry.n_out), np.float32)
+        _check(load().smilehip_mfcc_run_host(self.plan._h, self._h, pcm.ctypes.data, len(pcm),
+                                             out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            load().smilehip_batch_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def extract_mfcc(pcm_list, cfg=None, device=0):
+    """One-call helper: list of int16 arrays -> list of (T x n_out) matrices."""
+    ctx = Context(device)
+    plan = Plan(ctx, cfg)
+    lens = [len(p) for p in pcm_list]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([np.asarray(p, np.int16) for p in pcm_list]) if pcm_list else np.zeros(0, np.int16)
+    b = Batch(plan, off)
+    out = b.run_host(pcm)
+    res = [out[b.frame_offsets[i]:b.frame_offsets[i + 1]] for i in range(len(pcm_list))]
+    b.close()
+    plan.close()
+    ctx.close()
+    return res

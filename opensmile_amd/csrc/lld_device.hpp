@@ -1,0 +1,96 @@
+// Device helpers shared by the LLD kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace smilehip {
+
+// R0: smilePcm_convertSamples, 16-bit mono (smileUtil.c:2527-2535):
+// (float)s / 32767.0f, IEEE correctly rounded. Implemented as a reciprocal
+// multiply plus one exact-residual correction (Markstein): q0 = RN(s*r),
+// e = fma(-q0, 32767, s) (exact), q = RN(q0 + e*r). Verified against the
+// correctly-rounded quotient for all 65536 inputs by tests/test_gpu_stages.py
+// (and on the host by tests/test_host_logic.py with the same fmaf sequence).
+__device__ __forceinline__ float pcm16_to_float(int16_t s) {
+  const float a = (float)s;
+  const float r = 1.0f / 32767.0f;           // constant-folded, correctly rounded
+  const float q0 = a * r;
+  const float e = fmaf(-q0, 32767.0f, a);
+  return fmaf(e, r, q0);
+}
+
+// R6: one mel band in the reference's accumulation order
+// (cMelspec::processVector, melspec.cpp:544-553): ascending bins, first the
+// rising-slope run (p - p*w), then the falling-slope run (p*w). The reference
+// forms p*w as (float)((double)p*(double)w): a 24x24-bit product is exact in
+// double, so rounding it to float equals the float product.
+__device__ __forceinline__ float mel_band_exact(const float *p, const float *coef, const int32_t *rng,
+                                                int b, float scale) {
+  const int rl = rng[4 * b + 0], rh = rng[4 * b + 1], fl = rng[4 * b + 2], fh = rng[4 * b + 3];
+  float acc = 0.0f;
+  for (int n = rl; n < rh; ++n) {
+    const float a = p[n] * coef[n];
+    acc += p[n] - a;
+  }
+  for (int n = fl; n < fh; ++n) {
+    const float a = p[n] * coef[n];
+    acc += a;
+  }
+  return acc * scale;
+}
+
+// R4 core: in-place radix-2 DIT complex FFT of length M in LDS (re/im already
+// loaded in bit-reversed order), executed by the whole workgroup.
+__device__ __forceinline__ void block_cfft_radix2(float *re, float *im, int M, const float2 *tw_half) {
+  for (int len = 2; len <= M; len <<= 1) {
+    const int half = len >> 1;
+    const int tstep = M / len;
+    for (int b = threadIdx.x; b < (M >> 1); b += blockDim.x) {
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j;
+      const int i1 = i0 + half;
+      const float2 w = tw_half[j * tstep];
+      const float xr = re[i1], xi = im[i1];
+      const float tr = fmaf(xr, w.x, -xi * w.y);
+      const float ti = fmaf(xr, w.y, xi * w.x);
+      const float ar = re[i0], ai = im[i0];
+      re[i1] = ar - tr; im[i1] = ai - ti;
+      re[i0] = ar + tr; im[i0] = ai + ti;
+    }
+    __syncthreads();
+  }
+}
+
+// Real-FFT untangle of bin k (0 <= k <= M) from the half-length complex FFT Z
+// of z[i] = x[2i] + i x[2i+1]:
+//   X[k] = 1/2 [ (Z[k] + conj Z[M-k]) - i w^k (Z[k] - conj Z[M-k]) ],  w = e^{-2 pi i/(2M)}
+// Returns the standard DFT X[k] = sum x[n] e^{-2 pi i nk/Nfft}.
+__device__ __forceinline__ float2 untangle_bin(const float *re, const float *im, int M, int k,
+                                               const float2 *tw_full) {
+  if (k == 0) return make_float2(re[0] + im[0], 0.0f);
+  if (k == M) return make_float2(re[0] - im[0], 0.0f);
+  const float a = re[k], b = im[k], c = re[M - k], d = im[M - k];
+  const float2 w = (k <= (M >> 1)) ? tw_full[k] : make_float2(-tw_full[M - k].x, tw_full[M - k].y);
+  const float sr = a + c, si = b - d, dr = a - c, di = b + d;
+  return make_float2(0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr)), 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si)));
+}
+
+// R5: cFFTmagphase magnitude (fftmagphase.cpp:215-221)
+__device__ __forceinline__ float bin_magnitude(float2 X, bool edge) {
+  return edge ? fabsf(X.x) : __fsqrt_rn(X.x * X.x + X.y * X.y);
+}
+
+// R7: log floor (mfcc.cpp:239-243)
+__device__ __forceinline__ float log_mel(float v, float melfloor, float log_floor) {
+  return (v < melfloor) ? log_floor : logf(v);
+}
+
+// R7: one cepstral coefficient, sequential band order (mfcc.cpp:251-273)
+__device__ __forceinline__ float dct_coeff(const float *lmel, const float *row_c, int n_bands, float gain) {
+  float acc = 0.0f;
+  for (int m = 0; m < n_bands; ++m) acc += lmel[m] * row_c[m];
+  return acc * gain;
+}
+
+}  // namespace smilehip

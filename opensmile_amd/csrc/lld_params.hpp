@@ -1,0 +1,55 @@
+// Kernel parameter block shared by the host API (smilehip.cpp) and the device
+// code (lld_kernels.hip). Plain data, passed by value at launch.
+#pragma once
+#include <cstdint>
+
+namespace smilehip {
+
+struct LldParams {
+  // batch
+  const int16_t *pcm;          // packed utterances
+  const int64_t *samp_off;     // [n_utt+1] sample offsets (device)
+  const int64_t *frame_off;    // [n_utt+1] output row offsets (device)
+  const int32_t *tile_utt;     // [n_tiles] utterance of tile
+  const int32_t *tile_t0;      // [n_tiles] first frame of tile (within utterance)
+  int32_t n_utt;
+  int32_t n_tiles;
+  int64_t total_frames;
+  float *out;                  // [total_frames x ld_out]
+  int64_t ld_out;
+  // geometry
+  int32_t N, H, Nfft, K, pad_left;
+  // R2 / R3
+  int32_t preemph, de;
+  float k, one_minus_k, win_offset;
+  const float *window;         // [N]
+  // R4: complex FFT of length M = Nfft/2 + real untangle
+  const float2 *tw_half;       // [M/2]  e^{-2 pi i j / M}
+  const float2 *tw_full;       // [M/2+1] e^{-2 pi i k / Nfft}
+  // R6
+  const float *mel_coef;       // [K]
+  const int32_t *mel_rng;      // [4*n_bands] rise_lo, rise_hi, fall_lo, fall_hi per band
+  float mel_scale;
+  int32_t use_power, n_bands;
+  // R7
+  const float *dct_rows;       // [n_mfcc x n_bands], row = output position
+  const float *dct_gain;       // [n_mfcc]
+  int32_t n_mfcc;
+  float melfloor, log_floor;
+};
+
+struct DeltaParams {
+  const int64_t *frame_off;    // [n_utt+1]
+  const int32_t *row_utt;      // optional [total_frames] (unused when null)
+  int32_t n_utt;
+  int64_t total_frames;
+  float *io;                   // rows: [static D | delta D | accel D ...]
+  int64_t ld;
+  int32_t D, W, n_orders;
+  float norm;
+  int32_t short_T;             // utterances with T <= short_T go to the tick-accurate path
+  const int32_t *short_utts;   // [n_short]
+  int32_t n_short;
+};
+
+}  // namespace smilehip

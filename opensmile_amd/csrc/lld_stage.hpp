@@ -1,0 +1,20 @@
+// Launchers of the per-component kernels (lld_stage_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace smilehip {
+hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s);
+hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,
+                         int de, hipStream_t s);
+hipError_t stage_window(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
+                        const float *w, float off, hipStream_t s);
+hipError_t stage_rfft(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
+                      int pad_left, const float2 *twh, const float2 *twf, hipStream_t s);
+hipError_t stage_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, hipStream_t s);
+hipError_t stage_melspec(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_bands,
+                         int use_power, const float *coef, const int32_t *rng, float scale, hipStream_t s);
+hipError_t stage_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int n_bands, int n_mfcc,
+                      const float *rows, const float *gain, float melfloor, float log_floor, hipStream_t s);
+}  // namespace smilehip

@@ -1,0 +1,156 @@
+// Per-component batched kernels: one reference component at a time over a
+// block of frames (plugin per-component mode, stage-level parity tests).
+// Same device functions as the fused kernels, so results are identical.
+#include <hip/hip_runtime.h>
+
+#include "lld_device.hpp"
+#include "lld_stage.hpp"
+
+namespace smilehip {
+
+__global__ void k_pcm16_to_float(const int16_t *pcm, int64_t n, float *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pcm16_to_float(pcm[i]);
+}
+
+// cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107)
+__global__ void k_preemphasis(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
+                              float k, float omk, int de) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nF * N) return;
+  const int64_t f = i / N, n = i - f * N;
+  const float *x = src + f * lds;
+  float y;
+  if (n == 0) y = omk * x[0];
+  else y = de ? (x[n] + k * x[n - 1]) : (x[n] - k * x[n - 1]);
+  dst[f * ldd + n] = y;
+}
+
+// cWindower::processVector (windower.cpp:221-229)
+__global__ void k_window(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
+                         const float *w, float offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nF * N) return;
+  const int64_t f = i / N, n = i - f * N;
+  dst[f * ldd + n] = src[f * lds + n] * w[n] + offset;
+}
+
+// cTransformFFT::processVector forward (transformFft.cpp:165-223), packed as
+// Ooura's rdft does (fftsg.c:103-135): a[0]=Re X0, a[1]=Re X[n/2],
+// a[2k]=Re Xk, a[2k+1]=+sum x sin(2 pi jk/n) = -Im of the standard DFT.
+__global__ void __launch_bounds__(256) k_rfft(const float *src, int64_t lds, float *dst, int64_t ldd, int N,
+                                              int Nfft, int pad_left, const float2 *tw_half,
+                                              const float2 *tw_full) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = Nfft >> 1;
+  float *re = smem, *im = smem + M;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  const float *x = src + (int64_t)blockIdx.x * lds;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const int n0 = 2 * i - pad_left, n1 = n0 + 1;
+    const float v0 = (n0 >= 0 && n0 < N) ? x[n0] : 0.0f;
+    const float v1 = (n1 >= 0 && n1 < N) ? x[n1] : 0.0f;
+    const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+    re[r] = v0;
+    im[r] = v1;
+  }
+  __syncthreads();
+  block_cfft_radix2(re, im, M, tw_half);
+  float *o = dst + (int64_t)blockIdx.x * ldd;
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    const float2 X = untangle_bin(re, im, M, k, tw_full);
+    if (k == 0) o[0] = X.x;
+    else if (k == M) o[1] = X.x;
+    else { o[2 * k] = X.x; o[2 * k + 1] = -X.y; }
+  }
+}
+
+// cFFTmagphase::processVector, magnitude branch (fftmagphase.cpp:215-221)
+__global__ void k_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft) {
+  const int K = Nfft / 2 + 1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nF * K) return;
+  const int64_t f = i / K;
+  const int k = (int)(i - f * K);
+  const float *a = src + f * lds;
+  float m;
+  if (k == 0) m = fabsf(a[0]);
+  else if (k == K - 1) m = fabsf(a[1]);
+  else m = __fsqrt_rn(a[2 * k] * a[2 * k] + a[2 * k + 1] * a[2 * k + 1]);
+  dst[f * ldd + k] = m;
+}
+
+// cMelspec::processVector (melspec.cpp:519-570); one workgroup per frame so
+// the squared spectrum is staged once in LDS.
+__global__ void __launch_bounds__(256) k_melspec(const float *src, int64_t lds, float *dst, int64_t ldd, int K,
+                                                 int n_bands, int use_power, const float *coef,
+                                                 const int32_t *rng, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float *m = src + (int64_t)blockIdx.x * lds;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) smem[k] = use_power ? m[k] * m[k] : m[k];
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_bands; b += blockDim.x)
+    dst[(int64_t)blockIdx.x * ldd + b] = mel_band_exact(smem, coef, rng, b, scale);
+}
+
+// cMfcc::processVector (mfcc.cpp:239-273)
+__global__ void __launch_bounds__(64) k_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, int n_bands,
+                                             int n_mfcc, const float *rows, const float *gain, float melfloor,
+                                             float log_floor) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float *m = src + (int64_t)blockIdx.x * lds;
+  for (int b = threadIdx.x; b < n_bands; b += blockDim.x) smem[b] = log_mel(m[b], melfloor, log_floor);
+  __syncthreads();
+  for (int r = threadIdx.x; r < n_mfcc; r += blockDim.x)
+    dst[(int64_t)blockIdx.x * ldd + r] = dct_coeff(smem, rows + r * n_bands, n_bands, gain[r]);
+}
+
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_pcm16_to_float, dim3(nblk(n, 256)), dim3(256), 0, s, pcm, n, out);
+  return hipGetLastError();
+}
+hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,
+                         int de, hipStream_t s) {
+  if (nF * N > 0)
+    hipLaunchKernelGGL(k_preemphasis, dim3(nblk(nF * N, 256)), dim3(256), 0, s, src, lds, dst, ldd, nF, N, k,
+                       1 - k, de);
+  return hipGetLastError();
+}
+hipError_t stage_window(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
+                        const float *w, float off, hipStream_t s) {
+  if (nF * N > 0)
+    hipLaunchKernelGGL(k_window, dim3(nblk(nF * N, 256)), dim3(256), 0, s, src, lds, dst, ldd, nF, N, w, off);
+  return hipGetLastError();
+}
+hipError_t stage_rfft(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
+                      int pad_left, const float2 *twh, const float2 *twf, hipStream_t s) {
+  if (nF > 0)
+    hipLaunchKernelGGL(k_rfft, dim3((unsigned)nF), dim3(256), sizeof(float) * (size_t)Nfft, s, src, lds, dst, ldd,
+                       N, Nfft, pad_left, twh, twf);
+  return hipGetLastError();
+}
+hipError_t stage_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft,
+                        hipStream_t s) {
+  const int64_t n = nF * (Nfft / 2 + 1);
+  if (n > 0) hipLaunchKernelGGL(k_fftmag, dim3(nblk(n, 256)), dim3(256), 0, s, src, lds, dst, ldd, nF, Nfft);
+  return hipGetLastError();
+}
+hipError_t stage_melspec(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_bands,
+                         int use_power, const float *coef, const int32_t *rng, float scale, hipStream_t s) {
+  if (nF > 0)
+    hipLaunchKernelGGL(k_melspec, dim3((unsigned)nF), dim3(256), sizeof(float) * (size_t)(K + 4), s, src, lds, dst,
+                       ldd, K, n_bands, use_power, coef, rng, scale);
+  return hipGetLastError();
+}
+hipError_t stage_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int n_bands, int n_mfcc,
+                      const float *rows, const float *gain, float melfloor, float log_floor, hipStream_t s) {
+  if (nF > 0)
+    hipLaunchKernelGGL(k_mfcc, dim3((unsigned)nF), dim3(64), sizeof(float) * (size_t)(n_bands + 4), s, src, lds,
+                       dst, ldd, n_bands, n_mfcc, rows, gain, melfloor, log_floor);
+  return hipGetLastError();
+}
+
+}  // namespace smilehip

@@ -1,0 +1,579 @@
+// libsmilehip.so -- C ABI implementation (see include/smilehip.h).
+// Host side: table generation (tables.cpp), device buffers, launch logic.
+// There is no CPU fallback: every compute entry point launches HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/smilehip.h"
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+#include "tables.hpp"
+
+using namespace smilehip;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(SMILEHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+extern "C" const char *smilehip_last_error(void) { return g_err.c_str(); }
+extern "C" int smilehip_version(void) { return SMILEHIP_VERSION; }
+
+// ----------------------------------------------------------------- objects
+struct smilehip_context {
+  int device = 0;
+  hipDeviceProp_t prop{};
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int upload(const std::vector<T> &h) {
+    release();
+    n = h.size();
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    if (n) HIP_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return SMILEHIP_OK;
+  }
+};
+
+struct smilehip_plan {
+  smilehip_context *ctx = nullptr;
+  smilehip_lld_config cfg{};
+  Geometry geo;
+  std::vector<float> h_window;
+  MelBank mel;
+  DctTables dct;
+  DevBuf<float> d_window, d_mel_coef, d_dct_rows, d_dct_gain;
+  DevBuf<int32_t> d_mel_rng;
+  DevBuf<float2> d_tw_half, d_tw_full, d_tw16x16;
+  // timing
+  // HIP-event timing ring: slot i holds {before main, after main, after delta}
+  static constexpr int kRing = 128;
+  bool timing = false;
+  hipEvent_t ev[kRing][3] = {};
+  int64_t n_timed = 0;
+  int force_generic = 0;
+  ~smilehip_plan() {
+    for (auto &slot : ev)
+      for (auto &e : slot)
+        if (e) (void)hipEventDestroy(e);
+  }
+};
+
+struct smilehip_batch {
+  smilehip_plan *plan = nullptr;
+  int32_t n_utt = 0;
+  int64_t total_frames = 0;
+  std::vector<int64_t> h_samp_off, h_frame_off;
+  std::vector<int32_t> h_short;
+  DevBuf<int64_t> d_samp_off, d_frame_off;
+  DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short;
+  int32_t n_tiles = 0;
+};
+
+// ------------------------------------------------------------- life cycle
+extern "C" int smilehip_init(int device, smilehip_context **out) {
+  if (!out) return fail(SMILEHIP_ERR_INVALID, "smilehip_init: null output pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(SMILEHIP_ERR_NO_DEVICE, "no HIP device visible (libsmilehip has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(SMILEHIP_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  auto *c = new (std::nothrow) smilehip_context();
+  if (!c) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+    delete c;
+    return fail(SMILEHIP_ERR_HIP, "cannot open HIP device %d", device);
+  }
+  if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = c->prop.gcnArchName;
+    delete c;
+    return fail(SMILEHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                arch.c_str());
+  }
+  *out = c;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_shutdown(smilehip_context *ctx) { delete ctx; }
+
+extern "C" int smilehip_device_name(smilehip_context *ctx, char *buf, int buflen) {
+  if (!ctx || !buf || buflen <= 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_device_name: bad argument");
+  snprintf(buf, buflen, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c) {
+  std::memset(c, 0, sizeof(*c));
+  c->struct_size = sizeof(*c);
+  c->sample_rate = 16000.0;
+  c->frame_size_sec = 0.0250;
+  c->frame_step_sec = 0.010;
+  c->preemph = 1;
+  c->preemph_k = 0.97f;
+  c->preemph_de = 0;
+  c->win_func = SMILEHIP_WIN_HAMM;
+  c->win_sigma = 0.4;
+  c->win_gain = 1.0;
+  c->win_offset = 0.0;
+  c->zero_pad_symmetric = 0;
+  c->n_bands = 26;
+  c->lofreq = 0.0f;
+  c->hifreq = 8000.0f;
+  c->use_power = 1;
+  c->mel_htk_compatible = 1;
+  c->first_mfcc = 0;
+  c->last_mfcc = 12;
+  c->cep_lifter = 22.0f;
+  c->mfcc_htk_compatible = 1;
+  c->melfloor = 1e-8f;
+  c->n_delta = 2;
+  c->delta_win = 2;
+}
+
+// ------------------------------------------------------------------- plan
+static int build_tables(smilehip_plan *p, bool upload = true) {
+  int rc;
+  if ((rc = make_geometry(p->cfg, p->geo)) != SMILEHIP_OK) return fail(rc, "invalid framing parameters");
+  if (p->geo.Nfft > 8192) return fail(SMILEHIP_ERR_INVALID, "FFT length %lld > 8192 unsupported", (long long)p->geo.Nfft);
+  if ((rc = make_window(p->cfg, p->geo.N, p->h_window)) != SMILEHIP_OK) return fail(rc, "unknown window function %d", p->cfg.win_func);
+  if ((rc = make_mel(p->cfg, p->geo, p->mel)) != SMILEHIP_OK) return fail(rc, "invalid mel bank parameters");
+  if ((rc = make_dct(p->cfg, p->dct)) != SMILEHIP_OK) return fail(rc, "invalid MFCC range");
+  if (p->cfg.n_delta < 0 || p->cfg.n_delta > 2) return fail(SMILEHIP_ERR_INVALID, "n_delta must be 0..2");
+  if (p->cfg.n_delta > 0 && (p->cfg.delta_win < 1 || p->cfg.delta_win > 4))
+    return fail(SMILEHIP_ERR_INVALID, "delta_win must be 1..4");
+
+  const int64_t M = p->geo.Nfft / 2;
+  std::vector<float2> twh(static_cast<size_t>(M / 2 > 0 ? M / 2 : 1)), twf(static_cast<size_t>(M / 2 + 1));
+  for (int64_t j = 0; j < M / 2; ++j) {
+    const double a = -2.0 * M_PI * double(j) / double(M);
+    twh[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+  }
+  for (int64_t k = 0; k <= M / 2; ++k) {
+    const double a = -2.0 * M_PI * double(k) / double(p->geo.Nfft);
+    twf[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+  }
+  std::vector<int32_t> rng(size_t(4) * p->mel.n_bands);
+  for (int b = 0; b < p->mel.n_bands; ++b) {
+    rng[4 * b + 0] = p->mel.rise_lo[b];
+    rng[4 * b + 1] = p->mel.rise_hi[b];
+    rng[4 * b + 2] = p->mel.fall_lo[b];
+    rng[4 * b + 3] = p->mel.fall_hi[b];
+  }
+  if (!upload) return SMILEHIP_OK;
+  if ((rc = p->d_window.upload(p->h_window))) return rc;
+  if ((rc = p->d_mel_coef.upload(p->mel.coef))) return rc;
+  if ((rc = p->d_mel_rng.upload(rng))) return rc;
+  if ((rc = p->d_dct_rows.upload(p->dct.cos_rows))) return rc;
+  if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
+  if ((rc = p->d_tw_half.upload(twh))) return rc;
+  if ((rc = p->d_tw_full.upload(twf))) return rc;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_config *cfg, smilehip_plan **out) {
+  if (!ctx || !cfg || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(smilehip_lld_config))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(smilehip_lld_config));
+  HIP_TRY(hipSetDevice(ctx->device));
+  auto *p = new (std::nothrow) smilehip_plan();
+  if (!p) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->cfg = *cfg;
+  const char *fg = getenv("SMILEHIP_FORCE_GENERIC");
+  p->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+  int rc = build_tables(p);
+  if (rc != SMILEHIP_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_plan_create_host_only(const smilehip_lld_config *cfg, smilehip_plan **out) {
+  if (!cfg || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_create_host_only: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(smilehip_lld_config))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(smilehip_lld_config));
+  auto *p = new (std::nothrow) smilehip_plan();
+  if (!p) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  p->cfg = *cfg;
+  int rc = build_tables(p, false);
+  if (rc != SMILEHIP_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
+
+extern "C" int smilehip_plan_geometry(const smilehip_plan *p, smilehip_geometry *g) {
+  if (!p || !g) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_geometry: null argument");
+  g->frame_size = p->geo.N;
+  g->frame_step = p->geo.H;
+  g->fft_size = p->geo.Nfft;
+  g->n_bins = p->geo.K;
+  g->n_static = p->dct.n_mfcc;
+  g->n_out = p->dct.n_mfcc * (1 + p->cfg.n_delta);
+  g->frame_period = p->geo.frame_period;
+  g->fft_frame_size_sec = p->geo.fft_frame_size_sec;
+  return SMILEHIP_OK;
+}
+
+extern "C" int64_t smilehip_num_frames(const smilehip_plan *p, int64_t n_samples) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_num_frames: null plan");
+  if (n_samples < p->geo.N) return 0;
+  return (n_samples - p->geo.N) / p->geo.H + 1;
+}
+
+extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
+  // vIdx * level period; the framer's level period is frameStep
+  // (winToVecProcessor.cpp:562-568), time = vIdx*T via squashTimeMeta
+  return p ? double(t) * p->geo.frame_period : 0.0;
+}
+
+template <typename T>
+static int64_t copy_out(const std::vector<T> &v, T *out, int64_t cap) {
+  if (out) {
+    if (cap < (int64_t)v.size()) return fail(SMILEHIP_ERR_INVALID, "output buffer too small");
+    std::memcpy(out, v.data(), v.size() * sizeof(T));
+  }
+  return (int64_t)v.size();
+}
+extern "C" int64_t smilehip_plan_get_window(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->h_window, o, cap); }
+extern "C" int64_t smilehip_plan_get_mel_weights(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->mel.coef, o, cap); }
+extern "C" int64_t smilehip_plan_get_mel_chanmap(const smilehip_plan *p, int32_t *o, int64_t cap) { return copy_out(p->mel.chan, o, cap); }
+extern "C" int64_t smilehip_plan_get_dct(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->dct.cos_rows, o, cap); }
+extern "C" int64_t smilehip_plan_get_lifter(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->dct.lifter, o, cap); }
+
+// ------------------------------------------------------------------ batch
+extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, int32_t n_utt, smilehip_batch **out) {
+  if (!plan || !out || n_utt < 0 || (n_utt > 0 && !h_off)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_create: bad argument");
+  *out = nullptr;
+  if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached (tables only)");
+  HIP_TRY(hipSetDevice(plan->ctx->device));
+  auto *b = new (std::nothrow) smilehip_batch();
+  if (!b) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  b->plan = plan;
+  b->n_utt = n_utt;
+  b->h_samp_off.assign(h_off, h_off + (n_utt ? n_utt + 1 : 0));
+  if (n_utt == 0) b->h_samp_off.assign(1, 0);
+  b->h_frame_off.assign(size_t(n_utt) + 1, 0);
+  const int short_T = 4 * plan->cfg.delta_win;
+  std::vector<int32_t> tile_utt, tile_t0;
+  const int tile_frames = launch_tile_frames((int)plan->geo.Nfft, (int)plan->geo.N, plan->force_generic);
+  for (int32_t u = 0; u < n_utt; ++u) {
+    const int64_t len = h_off[u + 1] - h_off[u];
+    if (len < 0) {
+      delete b;
+      return fail(SMILEHIP_ERR_INVALID, "sample offsets must be non-decreasing (utterance %d)", u);
+    }
+    const int64_t T = smilehip_num_frames(plan, len);
+    b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
+    if (T > 0 && T <= short_T) b->h_short.push_back(u);
+    for (int64_t t0 = 0; t0 < T; t0 += tile_frames) {
+      tile_utt.push_back(u);
+      tile_t0.push_back((int32_t)t0);
+    }
+  }
+  b->total_frames = b->h_frame_off[n_utt];
+  b->n_tiles = (int32_t)tile_utt.size();
+  int rc;
+  if ((rc = b->d_samp_off.upload(b->h_samp_off)) || (rc = b->d_frame_off.upload(b->h_frame_off)) ||
+      (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) ||
+      (rc = b->d_short.upload(b->h_short))) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_batch_destroy(smilehip_batch *b) { delete b; }
+extern "C" int64_t smilehip_batch_total_frames(const smilehip_batch *b) { return b ? b->total_frames : 0; }
+extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o) {
+  if (!b || !o) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_frame_offsets: null argument");
+  std::memcpy(o, b->h_frame_off.data(), b->h_frame_off.size() * sizeof(int64_t));
+  return SMILEHIP_OK;
+}
+
+// -------------------------------------------------------------------- run
+static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const int16_t *d_pcm, float *d_out,
+                        int64_t ld, LldParams &P) {
+  std::memset(&P, 0, sizeof(P));
+  P.pcm = d_pcm;
+  P.samp_off = b->d_samp_off.p;
+  P.frame_off = b->d_frame_off.p;
+  P.tile_utt = b->d_tile_utt.p;
+  P.tile_t0 = b->d_tile_t0.p;
+  P.n_utt = b->n_utt;
+  P.n_tiles = b->n_tiles;
+  P.total_frames = b->total_frames;
+  P.out = d_out;
+  P.ld_out = ld;
+  P.N = (int32_t)p->geo.N;
+  P.H = (int32_t)p->geo.H;
+  P.Nfft = (int32_t)p->geo.Nfft;
+  P.K = (int32_t)p->geo.K;
+  P.pad_left = p->cfg.zero_pad_symmetric ? (int32_t)((p->geo.Nfft - p->geo.N) / 2) : 0;
+  P.preemph = p->cfg.preemph;
+  P.de = p->cfg.preemph_de;
+  P.k = p->cfg.preemph_k;
+  P.one_minus_k = 1 - p->cfg.preemph_k;     // (1-k) in float, vectorPreemphasis.cpp:94
+  P.win_offset = (float)p->cfg.win_offset;
+  P.window = p->d_window.p;
+  P.tw_half = p->d_tw_half.p;
+  P.tw_full = p->d_tw_full.p;
+  P.mel_coef = p->d_mel_coef.p;
+  P.mel_rng = p->d_mel_rng.p;
+  P.mel_scale = p->mel.scale;
+  P.use_power = p->cfg.use_power;
+  P.n_bands = p->mel.n_bands;
+  P.dct_rows = p->d_dct_rows.p;
+  P.dct_gain = p->d_dct_gain.p;
+  P.n_mfcc = p->dct.n_mfcc;
+  P.melfloor = p->dct.melfloor;
+  P.log_floor = p->dct.log_floor;
+}
+
+extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, float *d_io, int64_t ld, int32_t D,
+                                    int32_t W, int32_t n_orders, void *stream) {
+  if (!plan || !b || !d_io) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: null argument");
+  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || ld < (int64_t)D * (1 + n_orders))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  DeltaParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.frame_off = b->d_frame_off.p;
+  Q.n_utt = b->n_utt;
+  Q.total_frames = b->total_frames;
+  Q.io = d_io;
+  Q.ld = ld;
+  Q.D = D;
+  Q.W = W;
+  Q.n_orders = n_orders;
+  Q.norm = delta_norm(W);
+  Q.short_T = 4 * W;
+  // the batch's short list was built with the plan's delta_win; rebuild if W differs
+  std::vector<int32_t> shorts;
+  const int32_t *d_short = b->d_short.p;
+  int32_t n_short = (int32_t)b->h_short.size();
+  DevBuf<int32_t> tmp;
+  if (W != plan->cfg.delta_win) {
+    for (int32_t u = 0; u < b->n_utt; ++u) {
+      const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
+      if (T > 0 && T <= Q.short_T) shorts.push_back(u);
+    }
+    int rc = tmp.upload(shorts);
+    if (rc) return rc;
+    d_short = tmp.p;
+    n_short = (int32_t)shorts.size();
+  }
+  Q.short_utts = d_short;
+  Q.n_short = n_short;
+  hipError_t e = launch_delta(Q, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "delta kernel launch failed: %s", hipGetErrorString(e));
+  if (tmp.p) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // tmp is freed on return
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out,
+                                 int64_t ld_out, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
+  const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  hipEvent_t *ev = plan->ev[plan->n_timed % smilehip_plan::kRing];
+  if (plan->timing) {
+    for (int i = 0; i < 3; ++i)
+      if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipEventRecord(ev[0], s));
+  }
+  hipError_t e = launch_mfcc(P, plan->force_generic, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
+  if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
+  if (plan->cfg.n_delta > 0) {
+    int rc = smilehip_delta_chain(plan, b, d_out, ld_out, plan->dct.n_mfcc, plan->cfg.delta_win, plan->cfg.n_delta, stream);
+    if (rc) return rc;
+  }
+  if (plan->timing) {
+    HIP_TRY(hipEventRecord(ev[2], s));
+    plan->n_timed++;
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
+                                      float *h_out) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: plan/batch mismatch");
+  if (n_samples < b->h_samp_off.back()) return fail(SMILEHIP_ERR_INVALID, "PCM buffer shorter than the batch layout");
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  if (!h_pcm || !h_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: null pointer");
+  HIP_TRY(hipSetDevice(plan->ctx->device));
+  const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
+  int16_t *d_pcm = nullptr;
+  float *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_pcm, size_t(n_samples) * sizeof(int16_t)));
+  hipError_t e = hipMalloc((void **)&d_out, size_t(b->total_frames) * n_out * sizeof(float));
+  if (e != hipSuccess) {
+    (void)hipFree(d_pcm);
+    return fail(SMILEHIP_ERR_HIP, "hipMalloc(out) failed: %s", hipGetErrorString(e));
+  }
+  int rc = SMILEHIP_OK;
+  e = hipMemcpy(d_pcm, h_pcm, size_t(n_samples) * sizeof(int16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = smilehip_mfcc_run(plan, b, d_pcm, d_out, n_out, nullptr);
+    if (rc == SMILEHIP_OK) e = hipMemcpy(h_out, d_out, size_t(b->total_frames) * n_out * sizeof(float), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_pcm);
+  (void)hipFree(d_out);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_plan_set_timing(smilehip_plan *plan, int enable) {
+  if (!plan) return fail(SMILEHIP_ERR_INVALID, "null plan");
+  plan->timing = enable != 0;
+  plan->n_timed = 0;
+  return SMILEHIP_OK;
+}
+
+// Average over the runs recorded since set_timing (at most the last kRing).
+// The caller must have synchronised the stream.
+extern "C" int smilehip_plan_last_timing(smilehip_plan *plan, float *ms_main, float *ms_delta) {
+  if (!plan || plan->n_timed <= 0) return fail(SMILEHIP_ERR_INVALID, "no timing recorded");
+  const int64_t n = plan->n_timed < smilehip_plan::kRing ? plan->n_timed : smilehip_plan::kRing;
+  double sa = 0.0, sd = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    float a = 0.f, d = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, plan->ev[i][0], plan->ev[i][1]));
+    HIP_TRY(hipEventElapsedTime(&d, plan->ev[i][1], plan->ev[i][2]));
+    sa += a;
+    sd += d;
+  }
+  if (ms_main) *ms_main = float(sa / double(n));
+  if (ms_delta) *ms_delta = float(sd / double(n));
+  return SMILEHIP_OK;
+}
+
+// ---------------------------------------------- per-component entry points
+#include "lld_stage.hpp"
+
+#define STAGE_RET(expr, what)                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(SMILEHIP_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e_)); \
+    return SMILEHIP_OK;                                                                    \
+  } while (0)
+
+static int check_frames(const void *s, const void *d, int64_t lds, int64_t ldd, int64_t nF, int64_t ws, int64_t wd,
+                        const char *fn) {
+  if (nF < 0 || (nF > 0 && (!s || !d))) return fail(SMILEHIP_ERR_INVALID, "%s: null pointer", fn);
+  if (lds < ws || ldd < wd) return fail(SMILEHIP_ERR_INVALID, "%s: leading dimension too small", fn);
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t n, float *d_out, void *stream) {
+  if (!ctx || n < 0 || (n > 0 && (!d_pcm || !d_out))) return fail(SMILEHIP_ERR_INVALID, "smilehip_pcm16_to_float: bad argument");
+  STAGE_RET(stage_pcm16(d_pcm, n, d_out, (hipStream_t)stream), "pcm16_to_float");
+}
+
+extern "C" int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
+                                           int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream) {
+  if (!ctx || N < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_preemphasis_frames: bad argument");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, N, N, "smilehip_preemphasis_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_preemph(d_src, ld_src, d_dst, ld_dst, n_frames, N, k, de, (hipStream_t)stream), "preemphasis");
+}
+
+extern "C" int smilehip_window_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                      int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_window_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.N, "smilehip_window_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_window(d_src, ld_src, d_dst, ld_dst, n_frames, p->geo.N, p->d_window.p, (float)p->cfg.win_offset,
+                         (hipStream_t)stream), "window");
+}
+
+extern "C" int smilehip_rfft_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                    int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_rfft_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.Nfft, "smilehip_rfft_frames");
+  if (rc) return rc;
+  const int pad = p->cfg.zero_pad_symmetric ? (int)((p->geo.Nfft - p->geo.N) / 2) : 0;
+  STAGE_RET(stage_rfft(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.N, (int)p->geo.Nfft, pad, p->d_tw_half.p,
+                       p->d_tw_full.p, (hipStream_t)stream), "rfft");
+}
+
+extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                      int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmag_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.Nfft, p->geo.K, "smilehip_fftmag_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_fftmag(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.Nfft, (hipStream_t)stream), "fftmag");
+}
+
+extern "C" int smilehip_melspec_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                       int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, p->mel.n_bands, "smilehip_melspec_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_melspec(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, p->mel.n_bands, p->cfg.use_power,
+                          p->d_mel_coef.p, p->d_mel_rng.p, p->mel.scale, (hipStream_t)stream), "melspec");
+}
+
+extern "C" int smilehip_mfcc_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                    int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, "smilehip_mfcc_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_mfcc(d_src, ld_src, d_dst, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, p->d_dct_rows.p,
+                       p->d_dct_gain.p, p->dct.melfloor, p->dct.log_floor, (hipStream_t)stream), "mfcc");
+}

@@ -1,0 +1,47 @@
+// Host-side table generation for the LLD chain (product code; independent of
+// oracle/). Every table is computed with the reference's own precision
+// recipe -- double math, one rounding to float where the reference rounds --
+// so that the device kernels consume bit-identical constants.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/smilehip.h"
+
+namespace smilehip {
+
+struct Geometry {
+  int64_t N = 0, H = 0, Nfft = 0, K = 0;
+  double period = 0.0;          // sample period T = 1/fs
+  double frame_period = 0.0;    // H*T as the framer's level period (= frameStep)
+  double fft_frame_size_sec = 0.0;
+};
+
+struct MelBank {
+  int n_bands = 0;
+  int64_t nLo = 0, nHi = 0;
+  std::vector<float> coef;        // one weight per bin (falling slope of band chan[n])
+  std::vector<int32_t> chan;      // band index of the falling slope, -3 = unused bin
+  std::vector<float> centres;     // n_bands+2 band edges/centres on the mel axis
+  // per-band bin ranges derived from chan[] (device-side iteration order):
+  // band b sums bins [rise_lo[b], rise_hi[b]) with (p - p*w) then
+  // [fall_lo[b], fall_hi[b]) with p*w -- the reference's bin-ascending order.
+  std::vector<int32_t> rise_lo, rise_hi, fall_lo, fall_hi;
+  float scale = 1.0f;             // HTK sample-value scaling applied after the sums
+};
+
+struct DctTables {
+  int n_bands = 0, first = 0, last = 0, n_mfcc = 0;
+  std::vector<float> cos_rows;    // n_mfcc rows of n_bands, row r = OUTPUT position r
+  std::vector<float> gain;        // per output position: lifter * sqrt(2/nB) (one float product)
+  std::vector<float> lifter;      // raw lifter table (sintable), reference order
+  float melfloor = 0.0f, log_floor = 0.0f;
+};
+
+int  make_geometry(const smilehip_lld_config &c, Geometry &g);
+int  make_window(const smilehip_lld_config &c, int64_t N, std::vector<float> &w);
+int  make_mel(const smilehip_lld_config &c, const Geometry &g, MelBank &m);
+int  make_dct(const smilehip_lld_config &c, DctTables &d);
+float delta_norm(int W);
+
+}  // namespace smilehip
