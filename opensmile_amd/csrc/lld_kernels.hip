@@ -227,15 +227,7 @@ __global__ void __launch_bounds__(64) lld_delta_short(DeltaParams P) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-bool fast512_applicable(int, int) { return false; }
-
-int launch_tile_frames(int Nfft, int N, int force_generic) {
-  if (!force_generic && fast512_applicable(Nfft, N)) return 32;
-  return 1 << 30;   // generic kernel: one workgroup per frame, no tile table needed
-}
-
-hipError_t launch_mfcc(const LldParams &P, int force_generic, hipStream_t s) {
-  (void)force_generic;
+hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   const int M = P.Nfft / 2;
   const size_t lds = sizeof(float) * (size_t)(2 * M + P.K + 1 + P.n_bands + 8);
   hipLaunchKernelGGL(lld_mfcc_generic, dim3((unsigned)P.total_frames), dim3(256), lds, s, P);

@@ -1,6 +1,8 @@
 // Kernel parameter block shared by the host API (smilehip.cpp) and the device
 // code (lld_kernels.hip). Plain data, passed by value at launch.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 namespace smilehip {
@@ -36,6 +38,16 @@ struct LldParams {
   const float *dct_gain;       // [n_mfcc]
   int32_t n_mfcc;
   float melfloor, log_floor;
+};
+
+// Device-side tables of the fast Nfft=512 kernel (lld_mfcc512.hip)
+struct Fast512Tables {
+  const float2 *tw256;        // [16*16] w256^(j*k1), index j*16+k1
+  const float2 *tw512;        // [256]   e^{-2 pi i k/512}
+  const uint2 *mel_entries;   // [mel_iters][16]: {byte offset of bin | slot<<16, weight bits}
+  const int32_t *band_slots;  // [2*n_bands]: partial-slot range [s, e) per band
+  int32_t mel_iters;
+  int32_t n_slots;
 };
 
 struct DeltaParams {

@@ -75,7 +75,11 @@ struct smilehip_plan {
   DctTables dct;
   DevBuf<float> d_window, d_mel_coef, d_dct_rows, d_dct_gain;
   DevBuf<int32_t> d_mel_rng;
-  DevBuf<float2> d_tw_half, d_tw_full, d_tw16x16;
+  DevBuf<float2> d_tw_half, d_tw_full, d_tw256, d_tw512;
+  DevBuf<uint2> d_mel_entries;
+  DevBuf<int32_t> d_band_slots;
+  Fast512Host fast;
+  bool use_fast = false;
   // timing
   // HIP-event timing ring: slot i holds {before main, after main, after delta}
   static constexpr int kRing = 128;
@@ -191,6 +195,12 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     rng[4 * b + 2] = p->mel.fall_lo[b];
     rng[4 * b + 3] = p->mel.fall_hi[b];
   }
+  // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
+  p->use_fast = false;
+  if (!p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
+    const int pad = p->cfg.zero_pad_symmetric ? (int)((p->geo.Nfft - p->geo.N) / 2) : 0;
+    p->use_fast = fast512_build_host(p->mel, p->dct.n_mfcc, p->cfg.win_offset, pad, (int)p->geo.H, p->fast) == 0;
+  }
   if (!upload) return SMILEHIP_OK;
   if ((rc = p->d_window.upload(p->h_window))) return rc;
   if ((rc = p->d_mel_coef.upload(p->mel.coef))) return rc;
@@ -199,6 +209,12 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
   if ((rc = p->d_tw_half.upload(twh))) return rc;
   if ((rc = p->d_tw_full.upload(twf))) return rc;
+  if (p->use_fast) {
+    if ((rc = p->d_tw256.upload(p->fast.tw256))) return rc;
+    if ((rc = p->d_tw512.upload(p->fast.tw512))) return rc;
+    if ((rc = p->d_mel_entries.upload(p->fast.mel_entries))) return rc;
+    if ((rc = p->d_band_slots.upload(p->fast.band_slots))) return rc;
+  }
   return SMILEHIP_OK;
 }
 
@@ -298,7 +314,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   b->h_frame_off.assign(size_t(n_utt) + 1, 0);
   const int short_T = 4 * plan->cfg.delta_win;
   std::vector<int32_t> tile_utt, tile_t0;
-  const int tile_frames = launch_tile_frames((int)plan->geo.Nfft, (int)plan->geo.N, plan->force_generic);
+  const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
   for (int32_t u = 0; u < n_utt; ++u) {
     const int64_t len = h_off[u + 1] - h_off[u];
     if (len < 0) {
@@ -430,7 +446,19 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
       if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], s));
   }
-  hipError_t e = launch_mfcc(P, plan->force_generic, s);
+  hipError_t e;
+  if (plan->use_fast) {
+    Fast512Tables F;
+    F.tw256 = plan->d_tw256.p;
+    F.tw512 = plan->d_tw512.p;
+    F.mel_entries = plan->d_mel_entries.p;
+    F.band_slots = plan->d_band_slots.p;
+    F.mel_iters = plan->fast.mel_iters;
+    F.n_slots = plan->fast.n_slots;
+    e = launch_mfcc512(P, F, s);
+  } else {
+    e = launch_mfcc_generic(P, s);
+  }
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
   if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
   if (plan->cfg.n_delta > 0) {

@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# PyTorch bundles its own HIP runtime: when a test uses both torch and
+# libsmilehip.so in one process, torch must be imported FIRST so that the
+# library binds to the runtime that is already loaded (the other order leaves
+# two runtimes in the process and torch then reports "No HIP GPUs").
+try:
+    import torch  # noqa: F401
+except Exception:  # CPU-only environments without torch still run the CPU suite
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tolerance import assert_parity, frame_scaled_err
+from tolerance import assert_parity, corpus_col_scale
 
 pytestmark = pytest.mark.gpu
 
@@ -59,12 +59,13 @@ def test_golden_batch_ragged(hip, plan, golden_synth):
     assert b.total_frames == sum(r.shape[0] for r in refs)
     np.testing.assert_array_equal(np.diff(b.frame_offsets), [r.shape[0] for r in refs])
     out = b.run_host(np.concatenate(pcms))
+    s_col = corpus_col_scale(refs, 13)
     for i, k in enumerate(SYNTH_KEYS):
         o = out[b.frame_offsets[i]:b.frame_offsets[i + 1]]
         if refs[i].shape[0] == 0:
             assert o.shape[0] == 0
             continue
-        assert_parity(o, refs[i], block=13, what=k)
+        assert_parity(o, refs[i], block=13, what=k, col_scale=s_col)
     b.close()
 
 
@@ -80,10 +81,11 @@ def test_vs_oracle_10s(hip, plan, oracle):
     out = b.run_host(np.concatenate(pcms))
     cfg = oracle.default_cfg()
     worst = 0.0
+    refs = [oracle.mfcc_chain(cfg, p) for p in pcms]
+    s_col = corpus_col_scale(refs, 13)
     for i, u in enumerate(us):
-        ref = oracle.mfcc_chain(cfg, pcms[i])
         o = out[b.frame_offsets[i]:b.frame_offsets[i + 1]]
-        e2, _ = assert_parity(o, ref, block=13, what=f"u{u}")
+        e2, _ = assert_parity(o, refs[i], block=13, what=f"u{u}", col_scale=s_col)
         worst = max(worst, e2)
     print(f"worst per-frame-scaled error vs oracle: {worst:.3e}")
     b.close()

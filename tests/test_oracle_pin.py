@@ -9,7 +9,7 @@ CPU only -- no GPU needed.
 import numpy as np
 import pytest
 
-from tolerance import assert_parity
+from tolerance import assert_parity, corpus_col_scale
 
 SYNTH_KEYS = ["u0_16000", "u1_16000", "u2_16000", "u3_16000", "u10_16000",
               "u7_399", "u7_400", "u7_401", "u7_559", "u7_560", "u7_561", "u7_1000"]
@@ -42,7 +42,8 @@ def test_oracle_vs_golden_own_fft(oracle, golden_synth, key):
     if ref.shape[0] == 0:
         assert out.shape[0] == 0
         return
-    assert_parity(out, ref, block=13, what=key)
+    s_col = corpus_col_scale([golden_synth["out_" + k] for k in SYNTH_KEYS], 13)
+    assert_parity(out, ref, block=13, what=key, col_scale=s_col)
 
 
 @pytest.mark.parametrize("key", SYNTH_KEYS)
