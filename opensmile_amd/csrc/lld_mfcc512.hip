@@ -113,10 +113,50 @@ __device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
 
 }  // namespace
 
+// One lane's share of the next pass's PCM: 8 packed sample pairs (+ the frame-
+// first sample of frame tp+lane for lanes < 4). Pure global loads into
+// registers, issued early so that their latency hides behind the current
+// pass's arithmetic.
+struct PcmRegs {
+  uint32_t pair[8];
+  int32_t first;
+};
+
+__device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, int64_t sbase, int H, int stage_floats,
+                                             bool aligned, int lane, PcmRegs &R) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int i2 = lane + 64 * r;
+    const int64_t s0 = sbase + 2 * i2;
+    uint32_t v = 0;
+    if (2 * i2 < stage_floats) {
+      if (aligned && s0 + 1 < utt_len) {
+        v = *reinterpret_cast<const uint32_t *>(x + s0);
+      } else {
+        const uint32_t lo = (s0 < utt_len) ? (uint16_t)x[s0] : 0u;
+        const uint32_t hi = (s0 + 1 < utt_len) ? (uint16_t)x[s0 + 1] : 0u;
+        v = lo | (hi << 16);
+      }
+    }
+    R.pair[r] = v;
+  }
+  R.first = 0;
+  if (lane < 4) {
+    const int64_t s0 = sbase + (int64_t)lane * H;
+    R.first = (s0 < utt_len) ? (int32_t)x[s0] : 0;
+  }
+}
+
+// value of lane-1 (wave-wide shift right by one lane); lane 0 receives `fill`
+__device__ __forceinline__ float lane_shr1(float v, float fill, int lane) {
+  const float s = __shfl_up(v, 1);
+  return lane == 0 ? fill : s;
+}
+
 // LDS layout (dynamic):
-//   shared tables: tw512 [256 float2] | mel_entries [mel_iters*16 uint2] | dct rows | band slots ...
-//   per wave:      stage [S floats] (aliased later by PB: 4 x 260 floats) | 4 x group buffer (2176 B)
-template <int MP>
+//   shared tables: tw512 [256 float2] | mel_entries [mel_iters*16 uint2] | dct rows | band slots
+//   per wave:      stage [S floats] (aliased later by PB: 4 x 260 floats) | spec[4] | 4 x group buffer (2176 B)
+template <int MP, bool PREEMPH, bool USE_POWER>
 __global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, Fast512Tables F, int stage_floats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -157,6 +197,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, 
   const int64_t row0 = P.frame_off[u];
   const int T = (int)(P.frame_off[u + 1] - row0);
   const int16_t *x = P.pcm + s_utt;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 3) == 0);   // H even => every pair start is even
 
   // ---- per-lane constants: window for my sample pairs, inter-stage twiddles
   float wre[MP], wim[MP];
@@ -173,43 +214,49 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, 
     twr[k1] = w.x; twi[k1] = w.y;
   }
   const float dgain = (j < P.n_mfcc) ? P.dct_gain[j] : 0.0f;
+  const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
 
   const int t_end = (t_first + kTileFrames < T) ? t_first + kTileFrames : T;
+  PcmRegs R;
+  pcm_prefetch(x, utt_len, (int64_t)t_first * P.H, P.H, stage_floats, aligned, lane, R);
+
   for (int tp = t_first; tp < t_end; tp += 4) {
     const int t = tp + g;                       // my frame
     const bool live = t < t_end;
-    // ------------------------------------------------------------ stage PCM
-    // samples [tp*H, tp*H + stage_floats) of the utterance, two per lane per step
-    const int64_t sbase = (int64_t)tp * P.H;
-    for (int i2 = lane; 2 * i2 < stage_floats; i2 += 64) {
-      const int64_t s0 = sbase + 2 * i2;
-      const float a = (s0 < utt_len) ? pcm16_to_float(x[s0]) : 0.0f;
-      const float b = (s0 + 1 < utt_len) ? pcm16_to_float(x[s0 + 1]) : 0.0f;
-      float ya = a, yb = b;
-      if (P.preemph) {
-        const float pa = (s0 >= 1 && s0 - 1 < utt_len) ? pcm16_to_float(x[s0 - 1]) : 0.0f;
-        if (P.de) { ya = a + P.k * pa; yb = b + P.k * a; }
-        else      { ya = a - P.k * pa; yb = b - P.k * a; }
+    // ------------------------------------------------------------ stage PCM (R0, R2) from registers
+    {
+      float carry = 0.0f;                       // odd sample of lane 63 of the previous step
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int i2 = lane + 64 * r;
+        const float a = pcm16_to_float((int16_t)(R.pair[r] & 0xffffu));
+        const float b = pcm16_to_float((int16_t)(R.pair[r] >> 16));
+        float ya = a, yb = b;
+        if (PREEMPH) {
+          const float pa = lane_shr1(b, carry, lane);
+          carry = __shfl(b, 63);
+          ya = a - kpre * pa;
+          yb = b - kpre * a;
+        }
+        if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
       }
-      *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
-    }
-    if (P.preemph && lane < 4) {
-      const int64_t s0 = sbase + (int64_t)lane * P.H;       // first sample of frame tp+lane
-      s_spec[lane] = (s0 < utt_len) ? P.one_minus_k * pcm16_to_float(x[s0]) : 0.0f;
+      if (PREEMPH && lane < 4) s_spec[lane] = P.one_minus_k * pcm16_to_float((int16_t)R.first);
     }
     wave_lds_fence();
+    // next pass's PCM: loads fly while this pass computes
+    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, stage_floats, aligned, lane, R);
 
-    // ------------------------------------------------------------ load frame
+    // ------------------------------------------------------------ load frame (R3)
     float re[16], im[16];
-    const float *fr = s_stage + g * P.H - P.pad_left;       // fr[n] = sample n of my frame
+    const float *fr = s_stage + g * P.H - P.pad_left;       // fr[q - ...]: sample n = q - pad_left of my frame
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       if (m < MP) {
         const int q = 2 * (j + 16 * m);
-        // n = q - pad_left < 0 only inside the left zero padding (window 0 there, but the
+        // q < pad_left only inside the left zero padding (window 0 there, but the
         // address would fall in front of the staged samples: do not touch it)
         float2 v = (q >= P.pad_left) ? *reinterpret_cast<const float2 *>(fr + q) : make_float2(0.0f, 0.0f);
-        if (P.preemph && q == P.pad_left) v.x = s_spec[g];  // y[0] = (1-k) x[0]
+        if (PREEMPH && q == P.pad_left) v.x = s_spec[g];    // y[0] = (1-k) x[0]
         re[m] = v.x * wre[m];
         im[m] = v.y * wim[m];
       } else {
@@ -249,12 +296,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, 
       const float xr = 0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr));
       const float xi = 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si));
       const float s = fmaf(xi, xi, xr * xr);
-      pw[k2] = P.use_power ? s : __fsqrt_rn(s);
+      pw[k2] = USE_POWER ? s : __fsqrt_rn(s);
     }
     float p_nyq = 0.0f;
     if (j == 0) {                                            // X[256] = Re Z0 - Im Z0
       const float v = re[0] - im[0];
-      p_nyq = P.use_power ? v * v : fabsf(v);
+      p_nyq = USE_POWER ? v * v : fabsf(v);
     }
     wave_lds_fence();   // all partner reads done before PS (alias of the Z buffer) is written
 #pragma unroll
@@ -367,16 +414,24 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, hipStream_
   const size_t lds = size_t(shared_bytes) + size_t(kWavesPerBlock) * wave_bytes;
   const unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   const bool mp13 = (P.pad_left + P.N) <= 13 * 32;
-  hipError_t e;
-  if (mp13) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_mfcc512<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lld_mfcc512<13>, dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F, stage_floats);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_mfcc512<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lld_mfcc512<16>, dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F, stage_floats);
+  if (3 * P.H + 512 > 8 * 128) return hipErrorInvalidValue;   // PcmRegs holds 8 x 64 pairs
+  const void *fn = nullptr;
+#define SMILEHIP_PICK(MPV, PE, UP)                                                                       \
+  if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP) {                         \
+    fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP>);                                        \
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    if (e != hipSuccess) return e;                                                                         \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F, stage_floats); \
   }
+  SMILEHIP_PICK(13, true, true)
+  SMILEHIP_PICK(13, true, false)
+  SMILEHIP_PICK(13, false, true)
+  SMILEHIP_PICK(13, false, false)
+  SMILEHIP_PICK(16, true, true)
+  SMILEHIP_PICK(16, true, false)
+  SMILEHIP_PICK(16, false, true)
+  SMILEHIP_PICK(16, false, false)
+#undef SMILEHIP_PICK
   return hipGetLastError();
 }
 
