@@ -117,34 +117,65 @@ __device__ __forceinline__ float delta1(const float *x, int64_t ld, int64_t T, i
   return num / norm;
 }
 
-__global__ void __launch_bounds__(256) lld_delta_long(DeltaParams P) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t row = gid / P.D;
-  const int d = (int)(gid - row * P.D);
-  if (row >= P.total_frames) return;
-  int lo = 0, hi = P.n_utt;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (P.frame_off[mid] <= row) lo = mid; else hi = mid;
-  }
-  const int64_t r0 = P.frame_off[lo];
-  const int64_t T = P.frame_off[lo + 1] - r0;
+// Tiled form: one workgroup per tile of kDeltaTile consecutive frames of one
+// utterance. The static block (with a halo of 2W frames, indices clamped to
+// [0, T-1] = first/last-frame replication) is staged in LDS, the order-1 level
+// d[t] is formed for t in [t0-W, t0+nF+W) (d[t<0] := d[0]: the accel
+// component's own left padding), then the order-2 level. All float
+// expressions are those of delta1() above, so results are bit-identical to the
+// one-thread-per-element form.
+constexpr int kDeltaTile = 128;
+constexpr int kDeltaMaxD = 16;
+constexpr int kDeltaMaxW = 4;
+
+__global__ void __launch_bounds__(256) lld_delta_tiled(DeltaParams P) {
+  __shared__ float xs[(kDeltaTile + 4 * kDeltaMaxW) * kDeltaMaxD];
+  __shared__ float ds[(kDeltaTile + 2 * kDeltaMaxW) * kDeltaMaxD];
+  const int u = P.tile_utt[blockIdx.x];
+  const int t0 = P.tile_t0[blockIdx.x];
+  const int64_t r0 = P.frame_off[u];
+  const int T = (int)(P.frame_off[u + 1] - r0);
   if (T <= P.short_T) return;                 // handled by lld_delta_short
-  const int64_t t = row - r0;
-  const float *x = P.io + r0 * P.ld + d;      // static column d of this utterance
-  float *o = P.io + row * P.ld + d;
-  const float d0 = delta1(x, P.ld, T, t, P.W, P.norm);
-  o[P.D] = d0;
-  if (P.n_orders >= 2) {
+  const int D = P.D, W = P.W;
+  const int nF = (T - t0 < kDeltaTile) ? T - t0 : kDeltaTile;
+  const float *x = P.io + r0 * P.ld;
+  // stage xs[i][d] = x[clamp(t0 - 2W + i)][d]
+  const int nX = nF + 4 * W;
+  for (int idx = threadIdx.x; idx < nX * D; idx += blockDim.x) {
+    const int i = idx / D, d = idx - i * D;
+    int tt = t0 - 2 * W + i;
+    tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+    xs[i * D + d] = x[(int64_t)tt * P.ld + d];
+  }
+  __syncthreads();
+  // order 1: ds[i][d] = d[max(t0 - W + i, 0)]
+  const int nD = nF + 2 * W;
+  for (int idx = threadIdx.x; idx < nD * D; idx += blockDim.x) {
+    const int i = idx / D, d = idx - i * D;
+    int t = t0 - W + i;
+    t = t < 0 ? 0 : t;
+    const int c = t - (t0 - 2 * W);             // centre position in xs
     float num = 0.0f;
-    for (int i = 1; i <= P.W; ++i) {
-      int64_t a = t - i;
-      const int64_t b = t + i;                // <= T-1+W: inside the T+W frames of the delta level
-      a = a < 0 ? 0 : a;
-      const float delta = delta1(x, P.ld, T, b, P.W, P.norm) - delta1(x, P.ld, T, a, P.W, P.norm);
-      num += (float)i * delta;
+    for (int k = 1; k <= W; ++k) {
+      const float delta = xs[(c + k) * D + d] - xs[(c - k) * D + d];
+      num += (float)k * delta;
     }
-    o[2 * P.D] = num / P.norm;
+    ds[i * D + d] = num / P.norm;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nF * D; idx += blockDim.x) {
+    const int f = idx / D, d = idx - f * D;
+    float *o = P.io + (r0 + t0 + f) * P.ld + d;
+    const int c = f + W;                         // position of frame t0+f in ds
+    o[D] = ds[c * D + d];
+    if (P.n_orders >= 2) {
+      float num = 0.0f;
+      for (int k = 1; k <= W; ++k) {
+        const float delta = ds[(c + k) * D + d] - ds[(c - k) * D + d];
+        num += (float)k * delta;
+      }
+      o[2 * D] = num / P.norm;
+    }
   }
 }
 
@@ -153,7 +184,7 @@ __global__ void __launch_bounds__(256) lld_delta_long(DeltaParams P) {
 // getMatrix reads never-written (zero) slots in its left-padding branch
 // (dataMemoryLevel.cpp:1687-1698) -- see DESIGN.md "R13 end-of-input". One
 // thread per (short utterance, column) replays that loop.
-constexpr int kShortMaxW = 4;
+constexpr int kShortMaxW = kDeltaMaxW;
 constexpr int kShortMaxOrders = 2;
 constexpr int kShortCap = 4 * kShortMaxW + kShortMaxW * kShortMaxOrders + 2 * kShortMaxW + 2;
 
@@ -234,9 +265,11 @@ hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   return hipGetLastError();
 }
 
+int delta_tile_frames() { return kDeltaTile; }
+
 hipError_t launch_delta(const DeltaParams &P, hipStream_t s) {
-  const int64_t n = P.total_frames * P.D;
-  hipLaunchKernelGGL(lld_delta_long, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+  if (P.D > kDeltaMaxD || P.W > kDeltaMaxW || P.W < 1) return hipErrorInvalidValue;
+  if (P.n_dtiles > 0) hipLaunchKernelGGL(lld_delta_tiled, dim3((unsigned)P.n_dtiles), dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (P.n_short > 0) {

@@ -9,16 +9,21 @@
 
 namespace smilehip {
 struct Fast512Host {
-  std::vector<float2> tw256, tw512;
-  std::vector<uint2> mel_entries;
+  std::vector<float2> tw256, tw512, win;
+  std::vector<float4> melw;
+  std::vector<uint32_t> melo;
+  std::vector<float> dct28;
   std::vector<int32_t> band_slots;
-  int mel_iters = 0, n_slots = 0;
+  int mel_units = 0, n_slots = 0, mp = 13, stage_floats = 0, stage_alloc = 0;
+  float mel_scale = 1.0f;
 };
 bool fast512_applicable(int Nfft, int N);
 int fast512_tile_frames();
 // 0 on success, -1 if this configuration cannot use the fast kernel
-int fast512_build_host(const MelBank &mel, int n_mfcc, double win_offset, int pad_left, int H, Fast512Host &h);
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, hipStream_t s);
+int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, const std::vector<float> &window,
+                       const MelBank &mel, const DctTables &dct, Fast512Host &h);
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
 hipError_t launch_delta(const DeltaParams &P, hipStream_t s);
+int delta_tile_frames();
 }  // namespace smilehip

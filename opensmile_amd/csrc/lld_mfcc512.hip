@@ -3,29 +3,41 @@
 // Mapping (wave64-native): ONE WAVE processes FOUR frames at a time, 16 lanes
 // per frame; a wave walks a tile of consecutive frames of one utterance in
 // "passes" of 4 frames. Waves are autonomous -- no __syncthreads in the frame
-// loop, all exchange is wave-local through LDS.
+// loop, all exchange is wave-local through LDS. Sized for 4 waves per SIMD
+// (<= 128 VGPRs, ~8 KB of LDS per wave): one wave can issue a VALU op only
+// every ~5 cycles (tools/ubench/valu_rate.hip), so the SIMD needs several
+// waves to approach its 2-cycle issue rate.
 //
-// Per pass (lane j = lane&15 of group g = lane>>4, frame t = t0 + 4*pass + g):
-//   stage   int16 PCM of the 4 frames -> float (R0) -> pre-emphasis (R2) -> LDS,
-//           coalesced loads, each sample converted once per pass
+// Per pass (lane j = lane&15 of group g = lane>>4, frame t = tp + g):
+//   stage   next pass's int16 PCM is prefetched into registers one pass ahead
+//           (global-load latency hides behind arithmetic); at pass start it is
+//           converted (R0, scale folded into the window table), pre-emphasised
+//           (R2, the reference's two roundings) and written to LDS once
 //   load    z[m] = y[2n] + i*y[2n+1], n = j + 16m, times the window (R3); the
 //           real 512-FFT is a complex 256-FFT of z plus an untangle pass
 //   FFT     256 = 16 x 16: radix-16 DFT over m in registers (two radix-4
-//           layers, constants only), twiddle by w256^(j*k1) (per-lane registers),
-//           ONE 16x16 transpose through LDS (row stride 17 float2: conflict
-//           free for ds_write_b64 / ds_read_b64), radix-16 DFT over j
-//   spect.  Z -> LDS -> each lane reads its partner bins Z[256-k], untangles
-//           X[k] (R4), power |X|^2 (R5+R6 square) -> LDS
-//   mel     table-driven band sums (R6): every band's ordered contribution
-//           list is cut into chunks of 8, chunks are dealt to the 16 lanes,
-//           partial sums go to LDS slots, band lanes add their partials
-//   cep     log floor, DCT-II rows, lifter (R7): one lane per coefficient
+//           layers, constants only), twiddle by w256^(j*k1) (LDS table), ONE
+//           16x16 transpose through LDS (row stride 17: conflict free), done
+//           for re and im one after the other to halve the buffer, radix-16
+//           DFT over j
+//   spect.  lanes j and 16-j own mirror-image bins: each writes the half of its
+//           Z the partner needs, reads the partner's half and untangles BOTH
+//           X[k] and X[256-k] from one (Z[k], Z[256-k]) pair (R4), power (R5,
+//           R6's square) -> LDS
+//   mel     R6 as table-driven work units: a unit = one aligned octet of bins
+//           x one band (8 weights, zero outside the band), units dealt round
+//           robin to the 16 lanes: 2 x ds_read_b128 of power + 2 x b128 of
+//           weights + 8 FMA per unit, partial sums to LDS slots, band lanes add
+//           their partials in a fixed order, log floor
+//   cep     DCT-II rows + lifter (R7): one lane per coefficient, b128 reads
 //
-// Numerics: identical operation order to the reference for R0, R2, R3 (the
-// (1-k), x-k*x', *w roundings); the FFT uses FMA and its own butterfly order
-// (cannot match Ooura's split radix anyway), power skips the reference's
-// sqrt-then-square (<= 1 ulp), mel/DCT sums use FMA in a fixed deterministic
-// order. Measured deviation from the reference: see DESIGN.md / tests.
+// Numerics: R2/R3 keep the reference's rounding sequence on integer-valued
+// samples (the 1/32767 of R0 is folded into the window table, <= 1 ulp per
+// sample); the FFT uses FMA and its own butterfly order (cannot match Ooura's
+// split radix anyway); power skips the reference's sqrt-then-square; mel/DCT
+// sums use FMA in a fixed deterministic order. Deviation from the reference is
+// measured in tests/test_gpu_mfcc.py; the reference-order path is
+// lld_mfcc_generic (SMILEHIP_FORCE_GENERIC=1).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -42,12 +54,13 @@ namespace smilehip {
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 8;
 constexpr int kTileFrames = 32;       // frames per wave tile (8 passes)
-constexpr int kTBStride = 17;         // float2 row stride of the transpose buffer
-constexpr int kGroupBytes = 16 * kTBStride * 8;   // 2176 B: TB, later ZB (257 float2 = 2056 B), later PS+lmel
-constexpr int kMelChunk = 8;          // entries per mel work chunk
-constexpr int kMaxChunksPerLane = 8;
+constexpr int kTBStride = 17;         // row stride (floats) of the transpose buffer
+constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame group
+constexpr int kMaxUnitsPerLane = 8;
+constexpr int kMaxSlots = 96;
+constexpr int kMinStage = 512;        // PS + lmel (4 x 128 floats) alias the stage area
 
 constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
 constexpr float S1 = 0.38268343236508978178f;   // sin(pi/8)
@@ -114,31 +127,31 @@ __device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
 }  // namespace
 
 // One lane's share of the next pass's PCM: 8 packed sample pairs (+ the frame-
-// first sample of frame tp+lane for lanes < 4). Pure global loads into
-// registers, issued early so that their latency hides behind the current
-// pass's arithmetic.
+// first sample of frame tp+lane for lanes < 4).
 struct PcmRegs {
   uint32_t pair[8];
   int32_t first;
 };
 
-__device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, int64_t sbase, int H, int stage_floats,
+__device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, int64_t sbase, int H, int n_steps,
                                              bool aligned, int lane, PcmRegs &R) {
+  if (aligned && sbase + 128 * n_steps <= utt_len) {
+    // whole span inside the utterance and 4-byte aligned (wave-uniform): plain dword loads
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(x + sbase) + lane;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int i2 = lane + 64 * r;
-    const int64_t s0 = sbase + 2 * i2;
-    uint32_t v = 0;
-    if (2 * i2 < stage_floats) {
-      if (aligned && s0 + 1 < utt_len) {
-        v = *reinterpret_cast<const uint32_t *>(x + s0);
-      } else {
+    for (int r = 0; r < 8; ++r) R.pair[r] = (r < n_steps) ? p[64 * r] : 0u;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t s0 = sbase + 2 * (lane + 64 * r);
+      uint32_t v = 0;
+      if (r < n_steps) {
         const uint32_t lo = (s0 < utt_len) ? (uint16_t)x[s0] : 0u;
         const uint32_t hi = (s0 + 1 < utt_len) ? (uint16_t)x[s0 + 1] : 0u;
         v = lo | (hi << 16);
       }
+      R.pair[r] = v;
     }
-    R.pair[r] = v;
   }
   R.first = 0;
   if (lane < 4) {
@@ -147,45 +160,53 @@ __device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, 
   }
 }
 
-// value of lane-1 (wave-wide shift right by one lane); lane 0 receives `fill`
-__device__ __forceinline__ float lane_shr1(float v, float fill, int lane) {
-  const float s = __shfl_up(v, 1);
-  return lane == 0 ? fill : s;
+// value of lane-1 (wave-wide shift right by one lane, DPP wave_shr:1); lane 0 receives `fill`
+__device__ __forceinline__ float lane_shr1(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
-// LDS layout (dynamic):
-//   shared tables: tw512 [256 float2] | mel_entries [mel_iters*16 uint2] | dct rows | band slots
-//   per wave:      stage [S floats] (aliased later by PB: 4 x 260 floats) | spec[4] | 4 x group buffer (2176 B)
+
+// LDS layout (dynamic), sizes in floats:
+//   shared tables : tw512 [256 f2] | win [MP*16 f2] | tw256 [256 f2, index k1*16+j] |
+//                   melw0 [U*16 f4] | melw1 [U*16 f4] | melo [U*16 u32] | dct [16 x 28] | slots [64 i32]
+//   per wave      : stage [S >= 512] (later PS+lmel: 4 x 128) | spec [4] | 4 x group buffer [272]
 template <int MP, bool PREEMPH, bool USE_POWER>
-__global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, Fast512Tables F, int stage_floats) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4;
   const int j = lane & 15;
+  const int U = F.mel_units;
+  const int stage_floats = F.stage_floats;
+  const int stage_alloc = F.stage_alloc;
 
   // ---- carve shared memory
-  float2 *s_tw512 = reinterpret_cast<float2 *>(smem_raw);
-  uint2 *s_mel = reinterpret_cast<uint2 *>(s_tw512 + 256);
-  float *s_dct = reinterpret_cast<float *>(s_mel + F.mel_iters * 16);
-  int32_t *s_slots = reinterpret_cast<int32_t *>(s_dct + P.n_mfcc * P.n_bands);
-  const int shared_bytes = (256 * 8 + F.mel_iters * 16 * 8 + P.n_mfcc * P.n_bands * 4 + 2 * P.n_bands * 4 + 15) & ~15;
-  const int wave_floats = (stage_floats > 4 * 260 ? stage_floats : 4 * 260) + 4;
-  const int wave_bytes = ((wave_floats * 4 + 15) & ~15) + 4 * kGroupBytes;
-  unsigned char *wbase = smem_raw + shared_bytes + wave * wave_bytes;
-  float *s_stage = reinterpret_cast<float *>(wbase);
-  float *s_spec = s_stage + (wave_floats - 4);                    // 4 frame-first specials
-  unsigned char *gbase = wbase + ((wave_floats * 4 + 15) & ~15) + g * kGroupBytes;
-  float2 *s_tb = reinterpret_cast<float2 *>(gbase);               // transpose buffer / Z buffer
-  float *s_pb = s_stage + g * 260;                                // power spectrum of group g (aliases stage)
-  float *s_ps = reinterpret_cast<float *>(gbase);                 // partial mel sums (aliases Z buffer)
-  float *s_lmel = s_ps + 96;                                      // log-mel of the frame
+  float2 *s_tw512 = reinterpret_cast<float2 *>(smem);
+  float2 *s_win = s_tw512 + 256;
+  float2 *s_tw256 = s_win + MP * 16;
+  float4 *s_melw0 = reinterpret_cast<float4 *>(s_tw256 + 256);
+  float4 *s_melw1 = s_melw0 + U * 16;
+  uint32_t *s_melo = reinterpret_cast<uint32_t *>(s_melw1 + U * 16);
+  float *s_dct = reinterpret_cast<float *>(s_melo + U * 16);
+  int32_t *s_slots = reinterpret_cast<int32_t *>(s_dct + 16 * 28);
+  const int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 9 + 16 * 28 + 64;
+  const int wave_floats = stage_alloc + 4 + 4 * kGroupFloats;
+  float *wbase = smem + shared_floats + wave * wave_floats;
+  float *s_stage = wbase;
+  float *s_spec = wbase + stage_alloc;
+  float *s_gb = s_spec + 4 + g * kGroupFloats;                    // my group's buffer: TB -> ZX -> PB
+  float *s_ps = s_stage + g * 128;                                // partial mel sums (aliases stage)
+  float *s_lmel = s_ps + kMaxSlots;                               // log-mel of the frame (32 floats)
 
   // ---- cooperative load of the shared tables
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tw512[i] = F.tw512[i];
-  for (int i = threadIdx.x; i < F.mel_iters * 16; i += blockDim.x) s_mel[i] = F.mel_entries[i];
-  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
-  for (int i = threadIdx.x; i < 2 * P.n_bands; i += blockDim.x) s_slots[i] = F.band_slots[i];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) { s_tw512[i] = F.tw512[i]; s_tw256[i] = F.tw256[i]; }
+  for (int i = threadIdx.x; i < MP * 16; i += blockDim.x) s_win[i] = F.win[i];
+  for (int i = threadIdx.x; i < U * 16; i += blockDim.x) {
+    s_melw0[i] = F.melw[2 * i]; s_melw1[i] = F.melw[2 * i + 1]; s_melo[i] = F.melo[i];
+  }
+  for (int i = threadIdx.x; i < 16 * 28; i += blockDim.x) s_dct[i] = F.dct28[i];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
   __syncthreads();
 
   const int tile = blockIdx.x * kWavesPerBlock + wave;
@@ -199,154 +220,169 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) lld_mfcc512(LldParams P, 
   const int16_t *x = P.pcm + s_utt;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 3) == 0);   // H even => every pair start is even
 
-  // ---- per-lane constants: window for my sample pairs, inter-stage twiddles
-  float wre[MP], wim[MP];
-#pragma unroll
-  for (int m = 0; m < MP; ++m) {
-    const int n = 2 * (j + 16 * m) - P.pad_left;
-    wre[m] = (n >= 0 && n < P.N) ? P.window[n] : 0.0f;
-    wim[m] = (n + 1 >= 0 && n + 1 < P.N) ? P.window[n + 1] : 0.0f;
-  }
-  float twr[16], twi[16];
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    const float2 w = F.tw256[j * 16 + k1];
-    twr[k1] = w.x; twi[k1] = w.y;
-  }
   const float dgain = (j < P.n_mfcc) ? P.dct_gain[j] : 0.0f;
   const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
+  const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
+  const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
+  const int pj = (16 - j) & 15;                                       // partner lane (bins 256-k)
+  const int zrow = (j == 0) ? 16 : 0;
+  const int n_steps = (stage_floats + 127) >> 7;
 
   const int t_end = (t_first + kTileFrames < T) ? t_first + kTileFrames : T;
   PcmRegs R;
-  pcm_prefetch(x, utt_len, (int64_t)t_first * P.H, P.H, stage_floats, aligned, lane, R);
+  pcm_prefetch(x, utt_len, (int64_t)t_first * P.H, P.H, n_steps, aligned, lane, R);
 
   for (int tp = t_first; tp < t_end; tp += 4) {
     const int t = tp + g;                       // my frame
     const bool live = t < t_end;
-    // ------------------------------------------------------------ stage PCM (R0, R2) from registers
+    // ------------------------------------------------------------ stage PCM (R0 scale folded, R2)
     {
       float carry = 0.0f;                       // odd sample of lane 63 of the previous step
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int i2 = lane + 64 * r;
-        const float a = pcm16_to_float((int16_t)(R.pair[r] & 0xffffu));
-        const float b = pcm16_to_float((int16_t)(R.pair[r] >> 16));
-        float ya = a, yb = b;
-        if (PREEMPH) {
-          const float pa = lane_shr1(b, carry, lane);
-          carry = __shfl(b, 63);
-          ya = a - kpre * pa;
-          yb = b - kpre * a;
+        if (r < n_steps) {
+          const float a = (float)(int16_t)(R.pair[r] & 0xffffu);
+          const float b = (float)(int16_t)(R.pair[r] >> 16);
+          float ya = a, yb = b;
+          if (PREEMPH) {
+            const float pa = lane_shr1(b, carry);
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+            ya = a - kpre * pa;
+            yb = b - kpre * a;
+          }
+          const int i2 = lane + 64 * r;
+          if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
         }
-        if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
       }
-      if (PREEMPH && lane < 4) s_spec[lane] = P.one_minus_k * pcm16_to_float((int16_t)R.first);
+      if (PREEMPH && lane < 4) s_spec[lane] = P.one_minus_k * (float)R.first;
     }
     wave_lds_fence();
     // next pass's PCM: loads fly while this pass computes
-    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, stage_floats, aligned, lane, R);
+    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, n_steps, aligned, lane, R);
 
     // ------------------------------------------------------------ load frame (R3)
     float re[16], im[16];
-    const float *fr = s_stage + g * P.H - P.pad_left;       // fr[q - ...]: sample n = q - pad_left of my frame
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       if (m < MP) {
-        const int q = 2 * (j + 16 * m);
-        // q < pad_left only inside the left zero padding (window 0 there, but the
-        // address would fall in front of the staged samples: do not touch it)
-        float2 v = (q >= P.pad_left) ? *reinterpret_cast<const float2 *>(fr + q) : make_float2(0.0f, 0.0f);
-        if (PREEMPH && q == P.pad_left) v.x = s_spec[g];    // y[0] = (1-k) x[0]
-        re[m] = v.x * wre[m];
-        im[m] = v.y * wim[m];
+        int e = fo + 32 * m;
+        e = e < 0 ? 0 : e;                     // left zero padding: window is 0 there, keep the address legal
+        float2 v = *reinterpret_cast<const float2 *>(s_stage + e);
+        if (PREEMPH && m == m0 && j == j0) v.x = s_spec[g];   // y[0] = (1-k) x[0]
+        const float2 w = s_win[m * 16 + j];
+        re[m] = v.x * w.x;
+        im[m] = v.y * w.y;
       } else {
         re[m] = 0.0f; im[m] = 0.0f;
       }
     }
-    wave_lds_fence();   // stage area is dead from here (PB aliases it)
+    wave_lds_fence();   // stage area is dead from here (PS/lmel alias it)
 
     // ------------------------------------------------------------ 256-point complex FFT
     dft16(re, im);                                           // over m  -> index k1
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) cmul(re[k1], im[k1], twr[k1], twi[k1]);
+    for (int k1 = 1; k1 < 16; ++k1) {
+      const float2 w = s_tw256[k1 * 16 + j];
+      cmul(re[k1], im[k1], w.x, w.y);
+    }
+    // 16x16 transpose, re then im through the same 272-float buffer
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) s_tb[k1 * kTBStride + j] = make_float2(re[k1], im[k1]);
+    for (int k1 = 0; k1 < 16; ++k1) s_gb[k1 * kTBStride + j] = re[k1];
     wave_lds_fence();
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const float2 v = s_tb[j * kTBStride + jj];             // lane j now plays k1 = j
-      re[jj] = v.x; im[jj] = v.y;
-    }
+    for (int jj = 0; jj < 16; ++jj) re[jj] = s_gb[j * kTBStride + jj];
+    wave_lds_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) s_gb[k1 * kTBStride + j] = im[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) im[jj] = s_gb[j * kTBStride + jj];
     wave_lds_fence();
     dft16(re, im);                                           // over j -> k2 ; Z[j + 16 k2]
 
-    // ------------------------------------------------------------ untangle + power
+    // ------------------------------------------------------------ untangle pairs + power
+    // lane j writes Z[j+16 k2], k2 = 8..15 (what lane 16-j needs); reads the partner's
+    // Z[256 - (j+16 q)] for q = 0..7.
+    float2 *s_zx = reinterpret_cast<float2 *>(s_gb);
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) s_tb[j + 16 * k2] = make_float2(re[k2], im[k2]);
-    if (j == 0) s_tb[256] = make_float2(re[0], im[0]);       // Z[256] == Z[0]
+    for (int k2 = 8; k2 < 16; ++k2) s_zx[(k2 - 8) * 16 + j] = make_float2(re[k2], im[k2]);
     wave_lds_fence();
-    float pw[16];
+    float zr[8], zi[8];
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
-      const int k = j + 16 * k2;
-      const float2 zp = s_tb[256 - k];
+    for (int q = 0; q < 8; ++q) {
+      const float2 v = s_zx[(7 - q) * 16 + pj + zrow];
+      zr[q] = v.x; zi[q] = v.y;
+    }
+    wave_lds_fence();   // partner reads done: the buffer becomes PB
+    float *s_pb = s_gb;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = j + 16 * q;
       const float2 w = s_tw512[k];
-      const float a = re[k2], b = im[k2], c = zp.x, d = zp.y;
+      const float a = re[q], b = im[q], c = zr[q], d = zi[q];
       const float sr = a + c, si = b - d, dr = a - c, di = b + d;
-      const float xr = 0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr));
-      const float xi = 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si));
-      const float s = fmaf(xi, xi, xr * xr);
-      pw[k2] = USE_POWER ? s : __fsqrt_rn(s);
+      const float ur = fmaf(w.x, dr, -w.y * di);
+      const float ui = fmaf(w.x, di, w.y * dr);
+      const float xr = sr + ui, xi = si - ur;      // 2 X[k]
+      const float yr = sr - ui, yi = si + ur;      // same modulus as 2 X[256-k]
+      float pk = fmaf(xi, xi, xr * xr);            // 4 |X[k]|^2
+      float pm = fmaf(yi, yi, yr * yr);            // 4 |X[256-k]|^2
+      if (q == 0 && j == 0) {                      // DC / Nyquist: X[0] = a+b, X[256] = a-b
+        const float v0 = 2.0f * (a + b), v1 = 2.0f * (a - b);
+        pk = v0 * v0; pm = v1 * v1;
+      }
+      if (!USE_POWER) { pk = __fsqrt_rn(pk); pm = __fsqrt_rn(pm); }
+      s_pb[k] = pk;
+      s_pb[256 - k] = pm;
     }
-    float p_nyq = 0.0f;
-    if (j == 0) {                                            // X[256] = Re Z0 - Im Z0
-      const float v = re[0] - im[0];
-      p_nyq = USE_POWER ? v * v : fabsf(v);
+    if (j == 0) {                                  // k = 128 pairs with itself
+      const float a = re[8], b = im[8];
+      const float s = 4.0f * fmaf(b, b, a * a);
+      s_pb[128] = USE_POWER ? s : __fsqrt_rn(s);
+    } else if (j < 8) {
+      s_pb[256 + j] = 0.0f;                        // octet 32 is read as a whole by the mel units
     }
-    wave_lds_fence();   // all partner reads done before PS (alias of the Z buffer) is written
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) s_pb[j + 16 * k2] = pw[k2];
-    if (j == 0) s_pb[256] = p_nyq;
     wave_lds_fence();
 
     // ------------------------------------------------------------ mel (R6)
-    {
-      const unsigned char *pbb = reinterpret_cast<const unsigned char *>(s_pb);
-      float acc = 0.0f;
-      for (int c = 0; c < F.mel_iters; c += kMelChunk) {
-        unsigned slot = 0;
-#pragma unroll
-        for (int e = 0; e < kMelChunk; ++e) {
-          const uint2 en = s_mel[(c + e) * 16 + j];
-          const float pv = *reinterpret_cast<const float *>(pbb + (en.x & 0xffffu));
-          acc = fmaf(pv, __uint_as_float(en.y), acc);
-          slot = en.x >> 16;
-        }
-        s_ps[slot] = acc;        // slot of the chunk (dummy slot for padding chunks)
-        acc = 0.0f;
-      }
+    for (int i = 0; i < U; ++i) {
+      const uint32_t o = s_melo[i * 16 + j];
+      const float4 *pp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(s_pb) + (o & 0xffffu));
+      const float4 p0 = pp[0], p1 = pp[1];
+      const float4 w0 = s_melw0[i * 16 + j], w1 = s_melw1[i * 16 + j];
+      float acc = p0.x * w0.x;
+      acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
+      acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
+      s_ps[o >> 16] = acc;        // slot of the unit (dummy slot for padding units)
     }
     wave_lds_fence();
-    // band sums: lane j handles bands j and j+16
+    // band sums: lane j handles bands j and j+16 (pads up to 32 with zeros for the b128 DCT reads)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int b = j + 16 * h;
       if (b < P.n_bands) {
         float acc = 0.0f;
         for (int s = s_slots[2 * b]; s < s_slots[2 * b + 1]; ++s) acc += s_ps[s];
-        s_lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
+        s_lmel[b] = log_mel(acc * F.mel_scale, P.melfloor, P.log_floor);
+      } else {
+        s_lmel[b] = 0.0f;
       }
     }
     wave_lds_fence();
 
     // ------------------------------------------------------------ DCT + lifter (R7)
     if (j < P.n_mfcc) {
-      const float *row_c = s_dct + j * P.n_bands;
+      const float4 *row_c = reinterpret_cast<const float4 *>(s_dct + j * 28);
+      const float4 *lm = reinterpret_cast<const float4 *>(s_lmel);
       float acc = 0.0f;
-      for (int m = 0; m < P.n_bands; ++m) acc = fmaf(s_lmel[m], row_c[m], acc);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const float4 l = lm[q], c = row_c[q];
+        acc = fmaf(l.x, c.x, acc); acc = fmaf(l.y, c.y, acc); acc = fmaf(l.z, c.z, acc); acc = fmaf(l.w, c.w, acc);
+      }
       if (live) P.out[(row0 + t) * P.ld_out + j] = acc * dgain;
     }
-    wave_lds_fence();   // PB/PS areas are reused by the next pass's staging
+    wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
   }
 }
 
@@ -357,71 +393,99 @@ bool fast512_applicable(int Nfft, int N) { return Nfft == 512 && N <= 512 && N >
 
 int fast512_tile_frames() { return kTileFrames; }
 
-// Mel work list: every band's contributions in the reference's order (rising
-// bins with weight 1-w, then falling bins with weight w; melspec.cpp:544-553),
-// cut into chunks of kMelChunk entries (zero-weight padded), chunk c dealt to
-// lane c % 16 at position c / 16, partial slot = c.
-int fast512_build_host(const MelBank &mel, int n_mfcc, double win_offset, int pad_left, int H, Fast512Host &h) {
-  if (mel.n_bands > 32 || n_mfcc > 16 || win_offset != 0.0 || (pad_left & 1) || (H & 1) || H < 2) return -1;
+// Tables of the fast kernel. Mel work units: for every band, every aligned
+// octet of bins that intersects the band's bin range [rise_lo, fall_hi) is one
+// unit with 8 weights (1-w on the rising run, w on the falling run, 0 outside;
+// melspec.cpp:544-553), unit c is dealt to lane c % 16 at position c / 16 and
+// writes partial slot c; a band's partials are consecutive slots.
+int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, const std::vector<float> &window,
+                       const MelBank &mel, const DctTables &dct, Fast512Host &h) {
+  const int pad_left = cfg.zero_pad_symmetric ? (int)((geo.Nfft - geo.N) / 2) : 0;
+  const int H = (int)geo.H, N = (int)geo.N;
+  if (mel.n_bands > 28 || dct.n_mfcc > 16 || cfg.win_offset != 0.0 || (pad_left & 1) || (H & 1) || H < 2) return -1;
+  h.mp = (pad_left + N) <= 13 * 32 ? 13 : 16;
+  h.stage_floats = 3 * H + 32 * h.mp;
+  if (h.stage_floats > 8 * 128) return -1;                     // PcmRegs holds 8 x 64 pairs
+  h.stage_alloc = std::max((h.stage_floats + 3) & ~3, kMinStage);
   h.tw256.resize(256);
-  for (int j = 0; j < 16; ++j)
-    for (int k1 = 0; k1 < 16; ++k1) {
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int j = 0; j < 16; ++j) {
       const double a = -2.0 * M_PI * double(j * k1) / 256.0;
-      h.tw256[j * 16 + k1] = make_float2(float(cos(a)), float(sin(a)));
+      h.tw256[k1 * 16 + j] = make_float2(float(cos(a)), float(sin(a)));
     }
   h.tw512.resize(256);
   for (int k = 0; k < 256; ++k) {
     const double a = -2.0 * M_PI * double(k) / 512.0;
     h.tw512[k] = make_float2(float(cos(a)), float(sin(a)));
   }
-  struct Entry { uint32_t off; float w; };
-  std::vector<std::vector<Entry>> chunks;
-  h.band_slots.assign(size_t(2) * mel.n_bands, 0);
-  for (int b = 0; b < mel.n_bands; ++b) {
-    std::vector<Entry> list;
-    for (int n = mel.rise_lo[b]; n < mel.rise_hi[b]; ++n) list.push_back({uint32_t(n) * 4u, 1.0f - mel.coef[n]});
-    for (int n = mel.fall_lo[b]; n < mel.fall_hi[b]; ++n) list.push_back({uint32_t(n) * 4u, mel.coef[n]});
-    h.band_slots[2 * b] = int32_t(chunks.size());
-    for (size_t i = 0; i < list.size(); i += kMelChunk) {
-      std::vector<Entry> c(list.begin() + i, list.begin() + std::min(list.size(), i + kMelChunk));
-      c.resize(kMelChunk, Entry{0u, 0.0f});
-      chunks.push_back(c);
+  // window pairs with R0's 1/32767 folded in (one rounding from the double quotient)
+  h.win.assign(size_t(h.mp) * 16, make_float2(0.f, 0.f));
+  for (int m = 0; m < h.mp; ++m)
+    for (int j = 0; j < 16; ++j) {
+      const int n = 2 * (j + 16 * m) - pad_left;
+      float a = 0.f, b = 0.f;
+      if (n >= 0 && n < N) a = float(double(window[n]) / 32767.0);
+      if (n + 1 >= 0 && n + 1 < N) b = float(double(window[n + 1]) / 32767.0);
+      h.win[size_t(m) * 16 + j] = make_float2(a, b);
     }
-    h.band_slots[2 * b + 1] = int32_t(chunks.size());
+  // mel units
+  struct Unit { uint32_t off; float w[8]; };
+  std::vector<Unit> units;
+  h.band_slots.assign(64, 0);
+  for (int b = 0; b < mel.n_bands; ++b) {
+    int lo = -1, hi = -1;
+    if (mel.rise_hi[b] > mel.rise_lo[b]) { lo = mel.rise_lo[b]; hi = mel.rise_hi[b]; }
+    if (mel.fall_hi[b] > mel.fall_lo[b]) { if (lo < 0) lo = mel.fall_lo[b]; hi = mel.fall_hi[b]; }
+    h.band_slots[2 * b] = int32_t(units.size());
+    if (lo >= 0) {
+      for (int o = lo / 8; o <= (hi - 1) / 8; ++o) {
+        Unit un;
+        un.off = uint32_t(o) * 32u;
+        for (int e = 0; e < 8; ++e) {
+          const int n = 8 * o + e;
+          float w = 0.0f;
+          if (n >= mel.rise_lo[b] && n < mel.rise_hi[b]) w = 1.0f - mel.coef[n];
+          else if (n >= mel.fall_lo[b] && n < mel.fall_hi[b]) w = mel.coef[n];
+          un.w[e] = w;
+        }
+        units.push_back(un);
+      }
+    }
+    h.band_slots[2 * b + 1] = int32_t(units.size());
   }
-  h.n_slots = int(chunks.size());
-  if (h.n_slots + 1 > 96) return -1;
-  const int per_lane = (h.n_slots + 15) / 16;
-  if (per_lane > kMaxChunksPerLane) return -1;
-  h.mel_iters = per_lane * kMelChunk;
-  h.mel_entries.assign(size_t(h.mel_iters) * 16, make_uint2(uint32_t(h.n_slots) << 16, 0u));
+  h.n_slots = int(units.size());
+  if (h.n_slots + 1 > kMaxSlots) return -1;
+  h.mel_units = (h.n_slots + 15) / 16;
+  if (h.mel_units > kMaxUnitsPerLane || h.mel_units < 1) return -1;
+  h.melw.assign(size_t(h.mel_units) * 16 * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+  h.melo.assign(size_t(h.mel_units) * 16, uint32_t(h.n_slots) << 16);     // padding units: octet 0, dummy slot
   for (int c = 0; c < h.n_slots; ++c) {
     const int lane = c % 16, pos = c / 16;
-    for (int e = 0; e < kMelChunk; ++e) {
-      uint32_t wbits;
-      std::memcpy(&wbits, &chunks[c][e].w, 4);
-      h.mel_entries[size_t(pos * kMelChunk + e) * 16 + lane] = make_uint2(chunks[c][e].off | (uint32_t(c) << 16), wbits);
-    }
+    const size_t idx = size_t(pos) * 16 + lane;
+    h.melw[2 * idx] = make_float4(units[c].w[0], units[c].w[1], units[c].w[2], units[c].w[3]);
+    h.melw[2 * idx + 1] = make_float4(units[c].w[4], units[c].w[5], units[c].w[6], units[c].w[7]);
+    h.melo[idx] = units[c].off | (uint32_t(c) << 16);
   }
+  // the kernel leaves 4|X|^2 (or 2|X| without usePower) in the power buffer
+  h.mel_scale = mel.scale * (cfg.use_power ? 0.25f : 0.5f);
+  h.dct28.assign(16 * 28, 0.0f);
+  for (int r = 0; r < dct.n_mfcc; ++r)
+    for (int m = 0; m < mel.n_bands; ++m) h.dct28[size_t(r) * 28 + m] = dct.cos_rows[size_t(r) * mel.n_bands + m];
   return 0;
 }
 
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, hipStream_t s) {
-  const int stage_floats = 3 * P.H + 512;
-  const int shared_bytes = (256 * 8 + F.mel_iters * 16 * 8 + P.n_mfcc * P.n_bands * 4 + 2 * P.n_bands * 4 + 15) & ~15;
-  const int wave_floats = (stage_floats > 4 * 260 ? stage_floats : 4 * 260) + 4;
-  const int wave_bytes = ((wave_floats * 4 + 15) & ~15) + 4 * kGroupBytes;
-  const size_t lds = size_t(shared_bytes) + size_t(kWavesPerBlock) * wave_bytes;
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, hipStream_t s) {
+  const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64;
+  const int wave_floats = h.stage_alloc + 4 + 4 * kGroupFloats;
+  const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
   const unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
-  const bool mp13 = (P.pad_left + P.N) <= 13 * 32;
-  if (3 * P.H + 512 > 8 * 128) return hipErrorInvalidValue;   // PcmRegs holds 8 x 64 pairs
-  const void *fn = nullptr;
-#define SMILEHIP_PICK(MPV, PE, UP)                                                                       \
+  const bool mp13 = h.mp == 13;
+#define SMILEHIP_PICK(MPV, PE, UP)                                                                        \
   if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP) {                         \
-    fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP>);                                        \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP>);                            \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
     if (e != hipSuccess) return e;                                                                         \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F, stage_floats); \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F);   \
   }
   SMILEHIP_PICK(13, true, true)
   SMILEHIP_PICK(13, true, false)

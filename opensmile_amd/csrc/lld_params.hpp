@@ -42,17 +42,24 @@ struct LldParams {
 
 // Device-side tables of the fast Nfft=512 kernel (lld_mfcc512.hip)
 struct Fast512Tables {
-  const float2 *tw256;        // [16*16] w256^(j*k1), index j*16+k1
-  const float2 *tw512;        // [256]   e^{-2 pi i k/512}
-  const uint2 *mel_entries;   // [mel_iters][16]: {byte offset of bin | slot<<16, weight bits}
-  const int32_t *band_slots;  // [2*n_bands]: partial-slot range [s, e) per band
-  int32_t mel_iters;
+  const float2 *tw256;        // [256] w256^(j*k1), index k1*16+j
+  const float2 *tw512;        // [256] e^{-2 pi i k/512}
+  const float2 *win;          // [MP*16] window pairs (x 1/32767), index m*16+j
+  const float4 *melw;         // [U*16*2] weights of unit (pos, lane): two float4
+  const uint32_t *melo;       // [U*16] byte offset of the unit's octet | slot << 16
+  const float *dct28;         // [16 x 28] DCT rows padded to 28
+  const int32_t *band_slots;  // [64] partial-slot range [s, e) per band
+  int32_t mel_units;          // units per lane
   int32_t n_slots;
+  int32_t stage_floats, stage_alloc;
+  float mel_scale;
 };
 
 struct DeltaParams {
   const int64_t *frame_off;    // [n_utt+1]
-  const int32_t *row_utt;      // optional [total_frames] (unused when null)
+  const int32_t *tile_utt;     // [n_dtiles] delta tiles: utterance
+  const int32_t *tile_t0;      // [n_dtiles] first frame of the tile
+  int32_t n_dtiles;
   int32_t n_utt;
   int64_t total_frames;
   float *io;                   // rows: [static D | delta D | accel D ...]

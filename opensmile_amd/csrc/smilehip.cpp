@@ -75,8 +75,10 @@ struct smilehip_plan {
   DctTables dct;
   DevBuf<float> d_window, d_mel_coef, d_dct_rows, d_dct_gain;
   DevBuf<int32_t> d_mel_rng;
-  DevBuf<float2> d_tw_half, d_tw_full, d_tw256, d_tw512;
-  DevBuf<uint2> d_mel_entries;
+  DevBuf<float2> d_tw_half, d_tw_full, d_tw256, d_tw512, d_fwin;
+  DevBuf<float4> d_melw;
+  DevBuf<uint32_t> d_melo;
+  DevBuf<float> d_dct28;
   DevBuf<int32_t> d_band_slots;
   Fast512Host fast;
   bool use_fast = false;
@@ -101,8 +103,8 @@ struct smilehip_batch {
   std::vector<int64_t> h_samp_off, h_frame_off;
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
-  DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short;
-  int32_t n_tiles = 0;
+  DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
+  int32_t n_tiles = 0, n_dtiles = 0;
 };
 
 // ------------------------------------------------------------- life cycle
@@ -198,8 +200,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
   p->use_fast = false;
   if (!p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
-    const int pad = p->cfg.zero_pad_symmetric ? (int)((p->geo.Nfft - p->geo.N) / 2) : 0;
-    p->use_fast = fast512_build_host(p->mel, p->dct.n_mfcc, p->cfg.win_offset, pad, (int)p->geo.H, p->fast) == 0;
+    p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
   }
   if (!upload) return SMILEHIP_OK;
   if ((rc = p->d_window.upload(p->h_window))) return rc;
@@ -212,7 +213,10 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if (p->use_fast) {
     if ((rc = p->d_tw256.upload(p->fast.tw256))) return rc;
     if ((rc = p->d_tw512.upload(p->fast.tw512))) return rc;
-    if ((rc = p->d_mel_entries.upload(p->fast.mel_entries))) return rc;
+    if ((rc = p->d_fwin.upload(p->fast.win))) return rc;
+    if ((rc = p->d_melw.upload(p->fast.melw))) return rc;
+    if ((rc = p->d_melo.upload(p->fast.melo))) return rc;
+    if ((rc = p->d_dct28.upload(p->fast.dct28))) return rc;
     if ((rc = p->d_band_slots.upload(p->fast.band_slots))) return rc;
   }
   return SMILEHIP_OK;
@@ -313,7 +317,8 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   if (n_utt == 0) b->h_samp_off.assign(1, 0);
   b->h_frame_off.assign(size_t(n_utt) + 1, 0);
   const int short_T = 4 * plan->cfg.delta_win;
-  std::vector<int32_t> tile_utt, tile_t0;
+  std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0;
+  const int64_t dtile = delta_tile_frames();
   const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
   for (int32_t u = 0; u < n_utt; ++u) {
     const int64_t len = h_off[u + 1] - h_off[u];
@@ -328,12 +333,18 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       tile_utt.push_back(u);
       tile_t0.push_back((int32_t)t0);
     }
+    for (int64_t t0 = 0; t0 < T; t0 += dtile) {
+      dtile_utt.push_back(u);
+      dtile_t0.push_back((int32_t)t0);
+    }
   }
   b->total_frames = b->h_frame_off[n_utt];
   b->n_tiles = (int32_t)tile_utt.size();
+  b->n_dtiles = (int32_t)dtile_utt.size();
   int rc;
   if ((rc = b->d_samp_off.upload(b->h_samp_off)) || (rc = b->d_frame_off.upload(b->h_frame_off)) ||
       (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) ||
+      (rc = b->d_dtile_utt.upload(dtile_utt)) || (rc = b->d_dtile_t0.upload(dtile_t0)) ||
       (rc = b->d_short.upload(b->h_short))) {
     delete b;
     return rc;
@@ -392,12 +403,15 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
 extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, float *d_io, int64_t ld, int32_t D,
                                     int32_t W, int32_t n_orders, void *stream) {
   if (!plan || !b || !d_io) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: null argument");
-  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || ld < (int64_t)D * (1 + n_orders))
+  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 16 || ld < (int64_t)D * (1 + n_orders))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
   if (b->total_frames == 0) return SMILEHIP_OK;
   DeltaParams Q;
   std::memset(&Q, 0, sizeof(Q));
   Q.frame_off = b->d_frame_off.p;
+  Q.tile_utt = b->d_dtile_utt.p;
+  Q.tile_t0 = b->d_dtile_t0.p;
+  Q.n_dtiles = b->n_dtiles;
   Q.n_utt = b->n_utt;
   Q.total_frames = b->total_frames;
   Q.io = d_io;
@@ -451,11 +465,17 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     Fast512Tables F;
     F.tw256 = plan->d_tw256.p;
     F.tw512 = plan->d_tw512.p;
-    F.mel_entries = plan->d_mel_entries.p;
+    F.win = plan->d_fwin.p;
+    F.melw = plan->d_melw.p;
+    F.melo = plan->d_melo.p;
+    F.dct28 = plan->d_dct28.p;
     F.band_slots = plan->d_band_slots.p;
-    F.mel_iters = plan->fast.mel_iters;
+    F.mel_units = plan->fast.mel_units;
     F.n_slots = plan->fast.n_slots;
-    e = launch_mfcc512(P, F, s);
+    F.stage_floats = plan->fast.stage_floats;
+    F.stage_alloc = plan->fast.stage_alloc;
+    F.mel_scale = plan->fast.mel_scale;
+    e = launch_mfcc512(P, F, plan->fast, s);
   } else {
     e = launch_mfcc_generic(P, s);
   }
