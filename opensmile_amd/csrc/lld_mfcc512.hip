@@ -133,6 +133,23 @@ struct PcmRegs {
   int32_t first;
 };
 
+// tail of an utterance / unaligned PCM: guarded element loads (rare, kept out of line
+// so that its registers and code do not burden the hot path)
+__device__ __noinline__ void pcm_prefetch_slow(const int16_t *x, int64_t utt_len, int64_t sbase, int n_steps,
+                                               int lane, uint32_t *pair) {
+#pragma unroll 1
+  for (int r = 0; r < 8; ++r) {
+    const int64_t s0 = sbase + 2 * (lane + 64 * r);
+    uint32_t v = 0;
+    if (r < n_steps) {
+      const uint32_t lo = (s0 < utt_len) ? (uint16_t)x[s0] : 0u;
+      const uint32_t hi = (s0 + 1 < utt_len) ? (uint16_t)x[s0 + 1] : 0u;
+      v = lo | (hi << 16);
+    }
+    pair[r] = v;
+  }
+}
+
 __device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, int64_t sbase, int H, int n_steps,
                                              bool aligned, int lane, PcmRegs &R) {
   if (aligned && sbase + 128 * n_steps <= utt_len) {
@@ -141,17 +158,10 @@ __device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, 
 #pragma unroll
     for (int r = 0; r < 8; ++r) R.pair[r] = (r < n_steps) ? p[64 * r] : 0u;
   } else {
+    uint32_t tmp[8];
+    pcm_prefetch_slow(x, utt_len, sbase, n_steps, lane, tmp);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int64_t s0 = sbase + 2 * (lane + 64 * r);
-      uint32_t v = 0;
-      if (r < n_steps) {
-        const uint32_t lo = (s0 < utt_len) ? (uint16_t)x[s0] : 0u;
-        const uint32_t hi = (s0 + 1 < utt_len) ? (uint16_t)x[s0 + 1] : 0u;
-        v = lo | (hi << 16);
-      }
-      R.pair[r] = v;
-    }
+    for (int r = 0; r < 8; ++r) R.pair[r] = tmp[r];
   }
   R.first = 0;
   if (lane < 4) {
@@ -257,9 +267,6 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       if (PREEMPH && lane < 4) s_spec[lane] = P.one_minus_k * (float)R.first;
     }
     wave_lds_fence();
-    // next pass's PCM: loads fly while this pass computes
-    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, n_steps, aligned, lane, R);
-
     // ------------------------------------------------------------ load frame (R3)
     float re[16], im[16];
 #pragma unroll
@@ -343,6 +350,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       s_pb[256 + j] = 0.0f;                        // octet 32 is read as a whole by the mel units
     }
     wave_lds_fence();
+
+    // next pass's PCM: issued here, where register pressure is low; the loads fly
+    // during mel/DCT of this pass and the other resident waves' arithmetic
+    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, n_steps, aligned, lane, R);
 
     // ------------------------------------------------------------ mel (R6)
     for (int i = 0; i < U; ++i) {
