@@ -72,14 +72,14 @@ def cpu_baseline(max_seconds=25.0):
         n_cal = 8
         for i in range(n_cal):
             subprocess.run([exe, "-C", conf, "-I", os.path.join(td, f"u{i % n_unique}.wav"),
-                            "-O", os.path.join(td, "cal.htk"), "-l", "0", "-nologfile"],
+                            "-O", os.path.join(td, "cal.htk"), "-l", "0"],
                            cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         per_file = (time.perf_counter() - t0) / n_cal
         one_core = 998 / per_file
         n_files = int(max(cores * 4, min(2000, (max_seconds * 0.6) / per_file * cores)))
         jobs = "\n".join(f"{i % n_unique} {i}" for i in range(n_files))
         cmd = (f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {td}/u$0.wav -O {td}/o$1.htk "
-               f"-l 0 -nologfile >/dev/null 2>&1'")
+               f"-l 0 >/dev/null 2>&1'")
         t0 = time.perf_counter()
         subprocess.run(cmd, shell=True, input=jobs.encode(), cwd=td, check=True)
         dt = time.perf_counter() - t0

@@ -91,7 +91,21 @@ typedef struct smilehip_lld_config {
    * 0 = static only, 1 = +delta, 2 = +delta+accel (cVectorConcat order) */
   int32_t n_delta;
   int32_t delta_win;
+  /* --- single-component plans (the plugin's per-component overrides) ---
+   * A component sitting in the middle of a graph knows its input size and the
+   * level's frameSizeSec, not the wave source's sample rate: when > 0 these
+   * replace the values derived from sample_rate/frame_size_sec. stage_mask
+   * selects which tables the plan builds (0 = whole chain). */
+  int64_t  force_frame_size;            /* N  */
+  double   force_fft_frame_size_sec;    /* frameSizeSec of the spectrum level (cMelspec::configureField, melspec.cpp:150-173) */
+  uint32_t stage_mask;                  /* SMILEHIP_STAGE_* bits */
 } smilehip_lld_config;
+
+#define SMILEHIP_STAGE_WINDOW 1u
+#define SMILEHIP_STAGE_FFT    2u
+#define SMILEHIP_STAGE_MEL    4u
+#define SMILEHIP_STAGE_MFCC   8u
+#define SMILEHIP_STAGE_ALL    15u
 
 /* Integer geometry derived from the config -- the part of the contract that
  * must be bit-exact. */
@@ -119,6 +133,14 @@ const char *smilehip_last_error(void);
 int  smilehip_init(int device, smilehip_context **ctx);
 void smilehip_shutdown(smilehip_context *ctx);
 int  smilehip_device_name(smilehip_context *ctx, char *buf, int buflen);
+
+/* Plain device-memory plumbing for hosts that do not link the HIP runtime
+ * themselves (the openSMILE plugin is compiled with the host g++ only). */
+int  smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr);
+int  smilehip_free(smilehip_context *ctx, void *d_ptr);
+int  smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream);
+int  smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream);
+int  smilehip_stream_synchronize(smilehip_context *ctx, void *stream);
 
 /* fills c with config/mfcc/MFCC12_0_D_A.conf's values */
 void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c);

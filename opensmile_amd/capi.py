@@ -36,7 +36,12 @@ class LldConfig(C.Structure):
         ("first_mfcc", C.c_int32), ("last_mfcc", C.c_int32), ("cep_lifter", C.c_float),
         ("mfcc_htk_compatible", C.c_int32), ("melfloor", C.c_float),
         ("n_delta", C.c_int32), ("delta_win", C.c_int32),
+        ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
+        ("stage_mask", C.c_uint32),
     ]
+
+
+STAGE_WINDOW, STAGE_FFT, STAGE_MEL, STAGE_MFCC, STAGE_ALL = 1, 2, 4, 8, 15
 
 
 class Geometry(C.Structure):
@@ -54,6 +59,11 @@ SYMBOLS = {
     "smilehip_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "smilehip_shutdown": (None, [_vp]),
     "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "smilehip_free": (C.c_int, [_vp, _vp]),
+    "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "smilehip_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "smilehip_stream_synchronize": (C.c_int, [_vp, _vp]),
     "smilehip_config_mfcc12_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_plan_create": (C.c_int, [_vp, C.POINTER(LldConfig), C.POINTER(_vp)]),
     "smilehip_plan_create_host_only": (C.c_int, [C.POINTER(LldConfig), C.POINTER(_vp)]),
@@ -254,3 +264,38 @@ def extract_mfcc(pcm_list, cfg=None, device=0):
     plan.close()
     ctx.close()
     return res
+
+
+# ------------------------------------------------ per-component entry points
+# Device pointers are plain ints (e.g. torch.Tensor.data_ptr()); ld = leading
+# dimension in floats. Asynchronous on `stream`.
+def pcm16_to_float(ctx, d_pcm, n, d_out, stream=None):
+    _check(load().smilehip_pcm16_to_float(ctx._h, d_pcm, n, d_out, stream))
+
+
+def preemphasis_frames(ctx, d_src, ld_src, d_dst, ld_dst, n_frames, N, k, de=0, stream=None):
+    _check(load().smilehip_preemphasis_frames(ctx._h, d_src, ld_src, d_dst, ld_dst, n_frames, N, k, de, stream))
+
+
+def window_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
+    _check(load().smilehip_window_frames(plan._h, d_src, ld_src, d_dst, ld_dst, n_frames, stream))
+
+
+def rfft_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
+    _check(load().smilehip_rfft_frames(plan._h, d_src, ld_src, d_dst, ld_dst, n_frames, stream))
+
+
+def fftmag_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
+    _check(load().smilehip_fftmag_frames(plan._h, d_src, ld_src, d_dst, ld_dst, n_frames, stream))
+
+
+def melspec_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
+    _check(load().smilehip_melspec_frames(plan._h, d_src, ld_src, d_dst, ld_dst, n_frames, stream))
+
+
+def mfcc_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
+    _check(load().smilehip_mfcc_frames(plan._h, d_src, ld_src, d_dst, ld_dst, n_frames, stream))
+
+
+def delta_chain(plan, batch, d_io, ld, D, W, n_orders, stream=None):
+    _check(load().smilehip_delta_chain(plan._h, batch._h, d_io, ld, D, W, n_orders, stream))

@@ -76,13 +76,21 @@ __device__ __forceinline__ float2 untangle_bin(const float *re, const float *im,
   return make_float2(0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr)), 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si)));
 }
 
-// R5: cFFTmagphase magnitude (fftmagphase.cpp:215-221)
+// R5: cFFTmagphase magnitude (fftmagphase.cpp:215-221). sqrtf() compiles to the
+// correctly rounded sequence (v_sqrt_f32 + two FMA fix-ups); __fsqrt_rn is the
+// bare 1-ulp instruction on gfx950 and must not be used where bit-parity counts.
 __device__ __forceinline__ float bin_magnitude(float2 X, bool edge) {
-  return edge ? fabsf(X.x) : __fsqrt_rn(X.x * X.x + X.y * X.y);
+  return edge ? fabsf(X.x) : sqrtf(X.x * X.x + X.y * X.y);
 }
 
-// R7: log floor (mfcc.cpp:239-243)
+// R7: log floor (mfcc.cpp:239-243). The reference's logf (glibc) is correctly
+// rounded in practice; the device logf (v_log_f32 based) is ~1 ulp. The
+// reference-order kernels therefore take the double-precision log and round
+// once; the fast kernel uses log_mel_fast.
 __device__ __forceinline__ float log_mel(float v, float melfloor, float log_floor) {
+  return (v < melfloor) ? log_floor : (float)log((double)v);
+}
+__device__ __forceinline__ float log_mel_fast(float v, float melfloor, float log_floor) {
   return (v < melfloor) ? log_floor : logf(v);
 }
 

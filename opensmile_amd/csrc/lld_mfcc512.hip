@@ -338,14 +338,14 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         const float v0 = 2.0f * (a + b), v1 = 2.0f * (a - b);
         pk = v0 * v0; pm = v1 * v1;
       }
-      if (!USE_POWER) { pk = __fsqrt_rn(pk); pm = __fsqrt_rn(pm); }
+      if (!USE_POWER) { pk = sqrtf(pk); pm = sqrtf(pm); }
       s_pb[k] = pk;
       s_pb[256 - k] = pm;
     }
     if (j == 0) {                                  // k = 128 pairs with itself
       const float a = re[8], b = im[8];
       const float s = 4.0f * fmaf(b, b, a * a);
-      s_pb[128] = USE_POWER ? s : __fsqrt_rn(s);
+      s_pb[128] = USE_POWER ? s : sqrtf(s);
     } else if (j < 8) {
       s_pb[256 + j] = 0.0f;                        // octet 32 is read as a whole by the mel units
     }
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       if (b < P.n_bands) {
         float acc = 0.0f;
         for (int s = s_slots[2 * b]; s < s_slots[2 * b + 1]; ++s) acc += s_ps[s];
-        s_lmel[b] = log_mel(acc * F.mel_scale, P.melfloor, P.log_floor);
+        s_lmel[b] = log_mel_fast(acc * F.mel_scale, P.melfloor, P.log_floor);
       } else {
         s_lmel[b] = 0.0f;
       }

@@ -77,7 +77,7 @@ __global__ void k_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd,
   float m;
   if (k == 0) m = fabsf(a[0]);
   else if (k == K - 1) m = fabsf(a[1]);
-  else m = __fsqrt_rn(a[2 * k] * a[2 * k] + a[2 * k + 1] * a[2 * k + 1]);
+  else m = sqrtf(a[2 * k] * a[2 * k] + a[2 * k + 1] * a[2 * k + 1]);
   dst[f * ldd + k] = m;
 }
 

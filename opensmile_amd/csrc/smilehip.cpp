@@ -89,6 +89,7 @@ struct smilehip_plan {
   hipEvent_t ev[kRing][3] = {};
   int64_t n_timed = 0;
   int force_generic = 0;
+  uint32_t stage_mask = SMILEHIP_STAGE_ALL;
   ~smilehip_plan() {
     for (auto &slot : ev)
       for (auto &e : slot)
@@ -140,6 +141,33 @@ extern "C" int smilehip_device_name(smilehip_context *ctx, char *buf, int buflen
   return SMILEHIP_OK;
 }
 
+extern "C" int smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr) {
+  if (!ctx || !d_ptr) return fail(SMILEHIP_ERR_INVALID, "smilehip_alloc: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_free(smilehip_context *ctx, void *d_ptr) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_free: null context");
+  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_device: null argument");
+  if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
+  if (!ctx || (bytes && (!h_dst || !d_src))) return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_host: null argument");
+  if (bytes) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_stream_synchronize(smilehip_context *ctx, void *stream) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_synchronize: null context");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+
 extern "C" void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c) {
   std::memset(c, 0, sizeof(*c));
   c->struct_size = sizeof(*c);
@@ -173,9 +201,22 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   int rc;
   if ((rc = make_geometry(p->cfg, p->geo)) != SMILEHIP_OK) return fail(rc, "invalid framing parameters");
   if (p->geo.Nfft > 8192) return fail(SMILEHIP_ERR_INVALID, "FFT length %lld > 8192 unsupported", (long long)p->geo.Nfft);
-  if ((rc = make_window(p->cfg, p->geo.N, p->h_window)) != SMILEHIP_OK) return fail(rc, "unknown window function %d", p->cfg.win_func);
-  if ((rc = make_mel(p->cfg, p->geo, p->mel)) != SMILEHIP_OK) return fail(rc, "invalid mel bank parameters");
-  if ((rc = make_dct(p->cfg, p->dct)) != SMILEHIP_OK) return fail(rc, "invalid MFCC range");
+  const uint32_t mask = p->cfg.stage_mask ? p->cfg.stage_mask : SMILEHIP_STAGE_ALL;
+  p->h_window.assign(size_t(p->geo.N), 1.0f);
+  if ((mask & SMILEHIP_STAGE_WINDOW) && (rc = make_window(p->cfg, p->geo.N, p->h_window)) != SMILEHIP_OK)
+    return fail(rc, "unknown window function %d", p->cfg.win_func);
+  if (mask & SMILEHIP_STAGE_MEL) {
+    if ((rc = make_mel(p->cfg, p->geo, p->mel)) != SMILEHIP_OK) return fail(rc, "invalid mel bank parameters");
+  } else {
+    p->mel = MelBank();
+    p->mel.n_bands = p->cfg.n_bands;
+  }
+  if (mask & SMILEHIP_STAGE_MFCC) {
+    if ((rc = make_dct(p->cfg, p->dct)) != SMILEHIP_OK) return fail(rc, "invalid MFCC range");
+  } else {
+    p->dct = DctTables();
+  }
+  p->stage_mask = mask;
   if (p->cfg.n_delta < 0 || p->cfg.n_delta > 2) return fail(SMILEHIP_ERR_INVALID, "n_delta must be 0..2");
   if (p->cfg.n_delta > 0 && (p->cfg.delta_win < 1 || p->cfg.delta_win > 4))
     return fail(SMILEHIP_ERR_INVALID, "delta_win must be 1..4");
@@ -190,8 +231,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     const double a = -2.0 * M_PI * double(k) / double(p->geo.Nfft);
     twf[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
   }
-  std::vector<int32_t> rng(size_t(4) * p->mel.n_bands);
-  for (int b = 0; b < p->mel.n_bands; ++b) {
+  std::vector<int32_t> rng((mask & SMILEHIP_STAGE_MEL) ? size_t(4) * p->mel.n_bands : 0);
+  for (int b = 0; b < p->mel.n_bands && (mask & SMILEHIP_STAGE_MEL); ++b) {
     rng[4 * b + 0] = p->mel.rise_lo[b];
     rng[4 * b + 1] = p->mel.rise_hi[b];
     rng[4 * b + 2] = p->mel.fall_lo[b];
@@ -199,7 +240,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   }
   // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
   p->use_fast = false;
-  if (!p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
+  if (mask == SMILEHIP_STAGE_ALL && !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
     p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
   }
   if (!upload) return SMILEHIP_OK;
@@ -308,6 +349,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   if (!plan || !out || n_utt < 0 || (n_utt > 0 && !h_off)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_create: bad argument");
   *out = nullptr;
   if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached (tables only)");
+  if (plan->stage_mask != SMILEHIP_STAGE_ALL) return fail(SMILEHIP_ERR_INVALID, "single-component plan cannot run the fused chain");
   HIP_TRY(hipSetDevice(plan->ctx->device));
   auto *b = new (std::nothrow) smilehip_batch();
   if (!b) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
@@ -580,6 +622,7 @@ extern "C" int smilehip_window_frames(smilehip_plan *p, const float *d_src, int6
                                       int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_window_frames: null plan");
   if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_WINDOW)) return fail(SMILEHIP_ERR_INVALID, "smilehip_window_frames: plan was built without this stage's tables");
   int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.N, "smilehip_window_frames");
   if (rc) return rc;
   STAGE_RET(stage_window(d_src, ld_src, d_dst, ld_dst, n_frames, p->geo.N, p->d_window.p, (float)p->cfg.win_offset,
@@ -610,6 +653,7 @@ extern "C" int smilehip_melspec_frames(smilehip_plan *p, const float *d_src, int
                                        int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: null plan");
   if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_MEL)) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: plan was built without this stage's tables");
   int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, p->mel.n_bands, "smilehip_melspec_frames");
   if (rc) return rc;
   STAGE_RET(stage_melspec(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, p->mel.n_bands, p->cfg.use_power,
@@ -620,6 +664,7 @@ extern "C" int smilehip_mfcc_frames(smilehip_plan *p, const float *d_src, int64_
                                     int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_frames: null plan");
   if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_MFCC)) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_frames: plan was built without this stage's tables");
   int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, "smilehip_mfcc_frames");
   if (rc) return rc;
   STAGE_RET(stage_mfcc(d_src, ld_src, d_dst, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, p->d_dct_rows.p,

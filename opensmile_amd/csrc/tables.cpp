@@ -23,6 +23,7 @@ int make_geometry(const smilehip_lld_config &c, Geometry &g) {
   g.N = std::lround(c.frame_size_sec / T);
   const double step = (c.frame_step_sec == 0.0) ? c.frame_size_sec : c.frame_step_sec;
   g.H = std::lround(step / T);
+  if (c.force_frame_size > 0) g.N = c.force_frame_size;   // single-component plan: size of the input field
   if (g.H == 0) g.H = g.N;
   if (g.N < 1) return SMILEHIP_ERR_INVALID;
   g.frame_period = step;
@@ -35,7 +36,7 @@ int make_geometry(const smilehip_lld_config &c, Geometry &g) {
   if (nfft < 4) nfft = 4;
   g.Nfft = nfft;
   g.K = nfft / 2 + 1;
-  g.fft_frame_size_sec = fss;
+  g.fft_frame_size_sec = (c.force_fft_frame_size_sec > 0.0) ? c.force_fft_frame_size_sec : fss;
   return SMILEHIP_OK;
 }
 

@@ -1,0 +1,377 @@
+// libsmilehip_plugin.so -- openSMILE-side adapter of libsmilehip (C++).
+//
+// Dropped into ./plugins/ of a SHARED openSMILE build it is dlopen'ed by
+// cComponentManager::registerPlugins (src/core/componentManager.cpp:289-424),
+// which calls the C symbol registerPluginComponent below. The components it
+// returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
+// cTransformFFT, cFFTmagphase, cMelspec, cMfcc), so their factories replace the
+// built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
+// every existing option -- stay (configManager.cpp:2818-2827): unmodified
+// config files run through the HIP kernels.
+//
+// Each override derives from the reference's own class: configuration, field
+// naming, frequency-axis metadata and the tick logic are inherited; only the
+// per-frame operator processVector() is replaced by a call into the C ABI
+// (include/smilehip.h). Errors from the C layer become COMP_ERR
+// (src/include/core/exceptions.hpp:137) -- nothing throws across the C ABI.
+//
+// This file is compiled with the HOST g++ against the reference's headers
+// (ABI-coupled to libopensmile.so); it contains no HIP code.
+#include <core/componentManager.hpp>
+#include <core/smileCommon.hpp>
+#include <dspcore/fftmagphase.hpp>
+#include <dspcore/transformFft.hpp>
+#include <dspcore/vectorPreemphasis.hpp>
+#include <dspcore/windower.hpp>
+#include <lldcore/melspec.hpp>
+#include <lldcore/mfcc.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/smilehip.h"
+
+#define MODULE "smilehipPlugin"
+
+namespace {
+
+// ---------------------------------------------------------------- shared state
+smilehip_context *g_ctx = nullptr;
+long g_frames[6] = {0, 0, 0, 0, 0, 0};
+const char *const g_names[6] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc"};
+
+smilehip_context *context() {
+  if (!g_ctx) {
+    const char *dev = getenv("SMILEHIP_DEVICE");
+    if (smilehip_init(dev ? atoi(dev) : 0, &g_ctx) != SMILEHIP_OK)
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  return g_ctx;
+}
+
+// device scratch for one frame in / one frame out
+struct FrameIO {
+  float *d_in = nullptr, *d_out = nullptr;
+  long cap_in = 0, cap_out = 0;
+  void ensure(long n_in, long n_out) {
+    if (n_in > cap_in) {
+      if (d_in) smilehip_free(context(), d_in);
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_in, (void **)&d_in)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_in = n_in;
+    }
+    if (n_out > cap_out) {
+      if (d_out) smilehip_free(context(), d_out);
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_out, (void **)&d_out)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_out = n_out;
+    }
+  }
+  void up(const FLOAT_DMEM *src, long n) {
+    if (smilehip_copy_to_device(context(), d_in, src, sizeof(float) * (uint64_t)n, nullptr)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  void down(FLOAT_DMEM *dst, long n) {
+    if (smilehip_copy_to_host(context(), dst, d_out, sizeof(float) * (uint64_t)n, nullptr) ||
+        smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  ~FrameIO() {
+    if (g_ctx) {
+      if (d_in) smilehip_free(g_ctx, d_in);
+      if (d_out) smilehip_free(g_ctx, d_out);
+    }
+  }
+};
+
+void check(int rc) {
+  if (rc != SMILEHIP_OK) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+}
+
+smilehip_lld_config base_config(long N, uint32_t stages) {
+  smilehip_lld_config c;
+  smilehip_config_mfcc12_0_d_a(&c);
+  c.force_frame_size = N;
+  c.stage_mask = stages;
+  c.n_delta = 0;
+  return c;
+}
+
+int winfunc_id(const char *s) {
+  // same prefixes cWindower accepts (winFuncToInt, smileUtil.c)
+  if (!s) return -1;
+  if (!strncasecmp(s, "han", 3)) return SMILEHIP_WIN_HANN;
+  if (!strncasecmp(s, "ham", 3)) return SMILEHIP_WIN_HAMM;
+  if (!strncasecmp(s, "rec", 3)) return SMILEHIP_WIN_RECT;
+  if (!strncasecmp(s, "gau", 3)) return SMILEHIP_WIN_GAUSS;
+  if (!strncasecmp(s, "sin", 3) || !strncasecmp(s, "cos", 3)) return SMILEHIP_WIN_SINE;
+  if (!strncasecmp(s, "tri", 3)) return SMILEHIP_WIN_TRI;
+  if (!strncasecmp(s, "bar", 3) && strncasecmp(s, "barth", 5)) return SMILEHIP_WIN_BARTLETT;
+  if (!strncasecmp(s, "lac", 3)) return SMILEHIP_WIN_LANCZOS;
+  return -1;
+}
+
+// ---------------------------------------------------------------- overrides
+// R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
+class cHipVectorPreemphasis : public cVectorPreemphasis {
+  FrameIO io_;
+  float k_ = 0.f;
+  int de_ = 0;
+  bool ready_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (!ready_) {
+      double f = isSet("f") ? getDouble("f") : -1.0;
+      k_ = (FLOAT_DMEM)getDouble("k");
+      if (f >= 0.0) k_ = (FLOAT_DMEM)exp(-2.0 * M_PI * f * getBasePeriod());   // vectorPreemphasis.cpp:78-86
+      de_ = getInt("de");
+      ready_ = true;
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_preemphasis_frames(context(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, Ndst, k_, de_, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[0]++;
+    return 1;
+  }
+ public:
+  explicit cHipVectorPreemphasis(const char *n) : cVectorPreemphasis(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipVectorPreemphasis(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// one plan per input field configuration
+template <int NPLANS = 8>
+struct PlanSet {
+  smilehip_plan *p[NPLANS];
+  PlanSet() { for (auto &x : p) x = nullptr; }
+  ~PlanSet() { for (auto &x : p) if (x) smilehip_plan_destroy(x); }
+  smilehip_plan *&at(int i) {
+    if (i < 0 || i >= NPLANS) COMP_ERR("libsmilehip plugin: more than %d differently sized fields", NPLANS);
+    return p[i];
+  }
+};
+
+// R3  cWindower::processVector  (src/dspcore/windower.cpp:221-229)
+class cHipWindower : public cWindower {
+  FrameIO io_;
+  PlanSet<> plans_;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      if (getDouble("fade") > 0.0 || getInt("squareRoot") || getDouble("xshift") != 0.0)
+        COMP_ERR("libsmilehip plugin: cWindower options fade/squareRoot/xshift are not supported on the HIP path");
+      smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_WINDOW);
+      c.win_func = winfunc_id(getStr("winFunc"));
+      if (c.win_func < 0) COMP_ERR("libsmilehip plugin: window function '%s' not supported on the HIP path", getStr("winFunc"));
+      c.win_sigma = getDouble("sigma");
+      c.win_gain = getDouble("gain");
+      c.win_offset = getDouble("offset");
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_window_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[1]++;
+    return 1;
+  }
+ public:
+  explicit cHipWindower(const char *n) : cWindower(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipWindower(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R4  cTransformFFT::processVector, forward  (src/dspcore/transformFft.cpp:165-223)
+class cHipTransformFFT : public cTransformFFT {
+  FrameIO io_;
+  PlanSet<> plans_;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (getInt("inverse")) return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi);   // inverse stays on the CPU
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
+      c.zero_pad_symmetric = getInt("zeroPadSymmetric");
+      check(smilehip_plan_create(context(), &c, &pl));
+      smilehip_geometry g;
+      check(smilehip_plan_geometry(pl, &g));
+      if (g.fft_size != Ndst) COMP_ERR("libsmilehip plugin: FFT size mismatch (%ld vs %ld)", (long)g.fft_size, Ndst);
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_rfft_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[2]++;
+    return 1;
+  }
+ public:
+  explicit cHipTransformFFT(const char *n) : cTransformFFT(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipTransformFFT(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R5  cFFTmagphase::processVector, magnitude branch  (src/dspcore/fftmagphase.cpp:215-221)
+class cHipFFTmagphase : public cFFTmagphase {
+  FrameIO io_;
+  PlanSet<> plans_;
+  int plain_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0)
+      plain_ = (!getInt("inverse") && getInt("magnitude") && !getInt("phase") && !getInt("normalise") &&
+                !getInt("power") && !getInt("dBpsd")) ? 1 : 0;
+    if (!plain_) return cFFTmagphase::processVector(src, dst, Nsrc, Ndst, idxi);   // other modes stay on the CPU
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_fftmag_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[3]++;
+    return 1;
+  }
+ public:
+  explicit cHipFFTmagphase(const char *n) : cFFTmagphase(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipFFTmagphase(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R6  cMelspec::processVector  (src/lldcore/melspec.cpp:519-570)
+class cHipMelspec : public cMelspec {
+  FrameIO io_;
+  PlanSet<> plans_;
+  int plain_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) {
+      const char *bw = getStr("bwMethod");
+      const char *sc = getStr("specScale");
+      const bool mel = getInt("htkcompatible") || (sc && !strcasecmp(sc, "mel"));
+      plain_ = (!getInt("inverse") && mel && bw && !strncasecmp(bw, "lr", 2)) ? 1 : 0;
+    }
+    if (!plain_) return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi);   // HFCC / bark / inverse stay on the CPU
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      // frame size of the input spectrum, cMelspec::configureField (melspec.cpp:150-173)
+      const sDmLevelConfig *lc = reader_->getLevelConfig();
+      double fss = isSet("overrideFrameSizeSec") ? getDouble("overrideFrameSizeSec")
+                                                 : (lc->frameSizeSec > 0.0 ? lc->frameSizeSec : lc->lastFrameSizeSec);
+      smilehip_lld_config c = base_config((Nsrc - 1) * 2, SMILEHIP_STAGE_MEL);
+      c.force_fft_frame_size_sec = fss;
+      c.n_bands = getInt("nBands");
+      c.lofreq = (FLOAT_DMEM)getDouble("lofreq");
+      c.hifreq = (FLOAT_DMEM)getDouble("hifreq");
+      c.use_power = getInt("usePower");
+      c.mel_htk_compatible = getInt("htkcompatible");
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_melspec_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[4]++;
+    return 1;
+  }
+ public:
+  explicit cHipMelspec(const char *n) : cMelspec(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipMelspec(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R7  cMfcc::processVector, forward  (src/lldcore/mfcc.cpp:239-273)
+class cHipMfcc : public cMfcc {
+  FrameIO io_;
+  PlanSet<> plans_;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (getInt("inverse") || !getInt("doLog")) return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi);
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      smilehip_lld_config c = base_config(512, SMILEHIP_STAGE_MFCC);
+      c.n_bands = (int)Nsrc;
+      c.first_mfcc = getInt("firstMfcc");
+      c.last_mfcc = getInt("lastMfcc");
+      if (!isSet("lastMfcc") && isSet("nMfcc")) c.last_mfcc = c.first_mfcc + getInt("nMfcc") - 1;   // mfcc.cpp:77-82
+      c.cep_lifter = (FLOAT_DMEM)getDouble("cepLifter");
+      c.mfcc_htk_compatible = getInt("htkcompatible");
+      c.melfloor = (FLOAT_DMEM)getDouble("melfloor");
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_mfcc_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[5]++;
+    return 1;
+  }
+ public:
+  explicit cHipMfcc(const char *n) : cMfcc(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipMfcc(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
+// component with the number of frames it pushed through the HIP kernels
+struct TraceAtExit {
+  ~TraceAtExit() {
+    const char *path = getenv("SMILEHIP_PLUGIN_TRACE");
+    if (!path) return;
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    for (int i = 0; i < 6; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
+    fclose(f);
+  }
+} g_trace;
+
+typedef sComponentInfo *(*regfn)(cConfigManager *, cComponentManager *, int);
+typedef cSmileComponent *(*createfn)(const char *);
+
+sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cComponentManager *m, int it,
+                            sComponentInfo *next) {
+  // the built-in registerComponent builds the info (and re-offers the ConfigType,
+  // which the config manager ignores because the type already exists)
+  sComponentInfo *ci = builtin(c, m, it);
+  if (!ci) return next;
+  ci->create = mine;
+  ci->builtIn = 0;
+  ci->next = next;
+  return ci;
+}
+
+}  // namespace
+
+// The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
+extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
+  sComponentInfo *head = nullptr;
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all six
+  auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cMfcc")) head = override_of(&cMfcc::registerComponent, &cHipMfcc::create, confman, compman, iteration, head);
+  if (want("cMelspec")) head = override_of(&cMelspec::registerComponent, &cHipMelspec::create, confman, compman, iteration, head);
+  if (want("cFFTmagphase")) head = override_of(&cFFTmagphase::registerComponent, &cHipFFTmagphase::create, confman, compman, iteration, head);
+  if (want("cTransformFFT")) head = override_of(&cTransformFFT::registerComponent, &cHipTransformFFT::create, confman, compman, iteration, head);
+  if (want("cWindower")) head = override_of(&cWindower::registerComponent, &cHipWindower::create, confman, compman, iteration, head);
+  if (want("cVectorPreemphasis")) head = override_of(&cVectorPreemphasis::registerComponent, &cHipVectorPreemphasis::create, confman, compman, iteration, head);
+  return head;
+}

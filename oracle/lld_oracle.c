@@ -579,3 +579,21 @@ long lldo_mfcc_chain(const lldo_mfcc_cfg *c, const int16_t *pcm, long n_samples,
   lldo_mel_free(&mel); lldo_mfcc_free(&dct);
   return T;
 }
+
+/* table export for table-level parity tests (tests/test_host_logic.py) */
+void lldo_export_tables(const lldo_mfcc_cfg *c, float *win, float *melcoef, int *chan, float *costable, float *lifter)
+{
+  lldo_geom g;
+  lldo_geometry(c, &g);
+  double *w = (double *)malloc(sizeof(double) * (size_t)g.N);
+  lldo_window_table(c->win_func, g.N, c->win_sigma, c->win_gain, w);
+  for (long n = 0; n < g.N; n++) win[n] = (float)w[n];
+  free(w);
+  lldo_mel mel; lldo_dct dct;
+  lldo_mel_init(&mel, g.K, g.frame_size_sec_fft, c->n_bands, c->lofreq, c->hifreq, c->use_power, c->mel_htk_compatible);
+  for (long n = 0; n < g.K; n++) { melcoef[n] = mel.coef[n]; chan[n] = (int)mel.chan_map[n]; }
+  lldo_mfcc_init(&dct, c->n_bands, c->first_mfcc, c->last_mfcc, c->cep_lifter, c->mfcc_htk_compatible, c->melfloor);
+  memcpy(costable, dct.costable, sizeof(float) * (size_t)dct.n_mfcc * (size_t)c->n_bands);
+  memcpy(lifter, dct.sintable, sizeof(float) * (size_t)dct.n_mfcc);
+  lldo_mel_free(&mel); lldo_mfcc_free(&dct);
+}

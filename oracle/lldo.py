@@ -168,7 +168,7 @@ def run_reference(conf_rel, pcm, fs=16000, extra_args=()):
         wav = os.path.join(td, "in.wav")
         out = os.path.join(td, "out.htk")
         write_wav(wav, pcm, fs)
-        subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "0", "-nologfile",
+        subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "0",
                         *extra_args], check=True, cwd=td,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         if not os.path.exists(out):
@@ -186,3 +186,20 @@ def delta_chain(x, W, n_orders):
     L.lldo_delta_chain.restype = None
     L.lldo_delta_chain(x.ctypes.data, T, D, W, n_orders, y.ctypes.data)
     return y
+
+
+def export_tables(cfg):
+    """(window f32[N], mel coef f32[K], chanmap i32[K], costable f32[n_mfcc, n_bands], lifter f32[n_mfcc])"""
+    g = geometry(cfg)
+    n_mfcc = cfg.last_mfcc - cfg.first_mfcc + 1
+    win = np.zeros(g.N, np.float32)
+    coef = np.zeros(g.K, np.float32)
+    chan = np.zeros(g.K, np.int32)
+    cos = np.zeros((n_mfcc, cfg.n_bands), np.float32)
+    lif = np.zeros(n_mfcc, np.float32)
+    L = lib()
+    L.lldo_export_tables.argtypes = [C.POINTER(MfccCfg)] + [C.c_void_p] * 5
+    L.lldo_export_tables.restype = None
+    L.lldo_export_tables(C.byref(cfg), win.ctypes.data, coef.ctypes.data, chan.ctypes.data,
+                         cos.ctypes.data, lif.ctypes.data)
+    return win, coef, chan, cos, lif

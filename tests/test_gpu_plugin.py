@@ -1,0 +1,63 @@
+"""Drop-in boundary: the UNMODIFIED reference binary (oracle/_ref/SMILExtract,
+shared build) runs the UNMODIFIED config/mfcc/MFCC12_0_D_A.conf with
+opensmile_amd/plugin/plugins/libsmilehip_plugin.so in ./plugins: the six chain
+components are replaced by name and push every frame through the HIP kernels."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tolerance import assert_parity, corpus_col_scale
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGDIR = os.path.join(ROOT, "opensmile_amd", "plugin")
+
+
+def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf"):
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built (needs /root/reference at build time)")
+    with tempfile.TemporaryDirectory() as td:
+        wav, out, trace = (os.path.join(td, n) for n in ("in.wav", "out.htk", "trace.txt"))
+        oracle.write_wav(wav, pcm)
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join(
+            [os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        env.update(env_extra or {})
+        # cwd = the directory that contains ./plugins (componentManager.cpp:347-364)
+        r = subprocess.run([exe, "-C", os.path.join(oracle.REF_DIR, "config", conf), "-I", wav, "-O", out,
+                            "-l", "1"], cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert os.path.exists(out), r.stderr[-2000:]
+        y = oracle.read_htk(out)[0]
+        tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip()) if os.path.exists(trace) else {}
+    return y, {k: int(v) for k, v in tr.items()}
+
+
+def test_plugin_runs_unmodified_config(oracle, golden_synth):
+    keys = ["u2_16000", "u10_16000", "u0_16000"]
+    s_col = corpus_col_scale([golden_synth["out_" + k] for k in keys], 13)
+    for k in keys:
+        y, tr = _run(oracle, golden_synth["pcm_" + k])
+        ref = golden_synth["out_" + k]
+        # every overridden component saw every frame (98 frames; the FFT etc. run once per frame)
+        for comp in ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc"):
+            assert tr.get(comp, 0) == ref.shape[0], f"{comp} not routed through the plugin: {tr}"
+        assert_parity(y, ref, block=13, what=f"plugin {k}", col_scale=s_col)
+
+
+def test_plugin_exact_stages_are_bit_exact(oracle, golden_synth):
+    """Overriding only the stages whose arithmetic order is the reference's own
+    (everything except the FFT) must reproduce the reference BIT FOR BIT."""
+    k = "u3_16000"
+    y, tr = _run(oracle, golden_synth["pcm_" + k],
+                 {"SMILEHIP_PLUGIN_COMPONENTS": "cVectorPreemphasis,cWindower,cFFTmagphase,cMelspec,cMfcc"})
+    ref = golden_synth["out_" + k]
+    assert tr["cTransformFFT"] == 0 and tr["cMfcc"] == ref.shape[0]
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), f"max abs {np.abs(y - ref).max()}"
