@@ -16,6 +16,7 @@ struct Fast512Host {
   std::vector<int32_t> band_slots;
   int mel_units = 0, n_slots = 0, mp = 13, stage_floats = 0, stage_alloc = 0;
   float mel_scale = 1.0f;
+  int max_blocks = 512;     // resident blocks of the fast kernel (2 per CU), set from the device
 };
 bool fast512_applicable(int Nfft, int N);
 int fast512_tile_frames();

@@ -219,8 +219,17 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
   __syncthreads();
 
-  const int tile = blockIdx.x * kWavesPerBlock + wave;
-  if (tile >= P.n_tiles) return;
+  const float dgain = (j < P.n_mfcc) ? P.dct_gain[j] : 0.0f;
+  const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
+  const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
+  const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
+  const int pj = (16 - j) & 15;                                       // partner lane (bins 256-k)
+  const int zrow = (j == 0) ? 16 : 0;
+  const int n_steps = (stage_floats + 127) >> 7;
+
+  // persistent waves: a wave walks tiles tile, tile + #waves, ... so that the table
+  // load above and the per-lane constants are paid once per wave, not once per tile
+  for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < P.n_tiles; tile += gridDim.x * kWavesPerBlock) {
   const int u = P.tile_utt[tile];
   const int t_first = P.tile_t0[tile];
   const int64_t s_utt = P.samp_off[u];
@@ -229,14 +238,6 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   const int T = (int)(P.frame_off[u + 1] - row0);
   const int16_t *x = P.pcm + s_utt;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 3) == 0);   // H even => every pair start is even
-
-  const float dgain = (j < P.n_mfcc) ? P.dct_gain[j] : 0.0f;
-  const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
-  const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
-  const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
-  const int pj = (16 - j) & 15;                                       // partner lane (bins 256-k)
-  const int zrow = (j == 0) ? 16 : 0;
-  const int n_steps = (stage_floats + 127) >> 7;
 
   const int t_end = (t_first + kTileFrames < T) ? t_first + kTileFrames : T;
   PcmRegs R;
@@ -395,6 +396,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
   }
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------
@@ -489,7 +491,8 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
   const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64;
   const int wave_floats = h.stage_alloc + 4 + 4 * kGroupFloats;
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
-  const unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (grid > (unsigned)h.max_blocks) grid = (unsigned)h.max_blocks;   // persistent: 2 blocks of 8 waves per CU
   const bool mp13 = h.mp == 13;
 #define SMILEHIP_PICK(MPV, PE, UP)                                                                        \
   if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP) {                         \

@@ -242,6 +242,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   p->use_fast = false;
   if (mask == SMILEHIP_STAGE_ALL && !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
     p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
+    if (p->ctx) p->fast.max_blocks = 2 * p->ctx->prop.multiProcessorCount;
   }
   if (!upload) return SMILEHIP_OK;
   if ((rc = p->d_window.upload(p->h_window))) return rc;
