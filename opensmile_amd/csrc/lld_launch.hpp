@@ -23,7 +23,8 @@ int fast512_tile_frames();
 // 0 on success, -1 if this configuration cannot use the fast kernel
 int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, const std::vector<float> &window,
                        const MelBank &mel, const DctTables &dct, Fast512Host &h);
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, hipStream_t s);
+// aligned: PCM buffer 4-byte aligned and every utterance starts at an even sample
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
 hipError_t launch_delta(const DeltaParams &P, hipStream_t s);
 int delta_tile_frames();

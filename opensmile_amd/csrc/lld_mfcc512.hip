@@ -133,41 +133,35 @@ struct PcmRegs {
   int32_t first;
 };
 
-// tail of an utterance / unaligned PCM: guarded element loads (rare, kept out of line
-// so that its registers and code do not burden the hot path)
-__device__ __noinline__ void pcm_prefetch_slow(const int16_t *x, int64_t utt_len, int64_t sbase, int n_steps,
-                                               int lane, uint32_t *pair) {
-#pragma unroll 1
+// Loads for one pass: the staged span [sbase, sbase + 128*n_steps) of utterance samples.
+// Samples past the utterance end only ever feed frames that are not stored (every
+// stored frame lies inside its utterance), so instead of zero-filling them the
+// addresses are merely clamped to stay inside the PCM buffer: no per-element guards.
+// ALIGNED: the buffer is 4-byte aligned and every utterance starts at an even sample
+// (checked on the host) -> one dword load per sample pair; otherwise two 16-bit loads.
+template <bool ALIGNED>
+__device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t abs_base, int H,
+                                             int n_steps, int lane, PcmRegs &R) {
+  const int64_t last_pair = (pcm_total >> 1) - 1;        // pcm_total >= 2 whenever a frame exists
+#pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int64_t s0 = sbase + 2 * (lane + 64 * r);
     uint32_t v = 0;
     if (r < n_steps) {
-      const uint32_t lo = (s0 < utt_len) ? (uint16_t)x[s0] : 0u;
-      const uint32_t hi = (s0 + 1 < utt_len) ? (uint16_t)x[s0 + 1] : 0u;
-      v = lo | (hi << 16);
+      if (ALIGNED) {
+        int64_t pi = (abs_base >> 1) + lane + 64 * r;
+        pi = pi > last_pair ? last_pair : pi;
+        v = reinterpret_cast<const uint32_t *>(pcm)[pi];
+      } else {
+        int64_t s0 = abs_base + 2 * (lane + 64 * r);
+        s0 = s0 > pcm_total - 2 ? pcm_total - 2 : s0;
+        v = (uint32_t)(uint16_t)pcm[s0] | ((uint32_t)(uint16_t)pcm[s0 + 1] << 16);
+      }
     }
-    pair[r] = v;
+    R.pair[r] = v;
   }
-}
-
-__device__ __forceinline__ void pcm_prefetch(const int16_t *x, int64_t utt_len, int64_t sbase, int H, int n_steps,
-                                             bool aligned, int lane, PcmRegs &R) {
-  if (aligned && sbase + 128 * n_steps <= utt_len) {
-    // whole span inside the utterance and 4-byte aligned (wave-uniform): plain dword loads
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(x + sbase) + lane;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) R.pair[r] = (r < n_steps) ? p[64 * r] : 0u;
-  } else {
-    uint32_t tmp[8];
-    pcm_prefetch_slow(x, utt_len, sbase, n_steps, lane, tmp);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) R.pair[r] = tmp[r];
-  }
-  R.first = 0;
-  if (lane < 4) {
-    const int64_t s0 = sbase + (int64_t)lane * H;
-    R.first = (s0 < utt_len) ? (int32_t)x[s0] : 0;
-  }
+  int64_t sf = abs_base + (int64_t)(lane & 3) * H;
+  sf = sf > pcm_total - 1 ? pcm_total - 1 : sf;
+  R.first = (int32_t)pcm[sf];
 }
 
 // value of lane-1 (wave-wide shift right by one lane, DPP wave_shr:1); lane 0 receives `fill`
@@ -180,11 +174,13 @@ __device__ __forceinline__ float lane_shr1(float v, float fill) {
 //   shared tables : tw512 [256 f2] | win [MP*16 f2] | tw256 [256 f2, index k1*16+j] |
 //                   melw0 [U*16 f4] | melw1 [U*16 f4] | melo [U*16 u32] | dct [16 x 28] | slots [64 i32]
 //   per wave      : stage [S >= 512] (later PS+lmel: 4 x 128) | spec [4] | 4 x group buffer [272]
-template <int MP, bool PREEMPH, bool USE_POWER>
+template <int MP, bool PREEMPH, bool USE_POWER, bool ALIGNED>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction; tell the compiler so that everything derived from it
+  // (tile, utterance, offsets, pointers) lives in SGPRs instead of VGPR pairs
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int j = lane & 15;
   const int U = F.mel_units;
@@ -233,15 +229,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   const int u = P.tile_utt[tile];
   const int t_first = P.tile_t0[tile];
   const int64_t s_utt = P.samp_off[u];
-  const int64_t utt_len = P.samp_off[u + 1] - s_utt;
   const int64_t row0 = P.frame_off[u];
   const int T = (int)(P.frame_off[u + 1] - row0);
-  const int16_t *x = P.pcm + s_utt;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 3) == 0);   // H even => every pair start is even
 
   const int t_end = (t_first + kTileFrames < T) ? t_first + kTileFrames : T;
   PcmRegs R;
-  pcm_prefetch(x, utt_len, (int64_t)t_first * P.H, P.H, n_steps, aligned, lane, R);
+  pcm_prefetch<ALIGNED>(P.pcm, P.pcm_total, s_utt + (int64_t)t_first * P.H, P.H, n_steps, lane, R);
 
   for (int tp = t_first; tp < t_end; tp += 4) {
     const int t = tp + g;                       // my frame
@@ -354,7 +347,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
 
     // next pass's PCM: issued here, where register pressure is low; the loads fly
     // during mel/DCT of this pass and the other resident waves' arithmetic
-    if (tp + 4 < t_end) pcm_prefetch(x, utt_len, (int64_t)(tp + 4) * P.H, P.H, n_steps, aligned, lane, R);
+    if (tp + 4 < t_end) pcm_prefetch<ALIGNED>(P.pcm, P.pcm_total, s_utt + (int64_t)(tp + 4) * P.H, P.H, n_steps, lane, R);
 
     // ------------------------------------------------------------ mel (R6)
     for (int i = 0; i < U; ++i) {
@@ -487,28 +480,30 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
   return 0;
 }
 
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, hipStream_t s) {
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
   const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64;
   const int wave_floats = h.stage_alloc + 4 + 4 * kGroupFloats;
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
   unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (grid > (unsigned)h.max_blocks) grid = (unsigned)h.max_blocks;   // persistent: 2 blocks of 8 waves per CU
   const bool mp13 = h.mp == 13;
-#define SMILEHIP_PICK(MPV, PE, UP)                                                                        \
-  if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP) {                         \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP>);                            \
+#define SMILEHIP_PICK(MPV, PE, UP, AL)                                                                    \
+  if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL) {        \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP, AL>);                        \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
     if (e != hipSuccess) return e;                                                                         \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F);   \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP, AL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
   }
-  SMILEHIP_PICK(13, true, true)
-  SMILEHIP_PICK(13, true, false)
-  SMILEHIP_PICK(13, false, true)
-  SMILEHIP_PICK(13, false, false)
-  SMILEHIP_PICK(16, true, true)
-  SMILEHIP_PICK(16, true, false)
-  SMILEHIP_PICK(16, false, true)
-  SMILEHIP_PICK(16, false, false)
+#define SMILEHIP_PICK2(MPV, PE, UP) SMILEHIP_PICK(MPV, PE, UP, true) SMILEHIP_PICK(MPV, PE, UP, false)
+  SMILEHIP_PICK2(13, true, true)
+  SMILEHIP_PICK2(13, true, false)
+  SMILEHIP_PICK2(13, false, true)
+  SMILEHIP_PICK2(13, false, false)
+  SMILEHIP_PICK2(16, true, true)
+  SMILEHIP_PICK2(16, true, false)
+  SMILEHIP_PICK2(16, false, true)
+  SMILEHIP_PICK2(16, false, false)
+#undef SMILEHIP_PICK2
 #undef SMILEHIP_PICK
   return hipGetLastError();
 }

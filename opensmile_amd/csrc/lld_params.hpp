@@ -10,6 +10,7 @@ namespace smilehip {
 struct LldParams {
   // batch
   const int16_t *pcm;          // packed utterances
+  int64_t pcm_total;           // samples in the packed buffer (= samp_off[n_utt])
   const int64_t *samp_off;     // [n_utt+1] sample offsets (device)
   const int64_t *frame_off;    // [n_utt+1] output row offsets (device)
   const int32_t *tile_utt;     // [n_tiles] utterance of tile

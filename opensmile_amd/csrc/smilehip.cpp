@@ -106,6 +106,7 @@ struct smilehip_batch {
   DevBuf<int64_t> d_samp_off, d_frame_off;
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
   int32_t n_tiles = 0, n_dtiles = 0;
+  bool all_even = true;      // every utterance with frames starts at an even sample offset
 };
 
 // ------------------------------------------------------------- life cycle
@@ -372,6 +373,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     const int64_t T = smilehip_num_frames(plan, len);
     b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
     if (T > 0 && T <= short_T) b->h_short.push_back(u);
+    if (T > 0 && (h_off[u] & 1)) b->all_even = false;
     for (int64_t t0 = 0; t0 < T; t0 += tile_frames) {
       tile_utt.push_back(u);
       tile_t0.push_back((int32_t)t0);
@@ -409,6 +411,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
                         int64_t ld, LldParams &P) {
   std::memset(&P, 0, sizeof(P));
   P.pcm = d_pcm;
+  P.pcm_total = b->h_samp_off.back();
   P.samp_off = b->d_samp_off.p;
   P.frame_off = b->d_frame_off.p;
   P.tile_utt = b->d_tile_utt.p;
@@ -518,7 +521,8 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     F.stage_floats = plan->fast.stage_floats;
     F.stage_alloc = plan->fast.stage_alloc;
     F.mel_scale = plan->fast.mel_scale;
-    e = launch_mfcc512(P, F, plan->fast, s);
+    const bool aligned = b->all_even && ((reinterpret_cast<uintptr_t>(d_pcm) & 3) == 0);
+    e = launch_mfcc512(P, F, plan->fast, aligned, s);
   } else {
     e = launch_mfcc_generic(P, s);
   }
