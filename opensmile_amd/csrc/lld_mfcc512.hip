@@ -60,7 +60,7 @@ constexpr int kTBStride = 17;         // row stride (floats) of the transpose bu
 constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame group
 constexpr int kMaxUnitsPerLane = 8;
 constexpr int kMaxSlots = 96;
-constexpr int kMinStage = 512;        // PS + lmel (4 x 128 floats) alias the stage area
+constexpr int kMinStage = 576;        // PS + lmel (4 x 144 floats) alias the stage area
 
 constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
 constexpr float S1 = 0.38268343236508978178f;   // sin(pi/8)
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   float *s_stage = wbase;
   float *s_spec = wbase + stage_alloc;
   float *s_gb = s_spec + 4 + g * kGroupFloats;                    // my group's buffer: TB -> ZX -> PB
-  float *s_ps = s_stage + g * 128;                                // partial mel sums (aliases stage)
+  float *s_ps = s_stage + g * 144;                                // partial mel sums (aliases stage); 144: odd multiple of 16 banks
   float *s_lmel = s_ps + kMaxSlots;                               // log-mel of the frame (32 floats)
 
   // ---- cooperative load of the shared tables
