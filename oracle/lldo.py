@@ -73,6 +73,9 @@ def lib():
         L.lldo_delta_regression.restype = C.c_long
         L.lldo_delta_regression.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p]
         L.lldo_set_rfft_hook.argtypes = [C.c_void_p]
+        L.lldo_set_rfft_hook2.argtypes = [C.c_void_p]
+        L.lldo_is09_chain.restype = C.c_long
+        L.lldo_is09_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         L.lldo_pcm16_to_float.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.lldo_window_table.argtypes = [C.c_int, C.c_long, C.c_double, C.c_double, C.c_void_p]
         L.lldo_window_table.restype = C.c_int
@@ -92,6 +95,7 @@ def use_reference_fft(enable=True):
     global _ref_dsp
     if not enable:
         lib().lldo_set_rfft_hook(None)
+        lib().lldo_set_rfft_hook2(None)
         return True
     p = os.path.join(REF_DIR, "libref_dsp.so")
     if not os.path.exists(p):
@@ -99,6 +103,7 @@ def use_reference_fft(enable=True):
     if _ref_dsp is None:
         _ref_dsp = C.CDLL(p)
     lib().lldo_set_rfft_hook(C.cast(_ref_dsp.rdft, C.c_void_p))
+    lib().lldo_set_rfft_hook2(C.cast(_ref_dsp.rdft, C.c_void_p))
     return True
 
 
@@ -203,3 +208,29 @@ def export_tables(cfg):
     L.lldo_export_tables(C.byref(cfg), win.ctypes.data, coef.ctypes.data, chan.ctypes.data,
                          cos.ctypes.data, lif.ctypes.data)
     return win, coef, chan, cos, lif
+
+
+def is09_chain(pcm, raw=False):
+    """IS09_emotion LLD level as the LLD sinks see it: (T+1) x 32 [, T x 16 pre-SMA columns]."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    rows = lib().lldo_is09_chain(pcm.ctypes.data, len(pcm), None, None)
+    out = np.zeros((max(rows, 0), 32), np.float32)
+    r16 = np.zeros((max(rows - 1, 0), 16), np.float32)
+    if rows > 0:
+        lib().lldo_is09_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, r16.ctypes.data)
+    return (out, r16) if raw else out
+
+
+def run_reference_lld(conf_rel, pcm, fs=16000):
+    """Real SMILExtract, LLD-level HTK output (-lldhtkoutput) of a standard_data_output config."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    conf = os.path.join(REF_DIR, "config", conf_rel)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        out = os.path.join(td, "lld.htk")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", conf, "-I", wav, "-lldhtkoutput", out, "-l", "0"], check=True, cwd=td,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if not os.path.exists(out):
+            return np.zeros((0, 0), np.float32)
+        return read_htk(out)[0]

@@ -38,3 +38,9 @@ def golden_synth():
 def golden_config1():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "mfcc12_0_d_a_config1.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_is09():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "is09_lld_synth.npz"))

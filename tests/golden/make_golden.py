@@ -39,6 +39,19 @@ def main():
         print(k, y.shape)
     np.savez_compressed(os.path.join(OUT, "mfcc12_0_d_a_synth.npz"), **ref)
 
+    # config 3 shape (IS09_emotion LLD level, 16 LLD + 16 delta, T+1 rows), shortened
+    ref = {}
+    for name, (u, n) in {"u2_16000": (2, 16000), "u3_16000": (3, 16000), "u10_16000": (10, 16000),
+                          "u1_16000": (1, 16000), "u0_16000": (0, 16000), "u7_399": (7, 399), "u7_400": (7, 400),
+                          "u7_560": (7, 560), "u7_720": (7, 720), "u7_880": (7, 880), "u7_1040": (7, 1040),
+                          "u4_48000": (4, 48000)}.items():
+        pcm = synth.utterance(u, n)
+        y = lldo.run_reference_lld("is09-13/IS09_emotion.conf", pcm)
+        ref["pcm_" + name] = pcm
+        ref["out_" + name] = y
+        print("is09", name, y.shape)
+    np.savez_compressed(os.path.join(OUT, "is09_lld_synth.npz"), **ref)
+
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
     wav = os.path.join(lldo.REF_DIR, "opensmile.wav")
