@@ -96,10 +96,27 @@ typedef struct smilehip_lld_config {
    * level's frameSizeSec, not the wave source's sample rate: when > 0 these
    * replace the values derived from sample_rate/frame_size_sec. stage_mask
    * selects which tables the plan builds (0 = whole chain). */
+  /* --- LLD set --- chain_kind selects what smilehip_lld_run computes:
+   *   SMILEHIP_CHAIN_MFCC: [mfcc | delta | accel]           (config/mfcc/MFCC12_0_D_A.conf)
+   *   SMILEHIP_CHAIN_IS09: IS09_emotion's LLD level as its LLD sinks see it
+   *     (config/is09-13/IS09_emotion_core.lld.conf.inc): 16 columns
+   *     [pcm_RMSenergy | mfcc firstMfcc..lastMfcc (12) | pcm_zcr | voiceProb | F0]
+   *     smoothed by cContourSmoother(smaWin) followed by their 16 cDeltaRegression
+   *     columns; T+smaWin/2 rows per utterance (the SMA's end-of-input frame is kept).
+   *     Uses cEnergy rms (src/lldcore/energy.cpp:152-168) on the windowed frame, cMZcr zcr
+   *     (src/lldcore/mzcr.cpp:109-126) on the raw frame, two cAcf instances
+   *     (src/dspcore/acf.cpp:249-349) and cPitchACF (src/lldcore/pitchACF.cpp:137-247). */
+  int32_t  chain_kind;
+  double   pitch_max;                   /* cPitchACF maxPitch */
+  double   voicing_cutoff;              /* cPitchACF voicingCutoff */
+  int32_t  sma_win;                     /* cContourSmoother smaWin (odd) */
   int64_t  force_frame_size;            /* N  */
   double   force_fft_frame_size_sec;    /* frameSizeSec of the spectrum level (cMelspec::configureField, melspec.cpp:150-173) */
   uint32_t stage_mask;                  /* SMILEHIP_STAGE_* bits */
 } smilehip_lld_config;
+
+#define SMILEHIP_CHAIN_MFCC 0
+#define SMILEHIP_CHAIN_IS09 1
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -133,6 +150,9 @@ const char *smilehip_last_error(void);
 int  smilehip_init(int device, smilehip_context **ctx);
 void smilehip_shutdown(smilehip_context *ctx);
 int  smilehip_device_name(smilehip_context *ctx, char *buf, int buflen);
+
+/* fills c with the LLD part of config/is09-13/IS09_emotion.conf (chain_kind = IS09) */
+void smilehip_config_is09_lld(smilehip_lld_config *c);
 
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */
@@ -183,8 +203,11 @@ int  smilehip_batch_create(smilehip_plan *plan, const int64_t *h_sample_offsets,
                            smilehip_batch **batch);
 void smilehip_batch_destroy(smilehip_batch *batch);
 int64_t smilehip_batch_total_frames(const smilehip_batch *batch);
-/* h_frame_offsets[n_utt+1]: row range of utterance u in the output matrix */
-int  smilehip_batch_frame_offsets(const smilehip_batch *batch, int64_t *h_frame_offsets);
+/* rows of the output matrix (= frames for the MFCC chain; frames + 1 per non-empty
+ * utterance for the IS09 chain, whose smoother emits one end-of-input frame) */
+int64_t smilehip_batch_total_rows(const smilehip_batch *batch);
+/* h_row_offsets[n_utt+1]: row range of utterance u in the output matrix */
+int  smilehip_batch_frame_offsets(const smilehip_batch *batch, int64_t *h_row_offsets);
 
 /* The fused chain: R0 smilePcm_convertSamples (smileUtil.c:2527-2535) ->
  * R1 cFramer -> R2 cVectorPreemphasis::processVector -> R3
@@ -196,6 +219,16 @@ int  smilehip_batch_frame_offsets(const smilehip_batch *batch, int64_t *h_frame_
  * Asynchronous on `stream`. */
 int  smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *batch, const int16_t *d_pcm,
                        float *d_out, int64_t ld_out, void *stream);
+
+/* The LLD set selected by chain_kind (smilehip_mfcc_run for SMILEHIP_CHAIN_MFCC plans;
+ * for SMILEHIP_CHAIN_IS09: R0-R7 + R9 + R10 + R12 per frame, cPitchACF's smoother per
+ * utterance, then cContourSmoother + cDeltaRegression with the reference's end-of-input
+ * rules). d_out: total_rows x ld_out, ld_out >= n_out. Asynchronous on `stream`. */
+int  smilehip_lld_run(smilehip_plan *plan, smilehip_batch *batch, const int16_t *d_pcm,
+                      float *d_out, int64_t ld_out, void *stream);
+/* host-buffer convenience of the same (H2D, run, D2H, synchronises) */
+int  smilehip_lld_run_host(smilehip_plan *plan, smilehip_batch *batch, const int16_t *h_pcm,
+                           int64_t n_samples, float *h_out);
 
 /* Convenience for hosts that hold plain memory (the plugin / batch driver):
  * H2D, run, D2H, synchronises. h_out must hold total_frames*n_out floats. */

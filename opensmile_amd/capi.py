@@ -36,6 +36,8 @@ class LldConfig(C.Structure):
         ("first_mfcc", C.c_int32), ("last_mfcc", C.c_int32), ("cep_lifter", C.c_float),
         ("mfcc_htk_compatible", C.c_int32), ("melfloor", C.c_float),
         ("n_delta", C.c_int32), ("delta_win", C.c_int32),
+        ("chain_kind", C.c_int32), ("pitch_max", C.c_double), ("voicing_cutoff", C.c_double),
+        ("sma_win", C.c_int32),
         ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
         ("stage_mask", C.c_uint32),
     ]
@@ -59,6 +61,10 @@ SYMBOLS = {
     "smilehip_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "smilehip_shutdown": (None, [_vp]),
     "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
+    "smilehip_batch_total_rows": (_i64, [_vp]),
+    "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     "smilehip_free": (C.c_int, [_vp, _vp]),
     "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
@@ -118,6 +124,12 @@ def load():
 def _check(rc):
     if rc != 0:
         raise SmileHipError(f"smilehip error {rc}: {load().smilehip_last_error().decode()}")
+
+
+def is09_lld_config():
+    c = LldConfig()
+    load().smilehip_config_is09_lld(C.byref(c))
+    return c
 
 
 def mfcc12_0_d_a_config():
@@ -223,19 +235,20 @@ class Batch:
         self._h = _vp()
         _check(load().smilehip_batch_create(plan._h, off.ctypes.data, self.n_utt, C.byref(self._h)))
         self.total_frames = int(load().smilehip_batch_total_frames(self._h))
+        self.total_rows = int(load().smilehip_batch_total_rows(self._h))
         fo = np.zeros(self.n_utt + 1, np.int64)
         _check(load().smilehip_batch_frame_offsets(self._h, fo.ctypes.data))
         self.frame_offsets = fo
 
     def run_device(self, d_pcm_ptr, d_out_ptr, ld_out, stream=None):
         """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int)."""
-        _check(load().smilehip_mfcc_run(self.plan._h, self._h, d_pcm_ptr, d_out_ptr, ld_out, stream))
+        _check(load().smilehip_lld_run(self.plan._h, self._h, d_pcm_ptr, d_out_ptr, ld_out, stream))
 
     def run_host(self, pcm):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
-        out = np.zeros((self.total_frames, self.plan.geometry.n_out), np.float32)
-        _check(load().smilehip_mfcc_run_host(self.plan._h, self._h, pcm.ctypes.data, len(pcm),
-                                             out.ctypes.data))
+        out = np.zeros((self.total_rows, self.plan.geometry.n_out), np.float32)
+        _check(load().smilehip_lld_run_host(self.plan._h, self._h, pcm.ctypes.data, len(pcm),
+                                            out.ctypes.data))
         return out
 
     def close(self):

@@ -1,0 +1,257 @@
+// IS09_emotion LLD set (SURVEY.md 8a rows R9 cAcf, R10 cPitchACF, R12 cEnergy / cMZcr on
+// top of the MFCC chain), reference-order kernels: one 256-thread workgroup per frame
+// computes the 16 pre-smoothing LLD columns
+//   [RMS energy | mfcc 1..12 | zcr | voicing probability | pitch candidate]
+// a per-utterance scan applies cPitchACF's causal contour smoother, and the generic
+// window chain (lld_kernels.hip) adds SMA + delta. Correctness first: this path is
+// not yet tuned (three LDS FFTs per frame).
+#include <hip/hip_runtime.h>
+
+#include "lld_device.hpp"
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+
+namespace smilehip {
+
+namespace {
+
+// block-wide reductions over 256 threads through LDS scratch (all threads get the result)
+__device__ __forceinline__ double block_sum(double v, double *scr) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return scr[0] + scr[1] + scr[2] + scr[3];
+}
+__device__ __forceinline__ double block_max(double v, double *scr) {
+  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double m = scr[0];
+  for (int i = 1; i < 4; ++i) m = scr[i] > m ? scr[i] : m;
+  return m;
+}
+__device__ __forceinline__ int block_sum_i(int v, int *scr) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return scr[0] + scr[1] + scr[2] + scr[3];
+}
+__device__ __forceinline__ int block_min_i(int v, int *scr) {
+  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int m = scr[0];
+  for (int i = 1; i < 4; ++i) m = scr[i] < m ? scr[i] : m;
+  return m;
+}
+
+// Inverse of the packed real FFT for a purely real spectrum R[0..M] (what cAcf feeds
+// Ooura's rdft(n,-1), fftsg.c:103-135):  a[k] = R0/2 + R_M (-1)^k / 2 + sum_j R_j cos(2 pi jk/n).
+// Computed as half the forward DFT of the even extension s[j] = s[n-j] = R_j, through the
+// same half-length complex FFT + untangle the forward transform uses.
+__device__ void irfft_even(const float *R, float *re, float *im, int M, int logM, const float2 *tw_half,
+                           const float2 *tw_full, float *out, float inv_norm, bool take_abs) {
+  const int n = 2 * M;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const int n0 = 2 * i, n1 = 2 * i + 1;
+    const float v0 = R[n0 <= M ? n0 : n - n0];
+    const float v1 = R[n1 <= M ? n1 : n - n1];
+    const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+    re[r] = v0;
+    im[r] = v1;
+  }
+  __syncthreads();
+  block_cfft_radix2(re, im, M, tw_half);
+  for (int k = threadIdx.x; k < M; k += blockDim.x) {
+    const float a = 0.5f * untangle_bin(re, im, M, k, tw_full).x;
+    const float v = a / inv_norm;                       // acf.cpp:321-325: (FLOAT_DMEM)data / (FLOAT_DMEM)Nsrc
+    out[k] = take_abs ? fabsf(v) : v;
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+// LDS: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
+__global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = P.Nfft >> 1;
+  const int Npad = (P.N + 3) & ~3;
+  float *xr = smem;
+  float *yv = xr + Npad;
+  float *re = yv + Npad;
+  float *im = re + M;
+  float *mg = im + M;
+  float *sp = mg + ((P.K + 3) & ~3);
+  float *acf = sp + ((P.K + 3) & ~3);
+  float *cep = acf + M;
+  float *lmel = cep + M;
+  double *scr = reinterpret_cast<double *>(lmel + 32);
+  int *iscr = reinterpret_cast<int *>(scr + 4);
+
+  const int64_t row = blockIdx.x;
+  int lo = 0, hi = P.n_utt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (P.frame_off[mid] <= row) lo = mid; else hi = mid;
+  }
+  const int64_t t = row - P.frame_off[lo];
+  const int16_t *x = P.pcm + P.samp_off[lo] + t * (int64_t)P.H;
+  float *out = Q.raw16 + row * 16;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+
+  for (int n = threadIdx.x; n < P.N; n += blockDim.x) xr[n] = pcm16_to_float(x[n]);      // R0
+  __syncthreads();
+
+  // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
+  {
+    int cnt = 0;
+    for (int i = 1 + threadIdx.x; i < P.N - 1; i += blockDim.x)
+      if (((xr[i - 1] * xr[i + 1] <= 0.0f) && (xr[i] == 0.0f)) || (xr[i - 1] * xr[i] < 0.0f)) ++cnt;
+    const int total = block_sum_i(cnt, iscr);
+    if (threadIdx.x == 0) out[13] = (float)total / (float)P.N;
+  }
+  // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
+  double e2 = 0.0;
+  for (int n = threadIdx.x; n < P.N; n += blockDim.x) {
+    float y = xr[n];
+    if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
+    y = y * P.window[n] + P.win_offset;
+    yv[n] = y;
+    const float sq = y * y;
+    e2 += (double)sq;
+  }
+  {
+    const double d = block_sum(e2, scr);
+    if (threadIdx.x == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
+  }
+  // R4 forward real FFT
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+    const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+    re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f;
+    im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f;
+  }
+  __syncthreads();
+  block_cfft_radix2(re, im, M, P.tw_half);
+  for (int k = threadIdx.x; k <= M; k += blockDim.x)
+    mg[k] = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);       // R5
+  __syncthreads();
+  // R6 / R7: mel (usePower per config) -> log -> DCT
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
+  __syncthreads();
+  for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x)
+    lmel[b] = log_mel(mel_band_exact(sp, P.mel_coef, P.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
+  __syncthreads();
+  for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
+    out[1 + r] = dct_coeff(lmel, P.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);
+  __syncthreads();
+
+  // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
+  __syncthreads();
+  irfft_even(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    const float p = mg[k] * mg[k];
+    sp[k] = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                              // :288-305
+  }
+  __syncthreads();
+  irfft_even(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
+
+  // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
+  const int n = M;                                      // 256 values each
+  const double Nd = (double)(2 * n);
+  const double Tsamp = Q.fsSec / Nd;
+  const int preskip = (Q.maxPitch <= 0.0) ? 0 : (int)(1.0 / (Q.maxPitch * Tsamp));
+  // voicingProb (:249-284)
+  double vmax = acf[n - 1];
+  for (int i = 1 + threadIdx.x; i < n; i += blockDim.x)
+    if (i >= preskip && (acf[i] > vmax) && (acf[i - 1] < acf[i])) vmax = acf[i];
+  // (the reference's running-max test "a[i] > max" only ever raises max, so the result is the
+  //  maximum over the qualifying set; taking it in parallel gives the same value)
+  vmax = block_max(vmax, scr);
+  const double voicing = (acf[0] > 0.0f) ? vmax / (double)acf[0] : 0.0;
+  // pitchPeak on the cepstrum (:286-310)
+  const int skip = preskip + 1;
+  double csum = 0.0, cmax = cep[n - 1];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double b = cep[i];
+    csum += fabs(b);
+    if (i >= skip && b > cmax) cmax = b;
+  }
+  csum = block_sum(csum, scr) / n;
+  cmax = block_max(cmax, scr);
+  const double thr = (cmax + csum) * 0.6;
+  int first = 1 << 30;
+  for (int i = skip + 1 + threadIdx.x; i < n - 1; i += blockDim.x)
+    if ((double)cep[i] > thr && (cep[i - 1] < cep[i]) && (cep[i] > cep[i + 1])) { first = i; break; }
+  first = block_min_i(first, iscr);
+  if (threadIdx.x == 0) {
+    long maxIdx = (first == (1 << 30)) ? 0 : first;
+    float pitch = 0.0f;
+    if (maxIdx > 0) pitch = 1.0f / ((float)maxIdx * (float)Tsamp);
+    if (voicing < Q.voicingCutoff) pitch = 0.0f;
+    out[14] = (float)voicing;
+    out[15] = pitch;                                    // smoothed in place by lld_pitch_smooth
+  }
+}
+
+// R10, sequential part: cPitchACF's causal contour smoother (pitchACF.cpp:199-243), state
+// per utterance (lastPitch, lastlastPitch, glMeanPitch, onsFlag). One thread per utterance.
+__global__ void __launch_bounds__(64) lld_pitch_smooth(const int64_t *frame_off, int n_utt, float *raw16) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_utt) return;
+  const int64_t f0 = frame_off[u];
+  const int64_t T = frame_off[u + 1] - f0;
+  float lastPitch = 0.0f, lastlastPitch = 0.0f, glMeanPitch = 0.0f;
+  int onsFlag = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    float *cell = raw16 + (f0 + t) * 16 + 15;
+    float pitch = *cell;
+    if ((lastPitch == 0.0f) && (pitch > 0.0f)) onsFlag = 1;
+    if ((lastPitch > 0.0f) && (pitch == 0.0f) && (onsFlag == 0)) onsFlag = -1;
+    if ((lastPitch > 0.0f) && (pitch > 0.0f)) onsFlag = 0;
+    if ((lastPitch == 0.0f) && (pitch == 0.0f)) onsFlag = 0;
+    if ((pitch == 0.0f) && (onsFlag == 1)) lastPitch = 0.0f;
+    const float oPitch = pitch;
+    const float tol = 0.4f;
+    float alpha = 0.3f;
+    if (pitch > 0.0f) {
+      if (glMeanPitch == 0.0f) glMeanPitch = pitch;
+      if (!((pitch < (1.0f + tol) * glMeanPitch) && (pitch > (1.0f - tol) * glMeanPitch))) {
+        pitch = glMeanPitch;
+        alpha /= 3.0f;
+      }
+      if (onsFlag && (lastPitch > pitch)) lastPitch *= 0.85f;
+    }
+    if ((pitch > 0.0f) && (onsFlag == -1)) lastPitch = pitch;
+    if (oPitch > 0.0f) glMeanPitch = (1.0f - alpha) * glMeanPitch + alpha * oPitch;
+    float o;
+    if ((lastlastPitch != 0.0f) && (lastPitch != 0.0f)) o = 0.5f * (lastlastPitch + lastPitch);
+    else o = lastPitch;
+    *cell = o;
+    lastlastPitch = lastPitch;
+    lastPitch = pitch;
+  }
+}
+
+hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
+  if (P.total_frames <= 0) return hipSuccess;
+  const int M = P.Nfft / 2;
+  const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)(2 * Npad + 2 * M + 2 * Kpad + 2 * M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_is09_frame, dim3((unsigned)P.total_frames), dim3(256), lds, s, P, Q);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_pitch_smooth, dim3((unsigned)((P.n_utt + 63) / 64)), dim3(64), 0, s, P.frame_off, P.n_utt, Q.raw16);
+  return hipGetLastError();
+}
+
+}  // namespace smilehip

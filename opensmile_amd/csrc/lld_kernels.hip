@@ -97,122 +97,111 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// R13: delta regression chain
+// R13: window-processor chain (cDeltaRegression, cContourSmoother)
 // ---------------------------------------------------------------------------
-// One thread per (row, column). Closed form valid for utterances longer than
-// short_T frames: order-1 output d[t], t in [0, T+W), uses x with indices
-// clamped to [0, T-1] (first/last frame replication at the level edges,
-// dataMemoryLevel.cpp:1687-1712); order-2 output a[t], t < T, uses d on
-// [0, T+W) with only the low clamp ever active. d is recomputed on the fly
-// with the identical float expression, so it is bit-identical to a stored d.
-__device__ __forceinline__ float delta1(const float *x, int64_t ld, int64_t T, int64_t t, int W, float norm) {
-  float num = 0.0f;
-  for (int i = 1; i <= W; ++i) {
-    int64_t a = t - i, b = t + i;
-    a = a < 0 ? 0 : (a > T - 1 ? T - 1 : a);
-    b = b > T - 1 ? T - 1 : b;
-    const float delta = x[b * ld] - x[a * ld];
-    num += (float)i * delta;
-  }
-  return num / norm;
-}
-
-// Tiled form: one workgroup per tile of kDeltaTile consecutive frames of one
-// utterance. The static block (with a halo of 2W frames, indices clamped to
-// [0, T-1] = first/last-frame replication) is staged in LDS, the order-1 level
-// d[t] is formed for t in [t0-W, t0+nF+W) (d[t<0] := d[0]: the accel
-// component's own left padding), then the order-2 level. All float
-// expressions are those of delta1() above, so results are bit-identical to the
-// one-thread-per-element form.
-constexpr int kDeltaTile = 128;
-constexpr int kDeltaMaxD = 16;
-constexpr int kDeltaMaxW = 4;
-
-__global__ void __launch_bounds__(256) lld_delta_tiled(DeltaParams P) {
-  __shared__ float xs[(kDeltaTile + 4 * kDeltaMaxW) * kDeltaMaxD];
-  __shared__ float ds[(kDeltaTile + 2 * kDeltaMaxW) * kDeltaMaxD];
-  const int u = P.tile_utt[blockIdx.x];
-  const int t0 = P.tile_t0[blockIdx.x];
-  const int64_t r0 = P.frame_off[u];
-  const int T = (int)(P.frame_off[u + 1] - r0);
-  if (T <= P.short_T) return;                 // handled by lld_delta_short
-  const int D = P.D, W = P.W;
-  const int nF = (T - t0 < kDeltaTile) ? T - t0 : kDeltaTile;
-  const float *x = P.io + r0 * P.ld;
-  // stage xs[i][d] = x[clamp(t0 - 2W + i)][d]
-  const int nX = nF + 4 * W;
-  for (int idx = threadIdx.x; idx < nX * D; idx += blockDim.x) {
-    const int i = idx / D, d = idx - i * D;
-    int tt = t0 - 2 * W + i;
-    tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-    xs[i * D + d] = x[(int64_t)tt * P.ld + d];
-  }
-  __syncthreads();
-  // order 1: ds[i][d] = d[max(t0 - W + i, 0)]
-  const int nD = nF + 2 * W;
-  for (int idx = threadIdx.x; idx < nD * D; idx += blockDim.x) {
-    const int i = idx / D, d = idx - i * D;
-    int t = t0 - W + i;
-    t = t < 0 ? 0 : t;
-    const int c = t - (t0 - 2 * W);             // centre position in xs
+// One stage applied at the centre position c of a staged level (stride D):
+//   kind 0: cDeltaRegression::processBuffer (deltaRegression.cpp:144-152, norm :77-79)
+//   kind 1: cContourSmoother::processBuffer (contourSmoother.cpp:104-111)
+__device__ __forceinline__ float chain_op(const float *lv, int c, int D, int d, int kind, int W) {
+  if (kind == 0) {
+    float norm = 0.0f;
+    for (int i = 1; i <= W; ++i) norm += (float)i * (float)i;
+    norm *= 2.0;
     float num = 0.0f;
     for (int k = 1; k <= W; ++k) {
-      const float delta = xs[(c + k) * D + d] - xs[(c - k) * D + d];
+      const float delta = lv[(c + k) * D + d] - lv[(c - k) * D + d];
       num += (float)k * delta;
     }
-    ds[i * D + d] = num / P.norm;
+    return num / norm;
+  }
+  float acc = lv[c * D + d];
+  for (int k = 1; k <= W; ++k) { acc += lv[(c - k) * D + d]; acc += lv[(c + k) * D + d]; }
+  return acc / (float)(2 * W + 1);
+}
+
+// Tiled closed form, valid for utterances longer than short_T frames: level s+1 at
+// index t uses level s at t-W..t+W with indices clamped to the level's own range
+// (first/last-frame replication, dataMemoryLevel.cpp:1687-1712); level s has
+// T + W_1 + .. + W_s rows, all of which the next stage consumes as real data.
+// One workgroup per tile of kChainTile output rows; levels are staged in LDS with
+// the halo the later stages need. Float expressions are the reference's.
+constexpr int kChainTile = 128;
+constexpr int kChainMaxD = 16;
+constexpr int kChainMaxW = 4;
+
+__global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
+  __shared__ float l0[(kChainTile + 4 * kChainMaxW) * kChainMaxD];
+  __shared__ float l1[(kChainTile + 2 * kChainMaxW) * kChainMaxD];
+  const int u = P.tile_utt[blockIdx.x];
+  const int t0 = P.tile_t0[blockIdx.x];
+  const int64_t f0 = P.frame_off[u];
+  const int T = (int)(P.frame_off[u + 1] - f0);
+  if (T <= P.short_T) return;                 // handled by lld_chain_short
+  const int rows = T + P.row_extra;
+  const int D = P.D;
+  const int W1 = P.W[0], W2 = (P.n_stages > 1) ? P.W[1] : 0;
+  const int nF = (rows - t0 < kChainTile) ? rows - t0 : kChainTile;
+  const int L1 = T + W1;                      // rows of level 1
+  const float *x = P.x + f0 * P.ld_x;
+  // level 0 at positions [t0 - W1 - W2, t0 + nF + W1 + W2), clamped to [0, T-1]
+  const int n0 = nF + 2 * (W1 + W2);
+  for (int idx = threadIdx.x; idx < n0 * D; idx += blockDim.x) {
+    const int i = idx / D, d = idx - i * D;
+    int tt = t0 - W1 - W2 + i;
+    tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+    l0[i * D + d] = x[(int64_t)tt * P.ld_x + d];
   }
   __syncthreads();
+  // level 1 at positions [t0 - W2, t0 + nF + W2), index clamped to [0, L1-1]
+  const int n1 = nF + 2 * W2;
+  for (int idx = threadIdx.x; idx < n1 * D; idx += blockDim.x) {
+    const int i = idx / D, d = idx - i * D;
+    int t = t0 - W2 + i;
+    t = t < 0 ? 0 : (t > L1 - 1 ? L1 - 1 : t);
+    l1[i * D + d] = chain_op(l0, t - (t0 - W1 - W2), D, d, P.kind[0], W1);
+  }
+  __syncthreads();
+  float *o = P.out + (P.row_off[u] + t0) * P.ld_out;
   for (int idx = threadIdx.x; idx < nF * D; idx += blockDim.x) {
     const int f = idx / D, d = idx - f * D;
-    float *o = P.io + (r0 + t0 + f) * P.ld + d;
-    const int c = f + W;                         // position of frame t0+f in ds
-    o[D] = ds[c * D + d];
-    if (P.n_orders >= 2) {
-      float num = 0.0f;
-      for (int k = 1; k <= W; ++k) {
-        const float delta = ds[(c + k) * D + d] - ds[(c - k) * D + d];
-        num += (float)k * delta;
-      }
-      o[2 * D] = num / P.norm;
-    }
+    o[(int64_t)f * P.ld_out + P.out_col[0] + d] = l1[(f + W2) * D + d];
+    if (P.n_stages > 1) o[(int64_t)f * P.ld_out + P.out_col[1] + d] = chain_op(l1, f + W2, D, d, P.kind[1], W2);
   }
 }
 
 // Tick-accurate path for very short utterances (T <= short_T): the reference's
-// components run in lockstep, one frame per tick, and cDataMemoryLevel::
-// getMatrix reads never-written (zero) slots in its left-padding branch
-// (dataMemoryLevel.cpp:1687-1698) -- see DESIGN.md "R13 end-of-input". One
-// thread per (short utterance, column) replays that loop.
-constexpr int kShortMaxW = kDeltaMaxW;
-constexpr int kShortMaxOrders = 2;
-constexpr int kShortCap = 4 * kShortMaxW + kShortMaxW * kShortMaxOrders + 2 * kShortMaxW + 2;
+// components run in lockstep, one frame per tick, and cDataMemoryLevel::getMatrix
+// reads never-written (zero) slots in its left-padding branch
+// (dataMemoryLevel.cpp:1687-1698) -- see DESIGN.md "R13 end-of-input". One thread
+// per (short utterance, column) replays that loop.
+constexpr int kShortMaxT = 16;
+constexpr int kShortCap = kShortMaxT + 6 * kChainMaxW + 4;
 
-__global__ void __launch_bounds__(64) lld_delta_short(DeltaParams P) {
+__global__ void __launch_bounds__(64) lld_chain_short(ChainParams P) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int si = gid / P.D;
   const int d = gid - si * P.D;
   if (si >= P.n_short) return;
   const int u = P.short_utts[si];
-  const int64_t r0 = P.frame_off[u];
-  const int T = (int)(P.frame_off[u + 1] - r0);
+  const int64_t f0 = P.frame_off[u];
+  const int T = (int)(P.frame_off[u + 1] - f0);
   if (T <= 0) return;
-  const int W = P.W;
-  float lv[kShortMaxOrders + 1][kShortCap];
-  int curW[kShortMaxOrders + 1];
-  bool done[kShortMaxOrders + 1];
-  for (int o = 0; o <= kShortMaxOrders; ++o) {
+  float lv[3][kShortCap];
+  int curW[3];
+  bool done[3];
+  for (int o = 0; o < 3; ++o) {
     curW[o] = 0; done[o] = false;
     for (int i = 0; i < kShortCap; ++i) lv[o][i] = 0.0f;
   }
-  for (int t = 0; t < T; ++t) lv[0][t] = P.io[(r0 + t) * P.ld + d];
+  for (int t = 0; t < T; ++t) lv[0][t] = P.x[(f0 + t) * P.ld_x + d];
   curW[0] = T;
   for (int eoi = 0; eoi <= 1; ++eoi) {
     bool progress = true;
     while (progress) {
       progress = false;
-      for (int o = 1; o <= P.n_orders; ++o) {
+      for (int o = 1; o <= P.n_stages; ++o) {
         if (done[o]) continue;
+        const int W = P.W[o - 1];
         const float *in = lv[o - 1];
         const int wIn = curW[o - 1];
         const int t = curW[o];
@@ -225,34 +214,27 @@ __global__ void __launch_bounds__(64) lld_delta_short(DeltaParams P) {
           if (padEnd >= vEnd - v) { done[o] = true; continue; }
         }
         if (!(v < wIn)) continue;
-        if (t >= kShortCap) { done[o] = true; continue; }
-        float num = 0.0f;
-        for (int i = 1; i <= W; ++i) {
-          // element at block index W+i / W-i, assembled as getMatrix does
-          float hiV, loV;
-          {
-            const int idx = t + i;     // absolute frame index of the later sample
-            if (vOld < 0) hiV = in[idx];                                  // raw read, may be past wIn (zeros)
-            else if (padEnd > 0) hiV = in[idx < wIn ? idx : wIn - 1];     // replicate last written frame
-            else hiV = in[idx];
-          }
-          {
-            const int idx = t - i;
-            if (idx < 0) loV = in[0];                                     // replicate first frame
-            else if (vOld >= 0 && padEnd > 0) loV = in[idx < wIn ? idx : wIn - 1];
-            else loV = in[idx];
-          }
-          const float delta = hiV - loV;
-          num += (float)i * delta;
+        if (t >= kShortCap - 1) { done[o] = true; continue; }
+        // block [t-W, t+W] assembled as getMatrix does
+        float blk[2 * kChainMaxW + 1];
+        for (int k = -W; k <= W; ++k) {
+          const int idx = t + k;
+          float val;
+          if (idx < 0) val = in[0];                                        // replicate first frame
+          else if (vOld < 0) val = in[idx];                                // raw read, may be past wIn (zeros)
+          else if (padEnd > 0) val = in[idx < wIn ? idx : wIn - 1];        // replicate last written frame
+          else val = in[idx];
+          blk[k + W] = val;
         }
-        lv[o][t] = num / P.norm;
+        lv[o][t] = chain_op(blk, W, 1, 0, P.kind[o - 1], W);
         curW[o] = t + 1;
         progress = true;
       }
     }
   }
-  for (int o = 1; o <= P.n_orders; ++o)
-    for (int t = 0; t < T; ++t) P.io[(r0 + t) * P.ld + o * P.D + d] = lv[o][t];
+  const int rows = T + P.row_extra;
+  for (int o = 1; o <= P.n_stages; ++o)
+    for (int t = 0; t < rows; ++t) P.out[(P.row_off[u] + t) * P.ld_out + P.out_col[o - 1] + d] = lv[o][t];
 }
 
 // ---------------------------------------------------------------------------
@@ -265,16 +247,20 @@ hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   return hipGetLastError();
 }
 
-int delta_tile_frames() { return kDeltaTile; }
+int chain_tile_rows() { return kChainTile; }
+int chain_short_max() { return kShortMaxT; }
 
-hipError_t launch_delta(const DeltaParams &P, hipStream_t s) {
-  if (P.D > kDeltaMaxD || P.W > kDeltaMaxW || P.W < 1) return hipErrorInvalidValue;
-  if (P.n_dtiles > 0) hipLaunchKernelGGL(lld_delta_tiled, dim3((unsigned)P.n_dtiles), dim3(256), 0, s, P);
+hipError_t launch_chain(const ChainParams &P, hipStream_t s) {
+  if (P.D > kChainMaxD || P.n_stages < 1 || P.n_stages > 2) return hipErrorInvalidValue;
+  for (int i = 0; i < P.n_stages; ++i)
+    if (P.W[i] < 1 || P.W[i] > kChainMaxW) return hipErrorInvalidValue;
+  if (P.short_T > kShortMaxT) return hipErrorInvalidValue;
+  if (P.n_tiles > 0) hipLaunchKernelGGL(lld_chain_tiled, dim3((unsigned)P.n_tiles), dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (P.n_short > 0) {
     const int m = P.n_short * P.D;
-    hipLaunchKernelGGL(lld_delta_short, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(lld_chain_short, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, P);
     e = hipGetLastError();
   }
   return e;

@@ -26,6 +26,8 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 // aligned: PCM buffer 4-byte aligned and every utterance starts at an even sample
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
-hipError_t launch_delta(const DeltaParams &P, hipStream_t s);
-int delta_tile_frames();
+hipError_t launch_chain(const ChainParams &P, hipStream_t s);
+hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
+int chain_tile_rows();
+int chain_short_max();
 }  // namespace smilehip

@@ -56,19 +56,39 @@ struct Fast512Tables {
   float mel_scale;
 };
 
-struct DeltaParams {
-  const int64_t *frame_off;    // [n_utt+1]
-  const int32_t *tile_utt;     // [n_dtiles] delta tiles: utterance
-  const int32_t *tile_t0;      // [n_dtiles] first frame of the tile
-  int32_t n_dtiles;
+// Extra parameters of the IS09 LLD frame kernel (lld_is09.hip)
+struct Is09Params {
+  float *raw16;              // [total_frames x 16] pre-smoothing LLD columns
+  float fsSec;               // (float) frameSizeSec of the ACF level (pitchACF.cpp:113-116)
+  double maxPitch;
+  double voicingCutoff;
+};
+
+// R13: chain of window processors (cDeltaRegression / cContourSmoother) over the
+// rows of each utterance. Level 0 = the input block x (T rows, D columns);
+// stage s (kind 0 = delta regression with deltawin W, 1 = simple moving average
+// with smaWin = 2W+1) maps level s to level s+1 which has W more rows.
+// The output keeps `rows = T + row_extra` rows per utterance (what the reference's
+// multi-level reader keeps: the shortest level that is written out).
+struct ChainParams {
+  const int64_t *frame_off;    // [n_utt+1] input rows (frames) per utterance
+  const int64_t *row_off;      // [n_utt+1] output rows per utterance
+  const int32_t *tile_utt;     // [n_tiles] output-row tiles: utterance
+  const int32_t *tile_t0;      // [n_tiles] first output row of the tile
+  int32_t n_tiles;
   int32_t n_utt;
-  int64_t total_frames;
-  float *io;                   // rows: [static D | delta D | accel D ...]
-  int64_t ld;
-  int32_t D, W, n_orders;
-  float norm;
+  const float *x;              // level 0
+  int64_t ld_x;
+  float *out;
+  int64_t ld_out;
+  int32_t D;
+  int32_t n_stages;            // 1 or 2
+  int32_t kind[2];
+  int32_t W[2];
+  int32_t out_col[2];          // column offset of level s+1 in `out`
+  int32_t row_extra;           // rows = T + row_extra
   int32_t short_T;             // utterances with T <= short_T go to the tick-accurate path
-  const int32_t *short_utts;   // [n_short]
+  const int32_t *short_utts;
   int32_t n_short;
 };
 

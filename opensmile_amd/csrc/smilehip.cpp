@@ -101,7 +101,10 @@ struct smilehip_batch {
   smilehip_plan *plan = nullptr;
   int32_t n_utt = 0;
   int64_t total_frames = 0;
-  std::vector<int64_t> h_samp_off, h_frame_off;
+  std::vector<int64_t> h_samp_off, h_frame_off, h_row_off;
+  int64_t total_rows = 0;
+  DevBuf<int64_t> d_row_off;
+  DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
@@ -197,6 +200,19 @@ extern "C" void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c) {
   c->delta_win = 2;
 }
 
+extern "C" void smilehip_config_is09_lld(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);
+  c->chain_kind = SMILEHIP_CHAIN_IS09;
+  c->use_power = 0;            // [is09_mspec] usePower = 0
+  c->first_mfcc = 1;
+  c->last_mfcc = 12;
+  c->n_delta = 1;
+  c->delta_win = 2;
+  c->pitch_max = 500.0;
+  c->voicing_cutoff = 0.55;
+  c->sma_win = 3;
+}
+
 // ------------------------------------------------------------------- plan
 static int build_tables(smilehip_plan *p, bool upload = true) {
   int rc;
@@ -219,6 +235,13 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   }
   p->stage_mask = mask;
   if (p->cfg.n_delta < 0 || p->cfg.n_delta > 2) return fail(SMILEHIP_ERR_INVALID, "n_delta must be 0..2");
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
+    if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 12 || p->cfg.n_delta != 1 || p->cfg.sma_win < 3 || !(p->cfg.sma_win & 1) ||
+        p->cfg.sma_win > 9)
+      return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
+  } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
+    return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
+  }
   if (p->cfg.n_delta > 0 && (p->cfg.delta_win < 1 || p->cfg.delta_win > 4))
     return fail(SMILEHIP_ERR_INVALID, "delta_win must be 1..4");
 
@@ -241,7 +264,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   }
   // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
   p->use_fast = false;
-  if (mask == SMILEHIP_STAGE_ALL && !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
+  if (mask == SMILEHIP_STAGE_ALL && p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC && !p->force_generic &&
+      fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
     p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
     if (p->ctx) p->fast.max_blocks = 2 * p->ctx->prop.multiProcessorCount;
   }
@@ -307,14 +331,18 @@ extern "C" int smilehip_plan_create_host_only(const smilehip_lld_config *cfg, sm
 
 extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 
+static int plan_n_static(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : p->dct.n_mfcc; }
+static int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }
+static int plan_row_extra(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? p->cfg.sma_win / 2 : 0; }
+
 extern "C" int smilehip_plan_geometry(const smilehip_plan *p, smilehip_geometry *g) {
   if (!p || !g) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_geometry: null argument");
   g->frame_size = p->geo.N;
   g->frame_step = p->geo.H;
   g->fft_size = p->geo.Nfft;
   g->n_bins = p->geo.K;
-  g->n_static = p->dct.n_mfcc;
-  g->n_out = p->dct.n_mfcc * (1 + p->cfg.n_delta);
+  g->n_static = plan_n_static(p);
+  g->n_out = plan_n_out(p);
   g->frame_period = p->geo.frame_period;
   g->fft_frame_size_sec = p->geo.fft_frame_size_sec;
   return SMILEHIP_OK;
@@ -360,9 +388,11 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   b->h_samp_off.assign(h_off, h_off + (n_utt ? n_utt + 1 : 0));
   if (n_utt == 0) b->h_samp_off.assign(1, 0);
   b->h_frame_off.assign(size_t(n_utt) + 1, 0);
-  const int short_T = 4 * plan->cfg.delta_win;
+  b->h_row_off.assign(size_t(n_utt) + 1, 0);
+  const int short_T = chain_short_max();
+  const int row_extra = plan_row_extra(plan);
   std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0;
-  const int64_t dtile = delta_tile_frames();
+  const int64_t dtile = chain_tile_rows();
   const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
   for (int32_t u = 0; u < n_utt; ++u) {
     const int64_t len = h_off[u + 1] - h_off[u];
@@ -371,28 +401,41 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_INVALID, "sample offsets must be non-decreasing (utterance %d)", u);
     }
     const int64_t T = smilehip_num_frames(plan, len);
+    const int64_t rows = T > 0 ? T + row_extra : 0;
     b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
+    b->h_row_off[u + 1] = b->h_row_off[u] + rows;
     if (T > 0 && T <= short_T) b->h_short.push_back(u);
     if (T > 0 && (h_off[u] & 1)) b->all_even = false;
     for (int64_t t0 = 0; t0 < T; t0 += tile_frames) {
       tile_utt.push_back(u);
       tile_t0.push_back((int32_t)t0);
     }
-    for (int64_t t0 = 0; t0 < T; t0 += dtile) {
+    for (int64_t t0 = 0; t0 < rows; t0 += dtile) {
       dtile_utt.push_back(u);
       dtile_t0.push_back((int32_t)t0);
     }
   }
   b->total_frames = b->h_frame_off[n_utt];
+  b->total_rows = b->h_row_off[n_utt];
   b->n_tiles = (int32_t)tile_utt.size();
   b->n_dtiles = (int32_t)dtile_utt.size();
   int rc;
   if ((rc = b->d_samp_off.upload(b->h_samp_off)) || (rc = b->d_frame_off.upload(b->h_frame_off)) ||
+      (rc = b->d_row_off.upload(b->h_row_off)) ||
       (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) ||
       (rc = b->d_dtile_utt.upload(dtile_utt)) || (rc = b->d_dtile_t0.upload(dtile_t0)) ||
       (rc = b->d_short.upload(b->h_short))) {
     delete b;
     return rc;
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
+    std::vector<float> zero;   // allocate only
+    b->d_raw16.release();
+    b->d_raw16.n = size_t(b->total_frames) * 16;
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_raw16.p), (b->d_raw16.n ? b->d_raw16.n : 1) * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the IS09 scratch matrix failed");
+    }
   }
   *out = b;
   return SMILEHIP_OK;
@@ -400,9 +443,10 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
 
 extern "C" void smilehip_batch_destroy(smilehip_batch *b) { delete b; }
 extern "C" int64_t smilehip_batch_total_frames(const smilehip_batch *b) { return b ? b->total_frames : 0; }
+extern "C" int64_t smilehip_batch_total_rows(const smilehip_batch *b) { return b ? b->total_rows : 0; }
 extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o) {
   if (!b || !o) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_frame_offsets: null argument");
-  std::memcpy(o, b->h_frame_off.data(), b->h_frame_off.size() * sizeof(int64_t));
+  std::memcpy(o, b->h_row_off.data(), b->h_row_off.size() * sizeof(int64_t));
   return SMILEHIP_OK;
 }
 
@@ -452,47 +496,39 @@ extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, floa
   if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 16 || ld < (int64_t)D * (1 + n_orders))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
   if (b->total_frames == 0) return SMILEHIP_OK;
-  DeltaParams Q;
+  // rows == frames is what this entry point assumes (d_io holds the static block)
+  if (b->total_rows != b->total_frames) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: batch belongs to a chain with extra rows");
+  ChainParams Q;
   std::memset(&Q, 0, sizeof(Q));
   Q.frame_off = b->d_frame_off.p;
+  Q.row_off = b->d_row_off.p;
   Q.tile_utt = b->d_dtile_utt.p;
   Q.tile_t0 = b->d_dtile_t0.p;
-  Q.n_dtiles = b->n_dtiles;
+  Q.n_tiles = b->n_dtiles;
   Q.n_utt = b->n_utt;
-  Q.total_frames = b->total_frames;
-  Q.io = d_io;
-  Q.ld = ld;
+  Q.x = d_io;
+  Q.ld_x = ld;
+  Q.out = d_io;
+  Q.ld_out = ld;
   Q.D = D;
-  Q.W = W;
-  Q.n_orders = n_orders;
-  Q.norm = delta_norm(W);
-  Q.short_T = 4 * W;
-  // the batch's short list was built with the plan's delta_win; rebuild if W differs
-  std::vector<int32_t> shorts;
-  const int32_t *d_short = b->d_short.p;
-  int32_t n_short = (int32_t)b->h_short.size();
-  DevBuf<int32_t> tmp;
-  if (W != plan->cfg.delta_win) {
-    for (int32_t u = 0; u < b->n_utt; ++u) {
-      const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
-      if (T > 0 && T <= Q.short_T) shorts.push_back(u);
-    }
-    int rc = tmp.upload(shorts);
-    if (rc) return rc;
-    d_short = tmp.p;
-    n_short = (int32_t)shorts.size();
-  }
-  Q.short_utts = d_short;
-  Q.n_short = n_short;
-  hipError_t e = launch_delta(Q, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "delta kernel launch failed: %s", hipGetErrorString(e));
-  if (tmp.p) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // tmp is freed on return
+  Q.n_stages = n_orders;
+  Q.kind[0] = Q.kind[1] = 0;
+  Q.W[0] = Q.W[1] = W;
+  Q.out_col[0] = D;
+  Q.out_col[1] = 2 * D;
+  Q.row_extra = 0;
+  Q.short_T = chain_short_max();
+  Q.short_utts = b->d_short.p;
+  Q.n_short = (int32_t)b->h_short.size();
+  hipError_t e = launch_chain(Q, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
 
 extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out,
                                  int64_t ld_out, void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan is not an MFCC chain (use smilehip_lld_run)");
   const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
   if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
@@ -539,18 +575,71 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   return SMILEHIP_OK;
 }
 
-extern "C" int smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
-                                      float *h_out) {
-  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: plan/batch mismatch");
-  if (n_samples < b->h_samp_off.back()) return fail(SMILEHIP_ERR_INVALID, "PCM buffer shorter than the batch layout");
+// IS09 LLD set: frame kernel -> pitch smoother -> SMA + delta chain
+static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  const int n_out = plan_n_out(plan);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
-  if (!h_pcm || !h_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: null pointer");
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  Is09Params I;
+  I.raw16 = b->d_raw16.p;
+  I.fsSec = (float)plan->geo.fft_frame_size_sec;
+  I.maxPitch = plan->cfg.pitch_max;
+  I.voicingCutoff = plan->cfg.voicing_cutoff;
+  if (I.voicingCutoff > 1.0) I.voicingCutoff = 1.0;       // pitchACF.cpp:96-98
+  if (I.voicingCutoff < 0.0) I.voicingCutoff = 0.0;
+  if (I.maxPitch < 0.0) I.maxPitch = 0.0;
+  hipError_t e = launch_is09(P, I, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "IS09 kernel launch failed: %s", hipGetErrorString(e));
+  ChainParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.frame_off = b->d_frame_off.p;
+  Q.row_off = b->d_row_off.p;
+  Q.tile_utt = b->d_dtile_utt.p;
+  Q.tile_t0 = b->d_dtile_t0.p;
+  Q.n_tiles = b->n_dtiles;
+  Q.n_utt = b->n_utt;
+  Q.x = b->d_raw16.p;
+  Q.ld_x = 16;
+  Q.out = d_out;
+  Q.ld_out = ld_out;
+  Q.D = 16;
+  Q.n_stages = 2;
+  Q.kind[0] = 1; Q.W[0] = plan->cfg.sma_win / 2;          // cContourSmoother
+  Q.kind[1] = 0; Q.W[1] = plan->cfg.delta_win;            // cDeltaRegression
+  Q.out_col[0] = 0;
+  Q.out_col[1] = 16;
+  Q.row_extra = plan_row_extra(plan);
+  Q.short_T = chain_short_max();
+  Q.short_utts = b->d_short.p;
+  Q.n_short = (int32_t)b->h_short.size();
+  e = launch_chain(Q, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,
+                                void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: plan/batch mismatch");
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC) return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
+  return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
+}
+
+extern "C" int smilehip_lld_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
+                                     float *h_out) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_host: plan/batch mismatch");
+  if (n_samples < b->h_samp_off.back()) return fail(SMILEHIP_ERR_INVALID, "PCM buffer shorter than the batch layout");
+  if (b->total_rows == 0) return SMILEHIP_OK;
+  if (!h_pcm || !h_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_host: null pointer");
   HIP_TRY(hipSetDevice(plan->ctx->device));
-  const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
+  const int n_out = plan_n_out(plan);
   int16_t *d_pcm = nullptr;
   float *d_out = nullptr;
   HIP_TRY(hipMalloc((void **)&d_pcm, size_t(n_samples) * sizeof(int16_t)));
-  hipError_t e = hipMalloc((void **)&d_out, size_t(b->total_frames) * n_out * sizeof(float));
+  hipError_t e = hipMalloc((void **)&d_out, size_t(b->total_rows) * n_out * sizeof(float));
   if (e != hipSuccess) {
     (void)hipFree(d_pcm);
     return fail(SMILEHIP_ERR_HIP, "hipMalloc(out) failed: %s", hipGetErrorString(e));
@@ -558,14 +647,20 @@ extern "C" int smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *b, co
   int rc = SMILEHIP_OK;
   e = hipMemcpy(d_pcm, h_pcm, size_t(n_samples) * sizeof(int16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    rc = smilehip_mfcc_run(plan, b, d_pcm, d_out, n_out, nullptr);
-    if (rc == SMILEHIP_OK) e = hipMemcpy(h_out, d_out, size_t(b->total_frames) * n_out * sizeof(float), hipMemcpyDeviceToHost);
+    rc = smilehip_lld_run(plan, b, d_pcm, d_out, n_out, nullptr);
+    if (rc == SMILEHIP_OK) e = hipMemcpy(h_out, d_out, size_t(b->total_rows) * n_out * sizeof(float), hipMemcpyDeviceToHost);
   }
   (void)hipFree(d_pcm);
   (void)hipFree(d_out);
   if (rc) return rc;
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
+                                      float *h_out) {
+  if (!plan || plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: plan is not an MFCC chain");
+  return smilehip_lld_run_host(plan, b, h_pcm, n_samples, h_out);
 }
 
 extern "C" int smilehip_plan_set_timing(smilehip_plan *plan, int enable) {
