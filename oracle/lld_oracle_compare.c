@@ -1,0 +1,406 @@
+/*
+ * lld_oracle_compare.c -- CPU ORACLE, part 3. TEST INFRASTRUCTURE ONLY (see lld_oracle.h).
+ *
+ * Restatement of the ComParE_2016 LLD groups A and B that lie on the hot path
+ * (SURVEY.md 8a rows R8 cPlp as auditory spectrum incl. RASTA, R11 cSpectral with
+ * ComParE's option set, R12 cEnergy/cMZcr on the 20 ms / 60 ms frames, cVectorOperation
+ * ll1) and of the SMA -> delta tail feeding the LLD sinks. The F0 group (SHS pitch,
+ * Viterbi, jitter/shimmer) is out of scope.
+ * Citations are relative to the reference root.
+ */
+#include "lld_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ---------------------------------------------------------------------- R11 */
+/* Bark scale (Traunmueller), smileDsp_specScaleTransfFwd SPECTSCALE_BARK, smileUtil.c:1123-1137 */
+static double hz_to_bark(double x)
+{
+  if (x > 0) {
+    double zz = (26.81 / (1.0 + 1960.0 / x)) - 0.53;
+    if (zz < 2) return (0.85 * zz + 0.3);
+    else if (zz > 20.1) return (1.22 * zz - 0.22 * 20.1);
+    else return zz;
+  }
+  return 0.0;
+}
+/* smileDsp_getSharpnessWeightG for a Bark argument, smileUtil.c:1063-1078 */
+static double sharp_g(double bark)
+{
+  if (bark <= 16.0) return 1.0;
+  return pow((bark - 16.0) / 4.0, 1.5849625) + 1.0;
+}
+
+/* smileStat_entropy, smileUtil.c:2079-2124 */
+static float stat_entropy(const float *vals, long N)
+{
+  const double entropy_floor = 0.0000001;
+  double e = 0.0, dn = 0.0;
+  float min = 0.0;
+  double l2 = (double)log(2.0);
+  long i;
+  for (i = 0; i < N; i++) { dn += (double)vals[i]; if (vals[i] < min) min = vals[i]; }
+  if (min < 0.0) {
+    double mf = entropy_floor + min;
+    for (i = 0; i < N; i++) { if (vals[i] <= mf) dn += mf - vals[i]; dn -= (double)min; }
+  } else {
+    min = 0.0;
+  }
+  if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+  for (i = 0; i < N; i++) {
+    double v = vals[i] - min, ln;
+    if (v <= entropy_floor) v = entropy_floor;
+    ln = v / dn;
+    if (ln > 0.0) e += ln * (double)log(ln) / l2;
+  }
+  return (float)(-e);
+}
+
+void lldo_spectral_init(lldo_spectral *s, long K, double frame_size_sec)
+{
+  s->K = K;
+  s->fsSec = frame_size_sec;
+  s->prev = (float *)calloc((size_t)K, sizeof(float));
+  s->have_prev = 0;
+  s->frq = (double *)malloc(sizeof(double) * (size_t)K);
+  /* frequency axis written by cTransformFFT::generateSpectralVectorInfo (transformFft.cpp:102-117)
+   * and copied through cFFTmagphase: frq[i] = F0 * i, F0 = 1/frameSizeSecOut */
+  double F0 = 1.0 / frame_size_sec;
+  for (long i = 0; i < K; i++) s->frq[i] = F0 * (double)i;
+  s->sharp = 0;
+}
+void lldo_spectral_reset(lldo_spectral *s) { s->have_prev = 0; }
+void lldo_spectral_free(lldo_spectral *s) { free(s->prev); free(s->frq); free(s->sharp); }
+
+/* band edge mapping of cSpectral::processVector with a frequency axis, spectral.cpp:779-826 */
+static double band_energy(const float *srcP, const double *frq, long Nsrc, long lo, long hi, long nBins)
+{
+  long ii;
+  double wghtL, wghtR, idxL, idxR;
+  for (ii = 0; ii < Nsrc; ii++) if (frq[ii] > (double)lo) break;
+  if ((ii < Nsrc) && (ii > 0)) wghtL = (frq[ii] - (double)lo) / (frq[ii] - frq[ii - 1]); else wghtL = 1.0;
+  idxL = (double)ii - 1.0;
+  if (idxL < 0) idxL = 0;
+  if (idxL >= Nsrc) idxL = Nsrc;
+  if (wghtL == 0.0) wghtL = 1.0;
+  for (ii = 0; ii < Nsrc; ii++) if (frq[ii] >= (float)hi) break;
+  if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi - frq[ii - 1]) / (frq[ii] - frq[ii - 1]); else wghtR = 1.0;
+  if ((ii < Nsrc) && (frq[ii] == (float)hi)) idxR = (double)ii; else idxR = (double)ii - 1.0;
+  if (idxR >= Nsrc) idxR = Nsrc - 1;
+  if (wghtR == 0.0) wghtR = 1.0;
+  long iL = (long)floor(idxL), iR = (long)floor(idxR), j;
+  if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+  if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+  if (iL < 0) iL = 0;
+  if (iR < 0) iR = 0;
+  double sum = (double)srcP[iL] * wghtL;                                   /* :832-836 */
+  for (j = iL + 1; j < iR; j++) sum += (double)srcP[j];
+  sum += (double)srcP[iR] * wghtR;
+  return sum / (double)nBins;                                              /* :853 (normBandEnergies=0, lin spectrum) */
+}
+
+/* cSpectral::processVector with [is13_spectral]'s options (ComParE_2016_core.lld.conf.inc):
+ * bands 250-650, 1000-4000; rollOff .25 .50 .75 .90; flux, centroid, entropy, variance,
+ * skewness, kurtosis, slope, sharpness, harmonicity; defaults squareInput=1,
+ * normBandEnergies=0, useLogSpectrum=0, buggyRollOff=0, oldSlopeScale=1, freqRange 0-0.
+ * src: magnitude spectrum (K). dst: 15 values in the reference's output order. */
+void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
+{
+  const long Nsrc = s->K;
+  const double *frq = s->frq;
+  long i, j, n = 0;
+  const long lo = 1, hi = Nsrc - 1;                  /* specRange 0-0 => bins 1 .. Nsrc-1 (:625-627) */
+  const long nBins = hi - lo + 1;
+  float *srcP = (float *)malloc(sizeof(float) * (size_t)Nsrc);
+  for (i = 0; i < Nsrc; i++) srcP[i] = src[i] * src[i];                    /* :676-683 */
+  const float *srcM = src, *srcLP = srcP;
+  double frameSum = 0.0;
+  for (i = lo; i <= hi; i++) frameSum += srcP[i];                          /* :762-767 */
+  dst[n++] = (float)band_energy(srcP, frq, Nsrc, 250, 650, nBins);
+  dst[n++] = (float)band_energy(srcP, frq, Nsrc, 1000, 4000, nBins);
+  double sumB = 0.0, sumC = 0.0;
+  for (j = lo; j <= hi; j++) sumB += (double)srcLP[j];                     /* :1093-1097 */
+  const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
+  float ro[4] = {0, 0, 0, 0};
+  for (j = lo; j <= hi; j++) {                                             /* :1102-1117 */
+    sumC += (double)srcP[j];
+    for (i = 0; i < 4; i++)
+      if ((ro[i] == 0.0) && (sumC >= rollOff[i] * frameSum)) ro[i] = (float)frq[j];
+  }
+  for (i = 0; i < 4; i++) dst[n++] = ro[i];
+  /* flux, :1124-1254 (first frame of a field: a single 0) */
+  if (!s->have_prev) {
+    dst[n++] = 0.0f;
+    s->have_prev = 1;
+  } else {
+    double myA = 0.0;
+    for (j = lo; j <= hi; j++) {
+      double myB = ((double)srcM[j] / 1.0 - (double)s->prev[j - lo] / 1.0);
+      myA += myB * myB;
+    }
+    double flux = (nBins > 0) ? myA / (double)nBins : 0.0;
+    dst[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+  }
+  for (j = lo; j <= hi; j++) s->prev[j - lo] = srcM[j];
+  /* centroid, :1256-1311 */
+  float ctr = 0.0f;
+  double sumA = 0.0;
+  for (j = lo; j <= hi; j++) sumA += (double)frq[j] * (double)srcLP[j];
+  if (sumB != 0.0) ctr = (float)(sumA / sumB);
+  dst[n++] = ctr;
+  dst[n++] = stat_entropy(srcLP + lo, hi - lo + 1);                        /* :1332-1336 */
+  /* moments, :1338-1397 */
+  double u = ctr, m2 = 0.0, m3 = 0.0, m4 = 0.0;
+  for (i = lo; i <= hi; i++) {
+    double t1 = ((double)frq[i] - u);
+    double m = t1 * t1 * (double)srcLP[i];
+    m2 += m; m *= t1; m3 += m; m4 += m * t1;
+  }
+  double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+  dst[n++] = (float)sigma2;
+  dst[n++] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
+  dst[n++] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
+  /* slope, :1399-1427 (oldSlopeScale = 1) */
+  {
+    double Sf = 0.0, S2f = 0.0, Nind = (double)nBins;
+    for (i = lo; i <= hi && i < Nsrc; i++) { S2f += (double)frq[i] * (double)frq[i]; Sf += (double)frq[i]; }
+    double deno = (Nind * S2f - Sf * Sf), slope = 0.0;
+    if (deno != 0.0) slope = (Nind * sumA - Sf * sumB) / deno;
+    dst[n++] = (float)(slope * (Nind - 1.0));
+  }
+  /* sharpness, :1429-1482 (frequency axis given, linear scale) */
+  {
+    if (!s->sharp) {
+      s->sharp = (double *)malloc(sizeof(double) * (size_t)(hi - lo + 1));
+      for (j = lo; j <= hi; j++) {
+        double f = hz_to_bark((double)frq[j]);      /* lin -> (inv lin = identity) -> bark */
+        s->sharp[j - lo] = f * sharp_g(f);
+      }
+    }
+    float sumAA = 0.0f, c2 = 0.0f;
+    for (j = lo; j <= hi; j++) sumAA += (float)(s->sharp[j - lo] * (double)srcP[j]);
+    if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
+    dst[n++] = (float)(0.11 * c2);
+  }
+  /* harmonicity, :1484-1513 */
+  {
+    float ptpSum = 0.0f, lastPeak = -99.0f;
+    for (j = lo + 2; j < hi - 1; j++) {
+      if ((srcLP[j - 2] < srcLP[j] && srcLP[j - 1] < srcLP[j] && srcLP[j] > srcLP[j + 1] && srcLP[j] > srcLP[j + 2]) ||
+          (srcLP[j - 2] > srcLP[j] && srcLP[j - 1] > srcLP[j] && srcLP[j] < srcLP[j + 1] && srcLP[j] < srcLP[j + 2])) {
+        if (lastPeak != -99.0) ptpSum += fabs(srcLP[j] - lastPeak);
+        lastPeak = srcLP[j];
+      }
+    }
+    ptpSum /= 2.0;
+    ptpSum /= (float)nBins;
+    dst[n++] = ptpSum;
+  }
+  free(srcP);
+}
+
+/* ---------------------------------------------------------------------- R8 */
+/* smileDsp_equalLoudnessWeight, smileUtil.c:1041-1054 */
+static double eql_weight(double frequency)
+{
+  double w = 2.0 * M_PI * frequency;
+  double w2 = w * w;
+  double c = w2 + 6300000.0;
+  if (c > 0.0) return (1e32 * ((w2 + 56.8e6) * w2 * w2) / (c * c * (w2 + 0.38e9) * (w2 * w2 * w2 * w + 1.7e31)));
+  return 0.0;
+}
+
+/* cPlp::initTables for doAud (+ newRASTA), src/lldcore/plp.cpp:335-402. band_hz: the
+ * band-centre metadata cMelspec writes (melspec.cpp:408-412); T: level period (0.01). */
+void lldo_plp_init(lldo_plp *p, int n_bands, const double *band_hz, int new_rasta, double T)
+{
+  p->n_bands = n_bands; p->new_rasta = new_rasta;
+  p->melfloor = (float)0.00000000093;
+  p->compression = (float)0.33;
+  p->eql = (float *)malloc(sizeof(float) * (size_t)n_bands);
+  /* RASTA / newRASTA force doLog = doInvLog = 1 (plp.cpp:168-175): the equal-loudness
+   * curve is then kept as its log (:349-352) */
+  for (int i = 0; i < n_bands; i++) {
+    p->eql[i] = (float)eql_weight((double)band_hz[i]);
+    if (new_rasta) p->eql[i] = logf(p->eql[i]);
+  }
+  float lower = (float)1.0, upper = (float)29.0;
+  p->rasta_iir = (float)(1.0 - sin(2.0 * M_PI * lower * T));
+  float om = (float)cos(2.0 * M_PI * upper * T);
+  float norm = (float)sqrt(10.0 * (32.0 * om * om + 8.0));
+  p->rasta_fir[0] = (float)(2.0 / norm);
+  p->rasta_fir[1] = (float)(-4.0 * om / norm);
+  p->rasta_fir[2] = 0.0;
+  p->rasta_fir[3] = -p->rasta_fir[1];
+  p->rasta_fir[4] = -p->rasta_fir[0];
+  p->buf = (float *)calloc((size_t)n_bands * 4, sizeof(float));
+  p->init = 0;
+}
+void lldo_plp_reset(lldo_plp *p) { memset(p->buf, 0, sizeof(float) * (size_t)p->n_bands * 4); p->init = 0; }
+void lldo_plp_free(lldo_plp *p) { free(p->eql); free(p->buf); }
+
+/* cPlp::processVector with doLog=0, doAud=1, doInvLog=0, doIDFT=0 ([is13_audspec],
+ * [is13_audspecRasta]), plp.cpp:416-593 */
+void lldo_plp_audspec(lldo_plp *p, const float *src, float *dst)
+{
+  int i, N = p->n_bands;
+  float *x = (float *)malloc(sizeof(float) * (size_t)N);
+  if (p->new_rasta) {                                                       /* doLog, :434-439 */
+    for (i = 0; i < N; i++) {
+      if (src[i] < p->melfloor) x[i] = logf(p->melfloor);
+      else x[i] = (float)logf(src[i]);
+    }
+  } else {
+    for (i = 0; i < N; i++) x[i] = src[i];
+  }
+  if (p->new_rasta) {                                                       /* :468-485 */
+    for (i = 0; i < N; i++) {
+      float *b = p->buf + i * 4;
+      float out = p->rasta_fir[0] * x[i] + b[0];
+      b[0] = p->rasta_fir[1] * x[i] + b[1] + (p->init >= 5) * p->rasta_iir * out;
+      b[1] = p->rasta_fir[2] * x[i] + b[2];
+      b[2] = p->rasta_fir[3] * x[i] + b[3];
+      b[3] = p->rasta_fir[4] * x[i];
+      if (p->init >= 5) x[i] = out; else x[i] = 0;
+    }
+    if (p->init < 5) p->init++;
+  }
+  if (p->new_rasta) {                                                       /* doAud in the log domain, :490-497 */
+    for (i = 0; i < N; i++) x[i] += p->eql[i];
+    for (i = 0; i < N; i++) x[i] *= p->compression;
+    for (i = 0; i < N; i++) dst[i] = expf(x[i]);                            /* doInvLog, :512-517 */
+  } else {
+    for (i = 0; i < N; i++) {                                               /* :499-503 */
+      if (x[i] < p->melfloor) x[i] = p->melfloor;
+      x[i] *= p->eql[i];
+    }
+    for (i = 0; i < N; i++) dst[i] = (float)pow((double)x[i], (double)p->compression);   /* :505-507 */
+  }
+  free(x);
+}
+
+/* cVectorOperation ll1, src/other/vectorOperation.cpp:475-481 */
+static float vec_ll1(const float *src, int N)
+{
+  float d = 0.0f;
+  for (int i = 0; i < N; i++) d += src[i];
+  if (N > 0) d /= (float)N;
+  return d;
+}
+
+/* ------------------------------------------------------------------- chain */
+/* ComParE_2016 LLD groups A (4) and B (55) -> SMA(3) -> delta(2), as the LLD sinks see
+ * them inside lld;lld_de (columns 6..64 and 71..129 of the 130-column file):
+ *   A: audspec_lengthL1norm, audspecRasta_lengthL1norm, pcm_RMSenergy (20 ms raw frame),
+ *      pcm_zcr (60 ms raw frame)
+ *   B: audSpec_Rfilt[26], spectral[15], mfcc[1..14]
+ * Level lengths differ: the 20 ms levels hold T20 frames, the zcr level T60 = T20 - 4.
+ * A multi-level reader serves a block only if EVERY level can (dataReader.cpp:446-522)
+ * and each level pads with ITS OWN last frame (dataMemoryLevel.cpp:1699-1708), so
+ *   - [is13_smoA] emits T60+1 frames; near the end the 20 ms columns still see real
+ *     frames while the zcr column sees its replicated last frame;
+ *   - [is13_smoB] (20 ms levels only) emits T20+1 frames, of which the sinks keep the
+ *     first T60+1: group B is free of end-of-input effects;
+ *   - the deltas are taken of those levels; the LLD sinks keep rows = T60+1.
+ * out: rows x 118 ([A|B] sma, then their deltas). Requires T60 >= 4 (the lockstep quirk
+ * of very short inputs is not restated for this multi-length graph); returns 0 otherwise. */
+long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float *raw59)
+{
+  lldo_mfcc_cfg c;
+  lldo_default_mfcc12_cfg(&c);
+  c.frame_size_sec = 0.020; c.preemph_enable = 0; c.zero_pad_symmetric = 1;
+  c.lofreq = 20.0f; c.first_mfcc = 1; c.last_mfcc = 14; c.n_delta = 0;
+  lldo_geom g;
+  lldo_geometry(&c, &g);
+  const long N60 = 960;
+  long T20 = lldo_num_frames(n_samples, g.N, g.H);
+  long T60 = lldo_num_frames(n_samples, N60, g.H);
+  if (T60 < 4) return 0;
+  const long rows = T60 + 1;
+  if (!out) return rows;
+  const int DA = 4, DB = 55, D = 59;
+  float *x = (float *)malloc(sizeof(float) * (size_t)n_samples);
+  lldo_pcm16_to_float(pcm, n_samples, x);
+  double *w = (double *)malloc(sizeof(double) * (size_t)g.N);
+  lldo_window_table(LLDO_WIN_HAMM, g.N, 0.4, 1.0, w);
+  lldo_mel mel1, mel2; lldo_dct dct;
+  lldo_mel_init(&mel1, g.K, g.frame_size_sec_fft, 26, 20.0f, 8000.0f, 1, 0);   /* [is13_melspec1]  htk = 0 */
+  lldo_mel_init(&mel2, g.K, g.frame_size_sec_fft, 26, 20.0f, 8000.0f, 1, 1);   /* [is13_melspecMfcc] htk = 1 */
+  lldo_mfcc_init(&dct, 26, 1, 14, 22.0f, 1, c.melfloor);
+  double band_hz[26];
+  for (int m = 1; m <= 26; m++) band_hz[m - 1] = 700.0 * (exp((double)mel1.cfs[m] / 1127.0) - 1.0);   /* melspec.cpp:408-412 */
+  lldo_plp plp, plpr;
+  lldo_plp_init(&plp, 26, band_hz, 0, c.frame_step_sec);
+  lldo_plp_init(&plpr, 26, band_hz, 1, c.frame_step_sec);
+  lldo_spectral spec;
+  lldo_spectral_init(&spec, g.K, g.frame_size_sec_fft);
+  float *fr = (float *)malloc(sizeof(float) * (size_t)g.N);
+  float *sp = (float *)malloc(sizeof(float) * (size_t)g.Nfft);
+  float *mg = (float *)malloc(sizeof(float) * (size_t)g.K);
+  float mb[26], aud[26];
+  float *la = (float *)calloc((size_t)T20 * DA, sizeof(float));     /* group A, column 3 valid for t < T60 */
+  float *lb = (float *)calloc((size_t)T20 * DB, sizeof(float));
+  for (long t = 0; t < T20; t++) {
+    const float *src = x + t * g.H;
+    float *ra = la + t * DA, *rb = lb + t * DB;
+    lldo_window_apply(src, fr, g.N, w, 0.0);
+    lldo_rfft_frame(fr, g.N, sp, g.Nfft, 1);
+    lldo_fftmag(sp, g.Nfft, mg);
+    lldo_melspec(&mel1, mg, mb);
+    lldo_plp_audspec(&plp, mb, aud);
+    ra[0] = vec_ll1(aud, 26);                                   /* audspec_lengthL1norm */
+    lldo_plp_audspec(&plpr, mb, rb);                            /* audSpec_Rfilt[26] */
+    ra[1] = vec_ll1(rb, 26);                                    /* audspecRasta_lengthL1norm */
+    ra[2] = lldo_energy_rms(src, g.N);                          /* [is13_energy] on is13_frame25 (raw) */
+    if (t < T60) ra[3] = lldo_zcr(src, N60);                    /* [is13_mzcr] on is13_frame60 (raw, 960 samples) */
+    lldo_spectral_compare(&spec, mg, rb + 26);
+    lldo_melspec(&mel2, mg, mb);
+    lldo_mfcc(&dct, mb, rb + 41);
+  }
+  if (raw59)
+    for (long t = 0; t < T60; t++) {
+      memcpy(raw59 + t * D, la + t * DA, sizeof(float) * DA);
+      memcpy(raw59 + t * D + DA, lb + t * DB, sizeof(float) * DB);
+    }
+  /* group A: SMA over levels of lengths (T20, T20, T20, T60), then delta of that level */
+  const long len[4] = {T20, T20, T20, T60};
+  float *sa = (float *)malloc(sizeof(float) * (size_t)rows * DA);
+  for (long t = 0; t < rows; t++)
+    for (int d = 0; d < DA; d++) {
+      long i0 = t, im = t - 1, ip = t + 1;
+      if (im < 0) im = 0;
+      if (i0 > len[d] - 1) i0 = len[d] - 1;
+      if (im > len[d] - 1) im = len[d] - 1;
+      if (ip > len[d] - 1) ip = len[d] - 1;
+      float y = la[i0 * DA + d];                                  /* contourSmoother.cpp:104-111 */
+      y += la[im * DA + d];
+      y += la[ip * DA + d];
+      y /= (float)3;
+      sa[t * DA + d] = y;
+    }
+  float *da = (float *)malloc(sizeof(float) * (size_t)(rows + 2) * DA);
+  { int kind = 0, Wv = 2; float *lv = da; lldo_window_chain(sa, rows, DA, 1, &kind, &Wv, &lv); }
+  /* group B: uniform lengths */
+  int kind[2] = {1, 0}, Wv[2] = {1, 2};
+  float *lvb[2];
+  lvb[0] = (float *)malloc(sizeof(float) * (size_t)(T20 + 1) * DB);
+  lvb[1] = (float *)malloc(sizeof(float) * (size_t)(T20 + 3) * DB);
+  lldo_window_chain(lb, T20, DB, 2, kind, Wv, lvb);
+  for (long t = 0; t < rows; t++) {
+    float *o = out + t * 2 * D;
+    memcpy(o, sa + t * DA, sizeof(float) * DA);
+    memcpy(o + DA, lvb[0] + t * DB, sizeof(float) * DB);
+    memcpy(o + D, da + t * DA, sizeof(float) * DA);
+    memcpy(o + D + DA, lvb[1] + t * DB, sizeof(float) * DB);
+  }
+  free(sa); free(da); free(lvb[0]); free(lvb[1]);
+  free(x); free(w); free(fr); free(sp); free(mg); free(la); free(lb);
+  lldo_mel_free(&mel1); lldo_mel_free(&mel2); lldo_mfcc_free(&dct);
+  lldo_plp_free(&plp); lldo_plp_free(&plpr); lldo_spectral_free(&spec);
+  return rows;
+}

@@ -234,3 +234,17 @@ def run_reference_lld(conf_rel, pcm, fs=16000):
         if not os.path.exists(out):
             return np.zeros((0, 0), np.float32)
         return read_htk(out)[0]
+
+
+def compare_ab_chain(pcm, raw=False):
+    """ComParE_2016 LLD groups A+B as the LLD sinks see them: rows x 118 [, rows-1 x 59 pre-SMA]."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_compare_ab_chain.restype = C.c_long
+    L.lldo_compare_ab_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    rows = L.lldo_compare_ab_chain(pcm.ctypes.data, len(pcm), None, None)
+    out = np.zeros((max(rows, 0), 118), np.float32)
+    r59 = np.zeros((max(rows - 1, 0), 59), np.float32)
+    if rows > 0:
+        L.lldo_compare_ab_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, r59.ctypes.data)
+    return (out, r59) if raw else out

@@ -44,3 +44,9 @@ def golden_config1():
 def golden_is09():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "is09_lld_synth.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_compare():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "compare16_ab_synth.npz"))

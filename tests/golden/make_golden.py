@@ -52,6 +52,18 @@ def main():
         print("is09", name, y.shape)
     np.savez_compressed(os.path.join(OUT, "is09_lld_synth.npz"), **ref)
 
+    # config 4 shape (ComParE_2016 LLD level), groups A+B = columns 6..64 and 71..129 of the 130-column file
+    ref = {}
+    for name, (u, n) in {"u2_16000": (2, 16000), "u3_16000": (3, 16000), "u10_16000": (10, 16000),
+                          "u1_16000": (1, 16000), "u0_16000": (0, 16000), "u7_1440": (7, 1440), "u7_1600": (7, 1600),
+                          "u4_48000": (4, 48000)}.items():
+        pcm = synth.utterance(u, n)
+        y = lldo.run_reference_lld("compare16/ComParE_2016.conf", pcm)
+        ref["pcm_" + name] = pcm
+        ref["out_" + name] = np.concatenate([y[:, 6:65], y[:, 71:130]], axis=1)
+        print("compare", name, y.shape)
+    np.savez_compressed(os.path.join(OUT, "compare16_ab_synth.npz"), **ref)
+
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
     wav = os.path.join(lldo.REF_DIR, "opensmile.wav")

@@ -1,0 +1,53 @@
+"""Pin the ComParE part of the CPU oracle (oracle/lld_oracle_compare.c: cSpectral with
+ComParE_2016's options, cPlp auditory spectrum incl. RASTA, cVectorOperation ll1,
+cEnergy / cMZcr on the 20 ms / 60 ms frames, MFCC 1-14, SMA + delta over levels of
+different lengths) against golden LLD-level outputs of the REAL reference binary
+(config/compare16/ComParE_2016.conf, -lldhtkoutput, columns of groups A and B)."""
+import numpy as np
+import pytest
+
+KEYS = ["u2_16000", "u3_16000", "u10_16000", "u1_16000", "u0_16000", "u7_1440", "u7_1600", "u4_48000"]
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_compare_ab_bit_exact_with_reference_fft(oracle, golden_compare, key):
+    ref = golden_compare["out_" + key]
+    if not oracle.use_reference_fft(True):
+        pytest.skip("oracle/_ref/libref_dsp.so not built")
+    try:
+        out = oracle.compare_ab_chain(golden_compare["pcm_" + key])
+    finally:
+        oracle.use_reference_fft(False)
+    assert out.shape == ref.shape          # T60+1 rows x 118
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"max abs {np.abs(out - ref).max()}"
+
+
+def compare_tolerances(out, ref, what=""):
+    """Per-descriptor gates for the built-in / HIP FFT (continuous quantities: 1e-5 of the
+    column's own scale over the utterance, mfcc per frame; roll-off points are bin
+    frequencies picked by a threshold test and may move by one bin on rare frames)."""
+    assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
+    assert np.isfinite(out).all()
+    o, r = out.astype(np.float64), ref.astype(np.float64)
+    d = np.abs(o - r)
+    D = 59
+    for half in (0, D):
+        cols = np.arange(D) + half
+        # delta columns are judged on the scale of the static column they derive from
+        scale = np.maximum(np.abs(r[:, np.arange(D)]).max(axis=0), 1e-12)
+        rel = d[:, cols] / scale[None, :]
+        ro = [32, 33, 34, 35]                              # roll-off columns (bin frequencies)
+        other = [c for c in range(D) if c not in ro and c < 45]
+        assert rel[:, other].max() <= 2e-5, f"{what}: col {other[int(rel[:, other].max(axis=0).argmax())]} rel {rel[:, other].max():.2e}"
+        # mfcc 1..14: per-frame scale
+        ms = np.maximum(np.abs(r[:, 45:59]).max(axis=1, keepdims=True), 1e-12)
+        assert (d[:, half + 45:half + 59] / ms).max() <= 1e-5, f"{what}: mfcc"
+        moved = (d[:, [c + half for c in ro]] > 1e-3).mean()
+        assert moved <= 0.02, f"{what}: roll-off moved on {moved * 100:.1f}% of cells"
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_compare_ab_own_fft_within_tolerance(oracle, golden_compare, key):
+    oracle.use_reference_fft(False)
+    out = oracle.compare_ab_chain(golden_compare["pcm_" + key])
+    compare_tolerances(out, golden_compare["out_" + key], key)
