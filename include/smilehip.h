@@ -105,7 +105,17 @@ typedef struct smilehip_lld_config {
    *     columns; T+smaWin/2 rows per utterance (the SMA's end-of-input frame is kept).
    *     Uses cEnergy rms (src/lldcore/energy.cpp:152-168) on the windowed frame, cMZcr zcr
    *     (src/lldcore/mzcr.cpp:109-126) on the raw frame, two cAcf instances
-   *     (src/dspcore/acf.cpp:249-349) and cPitchACF (src/lldcore/pitchACF.cpp:137-247). */
+   *     (src/dspcore/acf.cpp:249-349) and cPitchACF (src/lldcore/pitchACF.cpp:137-247).
+   *   SMILEHIP_CHAIN_COMPARE_AB: ComParE_2016's LLD groups A and B as its LLD sinks see them
+   *     (config/compare16/ComParE_2016_core.lld.conf.inc; columns 6..64 and 71..129 of the
+   *     130-column lld;lld_de file): 59 columns
+   *     [audspec_lengthL1norm | audspecRasta_lengthL1norm | pcm_RMSenergy | pcm_zcr (60 ms frame) |
+   *      audSpec_Rfilt[26] | cSpectral x 15 | mfcc 1..14] after cContourSmoother(3), then their 59
+   *     cDeltaRegression columns; T60+1 rows per utterance (T60 = frames of the 60 ms framer).
+   *     cPlp as auditory spectrum with and without newRASTA (src/lldcore/plp.cpp:416-593),
+   *     cSpectral with [is13_spectral]'s options (src/lldcore/spectral.cpp:586-1560),
+   *     cVectorOperation ll1 (src/other/vectorOperation.cpp:475-481). The F0 group (SHS pitch,
+   *     Viterbi, jitter) is out of scope. Utterances with T60 < 4 yield no rows. */
   int32_t  chain_kind;
   double   pitch_max;                   /* cPitchACF maxPitch */
   double   voicing_cutoff;              /* cPitchACF voicingCutoff */
@@ -117,6 +127,7 @@ typedef struct smilehip_lld_config {
 
 #define SMILEHIP_CHAIN_MFCC 0
 #define SMILEHIP_CHAIN_IS09 1
+#define SMILEHIP_CHAIN_COMPARE_AB 2
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -153,6 +164,9 @@ int  smilehip_device_name(smilehip_context *ctx, char *buf, int buflen);
 
 /* fills c with the LLD part of config/is09-13/IS09_emotion.conf (chain_kind = IS09) */
 void smilehip_config_is09_lld(smilehip_lld_config *c);
+
+/* fills c with groups A+B of config/compare16/ComParE_2016.conf (chain_kind = COMPARE_AB) */
+void smilehip_config_compare16_ab(smilehip_lld_config *c);
 
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */

@@ -62,6 +62,7 @@ SYMBOLS = {
     "smilehip_shutdown": (None, [_vp]),
     "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -124,6 +125,12 @@ def load():
 def _check(rc):
     if rc != 0:
         raise SmileHipError(f"smilehip error {rc}: {load().smilehip_last_error().decode()}")
+
+
+def compare16_ab_config():
+    c = LldConfig()
+    load().smilehip_config_compare16_ab(C.byref(c))
+    return c
 
 
 def is09_lld_config():

@@ -1,0 +1,351 @@
+// ComParE_2016 LLD groups A and B on the hot path (SURVEY.md 8a rows R8 cPlp as auditory
+// spectrum incl. RASTA, R11 cSpectral with ComParE's option set, R12 cEnergy / cMZcr on the
+// 20 ms / 60 ms frames), reference-order kernels (parity first, not tuned):
+//   lld_compare_frame   one workgroup per run of 8 consecutive 20 ms frames: window, FFT,
+//                       magnitude; mel (one bank, two scalings) -> audspec + its mean,
+//                       MFCC 1..14; the 15 spectral descriptors, each evaluated by one lane
+//                       in the reference's own loop order (four waves work on different
+//                       descriptors concurrently); RMS energy of the raw frame; ZCR of the
+//                       60 ms frame; the un-filtered mel spectrum goes to scratch for RASTA
+//   lld_compare_rasta   one wave per utterance: log -> RASTA IIR over frames (sequential by
+//                       nature) -> equal loudness + compression in the log domain -> exp,
+//                       and the mean over bands
+//   lld_compare_groupA  SMA + delta of group A, whose levels have different lengths
+// Group B's SMA + delta run through the generic window chain (lld_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include "lld_device.hpp"
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+
+namespace smilehip {
+
+namespace {
+constexpr int kRun = 8;          // frames per workgroup (the flux needs the previous frame's magnitudes)
+
+// band energy with a frequency axis, cSpectral::processVector spectral.cpp:779-853
+__device__ float band_energy(const float *srcP, double F0, int Nsrc, int lo, int hi, int nBins) {
+  int ii;
+  double wghtL, wghtR, idxL, idxR;
+  for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)lo) break;
+  if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)lo) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
+  idxL = (double)ii - 1.0;
+  if (idxL < 0) idxL = 0;
+  if (idxL >= Nsrc) idxL = Nsrc;
+  if (wghtL == 0.0) wghtL = 1.0;
+  for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)hi) break;
+  if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
+  if ((ii < Nsrc) && (F0 * ii == (float)hi)) idxR = (double)ii; else idxR = (double)ii - 1.0;
+  if (idxR >= Nsrc) idxR = Nsrc - 1;
+  if (wghtR == 0.0) wghtR = 1.0;
+  int iL = (int)floor(idxL), iR = (int)floor(idxR);
+  if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+  if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+  if (iL < 0) iL = 0;
+  if (iR < 0) iR = 0;
+  double sum = (double)srcP[iL] * wghtL;
+  for (int j = iL + 1; j < iR; j++) sum += (double)srcP[j];
+  sum += (double)srcP[iR] * wghtR;
+  return (float)(sum / (double)nBins);
+}
+
+// smileStat_entropy, smileUtil.c:2079-2124 (values are powers: min = 0 branch)
+__device__ float stat_entropy(const float *vals, int N) {
+  const double entropy_floor = 0.0000001;
+  double e = 0.0, dn = 0.0;
+  const double l2 = log(2.0);
+  for (int i = 0; i < N; i++) dn += (double)vals[i];
+  if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+  for (int i = 0; i < N; i++) {
+    double v = vals[i];
+    if (v <= entropy_floor) v = entropy_floor;
+    const double ln = v / dn;
+    if (ln > 0.0) e += ln * log(ln) / l2;
+  }
+  return (float)(-e);
+}
+}  // namespace
+
+// LDS: yv[N] | re[M] | im[M] | mg[K] | pw[K] | prev[K] | mel[32] | aud[32] | lmel[32]
+__global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, CompareParams Q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = P.Nfft >> 1, K = P.K;
+  const int Npad = (P.N + 3) & ~3, Kpad = (K + 3) & ~3;
+  float *yv = smem;
+  float *re = yv + Npad;
+  float *im = re + M;
+  float *mg = im + M;
+  float *pw = mg + Kpad;
+  float *prev = pw + Kpad;
+  float *melv = prev + Kpad;
+  float *aud = melv + 32;
+  float *lmel = aud + 32;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+
+  const int u = Q.run_utt[blockIdx.x];
+  const int t0 = Q.run_t0[blockIdx.x];
+  const int64_t f0 = P.frame_off[u];
+  const int T20 = (int)(P.frame_off[u + 1] - f0);
+  const int64_t s_utt = P.samp_off[u];
+  const int64_t utt_len = P.samp_off[u + 1] - s_utt;
+  const int T60 = (utt_len >= Q.N60) ? (int)((utt_len - Q.N60) / P.H + 1) : 0;
+  const int16_t *xu = P.pcm + s_utt;
+  const double F0 = 1.0 / Q.fsSec;                      // frq[i] = F0 * i (transformFft.cpp:102-117)
+  const int lo = 1, hi = K - 1, nBins = K - 1;          // freqRange 0-0 (spectral.cpp:625-627)
+  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+
+  // frames t0-1 (magnitudes only, for the flux) .. t_last-1
+  for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+    const bool warm = t < t0;
+    const int16_t *x = xu + (int64_t)t * P.H;
+    float *rawA = Q.rawA + (f0 + t) * 4;
+    float *rawB = Q.rawB + (f0 + t) * 55;
+    // R3 (no pre-emphasis in this chain) + R12 energy of the RAW frame ([is13_energy] reads is13_frame25)
+    for (int n = threadIdx.x; n < P.N; n += blockDim.x) yv[n] = pcm16_to_float(x[n]);
+    __syncthreads();
+    if (!warm && threadIdx.x == 64) {                   // cEnergy rms, energy.cpp:152-168 (sequential double sum)
+      double d = 0.0;
+      for (int i = 0; i < P.N; i++) { const float tmp = yv[i]; d += tmp * tmp; }
+      rawA[2] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
+    }
+    if (!warm && threadIdx.x == 128 && t < T60) {       // cMZcr zcr of the 60 ms frame, mzcr.cpp:117-124
+      float nzc = 0.0f;
+      float a = pcm16_to_float(x[0]), b = pcm16_to_float(x[1]);
+      for (int i = 1; i < Q.N60 - 1; i++) {
+        const float c = pcm16_to_float(x[i + 1]);
+        if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) nzc += 1.0f;
+        a = b; b = c;
+      }
+      rawA[3] = nzc / (float)Q.N60;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
+      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+    }
+    __syncthreads();
+    block_cfft_radix2(re, im, M, P.tw_half);
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+      const float m = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
+      mg[k] = m;
+      pw[k] = m * m;                                    // squareInput (spectral.cpp:676-683) == melspec usePower
+    }
+    __syncthreads();
+    if (warm) {
+      for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
+      __syncthreads();
+      continue;
+    }
+    // R6 once, two scalings: [is13_melspec1] (htk=0) feeds cPlp, [is13_melspecMfcc] (htk=1) feeds cMfcc
+    for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x) {
+      const float acc = mel_band_exact(pw, P.mel_coef, P.mel_rng, b, 1.0f);
+      melv[b] = acc;
+      // log mel spectrum for the RASTA pass (doLog, plp.cpp:434-439; double log = correctly rounded logf)
+      Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
+      // R8 cPlp without RASTA: melfloor, equal loudness, power-law compression (plp.cpp:499-507)
+      float v = acc < Q.plp_melfloor ? Q.plp_melfloor : acc;
+      v *= Q.eql[b];
+      aud[b] = (float)pow((double)v, (double)Q.compression);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
+      rawB[41 + r] = dct_coeff(lmel, P.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);   // R7
+    if (threadIdx.x == 192) {                           // cVectorOperation ll1, vectorOperation.cpp:475-481
+      float d = 0.0f;
+      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      rawA[0] = d / (float)P.n_bands;
+    }
+    // R11: one lane per group of descriptors, each in the reference's own loop order
+    float *sp = rawB + 26;
+    if (threadIdx.x == 0) {                             // frame energy, bands, roll-off (spectral.cpp:762-853, 1102-1122)
+      double frameSum = 0.0;
+      for (int i = lo; i <= hi; i++) frameSum += pw[i];
+      sp[0] = band_energy(pw, F0, K, 250, 650, nBins);
+      sp[1] = band_energy(pw, F0, K, 1000, 4000, nBins);
+      const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
+      float ro[4] = {0.f, 0.f, 0.f, 0.f};
+      double sumC = 0.0;
+      for (int j = lo; j <= hi; j++) {
+        sumC += (double)pw[j];
+        for (int i = 0; i < 4; i++)
+          if ((ro[i] == 0.0f) && (sumC >= rollOff[i] * frameSum)) ro[i] = (float)(F0 * j);
+      }
+      for (int i = 0; i < 4; i++) sp[2 + i] = ro[i];
+      // sharpness (:1429-1482)
+      float sumAA = 0.0f, c2 = 0.0f;
+      for (int j = lo; j <= hi; j++) sumAA += (float)(Q.sharp_w[j - lo] * (double)pw[j]);
+      if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
+      sp[13] = (float)(0.11 * c2);
+    } else if (threadIdx.x == 64) {                     // flux (:1124-1254): first frame of an utterance -> 0
+      if (t == 0) sp[6] = 0.0f;
+      else {
+        double myA = 0.0;
+        for (int j = lo; j <= hi; j++) { const double myB = ((double)mg[j] / 1.0 - (double)prev[j] / 1.0); myA += myB * myB; }
+        const double flux = myA / (double)nBins;
+        sp[6] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+      }
+    } else if (threadIdx.x == 128) {                    // centroid, moments, slope (:1256-1427)
+      double sumB = 0.0, sumA = 0.0;
+      for (int j = lo; j <= hi; j++) sumB += (double)pw[j];
+      for (int j = lo; j <= hi; j++) sumA += (F0 * j) * (double)pw[j];
+      float ctr = 0.0f;
+      if (sumB != 0.0) ctr = (float)(sumA / sumB);
+      sp[7] = ctr;
+      const double uu = ctr;
+      double m2 = 0.0, m3 = 0.0, m4 = 0.0;
+      for (int i = lo; i <= hi; i++) {
+        const double t1 = (F0 * i - uu);
+        double m = t1 * t1 * (double)pw[i];
+        m2 += m; m *= t1; m3 += m; m4 += m * t1;
+      }
+      const double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+      sp[9] = (float)sigma2;
+      sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
+      sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
+      double Sf = 0.0, S2f = 0.0;
+      const double Nind = (double)nBins;
+      for (int i = lo; i <= hi && i < K; i++) { S2f += (F0 * i) * (F0 * i); Sf += F0 * i; }
+      const double deno = (Nind * S2f - Sf * Sf);
+      double slope = 0.0;
+      if (deno != 0.0) slope = (Nind * sumA - Sf * sumB) / deno;
+      sp[12] = (float)(slope * (Nind - 1.0));            // oldSlopeScale = 1
+    } else if (threadIdx.x == 192) {                    // entropy (:1332-1336), harmonicity (:1484-1513)
+      sp[8] = stat_entropy(pw + lo, hi - lo + 1);
+      float ptpSum = 0.0f, lastPeak = -99.0f;
+      for (int j = lo + 2; j < hi - 1; j++) {
+        const float c = pw[j];
+        if ((pw[j - 2] < c && pw[j - 1] < c && c > pw[j + 1] && c > pw[j + 2]) ||
+            (pw[j - 2] > c && pw[j - 1] > c && c < pw[j + 1] && c < pw[j + 2])) {
+          if (lastPeak != -99.0f) ptpSum += fabsf(c - lastPeak);
+          lastPeak = c;
+        }
+      }
+      ptpSum /= 2.0f;
+      ptpSum /= (float)nBins;
+      sp[14] = ptpSum;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
+    __syncthreads();
+  }
+}
+
+// R8 with newRASTA (plp.cpp:434-439, 468-485, 490-497, 512-517): log -> 4-tap FIR + 1-pole IIR
+// per band over the frames of an utterance -> + log equal loudness, x compression -> exp.
+// One wave per utterance, lane = band. Writes audSpec_Rfilt[26] (group B) and its ll1 mean (group A).
+__global__ void __launch_bounds__(64) lld_compare_rasta(const int64_t *frame_off, int n_utt, CompareParams Q) {
+  const int u = blockIdx.x;
+  if (u >= n_utt) return;
+  const int b = threadIdx.x;
+  const int bb = b < 26 ? b : 25;
+  const int64_t f0 = frame_off[u];
+  const int T = (int)(frame_off[u + 1] - f0);
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  int init = 0;
+  constexpr int kDepth = 8;                 // frames loaded ahead of the recursion
+  __shared__ float row[kDepth][32];
+  const float eq = Q.eql_log[bb];
+  for (int tc = 0; tc < T; tc += kDepth) {
+    float xs[kDepth];
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i) {
+      const int t = (tc + i < T) ? tc + i : T - 1;
+      xs[i] = Q.mel1[(f0 + t) * 26 + bb];
+    }
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i) {
+      float x = xs[i];
+      const float out = Q.rasta_fir[0] * x + b0;
+      b0 = Q.rasta_fir[1] * x + b1 + (float)(init >= 5) * Q.rasta_iir * out;
+      b1 = Q.rasta_fir[2] * x + b2;
+      b2 = Q.rasta_fir[3] * x + b3;
+      b3 = Q.rasta_fir[4] * x;
+      x = (init >= 5) ? out : 0.0f;
+      if (init < 5) init++;
+      x += eq;
+      x *= Q.compression;
+      const float y = (float)exp((double)x);
+      if (b < 26) {
+        row[i][b] = y;
+        if (tc + i < T) Q.rawB[(f0 + tc + i) * 55 + b] = y;
+      }
+    }
+    __syncthreads();
+    if (b < kDepth && tc + b < T) {         // ll1 of each frame of the chunk, one lane per frame
+      float d = 0.0f;
+      for (int i = 0; i < 26; i++) d += row[b][i];
+      Q.rawA[(f0 + tc + b) * 4 + 1] = d / 26.0f;
+    }
+    __syncthreads();
+  }
+}
+
+// Group A: [is13_smoA] reads levels of lengths (T20, T20, T20, T60); a multi-level reader serves
+// a block only if every level can, and each level pads with its own last frame
+// (dataReader.cpp:446-522, dataMemoryLevel.cpp:1699-1708): T60+1 SMA frames; [is13_deA] is the
+// delta of that level. One thread per (output row, column).
+__device__ __forceinline__ float sma_a(const float *la, int t, int d, int len) {
+  int i0 = t, im = t - 1, ip = t + 1;
+  if (im < 0) im = 0;
+  if (i0 > len - 1) i0 = len - 1;
+  if (im > len - 1) im = len - 1;
+  if (ip > len - 1) ip = len - 1;
+  float y = la[i0 * 4 + d];
+  y += la[im * 4 + d];
+  y += la[ip * 4 + d];
+  return y / 3.0f;
+}
+__global__ void __launch_bounds__(256) lld_compare_groupA(const int64_t *frame_off, const int64_t *row_off, int n_utt,
+                                                         int64_t total_rows, CompareParams Q, float *out, int64_t ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid >> 2;
+  const int d = (int)(gid & 3);
+  if (row >= total_rows) return;
+  int lo = 0, hi = n_utt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (row_off[mid] <= row) lo = mid; else hi = mid;
+  }
+  const int rows = (int)(row_off[lo + 1] - row_off[lo]);
+  const int t = (int)(row - row_off[lo]);
+  const int T20 = (int)(frame_off[lo + 1] - frame_off[lo]);
+  const int T60 = rows - 1;
+  const int len = (d == 3) ? T60 : T20;
+  const float *la = Q.rawA + frame_off[lo] * 4;
+  out[row * ld + d] = sma_a(la, t, d, len);
+  // delta (deltaRegression.cpp:144-152) of the SMA level (rows frames, replicated at both ends)
+  float num = 0.0f;
+  for (int i = 1; i <= 2; ++i) {
+    int a = t - i, b = t + i;
+    a = a < 0 ? 0 : a;
+    b = b > rows - 1 ? rows - 1 : b;
+    num += (float)i * (sma_a(la, b, d, len) - sma_a(la, a, d, len));
+  }
+  out[row * ld + 59 + d] = num / 10.0f;
+}
+
+hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
+                          int64_t total_rows, float *d_out, int64_t ld_out, hipStream_t s) {
+  if (n_runs <= 0) return hipSuccess;
+  const int M = P.Nfft / 2;
+  const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96);
+  hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_compare_rasta, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (total_rows > 0)
+    hipLaunchKernelGGL(lld_compare_groupA, dim3((unsigned)((total_rows * 4 + 255) / 256)), dim3(256), 0, s, P.frame_off,
+                       d_row_off, P.n_utt, total_rows, Q, d_out, ld_out);
+  return hipGetLastError();
+}
+
+int compare_run_frames() { return kRun; }
+
+}  // namespace smilehip

@@ -137,12 +137,13 @@ __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
   const int64_t f0 = P.frame_off[u];
   const int T = (int)(P.frame_off[u + 1] - f0);
   if (T <= P.short_T) return;                 // handled by lld_chain_short
-  const int rows = T + P.row_extra;
-  const int D = P.D;
+  const int rows = (int)(P.row_off[u + 1] - P.row_off[u]);
+  const int c0 = blockIdx.y * kChainMaxD;     // column block
+  const int D = (P.D - c0 < kChainMaxD) ? P.D - c0 : kChainMaxD;
   const int W1 = P.W[0], W2 = (P.n_stages > 1) ? P.W[1] : 0;
   const int nF = (rows - t0 < kChainTile) ? rows - t0 : kChainTile;
   const int L1 = T + W1;                      // rows of level 1
-  const float *x = P.x + f0 * P.ld_x;
+  const float *x = P.x + f0 * P.ld_x + c0;
   // level 0 at positions [t0 - W1 - W2, t0 + nF + W1 + W2), clamped to [0, T-1]
   const int n0 = nF + 2 * (W1 + W2);
   for (int idx = threadIdx.x; idx < n0 * D; idx += blockDim.x) {
@@ -164,8 +165,8 @@ __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
   float *o = P.out + (P.row_off[u] + t0) * P.ld_out;
   for (int idx = threadIdx.x; idx < nF * D; idx += blockDim.x) {
     const int f = idx / D, d = idx - f * D;
-    o[(int64_t)f * P.ld_out + P.out_col[0] + d] = l1[(f + W2) * D + d];
-    if (P.n_stages > 1) o[(int64_t)f * P.ld_out + P.out_col[1] + d] = chain_op(l1, f + W2, D, d, P.kind[1], W2);
+    o[(int64_t)f * P.ld_out + P.out_col[0] + c0 + d] = l1[(f + W2) * D + d];
+    if (P.n_stages > 1) o[(int64_t)f * P.ld_out + P.out_col[1] + c0 + d] = chain_op(l1, f + W2, D, d, P.kind[1], W2);
   }
 }
 
@@ -232,9 +233,9 @@ __global__ void __launch_bounds__(64) lld_chain_short(ChainParams P) {
       }
     }
   }
-  const int rows = T + P.row_extra;
+  const int rows = (int)(P.row_off[u + 1] - P.row_off[u]);
   for (int o = 1; o <= P.n_stages; ++o)
-    for (int t = 0; t < rows; ++t) P.out[(P.row_off[u] + t) * P.ld_out + P.out_col[o - 1] + d] = lv[o][t];
+    for (int t = 0; t < rows && t < kShortCap; ++t) P.out[(P.row_off[u] + t) * P.ld_out + P.out_col[o - 1] + d] = lv[o][t];
 }
 
 // ---------------------------------------------------------------------------
@@ -251,11 +252,12 @@ int chain_tile_rows() { return kChainTile; }
 int chain_short_max() { return kShortMaxT; }
 
 hipError_t launch_chain(const ChainParams &P, hipStream_t s) {
-  if (P.D > kChainMaxD || P.n_stages < 1 || P.n_stages > 2) return hipErrorInvalidValue;
+  if (P.D < 1 || P.D > 4 * kChainMaxD || P.n_stages < 1 || P.n_stages > 2) return hipErrorInvalidValue;
   for (int i = 0; i < P.n_stages; ++i)
     if (P.W[i] < 1 || P.W[i] > kChainMaxW) return hipErrorInvalidValue;
   if (P.short_T > kShortMaxT) return hipErrorInvalidValue;
-  if (P.n_tiles > 0) hipLaunchKernelGGL(lld_chain_tiled, dim3((unsigned)P.n_tiles), dim3(256), 0, s, P);
+  if (P.n_tiles > 0)
+    hipLaunchKernelGGL(lld_chain_tiled, dim3((unsigned)P.n_tiles, (unsigned)((P.D + kChainMaxD - 1) / kChainMaxD)), dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (P.n_short > 0) {

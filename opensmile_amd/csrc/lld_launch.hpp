@@ -27,6 +27,9 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
 hipError_t launch_chain(const ChainParams &P, hipStream_t s);
+hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
+                          int64_t total_rows, float *d_out, int64_t ld_out, hipStream_t s);
+int compare_run_frames();
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
 int chain_tile_rows();
 int chain_short_max();

@@ -64,12 +64,28 @@ struct Is09Params {
   double voicingCutoff;
 };
 
+// Parameters of the ComParE A+B kernels (lld_compare.hip)
+struct CompareParams {
+  const int32_t *run_utt;    // [n_runs] runs of 8 consecutive 20 ms frames: utterance
+  const int32_t *run_t0;     // [n_runs] first frame
+  float *rawA;               // [total_frames20 x 4]  audspecSum, audspecRastaSum, rms, zcr (zcr valid for t < T60)
+  float *rawB;               // [total_frames20 x 55] audSpec_Rfilt[26], spectral[15], mfcc[14]
+  float *mel1;               // [total_frames20 x 26] un-filtered mel power spectrum (input of the RASTA pass)
+  const float *eql;          // [26] equal-loudness weights (linear), plp.cpp:335-357
+  const float *eql_log;      // [26] their logs (RASTA instance: doLog forced)
+  const double *sharp_w;     // [K-1] sharpness weights bark * g(bark) per bin 1..K-1
+  float plp_melfloor, compression, rasta_iir;
+  float rasta_fir[5];
+  double fsSec;              // frameSizeSec of the magnitude level
+  int32_t N60;               // samples of a 60 ms frame
+};
+
 // R13: chain of window processors (cDeltaRegression / cContourSmoother) over the
 // rows of each utterance. Level 0 = the input block x (T rows, D columns);
 // stage s (kind 0 = delta regression with deltawin W, 1 = simple moving average
 // with smaWin = 2W+1) maps level s to level s+1 which has W more rows.
-// The output keeps `rows = T + row_extra` rows per utterance (what the reference's
-// multi-level reader keeps: the shortest level that is written out).
+// The output keeps row_off[u+1]-row_off[u] rows per utterance (what the reference's
+// multi-level readers keep: the shortest level that is written out).
 struct ChainParams {
   const int64_t *frame_off;    // [n_utt+1] input rows (frames) per utterance
   const int64_t *row_off;      // [n_utt+1] output rows per utterance
@@ -86,7 +102,6 @@ struct ChainParams {
   int32_t kind[2];
   int32_t W[2];
   int32_t out_col[2];          // column offset of level s+1 in `out`
-  int32_t row_extra;           // rows = T + row_extra
   int32_t short_T;             // utterances with T <= short_T go to the tick-accurate path
   const int32_t *short_utts;
   int32_t n_short;

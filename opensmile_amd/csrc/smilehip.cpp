@@ -82,6 +82,9 @@ struct smilehip_plan {
   DevBuf<int32_t> d_band_slots;
   Fast512Host fast;
   bool use_fast = false;
+  DevBuf<float> d_eql, d_eql_log;
+  DevBuf<double> d_sharp;
+  float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
   // timing
   // HIP-event timing ring: slot i holds {before main, after main, after delta}
   static constexpr int kRing = 128;
@@ -105,6 +108,9 @@ struct smilehip_batch {
   int64_t total_rows = 0;
   DevBuf<int64_t> d_row_off;
   DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
+  DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
+  DevBuf<int32_t> d_run_utt, d_run_t0;
+  int32_t n_runs = 0;
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
@@ -213,6 +219,22 @@ extern "C" void smilehip_config_is09_lld(smilehip_lld_config *c) {
   c->sma_win = 3;
 }
 
+extern "C" void smilehip_config_compare16_ab(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);
+  c->chain_kind = SMILEHIP_CHAIN_COMPARE_AB;
+  c->frame_size_sec = 0.020;       // [is13_frame25]
+  c->preemph = 0;
+  c->win_func = SMILEHIP_WIN_HAMM; // [is13_win25]
+  c->zero_pad_symmetric = 1;       // [is13_fft25]
+  c->lofreq = 20.0f;               // [is13_melspec1], [is13_melspecMfcc]
+  c->use_power = 1;
+  c->first_mfcc = 1;               // [is13_mfcc]
+  c->last_mfcc = 14;
+  c->n_delta = 1;
+  c->delta_win = 2;
+  c->sma_win = 3;
+}
+
 // ------------------------------------------------------------------- plan
 static int build_tables(smilehip_plan *p, bool upload = true) {
   int rc;
@@ -239,6 +261,10 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 12 || p->cfg.n_delta != 1 || p->cfg.sma_win < 3 || !(p->cfg.sma_win & 1) ||
         p->cfg.sma_win > 9)
       return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
+        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph)
+      return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
     return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
   }
@@ -277,6 +303,43 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
   if ((rc = p->d_tw_half.upload(twh))) return rc;
   if ((rc = p->d_tw_full.upload(twf))) return rc;
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
+    // publishes as metadata (melspec.cpp:408-412), and the newRASTA filter coefficients
+    std::vector<float> eql(26), eqll(26);
+    for (int m = 1; m <= 26; ++m) {
+      const double hz = 700.0 * (std::exp(double(p->mel.centres[m]) / 1127.0) - 1.0);
+      const double w = 2.0 * M_PI * hz, w2 = w * w, c = w2 + 6300000.0;
+      const double e = (c > 0.0) ? (1e32 * ((w2 + 56.8e6) * w2 * w2) / (c * c * (w2 + 0.38e9) * (w2 * w2 * w2 * w + 1.7e31))) : 0.0;
+      eql[m - 1] = float(e);
+      eqll[m - 1] = std::log(eql[m - 1]);
+    }
+    const double Tl = p->geo.frame_period;
+    const float lower = 1.0f, upper = 29.0f;
+    p->rasta_iir = float(1.0 - std::sin(2.0 * M_PI * lower * Tl));
+    const float om = float(std::cos(2.0 * M_PI * upper * Tl));
+    const float norm = float(std::sqrt(10.0 * (32.0 * om * om + 8.0)));
+    p->rasta_fir[0] = float(2.0 / norm);
+    p->rasta_fir[1] = float(-4.0 * om / norm);
+    p->rasta_fir[2] = 0.0f;
+    p->rasta_fir[3] = -p->rasta_fir[1];
+    p->rasta_fir[4] = -p->rasta_fir[0];
+    // sharpness weights (spectral.cpp:1440-1455): bark(f) * g(bark(f)) for bins 1..K-1
+    std::vector<double> sw(size_t(p->geo.K - 1));
+    const double F0 = 1.0 / p->geo.fft_frame_size_sec;
+    for (int64_t j = 1; j < p->geo.K; ++j) {
+      const double x = F0 * double(j);
+      double zz = 0.0;
+      if (x > 0) {
+        zz = (26.81 / (1.0 + 1960.0 / x)) - 0.53;
+        if (zz < 2) zz = 0.85 * zz + 0.3;
+        else if (zz > 20.1) zz = 1.22 * zz - 0.22 * 20.1;
+      }
+      const double g = (zz <= 16.0) ? 1.0 : std::pow((zz - 16.0) / 4.0, 1.5849625) + 1.0;
+      sw[size_t(j - 1)] = zz * g;
+    }
+    if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll)) || (rc = p->d_sharp.upload(sw))) return rc;
+  }
   if (p->use_fast) {
     if ((rc = p->d_tw256.upload(p->fast.tw256))) return rc;
     if ((rc = p->d_tw512.upload(p->fast.tw512))) return rc;
@@ -331,7 +394,9 @@ extern "C" int smilehip_plan_create_host_only(const smilehip_lld_config *cfg, sm
 
 extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 
-static int plan_n_static(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : p->dct.n_mfcc; }
+static int plan_n_static(const smilehip_plan *p) {
+  return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc);
+}
 static int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }
 static int plan_row_extra(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? p->cfg.sma_win / 2 : 0; }
 
@@ -391,7 +456,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   b->h_row_off.assign(size_t(n_utt) + 1, 0);
   const int short_T = chain_short_max();
   const int row_extra = plan_row_extra(plan);
-  std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0;
+  std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0, run_utt, run_t0;
   const int64_t dtile = chain_tile_rows();
   const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
   for (int32_t u = 0; u < n_utt; ++u) {
@@ -401,7 +466,17 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_INVALID, "sample offsets must be non-decreasing (utterance %d)", u);
     }
     const int64_t T = smilehip_num_frames(plan, len);
-    const int64_t rows = T > 0 ? T + row_extra : 0;
+    int64_t rows = T > 0 ? T + row_extra : 0;
+    if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+      // rows = T60 + 1 where T60 = frames of the 60 ms framer ([is13_frame60]); none if T60 < 4
+      const int64_t N60 = std::lround(0.060 / plan->geo.period);
+      const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
+      rows = (T60 >= 4) ? T60 + 1 : 0;
+      for (int64_t t0 = 0; t0 < T; t0 += compare_run_frames()) {
+        run_utt.push_back(u);
+        run_t0.push_back((int32_t)t0);
+      }
+    }
     b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
     b->h_row_off[u + 1] = b->h_row_off[u] + rows;
     if (T > 0 && T <= short_T) b->h_short.push_back(u);
@@ -427,6 +502,22 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       (rc = b->d_short.upload(b->h_short))) {
     delete b;
     return rc;
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    b->n_runs = (int32_t)run_utt.size();
+    if ((rc = b->d_run_utt.upload(run_utt)) || (rc = b->d_run_t0.upload(run_t0))) {
+      delete b;
+      return rc;
+    }
+    const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_rawA.p), nf * 4 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_rawB.p), nf * 55 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_mel1.p), nf * 26 * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
+    }
+    b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
+    (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
   }
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
     std::vector<float> zero;   // allocate only
@@ -516,7 +607,6 @@ extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, floa
   Q.W[0] = Q.W[1] = W;
   Q.out_col[0] = D;
   Q.out_col[1] = 2 * D;
-  Q.row_extra = 0;
   Q.short_T = chain_short_max();
   Q.short_utts = b->d_short.p;
   Q.n_short = (int32_t)b->h_short.size();
@@ -612,7 +702,6 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
   Q.kind[1] = 0; Q.W[1] = plan->cfg.delta_win;            // cDeltaRegression
   Q.out_col[0] = 0;
   Q.out_col[1] = 16;
-  Q.row_extra = plan_row_extra(plan);
   Q.short_T = chain_short_max();
   Q.short_utts = b->d_short.p;
   Q.n_short = (int32_t)b->h_short.size();
@@ -621,10 +710,64 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
   return SMILEHIP_OK;
 }
 
+// ComParE groups A+B: frame kernel -> RASTA scan -> group A (multi-length SMA+delta) + group B chain
+static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  const int n_out = plan_n_out(plan);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
+  if (b->total_frames == 0 || b->total_rows == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  CompareParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.run_utt = b->d_run_utt.p;
+  Q.run_t0 = b->d_run_t0.p;
+  Q.rawA = b->d_rawA.p;
+  Q.rawB = b->d_rawB.p;
+  Q.mel1 = b->d_mel1.p;
+  Q.eql = plan->d_eql.p;
+  Q.eql_log = plan->d_eql_log.p;
+  Q.sharp_w = plan->d_sharp.p;
+  Q.plp_melfloor = 0.00000000093f;     // cPlp melfloor default (plp.cpp:66), htkcompatible = 0
+  Q.compression = 0.33f;
+  Q.rasta_iir = plan->rasta_iir;
+  for (int i = 0; i < 5; ++i) Q.rasta_fir[i] = plan->rasta_fir[i];
+  Q.fsSec = plan->geo.fft_frame_size_sec;
+  Q.N60 = (int32_t)std::lround(0.060 / plan->geo.period);
+  hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "ComParE kernel launch failed: %s", hipGetErrorString(e));
+  ChainParams C;
+  std::memset(&C, 0, sizeof(C));
+  C.frame_off = b->d_frame_off.p;
+  C.row_off = b->d_row_off.p;
+  C.tile_utt = b->d_dtile_utt.p;
+  C.tile_t0 = b->d_dtile_t0.p;
+  C.n_tiles = b->n_dtiles;
+  C.n_utt = b->n_utt;
+  C.x = b->d_rawB.p;
+  C.ld_x = 55;
+  C.out = d_out;
+  C.ld_out = ld_out;
+  C.D = 55;
+  C.n_stages = 2;
+  C.kind[0] = 1; C.W[0] = 1;
+  C.kind[1] = 0; C.W[1] = 2;
+  C.out_col[0] = 4;
+  C.out_col[1] = 59 + 4;
+  C.short_T = chain_short_max();
+  C.short_utts = b->d_short.p;
+  C.n_short = (int32_t)b->h_short.size();
+  e = launch_chain(C, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,
                                 void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: plan/batch mismatch");
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC) return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
 }
 
