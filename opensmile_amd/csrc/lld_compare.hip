@@ -23,50 +23,30 @@ namespace smilehip {
 namespace {
 constexpr int kRun = 8;          // frames per workgroup (the flux needs the previous frame's magnitudes)
 
-// band energy with a frequency axis, cSpectral::processVector spectral.cpp:779-853
-__device__ float band_energy(const float *srcP, double F0, int Nsrc, int lo, int hi, int nBins) {
-  int ii;
-  double wghtL, wghtR, idxL, idxR;
-  for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)lo) break;
-  if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)lo) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
-  idxL = (double)ii - 1.0;
-  if (idxL < 0) idxL = 0;
-  if (idxL >= Nsrc) idxL = Nsrc;
-  if (wghtL == 0.0) wghtL = 1.0;
-  for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)hi) break;
-  if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
-  if ((ii < Nsrc) && (F0 * ii == (float)hi)) idxR = (double)ii; else idxR = (double)ii - 1.0;
-  if (idxR >= Nsrc) idxR = Nsrc - 1;
-  if (wghtR == 0.0) wghtR = 1.0;
-  int iL = (int)floor(idxL), iR = (int)floor(idxR);
-  if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
-  if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
-  if (iL < 0) iL = 0;
-  if (iR < 0) iR = 0;
-  double sum = (double)srcP[iL] * wghtL;
-  for (int j = iL + 1; j < iR; j++) sum += (double)srcP[j];
-  sum += (double)srcP[iR] * wghtR;
-  return (float)(sum / (double)nBins);
-}
-
-// smileStat_entropy, smileUtil.c:2079-2124 (values are powers: min = 0 branch)
-__device__ float stat_entropy(const float *vals, int N) {
-  const double entropy_floor = 0.0000001;
-  double e = 0.0, dn = 0.0;
-  const double l2 = log(2.0);
-  for (int i = 0; i < N; i++) dn += (double)vals[i];
-  if (dn < (float)entropy_floor) dn = (float)entropy_floor;
-  for (int i = 0; i < N; i++) {
-    double v = vals[i];
-    if (v <= entropy_floor) v = entropy_floor;
-    const double ln = v / dn;
-    if (ln > 0.0) e += ln * log(ln) / l2;
+// sums of NV doubles over the 256 threads of the block (4 waves); every thread gets the totals.
+// red: 4*NV doubles of LDS. The order differs from the reference's sequential loops, the
+// accumulator type (double) does not.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
   }
-  return (float)(-e);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
+  __syncthreads();
 }
 }  // namespace
 
-// LDS: yv[N] | re[M] | im[M] | mg[K] | pw[K] | prev[K] | mel[32] | aud[32] | lmel[32]
+// LDS: yv[N] | re[M] | im[M] | mg[K] | pw[K] | prev[K] | mel[32] | aud[32] | lmel[32] | double red[64] | double cum[256] | peaks
+// Nfft = 512 only: thread i of the 256 owns bin i+1 in the descriptor section.
 __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, CompareParams Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = P.Nfft >> 1, K = P.K;
@@ -80,6 +60,10 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   float *melv = prev + Kpad;
   float *aud = melv + 32;
   float *lmel = aud + 32;
+  double *red = reinterpret_cast<double *>(lmel + 32);
+  double *cum = red + 64;
+  float *pk_val = reinterpret_cast<float *>(cum + 256);   // [4] last peak of each wave
+  int *pk_has = reinterpret_cast<int *>(pk_val + 4);      // [4]
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
@@ -103,22 +87,6 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
     float *rawB = Q.rawB + (f0 + t) * 55;
     // R3 (no pre-emphasis in this chain) + R12 energy of the RAW frame ([is13_energy] reads is13_frame25)
     for (int n = threadIdx.x; n < P.N; n += blockDim.x) yv[n] = pcm16_to_float(x[n]);
-    __syncthreads();
-    if (!warm && threadIdx.x == 64) {                   // cEnergy rms, energy.cpp:152-168 (sequential double sum)
-      double d = 0.0;
-      for (int i = 0; i < P.N; i++) { const float tmp = yv[i]; d += tmp * tmp; }
-      rawA[2] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
-    }
-    if (!warm && threadIdx.x == 128 && t < T60) {       // cMZcr zcr of the 60 ms frame, mzcr.cpp:117-124
-      float nzc = 0.0f;
-      float a = pcm16_to_float(x[0]), b = pcm16_to_float(x[1]);
-      for (int i = 1; i < Q.N60 - 1; i++) {
-        const float c = pcm16_to_float(x[i + 1]);
-        if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) nzc += 1.0f;
-        a = b; b = c;
-      }
-      rawA[3] = nzc / (float)Q.N60;
-    }
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
@@ -159,74 +127,124 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       for (int i = 0; i < P.n_bands; i++) d += aud[i];
       rawA[0] = d / (float)P.n_bands;
     }
-    // R11: one lane per group of descriptors, each in the reference's own loop order
+    // R11 + R12, block-parallel: thread i owns bin j = i+1 (freqRange 0-0 -> bins 1..K-1)
     float *sp = rawB + 26;
-    if (threadIdx.x == 0) {                             // frame energy, bands, roll-off (spectral.cpp:762-853, 1102-1122)
-      double frameSum = 0.0;
-      for (int i = lo; i <= hi; i++) frameSum += pw[i];
-      sp[0] = band_energy(pw, F0, K, 250, 650, nBins);
-      sp[1] = band_energy(pw, F0, K, 1000, 4000, nBins);
+    const int tid = threadIdx.x, j = tid + 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float pf = pw[j];
+    const double p = (double)pf, fj = F0 * j;
+    double v1[8];
+    v1[0] = p;                                          // frame energy (spectral.cpp:762-767), centroid denominator
+    v1[1] = fj * p;                                     // centroid numerator (:1256-1330)
+    v1[2] = Q.sharp_w[tid] * p;                         // sharpness (:1429-1482)
+    { const double myB = (double)mg[j] - (double)prev[j]; v1[3] = (t == 0) ? 0.0 : myB * myB; }   // flux (:1124-1254)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {                       // band energies (:779-853), edges resolved on the host
+      auto part = [&](int k) {
+        const double pk = (double)pw[k];
+        double c = 0.0;
+        if (k == Q.band_iL[b]) c += pk * Q.band_wL[b];
+        if (k > Q.band_iL[b] && k < Q.band_iR[b]) c += pk;
+        if (k == Q.band_iR[b]) c += pk * Q.band_wR[b];
+        return c;
+      };
+      v1[4 + b] = part(j) + (tid == 0 ? part(0) : 0.0);
+    }
+    { double d = 0.0;                                   // cEnergy rms of the raw frame, energy.cpp:152-168
+      for (int n = tid; n < P.N; n += 256) { const float tmp = yv[n]; d += tmp * tmp; }
+      v1[6] = d; }
+    { double nz = 0.0;                                  // cMZcr zcr of the 60 ms frame, mzcr.cpp:117-124
+      if (t < T60)
+        for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
+          const float a = pcm16_to_float(x[i - 1]), b = pcm16_to_float(x[i]), c = pcm16_to_float(x[i + 1]);
+          if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) nz += 1.0;
+        }
+      v1[7] = nz; }
+    block_sum<8>(v1, red);
+    const double frameSum = v1[0], sumA = v1[1];
+    float ctr = 0.0f;
+    if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
+    // roll-off (:1102-1122): inclusive prefix of the power in double, first bin whose prefix reaches the share
+    {
+      double c = p;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(c, off, 64); if (lane >= off) c += o; }
+      if (lane == 63) red[wave] = c;
+      __syncthreads();
+      for (int w = 0; w < wave; ++w) c += red[w];
+      cum[tid] = c;
+      __syncthreads();
+      const double before = tid ? cum[tid - 1] : -1.0;
       const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
-      float ro[4] = {0.f, 0.f, 0.f, 0.f};
-      double sumC = 0.0;
-      for (int j = lo; j <= hi; j++) {
-        sumC += (double)pw[j];
-        for (int i = 0; i < 4; i++)
-          if ((ro[i] == 0.0f) && (sumC >= rollOff[i] * frameSum)) ro[i] = (float)(F0 * j);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double th = rollOff[i] * frameSum;
+        if (c >= th && (tid == 0 || !(before >= th))) sp[2 + i] = (float)(F0 * j);
       }
-      for (int i = 0; i < 4; i++) sp[2 + i] = ro[i];
-      // sharpness (:1429-1482)
-      float sumAA = 0.0f, c2 = 0.0f;
-      for (int j = lo; j <= hi; j++) sumAA += (float)(Q.sharp_w[j - lo] * (double)pw[j]);
+    }
+    // harmonicity (:1484-1513): alternating peaks/valleys, distance to the previous one
+    float hc = 0.0f;
+    {
+      bool flag = false;
+      if (j >= lo + 2 && j < hi - 1)
+        flag = (pw[j - 2] < pf && pw[j - 1] < pf && pf > pw[j + 1] && pf > pw[j + 2]) ||
+               (pw[j - 2] > pf && pw[j - 1] > pf && pf < pw[j + 1] && pf < pw[j + 2]);
+      const unsigned long long mask = __ballot(flag);
+      const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+      const int src = lower ? 63 - __clzll(lower) : 0;
+      const float prevw = __shfl(pf, src, 64);
+      if (mask && lane == 63 - __clzll(mask)) pk_val[wave] = pf;
+      if (lane == 0) pk_has[wave] = mask != 0ull;
+      __syncthreads();
+      if (flag) {
+        if (lower) hc = fabsf(pf - prevw);
+        else
+          for (int w = wave - 1; w >= 0; --w)
+            if (pk_has[w]) { hc = fabsf(pf - pk_val[w]); break; }
+      }
+    }
+    double v2[5];
+    {                                                   // entropy (smileStat_entropy, smileUtil.c:2079-2124; powers: min = 0)
+      const double entropy_floor = 0.0000001;
+      double dn = frameSum;
+      if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+      double v = p;
+      if (v <= entropy_floor) v = entropy_floor;
+      const double ln = v / dn;
+      v2[0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
+      const double t1 = fj - (double)ctr;               // moments (:1338-1397)
+      double m = t1 * t1 * p;
+      v2[1] = m; m *= t1; v2[2] = m; v2[3] = m * t1;
+      v2[4] = (double)hc;
+    }
+    block_sum<5>(v2, red);
+    if (tid == 0) {
+      sp[0] = (float)(v1[4] / (double)nBins);
+      sp[1] = (float)(v1[5] / (double)nBins);
+      float c2 = 0.0f;
+      const float sumAA = (float)v1[2];
       if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
       sp[13] = (float)(0.11 * c2);
-    } else if (threadIdx.x == 64) {                     // flux (:1124-1254): first frame of an utterance -> 0
-      if (t == 0) sp[6] = 0.0f;
-      else {
-        double myA = 0.0;
-        for (int j = lo; j <= hi; j++) { const double myB = ((double)mg[j] / 1.0 - (double)prev[j] / 1.0); myA += myB * myB; }
-        const double flux = myA / (double)nBins;
-        sp[6] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
-      }
-    } else if (threadIdx.x == 128) {                    // centroid, moments, slope (:1256-1427)
-      double sumB = 0.0, sumA = 0.0;
-      for (int j = lo; j <= hi; j++) sumB += (double)pw[j];
-      for (int j = lo; j <= hi; j++) sumA += (F0 * j) * (double)pw[j];
-      float ctr = 0.0f;
-      if (sumB != 0.0) ctr = (float)(sumA / sumB);
+      const double flux = v1[3] / (double)nBins;
+      sp[6] = (t > 0 && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
       sp[7] = ctr;
-      const double uu = ctr;
-      double m2 = 0.0, m3 = 0.0, m4 = 0.0;
-      for (int i = lo; i <= hi; i++) {
-        const double t1 = (F0 * i - uu);
-        double m = t1 * t1 * (double)pw[i];
-        m2 += m; m *= t1; m3 += m; m4 += m * t1;
-      }
-      const double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+      sp[8] = (float)(-v2[0]);
+      const double sumB = frameSum;
+      const double sigma2 = (sumB != 0.0) ? v2[1] / sumB : 0.0;
       sp[9] = (float)sigma2;
-      sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
-      sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
-      double Sf = 0.0, S2f = 0.0;
+      sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(v2[2] / (sumB * sigma2 * sqrt(sigma2)));
+      sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(v2[3] / (sumB * sigma2 * sigma2));
       const double Nind = (double)nBins;
-      for (int i = lo; i <= hi && i < K; i++) { S2f += (F0 * i) * (F0 * i); Sf += F0 * i; }
-      const double deno = (Nind * S2f - Sf * Sf);
+      const double deno = (Nind * Q.slope_S2f - Q.slope_Sf * Q.slope_Sf);
       double slope = 0.0;
-      if (deno != 0.0) slope = (Nind * sumA - Sf * sumB) / deno;
+      if (deno != 0.0) slope = (Nind * sumA - Q.slope_Sf * sumB) / deno;
       sp[12] = (float)(slope * (Nind - 1.0));            // oldSlopeScale = 1
-    } else if (threadIdx.x == 192) {                    // entropy (:1332-1336), harmonicity (:1484-1513)
-      sp[8] = stat_entropy(pw + lo, hi - lo + 1);
-      float ptpSum = 0.0f, lastPeak = -99.0f;
-      for (int j = lo + 2; j < hi - 1; j++) {
-        const float c = pw[j];
-        if ((pw[j - 2] < c && pw[j - 1] < c && c > pw[j + 1] && c > pw[j + 2]) ||
-            (pw[j - 2] > c && pw[j - 1] > c && c < pw[j + 1] && c < pw[j + 2])) {
-          if (lastPeak != -99.0f) ptpSum += fabsf(c - lastPeak);
-          lastPeak = c;
-        }
-      }
+      float ptpSum = (float)v2[4];
       ptpSum /= 2.0f;
       ptpSum /= (float)nBins;
       sp[14] = ptpSum;
+      rawA[2] = (float)sqrt(v1[6] / (float)P.N) * 1.0f + 0.0f;
+      if (t < T60) rawA[3] = (float)v1[7] / (float)Q.N60;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
@@ -333,7 +351,8 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if (n_runs <= 0) return hipSuccess;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96);
+  if (P.Nfft != 512) return hipErrorInvalidValue;
+  const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96) + sizeof(double) * (64 + 256) + 32;
   hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

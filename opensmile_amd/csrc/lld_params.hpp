@@ -78,6 +78,10 @@ struct CompareParams {
   float rasta_fir[5];
   double fsSec;              // frameSizeSec of the magnitude level
   int32_t N60;               // samples of a 60 ms frame
+  // band-energy edges (spectral.cpp:779-853), resolved on the host: first/last bin and their weights
+  int32_t band_iL[2], band_iR[2];
+  double band_wL[2], band_wR[2];
+  double slope_Sf, slope_S2f;   // sums of f and f^2 over bins 1..K-1 (spectral.cpp:1399-1427)
 };
 
 // R13: chain of window processors (cDeltaRegression / cContourSmoother) over the

@@ -85,6 +85,8 @@ struct smilehip_plan {
   DevBuf<float> d_eql, d_eql_log;
   DevBuf<double> d_sharp;
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
+  int32_t band_iL[2] = {0, 0}, band_iR[2] = {0, 0};
+  double band_wL[2] = {0, 0}, band_wR[2] = {0, 0}, slope_Sf = 0, slope_S2f = 0;
   // timing
   // HIP-event timing ring: slot i holds {before main, after main, after delta}
   static constexpr int kRing = 128;
@@ -263,7 +265,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
-        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph)
+        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
       return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
     return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
@@ -338,6 +340,34 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       const double g = (zz <= 16.0) ? 1.0 : std::pow((zz - 16.0) / 4.0, 1.5849625) + 1.0;
       sw[size_t(j - 1)] = zz * g;
     }
+    // band edges of [is13_spectral] bands 250-650 and 1000-4000 (spectral.cpp:779-853)
+    const int band_lo[2] = {250, 1000}, band_hi[2] = {650, 4000};
+    const int Nsrc = (int)p->geo.K;
+    for (int b = 0; b < 2; ++b) {
+      int ii;
+      double wghtL, wghtR, idxL, idxR;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)band_lo[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)band_lo[b]) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
+      idxL = (double)ii - 1.0;
+      if (idxL < 0) idxL = 0;
+      if (idxL >= Nsrc) idxL = Nsrc;
+      if (wghtL == 0.0) wghtL = 1.0;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)band_hi[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)band_hi[b] - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
+      if ((ii < Nsrc) && (F0 * ii == (float)band_hi[b])) idxR = (double)ii; else idxR = (double)ii - 1.0;
+      if (idxR >= Nsrc) idxR = Nsrc - 1;
+      if (wghtR == 0.0) wghtR = 1.0;
+      int iL = (int)std::floor(idxL), iR = (int)std::floor(idxR);
+      if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+      if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+      if (iL < 0) iL = 0;
+      if (iR < 0) iR = 0;
+      p->band_iL[b] = iL; p->band_iR[b] = iR; p->band_wL[b] = wghtL; p->band_wR[b] = wghtR;
+    }
+    double Sf = 0.0, S2f = 0.0;
+    for (int64_t i = 1; i < p->geo.K; ++i) { S2f += (F0 * i) * (F0 * i); Sf += F0 * i; }
+    p->slope_Sf = Sf;
+    p->slope_S2f = S2f;
     if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll)) || (rc = p->d_sharp.upload(sw))) return rc;
   }
   if (p->use_fast) {
@@ -735,6 +765,12 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   for (int i = 0; i < 5; ++i) Q.rasta_fir[i] = plan->rasta_fir[i];
   Q.fsSec = plan->geo.fft_frame_size_sec;
   Q.N60 = (int32_t)std::lround(0.060 / plan->geo.period);
+  for (int i = 0; i < 2; ++i) {
+    Q.band_iL[i] = plan->band_iL[i]; Q.band_iR[i] = plan->band_iR[i];
+    Q.band_wL[i] = plan->band_wL[i]; Q.band_wR[i] = plan->band_wR[i];
+  }
+  Q.slope_Sf = plan->slope_Sf;
+  Q.slope_S2f = plan->slope_S2f;
   hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "ComParE kernel launch failed: %s", hipGetErrorString(e));
   ChainParams C;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Throughput of the IS09_emotion and ComParE_2016 (groups A+B) LLD chains on one GPU
+(configs 3/4 of BASELINE.json, per-GPU share). Not the driver's bench line (bench.py);
+prints one JSON object per chain: frames/s with PCM resident in HBM."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--sets", default="is09,compare")
+    args = ap.parse_args()
+    import torch
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    pcm, off = synth.corpus_tiled(args.utts, 160000, n_unique=32)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    for name in args.sets.split(","):
+        cfg = {"is09": capi.is09_lld_config, "compare": capi.compare16_ab_config, "mfcc": capi.mfcc12_0_d_a_config}[name]()
+        plan = capi.Plan(ctx, cfg)
+        b = capi.Batch(plan, off)
+        n_out = plan.geometry.n_out
+        rows = int(b.frame_offsets[-1])
+        d_out = torch.empty((max(rows, 1), n_out), dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        b.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            b.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, st)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"set": name, "utterances": args.utts, "frames": b.total_frames, "rows": rows, "cols": n_out,
+                          "ms_per_step": dt * 1e3, "frames_per_s": b.total_frames / dt}), flush=True)
+        b.close()
+        plan.close()
+
+
+if __name__ == "__main__":
+    main()
