@@ -134,34 +134,56 @@ struct PcmRegs {
 };
 
 // Loads for one pass: the staged span [sbase, sbase + 128*n_steps) of utterance samples.
-// Samples past the utterance end only ever feed frames that are not stored (every
-// stored frame lies inside its utterance), so instead of zero-filling them the
-// addresses are merely clamped to stay inside the PCM buffer: no per-element guards.
+// Everything but the lane's own byte offset is wave-uniform: `span` = pcm + sbase lives in
+// SGPRs and load r is `global_load_dword v, v_lane4, s[span] offset:256*r` -- one VGPR of
+// address for all eight loads, no 64-bit per-lane arithmetic, nothing to spill (a spill
+// reload would put an s_waitcnt vmcnt(0) behind the loads and wait out the whole memory
+// latency in every pass). `lane4` is made opaque per call so that the compiler cannot hoist
+// eight loop-invariant offsets into registers.
+// Samples past the utterance end only ever feed frames that are not stored (every stored
+// frame lies inside its utterance), so they need no zero fill; only the very last span of
+// the PCM buffer must not read past its end: that (wave-uniform, rare) case clamps offsets.
 // ALIGNED: the buffer is 4-byte aligned and every utterance starts at an even sample
 // (checked on the host) -> one dword load per sample pair; otherwise two 16-bit loads.
 template <bool ALIGNED>
 __device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t abs_base, int H,
                                              int n_steps, int lane, PcmRegs &R) {
-  const int64_t last_pair = (pcm_total >> 1) - 1;        // pcm_total >= 2 whenever a frame exists
+  const unsigned char *span = reinterpret_cast<const unsigned char *>(pcm + abs_base);
+  const int64_t room = pcm_total - abs_base;             // samples from the span start to the buffer end, >= 2
+  uint32_t lane4 = 4u * (uint32_t)lane;
+  asm volatile("" : "+v"(lane4));
+  if (room >= (int64_t)128 * n_steps) {                  // the whole span is inside the buffer
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    uint32_t v = 0;
-    if (r < n_steps) {
-      if (ALIGNED) {
-        int64_t pi = (abs_base >> 1) + lane + 64 * r;
-        pi = pi > last_pair ? last_pair : pi;
-        v = reinterpret_cast<const uint32_t *>(pcm)[pi];
-      } else {
-        int64_t s0 = abs_base + 2 * (lane + 64 * r);
-        s0 = s0 > pcm_total - 2 ? pcm_total - 2 : s0;
-        v = (uint32_t)(uint16_t)pcm[s0] | ((uint32_t)(uint16_t)pcm[s0 + 1] << 16);
+    for (int r = 0; r < 8; ++r) {
+      uint32_t v = 0;
+      if (r < n_steps) {
+        const unsigned char *q = (span + 256 * r) + lane4;
+        if (ALIGNED) v = *reinterpret_cast<const uint32_t *>(q);
+        else v = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
       }
+      R.pair[r] = v;
     }
-    R.pair[r] = v;
+    const uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;         // (lane & 3) * H samples, in bytes
+    R.first = (int32_t)*reinterpret_cast<const int16_t *>(span + fo);
+  } else {
+    const uint32_t limit = (uint32_t)((ALIGNED ? ((pcm_total >> 1) - 1 - (abs_base >> 1)) * 2 : room - 2) * 2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t v = 0;
+      if (r < n_steps) {
+        uint32_t off = lane4 + 256u * r;
+        off = off > limit ? limit : off;
+        const unsigned char *q = span + off;
+        if (ALIGNED) v = *reinterpret_cast<const uint32_t *>(q);
+        else v = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
+      }
+      R.pair[r] = v;
+    }
+    uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;
+    const uint32_t flim = (uint32_t)(room - 1) * 2u;
+    fo = fo > flim ? flim : fo;
+    R.first = (int32_t)*reinterpret_cast<const int16_t *>(span + fo);
   }
-  int64_t sf = abs_base + (int64_t)(lane & 3) * H;
-  sf = sf > pcm_total - 1 ? pcm_total - 1 : sf;
-  R.first = (int32_t)pcm[sf];
 }
 
 // value of lane-1 (wave-wide shift right by one lane, DPP wave_shr:1); lane 0 receives `fill`
@@ -215,7 +237,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
   __syncthreads();
 
-  const float dgain = (j < P.n_mfcc) ? P.dct_gain[j] : 0.0f;
+  const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;    // my cell relative to the pass's first output row
   const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
   const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
   const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
@@ -258,7 +280,11 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
           if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
         }
       }
-      if (PREEMPH && lane < 4) s_spec[lane] = P.one_minus_k * (float)R.first;
+      if (PREEMPH && lane < 4) {
+        uint32_t l4 = 4u * (uint32_t)lane;
+        asm volatile("" : "+v"(l4));               // recompute the address rather than keep (and spill) it
+        *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_spec) + l4) = P.one_minus_k * (float)R.first;
+      }
     }
     wave_lds_fence();
     // ------------------------------------------------------------ load frame (R3)
@@ -379,13 +405,19 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     if (j < P.n_mfcc) {
       const float4 *row_c = reinterpret_cast<const float4 *>(s_dct + j * 28);
       const float4 *lm = reinterpret_cast<const float4 *>(s_lmel);
-      float acc = 0.0f;
+      float acc = 0.0f, dgain = 0.0f;
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const float4 l = lm[q], c = row_c[q];
-        acc = fmaf(l.x, c.x, acc); acc = fmaf(l.y, c.y, acc); acc = fmaf(l.z, c.z, acc); acc = fmaf(l.w, c.w, acc);
+        acc = fmaf(l.x, c.x, acc); acc = fmaf(l.y, c.y, acc); acc = fmaf(l.z, c.z, acc);
+        if (q < 6) acc = fmaf(l.w, c.w, acc); else dgain = c.w;      // row[27] carries lifter * sqrt(2/nB)
       }
-      if (live) P.out[(row0 + t) * P.ld_out + j] = acc * dgain;
+      if (live) {
+        unsigned char *orow = reinterpret_cast<unsigned char *>(P.out + (row0 + tp) * P.ld_out);   // wave-uniform
+        uint32_t oo = out_off;
+        asm volatile("" : "+v"(oo));                 // keep the 32-bit offset, not a hoisted 64-bit pointer
+        *reinterpret_cast<float *>(orow + oo) = acc * dgain;
+      }
     }
     wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
   }
@@ -408,7 +440,7 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
                        const MelBank &mel, const DctTables &dct, Fast512Host &h) {
   const int pad_left = cfg.zero_pad_symmetric ? (int)((geo.Nfft - geo.N) / 2) : 0;
   const int H = (int)geo.H, N = (int)geo.N;
-  if (mel.n_bands > 28 || dct.n_mfcc > 16 || cfg.win_offset != 0.0 || (pad_left & 1) || (H & 1) || H < 2) return -1;
+  if (mel.n_bands > 27 || dct.n_mfcc > 16 || cfg.win_offset != 0.0 || (pad_left & 1) || (H & 1) || H < 2) return -1;
   h.mp = (pad_left + N) <= 13 * 32 ? 13 : 16;
   h.stage_floats = 3 * H + 32 * h.mp;
   if (h.stage_floats > 8 * 128) return -1;                     // PcmRegs holds 8 x 64 pairs
@@ -477,6 +509,7 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
   h.dct28.assign(16 * 28, 0.0f);
   for (int r = 0; r < dct.n_mfcc; ++r)
     for (int m = 0; m < mel.n_bands; ++m) h.dct28[size_t(r) * 28 + m] = dct.cos_rows[size_t(r) * mel.n_bands + m];
+  for (int r = 0; r < dct.n_mfcc; ++r) h.dct28[size_t(r) * 28 + 27] = dct.gain[r];     // read with the row's last b128
   return 0;
 }
 
