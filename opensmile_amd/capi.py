@@ -109,11 +109,12 @@ def load():
     library has not been built -- there is no fallback."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("SMILEHIP_LIB", LIB_PATH)     # developer override (instrumented builds)
+        if not os.path.exists(path):
             raise SmileHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C opensmile_amd/csrc). libsmilehip has no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res

@@ -17,9 +17,9 @@
 //           real 512-FFT is a complex 256-FFT of z plus an untangle pass
 //   FFT     256 = 16 x 16: radix-16 DFT over m in registers (two radix-4
 //           layers, constants only), twiddle by w256^(j*k1) (LDS table), ONE
-//           16x16 transpose through LDS (row stride 17: conflict free), done
-//           for re and im one after the other to halve the buffer, radix-16
-//           DFT over j
+//           16x16 transpose of (re,im) pairs through LDS (b64 stores and loads,
+//           conflict-free interleaved layout overlaying the dead stage area),
+//           radix-16 DFT over j
 //   spect.  lanes j and 16-j own mirror-image bins: each writes the half of its
 //           Z the partner needs, reads the partner's half and untangles BOTH
 //           X[k] and X[256-k] from one (Z[k], Z[256-k]) pair (R4), power (R5,
@@ -56,8 +56,10 @@ namespace {
 
 constexpr int kWavesPerBlock = 8;
 constexpr int kTileFrames = 32;       // frames per wave tile (8 passes)
-constexpr int kTBStride = 17;         // row stride (floats) of the transpose buffer
-constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame group
+constexpr int kTBStride = 17;
+constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame group (ZX, then PB)
+constexpr int kTB2Row = 65;           // float2 per 4-group row of the transpose buffer (520 B)
+constexpr int kTB2Floats = 2 * (15 * kTB2Row + 3 * 16 + 16);   // 2078 floats: footprint of the transpose buffer
 constexpr int kMaxUnitsPerLane = 8;
 constexpr int kMaxSlots = 96;
 constexpr int kMinStage = 576;        // PS + lmel (4 x 144 floats) alias the stage area
@@ -65,6 +67,12 @@ constexpr int kMinStage = 576;        // PS + lmel (4 x 144 floats) alias the st
 constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
 constexpr float S1 = 0.38268343236508978178f;   // sin(pi/8)
 constexpr float R2 = 0.70710678118654752440f;   // sqrt(1/2)
+
+// per-wave LDS region: stage | spec[4] | 4 group buffers, overlaid by the transpose buffer
+__host__ __device__ inline int wave_region_floats(int stage_alloc) {
+  const int a = stage_alloc + 4 + 4 * kGroupFloats, b = (kTB2Floats + 3) & ~3;
+  return a > b ? a : b;
+}
 
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in order; this only stops the compiler
@@ -145,39 +153,41 @@ struct PcmRegs {
 // the PCM buffer must not read past its end: that (wave-uniform, rare) case clamps offsets.
 // ALIGNED: the buffer is 4-byte aligned and every utterance starts at an even sample
 // (checked on the host) -> one dword load per sample pair; otherwise two 16-bit loads.
-template <bool ALIGNED>
-__device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t abs_base, int H,
-                                             int n_steps, int lane, PcmRegs &R) {
+// NSTEPS (7 or 8) x 128 samples cover the staged span; compile-time so that every load and
+// every use is unconditional (the waitcnt bookkeeping stays exact).
+template <int NSTEPS, bool ALIGNED>
+__device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t abs_base, int H, int lane,
+                                             PcmRegs &R) {
+#ifdef SMILEHIP_DEBUG_SAME_SPAN
+  abs_base &= 0xfffff;                                   // experiment: every span inside the first 2 MB (L2 resident)
+#endif
   const unsigned char *span = reinterpret_cast<const unsigned char *>(pcm + abs_base);
   const int64_t room = pcm_total - abs_base;             // samples from the span start to the buffer end, >= 2
   uint32_t lane4 = 4u * (uint32_t)lane;
   asm volatile("" : "+v"(lane4));
-  if (room >= (int64_t)128 * n_steps) {                  // the whole span is inside the buffer
+#ifdef SMILEHIP_DEBUG_NO_LOADS
+  for (int r = 0; r < NSTEPS; ++r) R.pair[r] = lane4 * (r + 3);      // experiment: no global loads at all
+  R.first = lane;
+  return;
+#endif
+  if (room >= (int64_t)128 * NSTEPS) {                   // the whole span is inside the buffer
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      uint32_t v = 0;
-      if (r < n_steps) {
-        const unsigned char *q = (span + 256 * r) + lane4;
-        if (ALIGNED) v = *reinterpret_cast<const uint32_t *>(q);
-        else v = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
-      }
-      R.pair[r] = v;
+    for (int r = 0; r < NSTEPS; ++r) {
+      const unsigned char *q = (span + 256 * r) + lane4;
+      if (ALIGNED) R.pair[r] = *reinterpret_cast<const uint32_t *>(q);
+      else R.pair[r] = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
     }
     const uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;         // (lane & 3) * H samples, in bytes
     R.first = (int32_t)*reinterpret_cast<const int16_t *>(span + fo);
   } else {
     const uint32_t limit = (uint32_t)((ALIGNED ? ((pcm_total >> 1) - 1 - (abs_base >> 1)) * 2 : room - 2) * 2);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      uint32_t v = 0;
-      if (r < n_steps) {
-        uint32_t off = lane4 + 256u * r;
-        off = off > limit ? limit : off;
-        const unsigned char *q = span + off;
-        if (ALIGNED) v = *reinterpret_cast<const uint32_t *>(q);
-        else v = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
-      }
-      R.pair[r] = v;
+    for (int r = 0; r < NSTEPS; ++r) {
+      uint32_t off = lane4 + 256u * r;
+      off = off > limit ? limit : off;
+      const unsigned char *q = span + off;
+      if (ALIGNED) R.pair[r] = *reinterpret_cast<const uint32_t *>(q);
+      else R.pair[r] = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
     }
     uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;
     const uint32_t flim = (uint32_t)(room - 1) * 2u;
@@ -192,11 +202,26 @@ __device__ __forceinline__ float lane_shr1(float v, float fill) {
 }
 
 
+// Developer instrumentation (tools/ubench/variant.sh builds a private copy of the library
+// with -DSMILEHIP_PHASE_TIMING): s_memtime at the phase boundaries of the pass loop, summed
+// over all waves. Not compiled into the product.
+#ifdef SMILEHIP_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define PHASE_DECL unsigned long long ph_acc[12] = {0}; unsigned long long ph_last = __builtin_amdgcn_s_memtime();
+#define PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
+#define PHASE_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); } while (0)
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#endif
+
 // LDS layout (dynamic), sizes in floats:
 //   shared tables : tw512 [256 f2] | win [MP*16 f2] | tw256 [256 f2, index k1*16+j] |
 //                   melw0 [U*16 f4] | melw1 [U*16 f4] | melo [U*16 u32] | dct [16 x 28] | slots [64 i32]
-//   per wave      : stage [S >= 512] (later PS+lmel: 4 x 128) | spec [4] | 4 x group buffer [272]
-template <int MP, bool PREEMPH, bool USE_POWER, bool ALIGNED>
+//   per wave      : stage [S >= 512] (later PS+lmel: 4 x 144) | spec [4] | 4 x group buffer [272];
+//                   the (re,im) transpose buffer [2078] overlays all of it between frame load and untangle
+template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -219,7 +244,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   float *s_dct = reinterpret_cast<float *>(s_melo + U * 16);
   int32_t *s_slots = reinterpret_cast<int32_t *>(s_dct + 16 * 28);
   const int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 9 + 16 * 28 + 64;
-  const int wave_floats = stage_alloc + 4 + 4 * kGroupFloats;
+  const int wave_floats = wave_region_floats(stage_alloc);
   float *wbase = smem + shared_floats + wave * wave_floats;
   float *s_stage = wbase;
   float *s_spec = wbase + stage_alloc;
@@ -243,30 +268,48 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
   const int pj = (16 - j) & 15;                                       // partner lane (bins 256-k)
   const int zrow = (j == 0) ? 16 : 0;
-  const int n_steps = (stage_floats + 127) >> 7;
 
-  // persistent waves: a wave walks tiles tile, tile + #waves, ... so that the table
-  // load above and the per-lane constants are paid once per wave, not once per tile
-  for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < P.n_tiles; tile += gridDim.x * kWavesPerBlock) {
-  const int u = P.tile_utt[tile];
-  const int t_first = P.tile_t0[tile];
-  const int64_t s_utt = P.samp_off[u];
-  const int64_t row0 = P.frame_off[u];
-  const int T = (int)(P.frame_off[u + 1] - row0);
-
-  const int t_end = (t_first + kTileFrames < T) ? t_first + kTileFrames : T;
+  PHASE_DECL
+  // Persistent waves walk tiles tile, tile + #waves, ... as ONE flat stream of passes: the
+  // next pass's PCM (same tile or the first pass of the next tile) is always in flight, tile
+  // records are fetched one tile ahead, and a pass's results are stored at the top of the
+  // following pass. The only s_waitcnt vmcnt in steady state is the one that consumes the
+  // prefetched PCM, and everything older than those loads (the deferred store) was issued a
+  // full pass earlier.
+  const int tile_stride = __builtin_amdgcn_readfirstlane((int)gridDim.x) * kWavesPerBlock;   // (a vector load otherwise)
+  int tile = blockIdx.x * kWavesPerBlock + wave;
+  if (tile >= P.n_tiles) return;                       // wave-uniform; no block barrier below
+  // records are read through the constant address space: read-only for the kernel's lifetime,
+  // so wave-uniform addresses become s_load and the values (and every address derived from
+  // them) stay in SGPRs
+  typedef const __attribute__((address_space(4))) TileRec *ConstRecPtr;
+  const ConstRecPtr recs = (ConstRecPtr)(uintptr_t)P.tile_rec;
+  int64_t cur_samp0 = recs[tile].samp0, cur_row0 = recs[tile].row0;
+  int cur_n = recs[tile].n_frames;
+  bool has_next = tile + tile_stride < P.n_tiles;
+  int64_t nxt_samp0 = cur_samp0, nxt_row0 = cur_row0;
+  int nxt_n = cur_n;
+  if (has_next) {
+    nxt_samp0 = recs[tile + tile_stride].samp0;
+    nxt_row0 = recs[tile + tile_stride].row0;
+    nxt_n = recs[tile + tile_stride].n_frames;
+  }
+  int tp = 0;                                          // first frame of the pass, relative to the tile
   PcmRegs R;
-  pcm_prefetch<ALIGNED>(P.pcm, P.pcm_total, s_utt + (int64_t)t_first * P.H, P.H, n_steps, lane, R);
+  pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, cur_samp0, P.H, lane, R);
+  unsigned char *pend_row = nullptr;                   // deferred store of the previous pass (wave-uniform row base)
+  float pend_val = 0.0f;
+  bool pend_live = false;
 
-  for (int tp = t_first; tp < t_end; tp += 4) {
-    const int t = tp + g;                       // my frame
-    const bool live = t < t_end;
+  for (;;) {
+    const bool live = tp + g < cur_n;
+    PHASE(0);                                   // loop overhead
     // ------------------------------------------------------------ stage PCM (R0 scale folded, R2)
     {
       float carry = 0.0f;                       // odd sample of lane 63 of the previous step
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (r < n_steps) {
+      for (int r = 0; r < NSTEPS; ++r) {
+        {
           const float a = (float)(int16_t)(R.pair[r] & 0xffffu);
           const float b = (float)(int16_t)(R.pair[r] >> 16);
           float ya = a, yb = b;
@@ -286,7 +329,17 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_spec) + l4) = P.one_minus_k * (float)R.first;
       }
     }
+    {
+      int32_t f_ = R.first;
+      asm volatile("" : : "v"(f_));             // every prefetched register is consumed here, unconditionally
+    }
+    if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
+      uint32_t oo = out_off;
+      asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
+      *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+    }
     wave_lds_fence();
+    PHASE(1);                                   // wait for the prefetch + stage
     // ------------------------------------------------------------ load frame (R3)
     float re[16], im[16];
 #pragma unroll
@@ -304,6 +357,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       }
     }
     wave_lds_fence();   // stage area is dead from here (PS/lmel alias it)
+    PHASE(2);                                   // frame load x window
 
     // ------------------------------------------------------------ 256-point complex FFT
     dft16(re, im);                                           // over m  -> index k1
@@ -312,20 +366,28 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       const float2 w = s_tw256[k1 * 16 + j];
       cmul(re[k1], im[k1], w.x, w.y);
     }
-    // 16x16 transpose, re then im through the same 272-float buffer
+    PHASE(3);                                   // dft16 + twiddles
+    // 16x16 transpose of (re, im) pairs: 16 ds_write_b64 + 16 ds_read_b64 through a buffer that
+    // overlays the whole per-wave region (stage, spec and the group buffers are all dead here).
+    // Element (row r, column c) of group g sits at byte g*128 + r*520 + c*8: the four groups'
+    // rows are interleaved and each 4-group row is padded by 8 bytes, which makes both the
+    // row-wise b64 stores (16-lane groups) and the column-wise b64 loads (32-lane groups)
+    // bank-conflict free with immediate offsets only (tools/lds_bank_sim.py).
+    {
+      float2 *tbw = reinterpret_cast<float2 *>(wbase) + g * 16 + j;
+      const float2 *tbr = reinterpret_cast<const float2 *>(wbase) + g * 16 + j * kTB2Row;
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) s_gb[k1 * kTBStride + j] = re[k1];
-    wave_lds_fence();
+      for (int k1 = 0; k1 < 16; ++k1) tbw[k1 * kTB2Row] = make_float2(re[k1], im[k1]);
+      wave_lds_fence();
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) re[jj] = s_gb[j * kTBStride + jj];
-    wave_lds_fence();
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) s_gb[k1 * kTBStride + j] = im[k1];
-    wave_lds_fence();
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) im[jj] = s_gb[j * kTBStride + jj];
-    wave_lds_fence();
+      for (int jj = 0; jj < 16; ++jj) { const float2 v = tbr[jj]; re[jj] = v.x; im[jj] = v.y; }
+      wave_lds_fence();
+    }
+    PHASE(4);                                   // transposes
+#ifndef SMILEHIP_DEBUG_SKIP_DFT2
     dft16(re, im);                                           // over j -> k2 ; Z[j + 16 k2]
+#endif
+    PHASE(5);                                   // second dft16
 
     // ------------------------------------------------------------ untangle pairs + power
     // lane j writes Z[j+16 k2], k2 = 8..15 (what lane 16-j needs); reads the partner's
@@ -371,12 +433,22 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     wave_lds_fence();
 
+    PHASE(6);                                   // untangle + power
     // next pass's PCM: issued here, where register pressure is low; the loads fly
     // during mel/DCT of this pass and the other resident waves' arithmetic
-    if (tp + 4 < t_end) pcm_prefetch<ALIGNED>(P.pcm, P.pcm_total, s_utt + (int64_t)(tp + 4) * P.H, P.H, n_steps, lane, R);
+    int ntp = tp + 4;
+    const bool advance = ntp >= cur_n;
+    const bool more = !advance || has_next;
+    if (advance) ntp = 0;
+    if (more) pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, (advance ? nxt_samp0 : cur_samp0) + (int64_t)ntp * P.H, P.H, lane, R);
 
+    PHASE(7);                                   // prefetch issue
     // ------------------------------------------------------------ mel (R6)
+#ifdef SMILEHIP_DEBUG_SKIP_MEL
+    for (int i = 0; i < 1; ++i) {
+#else
     for (int i = 0; i < U; ++i) {
+#endif
       const uint32_t o = s_melo[i * 16 + j];
       const float4 *pp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(s_pb) + (o & 0xffffu));
       const float4 p0 = pp[0], p1 = pp[1];
@@ -387,6 +459,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       s_ps[o >> 16] = acc;        // slot of the unit (dummy slot for padding units)
     }
     wave_lds_fence();
+    PHASE(8);                                   // mel units
     // band sums: lane j handles bands j and j+16 (pads up to 32 with zeros for the b128 DCT reads)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -401,6 +474,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     wave_lds_fence();
 
+    PHASE(9);                                   // band sums + log
     // ------------------------------------------------------------ DCT + lifter (R7)
     if (j < P.n_mfcc) {
       const float4 *row_c = reinterpret_cast<const float4 *>(s_dct + j * 28);
@@ -412,17 +486,43 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         acc = fmaf(l.x, c.x, acc); acc = fmaf(l.y, c.y, acc); acc = fmaf(l.z, c.z, acc);
         if (q < 6) acc = fmaf(l.w, c.w, acc); else dgain = c.w;      // row[27] carries lifter * sqrt(2/nB)
       }
-      if (live) {
-        unsigned char *orow = reinterpret_cast<unsigned char *>(P.out + (row0 + tp) * P.ld_out);   // wave-uniform
-        uint32_t oo = out_off;
-        asm volatile("" : "+v"(oo));                 // keep the 32-bit offset, not a hoisted 64-bit pointer
-        *reinterpret_cast<float *>(orow + oo) = acc * dgain;
+      pend_val = acc * dgain;
+    }
+    pend_live = live && j < P.n_mfcc;
+    pend_row = reinterpret_cast<unsigned char *>(P.out + (cur_row0 + tp) * P.ld_out);   // wave-uniform
+    wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
+    PHASE(10);                                  // DCT
+    if (!more) break;
+    if (advance) {
+      tile += tile_stride;
+      cur_samp0 = nxt_samp0; cur_row0 = nxt_row0; cur_n = nxt_n;
+      has_next = tile + tile_stride < P.n_tiles;
+      if (has_next) {
+        nxt_samp0 = recs[tile + tile_stride].samp0;
+        nxt_row0 = recs[tile + tile_stride].row0;
+        nxt_n = recs[tile + tile_stride].n_frames;
       }
     }
-    wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
+    tp = ntp;
   }
-  }  // tile loop
+  if (pend_live) {
+    uint32_t oo = out_off;
+    asm volatile("" : "+v"(oo));
+    *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+  }
+  PHASE_FLUSH;
 }
+
+#ifdef SMILEHIP_PHASE_TIMING
+extern "C" int smilehip_debug_phase(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // host side
@@ -515,27 +615,28 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
   const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64;
-  const int wave_floats = h.stage_alloc + 4 + 4 * kGroupFloats;
+  const int wave_floats = wave_region_floats(h.stage_alloc);
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
   unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (grid > (unsigned)h.max_blocks) grid = (unsigned)h.max_blocks;   // persistent: 2 blocks of 8 waves per CU
-  const bool mp13 = h.mp == 13;
-#define SMILEHIP_PICK(MPV, PE, UP, AL)                                                                    \
-  if (mp13 == (MPV == 13) && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL) {        \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP, AL>);                        \
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-    if (e != hipSuccess) return e;                                                                         \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP, AL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+#ifdef SMILEHIP_DEBUG_KNOBS
+  if (const char *e = getenv("SMILEHIP_DEBUG_GRID")) grid = (unsigned)atoi(e);
+#endif
+  const int nsteps = std::max(7, (h.stage_floats + 127) / 128);   // 7 or 8 (fast512_build_host caps the span at 1024)
+#define SMILEHIP_PICK(MPV, NS, PE, UP, AL)                                                                     \
+  if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL) {     \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL>);                         \
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+    if (e != hipSuccess) return e;                                                                              \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
   }
-#define SMILEHIP_PICK2(MPV, PE, UP) SMILEHIP_PICK(MPV, PE, UP, true) SMILEHIP_PICK(MPV, PE, UP, false)
-  SMILEHIP_PICK2(13, true, true)
-  SMILEHIP_PICK2(13, true, false)
-  SMILEHIP_PICK2(13, false, true)
-  SMILEHIP_PICK2(13, false, false)
-  SMILEHIP_PICK2(16, true, true)
-  SMILEHIP_PICK2(16, true, false)
-  SMILEHIP_PICK2(16, false, true)
-  SMILEHIP_PICK2(16, false, false)
+#define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true) SMILEHIP_PICK(MPV, NS, PE, UP, false)
+#define SMILEHIP_PICK4(MPV, NS) SMILEHIP_PICK2(MPV, NS, true, true) SMILEHIP_PICK2(MPV, NS, true, false) \
+                                SMILEHIP_PICK2(MPV, NS, false, true) SMILEHIP_PICK2(MPV, NS, false, false)
+  SMILEHIP_PICK4(13, 7)
+  SMILEHIP_PICK4(13, 8)
+  SMILEHIP_PICK4(16, 8)
+#undef SMILEHIP_PICK4
 #undef SMILEHIP_PICK2
 #undef SMILEHIP_PICK
   return hipGetLastError();

@@ -7,6 +7,15 @@
 
 namespace smilehip {
 
+// One tile of the fast kernel: up to fast512_tile_frames() consecutive frames of one utterance,
+// everything a wave needs in one 24-byte scalar load (no dependent loads through the utterance tables).
+struct TileRec {
+  int64_t samp0;      // absolute index (in the packed PCM) of the first frame's first sample
+  int64_t row0;       // output row of the first frame
+  int32_t n_frames;   // frames of the tile
+  int32_t pad;
+};
+
 struct LldParams {
   // batch
   const int16_t *pcm;          // packed utterances
@@ -15,6 +24,7 @@ struct LldParams {
   const int64_t *frame_off;    // [n_utt+1] output row offsets (device)
   const int32_t *tile_utt;     // [n_tiles] utterance of tile
   const int32_t *tile_t0;      // [n_tiles] first frame of tile (within utterance)
+  const TileRec *tile_rec;     // [n_tiles] the same tiles, resolved (fast kernel)
   int32_t n_utt;
   int32_t n_tiles;
   int64_t total_frames;

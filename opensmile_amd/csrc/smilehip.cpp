@@ -116,6 +116,7 @@ struct smilehip_batch {
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
+  DevBuf<TileRec> d_tile_rec;
   int32_t n_tiles = 0, n_dtiles = 0;
   bool all_even = true;      // every utterance with frames starts at an even sample offset
 };
@@ -487,6 +488,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   const int short_T = chain_short_max();
   const int row_extra = plan_row_extra(plan);
   std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0, run_utt, run_t0;
+  std::vector<TileRec> tile_rec;
   const int64_t dtile = chain_tile_rows();
   const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
   for (int32_t u = 0; u < n_utt; ++u) {
@@ -514,6 +516,12 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     for (int64_t t0 = 0; t0 < T; t0 += tile_frames) {
       tile_utt.push_back(u);
       tile_t0.push_back((int32_t)t0);
+      TileRec r;
+      r.samp0 = h_off[u] + t0 * plan->geo.H;
+      r.row0 = b->h_frame_off[u] + t0;
+      r.n_frames = (int32_t)std::min<int64_t>(tile_frames, T - t0);
+      r.pad = 0;
+      tile_rec.push_back(r);
     }
     for (int64_t t0 = 0; t0 < rows; t0 += dtile) {
       dtile_utt.push_back(u);
@@ -527,7 +535,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   int rc;
   if ((rc = b->d_samp_off.upload(b->h_samp_off)) || (rc = b->d_frame_off.upload(b->h_frame_off)) ||
       (rc = b->d_row_off.upload(b->h_row_off)) ||
-      (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) ||
+      (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) || (rc = b->d_tile_rec.upload(tile_rec)) ||
       (rc = b->d_dtile_utt.upload(dtile_utt)) || (rc = b->d_dtile_t0.upload(dtile_t0)) ||
       (rc = b->d_short.upload(b->h_short))) {
     delete b;
@@ -581,6 +589,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.frame_off = b->d_frame_off.p;
   P.tile_utt = b->d_tile_utt.p;
   P.tile_t0 = b->d_tile_t0.p;
+  P.tile_rec = b->d_tile_rec.p;
   P.n_utt = b->n_utt;
   P.n_tiles = b->n_tiles;
   P.total_frames = b->total_frames;
