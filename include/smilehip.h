@@ -168,6 +168,47 @@ void smilehip_config_is09_lld(smilehip_lld_config *c);
 /* fills c with groups A+B of config/compare16/ComParE_2016.conf (chain_kind = COMPARE_AB) */
 void smilehip_config_compare16_ab(smilehip_lld_config *c);
 
+/* ---- functionals over the LLD level ---------------------------------
+ * cFunctionals in frameMode=full (src/functionals/functionals.cpp:284-330, one output vector
+ * per utterance) with cFunctionalExtremes (functionalExtremes.cpp:92-134, norm=frame),
+ * the linear part of cFunctionalRegression (functionalRegression.cpp:140-425, normInputs =
+ * normRegCoeff = doRatioLimit = 0) and cFunctionalMoments (functionalMoments.cpp:88-165).
+ * Bit i of the mask enables value i; values keep the reference's order (functionalsEnabled =
+ * Extremes;Regression;Moments), the output vector is element-major: column c's values sit at
+ * [c*count, (c+1)*count) like the reference's func level (functionals.cpp:233-262). */
+#define SMILEHIP_FUNC_MAX          (1u << 0)
+#define SMILEHIP_FUNC_MIN          (1u << 1)
+#define SMILEHIP_FUNC_RANGE        (1u << 2)
+#define SMILEHIP_FUNC_MAXPOS       (1u << 3)
+#define SMILEHIP_FUNC_MINPOS       (1u << 4)
+#define SMILEHIP_FUNC_AMEAN        (1u << 5)
+#define SMILEHIP_FUNC_MAXAMEANDIST (1u << 6)
+#define SMILEHIP_FUNC_MINAMEANDIST (1u << 7)
+#define SMILEHIP_FUNC_LINREGC1     (1u << 8)
+#define SMILEHIP_FUNC_LINREGC2     (1u << 9)
+#define SMILEHIP_FUNC_LINREGERRA   (1u << 10)
+#define SMILEHIP_FUNC_LINREGERRQ   (1u << 11)
+#define SMILEHIP_FUNC_VARIANCE     (1u << 12)
+#define SMILEHIP_FUNC_STDDEV       (1u << 13)
+#define SMILEHIP_FUNC_SKEWNESS     (1u << 14)
+#define SMILEHIP_FUNC_KURTOSIS     (1u << 15)
+#define SMILEHIP_FUNC_AMEAN_M      (1u << 16)
+#define SMILEHIP_FUNC_ALL          0x1ffffu
+/* the 12 functionals of config/is09-13/IS09_emotion_core.func.conf.inc */
+uint32_t smilehip_functionals_is09_mask(void);
+/* values per LLD column for a mask; < 0 on unknown bits */
+int smilehip_functionals_count(uint32_t mask);
+/* Number of LLD rows each utterance's functionals summarise, rows[n_utt] (host). In full mode
+ * cFunctionals consumes what its input levels hold at its first end-of-input tick
+ * (src/core/winToVecProcessor.cpp:504-528, 868-1098): for the IS09 chain (SMA(3) -> delta(2))
+ * that is max(1, T-2) of the T+1 rows the LLD sinks get; 0 for utterances without a frame. */
+int smilehip_batch_func_rows(const smilehip_batch *batch, int64_t *rows);
+/* d_lld: the matrix smilehip_lld_run produced for this batch (IS09 chain plans only);
+ * d_func: n_utt x ld_func, n_out * count(mask) values per utterance (zeros for utterances
+ * without a frame, where the reference writes no instance). Asynchronous on `stream`. */
+int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *batch, const float *d_lld, int64_t ld_lld,
+                               uint32_t mask, float *d_func, int64_t ld_func, void *stream);
+
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */
 int  smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr);

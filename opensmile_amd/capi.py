@@ -64,6 +64,10 @@ SYMBOLS = {
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
+    "smilehip_functionals_is09_mask": (C.c_uint32, []),
+    "smilehip_functionals_count": (C.c_int, [C.c_uint32]),
+    "smilehip_batch_func_rows": (C.c_int, [_vp, _vp]),
+    "smilehip_batch_functionals": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint32, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
@@ -257,6 +261,42 @@ class Batch:
         out = np.zeros((self.total_rows, self.plan.geometry.n_out), np.float32)
         _check(load().smilehip_lld_run_host(self.plan._h, self._h, pcm.ctypes.data, len(pcm),
                                             out.ctypes.data))
+        return out
+
+    def func_rows(self):
+        """LLD rows each utterance's functionals summarise (IS09 chain plans)."""
+        r = np.zeros(self.n_utt, np.int64)
+        _check(load().smilehip_batch_func_rows(self._h, r.ctypes.data))
+        return r
+
+    def functionals_device(self, d_lld_ptr, ld_lld, d_func_ptr, ld_func, mask=None, stream=None):
+        L = load()
+        mask = L.smilehip_functionals_is09_mask() if mask is None else mask
+        _check(L.smilehip_batch_functionals(self.plan._h, self._h, d_lld_ptr, ld_lld, mask, d_func_ptr, ld_func, stream))
+
+    def functionals_host(self, lld, mask=None):
+        """lld: the matrix run_host returned -> n_utt x (n_out * count(mask))."""
+        L = load()
+        mask = L.smilehip_functionals_is09_mask() if mask is None else mask
+        per = L.smilehip_functionals_count(mask)
+        n_out = self.plan.geometry.n_out
+        lld = np.ascontiguousarray(lld, dtype=np.float32)
+        assert lld.shape == (self.total_rows, n_out)
+        out = np.zeros((self.n_utt, n_out * per), np.float32)
+        ctx = self.plan.ctx._h
+        d_lld, d_out = _vp(), _vp()
+        _check(L.smilehip_alloc(ctx, max(lld.nbytes, 4), C.byref(d_lld)))
+        _check(L.smilehip_alloc(ctx, max(out.nbytes, 4), C.byref(d_out)))
+        try:
+            if lld.nbytes:
+                _check(L.smilehip_copy_to_device(ctx, d_lld, lld.ctypes.data, lld.nbytes, None))
+            _check(L.smilehip_batch_functionals(self.plan._h, self._h, d_lld, n_out, mask, d_out, n_out * per, None))
+            _check(L.smilehip_stream_synchronize(ctx, None))
+            if out.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, out.ctypes.data, d_out, out.nbytes, None))
+        finally:
+            L.smilehip_free(ctx, d_lld)
+            L.smilehip_free(ctx, d_out)
         return out
 
     def close(self):

@@ -31,6 +31,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                           int64_t total_rows, float *d_out, int64_t ld_out, hipStream_t s);
 int compare_run_frames();
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
+hipError_t launch_functionals(const FuncParams &P, int n_utt, hipStream_t s);
 int chain_tile_rows();
 int chain_short_max();
 }  // namespace smilehip

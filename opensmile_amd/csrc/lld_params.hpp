@@ -94,6 +94,21 @@ struct CompareParams {
   double slope_Sf, slope_S2f;   // sums of f and f^2 over bins 1..K-1 (spectral.cpp:1399-1427)
 };
 
+// Functionals over the LLD rows of each utterance (lld_functionals.hip)
+struct FuncParams {
+  const int64_t *row_off;    // [n_utt+1] LLD rows per utterance
+  const float *x;            // LLD matrix
+  int64_t ld_x;
+  int32_t n_cols;
+  // cFunctionals in frameMode=full summarises what its input levels hold at its first
+  // end-of-input tick, not the rows the sinks eventually get: with IS09's SMA(3) -> delta(2)
+  // tail that is max(1, T-2) = max(1, rows-3) rows (measured against the binary, T = 1..998)
+  int32_t rows_cut;
+  uint32_t mask;             // SMILEHIP_FUNC_* bits
+  float *out;                // [n_utt x ld_out], n_cols * popcount(mask) values per utterance
+  int64_t ld_out;
+};
+
 // R13: chain of window processors (cDeltaRegression / cContourSmoother) over the
 // rows of each utterance. Level 0 = the input block x (T rows, D columns);
 // stage s (kind 0 = delta regression with deltawin W, 1 = simple moving average

@@ -808,6 +808,59 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   return SMILEHIP_OK;
 }
 
+// ------------------------------------------------------------- functionals
+extern "C" uint32_t smilehip_functionals_is09_mask(void) {
+  return SMILEHIP_FUNC_MAX | SMILEHIP_FUNC_MIN | SMILEHIP_FUNC_RANGE | SMILEHIP_FUNC_MAXPOS | SMILEHIP_FUNC_MINPOS |
+         SMILEHIP_FUNC_AMEAN | SMILEHIP_FUNC_LINREGC1 | SMILEHIP_FUNC_LINREGC2 | SMILEHIP_FUNC_LINREGERRQ |
+         SMILEHIP_FUNC_STDDEV | SMILEHIP_FUNC_SKEWNESS | SMILEHIP_FUNC_KURTOSIS;
+}
+
+extern "C" int smilehip_functionals_count(uint32_t mask) {
+  if (mask & ~SMILEHIP_FUNC_ALL) return -1;
+  return __builtin_popcount(mask);
+}
+
+static const int kIs09FuncRowsCut = 3;      // rows = T+1; functionals see max(1, T-2)
+
+extern "C" int smilehip_batch_func_rows(const smilehip_batch *b, int64_t *rows) {
+  if (!b || !rows) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_func_rows: null argument");
+  if (b->plan->cfg.chain_kind != SMILEHIP_CHAIN_IS09)
+    return fail(SMILEHIP_ERR_INVALID, "functionals are defined for IS09 chain plans only");
+  for (int32_t u = 0; u < b->n_utt; ++u) {
+    const int64_t r = b->h_row_off[u + 1] - b->h_row_off[u];
+    rows[u] = r > 0 ? std::max<int64_t>(1, r - kIs09FuncRowsCut) : 0;
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld,
+                                          uint32_t mask, float *d_func, int64_t ld_func, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_IS09)
+    return fail(SMILEHIP_ERR_INVALID, "functionals are defined for IS09 chain plans only");
+  const int per = smilehip_functionals_count(mask);
+  if (per <= 0) return fail(SMILEHIP_ERR_INVALID, "invalid functionals mask 0x%x", mask);
+  const int n_cols = plan_n_out(plan);
+  if (ld_lld < n_cols || ld_func < (int64_t)n_cols * per)
+    return fail(SMILEHIP_ERR_INVALID, "leading dimensions too small (ld_lld %lld, ld_func %lld)", (long long)ld_lld,
+                (long long)ld_func);
+  if (b->n_utt == 0) return SMILEHIP_OK;
+  if (!d_func || (!d_lld && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals: null device pointer");
+  FuncParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.row_off = b->d_row_off.p;
+  P.x = d_lld;
+  P.ld_x = ld_lld;
+  P.n_cols = n_cols;
+  P.rows_cut = kIs09FuncRowsCut;
+  P.mask = mask;
+  P.out = d_func;
+  P.ld_out = ld_func;
+  hipError_t e = launch_functionals(P, b->n_utt, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,
                                 void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: plan/batch mismatch");

@@ -236,6 +236,45 @@ def run_reference_lld(conf_rel, pcm, fs=16000):
         return read_htk(out)[0]
 
 
+def run_reference_func(conf_rel, pcm, fs=16000):
+    """Real SMILExtract, functionals-level HTK output (-htkoutput) of a standard_data_output
+    config, together with the LLD level (-lldhtkoutput): (func[1 x F] or empty, lld[rows x D])."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    conf = os.path.join(REF_DIR, "config", conf_rel)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        out = os.path.join(td, "func.htk")
+        lld = os.path.join(td, "lld.htk")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", conf, "-I", wav, "-htkoutput", out, "-lldhtkoutput", lld, "-l", "0"], check=True,
+                       cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        f = read_htk(out)[0] if os.path.exists(out) else np.zeros((0, 0), np.float32)
+        x = read_htk(lld)[0] if os.path.exists(lld) else np.zeros((0, 0), np.float32)
+        return f, x
+
+
+FUNC_BITS = ["max", "min", "range", "maxpos", "minpos", "amean", "maxameandist", "minameandist", "linregc1", "linregc2",
+             "linregerrA", "linregerrQ", "variance", "stddev", "skewness", "kurtosis", "amean_m"]
+FUNC_IS09 = sum(1 << FUNC_BITS.index(n) for n in ["max", "min", "range", "maxpos", "minpos", "amean", "linregc1", "linregc2",
+                                                    "linregerrQ", "stddev", "skewness", "kurtosis"])
+
+
+def functionals(x, mask=FUNC_IS09):
+    """rows x cols matrix -> cols x count(mask) functionals (cFunctionals, frameMode=full)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    L = lib()
+    L.lldo_functionals_count.restype = C.c_int
+    L.lldo_functionals_count.argtypes = [C.c_uint32]
+    L.lldo_functionals.restype = C.c_int
+    L.lldo_functionals.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_uint32, C.c_void_p]
+    per = L.lldo_functionals_count(mask)
+    rows, cols = x.shape
+    out = np.zeros((cols, per), np.float32)
+    if rows > 0:
+        L.lldo_functionals(x.ctypes.data, cols, rows, cols, mask, out.ctypes.data)
+    return out
+
+
 def compare_ab_chain(pcm, raw=False):
     """ComParE_2016 LLD groups A+B as the LLD sinks see them: rows x 118 [, rows-1 x 59 pre-SMA]."""
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)

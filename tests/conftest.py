@@ -47,6 +47,12 @@ def golden_is09():
 
 
 @pytest.fixture(scope="session")
+def golden_func():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "is09_func_synth.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_compare():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "compare16_ab_synth.npz"))

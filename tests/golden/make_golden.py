@@ -20,9 +20,26 @@ from opensmile_amd import synth  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def main():
+def gen_func():
+    # IS09_emotion functionals (func level, 384 = 32 x 12) together with the LLD level they summarise
+    ref = {}
+    for name, (u, n) in {"u2_32000": (2, 32000), "u3_16000": (3, 16000), "u10_16000": (10, 16000), "u1_16000": (1, 16000),
+                          "u0_16000": (0, 16000), "u7_400": (7, 400), "u7_560": (7, 560), "u5_160000": (5, 160000)}.items():
+        pcm = synth.utterance(u, n)
+        f, x = lldo.run_reference_func("is09-13/IS09_emotion.conf", pcm)
+        ref["pcm_" + name] = pcm
+        ref["lld_" + name] = x
+        ref["func_" + name] = f
+        print("is09 func", name, x.shape, f.shape)
+    np.savez_compressed(os.path.join(OUT, "is09_func_synth.npz"), **ref)
+
+
+def main(only=None):
     lldo.build()
     assert lldo.have_ref(), "oracle/_ref/SMILExtract missing (needs /root/reference)"
+    if only == "func":
+        gen_func()
+        return
     # config 2 shape, shortened: utterances 0 (zeros), 1 (square), 2, 3 (voiced), 10 (noise)
     # at 1.0 s, plus ragged lengths around the frame boundary (399/400/401/559/560/561 samples)
     cases = {}
@@ -64,6 +81,8 @@ def main():
         print("compare", name, y.shape)
     np.savez_compressed(os.path.join(OUT, "compare16_ab_synth.npz"), **ref)
 
+    gen_func()
+
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
     wav = os.path.join(lldo.REF_DIR, "opensmile.wav")
@@ -77,4 +96,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
