@@ -305,6 +305,13 @@ int  smilehip_plan_last_timing(smilehip_plan *plan, float *ms_main, float *ms_de
 
 /* R0: smilePcm_convertSamples, 16-bit mono (smileUtil.c:2527-2535) */
 int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t n, float *d_out, void *stream);
+/* R0, all sample formats of smilePcm_convertSamples (smileUtil.c:2500-2627): n_bps bytes per
+ * sample (1, 2, 3, 4; n_bits = 24 or 32 selects packed-24 vs int32 when n_bps == 4), n_chan
+ * interleaved channels, n sample frames. mono_mixdown != 0 (cWaveSource's default): n floats,
+ * (sum_c s_c / n_chan) / full_scale; else n * n_chan floats, interleaved as in the input.
+ * Full scales: 127, 32767, 32767*256, 2147483647. The fused batch path takes 16-bit mono. */
+int smilehip_pcm_convert(smilehip_context *ctx, const void *d_raw, int n_bps, int n_bits, int n_chan, int mono_mixdown,
+                         int64_t n, float *d_out, void *stream);
 /* R2: cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107) */
 int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
                                 int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream);

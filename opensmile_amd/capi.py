@@ -95,6 +95,7 @@ SYMBOLS = {
     "smilehip_mfcc_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "smilehip_plan_last_timing": (C.c_int, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
+    "smilehip_pcm_convert": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
     "smilehip_pcm16_to_float": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_preemphasis_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, C.c_int, _vp]),
     "smilehip_window_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
@@ -330,6 +331,28 @@ def extract_mfcc(pcm_list, cfg=None, device=0):
 # ------------------------------------------------ per-component entry points
 # Device pointers are plain ints (e.g. torch.Tensor.data_ptr()); ld = leading
 # dimension in floats. Asynchronous on `stream`.
+def pcm_convert_host(ctx, raw, n_bps, n_bits, n_chan, mixdown=True):
+    """raw: bytes / uint8 array of interleaved PCM -> float32 array (n,) or (n, n_chan)."""
+    L = load()
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8))
+    n = len(raw) // (n_bps * n_chan)
+    out = np.zeros(n if mixdown else (n, n_chan), np.float32)
+    d_in, d_out = _vp(), _vp()
+    _check(L.smilehip_alloc(ctx._h, max(raw.nbytes, 4), C.byref(d_in)))
+    _check(L.smilehip_alloc(ctx._h, max(out.nbytes, 4), C.byref(d_out)))
+    try:
+        if raw.nbytes:
+            _check(L.smilehip_copy_to_device(ctx._h, d_in, raw.ctypes.data, raw.nbytes, None))
+        _check(L.smilehip_pcm_convert(ctx._h, d_in, n_bps, n_bits, n_chan, int(mixdown), n, d_out, None))
+        _check(L.smilehip_stream_synchronize(ctx._h, None))
+        if out.nbytes:
+            _check(L.smilehip_copy_to_host(ctx._h, out.ctypes.data, d_out, out.nbytes, None))
+    finally:
+        L.smilehip_free(ctx._h, d_in)
+        L.smilehip_free(ctx._h, d_out)
+    return out
+
+
 def pcm16_to_float(ctx, d_pcm, n, d_out, stream=None):
     _check(load().smilehip_pcm16_to_float(ctx._h, d_pcm, n, d_out, stream))
 

@@ -106,10 +106,59 @@ __global__ void __launch_bounds__(64) k_mfcc(const float *src, int64_t lds, floa
     dst[(int64_t)blockIdx.x * ldd + r] = dct_coeff(smem, rows + r * n_bands, n_bands, gain[r]);
 }
 
+// R0, every sample format of smilePcm_convertSamples (smileUtil.c:2500-2627): one thread per
+// output sample (mixdown) or per (sample, channel). The divisions are IEEE float divisions in
+// the reference's order: (sum / nChan) / full-scale.
+__device__ __forceinline__ float pcm_sample(const unsigned char *buf, int64_t idx, int n_bps, int n_bits) {
+  switch (n_bps) {
+    case 1: return (float)reinterpret_cast<const int8_t *>(buf)[idx];
+    case 2: return (float)reinterpret_cast<const int16_t *>(buf)[idx];
+    case 3: {
+      uint32_t is = 0;
+      is |= (uint32_t)(buf[idx * 3]) << 8;
+      is |= (uint32_t)(buf[idx * 3 + 1]) << 16;
+      is |= (uint32_t)(buf[idx * 3 + 2]) << 24;
+      return (float)((int32_t)is >> 8);
+    }
+    default: {
+      const int32_t v = reinterpret_cast<const int32_t *>(buf)[idx];
+      return (n_bits == 24) ? (float)(v & 0xFFFFFF) : (float)v;
+    }
+  }
+}
+__device__ __forceinline__ float pcm_full_scale(int n_bps, int n_bits) {
+  if (n_bps == 1) return (float)127.0;
+  if (n_bps == 2) return (float)32767.0;
+  if (n_bps == 3 || n_bits == 24) return (float)(32767.0 * 256.0);
+  return (float)2147483647.0;
+}
+__global__ void k_pcm_convert(const unsigned char *buf, int n_bps, int n_bits, int n_chan, int mixdown, int64_t n,
+                              float *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float fs = pcm_full_scale(n_bps, n_bits);
+  if (mixdown) {
+    if (i >= n) return;
+    float tmp = 0.0f;
+    for (int c = 0; c < n_chan; c++) tmp += pcm_sample(buf, i * n_chan + c, n_bps, n_bits);
+    out[i] = (tmp / (float)n_chan) / fs;
+  } else {
+    if (i >= n * n_chan) return;
+    out[i] = pcm_sample(buf, i, n_bps, n_bits) / fs;
+  }
+}
+
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_pcm16_to_float, dim3(nblk(n, 256)), dim3(256), 0, s, pcm, n, out);
+  return hipGetLastError();
+}
+hipError_t stage_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan, int mixdown, int64_t n, float *out,
+                             hipStream_t s) {
+  const int64_t work = mixdown ? n : n * n_chan;
+  if (work > 0)
+    hipLaunchKernelGGL(k_pcm_convert, dim3(nblk(work, 256)), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(buf),
+                       n_bps, n_bits, n_chan, mixdown, n, out);
   return hipGetLastError();
 }
 hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,

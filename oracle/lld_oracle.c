@@ -80,6 +80,48 @@ long lldo_num_frames(long n_samples, long N, long H)
 /* ---------------------------------------------------------------------- R0 */
 /* smilePcm_convertSamples, 16-bit mono-mixdown branch,
  * src/smileutil/smileUtil.c:2527-2535: (tmp/(float)nChan)/(float)32767.0 */
+/* R0, every sample format: smilePcm_convertSamples, smileUtil.c:2500-2627. n sample frames of
+ * n_chan interleaved channels; mixdown -> n floats, else n*n_chan floats. Returns n, 0 on an
+ * unknown format. */
+static float pcm_sample(const unsigned char *buf, long idx, int n_bps, int n_bits)
+{
+  switch (n_bps) {
+    case 1: return (float)((const int8_t *)buf)[idx];
+    case 2: return (float)((const int16_t *)buf)[idx];
+    case 3: {
+      uint32_t is = 0;
+      is |= (uint32_t)(buf[idx * 3]) << 8;
+      is |= (uint32_t)(buf[idx * 3 + 1]) << 16;
+      is |= (uint32_t)(buf[idx * 3 + 2]) << 24;
+      return (float)((int32_t)is >> 8);
+    }
+    default: {
+      const int32_t v = ((const int32_t *)buf)[idx];
+      return (n_bits == 24) ? (float)(v & 0xFFFFFF) : (float)v;
+    }
+  }
+}
+long lldo_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan, int mixdown, long n, float *out)
+{
+  float fs;
+  if (n_bps == 1) fs = (float)127.0;
+  else if (n_bps == 2) fs = (float)32767.0;
+  else if (n_bps == 3 || (n_bps == 4 && n_bits == 24)) fs = (float)(32767.0 * 256.0);
+  else if (n_bps == 4 && n_bits == 32) fs = (float)2147483647.0;
+  else return 0;
+  const unsigned char *b = (const unsigned char *)buf;
+  if (mixdown) {
+    for (long i = 0; i < n; i++) {
+      float tmp = 0.0f;
+      for (int c = 0; c < n_chan; c++) tmp += pcm_sample(b, i * n_chan + c, n_bps, n_bits);
+      out[i] = (tmp / (float)n_chan) / fs;
+    }
+  } else {
+    for (long i = 0; i < n * n_chan; i++) out[i] = pcm_sample(b, i, n_bps, n_bits) / fs;
+  }
+  return n;
+}
+
 void lldo_pcm16_to_float(const int16_t *pcm, long n, float *out)
 {
   for (long i = 0; i < n; i++) {

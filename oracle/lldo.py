@@ -236,6 +236,40 @@ def run_reference_lld(conf_rel, pcm, fs=16000):
         return read_htk(out)[0]
 
 
+def pcm_convert(raw, n_bps, n_bits, n_chan, mixdown=True):
+    """Oracle restatement of smilePcm_convertSamples for every sample format."""
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8))
+    n = len(raw) // (n_bps * n_chan)
+    out = np.zeros(n if mixdown else (n, n_chan), np.float32)
+    L = lib()
+    L.lldo_pcm_convert.restype = C.c_long
+    L.lldo_pcm_convert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p]
+    assert L.lldo_pcm_convert(raw.ctypes.data, n_bps, n_bits, n_chan, int(mixdown), n, out.ctypes.data) == n
+    return out
+
+
+class _WaveParameters(C.Structure):       # sWaveParameters, src/include/smileutil/smileUtil.h:650-661
+    _fields_ = [("sampleRate", C.c_long), ("sampleType", C.c_int), ("nChan", C.c_int), ("blockSize", C.c_int),
+                ("nBPS", C.c_int), ("nBits", C.c_int), ("byteOrder", C.c_int), ("memOrga", C.c_int),
+                ("nBlocks", C.c_long), ("headerOffset", C.c_int)]
+
+
+def ref_pcm_convert(raw, n_bps, n_bits, n_chan, mixdown=True):
+    """The REAL smilePcm_convertSamples (oracle/_ref/libref_dsp.so, compiled from smileUtil.c); None if not built."""
+    path = os.path.join(REF_DIR, "libref_dsp.so")
+    if not os.path.exists(path):
+        return None
+    R = C.CDLL(path)
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8))
+    n = len(raw) // (n_bps * n_chan)
+    out = np.zeros(n if mixdown else (n, n_chan), np.float32)
+    wp = _WaveParameters(16000, 1, n_chan, n_bps * n_chan, n_bps, n_bits, 0, 0, n, 44)
+    R.smilePcm_convertSamples.restype = C.c_int
+    R.smilePcm_convertSamples.argtypes = [C.c_void_p, C.POINTER(_WaveParameters), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    R.smilePcm_convertSamples(raw.ctypes.data, C.byref(wp), out.ctypes.data, 1 if mixdown else n_chan, n, int(mixdown))
+    return out
+
+
 def run_reference_func(conf_rel, pcm, fs=16000):
     """Real SMILExtract, functionals-level HTK output (-htkoutput) of a standard_data_output
     config, together with the LLD level (-lldhtkoutput): (func[1 x F] or empty, lld[rows x D])."""
