@@ -238,6 +238,12 @@ int64_t smilehip_num_frames(const smilehip_plan *plan, int64_t n_samples);
 /* frame t's time stamp = t*H/fs (cMatrix::squashTimeMeta,
  * src/core/dataMemoryLevel.cpp:617-626) and vIdx = t */
 double  smilehip_frame_time(const smilehip_plan *plan, int64_t t);
+/* Time stamp (TimeMetaInfo::time, what cCsvSink/cArffSink print as frameTime) of output row
+ * `row` of an utterance with n_frames frames. MFCC chain: row * frame period. IS09 / ComParE
+ * chains: the rows a window processor emits at end of input carry the time of the last real
+ * frame, i.e. min(row, n_frames-1) * period -- except for n_frames == 1, where the binary
+ * stamps the extra row with `period` (measured: tests/golden/files, test_host_io.py). */
+double  smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row);
 /* host copies of the generated tables (for table-level parity tests); each
  * returns the element count or a negative status. out may be NULL. */
 int64_t smilehip_plan_get_window(const smilehip_plan *plan, float *out, int64_t cap);

@@ -82,6 +82,7 @@ SYMBOLS = {
     "smilehip_plan_geometry": (C.c_int, [_vp, C.POINTER(Geometry)]),
     "smilehip_num_frames": (_i64, [_vp, _i64]),
     "smilehip_frame_time": (_dbl, [_vp, _i64]),
+    "smilehip_row_time": (_dbl, [_vp, _i64, _i64]),
     "smilehip_plan_get_window": (_i64, [_vp, _vp, _i64]),
     "smilehip_plan_get_mel_weights": (_i64, [_vp, _vp, _i64]),
     "smilehip_plan_get_mel_chanmap": (_i64, [_vp, _vp, _i64]),

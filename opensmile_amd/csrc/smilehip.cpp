@@ -456,6 +456,12 @@ extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
   return p ? double(t) * p->geo.frame_period : 0.0;
 }
 
+extern "C" double smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row) {
+  if (!plan || row < 0) return 0.0;
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || n_frames <= 1) return smilehip_frame_time(plan, row);
+  return smilehip_frame_time(plan, row < n_frames - 1 ? row : n_frames - 1);
+}
+
 template <typename T>
 static int64_t copy_out(const std::vector<T> &v, T *out, int64_t cap) {
   if (out) {

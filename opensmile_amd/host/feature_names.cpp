@@ -1,0 +1,38 @@
+// Element names of the levels the two supported feature sets write, as the reference's data
+// memory builds them: field name (cMfcc: "<input>_mfcc", cWindowProcessor nameAppend: "_de",
+// "_sma") plus "[i]" with the array's first index (mfcc.cpp:107-132; arrNameOffset).
+#include "smilehip_host.hpp"
+
+namespace smilehip_host {
+
+static std::string arr(const std::string &base, int i) { return base + "[" + std::to_string(i) + "]"; }
+
+std::vector<std::string> lld_names_mfcc12_0_d_a() {
+  std::vector<std::string> n;
+  for (const char *suffix : {"", "_de", "_de_de"})
+    for (int i = 0; i <= 12; ++i) n.push_back(arr(std::string("pcm_fftMag_mfcc") + suffix, i));
+  return n;
+}
+
+std::vector<std::string> lld_names_is09() {
+  std::vector<std::string> n;
+  for (const char *suffix : {"_sma", "_sma_de"}) {
+    n.push_back(std::string("pcm_RMSenergy") + suffix);
+    for (int i = 1; i <= 12; ++i) n.push_back(arr(std::string("pcm_fftMag_mfcc") + suffix, i));
+    n.push_back(std::string("pcm_zcr") + suffix);
+    n.push_back(std::string("voiceProb") + suffix);
+    n.push_back(std::string("F0") + suffix);
+  }
+  return n;
+}
+
+std::vector<std::string> func_names_is09() {
+  static const char *f[12] = {"max", "min", "range", "maxPos", "minPos", "amean", "linregc1", "linregc2", "linregerrQ",
+                              "stddev", "skewness", "kurtosis"};
+  std::vector<std::string> n;
+  for (const std::string &l : lld_names_is09())
+    for (const char *v : f) n.push_back(l + "_" + v);
+  return n;
+}
+
+}  // namespace smilehip_host

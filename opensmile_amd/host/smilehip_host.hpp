@@ -1,0 +1,61 @@
+// Host-side C++ above the C ABI (include/smilehip.h): the data formats either side of the
+// LLD path -- RIFF/WAVE ingest and the HTK / CSV / ARFF writers, byte
+// layouts and text formats as the reference's source and sinks produce them. No HIP headers:
+// the device is reached only through libsmilehip's extern "C" entry points.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace smilehip_host {
+
+// sWaveParameters as filled by smilePcm_readWaveHeader (src/smileutil/smileUtil.c:2374-2487)
+struct WaveInfo {
+  long sample_rate = 0;
+  int sample_type = 0;      // 1 = PCM, 3 = IEEE float
+  int n_chan = 0;
+  int block_size = 0;
+  int n_bps = 0;            // bytes per sample
+  int n_bits = 0;
+  long n_blocks = 0;        // sample frames in the data chunk
+  long header_offset = 0;   // byte offset of the first sample
+};
+
+// Parses the header the way the reference does (RIFF/WAVE magic, chunks before "fmt " and
+// "data" skipped with their pad byte, fmt size 16/18/40, PCM or IEEE float) and reads the
+// data chunk (clipped to what the file really holds). Returns false + err on failure.
+bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigned char> &data, std::string &err);
+
+// Element names of a level, as cCsvSink/cArffSink obtain them from the data memory
+// (src/core/dataMemoryLevel.cpp naming: field name + "[index]" for array fields).
+std::vector<std::string> lld_names_mfcc12_0_d_a();
+std::vector<std::string> lld_names_is09();
+std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
+
+// cHtkSink (src/iocore/htkSink.cpp:90-105, 183-213): 12-byte big-endian header
+// {nSamples u32, samplePeriod u32 [100 ns], sampleSize u16, parmKind u16} + big-endian float32 rows.
+bool write_htk(const std::string &path, const float *x, int64_t rows, int cols, int64_t ld, double period_sec,
+               int parm_kind, std::string &err);
+
+// cCsvSink (src/iocore/csvSink.cpp:157-240): optional header line, 'name';frameTime;values with
+// "%.0f" for integral values and "%e" otherwise, ';' delimiter.
+struct CsvOptions {
+  bool append = false, print_header = true, timestamp = true;
+  std::string instance_name = "unknown";
+};
+// times: frameTime of each row (smilehip_row_time), or nullptr for row * period_sec
+bool write_csv(const std::string &path, const std::vector<std::string> &names, const float *x, int64_t rows, int cols,
+               int64_t ld, double period_sec, const double *times, const CsvOptions &opt, std::string &err);
+
+// cArffSink (src/iocore/arffSink.cpp:246-333 header, 336-430 rows) with the shared
+// arff_targets.conf.inc defaults: one numeric attribute "class", target "?" for every instance.
+struct ArffOptions {
+  bool append = true, timestamp = false;
+  std::string relation = "openSMILE_features", instance_name = "unknown", class_type = "numeric", class_value = "?";
+};
+std::string arff_escape(const std::string &s);
+bool write_arff(const std::string &path, const std::vector<std::string> &names, const float *x, int64_t rows, int cols,
+                int64_t ld, double period_sec, const ArffOptions &opt, std::string &err);
+
+}  // namespace smilehip_host

@@ -1,0 +1,209 @@
+// smilextract_hip -- batch front end of the fused GPU path for the two feature sets whose
+// whole graph the C ABI covers: config/mfcc/MFCC12_0_D_A.conf and config/is09-13/IS09_emotion.conf.
+// It is NOT a re-implementation of SMILExtract's config language (that stays with the
+// reference; unmodified configs run through the plugin): the set is picked
+// by name and the file options keep the names those configs declare via \cm[...]:
+//
+//   smilextract_hip --set mfcc12_0_d_a  (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
+//   smilextract_hip --set is09_emotion  (-I in.wav | -filelist list.txt) [-O func.arff] [-csvoutput func.csv]
+//                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
+//   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
+//
+// -filelist: one "wav[<TAB>instname]" per line. Per-file outputs (HTK, LLD CSV) of a list go to
+// -outdir/<basename>.<ext>; summary outputs (func ARFF/CSV) append one row per file, like the
+// reference's append=1 default. --rank/--world: this process takes files r, r+n, r+2n, ...
+// (utterances shard with no communication; one process per GPU).
+// All files of a chunk are packed into one device batch: one kernel sequence per chunk.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "smilehip.h"
+#include "smilehip_host.hpp"
+
+using namespace smilehip_host;
+
+namespace {
+
+struct Job { std::string wav, inst; };
+
+[[noreturn]] void die(const std::string &m) {
+  fprintf(stderr, "smilextract_hip: %s\n", m.c_str());
+  exit(1);
+}
+void check(int rc, const char *what) {
+  if (rc != SMILEHIP_OK) die(std::string(what) + ": " + smilehip_last_error());
+}
+std::string basename_noext(const std::string &p) {
+  size_t s = p.find_last_of('/');
+  std::string b = (s == std::string::npos) ? p : p.substr(s + 1);
+  size_t d = b.find_last_of('.');
+  return d == std::string::npos ? b : b.substr(0, d);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::map<std::string, std::string> opt;
+  const char *with_value[] = {"--set", "-I", "-filelist", "-O", "-csvoutput", "-htkoutput", "-lldcsvoutput", "-lldhtkoutput",
+                              "-instname", "-N", "-outdir", "--device", "--rank", "--world", "--chunk-files"};
+  for (int i = 1; i < argc; ++i) {
+    bool known = false;
+    for (const char *w : with_value)
+      if (!strcmp(argv[i], w)) {
+        if (i + 1 >= argc) die(std::string("option ") + w + " needs a value");
+        opt[w] = argv[++i];
+        known = true;
+      }
+    if (!known) die(std::string("unknown option ") + argv[i]);
+  }
+  const std::string set = opt.count("--set") ? opt["--set"] : "";
+  const bool is09 = set == "is09_emotion";
+  if (!is09 && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a or is09_emotion");
+  std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
+
+  std::vector<Job> jobs;
+  if (opt.count("-I")) jobs.push_back({opt["-I"], instname});
+  if (opt.count("-filelist")) {
+    FILE *f = fopen(opt["-filelist"].c_str(), "r");
+    if (!f) die("cannot open file list '" + opt["-filelist"] + "'");
+    char line[8192];
+    while (fgets(line, sizeof(line), f)) {
+      std::string s(line);
+      while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+      if (s.empty()) continue;
+      const size_t tab = s.find('\t');
+      jobs.push_back(tab == std::string::npos ? Job{s, basename_noext(s)} : Job{s.substr(0, tab), s.substr(tab + 1)});
+    }
+    fclose(f);
+  }
+  if (jobs.empty()) die("no input (-I or -filelist)");
+  const int rank = opt.count("--rank") ? atoi(opt["--rank"].c_str()) : 0;
+  const int world = opt.count("--world") ? atoi(opt["--world"].c_str()) : 1;
+  if (world < 1 || rank < 0 || rank >= world) die("bad --rank/--world");
+  if (world > 1) {
+    std::vector<Job> mine;
+    for (size_t i = (size_t)rank; i < jobs.size(); i += (size_t)world) mine.push_back(jobs[i]);
+    jobs.swap(mine);
+  }
+  const bool list_mode = opt.count("-filelist") != 0;
+  const std::string outdir = opt.count("-outdir") ? opt["-outdir"] : "";
+  if (list_mode && outdir.empty() && (opt.count("-lldhtkoutput") || opt.count("-lldcsvoutput") || opt.count("-htkoutput") ||
+                                       (!is09 && (opt.count("-O") || opt.count("-csvoutput")))))
+    die("per-file outputs of a file list need -outdir (the file options then only switch the output on)");
+  auto per_file = [&](const Job &j, const std::string &optname, const char *ext) {
+    return list_mode ? outdir + "/" + basename_noext(j.wav) + ext : opt[optname];
+  };
+
+  smilehip_context *ctx = nullptr;
+  check(smilehip_init(opt.count("--device") ? atoi(opt["--device"].c_str()) : 0, &ctx), "smilehip_init");
+  std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
+  const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
+  const std::vector<std::string> lld_names = is09 ? lld_names_is09() : lld_names_mfcc12_0_d_a();
+  const std::vector<std::string> fnames = is09 ? func_names_is09() : std::vector<std::string>();
+  const uint32_t fmask = smilehip_functionals_is09_mask();
+  std::string err;
+
+  for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_files) {
+    const size_t j1 = std::min(jobs.size(), j0 + chunk_files);
+    // ---- ingest: 16-bit mono PCM is what the fused kernels take
+    std::map<long, std::vector<size_t>> by_rate;
+    std::vector<std::vector<unsigned char>> raw(j1 - j0);
+    for (size_t j = j0; j < j1; ++j) {
+      WaveInfo wi;
+      if (!read_wave_file(jobs[j].wav, wi, raw[j - j0], err)) die(err);
+      if (wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1)
+        die("'" + jobs[j].wav + "': the fused path takes 16-bit mono PCM (other formats: smilehip_pcm_convert + the plugin path)");
+      by_rate[wi.sample_rate].push_back(j);
+    }
+    for (auto &kv : by_rate) {
+      smilehip_plan *&plan = plans[kv.first];
+      if (!plan) {
+        smilehip_lld_config cfg;
+        if (is09) smilehip_config_is09_lld(&cfg); else smilehip_config_mfcc12_0_d_a(&cfg);
+        cfg.sample_rate = (double)kv.first;
+        check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
+      }
+      smilehip_geometry g;
+      check(smilehip_plan_geometry(plan, &g), "smilehip_plan_geometry");
+      const std::vector<size_t> &idx = kv.second;
+      // exact packing: utterance u = samples [off[u], off[u+1]) of one buffer (the kernels use
+      // dword PCM loads when every offset is even, 16-bit loads otherwise)
+      std::vector<int64_t> true_off(idx.size() + 1, 0);
+      for (size_t i = 0; i < idx.size(); ++i) true_off[i + 1] = true_off[i] + (int64_t)(raw[idx[i] - j0].size() / 2);
+      std::vector<int16_t> pcm((size_t)true_off.back() + 2, 0);
+      for (size_t i = 0; i < idx.size(); ++i) {
+        const auto &r = raw[idx[i] - j0];
+        if (!r.empty()) std::memcpy(&pcm[(size_t)true_off[i]], r.data(), r.size() & ~(size_t)1);
+      }
+      smilehip_batch *b = nullptr;
+      check(smilehip_batch_create(plan, true_off.data(), (int32_t)idx.size(), &b), "smilehip_batch_create");
+      const int64_t rows = smilehip_batch_total_rows(b);
+      std::vector<int64_t> row_off(idx.size() + 1, 0);
+      check(smilehip_batch_frame_offsets(b, row_off.data()), "smilehip_batch_frame_offsets");
+      const int n_out = g.n_out;
+      void *d_pcm = nullptr, *d_lld = nullptr, *d_func = nullptr;
+      const uint64_t pcm_bytes = (uint64_t)std::max<int64_t>(true_off.back(), 2) * 2;
+      check(smilehip_alloc(ctx, pcm_bytes, &d_pcm), "smilehip_alloc");
+      check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4, &d_lld), "smilehip_alloc");
+      check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
+      check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
+      std::vector<float> lld((size_t)std::max<int64_t>(rows, 1) * n_out), func;
+      const int n_func = is09 ? n_out * smilehip_functionals_count(fmask) : 0;
+      if (is09) {
+        check(smilehip_alloc(ctx, (uint64_t)idx.size() * n_func * 4, &d_func), "smilehip_alloc");
+        check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
+              "smilehip_batch_functionals");
+        func.resize(idx.size() * (size_t)n_func);
+        check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, nullptr), "copy_to_host");
+      }
+      if (rows > 0) check(smilehip_copy_to_host(ctx, lld.data(), d_lld, (uint64_t)rows * n_out * 4, nullptr), "copy_to_host");
+      check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
+      // ---- sinks
+      for (size_t i = 0; i < idx.size(); ++i) {
+        const Job &job = jobs[idx[i]];
+        const float *x = lld.data() + (size_t)row_off[i] * n_out;
+        const int64_t r = row_off[i + 1] - row_off[i];
+        const std::string lld_htk_opt = is09 ? "-lldhtkoutput" : "-O", lld_csv_opt = is09 ? "-lldcsvoutput" : "-csvoutput";
+        if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
+          if (!write_htk(per_file(job, lld_htk_opt, is09 ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, 9, err)) die(err);
+        if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
+          CsvOptions co;
+          co.instance_name = job.inst;
+          const int64_t n_frames = smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
+          std::vector<double> times((size_t)r);
+          for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
+          if (!write_csv(per_file(job, lld_csv_opt, is09 ? ".lld.csv" : ".csv"), lld_names, x, r, n_out, n_out, g.frame_period,
+                         times.data(), co, err))
+            die(err);
+        }
+        if (is09 && r > 0) {                              // no frame -> the reference writes no instance
+          const float *fv = func.data() + i * (size_t)n_func;
+          if (opt.count("-O") && opt["-O"] != "?") {
+            ArffOptions ao;
+            ao.instance_name = job.inst;
+            if (!write_arff(opt["-O"], fnames, fv, 1, n_func, n_func, 0.0, ao, err)) die(err);
+          }
+          if (opt.count("-csvoutput") && opt["-csvoutput"] != "?") {
+            CsvOptions co;
+            co.instance_name = job.inst;
+            co.append = true;
+            if (!write_csv(opt["-csvoutput"], fnames, fv, 1, n_func, n_func, 0.0, nullptr, co, err)) die(err);
+          }
+          if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
+            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_func, n_func, 0.0, 9, err)) die(err);
+        }
+      }
+      smilehip_free(ctx, d_pcm);
+      smilehip_free(ctx, d_lld);
+      if (d_func) smilehip_free(ctx, d_func);
+      smilehip_batch_destroy(b);
+    }
+  }
+  for (auto &kv : plans) smilehip_plan_destroy(kv.second);
+  smilehip_shutdown(ctx);
+  return 0;
+}

@@ -1,0 +1,66 @@
+// RIFF/WAVE ingest: the header walk of smilePcm_readWaveHeader (smileUtil.c:2374-2487).
+#include <cstring>
+
+#include "smilehip_host.hpp"
+
+namespace smilehip_host {
+
+namespace {
+struct ChunkHead { uint32_t id, size; };
+uint32_t le32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t le16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+bool read_chunk_head(FILE *f, ChunkHead &h) {
+  unsigned char b[8];
+  if (fread(b, 1, 8, f) != 8) return false;
+  h.id = le32(b);
+  h.size = le32(b + 4);
+  return true;
+}
+}  // namespace
+
+bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigned char> &data, std::string &err) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) { err = "cannot open '" + path + "'"; return false; }
+  auto fail = [&](const std::string &m) { err = m + " ('" + path + "')"; fclose(f); return false; };
+  unsigned char head[12];
+  if (fread(head, 1, 12, f) != 12) return fail("file too short for a RIFF header");
+  if (le32(head) != 0x46464952u || le32(head + 8) != 0x45564157u) return fail("bogus wave/riff header");
+  ChunkHead ch;
+  if (!read_chunk_head(f, ch)) return fail("file ends inside the sub-chunk header");
+  while (ch.id != 0x20746D66u) {                       // "fmt " need not be the first sub-chunk
+    fseek(f, (long)ch.size + (long)(ch.size % 2), SEEK_CUR);
+    if (!read_chunk_head(f, ch)) return fail("no fmt chunk");
+  }
+  if (ch.size != 16 && ch.size != 18 && ch.size != 40) return fail("fmt chunk of unsupported size");
+  unsigned char fmt[16];
+  if (fread(fmt, 1, 16, f) != 16) return fail("file ends inside the fmt chunk");
+  if (ch.size > 16) fseek(f, (long)ch.size - 16, SEEK_CUR);
+  const uint16_t audio_format = le16(fmt), n_chan = le16(fmt + 2);
+  const uint32_t rate = le32(fmt + 4);
+  const uint16_t block_align = le16(fmt + 12), bits = le16(fmt + 14);
+  if (audio_format != 1 && audio_format != 3) return fail("only PCM and IEEE float wave formats are supported");
+  if (n_chan == 0 || block_align == 0) return fail("fmt chunk with zero channels or block size");
+  if (!read_chunk_head(f, ch)) return fail("no data chunk");
+  while (ch.id != 0x61746164u) {
+    fseek(f, (long)ch.size + (long)(ch.size % 2), SEEK_CUR);
+    if (!read_chunk_head(f, ch)) return fail("no data chunk");
+  }
+  info.sample_type = audio_format;
+  info.sample_rate = (long)rate;
+  info.n_chan = n_chan;
+  info.n_bps = block_align / n_chan;
+  info.n_bits = bits;
+  info.n_blocks = (long)(ch.size / block_align);
+  info.block_size = block_align;
+  info.header_offset = ftell(f);
+  data.resize((size_t)info.n_blocks * block_align);
+  const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
+  if (got < data.size()) {                               // cWaveSource reads until EOF: a short data chunk just ends earlier
+    info.n_blocks = (long)(got / block_align);
+    data.resize((size_t)info.n_blocks * block_align);
+  }
+  fclose(f);
+  return true;
+}
+
+}  // namespace smilehip_host

@@ -1,0 +1,45 @@
+// Test-only C shim over the C++ host I/O library (opensmile_amd/host) so that the CPU tests
+// can drive the writers and the wave reader through ctypes.
+#include <cstring>
+
+#include "smilehip_host.hpp"
+
+using namespace smilehip_host;
+
+extern "C" int shim_write_htk(const char *path, const float *x, int64_t rows, int cols, double period) {
+  std::string err;
+  return write_htk(path, x, rows, cols, cols, period, 9, err) ? 1 : 0;
+}
+
+// names: 0 = MFCC12_0_D_A lld, 1 = IS09 lld, 2 = IS09 func
+extern "C" int shim_write_csv(const char *path, int names, const float *x, int64_t rows, int cols, double period,
+                              const char *inst, int append, const double *times) {
+  std::string err;
+  CsvOptions o;
+  o.instance_name = inst;
+  o.append = append != 0;
+  const std::vector<std::string> n = names == 0 ? lld_names_mfcc12_0_d_a() : (names == 1 ? lld_names_is09() : func_names_is09());
+  if ((int)n.size() != cols) return -1;
+  return write_csv(path, n, x, rows, cols, cols, period, times, o, err) ? 1 : 0;
+}
+
+extern "C" int shim_write_arff(const char *path, const float *x, int cols, const char *inst) {
+  std::string err;
+  ArffOptions o;
+  o.instance_name = inst;
+  const std::vector<std::string> n = func_names_is09();
+  if ((int)n.size() != cols) return -1;
+  return write_arff(path, n, x, 1, cols, cols, 0.0, o, err) ? 1 : 0;
+}
+
+// info: sample_rate, sample_type, n_chan, n_bps, n_bits, n_blocks, block_size, header_offset; returns bytes or -1
+extern "C" long shim_read_wave(const char *path, long *info, void *buf, int64_t cap) {
+  WaveInfo w;
+  std::vector<unsigned char> d;
+  std::string err;
+  if (!read_wave_file(path, w, d, err)) return -1;
+  info[0] = w.sample_rate; info[1] = w.sample_type; info[2] = w.n_chan; info[3] = w.n_bps; info[4] = w.n_bits;
+  info[5] = w.n_blocks; info[6] = w.block_size; info[7] = w.header_offset;
+  if (buf && cap > 0) std::memcpy(buf, d.data(), (size_t)std::min<int64_t>(cap, (int64_t)d.size()));
+  return (long)d.size();
+}

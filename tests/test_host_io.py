@@ -1,0 +1,180 @@
+"""The data formats either side of the path: WAV ingest and the HTK /
+CSV / ARFF writers of opensmile_amd/host, against files written by the REAL reference binary
+(tests/golden/files, made by tests/golden/make_golden_files.py). CPU part: the writers fed
+with the reference's own numbers must reproduce its files byte for byte. GPU part: the
+smilextract_hip front end end to end (headers/structure identical, values within tolerance)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "files")
+EXE = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
+
+
+def read_htk(path):
+    b = open(path, "rb").read()
+    n, period, size, kind = struct.unpack(">IIHH", b[:12])
+    x = np.frombuffer(b[12:], dtype=">f4").astype(np.float32).reshape(n, size // 4)
+    return (n, period, size, kind), x
+
+
+def parse_csv(path):
+    lines = open(path).read().split("\n")
+    assert lines[-1] == ""
+    head = lines[0]
+    rows = [l.split(";") for l in lines[1:-1]]
+    names = [r[0] for r in rows]
+    vals = np.array([[float(v) for v in r[1:]] for r in rows], dtype=np.float64)
+    return head, names, vals, rows
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    """Thin C shim over the C++ writers, compiled on the fly (g++ only, no GPU)."""
+    src = os.path.join(ROOT, "tests", "host_io_shim.cpp")
+    so = os.path.join(ROOT, "tests", "_host_io_shim.so")
+    host = os.path.join(ROOT, "opensmile_amd", "host")
+    subprocess.run(["make", "-s", "-C", host, "../libsmilehip_host.so"], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + host, "-I" + os.path.join(ROOT, "include"), src,
+                    os.path.join(host, "wave_io.o"), os.path.join(host, "sinks.o"), os.path.join(host, "feature_names.o"),
+                    "-o", so], check=True)
+    L = C.CDLL(so)
+    L.shim_write_htk.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double]
+    L.shim_write_csv.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_char_p, C.c_int, C.c_void_p]
+    L.shim_write_arff.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
+    L.shim_read_wave.argtypes = [C.c_char_p, C.POINTER(C.c_long), C.c_void_p, C.c_int64]
+    L.shim_read_wave.restype = C.c_long
+    return L
+
+
+def test_htk_writer_byte_exact(hostlib, tmp_path):
+    for f, period in (("mfcc_u2_8000.htk", 0.01), ("is09_lld_u3.htk", 0.01), ("is09_func_u3.htk", 0.0)):
+        _, x = read_htk(os.path.join(G, f))
+        x = np.ascontiguousarray(x)
+        out = str(tmp_path / f)
+        assert hostlib.shim_write_htk(out.encode(), x.ctypes.data, x.shape[0], x.shape[1], period) == 1
+        assert open(out, "rb").read() == open(os.path.join(G, f), "rb").read(), f
+
+
+def test_csv_and_arff_writers_byte_exact(hostlib, tmp_path):
+    """%e prints 7 significant digits: feed the writers the values parsed back from the
+    reference's text (exactly representable in the printed precision after float32 rounding
+    of the parsed number is not guaranteed, so use the HTK twin of each file for the data)."""
+    # LLD csv of IS09 <- data of the HTK twin
+    _, x = read_htk(os.path.join(G, "is09_lld_u3.htk"))
+    x = np.ascontiguousarray(x)
+    out = str(tmp_path / "lld.csv")
+    # the end-of-input row repeats the last real frame's time stamp (smilehip_row_time)
+    times = np.minimum(np.arange(x.shape[0]), x.shape[0] - 2) * 0.01
+    assert hostlib.shim_write_csv(out.encode(), 1, x.ctypes.data, x.shape[0], x.shape[1], 0.01, b"b'x", 0, times.ctypes.data) == 1
+    assert open(out).read() == open(os.path.join(G, "is09_lld_u3.csv")).read()
+    # MFCC csv
+    _, x = read_htk(os.path.join(G, "mfcc_u2_8000.htk"))
+    x = np.ascontiguousarray(x)
+    out = str(tmp_path / "m.csv")
+    assert hostlib.shim_write_csv(out.encode(), 0, x.ctypes.data, x.shape[0], x.shape[1], 0.01, b"utt two", 0, None) == 1
+    assert open(out).read() == open(os.path.join(G, "mfcc_u2_8000.csv")).read()
+    # functionals: second instance's values from its HTK twin; first instance's line is copied
+    _, f3 = read_htk(os.path.join(G, "is09_func_u3.htk"))
+    f3 = np.ascontiguousarray(f3)
+    ref_arff = open(os.path.join(G, "is09_func.arff")).read().split("\n")
+    ref_csv = open(os.path.join(G, "is09_func.csv")).read().split("\n")
+    out = str(tmp_path / "f.arff")
+    assert hostlib.shim_write_arff(out.encode(), f3.ctypes.data, f3.shape[1], b"b'x") == 1
+    got = open(out).read().split("\n")
+    assert got[:-2] == ref_arff[:len(got) - 2]            # header incl. @data and the blank line
+    assert got[-2] == ref_arff[-2]                         # the instance line of u3 ('b\\'x', values, ?)
+    out = str(tmp_path / "f.csv")
+    assert hostlib.shim_write_csv(out.encode(), 2, f3.ctypes.data, 1, f3.shape[1], 0.0, b"b'x", 1, None) == 1
+    got = open(out).read().split("\n")
+    assert got[0] == ref_csv[0] and got[1] == ref_csv[2]
+
+
+def test_wave_reader(hostlib, tmp_path):
+    import wave
+    info = (C.c_long * 8)()
+    n = hostlib.shim_read_wave(os.path.join(G, "u2_8000.wav").encode(), info, None, 0)
+    assert n == 16000 and list(info)[:6] == [16000, 1, 1, 2, 16, 8000]
+    buf = np.zeros(8000, np.int16)
+    hostlib.shim_read_wave(os.path.join(G, "u2_8000.wav").encode(), info, buf.ctypes.data, 16000)
+    with wave.open(os.path.join(G, "u2_8000.wav"), "rb") as w:
+        ref = np.frombuffer(w.readframes(8000), dtype="<i2")
+    assert np.array_equal(buf, ref)
+    # extra chunk before "fmt " and an odd-sized chunk before "data", 18-byte fmt
+    body = (b"LIST" + struct.pack("<I", 3) + b"abc\0" +
+            b"fmt " + struct.pack("<IHHIIHHH", 18, 1, 2, 8000, 32000, 4, 16, 0) +
+            b"fact" + struct.pack("<I", 4) + b"\0\0\0\0" +
+            b"data" + struct.pack("<I", 8) + struct.pack("<4h", 1, -2, 3, -4))
+    p = tmp_path / "x.wav"
+    p.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body)
+    n = hostlib.shim_read_wave(str(p).encode(), info, None, 0)
+    assert n == 8 and list(info)[:6] == [8000, 1, 2, 2, 16, 2]
+    (tmp_path / "bad.wav").write_bytes(b"RIFX" + b"\0" * 40)
+    assert hostlib.shim_read_wave(str(tmp_path / "bad.wav").encode(), info, None, 0) < 0
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_mfcc(tmp_path):
+    out_htk, out_csv = str(tmp_path / "m.htk"), str(tmp_path / "m.csv")
+    subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-I", os.path.join(G, "u2_8000.wav"), "-O", out_htk, "-csvoutput", out_csv,
+                    "-instname", "utt two"], check=True)
+    h, x = read_htk(out_htk)
+    hr, xr = read_htk(os.path.join(G, "mfcc_u2_8000.htk"))
+    assert h == hr
+    scale = np.abs(xr[:, :13]).max(axis=1, keepdims=True)
+    assert (np.abs(x - xr) / scale).max() <= 1e-5
+    head, names, vals, _ = parse_csv(out_csv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "mfcc_u2_8000.csv"))
+    assert head == head_r and names == names_r
+    assert np.array_equal(vals[:, 0], vals_r[:, 0])                     # frameTime column
+    assert (np.abs(vals[:, 1:] - vals_r[:, 1:]) / scale).max() <= 2e-5   # %e carries 7 digits
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_is09_filelist(tmp_path):
+    lst = tmp_path / "list.txt"
+    lst.write_text(f"{os.path.join(G, 'u2_8000.wav')}\ta.wav\n{os.path.join(G, 'u3_4000.wav')}\tb'x\n")
+    od = tmp_path / "out"
+    od.mkdir()
+    arff, fcsv = str(tmp_path / "f.arff"), str(tmp_path / "f.csv")
+    subprocess.run([EXE, "--set", "is09_emotion", "-filelist", str(lst), "-O", arff, "-csvoutput", fcsv, "-htkoutput", "1",
+                    "-lldcsvoutput", "1", "-lldhtkoutput", "1", "-outdir", str(od)], check=True)
+    # LLD level of the second file
+    h, x = read_htk(str(od / "u3_4000.lld.htk"))
+    hr, xr = read_htk(os.path.join(G, "is09_lld_u3.htk"))
+    assert h == hr
+    cols = [c for c in range(32) if c not in (15, 31)]
+    assert np.abs(x[:, 1:13] - xr[:, 1:13]).max() <= 1e-5 * np.abs(xr[:, 1:13]).max()
+    assert np.abs(x[:, cols] - xr[:, cols]).max() <= 1e-4
+    head, names, vals, _ = parse_csv(str(od / "u3_4000.lld.csv"))
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "is09_lld_u3.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape
+    # functionals: same attribute block, same instance names, two data lines
+    got, ref = open(arff).read().split("\n"), open(os.path.join(G, "is09_func.arff")).read().split("\n")
+    assert len(got) == len(ref)
+    k = ref.index("@data")
+    assert got[:k + 2] == ref[:k + 2]
+    for a, b in zip(got[k + 2:-1], ref[k + 2:-1]):
+        assert a.split(",")[0] == b.split(",")[0] and a.split(",")[-1] == b.split(",")[-1] == "?"
+        assert len(a.split(",")) == len(b.split(",")) == 386
+    head, names, vals, _ = parse_csv(fcsv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "is09_func.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape == (2, 385)
+    v, r = vals[:, 1:].reshape(2, 32, 12), vals_r[:, 1:].reshape(2, 32, 12)
+    assert np.array_equal(v[:, cols][..., [3, 4]], r[:, cols][..., [3, 4]])          # maxPos / minPos
+    hf, xf = read_htk(str(od / "u3_4000.func.htk"))
+    assert hf == read_htk(os.path.join(G, "is09_func_u3.htk"))[0]
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_errors(tmp_path):
+    r = subprocess.run([EXE, "--set", "nope", "-I", "x.wav"], capture_output=True)
+    assert r.returncode != 0 and b"--set" in r.stderr
+    r = subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-I", str(tmp_path / "missing.wav"), "-O", str(tmp_path / "o.htk")],
+                       capture_output=True)
+    assert r.returncode != 0 and b"cannot open" in r.stderr
