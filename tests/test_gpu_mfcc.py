@@ -173,3 +173,59 @@ def test_linearity_free_properties_full_size(hip, plan):
     assert np.array_equal(shifted[:, :13], solo[1:, :13])
     for x in (b, b1, sh):
         x.close()
+
+
+def test_maximum_sizes(hip, plan, oracle):
+    """Edge of the size range: (1) ONE 30-minute utterance (28.8 M samples, 179 998 frames,
+    5 625 tiles of one utterance); (2) 150 000 one- and two-frame utterances in one batch
+    (every tile is a partial tile, every utterance takes the tick-accurate short delta path)."""
+    capi, _ = hip
+    import torch
+    from opensmile_amd import synth
+    # (1)
+    S = 28_800_000
+    base = synth.utterance(2, 160000)
+    pcm = np.tile(base, S // len(base))
+    b = capi.Batch(plan, np.array([0, S], np.int64))
+    T = (S - 400) // 160 + 1
+    assert b.total_frames == T == 179998
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_out = torch.empty((T, 39), dtype=torch.float32, device="cuda")
+    b.run_device(d_pcm.data_ptr(), d_out.data_ptr(), 39)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.isfinite(out).all()
+    for t0 in (0, 1000 * 37, T - 98):                      # slices that start on a hop boundary
+        sl = pcm[t0 * 160: t0 * 160 + 16000]
+        ref = oracle.mfcc_chain(oracle.default_cfg(), sl)[:, :13]
+        got = out[t0:t0 + ref.shape[0], :13]
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        assert (np.abs(got - ref) / scale).max() <= 1e-5
+    # interior delta rows follow the closed form on the GPU's own static block
+    t = 90000
+    num = sum(i * (out[t + i, :13] - out[t - i, :13]) for i in (1, 2))
+    assert np.allclose(out[t, 13:26], num / 10.0, rtol=0, atol=2e-6 * np.abs(out[t, :13]).max())
+    b.close()
+    del d_pcm, d_out
+    # (2)
+    n_utt = 150_000
+    lens = np.where(np.arange(n_utt) % 2 == 0, 400, 560).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    src = synth.utterance(3, 16000)
+    pcm2 = np.concatenate([src[:400], src[100:660]] * (n_utt // 2))
+    b = capi.Batch(plan, off)
+    assert b.total_frames == n_utt // 2 * 3
+    out = b.run_host(pcm2)
+    r1 = oracle.mfcc_chain(oracle.default_cfg(), src[:400])
+    r2 = oracle.mfcc_chain(oracle.default_cfg(), src[100:660])
+    assert r1.shape == (1, 39) and r2.shape == (2, 39)
+    fo = b.frame_offsets
+    for u in (0, 1, 2, 77777, n_utt - 2, n_utt - 1):
+        ref = r1 if u % 2 == 0 else r2
+        got = out[fo[u]:fo[u + 1]]
+        assert got.shape == ref.shape
+        assert (np.abs(got - ref)).max() <= 1e-5 * np.abs(ref[:, :13]).max()
+    # every even (odd) utterance is the same input: identical rows
+    assert np.array_equal(out[fo[0]:fo[1]], out[fo[n_utt - 2]:fo[n_utt - 1]])
+    assert np.array_equal(out[fo[1]:fo[2]], out[fo[n_utt - 1]:fo[n_utt]])
+    b.close()
