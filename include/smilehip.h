@@ -337,6 +337,30 @@ int smilehip_melspec_frames(smilehip_plan *plan, const float *d_src, int64_t ld_
 /* R7: cMfcc::processVector (mfcc.cpp:239-273) */
 int smilehip_mfcc_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
                          int64_t ld_dst, int64_t n_frames, void *stream);
+/* R12: the accumulation of cEnergy::processVector (energy.cpp:152-161): d_out[f] = sum_n x[n]*x[n] with the
+ * float product added to a double; rms / squared / log variants are one host expression on d. */
+int smilehip_sumsq_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                          double *d_out, void *stream);
+/* R12: the zero-crossing count of cMZcr::processVector (mzcr.cpp:117-124); zcr = count / N */
+int smilehip_zcr_count_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                              int32_t *d_out, void *stream);
+/* R9: cAcf::processVector, forward path (acf.cpp:249-349) on a plan whose FFT size is 2*(K-1): input K
+ * magnitudes per frame, output the first n_out (<= 2*(K-1)) lags. use_power squares the input (:252-259),
+ * cepstrum takes log(x+1) first (:288-305; oldCompatCepstrum and cosLifterCepstrum are not covered),
+ * norm_output divides by K (:321-325), abs_cepstrum takes |.| of the cepstrum (:327-331; the ACF is
+ * always |.|, :343). */
+int smilehip_acf_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_out,
+                        int64_t n_frames, int use_power, int cepstrum, int norm_output, int abs_cepstrum, void *stream);
+/* R10: the per-frame analysis of cPitchACF::processVector (pitchACF.cpp:137-192, voicingProb :249-284,
+ * pitchPeak :286-310). Input per frame: [acf(n) | cepstrum(n)]; output the voicing probability (double) and
+ * the index of the cepstral pitch peak (0 = none). F0 = 1/(idx*Tsamp), the voicing cut-off and the causal
+ * contour smoother (:189-243) are scalar host code in the caller (the plugin keeps the five state variables). */
+int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
+                             double fs_sec, double max_pitch, double *d_voicing, int32_t *d_max_idx, void *stream);
+/* R13: cDeltaRegression::processBuffer (kind 0, deltaRegression.cpp:144-152, norm = 2*sum i^2) and
+ * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
+ * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */
+int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W, void *stream);
 /* R13: n_orders chained cDeltaRegression::processBuffer (deltaRegression.cpp:
  * 113-170) with the reference's end-of-input semantics, per utterance of the
  * batch; reads columns [0,D) of d_io rows, writes columns [D, D*(1+n_orders)). */

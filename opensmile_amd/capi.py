@@ -96,6 +96,11 @@ SYMBOLS = {
     "smilehip_mfcc_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "smilehip_plan_last_timing": (C.c_int, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
+    "smilehip_sumsq_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "smilehip_zcr_count_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "smilehip_acf_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "smilehip_pitchacf_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
+    "smilehip_window_op_row": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "smilehip_pcm_convert": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
     "smilehip_pcm16_to_float": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_preemphasis_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, C.c_int, _vp]),

@@ -19,4 +19,13 @@ hipError_t stage_melspec(const float *src, int64_t lds, float *dst, int64_t ldd,
                          int use_power, const float *coef, const int32_t *rng, float scale, hipStream_t s);
 hipError_t stage_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int n_bands, int n_mfcc,
                       const float *rows, const float *gain, float melfloor, float log_floor, hipStream_t s);
+// second set (lld_stage2_kernels.hip): R9, R10, R12, R13 one component at a time
+hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s);
+hipError_t stage_zcr_count(const float *src, int64_t lds, int64_t N, int64_t nF, int32_t *out, hipStream_t s);
+hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_out, int use_power,
+                     int cepstrum, int norm_output, int abs_cepstrum, const float2 *tw_half, const float2 *tw_full,
+                     hipStream_t s);
+hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,
+                          int32_t *max_idx, hipStream_t s);
+hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s);
 }  // namespace smilehip

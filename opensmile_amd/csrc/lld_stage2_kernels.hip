@@ -1,0 +1,118 @@
+// Per-component kernels, second set: the batched operators
+// behind the plugin's cEnergy / cMZcr / cAcf / cPitchACF / cDeltaRegression / cContourSmoother
+// overrides. One 256-thread workgroup per frame (or per row); they share their device
+// functions with the fused IS09 kernel (lld_blocks.hpp), so plugin and fused results agree.
+#include <hip/hip_runtime.h>
+
+#include "lld_blocks.hpp"
+#include "lld_device.hpp"
+#include "lld_stage.hpp"
+
+namespace smilehip {
+
+// R12 cEnergy::processVector (energy.cpp:152-168): d = sum of float squares, accumulated in double
+__global__ void __launch_bounds__(256) k_sumsq(const float *src, int64_t lds, int64_t N, double *out) {
+  __shared__ double scr[4];
+  const float *x = src + (int64_t)blockIdx.x * lds;
+  double d = 0.0;
+  for (int64_t n = threadIdx.x; n < N; n += blockDim.x) { const float t = x[n]; d += t * t; }
+  d = block_sum(d, scr);
+  if (threadIdx.x == 0) out[blockIdx.x] = d;
+}
+
+// R12 cMZcr::processVector, zero crossings (mzcr.cpp:117-124): the count; the caller divides by N
+__global__ void __launch_bounds__(256) k_zcr_count(const float *src, int64_t lds, int64_t N, int32_t *out) {
+  __shared__ int iscr[4];
+  const float *x = src + (int64_t)blockIdx.x * lds;
+  int cnt = 0;
+  for (int64_t i = 1 + threadIdx.x; i < N - 1; i += blockDim.x)
+    if (((x[i - 1] * x[i + 1] <= 0.0f) && (x[i] == 0.0f)) || (x[i - 1] * x[i] < 0.0f)) ++cnt;
+  cnt = block_sum_i(cnt, iscr);
+  if (threadIdx.x == 0) out[blockIdx.x] = cnt;
+}
+
+// R9 cAcf::processVector, forward path (acf.cpp:249-349). LDS: sp[K+3] | re[M] | im[M] | res[M]
+__global__ void __launch_bounds__(256) k_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int K, int n_out,
+                                             int use_power, int cepstrum, int norm_output, int abs_cepstrum,
+                                             const float2 *tw_half, const float2 *tw_full) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = K - 1;
+  float *sp = smem;
+  float *re = sp + ((K + 3) & ~3);
+  float *im = re + M;
+  float *res = im + M;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  const float *m = src + (int64_t)blockIdx.x * lds;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float p = m[k];
+    if (use_power) p = p * p;                                                              // :252-259
+    if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
+    sp[k] = p;
+  }
+  __syncthreads();
+  irfft_even(sp, re, im, M, logM, tw_half, tw_full, res, norm_output ? (float)K : 1.0f, cepstrum ? abs_cepstrum != 0 : true);
+  for (int k = threadIdx.x; k < n_out; k += blockDim.x) dst[(int64_t)blockIdx.x * ldd + k] = res[k];
+}
+
+// R10 cPitchACF::processVector, per-frame analysis (pitchACF.cpp:137-192): src = [acf(n) | cepstrum(n)]
+__global__ void __launch_bounds__(256) k_pitchacf(const float *src, int64_t lds, int n, double fs_sec, double max_pitch,
+                                                  double *voicing, int32_t *max_idx) {
+  __shared__ double scr[4];
+  __shared__ int iscr[4];
+  const float *a = src + (int64_t)blockIdx.x * lds;
+  double v, Tsamp;
+  int mi;
+  pitchacf_frame(a, a + n, n, fs_sec, max_pitch, scr, iscr, v, mi, Tsamp);
+  if (threadIdx.x == 0) { voicing[blockIdx.x] = v; max_idx[blockIdx.x] = mi; }
+}
+
+// R13 cDeltaRegression / cContourSmoother::processBuffer on one row: x points at index 0 and is
+// valid on [-W, nT+W) (deltaRegression.cpp:144-152, contourSmoother.cpp:106-114)
+__global__ void k_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nT) return;
+  if (kind == 0) {
+    float num = 0.0f;
+    for (int i = 1; i <= W; ++i) num += (float)i * (x[n + i] - x[n - i]);
+    y[n] = num / norm;
+  } else {
+    float v = x[n];
+    for (int w = 1; w <= W; ++w) { v += x[n - w]; v += x[n + w]; }
+    y[n] = v / (float)(2 * W + 1);
+  }
+}
+
+static inline unsigned nblk2(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_sumsq, dim3((unsigned)nF), dim3(256), 0, s, src, lds, N, out);
+  return hipGetLastError();
+}
+hipError_t stage_zcr_count(const float *src, int64_t lds, int64_t N, int64_t nF, int32_t *out, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_zcr_count, dim3((unsigned)nF), dim3(256), 0, s, src, lds, N, out);
+  return hipGetLastError();
+}
+hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_out, int use_power,
+                     int cepstrum, int norm_output, int abs_cepstrum, const float2 *tw_half, const float2 *tw_full,
+                     hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  const int M = K - 1;
+  const size_t lds_bytes = sizeof(float) * (size_t)(((K + 3) & ~3) + 3 * M);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_acf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_acf, dim3((unsigned)nF), dim3(256), lds_bytes, s, src, lds, dst, ldd, K, n_out, use_power, cepstrum,
+                     norm_output, abs_cepstrum, tw_half, tw_full);
+  return hipGetLastError();
+}
+hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,
+                          int32_t *max_idx, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_pitchacf, dim3((unsigned)nF), dim3(256), 0, s, src, lds, n, fs_sec, max_pitch, voicing, max_idx);
+  return hipGetLastError();
+}
+hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {
+  if (nT > 0) hipLaunchKernelGGL(k_window_op, dim3(nblk2(nT, 256)), dim3(256), 0, s, x, y, nT, kind, W, norm);
+  return hipGetLastError();
+}
+
+}  // namespace smilehip

@@ -996,6 +996,48 @@ extern "C" int smilehip_rfft_frames(smilehip_plan *p, const float *d_src, int64_
                        p->d_tw_full.p, (hipStream_t)stream), "rfft");
 }
 
+extern "C" int smilehip_sumsq_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                                     double *d_out, void *stream) {
+  if (!ctx || N < 1 || n_frames < 0 || ld_src < N || (n_frames > 0 && (!d_src || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_sumsq_frames: bad argument");
+  STAGE_RET(stage_sumsq(d_src, ld_src, N, n_frames, d_out, (hipStream_t)stream), "sumsq");
+}
+
+extern "C" int smilehip_zcr_count_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N,
+                                         int64_t n_frames, int32_t *d_out, void *stream) {
+  if (!ctx || N < 1 || n_frames < 0 || ld_src < N || (n_frames > 0 && (!d_src || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_zcr_count_frames: bad argument");
+  STAGE_RET(stage_zcr_count(d_src, ld_src, N, n_frames, d_out, (hipStream_t)stream), "zcr_count");
+}
+
+extern "C" int smilehip_acf_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                   int64_t n_out, int64_t n_frames, int use_power, int cepstrum, int norm_output,
+                                   int abs_cepstrum, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_acf_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (n_out < 1 || n_out > p->geo.Nfft / 2)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_acf_frames: n_out %lld outside [1, %lld] (symmetric half of the inverse FFT)",
+                (long long)n_out, (long long)(p->geo.Nfft / 2));
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, n_out, "smilehip_acf_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_acf(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, (int)n_out, use_power, cepstrum, norm_output,
+                      abs_cepstrum, p->d_tw_half.p, p->d_tw_full.p, (hipStream_t)stream), "acf");
+}
+
+extern "C" int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
+                                        double fs_sec, double max_pitch, double *d_voicing, int32_t *d_max_idx, void *stream) {
+  if (!ctx || n < 4 || n_frames < 0 || ld_src < 2 * n || (n_frames > 0 && (!d_src || !d_voicing || !d_max_idx)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_frames: bad argument");
+  STAGE_RET(stage_pitchacf(d_src, ld_src, n_frames, (int)n, fs_sec, max_pitch, d_voicing, d_max_idx, (hipStream_t)stream), "pitchacf");
+}
+
+extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,
+                                      void *stream) {
+  if (!ctx || n_t < 0 || W < 1 || (kind != 0 && kind != 1) || (n_t > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_window_op_row: bad argument");
+  STAGE_RET(stage_window_op(d_x, d_y, n_t, kind, W, delta_norm(W), (hipStream_t)stream), "window_op");
+}
+
 extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
                                       int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmag_frames: null plan");

@@ -4,7 +4,8 @@
 // cComponentManager::registerPlugins (src/core/componentManager.cpp:289-424),
 // which calls the C symbol registerPluginComponent below. The components it
 // returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
-// cTransformFFT, cFFTmagphase, cMelspec, cMfcc), so their factories replace the
+// cTransformFFT, cFFTmagphase, cMelspec, cMfcc, cEnergy, cMZcr, cAcf, cPitchACF,
+// cDeltaRegression, cContourSmoother), so their factories replace the
 // built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
 // every existing option -- stay (configManager.cpp:2818-2827): unmodified
 // config files run through the HIP kernels.
@@ -19,12 +20,18 @@
 // (ABI-coupled to libopensmile.so); it contains no HIP code.
 #include <core/componentManager.hpp>
 #include <core/smileCommon.hpp>
+#include <dspcore/acf.hpp>
+#include <dspcore/contourSmoother.hpp>
+#include <dspcore/deltaRegression.hpp>
 #include <dspcore/fftmagphase.hpp>
 #include <dspcore/transformFft.hpp>
 #include <dspcore/vectorPreemphasis.hpp>
 #include <dspcore/windower.hpp>
+#include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
+#include <lldcore/mzcr.hpp>
+#include <lldcore/pitchACF.hpp>
 
 #include <cstdio>
 #include <cstdlib>
@@ -39,8 +46,10 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-long g_frames[6] = {0, 0, 0, 0, 0, 0};
-const char *const g_names[6] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc"};
+constexpr int kNumOverrides = 12;
+long g_frames[kNumOverrides] = {0};
+const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
+                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother"};
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -332,6 +341,293 @@ class cHipMfcc : public cMfcc {
   }
 };
 
+// a small device buffer of raw bytes (results that are not float frames)
+struct DevBytes {
+  void *d = nullptr;
+  uint64_t cap = 0;
+  void *ensure(uint64_t bytes) {
+    if (bytes > cap) {
+      if (d) smilehip_free(context(), d);
+      if (smilehip_alloc(context(), bytes, &d)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap = bytes;
+    }
+    return d;
+  }
+  void down(void *h, uint64_t bytes) {
+    if (smilehip_copy_to_host(context(), h, d, bytes, nullptr) || smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  ~DevBytes() { if (g_ctx && d) smilehip_free(g_ctx, d); }
+};
+
+// R12  cEnergy::processVector  (src/lldcore/energy.cpp:152-185): the double-accumulated sum of
+// squares comes from the device, the rms / squared / log expressions are the reference's
+class cHipEnergy : public cEnergy {
+  FrameIO io_;
+  DevBytes res_;
+  int htk_ = 0, erms_ = 0, e2_ = 0, elog_ = 0;
+  FLOAT_DMEM sRms_ = 1, sLog_ = 1, sSq_ = 1, bLog_ = 0, bRms_ = 0, bSq_ = 0;
+  bool ready_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (Nsrc == 0) return 0;
+    if (!ready_) {                                       // cEnergy::myFetchConfig, energy.cpp:58-81
+      htk_ = getInt("htkcompatible");
+      erms_ = getInt("rms"); e2_ = getInt("energy2"); elog_ = getInt("log");
+      if (htk_) { elog_ = 1; erms_ = 0; }
+      bLog_ = (FLOAT_DMEM)getDouble("ebiasLog"); bRms_ = (FLOAT_DMEM)getDouble("ebiasRms"); bSq_ = (FLOAT_DMEM)getDouble("ebiasSquare");
+      sRms_ = (FLOAT_DMEM)getDouble("escaleRms"); sSq_ = (FLOAT_DMEM)getDouble("escaleSquare"); sLog_ = (FLOAT_DMEM)getDouble("escaleLog");
+      ready_ = true;
+    }
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    double *d_d = (double *)res_.ensure(sizeof(double));
+    check(smilehip_sumsq_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_d, nullptr));
+    double d = 0.0;
+    res_.down(&d, sizeof(double));
+    int n = 0;
+    if (erms_) dst[n++] = (FLOAT_DMEM)sqrt(d / (FLOAT_DMEM)Nsrc) * sRms_ + bRms_;
+    if (e2_) dst[n++] = (FLOAT_DMEM)(d / (double)Nsrc) * sSq_ + bSq_;
+    if (elog_) {
+      const double minE = 8.674676e-019;
+      if (!htk_) {
+        d /= (FLOAT_DMEM)Nsrc;
+        if (d < minE) d = minE;
+        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+      } else {
+        d *= 32767.0 * 32767.0;
+        if (d <= 1.0) d = 1.0;
+        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+      }
+    }
+    g_frames[6]++;
+    return n;
+  }
+ public:
+  explicit cHipEnergy(const char *n) : cEnergy(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipEnergy(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R12  cMZcr::processVector, zero-crossing rate  (src/lldcore/mzcr.cpp:109-150)
+class cHipMZcr : public cMZcr {
+  FrameIO io_;
+  DevBytes res_;
+  int plain_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
+    if (!plain_ || Nsrc == 0) return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi);   // mean-crossing / extrema stay on the CPU
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t));
+    check(smilehip_zcr_count_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_c, nullptr));
+    int32_t c = 0;
+    res_.down(&c, sizeof(c));
+    FLOAT_DMEM nzc = (FLOAT_DMEM)c;
+    nzc /= (FLOAT_DMEM)Nsrc;
+    dst[0] = nzc;
+    g_frames[7]++;
+    return 1;
+  }
+ public:
+  explicit cHipMZcr(const char *n) : cMZcr(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipMZcr(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R9  cAcf::processVector, forward path  (src/dspcore/acf.cpp:249-349)
+class cHipAcf : public cAcf {
+  FrameIO io_;
+  PlanSet<> plans_;
+  int plain_ = -1, use_power_ = 0, cepstrum_ = 0, norm_ = 0, abs_ceps_ = 0;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) {                                    // cAcf::myFetchConfig, acf.cpp:77-110
+      cepstrum_ = getInt("cepstrum");
+      use_power_ = cepstrum_ ? (isSet("usePower") ? getInt("usePower") : 0) : getInt("usePower");
+      norm_ = getInt("acfCepsNormOutput");
+      abs_ceps_ = getInt("absCepstrum");
+      plain_ = (!getInt("inverse") && !getInt("oldCompatCepstrum") && !getInt("cosLifterCepstrum")) ? 1 : 0;
+    }
+    const long N = (Nsrc - 1) * 2;
+    if (!plain_ || Nsrc < 5 || (N & (N - 1)) != 0 || Ndst > N / 2)
+      return cAcf::processVector(src, dst, Nsrc, Ndst, idxi);   // inverse / legacy cepstrum / liftering stay on the CPU
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      smilehip_lld_config c = base_config(N, SMILEHIP_STAGE_FFT);
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_acf_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, Ndst, 1, use_power_, cepstrum_, norm_, abs_ceps_, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[8]++;
+    return 1;
+  }
+ public:
+  explicit cHipAcf(const char *n) : cAcf(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipAcf(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R10  cPitchACF::processVector  (src/lldcore/pitchACF.cpp:137-247): voicing probability and the
+// cepstral peak index come from the device; F0, the voicing cut-off and the causal contour
+// smoother are the reference's scalar code on this object's own copy of the five state variables
+class cHipPitchACF : public cPitchACF {
+  FrameIO io_;
+  DevBytes res_;
+  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, onsFlag_ = 0;
+  double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
+  FLOAT_DMEM lastPitch_ = 0, lastlastPitch_ = 0, glMeanPitch_ = 0, pitchEnv_ = 0;
+  float fsSec_ = -1.0f;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) {                                    // cPitchACF::myFetchConfig, pitchACF.cpp:75-104
+      voiceProb_ = getInt("voiceProb"); F0_ = getInt("F0"); F0raw_ = getInt("F0raw"); F0env_ = getInt("F0env");
+      voicingCutoff_ = getDouble("voicingCutoff");
+      if (voicingCutoff_ > 1.0) voicingCutoff_ = 1.0;
+      if (voicingCutoff_ < 0.0) voicingCutoff_ = 0.0;
+      maxPitch_ = getDouble("maxPitch");
+      if (maxPitch_ < 0.0) maxPitch_ = 0.0;
+      fsSec_ = (float)(reader_->getLevelConfig()->frameSizeSec);          // setupNewNames, :110-114
+      plain_ = (!getInt("HNR") && !getInt("HNRdB") && !getInt("linHNR") && !getInt("voiceQual")) ? 1 : 0;
+    }
+    const long N = (int)floor(Nsrc / 2.0);
+    if (!plain_ || N < 4 || 2 * N != Nsrc) return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi);   // HNR variants stay on the CPU
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    unsigned char *r = (unsigned char *)res_.ensure(16);
+    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)r, (int32_t *)(r + 8), nullptr));
+    struct { double voicing; int32_t idx; int32_t pad; } h;
+    res_.down(&h, 16);
+    const double voicing = h.voicing;
+    long maxIdx = h.idx;
+    const double Tsamp = fsSec_ / (double)Nsrc;
+    int n = 0;
+    if (voiceProb_) dst[n++] = (FLOAT_DMEM)voicing;
+    if (F0_ || F0env_ || F0raw_) {
+      FLOAT_DMEM pitch = 0.0, rawF0 = 0.0;
+      if (maxIdx > 0) {
+        pitch = (FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(maxIdx) * (FLOAT_DMEM)Tsamp);
+        rawF0 = pitch;
+      }
+      if (voicing < voicingCutoff_) { maxIdx = 0; pitch = 0.0; }
+      // contour smoothing, pitchACF.cpp:199-243
+      if ((lastPitch_ == 0.0) && (pitch > 0.0)) onsFlag_ = 1;
+      if ((lastPitch_ > 0.0) && (pitch == 0.0) && (onsFlag_ == 0)) onsFlag_ = -1;
+      if ((lastPitch_ > 0.0) && (pitch > 0.0)) onsFlag_ = 0;
+      if ((lastPitch_ == 0.0) && (pitch == 0.0)) onsFlag_ = 0;
+      if ((pitch == 0.0) && (onsFlag_ == 1)) { lastPitch_ = 0.0; }
+      FLOAT_DMEM oPitch = pitch;
+      FLOAT_DMEM tol = (FLOAT_DMEM)0.4;
+      FLOAT_DMEM alpha = (FLOAT_DMEM)0.3;
+      if (pitch > 0.0) {
+        if (glMeanPitch_ == 0.0) glMeanPitch_ = pitch;
+        if (!((pitch < ((FLOAT_DMEM)1.0 + tol) * glMeanPitch_) && (pitch > ((FLOAT_DMEM)1.0 - tol) * glMeanPitch_))) {
+          pitch = glMeanPitch_;
+          alpha /= (FLOAT_DMEM)3.0;
+        }
+        if (onsFlag_ && (lastPitch_ > pitch)) lastPitch_ *= (FLOAT_DMEM)0.85;
+      }
+      if ((pitch > 0.0) && (onsFlag_ == -1)) { lastPitch_ = pitch; }
+      if (oPitch > (FLOAT_DMEM)0.0) glMeanPitch_ = ((FLOAT_DMEM)1.0 - alpha) * glMeanPitch_ + alpha * oPitch;
+      FLOAT_DMEM out;
+      if ((lastlastPitch_ != (FLOAT_DMEM)0.0) && (lastPitch_ != 0.0)) out = (FLOAT_DMEM)0.5 * (lastlastPitch_ + lastPitch_);
+      else out = lastPitch_;
+      if (F0_) dst[n++] = out;
+      if (F0raw_) dst[n++] = rawF0;
+      lastlastPitch_ = lastPitch_;
+      lastPitch_ = pitch;
+      if (F0env_) {
+        if (out > 0.0) pitchEnv_ = (FLOAT_DMEM)0.75 * pitchEnv_ + (FLOAT_DMEM)0.25 * out;
+        dst[n++] = pitchEnv_;
+      }
+    }
+    g_frames[9]++;
+    return n;
+  }
+ public:
+  explicit cHipPitchACF(const char *n) : cPitchACF(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchACF(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R13  cWindowProcessor::processBuffer of cDeltaRegression (src/dspcore/deltaRegression.cpp:113-170) and
+// cContourSmoother (src/dspcore/contourSmoother.cpp:85-118): one row of the block the window
+// processor's tick hands over, valid on [-pre, nT+post)
+struct RowIO {
+  FrameIO io;
+  void run(cMatrix *in, cMatrix *out, int pre, int post, int kind, int W) {
+    const long nT = out->nT;
+    if (nT <= 0) return;
+    io.ensure(nT + pre + post, nT);
+    io.up(in->data - pre, nT + pre + post);
+    check(smilehip_window_op_row(context(), io.d_in + pre, io.d_out, nT, kind, W, nullptr));
+    io.down(out->data, nT);
+  }
+};
+
+class cHipDeltaRegression : public cDeltaRegression {
+  RowIO row_;
+  int plain_ = -1, W_ = 0;
+ protected:
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    if (plain_ < 0) {
+      W_ = getInt("deltawin");
+      plain_ = (W_ > 0 && !getInt("onlyInSegments") && !getInt("relativeDelta") && !getInt("halfWaveRect") &&
+                !getInt("absOutput")) ? 1 : 0;
+    }
+    if (!plain_ || pre < W_ || post < W_) return cDeltaRegression::processBuffer(in, out, pre, post);   // segment / relative / rectified variants stay on the CPU
+    row_.run(in, out, pre, post, 0, W_);
+    g_frames[10] += out->nT;
+    return 1;
+  }
+ public:
+  explicit cHipDeltaRegression(const char *n) : cDeltaRegression(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipDeltaRegression(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+class cHipContourSmoother : public cContourSmoother {
+  RowIO row_;
+  int plain_ = -1, W_ = 0;
+ protected:
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    if (plain_ < 0) {
+      const int smaWin = getInt("smaWin");
+      W_ = smaWin / 2;
+      plain_ = (!getInt("noZeroSma") && (smaWin & 1) && W_ >= 1) ? 1 : 0;
+    }
+    if (!plain_ || pre < W_ || post < W_) return cContourSmoother::processBuffer(in, out, pre, post);   // noZeroSma stays on the CPU
+    row_.run(in, out, pre, post, 1, W_);
+    g_frames[11] += out->nT;
+    return 1;
+  }
+ public:
+  explicit cHipContourSmoother(const char *n) : cContourSmoother(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipContourSmoother(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
 // component with the number of frames it pushed through the HIP kernels
 struct TraceAtExit {
@@ -340,7 +636,7 @@ struct TraceAtExit {
     if (!path) return;
     FILE *f = fopen(path, "a");
     if (!f) return;
-    for (int i = 0; i < 6; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
+    for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
     fclose(f);
   }
 } g_trace;
@@ -365,8 +661,14 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all six
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twelve
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cContourSmoother")) head = override_of(&cContourSmoother::registerComponent, &cHipContourSmoother::create, confman, compman, iteration, head);
+  if (want("cDeltaRegression")) head = override_of(&cDeltaRegression::registerComponent, &cHipDeltaRegression::create, confman, compman, iteration, head);
+  if (want("cPitchACF")) head = override_of(&cPitchACF::registerComponent, &cHipPitchACF::create, confman, compman, iteration, head);
+  if (want("cAcf")) head = override_of(&cAcf::registerComponent, &cHipAcf::create, confman, compman, iteration, head);
+  if (want("cMZcr")) head = override_of(&cMZcr::registerComponent, &cHipMZcr::create, confman, compman, iteration, head);
+  if (want("cEnergy")) head = override_of(&cEnergy::registerComponent, &cHipEnergy::create, confman, compman, iteration, head);
   if (want("cMfcc")) head = override_of(&cMfcc::registerComponent, &cHipMfcc::create, confman, compman, iteration, head);
   if (want("cMelspec")) head = override_of(&cMelspec::registerComponent, &cHipMelspec::create, confman, compman, iteration, head);
   if (want("cFFTmagphase")) head = override_of(&cFFTmagphase::registerComponent, &cHipFFTmagphase::create, confman, compman, iteration, head);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLUGDIR = os.path.join(ROOT, "opensmile_amd", "plugin")
 
 
-def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf"):
+def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf", out_opt="-O"):
     exe = os.path.join(oracle.REF_DIR, "SMILExtract")
     plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
     if not (os.path.exists(exe) and os.path.exists(plug)):
@@ -31,7 +31,7 @@ def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf"):
         env["SMILEHIP_PLUGIN_TRACE"] = trace
         env.update(env_extra or {})
         # cwd = the directory that contains ./plugins (componentManager.cpp:347-364)
-        r = subprocess.run([exe, "-C", os.path.join(oracle.REF_DIR, "config", conf), "-I", wav, "-O", out,
+        r = subprocess.run([exe, "-C", os.path.join(oracle.REF_DIR, "config", conf), "-I", wav, out_opt, out,
                             "-l", "1"], cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         assert os.path.exists(out), r.stderr[-2000:]
@@ -68,3 +68,43 @@ def test_plugin_exact_stages_are_bit_exact(oracle, golden_synth):
         assert tr["cMfcc"] == ref.shape[0]
         scale = np.abs(ref[:, :13]).max(axis=1, keepdims=True)
         assert (np.abs(y - ref) / np.tile(np.maximum(scale, 1e-30), (1, 1))).max() < 1e-6
+
+
+IS09 = "is09-13/IS09_emotion.conf"
+IS09_COMPS = ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cEnergy", "cMZcr",
+              "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother")
+
+
+def test_plugin_is09_exact_components_are_bit_exact(oracle, golden_is09):
+    """IS09_emotion.conf, unmodified, with the components whose arithmetic is the reference's own
+    sequence replaced: cMZcr (integer count), cContourSmoother and cDeltaRegression (float stencils
+    through cWindowProcessor::processBuffer, incl. its end-of-input padding) and cPitchACF's scalar
+    smoother around the device's peak pick must reproduce the binary's LLD file bit for bit;
+    cEnergy (parallel double sum) to float round-off."""
+    for k in ("u2_16000", "u7_560", "u7_400"):
+        ref = golden_is09["out_" + k]
+        y, tr = _run(oracle, golden_is09["pcm_" + k],
+                     {"SMILEHIP_PLUGIN_COMPONENTS": "cMZcr,cContourSmoother,cDeltaRegression,cPitchACF"}, IS09, "-lldhtkoutput")
+        assert y.shape == ref.shape
+        T = ref.shape[0] - 1
+        assert tr["cMZcr"] == T and tr["cPitchACF"] == T and tr["cWindower"] == 0
+        assert tr["cContourSmoother"] == 16 * (T + 1) and tr["cDeltaRegression"] == 16 * (T + 3)   # rows x elements incl. EOI rows
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), f"{k}: max abs {np.abs(y - ref).max()}"
+    ref = golden_is09["out_u3_16000"]
+    y, tr = _run(oracle, golden_is09["pcm_u3_16000"], {"SMILEHIP_PLUGIN_COMPONENTS": "cEnergy"}, IS09, "-lldhtkoutput")
+    assert tr["cEnergy"] == ref.shape[0] - 1
+    assert np.abs(y[:, 0] - ref[:, 0]).max() <= 1e-7 * np.abs(ref[:, 0]).max()
+    assert np.array_equal(y[:, 1:16], ref[:, 1:16])
+
+
+def test_plugin_is09_all_twelve(oracle, golden_is09):
+    """Every §8(a) component of the IS09 chain behind the reference's own operator API."""
+    from test_gpu_is09 import check_lld
+    for k in ("u2_16000", "u10_16000", "u0_16000"):
+        ref = golden_is09["out_" + k]
+        y, tr = _run(oracle, golden_is09["pcm_" + k], None, IS09, "-lldhtkoutput")
+        T = ref.shape[0] - 1
+        for comp in IS09_COMPS:
+            assert tr.get(comp, 0) >= T, f"{comp} not routed through the plugin: {tr}"
+        assert tr["cAcf"] == 2 * T                       # the ACF and the cepstrum instance
+        check_lld(y, ref, f"plugin is09 {k}")

@@ -129,3 +129,120 @@ def test_r13_delta_chain_bit_exact(env, W, orders):
             assert np.array_equal(bits(got[r0:r0 + T, D * (o + 1):D * (o + 2)]), bits(ref[o])), \
                 f"T={T} order={o + 1} W={W}"
     b.close()
+
+
+# ---- second set: R9, R10, R12, R13 as per-component operators (what the plugin's cEnergy, cMZcr, cAcf,
+# cPitchACF, cDeltaRegression, cContourSmoother overrides call), against the oracle's functions
+def _dev(capi, ctx, arr):
+    import ctypes as C
+    L = capi.load()
+    p = C.c_void_p()
+    assert L.smilehip_alloc(ctx._h, max(arr.nbytes, 8), C.byref(p)) == 0
+    if arr.nbytes:
+        assert L.smilehip_copy_to_device(ctx._h, p, arr.ctypes.data, arr.nbytes, None) == 0
+    return p
+
+
+def _host(capi, ctx, p, shape, dtype):
+    L = capi.load()
+    out = np.zeros(shape, dtype)
+    assert L.smilehip_copy_to_host(ctx._h, out.ctypes.data, p, out.nbytes, None) == 0
+    assert L.smilehip_stream_synchronize(ctx._h, None) == 0
+    return out
+
+
+def test_energy_zcr_acf_pitch_window_ops(oracle):
+    import ctypes as C
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    L = capi.load()
+    OL = oracle.lib()
+    rng = np.random.default_rng(21)
+    nF, N = 37, 400
+    x = (rng.standard_normal((nF, N)) * 0.1).astype(np.float32)
+    x[3] = 0.0
+    x[4, ::2] = 0.0                                      # exact zeros exercise the (b == 0) branch of the ZCR test
+    d_x = _dev(capi, ctx, x)
+    # R12 sum of squares (double) and zero-crossing count
+    d_d = _dev(capi, ctx, np.zeros(nF, np.float64))
+    assert L.smilehip_sumsq_frames(ctx._h, d_x, N, N, nF, d_d, None) == 0
+    d = _host(capi, ctx, d_d, nF, np.float64)
+    OL.lldo_energy_rms.restype = C.c_float
+    OL.lldo_energy_rms.argtypes = [C.c_void_p, C.c_long]
+    OL.lldo_zcr.restype = C.c_float
+    OL.lldo_zcr.argtypes = [C.c_void_p, C.c_long]
+    for f in range(nF):
+        rms = np.float32(np.sqrt(d[f] / np.float32(N)))
+        assert abs(float(rms) - OL.lldo_energy_rms(x[f].ctypes.data, N)) <= 1e-7 * max(float(rms), 1e-30)
+    d_c = _dev(capi, ctx, np.zeros(nF, np.int32))
+    assert L.smilehip_zcr_count_frames(ctx._h, d_x, N, N, nF, d_c, None) == 0
+    c = _host(capi, ctx, d_c, nF, np.int32)
+    for f in range(nF):
+        assert np.float32(c[f]) / np.float32(N) == np.float32(OL.lldo_zcr(x[f].ctypes.data, N))
+    # R9 ACF and cepstrum of a magnitude spectrum (K = 257), then R10 on [acf | cepstrum]
+    K = 257
+    mag = np.abs(rng.standard_normal((nF, K))).astype(np.float32) + 0.01
+    t = np.arange(K)
+    mag += (2.0 + 2.0 * np.cos(2 * np.pi * t / 16.0)).astype(np.float32)    # harmonic structure -> a clear pitch peak
+    cfg = capi.mfcc12_0_d_a_config()
+    cfg.force_frame_size = 512
+    cfg.stage_mask = 2                                   # SMILEHIP_STAGE_FFT
+    cfg.n_delta = 0
+    plan = capi.Plan(ctx, cfg)
+    d_m = _dev(capi, ctx, mag)
+    d_ac = _dev(capi, ctx, np.zeros((nF, 512), np.float32))
+    assert L.smilehip_acf_frames(plan._h, d_m, K, d_ac, 512, 256, nF, 1, 0, 1, 0, None) == 0
+    ac = _host(capi, ctx, d_ac, (nF, 512), np.float32)
+    d_ce = C.c_void_p(d_ac.value + 256 * 4)
+    assert L.smilehip_acf_frames(plan._h, d_m, K, d_ce, 512, 256, nF, 1, 1, 1, 0, None) == 0
+    ac = _host(capi, ctx, d_ac, (nF, 512), np.float32)
+    OL.lldo_acf.restype = None
+    OL.lldo_acf.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    ref = np.zeros((nF, 512), np.float32)
+    for f in range(nF):
+        OL.lldo_acf(mag[f].ctypes.data, K, 0, ref[f].ctypes.data)
+        OL.lldo_acf(mag[f].ctypes.data, K, 1, ref[f, 256:].ctypes.data)
+    assert np.abs(ac - ref).max() <= 2e-6 * np.abs(ref).max()
+    d_v = _dev(capi, ctx, np.zeros(nF, np.float64))
+    d_i = _dev(capi, ctx, np.zeros(nF, np.int32))
+    # fsSec is a float in cPitchACF (pitchACF.hpp): the caller hands over its double value
+    assert L.smilehip_pitchacf_frames(ctx._h, d_ac, 512, 256, nF, float(np.float32(0.032)), 500.0, d_v, d_i, None) == 0
+    v = _host(capi, ctx, d_v, nF, np.float64)
+    idx = _host(capi, ctx, d_i, nF, np.int32)
+    class St(C.Structure):
+        _fields_ = [("lastPitch", C.c_float), ("lastlastPitch", C.c_float), ("glMeanPitch", C.c_float), ("onsFlag", C.c_int),
+                    ("pitchEnv", C.c_float)]
+    OL.lldo_pitch_acf.restype = None
+    OL.lldo_pitch_acf.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_double, C.c_double, C.POINTER(St),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    OL.lldo_pitch_state_init.argtypes = [C.POINTER(St)]
+    Tsamp = float(np.float32(0.032)) / 512.0
+    for f in range(nF):
+        st = St()
+        OL.lldo_pitch_state_init(C.byref(st))
+        vp, f0, raw = C.c_float(), C.c_float(), C.c_float()
+        OL.lldo_pitch_acf(ref[f].ctypes.data, ref[f, 256:].ctypes.data, 256, np.float32(0.032), 500.0, 0.0, C.byref(st),
+                          C.byref(vp), C.byref(f0), C.byref(raw))
+        # same inputs up to FFT round-off: the voicing probability agrees to 1e-5, the peak index exactly
+        # (or, on a near-tie of two cepstral peaks, within the discontinuity the LLD tests bound)
+        assert abs(np.float32(v[f]) - vp.value) <= 1e-5
+        mine = np.float32(1.0) / (np.float32(idx[f]) * np.float32(Tsamp)) if idx[f] > 0 else np.float32(0.0)
+        assert mine == np.float32(raw.value), (f, idx[f], mine, raw.value)
+    # R13 one row through both window operators, valid on [-W, nT + W)
+    nT, W = 1000, 2
+    row = rng.standard_normal(nT + 2 * W).astype(np.float32)
+    d_r = _dev(capi, ctx, row)
+    d_y = _dev(capi, ctx, np.zeros(nT, np.float32))
+    assert L.smilehip_window_op_row(ctx._h, C.c_void_p(d_r.value + 4 * W), d_y, nT, 0, W, None) == 0
+    y = _host(capi, ctx, d_y, nT, np.float32)
+    num = np.zeros(nT, np.float32)
+    for i in (1, 2):
+        num += np.float32(i) * (row[W + i:W + i + nT] - row[W - i:W - i + nT])
+    assert np.array_equal(y, num / np.float32(10.0))
+    assert L.smilehip_window_op_row(ctx._h, C.c_void_p(d_r.value + 4 * W), d_y, nT, 1, 1, None) == 0
+    y = _host(capi, ctx, d_y, nT, np.float32)
+    sma = row[W:W + nT].copy()
+    sma += row[W - 1:W - 1 + nT]
+    sma += row[W + 1:W + 1 + nT]
+    assert np.array_equal(y, sma / np.float32(3.0))
+    assert L.smilehip_window_op_row(ctx._h, d_r, d_y, nT, 2, 1, None) != 0       # unknown kind
