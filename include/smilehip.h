@@ -134,6 +134,7 @@ typedef struct smilehip_lld_config {
 #define SMILEHIP_STAGE_MEL    4u
 #define SMILEHIP_STAGE_MFCC   8u
 #define SMILEHIP_STAGE_ALL    15u
+#define SMILEHIP_STAGE_SPECTRAL 16u   /* cSpectral constants for a K-bin spectrum (single-component plans) */
 
 /* Integer geometry derived from the config -- the part of the contract that
  * must be bit-exact. */
@@ -357,6 +358,22 @@ int smilehip_acf_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src,
  * contour smoother (:189-243) are scalar host code in the caller (the plugin keeps the five state variables). */
 int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
                              double fs_sec, double max_pitch, double *d_voicing, int32_t *d_max_idx, void *stream);
+/* R11: cSpectral::processVector with ComParE_2016's option set (spectral.cpp:586-1560; bands 250-650 and
+ * 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope, sharpness,
+ * harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1): 15 values per frame, in the reference's
+ * output order. The frames of ONE stream, in order: d_state (K floats) carries the previous frame's magnitudes
+ * across calls (the flux; `first` != 0 marks the stream's first frame, whose flux is 0). Plan: K = 257, built
+ * with SMILEHIP_STAGE_SPECTRAL (or a ComParE chain plan). */
+int smilehip_spectral_frames(smilehip_plan *plan, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                             float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R8: cPlp::processVector as auditory spectrum (doAud = 1, doIDFT = doLP = 0; plp.cpp:416-593). d_eql: the
+ * equal-loudness weights of the bands (their logs when new_rasta, plp.cpp:335-357), as cPlp::initTables
+ * derives them from the input level's band-centre metadata. new_rasta: rasta_coef (host) = {iir, fir[0..4]}
+ * (plp.cpp:369-399) and d_state = 4*n_bands + 1 floats, zeroed before a stream's first frame, carries the
+ * filter taps and the frame counter across calls. */
+int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                                float melfloor, float compression, int new_rasta, const float *rasta_coef, float *d_state,
+                                float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
 /* R13: cDeltaRegression::processBuffer (kind 0, deltaRegression.cpp:144-152, norm = 2*sum i^2) and
  * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
  * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */

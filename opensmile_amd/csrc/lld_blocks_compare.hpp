@@ -1,0 +1,173 @@
+// Block-level (256 threads, Nfft = 512) building blocks of the ComParE descriptors, shared by the
+// fused kernel (lld_compare.hip) and the per-component operators (lld_stage2_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lld_params.hpp"
+
+namespace smilehip {
+
+// sums of NV doubles over the 256 threads of the block (4 waves); every thread gets the totals.
+// red: 4*NV doubles of LDS. The order differs from the reference's sequential loops, the
+// accumulator type (double) does not.
+template <int NV>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV], double *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
+  __syncthreads();
+}
+
+// R11 cSpectral::processVector with ComParE_2016's option set ([is13_spectral]: bands 250-650 and
+// 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope,
+// sharpness, harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1; spectral.cpp:586-1560).
+// Thread i of 256 owns bin j = i+1. mg / pw: magnitudes and powers of the K = 257 bins, prev: the
+// previous frame's magnitudes (ignored when first). red: 64 doubles, cum: 256 doubles, pk_val[4],
+// pk_has[4] of LDS scratch. Writes sp[0..14]; thread 0 returns valid frameSum-based values; ends
+// with a block barrier. The sums are double like the reference's, combined in a fixed tree order.
+__device__ __forceinline__ void spectral_frame(const float *mg, const float *pw, const float *prev, bool first,
+                                               const SpectralConsts &C, int K, double *red, double *cum, float *pk_val,
+                                               int *pk_has, float *sp) {
+  const double F0 = 1.0 / C.fsSec;
+  const int lo = 1, hi = K - 1, nBins = K - 1;          // freqRange 0-0 (spectral.cpp:625-627)
+  const int tid = threadIdx.x, j = tid + 1;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float pf = pw[j];
+  const double p = (double)pf, fj = F0 * j;
+  double v1[6];
+  v1[0] = p;                                            // frame energy (:762-767), centroid denominator
+  v1[1] = fj * p;                                       // centroid numerator (:1256-1330)
+  v1[2] = C.sharp_w[tid] * p;                           // sharpness (:1429-1482)
+  { const double myB = (double)mg[j] - (double)prev[j]; v1[3] = first ? 0.0 : myB * myB; }   // flux (:1124-1254)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {                         // band energies (:779-853), edges resolved on the host
+    auto part = [&](int k) {
+      const double pk = (double)pw[k];
+      double c = 0.0;
+      if (k == C.band_iL[b]) c += pk * C.band_wL[b];
+      if (k > C.band_iL[b] && k < C.band_iR[b]) c += pk;
+      if (k == C.band_iR[b]) c += pk * C.band_wR[b];
+      return c;
+    };
+    v1[4 + b] = part(j) + (tid == 0 ? part(0) : 0.0);
+  }
+  block_sum_n<6>(v1, red);
+  const double frameSum = v1[0], sumA = v1[1];
+  float ctr = 0.0f;
+  if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
+  // roll-off (:1102-1122): inclusive prefix of the power in double, first bin whose prefix reaches the share
+  {
+    double c = p;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(c, off, 64); if (lane >= off) c += o; }
+    if (lane == 63) red[wave] = c;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) c += red[w];
+    cum[tid] = c;
+    __syncthreads();
+    const double before = tid ? cum[tid - 1] : -1.0;
+    const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double th = rollOff[i] * frameSum;
+      if (c >= th && (tid == 0 || !(before >= th))) sp[2 + i] = (float)(F0 * j);
+    }
+  }
+  // harmonicity (:1484-1513): alternating peaks/valleys, distance to the previous one
+  float hc = 0.0f;
+  {
+    bool flag = false;
+    if (j >= lo + 2 && j < hi - 1)
+      flag = (pw[j - 2] < pf && pw[j - 1] < pf && pf > pw[j + 1] && pf > pw[j + 2]) ||
+             (pw[j - 2] > pf && pw[j - 1] > pf && pf < pw[j + 1] && pf < pw[j + 2]);
+    const unsigned long long mask = __ballot(flag);
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    const int src = lower ? 63 - __clzll(lower) : 0;
+    const float prevw = __shfl(pf, src, 64);
+    if (mask && lane == 63 - __clzll(mask)) pk_val[wave] = pf;
+    if (lane == 0) pk_has[wave] = mask != 0ull;
+    __syncthreads();
+    if (flag) {
+      if (lower) hc = fabsf(pf - prevw);
+      else
+        for (int w = wave - 1; w >= 0; --w)
+          if (pk_has[w]) { hc = fabsf(pf - pk_val[w]); break; }
+    }
+  }
+  double v2[5];
+  {                                                     // entropy (smileStat_entropy, smileUtil.c:2079-2124; powers: min = 0)
+    const double entropy_floor = 0.0000001;
+    double dn = frameSum;
+    if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+    double v = p;
+    if (v <= entropy_floor) v = entropy_floor;
+    const double ln = v / dn;
+    v2[0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
+    const double t1 = fj - (double)ctr;                 // moments (:1338-1397)
+    double m = t1 * t1 * p;
+    v2[1] = m; m *= t1; v2[2] = m; v2[3] = m * t1;
+    v2[4] = (double)hc;
+  }
+  block_sum_n<5>(v2, red);
+  if (tid == 0) {
+    sp[0] = (float)(v1[4] / (double)nBins);
+    sp[1] = (float)(v1[5] / (double)nBins);
+    float c2 = 0.0f;
+    const float sumAA = (float)v1[2];
+    if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
+    sp[13] = (float)(0.11 * c2);
+    const double flux = v1[3] / (double)nBins;
+    sp[6] = (!first && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+    sp[7] = ctr;
+    sp[8] = (float)(-v2[0]);
+    const double sumB = frameSum;
+    const double sigma2 = (sumB != 0.0) ? v2[1] / sumB : 0.0;
+    sp[9] = (float)sigma2;
+    sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(v2[2] / (sumB * sigma2 * sqrt(sigma2)));
+    sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(v2[3] / (sumB * sigma2 * sigma2));
+    const double Nind = (double)nBins;
+    const double deno = (Nind * C.slope_S2f - C.slope_Sf * C.slope_Sf);
+    double slope = 0.0;
+    if (deno != 0.0) slope = (Nind * sumA - C.slope_Sf * sumB) / deno;
+    sp[12] = (float)(slope * (Nind - 1.0));              // oldSlopeScale = 1
+    float ptpSum = (float)v2[4];
+    ptpSum /= 2.0f;
+    ptpSum /= (float)nBins;
+    sp[14] = ptpSum;
+  }
+  __syncthreads();
+}
+
+// R8 cPlp as auditory spectrum, one band (plp.cpp:416-593 with doAud = 1, doIDFT = doLP = 0).
+// Without RASTA: melfloor, x equal loudness, power-law compression through double pow (:499-507).
+__device__ __forceinline__ float plp_aud_band(float mel, float melfloor, float eql, float compression) {
+  float v = mel < melfloor ? melfloor : mel;
+  v *= eql;
+  return (float)pow((double)v, (double)compression);
+}
+// newRASTA in the log domain (:434-439 doLog, :468-485 filter, :490-497 log equal loudness and compression,
+// :512-517 exp): x = log of the floored band, st = the band's 4 filter taps, init = frames seen (capped at 5)
+__device__ __forceinline__ float plp_rasta_band(float x, float (&st)[4], int init, const float *fir, float iir, float eql_log,
+                                                float compression) {
+  const float out = fir[0] * x + st[0];
+  st[0] = fir[1] * x + st[1] + (float)(init >= 5) * iir * out;
+  st[1] = fir[2] * x + st[2];
+  st[2] = fir[3] * x + st[3];
+  st[3] = fir[4] * x;
+  x = (init >= 5) ? out : 0.0f;
+  x += eql_log;
+  x *= compression;
+  return (float)exp((double)x);
+}
+
+}  // namespace smilehip

@@ -14,6 +14,7 @@
 // Group B's SMA + delta run through the generic window chain (lld_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include "lld_blocks_compare.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
@@ -23,26 +24,6 @@ namespace smilehip {
 namespace {
 constexpr int kRun = 8;          // frames per workgroup (the flux needs the previous frame's magnitudes)
 
-// sums of NV doubles over the 256 threads of the block (4 waves); every thread gets the totals.
-// red: 4*NV doubles of LDS. The order differs from the reference's sequential loops, the
-// accumulator type (double) does not.
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
-  __syncthreads();
-}
 }  // namespace
 
 // LDS: yv[N] | re[M] | im[M] | mg[K] | pw[K] | prev[K] | mel[32] | aud[32] | lmel[32] | double red[64] | double cum[256] | peaks
@@ -75,8 +56,15 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   const int64_t utt_len = P.samp_off[u + 1] - s_utt;
   const int T60 = (utt_len >= Q.N60) ? (int)((utt_len - Q.N60) / P.H + 1) : 0;
   const int16_t *xu = P.pcm + s_utt;
-  const double F0 = 1.0 / Q.fsSec;                      // frq[i] = F0 * i (transformFft.cpp:102-117)
-  const int lo = 1, hi = K - 1, nBins = K - 1;          // freqRange 0-0 (spectral.cpp:625-627)
+  SpectralConsts SC;
+  SC.fsSec = Q.fsSec;
+  SC.sharp_w = Q.sharp_w;
+  for (int i = 0; i < 2; ++i) {
+    SC.band_iL[i] = Q.band_iL[i]; SC.band_iR[i] = Q.band_iR[i];
+    SC.band_wL[i] = Q.band_wL[i]; SC.band_wR[i] = Q.band_wR[i];
+  }
+  SC.slope_Sf = Q.slope_Sf;
+  SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
 
   // frames t0-1 (magnitudes only, for the flux) .. t_last-1
@@ -115,9 +103,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       // R8 cPlp without RASTA: melfloor, equal loudness, power-law compression (plp.cpp:499-507)
-      float v = acc < Q.plp_melfloor ? Q.plp_melfloor : acc;
-      v *= Q.eql[b];
-      aud[b] = (float)pow((double)v, (double)Q.compression);
+      aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
     }
     __syncthreads();
     for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
@@ -127,126 +113,24 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       for (int i = 0; i < P.n_bands; i++) d += aud[i];
       rawA[0] = d / (float)P.n_bands;
     }
-    // R11 + R12, block-parallel: thread i owns bin j = i+1 (freqRange 0-0 -> bins 1..K-1)
-    float *sp = rawB + 26;
-    const int tid = threadIdx.x, j = tid + 1;
-    const int lane = tid & 63, wave = tid >> 6;
-    const float pf = pw[j];
-    const double p = (double)pf, fj = F0 * j;
-    double v1[8];
-    v1[0] = p;                                          // frame energy (spectral.cpp:762-767), centroid denominator
-    v1[1] = fj * p;                                     // centroid numerator (:1256-1330)
-    v1[2] = Q.sharp_w[tid] * p;                         // sharpness (:1429-1482)
-    { const double myB = (double)mg[j] - (double)prev[j]; v1[3] = (t == 0) ? 0.0 : myB * myB; }   // flux (:1124-1254)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {                       // band energies (:779-853), edges resolved on the host
-      auto part = [&](int k) {
-        const double pk = (double)pw[k];
-        double c = 0.0;
-        if (k == Q.band_iL[b]) c += pk * Q.band_wL[b];
-        if (k > Q.band_iL[b] && k < Q.band_iR[b]) c += pk;
-        if (k == Q.band_iR[b]) c += pk * Q.band_wR[b];
-        return c;
-      };
-      v1[4 + b] = part(j) + (tid == 0 ? part(0) : 0.0);
-    }
-    { double d = 0.0;                                   // cEnergy rms of the raw frame, energy.cpp:152-168
-      for (int n = tid; n < P.N; n += 256) { const float tmp = yv[n]; d += tmp * tmp; }
-      v1[6] = d; }
-    { double nz = 0.0;                                  // cMZcr zcr of the 60 ms frame, mzcr.cpp:117-124
+    // R12: energy of the raw 20 ms frame (energy.cpp:152-168) and ZCR of the 60 ms frame (mzcr.cpp:117-124)
+    {
+      const int tid = threadIdx.x;
+      double v0[2] = {0.0, 0.0};
+      for (int n = tid; n < P.N; n += 256) { const float tmp = yv[n]; v0[0] += tmp * tmp; }
       if (t < T60)
         for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
           const float a = pcm16_to_float(x[i - 1]), b = pcm16_to_float(x[i]), c = pcm16_to_float(x[i + 1]);
-          if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) nz += 1.0;
+          if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) v0[1] += 1.0;
         }
-      v1[7] = nz; }
-    block_sum<8>(v1, red);
-    const double frameSum = v1[0], sumA = v1[1];
-    float ctr = 0.0f;
-    if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
-    // roll-off (:1102-1122): inclusive prefix of the power in double, first bin whose prefix reaches the share
-    {
-      double c = p;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(c, off, 64); if (lane >= off) c += o; }
-      if (lane == 63) red[wave] = c;
-      __syncthreads();
-      for (int w = 0; w < wave; ++w) c += red[w];
-      cum[tid] = c;
-      __syncthreads();
-      const double before = tid ? cum[tid - 1] : -1.0;
-      const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const double th = rollOff[i] * frameSum;
-        if (c >= th && (tid == 0 || !(before >= th))) sp[2 + i] = (float)(F0 * j);
+      block_sum_n<2>(v0, red);
+      if (tid == 0) {
+        rawA[2] = (float)sqrt(v0[0] / (float)P.N) * 1.0f + 0.0f;
+        if (t < T60) rawA[3] = (float)v0[1] / (float)Q.N60;
       }
     }
-    // harmonicity (:1484-1513): alternating peaks/valleys, distance to the previous one
-    float hc = 0.0f;
-    {
-      bool flag = false;
-      if (j >= lo + 2 && j < hi - 1)
-        flag = (pw[j - 2] < pf && pw[j - 1] < pf && pf > pw[j + 1] && pf > pw[j + 2]) ||
-               (pw[j - 2] > pf && pw[j - 1] > pf && pf < pw[j + 1] && pf < pw[j + 2]);
-      const unsigned long long mask = __ballot(flag);
-      const unsigned long long lower = mask & ((1ull << lane) - 1ull);
-      const int src = lower ? 63 - __clzll(lower) : 0;
-      const float prevw = __shfl(pf, src, 64);
-      if (mask && lane == 63 - __clzll(mask)) pk_val[wave] = pf;
-      if (lane == 0) pk_has[wave] = mask != 0ull;
-      __syncthreads();
-      if (flag) {
-        if (lower) hc = fabsf(pf - prevw);
-        else
-          for (int w = wave - 1; w >= 0; --w)
-            if (pk_has[w]) { hc = fabsf(pf - pk_val[w]); break; }
-      }
-    }
-    double v2[5];
-    {                                                   // entropy (smileStat_entropy, smileUtil.c:2079-2124; powers: min = 0)
-      const double entropy_floor = 0.0000001;
-      double dn = frameSum;
-      if (dn < (float)entropy_floor) dn = (float)entropy_floor;
-      double v = p;
-      if (v <= entropy_floor) v = entropy_floor;
-      const double ln = v / dn;
-      v2[0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
-      const double t1 = fj - (double)ctr;               // moments (:1338-1397)
-      double m = t1 * t1 * p;
-      v2[1] = m; m *= t1; v2[2] = m; v2[3] = m * t1;
-      v2[4] = (double)hc;
-    }
-    block_sum<5>(v2, red);
-    if (tid == 0) {
-      sp[0] = (float)(v1[4] / (double)nBins);
-      sp[1] = (float)(v1[5] / (double)nBins);
-      float c2 = 0.0f;
-      const float sumAA = (float)v1[2];
-      if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
-      sp[13] = (float)(0.11 * c2);
-      const double flux = v1[3] / (double)nBins;
-      sp[6] = (t > 0 && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
-      sp[7] = ctr;
-      sp[8] = (float)(-v2[0]);
-      const double sumB = frameSum;
-      const double sigma2 = (sumB != 0.0) ? v2[1] / sumB : 0.0;
-      sp[9] = (float)sigma2;
-      sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(v2[2] / (sumB * sigma2 * sqrt(sigma2)));
-      sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(v2[3] / (sumB * sigma2 * sigma2));
-      const double Nind = (double)nBins;
-      const double deno = (Nind * Q.slope_S2f - Q.slope_Sf * Q.slope_Sf);
-      double slope = 0.0;
-      if (deno != 0.0) slope = (Nind * sumA - Q.slope_Sf * sumB) / deno;
-      sp[12] = (float)(slope * (Nind - 1.0));            // oldSlopeScale = 1
-      float ptpSum = (float)v2[4];
-      ptpSum /= 2.0f;
-      ptpSum /= (float)nBins;
-      sp[14] = ptpSum;
-      rawA[2] = (float)sqrt(v1[6] / (float)P.N) * 1.0f + 0.0f;
-      if (t < T60) rawA[3] = (float)v1[7] / (float)Q.N60;
-    }
-    __syncthreads();
+    // R11: the 15 spectral descriptors, block-parallel (lld_blocks_compare.hpp)
+    spectral_frame(mg, pw, prev, t == 0, SC, K, red, cum, pk_val, pk_has, rawB + 26);
     for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
     __syncthreads();
   }

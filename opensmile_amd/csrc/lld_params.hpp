@@ -94,6 +94,15 @@ struct CompareParams {
   double slope_Sf, slope_S2f;   // sums of f and f^2 over bins 1..K-1 (spectral.cpp:1399-1427)
 };
 
+// Constants of cSpectral for one spectrum geometry (host-resolved, SpectralHost in smilehip.cpp)
+struct SpectralConsts {
+  double fsSec;               // frameSizeSec of the magnitude level: frq[i] = i / fsSec (transformFft.cpp:102-117)
+  const double *sharp_w;      // [K-1] bark(f) * g(bark(f)) for bins 1..K-1 (spectral.cpp:1440-1455)
+  int32_t band_iL[2], band_iR[2];
+  double band_wL[2], band_wR[2];
+  double slope_Sf, slope_S2f;
+};
+
 // Functionals over the LLD rows of each utterance (lld_functionals.hip)
 struct FuncParams {
   const int64_t *row_off;    // [n_utt+1] LLD rows per utterance

@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "lld_params.hpp"
+
 namespace smilehip {
 hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s);
 hipError_t stage_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan, int mixdown, int64_t n, float *out,
@@ -27,5 +29,10 @@ hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int
                      hipStream_t s);
 hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,
                           int32_t *max_idx, hipStream_t s);
+struct PlpConsts { float melfloor, compression, iir, fir[5]; };
+hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF, int K,
+                          const SpectralConsts &C, hipStream_t s);
+hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, bool rasta, float *state,
+                     float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s);
 }  // namespace smilehip

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lld_blocks.hpp"
+#include "lld_blocks_compare.hpp"
 #include "lld_device.hpp"
 #include "lld_stage.hpp"
 
@@ -83,6 +84,50 @@ __global__ void k_window_op(const float *x, float *y, int64_t nT, int kind, int 
   }
 }
 
+// R11 cSpectral::processVector, ComParE option set: the frames of one stream in order (the flux needs the
+// previous frame's magnitudes; `state` carries them across calls). One workgroup, K = 257.
+__global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds, float *state, int first, float *dst,
+                                                  int64_t ldd, int64_t nF, int K, SpectralConsts C) {
+  __shared__ __attribute__((aligned(16))) float mg[260], pw[260], prev[260];
+  __shared__ double red[64], cum[256];
+  __shared__ float pk_val[4];
+  __shared__ int pk_has[4];
+  for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = first ? 0.0f : state[k];
+  __syncthreads();
+  for (int64_t f = 0; f < nF; ++f) {
+    const float *m = src + f * lds;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { const float v = m[k]; mg[k] = v; pw[k] = v * v; }   // squareInput (:676-683)
+    __syncthreads();
+    spectral_frame(mg, pw, prev, first && f == 0, C, K, red, cum, pk_val, pk_has, dst + f * ldd);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) state[k] = prev[k];
+}
+
+// R8 cPlp::processVector as auditory spectrum (doAud = 1, no IDFT / LP), with or without newRASTA: the frames of
+// one stream in order, lane = band. state: 4 filter taps per band + the frame counter (as a float) at [4*nB].
+__global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int nB, const float *eql, PlpConsts Q, int rasta,
+                                            float *state, float *dst, int64_t ldd, int64_t nF) {
+  const int b = threadIdx.x;
+  if (b >= nB) return;
+  const float e = eql[b];
+  if (!rasta) {
+    for (int64_t f = 0; f < nF; ++f) dst[f * ldd + b] = plp_aud_band(src[f * lds + b], Q.melfloor, e, Q.compression);
+    return;
+  }
+  float st[4] = {state[4 * b], state[4 * b + 1], state[4 * b + 2], state[4 * b + 3]};
+  int init = (int)state[4 * nB];
+  for (int64_t f = 0; f < nF; ++f) {
+    const float v = src[f * lds + b];
+    const float x = (float)log((double)(v < Q.melfloor ? Q.melfloor : v));          // doLog, plp.cpp:434-439
+    dst[f * ldd + b] = plp_rasta_band(x, st, init, Q.fir, Q.iir, e, Q.compression);
+    if (init < 5) init++;
+  }
+  for (int i = 0; i < 4; ++i) state[4 * b + i] = st[i];
+  if (b == 0) state[4 * nB] = (float)init;
+}
+
 static inline unsigned nblk2(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s) {
@@ -108,6 +153,16 @@ hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int
 hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,
                           int32_t *max_idx, hipStream_t s) {
   if (nF > 0) hipLaunchKernelGGL(k_pitchacf, dim3((unsigned)nF), dim3(256), 0, s, src, lds, n, fs_sec, max_pitch, voicing, max_idx);
+  return hipGetLastError();
+}
+hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF, int K,
+                          const SpectralConsts &C, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_spectral, dim3(1), dim3(256), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, C);
+  return hipGetLastError();
+}
+hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, bool rasta, float *state,
+                     float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_plp, dim3(1), dim3(64), 0, s, src, lds, n_bands, eql, Q, rasta ? 1 : 0, state, dst, ldd, nF);
   return hipGetLastError();
 }
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {

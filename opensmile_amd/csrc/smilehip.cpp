@@ -327,6 +327,9 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     p->rasta_fir[2] = 0.0f;
     p->rasta_fir[3] = -p->rasta_fir[1];
     p->rasta_fir[4] = -p->rasta_fir[0];
+    if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll))) return rc;
+  }
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || (mask & SMILEHIP_STAGE_SPECTRAL)) {
     // sharpness weights (spectral.cpp:1440-1455): bark(f) * g(bark(f)) for bins 1..K-1
     std::vector<double> sw(size_t(p->geo.K - 1));
     const double F0 = 1.0 / p->geo.fft_frame_size_sec;
@@ -369,7 +372,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     for (int64_t i = 1; i < p->geo.K; ++i) { S2f += (F0 * i) * (F0 * i); Sf += F0 * i; }
     p->slope_Sf = Sf;
     p->slope_S2f = S2f;
-    if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll)) || (rc = p->d_sharp.upload(sw))) return rc;
+    if ((rc = p->d_sharp.upload(sw))) return rc;
   }
   if (p->use_fast) {
     if ((rc = p->d_tw256.upload(p->fast.tw256))) return rc;
@@ -1029,6 +1032,43 @@ extern "C" int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_sr
   if (!ctx || n < 4 || n_frames < 0 || ld_src < 2 * n || (n_frames > 0 && (!d_src || !d_voicing || !d_max_idx)))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_frames: bad argument");
   STAGE_RET(stage_pitchacf(d_src, ld_src, n_frames, (int)n, fs_sec, max_pitch, d_voicing, d_max_idx, (hipStream_t)stream), "pitchacf");
+}
+
+extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                                        float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!p->d_sharp.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: plan was built without SMILEHIP_STAGE_SPECTRAL");
+  if (p->geo.K != 257) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: K = %lld, the kernel covers K = 257", (long long)p->geo.K);
+  if (!d_state && n_frames > 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null state buffer");
+  int rc = check_frames(d_mag, d_dst, ld_src, ld_dst, n_frames, p->geo.K, 15, "smilehip_spectral_frames");
+  if (rc) return rc;
+  SpectralConsts C;
+  C.fsSec = p->geo.fft_frame_size_sec;
+  C.sharp_w = p->d_sharp.p;
+  for (int i = 0; i < 2; ++i) {
+    C.band_iL[i] = p->band_iL[i]; C.band_iR[i] = p->band_iR[i];
+    C.band_wL[i] = p->band_wL[i]; C.band_wR[i] = p->band_wR[i];
+  }
+  C.slope_Sf = p->slope_Sf;
+  C.slope_S2f = p->slope_S2f;
+  STAGE_RET(stage_spectral(d_mag, ld_src, d_state, first != 0, d_dst, ld_dst, n_frames, (int)p->geo.K, C, (hipStream_t)stream), "spectral");
+}
+
+extern "C" int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands,
+                                           const float *d_eql, float melfloor, float compression, int new_rasta,
+                                           const float *rasta_coef, float *d_state, float *d_dst, int64_t ld_dst,
+                                           int64_t n_frames, void *stream) {
+  if (!ctx || n_bands < 1 || n_bands > 64 || !d_eql) return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_audspec_frames: bad argument (1..64 bands)");
+  if (new_rasta && (!rasta_coef || !d_state)) return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_audspec_frames: RASTA needs coefficients and a state buffer");
+  int rc = check_frames(d_mel, d_dst, ld_src, ld_dst, n_frames, n_bands, n_bands, "smilehip_plp_audspec_frames");
+  if (rc) return rc;
+  PlpConsts Q;
+  Q.melfloor = melfloor;
+  Q.compression = compression;
+  Q.iir = new_rasta ? rasta_coef[0] : 0.0f;
+  for (int i = 0; i < 5; ++i) Q.fir[i] = new_rasta ? rasta_coef[1 + i] : 0.0f;
+  STAGE_RET(stage_plp(d_mel, ld_src, n_bands, d_eql, Q, new_rasta != 0, d_state, d_dst, ld_dst, n_frames, (hipStream_t)stream), "plp");
 }
 
 extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,

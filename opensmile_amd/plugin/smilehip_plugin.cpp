@@ -5,7 +5,7 @@
 // which calls the C symbol registerPluginComponent below. The components it
 // returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
 // cTransformFFT, cFFTmagphase, cMelspec, cMfcc, cEnergy, cMZcr, cAcf, cPitchACF,
-// cDeltaRegression, cContourSmoother), so their factories replace the
+// cDeltaRegression, cContourSmoother, cSpectral, cPlp), so their factories replace the
 // built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
 // every existing option -- stay (configManager.cpp:2818-2827): unmodified
 // config files run through the HIP kernels.
@@ -32,11 +32,15 @@
 #include <lldcore/mfcc.hpp>
 #include <lldcore/mzcr.hpp>
 #include <lldcore/pitchACF.hpp>
+#include <lldcore/plp.hpp>
+#include <lldcore/spectral.hpp>
+#include <smileutil/smileUtil.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/smilehip.h"
 
@@ -46,10 +50,10 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 12;
+constexpr int kNumOverrides = 14;
 long g_frames[kNumOverrides] = {0};
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
-                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother"};
+                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp"};
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -628,6 +632,137 @@ class cHipContourSmoother : public cContourSmoother {
   }
 };
 
+// R11  cSpectral::processVector with ComParE_2016's option set  (src/lldcore/spectral.cpp:586-1560)
+class cHipSpectral : public cSpectral {
+  FrameIO io_;
+  PlanSet<> plans_;
+  DevBytes prev_[8];
+  bool seen_[8] = {false, false, false, false, false, false, false, false};
+  int plain_ = -1;
+  bool array_is(const char *name, int n, const char *const *vals) {
+    if (getArraySize(name) != n) return false;
+    for (int i = 0; i < n; ++i) {
+      const char *v = getStr_f(myvprint("%s[%i]", name, i));
+      if (!v || strcmp(v, vals[i]) != 0) return false;
+    }
+    return true;
+  }
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) {
+      static const char *const bands[2] = {"250-650", "1000-4000"};
+      bool ok = array_is("bands", 2, bands) && getArraySize("rollOff") == 4 && getArraySize("slopes") <= 0;
+      static const double ro[4] = {0.25, 0.50, 0.75, 0.90};
+      for (int i = 0; ok && i < 4; ++i) ok = getDouble_f(myvprint("rollOff[%i]", i)) == ro[i];
+      static const char *const on[] = {"squareInput", "flux", "centroid", "entropy", "variance", "skewness", "kurtosis", "slope",
+                                       "sharpness", "harmonicity", "oldSlopeScale"};
+      static const char *const off[] = {"normBandEnergies", "specDiff", "specPosDiff", "fluxCentroid", "fluxAtFluxCentroid", "maxPos",
+                                        "minPos", "standardDeviation", "alphaRatio", "hammarbergIndex", "tonality", "flatness",
+                                        "logFlatness", "buggyRollOff", "useLogSpectrum"};
+      for (const char *o : on) ok = ok && getInt(o) != 0;
+      for (const char *o : off) ok = ok && getInt(o) == 0;
+      const char *fr = getStr("freqRange");
+      ok = ok && fr && !strcmp(fr, "0-0");
+      plain_ = ok ? 1 : 0;
+    }
+    const int fc = getFconf(idxi);
+    if (!plain_ || Nsrc != 257 || Ndst != 15 || fc < 0 || fc >= 8)
+      return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);   // any other option set / spectrum size stays on the CPU
+    smilehip_plan *&pl = plans_.at(fc);
+    if (!pl) {
+      const sDmLevelConfig *lc = reader_->getLevelConfig();
+      smilehip_lld_config c = base_config((Nsrc - 1) * 2, SMILEHIP_STAGE_SPECTRAL);
+      c.force_fft_frame_size_sec = lc->frameSizeSec;    // fsSec, spectral.cpp:382-385
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
+    check(smilehip_spectral_frames(pl, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, Ndst, 1, nullptr));
+    seen_[fc] = true;
+    io_.down(dst, Ndst);
+    g_frames[12]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipSpectral(const char *n) : cSpectral(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipSpectral(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
+class cHipPlp : public cPlp {
+  FrameIO io_;
+  DevBytes eql_[8], state_[8];
+  bool ready_[8] = {false, false, false, false, false, false, false, false};
+  int plain_ = -1, newRasta_ = 0;
+  FLOAT_DMEM compression_ = 0, melfloor_ = 0;
+  float coef_[6] = {0, 0, 0, 0, 0, 0};
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (plain_ < 0) {                                    // cPlp::myFetchConfig, plp.cpp:90-176
+      int doLP = getInt("doLP"), doLpToCeps = getInt("doLpToCeps"), doIDFT = getInt("doIDFT");
+      if (getInt("lpOrder") <= 0) { doLP = 0; doLpToCeps = 0; }
+      if (doLpToCeps) doLP = 1;
+      if (doLP) doIDFT = 1;
+      newRasta_ = getInt("newRASTA");
+      const int rasta = newRasta_ ? 0 : getInt("RASTA");
+      compression_ = (FLOAT_DMEM)getDouble("compression");
+      if (compression_ < 0.0) compression_ = 0.0;
+      melfloor_ = (FLOAT_DMEM)getDouble("melfloor");
+      const bool logs_ok = newRasta_ ? true : (!getInt("doLog") && !getInt("doInvLog"));
+      plain_ = (getInt("doAud") && !doIDFT && !doLP && !rasta && !getInt("htkcompatible") && logs_ok) ? 1 : 0;
+      if (newRasta_) {                                   // initTables, plp.cpp:381-399
+        const FLOAT_DMEM lo = (FLOAT_DMEM)getDouble("rastaLowerCutoff"), up = (FLOAT_DMEM)getDouble("rastaUpperCutoff");
+        coef_[0] = (FLOAT_DMEM)(1.0 - sin(2.0 * M_PI * lo * reader_->getLevelT()));
+        const FLOAT_DMEM om = (FLOAT_DMEM)cos(2.0 * M_PI * up * reader_->getLevelT());
+        const FLOAT_DMEM norm = (FLOAT_DMEM)sqrt(10.0 * (32.0 * om * om + 8.0));
+        coef_[1] = (FLOAT_DMEM)(2.0 / norm);
+        coef_[2] = (FLOAT_DMEM)(-4.0 * om / norm);
+        coef_[3] = 0.0;
+        coef_[4] = -coef_[2];
+        coef_[5] = -coef_[1];
+      }
+    }
+    const int fc = getFconf(idxi);
+    const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
+    if (!plain_ || Nsrc != Ndst || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
+        (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
+      return cPlp::processVector(src, dst, Nsrc, Ndst, idxi);   // PLP-CC (IDFT / LP / cepstra), old RASTA, HTK mode stay on the CPU
+    if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
+      const double *frq = (const double *)(fmeta->field[idxi].info);
+      std::vector<float> e((size_t)Nsrc), st((size_t)(4 * Nsrc + 1), 0.0f);
+      for (long i = 0; i < Nsrc; ++i) {
+        e[(size_t)i] = (FLOAT_DMEM)smileDsp_equalLoudnessWeight((double)frq[i]);
+        if (newRasta_) e[(size_t)i] = log(e[(size_t)i]);
+      }
+      void *d_e = eql_[fc].ensure(sizeof(float) * e.size());
+      void *d_s = state_[fc].ensure(sizeof(float) * st.size());
+      if (smilehip_copy_to_device(context(), d_e, e.data(), sizeof(float) * e.size(), nullptr) ||
+          smilehip_copy_to_device(context(), d_s, st.data(), sizeof(float) * st.size(), nullptr))
+        COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      ready_[fc] = true;
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
+                                      newRasta_, coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[13]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipPlp(const char *n) : cPlp(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPlp(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
 // component with the number of frames it pushed through the HIP kernels
 struct TraceAtExit {
@@ -661,8 +796,10 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twelve
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all fourteen
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cPlp")) head = override_of(&cPlp::registerComponent, &cHipPlp::create, confman, compman, iteration, head);
+  if (want("cSpectral")) head = override_of(&cSpectral::registerComponent, &cHipSpectral::create, confman, compman, iteration, head);
   if (want("cContourSmoother")) head = override_of(&cContourSmoother::registerComponent, &cHipContourSmoother::create, confman, compman, iteration, head);
   if (want("cDeltaRegression")) head = override_of(&cDeltaRegression::registerComponent, &cHipDeltaRegression::create, confman, compman, iteration, head);
   if (want("cPitchACF")) head = override_of(&cPitchACF::registerComponent, &cHipPitchACF::create, confman, compman, iteration, head);

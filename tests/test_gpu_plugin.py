@@ -108,3 +108,43 @@ def test_plugin_is09_all_twelve(oracle, golden_is09):
             assert tr.get(comp, 0) >= T, f"{comp} not routed through the plugin: {tr}"
         assert tr["cAcf"] == 2 * T                       # the ACF and the cepstrum instance
         check_lld(y, ref, f"plugin is09 {k}")
+
+
+COMPARE = "compare16/ComParE_2016.conf"
+
+
+def _ab(y):
+    return np.concatenate([y[:, 6:65], y[:, 71:130]], axis=1)
+
+
+def test_plugin_compare_spectral_and_plp(oracle, golden_compare):
+    """ComParE_2016.conf, unmodified: cSpectral and the two cPlp instances (auditory spectrum with and
+    without newRASTA) behind the reference's operator API. Their inputs are the binary's own magnitudes
+    and mel bands, so the outputs agree with the binary's LLD file to the round-off of the double-
+    accumulated sums / pow / log / exp (no FFT difference involved)."""
+    from test_oracle_pin_compare import compare_tolerances
+    for k in ("u2_16000", "u10_16000"):
+        ref = golden_compare["out_" + k]
+        y, tr = _run(oracle, golden_compare["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cSpectral,cPlp"}, COMPARE, "-lldhtkoutput")
+        y = _ab(y)
+        assert y.shape == ref.shape
+        T20 = ref.shape[0] + 3                          # rows = T60 + 1, T20 = T60 + 4
+        assert tr["cSpectral"] == T20 and tr["cPlp"] == 2 * T20 and tr["cMelspec"] == 0
+        d = np.abs(y.astype(np.float64) - ref)
+        scale = np.maximum(np.abs(ref[:, :59]).max(axis=0), 1e-12)
+        rel = np.concatenate([d[:, :59] / scale, d[:, 59:] / scale], axis=1)
+        ro = [32, 33, 34, 35, 59 + 32, 59 + 33, 59 + 34, 59 + 35]       # roll-off: threshold test on a prefix sum
+        other = [c for c in range(118) if c not in ro]
+        assert rel[:, other].max() <= 2e-6, f"{k}: col {other[int(rel[:, other].max(axis=0).argmax())]} rel {rel[:, other].max():.2e}"
+        assert (d[:, ro] > 1e-3).mean() <= 0.01
+        compare_tolerances(y, ref, k)
+
+
+def test_plugin_compare_all_overrides(oracle, golden_compare):
+    from test_oracle_pin_compare import compare_tolerances
+    ref = golden_compare["out_u3_16000"]
+    y, tr = _run(oracle, golden_compare["pcm_u3_16000"], None, COMPARE, "-lldhtkoutput")
+    for comp in ("cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cEnergy", "cMZcr", "cSpectral", "cPlp",
+                 "cDeltaRegression", "cContourSmoother"):
+        assert tr.get(comp, 0) > 0, f"{comp} not routed through the plugin: {tr}"
+    compare_tolerances(_ab(y), ref, "plugin compare all")
