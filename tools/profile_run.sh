@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_profile.sh <tag>  (run on the GPU box via gpurun): the default bench line, the same
+# usage: tools/profile_run.sh <tag>  (run on the GPU box via gpurun): the default bench line, the same
 # command under rocprofv3 --kernel-trace --stats, the SQ/LDS counter passes and the two HBM-traffic
 # passes (FETCH_SIZE, WRITE_SIZE: each alone, as MI355X_MICROARCH.md prescribes).
 set -u

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """usage: profile_summary.py gpurun_out/<tag> profiles/<prefix>
-Copies what the judge reads from a tools_profile.sh run into profiles/: the bench lines, rocprofv3's
+Copies what the judge reads from a tools/profile_run.sh run into profiles/: the bench lines, rocprofv3's
 kernel stats of the same command, the per-launch durations of the timed steps taken from the kernel
 trace (rocprof's own average also contains the warm-up launches, which run at lower clocks), the
 counter summary and the HBM traffic derived from FETCH_SIZE / WRITE_SIZE."""
@@ -48,7 +48,7 @@ def main():
                 write = float(ln.split()[2])
     frames = bench["config"]["frames_per_gpu"]
     t = {"kernel": "lld_mfcc512<13,7,true,true,true>",
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools_profile.sh)",
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_run.sh)",
          "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
          "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE x1",
          "hbm_bytes_per_launch": (2 * fetch + write) * 1024.0,
