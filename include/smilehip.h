@@ -210,6 +210,12 @@ int smilehip_batch_func_rows(const smilehip_batch *batch, int64_t *rows);
 int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *batch, const float *d_lld, int64_t ld_lld,
                                uint32_t mask, float *d_func, int64_t ld_func, void *stream);
 
+/* The same functionals over ONE matrix (rows x cols, leading dimension ld_x), all rows: what
+ * cFunctionals::doProcess computes for one input row of length `rows` (cols = 1) or for a block of them;
+ * d_out receives cols * count(mask) floats, element-major. */
+int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t ld_x, int64_t rows, int32_t cols,
+                                uint32_t mask, float *d_out, void *stream);
+
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */
 int  smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr);

@@ -66,6 +66,7 @@ SYMBOLS = {
     "smilehip_batch_total_rows": (_i64, [_vp]),
     "smilehip_functionals_is09_mask": (C.c_uint32, []),
     "smilehip_functionals_count": (C.c_int, [C.c_uint32]),
+    "smilehip_functionals_matrix": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_uint32, _vp, _vp]),
     "smilehip_batch_func_rows": (C.c_int, [_vp, _vp]),
     "smilehip_batch_functionals": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint32, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),

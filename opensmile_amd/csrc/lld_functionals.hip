@@ -27,10 +27,10 @@ constexpr int kRL = 8;       // row lanes
 __global__ void __launch_bounds__(kCW * kRL) lld_functionals(FuncParams P) {
   const int u = blockIdx.x;
   const int c_in = threadIdx.x % kCW, r = threadIdx.x / kCW;
-  const int64_t row0 = P.row_off[u];
-  const int64_t lld_rows = P.row_off[u + 1] - row0;
+  const int64_t row0 = P.single_rows >= 0 ? 0 : P.row_off[u];
+  const int64_t lld_rows = P.single_rows >= 0 ? P.single_rows : P.row_off[u + 1] - row0;
   // rows the reference's functionals see (see FuncParams::rows_cut)
-  int64_t NN = lld_rows - P.rows_cut;
+  int64_t NN = lld_rows - (P.single_rows >= 0 ? 0 : P.rows_cut);
   if (NN < 1) NN = lld_rows > 0 ? 1 : 0;
   float *orow = P.out + (int64_t)u * P.ld_out;
   const int per = __popc(P.mask);

@@ -114,6 +114,7 @@ struct FuncParams {
   // tail that is max(1, T-2) = max(1, rows-3) rows (measured against the binary, T = 1..998)
   int32_t rows_cut;
   uint32_t mask;             // SMILEHIP_FUNC_* bits
+  int64_t single_rows;       // >= 0: ONE segment of this many rows starting at x (row_off unused, no cut); -1: use row_off
   float *out;                // [n_utt x ld_out], n_cols * popcount(mask) values per utterance
   int64_t ld_out;
 };

@@ -862,10 +862,30 @@ extern "C" int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *b
   P.ld_x = ld_lld;
   P.n_cols = n_cols;
   P.rows_cut = kIs09FuncRowsCut;
+  P.single_rows = -1;
   P.mask = mask;
   P.out = d_func;
   P.ld_out = ld_func;
   hipError_t e = launch_functionals(P, b->n_utt, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t ld_x, int64_t rows, int32_t cols,
+                                           uint32_t mask, float *d_out, void *stream) {
+  const int per = smilehip_functionals_count(mask);
+  if (!ctx || per <= 0 || rows < 1 || cols < 1 || ld_x < cols || !d_x || !d_out)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_functionals_matrix: bad argument");
+  FuncParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.x = d_x;
+  P.ld_x = ld_x;
+  P.n_cols = cols;
+  P.mask = mask;
+  P.single_rows = rows;
+  P.out = d_out;
+  P.ld_out = (int64_t)cols * per;
+  hipError_t e = launch_functionals(P, 1, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }

@@ -5,7 +5,7 @@
 // which calls the C symbol registerPluginComponent below. The components it
 // returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
 // cTransformFFT, cFFTmagphase, cMelspec, cMfcc, cEnergy, cMZcr, cAcf, cPitchACF,
-// cDeltaRegression, cContourSmoother, cSpectral, cPlp), so their factories replace the
+// cDeltaRegression, cContourSmoother, cSpectral, cPlp, cFunctionals), so their factories replace the
 // built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
 // every existing option -- stay (configManager.cpp:2818-2827): unmodified
 // config files run through the HIP kernels.
@@ -27,6 +27,7 @@
 #include <dspcore/transformFft.hpp>
 #include <dspcore/vectorPreemphasis.hpp>
 #include <dspcore/windower.hpp>
+#include <functionals/functionals.hpp>
 #include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
@@ -50,10 +51,10 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 14;
+constexpr int kNumOverrides = 15;
 long g_frames[kNumOverrides] = {0};
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
-                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp"};
+                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals"};
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -763,6 +764,64 @@ class cHipPlp : public cPlp {
   }
 };
 
+// SURVEY 8f rank 1  cFunctionals::doProcess  (src/functionals/functionals.cpp:284-330) for the Extremes /
+// Regression (linear) / Moments families: one input row (one LLD contour) per call
+class cHipFunctionals : public cFunctionals {
+  FrameIO io_;
+  long mask_ = -1;                                       // -1 = not examined, 0 = not covered -> CPU
+  uint32_t build_mask() {
+    if (getInt("nonZeroFuncts")) return 0;
+    const int n = getArraySize("functionalsEnabled");
+    uint32_t m = 0;
+    int stage = 0;                                        // families must appear in the kernel's output order
+    for (int i = 0; i < n; ++i) {
+      const char *f = getStr_f(myvprint("functionalsEnabled[%i]", i));
+      if (!f) return 0;
+      if (!strcmp(f, "Extremes") && stage < 1) {
+        stage = 1;
+        const char *norm = getStr("Extremes.norm");
+        if (!norm || strncasecmp(norm, "fra", 3)) return 0;                         // positions in frames only
+        static const char *const o[8] = {"max", "min", "range", "maxpos", "minpos", "amean", "maxameandist", "minameandist"};
+        for (int k = 0; k < 8; ++k) if (getInt_f(myvprint("Extremes.%s", o[k]))) m |= 1u << k;
+      } else if (!strcmp(f, "Regression") && stage < 2) {
+        stage = 2;
+        static const char *const off[] = {"qregc1", "qregc2", "qregc3", "qregerrA", "qregerrQ", "centroid", "qregls", "qregrs", "qregx0",
+                                          "qregy0", "qregyr", "qregy0nn", "qregc3nn", "qregyrnn", "normRegCoeff", "normInputs",
+                                          "doRatioLimit", "centroidRatioLimit"};
+        for (const char *k : off) if (getInt_f(myvprint("Regression.%s", k))) return 0;
+        static const char *const o[4] = {"linregc1", "linregc2", "linregerrA", "linregerrQ"};
+        for (int k = 0; k < 4; ++k) if (getInt_f(myvprint("Regression.%s", o[k]))) m |= 1u << (8 + k);
+      } else if (!strcmp(f, "Moments") && stage < 3) {
+        stage = 3;
+        if (getInt("Moments.stddevNorm") || getInt("Moments.doRatioLimit")) return 0;
+        static const char *const o[5] = {"variance", "stddev", "skewness", "kurtosis", "amean"};
+        for (int k = 0; k < 5; ++k) if (getInt_f(myvprint("Moments.%s", o[k]))) m |= 1u << (12 + k);
+      } else {
+        return 0;                                         // another family (percentiles, peaks, times, ...) or another order
+      }
+    }
+    return (smilehip_functionals_count(m) == nFunctValues) ? m : 0;
+  }
+ protected:
+  int doProcess(int i, cMatrix *row, FLOAT_DMEM *y) override {
+    if (mask_ < 0) mask_ = build_mask();
+    if (!mask_ || row->nT <= 0) return cFunctionals::doProcess(i, row, y);
+    io_.ensure(row->nT, nFunctValues);
+    io_.up(row->data, row->nT);
+    check(smilehip_functionals_matrix(context(), io_.d_in, 1, row->nT, 1, (uint32_t)mask_, io_.d_out, nullptr));
+    io_.down(y, nFunctValues);
+    g_frames[14]++;
+    return nFunctValues;
+  }
+ public:
+  explicit cHipFunctionals(const char *n) : cFunctionals(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipFunctionals(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
 // component with the number of frames it pushed through the HIP kernels
 struct TraceAtExit {
@@ -796,8 +855,9 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all fourteen
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all fifteen
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cFunctionals")) head = override_of(&cFunctionals::registerComponent, &cHipFunctionals::create, confman, compman, iteration, head);
   if (want("cPlp")) head = override_of(&cPlp::registerComponent, &cHipPlp::create, confman, compman, iteration, head);
   if (want("cSpectral")) head = override_of(&cSpectral::registerComponent, &cHipSpectral::create, confman, compman, iteration, head);
   if (want("cContourSmoother")) head = override_of(&cContourSmoother::registerComponent, &cHipContourSmoother::create, confman, compman, iteration, head);

@@ -148,3 +148,19 @@ def test_plugin_compare_all_overrides(oracle, golden_compare):
                  "cDeltaRegression", "cContourSmoother"):
         assert tr.get(comp, 0) > 0, f"{comp} not routed through the plugin: {tr}"
     compare_tolerances(_ab(y), ref, "plugin compare all")
+
+
+def test_plugin_is09_functionals(oracle, golden_func):
+    """cFunctionals::doProcess behind the plugin: IS09_emotion's 384 functionals computed from the
+    binary's own LLD contours (only cFunctionals overridden) equal the binary's func level to the
+    round-off of the parallel double sums; positions and extremes exactly."""
+    for k in ("u3_16000", "u7_560", "u2_32000"):
+        ref = golden_func["func_" + k]
+        y, tr = _run(oracle, golden_func["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, IS09, "-htkoutput")
+        assert y.shape == ref.shape == (1, 384)
+        assert tr["cFunctionals"] == 32 and tr["cMfcc"] == 0          # one doProcess per LLD contour
+        exact = np.array([n in (0, 1, 2, 3, 4) for n in range(12)] * 32)
+        assert np.array_equal(y[0, exact], ref[0, exact]), k
+        d = np.abs(y.astype(np.float64) - ref)
+        assert (d <= 1e-5 * np.abs(ref) + 1e-12).all(), (k, float((d / np.maximum(np.abs(ref), 1e-30)).max()))
+        assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.97
