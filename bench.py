@@ -95,8 +95,8 @@ def cpu_baseline(max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)   # the clocks ramp over the first ~20 launches
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--utts", type=int, default=N_UTT, help="utterances per GPU (default: config 2)")
     args = ap.parse_args()
