@@ -130,8 +130,9 @@ constexpr int kChainMaxD = 16;
 constexpr int kChainMaxW = 4;
 
 __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
-  __shared__ float l0[(kChainTile + 4 * kChainMaxW) * kChainMaxD];
-  __shared__ float l1[(kChainTile + 2 * kChainMaxW) * kChainMaxD];
+  constexpr int S = kChainMaxD;               // LDS row stride; thread = (row lane r, column d): no integer divisions
+  __shared__ float l0[(kChainTile + 4 * kChainMaxW) * S];
+  __shared__ float l1[(kChainTile + 2 * kChainMaxW) * S];
   const int u = P.tile_utt[blockIdx.x];
   const int t0 = P.tile_t0[blockIdx.x];
   const int64_t f0 = P.frame_off[u];
@@ -144,30 +145,35 @@ __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
   const int nF = (rows - t0 < kChainTile) ? rows - t0 : kChainTile;
   const int L1 = T + W1;                      // rows of level 1
   const float *x = P.x + f0 * P.ld_x + c0;
+  const int d = threadIdx.x & (S - 1), r = threadIdx.x / S;
+  constexpr int R = 256 / S;
+  const bool on = d < D;
   // level 0 at positions [t0 - W1 - W2, t0 + nF + W1 + W2), clamped to [0, T-1]
   const int n0 = nF + 2 * (W1 + W2);
-  for (int idx = threadIdx.x; idx < n0 * D; idx += blockDim.x) {
-    const int i = idx / D, d = idx - i * D;
-    int tt = t0 - W1 - W2 + i;
-    tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-    l0[i * D + d] = x[(int64_t)tt * P.ld_x + d];
-  }
+  if (on)
+    for (int i = r; i < n0; i += R) {
+      int tt = t0 - W1 - W2 + i;
+      tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+      l0[i * S + d] = x[(int64_t)tt * P.ld_x + d];
+    }
   __syncthreads();
   // level 1 at positions [t0 - W2, t0 + nF + W2), index clamped to [0, L1-1]
   const int n1 = nF + 2 * W2;
-  for (int idx = threadIdx.x; idx < n1 * D; idx += blockDim.x) {
-    const int i = idx / D, d = idx - i * D;
-    int t = t0 - W2 + i;
-    t = t < 0 ? 0 : (t > L1 - 1 ? L1 - 1 : t);
-    l1[i * D + d] = chain_op(l0, t - (t0 - W1 - W2), D, d, P.kind[0], W1);
-  }
+  if (on)
+    for (int i = r; i < n1; i += R) {
+      int t = t0 - W2 + i;
+      t = t < 0 ? 0 : (t > L1 - 1 ? L1 - 1 : t);
+      l1[i * S + d] = chain_op(l0, t - (t0 - W1 - W2), S, d, P.kind[0], W1);
+    }
   __syncthreads();
   float *o = P.out + (P.row_off[u] + t0) * P.ld_out;
-  for (int idx = threadIdx.x; idx < nF * D; idx += blockDim.x) {
-    const int f = idx / D, d = idx - f * D;
-    o[(int64_t)f * P.ld_out + P.out_col[0] + c0 + d] = l1[(f + W2) * D + d];
-    if (P.n_stages > 1) o[(int64_t)f * P.ld_out + P.out_col[1] + c0 + d] = chain_op(l1, f + W2, D, d, P.kind[1], W2);
-  }
+  if (on)
+    for (int f = r; f < nF; f += R) {
+      float *orow = o + (int64_t)f * P.ld_out + c0 + d;
+      if (P.copy_col >= 0) orow[P.copy_col] = l0[(f + W1 + W2) * S + d];      // rows == frames for chains that copy
+      orow[P.out_col[0]] = l1[(f + W2) * S + d];
+      if (P.n_stages > 1) orow[P.out_col[1]] = chain_op(l1, f + W2, S, d, P.kind[1], W2);
+    }
 }
 
 // Tick-accurate path for very short utterances (T <= short_T): the reference's
@@ -236,6 +242,8 @@ __global__ void __launch_bounds__(64) lld_chain_short(ChainParams P) {
   const int rows = (int)(P.row_off[u + 1] - P.row_off[u]);
   for (int o = 1; o <= P.n_stages; ++o)
     for (int t = 0; t < rows && t < kShortCap; ++t) P.out[(P.row_off[u] + t) * P.ld_out + P.out_col[o - 1] + d] = lv[o][t];
+  if (P.copy_col >= 0)
+    for (int t = 0; t < T && t < rows; ++t) P.out[(P.row_off[u] + t) * P.ld_out + P.copy_col + d] = lv[0][t];
 }
 
 // ---------------------------------------------------------------------------

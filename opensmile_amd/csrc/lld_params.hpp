@@ -132,6 +132,7 @@ struct ChainParams {
   const int32_t *tile_t0;      // [n_tiles] first output row of the tile
   int32_t n_tiles;
   int32_t n_utt;
+  int32_t copy_col;            // >= 0: also copy level 0 (the input block) to this output column; -1: no copy
   const float *x;              // level 0
   int64_t ld_x;
   float *out;

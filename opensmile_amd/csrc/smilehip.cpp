@@ -110,6 +110,7 @@ struct smilehip_batch {
   int64_t total_rows = 0;
   DevBuf<int64_t> d_row_off;
   DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
+  DevBuf<float> d_static;       // MFCC chain with deltas: compact static block, total_frames x n_mfcc
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;
@@ -566,6 +567,14 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
     (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
   }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC && plan->cfg.n_delta > 0 && plan->ctx && b->total_frames > 0) {
+    const size_t n = size_t(b->total_frames) * size_t(plan->dct.n_mfcc);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the static-block scratch failed");
+    }
+    b->d_static.n = n;
+  }
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
     std::vector<float> zero;   // allocate only
     b->d_raw16.release();
@@ -629,8 +638,10 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.log_floor = p->dct.log_floor;
 }
 
-extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, float *d_io, int64_t ld, int32_t D,
-                                    int32_t W, int32_t n_orders, void *stream) {
+// R13 for a batch whose rows == frames: level 0 = x (leading dimension ld_x); writes [copy of x at copy_col (if >= 0) |
+// order 1 at D | order 2 at 2D] into out
+static int delta_chain_from(smilehip_plan *plan, smilehip_batch *b, const float *d_x, int64_t ld_x, int copy_col, float *d_io,
+                            int64_t ld, int32_t D, int32_t W, int32_t n_orders, void *stream) {
   if (!plan || !b || !d_io) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: null argument");
   if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 16 || ld < (int64_t)D * (1 + n_orders))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
@@ -645,8 +656,9 @@ extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, floa
   Q.tile_t0 = b->d_dtile_t0.p;
   Q.n_tiles = b->n_dtiles;
   Q.n_utt = b->n_utt;
-  Q.x = d_io;
-  Q.ld_x = ld;
+  Q.x = d_x;
+  Q.ld_x = ld_x;
+  Q.copy_col = copy_col;
   Q.out = d_io;
   Q.ld_out = ld;
   Q.D = D;
@@ -663,6 +675,11 @@ extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, floa
   return SMILEHIP_OK;
 }
 
+extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, float *d_io, int64_t ld, int32_t D,
+                                    int32_t W, int32_t n_orders, void *stream) {
+  return delta_chain_from(plan, b, d_io, ld, -1, d_io, ld, D, W, n_orders, stream);
+}
+
 extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out,
                                  int64_t ld_out, void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
@@ -674,6 +691,14 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   hipStream_t s = (hipStream_t)stream;
   LldParams P;
   fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  // With deltas to follow, the static block goes to a compact [frames x n_mfcc] scratch: the frame kernel
+  // then writes whole lines, the window-chain kernel reads 1/3 of what it would read from 39-float rows,
+  // and writes every output row in one piece (static | delta | accel).
+  const bool compact = plan->cfg.n_delta > 0 && b->d_static.p != nullptr;
+  if (compact) {
+    P.out = b->d_static.p;
+    P.ld_out = plan->dct.n_mfcc;
+  }
   hipEvent_t *ev = plan->ev[plan->n_timed % smilehip_plan::kRing];
   if (plan->timing) {
     for (int i = 0; i < 3; ++i)
@@ -703,7 +728,9 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
   if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
   if (plan->cfg.n_delta > 0) {
-    int rc = smilehip_delta_chain(plan, b, d_out, ld_out, plan->dct.n_mfcc, plan->cfg.delta_win, plan->cfg.n_delta, stream);
+    int rc = compact ? delta_chain_from(plan, b, b->d_static.p, plan->dct.n_mfcc, 0, d_out, ld_out, plan->dct.n_mfcc,
+                                        plan->cfg.delta_win, plan->cfg.n_delta, stream)
+                     : smilehip_delta_chain(plan, b, d_out, ld_out, plan->dct.n_mfcc, plan->cfg.delta_win, plan->cfg.n_delta, stream);
     if (rc) return rc;
   }
   if (plan->timing) {
@@ -742,6 +769,7 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
   Q.n_utt = b->n_utt;
   Q.x = b->d_raw16.p;
   Q.ld_x = 16;
+  Q.copy_col = -1;
   Q.out = d_out;
   Q.ld_out = ld_out;
   Q.D = 16;
@@ -801,6 +829,7 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   C.n_utt = b->n_utt;
   C.x = b->d_rawB.p;
   C.ld_x = 55;
+  C.copy_col = -1;
   C.out = d_out;
   C.ld_out = ld_out;
   C.D = 55;
