@@ -106,6 +106,9 @@ typedef struct smilehip_lld_config {
    *     Uses cEnergy rms (src/lldcore/energy.cpp:152-168) on the windowed frame, cMZcr zcr
    *     (src/lldcore/mzcr.cpp:109-126) on the raw frame, two cAcf instances
    *     (src/dspcore/acf.cpp:249-349) and cPitchACF (src/lldcore/pitchACF.cpp:137-247).
+   *   SMILEHIP_CHAIN_PLP: config/plp/PLP_0_D_A.conf: the MFCC chain with cPlp in cMfcc's place
+   *     (src/lldcore/plp.cpp:416-593 with doAud = doIDFT = doLP = doLpToCeps = 1, htkcompatible = 1):
+   *     [plp c1..c_lpOrder, c0 | delta | accel]; cep_lifter is cPlp's cepLifter.
    *   SMILEHIP_CHAIN_COMPARE_AB: ComParE_2016's LLD groups A and B as its LLD sinks see them
    *     (config/compare16/ComParE_2016_core.lld.conf.inc; columns 6..64 and 71..129 of the
    *     130-column lld;lld_de file): 59 columns
@@ -117,6 +120,8 @@ typedef struct smilehip_lld_config {
    *     cVectorOperation ll1 (src/other/vectorOperation.cpp:475-481). The F0 group (SHS pitch,
    *     Viterbi, jitter) is out of scope. Utterances with T60 < 4 yield no rows. */
   int32_t  chain_kind;
+  int32_t  plp_lp_order;                /* SMILEHIP_CHAIN_PLP: cPlp lpOrder (outputs lpOrder+1 cepstra, c0 last) */
+  float    plp_compression;             /* cPlp compression */
   double   pitch_max;                   /* cPitchACF maxPitch */
   double   voicing_cutoff;              /* cPitchACF voicingCutoff */
   int32_t  sma_win;                     /* cContourSmoother smaWin (odd) */
@@ -128,6 +133,7 @@ typedef struct smilehip_lld_config {
 #define SMILEHIP_CHAIN_MFCC 0
 #define SMILEHIP_CHAIN_IS09 1
 #define SMILEHIP_CHAIN_COMPARE_AB 2
+#define SMILEHIP_CHAIN_PLP 3
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -166,6 +172,8 @@ int  smilehip_device_name(smilehip_context *ctx, char *buf, int buflen);
 /* fills c with the LLD part of config/is09-13/IS09_emotion.conf (chain_kind = IS09) */
 void smilehip_config_is09_lld(smilehip_lld_config *c);
 
+/* fills c with config/plp/PLP_0_D_A.conf (chain_kind = PLP): 6 PLP cepstra + delta + accel */
+void smilehip_config_plp_0_d_a(smilehip_lld_config *c);
 /* fills c with groups A+B of config/compare16/ComParE_2016.conf (chain_kind = COMPARE_AB) */
 void smilehip_config_compare16_ab(smilehip_lld_config *c);
 

@@ -36,7 +36,7 @@ class LldConfig(C.Structure):
         ("first_mfcc", C.c_int32), ("last_mfcc", C.c_int32), ("cep_lifter", C.c_float),
         ("mfcc_htk_compatible", C.c_int32), ("melfloor", C.c_float),
         ("n_delta", C.c_int32), ("delta_win", C.c_int32),
-        ("chain_kind", C.c_int32), ("pitch_max", C.c_double), ("voicing_cutoff", C.c_double),
+        ("chain_kind", C.c_int32), ("plp_lp_order", C.c_int32), ("plp_compression", C.c_float), ("pitch_max", C.c_double), ("voicing_cutoff", C.c_double),
         ("sma_win", C.c_int32),
         ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
         ("stage_mask", C.c_uint32),
@@ -63,6 +63,7 @@ SYMBOLS = {
     "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_plp_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
     "smilehip_functionals_is09_mask": (C.c_uint32, []),
     "smilehip_functionals_count": (C.c_int, [C.c_uint32]),
@@ -141,6 +142,12 @@ def load():
 def _check(rc):
     if rc != 0:
         raise SmileHipError(f"smilehip error {rc}: {load().smilehip_last_error().decode()}")
+
+
+def plp_0_d_a_config():
+    c = LldConfig()
+    load().smilehip_config_plp_0_d_a(C.byref(c))
+    return c
 
 
 def compare16_ab_config():

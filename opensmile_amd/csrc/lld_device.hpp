@@ -101,4 +101,50 @@ __device__ __forceinline__ float dct_coeff(const float *lmel, const float *row_c
   return acc * gain;
 }
 
+// R8, PLP-CC branch of cPlp::processVector (plp.cpp:522-583, htkcompatible = 1, firstCC = 0):
+// autocorrelation by the IDFT cosine table (double accumulate) for lag i ...
+__device__ __forceinline__ float plp_acf_lag(const float *aud, const float *cosrow, int n_bands) {
+  const int nFreq = n_bands + 2;
+  double tmp = (double)cosrow[0] * (double)aud[0];
+  int m;
+  for (m = 1; m < nFreq - 1; m++) tmp += (double)cosrow[m] * (double)aud[m - 1];
+  tmp += (double)cosrow[m] * (double)aud[nFreq - 3];
+  return (float)(tmp / (2.0 * (nFreq - 1)));
+}
+// ... then Durbin (smileDsp_calcLpcAcf, smileUtil.c:1572-1630), LP -> cepstra (smileDsp_lpToCeps, :1532-1556) and the
+// lifter, all in the reference's float sequence; p <= 15. out: c1..cp, c0 (HTK order).
+__device__ __forceinline__ void plp_cc_serial(const float *r, int p, const float *sintable, float *out) {
+  float a[16], ceps[16];
+  for (int i = 0; i < 16; ++i) { a[i] = 0.0f; ceps[i] = 0.0f; }
+  float gain = 0.0f;
+  if (!((r[0] == 0.0f) || (r[0] == -0.0f))) {
+    float e = r[0];
+    for (int m = 1; m <= p; m++) {
+      float sum = (float)1.0 * r[m];
+      for (int i = 1; i < m; i++) sum += a[i - 1] * r[m - i];
+      const float k_m = ((float)-1.0 / e) * sum;
+      a[m - 1] = k_m;
+      for (int i = 1; i <= m / 2; i++) {
+        const float x = a[i - 1];
+        a[i - 1] += k_m * a[m - i - 1];
+        if ((i < (m / 2)) || ((m & 1) == 1)) a[m - i - 1] += k_m * x;
+      }
+      e *= ((float)1.0 - k_m * k_m);
+      if (e == 0.0f) { for (int i = m; i < p; i++) a[i] = 0.0f; break; }
+    }
+    gain = e;
+  }
+  if (gain <= 0) gain = (float)1.0;
+  for (int n = 1; n <= p; n++) {
+    double sum = 0;
+    for (int i = 1; i < n; i++) sum += (n - i) * a[i - 1] * ceps[n - i - 1];
+    ceps[n - 1] = -(a[n - 1] + (float)(sum / (double)n));
+  }
+  ceps[p] = (float)(-log(1.0 / (double)gain));            // zeroth coefficient goes last
+  for (int i = 0; i <= p; i++) {
+    const int i1 = (i == p) ? 0 : i + 1;
+    out[i] = ceps[i] * sintable[i1];
+  }
+}
+
 }  // namespace smilehip

@@ -86,6 +86,25 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
   for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x)
     lmel[b] = mel_band_exact(pw, P.mel_coef, P.mel_rng, b, P.mel_scale);
   __syncthreads();
+  if (P.plp) {
+    // R8 cPlp with IDFT / LP / cepstra (plp.cpp:499-583): auditory spectrum, autocorrelation, Durbin, cepstra, lifter
+    float *acf = lmel + P.n_bands;                      // 16 floats of slack behind the bands
+    for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x) {
+      float v = lmel[b];
+      if (v < P.melfloor) v = P.melfloor;
+      v *= P.plp_eql[b];
+      lmel[b] = (float)pow((double)v, (double)P.plp_compression);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= P.plp_order; i += blockDim.x) acf[i] = plp_acf_lag(lmel, P.plp_cos + i * (P.n_bands + 2), P.n_bands);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float o[16];
+      plp_cc_serial(acf, P.plp_order, P.plp_sin, o);
+      for (int r = 0; r <= P.plp_order; ++r) P.out[row * P.ld_out + r] = o[r];
+    }
+    return;
+  }
   // log floor, mfcc.cpp:239-243
   for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x)
     lmel[b] = log_mel(lmel[b], P.melfloor, P.log_floor);
@@ -251,7 +270,7 @@ __global__ void __launch_bounds__(64) lld_chain_short(ChainParams P) {
 // ---------------------------------------------------------------------------
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   const int M = P.Nfft / 2;
-  const size_t lds = sizeof(float) * (size_t)(2 * M + P.K + 1 + P.n_bands + 8);
+  const size_t lds = sizeof(float) * (size_t)(2 * M + P.K + 1 + P.n_bands + 24);
   hipLaunchKernelGGL(lld_mfcc_generic, dim3((unsigned)P.total_frames), dim3(256), lds, s, P);
   return hipGetLastError();
 }

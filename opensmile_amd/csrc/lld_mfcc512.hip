@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   uint32_t *s_melo = reinterpret_cast<uint32_t *>(s_melw1 + U * 16);
   float *s_dct = reinterpret_cast<float *>(s_melo + U * 16);
   int32_t *s_slots = reinterpret_cast<int32_t *>(s_dct + 16 * 28);
-  const int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 9 + 16 * 28 + 64;
+  float *s_plp = reinterpret_cast<float *>(s_slots + 64);            // PLP chain: eql[32] | sintable[16]
+  const int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 9 + 16 * 28 + 64 + 48;
   const int wave_floats = wave_region_floats(stage_alloc);
   float *wbase = smem + shared_floats + wave * wave_floats;
   float *s_stage = wbase;
@@ -260,6 +261,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   }
   for (int i = threadIdx.x; i < 16 * 28; i += blockDim.x) s_dct[i] = F.dct28[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
+  if (P.plp) {
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) s_plp[i] = F.plp_eql[i];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) s_plp[32 + i] = F.plp_sin[i];
+  }
   __syncthreads();
 
   const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;    // my cell relative to the pass's first output row
@@ -467,7 +472,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       if (b < P.n_bands) {
         float acc = 0.0f;
         for (int s = s_slots[2 * b]; s < s_slots[2 * b + 1]; ++s) acc += s_ps[s];
-        s_lmel[b] = log_mel_fast(acc * F.mel_scale, P.melfloor, P.log_floor);
+        if (P.plp) {                                   // R8: floor, HTK equal loudness, power-law compression (plp.cpp:499-507)
+          float v = acc * F.mel_scale;
+          v = v < P.melfloor ? P.melfloor : v;
+          s_lmel[b] = __expf(P.plp_compression * __logf(v * s_plp[b]));
+        } else {
+          s_lmel[b] = log_mel_fast(acc * F.mel_scale, P.melfloor, P.log_floor);
+        }
       } else {
         s_lmel[b] = 0.0f;
       }
@@ -475,6 +486,16 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     wave_lds_fence();
 
     PHASE(9);                                   // band sums + log
+    // ------------------------------------------------------------ PLP-CC (R8): IDFT rows (s_dct holds the cosine
+    // table, same 28-float rows), then Durbin + cepstra + lifter on the group's lane 0
+    if (P.plp) {
+      float *s_acf = s_lmel + 32;                       // 16 floats behind the padded band vector
+      if (j <= P.plp_order) s_acf[j] = plp_acf_lag(s_lmel, s_dct + j * 28, P.n_bands);
+      wave_lds_fence();
+      if (j == 0) plp_cc_serial(s_acf, P.plp_order, s_plp + 32, s_ps);       // the partial-sum slots are dead here
+      wave_lds_fence();
+      if (j < P.n_mfcc) pend_val = s_ps[j];
+    } else
     // ------------------------------------------------------------ DCT + lifter (R7)
     if (j < P.n_mfcc) {
       const float4 *row_c = reinterpret_cast<const float4 *>(s_dct + j * 28);
@@ -614,7 +635,7 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 }
 
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
-  const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64;
+  const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64 + 48;
   const int wave_floats = wave_region_floats(h.stage_alloc);
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
   unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);

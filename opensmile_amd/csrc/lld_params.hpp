@@ -49,6 +49,13 @@ struct LldParams {
   const float *dct_gain;       // [n_mfcc]
   int32_t n_mfcc;
   float melfloor, log_floor;
+  // R8 PLP-CC instead of R7 (SMILEHIP_CHAIN_PLP): cPlp after the mel bank
+  int32_t plp;                 // 0 = cMfcc, 1 = cPlp (n_mfcc = lp_order + 1 outputs)
+  int32_t plp_order;
+  float plp_compression;
+  const float *plp_eql;        // [n_bands] HTK equal-loudness weights at the band centres
+  const float *plp_cos;        // [(lp_order+1) x (n_bands+2)] IDFT cosine table
+  const float *plp_sin;        // [lp_order+1] lifter table
 };
 
 // Device-side tables of the fast Nfft=512 kernel (lld_mfcc512.hip)
@@ -64,6 +71,8 @@ struct Fast512Tables {
   int32_t n_slots;
   int32_t stage_floats, stage_alloc;
   float mel_scale;
+  const float *plp_eql;       // PLP chain: [32] equal-loudness weights (dct28 then holds the IDFT cosine rows)
+  const float *plp_sin;       // [16] lifter table
 };
 
 // Extra parameters of the IS09 LLD frame kernel (lld_is09.hip)

@@ -83,6 +83,8 @@ struct smilehip_plan {
   Fast512Host fast;
   bool use_fast = false;
   DevBuf<float> d_eql, d_eql_log;
+  DevBuf<float> d_plp_eql, d_plp_cos, d_plp_sin;     // PLP chain tables
+  std::vector<float> h_plp_cos;
   DevBuf<double> d_sharp;
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
   int32_t band_iL[2] = {0, 0}, band_iR[2] = {0, 0};
@@ -223,6 +225,16 @@ extern "C" void smilehip_config_is09_lld(smilehip_lld_config *c) {
   c->sma_win = 3;
 }
 
+extern "C" void smilehip_config_plp_0_d_a(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);        // same front end: 25 ms / 10 ms, k = 0.97, ham, 26 HTK mel bands
+  c->chain_kind = SMILEHIP_CHAIN_PLP;
+  c->plp_lp_order = 5;                    // [plp:cPlp] lpOrder = 5, compression = 0.33, cepLifter = 22
+  c->plp_compression = 0.33f;
+  c->cep_lifter = 22.0f;
+  c->first_mfcc = 0;
+  c->last_mfcc = 5;
+}
+
 extern "C" void smilehip_config_compare16_ab(smilehip_lld_config *c) {
   smilehip_config_mfcc12_0_d_a(c);
   c->chain_kind = SMILEHIP_CHAIN_COMPARE_AB;
@@ -269,6 +281,12 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
         p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
       return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_PLP) {
+    if (mask != SMILEHIP_STAGE_ALL || p->cfg.plp_lp_order < 1 || p->cfg.plp_lp_order > 15 || !p->cfg.mel_htk_compatible ||
+        !p->cfg.use_power || p->mel.n_bands > 30 || p->cfg.plp_compression < 0.0f)
+      return fail(SMILEHIP_ERR_INVALID, "PLP chain: lpOrder 1..15, HTK-scaled power mel bands (<= 30) required");
+    p->dct.n_mfcc = p->cfg.plp_lp_order + 1;            // outputs of the chain's static block
+    p->dct.melfloor = 1.0f;                              // htkcompatible forces melfloor = 1.0 (plp.cpp:150-160)
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
     return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
   }
@@ -292,11 +310,39 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     rng[4 * b + 2] = p->mel.fall_lo[b];
     rng[4 * b + 3] = p->mel.fall_hi[b];
   }
+  // PLP chain: cPlp::initTables (plp.cpp:288-357): IDFT cosine table, lifter table, HTK equal-loudness weights at
+  // the band centres cMelspec publishes (melspec.cpp:408-412)
+  std::vector<float> plp_eql(32, 0.0f), plp_sin(16, 1.0f);
+  const bool is_plp = p->cfg.chain_kind == SMILEHIP_CHAIN_PLP;
+  if (is_plp) {
+    const int nB = p->mel.n_bands, nFreq = nB + 2, nAuto = p->cfg.plp_lp_order + 1;
+    p->h_plp_cos.assign(size_t(nAuto) * nFreq, 0.0f);
+    const float a = (float)M_PI / (float)(nFreq - 1);
+    for (int i = 0; i < nAuto; i++) {
+      const int ib = i * nFreq;
+      int m;
+      p->h_plp_cos[ib] = 1.0f;
+      for (m = 1; m < (nFreq - 1); m++) p->h_plp_cos[m + ib] = (float)(2.0 * std::cos(a * (double)i * (double)m));
+      p->h_plp_cos[m + ib] = (float)(std::cos(a * (double)i * (double)m));
+    }
+    const float L = (float)(int)p->cfg.cep_lifter;      // cepLifter is read with getInt (plp.cpp:142)
+    for (int i = 0; i < nAuto; i++)
+      plp_sin[i] = (L > 0.0f) ? ((float)1.0 + L / (float)2.0 * std::sin((float)M_PI * ((float)(i)) / L)) : 1.0f;
+    for (int m = 1; m <= nB; ++m) {
+      const double hz = 700.0 * (std::exp(double(p->mel.centres[m]) / 1127.0) - 1.0);
+      const double f2 = hz * hz, fs = f2 / (f2 + 1.6e5);
+      plp_eql[m - 1] = (float)(fs * fs * ((f2 + 1.44e6) / (f2 + 9.61e6)));   // smileDsp_equalLoudnessWeight_htk
+    }
+  }
   // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
   p->use_fast = false;
-  if (mask == SMILEHIP_STAGE_ALL && p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC && !p->force_generic &&
-      fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
+  if (mask == SMILEHIP_STAGE_ALL && (p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || (is_plp && p->mel.n_bands == 26)) &&
+      !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
     p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
+    if (p->use_fast && is_plp) {                          // the DCT rows' place holds the IDFT cosine rows (28 floats each)
+      p->fast.dct28.assign(16 * 28, 0.0f);
+      std::copy(p->h_plp_cos.begin(), p->h_plp_cos.end(), p->fast.dct28.begin());
+    }
     if (p->ctx) p->fast.max_blocks = 2 * p->ctx->prop.multiProcessorCount;
   }
   if (!upload) return SMILEHIP_OK;
@@ -307,6 +353,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
   if ((rc = p->d_tw_half.upload(twh))) return rc;
   if ((rc = p->d_tw_full.upload(twf))) return rc;
+  if (is_plp && ((rc = p->d_plp_eql.upload(plp_eql)) || (rc = p->d_plp_cos.upload(p->h_plp_cos)) || (rc = p->d_plp_sin.upload(plp_sin))))
+    return rc;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
     // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
     // publishes as metadata (melspec.cpp:408-412), and the newRASTA filter coefficients
@@ -462,7 +510,8 @@ extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
 
 extern "C" double smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row) {
   if (!plan || row < 0) return 0.0;
-  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || n_frames <= 1) return smilehip_frame_time(plan, row);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP || n_frames <= 1)
+    return smilehip_frame_time(plan, row);
   return smilehip_frame_time(plan, row < n_frames - 1 ? row : n_frames - 1);
 }
 
@@ -567,7 +616,8 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
     (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
   }
-  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC && plan->cfg.n_delta > 0 && plan->ctx && b->total_frames > 0) {
+  if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
+      plan->ctx && b->total_frames > 0) {
     const size_t n = size_t(b->total_frames) * size_t(plan->dct.n_mfcc);
     if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
       delete b;
@@ -636,6 +686,12 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.n_mfcc = p->dct.n_mfcc;
   P.melfloor = p->dct.melfloor;
   P.log_floor = p->dct.log_floor;
+  P.plp = p->cfg.chain_kind == SMILEHIP_CHAIN_PLP;
+  P.plp_order = p->cfg.plp_lp_order;
+  P.plp_compression = p->cfg.plp_compression;
+  P.plp_eql = p->d_plp_eql.p;
+  P.plp_cos = p->d_plp_cos.p;
+  P.plp_sin = p->d_plp_sin.p;
 }
 
 // R13 for a batch whose rows == frames: level 0 = x (leading dimension ld_x); writes [copy of x at copy_col (if >= 0) |
@@ -683,7 +739,8 @@ extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, floa
 extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out,
                                  int64_t ld_out, void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
-  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan is not an MFCC chain (use smilehip_lld_run)");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC && plan->cfg.chain_kind != SMILEHIP_CHAIN_PLP)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan is not an MFCC / PLP chain (use smilehip_lld_run)");
   const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
   if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
@@ -720,6 +777,8 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     F.stage_floats = plan->fast.stage_floats;
     F.stage_alloc = plan->fast.stage_alloc;
     F.mel_scale = plan->fast.mel_scale;
+    F.plp_eql = plan->d_plp_eql.p;
+    F.plp_sin = plan->d_plp_sin.p;
     const bool aligned = b->all_even && ((reinterpret_cast<uintptr_t>(d_pcm) & 3) == 0);
     e = launch_mfcc512(P, F, plan->fast, aligned, s);
   } else {
@@ -922,7 +981,8 @@ extern "C" int smilehip_functionals_matrix(smilehip_context *ctx, const float *d
 extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,
                                 void *stream) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: plan/batch mismatch");
-  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC) return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP)
+    return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
 }

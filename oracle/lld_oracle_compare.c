@@ -404,3 +404,133 @@ long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float
   lldo_plp_free(&plp); lldo_plp_free(&plpr); lldo_spectral_free(&spec);
   return rows;
 }
+
+/* ------------------------------------------------------------- R8, PLP-CC branch */
+/* cPlp::processVector with doAud = doIDFT = doLP = doLpToCeps = 1, htkcompatible = 1, no log / RASTA
+ * (config/plp/PLP_0_D_A.conf [plp:cPlp]; src/lldcore/plp.cpp:416-593, tables :276-334):
+ * mel bands -> floor 1.0, HTK equal-loudness weights, pow(x, compression) -> IDFT by cosine table
+ * (double accumulate) -> Durbin (smileDsp_calcLpcAcf, smileUtil.c:1572-1630) -> cepstra
+ * (smileDsp_lpToCeps, :1532-1556) -> lifter; output order c1..c_lpOrder, c0 (HTK). */
+static double eql_weight_htk(double frequency)          /* smileDsp_equalLoudnessWeight_htk, smileUtil.c:1056-1062 */
+{
+  double f2 = (frequency * frequency);
+  double fs = f2 / (f2 + 1.6e5);
+  return fs * fs * ((f2 + 1.44e6) / (f2 + 9.61e6));
+}
+
+static void calc_lpc_acf(const float *r, float *a, int p, float *gain)
+{
+  int i, m;
+  float e, k_m;
+  if ((r[0] == 0.0) || (r[0] == -0.0)) { for (i = 0; i < p; i++) a[i] = 0.0; return; }   /* gain stays as the caller set it */
+  e = r[0];
+  for (m = 1; m <= p; m++) {
+    float sum = (float)1.0 * r[m];
+    for (i = 1; i < m; i++) sum += a[i - 1] * r[m - i];
+    k_m = ((float)-1.0 / e) * sum;
+    a[m - 1] = k_m;
+    for (i = 1; i <= m / 2; i++) {
+      float x = a[i - 1];
+      a[i - 1] += k_m * a[m - i - 1];
+      if ((i < (m / 2)) || ((m & 1) == 1)) a[m - i - 1] += k_m * x;
+    }
+    e *= ((float)1.0 - k_m * k_m);
+    if (e == 0.0) { for (i = m; i < p; i++) a[i] = 0.0; break; }
+  }
+  *gain = e;
+}
+
+static float lp_to_ceps(const float *lp, int nLp, float lpGain, float *ceps, int firstCC, int lastCC)
+{
+  if (firstCC < 1) firstCC = 1;
+  if (lastCC > nLp) lastCC = nLp;
+  for (int n = firstCC; n <= lastCC; n++) {
+    double sum = 0;
+    for (int i = 1; i < n; i++) sum += (n - i) * lp[i - 1] * ceps[n - i - 1];
+    ceps[n - firstCC] = -(lp[n - firstCC] + (float)(sum / (double)n));
+  }
+  if (lpGain <= 0.0) lpGain = (float)1.0;
+  return (float)(-log(1.0 / (double)lpGain));
+}
+
+/* band_hz: the band-centre metadata of the mel level; mel: n_bands values; out: lp_order + 1 values */
+void lldo_plp_cc(const float *mel, int n_bands, const double *band_hz, int lp_order, float compression, int cep_lifter_i,
+                 float *out)
+{
+  const float melfloor = 1.0f;                            /* htkcompatible forces melfloor = 1.0, plp.cpp:150-160 */
+  const int nFreq = n_bands + 2, nAuto = lp_order + 1, nCeps = lp_order + 1, firstCC = 0, lastCC = lp_order;
+  float *src = (float *)malloc(sizeof(float) * (size_t)n_bands);
+  float *costable = (float *)malloc(sizeof(float) * (size_t)nAuto * (size_t)nFreq);
+  float acf[32], lpc[32], ceps[32], sintable[32];
+  const float cepLifter = (float)cep_lifter_i;
+  int i, m;
+  /* initTables, plp.cpp:288-334 */
+  float a = (float)M_PI / (float)(nFreq - 1);
+  for (i = 0; i < nAuto; i++) {
+    int ib = i * nFreq;
+    costable[ib] = 1.0;
+    for (m = 1; m < (nFreq - 1); m++) costable[m + ib] = (float)(2.0 * cos(a * (double)i * (double)m));
+    costable[m + ib] = (float)(cos(a * (double)i * (double)m));
+  }
+  for (i = firstCC; i <= lastCC; i++) {
+    if (cepLifter > 0.0) sintable[i - firstCC] = ((float)1.0 + cepLifter / (float)2.0 * sinf((float)M_PI * ((float)(i)) / cepLifter));
+    else sintable[i - firstCC] = 1.0;
+  }
+  /* doAud, linear domain (:499-507) */
+  for (i = 0; i < n_bands; i++) {
+    float v = mel[i];
+    if (v < melfloor) v = melfloor;
+    v *= (float)eql_weight_htk(band_hz[i]);
+    src[i] = (float)pow((double)v, (double)compression);
+  }
+  /* IDFT (:522-532) */
+  for (i = 0; i < nAuto; i++) {
+    double tmp = (double)costable[i * nFreq] * (double)src[0];
+    for (m = 1; m < nFreq - 1; m++) tmp += (double)costable[m + i * nFreq] * (double)src[m - 1];
+    tmp += (double)costable[m + i * nFreq] * (double)src[nFreq - 3];
+    acf[i] = (float)(tmp / (2.0 * (nFreq - 1)));
+  }
+  float lpGain = 0.0f;
+  for (i = 0; i < 32; i++) { lpc[i] = 0.0f; ceps[i] = 0.0f; }
+  calc_lpc_acf(acf, lpc, lp_order, &lpGain);
+  if (lpGain <= 0) lpGain = (float)1.0;
+  float zeroth = lp_to_ceps(lpc, lp_order, lpGain, ceps, firstCC, lastCC);
+  ceps[nCeps - 1] = zeroth;                               /* htkcompatible && firstCC == 0 */
+  for (i = firstCC; i <= lastCC; i++) {
+    int i0 = i - firstCC, i1 = (i == lastCC) ? 0 : i0 + 1;
+    out[i0] = (cepLifter > 0.0) ? ceps[i0] * sintable[i1] : ceps[i0];
+  }
+  free(src); free(costable);
+}
+
+/* config/plp/PLP_0_D_A.conf: the MFCC12_0_D_A front end (R0-R6) -> cPlp -> delta -> accel; T x 18 */
+long lldo_plp_chain(const int16_t *pcm, long n_samples, float *out)
+{
+  lldo_mfcc_cfg c;
+  lldo_default_mfcc12_cfg(&c);
+  lldo_geom g;
+  lldo_geometry(&c, &g);
+  const long T = lldo_num_frames(n_samples, g.N, g.H);
+  if (!out || T <= 0) return T;
+  const int D = 6;
+  c.n_delta = 0;
+  float *mfcc = (float *)malloc(sizeof(float) * (size_t)T * 13);
+  float *mel = (float *)malloc(sizeof(float) * (size_t)T * 26);
+  lldo_mfcc_chain(&c, pcm, n_samples, mfcc, NULL, NULL, NULL, mel);
+  lldo_mel mb;
+  lldo_mel_init(&mb, g.K, g.frame_size_sec_fft, 26, c.lofreq, c.hifreq, c.use_power, c.mel_htk_compatible);
+  double band_hz[26];
+  for (int m = 1; m <= 26; m++) band_hz[m - 1] = 700.0 * (exp((double)mb.cfs[m] / 1127.0) - 1.0);   /* melspec.cpp:408-412 */
+  float *st = (float *)malloc(sizeof(float) * (size_t)T * D);
+  for (long t = 0; t < T; t++) lldo_plp_cc(mel + t * 26, 26, band_hz, 5, (float)0.33, 22, st + t * D);
+  /* R13: [static | delta | accel], orders stored order-major by lldo_delta_chain */
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)T * D * 2);
+  lldo_delta_chain(st, T, D, 2, 2, tmp);
+  for (long t = 0; t < T; t++) {
+    memcpy(out + t * 3 * D, st + t * D, sizeof(float) * D);
+    for (int o = 1; o <= 2; o++) memcpy(out + t * 3 * D + o * D, tmp + ((size_t)(o - 1) * (size_t)T + (size_t)t) * D, sizeof(float) * D);
+  }
+  lldo_mel_free(&mb);
+  free(mfcc); free(mel); free(st); free(tmp);
+  return T;
+}

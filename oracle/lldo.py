@@ -309,6 +309,19 @@ def functionals(x, mask=FUNC_IS09):
     return out
 
 
+def plp_chain(pcm):
+    """config/plp/PLP_0_D_A.conf: T x 18 [plp c1..c5,c0 | delta | accel]."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_plp_chain.restype = C.c_long
+    L.lldo_plp_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    T = L.lldo_plp_chain(pcm.ctypes.data, len(pcm), None)
+    out = np.zeros((max(T, 0), 18), np.float32)
+    if T > 0:
+        L.lldo_plp_chain(pcm.ctypes.data, len(pcm), out.ctypes.data)
+    return out
+
+
 def compare_ab_chain(pcm, raw=False):
     """ComParE_2016 LLD groups A+B as the LLD sinks see them: rows x 118 [, rows-1 x 59 pre-SMA]."""
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)

@@ -53,6 +53,12 @@ def golden_func():
 
 
 @pytest.fixture(scope="session")
+def golden_plp():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "plp_0_d_a_synth.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_compare():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "compare16_ab_synth.npz"))

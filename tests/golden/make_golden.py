@@ -34,11 +34,28 @@ def gen_func():
     np.savez_compressed(os.path.join(OUT, "is09_func_synth.npz"), **ref)
 
 
+def gen_plp():
+    # config/plp/PLP_0_D_A.conf (PLP-CC + delta + accel, 18 columns): R8's IDFT / LP / cepstrum branch
+    ref = {}
+    for name, (u, n) in {"u2_16000": (2, 16000), "u3_16000": (3, 16000), "u10_16000": (10, 16000), "u1_16000": (1, 16000),
+                          "u0_16000": (0, 16000), "u7_399": (7, 399), "u7_400": (7, 400), "u7_560": (7, 560),
+                          "u7_1000": (7, 1000), "u5_160000": (5, 160000)}.items():
+        pcm = synth.utterance(u, n)
+        y = lldo.run_reference("plp/PLP_0_D_A.conf", pcm)
+        ref["pcm_" + name] = pcm
+        ref["out_" + name] = y if y.size else np.zeros((0, 18), np.float32)
+        print("plp", name, y.shape)
+    np.savez_compressed(os.path.join(OUT, "plp_0_d_a_synth.npz"), **ref)
+
+
 def main(only=None):
     lldo.build()
     assert lldo.have_ref(), "oracle/_ref/SMILExtract missing (needs /root/reference)"
     if only == "func":
         gen_func()
+        return
+    if only == "plp":
+        gen_plp()
         return
     # config 2 shape, shortened: utterances 0 (zeros), 1 (square), 2, 3 (voiced), 10 (noise)
     # at 1.0 s, plus ragged lengths around the frame boundary (399/400/401/559/560/561 samples)
@@ -82,6 +99,7 @@ def main(only=None):
     np.savez_compressed(os.path.join(OUT, "compare16_ab_synth.npz"), **ref)
 
     gen_func()
+    gen_plp()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
