@@ -388,6 +388,13 @@ int smilehip_spectral_frames(smilehip_plan *plan, const float *d_mag, int64_t ld
 int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
                                 float melfloor, float compression, int new_rasta, const float *rasta_coef, float *d_state,
                                 float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R8: cPlp::processVector producing PLP cepstra (doAud = doIDFT = doLP = doLpToCeps = 1, htkcompatible = 1,
+ * firstCC = 0; plp.cpp:499-583): n_bands mel values in, lp_order + 1 cepstra out (c1..c_lpOrder, c0).
+ * d_eql: HTK equal-loudness weights of the bands; d_cos: the (lp_order+1) x (n_bands+2) IDFT cosine table and
+ * d_sin: the lp_order+1 lifter values of cPlp::initTables (plp.cpp:288-334), all device arrays. */
+int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                           float melfloor, float compression, int lp_order, const float *d_cos, const float *d_sin,
+                           float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
 /* R13: cDeltaRegression::processBuffer (kind 0, deltaRegression.cpp:144-152, norm = 2*sum i^2) and
  * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
  * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */

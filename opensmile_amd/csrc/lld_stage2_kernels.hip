@@ -128,6 +128,30 @@ __global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int n
   if (b == 0) state[4 * nB] = (float)init;
 }
 
+// R8 cPlp::processVector with doAud = doIDFT = doLP = doLpToCeps = 1, htkcompatible = 1 (PLP cepstra, plp.cpp:499-583):
+// one 64-thread workgroup per frame. LDS: aud[n_bands] | acf[16]
+__global__ void __launch_bounds__(64) k_plp_cc(const float *src, int64_t lds, int nB, const float *eql, float melfloor,
+                                               float compression, int order, const float *costab, const float *sintab,
+                                               float *dst, int64_t ldd) {
+  __shared__ float aud[64], acf[16];
+  const float *m = src + (int64_t)blockIdx.x * lds;
+  const int b = threadIdx.x;
+  if (b < nB) {
+    float v = m[b];
+    if (v < melfloor) v = melfloor;
+    v *= eql[b];
+    aud[b] = (float)pow((double)v, (double)compression);
+  }
+  __syncthreads();
+  if (b <= order) acf[b] = plp_acf_lag(aud, costab + b * (nB + 2), nB);
+  __syncthreads();
+  if (b == 0) {
+    float o[16];
+    plp_cc_serial(acf, order, sintab, o);
+    for (int r = 0; r <= order; ++r) dst[(int64_t)blockIdx.x * ldd + r] = o[r];
+  }
+}
+
 static inline unsigned nblk2(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s) {
@@ -163,6 +187,13 @@ hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool firs
 hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, bool rasta, float *state,
                      float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
   if (nF > 0) hipLaunchKernelGGL(k_plp, dim3(1), dim3(64), 0, s, src, lds, n_bands, eql, Q, rasta ? 1 : 0, state, dst, ldd, nF);
+  return hipGetLastError();
+}
+hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,
+                        int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
+  if (nF > 0)
+    hipLaunchKernelGGL(k_plp_cc, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n_bands, eql, melfloor, compression, order, costab,
+                       sintab, dst, ldd);
   return hipGetLastError();
 }
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {

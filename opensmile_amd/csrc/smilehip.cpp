@@ -1180,6 +1180,17 @@ extern "C" int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d
   STAGE_RET(stage_plp(d_mel, ld_src, n_bands, d_eql, Q, new_rasta != 0, d_state, d_dst, ld_dst, n_frames, (hipStream_t)stream), "plp");
 }
 
+extern "C" int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                                      float melfloor, float compression, int lp_order, const float *d_cos, const float *d_sin,
+                                      float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!ctx || n_bands < 2 || n_bands > 64 || lp_order < 1 || lp_order > 15 || !d_eql || !d_cos || !d_sin)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_cc_frames: bad argument (2..64 bands, lpOrder 1..15)");
+  int rc = check_frames(d_mel, d_dst, ld_src, ld_dst, n_frames, n_bands, lp_order + 1, "smilehip_plp_cc_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_plp_cc(d_mel, ld_src, n_bands, d_eql, melfloor, compression, lp_order, d_cos, d_sin, d_dst, ld_dst, n_frames,
+                         (hipStream_t)stream), "plp_cc");
+}
+
 extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,
                                       void *stream) {
   if (!ctx || n_t < 0 || W < 1 || (kind != 0 && kind != 1) || (n_t > 0 && (!d_x || !d_y)))

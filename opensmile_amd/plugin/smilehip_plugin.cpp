@@ -697,9 +697,9 @@ class cHipSpectral : public cSpectral {
 // R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
 class cHipPlp : public cPlp {
   FrameIO io_;
-  DevBytes eql_[8], state_[8];
+  DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1, newRasta_ = 0;
+  int plain_ = -1, newRasta_ = 0, cc_ = 0, lpOrder_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
  protected:
@@ -716,6 +716,12 @@ class cHipPlp : public cPlp {
       melfloor_ = (FLOAT_DMEM)getDouble("melfloor");
       const bool logs_ok = newRasta_ ? true : (!getInt("doLog") && !getInt("doInvLog"));
       plain_ = (getInt("doAud") && !doIDFT && !doLP && !rasta && !getInt("htkcompatible") && logs_ok) ? 1 : 0;
+      // PLP cepstra in HTK mode (config/plp/*.conf): doAud -> IDFT -> LP -> cepstra, c0 last
+      lpOrder_ = getInt("lpOrder");
+      const int lastCC = getInt("lastCC"), nCeps = getInt("nCeps");
+      cc_ = (getInt("htkcompatible") && doIDFT && doLP && doLpToCeps && !rasta && !newRasta_ && getInt("firstCC") == 0 &&
+             lpOrder_ >= 1 && lpOrder_ <= 15 && (lastCC < 0 || lastCC == lpOrder_) && (nCeps < 0 || nCeps == lpOrder_ + 1)) ? 1 : 0;
+      if (cc_) { plain_ = 1; melfloor_ = 1.0; }           // htkcompatible forces melfloor = 1, doAud = 1, no logs (plp.cpp:150-160)
       if (newRasta_) {                                   // initTables, plp.cpp:381-399
         const FLOAT_DMEM lo = (FLOAT_DMEM)getDouble("rastaLowerCutoff"), up = (FLOAT_DMEM)getDouble("rastaUpperCutoff");
         coef_[0] = (FLOAT_DMEM)(1.0 - sin(2.0 * M_PI * lo * reader_->getLevelT()));
@@ -730,15 +736,36 @@ class cHipPlp : public cPlp {
     }
     const int fc = getFconf(idxi);
     const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
-    if (!plain_ || Nsrc != Ndst || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
+    if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
         (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
       return cPlp::processVector(src, dst, Nsrc, Ndst, idxi);   // PLP-CC (IDFT / LP / cepstra), old RASTA, HTK mode stay on the CPU
     if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
       const double *frq = (const double *)(fmeta->field[idxi].info);
       std::vector<float> e((size_t)Nsrc), st((size_t)(4 * Nsrc + 1), 0.0f);
       for (long i = 0; i < Nsrc; ++i) {
-        e[(size_t)i] = (FLOAT_DMEM)smileDsp_equalLoudnessWeight((double)frq[i]);
+        e[(size_t)i] = cc_ ? (FLOAT_DMEM)smileDsp_equalLoudnessWeight_htk((double)frq[i])
+                           : (FLOAT_DMEM)smileDsp_equalLoudnessWeight((double)frq[i]);
         if (newRasta_) e[(size_t)i] = log(e[(size_t)i]);
+      }
+      if (cc_) {                                         // IDFT cosine table and lifter, plp.cpp:288-334
+        const int nFreq = (int)Nsrc + 2, nAuto = lpOrder_ + 1;
+        std::vector<float> ct((size_t)nAuto * nFreq), sn((size_t)nAuto);
+        const FLOAT_DMEM a = (FLOAT_DMEM)M_PI / (FLOAT_DMEM)(nFreq - 1);
+        for (int i = 0; i < nAuto; i++) {
+          const int ib = i * nFreq;
+          int m;
+          ct[(size_t)ib] = 1.0;
+          for (m = 1; m < (nFreq - 1); m++) ct[(size_t)(m + ib)] = (FLOAT_DMEM)(2.0 * cos(a * (double)i * (double)m));
+          ct[(size_t)(m + ib)] = (FLOAT_DMEM)(cos(a * (double)i * (double)m));
+        }
+        const FLOAT_DMEM L = (FLOAT_DMEM)getInt("cepLifter");
+        for (int i = 0; i < nAuto; i++)
+          sn[(size_t)i] = (L > 0.0) ? ((FLOAT_DMEM)1.0 + L / (FLOAT_DMEM)2.0 * sin((FLOAT_DMEM)M_PI * ((FLOAT_DMEM)(i)) / L)) : (FLOAT_DMEM)1.0;
+        void *d_c = cos_[fc].ensure(sizeof(float) * ct.size());
+        void *d_n = sin_[fc].ensure(sizeof(float) * sn.size());
+        if (smilehip_copy_to_device(context(), d_c, ct.data(), sizeof(float) * ct.size(), nullptr) ||
+            smilehip_copy_to_device(context(), d_n, sn.data(), sizeof(float) * sn.size(), nullptr))
+          COMP_ERR("libsmilehip: %s", smilehip_last_error());
       }
       void *d_e = eql_[fc].ensure(sizeof(float) * e.size());
       void *d_s = state_[fc].ensure(sizeof(float) * st.size());
@@ -749,8 +776,12 @@ class cHipPlp : public cPlp {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
-                                      newRasta_, coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
+    if (cc_)
+      check(smilehip_plp_cc_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_, lpOrder_,
+                                   (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, Ndst, 1, nullptr));
+    else
+      check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
+                                        newRasta_, coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[13]++;
     return (int)Ndst;

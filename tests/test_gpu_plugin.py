@@ -164,3 +164,16 @@ def test_plugin_is09_functionals(oracle, golden_func):
         d = np.abs(y.astype(np.float64) - ref)
         assert (d <= 1e-5 * np.abs(ref) + 1e-12).all(), (k, float((d / np.maximum(np.abs(ref), 1e-30)).max()))
         assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.97
+
+
+def test_plugin_plp_cepstra_bit_exact(oracle, golden_plp):
+    """config/plp/PLP_0_D_A.conf, unmodified, with cPlp (PLP cepstra: IDFT, Durbin, LP -> cepstra, lifter) and the
+    delta components behind the plugin: same float sequence as the reference, pow through a correctly
+    rounded double pow -> the binary's output is reproduced bit for bit (or to 1 ulp of libm's pow)."""
+    for k in ("u2_16000", "u7_560"):
+        ref = golden_plp["out_" + k]
+        y, tr = _run(oracle, golden_plp["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cPlp,cDeltaRegression"}, "plp/PLP_0_D_A.conf")
+        assert y.shape == ref.shape and tr["cPlp"] == ref.shape[0] and tr["cMelspec"] == 0
+        scale = np.abs(ref[:, :6]).max(axis=1, keepdims=True)
+        assert (np.abs(y - ref) / scale).max() <= 1e-6
+        assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.95
