@@ -14,6 +14,13 @@ std::vector<std::string> lld_names_mfcc12_0_d_a() {
   return n;
 }
 
+std::vector<std::string> lld_names_plp_0_d_a() {          // cPlp names its cepstra "PlpCC" (plp.cpp setupNamesForField)
+  std::vector<std::string> n;
+  for (const char *suffix : {"", "_de", "_de_de"})
+    for (int i = 0; i <= 5; ++i) n.push_back(arr(std::string("PlpCC") + suffix, i));
+  return n;
+}
+
 std::vector<std::string> lld_names_is09() {
   std::vector<std::string> n;
   for (const char *suffix : {"_sma", "_sma_de"}) {

@@ -30,6 +30,7 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
 // Element names of a level, as cCsvSink/cArffSink obtain them from the data memory
 // (src/core/dataMemoryLevel.cpp naming: field name + "[index]" for array fields).
 std::vector<std::string> lld_names_mfcc12_0_d_a();
+std::vector<std::string> lld_names_plp_0_d_a();
 std::vector<std::string> lld_names_is09();
 std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
 

@@ -1,10 +1,11 @@
 // smilextract_hip -- batch front end of the fused GPU path for the two feature sets whose
-// whole graph the C ABI covers: config/mfcc/MFCC12_0_D_A.conf and config/is09-13/IS09_emotion.conf.
+// whole graph the C ABI covers: config/mfcc/MFCC12_0_D_A.conf, config/plp/PLP_0_D_A.conf and
+// config/is09-13/IS09_emotion.conf.
 // It is NOT a re-implementation of SMILExtract's config language (that stays with the
 // reference; unmodified configs run through the plugin): the set is picked
 // by name and the file options keep the names those configs declare via \cm[...]:
 //
-//   smilextract_hip --set mfcc12_0_d_a  (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
+//   smilextract_hip --set mfcc12_0_d_a|plp_0_d_a  (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
 //   smilextract_hip --set is09_emotion  (-I in.wav | -filelist list.txt) [-O func.arff] [-csvoutput func.csv]
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
@@ -62,7 +63,8 @@ int main(int argc, char **argv) {
   }
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
-  if (!is09 && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a or is09_emotion");
+  const bool plp = set == "plp_0_d_a";
+  if (!is09 && !plp && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a, plp_0_d_a or is09_emotion");
   std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
 
   std::vector<Job> jobs;
@@ -102,7 +104,7 @@ int main(int argc, char **argv) {
   check(smilehip_init(opt.count("--device") ? atoi(opt["--device"].c_str()) : 0, &ctx), "smilehip_init");
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
   const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
-  const std::vector<std::string> lld_names = is09 ? lld_names_is09() : lld_names_mfcc12_0_d_a();
+  const std::vector<std::string> lld_names = is09 ? lld_names_is09() : (plp ? lld_names_plp_0_d_a() : lld_names_mfcc12_0_d_a());
   const std::vector<std::string> fnames = is09 ? func_names_is09() : std::vector<std::string>();
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
@@ -123,7 +125,9 @@ int main(int argc, char **argv) {
       smilehip_plan *&plan = plans[kv.first];
       if (!plan) {
         smilehip_lld_config cfg;
-        if (is09) smilehip_config_is09_lld(&cfg); else smilehip_config_mfcc12_0_d_a(&cfg);
+        if (is09) smilehip_config_is09_lld(&cfg);
+        else if (plp) smilehip_config_plp_0_d_a(&cfg);
+        else smilehip_config_mfcc12_0_d_a(&cfg);
         cfg.sample_rate = (double)kv.first;
         check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
       }

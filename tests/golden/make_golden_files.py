@@ -34,6 +34,12 @@ def main():
                         "-csvoutput", os.path.join(td, "m.csv"), "-instname", "utt two", "-l", "0"], check=True, cwd=td)
         shutil.copy(os.path.join(td, "m.htk"), os.path.join(out, "mfcc_u2_8000.htk"))
         shutil.copy(os.path.join(td, "m.csv"), os.path.join(out, "mfcc_u2_8000.csv"))
+        # PLP_0_D_A: LLD level as HTK + CSV
+        conf = os.path.join(lldo.REF_DIR, "config", "plp", "PLP_0_D_A.conf")
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u2.wav"), "-O", os.path.join(td, "p.htk"),
+                        "-csvoutput", os.path.join(td, "p.csv"), "-l", "0"], check=True, cwd=td)
+        shutil.copy(os.path.join(td, "p.htk"), os.path.join(out, "plp_u2_8000.htk"))
+        shutil.copy(os.path.join(td, "p.csv"), os.path.join(out, "plp_u2_8000.csv"))
         # IS09_emotion: two files appended into one ARFF / functionals CSV; LLD CSV + HTK and the
         # functionals HTK of the second one (instance names exercise the ARFF escaping)
         conf = os.path.join(lldo.REF_DIR, "config", "is09-13", "IS09_emotion.conf")

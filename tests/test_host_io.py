@@ -178,3 +178,17 @@ def test_smilextract_hip_errors(tmp_path):
     r = subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-I", str(tmp_path / "missing.wav"), "-O", str(tmp_path / "o.htk")],
                        capture_output=True)
     assert r.returncode != 0 and b"cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_plp(tmp_path):
+    out_htk, out_csv = str(tmp_path / "p.htk"), str(tmp_path / "p.csv")
+    subprocess.run([EXE, "--set", "plp_0_d_a", "-I", os.path.join(G, "u2_8000.wav"), "-O", out_htk, "-csvoutput", out_csv], check=True)
+    h, x = read_htk(out_htk)
+    hr, xr = read_htk(os.path.join(G, "plp_u2_8000.htk"))
+    assert h == hr
+    scale = np.abs(xr[:, :6]).max(axis=1, keepdims=True)
+    assert (np.abs(x - xr) / scale).max() <= 1e-5
+    head, names, vals, _ = parse_csv(out_csv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "plp_u2_8000.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape
