@@ -110,8 +110,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL ("nccl" on ROCm). SMILEHIP_DIST_BACKEND=gloo lets two ranks share one GPU
+        # for a smoke test of this code path on a single-GPU box (tools/smoke_multirank.sh).
+        backend = os.environ.get("SMILEHIP_DIST_BACKEND", "nccl")
+        local_rank %= max(torch.cuda.device_count(), 1) if backend != "nccl" else 10 ** 9
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
