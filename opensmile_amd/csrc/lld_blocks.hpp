@@ -1,5 +1,9 @@
-// Block-level (256-thread workgroup) building blocks shared by the reference-order kernels:
-// reductions, the inverse real FFT cAcf needs, and cPitchACF's per-frame analysis.
+// Building blocks shared by the reference-order kernels: reductions, the half-length complex FFT,
+// the inverse real FFT cAcf needs, and cPitchACF's per-frame analysis. Every function is written
+// against a "group" policy G -- the set of threads that cooperates on one frame:
+//   BlockG  the whole 256-thread workgroup (barriers + LDS scratch for the reductions)
+//   WaveG   one 64-lane wave (no barriers at all: a wave's LDS operations execute in order, the
+//           reductions are cross-lane shuffles), so four frames proceed independently per workgroup
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -7,48 +11,106 @@
 
 namespace smilehip {
 
-// block-wide reductions over 256 threads through LDS scratch (all threads get the result)
-__device__ __forceinline__ double block_sum(double v, double *scr) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return scr[0] + scr[1] + scr[2] + scr[3];
-}
-__device__ __forceinline__ double block_max(double v, double *scr) {
-  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double m = scr[0];
-  for (int i = 1; i < 4; ++i) m = scr[i] > m ? scr[i] : m;
-  return m;
-}
-__device__ __forceinline__ int block_sum_i(int v, int *scr) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return scr[0] + scr[1] + scr[2] + scr[3];
-}
-__device__ __forceinline__ int block_min_i(int v, int *scr) {
-  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int m = scr[0];
-  for (int i = 1; i < 4; ++i) m = scr[i] < m ? scr[i] : m;
-  return m;
+struct BlockG {
+  __device__ static __forceinline__ int tid() { return threadIdx.x; }
+  __device__ static __forceinline__ int size() { return blockDim.x; }
+  __device__ static __forceinline__ void sync() { __syncthreads(); }
+  __device__ static __forceinline__ double sum(double v, double *scr) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scr[0] + scr[1] + scr[2] + scr[3];
+  }
+  __device__ static __forceinline__ double max(double v, double *scr) {
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double m = scr[0];
+    for (int i = 1; i < 4; ++i) m = scr[i] > m ? scr[i] : m;
+    return m;
+  }
+  __device__ static __forceinline__ int sum_i(int v, int *scr) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scr[0] + scr[1] + scr[2] + scr[3];
+  }
+  __device__ static __forceinline__ int min_i(int v, int *scr) {
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int m = scr[0];
+    for (int i = 1; i < 4; ++i) m = scr[i] < m ? scr[i] : m;
+    return m;
+  }
+};
+
+struct WaveG {
+  __device__ static __forceinline__ int tid() { return threadIdx.x & 63; }
+  __device__ static __forceinline__ int size() { return 64; }
+  __device__ static __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ static __forceinline__ double sum(double v, double *) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+  __device__ static __forceinline__ double max(double v, double *) {
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+  }
+  __device__ static __forceinline__ int sum_i(int v, int *) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+  __device__ static __forceinline__ int min_i(int v, int *) {
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+  }
+};
+
+// workgroup-wide shorthands used by the per-component kernels
+__device__ __forceinline__ double block_sum(double v, double *scr) { return BlockG::sum(v, scr); }
+__device__ __forceinline__ double block_max(double v, double *scr) { return BlockG::max(v, scr); }
+__device__ __forceinline__ int block_sum_i(int v, int *scr) { return BlockG::sum_i(v, scr); }
+__device__ __forceinline__ int block_min_i(int v, int *scr) { return BlockG::min_i(v, scr); }
+
+// R4 core: in-place radix-2 DIT complex FFT of length M in LDS (re/im loaded in bit-reversed order)
+template <class G>
+__device__ __forceinline__ void group_cfft_radix2(float *re, float *im, int M, const float2 *tw_half) {
+  for (int len = 2; len <= M; len <<= 1) {
+    const int half = len >> 1;
+    const int tstep = M / len;
+    for (int b = G::tid(); b < (M >> 1); b += G::size()) {
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j;
+      const int i1 = i0 + half;
+      const float2 w = tw_half[j * tstep];
+      const float xr = re[i1], xi = im[i1];
+      const float tr = fmaf(xr, w.x, -xi * w.y);
+      const float ti = fmaf(xr, w.y, xi * w.x);
+      const float ar = re[i0], ai = im[i0];
+      re[i1] = ar - tr; im[i1] = ai - ti;
+      re[i0] = ar + tr; im[i0] = ai + ti;
+    }
+    G::sync();
+  }
 }
 
 // Inverse of the packed real FFT for a purely real spectrum R[0..M] (what cAcf feeds
 // Ooura's rdft(n,-1), fftsg.c:103-135):  a[k] = R0/2 + R_M (-1)^k / 2 + sum_j R_j cos(2 pi jk/n).
 // Computed as half the forward DFT of the even extension s[j] = s[n-j] = R_j, through the
 // same half-length complex FFT + untangle the forward transform uses.
-__device__ void irfft_even(const float *R, float *re, float *im, int M, int logM, const float2 *tw_half,
-                           const float2 *tw_full, float *out, float inv_norm, bool take_abs) {
+template <class G>
+__device__ __forceinline__ void group_irfft_even(const float *R, float *re, float *im, int M, int logM, const float2 *tw_half,
+                                                 const float2 *tw_full, float *out, float inv_norm, bool take_abs) {
   const int n = 2 * M;
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+  for (int i = G::tid(); i < M; i += G::size()) {
     const int n0 = 2 * i, n1 = 2 * i + 1;
     const float v0 = R[n0 <= M ? n0 : n - n0];
     const float v1 = R[n1 <= M ? n1 : n - n1];
@@ -56,49 +118,57 @@ __device__ void irfft_even(const float *R, float *re, float *im, int M, int logM
     re[r] = v0;
     im[r] = v1;
   }
-  __syncthreads();
-  block_cfft_radix2(re, im, M, tw_half);
-  for (int k = threadIdx.x; k < M; k += blockDim.x) {
+  G::sync();
+  group_cfft_radix2<G>(re, im, M, tw_half);
+  for (int k = G::tid(); k < M; k += G::size()) {
     const float a = 0.5f * untangle_bin(re, im, M, k, tw_full).x;
     const float v = a / inv_norm;                       // acf.cpp:321-325: (FLOAT_DMEM)data / (FLOAT_DMEM)Nsrc
     out[k] = take_abs ? fabsf(v) : v;
   }
-  __syncthreads();
+  G::sync();
 }
-
+__device__ __forceinline__ void irfft_even(const float *R, float *re, float *im, int M, int logM, const float2 *tw_half,
+                                           const float2 *tw_full, float *out, float inv_norm, bool take_abs) {
+  group_irfft_even<BlockG>(R, re, im, M, logM, tw_half, tw_full, out, inv_norm, take_abs);
+}
 
 // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192): voicing probability from
 // the ACF (voicingProb, :249-284) and the index of the first cepstral peak above
 // 0.6 * (max + mean|.|) (pitchPeak, :286-310). acf / cep: n values each, in LDS or global.
-// Every thread returns the same (voicing, maxIdx).
-__device__ __forceinline__ void pitchacf_frame(const float *acf, const float *cep, int n, double fsSec, double maxPitch,
-                                               double *scr, int *iscr, double &voicing, int &max_idx, double &Tsamp_out) {
+// Every thread of the group returns the same (voicing, maxIdx).
+template <class G>
+__device__ __forceinline__ void group_pitchacf_frame(const float *acf, const float *cep, int n, double fsSec, double maxPitch,
+                                                     double *scr, int *iscr, double &voicing, int &max_idx, double &Tsamp_out) {
   const double Nd = (double)(2 * n);
   const double Tsamp = fsSec / Nd;
   Tsamp_out = Tsamp;
   const int preskip = (maxPitch <= 0.0) ? 0 : (int)(1.0 / (maxPitch * Tsamp));
   double vmax = acf[n - 1];
-  for (int i = 1 + threadIdx.x; i < n; i += blockDim.x)
+  for (int i = 1 + G::tid(); i < n; i += G::size())
     if (i >= preskip && (acf[i] > vmax) && (acf[i - 1] < acf[i])) vmax = acf[i];
   // (the reference's running-max test "a[i] > max" only ever raises max, so the result is the
   //  maximum over the qualifying set; taking it in parallel gives the same value)
-  vmax = block_max(vmax, scr);
+  vmax = G::max(vmax, scr);
   voicing = (acf[0] > 0.0f) ? vmax / (double)acf[0] : 0.0;
   const int skip = preskip + 1;
   double csum = 0.0, cmax = cep[n - 1];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = G::tid(); i < n; i += G::size()) {
     const double b = cep[i];
     csum += fabs(b);
     if (i >= skip && b > cmax) cmax = b;
   }
-  csum = block_sum(csum, scr) / n;
-  cmax = block_max(cmax, scr);
+  csum = G::sum(csum, scr) / n;
+  cmax = G::max(cmax, scr);
   const double thr = (cmax + csum) * 0.6;
   int first = 1 << 30;
-  for (int i = skip + 1 + threadIdx.x; i < n - 1; i += blockDim.x)
+  for (int i = skip + 1 + G::tid(); i < n - 1; i += G::size())
     if ((double)cep[i] > thr && (cep[i - 1] < cep[i]) && (cep[i] > cep[i + 1])) { first = i; break; }
-  first = block_min_i(first, iscr);
+  first = G::min_i(first, iscr);
   max_idx = (first == (1 << 30)) ? 0 : first;
+}
+__device__ __forceinline__ void pitchacf_frame(const float *acf, const float *cep, int n, double fsSec, double maxPitch,
+                                               double *scr, int *iscr, double &voicing, int &max_idx, double &Tsamp_out) {
+  group_pitchacf_frame<BlockG>(acf, cep, n, fsSec, maxPitch, scr, iscr, voicing, max_idx, Tsamp_out);
 }
 
 }  // namespace smilehip

@@ -7,6 +7,8 @@
 // not yet tuned (three LDS FFTs per frame).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lld_blocks.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
@@ -15,8 +17,8 @@
 namespace smilehip {
 
 // LDS: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
-__global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <class G>
+__device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Params &Q, int64_t row, float *smem) {
   const int M = P.Nfft >> 1;
   const int Npad = (P.N + 3) & ~3;
   float *xr = smem;
@@ -31,7 +33,6 @@ __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q)
   double *scr = reinterpret_cast<double *>(lmel + 32);
   int *iscr = reinterpret_cast<int *>(scr + 4);
 
-  const int64_t row = blockIdx.x;
   int lo = 0, hi = P.n_utt;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -43,20 +44,20 @@ __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q)
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
-  for (int n = threadIdx.x; n < P.N; n += blockDim.x) xr[n] = pcm16_to_float(x[n]);      // R0
-  __syncthreads();
+  for (int n = G::tid(); n < P.N; n += G::size()) xr[n] = pcm16_to_float(x[n]);      // R0
+  G::sync();
 
   // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
   {
     int cnt = 0;
-    for (int i = 1 + threadIdx.x; i < P.N - 1; i += blockDim.x)
+    for (int i = 1 + G::tid(); i < P.N - 1; i += G::size())
       if (((xr[i - 1] * xr[i + 1] <= 0.0f) && (xr[i] == 0.0f)) || (xr[i - 1] * xr[i] < 0.0f)) ++cnt;
-    const int total = block_sum_i(cnt, iscr);
-    if (threadIdx.x == 0) out[13] = (float)total / (float)P.N;
+    const int total = G::sum_i(cnt, iscr);
+    if (G::tid() == 0) out[13] = (float)total / (float)P.N;
   }
   // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
   double e2 = 0.0;
-  for (int n = threadIdx.x; n < P.N; n += blockDim.x) {
+  for (int n = G::tid(); n < P.N; n += G::size()) {
     float y = xr[n];
     if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
     y = y * P.window[n] + P.win_offset;
@@ -65,47 +66,47 @@ __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q)
     e2 += (double)sq;
   }
   {
-    const double d = block_sum(e2, scr);
-    if (threadIdx.x == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
+    const double d = G::sum(e2, scr);
+    if (G::tid() == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
   }
   // R4 forward real FFT
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+  for (int i = G::tid(); i < M; i += G::size()) {
     const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
     const int r = (int)(__brev((unsigned)i) >> (32 - logM));
     re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f;
     im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f;
   }
-  __syncthreads();
-  block_cfft_radix2(re, im, M, P.tw_half);
-  for (int k = threadIdx.x; k <= M; k += blockDim.x)
+  G::sync();
+  group_cfft_radix2<G>(re, im, M, P.tw_half);
+  for (int k = G::tid(); k <= M; k += G::size())
     mg[k] = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);       // R5
-  __syncthreads();
+  G::sync();
   // R6 / R7: mel (usePower per config) -> log -> DCT
-  for (int k = threadIdx.x; k <= M; k += blockDim.x) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
-  __syncthreads();
-  for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x)
+  for (int k = G::tid(); k <= M; k += G::size()) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
+  G::sync();
+  for (int b = G::tid(); b < P.n_bands; b += G::size())
     lmel[b] = log_mel(mel_band_exact(sp, P.mel_coef, P.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
-  __syncthreads();
-  for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
+  G::sync();
+  for (int r = G::tid(); r < P.n_mfcc; r += G::size())
     out[1 + r] = dct_coeff(lmel, P.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);
-  __syncthreads();
+  G::sync();
 
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
-  for (int k = threadIdx.x; k <= M; k += blockDim.x) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
-  __syncthreads();
-  irfft_even(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
-  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+  for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
+  G::sync();
+  group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
+  for (int k = G::tid(); k <= M; k += G::size()) {
     const float p = mg[k] * mg[k];
     sp[k] = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                              // :288-305
   }
-  __syncthreads();
-  irfft_even(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
+  G::sync();
+  group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
 
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
   double voicing, Tsamp;
   int max_idx;
-  pitchacf_frame(acf, cep, M, Q.fsSec, Q.maxPitch, scr, iscr, voicing, max_idx, Tsamp);
-  if (threadIdx.x == 0) {
+  group_pitchacf_frame<G>(acf, cep, M, Q.fsSec, Q.maxPitch, scr, iscr, voicing, max_idx, Tsamp);
+  if (G::tid() == 0) {
     long maxIdx = max_idx;
     float pitch = 0.0f;
     if (maxIdx > 0) pitch = 1.0f / ((float)maxIdx * (float)Tsamp);
@@ -113,6 +114,20 @@ __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q)
     out[14] = (float)voicing;
     out[15] = pitch;                                    // smoothed in place by lld_pitch_smooth
   }
+}
+
+// one workgroup per frame (any FFT size the LDS holds)
+__global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  is09_frame_body<BlockG>(P, Q, (int64_t)blockIdx.x, smem);
+}
+
+// one WAVE per frame, four frames per workgroup, no barriers
+__global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Params Q, int wave_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P.total_frames) return;
+  is09_frame_body<WaveG>(P, Q, row, smem + (threadIdx.x >> 6) * wave_floats);
 }
 
 // R10, sequential part: cPitchACF's causal contour smoother (pitchACF.cpp:199-243), state
@@ -159,9 +174,19 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(2 * Npad + 2 * M + 2 * Kpad + 2 * M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_is09_frame, dim3((unsigned)P.total_frames), dim3(256), lds, s, P, Q);
+  hipError_t e;
+  if (4 * lds <= 64 * 1024 && !getenv("SMILEHIP_IS09_BLOCK")) {       // a wave per frame: four frames per workgroup
+    const int wave_floats = (int)((lds + 15) / 16) * 4;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * wave_floats * (int)sizeof(float));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), 4 * wave_floats * sizeof(float), s,
+                       P, Q, wave_floats);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lld_is09_frame, dim3((unsigned)P.total_frames), dim3(256), lds, s, P, Q);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_pitch_smooth, dim3((unsigned)((P.n_utt + 63) / 64)), dim3(64), 0, s, P.frame_off, P.n_utt, Q.raw16);
