@@ -1,4 +1,4 @@
-// Kernel parameter block shared by the host API (smilehip.cpp) and the device
+// Kernel parameter block shared by the host API (smilehip_*.cpp) and the device
 // code (lld_kernels.hip). Plain data, passed by value at launch.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -103,7 +103,7 @@ struct CompareParams {
   double slope_Sf, slope_S2f;   // sums of f and f^2 over bins 1..K-1 (spectral.cpp:1399-1427)
 };
 
-// Constants of cSpectral for one spectrum geometry (host-resolved, SpectralHost in smilehip.cpp)
+// Constants of cSpectral for one spectrum geometry (host-resolved in smilehip_plan.cpp)
 struct SpectralConsts {
   double fsSec;               // frameSizeSec of the magnitude level: frq[i] = i / fsSec (transformFft.cpp:102-117)
   const double *sharp_w;      // [K-1] bark(f) * g(bark(f)) for bins 1..K-1 (spectral.cpp:1440-1455)

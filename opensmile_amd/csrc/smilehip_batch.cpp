@@ -1,0 +1,520 @@
+// libsmilehip, C ABI part 3: batches (packed utterances), the fused chain runs, functionals, timing.
+#include "smilehip_internal.hpp"
+
+// ------------------------------------------------------------------ batch
+extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, int32_t n_utt, smilehip_batch **out) {
+  if (!plan || !out || n_utt < 0 || (n_utt > 0 && !h_off)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_create: bad argument");
+  *out = nullptr;
+  if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached (tables only)");
+  if (plan->stage_mask != SMILEHIP_STAGE_ALL) return fail(SMILEHIP_ERR_INVALID, "single-component plan cannot run the fused chain");
+  HIP_TRY(hipSetDevice(plan->ctx->device));
+  auto *b = new (std::nothrow) smilehip_batch();
+  if (!b) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  b->plan = plan;
+  b->n_utt = n_utt;
+  b->h_samp_off.assign(h_off, h_off + (n_utt ? n_utt + 1 : 0));
+  if (n_utt == 0) b->h_samp_off.assign(1, 0);
+  b->h_frame_off.assign(size_t(n_utt) + 1, 0);
+  b->h_row_off.assign(size_t(n_utt) + 1, 0);
+  const int short_T = chain_short_max();
+  const int row_extra = plan_row_extra(plan);
+  std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0, run_utt, run_t0;
+  std::vector<TileRec> tile_rec;
+  const int64_t dtile = chain_tile_rows();
+  const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
+  for (int32_t u = 0; u < n_utt; ++u) {
+    const int64_t len = h_off[u + 1] - h_off[u];
+    if (len < 0) {
+      delete b;
+      return fail(SMILEHIP_ERR_INVALID, "sample offsets must be non-decreasing (utterance %d)", u);
+    }
+    const int64_t T = smilehip_num_frames(plan, len);
+    int64_t rows = T > 0 ? T + row_extra : 0;
+    if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+      // rows = T60 + 1 where T60 = frames of the 60 ms framer ([is13_frame60]); none if T60 < 4
+      const int64_t N60 = std::lround(0.060 / plan->geo.period);
+      const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
+      rows = (T60 >= 4) ? T60 + 1 : 0;
+      for (int64_t t0 = 0; t0 < T; t0 += compare_run_frames()) {
+        run_utt.push_back(u);
+        run_t0.push_back((int32_t)t0);
+      }
+    }
+    b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
+    b->h_row_off[u + 1] = b->h_row_off[u] + rows;
+    if (T > 0 && T <= short_T) b->h_short.push_back(u);
+    if (T > 0 && (h_off[u] & 1)) b->all_even = false;
+    for (int64_t t0 = 0; t0 < T; t0 += tile_frames) {
+      tile_utt.push_back(u);
+      tile_t0.push_back((int32_t)t0);
+      TileRec r;
+      r.samp0 = h_off[u] + t0 * plan->geo.H;
+      r.row0 = b->h_frame_off[u] + t0;
+      r.n_frames = (int32_t)std::min<int64_t>(tile_frames, T - t0);
+      r.pad = 0;
+      tile_rec.push_back(r);
+    }
+    for (int64_t t0 = 0; t0 < rows; t0 += dtile) {
+      dtile_utt.push_back(u);
+      dtile_t0.push_back((int32_t)t0);
+    }
+  }
+  b->total_frames = b->h_frame_off[n_utt];
+  b->total_rows = b->h_row_off[n_utt];
+  b->n_tiles = (int32_t)tile_utt.size();
+  b->n_dtiles = (int32_t)dtile_utt.size();
+  int rc;
+  if ((rc = b->d_samp_off.upload(b->h_samp_off)) || (rc = b->d_frame_off.upload(b->h_frame_off)) ||
+      (rc = b->d_row_off.upload(b->h_row_off)) ||
+      (rc = b->d_tile_utt.upload(tile_utt)) || (rc = b->d_tile_t0.upload(tile_t0)) || (rc = b->d_tile_rec.upload(tile_rec)) ||
+      (rc = b->d_dtile_utt.upload(dtile_utt)) || (rc = b->d_dtile_t0.upload(dtile_t0)) ||
+      (rc = b->d_short.upload(b->h_short))) {
+    delete b;
+    return rc;
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    b->n_runs = (int32_t)run_utt.size();
+    if ((rc = b->d_run_utt.upload(run_utt)) || (rc = b->d_run_t0.upload(run_t0))) {
+      delete b;
+      return rc;
+    }
+    const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_rawA.p), nf * 4 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_rawB.p), nf * 55 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_mel1.p), nf * 26 * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
+    }
+    b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
+    (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
+  }
+  if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
+      plan->ctx && b->total_frames > 0) {
+    const size_t n = size_t(b->total_frames) * size_t(plan->dct.n_mfcc);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the static-block scratch failed");
+    }
+    b->d_static.n = n;
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
+    std::vector<float> zero;   // allocate only
+    b->d_raw16.release();
+    b->d_raw16.n = size_t(b->total_frames) * 16;
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_raw16.p), (b->d_raw16.n ? b->d_raw16.n : 1) * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the IS09 scratch matrix failed");
+    }
+  }
+  *out = b;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_batch_destroy(smilehip_batch *b) { delete b; }
+extern "C" int64_t smilehip_batch_total_frames(const smilehip_batch *b) { return b ? b->total_frames : 0; }
+extern "C" int64_t smilehip_batch_total_rows(const smilehip_batch *b) { return b ? b->total_rows : 0; }
+extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o) {
+  if (!b || !o) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_frame_offsets: null argument");
+  std::memcpy(o, b->h_row_off.data(), b->h_row_off.size() * sizeof(int64_t));
+  return SMILEHIP_OK;
+}
+
+// -------------------------------------------------------------------- run
+static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const int16_t *d_pcm, float *d_out,
+                        int64_t ld, LldParams &P) {
+  std::memset(&P, 0, sizeof(P));
+  P.pcm = d_pcm;
+  P.pcm_total = b->h_samp_off.back();
+  P.samp_off = b->d_samp_off.p;
+  P.frame_off = b->d_frame_off.p;
+  P.tile_utt = b->d_tile_utt.p;
+  P.tile_t0 = b->d_tile_t0.p;
+  P.tile_rec = b->d_tile_rec.p;
+  P.n_utt = b->n_utt;
+  P.n_tiles = b->n_tiles;
+  P.total_frames = b->total_frames;
+  P.out = d_out;
+  P.ld_out = ld;
+  P.N = (int32_t)p->geo.N;
+  P.H = (int32_t)p->geo.H;
+  P.Nfft = (int32_t)p->geo.Nfft;
+  P.K = (int32_t)p->geo.K;
+  P.pad_left = p->cfg.zero_pad_symmetric ? (int32_t)((p->geo.Nfft - p->geo.N) / 2) : 0;
+  P.preemph = p->cfg.preemph;
+  P.de = p->cfg.preemph_de;
+  P.k = p->cfg.preemph_k;
+  P.one_minus_k = 1 - p->cfg.preemph_k;     // (1-k) in float, vectorPreemphasis.cpp:94
+  P.win_offset = (float)p->cfg.win_offset;
+  P.window = p->d_window.p;
+  P.tw_half = p->d_tw_half.p;
+  P.tw_full = p->d_tw_full.p;
+  P.mel_coef = p->d_mel_coef.p;
+  P.mel_rng = p->d_mel_rng.p;
+  P.mel_scale = p->mel.scale;
+  P.use_power = p->cfg.use_power;
+  P.n_bands = p->mel.n_bands;
+  P.dct_rows = p->d_dct_rows.p;
+  P.dct_gain = p->d_dct_gain.p;
+  P.n_mfcc = p->dct.n_mfcc;
+  P.melfloor = p->dct.melfloor;
+  P.log_floor = p->dct.log_floor;
+  P.plp = p->cfg.chain_kind == SMILEHIP_CHAIN_PLP;
+  P.plp_order = p->cfg.plp_lp_order;
+  P.plp_compression = p->cfg.plp_compression;
+  P.plp_eql = p->d_plp_eql.p;
+  P.plp_cos = p->d_plp_cos.p;
+  P.plp_sin = p->d_plp_sin.p;
+}
+
+// R13 for a batch whose rows == frames: level 0 = x (leading dimension ld_x); writes [copy of x at copy_col (if >= 0) |
+// order 1 at D | order 2 at 2D] into out
+static int delta_chain_from(smilehip_plan *plan, smilehip_batch *b, const float *d_x, int64_t ld_x, int copy_col, float *d_io,
+                            int64_t ld, int32_t D, int32_t W, int32_t n_orders, void *stream) {
+  if (!plan || !b || !d_io) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: null argument");
+  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 16 || ld < (int64_t)D * (1 + n_orders))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  // rows == frames is what this entry point assumes (d_io holds the static block)
+  if (b->total_rows != b->total_frames) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: batch belongs to a chain with extra rows");
+  ChainParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.frame_off = b->d_frame_off.p;
+  Q.row_off = b->d_row_off.p;
+  Q.tile_utt = b->d_dtile_utt.p;
+  Q.tile_t0 = b->d_dtile_t0.p;
+  Q.n_tiles = b->n_dtiles;
+  Q.n_utt = b->n_utt;
+  Q.x = d_x;
+  Q.ld_x = ld_x;
+  Q.copy_col = copy_col;
+  Q.out = d_io;
+  Q.ld_out = ld;
+  Q.D = D;
+  Q.n_stages = n_orders;
+  Q.kind[0] = Q.kind[1] = 0;
+  Q.W[0] = Q.W[1] = W;
+  Q.out_col[0] = D;
+  Q.out_col[1] = 2 * D;
+  Q.short_T = chain_short_max();
+  Q.short_utts = b->d_short.p;
+  Q.n_short = (int32_t)b->h_short.size();
+  hipError_t e = launch_chain(Q, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *b, float *d_io, int64_t ld, int32_t D,
+                                    int32_t W, int32_t n_orders, void *stream) {
+  return delta_chain_from(plan, b, d_io, ld, -1, d_io, ld, D, W, n_orders, stream);
+}
+
+extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out,
+                                 int64_t ld_out, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC && plan->cfg.chain_kind != SMILEHIP_CHAIN_PLP)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan is not an MFCC / PLP chain (use smilehip_lld_run)");
+  const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  // With deltas to follow, the static block goes to a compact [frames x n_mfcc] scratch: the frame kernel
+  // then writes whole lines, the window-chain kernel reads 1/3 of what it would read from 39-float rows,
+  // and writes every output row in one piece (static | delta | accel).
+  const bool compact = plan->cfg.n_delta > 0 && b->d_static.p != nullptr;
+  if (compact) {
+    P.out = b->d_static.p;
+    P.ld_out = plan->dct.n_mfcc;
+  }
+  hipEvent_t *ev = plan->ev[plan->n_timed % smilehip_plan::kRing];
+  if (plan->timing) {
+    for (int i = 0; i < 3; ++i)
+      if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipEventRecord(ev[0], s));
+  }
+  hipError_t e;
+  if (plan->use_fast) {
+    Fast512Tables F;
+    F.tw256 = plan->d_tw256.p;
+    F.tw512 = plan->d_tw512.p;
+    F.win = plan->d_fwin.p;
+    F.melw = plan->d_melw.p;
+    F.melo = plan->d_melo.p;
+    F.dct28 = plan->d_dct28.p;
+    F.band_slots = plan->d_band_slots.p;
+    F.mel_units = plan->fast.mel_units;
+    F.n_slots = plan->fast.n_slots;
+    F.stage_floats = plan->fast.stage_floats;
+    F.stage_alloc = plan->fast.stage_alloc;
+    F.mel_scale = plan->fast.mel_scale;
+    F.plp_eql = plan->d_plp_eql.p;
+    F.plp_sin = plan->d_plp_sin.p;
+    const bool aligned = b->all_even && ((reinterpret_cast<uintptr_t>(d_pcm) & 3) == 0);
+    e = launch_mfcc512(P, F, plan->fast, aligned, s);
+  } else {
+    e = launch_mfcc_generic(P, s);
+  }
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
+  if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
+  if (plan->cfg.n_delta > 0) {
+    int rc = compact ? delta_chain_from(plan, b, b->d_static.p, plan->dct.n_mfcc, 0, d_out, ld_out, plan->dct.n_mfcc,
+                                        plan->cfg.delta_win, plan->cfg.n_delta, stream)
+                     : smilehip_delta_chain(plan, b, d_out, ld_out, plan->dct.n_mfcc, plan->cfg.delta_win, plan->cfg.n_delta, stream);
+    if (rc) return rc;
+  }
+  if (plan->timing) {
+    HIP_TRY(hipEventRecord(ev[2], s));
+    plan->n_timed++;
+  }
+  return SMILEHIP_OK;
+}
+
+// IS09 LLD set: frame kernel -> pitch smoother -> SMA + delta chain
+static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  const int n_out = plan_n_out(plan);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  Is09Params I;
+  I.raw16 = b->d_raw16.p;
+  I.fsSec = (float)plan->geo.fft_frame_size_sec;
+  I.maxPitch = plan->cfg.pitch_max;
+  I.voicingCutoff = plan->cfg.voicing_cutoff;
+  if (I.voicingCutoff > 1.0) I.voicingCutoff = 1.0;       // pitchACF.cpp:96-98
+  if (I.voicingCutoff < 0.0) I.voicingCutoff = 0.0;
+  if (I.maxPitch < 0.0) I.maxPitch = 0.0;
+  hipError_t e = launch_is09(P, I, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "IS09 kernel launch failed: %s", hipGetErrorString(e));
+  ChainParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.frame_off = b->d_frame_off.p;
+  Q.row_off = b->d_row_off.p;
+  Q.tile_utt = b->d_dtile_utt.p;
+  Q.tile_t0 = b->d_dtile_t0.p;
+  Q.n_tiles = b->n_dtiles;
+  Q.n_utt = b->n_utt;
+  Q.x = b->d_raw16.p;
+  Q.ld_x = 16;
+  Q.copy_col = -1;
+  Q.out = d_out;
+  Q.ld_out = ld_out;
+  Q.D = 16;
+  Q.n_stages = 2;
+  Q.kind[0] = 1; Q.W[0] = plan->cfg.sma_win / 2;          // cContourSmoother
+  Q.kind[1] = 0; Q.W[1] = plan->cfg.delta_win;            // cDeltaRegression
+  Q.out_col[0] = 0;
+  Q.out_col[1] = 16;
+  Q.short_T = chain_short_max();
+  Q.short_utts = b->d_short.p;
+  Q.n_short = (int32_t)b->h_short.size();
+  e = launch_chain(Q, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+// ComParE groups A+B: frame kernel -> RASTA scan -> group A (multi-length SMA+delta) + group B chain
+static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  const int n_out = plan_n_out(plan);
+  if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
+  if (b->total_frames == 0 || b->total_rows == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  CompareParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.run_utt = b->d_run_utt.p;
+  Q.run_t0 = b->d_run_t0.p;
+  Q.rawA = b->d_rawA.p;
+  Q.rawB = b->d_rawB.p;
+  Q.mel1 = b->d_mel1.p;
+  Q.eql = plan->d_eql.p;
+  Q.eql_log = plan->d_eql_log.p;
+  Q.sharp_w = plan->d_sharp.p;
+  Q.plp_melfloor = 0.00000000093f;     // cPlp melfloor default (plp.cpp:66), htkcompatible = 0
+  Q.compression = 0.33f;
+  Q.rasta_iir = plan->rasta_iir;
+  for (int i = 0; i < 5; ++i) Q.rasta_fir[i] = plan->rasta_fir[i];
+  Q.fsSec = plan->geo.fft_frame_size_sec;
+  Q.N60 = (int32_t)std::lround(0.060 / plan->geo.period);
+  for (int i = 0; i < 2; ++i) {
+    Q.band_iL[i] = plan->band_iL[i]; Q.band_iR[i] = plan->band_iR[i];
+    Q.band_wL[i] = plan->band_wL[i]; Q.band_wR[i] = plan->band_wR[i];
+  }
+  Q.slope_Sf = plan->slope_Sf;
+  Q.slope_S2f = plan->slope_S2f;
+  hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "ComParE kernel launch failed: %s", hipGetErrorString(e));
+  ChainParams C;
+  std::memset(&C, 0, sizeof(C));
+  C.frame_off = b->d_frame_off.p;
+  C.row_off = b->d_row_off.p;
+  C.tile_utt = b->d_dtile_utt.p;
+  C.tile_t0 = b->d_dtile_t0.p;
+  C.n_tiles = b->n_dtiles;
+  C.n_utt = b->n_utt;
+  C.x = b->d_rawB.p;
+  C.ld_x = 55;
+  C.copy_col = -1;
+  C.out = d_out;
+  C.ld_out = ld_out;
+  C.D = 55;
+  C.n_stages = 2;
+  C.kind[0] = 1; C.W[0] = 1;
+  C.kind[1] = 0; C.W[1] = 2;
+  C.out_col[0] = 4;
+  C.out_col[1] = 59 + 4;
+  C.short_T = chain_short_max();
+  C.short_utts = b->d_short.p;
+  C.n_short = (int32_t)b->h_short.size();
+  e = launch_chain(C, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+// ------------------------------------------------------------- functionals
+extern "C" uint32_t smilehip_functionals_is09_mask(void) {
+  return SMILEHIP_FUNC_MAX | SMILEHIP_FUNC_MIN | SMILEHIP_FUNC_RANGE | SMILEHIP_FUNC_MAXPOS | SMILEHIP_FUNC_MINPOS |
+         SMILEHIP_FUNC_AMEAN | SMILEHIP_FUNC_LINREGC1 | SMILEHIP_FUNC_LINREGC2 | SMILEHIP_FUNC_LINREGERRQ |
+         SMILEHIP_FUNC_STDDEV | SMILEHIP_FUNC_SKEWNESS | SMILEHIP_FUNC_KURTOSIS;
+}
+
+extern "C" int smilehip_functionals_count(uint32_t mask) {
+  if (mask & ~SMILEHIP_FUNC_ALL) return -1;
+  return __builtin_popcount(mask);
+}
+
+static const int kIs09FuncRowsCut = 3;      // rows = T+1; functionals see max(1, T-2)
+
+extern "C" int smilehip_batch_func_rows(const smilehip_batch *b, int64_t *rows) {
+  if (!b || !rows) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_func_rows: null argument");
+  if (b->plan->cfg.chain_kind != SMILEHIP_CHAIN_IS09)
+    return fail(SMILEHIP_ERR_INVALID, "functionals are defined for IS09 chain plans only");
+  for (int32_t u = 0; u < b->n_utt; ++u) {
+    const int64_t r = b->h_row_off[u + 1] - b->h_row_off[u];
+    rows[u] = r > 0 ? std::max<int64_t>(1, r - kIs09FuncRowsCut) : 0;
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld,
+                                          uint32_t mask, float *d_func, int64_t ld_func, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_IS09)
+    return fail(SMILEHIP_ERR_INVALID, "functionals are defined for IS09 chain plans only");
+  const int per = smilehip_functionals_count(mask);
+  if (per <= 0) return fail(SMILEHIP_ERR_INVALID, "invalid functionals mask 0x%x", mask);
+  const int n_cols = plan_n_out(plan);
+  if (ld_lld < n_cols || ld_func < (int64_t)n_cols * per)
+    return fail(SMILEHIP_ERR_INVALID, "leading dimensions too small (ld_lld %lld, ld_func %lld)", (long long)ld_lld,
+                (long long)ld_func);
+  if (b->n_utt == 0) return SMILEHIP_OK;
+  if (!d_func || (!d_lld && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals: null device pointer");
+  FuncParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.row_off = b->d_row_off.p;
+  P.x = d_lld;
+  P.ld_x = ld_lld;
+  P.n_cols = n_cols;
+  P.rows_cut = kIs09FuncRowsCut;
+  P.single_rows = -1;
+  P.mask = mask;
+  P.out = d_func;
+  P.ld_out = ld_func;
+  hipError_t e = launch_functionals(P, b->n_utt, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t ld_x, int64_t rows, int32_t cols,
+                                           uint32_t mask, float *d_out, void *stream) {
+  const int per = smilehip_functionals_count(mask);
+  if (!ctx || per <= 0 || rows < 1 || cols < 1 || ld_x < cols || !d_x || !d_out)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_functionals_matrix: bad argument");
+  FuncParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.x = d_x;
+  P.ld_x = ld_x;
+  P.n_cols = cols;
+  P.mask = mask;
+  P.single_rows = rows;
+  P.out = d_out;
+  P.ld_out = (int64_t)cols * per;
+  hipError_t e = launch_functionals(P, 1, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,
+                                void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: plan/batch mismatch");
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP)
+    return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
+  return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
+}
+
+extern "C" int smilehip_lld_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
+                                     float *h_out) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_host: plan/batch mismatch");
+  if (n_samples < b->h_samp_off.back()) return fail(SMILEHIP_ERR_INVALID, "PCM buffer shorter than the batch layout");
+  if (b->total_rows == 0) return SMILEHIP_OK;
+  if (!h_pcm || !h_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_host: null pointer");
+  HIP_TRY(hipSetDevice(plan->ctx->device));
+  const int n_out = plan_n_out(plan);
+  int16_t *d_pcm = nullptr;
+  float *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_pcm, size_t(n_samples) * sizeof(int16_t)));
+  hipError_t e = hipMalloc((void **)&d_out, size_t(b->total_rows) * n_out * sizeof(float));
+  if (e != hipSuccess) {
+    (void)hipFree(d_pcm);
+    return fail(SMILEHIP_ERR_HIP, "hipMalloc(out) failed: %s", hipGetErrorString(e));
+  }
+  int rc = SMILEHIP_OK;
+  e = hipMemcpy(d_pcm, h_pcm, size_t(n_samples) * sizeof(int16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = smilehip_lld_run(plan, b, d_pcm, d_out, n_out, nullptr);
+    if (rc == SMILEHIP_OK) e = hipMemcpy(h_out, d_out, size_t(b->total_rows) * n_out * sizeof(float), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_pcm);
+  (void)hipFree(d_out);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "HIP copy failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,
+                                      float *h_out) {
+  if (!plan || plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run_host: plan is not an MFCC chain");
+  return smilehip_lld_run_host(plan, b, h_pcm, n_samples, h_out);
+}
+
+extern "C" int smilehip_plan_set_timing(smilehip_plan *plan, int enable) {
+  if (!plan) return fail(SMILEHIP_ERR_INVALID, "null plan");
+  plan->timing = enable != 0;
+  plan->n_timed = 0;
+  return SMILEHIP_OK;
+}
+
+// Average over the runs recorded since set_timing (at most the last kRing).
+// The caller must have synchronised the stream.
+extern "C" int smilehip_plan_last_timing(smilehip_plan *plan, float *ms_main, float *ms_delta) {
+  if (!plan || plan->n_timed <= 0) return fail(SMILEHIP_ERR_INVALID, "no timing recorded");
+  const int64_t n = plan->n_timed < smilehip_plan::kRing ? plan->n_timed : smilehip_plan::kRing;
+  double sa = 0.0, sd = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    float a = 0.f, d = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, plan->ev[i][0], plan->ev[i][1]));
+    HIP_TRY(hipEventElapsedTime(&d, plan->ev[i][1], plan->ev[i][2]));
+    sa += a;
+    sd += d;
+  }
+  if (ms_main) *ms_main = float(sa / double(n));
+  if (ms_delta) *ms_delta = float(sd / double(n));
+  return SMILEHIP_OK;
+}

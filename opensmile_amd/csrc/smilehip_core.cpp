@@ -1,0 +1,77 @@
+// libsmilehip, C ABI part 1: errors, context life cycle, device-memory plumbing (include/smilehip.h).
+#include "smilehip_internal.hpp"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+extern "C" const char *smilehip_last_error(void) { return g_err.c_str(); }
+extern "C" int smilehip_version(void) { return SMILEHIP_VERSION; }
+
+// ------------------------------------------------------------- life cycle
+extern "C" int smilehip_init(int device, smilehip_context **out) {
+  if (!out) return fail(SMILEHIP_ERR_INVALID, "smilehip_init: null output pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(SMILEHIP_ERR_NO_DEVICE, "no HIP device visible (libsmilehip has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(SMILEHIP_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  auto *c = new (std::nothrow) smilehip_context();
+  if (!c) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+    delete c;
+    return fail(SMILEHIP_ERR_HIP, "cannot open HIP device %d", device);
+  }
+  if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = c->prop.gcnArchName;
+    delete c;
+    return fail(SMILEHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                arch.c_str());
+  }
+  *out = c;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_shutdown(smilehip_context *ctx) { delete ctx; }
+
+extern "C" int smilehip_device_name(smilehip_context *ctx, char *buf, int buflen) {
+  if (!ctx || !buf || buflen <= 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_device_name: bad argument");
+  snprintf(buf, buflen, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr) {
+  if (!ctx || !d_ptr) return fail(SMILEHIP_ERR_INVALID, "smilehip_alloc: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_free(smilehip_context *ctx, void *d_ptr) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_free: null context");
+  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_device: null argument");
+  if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
+  if (!ctx || (bytes && (!h_dst || !d_src))) return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_host: null argument");
+  if (bytes) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_stream_synchronize(smilehip_context *ctx, void *stream) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_synchronize: null context");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SMILEHIP_OK;
+}

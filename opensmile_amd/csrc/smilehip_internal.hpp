@@ -1,0 +1,119 @@
+// Internal declarations shared by the C ABI's translation units (smilehip_core / _plan / _batch / _stage .cpp).
+// Not installed: the public surface is include/smilehip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/smilehip.h"
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+#include "tables.hpp"
+
+using namespace smilehip;
+
+// ------------------------------------------------------------------ errors
+
+int fail(int code, const char *fmt, ...);   // records the thread-local message, returns code
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(SMILEHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+// ----------------------------------------------------------------- objects
+struct smilehip_context {
+  int device = 0;
+  hipDeviceProp_t prop{};
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int upload(const std::vector<T> &h) {
+    release();
+    n = h.size();
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    if (n) HIP_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return SMILEHIP_OK;
+  }
+};
+
+struct smilehip_plan {
+  smilehip_context *ctx = nullptr;
+  smilehip_lld_config cfg{};
+  Geometry geo;
+  std::vector<float> h_window;
+  MelBank mel;
+  DctTables dct;
+  DevBuf<float> d_window, d_mel_coef, d_dct_rows, d_dct_gain;
+  DevBuf<int32_t> d_mel_rng;
+  DevBuf<float2> d_tw_half, d_tw_full, d_tw256, d_tw512, d_fwin;
+  DevBuf<float4> d_melw;
+  DevBuf<uint32_t> d_melo;
+  DevBuf<float> d_dct28;
+  DevBuf<int32_t> d_band_slots;
+  Fast512Host fast;
+  bool use_fast = false;
+  DevBuf<float> d_eql, d_eql_log;
+  DevBuf<float> d_plp_eql, d_plp_cos, d_plp_sin;     // PLP chain tables
+  std::vector<float> h_plp_cos;
+  DevBuf<double> d_sharp;
+  float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
+  int32_t band_iL[2] = {0, 0}, band_iR[2] = {0, 0};
+  double band_wL[2] = {0, 0}, band_wR[2] = {0, 0}, slope_Sf = 0, slope_S2f = 0;
+  // timing
+  // HIP-event timing ring: slot i holds {before main, after main, after delta}
+  static constexpr int kRing = 128;
+  bool timing = false;
+  hipEvent_t ev[kRing][3] = {};
+  int64_t n_timed = 0;
+  int force_generic = 0;
+  uint32_t stage_mask = SMILEHIP_STAGE_ALL;
+  ~smilehip_plan() {
+    for (auto &slot : ev)
+      for (auto &e : slot)
+        if (e) (void)hipEventDestroy(e);
+  }
+};
+
+struct smilehip_batch {
+  smilehip_plan *plan = nullptr;
+  int32_t n_utt = 0;
+  int64_t total_frames = 0;
+  std::vector<int64_t> h_samp_off, h_frame_off, h_row_off;
+  int64_t total_rows = 0;
+  DevBuf<int64_t> d_row_off;
+  DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
+  DevBuf<float> d_static;       // MFCC chain with deltas: compact static block, total_frames x n_mfcc
+  DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
+  DevBuf<int32_t> d_run_utt, d_run_t0;
+  int32_t n_runs = 0;
+  std::vector<int32_t> h_short;
+  DevBuf<int64_t> d_samp_off, d_frame_off;
+  DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
+  DevBuf<TileRec> d_tile_rec;
+  int32_t n_tiles = 0, n_dtiles = 0;
+  bool all_even = true;      // every utterance with frames starts at an even sample offset
+};
+
+// helpers shared by the translation units (defined in smilehip_plan.cpp)
+int plan_n_static(const smilehip_plan *p);
+int plan_n_out(const smilehip_plan *p);
+int plan_row_extra(const smilehip_plan *p);

@@ -1,0 +1,347 @@
+// libsmilehip, C ABI part 2: configuration presets, plan creation (host tables -> device), plan getters.
+#include "smilehip_internal.hpp"
+
+extern "C" void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c) {
+  std::memset(c, 0, sizeof(*c));
+  c->struct_size = sizeof(*c);
+  c->sample_rate = 16000.0;
+  c->frame_size_sec = 0.0250;
+  c->frame_step_sec = 0.010;
+  c->preemph = 1;
+  c->preemph_k = 0.97f;
+  c->preemph_de = 0;
+  c->win_func = SMILEHIP_WIN_HAMM;
+  c->win_sigma = 0.4;
+  c->win_gain = 1.0;
+  c->win_offset = 0.0;
+  c->zero_pad_symmetric = 0;
+  c->n_bands = 26;
+  c->lofreq = 0.0f;
+  c->hifreq = 8000.0f;
+  c->use_power = 1;
+  c->mel_htk_compatible = 1;
+  c->first_mfcc = 0;
+  c->last_mfcc = 12;
+  c->cep_lifter = 22.0f;
+  c->mfcc_htk_compatible = 1;
+  c->melfloor = 1e-8f;
+  c->n_delta = 2;
+  c->delta_win = 2;
+}
+
+extern "C" void smilehip_config_is09_lld(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);
+  c->chain_kind = SMILEHIP_CHAIN_IS09;
+  c->use_power = 0;            // [is09_mspec] usePower = 0
+  c->first_mfcc = 1;
+  c->last_mfcc = 12;
+  c->n_delta = 1;
+  c->delta_win = 2;
+  c->pitch_max = 500.0;
+  c->voicing_cutoff = 0.55;
+  c->sma_win = 3;
+}
+
+extern "C" void smilehip_config_plp_0_d_a(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);        // same front end: 25 ms / 10 ms, k = 0.97, ham, 26 HTK mel bands
+  c->chain_kind = SMILEHIP_CHAIN_PLP;
+  c->plp_lp_order = 5;                    // [plp:cPlp] lpOrder = 5, compression = 0.33, cepLifter = 22
+  c->plp_compression = 0.33f;
+  c->cep_lifter = 22.0f;
+  c->first_mfcc = 0;
+  c->last_mfcc = 5;
+}
+
+extern "C" void smilehip_config_compare16_ab(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);
+  c->chain_kind = SMILEHIP_CHAIN_COMPARE_AB;
+  c->frame_size_sec = 0.020;       // [is13_frame25]
+  c->preemph = 0;
+  c->win_func = SMILEHIP_WIN_HAMM; // [is13_win25]
+  c->zero_pad_symmetric = 1;       // [is13_fft25]
+  c->lofreq = 20.0f;               // [is13_melspec1], [is13_melspecMfcc]
+  c->use_power = 1;
+  c->first_mfcc = 1;               // [is13_mfcc]
+  c->last_mfcc = 14;
+  c->n_delta = 1;
+  c->delta_win = 2;
+  c->sma_win = 3;
+}
+
+// ------------------------------------------------------------------- plan
+static int build_tables(smilehip_plan *p, bool upload = true) {
+  int rc;
+  if ((rc = make_geometry(p->cfg, p->geo)) != SMILEHIP_OK) return fail(rc, "invalid framing parameters");
+  if (p->geo.Nfft > 8192) return fail(SMILEHIP_ERR_INVALID, "FFT length %lld > 8192 unsupported", (long long)p->geo.Nfft);
+  const uint32_t mask = p->cfg.stage_mask ? p->cfg.stage_mask : SMILEHIP_STAGE_ALL;
+  p->h_window.assign(size_t(p->geo.N), 1.0f);
+  if ((mask & SMILEHIP_STAGE_WINDOW) && (rc = make_window(p->cfg, p->geo.N, p->h_window)) != SMILEHIP_OK)
+    return fail(rc, "unknown window function %d", p->cfg.win_func);
+  if (mask & SMILEHIP_STAGE_MEL) {
+    if ((rc = make_mel(p->cfg, p->geo, p->mel)) != SMILEHIP_OK) return fail(rc, "invalid mel bank parameters");
+  } else {
+    p->mel = MelBank();
+    p->mel.n_bands = p->cfg.n_bands;
+  }
+  if (mask & SMILEHIP_STAGE_MFCC) {
+    if ((rc = make_dct(p->cfg, p->dct)) != SMILEHIP_OK) return fail(rc, "invalid MFCC range");
+  } else {
+    p->dct = DctTables();
+  }
+  p->stage_mask = mask;
+  if (p->cfg.n_delta < 0 || p->cfg.n_delta > 2) return fail(SMILEHIP_ERR_INVALID, "n_delta must be 0..2");
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
+    if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 12 || p->cfg.n_delta != 1 || p->cfg.sma_win < 3 || !(p->cfg.sma_win & 1) ||
+        p->cfg.sma_win > 9)
+      return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
+        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
+      return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_PLP) {
+    if (mask != SMILEHIP_STAGE_ALL || p->cfg.plp_lp_order < 1 || p->cfg.plp_lp_order > 15 || !p->cfg.mel_htk_compatible ||
+        !p->cfg.use_power || p->mel.n_bands > 30 || p->cfg.plp_compression < 0.0f)
+      return fail(SMILEHIP_ERR_INVALID, "PLP chain: lpOrder 1..15, HTK-scaled power mel bands (<= 30) required");
+    p->dct.n_mfcc = p->cfg.plp_lp_order + 1;            // outputs of the chain's static block
+    p->dct.melfloor = 1.0f;                              // htkcompatible forces melfloor = 1.0 (plp.cpp:150-160)
+  } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
+    return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
+  }
+  if (p->cfg.n_delta > 0 && (p->cfg.delta_win < 1 || p->cfg.delta_win > 4))
+    return fail(SMILEHIP_ERR_INVALID, "delta_win must be 1..4");
+
+  const int64_t M = p->geo.Nfft / 2;
+  std::vector<float2> twh(static_cast<size_t>(M / 2 > 0 ? M / 2 : 1)), twf(static_cast<size_t>(M / 2 + 1));
+  for (int64_t j = 0; j < M / 2; ++j) {
+    const double a = -2.0 * M_PI * double(j) / double(M);
+    twh[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+  }
+  for (int64_t k = 0; k <= M / 2; ++k) {
+    const double a = -2.0 * M_PI * double(k) / double(p->geo.Nfft);
+    twf[k] = make_float2(float(std::cos(a)), float(std::sin(a)));
+  }
+  std::vector<int32_t> rng((mask & SMILEHIP_STAGE_MEL) ? size_t(4) * p->mel.n_bands : 0);
+  for (int b = 0; b < p->mel.n_bands && (mask & SMILEHIP_STAGE_MEL); ++b) {
+    rng[4 * b + 0] = p->mel.rise_lo[b];
+    rng[4 * b + 1] = p->mel.rise_hi[b];
+    rng[4 * b + 2] = p->mel.fall_lo[b];
+    rng[4 * b + 3] = p->mel.fall_hi[b];
+  }
+  // PLP chain: cPlp::initTables (plp.cpp:288-357): IDFT cosine table, lifter table, HTK equal-loudness weights at
+  // the band centres cMelspec publishes (melspec.cpp:408-412)
+  std::vector<float> plp_eql(32, 0.0f), plp_sin(16, 1.0f);
+  const bool is_plp = p->cfg.chain_kind == SMILEHIP_CHAIN_PLP;
+  if (is_plp) {
+    const int nB = p->mel.n_bands, nFreq = nB + 2, nAuto = p->cfg.plp_lp_order + 1;
+    p->h_plp_cos.assign(size_t(nAuto) * nFreq, 0.0f);
+    const float a = (float)M_PI / (float)(nFreq - 1);
+    for (int i = 0; i < nAuto; i++) {
+      const int ib = i * nFreq;
+      int m;
+      p->h_plp_cos[ib] = 1.0f;
+      for (m = 1; m < (nFreq - 1); m++) p->h_plp_cos[m + ib] = (float)(2.0 * std::cos(a * (double)i * (double)m));
+      p->h_plp_cos[m + ib] = (float)(std::cos(a * (double)i * (double)m));
+    }
+    const float L = (float)(int)p->cfg.cep_lifter;      // cepLifter is read with getInt (plp.cpp:142)
+    for (int i = 0; i < nAuto; i++)
+      plp_sin[i] = (L > 0.0f) ? ((float)1.0 + L / (float)2.0 * std::sin((float)M_PI * ((float)(i)) / L)) : 1.0f;
+    for (int m = 1; m <= nB; ++m) {
+      const double hz = 700.0 * (std::exp(double(p->mel.centres[m]) / 1127.0) - 1.0);
+      const double f2 = hz * hz, fs = f2 / (f2 + 1.6e5);
+      plp_eql[m - 1] = (float)(fs * fs * ((f2 + 1.44e6) / (f2 + 9.61e6)));   // smileDsp_equalLoudnessWeight_htk
+    }
+  }
+  // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
+  p->use_fast = false;
+  if (mask == SMILEHIP_STAGE_ALL && (p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || (is_plp && p->mel.n_bands == 26)) &&
+      !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
+    p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
+    if (p->use_fast && is_plp) {                          // the DCT rows' place holds the IDFT cosine rows (28 floats each)
+      p->fast.dct28.assign(16 * 28, 0.0f);
+      std::copy(p->h_plp_cos.begin(), p->h_plp_cos.end(), p->fast.dct28.begin());
+    }
+    if (p->ctx) p->fast.max_blocks = 2 * p->ctx->prop.multiProcessorCount;
+  }
+  if (!upload) return SMILEHIP_OK;
+  if ((rc = p->d_window.upload(p->h_window))) return rc;
+  if ((rc = p->d_mel_coef.upload(p->mel.coef))) return rc;
+  if ((rc = p->d_mel_rng.upload(rng))) return rc;
+  if ((rc = p->d_dct_rows.upload(p->dct.cos_rows))) return rc;
+  if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
+  if ((rc = p->d_tw_half.upload(twh))) return rc;
+  if ((rc = p->d_tw_full.upload(twf))) return rc;
+  if (is_plp && ((rc = p->d_plp_eql.upload(plp_eql)) || (rc = p->d_plp_cos.upload(p->h_plp_cos)) || (rc = p->d_plp_sin.upload(plp_sin))))
+    return rc;
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
+    // publishes as metadata (melspec.cpp:408-412), and the newRASTA filter coefficients
+    std::vector<float> eql(26), eqll(26);
+    for (int m = 1; m <= 26; ++m) {
+      const double hz = 700.0 * (std::exp(double(p->mel.centres[m]) / 1127.0) - 1.0);
+      const double w = 2.0 * M_PI * hz, w2 = w * w, c = w2 + 6300000.0;
+      const double e = (c > 0.0) ? (1e32 * ((w2 + 56.8e6) * w2 * w2) / (c * c * (w2 + 0.38e9) * (w2 * w2 * w2 * w + 1.7e31))) : 0.0;
+      eql[m - 1] = float(e);
+      eqll[m - 1] = std::log(eql[m - 1]);
+    }
+    const double Tl = p->geo.frame_period;
+    const float lower = 1.0f, upper = 29.0f;
+    p->rasta_iir = float(1.0 - std::sin(2.0 * M_PI * lower * Tl));
+    const float om = float(std::cos(2.0 * M_PI * upper * Tl));
+    const float norm = float(std::sqrt(10.0 * (32.0 * om * om + 8.0)));
+    p->rasta_fir[0] = float(2.0 / norm);
+    p->rasta_fir[1] = float(-4.0 * om / norm);
+    p->rasta_fir[2] = 0.0f;
+    p->rasta_fir[3] = -p->rasta_fir[1];
+    p->rasta_fir[4] = -p->rasta_fir[0];
+    if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll))) return rc;
+  }
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || (mask & SMILEHIP_STAGE_SPECTRAL)) {
+    // sharpness weights (spectral.cpp:1440-1455): bark(f) * g(bark(f)) for bins 1..K-1
+    std::vector<double> sw(size_t(p->geo.K - 1));
+    const double F0 = 1.0 / p->geo.fft_frame_size_sec;
+    for (int64_t j = 1; j < p->geo.K; ++j) {
+      const double x = F0 * double(j);
+      double zz = 0.0;
+      if (x > 0) {
+        zz = (26.81 / (1.0 + 1960.0 / x)) - 0.53;
+        if (zz < 2) zz = 0.85 * zz + 0.3;
+        else if (zz > 20.1) zz = 1.22 * zz - 0.22 * 20.1;
+      }
+      const double g = (zz <= 16.0) ? 1.0 : std::pow((zz - 16.0) / 4.0, 1.5849625) + 1.0;
+      sw[size_t(j - 1)] = zz * g;
+    }
+    // band edges of [is13_spectral] bands 250-650 and 1000-4000 (spectral.cpp:779-853)
+    const int band_lo[2] = {250, 1000}, band_hi[2] = {650, 4000};
+    const int Nsrc = (int)p->geo.K;
+    for (int b = 0; b < 2; ++b) {
+      int ii;
+      double wghtL, wghtR, idxL, idxR;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)band_lo[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)band_lo[b]) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
+      idxL = (double)ii - 1.0;
+      if (idxL < 0) idxL = 0;
+      if (idxL >= Nsrc) idxL = Nsrc;
+      if (wghtL == 0.0) wghtL = 1.0;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)band_hi[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)band_hi[b] - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
+      if ((ii < Nsrc) && (F0 * ii == (float)band_hi[b])) idxR = (double)ii; else idxR = (double)ii - 1.0;
+      if (idxR >= Nsrc) idxR = Nsrc - 1;
+      if (wghtR == 0.0) wghtR = 1.0;
+      int iL = (int)std::floor(idxL), iR = (int)std::floor(idxR);
+      if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+      if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+      if (iL < 0) iL = 0;
+      if (iR < 0) iR = 0;
+      p->band_iL[b] = iL; p->band_iR[b] = iR; p->band_wL[b] = wghtL; p->band_wR[b] = wghtR;
+    }
+    double Sf = 0.0, S2f = 0.0;
+    for (int64_t i = 1; i < p->geo.K; ++i) { S2f += (F0 * i) * (F0 * i); Sf += F0 * i; }
+    p->slope_Sf = Sf;
+    p->slope_S2f = S2f;
+    if ((rc = p->d_sharp.upload(sw))) return rc;
+  }
+  if (p->use_fast) {
+    if ((rc = p->d_tw256.upload(p->fast.tw256))) return rc;
+    if ((rc = p->d_tw512.upload(p->fast.tw512))) return rc;
+    if ((rc = p->d_fwin.upload(p->fast.win))) return rc;
+    if ((rc = p->d_melw.upload(p->fast.melw))) return rc;
+    if ((rc = p->d_melo.upload(p->fast.melo))) return rc;
+    if ((rc = p->d_dct28.upload(p->fast.dct28))) return rc;
+    if ((rc = p->d_band_slots.upload(p->fast.band_slots))) return rc;
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_config *cfg, smilehip_plan **out) {
+  if (!ctx || !cfg || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(smilehip_lld_config))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(smilehip_lld_config));
+  HIP_TRY(hipSetDevice(ctx->device));
+  auto *p = new (std::nothrow) smilehip_plan();
+  if (!p) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->cfg = *cfg;
+  const char *fg = getenv("SMILEHIP_FORCE_GENERIC");
+  p->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+  int rc = build_tables(p);
+  if (rc != SMILEHIP_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_plan_create_host_only(const smilehip_lld_config *cfg, smilehip_plan **out) {
+  if (!cfg || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_create_host_only: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(smilehip_lld_config))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(smilehip_lld_config));
+  auto *p = new (std::nothrow) smilehip_plan();
+  if (!p) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  p->cfg = *cfg;
+  int rc = build_tables(p, false);
+  if (rc != SMILEHIP_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SMILEHIP_OK;
+}
+
+extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
+
+int plan_n_static(const smilehip_plan *p) {
+  return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc);
+}
+int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }
+int plan_row_extra(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? p->cfg.sma_win / 2 : 0; }
+
+extern "C" int smilehip_plan_geometry(const smilehip_plan *p, smilehip_geometry *g) {
+  if (!p || !g) return fail(SMILEHIP_ERR_INVALID, "smilehip_plan_geometry: null argument");
+  g->frame_size = p->geo.N;
+  g->frame_step = p->geo.H;
+  g->fft_size = p->geo.Nfft;
+  g->n_bins = p->geo.K;
+  g->n_static = plan_n_static(p);
+  g->n_out = plan_n_out(p);
+  g->frame_period = p->geo.frame_period;
+  g->fft_frame_size_sec = p->geo.fft_frame_size_sec;
+  return SMILEHIP_OK;
+}
+
+extern "C" int64_t smilehip_num_frames(const smilehip_plan *p, int64_t n_samples) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_num_frames: null plan");
+  if (n_samples < p->geo.N) return 0;
+  return (n_samples - p->geo.N) / p->geo.H + 1;
+}
+
+extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
+  // vIdx * level period; the framer's level period is frameStep
+  // (winToVecProcessor.cpp:562-568), time = vIdx*T via squashTimeMeta
+  return p ? double(t) * p->geo.frame_period : 0.0;
+}
+
+extern "C" double smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row) {
+  if (!plan || row < 0) return 0.0;
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP || n_frames <= 1)
+    return smilehip_frame_time(plan, row);
+  return smilehip_frame_time(plan, row < n_frames - 1 ? row : n_frames - 1);
+}
+
+template <typename T>
+static int64_t copy_out(const std::vector<T> &v, T *out, int64_t cap) {
+  if (out) {
+    if (cap < (int64_t)v.size()) return fail(SMILEHIP_ERR_INVALID, "output buffer too small");
+    std::memcpy(out, v.data(), v.size() * sizeof(T));
+  }
+  return (int64_t)v.size();
+}
+extern "C" int64_t smilehip_plan_get_window(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->h_window, o, cap); }
+extern "C" int64_t smilehip_plan_get_mel_weights(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->mel.coef, o, cap); }
+extern "C" int64_t smilehip_plan_get_mel_chanmap(const smilehip_plan *p, int32_t *o, int64_t cap) { return copy_out(p->mel.chan, o, cap); }
+extern "C" int64_t smilehip_plan_get_dct(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->dct.cos_rows, o, cap); }
+extern "C" int64_t smilehip_plan_get_lifter(const smilehip_plan *p, float *o, int64_t cap) { return copy_out(p->dct.lifter, o, cap); }

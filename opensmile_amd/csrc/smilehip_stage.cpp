@@ -1,0 +1,184 @@
+// libsmilehip, C ABI part 4: the per-component batched operators (what the plugin's overrides call).
+#include "smilehip_internal.hpp"
+
+// ---------------------------------------------- per-component entry points
+#include "lld_stage.hpp"
+
+#define STAGE_RET(expr, what)                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(SMILEHIP_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e_)); \
+    return SMILEHIP_OK;                                                                    \
+  } while (0)
+
+static int check_frames(const void *s, const void *d, int64_t lds, int64_t ldd, int64_t nF, int64_t ws, int64_t wd,
+                        const char *fn) {
+  if (nF < 0 || (nF > 0 && (!s || !d))) return fail(SMILEHIP_ERR_INVALID, "%s: null pointer", fn);
+  if (lds < ws || ldd < wd) return fail(SMILEHIP_ERR_INVALID, "%s: leading dimension too small", fn);
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t n, float *d_out, void *stream) {
+  if (!ctx || n < 0 || (n > 0 && (!d_pcm || !d_out))) return fail(SMILEHIP_ERR_INVALID, "smilehip_pcm16_to_float: bad argument");
+  STAGE_RET(stage_pcm16(d_pcm, n, d_out, (hipStream_t)stream), "pcm16_to_float");
+}
+
+extern "C" int smilehip_pcm_convert(smilehip_context *ctx, const void *d_raw, int n_bps, int n_bits, int n_chan,
+                                    int mono_mixdown, int64_t n, float *d_out, void *stream) {
+  if (!ctx || n < 0 || n_chan < 1 || (n > 0 && (!d_raw || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pcm_convert: bad argument");
+  if (n_bps < 1 || n_bps > 4 || (n_bps == 4 && n_bits != 24 && n_bits != 32))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pcm_convert: unknown sample format (nBPS=%d, nBits=%d)", n_bps, n_bits);
+  STAGE_RET(stage_pcm_convert(d_raw, n_bps, n_bits, n_chan, mono_mixdown != 0, n, d_out, (hipStream_t)stream), "pcm_convert");
+}
+
+extern "C" int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
+                                           int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream) {
+  if (!ctx || N < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_preemphasis_frames: bad argument");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, N, N, "smilehip_preemphasis_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_preemph(d_src, ld_src, d_dst, ld_dst, n_frames, N, k, de, (hipStream_t)stream), "preemphasis");
+}
+
+extern "C" int smilehip_window_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                      int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_window_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_WINDOW)) return fail(SMILEHIP_ERR_INVALID, "smilehip_window_frames: plan was built without this stage's tables");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.N, "smilehip_window_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_window(d_src, ld_src, d_dst, ld_dst, n_frames, p->geo.N, p->d_window.p, (float)p->cfg.win_offset,
+                         (hipStream_t)stream), "window");
+}
+
+extern "C" int smilehip_rfft_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                    int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_rfft_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.Nfft, "smilehip_rfft_frames");
+  if (rc) return rc;
+  const int pad = p->cfg.zero_pad_symmetric ? (int)((p->geo.Nfft - p->geo.N) / 2) : 0;
+  STAGE_RET(stage_rfft(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.N, (int)p->geo.Nfft, pad, p->d_tw_half.p,
+                       p->d_tw_full.p, (hipStream_t)stream), "rfft");
+}
+
+extern "C" int smilehip_sumsq_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                                     double *d_out, void *stream) {
+  if (!ctx || N < 1 || n_frames < 0 || ld_src < N || (n_frames > 0 && (!d_src || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_sumsq_frames: bad argument");
+  STAGE_RET(stage_sumsq(d_src, ld_src, N, n_frames, d_out, (hipStream_t)stream), "sumsq");
+}
+
+extern "C" int smilehip_zcr_count_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N,
+                                         int64_t n_frames, int32_t *d_out, void *stream) {
+  if (!ctx || N < 1 || n_frames < 0 || ld_src < N || (n_frames > 0 && (!d_src || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_zcr_count_frames: bad argument");
+  STAGE_RET(stage_zcr_count(d_src, ld_src, N, n_frames, d_out, (hipStream_t)stream), "zcr_count");
+}
+
+extern "C" int smilehip_acf_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                   int64_t n_out, int64_t n_frames, int use_power, int cepstrum, int norm_output,
+                                   int abs_cepstrum, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_acf_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (n_out < 1 || n_out > p->geo.Nfft / 2)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_acf_frames: n_out %lld outside [1, %lld] (symmetric half of the inverse FFT)",
+                (long long)n_out, (long long)(p->geo.Nfft / 2));
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, n_out, "smilehip_acf_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_acf(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, (int)n_out, use_power, cepstrum, norm_output,
+                      abs_cepstrum, p->d_tw_half.p, p->d_tw_full.p, (hipStream_t)stream), "acf");
+}
+
+extern "C" int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
+                                        double fs_sec, double max_pitch, double *d_voicing, int32_t *d_max_idx, void *stream) {
+  if (!ctx || n < 4 || n_frames < 0 || ld_src < 2 * n || (n_frames > 0 && (!d_src || !d_voicing || !d_max_idx)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_frames: bad argument");
+  STAGE_RET(stage_pitchacf(d_src, ld_src, n_frames, (int)n, fs_sec, max_pitch, d_voicing, d_max_idx, (hipStream_t)stream), "pitchacf");
+}
+
+extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                                        float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!p->d_sharp.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: plan was built without SMILEHIP_STAGE_SPECTRAL");
+  if (p->geo.K != 257) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: K = %lld, the kernel covers K = 257", (long long)p->geo.K);
+  if (!d_state && n_frames > 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null state buffer");
+  int rc = check_frames(d_mag, d_dst, ld_src, ld_dst, n_frames, p->geo.K, 15, "smilehip_spectral_frames");
+  if (rc) return rc;
+  SpectralConsts C;
+  C.fsSec = p->geo.fft_frame_size_sec;
+  C.sharp_w = p->d_sharp.p;
+  for (int i = 0; i < 2; ++i) {
+    C.band_iL[i] = p->band_iL[i]; C.band_iR[i] = p->band_iR[i];
+    C.band_wL[i] = p->band_wL[i]; C.band_wR[i] = p->band_wR[i];
+  }
+  C.slope_Sf = p->slope_Sf;
+  C.slope_S2f = p->slope_S2f;
+  STAGE_RET(stage_spectral(d_mag, ld_src, d_state, first != 0, d_dst, ld_dst, n_frames, (int)p->geo.K, C, (hipStream_t)stream), "spectral");
+}
+
+extern "C" int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands,
+                                           const float *d_eql, float melfloor, float compression, int new_rasta,
+                                           const float *rasta_coef, float *d_state, float *d_dst, int64_t ld_dst,
+                                           int64_t n_frames, void *stream) {
+  if (!ctx || n_bands < 1 || n_bands > 64 || !d_eql) return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_audspec_frames: bad argument (1..64 bands)");
+  if (new_rasta && (!rasta_coef || !d_state)) return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_audspec_frames: RASTA needs coefficients and a state buffer");
+  int rc = check_frames(d_mel, d_dst, ld_src, ld_dst, n_frames, n_bands, n_bands, "smilehip_plp_audspec_frames");
+  if (rc) return rc;
+  PlpConsts Q;
+  Q.melfloor = melfloor;
+  Q.compression = compression;
+  Q.iir = new_rasta ? rasta_coef[0] : 0.0f;
+  for (int i = 0; i < 5; ++i) Q.fir[i] = new_rasta ? rasta_coef[1 + i] : 0.0f;
+  STAGE_RET(stage_plp(d_mel, ld_src, n_bands, d_eql, Q, new_rasta != 0, d_state, d_dst, ld_dst, n_frames, (hipStream_t)stream), "plp");
+}
+
+extern "C" int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                                      float melfloor, float compression, int lp_order, const float *d_cos, const float *d_sin,
+                                      float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!ctx || n_bands < 2 || n_bands > 64 || lp_order < 1 || lp_order > 15 || !d_eql || !d_cos || !d_sin)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_cc_frames: bad argument (2..64 bands, lpOrder 1..15)");
+  int rc = check_frames(d_mel, d_dst, ld_src, ld_dst, n_frames, n_bands, lp_order + 1, "smilehip_plp_cc_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_plp_cc(d_mel, ld_src, n_bands, d_eql, melfloor, compression, lp_order, d_cos, d_sin, d_dst, ld_dst, n_frames,
+                         (hipStream_t)stream), "plp_cc");
+}
+
+extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,
+                                      void *stream) {
+  if (!ctx || n_t < 0 || W < 1 || (kind != 0 && kind != 1) || (n_t > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_window_op_row: bad argument");
+  STAGE_RET(stage_window_op(d_x, d_y, n_t, kind, W, delta_norm(W), (hipStream_t)stream), "window_op");
+}
+
+extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                      int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmag_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.Nfft, p->geo.K, "smilehip_fftmag_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_fftmag(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.Nfft, (hipStream_t)stream), "fftmag");
+}
+
+extern "C" int smilehip_melspec_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                       int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_MEL)) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: plan was built without this stage's tables");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, p->mel.n_bands, "smilehip_melspec_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_melspec(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, p->mel.n_bands, p->cfg.use_power,
+                          p->d_mel_coef.p, p->d_mel_rng.p, p->mel.scale, (hipStream_t)stream), "melspec");
+}
+
+extern "C" int smilehip_mfcc_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                    int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_MFCC)) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_frames: plan was built without this stage's tables");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, "smilehip_mfcc_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_mfcc(d_src, ld_src, d_dst, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, p->d_dct_rows.p,
+                       p->d_dct_gain.p, p->dct.melfloor, p->dct.log_floor, (hipStream_t)stream), "mfcc");
+}
