@@ -643,13 +643,17 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
 #ifdef SMILEHIP_DEBUG_KNOBS
   if (const char *e = getenv("SMILEHIP_DEBUG_GRID")) grid = (unsigned)atoi(e);
 #endif
-  const int nsteps = std::max(7, (h.stage_floats + 127) / 128);   // 7 or 8 (fast512_build_host caps the span at 1024)
+  // 7 or 8 x 128 samples per pass (fast512_build_host caps the span at 1024); spans shorter than that still load
+  // 7 (MP = 13) or 8 (MP = 16) steps -- the extra samples are never staged
+  const int nsteps = (h.mp == 16) ? 8 : std::max(7, (h.stage_floats + 127) / 128);
+  bool launched = false;
 #define SMILEHIP_PICK(MPV, NS, PE, UP, AL)                                                                     \
   if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL) {     \
     const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL>);                         \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+    launched = true;                                                                                            \
   }
 #define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true) SMILEHIP_PICK(MPV, NS, PE, UP, false)
 #define SMILEHIP_PICK4(MPV, NS) SMILEHIP_PICK2(MPV, NS, true, true) SMILEHIP_PICK2(MPV, NS, true, false) \
@@ -660,6 +664,7 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
 #undef SMILEHIP_PICK4
 #undef SMILEHIP_PICK2
 #undef SMILEHIP_PICK
+  if (!launched) return hipErrorInvalidConfiguration;     // no instantiation for this geometry: fail, never skip
   return hipGetLastError();
 }
 

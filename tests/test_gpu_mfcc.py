@@ -229,3 +229,55 @@ def test_maximum_sizes(hip, plan, oracle):
     assert np.array_equal(out[fo[0]:fo[1]], out[fo[n_utt - 2]:fo[n_utt - 1]])
     assert np.array_equal(out[fo[1]:fo[2]], out[fo[n_utt - 1]:fo[n_utt]])
     b.close()
+
+
+GEOMETRIES = [
+    # frame, step, preemph, win (smilehip id), symmetric pad, use_power, first, last  -> which fast-kernel instantiation
+    dict(fs=0.025, st=0.010, pe=1, win="ham", sym=0, pw=1, first=0, last=12),     # <13,7,pe,pw>   (MFCC12_0_D_A)
+    dict(fs=0.032, st=0.010, pe=1, win="han", sym=0, pw=1, first=0, last=12),     # N=512: <16,8>
+    dict(fs=0.020, st=0.010, pe=0, win="ham", sym=1, pw=1, first=1, last=14),     # symmetric zero pad, no pre-emphasis (ComParE front end)
+    dict(fs=0.025, st=0.0125, pe=1, win="ham", sym=0, pw=0, first=1, last=12),    # H=200: <13,8>, magnitudes into the mel bank (IS09 front end)
+    dict(fs=0.025, st=0.005, pe=1, win="gau", sym=1, pw=1, first=0, last=12),     # H=80, Gauss window, padded
+    dict(fs=0.0301, st=0.010, pe=0, win="rec", sym=0, pw=0, first=0, last=5),     # odd N=482 -> (pad_left odd with sym=0 is 0) rectangular
+]
+WIN_IDS = {"rec": 0, "han": 1, "ham": 2, "gau": 3}    # same ids in smilehip.h and lld_oracle.h
+
+
+@pytest.mark.parametrize("kind", ["fast", "generic"])
+@pytest.mark.parametrize("geo", GEOMETRIES, ids=lambda g: f"{g['fs']}-{g['st']}-{g['win']}-pe{g['pe']}-sym{g['sym']}-pw{g['pw']}")
+def test_other_geometries_and_options_vs_oracle(hip, oracle, geo, kind):
+    """The template instantiations the BASELINE configs do not reach (N = 512, 8 PCM steps, no pre-emphasis, symmetric
+    zero padding, magnitude mel input, other windows / hops), fast and reference-order kernels, against the oracle."""
+    capi, ctx = hip
+    from opensmile_amd import synth
+    cfg = capi.mfcc12_0_d_a_config()
+    oc = oracle.default_cfg()
+    cfg.frame_size_sec = oc.frame_size_sec = geo["fs"]
+    cfg.frame_step_sec = oc.frame_step_sec = geo["st"]
+    cfg.preemph = oc.preemph_enable = geo["pe"]
+    cfg.win_func = WIN_IDS[geo["win"]]
+    oc.win_func = WIN_IDS[geo["win"]]
+    cfg.win_sigma = oc.win_sigma = 0.4
+    cfg.zero_pad_symmetric = oc.zero_pad_symmetric = geo["sym"]
+    cfg.use_power = oc.use_power = geo["pw"]
+    cfg.first_mfcc = oc.first_mfcc = geo["first"]
+    cfg.last_mfcc = oc.last_mfcc = geo["last"]
+    os.environ["SMILEHIP_FORCE_GENERIC"] = "1" if kind == "generic" else "0"
+    try:
+        plan = capi.Plan(ctx, cfg)
+    finally:
+        os.environ.pop("SMILEHIP_FORCE_GENERIC", None)
+    D = geo["last"] - geo["first"] + 1
+    lens = [16000, 7001, 3 * int(round(geo["fs"] * 16000))]
+    pcms = [synth.utterance(60 + i, n) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    out = b.run_host(np.concatenate(pcms))
+    for i, p in enumerate(pcms):
+        ref = oracle.mfcc_chain(oc, p)
+        got = out[b.frame_offsets[i]:b.frame_offsets[i + 1]]
+        assert got.shape == ref.shape, (kind, geo, got.shape, ref.shape)
+        scale = np.abs(ref[:, :D]).max(axis=1, keepdims=True)
+        assert (np.abs(got - ref) / np.maximum(scale, 1e-30)).max() <= 1e-5, (kind, geo)
+    b.close()
+    plan.close()
