@@ -152,8 +152,13 @@ __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
   constexpr int S = kChainMaxD;               // LDS row stride; thread = (row lane r, column d): no integer divisions
   __shared__ float l0[(kChainTile + 4 * kChainMaxW) * S];
   __shared__ float l1[(kChainTile + 2 * kChainMaxW) * S];
-  const int u = P.tile_utt[blockIdx.x];
-  const int t0 = P.tile_t0[blockIdx.x];
+  // Natural tile order: workgroup b takes tile b. An XCD-grouped order (tile (b % 8) * ceil(n/8) + b / 8, so that
+  // neighbouring tiles share one L2) was measured 19 % SLOWER for this streaming kernel (0.063 vs 0.053 ms): the eight
+  // XCDs then stream eight distant regions instead of one, and the shared halo is only 6 % of a tile.
+  const int tile = (int)blockIdx.x;
+  if (tile >= P.n_tiles) return;
+  const int u = P.tile_utt[tile];
+  const int t0 = P.tile_t0[tile];
   const int64_t f0 = P.frame_off[u];
   const int T = (int)(P.frame_off[u + 1] - f0);
   if (T <= P.short_T) return;                 // handled by lld_chain_short
