@@ -221,7 +221,7 @@ __device__ unsigned long long g_phase[16];
 //                   melw0 [U*16 f4] | melw1 [U*16 f4] | melo [U*16 u32] | dct [16 x 28] | slots [64 i32]
 //   per wave      : stage [S >= 512] (later PS+lmel: 4 x 144) | spec [4] | 4 x group buffer [272];
 //                   the (re,im) transpose buffer [2078] overlays all of it between frame load and untangle
-template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED>
+template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   }
   for (int i = threadIdx.x; i < 16 * 28; i += blockDim.x) s_dct[i] = F.dct28[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
-  if (P.plp) {
+  if (PLP) {
     for (int i = threadIdx.x; i < 32; i += blockDim.x) s_plp[i] = F.plp_eql[i];
     for (int i = threadIdx.x; i < 16; i += blockDim.x) s_plp[32 + i] = F.plp_sin[i];
   }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       if (b < P.n_bands) {
         float acc = 0.0f;
         for (int s = s_slots[2 * b]; s < s_slots[2 * b + 1]; ++s) acc += s_ps[s];
-        if (P.plp) {                                   // R8: floor, HTK equal loudness, power-law compression (plp.cpp:499-507)
+        if (PLP) {                                     // R8: floor, HTK equal loudness, power-law compression (plp.cpp:499-507)
           float v = acc * F.mel_scale;
           v = v < P.melfloor ? P.melfloor : v;
           s_lmel[b] = __expf(P.plp_compression * __logf(v * s_plp[b]));
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     PHASE(9);                                   // band sums + log
     // ------------------------------------------------------------ PLP-CC (R8): IDFT rows (s_dct holds the cosine
     // table, same 28-float rows), then Durbin + cepstra + lifter on the group's lane 0
-    if (P.plp) {
+    if (PLP) {
       float *s_acf = s_lmel + 32;                       // 16 floats behind the padded band vector
       if (j <= P.plp_order) s_acf[j] = plp_acf_lag(s_lmel, s_dct + j * 28, P.n_bands);
       wave_lds_fence();
@@ -647,17 +647,21 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
   // 7 (MP = 13) or 8 (MP = 16) steps -- the extra samples are never staged
   const int nsteps = (h.mp == 16) ? 8 : std::max(7, (h.stage_floats + 127) / 128);
   bool launched = false;
-#define SMILEHIP_PICK(MPV, NS, PE, UP, AL)                                                                     \
-  if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL) {     \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL>);                         \
+#define SMILEHIP_PICK(MPV, NS, PE, UP, AL, PL)                                                                 \
+  if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL &&     \
+      (P.plp != 0) == PL) {                                                                                     \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL, PL>);                     \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL, PL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
     launched = true;                                                                                            \
   }
-#define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true) SMILEHIP_PICK(MPV, NS, PE, UP, false)
+#define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true, false) SMILEHIP_PICK(MPV, NS, PE, UP, false, false)
 #define SMILEHIP_PICK4(MPV, NS) SMILEHIP_PICK2(MPV, NS, true, true) SMILEHIP_PICK2(MPV, NS, true, false) \
-                                SMILEHIP_PICK2(MPV, NS, false, true) SMILEHIP_PICK2(MPV, NS, false, false)
+                                SMILEHIP_PICK2(MPV, NS, false, true) SMILEHIP_PICK2(MPV, NS, false, false) \
+                                /* the PLP chain works on the power spectrum (the plan checks use_power) */ \
+                                SMILEHIP_PICK(MPV, NS, true, true, true, true) SMILEHIP_PICK(MPV, NS, true, true, false, true) \
+                                SMILEHIP_PICK(MPV, NS, false, true, true, true) SMILEHIP_PICK(MPV, NS, false, true, false, true)
   SMILEHIP_PICK4(13, 7)
   SMILEHIP_PICK4(13, 8)
   SMILEHIP_PICK4(16, 8)

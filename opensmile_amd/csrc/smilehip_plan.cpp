@@ -153,7 +153,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   }
   // fast Nfft=512 kernel if the geometry allows it (SMILEHIP_FORCE_GENERIC=1 disables it)
   p->use_fast = false;
-  if (mask == SMILEHIP_STAGE_ALL && (p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || (is_plp && p->mel.n_bands == 26)) &&
+  if (mask == SMILEHIP_STAGE_ALL && (p->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || (is_plp && p->mel.n_bands == 26 && p->cfg.use_power)) &&
       !p->force_generic && fast512_applicable((int)p->geo.Nfft, (int)p->geo.N)) {
     p->use_fast = fast512_build_host(p->cfg, p->geo, p->h_window, p->mel, p->dct, p->fast) == 0;
     if (p->use_fast && is_plp) {                          // the DCT rows' place holds the IDFT cosine rows (28 floats each)
