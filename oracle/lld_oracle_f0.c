@@ -1,0 +1,476 @@
+/*
+ * lld_oracle_f0.c -- CPU ORACLE. TEST INFRASTRUCTURE ONLY (see lld_oracle.h).
+ *
+ * the F0 group of ComParE_2016 / GeMAPS,
+ *   is13_frame60 -> gauss window -> FFT 1024 -> magnitude
+ *     -> cSpecScale (octave axis by cubic-spline resampling, peak enhancement, smoothing, auditory weighting)
+ *     -> cPitchShs  (sub-harmonic summation, six candidates, greedy peak picking; base class cPitchBase)
+ *     -> cPitchSmootherViterbi (incremental Viterbi over 6 candidates + "unvoiced", 30-frame buffer)
+ *     -> cValbasedSelector (frames with 60 ms RMS energy <= 0.001 are zeroed)
+ * restated from config/compare16/ComParE_2016_core.lld.conf.inc:11-38,76-164 and the sources cited at
+ * each function. Everything the reference does in double is done in double, in the reference's order.
+ *
+ * Pinning (tests/test_oracle_pin_f0.py): with the reference's own rdft plugged in, every level of this
+ * chain is compared with the real SMILExtract's level of the same name (HTK taps, oracle/conf/compare_f0_taps.conf).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "lld_oracle.h"
+
+/* ------------------------------------------------------------------ cSpecScale */
+/* smileDsp_specScaleTransfFwd, SPECTSCALE_LOG branch (smileUtil.c:1100-1105) */
+static double to_log_scale(double x, double base) { return x > 0 ? log(x) / log(base) : 0.0; }
+
+/* cSpecScale::dataProcessorCustomFinalise (specScale.cpp:228-300) for scale=octave, sourceScale=lin, minF=25,
+ * maxF=-1, nPointsTarget=0 (-> K), auditoryWeighting=1; spline caches: smileMath_cspline_init
+ * (smileUtilSpline.c:139-155), smileMath_csplint_init (:296-342) */
+int lldo_specscale_init(lldo_specscale *s, long K, double frame_size_sec_level)
+{
+  memset(s, 0, sizeof(*s));
+  s->K = K;
+  const double fsSec = (double)(float)frame_size_sec_level;       /* specScale.cpp:186 */
+  const double deltaF = 1.0 / fsSec;                              /* :207 */
+  const double base = 2.0;
+  double minF = 25.0, maxF = -1.0;
+  const double samplF = deltaF * (double)(K - 1);                 /* :235-238 */
+  if (maxF <= minF || maxF > samplF) maxF = samplF;
+  const double fmin_t = to_log_scale(minF, base), fmax_t = to_log_scale(maxF, base);
+  const double deltaF_t = (fmax_t - fmin_t) / (double)(K - 1);
+  s->ft = (double *)malloc(sizeof(double) * (size_t)K);
+  s->sigma = (double *)calloc((size_t)K, sizeof(double));
+  s->d1 = (double *)calloc((size_t)K, sizeof(double));
+  s->d2 = (double *)calloc((size_t)K, sizeof(double));
+  s->k = (long *)malloc(sizeof(long) * (size_t)K);
+  s->co = (double *)malloc(sizeof(double) * 3 * (size_t)K);
+  s->audw = (double *)malloc(sizeof(double) * (size_t)K);
+  for (long i = 1; i < K; i++) s->ft[i] = to_log_scale((double)i * deltaF, base);
+  s->ft[0] = 2.0 * s->ft[1] - s->ft[2];                           /* :253 */
+  const double *x = s->ft;
+  for (long i = 1; i < K - 1; i++) {
+    s->sigma[i] = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    s->d1[i] = (x[i + 1] - x[i]) * (x[i + 1] - x[i - 1]);
+    s->d2[i] = (x[i] - x[i - 1]) * (x[i + 1] - x[i - 1]);
+  }
+  long hi = 1;
+  for (long i = 0; i < K; i++) {
+    const double xt = fmin_t + (double)i * deltaF_t;
+    if (i == 0 && xt < x[0]) return 0;
+    while (hi < K && x[hi] < xt) hi++;
+    if (hi == K) return 0;                                        /* the reference disables its output here */
+    const long lo = hi - 1;
+    s->k[i] = lo;
+    const double range = x[hi] - x[lo];
+    if (range == 0.0) return 0;
+    const double a = (x[hi] - xt) / range, b = 1.0 - a, r2 = range * range / 6.0;
+    s->co[3 * i] = a;
+    s->co[3 * i + 1] = (a * a * a - a) * r2;
+    s->co[3 * i + 2] = (b * b * b - b) * r2;
+  }
+  const double nOct = log(maxF / minF) / log(2.0);
+  const double nPPO = (double)K / nOct;                            /* :281 */
+  const double atan_s = nPPO * (log(65.0 / 50.0) / log(2.0)) - 1.0;
+  for (long i = 0; i < K; i++) s->audw[i] = 0.5 + atan(3.0 * ((double)i + 1 - atan_s) / nPPO) / M_PI;
+  s->meta[0] = (float)minF; s->meta[1] = (float)maxF; s->meta[2] = (float)nOct; s->meta[3] = (float)nPPO;   /* :289-299 */
+  s->meta[4] = (float)fmin_t; s->meta[5] = (float)fmax_t; s->meta[6] = 0.0f; s->meta[7] = (float)base;
+  return 1;
+}
+
+void lldo_specscale_free(lldo_specscale *s)
+{
+  free(s->ft); free(s->sigma); free(s->d1); free(s->d2); free(s->k); free(s->co); free(s->audw);
+  memset(s, 0, sizeof(*s));
+}
+
+/* smileDsp_specEnhanceSHS (smileUtil.c:1965-2001): everything further than 2 bins from a local maximum is
+ * zeroed BETWEEN consecutive maxima (not before the first / after the last). With exactly one maximum the
+ * reference indexes posmax[1] of its zero-initialised list, i.e. treats it as a maximum at 0. */
+static void enhance_peaks(double *a, long n, long *pos)
+{
+  long m = 0;
+  if (n < 2) return;
+  pos[0] = pos[1] = 0;
+  if (a[0] > a[1]) pos[m++] = 0;
+  for (long i = 1; i < n - 1; i++)
+    if (a[i] > a[i - 1] && a[i] >= a[i + 1]) pos[m++] = i;
+  if (a[n - 1] > a[n - 2]) pos[m++] = n - 1;
+  if (m == 1) {
+    const long p1 = 0;                                             /* calloc'ed posmax[1] */
+    for (long j = 0; j <= p1 - 3; j++) a[j] = 0;
+    for (long j = p1 + 3; j < n; j++) a[j] = 0;
+  } else {
+    for (long i = 1; i < m; i++)
+      for (long j = pos[i - 1] + 3; j <= pos[i] - 3; j++) a[j] = 0;
+  }
+}
+
+/* smileDsp_specSmoothSHS (smileUtil.c:2004-2014): (1,2,1)/4 over the ORIGINAL neighbours, last bin untouched */
+static void smooth_121(double *a, long n)
+{
+  double prev = 0.0;
+  for (long i = 0; i < n - 1; i++) {
+    const double cur = a[i];
+    a[i] = (prev + 2.0 * cur + a[i + 1]) / 4.0;
+    prev = cur;
+  }
+}
+
+/* cSpecScale::processVector (specScale.cpp:305-357); natural spline by smileMath_cspline
+ * (smileUtilSpline.c:157-212), evaluation by smileMath_csplint (:344-357) */
+void lldo_specscale_frame(const lldo_specscale *s, const float *mag, float *dst)
+{
+  const long K = s->K;
+  double *y = (double *)malloc(sizeof(double) * (size_t)K * 3);
+  double *y2 = y + K, *u = y2 + K;
+  long *pos = (long *)malloc(sizeof(long) * (size_t)(K / 2 + 3));
+  for (long i = 0; i < K; i++) y[i] = (double)mag[i];
+  enhance_peaks(y, K, pos);
+  smooth_121(y, K);
+  u[0] = 0.0; y2[0] = 0.0;
+  for (long i = 1; i < K - 1; i++) {
+    const double sg = s->sigma[i];
+    const double p = 1.0 / (sg * y2[i - 1] + 2.0);
+    y2[i] = (sg - 1.0) * p;
+    const double ut = (y[i + 1] - y[i]) / s->d1[i] - (y[i] - y[i - 1]) / s->d2[i];
+    u[i] = p * (6.0 * ut - sg * u[i - 1]);
+  }
+  y2[K - 1] = (0.0 - 0.0 * u[K - 2]) / (0.0 * y2[K - 2] + 1.0);
+  for (long j = K - 2; j >= 0; j--) y2[j] = y2[j] * y2[j + 1] + u[j];
+  for (long i = 0; i < K; i++) {
+    const double a = s->co[3 * i], b = 1.0 - a, c = s->co[3 * i + 1], d = s->co[3 * i + 2];
+    const long k = s->k[i];
+    const double o = a * y[k] + b * y[k + 1] + c * y2[k] + d * y2[k + 1];
+    float v = (float)o;
+    if (v > 0.0) v = (float)((double)v * s->audw[i]); else v = 0.0f;
+    dst[i] = v;
+  }
+  free(y); free(pos);
+}
+
+/* ------------------------------------------------------------------ cPitchShs / cPitchBase */
+/* cPitchShs::setupNewNames (pitchShs.cpp:178-204) reading the level meta data of cSpecScale */
+void lldo_shs_init(lldo_shs *h, const lldo_specscale *s)
+{
+  memset(h, 0, sizeof(*h));
+  h->N = s->K;
+  const float fmin = s->meta[0], fmint = s->meta[4], fmaxt = s->meta[5];
+  h->n_octaves = s->meta[2];
+  h->points_per_octave = s->meta[3];
+  h->base = exp(log((double)fmin) / (double)fmint);
+  if (fabs(h->base - 2.0) < 0.00001) h->base = 2.0;
+  h->Fmint = fmint;
+  h->Fstept = (fmaxt - fmint) / (float)(h->N - 1);
+  h->n_harmonics = 15; h->compression = (float)0.85; h->n_cand = 6;
+  h->min_pitch = 52.0; h->max_pitch = 620.0; h->voicing_cutoff = (float)0.7;
+}
+
+/* smileMath_quadFrom3pts (smileUtil.c:1009-1033) */
+static double quad_vertex(double x1, double y1, double x2, double y2, double x3, double y3, double *y)
+{
+  const double den = x1 * x1 * x2 + x2 * x2 * x3 + x3 * x3 * x1 - x3 * x3 * x2 - x2 * x2 * x1 - x1 * x1 * x3;
+  if (den != 0.0) {
+    const double a = (y1 * x2 + y2 * x3 + y3 * x1 - y3 * x2 - y2 * x1 - y1 * x3) / den;
+    const double b = (x1 * x1 * y2 + x2 * x2 * y3 + x3 * x3 * y1 - x3 * x3 * y2 - x2 * x2 * y1 - x1 * x1 * y3) / den;
+    const double c = (x1 * x1 * x2 * y3 + x2 * x2 * x3 * y1 + x3 * x3 * x1 * y2 - x3 * x3 * x2 * y1 - x2 * x2 * x1 * y3 - x1 * x1 * x3 * y2) / den;
+    if (a != 0.0) {
+      const double x = -b / (2.0 * a);
+      *y = c - a * x * x;
+      return x;
+    }
+  }
+  if (y1 > y2 && y1 > y3) { *y = y1; return x1; }
+  if (y2 > y1 && y2 > y3) { *y = y2; return x2; }
+  if (y3 > y1 && y3 > y2) { *y = y3; return x3; }
+  *y = y1;
+  return x1;
+}
+
+/* One frame: cPitchBase::processVector (pitchBase.cpp:187-310) around cPitchShs::pitchDetect
+ * (pitchShs.cpp:214-347, greedyPeakAlgo=1, octaveCorrection=0). dst: 21 values
+ * [nCandidates | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip].
+ * ss_out (optional, N floats) receives the summation spectrum. */
+void lldo_pitch_shs(const lldo_shs *h, const float *in, float *dst, float *ss_out)
+{
+  const long N = h->N;
+  const int NC = h->n_cand;
+  float f0c[LLDO_SHS_MAX_CAND], cv[LLDO_SHS_MAX_CAND], cs[LLDO_SHS_MAX_CAND];
+  for (int i = 0; i < NC; i++) f0c[i] = cv[i] = cs[i] = 0.0f;
+  float *SS = (float *)malloc(sizeof(float) * (size_t)N);
+  for (long j = 0; j < N; j++) SS[j] = in[j];
+  float scale = h->compression;
+  for (int i = 2; i < h->n_harmonics + 1; i++) {
+    const long shift = (long)floor((double)h->points_per_octave * (log((double)i) / log(2.0)));
+    for (long j = shift; j < N; j++) SS[j - shift] += in[j] * scale;
+    scale *= h->compression;
+  }
+  for (long j = 0; j < N; j++) {
+    SS[j] /= (float)h->n_harmonics;
+    if (SS[j] < 0) SS[j] = 0.0f;
+  }
+  if (ss_out) memcpy(ss_out, SS, sizeof(float) * (size_t)N);
+  int n_found = 0;
+  double mean = (double)SS[0];
+  long i;
+  for (i = 1; i < N - 1; i++) {
+    if (SS[i - 1] < SS[i] && SS[i] > SS[i + 1]) {
+      for (int j = 0; j < NC; j++) {
+        if (cs[j] == 0.0 || cs[j] < SS[i]) {
+          for (int jj = NC - 1; jj > j; jj--) { cs[jj] = cs[jj - 1]; f0c[jj] = f0c[jj - 1]; }
+          f0c[j] = (float)i;
+          cs[j] = SS[i];
+          if (n_found < NC) n_found++;
+          break;
+        }
+      }
+    }
+    mean += (double)SS[i];
+  }
+  mean = (mean + (double)SS[i]) / (double)N;
+  for (int c = 0; c < n_found; c++) {
+    const long j = (long)f0c[c];
+    const float f1 = f0c[c] * h->Fstept + h->Fmint;
+    const float f2 = (f0c[c] + (float)1.0) * h->Fstept + h->Fmint;
+    const float f0 = (f0c[c] - (float)1.0) * h->Fstept + h->Fmint;
+    double sc = 0;
+    const double fx = quad_vertex((double)f0, (double)SS[j - 1], (double)f1, (double)SS[j], (double)f2, (double)SS[j + 1], &sc);
+    f0c[c] = (float)exp(fx * log(h->base));
+    cs[c] = (float)sc;
+    cv[c] = (sc > 0.0 && sc > mean) ? (float)(1.0 - mean / sc) : 0.0f;
+  }
+  free(SS);
+  /* candidates outside [minPitch, maxPitch] are removed, the rest moves up (pitchBase.cpp:212-229) */
+  int n = n_found;
+  if (n > 0) {
+    for (int c = 0; c < NC && n > 0; c++) {
+      if ((double)f0c[c] > h->max_pitch || (double)f0c[c] < h->min_pitch) {
+        const float orig = f0c[c];
+        int j;
+        for (j = c + 1; j < NC; j++) { f0c[j - 1] = f0c[j]; cv[j - 1] = cv[j]; cs[j - 1] = cs[j]; }
+        f0c[j - 1] = 0; cv[j - 1] = 0; cs[j - 1] = 0;
+        if (orig > 0.0) { n--; c--; }
+      }
+    }
+  }
+  /* best-scored candidate first (:238-258) */
+  int best = 0;
+  float mx = cs[0];
+  for (int c = 1; c < NC; c++) if (cs[c] > mx) { mx = cs[c]; best = c; }
+  if (best > 0) {
+    float t;
+    t = f0c[0]; f0c[0] = f0c[best]; f0c[best] = t;
+    t = cv[0]; cv[0] = cv[best]; cv[best] = t;
+    t = cs[0]; cs[0] = cs[best]; cs[best] = t;
+  }
+  float *o = dst;
+  *o++ = (float)n;
+  for (int c = 0; c < NC; c++) *o++ = f0c[c];
+  for (int c = 0; c < NC; c++) *o++ = cv[c];
+  for (int c = 0; c < NC; c++) *o++ = cs[c];
+  *o++ = (cv[0] <= h->voicing_cutoff) ? 0.0f : f0c[0];           /* F0raw */
+  *o++ = (cv[0] <= h->voicing_cutoff) ? 0.0f : cv[0];            /* voicingClip */
+}
+
+/* ------------------------------------------------------------------ cPitchSmootherViterbi */
+/* cSmileViterbiPitchSmooth (pitchSmootherViterbi.hpp:158-300) driven by cSmileViterbi::addFrame / flushTrellis /
+ * getNextOutputFrame (pitchSmootherViterbi.cpp:80-216, .hpp:105-125) exactly as cPitchSmootherViterbi::myTick
+ * (:451-570) drives them: one addFrame per input frame, every decided frame is read at once, flush at end of input.
+ * Weights as ComParE sets them AFTER setWeights' own assignment wTvvd = tvv (.hpp:291-299). Frames of 2*NC+4 floats:
+ * [f0, voicing] x NC, then data[F0rawI=0] (= nCandidates), 0, 0, vIdx (:471-486 with the unset field indices). */
+#define VIT_BUF 30
+typedef struct {
+  int nS, fsz;
+  float thresh;
+  double wLocal, wTvv, wTvvd, wTvuv, wThr, wRange;
+  double lastChange;
+  long wr, rd, pathIdx, convIdx;
+  int pathBuf;
+  float *buf, *prev;
+  int *paths[2], *best;
+  double *cost, *costNew;
+} viterbi_t;
+
+static double f_weight(float f)
+{
+  if (f > 0.0 && f < 100.0) return -(1.0 / 100.0) * f + 1.0;
+  else if (f >= 100.0 && f < 350.0) return 0.0;
+  else if (f >= 350.0 && f < 600.0) return ((f - 350.0) / 250.0);
+  else if (f >= 600.0) return 1.2;
+  else if (f <= 0) return 2.0;
+  return 0.0;
+}
+
+static double local_cost(const viterbi_t *v, int i, const float *fr)
+{
+  double pv = (double)fr[i * 2 + 1], thr = 0.0;
+  if (pv < 0.01) pv = 0.01;
+  if (pv > 1.00) pv = 1.00;
+  if (pv < v->thresh) thr = v->wThr;
+  if (i < v->nS - 1) return (-log(pv) + thr) * v->wLocal + f_weight(fr[i * 2]) * v->wRange;
+  double flag = 0.0;
+  for (int j = 0; j < v->nS; j++) if (fr[j * 2 + 1] >= v->thresh) { flag = v->wThr; break; }
+  return v->wLocal * flag;
+}
+
+/* i: state in the current frame, j: state in the previous frame. `i == j == nStates-1` of the reference compares
+ * (i == j) with 6 and never holds, so u->u falls through to the final "return 1.0". */
+static double trans_cost(viterbi_t *v, int i, int j, const float *prev, const float *cur)
+{
+  const int U = v->nS - 1;
+  if (i < U && j < U) {
+    const float f0 = prev[j * 2], f1 = cur[i * 2];
+    if (f0 == 0 || f1 == 0) return 999.0;
+    const double r = log((double)(f1 / f0));
+    const double x = v->wTvv * fabs(r) + v->wTvvd * fabs(r - v->lastChange);
+    v->lastChange = r;
+    return x;
+  }
+  if ((i == U && j < U) || (i < U && j == U)) { v->lastChange = 0.0; return v->wTvuv; }
+  return 1.0;
+}
+
+static void vit_add(viterbi_t *v, const float *frame)
+{
+  const int nS = v->nS;
+  float *b = v->buf + (v->wr % VIT_BUF) * v->fsz;
+  memcpy(b, frame, sizeof(float) * (size_t)v->fsz);
+  v->wr++;
+  const float *a = v->prev;
+  v->prev = b;
+  if (v->pathIdx == 0 || a == NULL) {
+    v->pathIdx = 0; v->convIdx = -1;
+    for (int i = 0; i < nS; i++) { v->cost[i] = local_cost(v, i, b); v->paths[v->pathBuf][i * VIT_BUF] = i; }
+  } else {
+    const int nb = (v->pathBuf + 1) % 2;
+    for (int i = 0; i < nS; i++) {
+      int ms = 0;
+      double mc = trans_cost(v, i, 0, a, b) + v->cost[0];
+      for (int j = 1; j < nS; j++) {
+        const double c = trans_cost(v, i, j, a, b) + v->cost[j];
+        if (c < mc) { ms = j; mc = c; }
+      }
+      v->costNew[i] = mc + local_cost(v, i, b);
+      memcpy(v->paths[nb] + i * VIT_BUF, v->paths[v->pathBuf] + ms * VIT_BUF, VIT_BUF * sizeof(int));
+      v->paths[nb][i * VIT_BUF + v->pathIdx % VIT_BUF] = i;
+    }
+    double *t = v->cost; v->cost = v->costNew; v->costNew = t;
+    v->pathBuf = nb;
+  }
+  v->pathIdx++;
+  const int *P = v->paths[v->pathBuf];
+  if (v->pathIdx - v->convIdx > VIT_BUF) {                        /* forced decision for the oldest open frame */
+    int ms = 0;
+    for (int i = 1; i < nS; i++) if (v->cost[i] < v->cost[ms]) ms = i;
+    v->convIdx++;
+    v->best[v->convIdx % VIT_BUF] = P[ms * VIT_BUF + v->convIdx % VIT_BUF];
+  } else {                                                        /* decide up to where all paths agree */
+    for (long n = v->convIdx + 1; n < v->pathIdx; n++) {
+      const int x = P[n % VIT_BUF];
+      int match = 1;
+      for (int i = 1; i < nS; i++) if (x != P[i * VIT_BUF + n % VIT_BUF]) { match = 0; break; }
+      if (!match) break;
+      v->convIdx++;
+      v->best[v->convIdx % VIT_BUF] = x;
+    }
+  }
+}
+
+static void vit_flush(viterbi_t *v)
+{
+  int ms = 0;
+  for (int i = 1; i < v->nS; i++) if (v->cost[i] < v->cost[ms]) ms = i;
+  const int *P = v->paths[v->pathBuf];
+  for (long i = v->convIdx + 1; i < v->pathIdx; i++) {
+    v->convIdx++;
+    v->best[v->convIdx % VIT_BUF] = P[ms * VIT_BUF + v->convIdx % VIT_BUF];
+  }
+}
+
+/* shs: T x 21 rows of lldo_pitch_shs; out: T x 2 [F0final, voicingFinalUnclipped]; states (optional): T ints */
+void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *out, int *states)
+{
+  enum { NC = 6, FSZ = NC * 2 + 4 };
+  viterbi_t v;
+  memset(&v, 0, sizeof(v));
+  v.nS = NC + 1; v.fsz = FSZ; v.thresh = voicing_cutoff;
+  v.wLocal = 2.0; v.wTvv = 10.0; v.wTvvd = 10.0; v.wTvuv = 10.0; v.wThr = 4.0; v.wRange = 1.0;
+  v.lastChange = 1.0;
+  v.convIdx = -1;
+  v.buf = (float *)malloc(sizeof(float) * FSZ * VIT_BUF);
+  v.paths[0] = (int *)malloc(sizeof(int) * v.nS * VIT_BUF);
+  v.paths[1] = (int *)malloc(sizeof(int) * v.nS * VIT_BUF);
+  v.best = (int *)malloc(sizeof(int) * v.nS * VIT_BUF);
+  v.cost = (double *)calloc((size_t)v.nS, sizeof(double));
+  v.costNew = (double *)calloc((size_t)v.nS, sizeof(double));
+  long n_out = 0;
+  for (long t = 0; t <= T; t++) {
+    if (t < T) {
+      const float *r = shs + t * 21;
+      float fr[FSZ];
+      for (int i = 0; i < NC; i++) { fr[2 * i] = r[1 + i]; fr[2 * i + 1] = r[1 + NC + i]; }
+      fr[2 * NC] = r[0]; fr[2 * NC + 1] = 0.0f; fr[2 * NC + 2] = 0.0f; fr[2 * NC + 3] = (float)t;
+      vit_add(&v, fr);
+    } else {
+      if (T > 0) vit_flush(&v);
+    }
+    while (v.convIdx + 1 - v.rd > 0) {
+      const int s = v.best[v.rd % VIT_BUF];
+      const float *b = v.buf + (v.rd % VIT_BUF) * FSZ;
+      out[2 * n_out] = (s < NC) ? b[2 * s] : 0.0f;
+      out[2 * n_out + 1] = (s < NC) ? b[2 * s + 1] : b[1];
+      if (states) states[n_out] = s;
+      n_out++;
+      v.rd++;
+    }
+  }
+  free(v.buf); free(v.paths[0]); free(v.paths[1]); free(v.best); free(v.cost); free(v.costNew);
+}
+
+/* ------------------------------------------------------------------ the group for one utterance */
+/* out: T60 x 2 = level is13_pitchG60 [F0final, voicingFinalUnclipped] after cValbasedSelector
+ * (valbasedSelector.cpp:139-237: idx 0 = RMS energy of the windowed 60 ms frame, threshold 0.001, zeroVec).
+ * Optional taps: hps T60 x 513 (is13_hpsG60), shs T60 x 21 (is13_pitchShsG60), vit T60 x 2 (is13_pitchG60_viterbi),
+ * e60 T60 (is13_e60). Returns T60 (out == NULL: query). */
+long lldo_compare_f0_chain(const int16_t *pcm, long n_samples, float *out, float *tap_hps, float *tap_shs,
+                           float *tap_vit, float *tap_e60)
+{
+  lldo_mfcc_cfg c;
+  lldo_default_mfcc12_cfg(&c);
+  c.frame_size_sec = 0.060; c.preemph_enable = 0; c.zero_pad_symmetric = 1;
+  lldo_geom g;
+  lldo_geometry(&c, &g);
+  const long T = lldo_num_frames(n_samples, g.N, g.H);
+  if (!out) return T;
+  if (T <= 0) return 0;
+  float *x = (float *)malloc(sizeof(float) * (size_t)n_samples);
+  lldo_pcm16_to_float(pcm, n_samples, x);
+  double *w = (double *)malloc(sizeof(double) * (size_t)g.N);
+  lldo_window_table(LLDO_WIN_GAUSS, g.N, 0.4, 1.0, w);
+  lldo_specscale ss;
+  lldo_shs sh;
+  if (!lldo_specscale_init(&ss, g.K, g.frame_size_sec_fft)) { free(x); free(w); return -1; }
+  lldo_shs_init(&sh, &ss);
+  float *fr = (float *)malloc(sizeof(float) * (size_t)g.N);
+  float *sp = (float *)malloc(sizeof(float) * (size_t)g.Nfft);
+  float *mg = (float *)malloc(sizeof(float) * (size_t)g.K);
+  float *hp = (float *)malloc(sizeof(float) * (size_t)g.K);
+  float *shs = (float *)malloc(sizeof(float) * 21 * (size_t)T);
+  float *e60 = (float *)malloc(sizeof(float) * (size_t)T);
+  for (long t = 0; t < T; t++) {
+    lldo_window_apply(x + t * g.H, fr, g.N, w, 0.0);
+    e60[t] = lldo_energy_rms(fr, g.N);                            /* [is13_energy60] on is13_winG60 */
+    lldo_rfft_frame(fr, g.N, sp, g.Nfft, 1);
+    lldo_fftmag(sp, g.Nfft, mg);
+    lldo_specscale_frame(&ss, mg, hp);
+    if (tap_hps) memcpy(tap_hps + t * g.K, hp, sizeof(float) * (size_t)g.K);
+    lldo_pitch_shs(&sh, hp, shs + t * 21, NULL);
+  }
+  lldo_pitch_viterbi(shs, T, sh.voicing_cutoff, out, NULL);
+  if (tap_shs) memcpy(tap_shs, shs, sizeof(float) * 21 * (size_t)T);
+  if (tap_vit) memcpy(tap_vit, out, sizeof(float) * 2 * (size_t)T);
+  if (tap_e60) memcpy(tap_e60, e60, sizeof(float) * (size_t)T);
+  for (long t = 0; t < T; t++)
+    if (!(e60[t] > (float)0.001)) { out[2 * t] = 0.0f; out[2 * t + 1] = 0.0f; }
+  free(x); free(w); free(fr); free(sp); free(mg); free(hp); free(shs); free(e60);
+  lldo_specscale_free(&ss);
+  return T;
+}

@@ -334,3 +334,43 @@ def compare_ab_chain(pcm, raw=False):
     if rows > 0:
         L.lldo_compare_ab_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, r59.ctypes.data)
     return (out, r59) if raw else out
+
+
+F0_TAPS_CONF = os.path.join(HERE, "conf", "compare_f0_taps.conf")
+
+
+def run_reference_taps(pcm, names=("hps", "shs", "vit", "pitch", "e60", "jit", "nzsmo", "nzsmo_de"), fs=16000,
+                       conf=None):
+    """Real SMILExtract on ComParE_2016 with HTK taps on the F0-group levels (oracle/conf/compare_f0_taps.conf).
+    Returns {tap name: matrix} plus "lld" (the 130-column LLD level)."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", conf or F0_TAPS_CONF, "-I", wav, "-lldhtkoutput", "lld.htk", "-l", "0"], check=True,
+                       cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for n in tuple(names) + ("lld",):
+            p = os.path.join(td, "lld.htk" if n == "lld" else "tap_%s.htk" % n)
+            out[n] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        return out
+
+
+def compare_f0_chain(pcm, taps=False):
+    """ComParE_2016 F0 group, level is13_pitchG60: T60 x 2 [F0final, voicingFinalUnclipped];
+    taps=True also returns {hps, shs, vit, e60} (the levels of the same names, see lld_oracle_f0.c)."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_compare_f0_chain.restype = C.c_long
+    L.lldo_compare_f0_chain.argtypes = [C.c_void_p, C.c_long] + [C.c_void_p] * 5
+    T = L.lldo_compare_f0_chain(pcm.ctypes.data, len(pcm), None, None, None, None, None)
+    T = max(T, 0)
+    out = np.zeros((T, 2), np.float32)
+    t = {"hps": np.zeros((T, 513), np.float32), "shs": np.zeros((T, 21), np.float32),
+         "vit": np.zeros((T, 2), np.float32), "e60": np.zeros((T, 1), np.float32)}
+    if T > 0:
+        r = L.lldo_compare_f0_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, t["hps"].ctypes.data,
+                                    t["shs"].ctypes.data, t["vit"].ctypes.data, t["e60"].ctypes.data)
+        if r < 0:
+            raise RuntimeError("lldo_compare_f0_chain failed")
+    return (out, t) if taps else out

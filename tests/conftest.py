@@ -62,3 +62,9 @@ def golden_plp():
 def golden_compare():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "compare16_ab_synth.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_f0():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "compare16_f0_synth.npz"))

@@ -34,6 +34,27 @@ def gen_func():
     np.savez_compressed(os.path.join(OUT, "is09_func_synth.npz"), **ref)
 
 
+
+def gen_f0():
+    """ComParE_2016 F0 group: the levels of oracle/conf/compare_f0_taps.conf from the real binary
+    (pitch = is13_pitchG60, shs = is13_pitchShsG60, vit = is13_pitchG60_viterbi, e60 = is13_e60,
+    jit = is13_jitterShimmer, nzsmo / nzsmo_de = is13_lld_nzsmo[_de], lld = the 130-column LLD level;
+    hps = is13_hpsG60 only for two short inputs, it is 513 columns wide)."""
+    ref = {}
+    for name, (u, n) in {"u2_16000": (2, 16000), "u3_16000": (3, 16000), "u10_16000": (10, 16000),
+                          "u1_16000": (1, 16000), "u0_16000": (0, 16000), "u7_960": (7, 960), "u7_1120": (7, 1120),
+                          "u7_1600": (7, 1600), "u4_48000": (4, 48000), "u11_160000": (11, 160000)}.items():
+        pcm = synth.utterance(u, n)
+        t = lldo.run_reference_taps(pcm)
+        ref["pcm_" + name] = pcm
+        for k in ("pitch", "shs", "vit", "e60", "jit", "nzsmo", "nzsmo_de"):
+            ref[k + "_" + name] = t[k]
+        ref["lldf0_" + name] = np.concatenate([t["lld"][:, 0:6], t["lld"][:, 65:71]], axis=1)
+        if name in ("u2_16000", "u7_1120"):
+            ref["hps_" + name] = t["hps"]
+        print("f0", name, t["pitch"].shape, t["lld"].shape)
+    np.savez_compressed(os.path.join(OUT, "compare16_f0_synth.npz"), **ref)
+
 def gen_plp():
     # config/plp/PLP_0_D_A.conf (PLP-CC + delta + accel, 18 columns): R8's IDFT / LP / cepstrum branch
     ref = {}
@@ -100,6 +121,7 @@ def main(only=None):
 
     gen_func()
     gen_plp()
+    gen_f0()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave

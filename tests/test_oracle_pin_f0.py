@@ -1,0 +1,70 @@
+"""Pin the F0 group of the CPU oracle (oracle/lld_oracle_f0.c: cSpecScale, cPitchShs / cPitchBase,
+cPitchSmootherViterbi, cValbasedSelector on the 60 ms gauss-windowed frames of ComParE_2016) level by
+level against the REAL reference binary's levels of the same names (HTK taps of
+oracle/conf/compare_f0_taps.conf; golden file made by tests/golden/make_golden.py gen_f0)."""
+import numpy as np
+import pytest
+
+KEYS = ["u2_16000", "u3_16000", "u10_16000", "u1_16000", "u0_16000", "u7_960", "u7_1120", "u7_1600", "u4_48000",
+        "u11_160000"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_f0_levels_bit_exact_with_reference_fft(oracle, golden_f0, key):
+    if not oracle.use_reference_fft(True):
+        pytest.skip("oracle/_ref/libref_dsp.so not built")
+    try:
+        out, taps = oracle.compare_f0_chain(golden_f0["pcm_" + key], taps=True)
+    finally:
+        oracle.use_reference_fft(False)
+    for lvl in ("e60", "shs", "vit"):
+        ref = golden_f0[lvl + "_" + key]
+        assert taps[lvl].shape == ref.shape, lvl
+        assert np.array_equal(bits(taps[lvl]), bits(ref)), f"{lvl}: max abs {np.abs(taps[lvl] - ref).max()}"
+    if "hps_" + key in golden_f0.files:
+        assert np.array_equal(bits(taps["hps"]), bits(golden_f0["hps_" + key]))
+    ref = golden_f0["pitch_" + key]
+    assert out.shape == ref.shape                 # T60 x [F0final, voicingFinalUnclipped]
+    assert np.array_equal(bits(out), bits(ref))
+
+
+def f0_tolerances(out, ref, what=""):
+    """Gate for an FFT other than the reference's (built-in or HIP): F0 within 1e-5 relative on frames where both
+    decide "voiced", voicing within 1e-5 absolute; the voiced/unvoiced and candidate decisions of the Viterbi pass
+    are discrete, so a small share of frames may legitimately take the other branch."""
+    assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
+    if out.shape[0] == 0:
+        return
+    o, r = out.astype(np.float64), ref.astype(np.float64)
+    same = np.abs(o[:, 0] - r[:, 0]) <= 1e-5 * np.maximum(np.abs(r[:, 0]), 1.0)
+    same &= np.abs(o[:, 1] - r[:, 1]) <= 1e-5
+    assert (~same).mean() <= 0.01, f"{what}: {int((~same).sum())} of {len(same)} frames differ"
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_f0_own_fft_within_tolerance(oracle, golden_f0, key):
+    oracle.use_reference_fft(False)
+    out = oracle.compare_f0_chain(golden_f0["pcm_" + key])
+    f0_tolerances(out, golden_f0["pitch_" + key], key)
+
+
+@pytest.mark.skipif(not __import__("oracle.lldo", fromlist=["x"]).have_ref(), reason="oracle/_ref not built")
+def test_f0_levels_against_live_reference(oracle):
+    """Fresh inputs (not in the golden file) through the real binary, where it is available."""
+    from opensmile_amd import synth
+    if not oracle.use_reference_fft(True):
+        pytest.skip("oracle/_ref/libref_dsp.so not built")
+    try:
+        for u, n in ((12, 24000), (13, 40000)):
+            pcm = synth.utterance(u, n)
+            ref = oracle.run_reference_taps(pcm, names=("pitch", "shs", "hps"))
+            out, taps = oracle.compare_f0_chain(pcm, taps=True)
+            assert np.array_equal(bits(taps["hps"]), bits(ref["hps"]))
+            assert np.array_equal(bits(taps["shs"]), bits(ref["shs"]))
+            assert np.array_equal(bits(out), bits(ref["pitch"]))
+    finally:
+        oracle.use_reference_fft(False)
