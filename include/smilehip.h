@@ -128,12 +128,19 @@ typedef struct smilehip_lld_config {
   int64_t  force_frame_size;            /* N  */
   double   force_fft_frame_size_sec;    /* frameSizeSec of the spectrum level (cMelspec::configureField, melspec.cpp:150-173) */
   uint32_t stage_mask;                  /* SMILEHIP_STAGE_* bits */
+  /* SMILEHIP_CHAIN_COMPARE_F0 (pitch_max = cPitchShs maxPitch, voicing_cutoff = its voicingCutoff) */
+  double   pitch_min;                   /* cPitchBase minPitch */
+  int32_t  shs_n_harmonics;             /* cPitchShs nHarmonics (<= 16) */
+  float    shs_compression;             /* cPitchShs compressionFactor */
+  float    f0_min_energy;               /* cValbasedSelector threshold on the 60 ms frame's RMS energy */
+  int32_t  reserved0;
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
 #define SMILEHIP_CHAIN_IS09 1
 #define SMILEHIP_CHAIN_COMPARE_AB 2
 #define SMILEHIP_CHAIN_PLP 3
+#define SMILEHIP_CHAIN_COMPARE_F0 4
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -176,6 +183,14 @@ void smilehip_config_is09_lld(smilehip_lld_config *c);
 void smilehip_config_plp_0_d_a(smilehip_lld_config *c);
 /* fills c with groups A+B of config/compare16/ComParE_2016.conf (chain_kind = COMPARE_AB) */
 void smilehip_config_compare16_ab(smilehip_lld_config *c);
+/* fills c with the F0 group of config/compare16/ComParE_2016.conf up to is13_pitchG60 (chain_kind = COMPARE_F0) */
+void smilehip_config_compare16_f0(smilehip_lld_config *c);
+
+/* F0 chain taps (tests / diagnostics): device pointers to the per-frame scratch the last smilehip_lld_run of this
+ * batch filled -- candidates [total_frames x 21] = level is13_pitchShsG60 (nCandidates | F0Cand[6] | candVoicing[6] |
+ * candScores[6] | F0raw | voicingClip), energies [total_frames] = level is13_e60 -- and an optional caller-owned
+ * destination [total_frames x n_bins] for level is13_hpsG60 (NULL switches the tap off). */
+int smilehip_batch_f0_taps(smilehip_batch *b, float *d_hps_dst, const float **d_shs, const float **d_e60);
 
 /* ---- functionals over the LLD level ---------------------------------
  * cFunctionals in frameMode=full (src/functionals/functionals.cpp:284-330, one output vector

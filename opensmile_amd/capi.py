@@ -40,6 +40,8 @@ class LldConfig(C.Structure):
         ("sma_win", C.c_int32),
         ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
         ("stage_mask", C.c_uint32),
+        ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
+        ("f0_min_energy", C.c_float), ("reserved0", C.c_int32),
     ]
 
 
@@ -63,6 +65,8 @@ SYMBOLS = {
     "smilehip_device_name": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_compare16_f0": (None, [C.POINTER(LldConfig)]),
+    "smilehip_batch_f0_taps": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "smilehip_config_plp_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
     "smilehip_functionals_is09_mask": (C.c_uint32, []),
@@ -155,6 +159,12 @@ def plp_0_d_a_config():
 def compare16_ab_config():
     c = LldConfig()
     load().smilehip_config_compare16_ab(C.byref(c))
+    return c
+
+
+def compare16_f0_config():
+    c = LldConfig()
+    load().smilehip_config_compare16_f0(C.byref(c))
     return c
 
 
@@ -282,6 +292,40 @@ class Batch:
         _check(load().smilehip_lld_run_host(self.plan._h, self._h, pcm.ctypes.data, len(pcm),
                                             out.ctypes.data))
         return out
+
+    def f0_run_host_taps(self, pcm):
+        """F0 chain plans: run on host data and also return the intermediate levels
+        {hps: total_frames x n_bins, shs: total_frames x 21, e60: total_frames} next to the output matrix."""
+        L = load()
+        ctx = self.plan.ctx._h
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        K = self.plan.geometry.n_bins
+        nf = self.total_frames
+        out = np.zeros((self.total_rows, self.plan.geometry.n_out), np.float32)
+        taps = {"hps": np.zeros((nf, K), np.float32), "shs": np.zeros((nf, 21), np.float32), "e60": np.zeros((nf, 1), np.float32)}
+        d_pcm, d_out, d_hps = _vp(), _vp(), _vp()
+        _check(L.smilehip_alloc(ctx, max(pcm.nbytes, 4), C.byref(d_pcm)))
+        _check(L.smilehip_alloc(ctx, max(out.nbytes, 4), C.byref(d_out)))
+        _check(L.smilehip_alloc(ctx, max(taps["hps"].nbytes, 4), C.byref(d_hps)))
+        try:
+            if pcm.nbytes:
+                _check(L.smilehip_copy_to_device(ctx, d_pcm, pcm.ctypes.data, pcm.nbytes, None))
+            d_shs, d_e60 = _vp(), _vp()
+            _check(L.smilehip_batch_f0_taps(self._h, d_hps, C.byref(d_shs), C.byref(d_e60)))
+            _check(L.smilehip_lld_run(self.plan._h, self._h, d_pcm, d_out, self.plan.geometry.n_out, None))
+            _check(L.smilehip_stream_synchronize(ctx, None))
+            if out.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, out.ctypes.data, d_out, out.nbytes, None))
+            if nf:
+                _check(L.smilehip_copy_to_host(ctx, taps["hps"].ctypes.data, d_hps, taps["hps"].nbytes, None))
+                _check(L.smilehip_copy_to_host(ctx, taps["shs"].ctypes.data, d_shs, taps["shs"].nbytes, None))
+                _check(L.smilehip_copy_to_host(ctx, taps["e60"].ctypes.data, d_e60, taps["e60"].nbytes, None))
+            _check(L.smilehip_batch_f0_taps(self._h, None, None, None))
+        finally:
+            L.smilehip_free(ctx, d_pcm)
+            L.smilehip_free(ctx, d_out)
+            L.smilehip_free(ctx, d_hps)
+        return out, taps
 
     def func_rows(self):
         """LLD rows each utterance's functionals summarise (IS09 chain plans)."""

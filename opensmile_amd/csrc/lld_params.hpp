@@ -103,6 +103,35 @@ struct CompareParams {
   double slope_Sf, slope_S2f;   // sums of f and f^2 over bins 1..K-1 (spectral.cpp:1399-1427)
 };
 
+// ComParE / GeMAPS F0 group (lld_f0.hip): 60 ms frames -> cSpecScale -> cPitchShs -> Viterbi -> selector
+struct F0Params {
+  int32_t N, H, Nfft, K, pad_left;  // 60 ms framing @ 16 kHz: 960, 160, 1024, 513, 32
+  const float *window;              // [N]
+  const float2 *tw_half;            // [M/2], M = Nfft/2
+  const float2 *tw_full;            // [M/2+1]
+  // cSpecScale: natural cubic spline over the octave-scaled bin positions (smileUtilSpline.c:139-212); the
+  // decomposition part of the tridiagonal sweep does not depend on the data and is precomputed:
+  const double *sp_rec;             // [K x 4] per bin i: sigma_i, p_i = 1/(sigma_i*dec_{i-1}+2), dec_i = (sigma_i-1)*p_i, 0
+  const double *sp_d1, *sp_d2;      // [K] (x[i+1]-x[i])(x[i+1]-x[i-1]), (x[i]-x[i-1])(x[i+1]-x[i-1])
+  const int32_t *ip_k;              // [K] lower source bin of target point i (smileMath_csplint_init, :296-342)
+  const double *ip_co;              // [K x 3] a, c, d of target point i
+  const double *audw;               // [K] auditory weighting (specScale.cpp:279-287)
+  // cPitchShs
+  int32_t n_harm;
+  int32_t shift[16];                // shift[i-2] for harmonic i = 2..n_harm
+  float scale[16];                  // compressionFactor^(i-1)
+  float Fmint, Fstept;
+  double log_base;
+  double min_pitch, max_pitch;
+  float voicing_cutoff;
+  float min_energy;
+  double vit_w[6];                  // cPitchSmootherViterbi: wLocal, wTvv, wTvvd, wTvuv, wThr, wRange (wTuu is never used)
+  // per-frame results between the kernels
+  float *shs;                       // [total_frames x 21] nCand | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip
+  float *e60;                       // [total_frames] RMS energy of the windowed frame
+  float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
+};
+
 // Constants of cSpectral for one spectrum geometry (host-resolved in smilehip_plan.cpp)
 struct SpectralConsts {
   double fsSec;               // frameSizeSec of the magnitude level: frq[i] = i / fsSec (transformFft.cpp:102-117)

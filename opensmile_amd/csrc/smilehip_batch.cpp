@@ -21,7 +21,8 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   std::vector<int32_t> tile_utt, tile_t0, dtile_utt, dtile_t0, run_utt, run_t0;
   std::vector<TileRec> tile_rec;
   const int64_t dtile = chain_tile_rows();
-  const int64_t tile_frames = plan->use_fast ? fast512_tile_frames() : (int64_t(1) << 40);
+  const int64_t tile_frames = plan->use_fast ? fast512_tile_frames()
+                              : (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 ? f0_tile_frames() : (int64_t(1) << 40));
   for (int32_t u = 0; u < n_utt; ++u) {
     const int64_t len = h_off[u + 1] - h_off[u];
     if (len < 0) {
@@ -96,6 +97,15 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the static-block scratch failed");
     }
     b->d_static.n = n;
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
+    const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_shs.p), nf * 21 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_e60.p), nf * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 scratch matrices failed");
+    }
+    b->d_shs.n = nf * 21; b->d_e60.n = nf;
   }
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
     std::vector<float> zero;   // allocate only
@@ -377,6 +387,55 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   return SMILEHIP_OK;
 }
 
+void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
+  std::memset(&Q, 0, sizeof(Q));
+  Q.N = (int32_t)plan->geo.N; Q.H = (int32_t)plan->geo.H; Q.Nfft = (int32_t)plan->geo.Nfft; Q.K = (int32_t)plan->geo.K;
+  Q.pad_left = plan->cfg.zero_pad_symmetric ? (int32_t)((plan->geo.Nfft - plan->geo.N) / 2) : 0;
+  Q.window = plan->d_window.p;
+  Q.tw_half = plan->d_tw_half.p;
+  Q.tw_full = plan->d_tw_full.p;
+  Q.sp_rec = plan->d_f0_rec.p; Q.sp_d1 = plan->d_f0_d1.p; Q.sp_d2 = plan->d_f0_d2.p;
+  Q.ip_k = plan->d_f0_k.p; Q.ip_co = plan->d_f0_co.p; Q.audw = plan->d_f0_audw.p;
+  Q.n_harm = plan->f0.n_harm;
+  for (int i = 0; i < 16; ++i) { Q.shift[i] = plan->f0.shift[i]; Q.scale[i] = plan->f0.scale[i]; }
+  Q.Fmint = plan->f0.Fmint; Q.Fstept = plan->f0.Fstept;
+  Q.log_base = plan->f0.log_base;
+  Q.min_pitch = plan->cfg.pitch_min; Q.max_pitch = plan->cfg.pitch_max;
+  Q.voicing_cutoff = (float)plan->cfg.voicing_cutoff;
+  Q.min_energy = plan->cfg.f0_min_energy;
+  // [is13_pitchSmoothViterbi]: wLocal 2, wTvv 10, wTvvd 5, wTvuv 10, wThr 4, wRange 1 -- but
+  // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd (pitchSmootherViterbi.hpp:291-299): 10
+  Q.vit_w[0] = 2.0; Q.vit_w[1] = 10.0; Q.vit_w[2] = 10.0; Q.vit_w[3] = 10.0; Q.vit_w[4] = 4.0; Q.vit_w[5] = 1.0;
+}
+
+static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  if (ld_out < 2) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 2", (long long)ld_out);
+  if (b->total_frames == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  F0Params Q;
+  fill_f0_params(plan, Q);
+  Q.shs = b->d_shs.p;
+  Q.e60 = b->d_e60.p;
+  Q.hps_tap = b->d_hps_tap;
+  hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+// Test/diagnostic taps of the F0 chain: device pointers to the per-frame scratch of the LAST run
+// (candidates: total_frames x 21, level is13_pitchShsG60; energy: total_frames, level is13_e60) and an optional
+// destination for the octave-scaled spectra (total_frames x K, level is13_hpsG60; pass NULL to switch it off).
+extern "C" int smilehip_batch_f0_taps(smilehip_batch *b, float *d_hps_dst, const float **d_shs, const float **d_e60) {
+  if (!b || b->plan->cfg.chain_kind != SMILEHIP_CHAIN_COMPARE_F0)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_f0_taps: not an F0 chain batch");
+  b->d_hps_tap = d_hps_dst;
+  if (d_shs) *d_shs = b->d_shs.p;
+  if (d_e60) *d_e60 = b->d_e60.p;
+  return SMILEHIP_OK;
+}
+
 // ------------------------------------------------------------- functionals
 extern "C" uint32_t smilehip_functionals_is09_mask(void) {
   return SMILEHIP_FUNC_MAX | SMILEHIP_FUNC_MIN | SMILEHIP_FUNC_RANGE | SMILEHIP_FUNC_MAXPOS | SMILEHIP_FUNC_MINPOS |
@@ -456,6 +515,7 @@ extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const in
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP)
     return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return f0_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
 }
 

@@ -75,6 +75,10 @@ struct smilehip_plan {
   DevBuf<float> d_plp_eql, d_plp_cos, d_plp_sin;     // PLP chain tables
   std::vector<float> h_plp_cos;
   DevBuf<double> d_sharp;
+  // F0 group (SMILEHIP_CHAIN_COMPARE_F0)
+  F0Host f0;
+  DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
+  DevBuf<int32_t> d_f0_k;
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
   int32_t band_iL[2] = {0, 0}, band_iR[2] = {0, 0};
   double band_wL[2] = {0, 0}, band_wR[2] = {0, 0}, slope_Sf = 0, slope_S2f = 0;
@@ -103,6 +107,8 @@ struct smilehip_batch {
   DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
   DevBuf<float> d_static;       // MFCC chain with deltas: compact static block, total_frames x n_mfcc
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
+  DevBuf<float> d_shs, d_e60;             // F0 group: candidates (total_frames x 21) and frame energies
+  float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;
   std::vector<int32_t> h_short;
@@ -117,3 +123,4 @@ struct smilehip_batch {
 int plan_n_static(const smilehip_plan *p);
 int plan_n_out(const smilehip_plan *p);
 int plan_row_extra(const smilehip_plan *p);
+void fill_f0_params(const smilehip_plan *plan, smilehip::F0Params &Q);   // smilehip_batch.cpp

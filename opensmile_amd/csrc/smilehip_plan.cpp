@@ -68,6 +68,23 @@ extern "C" void smilehip_config_compare16_ab(smilehip_lld_config *c) {
   c->sma_win = 3;
 }
 
+extern "C" void smilehip_config_compare16_f0(smilehip_lld_config *c) {
+  smilehip_config_mfcc12_0_d_a(c);
+  c->chain_kind = SMILEHIP_CHAIN_COMPARE_F0;
+  c->frame_size_sec = 0.060;        // [is13_frame60]
+  c->preemph = 0;
+  c->win_func = SMILEHIP_WIN_GAUSS; // [is13_win60] sigma 0.4
+  c->win_sigma = 0.4;
+  c->zero_pad_symmetric = 1;        // [is13_fft60]
+  c->n_delta = 0;
+  c->pitch_min = 52.0;              // [is13_shs]
+  c->pitch_max = 620.0;
+  c->voicing_cutoff = 0.7;
+  c->shs_n_harmonics = 15;
+  c->shs_compression = 0.85f;
+  c->f0_min_energy = 0.001f;        // [is13_volmerge] threshold
+}
+
 // ------------------------------------------------------------------- plan
 static int build_tables(smilehip_plan *p, bool upload = true) {
   int rc;
@@ -104,6 +121,12 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       return fail(SMILEHIP_ERR_INVALID, "PLP chain: lpOrder 1..15, HTK-scaled power mel bands (<= 30) required");
     p->dct.n_mfcc = p->cfg.plp_lp_order + 1;            // outputs of the chain's static block
     p->dct.melfloor = 1.0f;                              // htkcompatible forces melfloor = 1.0 (plp.cpp:150-160)
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
+    if (mask != SMILEHIP_STAGE_ALL || p->cfg.preemph || p->cfg.n_delta != 0 || p->geo.Nfft < 128 || p->geo.Nfft > 4096 ||
+        p->cfg.win_offset != 0.0)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: no pre-emphasis / deltas / window offset, FFT length 128..4096");
+    if ((rc = make_f0_tables(p->geo.K, p->geo.fft_frame_size_sec, p->cfg.shs_n_harmonics, p->cfg.shs_compression, p->f0)))
+      return fail(rc, "F0 chain: spectrum geometry / nHarmonics not usable by cSpecScale / cPitchShs");
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
     return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);
   }
@@ -171,6 +194,10 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if ((rc = p->d_tw_half.upload(twh))) return rc;
   if ((rc = p->d_tw_full.upload(twf))) return rc;
   if (is_plp && ((rc = p->d_plp_eql.upload(plp_eql)) || (rc = p->d_plp_cos.upload(p->h_plp_cos)) || (rc = p->d_plp_sin.upload(plp_sin))))
+    return rc;
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 &&
+      ((rc = p->d_f0_rec.upload(p->f0.sp_rec)) || (rc = p->d_f0_d1.upload(p->f0.sp_d1)) || (rc = p->d_f0_d2.upload(p->f0.sp_d2)) ||
+       (rc = p->d_f0_co.upload(p->f0.ip_co)) || (rc = p->d_f0_audw.upload(p->f0.audw)) || (rc = p->d_f0_k.upload(p->f0.ip_k))))
     return rc;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
     // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
@@ -295,6 +322,7 @@ extern "C" int smilehip_plan_create_host_only(const smilehip_lld_config *cfg, sm
 extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 
 int plan_n_static(const smilehip_plan *p) {
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return 2;
   return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc);
 }
 int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }
@@ -327,7 +355,8 @@ extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
 
 extern "C" double smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row) {
   if (!plan || row < 0) return 0.0;
-  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP || n_frames <= 1)
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP ||
+      plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 || n_frames <= 1)
     return smilehip_frame_time(plan, row);
   return smilehip_frame_time(plan, row < n_frames - 1 ? row : n_frames - 1);
 }

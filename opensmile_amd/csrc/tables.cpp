@@ -226,3 +226,77 @@ float delta_norm(int W) {
 }
 
 }  // namespace smilehip
+
+namespace smilehip {
+
+// cSpecScale::dataProcessorCustomFinalise (src/dsp/specScale.cpp:228-300), smileMath_cspline_init /
+// smileMath_csplint_init (src/smileutil/smileUtilSpline.c:139-155, 296-342), the level meta data cPitchShs reads
+// in setupNewNames (src/lld/pitchShs.cpp:178-204) and its per-harmonic shifts (:235-243). All in double, rounded
+// where the reference rounds (the meta data travels as FLOAT_DMEM).
+int make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, F0Host &h) {
+  if (K < 4 || n_harmonics < 1 || n_harmonics > 17) return SMILEHIP_ERR_INVALID;
+  const double fsSec = (double)(float)fft_frame_size_sec;
+  const double deltaF = 1.0 / fsSec;
+  const double minF = 25.0;
+  const double maxF = deltaF * (double)(K - 1);
+  const double l2 = std::log(2.0);
+  const double fmin_t = std::log(minF) / l2, fmax_t = std::log(maxF) / l2;
+  const double step_t = (fmax_t - fmin_t) / (double)(K - 1);
+  std::vector<double> x(static_cast<size_t>(K));
+  for (int64_t i = 1; i < K; ++i) x[i] = std::log((double)i * deltaF) / l2;
+  x[0] = 2.0 * x[1] - x[2];
+  h.sp_rec.assign(size_t(K) * 4, 0.0);
+  h.sp_d1.assign(size_t(K), 1.0);
+  h.sp_d2.assign(size_t(K), 1.0);
+  double dec_prev = 0.0;                                  // y2[0] = 0 (natural boundary)
+  for (int64_t i = 1; i < K - 1; ++i) {
+    const double sigma = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    h.sp_d1[i] = (x[i + 1] - x[i]) * (x[i + 1] - x[i - 1]);
+    h.sp_d2[i] = (x[i] - x[i - 1]) * (x[i + 1] - x[i - 1]);
+    const double p = 1.0 / (sigma * dec_prev + 2.0);
+    const double dec = (sigma - 1.0) * p;
+    h.sp_rec[4 * i + 0] = sigma;
+    h.sp_rec[4 * i + 1] = p;
+    h.sp_rec[4 * i + 2] = dec;
+    dec_prev = dec;
+  }
+  h.ip_k.assign(size_t(K), 0);
+  h.ip_co.assign(size_t(K) * 3, 0.0);
+  int64_t hi = 1;
+  for (int64_t i = 0; i < K; ++i) {
+    const double xt = fmin_t + (double)i * step_t;
+    if (i == 0 && xt < x[0]) return SMILEHIP_ERR_INVALID;
+    while (hi < K && x[hi] < xt) hi++;
+    if (hi == K) return SMILEHIP_ERR_INVALID;             // the reference's csplint_init fails here too
+    const int64_t lo = hi - 1;
+    const double range = x[hi] - x[lo];
+    if (range == 0.0) return SMILEHIP_ERR_INVALID;
+    const double a = (x[hi] - xt) / range, b = 1.0 - a, r2 = range * range / 6.0;
+    h.ip_k[i] = (int32_t)lo;
+    h.ip_co[3 * i + 0] = a;
+    h.ip_co[3 * i + 1] = (a * a * a - a) * r2;
+    h.ip_co[3 * i + 2] = (b * b * b - b) * r2;
+  }
+  const double nOct = std::log(maxF / minF) / l2;
+  const double nPPO = (double)K / nOct;
+  const double atan_s = nPPO * (std::log(65.0 / 50.0) / l2) - 1.0;
+  h.audw.assign(size_t(K), 0.0);
+  for (int64_t i = 0; i < K; ++i) h.audw[i] = 0.5 + std::atan(3.0 * ((double)i + 1 - atan_s) / nPPO) / M_PI;
+  // what cPitchShs sees: FLOAT_DMEM meta data
+  const float m_fmin = (float)minF, m_ppo = (float)nPPO, m_fmint = (float)fmin_t, m_fmaxt = (float)fmax_t;
+  double base = std::exp(std::log((double)m_fmin) / (double)m_fmint);
+  if (std::fabs(base - 2.0) < 0.00001) base = 2.0;
+  h.log_base = std::log(base);
+  h.Fmint = m_fmint;
+  h.Fstept = (m_fmaxt - m_fmint) / (float)(K - 1);
+  h.n_harm = n_harmonics;
+  float sc = compression;
+  for (int i = 2; i < n_harmonics + 1; ++i) {
+    h.shift[i - 2] = (int32_t)std::floor((double)m_ppo * (std::log((double)i) / l2));
+    h.scale[i - 2] = sc;
+    sc *= compression;
+  }
+  return SMILEHIP_OK;
+}
+
+}  // namespace smilehip

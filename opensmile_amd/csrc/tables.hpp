@@ -38,6 +38,20 @@ struct DctTables {
   float melfloor = 0.0f, log_floor = 0.0f;
 };
 
+// ComParE / GeMAPS F0 group: cSpecScale (scale=octave, interpMethod=spline, specSmooth=specEnhance=
+// auditoryWeighting=1, minF=25, maxF=-1, nPointsTarget=0) and cPitchShs constants for one spectrum geometry
+struct F0Host {
+  std::vector<double> sp_rec, sp_d1, sp_d2, ip_co, audw;
+  std::vector<int32_t> ip_k;
+  int32_t n_harm = 15;
+  int32_t shift[16] = {0};
+  float scale[16] = {0};
+  float Fmint = 0.f, Fstept = 0.f;
+  double log_base = 0.0;
+};
+// K bins of a spectrum level whose frameSizeSec is fft_frame_size_sec; 0 on success
+int  make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, F0Host &h);
+
 int  make_geometry(const smilehip_lld_config &c, Geometry &g);
 int  make_window(const smilehip_lld_config &c, int64_t N, std::vector<float> &w);
 int  make_mel(const smilehip_lld_config &c, const Geometry &g, MelBank &m);

@@ -1,0 +1,109 @@
+"""the F0 group of ComParE_2016 (cSpecScale -> cPitchShs -> cPitchSmootherViterbi ->
+cValbasedSelector on the 60 ms frames) through the C ABI's smilehip_lld_run (chain_kind COMPARE_F0), against
+golden levels of the real reference binary and against the CPU oracle, level by level."""
+import numpy as np
+import pytest
+
+from test_oracle_pin_f0 import KEYS, f0_tolerances
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    plan = capi.Plan(ctx, capi.compare16_f0_config())
+    g = plan.geometry
+    assert (g.frame_size, g.frame_step, g.fft_size, g.n_bins, g.n_out) == (960, 160, 1024, 513, 2)
+    return capi, ctx, plan
+
+
+def level_tolerances(taps, ref_hps, ref_shs, ref_e60, what):
+    """hps / e60 are continuous: 1e-5 of the frame's (level's) scale. Candidate lists are ordered by score, so two
+    near-equal candidates may swap on rare frames: compare the best candidate and the candidate count."""
+    if ref_hps is not None and ref_hps.size:
+        sc = np.maximum(np.abs(ref_hps).max(axis=1, keepdims=True), 1e-12)
+        assert (np.abs(taps["hps"] - ref_hps) / sc).max() <= 1e-5, f"{what}: hps"
+    if ref_e60.size:
+        assert np.abs(taps["e60"] - ref_e60).max() <= 1e-6 * max(np.abs(ref_e60).max(), 1e-12) + 1e-12, f"{what}: e60"
+    if ref_shs.size:
+        o, r = taps["shs"].astype(np.float64), ref_shs.astype(np.float64)
+        same = (o[:, 0] == r[:, 0])
+        same &= np.abs(o[:, 1] - r[:, 1]) <= 1e-5 * np.maximum(np.abs(r[:, 1]), 1.0)      # best candidate's F0
+        same &= np.abs(o[:, 7] - r[:, 7]) <= 1e-5                                           # ... and voicing
+        assert (~same).mean() <= 0.01, f"{what}: {int((~same).sum())} of {len(same)} candidate rows differ"
+
+
+def test_f0_golden_batch_ragged(hip, golden_f0):
+    capi, ctx, plan = hip
+    pcms = [golden_f0["pcm_" + k] for k in KEYS]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    np.testing.assert_array_equal(np.diff(b.frame_offsets), [golden_f0["pitch_" + k].shape[0] for k in KEYS])   # T60 rows
+    out, taps = b.f0_run_host_taps(np.concatenate(pcms))
+    for i, k in enumerate(KEYS):
+        sl = slice(b.frame_offsets[i], b.frame_offsets[i + 1])
+        t = {n: v[sl] for n, v in taps.items()}
+        hps = golden_f0["hps_" + k] if "hps_" + k in golden_f0.files else None
+        level_tolerances(t, hps, golden_f0["shs_" + k], golden_f0["e60_" + k], k)
+        f0_tolerances(out[sl], golden_f0["pitch_" + k], k)
+    b.close()
+
+
+def test_f0_vs_oracle_ragged_lengths(hip, oracle):
+    """10 s utterances, inputs shorter than one 60 ms frame, one/two/three frames, lengths around the 30-frame
+    Viterbi buffer (forced decisions start at 31 frames)."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    lens = [160000, 100, 959, 960, 1120, 1280, 5600, 5760, 5920, 9600, 160000, 48000, 0, 80000]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(70 + i, n) if n else np.zeros(0, np.int16) for i, n in enumerate(lens)])
+    b = capi.Batch(plan, off)
+    out, taps = b.f0_run_host_taps(pcm)
+    assert out.shape[1] == 2
+    oracle.use_reference_fft(False)
+    for i, n in enumerate(lens):
+        ref, rt = oracle.compare_f0_chain(pcm[off[i]:off[i + 1]], taps=True)
+        sl = slice(b.frame_offsets[i], b.frame_offsets[i + 1])
+        assert out[sl].shape == ref.shape, (n, out[sl].shape, ref.shape)
+        if ref.shape[0]:
+            level_tolerances({k: v[sl] for k, v in taps.items()}, rt["hps"], rt["shs"], rt["e60"], f"len{n}")
+            f0_tolerances(out[sl], ref, f"len{n}")
+    b.close()
+
+
+def test_f0_viterbi_exact_on_identical_candidates(hip, oracle):
+    """The Viterbi pass and the energy gate are discrete: fed with the SAME candidate rows (the device's own
+    is13_pitchShsG60 level), device and oracle must pick the same path and emit identical values."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    lens = [160000, 4800, 5920, 16000, 64000]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(90 + i, n) for i, n in enumerate(lens)])
+    b = capi.Batch(plan, off)
+    out, taps = b.f0_run_host_taps(pcm)
+    import ctypes as C
+    L = oracle.lib()
+    L.lldo_pitch_viterbi.restype = None
+    L.lldo_pitch_viterbi.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p]
+    for i in range(len(lens)):
+        sl = slice(b.frame_offsets[i], b.frame_offsets[i + 1])
+        shs = np.ascontiguousarray(taps["shs"][sl])
+        T = shs.shape[0]
+        ref = np.zeros((T, 2), np.float32)
+        L.lldo_pitch_viterbi(shs.ctypes.data, T, np.float32(0.7), ref.ctypes.data, None)
+        ref[~(taps["e60"][sl, 0] > np.float32(0.001))] = 0.0
+        assert np.array_equal(out[sl].view(np.uint32), ref.view(np.uint32)), f"utt {i}: {(out[sl] != ref).any(axis=1).sum()} rows"
+    b.close()
+
+
+def test_f0_rerun_is_deterministic(hip):
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    pcm = np.concatenate([synth.utterance(3, 32000), synth.utterance(4, 16000)])
+    b = capi.Batch(plan, np.array([0, 32000, 48000], np.int64))
+    a = b.run_host(pcm)
+    c = b.run_host(pcm)
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    b.close()
