@@ -385,8 +385,9 @@ static void vit_flush(viterbi_t *v)
   }
 }
 
-/* shs: T x 21 rows of lldo_pitch_shs; out: T x 2 [F0final, voicingFinalUnclipped]; states (optional): T ints */
-void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *out, int *states)
+/* shs: T x 21 rows of lldo_pitch_shs; out: T x 2 [F0final, voicingFinalUnclipped]; states (optional): T ints;
+ * pending (optional): number of frames that were still undecided at the end of input (decided by flushTrellis) */
+void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *out, int *states, long *pending)
 {
   enum { NC = 6, FSZ = NC * 2 + 4 };
   viterbi_t v;
@@ -410,6 +411,7 @@ void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *o
       fr[2 * NC] = r[0]; fr[2 * NC + 1] = 0.0f; fr[2 * NC + 2] = 0.0f; fr[2 * NC + 3] = (float)t;
       vit_add(&v, fr);
     } else {
+      if (pending) *pending = (T > 0) ? v.pathIdx - (v.convIdx + 1) : 0;
       if (T > 0) vit_flush(&v);
     }
     while (v.convIdx + 1 - v.rd > 0) {
@@ -464,7 +466,7 @@ long lldo_compare_f0_chain(const int16_t *pcm, long n_samples, float *out, float
     if (tap_hps) memcpy(tap_hps + t * g.K, hp, sizeof(float) * (size_t)g.K);
     lldo_pitch_shs(&sh, hp, shs + t * 21, NULL);
   }
-  lldo_pitch_viterbi(shs, T, sh.voicing_cutoff, out, NULL);
+  lldo_pitch_viterbi(shs, T, sh.voicing_cutoff, out, NULL, NULL);
   if (tap_shs) memcpy(tap_shs, shs, sizeof(float) * 21 * (size_t)T);
   if (tap_vit) memcpy(tap_vit, out, sizeof(float) * 2 * (size_t)T);
   if (tap_e60) memcpy(tap_e60, e60, sizeof(float) * (size_t)T);
@@ -473,4 +475,330 @@ long lldo_compare_f0_chain(const int16_t *pcm, long n_samples, float *out, float
   free(x); free(w); free(fr); free(sp); free(mg); free(hp); free(shs); free(e60);
   lldo_specscale_free(&ss);
   return T;
+}
+
+/* ------------------------------------------------------------------ cPitchJitter */
+/* cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1064) for [is13_pitchJitter]: searchRangeRel 0.25, minNumPeriods 2,
+ * minCC 0.5, useBrokenJitterThresh 0, usePeakToPeakPeriodLength 0, shimmerUseRmsAmplitude 0, lgHNRfloor -100;
+ * outputs jitterLocal, jitterDDP, shimmerLocal, logHNR. One call per F0 frame in order; the state (read position in the
+ * wave, left-over samples, last period / difference, last jitter / shimmer values) carries over between frames.
+ * Time meta of frame t as the framer produces it from a wave level without stored time stamps
+ * (dataMemoryLevel.cpp:617-626,1226-1245; waveSource.cpp:196): time = (tH)*Tw, lengthSec = ((tH+N-1)*Tw - (tH)*Tw) + Tw,
+ * framePeriod = Tw, period = frameStep -- lenF = ceil(lengthSec/framePeriod) is N or N+1 depending on rounding. */
+static double cross_corr(const float *x, const float *y, long N)          /* crossCorr, :331-418 */
+{
+  double cc = 0.0, mx = 0.0, my = 0.0, nx = 0, ny = 0;
+  for (long i = 0; i < N; i++) { mx += x[i]; my += y[i]; }
+  mx /= (double)N;
+  my /= (double)N;
+  for (long i = 0; i < N; i++) {
+    cc += (x[i] - mx) * (y[i] - my);
+    nx += (x[i] - mx) * (x[i] - mx);
+    ny += (y[i] - my) * (y[i] - my);
+  }
+  cc /= sqrt(nx) * sqrt(ny);
+  return cc;
+}
+
+/* amplitudeDiff (:422-459); the parabolic peak positions are only used with usePeakToPeakPeriodLength */
+static float amplitude_diff(const float *x, long Nx, const float *y, long Ny, float *a0, float *a1)
+{
+  float max0 = x[1], min0 = x[1];
+  for (long i = 1; i < Nx - 1; i++) { if (x[i] > max0) max0 = x[i]; if (x[i] < min0) min0 = x[i]; }
+  float max1 = y[1], min1 = y[1];
+  for (long i = 1; i < Ny - 1; i++) { if (y[i] > max1) max1 = y[i]; if (y[i] < min1) min1 = y[i]; }
+  *a0 = max0 - min0;
+  *a1 = max1 - min1;
+  return fabsf((max0 - min0) - (max1 - min1));
+}
+
+/* smileMath_quadFrom3pts with the curvature output unused */
+static double quad_vertex_y(double x1, double y1, double x2, double y2, double x3, double y3, double *y)
+{
+  return quad_vertex(x1, y1, x2, y2, x3, y3, y);
+}
+
+/* wave: the utterance as floats (n samples); f0: T values (level is13_pitchG60, column F0final);
+ * out: T x 4 [jitterLocal, jitterDDP, shimmerLocal, logHNR]. N, H: frame size / step in samples. */
+void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
+                       double frame_step_sec, float *out)
+{
+  const double Tw = 1.0 / sample_rate;                              /* waveSource.cpp:190 */
+  const double searchRangeRel = 0.25;
+  const int minNumPeriods = 2;
+  const float threshCC = (float)0.5;
+  const float lgHNRfloor = (float)-100.0;
+  long lastIdx = 0, lastMis = 0;
+  float lastT0 = 0.0f, lastDiff = 0.0f, lastJitterLocal = 0.0f, lastJitterDDP = 0.0f, lastShimmerLocal = 0.0f;
+  for (long t = 0; t < T; t++) {
+    const float F0 = f0[t];
+    const double time = (double)(t * H) * Tw;
+    const double lengthSec = ((double)(t * H + N - 1) * Tw - (double)(t * H) * Tw) + Tw;
+    const long lenF = (long)ceil(lengthSec / Tw);
+    const long startVidx = (long)round(time / Tw);
+    const long ppLen = (long)ceil(frame_step_sec / Tw);
+    long toRead0 = ppLen + lastMis, toRead = toRead0;
+    double Tf = 0.0;
+    long T0f = 0, T0minF = 0, T0maxF = 0, two_pp = 0;
+    if (F0 > 0.0) {
+      const double T0 = 1.0 / F0;
+      Tf = T0 / Tw;
+      T0f = (long)round(Tf);
+      T0minF = (long)floor((1.0 - searchRangeRel) * Tf);
+      T0maxF = (long)ceil((1.0 + searchRangeRel) * Tf);
+      two_pp = minNumPeriods * T0maxF + minNumPeriods;
+      if (toRead < two_pp) toRead = two_pp;
+    }
+    long maxRead = lastMis + lenF;
+    if (toRead > maxRead) toRead = maxRead;
+    if (startVidx - lastMis != lastIdx) {
+      lastIdx = startVidx;
+      if (toRead > lenF) toRead = lenF;
+      if (maxRead > lenF) maxRead = lenF;
+    }
+    float *o = out + 4 * t;
+    if (lastIdx + toRead > n) {                                     /* no pcm data: the frame yields no output row */
+      lastIdx += toRead0;                                           /* (cannot happen for complete frames) */
+      o[0] = o[1] = o[2] = o[3] = 0.0f;
+      continue;
+    }
+    const float *d = wave + lastIdx;
+    const long nT = toRead;
+    float nPeriodsLocal = 0, nPeriodsDDP = 0, nPeriods = 0, avgPeriod = 0.0f, JitterDDP = 0.0f, JitterLocal = 0.0f;
+    float avgAmp = 0.0f, avgAmpDiff = 0.0f, lgHNR = 0.0f;
+    long start = 0, lastPeriod = 0;
+    if (F0 > 0.0) {
+      int numPeriods = 0;
+      long *periodBuffer = (long *)calloc(1, sizeof(long) * (size_t)((T0f > 0 ? maxRead / T0minF + 3 : maxRead + 2) + 2));
+      float *avgWf = (float *)calloc(1, sizeof(float) * (size_t)(T0f + 1));
+      double *cc = (double *)calloc(1, sizeof(double) * (size_t)((int)(T0maxF - T0minF) + 1));
+      long pp = 0;
+      while (start < nT - 2 * T0maxF - 1) {
+        for (long tf = T0minF; tf <= T0maxF; tf++) cc[tf - T0minF] = cross_corr(d + start, d + start + tf, tf);
+        long maxI = -1;
+        double mx = cc[T0f - T0minF];
+        for (long i = 1; i < T0maxF - T0minF - 1; i++) {
+          if (cc[i - 1] < cc[i] && cc[i] > cc[i + 1]) {
+            if (maxI == -1) { maxI = i; mx = cc[i]; }
+            else if (cc[i] > mx) { maxI = i; mx = cc[i]; }
+          }
+        }
+        pp = (maxI == -1) ? T0f : T0minF + maxI;
+        const long os = start;
+        if (maxI >= 0) {
+          start += pp;
+          float a0 = 0.0f, a1 = 0.0f;
+          const float ad = amplitude_diff(d + os, pp, d + start, pp, &a0, &a1);
+          periodBuffer[numPeriods++] = os;
+          for (long i = 0; i < T0f; i++) avgWf[i] += d[os + i];
+          double ccI = 0.0;
+          const double maxId = fabs(((double)T0minF + quad_vertex_y((double)(maxI - 1), cc[maxI - 1], (double)maxI, cc[maxI],
+                                                                    (double)(maxI + 1), cc[maxI + 1], &ccI))) * Tw;
+          if (ccI > threshCC) {
+            const float period = (float)maxId;
+            avgPeriod += period;
+            nPeriods += 1.0;
+            if (lastT0 > 0.0) {
+              const float diff = fabsf(lastT0 - period);
+              JitterLocal += diff;
+              nPeriodsLocal += 1.0;
+              if (lastDiff > 0.0) { JitterDDP += fabsf(lastDiff - diff); nPeriodsDDP += 1.0; }
+              lastDiff = diff;
+            }
+            lastT0 = period;
+            avgAmp += (a0 + a1) / (float)2.0;
+            avgAmpDiff += ad;
+          }
+        } else {
+          start += T0f;
+        }
+        if (start < toRead0 - 1) lastPeriod = start;
+      }
+      periodBuffer[numPeriods++] = start;
+      float Eh = 0.0f;
+      for (long i = 0; i < T0f && start + i < nT; i++) {
+        avgWf[i] += d[start + i];
+        avgWf[i] /= (float)numPeriods;
+        if (i > 2 && i < T0f - 2) Eh += avgWf[i] * avgWf[i];
+      }
+      if (T0f - 4 > 0) Eh /= (float)(T0f - 4);
+      Eh = sqrtf(Eh);
+      float En = 0.0f;
+      long nEn = 0;
+      if (pp > 0) periodBuffer[numPeriods] = start + pp;
+      for (int i = 0; i < numPeriods; i++) {
+        long k = 2;
+        const long lim = (periodBuffer[i + 1] < periodBuffer[i] + T0f ? periodBuffer[i + 1] : periodBuffer[i] + T0f) - 2;
+        for (long j = periodBuffer[i] + 2; j < lim; j++) {
+          const float delta = d[j] - avgWf[k++];
+          En += delta * delta;
+          nEn++;
+        }
+      }
+      if (nEn > 0) En /= (float)nEn;
+      En = sqrtf(En);
+      if (En > 0.0) {
+        const float HNR = Eh / En;
+        if (HNR > 0.0) lgHNR = (float)(20.0 * log((double)HNR) / log(10.0));
+        else lgHNR = lgHNRfloor;
+      }
+      lastMis = toRead0 - lastPeriod;
+      free(cc); free(periodBuffer); free(avgWf);
+    } else {
+      lastPeriod = toRead0;
+      lastMis = 0;
+      lastT0 = 0.0f; lastDiff = 0.0f;
+      lastJitterDDP = 0.0f; lastJitterLocal = 0.0f; lastShimmerLocal = 0.0f;
+      lgHNR = lgHNRfloor;
+    }
+    lastIdx += lastPeriod;
+    /* output vector (:906-1040) */
+    if (nPeriods > 0.0 && nPeriodsLocal > 0.0 && F0 > 0.0) {
+      JitterLocal /= nPeriodsLocal;
+      lastJitterLocal = JitterLocal / (avgPeriod / nPeriods);
+    }
+    if (nPeriods > 0.0 && nPeriodsLocal > 0.0 && F0 > 0.0) {
+      if (lastJitterLocal > 1.0) lastJitterLocal = 1.0;
+      o[0] = lastJitterLocal;
+    } else if (nPeriods == 0.0 && F0 > 0.0) {
+      if (lastJitterLocal > 1.0) lastJitterLocal = 1.0;
+      o[0] = lastJitterLocal;
+    } else o[0] = 0.0f;
+    if (nPeriods > 0.0 && nPeriodsDDP > 0.0 && F0 > 0.0) {
+      JitterDDP /= nPeriodsDDP;
+      lastJitterDDP = JitterDDP / (avgPeriod / nPeriods);
+    }
+    if (nPeriods > 0.0 && nPeriodsDDP > 0.0 && F0 > 0.0) {
+      if (lastJitterDDP > 1.0) lastJitterDDP = 1.0;
+      o[1] = lastJitterDDP;
+    } else if (nPeriods == 0.0 && F0 > 0.0) {
+      if (lastJitterDDP > 1.0) lastJitterDDP = 1.0;
+      o[1] = lastJitterDDP;
+    } else o[1] = 0.0f;
+    if (nPeriods > 0.0 && F0 > 0.0) {
+      if (avgAmp > 0.0) lastShimmerLocal = avgAmpDiff / avgAmp;
+      else lastShimmerLocal = 0.0f;
+    }
+    if (nPeriods > 0.0 && F0 > 0.0) {
+      if (lastShimmerLocal > 1.0) lastShimmerLocal = 1.0;
+      o[2] = lastShimmerLocal;
+    } else if (nPeriods == 0.0 && F0 > 0.0) {
+      if (lastShimmerLocal > 1.0) lastShimmerLocal = 1.0;
+      o[2] = lastShimmerLocal;
+    } else o[2] = 0.0f;
+    if (lgHNR < lgHNRfloor) lgHNR = lgHNRfloor;
+    o[3] = lgHNR;
+  }
+}
+
+/* ------------------------------------------------------------------ [is13_smoNz] + [is13_deNz] */
+/* The F0 group's LLD columns as the LLD sinks see them: T60+1 rows x 12 =
+ *   [F0final_sma, voicingFinalUnclipped_sma, jitterLocal_sma, jitterDDP_sma, shimmerLocal_sma, logHNR_sma | their deltas]
+ * cContourSmoother with noZeroSma (contourSmoother.cpp:85-100) over the two levels is13_pitchG60 / is13_jitterShimmer,
+ * then cDeltaRegression with onlyInSegments = zeroSegBound = 1 (deltaRegression.cpp:113-135), whose `norm` member
+ * keeps growing by i^2 for every valid pair: rows in order, within a row columns in order (blocksize 1,
+ * windowProcessor.cpp:164-229).
+ * End of input [measured against the binary, T60 = 4..995, P = 1..7]: cPitchJitter does not run during end-of-input
+ * ticks (pitchJitter.cpp:593), and the Viterbi smoother releases its last P frames only then. The tick loop alternates
+ * end-of-input and normal phases (componentManager.cpp:1416-1560), each window processor padding with the last frame
+ * it can see while at least one real frame is in its window:
+ *   - smoNz: rows n <= T-P see the jitter level clipped at frame T-P-1 (the pitch level is complete);
+ *   - deNz: rows n <= T-P+2 see the smoothed level clipped at row T-P, row T-P+3 at row T-1, later rows all of it;
+ *   - P == T (nothing decided before the end): no clipping.
+ * Requires T60 >= 4 like the A+B groups (returns 0 rows otherwise). */
+long lldo_compare_f0_lld(const int16_t *pcm, long n_samples, float *out12)
+{
+  const long N = 960, H = 160;
+  const long T = lldo_num_frames(n_samples, N, H);
+  if (T < 4) return 0;
+  const long rows = T + 1;
+  if (!out12) return rows;
+  float *x6 = (float *)malloc(sizeof(float) * 6 * (size_t)T);
+  float *p2 = (float *)malloc(sizeof(float) * 2 * (size_t)T);
+  float *shs = (float *)malloc(sizeof(float) * 21 * (size_t)T);
+  float *e60 = (float *)malloc(sizeof(float) * (size_t)T);
+  float *wave = (float *)malloc(sizeof(float) * (size_t)n_samples);
+  float *j4 = (float *)malloc(sizeof(float) * 4 * (size_t)T);
+  float *f0 = (float *)malloc(sizeof(float) * (size_t)T);
+  lldo_compare_f0_chain(pcm, n_samples, p2, NULL, shs, NULL, e60);
+  long P = 0;
+  { float *tmp = (float *)malloc(sizeof(float) * 2 * (size_t)T);
+    lldo_pitch_viterbi(shs, T, (float)0.7, tmp, NULL, &P);
+    free(tmp); }
+  lldo_pcm16_to_float(pcm, n_samples, wave);
+  for (long t = 0; t < T; t++) f0[t] = p2[2 * t];
+  lldo_pitch_jitter(wave, n_samples, f0, T, N, H, 16000.0, 0.010, j4);
+  for (long t = 0; t < T; t++) {
+    x6[6 * t] = p2[2 * t]; x6[6 * t + 1] = p2[2 * t + 1];
+    for (int d = 0; d < 4; d++) x6[6 * t + 2 + d] = j4[4 * t + d];
+  }
+  float *z = out12;                                    /* smoothed level, row stride 12 */
+  for (long n = 0; n < rows; n++)
+    for (int d = 0; d < 6; d++) {
+      long clip = T - 1;
+      if (d >= 2 && n <= T - P && P < T) clip = T - P - 1;
+      if (clip < 0) clip = 0;
+#define XC(i) x6[6 * ((i) < 0 ? 0 : ((i) > clip ? clip : (i))) + d]
+      const float c = XC(n);
+      float y = 0.0f;
+      if (c != 0.0) {
+        long cnt = 1;
+        y = c;
+        if (XC(n - 1) != 0.0) { y += XC(n - 1); cnt++; }
+        if (XC(n + 1) != 0.0) { y += XC(n + 1); cnt++; }
+        y /= (float)cnt;
+      }
+#undef XC
+      z[12 * n + d] = y;
+    }
+  float norm = 0.0f;
+  for (int i = 1; i <= 2; i++) norm += (float)i * (float)i;
+  norm *= 2.0;
+  for (long n = 0; n < rows; n++) {
+    long clip = T;
+    if (P < T) clip = (n <= T - P + 2) ? T - P : ((n == T - P + 3) ? T - 1 : T);
+    if (clip < 0) clip = 0;
+    if (clip > rows - 1) clip = rows - 1;
+    for (int d = 0; d < 6; d++) {
+      float num = 0.0f;
+      for (int i = 1; i <= 2; i++) {
+        long ia = n - i, ib = n + i;
+        if (ia < 0) ia = 0;
+        if (ia > clip) ia = clip;
+        if (ib > clip) ib = clip;
+        const float a = z[12 * ia + d], b = z[12 * ib + d];
+        if (!(a == 0.0 || b == 0.0 || isnan(a) || isnan(b))) {
+          const float delta = b - a;
+          num += (float)i * delta;
+          norm += (float)i * (float)i;
+        }
+      }
+      z[12 * n + 6 + d] = (norm != 0.0) ? num / norm : 0.0f;
+    }
+  }
+  free(x6); free(p2); free(shs); free(e60); free(wave); free(j4); free(f0);
+  return rows;
+}
+
+/* The whole LLD level of ComParE_2016 (lld;lld_de of config/compare16/ComParE_2016.conf, 130 columns):
+ * [F0 group (6) | group A (4) | group B (55) | the same 65 columns' deltas]; rows = T60 + 1 */
+long lldo_compare_lld_chain(const int16_t *pcm, long n_samples, float *out130)
+{
+  const long rows = lldo_compare_ab_chain(pcm, n_samples, NULL, NULL);
+  if (rows <= 0) return 0;
+  if (!out130) return rows;
+  float *ab = (float *)malloc(sizeof(float) * 118 * (size_t)rows);
+  float *f = (float *)malloc(sizeof(float) * 12 * (size_t)rows);
+  lldo_compare_ab_chain(pcm, n_samples, ab, NULL);
+  const long r2 = lldo_compare_f0_lld(pcm, n_samples, f);
+  if (r2 != rows) { free(ab); free(f); return -1; }
+  for (long r = 0; r < rows; r++) {
+    float *o = out130 + 130 * r;
+    memcpy(o, f + 12 * r, sizeof(float) * 6);
+    memcpy(o + 6, ab + 118 * r, sizeof(float) * 59);
+    memcpy(o + 65, f + 12 * r + 6, sizeof(float) * 6);
+    memcpy(o + 71, ab + 118 * r + 59, sizeof(float) * 59);
+  }
+  free(ab); free(f);
+  return rows;
 }

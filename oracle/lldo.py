@@ -374,3 +374,46 @@ def compare_f0_chain(pcm, taps=False):
         if r < 0:
             raise RuntimeError("lldo_compare_f0_chain failed")
     return (out, t) if taps else out
+
+
+def pitch_jitter(pcm, f0, N=960, H=160, fs=16000.0, step=0.010):
+    """cPitchJitter as [is13_pitchJitter] configures it: (T x 4) [jitterLocal, jitterDDP, shimmerLocal, logHNR]
+    from the utterance and its F0final contour (one value per 60 ms frame)."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    x = np.zeros(len(pcm), np.float32)
+    L.lldo_pcm16_to_float.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    L.lldo_pcm16_to_float.restype = None
+    L.lldo_pcm16_to_float(pcm.ctypes.data, len(pcm), x.ctypes.data)
+    f0 = np.ascontiguousarray(f0, dtype=np.float32)
+    out = np.zeros((len(f0), 4), np.float32)
+    L.lldo_pitch_jitter.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_double, C.c_double, C.c_void_p]
+    L.lldo_pitch_jitter.restype = None
+    L.lldo_pitch_jitter(x.ctypes.data, len(x), f0.ctypes.data, len(f0), N, H, fs, step, out.ctypes.data)
+    return out
+
+
+def compare_lld_chain(pcm):
+    """ComParE_2016's whole LLD level as its LLD sinks see it: (T60+1) x 130."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_compare_lld_chain.restype = C.c_long
+    L.lldo_compare_lld_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    rows = L.lldo_compare_lld_chain(pcm.ctypes.data, len(pcm), None)
+    out = np.zeros((max(rows, 0), 130), np.float32)
+    if rows > 0 and L.lldo_compare_lld_chain(pcm.ctypes.data, len(pcm), out.ctypes.data) != rows:
+        raise RuntimeError("lldo_compare_lld_chain failed")
+    return out
+
+
+def compare_f0_lld(pcm):
+    """The F0 group's 12 LLD columns [6 smoothed | 6 deltas], T60+1 rows."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_compare_f0_lld.restype = C.c_long
+    L.lldo_compare_f0_lld.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    rows = L.lldo_compare_f0_lld(pcm.ctypes.data, len(pcm), None)
+    out = np.zeros((max(rows, 0), 12), np.float32)
+    if rows > 0:
+        L.lldo_compare_f0_lld(pcm.ctypes.data, len(pcm), out.ctypes.data)
+    return out

@@ -43,13 +43,17 @@ def gen_f0():
     ref = {}
     for name, (u, n) in {"u2_16000": (2, 16000), "u3_16000": (3, 16000), "u10_16000": (10, 16000),
                           "u1_16000": (1, 16000), "u0_16000": (0, 16000), "u7_960": (7, 960), "u7_1120": (7, 1120),
-                          "u7_1600": (7, 1600), "u4_48000": (4, 48000), "u11_160000": (11, 160000)}.items():
+                          "u7_1600": (7, 1600), "u4_48000": (4, 48000), "u11_160000": (11, 160000),
+                          # ends with 5 / 4 / 3 frames the Viterbi smoother had not decided (end-of-input phases)
+                          "u4_9000": (4, 9000), "u37_9000": (37, 9000), "u2_8720": (2, 8720)}.items():
         pcm = synth.utterance(u, n)
         t = lldo.run_reference_taps(pcm)
         ref["pcm_" + name] = pcm
         for k in ("pitch", "shs", "vit", "e60", "jit", "nzsmo", "nzsmo_de"):
             ref[k + "_" + name] = t[k]
         ref["lldf0_" + name] = np.concatenate([t["lld"][:, 0:6], t["lld"][:, 65:71]], axis=1)
+        if name in ("u2_16000", "u4_9000", "u37_9000", "u2_8720", "u7_1600", "u10_16000"):
+            ref["lld130_" + name] = t["lld"]          # the whole LLD level (groups A+B are also in compare16_ab_synth.npz)
         if name in ("u2_16000", "u7_1120"):
             ref["hps_" + name] = t["hps"]
         print("f0", name, t["pitch"].shape, t["lld"].shape)

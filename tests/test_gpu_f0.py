@@ -86,13 +86,13 @@ def test_f0_viterbi_exact_on_identical_candidates(hip, oracle):
     import ctypes as C
     L = oracle.lib()
     L.lldo_pitch_viterbi.restype = None
-    L.lldo_pitch_viterbi.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p]
+    L.lldo_pitch_viterbi.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     for i in range(len(lens)):
         sl = slice(b.frame_offsets[i], b.frame_offsets[i + 1])
         shs = np.ascontiguousarray(taps["shs"][sl])
         T = shs.shape[0]
         ref = np.zeros((T, 2), np.float32)
-        L.lldo_pitch_viterbi(shs.ctypes.data, T, np.float32(0.7), ref.ctypes.data, None)
+        L.lldo_pitch_viterbi(shs.ctypes.data, T, np.float32(0.7), ref.ctypes.data, None, None)
         ref[~(taps["e60"][sl, 0] > np.float32(0.001))] = 0.0
         assert np.array_equal(out[sl].view(np.uint32), ref.view(np.uint32)), f"utt {i}: {(out[sl] != ref).any(axis=1).sum()} rows"
     b.close()

@@ -6,7 +6,9 @@ import numpy as np
 import pytest
 
 KEYS = ["u2_16000", "u3_16000", "u10_16000", "u1_16000", "u0_16000", "u7_960", "u7_1120", "u7_1600", "u4_48000",
-        "u11_160000"]
+        "u11_160000", "u4_9000", "u37_9000", "u2_8720"]
+KEYS_LLD = [k for k in KEYS if k not in ("u7_960", "u7_1120")]          # T60 >= 4: the LLD level has rows
+KEYS_130 = ["u2_16000", "u4_9000", "u37_9000", "u2_8720", "u7_1600", "u10_16000"]
 
 
 def bits(a):
@@ -68,3 +70,48 @@ def test_f0_levels_against_live_reference(oracle):
             assert np.array_equal(bits(out), bits(ref["pitch"]))
     finally:
         oracle.use_reference_fft(False)
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_jitter_shimmer_bit_exact_on_reference_f0(oracle, golden_f0, key):
+    """cPitchJitter reads the wave and the F0 contour only: fed with the binary's own F0final it must reproduce the
+    binary's level is13_jitterShimmer (jitterLocal, jitterDDP, shimmerLocal, logHNR) bit for bit."""
+    ref = golden_f0["jit_" + key]
+    out = oracle.pitch_jitter(golden_f0["pcm_" + key], golden_f0["pitch_" + key][:, 0])
+    assert out.shape == ref.shape
+    assert np.array_equal(bits(out), bits(ref)), f"max abs {np.abs(out - ref).max()}"
+
+
+@pytest.mark.parametrize("key", KEYS_LLD)
+def test_f0_lld_columns_bit_exact_with_reference_fft(oracle, golden_f0, key):
+    """The F0 group's 12 columns of the LLD level (noZeroSma smoothing, onlyInSegments deltas with the growing norm,
+    the end-of-input phases of the tick loop), incl. inputs that end with 3..5 undecided Viterbi frames."""
+    if not oracle.use_reference_fft(True):
+        pytest.skip("oracle/_ref/libref_dsp.so not built")
+    try:
+        out = oracle.compare_f0_lld(golden_f0["pcm_" + key])
+    finally:
+        oracle.use_reference_fft(False)
+    ref = golden_f0["lldf0_" + key]
+    assert out.shape == ref.shape                 # T60+1 rows x [6 smoothed | 6 deltas]
+    assert np.array_equal(bits(out), bits(ref)), f"rows {sorted(set(np.argwhere(bits(out) != bits(ref))[:, 0]))[:8]}"
+
+
+@pytest.mark.parametrize("key", KEYS_130)
+def test_compare_lld_level_bit_exact_with_reference_fft(oracle, golden_f0, key):
+    """All 130 columns of ComParE_2016's LLD level (lld;lld_de)."""
+    if not oracle.use_reference_fft(True):
+        pytest.skip("oracle/_ref/libref_dsp.so not built")
+    try:
+        out = oracle.compare_lld_chain(golden_f0["pcm_" + key])
+    finally:
+        oracle.use_reference_fft(False)
+    ref = golden_f0["lld130_" + key]
+    assert out.shape == ref.shape
+    assert np.array_equal(bits(out), bits(ref))
+
+
+def test_short_inputs_have_no_lld_rows(oracle, golden_f0):
+    for key in ("u7_960", "u7_1120"):
+        assert oracle.compare_f0_lld(golden_f0["pcm_" + key]).shape == (0, 12)
+        assert oracle.compare_lld_chain(golden_f0["pcm_" + key]).shape == (0, 130)
