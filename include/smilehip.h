@@ -141,6 +141,7 @@ typedef struct smilehip_lld_config {
 #define SMILEHIP_CHAIN_COMPARE_AB 2
 #define SMILEHIP_CHAIN_PLP 3
 #define SMILEHIP_CHAIN_COMPARE_F0 4
+#define SMILEHIP_CHAIN_COMPARE 5
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -185,6 +186,8 @@ void smilehip_config_plp_0_d_a(smilehip_lld_config *c);
 void smilehip_config_compare16_ab(smilehip_lld_config *c);
 /* fills c with the F0 group of config/compare16/ComParE_2016.conf up to is13_pitchG60 (chain_kind = COMPARE_F0) */
 void smilehip_config_compare16_f0(smilehip_lld_config *c);
+/* fills c with the whole LLD level of config/compare16/ComParE_2016.conf (chain_kind = COMPARE, 130 columns) */
+void smilehip_config_compare16(smilehip_lld_config *c);
 
 /* F0 chain taps (tests / diagnostics): device pointers to the per-frame scratch the last smilehip_lld_run of this
  * batch filled -- candidates [total_frames x 21] = level is13_pitchShsG60 (nCandidates | F0Cand[6] | candVoicing[6] |

@@ -66,6 +66,7 @@ SYMBOLS = {
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_f0": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_compare16": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_f0_taps": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "smilehip_config_plp_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
@@ -159,6 +160,12 @@ def plp_0_d_a_config():
 def compare16_ab_config():
     c = LldConfig()
     load().smilehip_config_compare16_ab(C.byref(c))
+    return c
+
+
+def compare16_config():
+    c = LldConfig()
+    load().smilehip_config_compare16(C.byref(c))
     return c
 
 

@@ -202,7 +202,7 @@ __device__ __forceinline__ float sma_a(const float *la, int t, int d, int len) {
   return y / 3.0f;
 }
 __global__ void __launch_bounds__(256) lld_compare_groupA(const int64_t *frame_off, const int64_t *row_off, int n_utt,
-                                                         int64_t total_rows, CompareParams Q, float *out, int64_t ld) {
+                                                         int64_t total_rows, CompareParams Q, float *out, int64_t ld, int de_col) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid >> 2;
   const int d = (int)(gid & 3);
@@ -227,11 +227,11 @@ __global__ void __launch_bounds__(256) lld_compare_groupA(const int64_t *frame_o
     b = b > rows - 1 ? rows - 1 : b;
     num += (float)i * (sma_a(la, b, d, len) - sma_a(la, a, d, len));
   }
-  out[row * ld + 59 + d] = num / 10.0f;
+  out[row * ld + de_col + d] = num / 10.0f;
 }
 
 hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
-                          int64_t total_rows, float *d_out, int64_t ld_out, hipStream_t s) {
+                          int64_t total_rows, float *d_out, int64_t ld_out, int de_col, hipStream_t s) {
   if (n_runs <= 0) return hipSuccess;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
@@ -245,7 +245,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if (e != hipSuccess) return e;
   if (total_rows > 0)
     hipLaunchKernelGGL(lld_compare_groupA, dim3((unsigned)((total_rows * 4 + 255) / 256)), dim3(256), 0, s, P.frame_off,
-                       d_row_off, P.n_utt, total_rows, Q, d_out, ld_out);
+                       d_row_off, P.n_utt, total_rows, Q, d_out, ld_out, de_col);
   return hipGetLastError();
 }
 

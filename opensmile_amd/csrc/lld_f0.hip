@@ -578,11 +578,332 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
     __syncthreads();
   }
   // flushTrellis at end of input
+  if (lane == 0 && Q.pending) Q.pending[u] = pathIdx - (convIdx + 1);      // frames only decided by the flush
   {
     int ms = 0;
     for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
     const int *Pp = paths[pathBuf];
     for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB]);
+  }
+}
+
+// cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1064) as [is13_pitchJitter] configures it (searchRangeRel 0.25,
+// minNumPeriods 2, minCC 0.5, useBrokenJitterThresh 0, peak amplitudes, lgHNRfloor -100): jitterLocal, jitterDDP,
+// shimmerLocal, logHNR per F0 frame. One wave per utterance, frames in order (the read position in the wave, the
+// left-over samples and the last period / difference / jitter / shimmer values carry over from frame to frame).
+// Per period step every lane cross-correlates one candidate period length (crossCorr, :331-418: two sequential passes
+// in double per candidate, the order the reference sums in); the local-maximum search, the amplitude extremes and the
+// averaged period waveform are wave-parallel, the energy sums run in the reference's float order.
+// Time meta of frame t as the framer derives it from a wave level without stored time stamps
+// (dataMemoryLevel.cpp:617-626,1226-1245): lengthSec = ((tH+N-1)Tw - tH Tw) + Tw, so lenF = ceil(lengthSec/Tw) is N or N+1.
+namespace {
+constexpr int kJitCap = 2560;      // samples of wave the kernel can hold per frame (frame + left-over of the previous frames)
+constexpr int kJitMaxCand = 192;   // candidate period lengths per step: T0maxF - T0minF + 1 <= 156 for F0 >= 52 Hz
+constexpr int kJitMaxPeriod = 448; // T0f + 1 <= 309
+constexpr int kJitMaxPeriods = 160;
+}
+
+__global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
+  const int u = blockIdx.x;
+  if (u >= P.n_utt) return;
+  const int64_t fo = P.frame_off[u];
+  const int T = (int)(P.frame_off[u + 1] - fo);
+  if (T <= 0) return;
+  const int lane = threadIdx.x;
+  __shared__ float wv[kJitCap];
+  __shared__ double ccs[kJitMaxCand];
+  __shared__ float avgWf[kJitMaxPeriod];
+  __shared__ int pbuf[kJitMaxPeriods];
+  const int64_t s0 = P.samp_off[u];
+  const int64_t n_samp = P.samp_off[u + 1] - s0;
+  const int16_t *x = P.pcm + s0;
+  const double Tw = Q.jit_Tw;
+  const int N = Q.N, H = Q.H;
+  const long ppLen = (long)ceil(Q.jit_step_sec / Tw);
+  long lastIdx = 0, lastMis = 0;
+  float lastT0 = 0.0f, lastDiff = 0.0f, lastJL = 0.0f, lastJD = 0.0f, lastSh = 0.0f;
+  for (int t = 0; t < T; ++t) {
+    const float F0 = f0[(fo + t) * ld_f0];
+    const double time = (double)((long)t * H) * Tw;
+    const double lengthSec = ((double)((long)t * H + N - 1) * Tw - (double)((long)t * H) * Tw) + Tw;
+    const long lenF = (long)ceil(lengthSec / Tw);
+    const long startVidx = (long)round(time / Tw);
+    long toRead0 = ppLen + lastMis, toRead = toRead0;
+    double Tf = 0.0;
+    long T0f = 0, T0minF = 0, T0maxF = 0;
+    if (F0 > 0.0f) {
+      const double T0 = 1.0 / F0;
+      Tf = T0 / Tw;
+      T0f = (long)round(Tf);
+      T0minF = (long)floor((1.0 - 0.25) * Tf);
+      T0maxF = (long)ceil((1.0 + 0.25) * Tf);
+      const long two_pp = 2 * T0maxF + 2;
+      if (toRead < two_pp) toRead = two_pp;
+    }
+    long maxRead = lastMis + lenF;
+    if (toRead > maxRead) toRead = maxRead;
+    if (startVidx - lastMis != lastIdx) {
+      lastIdx = startVidx;
+      if (toRead > lenF) toRead = lenF;
+      if (maxRead > lenF) maxRead = lenF;
+    }
+    float *o = out4 + (fo + t) * 4;
+    const bool fits = toRead <= kJitCap && (T0maxF - T0minF + 1) <= kJitMaxCand && T0f + 1 <= kJitMaxPeriod &&
+                      (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
+    if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
+      lastIdx += toRead0;
+      if (lane == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
+      continue;
+    }
+    const long nT = toRead;
+    float nPeriodsLocal = 0, nPeriodsDDP = 0, nPeriods = 0, avgPeriod = 0.0f, JitterDDP = 0.0f, JitterLocal = 0.0f;
+    float avgAmp = 0.0f, avgAmpDiff = 0.0f, lgHNR = 0.0f;
+    long start = 0, lastPeriod = 0;
+    if (F0 > 0.0f) {
+      __syncthreads();
+      for (long i = lane; i < nT; i += 64) wv[i] = pcm16_to_float(x[lastIdx + i]);
+      for (long i = lane; i <= T0f; i += 64) avgWf[i] = 0.0f;
+      __syncthreads();
+      int numPeriods = 0;
+      long pp = 0;
+      const int nc = (int)(T0maxF - T0minF) + 1;
+      while (start < nT - 2 * T0maxF - 1) {
+        for (int c = lane; c < nc; c += 64) {                   // crossCorr of [start, start+tf) with [start+tf, start+2tf)
+          const long tf = T0minF + c;
+          const float *xa = wv + start, *ya = wv + start + tf;
+          double mx = 0.0, my = 0.0;
+          for (long i = 0; i < tf; i++) { mx += xa[i]; my += ya[i]; }
+          mx /= (double)tf;
+          my /= (double)tf;
+          double cc = 0.0, nx = 0.0, ny = 0.0;
+          for (long i = 0; i < tf; i++) {
+            const double dx = xa[i] - mx, dy = ya[i] - my;
+            cc += dx * dy;
+            nx += dx * dx;
+            ny += dy * dy;
+          }
+          cc /= sqrt(nx) * sqrt(ny);
+          ccs[c] = cc;
+        }
+        __syncthreads();
+        // the greatest local maximum of cc[1 .. nc-3], the first one among equals (:734-747)
+        double bv = 0.0;
+        int bi = 1 << 30;
+        for (int i = 1 + lane; i < nc - 2; i += 64) {
+          const double v = ccs[i];
+          if (ccs[i - 1] < v && v > ccs[i + 1] && (bi == (1 << 30) || v > bv)) { bv = v; bi = i; }
+        }
+        for (int of = 32; of > 0; of >>= 1) {
+          const double ov = __shfl_xor(bv, of);
+          const int oi = __shfl_xor(bi, of);
+          if (oi != (1 << 30) && (bi == (1 << 30) || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        const long maxI = (bi == (1 << 30)) ? -1 : bi;
+        pp = (maxI == -1) ? T0f : T0minF + maxI;
+        const long os = start;
+        if (maxI >= 0) {
+          start += pp;
+          // amplitudeDiff (:422-459): max - min of x[1 .. pp-2] in both periods
+          float mx0 = wv[os + 1], mn0 = mx0, mx1 = wv[start + 1], mn1 = mx1;
+          for (long i = 1 + lane; i < pp - 1; i += 64) {
+            const float a = wv[os + i], b = wv[start + i];
+            mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
+            mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
+          }
+          for (int of = 32; of > 0; of >>= 1) {
+            float v;
+            v = __shfl_xor(mx0, of); mx0 = v > mx0 ? v : mx0;
+            v = __shfl_xor(mn0, of); mn0 = v < mn0 ? v : mn0;
+            v = __shfl_xor(mx1, of); mx1 = v > mx1 ? v : mx1;
+            v = __shfl_xor(mn1, of); mn1 = v < mn1 ? v : mn1;
+          }
+          const float a0 = mx0 - mn0, a1 = mx1 - mn1;
+          const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
+          if (lane == 0) pbuf[numPeriods] = (int)os;
+          numPeriods++;
+          for (long i = lane; i < T0f; i += 64) avgWf[i] += wv[os + i];
+          double ccI = 0.0;
+          const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
+                                                                 (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
+          if (ccI > (float)0.5) {
+            const float period = (float)maxId;
+            avgPeriod += period;
+            nPeriods += 1.0f;
+            if (lastT0 > 0.0f) {
+              const float diff = fabsf(lastT0 - period);
+              JitterLocal += diff;
+              nPeriodsLocal += 1.0f;
+              if (lastDiff > 0.0f) { JitterDDP += fabsf(lastDiff - diff); nPeriodsDDP += 1.0f; }
+              lastDiff = diff;
+            }
+            lastT0 = period;
+            avgAmp += (a0 + a1) / (float)2.0;
+            avgAmpDiff += ad;
+          }
+        } else {
+          start += T0f;
+        }
+        if (start < toRead0 - 1) lastPeriod = start;
+        __syncthreads();
+      }
+      if (lane == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
+      numPeriods++;
+      for (long i = lane; i < T0f && start + i < nT; i += 64) {
+        avgWf[i] += wv[start + i];
+        avgWf[i] /= (float)numPeriods;
+      }
+      __syncthreads();
+      // harmonic / noise energy in the reference's summation order (:843-873), every lane the same chain
+      float Eh = 0.0f;
+      for (long i = 0; i < T0f && start + i < nT; i++)
+        if (i > 2 && i < T0f - 2) Eh += avgWf[i] * avgWf[i];
+      if (T0f - 4 > 0) Eh /= (float)(T0f - 4);
+      Eh = sqrtf(Eh);
+      float En = 0.0f;
+      long nEn = 0;
+      for (int i = 0; i < numPeriods; i++) {
+        long k = 2;
+        const long p0 = pbuf[i], p1 = pbuf[i + 1];
+        const long lim = (p1 < p0 + T0f ? p1 : p0 + T0f) - 2;
+        for (long j = p0 + 2; j < lim; j++) {
+          const float delta = wv[j] - avgWf[k++];
+          En += delta * delta;
+          nEn++;
+        }
+      }
+      if (nEn > 0) En /= (float)nEn;
+      En = sqrtf(En);
+      if (En > 0.0f) {
+        const float HNR = Eh / En;
+        if (HNR > 0.0f) lgHNR = (float)(20.0 * log((double)HNR) / log(10.0));
+        else lgHNR = -100.0f;
+      }
+      lastMis = toRead0 - lastPeriod;
+    } else {
+      lastPeriod = toRead0;
+      lastMis = 0;
+      lastT0 = 0.0f; lastDiff = 0.0f;
+      lastJD = 0.0f; lastJL = 0.0f; lastSh = 0.0f;
+      lgHNR = -100.0f;
+    }
+    lastIdx += lastPeriod;
+    float o0, o1, o2;
+    const bool voiced = F0 > 0.0f;
+    if (nPeriods > 0.0f && nPeriodsLocal > 0.0f && voiced) {
+      JitterLocal /= nPeriodsLocal;
+      lastJL = JitterLocal / (avgPeriod / nPeriods);
+    }
+    if ((nPeriods > 0.0f && nPeriodsLocal > 0.0f && voiced) || (nPeriods == 0.0f && voiced)) {
+      if (lastJL > 1.0f) lastJL = 1.0f;
+      o0 = lastJL;
+    } else o0 = 0.0f;
+    if (nPeriods > 0.0f && nPeriodsDDP > 0.0f && voiced) {
+      JitterDDP /= nPeriodsDDP;
+      lastJD = JitterDDP / (avgPeriod / nPeriods);
+    }
+    if ((nPeriods > 0.0f && nPeriodsDDP > 0.0f && voiced) || (nPeriods == 0.0f && voiced)) {
+      if (lastJD > 1.0f) lastJD = 1.0f;
+      o1 = lastJD;
+    } else o1 = 0.0f;
+    if (nPeriods > 0.0f && voiced) lastSh = (avgAmp > 0.0f) ? avgAmpDiff / avgAmp : 0.0f;
+    if (voiced) {                                          // nPeriods > 0 or == 0: both branches clip and emit the held value
+      if (lastSh > 1.0f) lastSh = 1.0f;
+      o2 = lastSh;
+    } else o2 = 0.0f;
+    if (lgHNR < -100.0f) lgHNR = -100.0f;
+    if (lane == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR; }
+  }
+}
+
+// [is13_smoNz] + [is13_deNz]: the F0 group's columns of the LLD level, T60+1 rows per utterance:
+// cContourSmoother with noZeroSma (contourSmoother.cpp:85-100) over [F0final, voicing | jitterLocal, jitterDDP,
+// shimmerLocal, logHNR], then cDeltaRegression with onlyInSegments (deltaRegression.cpp:113-135) whose `norm` grows by
+// i^2 with every valid pair, rows in order, columns in order within a row (here: integer prefix sums, exact in float
+// below 2^24 pairs). End of input as measured against the binary (oracle/lld_oracle_f0.c, lldo_compare_f0_lld): with
+// P frames undecided by the Viterbi pass at the end of input, smoothed rows n <= T-P see the jitter columns clipped
+// at frame T-P-1, delta rows n <= T-P+2 see the smoothed level clipped at row T-P and row T-P+3 at row T-1; P == T: no
+// clipping. One wave per utterance.
+__global__ void __launch_bounds__(64) lld_f0_lld(const int64_t *frame_off, const int64_t *row_off, int n_utt, const float *pitch2,
+                                                const float *jit4, const int32_t *pending, float *out, int64_t ld, int col_sma,
+                                                int col_de) {
+  const int u = blockIdx.x;
+  if (u >= n_utt) return;
+  const int64_t fo = frame_off[u], ro = row_off[u];
+  const int T = (int)(frame_off[u + 1] - fo);
+  const int rows = (int)(row_off[u + 1] - ro);
+  if (rows <= 0 || T <= 0) return;
+  const int lane = threadIdx.x;
+  const int Pn = pending[u];
+  const float *p2 = pitch2 + fo * 2, *j4 = jit4 + fo * 4;
+  float *o = out + ro * ld;
+  for (int n = lane; n < rows; n += 64)
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      int clip = T - 1;
+      if (d >= 2 && n <= T - Pn && Pn < T) clip = T - Pn - 1;
+      if (clip < 0) clip = 0;
+      auto X = [&](int i) {
+        i = i < 0 ? 0 : (i > clip ? clip : i);
+        return d < 2 ? p2[(int64_t)i * 2 + d] : j4[(int64_t)i * 4 + (d - 2)];
+      };
+      const float c = X(n);
+      float y = 0.0f;
+      if (c != 0.0f) {
+        int cnt = 1;
+        y = c;
+        const float l = X(n - 1), r = X(n + 1);
+        if (l != 0.0f) { y += l; cnt++; }
+        if (r != 0.0f) { y += r; cnt++; }
+        y /= (float)cnt;
+      }
+      o[(int64_t)n * ld + col_sma + d] = y;
+    }
+  __threadfence_block();
+  __syncthreads();
+  int base = 0;                                           // valid pairs' i^2 summed over all earlier rows
+  for (int n0 = 0; n0 < rows; n0 += 64) {
+    const int n = n0 + lane;
+    float num[6];
+    int inc[6];
+    int tot = 0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { num[d] = 0.0f; inc[d] = 0; }
+    if (n < rows) {
+      int clip = T;
+      if (Pn < T) clip = (n <= T - Pn + 2) ? T - Pn : ((n == T - Pn + 3) ? T - 1 : T);
+      clip = clip < 0 ? 0 : (clip > rows - 1 ? rows - 1 : clip);
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+#pragma unroll
+        for (int i = 1; i <= 2; ++i) {
+          int ia = n - i, ib = n + i;
+          ia = ia < 0 ? 0 : (ia > clip ? clip : ia);
+          ib = ib > clip ? clip : ib;
+          const float a = o[(int64_t)ia * ld + col_sma + d], b = o[(int64_t)ib * ld + col_sma + d];
+          if (!(a == 0.0f || b == 0.0f || a != a || b != b)) {
+            num[d] += (float)i * (b - a);
+            inc[d] += i * i;
+          }
+        }
+#pragma unroll
+      for (int d = 0; d < 6; ++d) tot += inc[d];
+    }
+    int pre = tot;                                        // inclusive prefix over the lanes (rows of this round)
+    for (int of = 1; of < 64; of <<= 1) {
+      const int v = __shfl_up(pre, of);
+      if (lane >= of) pre += v;
+    }
+    const int round_total = __shfl(pre, 63);
+    if (n < rows) {
+      int cnt = base + pre - tot;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        cnt += inc[d];
+        const float norm = 10.0f + (float)cnt;
+        o[(int64_t)n * ld + col_de + d] = num[d] / norm;
+      }
+    }
+    base += round_total;
   }
 }
 
@@ -601,6 +922,19 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, floa
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q, d_out, ld_out);
+  return hipGetLastError();
+}
+
+
+// jitter / shimmer / HNR from the wave and the F0 contour (pitch2, T60 x 2), then the F0 group's 12 LLD columns
+hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
+                         float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s) {
+  if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_f0_jitter, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
+                     Q.pending, d_out, ld_out, col_sma, col_de);
   return hipGetLastError();
 }
 

@@ -125,11 +125,14 @@ struct F0Params {
   double min_pitch, max_pitch;
   float voicing_cutoff;
   float min_energy;
+  double jit_Tw;                    // cPitchJitter: sample period of the wave level, 1.0 / sampleRate
+  double jit_step_sec;              // period of the F0 level (frameStep)
   double vit_w[6];                  // cPitchSmootherViterbi: wLocal, wTvv, wTvvd, wTvuv, wThr, wRange (wTuu is never used)
   // per-frame results between the kernels
   float *shs;                       // [total_frames x 21] nCand | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip
   float *e60;                       // [total_frames] RMS energy of the windowed frame
   float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
+  int32_t *pending;                 // optional [n_utt]: frames the Viterbi pass had not decided at the end of input
 };
 
 // Constants of cSpectral for one spectrum geometry (host-resolved in smilehip_plan.cpp)

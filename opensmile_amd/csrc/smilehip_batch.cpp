@@ -2,6 +2,12 @@
 #include "smilehip_internal.hpp"
 
 // ------------------------------------------------------------------ batch
+smilehip_batch::~smilehip_batch() { delete f0_batch; }
+
+static inline bool compare_ab_like(const smilehip_plan *p) {
+  return p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE;
+}
+
 extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, int32_t n_utt, smilehip_batch **out) {
   if (!plan || !out || n_utt < 0 || (n_utt > 0 && !h_off)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_create: bad argument");
   *out = nullptr;
@@ -31,7 +37,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     }
     const int64_t T = smilehip_num_frames(plan, len);
     int64_t rows = T > 0 ? T + row_extra : 0;
-    if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+    if (compare_ab_like(plan)) {
       // rows = T60 + 1 where T60 = frames of the 60 ms framer ([is13_frame60]); none if T60 < 4
       const int64_t N60 = std::lround(0.060 / plan->geo.period);
       const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
@@ -73,7 +79,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     delete b;
     return rc;
   }
-  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+  if (compare_ab_like(plan)) {
     b->n_runs = (int32_t)run_utt.size();
     if ((rc = b->d_run_utt.upload(run_utt)) || (rc = b->d_run_t0.upload(run_t0))) {
       delete b;
@@ -106,6 +112,24 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 scratch matrices failed");
     }
     b->d_shs.n = nf * 21; b->d_e60.n = nf;
+    std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
+    if ((rc = b->d_pending.upload(zp))) {
+      delete b;
+      return rc;
+    }
+  }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) {
+    if ((rc = smilehip_batch_create(plan->f0_plan, h_off, n_utt, &b->f0_batch))) {
+      delete b;
+      return rc;
+    }
+    const size_t nf = size_t(b->f0_batch->total_frames ? b->f0_batch->total_frames : 1);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_pitch2.p), nf * 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b->d_jit4.p), nf * 4 * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 group's scratch matrices failed");
+    }
+    b->d_pitch2.n = nf * 2; b->d_jit4.n = nf * 4;
   }
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09) {
     std::vector<float> zero;   // allocate only
@@ -328,7 +352,8 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
 }
 
 // ComParE groups A+B: frame kernel -> RASTA scan -> group A (multi-length SMA+delta) + group B chain
-static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream,
+                       int de_col = 59) {
   const int n_out = plan_n_out(plan);
   if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
   if (b->total_frames == 0 || b->total_rows == 0) return SMILEHIP_OK;
@@ -358,7 +383,7 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   }
   Q.slope_Sf = plan->slope_Sf;
   Q.slope_S2f = plan->slope_S2f;
-  hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, s);
+  hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, de_col, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "ComParE kernel launch failed: %s", hipGetErrorString(e));
   ChainParams C;
   std::memset(&C, 0, sizeof(C));
@@ -378,7 +403,7 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   C.kind[0] = 1; C.W[0] = 1;
   C.kind[1] = 0; C.W[1] = 2;
   C.out_col[0] = 4;
-  C.out_col[1] = 59 + 4;
+  C.out_col[1] = de_col + 4;
   C.short_T = chain_short_max();
   C.short_utts = b->d_short.p;
   C.n_short = (int32_t)b->h_short.size();
@@ -403,6 +428,8 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.min_pitch = plan->cfg.pitch_min; Q.max_pitch = plan->cfg.pitch_max;
   Q.voicing_cutoff = (float)plan->cfg.voicing_cutoff;
   Q.min_energy = plan->cfg.f0_min_energy;
+  Q.jit_Tw = plan->geo.period;                 // 1.0 / (double)sampleRate, waveSource.cpp:190
+  Q.jit_step_sec = plan->cfg.frame_step_sec;
   // [is13_pitchSmoothViterbi]: wLocal 2, wTvv 10, wTvvd 5, wTvuv 10, wThr 4, wRange 1 -- but
   // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd (pitchSmootherViterbi.hpp:291-299): 10
   Q.vit_w[0] = 2.0; Q.vit_w[1] = 10.0; Q.vit_w[2] = 10.0; Q.vit_w[3] = 10.0; Q.vit_w[4] = 4.0; Q.vit_w[5] = 1.0;
@@ -419,8 +446,29 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.shs = b->d_shs.p;
   Q.e60 = b->d_e60.p;
   Q.hps_tap = b->d_hps_tap;
+  Q.pending = b->d_pending.p;
   hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+// SMILEHIP_CHAIN_COMPARE: groups A+B into columns 6..64 / 71..129, the 60 ms sub-chain (F0 contour into scratch), then
+// cPitchJitter and the F0 group's 12 LLD columns into 0..5 / 65..70
+static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  if (ld_out < 130) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 130", (long long)ld_out);
+  if (b->total_rows == 0) return SMILEHIP_OK;
+  if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  int rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, stream, 65);
+  if (rc) return rc;
+  smilehip_batch *fb = b->f0_batch;
+  if ((rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream))) return rc;
+  LldParams P;
+  fill_params(plan->f0_plan, fb, d_pcm, d_out, ld_out, P);
+  F0Params Q;
+  fill_f0_params(plan->f0_plan, Q);
+  Q.pending = fb->d_pending.p;
+  hipError_t e = launch_f0_lld(P, Q, b->d_row_off.p, b->d_pitch2.p, b->d_jit4.p, d_out, ld_out, 0, 65, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 LLD kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
 
@@ -516,6 +564,7 @@ extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const in
     return smilehip_mfcc_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return f0_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return compare_full_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
 }
 

@@ -55,6 +55,8 @@ struct DevBuf {
   }
 };
 
+struct smilehip_plan;
+struct smilehip_batch;
 struct smilehip_plan {
   smilehip_context *ctx = nullptr;
   smilehip_lld_config cfg{};
@@ -75,7 +77,8 @@ struct smilehip_plan {
   DevBuf<float> d_plp_eql, d_plp_cos, d_plp_sin;     // PLP chain tables
   std::vector<float> h_plp_cos;
   DevBuf<double> d_sharp;
-  // F0 group (SMILEHIP_CHAIN_COMPARE_F0)
+  // F0 group (SMILEHIP_CHAIN_COMPARE_F0); the whole-level chain (SMILEHIP_CHAIN_COMPARE) owns a second plan for it
+  smilehip_plan *f0_plan = nullptr;
   F0Host f0;
   DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
   DevBuf<int32_t> d_f0_k;
@@ -91,6 +94,7 @@ struct smilehip_plan {
   int force_generic = 0;
   uint32_t stage_mask = SMILEHIP_STAGE_ALL;
   ~smilehip_plan() {
+    delete f0_plan;
     for (auto &slot : ev)
       for (auto &e : slot)
         if (e) (void)hipEventDestroy(e);
@@ -109,6 +113,10 @@ struct smilehip_batch {
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
   DevBuf<float> d_shs, d_e60;             // F0 group: candidates (total_frames x 21) and frame energies
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
+  DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance
+  DevBuf<float> d_pitch2, d_jit4;         // whole-level chain: F0final/voicing (T60 x 2) and jitter/shimmer/HNR (T60 x 4)
+  smilehip_batch *f0_batch = nullptr;     // whole-level chain: the 60 ms sub-chain's batch
+  ~smilehip_batch();
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;
   std::vector<int32_t> h_short;

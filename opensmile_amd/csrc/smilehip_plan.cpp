@@ -85,6 +85,15 @@ extern "C" void smilehip_config_compare16_f0(smilehip_lld_config *c) {
   c->f0_min_energy = 0.001f;        // [is13_volmerge] threshold
 }
 
+extern "C" void smilehip_config_compare16(smilehip_lld_config *c) {
+  smilehip_config_compare16_ab(c);
+  c->chain_kind = SMILEHIP_CHAIN_COMPARE;
+}
+
+static inline bool is_compare_ab_like(const smilehip_lld_config &c) {
+  return c.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || c.chain_kind == SMILEHIP_CHAIN_COMPARE;
+}
+
 // ------------------------------------------------------------------- plan
 static int build_tables(smilehip_plan *p, bool upload = true) {
   int rc;
@@ -111,7 +120,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 12 || p->cfg.n_delta != 1 || p->cfg.sma_win < 3 || !(p->cfg.sma_win & 1) ||
         p->cfg.sma_win > 9)
       return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
-  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+  } else if (is_compare_ab_like(p->cfg)) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
         p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
       return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
@@ -199,7 +208,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       ((rc = p->d_f0_rec.upload(p->f0.sp_rec)) || (rc = p->d_f0_d1.upload(p->f0.sp_d1)) || (rc = p->d_f0_d2.upload(p->f0.sp_d2)) ||
        (rc = p->d_f0_co.upload(p->f0.ip_co)) || (rc = p->d_f0_audw.upload(p->f0.audw)) || (rc = p->d_f0_k.upload(p->f0.ip_k))))
     return rc;
-  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) {
+  if (is_compare_ab_like(p->cfg)) {
     // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
     // publishes as metadata (melspec.cpp:408-412), and the newRASTA filter coefficients
     std::vector<float> eql(26), eqll(26);
@@ -222,7 +231,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     p->rasta_fir[4] = -p->rasta_fir[0];
     if ((rc = p->d_eql.upload(eql)) || (rc = p->d_eql_log.upload(eqll))) return rc;
   }
-  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || (mask & SMILEHIP_STAGE_SPECTRAL)) {
+  if (is_compare_ab_like(p->cfg) || (mask & SMILEHIP_STAGE_SPECTRAL)) {
     // sharpness weights (spectral.cpp:1440-1455): bark(f) * g(bark(f)) for bins 1..K-1
     std::vector<double> sw(size_t(p->geo.K - 1));
     const double F0 = 1.0 / p->geo.fft_frame_size_sec;
@@ -293,6 +302,13 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
   const char *fg = getenv("SMILEHIP_FORCE_GENERIC");
   p->force_generic = (fg && fg[0] == '1') ? 1 : 0;
   int rc = build_tables(p);
+  if (rc == SMILEHIP_OK && cfg->chain_kind == SMILEHIP_CHAIN_COMPARE) {      // the 60 ms sub-chain
+    smilehip_lld_config c60;
+    smilehip_config_compare16_f0(&c60);
+    c60.sample_rate = cfg->sample_rate;
+    c60.frame_step_sec = cfg->frame_step_sec;
+    rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
+  }
   if (rc != SMILEHIP_OK) {
     delete p;
     return rc;
@@ -323,6 +339,7 @@ extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 
 int plan_n_static(const smilehip_plan *p) {
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return 2;
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return 65;
   return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc);
 }
 int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }

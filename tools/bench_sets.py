@@ -26,7 +26,7 @@ def main():
     d_pcm = torch.from_numpy(pcm).cuda()
     for name in args.sets.split(","):
         cfg = {"is09": capi.is09_lld_config, "compare": capi.compare16_ab_config, "mfcc": capi.mfcc12_0_d_a_config,
-               "plp": capi.plp_0_d_a_config, "f0": capi.compare16_f0_config}[name]()
+               "plp": capi.plp_0_d_a_config, "f0": capi.compare16_f0_config, "compare_full": capi.compare16_config}[name]()
         plan = capi.Plan(ctx, cfg)
         b = capi.Batch(plan, off)
         n_out = plan.geometry.n_out
