@@ -589,9 +589,9 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
 
 // cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1064) as [is13_pitchJitter] configures it (searchRangeRel 0.25,
 // minNumPeriods 2, minCC 0.5, useBrokenJitterThresh 0, peak amplitudes, lgHNRfloor -100): jitterLocal, jitterDDP,
-// shimmerLocal, logHNR per F0 frame. One wave per utterance, frames in order (the read position in the wave, the
+// shimmerLocal, logHNR per F0 frame. One workgroup per utterance, frames in order (the read position in the wave, the
 // left-over samples and the last period / difference / jitter / shimmer values carry over from frame to frame).
-// Per period step every lane cross-correlates one candidate period length (crossCorr, :331-418: two sequential passes
+// Per period step every thread cross-correlates one candidate period length (crossCorr, :331-418: two sequential passes
 // in double per candidate, the order the reference sums in); the local-maximum search, the amplitude extremes and the
 // averaged period waveform are wave-parallel, the energy sums run in the reference's float order.
 // Time meta of frame t as the framer derives it from a wave level without stored time stamps
@@ -603,13 +603,16 @@ constexpr int kJitMaxPeriod = 448; // T0f + 1 <= 309
 constexpr int kJitMaxPeriods = 160;
 }
 
-__global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
+// kJitThreads: 64 (one wave per utterance: best throughput when the batch fills the device) or 256 (four waves, one
+// candidate per thread: lower latency for small batches; the scalar logic then runs redundantly in every wave)
+template <int kJitThreads>
+__global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
   const int u = blockIdx.x;
   if (u >= P.n_utt) return;
   const int64_t fo = P.frame_off[u];
   const int T = (int)(P.frame_off[u + 1] - fo);
   if (T <= 0) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
   __shared__ float wv[kJitCap];
   __shared__ double ccs[kJitMaxCand];
   __shared__ float avgWf[kJitMaxPeriod];
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, con
                       (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
     if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
       lastIdx += toRead0;
-      if (lane == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
+      if (tid == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
       continue;
     }
     const long nT = toRead;
@@ -661,14 +664,14 @@ __global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, con
     long start = 0, lastPeriod = 0;
     if (F0 > 0.0f) {
       __syncthreads();
-      for (long i = lane; i < nT; i += 64) wv[i] = pcm16_to_float(x[lastIdx + i]);
-      for (long i = lane; i <= T0f; i += 64) avgWf[i] = 0.0f;
+      for (long i = tid; i < nT; i += kJitThreads) wv[i] = pcm16_to_float(x[lastIdx + i]);
+      for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
       __syncthreads();
       int numPeriods = 0;
       long pp = 0;
       const int nc = (int)(T0maxF - T0minF) + 1;
       while (start < nT - 2 * T0maxF - 1) {
-        for (int c = lane; c < nc; c += 64) {                   // crossCorr of [start, start+tf) with [start+tf, start+2tf)
+        for (int c = tid; c < nc; c += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
           const long tf = T0minF + c;
           const float *xa = wv + start, *ya = wv + start + tf;
           double mx = 0.0, my = 0.0;
@@ -719,9 +722,9 @@ __global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, con
           }
           const float a0 = mx0 - mn0, a1 = mx1 - mn1;
           const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
-          if (lane == 0) pbuf[numPeriods] = (int)os;
+          if (tid == 0) pbuf[numPeriods] = (int)os;
           numPeriods++;
-          for (long i = lane; i < T0f; i += 64) avgWf[i] += wv[os + i];
+          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += wv[os + i];
           double ccI = 0.0;
           const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
                                                                  (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
@@ -746,9 +749,9 @@ __global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, con
         if (start < toRead0 - 1) lastPeriod = start;
         __syncthreads();
       }
-      if (lane == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
+      if (tid == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
       numPeriods++;
-      for (long i = lane; i < T0f && start + i < nT; i += 64) {
+      for (long i = tid; i < T0f && start + i < nT; i += kJitThreads) {
         avgWf[i] += wv[start + i];
         avgWf[i] /= (float)numPeriods;
       }
@@ -811,7 +814,7 @@ __global__ void __launch_bounds__(64) lld_f0_jitter(LldParams P, F0Params Q, con
       o2 = lastSh;
     } else o2 = 0.0f;
     if (lgHNR < -100.0f) lgHNR = -100.0f;
-    if (lane == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR; }
+    if (tid == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR; }
   }
 }
 
@@ -930,7 +933,10 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, floa
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s) {
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_f0_jitter, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
+  if (P.n_utt >= 512)
+    hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
+  else
+    hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
