@@ -33,6 +33,24 @@ std::vector<std::string> lld_names_is09() {
   return n;
 }
 
+// ComParE_2016's LLD level (lld;lld_de): F0 group, groups A and B, each smoothed ("_sma"), then their deltas
+std::vector<std::string> lld_names_compare16() {
+  static const char *spectral[15] = {"fband250-650", "fband1000-4000", "spectralRollOff25.0", "spectralRollOff50.0",
+                                     "spectralRollOff75.0", "spectralRollOff90.0", "spectralFlux", "spectralCentroid",
+                                     "spectralEntropy", "spectralVariance", "spectralSkewness", "spectralKurtosis",
+                                     "spectralSlope", "psySharpness", "spectralHarmonicity"};
+  std::vector<std::string> n;
+  for (const char *suffix : {"_sma", "_sma_de"}) {
+    for (const char *f : {"F0final", "voicingFinalUnclipped", "jitterLocal", "jitterDDP", "shimmerLocal", "logHNR",
+                          "audspec_lengthL1norm", "audspecRasta_lengthL1norm", "pcm_RMSenergy", "pcm_zcr"})
+      n.push_back(std::string(f) + suffix);
+    for (int i = 0; i < 26; ++i) n.push_back(arr(std::string("audSpec_Rfilt") + suffix, i));
+    for (const char *f : spectral) n.push_back(std::string("pcm_fftMag_") + f + suffix);
+    for (int i = 1; i <= 14; ++i) n.push_back(arr(std::string("mfcc") + suffix, i));
+  }
+  return n;
+}
+
 std::vector<std::string> func_names_is09() {
   static const char *f[12] = {"max", "min", "range", "maxPos", "minPos", "amean", "linregc1", "linregc2", "linregerrQ",
                               "stddev", "skewness", "kurtosis"};

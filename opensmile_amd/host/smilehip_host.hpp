@@ -32,6 +32,7 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
 std::vector<std::string> lld_names_mfcc12_0_d_a();
 std::vector<std::string> lld_names_plp_0_d_a();
 std::vector<std::string> lld_names_is09();
+std::vector<std::string> lld_names_compare16();
 std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
 
 // cHtkSink (src/iocore/htkSink.cpp:90-105, 183-213): 12-byte big-endian header

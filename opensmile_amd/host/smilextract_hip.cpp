@@ -7,6 +7,8 @@
 //
 //   smilextract_hip --set mfcc12_0_d_a|plp_0_d_a  (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
 //   smilextract_hip --set is09_emotion  (-I in.wav | -filelist list.txt) [-O func.arff] [-csvoutput func.csv]
+//   smilextract_hip --set compare16_lld (-I in.wav | -filelist list.txt) [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
+//                   (the 130-column LLD level of ComParE_2016; its functionals are not built)
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
 //
@@ -64,7 +66,9 @@ int main(int argc, char **argv) {
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
   const bool plp = set == "plp_0_d_a";
-  if (!is09 && !plp && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a, plp_0_d_a or is09_emotion");
+  const bool cmp16 = set == "compare16_lld";
+  if (!is09 && !plp && !cmp16 && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a, plp_0_d_a, is09_emotion or compare16_lld");
+  const bool lld_opts = is09 || cmp16;              // LLD files through -lldhtkoutput / -lldcsvoutput as in the reference
   std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
 
   std::vector<Job> jobs;
@@ -94,7 +98,7 @@ int main(int argc, char **argv) {
   const bool list_mode = opt.count("-filelist") != 0;
   const std::string outdir = opt.count("-outdir") ? opt["-outdir"] : "";
   if (list_mode && outdir.empty() && (opt.count("-lldhtkoutput") || opt.count("-lldcsvoutput") || opt.count("-htkoutput") ||
-                                       (!is09 && (opt.count("-O") || opt.count("-csvoutput")))))
+                                       (!lld_opts && (opt.count("-O") || opt.count("-csvoutput")))))
     die("per-file outputs of a file list need -outdir (the file options then only switch the output on)");
   auto per_file = [&](const Job &j, const std::string &optname, const char *ext) {
     return list_mode ? outdir + "/" + basename_noext(j.wav) + ext : opt[optname];
@@ -104,7 +108,8 @@ int main(int argc, char **argv) {
   check(smilehip_init(opt.count("--device") ? atoi(opt["--device"].c_str()) : 0, &ctx), "smilehip_init");
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
   const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
-  const std::vector<std::string> lld_names = is09 ? lld_names_is09() : (plp ? lld_names_plp_0_d_a() : lld_names_mfcc12_0_d_a());
+  const std::vector<std::string> lld_names =
+      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (plp ? lld_names_plp_0_d_a() : lld_names_mfcc12_0_d_a()));
   const std::vector<std::string> fnames = is09 ? func_names_is09() : std::vector<std::string>();
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
@@ -126,6 +131,7 @@ int main(int argc, char **argv) {
       if (!plan) {
         smilehip_lld_config cfg;
         if (is09) smilehip_config_is09_lld(&cfg);
+        else if (cmp16) smilehip_config_compare16(&cfg);
         else if (plp) smilehip_config_plp_0_d_a(&cfg);
         else smilehip_config_mfcc12_0_d_a(&cfg);
         cfg.sample_rate = (double)kv.first;
@@ -171,16 +177,17 @@ int main(int argc, char **argv) {
         const Job &job = jobs[idx[i]];
         const float *x = lld.data() + (size_t)row_off[i] * n_out;
         const int64_t r = row_off[i + 1] - row_off[i];
-        const std::string lld_htk_opt = is09 ? "-lldhtkoutput" : "-O", lld_csv_opt = is09 ? "-lldcsvoutput" : "-csvoutput";
+        const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
         if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
-          if (!write_htk(per_file(job, lld_htk_opt, is09 ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, 9, err)) die(err);
+          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, 9, err)) die(err);
         if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
           CsvOptions co;
           co.instance_name = job.inst;
-          const int64_t n_frames = smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
+          // rows of the ComParE level follow the 60 ms framer: T60 + 1
+          const int64_t n_frames = cmp16 ? r - 1 : smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
           std::vector<double> times((size_t)r);
           for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
-          if (!write_csv(per_file(job, lld_csv_opt, is09 ? ".lld.csv" : ".csv"), lld_names, x, r, n_out, n_out, g.frame_period,
+          if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_out, n_out, g.frame_period,
                          times.data(), co, err))
             die(err);
         }

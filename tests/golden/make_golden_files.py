@@ -40,6 +40,12 @@ def main():
                         "-csvoutput", os.path.join(td, "p.csv"), "-l", "0"], check=True, cwd=td)
         shutil.copy(os.path.join(td, "p.htk"), os.path.join(out, "plp_u2_8000.htk"))
         shutil.copy(os.path.join(td, "p.csv"), os.path.join(out, "plp_u2_8000.csv"))
+        # ComParE_2016: the 130-column LLD level as CSV + HTK
+        conf = os.path.join(lldo.REF_DIR, "config", "compare16", "ComParE_2016.conf")
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u3.wav"), "-lldcsvoutput", os.path.join(td, "c.csv"),
+                        "-lldhtkoutput", os.path.join(td, "c.htk"), "-instname", "u3", "-l", "0"], check=True, cwd=td)
+        shutil.copy(os.path.join(td, "c.htk"), os.path.join(out, "compare16_lld_u3.htk"))
+        shutil.copy(os.path.join(td, "c.csv"), os.path.join(out, "compare16_lld_u3.csv"))
         # IS09_emotion: two files appended into one ARFF / functionals CSV; LLD CSV + HTK and the
         # functionals HTK of the second one (instance names exercise the ARFF escaping)
         conf = os.path.join(lldo.REF_DIR, "config", "is09-13", "IS09_emotion.conf")

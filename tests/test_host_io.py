@@ -172,6 +172,26 @@ def test_smilextract_hip_is09_filelist(tmp_path):
 
 
 @pytest.mark.gpu
+def test_smilextract_hip_compare16_lld(tmp_path):
+    """The 130-column LLD level of ComParE_2016: header, instance name, row times (the end-of-input row repeats the
+    last frame's time) identical to the reference's files, values within the chain's tolerances."""
+    out_htk, out_csv = str(tmp_path / "c.htk"), str(tmp_path / "c.csv")
+    subprocess.run([EXE, "--set", "compare16_lld", "-I", os.path.join(G, "u3_4000.wav"), "-lldhtkoutput", out_htk,
+                    "-lldcsvoutput", out_csv, "-instname", "u3"], check=True)
+    h, x = read_htk(out_htk)
+    hr, xr = read_htk(os.path.join(G, "compare16_lld_u3.htk"))
+    assert h == hr and x.shape == xr.shape
+    head, names, vals, _ = parse_csv(out_csv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "compare16_lld_u3.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape
+    assert np.array_equal(vals[:, 0], vals_r[:, 0])                     # frameTime column
+    scale = np.maximum(np.abs(xr[:, :65]).max(axis=0), 1e-6)
+    scale = np.concatenate([scale, scale])
+    ok = np.abs(x - xr) <= 1e-4 * scale[None, :]
+    assert ok.mean() >= 0.995
+
+
+@pytest.mark.gpu
 def test_smilextract_hip_errors(tmp_path):
     r = subprocess.run([EXE, "--set", "nope", "-I", "x.wav"], capture_output=True)
     assert r.returncode != 0 and b"--set" in r.stderr
