@@ -189,6 +189,18 @@ void smilehip_config_compare16_f0(smilehip_lld_config *c);
 /* fills c with the whole LLD level of config/compare16/ComParE_2016.conf (chain_kind = COMPARE, 130 columns) */
 void smilehip_config_compare16(smilehip_lld_config *c);
 
+/* F0 group, per component, on an F0 chain plan (smilehip_config_compare16_f0; the plan's spectrum geometry -- n_bins and
+ * the level's frameSizeSec, force_fft_frame_size_sec -- must be the input level's):
+ * cSpecScale::processVector (src/dsp/specScale.cpp:305-357) with scale=octave, sourceScale=lin, interpMethod=spline,
+ * minF=25, maxF=-1, nPointsTarget=0, specSmooth=specEnhance=auditoryWeighting=1: n_bins magnitudes -> n_bins values */
+int smilehip_specscale_frames(smilehip_plan *plan, const float *d_mag, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                              int64_t n_frames, void *stream);
+/* cPitchBase::processVector around cPitchShs::pitchDetect (src/lldcore/pitchBase.cpp:187-310, src/lld/pitchShs.cpp:214-347;
+ * nCandidates=6, scores=voicing=1, F0raw=voicingClip=1, greedyPeakAlgo=1, octaveCorrection=0): n_bins octave-scale values ->
+ * 21 values [nCandidates | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip] */
+int smilehip_pitchshs_frames(smilehip_plan *plan, const float *d_hps, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                             int64_t n_frames, void *stream);
+
 /* F0 chain taps (tests / diagnostics): device pointers to the per-frame scratch the last smilehip_lld_run of this
  * batch filled -- candidates [total_frames x 21] = level is13_pitchShsG60 (nCandidates | F0Cand[6] | candVoicing[6] |
  * candScores[6] | F0raw | voicingClip), energies [total_frames] = level is13_e60 -- and an optional caller-owned

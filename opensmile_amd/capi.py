@@ -67,6 +67,8 @@ SYMBOLS = {
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_f0": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16": (None, [C.POINTER(LldConfig)]),
+    "smilehip_specscale_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_pitchshs_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_batch_f0_taps": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "smilehip_config_plp_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),

@@ -22,6 +22,8 @@
 //                   lane = (state now, state before) pair; then cValbasedSelector's energy gate. 2.6 ms.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "lld_blocks.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
@@ -113,11 +115,15 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
-__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const int16_t *x, int lane, double *A,
-                                              double *B) {
+__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const int16_t *x, const float *mag_in, int lane,
+                                              double *A, double *B) {
   float *re = reinterpret_cast<float *>(A), *im = re + kM;
-  // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168)
   double esum = 0.0;
+  double mg[kPer];
+  if (mag_in) {                                          // per-component mode: cSpecScale on a given magnitude spectrum
+    F0_FOR_BINS(m, k) mg[m] = (k < kK) ? (double)mag_in[k] : 0.0;
+  } else {
+  // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168)
 #pragma unroll
   for (int m = 0; m < kM / 64; ++m) {
     const int i = lane + 64 * m;
@@ -132,10 +138,10 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   esum = WaveG::sum(esum, nullptr);
   WaveG::sync();
   group_cfft_radix2<WaveG>(re, im, kM, T.twh);
-  double mg[kPer];
   F0_FOR_BINS(m, k) {
     mg[m] = 0.0;
     if (k < kK) mg[m] = (double)bin_magnitude(untangle_bin(re, im, kM, k, T.twf), k == 0 || k == kM);
+  }
   }
   F0_FOR_BINS(m, k) if (k < kK) B[k] = mg[m];
   WaveG::sync();
@@ -250,22 +256,28 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // smileMath_csplint + auditory weighting (specScale.cpp:340-353), then cPitchShs::pitchDetect's summation and
 // peak picking (pitchShs.cpp:226-283). Leaves hps | SS (floats) in A, SS as doubles in B, the candidate bins in ci.
 // Returns the number of candidates.
-__device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane, int64_t g, double *A, double *B, int *ci) {
+// hps_in != null: per-component mode, cPitchShs on a given octave-scale spectrum (no interpolation);
+// only_scale: per-component mode, cSpecScale alone (stop after the spectrum has been written to Q.hps_tap)
+__device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane, int64_t g, double *A, double *B, int *ci,
+                                      const float *hps_in, bool only_scale) {
   float *hps = reinterpret_cast<float *>(A), *SS = hps + kKP;
   float hv[kPer];
   F0_FOR_BINS(m, i) {
     hv[m] = 0.0f;
-    if (i < kK) {
+    if (hps_in) {
+      if (i < kK) hv[m] = hps_in[i];
+    } else if (i < kK) {
       const int k = T.k[i];
       const double a = T.a[i], b = 1.0 - a, c = T.c[i], d = T.d[i];
       const double o = a * A[k] + b * A[k + 1] + c * B[k] + d * B[k + 1];
       float v = (float)o;
       v = (v > 0.0f) ? (float)((double)v * T.audw[i]) : 0.0f;
       hv[m] = v;
-      if (Q.hps_tap) Q.hps_tap[g * kK + i] = v;
+      if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = v;
     }
   }
   WaveG::sync();
+  if (only_scale) return 0;
   F0_FOR_BINS(m, i) if (i < kK) hps[i] = hv[m];
   WaveG::sync();
   // SS[j] = (in[j] + sum_h in[j + shift_h] * scale_h) / nHarmonics, terms in harmonic order
@@ -378,12 +390,12 @@ __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64
       tmp = cv[0]; cv[0] = cv[best]; cv[best] = tmp;
       tmp = cs[0]; cs[0] = cs[best]; cs[best] = tmp;
     }
-    float *o = Q.shs + g * 21;
+    float *o = Q.shs + g * Q.ld_shs;
     o[0] = (float)n;
     for (int c = 0; c < kNC; c++) { o[1 + c] = f0c[c]; o[1 + kNC + c] = cv[c]; o[1 + 2 * kNC + c] = cs[c]; }
     o[19] = (cv[0] <= Q.voicing_cutoff) ? 0.0f : f0c[0];
     o[20] = (cv[0] <= Q.voicing_cutoff) ? 0.0f : cv[0];
-    Q.e60[g] = (float)sqrt(esum / (float)Q.N) * 1.0f + 0.0f;
+    if (Q.e60) Q.e60[g] = (float)sqrt(esum / (float)Q.N) * 1.0f + 0.0f;
   }
   WaveG::sync();
 }
@@ -419,30 +431,37 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
   PHASE_DECL
   // persistent waves: work item = up to kTileFrames consecutive frames of one utterance (TileRec), kW at a time
   const int tile_stride = __builtin_amdgcn_readfirstlane((int)gridDim.x) * kWaves;
-  for (int tile = blockIdx.x * kWaves + wave; tile < P.n_tiles; tile += tile_stride) {
-    const int64_t samp0 = P.tile_rec[tile].samp0, row0 = P.tile_rec[tile].row0;
-    const int n_fr = P.tile_rec[tile].n_frames;
+  const int mode = Q.mode;                               // 0 chain, 1 cSpecScale only, 2 cPitchShs only (per-component operators)
+  const int n_tiles = mode ? (int)((Q.n_rows + kTileFrames - 1) / kTileFrames) : P.n_tiles;
+  for (int tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += tile_stride) {
+    int64_t samp0 = 0, row0 = (int64_t)tile * kTileFrames;
+    int n_fr = (int)((Q.n_rows - row0 < kTileFrames) ? Q.n_rows - row0 : kTileFrames);
+    if (!mode) { samp0 = P.tile_rec[tile].samp0; row0 = P.tile_rec[tile].row0; n_fr = P.tile_rec[tile].n_frames; }
     for (int tf = 0; tf < n_fr; tf += kW) {
       const int n_act = (n_fr - tf < kW) ? n_fr - tf : kW;
 #pragma unroll 1
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
-        const double es = f0_spectrum(T, Q, P.pcm + samp0 + (int64_t)(tf + w) * Q.H, lane, A, A + kKP);
+        if (mode == 2) break;
+        const double es = f0_spectrum(T, Q, P.pcm + samp0 + (int64_t)(tf + w) * Q.H,
+                                      mode == 1 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr, lane, A, A + kKP);
         if (lane == 0) *reinterpret_cast<double *>(reinterpret_cast<int *>(A + 2 * kKP) + 8 + 24) = es;
       }
       PHASE(0);   // load .. 6*ut
-      if (lane < n_act) f0_spline_serial(T, reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
+      if (lane < n_act && mode != 2) f0_spline_serial(T, reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
       WaveG::sync();
       PHASE(1);   // recurrences
 #pragma unroll 1
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         int *ci = reinterpret_cast<int *>(A + 2 * kKP);
-        const int nf = f0_shs(T, Q, lane, row0 + tf + w, A, A + kKP, ci);
+        const int nf = f0_shs(T, Q, lane, row0 + tf + w, A, A + kKP, ci, mode == 2 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr,
+                              mode == 1);
         if (lane == 0) ci[7] = nf;
       }
       WaveG::sync();
       PHASE(2);   // interpolation, summation, top six
+      if (mode == 1) continue;
       double mean = 0.0;
       if (lane < n_act) mean = f0_mean_serial(reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
       PHASE(3);   // mean
@@ -928,6 +947,24 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, floa
   return hipGetLastError();
 }
 
+
+// per-component operators on n_rows rows: mode 1 = cSpecScale (magnitudes -> Q.hps_tap), mode 2 = cPitchShs (octave-scale
+// spectra -> Q.shs, 21 values per row)
+hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
+  if (Q.n_rows <= 0) return hipSuccess;
+  if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17 || (Q.mode != 1 && Q.mode != 2)) return hipErrorInvalidValue;
+  const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
+  const void *fn = reinterpret_cast<const void *>(&lld_f0_frame);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int64_t tiles = (Q.n_rows + kTileFrames - 1) / kTileFrames;
+  unsigned grid = (unsigned)((tiles + kWaves - 1) / kWaves);
+  if (grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;
+  LldParams P;
+  std::memset(&P, 0, sizeof(P));
+  hipLaunchKernelGGL(lld_f0_frame, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  return hipGetLastError();
+}
 
 // jitter / shimmer / HNR from the wave and the F0 contour (pitch2, T60 x 2), then the F0 group's 12 LLD columns
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,

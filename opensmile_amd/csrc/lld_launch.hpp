@@ -32,6 +32,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
 int compare_run_frames();
 hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s);
 int f0_tile_frames();
+hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);

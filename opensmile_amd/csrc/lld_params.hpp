@@ -132,6 +132,11 @@ struct F0Params {
   float *shs;                       // [total_frames x 21] nCand | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip
   float *e60;                       // [total_frames] RMS energy of the windowed frame
   float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
+  // per-component operators (mode 1: cSpecScale rows -> hps_tap, mode 2: cPitchShs rows -> shs)
+  int32_t mode;
+  int64_t n_rows;
+  const float *in_rows;
+  int64_t ld_in, ld_tap, ld_shs;
   int32_t *pending;                 // optional [n_utt]: frames the Viterbi pass had not decided at the end of input
 };
 

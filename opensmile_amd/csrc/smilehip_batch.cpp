@@ -430,6 +430,8 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.min_energy = plan->cfg.f0_min_energy;
   Q.jit_Tw = plan->geo.period;                 // 1.0 / (double)sampleRate, waveSource.cpp:190
   Q.jit_step_sec = plan->cfg.frame_step_sec;
+  Q.ld_tap = plan->geo.K;
+  Q.ld_shs = 21;
   // [is13_pitchSmoothViterbi]: wLocal 2, wTvv 10, wTvvd 5, wTvuv 10, wThr 4, wRange 1 -- but
   // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd (pitchSmootherViterbi.hpp:291-299): 10
   Q.vit_w[0] = 2.0; Q.vit_w[1] = 10.0; Q.vit_w[2] = 10.0; Q.vit_w[3] = 10.0; Q.vit_w[4] = 4.0; Q.vit_w[5] = 1.0;

@@ -182,3 +182,32 @@ extern "C" int smilehip_mfcc_frames(smilehip_plan *p, const float *d_src, int64_
   STAGE_RET(stage_mfcc(d_src, ld_src, d_dst, ld_dst, n_frames, p->mel.n_bands, p->dct.n_mfcc, p->d_dct_rows.p,
                        p->d_dct_gain.p, p->dct.melfloor, p->dct.log_floor, (hipStream_t)stream), "mfcc");
 }
+
+// ---------------------------------------------- F0 group, per-component
+static int f0_rows(smilehip_plan *p, int mode, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_frames,
+                   void *stream, const char *fn) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "%s: null plan", fn);
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (p->cfg.chain_kind != SMILEHIP_CHAIN_COMPARE_F0) return fail(SMILEHIP_ERR_INVALID, "%s: plan is not an F0 chain plan", fn);
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, mode == 1 ? p->geo.K : 21, fn);
+  if (rc || n_frames == 0) return rc;
+  F0Params Q;
+  fill_f0_params(p, Q);
+  Q.mode = mode;
+  Q.n_rows = n_frames;
+  Q.in_rows = d_src;
+  Q.ld_in = ld_src;
+  if (mode == 1) { Q.hps_tap = d_dst; Q.ld_tap = ld_dst; }
+  else { Q.shs = d_dst; Q.ld_shs = ld_dst; }
+  STAGE_RET(launch_f0_rows(Q, p->ctx->prop.multiProcessorCount, (hipStream_t)stream), fn);
+}
+
+extern "C" int smilehip_specscale_frames(smilehip_plan *p, const float *d_mag, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                         int64_t n_frames, void *stream) {
+  return f0_rows(p, 1, d_mag, ld_src, d_dst, ld_dst, n_frames, stream, "smilehip_specscale_frames");
+}
+
+extern "C" int smilehip_pitchshs_frames(smilehip_plan *p, const float *d_hps, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                        int64_t n_frames, void *stream) {
+  return f0_rows(p, 2, d_hps, ld_src, d_dst, ld_dst, n_frames, stream, "smilehip_pitchshs_frames");
+}

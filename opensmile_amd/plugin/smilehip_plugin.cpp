@@ -5,7 +5,7 @@
 // which calls the C symbol registerPluginComponent below. The components it
 // returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
 // cTransformFFT, cFFTmagphase, cMelspec, cMfcc, cEnergy, cMZcr, cAcf, cPitchACF,
-// cDeltaRegression, cContourSmoother, cSpectral, cPlp, cFunctionals), so their factories replace the
+// cDeltaRegression, cContourSmoother, cSpectral, cPlp, cFunctionals, cSpecScale, cPitchShs), so their factories replace the
 // built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
 // every existing option -- stay (configManager.cpp:2818-2827): unmodified
 // config files run through the HIP kernels.
@@ -20,6 +20,7 @@
 // (ABI-coupled to libopensmile.so); it contains no HIP code.
 #include <core/componentManager.hpp>
 #include <core/smileCommon.hpp>
+#include <dsp/specScale.hpp>
 #include <dspcore/acf.hpp>
 #include <dspcore/contourSmoother.hpp>
 #include <dspcore/deltaRegression.hpp>
@@ -28,6 +29,7 @@
 #include <dspcore/vectorPreemphasis.hpp>
 #include <dspcore/windower.hpp>
 #include <functionals/functionals.hpp>
+#include <lld/pitchShs.hpp>
 #include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
@@ -51,10 +53,11 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 15;
+constexpr int kNumOverrides = 17;
 long g_frames[kNumOverrides] = {0};
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
-                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals"};
+                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
+                                            "cPitchShs"};
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -853,6 +856,104 @@ class cHipFunctionals : public cFunctionals {
   }
 };
 
+// SURVEY 8(f) rank 2, per component. An F0-chain plan carries cSpecScale's spline / weighting tables and cPitchShs'
+// shifts for one spectrum geometry (bins, frameSizeSec of the magnitude level).
+static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double min_pitch, double max_pitch, double cutoff,
+                                        int n_harm, double compression) {
+  smilehip_lld_config c;
+  smilehip_config_compare16_f0(&c);
+  c.force_fft_frame_size_sec = frame_size_sec;
+  c.pitch_min = min_pitch;
+  c.pitch_max = max_pitch;
+  c.voicing_cutoff = cutoff;
+  c.shs_n_harmonics = n_harm;
+  c.shs_compression = (float)compression;
+  smilehip_plan *pl = nullptr;
+  check(smilehip_plan_create(context(), &c, &pl));
+  smilehip_geometry g;
+  check(smilehip_plan_geometry(pl, &g));
+  if (g.n_bins != K) {                                   // the kernels cover the 1024-point spectrum of 60 ms / 16 kHz frames
+    smilehip_plan_destroy(pl);
+    return nullptr;
+  }
+  return pl;
+}
+
+// cSpecScale::processVector (src/dsp/specScale.cpp:305-357) for the option set the F0 chains use (octave target scale,
+// spline interpolation, minF 25, maxF -1, nPointsTarget 0, smoothing + enhancement + auditory weighting); anything else
+// stays on the reference's CPU code. Names, frequency-axis info and the level meta data cPitchShs reads are inherited.
+class cHipSpecScale : public cSpecScale {
+  FrameIO io_;
+  smilehip_plan *pl_ = nullptr;
+  int usable_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      const char *sc = getStr("scale"), *ss = getStr("sourceScale"), *im = getStr("interpMethod");
+      usable_ = sc && !strncasecmp(sc, "oct", 3) && ss && !strncasecmp(ss, "lin", 3) && im && !strncasecmp(im, "spl", 3) &&
+                getDouble("minF") == 25.0 && getDouble("maxF") == -1.0 && getInt("nPointsTarget") <= 0 && getInt("specSmooth") == 1 &&
+                getInt("specEnhance") == 1 && getInt("auditoryWeighting") == 1 && Nsrc == Ndst;
+      if (usable_) {
+        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, 52.0, 620.0, 0.7, 15, 0.85);
+        if (!pl_) usable_ = 0;
+      }
+    }
+    if (!usable_) return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi);
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[15]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipSpecScale(const char *n) : cSpecScale(n) {}
+  ~cHipSpecScale() override { if (pl_) smilehip_plan_destroy(pl_); }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipSpecScale(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cPitchBase::processVector around cPitchShs::pitchDetect (src/lldcore/pitchBase.cpp:187-310, src/lld/pitchShs.cpp:214-347)
+// for six candidates with scores + voicing, F0raw + voicingClip, greedyPeakAlgo, no octave correction / lfCut / SHS dump.
+class cHipPitchShs : public cPitchShs {
+  FrameIO io_;
+  smilehip_plan *pl_ = nullptr;
+  int usable_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      usable_ = getInt("nCandidates") == 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&
+                getInt("voicingC1") == 0 && getInt("F0raw") == 1 && getInt("voicingClip") == 1 && getInt("octaveCorrection") == 0 &&
+                getInt("greedyPeakAlgo") == 1 && getInt("shsSpectrumOutput") == 0 && getDouble("lfCut") <= 0.0 && Ndst == 21 &&
+                reader_->getLevelNf() == 1;
+      if (usable_) {
+        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, getDouble("minPitch"),
+                                getDouble("maxPitch"), (double)(float)getDouble("voicingCutoff"), getInt("nHarmonics"),
+                                (double)(float)getDouble("compressionFactor"));
+        if (!pl_) usable_ = 0;
+      }
+    }
+    if (!usable_) return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi);
+    io_.ensure(Nsrc, 21);
+    io_.up(src, Nsrc);
+    check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, 1, nullptr));
+    io_.down(dst, 21);
+    g_frames[16]++;
+    return 21;
+  }
+ public:
+  explicit cHipPitchShs(const char *n) : cPitchShs(n) {}
+  ~cHipPitchShs() override { if (pl_) smilehip_plan_destroy(pl_); }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchShs(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
 // component with the number of frames it pushed through the HIP kernels
 struct TraceAtExit {
@@ -886,8 +987,10 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all fifteen
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all seventeen
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cPitchShs")) head = override_of(&cPitchShs::registerComponent, &cHipPitchShs::create, confman, compman, iteration, head);
+  if (want("cSpecScale")) head = override_of(&cSpecScale::registerComponent, &cHipSpecScale::create, confman, compman, iteration, head);
   if (want("cFunctionals")) head = override_of(&cFunctionals::registerComponent, &cHipFunctionals::create, confman, compman, iteration, head);
   if (want("cPlp")) head = override_of(&cPlp::registerComponent, &cHipPlp::create, confman, compman, iteration, head);
   if (want("cSpectral")) head = override_of(&cSpectral::registerComponent, &cHipSpectral::create, confman, compman, iteration, head);

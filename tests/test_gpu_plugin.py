@@ -140,12 +140,33 @@ def test_plugin_compare_spectral_and_plp(oracle, golden_compare):
         compare_tolerances(y, ref, k)
 
 
+def test_plugin_compare_f0_components(oracle, golden_f0):
+    """ComParE_2016.conf, unmodified: cSpecScale and cPitchShs behind the reference's operator API. Their input is the
+    binary's own magnitude spectrum and everything after it (Viterbi smoother, jitter, smoothing, deltas) is the
+    binary's code, so the F0 group's 12 LLD columns must come out (almost) bit-identical: the one libm call on the
+    device path is exp() of the refined candidate frequency."""
+    for k in ("u2_16000", "u4_9000"):
+        ref = golden_f0["lld130_" + k]
+        y, tr = _run(oracle, golden_f0["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cSpecScale,cPitchShs"}, COMPARE, "-lldhtkoutput")
+        assert y.shape == ref.shape
+        T60 = ref.shape[0] - 1
+        assert tr["cSpecScale"] == T60 and tr["cPitchShs"] == T60 and tr["cMelspec"] == 0
+        cols = list(range(0, 6)) + list(range(65, 71))
+        same = (y[:, cols].view(np.uint32) == ref[:, cols].view(np.uint32)).all(axis=1)
+        assert same.mean() >= 0.97, f"{k}: {int((~same).sum())} of {len(same)} rows differ"
+        scale = np.maximum(np.abs(ref[:, :6]).max(axis=0), 1e-6)
+        assert (np.abs(y[:, cols] - ref[:, cols]) / np.concatenate([scale, scale])).max() <= 1e-4, k
+        # everything else is untouched reference code
+        rest = [c for c in range(130) if c not in cols]
+        assert np.array_equal(y[:, rest].view(np.uint32), ref[:, rest].view(np.uint32))
+
+
 def test_plugin_compare_all_overrides(oracle, golden_compare):
     from test_oracle_pin_compare import compare_tolerances
     ref = golden_compare["out_u3_16000"]
     y, tr = _run(oracle, golden_compare["pcm_u3_16000"], None, COMPARE, "-lldhtkoutput")
     for comp in ("cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cEnergy", "cMZcr", "cSpectral", "cPlp",
-                 "cDeltaRegression", "cContourSmoother"):
+                 "cDeltaRegression", "cContourSmoother", "cSpecScale", "cPitchShs"):
         assert tr.get(comp, 0) > 0, f"{comp} not routed through the plugin: {tr}"
     compare_tolerances(_ab(y), ref, "plugin compare all")
 

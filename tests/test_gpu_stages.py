@@ -246,3 +246,77 @@ def test_energy_zcr_acf_pitch_window_ops(oracle):
     sma += row[W + 1:W + 1 + nT]
     assert np.array_equal(y, sma / np.float32(3.0))
     assert L.smilehip_window_op_row(ctx._h, d_r, d_y, nT, 2, 1, None) != 0       # unknown kind
+
+
+def test_specscale_and_pitchshs_operators_bit_exact(oracle):
+    """cSpecScale and cPitchShs as per-component operators on GIVEN inputs: everything after the FFT is ordered double /
+    float arithmetic, so the device must reproduce the oracle bit for bit (rows: speech-like spectra, silence, a single
+    peak, one with exactly one local maximum -- the reference's zero-initialised-list quirk)."""
+    import ctypes as C
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    L = capi.load()
+    OL = oracle.lib()
+    plan = capi.Plan(ctx, capi.compare16_f0_config())
+    K = plan.geometry.n_bins
+    assert K == 513
+    # magnitude spectra of real frames (through the oracle's own front end) + special rows
+    pcm = np.concatenate([synth.utterance(u, 8000) for u in (2, 3, 4, 10)])
+    _, taps = oracle.compare_f0_chain(pcm, taps=True)
+    rng = np.random.default_rng(5)
+    mag = np.abs(rng.standard_normal((40, K))).astype(np.float32)
+    t = np.arange(K)
+    mag += (3.0 * (1 + np.cos(2 * np.pi * t / 13.0))).astype(np.float32)
+    mag[0] = 0.0
+    mag[1] = 0.0
+    mag[1, 77] = 5.0
+    mag[2] = np.linspace(1.0, 0.0, K, dtype=np.float32)          # exactly one local maximum (bin 0)
+    mag[3] = np.float32(1.0)                                       # flat: no maximum at all
+
+    class SS(C.Structure):
+        _fields_ = [("K", C.c_long), ("ft", C.c_void_p), ("sigma", C.c_void_p), ("d1", C.c_void_p), ("d2", C.c_void_p),
+                    ("k", C.c_void_p), ("co", C.c_void_p), ("audw", C.c_void_p), ("meta", C.c_float * 8)]
+
+    class SH(C.Structure):
+        _fields_ = [("N", C.c_long), ("n_octaves", C.c_float), ("points_per_octave", C.c_float), ("Fmint", C.c_float),
+                    ("Fstept", C.c_float), ("base", C.c_double), ("n_harmonics", C.c_int), ("compression", C.c_float),
+                    ("n_cand", C.c_int), ("min_pitch", C.c_double), ("max_pitch", C.c_double), ("voicing_cutoff", C.c_float)]
+    ss, sh = SS(), SH()
+    OL.lldo_specscale_init.restype = C.c_int
+    OL.lldo_specscale_init.argtypes = [C.c_void_p, C.c_long, C.c_double]
+    assert OL.lldo_specscale_init(C.byref(ss), K, plan.geometry.fft_frame_size_sec) == 1
+    OL.lldo_shs_init.restype = None
+    OL.lldo_shs_init.argtypes = [C.c_void_p, C.c_void_p]
+    OL.lldo_shs_init(C.byref(sh), C.byref(ss))
+    OL.lldo_specscale_frame.restype = None
+    OL.lldo_specscale_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    OL.lldo_pitch_shs.restype = None
+    OL.lldo_pitch_shs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    nF = mag.shape[0]
+    ref_h = np.zeros((nF, K), np.float32)
+    for f in range(nF):
+        OL.lldo_specscale_frame(C.byref(ss), mag[f].ctypes.data, ref_h[f].ctypes.data)
+    d_m = _dev(capi, ctx, mag)
+    d_h = _dev(capi, ctx, np.zeros((nF, K), np.float32))
+    assert L.smilehip_specscale_frames(plan._h, d_m, K, d_h, K, nF, None) == 0
+    h = _host(capi, ctx, d_h, (nF, K), np.float32)
+    assert np.array_equal(h.view(np.uint32), ref_h.view(np.uint32)), f"rows {sorted(set(np.argwhere(h != ref_h)[:, 0]))}"
+    # cPitchShs on octave-scale spectra: the oracle's own level of real frames + the rows above
+    hps = np.concatenate([taps["hps"], ref_h], axis=0)
+    nH = hps.shape[0]
+    ref_s = np.zeros((nH, 21), np.float32)
+    for f in range(nH):
+        OL.lldo_pitch_shs(C.byref(sh), hps[f].ctypes.data, ref_s[f].ctypes.data, None)
+    d_hp = _dev(capi, ctx, hps)
+    d_s = _dev(capi, ctx, np.zeros((nH, 21), np.float32))
+    assert L.smilehip_pitchshs_frames(plan._h, d_hp, K, d_s, 21, nH, None) == 0
+    s = _host(capi, ctx, d_s, (nH, 21), np.float32)
+    same = (s.view(np.uint32) == ref_s.view(np.uint32)).all(axis=1)
+    # exp() of the refined log2 frequency is the one libm call on the path (device vs glibc: <= 1 ulp in double,
+    # visible after rounding to float on rare rows)
+    assert same.mean() >= 0.99, f"{int((~same).sum())} of {nH} rows differ"
+    assert np.abs(s - ref_s).max() <= 1e-6 * max(np.abs(ref_s).max(), 1.0)
+    # error paths
+    assert L.smilehip_specscale_frames(plan._h, d_m, K - 1, d_h, K, nF, None) != 0
+    mf = capi.Plan(ctx, capi.mfcc12_0_d_a_config())
+    assert L.smilehip_pitchshs_frames(mf._h, d_hp, K, d_s, 21, nH, None) != 0
