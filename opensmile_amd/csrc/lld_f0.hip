@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   const int T = (int)(P.frame_off[u + 1] - fo);
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
-  __shared__ float wv[kJitCap];
+  __shared__ double wv[kJitCap];          // the frame's wave samples, widened once (crossCorr works in double)
   __shared__ double ccs[kJitMaxCand];
   __shared__ float avgWf[kJitMaxPeriod];
   __shared__ int pbuf[kJitMaxPeriods];
@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   const double Tw = Q.jit_Tw;
   const int N = Q.N, H = Q.H;
   const long ppLen = (long)ceil(Q.jit_step_sec / Tw);
+  PHASE_DECL
   long lastIdx = 0, lastMis = 0;
   float lastT0 = 0.0f, lastDiff = 0.0f, lastJL = 0.0f, lastJD = 0.0f, lastSh = 0.0f;
   for (int t = 0; t < T; ++t) {
@@ -670,7 +671,8 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       if (maxRead > lenF) maxRead = lenF;
     }
     float *o = out4 + (fo + t) * 4;
-    const bool fits = toRead <= kJitCap && (T0maxF - T0minF + 1) <= kJitMaxCand && T0f + 1 <= kJitMaxPeriod &&
+    const bool fits = toRead + 16 <= kJitCap &&        // (+16: the sample loops read ahead by up to two rounds)
+                      (T0maxF - T0minF + 1) <= kJitMaxCand && T0f + 1 <= kJitMaxPeriod &&
                       (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
     if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
       lastIdx += toRead0;
@@ -683,31 +685,72 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     long start = 0, lastPeriod = 0;
     if (F0 > 0.0f) {
       __syncthreads();
-      for (long i = tid; i < nT; i += kJitThreads) wv[i] = pcm16_to_float(x[lastIdx + i]);
+      for (long i = tid; i < nT; i += kJitThreads) wv[i] = (double)pcm16_to_float(x[lastIdx + i]);
       for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
       __syncthreads();
+      PHASE(5);   // frame set-up + wave load
       int numPeriods = 0;
       long pp = 0;
       const int nc = (int)(T0maxF - T0minF) + 1;
       while (start < nT - 2 * T0maxF - 1) {
         for (int c = tid; c < nc; c += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
           const long tf = T0minF + c;
-          const float *xa = wv + start, *ya = wv + start + tf;
+          const double *xa = wv + start, *ya = wv + start + tf;
+          // both passes in rounds of eight samples, the next round's samples loaded before the current round's sums
+          // (the sums stay sequential in the reference's order)
+          const long nr = tf >> 3;
           double mx = 0.0, my = 0.0;
-          for (long i = 0; i < tf; i++) { mx += xa[i]; my += ya[i]; }
+          {
+            double xv[8], yv[8], xn[8], yn[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }      // (reads past tf stay inside wv: start + 2 tf < nT)
+            for (long r = 0; r < nr; ++r) {
+              const long i1 = (r + 1) << 3;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { mx += xv[q]; my += yv[q]; }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if ((nr << 3) + q < tf) { mx += xv[q]; my += yv[q]; }
+          }
           mx /= (double)tf;
           my /= (double)tf;
           double cc = 0.0, nx = 0.0, ny = 0.0;
-          for (long i = 0; i < tf; i++) {
-            const double dx = xa[i] - mx, dy = ya[i] - my;
-            cc += dx * dy;
-            nx += dx * dx;
-            ny += dy * dy;
+          {
+            double xv[8], yv[8], xn[8], yn[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
+            for (long r = 0; r < nr; ++r) {
+              const long i1 = (r + 1) << 3;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const double dx = xv[q] - mx, dy = yv[q] - my;
+                cc += dx * dy;
+                nx += dx * dx;
+                ny += dy * dy;
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if ((nr << 3) + q < tf) {
+                const double dx = xv[q] - mx, dy = yv[q] - my;
+                cc += dx * dy;
+                nx += dx * dx;
+                ny += dy * dy;
+              }
           }
           cc /= sqrt(nx) * sqrt(ny);
           ccs[c] = cc;
         }
         __syncthreads();
+        PHASE(6);   // cross-correlations
         // the greatest local maximum of cc[1 .. nc-3], the first one among equals (:734-747)
         double bv = 0.0;
         int bi = 1 << 30;
@@ -726,9 +769,9 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         if (maxI >= 0) {
           start += pp;
           // amplitudeDiff (:422-459): max - min of x[1 .. pp-2] in both periods
-          float mx0 = wv[os + 1], mn0 = mx0, mx1 = wv[start + 1], mn1 = mx1;
+          float mx0 = (float)wv[os + 1], mn0 = mx0, mx1 = (float)wv[start + 1], mn1 = mx1;
           for (long i = 1 + lane; i < pp - 1; i += 64) {
-            const float a = wv[os + i], b = wv[start + i];
+            const float a = (float)wv[os + i], b = (float)wv[start + i];
             mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
             mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
           }
@@ -743,7 +786,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
           if (tid == 0) pbuf[numPeriods] = (int)os;
           numPeriods++;
-          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += wv[os + i];
+          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += (float)wv[os + i];
           double ccI = 0.0;
           const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
                                                                  (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
@@ -767,18 +810,30 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         }
         if (start < toRead0 - 1) lastPeriod = start;
         __syncthreads();
+        PHASE(7);   // peak, amplitudes, averaged waveform, jitter sums
       }
       if (tid == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
       numPeriods++;
       for (long i = tid; i < T0f && start + i < nT; i += kJitThreads) {
-        avgWf[i] += wv[start + i];
+        avgWf[i] += (float)wv[start + i];
         avgWf[i] /= (float)numPeriods;
       }
       __syncthreads();
       // harmonic / noise energy in the reference's summation order (:843-873), every lane the same chain
       float Eh = 0.0f;
-      for (long i = 0; i < T0f && start + i < nT; i++)
-        if (i > 2 && i < T0f - 2) Eh += avgWf[i] * avgWf[i];
+      {
+        long hi = T0f - 2;                                  // i in [3, min(T0f-2, nT-start)): the reference's three conditions
+        if (nT - start < hi) hi = nT - start;
+        long i = 3;
+        for (; i + 8 <= hi; i += 8) {
+          float aq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) aq[q] = avgWf[i + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) Eh += aq[q] * aq[q];
+        }
+        for (; i < hi; i++) Eh += avgWf[i] * avgWf[i];
+      }
       if (T0f - 4 > 0) Eh /= (float)(T0f - 4);
       Eh = sqrtf(Eh);
       float En = 0.0f;
@@ -787,8 +842,17 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         long k = 2;
         const long p0 = pbuf[i], p1 = pbuf[i + 1];
         const long lim = (p1 < p0 + T0f ? p1 : p0 + T0f) - 2;
-        for (long j = p0 + 2; j < lim; j++) {
-          const float delta = wv[j] - avgWf[k++];
+        long j = p0 + 2;
+        for (; j + 8 <= lim; j += 8, k += 8) {
+          float wq[8], aq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { wq[q] = (float)wv[j + q]; aq[q] = avgWf[k + q]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const float delta = wq[q] - aq[q]; En += delta * delta; }
+          nEn += 8;
+        }
+        for (; j < lim; j++) {
+          const float delta = (float)wv[j] - avgWf[k++];
           En += delta * delta;
           nEn++;
         }
@@ -801,6 +865,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         else lgHNR = -100.0f;
       }
       lastMis = toRead0 - lastPeriod;
+      PHASE(8);   // harmonic / noise energies
     } else {
       lastPeriod = toRead0;
       lastMis = 0;
@@ -834,7 +899,9 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     } else o2 = 0.0f;
     if (lgHNR < -100.0f) lgHNR = -100.0f;
     if (tid == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR; }
+    PHASE(9);   // output
   }
+  PHASE_FLUSH;
 }
 
 // [is13_smoNz] + [is13_deNz]: the F0 group's columns of the LLD level, T60+1 rows per utterance:

@@ -460,8 +460,13 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   if (ld_out < 130) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 130", (long long)ld_out);
   if (b->total_rows == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
-  int rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, stream, 65);
+  // the two groups share nothing but the PCM: groups A+B on the plan's side stream, the F0 group on the caller's
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipEventRecord(plan->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
+  int rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, plan->side_stream, 65);
   if (rc) return rc;
+  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
   smilehip_batch *fb = b->f0_batch;
   if ((rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream))) return rc;
   LldParams P;
@@ -471,6 +476,7 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   Q.pending = fb->d_pending.p;
   hipError_t e = launch_f0_lld(P, Q, b->d_row_off.p, b->d_pitch2.p, b->d_jit4.p, d_out, ld_out, 0, 65, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 LLD kernel launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
   return SMILEHIP_OK;
 }
 

@@ -79,6 +79,8 @@ struct smilehip_plan {
   DevBuf<double> d_sharp;
   // F0 group (SMILEHIP_CHAIN_COMPARE_F0); the whole-level chain (SMILEHIP_CHAIN_COMPARE) owns a second plan for it
   smilehip_plan *f0_plan = nullptr;
+  hipStream_t side_stream = nullptr;      // whole-level chain: groups A+B run here, concurrently with the F0 group
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   F0Host f0;
   DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
   DevBuf<int32_t> d_f0_k;
@@ -95,6 +97,9 @@ struct smilehip_plan {
   uint32_t stage_mask = SMILEHIP_STAGE_ALL;
   ~smilehip_plan() {
     delete f0_plan;
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto &slot : ev)
       for (auto &e : slot)
         if (e) (void)hipEventDestroy(e);

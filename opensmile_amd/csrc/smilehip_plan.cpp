@@ -308,6 +308,10 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
     c60.sample_rate = cfg->sample_rate;
     c60.frame_step_sec = cfg->frame_step_sec;
     rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
+    if (rc == SMILEHIP_OK && (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
+      rc = fail(SMILEHIP_ERR_HIP, "could not create the side stream of the ComParE chain");
   }
   if (rc != SMILEHIP_OK) {
     delete p;
