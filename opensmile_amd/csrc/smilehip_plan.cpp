@@ -131,9 +131,14 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     p->dct.n_mfcc = p->cfg.plp_lp_order + 1;            // outputs of the chain's static block
     p->dct.melfloor = 1.0f;                              // htkcompatible forces melfloor = 1.0 (plp.cpp:150-160)
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
-    if (mask != SMILEHIP_STAGE_ALL || p->cfg.preemph || p->cfg.n_delta != 0 || p->geo.Nfft < 128 || p->geo.Nfft > 4096 ||
-        p->cfg.win_offset != 0.0)
-      return fail(SMILEHIP_ERR_INVALID, "F0 chain: no pre-emphasis / deltas / window offset, FFT length 128..4096");
+    if (mask != SMILEHIP_STAGE_ALL || p->cfg.preemph || p->cfg.n_delta != 0 || p->cfg.win_offset != 0.0)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: no pre-emphasis / deltas / window offset");
+    if (p->geo.Nfft != 1024)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: the kernels are built for the 1024-point spectrum of 60 ms frames at 16 kHz "
+                  "(this configuration gives %lld points)", (long long)p->geo.Nfft);
+    if (p->cfg.shs_n_harmonics < 1 || p->cfg.shs_n_harmonics > 17 || !(p->cfg.pitch_max > p->cfg.pitch_min) || p->cfg.pitch_min < 40.0)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: nHarmonics 1..17, minPitch >= 40 Hz (period search window of the jitter kernel), "
+                  "maxPitch > minPitch");
     if ((rc = make_f0_tables(p->geo.K, p->geo.fft_frame_size_sec, p->cfg.shs_n_harmonics, p->cfg.shs_compression, p->f0)))
       return fail(rc, "F0 chain: spectrum geometry / nHarmonics not usable by cSpecScale / cPitchShs");
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {

@@ -25,16 +25,18 @@ def test_no_device_memory_leak_over_plan_and_batch_cycles():
         plan.close()
         return out
 
-    for fn in (capi.mfcc12_0_d_a_config, capi.plp_0_d_a_config, capi.is09_lld_config, capi.compare16_ab_config):
+    for fn in (capi.mfcc12_0_d_a_config, capi.plp_0_d_a_config, capi.is09_lld_config, capi.compare16_ab_config,
+               capi.compare16_f0_config, capi.compare16_config):
         cycle(fn)                                        # warm allocator pools
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
     for _ in range(40):
-        for fn in (capi.mfcc12_0_d_a_config, capi.plp_0_d_a_config, capi.is09_lld_config, capi.compare16_ab_config):
+        for fn in (capi.mfcc12_0_d_a_config, capi.plp_0_d_a_config, capi.is09_lld_config, capi.compare16_ab_config,
+                   capi.compare16_f0_config, capi.compare16_config):
             cycle(fn)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 8 * 2 ** 20, f"device memory shrank by {(free0 - free1) / 2 ** 20:.1f} MiB over 160 cycles"
+    assert free0 - free1 < 8 * 2 ** 20, f"device memory shrank by {(free0 - free1) / 2 ** 20:.1f} MiB over 240 cycles"
 
 
 def test_two_batches_on_two_streams_match_serial_results():
@@ -75,6 +77,14 @@ def test_error_paths_fail_loudly():
         capi.Plan(ctx, cfg)
     cfg = capi.is09_lld_config()
     cfg.sma_win = 4                                      # even smaWin is not a cContourSmoother window
+    with pytest.raises(capi.SmileHipError):
+        capi.Plan(ctx, cfg)
+    cfg = capi.compare16_f0_config()
+    cfg.sample_rate = 44100.0                            # 60 ms -> 4096-point spectrum: the F0 kernels are not built for it
+    with pytest.raises(capi.SmileHipError, match="1024-point"):
+        capi.Plan(ctx, cfg)
+    cfg = capi.compare16_config()
+    cfg.sample_rate = 44100.0                            # (the 20 ms part refuses first: 1024 instead of 512 points)
     with pytest.raises(capi.SmileHipError):
         capi.Plan(ctx, cfg)
     plan = capi.Plan(ctx)
