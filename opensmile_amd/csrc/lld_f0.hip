@@ -207,49 +207,67 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   return esum;
 }
 
-// the spline's two recurrences for this lane's frame, eight steps per round; the next round's operands are loaded
-// before the current round's dependent chain runs (the loads are off the chain)
+// the spline's two recurrences for this lane's frame, eight steps per round. Two operand sets alternate: while one
+// round's dependent chain runs on set A the next round's operands are already being loaded into set B (no copies).
+// A round is 12 LDS instructions: the outstanding-load counter (lgkmcnt, 4 bits) can then still tell the two sets apart;
+// the scheduling barriers keep the compiler from sinking the prefetch below the chain it is meant to overlap.
 __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
   constexpr int R = 8;
   constexpr int nfw = (kK - 2) / R;                      // full rounds of the forward sweep (bins 1 .. kK-2)
   double up = 0.0;
-  double cc[R], nc[R];
-  double2 sp[R], ns[R];
+  double ca[R], cb[R];
+  double2 sa[R], sb[R];
+  auto fw_load = [&](double (&c)[R], double2 (&sp)[R], int i) {
 #pragma unroll
-  for (int q = 0; q < R; ++q) { cc[q] = B[1 + q]; sp[q] = T.sp[1 + q]; }
-  for (int r = 0; r < nfw; ++r) {
-    const int i = 1 + r * R;
-    if (r + 1 < nfw) {
+    for (int q = 0; q < R; ++q) { c[q] = B[i + q]; sp[q] = T.sp[i + q]; }
+  };
+  auto fw_run = [&](double (&c)[R], double2 (&sp)[R], int i) {
 #pragma unroll
-      for (int q = 0; q < R; ++q) { nc[q] = B[i + R + q]; ns[q] = T.sp[i + R + q]; }
-    }
+    for (int q = 0; q < R; ++q) { up = sp[q].y * (c[q] - sp[q].x * up); c[q] = up; }
 #pragma unroll
-    for (int q = 0; q < R; ++q) { up = sp[q].y * (cc[q] - sp[q].x * up); cc[q] = up; }
-#pragma unroll
-    for (int q = 0; q < R; ++q) B[i + q] = cc[q];
-#pragma unroll
-    for (int q = 0; q < R; ++q) { cc[q] = nc[q]; sp[q] = ns[q]; }
+    for (int q = 0; q < R; ++q) B[i + q] = c[q];
+  };
+  fw_load(ca, sa, 1);
+  int r = 0;
+  for (; r + 2 <= nfw; r += 2) {
+    fw_load(cb, sb, 1 + (r + 1) * R);
+    __builtin_amdgcn_sched_barrier(0);
+    fw_run(ca, sa, 1 + r * R);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 2 < nfw) fw_load(ca, sa, 1 + (r + 2) * R);
+    __builtin_amdgcn_sched_barrier(0);
+    fw_run(cb, sb, 1 + (r + 1) * R);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (r < nfw) fw_run(ca, sa, 1 + r * R);
   for (int i = 1 + nfw * R; i < kK - 1; ++i) { const double2 s1 = T.sp[i]; up = s1.y * (B[i] - s1.x * up); B[i] = up; }
   double yn = 0.0;                                       // y2[K-1] of the natural spline
   B[kK - 1] = 0.0;
   constexpr int nbw = (kK - 1) / R;                      // full rounds of the backward sweep (bins kK-2 .. 0)
-  double dd[R], nd[R];
+  double da[R], db[R];
+  auto bw_load = [&](double (&c)[R], double (&d)[R], int j) {
 #pragma unroll
-  for (int q = 0; q < R; ++q) { cc[q] = B[kK - 2 - q]; dd[q] = T.dec[kK - 2 - q]; }
-  for (int r = 0; r < nbw; ++r) {
-    const int j = kK - 2 - r * R;
-    if (r + 1 < nbw) {
+    for (int q = 0; q < R; ++q) { c[q] = B[j - q]; d[q] = T.dec[j - q]; }
+  };
+  auto bw_run = [&](double (&c)[R], double (&d)[R], int j) {
 #pragma unroll
-      for (int q = 0; q < R; ++q) { nc[q] = B[j - R - q]; nd[q] = T.dec[j - R - q]; }
-    }
+    for (int q = 0; q < R; ++q) { yn = d[q] * yn + c[q]; c[q] = yn; }
 #pragma unroll
-    for (int q = 0; q < R; ++q) { yn = dd[q] * yn + cc[q]; cc[q] = yn; }
-#pragma unroll
-    for (int q = 0; q < R; ++q) B[j - q] = cc[q];
-#pragma unroll
-    for (int q = 0; q < R; ++q) { cc[q] = nc[q]; dd[q] = nd[q]; }
+    for (int q = 0; q < R; ++q) B[j - q] = c[q];
+  };
+  bw_load(ca, da, kK - 2);
+  r = 0;
+  for (; r + 2 <= nbw; r += 2) {
+    bw_load(cb, db, kK - 2 - (r + 1) * R);
+    __builtin_amdgcn_sched_barrier(0);
+    bw_run(ca, da, kK - 2 - r * R);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 2 < nbw) bw_load(ca, da, kK - 2 - (r + 2) * R);
+    __builtin_amdgcn_sched_barrier(0);
+    bw_run(cb, db, kK - 2 - (r + 1) * R);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (r < nbw) bw_run(ca, da, kK - 2 - r * R);
   for (int j = kK - 2 - nbw * R; j >= 0; --j) { yn = T.dec[j] * yn + B[j]; B[j] = yn; }
 }
 

@@ -47,6 +47,12 @@ int main() {
       printf("lanes %2d  %-40s %.2f memtime ticks/op\n", lanes, names[mode], (double)h / n / ops);
     }
   }
+  // the same dependent chain with the whole device busy (one wave per SIMD, then four): issue rate under load
+  for (int grid : {1024, 4096}) {
+    for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(k<0>, dim3(grid), dim3(64), 0, 0, d, t, 1.0000001, 0.9999999, n); hipDeviceSynchronize(); }
+    unsigned long long hh[8]; hipMemcpy(hh, t, 64, hipMemcpyDeviceToHost);
+    printf("grid %4d x 64  f64 dependent mul+add: %.2f memtime ticks/op (block 0)\n", grid, (double)hh[0] / n / 32);
+  }
   // clock: ticks per microsecond
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, d, t, 1.0000001, 0.9999999, 20000); hipEventRecord(e1); hipEventSynchronize(e1);
