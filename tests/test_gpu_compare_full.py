@@ -143,3 +143,31 @@ def test_jitter_and_lld_columns_exact_on_identical_f0(hip, oracle):
         assert np.array_equal(o.view(np.uint32), ref.view(np.uint32)), f"utt {i}: rows {sorted(set(np.argwhere(o != ref)[:, 0]))[:8]}"
     b.close()
     bf.close()
+
+
+def test_compare_full_large_batch_properties(hip, oracle):
+    """A per-GPU share in the direction of config 4 (3000 x 10 s = 3.0 M rows x 130 columns): size-independent
+    properties -- row counts, copies of the same utterance give bit-identical rows wherever they sit in the batch,
+    value ranges of the F0 group -- and one utterance checked against the oracle."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    n_utt, S, n_unique = 3000, 160000, 12
+    pcm, off = synth.corpus_tiled(n_utt, S, n_unique=n_unique)
+    b = capi.Batch(plan, off)
+    assert b.total_rows == n_utt * 996
+    out = b.run_host(pcm).reshape(n_utt, 996, 130)
+    assert np.isfinite(out).all()
+    for u in range(n_unique):
+        same = (out[u::n_unique].view(np.uint32) == out[u].view(np.uint32)[None]).all()
+        assert same, f"copies of utterance {u} differ"
+    f0, voi, jl, jd, sh, hnr = (out[..., c] for c in range(6))
+    assert ((f0 == 0) | ((f0 >= 52.0 * 0.999) & (f0 <= 620.0 * 1.001))).all()
+    assert (voi >= 0).all() and (voi <= 1.0).all()
+    for x in (jl, jd, sh):
+        assert (x >= 0).all() and (x <= 1.0).all()
+    assert (hnr >= -100.0).all()
+    oracle.use_reference_fft(False)
+    ref = oracle.compare_lld_chain(pcm[off[5]:off[6]])
+    compare_tolerances(out[5][:, AB], ref[:, AB], "large batch, utterance 5")
+    f0_lld_tolerances(out[5][:, F0], ref[:, F0], "large batch, utterance 5")
+    b.close()
