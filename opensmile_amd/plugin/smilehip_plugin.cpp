@@ -19,6 +19,7 @@
 // This file is compiled with the HOST g++ against the reference's headers
 // (ABI-coupled to libopensmile.so); it contains no HIP code.
 #include <core/componentManager.hpp>
+#include <core/dataSource.hpp>
 #include <core/smileCommon.hpp>
 #include <dsp/specScale.hpp>
 #include <dspcore/acf.hpp>
@@ -46,6 +47,7 @@
 #include <vector>
 
 #include "../../include/smilehip.h"
+#include "../host/smilehip_host.hpp"
 
 #define MODULE "smilehipPlugin"
 
@@ -954,6 +956,135 @@ class cHipPitchShs : public cPitchShs {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Fused mode behind the component API: ONE data source that owns a whole file and replaces the wave source plus
+// every component of the chain. It runs the fused kernels once (smilehip_lld_run_host) and then feeds the finished
+// feature rows into the level the chain's last component used to write, so that every sink / functional of a config
+// keeps working (conf/MFCC12_0_D_A_hip.conf). A new component type with its own options:
+//   filename    the RIFF/WAVE file (16-bit mono)
+//   featureSet  mfcc12_0_d_a | plp_0_d_a   (the sets whose rows are frames: row time = row * frameStep)
+#define COMPONENT_NAME_CHIPLLDSOURCE "cHipLldSource"
+#define COMPONENT_DESCRIPTION_CHIPLLDSOURCE "Reads a wave file and writes the LLD rows of a whole feature set, computed by the fused HIP kernels of libsmilehip, to a dataMemory level."
+class cHipLldSource : public cDataSource {
+  std::string filename_, set_;
+  std::vector<float> rows_;
+  std::vector<std::string> names_;
+  long n_rows_ = 0, next_ = 0;
+  int n_cols_ = 0;
+  double period_sec_ = 0.01, frame_size_sec_ = 0.025;
+  bool ran_ = false;
+  cMatrix *block_ = nullptr;
+
+  void config_for(smilehip_lld_config &c) {
+    if (set_ == "plp_0_d_a") smilehip_config_plp_0_d_a(&c);
+    else if (set_ == "mfcc12_0_d_a") smilehip_config_mfcc12_0_d_a(&c);
+    else COMP_ERR("cHipLldSource: unknown featureSet '%s' (mfcc12_0_d_a, plp_0_d_a)", set_.c_str());
+  }
+  void run_once() {
+    smilehip_host::WaveInfo wi;
+    std::vector<unsigned char> raw;
+    std::string err;
+    if (!smilehip_host::read_wave_file(filename_, wi, raw, err)) COMP_ERR("cHipLldSource: %s", err.c_str());
+    if (wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) COMP_ERR("cHipLldSource: '%s' is not 16-bit mono PCM", filename_.c_str());
+    smilehip_lld_config c;
+    config_for(c);
+    c.sample_rate = (double)wi.sample_rate;
+    smilehip_plan *pl = nullptr;
+    check(smilehip_plan_create(context(), &c, &pl));
+    const int64_t n = (int64_t)(raw.size() / 2);
+    const int64_t off[2] = {0, n};
+    smilehip_batch *b = nullptr;
+    check(smilehip_batch_create(pl, off, 1, &b));
+    n_rows_ = (long)smilehip_batch_total_rows(b);
+    rows_.assign((size_t)(n_rows_ > 0 ? n_rows_ : 1) * n_cols_, 0.0f);
+    if (n_rows_ > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows_.data()));
+    smilehip_batch_destroy(b);
+    smilehip_plan_destroy(pl);
+    ran_ = true;
+  }
+ protected:
+  SMILECOMPONENT_STATIC_DECL_PR
+  void myFetchConfig() override {
+    cDataSource::myFetchConfig();
+    filename_ = getStr("filename") ? getStr("filename") : "";
+    set_ = getStr("featureSet") ? getStr("featureSet") : "mfcc12_0_d_a";
+    smilehip_lld_config c;
+    config_for(c);
+    period_sec_ = c.frame_step_sec;
+    frame_size_sec_ = c.frame_size_sec;
+    names_ = (set_ == "plp_0_d_a") ? smilehip_host::lld_names_plp_0_d_a() : smilehip_host::lld_names_mfcc12_0_d_a();
+    n_cols_ = (int)names_.size();
+  }
+  int configureWriter(sDmLevelConfig &c) override {
+    c.T = period_sec_;                                  // the level the chain's cVectorConcat writes: period = frameStep
+    c.frameSizeSec = frame_size_sec_;
+    c.basePeriod = period_sec_;
+    return 1;
+  }
+  int setupNewNames(long) override {
+    // element names "base[i]" back into array fields (field name, size, first index), as the chain's components add them
+    size_t i = 0;
+    while (i < names_.size()) {
+      const std::string &nm = names_[i];
+      const size_t br = nm.rfind('[');
+      if (br == std::string::npos) { writer_->addField(nm.c_str(), 1); ++i; continue; }
+      const std::string base = nm.substr(0, br);
+      const int first = atoi(nm.c_str() + br + 1);
+      size_t j = i;
+      while (j < names_.size() && names_[j].compare(0, br + 1, base + "[") == 0 && names_[j].rfind('[') == br) ++j;
+      writer_->addField(base.c_str(), (int)(j - i), first);
+      i = j;
+    }
+    namesAreSet_ = 1;
+    return 1;
+  }
+  eTickResult myTick(long long) override {
+    if (isEOI()) return TICK_INACTIVE;
+    if (!ran_) run_once();
+    long n = n_rows_ - next_;
+    if (n <= 0) return TICK_INACTIVE;
+    if (n > blocksizeW_ && blocksizeW_ > 0) n = blocksizeW_;
+    if (n > 64) n = 64;
+    if (!writer_->checkWrite(n)) {
+      n = 1;
+      if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
+    }
+    if (!block_ || block_->nT != n) {
+      delete block_;
+      block_ = new cMatrix(n_cols_, n);
+    }
+    memcpy(block_->data, rows_.data() + (size_t)next_ * n_cols_, sizeof(float) * (size_t)n * n_cols_);   // data[el + t*N]
+    for (long t = 0; t < n; ++t) {                      // frame time stamps as the framer gives them: vIdx * frameStep
+      block_->tmeta[t].time = (double)(next_ + t) * period_sec_;
+      block_->tmeta[t].lengthSec = frame_size_sec_;
+      block_->tmeta[t].period = period_sec_;
+    }
+    writer_->setNextMatrix(block_);
+    next_ += n;
+    return TICK_SUCCESS;
+  }
+ public:
+  SMILECOMPONENT_STATIC_DECL
+  explicit cHipLldSource(const char *n) : cDataSource(n) {}
+  ~cHipLldSource() override { delete block_; }
+};
+
+SMILECOMPONENT_STATICS(cHipLldSource)
+
+SMILECOMPONENT_REGCOMP(cHipLldSource) {
+  SMILECOMPONENT_REGCOMP_INIT
+  scname = COMPONENT_NAME_CHIPLLDSOURCE;
+  sdescription = COMPONENT_DESCRIPTION_CHIPLLDSOURCE;
+  SMILECOMPONENT_INHERIT_CONFIGTYPE("cDataSource")
+  SMILECOMPONENT_IFNOTREGAGAIN(
+    ct->setField("filename", "The RIFF/WAVE file to process (16-bit mono PCM)", "input.wav");
+    ct->setField("featureSet", "The feature set whose LLD rows are produced: mfcc12_0_d_a (config/mfcc/MFCC12_0_D_A.conf) or plp_0_d_a (config/plp/PLP_0_D_A.conf)", "mfcc12_0_d_a");
+  )
+  SMILECOMPONENT_MAKEINFO(cHipLldSource);
+}
+
+SMILECOMPONENT_CREATE(cHipLldSource)
+
 // optional usage trace: SMILEHIP_PLUGIN_TRACE=<file> gets one line per overridden
 // component with the number of frames it pushed through the HIP kernels
 struct TraceAtExit {
@@ -989,6 +1120,10 @@ extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cCom
   sComponentInfo *head = nullptr;
   const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all seventeen
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  if (want("cHipLldSource")) {                             // a NEW type (fused mode), not an override
+    sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
+    if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
+  }
   if (want("cPitchShs")) head = override_of(&cPitchShs::registerComponent, &cHipPitchShs::create, confman, compman, iteration, head);
   if (want("cSpecScale")) head = override_of(&cSpecScale::registerComponent, &cHipSpecScale::create, confman, compman, iteration, head);
   if (want("cFunctionals")) head = override_of(&cFunctionals::registerComponent, &cHipFunctionals::create, confman, compman, iteration, head);

@@ -198,3 +198,39 @@ def test_plugin_plp_cepstra_bit_exact(oracle, golden_plp):
         scale = np.abs(ref[:, :6]).max(axis=1, keepdims=True)
         assert (np.abs(y - ref) / scale).max() <= 1e-6
         assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.95
+
+
+def test_plugin_fused_source_component(oracle, golden_synth):
+    """Fused mode behind the component API: cHipLldSource (a new component type of the plugin) replaces the wave
+    source and the nine chain components of MFCC12_0_D_A.conf; the reference's own output section writes the file.
+    Same rows, same HTK header and CSV layout as the unmodified config gives with the CPU chain."""
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    from test_host_io import parse_csv
+    for key, fset, conf_ref in (("u2_16000", "mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf"), ("u3_16000", "plp_0_d_a", "plp/PLP_0_D_A.conf")):
+        pcm = golden_synth["pcm_" + key]
+        with tempfile.TemporaryDirectory() as td:
+            wav = os.path.join(td, "in.wav")
+            oracle.write_wav(wav, pcm)
+            env = dict(os.environ)
+            env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+            outs = {}
+            for tag, conf, extra in (("hip", os.path.join(PLUGDIR, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", fset]),
+                                     ("ref", os.path.join(oracle.REF_DIR, "config", conf_ref), [])):
+                htk, csv = os.path.join(td, tag + ".htk"), os.path.join(td, tag + ".csv")
+                e = dict(env)
+                if tag == "ref":
+                    e["SMILEHIP_PLUGIN_COMPONENTS"] = "none"          # the plain CPU chain
+                r = subprocess.run([exe, "-C", conf, "-I", wav, "-O", htk, "-csvoutput", csv, "-instname", "utt", "-l", "1"] + extra,
+                                   cwd=PLUGDIR, env=e, capture_output=True, text=True, timeout=300)
+                assert r.returncode == 0 and os.path.exists(htk), r.stderr[-2000:]
+                outs[tag] = (open(htk, "rb").read()[:12], oracle.read_htk(htk)[0], parse_csv(csv))
+        (hh, xh, ch), (hr, xr, cr) = outs["hip"], outs["ref"]
+        assert hh == hr and xh.shape == xr.shape                        # HTK header: rows, period, vector size, parmKind
+        n_static = xr.shape[1] // 3
+        scale = np.abs(xr[:, :n_static]).max(axis=1, keepdims=True)
+        assert (np.abs(xh - xr) / scale).max() <= 1e-5
+        assert ch[0] == cr[0] and ch[1] == cr[1] and ch[2].shape == cr[2].shape    # CSV head line, element names
+        assert np.array_equal(ch[2][:, 0], cr[2][:, 0])                 # frameTime column
