@@ -534,3 +534,79 @@ long lldo_plp_chain(const int16_t *pcm, long n_samples, float *out)
   free(mfcc); free(mel); free(st); free(tmp);
   return T;
 }
+
+/* ------------------------------------------------------------- the other configs of config/mfcc and config/plp */
+/* MFCC12_E_D_A, MFCC12_0_D_A_Z, MFCC12_E_D_A_Z, PLP_E_D_A, PLP_0_D_A_Z, PLP_E_D_A_Z next to the _0_D_A pair:
+ *   E: cMfcc firstMfcc = 1 (cPlp firstCC = 1) and a cEnergy column appended to the static block -- log energy of the RAW
+ *      frame, HTK style (src/lldcore/energy.cpp:152-185 with log = 1, htkcompatible = 1: log(max(1, 32767^2 sum x^2)));
+ *      the deltas are taken of [cepstra | energy] ([cat:cVectorConcat] -> ft0 / delta1e, delta2e: same numbers);
+ *   Z: cFullinputMean on the cepstra (src/dspcore/fullinputMean.cpp, multiLoopMode = 0, meanNorm = amean): the float
+ *      sum of all frames in order, divided by (float)T, subtracted from the static cepstra only; the deltas come from
+ *      the un-normalised level, the energy column is not normalised.
+ * Column order of every variant: [cepstra (mean-normalised with Z) | E] [their deltas] [their accelerations]. */
+long lldo_htk_variant_chain(int plp, int energy, int cms, const int16_t *pcm, long n_samples, float *out)
+{
+  lldo_mfcc_cfg c;
+  lldo_default_mfcc12_cfg(&c);
+  if (cms) c.zero_pad_symmetric = 1;          /* the _Z files do not set [fft] zeroPadSymmetric = 0: the default (1) applies */
+  lldo_geom g;
+  lldo_geometry(&c, &g);
+  const long T = lldo_num_frames(n_samples, g.N, g.H);
+  const int first = energy ? 1 : 0;
+  const int Dc = plp ? (5 + 1 - first) : (12 + 1 - first);    /* cepstra */
+  const int D = Dc + (energy ? 1 : 0);
+  if (!out || T <= 0) return T;
+  float *st = (float *)malloc(sizeof(float) * (size_t)T * D);
+  float *x = (float *)malloc(sizeof(float) * (size_t)n_samples);
+  lldo_pcm16_to_float(pcm, n_samples, x);
+  if (!plp) {
+    c.first_mfcc = first; c.last_mfcc = 12; c.n_delta = 0;
+    float *cep = (float *)malloc(sizeof(float) * (size_t)T * Dc);
+    lldo_mfcc_chain(&c, pcm, n_samples, cep, NULL, NULL, NULL, NULL);
+    for (long t = 0; t < T; t++) memcpy(st + t * D, cep + t * Dc, sizeof(float) * Dc);
+    free(cep);
+  } else {
+    c.n_delta = 0;
+    float *mfcc = (float *)malloc(sizeof(float) * (size_t)T * 13);
+    float *mel = (float *)malloc(sizeof(float) * (size_t)T * 26);
+    lldo_mfcc_chain(&c, pcm, n_samples, mfcc, NULL, NULL, NULL, mel);
+    lldo_mel mb;
+    lldo_mel_init(&mb, g.K, g.frame_size_sec_fft, 26, c.lofreq, c.hifreq, c.use_power, c.mel_htk_compatible);
+    double band_hz[26];
+    for (int m = 1; m <= 26; m++) band_hz[m - 1] = 700.0 * (exp((double)mb.cfs[m] / 1127.0) - 1.0);
+    float cc6[6];
+    for (long t = 0; t < T; t++) {
+      lldo_plp_cc(mel + t * 26, 26, band_hz, 5, (float)0.33, 22, cc6);      /* c1..c5, c0 */
+      memcpy(st + t * D, cc6, sizeof(float) * Dc);                            /* firstCC = 1 drops c0 (the last one) */
+    }
+    lldo_mel_free(&mb);
+    free(mfcc); free(mel);
+  }
+  if (energy)
+    for (long t = 0; t < T; t++) {
+      const float *src = x + t * g.H;
+      double d = 0.0;
+      for (long i = 0; i < g.N; i++) { float tmp = src[i]; d += tmp * tmp; }
+      d *= 32767.0 * 32767.0;
+      if (d <= 1.0) d = 1.0;
+      st[t * D + Dc] = (float)log(d) * 1.0f + 0.0f;
+    }
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)T * D * 2);
+  lldo_delta_chain(st, T, D, 2, 2, tmp);
+  float mean[16];
+  if (cms) {
+    for (int i = 0; i < Dc; i++) mean[i] = st[i];
+    for (long t = 1; t < T; t++)
+      for (int i = 0; i < Dc; i++) mean[i] += st[t * D + i];
+    const float nM = (float)T;
+    for (int i = 0; i < Dc; i++) mean[i] /= nM;
+  }
+  for (long t = 0; t < T; t++) {
+    float *o = out + t * 3 * D;
+    memcpy(o, st + t * D, sizeof(float) * D);
+    if (cms) for (int i = 0; i < Dc; i++) o[i] -= mean[i];
+    for (int k = 1; k <= 2; k++) memcpy(o + k * D, tmp + ((size_t)(k - 1) * (size_t)T + (size_t)t) * D, sizeof(float) * D);
+  }
+  free(st); free(x); free(tmp);
+  return T;
+}

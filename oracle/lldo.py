@@ -417,3 +417,26 @@ def compare_f0_lld(pcm):
     if rows > 0:
         L.lldo_compare_f0_lld(pcm.ctypes.data, len(pcm), out.ctypes.data)
     return out
+
+
+HTK_VARIANTS = {  # name: (config file, plp, energy, cms)
+    "MFCC12_0_D_A": ("mfcc/MFCC12_0_D_A.conf", 0, 0, 0), "MFCC12_E_D_A": ("mfcc/MFCC12_E_D_A.conf", 0, 1, 0),
+    "MFCC12_0_D_A_Z": ("mfcc/MFCC12_0_D_A_Z.conf", 0, 0, 1), "MFCC12_E_D_A_Z": ("mfcc/MFCC12_E_D_A_Z.conf", 0, 1, 1),
+    "PLP_0_D_A": ("plp/PLP_0_D_A.conf", 1, 0, 0), "PLP_E_D_A": ("plp/PLP_E_D_A.conf", 1, 1, 0),
+    "PLP_0_D_A_Z": ("plp/PLP_0_D_A_Z.conf", 1, 0, 1), "PLP_E_D_A_Z": ("plp/PLP_E_D_A_Z.conf", 1, 1, 1),
+}
+
+
+def htk_variant_chain(name, pcm):
+    """The eight configs of config/mfcc and config/plp: T x 3*(cepstra [+ energy])."""
+    _, plp, energy, cms = HTK_VARIANTS[name]
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_htk_variant_chain.restype = C.c_long
+    L.lldo_htk_variant_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+    T = max(L.lldo_htk_variant_chain(plp, energy, cms, pcm.ctypes.data, len(pcm), None), 0)
+    D = ((5 if plp else 12) + (0 if energy else 1) + (1 if energy else 0)) * 3
+    out = np.zeros((T, D), np.float32)
+    if T > 0:
+        L.lldo_htk_variant_chain(plp, energy, cms, pcm.ctypes.data, len(pcm), out.ctypes.data)
+    return out

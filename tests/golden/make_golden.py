@@ -35,6 +35,21 @@ def gen_func():
 
 
 
+
+def gen_htk_variants():
+    """The six sibling configs of config/mfcc and config/plp (log-energy column, cepstral mean subtraction)."""
+    ref = {}
+    for name, (conf, _, _, _) in lldo.HTK_VARIANTS.items():
+        if name in ("MFCC12_0_D_A", "PLP_0_D_A"):
+            continue
+        for key, (u, n) in {"u2_16000": (2, 16000), "u0_8000": (0, 8000), "u10_8000": (10, 8000), "u7_400": (7, 400),
+                            "u7_720": (7, 720), "u7_1040": (7, 1040)}.items():
+            pcm = synth.utterance(u, n)
+            ref["pcm_" + key] = pcm
+            ref[name + "_" + key] = lldo.run_reference(conf, pcm)
+        print("variant", name)
+    np.savez_compressed(os.path.join(OUT, "htk_variants_synth.npz"), **ref)
+
 def gen_f0():
     """ComParE_2016 F0 group: the levels of oracle/conf/compare_f0_taps.conf from the real binary
     (pitch = is13_pitchG60, shs = is13_pitchShsG60, vit = is13_pitchG60_viterbi, e60 = is13_e60,
@@ -126,6 +141,7 @@ def main(only=None):
     gen_func()
     gen_plp()
     gen_f0()
+    gen_htk_variants()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
