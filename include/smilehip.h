@@ -133,6 +133,12 @@ typedef struct smilehip_lld_config {
   int32_t  shs_n_harmonics;             /* cPitchShs nHarmonics (<= 16) */
   float    shs_compression;             /* cPitchShs compressionFactor */
   float    f0_min_energy;               /* cValbasedSelector threshold on the 60 ms frame's RMS energy */
+  /* SMILEHIP_CHAIN_MFCC / _PLP: the other files of config/mfcc and config/plp (MFCC12_E_D_A, *_Z, PLP_E_D_A, ...) */
+  int32_t  append_log_energy;           /* [energy:cEnergy] log = 1, htkcompatible = 1 on the raw frame (src/lldcore/energy.cpp:152-185),
+                                           appended to the static block ([cat:cVectorConcat]); the deltas cover it */
+  int32_t  cms;                         /* [cms:cFullinputMean] (src/dspcore/fullinputMean.cpp, multiLoopMode = 0, meanNorm = amean):
+                                           the utterance's mean is subtracted from the static cepstra (not from the energy
+                                           column; the deltas come from the un-normalised level) */
   int32_t  reserved0;
 } smilehip_lld_config;
 
@@ -184,6 +190,11 @@ void smilehip_config_is09_lld(smilehip_lld_config *c);
 void smilehip_config_plp_0_d_a(smilehip_lld_config *c);
 /* fills c with groups A+B of config/compare16/ComParE_2016.conf (chain_kind = COMPARE_AB) */
 void smilehip_config_compare16_ab(smilehip_lld_config *c);
+/* fills c with one of the eight files of config/mfcc and config/plp, by name without the extension: MFCC12_0_D_A,
+ * MFCC12_E_D_A, MFCC12_0_D_A_Z, MFCC12_E_D_A_Z, PLP_0_D_A, PLP_E_D_A, PLP_0_D_A_Z, PLP_E_D_A_Z (E: cepstra 1.. + HTK log
+ * energy; Z: cepstral mean subtraction, and the default symmetric zero padding those files leave in place).
+ * Returns SMILEHIP_ERR_INVALID for any other name. */
+int smilehip_config_htk_variant(smilehip_lld_config *c, const char *name);
 /* fills c with the F0 group of config/compare16/ComParE_2016.conf up to is13_pitchG60 (chain_kind = COMPARE_F0) */
 void smilehip_config_compare16_f0(smilehip_lld_config *c);
 /* fills c with the whole LLD level of config/compare16/ComParE_2016.conf (chain_kind = COMPARE, 130 columns) */

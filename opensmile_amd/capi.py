@@ -41,7 +41,7 @@ class LldConfig(C.Structure):
         ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
-        ("f0_min_energy", C.c_float), ("reserved0", C.c_int32),
+        ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -66,6 +66,7 @@ SYMBOLS = {
     "smilehip_config_is09_lld": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_ab": (None, [C.POINTER(LldConfig)]),
     "smilehip_config_compare16_f0": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_htk_variant": (C.c_int, [C.POINTER(LldConfig), C.c_char_p]),
     "smilehip_config_compare16": (None, [C.POINTER(LldConfig)]),
     "smilehip_specscale_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_pitchshs_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
@@ -162,6 +163,13 @@ def plp_0_d_a_config():
 def compare16_ab_config():
     c = LldConfig()
     load().smilehip_config_compare16_ab(C.byref(c))
+    return c
+
+
+def htk_variant_config(name):
+    """One of the eight files of config/mfcc and config/plp: MFCC12_{0,E}_D_A[_Z], PLP_{0,E}_D_A[_Z]."""
+    c = LldConfig()
+    _check(load().smilehip_config_htk_variant(C.byref(c), name.encode()))
     return c
 
 

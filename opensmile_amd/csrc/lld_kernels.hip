@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
     if (threadIdx.x == 0) {
       float o[16];
       plp_cc_serial(acf, P.plp_order, P.plp_sin, o);
-      for (int r = 0; r <= P.plp_order; ++r) P.out[row * P.ld_out + r] = o[r];
+      for (int r = 0; r < P.n_mfcc; ++r) P.out[row * P.ld_out + r] = o[r];      // firstCC = 1 drops c0 (the last one)
     }
     return;
   }
@@ -277,6 +277,73 @@ hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   const int M = P.Nfft / 2;
   const size_t lds = sizeof(float) * (size_t)(2 * M + P.K + 1 + P.n_bands + 24);
   hipLaunchKernelGGL(lld_mfcc_generic, dim3((unsigned)P.total_frames), dim3(256), lds, s, P);
+  return hipGetLastError();
+}
+
+// [energy:cEnergy] of the E variants (src/lldcore/energy.cpp:152-185 with log = 1, htkcompatible = 1) on the RAW frame:
+// d = sum (float)(x*x) accumulated in double in sample order, times 32767^2, floored at 1, (float)log(d).
+// One thread per frame, the reference's own summation order (the column is bit-exact). dst[frame * ld + col].
+__global__ void __launch_bounds__(256) lld_log_energy(LldParams P, float *dst, int64_t ld, int col) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.total_frames) return;
+  int lo = 0, hi = P.n_utt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (P.frame_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  const int16_t *x = P.pcm + P.samp_off[lo] + (g - P.frame_off[lo]) * P.H;
+  double d = 0.0;
+  int i = 0;
+  for (; i + 8 <= P.N; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = pcm16_to_float(x[i + q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float sq = v[q] * v[q]; d += (double)sq; }
+  }
+  for (; i < P.N; ++i) { const float t = pcm16_to_float(x[i]); const float sq = t * t; d += (double)sq; }
+  d *= 32767.0 * 32767.0;
+  if (d <= 1.0) d = 1.0;
+  dst[g * ld + col] = (float)log(d) * 1.0f + 0.0f;
+}
+
+// [cms:cFullinputMean] of the Z variants (src/dspcore/fullinputMean.cpp, multiLoopMode = 0, meanNorm = amean): per column
+// the float sum of all frames in order (first frame, then += ...), divided by (float)T, subtracted from every frame.
+// x: the un-normalised static block (ld_x), out: the output rows (ld_out); columns 0 .. n_cols-1. One wave per utterance.
+__global__ void __launch_bounds__(64) lld_cms(const int64_t *frame_off, int n_utt, const float *x, int64_t ld_x, float *out,
+                                              int64_t ld_out, int n_cols) {
+  const int u = blockIdx.x;
+  if (u >= n_utt) return;
+  const int64_t f0 = frame_off[u];
+  const int T = (int)(frame_off[u + 1] - f0);
+  if (T <= 0) return;
+  const int lane = threadIdx.x;
+  __shared__ float mean[64];
+  if (lane < n_cols) {
+    const float *p = x + f0 * ld_x + lane;
+    float m = p[0];
+    for (int t = 1; t < T; ++t) m += p[(int64_t)t * ld_x];
+    mean[lane] = m / (float)T;
+  }
+  __syncthreads();
+  for (int64_t e = lane; e < (int64_t)T * n_cols; e += 64) {
+    const int64_t t = e / n_cols;
+    const int c = (int)(e - t * n_cols);
+    out[(f0 + t) * ld_out + c] = x[(f0 + t) * ld_x + c] - mean[c];
+  }
+}
+
+hipError_t launch_log_energy(const LldParams &P, float *dst, int64_t ld, int col, hipStream_t s) {
+  if (P.total_frames <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_log_energy, dim3((unsigned)((P.total_frames + 255) / 256)), dim3(256), 0, s, P, dst, ld, col);
+  return hipGetLastError();
+}
+
+hipError_t launch_cms(const int64_t *d_frame_off, int n_utt, const float *x, int64_t ld_x, float *out, int64_t ld_out, int n_cols,
+                      hipStream_t s) {
+  if (n_utt <= 0 || n_cols <= 0) return hipSuccess;
+  if (n_cols > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lld_cms, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, n_utt, x, ld_x, out, ld_out, n_cols);
   return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   }
   if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
       plan->ctx && b->total_frames > 0) {
-    const size_t n = size_t(b->total_frames) * size_t(plan->dct.n_mfcc);
+    const size_t n = size_t(b->total_frames) * size_t(plan_n_static(plan));
     if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the static-block scratch failed");
@@ -247,7 +247,8 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan/batch mismatch");
   if (plan->cfg.chain_kind != SMILEHIP_CHAIN_MFCC && plan->cfg.chain_kind != SMILEHIP_CHAIN_PLP)
     return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: plan is not an MFCC / PLP chain (use smilehip_lld_run)");
-  const int n_out = plan->dct.n_mfcc * (1 + plan->cfg.n_delta);
+  const int n_static = plan_n_static(plan), n_cep = plan->dct.n_mfcc;      // cepstra [+ log energy]
+  const int n_out = n_static * (1 + plan->cfg.n_delta);
   if (ld_out < n_out) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < n_out %d", (long long)ld_out, n_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_run: null device pointer");
@@ -260,7 +261,7 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   const bool compact = plan->cfg.n_delta > 0 && b->d_static.p != nullptr;
   if (compact) {
     P.out = b->d_static.p;
-    P.ld_out = plan->dct.n_mfcc;
+    P.ld_out = n_static;
   }
   hipEvent_t *ev = plan->ev[plan->n_timed % smilehip_plan::kRing];
   if (plan->timing) {
@@ -291,12 +292,20 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     e = launch_mfcc_generic(P, s);
   }
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
+  if (plan->cfg.append_log_energy) {                   // E variants: [energy:cEnergy] into the static block's last column
+    e = launch_log_energy(P, P.out, P.ld_out, n_cep, s);
+    if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "log-energy kernel launch failed: %s", hipGetErrorString(e));
+  }
   if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
   if (plan->cfg.n_delta > 0) {
-    int rc = compact ? delta_chain_from(plan, b, b->d_static.p, plan->dct.n_mfcc, 0, d_out, ld_out, plan->dct.n_mfcc,
+    int rc = compact ? delta_chain_from(plan, b, b->d_static.p, n_static, 0, d_out, ld_out, n_static,
                                         plan->cfg.delta_win, plan->cfg.n_delta, stream)
-                     : smilehip_delta_chain(plan, b, d_out, ld_out, plan->dct.n_mfcc, plan->cfg.delta_win, plan->cfg.n_delta, stream);
+                     : smilehip_delta_chain(plan, b, d_out, ld_out, n_static, plan->cfg.delta_win, plan->cfg.n_delta, stream);
     if (rc) return rc;
+  }
+  if (plan->cfg.cms) {                                 // Z variants: [cms:cFullinputMean] on the cepstra of the output rows
+    e = launch_cms(b->d_frame_off.p, b->n_utt, P.out, P.ld_out, d_out, ld_out, n_cep, s);   // P.out: the un-normalised block
+    if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mean-subtraction kernel launch failed: %s", hipGetErrorString(e));
   }
   if (plan->timing) {
     HIP_TRY(hipEventRecord(ev[2], s));

@@ -52,6 +52,22 @@ extern "C" void smilehip_config_plp_0_d_a(smilehip_lld_config *c) {
   c->last_mfcc = 5;
 }
 
+extern "C" int smilehip_config_htk_variant(smilehip_lld_config *c, const char *name) {
+  if (!c || !name) return fail(SMILEHIP_ERR_INVALID, "smilehip_config_htk_variant: null argument");
+  std::string n(name);
+  const bool plp = n.rfind("PLP_", 0) == 0, mfcc = n.rfind("MFCC12_", 0) == 0;
+  if (!plp && !mfcc) return fail(SMILEHIP_ERR_INVALID, "unknown config name '%s'", name);
+  std::string rest = n.substr(plp ? 4 : 7);
+  bool z = false;
+  if (rest.size() > 2 && rest.compare(rest.size() - 2, 2, "_Z") == 0) { z = true; rest.resize(rest.size() - 2); }
+  if (rest != "0_D_A" && rest != "E_D_A") return fail(SMILEHIP_ERR_INVALID, "unknown config name '%s'", name);
+  const bool e = rest[0] == 'E';
+  if (plp) smilehip_config_plp_0_d_a(c); else smilehip_config_mfcc12_0_d_a(c);
+  if (e) { c->first_mfcc = 1; c->append_log_energy = 1; }     // [mfcc] firstMfcc = 1 / [plp] firstCC = 1, [energy:cEnergy]
+  if (z) { c->cms = 1; c->zero_pad_symmetric = 1; }           // the _Z files do not set [fft] zeroPadSymmetric = 0
+  return SMILEHIP_OK;
+}
+
 extern "C" void smilehip_config_compare16_ab(smilehip_lld_config *c) {
   smilehip_config_mfcc12_0_d_a(c);
   c->chain_kind = SMILEHIP_CHAIN_COMPARE_AB;
@@ -128,7 +144,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (mask != SMILEHIP_STAGE_ALL || p->cfg.plp_lp_order < 1 || p->cfg.plp_lp_order > 15 || !p->cfg.mel_htk_compatible ||
         !p->cfg.use_power || p->mel.n_bands > 30 || p->cfg.plp_compression < 0.0f)
       return fail(SMILEHIP_ERR_INVALID, "PLP chain: lpOrder 1..15, HTK-scaled power mel bands (<= 30) required");
-    p->dct.n_mfcc = p->cfg.plp_lp_order + 1;            // outputs of the chain's static block
+    if (p->cfg.first_mfcc != 0 && p->cfg.first_mfcc != 1) return fail(SMILEHIP_ERR_INVALID, "PLP chain: firstCC must be 0 or 1");
+    p->dct.n_mfcc = p->cfg.plp_lp_order + (p->cfg.first_mfcc == 0 ? 1 : 0);   // c1..c_lpOrder [, c0]: outputs of cPlp
     p->dct.melfloor = 1.0f;                              // htkcompatible forces melfloor = 1.0 (plp.cpp:150-160)
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
     if (mask != SMILEHIP_STAGE_ALL || p->cfg.preemph || p->cfg.n_delta != 0 || p->cfg.win_offset != 0.0)
@@ -349,7 +366,8 @@ extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 int plan_n_static(const smilehip_plan *p) {
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return 2;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return 65;
-  return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16 : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc);
+  return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16
+         : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc + (p->cfg.append_log_energy ? 1 : 0));
 }
 int plan_n_out(const smilehip_plan *p) { return plan_n_static(p) * (1 + p->cfg.n_delta); }
 int plan_row_extra(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? p->cfg.sma_win / 2 : 0; }
