@@ -21,6 +21,18 @@ std::vector<std::string> lld_names_plp_0_d_a() {          // cPlp names its ceps
   return n;
 }
 
+// the eight files of config/mfcc and config/plp: cepstra (cMfcc "pcm_fftMag_mfcc[first..12]", cPlp "PlpCC[0..]" -- cPlp
+// numbers its outputs from 0 whatever firstCC is), with E the cEnergy column "pcm_LOGenergy", each block with its suffix
+std::vector<std::string> lld_names_htk_variant(bool plp, bool energy) {
+  std::vector<std::string> n;
+  for (const char *suffix : {"", "_de", "_de_de"}) {
+    if (plp) for (int i = 0; i < (energy ? 5 : 6); ++i) n.push_back(arr(std::string("PlpCC") + suffix, i));
+    else for (int i = energy ? 1 : 0; i <= 12; ++i) n.push_back(arr(std::string("pcm_fftMag_mfcc") + suffix, i));
+    if (energy) n.push_back(std::string("pcm_LOGenergy") + suffix);
+  }
+  return n;
+}
+
 std::vector<std::string> lld_names_is09() {
   std::vector<std::string> n;
   for (const char *suffix : {"_sma", "_sma_de"}) {

@@ -31,6 +31,7 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
 // (src/core/dataMemoryLevel.cpp naming: field name + "[index]" for array fields).
 std::vector<std::string> lld_names_mfcc12_0_d_a();
 std::vector<std::string> lld_names_plp_0_d_a();
+std::vector<std::string> lld_names_htk_variant(bool plp, bool energy);   // MFCC12_{0,E}_D_A[_Z], PLP_{0,E}_D_A[_Z]
 std::vector<std::string> lld_names_is09();
 std::vector<std::string> lld_names_compare16();
 std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>

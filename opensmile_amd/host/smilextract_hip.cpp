@@ -5,7 +5,8 @@
 // reference; unmodified configs run through the plugin): the set is picked
 // by name and the file options keep the names those configs declare via \cm[...]:
 //
-//   smilextract_hip --set mfcc12_0_d_a|plp_0_d_a  (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
+//   smilextract_hip --set mfcc12_0_d_a|mfcc12_e_d_a|mfcc12_0_d_a_z|mfcc12_e_d_a_z|plp_0_d_a|plp_e_d_a|plp_0_d_a_z|plp_e_d_a_z
+//                   (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
 //   smilextract_hip --set is09_emotion  (-I in.wav | -filelist list.txt) [-O func.arff] [-csvoutput func.csv]
 //   smilextract_hip --set compare16_lld (-I in.wav | -filelist list.txt) [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //                   (the 130-column LLD level of ComParE_2016; its functionals are not built)
@@ -18,6 +19,7 @@
 // (utterances shard with no communication; one process per GPU).
 // All files of a chunk are packed into one device batch: one kernel sequence per chunk.
 #include <algorithm>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -65,9 +67,21 @@ int main(int argc, char **argv) {
   }
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
-  const bool plp = set == "plp_0_d_a";
   const bool cmp16 = set == "compare16_lld";
-  if (!is09 && !plp && !cmp16 && set != "mfcc12_0_d_a") die("--set must be mfcc12_0_d_a, plp_0_d_a, is09_emotion or compare16_lld");
+  // the eight files of config/mfcc and config/plp, by their names in lower case
+  std::string variant;                             // upper-case config name for smilehip_config_htk_variant
+  for (char ch : set) variant += (char)toupper((unsigned char)ch);
+  smilehip_lld_config vcfg;
+  const bool htk_variant = !is09 && !cmp16 && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
+  const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
+  if (!is09 && !cmp16 && !htk_variant)
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion or compare16_lld");
+  // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
+  int parm_kind = 9;
+  if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
+  else if (variant == "MFCC12_E_D_A_Z") parm_kind = 2886;
+  else if (variant == "PLP_0_D_A_Z") parm_kind = 11019;
+  else if (variant == "PLP_E_D_A_Z") parm_kind = 8971;
   const bool lld_opts = is09 || cmp16;              // LLD files through -lldhtkoutput / -lldcsvoutput as in the reference
   std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
 
@@ -109,7 +123,7 @@ int main(int argc, char **argv) {
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
   const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
   const std::vector<std::string> lld_names =
-      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (plp ? lld_names_plp_0_d_a() : lld_names_mfcc12_0_d_a()));
+      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy));
   const std::vector<std::string> fnames = is09 ? func_names_is09() : std::vector<std::string>();
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
@@ -132,8 +146,7 @@ int main(int argc, char **argv) {
         smilehip_lld_config cfg;
         if (is09) smilehip_config_is09_lld(&cfg);
         else if (cmp16) smilehip_config_compare16(&cfg);
-        else if (plp) smilehip_config_plp_0_d_a(&cfg);
-        else smilehip_config_mfcc12_0_d_a(&cfg);
+        else cfg = vcfg;
         cfg.sample_rate = (double)kv.first;
         check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
       }
@@ -179,7 +192,7 @@ int main(int argc, char **argv) {
         const int64_t r = row_off[i + 1] - row_off[i];
         const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
         if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
-          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, 9, err)) die(err);
+          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, lld_opts ? 9 : parm_kind, err)) die(err);
         if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
           CsvOptions co;
           co.instance_name = job.inst;

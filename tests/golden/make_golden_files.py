@@ -40,6 +40,16 @@ def main():
                         "-csvoutput", os.path.join(td, "p.csv"), "-l", "0"], check=True, cwd=td)
         shutil.copy(os.path.join(td, "p.htk"), os.path.join(out, "plp_u2_8000.htk"))
         shutil.copy(os.path.join(td, "p.csv"), os.path.join(out, "plp_u2_8000.csv"))
+        # MFCC12_E_D_A (CSV + HTK through the standard output section) and MFCC12_E_D_A_Z (its own cHtkSink, parmKind 2886)
+        conf = os.path.join(lldo.REF_DIR, "config", "mfcc", "MFCC12_E_D_A.conf")
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u2.wav"), "-O", os.path.join(td, "e.htk"),
+                        "-csvoutput", os.path.join(td, "e.csv"), "-l", "0"], check=True, cwd=td)
+        shutil.copy(os.path.join(td, "e.htk"), os.path.join(out, "mfcc_e_u2_8000.htk"))
+        shutil.copy(os.path.join(td, "e.csv"), os.path.join(out, "mfcc_e_u2_8000.csv"))
+        conf = os.path.join(lldo.REF_DIR, "config", "mfcc", "MFCC12_E_D_A_Z.conf")
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u2.wav"), "-O", os.path.join(td, "ez.htk"), "-l", "0"],
+                       check=True, cwd=td)
+        shutil.copy(os.path.join(td, "ez.htk"), os.path.join(out, "mfcc_e_z_u2_8000.htk"))
         # ComParE_2016: the 130-column LLD level as CSV + HTK
         conf = os.path.join(lldo.REF_DIR, "config", "compare16", "ComParE_2016.conf")
         subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u3.wav"), "-lldcsvoutput", os.path.join(td, "c.csv"),

@@ -234,3 +234,18 @@ def test_plugin_fused_source_component(oracle, golden_synth):
         assert (np.abs(xh - xr) / scale).max() <= 1e-5
         assert ch[0] == cr[0] and ch[1] == cr[1] and ch[2].shape == cr[2].shape    # CSV head line, element names
         assert np.array_equal(ch[2][:, 0], cr[2][:, 0])                 # frameTime column
+
+
+def test_plugin_mfcc_e_z_config_all_overrides(oracle):
+    """config/mfcc/MFCC12_E_D_A_Z.conf, unmodified, every override active (cEnergy's HTK log branch on the raw frames,
+    the reference's own cFullinputMean / cVectorConcat around the HIP components)."""
+    import numpy as _np
+    g = _np.load(os.path.join(ROOT, "tests", "golden", "htk_variants_synth.npz"))
+    from test_oracle_pin_variants import variant_tolerance
+    pcm = g["pcm_u2_16000"]
+    y, tr = _run(oracle, pcm, None, "mfcc/MFCC12_E_D_A_Z.conf")
+    ref = g["MFCC12_E_D_A_Z_u2_16000"]
+    for comp in ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cEnergy", "cDeltaRegression"):
+        assert tr.get(comp, 0) > 0, f"{comp} not routed through the plugin: {tr}"
+    oracle.use_reference_fft(False)
+    variant_tolerance(y, ref, 12, "plugin MFCC12_E_D_A_Z", oracle.htk_variant_chain("MFCC12_E_D_A", pcm))

@@ -172,6 +172,24 @@ def test_smilextract_hip_is09_filelist(tmp_path):
 
 
 @pytest.mark.gpu
+def test_smilextract_hip_mfcc_e_variants(tmp_path):
+    """MFCC12_E_D_A (names incl. pcm_LOGenergy, parmKind 9) and MFCC12_E_D_A_Z (the file's own cHtkSink: parmKind 2886)."""
+    out_htk, out_csv, z_htk = str(tmp_path / "e.htk"), str(tmp_path / "e.csv"), str(tmp_path / "ez.htk")
+    wav = os.path.join(G, "u2_8000.wav")
+    subprocess.run([EXE, "--set", "mfcc12_e_d_a", "-I", wav, "-O", out_htk, "-csvoutput", out_csv], check=True)
+    subprocess.run([EXE, "--set", "mfcc12_e_d_a_z", "-I", wav, "-O", z_htk], check=True)
+    for mine, ref in ((out_htk, "mfcc_e_u2_8000.htk"), (z_htk, "mfcc_e_z_u2_8000.htk")):
+        h, x = read_htk(mine)
+        hr, xr = read_htk(os.path.join(G, ref))
+        assert h == hr and x.shape == xr.shape
+        assert np.array_equal(x[:, 12], xr[:, 12])                      # log energy: bit-exact
+        assert np.abs(x - xr).max() <= 1e-4
+    head, names, vals, _ = parse_csv(out_csv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "mfcc_e_u2_8000.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape
+
+
+@pytest.mark.gpu
 def test_smilextract_hip_compare16_lld(tmp_path):
     """The 130-column LLD level of ComParE_2016: header, instance name, row times (the end-of-input row repeats the
     last frame's time) identical to the reference's files, values within the chain's tolerances."""
