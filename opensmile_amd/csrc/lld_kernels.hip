@@ -281,30 +281,88 @@ hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
 }
 
 // [energy:cEnergy] of the E variants (src/lldcore/energy.cpp:152-185 with log = 1, htkcompatible = 1) on the RAW frame:
-// d = sum (float)(x*x) accumulated in double in sample order, times 32767^2, floored at 1, (float)log(d).
-// One thread per frame, the reference's own summation order (the column is bit-exact). dst[frame * ld + col].
-__global__ void __launch_bounds__(256) lld_log_energy(LldParams P, float *dst, int64_t ld, int col) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.total_frames) return;
-  int lo = 0, hi = P.n_utt;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (P.frame_off[mid] <= g) lo = mid; else hi = mid;
-  }
-  const int16_t *x = P.pcm + P.samp_off[lo] + (g - P.frame_off[lo]) * P.H;
-  double d = 0.0;
-  int i = 0;
-  for (; i + 8 <= P.N; i += 8) {
-    float v[8];
+// d = sum (float)(x*x) accumulated in double in sample order, times 32767^2, floored at 1, (float)log(d) -- the
+// reference's own summation order, so the column is bit-exact. One wave per tile of output rows (the window-chain
+// kernel's tiles), 32 frames at a time: the squares of the frames' common span are staged in LDS (coalesced PCM reads,
+// one pad word per hop so that the 32 lanes' strided reads fall into different banks), then lane f sums frame f.
+constexpr int kEnFrames = 32;
+__global__ void __launch_bounds__(64) lld_log_energy(LldParams P, const int32_t *tile_utt, const int32_t *tile_t0, int tile_rows,
+                                                     float *dst, int64_t ld, int col) {
+  extern __shared__ float s_sq[];
+  const int u = tile_utt[blockIdx.x];
+  const int t_first = tile_t0[blockIdx.x];
+  const int64_t f0 = P.frame_off[u];
+  const int T = (int)(P.frame_off[u + 1] - f0);
+  const int t_end = (t_first + tile_rows < T) ? t_first + tile_rows : T;
+  const int lane = threadIdx.x;
+  for (int tc = t_first; tc < t_end; tc += kEnFrames) {
+    const int nf = (t_end - tc < kEnFrames) ? t_end - tc : kEnFrames;
+    const int span = (nf - 1) * P.H + P.N;
+    __syncthreads();
+    const int pitch = P.H + 1;                            // one pad word per hop: lane-strided reads hit different banks
+    // the PCM of the span in 16-byte vectors (8 samples) from the 16-byte boundary below its first sample; vectors that
+    // would reach past the end of the packed buffer are read sample by sample
+    const float rH = 1.0f / (float)P.H;                   // hop of sample i: floor((i + 0.5) / H), exact for these sizes
+    const int64_t first = P.samp_off[u] + (int64_t)tc * P.H;          // absolute sample index of the span's start
+    const int64_t a16 = first & ~(int64_t)7;
+    const int par = (int)(first - a16);
+    const int nvec = (par + span + 7) >> 3;
+    for (int k0 = lane; k0 < nvec; k0 += 64 * 4) {
+      int16_t r[4][8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = pcm16_to_float(x[i + q]);
+      for (int m = 0; m < 4; ++m) {
+        const int k = k0 + 64 * m;
+        if (k < nvec) {
+          const int64_t s8 = a16 + 8 * (int64_t)k;
+          if (s8 + 8 <= P.pcm_total) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(P.pcm + s8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const float sq = v[q] * v[q]; d += (double)sq; }
+            for (int q = 0; q < 8; ++q) r[m][q] = (int16_t)(w[q >> 1] >> (16 * (q & 1)));
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[m][q] = (s8 + q < P.pcm_total) ? P.pcm[s8 + q] : (int16_t)0;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = k0 + 64 * m;
+        if (k < nvec) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int i = 8 * k + q - par;
+            if (i >= 0 && i < span) {
+              const int h = (int)(((float)i + 0.5f) * rH);
+              const float v = pcm16_to_float(r[m][q]);
+              s_sq[h * pitch + (i - h * P.H)] = v * v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane < nf) {
+      double d = 0.0;
+      for (int h = 0, done = 0; done < P.N; ++h) {        // frame `lane` = hops lane, lane+1, ... of the span
+        const int len = (P.N - done < P.H) ? P.N - done : P.H;
+        const float *row = s_sq + (lane + h) * pitch;
+        int j = 0;
+        for (; j + 8 <= len; j += 8) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = row[j + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) d += (double)v[q];
+        }
+        for (; j < len; ++j) d += (double)row[j];
+        done += len;
+      }
+      d *= 32767.0 * 32767.0;
+      if (d <= 1.0) d = 1.0;
+      dst[(f0 + tc + lane) * ld + col] = (float)log(d) * 1.0f + 0.0f;
+    }
   }
-  for (; i < P.N; ++i) { const float t = pcm16_to_float(x[i]); const float sq = t * t; d += (double)sq; }
-  d *= 32767.0 * 32767.0;
-  if (d <= 1.0) d = 1.0;
-  dst[g * ld + col] = (float)log(d) * 1.0f + 0.0f;
 }
 
 // [cms:cFullinputMean] of the Z variants (src/dspcore/fullinputMean.cpp, multiLoopMode = 0, meanNorm = amean): per column
@@ -322,7 +380,15 @@ __global__ void __launch_bounds__(64) lld_cms(const int64_t *frame_off, int n_ut
   if (lane < n_cols) {
     const float *p = x + f0 * ld_x + lane;
     float m = p[0];
-    for (int t = 1; t < T; ++t) m += p[(int64_t)t * ld_x];
+    int t = 1;
+    for (; t + 8 <= T; t += 8) {                          // eight rows' loads in flight, the sum stays sequential
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(t + q) * ld_x];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m += v[q];
+    }
+    for (; t < T; ++t) m += p[(int64_t)t * ld_x];
     mean[lane] = m / (float)T;
   }
   __syncthreads();
@@ -333,9 +399,13 @@ __global__ void __launch_bounds__(64) lld_cms(const int64_t *frame_off, int n_ut
   }
 }
 
-hipError_t launch_log_energy(const LldParams &P, float *dst, int64_t ld, int col, hipStream_t s) {
-  if (P.total_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_log_energy, dim3((unsigned)((P.total_frames + 255) / 256)), dim3(256), 0, s, P, dst, ld, col);
+hipError_t launch_log_energy(const LldParams &P, const int32_t *d_tile_utt, const int32_t *d_tile_t0, int n_tiles, float *dst,
+                             int64_t ld, int col, hipStream_t s) {
+  if (P.total_frames <= 0 || n_tiles <= 0) return hipSuccess;
+  const int span = (kEnFrames - 1) * P.H + P.N;
+  const size_t lds = sizeof(float) * (size_t)((span / (P.H > 0 ? P.H : 1) + 2) * (P.H + 1));
+  if (lds > 60 * 1024) return hipErrorInvalidValue;      // frame geometry far outside the speech configs
+  hipLaunchKernelGGL(lld_log_energy, dim3((unsigned)n_tiles), dim3(64), lds, s, P, d_tile_utt, d_tile_t0, kChainTile, dst, ld, col);
   return hipGetLastError();
 }
 

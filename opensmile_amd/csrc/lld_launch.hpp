@@ -27,7 +27,8 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
 hipError_t launch_chain(const ChainParams &P, hipStream_t s);
-hipError_t launch_log_energy(const LldParams &P, float *dst, int64_t ld, int col, hipStream_t s);
+hipError_t launch_log_energy(const LldParams &P, const int32_t *d_tile_utt, const int32_t *d_tile_t0, int n_tiles, float *dst,
+                             int64_t ld, int col, hipStream_t s);
 hipError_t launch_cms(const int64_t *d_frame_off, int n_utt, const float *x, int64_t ld_x, float *out, int64_t ld_out, int n_cols,
                       hipStream_t s);
 hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,

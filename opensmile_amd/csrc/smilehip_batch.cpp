@@ -293,7 +293,7 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   }
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "mfcc kernel launch failed: %s", hipGetErrorString(e));
   if (plan->cfg.append_log_energy) {                   // E variants: [energy:cEnergy] into the static block's last column
-    e = launch_log_energy(P, P.out, P.ld_out, n_cep, s);
+    e = launch_log_energy(P, b->d_dtile_utt.p, b->d_dtile_t0.p, b->n_dtiles, P.out, P.ld_out, n_cep, s);
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "log-energy kernel launch failed: %s", hipGetErrorString(e));
   }
   if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));

@@ -25,7 +25,11 @@ def main():
     pcm, off = synth.corpus_tiled(args.utts, 160000, n_unique=32)
     d_pcm = torch.from_numpy(pcm).cuda()
     for name in args.sets.split(","):
-        cfg = {"is09": capi.is09_lld_config, "compare": capi.compare16_ab_config, "mfcc": capi.mfcc12_0_d_a_config,
+        if name.upper() in ("MFCC12_E_D_A", "MFCC12_0_D_A_Z", "MFCC12_E_D_A_Z", "PLP_E_D_A", "PLP_0_D_A_Z", "PLP_E_D_A_Z"):
+            cfg_fn = (lambda n=name.upper(): capi.htk_variant_config(n))
+        else:
+            cfg_fn = None
+        cfg = cfg_fn() if cfg_fn else {"is09": capi.is09_lld_config, "compare": capi.compare16_ab_config, "mfcc": capi.mfcc12_0_d_a_config,
                "plp": capi.plp_0_d_a_config, "f0": capi.compare16_f0_config, "compare_full": capi.compare16_config}[name]()
         plan = capi.Plan(ctx, cfg)
         b = capi.Batch(plan, off)
