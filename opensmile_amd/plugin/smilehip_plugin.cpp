@@ -40,6 +40,7 @@
 #include <lldcore/spectral.hpp>
 #include <smileutil/smileUtil.h>
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -962,7 +963,7 @@ class cHipPitchShs : public cPitchShs {
 // feature rows into the level the chain's last component used to write, so that every sink / functional of a config
 // keeps working (conf/MFCC12_0_D_A_hip.conf). A new component type with its own options:
 //   filename    the RIFF/WAVE file (16-bit mono)
-//   featureSet  mfcc12_0_d_a | plp_0_d_a   (the sets whose rows are frames: row time = row * frameStep)
+//   featureSet  mfcc12_{0,e}_d_a[_z] | plp_{0,e}_d_a[_z]   (the sets whose rows are frames: row time = row * frameStep)
 #define COMPONENT_NAME_CHIPLLDSOURCE "cHipLldSource"
 #define COMPONENT_DESCRIPTION_CHIPLLDSOURCE "Reads a wave file and writes the LLD rows of a whole feature set, computed by the fused HIP kernels of libsmilehip, to a dataMemory level."
 class cHipLldSource : public cDataSource {
@@ -975,10 +976,11 @@ class cHipLldSource : public cDataSource {
   bool ran_ = false;
   cMatrix *block_ = nullptr;
 
-  void config_for(smilehip_lld_config &c) {
-    if (set_ == "plp_0_d_a") smilehip_config_plp_0_d_a(&c);
-    else if (set_ == "mfcc12_0_d_a") smilehip_config_mfcc12_0_d_a(&c);
-    else COMP_ERR("cHipLldSource: unknown featureSet '%s' (mfcc12_0_d_a, plp_0_d_a)", set_.c_str());
+  void config_for(smilehip_lld_config &c) {              // any of the eight files of config/mfcc and config/plp, by name
+    std::string up;
+    for (char ch : set_) up += (char)toupper((unsigned char)ch);
+    if (smilehip_config_htk_variant(&c, up.c_str()) != SMILEHIP_OK)
+      COMP_ERR("cHipLldSource: unknown featureSet '%s' (mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z])", set_.c_str());
   }
   void run_once() {
     smilehip_host::WaveInfo wi;
@@ -1012,7 +1014,7 @@ class cHipLldSource : public cDataSource {
     config_for(c);
     period_sec_ = c.frame_step_sec;
     frame_size_sec_ = c.frame_size_sec;
-    names_ = (set_ == "plp_0_d_a") ? smilehip_host::lld_names_plp_0_d_a() : smilehip_host::lld_names_mfcc12_0_d_a();
+    names_ = smilehip_host::lld_names_htk_variant(c.chain_kind == SMILEHIP_CHAIN_PLP, c.append_log_energy != 0);
     n_cols_ = (int)names_.size();
   }
   int configureWriter(sDmLevelConfig &c) override {
@@ -1078,7 +1080,7 @@ SMILECOMPONENT_REGCOMP(cHipLldSource) {
   SMILECOMPONENT_INHERIT_CONFIGTYPE("cDataSource")
   SMILECOMPONENT_IFNOTREGAGAIN(
     ct->setField("filename", "The RIFF/WAVE file to process (16-bit mono PCM)", "input.wav");
-    ct->setField("featureSet", "The feature set whose LLD rows are produced: mfcc12_0_d_a (config/mfcc/MFCC12_0_D_A.conf) or plp_0_d_a (config/plp/PLP_0_D_A.conf)", "mfcc12_0_d_a");
+    ct->setField("featureSet", "The feature set whose LLD rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z", "mfcc12_0_d_a");
   )
   SMILECOMPONENT_MAKEINFO(cHipLldSource);
 }

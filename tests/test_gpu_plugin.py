@@ -209,7 +209,8 @@ def test_plugin_fused_source_component(oracle, golden_synth):
     if not (os.path.exists(exe) and os.path.exists(plug)):
         pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
     from test_host_io import parse_csv
-    for key, fset, conf_ref in (("u2_16000", "mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf"), ("u3_16000", "plp_0_d_a", "plp/PLP_0_D_A.conf")):
+    for key, fset, conf_ref in (("u2_16000", "mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf"), ("u3_16000", "plp_0_d_a", "plp/PLP_0_D_A.conf"),
+                                ("u3_16000", "mfcc12_e_d_a", "mfcc/MFCC12_E_D_A.conf")):
         pcm = golden_synth["pcm_" + key]
         with tempfile.TemporaryDirectory() as td:
             wav = os.path.join(td, "in.wav")
