@@ -148,6 +148,172 @@ __device__ __forceinline__ void spectral_frame(const float *mg, const float *pw,
   __syncthreads();
 }
 
+// ---- the same sums with ONE wave per frame: lane l plays the four threads l, l+64, l+128, l+192 of the block version
+// (index w = the block version's wave), so every reduction keeps the block version's tree: shuffle-down inside each group
+// of 64, then ((s0 + s1) + s2) + s3 -- the results are bit-identical to block_sum_n / spectral_frame.
+template <int NV>
+__device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      double x = v[w][i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      s[w] = __shfl(x, 0, 64);
+    }
+    tot[i] = ((s[0] + s[1]) + s[2]) + s[3];
+  }
+}
+
+// spectral_frame for one wave (K = 257): no LDS scratch, no barriers. mg / pw / prev as above; sp[0..14] written by lane 0
+// (roll-off points by the lane that owns the crossing bin).
+__device__ __forceinline__ void spectral_frame_wave(const float *mg, const float *pw, const float *prev, bool first,
+                                                    const SpectralConsts &C, int K, float *sp) {
+  const double F0 = 1.0 / C.fsSec;
+  const int lo = 1, hi = K - 1, nBins = K - 1;
+  const int lane = threadIdx.x & 63;
+  float pf[4];
+  double p[4], fj[4], v1[4][6];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int tid = lane + 64 * w, j = tid + 1;
+    pf[w] = pw[j];
+    p[w] = (double)pf[w];
+    fj[w] = F0 * j;
+    v1[w][0] = p[w];
+    v1[w][1] = fj[w] * p[w];
+    v1[w][2] = C.sharp_w[tid] * p[w];
+    { const double myB = (double)mg[j] - (double)prev[j]; v1[w][3] = first ? 0.0 : myB * myB; }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      auto part = [&](int k) {
+        const double pk = (double)pw[k];
+        double c = 0.0;
+        if (k == C.band_iL[b]) c += pk * C.band_wL[b];
+        if (k > C.band_iL[b] && k < C.band_iR[b]) c += pk;
+        if (k == C.band_iR[b]) c += pk * C.band_wR[b];
+        return c;
+      };
+      v1[w][4 + b] = part(j) + (tid == 0 ? part(0) : 0.0);
+    }
+  }
+  double t1v[6];
+  wave_sum4<6>(v1, t1v);
+  const double frameSum = t1v[0], sumA = t1v[1];
+  float ctr = 0.0f;
+  if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
+  // roll-off: inclusive prefix in the block version's order (scan inside each group of 64, then + the earlier groups' totals)
+  {
+    double c[4], red[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      double x = p[w];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
+      red[w] = __shfl(x, 63, 64);
+      c[w] = x;
+    }
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+      for (int w2 = 0; w2 < w; ++w2) c[w] += red[w2];
+    const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int tid = lane + 64 * w, j = tid + 1;
+      const double up1 = __shfl_up(c[w], 1, 64);
+      const double prev63 = __shfl(c[w > 0 ? w - 1 : 0], 63, 64);
+      const double before = (lane == 0) ? (w == 0 ? -1.0 : prev63) : up1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double th = rollOff[i] * frameSum;
+        if (c[w] >= th && (tid == 0 || !(before >= th))) sp[2 + i] = (float)(F0 * j);
+      }
+    }
+  }
+  // harmonicity: alternating peaks/valleys, distance to the previous one
+  float hc[4];
+  {
+    float pk_val[4];
+    bool pk_has[4];
+    bool flag[4];
+    unsigned long long lower[4];
+    float prevw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j = lane + 64 * w + 1;
+      flag[w] = false;
+      if (j >= lo + 2 && j < hi - 1)
+        flag[w] = (pw[j - 2] < pf[w] && pw[j - 1] < pf[w] && pf[w] > pw[j + 1] && pf[w] > pw[j + 2]) ||
+                  (pw[j - 2] > pf[w] && pw[j - 1] > pf[w] && pf[w] < pw[j + 1] && pf[w] < pw[j + 2]);
+      const unsigned long long mask = __ballot(flag[w]);
+      lower[w] = mask & ((1ull << lane) - 1ull);
+      const int src = lower[w] ? 63 - __clzll((long long)lower[w]) : 0;
+      prevw[w] = __shfl(pf[w], src, 64);
+      pk_has[w] = mask != 0ull;
+      pk_val[w] = __shfl(pf[w], mask ? 63 - __clzll((long long)mask) : 0, 64);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      hc[w] = 0.0f;
+      if (flag[w]) {
+        if (lower[w]) hc[w] = fabsf(pf[w] - prevw[w]);
+        else {
+          bool found = false;
+#pragma unroll
+          for (int w2 = 3; w2 >= 0; --w2)
+            if (w2 < w && !found && pk_has[w2]) { hc[w] = fabsf(pf[w] - pk_val[w2]); found = true; }
+        }
+      }
+    }
+  }
+  double v2[4][5];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const double entropy_floor = 0.0000001;
+    double dn = frameSum;
+    if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+    double v = p[w];
+    if (v <= entropy_floor) v = entropy_floor;
+    const double ln = v / dn;
+    v2[w][0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
+    const double t1 = fj[w] - (double)ctr;
+    double m = t1 * t1 * p[w];
+    v2[w][1] = m; m *= t1; v2[w][2] = m; v2[w][3] = m * t1;
+    v2[w][4] = (double)hc[w];
+  }
+  double t2v[5];
+  wave_sum4<5>(v2, t2v);
+  if (lane == 0) {
+    sp[0] = (float)(t1v[4] / (double)nBins);
+    sp[1] = (float)(t1v[5] / (double)nBins);
+    float c2 = 0.0f;
+    const float sumAA = (float)t1v[2];
+    if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
+    sp[13] = (float)(0.11 * c2);
+    const double flux = t1v[3] / (double)nBins;
+    sp[6] = (!first && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+    sp[7] = ctr;
+    sp[8] = (float)(-t2v[0]);
+    const double sumB = frameSum;
+    const double sigma2 = (sumB != 0.0) ? t2v[1] / sumB : 0.0;
+    sp[9] = (float)sigma2;
+    sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(t2v[2] / (sumB * sigma2 * sqrt(sigma2)));
+    sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(t2v[3] / (sumB * sigma2 * sigma2));
+    const double Nind = (double)nBins;
+    const double deno = (Nind * C.slope_S2f - C.slope_Sf * C.slope_Sf);
+    double slope = 0.0;
+    if (deno != 0.0) slope = (Nind * sumA - C.slope_Sf * sumB) / deno;
+    sp[12] = (float)(slope * (Nind - 1.0));
+    float ptpSum = (float)t2v[4];
+    ptpSum /= 2.0f;
+    ptpSum /= (float)nBins;
+    sp[14] = ptpSum;
+  }
+}
+
 // R8 cPlp as auditory spectrum, one band (plp.cpp:416-593 with doAud = 1, doIDFT = doLP = 0).
 // Without RASTA: melfloor, x equal loudness, power-law compression through double pow (:499-507).
 __device__ __forceinline__ float plp_aud_band(float mel, float melfloor, float eql, float compression) {

@@ -14,6 +14,9 @@
 // Group B's SMA + delta run through the generic window chain (lld_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+#include "lld_blocks.hpp"
 #include "lld_blocks_compare.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
@@ -25,6 +28,27 @@ namespace {
 constexpr int kRun = 8;          // frames per workgroup (the flux needs the previous frame's magnitudes)
 
 }  // namespace
+
+// Development instrumentation (-DSMILEHIP_PHASE_TIMING in a private build, tools/ubench): s_memtime at the phase
+// boundaries of the frame loop, summed over all workgroups by thread 0. Not compiled into the product.
+#ifdef SMILEHIP_PHASE_TIMING
+__device__ unsigned long long g_phase_cmp[16];
+#define PHASE_DECL unsigned long long ph_acc[8] = {0}; unsigned long long ph_last = __builtin_amdgcn_s_memtime();
+#define PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
+#define PHASE_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_cmp[i_], ph_acc[i_]); } while (0)
+extern "C" int smilehip_debug_phase_cmp(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cmp), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cmp), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#endif
 
 // LDS: yv[N] | re[M] | im[M] | mg[K] | pw[K] | prev[K] | mel[32] | aud[32] | lmel[32] | double red[64] | double cum[256] | peaks
 // Nfft = 512 only: thread i of the 256 owns bin i+1 in the descriptor section.
@@ -45,6 +69,14 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   double *cum = red + 64;
   float *pk_val = reinterpret_cast<float *>(cum + 256);   // [4] last peak of each wave
   int *pk_has = reinterpret_cast<int *>(pk_val + 4);      // [4]
+  // tables of the mel / MFCC section, staged once per workgroup (the few threads that walk them would otherwise wait
+  // on global memory at every step): mel weights [Kpad], band ranges [4 x 32], DCT rows [16 x 32]
+  float *s_coef = reinterpret_cast<float *>(pk_has + 4);
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + Kpad);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
@@ -66,6 +98,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  PHASE_DECL
 
   // frames t0-1 (magnitudes only, for the flux) .. t_last-1
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
@@ -83,13 +116,16 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
     }
     __syncthreads();
+    PHASE(0);   // load + window
     block_cfft_radix2(re, im, M, P.tw_half);
+    PHASE(1);   // FFT
     for (int k = threadIdx.x; k <= M; k += blockDim.x) {
       const float m = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;                                    // squareInput (spectral.cpp:676-683) == melspec usePower
     }
     __syncthreads();
+    PHASE(2);   // magnitudes
     if (warm) {
       for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
       __syncthreads();
@@ -97,7 +133,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
     }
     // R6 once, two scalings: [is13_melspec1] (htk=0) feeds cPlp, [is13_melspecMfcc] (htk=1) feeds cMfcc
     for (int b = threadIdx.x; b < P.n_bands; b += blockDim.x) {
-      const float acc = mel_band_exact(pw, P.mel_coef, P.mel_rng, b, 1.0f);
+      const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
       melv[b] = acc;
       // log mel spectrum for the RASTA pass (doLog, plp.cpp:434-439; double log = correctly rounded logf)
       Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
@@ -107,12 +143,13 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
     }
     __syncthreads();
     for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
-      rawB[41 + r] = dct_coeff(lmel, P.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);   // R7
+      rawB[41 + r] = dct_coeff(lmel, s_dct + r * P.n_bands, P.n_bands, P.dct_gain[r]);   // R7
     if (threadIdx.x == 192) {                           // cVectorOperation ll1, vectorOperation.cpp:475-481
       float d = 0.0f;
       for (int i = 0; i < P.n_bands; i++) d += aud[i];
       rawA[0] = d / (float)P.n_bands;
     }
+    PHASE(3);   // mel, auditory spectrum, MFCC
     // R12: energy of the raw 20 ms frame (energy.cpp:152-168) and ZCR of the 60 ms frame (mzcr.cpp:117-124)
     {
       const int tid = threadIdx.x;
@@ -129,10 +166,133 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
         if (t < T60) rawA[3] = (float)v0[1] / (float)Q.N60;
       }
     }
+    PHASE(4);   // energy + ZCR
     // R11: the 15 spectral descriptors, block-parallel (lld_blocks_compare.hpp)
     spectral_frame(mg, pw, prev, t == 0, SC, K, red, cum, pk_val, pk_has, rawB + 26);
     for (int k = threadIdx.x; k < K; k += blockDim.x) prev[k] = mg[k];
     __syncthreads();
+    PHASE(5);   // spectral descriptors
+  }
+  PHASE_FLUSH;
+}
+
+// The same frame pipeline with ONE wave per frame and four independent runs per workgroup: no workgroup barriers after
+// the table staging, the thinly parallel sections (26 mel bands, 14 cepstra, scalar tails) of four frames overlap. Every sum
+// keeps the block kernel's order (lld_blocks_compare.hpp), so the two kernels give bit-identical rows.
+// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave yv[Npad] | re[M] | im[M] | mg[Kpad] | pw[Kpad] | prev[Kpad] |
+// mel[32] | aud[32] | lmel[32]
+__global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = P.Nfft >> 1, K = P.K;
+  const int Npad = (P.N + 3) & ~3, Kpad = (K + 3) & ~3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *s_coef = smem;
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + Kpad);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
+  __syncthreads();                                       // the only workgroup barrier
+  const int run = blockIdx.x * 4 + wave;
+  if (run >= n_runs) return;
+  const int per_wave = Npad + 2 * M + 3 * Kpad + 96;
+  float *yv = s_dct + 16 * 32 + wave * per_wave;
+  float *re = yv + Npad;
+  float *im = re + M;
+  float *mg = im + M;
+  float *pw = mg + Kpad;
+  float *prev = pw + Kpad;
+  float *melv = prev + Kpad;
+  float *aud = melv + 32;
+  float *lmel = aud + 32;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+
+  const int u = Q.run_utt[run];
+  const int t0 = Q.run_t0[run];
+  const int64_t f0 = P.frame_off[u];
+  const int T20 = (int)(P.frame_off[u + 1] - f0);
+  const int64_t s_utt = P.samp_off[u];
+  const int64_t utt_len = P.samp_off[u + 1] - s_utt;
+  const int T60 = (utt_len >= Q.N60) ? (int)((utt_len - Q.N60) / P.H + 1) : 0;
+  const int16_t *xu = P.pcm + s_utt;
+  SpectralConsts SC;
+  SC.fsSec = Q.fsSec;
+  SC.sharp_w = Q.sharp_w;
+  for (int i = 0; i < 2; ++i) {
+    SC.band_iL[i] = Q.band_iL[i]; SC.band_iR[i] = Q.band_iR[i];
+    SC.band_wL[i] = Q.band_wL[i]; SC.band_wR[i] = Q.band_wR[i];
+  }
+  SC.slope_Sf = Q.slope_Sf;
+  SC.slope_S2f = Q.slope_S2f;
+  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+    const bool warm = t < t0;
+    const int16_t *x = xu + (int64_t)t * P.H;
+    float *rawA = Q.rawA + (f0 + t) * 4;
+    float *rawB = Q.rawB + (f0 + t) * 55;
+    for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
+    WaveG::sync();
+    for (int i = lane; i < M; i += 64) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
+      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+    }
+    WaveG::sync();
+    group_cfft_radix2<WaveG>(re, im, M, P.tw_half);
+    for (int k = lane; k <= M; k += 64) {
+      const float m = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
+      mg[k] = m;
+      pw[k] = m * m;
+    }
+    WaveG::sync();
+    if (warm) {
+      for (int k = lane; k < K; k += 64) prev[k] = mg[k];
+      WaveG::sync();
+      continue;
+    }
+    if (lane < P.n_bands) {
+      const int b = lane;
+      const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
+      melv[b] = acc;
+      Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
+      aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
+    }
+    WaveG::sync();
+    if (lane < P.n_mfcc) rawB[41 + lane] = dct_coeff(lmel, s_dct + lane * P.n_bands, P.n_bands, P.dct_gain[lane]);   // R7
+    if (lane == 32) {                                    // cVectorOperation ll1, vectorOperation.cpp:475-481
+      float d = 0.0f;
+      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      rawA[0] = d / (float)P.n_bands;
+    }
+    // R12 in the block kernel's summation order: lane l holds the partial sums of its threads l, l+64, l+128, l+192
+    {
+      double v0[4][2];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int tid = lane + 64 * w;
+        v0[w][0] = 0.0; v0[w][1] = 0.0;
+        for (int n = tid; n < P.N; n += 256) { const float tmp = yv[n]; v0[w][0] += tmp * tmp; }
+        if (t < T60)
+          for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
+            const float a = pcm16_to_float(x[i - 1]), b = pcm16_to_float(x[i]), c = pcm16_to_float(x[i + 1]);
+            if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) v0[w][1] += 1.0;
+          }
+      }
+      double tot[2];
+      wave_sum4<2>(v0, tot);
+      if (lane == 0) {
+        rawA[2] = (float)sqrt(tot[0] / (float)P.N) * 1.0f + 0.0f;
+        if (t < T60) rawA[3] = (float)tot[1] / (float)Q.N60;
+      }
+    }
+    spectral_frame_wave(mg, pw, prev, t == 0, SC, K, rawB + 26);
+    WaveG::sync();
+    for (int k = lane; k < K; k += 64) prev[k] = mg[k];
+    WaveG::sync();
   }
 }
 
@@ -236,8 +396,15 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
   if (P.Nfft != 512) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96) + sizeof(double) * (64 + 256) + 32;
-  hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
+  static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks)
+  if (use_block) {
+    const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96) + sizeof(double) * (64 + 256) + 32 +
+                       sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
+    hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
+  } else {
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (Npad + 2 * M + 3 * Kpad + 96));
+    hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_compare_rasta, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q);

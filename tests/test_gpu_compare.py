@@ -65,3 +65,30 @@ def test_compare_ab_rerun_is_deterministic(hip):
     a2 = b.run_host(pcm)
     assert np.array_equal(a1.view(np.uint32), a2.view(np.uint32))
     b.close()
+
+
+def test_compare_wave_kernel_equals_block_kernel(tmp_path):
+    """The wave-per-frame frame kernel keeps the summation order of the workgroup-per-run kernel (SMILEHIP_COMPARE_BLOCK=1
+    selects the latter at its first launch, hence two processes): bit-identical rows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from opensmile_amd import capi, synth\n"
+        "ctx = capi.Context(0); plan = capi.Plan(ctx, capi.compare16_ab_config())\n"
+        "lens = [48000, 1600, 9000, 160000, 2720]\n"
+        "off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)\n"
+        "pcm = np.concatenate([synth.utterance(40 + i, n) for i, n in enumerate(lens)])\n"
+        "b = capi.Batch(plan, off); np.save(sys.argv[1], b.run_host(pcm))\n" % root)
+    outs = []
+    for tag, env_extra in (("wave", {}), ("block", {"SMILEHIP_COMPARE_BLOCK": "1"})):
+        path = str(tmp_path / (tag + ".npy"))
+        env = dict(os.environ)
+        env.update(env_extra)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+        outs.append(np.load(path))
+    assert outs[0].shape == outs[1].shape and outs[0].shape[1] == 118
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
