@@ -265,6 +265,73 @@ int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *batch, const
 int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t ld_x, int64_t rows, int32_t cols,
                                 uint32_t mask, float *d_out, void *stream);
 
+/* ---- general functionals: any cFunctionals instance -------------------
+ * One instance = the ordered family list `functionalsEnabled` (src/functionals/functionals.cpp:179-222) plus the
+ * options of each family. Bit i of a family mask enables the family's value i in the reference's own enab[] order,
+ * which is also its output order:
+ *   Extremes    (functionalExtremes.cpp:91-134)    max min range maxPos minPos amean maxameandist minameandist
+ *   Means       (functionalMeans.cpp:115-259)      amean absmean qmean nzamean nzabsmean nzqmean nzgmean nnz flatness
+ *                                                  posamean negamean posqmean posrqmean negqmean negrqmean rqmean nzrqmean
+ *   Moments     (functionalMoments.cpp:88-165)     variance stddev skewness kurtosis amean stddevNorm
+ *   Regression  (functionalRegression.cpp:142-425) linregc1 linregc2 linregerrA linregerrQ qregc1 qregc2 qregc3 qregerrA
+ *                                                  qregerrQ centroid qregls qregrs qregx0 qregy0 qregyr qregy0nn qregc3nn qregyrnn
+ *   Percentiles (functionalPercentiles.cpp:312-417) quartile1..3 iqr1-2 iqr2-3 iqr1-3, percentile[], pctlrange[]
+ *   Times       (functionalTimes.cpp:213-367)      up/downleveltime25,50,75,90 risetime falltime leftctime rightctime duration
+ *   Segments    (functionalSegments.cpp:309-367, 656-725, 801-958; relTh and nonX) numSegments meanSegLen maxSegLen
+ *                                                  minSegLen segLenStddev
+ *   Lpc         (functionalLpc.cpp:95-119)         lpgain, lpc[first..order)
+ *   Peaks2      (functionalPeaks2.cpp:316-905)     its 32 values in the order of functionalPeaks2.cpp:60-67
+ * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
+ * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
+ * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange, the other
+ * segmentation algorithms, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
+enum {
+  SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
+  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_COUNT
+};
+enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
+enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1 };
+
+typedef struct smilehip_func_spec {
+  int32_t n_fam;
+  int32_t fam[12];              /* functionalsEnabled, in order */
+  int32_t non_zero_functs;      /* cFunctionals.nonZeroFuncts: 0, 1 (x != 0), 2 (x > 0) */
+  int32_t reserved0;
+  double period;                /* period of the input level in seconds */
+  uint32_t ext_mask; int32_t ext_norm;
+  uint32_t means_mask; int32_t means_norm;
+  uint32_t mom_mask; int32_t mom_stddev_norm; int32_t mom_ratio_limit; int32_t reserved1;
+  uint32_t reg_mask; int32_t reg_centroid_norm, reg_norm_coeff, reg_norm_inputs, reg_centroid_abs,
+      reg_centroid_limit, reg_ratio_limit, reg_old_buggy_qerr;
+  uint32_t pct_mask; int32_t pct_interp, n_pctl, n_range;
+  double pctl[8]; int32_t range_a[8], range_b[8];
+  uint32_t times_mask; int32_t times_norm, times_buggy_sec_norm, reserved2;
+  uint32_t seg_mask; int32_t seg_norm, seg_algo, seg_max_num, seg_min_lng, seg_auto_min_lng, seg_pause_min_lng,
+      seg_x_is_rel, seg_n_thresholds, reserved3;
+  float seg_x; float seg_thresholds[8]; float reserved4;
+  int32_t lpc_gain, lpc_coeffs, lpc_first, lpc_order;      /* order <= 16 */
+  uint32_t pk_mask; int32_t pk_norm, pk_ratio_limit, pk_dyn_rel, pk_use_abs, reserved5;
+  float pk_rel_thresh, pk_abs_thresh;
+} smilehip_func_spec;
+
+/* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */
+int smilehip_funcspec_count(const smilehip_func_spec *spec);
+/* The six cFunctionals instances of config/compare16/ComParE_2016_core.func.conf.inc: "A", "B", "F0", "Nz", "LLD",
+ * "Delta" ([is13_functionalsA] ... [is13_functionalsDelta]); period = 0.01 s. */
+int smilehip_funcspec_compare16(const char *instance, smilehip_func_spec *spec);
+/* cFunctionals::doProcess for every column of ONE matrix (rows x cols, leading dimension ld_x, all rows): d_out
+ * receives cols * count(spec) floats, element-major (column c's values at [c*count, (c+1)*count)). Scratch is owned
+ * by the context and grown on demand. Asynchronous on `stream`. */
+int smilehip_funcspec_matrix(smilehip_context *ctx, const smilehip_func_spec *spec, const float *d_x, int64_t ld_x,
+                             int64_t rows, int32_t cols, float *d_out, void *stream);
+/* The same over a batch's LLD matrix: for each utterance, columns [col_first, col_first + n_cols) of its rows
+ * 0 .. rows_u - rows_cut - 1 (at least one row if the utterance has any), optionally followed by ONE more row taken from
+ * d_extra[u * ld_extra + (0 .. n_cols)] (NULL: none). d_func: n_utt x ld_func, n_cols * count(spec) values per
+ * utterance (zeros for utterances without rows). */
+int smilehip_batch_funcspec(smilehip_plan *plan, smilehip_batch *batch, const smilehip_func_spec *spec,
+                            const float *d_lld, int64_t ld_lld, int32_t col_first, int32_t n_cols, int32_t rows_cut,
+                            const float *d_extra, int64_t ld_extra, float *d_func, int64_t ld_func, void *stream);
+
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */
 int  smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr);

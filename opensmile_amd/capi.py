@@ -48,6 +48,31 @@ class LldConfig(C.Structure):
 STAGE_WINDOW, STAGE_FFT, STAGE_MEL, STAGE_MFCC, STAGE_ALL = 1, 2, 4, 8, 15
 
 
+class FuncSpec(C.Structure):
+    """smilehip_func_spec (include/smilehip.h), field for field: one cFunctionals instance."""
+    _fields_ = [
+        ("n_fam", C.c_int32), ("fam", C.c_int32 * 12), ("non_zero_functs", C.c_int32), ("reserved0", C.c_int32),
+        ("period", C.c_double),
+        ("ext_mask", C.c_uint32), ("ext_norm", C.c_int32),
+        ("means_mask", C.c_uint32), ("means_norm", C.c_int32),
+        ("mom_mask", C.c_uint32), ("mom_stddev_norm", C.c_int32), ("mom_ratio_limit", C.c_int32), ("reserved1", C.c_int32),
+        ("reg_mask", C.c_uint32), ("reg_centroid_norm", C.c_int32), ("reg_norm_coeff", C.c_int32),
+        ("reg_norm_inputs", C.c_int32), ("reg_centroid_abs", C.c_int32), ("reg_centroid_limit", C.c_int32),
+        ("reg_ratio_limit", C.c_int32), ("reg_old_buggy_qerr", C.c_int32),
+        ("pct_mask", C.c_uint32), ("pct_interp", C.c_int32), ("n_pctl", C.c_int32), ("n_range", C.c_int32),
+        ("pctl", C.c_double * 8), ("range_a", C.c_int32 * 8), ("range_b", C.c_int32 * 8),
+        ("times_mask", C.c_uint32), ("times_norm", C.c_int32), ("times_buggy_sec_norm", C.c_int32), ("reserved2", C.c_int32),
+        ("seg_mask", C.c_uint32), ("seg_norm", C.c_int32), ("seg_algo", C.c_int32), ("seg_max_num", C.c_int32),
+        ("seg_min_lng", C.c_int32), ("seg_auto_min_lng", C.c_int32), ("seg_pause_min_lng", C.c_int32),
+        ("seg_x_is_rel", C.c_int32), ("seg_n_thresholds", C.c_int32), ("reserved3", C.c_int32),
+        ("seg_x", C.c_float), ("seg_thresholds", C.c_float * 8), ("reserved4", C.c_float),
+        ("lpc_gain", C.c_int32), ("lpc_coeffs", C.c_int32), ("lpc_first", C.c_int32), ("lpc_order", C.c_int32),
+        ("pk_mask", C.c_uint32), ("pk_norm", C.c_int32), ("pk_ratio_limit", C.c_int32), ("pk_dyn_rel", C.c_int32),
+        ("pk_use_abs", C.c_int32), ("reserved5", C.c_int32),
+        ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
+    ]
+
+
 class Geometry(C.Structure):
     """smilehip_geometry"""
     _fields_ = [("frame_size", C.c_int64), ("frame_step", C.c_int64), ("fft_size", C.c_int64),
@@ -78,6 +103,10 @@ SYMBOLS = {
     "smilehip_functionals_matrix": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_uint32, _vp, _vp]),
     "smilehip_batch_func_rows": (C.c_int, [_vp, _vp]),
     "smilehip_batch_functionals": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint32, _vp, _i64, _vp]),
+    "smilehip_funcspec_count": (C.c_int, [_vp]),
+    "smilehip_funcspec_compare16": (C.c_int, [C.c_char_p, _vp]),
+    "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
+    "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
@@ -183,6 +212,41 @@ def compare16_f0_config():
     c = LldConfig()
     load().smilehip_config_compare16_f0(C.byref(c))
     return c
+
+
+def funcspec_compare16(instance):
+    """One of ComParE_2016's six cFunctionals instances: "A", "B", "F0", "Nz", "LLD", "Delta"."""
+    s = FuncSpec()
+    _check(load().smilehip_funcspec_compare16(instance.encode(), C.byref(s)))
+    return s
+
+
+def funcspec_count(spec):
+    n = load().smilehip_funcspec_count(C.byref(spec))
+    if n < 0:
+        _check(n)
+    return n
+
+
+def funcspec_matrix_host(ctx, spec, x):
+    """rows x cols host matrix -> cols x count(spec) functionals through smilehip_funcspec_matrix."""
+    L = load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, cols = x.shape
+    per = funcspec_count(spec)
+    out = np.zeros((cols, per), np.float32)
+    d_x, d_out = _vp(), _vp()
+    _check(L.smilehip_alloc(ctx._h, max(x.nbytes, 4), C.byref(d_x)))
+    _check(L.smilehip_alloc(ctx._h, max(out.nbytes, 4), C.byref(d_out)))
+    try:
+        _check(L.smilehip_copy_to_device(ctx._h, d_x, x.ctypes.data, x.nbytes, None))
+        _check(L.smilehip_funcspec_matrix(ctx._h, C.byref(spec), d_x, cols, rows, cols, d_out, None))
+        _check(L.smilehip_stream_synchronize(ctx._h, None))
+        _check(L.smilehip_copy_to_host(ctx._h, out.ctypes.data, d_out, out.nbytes, None))
+    finally:
+        L.smilehip_free(ctx._h, d_x)
+        L.smilehip_free(ctx._h, d_out)
+    return out
 
 
 def is09_lld_config():
@@ -378,6 +442,39 @@ class Batch:
         finally:
             L.smilehip_free(ctx, d_lld)
             L.smilehip_free(ctx, d_out)
+        return out
+
+    def funcspec_host(self, lld, spec, col_first, n_cols, rows_cut, extra=None):
+        """lld: the matrix run_host returned -> n_utt x (n_cols * count(spec)) through smilehip_batch_funcspec;
+        extra: optional n_utt x n_cols matrix, one more row per utterance."""
+        L = load()
+        per = funcspec_count(spec)
+        lld = np.ascontiguousarray(lld, dtype=np.float32)
+        ld = lld.shape[1]
+        assert lld.shape[0] == self.total_rows
+        out = np.zeros((self.n_utt, n_cols * per), np.float32)
+        ctx = self.plan.ctx._h
+        d_lld, d_out, d_ex = _vp(), _vp(), _vp()
+        _check(L.smilehip_alloc(ctx, max(lld.nbytes, 4), C.byref(d_lld)))
+        _check(L.smilehip_alloc(ctx, max(out.nbytes, 4), C.byref(d_out)))
+        try:
+            if extra is not None:
+                extra = np.ascontiguousarray(extra, dtype=np.float32)
+                assert extra.shape == (self.n_utt, n_cols)
+                _check(L.smilehip_alloc(ctx, max(extra.nbytes, 4), C.byref(d_ex)))
+                _check(L.smilehip_copy_to_device(ctx, d_ex, extra.ctypes.data, extra.nbytes, None))
+            if lld.nbytes:
+                _check(L.smilehip_copy_to_device(ctx, d_lld, lld.ctypes.data, lld.nbytes, None))
+            _check(L.smilehip_batch_funcspec(self.plan._h, self._h, C.byref(spec), d_lld, ld, col_first, n_cols, rows_cut,
+                                             d_ex if extra is not None else None, n_cols, d_out, n_cols * per, None))
+            _check(L.smilehip_stream_synchronize(ctx, None))
+            if out.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, out.ctypes.data, d_out, out.nbytes, None))
+        finally:
+            L.smilehip_free(ctx, d_lld)
+            L.smilehip_free(ctx, d_out)
+            if extra is not None:
+                L.smilehip_free(ctx, d_ex)
         return out
 
     def close(self):

@@ -1,0 +1,1135 @@
+// General functionals: any cFunctionals instance -- the nine families the ComParE_2016 set
+// uses -- over the columns of LLD matrices.
+//   cFunctionals::doProcess          src/functionals/functionals.cpp:320-389
+//   cFunctionalExtremes / Means / Moments / Regression / Percentiles / Times / Segments / Lpc / Peaks2 ::process
+//                                    src/functionals/functional*.cpp (line ranges in include/smilehip.h)
+// Mapping: ONE THREAD PER (utterance, column). Most of these functionals are order-sensitive scans (double sums in
+// index order, state machines over the contour, a linked list of extrema that is pruned in several passes), so a
+// column is walked sequentially by its thread exactly as the reference walks it -- results agree bit for bit up to
+// libm (log / exp) -- and parallelism comes from the 10^5 (utterance, column) pairs of a batch. A wave holds 64
+// neighbouring columns of one utterance, so every step of a scan is one coalesced row segment (256 B) that stays in
+// L2 across the passes. The only stage with a different shape is the sort Percentiles needs: one workgroup per
+// (utterance, column), bitonic network in LDS.
+//   fs_stats      nonZeroFuncts compaction, min / max / mean, N     (functionals.cpp:326-363)
+//   fs_family<F>  one launch per enabled family
+//   fs_percentiles sort + percentile read-out
+// Peaks2's list of local extrema is not materialised: an element is identified by its row index and only an
+// "alive" byte per row is kept; each pruning pass re-derives the extrema from three neighbouring samples.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+
+namespace smilehip {
+
+namespace {
+
+constexpr int kColsPerBlock = 64;
+constexpr int kSortThreads = 256;
+constexpr int kSortLds = 8192;
+
+#define FS_BIT(m, i) (((m) >> (i)) & 1u)
+
+struct Col {                       // one thread's view of its column
+  const float *p;                  // element t at p[t * ld]
+  int64_t ld;
+  int64_t n_main;                  // rows served by p; row n_main (if N > n_main) comes from *pe
+  const float *pe;
+  int64_t N;
+  __device__ __forceinline__ float operator[](int64_t t) const { return t < n_main ? p[t * ld] : *pe; }
+};
+
+struct Where {                     // what a thread works on
+  int u, c;                        // utterance, column inside the instance
+  int64_t srow0;                   // first scratch row of the utterance
+  int64_t rows;                    // rows before nonZeroFuncts
+  bool on;
+};
+
+__device__ __forceinline__ Where locate(const FsParams &P) {
+  Where w;
+  const int groups = (P.n_cols + kColsPerBlock - 1) / kColsPerBlock;
+  w.u = blockIdx.x / groups;
+  w.c = (blockIdx.x % groups) * kColsPerBlock + threadIdx.x;
+  w.on = w.c < P.n_cols;
+  if (P.single_rows >= 0) {
+    w.srow0 = 0;
+    w.rows = P.single_rows;
+  } else {
+    const int64_t r0 = P.row_off[w.u], lld = P.row_off[w.u + 1] - r0;
+    int64_t n = lld - P.rows_cut;
+    if (n < 1) n = lld > 0 ? 1 : 0;
+    if (n > 0 && P.extra) n += 1;
+    w.srow0 = r0 + w.u;
+    w.rows = n;
+  }
+  return w;
+}
+
+__device__ __forceinline__ Col raw_col(const FsParams &P, const Where &w) {
+  Col x;
+  const int64_t r0 = P.single_rows >= 0 ? 0 : P.row_off[w.u];
+  x.p = P.x + r0 * P.ld_x + P.col_first + w.c;
+  x.ld = P.ld_x;
+  x.N = w.rows;
+  x.n_main = (P.single_rows < 0 && P.extra) ? w.rows - 1 : w.rows;
+  x.pe = P.extra ? P.extra + (int64_t)w.u * P.ld_extra + w.c : x.p;
+  return x;
+}
+
+// the column the families see: the compacted copy if nonZeroFuncts, else the input itself
+__device__ __forceinline__ Col data_col(const FsParams &P, const Where &w) {
+  if (!P.spec.non_zero_functs) return raw_col(P, w);
+  Col x;
+  x.p = P.nz + w.srow0 * P.n_cols + w.c;
+  x.ld = P.n_cols;
+  x.N = x.n_main = P.st_n[(int64_t)w.u * P.n_cols + w.c];
+  x.pe = x.p;
+  return x;
+}
+
+// smileMath_ratioLimit and friends (smileUtil.c:586-613), float / double promotions as written there
+__device__ float fs_logistic(float x) {
+  const float lim = (float)log((double)FLT_MAX);
+  if (x > lim) return 1.0f;
+  else if (x < -lim) return 0.0f;
+  return (float)(1.0 / (1.0 + exp(-(double)x)));
+}
+__device__ float fs_tanh(float x) { return 2.0f * fs_logistic(2.0f * x) - 1.0f; }
+__device__ float fs_ratio_limit(float x, float limit1, float excess) {
+  if (x > limit1) {
+    return fs_tanh((float)((sqrt((double)(x - limit1) + 1.0) - 1.0) / ((double)excess * 0.5))) * excess + limit1;
+  } else if (x < -limit1) {
+    return fs_tanh((float)(-(sqrt(-1.0 * (double)(x + limit1) + 1.0) - 1.0) / ((double)excess * 0.5))) * excess - limit1;
+  }
+  return x;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ stats
+__global__ void __launch_bounds__(kColsPerBlock) fs_stats(FsParams P) {
+  const Where w = locate(P);
+  if (!w.on) return;
+  const Col r = raw_col(P, w);
+  const int64_t si = (int64_t)w.u * P.n_cols + w.c;
+  int64_t NN = r.N;
+  if (P.spec.non_zero_functs) {
+    float *d = P.nz + w.srow0 * P.n_cols + w.c;
+    NN = 0;
+    const bool pos = P.spec.non_zero_functs == 2;
+    for (int64_t t = 0; t < r.N; ++t) {
+      const float v = r[t];
+      if (pos ? (v > 0.0f) : (v != 0.0f)) d[(NN++) * P.n_cols] = v;
+    }
+  }
+  P.st_n[si] = (int32_t)NN;
+  if (NN <= 0) {
+    P.st_min[si] = P.st_max[si] = P.st_mean[si] = 0.0f;
+    float *o = P.out + (int64_t)w.u * P.ld_out + (int64_t)w.c * P.per;      // every family yields nothing: zeros
+    for (int i = 0; i < P.per; ++i) o[i] = 0.0f;
+    return;
+  }
+  const Col x = data_col(P, w);
+  float mn = x[0], mx = mn;
+  double mean = mn;
+  for (int64_t t = 1; t < NN; ++t) {
+    const float v = x[t];
+    if (v < mn) mn = v;
+    if (v > mx) mx = v;
+    mean += (double)v;
+  }
+  mean /= (double)NN;
+  P.st_min[si] = mn; P.st_max[si] = mx; P.st_mean[si] = (float)mean;
+}
+
+// ------------------------------------------------------------------ families
+namespace {
+
+__device__ int f_extremes(const smilehip_func_spec &s, const Col &in, float min, float max, float mean, float *out) {
+  const int64_t Nin = in.N;
+  int64_t minpos = -1, maxpos = -1;
+  for (int64_t i = 0; i < Nin; ++i) {
+    const float v = in[i];
+    if ((v == max) && (maxpos == -1)) maxpos = i;
+    if ((v == min) && (minpos == -1)) minpos = i;
+    if (maxpos >= 0 && minpos >= 0) break;
+  }
+  float maxposD = (float)maxpos, minposD = (float)minpos;
+  if (s.ext_norm == SMILEHIP_NORM_SEGMENT) {
+    maxposD /= (float)Nin;
+    minposD /= (float)Nin;
+  } else if (s.ext_norm == SMILEHIP_NORM_SECOND) {
+    const float T = (float)s.period;
+    if (T != 0.0f) { maxposD *= T; minposD *= T; }
+  }
+  const uint32_t m = s.ext_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = max;
+  if (FS_BIT(m, 1)) out[n++] = min;
+  if (FS_BIT(m, 2)) out[n++] = max - min;
+  if (FS_BIT(m, 3)) out[n++] = maxposD;
+  if (FS_BIT(m, 4)) out[n++] = minposD;
+  if (FS_BIT(m, 5)) out[n++] = mean;
+  if (FS_BIT(m, 6)) out[n++] = max - mean;
+  if (FS_BIT(m, 7)) out[n++] = mean - min;
+  return n;
+}
+
+__device__ int f_means(const smilehip_func_spec &s, const Col &in, float mean, float *out) {
+  const int64_t Nin = in.N;
+  const uint32_t m = s.means_mask;
+  const bool need_log = (m & ((1u << 6) | (1u << 8))) != 0;      // nzgmean / flatness
+  double tmp = (double)in[0];
+  double fa = fabs(tmp);
+  double absmean = fa, qmean = tmp * tmp;
+  int64_t nnz;
+  double nzamean, nzabsmean, nzqmean, nzgmean;
+  double posamean = 0.0, negamean = 0.0, posqmean = 0.0, negqmean = 0.0;
+  int64_t nPos = 0, nNeg = 0;
+  if (tmp != 0.0) {
+    nzamean = tmp; nzabsmean = fa; nzqmean = tmp * tmp; nzgmean = need_log ? log(fa) : 0.0; nnz = 1;
+    if (tmp > 0) { posamean += tmp; posqmean += tmp * tmp; nPos++; }
+    else { negamean += tmp; negqmean += tmp * tmp; nNeg++; }
+  } else {
+    nzamean = nzabsmean = nzqmean = nzgmean = 0.0; nnz = 0;
+  }
+  for (int64_t i = 1; i < Nin; ++i) {
+    tmp = (double)in[i];
+    fa = fabs(tmp);
+    absmean += fa;
+    if (tmp > 0) { posamean += tmp; nPos++; }
+    if (tmp < 0) { negamean += tmp; nNeg++; }
+    const double t0 = tmp;
+    if (tmp != 0.0) {
+      nzamean += tmp;
+      nzabsmean += fa;
+      if (need_log) nzgmean += log(fa);
+      tmp *= tmp;
+      nzqmean += tmp;
+      nnz++;
+      if (t0 > 0) posqmean += tmp;
+      if (t0 < 0) negqmean += tmp;
+      qmean += tmp;
+    }
+  }
+  tmp = (double)Nin;
+  absmean = absmean / tmp;
+  qmean = qmean / tmp;
+  if (nnz > 0) {
+    tmp = (double)nnz;
+    nzamean /= tmp; nzabsmean /= tmp; nzqmean /= tmp; nzgmean /= tmp;
+    nzgmean = exp(nzgmean);
+  }
+  if (nPos > 0) { posamean /= (double)nPos; posqmean /= (double)nPos; }
+  if (nNeg > 0) { negamean /= (double)nNeg; negqmean /= (double)nNeg; }
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = (float)mean;
+  if (FS_BIT(m, 1)) out[n++] = (float)absmean;
+  if (FS_BIT(m, 2)) out[n++] = (float)qmean;
+  if (FS_BIT(m, 3)) out[n++] = (float)nzamean;
+  if (FS_BIT(m, 4)) out[n++] = (float)nzabsmean;
+  if (FS_BIT(m, 5)) out[n++] = (float)nzqmean;
+  if (FS_BIT(m, 6)) out[n++] = (float)nzgmean;
+  if (FS_BIT(m, 7)) {
+    if (s.means_norm == SMILEHIP_NORM_FRAME) out[n++] = (float)nnz;
+    else if (s.means_norm == SMILEHIP_NORM_SEGMENT) out[n++] = (float)nnz / (float)Nin;
+    else out[n++] = (float)nnz / (float)s.period;
+  }
+  if (FS_BIT(m, 8)) out[n++] = (absmean != 0.0) ? (float)(nzgmean / absmean) : 1.0f;
+  if (FS_BIT(m, 9)) out[n++] = (float)posamean;
+  if (FS_BIT(m, 10)) out[n++] = (float)negamean;
+  if (FS_BIT(m, 11)) out[n++] = (float)posqmean;
+  if (FS_BIT(m, 12)) out[n++] = (float)sqrt(posqmean);
+  if (FS_BIT(m, 13)) out[n++] = (float)negqmean;
+  if (FS_BIT(m, 14)) out[n++] = (float)sqrt(negqmean);
+  if (FS_BIT(m, 15)) out[n++] = (float)sqrt(qmean);
+  if (FS_BIT(m, 16)) out[n++] = (float)sqrt(nzqmean);
+  return n;
+}
+
+__device__ int f_moments(const smilehip_func_spec &s, const Col &in, float mean, float *out) {
+  const int64_t Nin = in.N;
+  double m2 = 0.0, m3 = 0.0, m4 = 0.0;
+  const double Nind = (double)Nin, meanD = (double)mean;
+  for (int64_t i = 0; i < Nin; ++i) {
+    const double tmp = ((double)in[i] - meanD);
+    double tmp2 = tmp * tmp;
+    m2 += tmp2;
+    tmp2 *= tmp;
+    m3 += tmp2;
+    m4 += tmp2 * tmp;
+  }
+  m2 /= Nind;
+  const uint32_t m = s.mom_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = (float)m2;
+  const double sqm2 = sqrt(m2);
+  if (FS_BIT(m, 1)) out[n++] = (m2 > 0.0) ? (float)sqm2 : 0.0f;
+  if (FS_BIT(m, 2)) out[n++] = (m2 > 0.0) ? (float)(m3 / (Nind * m2 * sqm2)) : 0.0f;
+  if (FS_BIT(m, 3)) out[n++] = (m2 > 0.0) ? (float)(m4 / (Nind * m2 * m2)) : 0.0f;
+  if (FS_BIT(m, 4)) out[n++] = (float)mean;
+  if (FS_BIT(m, 5)) {
+    if (m2 > 0.0) {
+      const float meanLocal = (s.mom_stddev_norm == 1) ? fabsf(mean) : mean;
+      if (s.mom_ratio_limit) {
+        if (meanLocal != 0.0f) out[n++] = fs_ratio_limit((float)(sqm2 / (double)meanLocal), 10.0f, 20.0f);
+        else out[n++] = 20.0f;
+      } else {
+        double mean1 = (double)meanLocal;
+        if (mean1 == 0.0) mean1 = 1.0;
+        out[n++] = (float)(sqm2 / mean1);
+      }
+    } else out[n++] = 0.0f;
+  }
+  return n;
+}
+
+__device__ int f_regression(const smilehip_func_spec &s, const Col &in, float min, float max, float mean, float *out) {
+  const int64_t Nin = in.N;
+  const double Nind = (double)Nin;
+  double range = (double)(max - min), rangeInv;
+  if (range <= 0.0) { range = 1.0; rangeInv = 0.0; } else rangeInv = 1.0 / range;
+  const bool enQreg = (s.reg_mask & 0x3fff0u) != 0;
+  double num = 0.0, numAbs = 0.0, num2 = 0.0, tmp = 0.0, ii = 0.0, asumAbs = 0.0;
+  const double asum = (double)mean * Nind;
+  for (int64_t i = 0; i < Nin; ++i) {
+    const float v = in[i];
+    if (s.reg_centroid_abs) {
+      asumAbs += (double)fabsf(v);
+      numAbs += (double)fabsf(v) * ii;
+    }
+    tmp = (double)v * ii;
+    num += tmp;
+    tmp *= ii;
+    ii += 1.0;
+    num2 += tmp;
+  }
+  double centroid;
+  if (s.reg_centroid_abs) centroid = (asumAbs != 0.0) ? numAbs / asumAbs : 0.0;
+  else centroid = (asum != 0.0) ? num / asum : 0.0;
+  if (s.reg_centroid_limit) centroid = (double)fs_ratio_limit((float)centroid, (float)Nind, (float)Nind);
+  if (s.reg_centroid_norm == SMILEHIP_NORM_SECOND) centroid *= s.period;
+  else if (s.reg_centroid_norm == SMILEHIP_NORM_SEGMENT) centroid /= Nind;
+
+  double m = 0.0, t = 0.0, leq = 0.0, lea = 0.0, a = 0.0, b = 0.0, c = 0.0, qeq = 0.0, qea = 0.0;
+  if (Nin > 1) {
+    const double NNm1 = (Nind) * (Nind - 1.0);
+    const double S1 = NNm1 / 2.0;
+    const double S2 = NNm1 * (2.0 * Nind - 1.0) / 6.0;
+    const double S1dS2 = S1 / S2;
+    const double d = (Nind - S1 * S1dS2);
+    if (d == 0.0) t = 0.0; else t = (asum - num * S1dS2) / d;
+    m = (num - t * S1) / S2;
+    const double S3 = S1 * S1;
+    const double Nind1 = Nind - 1.0;
+    const double S4 = S2 * (3.0 * (Nind1 * Nind1 + Nind1) - 1.0) / 5.0;
+    if (enQreg) {
+      const double S3S3 = S3 * S3, S2S2 = S2 * S2, S1S2 = S1 * S2, S1S1 = S3;
+      const double det = S4 * S2 * Nind + 2.0 * S3 * S1S2 - S2S2 * S2 - S3S3 * Nind - S1S1 * S4;
+      if (det != 0.0) {
+        a = ((S2 * Nind - S1S1) * num2 + (S1S2 - S3 * Nind) * num + (S3 * S1 - S2S2) * asum) / det;
+        b = ((S1S2 - S3 * Nind) * num2 + (S4 * Nind - S2S2) * num + (S3 * S2 - S4 * S1) * asum) / det;
+        c = ((S3 * S1 - S2S2) * num2 + (S3 * S2 - S4 * S1) * num + (S4 * S2 - S3S3) * asum) / det;
+      }
+    }
+  } else {
+    m = 0; t = c = (double)in[0];
+  }
+  ii = 0.0;
+  for (int64_t i = 0; i < Nin; ++i) {              // both residual sweeps share one walk; each sum keeps its own order
+    const double v = (double)in[i];
+    double e = v - (m * ii + t);
+    if (s.reg_norm_inputs) e *= rangeInv;
+    lea += fabs(e);
+    leq += e * e;
+    if (enQreg) {
+      double q = v - (a * ii * ii + b * ii + c);
+      if (s.reg_norm_inputs) q *= rangeInv;
+      qea += fabs(q);
+      qeq += q * q;
+    }
+    ii += 1.0;
+  }
+  double rs = 0.0, ls = 0.0, x0 = 0.0, y0 = 0.0, yr = 0.0, yrnn = 0.0, c3nn = 0.0, y0nn = 0.0;
+  if (enQreg) {
+    x0 = b / (-2.0 * a);
+    if (x0 < -1.0 * Nind) x0 = -Nind;
+    if (x0 > Nind) x0 = Nind;
+    if (!isfinite(x0)) x0 = Nind;
+    y0 = c - b * b / (4.0 * a);
+    if (!isfinite(y0)) y0 = 0.0;
+    y0nn = y0;
+    yrnn = yr = a * (Nind - 1.0) * (Nind - 1.0) + b * (Nind - 1.0) + c;
+    if (!isfinite(yr)) { yr = 0.0; yrnn = 0.0; }
+    c3nn = c;
+  }
+  double NOneSec = 1.0;
+  if (s.reg_norm_coeff == 2) NOneSec = 1.0 / s.period;
+  if (s.reg_ratio_limit) {
+    m = fs_ratio_limit((float)m, (float)(range / 10.0), (float)(range / 10.0 + 0.01));
+    a = fs_ratio_limit((float)a, (float)(sqrt(range / 10.0)), (float)(sqrt(range / 10.0) + 0.01));
+    b = fs_ratio_limit((float)b, (float)(range / 10.0), (float)(range / 10.0 + 0.01));
+  }
+  if (s.reg_norm_coeff == 1) {
+    m *= Nind - 1.0;
+    a *= (Nind - 1.0) * (Nind - 1.0);
+    b *= Nind - 1.0;
+    if (Nind != 1.0) x0 /= Nind - 1.0; else x0 = 0.0;
+  } else if (s.reg_norm_coeff == 2) {
+    m *= NOneSec;
+    a *= NOneSec * NOneSec;
+    b *= NOneSec;
+    if (NOneSec != 1.0) x0 /= NOneSec; else x0 = 0.0;
+  }
+  if (s.reg_norm_inputs) {
+    m *= rangeInv;
+    t = (t - (double)min) * rangeInv;
+    a *= rangeInv;
+    b *= rangeInv;
+    c = (c - (double)min) * rangeInv;
+    y0 = (y0 - (double)min) * rangeInv;
+    yr = (yr - (double)min) * rangeInv;
+  }
+  if (enQreg) {
+    if (x0 > 0) ls = (y0 - c) / x0;
+    if (s.reg_norm_coeff == 1) {
+      if (x0 < 1.0) rs = (yr - y0) / (1.0 - x0);
+    } else if (s.reg_norm_coeff == 2) {
+      const double len_t = (Nind - 1.0) / NOneSec;
+      if (x0 < len_t) rs = (yr - y0) / (len_t - x0);
+    } else {
+      if (x0 < Nind - 1.0) rs = (yr - y0) / (Nind - 1.0 - x0);
+    }
+  }
+  if (!isfinite(m)) m = 0.0;
+  if (!isfinite(t)) t = 0.0;
+  if (!isfinite(lea / Nind)) lea = 0.0;
+  if (!isfinite(leq / Nind)) leq = 0.0;
+  if (!isfinite(a)) a = 0.0;
+  if (!isfinite(b)) b = 0.0;
+  if (!isfinite(c)) { c = 0.0; c3nn = 0.0; }
+  if (!isfinite(ls)) ls = 0.0;
+  if (!isfinite(rs)) rs = 0.0;
+  if (!isfinite(qea / Nind)) qea = 0.0;
+  if (!isfinite(qeq / Nind)) qeq = 0.0;
+  if (!isfinite(centroid)) centroid = 0.0;
+  const uint32_t k = s.reg_mask;
+  int n = 0;
+  if (FS_BIT(k, 0)) out[n++] = (float)m;
+  if (FS_BIT(k, 1)) out[n++] = (float)t;
+  if (FS_BIT(k, 2)) out[n++] = (float)(lea / Nind);
+  if (FS_BIT(k, 3)) out[n++] = (float)(leq / Nind);
+  if (FS_BIT(k, 4)) out[n++] = (float)a;
+  if (FS_BIT(k, 5)) out[n++] = (float)b;
+  if (FS_BIT(k, 6)) out[n++] = (float)c;
+  if (!s.reg_old_buggy_qerr) {
+    if (FS_BIT(k, 7)) out[n++] = (float)(qea / Nind);
+    if (FS_BIT(k, 8)) out[n++] = (float)(qeq / Nind);
+  } else {
+    if (FS_BIT(k, 7)) out[n++] = (float)(qea);
+    if (FS_BIT(k, 8)) out[n++] = (float)(qeq);
+  }
+  if (FS_BIT(k, 9)) out[n++] = (float)centroid;
+  if (FS_BIT(k, 10)) out[n++] = (float)ls;
+  if (FS_BIT(k, 11)) out[n++] = (float)rs;
+  if (FS_BIT(k, 12)) out[n++] = (float)x0;
+  if (FS_BIT(k, 13)) out[n++] = (float)y0;
+  if (FS_BIT(k, 14)) out[n++] = (float)yr;
+  if (FS_BIT(k, 15)) out[n++] = (float)y0nn;
+  if (FS_BIT(k, 16)) out[n++] = (float)c3nn;
+  if (FS_BIT(k, 17)) out[n++] = (float)yrnn;
+  return n;
+}
+
+__device__ int f_times(const smilehip_func_spec &s, const Col &in, float min, float max, float *out) {
+  const int64_t Nin = in.N;
+  const float Nind = (float)Nin;
+  float Norm = Nind, Norm1 = Nind - 1.0f, Norm2 = Nind - 2.0f;
+  float T = 1.0f;
+  if (s.times_norm == SMILEHIP_NORM_SECOND) {
+    T = (float)s.period;
+    if (T != 0.0f) {
+      if (s.times_buggy_sec_norm) { Norm /= T; Norm1 /= T; Norm2 /= T; }
+      else { Norm = 1.0f / T; Norm1 /= Nind * T; Norm2 /= Nind * T; }
+    }
+  }
+  if (s.times_norm == SMILEHIP_NORM_FRAME) { Norm = 1.0f; Norm1 /= Nind; Norm2 /= Nind; }
+  const float range = max - min;
+  const float l25 = 0.25f * range + min, l50 = 0.50f * range + min, l75 = 0.75f * range + min, l90 = 0.90f * range + min;
+  int64_t n25 = 0, n50 = 0, n75 = 0, n90 = 0, nR = 0, nF = 0, nLC = 0, nRC = 0;
+  float pm = 0.0f, p0 = in[0];                     // in[i-1], in[i]; all counts are integers: one fused walk
+  for (int64_t i = 0; i < Nin; ++i) {
+    const float pn = (i + 1 < Nin) ? in[i + 1] : 0.0f;
+    if (p0 <= l25) n25++;
+    if (p0 <= l50) n50++;
+    if (p0 <= l75) n75++;
+    if (p0 <= l90) n90++;
+    if (i >= 1) {
+      if (pm < p0) nR++;
+      else if (pm > p0) nF++;
+      if (i + 1 < Nin) {
+        const float a1 = p0 - pm, a2 = pn - p0;
+        if (a2 < a1) nRC++;
+        else if (a1 < a2) nLC++;
+      }
+    }
+    pm = p0; p0 = pn;
+  }
+  const uint32_t m = s.times_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = ((float)(Nin - n25)) / Norm;
+  if (FS_BIT(m, 1)) out[n++] = ((float)(n25)) / Norm;
+  if (FS_BIT(m, 2)) out[n++] = ((float)(Nin - n50)) / Norm;
+  if (FS_BIT(m, 3)) out[n++] = ((float)(n50)) / Norm;
+  if (FS_BIT(m, 4)) out[n++] = ((float)(Nin - n75)) / Norm;
+  if (FS_BIT(m, 5)) out[n++] = ((float)(n75)) / Norm;
+  if (FS_BIT(m, 6)) out[n++] = ((float)(Nin - n90)) / Norm;
+  if (FS_BIT(m, 7)) out[n++] = ((float)(n90)) / Norm;
+  if (FS_BIT(m, 8)) out[n++] = (Norm1 != 0.0f) ? ((float)nR) / Norm1 : 0.0f;
+  if (FS_BIT(m, 9)) out[n++] = (Norm1 != 0.0f) ? ((float)nF) / Norm1 : 0.0f;
+  if (FS_BIT(m, 10)) out[n++] = (Norm2 != 0.0f) ? ((float)nLC) / Norm2 : 0.0f;
+  if (FS_BIT(m, 11)) out[n++] = (Norm2 != 0.0f) ? ((float)nRC) / Norm2 : 0.0f;
+  if (FS_BIT(m, 12)) out[n++] = (s.times_norm == SMILEHIP_NORM_SECOND) ? ((float)(Nin) * T) : (float)Nin;
+  return n;
+}
+
+// Segments: the segmentation runs twice -- first to get count / sum / extremes of the segment lengths, then again to
+// accumulate the squared deviations from the mean in the same order (instead of keeping the reference's segLens[])
+struct SegAcc {
+  int64_t n, sum, maxl, minl, cap;
+  bool second;
+  float mean, dev;
+  __device__ void add(int64_t i, int64_t last) {
+    const int64_t len = i - last;
+    if (n < cap) {
+      if (!second) {
+        sum += len;
+        if (len > maxl) maxl = len;
+        if ((minl == 0) || (len < minl)) minl = len;
+      } else {
+        dev += ((float)len - mean) * ((float)len - mean);
+      }
+      n++;
+    }
+  }
+};
+
+__device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, float range, SegAcc &r) {
+  const int64_t Nin = in.N;
+  if (s.seg_algo == SMILEHIP_SEG_RELTH) {
+    float th[8];
+    for (int j = 0; j < 8; ++j) th[j] = (j < s.seg_n_thresholds) ? min + range * s.seg_thresholds[j] : 0.0f;
+    int64_t segMinLng = s.seg_min_lng;
+    if (s.seg_auto_min_lng) {
+      segMinLng = Nin / s.seg_max_num - 1;
+      if (segMinLng < 2) segMinLng = 2;
+    }
+    int64_t lastSeg = -segMinLng / 2;
+    float ravg = 0.0f, raLast = 0.0f;
+    float h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;           // in[i-1], in[i-2], in[i-3]
+    for (int64_t i = 0; i < Nin; ++i) {
+      const float v = in[i];
+      ravg += v;
+      if (i >= 3) ravg -= h3;
+      const float ra = ravg / (float)((i + 1 < 3) ? (i + 1) : 3);
+      bool cross = false;
+      for (int j = 0; j < 8; ++j)
+        if (j < s.seg_n_thresholds && ((ra > th[j] && raLast <= th[j]) || (ra < th[j] && raLast >= th[j]))) cross = true;
+      raLast = ra;
+      if (cross && (i - lastSeg > segMinLng)) { r.add(i, lastSeg); lastSeg = i; }
+      h3 = h2; h2 = h1; h1 = v;
+    }
+  } else {
+    const float X = s.seg_x_is_rel ? (min + range * s.seg_x) : s.seg_x;
+    int64_t startIdx = 0, i;
+    int inSeg = 0, segStart = 0, segEnd = 0;
+    for (i = 0; i < Nin; ++i) {
+      const float v = in[i];
+      if (v != X) {
+        if (inSeg == 1) {
+          segEnd = 0;
+          segStart++;
+          if (segStart >= s.seg_min_lng) { segStart = 0; inSeg = 2; }
+        } else if (inSeg == 0) {
+          segStart++;
+          startIdx = i;
+          inSeg = 1;
+        } else if (inSeg == 2) {
+          segEnd = 0;
+        }
+      }
+      if (v == X) {
+        if (inSeg == 2) {
+          segStart = 0;
+          segEnd++;
+          if (segEnd >= s.seg_pause_min_lng) {
+            inSeg = 0;
+            r.add(i - segEnd, startIdx);
+            segEnd = 0;
+          }
+        } else if (inSeg == 1) {
+          segEnd++;
+          if (segEnd >= s.seg_pause_min_lng) { inSeg = 0; segEnd = 0; segStart = 0; }
+        }
+      }
+    }
+    if (inSeg == 2) {
+      segEnd++;
+      r.add(i - segEnd, startIdx);
+    }
+  }
+}
+
+__device__ int f_segments(const smilehip_func_spec &s, const Col &in, float min, float max, float *out) {
+  const int64_t Nin = in.N;
+  const float range = max - min;
+  SegAcc r;
+  r.n = r.sum = r.maxl = r.minl = 0; r.cap = s.seg_max_num; r.second = false; r.mean = r.dev = 0.0f;
+  seg_walk(s, in, min, range, r);
+  const int64_t nSeg = r.n;
+  float mean = (nSeg > 1) ? (float)r.sum / ((float)nSeg) : (float)r.sum;
+  float lenDev = 0.0f;
+  if (nSeg > 1 && FS_BIT(s.seg_mask, 4)) {
+    r.second = true; r.n = 0; r.mean = mean; r.dev = 0.0f;
+    seg_walk(s, in, min, range, r);
+    lenDev = r.dev / (float)nSeg;
+    lenDev = (float)sqrt((double)lenDev);
+  }
+  const uint32_t m = s.seg_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) {
+    if (s.seg_norm == SMILEHIP_NORM_SECOND) {
+      const float T = (float)s.period;
+      float Norm = 1.0f;
+      if (T != 0.0f) Norm = T;
+      Norm *= (float)Nin;
+      out[n++] = (float)nSeg / Norm;
+    } else if (s.seg_norm == SMILEHIP_NORM_SEGMENT) out[n++] = (float)nSeg / (float)(s.seg_max_num);
+    else out[n++] = (float)nSeg;
+  }
+  if (s.seg_norm == SMILEHIP_NORM_SEGMENT) {
+    if (FS_BIT(m, 1)) out[n++] = mean / (float)(Nin);
+    if (FS_BIT(m, 2)) out[n++] = (float)r.maxl / (float)(Nin);
+    if (FS_BIT(m, 3)) out[n++] = (float)r.minl / (float)(Nin);
+    if (FS_BIT(m, 4)) out[n++] = lenDev / (float)(Nin);
+  } else if (s.seg_norm == SMILEHIP_NORM_FRAME) {
+    if (FS_BIT(m, 1)) out[n++] = mean;
+    if (FS_BIT(m, 2)) out[n++] = (float)r.maxl;
+    if (FS_BIT(m, 3)) out[n++] = (float)r.minl;
+    if (FS_BIT(m, 4)) out[n++] = lenDev;
+  } else {
+    const float T = (float)s.period;
+    float Norm = 1.0f;
+    if (T != 0.0f) Norm = T;
+    if (FS_BIT(m, 1)) out[n++] = mean * Norm;
+    if (FS_BIT(m, 2)) out[n++] = (float)r.maxl * Norm;
+    if (FS_BIT(m, 3)) out[n++] = (float)r.minl * Norm;
+    if (FS_BIT(m, 4)) out[n++] = lenDev * Norm;
+  }
+  return n;
+}
+
+// Lpc: the reference fills acf[lag] with one sequential float sum per lag (lags p .. 0); here all lags advance in one
+// walk over the contour with a register delay line -- each sum still adds its products in index order.
+template <int P>
+__device__ int f_lpc_p(const smilehip_func_spec &s, const Col &in, float *out) {
+  const int64_t Nin = in.N;
+  float acf[P + 1], d[P + 1], a[P + 1];
+#pragma unroll
+  for (int k = 0; k <= P; ++k) { acf[k] = 0.0f; d[k] = 0.0f; a[k] = 0.0f; }
+  const int n32 = (int)Nin;                              // smileDsp_autoCorr takes an int
+  for (int i = 0; i < n32; ++i) {
+#pragma unroll
+    for (int k = P; k >= 1; --k) d[k] = d[k - 1];
+    d[0] = in[i];
+#pragma unroll
+    for (int k = 0; k <= P; ++k)
+      if (i >= k) acf[k] += d[0] * d[k];
+  }
+  float gain = 0.0f;
+  if (!(acf[0] == 0.0f)) {
+    float e = acf[0];
+#pragma unroll
+    for (int m = 1; m <= P; ++m) {
+      float sum = 1.0f * acf[m];
+#pragma unroll
+      for (int i = 1; i < m; ++i) sum += a[i - 1] * acf[m - i];
+      const float k_m = (-1.0f / e) * sum;
+      a[m - 1] = k_m;
+#pragma unroll
+      for (int i = 1; i <= m / 2; ++i) {
+        const float x = a[i - 1];
+        a[i - 1] += k_m * a[m - i - 1];
+        if ((i < (m / 2)) || ((m & 1) == 1)) a[m - i - 1] += k_m * x;
+      }
+      e *= (1.0f - k_m * k_m);
+      if (e == 0.0f) {
+#pragma unroll
+        for (int i = 0; i <= P; ++i)
+          if (i >= m) a[i] = 0.0f;
+        break;
+      }
+    }
+    gain = e;
+  }
+  int n = 0;
+  if (s.lpc_gain) out[n++] = gain / (float)Nin;
+  if (s.lpc_coeffs) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      if (i >= s.lpc_first) out[n++] = a[i];
+  }
+  return n;
+}
+
+__device__ int f_lpc(const smilehip_func_spec &s, const Col &in, float *out) {
+  switch (s.lpc_order) {
+    case 1: return f_lpc_p<1>(s, in, out);
+    case 2: return f_lpc_p<2>(s, in, out);
+    case 3: return f_lpc_p<3>(s, in, out);
+    case 4: return f_lpc_p<4>(s, in, out);
+    case 5: return f_lpc_p<5>(s, in, out);
+    case 6: return f_lpc_p<6>(s, in, out);
+    case 7: return f_lpc_p<7>(s, in, out);
+    case 8: return f_lpc_p<8>(s, in, out);
+    case 10: return f_lpc_p<10>(s, in, out);
+    case 12: return f_lpc_p<12>(s, in, out);
+    case 16: return f_lpc_p<16>(s, in, out);
+  }
+  return 0;
+}
+
+// ---- Peaks2
+__device__ __forceinline__ bool pk_below(const smilehip_func_spec &s, float absThresh, float diff, float base) {
+  if (s.pk_dyn_rel) {
+    if (base == 0.0f) return diff != 0.0f;
+    return fabs((double)(diff / base)) < (double)s.pk_rel_thresh;
+  }
+  return diff < absThresh;
+}
+__device__ __forceinline__ float pk_rl(const smilehip_func_spec &s, float x) { return s.pk_ratio_limit ? fs_ratio_limit(x, 10.0f, 10.0f) : x; }
+__device__ __forceinline__ float pk_rlmax(const smilehip_func_spec &s, float alt) { return s.pk_ratio_limit ? 20.0f : alt; }
+__device__ __forceinline__ float pk_rlu(const smilehip_func_spec &s, float x) {
+  if (s.pk_ratio_limit) {
+    if (x > 1.0f) return 1.0f;
+    if (x < -1.0f) return -1.0f;
+  }
+  return x;
+}
+
+// walks the local extrema of the contour in index order: calls f(i, y, is_max) for rows 2 .. N-3 that are strict
+// local maxima / minima (functionalPeaks2.cpp:343-349) and, if `only_alive`, still alive
+template <typename F>
+__device__ __forceinline__ void pk_for_each(const Col &in, const unsigned char *alive, int64_t ald, bool only_alive, F f) {
+  const int64_t N = in.N;
+  if (N < 5) return;
+  float a = in[1], b = in[2];
+  for (int64_t i = 2; i < N - 2; ++i) {
+    const float c = in[i + 1];
+    const bool mx = b > a && b > c, mi = b < a && b < c;
+    if ((mx || mi) && (!only_alive || alive[i * ald])) f(i, b, mx);
+    a = b; b = c;
+  }
+}
+
+__device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, float max, float mean, unsigned char *alive,
+                        int64_t ald, float *out) {
+  const int64_t Nin = in.N;
+  const float range = max - min;
+  const float absThresh = s.pk_use_abs ? s.pk_abs_thresh : s.pk_rel_thresh * range;
+  const float in0 = in[0], inL = in[Nin - 1];
+  // pass 1: minimum rise / fall (functionalPeaks2.cpp:352-404); an element = its row index
+  {
+    float lastVal = in0, lastMin = in0, lastMax = in0;
+    bool minFlag = false;
+    int64_t lastMaxPtr = -1;
+    pk_for_each(in, alive, ald, false, [&](int64_t i, float y, bool is_max) {
+      unsigned char keep = 1;
+      if (is_max) {
+        if (pk_below(s, absThresh, (float)fabs((double)(y - lastVal)), fminf(y, lastVal))) {
+          if (pk_below(s, absThresh, y - lastMin, lastMin)) {
+            keep = 0;
+          } else {
+            if ((double)y > (double)lastMax * 1.05) {
+              if (lastMaxPtr != -1) alive[lastMaxPtr * ald] = 0;
+              lastMax = y;
+              lastMaxPtr = i;
+            } else {
+              if (minFlag) { lastMax = y; lastMaxPtr = i; }
+              else keep = 0;
+            }
+            minFlag = false;
+          }
+        } else {
+          minFlag = false;
+          lastMax = y;
+          lastMaxPtr = i;
+        }
+      } else {
+        if (!pk_below(s, absThresh, (float)fabs((double)(y - lastVal)), fminf(y, lastVal))) {
+          minFlag = true;
+          lastMin = y;
+        }
+      }
+      lastVal = y;
+      alive[i * ald] = keep;
+    });
+  }
+  // pass 2: minima too close below the last maximum (:407-421)
+  {
+    float lastMax = in0;
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        if (pk_below(s, absThresh, lastMax - y, y)) alive[i * ald] = 0;
+      } else lastMax = y;
+    });
+  }
+  // pass 3: alternation (:424-470)
+  {
+    float lastMax = in0, lastMin = in0;
+    bool minFlag = false, init = true;
+    int64_t lastMaxPtr = -1, lastMinPtr = -1;
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        if (!minFlag || init) { lastMin = y; lastMinPtr = i; minFlag = true; init = false; }
+        else {
+          if (y >= lastMin) alive[i * ald] = 0;
+          else { alive[lastMinPtr * ald] = 0; lastMinPtr = i; lastMin = y; }
+        }
+      } else {
+        if (minFlag || init) { lastMax = y; lastMaxPtr = i; minFlag = false; init = false; }
+        else {
+          if (y <= lastMax) alive[i * ald] = 0;
+          else { alive[lastMaxPtr * ald] = 0; lastMaxPtr = i; lastMax = y; }
+        }
+      }
+    });
+  }
+  // statistics of the surviving extrema (:474-560)
+  float peakMax = 0.0f, peakMin = 0.0f, peakDist = 0.0f, peakDiff = 0.0f, peakStddevDist = 0.0f, peakStddevDiff = 0.0f;
+  float peakMean = 0.0f, minMax = 0.0f, minMin = 0.0f, minDist = 0.0f, minDiff = 0.0f, minStddevDist = 0.0f;
+  float minStddevDiff = 0.0f, minMean = 0.0f;
+  int64_t nPeakDist = 0, nPeaks = 0, nMinDist = 0, nMins = 0;
+  {
+    int64_t lmx = -1, lmn = -1;
+    float lmy = 0.0f, lny = 0.0f;
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        if (lmn == -1) { minMin = y; minMax = y; }
+        else {
+          nMinDist++;
+          minDist += (float)(i - lmn);
+          minDiff += (float)fabs((double)(y - lny));
+          if (minMin > y) minMin = y;
+          if (minMax < y) minMax = y;
+        }
+        lmn = i; lny = y;
+        minMean += y;
+        nMins++;
+      } else {
+        if (lmx == -1) { peakMin = y; peakMax = y; }
+        else {
+          nPeakDist++;
+          peakDist += (float)(i - lmx);
+          peakDiff += (float)fabs((double)(y - lmy));
+          if (peakMin > y) peakMin = y;
+          if (peakMax < y) peakMax = y;
+        }
+        lmx = i; lmy = y;
+        peakMean += y;
+        nPeaks++;
+      }
+    });
+  }
+  if (nPeaks > 1) {
+    peakMean /= (float)nPeaks;
+    if (nPeakDist > 1) { peakDist /= (float)nPeakDist; peakDiff /= (float)nPeakDist; }
+  }
+  if (nMins > 0) {
+    minMean /= (float)nMins;
+    if (nMinDist > 1) { minDist /= (float)nMinDist; minDiff /= (float)nMinDist; }
+  }
+  {
+    bool haveMax = false;
+    int64_t lmn = -1;
+    float lny = 0.0f;
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        if (lmn != -1) {
+          const float dx = (float)(i - lmn), dy = (float)fabs((double)(y - lny));
+          minStddevDist += (dx - minDist) * (dx - minDist);
+          minStddevDiff += (dy - minDiff) * (dy - minDiff);
+        }
+        lmn = i; lny = y;
+      } else {
+        if (!haveMax) haveMax = true;
+        else if (lmn != -1) {                    // measured against the last MINIMUM, as the reference does (:594-598)
+          const float dx = (float)(i - lmn), dy = (float)fabs((double)(y - lny));
+          peakStddevDist += (dx - peakDist) * (dx - peakDist);
+          peakStddevDiff += (dy - peakDiff) * (dy - peakDiff);
+        }
+      }
+    });
+  }
+  if (nPeakDist > 1) { peakStddevDist /= (float)nPeakDist; peakStddevDiff /= (float)nPeakDist; }
+  peakStddevDist = (peakStddevDist > 0.0f) ? (float)sqrt((double)peakStddevDist) : 0.0f;
+  peakStddevDiff = (peakStddevDiff > 0.0f) ? (float)sqrt((double)peakStddevDiff) : 0.0f;
+  if (nMinDist > 1) { minStddevDist /= (float)nMinDist; minStddevDiff /= (float)nMinDist; }
+  minStddevDist = (minStddevDist > 0.0f) ? (float)sqrt((double)minStddevDist) : 0.0f;
+  minStddevDiff = (minStddevDiff > 0.0f) ? (float)sqrt((double)minStddevDiff) : 0.0f;
+
+  float meanRisingSlope = 0.0f, meanFallingSlope = 0.0f, minRisingSlope = 0.0f, maxRisingSlope = 0.0f;
+  float minFallingSlope = 0.0f, maxFallingSlope = 0.0f, stddevRisingSlope = 0.0f, stddevFallingSlope = 0.0f;
+  int nRising = 0, nFalling = 0, lastIsMax = -1;
+  if (s.pk_mask & 0xffc00000u) {
+    const float T = (float)s.period;
+    float lastMax = in0, lastMin = in0;
+    int64_t lastMaxPos = 0, lastMinPos = 0;
+    auto fall = [&](float slope) {
+      meanFallingSlope += slope;
+      if (nFalling == 0) { minFallingSlope = slope; maxFallingSlope = slope; }
+      else {
+        if (slope < minFallingSlope) minFallingSlope = slope;
+        if (slope > maxFallingSlope) maxFallingSlope = slope;
+      }
+      nFalling++;
+    };
+    auto rise = [&](float slope) {
+      meanRisingSlope += slope;
+      if (nRising == 0) { minRisingSlope = slope; maxRisingSlope = slope; }
+      else {
+        if (slope < minRisingSlope) minRisingSlope = slope;
+        if (slope > maxRisingSlope) maxRisingSlope = slope;
+      }
+      nRising++;
+    };
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        lastMin = y; lastMinPos = i;
+        if (lastMinPos - lastMaxPos > 0) { fall((lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T)); lastIsMax = 0; }
+      } else {
+        lastMax = y; lastMaxPos = i;
+        if (lastMaxPos - lastMinPos > 0) { rise((lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T)); lastIsMax = 1; }
+      }
+    });
+    if (lastIsMax == 1) {
+      if (Nin - 1 - lastMaxPos > 0) fall((inL - lastMax) / ((float)(Nin - 1 - lastMaxPos) * T));
+    } else if (lastIsMax == 0) {
+      if (Nin - 1 - lastMinPos > 0) rise((inL - lastMin) / ((float)(Nin - 1 - lastMinPos) * T));
+    } else {
+      const float slope = (inL - in0) / (float)Nin;
+      if (slope > 0) { meanRisingSlope = maxRisingSlope = minRisingSlope = slope; nRising = 1; }
+      else if (slope < 0) { meanFallingSlope = maxFallingSlope = minFallingSlope = slope; nFalling = 1; }
+    }
+    if (nRising > 1) meanRisingSlope /= (float)nRising;
+    if (nFalling > 1) meanFallingSlope /= (float)nFalling;
+    lastMax = in0; lastMaxPos = 0; lastMin = in0; lastMinPos = 0;
+    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
+      if (!is_max) {
+        lastMin = y; lastMinPos = i;
+        if (lastMinPos - lastMaxPos > 0) {
+          const float slope = (lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T);
+          stddevFallingSlope += (slope - meanFallingSlope) * (slope - meanFallingSlope);
+        }
+      } else {
+        lastMax = y; lastMaxPos = i;
+        if (lastMaxPos - lastMinPos) {
+          const float slope = (lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T);
+          stddevRisingSlope += (slope - meanRisingSlope) * (slope - meanRisingSlope);
+        }
+      }
+    });
+    if (nRising > 1) stddevRisingSlope /= (float)nRising;
+    if (nFalling > 1) stddevFallingSlope /= (float)nFalling;
+    stddevRisingSlope = (stddevRisingSlope > 0.0f) ? (float)sqrt((double)stddevRisingSlope) : 0.0f;
+    stddevFallingSlope = (stddevFallingSlope > 0.0f) ? (float)sqrt((double)stddevFallingSlope) : 0.0f;
+  }
+  if (s.pk_norm == SMILEHIP_NORM_SECOND) {
+    const float T = (float)s.period;
+    peakDist *= T; peakStddevDist *= T; minDist *= T; minStddevDist *= T;
+  } else if (s.pk_norm == SMILEHIP_NORM_SEGMENT) {
+    peakDist /= (float)Nin; peakStddevDist /= (float)Nin; minDist /= (float)Nin; minStddevDist /= (float)Nin;
+  }
+  const uint32_t m = s.pk_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = (s.pk_norm == SMILEHIP_NORM_SECOND) ? ((float)nPeaks) / ((float)Nin * (float)s.period) : (float)nPeaks;
+  if (FS_BIT(m, 1)) out[n++] = peakDist;
+  if (FS_BIT(m, 2)) out[n++] = 0.0f;
+  if (FS_BIT(m, 3)) out[n++] = peakStddevDist;
+  if (FS_BIT(m, 4)) out[n++] = peakMax - peakMin;
+  if (FS_BIT(m, 5)) out[n++] = (range != 0.0f) ? pk_rlu(s, (float)fabs((double)((peakMax - peakMin) / range))) : peakMax - peakMin;
+  if (FS_BIT(m, 6)) out[n++] = peakMean;
+  if (FS_BIT(m, 7)) out[n++] = peakMean - mean;
+  if (FS_BIT(m, 8)) out[n++] = (mean != 0.0f) ? pk_rl(s, peakMean / mean) : pk_rlmax(s, peakMean);
+  if (FS_BIT(m, 9)) out[n++] = peakDiff;
+  if (FS_BIT(m, 10)) out[n++] = (range != 0.0f) ? pk_rlu(s, peakDiff / range) : peakDiff;
+  if (FS_BIT(m, 11)) out[n++] = peakStddevDiff;
+  if (FS_BIT(m, 12)) out[n++] = (range != 0.0f) ? pk_rlu(s, peakStddevDiff / range) : peakStddevDiff;
+  if (FS_BIT(m, 13)) out[n++] = minMax - minMin;
+  if (FS_BIT(m, 14)) out[n++] = (range != 0.0f) ? pk_rlu(s, (float)fabs((double)((minMax - minMin) / range))) : minMax - minMin;
+  if (FS_BIT(m, 15)) out[n++] = minMean;
+  if (FS_BIT(m, 16)) out[n++] = mean - minMean;
+  if (FS_BIT(m, 17)) out[n++] = (mean != 0.0f) ? pk_rl(s, minMean / mean) : pk_rlmax(s, minMean);
+  if (FS_BIT(m, 18)) out[n++] = minDiff;
+  if (FS_BIT(m, 19)) out[n++] = (range != 0.0f) ? pk_rlu(s, minDiff / range) : minDiff;
+  if (FS_BIT(m, 20)) out[n++] = minStddevDiff;
+  if (FS_BIT(m, 21)) out[n++] = (range != 0.0f) ? pk_rlu(s, minStddevDiff / range) : minStddevDiff;
+  if (FS_BIT(m, 22)) out[n++] = meanRisingSlope;
+  if (FS_BIT(m, 23)) out[n++] = maxRisingSlope;
+  if (FS_BIT(m, 24)) out[n++] = minRisingSlope;
+  if (FS_BIT(m, 25)) out[n++] = stddevRisingSlope;
+  if (FS_BIT(m, 26)) out[n++] = meanFallingSlope;
+  if (FS_BIT(m, 27)) out[n++] = maxFallingSlope;
+  if (FS_BIT(m, 28)) out[n++] = minFallingSlope;
+  if (FS_BIT(m, 29)) out[n++] = stddevFallingSlope;
+  if (FS_BIT(m, 30)) out[n++] = (meanFallingSlope > 0.0f) ? pk_rl(s, stddevFallingSlope / meanFallingSlope) : 0.0f;
+  if (FS_BIT(m, 31)) out[n++] = (meanRisingSlope > 0.0f) ? pk_rl(s, stddevRisingSlope / meanRisingSlope) : 0.0f;
+  return n;
+}
+
+}  // namespace
+
+template <int FAM>
+__global__ void __launch_bounds__(kColsPerBlock) fs_family(FsParams P, int out_off, int want) {
+  const Where w = locate(P);
+  if (!w.on) return;
+  const int64_t si = (int64_t)w.u * P.n_cols + w.c;
+  if (P.st_n[si] <= 0) return;                          // zero-filled by fs_stats
+  const Col x = data_col(P, w);
+  const float mn = P.st_min[si], mx = P.st_max[si], mean = P.st_mean[si];
+  float *o = P.out + (int64_t)w.u * P.ld_out + (int64_t)w.c * P.per + out_off;
+  int got = 0;
+  if (FAM == SMILEHIP_FAM_EXTREMES) got = f_extremes(P.spec, x, mn, mx, mean, o);
+  if (FAM == SMILEHIP_FAM_MEANS) got = f_means(P.spec, x, mean, o);
+  if (FAM == SMILEHIP_FAM_MOMENTS) got = f_moments(P.spec, x, mean, o);
+  if (FAM == SMILEHIP_FAM_REGRESSION) got = f_regression(P.spec, x, mn, mx, mean, o);
+  if (FAM == SMILEHIP_FAM_TIMES) got = f_times(P.spec, x, mn, mx, o);
+  if (FAM == SMILEHIP_FAM_SEGMENTS) got = f_segments(P.spec, x, mn, mx, o);
+  if (FAM == SMILEHIP_FAM_LPC) got = f_lpc(P.spec, x, o);
+  if (FAM == SMILEHIP_FAM_PEAKS2)
+    got = f_peaks2(P.spec, x, mn, mx, mean, P.alive + w.srow0 * P.n_cols + w.c, P.n_cols, o);
+  for (int j = got; j < want; ++j) o[j] = 0.0f;
+}
+
+// ------------------------------------------------------------------ percentiles
+namespace {
+
+__device__ float interp_pctl(double p, const float *sorted, int64_t N) {
+  const double idx = p * (double)(N - 1);
+  int64_t i1 = (int64_t)floor(idx), i2 = (int64_t)ceil(idx);
+  if (i1 < 0) i1 = 0;
+  if (i2 < 0) i2 = 0;
+  if (i1 >= N) i1 = N - 1;
+  if (i2 >= N) i2 = N - 1;
+  if (i1 != i2) {
+    const double w1 = idx - (double)i1, w2 = (double)i2 - idx;
+    return sorted[i1] * (float)w2 + sorted[i2] * (float)w1;
+  }
+  return sorted[i1];
+}
+__device__ int64_t pctl_idx(double p, int64_t N) {
+  int64_t r = (int64_t)round(p * (double)(N - 1));
+  if (r < 0) return 0;
+  if (r >= N) return N - 1;
+  return r;
+}
+
+__device__ void bitonic_sort(float *a, int n2) {       // n2 = power of two, whole workgroup
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float x = a[i], y = a[l];
+          const bool up = (i & k) == 0;
+          if (up ? (x > y) : (x < y)) { a[i] = y; a[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int out_off) {
+  __shared__ float lds[kSortLds];
+  Where w;
+  w.u = blockIdx.x / P.n_cols;
+  w.c = blockIdx.x % P.n_cols;
+  w.on = true;
+  if (P.single_rows >= 0) { w.srow0 = 0; w.rows = P.single_rows; }
+  else {
+    const int64_t r0 = P.row_off[w.u], lld = P.row_off[w.u + 1] - r0;
+    int64_t n = lld - P.rows_cut;
+    if (n < 1) n = lld > 0 ? 1 : 0;
+    if (n > 0 && P.extra) n += 1;
+    w.srow0 = r0 + w.u;
+    w.rows = n;
+  }
+  const int64_t si = (int64_t)w.u * P.n_cols + w.c;
+  const int64_t N = P.st_n[si];
+  if (N <= 0) return;
+  const Col x = data_col(P, w);
+  int n2 = 1;
+  while (n2 < N) n2 <<= 1;
+  float *a = (n2 <= kSortLds) ? lds : P.sorted + 2 * w.srow0 * P.n_cols + (int64_t)w.c * n2;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) a[i] = (i < N) ? x[i] : INFINITY;
+  __syncthreads();
+  bitonic_sort(a, n2);
+  if (threadIdx.x != 0) return;
+  const smilehip_func_spec &s = P.spec;
+  float *out = P.out + (int64_t)w.u * P.ld_out + (int64_t)w.c * P.per + out_off;
+  float q1, q2, q3;
+  if (s.pct_interp) { q1 = interp_pctl(0.25, a, N); q2 = interp_pctl(0.50, a, N); q3 = interp_pctl(0.75, a, N); }
+  else { q1 = a[pctl_idx(0.25, N)]; q2 = a[pctl_idx(0.50, N)]; q3 = a[pctl_idx(0.75, N)]; }
+  const uint32_t m = s.pct_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = q1;
+  if (FS_BIT(m, 1)) out[n++] = q2;
+  if (FS_BIT(m, 2)) out[n++] = q3;
+  if (FS_BIT(m, 3)) out[n++] = q2 - q1;
+  if (FS_BIT(m, 4)) out[n++] = q3 - q2;
+  if (FS_BIT(m, 5)) out[n++] = q3 - q1;
+  if (s.n_pctl > 0) {
+    const int n0 = n;
+    for (int i = 0; i < s.n_pctl; ++i) out[n++] = s.pct_interp ? interp_pctl(s.pctl[i], a, N) : a[pctl_idx(s.pctl[i], N)];
+    for (int i = 0; i < s.n_range; ++i) {
+      const float v = (float)fabs((double)(out[n0 + s.range_b[i]] - out[n0 + s.range_a[i]]));
+      out[n++] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ launch
+int fs_sort_lds_rows() { return kSortLds; }
+
+hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s) {
+  if (n_utt <= 0 || P.n_cols <= 0) return hipSuccess;
+  const int groups = (P.n_cols + kColsPerBlock - 1) / kColsPerBlock;
+  const dim3 grid((unsigned)(n_utt * groups)), block(kColsPerBlock);
+  hipLaunchKernelGGL(fs_stats, grid, block, 0, s, P);
+  for (int i = 0; i < P.spec.n_fam; ++i) {
+    const int off = fam_off[i], want = fam_want[i];
+    switch (P.spec.fam[i]) {
+      case SMILEHIP_FAM_EXTREMES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_EXTREMES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_MEANS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_MEANS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_MOMENTS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_MOMENTS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_REGRESSION: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_REGRESSION>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_TIMES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_TIMES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_SEGMENTS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SEGMENTS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_LPC: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_PERCENTILES:
+        hipLaunchKernelGGL(fs_percentiles, dim3((unsigned)(n_utt * P.n_cols)), dim3(kSortThreads), 0, s, P, off);
+        break;
+      default: return hipErrorInvalidValue;
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace smilehip

@@ -5,6 +5,8 @@
 
 #include <cstdint>
 
+#include "../../include/smilehip.h"
+
 namespace smilehip {
 
 // One tile of the fast kernel: up to fast512_tile_frames() consecutive frames of one utterance,
@@ -162,6 +164,29 @@ struct FuncParams {
   uint32_t mask;             // SMILEHIP_FUNC_* bits
   int64_t single_rows;       // >= 0: ONE segment of this many rows starting at x (row_off unused, no cut); -1: use row_off
   float *out;                // [n_utt x ld_out], n_cols * popcount(mask) values per utterance
+  int64_t ld_out;
+};
+
+// General functionals (lld_funcspec.hip): one cFunctionals instance over columns [col_first, col_first + n_cols) of
+// the utterances' rows (or of ONE matrix if single_rows >= 0).
+struct FsParams {
+  smilehip_func_spec spec;
+  const float *x;
+  int64_t ld_x;
+  int32_t col_first, n_cols;
+  const int64_t *row_off;    // [n_utt+1]; unused if single_rows >= 0
+  int64_t single_rows;
+  int32_t rows_cut;          // rows used per utterance = max(1, rows - rows_cut) (0 if the utterance has none)
+  int32_t per;               // values per column
+  const float *extra;        // optional: one more row per utterance, [n_utt x ld_extra]
+  int64_t ld_extra;
+  // scratch, all indexed by scratch row = row_off[u] + u (+ t) and column: [scratch_rows x n_cols]
+  float *nz;                 // compacted columns (nonZeroFuncts)
+  unsigned char *alive;      // Peaks2
+  float *sorted;             // Percentiles beyond the LDS capacity: 2 * scratch_rows * n_cols floats
+  float *st_min, *st_max, *st_mean;   // [n_utt x n_cols]
+  int32_t *st_n;
+  float *out;                // [n_utt x ld_out]
   int64_t ld_out;
 };
 

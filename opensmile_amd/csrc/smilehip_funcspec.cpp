@@ -1,0 +1,258 @@
+// libsmilehip, C ABI part 5: general functionals -- any cFunctionals instance over LLD matrices
+// (include/smilehip.h, "general functionals"; kernels in lld_funcspec.hip).
+#include "smilehip_internal.hpp"
+
+namespace {
+
+int popc(uint32_t v) { return __builtin_popcount(v); }
+
+// values a family contributes; < 0 + message if the spec cannot be run
+int family_count(const smilehip_func_spec &s, int fam) {
+  switch (fam) {
+    case SMILEHIP_FAM_EXTREMES:
+      if (s.ext_mask & ~0xffu) return fail(SMILEHIP_ERR_INVALID, "Extremes: unknown bits in mask 0x%x", s.ext_mask);
+      return popc(s.ext_mask);
+    case SMILEHIP_FAM_MEANS:
+      if (s.means_mask & ~0x1ffffu) return fail(SMILEHIP_ERR_INVALID, "Means: unknown bits in mask 0x%x", s.means_mask);
+      return popc(s.means_mask);
+    case SMILEHIP_FAM_MOMENTS:
+      if (s.mom_mask & ~0x3fu) return fail(SMILEHIP_ERR_INVALID, "Moments: unknown bits in mask 0x%x", s.mom_mask);
+      if ((s.mom_mask & 0x20u) && s.mom_stddev_norm != 1 && s.mom_stddev_norm != 2)
+        return fail(SMILEHIP_ERR_INVALID, "Moments.stddevNorm must be 1 or 2 when its value is enabled");
+      return popc(s.mom_mask);
+    case SMILEHIP_FAM_REGRESSION:
+      if (s.reg_mask & ~0x3ffffu) return fail(SMILEHIP_ERR_INVALID, "Regression: unknown bits in mask 0x%x", s.reg_mask);
+      if (s.reg_norm_coeff < 0 || s.reg_norm_coeff > 2) return fail(SMILEHIP_ERR_INVALID, "Regression.normRegCoeff %d not in 0..2", s.reg_norm_coeff);
+      return popc(s.reg_mask);
+    case SMILEHIP_FAM_PERCENTILES:
+      if (s.pct_mask & ~0x3fu) return fail(SMILEHIP_ERR_INVALID, "Percentiles: unknown bits in mask 0x%x", s.pct_mask);
+      if (s.n_pctl < 0 || s.n_pctl > 8 || s.n_range < 0 || s.n_range > 8)
+        return fail(SMILEHIP_ERR_INVALID, "Percentiles: at most 8 percentile[] and 8 pctlrange[] entries");
+      if (s.n_pctl == 0 && s.n_range > 0) return fail(SMILEHIP_ERR_INVALID, "Percentiles: pctlrange[] without percentile[]");
+      for (int i = 0; i < s.n_pctl; ++i)
+        if (!(s.pctl[i] >= 0.0 && s.pctl[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Percentiles: percentile[%d] = %g not in [0, 1]", i, s.pctl[i]);
+      for (int i = 0; i < s.n_range; ++i)
+        if (s.range_a[i] < 0 || s.range_a[i] >= s.n_pctl || s.range_b[i] < 0 || s.range_b[i] >= s.n_pctl || s.range_a[i] == s.range_b[i])
+          return fail(SMILEHIP_ERR_INVALID, "Percentiles: pctlrange[%d] = %d-%d is not a pair of distinct percentile[] indices", i, s.range_a[i], s.range_b[i]);
+      return popc(s.pct_mask) + s.n_pctl + s.n_range;
+    case SMILEHIP_FAM_TIMES:
+      if (s.times_mask & ~0x1fffu) return fail(SMILEHIP_ERR_INVALID, "Times: unknown bits in mask 0x%x", s.times_mask);
+      return popc(s.times_mask);
+    case SMILEHIP_FAM_SEGMENTS:
+      if (s.seg_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Segments: unknown bits in mask 0x%x", s.seg_mask);
+      if (s.seg_algo != SMILEHIP_SEG_RELTH && s.seg_algo != SMILEHIP_SEG_NONX)
+        return fail(SMILEHIP_ERR_INVALID, "Segments: segmentationAlgorithm %d is not built (relTh and nonX are)", s.seg_algo);
+      if (s.seg_max_num < 1) return fail(SMILEHIP_ERR_INVALID, "Segments.maxNumSeg must be >= 1");
+      if (s.seg_n_thresholds < 0 || s.seg_n_thresholds > 8) return fail(SMILEHIP_ERR_INVALID, "Segments: at most 8 thresholds");
+      if (s.seg_min_lng < 1 || s.seg_pause_min_lng < 1) return fail(SMILEHIP_ERR_INVALID, "Segments: segMinLng and pauseMinLng must be >= 1");
+      return popc(s.seg_mask);
+    case SMILEHIP_FAM_LPC: {
+      const int o = s.lpc_order;
+      const bool built = (o >= 1 && o <= 8) || o == 10 || o == 12 || o == 16;
+      if (!built) return fail(SMILEHIP_ERR_INVALID, "Lpc.order %d is not built (1..8, 10, 12, 16 are)", o);
+      if (s.lpc_first < 0 || s.lpc_first >= o) return fail(SMILEHIP_ERR_INVALID, "Lpc.firstCoeff %d not in 0..order-1", s.lpc_first);
+      return (s.lpc_gain ? 1 : 0) + (s.lpc_coeffs ? o - s.lpc_first : 0);
+    }
+    case SMILEHIP_FAM_PEAKS2:
+      return popc(s.pk_mask);
+  }
+  return fail(SMILEHIP_ERR_INVALID, "unknown functional family %d", fam);
+}
+
+int norm_ok(int v) { return v == SMILEHIP_NORM_SEGMENT || v == SMILEHIP_NORM_SECOND || v == SMILEHIP_NORM_FRAME; }
+
+int spec_layout(const smilehip_func_spec *s, int *fam_off, int *fam_want) {
+  if (!s) return fail(SMILEHIP_ERR_INVALID, "null functionals spec");
+  if (s->n_fam < 1 || s->n_fam > 12) return fail(SMILEHIP_ERR_INVALID, "functionalsEnabled: %d families (1..12)", s->n_fam);
+  if (s->non_zero_functs < 0 || s->non_zero_functs > 2) return fail(SMILEHIP_ERR_INVALID, "nonZeroFuncts %d not in 0..2", s->non_zero_functs);
+  if (!norm_ok(s->ext_norm) || !norm_ok(s->means_norm) || !norm_ok(s->times_norm) || !norm_ok(s->seg_norm) || !norm_ok(s->pk_norm) ||
+      !norm_ok(s->reg_centroid_norm))
+    return fail(SMILEHIP_ERR_INVALID, "time norm must be 0 (segment), 1 (second) or 2 (frame)");
+  if (!(s->period > 0.0)) return fail(SMILEHIP_ERR_INVALID, "functionals spec: period must be > 0");
+  int n = 0;
+  for (int i = 0; i < s->n_fam; ++i) {
+    const int c = family_count(*s, s->fam[i]);
+    if (c < 0) return c;
+    if (fam_off) fam_off[i] = n;
+    if (fam_want) fam_want[i] = c;
+    n += c;
+  }
+  if (n < 1) return fail(SMILEHIP_ERR_INVALID, "functionals spec enables no value");
+  return n;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// carves the scratch for scratch_rows x n_cols (+ per-utterance stats) out of the context's buffer
+int fs_scratch(smilehip_context *ctx, FsParams &P, int64_t scratch_rows, int n_utt, bool need_nz, bool need_alive, bool need_sorted,
+               hipStream_t stream) {
+  const size_t cells = size_t(scratch_rows) * size_t(P.n_cols), st = size_t(n_utt) * size_t(P.n_cols);
+  size_t off = 0;
+  const size_t o_nz = off; off += need_nz ? align256(cells * 4) : 0;
+  const size_t o_alive = off; off += need_alive ? align256(cells) : 0;
+  const size_t o_sorted = off; off += need_sorted ? align256(cells * 8) : 0;
+  const size_t o_st = off; off += 4 * align256(st * 4);
+  if (off > ctx->fs_cap) {
+    // earlier launches may still read the old buffer
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->fs_scratch) (void)hipFree(ctx->fs_scratch);
+    ctx->fs_scratch = nullptr;
+    ctx->fs_cap = 0;
+    const size_t want = off + off / 4;
+    HIP_TRY(hipMalloc(&ctx->fs_scratch, want));
+    ctx->fs_cap = want;
+  }
+  char *b = static_cast<char *>(ctx->fs_scratch);
+  P.nz = need_nz ? reinterpret_cast<float *>(b + o_nz) : nullptr;
+  P.alive = need_alive ? reinterpret_cast<unsigned char *>(b + o_alive) : nullptr;
+  P.sorted = need_sorted ? reinterpret_cast<float *>(b + o_sorted) : nullptr;
+  P.st_min = reinterpret_cast<float *>(b + o_st);
+  P.st_max = reinterpret_cast<float *>(b + o_st + align256(st * 4));
+  P.st_mean = reinterpret_cast<float *>(b + o_st + 2 * align256(st * 4));
+  P.st_n = reinterpret_cast<int32_t *>(b + o_st + 3 * align256(st * 4));
+  return SMILEHIP_OK;
+}
+
+bool has_family(const smilehip_func_spec &s, int fam) {
+  for (int i = 0; i < s.n_fam; ++i)
+    if (s.fam[i] == fam) return true;
+  return false;
+}
+
+int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows, int64_t max_rows, hipStream_t stream) {
+  int fam_off[12], fam_want[12];
+  const int per = spec_layout(&P.spec, fam_off, fam_want);
+  if (per < 0) return per;
+  P.per = per;
+  const bool need_sorted = has_family(P.spec, SMILEHIP_FAM_PERCENTILES) && max_rows > fs_sort_lds_rows();
+  int rc = fs_scratch(ctx, P, scratch_rows, n_utt, P.spec.non_zero_functs != 0, has_family(P.spec, SMILEHIP_FAM_PEAKS2), need_sorted, stream);
+  if (rc) return rc;
+  hipError_t e = launch_funcspec(P, n_utt, fam_off, fam_want, stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int smilehip_funcspec_count(const smilehip_func_spec *spec) { return spec_layout(spec, nullptr, nullptr); }
+
+// config/compare16/ComParE_2016_core.func.conf.inc
+extern "C" int smilehip_funcspec_compare16(const char *instance, smilehip_func_spec *s) {
+  if (!instance || !s) return fail(SMILEHIP_ERR_INVALID, "smilehip_funcspec_compare16: null argument");
+  std::memset(s, 0, sizeof(*s));
+  s->period = 0.01;
+  const std::string k(instance);
+  auto fams = [&](std::initializer_list<int> l) {
+    s->n_fam = 0;
+    for (int f : l) s->fam[s->n_fam++] = f;
+  };
+  auto extremes = [&] { s->ext_mask = (1u << 2) | (1u << 3) | (1u << 4); s->ext_norm = SMILEHIP_NORM_SEGMENT; };       // range maxPos minPos; masterTimeNorm
+  auto percentiles = [&] {
+    s->pct_mask = 0x3f; s->pct_interp = 1; s->n_pctl = 2; s->pctl[0] = 0.01; s->pctl[1] = 0.99;
+    s->n_range = 1; s->range_a[0] = 0; s->range_b[0] = 1;
+  };
+  auto moments = [&] { s->mom_mask = (1u << 1) | (1u << 2) | (1u << 3); s->mom_ratio_limit = 1; };
+  auto times = [&] {
+    s->times_mask = (1u << 0) | (1u << 2) | (1u << 4) | (1u << 6) | (1u << 8) | (1u << 10);
+    s->times_norm = SMILEHIP_NORM_SEGMENT;
+  };
+  auto lpc = [&] { s->lpc_gain = 1; s->lpc_coeffs = 1; s->lpc_first = 0; s->lpc_order = 5; };
+  auto segments = [&](int algo) {
+    s->seg_mask = 0x1e; s->seg_norm = SMILEHIP_NORM_SECOND; s->seg_algo = algo; s->seg_max_num = 100;
+    s->seg_min_lng = 3; s->seg_auto_min_lng = 1; s->seg_pause_min_lng = 2;
+    if (algo == SMILEHIP_SEG_RELTH) { s->seg_n_thresholds = 2; s->seg_thresholds[0] = 0.25f; s->seg_thresholds[1] = 0.75f; }
+  };
+  auto regression = [&](int norm_coeff) {
+    s->reg_mask = (1u << 0) | (1u << 1) | (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9);
+    s->reg_centroid_norm = SMILEHIP_NORM_SEGMENT; s->reg_norm_coeff = norm_coeff;
+    s->reg_norm_inputs = s->reg_centroid_abs = s->reg_centroid_limit = s->reg_ratio_limit = 1;
+  };
+  auto peaks2 = [&] {
+    s->pk_mask = (1u << 1) | (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8) | (1u << 14) | (1u << 22) |
+                 (1u << 25) | (1u << 26) | (1u << 29);
+    s->pk_norm = SMILEHIP_NORM_SECOND; s->pk_ratio_limit = 1; s->pk_rel_thresh = 0.1f;
+  };
+  // norms a family does not use still have to be valid
+  s->means_norm = SMILEHIP_NORM_FRAME; s->seg_norm = SMILEHIP_NORM_SEGMENT; s->pk_norm = SMILEHIP_NORM_FRAME;
+  if (k == "A" || k == "B") {
+    fams({SMILEHIP_FAM_EXTREMES, SMILEHIP_FAM_PERCENTILES, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_TIMES, SMILEHIP_FAM_LPC});
+    extremes(); percentiles(); moments(); segments(SMILEHIP_SEG_RELTH); times(); lpc();
+  } else if (k == "F0") {
+    fams({SMILEHIP_FAM_MEANS, SMILEHIP_FAM_SEGMENTS});
+    s->means_mask = 1u << 7; s->means_norm = SMILEHIP_NORM_SEGMENT;
+    segments(SMILEHIP_SEG_NONX);
+    s->seg_x = 0.0f;
+  } else if (k == "Nz") {
+    fams({SMILEHIP_FAM_MEANS, SMILEHIP_FAM_EXTREMES, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES, SMILEHIP_FAM_MOMENTS,
+          SMILEHIP_FAM_TIMES, SMILEHIP_FAM_LPC});
+    s->non_zero_functs = 1;
+    s->means_mask = (1u << 0) | (1u << 8) | (1u << 9) | (1u << 15); s->means_norm = SMILEHIP_NORM_FRAME;
+    extremes(); regression(0); percentiles(); moments(); times(); lpc();
+  } else if (k == "LLD") {
+    fams({SMILEHIP_FAM_MEANS, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_REGRESSION});
+    s->means_mask = (1u << 0) | (1u << 8) | (1u << 15);
+    peaks2(); regression(2);
+  } else if (k == "Delta") {
+    fams({SMILEHIP_FAM_MEANS, SMILEHIP_FAM_PEAKS2});
+    s->means_mask = (1u << 8) | (1u << 9) | (1u << 15);
+    peaks2();
+  } else {
+    return fail(SMILEHIP_ERR_INVALID, "unknown ComParE_2016 functionals instance '%s' (A, B, F0, Nz, LLD, Delta)", instance);
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_funcspec_matrix(smilehip_context *ctx, const smilehip_func_spec *spec, const float *d_x, int64_t ld_x,
+                                        int64_t rows, int32_t cols, float *d_out, void *stream) {
+  if (!ctx || !spec || rows < 1 || cols < 1 || ld_x < cols || !d_x || !d_out)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_funcspec_matrix: bad argument");
+  FsParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.spec = *spec;
+  P.x = d_x;
+  P.ld_x = ld_x;
+  P.col_first = 0;
+  P.n_cols = cols;
+  P.single_rows = rows;
+  P.out = d_out;
+  const int per = spec_layout(spec, nullptr, nullptr);
+  if (per < 0) return per;
+  P.ld_out = (int64_t)cols * per;
+  return run_spec(ctx, P, 1, rows, rows, (hipStream_t)stream);
+}
+
+extern "C" int smilehip_batch_funcspec(smilehip_plan *plan, smilehip_batch *b, const smilehip_func_spec *spec, const float *d_lld,
+                                       int64_t ld_lld, int32_t col_first, int32_t n_cols, int32_t rows_cut, const float *d_extra,
+                                       int64_t ld_extra, float *d_func, int64_t ld_func, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_funcspec: plan/batch mismatch");
+  if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "smilehip_batch_funcspec: host-only plan");
+  const int per = spec_layout(spec, nullptr, nullptr);
+  if (per < 0) return per;
+  if (col_first < 0 || n_cols < 1 || col_first + n_cols > ld_lld)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_funcspec: columns [%d, %d) outside the matrix (ld %lld)", col_first,
+                col_first + n_cols, (long long)ld_lld);
+  if (rows_cut < 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_funcspec: rows_cut must be >= 0");
+  if (ld_func < (int64_t)n_cols * per)
+    return fail(SMILEHIP_ERR_INVALID, "ld_func %lld < %d values per utterance", (long long)ld_func, n_cols * per);
+  if (d_extra && ld_extra < n_cols) return fail(SMILEHIP_ERR_INVALID, "ld_extra %lld < n_cols %d", (long long)ld_extra, n_cols);
+  if (!d_func || (!d_lld && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_funcspec: null device pointer");
+  if (b->n_utt == 0) return SMILEHIP_OK;
+  int64_t max_rows = 0;
+  for (int u = 0; u < b->n_utt; ++u) max_rows = std::max(max_rows, b->h_row_off[u + 1] - b->h_row_off[u] + 1);
+  FsParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.spec = *spec;
+  P.x = d_lld;
+  P.ld_x = ld_lld;
+  P.col_first = col_first;
+  P.n_cols = n_cols;
+  P.row_off = b->d_row_off.p;
+  P.single_rows = -1;
+  P.rows_cut = rows_cut;
+  P.extra = d_extra;
+  P.ld_extra = ld_extra;
+  P.out = d_func;
+  P.ld_out = ld_func;
+  return run_spec(plan->ctx, P, b->n_utt, b->total_rows + b->n_utt, max_rows, (hipStream_t)stream);
+}

@@ -33,6 +33,12 @@ int fail(int code, const char *fmt, ...);   // records the thread-local message,
 struct smilehip_context {
   int device = 0;
   hipDeviceProp_t prop{};
+  // scratch of the general functionals (smilehip_funcspec.cpp), grown on demand
+  void *fs_scratch = nullptr;
+  size_t fs_cap = 0;
+  ~smilehip_context() {
+    if (fs_scratch) (void)hipFree(fs_scratch);
+  }
 };
 
 template <typename T>

@@ -440,3 +440,191 @@ def htk_variant_chain(name, pcm):
     if T > 0:
         L.lldo_htk_variant_chain(plp, energy, cms, pcm.ctypes.data, len(pcm), out.ctypes.data)
     return out
+
+
+# ---- general functionals engine (lld_oracle_funcspec.c) ---------------------------------------------------------
+FAM = {"Extremes": 0, "Means": 1, "Moments": 2, "Regression": 3, "Percentiles": 4, "Times": 5, "Segments": 6, "Lpc": 7,
+       "Peaks2": 8}
+NORM = {"segment": 0, "second": 1, "frame": 2}
+EXT_NAMES = ["max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"]
+MEANS_NAMES = ["amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness", "posamean",
+               "negamean", "posqmean", "posrqmean", "negqmean", "negrqmean", "rqmean", "nzrqmean"]
+MOM_NAMES = ["variance", "stddev", "skewness", "kurtosis", "amean", "stddevNorm"]
+REG_NAMES = ["linregc1", "linregc2", "linregerrA", "linregerrQ", "qregc1", "qregc2", "qregc3", "qregerrA", "qregerrQ",
+             "centroid", "qregls", "qregrs", "qregx0", "qregy0", "qregyr", "qregy0nn", "qregc3nn", "qregyrnn"]
+PCT_NAMES = ["quartile1", "quartile2", "quartile3", "iqr1-2", "iqr2-3", "iqr1-3"]
+TIMES_NAMES = ["upleveltime25", "downleveltime25", "upleveltime50", "downleveltime50", "upleveltime75", "downleveltime75",
+               "upleveltime90", "downleveltime90", "risetime", "falltime", "leftctime", "rightctime", "duration"]
+SEG_NAMES = ["numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"]
+PK_NAMES = ["numPeaks", "meanPeakDist", "meanPeakDistDelta", "peakDistStddev", "peakRangeAbs", "peakRangeRel", "peakMeanAbs",
+            "peakMeanMeanDist", "peakMeanRel", "ptpAmpMeanAbs", "ptpAmpMeanRel", "ptpAmpStddevAbs", "ptpAmpStddevRel",
+            "minRangeAbs", "minRangeRel", "minMeanAbs", "minMeanMeanDist", "minMeanRel", "mtmAmpMeanAbs", "mtmAmpMeanRel",
+            "mtmAmpStddevAbs", "mtmAmpStddevRel", "meanRisingSlope", "maxRisingSlope", "minRisingSlope", "stddevRisingSlope",
+            "meanFallingSlope", "maxFallingSlope", "minFallingSlope", "stddevFallingSlope", "covFallingSlope", "covRisingSlope"]
+
+
+def _mask(names, on):
+    return sum(1 << names.index(n) for n in on)
+
+
+class FuncSpec(C.Structure):
+    """lldo_func_spec (oracle/lld_oracle_funcspec.h), field for field."""
+    _fields_ = [
+        ("n_fam", C.c_int32), ("fam", C.c_int32 * 12), ("non_zero_functs", C.c_int32), ("reserved0", C.c_int32),
+        ("period", C.c_double),
+        ("ext_mask", C.c_uint32), ("ext_norm", C.c_int32),
+        ("means_mask", C.c_uint32), ("means_norm", C.c_int32),
+        ("mom_mask", C.c_uint32), ("mom_stddev_norm", C.c_int32), ("mom_ratio_limit", C.c_int32), ("reserved1", C.c_int32),
+        ("reg_mask", C.c_uint32), ("reg_centroid_norm", C.c_int32), ("reg_norm_coeff", C.c_int32),
+        ("reg_norm_inputs", C.c_int32), ("reg_centroid_abs", C.c_int32), ("reg_centroid_limit", C.c_int32),
+        ("reg_ratio_limit", C.c_int32), ("reg_old_buggy_qerr", C.c_int32),
+        ("pct_mask", C.c_uint32), ("pct_interp", C.c_int32), ("n_pctl", C.c_int32), ("n_range", C.c_int32),
+        ("pctl", C.c_double * 8), ("range_a", C.c_int32 * 8), ("range_b", C.c_int32 * 8),
+        ("times_mask", C.c_uint32), ("times_norm", C.c_int32), ("times_buggy_sec_norm", C.c_int32), ("reserved2", C.c_int32),
+        ("seg_mask", C.c_uint32), ("seg_norm", C.c_int32), ("seg_algo", C.c_int32), ("seg_max_num", C.c_int32),
+        ("seg_min_lng", C.c_int32), ("seg_auto_min_lng", C.c_int32), ("seg_pause_min_lng", C.c_int32),
+        ("seg_x_is_rel", C.c_int32), ("seg_n_thresholds", C.c_int32), ("reserved3", C.c_int32),
+        ("seg_x", C.c_float), ("seg_thresholds", C.c_float * 8), ("reserved4", C.c_float),
+        ("lpc_gain", C.c_int32), ("lpc_coeffs", C.c_int32), ("lpc_first", C.c_int32), ("lpc_order", C.c_int32),
+        ("pk_mask", C.c_uint32), ("pk_norm", C.c_int32), ("pk_ratio_limit", C.c_int32), ("pk_dyn_rel", C.c_int32),
+        ("pk_use_abs", C.c_int32), ("reserved5", C.c_int32),
+        ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
+    ]
+
+
+def _spec_common(s, fams, period=0.01):
+    s.n_fam = len(fams)
+    for i, f in enumerate(fams):
+        s.fam[i] = FAM[f]
+    s.period = period
+    return s
+
+
+def _set_ext(s):
+    s.ext_mask = _mask(EXT_NAMES, ["range", "maxPos", "minPos"])
+    s.ext_norm = NORM["segment"]
+
+
+def _set_pct(s):
+    s.pct_mask = 0x3f
+    s.pct_interp = 1
+    s.n_pctl = 2
+    s.pctl[0], s.pctl[1] = 0.01, 0.99
+    s.n_range = 1
+    s.range_a[0], s.range_b[0] = 0, 1
+
+
+def _set_mom(s):
+    s.mom_mask = _mask(MOM_NAMES, ["stddev", "skewness", "kurtosis"])
+    s.mom_ratio_limit = 1
+
+
+def _set_times(s):
+    s.times_mask = _mask(TIMES_NAMES, ["upleveltime25", "upleveltime50", "upleveltime75", "upleveltime90", "risetime",
+                                       "leftctime"])
+    s.times_norm = NORM["segment"]
+
+
+def _set_lpc(s):
+    s.lpc_gain, s.lpc_coeffs, s.lpc_first, s.lpc_order = 1, 1, 0, 5
+
+
+def _set_reg(s, norm_coeff):
+    s.reg_mask = _mask(REG_NAMES, ["linregc1", "linregc2", "linregerrQ", "qregc1", "qregc2", "qregc3", "qregerrQ", "centroid"])
+    s.reg_centroid_norm = NORM["segment"]
+    s.reg_norm_coeff = norm_coeff
+    s.reg_norm_inputs = s.reg_centroid_abs = s.reg_centroid_limit = s.reg_ratio_limit = 1
+
+
+def _set_pk(s):
+    s.pk_mask = _mask(PK_NAMES, ["meanPeakDist", "peakDistStddev", "peakRangeAbs", "peakRangeRel", "peakMeanAbs",
+                                 "peakMeanMeanDist", "peakMeanRel", "minRangeRel", "meanRisingSlope", "stddevRisingSlope",
+                                 "meanFallingSlope", "stddevFallingSlope"])
+    s.pk_norm = NORM["second"]
+    s.pk_ratio_limit = 1
+    s.pk_rel_thresh = 0.1
+
+
+def compare16_func_spec(inst):
+    """The six cFunctionals instances of config/compare16/ComParE_2016_core.func.conf.inc: 'A' (= 'B'), 'F0', 'Nz',
+    'LLD', 'Delta'."""
+    s = FuncSpec()
+    if inst in ("A", "B"):
+        _spec_common(s, ["Extremes", "Percentiles", "Moments", "Segments", "Times", "Lpc"])
+        _set_ext(s); _set_pct(s); _set_mom(s); _set_times(s); _set_lpc(s)
+        s.seg_mask = _mask(SEG_NAMES, ["meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"])
+        s.seg_norm, s.seg_algo, s.seg_max_num = NORM["second"], 0, 100
+        s.seg_min_lng, s.seg_auto_min_lng, s.seg_pause_min_lng = 3, 1, 2
+        s.seg_n_thresholds = 2
+        s.seg_thresholds[0], s.seg_thresholds[1] = 0.25, 0.75
+    elif inst == "F0":
+        _spec_common(s, ["Means", "Segments"])
+        s.means_mask, s.means_norm = _mask(MEANS_NAMES, ["nnz"]), NORM["segment"]
+        s.seg_mask = _mask(SEG_NAMES, ["meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"])
+        s.seg_norm, s.seg_algo, s.seg_max_num = NORM["second"], 1, 100
+        s.seg_min_lng, s.seg_auto_min_lng, s.seg_pause_min_lng = 3, 1, 2
+        s.seg_x = 0.0
+    elif inst == "Nz":
+        _spec_common(s, ["Means", "Extremes", "Regression", "Percentiles", "Moments", "Times", "Lpc"])
+        s.non_zero_functs = 1
+        s.means_mask, s.means_norm = _mask(MEANS_NAMES, ["amean", "posamean", "rqmean", "flatness"]), NORM["frame"]
+        _set_ext(s); _set_reg(s, 0); _set_pct(s); _set_mom(s); _set_times(s); _set_lpc(s)
+    elif inst == "LLD":
+        _spec_common(s, ["Means", "Peaks2", "Regression"])
+        s.means_mask, s.means_norm = _mask(MEANS_NAMES, ["amean", "rqmean", "flatness"]), NORM["frame"]
+        _set_pk(s); _set_reg(s, 2)
+    elif inst == "Delta":
+        _spec_common(s, ["Means", "Peaks2"])
+        s.means_mask, s.means_norm = _mask(MEANS_NAMES, ["posamean", "rqmean", "flatness"]), NORM["frame"]
+        _set_pk(s)
+    else:
+        raise ValueError(inst)
+    return s
+
+
+def funcspec_names(s):
+    """Value names of a spec in output order, as cFunctionals::setupNamesForElement builds the suffixes."""
+    out = []
+    inv = {v: k for k, v in FAM.items()}
+    for i in range(s.n_fam):
+        f = inv[s.fam[i]]
+        if f == "Extremes":
+            out += [n for k, n in enumerate(EXT_NAMES) if s.ext_mask >> k & 1]
+        elif f == "Means":
+            out += [n for k, n in enumerate(MEANS_NAMES) if s.means_mask >> k & 1]
+        elif f == "Moments":
+            out += [n for k, n in enumerate(MOM_NAMES) if s.mom_mask >> k & 1]
+        elif f == "Regression":
+            out += [n for k, n in enumerate(REG_NAMES) if s.reg_mask >> k & 1]
+        elif f == "Percentiles":
+            out += [n for k, n in enumerate(PCT_NAMES) if s.pct_mask >> k & 1]
+            out += ["percentile%.1f" % (s.pctl[k] * 100.0) for k in range(s.n_pctl)]
+            out += ["pctlrange%d-%d" % (s.range_a[k], s.range_b[k]) for k in range(s.n_range)]
+        elif f == "Times":
+            out += [n for k, n in enumerate(TIMES_NAMES) if s.times_mask >> k & 1]
+        elif f == "Segments":
+            out += [n for k, n in enumerate(SEG_NAMES) if s.seg_mask >> k & 1]
+        elif f == "Lpc":
+            out += (["lpgain"] if s.lpc_gain else []) + (["lpc%d" % k for k in range(s.lpc_first, s.lpc_order)]
+                                                         if s.lpc_coeffs else [])
+        elif f == "Peaks2":
+            out += [n for k, n in enumerate(PK_NAMES) if s.pk_mask >> k & 1]
+    return out
+
+
+def funcspec(x, spec):
+    """rows x cols matrix -> cols x count(spec) functionals."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    L = lib()
+    L.lldo_funcspec_count.restype = C.c_int
+    L.lldo_funcspec_count.argtypes = [C.c_void_p]
+    L.lldo_funcspec_apply.restype = C.c_int
+    L.lldo_funcspec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+    per = L.lldo_funcspec_count(C.byref(spec))
+    if per < 0:
+        raise ValueError("unusable functionals spec")
+    rows, cols = x.shape
+    out = np.zeros((cols, per), np.float32)
+    if rows > 0:
+        L.lldo_funcspec_apply(C.byref(spec), x.ctypes.data, x.strides[0] // 4, rows, cols, out.ctypes.data)
+    return out

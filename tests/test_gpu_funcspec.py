@@ -1,0 +1,177 @@
+"""General functionals (any cFunctionals instance, the nine families of ComParE_2016) through the C ABI's
+smilehip_funcspec_matrix / smilehip_batch_funcspec against the CPU oracle (oracle/lld_oracle_funcspec.c, itself pinned
+bit-exact against the real binary's functionals level in test_oracle_pin_funcspec.py).
+
+The device walks every column in the reference's order, so all values agree bit for bit except the few that pass
+through libm (log / exp: Means' nzgmean and flatness, the tanh soft limiter of ratio features): those are held to
+1e-6 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_oracle_pin_f0 import KEYS_130
+
+pytestmark = pytest.mark.gpu
+
+INSTANCES = ["A", "B", "F0", "Nz", "LLD", "Delta"]
+LIBM = {"flatness", "nzgmean", "peakMeanRel", "minMeanRel", "centroid", "linregc1", "qregc1", "qregc2", "stddevNorm",
+        "covFallingSlope", "covRisingSlope"}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from opensmile_amd import capi
+    return capi, capi.Context(0)
+
+
+def as_oracle_spec(oracle, spec):
+    o = oracle.FuncSpec()
+    assert C.sizeof(o) == C.sizeof(spec)
+    C.memmove(C.byref(o), C.byref(spec), C.sizeof(spec))
+    return o
+
+
+def check(oracle, spec, dev, ref, what):
+    names = oracle.funcspec_names(as_oracle_spec(oracle, spec))
+    assert dev.shape == ref.shape == (ref.shape[0], len(names)), (what, dev.shape, ref.shape, len(names))
+    for k, n in enumerate(names):
+        d, r = dev[:, k], ref[:, k]
+        if n in LIBM:
+            err = np.abs(d.astype(np.float64) - r) / np.maximum(np.abs(r), 1e-6)
+            assert err.max() <= 1e-6, f"{what}: {n} rel err {err.max():.3g}"
+        else:
+            same = d.view(np.uint32) == r.view(np.uint32)
+            assert same.all(), f"{what}: {n} differs in columns {np.flatnonzero(~same)[:6]}: {d[~same][:3]} vs {r[~same][:3]}"
+
+
+@pytest.mark.parametrize("inst", INSTANCES)
+def test_funcspec_matrix_vs_oracle_on_real_llds(hip, oracle, golden_f0, inst):
+    capi, ctx = hip
+    spec = capi.funcspec_compare16(inst)
+    for key in KEYS_130[:2]:
+        x = golden_f0["lld130_" + key]
+        if x.shape[0] < 8:
+            continue
+        cols = list(range(0, 12)) if inst in ("F0", "Nz") else list(range(6, 65)) + list(range(71, 130))
+        xs = np.ascontiguousarray(x[:, cols])
+        dev = capi.funcspec_matrix_host(ctx, spec, xs)
+        ref = oracle.funcspec(xs, as_oracle_spec(oracle, spec))
+        check(oracle, spec, dev, ref, f"{inst}/{key}")
+
+
+@pytest.mark.parametrize("inst", INSTANCES)
+def test_funcspec_edge_shapes(hip, oracle, inst):
+    """Very short contours (every N from 1 to 9), constant and all-zero columns, NaN-free ratio limits."""
+    capi, ctx = hip
+    spec = capi.funcspec_compare16(inst)
+    rng = np.random.default_rng(7)
+    for rows in list(range(1, 10)) + [37]:
+        x = rng.standard_normal((rows, 9)).astype(np.float32)
+        x[:, 1] = 0.0                        # all zero (nonZeroFuncts: no value at all)
+        x[:, 2] = 3.5                        # constant: range 0
+        x[:, 3] = np.where(np.arange(rows) % 3 == 0, 0.0, x[:, 3])      # zeros interleaved
+        x[:, 4] = np.abs(x[:, 4])
+        x[:, 5] = np.round(x[:, 5] * 2) / 2  # ties
+        dev = capi.funcspec_matrix_host(ctx, spec, x)
+        ref = oracle.funcspec(x, as_oracle_spec(oracle, spec))
+        assert np.isfinite(dev).all()
+        check(oracle, spec, dev, ref, f"{inst}/rows{rows}")
+
+
+def test_funcspec_long_contour_global_sort(hip, oracle):
+    """More rows than the LDS sort holds (8192): the percentile stage sorts in global scratch."""
+    capi, ctx = hip
+    spec = capi.funcspec_compare16("Nz")
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((20000, 3)).astype(np.float32)
+    x[::7, 1] = 0.0
+    dev = capi.funcspec_matrix_host(ctx, spec, x)
+    ref = oracle.funcspec(x, as_oracle_spec(oracle, spec))
+    check(oracle, spec, dev, ref, "Nz/20000 rows")
+
+
+def test_funcspec_custom_spec_all_values(hip, oracle):
+    """Every value of every family switched on, second / frame norms, nonX with a relative X, non-interpolated
+    percentiles: the option paths the ComParE instances do not take."""
+    capi, ctx = hip
+    s = capi.FuncSpec()
+    fams = [capi_f for capi_f in range(9)]
+    s.n_fam = len(fams)
+    for i, f in enumerate(fams):
+        s.fam[i] = f
+    s.period = 0.02
+    s.ext_mask, s.ext_norm = 0xff, 1
+    s.means_mask, s.means_norm = 0x1ffff, 1
+    s.mom_mask, s.mom_stddev_norm, s.mom_ratio_limit = 0x3f, 1, 1
+    s.reg_mask, s.reg_centroid_norm, s.reg_norm_coeff = 0x3ffff, 1, 1
+    s.reg_norm_inputs, s.reg_centroid_abs, s.reg_centroid_limit, s.reg_ratio_limit, s.reg_old_buggy_qerr = 0, 0, 0, 0, 1
+    s.pct_mask, s.pct_interp, s.n_pctl, s.n_range = 0x3f, 0, 3, 2
+    s.pctl[0], s.pctl[1], s.pctl[2] = 0.05, 0.5, 0.95
+    s.range_a[0], s.range_b[0], s.range_a[1], s.range_b[1] = 0, 2, 1, 0
+    s.times_mask, s.times_norm, s.times_buggy_sec_norm = 0x1fff, 1, 0
+    s.seg_mask, s.seg_norm, s.seg_algo, s.seg_max_num = 0x1f, 2, 1, 5
+    s.seg_min_lng, s.seg_auto_min_lng, s.seg_pause_min_lng, s.seg_x_is_rel, s.seg_x = 2, 0, 1, 1, 0.0
+    s.lpc_gain, s.lpc_coeffs, s.lpc_first, s.lpc_order = 1, 1, 1, 8
+    s.pk_mask, s.pk_norm, s.pk_ratio_limit, s.pk_dyn_rel, s.pk_rel_thresh = 0xffffffff, 0, 0, 1, 0.3
+    rng = np.random.default_rng(3)
+    x = np.abs(rng.standard_normal((400, 7))).astype(np.float32)
+    x[rng.random((400, 7)) < 0.3] = x.min(axis=0, keepdims=True).repeat(400, 0)[rng.random((400, 7)) < 0.3][:1].sum() * 0 + 0.0
+    dev = capi.funcspec_matrix_host(ctx, s, x)
+    ref = oracle.funcspec(x, as_oracle_spec(oracle, s))
+    names = oracle.funcspec_names(as_oracle_spec(oracle, s))
+    assert dev.shape == ref.shape
+    err = np.abs(dev.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-6)
+    assert err.max() <= 1e-6, [(names[k], float(err[:, k].max())) for k in np.argsort(-err.max(axis=0))[:4]]
+    exact = (dev.view(np.uint32) == ref.view(np.uint32)).mean()
+    assert exact > 0.97, exact
+
+
+def test_batch_funcspec_ragged_with_cut_and_extra_row(hip, oracle):
+    """smilehip_batch_funcspec on a ragged batch: per-utterance rows = max(1, rows - cut) (+ one extra row), column
+    sub-ranges, utterances without rows."""
+    capi, ctx = hip
+    from opensmile_amd import synth
+    plan = capi.Plan(ctx, capi.compare16_config())
+    lens = [48000, 0, 9000, 1760, 24000, 1600]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(70 + i, n) if n else np.zeros(0, np.int16) for i, n in enumerate(lens)])
+    b = capi.Batch(plan, off)
+    lld = b.run_host(pcm)
+    rng = np.random.default_rng(5)
+    for inst, c0, nc, cut, with_extra in (("A", 6, 4, 3, False), ("B", 10, 55, 0, True), ("Nz", 0, 6, 5, False),
+                                          ("LLD", 6, 59, 1, False), ("Delta", 71, 59, 3, False), ("F0", 0, 1, 3, False)):
+        spec = capi.funcspec_compare16(inst)
+        extra = rng.standard_normal((len(lens), nc)).astype(np.float32) if with_extra else None
+        dev = b.funcspec_host(lld, spec, c0, nc, cut, extra)
+        per = capi.funcspec_count(spec)
+        assert dev.shape == (len(lens), nc * per)
+        for u in range(len(lens)):
+            x = lld[b.frame_offsets[u]:b.frame_offsets[u + 1], c0:c0 + nc]
+            if x.shape[0] == 0:
+                assert not dev[u].any()
+                continue
+            x = x[:max(1, x.shape[0] - cut)]
+            if with_extra:
+                x = np.concatenate([x, extra[u:u + 1]], axis=0)
+            ref = oracle.funcspec(np.ascontiguousarray(x), as_oracle_spec(oracle, spec))
+            check(oracle, spec, dev[u].reshape(nc, per), ref, f"{inst}/utt{u}")
+    b.close()
+
+
+def test_funcspec_rejects_unusable_specs(hip):
+    capi, ctx = hip
+    s = capi.funcspec_compare16("A")
+    s.lpc_order = 9
+    with pytest.raises(capi.SmileHipError, match="Lpc.order"):
+        capi.funcspec_count(s)
+    s = capi.funcspec_compare16("A")
+    s.seg_algo = 7
+    with pytest.raises(capi.SmileHipError, match="segmentationAlgorithm"):
+        capi.funcspec_count(s)
+    s = capi.funcspec_compare16("Nz")
+    s.range_b[0] = 5
+    with pytest.raises(capi.SmileHipError, match="pctlrange"):
+        capi.funcspec_count(s)
+    with pytest.raises(capi.SmileHipError, match="unknown ComParE_2016 functionals instance"):
+        capi.funcspec_compare16("C")
