@@ -309,6 +309,12 @@ static float vec_ll1(const float *src, int N)
  *   - the deltas are taken of those levels; the LLD sinks keep rows = T60+1.
  * out: rows x 118 ([A|B] sma, then their deltas). Requires T60 >= 4 (the lockstep quirk
  * of very short inputs is not restated for this multi-length graph); returns 0 otherwise. */
+/* Row T60+1 of group B's own levels (55 sma values, then 55 deltas): [is13_functionalsB] reads lldB_smo;lldB_smo_de,
+ * which hold more rows than the T60+1 the LLD sinks keep, and summarises T20-2 = T60+2 of them. Set a destination
+ * before calling lldo_compare_ab_chain (NULL switches it off). */
+static float *g_b_extra = NULL;
+void lldo_compare_set_b_extra(float *dst110) { g_b_extra = dst110; }
+
 long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float *raw59)
 {
   lldo_mfcc_cfg c;
@@ -391,6 +397,10 @@ long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float
   lvb[0] = (float *)malloc(sizeof(float) * (size_t)(T20 + 1) * DB);
   lvb[1] = (float *)malloc(sizeof(float) * (size_t)(T20 + 3) * DB);
   lldo_window_chain(lb, T20, DB, 2, kind, Wv, lvb);
+  if (g_b_extra) {
+    memcpy(g_b_extra, lvb[0] + rows * DB, sizeof(float) * DB);            /* rows = T60+1 < T20+1 */
+    memcpy(g_b_extra + DB, lvb[1] + rows * DB, sizeof(float) * DB);
+  }
   for (long t = 0; t < rows; t++) {
     float *o = out + t * 2 * D;
     memcpy(o, sa + t * DA, sizeof(float) * DA);

@@ -309,6 +309,28 @@ def functionals(x, mask=FUNC_IS09):
     return out
 
 
+def compare_b_extra(pcm):
+    """Row T60+1 of ComParE's group-B levels: (110,) = 55 sma values + 55 deltas (what [is13_functionalsB] sees beyond
+    the rows of the LLD sinks); None if the utterance yields no rows."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L = lib()
+    L.lldo_compare_ab_chain.restype = C.c_long
+    L.lldo_compare_ab_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    L.lldo_compare_set_b_extra.restype = None
+    L.lldo_compare_set_b_extra.argtypes = [C.c_void_p]
+    rows = L.lldo_compare_ab_chain(pcm.ctypes.data, len(pcm), None, None)
+    if rows <= 0:
+        return None
+    out = np.zeros((rows, 118), np.float32)
+    ex = np.zeros(110, np.float32)
+    L.lldo_compare_set_b_extra(ex.ctypes.data)
+    try:
+        L.lldo_compare_ab_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, None)
+    finally:
+        L.lldo_compare_set_b_extra(None)
+    return ex
+
+
 def plp_chain(pcm):
     """config/plp/PLP_0_D_A.conf: T x 18 [plp c1..c5,c0 | delta | accel]."""
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
@@ -353,6 +375,30 @@ def run_reference_taps(pcm, names=("hps", "shs", "vit", "pitch", "e60", "jit", "
         for n in tuple(names) + ("lld",):
             p = os.path.join(td, "lld.htk" if n == "lld" else "tap_%s.htk" % n)
             out[n] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        return out
+
+
+FUNC_TAPS_CONF = os.path.join(HERE, "conf", "compare_func_taps.conf")
+FUNC_TAPS = ("a_smo", "a_de", "b_smo", "b_de", "nz_smo", "nz_de", "f0_smo")
+
+
+def run_reference_func_taps(pcm, fs=16000):
+    """Real SMILExtract on ComParE_2016 (oracle/conf/compare_func_taps.conf): {"func": (6373,) or empty, "names": list,
+    "lld": LLD level, tap name: the level a cFunctionals instance reads, all its rows}."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", FUNC_TAPS_CONF, "-I", wav, "-htkoutput", "func.htk", "-csvoutput", "func.csv",
+                        "-lldhtkoutput", "lld.htk", "-l", "0"], check=True, cwd=td, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        out = {}
+        for n in FUNC_TAPS + ("lld", "func"):
+            p = os.path.join(td, ("%s.htk" % n) if n in ("lld", "func") else "tap_%s.htk" % n)
+            out[n] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        out["func"] = out["func"][0] if out["func"].shape[0] else np.zeros(0, np.float32)
+        csv = os.path.join(td, "func.csv")
+        out["names"] = open(csv).readline().strip().split(";")[2:] if os.path.exists(csv) else []
         return out
 
 

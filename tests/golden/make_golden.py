@@ -74,6 +74,26 @@ def gen_f0():
         print("f0", name, t["pitch"].shape, t["lld"].shape)
     np.savez_compressed(os.path.join(OUT, "compare16_f0_synth.npz"), **ref)
 
+def gen_func16():
+    """ComParE_2016 functionals: the 6373-value vector of the real binary plus, from the taps of
+    oracle/conf/compare_func_taps.conf, every row of the levels its six cFunctionals instances read."""
+    ref = {}
+    names = None
+    for name, (u, n) in {"u3_48000": (3, 48000), "u5_16000": (5, 16000), "u4_9000": (4, 9000), "u37_9000": (37, 9000),
+                          "u2_8720": (2, 8720), "u7_2720": (7, 2720), "u7_1760": (7, 1760), "u7_1440": (7, 1440)}.items():
+        pcm = synth.utterance(u, n)
+        t = lldo.run_reference_func_taps(pcm)
+        ref["pcm_" + name] = pcm
+        ref["func_" + name] = t["func"]
+        for k in lldo.FUNC_TAPS:
+            ref[k + "_" + name] = t[k]
+        names = names or t["names"]
+        assert names == t["names"]
+        print("func16", name, t["func"].shape, t["b_smo"].shape)
+    ref["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "compare16_func_synth.npz"), **ref)
+
+
 def gen_plp():
     # config/plp/PLP_0_D_A.conf (PLP-CC + delta + accel, 18 columns): R8's IDFT / LP / cepstrum branch
     ref = {}
@@ -96,6 +116,9 @@ def main(only=None):
         return
     if only == "plp":
         gen_plp()
+        return
+    if only == "func16":
+        gen_func16()
         return
     # config 2 shape, shortened: utterances 0 (zeros), 1 (square), 2, 3 (voiced), 10 (noise)
     # at 1.0 s, plus ragged lengths around the frame boundary (399/400/401/559/560/561 samples)
@@ -142,6 +165,7 @@ def main(only=None):
     gen_plp()
     gen_f0()
     gen_htk_variants()
+    gen_func16()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave
