@@ -332,6 +332,21 @@ int smilehip_batch_funcspec(smilehip_plan *plan, smilehip_batch *batch, const sm
                             const float *d_lld, int64_t ld_lld, int32_t col_first, int32_t n_cols, int32_t rows_cut,
                             const float *d_extra, int64_t ld_extra, float *d_func, int64_t ld_func, void *stream);
 
+/* The whole functionals level of config/compare16/ComParE_2016.conf: 6373 values per utterance in the reference's own
+ * order ([functionals] concatenates is13_functionalsA, B, Nz, F0, LLD, Delta; names: smilehip_host func_names_compare16).
+ * d_lld: the 130-column matrix smilehip_lld_run produced for THIS batch on a smilehip_config_compare16 plan (the run also
+ * leaves what the functionals need beyond that matrix: the Viterbi smoother's undecided-frame counts and row T60+1 of
+ * group B's levels). Rows each instance summarises -- decided in the reference by its first end-of-input tick
+ * (winToVecProcessor.cpp:504-528, 868-1098), measured against the binary -- with T = rows - 1 and P = frames the
+ * smoother had not decided (0 if P >= T): A T-2, B T+2, Nz T-P-2, F0 T-P, LLD T, Delta T-2 (at least 1).
+ * d_func: n_utt x ld_func (zeros for utterances without rows, where the reference writes no instance). */
+int smilehip_functionals_compare16_count(void);
+int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehip_batch *batch, const float *d_lld, int64_t ld_lld,
+                                         float *d_func, int64_t ld_func, void *stream);
+/* Row T60+1 of group B's sma / delta levels, [n_utt x 110] device floats filled by the last smilehip_lld_run of a
+ * ComParE chain batch (tests / callers that run single instances through smilehip_batch_funcspec). */
+int smilehip_batch_compare_b_extra(smilehip_batch *batch, const float **d_extra);
+
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */
 int  smilehip_alloc(smilehip_context *ctx, uint64_t bytes, void **d_ptr);

@@ -103,6 +103,9 @@ SYMBOLS = {
     "smilehip_functionals_matrix": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_uint32, _vp, _vp]),
     "smilehip_batch_func_rows": (C.c_int, [_vp, _vp]),
     "smilehip_batch_functionals": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint32, _vp, _i64, _vp]),
+    "smilehip_functionals_compare16_count": (C.c_int, []),
+    "smilehip_batch_functionals_compare16": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "smilehip_batch_compare_b_extra": (C.c_int, [_vp, _vp]),
     "smilehip_funcspec_count": (C.c_int, [_vp]),
     "smilehip_funcspec_compare16": (C.c_int, [C.c_char_p, _vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
@@ -443,6 +446,41 @@ class Batch:
             L.smilehip_free(ctx, d_lld)
             L.smilehip_free(ctx, d_out)
         return out
+
+    def run_host_with_functionals16(self, pcm):
+        """ComParE whole-level plans: smilehip_lld_run + smilehip_batch_functionals_compare16 on the same device matrix.
+        Returns (lld [total_rows x 130], func [n_utt x 6373], b_extra [n_utt x 110], pending [n_utt])."""
+        L = load()
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        n_out = self.plan.geometry.n_out
+        nf = L.smilehip_functionals_compare16_count()
+        lld = np.zeros((self.total_rows, n_out), np.float32)
+        func = np.zeros((self.n_utt, nf), np.float32)
+        ex = np.zeros((self.n_utt, 110), np.float32)
+        ctx = self.plan.ctx._h
+        d_pcm, d_lld, d_func = _vp(), _vp(), _vp()
+        _check(L.smilehip_alloc(ctx, max(pcm.nbytes, 4), C.byref(d_pcm)))
+        _check(L.smilehip_alloc(ctx, max(lld.nbytes, 4), C.byref(d_lld)))
+        _check(L.smilehip_alloc(ctx, max(func.nbytes, 4), C.byref(d_func)))
+        try:
+            if pcm.nbytes:
+                _check(L.smilehip_copy_to_device(ctx, d_pcm, pcm.ctypes.data, pcm.nbytes, None))
+            _check(L.smilehip_lld_run(self.plan._h, self._h, d_pcm, d_lld, n_out, None))
+            _check(L.smilehip_batch_functionals_compare16(self.plan._h, self._h, d_lld, n_out, d_func, nf, None))
+            _check(L.smilehip_stream_synchronize(ctx, None))
+            if lld.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, lld.ctypes.data, d_lld, lld.nbytes, None))
+            if func.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, func.ctypes.data, d_func, func.nbytes, None))
+            d_ex = _vp()
+            _check(L.smilehip_batch_compare_b_extra(self._h, C.byref(d_ex)))
+            if ex.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, ex.ctypes.data, d_ex, ex.nbytes, None))
+        finally:
+            L.smilehip_free(ctx, d_pcm)
+            L.smilehip_free(ctx, d_lld)
+            L.smilehip_free(ctx, d_func)
+        return lld, func, ex
 
     def funcspec_host(self, lld, spec, col_first, n_cols, rows_cut, extra=None):
         """lld: the matrix run_host returned -> n_utt x (n_cols * count(spec)) through smilehip_batch_funcspec;

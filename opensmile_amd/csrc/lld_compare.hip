@@ -390,6 +390,48 @@ __global__ void __launch_bounds__(256) lld_compare_groupA(const int64_t *frame_o
   out[row * ld + de_col + d] = num / 10.0f;
 }
 
+// Row T60+1 of group B's own levels (55 sma values, then 55 deltas) per utterance: [is13_functionalsB] reads
+// lldB_smo;lldB_smo_de, which are longer than the T60+1 rows the LLD sinks keep, and summarises T60+2 of their rows
+// (tests/test_oracle_pin_funcspec.py). Same float expressions as the window chain (contourSmoother.cpp:104-111,
+// deltaRegression.cpp:144-152), indices clamped to each level's own range.
+__global__ void __launch_bounds__(64) lld_compare_b_extra(const int64_t *frame_off, const int64_t *row_off, int n_utt,
+                                                          const float *rawB, float *out110) {
+  const int u = blockIdx.x, d = threadIdx.x;
+  if (u >= n_utt || d >= 55) return;
+  float *o = out110 + (int64_t)u * 110;
+  const int64_t f0 = frame_off[u];
+  const int T20 = (int)(frame_off[u + 1] - f0);
+  const int rows = (int)(row_off[u + 1] - row_off[u]);
+  if (rows <= 0 || T20 <= 0) { o[d] = 0.0f; o[55 + d] = 0.0f; return; }
+  const float *x = rawB + f0 * 55 + d;
+  auto raw = [&](int t) { t = t < 0 ? 0 : (t > T20 - 1 ? T20 - 1 : t); return x[(int64_t)t * 55]; };
+  auto smo = [&](int t) {                       // level of T20+1 rows
+    t = t < 0 ? 0 : (t > T20 ? T20 : t);
+    float acc = raw(t);
+    acc += raw(t - 1);
+    acc += raw(t + 1);
+    return acc / 3.0f;
+  };
+  const int c = rows;                           // = T60 + 1
+  o[d] = smo(c);
+  float norm = 0.0f;
+  for (int i = 1; i <= 2; ++i) norm += (float)i * (float)i;
+  norm *= 2.0;
+  float num = 0.0f;
+  for (int k = 1; k <= 2; ++k) {
+    const float delta = smo(c + k) - smo(c - k);
+    num += (float)k * delta;
+  }
+  o[55 + d] = num / norm;
+}
+
+hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_row_off, int n_utt, const float *rawB, float *out110,
+                                  hipStream_t s) {
+  if (n_utt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_compare_b_extra, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, d_row_off, n_utt, rawB, out110);
+  return hipGetLastError();
+}
+
 hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
                           int64_t total_rows, float *d_out, int64_t ld_out, int de_col, hipStream_t s) {
   if (n_runs <= 0) return hipSuccess;

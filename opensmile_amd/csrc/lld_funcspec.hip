@@ -49,23 +49,31 @@ struct Where {                     // what a thread works on
   bool on;
 };
 
+__device__ __forceinline__ void utt_rows(const FsParams &P, Where &w) {
+  if (P.single_rows >= 0) {
+    w.srow0 = 0;
+    w.rows = P.single_rows;
+    return;
+  }
+  const int64_t r0 = P.row_off[w.u], lld = P.row_off[w.u + 1] - r0;
+  int64_t n = lld - P.rows_cut;
+  if (P.pending) {
+    const int64_t p = P.pending[w.u];
+    if (p < lld - 1) n -= p;
+  }
+  if (n < 1) n = lld > 0 ? 1 : 0;
+  if (n > 0 && P.extra) n += 1;
+  w.srow0 = r0 + w.u;
+  w.rows = n;
+}
+
 __device__ __forceinline__ Where locate(const FsParams &P) {
   Where w;
   const int groups = (P.n_cols + kColsPerBlock - 1) / kColsPerBlock;
   w.u = blockIdx.x / groups;
   w.c = (blockIdx.x % groups) * kColsPerBlock + threadIdx.x;
   w.on = w.c < P.n_cols;
-  if (P.single_rows >= 0) {
-    w.srow0 = 0;
-    w.rows = P.single_rows;
-  } else {
-    const int64_t r0 = P.row_off[w.u], lld = P.row_off[w.u + 1] - r0;
-    int64_t n = lld - P.rows_cut;
-    if (n < 1) n = lld > 0 ? 1 : 0;
-    if (n > 0 && P.extra) n += 1;
-    w.srow0 = r0 + w.u;
-    w.rows = n;
-  }
+  utt_rows(P, w);
   return w;
 }
 
@@ -1061,15 +1069,7 @@ __global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int o
   w.u = blockIdx.x / P.n_cols;
   w.c = blockIdx.x % P.n_cols;
   w.on = true;
-  if (P.single_rows >= 0) { w.srow0 = 0; w.rows = P.single_rows; }
-  else {
-    const int64_t r0 = P.row_off[w.u], lld = P.row_off[w.u + 1] - r0;
-    int64_t n = lld - P.rows_cut;
-    if (n < 1) n = lld > 0 ? 1 : 0;
-    if (n > 0 && P.extra) n += 1;
-    w.srow0 = r0 + w.u;
-    w.rows = n;
-  }
+  utt_rows(P, w);
   const int64_t si = (int64_t)w.u * P.n_cols + w.c;
   const int64_t N = P.st_n[si];
   if (N <= 0) return;

@@ -34,6 +34,8 @@ hipError_t launch_cms(const int64_t *d_frame_off, int n_utt, const float *x, int
 hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
                           int64_t total_rows, float *d_out, int64_t ld_out, int de_col, hipStream_t s);
 int compare_run_frames();
+hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_row_off, int n_utt, const float *rawB, float *out110,
+                                  hipStream_t s);
 hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s);
 int f0_tile_frames();
 hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);

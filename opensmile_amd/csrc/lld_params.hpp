@@ -176,7 +176,8 @@ struct FsParams {
   int32_t col_first, n_cols;
   const int64_t *row_off;    // [n_utt+1]; unused if single_rows >= 0
   int64_t single_rows;
-  int32_t rows_cut;          // rows used per utterance = max(1, rows - rows_cut) (0 if the utterance has none)
+  int32_t rows_cut;          // rows used per utterance = max(1, rows - rows_cut - p) (0 if the utterance has none)
+  const int32_t *pending;    // optional [n_utt]: p = pending[u] if smaller than the utterance's rows - 1, else 0
   int32_t per;               // values per column
   const float *extra;        // optional: one more row per utterance, [n_utt x ld_extra]
   int64_t ld_extra;

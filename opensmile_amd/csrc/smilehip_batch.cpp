@@ -93,6 +93,11 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
     }
     b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
+    b->d_b_extra.n = size_t(n_utt ? n_utt : 1) * 110;
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_b_extra.p), b->d_b_extra.n * sizeof(float)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
+    }
     (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
   }
   if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
@@ -418,6 +423,8 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   C.n_short = (int32_t)b->h_short.size();
   e = launch_chain(C, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+  e = launch_compare_b_extra(b->d_frame_off.p, b->d_row_off.p, b->n_utt, b->d_rawB.p, b->d_b_extra.p, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "group-B extra-row kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
 

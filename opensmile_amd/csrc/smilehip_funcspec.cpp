@@ -256,3 +256,70 @@ extern "C" int smilehip_batch_funcspec(smilehip_plan *plan, smilehip_batch *b, c
   P.ld_out = ld_func;
   return run_spec(plan->ctx, P, b->n_utt, b->total_rows + b->n_utt, max_rows, (hipStream_t)stream);
 }
+
+// ---- the whole functionals level of ComParE_2016 (6373 values per utterance)
+namespace {
+struct Part { const char *inst; int col_first, n_cols, rows_cut; bool pending; int extra_off; };   // extra_off < 0: no extra row
+// writer levels in the order [functionals] concatenates them (ComParE_2016.conf); row rules measured against the
+// binary (tests/test_oracle_pin_funcspec.py): T = rows - 1
+const Part kCompare16Parts[] = {
+    {"A", 6, 4, 3, false, -1},   {"A", 71, 4, 3, false, -1},       // lldA_smo ; lldA_smo_de        T-2
+    {"B", 10, 55, 0, false, 0},  {"B", 75, 55, 0, false, 55},      // lldB_smo ; lldB_smo_de        T+2 (extra row)
+    {"Nz", 0, 6, 3, true, -1},   {"Nz", 65, 6, 3, true, -1},       // lld_nzsmo ; lld_nzsmo_de      T-P-2
+    {"F0", 0, 1, 1, true, -1},                                     // lld_f0_nzsmo                  T-P
+    {"LLD", 6, 59, 1, false, -1},                                  // lldA_smo ; lldB_smo           T
+    {"Delta", 71, 59, 3, false, -1},                               // lldA_smo_de ; lldB_smo_de     T-2
+};
+}  // namespace
+
+extern "C" int smilehip_functionals_compare16_count(void) { return 6373; }
+
+extern "C" int smilehip_batch_compare_b_extra(smilehip_batch *b, const float **d_extra) {
+  if (!b || !d_extra) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_compare_b_extra: null argument");
+  if (!b->d_b_extra.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_compare_b_extra: not a ComParE chain batch");
+  *d_extra = b->d_b_extra.p;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld,
+                                                    float *d_func, int64_t ld_func, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_COMPARE)
+    return fail(SMILEHIP_ERR_INVALID, "the ComParE_2016 functionals are defined for the whole-level chain (smilehip_config_compare16)");
+  if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "smilehip_batch_functionals_compare16: host-only plan");
+  if (ld_lld < 130 || ld_func < 6373) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: ld_lld >= 130 and ld_func >= 6373 required");
+  if (!d_func || (!d_lld && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: null device pointer");
+  if (b->n_utt == 0) return SMILEHIP_OK;
+  if (!b->f0_batch || !b->f0_batch->d_pending.p || !b->d_b_extra.p)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: run smilehip_lld_run on this batch first");
+  int64_t max_rows = 0;
+  for (int u = 0; u < b->n_utt; ++u) max_rows = std::max(max_rows, b->h_row_off[u + 1] - b->h_row_off[u] + 1);
+  int off = 0;
+  for (const Part &part : kCompare16Parts) {
+    FsParams P;
+    std::memset(&P, 0, sizeof(P));
+    int rc = smilehip_funcspec_compare16(part.inst, &P.spec);
+    if (rc) return rc;
+    const int per = spec_layout(&P.spec, nullptr, nullptr);
+    if (per < 0) return per;
+    P.x = d_lld;
+    P.ld_x = ld_lld;
+    P.col_first = part.col_first;
+    P.n_cols = part.n_cols;
+    P.row_off = b->d_row_off.p;
+    P.single_rows = -1;
+    P.rows_cut = part.rows_cut;
+    P.pending = part.pending ? b->f0_batch->d_pending.p : nullptr;
+    if (part.extra_off >= 0) {
+      P.extra = b->d_b_extra.p + part.extra_off;
+      P.ld_extra = 110;
+    }
+    P.out = d_func + off;
+    P.ld_out = ld_func;
+    rc = run_spec(plan->ctx, P, b->n_utt, b->total_rows + b->n_utt, max_rows, (hipStream_t)stream);
+    if (rc) return rc;
+    off += per * part.n_cols;
+  }
+  if (off != 6373) return fail(SMILEHIP_ERR_INVALID, "internal: ComParE_2016 functionals layout adds up to %d", off);
+  return SMILEHIP_OK;
+}

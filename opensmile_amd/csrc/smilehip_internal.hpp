@@ -122,6 +122,7 @@ struct smilehip_batch {
   DevBuf<float> d_raw16;        // IS09: pre-smoothing LLD columns, total_frames x 16
   DevBuf<float> d_static;       // MFCC chain with deltas: compact static block, total_frames x n_mfcc
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
+  DevBuf<float> d_b_extra;                // [n_utt x 110] row T60+1 of group B's sma / delta levels (functionals)
   DevBuf<float> d_shs, d_e60;             // F0 group: candidates (total_frames x 21) and frame energies
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance

@@ -1,0 +1,115 @@
+"""The whole functionals level of ComParE_2016 (6373 values per utterance) through the C ABI: smilehip_lld_run on the
+whole-level chain + smilehip_batch_functionals_compare16, against
+  * the oracle's functionals of the SAME device LLD matrix with the row rules of test_oracle_pin_funcspec.py -- bit for
+    bit (libm-dependent values 1e-6), which checks the kernels, the layout and the per-utterance row rules, and
+  * the real binary's golden vectors: the LLD inputs agree to float round-off only (<= 1e-5), and order statistics /
+    positions / peak picking are discontinuous in them, so this comparison is statistical (documented below)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_funcspec import LIBM, as_oracle_spec
+from test_oracle_pin_funcspec import KEYS, ORDER, func_rows
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# (instance, first LLD column, columns) in output order
+PARTS = [("A", 6, 4), ("A", 71, 4), ("B", 10, 55), ("B", 75, 55), ("Nz", 0, 6), ("Nz", 65, 6), ("F0", 0, 1), ("LLD", 6, 59),
+         ("Delta", 71, 59)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    return capi, ctx, capi.Plan(ctx, capi.compare16_config())
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "compare16_func_synth.npz"))
+
+
+def device_pending(oracle, lld_u, pcm_u):
+    """P as the device's own F0 chain left it is not exported; the oracle's chain on the same samples gives the same
+    count (the Viterbi decisions are bit-exact on identical candidates, test_gpu_f0.py)."""
+    from test_oracle_pin_funcspec import pending
+    return pending(oracle, pcm_u)
+
+
+def test_functionals16_vs_oracle_on_device_lld(hip, oracle, golden):
+    capi, ctx, plan = hip
+    pcms = [golden["pcm_" + k] for k in KEYS] + [np.zeros(0, np.int16), np.zeros(500, np.int16)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, ex = b.run_host_with_functionals16(np.concatenate(pcms))
+    assert func.shape == (len(pcms), 6373)
+    assert not func[-1].any() and not func[-2].any()          # no rows -> no instance in the reference; zeros here
+    for u, key in enumerate(KEYS):
+        x = lld[b.frame_offsets[u]:b.frame_offsets[u + 1]]
+        T, P = device_pending(oracle, x, pcms[u])
+        assert x.shape[0] == T + 1
+        pos = 0
+        for inst, c0, nc in PARTS:
+            spec = capi.funcspec_compare16(inst)
+            ospec = as_oracle_spec(oracle, spec)
+            names = oracle.funcspec_names(ospec)
+            per = len(names)
+            n = func_rows(inst, T, P)
+            if inst == "B":
+                xi = np.concatenate([x[:, c0:c0 + nc], ex[u:u + 1, (0 if c0 == 10 else 55):(55 if c0 == 10 else 110)]], axis=0)
+                assert xi.shape[0] == n
+            else:
+                xi = x[:n, c0:c0 + nc]
+            ref = oracle.funcspec(np.ascontiguousarray(xi), ospec)
+            dev = func[u, pos:pos + per * nc].reshape(nc, per)
+            pos += per * nc
+            for k, nm in enumerate(names):
+                d, r = dev[:, k], ref[:, k]
+                if nm in LIBM:
+                    err = np.abs(d.astype(np.float64) - r) / np.maximum(np.abs(r), 1e-6)
+                    assert err.max() <= 1e-6, f"{key}/{inst}/{nm}: rel err {err.max():.3g}"
+                else:
+                    assert np.array_equal(d.view(np.uint32), r.view(np.uint32)), f"{key}/{inst}@{c0}/{nm} (T={T}, P={P}, rows={n})"
+        assert pos == 6373
+    b.close()
+
+
+def test_group_b_extra_row_vs_binary_levels(hip, oracle, golden):
+    """Row T60+1 of lldB_smo / lldB_smo_de as the real binary's levels hold it (taps) and as the oracle restates it."""
+    capi, ctx, plan = hip
+    pcms = [golden["pcm_" + k] for k in KEYS]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, ex = b.run_host_with_functionals16(np.concatenate(pcms))
+    for u, key in enumerate(KEYS):
+        T = b.frame_offsets[u + 1] - b.frame_offsets[u] - 1
+        ref = np.concatenate([golden["b_smo_" + key][T + 1], golden["b_de_" + key][T + 1]])
+        orc = oracle.compare_b_extra(pcms[u])
+        scale = np.maximum(np.abs(golden["b_smo_" + key]).max(axis=0), 1e-6)
+        scale = np.concatenate([scale, scale])
+        assert (np.abs(orc - ref) <= 1e-5 * scale).all(), key
+        assert (np.abs(ex[u] - ref) <= 1e-5 * scale).all(), key
+    b.close()
+
+
+def test_functionals16_vs_binary_statistics(hip, golden):
+    """Against the real binary's vectors. Smooth functionals (means, moments, regression, quartiles ...) follow the LLD
+    tolerance; discontinuous ones (arg-max positions, level-crossing counts, segment and peak statistics) can jump when an
+    input differs in the last bit. Bar: on every utterance >= 90 % of the 6373 values within 1e-3 of the binary's
+    (relative to max(|value|, the functional's own spread over the LLDs)), median error <= 1e-5."""
+    capi, ctx, plan = hip
+    pcms = [golden["pcm_" + k] for k in KEYS]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, ex = b.run_host_with_functionals16(np.concatenate(pcms))
+    for u, key in enumerate(KEYS):
+        ref = golden["func_" + key].astype(np.float64)
+        err = np.abs(func[u] - ref) / np.maximum(np.abs(ref), 1e-2)
+        frac = (err <= 1e-3).mean()
+        assert frac >= 0.90, f"{key}: only {frac:.3f} of the values within 1e-3"
+        assert np.median(err) <= 1e-5, f"{key}: median {np.median(err):.3g}"
+    b.close()
