@@ -42,6 +42,22 @@ struct Col {                       // one thread's view of its column
   __device__ __forceinline__ float operator[](int64_t t) const { return t < n_main ? p[t * ld] : *pe; }
 };
 
+// Sequential walk over rows [a, b) of a column with the loads batched eight ahead: a scan is a chain of dependent
+// steps, and one wave per SIMD cannot hide a memory round trip per step -- eight independent loads are in flight
+// before the first value is consumed. f(t, value) is called in index order.
+template <typename F>
+__device__ __forceinline__ void for_rows(const Col &in, int64_t a, int64_t b, F f) {
+  int64_t t = a;
+  for (; t + 8 <= b; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = in[t + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f(t + k, v[k]);
+  }
+  for (; t < b; ++t) f(t, in[t]);
+}
+
 struct Where {                     // what a thread works on
   int u, c;                        // utterance, column inside the instance
   int64_t srow0;                   // first scratch row of the utterance
@@ -129,10 +145,9 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_stats(FsParams P) {
     float *d = P.nz + w.srow0 * P.n_cols + w.c;
     NN = 0;
     const bool pos = P.spec.non_zero_functs == 2;
-    for (int64_t t = 0; t < r.N; ++t) {
-      const float v = r[t];
+    for_rows(r, 0, r.N, [&](int64_t, float v) {
       if (pos ? (v > 0.0f) : (v != 0.0f)) d[(NN++) * P.n_cols] = v;
-    }
+    });
   }
   P.st_n[si] = (int32_t)NN;
   if (NN <= 0) {
@@ -144,12 +159,11 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_stats(FsParams P) {
   const Col x = data_col(P, w);
   float mn = x[0], mx = mn;
   double mean = mn;
-  for (int64_t t = 1; t < NN; ++t) {
-    const float v = x[t];
+  for_rows(x, 1, NN, [&](int64_t, float v) {
     if (v < mn) mn = v;
     if (v > mx) mx = v;
     mean += (double)v;
-  }
+  });
   mean /= (double)NN;
   P.st_min[si] = mn; P.st_max[si] = mx; P.st_mean[si] = (float)mean;
 }
@@ -160,12 +174,10 @@ namespace {
 __device__ int f_extremes(const smilehip_func_spec &s, const Col &in, float min, float max, float mean, float *out) {
   const int64_t Nin = in.N;
   int64_t minpos = -1, maxpos = -1;
-  for (int64_t i = 0; i < Nin; ++i) {
-    const float v = in[i];
+  for_rows(in, 0, Nin, [&](int64_t i, float v) {
     if ((v == max) && (maxpos == -1)) maxpos = i;
     if ((v == min) && (minpos == -1)) minpos = i;
-    if (maxpos >= 0 && minpos >= 0) break;
-  }
+  });
   float maxposD = (float)maxpos, minposD = (float)minpos;
   if (s.ext_norm == SMILEHIP_NORM_SEGMENT) {
     maxposD /= (float)Nin;
@@ -205,8 +217,8 @@ __device__ int f_means(const smilehip_func_spec &s, const Col &in, float mean, f
   } else {
     nzamean = nzabsmean = nzqmean = nzgmean = 0.0; nnz = 0;
   }
-  for (int64_t i = 1; i < Nin; ++i) {
-    tmp = (double)in[i];
+  for_rows(in, 1, Nin, [&](int64_t, float vin) {
+    tmp = (double)vin;
     fa = fabs(tmp);
     absmean += fa;
     if (tmp > 0) { posamean += tmp; nPos++; }
@@ -223,7 +235,7 @@ __device__ int f_means(const smilehip_func_spec &s, const Col &in, float mean, f
       if (t0 < 0) negqmean += tmp;
       qmean += tmp;
     }
-  }
+  });
   tmp = (double)Nin;
   absmean = absmean / tmp;
   qmean = qmean / tmp;
@@ -263,14 +275,14 @@ __device__ int f_moments(const smilehip_func_spec &s, const Col &in, float mean,
   const int64_t Nin = in.N;
   double m2 = 0.0, m3 = 0.0, m4 = 0.0;
   const double Nind = (double)Nin, meanD = (double)mean;
-  for (int64_t i = 0; i < Nin; ++i) {
-    const double tmp = ((double)in[i] - meanD);
+  for_rows(in, 0, Nin, [&](int64_t, float v) {
+    const double tmp = ((double)v - meanD);
     double tmp2 = tmp * tmp;
     m2 += tmp2;
     tmp2 *= tmp;
     m3 += tmp2;
     m4 += tmp2 * tmp;
-  }
+  });
   m2 /= Nind;
   const uint32_t m = s.mom_mask;
   int n = 0;
@@ -304,8 +316,7 @@ __device__ int f_regression(const smilehip_func_spec &s, const Col &in, float mi
   const bool enQreg = (s.reg_mask & 0x3fff0u) != 0;
   double num = 0.0, numAbs = 0.0, num2 = 0.0, tmp = 0.0, ii = 0.0, asumAbs = 0.0;
   const double asum = (double)mean * Nind;
-  for (int64_t i = 0; i < Nin; ++i) {
-    const float v = in[i];
+  for_rows(in, 0, Nin, [&](int64_t, float v) {
     if (s.reg_centroid_abs) {
       asumAbs += (double)fabsf(v);
       numAbs += (double)fabsf(v) * ii;
@@ -315,7 +326,7 @@ __device__ int f_regression(const smilehip_func_spec &s, const Col &in, float mi
     tmp *= ii;
     ii += 1.0;
     num2 += tmp;
-  }
+  });
   double centroid;
   if (s.reg_centroid_abs) centroid = (asumAbs != 0.0) ? numAbs / asumAbs : 0.0;
   else centroid = (asum != 0.0) ? num / asum : 0.0;
@@ -348,8 +359,8 @@ __device__ int f_regression(const smilehip_func_spec &s, const Col &in, float mi
     m = 0; t = c = (double)in[0];
   }
   ii = 0.0;
-  for (int64_t i = 0; i < Nin; ++i) {              // both residual sweeps share one walk; each sum keeps its own order
-    const double v = (double)in[i];
+  for_rows(in, 0, Nin, [&](int64_t, float vin) {   // both residual sweeps share one walk; each sum keeps its own order
+    const double v = (double)vin;
     double e = v - (m * ii + t);
     if (s.reg_norm_inputs) e *= rangeInv;
     lea += fabs(e);
@@ -361,7 +372,7 @@ __device__ int f_regression(const smilehip_func_spec &s, const Col &in, float mi
       qeq += q * q;
     }
     ii += 1.0;
-  }
+  });
   double rs = 0.0, ls = 0.0, x0 = 0.0, y0 = 0.0, yr = 0.0, yrnn = 0.0, c3nn = 0.0, y0nn = 0.0;
   if (enQreg) {
     x0 = b / (-2.0 * a);
@@ -469,9 +480,9 @@ __device__ int f_times(const smilehip_func_spec &s, const Col &in, float min, fl
   const float range = max - min;
   const float l25 = 0.25f * range + min, l50 = 0.50f * range + min, l75 = 0.75f * range + min, l90 = 0.90f * range + min;
   int64_t n25 = 0, n50 = 0, n75 = 0, n90 = 0, nR = 0, nF = 0, nLC = 0, nRC = 0;
-  float pm = 0.0f, p0 = in[0];                     // in[i-1], in[i]; all counts are integers: one fused walk
-  for (int64_t i = 0; i < Nin; ++i) {
-    const float pn = (i + 1 < Nin) ? in[i + 1] : 0.0f;
+  // all counts are integers: one fused walk; sample i is classified when sample i+1 arrives (curvature looks ahead)
+  float pm = 0.0f, p0 = in[0];
+  auto step = [&](int64_t i, float pn, bool has_next) {
     if (p0 <= l25) n25++;
     if (p0 <= l50) n50++;
     if (p0 <= l75) n75++;
@@ -479,14 +490,16 @@ __device__ int f_times(const smilehip_func_spec &s, const Col &in, float min, fl
     if (i >= 1) {
       if (pm < p0) nR++;
       else if (pm > p0) nF++;
-      if (i + 1 < Nin) {
+      if (has_next) {
         const float a1 = p0 - pm, a2 = pn - p0;
         if (a2 < a1) nRC++;
         else if (a1 < a2) nLC++;
       }
     }
     pm = p0; p0 = pn;
-  }
+  };
+  for_rows(in, 1, Nin, [&](int64_t j, float v) { step(j - 1, v, true); });
+  step(Nin - 1, 0.0f, false);
   const uint32_t m = s.times_mask;
   int n = 0;
   if (FS_BIT(m, 0)) out[n++] = ((float)(Nin - n25)) / Norm;
@@ -539,8 +552,7 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
     int64_t lastSeg = -segMinLng / 2;
     float ravg = 0.0f, raLast = 0.0f;
     float h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;           // in[i-1], in[i-2], in[i-3]
-    for (int64_t i = 0; i < Nin; ++i) {
-      const float v = in[i];
+    for_rows(in, 0, Nin, [&](int64_t i, float v) {
       ravg += v;
       if (i >= 3) ravg -= h3;
       const float ra = ravg / (float)((i + 1 < 3) ? (i + 1) : 3);
@@ -550,13 +562,13 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
       raLast = ra;
       if (cross && (i - lastSeg > segMinLng)) { r.add(i, lastSeg); lastSeg = i; }
       h3 = h2; h2 = h1; h1 = v;
-    }
+    });
   } else {
     const float X = s.seg_x_is_rel ? (min + range * s.seg_x) : s.seg_x;
-    int64_t startIdx = 0, i;
+    int64_t startIdx = 0;
+    const int64_t i = Nin;                       // the index after the walk, as the reference's loop leaves it
     int inSeg = 0, segStart = 0, segEnd = 0;
-    for (i = 0; i < Nin; ++i) {
-      const float v = in[i];
+    for_rows(in, 0, Nin, [&](int64_t i, float v) {
       if (v != X) {
         if (inSeg == 1) {
           segEnd = 0;
@@ -584,7 +596,7 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
           if (segEnd >= s.seg_pause_min_lng) { inSeg = 0; segEnd = 0; segStart = 0; }
         }
       }
-    }
+    });
     if (inSeg == 2) {
       segEnd++;
       r.add(i - segEnd, startIdx);
@@ -650,14 +662,14 @@ __device__ int f_lpc_p(const smilehip_func_spec &s, const Col &in, float *out) {
 #pragma unroll
   for (int k = 0; k <= P; ++k) { acf[k] = 0.0f; d[k] = 0.0f; a[k] = 0.0f; }
   const int n32 = (int)Nin;                              // smileDsp_autoCorr takes an int
-  for (int i = 0; i < n32; ++i) {
+  for_rows(in, 0, (int64_t)n32, [&](int64_t i, float v) {
 #pragma unroll
     for (int k = P; k >= 1; --k) d[k] = d[k - 1];
-    d[0] = in[i];
+    d[0] = v;
 #pragma unroll
     for (int k = 0; k <= P; ++k)
       if (i >= k) acf[k] += d[0] * d[k];
-  }
+  });
   float gain = 0.0f;
   if (!(acf[0] == 0.0f)) {
     float e = acf[0];
@@ -736,12 +748,25 @@ __device__ __forceinline__ void pk_for_each(const Col &in, const unsigned char *
   const int64_t N = in.N;
   if (N < 5) return;
   float a = in[1], b = in[2];
-  for (int64_t i = 2; i < N - 2; ++i) {
-    const float c = in[i + 1];
+  auto step = [&](int64_t i, float c, bool live) {
     const bool mx = b > a && b > c, mi = b < a && b < c;
-    if ((mx || mi) && (!only_alive || alive[i * ald])) f(i, b, mx);
+    if ((mx || mi) && live) f(i, b, mx);
     a = b; b = c;
+  };
+  // the alive bytes of the rows ahead are fetched with the samples: a pass only ever clears the flag of the row it is
+  // at or of an earlier one, so a prefetched flag cannot be stale
+  int64_t j = 3;                                 // j = i + 1
+  for (; j + 8 <= N - 1; j += 8) {
+    float v[8];
+    unsigned char al[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = in[j + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) al[k] = only_alive ? alive[(j + k - 1) * ald] : (unsigned char)1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) step(j + k - 1, v[k], al[k] != 0);
   }
+  for (; j < N - 1; ++j) step(j - 1, in[j], !only_alive || alive[(j - 1) * ald] != 0);
 }
 
 __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, float max, float mean, unsigned char *alive,

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--utts", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--sets", default="is09,compare")
+    ap.add_argument("--func", action="store_true", help="compare_full: also time the ComParE_2016 functionals level")
     args = ap.parse_args()
     import torch
     from opensmile_amd import capi, synth
@@ -44,8 +45,26 @@ def main():
             b.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, st)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"set": name, "utterances": args.utts, "frames": b.total_frames, "rows": rows, "cols": n_out,
-                          "ms_per_step": dt * 1e3, "frames_per_s": b.total_frames / dt}), flush=True)
+        rec = {"set": name, "utterances": args.utts, "frames": b.total_frames, "rows": rows, "cols": n_out,
+               "ms_per_step": dt * 1e3, "frames_per_s": b.total_frames / dt}
+        if name == "compare_full" and args.func:
+            # the functionals level on top (6373 values per utterance), LLD matrix resident
+            import ctypes as C
+            L = capi.load()
+            d_func = torch.empty((args.utts, 6373), dtype=torch.float32, device="cuda")
+            def run_func():
+                capi._check(L.smilehip_batch_functionals_compare16(plan._h, b._h, C.c_void_p(d_out.data_ptr()), n_out,
+                                                                   C.c_void_p(d_func.data_ptr()), 6373, C.c_void_p(st)))
+            run_func()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run_func()
+            torch.cuda.synchronize()
+            df = (time.perf_counter() - t0) / args.steps
+            rec.update({"func_ms_per_step": df * 1e3, "lld_plus_func_frames_per_s": b.total_frames / (dt + df),
+                        "func_values_per_utt": 6373})
+        print(json.dumps(rec), flush=True)
         b.close()
         plan.close()
 
