@@ -72,4 +72,77 @@ std::vector<std::string> func_names_is09() {
   return n;
 }
 
+// Value-name suffixes of one cFunctionals instance, in output order: what cFunctionals::setupNamesForElement
+// (src/functionals/functionals.cpp:224-262) appends to each input element's name -- the families' getValueName()
+// strings (functionalExtremes.cpp:31, functionalMeans.cpp:34-36, functionalMoments.cpp:33, functionalRegression.cpp:50-53,
+// functionalPercentiles.cpp:35 + 229-262, functionalTimes.cpp:42, functionalSegments.cpp:37, functionalLpc.cpp:36 + 83-93,
+// functionalPeaks2.cpp:60-67), prefixed with "<functNameAppend>_" if the instance sets one.
+std::vector<std::string> funcspec_value_names(const smilehip_func_spec &s, const std::string &name_append) {
+  static const char *ext[] = {"max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"};
+  static const char *means[] = {"amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness",
+                                "posamean", "negamean", "posqmean", "posrqmean", "negqmean", "negrqmean", "rqmean", "nzrqmean"};
+  static const char *mom[] = {"variance", "stddev", "skewness", "kurtosis", "amean", "stddevNorm"};
+  static const char *reg[] = {"linregc1", "linregc2", "linregerrA", "linregerrQ", "qregc1", "qregc2", "qregc3", "qregerrA",
+                              "qregerrQ", "centroid", "qregls", "qregrs", "qregx0", "qregy0", "qregyr", "qregy0nn", "qregc3nn",
+                              "qregyrnn"};
+  static const char *pct[] = {"quartile1", "quartile2", "quartile3", "iqr1-2", "iqr2-3", "iqr1-3"};
+  static const char *times[] = {"upleveltime25", "downleveltime25", "upleveltime50", "downleveltime50", "upleveltime75",
+                                "downleveltime75", "upleveltime90", "downleveltime90", "risetime", "falltime", "leftctime",
+                                "rightctime", "duration"};
+  static const char *seg[] = {"numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"};
+  static const char *pk[] = {"numPeaks", "meanPeakDist", "meanPeakDistDelta", "peakDistStddev", "peakRangeAbs", "peakRangeRel",
+                             "peakMeanAbs", "peakMeanMeanDist", "peakMeanRel", "ptpAmpMeanAbs", "ptpAmpMeanRel", "ptpAmpStddevAbs",
+                             "ptpAmpStddevRel", "minRangeAbs", "minRangeRel", "minMeanAbs", "minMeanMeanDist", "minMeanRel",
+                             "mtmAmpMeanAbs", "mtmAmpMeanRel", "mtmAmpStddevAbs", "mtmAmpStddevRel", "meanRisingSlope",
+                             "maxRisingSlope", "minRisingSlope", "stddevRisingSlope", "meanFallingSlope", "maxFallingSlope",
+                             "minFallingSlope", "stddevFallingSlope", "covFallingSlope", "covRisingSlope"};
+  std::vector<std::string> out;
+  const std::string pre = name_append.empty() ? "" : name_append + "_";
+  auto masked = [&](uint32_t m, const char *const *names, int n) {
+    for (int i = 0; i < n; ++i)
+      if ((m >> i) & 1u) out.push_back(pre + names[i]);
+  };
+  char buf[64];
+  for (int i = 0; i < s.n_fam; ++i) {
+    switch (s.fam[i]) {
+      case SMILEHIP_FAM_EXTREMES: masked(s.ext_mask, ext, 8); break;
+      case SMILEHIP_FAM_MEANS: masked(s.means_mask, means, 17); break;
+      case SMILEHIP_FAM_MOMENTS: masked(s.mom_mask, mom, 6); break;
+      case SMILEHIP_FAM_REGRESSION: masked(s.reg_mask, reg, 18); break;
+      case SMILEHIP_FAM_PERCENTILES:
+        masked(s.pct_mask, pct, 6);
+        for (int k = 0; k < s.n_pctl; ++k) { std::snprintf(buf, sizeof buf, "percentile%.1f", s.pctl[k] * 100.0); out.push_back(pre + buf); }
+        for (int k = 0; k < s.n_range; ++k) { std::snprintf(buf, sizeof buf, "pctlrange%i-%i", s.range_a[k], s.range_b[k]); out.push_back(pre + buf); }
+        break;
+      case SMILEHIP_FAM_TIMES: masked(s.times_mask, times, 13); break;
+      case SMILEHIP_FAM_SEGMENTS: masked(s.seg_mask, seg, 5); break;
+      case SMILEHIP_FAM_LPC:
+        if (s.lpc_gain) out.push_back(pre + "lpgain");
+        if (s.lpc_coeffs)
+          for (int k = s.lpc_first; k < s.lpc_order; ++k) { std::snprintf(buf, sizeof buf, "lpc%i", k); out.push_back(pre + buf); }
+        break;
+      case SMILEHIP_FAM_PEAKS2: masked(s.pk_mask, pk, 32); break;
+    }
+  }
+  return out;
+}
+
+// The functionals level of config/compare16/ComParE_2016.conf: [functionals] concatenates is13_functionalsA, B, Nz, F0
+// (functNameAppend = ff0), LLD, Delta; each instance lists its input levels' elements in order.
+std::vector<std::string> func_names_compare16() {
+  const std::vector<std::string> lld = lld_names_compare16();      // [F0 group 6 | A 4 | B 55 | the same _de]
+  struct Part { const char *inst; int c0, n; const char *append; };
+  static const Part parts[] = {{"A", 6, 4, ""},   {"A", 71, 4, ""},  {"B", 10, 55, ""},  {"B", 75, 55, ""},    {"Nz", 0, 6, ""},
+                               {"Nz", 65, 6, ""}, {"F0", 0, 1, "ff0"}, {"LLD", 6, 59, ""}, {"Delta", 71, 59, ""}};
+  std::vector<std::string> out;
+  for (const Part &p : parts) {
+    smilehip_func_spec s;
+    if (smilehip_funcspec_compare16(p.inst, &s) != SMILEHIP_OK) return {};
+    const std::vector<std::string> v = funcspec_value_names(s, p.append);
+    for (int c = 0; c < p.n; ++c)
+      for (const std::string &f : v) out.push_back(lld[p.c0 + c] + "_" + f);
+  }
+  return out;
+}
+
 }  // namespace smilehip_host

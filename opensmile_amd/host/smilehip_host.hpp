@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include "smilehip.h"
+
 namespace smilehip_host {
 
 // sWaveParameters as filled by smilePcm_readWaveHeader (src/smileutil/smileUtil.c:2374-2487)
@@ -35,6 +37,9 @@ std::vector<std::string> lld_names_htk_variant(bool plp, bool energy);   // MFCC
 std::vector<std::string> lld_names_is09();
 std::vector<std::string> lld_names_compare16();
 std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
+std::vector<std::string> func_names_compare16();   // 6373, the functionals level of ComParE_2016.conf
+// value-name suffixes of one cFunctionals instance in output order (name_append = its functNameAppend option)
+std::vector<std::string> funcspec_value_names(const smilehip_func_spec &spec, const std::string &name_append = "");
 
 // cHtkSink (src/iocore/htkSink.cpp:90-105, 183-213): 12-byte big-endian header
 // {nSamples u32, samplePeriod u32 [100 ns], sampleSize u16, parmKind u16} + big-endian float32 rows.

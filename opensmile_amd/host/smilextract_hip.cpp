@@ -9,7 +9,8 @@
 //                   (-I in.wav | -filelist list.txt) [-O lld.htk] [-csvoutput lld.csv]
 //   smilextract_hip --set is09_emotion  (-I in.wav | -filelist list.txt) [-O func.arff] [-csvoutput func.csv]
 //   smilextract_hip --set compare16_lld (-I in.wav | -filelist list.txt) [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
-//                   (the 130-column LLD level of ComParE_2016; its functionals are not built)
+//                   (the 130-column LLD level of ComParE_2016 only)
+//   smilextract_hip --set compare16     same options as is09_emotion: the whole ComParE_2016.conf, LLD level + 6373 functionals
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
 //
@@ -67,7 +68,9 @@ int main(int argc, char **argv) {
   }
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
-  const bool cmp16 = set == "compare16_lld";
+  const bool cmp16f = set == "compare16";                      // the whole ComParE_2016.conf: LLD level + 6373 functionals
+  const bool cmp16 = set == "compare16_lld" || cmp16f;
+  const bool has_func = is09 || cmp16f;
   // the eight files of config/mfcc and config/plp, by their names in lower case
   std::string variant;                             // upper-case config name for smilehip_config_htk_variant
   for (char ch : set) variant += (char)toupper((unsigned char)ch);
@@ -75,7 +78,7 @@ int main(int argc, char **argv) {
   const bool htk_variant = !is09 && !cmp16 && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
   if (!is09 && !cmp16 && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion or compare16_lld");
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16 or compare16_lld");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
@@ -124,7 +127,7 @@ int main(int argc, char **argv) {
   const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
   const std::vector<std::string> lld_names =
       is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy));
-  const std::vector<std::string> fnames = is09 ? func_names_is09() : std::vector<std::string>();
+  const std::vector<std::string> fnames = is09 ? func_names_is09() : (cmp16f ? func_names_compare16() : std::vector<std::string>());
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
 
@@ -175,11 +178,15 @@ int main(int argc, char **argv) {
       check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
       check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
       std::vector<float> lld((size_t)std::max<int64_t>(rows, 1) * n_out), func;
-      const int n_func = is09 ? n_out * smilehip_functionals_count(fmask) : 0;
-      if (is09) {
+      const int n_func = is09 ? n_out * smilehip_functionals_count(fmask) : (cmp16f ? smilehip_functionals_compare16_count() : 0);
+      if (has_func) {
         check(smilehip_alloc(ctx, (uint64_t)idx.size() * n_func * 4, &d_func), "smilehip_alloc");
-        check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
-              "smilehip_batch_functionals");
+        if (is09)
+          check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
+                "smilehip_batch_functionals");
+        else
+          check(smilehip_batch_functionals_compare16(plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, nullptr),
+                "smilehip_batch_functionals_compare16");
         func.resize(idx.size() * (size_t)n_func);
         check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, nullptr), "copy_to_host");
       }
@@ -204,7 +211,7 @@ int main(int argc, char **argv) {
                          times.data(), co, err))
             die(err);
         }
-        if (is09 && r > 0) {                              // no frame -> the reference writes no instance
+        if (has_func && r > 0) {                          // no frame -> the reference writes no instance
           const float *fv = func.data() + i * (size_t)n_func;
           if (opt.count("-O") && opt["-O"] != "?") {
             ArffOptions ao;

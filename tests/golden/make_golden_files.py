@@ -56,6 +56,11 @@ def main():
                         "-lldhtkoutput", os.path.join(td, "c.htk"), "-instname", "u3", "-l", "0"], check=True, cwd=td)
         shutil.copy(os.path.join(td, "c.htk"), os.path.join(out, "compare16_lld_u3.htk"))
         shutil.copy(os.path.join(td, "c.csv"), os.path.join(out, "compare16_lld_u3.csv"))
+        # ... and its functionals level (6373 values) as ARFF + HTK
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u3.wav"), "-O", os.path.join(td, "cf.arff"),
+                        "-htkoutput", os.path.join(td, "cf.htk"), "-instname", "u3", "-l", "0"], check=True, cwd=td)
+        shutil.copy(os.path.join(td, "cf.arff"), os.path.join(out, "compare16_func_u3.arff"))
+        shutil.copy(os.path.join(td, "cf.htk"), os.path.join(out, "compare16_func_u3.htk"))
         # IS09_emotion: two files appended into one ARFF / functionals CSV; LLD CSV + HTK and the
         # functionals HTK of the second one (instance names exercise the ARFF escaping)
         conf = os.path.join(lldo.REF_DIR, "config", "is09-13", "IS09_emotion.conf")

@@ -43,3 +43,13 @@ extern "C" long shim_read_wave(const char *path, long *info, void *buf, int64_t 
   if (buf && cap > 0) std::memcpy(buf, d.data(), (size_t)std::min<int64_t>(cap, (int64_t)d.size()));
   return (long)d.size();
 }
+
+// names of a level, '\n'-joined: 3 = ComParE_2016 LLD (130), 4 = ComParE_2016 functionals (6373); returns the byte count
+extern "C" long shim_names(int which, char *buf, long cap) {
+  const std::vector<std::string> n = which == 3 ? lld_names_compare16() : func_names_compare16();
+  std::string all;
+  for (const std::string &x : n) { all += x; all += '\n'; }
+  if ((long)all.size() > cap) return -(long)all.size();
+  std::memcpy(buf, all.data(), all.size());
+  return (long)all.size();
+}

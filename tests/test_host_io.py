@@ -40,9 +40,10 @@ def hostlib():
     so = os.path.join(ROOT, "tests", "_host_io_shim.so")
     host = os.path.join(ROOT, "opensmile_amd", "host")
     subprocess.run(["make", "-s", "-C", host, "../libsmilehip_host.so"], check=True)
+    pkg = os.path.join(ROOT, "opensmile_amd")
     subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + host, "-I" + os.path.join(ROOT, "include"), src,
                     os.path.join(host, "wave_io.o"), os.path.join(host, "sinks.o"), os.path.join(host, "feature_names.o"),
-                    "-o", so], check=True)
+                    "-L" + pkg, "-lsmilehip", "-Wl,-rpath," + pkg, "-o", so], check=True)
     L = C.CDLL(so)
     L.shim_write_htk.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double]
     L.shim_write_csv.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_char_p, C.c_int, C.c_void_p]
@@ -210,6 +211,24 @@ def test_smilextract_hip_compare16_lld(tmp_path):
 
 
 @pytest.mark.gpu
+def test_smilextract_hip_compare16_functionals(tmp_path):
+    """--set compare16: the whole ComParE_2016.conf. The functionals ARFF has the reference's header (relation, 6373
+    attribute lines, class attribute) byte for byte; the values follow the statistical bar of test_gpu_func16.py."""
+    out_arff, out_htk = str(tmp_path / "f.arff"), str(tmp_path / "f.htk")
+    subprocess.run([EXE, "--set", "compare16", "-I", os.path.join(G, "u3_4000.wav"), "-O", out_arff, "-htkoutput", out_htk,
+                    "-instname", "u3"], check=True)
+    got, ref = open(out_arff).read(), open(os.path.join(G, "compare16_func_u3.arff")).read()
+    assert got.split("@data")[0] == ref.split("@data")[0]
+    dg, dr = got.split("@data")[1].strip().split(","), ref.split("@data")[1].strip().split(",")
+    assert len(dg) == len(dr) == 6373 + 2 and dg[0] == dr[0] == "u3" and dg[-1] == dr[-1]
+    h, x = read_htk(out_htk)
+    hr, xr = read_htk(os.path.join(G, "compare16_func_u3.htk"))
+    assert h == hr and x.shape == xr.shape == (1, 6373)
+    err = np.abs(x[0].astype(np.float64) - xr[0]) / np.maximum(np.abs(xr[0]), 1e-2)
+    assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_smilextract_hip_errors(tmp_path):
     r = subprocess.run([EXE, "--set", "nope", "-I", "x.wav"], capture_output=True)
     assert r.returncode != 0 and b"--set" in r.stderr
@@ -230,3 +249,18 @@ def test_smilextract_hip_plp(tmp_path):
     head, names, vals, _ = parse_csv(out_csv)
     head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "plp_u2_8000.csv"))
     assert head == head_r and names == names_r and vals.shape == vals_r.shape
+
+
+def test_compare16_functional_names_match_binary(hostlib):
+    """func_names_compare16(): the 6373 element names of ComParE_2016's functionals level, as the real binary's CSV
+    header lists them (tests/golden/compare16_func_synth.npz)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "compare16_func_synth.npz"))
+    want = [str(x) for x in g["names"]]
+    hostlib.shim_names.restype = C.c_long
+    hostlib.shim_names.argtypes = [C.c_int, C.c_char_p, C.c_long]
+    buf = C.create_string_buffer(1 << 20)
+    n = hostlib.shim_names(4, buf, len(buf))
+    assert n > 0
+    got = buf.raw[:n].decode().split("\n")[:-1]
+    assert len(got) == 6373
+    assert got == want
