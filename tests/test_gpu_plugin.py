@@ -187,6 +187,26 @@ def test_plugin_is09_functionals(oracle, golden_func):
         assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.97
 
 
+def test_plugin_compare16_functionals_all_families(oracle):
+    """ComParE_2016.conf, unmodified, with only cFunctionals behind the plugin: its six instances (Extremes, Means,
+    Moments, Regression incl. the quadratic part, Percentiles, Times, Segments, Lpc, Peaks2; nonZeroFuncts; three time
+    norms) are translated into specs and computed on the device from the binary's own LLD contours -- the 6373 values
+    equal the plain binary's bit for bit, except the few that pass through libm (log / exp; 1e-6)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "compare16_func_synth.npz"))
+    names = [str(n) for n in g["names"]]
+    libm = ("_flatness", "_peakMeanRel", "_centroid", "_linregc1", "_qregc1", "_qregc2")
+    soft = np.array([n.endswith(libm) for n in names])
+    for k in ("u7_2720", "u5_16000", "u4_9000"):
+        ref = g["func_" + k][None, :]
+        y, tr = _run(oracle, g["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, COMPARE, "-htkoutput")
+        assert y.shape == ref.shape == (1, 6373)
+        assert tr["cFunctionals"] == 8 + 110 + 12 + 1 + 59 + 59, tr       # one doProcess per input element
+        same = y.view(np.uint32) == ref.view(np.uint32)
+        assert same[0, ~soft].all(), (k, [names[i] for i in np.flatnonzero(~same[0] & ~soft)[:6]])
+        err = np.abs(y.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-6)
+        assert err.max() <= 1e-6, (k, names[int(err.argmax())], float(err.max()))
+
+
 def test_plugin_plp_cepstra_bit_exact(oracle, golden_plp):
     """config/plp/PLP_0_D_A.conf, unmodified, with cPlp (PLP cepstra: IDFT, Durbin, LP -> cepstra, lifter) and the
     delta components behind the plugin: same float sequence as the reference, pow through a correctly
