@@ -277,7 +277,7 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *                                                  qregerrQ centroid qregls qregrs qregx0 qregy0 qregyr qregy0nn qregc3nn qregyrnn
  *   Percentiles (functionalPercentiles.cpp:312-417) quartile1..3 iqr1-2 iqr2-3 iqr1-3, percentile[], pctlrange[]
  *   Times       (functionalTimes.cpp:213-367)      up/downleveltime25,50,75,90 risetime falltime leftctime rightctime duration
- *   Segments    (functionalSegments.cpp:309-367, 656-725, 801-958; relTh and nonX) numSegments meanSegLen maxSegLen
+ *   Segments    (functionalSegments.cpp:309-367, 656-799, 801-958; relTh, nonX and eqX) numSegments meanSegLen maxSegLen
  *                                                  minSegLen segLenStddev
  *   Lpc         (functionalLpc.cpp:95-119)         lpgain, lpc[first..order)
  *   Peaks2      (functionalPeaks2.cpp:316-905)     its 32 values in the order of functionalPeaks2.cpp:60-67
@@ -290,7 +290,7 @@ enum {
   SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
-enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1 };
+enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2 };
 
 typedef struct smilehip_func_spec {
   int32_t n_fam;

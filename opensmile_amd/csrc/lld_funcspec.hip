@@ -565,11 +565,12 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
     });
   } else {
     const float X = s.seg_x_is_rel ? (min + range * s.seg_x) : s.seg_x;
+    const bool eq = s.seg_algo == SMILEHIP_SEG_EQX;      // eqX (:728-799) is nonX with the two tests swapped
     int64_t startIdx = 0;
     const int64_t i = Nin;                       // the index after the walk, as the reference's loop leaves it
     int inSeg = 0, segStart = 0, segEnd = 0;
     for_rows(in, 0, Nin, [&](int64_t i, float v) {
-      if (v != X) {
+      if (eq ? (v == X) : (v != X)) {
         if (inSeg == 1) {
           segEnd = 0;
           segStart++;
@@ -582,7 +583,7 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
           segEnd = 0;
         }
       }
-      if (v == X) {
+      if (eq ? (v != X) : (v == X)) {
         if (inSeg == 2) {
           segStart = 0;
           segEnd++;

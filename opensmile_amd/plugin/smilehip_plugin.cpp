@@ -940,6 +940,7 @@ class cHipFunctionals : public cFunctionals {
         if (!alg) return false;
         if (!strncmp(alg, "relTh", 5)) s.seg_algo = SMILEHIP_SEG_RELTH;
         else if (!strncmp(alg, "nonX", 4)) s.seg_algo = SMILEHIP_SEG_NONX;
+        else if (!strncmp(alg, "eqX", 3)) s.seg_algo = SMILEHIP_SEG_EQX;
         else return false;
         if (opt_int(f, "growDynSegBuffer") || opt_int(f, "useOldBuggyChX")) return false;
         s.seg_max_num = opt_int(f, "maxNumSeg");

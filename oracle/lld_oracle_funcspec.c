@@ -11,7 +11,7 @@
  *   cFunctionalRegression::process   src/functionals/functionalRegression.cpp:142-425
  *   cFunctionalPercentiles::process  src/functionals/functionalPercentiles.cpp:312-417 (+ getInterpPctl 292-310)
  *   cFunctionalTimes::process        src/functionals/functionalTimes.cpp:213-367
- *   cFunctionalSegments::process     src/functionals/functionalSegments.cpp:309-367 (relTh), 656-725 (nonX), 801-958
+ *   cFunctionalSegments::process     src/functionals/functionalSegments.cpp:309-367 (relTh), 656-725 (nonX), 728-799 (eqX), 801-958
  *   cFunctionalLpc::process          src/functionals/functionalLpc.cpp:95-119, smileUtil.c:1560-1630
  *   cFunctionalPeaks2::process       src/functionals/functionalPeaks2.cpp:316-905
  *   smileMath_ratioLimit             src/smileutil/smileUtil.c:586-613
@@ -534,12 +534,13 @@ static int f_segments(const lldo_func_spec *s, const float *in, float min, float
       raLast = ra;
       if (cross && (i - lastSeg > segMinLng)) { seg_add(&r, i, lastSeg); lastSeg = i; }
     }
-  } else {                                               /* nonX */
+  } else {                                               /* nonX; eqX (:728-799) is its mirror image */
     const float X = s->seg_x_is_rel ? (min + range * s->seg_x) : s->seg_x;
+    const int eq = s->seg_algo == LLDO_SEG_EQX;
     long startIdx = 0, i;
     int inSeg = 0, segStart = 0, segEnd = 0;
     for (i = 0; i < Nin; i++) {
-      if (in[i] != X) {
+      if (eq ? (in[i] == X) : (in[i] != X)) {
         if (inSeg == 1) {
           segEnd = 0;
           segStart++;
@@ -552,7 +553,7 @@ static int f_segments(const lldo_func_spec *s, const float *in, float min, float
           segEnd = 0;
         }
       }
-      if (in[i] == X) {
+      if (eq ? (in[i] != X) : (in[i] == X)) {
         if (inSeg == 2) {
           segStart = 0;
           segEnd++;

@@ -11,7 +11,7 @@ enum {
   LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_COUNT
 };
 enum { LLDO_NORM_SEGMENT = 0, LLDO_NORM_SECOND = 1, LLDO_NORM_FRAME = 2 };   /* functionalComponent.hpp:27-33 */
-enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1 };
+enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1, LLDO_SEG_EQX = 2 };
 
 typedef struct lldo_func_spec {
   int32_t n_fam;

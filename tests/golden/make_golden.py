@@ -94,6 +94,20 @@ def gen_func16():
     np.savez_compressed(os.path.join(OUT, "compare16_func_synth.npz"), **ref)
 
 
+def gen_egemaps_func():
+    """eGeMAPSv02.conf on the real binary: the 88 functionals (summaries of LLDs this repo does not compute itself --
+    used to check the plugin's cFunctionals override on the instances of the GeMAPS sets: Moments with stddevNorm,
+    3-point percentiles, Peaks2 slopes / numPeaks, Segments nonX / eqX in seconds, nonZeroFuncts)."""
+    ref = {}
+    for name, (u, n) in {"u3_48000": (3, 48000), "u2_32000": (2, 32000), "u4_16000": (4, 16000), "u10_16000": (10, 16000)}.items():
+        pcm = synth.utterance(u, n)
+        f, _ = lldo.run_reference_func("egemaps/v02/eGeMAPSv02.conf", pcm)
+        ref["pcm_" + name] = pcm
+        ref["func_" + name] = f
+        print("egemaps", name, f.shape)
+    np.savez_compressed(os.path.join(OUT, "egemaps_func_synth.npz"), **ref)
+
+
 def gen_plp():
     # config/plp/PLP_0_D_A.conf (PLP-CC + delta + accel, 18 columns): R8's IDFT / LP / cepstrum branch
     ref = {}
@@ -116,6 +130,9 @@ def main(only=None):
         return
     if only == "plp":
         gen_plp()
+        return
+    if only == "egemaps":
+        gen_egemaps_func()
         return
     if only == "func16":
         gen_func16()
@@ -166,6 +183,7 @@ def main(only=None):
     gen_f0()
     gen_htk_variants()
     gen_func16()
+    gen_egemaps_func()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave

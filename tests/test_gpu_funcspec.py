@@ -127,6 +127,31 @@ def test_funcspec_custom_spec_all_values(hip, oracle):
     assert exact > 0.97, exact
 
 
+@pytest.mark.parametrize("algo", [1, 2])
+def test_funcspec_segments_nonx_eqx_seconds(hip, oracle, algo):
+    """Segments nonX / eqX with second norm and numSegments, as the GeMAPS sets configure them, on a voiced/unvoiced
+    pattern (runs of zeros)."""
+    capi, ctx = hip
+    s = capi.FuncSpec()
+    s.n_fam, s.period = 1, 0.01
+    s.fam[0] = 6
+    s.seg_mask, s.seg_norm, s.seg_algo, s.seg_max_num = 0x1f, 1, algo, 1000
+    s.seg_min_lng, s.seg_auto_min_lng, s.seg_pause_min_lng, s.seg_x = 3, 1, 2, 0.0
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((600, 8)).astype(np.float32)
+    for c in range(8):
+        pos = 0
+        while pos < 600:
+            run = int(rng.integers(1, 40))
+            if rng.random() < 0.5:
+                x[pos:pos + run, c] = 0.0
+            pos += run
+    dev = capi.funcspec_matrix_host(ctx, s, x)
+    ref = oracle.funcspec(x, as_oracle_spec(oracle, s))
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    assert (ref[:, 0] > 0).all()
+
+
 def test_batch_funcspec_ragged_with_cut_and_extra_row(hip, oracle):
     """smilehip_batch_funcspec on a ragged batch: per-utterance rows = max(1, rows - cut) (+ one extra row), column
     sub-ranges, utterances without rows."""

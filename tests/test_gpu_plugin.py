@@ -207,6 +207,22 @@ def test_plugin_compare16_functionals_all_families(oracle):
         assert err.max() <= 1e-6, (k, names[int(err.argmax())], float(err.max()))
 
 
+def test_plugin_egemaps_functionals(oracle):
+    """eGeMAPSv02.conf, unmodified, with only cFunctionals behind the plugin: the functionals instances of the GeMAPS sets
+    (Moments with stddevNorm = 2, 20/50/80 percentiles + range, Peaks2 slopes and numPeaks per second, Segments nonX and
+    eqX in seconds, nonZeroFuncts = 1, masterTimeNorm) run on the device from the binary's own LLD contours and give the
+    plain binary's 88 values (libm-dependent ones 1e-6)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "egemaps_func_synth.npz"))
+    for k in ("u3_48000", "u4_16000", "u10_16000"):
+        ref = g["func_" + k]
+        y, tr = _run(oracle, g["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, "egemaps/v02/eGeMAPSv02.conf", "-htkoutput")
+        assert y.shape == ref.shape == (1, 88)
+        assert tr["cFunctionals"] >= 25, tr                              # every instance went through the override
+        err = np.abs(y.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-6)
+        assert err.max() <= 1e-6, (k, int(err.argmax()), float(err.max()), float(y[0, err.argmax()]), float(ref[0, err.argmax()]))
+        assert (y.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.95
+
+
 def test_plugin_plp_cepstra_bit_exact(oracle, golden_plp):
     """config/plp/PLP_0_D_A.conf, unmodified, with cPlp (PLP cepstra: IDFT, Durbin, LP -> cepstra, lifter) and the
     delta components behind the plugin: same float sequence as the reference, pow through a correctly
