@@ -843,14 +843,42 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
       }
     });
   }
-  // statistics of the surviving extrema (:474-560)
+  // statistics of the surviving extrema (:474-560) and the slopes between them (:640-745). The reference takes four
+  // walks over its list (sums, squared deviations, slopes, squared slope deviations); the sums of the first and third
+  // are independent of each other, as are those of the second and fourth: two walks here, every accumulator in its own
+  // order.
   float peakMax = 0.0f, peakMin = 0.0f, peakDist = 0.0f, peakDiff = 0.0f, peakStddevDist = 0.0f, peakStddevDiff = 0.0f;
   float peakMean = 0.0f, minMax = 0.0f, minMin = 0.0f, minDist = 0.0f, minDiff = 0.0f, minStddevDist = 0.0f;
   float minStddevDiff = 0.0f, minMean = 0.0f;
   int64_t nPeakDist = 0, nPeaks = 0, nMinDist = 0, nMins = 0;
+  float meanRisingSlope = 0.0f, meanFallingSlope = 0.0f, minRisingSlope = 0.0f, maxRisingSlope = 0.0f;
+  float minFallingSlope = 0.0f, maxFallingSlope = 0.0f, stddevRisingSlope = 0.0f, stddevFallingSlope = 0.0f;
+  int nRising = 0, nFalling = 0, lastIsMax = -1;
+  const bool slopes = (s.pk_mask & 0xffc00000u) != 0;
+  const float T = (float)s.period;
+  auto fall = [&](float slope) {
+    meanFallingSlope += slope;
+    if (nFalling == 0) { minFallingSlope = slope; maxFallingSlope = slope; }
+    else {
+      if (slope < minFallingSlope) minFallingSlope = slope;
+      if (slope > maxFallingSlope) maxFallingSlope = slope;
+    }
+    nFalling++;
+  };
+  auto rise = [&](float slope) {
+    meanRisingSlope += slope;
+    if (nRising == 0) { minRisingSlope = slope; maxRisingSlope = slope; }
+    else {
+      if (slope < minRisingSlope) minRisingSlope = slope;
+      if (slope > maxRisingSlope) maxRisingSlope = slope;
+    }
+    nRising++;
+  };
   {
     int64_t lmx = -1, lmn = -1;
     float lmy = 0.0f, lny = 0.0f;
+    float lastMax = in0, lastMin = in0;
+    int64_t lastMaxPos = 0, lastMinPos = 0;
     pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
       if (!is_max) {
         if (lmn == -1) { minMin = y; minMax = y; }
@@ -864,6 +892,10 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
         lmn = i; lny = y;
         minMean += y;
         nMins++;
+        if (slopes) {
+          lastMin = y; lastMinPos = i;
+          if (lastMinPos - lastMaxPos > 0) { fall((lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T)); lastIsMax = 0; }
+        }
       } else {
         if (lmx == -1) { peakMin = y; peakMax = y; }
         else {
@@ -876,8 +908,25 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
         lmx = i; lmy = y;
         peakMean += y;
         nPeaks++;
+        if (slopes) {
+          lastMax = y; lastMaxPos = i;
+          if (lastMaxPos - lastMinPos > 0) { rise((lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T)); lastIsMax = 1; }
+        }
       }
     });
+    if (slopes) {
+      if (lastIsMax == 1) {
+        if (Nin - 1 - lastMaxPos > 0) fall((inL - lastMax) / ((float)(Nin - 1 - lastMaxPos) * T));
+      } else if (lastIsMax == 0) {
+        if (Nin - 1 - lastMinPos > 0) rise((inL - lastMin) / ((float)(Nin - 1 - lastMinPos) * T));
+      } else {
+        const float slope = (inL - in0) / (float)Nin;
+        if (slope > 0) { meanRisingSlope = maxRisingSlope = minRisingSlope = slope; nRising = 1; }
+        else if (slope < 0) { meanFallingSlope = maxFallingSlope = minFallingSlope = slope; nFalling = 1; }
+      }
+      if (nRising > 1) meanRisingSlope /= (float)nRising;
+      if (nFalling > 1) meanFallingSlope /= (float)nFalling;
+    }
   }
   if (nPeaks > 1) {
     peakMean /= (float)nPeaks;
@@ -891,6 +940,8 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
     bool haveMax = false;
     int64_t lmn = -1;
     float lny = 0.0f;
+    float lastMax = in0, lastMin = in0;
+    int64_t lastMaxPos = 0, lastMinPos = 0;
     pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
       if (!is_max) {
         if (lmn != -1) {
@@ -899,12 +950,26 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
           minStddevDiff += (dy - minDiff) * (dy - minDiff);
         }
         lmn = i; lny = y;
+        if (slopes) {
+          lastMin = y; lastMinPos = i;
+          if (lastMinPos - lastMaxPos > 0) {
+            const float slope = (lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T);
+            stddevFallingSlope += (slope - meanFallingSlope) * (slope - meanFallingSlope);
+          }
+        }
       } else {
         if (!haveMax) haveMax = true;
         else if (lmn != -1) {                    // measured against the last MINIMUM, as the reference does (:594-598)
           const float dx = (float)(i - lmn), dy = (float)fabs((double)(y - lny));
           peakStddevDist += (dx - peakDist) * (dx - peakDist);
           peakStddevDiff += (dy - peakDiff) * (dy - peakDiff);
+        }
+        if (slopes) {
+          lastMax = y; lastMaxPos = i;
+          if (lastMaxPos - lastMinPos) {
+            const float slope = (lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T);
+            stddevRisingSlope += (slope - meanRisingSlope) * (slope - meanRisingSlope);
+          }
         }
       }
     });
@@ -915,68 +980,7 @@ __device__ int f_peaks2(const smilehip_func_spec &s, const Col &in, float min, f
   if (nMinDist > 1) { minStddevDist /= (float)nMinDist; minStddevDiff /= (float)nMinDist; }
   minStddevDist = (minStddevDist > 0.0f) ? (float)sqrt((double)minStddevDist) : 0.0f;
   minStddevDiff = (minStddevDiff > 0.0f) ? (float)sqrt((double)minStddevDiff) : 0.0f;
-
-  float meanRisingSlope = 0.0f, meanFallingSlope = 0.0f, minRisingSlope = 0.0f, maxRisingSlope = 0.0f;
-  float minFallingSlope = 0.0f, maxFallingSlope = 0.0f, stddevRisingSlope = 0.0f, stddevFallingSlope = 0.0f;
-  int nRising = 0, nFalling = 0, lastIsMax = -1;
-  if (s.pk_mask & 0xffc00000u) {
-    const float T = (float)s.period;
-    float lastMax = in0, lastMin = in0;
-    int64_t lastMaxPos = 0, lastMinPos = 0;
-    auto fall = [&](float slope) {
-      meanFallingSlope += slope;
-      if (nFalling == 0) { minFallingSlope = slope; maxFallingSlope = slope; }
-      else {
-        if (slope < minFallingSlope) minFallingSlope = slope;
-        if (slope > maxFallingSlope) maxFallingSlope = slope;
-      }
-      nFalling++;
-    };
-    auto rise = [&](float slope) {
-      meanRisingSlope += slope;
-      if (nRising == 0) { minRisingSlope = slope; maxRisingSlope = slope; }
-      else {
-        if (slope < minRisingSlope) minRisingSlope = slope;
-        if (slope > maxRisingSlope) maxRisingSlope = slope;
-      }
-      nRising++;
-    };
-    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
-      if (!is_max) {
-        lastMin = y; lastMinPos = i;
-        if (lastMinPos - lastMaxPos > 0) { fall((lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T)); lastIsMax = 0; }
-      } else {
-        lastMax = y; lastMaxPos = i;
-        if (lastMaxPos - lastMinPos > 0) { rise((lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T)); lastIsMax = 1; }
-      }
-    });
-    if (lastIsMax == 1) {
-      if (Nin - 1 - lastMaxPos > 0) fall((inL - lastMax) / ((float)(Nin - 1 - lastMaxPos) * T));
-    } else if (lastIsMax == 0) {
-      if (Nin - 1 - lastMinPos > 0) rise((inL - lastMin) / ((float)(Nin - 1 - lastMinPos) * T));
-    } else {
-      const float slope = (inL - in0) / (float)Nin;
-      if (slope > 0) { meanRisingSlope = maxRisingSlope = minRisingSlope = slope; nRising = 1; }
-      else if (slope < 0) { meanFallingSlope = maxFallingSlope = minFallingSlope = slope; nFalling = 1; }
-    }
-    if (nRising > 1) meanRisingSlope /= (float)nRising;
-    if (nFalling > 1) meanFallingSlope /= (float)nFalling;
-    lastMax = in0; lastMaxPos = 0; lastMin = in0; lastMinPos = 0;
-    pk_for_each(in, alive, ald, true, [&](int64_t i, float y, bool is_max) {
-      if (!is_max) {
-        lastMin = y; lastMinPos = i;
-        if (lastMinPos - lastMaxPos > 0) {
-          const float slope = (lastMax - lastMin) / ((float)(lastMinPos - lastMaxPos) * T);
-          stddevFallingSlope += (slope - meanFallingSlope) * (slope - meanFallingSlope);
-        }
-      } else {
-        lastMax = y; lastMaxPos = i;
-        if (lastMaxPos - lastMinPos) {
-          const float slope = (lastMax - lastMin) / ((float)(lastMaxPos - lastMinPos) * T);
-          stddevRisingSlope += (slope - meanRisingSlope) * (slope - meanRisingSlope);
-        }
-      }
-    });
+  if (slopes) {
     if (nRising > 1) stddevRisingSlope /= (float)nRising;
     if (nFalling > 1) stddevFallingSlope /= (float)nFalling;
     stddevRisingSlope = (stddevRisingSlope > 0.0f) ? (float)sqrt((double)stddevRisingSlope) : 0.0f;
