@@ -83,34 +83,35 @@ int spec_layout(const smilehip_func_spec *s, int *fam_off, int *fam_want) {
 
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-// carves the scratch for scratch_rows x n_cols (+ per-utterance stats) out of the context's buffer
-int fs_scratch(smilehip_context *ctx, FsParams &P, int64_t scratch_rows, int n_utt, bool need_nz, bool need_alive, bool need_sorted,
-               hipStream_t stream) {
-  const size_t cells = size_t(scratch_rows) * size_t(P.n_cols), st = size_t(n_utt) * size_t(P.n_cols);
+// scratch of one launch set (scratch_rows x n_cols cells + per-utterance stats): its size, and its carving at `base`
+struct FsNeed { bool nz, alive, sorted; int64_t rows; int n_utt; };
+size_t fs_bytes(const FsParams &P, const FsNeed &n) {
+  const size_t cells = size_t(n.rows) * size_t(P.n_cols), st = size_t(n.n_utt) * size_t(P.n_cols);
+  return (n.nz ? align256(cells * 4) : 0) + (n.alive ? align256(cells) : 0) + (n.sorted ? align256(cells * 8) : 0) +
+         4 * align256(st * 4);
+}
+void fs_carve(char *b, FsParams &P, const FsNeed &n) {
+  const size_t cells = size_t(n.rows) * size_t(P.n_cols), st = size_t(n.n_utt) * size_t(P.n_cols);
   size_t off = 0;
-  const size_t o_nz = off; off += need_nz ? align256(cells * 4) : 0;
-  const size_t o_alive = off; off += need_alive ? align256(cells) : 0;
-  const size_t o_sorted = off; off += need_sorted ? align256(cells * 8) : 0;
-  const size_t o_st = off; off += 4 * align256(st * 4);
-  if (off > ctx->fs_cap) {
-    // earlier launches may still read the old buffer
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipDeviceSynchronize());
-    if (ctx->fs_scratch) (void)hipFree(ctx->fs_scratch);
-    ctx->fs_scratch = nullptr;
-    ctx->fs_cap = 0;
-    const size_t want = off + off / 4;
-    HIP_TRY(hipMalloc(&ctx->fs_scratch, want));
-    ctx->fs_cap = want;
-  }
-  char *b = static_cast<char *>(ctx->fs_scratch);
-  P.nz = need_nz ? reinterpret_cast<float *>(b + o_nz) : nullptr;
-  P.alive = need_alive ? reinterpret_cast<unsigned char *>(b + o_alive) : nullptr;
-  P.sorted = need_sorted ? reinterpret_cast<float *>(b + o_sorted) : nullptr;
-  P.st_min = reinterpret_cast<float *>(b + o_st);
-  P.st_max = reinterpret_cast<float *>(b + o_st + align256(st * 4));
-  P.st_mean = reinterpret_cast<float *>(b + o_st + 2 * align256(st * 4));
-  P.st_n = reinterpret_cast<int32_t *>(b + o_st + 3 * align256(st * 4));
+  P.nz = n.nz ? reinterpret_cast<float *>(b + off) : nullptr; off += n.nz ? align256(cells * 4) : 0;
+  P.alive = n.alive ? reinterpret_cast<unsigned char *>(b + off) : nullptr; off += n.alive ? align256(cells) : 0;
+  P.sorted = n.sorted ? reinterpret_cast<float *>(b + off) : nullptr; off += n.sorted ? align256(cells * 8) : 0;
+  P.st_min = reinterpret_cast<float *>(b + off);
+  P.st_max = reinterpret_cast<float *>(b + off + align256(st * 4));
+  P.st_mean = reinterpret_cast<float *>(b + off + 2 * align256(st * 4));
+  P.st_n = reinterpret_cast<int32_t *>(b + off + 3 * align256(st * 4));
+}
+int fs_reserve(smilehip_context *ctx, size_t bytes, hipStream_t stream) {
+  if (bytes <= ctx->fs_cap) return SMILEHIP_OK;
+  // earlier launches may still read the old buffer
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->fs_scratch) (void)hipFree(ctx->fs_scratch);
+  ctx->fs_scratch = nullptr;
+  ctx->fs_cap = 0;
+  const size_t want = bytes + bytes / 4;
+  HIP_TRY(hipMalloc(&ctx->fs_scratch, want));
+  ctx->fs_cap = want;
   return SMILEHIP_OK;
 }
 
@@ -120,17 +121,34 @@ bool has_family(const smilehip_func_spec &s, int fam) {
   return false;
 }
 
-int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows, int64_t max_rows, hipStream_t stream) {
+FsNeed spec_need(const FsParams &P, int n_utt, int64_t scratch_rows, int64_t max_rows) {
+  FsNeed n;
+  n.nz = P.spec.non_zero_functs != 0;
+  n.alive = has_family(P.spec, SMILEHIP_FAM_PEAKS2);
+  n.sorted = has_family(P.spec, SMILEHIP_FAM_PERCENTILES) && max_rows > fs_sort_lds_rows();
+  n.rows = scratch_rows;
+  n.n_utt = n_utt;
+  return n;
+}
+
+int launch_spec(FsParams &P, int n_utt, hipStream_t stream) {
   int fam_off[12], fam_want[12];
   const int per = spec_layout(&P.spec, fam_off, fam_want);
   if (per < 0) return per;
   P.per = per;
-  const bool need_sorted = has_family(P.spec, SMILEHIP_FAM_PERCENTILES) && max_rows > fs_sort_lds_rows();
-  int rc = fs_scratch(ctx, P, scratch_rows, n_utt, P.spec.non_zero_functs != 0, has_family(P.spec, SMILEHIP_FAM_PEAKS2), need_sorted, stream);
-  if (rc) return rc;
   hipError_t e = launch_funcspec(P, n_utt, fam_off, fam_want, stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
+}
+
+int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows, int64_t max_rows, hipStream_t stream) {
+  const int per = spec_layout(&P.spec, nullptr, nullptr);
+  if (per < 0) return per;
+  const FsNeed need = spec_need(P, n_utt, scratch_rows, max_rows);
+  int rc = fs_reserve(ctx, fs_bytes(P, need), stream);
+  if (rc) return rc;
+  fs_carve(static_cast<char *>(ctx->fs_scratch), P, need);
+  return launch_spec(P, n_utt, stream);
 }
 
 }  // namespace
@@ -294,9 +312,16 @@ extern "C" int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehi
     return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: run smilehip_lld_run on this batch first");
   int64_t max_rows = 0;
   for (int u = 0; u < b->n_utt; ++u) max_rows = std::max(max_rows, b->h_row_off[u + 1] - b->h_row_off[u] + 1);
+  // The nine launch sets are independent (own output columns, own scratch slice) and each is latency-bound with about
+  // one wave per SIMD: they run side by side on the context's auxiliary streams, forked from and joined to `stream`.
+  constexpr int kParts = sizeof(kCompare16Parts) / sizeof(kCompare16Parts[0]);
+  FsParams Ps[kParts];
+  FsNeed needs[kParts];
+  size_t offs[kParts], total = 0;
   int off = 0;
-  for (const Part &part : kCompare16Parts) {
-    FsParams P;
+  for (int i = 0; i < kParts; ++i) {
+    const Part &part = kCompare16Parts[i];
+    FsParams &P = Ps[i];
     std::memset(&P, 0, sizeof(P));
     int rc = smilehip_funcspec_compare16(part.inst, &P.spec);
     if (rc) return rc;
@@ -316,9 +341,38 @@ extern "C" int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehi
     }
     P.out = d_func + off;
     P.ld_out = ld_func;
-    rc = run_spec(plan->ctx, P, b->n_utt, b->total_rows + b->n_utt, max_rows, (hipStream_t)stream);
-    if (rc) return rc;
+    needs[i] = spec_need(P, b->n_utt, b->total_rows + b->n_utt, max_rows);
+    offs[i] = total;
+    total += fs_bytes(P, needs[i]);
     off += per * part.n_cols;
+  }
+  hipStream_t main = (hipStream_t)stream;
+  int rc = fs_reserve(plan->ctx, total, main);
+  if (rc) return rc;
+  smilehip_context *ctx = plan->ctx;
+  if (!ctx->fs_streams_ready) {
+    for (int k = 0; k < smilehip_context::kFsStreams; ++k) {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->fs_stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->fs_done[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&ctx->fs_fork, hipEventDisableTiming));
+    ctx->fs_streams_ready = true;
+  }
+  HIP_TRY(hipEventRecord(ctx->fs_fork, main));
+  for (int k = 0; k < smilehip_context::kFsStreams; ++k) HIP_TRY(hipStreamWaitEvent(ctx->fs_stream[k], ctx->fs_fork, 0));
+  // longest sets first, spread over main + auxiliary streams
+  static const int order[kParts] = {7, 8, 2, 3, 4, 5, 0, 1, 6};
+  for (int j = 0; j < kParts; ++j) {
+    const int i = order[j];
+    const int lane = j % (smilehip_context::kFsStreams + 1);
+    hipStream_t st = lane == 0 ? main : ctx->fs_stream[lane - 1];
+    fs_carve(static_cast<char *>(ctx->fs_scratch) + offs[i], Ps[i], needs[i]);
+    rc = launch_spec(Ps[i], b->n_utt, st);
+    if (rc) return rc;
+  }
+  for (int k = 0; k < smilehip_context::kFsStreams; ++k) {
+    HIP_TRY(hipEventRecord(ctx->fs_done[k], ctx->fs_stream[k]));
+    HIP_TRY(hipStreamWaitEvent(main, ctx->fs_done[k], 0));
   }
   if (off != 6373) return fail(SMILEHIP_ERR_INVALID, "internal: ComParE_2016 functionals layout adds up to %d", off);
   return SMILEHIP_OK;

@@ -36,8 +36,17 @@ struct smilehip_context {
   // scratch of the general functionals (smilehip_funcspec.cpp), grown on demand
   void *fs_scratch = nullptr;
   size_t fs_cap = 0;
+  // auxiliary streams on which independent functionals launch sets run side by side
+  static constexpr int kFsStreams = 4;
+  hipStream_t fs_stream[kFsStreams] = {};
+  hipEvent_t fs_done[kFsStreams] = {}, fs_fork = nullptr;
+  bool fs_streams_ready = false;
   ~smilehip_context() {
     if (fs_scratch) (void)hipFree(fs_scratch);
+    if (fs_streams_ready) {
+      for (int k = 0; k < kFsStreams; ++k) { (void)hipStreamDestroy(fs_stream[k]); (void)hipEventDestroy(fs_done[k]); }
+      (void)hipEventDestroy(fs_fork);
+    }
   }
 };
 
