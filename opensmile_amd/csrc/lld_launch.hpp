@@ -42,7 +42,6 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
-hipError_t launch_functionals(const FuncParams &P, int n_utt, hipStream_t s);
 hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s);
 int fs_sort_lds_rows();
 int chain_tile_rows();

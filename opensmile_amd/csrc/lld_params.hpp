@@ -151,22 +151,6 @@ struct SpectralConsts {
   double slope_Sf, slope_S2f;
 };
 
-// Functionals over the LLD rows of each utterance (lld_functionals.hip)
-struct FuncParams {
-  const int64_t *row_off;    // [n_utt+1] LLD rows per utterance
-  const float *x;            // LLD matrix
-  int64_t ld_x;
-  int32_t n_cols;
-  // cFunctionals in frameMode=full summarises what its input levels hold at its first
-  // end-of-input tick, not the rows the sinks eventually get: with IS09's SMA(3) -> delta(2)
-  // tail that is max(1, T-2) = max(1, rows-3) rows (measured against the binary, T = 1..998)
-  int32_t rows_cut;
-  uint32_t mask;             // SMILEHIP_FUNC_* bits
-  int64_t single_rows;       // >= 0: ONE segment of this many rows starting at x (row_off unused, no cut); -1: use row_off
-  float *out;                // [n_utt x ld_out], n_cols * popcount(mask) values per utterance
-  int64_t ld_out;
-};
-
 // General functionals (lld_funcspec.hip): one cFunctionals instance over columns [col_first, col_first + n_cols) of
 // the utterances' rows (or of ONE matrix if single_rows >= 0).
 struct FsParams {

@@ -546,20 +546,13 @@ extern "C" int smilehip_batch_functionals(smilehip_plan *plan, smilehip_batch *b
                 (long long)ld_func);
   if (b->n_utt == 0) return SMILEHIP_OK;
   if (!d_func || (!d_lld && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals: null device pointer");
-  FuncParams P;
-  std::memset(&P, 0, sizeof(P));
-  P.row_off = b->d_row_off.p;
-  P.x = d_lld;
-  P.ld_x = ld_lld;
-  P.n_cols = n_cols;
-  P.rows_cut = kIs09FuncRowsCut;
-  P.single_rows = -1;
-  P.mask = mask;
-  P.out = d_func;
-  P.ld_out = ld_func;
-  hipError_t e = launch_functionals(P, b->n_utt, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
-  return SMILEHIP_OK;
+  // the mask is a cFunctionals instance with functionalsEnabled = Extremes;Regression;Moments, frame-normalised
+  // positions and the linear regression only: one spec of the general engine (lld_funcspec.hip), which walks every
+  // contour in the reference's order
+  smilehip_func_spec spec;
+  int rc = smilehip_funcspec_from_mask(mask, plan->geo.frame_period > 0.0 ? plan->geo.frame_period : 0.01, &spec);
+  if (rc) return rc;
+  return smilehip_batch_funcspec(plan, b, &spec, d_lld, ld_lld, 0, n_cols, kIs09FuncRowsCut, nullptr, 0, d_func, ld_func, stream);
 }
 
 extern "C" int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t ld_x, int64_t rows, int32_t cols,
@@ -567,18 +560,10 @@ extern "C" int smilehip_functionals_matrix(smilehip_context *ctx, const float *d
   const int per = smilehip_functionals_count(mask);
   if (!ctx || per <= 0 || rows < 1 || cols < 1 || ld_x < cols || !d_x || !d_out)
     return fail(SMILEHIP_ERR_INVALID, "smilehip_functionals_matrix: bad argument");
-  FuncParams P;
-  std::memset(&P, 0, sizeof(P));
-  P.x = d_x;
-  P.ld_x = ld_x;
-  P.n_cols = cols;
-  P.mask = mask;
-  P.single_rows = rows;
-  P.out = d_out;
-  P.ld_out = (int64_t)cols * per;
-  hipError_t e = launch_functionals(P, 1, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "functionals kernel launch failed: %s", hipGetErrorString(e));
-  return SMILEHIP_OK;
+  smilehip_func_spec spec;
+  int rc = smilehip_funcspec_from_mask(mask, 0.01, &spec);
+  if (rc) return rc;
+  return smilehip_funcspec_matrix(ctx, &spec, d_x, ld_x, rows, cols, d_out, stream);
 }
 
 extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out,

@@ -153,6 +153,24 @@ int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows
 
 }  // namespace
 
+int smilehip_funcspec_from_mask(uint32_t mask, double period, smilehip_func_spec *s) {
+  if (!s || (mask & ~SMILEHIP_FUNC_ALL) || !mask) return fail(SMILEHIP_ERR_INVALID, "invalid functionals mask 0x%x", mask);
+  std::memset(s, 0, sizeof(*s));
+  s->period = period;
+  s->ext_norm = SMILEHIP_NORM_FRAME;                      // positions in frames (Extremes.norm = frame)
+  s->means_norm = s->times_norm = s->seg_norm = s->pk_norm = SMILEHIP_NORM_FRAME;
+  s->reg_centroid_norm = SMILEHIP_NORM_SEGMENT;
+  s->seg_max_num = 20; s->seg_min_lng = 3; s->seg_pause_min_lng = 2; s->lpc_order = 5;
+  s->ext_mask = mask & 0xffu;
+  s->reg_mask = (mask >> 8) & 0xfu;                       // linregc1 linregc2 linregerrA linregerrQ
+  s->reg_old_buggy_qerr = 1;                              // the option's default; no quadratic value is enabled
+  s->mom_mask = (mask >> 12) & 0x1fu;                     // variance stddev skewness kurtosis amean
+  if (s->ext_mask) s->fam[s->n_fam++] = SMILEHIP_FAM_EXTREMES;
+  if (s->reg_mask) s->fam[s->n_fam++] = SMILEHIP_FAM_REGRESSION;
+  if (s->mom_mask) s->fam[s->n_fam++] = SMILEHIP_FAM_MOMENTS;
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_funcspec_count(const smilehip_func_spec *spec) { return spec_layout(spec, nullptr, nullptr); }
 
 // config/compare16/ComParE_2016_core.func.conf.inc

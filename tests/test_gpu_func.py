@@ -21,8 +21,8 @@ def hip():
 
 
 def test_functionals_kernel_vs_oracle_on_reference_lld(hip, oracle, golden_func):
-    """Same input (the reference's own LLD matrix) -> the kernel must reproduce the oracle:
-    positions and extremes exactly, double-accumulated values to float round-off."""
+    """Same input (the REAL binary's own LLD matrix) -> the binary's functionals vector, bit for bit: every contour is
+    walked in the reference's order with its accumulator types (none of IS09's 12 functionals passes through libm)."""
     capi, ctx, plan = hip
     llds = [golden_func["lld_" + k] for k in KEYS]
     # a batch whose row counts equal the golden LLD row counts: T = rows - 1 frames
@@ -36,14 +36,8 @@ def test_functionals_kernel_vs_oracle_on_reference_lld(hip, oracle, golden_func)
     for i, k in enumerate(KEYS):
         ref = golden_func["func_" + k][0]
         o = out[i]
-        exact = [n in ("max", "min", "range", "maxpos", "minpos") for n in NAMES] * 32
-        assert np.array_equal(o[exact], ref[exact]), k
-        d = np.abs(o.astype(np.float64) - ref)
-        tol = 1e-6 * np.maximum(np.abs(ref), 1e-30) + 1e-12
-        # third/fourth standardised moments divide by sigma^3 / sigma^4: relative 1e-5
-        assert (d <= np.maximum(tol, 1e-5 * np.abs(ref))).all(), (k, float((d / np.maximum(np.abs(ref), 1e-30)).max()))
-        same = (o.view(np.uint32) == ref.view(np.uint32)).mean()
-        assert same >= 0.97, (k, same)
+        same = o.view(np.uint32) == ref.view(np.uint32)
+        assert same.all(), (k, [NAMES[j % 12] for j in np.flatnonzero(~same)[:6]])
     b.close()
 
 

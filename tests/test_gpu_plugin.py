@@ -173,8 +173,8 @@ def test_plugin_compare_all_overrides(oracle, golden_compare):
 
 def test_plugin_is09_functionals(oracle, golden_func):
     """cFunctionals::doProcess behind the plugin: IS09_emotion's 384 functionals computed from the
-    binary's own LLD contours (only cFunctionals overridden) equal the binary's func level to the
-    round-off of the parallel double sums; positions and extremes exactly."""
+    binary's own LLD contours (only cFunctionals overridden) equal the binary's func level (every contour is walked
+    in the reference's order: bit for bit but for the last-bit cases the bound below allows)."""
     for k in ("u3_16000", "u7_560", "u2_32000"):
         ref = golden_func["func_" + k]
         y, tr = _run(oracle, golden_func["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, IS09, "-htkoutput")
