@@ -1134,9 +1134,11 @@ class cHipLldSource : public cDataSource {
   int n_cols_ = 0;
   double period_sec_ = 0.01, frame_size_sec_ = 0.025;
   bool ran_ = false;
+  bool func16_ = false;                                  // featureSet compare16_func: ONE vector, ComParE_2016's functionals level
   cMatrix *block_ = nullptr;
 
   void config_for(smilehip_lld_config &c) {              // any of the eight files of config/mfcc and config/plp, by name
+    if (func16_) { smilehip_config_compare16(&c); return; }
     std::string up;
     for (char ch : set_) up += (char)toupper((unsigned char)ch);
     if (smilehip_config_htk_variant(&c, up.c_str()) != SMILEHIP_OK)
@@ -1159,7 +1161,25 @@ class cHipLldSource : public cDataSource {
     check(smilehip_batch_create(pl, off, 1, &b));
     n_rows_ = (long)smilehip_batch_total_rows(b);
     rows_.assign((size_t)(n_rows_ > 0 ? n_rows_ : 1) * n_cols_, 0.0f);
-    if (n_rows_ > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows_.data()));
+    if (func16_) {
+      // LLD level (130 columns) and its functionals stay on the device; only the 6373-value vector comes back
+      const int64_t lld_rows = n_rows_;
+      n_rows_ = lld_rows > 0 ? 1 : 0;                     // no frame -> the reference writes no instance
+      if (lld_rows > 0) {
+        void *d_pcm = nullptr, *d_lld = nullptr, *d_func = nullptr;
+        check(smilehip_alloc(context(), (uint64_t)n * 2, &d_pcm));
+        check(smilehip_alloc(context(), (uint64_t)lld_rows * 130 * 4, &d_lld));
+        check(smilehip_alloc(context(), (uint64_t)n_cols_ * 4, &d_func));
+        check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
+        check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, 130, nullptr));
+        check(smilehip_batch_functionals_compare16(pl, b, (const float *)d_lld, 130, (float *)d_func, n_cols_, nullptr));
+        check(smilehip_copy_to_host(context(), rows_.data(), d_func, (uint64_t)n_cols_ * 4, nullptr));
+        check(smilehip_stream_synchronize(context(), nullptr));
+        smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld); smilehip_free(context(), d_func);
+      }
+    } else if (n_rows_ > 0) {
+      check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows_.data()));
+    }
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
     ran_ = true;
@@ -1170,11 +1190,17 @@ class cHipLldSource : public cDataSource {
     cDataSource::myFetchConfig();
     filename_ = getStr("filename") ? getStr("filename") : "";
     set_ = getStr("featureSet") ? getStr("featureSet") : "mfcc12_0_d_a";
+    func16_ = !strcasecmp(set_.c_str(), "compare16_func");
     smilehip_lld_config c;
     config_for(c);
     period_sec_ = c.frame_step_sec;
     frame_size_sec_ = c.frame_size_sec;
-    names_ = smilehip_host::lld_names_htk_variant(c.chain_kind == SMILEHIP_CHAIN_PLP, c.append_log_energy != 0);
+    if (func16_) {
+      names_ = smilehip_host::func_names_compare16();
+      period_sec_ = 0.0;                                  // one vector per input, as cFunctionals in frameMode = full writes
+    } else {
+      names_ = smilehip_host::lld_names_htk_variant(c.chain_kind == SMILEHIP_CHAIN_PLP, c.append_log_energy != 0);
+    }
     n_cols_ = (int)names_.size();
   }
   int configureWriter(sDmLevelConfig &c) override {
@@ -1189,7 +1215,8 @@ class cHipLldSource : public cDataSource {
     while (i < names_.size()) {
       const std::string &nm = names_[i];
       const size_t br = nm.rfind('[');
-      if (br == std::string::npos) { writer_->addField(nm.c_str(), 1); ++i; continue; }
+      // functional names carry the element index in the middle ("mfcc_sma[3]_range"): one field each
+      if (br == std::string::npos || nm.back() != ']') { writer_->addField(nm.c_str(), 1); ++i; continue; }
       const std::string base = nm.substr(0, br);
       const int first = atoi(nm.c_str() + br + 1);
       size_t j = i;
@@ -1240,7 +1267,7 @@ SMILECOMPONENT_REGCOMP(cHipLldSource) {
   SMILECOMPONENT_INHERIT_CONFIGTYPE("cDataSource")
   SMILECOMPONENT_IFNOTREGAGAIN(
     ct->setField("filename", "The RIFF/WAVE file to process (16-bit mono PCM)", "input.wav");
-    ct->setField("featureSet", "The feature set whose LLD rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z", "mfcc12_0_d_a");
+    ct->setField("featureSet", "The feature set whose rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z (LLD rows); compare16_func: the functionals level of compare16/ComParE_2016.conf, one vector of 6373 values per input", "mfcc12_0_d_a");
   )
   SMILECOMPONENT_MAKEINFO(cHipLldSource);
 }

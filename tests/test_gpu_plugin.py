@@ -273,6 +273,38 @@ def test_plugin_fused_source_component(oracle, golden_synth):
         assert np.array_equal(ch[2][:, 0], cr[2][:, 0])                 # frameTime column
 
 
+def test_plugin_fused_source_compare16_functionals(oracle):
+    """Fused mode for a set that ends in functionals: cHipLldSource with featureSet = compare16_func replaces the wave
+    source, all LLD components and the six cFunctionals instances of ComParE_2016.conf and writes the 6373-value vector
+    into the level `func`; the reference's sinks write the files. ARFF attribute block, CSV head line and HTK header
+    are the unmodified config's, byte for byte; the values follow the statistical bar of test_gpu_func16.py."""
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    G = os.path.join(ROOT, "tests", "golden", "files")
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        arff, htk, csv = (os.path.join(td, n) for n in ("f.arff", "f.htk", "f.csv"))
+        r = subprocess.run([exe, "-C", os.path.join(PLUGDIR, "conf", "ComParE_2016_func_hip.conf"), "-I", os.path.join(G, "u3_4000.wav"),
+                            "-O", arff, "-htkoutput", htk, "-csvoutput", csv, "-instname", "u3", "-l", "1"],
+                           cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and os.path.exists(arff) and os.path.exists(htk), r.stderr[-2000:]
+        got, ref = open(arff).read(), open(os.path.join(G, "compare16_func_u3.arff")).read()
+        assert got.split("@data")[0] == ref.split("@data")[0]
+        dg, dr = got.split("@data")[1].strip().split(","), ref.split("@data")[1].strip().split(",")
+        assert len(dg) == len(dr) == 6375 and dg[0] == dr[0] == "u3" and dg[-1] == dr[-1]
+        assert open(htk, "rb").read()[:12] == open(os.path.join(G, "compare16_func_u3.htk"), "rb").read()[:12]
+        x, xr = oracle.read_htk(htk)[0], oracle.read_htk(os.path.join(G, "compare16_func_u3.htk"))[0]
+        err = np.abs(x[0].astype(np.float64) - xr[0]) / np.maximum(np.abs(xr[0]), 1e-2)
+        assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+        head = open(csv).readline().strip().split(";")
+        assert head[:2] == ["name", "frameTime"] and len(head) == 6375
+        row = open(csv).read().split("\n")[1].split(";")
+        assert row[0] == "'u3'" and float(row[1]) == 0.0
+
+
 def test_plugin_mfcc_e_z_config_all_overrides(oracle):
     """config/mfcc/MFCC12_E_D_A_Z.conf, unmodified, every override active (cEnergy's HTK log branch on the raw frames,
     the reference's own cFullinputMean / cVectorConcat around the HIP components)."""
