@@ -136,3 +136,43 @@ def test_functionals16_large_batch_properties(hip):
     lld2, func2, _ = b.run_host_with_functionals16(pcm)
     assert np.array_equal(func.view(np.uint32), func2.view(np.uint32))
     b.close()
+
+
+def test_functionals16_long_utterance_global_sort(hip, oracle):
+    """A 90 s utterance (8995 LLD rows: beyond the 8192-row LDS sort, so the percentile stage sorts in global scratch
+    inside a ragged batch) next to short ones: Percentiles / the whole B and Nz instances against the oracle on the
+    device's own LLD matrix."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    lens = [16000, 1440000, 9000]
+    pcms = [synth.utterance(90 + i, n) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, ex = b.run_host_with_functionals16(np.concatenate(pcms))
+    u = 1
+    x = lld[b.frame_offsets[u]:b.frame_offsets[u + 1]]
+    T = x.shape[0] - 1
+    assert T + 1 > 8192
+    from test_oracle_pin_funcspec import pending
+    T2, P = pending(oracle, pcms[u])
+    assert T2 == T
+    pos = 0
+    for inst, c0, nc in PARTS:
+        spec = capi.funcspec_compare16(inst)
+        ospec = as_oracle_spec(oracle, spec)
+        names = oracle.funcspec_names(ospec)
+        per = len(names)
+        if inst in ("B", "Nz"):
+            n = func_rows(inst, T, P)
+            xi = x[:n, c0:c0 + nc] if inst == "Nz" else np.concatenate(
+                [x[:, c0:c0 + nc], ex[u:u + 1, (0 if c0 == 10 else 55):(55 if c0 == 10 else 110)]], axis=0)
+            ref = oracle.funcspec(np.ascontiguousarray(xi), ospec)
+            dev = func[u, pos:pos + per * nc].reshape(nc, per)
+            for k, nm in enumerate(names):
+                if nm in LIBM:
+                    err = np.abs(dev[:, k].astype(np.float64) - ref[:, k]) / np.maximum(np.abs(ref[:, k]), 1e-6)
+                    assert err.max() <= 1e-6, (inst, nm)
+                else:
+                    assert np.array_equal(dev[:, k].view(np.uint32), ref[:, k].view(np.uint32)), (inst, c0, nm)
+        pos += per * nc
+    b.close()
