@@ -321,7 +321,9 @@ int smilehip_funcspec_count(const smilehip_func_spec *spec);
 int smilehip_funcspec_compare16(const char *instance, smilehip_func_spec *spec);
 /* cFunctionals::doProcess for every column of ONE matrix (rows x cols, leading dimension ld_x, all rows): d_out
  * receives cols * count(spec) floats, element-major (column c's values at [c*count, (c+1)*count)). Scratch is owned
- * by the context and grown on demand. Asynchronous on `stream`. */
+ * by the context and grown on demand (growing synchronises the device once). Asynchronous on `stream`; calls that use
+ * the same context's scratch must be issued in stream order from one host thread at a time -- use one context per
+ * host thread otherwise. */
 int smilehip_funcspec_matrix(smilehip_context *ctx, const smilehip_func_spec *spec, const float *d_x, int64_t ld_x,
                              int64_t rows, int32_t cols, float *d_out, void *stream);
 /* The same over a batch's LLD matrix: for each utterance, columns [col_first, col_first + n_cols) of its rows
