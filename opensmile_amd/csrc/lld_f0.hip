@@ -654,6 +654,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   __shared__ double ccs[kJitMaxCand];
   __shared__ float avgWf[kJitMaxPeriod];
   __shared__ int pbuf[kJitMaxPeriods];
+  __shared__ float jit_terms[kJitThreads];   // one term per lane and wave for the sequential energy sums
   const int64_t s0 = P.samp_off[u];
   const int64_t n_samp = P.samp_off[u + 1] - s0;
   const int16_t *x = P.pcm + s0;
@@ -837,42 +838,49 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         avgWf[i] /= (float)numPeriods;
       }
       __syncthreads();
-      // harmonic / noise energy in the reference's summation order (:843-873), every lane the same chain
+      // harmonic / noise energy in the reference's summation order (:843-873). The terms of 64 consecutive samples are
+      // formed one per lane; the sum itself stays one sequential float chain (every lane the same one), fed through
+      // one LDS word per sample (instead of two loads, a conversion, a subtraction and a product per sample in the chain).
+      const int ln = tid & 63;
+      float *tw = jit_terms + (tid & ~63);                        // this wave's 64 terms (LDS ops of one wave stay in order)
+      auto chain_add = [&](float acc, float term, int cnt) {      // acc += term[lane 0], term[lane 1], ... term[lane cnt-1]
+        tw[ln] = term;
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) {
+          float a[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) a[r] = tw[q + r];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc += a[r];
+        }
+        for (; q < cnt; ++q) acc += tw[q];
+        return acc;
+      };
       float Eh = 0.0f;
       {
         long hi = T0f - 2;                                  // i in [3, min(T0f-2, nT-start)): the reference's three conditions
         if (nT - start < hi) hi = nT - start;
-        long i = 3;
-        for (; i + 8 <= hi; i += 8) {
-          float aq[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) aq[q] = avgWf[i + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) Eh += aq[q] * aq[q];
+        for (long i = 3; i < hi; i += 64) {
+          const int cnt = (int)((hi - i < 64) ? (hi - i) : 64);
+          float t = 0.0f;
+          if (ln < cnt) { const float a = avgWf[i + ln]; t = a * a; }
+          Eh = chain_add(Eh, t, cnt);
         }
-        for (; i < hi; i++) Eh += avgWf[i] * avgWf[i];
       }
       if (T0f - 4 > 0) Eh /= (float)(T0f - 4);
       Eh = sqrtf(Eh);
       float En = 0.0f;
       long nEn = 0;
       for (int i = 0; i < numPeriods; i++) {
-        long k = 2;
         const long p0 = pbuf[i], p1 = pbuf[i + 1];
         const long lim = (p1 < p0 + T0f ? p1 : p0 + T0f) - 2;
-        long j = p0 + 2;
-        for (; j + 8 <= lim; j += 8, k += 8) {
-          float wq[8], aq[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { wq[q] = (float)wv[j + q]; aq[q] = avgWf[k + q]; }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { const float delta = wq[q] - aq[q]; En += delta * delta; }
-          nEn += 8;
-        }
-        for (; j < lim; j++) {
-          const float delta = (float)wv[j] - avgWf[k++];
-          En += delta * delta;
-          nEn++;
+        long k = 2;
+        for (long j = p0 + 2; j < lim; j += 64, k += 64) {
+          const int cnt = (int)((lim - j < 64) ? (lim - j) : 64);
+          float t = 0.0f;
+          if (ln < cnt) { const float delta = (float)wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
+          En = chain_add(En, t, cnt);
+          nEn += cnt;
         }
       }
       if (nEn > 0) En /= (float)nEn;
