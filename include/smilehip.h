@@ -139,7 +139,9 @@ typedef struct smilehip_lld_config {
   int32_t  cms;                         /* [cms:cFullinputMean] (src/dspcore/fullinputMean.cpp, multiLoopMode = 0, meanNorm = amean):
                                            the utterance's mean is subtracted from the static cepstra (not from the energy
                                            column; the deltas come from the un-normalised level) */
-  int32_t  reserved0;
+  int32_t  jitter_broken_thresh;        /* [is13_pitchJitter] useBrokenJitterThresh (src/lld/pitchJitter.cpp:801-809): the period
+                                           is accepted if its peak correlation exceeds the frame's running minimum (float)
+                                           instead of minCC = 0.5 -- IS13_ComParE.conf; 0 in ComParE_2016.conf */
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
@@ -199,6 +201,9 @@ int smilehip_config_htk_variant(smilehip_lld_config *c, const char *name);
 void smilehip_config_compare16_f0(smilehip_lld_config *c);
 /* fills c with the whole LLD level of config/compare16/ComParE_2016.conf (chain_kind = COMPARE, 130 columns) */
 void smilehip_config_compare16(smilehip_lld_config *c);
+/* ... of config/is09-13/IS13_ComParE.conf: the same graph with zeroPadSymmetric = 0 in both cTransformFFT instances and
+ * useBrokenJitterThresh = 1 (IS13_ComParE_core.lld.conf.inc vs ComParE_2016_core.lld.conf.inc) */
+void smilehip_config_is13_compare(smilehip_lld_config *c);
 
 /* F0 group, per component, on an F0 chain plan (smilehip_config_compare16_f0; the plan's spectrum geometry -- n_bins and
  * the level's frameSizeSec, force_fft_frame_size_sec -- must be the input level's):
@@ -319,6 +324,10 @@ int smilehip_funcspec_count(const smilehip_func_spec *spec);
 /* The six cFunctionals instances of config/compare16/ComParE_2016_core.func.conf.inc: "A", "B", "F0", "Nz", "LLD",
  * "Delta" ([is13_functionalsA] ... [is13_functionalsDelta]); period = 0.01 s. */
 int smilehip_funcspec_compare16(const char *instance, smilehip_func_spec *spec);
+/* The same six instances as config/is09-13/IS13_ComParE_core.func.conf.inc configures them: no soft limiting of ratio
+ * features (Moments / Regression / Peaks2 doRatioLimit = 0, centroidRatioLimit = 0), centroid of the signed values,
+ * normInputs = 0, normRegCoeff = 0. */
+int smilehip_funcspec_is13_compare(const char *instance, smilehip_func_spec *spec);
 /* cFunctionals::doProcess for every column of ONE matrix (rows x cols, leading dimension ld_x, all rows): d_out
  * receives cols * count(spec) floats, element-major (column c's values at [c*count, (c+1)*count)). Scratch is owned
  * by the context and grown on demand (growing synchronises the device once). Asynchronous on `stream`; calls that use
@@ -345,6 +354,10 @@ int smilehip_batch_funcspec(smilehip_plan *plan, smilehip_batch *batch, const sm
 int smilehip_functionals_compare16_count(void);
 int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehip_batch *batch, const float *d_lld, int64_t ld_lld,
                                          float *d_func, int64_t ld_func, void *stream);
+/* The functionals level of config/is09-13/IS13_ComParE.conf (same 6373 elements and names, the instances' options of
+ * smilehip_funcspec_is13_compare) on a smilehip_config_is13_compare plan. */
+int smilehip_batch_functionals_is13_compare(smilehip_plan *plan, smilehip_batch *batch, const float *d_lld, int64_t ld_lld,
+                                            float *d_func, int64_t ld_func, void *stream);
 /* Row T60+1 of group B's sma / delta levels, [n_utt x 110] device floats filled by the last smilehip_lld_run of a
  * ComParE chain batch (tests / callers that run single instances through smilehip_batch_funcspec). */
 int smilehip_batch_compare_b_extra(smilehip_batch *batch, const float **d_extra);

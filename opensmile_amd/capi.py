@@ -41,7 +41,7 @@ class LldConfig(C.Structure):
         ("force_frame_size", C.c_int64), ("force_fft_frame_size_sec", C.c_double),
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
-        ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("reserved0", C.c_int32),
+        ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
     ]
 
 
@@ -108,6 +108,9 @@ SYMBOLS = {
     "smilehip_batch_compare_b_extra": (C.c_int, [_vp, _vp]),
     "smilehip_funcspec_count": (C.c_int, [_vp]),
     "smilehip_funcspec_compare16": (C.c_int, [C.c_char_p, _vp]),
+    "smilehip_funcspec_is13_compare": (C.c_int, [C.c_char_p, _vp]),
+    "smilehip_batch_functionals_is13_compare": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "smilehip_config_is13_compare": (None, [_vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -209,6 +212,18 @@ def compare16_config():
     c = LldConfig()
     load().smilehip_config_compare16(C.byref(c))
     return c
+
+
+def is13_compare_config():
+    c = LldConfig()
+    load().smilehip_config_is13_compare(C.byref(c))
+    return c
+
+
+def funcspec_is13_compare(instance):
+    s = FuncSpec()
+    _check(load().smilehip_funcspec_is13_compare(instance.encode(), C.byref(s)))
+    return s
 
 
 def compare16_f0_config():
@@ -466,7 +481,8 @@ class Batch:
             if pcm.nbytes:
                 _check(L.smilehip_copy_to_device(ctx, d_pcm, pcm.ctypes.data, pcm.nbytes, None))
             _check(L.smilehip_lld_run(self.plan._h, self._h, d_pcm, d_lld, n_out, None))
-            _check(L.smilehip_batch_functionals_compare16(self.plan._h, self._h, d_lld, n_out, d_func, nf, None))
+            fn = L.smilehip_batch_functionals_is13_compare if self.plan.cfg.jitter_broken_thresh else L.smilehip_batch_functionals_compare16
+            _check(fn(self.plan._h, self._h, d_lld, n_out, d_func, nf, None))
             _check(L.smilehip_stream_synchronize(ctx, None))
             if lld.nbytes:
                 _check(L.smilehip_copy_to_host(ctx, lld.ctypes.data, d_lld, lld.nbytes, None))

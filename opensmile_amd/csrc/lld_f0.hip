@@ -710,6 +710,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       PHASE(5);   // frame set-up + wave load
       int numPeriods = 0;
       long pp = 0;
+      float minCC = -2.0f;
       const int nc = (int)(T0maxF - T0minF) + 1;
       while (start < nT - 2 * T0maxF - 1) {
         for (int c = tid; c < nc; c += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
@@ -809,7 +810,11 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           double ccI = 0.0;
           const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
                                                                  (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
-          if (ccI > (float)0.5) {
+          // :793-809: the accepted-period threshold is minCC = 0.5, or -- useBrokenJitterThresh -- the frame's running
+          // minimum of the peak correlations (which includes this period's own, rounded to float)
+          if (minCC == -2.0f || minCC > (float)ccI) minCC = (float)ccI;
+          const float thresh = Q.jit_broken_thresh ? minCC : (float)0.5;
+          if (ccI > thresh) {
             const float period = (float)maxId;
             avgPeriod += period;
             nPeriods += 1.0f;

@@ -128,6 +128,7 @@ struct F0Params {
   float voicing_cutoff;
   float min_energy;
   double jit_Tw;                    // cPitchJitter: sample period of the wave level, 1.0 / sampleRate
+  int32_t jit_broken_thresh;        // useBrokenJitterThresh (pitchJitter.cpp:801-809)
   double jit_step_sec;              // period of the F0 level (frameStep)
   double vit_w[6];                  // cPitchSmootherViterbi: wLocal, wTvv, wTvvd, wTvuv, wThr, wRange (wTuu is never used)
   // per-frame results between the kernels

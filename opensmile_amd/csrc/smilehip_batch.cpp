@@ -445,6 +445,7 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.voicing_cutoff = (float)plan->cfg.voicing_cutoff;
   Q.min_energy = plan->cfg.f0_min_energy;
   Q.jit_Tw = plan->geo.period;                 // 1.0 / (double)sampleRate, waveSource.cpp:190
+  Q.jit_broken_thresh = plan->cfg.jitter_broken_thresh;
   Q.jit_step_sec = plan->cfg.frame_step_sec;
   Q.ld_tap = plan->geo.K;
   Q.ld_shs = 21;

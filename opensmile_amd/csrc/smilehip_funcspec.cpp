@@ -239,6 +239,17 @@ extern "C" int smilehip_funcspec_compare16(const char *instance, smilehip_func_s
   return SMILEHIP_OK;
 }
 
+// config/is09-13/IS13_ComParE_core.func.conf.inc differs from ComParE_2016_core.func.conf.inc in these options only
+extern "C" int smilehip_funcspec_is13_compare(const char *instance, smilehip_func_spec *s) {
+  int rc = smilehip_funcspec_compare16(instance, s);
+  if (rc) return rc;
+  s->mom_ratio_limit = 0;
+  s->reg_centroid_abs = s->reg_centroid_limit = s->reg_ratio_limit = s->reg_norm_inputs = 0;
+  s->reg_norm_coeff = 0;
+  s->pk_ratio_limit = 0;
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_funcspec_matrix(smilehip_context *ctx, const smilehip_func_spec *spec, const float *d_x, int64_t ld_x,
                                         int64_t rows, int32_t cols, float *d_out, void *stream) {
   if (!ctx || !spec || rows < 1 || cols < 1 || ld_x < cols || !d_x || !d_out)
@@ -317,8 +328,21 @@ extern "C" int smilehip_batch_compare_b_extra(smilehip_batch *b, const float **d
   return SMILEHIP_OK;
 }
 
+static int functionals_compare_level(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld, float *d_func,
+                                     int64_t ld_func, void *stream, bool is13);
+
 extern "C" int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld,
                                                     float *d_func, int64_t ld_func, void *stream) {
+  return functionals_compare_level(plan, b, d_lld, ld_lld, d_func, ld_func, stream, false);
+}
+
+extern "C" int smilehip_batch_functionals_is13_compare(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld,
+                                                       float *d_func, int64_t ld_func, void *stream) {
+  return functionals_compare_level(plan, b, d_lld, ld_lld, d_func, ld_func, stream, true);
+}
+
+static int functionals_compare_level(smilehip_plan *plan, smilehip_batch *b, const float *d_lld, int64_t ld_lld, float *d_func,
+                                     int64_t ld_func, void *stream, bool is13) {
   if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_compare16: plan/batch mismatch");
   if (plan->cfg.chain_kind != SMILEHIP_CHAIN_COMPARE)
     return fail(SMILEHIP_ERR_INVALID, "the ComParE_2016 functionals are defined for the whole-level chain (smilehip_config_compare16)");
@@ -341,7 +365,7 @@ extern "C" int smilehip_batch_functionals_compare16(smilehip_plan *plan, smilehi
     const Part &part = kCompare16Parts[i];
     FsParams &P = Ps[i];
     std::memset(&P, 0, sizeof(P));
-    int rc = smilehip_funcspec_compare16(part.inst, &P.spec);
+    int rc = is13 ? smilehip_funcspec_is13_compare(part.inst, &P.spec) : smilehip_funcspec_compare16(part.inst, &P.spec);
     if (rc) return rc;
     const int per = spec_layout(&P.spec, nullptr, nullptr);
     if (per < 0) return per;

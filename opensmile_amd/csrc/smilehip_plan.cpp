@@ -106,6 +106,14 @@ extern "C" void smilehip_config_compare16(smilehip_lld_config *c) {
   c->chain_kind = SMILEHIP_CHAIN_COMPARE;
 }
 
+// config/is09-13/IS13_ComParE_core.lld.conf.inc = ComParE_2016_core.lld.conf.inc except [is13_fft25] / [is13_fft60]
+// zeroPadSymmetric = 0 and [is13_pitchJitter] useBrokenJitterThresh = 1
+extern "C" void smilehip_config_is13_compare(smilehip_lld_config *c) {
+  smilehip_config_compare16(c);
+  c->zero_pad_symmetric = 0;
+  c->jitter_broken_thresh = 1;
+}
+
 static inline bool is_compare_ab_like(const smilehip_lld_config &c) {
   return c.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || c.chain_kind == SMILEHIP_CHAIN_COMPARE;
 }
@@ -329,6 +337,8 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
     smilehip_config_compare16_f0(&c60);
     c60.sample_rate = cfg->sample_rate;
     c60.frame_step_sec = cfg->frame_step_sec;
+    c60.zero_pad_symmetric = cfg->zero_pad_symmetric;     // both cTransformFFT instances carry the set's value
+    c60.jitter_broken_thresh = cfg->jitter_broken_thresh;
     rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
     if (rc == SMILEHIP_OK && (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess ||
                               hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||

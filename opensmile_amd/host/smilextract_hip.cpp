@@ -11,6 +11,7 @@
 //   smilextract_hip --set compare16_lld (-I in.wav | -filelist list.txt) [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //                   (the 130-column LLD level of ComParE_2016 only)
 //   smilextract_hip --set compare16     same options as is09_emotion: the whole ComParE_2016.conf, LLD level + 6373 functionals
+//   smilextract_hip --set is13_compare  the same for config/is09-13/IS13_ComParE.conf
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
 //
@@ -68,7 +69,8 @@ int main(int argc, char **argv) {
   }
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
-  const bool cmp16f = set == "compare16";                      // the whole ComParE_2016.conf: LLD level + 6373 functionals
+  const bool is13 = set == "is13_compare";                     // config/is09-13/IS13_ComParE.conf: same elements, IS13 options
+  const bool cmp16f = set == "compare16" || is13;              // the whole ComParE_2016.conf: LLD level + 6373 functionals
   const bool cmp16 = set == "compare16_lld" || cmp16f;
   const bool has_func = is09 || cmp16f;
   // the eight files of config/mfcc and config/plp, by their names in lower case
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
   const bool htk_variant = !is09 && !cmp16 && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
   if (!is09 && !cmp16 && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16 or compare16_lld");
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld or is13_compare");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
@@ -148,6 +150,7 @@ int main(int argc, char **argv) {
       if (!plan) {
         smilehip_lld_config cfg;
         if (is09) smilehip_config_is09_lld(&cfg);
+        else if (is13) smilehip_config_is13_compare(&cfg);
         else if (cmp16) smilehip_config_compare16(&cfg);
         else cfg = vcfg;
         cfg.sample_rate = (double)kv.first;
@@ -185,7 +188,8 @@ int main(int argc, char **argv) {
           check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
                 "smilehip_batch_functionals");
         else
-          check(smilehip_batch_functionals_compare16(plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, nullptr),
+          check((is13 ? smilehip_batch_functionals_is13_compare : smilehip_batch_functionals_compare16)(
+                    plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, nullptr),
                 "smilehip_batch_functionals_compare16");
         func.resize(idx.size() * (size_t)n_func);
         check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, nullptr), "copy_to_host");

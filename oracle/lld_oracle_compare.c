@@ -312,6 +312,11 @@ static float vec_ll1(const float *src, int N)
 /* Row T60+1 of group B's own levels (55 sma values, then 55 deltas): [is13_functionalsB] reads lldB_smo;lldB_smo_de,
  * which hold more rows than the T60+1 the LLD sinks keep, and summarises T20-2 = T60+2 of them. Set a destination
  * before calling lldo_compare_ab_chain (NULL switches it off). */
+/* config/is09-13/IS13_ComParE.conf instead of compare16/ComParE_2016.conf: the same graph with zeroPadSymmetric = 0 in
+ * both cTransformFFT instances and useBrokenJitterThresh = 1 in cPitchJitter */
+int g_lldo_is13 = 0;
+void lldo_compare_set_is13(int on) { g_lldo_is13 = on ? 1 : 0; }
+
 static float *g_b_extra = NULL;
 void lldo_compare_set_b_extra(float *dst110) { g_b_extra = dst110; }
 
@@ -319,7 +324,7 @@ long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float
 {
   lldo_mfcc_cfg c;
   lldo_default_mfcc12_cfg(&c);
-  c.frame_size_sec = 0.020; c.preemph_enable = 0; c.zero_pad_symmetric = 1;
+  c.frame_size_sec = 0.020; c.preemph_enable = 0; c.zero_pad_symmetric = g_lldo_is13 ? 0 : 1;
   c.lofreq = 20.0f; c.first_mfcc = 1; c.last_mfcc = 14; c.n_delta = 0;
   lldo_geom g;
   lldo_geometry(&c, &g);
@@ -355,7 +360,7 @@ long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float
     const float *src = x + t * g.H;
     float *ra = la + t * DA, *rb = lb + t * DB;
     lldo_window_apply(src, fr, g.N, w, 0.0);
-    lldo_rfft_frame(fr, g.N, sp, g.Nfft, 1);
+    lldo_rfft_frame(fr, g.N, sp, g.Nfft, c.zero_pad_symmetric);
     lldo_fftmag(sp, g.Nfft, mg);
     lldo_melspec(&mel1, mg, mb);
     lldo_plp_audspec(&plp, mb, aud);

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "lld_oracle.h"
+extern int g_lldo_is13;     /* lld_oracle_compare.c: IS13_ComParE.conf instead of ComParE_2016.conf */
 
 /* ------------------------------------------------------------------ cSpecScale */
 /* smileDsp_specScaleTransfFwd, SPECTSCALE_LOG branch (smileUtil.c:1100-1105) */
@@ -437,7 +438,7 @@ long lldo_compare_f0_chain(const int16_t *pcm, long n_samples, float *out, float
 {
   lldo_mfcc_cfg c;
   lldo_default_mfcc12_cfg(&c);
-  c.frame_size_sec = 0.060; c.preemph_enable = 0; c.zero_pad_symmetric = 1;
+  c.frame_size_sec = 0.060; c.preemph_enable = 0; c.zero_pad_symmetric = g_lldo_is13 ? 0 : 1;
   lldo_geom g;
   lldo_geometry(&c, &g);
   const long T = lldo_num_frames(n_samples, g.N, g.H);
@@ -460,7 +461,7 @@ long lldo_compare_f0_chain(const int16_t *pcm, long n_samples, float *out, float
   for (long t = 0; t < T; t++) {
     lldo_window_apply(x + t * g.H, fr, g.N, w, 0.0);
     e60[t] = lldo_energy_rms(fr, g.N);                            /* [is13_energy60] on is13_winG60 */
-    lldo_rfft_frame(fr, g.N, sp, g.Nfft, 1);
+    lldo_rfft_frame(fr, g.N, sp, g.Nfft, c.zero_pad_symmetric);
     lldo_fftmag(sp, g.Nfft, mg);
     lldo_specscale_frame(&ss, mg, hp);
     if (tap_hps) memcpy(tap_hps + t * g.K, hp, sizeof(float) * (size_t)g.K);
@@ -526,7 +527,7 @@ void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long 
   const double Tw = 1.0 / sample_rate;                              /* waveSource.cpp:190 */
   const double searchRangeRel = 0.25;
   const int minNumPeriods = 2;
-  const float threshCC = (float)0.5;
+  float threshCC = (float)0.5;
   const float lgHNRfloor = (float)-100.0;
   long lastIdx = 0, lastMis = 0;
   float lastT0 = 0.0f, lastDiff = 0.0f, lastJitterLocal = 0.0f, lastJitterDDP = 0.0f, lastShimmerLocal = 0.0f;
@@ -569,6 +570,7 @@ void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long 
     long start = 0, lastPeriod = 0;
     if (F0 > 0.0) {
       int numPeriods = 0;
+      float minCC = (float)-2.0;                                    /* :696, per frame */
       long *periodBuffer = (long *)calloc(1, sizeof(long) * (size_t)((T0f > 0 ? maxRead / T0minF + 3 : maxRead + 2) + 2));
       float *avgWf = (float *)calloc(1, sizeof(float) * (size_t)(T0f + 1));
       double *cc = (double *)calloc(1, sizeof(double) * (size_t)((int)(T0maxF - T0minF) + 1));
@@ -594,6 +596,8 @@ void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long 
           double ccI = 0.0;
           const double maxId = fabs(((double)T0minF + quad_vertex_y((double)(maxI - 1), cc[maxI - 1], (double)maxI, cc[maxI],
                                                                     (double)(maxI + 1), cc[maxI + 1], &ccI))) * Tw;
+          if (minCC == (float)-2.0 || minCC > (float)ccI) minCC = (float)ccI;          /* :793-796 */
+          if (g_lldo_is13) threshCC = minCC;                            /* useBrokenJitterThresh, :801-807 */
           if (ccI > threshCC) {
             const float period = (float)maxId;
             avgPeriod += period;

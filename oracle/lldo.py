@@ -309,6 +309,25 @@ def functionals(x, mask=FUNC_IS09):
     return out
 
 
+def compare_set_is13(on):
+    """Switch the ComParE chain restatements (compare_ab_chain, compare_f0_chain, pitch_jitter, compare_lld_chain) to
+    config/is09-13/IS13_ComParE.conf (zeroPadSymmetric = 0, useBrokenJitterThresh = 1); off = ComParE_2016.conf."""
+    L = lib()
+    L.lldo_compare_set_is13.restype = None
+    L.lldo_compare_set_is13.argtypes = [C.c_int]
+    L.lldo_compare_set_is13(1 if on else 0)
+
+
+def is13_func_spec(inst):
+    """The six cFunctionals instances of config/is09-13/IS13_ComParE_core.func.conf.inc."""
+    s = compare16_func_spec(inst)
+    s.mom_ratio_limit = 0
+    s.reg_centroid_abs = s.reg_centroid_limit = s.reg_ratio_limit = s.reg_norm_inputs = 0
+    s.reg_norm_coeff = 0
+    s.pk_ratio_limit = 0
+    return s
+
+
 def compare_b_extra(pcm):
     """Row T60+1 of ComParE's group-B levels: (110,) = 55 sma values + 55 deltas (what [is13_functionalsB] sees beyond
     the rows of the LLD sinks); None if the utterance yields no rows."""
@@ -382,14 +401,20 @@ FUNC_TAPS_CONF = os.path.join(HERE, "conf", "compare_func_taps.conf")
 FUNC_TAPS = ("a_smo", "a_de", "b_smo", "b_de", "nz_smo", "nz_de", "f0_smo")
 
 
-def run_reference_func_taps(pcm, fs=16000):
+def run_reference_func_taps(pcm, fs=16000, is13=False):
     """Real SMILExtract on ComParE_2016 (oracle/conf/compare_func_taps.conf): {"func": (6373,) or empty, "names": list,
     "lld": LLD level, tap name: the level a cFunctionals instance reads, all its rows}."""
     exe = os.path.join(REF_DIR, "SMILExtract")
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         wav = os.path.join(td, "in.wav")
         write_wav(wav, pcm, fs)
-        subprocess.run([exe, "-C", FUNC_TAPS_CONF, "-I", wav, "-htkoutput", "func.htk", "-csvoutput", "func.csv",
+        conf = FUNC_TAPS_CONF
+        if is13:                                  # the same taps on IS13_ComParE.conf (identical level names)
+            conf = os.path.join(td, "taps_is13.conf")
+            with open(conf, "w") as f:
+                f.write(open(FUNC_TAPS_CONF).read().replace("../_ref/config/compare16/ComParE_2016.conf",
+                                                            os.path.join(REF_DIR, "config", "is09-13", "IS13_ComParE.conf")))
+        subprocess.run([exe, "-C", conf, "-I", wav, "-htkoutput", "func.htk", "-csvoutput", "func.csv",
                         "-lldhtkoutput", "lld.htk", "-l", "0"], check=True, cwd=td, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         out = {}

@@ -94,6 +94,23 @@ def gen_func16():
     np.savez_compressed(os.path.join(OUT, "compare16_func_synth.npz"), **ref)
 
 
+def gen_is13():
+    """config/is09-13/IS13_ComParE.conf on the real binary: the 130-column LLD level and the 6373 functionals (+ the rows
+    of the levels its functionals read, for the two short inputs)."""
+    ref = {}
+    for name, (u, n) in {"u3_48000": (3, 48000), "u4_9000": (4, 9000), "u7_1760": (7, 1760), "u10_16000": (10, 16000)}.items():
+        pcm = synth.utterance(u, n)
+        t = lldo.run_reference_func_taps(pcm, is13=True)
+        ref["pcm_" + name] = pcm
+        ref["lld130_" + name] = t["lld"]
+        ref["func_" + name] = t["func"]
+        if n <= 9000:
+            for k in lldo.FUNC_TAPS:
+                ref[k + "_" + name] = t[k]
+        print("is13", name, t["lld"].shape, t["func"].shape)
+    np.savez_compressed(os.path.join(OUT, "is13_compare_synth.npz"), **ref)
+
+
 def gen_egemaps_func():
     """eGeMAPSv02.conf on the real binary: the 88 functionals (summaries of LLDs this repo does not compute itself --
     used to check the plugin's cFunctionals override on the instances of the GeMAPS sets: Moments with stddevNorm,
@@ -130,6 +147,9 @@ def main(only=None):
         return
     if only == "plp":
         gen_plp()
+        return
+    if only == "is13":
+        gen_is13()
         return
     if only == "egemaps":
         gen_egemaps_func()
@@ -184,6 +204,7 @@ def main(only=None):
     gen_htk_variants()
     gen_func16()
     gen_egemaps_func()
+    gen_is13()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
     import wave

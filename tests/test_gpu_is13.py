@@ -1,0 +1,91 @@
+"""config/is09-13/IS13_ComParE.conf through the C ABI (smilehip_config_is13_compare + smilehip_batch_functionals_is13_compare):
+the LLD level against golden outputs of the real binary with the tolerances of the ComParE_2016 level, the functionals
+against the oracle's IS13 specs on the device's own LLD matrix (bit for bit) and statistically against the binary."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_compare_full import AB, F0, f0_lld_tolerances
+from test_gpu_func16 import PARTS
+from test_gpu_funcspec import LIBM, as_oracle_spec
+from test_oracle_pin_compare import compare_tolerances
+from test_oracle_pin_funcspec import func_rows, pending
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KEYS = ["u3_48000", "u4_9000", "u7_1760", "u10_16000"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    cfg = capi.is13_compare_config()
+    assert cfg.zero_pad_symmetric == 0 and cfg.jitter_broken_thresh == 1
+    return capi, ctx, capi.Plan(ctx, cfg)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "is13_compare_synth.npz"))
+
+
+def test_is13_lld_and_functionals(hip, oracle, golden):
+    capi, ctx, plan = hip
+    pcms = [golden["pcm_" + k] for k in KEYS]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, ex = b.run_host_with_functionals16(np.concatenate(pcms))
+    oracle.compare_set_is13(True)
+    try:
+        for u, key in enumerate(KEYS):
+            x = lld[b.frame_offsets[u]:b.frame_offsets[u + 1]]
+            ref = golden["lld130_" + key]
+            compare_tolerances(x[:, AB], ref[:, AB], "is13 " + key)
+            f0_lld_tolerances(x[:, F0], ref[:, F0], "is13 " + key)
+            T, P = pending(oracle, pcms[u])
+            pos = 0
+            for inst, c0, nc in PARTS:
+                ospec = oracle.is13_func_spec(inst)
+                spec = capi.funcspec_is13_compare(inst)
+                assert bytes(as_oracle_spec(oracle, spec))[:8] == bytes(ospec)[:8]
+                names = oracle.funcspec_names(ospec)
+                per = len(names)
+                n = func_rows(inst, T, P)
+                if inst == "B":
+                    xi = np.concatenate([x[:, c0:c0 + nc], ex[u:u + 1, (0 if c0 == 10 else 55):(55 if c0 == 10 else 110)]], axis=0)
+                else:
+                    xi = x[:n, c0:c0 + nc]
+                r = oracle.funcspec(np.ascontiguousarray(xi), as_oracle_spec(oracle, spec))
+                d = func[u, pos:pos + per * nc].reshape(nc, per)
+                pos += per * nc
+                for k, nm in enumerate(names):
+                    if nm in LIBM:
+                        err = np.abs(d[:, k].astype(np.float64) - r[:, k]) / np.maximum(np.abs(r[:, k]), 1e-6)
+                        assert err.max() <= 1e-6, (key, inst, nm)
+                    else:
+                        assert np.array_equal(d[:, k].view(np.uint32), r[:, k].view(np.uint32)), (key, inst, c0, nm)
+            assert pos == 6373
+            gref = golden["func_" + key].astype(np.float64)
+            err = np.abs(func[u] - gref) / np.maximum(np.abs(gref), 1e-2)
+            assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5, key
+    finally:
+        oracle.compare_set_is13(False)
+    b.close()
+
+
+def test_is13_broken_jitter_threshold_differs_from_2016(hip, golden):
+    """Same input through the ComParE_2016 plan: the jitter / shimmer columns differ (the threshold rule), the rest of
+    the F0 group does not depend on it."""
+    capi, ctx, plan = hip
+    pcm = golden["pcm_u3_48000"]
+    off = np.array([0, len(pcm)], np.int64)
+    b13 = capi.Batch(plan, off)
+    x13 = b13.run_host(pcm)
+    plan16 = capi.Plan(ctx, capi.compare16_config())
+    b16 = capi.Batch(plan16, off)
+    x16 = b16.run_host(pcm)
+    assert x13.shape == x16.shape
+    assert not np.array_equal(x13[:, 2:5], x16[:, 2:5])
+    b13.close(); b16.close()

@@ -207,6 +207,22 @@ def test_plugin_compare16_functionals_all_families(oracle):
         assert err.max() <= 1e-6, (k, names[int(err.argmax())], float(err.max()))
 
 
+def test_plugin_is13_compare_functionals(oracle):
+    """config/is09-13/IS13_ComParE.conf with only cFunctionals behind the plugin: the option translation picks up the
+    IS13 values (no ratio limiting, signed centroid, normInputs = 0, normRegCoeff = 0) and reproduces the binary."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "is13_compare_synth.npz"))
+    names = [str(n) for n in np.load(os.path.join(ROOT, "tests", "golden", "compare16_func_synth.npz"))["names"]]
+    soft = np.array([n.endswith(("_flatness",)) for n in names])
+    for k in ("u4_9000", "u10_16000"):
+        ref = g["func_" + k][None, :]
+        y, tr = _run(oracle, g["pcm_" + k], {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, "is09-13/IS13_ComParE.conf", "-htkoutput")
+        assert y.shape == ref.shape == (1, 6373) and tr["cFunctionals"] == 249
+        same = y.view(np.uint32) == ref.view(np.uint32)
+        assert same[0, ~soft].all(), (k, [names[i] for i in np.flatnonzero(~same[0] & ~soft)[:6]])
+        err = np.abs(y.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-6)
+        assert err.max() <= 1e-6
+
+
 def test_plugin_egemaps_functionals(oracle):
     """eGeMAPSv02.conf, unmodified, with only cFunctionals behind the plugin: the functionals instances of the GeMAPS sets
     (Moments with stddevNorm = 2, 20/50/80 percentiles + range, Peaks2 slopes and numPeaks per second, Segments nonX and

@@ -5,6 +5,7 @@ with the reference's own numbers must reproduce its files byte for byte. GPU par
 smilextract_hip front end end to end (headers/structure identical, values within tolerance)."""
 import ctypes as C
 import os
+import sys
 import struct
 import subprocess
 
@@ -225,6 +226,25 @@ def test_smilextract_hip_compare16_functionals(tmp_path):
     hr, xr = read_htk(os.path.join(G, "compare16_func_u3.htk"))
     assert h == hr and x.shape == xr.shape == (1, 6373)
     err = np.abs(x[0].astype(np.float64) - xr[0]) / np.maximum(np.abs(xr[0]), 1e-2)
+    assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_is13_compare(tmp_path):
+    """--set is13_compare: IS13_ComParE.conf's LLD level and functionals (golden: the real binary on the same file)."""
+    import tempfile
+    g = np.load(os.path.join(ROOT, "tests", "golden", "is13_compare_synth.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import lldo
+    wav = str(tmp_path / "u4.wav")
+    lldo.write_wav(wav, g["pcm_u4_9000"], 16000)
+    out_htk, out_lld = str(tmp_path / "f.htk"), str(tmp_path / "l.htk")
+    subprocess.run([EXE, "--set", "is13_compare", "-I", wav, "-htkoutput", out_htk, "-lldhtkoutput", out_lld], check=True)
+    _, x = read_htk(out_htk)
+    _, l = read_htk(out_lld)
+    assert x.shape == (1, 6373) and l.shape == g["lld130_u4_9000"].shape
+    ref = g["func_u4_9000"].astype(np.float64)
+    err = np.abs(x[0] - ref) / np.maximum(np.abs(ref), 1e-2)
     assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
 
 
