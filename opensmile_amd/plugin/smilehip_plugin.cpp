@@ -1134,11 +1134,12 @@ class cHipLldSource : public cDataSource {
   int n_cols_ = 0;
   double period_sec_ = 0.01, frame_size_sec_ = 0.025;
   bool ran_ = false;
-  bool func16_ = false;                                  // featureSet compare16_func: ONE vector, ComParE_2016's functionals level
+  bool func16_ = false;                                  // featureSet compare16_func / is13_compare_func: ONE vector, the functionals level
+  bool is13_ = false;                                    //   ... of ComParE_2016.conf / of IS13_ComParE.conf
   cMatrix *block_ = nullptr;
 
   void config_for(smilehip_lld_config &c) {              // any of the eight files of config/mfcc and config/plp, by name
-    if (func16_) { smilehip_config_compare16(&c); return; }
+    if (func16_) { if (is13_) smilehip_config_is13_compare(&c); else smilehip_config_compare16(&c); return; }
     std::string up;
     for (char ch : set_) up += (char)toupper((unsigned char)ch);
     if (smilehip_config_htk_variant(&c, up.c_str()) != SMILEHIP_OK)
@@ -1172,7 +1173,8 @@ class cHipLldSource : public cDataSource {
         check(smilehip_alloc(context(), (uint64_t)n_cols_ * 4, &d_func));
         check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
         check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, 130, nullptr));
-        check(smilehip_batch_functionals_compare16(pl, b, (const float *)d_lld, 130, (float *)d_func, n_cols_, nullptr));
+        check((is13_ ? smilehip_batch_functionals_is13_compare : smilehip_batch_functionals_compare16)(
+            pl, b, (const float *)d_lld, 130, (float *)d_func, n_cols_, nullptr));
         check(smilehip_copy_to_host(context(), rows_.data(), d_func, (uint64_t)n_cols_ * 4, nullptr));
         check(smilehip_stream_synchronize(context(), nullptr));
         smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld); smilehip_free(context(), d_func);
@@ -1190,7 +1192,8 @@ class cHipLldSource : public cDataSource {
     cDataSource::myFetchConfig();
     filename_ = getStr("filename") ? getStr("filename") : "";
     set_ = getStr("featureSet") ? getStr("featureSet") : "mfcc12_0_d_a";
-    func16_ = !strcasecmp(set_.c_str(), "compare16_func");
+    is13_ = !strcasecmp(set_.c_str(), "is13_compare_func");
+    func16_ = is13_ || !strcasecmp(set_.c_str(), "compare16_func");
     smilehip_lld_config c;
     config_for(c);
     period_sec_ = c.frame_step_sec;
@@ -1267,7 +1270,7 @@ SMILECOMPONENT_REGCOMP(cHipLldSource) {
   SMILECOMPONENT_INHERIT_CONFIGTYPE("cDataSource")
   SMILECOMPONENT_IFNOTREGAGAIN(
     ct->setField("filename", "The RIFF/WAVE file to process (16-bit mono PCM)", "input.wav");
-    ct->setField("featureSet", "The feature set whose rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z (LLD rows); compare16_func: the functionals level of compare16/ComParE_2016.conf, one vector of 6373 values per input", "mfcc12_0_d_a");
+    ct->setField("featureSet", "The feature set whose rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z (LLD rows); compare16_func / is13_compare_func: the functionals level of compare16/ComParE_2016.conf / is09-13/IS13_ComParE.conf, one vector of 6373 values per input", "mfcc12_0_d_a");
   )
   SMILECOMPONENT_MAKEINFO(cHipLldSource);
 }

@@ -319,6 +319,16 @@ def test_plugin_fused_source_compare16_functionals(oracle):
         assert head[:2] == ["name", "frameTime"] and len(head) == 6375
         row = open(csv).read().split("\n")[1].split(";")
         assert row[0] == "'u3'" and float(row[1]) == 0.0
+        # the IS13 variant of the set through the same component
+        htk13 = os.path.join(td, "f13.htk")
+        r = subprocess.run([exe, "-C", os.path.join(PLUGDIR, "conf", "ComParE_2016_func_hip.conf"), "-I", os.path.join(G, "u3_4000.wav"),
+                            "-htkoutput", htk13, "-featureSet", "is13_compare_func", "-l", "1"],
+                           cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and os.path.exists(htk13), r.stderr[-2000:]
+        x13 = oracle.read_htk(htk13)[0]
+        assert x13.shape == (1, 6373)
+        assert not np.array_equal(x13, x), "featureSet = is13_compare_func gave the ComParE_2016 vector"
+        assert np.isfinite(x13).mean() > 0.999
 
 
 def test_plugin_mfcc_e_z_config_all_overrides(oracle):
