@@ -277,9 +277,8 @@ void lldo_pitch_shs(const lldo_shs *h, const float *in, float *dst, float *ss_ou
  * (:451-570) drives them: one addFrame per input frame, every decided frame is read at once, flush at end of input.
  * Weights as ComParE sets them AFTER setWeights' own assignment wTvvd = tvv (.hpp:291-299). Frames of 2*NC+4 floats:
  * [f0, voicing] x NC, then data[F0rawI=0] (= nCandidates), 0, 0, vIdx (:471-486 with the unset field indices). */
-#define VIT_BUF 30
 typedef struct {
-  int nS, fsz;
+  int nS, fsz, L;          /* L = bufferLength */
   float thresh;
   double wLocal, wTvv, wTvvd, wTvuv, wThr, wRange;
   double lastChange;
@@ -332,14 +331,14 @@ static double trans_cost(viterbi_t *v, int i, int j, const float *prev, const fl
 static void vit_add(viterbi_t *v, const float *frame)
 {
   const int nS = v->nS;
-  float *b = v->buf + (v->wr % VIT_BUF) * v->fsz;
+  float *b = v->buf + (v->wr % v->L) * v->fsz;
   memcpy(b, frame, sizeof(float) * (size_t)v->fsz);
   v->wr++;
   const float *a = v->prev;
   v->prev = b;
   if (v->pathIdx == 0 || a == NULL) {
     v->pathIdx = 0; v->convIdx = -1;
-    for (int i = 0; i < nS; i++) { v->cost[i] = local_cost(v, i, b); v->paths[v->pathBuf][i * VIT_BUF] = i; }
+    for (int i = 0; i < nS; i++) { v->cost[i] = local_cost(v, i, b); v->paths[v->pathBuf][i * v->L] = i; }
   } else {
     const int nb = (v->pathBuf + 1) % 2;
     for (int i = 0; i < nS; i++) {
@@ -350,27 +349,27 @@ static void vit_add(viterbi_t *v, const float *frame)
         if (c < mc) { ms = j; mc = c; }
       }
       v->costNew[i] = mc + local_cost(v, i, b);
-      memcpy(v->paths[nb] + i * VIT_BUF, v->paths[v->pathBuf] + ms * VIT_BUF, VIT_BUF * sizeof(int));
-      v->paths[nb][i * VIT_BUF + v->pathIdx % VIT_BUF] = i;
+      memcpy(v->paths[nb] + i * v->L, v->paths[v->pathBuf] + ms * v->L, v->L * sizeof(int));
+      v->paths[nb][i * v->L + v->pathIdx % v->L] = i;
     }
     double *t = v->cost; v->cost = v->costNew; v->costNew = t;
     v->pathBuf = nb;
   }
   v->pathIdx++;
   const int *P = v->paths[v->pathBuf];
-  if (v->pathIdx - v->convIdx > VIT_BUF) {                        /* forced decision for the oldest open frame */
+  if (v->pathIdx - v->convIdx > v->L) {                        /* forced decision for the oldest open frame */
     int ms = 0;
     for (int i = 1; i < nS; i++) if (v->cost[i] < v->cost[ms]) ms = i;
     v->convIdx++;
-    v->best[v->convIdx % VIT_BUF] = P[ms * VIT_BUF + v->convIdx % VIT_BUF];
+    v->best[v->convIdx % v->L] = P[ms * v->L + v->convIdx % v->L];
   } else {                                                        /* decide up to where all paths agree */
     for (long n = v->convIdx + 1; n < v->pathIdx; n++) {
-      const int x = P[n % VIT_BUF];
+      const int x = P[n % v->L];
       int match = 1;
-      for (int i = 1; i < nS; i++) if (x != P[i * VIT_BUF + n % VIT_BUF]) { match = 0; break; }
+      for (int i = 1; i < nS; i++) if (x != P[i * v->L + n % v->L]) { match = 0; break; }
       if (!match) break;
       v->convIdx++;
-      v->best[v->convIdx % VIT_BUF] = x;
+      v->best[v->convIdx % v->L] = x;
     }
   }
 }
@@ -382,18 +381,19 @@ static void vit_flush(viterbi_t *v)
   const int *P = v->paths[v->pathBuf];
   for (long i = v->convIdx + 1; i < v->pathIdx; i++) {
     v->convIdx++;
-    v->best[v->convIdx % VIT_BUF] = P[ms * VIT_BUF + v->convIdx % VIT_BUF];
+    v->best[v->convIdx % v->L] = P[ms * v->L + v->convIdx % v->L];
   }
 }
 
 /* shs: T x 21 rows of lldo_pitch_shs; out: T x 2 [F0final, voicingFinalUnclipped]; states (optional): T ints;
  * pending (optional): number of frames that were still undecided at the end of input (decided by flushTrellis) */
-void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *out, int *states, long *pending)
+void lldo_pitch_viterbi_ex(const float *shs, long T, float voicing_cutoff, int buflen, float *out, int *states, long *pending)
 {
+  const int VIT_BUF = buflen;
   enum { NC = 6, FSZ = NC * 2 + 4 };
   viterbi_t v;
   memset(&v, 0, sizeof(v));
-  v.nS = NC + 1; v.fsz = FSZ; v.thresh = voicing_cutoff;
+  v.nS = NC + 1; v.fsz = FSZ; v.L = buflen; v.thresh = voicing_cutoff;
   v.wLocal = 2.0; v.wTvv = 10.0; v.wTvvd = 10.0; v.wTvuv = 10.0; v.wThr = 4.0; v.wRange = 1.0;
   v.lastChange = 1.0;
   v.convIdx = -1;
@@ -426,6 +426,11 @@ void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *o
     }
   }
   free(v.buf); free(v.paths[0]); free(v.paths[1]); free(v.best); free(v.cost); free(v.costNew);
+}
+
+void lldo_pitch_viterbi(const float *shs, long T, float voicing_cutoff, float *out, int *states, long *pending)
+{
+  lldo_pitch_viterbi_ex(shs, T, voicing_cutoff, 30, out, states, pending);      /* [is13_pitchSmooth] bufferLength = 30 */
 }
 
 /* ------------------------------------------------------------------ the group for one utterance */
@@ -521,11 +526,10 @@ static double quad_vertex_y(double x1, double y1, double x2, double y2, double x
 
 /* wave: the utterance as floats (n samples); f0: T values (level is13_pitchG60, column F0final);
  * out: T x 4 [jitterLocal, jitterDDP, shimmerLocal, logHNR]. N, H: frame size / step in samples. */
-void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
-                       double frame_step_sec, float *out)
+static void pitch_jitter_impl(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
+                              double frame_step_sec, double searchRangeRel, float *out, float *shimmer_db)
 {
   const double Tw = 1.0 / sample_rate;                              /* waveSource.cpp:190 */
-  const double searchRangeRel = 0.25;
   const int minNumPeriods = 2;
   float threshCC = (float)0.5;
   const float lgHNRfloor = (float)-100.0;
@@ -690,9 +694,30 @@ void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long 
       if (lastShimmerLocal > 1.0) lastShimmerLocal = 1.0;
       o[2] = lastShimmerLocal;
     } else o[2] = 0.0f;
+    if (shimmer_db) {                                                /* shimmerLocalDB (:1000-1030): smileDsp_amplitudeRatioToDB */
+      const int voiced_out = (nPeriods > 0.0 && F0 > 0.0) || (nPeriods == 0.0 && F0 > 0.0);
+      if (voiced_out) {
+        const double a = lastShimmerLocal + 1.0;
+        shimmer_db[t] = (float)((a > 10e-50) ? 20.0 * log(a) / log(10.0) : -1000.0);
+      } else shimmer_db[t] = 0.0f;
+    }
     if (lgHNR < lgHNRfloor) lgHNR = lgHNRfloor;
     o[3] = lgHNR;
   }
+}
+
+void lldo_pitch_jitter(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
+                       double frame_step_sec, float *out)
+{
+  pitch_jitter_impl(wave, n, f0, T, N, H, sample_rate, frame_step_sec, 0.25, out, NULL);       /* [is13_pitchJitter] */
+}
+
+/* GeMAPS' option set ([gemapsv01b_pitchJitter]: searchRangeRel 0.1, jitterLocal + shimmerLocalDB):
+ * out4 as above, shimmer_db[T] = 20 log10(shimmerLocal + 1) */
+void lldo_pitch_jitter_ex(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
+                          double frame_step_sec, double search_range_rel, float *out4, float *shimmer_db)
+{
+  pitch_jitter_impl(wave, n, f0, T, N, H, sample_rate, frame_step_sec, search_range_rel, out4, shimmer_db);
 }
 
 /* ------------------------------------------------------------------ [is13_smoNz] + [is13_deNz] */
