@@ -789,3 +789,244 @@ long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
   free(x); free(fr); free(sp); free(mg); free(res);
   return L->T60;
 }
+
+/* ------------------------------------------------------------------ selectors, gates, smoothers: the LLD level */
+/* cContourSmoother::processBuffer (contourSmoother.cpp:85-118), smaWin = 3, over rows 0 .. rows-1 of a level holding T
+ * frames of D values; clip[n] = the last frame row n can see (later ones are replaced by it: cDataMemoryLevel::getMatrix
+ * pads with the last frame it holds, dataMemoryLevel.cpp:1699-1708), frames before the first are replaced by frame 0. */
+static void sma3(const float *x, long T, int D, long rows, const long *clip, int nz, float *y)
+{
+  for (long n = 0; n < rows; n++) {
+    long c = clip ? clip[n] : T - 1;
+    if (c > T - 1) c = T - 1;
+    if (c < 0) c = 0;
+#define IX(i) ((i) < 0 ? 0 : ((i) > c ? c : (i)))
+    const float *a = x + IX(n) * D, *l = x + IX(n - 1) * D, *r = x + IX(n + 1) * D;
+#undef IX
+    for (int d = 0; d < D; d++) {
+      float v;
+      if (nz) {
+        if (a[d] != 0.0) {
+          long N = 1;
+          v = a[d];
+          if (l[d] != 0.0) { v += l[d]; N++; }
+          if (r[d] != 0.0) { v += r[d]; N++; }
+          v /= (float)N;
+        } else v = 0.0f;
+      } else {
+        v = a[d];
+        v += l[d];
+        v += r[d];
+        v /= (float)3;
+      }
+      y[n * D + d] = v;
+    }
+  }
+}
+
+/* End-of-input behaviour of the nine cContourSmoother instances, measured against the real binary (taps of
+ * oracle/conf/egemaps_taps.conf; T = T60 = 1 .. 995, P = frames the Viterbi smoother had not decided when the input
+ * ended) and explained by the tick loop (componentManager.cpp:1416-1560; every smoother has noPostEOIprocessing = 0):
+ *  - levels fed by 20 ms frames only (lldsetE, loudness, lldSetNoF0AndLoudnessZ): T20 + 1 rows, no effect.
+ *  - levels that follow the Viterbi smoother but not cPitchJitter (lld_single_logF0, lldSetSpectralNz, lldSetSpectralZ):
+ *    no effect when P < T (the smoother runs one frame behind its input); when P == T nothing was decided before the end
+ *    of input, the P frames are then released one per tick and the smoother follows in lockstep in end-of-input mode:
+ *    row n sees frames 0 .. n only, and row 0 reads the never-written slot of frame 1 as zero (getMatrix's left-padding
+ *    branch, dataMemoryLevel.cpp:1687-1698), i.e. row 0 = x[0].
+ *  - levels that also wait for cPitchJitter (lldsetF, lldSetNoF0AndLoudnessNz; cPitchJitter does not run in
+ *    end-of-input ticks, pitchJitter.cpp:593): at the first end of input they hold T - P frames: rows n <= T - P see the
+ *    level clipped at frame T - P - 1; P == T: no effect (the smoother has nothing to read until the next normal phase);
+ *    T == 1: row 0 = x[0] as above. */
+enum { EOI_NONE = 0, EOI_LOCKSTEP = 1, EOI_JITTER = 2 };
+static void smooth_level(const float *x, long T, int D, long P, int nz, int eoi_kind, float *y)
+{
+  const long rows = T + 1;
+  long *clip = (long *)malloc(sizeof(long) * (size_t)rows);
+  int first_exact = 0;
+  for (long n = 0; n < rows; n++) clip[n] = T - 1;
+  if (eoi_kind == EOI_LOCKSTEP && P >= T) {
+    for (long n = 0; n < rows; n++) clip[n] = n;
+    first_exact = 1;
+  } else if (eoi_kind == EOI_JITTER) {
+    if (T == 1) first_exact = 1;
+    else if (P < T) for (long n = 0; n <= T - P && n < rows; n++) clip[n] = T - P - 1;
+  }
+  sma3(x, T, D, rows, clip, nz, y);
+  if (first_exact) memcpy(y, x, sizeof(float) * (size_t)D);
+  free(clip);
+}
+
+void lldo_egemaps_smo_free(lldo_egemaps_smo *S)
+{
+  free(S->E); free(S->F); free(S->logf0); free(S->loud); free(S->NoZ); free(S->NoNz); free(S->specV); free(S->specU);
+  memset(S, 0, sizeof(*S));
+}
+
+/* The smoothed levels of the graph from the per-frame levels: cDataSelector picks (dataSelector.cpp), cValbasedSelector
+ * gates on F0finalLog with threshold 1e-6 (valbasedSelector.cpp:139-237; `invert` for the unvoiced set), then the
+ * smoothers. Requires T60 >= 1. */
+void lldo_egemaps_smooth(const lldo_egemaps_lv *L, lldo_egemaps_smo *S)
+{
+  memset(S, 0, sizeof(*S));
+  const long T20 = L->T20, T = L->T60, P = L->P;
+  if (T < 1) return;
+  S->T20 = T20; S->T60 = T; S->P = P;
+  float *E = (float *)malloc(sizeof(float) * 10 * (size_t)T20), *NoZ = (float *)malloc(sizeof(float) * 5 * (size_t)T20);
+  float *F = (float *)malloc(sizeof(float) * 15 * (size_t)T), *lf = (float *)malloc(sizeof(float) * (size_t)T);
+  float *NoNz = (float *)malloc(sizeof(float) * 14 * (size_t)T), *sV = (float *)malloc(sizeof(float) * 9 * (size_t)T);
+  float *sU = (float *)malloc(sizeof(float) * 5 * (size_t)T);
+  for (long t = 0; t < T20; t++) {
+    const float *ls = L->lspec + 4 * t, *mf = L->mfcc + 4 * t;
+    float *e = E + 10 * t;                                           /* [egemapsv02_lldSetSelectorE] */
+    e[0] = L->loudness[t]; e[1] = ls[2]; e[2] = ls[3]; e[3] = ls[0]; e[4] = ls[1]; e[5] = L->flux[t];
+    memcpy(e + 6, mf, sizeof(float) * 4);
+    NoZ[5 * t] = L->flux[t];                                         /* [egemapsv02_lldSetSelectorNoF0LoudnZ] */
+    memcpy(NoZ + 5 * t + 1, mf, sizeof(float) * 4);
+  }
+  for (long t = 0; t < T; t++) {
+    const float *p = L->pitch + 3 * t, *j = L->jitter + 2 * t, *h = L->harm + 6 * t, *fm = L->formants + 10 * t;
+    const float *ls = L->lspec + 4 * t, *mf = L->mfcc + 4 * t;
+    const float lg = p[1];
+    lf[t] = lg;                                                      /* [gemapsv01b_lldSetSelectorLogF0] */
+    float *f = F + 15 * t;                                           /* [egemapsv02_lldSetSelectorF] */
+    f[0] = lg; f[1] = j[0]; f[2] = j[1]; f[3] = h[0]; f[4] = h[1]; f[5] = h[2];
+    for (int k = 0; k < 3; k++) { f[6 + 3 * k] = fm[k]; f[7 + 3 * k] = fm[5 + k]; f[8 + 3 * k] = h[3 + k]; }
+    const int voiced = lg > (float)0.000001, unvoiced = lg < (float)0.000001;
+    float *z = NoNz + 14 * t;                                        /* [gemapsv01b_formantVoiced] + [egemapsv02_lldSetSelectorNoF0LoudnNz] */
+    z[0] = j[0]; z[1] = j[1]; z[2] = h[0]; z[3] = h[1]; z[4] = h[2];
+    for (int k = 0; k < 3; k++) {
+      z[5 + 3 * k] = voiced ? fm[k] : 0.0f; z[6 + 3 * k] = voiced ? fm[5 + k] : 0.0f; z[7 + 3 * k] = h[3 + k];
+    }
+    const float sp[9] = {ls[2], ls[3], ls[0], ls[1], L->flux[t], mf[0], mf[1], mf[2], mf[3]};
+    for (int k = 0; k < 9; k++) sV[9 * t + k] = voiced ? sp[k] : 0.0f;     /* [egemapsv02_logSpectralVoiced] + SelectorSpectralNz */
+    for (int k = 0; k < 5; k++) sU[5 * t + k] = unvoiced ? sp[k] : 0.0f;   /* [egemapsv02_logSpectralUnvoiced] + SelectorSpectralZ */
+  }
+  S->E = (float *)malloc(sizeof(float) * 10 * (size_t)(T20 + 1));
+  S->loud = (float *)malloc(sizeof(float) * (size_t)(T20 + 1));
+  S->NoZ = (float *)malloc(sizeof(float) * 5 * (size_t)(T20 + 1));
+  S->F = (float *)malloc(sizeof(float) * 15 * (size_t)(T + 1));
+  S->logf0 = (float *)malloc(sizeof(float) * (size_t)(T + 1));
+  S->NoNz = (float *)malloc(sizeof(float) * 14 * (size_t)(T + 1));
+  S->specV = (float *)malloc(sizeof(float) * 9 * (size_t)(T + 1));
+  S->specU = (float *)malloc(sizeof(float) * 5 * (size_t)(T + 1));
+  smooth_level(E, T20, 10, 0, 0, EOI_NONE, S->E);                    /* [egemapsv02_smoE] */
+  smooth_level(L->loudness, T20, 1, 0, 0, EOI_NONE, S->loud);        /* [gemapsv01b_smoLoudness] */
+  smooth_level(NoZ, T20, 5, 0, 0, EOI_NONE, S->NoZ);                 /* [egemapsv02_smoNoFLZ] */
+  smooth_level(F, T, 15, P, 1, EOI_JITTER, S->F);                    /* [egemapsv02_smoFnz] */
+  smooth_level(NoNz, T, 14, P, 1, EOI_JITTER, S->NoNz);              /* [egemapsv02_smoNoF0andLoudnNz] */
+  smooth_level(lf, T, 1, P, 1, EOI_LOCKSTEP, S->logf0);              /* [gemapsv01b_smoF0] */
+  smooth_level(sV, T, 9, P, 1, EOI_LOCKSTEP, S->specV);              /* [egemapsv02_smoSpectralNz] */
+  smooth_level(sU, T, 5, P, 1, EOI_LOCKSTEP, S->specU);              /* [egemapsv02_smoSpectralZ] */
+  free(E); free(NoZ); free(F); free(lf); free(NoNz); free(sV); free(sU);
+}
+
+/* The LLD level of eGeMAPSv02.conf ([lldconcat]: egemapsv02_lldsetE_smo; egemapsv02_lldsetF_smo), 25 columns:
+ *   Loudness, alphaRatio, hammarbergIndex, slope0-500, slope500-1500, spectralFlux, mfcc1..4 (_sma3) |
+ *   F0semitoneFrom27.5Hz, jitterLocal, shimmerLocaldB, HNRdBACF, logRelF0-H1-H2, logRelF0-H1-A3, F1frequency, F1bandwidth,
+ *   F1amplitudeLogRelF0, F2..., F3... (_sma3nz)
+ * rows = T60 + 1 (the rows both levels hold); 0 if the input has no 60 ms frame. out25 == NULL: query. */
+long lldo_egemaps_lld_chain(const int16_t *pcm, long n_samples, float *out25)
+{
+  const long T60 = lldo_num_frames(n_samples, 960, 160);
+  if (T60 < 1) return 0;
+  if (!out25) return T60 + 1;
+  lldo_egemaps_lv L;
+  lldo_egemaps_smo S;
+  lldo_egemaps_levels(pcm, n_samples, &L);
+  lldo_egemaps_smooth(&L, &S);
+  for (long r = 0; r <= T60; r++) {
+    memcpy(out25 + 25 * r, S.E + 10 * r, sizeof(float) * 10);
+    memcpy(out25 + 25 * r + 10, S.F + 15 * r, sizeof(float) * 15);
+  }
+  lldo_egemaps_smo_free(&S);
+  lldo_egemaps_levels_free(&L);
+  return T60 + 1;
+}
+
+/* ------------------------------------------------------------------ the functionals level (88 values) */
+/* The cFunctionals instances of GeMAPSv01b_core.func.conf.inc and eGeMAPSv02_core.func.conf.inc as specs of the general
+ * restatement (lld_oracle_funcspec.c): "F0" / "Loudness" ([gemapsv01b_functionalsF0] / [..Loudness]: Moments amean +
+ * stddevNorm, Percentiles 20/50/80 + range 0-2, Peaks2 rising / falling slope mean + stddev in seconds), "MVZ"
+ * ([egemapsv02_functionalsMVR]), "MVV" ([egemapsv02_functionalsMVRVoiced]), "MU" ([egemapsv02_functionalsMeanUV]), "numPeaks"
+ * ([gemapsv01b_temporalLoudness]), "segF0" / "segF0pause" ([gemapsv01b_temporalF0] / [..F0p]: Segments nonX / eqX, X = 0,
+ * maxNumSeg 1000, seconds), "leq" ([egemapsv02_leqLin]: Means amean). Returns 0 for an unknown name. */
+int lldo_funcspec_egemaps(const char *inst, lldo_func_spec *s)
+{
+  memset(s, 0, sizeof(*s));
+  s->period = 0.01;
+  s->ext_norm = s->means_norm = s->times_norm = s->seg_norm = s->pk_norm = s->reg_centroid_norm = LLDO_NORM_SEGMENT;
+  s->seg_max_num = 20; s->seg_min_lng = 3; s->seg_pause_min_lng = 2; s->lpc_order = 5;
+  if (!strcmp(inst, "F0") || !strcmp(inst, "Loudness")) {
+    s->n_fam = 3; s->fam[0] = LLDO_FAM_MOMENTS; s->fam[1] = LLDO_FAM_PERCENTILES; s->fam[2] = LLDO_FAM_PEAKS2;
+    s->non_zero_functs = !strcmp(inst, "F0") ? 1 : 0;
+    s->mom_mask = (1u << 4) | (1u << 5); s->mom_stddev_norm = 2;
+    s->pct_interp = 1; s->n_pctl = 3; s->pctl[0] = 0.20; s->pctl[1] = 0.50; s->pctl[2] = 0.80;
+    s->n_range = 1; s->range_a[0] = 0; s->range_b[0] = 2;
+    s->pk_mask = (1u << 22) | (1u << 25) | (1u << 26) | (1u << 29);
+    s->pk_norm = LLDO_NORM_SECOND; s->pk_rel_thresh = (float)0.1;
+  } else if (!strcmp(inst, "MVZ") || !strcmp(inst, "MVV")) {
+    s->n_fam = 1; s->fam[0] = LLDO_FAM_MOMENTS;
+    s->non_zero_functs = !strcmp(inst, "MVV") ? 1 : 0;
+    s->mom_mask = (1u << 4) | (1u << 5); s->mom_stddev_norm = 2;
+  } else if (!strcmp(inst, "MU")) {
+    s->n_fam = 1; s->fam[0] = LLDO_FAM_MOMENTS; s->non_zero_functs = 1; s->mom_mask = 1u << 4;
+  } else if (!strcmp(inst, "numPeaks")) {
+    s->n_fam = 1; s->fam[0] = LLDO_FAM_PEAKS2; s->pk_mask = 1u; s->pk_norm = LLDO_NORM_SECOND; s->pk_rel_thresh = (float)0.1;
+    s->pk_ratio_limit = 1;
+  } else if (!strcmp(inst, "segF0") || !strcmp(inst, "segF0pause")) {
+    const int pause = !strcmp(inst, "segF0pause");
+    s->n_fam = 1; s->fam[0] = LLDO_FAM_SEGMENTS;
+    s->seg_mask = pause ? ((1u << 1) | (1u << 4)) : ((1u << 0) | (1u << 1) | (1u << 4));
+    s->seg_norm = LLDO_NORM_SECOND; s->seg_algo = pause ? LLDO_SEG_EQX : LLDO_SEG_NONX; s->seg_max_num = 1000;
+    s->seg_min_lng = 3; s->seg_auto_min_lng = 1; s->seg_pause_min_lng = 2; s->seg_x = 0.0f;
+  } else if (!strcmp(inst, "leq")) {
+    s->n_fam = 1; s->fam[0] = LLDO_FAM_MEANS; s->means_mask = 1u;
+  } else return 0;
+  return 1;
+}
+
+/* Rows each instance summarises (its first end-of-input tick decides, winToVecProcessor.cpp:504-528, 868-1098;
+ * measured against the binary): instances on 20 ms levels T20 of the T20 + 1 rows; instances that follow the Viterbi
+ * smoother max(1, T60 - P); [egemapsv02_functionalsMVRVoiced], which also waits for cPitchJitter, T60 - P, or all T60
+ * when P == T60. out88 in [funcconcat]'s order: F0 (10), Loudness (10), MeanStddevZ (10), MeanStddevVoiced (46),
+ * MeanUnvoiced (5), temporalSet (6: loudnessPeaksPerSec, VoicedSegmentsPerSec, MeanVoicedSegmentLengthSec,
+ * StddevVoicedSegmentLengthSec, MeanUnvoicedSegmentLength, StddevUnvoicedSegmentLength), equivalentSoundLevel_dBp (1).
+ * Returns 1, or 0 when the input has no 60 ms frame (the reference then writes no functionals vector). */
+int lldo_egemaps_func_from_levels(const lldo_egemaps_lv *L, const lldo_egemaps_smo *S, float *out88)
+{
+  const long T20 = L->T20, T = L->T60, P = L->P;
+  if (T < 1) return 0;
+  const long rV = (T - P) > 1 ? (T - P) : 1, rJ = (P >= T) ? T : T - P;
+  lldo_func_spec sp;
+  float *o = out88, tmp[8];
+  lldo_funcspec_egemaps("F0", &sp); lldo_funcspec_apply(&sp, S->logf0, 1, rV, 1, o); o += 10;
+  lldo_funcspec_egemaps("Loudness", &sp); lldo_funcspec_apply(&sp, S->loud, 1, T20, 1, o); o += 10;
+  lldo_funcspec_egemaps("MVZ", &sp); lldo_funcspec_apply(&sp, S->NoZ, 5, T20, 5, o); o += 10;
+  lldo_funcspec_egemaps("MVV", &sp);
+  lldo_funcspec_apply(&sp, S->NoNz, 14, rJ, 14, o); o += 28;
+  lldo_funcspec_apply(&sp, S->specV, 9, rJ, 9, o); o += 18;
+  lldo_funcspec_egemaps("MU", &sp); lldo_funcspec_apply(&sp, S->specU, 5, rV, 5, o); o += 5;
+  lldo_funcspec_egemaps("numPeaks", &sp); lldo_funcspec_apply(&sp, S->loud, 1, T20, 1, o); o += 1;
+  lldo_funcspec_egemaps("segF0", &sp); lldo_funcspec_apply(&sp, S->logf0, 1, rV, 1, o); o += 3;
+  lldo_funcspec_egemaps("segF0pause", &sp); lldo_funcspec_apply(&sp, S->logf0, 1, rV, 1, o); o += 2;
+  lldo_funcspec_egemaps("leq", &sp); lldo_funcspec_apply(&sp, L->energy2, 1, T20, 1, tmp);
+  {                                                                  /* [egemapsv02_leq] cVectorOperation dBp, vectorOperation.cpp:507-516 */
+    const float factor = (float)(10.0 / log(10.0)), logfloor = (float)0.000000000001;
+    *o++ = (tmp[0] > logfloor) ? factor * logf(tmp[0]) : factor * logf(logfloor);
+  }
+  return 1;
+}
+
+int lldo_egemaps_func(const int16_t *pcm, long n_samples, float *out88)
+{
+  const long T60 = lldo_num_frames(n_samples, 960, 160);
+  if (T60 < 1) return 0;
+  lldo_egemaps_lv L;
+  lldo_egemaps_smo S;
+  lldo_egemaps_levels(pcm, n_samples, &L);
+  lldo_egemaps_smooth(&L, &S);
+  const int r = lldo_egemaps_func_from_levels(&L, &S, out88);
+  lldo_egemaps_smo_free(&S);
+  lldo_egemaps_levels_free(&L);
+  return r;
+}

@@ -4,6 +4,7 @@
 #ifndef LLD_ORACLE_GEMAPS_H
 #define LLD_ORACLE_GEMAPS_H
 #include <stdint.h>
+#include "lld_oracle_funcspec.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,6 +51,25 @@ typedef struct {
 } lldo_egemaps_lv;
 long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L);
 void lldo_egemaps_levels_free(lldo_egemaps_lv *L);
+
+/* the smoothed levels (cContourSmoother outputs) the LLD sinks and the functionals read */
+typedef struct {
+  long T20, T60, P;
+  float *E;                  /* (T20+1) x 10 egemapsv02_lldsetE_smo */
+  float *F;                  /* (T60+1) x 15 egemapsv02_lldsetF_smo */
+  float *logf0;              /* (T60+1)      gemapsv01b_lld_single_logF0_smo */
+  float *loud;               /* (T20+1)      gemapsv01b_loudness_smo */
+  float *NoZ;                /* (T20+1) x 5  egemapsv02_lldSetNoF0AndLoudnessZ_smo */
+  float *NoNz;               /* (T60+1) x 14 egemapsv02_lldSetNoF0AndLoudnessNz_smo */
+  float *specV;              /* (T60+1) x 9  egemapsv02_lldSetSpectralNz_smo */
+  float *specU;              /* (T60+1) x 5  egemapsv02_lldSetSpectralZ_smo */
+} lldo_egemaps_smo;
+void lldo_egemaps_smooth(const lldo_egemaps_lv *L, lldo_egemaps_smo *S);
+void lldo_egemaps_smo_free(lldo_egemaps_smo *S);
+long lldo_egemaps_lld_chain(const int16_t *pcm, long n_samples, float *out25);
+int  lldo_funcspec_egemaps(const char *inst, lldo_func_spec *s);
+int  lldo_egemaps_func_from_levels(const lldo_egemaps_lv *L, const lldo_egemaps_smo *S, float *out88);
+int  lldo_egemaps_func(const int16_t *pcm, long n_samples, float *out88);
 
 #ifdef __cplusplus
 }

@@ -699,3 +699,114 @@ def funcspec(x, spec):
     if rows > 0:
         L.lldo_funcspec_apply(C.byref(spec), x.ctypes.data, x.strides[0] // 4, rows, cols, out.ctypes.data)
     return out
+
+
+# ---------------------------------------------------------------- eGeMAPSv02 (oracle/lld_oracle_gemaps.c)
+EGEMAPS_TAPS_CONF = os.path.join(HERE, "conf", "egemaps_taps.conf")
+# key -> level of config/egemaps/v02/eGeMAPSv02.conf tapped by oracle/conf/egemaps_taps.conf
+EGEMAPS_LEVELS = {
+    "loudness": "gemapsv01b_loudness", "lspec": "gemapsv01b_logSpectral", "flux": "egemapsv02_logSpectral_flux",
+    "mfcc": "egemapsv02_mfcc", "energy2": "egemapsv02_energyRMS", "formants": "gemapsv01b_formants",
+    "pitch": "gemapsv01b_logPitch", "jitter": "gemapsv01b_jitterShimmer", "harm": "gemapsv01b_harmonics",
+    "shs": "gemapsv01b_pitchShsG60", "e60": "gemapsv01b_e60", "lpc": "gemapsv01b_lpc",
+    "E": "egemapsv02_lldsetE_smo", "F": "egemapsv02_lldsetF_smo", "logf0": "gemapsv01b_lld_single_logF0_smo",
+    "loud": "gemapsv01b_loudness_smo", "NoZ": "egemapsv02_lldSetNoF0AndLoudnessZ_smo",
+    "NoNz": "egemapsv02_lldSetNoF0AndLoudnessNz_smo", "specV": "egemapsv02_lldSetSpectralNz_smo",
+    "specU": "egemapsv02_lldSetSpectralZ_smo", "mag60": "gemapsv01b_fftmagG60", "mag20": "gemapsv01b_fftmagH25",
+}
+_EG_LV = [("loudness", 1, 20), ("lspec", 4, 20), ("flux", 1, 20), ("mfcc", 4, 20), ("energy2", 1, 20), ("formants", 10, 20),
+          ("pitch", 3, 60), ("jitter", 2, 60), ("harm", 6, 60), ("shs", 21, 60), ("e60", 1, 60)]
+_EG_SMO = [("E", 10, 20), ("F", 15, 60), ("logf0", 1, 60), ("loud", 1, 20), ("NoZ", 5, 20), ("NoNz", 14, 60), ("specV", 9, 60),
+           ("specU", 5, 60)]
+
+
+class _EgLv(C.Structure):
+    _fields_ = [("T20", C.c_long), ("T60", C.c_long), ("P", C.c_long)] + [(k, C.POINTER(C.c_float)) for k, _, _ in _EG_LV]
+
+
+class _EgSmo(C.Structure):
+    _fields_ = [("T20", C.c_long), ("T60", C.c_long), ("P", C.c_long)] + [(k, C.POINTER(C.c_float)) for k, _, _ in _EG_SMO]
+
+
+def _eg_bind():
+    L = lib()
+    L.lldo_egemaps_levels.restype = C.c_long
+    L.lldo_egemaps_levels.argtypes = [C.c_void_p, C.c_long, C.POINTER(_EgLv)]
+    L.lldo_egemaps_smooth.argtypes = [C.POINTER(_EgLv), C.POINTER(_EgSmo)]
+    L.lldo_egemaps_lld_chain.restype = C.c_long
+    L.lldo_egemaps_lld_chain.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    L.lldo_egemaps_func.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    L.lldo_egemaps_func_from_levels.argtypes = [C.POINTER(_EgLv), C.POINTER(_EgSmo), C.c_void_p]
+    L.lldo_funcspec_egemaps.argtypes = [C.c_char_p, C.c_void_p]
+    return L
+
+
+def _eg_arr(p, n, m):
+    return np.ctypeslib.as_array(p, (n, m)).copy() if n > 0 else np.zeros((0, m), np.float32)
+
+
+def egemaps_levels(pcm):
+    """Every per-frame and every smoothed level of eGeMAPSv02's LLD graph for one utterance:
+    {'T20', 'T60', 'P', per-frame levels ..., smoothed levels ...} (keys of EGEMAPS_LEVELS)."""
+    L = _eg_bind()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    lv, sm = _EgLv(), _EgSmo()
+    L.lldo_egemaps_levels(pcm.ctypes.data, len(pcm), C.byref(lv))
+    out = {"T20": lv.T20, "T60": lv.T60, "P": lv.P}
+    for k, m, f in _EG_LV:
+        out[k] = _eg_arr(getattr(lv, k), lv.T20 if f == 20 else lv.T60, m)
+    if lv.T60 >= 1:
+        L.lldo_egemaps_smooth(C.byref(lv), C.byref(sm))
+        for k, m, f in _EG_SMO:
+            out[k] = _eg_arr(getattr(sm, k), (lv.T20 if f == 20 else lv.T60) + 1, m)
+        L.lldo_egemaps_smo_free(C.byref(sm))
+    L.lldo_egemaps_levels_free(C.byref(lv))
+    return out
+
+
+def egemaps_lld_chain(pcm):
+    """The 25-column LLD level of eGeMAPSv02.conf, T60 + 1 rows."""
+    L = _eg_bind()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    rows = L.lldo_egemaps_lld_chain(pcm.ctypes.data, len(pcm), None)
+    out = np.zeros((max(rows, 0), 25), np.float32)
+    if rows > 0:
+        L.lldo_egemaps_lld_chain(pcm.ctypes.data, len(pcm), out.ctypes.data)
+    return out
+
+
+def egemaps_func(pcm):
+    """The 88 functionals of eGeMAPSv02.conf ((0, 88) when the reference writes no vector)."""
+    L = _eg_bind()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.zeros((1, 88), np.float32)
+    r = L.lldo_egemaps_func(pcm.ctypes.data, len(pcm), out.ctypes.data)
+    return out if r else np.zeros((0, 88), np.float32)
+
+
+def egemaps_func_spec(inst):
+    s = FuncSpec()
+    if not _eg_bind().lldo_funcspec_egemaps(inst.encode(), C.byref(s)):
+        raise ValueError(inst)
+    return s
+
+
+def run_reference_egemaps(pcm, fs=16000, levels=()):
+    """Real SMILExtract on the unmodified eGeMAPSv02.conf (+ HTK taps, oracle/conf/egemaps_taps.conf): returns
+    {'lld': T60+1 x 25, 'func': 1 x 88 (or 0 x 88), requested level keys of EGEMAPS_LEVELS ...}."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", EGEMAPS_TAPS_CONF, "-I", wav, "-lldhtkoutput", "lld.htk", "-htkoutput", "func.htk", "-l", "0"],
+                       check=True, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for k, fn, w in (("lld", "lld.htk", 25), ("func", "func.htk", 88)):
+            p = os.path.join(td, fn)
+            out[k] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, w), np.float32)
+            if out[k].size == 0:
+                out[k] = np.zeros((0, w), np.float32)
+        for k in levels:
+            p = os.path.join(td, "tap_%s.htk" % EGEMAPS_LEVELS[k])
+            out[k] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        return out

@@ -125,6 +125,31 @@ def gen_egemaps_func():
     np.savez_compressed(os.path.join(OUT, "egemaps_func_synth.npz"), **ref)
 
 
+def gen_egemaps():
+    """BASELINE config 5, config/egemaps/v02/eGeMAPSv02.conf on the real binary: the 25-column LLD level, the 88
+    functionals and HTK taps on the internal levels (oracle/conf/egemaps_taps.conf; keys of lldo.EGEMAPS_LEVELS).
+    The cases cover T60 = 1 .. 995 and the end-of-input situations of the graph: P (frames the Viterbi smoother had not
+    decided at the end) = 1 .. 9, P == T60, T60 - P = 2 .. 4, silence, noise, clipping square wave."""
+    ref = {}
+    lv = ("loudness", "lspec", "flux", "mfcc", "energy2", "formants", "lpc", "pitch", "jitter", "harm", "shs", "e60",
+          "E", "F", "logf0", "loud", "NoZ", "NoNz", "specV", "specU")
+    for name, (u, n) in {"u2_16000": (2, 16000), "u3_48000": (3, 48000), "u10_16000": (10, 16000), "u1_16000": (1, 16000),
+                          "u0_16000": (0, 16000), "u7_960": (7, 960), "u7_1120": (7, 1120), "u7_1600": (7, 1600),
+                          "u7_2720": (7, 2720), "u4_9000": (4, 9000), "u37_9000": (37, 9000), "u2_8720": (2, 8720),
+                          "u5_16000": (5, 16000), "u11_160000": (11, 160000), "u3_1600": (3, 1600), "u3_1760": (3, 1760),
+                          "u10_1280": (10, 1280), "u2_1760": (2, 1760), "u28_2240": (28, 2240), "u4_1920": (4, 1920),
+                          "u10_1440": (10, 1440), "u3_1280": (3, 1280), "u7_800": (7, 800)}.items():
+        pcm = synth.utterance(u, n)
+        t = lldo.run_reference_egemaps(pcm, levels=lv)
+        ref["pcm_" + name] = pcm
+        ref["lld_" + name] = t["lld"]
+        ref["func_" + name] = t["func"]
+        for k in lv:
+            ref[k + "_" + name] = t[k]
+        print("egemaps", name, t["lld"].shape, t["func"].shape)
+    np.savez_compressed(os.path.join(OUT, "egemaps_lld_synth.npz"), **ref)
+
+
 def gen_plp():
     # config/plp/PLP_0_D_A.conf (PLP-CC + delta + accel, 18 columns): R8's IDFT / LP / cepstrum branch
     ref = {}
@@ -153,6 +178,9 @@ def main(only=None):
         return
     if only == "egemaps":
         gen_egemaps_func()
+        return
+    if only == "egemaps_lld":
+        gen_egemaps()
         return
     if only == "func16":
         gen_func16()
@@ -204,6 +232,7 @@ def main(only=None):
     gen_htk_variants()
     gen_func16()
     gen_egemaps_func()
+    gen_egemaps()
     gen_is13()
 
     # config 1: the reference's example wav (44.1 kHz) -> known answer of SURVEY.md §8(c)
