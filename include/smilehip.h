@@ -142,6 +142,10 @@ typedef struct smilehip_lld_config {
   int32_t  jitter_broken_thresh;        /* [is13_pitchJitter] useBrokenJitterThresh (src/lld/pitchJitter.cpp:801-809): the period
                                            is accepted if its peak correlation exceeds the frame's running minimum (float)
                                            instead of minCC = 0.5 -- IS13_ComParE.conf; 0 in ComParE_2016.conf */
+  /* F0 chains: cPitchSmootherViterbi bufferLength (src/lld/pitchSmootherViterbi.cpp:241; 0 = 30 as in ComParE_2016, 40 in
+   * GeMAPS; <= 40) and cPitchJitter searchRangeRel (src/lld/pitchJitter.cpp:632-637; 0 = 0.25 as in ComParE_2016, 0.1 in GeMAPS) */
+  int32_t  vit_buffer_len;
+  double   jitter_search_range;
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
@@ -150,6 +154,17 @@ typedef struct smilehip_lld_config {
 #define SMILEHIP_CHAIN_PLP 3
 #define SMILEHIP_CHAIN_COMPARE_F0 4
 #define SMILEHIP_CHAIN_COMPARE 5
+/* SMILEHIP_CHAIN_EGEMAPS: the LLD level of config/egemaps/v02/eGeMAPSv02.conf (with config/gemaps/v01b/GeMAPSv01b_core.lld.conf.inc;
+ * BASELINE config 5), 25 columns, T60 + 1 rows per utterance (T60 = frames of the 60 ms framer; none if the input is shorter):
+ *   Loudness, alphaRatio, hammarbergIndex, slope0-500, slope500-1500, spectralFlux, mfcc1..4 (_sma3: [egemapsv02_smoE]) |
+ *   F0semitoneFrom27.5Hz, jitterLocal, shimmerLocaldB, HNRdBACF, logRelF0-H1-H2, logRelF0-H1-A3, F1frequency, F1bandwidth,
+ *   F1amplitudeLogRelF0, F2..., F3... (_sma3nz: [egemapsv02_smoFnz])
+ * from cSpectral with the GeMAPS option sets (src/lldcore/spectral.cpp:586-1254), cPlp as auditory spectrum + cVectorOperation
+ * ll1, cMfcc 1..4, cSpecResample -> cLpc -> cFormantLpc (src/dsp/specResample.cpp:175, src/lld/lpc.cpp:171,
+ * src/lld/formantLpc.cpp:192), the F0 group (cSpecScale, cPitchShs, cPitchSmootherViterbi with F0finalLog, cValbasedSelector),
+ * cPitchJitter (jitterLocal, shimmerLocalDB), cHarmonics (src/lld/harmonics.cpp:743), the voiced / unvoiced cValbasedSelector
+ * gates and cContourSmoother with the graph's end-of-input rules. */
+#define SMILEHIP_CHAIN_EGEMAPS 6
 
 #define SMILEHIP_STAGE_WINDOW 1u
 #define SMILEHIP_STAGE_FFT    2u
@@ -204,6 +219,9 @@ void smilehip_config_compare16(smilehip_lld_config *c);
 /* ... of config/is09-13/IS13_ComParE.conf: the same graph with zeroPadSymmetric = 0 in both cTransformFFT instances and
  * useBrokenJitterThresh = 1 (IS13_ComParE_core.lld.conf.inc vs ComParE_2016_core.lld.conf.inc) */
 void smilehip_config_is13_compare(smilehip_lld_config *c);
+
+/* fills c with the LLD level of config/egemaps/v02/eGeMAPSv02.conf (chain_kind = EGEMAPS, 25 columns) */
+void smilehip_config_egemapsv02(smilehip_lld_config *c);
 
 /* F0 group, per component, on an F0 chain plan (smilehip_config_compare16_f0; the plan's spectrum geometry -- n_bins and
  * the level's frameSizeSec, force_fft_frame_size_sec -- must be the input level's):
@@ -361,6 +379,33 @@ int smilehip_batch_functionals_is13_compare(smilehip_plan *plan, smilehip_batch 
 /* Row T60+1 of group B's sma / delta levels, [n_utt x 110] device floats filled by the last smilehip_lld_run of a
  * ComParE chain batch (tests / callers that run single instances through smilehip_batch_funcspec). */
 int smilehip_batch_compare_b_extra(smilehip_batch *batch, const float **d_extra);
+
+/* ---- eGeMAPSv02 functionals (config/gemaps/v01b/GeMAPSv01b_core.func.conf.inc + config/egemaps/v02/eGeMAPSv02_core.func.conf.inc)
+ * The cFunctionals instances as specs of the general engine: "F0" / "Loudness" ([gemapsv01b_functionalsF0] / [..Loudness]),
+ * "MVZ" ([egemapsv02_functionalsMVR]), "MVV" ([egemapsv02_functionalsMVRVoiced]), "MU" ([egemapsv02_functionalsMeanUV]), "numPeaks"
+ * ([gemapsv01b_temporalLoudness]), "segF0" / "segF0pause" ([gemapsv01b_temporalF0] / [..F0p]), "leq" ([egemapsv02_leqLin]). */
+int smilehip_funcspec_egemaps(const char *instance, smilehip_func_spec *spec);
+/* The whole functionals level: 88 values per utterance in [funcconcat]'s order (gemapsv01b_functionalsF0 (10),
+ * gemapsv01b_functionalsLoudness (10), egemapsv02_functionalsMeanStddevZ (10), ..MeanStddevVoiced (46), ..MeanUnvoiced (5),
+ * gemapsv01b_temporalSet (6), egemapsv02_leq (1, after cVectorOperation dBp); names: smilehip_host func_names_egemaps).
+ * Uses what the last smilehip_lld_run of THIS batch (a smilehip_config_egemapsv02 plan) left on the device: the smoothed
+ * levels the instances read, which hold more rows than the LLD matrix. Rows each instance summarises -- decided in the reference
+ * by its first end-of-input tick (winToVecProcessor.cpp:504-528, 868-1098), measured against the binary -- with T20 / T60 the
+ * frames of the 20 ms / 60 ms framers and P the frames the Viterbi smoother had not decided at the end of input: instances on
+ * 20 ms levels T20; instances that follow the Viterbi smoother max(1, T60 - P); MeanStddevVoiced, which also waits for
+ * cPitchJitter, T60 - P, or T60 when P = T60. d_func: n_utt x ld_func (zeros for utterances without a 60 ms frame, where the
+ * reference writes no instance). */
+int smilehip_functionals_egemaps_count(void);
+int smilehip_batch_functionals_egemaps(smilehip_plan *plan, smilehip_batch *batch, float *d_func, int64_t ld_func, void *stream);
+/* eGeMAPS chain taps (tests / diagnostics): device pointers to the per-frame scratch the last smilehip_lld_run of this batch
+ * filled. raw20 [frames20 x 12]: loudness | slope0-500, slope500-1500, alphaRatio, hammarbergIndex | flux | mfcc1..4 | energy2 | 0;
+ * lpc [frames20 x 12]: 11 LP coefficients; formants [frames20 x 10]: 5 frequencies | 5 bandwidths; pitch3 [frames60 x 3]: F0final,
+ * F0finalLog, voicingFinalUnclipped (level gemapsv01b_logPitch); jit4 [frames60 x 4]: jitterLocal in column 0; shim_db [frames60];
+ * harm6 [frames60 x 6]: level gemapsv01b_harmonics; func_in [(T20+1 rows per utterance with a 60 ms frame) x 36]: the levels the
+ * functionals read; pending [n_utt]. Any pointer may be NULL. h_frame_off60[n_utt+1] (host, may be NULL): 60 ms frame offsets. */
+int smilehip_batch_egemaps_taps(smilehip_batch *batch, const float **d_raw20, const float **d_lpc, const float **d_formants,
+                                const float **d_pitch3, const float **d_jit4, const float **d_shim_db, const float **d_harm6,
+                                const float **d_func_in, const int32_t **d_pending, int64_t *h_frame_off60);
 
 /* Plain device-memory plumbing for hosts that do not link the HIP runtime
  * themselves (the openSMILE plugin is compiled with the host g++ only). */

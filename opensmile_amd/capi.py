@@ -42,6 +42,7 @@ class LldConfig(C.Structure):
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
         ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
+        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double),
     ]
 
 
@@ -111,6 +112,11 @@ SYMBOLS = {
     "smilehip_funcspec_is13_compare": (C.c_int, [C.c_char_p, _vp]),
     "smilehip_batch_functionals_is13_compare": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_config_is13_compare": (None, [_vp]),
+    "smilehip_config_egemapsv02": (None, [C.POINTER(LldConfig)]),
+    "smilehip_funcspec_egemaps": (C.c_int, [C.c_char_p, _vp]),
+    "smilehip_functionals_egemaps_count": (C.c_int, []),
+    "smilehip_batch_functionals_egemaps": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "smilehip_batch_egemaps_taps": (C.c_int, [_vp] + [C.POINTER(_vp)] * 9 + [_vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -218,6 +224,20 @@ def is13_compare_config():
     c = LldConfig()
     load().smilehip_config_is13_compare(C.byref(c))
     return c
+
+
+def egemapsv02_config():
+    """config/egemaps/v02/eGeMAPSv02.conf (BASELINE config 5): the 25-column LLD level."""
+    c = LldConfig()
+    load().smilehip_config_egemapsv02(C.byref(c))
+    return c
+
+
+def funcspec_egemaps(instance):
+    """One of eGeMAPSv02's cFunctionals instances: F0, Loudness, MVZ, MVV, MU, numPeaks, segF0, segF0pause, leq."""
+    s = FuncSpec()
+    _check(load().smilehip_funcspec_egemaps(instance.encode(), C.byref(s)))
+    return s
 
 
 def funcspec_is13_compare(instance):
@@ -497,6 +517,63 @@ class Batch:
             L.smilehip_free(ctx, d_lld)
             L.smilehip_free(ctx, d_func)
         return lld, func, ex
+
+    def run_host_egemaps(self, pcm, functionals=True, taps=False):
+        """eGeMAPSv02 plans: smilehip_lld_run [+ smilehip_batch_functionals_egemaps] on host data. Returns
+        (lld [total_rows x 25], func [n_utt x 88] or None[, taps: dict of the per-frame scratch levels])."""
+        L = load()
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        n_out = self.plan.geometry.n_out
+        lld = np.zeros((self.total_rows, n_out), np.float32)
+        func = np.zeros((self.n_utt, 88), np.float32) if functionals else None
+        ctx = self.plan.ctx._h
+        d_pcm, d_lld, d_func = _vp(), _vp(), _vp()
+        _check(L.smilehip_alloc(ctx, max(pcm.nbytes, 4), C.byref(d_pcm)))
+        _check(L.smilehip_alloc(ctx, max(lld.nbytes, 4), C.byref(d_lld)))
+        _check(L.smilehip_alloc(ctx, max(self.n_utt * 88 * 4, 4), C.byref(d_func)))
+        out_taps = {}
+        try:
+            if pcm.nbytes:
+                _check(L.smilehip_copy_to_device(ctx, d_pcm, pcm.ctypes.data, pcm.nbytes, None))
+            _check(L.smilehip_lld_run(self.plan._h, self._h, d_pcm, d_lld, n_out, None))
+            if functionals:
+                _check(L.smilehip_batch_functionals_egemaps(self.plan._h, self._h, d_func, 88, None))
+            _check(L.smilehip_stream_synchronize(ctx, None))
+            if lld.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, lld.ctypes.data, d_lld, lld.nbytes, None))
+            if functionals and func.nbytes:
+                _check(L.smilehip_copy_to_host(ctx, func.ctypes.data, d_func, func.nbytes, None))
+            if taps:
+                ptrs = [_vp() for _ in range(9)]
+                fo60 = np.zeros(self.n_utt + 1, np.int64)
+                _check(L.smilehip_batch_egemaps_taps(self._h, *[C.byref(q) for q in ptrs], fo60.ctypes.data))
+                nf, nf60 = self.total_frames, int(fo60[-1])
+                T20 = np.diff(self.frame_offsets_frames())
+                T60 = np.diff(fo60)
+                nfin = int(np.where(T60 >= 1, T20 + 1, 0).sum())
+                shapes = [("raw20", (nf, 12)), ("lpc", (nf, 12)), ("formants", (nf, 10)), ("pitch3", (nf60, 3)), ("jit4", (nf60, 4)),
+                          ("shim_db", (nf60, 1)), ("harm6", (nf60, 6)), ("func_in", (nfin, 36))]
+                for (name, shp), q in zip(shapes, ptrs):
+                    a = np.zeros(shp, np.float32)
+                    if a.nbytes:
+                        _check(L.smilehip_copy_to_host(ctx, a.ctypes.data, q, a.nbytes, None))
+                    out_taps[name] = a
+                pend = np.zeros(self.n_utt, np.int32)
+                if pend.nbytes:
+                    _check(L.smilehip_copy_to_host(ctx, pend.ctypes.data, ptrs[8], pend.nbytes, None))
+                out_taps["pending"] = pend
+                out_taps["frame_off60"] = fo60
+                out_taps["fin_off"] = np.concatenate([[0], np.cumsum(np.where(T60 >= 1, T20 + 1, 0))]).astype(np.int64)
+        finally:
+            L.smilehip_free(ctx, d_pcm)
+            L.smilehip_free(ctx, d_lld)
+            L.smilehip_free(ctx, d_func)
+        return (lld, func, out_taps) if taps else (lld, func)
+
+    def frame_offsets_frames(self):
+        """Frame (not row) offsets per utterance: frames of the plan's own framer."""
+        T = [self.plan.num_frames(int(self.sample_offsets[u + 1] - self.sample_offsets[u])) for u in range(self.n_utt)]
+        return np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
 
     def funcspec_host(self, lld, spec, col_first, n_cols, rows_cut, extra=None):
         """lld: the matrix run_host returned -> n_utt x (n_cols * count(spec)) through smilehip_batch_funcspec;

@@ -36,7 +36,7 @@ constexpr int kWaves = 4;        // waves per persistent workgroup
 constexpr int kW = 3;            // frames a wave holds at a time: one lane each in the serial phases
 constexpr int kTileFrames = 8;   // consecutive frames of one utterance per work item
 constexpr int kNC = 6;           // candidates (nCandidates of [is13_shs])
-constexpr int kVB = 30;          // bufferLength of [is13_pitchSmoothViterbi]
+constexpr int kVBmax = 40;       // largest bufferLength ([is13_pitchSmoothViterbi] 30, [gemapsv01b_pitchSmoothViterbi] 40)
 constexpr int kNS = kNC + 1;     // Viterbi states: candidates + "unvoiced"
 // the frame kernel is written for the 60 ms / 16 kHz geometry of ComParE / GeMAPS: FFT 1024
 constexpr int kNfftF0 = 1024, kM = 512, kK = 513, kKP = 516, kPer = 9;   // complex points, bins, padded bins, bins per lane
@@ -508,7 +508,8 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
   const int64_t fo = frame_off[u];
   const int T = (int)(frame_off[u + 1] - fo);
   if (T <= 0) return;
-  __shared__ int paths[2][kNS * kVB];
+  __shared__ int paths[2][kNS * kVBmax];
+  const int kVB = Q.vit_buf;                               // bufferLength (<= kVBmax, checked by the launcher)
   __shared__ double cost[kNS];
   __shared__ int msel[kNS];
   const int lane = threadIdx.x;
@@ -529,7 +530,17 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
     float vp = (s < kNC) ? fr[1 + kNC + s] : fr[1 + kNC];
     if (!(Q.e60[row] > Q.min_energy)) { f = 0.0f; vp = 0.0f; }     // cValbasedSelector, zeroVec
     out[row * ld] = f;
-    out[row * ld + 1] = vp;
+    if (Q.vit_log_out) {
+      // F0finalLog (pitchSmootherViterbi.cpp:497-505): semitones above 27.5 Hz, float arithmetic throughout; the
+      // reference's logf is correctly rounded in practice, the device's is not: double log, rounded once
+      float sc = 0.0f;
+      if (f > 29.136) sc = (float)12.0 * (float)log((double)(f / (float)27.5)) / 0.693147182464599609375f;
+      else if (f > 0.0f) sc = 1.0f;
+      out[row * ld + 1] = sc;
+      out[row * ld + 2] = vp;
+    } else {
+      out[row * ld + 1] = vp;
+    }
   };
 
   for (int t = 0; t < T; ++t) {
@@ -677,8 +688,8 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       const double T0 = 1.0 / F0;
       Tf = T0 / Tw;
       T0f = (long)round(Tf);
-      T0minF = (long)floor((1.0 - 0.25) * Tf);
-      T0maxF = (long)ceil((1.0 + 0.25) * Tf);
+      T0minF = (long)floor((1.0 - Q.jit_search_range) * Tf);
+      T0maxF = (long)ceil((1.0 + Q.jit_search_range) * Tf);
       const long two_pp = 2 * T0maxF + 2;
       if (toRead < two_pp) toRead = two_pp;
     }
@@ -695,7 +706,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
                       (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
     if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
       lastIdx += toRead0;
-      if (tid == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
+      if (tid == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; if (Q.jit_shim_db) Q.jit_shim_db[fo + t] = 0.0f; }
       continue;
     }
     const long nT = toRead;
@@ -929,7 +940,13 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       o2 = lastSh;
     } else o2 = 0.0f;
     if (lgHNR < -100.0f) lgHNR = -100.0f;
-    if (tid == 0) { o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR; }
+    if (tid == 0) {
+      o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR;
+      if (Q.jit_shim_db) {                                 // shimmerLocalDB (:1000-1030): smileDsp_amplitudeRatioToDB(shimmer + 1)
+        const double a = (double)o2 + 1.0;
+        Q.jit_shim_db[fo + t] = voiced ? (float)((a > 10e-50) ? 20.0 * log(a) / log(10.0) : -1000.0) : 0.0f;
+      }
+    }
     PHASE(9);   // output
   }
   PHASE_FLUSH;
@@ -1031,7 +1048,7 @@ int f0_tile_frames() { return kTileFrames; }
 
 hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s) {
   if (P.total_frames <= 0) return hipSuccess;
-  if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
+  if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17 || Q.vit_buf < 2 || Q.vit_buf > kVBmax) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
   const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
   const void *fn = reinterpret_cast<const void *>(&lld_f0_frame);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1061,6 +1078,14 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   LldParams P;
   std::memset(&P, 0, sizeof(P));
   hipLaunchKernelGGL(lld_f0_frame, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  return hipGetLastError();
+}
+
+// cPitchJitter alone: F0 contour d_f0 (leading dimension ld_f0, F0final in column 0) -> d_jit4 [frames x 4] (+ Q.jit_shim_db)
+hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
+  if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
+  if (P.n_utt >= 512) hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_f0, ld_f0, d_jit4);
+  else hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), 0, s, P, Q, d_f0, ld_f0, d_jit4);
   return hipGetLastError();
 }
 

@@ -1106,7 +1106,12 @@ __global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int o
   const Col x = data_col(P, w);
   int n2 = 1;
   while (n2 < N) n2 <<= 1;
-  float *a = (n2 <= kSortLds) ? lds : P.sorted + 2 * w.srow0 * P.n_cols + (int64_t)w.c * n2;
+  // global scratch beyond the LDS capacity: the utterance's region holds 2 * (rows + 1) * n_cols floats; the column slots
+  // are spaced by the power of two covering the utterance's rows BEFORE nonZeroFuncts -- the columns' own sizes differ
+  // with nonZeroFuncts, and slots spaced by them would overlap
+  int64_t slot = 1;
+  while (slot < w.rows) slot <<= 1;
+  float *a = (n2 <= kSortLds) ? lds : P.sorted + 2 * w.srow0 * P.n_cols + (int64_t)w.c * slot;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) a[i] = (i < N) ? x[i] : INFINITY;
   __syncthreads();
   bitonic_sort(a, n2);

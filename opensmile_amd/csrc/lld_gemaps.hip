@@ -1,0 +1,943 @@
+// eGeMAPSv02 / GeMAPSv01b LLD level (BASELINE config 5, config/egemaps/v02/eGeMAPSv02.conf with
+// config/gemaps/v01b/GeMAPSv01b_core.lld.conf.inc), the kernels beside the F0 group of lld_f0.hip:
+//   lld_gemaps_frame20   one wave per run of 8 consecutive 20 ms frames (four runs per workgroup, no workgroup barrier after
+//                        the table staging): Hamming window, FFT 512, magnitude; one mel bank in two scalings ->
+//                        cPlp auditory spectrum + its ll1 mean (loudness), MFCC 1..4; cSpectral's GeMAPS option sets
+//                        (log-spectrum slopes 0-500 / 500-1500, alpha ratio, Hammarberg index, flux over 0-5000 Hz);
+//                        cEnergy energy2 of the raw frame; the 110 complex bins cSpecResample reads go to scratch
+//   lld_gemaps_lpc       cSpecResample (smileDsp_irdft: a 220 x 219 real matrix applied to every frame's spectrum) as a
+//                        register-tiled product -- one wave = 8 frames x 220 outputs, four outputs per lane, every
+//                        output's float sum in the reference's own order -- then cLpc: autocorrelation (one thread per
+//                        (frame, lag), sequential float sums) and Durbin's recursion
+//   lld_gemaps_formants  cFormantLpc: one thread per frame, roots of the LP polynomial by the reference's balanced
+//                        companion-matrix QR iteration in double (zerosolve.cpp), formant frequencies / bandwidths
+//   lld_gemaps_harm      cHarmonics, one wave per voiced 60 ms frame: gauss window, FFT 1024, magnitude; ACF of the squared
+//                        magnitudes by the inverse real FFT -> harmonics-to-noise ratio at the F0 lag; the 100 harmonic
+//                        peaks (one lane per harmonic), H1-H2, H1-A3, formant amplitudes F1..F3 relative to F0
+//   lld_gemaps_tail      per utterance: cDataSelector picks, the voiced / unvoiced cValbasedSelector gates, the nine
+//                        cContourSmoother instances with the graph's end-of-input rules -> the 25-column LLD level and the
+//                        levels the functionals read
+// Reference-order arithmetic where the result is order-sensitive (float sums of cSpecResample / cLpc, the QR iteration);
+// sums the reference keeps in double are formed as double tree sums. Parity first; bounds in DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "lld_blocks.hpp"
+#include "lld_blocks_compare.hpp"
+#include "lld_device.hpp"
+#include "lld_launch.hpp"
+#include "lld_params.hpp"
+
+namespace smilehip {
+
+namespace {
+constexpr int kRun = 8;            // 20 ms frames per run (same runs as the ComParE A+B kernel)
+constexpr int kRsI = 220;          // resampled samples per frame (cSpecResample: 20 ms at 11 kHz)
+constexpr int kRsB = 109;          // complex bins the slow inverse DFT uses (kMax/2 - 1)
+constexpr int kLpcP = 11;          // cLpc p
+constexpr int kLpcTile = 32;       // frames per workgroup of the resampling / LPC kernel (8 per wave)
+constexpr int kNH = 100;           // cHarmonics nHarmonics
+
+// smileMath_quadFrom3pts (smileUtil.c:1009-1033)
+__device__ __forceinline__ double quad3(double x1, double y1, double x2, double y2, double x3, double y3, double &y) {
+  const double den = x1 * x1 * x2 + x2 * x2 * x3 + x3 * x3 * x1 - x3 * x3 * x2 - x2 * x2 * x1 - x1 * x1 * x3;
+  if (den != 0.0) {
+    const double a = (y1 * x2 + y2 * x3 + y3 * x1 - y3 * x2 - y2 * x1 - y1 * x3) / den;
+    const double b = (x1 * x1 * y2 + x2 * x2 * y3 + x3 * x3 * y1 - x3 * x3 * y2 - x2 * x2 * y1 - x1 * x1 * y3) / den;
+    const double c = (x1 * x1 * x2 * y3 + x2 * x2 * x3 * y1 + x3 * x3 * x1 * y2 - x3 * x3 * x2 * y1 - x2 * x2 * x1 * y3 - x1 * x1 * x3 * y2) / den;
+    if (a != 0.0) {
+      const double x = -b / (2.0 * a);
+      y = c - a * x * x;
+      return x;
+    }
+  }
+  if (y1 > y2 && y1 > y3) { y = y1; return x1; }
+  if (y2 > y1 && y2 > y3) { y = y2; return x2; }
+  if (y3 > y1 && y3 > y2) { y = y3; return x3; }
+  y = y1;
+  return x1;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ 20 ms frames
+// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave yv[Npad] | re[M] | im[M] | mg[Kpad] | pw[Kpad] | prev[Kpad] |
+// lg[64] | mel[32] | aud[32] | lmel[32]
+__global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsParams G, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = P.Nfft >> 1, K = P.K;
+  const int Npad = (P.N + 3) & ~3, Kpad = (K + 3) & ~3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *s_coef = smem;
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + Kpad);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
+  __syncthreads();                                       // the only workgroup barrier
+  const int run = blockIdx.x * 4 + wave;
+  if (run >= n_runs) return;
+  const int per_wave = Npad + 2 * M + 3 * Kpad + 64 + 96;
+  float *yv = s_dct + 16 * 32 + wave * per_wave;
+  float *re = yv + Npad;
+  float *im = re + M;
+  float *mg = im + M;
+  float *pw = mg + Kpad;
+  float *prev = pw + Kpad;
+  float *lg = prev + Kpad;
+  float *melv = lg + 64;
+  float *aud = melv + 32;
+  float *lmel = aud + 32;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+
+  const int u = G.run_utt[run];
+  const int t0 = G.run_t0[run];
+  const int64_t f0 = P.frame_off[u];
+  const int T20 = (int)(P.frame_off[u + 1] - f0);
+  const int16_t *xu = P.pcm + P.samp_off[u];
+  const double F0 = 1.0 / G.fsSec;                       // frq[i] = F0 * i (transformFft.cpp:102-117)
+  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+    const bool warm = t < t0;
+    const int16_t *x = xu + (int64_t)t * P.H;
+    float *raw = G.raw20 + (f0 + t) * 12;
+    for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
+    WaveG::sync();
+    for (int i = lane; i < M; i += 64) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
+      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+    }
+    WaveG::sync();
+    group_cfft_radix2<WaveG>(re, im, M, P.tw_half);
+    float *spec = G.spec220 + (f0 + t) * kRsI;
+    for (int k = lane; k <= M; k += 64) {
+      const float2 X = untangle_bin(re, im, M, k, P.tw_full);
+      const float m = bin_magnitude(X, k == 0 || k == M);
+      mg[k] = m;
+      pw[k] = m * m;                                     // squareInput (spectral.cpp:677-684) == melspec usePower
+      if (!warm) {
+        // what cSpecResample reads of the complex level (Ooura packing, fftsg.c:103-135): a[0], then a[2k], a[2k+1] = -Im
+        // stored as (Re, Im) pairs of bins 1..109, then a[0], then one pad
+        if (k == 0) { spec[2 * kRsB] = X.x; spec[2 * kRsB + 1] = 0.0f; }
+        else if (k <= kRsB) { spec[2 * k - 2] = X.x; spec[2 * k - 1] = -X.y; }
+      }
+    }
+    WaveG::sync();
+    if (warm) {
+      for (int k = lane; k < K; k += 64) prev[k] = mg[k];
+      WaveG::sync();
+      continue;
+    }
+    // log power spectrum of the bins the two slopes cover (spectral.cpp:689-716): factor 10/ln 10 as float, floor at specFloor^2
+    {
+      const float p = pw[lane];
+      lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log((double)p);
+    }
+    // R6 once, two scalings: [gemapsv01b_melspec1] (htk = 0) feeds cPlp, [egemapsv02_melspecMfcc] (htk = 1) feeds cMfcc
+    if (lane < P.n_bands) {
+      const int b = lane;
+      const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
+      melv[b] = acc;
+      lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
+      aud[b] = plp_aud_band(acc, G.plp_melfloor, G.eql[b], G.compression);     // [gemapsv01b_audspec], plp.cpp:499-507
+    }
+    WaveG::sync();
+    if (lane < P.n_mfcc) raw[6 + lane] = dct_coeff(lmel, s_dct + lane * P.n_bands, P.n_bands, P.dct_gain[lane]);   // R7
+    if (lane == 32) {                                    // [gemapsv01b_audspecSum] ll1, vectorOperation.cpp:475-481
+      float d = 0.0f;
+      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      raw[0] = d / (float)P.n_bands;
+    }
+    // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
+    {
+      double d = 0.0;
+      for (int n = lane; n < P.N; n += 64) { const float tmp = yv[n]; d += tmp * tmp; }
+      d = WaveG::sum(d, nullptr);
+      if (lane == 0) raw[10] = (float)(d / (double)P.N) * 1.0f + 0.0f;
+    }
+    // band slopes of the log spectrum (spectral.cpp:872-992), frequency axis given: four double sums per band
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int iL = G.sl_iL[b], iR = G.sl_iR[b];
+      const double wL = G.sl_wL[b], wR = G.sl_wR[b];
+      double v[4] = {0.0, 0.0, 0.0, 0.0};                // Sf, S2f, sumA, sumB
+      const int j = iL + lane;
+      if (j <= iR) {
+        const double f = F0 * (double)j, l = (double)lg[j];
+        if (j == iL) { const double fw = f * wL; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wL * l; }
+        else if (j == iR) { const double fw = f * wR; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wR * l; }
+        else { v[0] = f; v[1] = f * f; v[2] = f * l; v[3] = l; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = WaveG::sum(v[q], nullptr);
+      if (lane == 0) {
+        const double Nind = G.sl_Nind[b];
+        const double deno = (Nind * v[1] - v[0] * v[0]);
+        double slope = 0.0;
+        if (deno != 0.0) slope = (Nind * v[2] - v[0] * v[3]) / deno;
+        raw[1 + b] = (float)slope;                       // oldSlopeScale = 0
+      }
+    }
+    // alpha ratio (:995-1037) and Hammarberg index (:1039-1089) over the bins up to 5000 Hz, flux (:1124-1254) over freqRange
+    {
+      double s01 = 0.0, s15 = 0.0, fl = 0.0;
+      float m02 = 0.0f, m25 = 0.0f;
+      for (int j = lane; j < K; j += 64) {
+        const double f = F0 * (double)j;
+        if (f > 5000.0) break;
+        const float p = pw[j];
+        if (f < 1000.0) s01 += (double)p; else s15 += (double)p;
+        if (f < 2000.0) m02 = p > m02 ? p : m02; else m25 = p > m25 ? p : m25;
+      }
+      for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
+        const double myB = (double)mg[j] - (double)prev[j];
+        fl += myB * myB;
+      }
+      s01 = WaveG::sum(s01, nullptr); s15 = WaveG::sum(s15, nullptr); fl = WaveG::sum(fl, nullptr);
+      for (int o = 32; o > 0; o >>= 1) {
+        float w = __shfl_xor(m02, o); m02 = w > m02 ? w : m02;
+        w = __shfl_xor(m25, o); m25 = w > m25 ? w : m25;
+      }
+      if (lane == 0) {
+        const float sum01 = (float)s01, sum15 = (float)s15;
+        float a = 0.0f, h = 0.0f;
+        if (sum01 > 0.0f) {
+          if (sum15 > G.spec_floor) a = (float)(10.0 * (double)(float)log((double)(sum15 / sum01)) / log(10.0));
+          else a = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)sum01)) / log(10.0));
+        }
+        if (m25 > 0.0f) {
+          if (m02 > G.spec_floor) h = (float)(10.0 * (double)(float)log((double)(m02 / m25)) / log(10.0));
+          else h = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)m25)) / log(10.0));
+        }
+        raw[3] = a;
+        raw[4] = h;
+        const int nBins = G.rng_hi - G.rng_lo + 1;
+        const double flux = (nBins > 0) ? fl / (double)nBins : 0.0;
+        raw[5] = (t > 0 && flux > 0.0) ? (float)sqrt(flux) : 0.0f;       // first frame of a stream: 0 (:1132-1136)
+        raw[11] = 0.0f;
+      }
+    }
+    WaveG::sync();
+    for (int k = lane; k < K; k += 64) prev[k] = mg[k];
+    WaveG::sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cSpecResample + cLpc
+// smileDsp_irdft (smileUtil.c:1800-1820): out[i] = in[0]; for k = 2, 4, ..: out[i] += in[k] * cos[k/2][i]; out[i] += in[k+1] *
+// sin[k/2][i]; out[i] /= (K/2) -- float, in this order, products rounded before they are added. One wave owns 8 frames of the
+// tile and all 220 outputs (lane l: outputs l, l+64, l+128, l+192): a table element is loaded once per 8 frames, a spectrum
+// element once per 4 outputs (LDS broadcast).
+__global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
+  __shared__ __attribute__((aligned(16))) float xs[kLpcTile][kRsI + 4];      // spectra, then the resampled signals
+  __shared__ float racf[kLpcTile][kLpcP + 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t g0 = (int64_t)blockIdx.x * kLpcTile;
+  const int n_fr = (int)((G.total_frames20 - g0 < kLpcTile) ? G.total_frames20 - g0 : kLpcTile);
+  for (int i = threadIdx.x; i < kLpcTile * kRsI; i += 256) {
+    const int f = i / kRsI, c = i - f * kRsI;
+    xs[f][c] = (f < n_fr) ? G.spec220[(g0 + f) * kRsI + c] : 0.0f;
+  }
+  __syncthreads();
+  {
+    constexpr int FW = kLpcTile / 4;                     // frames per wave
+    const int fw = wave * FW;
+    float acc[FW][4];
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const float dc = xs[fw + f][2 * kRsB];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[f][o] = dc;
+    }
+    const bool o3 = lane + 192 < kRsI;
+    for (int b = 0; b < kRsB; ++b) {
+      float c[4], s[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int i = lane + 64 * o;
+        c[o] = (o < 3 || o3) ? G.rs_cos[b * kRsI + i] : 0.0f;
+        s[o] = (o < 3 || o3) ? G.rs_sin[b * kRsI + i] : 0.0f;
+      }
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        const float2 z = *reinterpret_cast<const float2 *>(&xs[fw + f][2 * b]);       // (Re, Im Ooura) of bin b+1
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          acc[f][o] += z.x * c[o];
+          acc[f][o] += z.y * s[o];
+        }
+      }
+    }
+    WaveG::sync();                                       // this wave's rows are only read by this wave up to here
+#pragma unroll
+    for (int f = 0; f < FW; ++f)
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < 3 || o3) xs[fw + f][lane + 64 * o] = acc[f][o] / (float)256;   // /= (FLOAT_DMEM)(K/2), K = 512 inputs
+  }
+  __syncthreads();
+  // smileDsp_autoCorr (smileUtil.c:1560-1570): r[lag] = sum_{i >= lag} x[i] * x[i-lag], float, ascending i
+  for (int task = threadIdx.x; task < kLpcTile * (kLpcP + 1); task += 256) {
+    const int f = task / (kLpcP + 1), lag = task - f * (kLpcP + 1);
+    const float *x = xs[f];
+    float r = 0.0f;
+    for (int i = lag; i < kRsI; ++i) r += x[i] * x[i - lag];
+    racf[f][lag] = r;
+  }
+  __syncthreads();
+  // smileDsp_calcLpcAcf (Durbin, smileUtil.c:1572-1630); cLpc::processVector with saveLPCoeff only (lpc.cpp:171-213)
+  if (threadIdx.x < n_fr) {
+    const float *r = racf[threadIdx.x];
+    float a[kLpcP + 1];
+#pragma unroll
+    for (int i = 0; i <= kLpcP; ++i) a[i] = 0.0f;
+    if (!((r[0] == 0.0f) || (r[0] == -0.0f))) {
+      float e = r[0];
+#pragma unroll
+      for (int m = 1; m <= kLpcP; m++) {
+        float sum = (float)1.0 * r[m];
+#pragma unroll
+        for (int i = 1; i < m; i++) sum += a[i - 1] * r[m - i];
+        const float k_m = ((float)-1.0 / e) * sum;
+        a[m - 1] = k_m;
+#pragma unroll
+        for (int i = 1; i <= m / 2; i++) {
+          const float x = a[i - 1];
+          a[i - 1] += k_m * a[m - i - 1];
+          if ((i < (m / 2)) || ((m & 1) == 1)) a[m - i - 1] += k_m * x;
+        }
+        e *= ((float)1.0 - k_m * k_m);
+        if (e == 0.0f) {
+          for (int i = m; i < kLpcP; i++) a[i] = 0.0f;
+          break;
+        }
+      }
+    }
+    float *o = G.lpc + (g0 + threadIdx.x) * 12;
+#pragma unroll
+    for (int i = 0; i < kLpcP; ++i) o[i] = a[i];
+    o[kLpcP] = 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cFormantLpc
+// zerosolve.cpp restated for one thread: companion matrix of the monic polynomial, balancing, Francis QR steps; h is the
+// thread's private nc x nc matrix (row-major), 1-based accessors like the reference's MATF.
+namespace {
+constexpr int kNC = kLpcP;
+#define GM_MATC(m, i, j) ((m)[(i) * kNC + (j)])
+#define GM_MATF(m, i, j) ((m)[((i) - 1) * kNC + ((j) - 1)])
+#define GM_EPS 2.2204460492503131e-16
+
+__device__ void zs_balance(double *m) {                  // zerosolveBalanceCmatrix, zerosolve.cpp:22-84
+  const double radix = 2.0, radix2 = 4.0;
+  const int nc = kNC;
+  bool converged = false;
+  double nrow = 0, ncol = 0;
+  while (!converged) {
+    double t1, t2, t3;
+    converged = true;
+    for (int i = 0; i < nc; i++) {
+      if (i != nc - 1) ncol = fabs(GM_MATC(m, i + 1, i));
+      else { ncol = 0.0; for (int j = 0; j < nc - 1; j++) ncol += fabs(GM_MATC(m, j, nc - 1)); }
+      if (i == 0) nrow = fabs(GM_MATC(m, 0, nc - 1));
+      else if (i == nc - 1) nrow = fabs(GM_MATC(m, i, i - 1));
+      else nrow = (fabs(GM_MATC(m, i, i - 1)) + fabs(GM_MATC(m, i, nc - 1)));
+      if (ncol == 0.0 || nrow == 0.0) continue;
+      t2 = 1.0; t1 = nrow / radix; t3 = ncol + nrow;
+      while (ncol < t1) { t2 *= radix; ncol *= radix2; }
+      t1 = nrow * radix;
+      while (ncol > t1) { t2 /= radix; ncol /= radix2; }
+      if ((nrow + ncol) < 0.95 * t3 * t2) {
+        converged = false;
+        t1 = 1.0 / t2;
+        if (i == 0) GM_MATC(m, 0, nc - 1) *= t1;
+        else { GM_MATC(m, i, i - 1) *= t1; GM_MATC(m, i, nc - 1) *= t1; }
+        if (i == nc - 1) { for (int j = 0; j < nc; j++) GM_MATC(m, j, i) *= t2; }
+        else GM_MATC(m, i + 1, i) *= t2;
+      }
+    }
+  }
+}
+
+__device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, zerosolve.cpp:100-283
+  int i, j, k, m = 0, e, nit = 0, N = kNC;
+  double w, s, x, y, z, p = 0, q = 0, r = 0, t = 0.0;
+  for (;;) {
+    for (e = N; e >= 2; e--) {
+      const double a1 = fabs(GM_MATF(h, e, e - 1)), a2 = fabs(GM_MATF(h, e - 1, e - 1)), a3 = fabs(GM_MATF(h, e, e));
+      if (a1 <= GM_EPS * (a2 + a3)) break;
+    }
+    x = GM_MATF(h, N, N);
+    if (e == N) {
+      root[2 * (N - 1)] = x + t; root[2 * (N - 1) + 1] = 0;
+      N--;
+      if (N == 0) return 1;
+      nit = 0;
+      continue;
+    }
+    y = GM_MATF(h, N - 1, N - 1);
+    w = GM_MATF(h, N - 1, N) * GM_MATF(h, N, N - 1);
+    if (e == N - 1) {
+      p = (y - x) / 2;
+      q = p * p + w;
+      y = sqrt(fabs(q));
+      x += t;
+      if (q > 0) {
+        if (p < 0) y = -y;
+        y += p;
+        root[2 * (N - 1)] = x - w / y; root[2 * (N - 1) + 1] = 0;
+        root[2 * (N - 2)] = x + y; root[2 * (N - 2) + 1] = 0;
+      } else {
+        root[2 * (N - 1)] = x + p; root[2 * (N - 1) + 1] = -y;
+        root[2 * (N - 2)] = x + p; root[2 * (N - 2) + 1] = y;
+      }
+      N -= 2;
+      if (N == 0) return 1;
+      nit = 0;
+      continue;
+    }
+    if (nit == 70) return 0;
+    if (nit % 10 == 0 && nit > 0) {
+      t += x;
+      for (i = 1; i <= N; i++) GM_MATF(h, i, i) -= x;
+      s = fabs(GM_MATF(h, N, N - 1)) + fabs(GM_MATF(h, N - 1, N - 2));
+      y = 3.0 / 4.0 * s;
+      x = y;
+      w = -0.4375 * s * s;
+    }
+    nit++;
+    for (m = N - 2; m >= e; m--) {
+      z = GM_MATF(h, m, m);
+      r = x - z;
+      s = y - z;
+      p = GM_MATF(h, m, m + 1) + (r * s - w) / GM_MATF(h, m + 1, m);
+      q = GM_MATF(h, m + 1, m + 1) - z - r - s;
+      r = GM_MATF(h, m + 2, m + 1);
+      s = fabs(p) + fabs(q) + fabs(r);
+      p /= s; q /= s; r /= s;
+      if (m == e) break;
+      const double a1 = fabs(GM_MATF(h, m, m - 1)), a2 = fabs(GM_MATF(h, m - 1, m - 1)), a3 = fabs(GM_MATF(h, m + 1, m + 1));
+      if (a1 * (fabs(q) + fabs(r)) <= GM_EPS * fabs(p) * (a2 + a3)) break;
+    }
+    for (i = m + 2; i <= N; i++) GM_MATF(h, i, i - 2) = 0;
+    for (i = m + 3; i <= N; i++) GM_MATF(h, i, i - 3) = 0;
+    for (k = m; k <= N - 1; k++) {
+      const bool notlast = (k != N - 1);
+      if (k != m) {
+        p = GM_MATF(h, k, k - 1);
+        q = GM_MATF(h, k + 1, k - 1);
+        r = notlast ? GM_MATF(h, k + 2, k - 1) : 0.0;
+        x = fabs(p) + fabs(q) + fabs(r);
+        if (x == 0) continue;
+        p /= x; q /= x; r /= x;
+      }
+      s = sqrt(p * p + q * q + r * r);
+      if (p < 0) s = -s;
+      if (k != m) GM_MATF(h, k, k - 1) = -s * x;
+      else if (e != m) GM_MATF(h, k, k - 1) *= -1;
+      p += s;
+      z = r / s; y = q / s; x = p / s;
+      r /= p; q /= p;
+      for (j = k; j <= N; j++) {
+        p = GM_MATF(h, k, j) + q * GM_MATF(h, k + 1, j);
+        if (notlast) { p += r * GM_MATF(h, k + 2, j); GM_MATF(h, k + 2, j) -= p * z; }
+        GM_MATF(h, k + 1, j) -= p * y;
+        GM_MATF(h, k, j) -= p * x;
+      }
+      j = (k + 3 < N) ? k + 3 : N;
+      for (i = e; i <= j; i++) {
+        p = x * GM_MATF(h, i, k) + y * GM_MATF(h, i, k + 1);
+        if (notlast) { p += z * GM_MATF(h, i, k + 2); GM_MATF(h, i, k + 2) -= p * r; }
+        GM_MATF(h, i, k + 1) -= p * q;
+        GM_MATF(h, i, k) -= p;
+      }
+    }
+  }
+}
+}  // namespace
+
+// cFormantLpc::processVector (formantLpc.cpp:192-290), nFormants = 5, saveFormants = saveBandwidths = 1, no median filter /
+// octave correction. One thread per frame. When the QR iteration does not converge the reference goes on with what its
+// roots member held before (the previous frame's values); a frame here starts from zeros instead (not observed on speech).
+__global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
+  const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (g >= G.total_frames20) return;
+  const float *lp = G.lpc + g * 12;
+  double mat[kNC * kNC], roots[2 * kNC], fc[5], bc[5];
+  for (int i = 0; i < kNC * kNC; ++i) mat[i] = 0.0;
+  for (int i = 0; i < 2 * kNC; ++i) roots[i] = 0.0;
+  for (int i = 1; i < kNC; i++) GM_MATC(mat, i, i - 1) = 1.0;                 // zerosolveSetCmatrix, zerosolve.cpp:86-98
+  for (int i = 0; i < kNC; i++) GM_MATC(mat, i, kNC - 1) = -(double)(-lp[kNC - i - 1]) / 1.0;   // a[i] = -lpc[n-1-i], a[n] = 1
+  zs_balance(mat);
+  zs_qr(mat, roots);
+  for (int i = 0; i < kNC; i++) {                                            // smileMath_complexIntoUnitCircle, smileUtil.c:992-1003
+    const double re = roots[2 * i], im = roots[2 * i + 1];
+    if (sqrt(re * re + im * im) > 1.0) {
+      const double c = re, d = -im;                                          // 1 / conj(root), smileMath_complexDiv :951-977
+      double R = 0, I = 0;
+      if (fabs(c) >= fabs(d)) {
+        if (c != 0.0) { const double r = d / c, den = c + r * d; if (den != 0.0) { R = (1.0 + 0.0 * r) / den; I = (0.0 - r * 1.0) / den; } }
+      } else {
+        if (d != 0.0) { const double r = c / d, den = d + r * c; if (den != 0.0) { R = (1.0 * r + 0.0) / den; I = (0.0 * r - 1.0) / den; } }
+      }
+      roots[2 * i] = R; roots[2 * i + 1] = I;
+    }
+  }
+  int n_found = 0;                                                           // smileDsp_lpcrootsToFormants, smileUtil.c:2019-2053
+  {
+    const double spPi = G.fm_T * M_PI, spPi2 = spPi * 2.0;
+    double fHigh = G.fm_max;
+    if ((fHigh < G.fm_min) || (fHigh > 1.0 / G.fm_T)) fHigh = 0.5 / G.fm_T - G.fm_min;
+    for (int i = 0; i < kNC; i++) {
+      const double re = roots[2 * i], im = roots[2 * i + 1];
+      if (im < 0) continue;
+      const double f = fabs(atan2(im, re)) / spPi2;
+      if ((f >= G.fm_min) && (f <= fHigh)) {
+        bc[n_found] = -log(sqrt(re * re + im * im)) / spPi;
+        fc[n_found] = f;
+        n_found++;
+        if (n_found >= 5) break;
+      }
+    }
+    for (int i = n_found; i < 5; i++) { fc[i] = 0.0; bc[i] = 0.0; }
+  }
+  int nz = 0;                                                                // ascending order, formantLpc.cpp:270-289
+  for (nz = 0; nz < 5; nz++) if (fc[nz] == 0.0) break;
+  for (int i = 0; i < nz; i++)
+    for (int j = i + 1; j < nz; j++)
+      if (fc[j] < fc[i]) {
+        double t = fc[j]; fc[j] = fc[i]; fc[i] = t;
+        t = bc[j]; bc[j] = bc[i]; bc[i] = t;
+      }
+  float *o = G.formants + g * 10;
+  for (int i = 0; i < 5; i++) { o[i] = (float)fc[i]; o[5 + i] = (float)bc[i]; }
+}
+#undef GM_MATC
+#undef GM_MATF
+#undef GM_EPS
+
+// ------------------------------------------------------------------------------------------------ cHarmonics
+// cHarmonics::processVector (harmonics.cpp:743-1031) with [gemapsv01b_harmonics]'s options. One wave per tile of <= 8
+// consecutive 60 ms frames; unvoiced frames (F0final == 0) only write the constants the reference emits.
+// The 60 ms magnitude spectrum is recomputed here (window + FFT 1024) rather than kept from the pitch kernel: 2 KB per
+// frame of HBM traffic each way would cost more than the transform.
+// LDS: shared win[NP] | twh[256] | twf[260]; per wave re[512] | im[512] | mg[516] | acf[516] | hbin[128] | hfi[128] | hmag[128] |
+// hlr[128]
+namespace {
+constexpr int kHM = 512, kHK = 513, kHKP = 516;
+__device__ __forceinline__ int harm_is_peak(const float *x, int N, int n) {  // cHarmonics::isPeak, :369-390
+  if (n >= N || n < 0) return 0;
+  if (n + 1 < N) {
+    if (n > 0) { if (x[n] > x[n - 1] && x[n] > x[n + 1]) return 1; }
+    else { if (x[0] > x[1]) return 1; }
+  } else {
+    if (n > 0) { if (x[n] > x[n - 1]) return 1; }
+  }
+  return 0;
+}
+// freqToBin (:403-415) on the linear axis frq[i] = Fb * i: the first bin above freq, or its lower neighbour if that one
+// is closer; 0 if there is none. The reference's search start never lies above that bin (see the call sites), so the
+// result does not depend on it.
+__device__ __forceinline__ int harm_freq_to_bin(double Fb, float freq) {
+  const double f = (double)freq;
+  int s = (int)(f / Fb);
+  while (Fb * (double)s <= f) s++;
+  while (s > 0 && Fb * (double)(s - 1) > f) s--;
+  if (s >= kHK) return 0;
+  if (s < 1) s = 1;
+  return (Fb * (double)s - f > f - Fb * (double)(s - 1)) ? s - 1 : s;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, GemapsParams G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NP = (Q.N + 3) & ~3;
+  float *c_win = reinterpret_cast<float *>(smem_h);
+  float2 *c_twh = reinterpret_cast<float2 *>(c_win + NP);
+  float2 *c_twf = c_twh + kHM / 2;
+  for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
+  for (int i = threadIdx.x; i < kHM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
+  for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  __syncthreads();                                       // the only workgroup barrier
+  constexpr int per_wave = 2 * kHM + 2 * kHKP + 4 * 128;
+  float *re = reinterpret_cast<float *>(c_twf + (kHM / 2 + 4)) + (size_t)wave * per_wave;
+  float *im = re + kHM;
+  float *mg = im + kHM;
+  float *acf = mg + kHKP;
+  int *hbin = reinterpret_cast<int *>(acf + kHKP);
+  float *hfi = reinterpret_cast<float *>(hbin + 128);
+  float *hmag = hfi + 128;
+  float *hlr = hmag + 128;
+  const double Fb = 1.0 / G.fsSec60;                     // frequency axis of the 60 ms spectrum: frq[i] = Fb * i
+  const int tile_stride = (int)gridDim.x * 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < G.n_tiles60; tile += tile_stride) {
+    const int64_t samp0 = G.tile60[tile].samp0, row0 = G.tile60[tile].row0;
+    const int n_fr = G.tile60[tile].n_frames;
+    // the 20 ms frame with the same start sample: row0 - frame_off60[u] + frame_off20[u]; resolved through the utterance
+    int lo = 0, hi = P.n_utt;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (G.frame_off60[mid] <= row0) lo = mid; else hi = mid;
+    }
+    const int64_t r20 = row0 - G.frame_off60[lo] + P.frame_off[lo];
+    for (int tf = 0; tf < n_fr; ++tf) {
+      const int64_t g = row0 + tf;
+      const float F0 = G.pitch3[g * 3];
+      float *o = G.harm6 + g * 6;
+      if (!(F0 > 0.0f)) {
+        if (lane == 0) {                                 // :790-810 (no ACF peak), :1005-1025
+          o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+          o[3] = (float)-201.0; o[4] = (float)-201.0; o[5] = (float)-201.0;   // logRelValueFloorUnvoiced
+        }
+        continue;
+      }
+      const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
+      for (int i = lane; i < kHM; i += 64) {
+        const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
+        const int r = (int)(__brev((unsigned)i) >> (32 - 9));
+        re[r] = (n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f;
+        im[r] = (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f;
+      }
+      WaveG::sync();
+      group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
+      for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(untangle_bin(re, im, kHM, k, c_twf), k == 0 || k == kHM);
+      WaveG::sync();
+      // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
+      float *R = acf;                                    // squared magnitudes first, overwritten by the lags
+      for (int k = lane; k <= kHM; k += 64) R[k] = mg[k] * mg[k];
+      WaveG::sync();
+      {
+        const int n = 2 * kHM;
+        for (int i = lane; i < kHM; i += 64) {
+          const int n0 = 2 * i, n1 = 2 * i + 1;
+          const float v0 = R[n0 <= kHM ? n0 : n - n0];
+          const float v1 = R[n1 <= kHM ? n1 : n - n1];
+          const int r = (int)(__brev((unsigned)i) >> (32 - 9));
+          re[r] = v0;
+          im[r] = v1;
+        }
+        WaveG::sync();
+        group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
+        for (int k = lane; k <= kHM; k += 64) {
+          const float a = 0.5f * untangle_bin(re, im, kHM, k, c_twf).x;
+          acf[k] = fabsf(a) / (float)kHK;
+        }
+        WaveG::sync();
+      }
+      // HNR at the ACF peak closest to the F0 lag (freqToAcfBinLin :393-401, getClosestPeak :632-665, computeAcfHnr_dB :690-712)
+      float hnr_db = 0.0f;
+      {
+        const double fs = Fb * (double)(kHK - 1) * 2.0;
+        long idx = (long)(int)floor(fs / F0);
+        long refined = 0;
+        if (idx > 0) {
+          if (harm_is_peak(acf, kHK, (int)idx)) refined = idx;
+          else {
+            long off = 1;
+            bool found = false;
+            while (idx - off > 0 || idx + off < kHK - 1) {
+              if (idx - off > 0 && harm_is_peak(acf, kHK, (int)(idx - off))) { refined = idx - off; found = true; break; }
+              if (idx + off < kHK - 1 && harm_is_peak(acf, kHK, (int)(idx + off))) { refined = idx + off; found = true; break; }
+              off++;
+            }
+            if (!found) {
+              const long ic = idx < kHK ? idx : kHK - 1;   // (F0 >= minPitch keeps the lag inside the array)
+              const float xi = acf[ic];
+              if (acf[0] > xi && acf[kHK - 1] <= xi) refined = 0;
+              else if (acf[0] <= xi && acf[kHK - 1] > xi) refined = kHK - 1;
+              else if (acf[0] > xi && acf[kHK - 1] > xi) refined = (idx < kHK / 2) ? 0 : kHK - 1;
+              else refined = idx;
+            }
+          }
+        }
+        if (refined > 0 && refined < kHK) {
+          double hnr = acf[0] - acf[refined], ret;
+          if (hnr == 0.0) hnr = 10e10; else hnr = acf[refined] / hnr;
+          if (hnr > 10e10) ret = 10.0 * log10(10e10);
+          else if (hnr < 10e-10) ret = 10.0 * log10(10e-10);
+          else ret = 10.0 * log10(hnr);
+          hnr_db = (float)ret;
+        }
+      }
+      // findHarmonicPeaks, frequency-axis branch (:478-546): harmonic i = lane, lane + 64
+      const int firstBin = harm_freq_to_bin(Fb, 0.5f * F0);
+      for (int i = lane; i < 128; i += 64) {
+        int bin = -1;
+        float fi = 0.0f, mag = 0.0f, mi = 0.0f;
+        if (i < kNH) {
+          const int candBin = harm_freq_to_bin(Fb, (float)(i + 1) * F0);
+          int peakBin = -1;
+          if (harm_is_peak(mg, kHK, candBin)) peakBin = candBin;
+          else {
+            int cl = candBin - 1, cr = candBin + 1;
+            const int lower = harm_freq_to_bin(Fb, ((float)i + 0.5f) * F0);
+            const int upper = harm_freq_to_bin(Fb, ((float)i + 1.5f) * F0);
+            while ((cl >= lower || cr <= upper) && peakBin == -1) {
+              if (cr <= upper) { if (harm_is_peak(mg, kHK, cr)) { peakBin = cr; break; } cr++; }
+              if (cl >= lower) { if (harm_is_peak(mg, kHK, cl)) { peakBin = cl; break; } cl--; }
+            }
+          }
+          if (peakBin >= firstBin && peakBin < kHK - 1) {
+            bin = peakBin;
+            mag = mg[peakBin];
+            double m2 = 0.0;
+            fi = (float)quad3(Fb * (double)(peakBin - 1), (double)mg[peakBin - 1], Fb * (double)peakBin, (double)mg[peakBin],
+                              Fb * (double)(peakBin + 1), (double)mg[peakBin + 1], m2);
+            mi = (float)m2;
+          } else {
+            bin = candBin;
+          }
+        }
+        hbin[i] = bin; hfi[i] = fi; hmag[i] = mag; hlr[i] = mi;      // hlr: interpolated magnitude for now
+      }
+      WaveG::sync();
+      // postProcessHarmonics(…, true) (:550-588): log magnitudes relative to harmonic 0 (log10 of a float: log10f), then the
+      // duplicate removal, which is sequential (an entry is compared with its predecessor AFTER that one was cleared)
+      {
+        const float m0 = hmag[0];
+        const bool logRel = !(m0 == 0.0f);
+        const float lm0 = logRel ? (float)log10((double)m0) : 0.0f;
+        for (int i = lane; i < kNH; i += 64) {
+          float v;
+          if (i == 0) v = 0.0f;
+          else if (!logRel) v = -201.0f;
+          else if (hlr[i] > 0.0f) {
+            const double tmp = (double)(float)log10((double)hlr[i]);
+            v = (float)(20.0 * (tmp - (double)lm0));
+            if (v < -200.0f) v = -200.0f;
+          } else v = -200.0f;
+          hlr[i] = v;
+        }
+        WaveG::sync();
+        if (lane == 0) {
+          int prev_bin = hbin[0];
+#pragma unroll 4
+          for (int i = 1; i < kNH; ++i) {
+            const int b = hbin[i];
+            if (b == prev_bin) { hbin[i] = 0; hfi[i] = 0.0f; hmag[i] = 0.0f; hlr[i] = -201.0f; prev_bin = 0; }
+            else prev_bin = b;
+          }
+        }
+        WaveG::sync();
+      }
+      // getFormantAmplitudeIndices (:714-740): the strongest harmonic within 0.8 .. 1.2 of the formant frequency
+      int fa[3];
+      const float *fm = G.formants + (r20 + tf) * 10;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const float fl = 0.8f * fm[f], fr = 1.2f * fm[f];
+        float bm = 0.0f;
+        int bi = 1 << 30;
+        for (int h = lane; h < kNH; h += 64) {
+          const float v = hfi[h];
+          if (v >= fl && v <= fr && hmag[h] > bm) { bm = hmag[h]; bi = h; }      // ascending h: the first maximum
+        }
+        for (int of = 32; of > 0; of >>= 1) {
+          const float om = __shfl_xor(bm, of);
+          const int oi = __shfl_xor(bi, of);
+          if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+        }
+        fa[f] = (bi == (1 << 30) || !(bm > 0.0f)) ? -1 : bi;
+      }
+      if (lane == 0) {
+        o[0] = hnr_db;
+        float v = hlr[1] - hlr[2];                        // H1-H2 (:876-900)
+        v = v < -201.0f ? -201.0f : (v > 201.0f ? 201.0f : v);
+        o[1] = v;
+        v = (fa[2] >= 0) ? hlr[1] - hlr[fa[2]] : (float)(hlr[1] - 201.0f);       // H1-A3 (:903-917 when A3 has no harmonic)
+        v = v < -201.0f ? -201.0f : (v > 201.0f ? 201.0f : v);
+        o[2] = v;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) o[3 + f] = (fa[f] >= 0) ? hlr[fa[f]] : 0.0f;   // :957-973
+      }
+      WaveG::sync();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ selectors + smoothers
+// One workgroup per utterance. Rows: the LLD level keeps T60 + 1 (what both lldsetE_smo and lldsetF_smo hold); the levels
+// the functionals read go to func_in with T20 + 1 rows per utterance (none for utterances without a 60 ms frame). End-of-input rules of the nine cContourSmoother
+// instances as measured against the binary (oracle/lld_oracle_gemaps.c, smooth_level): levels that follow the Viterbi
+// smoother only run in lockstep with it when nothing was decided before the end (P == T60: row n sees frames 0 .. n, row 0
+// is x[0]); levels that also wait for cPitchJitter see themselves clipped at frame T60 - P - 1 in rows n <= T60 - P.
+namespace {
+enum { kEoiNone = 0, kEoiLockstep = 1, kEoiJitter = 2 };
+struct Sma {
+  int T, P, kind, n;
+  __device__ __forceinline__ int clip() const {
+    if (kind == kEoiLockstep && P >= T) return n < T - 1 ? n : T - 1;
+    if (kind == kEoiJitter && T > 1 && P < T && n <= T - P) return T - P - 1;
+    return T - 1;
+  }
+  __device__ __forceinline__ bool first_exact() const { return n == 0 && ((kind == kEoiLockstep && P >= T) || (kind == kEoiJitter && T == 1)); }
+};
+// cContourSmoother::processBuffer (contourSmoother.cpp:85-118), smaWin = 3; X(i): frame i of the level, clamped
+template <class F>
+__device__ __forceinline__ float sma3(const Sma &s, bool nz, F X) {
+  int c = s.clip();
+  if (c < 0) c = 0;
+  auto I = [&](int i) { return i < 0 ? 0 : (i > c ? c : i); };
+  const float a = X(I(s.n));
+  if (s.first_exact()) return a;
+  const float l = X(I(s.n - 1)), r = X(I(s.n + 1));
+  if (nz) {
+    if (a != 0.0f) {
+      int N = 1;
+      float v = a;
+      if (l != 0.0f) { v += l; N++; }
+      if (r != 0.0f) { v += r; N++; }
+      return v / (float)N;
+    }
+    return 0.0f;
+  }
+  float v = a;
+  v += l;
+  v += r;
+  return v / (float)3;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) lld_gemaps_tail(const int64_t *frame_off20, const int64_t *row_off, int n_utt, GemapsParams G,
+                                                      float *out, int64_t ld) {
+  const int u = blockIdx.x;
+  if (u >= n_utt) return;
+  const int64_t f20 = frame_off20[u], f60 = G.frame_off60[u];
+  const int T20 = (int)(frame_off20[u + 1] - f20), T = (int)(G.frame_off60[u + 1] - f60);
+  const int P = G.pending ? G.pending[u] : 0;
+  if (threadIdx.x == 0) G.pending_j[u] = (P < T) ? P : 0;
+  if (T < 1) return;                                     // no 60 ms frame: no LLD rows, no functionals (func_in holds no rows)
+  float *fin = G.func_in + G.fin_off[u] * 36;
+  const float *raw = G.raw20 + f20 * 12, *fm = G.formants + f20 * 10;
+  const float *p3 = G.pitch3 + f60 * 3, *j4 = G.jit4 + f60 * 4, *sdb = G.shim_db + f60, *h6 = G.harm6 + f60 * 6;
+  float *o = out + row_off[u] * ld;
+  // (row, column) items: columns 0..9 E (T20+1 rows, the first T+1 also go to the LLD level), 10..24 F, 25 logF0, 26..39 NoNz,
+  // 40..48 specV, 49..53 specU (T+1 rows each)
+  const int rowsE = T20 + 1, rowsF = T + 1;
+  // column maps
+  const int eRaw[10] = {0, 3, 4, 1, 2, 5, 6, 7, 8, 9};   // loudness, alphaRatio, hammarberg, slope0-500, slope500-1500, flux, mfcc1..4
+  const int spRaw[9] = {3, 4, 1, 2, 5, 6, 7, 8, 9};      // the spectral set of the voiced / unvoiced selectors
+  for (int64_t it = threadIdx.x; it < (int64_t)rowsE * 10; it += 256) {
+    const int n = (int)(it / 10), c = (int)(it - (int64_t)n * 10);
+    Sma s{T20, 0, kEoiNone, n};
+    const int rc = eRaw[c];
+    const float v = sma3(s, false, [&](int i) { return raw[(int64_t)i * 12 + rc]; });
+    if (n < rowsF) o[(int64_t)n * ld + c] = v;
+    if (c == 0) fin[(int64_t)n * 36] = v;                // loudness_sma3
+    else if (c >= 5) fin[(int64_t)n * 36 + (c - 4)] = v; // flux, mfcc1..4 _sma3
+  }
+  for (int64_t it = threadIdx.x; it < (int64_t)rowsF * 44; it += 256) {
+    const int n = (int)(it / 44), c = (int)(it - (int64_t)n * 44);
+    if (c < 15) {                                        // [egemapsv02_lldSetSelectorF] -> [egemapsv02_smoFnz]
+      Sma s{T, P, kEoiJitter, n};
+      const float v = sma3(s, true, [&](int i) -> float {
+        if (c == 0) return p3[(int64_t)i * 3 + 1];
+        if (c < 3) return c == 1 ? j4[(int64_t)i * 4] : sdb[i];
+        if (c < 6) return h6[(int64_t)i * 6 + (c - 3)];
+        const int k = (c - 6) / 3, w = (c - 6) - 3 * k;  // F(k+1): frequency, bandwidth, amplitude
+        return w == 0 ? fm[(int64_t)i * 10 + k] : (w == 1 ? fm[(int64_t)i * 10 + 5 + k] : h6[(int64_t)i * 6 + 3 + k]);
+      });
+      o[(int64_t)n * ld + 10 + c] = v;
+    } else if (c == 15) {                                // [gemapsv01b_lldSetSelectorLogF0] -> [gemapsv01b_smoF0]
+      Sma s{T, P, kEoiLockstep, n};
+      fin[(int64_t)n * 36 + 6] = sma3(s, true, [&](int i) { return p3[(int64_t)i * 3 + 1]; });
+    } else if (c < 30) {                                 // [gemapsv01b_formantVoiced] + [egemapsv02_lldSetSelectorNoF0LoudnNz]
+      const int d = c - 16;
+      Sma s{T, P, kEoiJitter, n};
+      fin[(int64_t)n * 36 + 7 + d] = sma3(s, true, [&](int i) -> float {
+        if (d < 2) return d == 0 ? j4[(int64_t)i * 4] : sdb[i];
+        if (d < 5) return h6[(int64_t)i * 6 + (d - 2)];
+        const int k = (d - 5) / 3, w = (d - 5) - 3 * k;
+        if (w == 2) return h6[(int64_t)i * 6 + 3 + k];
+        const bool voiced = p3[(int64_t)i * 3 + 1] > (float)0.000001;
+        return voiced ? fm[(int64_t)i * 10 + (w == 0 ? k : 5 + k)] : 0.0f;
+      });
+    } else if (c < 39) {                                 // [egemapsv02_logSpectralVoiced] + SelectorSpectralNz
+      const int d = c - 30;
+      Sma s{T, P, kEoiLockstep, n};
+      fin[(int64_t)n * 36 + 21 + d] = sma3(s, true, [&](int i) -> float {
+        return (p3[(int64_t)i * 3 + 1] > (float)0.000001) ? raw[(int64_t)i * 12 + spRaw[d]] : 0.0f;
+      });
+    } else {                                             // [egemapsv02_logSpectralUnvoiced] + SelectorSpectralZ
+      const int d = c - 39;
+      Sma s{T, P, kEoiLockstep, n};
+      fin[(int64_t)n * 36 + 30 + d] = sma3(s, true, [&](int i) -> float {
+        return (p3[(int64_t)i * 3 + 1] < (float)0.000001) ? raw[(int64_t)i * 12 + spRaw[d]] : 0.0f;
+      });
+    }
+  }
+  // rows of func_in beyond T (the 60 ms levels are shorter than the 20 ms ones): zero
+  for (int64_t it = threadIdx.x; it < (int64_t)(rowsE - rowsF) * 29; it += 256) {
+    const int n = rowsF + (int)(it / 29), c = 6 + (int)(it % 29);           // columns 6..34
+    fin[(int64_t)n * 36 + c] = 0.0f;
+  }
+  for (int n = threadIdx.x; n < rowsE; n += 256) fin[(int64_t)n * 36 + 35] = (n < T20) ? raw[(int64_t)n * 12 + 10] : 0.0f;   // energy2
+}
+
+// [egemapsv02_leq] cVectorOperation dBp (vectorOperation.cpp:507-516) on one value per utterance, in place
+__global__ void lld_gemaps_dbp(float *x, int64_t ld, int n_utt, const int64_t *row_off) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_utt) return;
+  if (row_off[u + 1] - row_off[u] <= 0) return;
+  const float factor = (float)(10.0 / log(10.0)), logfloor = (float)0.000000000001;
+  const float v = x[u * ld];
+  x[u * ld] = factor * (float)log((double)(v > logfloor ? v : logfloor));
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s) {
+  if (n_runs <= 0) return hipSuccess;
+  if (P.Nfft != 512 || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;
+  const int M = P.Nfft / 2;
+  const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (Npad + 2 * M + 3 * Kpad + 64 + 96));
+  hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (G.total_frames20 <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.total_frames20 + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((G.total_frames20 + 63) / 64)), dim3(64), 0, s, G);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s) {
+  if (G.n_tiles60 <= 0) return hipSuccess;
+  if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
+  const int NP = (Q.N + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)NP + sizeof(float2) * (size_t)(kHM / 2 + kHM / 2 + 4) +
+                     sizeof(float) * 4 * (size_t)(2 * kHM + 2 * kHKP + 4 * 128);
+  const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  unsigned grid = (unsigned)((G.n_tiles60 + 3) / 4);
+  if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);
+  hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(256), lds, s, P, Q, G);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemaps_tail(const int64_t *d_frame_off20, const int64_t *d_row_off, int n_utt, const GemapsParams &G, float *d_out,
+                              int64_t ld_out, hipStream_t s) {
+  if (n_utt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_tail, dim3((unsigned)n_utt), dim3(256), 0, s, d_frame_off20, d_row_off, n_utt, G, d_out, ld_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemaps_dbp(float *d_x, int64_t ld, int n_utt, const int64_t *d_row_off, hipStream_t s) {
+  if (n_utt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_dbp, dim3((unsigned)((n_utt + 255) / 256)), dim3(256), 0, s, d_x, ld, n_utt, d_row_off);
+  return hipGetLastError();
+}
+
+int gemaps_lpc_tile() { return kLpcTile; }
+
+}  // namespace smilehip

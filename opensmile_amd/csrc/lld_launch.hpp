@@ -43,6 +43,12 @@ hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
 hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s);
+hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s);
+hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s);
+hipError_t launch_gemaps_tail(const int64_t *d_frame_off20, const int64_t *d_row_off, int n_utt, const GemapsParams &G, float *d_out,
+                              int64_t ld_out, hipStream_t s);
+hipError_t launch_gemaps_dbp(float *d_x, int64_t ld, int n_utt, const int64_t *d_row_off, hipStream_t s);
+hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s);
 int fs_sort_lds_rows();
 int chain_tile_rows();
 int chain_short_max();

@@ -141,6 +141,49 @@ struct F0Params {
   const float *in_rows;
   int64_t ld_in, ld_tap, ld_shs;
   int32_t *pending;                 // optional [n_utt]: frames the Viterbi pass had not decided at the end of input
+  int32_t vit_buf;                  // cPitchSmootherViterbi bufferLength (30 ComParE, 40 GeMAPS; <= 40)
+  int32_t vit_log_out;              // 1: rows [F0final, F0finalLog, voicingFinalUnclipped] (GeMAPS), 0: [F0final, voicing]
+  double jit_search_range;          // cPitchJitter searchRangeRel (0.25 ComParE, 0.1 GeMAPS)
+  float *jit_shim_db;               // optional [total_frames]: shimmerLocalDB = 20 log10(shimmerLocal + 1)
+};
+
+// eGeMAPSv02 / GeMAPSv01b LLD level (lld_gemaps.hip): per-frame scratch and constants
+struct GemapsParams {
+  // ---- 20 ms chain ----
+  const int32_t *run_utt, *run_t0;  // runs of 8 consecutive 20 ms frames (the flux needs the previous frame)
+  float *raw20;                     // [total_frames20 x 12] loudness | slope0-500, slope500-1500, alphaRatio, hammarberg | flux |
+                                    //                        mfcc1..4 | energy2 | 0
+  float *spec220;                   // [total_frames20 x 220] what cSpecResample reads of the complex spectrum: (Re, Im Ooura) of
+                                    //                        bins 1..109, then the DC value, one pad
+  const float *eql;                 // [26] equal-loudness weights (plp.cpp:335-357)
+  float plp_melfloor, compression;
+  double fsSec;                     // frameSizeSec of the 20 ms spectrum level
+  int32_t sl_iL[2], sl_iR[2];       // cSpectral slopes 0-500 / 500-1500: edge bins, weights, Nind (spectral.cpp:872-946)
+  double sl_wL[2], sl_wR[2], sl_Nind[2];
+  int32_t rng_lo, rng_hi;           // freqRange 0-5000 in bins (flux)
+  float spec_floor, log_spec_floor, log_spec_factor;
+  // ---- cSpecResample -> cLpc -> cFormantLpc ----
+  const float *rs_cos, *rs_sin;     // [109 x 220] smileDsp_initIrdft's tables, transposed: [k/2 - 1][i]
+  float *lpc;                       // [total_frames20 x 12] 11 LP coefficients + pad
+  float *formants;                  // [total_frames20 x 10] 5 frequencies | 5 bandwidths
+  int64_t total_frames20;
+  double fm_T, fm_min, fm_max;      // sample period of the resampled signal, formant search range
+  // ---- 60 ms chain ----
+  double fsSec60;                   // frameSizeSec of the 60 ms spectrum level (frequency axis of cHarmonics)
+  const float *pitch3;              // [total_frames60 x 3] F0final, F0finalLog, voicing (after the energy gate)
+  const float *jit4;                // [total_frames60 x 4] cPitchJitter's outputs, jitterLocal in column 0
+  const float *shim_db;             // [total_frames60] shimmerLocalDB
+  float *harm6;                     // [total_frames60 x 6] cHarmonics' outputs
+  const int64_t *frame_off60;       // [n_utt+1]
+  const TileRec *tile60;            // tiles of <= 8 consecutive 60 ms frames
+  int32_t n_tiles60;
+  const int32_t *pending;           // [n_utt] frames the Viterbi pass had not decided at the end of input
+  // ---- smoothed levels ----
+  float *func_in;                   // [fin_off[n_utt] x 36], T20+1 rows per utterance that has a 60 ms frame:
+                                    //   loudness_sma3, flux_sma3, mfcc1..4_sma3 (6) | F0semitone_sma3nz (1) | lldSetNoF0AndLoudnessNz_smo (14) |
+                                    //   lldSetSpectralNz_smo (9) | lldSetSpectralZ_smo (5) | energy2 of the raw 20 ms frame (T20 rows)
+  const int64_t *fin_off;           // [n_utt+1] row offsets of func_in
+  int32_t *pending_j;               // [n_utt] P if P < T60 else 0: rows the jitter-gated functionals leave out
 };
 
 // Constants of cSpectral for one spectrum geometry (host-resolved in smilehip_plan.cpp)

@@ -7,6 +7,7 @@ smilehip_batch::~smilehip_batch() { delete f0_batch; }
 static inline bool compare_ab_like(const smilehip_plan *p) {
   return p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE;
 }
+static inline bool is_egemaps(const smilehip_plan *p) { return p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS; }
 
 extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, int32_t n_utt, smilehip_batch **out) {
   if (!plan || !out || n_utt < 0 || (n_utt > 0 && !h_off)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_create: bad argument");
@@ -46,6 +47,18 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
         run_utt.push_back(u);
         run_t0.push_back((int32_t)t0);
       }
+    }
+    if (is_egemaps(plan)) {
+      // rows = T60 + 1 (what both egemapsv02_lldsetE_smo and egemapsv02_lldsetF_smo hold); none without a 60 ms frame
+      const int64_t N60 = std::lround(0.060 / plan->geo.period);
+      const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
+      rows = (T60 >= 1) ? T60 + 1 : 0;
+      for (int64_t t0 = 0; t0 < T; t0 += compare_run_frames()) {
+        run_utt.push_back(u);
+        run_t0.push_back((int32_t)t0);
+      }
+      if (b->h_fin_off.empty()) b->h_fin_off.assign(size_t(n_utt) + 1, 0);
+      b->h_fin_off[u + 1] = b->h_fin_off[u] + (T60 >= 1 ? T + 1 : 0);
     }
     b->h_frame_off[u + 1] = b->h_frame_off[u] + T;
     b->h_row_off[u + 1] = b->h_row_off[u] + rows;
@@ -99,6 +112,36 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
     }
     (void)hipMemset(b->d_rawA.p, 0, nf * 4 * sizeof(float));
+  }
+  if (is_egemaps(plan)) {
+    b->n_runs = (int32_t)run_utt.size();
+    if (b->h_fin_off.empty()) b->h_fin_off.assign(size_t(n_utt) + 1, 0);
+    if ((rc = b->d_run_utt.upload(run_utt)) || (rc = b->d_run_t0.upload(run_t0)) || (rc = b->d_fin_off.upload(b->h_fin_off)) ||
+        (rc = smilehip_batch_create(plan->f0_plan, h_off, n_utt, &b->f0_batch))) {
+      delete b;
+      return rc;
+    }
+    const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
+    const size_t nf60 = size_t(b->f0_batch->total_frames ? b->f0_batch->total_frames : 1);
+    const size_t nfin = size_t(b->h_fin_off[n_utt] ? b->h_fin_off[n_utt] : 1);
+    auto alloc = [&](DevBuf<float> &d, size_t n) {
+      d.release();
+      if (hipMalloc(reinterpret_cast<void **>(&d.p), n * sizeof(float)) != hipSuccess) return false;
+      d.n = n;
+      return true;
+    };
+    if (!alloc(b->d_raw20, nf * 12) || !alloc(b->d_spec220, nf * 220) || !alloc(b->d_lpc, nf * 12) || !alloc(b->d_formants, nf * 10) ||
+        !alloc(b->d_pitch3, nf60 * 3) || !alloc(b->d_jit4, nf60 * 4) || !alloc(b->d_shim, nf60) || !alloc(b->d_harm6, nf60 * 6) ||
+        !alloc(b->d_func_in, nfin * 36)) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the eGeMAPS scratch matrices failed (%.1f GB needed)",
+                  double(nf * 254 + nf60 * 14 + nfin * 36) * 4e-9);
+    }
+    std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
+    if ((rc = b->d_pending_j.upload(zp))) {
+      delete b;
+      return rc;
+    }
   }
   if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
       plan->ctx && b->total_frames > 0) {
@@ -452,10 +495,14 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   // [is13_pitchSmoothViterbi]: wLocal 2, wTvv 10, wTvvd 5, wTvuv 10, wThr 4, wRange 1 -- but
   // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd (pitchSmootherViterbi.hpp:291-299): 10
   Q.vit_w[0] = 2.0; Q.vit_w[1] = 10.0; Q.vit_w[2] = 10.0; Q.vit_w[3] = 10.0; Q.vit_w[4] = 4.0; Q.vit_w[5] = 1.0;
+  Q.vit_buf = plan->cfg.vit_buffer_len > 0 ? plan->cfg.vit_buffer_len : 30;
+  Q.jit_search_range = plan->cfg.jitter_search_range > 0.0 ? plan->cfg.jitter_search_range : 0.25;
 }
 
-static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
-  if (ld_out < 2) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 2", (long long)ld_out);
+// log_out: rows [F0final, F0finalLog, voicingFinalUnclipped] (the eGeMAPS sub-chain, ld_out >= 3) instead of [F0final, voicing]
+static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream,
+                  bool log_out = false) {
+  if (ld_out < (log_out ? 3 : 2)) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld too small", (long long)ld_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
   LldParams P;
@@ -466,6 +513,7 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.e60 = b->d_e60.p;
   Q.hps_tap = b->d_hps_tap;
   Q.pending = b->d_pending.p;
+  Q.vit_log_out = log_out ? 1 : 0;
   hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
@@ -494,6 +542,94 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   hipError_t e = launch_f0_lld(P, Q, b->d_row_off.p, b->d_pitch2.p, b->d_jit4.p, d_out, ld_out, 0, 65, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 LLD kernel launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
+  return SMILEHIP_OK;
+}
+
+// SMILEHIP_CHAIN_EGEMAPS: the 20 ms kernels on the plan's side stream, the F0 group on the caller's; then cPitchJitter and
+// cHarmonics (which need the decided F0 contour, cHarmonics also the formants), then the selectors / smoothers
+static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *b, GemapsParams &G) {
+  std::memset(&G, 0, sizeof(G));
+  const smilehip_batch *fb = b->f0_batch;
+  G.run_utt = b->d_run_utt.p; G.run_t0 = b->d_run_t0.p;
+  G.raw20 = b->d_raw20.p; G.spec220 = b->d_spec220.p;
+  G.eql = plan->d_eql.p;
+  G.plp_melfloor = 0.00000000093f;     // cPlp melfloor default (plp.cpp:66), htkcompatible = 0
+  G.compression = 0.33f;
+  G.fsSec = plan->geo.fft_frame_size_sec;
+  for (int i = 0; i < 2; ++i) {
+    G.sl_iL[i] = plan->gm_sl_iL[i]; G.sl_iR[i] = plan->gm_sl_iR[i];
+    G.sl_wL[i] = plan->gm_sl_wL[i]; G.sl_wR[i] = plan->gm_sl_wR[i]; G.sl_Nind[i] = plan->gm_sl_Nind[i];
+  }
+  G.rng_lo = plan->gm_rng_lo; G.rng_hi = plan->gm_rng_hi;
+  G.spec_floor = plan->gm_spec_floor; G.log_spec_floor = plan->gm_log_spec_floor; G.log_spec_factor = plan->gm_log_spec_factor;
+  G.rs_cos = plan->d_rs_cos.p; G.rs_sin = plan->d_rs_sin.p;
+  G.lpc = b->d_lpc.p; G.formants = b->d_formants.p;
+  G.total_frames20 = b->total_frames;
+  G.fm_T = 1.0 / plan->gm_target_fs;   // cSpecResample::configureWriter: basePeriod = 1 / targetFs
+  G.fm_min = 50.0; G.fm_max = 5450.0;  // [gemapsv01b_formantLpc]
+  G.fsSec60 = plan->f0_plan->geo.fft_frame_size_sec;
+  G.pitch3 = b->d_pitch3.p; G.jit4 = b->d_jit4.p; G.shim_db = b->d_shim.p; G.harm6 = b->d_harm6.p;
+  G.frame_off60 = fb->d_frame_off.p;
+  G.tile60 = fb->d_tile_rec.p;
+  G.n_tiles60 = fb->n_tiles;
+  G.pending = fb->d_pending.p;
+  G.func_in = b->d_func_in.p;
+  G.fin_off = b->d_fin_off.p;
+  G.pending_j = b->d_pending_j.p;
+}
+
+static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
+  if (ld_out < 25) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 25", (long long)ld_out);
+  b->gm_ran = false;
+  if (b->total_frames == 0) { b->gm_ran = true; return SMILEHIP_OK; }
+  if (!d_pcm || (!d_out && b->total_rows > 0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  smilehip_batch *fb = b->f0_batch;
+  LldParams P;
+  fill_params(plan, b, d_pcm, d_out, ld_out, P);
+  GemapsParams G;
+  fill_gemaps_params(plan, b, G);
+  HIP_TRY(hipEventRecord(plan->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
+  hipError_t e = launch_gemaps_frames(P, G, b->n_runs, plan->side_stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS 20 ms kernels: launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
+  if (fb->total_frames > 0) {
+    int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch3.p, 3, stream, true);   // SHS candidates -> Viterbi -> energy gate
+    if (rc) return rc;
+    LldParams P60;
+    fill_params(plan->f0_plan, fb, d_pcm, nullptr, 0, P60);
+    F0Params Q;
+    fill_f0_params(plan->f0_plan, Q);
+    Q.jit_shim_db = b->d_shim.p;
+    e = launch_f0_jitter(P60, Q, b->d_pitch3.p, 3, b->d_jit4.p, s);
+    if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "jitter kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));                          // cHarmonics reads the formants
+    e = launch_gemaps_harm(P, Q, G, plan->ctx->prop.multiProcessorCount, s);
+    if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "harmonics kernel launch failed: %s", hipGetErrorString(e));
+  } else {
+    HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
+  }
+  e = launch_gemaps_tail(b->d_frame_off.p, b->d_row_off.p, b->n_utt, G, d_out, ld_out, s);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS tail kernel launch failed: %s", hipGetErrorString(e));
+  b->gm_ran = true;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_batch_egemaps_taps(smilehip_batch *b, const float **d_raw20, const float **d_lpc, const float **d_formants,
+                                           const float **d_pitch3, const float **d_jit4, const float **d_shim_db, const float **d_harm6,
+                                           const float **d_func_in, const int32_t **d_pending, int64_t *h_frame_off60) {
+  if (!b || !is_egemaps(b->plan)) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_egemaps_taps: not an eGeMAPS chain batch");
+  if (d_raw20) *d_raw20 = b->d_raw20.p;
+  if (d_lpc) *d_lpc = b->d_lpc.p;
+  if (d_formants) *d_formants = b->d_formants.p;
+  if (d_pitch3) *d_pitch3 = b->d_pitch3.p;
+  if (d_jit4) *d_jit4 = b->d_jit4.p;
+  if (d_shim_db) *d_shim_db = b->d_shim.p;
+  if (d_harm6) *d_harm6 = b->d_harm6.p;
+  if (d_func_in) *d_func_in = b->d_func_in.p;
+  if (d_pending) *d_pending = b->f0_batch->d_pending.p;
+  if (h_frame_off60) std::memcpy(h_frame_off60, b->f0_batch->h_frame_off.data(), b->f0_batch->h_frame_off.size() * sizeof(int64_t));
   return SMILEHIP_OK;
 }
 
@@ -575,6 +711,7 @@ extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const in
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB) return compare_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return f0_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return compare_full_run(plan, b, d_pcm, d_out, ld_out, stream);
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) return egemaps_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
 }
 

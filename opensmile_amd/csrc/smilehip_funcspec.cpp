@@ -419,3 +419,120 @@ static int functionals_compare_level(smilehip_plan *plan, smilehip_batch *b, con
   if (off != 6373) return fail(SMILEHIP_ERR_INVALID, "internal: ComParE_2016 functionals layout adds up to %d", off);
   return SMILEHIP_OK;
 }
+
+// ---- eGeMAPSv02: the functionals level (88 values per utterance)
+// config/gemaps/v01b/GeMAPSv01b_core.func.conf.inc + config/egemaps/v02/eGeMAPSv02_core.func.conf.inc
+extern "C" int smilehip_funcspec_egemaps(const char *instance, smilehip_func_spec *s) {
+  if (!instance || !s) return fail(SMILEHIP_ERR_INVALID, "smilehip_funcspec_egemaps: null argument");
+  std::memset(s, 0, sizeof(*s));
+  s->period = 0.01;
+  s->ext_norm = s->means_norm = s->times_norm = s->seg_norm = s->pk_norm = s->reg_centroid_norm = SMILEHIP_NORM_SEGMENT;
+  s->seg_max_num = 20; s->seg_min_lng = 3; s->seg_pause_min_lng = 2; s->lpc_order = 5;
+  const std::string k(instance);
+  if (k == "F0" || k == "Loudness") {
+    // Moments amean + stddevNorm (= 2); Percentiles 20 / 50 / 80 + range 0-2, interpolated; Peaks2 mean / stddev of the rising
+    // and falling slopes, in seconds, relThresh 0.1, doRatioLimit = 0; nonZeroFuncts = 1 for F0
+    s->n_fam = 3; s->fam[0] = SMILEHIP_FAM_MOMENTS; s->fam[1] = SMILEHIP_FAM_PERCENTILES; s->fam[2] = SMILEHIP_FAM_PEAKS2;
+    s->non_zero_functs = (k == "F0") ? 1 : 0;
+    s->mom_mask = (1u << 4) | (1u << 5); s->mom_stddev_norm = 2;
+    s->pct_interp = 1; s->n_pctl = 3; s->pctl[0] = 0.20; s->pctl[1] = 0.50; s->pctl[2] = 0.80;
+    s->n_range = 1; s->range_a[0] = 0; s->range_b[0] = 2;
+    s->pk_mask = (1u << 22) | (1u << 25) | (1u << 26) | (1u << 29);
+    s->pk_norm = SMILEHIP_NORM_SECOND; s->pk_rel_thresh = 0.1f;
+  } else if (k == "MVZ" || k == "MVV") {
+    s->n_fam = 1; s->fam[0] = SMILEHIP_FAM_MOMENTS;
+    s->non_zero_functs = (k == "MVV") ? 1 : 0;
+    s->mom_mask = (1u << 4) | (1u << 5); s->mom_stddev_norm = 2;
+  } else if (k == "MU") {
+    s->n_fam = 1; s->fam[0] = SMILEHIP_FAM_MOMENTS; s->non_zero_functs = 1; s->mom_mask = 1u << 4;
+  } else if (k == "numPeaks") {
+    s->n_fam = 1; s->fam[0] = SMILEHIP_FAM_PEAKS2; s->pk_mask = 1u; s->pk_norm = SMILEHIP_NORM_SECOND; s->pk_rel_thresh = 0.1f;
+    s->pk_ratio_limit = 1;
+  } else if (k == "segF0" || k == "segF0pause") {
+    const bool pause = k == "segF0pause";
+    s->n_fam = 1; s->fam[0] = SMILEHIP_FAM_SEGMENTS;
+    s->seg_mask = pause ? ((1u << 1) | (1u << 4)) : ((1u << 0) | (1u << 1) | (1u << 4));
+    s->seg_norm = SMILEHIP_NORM_SECOND; s->seg_algo = pause ? SMILEHIP_SEG_EQX : SMILEHIP_SEG_NONX; s->seg_max_num = 1000;
+    s->seg_min_lng = 3; s->seg_auto_min_lng = 1; s->seg_pause_min_lng = 2; s->seg_x = 0.0f;
+  } else if (k == "leq") {
+    s->n_fam = 1; s->fam[0] = SMILEHIP_FAM_MEANS; s->means_mask = 1u;
+  } else {
+    return fail(SMILEHIP_ERR_INVALID, "unknown eGeMAPSv02 functionals instance '%s' (F0, Loudness, MVZ, MVV, MU, numPeaks, segF0, "
+                "segF0pause, leq)", instance);
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_functionals_egemaps_count(void) { return 88; }
+
+namespace {
+// columns of the batch's func_in matrix (lld_params.hpp, GemapsParams::func_in); pend: 0 none, 1 the Viterbi smoother's
+// undecided frames P, 2 P if P < T60 else 0. Rows of func_in = T20 + 1 = T60 + 5.
+struct EgPart { const char *inst; int col_first, n_cols, rows_cut, pend; };
+const EgPart kEgemapsParts[] = {
+    {"F0", 6, 1, 5, 1},          // gemapsv01b_lld_single_logF0_smo                                max(1, T60 - P)
+    {"Loudness", 0, 1, 1, 0},    // gemapsv01b_loudness_smo                                        T20
+    {"MVZ", 1, 5, 1, 0},         // egemapsv02_lldSetNoF0AndLoudnessZ_smo                          T20
+    {"MVV", 7, 23, 5, 2},        // egemapsv02_lldSetNoF0AndLoudnessNz_smo; ..lldSetSpectralNz_smo T60 - P, T60 if P = T60
+    {"MU", 30, 5, 5, 1},         // egemapsv02_lldSetSpectralZ_smo                                 max(1, T60 - P)
+    {"numPeaks", 0, 1, 1, 0},    // gemapsv01b_temporalSet: loudnessPeaksPerSec
+    {"segF0", 6, 1, 5, 1},       //   VoicedSegmentsPerSec, MeanVoicedSegmentLengthSec, StddevVoicedSegmentLengthSec
+    {"segF0pause", 6, 1, 5, 1},  //   MeanUnvoicedSegmentLength, StddevUnvoicedSegmentLength
+    {"leq", 35, 1, 1, 0},        // egemapsv02_leqLin (amean of energy2), cVectorOperation dBp applied afterwards
+};
+}  // namespace
+
+extern "C" int smilehip_batch_functionals_egemaps(smilehip_plan *plan, smilehip_batch *b, float *d_func, int64_t ld_func, void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_egemaps: plan/batch mismatch");
+  if (plan->cfg.chain_kind != SMILEHIP_CHAIN_EGEMAPS)
+    return fail(SMILEHIP_ERR_INVALID, "the eGeMAPSv02 functionals are defined for smilehip_config_egemapsv02 plans");
+  if (!plan->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "smilehip_batch_functionals_egemaps: host-only plan");
+  if (ld_func < 88) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_egemaps: ld_func >= 88 required");
+  if (!d_func) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_egemaps: null device pointer");
+  if (b->n_utt == 0) return SMILEHIP_OK;
+  if (!b->gm_ran || !b->f0_batch) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_functionals_egemaps: run smilehip_lld_run on this batch first");
+  hipStream_t main = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(d_func, 0, size_t(b->n_utt) * size_t(ld_func) * sizeof(float), main));   // utterances without a 60 ms frame
+  const int64_t total_rows = b->h_fin_off[b->n_utt];
+  if (total_rows == 0) return SMILEHIP_OK;
+  int64_t max_rows = 0;
+  for (int u = 0; u < b->n_utt; ++u) max_rows = std::max(max_rows, b->h_fin_off[u + 1] - b->h_fin_off[u] + 1);
+  constexpr int kParts = sizeof(kEgemapsParts) / sizeof(kEgemapsParts[0]);
+  FsParams Ps[kParts];
+  FsNeed needs[kParts];
+  size_t offs[kParts], total = 0;
+  int off = 0;
+  for (int i = 0; i < kParts; ++i) {
+    const EgPart &part = kEgemapsParts[i];
+    FsParams &P = Ps[i];
+    std::memset(&P, 0, sizeof(P));
+    int rc = smilehip_funcspec_egemaps(part.inst, &P.spec);
+    if (rc) return rc;
+    const int per = spec_layout(&P.spec, nullptr, nullptr);
+    if (per < 0) return per;
+    P.x = b->d_func_in.p;
+    P.ld_x = 36;
+    P.col_first = part.col_first;
+    P.n_cols = part.n_cols;
+    P.row_off = b->d_fin_off.p;
+    P.single_rows = -1;
+    P.rows_cut = part.rows_cut;
+    P.pending = part.pend == 1 ? b->f0_batch->d_pending.p : (part.pend == 2 ? b->d_pending_j.p : nullptr);
+    P.out = d_func + off;
+    P.ld_out = ld_func;
+    needs[i] = spec_need(P, b->n_utt, total_rows + b->n_utt, max_rows);
+    offs[i] = total;
+    total += fs_bytes(P, needs[i]);
+    off += per * part.n_cols;
+  }
+  if (off != 88) return fail(SMILEHIP_ERR_INVALID, "internal: eGeMAPSv02 functionals layout adds up to %d", off);
+  int rc = fs_reserve(plan->ctx, total, main);
+  if (rc) return rc;
+  for (int i = 0; i < kParts; ++i) {
+    fs_carve(static_cast<char *>(plan->ctx->fs_scratch) + offs[i], Ps[i], needs[i]);
+    if ((rc = launch_spec(Ps[i], b->n_utt, main))) return rc;
+  }
+  hipError_t e = launch_gemaps_dbp(d_func + 87, ld_func, b->n_utt, b->d_fin_off.p, main);   // [egemapsv02_leq] dBp
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "dBp kernel launch failed: %s", hipGetErrorString(e));
+  return SMILEHIP_OK;
+}

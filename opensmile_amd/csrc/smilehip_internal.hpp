@@ -100,6 +100,12 @@ struct smilehip_plan {
   DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
   DevBuf<int32_t> d_f0_k;
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
+  // eGeMAPS chain: cSpecResample's tables (transposed), cSpectral's band-slope edges and frequency range
+  DevBuf<float> d_rs_cos, d_rs_sin;
+  int32_t gm_sl_iL[2] = {0, 0}, gm_sl_iR[2] = {0, 0}, gm_rng_lo = 0, gm_rng_hi = 0;
+  double gm_sl_wL[2] = {0, 0}, gm_sl_wR[2] = {0, 0}, gm_sl_Nind[2] = {0, 0};
+  float gm_spec_floor = 0.f, gm_log_spec_floor = 0.f, gm_log_spec_factor = 0.f;
+  double gm_target_fs = 0.0;
   int32_t band_iL[2] = {0, 0}, band_iR[2] = {0, 0};
   double band_wL[2] = {0, 0}, band_wR[2] = {0, 0}, slope_Sf = 0, slope_S2f = 0;
   // timing
@@ -137,6 +143,12 @@ struct smilehip_batch {
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance
   DevBuf<float> d_pitch2, d_jit4;         // whole-level chain: F0final/voicing (T60 x 2) and jitter/shimmer/HNR (T60 x 4)
   smilehip_batch *f0_batch = nullptr;     // whole-level chain: the 60 ms sub-chain's batch
+  // eGeMAPS chain scratch (lld_gemaps.hip)
+  DevBuf<float> d_raw20, d_spec220, d_lpc, d_formants, d_pitch3, d_shim, d_harm6, d_func_in;
+  DevBuf<int32_t> d_pending_j;
+  DevBuf<int64_t> d_fin_off;              // [n_utt+1] rows of func_in: T20 + 1 per utterance with a 60 ms frame
+  std::vector<int64_t> h_fin_off;
+  bool gm_ran = false;
   ~smilehip_batch();
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;

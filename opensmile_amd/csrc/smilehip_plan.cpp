@@ -114,6 +114,26 @@ extern "C" void smilehip_config_is13_compare(smilehip_lld_config *c) {
   c->jitter_broken_thresh = 1;
 }
 
+// config/egemaps/v02/eGeMAPSv02.conf: the 20 ms chain of GeMAPSv01b_core.lld.conf.inc ([gemapsv01b_frame25] 20 ms / 10 ms,
+// Hamming, symmetric zero padding, 26 mel bands from 20 Hz; [egemapsv02_mfcc] 1..4, lifter 22); the 60 ms sub-chain is
+// created by smilehip_plan_create
+extern "C" void smilehip_config_egemapsv02(smilehip_lld_config *c) {
+  smilehip_config_compare16_ab(c);
+  c->chain_kind = SMILEHIP_CHAIN_EGEMAPS;
+  c->first_mfcc = 1;
+  c->last_mfcc = 4;
+  c->n_delta = 0;
+  c->sma_win = 3;
+  c->pitch_min = 55.0;               // [gemapsv01b_shs]
+  c->pitch_max = 1000.0;
+  c->voicing_cutoff = 0.7;
+  c->shs_n_harmonics = 15;
+  c->shs_compression = 0.85f;
+  c->f0_min_energy = 0.001f;         // [gemapsv01b_volmerge]
+  c->vit_buffer_len = 40;            // [gemapsv01b_pitchSmoothViterbi] bufferLength
+  c->jitter_search_range = 0.1;      // [gemapsv01b_pitchJitter] searchRangeRel
+}
+
 static inline bool is_compare_ab_like(const smilehip_lld_config &c) {
   return c.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || c.chain_kind == SMILEHIP_CHAIN_COMPARE;
 }
@@ -148,6 +168,10 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
         p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
       return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
+  } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) {
+    if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 4 || p->mel.n_bands != 26 || p->cfg.n_delta != 0 || p->cfg.sma_win != 3 ||
+        !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512 || p->geo.N != 320)
+      return fail(SMILEHIP_ERR_INVALID, "eGeMAPS chain: unsupported parameter set (20 ms frames at 16 kHz, 26 bands, MFCC 1..4)");
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_PLP) {
     if (mask != SMILEHIP_STAGE_ALL || p->cfg.plp_lp_order < 1 || p->cfg.plp_lp_order > 15 || !p->cfg.mel_htk_compatible ||
         !p->cfg.use_power || p->mel.n_bands > 30 || p->cfg.plp_compression < 0.0f)
@@ -238,6 +262,96 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       ((rc = p->d_f0_rec.upload(p->f0.sp_rec)) || (rc = p->d_f0_d1.upload(p->f0.sp_d1)) || (rc = p->d_f0_d2.upload(p->f0.sp_d2)) ||
        (rc = p->d_f0_co.upload(p->f0.ip_co)) || (rc = p->d_f0_audw.upload(p->f0.audw)) || (rc = p->d_f0_k.upload(p->f0.ip_k))))
     return rc;
+  if (p->cfg.vit_buffer_len < 0 || p->cfg.vit_buffer_len == 1 || p->cfg.vit_buffer_len > 40)
+    return fail(SMILEHIP_ERR_INVALID, "vit_buffer_len must be 0 (= 30) or 2..40");
+  if (p->cfg.jitter_search_range < 0.0 || p->cfg.jitter_search_range >= 1.0)
+    return fail(SMILEHIP_ERR_INVALID, "jitter_search_range must be in [0, 1)");
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) {
+    // [gemapsv01b_audspec]: equal-loudness weights at the band centres (plp.cpp:335-357)
+    std::vector<float> eql(26);
+    for (int m = 1; m <= 26; ++m) {
+      const double hz = 700.0 * (std::exp(double(p->mel.centres[m]) / 1127.0) - 1.0);
+      const double w = 2.0 * M_PI * hz, w2 = w * w, c = w2 + 6300000.0;
+      eql[m - 1] = float((c > 0.0) ? (1e32 * ((w2 + 56.8e6) * w2 * w2) / (c * c * (w2 + 0.38e9) * (w2 * w2 * w2 * w + 1.7e31))) : 0.0);
+    }
+    if ((rc = p->d_eql.upload(eql))) return rc;
+    // [gemapsv01b_logSpectral]: slopes 0-500 and 500-1500 Hz of the log spectrum (spectral.cpp:872-946), freqRange 0-5000
+    // (:625-644), specFloor 1e-7 squared and its log (:228-235)
+    const int Nsrc = (int)p->geo.K;
+    const double F0 = 1.0 / p->geo.fft_frame_size_sec;
+    const int lo_hz[2] = {0, 500}, hi_hz[2] = {500, 1500};
+    for (int b = 0; b < 2; ++b) {
+      int ii;
+      double wghtL, wghtR, idxL, idxR;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)lo_hz[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)lo_hz[b]) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
+      idxL = (double)ii - 1.0;
+      if (idxL < 0) idxL = 0;
+      if (idxL >= Nsrc) idxL = Nsrc;
+      if (wghtL == 0.0) wghtL = 1.0;
+      for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)hi_hz[b]) break;
+      if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi_hz[b] - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
+      if ((ii < Nsrc) && (F0 * ii == (float)hi_hz[b])) idxR = (double)ii; else idxR = (double)ii - 1.0;
+      if (idxR >= Nsrc) idxR = Nsrc - 1;
+      if (wghtR == 0.0) wghtR = 1.0;
+      int iL = (int)std::floor(idxL), iR = (int)std::floor(idxR);
+      if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+      if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+      if (iL < 0) iL = 0;
+      if (iR < 0) iR = 0;
+      if (iR - iL >= 64 || iR >= 64) return fail(SMILEHIP_ERR_INVALID, "eGeMAPS chain: slope band wider than the kernel's 64 bins");
+      p->gm_sl_iL[b] = iL; p->gm_sl_iR[b] = iR; p->gm_sl_wL[b] = wghtL; p->gm_sl_wR[b] = wghtR; p->gm_sl_Nind[b] = idxR - idxL;
+    }
+    int lo = -1, hi = -1;
+    for (int i = 0; i < Nsrc; i++) {
+      if ((double)0 >= F0 * i) lo = i;
+      if ((double)5000 > F0 * i) hi = i;
+    }
+    if (hi == -1 || hi >= Nsrc) hi = Nsrc - 1;
+    if (lo < 0) lo = 0;
+    p->gm_rng_lo = lo; p->gm_rng_hi = hi;
+    float specFloor = (float)0.0000001;
+    specFloor = specFloor * specFloor;
+    p->gm_spec_floor = specFloor;
+    p->gm_log_spec_floor = (float)(10.0 * (double)std::log(specFloor) / std::log(10.0));
+    p->gm_log_spec_factor = (float)(10.0 / std::log(10.0));
+    // [gemapsv01b_resampLpc]: cSpecResample::setupNewNames (specResample.cpp:117-172) + smileDsp_initIrdft
+    // (smileUtil.c:1752-1786) for the Nfft-value complex spectrum, targetFs = 11000; the tables transposed to [k/2 - 1][i]
+    {
+      const long n_in = (long)p->geo.Nfft;
+      const double fs_sec = p->geo.fft_frame_size_sec, last_fs_sec = (double)p->geo.N * p->geo.period, bT = p->geo.period;
+      const double sr = 1.0 / bT;
+      double target_fs = 11000.0, ratio = target_fs / sr, nd;
+      long n_out;
+      if ((fs_sec != last_fs_sec) && (last_fs_sec != 0.0) && (last_fs_sec != bT)) {
+        const double nout0 = std::round((double)n_in * ratio * last_fs_sec / fs_sec);
+        const double new_ratio = nout0 / ((double)n_in * (last_fs_sec / fs_sec));
+        n_out = (long)nout0;
+        if (new_ratio != ratio) { target_fs = sr * new_ratio; ratio = new_ratio; }
+        nd = (double)n_in * ratio;
+      } else {
+        const double nout0 = std::round((double)n_in * ratio);
+        const double new_ratio = nout0 / (double)n_in;
+        n_out = (long)nout0;
+        if (new_ratio != ratio) { target_fs = sr * new_ratio; ratio = new_ratio; }
+        nd = nout0;
+      }
+      long kMax = n_in > n_out ? n_out : n_in;
+      if (kMax & 1) kMax--;
+      if (n_out != 220 || kMax / 2 - 1 != 109 || n_out >= n_in)
+        return fail(SMILEHIP_ERR_INVALID, "eGeMAPS chain: cSpecResample geometry %ld -> %ld is not the one the kernel is built for", n_in, n_out);
+      p->gm_target_fs = target_fs;
+      std::vector<float> ct(size_t(109) * 220), st(size_t(109) * 220);
+      const double pi2 = 2.0 * M_PI;
+      for (long i = 0; i < n_out; i++)
+        for (long k = 2; k < kMax; k += 2) {
+          const double kn = pi2 * (double)(k / 2 * i) / nd;
+          ct[size_t(k / 2 - 1) * 220 + i] = (float)std::cos(kn);
+          st[size_t(k / 2 - 1) * 220 + i] = (float)std::sin(kn);
+        }
+      if ((rc = p->d_rs_cos.upload(ct)) || (rc = p->d_rs_sin.upload(st))) return rc;
+    }
+  }
   if (is_compare_ab_like(p->cfg)) {
     // cPlp::initTables (plp.cpp:335-402): equal-loudness weights at the band centres cMelspec
     // publishes as metadata (melspec.cpp:408-412), and the newRASTA filter coefficients
@@ -345,6 +459,23 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
                               hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
       rc = fail(SMILEHIP_ERR_HIP, "could not create the side stream of the ComParE chain");
   }
+  if (rc == SMILEHIP_OK && cfg->chain_kind == SMILEHIP_CHAIN_EGEMAPS) {      // the 60 ms sub-chain of GeMAPSv01b_core.lld.conf.inc
+    smilehip_lld_config c60;
+    smilehip_config_compare16_f0(&c60);
+    c60.sample_rate = cfg->sample_rate;
+    c60.frame_step_sec = cfg->frame_step_sec;
+    c60.zero_pad_symmetric = cfg->zero_pad_symmetric;
+    c60.pitch_min = cfg->pitch_min; c60.pitch_max = cfg->pitch_max; c60.voicing_cutoff = cfg->voicing_cutoff;
+    c60.shs_n_harmonics = cfg->shs_n_harmonics; c60.shs_compression = cfg->shs_compression;
+    c60.f0_min_energy = cfg->f0_min_energy;
+    c60.vit_buffer_len = cfg->vit_buffer_len;
+    c60.jitter_search_range = cfg->jitter_search_range;
+    rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
+    if (rc == SMILEHIP_OK && (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
+      rc = fail(SMILEHIP_ERR_HIP, "could not create the side stream of the eGeMAPS chain");
+  }
   if (rc != SMILEHIP_OK) {
     delete p;
     return rc;
@@ -376,6 +507,7 @@ extern "C" void smilehip_plan_destroy(smilehip_plan *plan) { delete plan; }
 int plan_n_static(const smilehip_plan *p) {
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) return 2;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return 65;
+  if (p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) return 25;
   return p->cfg.chain_kind == SMILEHIP_CHAIN_IS09 ? 16
          : (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_AB ? 59 : p->dct.n_mfcc + (p->cfg.append_log_energy ? 1 : 0));
 }
