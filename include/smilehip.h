@@ -582,6 +582,35 @@ int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld
  * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
  * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */
 int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W, void *stream);
+/* ---- GeMAPS / eGeMAPS components, per component, on an eGeMAPS plan (smilehip_config_egemapsv02: 16 kHz, 20 ms Hamming frames
+ * -> 512-point spectrum; 60 ms frames -> 1024-point spectrum). Rows in, rows out, like the operators above. */
+/* cSpectral::processVector (src/lldcore/spectral.cpp:586-1254) with the GeMAPS option sets -- squareInput = 1, useLogSpectrum = 1,
+ * specFloor 1e-7, freqRange 0-5000: [gemapsv01b_logSpectral]'s four outputs in its own order (logSpectralSlopeOfBand0-500,
+ * ..500-1500, alphaRatioDB, hammarbergIndexDB) followed by [egemapsv02_logSpectral_flux]'s spectralFlux: 5 values per frame of
+ * K = 257 magnitudes. The frames of ONE stream in order; d_state (K floats) carries the previous frame's magnitudes across
+ * calls, `first` != 0 marks the stream's first frame (flux 0). */
+int smilehip_spectral_gemaps_frames(smilehip_plan *plan, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                                    float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* cSpecResample::processVector (src/dsp/specResample.cpp:175-185, smileDsp_irdft src/smileutil/smileUtil.c:1800-1820) for
+ * [gemapsv01b_resampLpc] (targetFs 11000): the Nfft-value complex spectrum of a 20 ms frame (Ooura packing, level
+ * gemapsv01b_fftcH25) -> 220 samples at 11 kHz; every output's float sum in the reference's order. */
+int smilehip_specresample_frames(smilehip_plan *plan, const float *d_spec, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                 int64_t n_frames, void *stream);
+/* cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, p = 11, saveLPCoeff only: smileDsp_autoCorr + Durbin
+ * (smileUtil.c:1560-1630) on 220 samples -> 11 coefficients */
+int smilehip_lpc_frames(smilehip_plan *plan, const float *d_x, int64_t ld_src, float *d_lpc, int64_t ld_dst, int64_t n_frames,
+                        void *stream);
+/* cFormantLpc::processVector (src/lld/formantLpc.cpp:192-290): nFormants = 5, saveFormants = saveBandwidths = 1, minF 50,
+ * maxF 5450, no median filter / octave correction; roots of the LP polynomial by the reference's balanced companion-matrix
+ * QR iteration (src/smileutil/zerosolve.cpp): 11 coefficients -> [5 frequencies | 5 bandwidths] */
+int smilehip_formantlpc_frames(smilehip_plan *plan, const float *d_lpc, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                               int64_t n_frames, void *stream);
+/* cHarmonics::processVector (src/lld/harmonics.cpp:743-1031) with [gemapsv01b_harmonics]'s options: per row F0 (Hz; 0 =
+ * unvoiced), the 10 values of level gemapsv01b_formants and the 513 magnitudes of the 60 ms frame -> 6 values
+ * [HarmonicsToNoiseRatioACFLogdB, HarmonicDifferenceLogRelH1-H2, ..H1-A3, FormantAmplitudeByMaxHarmonicLogRelF0[1..3]] */
+int smilehip_harmonics_frames(smilehip_plan *plan, const float *d_f0, const float *d_formants, int64_t ld_formants,
+                              const float *d_mag, int64_t ld_mag, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+
 /* R13: n_orders chained cDeltaRegression::processBuffer (deltaRegression.cpp:
  * 113-170) with the reference's end-of-input semantics, per utterance of the
  * batch; reads columns [0,D) of d_io rows, writes columns [D, D*(1+n_orders)). */

@@ -117,6 +117,11 @@ SYMBOLS = {
     "smilehip_functionals_egemaps_count": (C.c_int, []),
     "smilehip_batch_functionals_egemaps": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_batch_egemaps_taps": (C.c_int, [_vp] + [C.POINTER(_vp)] * 9 + [_vp]),
+    "smilehip_spectral_gemaps_frames": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp, _i64, _i64, _vp]),
+    "smilehip_specresample_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_lpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_formantlpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_harmonics_frames": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -238,6 +243,83 @@ def funcspec_egemaps(instance):
     s = FuncSpec()
     _check(load().smilehip_funcspec_egemaps(instance.encode(), C.byref(s)))
     return s
+
+
+def rows_op_host(ctx, fn, handle, inputs, out_cols, pre=(), post=()):
+    """Run a rows-in / rows-out operator on host matrices: inputs = list of 2-D float32 arrays (each uploaded, passed as
+    pointer + leading dimension), output n x out_cols. pre / post: extra scalar arguments before / after."""
+    L = load()
+    inputs = [np.ascontiguousarray(a, dtype=np.float32) for a in inputs]
+    n = inputs[0].shape[0]
+    out = np.zeros((n, out_cols), np.float32)
+    ptrs = []
+    d_out = _vp()
+    try:
+        for a in inputs:
+            d = _vp()
+            _check(L.smilehip_alloc(ctx._h, max(a.nbytes, 4), C.byref(d)))
+            ptrs.append(d)
+            if a.nbytes:
+                _check(L.smilehip_copy_to_device(ctx._h, d, a.ctypes.data, a.nbytes, None))
+        _check(L.smilehip_alloc(ctx._h, max(out.nbytes, 4), C.byref(d_out)))
+        args = [handle] + list(pre)
+        for a, d in zip(inputs, ptrs):
+            args += [d] + ([a.shape[1]] if a.ndim == 2 else [])
+        args += [d_out, out_cols, n] + list(post) + [None]
+        _check(fn(*args))
+        _check(L.smilehip_stream_synchronize(ctx._h, None))
+        if out.nbytes:
+            _check(L.smilehip_copy_to_host(ctx._h, out.ctypes.data, d_out, out.nbytes, None))
+    finally:
+        for d in ptrs:
+            L.smilehip_free(ctx._h, d)
+        L.smilehip_free(ctx._h, d_out)
+    return out
+
+
+def specresample_host(plan, spec):
+    return rows_op_host(plan.ctx, load().smilehip_specresample_frames, plan._h, [spec], 220)
+
+
+def lpc_host(plan, x):
+    return rows_op_host(plan.ctx, load().smilehip_lpc_frames, plan._h, [x], 11)
+
+
+def formantlpc_host(plan, lpc):
+    return rows_op_host(plan.ctx, load().smilehip_formantlpc_frames, plan._h, [lpc], 10)
+
+
+def harmonics_host(plan, f0, formants, mag):
+    f0 = np.ascontiguousarray(f0, dtype=np.float32).reshape(-1)
+    return rows_op_host(plan.ctx, load().smilehip_harmonics_frames, plan._h, [f0, formants, mag], 6)
+
+
+def spectral_gemaps_host(plan, mag):
+    """The frames of one stream (rows of mag, K = 257) -> n x 5."""
+    L = load()
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    n, K = mag.shape
+    out = np.zeros((n, 5), np.float32)
+    d_in, d_out, d_st = _vp(), _vp(), _vp()
+    ctx = plan.ctx
+    _check(L.smilehip_alloc(ctx._h, max(mag.nbytes, 4), C.byref(d_in)))
+    _check(L.smilehip_alloc(ctx._h, max(out.nbytes, 4), C.byref(d_out)))
+    _check(L.smilehip_alloc(ctx._h, K * 4, C.byref(d_st)))
+    try:
+        if mag.nbytes:
+            _check(L.smilehip_copy_to_device(ctx._h, d_in, mag.ctypes.data, mag.nbytes, None))
+        half = n // 2                       # two calls: the state buffer carries the flux across them
+        _check(L.smilehip_spectral_gemaps_frames(plan._h, d_in, K, d_st, 1, d_out, 5, half, None))
+        _check(L.smilehip_spectral_gemaps_frames(plan._h, d_in.value + half * K * 4, K, d_st, 1 if half == 0 else 0,
+                                                 d_out.value + half * 5 * 4, 5, n - half, None))
+        _check(L.smilehip_stream_synchronize(ctx._h, None))
+        if out.nbytes:
+            _check(L.smilehip_copy_to_host(ctx._h, out.ctypes.data, d_out, out.nbytes, None))
+    finally:
+        L.smilehip_free(ctx._h, d_in)
+        L.smilehip_free(ctx._h, d_out)
+        L.smilehip_free(ctx._h, d_st)
+    return out
 
 
 def funcspec_is13_compare(instance):

@@ -60,6 +60,83 @@ __device__ __forceinline__ double quad3(double x1, double y1, double x2, double 
 }
 }  // namespace
 
+// cSpectral::processVector with the GeMAPS option sets, one wave per frame: [gemapsv01b_logSpectral] (slopes 0-500 and
+// 500-1500 Hz of the log spectrum, alpha ratio, Hammarberg index) and [egemapsv02_logSpectral_flux] (flux over freqRange
+// 0-5000 Hz); squareInput = 1, useLogSpectrum = 1, specFloor 1e-7. mg / pw: magnitudes and powers of the K bins, prev: the
+// previous frame's magnitudes (ignored when first), lg: 64 floats of LDS scratch. dst5 (lane 0 writes): slope0-500,
+// slope500-1500, alphaRatioDB, hammarbergIndexDB, spectralFlux.
+__device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const float *pw, const float *prev, bool first, float *lg,
+                                                     const GemapsParams &G, int K, int lane, float *dst5) {
+  const double F0 = 1.0 / G.fsSec;                       // frq[i] = F0 * i (transformFft.cpp:102-117)
+  // log power spectrum of the bins the two slopes cover (spectral.cpp:689-716): factor 10/ln 10 as float, floor at specFloor^2
+  {
+    const float p = pw[lane];
+    lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log((double)p);
+  }
+  WaveG::sync();
+  // band slopes of the log spectrum (spectral.cpp:872-992), frequency axis given: four double sums per band
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int iL = G.sl_iL[b], iR = G.sl_iR[b];
+    const double wL = G.sl_wL[b], wR = G.sl_wR[b];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};                // Sf, S2f, sumA, sumB
+    const int j = iL + lane;
+    if (j <= iR) {
+      const double f = F0 * (double)j, l = (double)lg[j];
+      if (j == iL) { const double fw = f * wL; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wL * l; }
+      else if (j == iR) { const double fw = f * wR; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wR * l; }
+      else { v[0] = f; v[1] = f * f; v[2] = f * l; v[3] = l; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = WaveG::sum(v[q], nullptr);
+    if (lane == 0) {
+      const double Nind = G.sl_Nind[b];
+      const double deno = (Nind * v[1] - v[0] * v[0]);
+      double slope = 0.0;
+      if (deno != 0.0) slope = (Nind * v[2] - v[0] * v[3]) / deno;
+      dst5[b] = (float)slope;                       // oldSlopeScale = 0
+    }
+  }
+  // alpha ratio (:995-1037) and Hammarberg index (:1039-1089) over the bins up to 5000 Hz, flux (:1124-1254) over freqRange
+  {
+    double s01 = 0.0, s15 = 0.0, fl = 0.0;
+    float m02 = 0.0f, m25 = 0.0f;
+    for (int j = lane; j < K; j += 64) {
+      const double f = F0 * (double)j;
+      if (f > 5000.0) break;
+      const float p = pw[j];
+      if (f < 1000.0) s01 += (double)p; else s15 += (double)p;
+      if (f < 2000.0) m02 = p > m02 ? p : m02; else m25 = p > m25 ? p : m25;
+    }
+    for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
+      const double myB = (double)mg[j] - (double)prev[j];
+      fl += myB * myB;
+    }
+    s01 = WaveG::sum(s01, nullptr); s15 = WaveG::sum(s15, nullptr); fl = WaveG::sum(fl, nullptr);
+    for (int o = 32; o > 0; o >>= 1) {
+      float w = __shfl_xor(m02, o); m02 = w > m02 ? w : m02;
+      w = __shfl_xor(m25, o); m25 = w > m25 ? w : m25;
+    }
+    if (lane == 0) {
+      const float sum01 = (float)s01, sum15 = (float)s15;
+      float a = 0.0f, h = 0.0f;
+      if (sum01 > 0.0f) {
+        if (sum15 > G.spec_floor) a = (float)(10.0 * (double)(float)log((double)(sum15 / sum01)) / log(10.0));
+        else a = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)sum01)) / log(10.0));
+      }
+      if (m25 > 0.0f) {
+        if (m02 > G.spec_floor) h = (float)(10.0 * (double)(float)log((double)(m02 / m25)) / log(10.0));
+        else h = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)m25)) / log(10.0));
+      }
+      dst5[2] = a;
+      dst5[3] = h;
+      const int nBins = G.rng_hi - G.rng_lo + 1;
+      const double flux = (nBins > 0) ? fl / (double)nBins : 0.0;
+      dst5[4] = (!first && flux > 0.0) ? (float)sqrt(flux) : 0.0f;      // first frame of a stream: 0 (:1132-1136)
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ 20 ms frames
 // LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave yv[Npad] | re[M] | im[M] | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // lg[64] | mel[32] | aud[32] | lmel[32]
@@ -97,7 +174,6 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   const int64_t f0 = P.frame_off[u];
   const int T20 = (int)(P.frame_off[u + 1] - f0);
   const int16_t *xu = P.pcm + P.samp_off[u];
-  const double F0 = 1.0 / G.fsSec;                       // frq[i] = F0 * i (transformFft.cpp:102-117)
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     const bool warm = t < t0;
@@ -132,11 +208,6 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       WaveG::sync();
       continue;
     }
-    // log power spectrum of the bins the two slopes cover (spectral.cpp:689-716): factor 10/ln 10 as float, floor at specFloor^2
-    {
-      const float p = pw[lane];
-      lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log((double)p);
-    }
     // R6 once, two scalings: [gemapsv01b_melspec1] (htk = 0) feeds cPlp, [egemapsv02_melspecMfcc] (htk = 1) feeds cMfcc
     if (lane < P.n_bands) {
       const int b = lane;
@@ -159,68 +230,8 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       d = WaveG::sum(d, nullptr);
       if (lane == 0) raw[10] = (float)(d / (double)P.N) * 1.0f + 0.0f;
     }
-    // band slopes of the log spectrum (spectral.cpp:872-992), frequency axis given: four double sums per band
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int iL = G.sl_iL[b], iR = G.sl_iR[b];
-      const double wL = G.sl_wL[b], wR = G.sl_wR[b];
-      double v[4] = {0.0, 0.0, 0.0, 0.0};                // Sf, S2f, sumA, sumB
-      const int j = iL + lane;
-      if (j <= iR) {
-        const double f = F0 * (double)j, l = (double)lg[j];
-        if (j == iL) { const double fw = f * wL; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wL * l; }
-        else if (j == iR) { const double fw = f * wR; v[0] = fw; v[1] = fw * fw; v[2] = fw * l; v[3] = wR * l; }
-        else { v[0] = f; v[1] = f * f; v[2] = f * l; v[3] = l; }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = WaveG::sum(v[q], nullptr);
-      if (lane == 0) {
-        const double Nind = G.sl_Nind[b];
-        const double deno = (Nind * v[1] - v[0] * v[0]);
-        double slope = 0.0;
-        if (deno != 0.0) slope = (Nind * v[2] - v[0] * v[3]) / deno;
-        raw[1 + b] = (float)slope;                       // oldSlopeScale = 0
-      }
-    }
-    // alpha ratio (:995-1037) and Hammarberg index (:1039-1089) over the bins up to 5000 Hz, flux (:1124-1254) over freqRange
-    {
-      double s01 = 0.0, s15 = 0.0, fl = 0.0;
-      float m02 = 0.0f, m25 = 0.0f;
-      for (int j = lane; j < K; j += 64) {
-        const double f = F0 * (double)j;
-        if (f > 5000.0) break;
-        const float p = pw[j];
-        if (f < 1000.0) s01 += (double)p; else s15 += (double)p;
-        if (f < 2000.0) m02 = p > m02 ? p : m02; else m25 = p > m25 ? p : m25;
-      }
-      for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
-        const double myB = (double)mg[j] - (double)prev[j];
-        fl += myB * myB;
-      }
-      s01 = WaveG::sum(s01, nullptr); s15 = WaveG::sum(s15, nullptr); fl = WaveG::sum(fl, nullptr);
-      for (int o = 32; o > 0; o >>= 1) {
-        float w = __shfl_xor(m02, o); m02 = w > m02 ? w : m02;
-        w = __shfl_xor(m25, o); m25 = w > m25 ? w : m25;
-      }
-      if (lane == 0) {
-        const float sum01 = (float)s01, sum15 = (float)s15;
-        float a = 0.0f, h = 0.0f;
-        if (sum01 > 0.0f) {
-          if (sum15 > G.spec_floor) a = (float)(10.0 * (double)(float)log((double)(sum15 / sum01)) / log(10.0));
-          else a = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)sum01)) / log(10.0));
-        }
-        if (m25 > 0.0f) {
-          if (m02 > G.spec_floor) h = (float)(10.0 * (double)(float)log((double)(m02 / m25)) / log(10.0));
-          else h = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)m25)) / log(10.0));
-        }
-        raw[3] = a;
-        raw[4] = h;
-        const int nBins = G.rng_hi - G.rng_lo + 1;
-        const double flux = (nBins > 0) ? fl / (double)nBins : 0.0;
-        raw[5] = (t > 0 && flux > 0.0) ? (float)sqrt(flux) : 0.0f;       // first frame of a stream: 0 (:1132-1136)
-        raw[11] = 0.0f;
-      }
-    }
+    gemaps_spectral_wave(mg, pw, prev, t == 0, lg, G, K, lane, raw + 1);
+    if (lane == 0) raw[11] = 0.0f;
     WaveG::sync();
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
@@ -238,13 +249,23 @@ __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t g0 = (int64_t)blockIdx.x * kLpcTile;
-  const int n_fr = (int)((G.total_frames20 - g0 < kLpcTile) ? G.total_frames20 - g0 : kLpcTile);
+  const int64_t n_all = G.op_mode ? G.op_rows : G.total_frames20;
+  const int n_fr = (int)((n_all - g0 < kLpcTile) ? n_all - g0 : kLpcTile);
   for (int i = threadIdx.x; i < kLpcTile * kRsI; i += 256) {
     const int f = i / kRsI, c = i - f * kRsI;
-    xs[f][c] = (f < n_fr) ? G.spec220[(g0 + f) * kRsI + c] : 0.0f;
+    float v = 0.0f;
+    if (f < n_fr) {
+      if (G.op_mode == 0) v = G.spec220[(g0 + f) * kRsI + c];
+      else if (G.op_mode == 2) v = G.op_in[(g0 + f) * G.op_ld_in + c];                       // the resampled signal itself
+      else {                                                                                  // Ooura-packed spectrum row
+        const float *a = G.op_in + (g0 + f) * G.op_ld_in;
+        v = (c < 2 * kRsB) ? a[c + 2] : (c == 2 * kRsB ? a[0] : 0.0f);
+      }
+    }
+    xs[f][c] = v;
   }
   __syncthreads();
-  {
+  if (G.op_mode != 2) {
     constexpr int FW = kLpcTile / 4;                     // frames per wave
     const int fw = wave * FW;
     float acc[FW][4];
@@ -281,6 +302,13 @@ __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
         if (o < 3 || o3) xs[fw + f][lane + 64 * o] = acc[f][o] / (float)256;   // /= (FLOAT_DMEM)(K/2), K = 512 inputs
   }
   __syncthreads();
+  if (G.op_mode == 1) {                                  // cSpecResample alone: the resampled frames are the output
+    for (int i = threadIdx.x; i < n_fr * kRsI; i += 256) {
+      const int f = i / kRsI, c = i - f * kRsI;
+      G.op_out[(g0 + f) * G.op_ld_out + c] = xs[f][c];
+    }
+    return;
+  }
   // smileDsp_autoCorr (smileUtil.c:1560-1570): r[lag] = sum_{i >= lag} x[i] * x[i-lag], float, ascending i
   for (int task = threadIdx.x; task < kLpcTile * (kLpcP + 1); task += 256) {
     const int f = task / (kLpcP + 1), lag = task - f * (kLpcP + 1);
@@ -318,10 +346,10 @@ __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
         }
       }
     }
-    float *o = G.lpc + (g0 + threadIdx.x) * 12;
+    float *o = G.lpc + (g0 + threadIdx.x) * G.lpc_ld;
 #pragma unroll
     for (int i = 0; i < kLpcP; ++i) o[i] = a[i];
-    o[kLpcP] = 0.0f;
+    if (G.lpc_ld > kLpcP) o[kLpcP] = 0.0f;
   }
 }
 
@@ -467,8 +495,8 @@ __device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, z
 // roots member held before (the previous frame's values); a frame here starts from zeros instead (not observed on speech).
 __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
   const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (g >= G.total_frames20) return;
-  const float *lp = G.lpc + g * 12;
+  if (g >= (G.op_mode ? G.op_rows : G.total_frames20)) return;
+  const float *lp = G.lpc + g * G.lpc_ld;
   double mat[kNC * kNC], roots[2 * kNC], fc[5], bc[5];
   for (int i = 0; i < kNC * kNC; ++i) mat[i] = 0.0;
   for (int i = 0; i < 2 * kNC; ++i) roots[i] = 0.0;
@@ -515,7 +543,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
         double t = fc[j]; fc[j] = fc[i]; fc[i] = t;
         t = bc[j]; bc[j] = bc[i]; bc[i] = t;
       }
-  float *o = G.formants + g * 10;
+  float *o = G.formants + g * G.fm_ld;
   for (int i = 0; i < 5; i++) { o[i] = (float)fc[i]; o[5 + i] = (float)bc[i]; }
 }
 #undef GM_MATC
@@ -578,20 +606,25 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
   float *hlr = hmag + 128;
   const double Fb = 1.0 / G.fsSec60;                     // frequency axis of the 60 ms spectrum: frq[i] = Fb * i
   const int tile_stride = (int)gridDim.x * 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < G.n_tiles60; tile += tile_stride) {
-    const int64_t samp0 = G.tile60[tile].samp0, row0 = G.tile60[tile].row0;
-    const int n_fr = G.tile60[tile].n_frames;
-    // the 20 ms frame with the same start sample: row0 - frame_off60[u] + frame_off20[u]; resolved through the utterance
-    int lo = 0, hi = P.n_utt;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (G.frame_off60[mid] <= row0) lo = mid; else hi = mid;
+  const bool rows_mode = G.op_mode == 1;                 // per-component operator: F0, formants and magnitudes given per row
+  const int n_tiles = rows_mode ? (int)((G.op_rows + 7) / 8) : G.n_tiles60;
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
+    int64_t samp0 = 0, row0 = (int64_t)tile * 8, r20 = (int64_t)tile * 8;
+    int n_fr = (int)((G.op_rows - row0 < 8) ? G.op_rows - row0 : 8);
+    if (!rows_mode) {
+      samp0 = G.tile60[tile].samp0; row0 = G.tile60[tile].row0; n_fr = G.tile60[tile].n_frames;
+      // the 20 ms frame with the same start sample: row0 - frame_off60[u] + frame_off20[u]; resolved through the utterance
+      int lo = 0, hi = P.n_utt;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (G.frame_off60[mid] <= row0) lo = mid; else hi = mid;
+      }
+      r20 = row0 - G.frame_off60[lo] + P.frame_off[lo];
     }
-    const int64_t r20 = row0 - G.frame_off60[lo] + P.frame_off[lo];
     for (int tf = 0; tf < n_fr; ++tf) {
       const int64_t g = row0 + tf;
-      const float F0 = G.pitch3[g * 3];
-      float *o = G.harm6 + g * 6;
+      const float F0 = rows_mode ? G.op_f0[g] : G.pitch3[g * 3];
+      float *o = rows_mode ? G.op_out + g * G.op_ld_out : G.harm6 + g * 6;
       if (!(F0 > 0.0f)) {
         if (lane == 0) {                                 // :790-810 (no ACF peak), :1005-1025
           o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
@@ -599,16 +632,21 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
         }
         continue;
       }
-      const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
-      for (int i = lane; i < kHM; i += 64) {
-        const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
-        const int r = (int)(__brev((unsigned)i) >> (32 - 9));
-        re[r] = (n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f;
-        im[r] = (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f;
+      if (rows_mode) {
+        const float *mi = G.op_in + g * G.op_ld_in;
+        for (int k = lane; k <= kHM; k += 64) mg[k] = mi[k];
+      } else {
+        const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
+        for (int i = lane; i < kHM; i += 64) {
+          const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
+          const int r = (int)(__brev((unsigned)i) >> (32 - 9));
+          re[r] = (n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f;
+          im[r] = (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f;
+        }
+        WaveG::sync();
+        group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
+        for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(untangle_bin(re, im, kHM, k, c_twf), k == 0 || k == kHM);
       }
-      WaveG::sync();
-      group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
-      for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(untangle_bin(re, im, kHM, k, c_twf), k == 0 || k == kHM);
       WaveG::sync();
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
       float *R = acf;                                    // squared magnitudes first, overwritten by the lags
@@ -730,7 +768,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
       }
       // getFormantAmplitudeIndices (:714-740): the strongest harmonic within 0.8 .. 1.2 of the formant frequency
       int fa[3];
-      const float *fm = G.formants + (r20 + tf) * 10;
+      const float *fm = G.formants + (r20 + tf) * G.fm_ld;
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
         const float fl = 0.8f * fm[f], fr = 1.2f * fm[f];
@@ -892,7 +930,48 @@ __global__ void lld_gemaps_dbp(float *x, int64_t ld, int n_utt, const int64_t *r
   x[u * ld] = factor * (float)log((double)(v > logfloor ? v : logfloor));
 }
 
+// ------------------------------------------------------------------------------------------------ per-component: cSpectral
+// The frames of ONE stream in order (the flux needs the previous frame's magnitudes; `state` carries them across calls,
+// like smilehip_spectral_frames). One wave.
+__global__ void __launch_bounds__(64) lld_gemaps_spectral_rows(const float *src, int64_t lds, float *state, int first, float *dst,
+                                                              int64_t ldd, int64_t nF, int K, GemapsParams G) {
+  __shared__ __attribute__((aligned(16))) float mg[260], pw[260], prev[260], lg[64];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < K; k += 64) prev[k] = first ? 0.0f : state[k];
+  WaveG::sync();
+  for (int64_t f = 0; f < nF; ++f) {
+    const float *m = src + f * lds;
+    for (int k = lane; k < K; k += 64) { const float v = m[k]; mg[k] = v; pw[k] = v * v; }
+    WaveG::sync();
+    gemaps_spectral_wave(mg, pw, prev, first && f == 0, lg, G, K, lane, dst + f * ldd);
+    WaveG::sync();
+    for (int k = lane; k < K; k += 64) prev[k] = mg[k];
+    WaveG::sync();
+  }
+  for (int k = lane; k < K; k += 64) state[k] = prev[k];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_gemaps_spectral_rows(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF,
+                                       int K, const GemapsParams &G, hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  if (K > 260) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lld_gemaps_spectral_rows, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, G);
+  return hipGetLastError();
+}
+
+// op_mode 1 (cSpecResample rows) / 2 (cLpc rows) of the resampling kernel; cFormantLpc rows
+hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s) {
+  if (G.op_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.op_rows + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
+  return hipGetLastError();
+}
+hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s) {
+  if (G.op_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((G.op_rows + 63) / 64)), dim3(64), 0, s, G);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s) {
   if (n_runs <= 0) return hipSuccess;
   if (P.Nfft != 512 || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;
@@ -911,7 +990,8 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
 }
 
 hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s) {
-  if (G.n_tiles60 <= 0) return hipSuccess;
+  const int64_t n_tiles = G.op_mode == 1 ? (G.op_rows + 7) / 8 : G.n_tiles60;
+  if (n_tiles <= 0) return hipSuccess;
   if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
   const int NP = (Q.N + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)NP + sizeof(float2) * (size_t)(kHM / 2 + kHM / 2 + 4) +
@@ -919,7 +999,7 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
   const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  unsigned grid = (unsigned)((G.n_tiles60 + 3) / 4);
+  unsigned grid = (unsigned)((n_tiles + 3) / 4);
   if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);
   hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(256), lds, s, P, Q, G);
   return hipGetLastError();

@@ -47,6 +47,10 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
 hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s);
 hipError_t launch_gemaps_tail(const int64_t *d_frame_off20, const int64_t *d_row_off, int n_utt, const GemapsParams &G, float *d_out,
                               int64_t ld_out, hipStream_t s);
+hipError_t launch_gemaps_spectral_rows(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF,
+                                       int K, const GemapsParams &G, hipStream_t s);
+hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s);
+hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s);
 hipError_t launch_gemaps_dbp(float *d_x, int64_t ld, int n_utt, const int64_t *d_row_off, hipStream_t s);
 hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s);
 int fs_sort_lds_rows();

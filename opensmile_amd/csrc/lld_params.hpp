@@ -184,6 +184,16 @@ struct GemapsParams {
                                     //   lldSetSpectralNz_smo (9) | lldSetSpectralZ_smo (5) | energy2 of the raw 20 ms frame (T20 rows)
   const int64_t *fin_off;           // [n_utt+1] row offsets of func_in
   int32_t *pending_j;               // [n_utt] P if P < T60 else 0: rows the jitter-gated functionals leave out
+  // ---- per-component operators (the plugin's overrides, stage-level tests): rows instead of the batch scratch
+  int32_t op_mode;                  // lld_gemaps_lpc: 0 fused (spec220 -> lpc), 1 cSpecResample only (Ooura-packed spectra -> 220
+                                    //   samples), 2 cLpc only (220 samples -> 11 coefficients); lld_gemaps_harm: 1 = rows
+  const float *op_in;               // input rows
+  int64_t op_ld_in;
+  float *op_out;                    // output rows
+  int64_t op_ld_out;
+  int64_t op_rows;
+  int64_t lpc_ld, fm_ld;            // leading dimensions of lpc / formants (12 / 10 in the batch scratch)
+  const float *op_f0;               // cHarmonics rows: F0 per row; formants = `formants` with fm_ld; magnitudes = op_in
 };
 
 // Constants of cSpectral for one spectrum geometry (host-resolved in smilehip_plan.cpp)

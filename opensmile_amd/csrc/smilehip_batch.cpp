@@ -547,11 +547,8 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
 
 // SMILEHIP_CHAIN_EGEMAPS: the 20 ms kernels on the plan's side stream, the F0 group on the caller's; then cPitchJitter and
 // cHarmonics (which need the decided F0 contour, cHarmonics also the formants), then the selectors / smoothers
-static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *b, GemapsParams &G) {
+void gemaps_plan_consts(const smilehip_plan *plan, GemapsParams &G) {
   std::memset(&G, 0, sizeof(G));
-  const smilehip_batch *fb = b->f0_batch;
-  G.run_utt = b->d_run_utt.p; G.run_t0 = b->d_run_t0.p;
-  G.raw20 = b->d_raw20.p; G.spec220 = b->d_spec220.p;
   G.eql = plan->d_eql.p;
   G.plp_melfloor = 0.00000000093f;     // cPlp melfloor default (plp.cpp:66), htkcompatible = 0
   G.compression = 0.33f;
@@ -563,11 +560,19 @@ static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *
   G.rng_lo = plan->gm_rng_lo; G.rng_hi = plan->gm_rng_hi;
   G.spec_floor = plan->gm_spec_floor; G.log_spec_floor = plan->gm_log_spec_floor; G.log_spec_factor = plan->gm_log_spec_factor;
   G.rs_cos = plan->d_rs_cos.p; G.rs_sin = plan->d_rs_sin.p;
-  G.lpc = b->d_lpc.p; G.formants = b->d_formants.p;
-  G.total_frames20 = b->total_frames;
   G.fm_T = 1.0 / plan->gm_target_fs;   // cSpecResample::configureWriter: basePeriod = 1 / targetFs
   G.fm_min = 50.0; G.fm_max = 5450.0;  // [gemapsv01b_formantLpc]
   G.fsSec60 = plan->f0_plan->geo.fft_frame_size_sec;
+  G.lpc_ld = 12; G.fm_ld = 10;
+}
+
+static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *b, GemapsParams &G) {
+  gemaps_plan_consts(plan, G);
+  const smilehip_batch *fb = b->f0_batch;
+  G.run_utt = b->d_run_utt.p; G.run_t0 = b->d_run_t0.p;
+  G.raw20 = b->d_raw20.p; G.spec220 = b->d_spec220.p;
+  G.lpc = b->d_lpc.p; G.formants = b->d_formants.p;
+  G.total_frames20 = b->total_frames;
   G.pitch3 = b->d_pitch3.p; G.jit4 = b->d_jit4.p; G.shim_db = b->d_shim.p; G.harm6 = b->d_harm6.p;
   G.frame_off60 = fb->d_frame_off.p;
   G.tile60 = fb->d_tile_rec.p;

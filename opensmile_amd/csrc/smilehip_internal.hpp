@@ -165,6 +165,7 @@ int plan_n_static(const smilehip_plan *p);
 int plan_n_out(const smilehip_plan *p);
 int plan_row_extra(const smilehip_plan *p);
 void fill_f0_params(const smilehip_plan *plan, smilehip::F0Params &Q);   // smilehip_batch.cpp
+void gemaps_plan_consts(const smilehip_plan *plan, smilehip::GemapsParams &G);   // smilehip_batch.cpp: constants of an eGeMAPS plan
 
 // SMILEHIP_FUNC_* mask (Extremes;Regression;Moments, smilehip_batch_functionals) -> the general engine's spec
 int smilehip_funcspec_from_mask(uint32_t mask, double period, smilehip_func_spec *spec);

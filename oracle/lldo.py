@@ -810,3 +810,92 @@ def run_reference_egemaps(pcm, fs=16000, levels=()):
             p = os.path.join(td, "tap_%s.htk" % EGEMAPS_LEVELS[k])
             out[k] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
         return out
+
+
+# stage-level entry points of the eGeMAPS restatement (identical-input checks of the per-component HIP operators)
+class _GSpec(C.Structure):
+    _fields_ = [("K", C.c_long), ("lo", C.c_long), ("hi", C.c_long), ("frq", C.c_void_p), ("prev", C.c_void_p),
+                ("have_prev", C.c_int), ("spec_floor", C.c_float), ("log_spec_floor", C.c_float)]
+
+
+class _SpecRes(C.Structure):
+    _fields_ = [("K", C.c_long), ("I", C.c_long), ("kMax", C.c_long), ("target_fs", C.c_double), ("costable", C.c_void_p),
+                ("sintable", C.c_void_p)]
+
+
+def egemaps_spectral_rows(mag, frame_size_sec=512 / 16000.0):
+    """cSpectral with the GeMAPS option sets over the frames of one stream: n x K magnitudes -> n x 5."""
+    L = lib()
+    L.lldo_gspec_init.argtypes = [C.POINTER(_GSpec), C.c_long, C.c_double]
+    L.lldo_gspec_frame.argtypes = [C.POINTER(_GSpec), C.c_void_p, C.c_void_p]
+    L.lldo_gspec_free.argtypes = [C.POINTER(_GSpec)]
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    out = np.zeros((mag.shape[0], 5), np.float32)
+    s = _GSpec()
+    L.lldo_gspec_init(C.byref(s), mag.shape[1], frame_size_sec)
+    for i in range(mag.shape[0]):
+        L.lldo_gspec_frame(C.byref(s), mag[i].ctypes.data, out[i].ctypes.data)
+    L.lldo_gspec_free(C.byref(s))
+    return out
+
+
+def egemaps_specresample_rows(spec):
+    """cSpecResample of [gemapsv01b_resampLpc]: n x 512 packed spectra of 20 ms frames at 16 kHz -> n x 220."""
+    L = lib()
+    L.lldo_specresample_init.argtypes = [C.POINTER(_SpecRes), C.c_long, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.lldo_specresample_frame.argtypes = [C.POINTER(_SpecRes), C.c_void_p, C.c_void_p]
+    L.lldo_specresample_free.argtypes = [C.POINTER(_SpecRes)]
+    spec = np.ascontiguousarray(spec, dtype=np.float32)
+    r = _SpecRes()
+    L.lldo_specresample_init(C.byref(r), spec.shape[1], spec.shape[1] / 16000.0, 320 / 16000.0, 1.0 / 16000.0, 11000.0)
+    out = np.zeros((spec.shape[0], r.I), np.float32)
+    for i in range(spec.shape[0]):
+        L.lldo_specresample_frame(C.byref(r), spec[i].ctypes.data, out[i].ctypes.data)
+    L.lldo_specresample_free(C.byref(r))
+    return out
+
+
+def egemaps_lpc_rows(x, p=11):
+    L = lib()
+    L.lldo_lpc_acf.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((x.shape[0], p), np.float32)
+    for i in range(x.shape[0]):
+        L.lldo_lpc_acf(x[i].ctypes.data, x.shape[1], p, out[i].ctypes.data)
+    return out
+
+
+def egemaps_formant_rows(lpc):
+    L = lib()
+    L.lldo_formant_lpc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lpc = np.ascontiguousarray(lpc, dtype=np.float32)
+    out = np.zeros((lpc.shape[0], 10), np.float32)
+    roots = np.zeros(2 * lpc.shape[1], np.float64)
+    for i in range(lpc.shape[0]):
+        L.lldo_formant_lpc(lpc[i].ctypes.data, lpc.shape[1], 5, 1.0 / 11000.0, 50.0, 5450.0, roots.ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def egemaps_harmonics_rows(f0, formants, mag, fs_sec=1024 / 16000.0):
+    L = lib()
+    L.lldo_harmonics_frame.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_double, C.c_void_p]
+    formants = np.ascontiguousarray(formants, dtype=np.float32)
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    out = np.zeros((mag.shape[0], 6), np.float32)
+    for i in range(mag.shape[0]):
+        L.lldo_harmonics_frame(float(f0[i]), formants[i].ctypes.data, 5, mag[i].ctypes.data, mag.shape[1], fs_sec, out[i].ctypes.data)
+    return out
+
+
+def frames_cfg(frame_size_sec, win):
+    """MfccCfg of a framer + window + FFT front end as the GeMAPS / ComParE sets configure it (no pre-emphasis, symmetric
+    zero padding); use with mfcc_chain(cfg, pcm, taps=True) to get the 'fft' / 'mag' levels."""
+    c = default_cfg()
+    c.frame_size_sec = frame_size_sec
+    c.preemph_enable = 0
+    c.zero_pad_symmetric = 1
+    c.win_func = WIN[win]
+    c.win_sigma = 0.4
+    c.lofreq = 20.0
+    c.n_delta = 0
+    return c
