@@ -440,7 +440,8 @@ double  smilehip_frame_time(const smilehip_plan *plan, int64_t t);
  * `row` of an utterance with n_frames frames. MFCC chain: row * frame period. IS09 / ComParE
  * chains: the rows a window processor emits at end of input carry the time of the last real
  * frame, i.e. min(row, n_frames-1) * period -- except for n_frames == 1, where the binary
- * stamps the extra row with `period` (measured: tests/golden/files, test_host_io.py). */
+ * stamps the extra row with `period` (measured: tests/golden/files, test_host_io.py). eGeMAPS chain: row * period (the
+ * level's time stamps come from egemapsv02_lldsetE_smo, whose rows 0 .. T60 are regular frames of the 20 ms chain). */
 double  smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row);
 /* host copies of the generated tables (for table-level parity tests); each
  * returns the element count or a negative status. out may be NULL. */

@@ -542,7 +542,7 @@ extern "C" double smilehip_frame_time(const smilehip_plan *p, int64_t t) {
 extern "C" double smilehip_row_time(const smilehip_plan *plan, int64_t n_frames, int64_t row) {
   if (!plan || row < 0) return 0.0;
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP ||
-      plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 || n_frames <= 1)
+      plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 || plan->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS || n_frames <= 1)
     return smilehip_frame_time(plan, row);
   return smilehip_frame_time(plan, row < n_frames - 1 ? row : n_frames - 1);
 }

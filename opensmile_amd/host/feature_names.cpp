@@ -145,4 +145,48 @@ std::vector<std::string> func_names_compare16() {
   return out;
 }
 
+// config/egemaps/v02/eGeMAPSv02.conf: the LLD level ([lldconcat]: egemapsv02_lldsetE_smo; egemapsv02_lldsetF_smo, names given by the
+// cDataSelector instances' newNames + the smoothers' nameAppend) ...
+std::vector<std::string> lld_names_egemaps() {
+  static const char *e[] = {"Loudness", "alphaRatio", "hammarbergIndex", "slope0-500", "slope500-1500", "spectralFlux", "mfcc1", "mfcc2",
+                            "mfcc3", "mfcc4"};
+  static const char *f[] = {"F0semitoneFrom27.5Hz", "jitterLocal", "shimmerLocaldB", "HNRdBACF", "logRelF0-H1-H2", "logRelF0-H1-A3",
+                            "F1frequency", "F1bandwidth", "F1amplitudeLogRelF0", "F2frequency", "F2bandwidth", "F2amplitudeLogRelF0",
+                            "F3frequency", "F3bandwidth", "F3amplitudeLogRelF0"};
+  std::vector<std::string> n;
+  for (const char *x : e) n.push_back(std::string(x) + "_sma3");
+  for (const char *x : f) n.push_back(std::string(x) + "_sma3nz");
+  return n;
+}
+
+// ... and its functionals level ([funcconcat]): 88 names
+std::vector<std::string> func_names_egemaps() {
+  struct Part { const char *inst; std::vector<std::string> elems; };
+  const std::vector<std::string> lld = lld_names_egemaps();
+  std::vector<std::string> voiced(lld.begin() + 11, lld.end());                    // jitterLocal .. F3amplitudeLogRelF0 (_sma3nz)
+  for (const char *x : {"alphaRatioV", "hammarbergIndexV", "slopeV0-500", "slopeV500-1500", "spectralFluxV", "mfcc1V", "mfcc2V", "mfcc3V",
+                        "mfcc4V"})
+    voiced.push_back(std::string(x) + "_sma3nz");
+  const Part parts[] = {
+      {"F0", {"F0semitoneFrom27.5Hz_sma3nz"}},
+      {"Loudness", {"loudness_sma3"}},
+      {"MVZ", {"spectralFlux_sma3", "mfcc1_sma3", "mfcc2_sma3", "mfcc3_sma3", "mfcc4_sma3"}},
+      {"MVV", voiced},
+      {"MU", {"alphaRatioUV_sma3nz", "hammarbergIndexUV_sma3nz", "slopeUV0-500_sma3nz", "slopeUV500-1500_sma3nz", "spectralFluxUV_sma3nz"}},
+  };
+  std::vector<std::string> out;
+  for (const Part &p : parts) {
+    smilehip_func_spec s;
+    if (smilehip_funcspec_egemaps(p.inst, &s) != SMILEHIP_OK) return {};
+    const std::vector<std::string> v = funcspec_value_names(s);
+    for (const std::string &el : p.elems)
+      for (const std::string &f : v) out.push_back(el + "_" + f);
+  }
+  // [gemapsv01b_temporalSetNames] newNames, [egemapsv02_leq] nameBase + operation
+  for (const char *x : {"loudnessPeaksPerSec", "VoicedSegmentsPerSec", "MeanVoicedSegmentLengthSec", "StddevVoicedSegmentLengthSec",
+                        "MeanUnvoicedSegmentLength", "StddevUnvoicedSegmentLength", "equivalentSoundLevel_dBp"})
+    out.push_back(x);
+  return out;
+}
+
 }  // namespace smilehip_host

@@ -38,6 +38,8 @@ std::vector<std::string> lld_names_is09();
 std::vector<std::string> lld_names_compare16();
 std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
 std::vector<std::string> func_names_compare16();   // 6373, the functionals level of ComParE_2016.conf
+std::vector<std::string> lld_names_egemaps();      // 25, the LLD level of eGeMAPSv02.conf
+std::vector<std::string> func_names_egemaps();     // 88, its functionals level
 // value-name suffixes of one cFunctionals instance in output order (name_append = its functNameAppend option)
 std::vector<std::string> funcspec_value_names(const smilehip_func_spec &spec, const std::string &name_append = "");
 

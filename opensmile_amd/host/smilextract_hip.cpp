@@ -12,13 +12,15 @@
 //                   (the 130-column LLD level of ComParE_2016 only)
 //   smilextract_hip --set compare16     same options as is09_emotion: the whole ComParE_2016.conf, LLD level + 6373 functionals
 //   smilextract_hip --set is13_compare  the same for config/is09-13/IS13_ComParE.conf
+//   smilextract_hip --set egemapsv02    the whole config/egemaps/v02/eGeMAPSv02.conf: 25-column LLD level + 88 functionals
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
 //
 // -filelist: one "wav[<TAB>instname]" per line. Per-file outputs (HTK, LLD CSV) of a list go to
 // -outdir/<basename>.<ext>; summary outputs (func ARFF/CSV) append one row per file, like the
 // reference's append=1 default. --rank/--world: this process takes files r, r+n, r+2n, ...
-// (utterances shard with no communication; one process per GPU).
+// (utterances shard with no communication; one process per GPU); the summary outputs of rank r then go to
+// <name>.rank<r><ext> -- ranks never share a file -- and are concatenated afterwards.
 // All files of a chunk are packed into one device batch: one kernel sequence per chunk.
 #include <algorithm>
 #include <cctype>
@@ -72,22 +74,23 @@ int main(int argc, char **argv) {
   const bool is13 = set == "is13_compare";                     // config/is09-13/IS13_ComParE.conf: same elements, IS13 options
   const bool cmp16f = set == "compare16" || is13;              // the whole ComParE_2016.conf: LLD level + 6373 functionals
   const bool cmp16 = set == "compare16_lld" || cmp16f;
-  const bool has_func = is09 || cmp16f;
+  const bool egm = set == "egemapsv02";                          // config/egemaps/v02/eGeMAPSv02.conf
+  const bool has_func = is09 || cmp16f || egm;
   // the eight files of config/mfcc and config/plp, by their names in lower case
   std::string variant;                             // upper-case config name for smilehip_config_htk_variant
   for (char ch : set) variant += (char)toupper((unsigned char)ch);
   smilehip_lld_config vcfg;
-  const bool htk_variant = !is09 && !cmp16 && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
+  const bool htk_variant = !is09 && !cmp16 && !egm && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
-  if (!is09 && !cmp16 && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld or is13_compare");
+  if (!is09 && !cmp16 && !egm && !htk_variant)
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare or egemapsv02");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
   else if (variant == "MFCC12_E_D_A_Z") parm_kind = 2886;
   else if (variant == "PLP_0_D_A_Z") parm_kind = 11019;
   else if (variant == "PLP_E_D_A_Z") parm_kind = 8971;
-  const bool lld_opts = is09 || cmp16;              // LLD files through -lldhtkoutput / -lldcsvoutput as in the reference
+  const bool lld_opts = is09 || cmp16 || egm;           // LLD files through -lldhtkoutput / -lldcsvoutput as in the reference
   std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
 
   std::vector<Job> jobs;
@@ -126,10 +129,21 @@ int main(int argc, char **argv) {
   smilehip_context *ctx = nullptr;
   check(smilehip_init(opt.count("--device") ? atoi(opt["--device"].c_str()) : 0, &ctx), "smilehip_init");
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
-  const size_t chunk_files = opt.count("--chunk-files") ? (size_t)atol(opt["--chunk-files"].c_str()) : 4096;
+  const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 4096;
+  if (chunk_files_l < 1) die("--chunk-files must be a positive number");
+  const size_t chunk_files = (size_t)chunk_files_l;
+  // Summary sinks (one row per file appended to ONE file) of several ranks must not share a file: each rank of a
+  // --world > 1 run writes <name>.rank<r><ext>; concatenate them afterwards (the ARFF header is the same in each).
+  auto summary_path = [&](const std::string &p) {
+    if (world <= 1) return p;
+    const size_t d = p.find_last_of('.'), sl = p.find_last_of('/');
+    const std::string tag = ".rank" + std::to_string(rank);
+    return (d == std::string::npos || (sl != std::string::npos && d < sl)) ? p + tag : p.substr(0, d) + tag + p.substr(d);
+  };
   const std::vector<std::string> lld_names =
-      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy));
-  const std::vector<std::string> fnames = is09 ? func_names_is09() : (cmp16f ? func_names_compare16() : std::vector<std::string>());
+      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (egm ? lld_names_egemaps() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy)));
+  const std::vector<std::string> fnames =
+      is09 ? func_names_is09() : (cmp16f ? func_names_compare16() : (egm ? func_names_egemaps() : std::vector<std::string>()));
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
 
@@ -145,6 +159,7 @@ int main(int argc, char **argv) {
         die("'" + jobs[j].wav + "': the fused path takes 16-bit mono PCM (other formats: smilehip_pcm_convert + the plugin path)");
       by_rate[wi.sample_rate].push_back(j);
     }
+    std::vector<std::vector<float>> func_rows(j1 - j0);   // per job of the chunk; empty = no instance (no frame)
     for (auto &kv : by_rate) {
       smilehip_plan *&plan = plans[kv.first];
       if (!plan) {
@@ -152,6 +167,7 @@ int main(int argc, char **argv) {
         if (is09) smilehip_config_is09_lld(&cfg);
         else if (is13) smilehip_config_is13_compare(&cfg);
         else if (cmp16) smilehip_config_compare16(&cfg);
+        else if (egm) smilehip_config_egemapsv02(&cfg);
         else cfg = vcfg;
         cfg.sample_rate = (double)kv.first;
         check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
@@ -181,12 +197,15 @@ int main(int argc, char **argv) {
       check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
       check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
       std::vector<float> lld((size_t)std::max<int64_t>(rows, 1) * n_out), func;
-      const int n_func = is09 ? n_out * smilehip_functionals_count(fmask) : (cmp16f ? smilehip_functionals_compare16_count() : 0);
+      const int n_func = is09 ? n_out * smilehip_functionals_count(fmask)
+                              : (cmp16f ? smilehip_functionals_compare16_count() : (egm ? smilehip_functionals_egemaps_count() : 0));
       if (has_func) {
         check(smilehip_alloc(ctx, (uint64_t)idx.size() * n_func * 4, &d_func), "smilehip_alloc");
         if (is09)
           check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
                 "smilehip_batch_functionals");
+        else if (egm)
+          check(smilehip_batch_functionals_egemaps(plan, b, (float *)d_func, n_func, nullptr), "smilehip_batch_functionals_egemaps");
         else
           check((is13 ? smilehip_batch_functionals_is13_compare : smilehip_batch_functionals_compare16)(
                     plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, nullptr),
@@ -208,7 +227,7 @@ int main(int argc, char **argv) {
           CsvOptions co;
           co.instance_name = job.inst;
           // rows of the ComParE level follow the 60 ms framer: T60 + 1
-          const int64_t n_frames = cmp16 ? r - 1 : smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
+          const int64_t n_frames = (cmp16 || egm) ? r - 1 : smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
           std::vector<double> times((size_t)r);
           for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
           if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_out, n_out, g.frame_period,
@@ -217,17 +236,7 @@ int main(int argc, char **argv) {
         }
         if (has_func && r > 0) {                          // no frame -> the reference writes no instance
           const float *fv = func.data() + i * (size_t)n_func;
-          if (opt.count("-O") && opt["-O"] != "?") {
-            ArffOptions ao;
-            ao.instance_name = job.inst;
-            if (!write_arff(opt["-O"], fnames, fv, 1, n_func, n_func, 0.0, ao, err)) die(err);
-          }
-          if (opt.count("-csvoutput") && opt["-csvoutput"] != "?") {
-            CsvOptions co;
-            co.instance_name = job.inst;
-            co.append = true;
-            if (!write_csv(opt["-csvoutput"], fnames, fv, 1, n_func, n_func, 0.0, nullptr, co, err)) die(err);
-          }
+          func_rows[idx[i] - j0].assign(fv, fv + n_func);
           if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
             if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_func, n_func, 0.0, 9, err)) die(err);
         }
@@ -236,6 +245,23 @@ int main(int argc, char **argv) {
       smilehip_free(ctx, d_lld);
       if (d_func) smilehip_free(ctx, d_func);
       smilehip_batch_destroy(b);
+    }
+    // summary sinks in file-list order (the rate groups above may have processed the chunk's files in another order)
+    for (size_t j = j0; j < j1 && has_func; ++j) {
+      const std::vector<float> &fv = func_rows[j - j0];
+      if (fv.empty()) continue;
+      const int n_func = (int)fv.size();
+      if (opt.count("-O") && opt["-O"] != "?") {
+        ArffOptions ao;
+        ao.instance_name = jobs[j].inst;
+        if (!write_arff(summary_path(opt["-O"]), fnames, fv.data(), 1, n_func, n_func, 0.0, ao, err)) die(err);
+      }
+      if (opt.count("-csvoutput") && opt["-csvoutput"] != "?") {
+        CsvOptions co;
+        co.instance_name = jobs[j].inst;
+        co.append = true;
+        if (!write_csv(summary_path(opt["-csvoutput"]), fnames, fv.data(), 1, n_func, n_func, 0.0, nullptr, co, err)) die(err);
+      }
     }
   }
   for (auto &kv : plans) smilehip_plan_destroy(kv.second);

@@ -53,6 +53,18 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
   info.n_blocks = (long)(ch.size / block_align);
   info.block_size = block_align;
   info.header_offset = ftell(f);
+  // the header's data size is not trusted before allocating: files written to a pipe carry 0 or 0xFFFFFFFF there
+  // (the reference's cWaveSource reads block by block until EOF): clamp to what the file really holds
+  {
+    const long here = ftell(f);
+    long remaining = -1;
+    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+      const long end = ftell(f);
+      if (end >= here) remaining = end - here;
+      fseek(f, here, SEEK_SET);
+    }
+    if (remaining >= 0 && ((uint64_t)ch.size > (uint64_t)remaining || ch.size == 0)) info.n_blocks = remaining / block_align;
+  }
   data.resize((size_t)info.n_blocks * block_align);
   const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
   if (got < data.size()) {                               // cWaveSource reads until EOF: a short data chunk just ends earlier

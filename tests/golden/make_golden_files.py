@@ -72,6 +72,16 @@ def main():
         for f, g in (("f.arff", "is09_func.arff"), ("f.csv", "is09_func.csv"), ("f3.htk", "is09_func_u3.htk"),
                      ("l3.csv", "is09_lld_u3.csv"), ("l3.htk", "is09_lld_u3.htk")):
             shutil.copy(os.path.join(td, f), os.path.join(out, g))
+        # eGeMAPSv02: the 25-column LLD level as CSV + HTK, the 88 functionals as ARFF + CSV + HTK
+        conf = os.path.join(lldo.REF_DIR, "config", "egemaps", "v02", "eGeMAPSv02.conf")
+        subprocess.run([exe, "-C", conf, "-I", os.path.join(td, "u3.wav"), "-lldcsvoutput", os.path.join(td, "g.csv"),
+                        "-lldhtkoutput", os.path.join(td, "g.htk"), "-O", os.path.join(td, "gf.arff"), "-csvoutput",
+                        os.path.join(td, "gf.csv"), "-htkoutput", os.path.join(td, "gf.htk"), "-instname", "u3", "-l", "0"],
+                       check=True, cwd=td)
+        for a, b in (("g.csv", "egemaps_lld_u3.csv"), ("g.htk", "egemaps_lld_u3.htk"), ("gf.arff", "egemaps_func_u3.arff"),
+                     ("gf.csv", "egemaps_func_u3.csv"), ("gf.htk", "egemaps_func_u3.htk")):
+            shutil.copy(os.path.join(td, a), os.path.join(out, b))
+
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)))
 

@@ -284,3 +284,34 @@ def test_compare16_functional_names_match_binary(hostlib):
     got = buf.raw[:n].decode().split("\n")[:-1]
     assert len(got) == 6373
     assert got == want
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_egemapsv02(tmp_path):
+    """--set egemapsv02: the whole eGeMAPSv02.conf (BASELINE config 5). LLD CSV: header, instance name and every frameTime
+    as the reference writes them; functionals ARFF: the reference's header byte for byte (88 attribute names + class);
+    values within the chain's bars (tests/test_gpu_egemaps.py)."""
+    lld_csv, lld_htk = str(tmp_path / "l.csv"), str(tmp_path / "l.htk")
+    f_arff, f_csv, f_htk = str(tmp_path / "f.arff"), str(tmp_path / "f.csv"), str(tmp_path / "f.htk")
+    subprocess.run([EXE, "--set", "egemapsv02", "-I", os.path.join(G, "u3_4000.wav"), "-lldcsvoutput", lld_csv, "-lldhtkoutput", lld_htk,
+                    "-O", f_arff, "-csvoutput", f_csv, "-htkoutput", f_htk, "-instname", "u3"], check=True)
+    h, x = read_htk(lld_htk)
+    hr, xr = read_htk(os.path.join(G, "egemaps_lld_u3.htk"))
+    assert h == hr and x.shape == xr.shape and x.shape[1] == 25
+    head, names, vals, _ = parse_csv(lld_csv)
+    head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, "egemaps_lld_u3.csv"))
+    assert head == head_r and names == names_r and vals.shape == vals_r.shape
+    assert np.array_equal(vals[:, 0], vals_r[:, 0])                     # frameTime column
+    scale = np.maximum(np.abs(xr).max(axis=0), 1e-6)
+    err = np.abs(x - xr) / scale[None, :]
+    assert err[:, :13].max() <= 5e-6                                     # 20 ms descriptors, F0, jitter, shimmer
+    assert (err[:, 13:] > 1e-3).mean() <= 0.08                           # HNR, harmonic differences, formants: float32 LPC floor
+    got, ref = open(f_arff).read(), open(os.path.join(G, "egemaps_func_u3.arff")).read()
+    assert got.split("@data")[0] == ref.split("@data")[0]
+    assert open(f_csv).readline() == open(os.path.join(G, "egemaps_func_u3.csv")).readline()
+    hf, xf = read_htk(f_htk)
+    hfr, xfr = read_htk(os.path.join(G, "egemaps_func_u3.htk"))
+    assert hf == hfr and xf.shape == xfr.shape == (1, 88)
+    rel = np.abs(xf[0].astype(np.float64) - xfr[0]) / np.maximum(np.abs(xfr[0]), 1e-2)
+    well = list(range(0, 30)) + list(range(81, 88))
+    assert rel[well].max() <= 1e-3 and (rel <= 1e-3).mean() >= 0.85
