@@ -12,11 +12,13 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-SETS = {  # name: (config, output option, frames per 10 s file)
+SETS = {  # name: (config, output option, frames per file[, file length in samples])
     "is09": ("is09-13/IS09_emotion.conf", "-lldhtkoutput", 998),
     "compare": ("compare16/ComParE_2016.conf", "-lldhtkoutput", 995),
     "plp": ("plp/PLP_0_D_A.conf", "-O", 998),
     "mfcc_e_z": ("mfcc/MFCC12_E_D_A_Z.conf", "-O", 998),
+    # BASELINE config 5: eGeMAPSv02 on 3 s utterances, functionals (88 values) as the output; 299 frames of the 20 ms framer
+    "egemaps": ("egemaps/v02/eGeMAPSv02.conf", "-htkoutput", 299, 48000),
 }
 
 
@@ -33,10 +35,11 @@ def main():
     cores = os.cpu_count() or 1
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         n_unique = 8
-        for i in range(n_unique):
-            lldo.write_wav(os.path.join(td, f"u{i}.wav"), synth.utterance(2 + i, 160000))
         for name in args.sets.split(","):
-            conf_rel, opt, frames = SETS[name]
+            conf_rel, opt, frames = SETS[name][:3]
+            n_samp = SETS[name][3] if len(SETS[name]) > 3 else 160000
+            for i in range(n_unique):
+                lldo.write_wav(os.path.join(td, f"u{i}.wav"), synth.utterance(2 + i, n_samp))
             conf = os.path.join(lldo.REF_DIR, "config", conf_rel)
             t0 = time.perf_counter()
             n_cal = 4
@@ -50,7 +53,7 @@ def main():
             t0 = time.perf_counter()
             subprocess.run(cmd, shell=True, input=jobs.encode(), cwd=td, check=True)
             dt = time.perf_counter() - t0
-            print(json.dumps({"set": name, "config": conf_rel, "cores": cores, "files": n_files, "wall_s": dt,
+            print(json.dumps({"set": name, "config": conf_rel, "cores": cores, "files": n_files, "file_seconds": n_samp / 16000.0, "wall_s": dt,
                               "frames_per_s": n_files * frames / dt, "one_core_frames_per_s": frames / per_file}), flush=True)
 
 
