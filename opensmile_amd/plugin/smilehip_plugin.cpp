@@ -5,7 +5,8 @@
 // which calls the C symbol registerPluginComponent below. The components it
 // returns carry the BUILT-IN type names (cVectorPreemphasis, cWindower,
 // cTransformFFT, cFFTmagphase, cMelspec, cMfcc, cEnergy, cMZcr, cAcf, cPitchACF,
-// cDeltaRegression, cContourSmoother, cSpectral, cPlp, cFunctionals, cSpecScale, cPitchShs), so their factories replace the
+// cDeltaRegression, cContourSmoother, cSpectral, cPlp, cFunctionals, cSpecScale, cPitchShs, cSpecResample, cLpc, cFormantLpc,
+// cHarmonics), so their factories replace the
 // built-in ones (componentManager.cpp:104-129) while the built-in ConfigTypes --
 // every existing option -- stay (configManager.cpp:2818-2827): unmodified
 // config files run through the HIP kernels.
@@ -21,6 +22,7 @@
 #include <core/componentManager.hpp>
 #include <core/dataSource.hpp>
 #include <core/smileCommon.hpp>
+#include <dsp/specResample.hpp>
 #include <dsp/specScale.hpp>
 #include <dspcore/acf.hpp>
 #include <dspcore/contourSmoother.hpp>
@@ -30,6 +32,9 @@
 #include <dspcore/vectorPreemphasis.hpp>
 #include <dspcore/windower.hpp>
 #include <functionals/functionals.hpp>
+#include <lld/formantLpc.hpp>
+#include <lld/harmonics.hpp>
+#include <lld/lpc.hpp>
 #include <lld/pitchShs.hpp>
 #include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
@@ -56,11 +61,23 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 17;
+constexpr int kNumOverrides = 21;
 long g_frames[kNumOverrides] = {0};
+long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
                                             "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
-                                            "cPitchShs"};
+                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics"};
+
+// An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
+// says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
+#define HIP_FALLTHROUGH(idx, why)                                                                                  \
+  do {                                                                                                             \
+    if (!cpu_warned_) {                                                                                            \
+      SMILE_IWRN(1, "libsmilehip plugin: %s -- this instance runs the reference's CPU code", why);                 \
+      cpu_warned_ = true;                                                                                          \
+    }                                                                                                              \
+    g_cpu[idx]++;                                                                                                  \
+  } while (0)
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -134,6 +151,7 @@ int winfunc_id(const char *s) {
 // R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
 class cHipVectorPreemphasis : public cVectorPreemphasis {
   FrameIO io_;
+  bool cpu_warned_ = false;
   float k_ = 0.f;
   int de_ = 0;
   bool ready_ = false;
@@ -177,6 +195,7 @@ struct PlanSet {
 // R3  cWindower::processVector  (src/dspcore/windower.cpp:221-229)
 class cHipWindower : public cWindower {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
@@ -211,10 +230,11 @@ class cHipWindower : public cWindower {
 // R4  cTransformFFT::processVector, forward  (src/dspcore/transformFft.cpp:165-223)
 class cHipTransformFFT : public cTransformFFT {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (getInt("inverse")) return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi);   // inverse stays on the CPU
+    if (getInt("inverse")) { HIP_FALLTHROUGH(2, "cTransformFFT inverse = 1 is not built"); return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
@@ -243,6 +263,7 @@ class cHipTransformFFT : public cTransformFFT {
 // R5  cFFTmagphase::processVector, magnitude branch  (src/dspcore/fftmagphase.cpp:215-221)
 class cHipFFTmagphase : public cFFTmagphase {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1;
  protected:
@@ -250,7 +271,7 @@ class cHipFFTmagphase : public cFFTmagphase {
     if (plain_ < 0)
       plain_ = (!getInt("inverse") && getInt("magnitude") && !getInt("phase") && !getInt("normalise") &&
                 !getInt("power") && !getInt("dBpsd")) ? 1 : 0;
-    if (!plain_) return cFFTmagphase::processVector(src, dst, Nsrc, Ndst, idxi);   // other modes stay on the CPU
+    if (!plain_) { HIP_FALLTHROUGH(3, "cFFTmagphase: only the plain magnitude output is built (no phase / normalise / power / dBpsd / inverse)"); return cFFTmagphase::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
@@ -275,6 +296,7 @@ class cHipFFTmagphase : public cFFTmagphase {
 // R6  cMelspec::processVector  (src/lldcore/melspec.cpp:519-570)
 class cHipMelspec : public cMelspec {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1;
  protected:
@@ -285,7 +307,7 @@ class cHipMelspec : public cMelspec {
       const bool mel = getInt("htkcompatible") || (sc && !strcasecmp(sc, "mel"));
       plain_ = (!getInt("inverse") && mel && bw && !strncasecmp(bw, "lr", 2)) ? 1 : 0;
     }
-    if (!plain_) return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi);   // HFCC / bark / inverse stay on the CPU
+    if (!plain_) { HIP_FALLTHROUGH(4, "cMelspec: only the mel-scale triangular bank with bwMethod = lr is built (no HFCC / other scales / inverse)"); return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       // frame size of the input spectrum, cMelspec::configureField (melspec.cpp:150-173)
@@ -320,10 +342,11 @@ class cHipMelspec : public cMelspec {
 // R7  cMfcc::processVector, forward  (src/lldcore/mfcc.cpp:239-273)
 class cHipMfcc : public cMfcc {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (getInt("inverse") || !getInt("doLog")) return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi);
+    if (getInt("inverse") || !getInt("doLog")) { HIP_FALLTHROUGH(5, "cMfcc: inverse = 1 / doLog = 0 are not built"); return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(512, SMILEHIP_STAGE_MFCC);
@@ -375,6 +398,7 @@ struct DevBytes {
 // squares comes from the device, the rms / squared / log expressions are the reference's
 class cHipEnergy : public cEnergy {
   FrameIO io_;
+  bool cpu_warned_ = false;
   DevBytes res_;
   int htk_ = 0, erms_ = 0, e2_ = 0, elog_ = 0;
   FLOAT_DMEM sRms_ = 1, sLog_ = 1, sSq_ = 1, bLog_ = 0, bRms_ = 0, bSq_ = 0;
@@ -426,12 +450,13 @@ class cHipEnergy : public cEnergy {
 // R12  cMZcr::processVector, zero-crossing rate  (src/lldcore/mzcr.cpp:109-150)
 class cHipMZcr : public cMZcr {
   FrameIO io_;
+  bool cpu_warned_ = false;
   DevBytes res_;
   int plain_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (plain_ < 0) plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
-    if (!plain_ || Nsrc == 0) return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi);   // mean-crossing / extrema stay on the CPU
+    if (!plain_ || Nsrc == 0) { HIP_FALLTHROUGH(7, "cMZcr: only zcr is built (no mcr / amax / maxmin / dc)"); return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
     int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t));
@@ -456,6 +481,7 @@ class cHipMZcr : public cMZcr {
 // R9  cAcf::processVector, forward path  (src/dspcore/acf.cpp:249-349)
 class cHipAcf : public cAcf {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1, use_power_ = 0, cepstrum_ = 0, norm_ = 0, abs_ceps_ = 0;
  protected:
@@ -469,7 +495,7 @@ class cHipAcf : public cAcf {
     }
     const long N = (Nsrc - 1) * 2;
     if (!plain_ || Nsrc < 5 || (N & (N - 1)) != 0 || Ndst > N / 2)
-      return cAcf::processVector(src, dst, Nsrc, Ndst, idxi);   // inverse / legacy cepstrum / liftering stay on the CPU
+      { HIP_FALLTHROUGH(8, "cAcf: inverse / oldCompatCepstrum / cosLifterCepstrum / expBeforeAbs or this field size are not built"); return cAcf::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(N, SMILEHIP_STAGE_FFT);
@@ -496,6 +522,7 @@ class cHipAcf : public cAcf {
 // smoother are the reference's scalar code on this object's own copy of the five state variables
 class cHipPitchACF : public cPitchACF {
   FrameIO io_;
+  bool cpu_warned_ = false;
   DevBytes res_;
   int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, onsFlag_ = 0;
   double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
@@ -514,7 +541,7 @@ class cHipPitchACF : public cPitchACF {
       plain_ = (!getInt("HNR") && !getInt("HNRdB") && !getInt("linHNR") && !getInt("voiceQual")) ? 1 : 0;
     }
     const long N = (int)floor(Nsrc / 2.0);
-    if (!plain_ || N < 4 || 2 * N != Nsrc) return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi);   // HNR variants stay on the CPU
+    if (!plain_ || N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: only voiceProb + F0 (+ F0raw) from [acf | cepstrum] are built (no HNR outputs)"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
     unsigned char *r = (unsigned char *)res_.ensure(16);
@@ -593,6 +620,7 @@ struct RowIO {
 
 class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
+  bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0;
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
@@ -601,7 +629,7 @@ class cHipDeltaRegression : public cDeltaRegression {
       plain_ = (W_ > 0 && !getInt("onlyInSegments") && !getInt("relativeDelta") && !getInt("halfWaveRect") &&
                 !getInt("absOutput")) ? 1 : 0;
     }
-    if (!plain_ || pre < W_ || post < W_) return cDeltaRegression::processBuffer(in, out, pre, post);   // segment / relative / rectified variants stay on the CPU
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: onlyInSegments / relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, 0, W_);
     g_frames[10] += out->nT;
     return 1;
@@ -617,6 +645,7 @@ class cHipDeltaRegression : public cDeltaRegression {
 
 class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
+  bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0;
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
@@ -625,7 +654,7 @@ class cHipContourSmoother : public cContourSmoother {
       W_ = smaWin / 2;
       plain_ = (!getInt("noZeroSma") && (smaWin & 1) && W_ >= 1) ? 1 : 0;
     }
-    if (!plain_ || pre < W_ || post < W_) return cContourSmoother::processBuffer(in, out, pre, post);   // noZeroSma stays on the CPU
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: noZeroSma is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, 1, W_);
     g_frames[11] += out->nT;
     return 1;
@@ -642,10 +671,12 @@ class cHipContourSmoother : public cContourSmoother {
 // R11  cSpectral::processVector with ComParE_2016's option set  (src/lldcore/spectral.cpp:586-1560)
 class cHipSpectral : public cSpectral {
   FrameIO io_;
+  bool cpu_warned_ = false;
   PlanSet<> plans_;
   DevBytes prev_[8];
   bool seen_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1;
+  int plain_ = -1, gemaps_ = -1;
+  smilehip_plan *gm_plan_ = nullptr;
   bool array_is(const char *name, int n, const char *const *vals) {
     if (getArraySize(name) != n) return false;
     for (int i = 0; i < n; ++i) {
@@ -673,8 +704,49 @@ class cHipSpectral : public cSpectral {
       plain_ = ok ? 1 : 0;
     }
     const int fc = getFconf(idxi);
-    if (!plain_ || Nsrc != 257 || Ndst != 15 || fc < 0 || fc >= 8)
-      return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);   // any other option set / spectrum size stays on the CPU
+    if (gemaps_ < 0) {
+      // the two GeMAPS option sets (GeMAPSv01b_core.lld.conf.inc [gemapsv01b_logSpectral], eGeMAPSv02_core.lld.conf.inc
+      // [egemapsv02_logSpectral_flux]): log-spectrum slopes 0-500 / 500-1500 + alpha ratio + Hammarberg index, or flux alone
+      static const char *const slopes[2] = {"0-500", "500-1500"};
+      static const char *const off[] = {"specDiff", "specPosDiff", "fluxCentroid", "fluxAtFluxCentroid", "centroid", "maxPos", "minPos",
+                                        "entropy", "standardDeviation", "variance", "skewness", "kurtosis", "slope", "sharpness",
+                                        "tonality", "harmonicity", "flatness", "logFlatness", "buggyRollOff", "oldSlopeScale"};
+      bool ok = getInt("squareInput") == 1 && getInt("useLogSpectrum") == 1 && getInt("normBandEnergies") == 1 &&
+                getArraySize("bands") <= 0 && getArraySize("rollOff") <= 0 && getDouble("specFloor") == 0.0000001;
+      for (const char *o : off) ok = ok && getInt(o) == 0;
+      const char *fr = getStr("freqRange");
+      ok = ok && fr && !strcmp(fr, "0-5000");
+      gemaps_ = 0;
+      if (ok && array_is("slopes", 2, slopes) && getInt("alphaRatio") == 1 && getInt("hammarbergIndex") == 1 && getInt("flux") == 0)
+        gemaps_ = 1;                                     // 4 outputs
+      else if (ok && getArraySize("slopes") <= 0 && getInt("alphaRatio") == 0 && getInt("hammarbergIndex") == 0 && getInt("flux") == 1)
+        gemaps_ = 2;                                     // 1 output
+    }
+    if (gemaps_ > 0 && Nsrc == 257 && Ndst == (gemaps_ == 1 ? 4 : 1) && fc >= 0 && fc < 8) {
+      if (!gm_plan_) {
+        const sDmLevelConfig *lc = reader_->getLevelConfig();
+        smilehip_lld_config c;
+        smilehip_config_egemapsv02(&c);
+        if (!(std::fabs(lc->frameSizeSec - 512.0 / c.sample_rate) < 1e-9))
+          COMP_ERR("libsmilehip plugin: cSpectral (GeMAPS options): the HIP path is built for the 512-point spectrum at 16 kHz");
+        check(smilehip_plan_create(context(), &c, &gm_plan_));
+      }
+      io_.ensure(Nsrc, 5);
+      io_.up(src, Nsrc);
+      float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
+      check(smilehip_spectral_gemaps_frames(gm_plan_, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 5, 1, nullptr));
+      seen_[fc] = true;
+      float five[5];
+      io_.down(five, 5);
+      if (gemaps_ == 1) memcpy(dst, five, sizeof(float) * 4); else dst[0] = five[4];
+      g_frames[12]++;
+      return (int)Ndst;
+    }
+    if (!plain_ || Nsrc != 257 || Ndst != 15 || fc < 0 || fc >= 8) {
+      HIP_FALLTHROUGH(12, "cSpectral: only ComParE_2016's option set and the two GeMAPS sets (log-spectrum slopes + alphaRatio + "
+                          "hammarbergIndex; flux over 0-5000 Hz) on a 257-bin spectrum are built");
+      return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
     smilehip_plan *&pl = plans_.at(fc);
     if (!pl) {
       const sDmLevelConfig *lc = reader_->getLevelConfig();
@@ -693,6 +765,7 @@ class cHipSpectral : public cSpectral {
   }
  public:
   explicit cHipSpectral(const char *n) : cSpectral(n) {}
+  ~cHipSpectral() override { if (gm_plan_) smilehip_plan_destroy(gm_plan_); }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipSpectral(n);
     c->setComponentInfo(scname, sdescription);
@@ -703,6 +776,7 @@ class cHipSpectral : public cSpectral {
 // R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
 class cHipPlp : public cPlp {
   FrameIO io_;
+  bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
   int plain_ = -1, newRasta_ = 0, cc_ = 0, lpOrder_ = 0;
@@ -744,7 +818,7 @@ class cHipPlp : public cPlp {
     const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
     if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
         (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
-      return cPlp::processVector(src, dst, Nsrc, Ndst, idxi);   // PLP-CC (IDFT / LP / cepstra), old RASTA, HTK mode stay on the CPU
+      { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (with / without newRASTA) and the HTK PLP-CC mode are built (no old RASTA, no partial IDFT / LP modes)"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
     if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
       const double *frq = (const double *)(fmeta->field[idxi].info);
       std::vector<float> e((size_t)Nsrc), st((size_t)(4 * Nsrc + 1), 0.0f);
@@ -808,6 +882,7 @@ class cHipPlp : public cPlp {
 // once; an instance that uses an option the spec cannot express stays on the reference's own code.
 class cHipFunctionals : public cFunctionals {
   FrameIO io_;
+  bool cpu_warned_ = false;
   int state_ = -1;                                       // -1 = not examined, 0 = not expressible -> reference code, 1 = spec_
   smilehip_func_spec spec_;
   int opt_int(const char *fam, const char *o) { return (int)getInt_f(myvprint("%s.%s", fam, o)); }
@@ -1002,7 +1077,7 @@ class cHipFunctionals : public cFunctionals {
  protected:
   int doProcess(int i, cMatrix *row, FLOAT_DMEM *y) override {
     if (state_ < 0) state_ = build_spec() ? 1 : 0;
-    if (!state_ || row->nT <= 0) return cFunctionals::doProcess(i, row, y);
+    if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Crossings, DCT, Onset, Peaks, Samples, ModulationSpec, pctlquotient, ...)"); return cFunctionals::doProcess(i, row, y); }
     io_.ensure(row->nT, nFunctValues);
     io_.up(row->data, row->nT);
     check(smilehip_funcspec_matrix(context(), &spec_, io_.d_in, 1, row->nT, 1, io_.d_out, nullptr));
@@ -1047,6 +1122,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
 // stays on the reference's CPU code. Names, frequency-axis info and the level meta data cPitchShs reads are inherited.
 class cHipSpecScale : public cSpecScale {
   FrameIO io_;
+  bool cpu_warned_ = false;
   smilehip_plan *pl_ = nullptr;
   int usable_ = -1;
  protected:
@@ -1061,7 +1137,7 @@ class cHipSpecScale : public cSpecScale {
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi);
+    if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave-scale spline set of the F0 chains on a 1024-point spectrum is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
     check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
@@ -1083,6 +1159,7 @@ class cHipSpecScale : public cSpecScale {
 // for six candidates with scores + voicing, F0raw + voicingClip, greedyPeakAlgo, no octave correction / lfCut / SHS dump.
 class cHipPitchShs : public cPitchShs {
   FrameIO io_;
+  bool cpu_warned_ = false;
   smilehip_plan *pl_ = nullptr;
   int usable_ = -1;
  protected:
@@ -1099,7 +1176,7 @@ class cHipPitchShs : public cPitchShs {
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi);
+    if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only six candidates with scores / voicing / F0raw / voicingClip and greedyPeakAlgo are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 21);
     io_.up(src, Nsrc);
     check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, 1, nullptr));
@@ -1112,6 +1189,189 @@ class cHipPitchShs : public cPitchShs {
   ~cHipPitchShs() override { if (pl_) smilehip_plan_destroy(pl_); }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPitchShs(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// the formant / voice-quality components of GeMAPSv01b_core.lld.conf.inc, per component, on ONE shared
+// eGeMAPS plan (its tables fix the geometry: 16 kHz, 512-point spectrum of 20 ms frames -> 220 samples at 11 kHz, p = 11;
+// 1024-point spectrum of 60 ms frames).
+smilehip_plan *g_gm_plan = nullptr;
+smilehip_plan *gemaps_plan() {
+  if (!g_gm_plan) {
+    smilehip_lld_config c;
+    smilehip_config_egemapsv02(&c);
+    check(smilehip_plan_create(context(), &c, &g_gm_plan));
+  }
+  return g_gm_plan;
+}
+
+// cSpecResample::processVector (src/dsp/specResample.cpp:175-185) for [gemapsv01b_resampLpc]
+class cHipSpecResample : public cSpecResample {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  int usable_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      const sDmLevelConfig *c = reader_->getLevelConfig();
+      usable_ = !isSet("resampleRatio") && getDouble("targetFs") == 11000.0 && !getStr("inputFieldPartial") && Nsrc == 512 && Ndst == 220 &&
+                std::fabs(c->basePeriod - 1.0 / 16000.0) < 1e-12 && std::fabs(c->lastFrameSizeSec - 0.020) < 1e-9;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(17, "cSpecResample: only targetFs = 11000 on the 512-value spectrum of 20 ms frames at 16 kHz is built");
+      return cSpecResample::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_specresample_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[17]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipSpecResample(const char *n) : cSpecResample(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipSpecResample(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, p = 11, saveLPCoeff only, on 220 samples
+class cHipLpc : public cLpc {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  int usable_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      const char *met = getStr("method");
+      usable_ = met && !strncasecmp(met, "acf", 3) && getInt("p") == 11 && getInt("saveLPCoeff") == 1 && !getInt("saveRefCoeff") &&
+                !getInt("lpGain") && !getInt("residual") && !getInt("lpSpectrum") && Nsrc == 220 && Ndst == 11;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(18, "cLpc: only method = acf, p = 11, saveLPCoeff alone on 220-sample frames is built");
+      return cLpc::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_lpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[18]++;
+    return 1;
+  }
+ public:
+  explicit cHipLpc(const char *n) : cLpc(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipLpc(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cFormantLpc::processVector (src/lld/formantLpc.cpp:192-290): 5 formants + bandwidths from 11 LP coefficients at 11 kHz
+class cHipFormantLpc : public cFormantLpc {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  int usable_ = -1;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      const sDmLevelConfig *c = reader_->getLevelConfig();
+      usable_ = getInt("nFormants") == 5 && getInt("saveFormants") == 1 && getInt("saveBandwidths") == 1 && !getInt("saveIntensity") &&
+                !getInt("saveNumberOfValidFormants") && !getInt("useLpSpec") && !getInt("medianFilter") && !getInt("octaveCorrection") &&
+                getDouble("minF") == 50.0 && getDouble("maxF") == 5450.0 && Nsrc == 11 && Ndst == 10 &&
+                std::fabs(c->basePeriod - 1.0 / 11000.0) < 1e-12;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(19, "cFormantLpc: only nFormants = 5 with bandwidths, minF 50, maxF 5450, no median filter / octave correction on "
+                          "11 coefficients at 11 kHz is built");
+      return cFormantLpc::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_formantlpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[19]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipFormantLpc(const char *n) : cFormantLpc(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipFormantLpc(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cHarmonics::processVector (src/lld/harmonics.cpp:743-1031) with [gemapsv01b_harmonics]'s options: the input vector holds the F0
+// element, the formant frequency / bandwidth fields and the 513-bin magnitude field; the positions are looked up by name as the
+// reference does in setupNewNames (:226-307).
+class cHipHarmonics : public cHarmonics {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  int usable_ = -1;
+  long iF0_ = -1, iSpec_ = -1, iFf_ = -1, iFb_ = -1, nSpec_ = 0, nFf_ = 0, nFb_ = 0;
+  DevBytes fm_, f0_;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (usable_ < 0) {
+      static const char *const diffs[2] = {"H1-H2", "H1-A3"};
+      bool ok = getInt("nHarmonics") == 100 && getInt("nHarmonicMagnitudes") == 0 && getInt("harmonicDifferencesLog") == 1 &&
+                !getInt("harmonicDifferencesRatioLinear") && getInt("formantAmplitudes") == 1 && getInt("formantAmplitudesLogRel") == 1 &&
+                !getInt("formantAmplitudesLinear") && getInt("formantAmplitudesStart") == 1 && getInt("formantAmplitudesEnd") == 3 &&
+                getInt("computeAcfHnrLogdB") == 1 && !getInt("computeAcfHnrLinear") && getDouble("logRelValueFloorUnvoiced") == -201.0 &&
+                getArraySize("harmonicDifferences") == 2 && Ndst == 6 && idxi == 0;
+      for (int i = 0; ok && i < 2; ++i) {
+        const char *v = getStr_f(myvprint("harmonicDifferences[%i]", i));
+        ok = v && !strcmp(v, diffs[i]);
+      }
+      if (ok) {
+        iF0_ = findElement(getStr("f0ElementName"), getInt("f0ElementNameIsFull"), NULL, NULL, NULL);
+        int specField = -1;
+        iSpec_ = findField(getStr("magSpecFieldName"), getInt("magSpecFieldNameIsFull"), &nSpec_, NULL, -1, NULL, &specField);
+        const char *ff = getStr("formantFrequencyFieldName"), *fb = getStr("formantBandwidthFieldName");
+        if (ff && fb) {
+          iFf_ = findField(ff, getInt("formantFrequencyFieldNameIsFull"), &nFf_, NULL, -1, NULL);
+          iFb_ = findField(fb, getInt("formantBandwidthFieldNameIsFull"), &nFb_, NULL, -1, NULL);
+        }
+        // the frequency axis the reference reads from the magnitude field's meta data (harmonics.cpp:753-777): 513 bins of 15.625 Hz
+        const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
+        bool axis = false;
+        if (fmeta && specField >= 0 && specField < fmeta->N && fmeta->field[specField].info &&
+            fmeta->field[specField].infoSize == 513 * (long)sizeof(double)) {
+          const double *frq = (const double *)fmeta->field[specField].info;
+          axis = frq[0] == 0.0 && frq[1] == 15.625 && frq[512] == 8000.0;
+        }
+        ok = axis && iF0_ >= 0 && iSpec_ >= 0 && iFf_ >= 0 && iFb_ >= 0 && nSpec_ == 513 && nFf_ == 5 && nFb_ == 5 && iSpec_ + 513 <= Nsrc;
+      }
+      usable_ = ok ? 1 : 0;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(20, "cHarmonics: only GeMAPS' option set (H1-H2, H1-A3, formant amplitudes 1..3, ACF HNR in dB; 5 formants, 513-bin "
+                          "spectrum of 60 ms frames at 16 kHz) is built");
+      return cHarmonics::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(513, 6);
+    io_.up(src + iSpec_, 513);
+    float fm[10];
+    memcpy(fm, src + iFf_, sizeof(float) * 5);
+    memcpy(fm + 5, src + iFb_, sizeof(float) * 5);
+    float *d_fm = (float *)fm_.ensure(sizeof(float) * 10), *d_f0 = (float *)f0_.ensure(sizeof(float));
+    if (smilehip_copy_to_device(context(), d_fm, fm, sizeof(fm), nullptr) ||
+        smilehip_copy_to_device(context(), d_f0, src + iF0_, sizeof(float), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+    check(smilehip_harmonics_frames(gemaps_plan(), d_f0, d_fm, 10, io_.d_in, 513, io_.d_out, 6, 1, nullptr));
+    io_.down(dst, 6);
+    g_frames[20]++;
+    return 1;
+  }
+ public:
+  explicit cHipHarmonics(const char *n) : cHarmonics(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipHarmonics(n);
     c->setComponentInfo(scname, sdescription);
     return c;
   }
@@ -1286,6 +1546,7 @@ struct TraceAtExit {
     FILE *f = fopen(path, "a");
     if (!f) return;
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
+    for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s.cpu %ld\n", g_names[i], g_cpu[i]);
     fclose(f);
   }
 } g_trace;
@@ -1310,12 +1571,16 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all seventeen
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-one
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
   if (want("cHipLldSource")) {                             // a NEW type (fused mode), not an override
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cHarmonics")) head = override_of(&cHarmonics::registerComponent, &cHipHarmonics::create, confman, compman, iteration, head);
+  if (want("cFormantLpc")) head = override_of(&cFormantLpc::registerComponent, &cHipFormantLpc::create, confman, compman, iteration, head);
+  if (want("cLpc")) head = override_of(&cLpc::registerComponent, &cHipLpc::create, confman, compman, iteration, head);
+  if (want("cSpecResample")) head = override_of(&cSpecResample::registerComponent, &cHipSpecResample::create, confman, compman, iteration, head);
   if (want("cPitchShs")) head = override_of(&cPitchShs::registerComponent, &cHipPitchShs::create, confman, compman, iteration, head);
   if (want("cSpecScale")) head = override_of(&cSpecScale::registerComponent, &cHipSpecScale::create, confman, compman, iteration, head);
   if (want("cFunctionals")) head = override_of(&cFunctionals::registerComponent, &cHipFunctionals::create, confman, compman, iteration, head);

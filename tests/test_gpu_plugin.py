@@ -344,3 +344,53 @@ def test_plugin_mfcc_e_z_config_all_overrides(oracle):
         assert tr.get(comp, 0) > 0, f"{comp} not routed through the plugin: {tr}"
     oracle.use_reference_fft(False)
     variant_tolerance(y, ref, 12, "plugin MFCC12_E_D_A_Z", oracle.htk_variant_chain("MFCC12_E_D_A", pcm))
+
+
+def test_plugin_egemaps_whole_graph(oracle):
+    """The UNMODIFIED eGeMAPSv02.conf (BASELINE config 5) inside the unmodified binary with every override active: the
+    GeMAPS-specific components (cSpectral's log-spectrum option sets, cSpecResample, cLpc, cFormantLpc, cHarmonics) push every
+    frame through the HIP operators -- none of them falls through to the CPU code -- and the 88 functionals land within the
+    chain's bars of the plain binary's (tests/test_gpu_egemaps.py explains the formant columns' floor)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "egemaps_lld_synth.npz"))
+    for k in ("u2_16000", "u4_9000"):
+        y, tr = _run(oracle, g["pcm_" + k], None, "egemaps/v02/eGeMAPSv02.conf", "-htkoutput")
+        ref = g["func_" + k].reshape(-1, 88)
+        assert y.shape == ref.shape == (1, 88)
+        T20 = g["loudness_" + k].shape[0]
+        T60 = g["pitch_" + k].shape[0]
+        assert tr["cSpecResample"] == T20 and tr["cLpc"] == T20 and tr["cFormantLpc"] == T20, tr
+        assert tr["cSpectral"] == 2 * T20 and tr["cHarmonics"] == T60, tr          # two cSpectral instances
+        for comp in ("cSpectral", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cTransformFFT", "cFFTmagphase", "cMelspec",
+                     "cMfcc", "cPlp", "cEnergy", "cFunctionals", "cSpecScale", "cPitchShs", "cWindower"):
+            assert tr.get(comp + ".cpu", 0) == 0, (comp, tr)
+        assert tr["cContourSmoother.cpu"] > 0        # the noZeroSma instances stay on the reference's code -- and say so
+        rel = np.abs(y[0].astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1e-2)
+        well = list(range(0, 30)) + list(range(81, 88))
+        assert rel[well].max() <= 1e-3 and (rel <= 1e-3).mean() >= 0.85, (k, rel[well].max(), (rel <= 1e-3).mean())
+
+
+def test_plugin_logs_cpu_fallthrough(oracle, golden_synth):
+    """An option set the HIP path does not cover runs the reference's code, with a warning in the log and a counter in the
+    trace -- never silently: config/mfcc/MFCC12_0_D_A.conf with cMfcc doLog = 0 is not built."""
+    import tempfile
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    with tempfile.TemporaryDirectory() as td:
+        conf = os.path.join(td, "m.conf")
+        base = os.path.join(oracle.REF_DIR, "config", "mfcc", "MFCC12_0_D_A.conf")
+        txt = open(base).read().replace("[mfcc:cMfcc]", "[mfcc:cMfcc]\ndoLog = 0")
+        txt = txt.replace("\\{../shared/", "\\{" + os.path.join(oracle.REF_DIR, "config", "shared") + "/")
+        open(conf, "w").write(txt)
+        wav, out, trace = (os.path.join(td, n) for n in ("in.wav", "out.htk", "trace.txt"))
+        oracle.write_wav(wav, golden_synth["pcm_u2_16000"])
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        r = subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "2"], cwd=PLUGDIR, env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip())
+        assert int(tr["cMfcc.cpu"]) == 98 and int(tr["cMfcc"]) == 0
+        assert "runs the reference's CPU code" in (r.stderr + r.stdout)
