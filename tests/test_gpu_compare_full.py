@@ -23,9 +23,13 @@ def hip():
 
 
 def f0_lld_tolerances(out, ref, what=""):
-    """The 12 F0-group columns. F0 / voicing are continuous (1e-5); jitter, shimmer and HNR follow from integer period
-    bounds derived from F0 and from the voiced/unvoiced pattern, so they agree exactly on almost every row and may
-    differ on the rare rows where a decision flips: at most 2 % of the rows may deviate by more than 1e-4 relative."""
+    """The 12 F0-group columns. F0 / voicing are continuous; jitter, shimmer and HNR follow from integer period bounds
+    derived from F0 and from the voiced/unvoiced pattern, so they agree exactly on almost every row and may differ on the
+    rare rows where a decision flips. Measured (profiles/r02_gate_margins.json, and 32 770 rows of fresh utterances in
+    profiles/r01_final_compare_parity.json): no row beyond 1e-4 of the column scale, 0.3 % of the rows beyond 1e-5, largest
+    deviation 8.8e-5 (a frame where the parabolic refinement of the SHS peak sits on a different float of the summation
+    spectrum). Gates at about twice that: <= 0.2 % of the rows beyond 1e-4 (one row for short inputs), <= 1 % beyond 1e-5,
+    nothing beyond 2e-4."""
     assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
     if out.shape[0] == 0:
         return
@@ -33,7 +37,13 @@ def f0_lld_tolerances(out, ref, what=""):
     scale = np.maximum(np.abs(r[:, :6]).max(axis=0), 1e-6)
     scale = np.concatenate([scale, scale])
     bad = (np.abs(o - r) > 1e-4 * scale[None, :]).any(axis=1)
-    assert bad.mean() <= 0.02, f"{what}: {int(bad.sum())} of {len(bad)} rows deviate"
+    from tolerance import record
+    record("f0_lld_tolerances", what=what, rows=len(bad), bad_frac=bad.mean(), bad5_frac=(np.abs(o - r) > 1e-5 * scale[None, :]).any(axis=1).mean(),
+           max_scaled=(np.abs(o - r) / scale[None, :]).max())
+    assert bad.sum() <= max(1, 0.002 * len(bad)), f"{what}: {int(bad.sum())} of {len(bad)} rows deviate by more than 1e-4"
+    bad5 = (np.abs(o - r) > 1e-5 * scale[None, :]).any(axis=1)
+    assert bad5.sum() <= max(1, 0.01 * len(bad5)), f"{what}: {int(bad5.sum())} of {len(bad5)} rows deviate by more than 1e-5"
+    assert (np.abs(o - r) / scale[None, :]).max() <= 2e-4, f"{what}: largest deviation {(np.abs(o - r) / scale[None, :]).max():.3g}"
 
 
 def test_compare_full_golden_batch_ragged(hip, golden_f0):

@@ -99,8 +99,9 @@ def test_group_b_extra_row_vs_binary_levels(hip, oracle, golden):
 def test_functionals16_vs_binary_statistics(hip, golden):
     """Against the real binary's vectors. Smooth functionals (means, moments, regression, quartiles ...) follow the LLD
     tolerance; discontinuous ones (arg-max positions, level-crossing counts, segment and peak statistics) can jump when an
-    input differs in the last bit. Bar: on every utterance >= 90 % of the 6373 values within 1e-3 of the binary's
-    (relative to max(|value|, the functional's own spread over the LLDs)), median error <= 1e-5."""
+    input differs in the last bit. Measured (profiles/r02_gate_margins.json): 98.5 - 100 % of the 6373 values within 1e-3 of the
+    binary's (relative to max(|value|, 1e-2)), 92 - 99 % within 1e-5, median error 0. Bar: >= 97 % within 1e-3 on every
+    utterance, >= 85 % within 1e-5, median <= 1e-6."""
     capi, ctx, plan = hip
     pcms = [golden["pcm_" + k] for k in KEYS]
     off = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
@@ -110,8 +111,11 @@ def test_functionals16_vs_binary_statistics(hip, golden):
         ref = golden["func_" + key].astype(np.float64)
         err = np.abs(func[u] - ref) / np.maximum(np.abs(ref), 1e-2)
         frac = (err <= 1e-3).mean()
-        assert frac >= 0.90, f"{key}: only {frac:.3f} of the values within 1e-3"
-        assert np.median(err) <= 1e-5, f"{key}: median {np.median(err):.3g}"
+        from tolerance import record
+        record("func16_vs_binary", key=key, within_1em3=frac, median=np.median(err), within_1em5=(err <= 1e-5).mean())
+        assert frac >= 0.97, f"{key}: only {frac:.3f} of the values within 1e-3"
+        assert (err <= 1e-5).mean() >= 0.85, f"{key}: only {(err <= 1e-5).mean():.3f} of the values within 1e-5"
+        assert np.median(err) <= 1e-6, f"{key}: median {np.median(err):.3g}"
     b.close()
 
 

@@ -20,9 +20,10 @@ def hip():
 
 
 def check_lld(out, ref, what):
-    """Continuous columns: 1e-5 of their natural scale. ZCR: exact. F0: the pitch
-    decision is a peak pick on the cepstrum (discontinuous), isolated frames may flip;
-    flips are counted and bounded, and the smoother spreads one flip over ~3 frames."""
+    """Continuous columns: 1e-5 of their natural scale (measured 1.9e-6). ZCR: exact. voiceProb: measured 1.8e-7, gate
+    1e-6. F0: the pitch decision is a peak pick on the cepstrum (discontinuous), isolated frames may flip and the smoother
+    spreads one flip over ~3 frames: measured 0 flips on every test input (profiles/r02_gate_margins.json), gate one flip
+    event (3 rows) or 0.5 % of the rows."""
     assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
     assert np.isfinite(out).all()
     d = np.abs(out.astype(np.float64) - ref)
@@ -34,9 +35,12 @@ def check_lld(out, ref, what):
     assert d[:, 0].max() <= 1e-5 * max(float(ref[:, 0].max()), 1e-3), f"{what}: energy"
     assert d[:, 16].max() <= 1e-5 * max(float(ref[:, 0].max()), 1e-3), f"{what}: energy delta"
     assert d[:, 13].max() == 0.0 and d[:, 29].max() == 0.0, f"{what}: zcr must be exact"
-    assert d[:, 14].max() <= 1e-4, f"{what}: voiceProb {d[:, 14].max()}"
+    assert d[:, 14].max() <= 1e-6, f"{what}: voiceProb {d[:, 14].max()}"
     flips = (d[:, 15] > 1e-3 * np.maximum(np.abs(ref[:, 15]), 1.0)).mean()
-    assert flips <= 0.03, f"{what}: F0 differs on {flips * 100:.1f}% of rows"
+    from tolerance import record
+    record("is09_check_lld", what=what, rows=out.shape[0], voiceprob_max=d[:, 14].max(), f0_flip_frac=flips,
+           mfcc_max=(d[nz][:, 1:13] / mscale[nz]).max() if nz.any() else 0.0)
+    assert flips * out.shape[0] <= max(3, 0.005 * out.shape[0]), f"{what}: F0 differs on {flips * 100:.1f}% of rows"
     return flips
 
 

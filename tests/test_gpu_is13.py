@@ -69,7 +69,9 @@ def test_is13_lld_and_functionals(hip, oracle, golden):
             assert pos == 6373
             gref = golden["func_" + key].astype(np.float64)
             err = np.abs(func[u] - gref) / np.maximum(np.abs(gref), 1e-2)
-            assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5, key
+            from tolerance import record
+            record("is13_func_vs_binary", key=key, within_1em3=(err <= 1e-3).mean(), median=np.median(err))
+            assert (err <= 1e-3).mean() >= 0.97 and np.median(err) <= 1e-6, key       # measured 0.987 / 0
     finally:
         oracle.compare_set_is13(False)
     b.close()

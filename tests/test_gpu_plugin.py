@@ -314,7 +314,9 @@ def test_plugin_fused_source_compare16_functionals(oracle):
         assert open(htk, "rb").read()[:12] == open(os.path.join(G, "compare16_func_u3.htk"), "rb").read()[:12]
         x, xr = oracle.read_htk(htk)[0], oracle.read_htk(os.path.join(G, "compare16_func_u3.htk"))[0]
         err = np.abs(x[0].astype(np.float64) - xr[0]) / np.maximum(np.abs(xr[0]), 1e-2)
-        assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+        from tolerance import record
+        record("plugin_func16_source", within_1em3=(err <= 1e-3).mean(), median=np.median(err))
+        assert (err <= 1e-3).mean() >= 0.99 and np.median(err) <= 1e-6          # measured 0.9969 / 0
         head = open(csv).readline().strip().split(";")
         assert head[:2] == ["name", "frameTime"] and len(head) == 6375
         row = open(csv).read().split("\n")[1].split(";")

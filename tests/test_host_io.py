@@ -226,7 +226,9 @@ def test_smilextract_hip_compare16_functionals(tmp_path):
     hr, xr = read_htk(os.path.join(G, "compare16_func_u3.htk"))
     assert h == hr and x.shape == xr.shape == (1, 6373)
     err = np.abs(x[0].astype(np.float64) - xr[0]) / np.maximum(np.abs(xr[0]), 1e-2)
-    assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+    from tolerance import record
+    record("front_end_compare16_func", within_1em3=(err <= 1e-3).mean(), median=np.median(err))
+    assert (err <= 1e-3).mean() >= 0.99 and np.median(err) <= 1e-6              # measured 0.9969 / 0
 
 
 @pytest.mark.gpu
@@ -245,7 +247,9 @@ def test_smilextract_hip_is13_compare(tmp_path):
     assert x.shape == (1, 6373) and l.shape == g["lld130_u4_9000"].shape
     ref = g["func_u4_9000"].astype(np.float64)
     err = np.abs(x[0] - ref) / np.maximum(np.abs(ref), 1e-2)
-    assert (err <= 1e-3).mean() >= 0.90 and np.median(err) <= 1e-5
+    from tolerance import record
+    record("front_end_is13_func", within_1em3=(err <= 1e-3).mean(), median=np.median(err))
+    assert (err <= 1e-3).mean() >= 0.985 and np.median(err) <= 1e-6             # measured 0.9934 / 0
 
 
 @pytest.mark.gpu

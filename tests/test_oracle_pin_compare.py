@@ -23,9 +23,10 @@ def test_compare_ab_bit_exact_with_reference_fft(oracle, golden_compare, key):
 
 
 def compare_tolerances(out, ref, what=""):
-    """Per-descriptor gates for the built-in / HIP FFT (continuous quantities: 1e-5 of the
-    column's own scale over the utterance, mfcc per frame; roll-off points are bin
-    frequencies picked by a threshold test and may move by one bin on rare frames)."""
+    """Per-descriptor gates for the built-in / HIP FFT. Continuous quantities on the column's own scale over the
+    utterance, mfcc per frame: measured 1.7e-6 / 2.4e-6 (profiles/r02_gate_margins.json), gates 5e-6. Roll-off points
+    are bin frequencies picked by a threshold test and may move by one bin on rare frames: none moved on any test input
+    nor on 32 770 rows of fresh utterances (profiles/r01_final_compare_parity.json); gate 0.2 % of the cells."""
     assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
     assert np.isfinite(out).all()
     o, r = out.astype(np.float64), ref.astype(np.float64)
@@ -38,12 +39,15 @@ def compare_tolerances(out, ref, what=""):
         rel = d[:, cols] / scale[None, :]
         ro = [32, 33, 34, 35]                              # roll-off columns (bin frequencies)
         other = [c for c in range(D) if c not in ro and c < 45]
-        assert rel[:, other].max() <= 2e-5, f"{what}: col {other[int(rel[:, other].max(axis=0).argmax())]} rel {rel[:, other].max():.2e}"
+        assert rel[:, other].max() <= 5e-6, f"{what}: col {other[int(rel[:, other].max(axis=0).argmax())]} rel {rel[:, other].max():.2e}"
         # mfcc 1..14: per-frame scale
         ms = np.maximum(np.abs(r[:, 45:59]).max(axis=1, keepdims=True), 1e-12)
-        assert (d[:, half + 45:half + 59] / ms).max() <= 1e-5, f"{what}: mfcc"
+        assert (d[:, half + 45:half + 59] / ms).max() <= 5e-6, f"{what}: mfcc"
         moved = (d[:, [c + half for c in ro]] > 1e-3).mean()
-        assert moved <= 0.02, f"{what}: roll-off moved on {moved * 100:.1f}% of cells"
+        from tolerance import record
+        record("compare_tolerances", what=what, half=half, other_max=rel[:, other].max(), mfcc_max=(d[:, half + 45:half + 59] / ms).max(),
+               rolloff_moved_frac=moved)
+        assert moved <= 0.002, f"{what}: roll-off moved on {moved * 100:.1f}% of cells"
 
 
 @pytest.mark.parametrize("key", KEYS)

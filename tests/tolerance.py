@@ -16,6 +16,18 @@ import numpy as np
 RTOL = 1e-5
 
 
+def record(gate, **measured):
+    """Margin bookkeeping: with SMILEHIP_GATE_LOG=<file> every gate appends what it measured (one JSON object per line), so
+    that the thresholds can be kept at about twice the measured error (profiles/rNN_gate_margins.json) instead of drifting
+    apart from it."""
+    import json
+    import os
+    path = os.environ.get("SMILEHIP_GATE_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"gate": gate, **{k: (float(v) if not isinstance(v, str) else v) for k, v in measured.items()}}) + "\n")
+
+
 def corpus_col_scale(refs, block):
     """s_col of gate (iii): 99th percentile of |ref| per STATIC column, pooled
     over the evaluation corpus `refs` (list of T x D reference matrices)."""
