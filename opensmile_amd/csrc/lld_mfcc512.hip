@@ -25,10 +25,12 @@
 //           X[k] and X[256-k] from one (Z[k], Z[256-k]) pair (R4), power (R5,
 //           R6's square) -> LDS
 //   mel     R6 as table-driven work units: a unit = one aligned octet of bins
-//           x one band (8 weights, zero outside the band), units dealt round
-//           robin to the 16 lanes: 2 x ds_read_b128 of power + 2 x b128 of
-//           weights + 8 FMA per unit, partial sums to LDS slots, band lanes add
-//           their partials in a fixed order, log floor
+//           x one band (8 weights, zero outside the band): 2 x ds_read_b128 of
+//           power + 2 x b128 of weights + 8 FMA. Whole bands are dealt to the 16
+//           lanes, at most two per lane and UC (6 or 8) units per lane, so a band
+//           is summed in registers in unit order and its lane takes the log; the
+//           unit offsets are loop-invariant registers and the UC units of a pass
+//           are independent LDS reads (no partial-sum round trip)
 //   cep     DCT-II rows + lifter (R7): one lane per coefficient, b128 reads
 //
 // Numerics: R2/R3 keep the reference's rounding sequence on integer-valued
@@ -50,6 +52,13 @@
 #include "lld_params.hpp"
 #include "tables.hpp"
 
+#ifndef SMILEHIP_V_DIRECT
+#define SMILEHIP_V_DIRECT 1
+#endif
+#ifndef SMILEHIP_V_DPPUNT
+#define SMILEHIP_V_DPPUNT 1
+#endif
+
 namespace smilehip {
 
 namespace {
@@ -61,7 +70,6 @@ constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame 
 constexpr int kTB2Row = 65;           // float2 per 4-group row of the transpose buffer (520 B)
 constexpr int kTB2Floats = 2 * (15 * kTB2Row + 3 * 16 + 16);   // 2078 floats: footprint of the transpose buffer
 constexpr int kMaxUnitsPerLane = 8;
-constexpr int kMaxSlots = 96;
 constexpr int kMinStage = 576;        // PS + lmel (4 x 144 floats) alias the stage area
 
 constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
@@ -196,6 +204,43 @@ __device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_tot
   }
 }
 
+// Direct variant (ALIGNED only): lane (g, j) loads the sample pairs it will transform itself -- pair j + 16 m of frame
+// tp + g, m = 0..MP-1 -- so that a frame never passes through an LDS stage area (a ds_write_b64 costs ~6 LDS cycles per
+// wave, MI355X_MICROARCH.md LDS table; the vector-memory pipe is otherwise idle and the 2.5x overlap of the frames is
+// served by L1/L2). `base` = first sample of the pass's first frame minus the left padding; the per-lane byte offset
+// (g * H + 2 j) * 2 is one VGPR and load m adds the immediate 64 m. Samples outside a frame meet a zero of the window
+// table and every stored frame lies inside its utterance, so out-of-range addresses are only clamped into the buffer.
+template <int MP>
+__device__ __forceinline__ void pcm_prefetch_direct(const int16_t *pcm, int64_t pcm_total, int64_t base, int H, int lane,
+                                                    uint32_t (&pair)[16]) {
+  uint32_t lo = ((uint32_t)(lane >> 4) * (uint32_t)H + 2u * (uint32_t)(lane & 15)) * 2u;
+  asm volatile("" : "+v"(lo));
+  const unsigned char *span = reinterpret_cast<const unsigned char *>(pcm + base);
+  const int64_t room = pcm_total - base;
+  if (base >= 0 && room >= (int64_t)(3 * H + 32 * MP)) {
+#pragma unroll
+    for (int m = 0; m < MP; ++m) pair[m] = *reinterpret_cast<const uint32_t *>(span + 64 * m + lo);
+  } else {                                               // first / last span of the buffer (wave-uniform, rare)
+    const int64_t last = ((pcm_total >> 1) - 1) * 2;     // last even sample index with a whole pair behind it
+    const int32_t lim_lo = base < 0 ? (int32_t)(-base) * 2 : 0;
+    int64_t hi64 = (last - base) * 2;
+    hi64 = hi64 > (1 << 24) ? (1 << 24) : hi64;
+    const int32_t lim_hi = hi64 < lim_lo ? lim_lo : (int32_t)hi64;
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+      int32_t off = (int32_t)lo + 64 * m;
+      off = off < lim_lo ? lim_lo : (off > lim_hi ? lim_hi : off);
+      pair[m] = *reinterpret_cast<const uint32_t *>(span + off);
+    }
+  }
+}
+
+// DPP move with a compile-time control word (row_ror:n = 0x120 + n, row_mirror = 0x140, row_newbcast:n = 0x150 + n)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // value of lane-1 (wave-wide shift right by one lane, DPP wave_shr:1); lane 0 receives `fill`
 __device__ __forceinline__ float lane_shr1(float v, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -218,19 +263,20 @@ __device__ unsigned long long g_phase[16];
 
 // LDS layout (dynamic), sizes in floats:
 //   shared tables : tw512 [256 f2] | win [MP*16 f2] | tw256 [256 f2, index k1*16+j] |
-//                   melw0 [U*16 f4] | melw1 [U*16 f4] | melo [U*16 u32] | dct [16 x 28] | slots [64 i32]
+//                   melw0 [UC*16 f4] | melw1 [UC*16 f4] | dct [16 x 28] | plp [48]
 //   per wave      : stage [S >= 512] (later PS+lmel: 4 x 144) | spec [4] | 4 x group buffer [272];
 //                   the (re,im) transpose buffer [2078] overlays all of it between frame load and untangle
-template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP>
+template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP, int UC>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool DIRECT = ALIGNED && SMILEHIP_V_DIRECT;
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; tell the compiler so that everything derived from it
   // (tile, utterance, offsets, pointers) lives in SGPRs instead of VGPR pairs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int j = lane & 15;
-  const int U = F.mel_units;
+  constexpr int U = UC;
   const int stage_floats = F.stage_floats;
   const int stage_alloc = F.stage_alloc;
 
@@ -240,33 +286,33 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   float2 *s_tw256 = s_win + MP * 16;
   float4 *s_melw0 = reinterpret_cast<float4 *>(s_tw256 + 256);
   float4 *s_melw1 = s_melw0 + U * 16;
-  uint32_t *s_melo = reinterpret_cast<uint32_t *>(s_melw1 + U * 16);
-  float *s_dct = reinterpret_cast<float *>(s_melo + U * 16);
-  int32_t *s_slots = reinterpret_cast<int32_t *>(s_dct + 16 * 28);
-  float *s_plp = reinterpret_cast<float *>(s_slots + 64);            // PLP chain: eql[32] | sintable[16]
-  const int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 9 + 16 * 28 + 64 + 48;
+  float *s_dct = reinterpret_cast<float *>(s_melw1 + U * 16);
+  float *s_plp = s_dct + 16 * 28;                                    // PLP chain: eql[32] | sintable[16]
+  constexpr int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 8 + 16 * 28 + 48;
   const int wave_floats = wave_region_floats(stage_alloc);
   float *wbase = smem + shared_floats + wave * wave_floats;
   float *s_stage = wbase;
   float *s_spec = wbase + stage_alloc;
   float *s_gb = s_spec + 4 + g * kGroupFloats;                    // my group's buffer: TB -> ZX -> PB
-  float *s_ps = s_stage + g * 144;                                // partial mel sums (aliases stage); 144: odd multiple of 16 banks
-  float *s_lmel = s_ps + kMaxSlots;                               // log-mel of the frame (32 floats)
+  float *s_lmel = s_stage + g * 144;                              // log-mel of the frame (32 floats; aliases stage); 144: odd multiple of 16 banks
+  float *s_ps = s_lmel + 48;                                      // PLP: 16 cepstra behind the band vector and its 16 acf lags
 
   // ---- cooperative load of the shared tables
   for (int i = threadIdx.x; i < 256; i += blockDim.x) { s_tw512[i] = F.tw512[i]; s_tw256[i] = F.tw256[i]; }
   for (int i = threadIdx.x; i < MP * 16; i += blockDim.x) s_win[i] = F.win[i];
-  for (int i = threadIdx.x; i < U * 16; i += blockDim.x) {
-    s_melw0[i] = F.melw[2 * i]; s_melw1[i] = F.melw[2 * i + 1]; s_melo[i] = F.melo[i];
-  }
+  for (int i = threadIdx.x; i < U * 16; i += blockDim.x) { s_melw0[i] = F.melw[2 * i]; s_melw1[i] = F.melw[2 * i + 1]; }
   for (int i = threadIdx.x; i < 16 * 28; i += blockDim.x) s_dct[i] = F.dct28[i];
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_slots[i] = F.band_slots[i];
   if (PLP) {
     for (int i = threadIdx.x; i < 32; i += blockDim.x) s_plp[i] = F.plp_eql[i];
     for (int i = threadIdx.x; i < 16; i += blockDim.x) s_plp[32 + i] = F.plp_sin[i];
   }
   __syncthreads();
 
+  uint32_t mo[UC];                              // byte offsets of my units' octets in the power buffer
+#pragma unroll
+  for (int i = 0; i < UC; ++i) mo[i] = F.melo[i * 16 + j];
+  const uint32_t lane_bands = (uint32_t)F.band_slots[j];   // units of my first band | first band << 8 | second band << 16 (0xff: none)
+  const int n0 = (int)(lane_bands & 0xffu), band0 = (int)((lane_bands >> 8) & 0xffu), band1 = (int)((lane_bands >> 16) & 0xffu);
   const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;    // my cell relative to the pass's first output row
   const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
   const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
@@ -301,7 +347,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   }
   int tp = 0;                                          // first frame of the pass, relative to the tile
   PcmRegs R;
-  pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, cur_samp0, P.H, lane, R);
+  uint32_t D[16];                                      // direct variant: my MP sample pairs of the coming pass
+  if constexpr (DIRECT) pcm_prefetch_direct<MP>(P.pcm, P.pcm_total, cur_samp0 - P.pad_left, P.H, lane, D);
+  else pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, cur_samp0, P.H, lane, R);
   unsigned char *pend_row = nullptr;                   // deferred store of the previous pass (wave-uniform row base)
   float pend_val = 0.0f;
   bool pend_live = false;
@@ -309,59 +357,91 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   for (;;) {
     const bool live = tp + g < cur_n;
     PHASE(0);                                   // loop overhead
-    // ------------------------------------------------------------ stage PCM (R0 scale folded, R2)
-    {
-      float carry = 0.0f;                       // odd sample of lane 63 of the previous step
+    float re[16], im[16];
+    if constexpr (DIRECT) {
+      // -------------------------------------------------------- frame from registers: R0 (scale folded), R2, R3
+      if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
+        uint32_t oo = out_off;
+        asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
+        *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+      }
+      float tprev = 0.0f;                          // odd sample of pair 15 + 16 (m-1), as seen by lane j = 0
 #pragma unroll
-      for (int r = 0; r < NSTEPS; ++r) {
-        {
-          const float a = (float)(int16_t)(R.pair[r] & 0xffffu);
-          const float b = (float)(int16_t)(R.pair[r] >> 16);
+      for (int m = 0; m < 16; ++m) {
+        if (m < MP) {
+          const float a = (float)(int16_t)(D[m] & 0xffffu);
+          const float b = (float)(int16_t)(D[m] >> 16);
           float ya = a, yb = b;
           if (PREEMPH) {
-            const float pa = lane_shr1(b, carry);
-            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+            const float t = dpp_f<0x121>(b);       // row_ror:1 -- lane j sees the odd sample of pair j-1 (lane 0: of lane 15)
+            const float pa = (j == 0) ? tprev : t;
+            tprev = t;
             ya = a - kpre * pa;
             yb = b - kpre * a;
+            if (m == m0 && j == j0) ya = P.one_minus_k * a;      // y[0] = (1-k) x[0]
           }
-          const int i2 = lane + 64 * r;
-          if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
+          const float2 w = s_win[m * 16 + j];
+          re[m] = ya * w.x;
+          im[m] = yb * w.y;
+        } else {
+          re[m] = 0.0f; im[m] = 0.0f;
         }
       }
-      if (PREEMPH && lane < 4) {
-        uint32_t l4 = 4u * (uint32_t)lane;
-        asm volatile("" : "+v"(l4));               // recompute the address rather than keep (and spill) it
-        *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_spec) + l4) = P.one_minus_k * (float)R.first;
+      PHASE(1);
+    } else {
+      // ------------------------------------------------------------ stage PCM (R0 scale folded, R2)
+      {
+        float carry = 0.0f;                       // odd sample of lane 63 of the previous step
+  #pragma unroll
+        for (int r = 0; r < NSTEPS; ++r) {
+          {
+            const float a = (float)(int16_t)(R.pair[r] & 0xffffu);
+            const float b = (float)(int16_t)(R.pair[r] >> 16);
+            float ya = a, yb = b;
+            if (PREEMPH) {
+              const float pa = lane_shr1(b, carry);
+              carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+              ya = a - kpre * pa;
+              yb = b - kpre * a;
+            }
+            const int i2 = lane + 64 * r;
+            if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
+          }
+        }
+        if (PREEMPH && lane < 4) {
+          uint32_t l4 = 4u * (uint32_t)lane;
+          asm volatile("" : "+v"(l4));               // recompute the address rather than keep (and spill) it
+          *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_spec) + l4) = P.one_minus_k * (float)R.first;
+        }
+      }
+      {
+        int32_t f_ = R.first;
+        asm volatile("" : : "v"(f_));             // every prefetched register is consumed here, unconditionally
+      }
+      if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
+        uint32_t oo = out_off;
+        asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
+        *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+      }
+      wave_lds_fence();
+      PHASE(1);                                   // wait for the prefetch + stage
+      // ------------------------------------------------------------ load frame (R3)
+  #pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if (m < MP) {
+          int e = fo + 32 * m;
+          e = e < 0 ? 0 : e;                     // left zero padding: window is 0 there, keep the address legal
+          float2 v = *reinterpret_cast<const float2 *>(s_stage + e);
+          if (PREEMPH && m == m0 && j == j0) v.x = s_spec[g];   // y[0] = (1-k) x[0]
+          const float2 w = s_win[m * 16 + j];
+          re[m] = v.x * w.x;
+          im[m] = v.y * w.y;
+        } else {
+          re[m] = 0.0f; im[m] = 0.0f;
+        }
       }
     }
-    {
-      int32_t f_ = R.first;
-      asm volatile("" : : "v"(f_));             // every prefetched register is consumed here, unconditionally
-    }
-    if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
-      uint32_t oo = out_off;
-      asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
-      *reinterpret_cast<float *>(pend_row + oo) = pend_val;
-    }
-    wave_lds_fence();
-    PHASE(1);                                   // wait for the prefetch + stage
-    // ------------------------------------------------------------ load frame (R3)
-    float re[16], im[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      if (m < MP) {
-        int e = fo + 32 * m;
-        e = e < 0 ? 0 : e;                     // left zero padding: window is 0 there, keep the address legal
-        float2 v = *reinterpret_cast<const float2 *>(s_stage + e);
-        if (PREEMPH && m == m0 && j == j0) v.x = s_spec[g];   // y[0] = (1-k) x[0]
-        const float2 w = s_win[m * 16 + j];
-        re[m] = v.x * w.x;
-        im[m] = v.y * w.y;
-      } else {
-        re[m] = 0.0f; im[m] = 0.0f;
-      }
-    }
-    wave_lds_fence();   // stage area is dead from here (PS/lmel alias it)
+    if constexpr (!DIRECT) wave_lds_fence();   // stage area is dead from here (PS/lmel alias it)
     PHASE(2);                                   // frame load x window
 
     // ------------------------------------------------------------ 256-point complex FFT
@@ -397,6 +477,23 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     // ------------------------------------------------------------ untangle pairs + power
     // lane j writes Z[j+16 k2], k2 = 8..15 (what lane 16-j needs); reads the partner's
     // Z[256 - (j+16 q)] for q = 0..7.
+#if SMILEHIP_V_DPPUNT
+    // The partner of lane j is lane (16 - j) & 15 of the same row, reached without an LDS round trip: shift the row one
+    // lane down (row_shl:1, lane j <- lane j+1), then row_mirror (lane j <- lane 15 - j), the mirror riding on the add/sub
+    // that consumes the value. Lane 0 is its own partner one register up (bin 256 - 16 q = 0 + 16 (16 - q)): its value is
+    // parked in lane 15 first (row_ror:15), where the shift has no source and leaves it. q = 0 of lane 0 is the
+    // DC/Nyquist pair, handled below.
+    float zr[8], zi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float pr = q > 0 ? dpp_f<0x12f>(re[(16 - q) & 15]) : re[15];
+      const float pi = q > 0 ? dpp_f<0x12f>(im[(16 - q) & 15]) : im[15];
+      const float tr = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pr), __float_as_int(re[15 - q]), 0x101, 0xf, 0xf, false));
+      const float ti = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pi), __float_as_int(im[15 - q]), 0x101, 0xf, 0xf, false));
+      zr[q] = dpp_f<0x140>(tr);
+      zi[q] = dpp_f<0x140>(ti);
+    }
+#else
     float2 *s_zx = reinterpret_cast<float2 *>(s_gb);
 #pragma unroll
     for (int k2 = 8; k2 < 16; ++k2) s_zx[(k2 - 8) * 16 + j] = make_float2(re[k2], im[k2]);
@@ -408,6 +505,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       zr[q] = v.x; zi[q] = v.y;
     }
     wave_lds_fence();   // partner reads done: the buffer becomes PB
+#endif
     float *s_pb = s_gb;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -445,43 +543,45 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     const bool advance = ntp >= cur_n;
     const bool more = !advance || has_next;
     if (advance) ntp = 0;
-    if (more) pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, (advance ? nxt_samp0 : cur_samp0) + (int64_t)ntp * P.H, P.H, lane, R);
+    if (more) {
+      const int64_t nb = (advance ? nxt_samp0 : cur_samp0) + (int64_t)ntp * P.H;
+      if constexpr (DIRECT) pcm_prefetch_direct<MP>(P.pcm, P.pcm_total, nb - P.pad_left, P.H, lane, D);
+      else pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, nb, P.H, lane, R);
+    }
 
     PHASE(7);                                   // prefetch issue
     // ------------------------------------------------------------ mel (R6)
-#ifdef SMILEHIP_DEBUG_SKIP_MEL
-    for (int i = 0; i < 1; ++i) {
-#else
-    for (int i = 0; i < U; ++i) {
-#endif
-      const uint32_t o = s_melo[i * 16 + j];
-      const float4 *pp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(s_pb) + (o & 0xffffu));
-      const float4 p0 = pp[0], p1 = pp[1];
-      const float4 w0 = s_melw0[i * 16 + j], w1 = s_melw1[i * 16 + j];
-      float acc = p0.x * w0.x;
-      acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
-      acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
-      s_ps[o >> 16] = acc;        // slot of the unit (dummy slot for padding units)
-    }
-    wave_lds_fence();
-    PHASE(8);                                   // mel units
-    // band sums: lane j handles bands j and j+16 (pads up to 32 with zeros for the b128 DCT reads)
+    {
+      float a0 = 0.0f, a1 = 0.0f;                 // my two bands; a band's units are added in unit order, starting from 0
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int b = j + 16 * h;
-      if (b < P.n_bands) {
-        float acc = 0.0f;
-        for (int s = s_slots[2 * b]; s < s_slots[2 * b + 1]; ++s) acc += s_ps[s];
-        if (PLP) {                                     // R8: floor, HTK equal loudness, power-law compression (plp.cpp:499-507)
-          float v = acc * F.mel_scale;
-          v = v < P.melfloor ? P.melfloor : v;
-          s_lmel[b] = __expf(P.plp_compression * __logf(v * s_plp[b]));
-        } else {
-          s_lmel[b] = log_mel_fast(acc * F.mel_scale, P.melfloor, P.log_floor);
-        }
-      } else {
-        s_lmel[b] = 0.0f;
+      for (int i = 0; i < UC; ++i) {
+        const float4 *pp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(s_pb) + mo[i]);
+        const float4 p0 = pp[0], p1 = pp[1];
+        const float4 w0 = s_melw0[i * 16 + j], w1 = s_melw1[i * 16 + j];
+        float acc = p0.x * w0.x;
+        acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
+        acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
+        const bool first = i < n0;
+        a0 += first ? acc : 0.0f;                 // x + 0 is exact
+        a1 += first ? 0.0f : acc;
       }
+      PHASE(8);                                   // mel units
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int b = h ? band1 : band0;
+        const float acc = h ? a1 : a0;
+        if (b != 0xff) {
+          if (PLP) {                                     // R8: floor, HTK equal loudness, power-law compression (plp.cpp:499-507)
+            float v = acc * F.mel_scale;
+            v = v < P.melfloor ? P.melfloor : v;
+            s_lmel[b] = __expf(P.plp_compression * __logf(v * s_plp[b]));
+          } else {
+            s_lmel[b] = log_mel_fast(acc * F.mel_scale, P.melfloor, P.log_floor);
+          }
+        }
+      }
+      if (j + 16 >= P.n_bands) s_lmel[j + 16] = 0.0f;     // pads up to 32 for the b128 DCT reads
+      if (j >= P.n_bands) s_lmel[j] = 0.0f;
     }
     wave_lds_fence();
 
@@ -613,18 +713,53 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
     h.band_slots[2 * b + 1] = int32_t(units.size());
   }
   h.n_slots = int(units.size());
-  if (h.n_slots + 1 > kMaxSlots) return -1;
-  h.mel_units = (h.n_slots + 15) / 16;
-  if (h.mel_units > kMaxUnitsPerLane || h.mel_units < 1) return -1;
-  h.melw.assign(size_t(h.mel_units) * 16 * 2, make_float4(0.f, 0.f, 0.f, 0.f));
-  h.melo.assign(size_t(h.mel_units) * 16, uint32_t(h.n_slots) << 16);     // padding units: octet 0, dummy slot
-  for (int c = 0; c < h.n_slots; ++c) {
-    const int lane = c % 16, pos = c / 16;
-    const size_t idx = size_t(pos) * 16 + lane;
-    h.melw[2 * idx] = make_float4(units[c].w[0], units[c].w[1], units[c].w[2], units[c].w[3]);
-    h.melw[2 * idx + 1] = make_float4(units[c].w[4], units[c].w[5], units[c].w[6], units[c].w[7]);
-    h.melo[idx] = units[c].off | (uint32_t(c) << 16);
+  // Whole bands to lanes: at most two bands and `cap` units per lane (cap = 6 or 8: the two unit counts the kernel is
+  // instantiated for). Largest band first, partnered with the largest remaining band that still fits.
+  const int nb = mel.n_bands;
+  std::vector<int> size(nb), order(nb);
+  for (int b = 0; b < nb; ++b) { size[b] = h.band_slots[2 * b + 1] - h.band_slots[2 * b]; order[b] = b; }
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return size[x] > size[y]; });
+  int cap = 0;
+  std::vector<std::pair<int, int>> lanes;          // (first band, second band or -1)
+  for (int c : {6, 8}) {
+    lanes.clear();
+    std::vector<char> used(nb, 0);
+    bool ok = true;
+    for (int oi = 0; oi < nb && ok; ++oi) {
+      const int a = order[oi];
+      if (used[a]) continue;
+      used[a] = 1;
+      if (size[a] > c) { ok = false; break; }
+      int partner = -1;
+      for (int oj = oi + 1; oj < nb; ++oj)
+        if (!used[order[oj]] && size[a] + size[order[oj]] <= c) { partner = order[oj]; break; }
+      if (partner >= 0) used[partner] = 1;
+      lanes.push_back({a, partner});
+    }
+    if (ok && (int)lanes.size() <= 16) { cap = c; break; }
   }
+  if (cap == 0) return -1;
+  h.mel_units = cap;
+  h.melw.assign(size_t(cap) * 16 * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+  h.melo.assign(size_t(cap) * 16, 0u);                                     // padding units: octet 0, zero weights
+  std::vector<int32_t> lane_bands(64, int32_t(0xffff00));                  // no units, no bands
+  for (size_t l = 0; l < lanes.size(); ++l) {
+    int pos = 0;
+    for (int which = 0; which < 2; ++which) {
+      const int b = which ? lanes[l].second : lanes[l].first;
+      if (b < 0) continue;
+      for (int c = h.band_slots[2 * b]; c < h.band_slots[2 * b + 1]; ++c, ++pos) {
+        const size_t idx = size_t(pos) * 16 + l;
+        h.melw[2 * idx] = make_float4(units[c].w[0], units[c].w[1], units[c].w[2], units[c].w[3]);
+        h.melw[2 * idx + 1] = make_float4(units[c].w[4], units[c].w[5], units[c].w[6], units[c].w[7]);
+        h.melo[idx] = units[c].off;
+      }
+    }
+    const int n_first = size[lanes[l].first];
+    lane_bands[l] = int32_t(uint32_t(n_first) | (uint32_t(lanes[l].first) << 8) |
+                            (uint32_t(lanes[l].second < 0 ? 0xff : lanes[l].second) << 16));
+  }
+  h.band_slots = lane_bands;                       // what the device reads: [lane] units of the first band | band | band
   // the kernel leaves 4|X|^2 (or 2|X| without usePower) in the power buffer
   h.mel_scale = mel.scale * (cfg.use_power ? 0.25f : 0.5f);
   h.dct28.assign(16 * 28, 0.0f);
@@ -635,7 +770,7 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 }
 
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
-  const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 9 + 16 * 28 + 64 + 48;
+  const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 8 + 16 * 28 + 48;
   const int wave_floats = wave_region_floats(h.stage_alloc);
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
   unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -647,15 +782,16 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
   // 7 (MP = 13) or 8 (MP = 16) steps -- the extra samples are never staged
   const int nsteps = (h.mp == 16) ? 8 : std::max(7, (h.stage_floats + 127) / 128);
   bool launched = false;
-#define SMILEHIP_PICK(MPV, NS, PE, UP, AL, PL)                                                                 \
+#define SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, UCV)                                                           \
   if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL &&     \
-      (P.plp != 0) == PL) {                                                                                     \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL, PL>);                     \
+      (P.plp != 0) == PL && h.mel_units == UCV) {                                                                \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL, PL, UCV>);                \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL, PL>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL, PL, UCV>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
     launched = true;                                                                                            \
   }
+#define SMILEHIP_PICK(MPV, NS, PE, UP, AL, PL) SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, 6) SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, 8)
 #define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true, false) SMILEHIP_PICK(MPV, NS, PE, UP, false, false)
 #define SMILEHIP_PICK4(MPV, NS) SMILEHIP_PICK2(MPV, NS, true, true) SMILEHIP_PICK2(MPV, NS, true, false) \
                                 SMILEHIP_PICK2(MPV, NS, false, true) SMILEHIP_PICK2(MPV, NS, false, false) \
@@ -668,6 +804,7 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
 #undef SMILEHIP_PICK4
 #undef SMILEHIP_PICK2
 #undef SMILEHIP_PICK
+#undef SMILEHIP_PICK_U
   if (!launched) return hipErrorInvalidConfiguration;     // no instantiation for this geometry: fail, never skip
   return hipGetLastError();
 }

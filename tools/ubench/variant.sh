@@ -8,5 +8,5 @@ NAME=$1; shift
 SRC=../../opensmile_amd/csrc
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$SRC -I../../include"
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize -Xclang -target-feature -Xclang -load-store-opt "$@" -c $SRC/lld_mfcc512.hip -o build/lld_mfcc512_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsmilehip_$NAME.so build/lld_mfcc512_$NAME.o \
-  $SRC/lld_kernels.o $SRC/lld_stage_kernels.o $SRC/lld_stage2_kernels.o $SRC/lld_is09.o $SRC/lld_compare.o $SRC/lld_functionals.o $SRC/smilehip_core.o $SRC/smilehip_plan.o $SRC/smilehip_batch.o $SRC/smilehip_stage.o $SRC/tables.o
+OBJS=$(ls $SRC/*.o | grep -v lld_mfcc512.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsmilehip_$NAME.so build/lld_mfcc512_$NAME.o $OBJS
