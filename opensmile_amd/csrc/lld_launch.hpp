@@ -13,8 +13,9 @@ struct Fast512Host {
   std::vector<float4> melw;
   std::vector<uint32_t> melo;
   std::vector<float> dct28;
-  std::vector<int32_t> band_slots;
-  int mel_units = 0, n_slots = 0, mp = 13, stage_floats = 0, stage_alloc = 0;
+  std::vector<int32_t> lane_bands;
+  int mel_units = 0, n_slots = 0, mp = 13;
+  int mel_conflict_steps = 0;   // LDS bank model: extra cycles of the mel power reads per step set (0 = conflict-free)
   float mel_scale = 1.0f;
   int max_blocks = 512;     // resident blocks of the fast kernel (2 per CU), set from the device
 };

@@ -3,34 +3,36 @@
 // Mapping (wave64-native): ONE WAVE processes FOUR frames at a time, 16 lanes
 // per frame; a wave walks a tile of consecutive frames of one utterance in
 // "passes" of 4 frames. Waves are autonomous -- no __syncthreads in the frame
-// loop, all exchange is wave-local through LDS. Sized for 4 waves per SIMD
+// loop, all exchange is wave-local (LDS or DPP). Sized for 4 waves per SIMD
 // (<= 128 VGPRs, ~8 KB of LDS per wave): one wave can issue a VALU op only
 // every ~5 cycles (tools/ubench/valu_rate.hip), so the SIMD needs several
-// waves to approach its 2-cycle issue rate.
+// waves to approach its ~2.5-cycle issue rate.
 //
 // Per pass (lane j = lane&15 of group g = lane>>4, frame t = tp + g):
-//   stage   next pass's int16 PCM is prefetched into registers one pass ahead
-//           (global-load latency hides behind arithmetic); at pass start it is
-//           converted (R0, scale folded into the window table), pre-emphasised
-//           (R2, the reference's two roundings) and written to LDS once
-//   load    z[m] = y[2n] + i*y[2n+1], n = j + 16m, times the window (R3); the
-//           real 512-FFT is a complex 256-FFT of z plus an untangle pass
+//   load    lane (g, j) loads from global memory exactly the sample pairs it
+//           transforms -- pair n = j + 16 m of frame t, m < MP -- one pass ahead
+//           (the 2.5x overlap of the frames is served by L1/L2; no LDS stage).
+//           Conversion (R0, scale folded into the window table), pre-emphasis
+//           (R2, the reference's two roundings; the previous sample comes from
+//           the neighbour lane by DPP) and window (R3) happen in registers:
+//           z[m] = y[2n] + i*y[2n+1]; the real 512-FFT is a complex 256-FFT of z
+//           plus an untangle pass
 //   FFT     256 = 16 x 16: radix-16 DFT over m in registers (two radix-4
 //           layers, constants only), twiddle by w256^(j*k1) (LDS table), ONE
 //           16x16 transpose of (re,im) pairs through LDS (b64 stores and loads,
-//           conflict-free interleaved layout overlaying the dead stage area),
-//           radix-16 DFT over j
-//   spect.  lanes j and 16-j own mirror-image bins: each writes the half of its
-//           Z the partner needs, reads the partner's half and untangles BOTH
-//           X[k] and X[256-k] from one (Z[k], Z[256-k]) pair (R4), power (R5,
-//           R6's square) -> LDS
+//           conflict-free interleaved layout), radix-16 DFT over j
+//   spect.  lanes j and 16-j own mirror-image bins: the partner's half of Z
+//           arrives by two DPP steps (row shift + row mirror), BOTH X[k] and
+//           X[256-k] are untangled from one (Z[k], Z[256-k]) pair (R4), power
+//           (R5, R6's square) -> LDS power buffer (octets of bins, 12 floats apart)
 //   mel     R6 as table-driven work units: a unit = one aligned octet of bins
 //           x one band (8 weights, zero outside the band): 2 x ds_read_b128 of
 //           power + 2 x b128 of weights + 8 FMA. Whole bands are dealt to the 16
 //           lanes, at most two per lane and UC (6 or 8) units per lane, so a band
 //           is summed in registers in unit order and its lane takes the log; the
-//           unit offsets are loop-invariant registers and the UC units of a pass
-//           are independent LDS reads (no partial-sum round trip)
+//           unit offsets are loop-invariant registers and the host orders every
+//           lane's units so that the 16 lanes of a frame read 16 different bank
+//           quads at each step (fast512_build_host)
 //   cep     DCT-II rows + lifter (R7): one lane per coefficient, b128 reads
 //
 // Numerics: R2/R3 keep the reference's rounding sequence on integer-valued
@@ -44,6 +46,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,35 +56,26 @@
 #include "lld_params.hpp"
 #include "tables.hpp"
 
-#ifndef SMILEHIP_V_DIRECT
-#define SMILEHIP_V_DIRECT 1
-#endif
-#ifndef SMILEHIP_V_DPPUNT
-#define SMILEHIP_V_DPPUNT 1
-#endif
-
 namespace smilehip {
 
 namespace {
 
 constexpr int kWavesPerBlock = 8;
 constexpr int kTileFrames = 32;       // frames per wave tile (8 passes)
-constexpr int kTBStride = 17;
-constexpr int kGroupFloats = 16 * kTBStride;   // 272 floats = 1088 B per frame group (ZX, then PB)
 constexpr int kTB2Row = 65;           // float2 per 4-group row of the transpose buffer (520 B)
 constexpr int kTB2Floats = 2 * (15 * kTB2Row + 3 * 16 + 16);   // 2078 floats: footprint of the transpose buffer
-constexpr int kMaxUnitsPerLane = 8;
-constexpr int kMinStage = 576;        // PS + lmel (4 x 144 floats) alias the stage area
+constexpr int kLmelFloats = 64;       // per frame group: log-mel [32] | PLP acf [16] | PLP cepstra [16]
+constexpr int kOctetFloats = 12;      // an octet of power bins starts every 12 floats: octet o sits on bank quad 3 o mod 16
+constexpr int kPbFloats = 448;        // power buffer of one frame group (33 octets = 396 floats) rounded to a multiple of 64
+                                      // dwords: the four groups of a wave see the same banks
+constexpr int kWaveFloats = 2080;     // per-wave LDS: max(transpose buffer, 4 x (kLmelFloats + kPbFloats) = 2048), 16-byte multiple
+
+static_assert(kWaveFloats >= kTB2Floats && kWaveFloats >= 4 * (kLmelFloats + kPbFloats) && kWaveFloats % 4 == 0, "per-wave LDS region");
+static_assert(kPbFloats % 64 == 0 && kPbFloats >= 33 * kOctetFloats, "power buffer");
 
 constexpr float C1 = 0.92387953251128673848f;   // cos(pi/8)
 constexpr float S1 = 0.38268343236508978178f;   // sin(pi/8)
 constexpr float R2 = 0.70710678118654752440f;   // sqrt(1/2)
-
-// per-wave LDS region: stage | spec[4] | 4 group buffers, overlaid by the transpose buffer
-__host__ __device__ inline int wave_region_floats(int stage_alloc) {
-  const int a = stage_alloc + 4 + 4 * kGroupFloats, b = (kTB2Floats + 3) & ~3;
-  return a > b ? a : b;
-}
 
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in order; this only stops the compiler
@@ -88,6 +83,9 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+
+// position of power bin k in a frame group's buffer
+__host__ __device__ constexpr int pb_pos(int k) { return k + (kOctetFloats - 8) * (k >> 3); }
 
 // forward DFT4 on (a0..a3), in place: X[q] = sum_m a[m] e^{-2 pi i m q / 4}
 __device__ __forceinline__ void dft4(float &r0, float &i0, float &r1, float &i1, float &r2, float &i2,
@@ -140,88 +138,53 @@ __device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
   for (int k = 0; k < 16; ++k) { re[k] = tr[k]; im[k] = ti[k]; }
 }
 
-}  // namespace
-
-// One lane's share of the next pass's PCM: 8 packed sample pairs (+ the frame-
-// first sample of frame tp+lane for lanes < 4).
-struct PcmRegs {
-  uint32_t pair[8];
-  int32_t first;
-};
-
-// Loads for one pass: the staged span [sbase, sbase + 128*n_steps) of utterance samples.
-// Everything but the lane's own byte offset is wave-uniform: `span` = pcm + sbase lives in
-// SGPRs and load r is `global_load_dword v, v_lane4, s[span] offset:256*r` -- one VGPR of
-// address for all eight loads, no 64-bit per-lane arithmetic, nothing to spill (a spill
-// reload would put an s_waitcnt vmcnt(0) behind the loads and wait out the whole memory
-// latency in every pass). `lane4` is made opaque per call so that the compiler cannot hoist
-// eight loop-invariant offsets into registers.
-// Samples past the utterance end only ever feed frames that are not stored (every stored
-// frame lies inside its utterance), so they need no zero fill; only the very last span of
-// the PCM buffer must not read past its end: that (wave-uniform, rare) case clamps offsets.
-// ALIGNED: the buffer is 4-byte aligned and every utterance starts at an even sample
-// (checked on the host) -> one dword load per sample pair; otherwise two 16-bit loads.
-// NSTEPS (7 or 8) x 128 samples cover the staged span; compile-time so that every load and
-// every use is unconditional (the waitcnt bookkeeping stays exact).
-template <int NSTEPS, bool ALIGNED>
-__device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t abs_base, int H, int lane,
-                                             PcmRegs &R) {
-#ifdef SMILEHIP_DEBUG_SAME_SPAN
-  abs_base &= 0xfffff;                                   // experiment: every span inside the first 2 MB (L2 resident)
-#endif
-  const unsigned char *span = reinterpret_cast<const unsigned char *>(pcm + abs_base);
-  const int64_t room = pcm_total - abs_base;             // samples from the span start to the buffer end, >= 2
-  uint32_t lane4 = 4u * (uint32_t)lane;
-  asm volatile("" : "+v"(lane4));
-#ifdef SMILEHIP_DEBUG_NO_LOADS
-  for (int r = 0; r < NSTEPS; ++r) R.pair[r] = lane4 * (r + 3);      // experiment: no global loads at all
-  R.first = lane;
-  return;
-#endif
-  if (room >= (int64_t)128 * NSTEPS) {                   // the whole span is inside the buffer
-#pragma unroll
-    for (int r = 0; r < NSTEPS; ++r) {
-      const unsigned char *q = (span + 256 * r) + lane4;
-      if (ALIGNED) R.pair[r] = *reinterpret_cast<const uint32_t *>(q);
-      else R.pair[r] = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
-    }
-    const uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;         // (lane & 3) * H samples, in bytes
-    R.first = (int32_t)*reinterpret_cast<const int16_t *>(span + fo);
-  } else {
-    const uint32_t limit = (uint32_t)((ALIGNED ? ((pcm_total >> 1) - 1 - (abs_base >> 1)) * 2 : room - 2) * 2);
-#pragma unroll
-    for (int r = 0; r < NSTEPS; ++r) {
-      uint32_t off = lane4 + 256u * r;
-      off = off > limit ? limit : off;
-      const unsigned char *q = span + off;
-      if (ALIGNED) R.pair[r] = *reinterpret_cast<const uint32_t *>(q);
-      else R.pair[r] = (uint32_t) reinterpret_cast<const uint16_t *>(q)[0] | ((uint32_t) reinterpret_cast<const uint16_t *>(q)[1] << 16);
-    }
-    uint32_t fo = (lane4 & 12u) * (uint32_t)H >> 1;
-    const uint32_t flim = (uint32_t)(room - 1) * 2u;
-    fo = fo > flim ? flim : fo;
-    R.first = (int32_t)*reinterpret_cast<const int16_t *>(span + fo);
-  }
+// DPP move with a compile-time control word (row_shl:n = 0x100 + n, row_ror:n = 0x120 + n, row_mirror = 0x140)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-// Direct variant (ALIGNED only): lane (g, j) loads the sample pairs it will transform itself -- pair j + 16 m of frame
-// tp + g, m = 0..MP-1 -- so that a frame never passes through an LDS stage area (a ds_write_b64 costs ~6 LDS cycles per
-// wave, MI355X_MICROARCH.md LDS table; the vector-memory pipe is otherwise idle and the 2.5x overlap of the frames is
-// served by L1/L2). `base` = first sample of the pass's first frame minus the left padding; the per-lane byte offset
-// (g * H + 2 j) * 2 is one VGPR and load m adds the immediate 64 m. Samples outside a frame meet a zero of the window
-// table and every stored frame lies inside its utterance, so out-of-range addresses are only clamped into the buffer.
-template <int MP>
-__device__ __forceinline__ void pcm_prefetch_direct(const int16_t *pcm, int64_t pcm_total, int64_t base, int H, int lane,
-                                                    uint32_t (&pair)[16]) {
+}  // namespace
+
+// The next pass's samples of one lane: pair n = j + 16 m of frame tp + g for m < MP. ALIGNED (the buffer is 4-byte
+// aligned and every utterance starts at an even sample, checked on the host): one dword per pair; otherwise two
+// sign-extending 16-bit loads. `base` = first sample of the pass's first frame minus the left padding; the per-lane byte
+// offset (g H + 2 j) * 2 is ONE VGPR and load m adds the immediate 64 m -- everything else is wave-uniform and lives in
+// SGPRs: nothing to spill (a spill reload would put an s_waitcnt vmcnt(0) behind the loads and wait out the whole memory
+// latency in every pass). Samples outside a frame meet a zero of the window table and every stored frame lies inside
+// its utterance, so out-of-range addresses are only clamped into the buffer (wave-uniform branch, first / last span).
+template <int MP, bool ALIGNED>
+struct FrameRegs {
+  uint32_t v[ALIGNED ? MP : 2 * MP];
+};
+
+template <int MP, bool ALIGNED>
+__device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t base, int H, int lane,
+                                             FrameRegs<MP, ALIGNED> &R) {
+#ifdef SMILEHIP_DEBUG_SAME_SPAN
+  base &= 0xfffff;                                       // experiment: every span inside the first 2 MB (L2 resident)
+#endif
   uint32_t lo = ((uint32_t)(lane >> 4) * (uint32_t)H + 2u * (uint32_t)(lane & 15)) * 2u;
-  asm volatile("" : "+v"(lo));
+  asm volatile("" : "+v"(lo));                           // opaque per call: no hoisted per-m offset registers
+#ifdef SMILEHIP_DEBUG_NO_LOADS
+  for (int m = 0; m < (ALIGNED ? MP : 2 * MP); ++m) R.v[m] = lo * (m + 3);      // experiment: no global loads at all
+  return;
+#endif
   const unsigned char *span = reinterpret_cast<const unsigned char *>(pcm + base);
   const int64_t room = pcm_total - base;
   if (base >= 0 && room >= (int64_t)(3 * H + 32 * MP)) {
 #pragma unroll
-    for (int m = 0; m < MP; ++m) pair[m] = *reinterpret_cast<const uint32_t *>(span + 64 * m + lo);
-  } else {                                               // first / last span of the buffer (wave-uniform, rare)
-    const int64_t last = ((pcm_total >> 1) - 1) * 2;     // last even sample index with a whole pair behind it
+    for (int m = 0; m < MP; ++m) {
+      const unsigned char *q = span + 64 * m + lo;
+      if (ALIGNED) {
+        R.v[m] = *reinterpret_cast<const uint32_t *>(q);
+      } else {
+        R.v[2 * m] = (uint32_t)(int32_t) reinterpret_cast<const int16_t *>(q)[0];
+        R.v[2 * m + 1] = (uint32_t)(int32_t) reinterpret_cast<const int16_t *>(q)[1];
+      }
+    }
+  } else {
+    const int64_t last = ALIGNED ? ((pcm_total >> 1) - 1) * 2 : pcm_total - 2;     // last index with a whole pair behind it
     const int32_t lim_lo = base < 0 ? (int32_t)(-base) * 2 : 0;
     int64_t hi64 = (last - base) * 2;
     hi64 = hi64 > (1 << 24) ? (1 << 24) : hi64;
@@ -230,22 +193,16 @@ __device__ __forceinline__ void pcm_prefetch_direct(const int16_t *pcm, int64_t 
     for (int m = 0; m < MP; ++m) {
       int32_t off = (int32_t)lo + 64 * m;
       off = off < lim_lo ? lim_lo : (off > lim_hi ? lim_hi : off);
-      pair[m] = *reinterpret_cast<const uint32_t *>(span + off);
+      const unsigned char *q = span + off;
+      if (ALIGNED) {
+        R.v[m] = *reinterpret_cast<const uint32_t *>(q);
+      } else {
+        R.v[2 * m] = (uint32_t)(int32_t) reinterpret_cast<const int16_t *>(q)[0];
+        R.v[2 * m + 1] = (uint32_t)(int32_t) reinterpret_cast<const int16_t *>(q)[1];
+      }
     }
   }
 }
-
-// DPP move with a compile-time control word (row_ror:n = 0x120 + n, row_mirror = 0x140, row_newbcast:n = 0x150 + n)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-// value of lane-1 (wave-wide shift right by one lane, DPP wave_shr:1); lane 0 receives `fill`
-__device__ __forceinline__ float lane_shr1(float v, float fill) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-
 
 // Developer instrumentation (tools/ubench/variant.sh builds a private copy of the library
 // with -DSMILEHIP_PHASE_TIMING): s_memtime at the phase boundaries of the pass loop, summed
@@ -264,43 +221,36 @@ __device__ unsigned long long g_phase[16];
 // LDS layout (dynamic), sizes in floats:
 //   shared tables : tw512 [256 f2] | win [MP*16 f2] | tw256 [256 f2, index k1*16+j] |
 //                   melw0 [UC*16 f4] | melw1 [UC*16 f4] | dct [16 x 28] | plp [48]
-//   per wave      : stage [S >= 512] (later PS+lmel: 4 x 144) | spec [4] | 4 x group buffer [272];
-//                   the (re,im) transpose buffer [2078] overlays all of it between frame load and untangle
-template <int MP, int NSTEPS, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP, int UC>
+//   per wave      : 4 x (log-mel [32] | acf [16] | cepstra [16]) | 4 x power buffer [448];
+//                   the (re,im) transpose buffer [2078] overlays all of it between the two DFT16
+template <int MP, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP, int UC>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool DIRECT = ALIGNED && SMILEHIP_V_DIRECT;
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; tell the compiler so that everything derived from it
   // (tile, utterance, offsets, pointers) lives in SGPRs instead of VGPR pairs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int j = lane & 15;
-  constexpr int U = UC;
-  const int stage_floats = F.stage_floats;
-  const int stage_alloc = F.stage_alloc;
 
   // ---- carve shared memory
   float2 *s_tw512 = reinterpret_cast<float2 *>(smem);
   float2 *s_win = s_tw512 + 256;
   float2 *s_tw256 = s_win + MP * 16;
   float4 *s_melw0 = reinterpret_cast<float4 *>(s_tw256 + 256);
-  float4 *s_melw1 = s_melw0 + U * 16;
-  float *s_dct = reinterpret_cast<float *>(s_melw1 + U * 16);
+  float4 *s_melw1 = s_melw0 + UC * 16;
+  float *s_dct = reinterpret_cast<float *>(s_melw1 + UC * 16);
   float *s_plp = s_dct + 16 * 28;                                    // PLP chain: eql[32] | sintable[16]
-  constexpr int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + U * 16 * 8 + 16 * 28 + 48;
-  const int wave_floats = wave_region_floats(stage_alloc);
-  float *wbase = smem + shared_floats + wave * wave_floats;
-  float *s_stage = wbase;
-  float *s_spec = wbase + stage_alloc;
-  float *s_gb = s_spec + 4 + g * kGroupFloats;                    // my group's buffer: TB -> ZX -> PB
-  float *s_lmel = s_stage + g * 144;                              // log-mel of the frame (32 floats; aliases stage); 144: odd multiple of 16 banks
-  float *s_ps = s_lmel + 48;                                      // PLP: 16 cepstra behind the band vector and its 16 acf lags
+  constexpr int shared_floats = 256 * 2 + MP * 16 * 2 + 256 * 2 + UC * 16 * 8 + 16 * 28 + 48;
+  float *wbase = smem + shared_floats + wave * kWaveFloats;
+  float *s_lmel = wbase + g * kLmelFloats;                        // log-mel of my frame (28 read by the DCT)
+  float *s_cep = s_lmel + 48;                                     // PLP: 16 cepstra behind the band vector and its 16 acf lags
+  float *s_pb = wbase + 4 * kLmelFloats + g * kPbFloats;          // power spectrum of my frame
 
   // ---- cooperative load of the shared tables
   for (int i = threadIdx.x; i < 256; i += blockDim.x) { s_tw512[i] = F.tw512[i]; s_tw256[i] = F.tw256[i]; }
   for (int i = threadIdx.x; i < MP * 16; i += blockDim.x) s_win[i] = F.win[i];
-  for (int i = threadIdx.x; i < U * 16; i += blockDim.x) { s_melw0[i] = F.melw[2 * i]; s_melw1[i] = F.melw[2 * i + 1]; }
+  for (int i = threadIdx.x; i < UC * 16; i += blockDim.x) { s_melw0[i] = F.melw[2 * i]; s_melw1[i] = F.melw[2 * i + 1]; }
   for (int i = threadIdx.x; i < 16 * 28; i += blockDim.x) s_dct[i] = F.dct28[i];
   if (PLP) {
     for (int i = threadIdx.x; i < 32; i += blockDim.x) s_plp[i] = F.plp_eql[i];
@@ -311,22 +261,24 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   uint32_t mo[UC];                              // byte offsets of my units' octets in the power buffer
 #pragma unroll
   for (int i = 0; i < UC; ++i) mo[i] = F.melo[i * 16 + j];
-  const uint32_t lane_bands = (uint32_t)F.band_slots[j];   // units of my first band | first band << 8 | second band << 16 (0xff: none)
-  const int n0 = (int)(lane_bands & 0xffu), band0 = (int)((lane_bands >> 8) & 0xffu), band1 = (int)((lane_bands >> 16) & 0xffu);
+  // which of my units belong to my first band (bit i) | first band << 8 | second band << 16 (0xff: none)
+  const uint32_t lane_bands = (uint32_t)F.lane_bands[j];
+  const int band0 = (int)((lane_bands >> 8) & 0xffu), band1 = (int)((lane_bands >> 16) & 0xffu);
+  bool unit_first[UC];
+#pragma unroll
+  for (int i = 0; i < UC; ++i) unit_first[i] = ((lane_bands >> i) & 1u) != 0;
   const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;    // my cell relative to the pass's first output row
   const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
   const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
-  const int fo = g * P.H - P.pad_left + 2 * j;                        // stage index of my pair for m = 0
-  const int pj = (16 - j) & 15;                                       // partner lane (bins 256-k)
-  const int zrow = (j == 0) ? 16 : 0;
+  float *pb_k = s_pb + pb_pos(j);              // my bins k = j + 16 q sit 24 q floats further on
+  float *pb_m = s_pb + pb_pos(256 - j);        // their mirror images 256 - k sit 24 q floats back
 
   PHASE_DECL
   // Persistent waves walk tiles tile, tile + #waves, ... as ONE flat stream of passes: the
   // next pass's PCM (same tile or the first pass of the next tile) is always in flight, tile
   // records are fetched one tile ahead, and a pass's results are stored at the top of the
   // following pass. The only s_waitcnt vmcnt in steady state is the one that consumes the
-  // prefetched PCM, and everything older than those loads (the deferred store) was issued a
-  // full pass earlier.
+  // prefetched PCM, and everything older than those loads was issued a full pass earlier.
   const int tile_stride = __builtin_amdgcn_readfirstlane((int)gridDim.x) * kWavesPerBlock;   // (a vector load otherwise)
   int tile = blockIdx.x * kWavesPerBlock + wave;
   if (tile >= P.n_tiles) return;                       // wave-uniform; no block barrier below
@@ -346,10 +298,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     nxt_n = recs[tile + tile_stride].n_frames;
   }
   int tp = 0;                                          // first frame of the pass, relative to the tile
-  PcmRegs R;
-  uint32_t D[16];                                      // direct variant: my MP sample pairs of the coming pass
-  if constexpr (DIRECT) pcm_prefetch_direct<MP>(P.pcm, P.pcm_total, cur_samp0 - P.pad_left, P.H, lane, D);
-  else pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, cur_samp0, P.H, lane, R);
+  FrameRegs<MP, ALIGNED> R;
+  pcm_prefetch<MP, ALIGNED>(P.pcm, P.pcm_total, cur_samp0 - P.pad_left, P.H, lane, R);
   unsigned char *pend_row = nullptr;                   // deferred store of the previous pass (wave-uniform row base)
   float pend_val = 0.0f;
   bool pend_live = false;
@@ -357,23 +307,29 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   for (;;) {
     const bool live = tp + g < cur_n;
     PHASE(0);                                   // loop overhead
+    // ------------------------------------------------------------ frame from registers: R0 (scale folded), R2, R3
+    if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
+      uint32_t oo = out_off;
+      asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
+      *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+    }
     float re[16], im[16];
-    if constexpr (DIRECT) {
-      // -------------------------------------------------------- frame from registers: R0 (scale folded), R2, R3
-      if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
-        uint32_t oo = out_off;
-        asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
-        *reinterpret_cast<float *>(pend_row + oo) = pend_val;
-      }
-      float tprev = 0.0f;                          // odd sample of pair 15 + 16 (m-1), as seen by lane j = 0
+    {
+      float tprev = 0.0f;                        // odd sample of pair 15 + 16 (m-1), as lane j = 0 needs it
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         if (m < MP) {
-          const float a = (float)(int16_t)(D[m] & 0xffffu);
-          const float b = (float)(int16_t)(D[m] >> 16);
+          float a, b;
+          if constexpr (ALIGNED) {
+            a = (float)(int16_t)(R.v[m] & 0xffffu);
+            b = (float)(int16_t)(R.v[m] >> 16);
+          } else {
+            a = (float)(int32_t)R.v[2 * m];
+            b = (float)(int32_t)R.v[2 * m + 1];
+          }
           float ya = a, yb = b;
           if (PREEMPH) {
-            const float t = dpp_f<0x121>(b);       // row_ror:1 -- lane j sees the odd sample of pair j-1 (lane 0: of lane 15)
+            const float t = dpp_f<0x121>(b);     // row_ror:1 -- lane j sees the odd sample of pair j-1 (lane 0: of lane 15)
             const float pa = (j == 0) ? tprev : t;
             tprev = t;
             ya = a - kpre * pa;
@@ -387,62 +343,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
           re[m] = 0.0f; im[m] = 0.0f;
         }
       }
-      PHASE(1);
-    } else {
-      // ------------------------------------------------------------ stage PCM (R0 scale folded, R2)
-      {
-        float carry = 0.0f;                       // odd sample of lane 63 of the previous step
-  #pragma unroll
-        for (int r = 0; r < NSTEPS; ++r) {
-          {
-            const float a = (float)(int16_t)(R.pair[r] & 0xffffu);
-            const float b = (float)(int16_t)(R.pair[r] >> 16);
-            float ya = a, yb = b;
-            if (PREEMPH) {
-              const float pa = lane_shr1(b, carry);
-              carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
-              ya = a - kpre * pa;
-              yb = b - kpre * a;
-            }
-            const int i2 = lane + 64 * r;
-            if (2 * i2 < stage_floats) *reinterpret_cast<float2 *>(s_stage + 2 * i2) = make_float2(ya, yb);
-          }
-        }
-        if (PREEMPH && lane < 4) {
-          uint32_t l4 = 4u * (uint32_t)lane;
-          asm volatile("" : "+v"(l4));               // recompute the address rather than keep (and spill) it
-          *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_spec) + l4) = P.one_minus_k * (float)R.first;
-        }
-      }
-      {
-        int32_t f_ = R.first;
-        asm volatile("" : : "v"(f_));             // every prefetched register is consumed here, unconditionally
-      }
-      if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
-        uint32_t oo = out_off;
-        asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
-        *reinterpret_cast<float *>(pend_row + oo) = pend_val;
-      }
-      wave_lds_fence();
-      PHASE(1);                                   // wait for the prefetch + stage
-      // ------------------------------------------------------------ load frame (R3)
-  #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        if (m < MP) {
-          int e = fo + 32 * m;
-          e = e < 0 ? 0 : e;                     // left zero padding: window is 0 there, keep the address legal
-          float2 v = *reinterpret_cast<const float2 *>(s_stage + e);
-          if (PREEMPH && m == m0 && j == j0) v.x = s_spec[g];   // y[0] = (1-k) x[0]
-          const float2 w = s_win[m * 16 + j];
-          re[m] = v.x * w.x;
-          im[m] = v.y * w.y;
-        } else {
-          re[m] = 0.0f; im[m] = 0.0f;
-        }
-      }
     }
-    if constexpr (!DIRECT) wave_lds_fence();   // stage area is dead from here (PS/lmel alias it)
-    PHASE(2);                                   // frame load x window
+    PHASE(1);                                   // wait for the prefetch, pre-emphasis, window
 
     // ------------------------------------------------------------ 256-point complex FFT
     dft16(re, im);                                           // over m  -> index k1
@@ -453,7 +355,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     PHASE(3);                                   // dft16 + twiddles
     // 16x16 transpose of (re, im) pairs: 16 ds_write_b64 + 16 ds_read_b64 through a buffer that
-    // overlays the whole per-wave region (stage, spec and the group buffers are all dead here).
+    // overlays the whole per-wave region (band vector and power buffers are dead here).
     // Element (row r, column c) of group g sits at byte g*128 + r*520 + c*8: the four groups'
     // rows are interleaved and each 4-group row is padded by 8 bytes, which makes both the
     // row-wise b64 stores (16-lane groups) and the column-wise b64 loads (32-lane groups)
@@ -465,7 +367,11 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       for (int k1 = 0; k1 < 16; ++k1) tbw[k1 * kTB2Row] = make_float2(re[k1], im[k1]);
       wave_lds_fence();
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) { const float2 v = tbr[jj]; re[jj] = v.x; im[jj] = v.y; }
+      for (int jj = 0; jj < 16; ++jj) {          // one ds_read_b64 each (2 LDS cycles); paired into ds_read2_b64 they would take 8 per pair
+        typedef const volatile __attribute__((address_space(3))) unsigned long long *LdsU64;
+        const unsigned long long v = ((LdsU64)tbr)[jj];
+        re[jj] = __int_as_float((int)(uint32_t)v); im[jj] = __int_as_float((int)(uint32_t)(v >> 32));
+      }
       wave_lds_fence();
     }
     PHASE(4);                                   // transposes
@@ -475,14 +381,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     PHASE(5);                                   // second dft16
 
     // ------------------------------------------------------------ untangle pairs + power
-    // lane j writes Z[j+16 k2], k2 = 8..15 (what lane 16-j needs); reads the partner's
-    // Z[256 - (j+16 q)] for q = 0..7.
-#if SMILEHIP_V_DPPUNT
     // The partner of lane j is lane (16 - j) & 15 of the same row, reached without an LDS round trip: shift the row one
-    // lane down (row_shl:1, lane j <- lane j+1), then row_mirror (lane j <- lane 15 - j), the mirror riding on the add/sub
-    // that consumes the value. Lane 0 is its own partner one register up (bin 256 - 16 q = 0 + 16 (16 - q)): its value is
-    // parked in lane 15 first (row_ror:15), where the shift has no source and leaves it. q = 0 of lane 0 is the
-    // DC/Nyquist pair, handled below.
+    // lane down (row_shl:1, lane j <- lane j+1), then row_mirror (lane j <- lane 15 - j). Lane 0 is its own partner one
+    // register up (bin 256 - 16 q = 0 + 16 (16 - q)): its value is parked in lane 15 first (row_ror:15), where the shift
+    // has no source and leaves it. q = 0 of lane 0 is the DC/Nyquist pair, handled below.
     float zr[8], zi[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -493,24 +395,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       zr[q] = dpp_f<0x140>(tr);
       zi[q] = dpp_f<0x140>(ti);
     }
-#else
-    float2 *s_zx = reinterpret_cast<float2 *>(s_gb);
-#pragma unroll
-    for (int k2 = 8; k2 < 16; ++k2) s_zx[(k2 - 8) * 16 + j] = make_float2(re[k2], im[k2]);
-    wave_lds_fence();
-    float zr[8], zi[8];
+    float2 tw5[8];                                // e^{-2 pi i k/512} of my eight bins, all read before the first store to the
+#pragma unroll                                    // power buffer (the compiler cannot tell the two LDS regions apart)
+    for (int q = 0; q < 8; ++q) tw5[q] = s_tw512[j + 16 * q];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float2 v = s_zx[(7 - q) * 16 + pj + zrow];
-      zr[q] = v.x; zi[q] = v.y;
-    }
-    wave_lds_fence();   // partner reads done: the buffer becomes PB
-#endif
-    float *s_pb = s_gb;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = j + 16 * q;
-      const float2 w = s_tw512[k];
+      const float2 w = tw5[q];
       const float a = re[q], b = im[q], c = zr[q], d = zi[q];
       const float sr = a + c, si = b - d, dr = a - c, di = b + d;
       const float ur = fmaf(w.x, dr, -w.y * di);
@@ -524,15 +414,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         pk = v0 * v0; pm = v1 * v1;
       }
       if (!USE_POWER) { pk = sqrtf(pk); pm = sqrtf(pm); }
-      s_pb[k] = pk;
-      s_pb[256 - k] = pm;
+      pb_k[(2 * kOctetFloats) * q] = pk;           // bin j + 16 q
+      pb_m[-(2 * kOctetFloats) * q] = pm;          // bin 256 - j - 16 q
     }
     if (j == 0) {                                  // k = 128 pairs with itself
       const float a = re[8], b = im[8];
       const float s = 4.0f * fmaf(b, b, a * a);
-      s_pb[128] = USE_POWER ? s : sqrtf(s);
+      s_pb[pb_pos(128)] = USE_POWER ? s : sqrtf(s);
     } else if (j < 8) {
-      s_pb[256 + j] = 0.0f;                        // octet 32 is read as a whole by the mel units
+      s_pb[pb_pos(256) + j] = 0.0f;                // octet 32 is read as a whole by the mel units
     }
     wave_lds_fence();
 
@@ -543,11 +433,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     const bool advance = ntp >= cur_n;
     const bool more = !advance || has_next;
     if (advance) ntp = 0;
-    if (more) {
-      const int64_t nb = (advance ? nxt_samp0 : cur_samp0) + (int64_t)ntp * P.H;
-      if constexpr (DIRECT) pcm_prefetch_direct<MP>(P.pcm, P.pcm_total, nb - P.pad_left, P.H, lane, D);
-      else pcm_prefetch<NSTEPS, ALIGNED>(P.pcm, P.pcm_total, nb, P.H, lane, R);
-    }
+    if (more)
+      pcm_prefetch<MP, ALIGNED>(P.pcm, P.pcm_total, (advance ? nxt_samp0 : cur_samp0) + (int64_t)ntp * P.H - P.pad_left, P.H, lane, R);
 
     PHASE(7);                                   // prefetch issue
     // ------------------------------------------------------------ mel (R6)
@@ -561,9 +448,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         float acc = p0.x * w0.x;
         acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
         acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
-        const bool first = i < n0;
-        a0 += first ? acc : 0.0f;                 // x + 0 is exact
-        a1 += first ? 0.0f : acc;
+        a0 += unit_first[i] ? acc : 0.0f;         // x + 0 is exact
+        a1 += unit_first[i] ? 0.0f : acc;
       }
       PHASE(8);                                   // mel units
 #pragma unroll
@@ -592,9 +478,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       float *s_acf = s_lmel + 32;                       // 16 floats behind the padded band vector
       if (j <= P.plp_order) s_acf[j] = plp_acf_lag(s_lmel, s_dct + j * 28, P.n_bands);
       wave_lds_fence();
-      if (j == 0) plp_cc_serial(s_acf, P.plp_order, s_plp + 32, s_ps);       // the partial-sum slots are dead here
+      if (j == 0) plp_cc_serial(s_acf, P.plp_order, s_plp + 32, s_cep);
       wave_lds_fence();
-      if (j < P.n_mfcc) pend_val = s_ps[j];
+      if (j < P.n_mfcc) pend_val = s_cep[j];
     } else
     // ------------------------------------------------------------ DCT + lifter (R7)
     if (j < P.n_mfcc) {
@@ -611,7 +497,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     pend_live = live && j < P.n_mfcc;
     pend_row = reinterpret_cast<unsigned char *>(P.out + (cur_row0 + tp) * P.ld_out);   // wave-uniform
-    wave_lds_fence();   // PS/lmel (stage alias) and PB are reused by the next pass
+    wave_lds_fence();   // band vector and power buffer are overwritten by the next pass's transpose
     PHASE(10);                                  // DCT
     if (!more) break;
     if (advance) {
@@ -655,17 +541,14 @@ int fast512_tile_frames() { return kTileFrames; }
 // Tables of the fast kernel. Mel work units: for every band, every aligned
 // octet of bins that intersects the band's bin range [rise_lo, fall_hi) is one
 // unit with 8 weights (1-w on the rising run, w on the falling run, 0 outside;
-// melspec.cpp:544-553), unit c is dealt to lane c % 16 at position c / 16 and
-// writes partial slot c; a band's partials are consecutive slots.
+// melspec.cpp:544-553). Whole bands go to lanes (at most two per lane); a lane
+// adds its band's units in the order of its unit slots.
 int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, const std::vector<float> &window,
                        const MelBank &mel, const DctTables &dct, Fast512Host &h) {
   const int pad_left = cfg.zero_pad_symmetric ? (int)((geo.Nfft - geo.N) / 2) : 0;
   const int H = (int)geo.H, N = (int)geo.N;
   if (mel.n_bands > 27 || dct.n_mfcc > 16 || cfg.win_offset != 0.0 || (pad_left & 1) || (H & 1) || H < 2) return -1;
   h.mp = (pad_left + N) <= 13 * 32 ? 13 : 16;
-  h.stage_floats = 3 * H + 32 * h.mp;
-  if (h.stage_floats > 8 * 128) return -1;                     // PcmRegs holds 8 x 64 pairs
-  h.stage_alloc = std::max((h.stage_floats + 3) & ~3, kMinStage);
   h.tw256.resize(256);
   for (int k1 = 0; k1 < 16; ++k1)
     for (int j = 0; j < 16; ++j) {
@@ -687,19 +570,20 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
       if (n + 1 >= 0 && n + 1 < N) b = float(double(window[n + 1]) / 32767.0);
       h.win[size_t(m) * 16 + j] = make_float2(a, b);
     }
-  // mel units
-  struct Unit { uint32_t off; float w[8]; };
+  // mel units, band by band in octet order
+  struct Unit { int octet; float w[8]; };
   std::vector<Unit> units;
-  h.band_slots.assign(64, 0);
-  for (int b = 0; b < mel.n_bands; ++b) {
+  const int nb = mel.n_bands;
+  std::vector<int> first_unit(nb + 1, 0);
+  for (int b = 0; b < nb; ++b) {
     int lo = -1, hi = -1;
     if (mel.rise_hi[b] > mel.rise_lo[b]) { lo = mel.rise_lo[b]; hi = mel.rise_hi[b]; }
     if (mel.fall_hi[b] > mel.fall_lo[b]) { if (lo < 0) lo = mel.fall_lo[b]; hi = mel.fall_hi[b]; }
-    h.band_slots[2 * b] = int32_t(units.size());
+    first_unit[b] = int(units.size());
     if (lo >= 0) {
       for (int o = lo / 8; o <= (hi - 1) / 8; ++o) {
         Unit un;
-        un.off = uint32_t(o) * 32u;
+        un.octet = o;
         for (int e = 0; e < 8; ++e) {
           const int n = 8 * o + e;
           float w = 0.0f;
@@ -710,14 +594,13 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
         units.push_back(un);
       }
     }
-    h.band_slots[2 * b + 1] = int32_t(units.size());
   }
+  first_unit[nb] = int(units.size());
   h.n_slots = int(units.size());
   // Whole bands to lanes: at most two bands and `cap` units per lane (cap = 6 or 8: the two unit counts the kernel is
   // instantiated for). Largest band first, partnered with the largest remaining band that still fits.
-  const int nb = mel.n_bands;
   std::vector<int> size(nb), order(nb);
-  for (int b = 0; b < nb; ++b) { size[b] = h.band_slots[2 * b + 1] - h.band_slots[2 * b]; order[b] = b; }
+  for (int b = 0; b < nb; ++b) { size[b] = first_unit[b + 1] - first_unit[b]; order[b] = b; }
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return size[x] > size[y]; });
   int cap = 0;
   std::vector<std::pair<int, int>> lanes;          // (first band, second band or -1)
@@ -740,26 +623,80 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
   }
   if (cap == 0) return -1;
   h.mel_units = cap;
-  h.melw.assign(size_t(cap) * 16 * 2, make_float4(0.f, 0.f, 0.f, 0.f));
-  h.melo.assign(size_t(cap) * 16, 0u);                                     // padding units: octet 0, zero weights
-  std::vector<int32_t> lane_bands(64, int32_t(0xffff00));                  // no units, no bands
+  // Unit slots. At step i the 16 lanes of a frame issue one ds_read_b128 each (and a second one 16 bytes further on);
+  // the hardware serves the 16 lanes of a b128 lane group in one cycle iff they touch 16 different bank quads, and octet o
+  // sits on quad 3 o mod 16 of its frame's buffer (all four buffers of a wave start on the same bank): a step is
+  // conflict-free iff its 16 octets differ mod 16. The order of a lane's units is free (it only fixes the order of a
+  // band's additions), so: start from octet order, then swap slot pairs of one lane while that lowers
+  // (worst multiplicity per step, number of colliding lanes), lexicographically -- deterministic hill climbing.
+  std::vector<std::vector<int>> slot(16, std::vector<int>(cap, -1));       // unit index or -1 (padding)
   for (size_t l = 0; l < lanes.size(); ++l) {
     int pos = 0;
     for (int which = 0; which < 2; ++which) {
       const int b = which ? lanes[l].second : lanes[l].first;
       if (b < 0) continue;
-      for (int c = h.band_slots[2 * b]; c < h.band_slots[2 * b + 1]; ++c, ++pos) {
-        const size_t idx = size_t(pos) * 16 + l;
-        h.melw[2 * idx] = make_float4(units[c].w[0], units[c].w[1], units[c].w[2], units[c].w[3]);
-        h.melw[2 * idx + 1] = make_float4(units[c].w[4], units[c].w[5], units[c].w[6], units[c].w[7]);
-        h.melo[idx] = units[c].off;
+      for (int c = first_unit[b]; c < first_unit[b + 1]; ++c) slot[l][pos++] = c;
+    }
+  }
+  auto step_cost = [&](int i, int &worst, int &coll) {
+    int cnt[16] = {0};
+    for (int l = 0; l < 16; ++l)
+      if (slot[l][i] >= 0) ++cnt[units[slot[l][i]].octet & 15];
+    worst = 1; coll = 0;
+    for (int r = 0; r < 16; ++r) { worst = std::max(worst, cnt[r]); coll += std::max(0, cnt[r] - 1); }
+  };
+  auto total_cost = [&](long &primary, long &secondary) {
+    primary = secondary = 0;
+    for (int i = 0; i < cap; ++i) { int w, c; step_cost(i, w, c); primary += w; secondary += c; }
+  };
+  long best_p, best_s;
+  total_cost(best_p, best_s);
+  for (bool improved = true; improved;) {
+    improved = false;
+    for (int l = 0; l < 16; ++l)
+      for (int a = 0; a < cap; ++a)
+        for (int b = a + 1; b < cap; ++b) {
+          if (slot[l][a] == slot[l][b]) continue;
+          std::swap(slot[l][a], slot[l][b]);
+          long p, s2;
+          total_cost(p, s2);
+          if (p < best_p || (p == best_p && s2 < best_s)) { best_p = p; best_s = s2; improved = true; }
+          else std::swap(slot[l][a], slot[l][b]);
+        }
+  }
+  h.mel_conflict_steps = int(best_p - cap);         // extra LDS cycles per b128 read group and pass, 0 = conflict-free
+  if (getenv("SMILEHIP_DEBUG_TABLES"))
+    fprintf(stderr, "fast512: %d mel units on %zu lanes, %d per lane, bank model: %ld extra cycles over %d steps (%ld colliding lanes)\n",
+            h.n_slots, lanes.size(), cap, best_p - cap, cap, best_s);
+  h.melw.assign(size_t(cap) * 16 * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+  h.melo.assign(size_t(cap) * 16, 0u);
+  h.lane_bands.assign(16, int32_t(0xffff00));        // no units, no bands
+  for (int i = 0; i < cap; ++i) {
+    bool taken[16] = {false};
+    for (int l = 0; l < 16; ++l)
+      if (slot[l][i] >= 0) taken[units[slot[l][i]].octet & 15] = true;
+    for (int l = 0; l < 16; ++l) {
+      const size_t idx = size_t(i) * 16 + l;
+      if (slot[l][i] >= 0) {
+        const Unit &un = units[slot[l][i]];
+        h.melw[2 * idx] = make_float4(un.w[0], un.w[1], un.w[2], un.w[3]);
+        h.melw[2 * idx + 1] = make_float4(un.w[4], un.w[5], un.w[6], un.w[7]);
+        h.melo[idx] = uint32_t(un.octet) * uint32_t(kOctetFloats * 4);
+      } else {                                       // padding unit: zero weights on an octet whose bank quad is still free
+        int o = 0;
+        for (int r = 0; r < 16; ++r)
+          if (!taken[r]) { o = r; taken[r] = true; break; }
+        h.melo[idx] = uint32_t(o) * uint32_t(kOctetFloats * 4);
       }
     }
-    const int n_first = size[lanes[l].first];
-    lane_bands[l] = int32_t(uint32_t(n_first) | (uint32_t(lanes[l].first) << 8) |
-                            (uint32_t(lanes[l].second < 0 ? 0xff : lanes[l].second) << 16));
   }
-  h.band_slots = lane_bands;                       // what the device reads: [lane] units of the first band | band | band
+  for (size_t l = 0; l < lanes.size(); ++l) {
+    uint32_t mask = 0;
+    const int b0 = lanes[l].first;
+    for (int i = 0; i < cap; ++i)
+      if (slot[l][i] >= first_unit[b0] && slot[l][i] < first_unit[b0 + 1]) mask |= 1u << i;
+    h.lane_bands[l] = int32_t(mask | (uint32_t(b0) << 8) | (uint32_t(lanes[l].second < 0 ? 0xff : lanes[l].second) << 16));
+  }
   // the kernel leaves 4|X|^2 (or 2|X| without usePower) in the power buffer
   h.mel_scale = mel.scale * (cfg.use_power ? 0.25f : 0.5f);
   h.dct28.assign(16 * 28, 0.0f);
@@ -771,36 +708,31 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
 
 hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
   const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 8 + 16 * 28 + 48;
-  const int wave_floats = wave_region_floats(h.stage_alloc);
-  const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * wave_floats);
+  const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * kWaveFloats);
   unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (grid > (unsigned)h.max_blocks) grid = (unsigned)h.max_blocks;   // persistent: 2 blocks of 8 waves per CU
 #ifdef SMILEHIP_DEBUG_KNOBS
   if (const char *e = getenv("SMILEHIP_DEBUG_GRID")) grid = (unsigned)atoi(e);
 #endif
-  // 7 or 8 x 128 samples per pass (fast512_build_host caps the span at 1024); spans shorter than that still load
-  // 7 (MP = 13) or 8 (MP = 16) steps -- the extra samples are never staged
-  const int nsteps = (h.mp == 16) ? 8 : std::max(7, (h.stage_floats + 127) / 128);
   bool launched = false;
-#define SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, UCV)                                                           \
-  if (h.mp == MPV && nsteps == NS && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL &&     \
-      (P.plp != 0) == PL && h.mel_units == UCV) {                                                                \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, NS, PE, UP, AL, PL, UCV>);                \
+#define SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, UCV)                                                               \
+  if (h.mp == MPV && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL && (P.plp != 0) == PL && \
+      h.mel_units == UCV) {                                                                                     \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP, AL, PL, UCV>);                    \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, NS, PE, UP, AL, PL, UCV>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP, AL, PL, UCV>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
     launched = true;                                                                                            \
   }
-#define SMILEHIP_PICK(MPV, NS, PE, UP, AL, PL) SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, 6) SMILEHIP_PICK_U(MPV, NS, PE, UP, AL, PL, 8)
-#define SMILEHIP_PICK2(MPV, NS, PE, UP) SMILEHIP_PICK(MPV, NS, PE, UP, true, false) SMILEHIP_PICK(MPV, NS, PE, UP, false, false)
-#define SMILEHIP_PICK4(MPV, NS) SMILEHIP_PICK2(MPV, NS, true, true) SMILEHIP_PICK2(MPV, NS, true, false) \
-                                SMILEHIP_PICK2(MPV, NS, false, true) SMILEHIP_PICK2(MPV, NS, false, false) \
-                                /* the PLP chain works on the power spectrum (the plan checks use_power) */ \
-                                SMILEHIP_PICK(MPV, NS, true, true, true, true) SMILEHIP_PICK(MPV, NS, true, true, false, true) \
-                                SMILEHIP_PICK(MPV, NS, false, true, true, true) SMILEHIP_PICK(MPV, NS, false, true, false, true)
-  SMILEHIP_PICK4(13, 7)
-  SMILEHIP_PICK4(13, 8)
-  SMILEHIP_PICK4(16, 8)
+#define SMILEHIP_PICK(MPV, PE, UP, AL, PL) SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, 6) SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, 8)
+#define SMILEHIP_PICK2(MPV, PE, UP) SMILEHIP_PICK(MPV, PE, UP, true, false) SMILEHIP_PICK(MPV, PE, UP, false, false)
+#define SMILEHIP_PICK4(MPV) SMILEHIP_PICK2(MPV, true, true) SMILEHIP_PICK2(MPV, true, false) \
+                            SMILEHIP_PICK2(MPV, false, true) SMILEHIP_PICK2(MPV, false, false) \
+                            /* the PLP chain works on the power spectrum (the plan checks use_power) */ \
+                            SMILEHIP_PICK(MPV, true, true, true, true) SMILEHIP_PICK(MPV, true, true, false, true) \
+                            SMILEHIP_PICK(MPV, false, true, true, true) SMILEHIP_PICK(MPV, false, true, false, true)
+  SMILEHIP_PICK4(13)
+  SMILEHIP_PICK4(16)
 #undef SMILEHIP_PICK4
 #undef SMILEHIP_PICK2
 #undef SMILEHIP_PICK

@@ -65,13 +65,11 @@ struct Fast512Tables {
   const float2 *tw256;        // [256] w256^(j*k1), index k1*16+j
   const float2 *tw512;        // [256] e^{-2 pi i k/512}
   const float2 *win;          // [MP*16] window pairs (x 1/32767), index m*16+j
-  const float4 *melw;         // [U*16*2] weights of unit (pos, lane): two float4
-  const uint32_t *melo;       // [U*16] byte offset of the unit's octet | slot << 16
+  const float4 *melw;         // [U*16*2] weights of unit (step, lane): two float4
+  const uint32_t *melo;       // [U*16] byte offset of the unit's octet in the frame's power buffer
   const float *dct28;         // [16 x 28] DCT rows padded to 28
-  const int32_t *band_slots;  // [64] partial-slot range [s, e) per band
+  const int32_t *lane_bands;  // [16] per lane: bit i = unit i belongs to the first band | first band << 8 | second band << 16
   int32_t mel_units;          // units per lane
-  int32_t n_slots;
-  int32_t stage_floats, stage_alloc;
   float mel_scale;
   const float *plp_eql;       // PLP chain: [32] equal-loudness weights (dct28 then holds the IDFT cosine rows)
   const float *plp_sin;       // [16] lifter table

@@ -326,11 +326,8 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     F.melw = plan->d_melw.p;
     F.melo = plan->d_melo.p;
     F.dct28 = plan->d_dct28.p;
-    F.band_slots = plan->d_band_slots.p;
+    F.lane_bands = plan->d_lane_bands.p;
     F.mel_units = plan->fast.mel_units;
-    F.n_slots = plan->fast.n_slots;
-    F.stage_floats = plan->fast.stage_floats;
-    F.stage_alloc = plan->fast.stage_alloc;
     F.mel_scale = plan->fast.mel_scale;
     F.plp_eql = plan->d_plp_eql.p;
     F.plp_sin = plan->d_plp_sin.p;

@@ -85,7 +85,7 @@ struct smilehip_plan {
   DevBuf<float4> d_melw;
   DevBuf<uint32_t> d_melo;
   DevBuf<float> d_dct28;
-  DevBuf<int32_t> d_band_slots;
+  DevBuf<int32_t> d_lane_bands;
   Fast512Host fast;
   bool use_fast = false;
   DevBuf<float> d_eql, d_eql_log;

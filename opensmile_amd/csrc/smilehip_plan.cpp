@@ -427,7 +427,7 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if ((rc = p->d_melw.upload(p->fast.melw))) return rc;
     if ((rc = p->d_melo.upload(p->fast.melo))) return rc;
     if ((rc = p->d_dct28.upload(p->fast.dct28))) return rc;
-    if ((rc = p->d_band_slots.upload(p->fast.band_slots))) return rc;
+    if ((rc = p->d_lane_bands.upload(p->fast.lane_bands))) return rc;
   }
   return SMILEHIP_OK;
 }

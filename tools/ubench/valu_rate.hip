@@ -35,6 +35,14 @@ __global__ void k(float *out, long long *cyc, int iters) {
         asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
                      "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+      } else if (MODE == 6) {  // dependent chain of v_add_f32
+        asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n"
+                     "v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+      } else if (MODE == 7) {  // dependent chain of v_pk_add_f32
+        asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n"
+                     "v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %0, %0, %8\n"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pc));
       } else if (MODE == 5) {  // v_mul_f32 dpp row_shr
         asm volatile("v_add_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
                      "v_add_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
@@ -53,7 +61,7 @@ template <int MODE>
 void run(const char *name) {
   float *out; long long *cyc;
   hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 8);
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2, 3, 4, 5, 8}) {
     const int iters = 2000;
     const int threads = 64 * 4 * wps;  // one block per CU, wps waves per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -70,6 +78,6 @@ void run(const char *name) {
   }
 }
 int main() {
-  run<0>("v_add_f32"); run<1>("v_fma_f32"); run<2>("v_pk_add_f32"); run<3>("v_pk_fma_f32"); run<4>("v_mov_b32"); run<5>("v_add_f32_dpp");
+  run<0>("v_add_f32"); run<1>("v_fma_f32"); run<2>("v_pk_add_f32"); run<3>("v_pk_fma_f32"); run<4>("v_mov_b32"); run<5>("v_add_f32_dpp"); run<6>("v_add dep"); run<7>("v_pk_add dep");
   return 0;
 }
