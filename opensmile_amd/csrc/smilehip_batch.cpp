@@ -253,7 +253,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
 static int delta_chain_from(smilehip_plan *plan, smilehip_batch *b, const float *d_x, int64_t ld_x, int copy_col, float *d_io,
                             int64_t ld, int32_t D, int32_t W, int32_t n_orders, void *stream) {
   if (!plan || !b || !d_io) return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: null argument");
-  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 16 || ld < (int64_t)D * (1 + n_orders))
+  if (n_orders < 1 || n_orders > 2 || W < 1 || W > 4 || D < 1 || D > 64 || ld < (int64_t)D * (1 + n_orders))   // D: column blocks of 16 on blockIdx.y
     return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_chain: unsupported D=%d W=%d orders=%d ld=%lld", D, W, n_orders, (long long)ld);
   if (b->total_frames == 0) return SMILEHIP_OK;
   // rows == frames is what this entry point assumes (d_io holds the static block)

@@ -1,0 +1,46 @@
+// smilextract_hip -C file.conf: the reference's configuration file format read by this host library and mapped to a plan
+// of the fused path (see conf_plan.cpp). No reference code is linked.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "smilehip.h"
+
+namespace smilehip_host {
+
+struct ConfInstance {
+  std::string name, type;
+  std::vector<std::pair<std::string, std::string>> opts;      // in file order, later assignments replace earlier ones
+  bool has_section = false;
+  const std::string *find(const std::string &key) const;
+};
+
+struct ConfFile {
+  std::vector<ConfInstance> inst;                              // in instantiation order
+  std::map<std::string, std::string> cm_defaults;              // \cm[name{default}:...] options the file defines
+  std::map<std::string, std::string> cm_short;                 // long name -> its one-letter form
+  std::set<std::string> cm_used;
+};
+
+// cmdline: values for the file's \cm[...] options, keyed by the long or the one-letter name (no dash)
+bool conf_parse(const std::string &path, const std::map<std::string, std::string> &cmdline, ConfFile &out, std::string &err);
+
+// hash of every processing component (name, type, options; sources / sinks / data memory excluded)
+uint64_t conf_fingerprint(const ConfFile &f);
+
+struct ConfPlan {
+  std::string preset;                    // "is09_emotion", "compare16", "is13_compare", "egemapsv02", or "" = cfg below
+  smilehip_lld_config cfg;               // a cepstral chain (SMILEHIP_CHAIN_MFCC / _PLP) with the file's option values
+  bool plp = false;
+  int parm_kind = 9;                     // of the file's own cHtkSink
+  std::vector<std::string> lld_names;    // element names of the output level
+  std::string describe;
+};
+
+// false + err: the graph (component, option) the fused path cannot express
+bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err);
+
+}  // namespace smilehip_host

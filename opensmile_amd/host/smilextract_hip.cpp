@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 
+#include "conf_plan.hpp"
 #include "smilehip.h"
 #include "smilehip_host.hpp"
 
@@ -56,19 +57,75 @@ std::string basename_noext(const std::string &p) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::map<std::string, std::string> opt;
-  const char *with_value[] = {"--set", "-I", "-filelist", "-O", "-csvoutput", "-htkoutput", "-lldcsvoutput", "-lldhtkoutput",
+  std::map<std::string, std::string> opt, conf_cmdline;
+  const char *with_value[] = {"--set", "-C", "-I", "-filelist", "-O", "-csvoutput", "-htkoutput", "-lldcsvoutput", "-lldhtkoutput",
                               "-instname", "-N", "-outdir", "--device", "--rank", "--world", "--chunk-files"};
+  bool with_conf = false, print_fingerprint = false, describe_only = false;
+  for (int i = 1; i < argc; ++i)
+    if (!strcmp(argv[i], "-C")) with_conf = true;
   for (int i = 1; i < argc; ++i) {
     bool known = false;
+    if (!strcmp(argv[i], "--fingerprint")) { print_fingerprint = true; continue; }
+    if (!strcmp(argv[i], "--describe")) { describe_only = true; continue; }
     for (const char *w : with_value)
       if (!strcmp(argv[i], w)) {
         if (i + 1 >= argc) die(std::string("option ") + w + " needs a value");
-        opt[w] = argv[++i];
+        opt[w] = argv[i + 1];
         known = true;
       }
-    if (!known) die(std::string("unknown option ") + argv[i]);
+    // with -C every option is also offered to the file's \cm[...] references (long or one-letter name), as SMILExtract does;
+    // options the file does not define are refused after parsing
+    if (with_conf && argv[i][0] == '-' && argv[i][1] != '-' && strcmp(argv[i], "-C")) {
+      const bool has_val = i + 1 < argc && (argv[i + 1][0] != '-' || isdigit((unsigned char)argv[i + 1][1]) || argv[i + 1][1] == 0);
+      conf_cmdline[argv[i] + 1] = has_val ? argv[i + 1] : "1";
+      if (has_val) ++i;
+      continue;
+    }
+    if (known) { ++i; continue; }
+    die(std::string("unknown option ") + argv[i]);
   }
+  // ---- -C file.conf: the plan comes from the configuration file (conf_plan.cpp)
+  ConfPlan conf_plan;
+  if (with_conf) {
+    if (opt.count("--set")) die("-C and --set exclude each other");
+    ConfFile cf;
+    std::string cerr_;
+    if (!conf_parse(opt["-C"], conf_cmdline, cf, cerr_)) die("-C " + opt["-C"] + ": " + cerr_);
+    if (print_fingerprint) {
+      printf("%016llx\n", (unsigned long long)conf_fingerprint(cf));
+      return 0;
+    }
+    static const char *builtin[] = {"l", "loglevel", "nologfile", "noconsoleoutput", "logfile", "appendLogfile", "t", "nticks", "d", "debug",
+                                    "C", "configfile", "N", "instname", "filelist", "outdir"};
+    for (const auto &kv : conf_cmdline) {
+      bool ok = cf.cm_defaults.count(kv.first) != 0;
+      for (const auto &sh : cf.cm_short) ok = ok || sh.second == kv.first;
+      for (const char *b : builtin) ok = ok || kv.first == b;
+      if (!ok) die("option -" + kv.first + " is not defined by " + opt["-C"]);
+    }
+    if (!conf_to_plan(cf, conf_plan, cerr_)) die("-C " + opt["-C"] + " cannot run on the fused path: " + cerr_);
+    fprintf(stderr, "smilextract_hip: %s -> %s\n", opt["-C"].c_str(), conf_plan.describe.c_str());
+    if (!conf_plan.preset.empty()) opt["--set"] = conf_plan.preset;
+    if (describe_only) {                                   // what the file maps to, without touching a device
+      const smilehip_lld_config &c = conf_plan.cfg;
+      printf("preset=%s\n", conf_plan.preset.c_str());
+      if (conf_plan.preset.empty()) {
+        printf("chain_kind=%d\nframe_size_sec=%.17g\nframe_step_sec=%.17g\npreemph=%d\npreemph_k=%.9g\npreemph_de=%d\nwin_func=%d\n"
+               "win_sigma=%.17g\nwin_gain=%.17g\nwin_offset=%.17g\nzero_pad_symmetric=%d\nn_bands=%d\nlofreq=%.9g\nhifreq=%.9g\n"
+               "use_power=%d\nmel_htk_compatible=%d\nfirst_mfcc=%d\nlast_mfcc=%d\ncep_lifter=%.9g\nmfcc_htk_compatible=%d\nmelfloor=%.9g\n"
+               "n_delta=%d\ndelta_win=%d\nplp_lp_order=%d\nplp_compression=%.9g\nappend_log_energy=%d\ncms=%d\nparm_kind=%d\n",
+               c.chain_kind, c.frame_size_sec, c.frame_step_sec, c.preemph, (double)c.preemph_k, c.preemph_de, c.win_func, c.win_sigma,
+               c.win_gain, c.win_offset, c.zero_pad_symmetric, c.n_bands, (double)c.lofreq, (double)c.hifreq, c.use_power,
+               c.mel_htk_compatible, c.first_mfcc, c.last_mfcc, (double)c.cep_lifter, c.mfcc_htk_compatible, (double)c.melfloor, c.n_delta,
+               c.delta_win, c.plp_lp_order, (double)c.plp_compression, c.append_log_energy, c.cms, conf_plan.parm_kind);
+        printf("names=");
+        for (size_t k = 0; k < conf_plan.lld_names.size(); ++k) printf("%s%s", k ? ";" : "", conf_plan.lld_names[k].c_str());
+        printf("\n");
+      }
+      return 0;
+    }
+  }
+  const bool free_chain = with_conf && conf_plan.preset.empty();
   const std::string set = opt.count("--set") ? opt["--set"] : "";
   const bool is09 = set == "is09_emotion";
   const bool is13 = set == "is13_compare";                     // config/is09-13/IS13_ComParE.conf: same elements, IS13 options
@@ -80,16 +137,18 @@ int main(int argc, char **argv) {
   std::string variant;                             // upper-case config name for smilehip_config_htk_variant
   for (char ch : set) variant += (char)toupper((unsigned char)ch);
   smilehip_lld_config vcfg;
-  const bool htk_variant = !is09 && !cmp16 && !egm && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK;
+  if (free_chain) vcfg = conf_plan.cfg;
+  const bool htk_variant = free_chain || (!is09 && !cmp16 && !egm && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK);
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
   if (!is09 && !cmp16 && !egm && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare or egemapsv02");
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare or egemapsv02 (or use -C file.conf)");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
   else if (variant == "MFCC12_E_D_A_Z") parm_kind = 2886;
   else if (variant == "PLP_0_D_A_Z") parm_kind = 11019;
   else if (variant == "PLP_E_D_A_Z") parm_kind = 8971;
+  if (free_chain) parm_kind = conf_plan.parm_kind;
   const bool lld_opts = is09 || cmp16 || egm;           // LLD files through -lldhtkoutput / -lldcsvoutput as in the reference
   std::string instname = opt.count("-instname") ? opt["-instname"] : (opt.count("-N") ? opt["-N"] : "unknown");
 
@@ -141,7 +200,8 @@ int main(int argc, char **argv) {
     return (d == std::string::npos || (sl != std::string::npos && d < sl)) ? p + tag : p.substr(0, d) + tag + p.substr(d);
   };
   const std::vector<std::string> lld_names =
-      is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (egm ? lld_names_egemaps() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy)));
+      free_chain ? conf_plan.lld_names
+                 : (is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (egm ? lld_names_egemaps() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy))));
   const std::vector<std::string> fnames =
       is09 ? func_names_is09() : (cmp16f ? func_names_compare16() : (egm ? func_names_egemaps() : std::vector<std::string>()));
   const uint32_t fmask = smilehip_functionals_is09_mask();

@@ -1,0 +1,137 @@
+"""smilextract_hip -C file.conf: plans derived from the reference's configuration files by the host library's own reader
+(opensmile_amd/host/conf_plan.cpp). CPU part: the eight files of config/mfcc and config/plp map to exactly the presets
+(`smilehip_config_htk_variant`), the four big sets are recognised by their graph fingerprint, option changes land in the
+right fields, inexpressible graphs / options are refused by name. GPU part: -C runs end to end and equals --set."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
+CONF = os.path.join(ROOT, "oracle", "_ref", "config")
+G = os.path.join(ROOT, "tests", "golden", "files")
+
+needs_conf = pytest.mark.skipif(not (os.path.isdir(CONF) and os.path.exists(EXE)), reason="oracle/_ref/config or smilextract_hip not built")
+
+
+def describe(conf, *extra):
+    r = subprocess.run([EXE, "-C", conf, "--describe", *extra], capture_output=True, text=True)
+    kv = dict(l.split("=", 1) for l in r.stdout.split("\n") if "=" in l)
+    return r.returncode, kv, r.stderr
+
+
+@needs_conf
+def test_cepstral_confs_map_to_the_presets():
+    from opensmile_amd import capi
+    for d, name in (("mfcc", "MFCC12_0_D_A"), ("mfcc", "MFCC12_E_D_A"), ("mfcc", "MFCC12_0_D_A_Z"), ("mfcc", "MFCC12_E_D_A_Z"),
+                    ("plp", "PLP_0_D_A"), ("plp", "PLP_E_D_A"), ("plp", "PLP_0_D_A_Z"), ("plp", "PLP_E_D_A_Z")):
+        rc, kv, err = describe(os.path.join(CONF, d, name + ".conf"))
+        assert rc == 0 and kv["preset"] == "", err
+        ref = capi.htk_variant_config(name)
+        for f in ("chain_kind", "preemph", "preemph_de", "win_func", "zero_pad_symmetric", "n_bands", "use_power", "mel_htk_compatible",
+                  "first_mfcc", "mfcc_htk_compatible", "n_delta", "delta_win", "append_log_energy", "cms"):
+            assert int(kv[f]) == int(getattr(ref, f)), (name, f)
+        for f in ("frame_size_sec", "frame_step_sec", "preemph_k", "win_gain", "win_offset", "lofreq", "hifreq", "cep_lifter"):
+            assert float(kv[f]) == pytest.approx(float(getattr(ref, f)), rel=1e-7, abs=0), (name, f)
+        if name.startswith("PLP"):
+            assert int(kv["plp_lp_order"]) == ref.plp_lp_order and float(kv["plp_compression"]) == pytest.approx(ref.plp_compression, rel=1e-7)
+        else:
+            assert int(kv["last_mfcc"]) == ref.last_mfcc
+        names = kv["names"].split(";")
+        n_static = len(names) // 3
+        assert names[n_static].replace("_de", "") == names[0] and names[2 * n_static].replace("_de_de", "") == names[0]
+        if "_E_" in name:
+            assert names[n_static - 1] == "pcm_LOGenergy" and names[-1] == "pcm_LOGenergy_de_de"
+    assert {int(describe(os.path.join(CONF, d, n + ".conf"))[1]["parm_kind"]) for d, n in
+            (("mfcc", "MFCC12_0_D_A_Z"), ("mfcc", "MFCC12_E_D_A_Z"), ("plp", "PLP_0_D_A_Z"), ("plp", "PLP_E_D_A_Z"))} == {11014, 2886, 11019, 8971}
+
+
+@needs_conf
+def test_big_sets_are_recognised_by_their_graph():
+    for rel, preset in (("is09-13/IS09_emotion.conf", "is09_emotion"), ("compare16/ComParE_2016.conf", "compare16"),
+                        ("is09-13/IS13_ComParE.conf", "is13_compare"), ("egemaps/v02/eGeMAPSv02.conf", "egemapsv02")):
+        rc, kv, err = describe(os.path.join(CONF, rel))
+        assert rc == 0 and kv["preset"] == preset, err
+    # output options do not change the graph; a changed processing option does
+    rc, kv, err = describe(os.path.join(CONF, "is09-13/IS09_emotion.conf"), "-O", "x.arff", "-instname", "a")
+    assert rc == 0 and kv["preset"] == "is09_emotion"
+    # GeMAPSv01b is a different graph: refused, naming a component
+    rc, kv, err = describe(os.path.join(CONF, "gemaps/v01b/GeMAPSv01b.conf"))
+    assert rc != 0 and "cannot run on the fused path" in err and ":c" in err
+
+
+@needs_conf
+def test_option_changes_and_refusals(tmp_path):
+    src = os.path.join(CONF, "mfcc", "MFCC12_0_D_A.conf")
+    shutil.copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
+    os.makedirs(tmp_path / "mfcc")
+    txt = open(src).read()
+
+    def variant(name, *subs):
+        t = txt
+        for a, b in subs:
+            assert a in t, a
+            t = t.replace(a, b)
+        p = tmp_path / "mfcc" / name
+        p.write_text(t)
+        return str(p)
+
+    rc, kv, err = describe(variant("a.conf", ("frameSize = 0.0250", "frameSize = 0.032"), ("nBands = 26", "nBands = 40"),
+                                   ("lastMfcc  = 12", "lastMfcc  = 19"), ("hifreq = 8000", "hifreq = 7600"), ("winFunc = ham", "winFunc = Hann"),
+                                   ("k = 0.97", "k = 0.95"), ("cepLifter = 22.0", "cepLifter = 0")))
+    assert rc == 0, err
+    assert float(kv["frame_size_sec"]) == 0.032 and int(kv["n_bands"]) == 40 and int(kv["last_mfcc"]) == 19 and float(kv["hifreq"]) == 7600
+    assert int(kv["win_func"]) == 1 and float(kv["preemph_k"]) == pytest.approx(0.95, rel=1e-6) and float(kv["cep_lifter"]) == 0
+    assert len(kv["names"].split(";")) == 3 * 20
+    # defaults of the reference when a line is absent: cMelspec lofreq 20, cTransformFFT zeroPadSymmetric 1
+    rc, kv, err = describe(variant("b.conf", ("lofreq = 0\n", ""), ("zeroPadSymmetric = 0", "")))
+    assert rc == 0 and float(kv["lofreq"]) == 20.0 and int(kv["zero_pad_symmetric"]) == 1, err
+    # inexpressible option values and unknown options are refused by name
+    rc, kv, err = describe(variant("c.conf", ("specScale = mel", "specScale = bark")))
+    assert rc != 0 and "specScale" in err
+    rc, kv, err = describe(variant("d.conf", ("htkcompatible = 1\nnBands", "htkcompatible = 1\nshowFbank = 1\nnBands")))
+    assert rc != 0 and "showFbank" in err
+    rc, kv, err = describe(variant("e.conf", ("[accel:cDeltaRegression]\nreader.dmLevel=ft0de", "[accel:cDeltaRegression]\nreader.dmLevel=nowhere")))
+    assert rc != 0 and "nowhere" in err
+    # an option the file does not define is refused like SMILExtract refuses it
+    rc, kv, err = describe(src, "-nosuchoption", "1")
+    assert rc != 0 and "nosuchoption" in err
+
+
+@pytest.mark.gpu
+@needs_conf
+def test_conf_front_end_equals_set(tmp_path):
+    """-C <the reference's file> produces the same bytes as --set <its preset>; a modified file (32 ms frames, 40 bands, 20
+    cepstra, Hann window) equals the REAL binary on that file within the chain's tolerance."""
+    from test_host_io import read_htk
+    wav = os.path.join(G, "u3_4000.wav")
+    for rel, setname, opts in (("mfcc/MFCC12_0_D_A.conf", "mfcc12_0_d_a", ["-O"]), ("plp/PLP_E_D_A_Z.conf", "plp_e_d_a_z", ["-O"]),
+                               ("egemaps/v02/eGeMAPSv02.conf", "egemapsv02", ["-htkoutput"])):
+        a, b = str(tmp_path / "a.htk"), str(tmp_path / "b.htk")
+        subprocess.run([EXE, "-C", os.path.join(CONF, rel), "-I", wav, opts[0], a], check=True)
+        subprocess.run([EXE, "--set", setname, "-I", wav, opts[0], b], check=True)
+        assert open(a, "rb").read() == open(b, "rb").read(), rel
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/SMILExtract not built")
+    shutil.copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
+    os.makedirs(tmp_path / "mfcc")
+    t = open(os.path.join(CONF, "mfcc", "MFCC12_0_D_A.conf")).read()
+    for x, y in (("frameSize = 0.0250", "frameSize = 0.032"), ("nBands = 26", "nBands = 40"), ("lastMfcc  = 12", "lastMfcc  = 19"),
+                 ("winFunc = ham", "winFunc = Hann"), ("lofreq = 0\n", "lofreq = 100\n")):
+        assert x in t
+        t = t.replace(x, y)
+    conf = str(tmp_path / "mfcc" / "mod.conf")
+    open(conf, "w").write(t)
+    a, b = str(tmp_path / "m_hip.htk"), str(tmp_path / "m_ref.htk")
+    subprocess.run([EXE, "-C", conf, "-I", wav, "-O", a], check=True)
+    env = dict(os.environ, SMILEHIP_PLUGIN_COMPONENTS="none")
+    subprocess.run([ref_exe, "-C", conf, "-I", wav, "-O", b, "-l", "0"], check=True, env=env, cwd=str(tmp_path))
+    ha, xa = read_htk(a)
+    hb, xb = read_htk(b)
+    assert ha == hb and xa.shape == xb.shape and xa.shape[1] == 60
+    scale = np.abs(xb[:, :20]).max(axis=1, keepdims=True)
+    assert (np.abs(xa - xb) / scale).max() <= 1e-5
