@@ -1,0 +1,163 @@
+// libsmilehip_comm.so: RCCL gather of result rows to rank 0 (include/smilehip_comm.h).
+#include "../../include/smilehip_comm.h"
+
+#include <arpa/inet.h>
+#include <hip/hip_runtime.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <rccl/rccl.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+bool send_all(int fd, const void *p, size_t n) {
+  const char *c = static_cast<const char *>(p);
+  while (n) {
+    const ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL);
+    if (k <= 0) return false;
+    c += k; n -= (size_t)k;
+  }
+  return true;
+}
+bool recv_all(int fd, void *p, size_t n) {
+  char *c = static_cast<char *>(p);
+  while (n) {
+    const ssize_t k = ::recv(fd, c, n, 0);
+    if (k <= 0) return false;
+    c += k; n -= (size_t)k;
+  }
+  return true;
+}
+}  // namespace
+
+struct smilehip_comm {
+  ncclComm_t nccl = nullptr;
+  int rank = 0, world = 1, device = 0;
+  int64_t *d_counts = nullptr;       // [world + 1] device scratch of the count exchange
+};
+
+extern "C" const char *smilehip_comm_last_error(void) { return g_err; }
+
+extern "C" int smilehip_comm_bootstrap_bcast(int rank, int world, const char *master_addr, int master_port, void *buf, int32_t len) {
+  if (world <= 1) return 0;
+  if (!master_addr || master_port <= 0 || !buf || len <= 0 || rank < 0 || rank >= world) return fail("bootstrap: bad argument");
+  sockaddr_in sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)master_port);
+  if (inet_pton(AF_INET, master_addr, &sa.sin_addr) != 1) return fail("bootstrap: '%s' is not an IPv4 address", master_addr);
+  if (rank == 0) {
+    const int ls = socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) return fail("bootstrap: socket: %s", strerror(errno));
+    const int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (bind(ls, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || listen(ls, world) != 0) {
+      const int e = errno;
+      close(ls);
+      return fail("bootstrap: cannot listen on %s:%d: %s", master_addr, master_port, strerror(e));
+    }
+    std::vector<char> seen((size_t)world, 0);
+    for (int k = 1; k < world; ++k) {
+      const int fd = accept(ls, nullptr, nullptr);
+      int32_t peer = -1;
+      const bool ok = fd >= 0 && recv_all(fd, &peer, sizeof(peer)) && peer > 0 && peer < world && !seen[(size_t)peer] && send_all(fd, buf, (size_t)len);
+      if (fd >= 0) close(fd);
+      if (!ok) { close(ls); return fail("bootstrap: hand-over to a peer failed (rank %d)", (int)peer); }
+      seen[(size_t)peer] = 1;
+    }
+    close(ls);
+    return 0;
+  }
+  for (int attempt = 0; attempt < 600; ++attempt) {         // rank 0 may still be starting: retry for a minute
+    const int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return fail("bootstrap: socket: %s", strerror(errno));
+    if (connect(fd, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) == 0) {
+      const int32_t me = rank;
+      const bool ok = send_all(fd, &me, sizeof(me)) && recv_all(fd, buf, (size_t)len);
+      close(fd);
+      return ok ? 0 : fail("bootstrap: rank 0 closed the connection");
+    }
+    close(fd);
+    usleep(100 * 1000);
+  }
+  return fail("bootstrap: rank 0 not reachable at %s:%d", master_addr, master_port);
+}
+
+extern "C" int smilehip_comm_create(int device, int rank, int world, const char *master_addr, int master_port, smilehip_comm **out) {
+  if (!out || world < 1 || rank < 0 || rank >= world) return fail("smilehip_comm_create: bad argument");
+  if (hipSetDevice(device) != hipSuccess) return fail("smilehip_comm_create: hipSetDevice(%d) failed", device);
+  ncclUniqueId id;
+  memset(&id, 0, sizeof(id));
+  if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+  if (smilehip_comm_bootstrap_bcast(rank, world, master_addr, master_port, &id, (int32_t)sizeof(id)) != 0) return -1;
+  smilehip_comm *c = new smilehip_comm;
+  c->rank = rank; c->world = world; c->device = device;
+  const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank: %s", ncclGetErrorString(r)); }
+  if (hipMalloc(&c->d_counts, sizeof(int64_t) * (size_t)(world + 1)) != hipSuccess) {
+    ncclCommDestroy(c->nccl);
+    delete c;
+    return fail("smilehip_comm_create: hipMalloc failed");
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int smilehip_comm_destroy(smilehip_comm *c) {
+  if (!c) return 0;
+  if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->nccl) ncclCommDestroy(c->nccl);
+  delete c;
+  return 0;
+}
+
+extern "C" int smilehip_comm_allgather_count(smilehip_comm *c, int64_t n, int64_t *counts, void *stream) {
+  if (!c || !counts) return fail("smilehip_comm_allgather_count: null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(c->d_counts + c->world, &n, sizeof(n), hipMemcpyHostToDevice, s) != hipSuccess) return fail("count upload failed");
+  const ncclResult_t r = ncclAllGather(c->d_counts + c->world, c->d_counts, 1, ncclInt64, c->nccl, s);
+  if (r != ncclSuccess) return fail("ncclAllGather: %s", ncclGetErrorString(r));
+  if (hipMemcpyAsync(counts, c->d_counts, sizeof(int64_t) * (size_t)c->world, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return fail("count download failed");
+  return 0;
+}
+
+extern "C" int smilehip_comm_gather_rows(smilehip_comm *c, const float *d_rows, const int64_t *counts, int32_t cols, float *d_all, void *stream) {
+  if (!c || !counts || cols <= 0) return fail("smilehip_comm_gather_rows: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t mine = (size_t)counts[c->rank] * (size_t)cols;
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return fail("ncclGroupStart: %s", ncclGetErrorString(r));
+  if (c->rank == 0) {
+    if (!d_all) return fail("smilehip_comm_gather_rows: rank 0 needs d_all");
+    size_t off = (size_t)counts[0] * (size_t)cols;
+    for (int p = 1; p < c->world; ++p) {
+      const size_t n = (size_t)counts[p] * (size_t)cols;
+      if (n && (r = ncclRecv(d_all + off, n, ncclFloat, p, c->nccl, s)) != ncclSuccess) break;
+      off += n;
+    }
+  } else if (mine) {
+    r = ncclSend(d_rows, mine, ncclFloat, 0, c->nccl, s);
+  }
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess || r2 != ncclSuccess) return fail("gather: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+  if (c->rank == 0 && mine && hipMemcpyAsync(d_all, d_rows, mine * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return fail("gather: local copy failed");
+  if (!s && hipStreamSynchronize(s) != hipSuccess) return fail("gather: synchronize failed");      // null stream: blocking call
+  return 0;
+}

@@ -22,6 +22,8 @@
 // (utterances shard with no communication; one process per GPU); the summary outputs of rank r then go to
 // <name>.rank<r><ext> -- ranks never share a file -- and are concatenated afterwards.
 // All files of a chunk are packed into one device batch: one kernel sequence per chunk.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdlib>
@@ -32,6 +34,7 @@
 
 #include "conf_plan.hpp"
 #include "smilehip.h"
+#include "smilehip_comm.h"
 #include "smilehip_host.hpp"
 
 using namespace smilehip_host;
@@ -59,14 +62,15 @@ std::string basename_noext(const std::string &p) {
 int main(int argc, char **argv) {
   std::map<std::string, std::string> opt, conf_cmdline;
   const char *with_value[] = {"--set", "-C", "-I", "-filelist", "-O", "-csvoutput", "-htkoutput", "-lldcsvoutput", "-lldhtkoutput",
-                              "-instname", "-N", "-outdir", "--device", "--rank", "--world", "--chunk-files"};
-  bool with_conf = false, print_fingerprint = false, describe_only = false;
+                              "-instname", "-N", "-outdir", "--device", "--rank", "--world", "--chunk-files", "--master-addr", "--master-port"};
+  bool with_conf = false, print_fingerprint = false, describe_only = false, gather = false;
   for (int i = 1; i < argc; ++i)
     if (!strcmp(argv[i], "-C")) with_conf = true;
   for (int i = 1; i < argc; ++i) {
     bool known = false;
     if (!strcmp(argv[i], "--fingerprint")) { print_fingerprint = true; continue; }
     if (!strcmp(argv[i], "--describe")) { describe_only = true; continue; }
+    if (!strcmp(argv[i], "--gather")) { gather = true; continue; }
     for (const char *w : with_value)
       if (!strcmp(argv[i], w)) {
         if (i + 1 >= argc) die(std::string("option ") + w + " needs a value");
@@ -168,9 +172,13 @@ int main(int argc, char **argv) {
     fclose(f);
   }
   if (jobs.empty()) die("no input (-I or -filelist)");
-  const int rank = opt.count("--rank") ? atoi(opt["--rank"].c_str()) : 0;
-  const int world = opt.count("--world") ? atoi(opt["--world"].c_str()) : 1;
+  // one process per GPU: --rank / --world, or the RANK / WORLD_SIZE / LOCAL_RANK variables of torch.distributed.run
+  auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+  const int rank = opt.count("--rank") ? atoi(opt["--rank"].c_str()) : env_int("RANK", 0);
+  const int world = opt.count("--world") ? atoi(opt["--world"].c_str()) : env_int("WORLD_SIZE", 1);
   if (world < 1 || rank < 0 || rank >= world) die("bad --rank/--world");
+  const int device = opt.count("--device") ? atoi(opt["--device"].c_str()) : env_int("LOCAL_RANK", 0);
+  const std::vector<Job> all_jobs = jobs;                  // rank 0 names the gathered rows
   if (world > 1) {
     std::vector<Job> mine;
     for (size_t i = (size_t)rank; i < jobs.size(); i += (size_t)world) mine.push_back(jobs[i]);
@@ -186,7 +194,31 @@ int main(int argc, char **argv) {
   };
 
   smilehip_context *ctx = nullptr;
-  check(smilehip_init(opt.count("--device") ? atoi(opt["--device"].c_str()) : 0, &ctx), "smilehip_init");
+  check(smilehip_init(device, &ctx), "smilehip_init");
+  // --gather: the summary rows of every rank travel to rank 0 over RCCL (libsmilehip_comm.so, loaded only here) and rank 0
+  // writes ONE file in list order; without it every rank writes <name>.rank<r><ext>
+  smilehip_comm *comm = nullptr;
+  decltype(&smilehip_comm_create) comm_create = nullptr;
+  decltype(&smilehip_comm_destroy) comm_destroy = nullptr;
+  decltype(&smilehip_comm_allgather_count) comm_count = nullptr;
+  decltype(&smilehip_comm_gather_rows) comm_gather = nullptr;
+  decltype(&smilehip_comm_last_error) comm_error = nullptr;
+  if (gather) {
+    void *h = dlopen("libsmilehip_comm.so", RTLD_NOW);
+    if (!h) die(std::string("--gather: ") + dlerror());
+    comm_create = (decltype(comm_create))dlsym(h, "smilehip_comm_create");
+    comm_destroy = (decltype(comm_destroy))dlsym(h, "smilehip_comm_destroy");
+    comm_count = (decltype(comm_count))dlsym(h, "smilehip_comm_allgather_count");
+    comm_gather = (decltype(comm_gather))dlsym(h, "smilehip_comm_gather_rows");
+    comm_error = (decltype(comm_error))dlsym(h, "smilehip_comm_last_error");
+    if (!comm_create || !comm_destroy || !comm_count || !comm_gather || !comm_error) die("--gather: libsmilehip_comm.so lacks a symbol");
+    const char *ma = getenv("MASTER_ADDR"), *mp = getenv("MASTER_PORT");
+    const std::string addr = opt.count("--master-addr") ? opt["--master-addr"] : (ma && *ma ? ma : "127.0.0.1");
+    const int port = opt.count("--master-port") ? atoi(opt["--master-port"].c_str()) : (mp && *mp ? atoi(mp) + 1 : 29411);
+    if (comm_create(device, rank, world, addr.c_str(), port, &comm) != 0) die(std::string("--gather: ") + comm_error());
+  }
+  std::vector<float> gathered;                              // this rank's summary rows: n_func values + a "has an instance" flag each
+  int gathered_cols = 0;
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
   const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 4096;
   if (chunk_files_l < 1) die("--chunk-files must be a positive number");
@@ -194,7 +226,7 @@ int main(int argc, char **argv) {
   // Summary sinks (one row per file appended to ONE file) of several ranks must not share a file: each rank of a
   // --world > 1 run writes <name>.rank<r><ext>; concatenate them afterwards (the ARFF header is the same in each).
   auto summary_path = [&](const std::string &p) {
-    if (world <= 1) return p;
+    if (world <= 1 || gather) return p;
     const size_t d = p.find_last_of('.'), sl = p.find_last_of('/');
     const std::string tag = ".rank" + std::to_string(rank);
     return (d == std::string::npos || (sl != std::string::npos && d < sl)) ? p + tag : p.substr(0, d) + tag + p.substr(d);
@@ -307,7 +339,16 @@ int main(int argc, char **argv) {
       smilehip_batch_destroy(b);
     }
     // summary sinks in file-list order (the rate groups above may have processed the chunk's files in another order)
-    for (size_t j = j0; j < j1 && has_func; ++j) {
+    for (size_t j = j0; j < j1 && has_func && gather; ++j) {       // kept for the gather at the end
+      const std::vector<float> &fv = func_rows[j - j0];
+      const int n_func = is09 ? (int)lld_names.size() * smilehip_functionals_count(fmask)
+                              : (cmp16f ? smilehip_functionals_compare16_count() : smilehip_functionals_egemaps_count());
+      gathered_cols = n_func + 1;
+      const size_t at = gathered.size();
+      gathered.resize(at + (size_t)gathered_cols, 0.0f);
+      if (!fv.empty()) { std::copy(fv.begin(), fv.end(), gathered.begin() + (long)at); gathered[at + (size_t)n_func] = 1.0f; }
+    }
+    for (size_t j = j0; j < j1 && has_func && !gather; ++j) {
       const std::vector<float> &fv = func_rows[j - j0];
       if (fv.empty()) continue;
       const int n_func = (int)fv.size();
@@ -324,6 +365,53 @@ int main(int argc, char **argv) {
       }
     }
   }
+  if (gather && has_func) {
+    // rank r holds the rows of files r, r + world, ...: counts to everyone, rows to rank 0, rank 0 writes in list order
+    std::vector<int64_t> counts((size_t)world, 0);
+    if (comm_count(comm, (int64_t)jobs.size(), counts.data(), nullptr) != 0) die(std::string("--gather: ") + comm_error());
+    int cols = gathered_cols;
+    if (cols == 0) cols = 1 + (is09 ? (int)lld_names.size() * smilehip_functionals_count(fmask)
+                                    : (cmp16f ? smilehip_functionals_compare16_count() : smilehip_functionals_egemaps_count()));
+    int64_t total = 0;
+    for (int64_t c : counts) total += c;
+    void *d_mine = nullptr, *d_all = nullptr;
+    check(smilehip_alloc(ctx, std::max<uint64_t>(gathered.size(), 1) * 4, &d_mine), "smilehip_alloc");
+    if (!gathered.empty()) check(smilehip_copy_to_device(ctx, d_mine, gathered.data(), (uint64_t)gathered.size() * 4, nullptr), "copy_to_device");
+    if (rank == 0) check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(total, 1) * cols * 4, &d_all), "smilehip_alloc");
+    check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
+    if (comm_gather(comm, (const float *)d_mine, counts.data(), cols, (float *)d_all, nullptr) != 0) die(std::string("--gather: ") + comm_error());
+    if (rank == 0) {
+      std::vector<float> all((size_t)total * cols);
+      if (total > 0) check(smilehip_copy_to_host(ctx, all.data(), d_all, (uint64_t)all.size() * 4, nullptr), "copy_to_host");
+      check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
+      std::vector<int64_t> first((size_t)world + 1, 0);
+      for (int r = 0; r < world; ++r) first[(size_t)r + 1] = first[(size_t)r] + counts[(size_t)r];
+      const int n_func = cols - 1;
+      for (size_t j = 0; j < all_jobs.size(); ++j) {
+        const int r = (int)(j % (size_t)world);
+        const int64_t k = (int64_t)(j / (size_t)world);
+        if (k >= counts[(size_t)r]) die("--gather: the ranks disagree about the file list");
+        const float *fv = all.data() + (size_t)(first[(size_t)r] + k) * cols;
+        if (fv[n_func] == 0.0f) continue;                   // no frame -> the reference writes no instance
+        if (opt.count("-O") && opt["-O"] != "?") {
+          ArffOptions ao;
+          ao.instance_name = all_jobs[j].inst;
+          if (!write_arff(opt["-O"], fnames, fv, 1, n_func, n_func, 0.0, ao, err)) die(err);
+        }
+        if (opt.count("-csvoutput") && opt["-csvoutput"] != "?") {
+          CsvOptions co;
+          co.instance_name = all_jobs[j].inst;
+          co.append = true;
+          if (!write_csv(opt["-csvoutput"], fnames, fv, 1, n_func, n_func, 0.0, nullptr, co, err)) die(err);
+        }
+      }
+      smilehip_free(ctx, d_all);
+    } else {
+      check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
+    }
+    smilehip_free(ctx, d_mine);
+  }
+  if (comm) comm_destroy(comm);
   for (auto &kv : plans) smilehip_plan_destroy(kv.second);
   smilehip_shutdown(ctx);
   return 0;

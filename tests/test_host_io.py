@@ -319,3 +319,50 @@ def test_smilextract_hip_egemapsv02(tmp_path):
     rel = np.abs(xf[0].astype(np.float64) - xfr[0]) / np.maximum(np.abs(xfr[0]), 1e-2)
     well = list(range(0, 30)) + list(range(81, 88))
     assert rel[well].max() <= 1e-3 and (rel <= 1e-3).mean() >= 0.85
+
+
+def test_comm_bootstrap_hand_over():
+    """The TCP hand-over smilehip_comm_create uses for the RCCL unique id (rank 0 -> every other rank), three ranks as
+    threads on 127.0.0.1; no device involved."""
+    import threading
+    lib = os.path.join(ROOT, "opensmile_amd", "libsmilehip_comm.so")
+    if not os.path.exists(lib):
+        pytest.skip("libsmilehip_comm.so not built")
+    L = C.CDLL(lib)
+    L.smilehip_comm_bootstrap_bcast.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int32]
+    L.smilehip_comm_last_error.restype = C.c_char_p
+    port = 29000 + os.getpid() % 2000
+    payload = bytes(range(128))
+    bufs = [C.create_string_buffer(payload if r == 0 else b"\0" * 128, 128) for r in range(3)]
+    rcs = [None] * 3
+
+    def run(r):
+        rcs[r] = L.smilehip_comm_bootstrap_bcast(r, 3, b"127.0.0.1", port, bufs[r], 128)
+    ts = [threading.Thread(target=run, args=(r,)) for r in (2, 1, 0)]      # the peers start first and retry
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=90)
+    assert rcs == [0, 0, 0], L.smilehip_comm_last_error()
+    assert all(b.raw == payload for b in bufs)
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_gather_single_rank(tmp_path):
+    """--gather with one rank: the RCCL path (communicator, count all-gather, grouped send/recv, here rank 0's own block)
+    must give the files the plain run gives, incl. a file too short for an instance."""
+    import wave
+    short = str(tmp_path / "short.wav")
+    with wave.open(short, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.zeros(400, dtype=np.int16).tobytes())
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("\n".join([os.path.join(G, "u3_4000.wav") + "\ta", short + "\tb", os.path.join(G, "u3_4000.wav") + "\tc"]) + "\n")
+    outs = {}
+    for tag, extra in (("plain", []), ("gather", ["--gather", "--master-port", str(29500 + os.getpid() % 400)])):
+        arff, csv = str(tmp_path / (tag + ".arff")), str(tmp_path / (tag + ".csv"))
+        subprocess.run([EXE, "--set", "egemapsv02", "-filelist", lst, "-O", arff, "-csvoutput", csv] + extra, check=True)
+        outs[tag] = (open(arff).read(), open(csv).read())
+    assert outs["plain"] == outs["gather"]
+    rows = [l for l in outs["plain"][0].split("@data")[1].split("\n") if l]
+    assert [r.split(",")[0] for r in rows] == ["a", "c"]               # the 25 ms file has no 60 ms frame: no instance
