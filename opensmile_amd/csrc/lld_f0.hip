@@ -276,8 +276,14 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // Returns the number of candidates.
 // hps_in != null: per-component mode, cPitchShs on a given octave-scale spectrum (no interpolation);
 // only_scale: per-component mode, cSpecScale alone (stop after the spectrum has been written to Q.hps_tap)
-__device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane, int64_t g, double *A, double *B, int *ci,
+__device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane_in, int64_t g, double *A, double *B, int *ci,
                                       const float *hps_in, bool only_scale) {
+  // Everything below that depends only on the lane (135 clamped addresses and in-range masks of the harmonic shifts, table
+  // addresses ...) is loop-invariant over the frames of a wave, and the compiler keeps all of it in registers across the
+  // frame loop: 256 VGPRs + AGPR spills, one wave per SIMD. An opaque copy of the lane index makes it recompute them per
+  // frame (a few hundred integer operations) and brings the kernel to three waves per SIMD.
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
   float *hps = reinterpret_cast<float *>(A), *SS = hps + kKP;
   float hv[kPer];
   F0_FOR_BINS(m, i) {
@@ -492,6 +498,174 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
       }
       PHASE(4);   // candidates + output
     }
+  }
+  PHASE_FLUSH;
+}
+// ---- the chain as three kernels (round 2). The old kernel ran the spline's serial sweeps on one lane per frame with
+// three frames per wave: 61 idle lanes for 27 % of its time, and the LDS of three frames per wave capped the occupancy.
+// Now: lld_f0_spec (wave per frame: window .. 6*ut, rows of y and 6*ut to a global scratch), lld_f0_sweep (THREAD per
+// frame: 64 recurrences per wave, table operands by scalar loads), lld_f0_cand (wave per frame: evaluation, summation,
+// top six, mean, candidates). Same device functions, same operation order: results are bit-identical to the one-kernel
+// form, which stays for the per-component operators (mode 1 / 2).
+constexpr int kSpecWaves = 4;
+constexpr int kNBB = (kKP + 7) / 8;                    // 8-bin blocks of a row: 65
+// 6ut / y2 of frame fr (chunk-local), bin i: the 64 frames of a tile keep each 8-bin block side by side, so that the sweep
+// (one frame per lane) streams 4 KB per block and wave while the wave-per-frame kernels still write / read whole 64-byte
+// lines (8 consecutive bins of one frame)
+__device__ __forceinline__ int64_t f0_bb_index(int64_t fr, int i) {
+  return (((fr >> 6) * kNBB + (i >> 3)) * 64 + (fr & 63)) * 8 + (i & 7);
+}
+__host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // d1 | d2 | win | twh | twf
+  const size_t np = (size_t)((N + 3) & ~3);
+  return (size_t)kKP * 8 * 2 + np * 4 + (size_t)(kM / 2) * 8 + (size_t)(kM / 2 + 4) * 8;
+}
+__host__ __device__ inline size_t f0_cand_shared_bytes() { return (size_t)kKP * 8 * 4 + (size_t)kKP * 4; }   // a | c | d | audw | k
+
+__global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_spec(LldParams P, F0Params Q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NP = (Q.N + 3) & ~3;
+  double *c_d1 = reinterpret_cast<double *>(smem_f0), *c_d2 = c_d1 + kKP;
+  float *c_win = reinterpret_cast<float *>(c_d2 + kKP);
+  float2 *c_twh = reinterpret_cast<float2 *>(c_win + NP);
+  float2 *c_twf = c_twh + kM / 2;
+  for (int i = threadIdx.x; i < kK; i += blockDim.x) { c_d1[i] = Q.sp_d1[i]; c_d2[i] = Q.sp_d2[i]; }
+  for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
+  for (int i = threadIdx.x; i < kM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
+  for (int i = threadIdx.x; i <= kM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  __syncthreads();
+  F0Tbl T = {};
+  T.d1 = c_d1; T.d2 = c_d2; T.win = c_win; T.twh = c_twh; T.twf = c_twf;
+  double *A = reinterpret_cast<double *>(smem_f0 + f0_spec_shared_bytes(Q.N)) + (size_t)wave * 2 * kKP;
+  const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
+  if (tile >= Q.tile0 + Q.n_tiles_chunk) return;
+  const int64_t samp0 = P.tile_rec[tile].samp0;
+  const int n_fr = P.tile_rec[tile].n_frames;
+  for (int w = 0; w < n_fr; ++w) {
+    const double es = f0_spectrum(T, Q, P.pcm + samp0 + (int64_t)w * Q.H, nullptr, lane, A, A + kKP);
+    const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
+    double *row = Q.ab + fr * kKP;
+    double *bb = Q.ab + Q.ab_rows * kKP;
+#pragma unroll
+    for (int m = 0; m < kPer; ++m) {
+      const int i = lane + 64 * m;
+      if (i < kK) { row[i] = A[i]; bb[f0_bb_index(fr, i)] = A[kKP + i]; }
+    }
+    if (lane == 0) row[kK] = es;                       // the frame's sum of squares rides in the row's padding
+    WaveG::sync();
+  }
+}
+
+// the spline's two recurrences, one frame per thread, one 64-frame tile per wave. A round is one 8-bin block: the wave
+// reads / writes 4 KB of consecutive memory (lane = frame: its 64-byte line), the next block's operands are loaded before
+// the current block's chain runs (two register sets alternate; the blocks never overlap, which the compiler cannot know).
+__global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
+  double2 *T2 = reinterpret_cast<double2 *>(Q.ab + Q.ab_rows * kKP) + ((int64_t)blockIdx.x * kNBB * 64 + threadIdx.x) * 4;
+  const double *sp = Q.sp_rec;                         // [K x 4]: sigma_i, p_i, dec_i, 0 -- wave-uniform operands
+  auto blk = [&](int bb) { return T2 + (int64_t)bb * 64 * 4; };
+  auto ld = [&](double2 (&c)[4], int bb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = blk(bb)[q];
+  };
+  auto st = [&](const double2 (&c)[4], int bb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) blk(bb)[q] = c[q];
+  };
+  double up = 0.0;
+  auto fw = [&](double2 (&c)[4], int bb) {             // bins 8 bb .. 8 bb + 7, clipped to 1 .. kK-2
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = 8 * bb + e;
+      if (i >= 1 && i <= kK - 2) {
+        double &v = (e & 1) ? c[e >> 1].y : c[e >> 1].x;
+        up = sp[4 * i + 1] * (v - sp[4 * i] * up);
+        v = up;
+      }
+    }
+    st(c, bb);
+  };
+  constexpr int last_fw = (kK - 2) / 8;                // 63
+  double2 ca[4], cb[4];
+  ld(ca, 0);
+  for (int bb = 0; bb <= last_fw; bb += 2) {
+    if (bb + 1 <= last_fw) ld(cb, bb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fw(ca, bb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (bb + 2 <= last_fw) ld(ca, bb + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (bb + 1 <= last_fw) fw(cb, bb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double yn = 0.0;                                       // y2[K-1] of the natural spline
+  auto bw = [&](double2 (&c)[4], int bb) {             // bins 8 bb + 7 .. 8 bb, clipped to kK-1 (set to 0) .. 0
+#pragma unroll
+    for (int e = 7; e >= 0; --e) {
+      const int j = 8 * bb + e;
+      double &v = (e & 1) ? c[e >> 1].y : c[e >> 1].x;
+      if (j == kK - 1) v = 0.0;
+      else if (j <= kK - 2) { yn = sp[4 * j + 2] * yn + v; v = yn; }
+    }
+    st(c, bb);
+  };
+  constexpr int first_bw = (kK - 1) / 8;               // 64: holds bin kK-1 only
+  ld(ca, first_bw);
+  for (int bb = first_bw; bb >= 0; bb -= 2) {
+    if (bb - 1 >= 0) ld(cb, bb - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    bw(ca, bb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (bb - 2 >= 0) ld(ca, bb - 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (bb - 1 >= 0) bw(cb, bb - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_cand(LldParams P, F0Params Q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *c_a = reinterpret_cast<double *>(smem_f0), *c_c = c_a + kKP, *c_d = c_c + kKP, *c_audw = c_d + kKP;
+  int *c_k = reinterpret_cast<int *>(c_audw + kKP);
+  for (int i = threadIdx.x; i < kK; i += blockDim.x) {
+    c_a[i] = Q.ip_co[3 * i]; c_c[i] = Q.ip_co[3 * i + 1]; c_d[i] = Q.ip_co[3 * i + 2];
+    c_audw[i] = Q.audw[i];
+    c_k[i] = Q.ip_k[i];
+  }
+  __syncthreads();
+  F0Tbl T = {};
+  T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw; T.k = c_k;
+  unsigned char *base = smem_f0 + f0_cand_shared_bytes() + (size_t)wave * kFrameBytes;
+  double *A = reinterpret_cast<double *>(base);
+  int *ci = reinterpret_cast<int *>(A + 2 * kKP);
+  const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
+  if (tile >= Q.tile0 + Q.n_tiles_chunk) return;
+  const int64_t row0 = P.tile_rec[tile].row0;
+  const int n_fr = P.tile_rec[tile].n_frames;
+  PHASE_DECL
+  for (int w = 0; w < n_fr; ++w) {
+    const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
+    const double *row = Q.ab + fr * kKP;
+    const double *bb = Q.ab + Q.ab_rows * kKP;
+#pragma unroll
+    for (int m = 0; m < kPer; ++m) {
+      const int i = lane + 64 * m;
+      if (i < kK) { A[i] = row[i]; A[kKP + i] = bb[f0_bb_index(fr, i)]; }
+    }
+    const double es = row[kK];
+    WaveG::sync();
+    PHASE(0);   // rows from global
+    const int nf = f0_shs(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false);
+    WaveG::sync();
+    PHASE(2);   // interpolation, summation, top six
+    double mean = 0.0;
+    if (lane == 0) mean = f0_mean_serial(A + kKP);
+    mean = __shfl(mean, 0);
+    PHASE(3);   // mean
+    f0_candidates(Q, lane, row0 + w, A, ci, reinterpret_cast<float *>(ci + 8), nf, mean, es);
+    PHASE(4);   // candidates + output
   }
   PHASE_FLUSH;
 }
@@ -1046,21 +1220,38 @@ __global__ void __launch_bounds__(64) lld_f0_lld(const int64_t *frame_off, const
 
 int f0_tile_frames() { return kTileFrames; }
 
-hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s) {
+int f0_chunk_tiles() { return 16384; }                 // 131 072 frames = 1.08 GB of scratch rows per chunk
+
+hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s) {
   if (P.total_frames <= 0) return hipSuccess;
-  if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17 || Q.vit_buf < 2 || Q.vit_buf > kVBmax) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
-  const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
-  const void *fn = reinterpret_cast<const void *>(&lld_f0_frame);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (Q0.Nfft != kNfftF0 || Q0.K != kK || Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
+  (void)max_blocks;
+  const size_t lds_spec = f0_spec_shared_bytes(Q0.N) + (size_t)kSpecWaves * 2 * kKP * sizeof(double);
+  const size_t lds_cand = f0_cand_shared_bytes() + (size_t)kSpecWaves * kFrameBytes;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
   if (e != hipSuccess) return e;
-  unsigned grid = (unsigned)((P.n_tiles + kWaves - 1) / kWaves);
-  if (grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;         // persistent: one workgroup per CU
-  hipLaunchKernelGGL(lld_f0_frame, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
-  e = hipGetLastError();
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
+  F0Params Q = Q0;
+  for (int t0 = 0; t0 < P.n_tiles; t0 += f0_chunk_tiles()) {
+    Q.tile0 = t0;
+    Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
+    const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
+    hipLaunchKernelGGL(lld_f0_spec, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
+    hipLaunchKernelGGL(lld_f0_sweep, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
+    hipLaunchKernelGGL(lld_f0_cand, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q, d_out, ld_out);
   return hipGetLastError();
 }
+int64_t f0_scratch_rows(int64_t n_tiles) {                // rows of a chunk, a multiple of 64
+  const int64_t t = n_tiles < f0_chunk_tiles() ? n_tiles : f0_chunk_tiles();
+  return (t * kTileFrames + 63) / 64 * 64;
+}
+int64_t f0_scratch_doubles(int64_t n_tiles) { return f0_scratch_rows(n_tiles) * (kKP + kNBB * 8); }
 
 
 // per-component operators on n_rows rows: mode 1 = cSpecScale (magnitudes -> Q.hps_tap), mode 2 = cPitchShs (octave-scale

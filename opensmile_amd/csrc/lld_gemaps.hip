@@ -355,14 +355,18 @@ __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
 
 // ------------------------------------------------------------------------------------------------ cFormantLpc
 // zerosolve.cpp restated for one thread: companion matrix of the monic polynomial, balancing, Francis QR steps; h is the
-// thread's private nc x nc matrix (row-major), 1-based accessors like the reference's MATF.
+// thread's nc x nc matrix (row-major), 1-based accessors like the reference's MATF. The matrices of a wave's 64 frames
+// live in LDS, element-major: element e of lane l at double index e * 64 + l -- the bank of an access depends on the lane
+// only, so the 64 lanes never conflict however their indices diverge (as private arrays they were 1.2 KB of scratch per
+// lane: 60 GB of HBM traffic per million frames, profiles/r02_pmc_egemaps.txt).
 namespace {
 constexpr int kNC = kLpcP;
-#define GM_MATC(m, i, j) ((m)[(i) * kNC + (j)])
-#define GM_MATF(m, i, j) ((m)[((i) - 1) * kNC + ((j) - 1)])
+#define GM_MATC(m, i, j) ((m)[((i) * kNC + (j)) * 64])
+#define GM_MATF(m, i, j) ((m)[(((i) - 1) * kNC + ((j) - 1)) * 64])
+#define GM_ROOT(r, i) ((r)[(i) * 64])
 #define GM_EPS 2.2204460492503131e-16
 
-__device__ void zs_balance(double *m) {                  // zerosolveBalanceCmatrix, zerosolve.cpp:22-84
+__device__ __forceinline__ void zs_balance(double *m) {                  // zerosolveBalanceCmatrix, zerosolve.cpp:22-84
   const double radix = 2.0, radix2 = 4.0;
   const int nc = kNC;
   bool converged = false;
@@ -393,7 +397,7 @@ __device__ void zs_balance(double *m) {                  // zerosolveBalanceCmat
   }
 }
 
-__device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, zerosolve.cpp:100-283
+__device__ __forceinline__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, zerosolve.cpp:100-283
   int i, j, k, m = 0, e, nit = 0, N = kNC;
   double w, s, x, y, z, p = 0, q = 0, r = 0, t = 0.0;
   for (;;) {
@@ -403,7 +407,7 @@ __device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, z
     }
     x = GM_MATF(h, N, N);
     if (e == N) {
-      root[2 * (N - 1)] = x + t; root[2 * (N - 1) + 1] = 0;
+      GM_ROOT(root, 2 * (N - 1)) = x + t; GM_ROOT(root, 2 * (N - 1) + 1) = 0;
       N--;
       if (N == 0) return 1;
       nit = 0;
@@ -419,11 +423,11 @@ __device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, z
       if (q > 0) {
         if (p < 0) y = -y;
         y += p;
-        root[2 * (N - 1)] = x - w / y; root[2 * (N - 1) + 1] = 0;
-        root[2 * (N - 2)] = x + y; root[2 * (N - 2) + 1] = 0;
+        GM_ROOT(root, 2 * (N - 1)) = x - w / y; GM_ROOT(root, 2 * (N - 1) + 1) = 0;
+        GM_ROOT(root, 2 * (N - 2)) = x + y; GM_ROOT(root, 2 * (N - 2) + 1) = 0;
       } else {
-        root[2 * (N - 1)] = x + p; root[2 * (N - 1) + 1] = -y;
-        root[2 * (N - 2)] = x + p; root[2 * (N - 2) + 1] = y;
+        GM_ROOT(root, 2 * (N - 1)) = x + p; GM_ROOT(root, 2 * (N - 1) + 1) = -y;
+        GM_ROOT(root, 2 * (N - 2)) = x + p; GM_ROOT(root, 2 * (N - 2) + 1) = y;
       }
       N -= 2;
       if (N == 0) return 1;
@@ -493,19 +497,22 @@ __device__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, z
 // cFormantLpc::processVector (formantLpc.cpp:192-290), nFormants = 5, saveFormants = saveBandwidths = 1, no median filter /
 // octave correction. One thread per frame. When the QR iteration does not converge the reference goes on with what its
 // roots member held before (the previous frame's values); a frame here starts from zeros instead (not observed on speech).
+constexpr size_t kFormantLds = sizeof(double) * 64 * (kLpcP * kLpcP + 2 * kLpcP);      // 73 KB: two workgroups per CU
 __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
   const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (g >= (G.op_mode ? G.op_rows : G.total_frames20)) return;
   const float *lp = G.lpc + g * G.lpc_ld;
-  double mat[kNC * kNC], roots[2 * kNC], fc[5], bc[5];
-  for (int i = 0; i < kNC * kNC; ++i) mat[i] = 0.0;
-  for (int i = 0; i < 2 * kNC; ++i) roots[i] = 0.0;
+  extern __shared__ __attribute__((aligned(16))) double fm_smem[];       // [kNC*kNC + 2*kNC][64]
+  double *mat = fm_smem + threadIdx.x, *roots = fm_smem + kNC * kNC * 64 + threadIdx.x;
+  double fc[5], bc[5];
+  for (int i = 0; i < kNC * kNC; ++i) mat[i * 64] = 0.0;
+  for (int i = 0; i < 2 * kNC; ++i) GM_ROOT(roots, i) = 0.0;
   for (int i = 1; i < kNC; i++) GM_MATC(mat, i, i - 1) = 1.0;                 // zerosolveSetCmatrix, zerosolve.cpp:86-98
   for (int i = 0; i < kNC; i++) GM_MATC(mat, i, kNC - 1) = -(double)(-lp[kNC - i - 1]) / 1.0;   // a[i] = -lpc[n-1-i], a[n] = 1
   zs_balance(mat);
   zs_qr(mat, roots);
   for (int i = 0; i < kNC; i++) {                                            // smileMath_complexIntoUnitCircle, smileUtil.c:992-1003
-    const double re = roots[2 * i], im = roots[2 * i + 1];
+    const double re = GM_ROOT(roots, 2 * i), im = GM_ROOT(roots, 2 * i + 1);
     if (sqrt(re * re + im * im) > 1.0) {
       const double c = re, d = -im;                                          // 1 / conj(root), smileMath_complexDiv :951-977
       double R = 0, I = 0;
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
       } else {
         if (d != 0.0) { const double r = c / d, den = d + r * c; if (den != 0.0) { R = (1.0 * r + 0.0) / den; I = (0.0 * r - 1.0) / den; } }
       }
-      roots[2 * i] = R; roots[2 * i + 1] = I;
+      GM_ROOT(roots, 2 * i) = R; GM_ROOT(roots, 2 * i + 1) = I;
     }
   }
   int n_found = 0;                                                           // smileDsp_lpcrootsToFormants, smileUtil.c:2019-2053
@@ -523,7 +530,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
     double fHigh = G.fm_max;
     if ((fHigh < G.fm_min) || (fHigh > 1.0 / G.fm_T)) fHigh = 0.5 / G.fm_T - G.fm_min;
     for (int i = 0; i < kNC; i++) {
-      const double re = roots[2 * i], im = roots[2 * i + 1];
+      const double re = GM_ROOT(roots, 2 * i), im = GM_ROOT(roots, 2 * i + 1);
       if (im < 0) continue;
       const double f = fabs(atan2(im, re)) / spPi2;
       if ((f >= G.fm_min) && (f <= fHigh)) {
@@ -548,6 +555,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 }
 #undef GM_MATC
 #undef GM_MATF
+#undef GM_ROOT
 #undef GM_EPS
 
 // ------------------------------------------------------------------------------------------------ cHarmonics
@@ -966,10 +974,16 @@ hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s) {
   hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.op_rows + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
   return hipGetLastError();
 }
+static hipError_t launch_formants(const GemapsParams &G, int64_t rows, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_gemaps_formants), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kFormantLds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((rows + 63) / 64)), dim3(64), kFormantLds, s, G);
+  return hipGetLastError();
+}
 hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s) {
   if (G.op_rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((G.op_rows + 63) / 64)), dim3(64), 0, s, G);
-  return hipGetLastError();
+  return launch_formants(G, G.op_rows, s);
 }
 
 hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s) {
@@ -985,8 +999,7 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.total_frames20 + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((G.total_frames20 + 63) / 64)), dim3(64), 0, s, G);
-  return hipGetLastError();
+  return launch_formants(G, G.total_frames20, s);
 }
 
 hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s) {

@@ -135,6 +135,10 @@ struct F0Params {
   float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
   // per-component operators (mode 1: cSpecScale rows -> hps_tap, mode 2: cPitchShs rows -> shs)
   int32_t mode;
+  double *ab;                       // chain mode, between the three frame kernels: y rows [chunk frames x 516] (row-major), then
+                                    // 6ut -> y2 in blocks [64-frame tile][8-bin block (65)][frame (64)][bin in block (8)]
+  int64_t ab_rows;                  // rows the scratch holds (a multiple of 64)
+  int32_t tile0, n_tiles_chunk;     // the tiles [tile0, tile0 + n_tiles_chunk) this launch works on
   int64_t n_rows;
   const float *in_rows;
   int64_t ld_in, ld_tap, ld_shs;

@@ -160,6 +160,12 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 scratch matrices failed");
     }
     b->d_shs.n = nf * 21; b->d_e60.n = nf;
+    const size_t nab = (size_t)std::max<int64_t>(f0_scratch_doubles(b->n_tiles), 1);
+    if (hipMalloc(reinterpret_cast<void **>(&b->d_f0_ab.p), nab * sizeof(double)) != hipSuccess) {
+      delete b;
+      return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 row scratch (%zu MB) failed", nab * sizeof(double) >> 20);
+    }
+    b->d_f0_ab.n = nab;
     std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
     if ((rc = b->d_pending.upload(zp))) {
       delete b;
@@ -508,6 +514,8 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   fill_f0_params(plan, Q);
   Q.shs = b->d_shs.p;
   Q.e60 = b->d_e60.p;
+  Q.ab = b->d_f0_ab.p;
+  Q.ab_rows = f0_scratch_rows(b->n_tiles);
   Q.hps_tap = b->d_hps_tap;
   Q.pending = b->d_pending.p;
   Q.vit_log_out = log_out ? 1 : 0;

@@ -139,6 +139,7 @@ struct smilehip_batch {
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
   DevBuf<float> d_b_extra;                // [n_utt x 110] row T60+1 of group B's sma / delta levels (functionals)
   DevBuf<float> d_shs, d_e60;             // F0 group: candidates (total_frames x 21) and frame energies
+  DevBuf<double> d_f0_ab;                 // F0 group: rows of (y | 6ut -> y2) between the three frame kernels, one chunk of tiles
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance
   DevBuf<float> d_pitch2, d_jit4;         // whole-level chain: F0final/voicing (T60 x 2) and jitter/shimmer/HNR (T60 x 4)

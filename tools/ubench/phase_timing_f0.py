@@ -12,7 +12,7 @@ os.environ["SMILEHIP_LIB"] = os.path.join(ROOT, "tools", "ubench", "build", "lib
 import torch  # noqa: E402
 from opensmile_amd import capi, synth  # noqa: E402
 
-NAMES = ["load .. 6*ut", "recurrences", "interp + summation + top six", "mean", "candidates + output"]
+NAMES = ["rows from global (lld_f0_cand)", "-", "interp + summation + top six", "mean", "candidates + output"]
 
 
 def main():
