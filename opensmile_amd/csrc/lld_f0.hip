@@ -1222,7 +1222,8 @@ int f0_tile_frames() { return kTileFrames; }
 
 int f0_chunk_tiles() { return 16384; }                 // 131 072 frames = 1.08 GB of scratch rows per chunk
 
-hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s) {
+hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
+                     hipEvent_t frames_done) {
   if (P.total_frames <= 0) return hipSuccess;
   if (Q0.Nfft != kNfftF0 || Q0.K != kK || Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
   (void)max_blocks;
@@ -1244,6 +1245,7 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
+  if (frames_done && (e = hipEventRecord(frames_done, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q, d_out, ld_out);
   return hipGetLastError();
 }

@@ -37,7 +37,10 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
 int compare_run_frames();
 hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_row_off, int n_utt, const float *rawB, float *out110,
                                   hipStream_t s);
-hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s);
+// frames_done (optional): recorded on s after the frame kernels, before the Viterbi pass -- what follows (Viterbi, jitter) is
+// one wave per utterance and leaves the device to whatever a side stream starts then
+hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
+                     hipEvent_t frames_done = nullptr);
 int f0_tile_frames();
 int64_t f0_scratch_rows(int64_t n_tiles);
 int64_t f0_scratch_doubles(int64_t n_tiles);   // rows between the three frame kernels of the F0 chain, one chunk of tiles

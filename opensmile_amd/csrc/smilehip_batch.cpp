@@ -504,7 +504,7 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
 
 // log_out: rows [F0final, F0finalLog, voicingFinalUnclipped] (the eGeMAPS sub-chain, ld_out >= 3) instead of [F0final, voicing]
 static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream,
-                  bool log_out = false) {
+                  bool log_out = false, hipEvent_t frames_done = nullptr) {
   if (ld_out < (log_out ? 3 : 2)) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld too small", (long long)ld_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
@@ -519,7 +519,7 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.hps_tap = b->d_hps_tap;
   Q.pending = b->d_pending.p;
   Q.vit_log_out = log_out ? 1 : 0;
-  hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream);
+  hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream, frames_done);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
@@ -530,15 +530,17 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   if (ld_out < 130) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld < 130", (long long)ld_out);
   if (b->total_rows == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
-  // the two groups share nothing but the PCM: groups A+B on the plan's side stream, the F0 group on the caller's
+  // The two groups share nothing but the PCM. The F0 group's frame kernels fill the device; its Viterbi and jitter passes
+  // are one wave per utterance: groups A+B start on the plan's side stream when the frame kernels are done and run beside
+  // those (both groups filling the device at once only took turns).
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipEventRecord(plan->ev_fork, s));
-  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-  int rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, plan->side_stream, 65);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
   smilehip_batch *fb = b->f0_batch;
-  if ((rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream))) return rc;
+  int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream, false, plan->ev_fork);
+  if (rc) return rc;
+  if (fb->total_frames == 0) HIP_TRY(hipEventRecord(plan->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
+  if ((rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, plan->side_stream, 65))) return rc;
+  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
   LldParams P;
   fill_params(plan->f0_plan, fb, d_pcm, d_out, ld_out, P);
   F0Params Q;
@@ -599,14 +601,20 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   fill_params(plan, b, d_pcm, d_out, ld_out, P);
   GemapsParams G;
   fill_gemaps_params(plan, b, G);
-  HIP_TRY(hipEventRecord(plan->ev_fork, s));
+  // The F0 group's frame kernels fill the device, its Viterbi and jitter passes are one wave per utterance: the 20 ms chain
+  // (frame kernel, resampling + LPC, formant roots) starts on the side stream when the frame kernels are done
+  hipError_t e = hipSuccess;
+  if (fb->total_frames > 0) {
+    int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch3.p, 3, stream, true, plan->ev_fork);   // SHS candidates -> Viterbi -> energy gate
+    if (rc) return rc;
+  } else {
+    HIP_TRY(hipEventRecord(plan->ev_fork, s));
+  }
   HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-  hipError_t e = launch_gemaps_frames(P, G, b->n_runs, plan->side_stream);
+  e = launch_gemaps_frames(P, G, b->n_runs, plan->side_stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS 20 ms kernels: launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
   if (fb->total_frames > 0) {
-    int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch3.p, 3, stream, true);   // SHS candidates -> Viterbi -> energy gate
-    if (rc) return rc;
     LldParams P60;
     fill_params(plan->f0_plan, fb, d_pcm, nullptr, 0, P60);
     F0Params Q;
