@@ -227,7 +227,13 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  const int lane_in = lane;
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+    // an opaque copy of the lane index per frame: otherwise everything below that depends on the lane only (bit-reversed
+    // FFT addresses, table addresses, range tests) is hoisted out of the frame loop and kept in ~150 VGPRs across it --
+    // two waves per SIMD instead of four
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     const bool warm = t < t0;
     const int16_t *x = xu + (int64_t)t * P.H;
     float *rawA = Q.rawA + (f0 + t) * 4;
