@@ -369,6 +369,10 @@ bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
   }
   std::string level = lvl(fr, "writer.dmLevel");
   const std::string frames_level = level;
+  for (const ConfInstance *st : {pe, win, fft, mag, mel})
+    if (st) p.stage_levels.push_back(lvl(st, "writer.dmLevel"));
+  for (const ConfInstance &i : f.inst)
+    if (i.type == "cWaveSource") { const std::string *fn = i.find("filename"); if (fn) p.wave_file = *fn; }
   c.preemph = 0;
   if (pe) {                                             // src/dspcore/vectorPreemphasis.cpp:33-35
     OptReader o(*pe);
@@ -528,6 +532,18 @@ bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
     if (!progress) {
       err = "[" + pending[0]->name + ":" + pending[0]->type + "] reads level '" + lvl(pending[0], "reader.dmLevel") + "', which the cepstral chain does not produce";
       return false;
+    }
+  }
+  {
+    const int n_cep_ = p.plp ? c.plp_lp_order - c.first_mfcc + 1 : c.last_mfcc - c.first_mfcc + 1;
+    for (const auto &kv : levels) {
+      std::vector<int> cols;
+      bool plain = true;
+      for (const Col &cc : kv.second) {
+        if (cc.delta != 0 || cc.cms) { plain = false; break; }
+        cols.push_back(cc.kind == 1 ? n_cep_ : cc.index - c.first_mfcc);
+      }
+      if (plain && !cols.empty()) p.static_levels[kv.first] = cols;
     }
   }
   // what the sink reads

@@ -38,6 +38,11 @@ struct ConfPlan {
   int parm_kind = 9;                     // of the file's own cHtkSink
   std::vector<std::string> lld_names;    // element names of the output level
   std::string describe;
+  // cepstral chains: the levels between the framer and the cepstra (what the per-frame stages write), and the levels that
+  // hold plain static columns of the fused static block (cepstrum j -> j, log energy -> number of cepstra)
+  std::vector<std::string> stage_levels;
+  std::map<std::string, std::vector<int>> static_levels;
+  std::string wave_file;                 // the wave source's filename option, command-line options applied
 };
 
 // false + err: the graph (component, option) the fused path cannot express

@@ -52,8 +52,13 @@
 #include <string>
 #include <vector>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "../../include/smilehip.h"
 #include "../host/smilehip_host.hpp"
+#include "../host/conf_plan.hpp"
 
 #define MODULE "smilehipPlugin"
 
@@ -124,6 +129,103 @@ void check(int rc) {
   if (rc != SMILEHIP_OK) COMP_ERR("libsmilehip: %s", smilehip_last_error());
 }
 
+// ---------------------------------------------------------------- fused mode for UNMODIFIED configuration files
+// SMILEHIP_PLUGIN_FUSE=1: the first overridden component that is asked for a frame reads the process's own command line
+// (-C file.conf and the options the file defines), parses the file with the host library's reader (conf_plan.cpp) and, if
+// the graph is a cepstral chain, runs the WHOLE input file through the fused kernels in one batch. From then on the
+// per-frame stages of the chain (pre-emphasis .. mel bank) only mark their frames, and cMfcc / cPlp / cEnergy copy their
+// rows out of the batch result: one device round trip per file instead of one per frame and component. Everything
+// downstream (mean normalisation, delta regression, concatenation, sinks) runs the reference's own code on those rows,
+// at the reference's own ticks. Graphs that are not expressible stay on the per-component path (a warning says why).
+struct FusedChain {
+  bool tried = false, active = false;
+  smilehip_host::ConfPlan plan;
+  std::vector<float> rows;
+  long n_rows = 0;
+  int n_cols = 0;
+  long served = 0;
+
+  bool stage_level(const char *lvl) const {
+    if (!active || !lvl) return false;
+    for (const std::string &l : plan.stage_levels) if (l == lvl) return true;
+    return false;
+  }
+  const std::vector<int> *static_level(const char *lvl) const {
+    if (!active || !lvl) return nullptr;
+    auto it = plan.static_levels.find(lvl);
+    return it == plan.static_levels.end() ? nullptr : &it->second;
+  }
+  void init() {
+    if (tried) return;
+    tried = true;
+    const char *on = getenv("SMILEHIP_PLUGIN_FUSE");
+    if (!on || !*on || !strcmp(on, "0")) return;
+    std::vector<std::string> args;
+    if (FILE *f = fopen("/proc/self/cmdline", "rb")) {
+      std::string cur;
+      int ch;
+      while ((ch = fgetc(f)) != EOF) { if (ch == 0) { args.push_back(cur); cur.clear(); } else cur += (char)ch; }
+      if (!cur.empty()) args.push_back(cur);
+      fclose(f);
+    }
+    std::string conf;
+    std::map<std::string, std::string> cl;
+    for (size_t i = 1; i < args.size(); ++i) {
+      if (args[i].size() < 2 || args[i][0] != '-') continue;
+      const bool has_val = i + 1 < args.size() && (args[i + 1].empty() || args[i + 1][0] != '-' || isdigit((unsigned char)args[i + 1][1]));
+      const std::string key = args[i].substr(1), val = has_val ? args[i + 1] : "1";
+      if (key == "C" || key == "configfile") conf = val; else cl[key] = val;
+      if (has_val) ++i;
+    }
+    std::string err;
+    smilehip_host::ConfFile cf;
+    if (conf.empty() || !smilehip_host::conf_parse(conf, cl, cf, err)) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: cannot read the configuration file (%s) -- per-component path", err.c_str());
+      return;
+    }
+    if (!smilehip_host::conf_to_plan(cf, plan, err) || !plan.preset.empty()) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: %s -- per-component path",
+                plan.preset.empty() ? err.c_str() : "only the cepstral chains fuse inside the reference process (use smilextract_hip for the big sets)");
+      return;
+    }
+    smilehip_host::WaveInfo wi;
+    std::vector<unsigned char> raw;
+    if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
+      return;
+    }
+    smilehip_lld_config c = plan.cfg;
+    c.sample_rate = (double)wi.sample_rate;
+    c.n_delta = 0;                                        // the static block is all the chain components hand on;
+    c.cms = 0;                                            // mean normalisation and deltas stay with the reference's components
+    smilehip_plan *pl = nullptr;
+    check(smilehip_plan_create(context(), &c, &pl));
+    smilehip_geometry g;
+    check(smilehip_plan_geometry(pl, &g));
+    const int64_t n = (int64_t)(raw.size() / 2);
+    const int64_t off[2] = {0, n};
+    smilehip_batch *b = nullptr;
+    check(smilehip_batch_create(pl, off, 1, &b));
+    n_rows = (long)smilehip_batch_total_rows(b);
+    n_cols = g.n_out;
+    rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
+    if (n_rows > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows.data()));
+    smilehip_batch_destroy(b);
+    smilehip_plan_destroy(pl);
+    active = true;
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld frames of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+  }
+  // row `frame` of the fused static block, the columns of level `cols`
+  void copy(const std::vector<int> &cols, long frame, FLOAT_DMEM *dst, long Ndst) {
+    if (frame >= n_rows) COMP_ERR("libsmilehip plugin: fused mode: the graph asks for frame %ld, the batch has %ld", frame, n_rows);
+    const float *r = rows.data() + (size_t)frame * n_cols;
+    for (long k = 0; k < Ndst && k < (long)cols.size(); ++k) dst[k] = r[cols[k]];
+    ++served;
+  }
+};
+FusedChain g_fused;
+long g_fused_stage = 0;
+
 smilehip_lld_config base_config(long N, uint32_t stages) {
   smilehip_lld_config c;
   smilehip_config_mfcc12_0_d_a(&c);
@@ -150,6 +252,7 @@ int winfunc_id(const char *s) {
 // ---------------------------------------------------------------- overrides
 // R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
 class cHipVectorPreemphasis : public cVectorPreemphasis {
+  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   float k_ = 0.f;
@@ -157,6 +260,8 @@ class cHipVectorPreemphasis : public cVectorPreemphasis {
   bool ready_ = false;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
+    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (!ready_) {
       double f = isSet("f") ? getDouble("f") : -1.0;
       k_ = (FLOAT_DMEM)getDouble("k");
@@ -194,11 +299,14 @@ struct PlanSet {
 
 // R3  cWindower::processVector  (src/dspcore/windower.cpp:221-229)
 class cHipWindower : public cWindower {
+  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
+    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       if (getDouble("fade") > 0.0 || getInt("squareRoot") || getDouble("xshift") != 0.0)
@@ -229,11 +337,14 @@ class cHipWindower : public cWindower {
 
 // R4  cTransformFFT::processVector, forward  (src/dspcore/transformFft.cpp:165-223)
 class cHipTransformFFT : public cTransformFFT {
+  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
+    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (getInt("inverse")) { HIP_FALLTHROUGH(2, "cTransformFFT inverse = 1 is not built"); return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
@@ -262,12 +373,15 @@ class cHipTransformFFT : public cTransformFFT {
 
 // R5  cFFTmagphase::processVector, magnitude branch  (src/dspcore/fftmagphase.cpp:215-221)
 class cHipFFTmagphase : public cFFTmagphase {
+  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
+    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (plain_ < 0)
       plain_ = (!getInt("inverse") && getInt("magnitude") && !getInt("phase") && !getInt("normalise") &&
                 !getInt("power") && !getInt("dBpsd")) ? 1 : 0;
@@ -295,12 +409,15 @@ class cHipFFTmagphase : public cFFTmagphase {
 
 // R6  cMelspec::processVector  (src/lldcore/melspec.cpp:519-570)
 class cHipMelspec : public cMelspec {
+  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
+    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (plain_ < 0) {
       const char *bw = getStr("bwMethod");
       const char *sc = getStr("specScale");
@@ -341,11 +458,16 @@ class cHipMelspec : public cMelspec {
 
 // R7  cMfcc::processVector, forward  (src/lldcore/mfcc.cpp:239-273)
 class cHipMfcc : public cMfcc {
+  int fused_ = -1;
+  const std::vector<int> *fcols_ = nullptr;
+  long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (getInt("inverse") || !getInt("doLog")) { HIP_FALLTHROUGH(5, "cMfcc: inverse = 1 / doLog = 0 are not built"); return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
@@ -397,6 +519,9 @@ struct DevBytes {
 // R12  cEnergy::processVector  (src/lldcore/energy.cpp:152-185): the double-accumulated sum of
 // squares comes from the device, the rms / squared / log expressions are the reference's
 class cHipEnergy : public cEnergy {
+  int fused_ = -1;
+  const std::vector<int> *fcols_ = nullptr;
+  long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
@@ -405,6 +530,8 @@ class cHipEnergy : public cEnergy {
   bool ready_ = false;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (Nsrc == 0) return 0;
     if (!ready_) {                                       // cEnergy::myFetchConfig, energy.cpp:58-81
       htk_ = getInt("htkcompatible");
@@ -629,6 +756,7 @@ class cHipDeltaRegression : public cDeltaRegression {
       plain_ = (W_ > 0 && !getInt("onlyInSegments") && !getInt("relativeDelta") && !getInt("halfWaveRect") &&
                 !getInt("absOutput")) ? 1 : 0;
     }
+    if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
     if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: onlyInSegments / relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, 0, W_);
     g_frames[10] += out->nT;
@@ -775,6 +903,9 @@ class cHipSpectral : public cSpectral {
 
 // R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
 class cHipPlp : public cPlp {
+  int fused_ = -1;
+  const std::vector<int> *fcols_ = nullptr;
+  long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
@@ -784,6 +915,8 @@ class cHipPlp : public cPlp {
   float coef_[6] = {0, 0, 0, 0, 0, 0};
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (plain_ < 0) {                                    // cPlp::myFetchConfig, plp.cpp:90-176
       int doLP = getInt("doLP"), doLpToCeps = getInt("doLpToCeps"), doIDFT = getInt("doIDFT");
       if (getInt("lpOrder") <= 0) { doLP = 0; doLpToCeps = 0; }
@@ -1547,6 +1680,7 @@ struct TraceAtExit {
     if (!f) return;
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s.cpu %ld\n", g_names[i], g_cpu[i]);
+    fprintf(f, "fused.rows %ld\nfused.stage_frames %ld\nfused.batch_frames %ld\n", g_fused.served, g_fused_stage, g_fused.active ? g_fused.n_rows : 0L);
     fclose(f);
   }
 } g_trace;

@@ -396,3 +396,28 @@ def test_plugin_logs_cpu_fallthrough(oracle, golden_synth):
         tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip())
         assert int(tr["cMfcc.cpu"]) == 98 and int(tr["cMfcc"]) == 0
         assert "runs the reference's CPU code" in (r.stderr + r.stdout)
+
+
+def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
+    """SMILEHIP_PLUGIN_FUSE=1 with UNMODIFIED files of config/mfcc and config/plp: the plugin reads the configuration file
+    named on the process's own command line, runs the whole input through the fused kernels in one batch, and the chain's
+    components hand out its rows (no device round trip per frame); mean normalisation, deltas, concatenation and the sinks
+    stay the reference's. Same file as the plain CPU binary within the chain's tolerance."""
+    pcm = golden_synth["pcm_u10_16000"]
+    for conf in ("mfcc/MFCC12_0_D_A.conf", "mfcc/MFCC12_E_D_A_Z.conf", "plp/PLP_0_D_A.conf", "plp/PLP_E_D_A.conf"):
+        ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+        y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1"}, conf)
+        assert y.shape == ref.shape
+        n_static = ref.shape[1] // 3
+        scale = np.abs(ref[:, :n_static]).max(axis=1, keepdims=True)
+        assert (np.abs(y - ref) / scale).max() <= 1e-5, conf
+        frames = ref.shape[0]
+        assert tr["fused.batch_frames"] == frames
+        assert tr["fused.rows"] >= frames and tr["fused.stage_frames"] >= 4 * frames
+        # no per-frame kernel launches in the chain: the stage counters stay at zero
+        for comp in ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cPlp", "cEnergy", "cDeltaRegression"):
+            assert tr.get(comp, 0) == 0, (conf, comp, tr)
+    # a graph that is not a cepstral chain stays on the per-component path, and says so
+    y, tr = _run(oracle, golden_synth["pcm_u3_16000"], {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_COMPONENTS": "cMelspec,cMfcc"},
+                 "is09-13/IS09_emotion.conf", "-lldhtkoutput")
+    assert tr["fused.batch_frames"] == 0 and tr["cMfcc"] > 0

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the plugin path inside the unmodified reference binary, on one file (not a bench line).
 Three runs of oracle/_ref/SMILExtract on the same wav: (a) plain CPU binary (plugin disabled), (b) the per-component
-overrides (one upload / launch / download per frame per component), (c) the fused source component cHipLldSource.
+overrides (one upload / launch / download per frame per component), (c) the same unmodified file with SMILEHIP_PLUGIN_FUSE=1
+(whole file in one batch, the chain's components hand out its rows), (d) the fused source component cHipLldSource.
 Process wall time minus the time of an empty-input run of the same mode (start-up: config parsing, dlopen, HIP init) is
 reported as well. Prints one JSON object per (config, mode)."""
 import argparse
@@ -39,6 +40,7 @@ def main():
             modes = [("cpu_binary", {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, extra),
                      ("plugin_per_component", {}, conf, extra)]
             if name == "MFCC12_0_D_A":
+                modes.append(("plugin_fused_unmodified_conf", {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, extra))
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", "mfcc12_0_d_a"]))
             for mode, envx, c, ex in modes:
                 env = dict(env0)
