@@ -618,6 +618,22 @@ int smilehip_harmonics_frames(smilehip_plan *plan, const float *d_f0, const floa
 int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *batch, float *d_io, int64_t ld,
                          int32_t D, int32_t W, int32_t n_orders, void *stream);
 
+/* ---- cPitchSmootherViterbi as a stream (src/lld/pitchSmootherViterbi.cpp:451-564: myTick pushes one frame of candidates
+ * into cSmileViterbi::addFrame, :80-216, and writes every frame that has become decided; the rest at end of input through
+ * flushTrellis). What the plugin's tick-level override binds: one utterance, one frame per call, the trellis (7 states =
+ * 6 candidates + unvoiced, `buffer_len` frames of paths) lives on the device between the calls. weights6 = wLocal, wTvv,
+ * wTvvd, wTvuv, wThr, wRange as cSmileViterbiPitchSmooth uses them (note its setWeights stores wTvv into wTvvd,
+ * pitchSmootherViterbi.hpp:291-299 -- pass the effective values). Host pointers throughout.
+ * push / flush return the frames that became decided by this call, in order: frames[i] = frame index, states[i] = the state
+ * chosen (0..5 = candidate, 6 = unvoiced); F0 / voicing of a decided frame are the caller's own candidate values. */
+typedef struct smilehip_viterbi_stream smilehip_viterbi_stream;
+int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buffer_len, float voicing_cutoff, const double *weights6,
+                                   smilehip_viterbi_stream **out);
+int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing,
+                                 int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
+int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
+int smilehip_viterbi_stream_destroy(smilehip_viterbi_stream *s);
+
 #ifdef __cplusplus
 }
 #endif

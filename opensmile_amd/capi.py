@@ -122,6 +122,10 @@ SYMBOLS = {
     "smilehip_lpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_formantlpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_harmonics_frames": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_viterbi_stream_create": (C.c_int, [_vp, _i32, _f32, _vp, C.POINTER(_vp)]),
+    "smilehip_viterbi_stream_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "smilehip_viterbi_stream_flush": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),
+    "smilehip_viterbi_stream_destroy": (C.c_int, [_vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -773,3 +777,34 @@ def mfcc_frames(plan, d_src, ld_src, d_dst, ld_dst, n_frames, stream=None):
 
 def delta_chain(plan, batch, d_io, ld, D, W, n_orders, stream=None):
     _check(load().smilehip_delta_chain(plan._h, batch._h, d_io, ld, D, W, n_orders, stream))
+
+
+class ViterbiStream:
+    """cPitchSmootherViterbi as a stream (smilehip_viterbi_stream_*): push one frame of six (F0, voicing) candidates, get the
+    frames that became decided -- (frame index, state) pairs; flush() at end of input."""
+
+    def __init__(self, ctx, buffer_len=30, voicing_cutoff=0.7, weights=(2.0, 10.0, 10.0, 10.0, 4.0, 1.0)):
+        self._h = _vp()
+        w = (C.c_double * 6)(*weights)
+        _check(load().smilehip_viterbi_stream_create(ctx._h, buffer_len, voicing_cutoff, w, C.byref(self._h)))
+
+    def _out(self, fn, *head):
+        n = C.c_int32(0)
+        fr = (C.c_int32 * 64)()
+        st = (C.c_int32 * 64)()
+        _check(fn(self._h, *head, C.byref(n), fr, st, 64))
+        return [(fr[i], st[i]) for i in range(n.value)]
+
+    def push(self, cand_f0, cand_voicing):
+        f = np.ascontiguousarray(cand_f0, dtype=np.float32)
+        v = np.ascontiguousarray(cand_voicing, dtype=np.float32)
+        assert f.size == 6 and v.size == 6
+        return self._out(load().smilehip_viterbi_stream_push, f.ctypes.data, v.ctypes.data)
+
+    def flush(self):
+        return self._out(load().smilehip_viterbi_stream_flush)
+
+    def close(self):
+        if self._h:
+            load().smilehip_viterbi_stream_destroy(self._h)
+            self._h = None

@@ -676,6 +676,102 @@ __global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_cand(LldParams P, F0Pa
 // (:451-570): every decided frame is written at once. Quirks kept: setWeights stores tvv into wTvvd (.hpp:294);
 // `i == j == nStates-1` never holds, so unvoiced->unvoiced costs the final "return 1.0" (.hpp:229-252);
 // lastChange is one variable shared by all transitions in evaluation order (i outer, j inner) and across frames.
+// One frame of the incremental pass: local costs, transition costs, the new best predecessors, the path buffers, then the
+// decisions this frame makes possible. `emit(n, s)`: frame n has been decided as state s (called by the lanes that decide;
+// `emit_done(k)` once per frame by every lane with the number of frames decided). State: paths / cost / msel in LDS,
+// the scalars by reference. cur / prev: the frame's and the previous frame's 21 values.
+template <class Emit, class EmitDone>
+__device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, const float *prev, int t, int lane,
+                                          int (*paths)[kNS * kVBmax], double *cost, int *msel, double &lastChange, int &pathBuf,
+                                          int &pathIdx, int &convIdx, Emit emit, EmitDone emit_done) {
+  const int kVB = Q.vit_buf;                               // bufferLength (<= kVBmax, checked by the launcher)
+  const bool valid = lane < kNS * kNS;
+  const int si = valid ? lane / kNS : 0, sj = valid ? lane % kNS : 0;
+  const double wLocal = Q.vit_w[0], wTvv = Q.vit_w[1], wTvvd = Q.vit_w[2], wTvuv = Q.vit_w[3], wThr = Q.vit_w[4],
+               wRange = Q.vit_w[5];
+  const float thr = Q.voicing_cutoff;
+  double lc = 0.0;                                       // localCost of state `lane`
+  if (lane < kNC) {
+    double pv = (double)cur[1 + kNC + lane], tc = 0.0;
+    if (pv < 0.01) pv = 0.01;
+    if (pv > 1.00) pv = 1.00;
+    if (pv < thr) tc = wThr;
+    lc = (-log(pv) + tc) * wLocal + f_weight(cur[1 + lane]) * wRange;
+  } else if (lane == kNC) {
+    double flag = 0.0;
+    for (int c = 0; c < kNC; ++c) if (cur[1 + kNC + c] >= thr) { flag = wThr; break; }
+    if (flag == 0.0 && 0.0f >= thr) flag = wThr;         // frame[13] of the reference's buffer is 0
+    lc = wLocal * flag;
+  }
+  if (t == 0) {
+    if (lane < kNS) { cost[lane] = lc; paths[0][lane * kVB] = lane; }
+    __syncthreads();
+  } else {
+    const bool vv = valid && si < kNC && sj < kNC;
+    float fa = 0.0f, fb2 = 0.0f;
+    if (vv) { fa = prev[1 + sj]; fb2 = cur[1 + si]; }
+    const bool zero = vv && (fa == 0 || fb2 == 0);
+    const bool modr = vv && !zero;
+    const bool mod0 = valid && ((si == kNC) != (sj == kNC));
+    const double r = modr ? log((double)(fb2 / fa)) : 0.0;
+    const unsigned long long mask = __ballot(modr || mod0);
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    const int src = lower ? 63 - __clzll((long long)lower) : 0;
+    const double rprev = __shfl(r, src);
+    const double lastc = lower ? rprev : lastChange;
+    double c = 1.0;
+    if (vv) c = zero ? 999.0 : wTvv * fabs(r) + wTvvd * fabs(r - lastc);
+    else if (mod0) c = wTvuv;
+    if (mask) lastChange = __shfl(r, 63 - __clzll((long long)mask));
+    const double tot = valid ? c + cost[sj] : 0.0;
+    const int gb = si * kNS;
+    double mc = __shfl(tot, gb);
+    int ms = 0;
+#pragma unroll
+    for (int jj = 1; jj < kNS; ++jj) {
+      const double v = __shfl(tot, gb + jj);
+      if (v < mc) { mc = v; ms = jj; }
+    }
+    const double lci = __shfl(lc, si);
+    __syncthreads();
+    if (valid && sj == 0) { cost[si] = mc + lci; msel[si] = ms; }
+    __syncthreads();
+    const int nb = pathBuf ^ 1;
+    for (int idx = lane; idx < kNS * kVB; idx += 64) {
+      const int ii = idx / kVB, n = idx - ii * kVB;
+      paths[nb][idx] = paths[pathBuf][msel[ii] * kVB + n];
+    }
+    __syncthreads();
+    if (lane < kNS) paths[nb][lane * kVB + pathIdx % kVB] = lane;
+    __syncthreads();
+    pathBuf = nb;
+  }
+  pathIdx++;
+  const int *Pp = paths[pathBuf];
+  if (pathIdx - convIdx > kVB) {                         // forced decision for the oldest open frame
+    int ms = 0;
+    for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
+    convIdx++;
+    if (lane == 0) emit(convIdx, Pp[ms * kVB + convIdx % kVB], 0);
+    emit_done(1);
+  } else {                                               // decide up to where all paths agree
+    const int n = convIdx + 1 + lane;
+    bool match = false;
+    int xs = 0;
+    if (n < pathIdx) {
+      xs = Pp[n % kVB];
+      match = true;
+      for (int i = 1; i < kNS; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
+    }
+    const unsigned long long mm = __ballot(match);
+    const int nlead = __ffsll((long long)~mm) - 1;       // lanes >= 31 never match: ~mm != 0
+    if (lane < nlead) emit(n, xs, lane);
+    emit_done(nlead);
+    convIdx += nlead;
+  }
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, int n_utt, F0Params Q, float *out, int64_t ld) {
   const int u = blockIdx.x;
   if (u >= n_utt) return;
@@ -683,21 +779,16 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
   const int T = (int)(frame_off[u + 1] - fo);
   if (T <= 0) return;
   __shared__ int paths[2][kNS * kVBmax];
-  const int kVB = Q.vit_buf;                               // bufferLength (<= kVBmax, checked by the launcher)
+  const int kVB = Q.vit_buf;
   __shared__ double cost[kNS];
   __shared__ int msel[kNS];
   const int lane = threadIdx.x;
-  const bool valid = lane < kNS * kNS;
-  const int si = valid ? lane / kNS : 0, sj = valid ? lane % kNS : 0;
-  const double wLocal = Q.vit_w[0], wTvv = Q.vit_w[1], wTvvd = Q.vit_w[2], wTvuv = Q.vit_w[3], wThr = Q.vit_w[4],
-               wRange = Q.vit_w[5];
-  const float thr = Q.voicing_cutoff;
   const float *S = Q.shs + fo * 21;
   double lastChange = 1.0;
   int pathBuf = 0;
   int pathIdx = 0, convIdx = -1;
 
-  auto emit = [&](int n, int s) {
+  auto emit = [&](int n, int s, int) {
     const int64_t row = fo + n;
     const float *fr = S + (int64_t)n * 21;
     float f = (s < kNC) ? fr[1 + s] : 0.0f;
@@ -716,88 +807,11 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
       out[row * ld + 1] = vp;
     }
   };
+  auto emit_done = [](int) {};
 
   for (int t = 0; t < T; ++t) {
     const float *cur = S + (int64_t)t * 21;
-    double lc = 0.0;                                       // localCost of state `lane`
-    if (lane < kNC) {
-      double pv = (double)cur[1 + kNC + lane], tc = 0.0;
-      if (pv < 0.01) pv = 0.01;
-      if (pv > 1.00) pv = 1.00;
-      if (pv < thr) tc = wThr;
-      lc = (-log(pv) + tc) * wLocal + f_weight(cur[1 + lane]) * wRange;
-    } else if (lane == kNC) {
-      double flag = 0.0;
-      for (int c = 0; c < kNC; ++c) if (cur[1 + kNC + c] >= thr) { flag = wThr; break; }
-      if (flag == 0.0 && 0.0f >= thr) flag = wThr;         // frame[13] of the reference's buffer is 0
-      lc = wLocal * flag;
-    }
-    if (t == 0) {
-      if (lane < kNS) { cost[lane] = lc; paths[0][lane * kVB] = lane; }
-      __syncthreads();
-    } else {
-      const float *prev = cur - 21;
-      const bool vv = valid && si < kNC && sj < kNC;
-      float fa = 0.0f, fb2 = 0.0f;
-      if (vv) { fa = prev[1 + sj]; fb2 = cur[1 + si]; }
-      const bool zero = vv && (fa == 0 || fb2 == 0);
-      const bool modr = vv && !zero;
-      const bool mod0 = valid && ((si == kNC) != (sj == kNC));
-      const double r = modr ? log((double)(fb2 / fa)) : 0.0;
-      const unsigned long long mask = __ballot(modr || mod0);
-      const unsigned long long lower = mask & ((1ull << lane) - 1ull);
-      const int src = lower ? 63 - __clzll((long long)lower) : 0;
-      const double rprev = __shfl(r, src);
-      const double lastc = lower ? rprev : lastChange;
-      double c = 1.0;
-      if (vv) c = zero ? 999.0 : wTvv * fabs(r) + wTvvd * fabs(r - lastc);
-      else if (mod0) c = wTvuv;
-      if (mask) lastChange = __shfl(r, 63 - __clzll((long long)mask));
-      const double tot = valid ? c + cost[sj] : 0.0;
-      const int gb = si * kNS;
-      double mc = __shfl(tot, gb);
-      int ms = 0;
-#pragma unroll
-      for (int jj = 1; jj < kNS; ++jj) {
-        const double v = __shfl(tot, gb + jj);
-        if (v < mc) { mc = v; ms = jj; }
-      }
-      const double lci = __shfl(lc, si);
-      __syncthreads();
-      if (valid && sj == 0) { cost[si] = mc + lci; msel[si] = ms; }
-      __syncthreads();
-      const int nb = pathBuf ^ 1;
-      for (int idx = lane; idx < kNS * kVB; idx += 64) {
-        const int ii = idx / kVB, n = idx - ii * kVB;
-        paths[nb][idx] = paths[pathBuf][msel[ii] * kVB + n];
-      }
-      __syncthreads();
-      if (lane < kNS) paths[nb][lane * kVB + pathIdx % kVB] = lane;
-      __syncthreads();
-      pathBuf = nb;
-    }
-    pathIdx++;
-    const int *Pp = paths[pathBuf];
-    if (pathIdx - convIdx > kVB) {                         // forced decision for the oldest open frame
-      int ms = 0;
-      for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
-      convIdx++;
-      if (lane == 0) emit(convIdx, Pp[ms * kVB + convIdx % kVB]);
-    } else {                                               // decide up to where all paths agree
-      const int n = convIdx + 1 + lane;
-      bool match = false;
-      int xs = 0;
-      if (n < pathIdx) {
-        xs = Pp[n % kVB];
-        match = true;
-        for (int i = 1; i < kNS; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
-      }
-      const unsigned long long mm = __ballot(match);
-      const int nlead = __ffsll((long long)~mm) - 1;       // lanes >= 31 never match: ~mm != 0
-      if (lane < nlead) emit(n, xs);
-      convIdx += nlead;
-    }
-    __syncthreads();
+    vit_frame(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
   }
   // flushTrellis at end of input
   if (lane == 0 && Q.pending) Q.pending[u] = pathIdx - (convIdx + 1);      // frames only decided by the flush
@@ -805,8 +819,45 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
     int ms = 0;
     for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
     const int *Pp = paths[pathBuf];
-    for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB]);
+    for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB], 0);
   }
+}
+
+// The same pass as a STREAM (the plugin's cPitchSmootherViterbi override, smilehip_viterbi_stream_*): one frame per launch,
+// the trellis state lives in global memory between launches. st: [0] pathIdx, [1] convIdx, [2] pathBuf (always 0 when
+// stored), [3] number of decisions of this launch; dstate: cost[kNS], lastChange; spaths: kNS * kVBmax ints; decided:
+// (frame, state) pairs of this launch. frames: every frame pushed so far, 21 values each (only [1..12] are read).
+__global__ void __launch_bounds__(64) lld_f0_viterbi_step(F0Params Q, const float *frames, int *st, double *dstate, int *spaths,
+                                                          int *decided, int flush) {
+  __shared__ int paths[2][kNS * kVBmax];
+  __shared__ double cost[kNS];
+  __shared__ int msel[kNS];
+  const int lane = threadIdx.x;
+  const int kVB = Q.vit_buf;
+  int pathIdx = st[0], convIdx = st[1], pathBuf = 0;
+  double lastChange = dstate[kNS];
+  for (int i = lane; i < kNS * kVB; i += 64) paths[0][i] = spaths[i];
+  if (lane < kNS) cost[lane] = dstate[lane];
+  __syncthreads();
+  int n_dec = 0;
+  auto emit = [&](int n, int s, int slot) { decided[2 * (n_dec + slot)] = n; decided[2 * (n_dec + slot) + 1] = s; };
+  auto emit_done = [&](int k) { n_dec += k; };
+  if (!flush) {
+    const int t = pathIdx;
+    const float *cur = frames + (int64_t)t * 21;
+    vit_frame(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+  } else {                                                 // flushTrellis: everything still open follows the cheapest path
+    int ms = 0;
+    for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
+    const int *Pp = paths[pathBuf];
+    for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB], n - (convIdx + 1));
+    n_dec = pathIdx - (convIdx + 1);
+    convIdx = pathIdx - 1;
+  }
+  __syncthreads();
+  for (int i = lane; i < kNS * kVB; i += 64) spaths[i] = paths[pathBuf][i];
+  if (lane < kNS) dstate[lane] = cost[lane];
+  if (lane == 0) { dstate[kNS] = lastChange; st[0] = pathIdx; st[1] = convIdx; st[2] = 0; st[3] = n_dec; }
 }
 
 // cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1064) as [is13_pitchJitter] configures it (searchRangeRel 0.25,
@@ -1249,6 +1300,15 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
   hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q, d_out, ld_out);
   return hipGetLastError();
 }
+hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
+                                  int flush, hipStream_t s) {
+  if (Q.vit_buf < 2 || Q.vit_buf > kVBmax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lld_f0_viterbi_step, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, flush);
+  return hipGetLastError();
+}
+int f0_viterbi_max_buffer() { return kVBmax; }
+int f0_viterbi_states() { return kNS; }
+
 int64_t f0_scratch_rows(int64_t n_tiles) {                // rows of a chunk, a multiple of 64
   const int64_t t = n_tiles < f0_chunk_tiles() ? n_tiles : f0_chunk_tiles();
   return (t * kTileFrames + 63) / 64 * 64;

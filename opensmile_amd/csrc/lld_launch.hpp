@@ -42,6 +42,11 @@ hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_r
 hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
                      hipEvent_t frames_done = nullptr);
 int f0_tile_frames();
+// cPitchSmootherViterbi as a stream: one frame (or the flush) per launch, state in global memory
+hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
+                                  int flush, hipStream_t s);
+int f0_viterbi_max_buffer();
+int f0_viterbi_states();
 int64_t f0_scratch_rows(int64_t n_tiles);
 int64_t f0_scratch_doubles(int64_t n_tiles);   // rows between the three frame kernels of the F0 chain, one chunk of tiles
 hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);

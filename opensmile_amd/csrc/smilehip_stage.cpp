@@ -211,3 +211,100 @@ extern "C" int smilehip_pitchshs_frames(smilehip_plan *p, const float *d_hps, in
                                         int64_t n_frames, void *stream) {
   return f0_rows(p, 2, d_hps, ld_src, d_dst, ld_dst, n_frames, stream, "smilehip_pitchshs_frames");
 }
+
+// ---------------------------------------------- cPitchSmootherViterbi as a stream (the plugin's tick-level override)
+struct smilehip_viterbi_stream {
+  smilehip_context *ctx = nullptr;
+  F0Params Q;
+  float *d_frames = nullptr;
+  int64_t cap_frames = 0, n_frames = 0;
+  int *d_st = nullptr, *d_paths = nullptr, *d_decided = nullptr;
+  double *d_dstate = nullptr;
+};
+
+extern "C" int smilehip_viterbi_stream_destroy(smilehip_viterbi_stream *s) {
+  if (!s) return SMILEHIP_OK;
+  if (s->d_frames) (void)hipFree(s->d_frames);
+  if (s->d_st) (void)hipFree(s->d_st);
+  if (s->d_paths) (void)hipFree(s->d_paths);
+  if (s->d_decided) (void)hipFree(s->d_decided);
+  if (s->d_dstate) (void)hipFree(s->d_dstate);
+  delete s;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buffer_len, float voicing_cutoff, const double *weights6,
+                                              smilehip_viterbi_stream **out) {
+  if (!ctx || !weights6 || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_create: null argument");
+  if (buffer_len < 2 || buffer_len > f0_viterbi_max_buffer())
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_create: bufferLength %d outside 2..%d", buffer_len, f0_viterbi_max_buffer());
+  smilehip_viterbi_stream *s = new smilehip_viterbi_stream;
+  s->ctx = ctx;
+  std::memset(&s->Q, 0, sizeof(s->Q));
+  s->Q.vit_buf = buffer_len;
+  s->Q.voicing_cutoff = voicing_cutoff;
+  for (int i = 0; i < 6; ++i) s->Q.vit_w[i] = weights6[i];
+  const int ns = f0_viterbi_states(), np = ns * f0_viterbi_max_buffer();
+  std::vector<double> ds((size_t)ns + 1, 0.0);
+  ds[(size_t)ns] = 1.0;                                    // lastChange starts at 1.0 (pitchSmootherViterbi.hpp)
+  const int st0[4] = {0, -1, 0, 0};
+  if (hipMalloc(reinterpret_cast<void **>(&s->d_st), sizeof(st0)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&s->d_paths), sizeof(int) * (size_t)np) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&s->d_decided), sizeof(int) * 2 * 64) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&s->d_dstate), sizeof(double) * ds.size()) != hipSuccess ||
+      hipMemcpy(s->d_st, st0, sizeof(st0), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(s->d_paths, 0, sizeof(int) * (size_t)np) != hipSuccess ||
+      hipMemcpy(s->d_dstate, ds.data(), sizeof(double) * ds.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    smilehip_viterbi_stream_destroy(s);
+    return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_create: device allocation failed");
+  }
+  *out = s;
+  return SMILEHIP_OK;
+}
+
+static int viterbi_step(smilehip_viterbi_stream *s, int flush, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap) {
+  hipStream_t st = nullptr;                                  // a stream of single-frame steps: the null stream, synchronous
+  hipError_t e = launch_f0_viterbi_step(s->Q, s->d_frames, s->d_st, s->d_dstate, s->d_paths, s->d_decided, flush, st);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "viterbi step launch failed: %s", hipGetErrorString(e));
+  int h_st[4];
+  int h_dec[2 * 64];
+  if (hipMemcpyAsync(h_st, s->d_st, sizeof(h_st), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h_dec, s->d_decided, sizeof(h_dec), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "viterbi step: copy back failed");
+  const int n = h_st[3];
+  if (n > cap || n > 64) return fail(SMILEHIP_ERR_INVALID, "viterbi step: %d decisions, room for %d", n, cap);
+  for (int i = 0; i < n; ++i) { frames[i] = h_dec[2 * i]; states[i] = h_dec[2 * i + 1]; }
+  *n_decided = n;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing,
+                                            int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap) {
+  if (!s || !cand_f0 || !cand_voicing || !n_decided || !frames || !states) return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_push: null argument");
+  if (s->n_frames == s->cap_frames) {                      // the device keeps every frame: transitions and decisions look back
+    const int64_t ncap = s->cap_frames ? s->cap_frames * 2 : 4096;
+    float *nf = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&nf), sizeof(float) * 21 * (size_t)ncap) != hipSuccess)
+      return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push: device allocation failed");
+    if (s->n_frames && hipMemcpy(nf, s->d_frames, sizeof(float) * 21 * (size_t)s->n_frames, hipMemcpyDeviceToDevice) != hipSuccess) {
+      (void)hipFree(nf);
+      return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push: copy failed");
+    }
+    if (s->d_frames) (void)hipFree(s->d_frames);
+    s->d_frames = nf;
+    s->cap_frames = ncap;
+  }
+  float row[21] = {0};
+  for (int c = 0; c < 6; ++c) { row[1 + c] = cand_f0[c]; row[7 + c] = cand_voicing[c]; }
+  if (hipMemcpy(s->d_frames + 21 * s->n_frames, row, sizeof(row), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push: upload failed");
+  s->n_frames++;
+  return viterbi_step(s, 0, n_decided, frames, states, cap);
+}
+
+extern "C" int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap) {
+  if (!s || !n_decided || !frames || !states) return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_flush: null argument");
+  if (s->n_frames == 0) { *n_decided = 0; return SMILEHIP_OK; }
+  return viterbi_step(s, 1, n_decided, frames, states, cap);
+}

@@ -107,3 +107,43 @@ def test_f0_rerun_is_deterministic(hip):
     c = b.run_host(pcm)
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
     b.close()
+
+
+def test_viterbi_stream_equals_the_oracle_frame_by_frame(hip, oracle):
+    """smilehip_viterbi_stream_*: one frame per call, the trellis on the device between the calls. Every decided frame
+    carries the state the oracle's pass picks (identical F0 / voicing), and the frames become decided at exactly the pushes
+    at which the incremental reference algorithm releases them (the oracle's `pending` count at the end)."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    import ctypes as C
+    L = oracle.lib()
+    L.lldo_pitch_viterbi_ex.restype = None
+    L.lldo_pitch_viterbi_ex.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    for buflen, n_samp in ((30, 64000), (40, 48000), (30, 4800)):
+        pcm = synth.utterance(70 + buflen, n_samp)
+        b = capi.Batch(plan, np.array([0, n_samp], np.int64))
+        _, taps = b.f0_run_host_taps(pcm)
+        shs = np.ascontiguousarray(taps["shs"])
+        b.close()
+        T = shs.shape[0]
+        ref = np.zeros((T, 2), np.float32)
+        states = np.zeros(T, np.int32)
+        pend = C.c_long(0)
+        L.lldo_pitch_viterbi_ex(shs.ctypes.data, T, np.float32(0.7), buflen, ref.ctypes.data, states.ctypes.data, C.byref(pend))
+        vs = capi.ViterbiStream(ctx, buffer_len=buflen)
+        got = {}
+        before_flush = 0
+        for t in range(T):
+            for n, s in vs.push(shs[t, 1:7], shs[t, 7:13]):
+                assert n not in got
+                got[n] = s
+            before_flush = len(got)
+        for n, s in vs.flush():
+            assert n not in got
+            got[n] = s
+        vs.close()
+        assert sorted(got) == list(range(T))
+        assert T - before_flush == pend.value                         # what only the flush at end of input decides
+        f0 = np.array([shs[n, 1 + got[n]] if got[n] < 6 else 0.0 for n in range(T)], np.float32)
+        vp = np.array([shs[n, 7 + got[n]] if got[n] < 6 else shs[n, 7] for n in range(T)], np.float32)
+        assert np.array_equal(f0.view(np.uint32), ref[:, 0].view(np.uint32)) and np.array_equal(vp.view(np.uint32), ref[:, 1].view(np.uint32))

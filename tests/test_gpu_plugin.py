@@ -421,3 +421,20 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
     y, tr = _run(oracle, golden_synth["pcm_u3_16000"], {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_COMPONENTS": "cMelspec,cMfcc"},
                  "is09-13/IS09_emotion.conf", "-lldhtkoutput")
     assert tr["fused.batch_frames"] == 0 and tr["cMfcc"] > 0
+
+
+def test_plugin_viterbi_tick_level_override(oracle, golden_f0):
+    """cPitchSmootherViterbi as a tick-level override (myTick replaced: one frame of candidates per tick goes to the
+    device-resident trellis, decided frames are written at the tick at which the reference's incremental scheme releases
+    them). With ONLY this component overridden, the unmodified ComParE_2016.conf and eGeMAPSv02.conf (bufferLength 40,
+    F0finalLog) must reproduce the plain binary's LLD files BIT FOR BIT -- everything downstream (energy gate, jitter,
+    smoothers with their end-of-input behaviour) depends on which frames appear at which tick."""
+    from test_oracle_pin_f0 import KEYS
+    for k in KEYS[:3]:
+        pcm = golden_f0["pcm_" + k]
+        for conf in (COMPARE, "egemaps/v02/eGeMAPSv02.conf"):
+            ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
+            y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cPitchSmootherViterbi"}, conf, "-lldhtkoutput")
+            assert tr["cPitchSmootherViterbi"] > 0 and tr["cPitchSmootherViterbi.cpu"] == 0
+            assert y.shape == ref.shape
+            assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (k, conf, int((y != ref).any(axis=1).sum()))
