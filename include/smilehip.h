@@ -618,6 +618,14 @@ int smilehip_harmonics_frames(smilehip_plan *plan, const float *d_f0, const floa
 int smilehip_delta_chain(smilehip_plan *plan, smilehip_batch *batch, float *d_io, int64_t ld,
                          int32_t D, int32_t W, int32_t n_orders, void *stream);
 
+/* cValbasedSelector::myTick (src/other/valbasedSelector.cpp:139-247) for a block of frames, fixed threshold (adaptiveThreshold = 0):
+ * element min(idx, N-1) of a frame against `threshold` -- val > threshold (invert: <; allow_equal: also ==) -- decides:
+ * d_keep[t] = 1: the frame is handed on (d_dst row = the frame, without element idx if remove_idx); 2: zeroVec, the row is
+ * output_val everywhere; 0: the frame is dropped (no row is to be written). d_dst rows have N (remove_idx: N-1) values. */
+int smilehip_valbased_select_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                                    int32_t idx, float threshold, int32_t invert, int32_t allow_equal, int32_t zero_vec,
+                                    int32_t remove_idx, float output_val, float *d_dst, int64_t ld_dst, int32_t *d_keep, void *stream);
+
 /* ---- cPitchSmootherViterbi as a stream (src/lld/pitchSmootherViterbi.cpp:451-564: myTick pushes one frame of candidates
  * into cSmileViterbi::addFrame, :80-216, and writes every frame that has become decided; the rest at end of input through
  * flushTrellis). What the plugin's tick-level override binds: one utterance, one frame per call, the trellis (7 states =

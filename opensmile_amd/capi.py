@@ -122,6 +122,7 @@ SYMBOLS = {
     "smilehip_lpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_formantlpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_harmonics_frames": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "smilehip_valbased_select_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
     "smilehip_viterbi_stream_create": (C.c_int, [_vp, _i32, _f32, _vp, C.POINTER(_vp)]),
     "smilehip_viterbi_stream_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "smilehip_viterbi_stream_flush": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),

@@ -154,6 +154,34 @@ __global__ void __launch_bounds__(64) k_plp_cc(const float *src, int64_t lds, in
 
 static inline unsigned nblk2(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// cValbasedSelector::myTick (valbasedSelector.cpp:139-247) for a block of frames: element idx against the threshold decides
+// whether a frame is handed on (keep = 1), replaced by a constant vector (zeroVec: keep = 2) or dropped (keep = 0); removeIdx
+// takes the tested element out of the output vector. One thread per output element.
+__global__ void __launch_bounds__(256) k_valbased(const float *src, int64_t lds, int N, int idx, float threshold, int invert,
+                                                  int allow_equal, int zerovec, int remove_idx, float output_val, float *dst,
+                                                  int64_t ldd, int32_t *keep, int64_t nF) {
+  const int64_t f = blockIdx.x;
+  if (f >= nF) return;
+  const float *x = src + f * lds;
+  const int i = idx >= N ? N - 1 : idx;
+  const float val = x[i];
+  const bool copy = ((!invert) && (val > threshold)) || (invert && (val < threshold)) || (allow_equal && (val == threshold));
+  const int n_out = remove_idx ? N - 1 : N;
+  for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+    const int sj = (remove_idx && j >= i) ? j + 1 : j;
+    dst[f * ldd + j] = copy ? x[sj] : output_val;
+  }
+  if (threadIdx.x == 0) keep[f] = copy ? 1 : (zerovec ? 2 : 0);
+}
+
+hipError_t stage_valbased(const float *src, int64_t lds, int N, int64_t nF, int idx, float threshold, int invert, int allow_equal,
+                          int zerovec, int remove_idx, float output_val, float *dst, int64_t ldd, int32_t *keep, hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_valbased, dim3((unsigned)nF), dim3(N > 128 ? 256 : 64), 0, s, src, lds, N, idx, threshold, invert, allow_equal, zerovec,
+                     remove_idx, output_val, dst, ldd, keep, nF);
+  return hipGetLastError();
+}
+
 hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s) {
   if (nF > 0) hipLaunchKernelGGL(k_sumsq, dim3((unsigned)nF), dim3(256), 0, s, src, lds, N, out);
   return hipGetLastError();

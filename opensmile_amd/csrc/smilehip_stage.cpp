@@ -76,6 +76,18 @@ extern "C" int smilehip_zcr_count_frames(smilehip_context *ctx, const float *d_s
   STAGE_RET(stage_zcr_count(d_src, ld_src, N, n_frames, d_out, (hipStream_t)stream), "zcr_count");
 }
 
+extern "C" int smilehip_valbased_select_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,
+                                              int32_t idx, float threshold, int32_t invert, int32_t allow_equal, int32_t zero_vec,
+                                              int32_t remove_idx, float output_val, float *d_dst, int64_t ld_dst, int32_t *d_keep,
+                                              void *stream) {
+  const int64_t n_out = remove_idx ? N - 1 : N;
+  if (!ctx || N < 1 || N > (1 << 20) || n_out < 1 || idx < 0 || n_frames < 0 || ld_src < N || ld_dst < n_out ||
+      (n_frames > 0 && (!d_src || !d_dst || !d_keep)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_valbased_select_frames: bad argument");
+  STAGE_RET(stage_valbased(d_src, ld_src, (int)N, n_frames, idx, threshold, invert, allow_equal, zero_vec, remove_idx, output_val, d_dst,
+                           ld_dst, d_keep, (hipStream_t)stream), "valbased_select");
+}
+
 extern "C" int smilehip_acf_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
                                    int64_t n_out, int64_t n_frames, int use_power, int cepstrum, int norm_output,
                                    int abs_cepstrum, void *stream) {

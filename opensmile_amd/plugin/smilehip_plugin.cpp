@@ -44,6 +44,7 @@
 #include <lldcore/pitchACF.hpp>
 #include <lldcore/plp.hpp>
 #include <lldcore/spectral.hpp>
+#include <other/valbasedSelector.hpp>
 #include <smileutil/smileUtil.h>
 
 #include <cctype>
@@ -67,12 +68,12 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 22;
+constexpr int kNumOverrides = 23;
 long g_frames[kNumOverrides] = {0};
 long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
                                             "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
-                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi"};
+                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector"};
 
 // An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
 // says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
@@ -1511,6 +1512,59 @@ class cHipHarmonics : public cHarmonics {
   }
 };
 
+// cValbasedSelector::myTick (src/other/valbasedSelector.cpp:139-247) -- tick-level: a frame may be handed on, replaced by a
+// constant vector, or dropped, so myTick itself is replaced. The decision and the output vector come from the device
+// (smilehip_valbased_select_frames); the adaptive (running-average) threshold is not built.
+class cHipValbasedSelector : public cValbasedSelector {
+  FrameIO io_;
+  DevBytes keep_;
+  bool ready_ = false, cpu_warned_ = false;
+  long idx_ = 0;
+  int removeIdx_ = 0, invert_ = 0, allowEqual_ = 0, zerovec_ = 0, adaptive_ = 0;
+  FLOAT_DMEM outputVal_ = 0, threshold_ = 0;
+  cVector *my_ = nullptr;
+ protected:
+  eTickResult myTick(long long t) override {
+    if (!ready_) {
+      threshold_ = (FLOAT_DMEM)getDouble("threshold");
+      adaptive_ = (int)getInt("adaptiveThreshold");
+      idx_ = getInt("idx"); invert_ = getInt("invert"); allowEqual_ = getInt("allowEqual");
+      removeIdx_ = getInt("removeIdx"); zerovec_ = getInt("zeroVec");
+      outputVal_ = (FLOAT_DMEM)getDouble("outputVal");
+      ready_ = true;
+    }
+    if (adaptive_) { HIP_FALLTHROUGH(22, "cValbasedSelector: adaptiveThreshold = 1 is not built"); return cValbasedSelector::myTick(t); }
+    if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
+    cVector *vec = reader_->getNextFrame();
+    if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+    const long N = vec->N, nOut = removeIdx_ ? N - 1 : N;
+    if (nOut < 1) { HIP_FALLTHROUGH(22, "cValbasedSelector: removeIdx on a one-element vector"); return TICK_INACTIVE; }
+    io_.ensure(N, nOut);
+    io_.up(vec->data, N);
+    int32_t *d_keep = (int32_t *)keep_.ensure(sizeof(int32_t));
+    check(smilehip_valbased_select_frames(context(), io_.d_in, N, N, 1, (int32_t)idx_, threshold_, invert_, allowEqual_, zerovec_, removeIdx_,
+                                          outputVal_, io_.d_out, nOut, d_keep, nullptr));
+    if (my_ == NULL || my_->N != nOut) { delete my_; my_ = new cVector((int)nOut); }
+    io_.down(my_->data, nOut);
+    int32_t keep = 0;
+    keep_.down(&keep, sizeof(keep));
+    g_frames[22]++;
+    if (keep) {
+      my_->setTimeMeta(vec->tmeta);
+      writer_->setNextFrame(my_);
+    }
+    return TICK_SUCCESS;
+  }
+ public:
+  explicit cHipValbasedSelector(const char *n) : cValbasedSelector(n) {}
+  ~cHipValbasedSelector() override { delete my_; }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipValbasedSelector(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // cPitchSmootherViterbi::myTick (src/lld/pitchSmootherViterbi.cpp:451-564) -- a TICK-LEVEL override: the component keeps its
 // own buffering (frames are released when all surviving paths agree, or when the path buffer is full, the rest at end of
 // input), so what is replaced is myTick itself. One frame of candidates per tick goes to the device-resident trellis
@@ -1825,12 +1879,13 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-two
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-three
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
   if (want("cHipLldSource")) {                             // a NEW type (fused mode), not an override
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cValbasedSelector")) head = override_of(&cValbasedSelector::registerComponent, &cHipValbasedSelector::create, confman, compman, iteration, head);
   if (want("cPitchSmootherViterbi")) head = override_of(&cPitchSmootherViterbi::registerComponent, &cHipPitchSmootherViterbi::create, confman, compman, iteration, head);
   if (want("cHarmonics")) head = override_of(&cHarmonics::registerComponent, &cHipHarmonics::create, confman, compman, iteration, head);
   if (want("cFormantLpc")) head = override_of(&cFormantLpc::registerComponent, &cHipFormantLpc::create, confman, compman, iteration, head);

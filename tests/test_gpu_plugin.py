@@ -424,7 +424,8 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
 
 
 def test_plugin_viterbi_tick_level_override(oracle, golden_f0):
-    """cPitchSmootherViterbi as a tick-level override (myTick replaced: one frame of candidates per tick goes to the
+    """cPitchSmootherViterbi and cValbasedSelector as tick-level overrides (myTick replaced; the selectors decide per frame
+    whether it is handed on, zeroed or dropped). cPitchSmootherViterbi (myTick replaced: one frame of candidates per tick goes to the
     device-resident trellis, decided frames are written at the tick at which the reference's incremental scheme releases
     them). With ONLY this component overridden, the unmodified ComParE_2016.conf and eGeMAPSv02.conf (bufferLength 40,
     F0finalLog) must reproduce the plain binary's LLD files BIT FOR BIT -- everything downstream (energy gate, jitter,
@@ -434,7 +435,8 @@ def test_plugin_viterbi_tick_level_override(oracle, golden_f0):
         pcm = golden_f0["pcm_" + k]
         for conf in (COMPARE, "egemaps/v02/eGeMAPSv02.conf"):
             ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
-            y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cPitchSmootherViterbi"}, conf, "-lldhtkoutput")
+            y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cPitchSmootherViterbi,cValbasedSelector"}, conf, "-lldhtkoutput")
             assert tr["cPitchSmootherViterbi"] > 0 and tr["cPitchSmootherViterbi.cpu"] == 0
+            assert tr["cValbasedSelector"] > 0 and tr["cValbasedSelector.cpu"] == 0
             assert y.shape == ref.shape
             assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (k, conf, int((y != ref).any(axis=1).sum()))
