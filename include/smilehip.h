@@ -642,6 +642,22 @@ int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const float *cand_f
 int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
 int smilehip_viterbi_stream_destroy(smilehip_viterbi_stream *s);
 
+/* ---- cPitchJitter as a stream (src/lld/pitchJitter.cpp:591-1084, myTick: one F0 frame per tick, waveform matching around the
+ * pitch periods in the wave samples [lastIdx, lastIdx + toRead), with the read position, the left-over samples and the last
+ * period / difference / jitter / shimmer values carried from frame to frame). What the plugin's tick-level override binds: the
+ * carried state lives on the device; the caller reads the wave samples the reference would read (its own prologue, :604-668, from
+ * last_idx / last_mis returned by the previous push) and hands them over as 16-bit PCM with their absolute start index.
+ * n_pcm = 0: the samples could not be read (the reference's NULL matrix): the read position still advances, out5 is not valid.
+ * out5 = jitterLocal, jitterDDP, shimmerLocal, logHNR, shimmerLocalDB of this frame. sample_period = 1 / sample rate;
+ * frame_size / frame_step: the F0 frames in samples; frame_step_sec: their period as the level reports it. */
+typedef struct smilehip_jitter_stream smilehip_jitter_stream;
+int smilehip_jitter_stream_create(smilehip_context *ctx, double sample_period, int64_t frame_size, int64_t frame_step,
+                                  double frame_step_sec, double search_range_rel, int32_t broken_jitter_thresh,
+                                  smilehip_jitter_stream **out);
+int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, const int16_t *h_pcm, int64_t pcm_start, int64_t n_pcm,
+                                float *out5, int64_t *last_idx, int64_t *last_mis);
+int smilehip_jitter_stream_destroy(smilehip_jitter_stream *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,9 @@ SYMBOLS = {
     "smilehip_formantlpc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_harmonics_frames": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_valbased_select_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
+    "smilehip_jitter_stream_create": (C.c_int, [_vp, _dbl, _i64, _i64, _dbl, _dbl, _i32, C.POINTER(_vp)]),
+    "smilehip_jitter_stream_push": (C.c_int, [_vp, _f32, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "smilehip_jitter_stream_destroy": (C.c_int, [_vp]),
     "smilehip_viterbi_stream_create": (C.c_int, [_vp, _i32, _f32, _vp, C.POINTER(_vp)]),
     "smilehip_viterbi_stream_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "smilehip_viterbi_stream_flush": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),

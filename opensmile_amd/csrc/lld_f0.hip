@@ -900,7 +900,15 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   PHASE_DECL
   long lastIdx = 0, lastMis = 0;
   float lastT0 = 0.0f, lastDiff = 0.0f, lastJL = 0.0f, lastJD = 0.0f, lastSh = 0.0f;
-  for (int t = 0; t < T; ++t) {
+  int t_first = 0, t_end = T;
+  if (Q.jit_stream) {                                      // stream mode: the state of the frames before, one frame now
+    const double *js = Q.jit_stream;
+    lastIdx = (long)js[0]; lastMis = (long)js[1]; t_first = (int)js[2];
+    lastT0 = (float)js[3]; lastDiff = (float)js[4]; lastJL = (float)js[5]; lastJD = (float)js[6]; lastSh = (float)js[7];
+    t_end = t_first + 1 < T ? t_first + 1 : T;
+    __syncthreads();                                       // every thread has read the state before thread 0 rewrites it
+  }
+  for (int t = t_first; t < t_end; ++t) {
     const float F0 = f0[(fo + t) * ld_f0];
     const double time = (double)((long)t * H) * Tw;
     const double lengthSec = ((double)((long)t * H + N - 1) * Tw - (double)((long)t * H) * Tw) + Tw;
@@ -1173,6 +1181,11 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       }
     }
     PHASE(9);   // output
+  }
+  if (Q.jit_stream && tid == 0) {
+    double *js = Q.jit_stream;
+    js[0] = (double)lastIdx; js[1] = (double)lastMis; js[2] = (double)t_end;
+    js[3] = lastT0; js[4] = lastDiff; js[5] = lastJL; js[6] = lastJD; js[7] = lastSh;
   }
   PHASE_FLUSH;
 }

@@ -147,6 +147,8 @@ struct F0Params {
   int32_t vit_log_out;              // 1: rows [F0final, F0finalLog, voicingFinalUnclipped] (GeMAPS), 0: [F0final, voicing]
   double jit_search_range;          // cPitchJitter searchRangeRel (0.25 ComParE, 0.1 GeMAPS)
   float *jit_shim_db;               // optional [total_frames]: shimmerLocalDB = 20 log10(shimmerLocal + 1)
+  double *jit_stream;               // stream mode (one frame per launch, smilehip_jitter_stream_*): [0] lastIdx [1] lastMis [2] next frame
+                                    // [3] lastT0 [4] lastDiff [5] lastJitterLocal [6] lastJitterDDP [7] lastShimmerLocal; null = whole utterances
 };
 
 // eGeMAPSv02 / GeMAPSv01b LLD level (lld_gemaps.hip): per-frame scratch and constants

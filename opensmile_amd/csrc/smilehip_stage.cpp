@@ -320,3 +320,110 @@ extern "C" int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t
   if (s->n_frames == 0) { *n_decided = 0; return SMILEHIP_OK; }
   return viterbi_step(s, 1, n_decided, frames, states, cap);
 }
+
+// ---------------------------------------------- cPitchJitter as a stream (the plugin's tick-level override)
+struct smilehip_jitter_stream {
+  LldParams P;
+  F0Params Q;
+  int16_t *d_pcm = nullptr;
+  int64_t cap_pcm = 0;
+  float *d_f0 = nullptr, *d_out4 = nullptr, *d_shim = nullptr;
+  int64_t cap_frames = 0, n_frames = 0;
+  int64_t *d_off = nullptr;            // [0..1] frame_off, [2..3] samp_off
+  double *d_state = nullptr;
+};
+
+extern "C" int smilehip_jitter_stream_destroy(smilehip_jitter_stream *s) {
+  if (!s) return SMILEHIP_OK;
+  if (s->d_pcm) (void)hipFree(s->d_pcm);
+  if (s->d_f0) (void)hipFree(s->d_f0);
+  if (s->d_out4) (void)hipFree(s->d_out4);
+  if (s->d_shim) (void)hipFree(s->d_shim);
+  if (s->d_off) (void)hipFree(s->d_off);
+  if (s->d_state) (void)hipFree(s->d_state);
+  delete s;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_jitter_stream_create(smilehip_context *ctx, double sample_period, int64_t frame_size, int64_t frame_step,
+                                             double frame_step_sec, double search_range_rel, int32_t broken_jitter_thresh,
+                                             smilehip_jitter_stream **out) {
+  if (!ctx || !out || sample_period <= 0 || frame_size < 2 || frame_step < 1 || frame_step_sec <= 0 || search_range_rel <= 0)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_jitter_stream_create: bad argument");
+  smilehip_jitter_stream *s = new smilehip_jitter_stream;
+  std::memset(&s->P, 0, sizeof(s->P));
+  std::memset(&s->Q, 0, sizeof(s->Q));
+  s->P.n_utt = 1;
+  s->Q.N = (int32_t)frame_size; s->Q.H = (int32_t)frame_step;
+  s->Q.jit_Tw = sample_period;
+  s->Q.jit_step_sec = frame_step_sec;
+  s->Q.jit_search_range = search_range_rel;
+  s->Q.jit_broken_thresh = broken_jitter_thresh;
+  const double st0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMalloc(reinterpret_cast<void **>(&s->d_off), sizeof(int64_t) * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(st0)) != hipSuccess ||
+      hipMemcpy(s->d_state, st0, sizeof(st0), hipMemcpyHostToDevice) != hipSuccess) {
+    smilehip_jitter_stream_destroy(s);
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_create: device allocation failed");
+  }
+  *out = s;
+  return SMILEHIP_OK;
+}
+
+template <typename T>
+static int grow(T *&p, int64_t &cap, int64_t need, int64_t keep, int width) {
+  if (need <= cap) return SMILEHIP_OK;
+  int64_t ncap = cap ? cap : 4096;
+  while (ncap < need) ncap *= 2;
+  T *np = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&np), sizeof(T) * (size_t)ncap * width) != hipSuccess ||
+      hipMemset(np, 0, sizeof(T) * (size_t)ncap * width) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "stream buffer allocation failed");
+  if (p && keep > 0 && hipMemcpy(np, p, sizeof(T) * (size_t)keep * width, hipMemcpyDeviceToDevice) != hipSuccess) {
+    (void)hipFree(np);
+    return fail(SMILEHIP_ERR_HIP, "stream buffer copy failed");
+  }
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = ncap;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, const int16_t *h_pcm, int64_t pcm_start, int64_t n_pcm,
+                                           float *out5, int64_t *last_idx, int64_t *last_mis) {
+  if (!s || !out5 || n_pcm < 0 || pcm_start < 0 || (n_pcm > 0 && !h_pcm)) return fail(SMILEHIP_ERR_INVALID, "smilehip_jitter_stream_push: bad argument");
+  int rc;
+  const int64_t t = s->n_frames;
+  {                                                         // the three per-frame arrays grow together
+    int64_t c1 = s->cap_frames, c2 = s->cap_frames, c3 = s->cap_frames;
+    if ((rc = grow(s->d_f0, c1, t + 1, t, 1)) || (rc = grow(s->d_out4, c2, t + 1, t, 4)) || (rc = grow(s->d_shim, c3, t + 1, t, 1))) return rc;
+    s->cap_frames = c1;
+  }
+  const int64_t n_samp = n_pcm > 0 ? pcm_start + n_pcm : 0;           // no samples: the frame cannot be read (what the reference's
+  if (n_pcm > 0) {                                                     // NULL matrix means); the state still moves on
+    if ((rc = grow(s->d_pcm, s->cap_pcm, n_samp + 2, s->cap_pcm, 1))) return rc;
+    if (hipMemcpy(s->d_pcm + pcm_start, h_pcm, sizeof(int16_t) * (size_t)n_pcm, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push: upload failed");
+  } else if ((rc = grow(s->d_pcm, s->cap_pcm, 2, s->cap_pcm, 1))) return rc;
+  const int64_t off[4] = {0, t + 1, 0, n_samp};
+  if (hipMemcpy(s->d_off, off, sizeof(off), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->d_f0 + t, &f0, sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push: upload failed");
+  s->P.frame_off = s->d_off;
+  s->P.samp_off = s->d_off + 2;
+  s->P.pcm = s->d_pcm;
+  s->P.total_frames = t + 1;
+  s->Q.jit_shim_db = s->d_shim;
+  s->Q.jit_stream = s->d_state;
+  hipError_t e = launch_f0_jitter(s->P, s->Q, s->d_f0, 1, s->d_out4, nullptr);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "jitter step launch failed: %s", hipGetErrorString(e));
+  double st[8];
+  if (hipMemcpy(out5, s->d_out4 + 4 * t, sizeof(float) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(out5 + 4, s->d_shim + t, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(st, s->d_state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push: copy back failed");
+  if (last_idx) *last_idx = (int64_t)st[0];
+  if (last_mis) *last_mis = (int64_t)st[1];
+  s->n_frames = t + 1;
+  return SMILEHIP_OK;
+}

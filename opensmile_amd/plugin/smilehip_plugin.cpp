@@ -37,6 +37,12 @@
 #include <lld/lpc.hpp>
 #include <lld/pitchShs.hpp>
 #include <lld/pitchSmootherViterbi.hpp>
+// cPitchJitter keeps its second reader, its options and the state it carries from frame to frame private; a tick-level
+// override has to use them (the base class's own myTick must still work when an option set is not built). The header is
+// included with its access specifier relaxed -- nothing but access control changes, the object layout is the library's.
+#define private protected
+#include <lld/pitchJitter.hpp>
+#undef private
 #include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
@@ -68,12 +74,12 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 23;
+constexpr int kNumOverrides = 24;
 long g_frames[kNumOverrides] = {0};
 long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
                                             "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
-                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector"};
+                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter"};
 
 // An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
 // says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
@@ -1512,6 +1518,96 @@ class cHipHarmonics : public cHarmonics {
   }
 };
 
+// cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1084) -- tick-level: per F0 frame the component reads a stretch of the
+// wave level whose position and length depend on what the previous frames left over, matches pitch periods in it and
+// carries period / jitter / shimmer values on. The prologue (:604-668: which samples to read) runs here on the base class's
+// own members, the samples go to the device as 16-bit PCM, the matching itself and the carried values live in the
+// device-resident stream (smilehip_jitter_stream_push: the fused path's kernel, one frame per launch).
+class cHipPitchJitter : public cPitchJitter {
+  smilehip_jitter_stream *js_ = nullptr;
+  bool ready_ = false, usable_ = false, cpu_warned_ = false;
+  std::vector<int16_t> pcm_;
+ protected:
+  eTickResult myTick(long long t) override {
+    if (!ready_) {
+      ready_ = true;
+      usable_ = !jitterLocalEnv && !jitterDDPEnv && !shimmerLocalEnv && !shimmerLocalDBEnv && !shimmerUseRmsAmplitude && !harmonicERMS &&
+                !noiseERMS && !linearHNR && !sourceQualityRange && !sourceQualityMean && !periodLengths && !periodStarts && !refinedF0 &&
+                !usePeakToPeakPeriodLength_ && minNumPeriods == 2 && filehandle == NULL &&
+                (useBrokenJitterThresh_ || threshCC_ == (FLOAT_DMEM)0.5) && lgHNRfloor == (FLOAT_DMEM)-100.0 && reader_->getLevelN() == 1;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(23, "cPitchJitter: only jitterLocal / jitterDDP / shimmerLocal / shimmerLocalDB / logHNR with minNumPeriods = 2, minCC = 0.5 "
+                          "(or useBrokenJitterThresh), lgHNRfloor = -100 on a mono wave level are built");
+      return cPitchJitter::myTick(t);
+    }
+    if (isEOI()) return TICK_INACTIVE;
+    if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
+    cVector *fvec = F0reader->getNextFrame();
+    if (fvec == NULL) return TICK_SOURCE_NOT_AVAIL;
+    FLOAT_DMEM F0 = 0.0;
+    if (F0fieldIdx < fvec->N) F0 = fvec->data[F0fieldIdx];
+    const long lenF = (long)ceil(fvec->tmeta->lengthSec / fvec->tmeta->framePeriod);
+    const double T = reader_->getLevelT();
+    const long startVidx = (long)round(fvec->tmeta->time / T);
+    const double pitchT = fvec->tmeta->period;
+    const long ppLen = (long)ceil(pitchT / T);
+    if (!js_) {
+      const long H = (long)round(pitchT / T), N = (long)round(fvec->tmeta->lengthSec / T);   // (lenF itself is N or N + 1: rounding of the time stamps)
+      check(smilehip_jitter_stream_create(context(), T, N, H, pitchT, searchRangeRel, useBrokenJitterThresh_, &js_));
+    }
+    const long toRead0 = ppLen + lastMis;
+    long toRead = toRead0;
+    if (F0 > 0.0) {
+      const double Tf = (1.0 / F0) / T;
+      const long T0maxF = (long)ceil((1.0 + searchRangeRel) * Tf);
+      const long two_pp = minNumPeriods * T0maxF + minNumPeriods;
+      if (toRead < two_pp) toRead = two_pp;
+    }
+    long maxRead = lastMis + lenF;
+    if (toRead > maxRead) toRead = maxRead;
+    if (startVidx - lastMis != lastIdx) {
+      lastIdx = startVidx;
+      if (toRead > lenF) toRead = lenF;
+      if (maxRead > lenF) maxRead = lenF;
+    }
+    cMatrix *mat = reader_->getMatrix(lastIdx, toRead);
+    float out5[5] = {0, 0, 0, 0, 0};
+    int64_t li = 0, lm = 0;
+    if (mat == NULL) {                                     // (:660-665) the position still moves on
+      check(smilehip_jitter_stream_push(js_, F0, nullptr, 0, 0, out5, &li, &lm));
+      lastIdx = (long)li; lastMis = (long)lm;
+      return TICK_SOURCE_NOT_AVAIL;
+    }
+    if (maxRead < 1 || mat->data == NULL) return TICK_INACTIVE;
+    pcm_.resize((size_t)mat->nT);
+    for (long i = 0; i < mat->nT; ++i) pcm_[(size_t)i] = (int16_t)lrintf(mat->data[i] * 32767.0f);   // the level holds s / 32767: exact
+    check(smilehip_jitter_stream_push(js_, F0, pcm_.data(), lastIdx, mat->nT, out5, &li, &lm));
+    lastIdx = (long)li; lastMis = (long)lm;
+    g_frames[23]++;
+    if (Nout == 0) return TICK_INACTIVE;                    // (:941-947)
+    if (onlyVoiced && (F0 == 0.0)) return TICK_INACTIVE;
+    if (out == NULL) out = new cVector(Nout);
+    long n = 0;
+    if (jitterLocal) out->data[n++] = out5[0];
+    if (jitterDDP) out->data[n++] = out5[1];
+    if (shimmerLocal) out->data[n++] = out5[2];
+    if (shimmerLocalDB) out->data[n++] = out5[4];
+    if (logHNR) out->data[n++] = out5[3];
+    out->setTimeMeta(fvec->tmeta);
+    writer_->setNextFrame(out);
+    return TICK_SUCCESS;
+  }
+ public:
+  explicit cHipPitchJitter(const char *n) : cPitchJitter(n) {}
+  ~cHipPitchJitter() override { if (js_) smilehip_jitter_stream_destroy(js_); }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchJitter(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
 // cValbasedSelector::myTick (src/other/valbasedSelector.cpp:139-247) -- tick-level: a frame may be handed on, replaced by a
 // constant vector, or dropped, so myTick itself is replaced. The decision and the output vector come from the device
 // (smilehip_valbased_select_frames); the adaptive (running-average) threshold is not built.
@@ -1879,12 +1975,13 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-three
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-four
   auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
   if (want("cHipLldSource")) {                             // a NEW type (fused mode), not an override
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cPitchJitter")) head = override_of(&cPitchJitter::registerComponent, &cHipPitchJitter::create, confman, compman, iteration, head);
   if (want("cValbasedSelector")) head = override_of(&cValbasedSelector::registerComponent, &cHipValbasedSelector::create, confman, compman, iteration, head);
   if (want("cPitchSmootherViterbi")) head = override_of(&cPitchSmootherViterbi::registerComponent, &cHipPitchSmootherViterbi::create, confman, compman, iteration, head);
   if (want("cHarmonics")) head = override_of(&cHarmonics::registerComponent, &cHipHarmonics::create, confman, compman, iteration, head);

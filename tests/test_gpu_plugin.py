@@ -424,8 +424,9 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
 
 
 def test_plugin_viterbi_tick_level_override(oracle, golden_f0):
-    """cPitchSmootherViterbi and cValbasedSelector as tick-level overrides (myTick replaced; the selectors decide per frame
-    whether it is handed on, zeroed or dropped). cPitchSmootherViterbi (myTick replaced: one frame of candidates per tick goes to the
+    """cPitchSmootherViterbi, cValbasedSelector and cPitchJitter as tick-level overrides (myTick replaced; the selectors decide
+    per frame whether it is handed on, zeroed or dropped; the jitter component reads the wave stretch its carried state asks
+    for and hands it to the device-resident stream). cPitchSmootherViterbi (myTick replaced: one frame of candidates per tick goes to the
     device-resident trellis, decided frames are written at the tick at which the reference's incremental scheme releases
     them). With ONLY this component overridden, the unmodified ComParE_2016.conf and eGeMAPSv02.conf (bufferLength 40,
     F0finalLog) must reproduce the plain binary's LLD files BIT FOR BIT -- everything downstream (energy gate, jitter,
@@ -435,8 +436,29 @@ def test_plugin_viterbi_tick_level_override(oracle, golden_f0):
         pcm = golden_f0["pcm_" + k]
         for conf in (COMPARE, "egemaps/v02/eGeMAPSv02.conf"):
             ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
-            y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cPitchSmootherViterbi,cValbasedSelector"}, conf, "-lldhtkoutput")
+            y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cPitchSmootherViterbi,cValbasedSelector,cPitchJitter"}, conf, "-lldhtkoutput")
+            assert tr["cPitchJitter"] > 0 and tr["cPitchJitter.cpu"] == 0
             assert tr["cPitchSmootherViterbi"] > 0 and tr["cPitchSmootherViterbi.cpu"] == 0
             assert tr["cValbasedSelector"] > 0 and tr["cValbasedSelector.cpu"] == 0
             assert y.shape == ref.shape
             assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (k, conf, int((y != ref).any(axis=1).sum()))
+
+
+def test_plugin_compare16_every_component_overridden(oracle, golden_f0):
+    """The unmodified ComParE_2016.conf with EVERY overridable component on HIP -- the 20 ms and 60 ms front ends, cSpecScale,
+    cPitchShs, the tick-level cPitchSmootherViterbi / cValbasedSelector / cPitchJitter, cSpectral, cPlp, the smoothers and
+    deltas: the binary's 130-column LLD file within the tolerances of the fused path; the two option sets that are not built as
+    per-component operators (noZeroSma, onlyInSegments: two instances of the F0 group) run the reference's code and say so."""
+    from test_gpu_compare_full import AB, F0, KEYS_130, f0_lld_tolerances
+    from test_oracle_pin_compare import compare_tolerances
+    for k in KEYS_130[:2]:
+        y, tr = _run(oracle, golden_f0["pcm_" + k], {}, COMPARE, "-lldhtkoutput")   # no selection: every override
+        ref = golden_f0["lld130_" + k]
+        assert y.shape == ref.shape
+        compare_tolerances(y[:, AB], ref[:, AB], "plugin " + k)
+        f0_lld_tolerances(y[:, F0], ref[:, F0], "plugin " + k)
+        for comp in ("cTransformFFT", "cSpecScale", "cPitchShs", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter", "cSpectral", "cPlp",
+                     "cContourSmoother", "cDeltaRegression", "cMelspec", "cMfcc", "cEnergy", "cMZcr"):
+            assert tr.get(comp, 0) > 0, (comp, tr)
+        # the only CPU fall-through (logged by the instances): the F0 group's noZeroSma smoother and onlyInSegments delta
+        assert {n for n, v in tr.items() if n.endswith(".cpu") and v} == {"cContourSmoother.cpu", "cDeltaRegression.cpu"}
