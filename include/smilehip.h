@@ -25,6 +25,12 @@
  *    words, cMatrix data[n + t*N], src/include/core/dataMemoryLevel.hpp:152-217):
  *    element n of frame t is at base[t*ld + n].
  *  - FLOAT_DMEM = float (src/include/core/smileTypes.h:28).
+ *  - Concurrency: a context, a plan and a batch each own device scratch (functionals scratch and auxiliary streams in the
+ *    context; side stream, fork / join events and tables in the plan; per-batch scratch matrices) that calls reuse. Calls on
+ *    the SAME context / plan / batch must therefore be issued from one host thread at a time and on one stream at a time
+ *    (finish or synchronise before switching streams); different batches of one plan may run concurrently only through
+ *    entry points that do not use the plan's side stream (the MFCC / PLP / IS09 chains, the per-component operators), and
+ *    the functionals calls of one context serialise on its scratch. One context per host thread is the simple rule.
  */
 #ifndef SMILEHIP_H
 #define SMILEHIP_H
