@@ -366,128 +366,193 @@ constexpr int kNC = kLpcP;
 #define GM_ROOT(r, i) ((r)[(i) * 64])
 #define GM_EPS 2.2204460492503131e-16
 
-__device__ __forceinline__ void zs_balance(double *m) {                  // zerosolveBalanceCmatrix, zerosolve.cpp:22-84
+// Register form (round 2, third version): the matrix lives in the lane's registers. Every loop of the reference over matrix
+// indices is unrolled over its full static range 1..nc and its body predicated with the reference's runtime bounds, so that
+// every matrix access has compile-time indices; a body whose predicate is false for all 64 lanes is skipped by a wave-uniform
+// branch. Each executed operation is the reference's own, in its order: the roots are bit-identical to the serial code's.
+struct ZsMat {
+  double a[kNC][kNC];
+};
+#define ZM(m, i, j) ((m).a[(i) - 1][(j) - 1])             // 1-based like the reference's MATF; i, j compile-time after unrolling
+
+__device__ __forceinline__ void zs_balance_reg(ZsMat &m) {   // zerosolveBalanceCmatrix, zerosolve.cpp:22-84
   const double radix = 2.0, radix2 = 4.0;
-  const int nc = kNC;
   bool converged = false;
-  double nrow = 0, ncol = 0;
-  while (!converged) {
-    double t1, t2, t3;
+  while (__any(!converged)) {
+    const bool active = !converged;                        // lanes that are done go through the sweep without effect
     converged = true;
-    for (int i = 0; i < nc; i++) {
-      if (i != nc - 1) ncol = fabs(GM_MATC(m, i + 1, i));
-      else { ncol = 0.0; for (int j = 0; j < nc - 1; j++) ncol += fabs(GM_MATC(m, j, nc - 1)); }
-      if (i == 0) nrow = fabs(GM_MATC(m, 0, nc - 1));
-      else if (i == nc - 1) nrow = fabs(GM_MATC(m, i, i - 1));
-      else nrow = (fabs(GM_MATC(m, i, i - 1)) + fabs(GM_MATC(m, i, nc - 1)));
-      if (ncol == 0.0 || nrow == 0.0) continue;
-      t2 = 1.0; t1 = nrow / radix; t3 = ncol + nrow;
+#pragma unroll
+    for (int i = 0; i < kNC; i++) {
+      double nrow, ncol;
+      if (i != kNC - 1) ncol = fabs(m.a[i + 1][i]);
+      else {
+        ncol = 0.0;
+#pragma unroll
+        for (int j = 0; j < kNC - 1; j++) ncol += fabs(m.a[j][kNC - 1]);
+      }
+      if (i == 0) nrow = fabs(m.a[0][kNC - 1]);
+      else if (i == kNC - 1) nrow = fabs(m.a[i][i - 1]);
+      else nrow = (fabs(m.a[i][i - 1]) + fabs(m.a[i][kNC - 1]));
+      if (!active || ncol == 0.0 || nrow == 0.0) continue;
+      double t2 = 1.0, t1 = nrow / radix;
+      const double t3 = ncol + nrow;
       while (ncol < t1) { t2 *= radix; ncol *= radix2; }
       t1 = nrow * radix;
       while (ncol > t1) { t2 /= radix; ncol /= radix2; }
       if ((nrow + ncol) < 0.95 * t3 * t2) {
         converged = false;
         t1 = 1.0 / t2;
-        if (i == 0) GM_MATC(m, 0, nc - 1) *= t1;
-        else { GM_MATC(m, i, i - 1) *= t1; GM_MATC(m, i, nc - 1) *= t1; }
-        if (i == nc - 1) { for (int j = 0; j < nc; j++) GM_MATC(m, j, i) *= t2; }
-        else GM_MATC(m, i + 1, i) *= t2;
+        if (i == 0) m.a[0][kNC - 1] *= t1;
+        else { m.a[i][i - 1] *= t1; m.a[i][kNC - 1] *= t1; }
+        if (i == kNC - 1) {
+#pragma unroll
+          for (int j = 0; j < kNC; j++) m.a[j][i] *= t2;
+        } else m.a[i + 1][i] *= t2;
       }
     }
   }
 }
 
-__device__ __forceinline__ int zs_qr(double *h, double *root) {          // zerosolveQRhelper, zerosolve.cpp:100-283
-  int i, j, k, m = 0, e, nit = 0, N = kNC;
-  double w, s, x, y, z, p = 0, q = 0, r = 0, t = 0.0;
-  for (;;) {
-    for (e = N; e >= 2; e--) {
-      const double a1 = fabs(GM_MATF(h, e, e - 1)), a2 = fabs(GM_MATF(h, e - 1, e - 1)), a3 = fabs(GM_MATF(h, e, e));
-      if (a1 <= GM_EPS * (a2 + a3)) break;
+// zerosolveQRhelper, zerosolve.cpp:100-283. root: the lane's (re, im) pairs in LDS, element e at root[e * 64]
+__device__ __forceinline__ void zs_qr_reg(ZsMat &h, double *root) {
+  int N = kNC, nit = 0;
+  double t = 0.0;
+  bool live = true;                                        // false: all roots found, or given up after 70 iterations
+  while (__any(live)) {
+    // ---- e: the last small sub-diagonal element (e = N .. 2; 1 if none)
+    int e = 1;
+    {
+      bool found = false;
+#pragma unroll
+      for (int ec = kNC; ec >= 2; ec--) {
+        if (ec <= N && !found) {
+          const double a1 = fabs(ZM(h, ec, ec - 1)), a2 = fabs(ZM(h, ec - 1, ec - 1)), a3 = fabs(ZM(h, ec, ec));
+          if (a1 <= GM_EPS * (a2 + a3)) { found = true; e = ec; }
+        }
+      }
     }
-    x = GM_MATF(h, N, N);
-    if (e == N) {
-      GM_ROOT(root, 2 * (N - 1)) = x + t; GM_ROOT(root, 2 * (N - 1) + 1) = 0;
+    double x = 0.0, y = 0.0, w = 0.0;
+#pragma unroll
+    for (int c = 1; c <= kNC; c++) {
+      if (c == N) x = ZM(h, c, c);
+      if (c >= 2) { if (c == N) { y = ZM(h, c - 1, c - 1); w = ZM(h, c - 1, c) * ZM(h, c, c - 1); } }
+    }
+    if (live && e == N) {                                  // one real root
+      root[(2 * (N - 1)) * 64] = x + t; root[(2 * (N - 1) + 1) * 64] = 0;
       N--;
-      if (N == 0) return 1;
       nit = 0;
+      if (N == 0) live = false;
       continue;
     }
-    y = GM_MATF(h, N - 1, N - 1);
-    w = GM_MATF(h, N - 1, N) * GM_MATF(h, N, N - 1);
-    if (e == N - 1) {
-      p = (y - x) / 2;
-      q = p * p + w;
-      y = sqrt(fabs(q));
-      x += t;
+    if (live && e == N - 1) {                              // a pair
+      double p = (y - x) / 2;
+      const double q = p * p + w;
+      double yy = sqrt(fabs(q));
+      const double xx = x + t;
       if (q > 0) {
-        if (p < 0) y = -y;
-        y += p;
-        GM_ROOT(root, 2 * (N - 1)) = x - w / y; GM_ROOT(root, 2 * (N - 1) + 1) = 0;
-        GM_ROOT(root, 2 * (N - 2)) = x + y; GM_ROOT(root, 2 * (N - 2) + 1) = 0;
+        if (p < 0) yy = -yy;
+        yy += p;
+        root[(2 * (N - 1)) * 64] = xx - w / yy; root[(2 * (N - 1) + 1) * 64] = 0;
+        root[(2 * (N - 2)) * 64] = xx + yy; root[(2 * (N - 2) + 1) * 64] = 0;
       } else {
-        GM_ROOT(root, 2 * (N - 1)) = x + p; GM_ROOT(root, 2 * (N - 1) + 1) = -y;
-        GM_ROOT(root, 2 * (N - 2)) = x + p; GM_ROOT(root, 2 * (N - 2) + 1) = y;
+        root[(2 * (N - 1)) * 64] = xx + p; root[(2 * (N - 1) + 1) * 64] = -yy;
+        root[(2 * (N - 2)) * 64] = xx + p; root[(2 * (N - 2) + 1) * 64] = yy;
       }
       N -= 2;
-      if (N == 0) return 1;
       nit = 0;
+      if (N == 0) live = false;
       continue;
     }
-    if (nit == 70) return 0;
-    if (nit % 10 == 0 && nit > 0) {
+    if (live && nit == 70) live = false;
+    if (!live) continue;                                   // (lanes that are done idle until the wave's last lane is)
+    if (nit % 10 == 0 && nit > 0) {                        // exceptional shift
       t += x;
-      for (i = 1; i <= N; i++) GM_MATF(h, i, i) -= x;
-      s = fabs(GM_MATF(h, N, N - 1)) + fabs(GM_MATF(h, N - 1, N - 2));
+#pragma unroll
+      for (int i = 1; i <= kNC; i++) if (i <= N) ZM(h, i, i) -= x;
+      double sN = 0.0, sN1 = 0.0;
+#pragma unroll
+      for (int c = 3; c <= kNC; c++) if (c == N) { sN = ZM(h, c, c - 1); sN1 = ZM(h, c - 1, c - 2); }
+      const double s = fabs(sN) + fabs(sN1);
       y = 3.0 / 4.0 * s;
       x = y;
       w = -0.4375 * s * s;
     }
     nit++;
-    for (m = N - 2; m >= e; m--) {
-      z = GM_MATF(h, m, m);
-      r = x - z;
-      s = y - z;
-      p = GM_MATF(h, m, m + 1) + (r * s - w) / GM_MATF(h, m + 1, m);
-      q = GM_MATF(h, m + 1, m + 1) - z - r - s;
-      r = GM_MATF(h, m + 2, m + 1);
-      s = fabs(p) + fabs(q) + fabs(r);
-      p /= s; q /= s; r /= s;
-      if (m == e) break;
-      const double a1 = fabs(GM_MATF(h, m, m - 1)), a2 = fabs(GM_MATF(h, m - 1, m - 1)), a3 = fabs(GM_MATF(h, m + 1, m + 1));
-      if (a1 * (fabs(q) + fabs(r)) <= GM_EPS * fabs(p) * (a2 + a3)) break;
+    // ---- m: where the double-shift step starts (m = N-2 .. e)
+    int m = e;
+    double p = 0, q = 0, r = 0;
+    {
+      bool done = false;
+#pragma unroll
+      for (int mc = kNC - 2; mc >= 1; mc--) {
+        if (mc <= N - 2 && mc >= e && !done) {
+          const double z = ZM(h, mc, mc);
+          double rr = x - z, ss = y - z;
+          p = ZM(h, mc, mc + 1) + (rr * ss - w) / ZM(h, mc + 1, mc);
+          q = ZM(h, mc + 1, mc + 1) - z - rr - ss;
+          r = ZM(h, mc + 2, mc + 1);
+          ss = fabs(p) + fabs(q) + fabs(r);
+          p /= ss; q /= ss; r /= ss;
+          m = mc;
+          if (mc == e) done = true;
+          else if (mc >= 2) {
+            const double a1 = fabs(ZM(h, mc, mc - 1)), a2 = fabs(ZM(h, mc - 1, mc - 1)), a3 = fabs(ZM(h, mc + 1, mc + 1));
+            if (a1 * (fabs(q) + fabs(r)) <= GM_EPS * fabs(p) * (a2 + a3)) done = true;
+          }
+        }
+      }
     }
-    for (i = m + 2; i <= N; i++) GM_MATF(h, i, i - 2) = 0;
-    for (i = m + 3; i <= N; i++) GM_MATF(h, i, i - 3) = 0;
-    for (k = m; k <= N - 1; k++) {
+#pragma unroll
+    for (int i = 3; i <= kNC; i++) if (i >= m + 2 && i <= N) ZM(h, i, i - 2) = 0;
+#pragma unroll
+    for (int i = 4; i <= kNC; i++) if (i >= m + 3 && i <= N) ZM(h, i, i - 3) = 0;
+    // ---- the double QR step over k = m .. N-1
+    double s = 0, z = 0;
+#pragma unroll
+    for (int k = 1; k <= kNC - 1; k++) {
+      const bool on = k >= m && k <= N - 1;
+      if (!__any(on)) continue;
       const bool notlast = (k != N - 1);
-      if (k != m) {
-        p = GM_MATF(h, k, k - 1);
-        q = GM_MATF(h, k + 1, k - 1);
-        r = notlast ? GM_MATF(h, k + 2, k - 1) : 0.0;
-        x = fabs(p) + fabs(q) + fabs(r);
-        if (x == 0) continue;
-        p /= x; q /= x; r /= x;
+      bool go = on;
+      if (k >= 2) {
+        if (on && k != m) {
+          p = ZM(h, k, k - 1);
+          q = ZM(h, k + 1, k - 1);
+          r = 0.0;
+          if (k + 2 <= kNC) { if (notlast) r = ZM(h, k + 2, k - 1); }
+          x = fabs(p) + fabs(q) + fabs(r);
+          if (x == 0) go = false;
+          else { p /= x; q /= x; r /= x; }
+        }
       }
-      s = sqrt(p * p + q * q + r * r);
-      if (p < 0) s = -s;
-      if (k != m) GM_MATF(h, k, k - 1) = -s * x;
-      else if (e != m) GM_MATF(h, k, k - 1) *= -1;
-      p += s;
-      z = r / s; y = q / s; x = p / s;
-      r /= p; q /= p;
-      for (j = k; j <= N; j++) {
-        p = GM_MATF(h, k, j) + q * GM_MATF(h, k + 1, j);
-        if (notlast) { p += r * GM_MATF(h, k + 2, j); GM_MATF(h, k + 2, j) -= p * z; }
-        GM_MATF(h, k + 1, j) -= p * y;
-        GM_MATF(h, k, j) -= p * x;
+      if (go) {
+        s = sqrt(p * p + q * q + r * r);
+        if (p < 0) s = -s;
+        if (k >= 2) {
+          if (k != m) ZM(h, k, k - 1) = -s * x;
+          else if (e != m) ZM(h, k, k - 1) *= -1;
+        }
+        p += s;
+        z = r / s; y = q / s; x = p / s;
+        r /= p; q /= p;
       }
-      j = (k + 3 < N) ? k + 3 : N;
-      for (i = e; i <= j; i++) {
-        p = x * GM_MATF(h, i, k) + y * GM_MATF(h, i, k + 1);
-        if (notlast) { p += z * GM_MATF(h, i, k + 2); GM_MATF(h, i, k + 2) -= p * r; }
-        GM_MATF(h, i, k + 1) -= p * q;
-        GM_MATF(h, i, k) -= p;
+#pragma unroll
+      for (int j = k; j <= kNC; j++) {                     // rows k, k+1, k+2 over the columns j = k .. N
+        if (go && j <= N) {
+          double pp = ZM(h, k, j) + q * ZM(h, k + 1, j);
+          if (k + 2 <= kNC) { if (notlast) { pp += r * ZM(h, k + 2, j); ZM(h, k + 2, j) -= pp * z; } }
+          ZM(h, k + 1, j) -= pp * y;
+          ZM(h, k, j) -= pp * x;
+        }
+      }
+#pragma unroll
+      for (int i = 1; i <= (k + 3 < kNC ? k + 3 : kNC); i++) {   // columns k, k+1, k+2 over the rows i = e .. min(k+3, N)
+        if (go && i >= e && i <= N) {
+          double pp = x * ZM(h, i, k) + y * ZM(h, i, k + 1);
+          if (k + 2 <= kNC) { if (notlast) { pp += z * ZM(h, i, k + 2); ZM(h, i, k + 2) -= pp * r; } }
+          ZM(h, i, k + 1) -= pp * q;
+          ZM(h, i, k) -= pp;
+        }
       }
     }
   }
@@ -497,20 +562,25 @@ __device__ __forceinline__ int zs_qr(double *h, double *root) {          // zero
 // cFormantLpc::processVector (formantLpc.cpp:192-290), nFormants = 5, saveFormants = saveBandwidths = 1, no median filter /
 // octave correction. One thread per frame. When the QR iteration does not converge the reference goes on with what its
 // roots member held before (the previous frame's values); a frame here starts from zeros instead (not observed on speech).
-constexpr size_t kFormantLds = sizeof(double) * 64 * (kLpcP * kLpcP + 2 * kLpcP);      // 73 KB: two workgroups per CU
 __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
   const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (g >= (G.op_mode ? G.op_rows : G.total_frames20)) return;
   const float *lp = G.lpc + g * G.lpc_ld;
-  extern __shared__ __attribute__((aligned(16))) double fm_smem[];       // [kNC*kNC + 2*kNC][64]
-  double *mat = fm_smem + threadIdx.x, *roots = fm_smem + kNC * kNC * 64 + threadIdx.x;
+  __shared__ double fm_roots[2 * kNC * 64];                              // the lanes' roots, element-major
+  double *roots = fm_roots + threadIdx.x;
   double fc[5], bc[5];
-  for (int i = 0; i < kNC * kNC; ++i) mat[i * 64] = 0.0;
   for (int i = 0; i < 2 * kNC; ++i) GM_ROOT(roots, i) = 0.0;
-  for (int i = 1; i < kNC; i++) GM_MATC(mat, i, i - 1) = 1.0;                 // zerosolveSetCmatrix, zerosolve.cpp:86-98
-  for (int i = 0; i < kNC; i++) GM_MATC(mat, i, kNC - 1) = -(double)(-lp[kNC - i - 1]) / 1.0;   // a[i] = -lpc[n-1-i], a[n] = 1
-  zs_balance(mat);
-  zs_qr(mat, roots);
+  ZsMat mat;
+#pragma unroll
+  for (int i = 0; i < kNC; i++)
+#pragma unroll
+    for (int j = 0; j < kNC; j++) mat.a[i][j] = 0.0;
+#pragma unroll
+  for (int i = 1; i < kNC; i++) mat.a[i][i - 1] = 1.0;                       // zerosolveSetCmatrix, zerosolve.cpp:86-98
+#pragma unroll
+  for (int i = 0; i < kNC; i++) mat.a[i][kNC - 1] = -(double)(-lp[kNC - i - 1]) / 1.0;   // a[i] = -lpc[n-1-i], a[n] = 1
+  zs_balance_reg(mat);
+  zs_qr_reg(mat, roots);
   for (int i = 0; i < kNC; i++) {                                            // smileMath_complexIntoUnitCircle, smileUtil.c:992-1003
     const double re = GM_ROOT(roots, 2 * i), im = GM_ROOT(roots, 2 * i + 1);
     if (sqrt(re * re + im * im) > 1.0) {
@@ -556,6 +626,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 #undef GM_MATC
 #undef GM_MATF
 #undef GM_ROOT
+#undef ZM
 #undef GM_EPS
 
 // ------------------------------------------------------------------------------------------------ cHarmonics
@@ -975,10 +1046,8 @@ hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s) {
   return hipGetLastError();
 }
 static hipError_t launch_formants(const GemapsParams &G, int64_t rows, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_gemaps_formants), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kFormantLds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((rows + 63) / 64)), dim3(64), kFormantLds, s, G);
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, G);
   return hipGetLastError();
 }
 hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s) {
