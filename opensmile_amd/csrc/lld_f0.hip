@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   const int T = (int)(P.frame_off[u + 1] - fo);
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
-  __shared__ double wv[kJitCap];          // the frame's wave samples, widened once (crossCorr works in double)
+  __shared__ float wv[kJitCap];           // the frame's wave samples (crossCorr widens them to double as it reads: exact, and half the LDS)
   __shared__ double ccs[kJitMaxCand];
   __shared__ float avgWf[kJitMaxPeriod];
   __shared__ int pbuf[kJitMaxPeriods];
@@ -908,7 +908,10 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     t_end = t_first + 1 < T ? t_first + 1 : T;
     __syncthreads();                                       // every thread has read the state before thread 0 rewrites it
   }
+  const int lane_in = lane, tid_in = tid;
   for (int t = t_first; t < t_end; ++t) {
+    int lane = lane_in, tid = tid_in;                      // opaque per frame: lane-only address arithmetic is not kept in registers
+    asm volatile("" : "+v"(lane), "+v"(tid));              // across the frame loop (see f0_shs)
     const float F0 = f0[(fo + t) * ld_f0];
     const double time = (double)((long)t * H) * Tw;
     const double lengthSec = ((double)((long)t * H + N - 1) * Tw - (double)((long)t * H) * Tw) + Tw;
@@ -948,7 +951,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     long start = 0, lastPeriod = 0;
     if (F0 > 0.0f) {
       __syncthreads();
-      for (long i = tid; i < nT; i += kJitThreads) wv[i] = (double)pcm16_to_float(x[lastIdx + i]);
+      for (long i = tid; i < nT; i += kJitThreads) wv[i] = pcm16_to_float(x[lastIdx + i]);
       for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
       __syncthreads();
       PHASE(5);   // frame set-up + wave load
@@ -959,13 +962,13 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       while (start < nT - 2 * T0maxF - 1) {
         for (int c = tid; c < nc; c += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
           const long tf = T0minF + c;
-          const double *xa = wv + start, *ya = wv + start + tf;
+          const float *xa = wv + start, *ya = wv + start + tf;
           // both passes in rounds of eight samples, the next round's samples loaded before the current round's sums
           // (the sums stay sequential in the reference's order)
           const long nr = tf >> 3;
           double mx = 0.0, my = 0.0;
           {
-            double xv[8], yv[8], xn[8], yn[8];
+            float xv[8], yv[8], xn[8], yn[8];            // kept as float, widened where they enter the sums (exact)
 #pragma unroll
             for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }      // (reads past tf stay inside wv: start + 2 tf < nT)
             for (long r = 0; r < nr; ++r) {
@@ -973,18 +976,18 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
 #pragma unroll
               for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
 #pragma unroll
-              for (int q = 0; q < 8; ++q) { mx += xv[q]; my += yv[q]; }
+              for (int q = 0; q < 8; ++q) { mx += (double)xv[q]; my += (double)yv[q]; }
 #pragma unroll
               for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if ((nr << 3) + q < tf) { mx += xv[q]; my += yv[q]; }
+            for (int q = 0; q < 8; ++q) if ((nr << 3) + q < tf) { mx += (double)xv[q]; my += (double)yv[q]; }
           }
           mx /= (double)tf;
           my /= (double)tf;
           double cc = 0.0, nx = 0.0, ny = 0.0;
           {
-            double xv[8], yv[8], xn[8], yn[8];
+            float xv[8], yv[8], xn[8], yn[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
             for (long r = 0; r < nr; ++r) {
@@ -993,7 +996,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
               for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
-                const double dx = xv[q] - mx, dy = yv[q] - my;
+                const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
                 cc += dx * dy;
                 nx += dx * dx;
                 ny += dy * dy;
@@ -1004,7 +1007,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
 #pragma unroll
             for (int q = 0; q < 8; ++q)
               if ((nr << 3) + q < tf) {
-                const double dx = xv[q] - mx, dy = yv[q] - my;
+                const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
                 cc += dx * dy;
                 nx += dx * dx;
                 ny += dy * dy;
@@ -1033,9 +1036,9 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         if (maxI >= 0) {
           start += pp;
           // amplitudeDiff (:422-459): max - min of x[1 .. pp-2] in both periods
-          float mx0 = (float)wv[os + 1], mn0 = mx0, mx1 = (float)wv[start + 1], mn1 = mx1;
+          float mx0 = wv[os + 1], mn0 = mx0, mx1 = wv[start + 1], mn1 = mx1;
           for (long i = 1 + lane; i < pp - 1; i += 64) {
-            const float a = (float)wv[os + i], b = (float)wv[start + i];
+            const float a = wv[os + i], b = wv[start + i];
             mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
             mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
           }
@@ -1050,7 +1053,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
           if (tid == 0) pbuf[numPeriods] = (int)os;
           numPeriods++;
-          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += (float)wv[os + i];
+          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += wv[os + i];
           double ccI = 0.0;
           const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
                                                                  (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
@@ -1083,7 +1086,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       if (tid == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
       numPeriods++;
       for (long i = tid; i < T0f && start + i < nT; i += kJitThreads) {
-        avgWf[i] += (float)wv[start + i];
+        avgWf[i] += wv[start + i];
         avgWf[i] /= (float)numPeriods;
       }
       __syncthreads();
@@ -1127,7 +1130,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
         for (long j = p0 + 2; j < lim; j += 64, k += 64) {
           const int cnt = (int)((lim - j < 64) ? (lim - j) : 64);
           float t = 0.0f;
-          if (ln < cnt) { const float delta = (float)wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
+          if (ln < cnt) { const float delta = wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
           En = chain_add(En, t, cnt);
           nEn += cnt;
         }
