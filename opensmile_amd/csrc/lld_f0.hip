@@ -960,31 +960,38 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       float minCC = -2.0f;
       const int nc = (int)(T0maxF - T0minF) + 1;
       while (start < nT - 2 * T0maxF - 1) {
-        for (int c = tid; c < nc; c += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
+        for (int k0 = 0; k0 < nc; k0 += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
+          // Candidates in descending length, lane 0 of the first wave the longest (a second round then holds the shortest ones).
+          const int chi = nc - 1 - (k0 + (tid & ~63));             // this wave's candidates: chi - lane, down to clo
+          if (chi < 0) continue;
+          const int clo = chi - 63 > 0 ? chi - 63 : 0;
+          const int c = chi - lane;
+          // The two means (crossCorr :343-352 sums x and y sequentially in double). The samples are floats of magnitude
+          // <= 1 and >= 2^-15 (or zero), i.e. multiples of 2^-38, so every partial sum of up to 2^12 of them is exact in
+          // double in ANY order: the sums are formed by a wave reduction up to the shortest candidate and a scan over the
+          // candidates instead of one pass over the samples per candidate, with bit-identical results.
+          const long nb = T0minF + clo;
+          double bx = 0.0, bp = 0.0;
+          for (long i = lane; i < nb; i += 64) { bx += (double)wv[start + i]; bp += (double)wv[start + nb + i]; }
+          double ex = 0.0, ep = 0.0;
+          if (c > clo) {
+            const long tfc = T0minF + c;
+            ex = (double)wv[start + tfc - 1];
+            ep = (double)wv[start + 2 * tfc - 2] + (double)wv[start + 2 * tfc - 1];
+          }
+          for (int of = 32; of > 0; of >>= 1) { bx += __shfl_xor(bx, of); bp += __shfl_xor(bp, of); }
+          for (int of = 1; of < 64; of <<= 1) {                    // inclusive scan towards the longer candidates (the lower lanes)
+            const double ox = __shfl_down(ex, of), op = __shfl_down(ep, of);
+            if (lane + of < 64) { ex += ox; ep += op; }
+          }
+          if (c < clo) continue;
           const long tf = T0minF + c;
           const float *xa = wv + start, *ya = wv + start + tf;
-          // both passes in rounds of eight samples, the next round's samples loaded before the current round's sums
-          // (the sums stay sequential in the reference's order)
           const long nr = tf >> 3;
-          double mx = 0.0, my = 0.0;
-          {
-            float xv[8], yv[8], xn[8], yn[8];            // kept as float, widened where they enter the sums (exact)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }      // (reads past tf stay inside wv: start + 2 tf < nT)
-            for (long r = 0; r < nr; ++r) {
-              const long i1 = (r + 1) << 3;
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { mx += (double)xv[q]; my += (double)yv[q]; }
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if ((nr << 3) + q < tf) { mx += (double)xv[q]; my += (double)yv[q]; }
-          }
-          mx /= (double)tf;
-          my /= (double)tf;
+          const double sx = bx + ex, sy = (bx + bp + ep) - sx;     // sum of x[0..tf), sum of x[tf..2tf)
+          const double mx = sx / (double)tf, my = sy / (double)tf;
+          // one pass in rounds of eight samples, the next round's samples loaded before the current round's sums (the
+          // sums stay sequential in the reference's order)
           double cc = 0.0, nx = 0.0, ny = 0.0;
           {
             float xv[8], yv[8], xn[8], yn[8];
