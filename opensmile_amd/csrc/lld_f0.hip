@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "lld_blocks.hpp"
+#include "lld_fft.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
@@ -117,31 +118,28 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
 __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const int16_t *x, const float *mag_in, int lane,
                                               double *A, double *B) {
-  float *re = reinterpret_cast<float *>(A), *im = re + kM;
+  float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
   double esum = 0.0;
   double mg[kPer];
   if (mag_in) {                                          // per-component mode: cSpecScale on a given magnitude spectrum
     F0_FOR_BINS(m, k) mg[m] = (k < kK) ? (double)mag_in[k] : 0.0;
   } else {
-  // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168)
-#pragma unroll
-  for (int m = 0; m < kM / 64; ++m) {
-    const int i = lane + 64 * m;
+  // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168); the transform's first pass
+  // asks for the inputs it needs (lld_fft.hpp)
+  WaveFft<9>::forward(z, T.twh, lane, [&](int i) {
     const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
     float a = 0.0f, b = 0.0f;
     if (n0 >= 0 && n0 < Q.N) { a = pcm16_to_float(x[n0]) * T.win[n0]; const float sq = a * a; esum += (double)sq; }
     if (n1 >= 0 && n1 < Q.N) { b = pcm16_to_float(x[n1]) * T.win[n1]; const float sq = b * b; esum += (double)sq; }
-    const int r = (int)(__brev((unsigned)i) >> (32 - 9));
-    re[r] = a;
-    im[r] = b;
-  }
-  esum = WaveG::sum(esum, nullptr);
-  WaveG::sync();
-  group_cfft_radix2<WaveG>(re, im, kM, T.twh);
+    return make_float2(a, b);
+  });
+  // (lane l summed the inputs brev6(l) + 64 k: low offsets first is the tree the sum had when lane l held l + 64 m)
+  for (int o = 1; o < 64; o <<= 1) esum += __shfl_xor(esum, o);
   F0_FOR_BINS(m, k) {
     mg[m] = 0.0;
-    if (k < kK) mg[m] = (double)bin_magnitude(untangle_bin(re, im, kM, k, T.twf), k == 0 || k == kM);
+    if (k < kK) mg[m] = (double)bin_magnitude(fft_untangle<WaveFft<9>>(z, k, T.twf), k == 0 || k == kM);
   }
+  WaveG::sync();                                         // the transform's buffer reaches into B
   }
   F0_FOR_BINS(m, k) if (k < kK) B[k] = mg[m];
   WaveG::sync();

@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "lld_blocks.hpp"
+#include "lld_fft.hpp"
 #include "lld_blocks_compare.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
@@ -674,10 +675,10 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
   for (int i = threadIdx.x; i < kHM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
   for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
   __syncthreads();                                       // the only workgroup barrier
-  constexpr int per_wave = 2 * kHM + 2 * kHKP + 4 * 128;
-  float *re = reinterpret_cast<float *>(c_twf + (kHM / 2 + 4)) + (size_t)wave * per_wave;
-  float *im = re + kHM;
-  float *mg = im + kHM;
+  using Fft = WaveFft<9>;                                // kHM == 512: fused passes on (re, im) pairs, lld_fft.hpp
+  constexpr int per_wave = 2 * Fft::kZ + 2 * kHKP + 4 * 128;
+  float2 *z = reinterpret_cast<float2 *>(c_twf + (kHM / 2 + 4)) + (size_t)wave * (per_wave / 2);
+  float *mg = reinterpret_cast<float *>(z + Fft::kZ);
   float *acf = mg + kHKP;
   int *hbin = reinterpret_cast<int *>(acf + kHKP);
   float *hfi = reinterpret_cast<float *>(hbin + 128);
@@ -716,15 +717,12 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
         for (int k = lane; k <= kHM; k += 64) mg[k] = mi[k];
       } else {
         const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
-        for (int i = lane; i < kHM; i += 64) {
+        Fft::forward(z, c_twh, lane, [&](int i) {
           const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
-          const int r = (int)(__brev((unsigned)i) >> (32 - 9));
-          re[r] = (n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f;
-          im[r] = (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f;
-        }
-        WaveG::sync();
-        group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
-        for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(untangle_bin(re, im, kHM, k, c_twf), k == 0 || k == kHM);
+          return make_float2((n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f,
+                             (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f);
+        });
+        for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
       }
       WaveG::sync();
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
@@ -733,18 +731,12 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
       WaveG::sync();
       {
         const int n = 2 * kHM;
-        for (int i = lane; i < kHM; i += 64) {
+        Fft::forward(z, c_twh, lane, [&](int i) {
           const int n0 = 2 * i, n1 = 2 * i + 1;
-          const float v0 = R[n0 <= kHM ? n0 : n - n0];
-          const float v1 = R[n1 <= kHM ? n1 : n - n1];
-          const int r = (int)(__brev((unsigned)i) >> (32 - 9));
-          re[r] = v0;
-          im[r] = v1;
-        }
-        WaveG::sync();
-        group_cfft_radix2<WaveG>(re, im, kHM, c_twh);
+          return make_float2(R[n0 <= kHM ? n0 : n - n0], R[n1 <= kHM ? n1 : n - n1]);
+        });
         for (int k = lane; k <= kHM; k += 64) {
-          const float a = 0.5f * untangle_bin(re, im, kHM, k, c_twf).x;
+          const float a = 0.5f * fft_untangle<Fft>(z, k, c_twf).x;
           acf[k] = fabsf(a) / (float)kHK;
         }
         WaveG::sync();
@@ -1077,7 +1069,7 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
   if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
   const int NP = (Q.N + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)NP + sizeof(float2) * (size_t)(kHM / 2 + kHM / 2 + 4) +
-                     sizeof(float) * 4 * (size_t)(2 * kHM + 2 * kHKP + 4 * 128);
+                     sizeof(float) * 4 * (size_t)(2 * WaveFft<9>::kZ + 2 * kHKP + 4 * 128);
   const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
