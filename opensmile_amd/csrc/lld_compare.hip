@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "lld_blocks.hpp"
+#include "lld_fft.hpp"
 #include "lld_blocks_compare.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 // The same frame pipeline with ONE wave per frame and four independent runs per workgroup: no workgroup barriers after
 // the table staging, the thinly parallel sections (26 mel bands, 14 cepstra, scalar tails) of four frames overlap. Every sum
 // keeps the block kernel's order (lld_blocks_compare.hpp), so the two kernels give bit-identical rows.
-// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave yv[Npad] | re[M] | im[M] | mg[Kpad] | pw[Kpad] | prev[Kpad] |
+// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave z[fft_pairs(M)] pairs | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // mel[32] | aud[32] | lmel[32]
 __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,11 +197,11 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
-  const int per_wave = Npad + 2 * M + 3 * Kpad + 96;
-  float *yv = s_dct + 16 * 32 + wave * per_wave;
-  float *re = yv + Npad;
-  float *im = re + M;
-  float *mg = im + M;
+  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 96;
+  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + wave * per_wave);   // the transform's (re, im) pairs, lld_fft.hpp
+  const int zpad = fft_pad(M);
+  float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
+  float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
   float *pw = mg + Kpad;
   float *prev = pw + Kpad;
   float *melv = prev + Kpad;
@@ -240,16 +241,13 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
     float *rawB = Q.rawB + (f0 + t) * 55;
     for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
     WaveG::sync();
-    for (int i = lane; i < M; i += 64) {
+    wave_cfft(z, M, P.tw_half, lane, [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
-      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
-      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
-    }
-    WaveG::sync();
-    group_cfft_radix2<WaveG>(re, im, M, P.tw_half);
+      return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
+                         (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
+    });
     for (int k = lane; k <= M; k += 64) {
-      const float m = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
+      const float m = bin_magnitude(wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;
     }
@@ -281,7 +279,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
       for (int w = 0; w < 4; ++w) {
         const int tid = lane + 64 * w;
         v0[w][0] = 0.0; v0[w][1] = 0.0;
-        for (int n = tid; n < P.N; n += 256) { const float tmp = yv[n]; v0[w][0] += tmp * tmp; }
+        for (int n = tid; n < P.N; n += 256) { const float tmp = pcm16_to_float(x[n]); v0[w][0] += tmp * tmp; }   // (yv is gone by now)
         if (t < T60)
           for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
             const float a = pcm16_to_float(x[i - 1]), b = pcm16_to_float(x[i]), c = pcm16_to_float(x[i + 1]);
@@ -450,7 +448,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (Npad + 2 * M + 3 * Kpad + 96));
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
     hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }
   hipError_t e = hipGetLastError();

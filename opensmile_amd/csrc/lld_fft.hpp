@@ -161,4 +161,60 @@ __device__ __forceinline__ float2 fft_untangle(const float2 *z, int k, const flo
   return make_float2(0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr)), 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si)));
 }
 
+// ---- run-time M (the kernels whose frame geometry is a parameter): the fused forms for M = 512 / 256, otherwise the
+// in-place radix-2 stages on pairs in natural order. fft_pairs(M): pairs of LDS the transform needs; fft_pad(M): Z[e] sits at
+// z[e + (e >> 6) * fft_pad(M)].
+__host__ __device__ inline int fft_pairs(int M) { return M == 512 ? WaveFft<9>::kZ : (M == 256 ? WaveFft<8>::kZ : M); }
+__host__ __device__ inline int fft_pad(int M) { return M == 512 ? 8 : (M == 256 ? 16 : 0); }
+
+template <class Load>
+__device__ __forceinline__ void wave_cfft(float2 *z, int M, const float2 *tw_half, int lane, Load load) {
+  if (M == 512) { WaveFft<9>::forward(z, tw_half, lane, load); return; }
+  if (M == 256) { WaveFft<8>::forward(z, tw_half, lane, load); return; }
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  for (int i = lane; i < M; i += 64) z[(int)(__brev((unsigned)i) >> (32 - logM))] = load(i);
+  fft_wave_sync();
+  for (int len = 2; len <= M; len <<= 1) {
+    const int half = len >> 1, tstep = M / len;
+    for (int b = lane; b < (M >> 1); b += 64) {
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j;
+      float2 p0 = z[i0], p1 = z[i0 + half];
+      fft_bfly(p0, p1, tw_half[j * tstep]);
+      z[i0 + half] = p1;
+      z[i0] = p0;
+    }
+    fft_wave_sync();
+  }
+}
+
+__device__ __forceinline__ float2 wave_untangle(const float2 *z, int M, int pad, int k, const float2 *tw_full) {
+  if (k == 0) { const float2 a = z[0]; return make_float2(a.x + a.y, 0.0f); }
+  if (k == M) { const float2 a = z[0]; return make_float2(a.x - a.y, 0.0f); }
+  const int k2 = M - k;
+  const float2 p = z[k + (k >> 6) * pad], q = z[k2 + (k2 >> 6) * pad];
+  const float a = p.x, b = p.y, c = q.x, d = q.y;
+  const float2 w = (k <= (M >> 1)) ? tw_full[k] : make_float2(-tw_full[M - k].x, tw_full[M - k].y);
+  const float sr = a + c, si = b - d, dr = a - c, di = b + d;
+  return make_float2(0.5f * fmaf(w.x, di, fmaf(w.y, dr, sr)), 0.5f * fmaf(w.y, di, fmaf(-w.x, dr, si)));
+}
+
+// group_irfft_even (lld_blocks.hpp) on the fused transform: out[k] = (Re X[k] / 2) / inv_norm (or its magnitude), k < M, of
+// the even extension of the real spectrum R[0..M]
+__device__ __forceinline__ void wave_irfft_even(const float *R, float2 *z, int M, const float2 *tw_half, const float2 *tw_full,
+                                                float *out, float inv_norm, bool take_abs, int lane) {
+  const int n = 2 * M, pad = fft_pad(M);
+  wave_cfft(z, M, tw_half, lane, [&](int i) {
+    const int n0 = 2 * i, n1 = 2 * i + 1;
+    return make_float2(R[n0 <= M ? n0 : n - n0], R[n1 <= M ? n1 : n - n1]);
+  });
+  for (int k = lane; k < M; k += 64) {
+    const float a = 0.5f * wave_untangle(z, M, pad, k, tw_full).x;
+    const float v = a / inv_norm;                       // acf.cpp:321-325: (FLOAT_DMEM)data / (FLOAT_DMEM)Nsrc
+    out[k] = take_abs ? fabsf(v) : v;
+  }
+  fft_wave_sync();
+}
+
 }  // namespace smilehip

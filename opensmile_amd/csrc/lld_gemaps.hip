@@ -139,7 +139,7 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ 20 ms frames
-// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave yv[Npad] | re[M] | im[M] | mg[Kpad] | pw[Kpad] | prev[Kpad] |
+// LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave z[fft_pairs(M)] pairs | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // lg[64] | mel[32] | aud[32] | lmel[32]
 __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsParams G, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -156,11 +156,11 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
-  const int per_wave = Npad + 2 * M + 3 * Kpad + 64 + 96;
-  float *yv = s_dct + 16 * 32 + wave * per_wave;
-  float *re = yv + Npad;
-  float *im = re + M;
-  float *mg = im + M;
+  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 64 + 96;
+  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + wave * per_wave);   // the transform's (re, im) pairs, lld_fft.hpp
+  const int zpad = fft_pad(M);
+  float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
+  float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
   float *pw = mg + Kpad;
   float *prev = pw + Kpad;
   float *lg = prev + Kpad;
@@ -176,23 +176,29 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   const int T20 = (int)(P.frame_off[u + 1] - f0);
   const int16_t *xu = P.pcm + P.samp_off[u];
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  const int lane_in = lane;
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+    int lane = lane_in;                                  // opaque per frame (see lld_compare_frame_wave): nothing that depends on
+    asm volatile("" : "+v"(lane));                       // the lane only is kept in registers across the frame loop
     const bool warm = t < t0;
     const int16_t *x = xu + (int64_t)t * P.H;
     float *raw = G.raw20 + (f0 + t) * 12;
     for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
     WaveG::sync();
-    for (int i = lane; i < M; i += 64) {
-      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
-      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
-      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+    // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
+    double e2 = 0.0;
+    if (!warm) {
+      for (int n = lane; n < P.N; n += 64) { const float tmp = yv[n]; e2 += tmp * tmp; }
+      e2 = WaveG::sum(e2, nullptr);
     }
-    WaveG::sync();
-    group_cfft_radix2<WaveG>(re, im, M, P.tw_half);
+    wave_cfft(z, M, P.tw_half, lane, [&](int i) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
+                         (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
+    });
     float *spec = G.spec220 + (f0 + t) * kRsI;
     for (int k = lane; k <= M; k += 64) {
-      const float2 X = untangle_bin(re, im, M, k, P.tw_full);
+      const float2 X = wave_untangle(z, M, zpad, k, P.tw_full);
       const float m = bin_magnitude(X, k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;                                     // squareInput (spectral.cpp:677-684) == melspec usePower
@@ -224,13 +230,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       for (int i = 0; i < P.n_bands; i++) d += aud[i];
       raw[0] = d / (float)P.n_bands;
     }
-    // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
-    {
-      double d = 0.0;
-      for (int n = lane; n < P.N; n += 64) { const float tmp = yv[n]; d += tmp * tmp; }
-      d = WaveG::sum(d, nullptr);
-      if (lane == 0) raw[10] = (float)(d / (double)P.N) * 1.0f + 0.0f;
-    }
+    if (lane == 0) raw[10] = (float)(e2 / (double)P.N) * 1.0f + 0.0f;
     gemaps_spectral_wave(mg, pw, prev, t == 0, lg, G, K, lane, raw + 1);
     if (lane == 0) raw[11] = 0.0f;
     WaveG::sync();
@@ -686,6 +686,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
   float *hlr = hmag + 128;
   const double Fb = 1.0 / G.fsSec60;                     // frequency axis of the 60 ms spectrum: frq[i] = Fb * i
   const int tile_stride = (int)gridDim.x * 4;
+  const int lane_in = lane;
   const bool rows_mode = G.op_mode == 1;                 // per-component operator: F0, formants and magnitudes given per row
   const int n_tiles = rows_mode ? (int)((G.op_rows + 7) / 8) : G.n_tiles60;
   for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
@@ -702,6 +703,8 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
       r20 = row0 - G.frame_off60[lo] + P.frame_off[lo];
     }
     for (int tf = 0; tf < n_fr; ++tf) {
+      int lane = lane_in;                                // opaque per frame (see lld_compare_frame_wave)
+      asm volatile("" : "+v"(lane));
       const int64_t g = row0 + tf;
       const float F0 = rows_mode ? G.op_f0[g] : G.pitch3[g * 3];
       float *o = rows_mode ? G.op_out + g * G.op_ld_out : G.harm6 + g * 6;
@@ -1052,7 +1055,7 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   if (P.Nfft != 512 || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (Npad + 2 * M + 3 * Kpad + 64 + 96));
+  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (2 * fft_pairs(M) + 3 * Kpad + 64 + 96));
   hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -1074,7 +1077,7 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   unsigned grid = (unsigned)((n_tiles + 3) / 4);
-  if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);
+  if (grid > (unsigned)(3 * max_blocks)) grid = (unsigned)(3 * max_blocks);   // 51 KB of LDS per workgroup: three per CU
   hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(256), lds, s, P, Q, G);
   return hipGetLastError();
 }

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "lld_blocks.hpp"
@@ -27,9 +28,12 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   const int Npad = (P.N + 3) & ~3;
   float *xr = smem;
   float *yv = xr + Npad;
-  float *re = yv + Npad;
+  float *re = yv + Npad;                                 // wave form: fft_pairs(M) (re, im) pairs, lld_fft.hpp
   float *im = re + M;
-  float *mg = im + M;
+  float2 *z = reinterpret_cast<float2 *>(re);
+  constexpr bool kWave = std::is_same<G, WaveG>::value;
+  const int zpad = fft_pad(M);
+  float *mg = re + 2 * fft_pairs(M);
   float *sp = mg + ((P.K + 3) & ~3);
   float *acf = sp + ((P.K + 3) & ~3);
   float *cep = acf + M;
@@ -74,16 +78,25 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     if (G::tid() == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
   }
   // R4 forward real FFT
-  for (int i = G::tid(); i < M; i += G::size()) {
-    const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-    const int r = (int)(__brev((unsigned)i) >> (32 - logM));
-    re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f;
-    im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f;
+  if constexpr (kWave) {
+    wave_cfft(z, M, P.tw_half, G::tid(), [&](int i) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f);
+    });
+    for (int k = G::tid(); k <= M; k += 64)
+      mg[k] = bin_magnitude(wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);   // R5
+  } else {
+    for (int i = G::tid(); i < M; i += G::size()) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f;
+      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f;
+    }
+    G::sync();
+    group_cfft_radix2<G>(re, im, M, P.tw_half);
+    for (int k = G::tid(); k <= M; k += G::size())
+      mg[k] = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);     // R5
   }
-  G::sync();
-  group_cfft_radix2<G>(re, im, M, P.tw_half);
-  for (int k = G::tid(); k <= M; k += G::size())
-    mg[k] = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);       // R5
   G::sync();
   // R6 / R7: mel (usePower per config) -> log -> DCT
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
@@ -98,13 +111,15 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
   G::sync();
-  group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
+  if constexpr (kWave) wave_irfft_even(sp, z, M, P.tw_half, P.tw_full, acf, (float)P.K, true, G::tid());
+  else group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
   for (int k = G::tid(); k <= M; k += G::size()) {
     const float p = mg[k] * mg[k];
     sp[k] = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                              // :288-305
   }
   G::sync();
-  group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
+  if constexpr (kWave) wave_irfft_even(sp, z, M, P.tw_half, P.tw_full, cep, (float)P.K, false, G::tid());
+  else group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
 
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
   double voicing, Tsamp;
@@ -177,7 +192,7 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   if (P.total_frames <= 0) return hipSuccess;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(2 * Npad + 2 * M + 2 * Kpad + 2 * M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
+  const size_t lds = sizeof(float) * (size_t)(2 * Npad + 2 * fft_pairs(M) + 2 * Kpad + 2 * M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
   hipError_t e;
   if (4 * lds <= 64 * 1024 && !getenv("SMILEHIP_IS09_BLOCK")) {       // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds + 15) / 16) * 4;

@@ -620,11 +620,17 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
     F0Params Q;
     fill_f0_params(plan->f0_plan, Q);
     Q.jit_shim_db = b->d_shim.p;
-    e = launch_f0_jitter(P60, Q, b->d_pitch3.p, 3, b->d_jit4.p, s);
+    // cPitchJitter is one wave per utterance and latency-bound (a fifth of the VALU issue slots): it runs on the plan's
+    // lowest-priority stream beside the 20 ms chain and cHarmonics instead of holding the wave slots they need
+    HIP_TRY(hipEventRecord(plan->ev_bg_fork, s));
+    HIP_TRY(hipStreamWaitEvent(plan->bg_stream, plan->ev_bg_fork, 0));
+    e = launch_f0_jitter(P60, Q, b->d_pitch3.p, 3, b->d_jit4.p, plan->bg_stream);
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "jitter kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(plan->ev_bg_join, plan->bg_stream));
     HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));                          // cHarmonics reads the formants
     e = launch_gemaps_harm(P, Q, G, plan->ctx->prop.multiProcessorCount, s);
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "harmonics kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamWaitEvent(s, plan->ev_bg_join, 0));
   } else {
     HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
   }

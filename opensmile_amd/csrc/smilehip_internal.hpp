@@ -96,6 +96,8 @@ struct smilehip_plan {
   smilehip_plan *f0_plan = nullptr;
   hipStream_t side_stream = nullptr;      // whole-level chain: groups A+B run here, concurrently with the F0 group
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t bg_stream = nullptr;        // eGeMAPS: cPitchJitter (one wave per utterance, latency-bound) at the lowest priority, beside
+  hipEvent_t ev_bg_fork = nullptr, ev_bg_join = nullptr;   // the 20 ms chain and cHarmonics
   F0Host f0;
   DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
   DevBuf<int32_t> d_f0_k;
@@ -121,6 +123,9 @@ struct smilehip_plan {
     if (side_stream) (void)hipStreamDestroy(side_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (bg_stream) (void)hipStreamDestroy(bg_stream);
+    if (ev_bg_fork) (void)hipEventDestroy(ev_bg_fork);
+    if (ev_bg_join) (void)hipEventDestroy(ev_bg_join);
     for (auto &slot : ev)
       for (auto &e : slot)
         if (e) (void)hipEventDestroy(e);

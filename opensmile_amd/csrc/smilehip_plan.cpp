@@ -475,6 +475,12 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
                               hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
       rc = fail(SMILEHIP_ERR_HIP, "could not create the side stream of the eGeMAPS chain");
+    int prio_least = 0, prio_greatest = 0;
+    if (rc == SMILEHIP_OK && (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+                              hipStreamCreateWithPriority(&p->bg_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_bg_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&p->ev_bg_join, hipEventDisableTiming) != hipSuccess))
+      rc = fail(SMILEHIP_ERR_HIP, "could not create the background stream of the eGeMAPS chain");
   }
   if (rc != SMILEHIP_OK) {
     delete p;
