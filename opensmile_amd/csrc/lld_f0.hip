@@ -1292,7 +1292,7 @@ __global__ void __launch_bounds__(64) lld_f0_lld(const int64_t *frame_off, const
 
 int f0_tile_frames() { return kTileFrames; }
 
-int f0_chunk_tiles() { return 16384; }                 // 131 072 frames = 1.08 GB of scratch rows per chunk
+int f0_chunk_tiles() { return 16384; }                 // 131 072 frames = 1.08 GB of scratch rows per chunk (smaller chunks measured slower: 8192 +1 %, 4096 +6 %, 2048 +14 %)
 
 hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
                      hipEvent_t frames_done) {

@@ -604,16 +604,19 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   // The F0 group's frame kernels fill the device, its Viterbi and jitter passes are one wave per utterance: the 20 ms chain
   // (frame kernel, resampling + LPC, formant roots) starts on the side stream when the frame kernels are done
   hipError_t e = hipSuccess;
+  // SMILEHIP_SERIAL=1 (measurement aid): everything on the caller's stream, so that a kernel trace shows each kernel alone
+  static const bool serial = getenv("SMILEHIP_SERIAL") != nullptr;
+  hipStream_t side = serial ? s : plan->side_stream, bg = serial ? s : plan->bg_stream;
   if (fb->total_frames > 0) {
     int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch3.p, 3, stream, true, plan->ev_fork);   // SHS candidates -> Viterbi -> energy gate
     if (rc) return rc;
   } else {
     HIP_TRY(hipEventRecord(plan->ev_fork, s));
   }
-  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-  e = launch_gemaps_frames(P, G, b->n_runs, plan->side_stream);
+  HIP_TRY(hipStreamWaitEvent(side, plan->ev_fork, 0));
+  e = launch_gemaps_frames(P, G, b->n_runs, side);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS 20 ms kernels: launch failed: %s", hipGetErrorString(e));
-  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
+  HIP_TRY(hipEventRecord(plan->ev_join, side));
   if (fb->total_frames > 0) {
     LldParams P60;
     fill_params(plan->f0_plan, fb, d_pcm, nullptr, 0, P60);
@@ -623,10 +626,10 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
     // cPitchJitter is one wave per utterance and latency-bound (a fifth of the VALU issue slots): it runs on the plan's
     // lowest-priority stream beside the 20 ms chain and cHarmonics instead of holding the wave slots they need
     HIP_TRY(hipEventRecord(plan->ev_bg_fork, s));
-    HIP_TRY(hipStreamWaitEvent(plan->bg_stream, plan->ev_bg_fork, 0));
-    e = launch_f0_jitter(P60, Q, b->d_pitch3.p, 3, b->d_jit4.p, plan->bg_stream);
+    HIP_TRY(hipStreamWaitEvent(bg, plan->ev_bg_fork, 0));
+    e = launch_f0_jitter(P60, Q, b->d_pitch3.p, 3, b->d_jit4.p, bg);
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "jitter kernel launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(plan->ev_bg_join, plan->bg_stream));
+    HIP_TRY(hipEventRecord(plan->ev_bg_join, bg));
     HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));                          // cHarmonics reads the formants
     e = launch_gemaps_harm(P, Q, G, plan->ctx->prop.multiProcessorCount, s);
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "harmonics kernel launch failed: %s", hipGetErrorString(e));
