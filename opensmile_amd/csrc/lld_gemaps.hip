@@ -635,10 +635,11 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 // consecutive 60 ms frames; unvoiced frames (F0final == 0) only write the constants the reference emits.
 // The 60 ms magnitude spectrum is recomputed here (window + FFT 1024) rather than kept from the pitch kernel: 2 KB per
 // frame of HBM traffic each way would cost more than the transform.
-// LDS: shared win[NP] | twh[256] | twf[260]; per wave re[512] | im[512] | mg[516] | acf[516] | hbin[128] | hfi[128] | hmag[128] |
-// hlr[128]
+// LDS: shared win[NP] | twh[256] | twf[260]; per wave z[576 pairs] (later hbin[128] | hfi[128] | hmag[128] | hlr[128]) |
+// mg[516] | acf[516]
 namespace {
 constexpr int kHM = 512, kHK = 513, kHKP = 516;
+constexpr int kHarmWaves = 8;                          // 8.7 KB of LDS per wave + 7.9 KB of tables per workgroup: two workgroups = 16 waves per CU
 __device__ __forceinline__ int harm_is_peak(const float *x, int N, int n) {  // cHarmonics::isPeak, :369-390
   if (n >= N || n < 0) return 0;
   if (n + 1 < N) {
@@ -663,7 +664,7 @@ __device__ __forceinline__ int harm_freq_to_bin(double Fb, float freq) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, GemapsParams G) {
+__global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, F0Params Q, GemapsParams G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -676,20 +677,20 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
   for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
   __syncthreads();                                       // the only workgroup barrier
   using Fft = WaveFft<9>;                                // kHM == 512: fused passes on (re, im) pairs, lld_fft.hpp
-  constexpr int per_wave = 2 * Fft::kZ + 2 * kHKP + 4 * 128;
+  constexpr int per_wave = 2 * Fft::kZ + 2 * kHKP;
   float2 *z = reinterpret_cast<float2 *>(c_twf + (kHM / 2 + 4)) + (size_t)wave * (per_wave / 2);
   float *mg = reinterpret_cast<float *>(z + Fft::kZ);
   float *acf = mg + kHKP;
-  int *hbin = reinterpret_cast<int *>(acf + kHKP);
+  int *hbin = reinterpret_cast<int *>(z);                // the harmonics' arrays live in the transform's buffer (dead after the ACF)
   float *hfi = reinterpret_cast<float *>(hbin + 128);
   float *hmag = hfi + 128;
   float *hlr = hmag + 128;
   const double Fb = 1.0 / G.fsSec60;                     // frequency axis of the 60 ms spectrum: frq[i] = Fb * i
-  const int tile_stride = (int)gridDim.x * 4;
+  const int tile_stride = (int)gridDim.x * kHarmWaves;
   const int lane_in = lane;
   const bool rows_mode = G.op_mode == 1;                 // per-component operator: F0, formants and magnitudes given per row
   const int n_tiles = rows_mode ? (int)((G.op_rows + 7) / 8) : G.n_tiles60;
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_stride) {
+  for (int tile = blockIdx.x * kHarmWaves + wave; tile < n_tiles; tile += tile_stride) {
     int64_t samp0 = 0, row0 = (int64_t)tile * 8, r20 = (int64_t)tile * 8;
     int n_fr = (int)((G.op_rows - row0 < 8) ? G.op_rows - row0 : 8);
     if (!rows_mode) {
@@ -729,14 +730,12 @@ __global__ void __launch_bounds__(256) lld_gemaps_harm(LldParams P, F0Params Q, 
       }
       WaveG::sync();
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
-      float *R = acf;                                    // squared magnitudes first, overwritten by the lags
-      for (int k = lane; k <= kHM; k += 64) R[k] = mg[k] * mg[k];
-      WaveG::sync();
       {
         const int n = 2 * kHM;
-        Fft::forward(z, c_twh, lane, [&](int i) {
+        Fft::forward(z, c_twh, lane, [&](int i) {        // the squared magnitudes, formed as they are asked for
           const int n0 = 2 * i, n1 = 2 * i + 1;
-          return make_float2(R[n0 <= kHM ? n0 : n - n0], R[n1 <= kHM ? n1 : n - n1]);
+          const float m0 = mg[n0 <= kHM ? n0 : n - n0], m1 = mg[n1 <= kHM ? n1 : n - n1];
+          return make_float2(m0 * m0, m1 * m1);
         });
         for (int k = lane; k <= kHM; k += 64) {
           const float a = 0.5f * fft_untangle<Fft>(z, k, c_twf).x;
@@ -1072,13 +1071,13 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
   if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
   const int NP = (Q.N + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)NP + sizeof(float2) * (size_t)(kHM / 2 + kHM / 2 + 4) +
-                     sizeof(float) * 4 * (size_t)(2 * WaveFft<9>::kZ + 2 * kHKP + 4 * 128);
+                     sizeof(float) * kHarmWaves * (size_t)(2 * WaveFft<9>::kZ + 2 * kHKP);
   const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  unsigned grid = (unsigned)((n_tiles + 3) / 4);
-  if (grid > (unsigned)(3 * max_blocks)) grid = (unsigned)(3 * max_blocks);   // 51 KB of LDS per workgroup: three per CU
-  hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(256), lds, s, P, Q, G);
+  unsigned grid = (unsigned)((n_tiles + kHarmWaves - 1) / kHarmWaves);
+  if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);   // 78 KB of LDS per workgroup: two per CU
+  hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(kHarmWaves * 64), lds, s, P, Q, G);
   return hipGetLastError();
 }
 
