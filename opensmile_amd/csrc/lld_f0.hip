@@ -868,6 +868,16 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi_step(F0Params Q, const floa
 // Time meta of frame t as the framer derives it from a wave level without stored time stamps
 // (dataMemoryLevel.cpp:617-626,1226-1245): lengthSec = ((tH+N-1)Tw - tH Tw) + Tw, so lenF = ceil(lengthSec/Tw) is N or N+1.
 namespace {
+// Values that are the same in every lane but come out of vector instructions (loads through a vector address, double
+// arithmetic, wave reductions): moved to scalar registers, so that everything derived from them -- loop bounds, sample
+// positions, addresses -- is scalar work and stops occupying a vector register per value.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni(long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v & 0xffffffffu));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 constexpr int kJitCap = 2560;      // samples of wave the kernel can hold per frame (frame + left-over of the previous frames)
 constexpr int kJitMaxCand = 192;   // candidate period lengths per step: T0maxF - T0minF + 1 <= 156 for F0 >= 52 Hz
 constexpr int kJitMaxPeriod = 448; // T0f + 1 <= 309
@@ -894,7 +904,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   const int16_t *x = P.pcm + s0;
   const double Tw = Q.jit_Tw;
   const int N = Q.N, H = Q.H;
-  const long ppLen = (long)ceil(Q.jit_step_sec / Tw);
+  const long ppLen = uni((long)ceil(Q.jit_step_sec / Tw));
   PHASE_DECL
   long lastIdx = 0, lastMis = 0;
   float lastT0 = 0.0f, lastDiff = 0.0f, lastJL = 0.0f, lastJD = 0.0f, lastSh = 0.0f;
@@ -910,20 +920,20 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   for (int t = t_first; t < t_end; ++t) {
     int lane = lane_in, tid = tid_in;                      // opaque per frame: lane-only address arithmetic is not kept in registers
     asm volatile("" : "+v"(lane), "+v"(tid));              // across the frame loop (see f0_shs)
-    const float F0 = f0[(fo + t) * ld_f0];
+    const float F0 = uni(f0[(fo + t) * ld_f0]);
     const double time = (double)((long)t * H) * Tw;
     const double lengthSec = ((double)((long)t * H + N - 1) * Tw - (double)((long)t * H) * Tw) + Tw;
-    const long lenF = (long)ceil(lengthSec / Tw);
-    const long startVidx = (long)round(time / Tw);
+    const long lenF = uni((long)ceil(lengthSec / Tw));
+    const long startVidx = uni((long)round(time / Tw));
     long toRead0 = ppLen + lastMis, toRead = toRead0;
     double Tf = 0.0;
     long T0f = 0, T0minF = 0, T0maxF = 0;
     if (F0 > 0.0f) {
       const double T0 = 1.0 / F0;
       Tf = T0 / Tw;
-      T0f = (long)round(Tf);
-      T0minF = (long)floor((1.0 - Q.jit_search_range) * Tf);
-      T0maxF = (long)ceil((1.0 + Q.jit_search_range) * Tf);
+      T0f = uni((long)round(Tf));
+      T0minF = uni((long)floor((1.0 - Q.jit_search_range) * Tf));
+      T0maxF = uni((long)ceil((1.0 + Q.jit_search_range) * Tf));
       const long two_pp = 2 * T0maxF + 2;
       if (toRead < two_pp) toRead = two_pp;
     }
@@ -1035,7 +1045,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           const int oi = __shfl_xor(bi, of);
           if (oi != (1 << 30) && (bi == (1 << 30) || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
         }
-        const long maxI = (bi == (1 << 30)) ? -1 : bi;
+        const long maxI = (bi == (1 << 30)) ? -1 : uni(bi);
         pp = (maxI == -1) ? T0f : T0minF + maxI;
         const long os = start;
         if (maxI >= 0) {
@@ -1129,7 +1139,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       float En = 0.0f;
       long nEn = 0;
       for (int i = 0; i < numPeriods; i++) {
-        const long p0 = pbuf[i], p1 = pbuf[i + 1];
+        const long p0 = uni(pbuf[i]), p1 = uni(pbuf[i + 1]);
         const long lim = (p1 < p0 + T0f ? p1 : p0 + T0f) - 2;
         long k = 2;
         for (long j = p0 + 2; j < lim; j += 64, k += 64) {
