@@ -18,4 +18,4 @@ for r in rows[start:end + 1]:
     else:
         agg[n] = [s, e, 1, e - s]
 for n, (s, e, c, busy) in agg.items():
-    print(f"{n:36s} {s:8.2f} .. {e:8.2f} ms  x{c:<3d} busy {busy:7.2f}  vgpr {r['VGPR_Count'] if False else ''}")
+    print(f"{n:36s} {s:8.2f} .. {e:8.2f} ms  x{c:<3d} busy {busy:7.2f} ms")
