@@ -1790,23 +1790,34 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
 #define COMPONENT_NAME_CHIPLLDSOURCE "cHipLldSource"
 #define COMPONENT_DESCRIPTION_CHIPLLDSOURCE "Reads a wave file and writes the LLD rows of a whole feature set, computed by the fused HIP kernels of libsmilehip, to a dataMemory level."
 class cHipLldSource : public cDataSource {
+  // the sets: the eight HTK-style files (rows = frames), the LLD levels of the three big sets (their own row counts and
+  // end-of-input time stamps, smilehip_row_time), and the functionals levels (ONE vector per input)
+  enum Set { kHtkVariant, kIs09, kCompare16, kIs13, kEgemaps };
   std::string filename_, set_;
   std::vector<float> rows_;
+  std::vector<double> times_;
   std::vector<std::string> names_;
   long n_rows_ = 0, next_ = 0;
-  int n_cols_ = 0;
+  int n_cols_ = 0, n_lld_ = 0;
   double period_sec_ = 0.01, frame_size_sec_ = 0.025;
   bool ran_ = false;
-  bool func16_ = false;                                  // featureSet compare16_func / is13_compare_func: ONE vector, the functionals level
-  bool is13_ = false;                                    //   ... of ComParE_2016.conf / of IS13_ComParE.conf
+  Set kind_ = kHtkVariant;
+  bool func_ = false;                                    // featureSet <set>_func: the functionals level, one vector
   cMatrix *block_ = nullptr;
 
-  void config_for(smilehip_lld_config &c) {              // any of the eight files of config/mfcc and config/plp, by name
-    if (func16_) { if (is13_) smilehip_config_is13_compare(&c); else smilehip_config_compare16(&c); return; }
-    std::string up;
+  void config_for(smilehip_lld_config &c) {
+    switch (kind_) {
+      case kIs09: smilehip_config_is09_lld(&c); return;
+      case kCompare16: smilehip_config_compare16(&c); return;
+      case kIs13: smilehip_config_is13_compare(&c); return;
+      case kEgemaps: smilehip_config_egemapsv02(&c); return;
+      default: break;
+    }
+    std::string up;                                      // any of the eight files of config/mfcc and config/plp, by name
     for (char ch : set_) up += (char)toupper((unsigned char)ch);
     if (smilehip_config_htk_variant(&c, up.c_str()) != SMILEHIP_OK)
-      COMP_ERR("cHipLldSource: unknown featureSet '%s' (mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z])", set_.c_str());
+      COMP_ERR("cHipLldSource: unknown featureSet '%s' (mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_{lld,func}, compare16_{lld,func}, "
+               "is13_compare_{lld,func}, egemapsv02_{lld,func})", set_.c_str());
   }
   void run_once() {
     smilehip_host::WaveInfo wi;
@@ -1823,27 +1834,39 @@ class cHipLldSource : public cDataSource {
     const int64_t off[2] = {0, n};
     smilehip_batch *b = nullptr;
     check(smilehip_batch_create(pl, off, 1, &b));
-    n_rows_ = (long)smilehip_batch_total_rows(b);
+    const int64_t lld_rows = smilehip_batch_total_rows(b);
+    n_rows_ = func_ ? (lld_rows > 0 ? 1 : 0) : (long)lld_rows;   // no frame -> the reference writes no functionals instance
     rows_.assign((size_t)(n_rows_ > 0 ? n_rows_ : 1) * n_cols_, 0.0f);
-    if (func16_) {
-      // LLD level (130 columns) and its functionals stay on the device; only the 6373-value vector comes back
-      const int64_t lld_rows = n_rows_;
-      n_rows_ = lld_rows > 0 ? 1 : 0;                     // no frame -> the reference writes no instance
-      if (lld_rows > 0) {
-        void *d_pcm = nullptr, *d_lld = nullptr, *d_func = nullptr;
-        check(smilehip_alloc(context(), (uint64_t)n * 2, &d_pcm));
-        check(smilehip_alloc(context(), (uint64_t)lld_rows * 130 * 4, &d_lld));
+    if (lld_rows > 0) {
+      // the LLD level (and its functionals) stay on the device; only what the level below gets comes back
+      void *d_pcm = nullptr, *d_lld = nullptr, *d_func = nullptr;
+      check(smilehip_alloc(context(), (uint64_t)n * 2, &d_pcm));
+      check(smilehip_alloc(context(), (uint64_t)lld_rows * n_lld_ * 4, &d_lld));
+      check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
+      check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, n_lld_, nullptr));
+      if (func_) {
         check(smilehip_alloc(context(), (uint64_t)n_cols_ * 4, &d_func));
-        check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
-        check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, 130, nullptr));
-        check((is13_ ? smilehip_batch_functionals_is13_compare : smilehip_batch_functionals_compare16)(
-            pl, b, (const float *)d_lld, 130, (float *)d_func, n_cols_, nullptr));
+        switch (kind_) {
+          case kIs09:
+            check(smilehip_batch_functionals(pl, b, (const float *)d_lld, n_lld_, smilehip_functionals_is09_mask(), (float *)d_func, n_cols_, nullptr));
+            break;
+          case kEgemaps: check(smilehip_batch_functionals_egemaps(pl, b, (float *)d_func, n_cols_, nullptr)); break;
+          case kIs13: check(smilehip_batch_functionals_is13_compare(pl, b, (const float *)d_lld, n_lld_, (float *)d_func, n_cols_, nullptr)); break;
+          default: check(smilehip_batch_functionals_compare16(pl, b, (const float *)d_lld, n_lld_, (float *)d_func, n_cols_, nullptr)); break;
+        }
         check(smilehip_copy_to_host(context(), rows_.data(), d_func, (uint64_t)n_cols_ * 4, nullptr));
-        check(smilehip_stream_synchronize(context(), nullptr));
-        smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld); smilehip_free(context(), d_func);
+      } else {
+        check(smilehip_copy_to_host(context(), rows_.data(), d_lld, (uint64_t)lld_rows * n_lld_ * 4, nullptr));
       }
-    } else if (n_rows_ > 0) {
-      check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows_.data()));
+      check(smilehip_stream_synchronize(context(), nullptr));
+      smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld);
+      if (d_func) smilehip_free(context(), d_func);
+    }
+    // frame time stamps of the rows: the rows a window processor emits at end of input repeat the last frame's
+    times_.assign((size_t)(n_rows_ > 0 ? n_rows_ : 1), 0.0);
+    if (!func_) {
+      const int64_t n_frames = (kind_ == kCompare16 || kind_ == kIs13 || kind_ == kEgemaps) ? lld_rows - 1 : smilehip_num_frames(pl, n);
+      for (long t = 0; t < n_rows_; ++t) times_[(size_t)t] = smilehip_row_time(pl, n_frames, t);
     }
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
@@ -1855,17 +1878,31 @@ class cHipLldSource : public cDataSource {
     cDataSource::myFetchConfig();
     filename_ = getStr("filename") ? getStr("filename") : "";
     set_ = getStr("featureSet") ? getStr("featureSet") : "mfcc12_0_d_a";
-    is13_ = !strcasecmp(set_.c_str(), "is13_compare_func");
-    func16_ = is13_ || !strcasecmp(set_.c_str(), "compare16_func");
+    std::string lo;
+    for (char ch : set_) lo += (char)tolower((unsigned char)ch);
+    auto ends = [&](const char *suf) { const size_t k = strlen(suf); return lo.size() > k && lo.compare(lo.size() - k, k, suf) == 0; };
+    func_ = ends("_func");
+    const std::string base = (func_ || ends("_lld")) ? lo.substr(0, lo.rfind('_')) : lo;
+    kind_ = base == "is09" ? kIs09 : base == "compare16" ? kCompare16 : base == "is13_compare" ? kIs13 : base == "egemapsv02" ? kEgemaps : kHtkVariant;
+    if (kind_ == kHtkVariant && (func_ || ends("_lld")))
+      COMP_ERR("cHipLldSource: unknown featureSet '%s'", set_.c_str());
     smilehip_lld_config c;
     config_for(c);
     period_sec_ = c.frame_step_sec;
     frame_size_sec_ = c.frame_size_sec;
-    if (func16_) {
-      names_ = smilehip_host::func_names_compare16();
+    std::vector<std::string> lld_names;
+    switch (kind_) {
+      case kIs09: lld_names = smilehip_host::lld_names_is09(); break;
+      case kCompare16: case kIs13: lld_names = smilehip_host::lld_names_compare16(); break;
+      case kEgemaps: lld_names = smilehip_host::lld_names_egemaps(); break;
+      default: lld_names = smilehip_host::lld_names_htk_variant(c.chain_kind == SMILEHIP_CHAIN_PLP, c.append_log_energy != 0); break;
+    }
+    n_lld_ = (int)lld_names.size();
+    if (func_) {
+      names_ = kind_ == kIs09 ? smilehip_host::func_names_is09() : kind_ == kEgemaps ? smilehip_host::func_names_egemaps() : smilehip_host::func_names_compare16();
       period_sec_ = 0.0;                                  // one vector per input, as cFunctionals in frameMode = full writes
     } else {
-      names_ = smilehip_host::lld_names_htk_variant(c.chain_kind == SMILEHIP_CHAIN_PLP, c.append_log_energy != 0);
+      names_ = lld_names;
     }
     n_cols_ = (int)names_.size();
   }
@@ -1910,7 +1947,7 @@ class cHipLldSource : public cDataSource {
     }
     memcpy(block_->data, rows_.data() + (size_t)next_ * n_cols_, sizeof(float) * (size_t)n * n_cols_);   // data[el + t*N]
     for (long t = 0; t < n; ++t) {                      // frame time stamps as the framer gives them: vIdx * frameStep
-      block_->tmeta[t].time = (double)(next_ + t) * period_sec_;
+      block_->tmeta[t].time = times_[(size_t)(next_ + t)];
       block_->tmeta[t].lengthSec = frame_size_sec_;
       block_->tmeta[t].period = period_sec_;
     }
@@ -1933,7 +1970,7 @@ SMILECOMPONENT_REGCOMP(cHipLldSource) {
   SMILECOMPONENT_INHERIT_CONFIGTYPE("cDataSource")
   SMILECOMPONENT_IFNOTREGAGAIN(
     ct->setField("filename", "The RIFF/WAVE file to process (16-bit mono PCM)", "input.wav");
-    ct->setField("featureSet", "The feature set whose rows are produced, named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z (LLD rows); compare16_func / is13_compare_func: the functionals level of compare16/ComParE_2016.conf / is09-13/IS13_ComParE.conf, one vector of 6373 values per input", "mfcc12_0_d_a");
+    ct->setField("featureSet", "The feature set whose rows are produced. Named after its file in config/mfcc or config/plp: mfcc12_0_d_a, mfcc12_e_d_a, mfcc12_0_d_a_z, mfcc12_e_d_a_z, plp_0_d_a, plp_e_d_a, plp_0_d_a_z, plp_e_d_a_z (LLD rows). <set>_lld with <set> = is09 | compare16 | is13_compare | egemapsv02: the LLD level of is09-13/IS09_emotion.conf (32 columns), compare16/ComParE_2016.conf / is09-13/IS13_ComParE.conf (130), egemaps/v02/eGeMAPSv02.conf (25), with the rows and time stamps the reference's LLD sinks see. <set>_func: the functionals level of the same files, one vector of 384 / 6373 / 6373 / 88 values per input", "mfcc12_0_d_a");
   )
   SMILECOMPONENT_MAKEINFO(cHipLldSource);
 }

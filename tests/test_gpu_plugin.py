@@ -462,3 +462,40 @@ def test_plugin_compare16_every_component_overridden(oracle, golden_f0):
             assert tr.get(comp, 0) > 0, (comp, tr)
         # the only CPU fall-through (logged by the instances): the F0 group's noZeroSma smoother and onlyInSegments delta
         assert {n for n, v in tr.items() if n.endswith(".cpu") and v} == {"cContourSmoother.cpu", "cDeltaRegression.cpu"}
+
+
+@pytest.mark.gpu
+def test_plugin_fused_source_big_set_levels(oracle):
+    """cHipLldSource for the three big sets: featureSet = <set>_lld puts the whole LLD level (rows, end-of-input rows, time
+    stamps, names) into the level `lld`, <set>_func the functionals vector into `func`; the reference's own sinks write the
+    files. They must be the files smilextract_hip writes for the same input (same device path, same numbers: byte for byte),
+    which tests/test_host_io.py holds against the real binary's files; the CSV head line is compared with the binary's here too."""
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    hipexe = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
+    if not (os.path.exists(exe) and os.path.exists(plug) and os.path.exists(hipexe)):
+        pytest.skip("oracle/_ref/SMILExtract, the plugin .so or smilextract_hip not built")
+    G = os.path.join(ROOT, "tests", "golden", "files")
+    wav = os.path.join(G, "u3_4000.wav")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+    with tempfile.TemporaryDirectory() as td:
+        for fset, hipset, gold in (("is09", "is09_emotion", "is09_lld_u3.csv"), ("compare16", "compare16", "compare16_lld_u3.csv"),
+                                   ("is13_compare", "is13_compare", None), ("egemapsv02", "egemapsv02", "egemaps_lld_u3.csv")):
+            p_csv, p_htk, p_fhtk = (os.path.join(td, f"p_{fset}{e}") for e in (".csv", ".htk", ".f.htk"))
+            h_csv, h_htk, h_fhtk = (os.path.join(td, f"h_{fset}{e}") for e in (".csv", ".htk", ".f.htk"))
+            r = subprocess.run([exe, "-C", os.path.join(PLUGDIR, "conf", "LLD_hip.conf"), "-featureSet", fset + "_lld", "-I", wav,
+                                "-lldcsvoutput", p_csv, "-lldhtkoutput", p_htk, "-instname", "u3", "-l", "1"],
+                               cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and os.path.exists(p_csv) and os.path.exists(p_htk), (fset, r.stderr[-2000:])
+            r = subprocess.run([exe, "-C", os.path.join(PLUGDIR, "conf", "ComParE_2016_func_hip.conf"), "-featureSet", fset + "_func", "-I", wav,
+                                "-htkoutput", p_fhtk, "-instname", "u3", "-l", "1"],
+                               cwd=PLUGDIR, env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and os.path.exists(p_fhtk), (fset, r.stderr[-2000:])
+            subprocess.run([hipexe, "--set", hipset, "-I", wav, "-lldcsvoutput", h_csv, "-lldhtkoutput", h_htk, "-htkoutput", h_fhtk,
+                            "-instname", "u3"], check=True, env=env)
+            assert open(p_htk, "rb").read() == open(h_htk, "rb").read(), fset
+            assert open(p_csv).read() == open(h_csv).read(), fset
+            assert open(p_fhtk, "rb").read() == open(h_fhtk, "rb").read(), fset
+            if gold:
+                assert open(p_csv).readline() == open(os.path.join(G, gold)).readline(), fset

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--skip-per-component", action="store_true", help="per-component mode only for MFCC and ComParE (it takes ~25 s per run)")
     args = ap.parse_args()
     from oracle import lldo
     from opensmile_amd import synth
@@ -35,13 +36,20 @@ def main():
         cases = [
             ("MFCC12_0_D_A", os.path.join(lldo.REF_DIR, "config", "mfcc/MFCC12_0_D_A.conf"), "-O", [], int(args.seconds * 100) - 2),
             ("ComParE_2016 lld", os.path.join(lldo.REF_DIR, "config", "compare16/ComParE_2016.conf"), "-lldhtkoutput", [], int(args.seconds * 100) - 5),
+            ("IS09_emotion lld", os.path.join(lldo.REF_DIR, "config", "is09-13/IS09_emotion.conf"), "-lldhtkoutput", [], int(args.seconds * 100) - 2),
+            ("eGeMAPSv02 lld", os.path.join(lldo.REF_DIR, "config", "egemaps/v02/eGeMAPSv02.conf"), "-lldhtkoutput", [], int(args.seconds * 100) - 5),
         ]
+        fused_sets = {"ComParE_2016 lld": "compare16_lld", "IS09_emotion lld": "is09_lld", "eGeMAPSv02 lld": "egemapsv02_lld"}
         for name, conf, opt, extra, frames in cases:
             modes = [("cpu_binary", {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, extra),
                      ("plugin_per_component", {}, conf, extra)]
             if name == "MFCC12_0_D_A":
                 modes.append(("plugin_fused_unmodified_conf", {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, extra))
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", "mfcc12_0_d_a"]))
+            if name in fused_sets:                          # the whole LLD level from ONE source component, the reference's sinks
+                modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "LLD_hip.conf"), ["-featureSet", fused_sets[name]]))
+                if args.skip_per_component and name != "ComParE_2016 lld":
+                    modes = [m for m in modes if m[0] != "plugin_per_component"]
             for mode, envx, c, ex in modes:
                 env = dict(env0)
                 env.update(envx)
