@@ -21,23 +21,35 @@
 
 namespace smilehip {
 
-// LDS: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
+// the tables a frame reads: in global memory for the workgroup kernel, staged in LDS once per workgroup for the wave kernel
+// (143 global loads per frame and wave before: the kernel waited on them)
+struct Is09Tbl {
+  const float *window;
+  const float2 *tw_half, *tw_full;
+  const float *mel_coef;
+  const int32_t *mel_rng;
+  const float *dct_rows;
+};
+
+// LDS, workgroup form: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
+// wave form: xr[N] | z[fft_pairs(M)] pairs | mg[K+3] (yv first) | sp[K+3] (yv, later cep) | acf[M] | lmel[32] | scr
 template <class G>
-__device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Params &Q, int64_t row, float *smem) {
+__device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *smem) {
   const int M = P.Nfft >> 1;
   const int Npad = (P.N + 3) & ~3;
+  constexpr bool kWave = std::is_same<G, WaveG>::value;
+  const int Kpad = (P.K + 3) & ~3;
+  const int zpad = fft_pad(M);
   float *xr = smem;
-  float *yv = xr + Npad;
-  float *re = yv + Npad;                                 // wave form: fft_pairs(M) (re, im) pairs, lld_fft.hpp
+  float *re = kWave ? xr + Npad : xr + 2 * Npad;         // wave form: fft_pairs(M) (re, im) pairs, lld_fft.hpp
   float *im = re + M;
   float2 *z = reinterpret_cast<float2 *>(re);
-  constexpr bool kWave = std::is_same<G, WaveG>::value;
-  const int zpad = fft_pad(M);
   float *mg = re + 2 * fft_pairs(M);
-  float *sp = mg + ((P.K + 3) & ~3);
-  float *acf = sp + ((P.K + 3) & ~3);
-  float *cep = acf + M;
-  float *lmel = cep + M;
+  float *sp = mg + Kpad;
+  float *yv = kWave ? mg : xr + Npad;                    // wave form: the windowed frame lives in mg | sp until the transform has read it
+  float *acf = sp + Kpad;
+  float *cep = kWave ? sp : acf + M;                     // wave form: the cepstrum's lags replace its own input (read by then)
+  float *lmel = kWave ? acf + M : cep + M;
   double *scr = reinterpret_cast<double *>(lmel + 32);
   int *iscr = reinterpret_cast<int *>(scr + 4);
 
@@ -68,7 +80,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   for (int n = G::tid(); n < P.N; n += G::size()) {
     float y = xr[n];
     if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
-    y = y * P.window[n] + P.win_offset;
+    y = y * T.window[n] + P.win_offset;
     yv[n] = y;
     const float sq = y * y;
     e2 += (double)sq;
@@ -79,12 +91,12 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   }
   // R4 forward real FFT
   if constexpr (kWave) {
-    wave_cfft(z, M, P.tw_half, G::tid(), [&](int i) {
+    wave_cfft(z, M, T.tw_half, G::tid(), [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f);
     });
     for (int k = G::tid(); k <= M; k += 64)
-      mg[k] = bin_magnitude(wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);   // R5
+      mg[k] = bin_magnitude(wave_untangle(z, M, zpad, k, T.tw_full), k == 0 || k == M);   // R5
   } else {
     for (int i = G::tid(); i < M; i += G::size()) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
@@ -93,33 +105,33 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
       im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f;
     }
     G::sync();
-    group_cfft_radix2<G>(re, im, M, P.tw_half);
+    group_cfft_radix2<G>(re, im, M, T.tw_half);
     for (int k = G::tid(); k <= M; k += G::size())
-      mg[k] = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);     // R5
+      mg[k] = bin_magnitude(untangle_bin(re, im, M, k, T.tw_full), k == 0 || k == M);     // R5
   }
   G::sync();
   // R6 / R7: mel (usePower per config) -> log -> DCT
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
   G::sync();
   for (int b = G::tid(); b < P.n_bands; b += G::size())
-    lmel[b] = log_mel(mel_band_exact(sp, P.mel_coef, P.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
+    lmel[b] = log_mel(mel_band_exact(sp, T.mel_coef, T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
   G::sync();
   for (int r = G::tid(); r < P.n_mfcc; r += G::size())
-    out[1 + r] = dct_coeff(lmel, P.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);
+    out[1 + r] = dct_coeff(lmel, T.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);
   G::sync();
 
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
   G::sync();
-  if constexpr (kWave) wave_irfft_even(sp, z, M, P.tw_half, P.tw_full, acf, (float)P.K, true, G::tid());
-  else group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, acf, (float)P.K, true);
+  if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, acf, (float)P.K, true, G::tid());
+  else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, acf, (float)P.K, true);
   for (int k = G::tid(); k <= M; k += G::size()) {
     const float p = mg[k] * mg[k];
     sp[k] = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                              // :288-305
   }
   G::sync();
-  if constexpr (kWave) wave_irfft_even(sp, z, M, P.tw_half, P.tw_full, cep, (float)P.K, false, G::tid());
-  else group_irfft_even<G>(sp, re, im, M, logM, P.tw_half, P.tw_full, cep, (float)P.K, false);
+  if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
+  else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, cep, (float)P.K, false);
 
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
   double voicing, Tsamp;
@@ -138,15 +150,36 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
 // one workgroup per frame (any FFT size the LDS holds)
 __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  is09_frame_body<BlockG>(P, Q, (int64_t)blockIdx.x, smem);
+  const Is09Tbl T = {P.window, P.tw_half, P.tw_full, P.mel_coef, P.mel_rng, P.dct_rows};
+  is09_frame_body<BlockG>(P, Q, T, (int64_t)blockIdx.x, smem);
 }
 
-// one WAVE per frame, four frames per workgroup, no barriers
+// floats of LDS the wave kernel's shared tables take: window | tw_half | tw_full | mel_coef | mel_rng | dct_rows
+__host__ __device__ inline int is09_table_floats(int N, int M, int K) {
+  return ((N + 3) & ~3) + M + (M + 4) + ((K + 3) & ~3) + 128 + 16 * 32;
+}
+
+// one WAVE per frame, four frames per workgroup, no barriers after the table staging
 __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Params Q, int wave_floats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = P.Nfft >> 1, Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
+  float *s_win = smem;
+  float2 *s_twh = reinterpret_cast<float2 *>(s_win + Npad);
+  float2 *s_twf = s_twh + M / 2;
+  float *s_coef = reinterpret_cast<float *>(s_twf + M / 2 + 2);
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + Kpad);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < P.N; i += 256) s_win[i] = P.window[i];
+  for (int i = threadIdx.x; i < M / 2; i += 256) s_twh[i] = P.tw_half[i];
+  for (int i = threadIdx.x; i <= M / 2; i += 256) s_twf[i] = P.tw_full[i];
+  for (int i = threadIdx.x; i < P.K; i += 256) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * P.n_bands; i += 256) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += 256) s_dct[i] = P.dct_rows[i];
+  __syncthreads();                                       // the only workgroup barrier
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= P.total_frames) return;
-  is09_frame_body<WaveG>(P, Q, row, smem + (threadIdx.x >> 6) * wave_floats);
+  const Is09Tbl T = {s_win, s_twh, s_twf, s_coef, s_rng, s_dct};
+  is09_frame_body<WaveG>(P, Q, T, row, smem + is09_table_floats(P.N, M, P.K) + (threadIdx.x >> 6) * wave_floats);
 }
 
 // R10, sequential part: cPitchACF's causal contour smoother (pitchACF.cpp:199-243), state
@@ -193,14 +226,16 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(2 * Npad + 2 * fft_pairs(M) + 2 * Kpad + 2 * M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
+  // wave form: no yv, no cep of their own
+  const size_t lds_wave = sizeof(float) * (size_t)(Npad + 2 * fft_pairs(M) + 2 * Kpad + M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
   hipError_t e;
-  if (4 * lds <= 64 * 1024 && !getenv("SMILEHIP_IS09_BLOCK")) {       // a wave per frame: four frames per workgroup
-    const int wave_floats = (int)((lds + 15) / 16) * 4;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * wave_floats * (int)sizeof(float));
+  if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * (size_t)is09_table_floats(P.N, M, P.K) <= 64 * 1024 &&
+      !getenv("SMILEHIP_IS09_BLOCK")) {                                // a wave per frame: four frames per workgroup
+    const int wave_floats = (int)((lds_wave + 15) / 16) * 4;
+    const size_t total = sizeof(float) * ((size_t)is09_table_floats(P.N, M, P.K) + 4 * (size_t)wave_floats);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), 4 * wave_floats * sizeof(float), s,
-                       P, Q, wave_floats);
+    hipLaunchKernelGGL(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), total, s, P, Q, wave_floats);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
