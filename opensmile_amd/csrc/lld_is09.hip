@@ -33,12 +33,13 @@ struct Is09Tbl {
 
 // LDS, workgroup form: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
 // wave form: xr[N] | z[fft_pairs(M)] pairs | mg[K+3] (yv first) | sp[K+3] (yv, later cep) | acf[M] | lmel[32] | scr
-template <class G>
+// MC: M = Nfft / 2 when known at compile time (256: the 25 ms / 16 kHz geometry of the shipped configs), 0 = run-time
+template <class G, int MC = 0>
 __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *smem) {
-  const int M = P.Nfft >> 1;
+  const int M = MC > 0 ? MC : (P.Nfft >> 1);
   const int Npad = (P.N + 3) & ~3;
   constexpr bool kWave = std::is_same<G, WaveG>::value;
-  const int Kpad = (P.K + 3) & ~3;
+  const int Kpad = MC > 0 ? ((MC + 1 + 3) & ~3) : ((P.K + 3) & ~3);
   const int zpad = fft_pad(M);
   float *xr = smem;
   float *re = kWave ? xr + Npad : xr + 2 * Npad;         // wave form: fft_pairs(M) (re, im) pairs, lld_fft.hpp
@@ -179,7 +180,9 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= P.total_frames) return;
   const Is09Tbl T = {s_win, s_twh, s_twf, s_coef, s_rng, s_dct};
-  is09_frame_body<WaveG>(P, Q, T, row, smem + is09_table_floats(P.N, M, P.K) + (threadIdx.x >> 6) * wave_floats);
+  float *wave_mem = smem + is09_table_floats(P.N, M, P.K) + (threadIdx.x >> 6) * wave_floats;
+  if (M == 256) is09_frame_body<WaveG, 256>(P, Q, T, row, wave_mem);
+  else is09_frame_body<WaveG>(P, Q, T, row, wave_mem);
 }
 
 // R10, sequential part: cPitchACF's causal contour smoother (pitchACF.cpp:199-243), state
