@@ -112,7 +112,7 @@ __device__ __forceinline__ void spectral_frame(const float *mg, const float *pw,
     double v = p;
     if (v <= entropy_floor) v = entropy_floor;
     const double ln = v / dn;
-    v2[0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
+    v2[0] = (ln > 0.0) ? ln * log_d(ln) / log(2.0) : 0.0;
     const double t1 = fj - (double)ctr;                 // moments (:1338-1397)
     double m = t1 * t1 * p;
     v2[1] = m; m *= t1; v2[2] = m; v2[3] = m * t1;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     double v = p[w];
     if (v <= entropy_floor) v = entropy_floor;
     const double ln = v / dn;
-    v2[w][0] = (ln > 0.0) ? ln * log(ln) / log(2.0) : 0.0;
+    v2[w][0] = (ln > 0.0) ? ln * log_d(ln) / log(2.0) : 0.0;
     const double t1 = fj[w] - (double)ctr;
     double m = t1 * t1 * p[w];
     v2[w][1] = m; m *= t1; v2[w][2] = m; v2[w][3] = m * t1;

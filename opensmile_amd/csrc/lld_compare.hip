@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
       melv[b] = acc;
       // log mel spectrum for the RASTA pass (doLog, plp.cpp:434-439; double log = correctly rounded logf)
-      Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      Q.mel1[(f0 + t) * 26 + b] = (float)log_d((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       // R8 cPlp without RASTA: melfloor, equal loudness, power-law compression (plp.cpp:499-507)
       aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = P.Nfft >> 1, K = P.K;
-  const int Npad = (P.N + 3) & ~3, Kpad = (K + 3) & ~3;
+  const int Kpad = (K + 3) & ~3;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *s_coef = smem;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
       const int b = lane;
       const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
       melv[b] = acc;
-      Q.mel1[(f0 + t) * 26 + b] = (float)log((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      Q.mel1[(f0 + t) * 26 + b] = (float)log_d((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
     }

@@ -83,12 +83,40 @@ __device__ __forceinline__ float bin_magnitude(float2 X, bool edge) {
   return edge ? fabsf(X.x) : sqrtf(X.x * X.x + X.y * X.y);
 }
 
+// Natural logarithm in double for the per-bin / per-band logarithms of the frame kernels (the device library's log is ~95
+// instructions; the cepstrum instance of IS09 takes 257 of them per frame, ComParE's spectral entropy 256). Table + polynomial
+// after the scheme of glibc's log.c (S. Nagy): x = 2^k z, z in [0.6875, 1.375) cut into 128 sub-intervals, z = c (1 + r) with
+// |r| < 2^-7, log x = k ln2 + log c + log1p(r); the table (tools/gen_log_table.py) holds c with log c within 2^-64 of a
+// double; log1p by its series to r^9 (truncation < 2^-73). Error <= 1 ulp, <= 1.5 where k ln2 + log c straddles a binade boundary
+// (tests/test_gpu_fft.py measures it against long double) -- the class of the device library's own log, so "(float)log(double)" rounds like the reference's libm except for
+// the same one-in-2^28 near-ties. Zero, negative, subnormal, infinite and NaN arguments go to the library function.
+#include "log_table.inc"
+__device__ const double2 kLogTab[128] = {SMILEHIP_LOG_TABLE};
+__device__ __forceinline__ double log_d(double x) {
+  const unsigned long long ix = (unsigned long long)__double_as_longlong(x);
+  if (!(ix - 0x0010000000000000ull < 0x7fe0000000000000ull)) return log(x);
+  const unsigned long long tmp = ix - 0x3fe6000000000000ull;
+  const int i = (int)((tmp >> 45) & 127);
+  const long long k = (long long)tmp >> 52;
+  const double z = __longlong_as_double((long long)(ix - (tmp & (0xfffull << 52))));
+  const double2 t = kLogTab[i];
+  const double kd = (double)k;
+  const double r = fma(z, t.x, -1.0);
+  const double w = kd * SMILEHIP_LN2HI + t.y;           // the product is exact (42-bit constant, |k| < 2^11)
+  const double hi = w + r;
+  const double lo = w - hi + r + kd * SMILEHIP_LN2LO;
+  double q = 1.0 / 9.0;
+  q = fma(q, r, -1.0 / 8.0); q = fma(q, r, 1.0 / 7.0); q = fma(q, r, -1.0 / 6.0); q = fma(q, r, 1.0 / 5.0);
+  q = fma(q, r, -1.0 / 4.0); q = fma(q, r, 1.0 / 3.0); q = fma(q, r, -0.5);
+  return lo + (r * r) * q + hi;
+}
+
 // R7: log floor (mfcc.cpp:239-243). The reference's logf (glibc) is correctly
 // rounded in practice; the device logf (v_log_f32 based) is ~1 ulp. The
 // reference-order kernels therefore take the double-precision log and round
 // once; the fast kernel uses log_mel_fast.
 __device__ __forceinline__ float log_mel(float v, float melfloor, float log_floor) {
-  return (v < melfloor) ? log_floor : (float)log((double)v);
+  return (v < melfloor) ? log_floor : (float)log_d((double)v);
 }
 __device__ __forceinline__ float log_mel_fast(float v, float melfloor, float log_floor) {
   return (v < melfloor) ? log_floor : logf(v);

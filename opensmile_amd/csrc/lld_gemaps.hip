@@ -72,7 +72,7 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
   // log power spectrum of the bins the two slopes cover (spectral.cpp:689-716): factor 10/ln 10 as float, floor at specFloor^2
   {
     const float p = pw[lane];
-    lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log((double)p);
+    lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log_d((double)p);
   }
   WaveG::sync();
   // band slopes of the log spectrum (spectral.cpp:872-992), frequency axis given: four double sums per band
@@ -144,7 +144,7 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
 __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsParams G, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = P.Nfft >> 1, K = P.K;
-  const int Npad = (P.N + 3) & ~3, Kpad = (K + 3) & ~3;
+  const int Kpad = (K + 3) & ~3;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *s_coef = smem;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, acf, (float)P.K, true);
   for (int k = G::tid(); k <= M; k += G::size()) {
     const float p = mg[k] * mg[k];
-    sp[k] = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                              // :288-305
+    sp[k] = (p > 0.0f) ? (float)log_d((double)p + 1.0) : 0.0f;                              // :288-305
   }
   G::sync();
   if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
@@ -277,6 +277,26 @@ __global__ void __launch_bounds__(64) fft_check_kernel(const float2 *in, const f
   for (int k = lane; k < M; k += 64) out_fused[(size_t)blockIdx.x * M + k] = z[F::pos(k)];
 }
 }  // namespace smilehip
+
+namespace smilehip {
+__global__ void log_check_kernel(const double *x, double *y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = log_d(x[i]);
+}
+}  // namespace smilehip
+// test entry: log_d (lld_device.hpp) on n host doubles
+extern "C" int smilehip_debug_log_d(const double *in, double *out, int n) {
+  using namespace smilehip;
+  double *d_in = nullptr, *d_out = nullptr;
+  int rc = -2;
+  if (n > 0 && hipMalloc(&d_in, (size_t)n * 8) == hipSuccess && hipMalloc(&d_out, (size_t)n * 8) == hipSuccess &&
+      hipMemcpy(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess) {
+    hipLaunchKernelGGL(log_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, d_out, n);
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+  }
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return rc;
+}
 
 extern "C" int smilehip_debug_fft_check(int logM, const float *in_pairs, float *out_r2, float *out_fused, int n_transforms) {
   using namespace smilehip;
