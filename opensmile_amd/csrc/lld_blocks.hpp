@@ -49,7 +49,37 @@ struct BlockG {
   }
 };
 
-struct WaveG {
+// Lane l receives lane l + off's value for the lanes a shuffle-down reduction tree needs (l < off): two gfx950 lane swaps
+// and four DPP row shifts -- vector-ALU moves, where __shfl_down / __shfl_xor compile to ds_bpermute (the LDS pipe, ~10x
+// the latency). Lane 0 ends with the value of `for (off = 32; off; off >>= 1) x += __shfl_down(x, off)`, which is also what
+// every lane of the xor butterfly ends with (IEEE addition is commutative, the two trees are mirror images).
+template <int OFF>
+__device__ __forceinline__ int wave_down_i(int v) {
+  if constexpr (OFF == 32) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return r[1]; }
+  else if constexpr (OFF == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return r[1]; }
+  else return __builtin_amdgcn_update_dpp(0, v, 0x100 + OFF, 0xf, 0xf, true);      // row_shl:OFF
+}
+template <int OFF>
+__device__ __forceinline__ double wave_down_d(double x) {
+  return __hiloint2double(wave_down_i<OFF>(__double2hiint(x)), wave_down_i<OFF>(__double2loint(x)));
+}
+template <class Op>
+__device__ __forceinline__ double wave_tree_d(double x, Op op) {       // lane 0: the shuffle-down tree of op
+  x = op(x, wave_down_d<32>(x)); x = op(x, wave_down_d<16>(x)); x = op(x, wave_down_d<8>(x));
+  x = op(x, wave_down_d<4>(x)); x = op(x, wave_down_d<2>(x)); x = op(x, wave_down_d<1>(x));
+  return x;
+}
+template <class Op>
+__device__ __forceinline__ int wave_tree_i(int x, Op op) {
+  x = op(x, wave_down_i<32>(x)); x = op(x, wave_down_i<16>(x)); x = op(x, wave_down_i<8>(x));
+  x = op(x, wave_down_i<4>(x)); x = op(x, wave_down_i<2>(x)); x = op(x, wave_down_i<1>(x));
+  return x;
+}
+__device__ __forceinline__ double wave_first_d(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+struct WaveG {                                           // (all 64 lanes call these together)
   __device__ static __forceinline__ int tid() { return threadIdx.x & 63; }
   __device__ static __forceinline__ int size() { return 64; }
   __device__ static __forceinline__ void sync() {
@@ -57,20 +87,16 @@ struct WaveG {
     __builtin_amdgcn_wave_barrier();
   }
   __device__ static __forceinline__ double sum(double v, double *) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave_first_d(wave_tree_d(v, [](double a, double b) { return a + b; }));
   }
   __device__ static __forceinline__ double max(double v, double *) {
-    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
-    return v;
+    return wave_first_d(wave_tree_d(v, [](double a, double b) { return b > a ? b : a; }));
   }
   __device__ static __forceinline__ int sum_i(int v, int *) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return __builtin_amdgcn_readfirstlane(wave_tree_i(v, [](int a, int b) { return a + b; }));
   }
   __device__ static __forceinline__ int min_i(int v, int *) {
-    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
+    return __builtin_amdgcn_readfirstlane(wave_tree_i(v, [](int a, int b) { return b < a ? b : a; }));
   }
 };
 

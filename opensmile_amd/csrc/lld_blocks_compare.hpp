@@ -158,10 +158,7 @@ __device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot
     double s[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      double x = v[w][i];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      s[w] = __shfl(x, 0, 64);
+      s[w] = wave_first_d(wave_tree_d(v[w][i], [](double a, double b) { return a + b; }));   // the shuffle-down tree, lld_blocks.hpp
     }
     tot[i] = ((s[0] + s[1]) + s[2]) + s[3];
   }
