@@ -79,6 +79,21 @@ __device__ __forceinline__ double wave_first_d(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
+// the greatest value of the wave, among equals the smallest index (commutative: any tree gives the same winner); every lane
+// returns the winner
+template <int OFF>
+__device__ __forceinline__ void wave_argmax_step_f(float &bv, int &bi) {
+  const float ov = __int_as_float(wave_down_i<OFF>(__float_as_int(bv)));
+  const int oi = wave_down_i<OFF>(bi);
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+__device__ __forceinline__ void wave_argmax_f(float &bv, int &bi) {
+  wave_argmax_step_f<32>(bv, bi); wave_argmax_step_f<16>(bv, bi); wave_argmax_step_f<8>(bv, bi);
+  wave_argmax_step_f<4>(bv, bi); wave_argmax_step_f<2>(bv, bi); wave_argmax_step_f<1>(bv, bi);
+  bv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
+  bi = __builtin_amdgcn_readfirstlane(bi);
+}
+
 struct WaveG {                                           // (all 64 lanes call these together)
   __device__ static __forceinline__ int tid() { return threadIdx.x & 63; }
   __device__ static __forceinline__ int size() { return 64; }

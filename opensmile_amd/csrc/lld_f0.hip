@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include "lld_blocks.hpp"
 #include "lld_fft.hpp"
@@ -331,11 +332,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     float bv = -1.0f;
     int bi = 1 << 30;
     F0_FOR_BINS(m, j) if (((open >> m) & 1u) && hv[m] > bv) { bv = hv[m]; bi = j; }      // ascending j: first maximum
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    wave_argmax_f(bv, bi);
     if (bi != (1 << 30)) {
       if (lane == 0) ci[r] = bi;
       if ((bi & 63) == lane) open &= ~(1u << (bi >> 6));
@@ -987,7 +984,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
             ex = (double)wv[start + tfc - 1];
             ep = (double)wv[start + 2 * tfc - 2] + (double)wv[start + 2 * tfc - 1];
           }
-          for (int of = 32; of > 0; of >>= 1) { bx += __shfl_xor(bx, of); bp += __shfl_xor(bp, of); }
+          bx = WaveG::sum(bx, nullptr); bp = WaveG::sum(bp, nullptr);   // (exact sums: any tree)
           for (int of = 1; of < 64; of <<= 1) {                    // inclusive scan towards the longer candidates (the lower lanes)
             const double ox = __shfl_down(ex, of), op = __shfl_down(ep, of);
             if (lane + of < 64) { ex += ox; ep += op; }
@@ -1040,10 +1037,17 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           const double v = ccs[i];
           if (ccs[i - 1] < v && v > ccs[i + 1] && (bi == (1 << 30) || v > bv)) { bv = v; bi = i; }
         }
-        for (int of = 32; of > 0; of >>= 1) {
-          const double ov = __shfl_xor(bv, of);
-          const int oi = __shfl_xor(bi, of);
-          if (oi != (1 << 30) && (bi == (1 << 30) || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        {   // (commutative selection: any reduction tree gives the same winner; lane 0's tree, then broadcast)
+          auto st = [&](auto tag) {
+            constexpr int OFF = decltype(tag)::value;
+            const double ov = wave_down_d<OFF>(bv);
+            const int oi = wave_down_i<OFF>(bi);
+            if (oi != (1 << 30) && (bi == (1 << 30) || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+          };
+          st(std::integral_constant<int, 32>{}); st(std::integral_constant<int, 16>{}); st(std::integral_constant<int, 8>{});
+          st(std::integral_constant<int, 4>{}); st(std::integral_constant<int, 2>{}); st(std::integral_constant<int, 1>{});
+          bv = wave_first_d(bv);
+          bi = __builtin_amdgcn_readfirstlane(bi);
         }
         const long maxI = (bi == (1 << 30)) ? -1 : uni(bi);
         pp = (maxI == -1) ? T0f : T0minF + maxI;
@@ -1057,12 +1061,13 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
             mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
             mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
           }
-          for (int of = 32; of > 0; of >>= 1) {
-            float v;
-            v = __shfl_xor(mx0, of); mx0 = v > mx0 ? v : mx0;
-            v = __shfl_xor(mn0, of); mn0 = v < mn0 ? v : mn0;
-            v = __shfl_xor(mx1, of); mx1 = v > mx1 ? v : mx1;
-            v = __shfl_xor(mn1, of); mn1 = v < mn1 ? v : mn1;
+          {
+            auto fmx = [](int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; };
+            auto fmn = [](int a, int b) { return __int_as_float(b) < __int_as_float(a) ? b : a; };
+            mx0 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mx0), fmx)));
+            mn0 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mn0), fmn)));
+            mx1 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mx1), fmx)));
+            mn1 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mn1), fmn)));
           }
           const float a0 = mx0 - mn0, a1 = mx1 - mn1;
           const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
