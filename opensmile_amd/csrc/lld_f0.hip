@@ -135,7 +135,9 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     return make_float2(a, b);
   });
   // (lane l summed the inputs brev6(l) + 64 k: low offsets first is the tree the sum had when lane l held l + 64 m)
-  for (int o = 1; o < 64; o <<= 1) esum += __shfl_xor(esum, o);
+  esum += wave_down_d<1>(esum); esum += wave_down_d<2>(esum); esum += wave_down_d<4>(esum);     // (lane 0's tree of the xor
+  esum += wave_down_d<8>(esum); esum += wave_down_d<16>(esum); esum += wave_down_d<32>(esum);  //  butterfly, lld_blocks.hpp)
+  esum = wave_first_d(esum);
   F0_FOR_BINS(m, k) {
     mg[m] = 0.0;
     if (k < kK) mg[m] = (double)bin_magnitude(fft_untangle<WaveFft<9>>(z, k, T.twf), k == 0 || k == kM);

@@ -114,9 +114,10 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
       fl += myB * myB;
     }
     s01 = WaveG::sum(s01, nullptr); s15 = WaveG::sum(s15, nullptr); fl = WaveG::sum(fl, nullptr);
-    for (int o = 32; o > 0; o >>= 1) {
-      float w = __shfl_xor(m02, o); m02 = w > m02 ? w : m02;
-      w = __shfl_xor(m25, o); m25 = w > m25 ? w : m25;
+    {
+      auto fmx = [](int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; };
+      m02 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(m02), fmx)));
+      m25 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(m25), fmx)));
     }
     if (lane == 0) {
       const float sum01 = (float)s01, sum15 = (float)s15;
@@ -851,11 +852,7 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
           const float v = hfi[h];
           if (v >= fl && v <= fr && hmag[h] > bm) { bm = hmag[h]; bi = h; }      // ascending h: the first maximum
         }
-        for (int of = 32; of > 0; of >>= 1) {
-          const float om = __shfl_xor(bm, of);
-          const int oi = __shfl_xor(bi, of);
-          if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
-        }
+        wave_argmax_f(bm, bi);
         fa[f] = (bi == (1 << 30) || !(bm > 0.0f)) ? -1 : bi;
       }
       if (lane == 0) {
