@@ -277,8 +277,14 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // Returns the number of candidates.
 // hps_in != null: per-component mode, cPitchShs on a given octave-scale spectrum (no interpolation);
 // only_scale: per-component mode, cSpecScale alone (stop after the spectrum has been written to Q.hps_tap)
+// mean_exact (optional): receives the mean of the summation spectrum when it can be formed as a tree sum with a provably
+// exact result, NaN otherwise. The reference adds the 513 values (floats, widened) one after the other in double
+// (pitchShs.cpp:259-301); they are non-negative, so every partial sum of ANY summation order is at most the total S, and if
+// the smallest non-zero value's last bit 2^(e_min - 23) satisfies exponent(S) - e_min <= 28, every such partial sum is a
+// multiple of that bit below 2^53 of it -- representable: no addition rounds, all orders give the exact S, and the
+// sequential chain (one lane, 512 dependent additions: a fifth of the kernel's instructions) is not needed.
 __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane_in, int64_t g, double *A, double *B, int *ci,
-                                      const float *hps_in, bool only_scale) {
+                                      const float *hps_in, bool only_scale, double *mean_exact = nullptr) {
   // Everything below that depends only on the lane (135 clamped addresses and in-range masks of the harmonic shifts, table
   // addresses ...) is loop-invariant over the frames of a wave, and the compiler keeps all of it in registers across the
   // frame loop: 256 VGPRs + AGPR spills, one wave per SIMD. An opaque copy of the lane index makes it recompute them per
@@ -319,6 +325,17 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     hv[m] = s;
   }
   F0_FOR_BINS(m, j) if (j < kK) { SS[j] = hv[m]; B[j] = (double)hv[m]; }
+  if (mean_exact) {
+    double part = 0.0;
+    float mn = INFINITY;
+    F0_FOR_BINS(m, j) if (j < kK) { part += (double)hv[m]; if (hv[m] > 0.0f && hv[m] < mn) mn = hv[m]; }
+    const double S = WaveG::sum(part, nullptr);
+    mn = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mn), [](int a, int b) { return __int_as_float(b) < __int_as_float(a) ? b : a; })));
+    const int e_min = (int)((__float_as_uint(mn) >> 23) & 0xffu) - 127;                       // INFINITY (all zero): 128
+    const int e_sum = (int)(((unsigned long long)__double_as_longlong(S) >> 52) & 0x7ffull) - 1023;
+    const bool ok = (S == 0.0) || (mn >= 1.17549435e-38f && mn < INFINITY && e_sum - e_min <= 28);
+    *mean_exact = ok ? S / (double)kK : __longlong_as_double(0x7ff8000000000000ll);
+  }
   WaveG::sync();
   // local maxima, then the six best: greedy insertion (:262-283) keeps (score descending, bin ascending)
   float lf[kPer], rt[kPer];
@@ -654,12 +671,14 @@ __global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_cand(LldParams P, F0Pa
     const double es = row[kK];
     WaveG::sync();
     PHASE(0);   // rows from global
-    const int nf = f0_shs(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false);
+    double mean = 0.0;
+    const int nf = f0_shs(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean);
     WaveG::sync();
     PHASE(2);   // interpolation, summation, top six
-    double mean = 0.0;
-    if (lane == 0) mean = f0_mean_serial(A + kKP);
-    mean = __shfl(mean, 0);
+    if (mean != mean) {                                  // (wave-uniform) no exactness guarantee: the reference's chain
+      if (lane == 0) mean = f0_mean_serial(A + kKP);
+      mean = wave_first_d(mean);
+    }
     PHASE(3);   // mean
     f0_candidates(Q, lane, row0 + w, A, ci, reinterpret_cast<float *>(ci + 8), nf, mean, es);
     PHASE(4);   // candidates + output

@@ -147,3 +147,28 @@ def test_viterbi_stream_equals_the_oracle_frame_by_frame(hip, oracle):
         f0 = np.array([shs[n, 1 + got[n]] if got[n] < 6 else 0.0 for n in range(T)], np.float32)
         vp = np.array([shs[n, 7 + got[n]] if got[n] < 6 else shs[n, 7] for n in range(T)], np.float32)
         assert np.array_equal(f0.view(np.uint32), ref[:, 0].view(np.uint32)) and np.array_equal(vp.view(np.uint32), ref[:, 1].view(np.uint32))
+
+
+def test_f0_exact_tree_mean_equals_the_sequential_chain(hip):
+    """lld_f0_cand forms the mean of the summation spectrum as a tree sum when it can prove the sum exact (non-negative floats
+    whose smallest non-zero value's last bit keeps every partial sum representable) and runs the reference's sequential chain
+    otherwise. The per-component operator smilehip_pitchshs_frames always runs the sequential chain: fed with the chain's own
+    octave-scale spectra it must give the chain's 21 values bit for bit -- on an all-zero utterance (S = 0), a voiced one and a
+    noise one (whichever path the chain's test sends each frame down; the fallback is the operator's own code)."""
+    import torch
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    L = capi.load()
+    lens = [160000, 32000, 16000]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(0, lens[0]), synth.utterance(7, lens[1]), synth.utterance(10, lens[2])])   # zeros | voiced | noise
+    b = capi.Batch(plan, off)
+    _, taps = b.f0_run_host_taps(pcm)
+    b.close()
+    hps, shs = taps["hps"], taps["shs"]
+    nH, K = hps.shape
+    d_hp = torch.from_numpy(np.ascontiguousarray(hps)).cuda()
+    d_s = torch.zeros((nH, 21), dtype=torch.float32, device="cuda")
+    assert L.smilehip_pitchshs_frames(plan._h, d_hp.data_ptr(), K, d_s.data_ptr(), 21, nH, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_s.cpu().numpy().view(np.uint32), shs.view(np.uint32))
