@@ -351,7 +351,15 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     float bv = -1.0f;
     int bi = 1 << 30;
     F0_FOR_BINS(m, j) if (((open >> m) & 1u) && hv[m] > bv) { bv = hv[m]; bi = j; }      // ascending j: first maximum
-    wave_argmax_f(bv, bi);
+    {   // (score, bin) as ONE double whose order is (score descending, bin ascending): positive float bits in the high word
+        // order like the floats, 2^31 - 1 - bin in the low word breaks ties towards the lower bin; "none" is negative.
+        // The wave maximum is then six v_max_f64 (commutative: same winner as the pairwise selection).
+      const unsigned long long kbits = ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0x7fffffff - (bi & 0x7fffffff));
+      double key = (bi == (1 << 30)) ? -1.0 : __longlong_as_double((long long)kbits);
+      key = wave_first_d(wave_tree_d(key, [](double a, double b) { return fmax(a, b); }));
+      const unsigned long long wb = (unsigned long long)__double_as_longlong(key);
+      bi = (key < 0.0) ? (1 << 30) : 0x7fffffff - (int)(unsigned)(wb & 0xffffffffull);
+    }
     if (bi != (1 << 30)) {
       if (lane == 0) ci[r] = bi;
       if ((bi & 63) == lane) open &= ~(1u << (bi >> 6));
