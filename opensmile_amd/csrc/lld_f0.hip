@@ -315,9 +315,13 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
 #pragma unroll
   for (int h = 0; h < 16; ++h)
     if (h < Q.n_harm - 1) {
+      // bins past the end of the spectrum do not contribute. The loads need no clamp: a read past bin kK-1 stays inside
+      // this wave's A | B arrays and its value is not used (branch-free, so that the nine reads of a harmonic are in flight together)
+      const int sh = Q.shift[h], lim = kK - sh;
+      const float sc = Q.scale[h];
       float v[kPer];
-      F0_FOR_BINS(m, j) { const int jj = j + Q.shift[h]; v[m] = hps[jj < kK ? jj : kK - 1]; }
-      F0_FOR_BINS(m, j) { const float s2 = hv[m] + v[m] * Q.scale[h]; hv[m] = (j + Q.shift[h] < kK) ? s2 : hv[m]; }
+      F0_FOR_BINS(m, j) v[m] = hps[j + sh];
+      F0_FOR_BINS(m, j) { const float s2 = hv[m] + v[m] * sc; hv[m] = (j < lim) ? s2 : hv[m]; }
     }
   F0_FOR_BINS(m, j) {
     float s = hv[m] / (float)Q.n_harm;
