@@ -30,6 +30,7 @@ namespace {
 constexpr int kColsPerBlock = 64;
 constexpr int kSortThreads = 256;
 constexpr int kSortLds = 8192;
+constexpr int kWaveSortMaxDecl = 1024;   // contours up to this length are sorted by one wave (fs_percentiles_wave)
 
 #define FS_BIT(m, i) (((m) >> (i)) & 1u)
 
@@ -1093,29 +1094,7 @@ __device__ void bitonic_sort(float *a, int n2) {       // n2 = power of two, who
 
 }  // namespace
 
-__global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int out_off) {
-  __shared__ float lds[kSortLds];
-  Where w;
-  w.u = blockIdx.x / P.n_cols;
-  w.c = blockIdx.x % P.n_cols;
-  w.on = true;
-  utt_rows(P, w);
-  const int64_t si = (int64_t)w.u * P.n_cols + w.c;
-  const int64_t N = P.st_n[si];
-  if (N <= 0) return;
-  const Col x = data_col(P, w);
-  int n2 = 1;
-  while (n2 < N) n2 <<= 1;
-  // global scratch beyond the LDS capacity: the utterance's region holds 2 * (rows + 1) * n_cols floats; the column slots
-  // are spaced by the power of two covering the utterance's rows BEFORE nonZeroFuncts -- the columns' own sizes differ
-  // with nonZeroFuncts, and slots spaced by them would overlap
-  int64_t slot = 1;
-  while (slot < w.rows) slot <<= 1;
-  float *a = (n2 <= kSortLds) ? lds : P.sorted + 2 * w.srow0 * P.n_cols + (int64_t)w.c * slot;
-  for (int i = threadIdx.x; i < n2; i += blockDim.x) a[i] = (i < N) ? x[i] : INFINITY;
-  __syncthreads();
-  bitonic_sort(a, n2);
-  if (threadIdx.x != 0) return;
+__device__ void pctl_readout(const FsParams &P, const Where &w, const float *a, int64_t N, int out_off) {
   const smilehip_func_spec &s = P.spec;
   float *out = P.out + (int64_t)w.u * P.ld_out + (int64_t)w.c * P.per + out_off;
   float q1, q2, q3;
@@ -1139,6 +1118,134 @@ __global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int o
   }
 }
 
+__global__ void __launch_bounds__(kSortThreads) fs_percentiles(FsParams P, int out_off) {
+  __shared__ float lds[kSortLds];
+  Where w;
+  w.u = blockIdx.x / P.n_cols;
+  w.c = blockIdx.x % P.n_cols;
+  w.on = true;
+  utt_rows(P, w);
+  const int64_t si = (int64_t)w.u * P.n_cols + w.c;
+  const int64_t N = P.st_n[si];
+  if (N <= 0 || N <= kWaveSortMaxDecl) return;           // (up to 1024 rows: fs_percentiles_wave)
+  const Col x = data_col(P, w);
+  int n2 = 1;
+  while (n2 < N) n2 <<= 1;
+  // global scratch beyond the LDS capacity: the utterance's region holds 2 * (rows + 1) * n_cols floats; the column slots
+  // are spaced by the power of two covering the utterance's rows BEFORE nonZeroFuncts -- the columns' own sizes differ
+  // with nonZeroFuncts, and slots spaced by them would overlap
+  int64_t slot = 1;
+  while (slot < w.rows) slot <<= 1;
+  float *a = (n2 <= kSortLds) ? lds : P.sorted + 2 * w.srow0 * P.n_cols + (int64_t)w.c * slot;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) a[i] = (i < N) ? x[i] : INFINITY;
+  __syncthreads();
+  bitonic_sort(a, n2);
+  if (threadIdx.x != 0) return;
+  pctl_readout(P, w, a, N, out_off);
+}
+
+// ---- one WAVE per (utterance, column) for N <= 1024 (a 10 s contour): the SAME bitonic network as bitonic_sort above -- the
+// same compare-exchanges on the same element pairs, so the sorted order is identical down to the placement of equal values
+// -- with element e in lane e / R, register e % R (R = n2 / 64): strides below R are register pairs, strides from R up are
+// lane exchanges (DPP quad permutes and row rotations, v_permlane16_swap / v_permlane32_swap) -- no LDS, no barrier, where
+// the workgroup form spends 55 barrier-separated LDS passes of 256 threads on one contour and holds 32 KB of LDS for it.
+template <int D>
+__device__ __forceinline__ float lane_xor_f(float x, int lane) {           // lane l receives lane l ^ D
+  const int v = __float_as_int(x);
+  int r;
+  if constexpr (D == 1) r = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) r = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  else if constexpr (D == 4) {
+    const int a = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true);                  // row_ror:4: lane i <- i - 4
+    const int b = __builtin_amdgcn_update_dpp(0, v, 0x12C, 0xf, 0xf, true);                  // row_ror:12: lane i <- i + 4
+    r = (lane & 4) ? a : b;
+  } else if constexpr (D == 8) r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else if constexpr (D == 16) { const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false); r = (lane & 16) ? p[0] : p[1]; }
+  else { const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false); r = (lane & 32) ? p[0] : p[1]; }
+  return __int_as_float(r);
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void wave_bitonic_sort(const Col &x, int64_t N, int lane, float *dst) {
+  constexpr int N2 = 1 << LOG2N, R = N2 >= 64 ? N2 / 64 : 1;
+  float v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const int e = lane * R + r; v[r] = (e < N) ? x[e] : INFINITY; }
+#pragma unroll
+  for (int k = 2; k <= N2; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < R) {                                       // both elements in this lane: registers r and r | j
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r & j) continue;
+          const bool up = ((lane * R + r) & k) == 0;
+          const float a = v[r], b = v[r | j];
+          const bool sw = up ? (a > b) : (a < b);
+          v[r] = sw ? b : a;
+          v[r | j] = sw ? a : b;
+        }
+      } else {                                           // the partner element is register r of lane ^ (j / R)
+        const bool lower = (lane & (j / R)) == 0;
+        const bool up = ((lane * R) & k) == 0;           // (k >= 2 R here: the bit is a lane bit)
+        const bool want_gt = lower == up;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float a = v[r];
+          float b;
+          switch (j / R) {
+            case 1: b = lane_xor_f<1>(a, lane); break;
+            case 2: b = lane_xor_f<2>(a, lane); break;
+            case 4: b = lane_xor_f<4>(a, lane); break;
+            case 8: b = lane_xor_f<8>(a, lane); break;
+            case 16: b = lane_xor_f<16>(a, lane); break;
+            default: b = lane_xor_f<32>(a, lane); break;
+          }
+          const bool sw = want_gt ? (a > b) : (a < b);
+          v[r] = sw ? b : a;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) dst[lane * R + r] = v[r];
+}
+
+constexpr int kWaveSortMax = 1024;
+__global__ void __launch_bounds__(256) fs_percentiles_wave(FsParams P, int out_off, int n_items) {
+  __shared__ float lds_all[4 * kWaveSortMax];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;
+  Where w;
+  w.u = item / P.n_cols;
+  w.c = item % P.n_cols;
+  w.on = true;
+  utt_rows(P, w);
+  const int64_t N = P.st_n[(int64_t)w.u * P.n_cols + w.c];
+  if (N <= 0 || N > kWaveSortMax) return;                // longer contours: fs_percentiles
+  const Col x = data_col(P, w);
+  float *a = lds_all + wave * kWaveSortMax;
+  int lg = 1;
+  while ((1 << lg) < N) ++lg;
+  switch (lg) {
+    case 1: wave_bitonic_sort<1>(x, N, lane, a); break;
+    case 2: wave_bitonic_sort<2>(x, N, lane, a); break;
+    case 3: wave_bitonic_sort<3>(x, N, lane, a); break;
+    case 4: wave_bitonic_sort<4>(x, N, lane, a); break;
+    case 5: wave_bitonic_sort<5>(x, N, lane, a); break;
+    case 6: wave_bitonic_sort<6>(x, N, lane, a); break;
+    case 7: wave_bitonic_sort<7>(x, N, lane, a); break;
+    case 8: wave_bitonic_sort<8>(x, N, lane, a); break;
+    case 9: wave_bitonic_sort<9>(x, N, lane, a); break;
+    default: wave_bitonic_sort<10>(x, N, lane, a); break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) pctl_readout(P, w, a, N, out_off);
+}
+
 // ------------------------------------------------------------------ launch
 int fs_sort_lds_rows() { return kSortLds; }
 
@@ -1159,7 +1266,9 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
       case SMILEHIP_FAM_LPC: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PERCENTILES:
-        hipLaunchKernelGGL(fs_percentiles, dim3((unsigned)(n_utt * P.n_cols)), dim3(kSortThreads), 0, s, P, off);
+        hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
+        if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts
+          hipLaunchKernelGGL(fs_percentiles, dim3((unsigned)(n_utt * P.n_cols)), dim3(kSortThreads), 0, s, P, off);
         break;
       default: return hipErrorInvalidValue;
     }

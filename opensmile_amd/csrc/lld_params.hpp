@@ -231,6 +231,7 @@ struct FsParams {
   int32_t *st_n;
   float *out;                // [n_utt x ld_out]
   int64_t ld_out;
+  int64_t max_rows;          // upper bound of the rows of any column (host knowledge): decides whether the workgroup sort is launched
 };
 
 // R13: chain of window processors (cDeltaRegression / cContourSmoother) over the

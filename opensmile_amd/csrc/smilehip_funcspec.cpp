@@ -148,6 +148,7 @@ int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows
   int rc = fs_reserve(ctx, fs_bytes(P, need), stream);
   if (rc) return rc;
   fs_carve(static_cast<char *>(ctx->fs_scratch), P, need);
+  P.max_rows = max_rows;
   return launch_spec(P, n_utt, stream);
 }
 
@@ -409,6 +410,7 @@ static int functionals_compare_level(smilehip_plan *plan, smilehip_batch *b, con
     const int lane = j % (smilehip_context::kFsStreams + 1);
     hipStream_t st = lane == 0 ? main : ctx->fs_stream[lane - 1];
     fs_carve(static_cast<char *>(ctx->fs_scratch) + offs[i], Ps[i], needs[i]);
+    Ps[i].max_rows = max_rows;
     rc = launch_spec(Ps[i], b->n_utt, st);
     if (rc) return rc;
   }
@@ -530,6 +532,7 @@ extern "C" int smilehip_batch_functionals_egemaps(smilehip_plan *plan, smilehip_
   if (rc) return rc;
   for (int i = 0; i < kParts; ++i) {
     fs_carve(static_cast<char *>(plan->ctx->fs_scratch) + offs[i], Ps[i], needs[i]);
+    Ps[i].max_rows = max_rows;
     if ((rc = launch_spec(Ps[i], b->n_utt, main))) return rc;
   }
   hipError_t e = launch_gemaps_dbp(d_func + 87, ld_func, b->n_utt, b->d_fin_off.p, main);   // [egemapsv02_leq] dBp
