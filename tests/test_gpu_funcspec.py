@@ -79,6 +79,23 @@ def test_funcspec_edge_shapes(hip, oracle, inst):
         check(oracle, spec, dev, ref, f"{inst}/rows{rows}")
 
 
+def test_funcspec_percentile_sort_paths(hip, oracle):
+    """The three percentile sorts -- one wave per contour up to 1024 rows (registers + lane exchanges), the workgroup sort in LDS
+    up to 8192, global scratch beyond -- at their boundaries, with ties and signed zeros in the contour."""
+    capi, ctx = hip
+    spec = capi.funcspec_compare16("Nz")
+    rng = np.random.default_rng(5)
+    for rows in (63, 64, 65, 127, 129, 1000, 1024, 1025, 3000, 8192, 8193):
+        x = rng.standard_normal((rows, 5)).astype(np.float32)
+        x[:, 1] = np.round(x[:, 1] * 2) / 2          # ties
+        x[::5, 2] = 0.0
+        x[1::5, 2] = -0.0                            # signed zeros next to each other in sorted order
+        x[:, 3] = np.abs(x[:, 3])
+        dev = capi.funcspec_matrix_host(ctx, spec, x)
+        ref = oracle.funcspec(x, as_oracle_spec(oracle, spec))
+        check(oracle, spec, dev, ref, f"Nz/rows{rows}")
+
+
 def test_funcspec_long_contour_global_sort(hip, oracle):
     """More rows than the LDS sort holds (8192): the percentile stage sorts in global scratch."""
     capi, ctx = hip
