@@ -1340,7 +1340,13 @@ __global__ void __launch_bounds__(64) lld_f0_lld(const int64_t *frame_off, const
 
 int f0_tile_frames() { return kTileFrames; }
 
-int f0_chunk_tiles() { return 16384; }                 // 131 072 frames = 1.08 GB of scratch rows per chunk (smaller chunks measured slower: 8192 +1 %, 4096 +6 %, 2048 +14 %)
+// tiles per chunk: 32768 tiles = 262 144 frames = 2.2 GB of scratch rows (the sweep then has four waves per SIMD in flight;
+// measured on 4000 x 10 s: 16384 tiles 62.3 ms, 32768 60.7, 65536 60.2; smaller chunks are slower: 8192 +1 %, 2048 +14 %).
+// SMILEHIP_F0_CHUNK_TILES overrides (tuning aid).
+int f0_chunk_tiles() {
+  static const int n = [] { const char *e = getenv("SMILEHIP_F0_CHUNK_TILES"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 32768; }();
+  return n;
+}
 
 hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
                      hipEvent_t frames_done) {
