@@ -1025,33 +1025,33 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           if (c < clo) continue;
           const long tf = T0minF + c;
           const float *xa = wv + start, *ya = wv + start + tf;
-          const long nr = tf >> 3;
+          const long nr = tf >> 2;
           const double sx = bx + ex, sy = (bx + bp + ep) - sx;     // sum of x[0..tf), sum of x[tf..2tf)
           const double mx = sx / (double)tf, my = sy / (double)tf;
           // one pass in rounds of eight samples, the next round's samples loaded before the current round's sums (the
           // sums stay sequential in the reference's order)
           double cc = 0.0, nx = 0.0, ny = 0.0;
           {
-            float xv[8], yv[8], xn[8], yn[8];
+            float xv[4], yv[4], xn[4], yn[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
+            for (int q = 0; q < 4; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
             for (long r = 0; r < nr; ++r) {
-              const long i1 = (r + 1) << 3;
+              const long i1 = (r + 1) << 2;
 #pragma unroll
-              for (int q = 0; q < 8; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+              for (int q = 0; q < 4; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
+              for (int q = 0; q < 4; ++q) {
                 const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
                 cc += dx * dy;
                 nx += dx * dx;
                 ny += dy * dy;
               }
 #pragma unroll
-              for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
+              for (int q = 0; q < 4; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if ((nr << 3) + q < tf) {
+            for (int q = 0; q < 4; ++q)
+              if ((nr << 2) + q < tf) {
                 const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
                 cc += dx * dy;
                 nx += dx * dx;
