@@ -32,6 +32,29 @@
 
 namespace smilehip {
 
+// Development instrumentation (tools/ubench/variant_any.sh gemaps <name> -DSMILEHIP_PHASE_TIMING): s_memtime at the phase
+// boundaries of lld_gemaps_harm, summed over all waves. Not compiled into the product.
+#ifdef SMILEHIP_PHASE_TIMING
+__device__ unsigned long long g_phase_gm[16];
+#define GPHASE_DECL unsigned long long gph_acc[8] = {0}; unsigned long long gph_last = __builtin_amdgcn_s_memtime();
+#define GPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gph_acc[i] += t_ - gph_last; gph_last = t_; } while (0)
+#define GPHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_gm[i_], gph_acc[i_]); } while (0)
+}  // namespace smilehip
+extern "C" int smilehip_debug_phase_gm(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(smilehip::g_phase_gm), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smilehip::g_phase_gm), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace smilehip {
+#else
+#define GPHASE_DECL
+#define GPHASE(i)
+#define GPHASE_FLUSH
+#endif
+
 namespace {
 constexpr int kRun = 8;            // 20 ms frames per run (same runs as the ComParE A+B kernel)
 constexpr int kRsI = 220;          // resampled samples per frame (cSpecResample: 20 ms at 11 kHz)
@@ -688,6 +711,7 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
   float *hlr = hmag + 128;
   const double Fb = 1.0 / G.fsSec60;                     // frequency axis of the 60 ms spectrum: frq[i] = Fb * i
   const int tile_stride = (int)gridDim.x * kHarmWaves;
+  GPHASE_DECL
   const int lane_in = lane;
   const bool rows_mode = G.op_mode == 1;                 // per-component operator: F0, formants and magnitudes given per row
   const int n_tiles = rows_mode ? (int)((G.op_rows + 7) / 8) : G.n_tiles60;
@@ -730,6 +754,7 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
       }
       WaveG::sync();
+      GPHASE(0);   // load, window, FFT, magnitudes
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
       {
         const int n = 2 * kHM;
@@ -744,6 +769,7 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         }
         WaveG::sync();
       }
+      GPHASE(1);   // ACF
       // HNR at the ACF peak closest to the F0 lag (freqToAcfBinLin :393-401, getClosestPeak :632-665, computeAcfHnr_dB :690-712)
       float hnr_db = 0.0f;
       {
@@ -779,6 +805,7 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
           hnr_db = (float)ret;
         }
       }
+      GPHASE(2);   // HNR peak search
       // findHarmonicPeaks, frequency-axis branch (:478-546): harmonic i = lane, lane + 64
       const int firstBin = harm_freq_to_bin(Fb, 0.5f * F0);
       for (int i = lane; i < 128; i += 64) {
@@ -811,35 +838,46 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         hbin[i] = bin; hfi[i] = fi; hmag[i] = mag; hlr[i] = mi;      // hlr: interpolated magnitude for now
       }
       WaveG::sync();
+      GPHASE(3);   // harmonic peaks
       // postProcessHarmonics(…, true) (:550-588): log magnitudes relative to harmonic 0 (log10 of a float: log10f), then the
       // duplicate removal, which is sequential (an entry is compared with its predecessor AFTER that one was cleared)
       {
         const float m0 = hmag[0];
         const bool logRel = !(m0 == 0.0f);
-        const float lm0 = logRel ? (float)log10((double)m0) : 0.0f;
+        // log10 through log_d (lld_device.hpp): within 2.5 ulp of double, rounded to float like the library's
+        constexpr double kInvLn10 = 0.43429448190325182765;
+        const float lm0 = logRel ? (float)(log_d((double)m0) * kInvLn10) : 0.0f;
         for (int i = lane; i < kNH; i += 64) {
           float v;
           if (i == 0) v = 0.0f;
           else if (!logRel) v = -201.0f;
           else if (hlr[i] > 0.0f) {
-            const double tmp = (double)(float)log10((double)hlr[i]);
+            const double tmp = (double)(float)(log_d((double)hlr[i]) * kInvLn10);
             v = (float)(20.0 * (tmp - (double)lm0));
             if (v < -200.0f) v = -200.0f;
           } else v = -200.0f;
           hlr[i] = v;
         }
-        WaveG::sync();
-        if (lane == 0) {
-          int prev_bin = hbin[0];
-#pragma unroll 4
-          for (int i = 1; i < kNH; ++i) {
-            const int b = hbin[i];
-            if (b == prev_bin) { hbin[i] = 0; hfi[i] = 0.0f; hmag[i] = 0.0f; hlr[i] = -201.0f; prev_bin = 0; }
-            else prev_bin = b;
-          }
+        // Duplicate removal: entry i is cleared if its bin equals its predecessor's -- the predecessor's AFTER its own
+        // clearing (then 0). cleared[i] = cleared[i-1] ? (bin[i] == 0) : (bin[i] == bin[i-1]): a two-state recurrence over two
+        // bit masks, run on the scalar unit (the sequential loop over LDS it replaces was a quarter of the kernel's time).
+        static_assert(kNH <= 128, "two 64-bit masks");
+        const int b0 = hbin[lane], b0p = lane > 0 ? hbin[lane - 1] : -1;
+        const int b1 = hbin[64 + lane], b1p = hbin[63 + lane];
+        const unsigned long long E0 = __ballot(lane > 0 && b0 == b0p), Z0 = __ballot(b0 == 0);
+        const unsigned long long E1 = __ballot(64 + lane < kNH && b1 == b1p), Z1 = __ballot(64 + lane < kNH && b1 == 0);
+        unsigned long long C0 = 0ull, C1 = 0ull;
+        {
+          bool c = false;
+          for (int i = 1; i < 64; ++i) { c = ((c ? Z0 : E0) >> i) & 1ull; C0 |= (unsigned long long)c << i; }
+          for (int i = 0; i < kNH - 64; ++i) { c = ((c ? Z1 : E1) >> i) & 1ull; C1 |= (unsigned long long)c << i; }
         }
         WaveG::sync();
+        if ((C0 >> lane) & 1ull) { hbin[lane] = 0; hfi[lane] = 0.0f; hmag[lane] = 0.0f; hlr[lane] = -201.0f; }
+        if ((C1 >> lane) & 1ull) { hbin[64 + lane] = 0; hfi[64 + lane] = 0.0f; hmag[64 + lane] = 0.0f; hlr[64 + lane] = -201.0f; }
+        WaveG::sync();
       }
+      GPHASE(4);   // log magnitudes + duplicate removal
       // getFormantAmplitudeIndices (:714-740): the strongest harmonic within 0.8 .. 1.2 of the formant frequency
       int fa[3];
       const float *fm = G.formants + (r20 + tf) * G.fm_ld;
@@ -867,8 +905,10 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         for (int f = 0; f < 3; ++f) o[3 + f] = (fa[f] >= 0) ? hlr[fa[f]] : 0.0f;   // :957-973
       }
       WaveG::sync();
+      GPHASE(5);   // formant amplitudes + output
     }
   }
+  GPHASE_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------ selectors + smoothers
