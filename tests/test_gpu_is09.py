@@ -100,3 +100,30 @@ def test_window_chain_sma_delta_bit_exact(hip, oracle):
         ref = oracle.is09_chain(pcm[off[i]:off[i + 1]])
         check_lld(out[b.frame_offsets[i]:b.frame_offsets[i + 1]], ref, f"len{n}")
     b.close()
+
+
+def test_is09_other_sample_rates_wave_equals_workgroup_kernel():
+    """Geometries other than 16 kHz / 25 ms: 8 kHz (N = 200, M = 128: the wave kernel's run-time-M path with the generic pair
+    transform), 32 kHz (N = 800, M = 512: the fused transform) -- the wave-per-frame kernel against the one-workgroup-per-frame
+    kernel (SMILEHIP_IS09_BLOCK=1), which runs the in-place radix-2 transform and the workgroup reductions: same values within
+    the chain's tolerance (the energy sums use different trees)."""
+    import os
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    for fs in (8000, 32000):
+        cfg = capi.is09_lld_config()
+        cfg.sample_rate = float(fs)
+        plan = capi.Plan(ctx, cfg)
+        lens = [3 * fs, fs // 2, fs]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pcm = np.concatenate([synth.utterance(40 + i, n, fs=fs) for i, n in enumerate(lens)])
+        b = capi.Batch(plan, off)
+        a = b.run_host(pcm)
+        os.environ["SMILEHIP_IS09_BLOCK"] = "1"
+        try:
+            r = b.run_host(pcm)
+        finally:
+            del os.environ["SMILEHIP_IS09_BLOCK"]
+        b.close()
+        assert a.shape == r.shape and a.shape[0] > 0 and np.isfinite(a).all()
+        check_lld(a, r.astype(np.float64), f"fs{fs}")
