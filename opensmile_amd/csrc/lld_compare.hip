@@ -229,6 +229,14 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
   SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
+  // the raw samples of frame t + 1 are asked for while frame t is processed (N <= 512: eight per lane): the wave does not
+  // wait a memory round trip at the top of every frame
+  int16_t pre[8];
+  auto prefetch = [&](const int16_t *xx, int ln) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int n = ln + 64 * q; pre[q] = (n < P.N) ? xx[n] : (int16_t)0; }
+  };
+  prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     // an opaque copy of the lane index per frame: otherwise everything below that depends on the lane only (bit-reversed
     // FFT addresses, table addresses, range tests) is hoisted out of the frame loop and kept in ~150 VGPRs across it --
@@ -239,7 +247,9 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
     const int16_t *x = xu + (int64_t)t * P.H;
     float *rawA = Q.rawA + (f0 + t) * 4;
     float *rawB = Q.rawB + (f0 + t) * 55;
-    for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = pcm16_to_float(pre[q]); }
+    if (t + 1 < t_last) prefetch(x + P.H, lane);
     WaveG::sync();
     wave_cfft(z, M, P.tw_half, lane, [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;

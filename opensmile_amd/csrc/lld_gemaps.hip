@@ -201,13 +201,22 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   const int16_t *xu = P.pcm + P.samp_off[u];
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
+  // the raw samples of frame t + 1 are asked for while frame t is processed (see lld_compare_frame_wave)
+  int16_t pre[8];
+  auto prefetch = [&](const int16_t *xx, int ln) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int n = ln + 64 * q; pre[q] = (n < P.N) ? xx[n] : (int16_t)0; }
+  };
+  prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     int lane = lane_in;                                  // opaque per frame (see lld_compare_frame_wave): nothing that depends on
     asm volatile("" : "+v"(lane));                       // the lane only is kept in registers across the frame loop
     const bool warm = t < t0;
     const int16_t *x = xu + (int64_t)t * P.H;
     float *raw = G.raw20 + (f0 + t) * 12;
-    for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = pcm16_to_float(pre[q]); }
+    if (t + 1 < t_last) prefetch(x + P.H, lane);
     WaveG::sync();
     // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
     double e2 = 0.0;
