@@ -182,8 +182,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 // keeps the block kernel's order (lld_blocks_compare.hpp), so the two kernels give bit-identical rows.
 // LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave z[fft_pairs(M)] pairs | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // mel[32] | aud[32] | lmel[32]
-__global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, const CompareParams &Q, int n_runs, float *smem) {
   const int M = P.Nfft >> 1, K = P.K;
   const int Kpad = (K + 3) & ~3;
   const int lane = threadIdx.x & 63;
@@ -229,14 +228,6 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
   SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
-  // the raw samples of frame t + 1 are asked for while frame t is processed (N <= 512: eight per lane): the wave does not
-  // wait a memory round trip at the top of every frame
-  int16_t pre[8];
-  auto prefetch = [&](const int16_t *xx, int ln) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int n = ln + 64 * q; pre[q] = (n < P.N) ? xx[n] : (int16_t)0; }
-  };
-  prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     // an opaque copy of the lane index per frame: otherwise everything below that depends on the lane only (bit-reversed
     // FFT addresses, table addresses, range tests) is hoisted out of the frame loop and kept in ~150 VGPRs across it --
@@ -247,9 +238,9 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
     const int16_t *x = xu + (int64_t)t * P.H;
     float *rawA = Q.rawA + (f0 + t) * 4;
     float *rawB = Q.rawB + (f0 + t) * 55;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = pcm16_to_float(pre[q]); }
-    if (t + 1 < t_last) prefetch(x + P.H, lane);
+    // (asking for frame t + 1's samples here, a frame ahead, was measured: -2 % for this kernel alone, +24 % for the whole
+    // ComParE level of a small batch, where the kernel runs beside the jitter pass -- not kept)
+    for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
     WaveG::sync();
     wave_cfft(z, M, P.tw_half, lane, [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
@@ -308,6 +299,19 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
   }
+}
+
+// Two builds of the same body. Three waves per SIMD (167 VGPRs, 4 spilled): ComParE A+B alone 12.8 -> 10.1 ms per 1000 x 10 s,
+// one GPU's share of config 4 514 -> 473 ms. Beside the jitter pass of a SMALL batch (the whole level, fewer utterances than the
+// device has wave slots) the denser kernel takes the slots the jitter chains need and the level gets slower (44.7 -> 47.8 ms per
+// 1000 x 10 s): there the two-wave build runs.
+__global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  compare_frame_wave_body(P, Q, n_runs, smem);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_wave3(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  compare_frame_wave_body(P, Q, n_runs, smem);
 }
 
 // R8 with newRASTA (plp.cpp:434-439, 468-485, 490-497, 512-517): log -> 4-tap FIR + 1-pole IIR
@@ -459,7 +463,10 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
     const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
-    hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
+    const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
+    if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else hipLaunchKernelGGL(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
