@@ -133,3 +133,34 @@ def test_r0_reciprocal_division_exact_for_all_int16():
     e = (-(q0.astype(np.float64)) * 32767.0 + s.astype(np.float64)).astype(np.float32)
     q = (e.astype(np.float64) * np.float64(r) + q0.astype(np.float64)).astype(np.float32)
     assert np.array_equal(q.view(np.uint32), ref.view(np.uint32))
+
+
+def test_log_table_is_what_its_generator_writes(tmp_path):
+    """opensmile_amd/csrc/log_table.inc (the 128-entry table of log_d, lld_device.hpp) is generated, not edited: running
+    tools/gen_log_table.py again gives the committed file byte for byte, and every entry satisfies what the kernel relies on
+    (|z invc - 1| < 2^-7 over its sub-interval, log c within 2^-63 of the table value; c = 1 for the two intervals at 1)."""
+    import math
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "opensmile_amd", "csrc", "log_table.inc")
+    text = open(inc).read()
+    # a private copy of the tree layout the generator writes into
+    work = tmp_path / "w"
+    (work / "tools").mkdir(parents=True)
+    (work / "opensmile_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(os.path.join(root, "tools", "gen_log_table.py"), work / "tools" / "gen_log_table.py")
+    subprocess.run([sys.executable, str(work / "tools" / "gen_log_table.py")], check=True, capture_output=True)
+    assert (work / "opensmile_amd" / "csrc" / "log_table.inc").read_text() == text
+    pairs = re.findall(r"\{(-?0x[0-9a-f.]+p[+-]\d+), (-?0x[0-9a-f.]+p[+-]\d+)\}", text)
+    assert len(pairs) == 128
+    for i, (a, b) in enumerate(pairs):
+        invc, logc = float.fromhex(a), float.fromhex(b)
+        lo, w = (0.6875 + i * 2.0 ** -8, 2.0 ** -8) if i < 80 else (1.0 + (i - 80) * 2.0 ** -7, 2.0 ** -7)
+        assert max(abs(lo * invc - 1.0), abs((lo + w) * invc - 1.0)) < 2.0 ** -7 + 1e-12
+        if i in (79, 80):
+            assert invc == 1.0 and logc == 0.0
+        else:
+            assert abs(math.log(1.0 / invc) - logc) < 1e-15
