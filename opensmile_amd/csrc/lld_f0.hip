@@ -547,7 +547,7 @@ __host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // d1 | d2 
 }
 __host__ __device__ inline size_t f0_cand_shared_bytes() { return (size_t)kKP * 8 * 4 + (size_t)kKP * 4; }   // a | c | d | audw | k
 
-__global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_spec(LldParams P, F0Params Q) {
+__global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_f0_spec(LldParams P, F0Params Q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
