@@ -1352,6 +1352,8 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
                      hipEvent_t frames_done) {
   if (P.total_frames <= 0) return hipSuccess;
   if (Q0.Nfft != kNfftF0 || Q0.K != kK || Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
+  for (int h = 0; h + 1 < Q0.n_harm && h < 16; ++h)      // f0_shs reads bin j + shift without a clamp: it must stay inside the wave's A | B arrays
+    if (Q0.shift[h] < 0 || Q0.shift[h] > 4 * kKP - 9 * 64) return hipErrorInvalidValue;
   (void)max_blocks;
   const size_t lds_spec = f0_spec_shared_bytes(Q0.N) + (size_t)kSpecWaves * 2 * kKP * sizeof(double);
   const size_t lds_cand = f0_cand_shared_bytes() + (size_t)kSpecWaves * kFrameBytes;
@@ -1396,6 +1398,8 @@ int64_t f0_scratch_doubles(int64_t n_tiles) { return f0_scratch_rows(n_tiles) * 
 hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   if (Q.n_rows <= 0) return hipSuccess;
   if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17 || (Q.mode != 1 && Q.mode != 2)) return hipErrorInvalidValue;
+  for (int h = 0; h + 1 < Q.n_harm && h < 16; ++h)
+    if (Q.shift[h] < 0 || Q.shift[h] > 4 * kKP - 9 * 64) return hipErrorInvalidValue;
   const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
   const void *fn = reinterpret_cast<const void *>(&lld_f0_frame);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
