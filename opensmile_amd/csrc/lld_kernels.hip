@@ -155,6 +155,9 @@ __global__ void __launch_bounds__(256) lld_chain_tiled(ChainParams P) {
   // Natural tile order: workgroup b takes tile b. An XCD-grouped order (tile (b % 8) * ceil(n/8) + b / 8, so that
   // neighbouring tiles share one L2) was measured 19 % SLOWER for this streaming kernel (0.063 vs 0.053 ms): the eight
   // XCDs then stream eight distant regions instead of one, and the shared halo is only 6 % of a tile.
+  // Threads walking the tile's input / output elements in memory order (whole cache lines per store instead of 52-byte row
+  // pieces, group and column recovered per element) was measured too: 0.094 vs 0.056 ms -- the divergent per-element
+  // selection costs more than the partial lines, which L2 merges anyway.
   const int tile = (int)blockIdx.x;
   if (tile >= P.n_tiles) return;
   const int u = P.tile_utt[tile];
