@@ -1005,8 +1005,8 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
           const int clo = chi - 63 > 0 ? chi - 63 : 0;
           const int c = chi - lane;
           // The two means (crossCorr :343-352 sums x and y sequentially in double). The samples are floats of magnitude
-          // <= 1 and >= 2^-15 (or zero), i.e. multiples of 2^-38, so every partial sum of up to 2^12 of them is exact in
-          // double in ANY order: the sums are formed by a wave reduction up to the shortest candidate and a scan over the
+          // < 2 (32768 / 32767 at most) and >= 2^-15 (or zero), i.e. multiples of 2^-38, so every partial sum of up to 2^12 of
+          // them is below 2^13 and exact in double in ANY order (tests/test_exact_sum_claims.py): the sums are formed by a wave reduction up to the shortest candidate and a scan over the
           // candidates instead of one pass over the samples per candidate, with bit-identical results.
           const long nb = T0minF + clo;
           double bx = 0.0, bp = 0.0;
