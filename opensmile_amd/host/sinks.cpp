@@ -15,7 +15,130 @@ bool file_exists(const std::string &p) {
   fclose(f);
   return true;
 }
+
+typedef unsigned __int128 u128;
+const u128 kPow10[39] = {
+    (u128)1ull, (u128)10ull, (u128)100ull, (u128)1000ull, (u128)10000ull, (u128)100000ull, (u128)1000000ull, (u128)10000000ull,
+    (u128)100000000ull, (u128)1000000000ull, (u128)10000000000ull, (u128)100000000000ull, (u128)1000000000000ull,
+    (u128)10000000000000ull, (u128)100000000000000ull, (u128)1000000000000000ull, (u128)10000000000000000ull,
+    (u128)100000000000000000ull, (u128)1000000000000000000ull, (u128)10000000000000000000ull,
+    (u128)10000000000000000000ull * 10u, (u128)10000000000000000000ull * 100u, (u128)10000000000000000000ull * 1000u,
+    (u128)10000000000000000000ull * 10000u, (u128)10000000000000000000ull * 100000u, (u128)10000000000000000000ull * 1000000u,
+    (u128)10000000000000000000ull * 10000000u, (u128)10000000000000000000ull * 100000000u,
+    (u128)10000000000000000000ull * 1000000000u, (u128)10000000000000000000ull * 10000000000ull,
+    (u128)10000000000000000000ull * 100000000000ull, (u128)10000000000000000000ull * 1000000000000ull,
+    (u128)10000000000000000000ull * 10000000000000ull, (u128)10000000000000000000ull * 100000000000000ull,
+    (u128)10000000000000000000ull * 1000000000000000ull, (u128)10000000000000000000ull * 10000000000000000ull,
+    (u128)10000000000000000000ull * 100000000000000000ull, (u128)10000000000000000000ull * 1000000000000000000ull,
+    (u128)10000000000000000000ull * 10000000000000000000ull};
+
+// a buffered file: the writers below append text with memcpy and flush in 1 MB pieces
+struct OutBuf {
+  FILE *f;
+  std::vector<char> b;
+  size_t n = 0;
+  bool ok = true;
+  explicit OutBuf(FILE *file) : f(file), b((size_t)1 << 20) {}
+  char *room(size_t need) {
+    if (n + need > b.size()) flush();
+    return b.data() + n;
+  }
+  void put(const char *s, size_t len) {
+    if (len > b.size() / 2) { flush(); ok = ok && fwrite(s, 1, len, f) == len; return; }
+    std::memcpy(room(len), s, len);
+    n += len;
+  }
+  void put(const std::string &s) { put(s.data(), s.size()); }
+  void put(char c) { *room(1) = c; ++n; }
+  void flush() {
+    if (n) ok = ok && fwrite(b.data(), 1, n, f) == n;
+    n = 0;
+  }
+};
 }  // namespace
+
+int format_f0(float v, char *dst) {
+  if (!(std::fabs(v) < 9.0e18f)) return snprintf(dst, 48, "%.0f", v);          // huge, inf, nan
+  const double d = (double)v;
+  const double r = std::nearbyint(d);                     // round-half-even, as printf rounds
+  char tmp[24];
+  int n = 0;
+  unsigned long long a = (unsigned long long)std::fabs(r);
+  do { tmp[n++] = (char)('0' + a % 10); a /= 10; } while (a);
+  int len = 0;
+  if (std::signbit(d)) dst[len++] = '-';                  // "-0" for values in (-0.5, -0], as printf prints them
+  while (n) dst[len++] = tmp[--n];
+  return len;
+}
+
+int format_e6(float v, char *dst) {
+  uint32_t bits;
+  std::memcpy(&bits, &v, 4);
+  const uint32_t ex = (bits >> 23) & 0xffu;
+  int len = 0;
+  if (bits >> 31) dst[len++] = '-';
+  if ((bits & 0x7fffffffu) == 0) { std::memcpy(dst + len, "0.000000e+00", 12); return len + 12; }
+  const float av = std::fabs(v);
+  if (ex == 0 || ex == 0xff || av < 1e-21f) return snprintf(dst, 48, "%e", v);   // subnormal, tiny, inf, nan
+  const uint64_t m64 = (bits & 0x7fffffu) | 0x800000u;
+  const u128 m = m64;
+  const int e = (int)ex - 150;                             // v = m * 2^e
+  // decimal exponent: floor(log10 2^(ex-127)) is floor(log10 v) or one less; the loop below corrects it
+  int k = (((int)ex - 127) * 1233) >> 12;
+  {
+    static const float *const pow10f = [] {                // 10^k as floats, k = -23 .. 38 (rounded: the loop absorbs it)
+      static float t[62];
+      for (int i = 0; i < 62; ++i) t[i] = (float)std::pow(10.0, (double)(i - 23));
+      return t;
+    }();
+    if (k + 1 >= -23 && k + 1 <= 38 && av >= pow10f[k + 1 + 23]) ++k;
+  }
+  unsigned long long q = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    // digits = round(v / 10^(k-6)) = round(N / D), half to even
+    if (e < 0 && e >= -40 && k >= -5 && k <= 6) {          // the common case in 64 bits: N = m 10^(6-k) < 2^63, D = 2^-e
+      static const uint64_t p10[12] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull,
+                                       1000000000ull, 10000000000ull, 100000000000ull};
+      const uint64_t N = m64 * p10[6 - k], D = 1ull << (-e);
+      uint64_t qq = N >> (-e);
+      if (qq < 1000000u) { --k; continue; }                // v < 10^k: the estimate was one too high (tested BEFORE rounding)
+      if (qq >= 10000000u) { ++k; continue; }              // v >= 10^(k+1): one too low
+      const uint64_t twice = (N & (D - 1)) << 1;
+      if (twice > D || (twice == D && (qq & 1))) ++qq;
+      if (qq == 10000000u) { qq = 1000000u; ++k; }         // 9.9999995.. rounds up to 1.000000e(k+1)
+      q = qq;
+      break;
+    }
+    u128 N, D;
+    int shift = -1;                                        // D = 2^shift when >= 0
+    if (e >= 0) { N = m << e; D = kPow10[k - 6 > 0 ? k - 6 : 0]; if (k < 6) N *= kPow10[6 - k]; }
+    else if (k <= 6) { N = m * kPow10[6 - k]; D = (u128)1 << (-e); shift = -e; }
+    else { N = m; D = ((u128)1 << (-e)) * kPow10[k - 6]; }
+    u128 qq, rr;
+    if (shift >= 0) { qq = N >> shift; rr = N & (D - 1); }
+    else { qq = N / D; rr = N - qq * D; }
+    if (qq < 1000000u) { --k; continue; }
+    if (qq >= 10000000u) { ++k; continue; }
+    const u128 twice = rr << 1;
+    if (twice > D || (twice == D && (qq & 1))) ++qq;
+    if (qq == 10000000u) { qq = 1000000u; ++k; }
+    q = (unsigned long long)qq;
+    break;
+  }
+  if (q == 0) return snprintf(dst, 48, "%e", v);           // (cannot happen; keeps the output right if it does)
+  char dg[7];
+  for (int i = 6; i >= 0; --i) { dg[i] = (char)('0' + q % 10); q /= 10; }
+  dst[len++] = dg[0];
+  dst[len++] = '.';
+  std::memcpy(dst + len, dg + 1, 6);
+  len += 6;
+  dst[len++] = 'e';
+  dst[len++] = k < 0 ? '-' : '+';
+  const int ak = k < 0 ? -k : k;
+  dst[len++] = (char)('0' + ak / 10);
+  dst[len++] = (char)('0' + ak % 10);
+  return len;
+}
 
 bool write_htk(const std::string &path, const float *x, int64_t rows, int cols, int64_t ld, double period_sec,
                int parm_kind, std::string &err) {
@@ -54,17 +177,23 @@ bool write_csv(const std::string &path, const std::vector<std::string> &names, c
     for (int c = 0; c < cols - 1; ++c) fprintf(f, "%s%c", names[(size_t)c].c_str(), d);
     fprintf(f, "%s\n", names[(size_t)cols - 1].c_str());
   }
+  OutBuf o(f);
+  const std::string name = "'" + opt.instance_name + "'" + d;
+  char tb[64];
   for (int64_t t = 0; t < rows; ++t) {
-    fprintf(f, "'%s'%c", opt.instance_name.c_str(), d);
-    if (opt.timestamp) fprintf(f, "%f%c", times ? times[t] : (double)t * period_sec, d);
+    o.put(name);
+    if (opt.timestamp) { const int n = snprintf(tb, sizeof tb, "%f%c", times ? times[t] : (double)t * period_sec, d); o.put(tb, (size_t)n); }
+    char *p = o.room((size_t)cols * 50);
+    size_t n = 0;
     for (int c = 0; c < cols; ++c) {
       const float v = x[t * ld + c];
-      const char *end = (c == cols - 1) ? "\n" : ";";
-      if (v == std::floor(v)) fprintf(f, "%.0f%s", v, end);      // csvSink.cpp:224-235
-      else fprintf(f, "%e%s", v, end);
+      n += (size_t)((v == std::floor(v)) ? format_f0(v, p + n) : format_e6(v, p + n));      // csvSink.cpp:224-235
+      p[n++] = (c == cols - 1) ? '\n' : ';';
     }
+    o.n += n;
   }
-  const bool ok = fclose(f) == 0;
+  o.flush();
+  const bool ok = (fclose(f) == 0) && o.ok;
   if (!ok) err = "error writing '" + path + "'";
   return ok;
 }
@@ -101,16 +230,28 @@ bool write_arff(const std::string &path, const std::vector<std::string> &names, 
     else fprintf(f, "@attribute class %s\n", opt.class_type.c_str());
     fprintf(f, "\n@data\n\n");
   }
-  for (int64_t t = 0; t < rows; ++t) {
-    if (prname) fprintf(f, "%s,", arff_escape(opt.instance_name).c_str());
-    if (opt.timestamp) fprintf(f, "%f,", (double)t * period_sec);
-    fprintf(f, "%e", x[t * ld]);
-    for (int c = 1; c < cols; ++c) fprintf(f, ",%e", x[t * ld + c]);
-    fprintf(f, ",%s\n", opt.class_value.empty() ? "NULL" : opt.class_value.c_str());
+  {
+    OutBuf o(f);
+    const std::string name = prname ? arff_escape(opt.instance_name) + "," : std::string();
+    const std::string tail = "," + (opt.class_value.empty() ? std::string("NULL") : opt.class_value) + "\n";
+    char tb[64];
+    for (int64_t t = 0; t < rows; ++t) {
+      o.put(name);
+      if (opt.timestamp) { const int n = snprintf(tb, sizeof tb, "%f,", (double)t * period_sec); o.put(tb, (size_t)n); }
+      char *p = o.room((size_t)cols * 50);
+      size_t n = 0;
+      for (int c = 0; c < cols; ++c) {
+        if (c) p[n++] = ',';
+        n += (size_t)format_e6(x[t * ld + c], p + n);
+      }
+      o.n += n;
+      o.put(tail);
+    }
+    o.flush();
+    const bool ok = (fclose(f) == 0) && o.ok;
+    if (!ok) err = "error writing '" + path + "'";
+    return ok;
   }
-  const bool ok = fclose(f) == 0;
-  if (!ok) err = "error writing '" + path + "'";
-  return ok;
 }
 
 }  // namespace smilehip_host

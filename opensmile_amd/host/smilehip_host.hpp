@@ -48,6 +48,13 @@ std::vector<std::string> funcspec_value_names(const smilehip_func_spec &spec, co
 bool write_htk(const std::string &path, const float *x, int64_t rows, int cols, int64_t ld, double period_sec,
                int parm_kind, std::string &err);
 
+// printf("%e", v) / printf("%.0f", v) for a float argument without printf: the decimal digits by exact integer arithmetic
+// (the value is m * 2^e with m < 2^24: 128-bit integers hold every case with |v| in [1e-21, 3.4e38]; round-half-even like
+// glibc), snprintf for the rest (subnormal, tiny, inf, nan). Writes at dst (at least 48 bytes), returns the length; no
+// terminating NUL. The CSV / ARFF writers spend their time here: 2.7 M values/s with fprintf, see DESIGN.md.
+int format_e6(float v, char *dst);
+int format_f0(float v, char *dst);                   // "%.0f"; exact for every float
+
 // cCsvSink (src/iocore/csvSink.cpp:157-240): optional header line, 'name';frameTime;values with
 // "%.0f" for integral values and "%e" otherwise, ';' delimiter.
 struct CsvOptions {

@@ -53,3 +53,15 @@ extern "C" long shim_names(int which, char *buf, long cap) {
   std::memcpy(buf, all.data(), all.size());
   return (long)all.size();
 }
+
+// format_e6 / format_f0 on n floats against snprintf: returns the number of values whose text differs (first one in *bad)
+extern "C" long shim_format_check(const float *x, long n, int use_f0, long *bad) {
+  long diff = 0;
+  char a[64], b[64];
+  for (long i = 0; i < n; ++i) {
+    const int la = use_f0 ? format_f0(x[i], a) : format_e6(x[i], a);
+    const int lb = snprintf(b, sizeof b, use_f0 ? "%.0f" : "%e", x[i]);
+    if (la != lb || memcmp(a, b, (size_t)la) != 0) { if (!diff && bad) *bad = i; ++diff; }
+  }
+  return diff;
+}

@@ -366,3 +366,32 @@ def test_smilextract_hip_gather_single_rank(tmp_path):
     assert outs["plain"] == outs["gather"]
     rows = [l for l in outs["plain"][0].split("@data")[1].split("\n") if l]
     assert [r.split(",")[0] for r in rows] == ["a", "c"]               # the 25 ms file has no 60 ms frame: no instance
+
+
+def test_fast_number_formatting_equals_printf(hostlib):
+    """format_e6 / format_f0 (opensmile_amd/host/sinks.cpp), what the CSV / ARFF writers print numbers with: byte for byte
+    printf's "%e" / "%.0f" -- on 20 million random bit patterns (every exponent, both signs, subnormals, inf, nan), on values at
+    decimal rounding boundaries (d.dddddd5 ties, 9.9999995 -> 1.000000e+01), on the powers of ten and of two."""
+    hostlib.shim_format_check.restype = C.c_long
+    hostlib.shim_format_check.argtypes = [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_long)]
+    rng = np.random.default_rng(2)
+    bits = rng.integers(0, 2 ** 32, 20_000_000, dtype=np.uint64).astype(np.uint32)
+    specials = [0.0, -0.0, 1.0, -1.0, 9.9999995, 9.9999994, 9.99999951, 0.99999995, 999999.95, 1e-21, 9.99e-22, 1.0000001e-21,
+                3.4028235e38, 1.17549435e-38, 1e-45, np.inf, -np.inf, np.nan, 0.5, 1.5, 2.5, -0.5, -0.4, 8388608.0, 16777216.0,
+                1234567.5, 1234568.5, 0.1, 0.2, 0.3]
+    pow10 = [10.0 ** k for k in range(-44, 39)] + [np.nextafter(np.float32(10.0 ** k), np.float32(0)) for k in range(-30, 39)] + \
+            [np.nextafter(np.float32(10.0 ** k), np.float32(np.inf)) for k in range(-30, 38)]
+    pow2 = [2.0 ** k for k in range(-149, 128)]
+    # seven-digit decimals +- half a unit in the last place: the rounding boundaries of "%e"
+    ties = []
+    for k in range(-20, 30, 3):
+        for d in rng.integers(1000000, 9999999, 200):
+            ties += [(int(d) + 0.5) * 10.0 ** (k - 6), (int(d) + 0.49999) * 10.0 ** (k - 6), (int(d) + 0.50001) * 10.0 ** (k - 6)]
+    x = np.concatenate([bits.view(np.float32), np.array(specials + pow10 + pow2 + ties, np.float32),
+                        (rng.standard_normal(2_000_000) * 10.0 ** rng.integers(-8, 8, 2_000_000)).astype(np.float32),
+                        np.round(rng.standard_normal(200_000) * 1000).astype(np.float32)])
+    x = np.ascontiguousarray(x)
+    bad = C.c_long(-1)
+    for use_f0 in (0, 1):
+        n = hostlib.shim_format_check(x.ctypes.data, len(x), use_f0, C.byref(bad))
+        assert n == 0, (use_f0, n, float(x[bad.value]), hex(int(x[bad.value:bad.value + 1].view(np.uint32)[0])))
