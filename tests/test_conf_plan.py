@@ -135,3 +135,28 @@ def test_conf_front_end_equals_set(tmp_path):
     assert ha == hb and xa.shape == xb.shape and xa.shape[1] == 60
     scale = np.abs(xb[:, :20]).max(axis=1, keepdims=True)
     assert (np.abs(xa - xb) / scale).max() <= 1e-5
+
+
+@needs_conf
+def test_every_reference_conf_gets_a_plan_or_a_named_refusal():
+    """All configuration files of the reference's config/ tree through `smilextract_hip -C <file> --describe`: the twelve the fused
+    path covers produce a plan; every other one is refused with a message that names what is not covered (a component
+    instance, an option, a missing section) -- never a crash, a hang or a silent default."""
+    confs = sorted(os.path.join(d, f) for d, _, fs in os.walk(CONF) for f in fs if f.endswith(".conf"))
+    assert len(confs) >= 60
+    planned = []
+    for c in confs:
+        r = subprocess.run([EXE, "-C", c, "--describe"], capture_output=True, text=True, timeout=60)
+        rel = os.path.relpath(c, CONF)
+        assert r.returncode in (0, 1, 2), (rel, r.returncode, r.stderr[-300:])          # no signal, no abort
+        if r.returncode == 0:
+            planned.append(rel)
+            assert "chain_kind=" in r.stdout or "preset=" in r.stdout, rel
+        else:
+            msg = r.stderr.strip()
+            assert msg.startswith("smilextract_hip:") and len(msg) > 40, (rel, msg)
+            assert "cannot run on the fused path" in msg or "outside a section" in msg or "[" in msg, (rel, msg)
+    assert set(planned) == {"mfcc/MFCC12_0_D_A.conf", "mfcc/MFCC12_0_D_A_Z.conf", "mfcc/MFCC12_E_D_A.conf", "mfcc/MFCC12_E_D_A_Z.conf",
+                            "plp/PLP_0_D_A.conf", "plp/PLP_0_D_A_Z.conf", "plp/PLP_E_D_A.conf", "plp/PLP_E_D_A_Z.conf",
+                            "is09-13/IS09_emotion.conf", "is09-13/IS13_ComParE.conf", "compare16/ComParE_2016.conf",
+                            "egemaps/v02/eGeMAPSv02.conf"}
