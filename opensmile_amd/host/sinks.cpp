@@ -1,6 +1,10 @@
 // HTK / CSV / ARFF writers with the reference sinks' byte layouts and printf formats.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "smilehip_host.hpp"
 
@@ -41,6 +45,7 @@ struct OutBuf {
   explicit OutBuf(FILE *file) : f(file), b((size_t)1 << 20) {}
   char *room(size_t need) {
     if (n + need > b.size()) flush();
+    if (need > b.size()) b.resize(2 * need);
     return b.data() + n;
   }
   void put(const char *s, size_t len) {
@@ -55,6 +60,43 @@ struct OutBuf {
     n = 0;
   }
 };
+
+// rows of text, formatted by fmt(t, dst) -> bytes (at most max_row bytes each), written in order. Long matrices are
+// formatted by several threads, 512 rows per thread and round, and written in order; SMILEHIP_HOST_THREADS overrides the
+// thread count (1 = the sequential path).
+template <class Fmt>
+bool write_text_rows(FILE *f, int64_t rows, size_t max_row, Fmt fmt) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (const char *e = getenv("SMILEHIP_HOST_THREADS")) T = (unsigned)atoi(e);
+  if (T > 32) T = 32;
+  constexpr int64_t kSlice = 512;
+  if (T < 2 || rows < 8 * kSlice) {
+    OutBuf o(f);
+    for (int64_t t = 0; t < rows; ++t) o.n += fmt(t, o.room(max_row));
+    o.flush();
+    return o.ok;
+  }
+  std::vector<std::vector<char>> buf(T, std::vector<char>((size_t)kSlice * max_row));
+  std::vector<size_t> used(T, 0);
+  bool ok = true;
+  for (int64_t t0 = 0; ok && t0 < rows; t0 += (int64_t)T * kSlice) {
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < T; ++i) {
+      const int64_t a = t0 + (int64_t)i * kSlice, b = std::min(rows, a + kSlice);
+      used[i] = 0;
+      if (a >= b) continue;
+      th.emplace_back([&, i, a, b] {
+        size_t n = 0;
+        for (int64_t t = a; t < b; ++t) n += fmt(t, buf[i].data() + n);
+        used[i] = n;
+      });
+    }
+    for (auto &x : th) x.join();
+    for (unsigned i = 0; ok && i < T; ++i)
+      if (used[i]) ok = fwrite(buf[i].data(), 1, used[i], f) == used[i];
+  }
+  return ok;
+}
 }  // namespace
 
 int format_f0(float v, char *dst) {
@@ -177,23 +219,20 @@ bool write_csv(const std::string &path, const std::vector<std::string> &names, c
     for (int c = 0; c < cols - 1; ++c) fprintf(f, "%s%c", names[(size_t)c].c_str(), d);
     fprintf(f, "%s\n", names[(size_t)cols - 1].c_str());
   }
-  OutBuf o(f);
   const std::string name = "'" + opt.instance_name + "'" + d;
-  char tb[64];
-  for (int64_t t = 0; t < rows; ++t) {
-    o.put(name);
-    if (opt.timestamp) { const int n = snprintf(tb, sizeof tb, "%f%c", times ? times[t] : (double)t * period_sec, d); o.put(tb, (size_t)n); }
-    char *p = o.room((size_t)cols * 50);
-    size_t n = 0;
+  const size_t max_row = name.size() + 64 + (size_t)cols * 50;
+  const bool wrote = write_text_rows(f, rows, max_row, [&](int64_t t, char *p) {
+    size_t n = name.size();
+    std::memcpy(p, name.data(), n);
+    if (opt.timestamp) n += (size_t)snprintf(p + n, 64, "%f%c", times ? times[t] : (double)t * period_sec, d);
     for (int c = 0; c < cols; ++c) {
       const float v = x[t * ld + c];
       n += (size_t)((v == std::floor(v)) ? format_f0(v, p + n) : format_e6(v, p + n));      // csvSink.cpp:224-235
       p[n++] = (c == cols - 1) ? '\n' : ';';
     }
-    o.n += n;
-  }
-  o.flush();
-  const bool ok = (fclose(f) == 0) && o.ok;
+    return n;
+  });
+  const bool ok = (fclose(f) == 0) && wrote;
   if (!ok) err = "error writing '" + path + "'";
   return ok;
 }
@@ -231,24 +270,21 @@ bool write_arff(const std::string &path, const std::vector<std::string> &names, 
     fprintf(f, "\n@data\n\n");
   }
   {
-    OutBuf o(f);
     const std::string name = prname ? arff_escape(opt.instance_name) + "," : std::string();
     const std::string tail = "," + (opt.class_value.empty() ? std::string("NULL") : opt.class_value) + "\n";
-    char tb[64];
-    for (int64_t t = 0; t < rows; ++t) {
-      o.put(name);
-      if (opt.timestamp) { const int n = snprintf(tb, sizeof tb, "%f,", (double)t * period_sec); o.put(tb, (size_t)n); }
-      char *p = o.room((size_t)cols * 50);
-      size_t n = 0;
+    const size_t max_row = name.size() + tail.size() + 64 + (size_t)cols * 50;
+    const bool wrote = write_text_rows(f, rows, max_row, [&](int64_t t, char *p) {
+      size_t n = name.size();
+      std::memcpy(p, name.data(), n);
+      if (opt.timestamp) n += (size_t)snprintf(p + n, 64, "%f,", (double)t * period_sec);
       for (int c = 0; c < cols; ++c) {
         if (c) p[n++] = ',';
         n += (size_t)format_e6(x[t * ld + c], p + n);
       }
-      o.n += n;
-      o.put(tail);
-    }
-    o.flush();
-    const bool ok = (fclose(f) == 0) && o.ok;
+      std::memcpy(p + n, tail.data(), tail.size());
+      return n + tail.size();
+    });
+    const bool ok = (fclose(f) == 0) && wrote;
     if (!ok) err = "error writing '" + path + "'";
     return ok;
   }

@@ -395,3 +395,24 @@ def test_fast_number_formatting_equals_printf(hostlib):
     for use_f0 in (0, 1):
         n = hostlib.shim_format_check(x.ctypes.data, len(x), use_f0, C.byref(bad))
         assert n == 0, (use_f0, n, float(x[bad.value]), hex(int(x[bad.value:bad.value + 1].view(np.uint32)[0])))
+
+
+def test_text_writers_threaded_equals_sequential(hostlib, tmp_path):
+    """Long matrices are formatted by several threads (512 rows per thread and round) and written in order: the file is the
+    sequential writer's, byte for byte (20 000 rows: several rounds with a ragged last one; SMILEHIP_HOST_THREADS=1 forces the
+    sequential path)."""
+    rng = np.random.default_rng(9)
+    rows = 20_000 + 37
+    x = (rng.standard_normal((rows, 39)) * 10.0 ** rng.integers(-6, 6, (rows, 39))).astype(np.float32)
+    x[::11, 3] = np.round(x[::11, 3])                  # integral values take the "%.0f" branch
+    outs = {}
+    for tag, env in (("seq", "1"), ("par", "7"), ("auto", None)):
+        if env is None:
+            os.environ.pop("SMILEHIP_HOST_THREADS", None)
+        else:
+            os.environ["SMILEHIP_HOST_THREADS"] = env
+        p = str(tmp_path / (tag + ".csv"))
+        assert hostlib.shim_write_csv(p.encode(), 0, x.ctypes.data, rows, 39, 0.01, b"utt", 0, None) == 1
+        outs[tag] = open(p, "rb").read()
+    os.environ.pop("SMILEHIP_HOST_THREADS", None)
+    assert outs["seq"] == outs["par"] == outs["auto"] and outs["seq"].count(b"\n") == rows + 1
