@@ -189,4 +189,33 @@ std::vector<std::string> func_names_egemaps() {
   return out;
 }
 
+std::vector<int> egemaps_subset_columns(const std::string &set, bool func) {
+  if (set == "gemapsv01b") {
+    if (!func) return {0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 24};       // no flux, no MFCC, no F2 / F3 bandwidth
+    return {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43,
+            44, 45, 46, 47, 50, 51, 52, 53, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 76, 77, 78, 79, 81, 82, 83, 84, 85, 86};
+  }
+  if (set == "egemapsv01b") {
+    std::vector<int> c;
+    const int n = func ? 88 : 25;
+    for (int i = 0; i < n; ++i)
+      if (func || (i != 20 && i != 23)) c.push_back(i);    // the LLD level lacks F2 / F3 bandwidth; the 88 functionals are v02's
+    return c;
+  }
+  return {};
+}
+
+std::vector<std::string> select_names(const std::vector<std::string> &names, const std::vector<int> &cols) {
+  std::vector<std::string> out;
+  for (int c : cols) out.push_back(names.at((size_t)c));
+  return out;
+}
+
+std::vector<float> select_columns(const float *x, int64_t rows, int64_t ld, const std::vector<int> &cols) {
+  std::vector<float> out((size_t)rows * cols.size());
+  for (int64_t t = 0; t < rows; ++t)
+    for (size_t k = 0; k < cols.size(); ++k) out[(size_t)t * cols.size() + k] = x[t * ld + cols[k]];
+  return out;
+}
+
 }  // namespace smilehip_host

@@ -40,6 +40,14 @@ std::vector<std::string> func_names_is09();     // 384: <lld>_<functional>
 std::vector<std::string> func_names_compare16();   // 6373, the functionals level of ComParE_2016.conf
 std::vector<std::string> lld_names_egemaps();      // 25, the LLD level of eGeMAPSv02.conf
 std::vector<std::string> func_names_egemaps();     // 88, its functionals level
+// GeMAPSv01b.conf and eGeMAPSv01b.conf are sub-graphs of eGeMAPSv02.conf whose outputs are column subsets of its outputs (same
+// names, same values, same rows: measured against the binary, tests/test_gemaps_subsets.py): the columns of the v02 LLD level
+// (func = false) / functionals level (func = true) that `set` ("gemapsv01b" | "egemapsv01b") writes, in its order; empty for
+// any other name.
+std::vector<int> egemaps_subset_columns(const std::string &set, bool func);
+std::vector<std::string> select_names(const std::vector<std::string> &names, const std::vector<int> &cols);
+// rows x cols.size() matrix of the selected columns of x (rows x ld)
+std::vector<float> select_columns(const float *x, int64_t rows, int64_t ld, const std::vector<int> &cols);
 // value-name suffixes of one cFunctionals instance in output order (name_append = its functNameAppend option)
 std::vector<std::string> funcspec_value_names(const smilehip_func_spec &spec, const std::string &name_append = "");
 

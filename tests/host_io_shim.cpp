@@ -65,3 +65,19 @@ extern "C" long shim_format_check(const float *x, long n, int use_f0, long *bad)
   }
   return diff;
 }
+
+// egemaps_subset_columns: writes the indices to out (capacity cap), returns their number
+extern "C" int shim_egemaps_subset(const char *set, int func, int *out, int cap) {
+  const std::vector<int> c = egemaps_subset_columns(set, func != 0);
+  for (size_t i = 0; i < c.size() && (int)i < cap; ++i) out[i] = c[i];
+  return (int)c.size();
+}
+// names of the eGeMAPSv02 levels joined with ';' (func: the 88 functionals, else the 25 LLDs)
+extern "C" int shim_egemaps_names(int func, char *out, int cap) {
+  const std::vector<std::string> n = func ? func_names_egemaps() : lld_names_egemaps();
+  std::string s;
+  for (size_t i = 0; i < n.size(); ++i) s += (i ? ";" : "") + n[i];
+  if ((int)s.size() + 1 > cap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)n.size();
+}

@@ -36,6 +36,10 @@ def parse_csv(path):
 
 @pytest.fixture(scope="module")
 def hostlib():
+    return build_hostlib()
+
+
+def build_hostlib():
     """Thin C shim over the C++ writers, compiled on the fly (g++ only, no GPU)."""
     src = os.path.join(ROOT, "tests", "host_io_shim.cpp")
     so = os.path.join(ROOT, "tests", "_host_io_shim.so")
