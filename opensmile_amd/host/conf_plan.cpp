@@ -290,12 +290,15 @@ namespace {
 struct KnownSet { uint64_t fingerprint; const char *set; const char *file; };
 // fingerprints of the reference's own files (smilextract_hip -C <file> --fingerprint prints them), computed from
 // config/is09-13/IS09_emotion.conf, config/compare16/ComParE_2016.conf, config/is09-13/IS13_ComParE.conf and
-// config/egemaps/v02/eGeMAPSv02.conf with their includes and every command-line option at its default
+// config/egemaps/v02/eGeMAPSv02.conf (and its two sub-graphs, GeMAPSv01b.conf / eGeMAPSv01b.conf) with their includes and every command-line option at its default
 const KnownSet kKnownSets[] = {
     {0x84b42d91f07908acull, "is09_emotion", "IS09_emotion.conf"},
     {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf"},
     {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf"},
     {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf"},
+    // sub-graphs of eGeMAPSv02.conf: their levels are column subsets of its levels (smilehip_host.hpp, egemaps_subset_columns)
+    {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf"},
+    {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf"},
 };
 }  // namespace
 

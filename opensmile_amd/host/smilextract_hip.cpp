@@ -13,6 +13,8 @@
 //   smilextract_hip --set compare16     same options as is09_emotion: the whole ComParE_2016.conf, LLD level + 6373 functionals
 //   smilextract_hip --set is13_compare  the same for config/is09-13/IS13_ComParE.conf
 //   smilextract_hip --set egemapsv02    the whole config/egemaps/v02/eGeMAPSv02.conf: 25-column LLD level + 88 functionals
+//   smilextract_hip --set gemapsv01b | egemapsv01b   config/gemaps/v01b/GeMAPSv01b.conf (18 LLDs, 62 functionals) / config/egemaps/v01b/
+//                                       eGeMAPSv01b.conf (23, 88): sub-graphs of eGeMAPSv02.conf, written as column subsets of its levels
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
 //   common: [-instname name] [-outdir dir] [--device d] [--rank r --world n] [--chunk-files n]
 //
@@ -135,7 +137,11 @@ int main(int argc, char **argv) {
   const bool is13 = set == "is13_compare";                     // config/is09-13/IS13_ComParE.conf: same elements, IS13 options
   const bool cmp16f = set == "compare16" || is13;              // the whole ComParE_2016.conf: LLD level + 6373 functionals
   const bool cmp16 = set == "compare16_lld" || cmp16f;
-  const bool egm = set == "egemapsv02";                          // config/egemaps/v02/eGeMAPSv02.conf
+  // GeMAPSv01b.conf / eGeMAPSv01b.conf: sub-graphs of eGeMAPSv02.conf -- the v02 chain runs, the set's columns are written
+  const bool egm_subset = set == "gemapsv01b" || set == "egemapsv01b";
+  const bool egm = set == "egemapsv02" || egm_subset;            // config/egemaps/v02/eGeMAPSv02.conf
+  const std::vector<int> sel_lld = egemaps_subset_columns(set, false), sel_func = egemaps_subset_columns(set, true);
+  if (egm_subset && gather) die("--gather is not available with --set " + set + " (gather the eGeMAPSv02 vectors and select)");
   const bool has_func = is09 || cmp16f || egm;
   // the eight files of config/mfcc and config/plp, by their names in lower case
   std::string variant;                             // upper-case config name for smilehip_config_htk_variant
@@ -145,7 +151,7 @@ int main(int argc, char **argv) {
   const bool htk_variant = free_chain || (!is09 && !cmp16 && !egm && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK);
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
   if (!is09 && !cmp16 && !egm && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare or egemapsv02 (or use -C file.conf)");
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare, egemapsv02, gemapsv01b or egemapsv01b (or use -C file.conf)");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
@@ -233,9 +239,12 @@ int main(int argc, char **argv) {
   };
   const std::vector<std::string> lld_names =
       free_chain ? conf_plan.lld_names
-                 : (is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16() : (egm ? lld_names_egemaps() : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy))));
+                 : (is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16()
+                    : (egm ? (egm_subset ? select_names(lld_names_egemaps(), sel_lld) : lld_names_egemaps())
+                           : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy))));
   const std::vector<std::string> fnames =
-      is09 ? func_names_is09() : (cmp16f ? func_names_compare16() : (egm ? func_names_egemaps() : std::vector<std::string>()));
+      is09 ? func_names_is09() : (cmp16f ? func_names_compare16()
+           : (egm ? (egm_subset ? select_names(func_names_egemaps(), sel_func) : func_names_egemaps()) : std::vector<std::string>()));
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
 
@@ -312,9 +321,12 @@ int main(int argc, char **argv) {
         const Job &job = jobs[idx[i]];
         const float *x = lld.data() + (size_t)row_off[i] * n_out;
         const int64_t r = row_off[i + 1] - row_off[i];
+        int n_w = n_out;                                  // columns written (a subset preset writes its selection)
+        std::vector<float> x_sel;
+        if (egm_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
         const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
         if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
-          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_out, n_out, g.frame_period, lld_opts ? 9 : parm_kind, err)) die(err);
+          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)) die(err);
         if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
           CsvOptions co;
           co.instance_name = job.inst;
@@ -322,15 +334,18 @@ int main(int argc, char **argv) {
           const int64_t n_frames = (cmp16 || egm) ? r - 1 : smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
           std::vector<double> times((size_t)r);
           for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
-          if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_out, n_out, g.frame_period,
+          if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_w, n_w, g.frame_period,
                          times.data(), co, err))
             die(err);
         }
         if (has_func && r > 0) {                          // no frame -> the reference writes no instance
           const float *fv = func.data() + i * (size_t)n_func;
-          func_rows[idx[i] - j0].assign(fv, fv + n_func);
+          int n_fw = n_func;
+          std::vector<float> f_sel;
+          if (egm_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
+          func_rows[idx[i] - j0].assign(fv, fv + n_fw);
           if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
-            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_func, n_func, 0.0, 9, err)) die(err);
+            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) die(err);
         }
       }
       smilehip_free(ctx, d_pcm);

@@ -58,8 +58,12 @@ def test_big_sets_are_recognised_by_their_graph():
     # output options do not change the graph; a changed processing option does
     rc, kv, err = describe(os.path.join(CONF, "is09-13/IS09_emotion.conf"), "-O", "x.arff", "-instname", "a")
     assert rc == 0 and kv["preset"] == "is09_emotion"
-    # GeMAPSv01b is a different graph: refused, naming a component
-    rc, kv, err = describe(os.path.join(CONF, "gemaps/v01b/GeMAPSv01b.conf"))
+    # the two sub-graphs of eGeMAPSv02.conf are presets of their own (column subsets of its levels)
+    for rel, preset in (("gemaps/v01b/GeMAPSv01b.conf", "gemapsv01b"), ("egemaps/v01b/eGeMAPSv01b.conf", "egemapsv01b")):
+        rc, kv, err = describe(os.path.join(CONF, rel))
+        assert rc == 0 and kv["preset"] == preset, err
+    # GeMAPSv01a has other option values (zeroPadSymmetric, useBrokenJitterThresh, formant maxF): a different graph, refused by name
+    rc, kv, err = describe(os.path.join(CONF, "gemaps/v01a/GeMAPSv01a.conf"))
     assert rc != 0 and "cannot run on the fused path" in err and ":c" in err
 
 
@@ -139,7 +143,7 @@ def test_conf_front_end_equals_set(tmp_path):
 
 @needs_conf
 def test_every_reference_conf_gets_a_plan_or_a_named_refusal():
-    """All configuration files of the reference's config/ tree through `smilextract_hip -C <file> --describe`: the twelve the fused
+    """All configuration files of the reference's config/ tree through `smilextract_hip -C <file> --describe`: the fourteen the fused
     path covers produce a plan; every other one is refused with a message that names what is not covered (a component
     instance, an option, a missing section) -- never a crash, a hang or a silent default."""
     confs = sorted(os.path.join(d, f) for d, _, fs in os.walk(CONF) for f in fs if f.endswith(".conf"))
@@ -159,4 +163,4 @@ def test_every_reference_conf_gets_a_plan_or_a_named_refusal():
     assert set(planned) == {"mfcc/MFCC12_0_D_A.conf", "mfcc/MFCC12_0_D_A_Z.conf", "mfcc/MFCC12_E_D_A.conf", "mfcc/MFCC12_E_D_A_Z.conf",
                             "plp/PLP_0_D_A.conf", "plp/PLP_0_D_A_Z.conf", "plp/PLP_E_D_A.conf", "plp/PLP_E_D_A_Z.conf",
                             "is09-13/IS09_emotion.conf", "is09-13/IS13_ComParE.conf", "compare16/ComParE_2016.conf",
-                            "egemaps/v02/eGeMAPSv02.conf"}
+                            "egemaps/v02/eGeMAPSv02.conf", "gemaps/v01b/GeMAPSv01b.conf", "egemaps/v01b/eGeMAPSv01b.conf"}

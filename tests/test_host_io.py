@@ -420,3 +420,42 @@ def test_text_writers_threaded_equals_sequential(hostlib, tmp_path):
         outs[tag] = open(p, "rb").read()
     os.environ.pop("SMILEHIP_HOST_THREADS", None)
     assert outs["seq"] == outs["par"] == outs["auto"] and outs["seq"].count(b"\n") == rows + 1
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_gemaps_subsets(tmp_path):
+    """--set gemapsv01b / egemapsv01b (and -C <their files>): the eGeMAPSv02 chain runs and the sets' columns are written -- the
+    LLD CSV head line, instance name and time stamps and the ARFF attribute block are the real binary's for these files
+    (tests/golden/files/*v01b*), the numbers are the selected columns of what --set egemapsv02 writes for the same input, byte
+    for byte (tests/test_gemaps_subsets.py holds the selection against the binary; test_smilextract_hip_egemapsv02 the numbers)."""
+    wav = os.path.join(G, "u3_4000.wav")
+    v2_htk, v2_f = str(tmp_path / "v2.htk"), str(tmp_path / "v2f.htk")
+    subprocess.run([EXE, "--set", "egemapsv02", "-I", wav, "-lldhtkoutput", v2_htk, "-htkoutput", v2_f, "-instname", "u3"], check=True)
+    h2, x2 = read_htk(v2_htk)
+    _, f2 = read_htk(v2_f)
+    conf_dir = os.path.join(ROOT, "oracle", "_ref", "config")
+    for setname, n_l, n_f, conf in (("gemapsv01b", 18, 62, "gemaps/v01b/GeMAPSv01b.conf"), ("egemapsv01b", 23, 88, "egemaps/v01b/eGeMAPSv01b.conf")):
+        for how in (["--set", setname], ["-C", os.path.join(conf_dir, conf)]):
+            if how[0] == "-C" and not os.path.exists(how[1]):
+                continue
+            htk, csv, fhtk, arff = (str(tmp_path / (setname + e)) for e in (".htk", ".csv", ".f.htk", ".arff"))
+            for p in (htk, csv, fhtk, arff):
+                if os.path.exists(p):
+                    os.remove(p)
+            subprocess.run([EXE] + how + ["-I", wav, "-lldhtkoutput", htk, "-lldcsvoutput", csv, "-htkoutput", fhtk, "-O", arff,
+                                          "-instname", "u3"], check=True)
+            h, x = read_htk(htk)
+            _, f = read_htk(fhtk)
+            assert x.shape == (x2.shape[0], n_l) and f.shape == (1, n_f)
+            head, names, vals, _ = parse_csv(csv)
+            head_r, names_r, vals_r, _ = parse_csv(os.path.join(G, setname + "_lld_u3.csv"))
+            assert head == head_r and names == names_r and vals.shape == vals_r.shape
+            assert np.array_equal(vals[:, 0], vals_r[:, 0])                 # frameTime column
+            cols2 = parse_csv(os.path.join(G, "egemaps_lld_u3.csv"))[0].split(";")[2:]
+            cols = [cols2.index(n) for n in head.split(";")[2:]]
+            assert len(cols) == n_l and np.array_equal(x.view(np.uint32), x2[:, cols].view(np.uint32))
+            got, ref = open(arff).read(), open(os.path.join(G, setname + "_func_u3.arff")).read()
+            assert got.split("@data")[0] == ref.split("@data")[0]
+            fn2 = [l.split()[1] for l in open(os.path.join(G, "egemaps_func_u3.arff")).read().split("@data")[0].split("\n") if l.startswith("@attribute")][1:-1]
+            fn = [l.split()[1] for l in ref.split("@data")[0].split("\n") if l.startswith("@attribute")][1:-1]
+            assert len(fn) == n_f and np.array_equal(f.view(np.uint32), f2[:, [fn2.index(n) for n in fn]].view(np.uint32))
