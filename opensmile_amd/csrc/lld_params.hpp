@@ -1,6 +1,7 @@
 // Kernel parameter block shared by the host API (smilehip_*.cpp) and the device
 // code (lld_kernels.hip). Plain data, passed by value at launch.
 #pragma once
+#include "lld_ooura.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -14,6 +14,8 @@ hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd,
                          int de, hipStream_t s);
 hipError_t stage_window(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
                         const float *w, float off, hipStream_t s);
+hipError_t stage_rfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
+                         int pad_left, const OouraTab &T, hipStream_t s);
 hipError_t stage_rfft(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
                       int pad_left, const float2 *twh, const float2 *twf, hipStream_t s);
 hipError_t stage_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, hipStream_t s);

@@ -3,7 +3,9 @@
 // Same device functions as the fused kernels, so results are identical.
 #include <hip/hip_runtime.h>
 
+#include "lld_blocks.hpp"
 #include "lld_device.hpp"
+#include "lld_ooura.hpp"
 #include "lld_stage.hpp"
 
 namespace smilehip {
@@ -60,6 +62,26 @@ __global__ void __launch_bounds__(256) k_rfft(const float *src, int64_t lds, flo
   float *o = dst + (int64_t)blockIdx.x * ldd;
   for (int k = threadIdx.x; k <= M; k += blockDim.x) {
     const float2 X = untangle_bin(re, im, M, k, tw_full);
+    if (k == 0) o[0] = X.x;
+    else if (k == M) o[1] = X.x;
+    else { o[2 * k] = X.x; o[2 * k + 1] = -X.y; }
+  }
+}
+
+// The same operator on the reference-order transform (lld_ooura.hpp): bit-identical to rdft() of fftsg.c:322-363.
+__global__ void __launch_bounds__(256) k_rfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int N,
+                                                 int pad_left, const OouraTab T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2 *z = reinterpret_cast<float2 *>(smem);
+  const int M = T.M;
+  const float *x = src + (int64_t)blockIdx.x * lds;
+  ooura_forward<BlockG>(z, T, [&](int i) {
+    const int n0 = 2 * i - pad_left, n1 = n0 + 1;
+    return make_float2((n0 >= 0 && n0 < N) ? x[n0] : 0.0f, (n1 >= 0 && n1 < N) ? x[n1] : 0.0f);
+  });
+  float *o = dst + (int64_t)blockIdx.x * ldd;
+  for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+    const float2 X = ooura_bin(z, T, k);
     if (k == 0) o[0] = X.x;
     else if (k == M) o[1] = X.x;
     else { o[2 * k] = X.x; o[2 * k + 1] = -X.y; }
@@ -172,6 +194,13 @@ hipError_t stage_window(const float *src, int64_t lds, float *dst, int64_t ldd, 
                         const float *w, float off, hipStream_t s) {
   if (nF * N > 0)
     hipLaunchKernelGGL(k_window, dim3(nblk(nF * N, 256)), dim3(256), 0, s, src, lds, dst, ldd, nF, N, w, off);
+  return hipGetLastError();
+}
+hipError_t stage_rfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
+                         int pad_left, const OouraTab &T, hipStream_t s) {
+  if (nF > 0)
+    hipLaunchKernelGGL(k_rfft_oo, dim3((unsigned)nF), dim3(256), sizeof(float) * (size_t)Nfft, s, src, lds, dst, ldd,
+                       N, pad_left, T);
   return hipGetLastError();
 }
 hipError_t stage_rfft(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,

@@ -13,7 +13,9 @@
 
 #include "../../include/smilehip.h"
 #include "lld_launch.hpp"
+#include "lld_ooura.hpp"
 #include "lld_params.hpp"
+#include "ooura_tables.hpp"
 #include "tables.hpp"
 
 using namespace smilehip;
@@ -70,6 +72,32 @@ struct DevBuf {
   }
 };
 
+// reference-order FFT tables of one length on the device (ooura_tables.hpp / lld_ooura.hpp)
+struct OouraDev {
+  OouraHost h;
+  DevBuf<float4> d_tw;
+  DevBuf<float2> d_rft;
+  int build(int n, bool upload_tables) {
+    if (make_ooura(n, h)) return fail(SMILEHIP_ERR_INVALID, "reference-order FFT: length %d is not a power of two in [64, 8192]", n);
+    if (!upload_tables) return SMILEHIP_OK;
+    std::vector<float4> t4(h.tw.size() / 4);
+    std::memcpy(t4.data(), h.tw.data(), t4.size() * sizeof(float4));
+    std::vector<float2> r2(h.rft.size() / 2);
+    std::memcpy(r2.data(), h.rft.data(), r2.size() * sizeof(float2));
+    int rc;
+    if ((rc = d_tw.upload(t4)) || (rc = d_rft.upload(r2))) return rc;
+    return SMILEHIP_OK;
+  }
+  OouraTab tab() const {
+    OouraTab T{};
+    T.tw = d_tw.p; T.rft = d_rft.p;
+    T.M = h.M; T.logM = h.logM; T.nlev = h.nlev; T.leaf8 = h.leaf8;
+    for (int l = 0; l < kOouraLevels; ++l) { T.off1[l] = h.off1[l]; T.off2[l] = h.off2[l]; }
+    T.wn4r = h.wn4r; T.wk1r = h.wk1r; T.wk1i = h.wk1i;
+    return T;
+  }
+};
+
 struct smilehip_plan;
 struct smilehip_batch;
 struct smilehip_plan {
@@ -82,6 +110,8 @@ struct smilehip_plan {
   DevBuf<float> d_window, d_mel_coef, d_dct_rows, d_dct_gain;
   DevBuf<int32_t> d_mel_rng;
   DevBuf<float2> d_tw_half, d_tw_full, d_tw256, d_tw512, d_fwin;
+  OouraDev oo;                // the reference-order transform of length Nfft (every chain but the fast MFCC kernel)
+  int fft_radix2 = 0;         // SMILEHIP_FFT=radix2: the round-2 transforms (own butterfly order), kept for A/B timing
   DevBuf<float4> d_melw;
   DevBuf<uint32_t> d_melo;
   DevBuf<float> d_dct28;

@@ -256,6 +256,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   if ((rc = p->d_dct_gain.upload(p->dct.gain))) return rc;
   if ((rc = p->d_tw_half.upload(twh))) return rc;
   if ((rc = p->d_tw_full.upload(twf))) return rc;
+  if (p->geo.Nfft >= 64 && p->geo.Nfft <= 8192) { if ((rc = p->oo.build((int)p->geo.Nfft, true))) return rc; }
+  else p->fft_radix2 = 1;     // lengths the reference-order network is not built for: own radix-2 order (no BASELINE config)
   if (is_plp && ((rc = p->d_plp_eql.upload(plp_eql)) || (rc = p->d_plp_cos.upload(p->h_plp_cos)) || (rc = p->d_plp_sin.upload(plp_sin))))
     return rc;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 &&
@@ -445,6 +447,7 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
   p->cfg = *cfg;
   const char *fg = getenv("SMILEHIP_FORCE_GENERIC");
   p->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+  { const char *ff = std::getenv("SMILEHIP_FFT"); p->fft_radix2 = (ff && std::strcmp(ff, "radix2") == 0) ? 1 : 0; }
   int rc = build_tables(p);
   if (rc == SMILEHIP_OK && cfg->chain_kind == SMILEHIP_CHAIN_COMPARE) {      // the 60 ms sub-chain
     smilehip_lld_config c60;

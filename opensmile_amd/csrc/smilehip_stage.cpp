@@ -58,6 +58,9 @@ extern "C" int smilehip_rfft_frames(smilehip_plan *p, const float *d_src, int64_
   int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.N, p->geo.Nfft, "smilehip_rfft_frames");
   if (rc) return rc;
   const int pad = p->cfg.zero_pad_symmetric ? (int)((p->geo.Nfft - p->geo.N) / 2) : 0;
+  if (!p->fft_radix2)
+    STAGE_RET(stage_rfft_oo(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.N, (int)p->geo.Nfft, pad, p->oo.tab(),
+                            (hipStream_t)stream), "rfft");
   STAGE_RET(stage_rfft(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.N, (int)p->geo.Nfft, pad, p->d_tw_half.p,
                        p->d_tw_full.p, (hipStream_t)stream), "rfft");
 }

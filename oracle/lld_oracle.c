@@ -270,8 +270,10 @@ void lldo_rfft_frame(const float *src, long Nsrc, float *dst, long Nfft, int zer
     float *w = (float *)calloc(1, sizeof(float) * (size_t)(Nfft / 2 + 1));
     g_rfft_hook((int)Nfft, 1, dst, ip, w);
     free(ip); free(w);
+  } else if (Nfft >= 64) {
+    lldo_ooura_rdft((int)Nfft, 1, dst);   /* the reference's operation order, lld_oracle_fft.c */
   } else {
-    own_rfft_packed(dst, Nfft);
+    own_rfft_packed(dst, Nfft);           /* n < 64: own radix-2 order (no BASELINE config gets here) */
   }
 }
 

@@ -57,6 +57,7 @@ void lldo_irfft_packed_real(float *a, long n)
     free(ip); free(w);
     return;
   }
+  if (n >= 64 && lldo_ooura_rdft((int)n, -1, a) == 0) return;   /* the reference's operation order */
   /* s[j] = R_j (j <= n/2), s[n-j] = R_j: DFT(s)[k] = 2 a[k] */
   float *s = (float *)malloc(sizeof(float) * (size_t)n);
   float *f = (float *)malloc(sizeof(float) * (size_t)n);
