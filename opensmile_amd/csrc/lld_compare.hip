@@ -112,16 +112,24 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
-      re[r] = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
-      im[r] = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+      const float v0 = (n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f;
+      const float v1 = (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f;
+      if (P.oo.tw) {
+        reinterpret_cast<float2 *>(re)[i] = make_float2(v0, v1);
+      } else {
+        const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+        re[r] = v0;
+        im[r] = v1;
+      }
     }
     __syncthreads();
     PHASE(0);   // load + window
-    block_cfft_radix2(re, im, M, P.tw_half);
+    if (P.oo.tw) ooura_levels<BlockG, false>(reinterpret_cast<float2 *>(re), P.oo);   // the reference's rdft network
+    else block_cfft_radix2(re, im, M, P.tw_half);
     PHASE(1);   // FFT
     for (int k = threadIdx.x; k <= M; k += blockDim.x) {
-      const float m = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
+      const float2 X = P.oo.tw ? ooura_bin(reinterpret_cast<const float2 *>(re), P.oo, k) : untangle_bin(re, im, M, k, P.tw_full);
+      const float m = bin_magnitude(X, k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;                                    // squareInput (spectral.cpp:676-683) == melspec usePower
     }
@@ -193,11 +201,12 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
+  const OouraTab OO = oo_stage_tables(P.oo, s_dct + 16 * 32, threadIdx.x, blockDim.x);   // reference-order FFT tables (or none)
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
   const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 96;
-  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + wave * per_wave);   // the transform's (re, im) pairs, lld_fft.hpp
+  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
   float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
   float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
@@ -242,13 +251,15 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
     // ComParE level of a small batch, where the kernel runs beside the jitter pass -- not kept)
     for (int n = lane; n < P.N; n += 64) yv[n] = pcm16_to_float(x[n]);
     WaveG::sync();
-    wave_cfft(z, M, P.tw_half, lane, [&](int i) {
+    const auto load_pair = [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
                          (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
-    });
+    };
+    if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);   // the reference's rdft network (lld_ooura.hpp)
+    else wave_cfft(z, M, P.tw_half, lane, load_pair);
     for (int k = lane; k <= M; k += 64) {
-      const float m = bin_magnitude(wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
+      const float m = bin_magnitude(OO.tw ? ooura_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;
     }
@@ -462,7 +473,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
     static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);

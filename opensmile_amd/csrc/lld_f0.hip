@@ -51,10 +51,13 @@ struct F0Tbl {
   const float *win;      // [NP]
   const float2 *twh;     // [kM/2]
   const float2 *twf;     // [kM/2+4]
+  OouraTab oo;           // reference-order transform: its tables take the place of twh | twf (kF0TwBytes)
 };
+// LDS bytes of the transform's tables: radix-2 order twh | twf = 4128 B, reference order (lld_ooura.hpp, M = 512) 6016 B
+constexpr size_t kF0TwBytes = 6144;
 __host__ __device__ inline size_t f0_shared_bytes(int N) {
   const size_t np = (size_t)((N + 3) & ~3);
-  return (size_t)kKP * 16 + (size_t)kKP * 8 * 7 + (size_t)kKP * 4 + np * 4 + (size_t)(kM / 2) * 8 + (size_t)(kM / 2 + 4) * 8;
+  return (size_t)kKP * 16 + (size_t)kKP * 8 * 7 + (size_t)kKP * 4 + np * 4 + kF0TwBytes;
 }
 // one frame's LDS region: A[kKP] B[kKP] doubles | ci[8] ints (ci[7]: number of candidates) | cf[3][8] floats | double
 constexpr size_t kFrameBytes = (size_t)kKP * 16 + 8 * 4 + 24 * 4 + 16;   // + the frame's sum of squares
@@ -127,20 +130,26 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   } else {
   // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168); the transform's first pass
   // asks for the inputs it needs (lld_fft.hpp)
-  WaveFft<9>::forward(z, T.twh, lane, [&](int i) {
+  const auto load_pair = [&](int i) {
     const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
     float a = 0.0f, b = 0.0f;
     if (n0 >= 0 && n0 < Q.N) { a = pcm16_to_float(x[n0]) * T.win[n0]; const float sq = a * a; esum += (double)sq; }
     if (n1 >= 0 && n1 < Q.N) { b = pcm16_to_float(x[n1]) * T.win[n1]; const float sq = b * b; esum += (double)sq; }
     return make_float2(a, b);
-  });
-  // (lane l summed the inputs brev6(l) + 64 k: low offsets first is the tree the sum had when lane l held l + 64 m)
-  esum += wave_down_d<1>(esum); esum += wave_down_d<2>(esum); esum += wave_down_d<4>(esum);     // (lane 0's tree of the xor
-  esum += wave_down_d<8>(esum); esum += wave_down_d<16>(esum); esum += wave_down_d<32>(esum);  //  butterfly, lld_blocks.hpp)
-  esum = wave_first_d(esum);
+  };
+  if (T.oo.tw) {                                         // the reference's rdft network (lld_ooura.hpp); lane l holds l + 64 m
+    ooura_forward<WaveG>(z, T.oo, load_pair);
+    esum = WaveG::sum(esum, nullptr);
+  } else {
+    WaveFft<9>::forward(z, T.twh, lane, load_pair);
+    // (lane l summed the inputs brev6(l) + 64 k: low offsets first is the tree the sum had when lane l held l + 64 m)
+    esum += wave_down_d<1>(esum); esum += wave_down_d<2>(esum); esum += wave_down_d<4>(esum);     // (lane 0's tree of the xor
+    esum += wave_down_d<8>(esum); esum += wave_down_d<16>(esum); esum += wave_down_d<32>(esum);  //  butterfly, lld_blocks.hpp)
+    esum = wave_first_d(esum);
+  }
   F0_FOR_BINS(m, k) {
     mg[m] = 0.0;
-    if (k < kK) mg[m] = (double)bin_magnitude(fft_untangle<WaveFft<9>>(z, k, T.twf), k == 0 || k == kM);
+    if (k < kK) mg[m] = (double)bin_magnitude(T.oo.tw ? ooura_bin(z, T.oo, k) : fft_untangle<WaveFft<9>>(z, k, T.twf), k == 0 || k == kM);
   }
   WaveG::sync();                                         // the transform's buffer reaches into B
   }
@@ -471,10 +480,15 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
     c_k[i] = Q.ip_k[i];
   }
   for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
-  for (int i = threadIdx.x; i < kM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
-  for (int i = threadIdx.x; i <= kM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  OouraTab c_oo = OouraTab{};
+  if (Q.oo.tw) c_oo = oo_stage_tables(Q.oo, reinterpret_cast<float *>(c_twh), threadIdx.x, blockDim.x);
+  else {
+    for (int i = threadIdx.x; i < kM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
+    for (int i = threadIdx.x; i <= kM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  }
   __syncthreads();                                       // the only workgroup barrier
   F0Tbl T;
+  T.oo = c_oo;
   T.sp = c_sp; T.dec = c_dec; T.d1 = c_d1; T.d2 = c_d2; T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw;
   T.k = c_k; T.win = c_win; T.twh = c_twh; T.twf = c_twf;
   unsigned char *base = smem_f0 + f0_shared_bytes(Q.N) + (size_t)wave * (kW * kFrameBytes);
@@ -543,7 +557,7 @@ __device__ __forceinline__ int64_t f0_bb_index(int64_t fr, int i) {
 }
 __host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // d1 | d2 | win | twh | twf
   const size_t np = (size_t)((N + 3) & ~3);
-  return (size_t)kKP * 8 * 2 + np * 4 + (size_t)(kM / 2) * 8 + (size_t)(kM / 2 + 4) * 8;
+  return (size_t)kKP * 8 * 2 + np * 4 + kF0TwBytes;
 }
 __host__ __device__ inline size_t f0_cand_shared_bytes() { return (size_t)kKP * 8 * 4 + (size_t)kKP * 4; }   // a | c | d | audw | k
 
@@ -558,10 +572,15 @@ __global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_p
   float2 *c_twf = c_twh + kM / 2;
   for (int i = threadIdx.x; i < kK; i += blockDim.x) { c_d1[i] = Q.sp_d1[i]; c_d2[i] = Q.sp_d2[i]; }
   for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
-  for (int i = threadIdx.x; i < kM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
-  for (int i = threadIdx.x; i <= kM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  OouraTab c_oo = OouraTab{};
+  if (Q.oo.tw) c_oo = oo_stage_tables(Q.oo, reinterpret_cast<float *>(c_twh), threadIdx.x, blockDim.x);
+  else {
+    for (int i = threadIdx.x; i < kM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
+    for (int i = threadIdx.x; i <= kM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  }
   __syncthreads();
   F0Tbl T = {};
+  T.oo = c_oo;
   T.d1 = c_d1; T.d2 = c_d2; T.win = c_win; T.twh = c_twh; T.twf = c_twf;
   double *A = reinterpret_cast<double *>(smem_f0 + f0_spec_shared_bytes(Q.N)) + (size_t)wave * 2 * kKP;
   const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;

@@ -177,11 +177,12 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
+  const OouraTab OO = oo_stage_tables(P.oo, s_dct + 16 * 32, threadIdx.x, blockDim.x);   // reference-order FFT tables (or none)
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
   const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 64 + 96;
-  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + wave * per_wave);   // the transform's (re, im) pairs, lld_fft.hpp
+  float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
   float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
   float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
@@ -224,14 +225,16 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       for (int n = lane; n < P.N; n += 64) { const float tmp = yv[n]; e2 += tmp * tmp; }
       e2 = WaveG::sum(e2, nullptr);
     }
-    wave_cfft(z, M, P.tw_half, lane, [&](int i) {
+    const auto load_pair = [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
                          (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
-    });
+    };
+    if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);   // the reference's rdft network (lld_ooura.hpp)
+    else wave_cfft(z, M, P.tw_half, lane, load_pair);
     float *spec = G.spec220 + (f0 + t) * kRsI;
     for (int k = lane; k <= M; k += 64) {
-      const float2 X = wave_untangle(z, M, zpad, k, P.tw_full);
+      const float2 X = OO.tw ? ooura_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full);
       const float m = bin_magnitude(X, k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;                                     // squareInput (spectral.cpp:677-684) == melspec usePower
@@ -672,6 +675,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 // mg[516] | acf[516]
 namespace {
 constexpr int kHM = 512, kHK = 513, kHKP = 516;
+constexpr size_t kHarmTwBytes = 6144;                   // twh | twf (4128 B) or the reference-order tables (6016 B, lld_ooura.hpp)
 constexpr int kHarmWaves = 8;                          // 8.7 KB of LDS per wave + 7.9 KB of tables per workgroup: two workgroups = 16 waves per CU
 __device__ __forceinline__ int harm_is_peak(const float *x, int N, int n) {  // cHarmonics::isPeak, :369-390
   if (n >= N || n < 0) return 0;
@@ -706,12 +710,16 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
   float2 *c_twh = reinterpret_cast<float2 *>(c_win + NP);
   float2 *c_twf = c_twh + kHM / 2;
   for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
-  for (int i = threadIdx.x; i < kHM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
-  for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  OouraTab OO = OouraTab{};                              // reference-order transform: its tables take the place of twh | twf
+  if (Q.oo.tw) OO = oo_stage_tables(Q.oo, reinterpret_cast<float *>(c_twh), threadIdx.x, blockDim.x);
+  else {
+    for (int i = threadIdx.x; i < kHM / 2; i += blockDim.x) c_twh[i] = Q.tw_half[i];
+    for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
+  }
   __syncthreads();                                       // the only workgroup barrier
   using Fft = WaveFft<9>;                                // kHM == 512: fused passes on (re, im) pairs, lld_fft.hpp
   constexpr int per_wave = 2 * Fft::kZ + 2 * kHKP;
-  float2 *z = reinterpret_cast<float2 *>(c_twf + (kHM / 2 + 4)) + (size_t)wave * (per_wave / 2);
+  float2 *z = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(c_twh) + kHarmTwBytes) + (size_t)wave * (per_wave / 2);
   float *mg = reinterpret_cast<float *>(z + Fft::kZ);
   float *acf = mg + kHKP;
   int *hbin = reinterpret_cast<int *>(z);                // the harmonics' arrays live in the transform's buffer (dead after the ACF)
@@ -755,17 +763,28 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         for (int k = lane; k <= kHM; k += 64) mg[k] = mi[k];
       } else {
         const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
-        Fft::forward(z, c_twh, lane, [&](int i) {
+        const auto load_pair = [&](int i) {
           const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
           return make_float2((n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f,
                              (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f);
-        });
-        for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
+        };
+        if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);
+        else Fft::forward(z, c_twh, lane, load_pair);
+        for (int k = lane; k <= kHM; k += 64)
+          mg[k] = bin_magnitude(OO.tw ? ooura_bin(z, OO, k) : fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
       }
       WaveG::sync();
       GPHASE(0);   // load, window, FFT, magnitudes
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
-      {
+      if (OO.tw) {                                       // rdft(N, -1) on the packed squares (harmonics.cpp:609-627)
+        ooura_inverse<WaveG>(z, OO, [&](int e) {
+          if (e == 0) { const float m0 = mg[0], m1 = mg[kHM]; return make_float2(m0 * m0, m1 * m1); }
+          const float m = mg[e];
+          return make_float2(m * m, 0.0f);
+        });
+        for (int k = lane; k <= kHM; k += 64) acf[k] = fabsf(ooura_inverse_out(z, OO, k)) / (float)kHK;
+        WaveG::sync();
+      } else {
         const int n = 2 * kHM;
         Fft::forward(z, c_twh, lane, [&](int i) {        // the squared magnitudes, formed as they are asked for
           const int n0 = 2 * i, n1 = 2 * i + 1;
@@ -1100,7 +1119,7 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   if (P.Nfft != 512 || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + 4 * (2 * fft_pairs(M) + 3 * Kpad + 64 + 96));
+  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 64 + 96));
   hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -1116,7 +1135,8 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
   if (n_tiles <= 0) return hipSuccess;
   if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
   const int NP = (Q.N + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)NP + sizeof(float2) * (size_t)(kHM / 2 + kHM / 2 + 4) +
+  if (sizeof(float) * (size_t)oo_table_floats(Q.oo) > kHarmTwBytes) return hipErrorInvalidValue;
+  const size_t lds = sizeof(float) * (size_t)NP + kHarmTwBytes +
                      sizeof(float) * kHarmWaves * (size_t)(2 * WaveFft<9>::kZ + 2 * kHKP);
   const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -29,6 +29,7 @@ struct Is09Tbl {
   const float *mel_coef;
   const int32_t *mel_rng;
   const float *dct_rows;
+  OouraTab oo;
 };
 
 // LDS, workgroup form: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
@@ -91,7 +92,13 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     if (G::tid() == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
   }
   // R4 forward real FFT
-  if constexpr (kWave) {
+  if (T.oo.tw) {                                         // the reference's operation order (lld_ooura.hpp)
+    ooura_forward<G>(z, T.oo, [&](int i) {
+      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+      return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f);
+    });
+    for (int k = G::tid(); k <= M; k += G::size()) mg[k] = bin_magnitude(ooura_bin(z, T.oo, k), k == 0 || k == M);   // R5
+  } else if constexpr (kWave) {
     wave_cfft(z, M, T.tw_half, G::tid(), [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f);
@@ -124,14 +131,16 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
   G::sync();
-  if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, acf, (float)P.K, true, G::tid());
+  if (T.oo.tw) oo_irfft_even<G>(sp, z, T.oo, acf, (float)P.K, true);
+  else if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, acf, (float)P.K, true, G::tid());
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, acf, (float)P.K, true);
   for (int k = G::tid(); k <= M; k += G::size()) {
     const float p = mg[k] * mg[k];
     sp[k] = (p > 0.0f) ? (float)log_d((double)p + 1.0) : 0.0f;                              // :288-305
   }
   G::sync();
-  if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
+  if (T.oo.tw) oo_irfft_even<G>(sp, z, T.oo, cep, (float)P.K, false);
+  else if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, cep, (float)P.K, false);
 
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
@@ -151,7 +160,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
 // one workgroup per frame (any FFT size the LDS holds)
 __global__ void __launch_bounds__(256) lld_is09_frame(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Is09Tbl T = {P.window, P.tw_half, P.tw_full, P.mel_coef, P.mel_rng, P.dct_rows};
+  const Is09Tbl T = {P.window, P.tw_half, P.tw_full, P.mel_coef, P.mel_rng, P.dct_rows, P.oo};
   is09_frame_body<BlockG>(P, Q, T, (int64_t)blockIdx.x, smem);
 }
 
@@ -176,11 +185,12 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
   for (int i = threadIdx.x; i < P.K; i += 256) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += 256) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += 256) s_dct[i] = P.dct_rows[i];
+  const OouraTab s_oo = oo_stage_tables(P.oo, smem + is09_table_floats(P.N, M, P.K), threadIdx.x, 256);
   __syncthreads();                                       // the only workgroup barrier
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= P.total_frames) return;
-  const Is09Tbl T = {s_win, s_twh, s_twf, s_coef, s_rng, s_dct};
-  float *wave_mem = smem + is09_table_floats(P.N, M, P.K) + (threadIdx.x >> 6) * wave_floats;
+  const Is09Tbl T = {s_win, s_twh, s_twf, s_coef, s_rng, s_dct, s_oo};
+  float *wave_mem = smem + is09_table_floats(P.N, M, P.K) + oo_table_floats(P.oo) + (threadIdx.x >> 6) * wave_floats;
   if (M == 256) is09_frame_body<WaveG, 256>(P, Q, T, row, wave_mem);
   else is09_frame_body<WaveG>(P, Q, T, row, wave_mem);
 }
@@ -232,10 +242,11 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   // wave form: no yv, no cep of their own
   const size_t lds_wave = sizeof(float) * (size_t)(Npad + 2 * fft_pairs(M) + 2 * Kpad + M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
   hipError_t e;
-  if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * (size_t)is09_table_floats(P.N, M, P.K) <= 64 * 1024 &&
+  const size_t tbl_floats = (size_t)is09_table_floats(P.N, M, P.K) + (size_t)oo_table_floats(P.oo);
+  if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
       !getenv("SMILEHIP_IS09_BLOCK")) {                                // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds_wave + 15) / 16) * 4;
-    const size_t total = sizeof(float) * ((size_t)is09_table_floats(P.N, M, P.K) + 4 * (size_t)wave_floats);
+    const size_t total = sizeof(float) * (tbl_floats + 4 * (size_t)wave_floats);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), total, s, P, Q, wave_floats);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lld_device.hpp"
+#include "lld_blocks.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
 
@@ -66,18 +67,24 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
       }
       v[h] = y;
     }
-    const int r = (int)(__brev((unsigned)i) >> (32 - logM));
-    re[r] = v[0];
-    im[r] = v[1];
+    if (P.oo.tw) {                                         // reference-order transform: natural order, (re, im) pairs
+      reinterpret_cast<float2 *>(smem)[i] = make_float2(v[0], v[1]);
+    } else {
+      const int r = (int)(__brev((unsigned)i) >> (32 - logM));
+      re[r] = v[0];
+      im[r] = v[1];
+    }
   }
   __syncthreads();
 
-  // R4: radix-2 DIT, complex length M
-  block_cfft_radix2(re, im, M, P.tw_half);
+  // R4: the reference's rdft network (lld_ooura.hpp), or the radix-2 DIT of round 2 (SMILEHIP_FFT=radix2)
+  if (P.oo.tw) ooura_levels<BlockG, false>(reinterpret_cast<float2 *>(smem), P.oo);
+  else block_cfft_radix2(re, im, M, P.tw_half);
 
   // real-FFT untangle + R5 magnitude (+ R6's squaring, melspec.cpp:520-527)
   for (int k = threadIdx.x; k <= M; k += blockDim.x) {
-    const float mag = bin_magnitude(untangle_bin(re, im, M, k, P.tw_full), k == 0 || k == M);
+    const float2 X = P.oo.tw ? ooura_bin(reinterpret_cast<const float2 *>(smem), P.oo, k) : untangle_bin(re, im, M, k, P.tw_full);
+    const float mag = bin_magnitude(X, k == 0 || k == M);
     pw[k] = P.use_power ? mag * mag : mag;
   }
   __syncthreads();

@@ -20,6 +20,7 @@ struct OouraTab {                 // device view of OouraHost (ooura_tables.hpp)
   const float4 *tw;               // level tables
   const float2 *rft;              // (wkr, wki), k = 0 .. M/2 - 1
   int M, logM, nlev, leaf8;
+  int n_tw;                       // records (float4) in tw
   int off1[kOouraLevels], off2[kOouraLevels];
   float wn4r, wk1r, wk1i;
 };
@@ -280,6 +281,36 @@ __device__ __forceinline__ void ooura_inverse(float2 *z, const OouraTab &T, Load
 __device__ __forceinline__ float ooura_inverse_out(const float2 *z, const OouraTab &T, int i) {
   const float2 a = z[oo_rev(i >> 1, T.logM)];
   return (i & 1) ? -a.y : a.x;                               // bitrv2conj
+}
+
+
+// cAcf's use of the inverse transform (acf.cpp:308-343): the packed spectrum (R[0], R[M], R[1], 0, R[2], 0, ...) of the real
+// values R[0..M], rdft(2M, -1), lags 0 .. M-1 divided by inv_norm (acfCepsNormOutput: Nsrc = M + 1; otherwise 1), |.| for the ACF
+template <class G>
+__device__ __forceinline__ void oo_irfft_even(const float *R, float2 *z, const OouraTab &T, float *out, float inv_norm,
+                                              bool take_abs) {
+  const int M = T.M;
+  ooura_inverse<G>(z, T, [&](int e) { return e == 0 ? make_float2(R[0], R[M]) : make_float2(R[e], 0.0f); });
+  for (int i = G::tid(); i < M; i += G::size()) {
+    const float v = ooura_inverse_out(z, T, i) / inv_norm;     // acf.cpp:321-325: (FLOAT_DMEM)data / (FLOAT_DMEM)Nsrc
+    out[i] = take_abs ? fabsf(v) : v;
+  }
+  G::sync();
+}
+
+// floats of LDS a staged copy of the tables takes, and the staging itself (all threads of the workgroup; the caller
+// synchronises): the returned view points into lds
+__host__ __device__ inline int oo_table_floats(const OouraTab &T) { return T.tw ? 4 * T.n_tw + T.M : 0; }
+__device__ __forceinline__ OouraTab oo_stage_tables(const OouraTab &T, float *lds, int tid, int nthreads) {
+  OouraTab S = T;
+  if (!T.tw) return S;
+  float4 *tw = reinterpret_cast<float4 *>(lds);
+  float2 *rft = reinterpret_cast<float2 *>(lds + 4 * T.n_tw);
+  for (int i = tid; i < T.n_tw; i += nthreads) tw[i] = T.tw[i];
+  for (int i = tid; i < (T.M >> 1); i += nthreads) rft[i] = T.rft[i];
+  S.tw = tw;
+  S.rft = rft;
+  return S;
 }
 
 }  // namespace smilehip

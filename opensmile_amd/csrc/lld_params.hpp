@@ -42,6 +42,7 @@ struct LldParams {
   // R4: complex FFT of length M = Nfft/2 + real untangle
   const float2 *tw_half;       // [M/2]  e^{-2 pi i j / M}
   const float2 *tw_full;       // [M/2+1] e^{-2 pi i k / Nfft}
+  OouraTab oo;                 // reference-order transform (lld_ooura.hpp); oo.tw == nullptr: the radix-2 order above
   // R6
   const float *mel_coef;       // [K]
   const int32_t *mel_rng;      // [4*n_bands] rise_lo, rise_hi, fall_lo, fall_hi per band
@@ -110,6 +111,7 @@ struct F0Params {
   const float *window;              // [N]
   const float2 *tw_half;            // [M/2], M = Nfft/2
   const float2 *tw_full;            // [M/2+1]
+  OouraTab oo;                      // reference-order transform (lld_ooura.hpp); oo.tw == nullptr: the radix-2 order above
   // cSpecScale: natural cubic spline over the octave-scaled bin positions (smileUtilSpline.c:139-212); the
   // decomposition part of the tridiagonal sweep does not depend on the data and is precomputed:
   const double *sp_rec;             // [K x 4] per bin i: sigma_i, p_i = 1/(sigma_i*dec_{i-1}+2), dec_i = (sigma_i-1)*p_i, 0

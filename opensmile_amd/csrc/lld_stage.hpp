@@ -30,7 +30,7 @@ hipError_t stage_valbased(const float *src, int64_t lds, int N, int64_t nF, int 
                           int zerovec, int remove_idx, float output_val, float *dst, int64_t ldd, int32_t *keep, hipStream_t s);
 hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_out, int use_power,
                      int cepstrum, int norm_output, int abs_cepstrum, const float2 *tw_half, const float2 *tw_full,
-                     hipStream_t s);
+                     const OouraTab &OO, hipStream_t s);
 hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,
                           int32_t *max_idx, hipStream_t s);
 struct PlpConsts { float melfloor, compression, iir, fir[5]; };

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) k_zcr_count(const float *src, int64_t lds
 // R9 cAcf::processVector, forward path (acf.cpp:249-349). LDS: sp[K+3] | re[M] | im[M] | res[M]
 __global__ void __launch_bounds__(256) k_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int K, int n_out,
                                              int use_power, int cepstrum, int norm_output, int abs_cepstrum,
-                                             const float2 *tw_half, const float2 *tw_full) {
+                                             const float2 *tw_half, const float2 *tw_full, const OouraTab OO) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = K - 1;
   float *sp = smem;
@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(256) k_acf(const float *src, int64_t lds, floa
     sp[k] = p;
   }
   __syncthreads();
-  irfft_even(sp, re, im, M, logM, tw_half, tw_full, res, norm_output ? (float)K : 1.0f, cepstrum ? abs_cepstrum != 0 : true);
+  if (OO.tw) oo_irfft_even<BlockG>(sp, reinterpret_cast<float2 *>(re), OO, res, norm_output ? (float)K : 1.0f, cepstrum ? abs_cepstrum != 0 : true);
+  else irfft_even(sp, re, im, M, logM, tw_half, tw_full, res, norm_output ? (float)K : 1.0f, cepstrum ? abs_cepstrum != 0 : true);
   for (int k = threadIdx.x; k < n_out; k += blockDim.x) dst[(int64_t)blockIdx.x * ldd + k] = res[k];
 }
 
@@ -192,14 +193,14 @@ hipError_t stage_zcr_count(const float *src, int64_t lds, int64_t N, int64_t nF,
 }
 hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_out, int use_power,
                      int cepstrum, int norm_output, int abs_cepstrum, const float2 *tw_half, const float2 *tw_full,
-                     hipStream_t s) {
+                     const OouraTab &OO, hipStream_t s) {
   if (nF <= 0) return hipSuccess;
   const int M = K - 1;
   const size_t lds_bytes = sizeof(float) * (size_t)(((K + 3) & ~3) + 3 * M);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_acf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_acf, dim3((unsigned)nF), dim3(256), lds_bytes, s, src, lds, dst, ldd, K, n_out, use_power, cepstrum,
-                     norm_output, abs_cepstrum, tw_half, tw_full);
+                     norm_output, abs_cepstrum, tw_half, tw_full, OO);
   return hipGetLastError();
 }
 hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, double fs_sec, double max_pitch, double *voicing,

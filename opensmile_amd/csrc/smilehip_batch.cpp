@@ -236,6 +236,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.window = p->d_window.p;
   P.tw_half = p->d_tw_half.p;
   P.tw_full = p->d_tw_full.p;
+  P.oo = p->fft_radix2 ? OouraTab{} : p->oo.tab();
   P.mel_coef = p->d_mel_coef.p;
   P.mel_rng = p->d_mel_rng.p;
   P.mel_scale = p->mel.scale;
@@ -481,6 +482,7 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.window = plan->d_window.p;
   Q.tw_half = plan->d_tw_half.p;
   Q.tw_full = plan->d_tw_full.p;
+  Q.oo = plan->fft_radix2 ? OouraTab{} : plan->oo.tab();
   Q.sp_rec = plan->d_f0_rec.p; Q.sp_d1 = plan->d_f0_d1.p; Q.sp_d2 = plan->d_f0_d2.p;
   Q.ip_k = plan->d_f0_k.p; Q.ip_co = plan->d_f0_co.p; Q.audw = plan->d_f0_audw.p;
   Q.n_harm = plan->f0.n_harm;

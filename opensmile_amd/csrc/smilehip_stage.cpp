@@ -102,7 +102,7 @@ extern "C" int smilehip_acf_frames(smilehip_plan *p, const float *d_src, int64_t
   int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.K, n_out, "smilehip_acf_frames");
   if (rc) return rc;
   STAGE_RET(stage_acf(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.K, (int)n_out, use_power, cepstrum, norm_output,
-                      abs_cepstrum, p->d_tw_half.p, p->d_tw_full.p, (hipStream_t)stream), "acf");
+                      abs_cepstrum, p->d_tw_half.p, p->d_tw_full.p, p->fft_radix2 ? OouraTab{} : p->oo.tab(), (hipStream_t)stream), "acf");
 }
 
 extern "C" int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
