@@ -31,6 +31,7 @@ def main():
               "audSpec_Rfilt (sma)": list(range(10, 36)), "spectral (sma)": list(range(36, 51)), "mfcc 1-14 (sma)": list(range(51, 65)),
               "F0 group deltas": list(range(65, 71)), "groups A+B deltas": list(range(71, 130))}
     dev = {k: [] for k in groups}
+    same = {k: [] for k in groups}
     rows = 0
     for i, pcm in enumerate(pcms):
         ref = lldo.run_reference_lld("compare16/ComParE_2016.conf", pcm)
@@ -40,12 +41,15 @@ def main():
         scale = np.maximum(np.abs(ref[:, :65]).max(axis=0), 1e-6)
         scale = np.concatenate([scale, scale])
         rel = np.abs(o.astype(np.float64) - ref) / scale[None, :]
+        eq = np.ascontiguousarray(o, np.float32).view(np.uint32) == np.ascontiguousarray(ref, np.float32).view(np.uint32)
         for k, cols in groups.items():
             dev[k].append(rel[:, cols].max(axis=1))
+            same[k].append(eq[:, cols].ravel())
     res = {"utterances": args.utts, "rows": rows, "reference": "oracle/_ref/SMILExtract -C compare16/ComParE_2016.conf -lldhtkoutput"}
     for k, v in dev.items():
         d = np.concatenate(v)
-        res[k] = {"max_rel": float(d.max()), "rows_over_1e-5": float((d > 1e-5).mean()), "rows_over_1e-3": float((d > 1e-3).mean())}
+        res[k] = {"max_rel": float(d.max()), "rows_over_1e-5": float((d > 1e-5).mean()), "rows_over_1e-3": float((d > 1e-3).mean()),
+                  "rows_over_1e-6": float((d > 1e-6).mean()), "cells_bit_identical": float(np.concatenate(same[k]).mean())}
     print(json.dumps(res, indent=1))
 
 

@@ -21,7 +21,8 @@ def stats(a, b, scale=None):
         return {"n": 0}
     sc = np.maximum(np.abs(b).max(axis=0), 1e-6) if scale is None else scale
     e = np.abs(a - b) / sc
-    return {"n": int(a.shape[0]), "max_scaled": float(e.max()), "p999": float(np.quantile(e, 0.999)), "p99": float(np.quantile(e, 0.99)),
+    bi = float((np.asarray(a, np.float32).view(np.uint32) == np.asarray(b, np.float32).view(np.uint32)).mean())
+    return {"n": int(a.shape[0]), "bit_identical": bi, "frac_gt_1e-6": float((e > 1e-6).mean()), "max_scaled": float(e.max()), "p999": float(np.quantile(e, 0.999)), "p99": float(np.quantile(e, 0.99)),
             "frac_gt_1e-5": float((e > 1e-5).mean()), "frac_gt_1e-3": float((e > 1e-3).mean()),
             "worst_col": int(np.argmax(e.max(axis=0))) if e.ndim == 2 else 0}
 
@@ -73,7 +74,7 @@ def main():
             assert not func[i].any(), "utterance without a 60 ms frame must give zeros"
     fr = np.array(fr); fg = np.array(fg)
     rel = np.abs(fg - fr) / np.maximum(np.abs(fr), 1e-2)
-    rep["func"] = {"n_vectors": int(fr.shape[0]), "bit_identical_frac": float((fg == fr).mean()), "frac_within_1e-5": float((rel <= 1e-5).mean()),
+    rep["func"] = {"n_vectors": int(fr.shape[0]), "bit_identical_frac": float((fg.astype(np.float32).view(np.uint32) == fr.astype(np.float32).view(np.uint32)).mean()), "frac_within_1e-5": float((rel <= 1e-5).mean()),
                    "frac_within_1e-3": float((rel <= 1e-3).mean()), "max_rel": float(rel.max()), "p99_rel": float(np.quantile(rel, 0.99)),
                    "worst_cols": np.argsort(-rel.max(axis=0))[:8].tolist(), "worst_vals": np.sort(rel.max(axis=0))[::-1][:8].tolist()}
     rep["func"]["col87"] = [[float(a), float(b)] for a, b in zip(fg[:, 87], fr[:, 87])]
