@@ -23,27 +23,24 @@ def hip():
 
 
 def f0_lld_tolerances(out, ref, what=""):
-    """The 12 F0-group columns. F0 / voicing are continuous; jitter, shimmer and HNR follow from integer period bounds
-    derived from F0 and from the voiced/unvoiced pattern, so they agree exactly on almost every row and may differ on the
-    rare rows where a decision flips. Measured (profiles/r02_gate_margins.json, and 32 770 rows of fresh utterances in
-    profiles/r01_final_compare_parity.json): no row beyond 1e-4 of the column scale, 0.3 % of the rows beyond 1e-5, largest
-    deviation 8.8e-5 (a frame where the parabolic refinement of the SHS peak sits on a different float of the summation
-    spectrum). Gates at about twice that: <= 0.2 % of the rows beyond 1e-4 (one row for short inputs), <= 1 % beyond 1e-5,
-    nothing beyond 2e-4."""
+    """The 12 F0-group columns (F0final, voicing, jitterLocal, jitterDDP, shimmerLocal, logHNR and their deltas). Round 3: the
+    60 ms spectrum comes out of the reference's rdft network (lld_ooura.hpp) and every stage downstream of it was already
+    bit-exact on identical input, so the columns are the reference's bits (profiles/r03_compare_parity.json: 32 770 rows of
+    fresh utterances against the real binary, every cell identical). Only logHNR passes a libm call (log, in double): one cell
+    in ~1e8 may round the other way. Round 2's gate was statistical: <= 1 % of the rows beyond 1e-5, nothing beyond 2e-4."""
     assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
     if out.shape[0] == 0:
         return
-    o, r = out.astype(np.float64), ref.astype(np.float64)
+    o, r = np.ascontiguousarray(out, np.float32), np.ascontiguousarray(ref, np.float32)
+    same = (o.view(np.uint32) == r.view(np.uint32)) | ((o == 0) & (r == 0))
     scale = np.maximum(np.abs(r[:, :6]).max(axis=0), 1e-6)
     scale = np.concatenate([scale, scale])
-    bad = (np.abs(o - r) > 1e-4 * scale[None, :]).any(axis=1)
+    dev = (np.abs(o.astype(np.float64) - r) / scale[None, :]).max()
     from tolerance import record
-    record("f0_lld_tolerances", what=what, rows=len(bad), bad_frac=bad.mean(), bad5_frac=(np.abs(o - r) > 1e-5 * scale[None, :]).any(axis=1).mean(),
-           max_scaled=(np.abs(o - r) / scale[None, :]).max())
-    assert bad.sum() <= max(1, 0.002 * len(bad)), f"{what}: {int(bad.sum())} of {len(bad)} rows deviate by more than 1e-4"
-    bad5 = (np.abs(o - r) > 1e-5 * scale[None, :]).any(axis=1)
-    assert bad5.sum() <= max(1, 0.01 * len(bad5)), f"{what}: {int(bad5.sum())} of {len(bad5)} rows deviate by more than 1e-5"
-    assert (np.abs(o - r) / scale[None, :]).max() <= 2e-4, f"{what}: largest deviation {(np.abs(o - r) / scale[None, :]).max():.3g}"
+    record("f0_lld_tolerances", what=what, rows=o.shape[0], cells_identical=float(same.mean()), max_scaled=float(dev))
+    nolog = [0, 1, 2, 3, 4, 6, 7, 8, 9, 10]
+    assert same[:, nolog].all(), f"{what}: {int((~same[:, nolog]).sum())} F0 / voicing / jitter / shimmer cells differ from the reference"
+    assert dev <= 1e-6 and same.mean() >= 0.999, f"{what}: logHNR deviates by {dev:.3g}, {same.mean():.5f} identical"
 
 
 def test_compare_full_golden_batch_ragged(hip, golden_f0):

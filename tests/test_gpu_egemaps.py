@@ -86,46 +86,55 @@ def test_pending_counts_match_the_oracle(run_all, golden, oracle):
 
 
 # ------------------------------------------------------------------ chain vs the real binary's levels
-@pytest.mark.parametrize("level,cols,tol", [("loudness", slice(0, 1), 5e-7), ("lspec", slice(1, 5), 5e-6), ("flux", slice(5, 6), 8e-7),
-                                            ("mfcc", slice(6, 10), 5e-6), ("energy2", slice(10, 11), 1e-7)])
+@pytest.mark.parametrize("level,cols,tol", [("loudness", slice(0, 1), 0.0), ("lspec", slice(1, 5), 1e-6), ("flux", slice(5, 6), 0.0),
+                                            ("mfcc", slice(6, 10), 1e-6), ("energy2", slice(10, 11), 0.0)])
 def test_20ms_levels_vs_golden(run_all, golden, level, cols, tol):
+    """Round 3: the transform is the reference's rdft network, so every level that has no libm call downstream of it is
+    the binary's bit for bit (tol 0 = bits_equal); the log-spectrum and log-mel levels differ by the last bit of
+    logf / log (device library vs glibc), <= 1e-6 of the column scale."""
     width = cols.stop - cols.start
-    e = scaled_err(run_all["taps"]["raw20"][:, cols], cat(golden, level, width))
-    assert e.max() <= tol, f"{level}: {e.max():.3g}"
+    got, ref = run_all["taps"]["raw20"][:, cols], cat(golden, level, width)
+    if tol == 0.0:
+        assert bits_equal(got, ref).all(), f"{level}: {(~bits_equal(got, ref)).sum()} cells differ"
+    else:
+        e = scaled_err(got, ref)
+        assert e.max() <= tol, f"{level}: {e.max():.3g}"
 
 
 def test_pitch_level_vs_golden(run_all, golden):
-    """gemapsv01b_logPitch [F0final, F0finalLog, voicing]: same voicing decisions, values within 4e-7 of the column scale."""
+    """gemapsv01b_logPitch [F0final, F0finalLog, voicing]: F0final and voicing are the binary's bits; F0finalLog goes
+    through log(): <= 4e-7 of the column scale."""
     g, r = run_all["taps"]["pitch3"], cat(golden, "pitch", 3)
-    assert np.array_equal(g[:, 0] > 0, r[:, 0] > 0)
+    assert bits_equal(g[:, [0, 2]], r[:, [0, 2]]).all()
     assert scaled_err(g, r).max() <= 4e-7
 
 
 def test_jitter_shimmer_vs_golden(run_all, golden):
     t = run_all["taps"]
     jit = np.concatenate([t["jit4"][:, 0:1], t["shim_db"]], axis=1)
-    e = scaled_err(jit, cat(golden, "jitter", 2))
-    assert (e > 1e-6).mean() <= 0.002, f"jitter: {(e > 1e-6).mean():.4f} of the cells differ"
+    assert bits_equal(jit, cat(golden, "jitter", 2)).all()
 
 
-def test_formants_and_harmonics_vs_golden_at_the_float32_floor(run_all, golden):
-    """Measured: formants 1.9 % of the cells beyond 1e-3 of the scale, harmonics 0.2 % of the rows (the CPU oracle with a
-    different FFT: 1.9 % / 0.13 %). Gates at about twice that; the median deviation is 2.6e-6."""
+def test_lpc_formants_bit_identical_and_harmonics_vs_golden(run_all, golden):
+    """cSpecResample -> cLpc -> cFormantLpc from the 20 ms spectrum: the binary's bits (round 2: 1.9 % of the formant cells
+    beyond 1e-3 -- the root finder amplified the last bit of a different FFT order). Harmonics: dB values through log10,
+    <= 1e-6 of the column scale."""
     t = run_all["taps"]
-    ef = scaled_err(t["formants"], cat(golden, "formants", 10))
-    assert (ef > 1e-3).mean() <= 0.04 and np.median(ef) <= 6e-6, ((ef > 1e-3).mean(), np.median(ef))
+    assert bits_equal(t["lpc"][:, :11], cat(golden, "lpc", 11)).all()
+    assert bits_equal(t["formants"], cat(golden, "formants", 10)).all()
     eh = scaled_err(t["harm6"], cat(golden, "harm", 6))
-    assert (eh > 1e-5).any(axis=1).mean() <= 0.01, (eh > 1e-5).any(axis=1).mean()
+    assert eh.max() <= 1e-6, eh.max()
 
 
 def test_lld_level_vs_golden(run_all, golden):
     ref = np.concatenate([golden["lld_" + k].reshape(-1, 25) for k in KEYS], axis=0)
     e = scaled_err(run_all["lld"], ref)
-    well = list(range(0, 15))                       # 20 ms descriptors, F0, jitter, shimmer, H1-H2, (HNR: column 13)
-    assert e[:, [c for c in well if c != 13]].max() <= 5e-6
-    assert (e[:, 13] > 1e-5).mean() <= 0.005        # HNR: the ACF peak next to the F0 lag may move
-    # formant columns (frequency, bandwidth, amplitude of F1..F3) and H1-A3: bounded share of rows outside the band
-    assert (e[:, 15:] > 1e-3).mean() <= 0.08 and np.median(e[:, 15:]) <= 2e-5
+    assert e.max() <= 1e-6, (e.max(), int(np.argmax(e.max(axis=0))))
+    # columns without a libm call on their path: loudness, flux, F0 (semitone scale excluded), jitter, shimmer, formant
+    # frequencies and bandwidths -- the binary's bits
+    same = bits_equal(run_all["lld"], ref).mean(axis=0)
+    for c in (0, 5, 6, 8, 11, 12, 13, 16, 17, 19, 20, 22, 23):
+        assert same[c] == 1.0, (c, same[c])
 
 
 # ------------------------------------------------------------------ stages on identical inputs
@@ -166,9 +175,8 @@ def test_stage_harmonics_identical_input(gm, golden, oracle):
         ref = oracle.egemaps_harmonics_rows(f0, fm, t60["mag"])
         out = capi.harmonics_host(plan, f0, fm, t60["mag"])
         e = scaled_err(out, ref)
-        # the harmonic search is exact on identical magnitudes; the HNR's ACF comes from another FFT (peak may move: <= 1 %)
-        assert e[:, 1:].max() <= 1e-6, key
-        assert (e[:, 0] > 1e-5).mean() <= 0.01, key
+        # the harmonic search and the HNR's ACF (the reference's inverse rdft network) are exact on identical magnitudes
+        assert e.max() <= 1e-6, key
 
 
 # ------------------------------------------------------------------ selectors / smoothers / functionals
@@ -230,9 +238,8 @@ def test_functionals_vs_golden(run_all, golden):
     fr, fg = np.array(fr), np.array(fg)
     rel = np.abs(fg - fr) / np.maximum(np.abs(fr), 1e-2)
     # F0 (0..9), loudness (10..19), flux / mfcc mean + stddevNorm (20..29), temporal set (81..86), leq (87)
-    well = list(range(0, 30)) + list(range(81, 88))
-    assert np.quantile(rel[:, well], 0.98) <= 1e-4, np.quantile(rel[:, well], 0.98)
-    assert (rel <= 1e-3).mean() >= 0.93
+    assert rel.max() <= 2e-5, (rel.max(), int(np.argmax(rel.max(axis=0))))      # round 2: 93 % within 1e-3
+    assert bits_equal(fg, fr).mean() >= 0.94
 
 
 # ------------------------------------------------------------------ batch properties at a larger size
