@@ -256,10 +256,10 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
                          (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
     };
-    if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);   // the reference's rdft network (lld_ooura.hpp)
+    if (OO.tw) oo_wave_forward(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
     else wave_cfft(z, M, P.tw_half, lane, load_pair);
     for (int k = lane; k <= M; k += 64) {
-      const float m = bin_magnitude(OO.tw ? ooura_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
+      const float m = bin_magnitude(OO.tw ? oo_wave_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;
     }

@@ -120,6 +120,7 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
+template <bool OO>                                     // OO: the reference-order transform (one form per kernel instance: register budget)
 __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const int16_t *x, const float *mag_in, int lane,
                                               double *A, double *B) {
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
@@ -137,8 +138,8 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     if (n1 >= 0 && n1 < Q.N) { b = pcm16_to_float(x[n1]) * T.win[n1]; const float sq = b * b; esum += (double)sq; }
     return make_float2(a, b);
   };
-  if (T.oo.tw) {                                         // the reference's rdft network (lld_ooura.hpp); lane l holds l + 64 m
-    ooura_forward<WaveG>(z, T.oo, load_pair);
+  if constexpr (OO) {                                    // the reference's rdft network (lld_ooura_wave.hpp); lane l holds l + 64 m
+    oo_wave_forward<kM>(z, T.oo, lane, load_pair);
     esum = WaveG::sum(esum, nullptr);
   } else {
     WaveFft<9>::forward(z, T.twh, lane, load_pair);
@@ -149,7 +150,11 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   }
   F0_FOR_BINS(m, k) {
     mg[m] = 0.0;
-    if (k < kK) mg[m] = (double)bin_magnitude(T.oo.tw ? ooura_bin(z, T.oo, k) : fft_untangle<WaveFft<9>>(z, k, T.twf), k == 0 || k == kM);
+    if (k < kK) {
+      float2 X;
+      if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k); else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
+      mg[m] = (double)bin_magnitude(X, k == 0 || k == kM);
+    }
   }
   WaveG::sync();                                         // the transform's buffer reaches into B
   }
@@ -459,6 +464,7 @@ __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64
   WaveG::sync();
 }
 
+template <bool OO>
 __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Params Q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         if (mode == 2) break;
-        const double es = f0_spectrum(T, Q, P.pcm + samp0 + (int64_t)(tf + w) * Q.H,
+        const double es = f0_spectrum<OO>(T, Q, P.pcm + samp0 + (int64_t)(tf + w) * Q.H,
                                       mode == 1 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr, lane, A, A + kKP);
         if (lane == 0) *reinterpret_cast<double *>(reinterpret_cast<int *>(A + 2 * kKP) + 8 + 24) = es;
       }
@@ -561,6 +567,7 @@ __host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // d1 | d2 
 }
 __host__ __device__ inline size_t f0_cand_shared_bytes() { return (size_t)kKP * 8 * 4 + (size_t)kKP * 4; }   // a | c | d | audw | k
 
+template <bool OO>
 __global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_f0_spec(LldParams P, F0Params Q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
@@ -588,7 +595,7 @@ __global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_p
   const int64_t samp0 = P.tile_rec[tile].samp0;
   const int n_fr = P.tile_rec[tile].n_frames;
   for (int w = 0; w < n_fr; ++w) {
-    const double es = f0_spectrum(T, Q, P.pcm + samp0 + (int64_t)w * Q.H, nullptr, lane, A, A + kKP);
+    const double es = f0_spectrum<OO>(T, Q, P.pcm + samp0 + (int64_t)w * Q.H, nullptr, lane, A, A + kKP);
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     double *row = Q.ab + fr * kKP;
     double *bb = Q.ab + Q.ab_rows * kKP;
@@ -1376,7 +1383,9 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
   (void)max_blocks;
   const size_t lds_spec = f0_spec_shared_bytes(Q0.N) + (size_t)kSpecWaves * 2 * kKP * sizeof(double);
   const size_t lds_cand = f0_cand_shared_bytes() + (size_t)kSpecWaves * kFrameBytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
+  const bool oo = Q0.oo.tw != nullptr;
+  hipError_t e = hipFuncSetAttribute(oo ? reinterpret_cast<const void *>(&lld_f0_spec<true>) : reinterpret_cast<const void *>(&lld_f0_spec<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
@@ -1385,7 +1394,8 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
     Q.tile0 = t0;
     Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
     const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
-    hipLaunchKernelGGL(lld_f0_spec, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    if (oo) hipLaunchKernelGGL(lld_f0_spec<true>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    else hipLaunchKernelGGL(lld_f0_spec<false>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
     hipLaunchKernelGGL(lld_f0_sweep, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
     hipLaunchKernelGGL(lld_f0_cand, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
@@ -1420,7 +1430,8 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   for (int h = 0; h + 1 < Q.n_harm && h < 16; ++h)
     if (Q.shift[h] < 0 || Q.shift[h] > 4 * kKP - 9 * 64) return hipErrorInvalidValue;
   const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
-  const void *fn = reinterpret_cast<const void *>(&lld_f0_frame);
+  const bool oo = Q.oo.tw != nullptr;
+  const void *fn = oo ? reinterpret_cast<const void *>(&lld_f0_frame<true>) : reinterpret_cast<const void *>(&lld_f0_frame<false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int64_t tiles = (Q.n_rows + kTileFrames - 1) / kTileFrames;
@@ -1428,7 +1439,8 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   if (grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;
   LldParams P;
   std::memset(&P, 0, sizeof(P));
-  hipLaunchKernelGGL(lld_f0_frame, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  if (oo) hipLaunchKernelGGL(lld_f0_frame<true>, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  else hipLaunchKernelGGL(lld_f0_frame<false>, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
   return hipGetLastError();
 }
 

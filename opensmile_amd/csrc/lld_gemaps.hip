@@ -230,11 +230,11 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
                          (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
     };
-    if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);   // the reference's rdft network (lld_ooura.hpp)
+    if (OO.tw) oo_wave_forward(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
     else wave_cfft(z, M, P.tw_half, lane, load_pair);
     float *spec = G.spec220 + (f0 + t) * kRsI;
     for (int k = lane; k <= M; k += 64) {
-      const float2 X = OO.tw ? ooura_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full);
+      const float2 X = OO.tw ? oo_wave_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full);
       const float m = bin_magnitude(X, k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;                                     // squareInput (spectral.cpp:677-684) == melspec usePower
@@ -768,21 +768,21 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
           return make_float2((n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f,
                              (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f);
         };
-        if (OO.tw) ooura_forward<WaveG>(z, OO, load_pair);
+        if (OO.tw) oo_wave_forward<kHM>(z, OO, lane, load_pair);
         else Fft::forward(z, c_twh, lane, load_pair);
         for (int k = lane; k <= kHM; k += 64)
-          mg[k] = bin_magnitude(OO.tw ? ooura_bin(z, OO, k) : fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
+          mg[k] = bin_magnitude(OO.tw ? oo_wave_bin<kHM>(z, OO, k) : fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
       }
       WaveG::sync();
       GPHASE(0);   // load, window, FFT, magnitudes
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
       if (OO.tw) {                                       // rdft(N, -1) on the packed squares (harmonics.cpp:609-627)
-        ooura_inverse<WaveG>(z, OO, [&](int e) {
+        oo_wave_inverse<kHM>(z, OO, lane, [&](int e) {
           if (e == 0) { const float m0 = mg[0], m1 = mg[kHM]; return make_float2(m0 * m0, m1 * m1); }
           const float m = mg[e];
           return make_float2(m * m, 0.0f);
         });
-        for (int k = lane; k <= kHM; k += 64) acf[k] = fabsf(ooura_inverse_out(z, OO, k)) / (float)kHK;
+        for (int k = lane; k <= kHM; k += 64) acf[k] = fabsf(oo_wave_inverse_out<kHM>(z, OO, k)) / (float)kHK;
         WaveG::sync();
       } else {
         const int n = 2 * kHM;

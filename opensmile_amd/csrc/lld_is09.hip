@@ -92,12 +92,18 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     if (G::tid() == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
   }
   // R4 forward real FFT
-  if (T.oo.tw) {                                         // the reference's operation order (lld_ooura.hpp)
-    ooura_forward<G>(z, T.oo, [&](int i) {
+  if (T.oo.tw) {                                         // the reference's operation order (lld_ooura.hpp / lld_ooura_wave.hpp)
+    const auto load_pair = [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < P.N) ? yv[n1] : 0.0f);
-    });
-    for (int k = G::tid(); k <= M; k += G::size()) mg[k] = bin_magnitude(ooura_bin(z, T.oo, k), k == 0 || k == M);   // R5
+    };
+    if constexpr (kWave) {
+      oo_wave_forward<MC>(z, T.oo, G::tid(), load_pair);
+      for (int k = G::tid(); k <= M; k += 64) mg[k] = bin_magnitude(oo_wave_bin<MC>(z, T.oo, k), k == 0 || k == M);  // R5
+    } else {
+      ooura_forward<G>(z, T.oo, load_pair);
+      for (int k = G::tid(); k <= M; k += G::size()) mg[k] = bin_magnitude(ooura_bin(z, T.oo, k), k == 0 || k == M);   // R5
+    }
   } else if constexpr (kWave) {
     wave_cfft(z, M, T.tw_half, G::tid(), [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
@@ -131,7 +137,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
   G::sync();
-  if (T.oo.tw) oo_irfft_even<G>(sp, z, T.oo, acf, (float)P.K, true);
+  if (T.oo.tw) { if constexpr (kWave) oo_wave_irfft_even<MC>(sp, z, T.oo, acf, (float)P.K, true, G::tid()); else oo_irfft_even<G>(sp, z, T.oo, acf, (float)P.K, true); }
   else if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, acf, (float)P.K, true, G::tid());
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, acf, (float)P.K, true);
   for (int k = G::tid(); k <= M; k += G::size()) {
@@ -139,7 +145,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     sp[k] = (p > 0.0f) ? (float)log_d((double)p + 1.0) : 0.0f;                              // :288-305
   }
   G::sync();
-  if (T.oo.tw) oo_irfft_even<G>(sp, z, T.oo, cep, (float)P.K, false);
+  if (T.oo.tw) { if constexpr (kWave) oo_wave_irfft_even<MC>(sp, z, T.oo, cep, (float)P.K, false, G::tid()); else oo_irfft_even<G>(sp, z, T.oo, cep, (float)P.K, false); }
   else if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, cep, (float)P.K, false);
 

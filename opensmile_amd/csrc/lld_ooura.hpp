@@ -21,9 +21,10 @@ struct OouraTab {                 // device view of OouraHost (ooura_tables.hpp)
   const float2 *rft;              // (wkr, wki), k = 0 .. M/2 - 1
   int M, logM, nlev, leaf8;
   int n_tw;                       // records (float4) in tw
-  int off1[kOouraLevels], off2[kOouraLevels];
   float wn4r, wk1r, wk1i;
 };
+// Table layout (ooura_tables.cpp): level 0 (quarter q0 = M/4): q0 type-1 records at 0; every further level with q > 1: q type-1
+// records, then 2q type-2 records. (No offset arrays in the struct: a dynamically indexed member would put it into scratch.)
 
 // type of node `node` of level `level` (ooura_tables.hpp): trailing child-3 digits inherit, child 1 is type 2
 __device__ __forceinline__ int oo_node_type(unsigned node, int level) {
@@ -177,11 +178,12 @@ __device__ __forceinline__ void oo_leaf8_t2(float2 (&a)[8], float wn4r, float wk
 template <class G, bool BWD>
 __device__ __forceinline__ void ooura_levels(float2 *z, const OouraTab &T) {
   const int M = T.M;
-  int level = 0, lq = T.logM - 2;
+  int level = 0, lq = T.logM - 2, off = 0;
   for (; level < T.nlev; ++level, lq -= 2) {
     const int q = 1 << lq;
-    const float4 *t1 = T.tw + (T.off1[level] >= 0 ? T.off1[level] : 0);
-    const float4 *t2 = T.tw + (T.off2[level] >= 0 ? T.off2[level] : 0);
+    const float4 *t1 = T.tw + off;
+    const float4 *t2 = t1 + q;
+    off += level == 0 ? q : 3 * q;
     for (int b = G::tid(); b < (M >> 2); b += G::size()) {
       const unsigned node = (unsigned)b >> lq;
       const int c = b & (q - 1);

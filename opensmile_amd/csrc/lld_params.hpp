@@ -2,6 +2,7 @@
 // code (lld_kernels.hip). Plain data, passed by value at launch.
 #pragma once
 #include "lld_ooura.hpp"
+#include "lld_ooura_wave.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

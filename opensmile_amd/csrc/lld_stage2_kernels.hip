@@ -57,6 +57,35 @@ __global__ void __launch_bounds__(256) k_acf(const float *src, int64_t lds, floa
   for (int k = threadIdx.x; k < n_out; k += blockDim.x) dst[(int64_t)blockIdx.x * ldd + k] = res[k];
 }
 
+// the same operator for K = 257 / 513: one wave per frame on the register form of the inverse network, four frames per workgroup.
+// LDS per wave: sp[Kpad] | z[M pairs]
+__global__ void __launch_bounds__(256) k_acf_oo_wave(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K,
+                                                     int n_out, int use_power, int cepstrum, int norm_output, int abs_cepstrum,
+                                                     const OouraTab OO) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  if (f >= nF) return;
+  const int M = K - 1, Kpad = (K + 3) & ~3;
+  float *sp = smem + (size_t)wave * (Kpad + 2 * M);
+  float2 *z = reinterpret_cast<float2 *>(sp + Kpad);
+  const float *m = src + f * lds;
+  for (int k = lane; k < K; k += 64) {
+    float p = m[k];
+    if (use_power) p = p * p;                                                              // :252-259
+    if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
+    sp[k] = p;
+  }
+  oo_wave_sync();
+  oo_wave_inverse(z, OO, lane, [&](int e) { return e == 0 ? make_float2(sp[0], sp[M]) : make_float2(sp[e], 0.0f); });
+  const float inv_norm = norm_output ? (float)K : 1.0f;
+  const bool take_abs = cepstrum ? abs_cepstrum != 0 : true;
+  for (int i = lane; i < n_out; i += 64) {
+    const float v = oo_wave_inverse_out(z, OO, i) / inv_norm;
+    dst[f * ldd + i] = take_abs ? fabsf(v) : v;
+  }
+}
+
 // R10 cPitchACF::processVector, per-frame analysis (pitchACF.cpp:137-192): src = [acf(n) | cepstrum(n)]
 __global__ void __launch_bounds__(256) k_pitchacf(const float *src, int64_t lds, int n, double fs_sec, double max_pitch,
                                                   double *voicing, int32_t *max_idx) {
@@ -196,6 +225,12 @@ hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int
                      const OouraTab &OO, hipStream_t s) {
   if (nF <= 0) return hipSuccess;
   const int M = K - 1;
+  if (OO.tw && (M == 256 || M == 512)) {
+    const size_t lb = 4 * sizeof(float) * (size_t)(((K + 3) & ~3) + 2 * M);
+    hipLaunchKernelGGL(k_acf_oo_wave, dim3((unsigned)((nF + 3) / 4)), dim3(256), lb, s, src, lds, dst, ldd, nF, K, n_out, use_power,
+                       cepstrum, norm_output, abs_cepstrum, OO);
+    return hipGetLastError();
+  }
   const size_t lds_bytes = sizeof(float) * (size_t)(((K + 3) & ~3) + 3 * M);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_acf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;

@@ -88,6 +88,29 @@ __global__ void __launch_bounds__(256) k_rfft_oo(const float *src, int64_t lds, 
   }
 }
 
+// FFT 512 / 1024: one wave per frame, the register form of the same network (lld_ooura_wave.hpp), four frames per workgroup
+__global__ void __launch_bounds__(256) k_rfft_oo_wave(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N,
+                                                      int pad_left, const OouraTab T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  if (f >= nF) return;
+  const int M = T.M;
+  float2 *z = reinterpret_cast<float2 *>(smem) + (size_t)wave * M;
+  const float *x = src + f * lds;
+  oo_wave_forward(z, T, lane, [&](int i) {
+    const int n0 = 2 * i - pad_left, n1 = n0 + 1;
+    return make_float2((n0 >= 0 && n0 < N) ? x[n0] : 0.0f, (n1 >= 0 && n1 < N) ? x[n1] : 0.0f);
+  });
+  float *o = dst + f * ldd;
+  for (int k = lane; k <= M; k += 64) {
+    const float2 X = oo_wave_bin(z, T, k);
+    if (k == 0) o[0] = X.x;
+    else if (k == M) o[1] = X.x;
+    else { o[2 * k] = X.x; o[2 * k + 1] = -X.y; }
+  }
+}
+
 // cFFTmagphase::processVector, magnitude branch (fftmagphase.cpp:215-221)
 __global__ void k_fftmag(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft) {
   const int K = Nfft / 2 + 1;
@@ -198,7 +221,11 @@ hipError_t stage_window(const float *src, int64_t lds, float *dst, int64_t ldd, 
 }
 hipError_t stage_rfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int N, int Nfft,
                          int pad_left, const OouraTab &T, hipStream_t s) {
-  if (nF > 0)
+  if (nF <= 0) return hipSuccess;
+  if (T.M == 256 || T.M == 512)
+    hipLaunchKernelGGL(k_rfft_oo_wave, dim3((unsigned)((nF + 3) / 4)), dim3(256), 4 * sizeof(float) * (size_t)Nfft, s, src, lds,
+                       dst, ldd, nF, N, pad_left, T);
+  else
     hipLaunchKernelGGL(k_rfft_oo, dim3((unsigned)nF), dim3(256), sizeof(float) * (size_t)Nfft, s, src, lds, dst, ldd,
                        N, pad_left, T);
   return hipGetLastError();

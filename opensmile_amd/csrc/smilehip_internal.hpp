@@ -93,7 +93,6 @@ struct OouraDev {
     T.tw = d_tw.p; T.rft = d_rft.p;
     T.M = h.M; T.logM = h.logM; T.nlev = h.nlev; T.leaf8 = h.leaf8;
     T.n_tw = (int)(h.tw.size() / 4);
-    for (int l = 0; l < kOouraLevels; ++l) { T.off1[l] = h.off1[l]; T.off2[l] = h.off2[l]; }
     T.wn4r = h.wn4r; T.wk1r = h.wk1r; T.wk1i = h.wk1i;
     return T;
   }

@@ -62,3 +62,36 @@ def test_rfft_stage_bits_equal_reference_order(nfft, n_frame, sym):
     ref = own_rdft(padded, 1)
     diff = bits(got) != bits(ref)
     assert not diff.any(), f"Nfft={nfft}: {diff.sum()} of {diff.size} words differ, first at {np.argwhere(diff)[0]}"
+
+
+@pytest.mark.parametrize("nfft", [128, 512, 1024, 2048])
+def test_acf_stage_inverse_bits_equal_reference_order(nfft):
+    """cAcf's inverse transform (rdft(N, -1) on the packed real spectrum, acf.cpp:308-343) through smilehip_acf_frames:
+    |lag| values identical to the oracle's inverse network (pinned against the real rdft) -- FFT 512 / 1024 take the
+    register form (one wave per frame), the other lengths the in-place LDS form."""
+    import torch
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    cfg = capi.mfcc12_0_d_a_config()
+    cfg.force_frame_size = nfft
+    cfg.stage_mask = capi.STAGE_FFT
+    plan = capi.Plan(ctx, cfg)
+    K, M = nfft // 2 + 1, nfft // 2
+    rows = 120
+    rng = np.random.default_rng(5 + nfft)
+    mag = np.abs(rng.standard_normal((rows, K))).astype(np.float32)
+    mag[0] = 0.0
+    mag[1] = 0.0; mag[1, 3] = 1.0
+    mag[2] = np.round(mag[2] * 4) / 4
+    d_m = torch.from_numpy(mag).cuda()
+    d_a = torch.empty((rows, M), dtype=torch.float32, device="cuda")
+    capi._check(capi.load().smilehip_acf_frames(plan._h, d_m.data_ptr(), K, d_a.data_ptr(), M, M, rows, 0, 0, 0, 0, None))
+    torch.cuda.synchronize()
+    got = d_a.cpu().numpy()
+    packed = np.zeros((rows, nfft), dtype=np.float32)
+    packed[:, 0] = mag[:, 0]
+    packed[:, 1] = mag[:, K - 1]
+    packed[:, 2::2] = mag[:, 1:K - 1]
+    ref = np.abs(own_rdft(packed, -1)[:, :M])
+    diff = bits(got) != bits(ref)
+    assert not diff.any(), f"Nfft={nfft}: {diff.sum()} of {diff.size} words differ, first at {np.argwhere(diff)[0]}"
