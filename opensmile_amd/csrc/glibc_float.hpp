@@ -1,0 +1,117 @@
+// logf / expf / log10f as the reference's C library computes them.
+//
+// openSMILE calls logf (cMfcc's log-mel, cSpectral's log spectra, ...), expf and log10f of the host's glibc. Those are not
+// correctly rounded (logf: <= 0.818 ulp, it rounds a double of ~2^-26 relative error), so a correctly rounded device logarithm
+// differs from the reference in the last bit on a few percent of the arguments -- the only difference left between this
+// library's LLD levels and the reference's once the FFT follows the reference's order. The functions below restate glibc 2.35's
+// algorithms operation for operation (sysdeps/ieee754/flt-32/e_logf.c, e_expf.c: S. Nagy's table + polynomial in double, in
+// the x86-64 "fma" build the dynamic linker selects on every CPU with FMA -- the products and sums below are fused exactly where
+// GCC fuses them there; e_log10f.c: fdlibm's float formula around logf, built without FMA). tests/test_glibc_float.py compiles
+// this header for the host and sweeps every float argument against the real libm; the tables are read out of that libm by
+// tools/gen_glibc_float_tables.py.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GLF_HD __host__ __device__ __forceinline__
+#else
+#define GLF_HD inline
+#endif
+
+#include "glibc_float_tables.inc"
+
+namespace smilehip {
+
+namespace glf {
+struct LogEnt { double invc, logc; };
+GLF_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+GLF_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+GLF_HD uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+GLF_HD double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const LogEnt kLogTab[16] = {GLF_LOG_TAB};
+__device__ const uint64_t kExpTab[32] = {GLF_EXP_TAB};
+#else
+static const LogEnt kLogTab[16] = {GLF_LOG_TAB};
+static const uint64_t kExpTab[32] = {GLF_EXP_TAB};
+#endif
+}  // namespace glf
+
+// glibc 2.35 __logf (e_logf.c:36-85), fma build
+GLF_HD float glibc_logf(float x) {
+  uint32_t ix = glf::f2u(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2 == 0) return -1.0f / 0.0f;                  // log(+-0) = -inf
+    if (ix == 0x7f800000u) return x;                       // log(inf) = inf
+    if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return (x - x) / (x - x);   // negative or NaN
+    ix = glf::f2u(x * 0x1p23f);                            // subnormal: normalise
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) % 16u);
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  const double invc = glf::kLogTab[i].invc, logc = glf::kLogTab[i].logc;
+  const double z = (double)glf::u2f(iz);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = __builtin_fma((double)k, (double)GLF_LOG_LN2, logc);
+  const double r2 = r * r;
+  double y = __builtin_fma((double)GLF_LOG_A1, r, (double)GLF_LOG_A2);
+  y = __builtin_fma((double)GLF_LOG_A0, r2, y);
+  y = __builtin_fma(y, r2, y0 + r);
+  return (float)y;
+}
+
+// glibc 2.35 __expf (e_expf.c:38-108), fma build; the over- / underflow branches return what they return there
+GLF_HD float glibc_expf(float x) {
+  const double xd = (double)x;
+  const uint32_t abstop = (glf::f2u(x) >> 20) & 0x7ffu;
+  if (abstop >= (glf::f2u(88.0f) >> 20)) {
+    if (glf::f2u(x) == glf::f2u(-1.0f / 0.0f)) return 0.0f;
+    if (abstop >= (glf::f2u(1.0f / 0.0f) >> 20)) return x + x;
+    if (x > 0x1.62e42ep6f) return 0x1p97f * 0x1p97f;         // overflow
+    if (x < -0x1.9fe368p6f) return 0x1p-95f * 0x1p-95f;      // underflow
+  }
+  // z = InvLn2N * xd is only ever added to / subtracted from: GCC's FMA pass fuses the product into both uses (no rounded z)
+  double kd = __builtin_fma((double)GLF_EXP_INVLN2N, xd, (double)GLF_EXP_SHIFT);
+  const uint64_t ki = glf::d2u(kd);
+  kd -= (double)GLF_EXP_SHIFT;
+  const double r = __builtin_fma((double)GLF_EXP_INVLN2N, xd, -kd);
+  uint64_t t = glf::kExpTab[ki % 32u];
+  t += ki << (52 - 5);
+  const double s = glf::u2d(t);
+  const double zz = __builtin_fma((double)GLF_EXP_C0, r, (double)GLF_EXP_C1);
+  const double r2 = r * r;
+  double y = __builtin_fma((double)GLF_EXP_C2, r, 1.0);
+  y = __builtin_fma(zz, r2, y);
+  y = y * s;
+  return (float)y;
+}
+
+// glibc 2.35 __ieee754_log10f (e_log10f.c), no FMA
+GLF_HD float glibc_log10f(float x) {
+  const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+  int32_t hx = (int32_t)glf::f2u(x), k = 0;
+  if (hx < 0x00800000) {
+    if ((hx & 0x7fffffff) == 0) return -two25 / __builtin_fabsf(x);   // log(+-0) = -inf
+    if (hx < 0) return (x - x) / (x - x);
+    k -= 25;
+    x *= two25;
+    hx = (int32_t)glf::f2u(x);
+  }
+  if (hx >= 0x7f800000) return x + x;
+  k += (hx >> 23) - 127;
+  const int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+  const float y = (float)(k + i);
+  x = glf::u2f((uint32_t)hx);
+  const float p = y * log10_2lo, q = ivln10 * glibc_logf(x);
+  const float z = p + q;
+  const float w = y * log10_2hi;
+  return z + w;
+}
+
+}  // namespace smilehip

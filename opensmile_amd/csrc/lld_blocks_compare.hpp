@@ -28,6 +28,22 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double *red) {
   __syncthreads();
 }
 
+// Two float sums in index order, one addition after the other -- what the reference's FLOAT_DMEM accumulators do (sharpness
+// spectral.cpp:1435-1471, harmonicity :1485-1499, alpha ratio :997-1022). A float sum cannot be re-associated without changing
+// its bits, so ONE thread walks the terms (the two chains interleave: two independent dependency chains); n a multiple of 4,
+// a and b 16-byte aligned.
+__device__ __forceinline__ void seq_sum2_f32(const float *a, const float *b, int n, float &s0, float &s1) {
+  float x = 0.0f, y = 0.0f;
+  for (int i = 0; i < n; i += 4) {
+    const float4 u = *reinterpret_cast<const float4 *>(a + i), v = *reinterpret_cast<const float4 *>(b + i);
+    x += u.x; y += v.x;
+    x += u.y; y += v.y;
+    x += u.z; y += v.z;
+    x += u.w; y += v.w;
+  }
+  s0 = x; s1 = y;
+}
+
 // R11 cSpectral::processVector with ComParE_2016's option set ([is13_spectral]: bands 250-650 and
 // 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope,
 // sharpness, harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1; spectral.cpp:586-1560).
@@ -47,7 +63,7 @@ __device__ __forceinline__ void spectral_frame(const float *mg, const float *pw,
   double v1[6];
   v1[0] = p;                                            // frame energy (:762-767), centroid denominator
   v1[1] = fj * p;                                       // centroid numerator (:1256-1330)
-  v1[2] = C.sharp_w[tid] * p;                           // sharpness (:1429-1482)
+  v1[2] = 0.0;                                          // (sharpness: a float chain, below)
   { const double myB = (double)mg[j] - (double)prev[j]; v1[3] = first ? 0.0 : myB * myB; }   // flux (:1124-1254)
 #pragma unroll
   for (int b = 0; b < 2; ++b) {                         // band energies (:779-853), edges resolved on the host
@@ -116,14 +132,21 @@ __device__ __forceinline__ void spectral_frame(const float *mg, const float *pw,
     const double t1 = fj - (double)ctr;                 // moments (:1338-1397)
     double m = t1 * t1 * p;
     v2[1] = m; m *= t1; v2[2] = m; v2[3] = m * t1;
-    v2[4] = (double)hc;
+    v2[4] = 0.0;                                        // (harmonicity: a float chain, below)
   }
+  // sharpness and harmonicity accumulate in FLOAT_DMEM, bin after bin: the terms go to LDS (cum is free after the roll-off:
+  // the barrier of the harmonicity section lies behind its last read), thread 0 adds them in order
+  float *chain = reinterpret_cast<float *>(cum);
+  chain[tid] = (float)(C.sharp_w[tid] * p);             // (FLOAT_DMEM)(sharpnessWeights[j - lo] * (double)srcP[j]), :1455 / :1469
+  chain[256 + tid] = hc;                                // |srcLP[j] - lastPeak| of a flagged bin, +0 elsewhere (s + 0 = s), :1493
   block_sum_n<5>(v2, red);
   if (tid == 0) {
+    float sumAA_seq, ptp_seq;
+    seq_sum2_f32(chain, chain + 256, 256, sumAA_seq, ptp_seq);
     sp[0] = (float)(v1[4] / (double)nBins);
     sp[1] = (float)(v1[5] / (double)nBins);
     float c2 = 0.0f;
-    const float sumAA = (float)v1[2];
+    const float sumAA = sumAA_seq;
     if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
     sp[13] = (float)(0.11 * c2);
     const double flux = v1[3] / (double)nBins;
@@ -140,7 +163,7 @@ __device__ __forceinline__ void spectral_frame(const float *mg, const float *pw,
     double slope = 0.0;
     if (deno != 0.0) slope = (Nind * sumA - C.slope_Sf * sumB) / deno;
     sp[12] = (float)(slope * (Nind - 1.0));              // oldSlopeScale = 1
-    float ptpSum = (float)v2[4];
+    float ptpSum = ptp_seq;
     ptpSum /= 2.0f;
     ptpSum /= (float)nBins;
     sp[14] = ptpSum;
@@ -166,8 +189,9 @@ __device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot
 
 // spectral_frame for one wave (K = 257): no LDS scratch, no barriers. mg / pw / prev as above; sp[0..14] written by lane 0
 // (roll-off points by the lane that owns the crossing bin).
+// chain: 512 floats of LDS scratch (16-byte aligned) for the two float chains.
 __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float *pw, const float *prev, bool first,
-                                                    const SpectralConsts &C, int K, float *sp) {
+                                                    const SpectralConsts &C, int K, float *chain, float *sp) {
   const double F0 = 1.0 / C.fsSec;
   const int lo = 1, hi = K - 1, nBins = K - 1;
   const int lane = threadIdx.x & 63;
@@ -181,7 +205,8 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     fj[w] = F0 * j;
     v1[w][0] = p[w];
     v1[w][1] = fj[w] * p[w];
-    v1[w][2] = C.sharp_w[tid] * p[w];
+    v1[w][2] = 0.0;
+    chain[tid] = (float)(C.sharp_w[tid] * p[w]);        // sharpness term, :1455 / :1469
     { const double myB = (double)mg[j] - (double)prev[j]; v1[w][3] = first ? 0.0 : myB * myB; }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -279,15 +304,20 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     const double t1 = fj[w] - (double)ctr;
     double m = t1 * t1 * p[w];
     v2[w][1] = m; m *= t1; v2[w][2] = m; v2[w][3] = m * t1;
-    v2[w][4] = (double)hc[w];
+    v2[w][4] = 0.0;
+    chain[256 + lane + 64 * w] = hc[w];                 // harmonicity term, :1493
   }
   double t2v[5];
   wave_sum4<5>(v2, t2v);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
+    float sumAA_seq, ptp_seq;
+    seq_sum2_f32(chain, chain + 256, 256, sumAA_seq, ptp_seq);
     sp[0] = (float)(t1v[4] / (double)nBins);
     sp[1] = (float)(t1v[5] / (double)nBins);
     float c2 = 0.0f;
-    const float sumAA = (float)t1v[2];
+    const float sumAA = sumAA_seq;
     if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
     sp[13] = (float)(0.11 * c2);
     const double flux = t1v[3] / (double)nBins;
@@ -304,7 +334,7 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     double slope = 0.0;
     if (deno != 0.0) slope = (Nind * sumA - C.slope_Sf * sumB) / deno;
     sp[12] = (float)(slope * (Nind - 1.0));
-    float ptpSum = (float)t2v[4];
+    float ptpSum = ptp_seq;
     ptpSum /= 2.0f;
     ptpSum /= (float)nBins;
     sp[14] = ptpSum;
@@ -330,7 +360,7 @@ __device__ __forceinline__ float plp_rasta_band(float x, float (&st)[4], int ini
   x = (init >= 5) ? out : 0.0f;
   x += eql_log;
   x *= compression;
-  return (float)exp((double)x);
+  return glibc_expf(x);                                 // plp.cpp:512-517: exp() on a float is expf
 }
 
 }  // namespace smilehip

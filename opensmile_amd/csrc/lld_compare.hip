@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
       const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
       melv[b] = acc;
       // log mel spectrum for the RASTA pass (doLog, plp.cpp:434-439; double log = correctly rounded logf)
-      Q.mel1[(f0 + t) * 26 + b] = (float)log_d((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      Q.mel1[(f0 + t) * 26 + b] = glibc_logf(acc < Q.plp_melfloor ? Q.plp_melfloor : acc);   // plp.cpp:434-439: logf
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       // R8 cPlp without RASTA: melfloor, equal loudness, power-law compression (plp.cpp:499-507)
       aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       const int b = lane;
       const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
       melv[b] = acc;
-      Q.mel1[(f0 + t) * 26 + b] = (float)log_d((double)(acc < Q.plp_melfloor ? Q.plp_melfloor : acc));
+      Q.mel1[(f0 + t) * 26 + b] = glibc_logf(acc < Q.plp_melfloor ? Q.plp_melfloor : acc);   // plp.cpp:434-439: logf
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       aud[b] = plp_aud_band(acc, Q.plp_melfloor, Q.eql[b], Q.compression);
     }
@@ -305,7 +305,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
         if (t < T60) rawA[3] = (float)tot[1] / (float)Q.N60;
       }
     }
-    spectral_frame_wave(mg, pw, prev, t == 0, SC, K, rawB + 26);
+    spectral_frame_wave(mg, pw, prev, t == 0, SC, K, reinterpret_cast<float *>(z), rawB + 26);   // z: free between two transforms
     WaveG::sync();
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(64) lld_compare_rasta(const int64_t *frame_off
       if (init < 5) init++;
       x += eq;
       x *= Q.compression;
-      const float y = (float)exp((double)x);
+      const float y = glibc_expf(x);                      // plp.cpp:512-517: exp() on a float is expf
       if (b < 26) {
         row[i][b] = y;
         if (tc + i < T) Q.rawB[(f0 + tc + i) * 55 + b] = y;

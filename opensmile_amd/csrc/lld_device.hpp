@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "glibc_float.hpp"
+
 namespace smilehip {
 
 // R0: smilePcm_convertSamples, 16-bit mono (smileUtil.c:2527-2535):
@@ -116,7 +118,7 @@ __device__ __forceinline__ double log_d(double x) {
 // reference-order kernels therefore take the double-precision log and round
 // once; the fast kernel uses log_mel_fast.
 __device__ __forceinline__ float log_mel(float v, float melfloor, float log_floor) {
-  return (v < melfloor) ? log_floor : (float)log_d((double)v);
+  return (v < melfloor) ? log_floor : glibc_logf(v);     // mfcc.cpp:239-243: log() on a float is logf (glibc_float.hpp)
 }
 __device__ __forceinline__ float log_mel_fast(float v, float melfloor, float log_floor) {
   return (v < melfloor) ? log_floor : logf(v);

@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
       // F0finalLog (pitchSmootherViterbi.cpp:497-505): semitones above 27.5 Hz, float arithmetic throughout; the
       // reference's logf is correctly rounded in practice, the device's is not: double log, rounded once
       float sc = 0.0f;
-      if (f > 29.136) sc = (float)12.0 * (float)log((double)(f / (float)27.5)) / 0.693147182464599609375f;
+      if (f > 29.136) sc = (float)12.0 * glibc_logf(f / (float)27.5) / 0.693147182464599609375f;   // logf(x) / logf(2.0f)
       else if (f > 0.0f) sc = 1.0f;
       out[row * ld + 1] = sc;
       out[row * ld + 2] = vp;

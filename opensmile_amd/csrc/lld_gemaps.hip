@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
   // log power spectrum of the bins the two slopes cover (spectral.cpp:689-716): factor 10/ln 10 as float, floor at specFloor^2
   {
     const float p = pw[lane];
-    lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * (float)log_d((double)p);
+    lg[lane] = (p <= G.spec_floor) ? G.log_spec_floor : G.log_spec_factor * glibc_logf(p);
   }
   WaveG::sync();
   // band slopes of the log spectrum (spectral.cpp:872-992), frequency axis given: four double sums per band
@@ -123,35 +123,48 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
   }
   // alpha ratio (:995-1037) and Hammarberg index (:1039-1089) over the bins up to 5000 Hz, flux (:1124-1254) over freqRange
   {
-    double s01 = 0.0, s15 = 0.0, fl = 0.0;
+    double fl = 0.0;
     float m02 = 0.0f, m25 = 0.0f;
     for (int j = lane; j < K; j += 64) {
       const double f = F0 * (double)j;
       if (f > 5000.0) break;
       const float p = pw[j];
-      if (f < 1000.0) s01 += (double)p; else s15 += (double)p;
       if (f < 2000.0) m02 = p > m02 ? p : m02; else m25 = p > m25 ? p : m25;
+    }
+    // sum01 / sum15 are FLOAT_DMEM accumulators (:997-1022): one lane adds the powers bin after bin, the two bands as two
+    // interleaved chains (a band that has ended adds +0: s + 0 = s)
+    float s01 = 0.0f, s15 = 0.0f;
+    if (lane == 0) {
+      int n1 = 0, n2 = 0;                                // bins with f < 1000, bins with f <= 5000
+      while (n1 < K && F0 * (double)n1 < 1000.0) ++n1;
+      n2 = n1;
+      while (n2 < K && !(F0 * (double)n2 > 5000.0)) ++n2;
+      const int len = (n1 > n2 - n1) ? n1 : n2 - n1;
+      for (int i = 0; i < len; ++i) {
+        s01 += (i < n1) ? pw[i] : 0.0f;
+        s15 += (n1 + i < n2) ? pw[n1 + i] : 0.0f;
+      }
     }
     for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
       const double myB = (double)mg[j] - (double)prev[j];
       fl += myB * myB;
     }
-    s01 = WaveG::sum(s01, nullptr); s15 = WaveG::sum(s15, nullptr); fl = WaveG::sum(fl, nullptr);
+    fl = WaveG::sum(fl, nullptr);
     {
       auto fmx = [](int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; };
       m02 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(m02), fmx)));
       m25 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(m25), fmx)));
     }
     if (lane == 0) {
-      const float sum01 = (float)s01, sum15 = (float)s15;
+      const float sum01 = s01, sum15 = s15;
       float a = 0.0f, h = 0.0f;
       if (sum01 > 0.0f) {
-        if (sum15 > G.spec_floor) a = (float)(10.0 * (double)(float)log((double)(sum15 / sum01)) / log(10.0));
-        else a = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)sum01)) / log(10.0));
+        if (sum15 > G.spec_floor) a = (float)(10.0 * (double)glibc_logf(sum15 / sum01) / log(10.0));
+        else a = (float)(10.0 * (double)(glibc_logf(G.spec_floor) - glibc_logf(sum01)) / log(10.0));
       }
       if (m25 > 0.0f) {
-        if (m02 > G.spec_floor) h = (float)(10.0 * (double)(float)log((double)(m02 / m25)) / log(10.0));
-        else h = (float)(10.0 * (double)((float)log((double)G.spec_floor) - (float)log((double)m25)) / log(10.0));
+        if (m02 > G.spec_floor) h = (float)(10.0 * (double)glibc_logf(m02 / m25) / log(10.0));
+        else h = (float)(10.0 * (double)(glibc_logf(G.spec_floor) - glibc_logf(m25)) / log(10.0));
       }
       dst5[2] = a;
       dst5[3] = h;
@@ -872,15 +885,14 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
       {
         const float m0 = hmag[0];
         const bool logRel = !(m0 == 0.0f);
-        // log10 through log_d (lld_device.hpp): within 2.5 ulp of double, rounded to float like the library's
-        constexpr double kInvLn10 = 0.43429448190325182765;
-        const float lm0 = logRel ? (float)(log_d((double)m0) * kInvLn10) : 0.0f;
+        // log10f as glibc computes it (glibc_float.hpp)
+        const float lm0 = logRel ? glibc_log10f(m0) : 0.0f;
         for (int i = lane; i < kNH; i += 64) {
           float v;
           if (i == 0) v = 0.0f;
           else if (!logRel) v = -201.0f;
           else if (hlr[i] > 0.0f) {
-            const double tmp = (double)(float)(log_d((double)hlr[i]) * kInvLn10);
+            const double tmp = (double)glibc_log10f(hlr[i]);
             v = (float)(20.0 * (tmp - (double)lm0));
             if (v < -200.0f) v = -200.0f;
           } else v = -200.0f;
@@ -1065,7 +1077,7 @@ __global__ void lld_gemaps_dbp(float *x, int64_t ld, int n_utt, const int64_t *r
   if (row_off[u + 1] - row_off[u] <= 0) return;
   const float factor = (float)(10.0 / log(10.0)), logfloor = (float)0.000000000001;
   const float v = x[u * ld];
-  x[u * ld] = factor * (float)log((double)(v > logfloor ? v : logfloor));
+  x[u * ld] = factor * glibc_logf(v > logfloor ? v : logfloor);
 }
 
 // ------------------------------------------------------------------------------------------------ per-component: cSpectral

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int n
   int init = (int)state[4 * nB];
   for (int64_t f = 0; f < nF; ++f) {
     const float v = src[f * lds + b];
-    const float x = (float)log((double)(v < Q.melfloor ? Q.melfloor : v));          // doLog, plp.cpp:434-439
+    const float x = glibc_logf(v < Q.melfloor ? Q.melfloor : v);          // doLog, plp.cpp:434-439
     dst[f * ldd + b] = plp_rasta_band(x, st, init, Q.fir, Q.iir, e, Q.compression);
     if (init < 5) init++;
   }

@@ -50,6 +50,9 @@ def main():
         d = np.concatenate(v)
         res[k] = {"max_rel": float(d.max()), "rows_over_1e-5": float((d > 1e-5).mean()), "rows_over_1e-3": float((d > 1e-3).mean()),
                   "rows_over_1e-6": float((d > 1e-6).mean()), "cells_bit_identical": float(np.concatenate(same[k]).mean())}
+    eq_all = np.concatenate([np.stack(same[k][i].reshape(-1, len(groups[k])) for i in range(len(pcms))) if False else np.concatenate([x.reshape(-1, len(groups[k])) for x in same[k]]) for k in groups], axis=1)
+    cols = sum((groups[k] for k in groups), [])
+    res["columns_not_bit_identical"] = {str(c): float(1.0 - eq_all[:, i].mean()) for i, c in enumerate(cols) if eq_all[:, i].mean() < 1.0}
     print(json.dumps(res, indent=1))
 
 
