@@ -23,24 +23,11 @@ def hip():
 
 
 def f0_lld_tolerances(out, ref, what=""):
-    """The 12 F0-group columns (F0final, voicing, jitterLocal, jitterDDP, shimmerLocal, logHNR and their deltas). Round 3: the
-    60 ms spectrum comes out of the reference's rdft network (lld_ooura.hpp) and every stage downstream of it was already
-    bit-exact on identical input, so the columns are the reference's bits (profiles/r03_compare_parity.json: 32 770 rows of
-    fresh utterances against the real binary, every cell identical). Only logHNR passes a libm call (log, in double): one cell
-    in ~1e8 may round the other way. Round 2's gate was statistical: <= 1 % of the rows beyond 1e-5, nothing beyond 2e-4."""
-    assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
-    if out.shape[0] == 0:
-        return
-    o, r = np.ascontiguousarray(out, np.float32), np.ascontiguousarray(ref, np.float32)
-    same = (o.view(np.uint32) == r.view(np.uint32)) | ((o == 0) & (r == 0))
-    scale = np.maximum(np.abs(r[:, :6]).max(axis=0), 1e-6)
-    scale = np.concatenate([scale, scale])
-    dev = (np.abs(o.astype(np.float64) - r) / scale[None, :]).max()
-    from tolerance import record
-    record("f0_lld_tolerances", what=what, rows=o.shape[0], cells_identical=float(same.mean()), max_scaled=float(dev))
-    nolog = [0, 1, 2, 3, 4, 6, 7, 8, 9, 10]
-    assert same[:, nolog].all(), f"{what}: {int((~same[:, nolog]).sum())} F0 / voicing / jitter / shimmer cells differ from the reference"
-    assert dev <= 1e-6 and same.mean() >= 0.999, f"{what}: logHNR deviates by {dev:.3g}, {same.mean():.5f} identical"
+    """The 12 F0-group columns (F0final, voicing, jitterLocal, jitterDDP, shimmerLocal, logHNR and their deltas): the reference's
+    bits (profiles/r03_compare_parity.json: 32 770 rows of fresh utterances against the real binary, every cell identical).
+    Round 2's gate was statistical: <= 1 % of the rows beyond 1e-5, nothing beyond 2e-4."""
+    from tolerance import assert_bits_equal
+    assert_bits_equal(out, ref, what)
 
 
 def test_compare_full_golden_batch_ragged(hip, golden_f0):

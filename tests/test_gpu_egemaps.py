@@ -86,12 +86,12 @@ def test_pending_counts_match_the_oracle(run_all, golden, oracle):
 
 
 # ------------------------------------------------------------------ chain vs the real binary's levels
-@pytest.mark.parametrize("level,cols,tol", [("loudness", slice(0, 1), 0.0), ("lspec", slice(1, 5), 1e-6), ("flux", slice(5, 6), 0.0),
-                                            ("mfcc", slice(6, 10), 1e-6), ("energy2", slice(10, 11), 0.0)])
+@pytest.mark.parametrize("level,cols,tol", [("loudness", slice(0, 1), 0.0), ("lspec", slice(1, 5), 0.0), ("flux", slice(5, 6), 0.0),
+                                            ("mfcc", slice(6, 10), 0.0), ("energy2", slice(10, 11), 0.0)])
 def test_20ms_levels_vs_golden(run_all, golden, level, cols, tol):
     """Round 3: the transform is the reference's rdft network, so every level that has no libm call downstream of it is
-    the binary's bit for bit (tol 0 = bits_equal); the log-spectrum and log-mel levels differ by the last bit of
-    logf / log (device library vs glibc), <= 1e-6 of the column scale."""
+    the binary's bit for bit (tol 0 = bits_equal); so are the log-spectrum and log-mel levels since logf is glibc's algorithm
+    (glibc_float.hpp) and cSpectral's FLOAT_DMEM sums are sequential float chains."""
     width = cols.stop - cols.start
     got, ref = run_all["taps"]["raw20"][:, cols], cat(golden, level, width)
     if tol == 0.0:
@@ -105,8 +105,7 @@ def test_pitch_level_vs_golden(run_all, golden):
     """gemapsv01b_logPitch [F0final, F0finalLog, voicing]: F0final and voicing are the binary's bits; F0finalLog goes
     through log(): <= 4e-7 of the column scale."""
     g, r = run_all["taps"]["pitch3"], cat(golden, "pitch", 3)
-    assert bits_equal(g[:, [0, 2]], r[:, [0, 2]]).all()
-    assert scaled_err(g, r).max() <= 4e-7
+    assert bits_equal(g, r).all()
 
 
 def test_jitter_shimmer_vs_golden(run_all, golden):
@@ -122,19 +121,13 @@ def test_lpc_formants_bit_identical_and_harmonics_vs_golden(run_all, golden):
     t = run_all["taps"]
     assert bits_equal(t["lpc"][:, :11], cat(golden, "lpc", 11)).all()
     assert bits_equal(t["formants"], cat(golden, "formants", 10)).all()
-    eh = scaled_err(t["harm6"], cat(golden, "harm", 6))
-    assert eh.max() <= 1e-6, eh.max()
+    assert bits_equal(t["harm6"], cat(golden, "harm", 6)).all()      # dB values: log10f in glibc's order
 
 
 def test_lld_level_vs_golden(run_all, golden):
     ref = np.concatenate([golden["lld_" + k].reshape(-1, 25) for k in KEYS], axis=0)
-    e = scaled_err(run_all["lld"], ref)
-    assert e.max() <= 1e-6, (e.max(), int(np.argmax(e.max(axis=0))))
-    # columns without a libm call on their path: loudness, flux, F0 (semitone scale excluded), jitter, shimmer, formant
-    # frequencies and bandwidths -- the binary's bits
-    same = bits_equal(run_all["lld"], ref).mean(axis=0)
-    for c in (0, 5, 6, 8, 11, 12, 13, 16, 17, 19, 20, 22, 23):
-        assert same[c] == 1.0, (c, same[c])
+    same = bits_equal(run_all["lld"], ref)
+    assert same.all(), f"{int((~same).sum())} of {same.size} cells differ from the binary, columns {sorted(set(np.argwhere(~same)[:, 1]))}"
 
 
 # ------------------------------------------------------------------ stages on identical inputs
@@ -238,8 +231,7 @@ def test_functionals_vs_golden(run_all, golden):
     fr, fg = np.array(fr), np.array(fg)
     rel = np.abs(fg - fr) / np.maximum(np.abs(fr), 1e-2)
     # F0 (0..9), loudness (10..19), flux / mfcc mean + stddevNorm (20..29), temporal set (81..86), leq (87)
-    assert rel.max() <= 2e-5, (rel.max(), int(np.argmax(rel.max(axis=0))))      # round 2: 93 % within 1e-3
-    assert bits_equal(fg, fr).mean() >= 0.94
+    assert bits_equal(fg, fr).all(), (rel.max(), int(np.argmax(rel.max(axis=0))))      # round 2: 93 % within 1e-3
 
 
 # ------------------------------------------------------------------ batch properties at a larger size

@@ -42,8 +42,8 @@ def test_oracle_vs_golden_own_fft(oracle, golden_synth, key):
     if ref.shape[0] == 0:
         assert out.shape[0] == 0
         return
-    s_col = corpus_col_scale([golden_synth["out_" + k] for k in SYNTH_KEYS], 13)
-    assert_parity(out, ref, block=13, what=key, col_scale=s_col)
+    from tolerance import assert_bits_equal
+    assert_bits_equal(out, ref, key)      # round 3: the built-in transform (lld_oracle_fft.c) is the reference's rdft network
 
 
 @pytest.mark.parametrize("key", SYNTH_KEYS)
@@ -86,7 +86,7 @@ def test_config1_known_answer(oracle, golden_config1):
     cfg = oracle.default_cfg()
     cfg.sample_rate = float(fs)
     out = oracle.mfcc_chain(cfg, pcm)
-    assert_parity(out, ref, block=13, what="config1")
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), "config 1 (44.1 kHz, FFT 2048) with the built-in transform" 
     if oracle.use_reference_fft(True):
         try:
             out = oracle.mfcc_chain(cfg, pcm)
@@ -106,7 +106,7 @@ def test_oracle_vs_live_reference_10s(oracle):
         ref = oracle.run_reference("mfcc/MFCC12_0_D_A.conf", pcm)
         assert ref.shape == (998, 39)
         out = oracle.mfcc_chain(cfg, pcm)
-        assert_parity(out, ref, block=13, what=f"u{u}")
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"u{u} with the built-in transform" 
         oracle.use_reference_fft(True)
         try:
             out = oracle.mfcc_chain(cfg, pcm)

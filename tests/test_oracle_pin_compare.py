@@ -23,35 +23,18 @@ def test_compare_ab_bit_exact_with_reference_fft(oracle, golden_compare, key):
 
 
 def compare_tolerances(out, ref, what=""):
-    """Per-descriptor gates for the built-in / HIP FFT. Continuous quantities on the column's own scale over the
-    utterance, mfcc per frame: measured 1.7e-6 / 2.4e-6 (profiles/r02_gate_margins.json), gates 5e-6. Roll-off points
-    are bin frequencies picked by a threshold test and may move by one bin on rare frames: none moved on any test input
-    nor on 32 770 rows of fresh utterances (profiles/r01_final_compare_parity.json); gate 0.2 % of the cells."""
-    assert out.shape == ref.shape, f"{what}: {out.shape} vs {ref.shape}"
+    """Groups A + B [sma | delta] of ComParE_2016. Rounds 1-2 gated these per descriptor (5e-6 of the column scale, roll-off
+    points allowed to move on 0.2 % of the cells) because the transform had its own butterfly order. Round 3: the oracle's
+    built-in transform and the device's are the reference's rdft network, logf / expf are glibc's, the FLOAT_DMEM sums are
+    sequential -- the columns are the reference's bits."""
+    from tolerance import assert_bits_equal
     assert np.isfinite(out).all()
-    o, r = out.astype(np.float64), ref.astype(np.float64)
-    d = np.abs(o - r)
-    D = 59
-    for half in (0, D):
-        cols = np.arange(D) + half
-        # delta columns are judged on the scale of the static column they derive from
-        scale = np.maximum(np.abs(r[:, np.arange(D)]).max(axis=0), 1e-12)
-        rel = d[:, cols] / scale[None, :]
-        ro = [32, 33, 34, 35]                              # roll-off columns (bin frequencies)
-        other = [c for c in range(D) if c not in ro and c < 45]
-        assert rel[:, other].max() <= 5e-6, f"{what}: col {other[int(rel[:, other].max(axis=0).argmax())]} rel {rel[:, other].max():.2e}"
-        # mfcc 1..14: per-frame scale
-        ms = np.maximum(np.abs(r[:, 45:59]).max(axis=1, keepdims=True), 1e-12)
-        assert (d[:, half + 45:half + 59] / ms).max() <= 5e-6, f"{what}: mfcc"
-        moved = (d[:, [c + half for c in ro]] > 1e-3).mean()
-        from tolerance import record
-        record("compare_tolerances", what=what, half=half, other_max=rel[:, other].max(), mfcc_max=(d[:, half + 45:half + 59] / ms).max(),
-               rolloff_moved_frac=moved)
-        assert moved <= 0.002, f"{what}: roll-off moved on {moved * 100:.1f}% of cells"
+    assert_bits_equal(out, ref, what)
 
 
 @pytest.mark.parametrize("key", KEYS)
-def test_compare_ab_own_fft_within_tolerance(oracle, golden_compare, key):
+def test_compare_ab_builtin_fft_bit_exact(oracle, golden_compare, key):
+    """without the hook: the oracle's own restatement of the rdft network (lld_oracle_fft.c)"""
     oracle.use_reference_fft(False)
     out = oracle.compare_ab_chain(golden_compare["pcm_" + key])
     compare_tolerances(out, golden_compare["out_" + key], key)

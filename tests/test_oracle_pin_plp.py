@@ -21,11 +21,9 @@ def test_plp_bit_exact_with_reference_fft(oracle, golden_plp, key):
 
 
 @pytest.mark.parametrize("key", KEYS)
-def test_plp_own_fft_within_tolerance(oracle, golden_plp, key):
+def test_plp_builtin_fft_bit_exact(oracle, golden_plp, key):
     oracle.use_reference_fft(False)
     ref = golden_plp["out_" + key]
     out = oracle.plp_chain(golden_plp["pcm_" + key])
-    assert out.shape == ref.shape
-    if ref.size:
-        scale = np.abs(ref[:, :6]).max(axis=1, keepdims=True)
-        assert (np.abs(out - ref) / scale).max() <= 1e-5
+    from tolerance import assert_bits_equal
+    assert_bits_equal(out, ref, key)      # round 3: the oracle's built-in transform is the reference's rdft network

@@ -16,6 +16,19 @@ import numpy as np
 RTOL = 1e-5
 
 
+def assert_bits_equal(out, ref, what=""):
+    """Round 3: every reference-order chain (everything but the fast MFCC / PLP kernel, which keeps its own transform and
+    the RTOL gate below) follows the reference's operation order stage by stage -- rdft network, glibc's logf / expf /
+    log10f, FLOAT_DMEM accumulators -- so its outputs are compared with the real binary's (and the oracle's) as bit patterns."""
+    o = np.ascontiguousarray(out, np.float32)
+    r = np.ascontiguousarray(ref, np.float32)
+    assert o.shape == r.shape, f"{what}: {o.shape} vs {r.shape}"
+    same = o.view(np.uint32) == r.view(np.uint32)
+    record("assert_bits_equal", what=what, cells=same.size, identical=float(same.mean()) if same.size else 1.0)
+    assert same.all(), (f"{what}: {int((~same).sum())} of {same.size} cells differ from the reference's bits, first at "
+                        f"{tuple(np.argwhere(~same)[0])}, largest |difference| {np.abs(o.astype(np.float64) - r).max():.3g}")
+
+
 def record(gate, **measured):
     """Margin bookkeeping: with SMILEHIP_GATE_LOG=<file> every gate appends what it measured (one JSON object per line), so
     that the thresholds can be kept at about twice the measured error (profiles/rNN_gate_margins.json) instead of drifting
