@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's config 2.
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config 2 (default), or --config 3 | 4 | 5.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+
+--config 3: IS09_emotion LLD (16 + 16 delta) on 10 000 x 10 s; --config 4: the whole ComParE_2016 LLD level (130 columns) on
+12 500 x 10 s (the per-GPU share of 100 000 utterances over 8 GPUs); --config 5: eGeMAPSv02 LLD + the 88 functionals on
+125 000 x 3 s (the per-GPU share of 10^6). Same JSON schema, the config's own workload / roofline kernel / CPU baseline
+(the real SMILExtract on that conf). Steps and warm-up default to what finishes in about a minute.
 
 A "step" is one pass of the fused LLD chain (MFCC12_0_D_A: int16 PCM ->
 13 MFCC + delta + accel) over one batch of synthetic audio: 1000 utterances x
@@ -42,15 +47,42 @@ ALG_BYTES_PER_FRAME_MAIN = 2 * 160 + 4 * 13      # int16 hop in + 13 f32 out (SU
 ALG_BYTES_PER_FRAME_CHAIN = 2 * 160 + 4 * 39     # incl. delta/accel columns
 ALG_FLOP_PER_FRAME = 1.52e4
 
+# --config: (capi config factory, utterances per GPU, samples per utterance, default steps, default warm-up, workload text,
+#            roofline kernel name, algorithmic bytes per 10 ms frame of that kernel, what the bytes are, reference conf, output
+#            option of the reference binary, frames per file of the reference run)
+CONFIGS = {
+    3: dict(cfg="is09_lld_config", utts=10000, samples=160000, steps=10, warmup=3,
+            workload="IS09_emotion LLD (MFCC 1-12, RMS energy, ZCR, voiceProb, F0 via cAcf / cPitchACF; 16 LLD + 16 delta) on "
+                     "10 000 x 10 s synthetic 16 kHz mono int16 per GPU, 25 ms / 10 ms, PCM resident in HBM",
+            kernel="lld_is09_frame_wave (+ lld_pitch_smooth)", alg_bytes=2 * 160 + 4 * 16,
+            alg_note="int16 hop in + 16 f32 pre-smoothing columns out per frame (SURVEY 8d counts 448 B for the whole chain incl. deltas)",
+            conf="is09-13/IS09_emotion.conf", opt="-lldhtkoutput"),
+    4: dict(cfg="compare16_config", utts=12500, samples=160000, steps=4, warmup=1,
+            workload="ComParE_2016 whole LLD level (130 columns: F0 group incl. Viterbi + jitter / shimmer, groups A + B, deltas) on "
+                     "12 500 x 10 s synthetic 16 kHz mono int16 per GPU (config 4's share of 100 000 utterances over 8 GPUs), "
+                     "PCM resident in HBM",
+            kernel="lld_compare_frame_wave3 (+ RASTA scan, group A)", alg_bytes=2 * 160 + 4 * (4 + 55),
+            alg_note="int16 hop in + 59 f32 pre-smoothing columns of groups A + B out per 20 ms frame",
+            conf="compare16/ComParE_2016.conf", opt="-lldhtkoutput"),
+    5: dict(cfg="egemapsv02_config", utts=125000, samples=48000, steps=3, warmup=1,
+            workload="eGeMAPSv02 LLD (25 columns) + 88 functionals per utterance on 125 000 x 3 s synthetic 16 kHz mono int16 per GPU "
+                     "(config 5's share of 10^6 utterances over 8 GPUs), PCM resident in HBM",
+            kernel="lld_gemaps_frame20 + lld_gemaps_lpc + lld_gemaps_formants", alg_bytes=2 * 160 + 4 * (12 + 222 + 12 + 10),
+            alg_note="int16 hop in + 12 f32 raw descriptors + 222 f32 of cSpecResample's input + 12 LP + 10 formant values out per 20 ms frame",
+            conf="egemaps/v02/eGeMAPSv02.conf", opt="-htkoutput"),
+}
 
-def cpu_baseline(max_seconds=25.0):
-    """Time the real reference binary (one process per 10 s file, HTK output to
+
+def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", n_samples=UTT_SAMPLES, frames_per_file=998):
+    """Time the real reference binary (one process per file, HTK output to
     /dev/shm, log level 0) on all host cores; bounded sample, scaled to frames/s."""
     from oracle import lldo
     from opensmile_amd import synth
     exe = os.path.join(lldo.REF_DIR, "SMILExtract")
-    conf = os.path.join(lldo.REF_DIR, "config", "mfcc", "MFCC12_0_D_A.conf")
+    conf = os.path.join(lldo.REF_DIR, "config", *conf_rel.split("/"))
     cores = os.cpu_count() or 1
+    if not os.path.exists(exe) and conf_rel != "mfcc/MFCC12_0_D_A.conf":
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref/SMILExtract not built"}
     if not os.path.exists(exe):
         # fall back to the C restatement ("port"), single thread
         cfg = lldo.default_cfg()
@@ -66,43 +98,49 @@ def cpu_baseline(max_seconds=25.0):
     with tempfile.TemporaryDirectory(dir=base) as td:
         n_unique = 8
         for i in range(n_unique):
-            lldo.write_wav(os.path.join(td, f"u{i}.wav"), synth.utterance(2 + i, UTT_SAMPLES))
+            lldo.write_wav(os.path.join(td, f"u{i}.wav"), synth.utterance(2 + i, n_samples))
         # calibrate on a few files, 1 core
         t0 = time.perf_counter()
         n_cal = 8
         for i in range(n_cal):
             subprocess.run([exe, "-C", conf, "-I", os.path.join(td, f"u{i % n_unique}.wav"),
-                            "-O", os.path.join(td, "cal.htk"), "-l", "0"],
+                            opt, os.path.join(td, "cal.htk"), "-l", "0"],
                            cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         per_file = (time.perf_counter() - t0) / n_cal
-        one_core = 998 / per_file
+        one_core = frames_per_file / per_file
         # ~10-15 s of wall clock on all cores; outputs reuse 4*cores file names
         n_files = int(max(cores * 4, min(14000, 12.0 / per_file * cores)))
         jobs = "\n".join(f"{i % n_unique} {i % (4 * cores)}" for i in range(n_files))
-        cmd = (f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {td}/u$0.wav -O {td}/o$1.htk "
+        cmd = (f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {td}/u$0.wav {opt} {td}/o$1.htk "
                f"-l 0 >/dev/null 2>&1'")
         t0 = time.perf_counter()
         subprocess.run(cmd, shell=True, input=jobs.encode(), cwd=td, check=True)
         dt = time.perf_counter() - t0
         produced = sum(1 for f in os.listdir(td) if f.startswith("o") and f.endswith(".htk"))
         done = n_files if produced >= min(n_files, 4 * cores) else 0
-    return {"value": done * 998 / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
-            "sample": (f"{done} x 10 s files, one SMILExtract process per file, {cores} in parallel "
-                       f"(xargs -P), -O /dev/shm/*.htk -l 0; {dt:.1f} s wall"),
+    return {"value": done * frames_per_file / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": (f"{done} x {n_samples / 16000.0:g} s files, one SMILExtract -C {conf_rel} process per file, {cores} in parallel "
+                       f"(xargs -P), {opt} /dev/shm/*.htk -l 0; {dt:.1f} s wall"),
             "one_core_value": one_core}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=30)   # the clocks ramp over the first ~20 launches
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json config (default 2: the headline)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)   # config 2: the clocks ramp over the first ~20 launches
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--utts", type=int, default=N_UTT, help="utterances per GPU (default: config 2)")
+    ap.add_argument("--utts", type=int, default=None, help="utterances per GPU (default: the config's)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the driver's contract): every rank its own 1000 x 10 s; strong: ONE ragged corpus of "
                          "--utts utterances (5..15 s) sharded over the ranks by frame count (gather.shard_utterances)")
     args = ap.parse_args()
+    if args.config != 2:
+        return main_other(args)
+    args.steps = 100 if args.steps is None else args.steps
+    args.warmup = 30 if args.warmup is None else args.warmup
+    args.utts = N_UTT if args.utts is None else args.utts
 
     import torch
     from opensmile_amd import capi, synth
@@ -168,10 +206,13 @@ def main():
     ms_main, ms_delta = plan.last_timing()
     plan.set_timing(False)
 
+    dts = [dt]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        dts = [float(x.item()) for x in all_t]
+        dt = max(dts)
         fr = torch.tensor([frames], dtype=torch.int64, device="cuda")
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         total_frames = int(fr.item())
@@ -213,6 +254,7 @@ def main():
                        "utterances_per_gpu": args.utts if args.scaling == "weak" else None,
                        "utterances_total": args.utts * world if args.scaling == "weak" else args.utts,
                        "frames_rank0": frames, "out_cols": n_out,
+                       "ranks_seen": world, "rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3},
                        "corpus": ("32 seeded utterances of the SURVEY 8(d) contract tiled to 1000 per GPU (work per frame is "
                                   "data-independent)") if args.scaling == "weak" else
                                  "one ragged corpus (5..15 s utterances), LPT-sharded by frame count over the ranks",
@@ -221,9 +263,10 @@ def main():
                        "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "fused MFCC (R0-R7)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic": traffic, "traffic_source": traffic_source,      # from profiles/ (a separate --pmc pass), not this run
                          # the schema offers hbm | mfma and the north star names HBM; the counters say the kernel is limited by
                          # the per-CU LDS pipe first and FP32 VALU issue second (profiles/): both fractions below
+                         "bound_by_counters": "valu+lds",
                          "limited_by": "lds_pipe+fp32_valu (not HBM: arithmetic intensity 41 FLOP/B vs ridge 20)",
                          "alg_bytes_per_frame": ALG_BYTES_PER_FRAME_MAIN,
                          "kernel_ms": ms_main, "delta_kernel_ms": ms_delta,
@@ -237,6 +280,110 @@ def main():
             except Exception as e:  # the baseline must never take the bench line down
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_other(args):
+    """--config 3 | 4 | 5: the same protocol (warm-up, K timed steps between barrier + synchronize, max over ranks, one JSON
+    line from rank 0) on that config's chain through smilehip_lld_run; weak scaling, every rank its own batch."""
+    import ctypes as C
+
+    import torch
+    from opensmile_amd import capi, synth
+    c = CONFIGS[args.config]
+    steps = c["steps"] if args.steps is None else args.steps
+    warmup = c["warmup"] if args.warmup is None else args.warmup
+    utts = c["utts"] if args.utts is None else args.utts
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SMILEHIP_DIST_BACKEND", "nccl")
+        local_rank %= max(torch.cuda.device_count(), 1) if backend != "nccl" else 10 ** 9
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
+    ctx = capi.Context(torch.cuda.current_device())
+    plan = capi.Plan(ctx, getattr(capi, c["cfg"])())
+    n_out = plan.geometry.n_out
+    pcm, off = synth.corpus_tiled(utts, c["samples"], n_unique=32)
+    batch = capi.Batch(plan, off)
+    frames, rows = batch.total_frames, int(batch.frame_offsets[-1])
+    d_pcm = torch.from_numpy(pcm).cuda()
+    del pcm
+    d_out = torch.empty((max(rows, 1), n_out), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    L = capi.load()
+    d_func = torch.empty((utts, 88), dtype=torch.float32, device="cuda") if args.config == 5 else None
+
+    def step():
+        batch.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, stream)
+        if args.config == 5:     # the functionals level on the smoothed levels the run left in the batch's scratch
+            capi._check(L.smilehip_batch_functionals_egemaps(plan._h, batch._h, C.c_void_p(d_func.data_ptr()), 88, C.c_void_p(stream)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    plan.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_main, ms_rest = plan.last_timing()
+    plan.set_timing(False)
+    dts = [dt]
+    total_frames = frames
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        dts = [float(x.item()) for x in all_t]
+        dt = max(dts)
+        fr = torch.tensor([frames], dtype=torch.int64, device="cuda")
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        total_frames = int(fr.item())
+    if rank == 0:
+        achieved = c["alg_bytes"] * frames / (ms_main * 1e-3) / 1e9
+        res = {
+            "metric": {3: "IS09_emotion LLD frames/sec (16kHz, 25ms/10ms)", 4: "ComParE_2016 LLD frames/sec (16kHz, 20ms+60ms/10ms)",
+                       5: "eGeMAPSv02 LLD+functionals frames/sec (16kHz, 20ms+60ms/10ms)"}[args.config],
+            "value": total_frames * steps / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": c["workload"], "baseline_config": args.config, "utterances_per_gpu": utts,
+                       "utterances_total": utts * world, "utterances_per_s": utts * world * steps / dt,
+                       "frames_rank0": frames, "rows_rank0": rows, "out_cols": n_out,
+                       "ranks_seen": world, "rank_ms_per_step": {"min": min(dts) / steps * 1e3, "max": max(dts) / steps * 1e3},
+                       "corpus": "32 seeded utterances of the SURVEY 8(d) contract tiled (work per frame is data-independent except "
+                                 "for the voiced / unvoiced pattern, which the 32 cover)",
+                       "parallelism": f"utterance-sharded x{world}"},
+            "roofline": {"bound": "hbm", "bound_by_counters": "valu+lds (latency)", "kernel": c["kernel"], "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_source": "not measured in this run; per-kernel FETCH / WRITE tables: profiles/r03_pmc_*.txt",
+                         "alg_bytes_per_frame": c["alg_bytes"], "alg_bytes_note": c["alg_note"], "kernel_ms": ms_main,
+                         "rest_of_step_ms": ms_rest},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                fpf = plan.num_frames(c["samples"])
+                res["cpu_baseline"] = cpu_baseline(conf_rel=c["conf"], opt=c["opt"], n_samples=c["samples"], frames_per_file=fpf)
+            except Exception as e:
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

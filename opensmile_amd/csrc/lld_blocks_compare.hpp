@@ -34,14 +34,35 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV], double *red) {
 // a and b 16-byte aligned.
 __device__ __forceinline__ void seq_sum2_f32(const float *a, const float *b, int n, float &s0, float &s1) {
   float x = 0.0f, y = 0.0f;
-  for (int i = 0; i < n; i += 4) {
-    const float4 u = *reinterpret_cast<const float4 *>(a + i), v = *reinterpret_cast<const float4 *>(b + i);
+  float4 u = *reinterpret_cast<const float4 *>(a), v = *reinterpret_cast<const float4 *>(b);
+  for (int i = 4; i <= n; i += 4) {
+    float4 un = u, vn = v;                               // the next block's loads are in flight while this block's adds run
+    if (i < n) { un = *reinterpret_cast<const float4 *>(a + i); vn = *reinterpret_cast<const float4 *>(b + i); }
     x += u.x; y += v.x;
     x += u.y; y += v.y;
     x += u.z; y += v.z;
     x += u.w; y += v.w;
+    u = un; v = vn;
   }
   s0 = x; s1 = y;
+}
+
+// sum of x[lo .. hi) in index order, one float addition after the other; the loads run a few elements ahead of the adds
+__device__ __forceinline__ float seq_sum_f32(const float *x, int lo, int hi) {
+  float s = 0.0f;
+  int i = lo;
+  for (; i < hi && (i & 3); ++i) s += x[i];
+  if (i + 4 <= hi) {
+    float4 u = *reinterpret_cast<const float4 *>(x + i);
+    for (i += 4; i + 4 <= hi; i += 4) {
+      const float4 un = *reinterpret_cast<const float4 *>(x + i);
+      s += u.x; s += u.y; s += u.z; s += u.w;
+      u = un;
+    }
+    s += u.x; s += u.y; s += u.z; s += u.w;
+  }
+  for (; i < hi; ++i) s += x[i];
+  return s;
 }
 
 // R11 cSpectral::processVector with ComParE_2016's option set ([is13_spectral]: bands 250-650 and
@@ -195,7 +216,7 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
   const double F0 = 1.0 / C.fsSec;
   const int lo = 1, hi = K - 1, nBins = K - 1;
   const int lane = threadIdx.x & 63;
-  float pf[4];
+  float pf[4], tsh[4];
   double p[4], fj[4], v1[4][6];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -206,7 +227,7 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     v1[w][0] = p[w];
     v1[w][1] = fj[w] * p[w];
     v1[w][2] = 0.0;
-    chain[tid] = (float)(C.sharp_w[tid] * p[w]);        // sharpness term, :1455 / :1469
+    tsh[w] = (float)(C.sharp_w[tid] * p[w]);            // sharpness term, :1455 / :1469
     { const double myB = (double)mg[j] - (double)prev[j]; v1[w][3] = first ? 0.0 : myB * myB; }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -305,10 +326,17 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     double m = t1 * t1 * p[w];
     v2[w][1] = m; m *= t1; v2[w][2] = m; v2[w][3] = m * t1;
     v2[w][4] = 0.0;
-    chain[256 + lane + 64 * w] = hc[w];                 // harmonicity term, :1493
   }
   double t2v[5];
   wave_sum4<5>(v2, t2v);
+  // sharpness and harmonicity accumulate in FLOAT_DMEM, bin after bin (:1435-1471, :1485-1499): the terms go to LDS, lane 0
+  // adds them in order. (Measured alternative: every lane walking the chains with 512 unrolled v_readlane + v_add was 17 %
+  // slower for the whole kernel -- issue slots and registers -- than one lane reading float4s one block ahead.)
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    chain[lane + 64 * w] = tsh[w];
+    chain[256 + lane + 64 * w] = hc[w];                 // |srcLP[j] - lastPeak| of a flagged bin, +0 elsewhere (s + 0 = s)
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {

@@ -139,11 +139,8 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
       while (n1 < K && F0 * (double)n1 < 1000.0) ++n1;
       n2 = n1;
       while (n2 < K && !(F0 * (double)n2 > 5000.0)) ++n2;
-      const int len = (n1 > n2 - n1) ? n1 : n2 - n1;
-      for (int i = 0; i < len; ++i) {
-        s01 += (i < n1) ? pw[i] : 0.0f;
-        s15 += (n1 + i < n2) ? pw[n1 + i] : 0.0f;
-      }
+      s01 = seq_sum_f32(pw, 0, n1);                      // (measured alternative: every lane walking the bins with v_readlane, 2 % slower)
+      s15 = seq_sum_f32(pw, n1, n2);
     }
     for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
       const double myB = (double)mg[j] - (double)prev[j];

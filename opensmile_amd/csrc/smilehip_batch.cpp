@@ -366,6 +366,17 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   return SMILEHIP_OK;
 }
 
+// HIP-event marks of the timing ring for the chains run through smilehip_lld_run: 0 / 1 bracket the chain's dominant frame
+// kernel(s) ON THE STREAM THEY ARE LAUNCHED ON, 2 closes the run on the caller's stream (smilehip_plan_last_timing)
+static int timing_mark(smilehip_plan *plan, int which, hipStream_t s) {
+  if (!plan->timing) return SMILEHIP_OK;
+  hipEvent_t *ev = plan->ev[plan->n_timed % smilehip_plan::kRing];
+  if (!ev[which]) HIP_TRY(hipEventCreate(&ev[which]));
+  HIP_TRY(hipEventRecord(ev[which], s));
+  if (which == 2) plan->n_timed++;
+  return SMILEHIP_OK;
+}
+
 // IS09 LLD set: frame kernel -> pitch smoother -> SMA + delta chain
 static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream) {
   const int n_out = plan_n_out(plan);
@@ -383,8 +394,11 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
   if (I.voicingCutoff > 1.0) I.voicingCutoff = 1.0;       // pitchACF.cpp:96-98
   if (I.voicingCutoff < 0.0) I.voicingCutoff = 0.0;
   if (I.maxPitch < 0.0) I.maxPitch = 0.0;
+  int trc;
+  if ((trc = timing_mark(plan, 0, s))) return trc;
   hipError_t e = launch_is09(P, I, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "IS09 kernel launch failed: %s", hipGetErrorString(e));
+  if ((trc = timing_mark(plan, 1, s))) return trc;
   ChainParams Q;
   std::memset(&Q, 0, sizeof(Q));
   Q.frame_off = b->d_frame_off.p;
@@ -409,7 +423,7 @@ static int is09_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm
   Q.n_short = (int32_t)b->h_short.size();
   e = launch_chain(Q, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
-  return SMILEHIP_OK;
+  return timing_mark(plan, 2, s);
 }
 
 // ComParE groups A+B: frame kernel -> RASTA scan -> group A (multi-length SMA+delta) + group B chain
@@ -444,8 +458,11 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   }
   Q.slope_Sf = plan->slope_Sf;
   Q.slope_S2f = plan->slope_S2f;
+  int trc;
+  if ((trc = timing_mark(plan, 0, s))) return trc;
   hipError_t e = launch_compare(P, Q, b->n_runs, b->d_row_off.p, b->total_rows, d_out, ld_out, de_col, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "ComParE kernel launch failed: %s", hipGetErrorString(e));
+  if ((trc = timing_mark(plan, 1, s))) return trc;
   ChainParams C;
   std::memset(&C, 0, sizeof(C));
   C.frame_off = b->d_frame_off.p;
@@ -472,7 +489,7 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
   e = launch_compare_b_extra(b->d_frame_off.p, b->d_row_off.p, b->n_utt, b->d_rawB.p, b->d_b_extra.p, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "group-B extra-row kernel launch failed: %s", hipGetErrorString(e));
-  return SMILEHIP_OK;
+  return de_col == 59 ? timing_mark(plan, 2, s) : SMILEHIP_OK;     // (inside the whole-level chain the caller closes the run)
 }
 
 void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
@@ -521,9 +538,12 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.hps_tap = b->d_hps_tap;
   Q.pending = b->d_pending.p;
   Q.vit_log_out = log_out ? 1 : 0;
+  int trc;
+  if ((trc = timing_mark(plan, 0, (hipStream_t)stream))) return trc;       // (a sub-chain's plan never has timing switched on)
   hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream, frames_done);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
-  return SMILEHIP_OK;
+  if ((trc = timing_mark(plan, 1, (hipStream_t)stream))) return trc;
+  return timing_mark(plan, 2, (hipStream_t)stream);
 }
 
 // SMILEHIP_CHAIN_COMPARE: groups A+B into columns 6..64 / 71..129, the 60 ms sub-chain (F0 contour into scratch), then
@@ -551,7 +571,7 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   hipError_t e = launch_f0_lld(P, Q, b->d_row_off.p, b->d_pitch2.p, b->d_jit4.p, d_out, ld_out, 0, 65, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 LLD kernel launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
-  return SMILEHIP_OK;
+  return timing_mark(plan, 2, s);
 }
 
 // SMILEHIP_CHAIN_EGEMAPS: the 20 ms kernels on the plan's side stream, the F0 group on the caller's; then cPitchJitter and
@@ -616,8 +636,11 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
     HIP_TRY(hipEventRecord(plan->ev_fork, s));
   }
   HIP_TRY(hipStreamWaitEvent(side, plan->ev_fork, 0));
+  int trc;
+  if ((trc = timing_mark(plan, 0, side))) return trc;
   e = launch_gemaps_frames(P, G, b->n_runs, side);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS 20 ms kernels: launch failed: %s", hipGetErrorString(e));
+  if ((trc = timing_mark(plan, 1, side))) return trc;
   HIP_TRY(hipEventRecord(plan->ev_join, side));
   if (fb->total_frames > 0) {
     LldParams P60;
@@ -642,7 +665,7 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   e = launch_gemaps_tail(b->d_frame_off.p, b->d_row_off.p, b->n_utt, G, d_out, ld_out, s);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "eGeMAPS tail kernel launch failed: %s", hipGetErrorString(e));
   b->gm_ran = true;
-  return SMILEHIP_OK;
+  return timing_mark(plan, 2, s);
 }
 
 extern "C" int smilehip_batch_egemaps_taps(smilehip_batch *b, const float **d_raw20, const float **d_lpc, const float **d_formants,
