@@ -25,13 +25,18 @@
 // <name>.rank<r><ext> -- ranks never share a file -- and are concatenated afterwards.
 // All files of a chunk are packed into one device batch: one kernel sequence per chunk.
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "conf_plan.hpp"
@@ -58,6 +63,30 @@ std::string basename_noext(const std::string &p) {
   size_t d = b.find_last_of('.');
   return d == std::string::npos ? b : b.substr(0, d);
 }
+
+
+// f(i) for i in [0, n) on up to 32 threads (file ingest and the per-file sinks: one open / read-or-write / close each, which a
+// single thread spends most of its time waiting on); the first error message wins and is reported after the join
+template <class F>
+void parallel_for(size_t n, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned)CPU_COUNT(&set);      // cgroup / taskset limits
+  const size_t nt = std::min<size_t>(n, std::min<unsigned>(32u, std::max(1u, hw)));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+  for (auto &t : th) t.join();
+}
+
+struct Chunk {                                             // the files [j0, j1) of the list, read
+  size_t j0 = 0, j1 = 0;
+  std::vector<std::vector<unsigned char>> raw;
+  std::vector<WaveInfo> info;
+  std::string err;
+};
 
 }  // namespace
 
@@ -226,7 +255,7 @@ int main(int argc, char **argv) {
   std::vector<float> gathered;                              // this rank's summary rows: n_func values + a "has an instance" flag each
   int gathered_cols = 0;
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
-  const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 4096;
+  const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 1024;
   if (chunk_files_l < 1) die("--chunk-files must be a positive number");
   const size_t chunk_files = (size_t)chunk_files_l;
   // Summary sinks (one row per file appended to ONE file) of several ranks must not share a file: each rank of a
@@ -248,18 +277,35 @@ int main(int argc, char **argv) {
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
 
+  // ---- ingest: the files of a chunk are read by up to 32 threads, and chunk k + 1 is read while chunk k is on the device
+  // and in the sinks (16-bit mono PCM is what the fused kernels take)
+  auto ingest = [&](size_t j0) {
+    Chunk c;
+    c.j0 = j0;
+    c.j1 = std::min(jobs.size(), j0 + chunk_files);
+    c.raw.resize(c.j1 - c.j0);
+    c.info.resize(c.j1 - c.j0);
+    std::mutex m;
+    parallel_for(c.j1 - c.j0, [&](size_t k) {
+      std::string e;
+      WaveInfo &wi = c.info[k];
+      if (!read_wave_file(jobs[c.j0 + k].wav, wi, c.raw[k], e)) { std::lock_guard<std::mutex> g(m); if (c.err.empty()) c.err = e; return; }
+      if (wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
+        std::lock_guard<std::mutex> g(m);
+        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': the fused path takes 16-bit mono PCM (other formats: smilehip_pcm_convert + the plugin path)";
+      }
+    });
+    return c;
+  };
+  std::future<Chunk> ahead = std::async(std::launch::async, ingest, (size_t)0);
   for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_files) {
     const size_t j1 = std::min(jobs.size(), j0 + chunk_files);
-    // ---- ingest: 16-bit mono PCM is what the fused kernels take
+    Chunk chunk = ahead.get();
+    if (j1 < jobs.size()) ahead = std::async(std::launch::async, ingest, j1);
+    if (!chunk.err.empty()) die(chunk.err);
     std::map<long, std::vector<size_t>> by_rate;
-    std::vector<std::vector<unsigned char>> raw(j1 - j0);
-    for (size_t j = j0; j < j1; ++j) {
-      WaveInfo wi;
-      if (!read_wave_file(jobs[j].wav, wi, raw[j - j0], err)) die(err);
-      if (wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1)
-        die("'" + jobs[j].wav + "': the fused path takes 16-bit mono PCM (other formats: smilehip_pcm_convert + the plugin path)");
-      by_rate[wi.sample_rate].push_back(j);
-    }
+    std::vector<std::vector<unsigned char>> &raw = chunk.raw;
+    for (size_t j = j0; j < j1; ++j) by_rate[chunk.info[j - j0].sample_rate].push_back(j);
     std::vector<std::vector<float>> func_rows(j1 - j0);   // per job of the chunk; empty = no instance (no frame)
     for (auto &kv : by_rate) {
       smilehip_plan *&plan = plans[kv.first];
@@ -316,8 +362,13 @@ int main(int argc, char **argv) {
       }
       if (rows > 0) check(smilehip_copy_to_host(ctx, lld.data(), d_lld, (uint64_t)rows * n_out * 4, nullptr), "copy_to_host");
       check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
-      // ---- sinks
-      for (size_t i = 0; i < idx.size(); ++i) {
+      // ---- sinks: the per-file outputs of the chunk are written by up to 32 threads (different files; the summary rows are
+      // collected here and appended in list order below)
+      std::mutex sink_m;
+      std::string sink_err;
+      parallel_for(idx.size(), [&](size_t i) {
+        std::string err;                                  // (shadows the function's: one per thread)
+        auto die = [&](const std::string &m) { std::lock_guard<std::mutex> g(sink_m); if (sink_err.empty()) sink_err = m; };
         const Job &job = jobs[idx[i]];
         const float *x = lld.data() + (size_t)row_off[i] * n_out;
         const int64_t r = row_off[i + 1] - row_off[i];
@@ -347,7 +398,8 @@ int main(int argc, char **argv) {
           if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
             if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) die(err);
         }
-      }
+      });
+      if (!sink_err.empty()) die(sink_err);
       smilehip_free(ctx, d_pcm);
       smilehip_free(ctx, d_lld);
       if (d_func) smilehip_free(ctx, d_func);

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""End to end, files in -> files out, beside the reference on the same list:
+
+    N x 10 s (3 s for eGeMAPS) 16-bit mono WAV files on /dev/shm
+      -> opensmile_amd/smilextract_hip --set <set> -filelist ... (one process, one GPU; HTK files per input / one ARFF)
+      -> xargs -P $(nproc) oracle/_ref/SMILExtract -C <conf> -I f ... (one process per file, all host cores)
+
+Wall clock of both, files per second, and -- for the sets whose chain is the reference's bit for bit -- a byte comparison
+of the outputs. One JSON object per set on stdout (profiles/r03_e2e.jsonl)."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SETS = {
+    # name: (smilextract_hip --set, reference conf, seconds per file, hip output options, reference output option, per-file ext)
+    "mfcc12_0_d_a": ("mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf", 10.0, ["-O", "1"], "-O", ".htk"),
+    "is09_emotion": ("is09_emotion", "is09-13/IS09_emotion.conf", 10.0, ["-lldhtkoutput", "1"], "-lldhtkoutput", ".lld.htk"),
+    "egemapsv02": ("egemapsv02", "egemaps/v02/eGeMAPSv02.conf", 3.0, ["-lldhtkoutput", "1"], "-lldhtkoutput", ".lld.htk"),
+    "compare16": ("compare16_lld", "compare16/ComParE_2016.conf", 10.0, ["-lldhtkoutput", "1"], "-lldhtkoutput", ".lld.htk"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--files", type=int, default=1000)
+    ap.add_argument("--sets", default="mfcc12_0_d_a,egemapsv02")
+    ap.add_argument("--ref-files", type=int, default=0, help="files the reference runs on (0 = all); its rate is per file anyway")
+    ap.add_argument("--dir", default="/dev/shm/smilehip_e2e")
+    args = ap.parse_args()
+    from opensmile_amd import synth
+    from oracle import lldo
+    exe = os.path.join(lldo.REF_DIR, "SMILExtract")
+    hip = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
+    cores = os.cpu_count() or 1
+    for name in args.sets.split(","):
+        hset, conf_rel, secs, hip_out, ref_opt, ext = SETS[name]
+        d = args.dir
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d + "/in"); os.makedirs(d + "/hip"); os.makedirs(d + "/ref")
+        n_samp = int(secs * 16000)
+        uniq = [synth.utterance(2 + i, n_samp) for i in range(32)]
+        paths = []
+        for i in range(args.files):
+            p = f"{d}/in/u{i:05d}.wav"
+            lldo.write_wav(p, uniq[i % 32])
+            paths.append(p)
+        lst = d + "/list.txt"
+        open(lst, "w").write("\n".join(paths) + "\n")
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "opensmile_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        t0 = time.perf_counter()
+        r = subprocess.run([hip, "--set", hset, "-filelist", lst, "-outdir", d + "/hip"] + hip_out, env=env, capture_output=True, text=True)
+        t_hip = time.perf_counter() - t0
+        if r.returncode != 0:
+            print(json.dumps({"set": name, "error": r.stderr[-400:]}), flush=True)
+            continue
+        n_ref = args.ref_files or args.files
+        conf = os.path.join(lldo.REF_DIR, "config", *conf_rel.split("/"))
+        jobs = "\n".join(f"u{i:05d}" for i in range(n_ref))
+        cmd = f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {d}/in/$0.wav {ref_opt} {d}/ref/$0{ext} -l 0 >/dev/null 2>&1'"
+        t0 = time.perf_counter()
+        subprocess.run(cmd, shell=True, input=jobs.encode(), cwd=d, check=True)
+        t_ref = time.perf_counter() - t0
+        same = diff = 0
+        for i in range(0, n_ref, max(1, n_ref // 64)):
+            a, b = f"{d}/hip/u{i:05d}{ext}", f"{d}/ref/u{i:05d}{ext}"
+            if os.path.exists(a) and os.path.exists(b):
+                if open(a, "rb").read() == open(b, "rb").read():
+                    same += 1
+                else:
+                    diff += 1
+        print(json.dumps({"set": name, "files": args.files, "seconds_per_file": secs, "smilextract_hip_wall_s": t_hip,
+                          "smilextract_hip_files_per_s": args.files / t_hip, "smilextract_hip_audio_s_per_s": args.files * secs / t_hip,
+                          "reference_files": n_ref, "reference_cores": cores, "reference_wall_s": t_ref,
+                          "reference_files_per_s": n_ref / t_ref, "speedup_files_per_s": (args.files / t_hip) / (n_ref / t_ref),
+                          "outputs_compared": same + diff, "outputs_byte_identical": same,
+                          "note": "smilextract_hip: one process, one GPU, start-up included; reference: one SMILExtract process per file on all host cores"}),
+              flush=True)
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
