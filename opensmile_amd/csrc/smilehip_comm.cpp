@@ -7,6 +7,7 @@
 #include <netinet/tcp.h>
 #include <rccl/rccl.h>
 #include <sys/socket.h>
+#include <poll.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -72,6 +73,10 @@ extern "C" int smilehip_comm_bootstrap_bcast(int rank, int world, const char *ma
     }
     std::vector<char> seen((size_t)world, 0);
     for (int k = 1; k < world; ++k) {
+      // a peer that died before connecting must not hang rank 0 forever: wait at most two minutes per peer
+      pollfd pf{ls, POLLIN, 0};
+      const int pr = poll(&pf, 1, 120 * 1000);
+      if (pr <= 0) { close(ls); return fail("bootstrap: %d of %d peers connected within 120 s", k - 1, world - 1); }
       const int fd = accept(ls, nullptr, nullptr);
       int32_t peer = -1;
       const bool ok = fd >= 0 && recv_all(fd, &peer, sizeof(peer)) && peer > 0 && peer < world && !seen[(size_t)peer] && send_all(fd, buf, (size_t)len);
@@ -141,10 +146,13 @@ extern "C" int smilehip_comm_gather_rows(smilehip_comm *c, const float *d_rows, 
   if (!c || !counts || cols <= 0) return fail("smilehip_comm_gather_rows: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t mine = (size_t)counts[c->rank] * (size_t)cols;
+  // every argument is checked BEFORE the group opens: a return between ncclGroupStart and ncclGroupEnd would leave the
+  // communicator inside an open group
+  if (c->rank == 0 && !d_all) return fail("smilehip_comm_gather_rows: rank 0 needs d_all");
+  if (mine && !d_rows) return fail("smilehip_comm_gather_rows: rank %d has %lld rows but no d_rows", c->rank, (long long)counts[c->rank]);
   ncclResult_t r = ncclGroupStart();
   if (r != ncclSuccess) return fail("ncclGroupStart: %s", ncclGetErrorString(r));
   if (c->rank == 0) {
-    if (!d_all) return fail("smilehip_comm_gather_rows: rank 0 needs d_all");
     size_t off = (size_t)counts[0] * (size_t)cols;
     for (int p = 1; p < c->world; ++p) {
       const size_t n = (size_t)counts[p] * (size_t)cols;

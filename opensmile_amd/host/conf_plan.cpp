@@ -302,11 +302,82 @@ const KnownSet kKnownSets[] = {
 };
 }  // namespace
 
+bool conf_check_io(const ConfFile &f, const std::set<std::string> &produced, std::string &err) {
+  auto num_is = [](const std::string &v, double want) {
+    char *end = nullptr;
+    const double d = strtod(v.c_str(), &end);
+    return end != v.c_str() && d == want;
+  };
+  for (const ConfInstance &i : f.inst) {
+    if (i.type == "cWaveSource") {
+      // waveSource.cpp:52-68: the fused path packs whole files
+      static const std::pair<const char *, double> whole[] = {{"start", 0}, {"end", -1}, {"endrel", 0}, {"startSamples", 0},
+                                                               {"endSamples", -1}, {"endrelSamples", 0}, {"noHeader", 0}};
+      for (const auto &w : whole) {
+        const std::string *v = i.find(w.first);
+        if (v && !num_is(*v, w.second)) {
+          err = "[" + i.name + ":cWaveSource] " + w.first + " = " + *v + ": the fused path reads whole files (only " + w.first + " = " +
+                canonical_value(std::to_string(w.second)) + " is implemented)";
+          return false;
+        }
+      }
+      const std::string *seg = i.find("segmentList");
+      if (seg && !seg->empty()) { err = "[" + i.name + ":cWaveSource] segmentList is not implemented by the fused path"; return false; }
+      continue;
+    }
+    const bool sink = i.type.size() > 4 && i.type.compare(i.type.size() - 4, 4, "Sink") == 0;
+    if (!sink) continue;
+    const std::string *fn = i.find("filename");
+    if (!fn || *fn == "?") continue;                       // a disabled sink (the shared output files' default)
+    if (i.type != "cHtkSink" && i.type != "cCsvSink" && i.type != "cArffSink") {
+      err = "[" + i.name + ":" + i.type + "] is active (filename = " + *fn + ") but smilextract_hip has no writer for it";
+      return false;
+    }
+    const std::string *lv = i.find("reader.dmLevel");
+    if (lv && !produced.empty()) {
+      size_t a = 0;
+      while (a <= lv->size()) {                            // "lld;lld_de": every level the sink reads
+        const size_t b = lv->find(';', a);
+        const std::string one = lv->substr(a, b == std::string::npos ? std::string::npos : b - a);
+        if (!one.empty() && !produced.count(one)) {
+          err = "[" + i.name + ":" + i.type + "] reads level '" + one + "', which the fused path does not write (it keeps only the "
+                "output levels; intermediate levels: per-component operators through the plugin)";
+          return false;
+        }
+        if (b == std::string::npos) break;
+        a = b + 1;
+      }
+    }
+    const bool on_func = lv && *lv == "func";
+    // option -> the one value the writers of opensmile_amd/host/sinks.cpp implement for this kind of sink
+    std::vector<std::pair<std::string, double>> fixed;
+    if (i.type == "cCsvSink") fixed = {{"timestamp", 1}, {"frameTime", 1}, {"printHeader", 1}, {"number", 0}, {"frameIndex", 0}, {"append", on_func ? 1.0 : 0.0}};
+    if (i.type == "cArffSink") fixed = {{"frameIndex", 0}, {"frameTime", on_func ? 0.0 : 1.0}, {"timestamp", on_func ? 0.0 : 1.0}, {"frameTimeAdd", 0}, {"append", 1}};
+    if (i.type == "cHtkSink") fixed = {{"append", 0}};
+    for (const auto &kv : fixed) {
+      const std::string *v = i.find(kv.first);
+      if (v && !num_is(*v, kv.second)) {
+        err = "[" + i.name + ":" + i.type + "] " + kv.first + " = " + *v + " is not implemented by smilextract_hip's writer (only " + kv.first +
+              " = " + canonical_value(std::to_string(kv.second)) + ")";
+        return false;
+      }
+    }
+    if (i.type == "cArffSink" && !on_func) {
+      err = "[" + i.name + ":cArffSink] an ARFF file of the LLD level (-lldarffoutput) is not implemented by smilextract_hip";
+      return false;
+    }
+    const std::string *delim = i.find("delimChar");
+    if (delim && *delim != ";") { err = "[" + i.name + ":cCsvSink] delimChar = " + *delim + " is not implemented (only ';')"; return false; }
+  }
+  return true;
+}
+
 bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
   p = ConfPlan();
   const uint64_t fp = conf_fingerprint(f);
   for (const KnownSet &k : kKnownSets)
     if (k.fingerprint == fp && fp != 0) {
+      if (!conf_check_io(f, {"lld", "lld_de", "func"}, err)) return false;   // the shared output file's levels
       p.preset = k.set;
       p.describe = std::string("the graph of ") + k.file + " (every processing component and option identical)";
       return true;
@@ -556,6 +627,24 @@ bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
     auto it = levels.find(l);
     if (it == levels.end()) { err = "[" + any_sink->name + ":" + any_sink->type + "] reads level '" + l + "', which the cepstral chain does not produce"; return false; }
     outc.insert(outc.end(), it->second.begin(), it->second.end());
+  }
+  // every other active sink must read the same levels (the fused path writes one output matrix; a sink on a stage level or on
+  // another combination would silently get nothing), and the source / sink options must be the ones the writers implement
+  {
+    const std::string want = lvl(any_sink, "reader.dmLevel");
+    for (const ConfInstance &i : f.inst) {
+      const bool is_sink = i.type.size() > 4 && i.type.compare(i.type.size() - 4, 4, "Sink") == 0;
+      const std::string *fn = i.find("filename");
+      if (!is_sink || &i == any_sink || !fn || *fn == "?") continue;
+      if (lvl(&i, "reader.dmLevel") != want) {
+        err = "[" + i.name + ":" + i.type + "] reads '" + lvl(&i, "reader.dmLevel") + "' while [" + any_sink->name + "] reads '" + want +
+              "': the fused path writes one output matrix (a sink on a stage level: per-component operators through the plugin)";
+        return false;
+      }
+    }
+    std::set<std::string> produced;
+    for (const std::string &l : split_levels(want)) produced.insert(l);
+    if (!conf_check_io(f, produced, err)) return false;
   }
   // must be [cepstra (, energy)] x (1 + n_delta) blocks, the cepstra of block 0 either all normalised or none
   const int n_cep = p.plp ? c.plp_lp_order - c.first_mfcc + 1 : c.last_mfcc - c.first_mfcc + 1;

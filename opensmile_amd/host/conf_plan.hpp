@@ -48,4 +48,11 @@ struct ConfPlan {
 // false + err: the graph (component, option) the fused path cannot express
 bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err);
 
+// Sources and sinks are outside the fingerprint and the plan: this checks them. Every cWaveSource must read the whole file
+// (start 0, end -1, no sample-based range, a RIFF header), every ACTIVE sink (filename other than "?") must be one
+// smilextract_hip writes (cHtkSink / cCsvSink on the lld level, cArffSink / cCsvSink / cHtkSink on the functionals level, or
+// the cepstral files' own cHtkSink) with the option values its writers implement; produced: the levels the plan writes
+// (a sink reading any other level would get nothing). false + err names the instance and option.
+bool conf_check_io(const ConfFile &f, const std::set<std::string> &produced, std::string &err);
+
 }  // namespace smilehip_host

@@ -132,11 +132,36 @@ int main(int argc, char **argv) {
     }
     static const char *builtin[] = {"l", "loglevel", "nologfile", "noconsoleoutput", "logfile", "appendLogfile", "t", "nticks", "d", "debug",
                                     "C", "configfile", "N", "instname", "filelist", "outdir"};
+    // the \cm options this program acts on (with their one-letter forms); every other option the file defines is accepted only
+    // with the file's own default value -- it would be parsed and then silently ignored otherwise (-start, -end, -arffoutput,
+    // -timestampcsv, -appendcsv, -relation, -frameTimeAdd, ...)
+    static const char *honoured[] = {"inputfile", "I", "output", "O", "csvoutput", "htkoutput", "lldcsvoutput", "D", "lldhtkoutput",
+                                     "instname", "N"};
     for (const auto &kv : conf_cmdline) {
       bool ok = cf.cm_defaults.count(kv.first) != 0;
-      for (const auto &sh : cf.cm_short) ok = ok || sh.second == kv.first;
-      for (const char *b : builtin) ok = ok || kv.first == b;
-      if (!ok) die("option -" + kv.first + " is not defined by " + opt["-C"]);
+      std::string long_name = kv.first;
+      for (const auto &sh : cf.cm_short) if (sh.second == kv.first) { ok = true; long_name = sh.first; }
+      bool is_builtin = false, acted_on = false;
+      for (const char *b : builtin) is_builtin = is_builtin || kv.first == b;
+      for (const char *h : honoured) acted_on = acted_on || kv.first == h || long_name == h;
+      if (!ok && !is_builtin) die("option -" + kv.first + " is not defined by " + opt["-C"]);
+      if (is_builtin || acted_on) continue;
+      const auto dflt = cf.cm_defaults.find(long_name);
+      if (dflt == cf.cm_defaults.end() || dflt->second != kv.second)
+        die("option -" + kv.first + " " + kv.second + ": " + opt["-C"] + " defines it, but smilextract_hip does not implement it (only its "
+            "default" + (dflt != cf.cm_defaults.end() ? " '" + dflt->second + "'" : "") + "); implemented: -I -O -csvoutput -htkoutput "
+            "-lldcsvoutput -lldhtkoutput -instname");
+    }
+    // an output option the file gives a default file name (MFCC12_0_D_A.conf: output(O){output.htk}) is written there, as the
+    // reference does, unless the command line says otherwise
+    {
+      static const std::pair<const char *, const char *> outs[] = {{"output", "-O"}, {"csvoutput", "-csvoutput"}, {"htkoutput", "-htkoutput"},
+                                                                    {"lldcsvoutput", "-lldcsvoutput"}, {"lldhtkoutput", "-lldhtkoutput"}};
+      for (const auto &o : outs) {
+        const auto dflt = cf.cm_defaults.find(o.first);
+        if (dflt != cf.cm_defaults.end() && dflt->second != "?" && !dflt->second.empty() && !opt.count(o.second) && !opt.count("-filelist"))
+          opt[o.second] = dflt->second;
+      }
     }
     if (!conf_to_plan(cf, conf_plan, cerr_)) die("-C " + opt["-C"] + " cannot run on the fused path: " + cerr_);
     fprintf(stderr, "smilextract_hip: %s -> %s\n", opt["-C"].c_str(), conf_plan.describe.c_str());

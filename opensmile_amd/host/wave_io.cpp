@@ -63,7 +63,21 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
       if (end >= here) remaining = end - here;
       fseek(f, here, SEEK_SET);
     }
-    if (remaining >= 0 && ((uint64_t)ch.size > (uint64_t)remaining || ch.size == 0)) info.n_blocks = remaining / block_align;
+    bool to_eof = remaining >= 0 && (uint64_t)ch.size > (uint64_t)remaining;
+    if (remaining >= 8 && ch.size == 0) {
+      // size 0: a stream written to a pipe (audio until EOF) -- unless what follows is itself a well-formed chunk (an empty
+      // data chunk before LIST / id3 / ... metadata): four printable id bytes and a size that fits the rest of the file
+      unsigned char h[8];
+      const bool got8 = fread(h, 1, 8, f) == 8;
+      fseek(f, here, SEEK_SET);
+      const uint32_t sz = got8 ? (uint32_t)h[4] | ((uint32_t)h[5] << 8) | ((uint32_t)h[6] << 16) | ((uint32_t)h[7] << 24) : 0;
+      bool printable = got8;
+      for (int q = 0; q < 4 && printable; ++q) printable = (h[q] >= 'A' && h[q] <= 'Z') || (h[q] >= 'a' && h[q] <= 'z') || (h[q] >= '0' && h[q] <= '9') || h[q] == ' ';
+      to_eof = !(printable && (uint64_t)sz + 8 <= (uint64_t)remaining);
+    } else if (remaining >= 0 && remaining < 8 && ch.size == 0) {
+      to_eof = remaining > 0;
+    }
+    if (to_eof) info.n_blocks = remaining / block_align;
   }
   data.resize((size_t)info.n_blocks * block_align);
   const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);

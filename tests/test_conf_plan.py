@@ -76,9 +76,10 @@ def test_option_changes_and_refusals(tmp_path):
 
     def variant(name, *subs):
         t = txt
-        for a, b in subs:
+        for sub in subs:
+            a, b = sub[0], sub[1]
             assert a in t, a
-            t = t.replace(a, b)
+            t = t.replace(a, b, sub[2]) if len(sub) > 2 else t.replace(a, b)
         p = tmp_path / "mfcc" / name
         p.write_text(t)
         return str(p)
@@ -103,6 +104,23 @@ def test_option_changes_and_refusals(tmp_path):
     # an option the file does not define is refused like SMILExtract refuses it
     rc, kv, err = describe(src, "-nosuchoption", "1")
     assert rc != 0 and "nosuchoption" in err
+    # options the file defines but this program does not implement are refused (they used to be parsed and ignored:
+    # ADVICE r2): a segment of the file, a second sink, another timestamp / header / append setting
+    for extra in (("-start", "1"), ("-end", "2"), ("-appendcsv", "1"), ("-timestampcsv", "0"), ("-headercsv", "0"), ("-arffoutput", "a.arff")):
+        rc, kv, err = describe(src, *extra)
+        assert rc != 0 and extra[0][1:] in err and "does not implement" in err, (extra, err)
+    rc, kv, err = describe(src, "-start", "0", "-end", "-1")            # the defaults themselves are fine
+    assert rc == 0, err
+    big = os.path.join(CONF, "is09-13", "IS09_emotion.conf")
+    for extra in (("-lldarffoutput", "a.arff"), ("-timestampcsv", "0"), ("-appendarff", "0"), ("-relation", "x"), ("-frameTimeAdd", "1")):
+        rc, kv, err = describe(big, *extra)
+        assert rc != 0 and extra[0][1:] in err, (extra, err)
+    # source / sink sections edited in the file itself: a segment, a second sink on a stage level, an unknown sink type
+    rc, kv, err = describe(variant("f.conf", ("instance[frame].type=cFramer", "instance[frame].type=cFramer\ninstance[waveIn2].type=cWaveSource"), ("[frame:cFramer]", "[waveIn2:cWaveSource]\nstart = 0.5\n[frame:cFramer]")))
+    assert rc != 0 and "start" in err, err
+    rc, kv, err = describe(variant("g.conf", ("instance[frame].type=cFramer", "instance[frame].type=cFramer\ninstance[tap].type=cCsvSink"),
+                                   ("[frame:cFramer]", "[tap:cCsvSink]\nreader.dmLevel=melspec\nfilename=tap.csv\n[frame:cFramer]")))
+    assert rc != 0 and "melspec" in err, err
 
 
 @pytest.mark.gpu
