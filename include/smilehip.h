@@ -589,6 +589,13 @@ int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld
  * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
  * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */
 int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W, void *stream);
+/* The option variants of the same two components, one row: kind 2 = cContourSmoother with noZeroSma (contourSmoother.cpp:91-104);
+ * kind 3 = cDeltaRegression with onlyInSegments (deltaRegression.cpp:121-137). The reference's onlyInSegments branch adds i^2 to
+ * its `norm` member for every pair it uses and never resets it: d_norm_io (one device float, initialised by the caller to
+ * 2 * sum i^2 -- deltaRegression.cpp:77-79) is that member, read and written by every call in the instance's processing order.
+ * kinds 0 / 1 forward to smilehip_window_op_row. */
+int smilehip_window_op_row_ex(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W, float *d_norm_io,
+                              void *stream);
 /* ---- GeMAPS / eGeMAPS components, per component, on an eGeMAPS plan (smilehip_config_egemapsv02: 16 kHz, 20 ms Hamming frames
  * -> 512-point spectrum; 60 ms frames -> 1024-point spectrum). Rows in, rows out, like the operators above. */
 /* cSpectral::processVector (src/lldcore/spectral.cpp:586-1254) with the GeMAPS option sets -- squareInput = 1, useLogSpectrum = 1,

@@ -114,6 +114,44 @@ __global__ void k_window_op(const float *x, float *y, int64_t nT, int kind, int 
   }
 }
 
+// The option variants of the two window processors, one row: kind 2 = cContourSmoother with noZeroSma (contourSmoother.cpp:91-104:
+// a zero stays zero, the mean runs over the non-zero neighbours); kind 3 = cDeltaRegression with onlyInSegments
+// (deltaRegression.cpp:121-137): pairs with a zero / NaN member are skipped -- and the reference ADDS i^2 to its norm member for
+// every pair it uses, frame after frame, field after field (the member is never reset): the divisor is state carried through
+// every row the instance ever processes. One thread walks the row in order; *norm_io is that member, in and out.
+__global__ void k_window_op_seq(const float *x, float *y, int64_t nT, int kind, int W, float *norm_io) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (kind == 2) {
+    for (int64_t n = 0; n < nT; ++n) {
+      if (x[n] != 0.0f) {
+        long N = 1;
+        float v = x[n];
+        for (int w = 1; w <= W; ++w) {
+          if (x[n - w] != 0.0f) { v += x[n - w]; N++; }
+          if (x[n + w] != 0.0f) { v += x[n + w]; N++; }
+        }
+        y[n] = v / (float)N;
+      } else {
+        y[n] = 0.0f;
+      }
+    }
+    return;
+  }
+  float norm = *norm_io;
+  for (int64_t n = 0; n < nT; ++n) {
+    float num = 0.0f;
+    for (int i = 1; i <= W; ++i) {
+      const float a = x[n + i], b = x[n - i];
+      if (!(a == 0.0f || a != a || b == 0.0f || b != b)) {
+        num += (float)i * (a - b);
+        norm += (float)i * (float)i;
+      }
+    }
+    y[n] = (norm != 0.0f) ? num / norm : 0.0f;
+  }
+  *norm_io = norm;
+}
+
 // R11 cSpectral::processVector, ComParE option set: the frames of one stream in order (the flux needs the
 // previous frame's magnitudes; `state` carries them across calls). One workgroup, K = 257.
 __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds, float *state, int first, float *dst,
@@ -258,6 +296,10 @@ hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float 
   if (nF > 0)
     hipLaunchKernelGGL(k_plp_cc, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n_bands, eql, melfloor, compression, order, costab,
                        sintab, dst, ldd);
+  return hipGetLastError();
+}
+hipError_t stage_window_op_seq(const float *x, float *y, int64_t nT, int kind, int W, float *d_norm, hipStream_t s) {
+  if (nT > 0) hipLaunchKernelGGL(k_window_op_seq, dim3(1), dim3(64), 0, s, x, y, nT, kind, W, d_norm);
   return hipGetLastError();
 }
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {

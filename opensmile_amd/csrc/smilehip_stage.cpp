@@ -167,6 +167,14 @@ extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, f
   STAGE_RET(stage_window_op(d_x, d_y, n_t, kind, W, delta_norm(W), (hipStream_t)stream), "window_op");
 }
 
+extern "C" int smilehip_window_op_row_ex(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,
+                                         float *d_norm_io, void *stream) {
+  if (kind == 0 || kind == 1) return smilehip_window_op_row(ctx, d_x, d_y, n_t, kind, W, stream);
+  if (!ctx || n_t < 0 || W < 1 || (kind != 2 && kind != 3) || (kind == 3 && !d_norm_io) || (n_t > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_window_op_row_ex: bad argument");
+  STAGE_RET(stage_window_op_seq(d_x, d_y, n_t, kind, W, d_norm_io, (hipStream_t)stream), "window_op_seq");
+}
+
 extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
                                       int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmag_frames: null plan");

@@ -20,12 +20,13 @@
 //
 // -filelist: one "wav[<TAB>instname]" per line. Per-file outputs (HTK, LLD CSV) of a list go to
 // -outdir/<basename>.<ext>; summary outputs (func ARFF/CSV) append one row per file, like the
-// reference's append=1 default. --rank/--world: this process takes files r, r+n, r+2n, ...
+// reference's append=1 default. --rank/--world: this process takes its share of an LPT partition of the list by file size
 // (utterances shard with no communication; one process per GPU); the summary outputs of rank r then go to
 // <name>.rank<r><ext> -- ranks never share a file -- and are concatenated afterwards.
 // All files of a chunk are packed into one device batch: one kernel sequence per chunk.
 #include <dlfcn.h>
 #include <sched.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -239,10 +240,30 @@ int main(int argc, char **argv) {
   if (world < 1 || rank < 0 || rank >= world) die("bad --rank/--world");
   const int device = opt.count("--device") ? atoi(opt["--device"].c_str()) : env_int("LOCAL_RANK", 0);
   const std::vector<Job> all_jobs = jobs;                  // rank 0 names the gathered rows
+  // Sharding: longest-processing-time first on the files' sizes (a WAV's size is its frame count up to the header),
+  // computed identically by every rank from the list alone -- no communication; within a rank the list order is kept.
+  // shard[r] = list indices of rank r.
+  std::vector<std::vector<size_t>> shard((size_t)world);
   if (world > 1) {
+    std::vector<std::pair<long long, size_t>> by_size(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) {
+      struct stat st;
+      by_size[i] = {stat(jobs[i].wav.c_str(), &st) == 0 ? (long long)st.st_size : 0LL, i};
+    }
+    std::stable_sort(by_size.begin(), by_size.end(), [](const std::pair<long long, size_t> &a, const std::pair<long long, size_t> &b) { return a.first > b.first; });
+    std::vector<long long> load((size_t)world, 0);
+    for (const auto &f : by_size) {
+      size_t best = 0;
+      for (size_t r = 1; r < (size_t)world; ++r) if (load[r] < load[best]) best = r;
+      load[best] += f.first > 0 ? f.first : 1;
+      shard[best].push_back(f.second);
+    }
+    for (auto &v : shard) std::sort(v.begin(), v.end());
     std::vector<Job> mine;
-    for (size_t i = (size_t)rank; i < jobs.size(); i += (size_t)world) mine.push_back(jobs[i]);
+    for (size_t i : shard[(size_t)rank]) mine.push_back(jobs[i]);
     jobs.swap(mine);
+  } else {
+    for (size_t i = 0; i < jobs.size(); ++i) shard[0].push_back(i);
   }
   const bool list_mode = opt.count("-filelist") != 0;
   const std::string outdir = opt.count("-outdir") ? opt["-outdir"] : "";
@@ -479,10 +500,14 @@ int main(int argc, char **argv) {
       std::vector<int64_t> first((size_t)world + 1, 0);
       for (int r = 0; r < world; ++r) first[(size_t)r + 1] = first[(size_t)r] + counts[(size_t)r];
       const int n_func = cols - 1;
+      std::vector<std::pair<int, int64_t>> where(all_jobs.size());      // list index -> (rank, position in that rank's rows)
+      for (int r = 0; r < world; ++r) {
+        if ((int64_t)shard[(size_t)r].size() != counts[(size_t)r]) die("--gather: the ranks disagree about the file list");
+        for (size_t k = 0; k < shard[(size_t)r].size(); ++k) where[shard[(size_t)r][k]] = {r, (int64_t)k};
+      }
       for (size_t j = 0; j < all_jobs.size(); ++j) {
-        const int r = (int)(j % (size_t)world);
-        const int64_t k = (int64_t)(j / (size_t)world);
-        if (k >= counts[(size_t)r]) die("--gather: the ranks disagree about the file list");
+        const int r = where[j].first;
+        const int64_t k = where[j].second;
         const float *fv = all.data() + (size_t)(first[(size_t)r] + k) * cols;
         if (fv[n_func] == 0.0f) continue;                   // no frame -> the reference writes no instance
         if (opt.count("-O") && opt["-O"] != "?") {

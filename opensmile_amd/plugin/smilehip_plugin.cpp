@@ -38,11 +38,10 @@
 #include <lld/pitchShs.hpp>
 #include <lld/pitchSmootherViterbi.hpp>
 // cPitchJitter keeps its second reader, its options and the state it carries from frame to frame private; a tick-level
-// override has to use them (the base class's own myTick must still work when an option set is not built). The header is
-// included with its access specifier relaxed -- nothing but access control changes, the object layout is the library's.
-#define private protected
+// override has to use them (the base class's own myTick must still work when an option set is not built). This translation
+// unit is compiled with -fno-access-control (plugin/Makefile): the compiler skips access CHECKS, no keyword is redefined and
+// the header is the library's, token for token -- same layout, same mangled names.
 #include <lld/pitchJitter.hpp>
-#undef private
 #include <lldcore/energy.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
@@ -83,8 +82,17 @@ const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "
 
 // An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
 // says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
+// Round 3: that is opt-in. By default an option set that is not built is an ERROR of the component (COMP_ERR, like any
+// configuration the reference cannot run) -- "the plugin is loaded" then means "the frames were computed on the GPU";
+// SMILEHIP_PLUGIN_ALLOW_CPU=1 brings back the logged and counted fall-through.
+inline bool allow_cpu() {
+  static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_ALLOW_CPU"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
 #define HIP_FALLTHROUGH(idx, why)                                                                                  \
   do {                                                                                                             \
+    if (!allow_cpu())                                                                                              \
+      COMP_ERR("libsmilehip plugin: %s (set SMILEHIP_PLUGIN_ALLOW_CPU=1 to run this instance on the reference's CPU code)", why); \
     if (!cpu_warned_) {                                                                                            \
       SMILE_IWRN(1, "libsmilehip plugin: %s -- this instance runs the reference's CPU code", why);                 \
       cpu_warned_ = true;                                                                                          \
@@ -748,25 +756,34 @@ struct RowIO {
     if (nT <= 0) return;
     io.ensure(nT + pre + post, nT);
     io.up(in->data - pre, nT + pre + post);
-    check(smilehip_window_op_row(context(), io.d_in + pre, io.d_out, nT, kind, W, nullptr));
+    check(smilehip_window_op_row_ex(context(), io.d_in + pre, io.d_out, nT, kind, W, d_norm, nullptr));
     io.down(out->data, nT);
   }
+  float *d_norm = nullptr;                                 // kind 3: the instance's carried divisor (one device float)
 };
 
 class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
   bool cpu_warned_ = false;
-  int plain_ = -1, W_ = 0;
+  int plain_ = -1, W_ = 0, segs_ = 0;
+  DevBytes norm_;
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
       W_ = getInt("deltawin");
-      plain_ = (W_ > 0 && !getInt("onlyInSegments") && !getInt("relativeDelta") && !getInt("halfWaveRect") &&
-                !getInt("absOutput")) ? 1 : 0;
+      segs_ = getInt("onlyInSegments") ? 1 : 0;
+      plain_ = (W_ > 0 && !getInt("relativeDelta") && !getInt("halfWaveRect") && !getInt("absOutput")) ? 1 : 0;
+      if (plain_ && segs_) {                               // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
+        float n0 = 0.0f;
+        for (int i = 1; i <= W_; i++) n0 += (float)i * (float)i;
+        n0 *= 2.0f;
+        row_.d_norm = (float *)norm_.ensure(sizeof(float));
+        check(smilehip_copy_to_device(context(), row_.d_norm, &n0, sizeof(float), nullptr));
+      }
     }
     if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
-    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: onlyInSegments / relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
-    row_.run(in, out, pre, post, 0, W_);
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
+    row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
     g_frames[10] += out->nT;
     return 1;
   }
@@ -782,16 +799,17 @@ class cHipDeltaRegression : public cDeltaRegression {
 class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
   bool cpu_warned_ = false;
-  int plain_ = -1, W_ = 0;
+  int plain_ = -1, W_ = 0, nz_ = 0;
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
       const int smaWin = getInt("smaWin");
       W_ = smaWin / 2;
-      plain_ = (!getInt("noZeroSma") && (smaWin & 1) && W_ >= 1) ? 1 : 0;
+      plain_ = ((smaWin & 1) && W_ >= 1) ? 1 : 0;
+      nz_ = getInt("noZeroSma") ? 1 : 0;
     }
-    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: noZeroSma is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
-    row_.run(in, out, pre, post, 1, W_);
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: an even smaWin is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
+    row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);
     g_frames[11] += out->nT;
     return 1;
   }

@@ -372,6 +372,45 @@ def test_smilextract_hip_gather_single_rank(tmp_path):
     assert [r.split(",")[0] for r in rows] == ["a", "c"]               # the 25 ms file has no 60 ms frame: no instance
 
 
+@pytest.mark.gpu
+def test_smilextract_hip_lpt_shards_and_two_rank_gather(tmp_path):
+    """--world 2 on a ragged list: (a) the two ranks' LPT shares (by file size) are disjoint, cover the list, are balanced, and
+    their summary rows put back into list order equal the one-rank file; (b) on a box with two GPUs the --gather run of two ranks
+    (RCCL send / recv between them) writes byte for byte the one-rank ARFF."""
+    import wave
+    from opensmile_amd import synth
+    lens = [48000, 16000, 160000, 9000, 80000, 16000, 120000, 32000, 4000, 64000]
+    paths = []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f"f{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(synth.utterance(60 + i, n).tobytes())
+        paths.append(p)
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("".join(f"{p}\tinst{i}\n" for i, p in enumerate(paths)))
+    one = str(tmp_path / "one.arff")
+    subprocess.run([EXE, "--set", "egemapsv02", "-filelist", lst, "-O", one], check=True)
+    rows_one = [l for l in open(one).read().split("@data")[1].split("\n") if l]
+    got = {}
+    for r in (0, 1):
+        subprocess.run([EXE, "--set", "egemapsv02", "-filelist", lst, "-O", str(tmp_path / "two.arff"), "--rank", str(r), "--world", "2",
+                        "--device", "0"], check=True)
+        rows = [l for l in open(str(tmp_path / f"two.rank{r}.arff")).read().split("@data")[1].split("\n") if l]
+        got[r] = rows
+    names = [set(x.split(",")[0] for x in got[r]) for r in (0, 1)]
+    assert not (names[0] & names[1]) and len(names[0] | names[1]) == len(rows_one)
+    merged = sorted(got[0] + got[1], key=lambda l: int(l.split(",")[0].strip("'")[4:]))
+    assert merged == rows_one
+    load = [sum(lens[int(n.strip("'")[4:])] for n in names[r]) for r in (0, 1)]
+    assert abs(load[0] - load[1]) <= max(lens), load                      # LPT: within the longest file of each other
+    import torch
+    if torch.cuda.device_count() >= 2:
+        out = str(tmp_path / "gathered.arff")
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "smoke_gather.sh"), "2", lst, out], check=True, timeout=600)
+        assert open(out).read() == open(one).read()
+
+
 def test_fast_number_formatting_equals_printf(hostlib):
     """format_e6 / format_f0 (opensmile_amd/host/sinks.cpp), what the CSV / ARFF writers print numbers with: byte for byte
     printf's "%e" / "%.0f" -- on 20 million random bit patterns (every exponent, both signs, subnormals, inf, nan), on values at
