@@ -104,6 +104,16 @@ extern "C" void smilehip_config_compare16_f0(smilehip_lld_config *c) {
 extern "C" void smilehip_config_compare16(smilehip_lld_config *c) {
   smilehip_config_compare16_ab(c);
   c->chain_kind = SMILEHIP_CHAIN_COMPARE;
+  // the F0 group's parameters (forwarded to the 60 ms sub-chain by smilehip_plan_create): [is13_shs], [is13_volmerge],
+  // [is13_pitchSmoothViterbi] bufferLength, [is13_pitchJitter] searchRangeRel
+  c->pitch_min = 52.0;
+  c->pitch_max = 620.0;
+  c->voicing_cutoff = 0.7;
+  c->shs_n_harmonics = 15;
+  c->shs_compression = 0.85f;
+  c->f0_min_energy = 0.001f;
+  c->vit_buffer_len = 30;
+  c->jitter_search_range = 0.25;
 }
 
 // config/is09-13/IS13_ComParE_core.lld.conf.inc = ComParE_2016_core.lld.conf.inc except [is13_fft25] / [is13_fft60]
@@ -456,6 +466,13 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
     c60.frame_step_sec = cfg->frame_step_sec;
     c60.zero_pad_symmetric = cfg->zero_pad_symmetric;     // both cTransformFFT instances carry the set's value
     c60.jitter_broken_thresh = cfg->jitter_broken_thresh;
+    if (cfg->pitch_max > 0.0) {                           // the F0 group's parameters (an edited ComParE_2016.conf; 0 = a config struct from before they were forwarded)
+      c60.pitch_min = cfg->pitch_min; c60.pitch_max = cfg->pitch_max; c60.voicing_cutoff = cfg->voicing_cutoff;
+      c60.shs_n_harmonics = cfg->shs_n_harmonics; c60.shs_compression = cfg->shs_compression;
+      c60.f0_min_energy = cfg->f0_min_energy;
+      if (cfg->vit_buffer_len > 0) c60.vit_buffer_len = cfg->vit_buffer_len;
+      if (cfg->jitter_search_range > 0.0) c60.jitter_search_range = cfg->jitter_search_range;
+    }
     rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
     if (rc == SMILEHIP_OK && (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess ||
                               hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||

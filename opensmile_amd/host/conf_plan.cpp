@@ -286,19 +286,71 @@ uint64_t conf_fingerprint(const ConfFile &f) {
   return h;
 }
 
+// The options of the F0 group the chains take as parameters (smilehip_lld_config fields): cPitchShs (pitchShs.cpp /
+// pitchBase.cpp options), cPitchSmootherViterbi bufferLength, cPitchJitter searchRangeRel / useBrokenJitterThresh and the
+// threshold of the energy gate ([is13_volmerge] / [gemapsv01b_volmerge]). Returns the config field's name, or nullptr.
+static const char *conf_is_f0_param(const ConfInstance &i, const std::string &key) {
+  if (i.type == "cPitchShs") {
+    if (key == "minPitch") return "pitch_min";
+    if (key == "maxPitch") return "pitch_max";
+    if (key == "voicingCutoff") return "voicing_cutoff";
+    if (key == "nHarmonics") return "shs_n_harmonics";
+    if (key == "compressionFactor") return "shs_compression";
+  }
+  if (i.type == "cPitchSmootherViterbi" && key == "bufferLength") return "vit_buffer_len";
+  if (i.type == "cPitchJitter") {
+    if (key == "searchRangeRel") return "jitter_search_range";
+    if (key == "useBrokenJitterThresh") return "jitter_broken_thresh";
+  }
+  if (i.type == "cValbasedSelector" && key == "threshold" && i.name.size() >= 8 && i.name.compare(i.name.size() - 8, 8, "volmerge") == 0)
+    return "f0_min_energy";
+  return nullptr;
+}
+
+uint64_t conf_fingerprint_masked(const ConfFile &f) {
+  uint64_t h = 1469598103934665603ull;
+  auto eat = [&](const std::string &s) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    h ^= '\n'; h *= 1099511628211ull;
+  };
+  for (const ConfInstance &i : f.inst) {
+    if (is_io_type(i.type)) continue;
+    eat(i.name + ":" + i.type);
+    std::vector<std::pair<std::string, std::string>> o = i.opts;
+    std::sort(o.begin(), o.end());
+    for (const auto &kv : o)
+      if (!conf_is_f0_param(i, kv.first)) eat(kv.first + "=" + canonical_value(kv.second));
+  }
+  return h;
+}
+
+void conf_apply_f0_params(const ConfPlan &p, smilehip_lld_config &c) {
+  for (const auto &kv : p.f0_params) {
+    if (kv.first == "pitch_min") c.pitch_min = kv.second;
+    else if (kv.first == "pitch_max") c.pitch_max = kv.second;
+    else if (kv.first == "voicing_cutoff") c.voicing_cutoff = kv.second;
+    else if (kv.first == "shs_n_harmonics") c.shs_n_harmonics = (int32_t)kv.second;
+    else if (kv.first == "shs_compression") c.shs_compression = (float)kv.second;
+    else if (kv.first == "vit_buffer_len") c.vit_buffer_len = (int32_t)kv.second;
+    else if (kv.first == "jitter_search_range") c.jitter_search_range = kv.second;
+    else if (kv.first == "jitter_broken_thresh") c.jitter_broken_thresh = (int32_t)kv.second;
+    else if (kv.first == "f0_min_energy") c.f0_min_energy = (float)kv.second;
+  }
+}
+
 namespace {
-struct KnownSet { uint64_t fingerprint; const char *set; const char *file; };
+struct KnownSet { uint64_t fingerprint; const char *set; const char *file; uint64_t masked; };
 // fingerprints of the reference's own files (smilextract_hip -C <file> --fingerprint prints them), computed from
 // config/is09-13/IS09_emotion.conf, config/compare16/ComParE_2016.conf, config/is09-13/IS13_ComParE.conf and
 // config/egemaps/v02/eGeMAPSv02.conf (and its two sub-graphs, GeMAPSv01b.conf / eGeMAPSv01b.conf) with their includes and every command-line option at its default
 const KnownSet kKnownSets[] = {
-    {0x84b42d91f07908acull, "is09_emotion", "IS09_emotion.conf"},
-    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf"},
-    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf"},
-    {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf"},
+    {0x84b42d91f07908acull, "is09_emotion", "IS09_emotion.conf", 0},
+    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf", 0x27e03c47ce1ea38aull},
+    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf", 0x7d6ca59726bab51dull},
+    {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf", 0x0a4014c8c2747c7aull},
     // sub-graphs of eGeMAPSv02.conf: their levels are column subsets of its levels (smilehip_host.hpp, egemaps_subset_columns)
-    {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf"},
-    {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf"},
+    {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf", 0xd9d453405c7cfe69ull},
+    {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf", 0x4bea506faa49e282ull},
 };
 }  // namespace
 
@@ -380,6 +432,27 @@ bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
       if (!conf_check_io(f, {"lld", "lld_de", "func"}, err)) return false;   // the shared output file's levels
       p.preset = k.set;
       p.describe = std::string("the graph of ") + k.file + " (every processing component and option identical)";
+      return true;
+    }
+  // the same graph with other values of the options the kernels take as parameters (the F0 group's pitch range, harmonics,
+  // compression, voicing cutoff, Viterbi buffer, jitter search range / threshold rule, energy gate)
+  const uint64_t fpm = conf_fingerprint_masked(f);
+  for (const KnownSet &k : kKnownSets)
+    if (k.masked != 0 && k.masked == fpm) {
+      if (!conf_check_io(f, {"lld", "lld_de", "func"}, err)) return false;
+      p.preset = k.set;
+      std::string what;
+      for (const ConfInstance &i : f.inst)
+        for (const auto &kv : i.opts) {
+          const char *field = conf_is_f0_param(i, kv.first);
+          if (!field) continue;
+          char *end = nullptr;
+          const double v = strtod(kv.second.c_str(), &end);
+          if (end == kv.second.c_str()) { err = "[" + i.name + ":" + i.type + "] " + kv.first + " = " + kv.second + " is not a number"; return false; }
+          p.f0_params[field] = v;
+          what += (what.empty() ? "" : ", ") + kv.first + " = " + canonical_value(kv.second);
+        }
+      p.describe = std::string("the graph of ") + k.file + " with the file's own parameter values (" + what + ")";
       return true;
     }
   // ---- a cepstral chain: framer -> [pre-emphasis] -> window -> FFT -> magnitude -> mel -> MFCC | PLP, optional log energy,

@@ -30,6 +30,9 @@ bool conf_parse(const std::string &path, const std::map<std::string, std::string
 
 // hash of every processing component (name, type, options; sources / sinks / data memory excluded)
 uint64_t conf_fingerprint(const ConfFile &f);
+// the same hash with the options left out that the kernels of the big sets take as parameters (conf_plan.cpp: conf_is_f0_param):
+// a file that differs from a shipped set only in those is the set with other parameter values
+uint64_t conf_fingerprint_masked(const ConfFile &f);
 
 struct ConfPlan {
   std::string preset;                    // "is09_emotion", "compare16", "is13_compare", "egemapsv02", or "" = cfg below
@@ -43,7 +46,12 @@ struct ConfPlan {
   std::vector<std::string> stage_levels;
   std::map<std::string, std::vector<int>> static_levels;
   std::string wave_file;                 // the wave source's filename option, command-line options applied
+  // big sets recognised through the masked fingerprint: the values of the parameter options the file sets, keyed by the
+  // smilehip_lld_config field they map to (pitch_min, pitch_max, voicing_cutoff, shs_n_harmonics, shs_compression,
+  // vit_buffer_len, jitter_search_range, jitter_broken_thresh, f0_min_energy)
+  std::map<std::string, double> f0_params;
 };
+void conf_apply_f0_params(const ConfPlan &p, smilehip_lld_config &cfg);
 
 // false + err: the graph (component, option) the fused path cannot express
 bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err);

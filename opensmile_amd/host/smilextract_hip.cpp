@@ -128,7 +128,7 @@ int main(int argc, char **argv) {
     std::string cerr_;
     if (!conf_parse(opt["-C"], conf_cmdline, cf, cerr_)) die("-C " + opt["-C"] + ": " + cerr_);
     if (print_fingerprint) {
-      printf("%016llx\n", (unsigned long long)conf_fingerprint(cf));
+      printf("%016llx %016llx\n", (unsigned long long)conf_fingerprint(cf), (unsigned long long)conf_fingerprint_masked(cf));
       return 0;
     }
     static const char *builtin[] = {"l", "loglevel", "nologfile", "noconsoleoutput", "logfile", "appendLogfile", "t", "nticks", "d", "debug",
@@ -170,6 +170,7 @@ int main(int argc, char **argv) {
     if (describe_only) {                                   // what the file maps to, without touching a device
       const smilehip_lld_config &c = conf_plan.cfg;
       printf("preset=%s\n", conf_plan.preset.c_str());
+      for (const auto &kv : conf_plan.f0_params) printf("param.%s=%.9g\n", kv.first.c_str(), kv.second);
       if (conf_plan.preset.empty()) {
         printf("chain_kind=%d\nframe_size_sec=%.17g\nframe_step_sec=%.17g\npreemph=%d\npreemph_k=%.9g\npreemph_de=%d\nwin_func=%d\n"
                "win_sigma=%.17g\nwin_gain=%.17g\nwin_offset=%.17g\nzero_pad_symmetric=%d\nn_bands=%d\nlofreq=%.9g\nhifreq=%.9g\n"
@@ -362,6 +363,7 @@ int main(int argc, char **argv) {
         else if (cmp16) smilehip_config_compare16(&cfg);
         else if (egm) smilehip_config_egemapsv02(&cfg);
         else cfg = vcfg;
+        if (with_conf) conf_apply_f0_params(conf_plan, cfg);     // an edited big-set file: its own pitch range, harmonics, buffer ...
         cfg.sample_rate = (double)kv.first;
         check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
       }

@@ -182,3 +182,69 @@ def test_every_reference_conf_gets_a_plan_or_a_named_refusal():
                             "plp/PLP_0_D_A.conf", "plp/PLP_0_D_A_Z.conf", "plp/PLP_E_D_A.conf", "plp/PLP_E_D_A_Z.conf",
                             "is09-13/IS09_emotion.conf", "is09-13/IS13_ComParE.conf", "compare16/ComParE_2016.conf",
                             "egemaps/v02/eGeMAPSv02.conf", "gemaps/v01b/GeMAPSv01b.conf", "egemaps/v01b/eGeMAPSv01b.conf"}
+
+
+@needs_conf
+def test_edited_big_set_files_are_the_set_with_other_parameters(tmp_path):
+    """ComParE_2016.conf / eGeMAPSv02.conf with other values of the F0 group's options are recognised through the masked
+    fingerprint (the graph is the shipped one, only parameter options differ) and --describe lists the values it will run
+    with; an edit of any other option is still refused."""
+    shutil.copytree(CONF, tmp_path / "config")
+    inc = tmp_path / "config" / "compare16" / "ComParE_2016_core.lld.conf.inc"
+    t = inc.read_text()
+    for a, b in (("maxPitch = 620", "maxPitch = 500"), ("minPitch = 52", "minPitch = 60"), ("nHarmonics = 15", "nHarmonics = 12"),
+                 ("bufferLength=30", "bufferLength=20"), ("searchRangeRel = 0.250000", "searchRangeRel = 0.2"),
+                 ("voicingCutoff = 0.700000", "voicingCutoff = 0.65"), ("threshold=0.001", "threshold=0.002")):
+        assert a in t, a
+        t = t.replace(a, b)
+    inc.write_text(t)
+    rc, kv, err = describe(str(tmp_path / "config" / "compare16" / "ComParE_2016.conf"))
+    assert rc == 0 and kv["preset"] == "compare16", err
+    assert float(kv["param.pitch_max"]) == 500 and float(kv["param.pitch_min"]) == 60 and float(kv["param.shs_n_harmonics"]) == 12
+    assert float(kv["param.vit_buffer_len"]) == 20 and float(kv["param.jitter_search_range"]) == 0.2
+    assert float(kv["param.voicing_cutoff"]) == 0.65 and float(kv["param.f0_min_energy"]) == pytest.approx(0.002)
+    inc.write_text(t.replace("nCandidates = 6", "nCandidates = 5"))            # not a parameter of the kernels: refused
+    rc, kv, err = describe(str(tmp_path / "config" / "compare16" / "ComParE_2016.conf"))
+    assert rc != 0
+
+
+@pytest.mark.gpu
+@needs_conf
+def test_edited_big_set_files_equal_the_binary_on_the_same_file(tmp_path):
+    """The edited files through smilextract_hip -C against the REAL binary on the same edited files: LLD level and
+    functionals bit for bit."""
+    from test_host_io import read_htk
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/SMILExtract not built")
+    import wave
+    from opensmile_amd import synth
+    wav = str(tmp_path / "u.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(synth.utterance(7, 64000).tobytes())
+    shutil.copytree(CONF, tmp_path / "config")
+    edits = {
+        "compare16/ComParE_2016_core.lld.conf.inc": (("maxPitch = 620", "maxPitch = 500"), ("minPitch = 52", "minPitch = 60"),
+                                                    ("nHarmonics = 15", "nHarmonics = 12"), ("bufferLength=30", "bufferLength=20"),
+                                                    ("searchRangeRel = 0.250000", "searchRangeRel = 0.2")),
+        "gemaps/v01b/GeMAPSv01b_core.lld.conf.inc": (("maxPitch = 1000", "maxPitch = 800"), ("nHarmonics = 15", "nHarmonics = 10")),
+    }
+    for rel, subs in edits.items():
+        p = tmp_path / "config" / rel
+        t = p.read_text()
+        for a, b in subs:
+            assert a in t, (rel, a)
+            t = t.replace(a, b)
+        p.write_text(t)
+    for rel in ("compare16/ComParE_2016.conf", "egemaps/v02/eGeMAPSv02.conf"):
+        conf = str(tmp_path / "config" / rel)
+        outs = {}
+        for tag, exe, extra, env in (("hip", EXE, [], None), ("ref", ref_exe, ["-l", "0"], dict(os.environ, SMILEHIP_PLUGIN_COMPONENTS="none"))):
+            lld, fun = str(tmp_path / f"{tag}.lld.htk"), str(tmp_path / f"{tag}.func.htk")
+            subprocess.run([exe, "-C", conf, "-I", wav, "-lldhtkoutput", lld, "-htkoutput", fun] + extra, check=True, env=env, cwd=str(tmp_path))
+            outs[tag] = (read_htk(lld), read_htk(fun))
+        for k in (0, 1):
+            (ha, xa), (hb, xb) = outs["hip"][k], outs["ref"][k]
+            assert ha == hb and xa.shape == xb.shape, rel
+            assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)), (rel, k, np.abs(xa - xb).max())
