@@ -46,7 +46,7 @@ def main():
                 fetch = float(ln.split()[2])
             if "WRITE_SIZE" in ln:
                 write = float(ln.split()[2])
-    frames = bench["config"]["frames_per_gpu"]
+    frames = bench["config"].get("frames_per_gpu", bench["config"].get("frames_rank0"))
     t = {"kernel": "lld_mfcc512<13,7,true,true,true,false>",
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_run.sh)",
          "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
