@@ -492,6 +492,13 @@ int  smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *batch, const int16_t
  * rules). d_out: total_rows x ld_out, ld_out >= n_out. Asynchronous on `stream`. */
 int  smilehip_lld_run(smilehip_plan *plan, smilehip_batch *batch, const int16_t *d_pcm,
                       float *d_out, int64_t ld_out, void *stream);
+/* The same chains on samples that are floats already: d_pcm_f32 = the batch's packed utterances after R0, i.e. the output of
+ * smilehip_pcm_convert for ANY sample format / channel count (8 / 16 / 24 / 32-bit, mono mix-down of N channels: what
+ * cWaveSource hands to the graph, waveSource.cpp:240-294 + smileUtil.c:2500-2627) or of smilehip_pcm16_to_float. Every
+ * reference-order chain reads them in place of the int16 PCM -- same bits downstream; the MFCC / PLP chains run on the
+ * reference-order kernel (the fast kernel's loader is int16-specific). */
+int  smilehip_lld_run_f32(smilehip_plan *plan, smilehip_batch *batch, const float *d_pcm_f32,
+                          float *d_out, int64_t ld_out, void *stream);
 /* host-buffer convenience of the same (H2D, run, D2H, synchronises) */
 int  smilehip_lld_run_host(smilehip_plan *plan, smilehip_batch *batch, const int16_t *h_pcm,
                            int64_t n_samples, float *h_out);

@@ -133,6 +133,7 @@ SYMBOLS = {
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "smilehip_batch_funcspec": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_lld_run": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "smilehip_lld_run_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     "smilehip_free": (C.c_int, [_vp, _vp]),
@@ -495,6 +496,10 @@ class Batch:
     def run_device(self, d_pcm_ptr, d_out_ptr, ld_out, stream=None):
         """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int)."""
         _check(load().smilehip_lld_run(self.plan._h, self._h, d_pcm_ptr, d_out_ptr, ld_out, stream))
+
+    def run_device_f32(self, d_pcm_f32_ptr, d_out_ptr, ld_out, stream=None):
+        """The same on float samples (the output of smilehip_pcm_convert / smilehip_pcm16_to_float)."""
+        _check(load().smilehip_lld_run_f32(self.plan._h, self._h, d_pcm_f32_ptr, d_out_ptr, ld_out, stream))
 
     def run_host(self, pcm):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)

@@ -22,6 +22,15 @@ __device__ __forceinline__ float pcm16_to_float(int16_t s) {
   return fmaf(e, r, q0);
 }
 
+// The chains' input: 16-bit mono PCM (the fused path's native format; R0 happens at the load) or float samples that
+// smilehip_pcm_convert produced from any other sample format / channel count (R0 done: smilehip_lld_run_f32)
+struct PcmIn {
+  const int16_t *s;
+  const float *f;
+  __device__ __forceinline__ float operator[](int64_t n) const { return f ? f[n] : pcm16_to_float(s[n]); }
+  __device__ __forceinline__ PcmIn operator+(int64_t o) const { PcmIn r; r.s = s + o; r.f = f ? f + o : nullptr; return r; }
+};
+
 // R6: one mel band in the reference's accumulation order
 // (cMelspec::processVector, melspec.cpp:544-553): ascending bins, first the
 // rising-slope run (p - p*w), then the falling-slope run (p*w). The reference

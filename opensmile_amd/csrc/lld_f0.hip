@@ -121,7 +121,7 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
 template <bool OO>                                     // OO: the reference-order transform (one form per kernel instance: register budget)
-__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const int16_t *x, const float *mag_in, int lane,
+__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const PcmIn x, const float *mag_in, int lane,
                                               double *A, double *B) {
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
   double esum = 0.0;
@@ -134,8 +134,8 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   const auto load_pair = [&](int i) {
     const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
     float a = 0.0f, b = 0.0f;
-    if (n0 >= 0 && n0 < Q.N) { a = pcm16_to_float(x[n0]) * T.win[n0]; const float sq = a * a; esum += (double)sq; }
-    if (n1 >= 0 && n1 < Q.N) { b = pcm16_to_float(x[n1]) * T.win[n1]; const float sq = b * b; esum += (double)sq; }
+    if (n0 >= 0 && n0 < Q.N) { a = x[n0] * T.win[n0]; const float sq = a * a; esum += (double)sq; }
+    if (n1 >= 0 && n1 < Q.N) { b = x[n1] * T.win[n1]; const float sq = b * b; esum += (double)sq; }
     return make_float2(a, b);
   };
   if constexpr (OO) {                                    // the reference's rdft network (lld_ooura_wave.hpp); lane l holds l + 64 m
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         if (mode == 2) break;
-        const double es = f0_spectrum<OO>(T, Q, P.pcm + samp0 + (int64_t)(tf + w) * Q.H,
+        const double es = f0_spectrum<OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)(tf + w) * Q.H),
                                       mode == 1 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr, lane, A, A + kKP);
         if (lane == 0) *reinterpret_cast<double *>(reinterpret_cast<int *>(A + 2 * kKP) + 8 + 24) = es;
       }
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_p
   const int64_t samp0 = P.tile_rec[tile].samp0;
   const int n_fr = P.tile_rec[tile].n_frames;
   for (int w = 0; w < n_fr; ++w) {
-    const double es = f0_spectrum<OO>(T, Q, P.pcm + samp0 + (int64_t)w * Q.H, nullptr, lane, A, A + kKP);
+    const double es = f0_spectrum<OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     double *row = Q.ab + fr * kKP;
     double *bb = Q.ab + Q.ab_rows * kKP;
@@ -957,7 +957,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   __shared__ float jit_terms[kJitThreads];   // one term per lane and wave for the sequential energy sums
   const int64_t s0 = P.samp_off[u];
   const int64_t n_samp = P.samp_off[u + 1] - s0;
-  const int16_t *x = P.pcm + s0;
+  const PcmIn x = pcm_in(P) + s0;
   const double Tw = Q.jit_Tw;
   const int N = Q.N, H = Q.H;
   const long ppLen = uni((long)ceil(Q.jit_step_sec / Tw));
@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     long start = 0, lastPeriod = 0;
     if (F0 > 0.0f) {
       __syncthreads();
-      for (long i = tid; i < nT; i += kJitThreads) wv[i] = pcm16_to_float(x[lastIdx + i]);
+      for (long i = tid; i < nT; i += kJitThreads) wv[i] = x[lastIdx + i];
       for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
       __syncthreads();
       PHASE(5);   // frame set-up + wave load

@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   const int64_t f0 = P.frame_off[u];
   const int T20 = (int)(P.frame_off[u + 1] - f0);
   const int16_t *xu = P.pcm + P.samp_off[u];
+  const float *xuf = P.pcm_f32 ? P.pcm_f32 + P.samp_off[u] : nullptr;    // float input (smilehip_lld_run_f32): read at the frame, no prefetch
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
   // the raw samples of frame t + 1 are asked for while frame t is processed (see lld_compare_frame_wave)
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int n = ln + 64 * q; pre[q] = (n < P.N) ? xx[n] : (int16_t)0; }
   };
-  prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
+  if (!xuf) prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     int lane = lane_in;                                  // opaque per frame (see lld_compare_frame_wave): nothing that depends on
     asm volatile("" : "+v"(lane));                       // the lane only is kept in registers across the frame loop
@@ -226,8 +227,8 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
     const int16_t *x = xu + (int64_t)t * P.H;
     float *raw = G.raw20 + (f0 + t) * 12;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = pcm16_to_float(pre[q]); }
-    if (t + 1 < t_last) prefetch(x + P.H, lane);
+    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = xuf ? xuf[(int64_t)t * P.H + n] : pcm16_to_float(pre[q]); }
+    if (!xuf && t + 1 < t_last) prefetch(x + P.H, lane);
     WaveG::sync();
     // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
     double e2 = 0.0;
@@ -772,11 +773,11 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
         const float *mi = G.op_in + g * G.op_ld_in;
         for (int k = lane; k <= kHM; k += 64) mg[k] = mi[k];
       } else {
-        const int16_t *x = P.pcm + samp0 + (int64_t)tf * Q.H;
+        const PcmIn x = pcm_in(P) + (samp0 + (int64_t)tf * Q.H);
         const auto load_pair = [&](int i) {
           const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
-          return make_float2((n0 >= 0 && n0 < Q.N) ? pcm16_to_float(x[n0]) * c_win[n0] : 0.0f,
-                             (n1 >= 0 && n1 < Q.N) ? pcm16_to_float(x[n1]) * c_win[n1] : 0.0f);
+          return make_float2((n0 >= 0 && n0 < Q.N) ? x[n0] * c_win[n0] : 0.0f,
+                             (n1 >= 0 && n1 < Q.N) ? x[n1] * c_win[n1] : 0.0f);
         };
         if (OO.tw) oo_wave_forward<kHM>(z, OO, lane, load_pair);
         else Fft::forward(z, c_twh, lane, load_pair);

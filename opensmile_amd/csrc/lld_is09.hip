@@ -61,12 +61,12 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     if (P.frame_off[mid] <= row) lo = mid; else hi = mid;
   }
   const int64_t t = row - P.frame_off[lo];
-  const int16_t *x = P.pcm + P.samp_off[lo] + t * (int64_t)P.H;
+  const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
   float *out = Q.raw16 + row * 16;
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
-  for (int n = G::tid(); n < P.N; n += G::size()) xr[n] = pcm16_to_float(x[n]);      // R0
+  for (int n = G::tid(); n < P.N; n += G::size()) xr[n] = x[n];                      // R0 (or already done: float input)
   G::sync();
 
   // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
   }
   const int u = lo;
   const int64_t t = row - P.frame_off[u];
-  const int16_t *x = P.pcm + P.samp_off[u] + t * (int64_t)P.H;
+  const PcmIn x = pcm_in(P) + (P.samp_off[u] + t * (int64_t)P.H);
 
   int logM = 0;
   while ((1 << logM) < M) ++logM;
@@ -55,11 +55,11 @@ __global__ void __launch_bounds__(256) lld_mfcc_generic(LldParams P) {
       const int n = 2 * i + h - P.pad_left;     // sample index within the frame
       float y = 0.0f;
       if (n >= 0 && n < P.N) {
-        const float s = pcm16_to_float(x[n]);                       // R0
+        const float s = x[n];                                       // R0 (or already done: float input)
         if (P.preemph) {                                            // R2
           if (n == 0) y = P.one_minus_k * s;
           else {
-            const float sp = pcm16_to_float(x[n - 1]);
+            const float sp = x[n - 1];
             y = P.de ? (s + P.k * sp) : (s - P.k * sp);
           }
         } else y = s;
@@ -324,7 +324,9 @@ __global__ void __launch_bounds__(64) lld_log_energy(LldParams P, const int32_t 
         const int k = k0 + 64 * m;
         if (k < nvec) {
           const int64_t s8 = a16 + 8 * (int64_t)k;
-          if (s8 + 8 <= P.pcm_total) {
+          if (P.pcm_f32) {
+            // float input: the samples are read where they are used, below
+          } else if (s8 + 8 <= P.pcm_total) {
             const uint4 v = *reinterpret_cast<const uint4 *>(P.pcm + s8);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(64) lld_log_energy(LldParams P, const int32_t 
             const int i = 8 * k + q - par;
             if (i >= 0 && i < span) {
               const int h = (int)(((float)i + 0.5f) * rH);
-              const float v = pcm16_to_float(r[m][q]);
+              const float v = P.pcm_f32 ? P.pcm_f32[a16 + 8 * (int64_t)k + q] : pcm16_to_float(r[m][q]);
               s_sq[h * pitch + (i - h * P.H)] = v * v;
             }
           }

@@ -1,6 +1,7 @@
 // Kernel parameter block shared by the host API (smilehip_*.cpp) and the device
 // code (lld_kernels.hip). Plain data, passed by value at launch.
 #pragma once
+#include "lld_device.hpp"
 #include "lld_ooura.hpp"
 #include "lld_ooura_wave.hpp"
 #include <hip/hip_runtime.h>
@@ -23,6 +24,7 @@ struct TileRec {
 struct LldParams {
   // batch
   const int16_t *pcm;          // packed utterances
+  const float *pcm_f32;        // the same samples as floats (R0 done by smilehip_pcm_convert), or nullptr: then pcm is read
   int64_t pcm_total;           // samples in the packed buffer (= samp_off[n_utt])
   const int64_t *samp_off;     // [n_utt+1] sample offsets (device)
   const int64_t *frame_off;    // [n_utt+1] output row offsets (device)
@@ -62,6 +64,9 @@ struct LldParams {
   const float *plp_cos;        // [(lp_order+1) x (n_bands+2)] IDFT cosine table
   const float *plp_sin;        // [lp_order+1] lifter table
 };
+
+// the batch's samples as the kernels read them (lld_device.hpp: PcmIn)
+__device__ __forceinline__ PcmIn pcm_in(const LldParams &P) { PcmIn r; r.s = P.pcm; r.f = P.pcm_f32; return r; }
 
 // Device-side tables of the fast Nfft=512 kernel (lld_mfcc512.hip)
 struct Fast512Tables {

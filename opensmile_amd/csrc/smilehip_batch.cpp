@@ -212,6 +212,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
                         int64_t ld, LldParams &P) {
   std::memset(&P, 0, sizeof(P));
   P.pcm = d_pcm;
+  P.pcm_f32 = b->run_pcm_f32;
   P.pcm_total = b->h_samp_off.back();
   P.samp_off = b->d_samp_off.p;
   P.frame_off = b->d_frame_off.p;
@@ -325,7 +326,7 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     HIP_TRY(hipEventRecord(ev[0], s));
   }
   hipError_t e;
-  if (plan->use_fast) {
+  if (plan->use_fast && !b->run_pcm_f32) {               // (float input: the reference-order kernel; the fast one converts int16 itself)
     Fast512Tables F;
     F.tw256 = plan->d_tw256.p;
     F.tw512 = plan->d_tw512.p;
@@ -765,6 +766,19 @@ extern "C" int smilehip_lld_run(smilehip_plan *plan, smilehip_batch *b, const in
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE) return compare_full_run(plan, b, d_pcm, d_out, ld_out, stream);
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) return egemaps_run(plan, b, d_pcm, d_out, ld_out, stream);
   return is09_run(plan, b, d_pcm, d_out, ld_out, stream);
+}
+
+extern "C" int smilehip_lld_run_f32(smilehip_plan *plan, smilehip_batch *b, const float *d_pcm_f32, float *d_out, int64_t ld_out,
+                                    void *stream) {
+  if (!plan || !b || b->plan != plan) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_f32: plan/batch mismatch");
+  if (!d_pcm_f32 && b->total_frames > 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run_f32: null device pointer");
+  b->run_pcm_f32 = d_pcm_f32;
+  if (b->f0_batch) b->f0_batch->run_pcm_f32 = d_pcm_f32;
+  // the int16 pointer is never dereferenced while run_pcm_f32 is set (PcmIn, lld_device.hpp); it only has to be non-null
+  const int rc = smilehip_lld_run(plan, b, reinterpret_cast<const int16_t *>(d_pcm_f32), d_out, ld_out, stream);
+  b->run_pcm_f32 = nullptr;
+  if (b->f0_batch) b->f0_batch->run_pcm_f32 = nullptr;
+  return rc;
 }
 
 extern "C" int smilehip_lld_run_host(smilehip_plan *plan, smilehip_batch *b, const int16_t *h_pcm, int64_t n_samples,

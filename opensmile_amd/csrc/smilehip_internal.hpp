@@ -185,6 +185,7 @@ struct smilehip_batch {
   DevBuf<int64_t> d_fin_off;              // [n_utt+1] rows of func_in: T20 + 1 per utterance with a 60 ms frame
   std::vector<int64_t> h_fin_off;
   bool gm_ran = false;
+  const float *run_pcm_f32 = nullptr;     // set for the duration of smilehip_lld_run_f32: the kernels read these floats instead of the int16 PCM
   ~smilehip_batch();
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;

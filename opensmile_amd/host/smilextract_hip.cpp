@@ -337,9 +337,10 @@ int main(int argc, char **argv) {
       std::string e;
       WaveInfo &wi = c.info[k];
       if (!read_wave_file(jobs[c.j0 + k].wav, wi, c.raw[k], e)) { std::lock_guard<std::mutex> g(m); if (c.err.empty()) c.err = e; return; }
-      if (wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
+      if (wi.sample_type != 1 || wi.n_chan < 1 || wi.n_bps < 1 || wi.n_bps > 4) {       // integer PCM of any width / channel count
         std::lock_guard<std::mutex> g(m);
-        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': the fused path takes 16-bit mono PCM (other formats: smilehip_pcm_convert + the plugin path)";
+        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': integer PCM (8 / 16 / 24 / 32 bit, any number of channels) is what the fused path reads; "
+                                   "this file's sample type is not (IEEE-float WAV: not built)";
       }
     });
     return c;
@@ -371,11 +372,22 @@ int main(int argc, char **argv) {
       check(smilehip_plan_geometry(plan, &g), "smilehip_plan_geometry");
       const std::vector<size_t> &idx = kv.second;
       // exact packing: utterance u = samples [off[u], off[u+1]) of one buffer (the kernels use
-      // dword PCM loads when every offset is even, 16-bit loads otherwise)
-      std::vector<int64_t> true_off(idx.size() + 1, 0);
-      for (size_t i = 0; i < idx.size(); ++i) true_off[i + 1] = true_off[i] + (int64_t)(raw[idx[i] - j0].size() / 2);
-      std::vector<int16_t> pcm((size_t)true_off.back() + 2, 0);
+      // dword PCM loads when every offset is even, 16-bit loads otherwise). 16-bit mono files go to the device as they are
+      // (the kernels convert at the load); any other integer format / channel count is converted on the device by
+      // smilehip_pcm_convert -- cWaveSource's monoMixdown = 1 of every shipped file (standard_wave_input.conf.inc) -- and the chain
+      // reads floats (smilehip_lld_run_f32)
+      bool all_s16_mono = true;
       for (size_t i = 0; i < idx.size(); ++i) {
+        const WaveInfo &wi = chunk.info[idx[i] - j0];
+        all_s16_mono = all_s16_mono && wi.n_bps == 2 && wi.n_chan == 1;
+      }
+      std::vector<int64_t> true_off(idx.size() + 1, 0);
+      for (size_t i = 0; i < idx.size(); ++i) {
+        const WaveInfo &wi = chunk.info[idx[i] - j0];
+        true_off[i + 1] = true_off[i] + (int64_t)(raw[idx[i] - j0].size() / (size_t)(wi.n_bps * wi.n_chan));
+      }
+      std::vector<int16_t> pcm(all_s16_mono ? (size_t)true_off.back() + 2 : 2, 0);
+      for (size_t i = 0; i < idx.size() && all_s16_mono; ++i) {
         const auto &r = raw[idx[i] - j0];
         if (!r.empty()) std::memcpy(&pcm[(size_t)true_off[i]], r.data(), r.size() & ~(size_t)1);
       }
@@ -389,8 +401,28 @@ int main(int argc, char **argv) {
       const uint64_t pcm_bytes = (uint64_t)std::max<int64_t>(true_off.back(), 2) * 2;
       check(smilehip_alloc(ctx, pcm_bytes, &d_pcm), "smilehip_alloc");
       check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4, &d_lld), "smilehip_alloc");
-      check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
-      check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
+      void *d_f32 = nullptr;
+      if (all_s16_mono) {
+        check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
+        check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
+      } else {
+        check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(true_off.back(), 1) * 4, &d_f32), "smilehip_alloc");
+        size_t biggest = 1;
+        for (size_t i = 0; i < idx.size(); ++i) biggest = std::max(biggest, raw[idx[i] - j0].size());
+        void *d_raw = nullptr;
+        check(smilehip_alloc(ctx, biggest, &d_raw), "smilehip_alloc");
+        for (size_t i = 0; i < idx.size(); ++i) {
+          const WaveInfo &wi = chunk.info[idx[i] - j0];
+          const auto &r = raw[idx[i] - j0];
+          const int64_t n = true_off[i + 1] - true_off[i];
+          if (n <= 0) continue;
+          check(smilehip_copy_to_device(ctx, d_raw, r.data(), (uint64_t)n * wi.n_bps * wi.n_chan, nullptr), "copy_to_device");
+          check(smilehip_pcm_convert(ctx, d_raw, wi.n_bps, wi.n_bits, wi.n_chan, 1, n, (float *)d_f32 + true_off[i], nullptr), "smilehip_pcm_convert");
+          check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");      // d_raw is reused by the next file
+        }
+        smilehip_free(ctx, d_raw);
+        check(smilehip_lld_run_f32(plan, b, (const float *)d_f32, (float *)d_lld, n_out, nullptr), "smilehip_lld_run_f32");
+      }
       std::vector<float> lld((size_t)std::max<int64_t>(rows, 1) * n_out), func;
       const int n_func = is09 ? n_out * smilehip_functionals_count(fmask)
                               : (cmp16f ? smilehip_functionals_compare16_count() : (egm ? smilehip_functionals_egemaps_count() : 0));
@@ -449,6 +481,7 @@ int main(int argc, char **argv) {
       });
       if (!sink_err.empty()) die(sink_err);
       smilehip_free(ctx, d_pcm);
+      if (d_f32) smilehip_free(ctx, d_f32);
       smilehip_free(ctx, d_lld);
       if (d_func) smilehip_free(ctx, d_func);
       smilehip_batch_destroy(b);
