@@ -40,8 +40,22 @@ constexpr int kTileFrames = 8;   // consecutive frames of one utterance per work
 constexpr int kNC = 6;           // candidates (nCandidates of [is13_shs])
 constexpr int kVBmax = 40;       // largest bufferLength ([is13_pitchSmoothViterbi] 30, [gemapsv01b_pitchSmoothViterbi] 40)
 constexpr int kNS = kNC + 1;     // Viterbi states: candidates + "unvoiced"
-// the frame kernel is written for the 60 ms / 16 kHz geometry of ComParE / GeMAPS: FFT 1024
-constexpr int kNfftF0 = 1024, kM = 512, kK = 513, kKP = 516, kPer = 9;   // complex points, bins, padded bins, bins per lane
+// Geometry of the 60 ms frame's transform, by sample rate: FFT 512 (8 kHz), 1024 (11.025 / 16 kHz: the geometry the kernels were
+// tuned on -- BASELINE's configs), 2048 (22.05 / 24 / 32 kHz), 4096 (44.1 / 48 kHz). Everything below is written against
+// these constants: complex points, bins, padded bins, bins per lane (lane l owns bins l + 64 m).
+template <int LOGM>
+struct F0G {
+  static constexpr int kLogM = LOGM, kM = 1 << LOGM, kNfft = 2 * kM, kK = kM + 1, kKP = kM + 4, kPer = (kK + 63) / 64;
+  static constexpr int kNBB = (kKP + 7) / 8;               // 8-bin blocks of a row (65 for K = 513)
+  static constexpr bool kRegFft = LOGM <= 9;                // register-resident transform (lld_ooura_wave.hpp: M = 256 / 512)
+  static constexpr bool kLdsTables = LOGM <= 9;             // per-bin tables staged in LDS (above: read through the caches)
+  static constexpr int kSpecWaves = LOGM <= 9 ? 4 : (LOGM == 10 ? 2 : 1);   // frames (waves) per workgroup of spec / cand
+  // LDS bytes of the transform's tables: radix-2 order twh | twf = 4128 B (M = 512), reference order <= 12 M (6016 B for M = 512)
+  static constexpr size_t kTwBytes = (size_t)12 * kM;
+  // one frame's LDS region: A[kKP] B[kKP] doubles | ci[8] ints (ci[7]: number of candidates) | cf[3][8] floats | double
+  static constexpr size_t kFrameBytes = (size_t)kKP * 16 + 8 * 4 + 24 * 4 + 16;   // + the frame's sum of squares
+};
+#define F0_GEO constexpr int kM = G::kM, kK = G::kK, kKP = G::kKP, kPer = G::kPer; (void)kM; (void)kK; (void)kKP; (void)kPer
 
 // LDS tables shared by the workgroup for its whole life (every table the per-frame code reads)
 struct F0Tbl {
@@ -53,14 +67,11 @@ struct F0Tbl {
   const float2 *twf;     // [kM/2+4]
   OouraTab oo;           // reference-order transform: its tables take the place of twh | twf (kF0TwBytes)
 };
-// LDS bytes of the transform's tables: radix-2 order twh | twf = 4128 B, reference order (lld_ooura.hpp, M = 512) 6016 B
-constexpr size_t kF0TwBytes = 6144;
+template <class G>
 __host__ __device__ inline size_t f0_shared_bytes(int N) {
   const size_t np = (size_t)((N + 3) & ~3);
-  return (size_t)kKP * 16 + (size_t)kKP * 8 * 7 + (size_t)kKP * 4 + np * 4 + kF0TwBytes;
+  return (size_t)G::kKP * 16 + (size_t)G::kKP * 8 * 7 + (size_t)G::kKP * 4 + np * 4 + G::kTwBytes;
 }
-// one frame's LDS region: A[kKP] B[kKP] doubles | ci[8] ints (ci[7]: number of candidates) | cf[3][8] floats | double
-constexpr size_t kFrameBytes = (size_t)kKP * 16 + 8 * 4 + 24 * 4 + 16;   // + the frame's sum of squares
 
 // smileMath_quadFrom3pts (smileUtil.c:1009-1033)
 __device__ __forceinline__ double quad_vertex(double x1, double y1, double x2, double y2, double x3, double y3, double &y) {
@@ -120,9 +131,10 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
-template <bool OO>                                     // OO: the reference-order transform (one form per kernel instance: register budget)
+template <class G, bool OO>                            // OO: the reference-order transform (one form per kernel instance: register budget)
 __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const PcmIn x, const float *mag_in, int lane,
                                               double *A, double *B) {
+  F0_GEO;
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
   double esum = 0.0;
   double mg[kPer];
@@ -138,10 +150,14 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     if (n1 >= 0 && n1 < Q.N) { b = x[n1] * T.win[n1]; const float sq = b * b; esum += (double)sq; }
     return make_float2(a, b);
   };
-  if constexpr (OO) {                                    // the reference's rdft network (lld_ooura_wave.hpp); lane l holds l + 64 m
+  if constexpr (OO && !G::kRegFft) {                     // the reference's rdft network in place in LDS (lld_ooura.hpp): any length
+    ooura_forward<WaveG>(z, T.oo, load_pair);
+    esum = WaveG::sum(esum, nullptr);
+  } else if constexpr (OO) {                             // the same network register-resident (lld_ooura_wave.hpp); lane l holds l + 64 m
     oo_wave_forward<kM>(z, T.oo, lane, load_pair);
     esum = WaveG::sum(esum, nullptr);
   } else {
+    static_assert(OO || G::kLogM == 9, "the radix-2 order transform exists for FFT 1024 only");
     WaveFft<9>::forward(z, T.twh, lane, load_pair);
     // (lane l summed the inputs brev6(l) + 64 k: low offsets first is the tree the sum had when lane l held l + 64 m)
     esum += wave_down_d<1>(esum); esum += wave_down_d<2>(esum); esum += wave_down_d<4>(esum);     // (lane 0's tree of the xor
@@ -152,7 +168,9 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     mg[m] = 0.0;
     if (k < kK) {
       float2 X;
-      if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k); else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
+      if constexpr (OO && !G::kRegFft) X = ooura_bin(z, T.oo, k);
+      else if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k);
+      else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
       mg[m] = (double)bin_magnitude(X, k == 0 || k == kM);
     }
   }
@@ -226,7 +244,9 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
 // round's dependent chain runs on set A the next round's operands are already being loaded into set B (no copies).
 // A round is 12 LDS instructions: the outstanding-load counter (lgkmcnt, 4 bits) can then still tell the two sets apart;
 // the scheduling barriers keep the compiler from sinking the prefetch below the chain it is meant to overlap.
+template <class G>
 __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
+  F0_GEO;
   constexpr int R = 8;
   constexpr int nfw = (kK - 2) / R;                      // full rounds of the forward sweep (bins 1 .. kK-2)
   double up = 0.0;
@@ -297,8 +317,10 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // the smallest non-zero value's last bit 2^(e_min - 23) satisfies exponent(S) - e_min <= 28, every such partial sum is a
 // multiple of that bit below 2^53 of it -- representable: no addition rounds, all orders give the exact S, and the
 // sequential chain (one lane, 512 dependent additions: a fifth of the kernel's instructions) is not needed.
+template <class G>
 __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane_in, int64_t g, double *A, double *B, int *ci,
                                       const float *hps_in, bool only_scale, double *mean_exact = nullptr) {
+  F0_GEO;
   // Everything below that depends only on the lane (135 clamped addresses and in-range masks of the harmonic shifts, table
   // addresses ...) is loop-invariant over the frames of a wave, and the compiler keeps all of it in registers across the
   // frame loop: 256 VGPRs + AGPR spills, one wave per SIMD. An opaque copy of the lane index makes it recompute them per
@@ -313,7 +335,10 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
       if (i < kK) hv[m] = hps_in[i];
     } else if (i < kK) {
       const int k = T.k[i];
-      const double a = T.a[i], b = 1.0 - a, c = T.c[i], d = T.d[i];
+      double a, c, d;
+      if constexpr (G::kLdsTables) { a = T.a[i]; c = T.c[i]; d = T.d[i]; }
+      else { a = Q.ip_co[3 * i]; c = Q.ip_co[3 * i + 1]; d = Q.ip_co[3 * i + 2]; }       // (through the caches: K x 36 B of tables do not fit LDS)
+      const double b = 1.0 - a;
       const double o = a * A[k] + b * A[k + 1] + c * B[k] + d * B[k + 1];
       float v = (float)o;
       v = (v > 0.0f) ? (float)((double)v * T.audw[i]) : 0.0f;
@@ -361,14 +386,14 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     lf[m] = (j >= 1 && j < kK) ? SS[j - 1] : 0.0f;
     rt[m] = (j < kK - 1) ? SS[j + 1] : 0.0f;
   }
-  unsigned open = 0;
-  F0_FOR_BINS(m, j) if (j >= 1 && j < kK - 1 && lf[m] < hv[m] && hv[m] > rt[m]) open |= 1u << m;
+  unsigned long long open = 0;                           // bit m: this lane's bin lane + 64 m is a local maximum not yet taken (kPer <= 33)
+  F0_FOR_BINS(m, j) if (j >= 1 && j < kK - 1 && lf[m] < hv[m] && hv[m] > rt[m]) open |= 1ull << m;
   int n_found = 0;
 #pragma unroll
   for (int r = 0; r < kNC; ++r) {
     float bv = -1.0f;
     int bi = 1 << 30;
-    F0_FOR_BINS(m, j) if (((open >> m) & 1u) && hv[m] > bv) { bv = hv[m]; bi = j; }      // ascending j: first maximum
+    F0_FOR_BINS(m, j) if (((open >> m) & 1ull) && hv[m] > bv) { bv = hv[m]; bi = j; }     // ascending j: first maximum
     {   // (score, bin) as ONE double whose order is (score descending, bin ascending): positive float bits in the high word
         // order like the floats, 2^31 - 1 - bin in the low word breaks ties towards the lower bin; "none" is negative.
         // The wave maximum is then six v_max_f64 (commutative: same winner as the pairwise selection).
@@ -380,7 +405,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     }
     if (bi != (1 << 30)) {
       if (lane == 0) ci[r] = bi;
-      if ((bi & 63) == lane) open &= ~(1u << (bi >> 6));
+      if ((bi & 63) == lane) open &= ~(1ull << (bi >> 6));
       n_found = r + 1;
     }
   }
@@ -388,7 +413,9 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
 }
 
 // the reference's sequential double sum of the summation spectrum (pitchShs.cpp:259-301) for this lane's frame
+template <class G>
 __device__ __forceinline__ double f0_mean_serial(const double *B) {
+  F0_GEO;
   constexpr int R = 16;
   constexpr int nr = (kK - 2) / R;
   double mean = B[0];
@@ -411,8 +438,10 @@ __device__ __forceinline__ double f0_mean_serial(const double *B) {
 
 // candidate refinement (pitchShs.cpp:304-325), cPitchBase::processVector's range filter, best-first reordering and
 // output vector (pitchBase.cpp:212-300), the frame energy
+template <class G>
 __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64_t g, const double *A, const int *ci, float *cf,
                                               int n_found, double mean, double esum) {
+  F0_GEO;
   const float *SS = reinterpret_cast<const float *>(A) + kKP;
   if (lane < 8) {
     float f0c = 0.0f, cv = 0.0f, cs = 0.0f;
@@ -464,8 +493,11 @@ __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64
   WaveG::sync();
 }
 
-template <bool OO>
+template <int LOGM, bool OO>
 __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Params Q) {
+  using G = F0G<LOGM>;
+  F0_GEO;
+  constexpr size_t kFrameBytes = G::kFrameBytes;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -497,7 +529,7 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
   T.oo = c_oo;
   T.sp = c_sp; T.dec = c_dec; T.d1 = c_d1; T.d2 = c_d2; T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw;
   T.k = c_k; T.win = c_win; T.twh = c_twh; T.twf = c_twf;
-  unsigned char *base = smem_f0 + f0_shared_bytes(Q.N) + (size_t)wave * (kW * kFrameBytes);
+  unsigned char *base = smem_f0 + f0_shared_bytes<G>(Q.N) + (size_t)wave * (kW * kFrameBytes);
   PHASE_DECL
   // persistent waves: work item = up to kTileFrames consecutive frames of one utterance (TileRec), kW at a time
   const int tile_stride = __builtin_amdgcn_readfirstlane((int)gridDim.x) * kWaves;
@@ -513,19 +545,19 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         if (mode == 2) break;
-        const double es = f0_spectrum<OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)(tf + w) * Q.H),
+        const double es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)(tf + w) * Q.H),
                                       mode == 1 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr, lane, A, A + kKP);
         if (lane == 0) *reinterpret_cast<double *>(reinterpret_cast<int *>(A + 2 * kKP) + 8 + 24) = es;
       }
       PHASE(0);   // load .. 6*ut
-      if (lane < n_act && mode != 2) f0_spline_serial(T, reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
+      if (lane < n_act && mode != 2) f0_spline_serial<G>(T, reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
       WaveG::sync();
       PHASE(1);   // recurrences
 #pragma unroll 1
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         int *ci = reinterpret_cast<int *>(A + 2 * kKP);
-        const int nf = f0_shs(T, Q, lane, row0 + tf + w, A, A + kKP, ci, mode == 2 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr,
+        const int nf = f0_shs<G>(T, Q, lane, row0 + tf + w, A, A + kKP, ci, mode == 2 ? Q.in_rows + (row0 + tf + w) * Q.ld_in : nullptr,
                               mode == 1);
         if (lane == 0) ci[7] = nf;
       }
@@ -533,14 +565,14 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
       PHASE(2);   // interpolation, summation, top six
       if (mode == 1) continue;
       double mean = 0.0;
-      if (lane < n_act) mean = f0_mean_serial(reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
+      if (lane < n_act) mean = f0_mean_serial<G>(reinterpret_cast<double *>(base + lane * kFrameBytes) + kKP);
       PHASE(3);   // mean
 #pragma unroll 1
       for (int w = 0; w < n_act; ++w) {
         double *A = reinterpret_cast<double *>(base + w * kFrameBytes);
         int *ci = reinterpret_cast<int *>(A + 2 * kKP);
         const double es = *reinterpret_cast<double *>(ci + 8 + 24);
-        f0_candidates(Q, lane, row0 + tf + w, A, ci, reinterpret_cast<float *>(ci + 8), ci[7], __shfl(mean, w), es);
+        f0_candidates<G>(Q, lane, row0 + tf + w, A, ci, reinterpret_cast<float *>(ci + 8), ci[7], __shfl(mean, w), es);
       }
       PHASE(4);   // candidates + output
     }
@@ -553,31 +585,38 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
 // frame: 64 recurrences per wave, table operands by scalar loads), lld_f0_cand (wave per frame: evaluation, summation,
 // top six, mean, candidates). Same device functions, same operation order: results are bit-identical to the one-kernel
 // form, which stays for the per-component operators (mode 1 / 2).
-constexpr int kSpecWaves = 4;
-constexpr int kNBB = (kKP + 7) / 8;                    // 8-bin blocks of a row: 65
 // 6ut / y2 of frame fr (chunk-local), bin i: the 64 frames of a tile keep each 8-bin block side by side, so that the sweep
 // (one frame per lane) streams 4 KB per block and wave while the wave-per-frame kernels still write / read whole 64-byte
 // lines (8 consecutive bins of one frame)
+template <class G>
 __device__ __forceinline__ int64_t f0_bb_index(int64_t fr, int i) {
-  return (((fr >> 6) * kNBB + (i >> 3)) * 64 + (fr & 63)) * 8 + (i & 7);
+  return (((fr >> 6) * G::kNBB + (i >> 3)) * 64 + (fr & 63)) * 8 + (i & 7);
 }
-__host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // d1 | d2 | win | twh | twf
+template <class G>
+__host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // [d1 | d2 |] win | twh | twf
   const size_t np = (size_t)((N + 3) & ~3);
-  return (size_t)kKP * 8 * 2 + np * 4 + kF0TwBytes;
+  return (G::kLdsTables ? (size_t)G::kKP * 8 * 2 : 0) + np * 4 + G::kTwBytes;
 }
-__host__ __device__ inline size_t f0_cand_shared_bytes() { return (size_t)kKP * 8 * 4 + (size_t)kKP * 4; }   // a | c | d | audw | k
+template <class G>
+__host__ __device__ inline size_t f0_cand_shared_bytes() {           // a | c | d | audw | k
+  return G::kLdsTables ? (size_t)G::kKP * 8 * 4 + (size_t)G::kKP * 4 : 0;
+}
 
-template <bool OO>
-__global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_f0_spec(LldParams P, F0Params Q) {
+template <int LOGM, bool OO>
+__device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params &Q) {
+  using G = F0G<LOGM>;
+  F0_GEO;
+  constexpr int kSpecWaves = G::kSpecWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NP = (Q.N + 3) & ~3;
   double *c_d1 = reinterpret_cast<double *>(smem_f0), *c_d2 = c_d1 + kKP;
-  float *c_win = reinterpret_cast<float *>(c_d2 + kKP);
+  float *c_win = reinterpret_cast<float *>(G::kLdsTables ? c_d2 + kKP : c_d1);
   float2 *c_twh = reinterpret_cast<float2 *>(c_win + NP);
   float2 *c_twf = c_twh + kM / 2;
-  for (int i = threadIdx.x; i < kK; i += blockDim.x) { c_d1[i] = Q.sp_d1[i]; c_d2[i] = Q.sp_d2[i]; }
+  if constexpr (G::kLdsTables)
+    for (int i = threadIdx.x; i < kK; i += blockDim.x) { c_d1[i] = Q.sp_d1[i]; c_d2[i] = Q.sp_d2[i]; }
   for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
   OouraTab c_oo = OouraTab{};
   if (Q.oo.tw) c_oo = oo_stage_tables(Q.oo, reinterpret_cast<float *>(c_twh), threadIdx.x, blockDim.x);
@@ -588,31 +627,45 @@ __global__ void __launch_bounds__(kSpecWaves * 64) __attribute__((amdgpu_waves_p
   __syncthreads();
   F0Tbl T = {};
   T.oo = c_oo;
-  T.d1 = c_d1; T.d2 = c_d2; T.win = c_win; T.twh = c_twh; T.twf = c_twf;
-  double *A = reinterpret_cast<double *>(smem_f0 + f0_spec_shared_bytes(Q.N)) + (size_t)wave * 2 * kKP;
+  if constexpr (G::kLdsTables) { T.d1 = c_d1; T.d2 = c_d2; } else { T.d1 = Q.sp_d1; T.d2 = Q.sp_d2; }
+  T.win = c_win; T.twh = c_twh; T.twf = c_twf;
+  double *A = reinterpret_cast<double *>(smem_f0 + f0_spec_shared_bytes<G>(Q.N)) + (size_t)wave * 2 * kKP;
   const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
   if (tile >= Q.tile0 + Q.n_tiles_chunk) return;
   const int64_t samp0 = P.tile_rec[tile].samp0;
   const int n_fr = P.tile_rec[tile].n_frames;
   for (int w = 0; w < n_fr; ++w) {
-    const double es = f0_spectrum<OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
+    const double es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     double *row = Q.ab + fr * kKP;
     double *bb = Q.ab + Q.ab_rows * kKP;
 #pragma unroll
     for (int m = 0; m < kPer; ++m) {
       const int i = lane + 64 * m;
-      if (i < kK) { row[i] = A[i]; bb[f0_bb_index(fr, i)] = A[kKP + i]; }
+      if (i < kK) { row[i] = A[i]; bb[f0_bb_index<G>(fr, i)] = A[kKP + i]; }
     }
     if (lane == 0) row[kK] = es;                       // the frame's sum of squares rides in the row's padding
     WaveG::sync();
   }
 }
+// (the register budget of the tuned geometry is pinned; the other geometries take what the compiler gives them)
+template <bool OO>
+__global__ void __launch_bounds__(F0G<9>::kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_f0_spec(LldParams P, F0Params Q) {
+  f0_spec_body<9, OO>(P, Q);
+}
+template <int LOGM>
+__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_spec_g(LldParams P, F0Params Q) {
+  f0_spec_body<LOGM, true>(P, Q);
+}
 
 // the spline's two recurrences, one frame per thread, one 64-frame tile per wave. A round is one 8-bin block: the wave
 // reads / writes 4 KB of consecutive memory (lane = frame: its 64-byte line), the next block's operands are loaded before
 // the current block's chain runs (two register sets alternate; the blocks never overlap, which the compiler cannot know).
+template <int LOGM>
 __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
+  using G = F0G<LOGM>;
+  F0_GEO;
+  constexpr int kNBB = G::kNBB;
   double2 *T2 = reinterpret_cast<double2 *>(Q.ab + Q.ab_rows * kKP) + ((int64_t)blockIdx.x * kNBB * 64 + threadIdx.x) * 4;
   const double *sp = Q.sp_rec;                         // [K x 4]: sigma_i, p_i, dec_i, 0 -- wave-uniform operands
   auto blk = [&](int bb) { return T2 + (int64_t)bb * 64 * 4; };
@@ -675,21 +728,30 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
   }
 }
 
-__global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_cand(LldParams P, F0Params Q) {
+template <int LOGM>
+__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_cand(LldParams P, F0Params Q) {
+  using G = F0G<LOGM>;
+  F0_GEO;
+  constexpr int kSpecWaves = G::kSpecWaves;
+  constexpr size_t kFrameBytes = G::kFrameBytes;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *c_a = reinterpret_cast<double *>(smem_f0), *c_c = c_a + kKP, *c_d = c_c + kKP, *c_audw = c_d + kKP;
   int *c_k = reinterpret_cast<int *>(c_audw + kKP);
-  for (int i = threadIdx.x; i < kK; i += blockDim.x) {
-    c_a[i] = Q.ip_co[3 * i]; c_c[i] = Q.ip_co[3 * i + 1]; c_d[i] = Q.ip_co[3 * i + 2];
-    c_audw[i] = Q.audw[i];
-    c_k[i] = Q.ip_k[i];
-  }
-  __syncthreads();
   F0Tbl T = {};
-  T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw; T.k = c_k;
-  unsigned char *base = smem_f0 + f0_cand_shared_bytes() + (size_t)wave * kFrameBytes;
+  if constexpr (G::kLdsTables) {
+    for (int i = threadIdx.x; i < kK; i += blockDim.x) {
+      c_a[i] = Q.ip_co[3 * i]; c_c[i] = Q.ip_co[3 * i + 1]; c_d[i] = Q.ip_co[3 * i + 2];
+      c_audw[i] = Q.audw[i];
+      c_k[i] = Q.ip_k[i];
+    }
+    __syncthreads();
+    T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw; T.k = c_k;
+  } else {                                               // the tables stay in global memory (a | c | d: Q.ip_co, read in f0_shs)
+    T.audw = Q.audw; T.k = Q.ip_k;
+  }
+  unsigned char *base = smem_f0 + f0_cand_shared_bytes<G>() + (size_t)wave * kFrameBytes;
   double *A = reinterpret_cast<double *>(base);
   int *ci = reinterpret_cast<int *>(A + 2 * kKP);
   const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
@@ -704,21 +766,21 @@ __global__ void __launch_bounds__(kSpecWaves * 64) lld_f0_cand(LldParams P, F0Pa
 #pragma unroll
     for (int m = 0; m < kPer; ++m) {
       const int i = lane + 64 * m;
-      if (i < kK) { A[i] = row[i]; A[kKP + i] = bb[f0_bb_index(fr, i)]; }
+      if (i < kK) { A[i] = row[i]; A[kKP + i] = bb[f0_bb_index<G>(fr, i)]; }
     }
     const double es = row[kK];
     WaveG::sync();
     PHASE(0);   // rows from global
     double mean = 0.0;
-    const int nf = f0_shs(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean);
+    const int nf = f0_shs<G>(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean);
     WaveG::sync();
     PHASE(2);   // interpolation, summation, top six
     if (mean != mean) {                                  // (wave-uniform) no exactness guarantee: the reference's chain
-      if (lane == 0) mean = f0_mean_serial(A + kKP);
+      if (lane == 0) mean = f0_mean_serial<G>(A + kKP);
       mean = wave_first_d(mean);
     }
     PHASE(3);   // mean
-    f0_candidates(Q, lane, row0 + w, A, ci, reinterpret_cast<float *>(ci + 8), nf, mean, es);
+    f0_candidates<G>(Q, lane, row0 + w, A, ci, reinterpret_cast<float *>(ci + 8), nf, mean, es);
     PHASE(4);   // candidates + output
   }
   PHASE_FLUSH;
@@ -934,10 +996,19 @@ __device__ __forceinline__ long uni(long v) {
   return (long)(((unsigned long)hi << 32) | lo);
 }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// capacities at 16 kHz; every one but the number of periods scales with the sample rate (jit_scale: 1 up to 16 kHz, 3 at 48 kHz)
 constexpr int kJitCap = 2560;      // samples of wave the kernel can hold per frame (frame + left-over of the previous frames)
 constexpr int kJitMaxCand = 192;   // candidate period lengths per step: T0maxF - T0minF + 1 <= 156 for F0 >= 52 Hz
 constexpr int kJitMaxPeriod = 448; // T0f + 1 <= 309
 constexpr int kJitMaxPeriods = 160;
+__host__ __device__ inline int jit_scale(double Tw) {
+  const int r = (int)ceil(1.0 / (Tw * 16000.0) - 1e-9);
+  return r < 1 ? 1 : r;
+}
+inline size_t jit_shared_bytes(double Tw, int threads) {   // ccs (doubles) | wv | avgWf | pbuf | jit_terms
+  const size_t r = (size_t)jit_scale(Tw);
+  return r * kJitMaxCand * 8 + r * kJitCap * 4 + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 + (size_t)threads * 4;
+}
 }
 
 // kJitThreads: 64 (one wave per utterance: best throughput when the batch fills the device) or 256 (four waves, one
@@ -950,11 +1021,14 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   const int T = (int)(P.frame_off[u + 1] - fo);
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
-  __shared__ float wv[kJitCap];           // the frame's wave samples (crossCorr widens them to double as it reads: exact, and half the LDS)
-  __shared__ double ccs[kJitMaxCand];
-  __shared__ float avgWf[kJitMaxPeriod];
-  __shared__ int pbuf[kJitMaxPeriods];
-  __shared__ float jit_terms[kJitThreads];   // one term per lane and wave for the sequential energy sums
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_jit[];
+  const int jr = uni(jit_scale(Q.jit_Tw));
+  const int jitCap = jr * kJitCap, jitMaxCand = jr * kJitMaxCand, jitMaxPeriod = jr * kJitMaxPeriod;
+  double *ccs = reinterpret_cast<double *>(smem_jit);                    // [jitMaxCand]
+  float *wv = reinterpret_cast<float *>(ccs + jitMaxCand);               // [jitCap] the frame's wave samples (crossCorr widens them to double as it reads: exact, and half the LDS)
+  float *avgWf = wv + jitCap;                                            // [jitMaxPeriod]
+  int *pbuf = reinterpret_cast<int *>(avgWf + jitMaxPeriod);             // [kJitMaxPeriods]
+  float *jit_terms = reinterpret_cast<float *>(pbuf + kJitMaxPeriods);   // [kJitThreads] one term per lane and wave for the sequential energy sums
   const int64_t s0 = P.samp_off[u];
   const int64_t n_samp = P.samp_off[u + 1] - s0;
   const PcmIn x = pcm_in(P) + s0;
@@ -1001,8 +1075,8 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
       if (maxRead > lenF) maxRead = lenF;
     }
     float *o = out4 + (fo + t) * 4;
-    const bool fits = toRead + 16 <= kJitCap &&        // (+16: the sample loops read ahead by up to two rounds)
-                      (T0maxF - T0minF + 1) <= kJitMaxCand && T0f + 1 <= kJitMaxPeriod &&
+    const bool fits = toRead + 16 <= jitCap &&         // (+16: the sample loops read ahead by up to two rounds)
+                      (T0maxF - T0minF + 1) <= jitMaxCand && T0f + 1 <= jitMaxPeriod &&
                       (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
     if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
       lastIdx += toRead0;
@@ -1374,36 +1448,70 @@ int f0_chunk_tiles() {
   return n;
 }
 
-hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
-                     hipEvent_t frames_done) {
-  if (P.total_frames <= 0) return hipSuccess;
-  if (Q0.Nfft != kNfftF0 || Q0.K != kK || Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;    // 60 ms @ 16 kHz geometry only
-  for (int h = 0; h + 1 < Q0.n_harm && h < 16; ++h)      // f0_shs reads bin j + shift without a clamp: it must stay inside the wave's A | B arrays
-    if (Q0.shift[h] < 0 || Q0.shift[h] > 4 * kKP - 9 * 64) return hipErrorInvalidValue;
-  (void)max_blocks;
-  const size_t lds_spec = f0_spec_shared_bytes(Q0.N) + (size_t)kSpecWaves * 2 * kKP * sizeof(double);
-  const size_t lds_cand = f0_cand_shared_bytes() + (size_t)kSpecWaves * kFrameBytes;
+namespace {
+inline int f0_logm(const F0Params &Q) {                  // the instantiated geometries: FFT 512 .. 4096
+  for (int l = 8; l <= 11; ++l) if (Q.Nfft == (2 << l) && Q.K == (1 << l) + 1) return l;
+  return 0;
+}
+template <class G>
+bool f0_shifts_fit(const F0Params &Q) {                  // f0_shs reads bin j + shift without a clamp: it must stay inside the wave's A | B arrays
+  for (int h = 0; h + 1 < Q.n_harm && h < 16; ++h)
+    if (Q.shift[h] < 0 || Q.shift[h] > 4 * G::kKP - G::kPer * 64) return false;
+  return true;
+}
+template <int LOGM>
+hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t s) {
+  using G = F0G<LOGM>;
+  if (!f0_shifts_fit<G>(Q0)) return hipErrorInvalidValue;
+  constexpr int kSpecWaves = G::kSpecWaves;
+  const size_t lds_spec = f0_spec_shared_bytes<G>(Q0.N) + (size_t)kSpecWaves * 2 * G::kKP * sizeof(double);
+  const size_t lds_cand = f0_cand_shared_bytes<G>() + (size_t)kSpecWaves * G::kFrameBytes;
   const bool oo = Q0.oo.tw != nullptr;
-  hipError_t e = hipFuncSetAttribute(oo ? reinterpret_cast<const void *>(&lld_f0_spec<true>) : reinterpret_cast<const void *>(&lld_f0_spec<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
+  if (!oo && LOGM != 9) return hipErrorInvalidValue;     // SMILEHIP_FFT=radix2 (the A/B switch) exists for FFT 1024 only
+  const void *spec;
+  if constexpr (LOGM == 9) spec = oo ? reinterpret_cast<const void *>(&lld_f0_spec<true>) : reinterpret_cast<const void *>(&lld_f0_spec<false>);
+  else spec = reinterpret_cast<const void *>(&lld_f0_spec_g<LOGM>);
+  hipError_t e = hipFuncSetAttribute(spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand<LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
   F0Params Q = Q0;
   for (int t0 = 0; t0 < P.n_tiles; t0 += f0_chunk_tiles()) {
     Q.tile0 = t0;
     Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
     const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
-    if (oo) hipLaunchKernelGGL(lld_f0_spec<true>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-    else hipLaunchKernelGGL(lld_f0_spec<false>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    if constexpr (LOGM == 9) {
+      if (oo) hipLaunchKernelGGL(lld_f0_spec<true>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else hipLaunchKernelGGL(lld_f0_spec<false>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    } else {
+      hipLaunchKernelGGL(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+    }
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
-    hipLaunchKernelGGL(lld_f0_sweep, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
-    hipLaunchKernelGGL(lld_f0_cand, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    hipLaunchKernelGGL(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
+    hipLaunchKernelGGL(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
+  return hipSuccess;
+}
+}  // namespace
+
+hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
+                     hipEvent_t frames_done) {
+  if (P.total_frames <= 0) return hipSuccess;
+  if (Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;
+  (void)max_blocks;
+  hipError_t e;
+  switch (f0_logm(Q0)) {
+    case 8: e = launch_f0_chunks<8>(P, Q0, s); break;
+    case 9: e = launch_f0_chunks<9>(P, Q0, s); break;
+    case 10: e = launch_f0_chunks<10>(P, Q0, s); break;
+    case 11: e = launch_f0_chunks<11>(P, Q0, s); break;
+    default: return hipErrorInvalidValue;                 // 60 ms frames of 8 .. 48 kHz
+  }
+  if (e != hipSuccess) return e;
   if (frames_done && (e = hipEventRecord(frames_done, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q, d_out, ld_out);
+  hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q0, d_out, ld_out);
   return hipGetLastError();
 }
 hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
@@ -1419,19 +1527,25 @@ int64_t f0_scratch_rows(int64_t n_tiles) {                // rows of a chunk, a 
   const int64_t t = n_tiles < f0_chunk_tiles() ? n_tiles : f0_chunk_tiles();
   return (t * kTileFrames + 63) / 64 * 64;
 }
-int64_t f0_scratch_doubles(int64_t n_tiles) { return f0_scratch_rows(n_tiles) * (kKP + kNBB * 8); }
+int64_t f0_scratch_doubles(int64_t n_tiles, int K) {      // y rows [K + 3] + the 6ut / y2 blocks [ceil((K + 3) / 8) x 8]
+  const int64_t kp = K + 3;
+  return f0_scratch_rows(n_tiles) * (kp + (kp + 7) / 8 * 8);
+}
 
 
 // per-component operators on n_rows rows: mode 1 = cSpecScale (magnitudes -> Q.hps_tap), mode 2 = cPitchShs (octave-scale
-// spectra -> Q.shs, 21 values per row)
-hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
-  if (Q.n_rows <= 0) return hipSuccess;
-  if (Q.Nfft != kNfftF0 || Q.K != kK || Q.n_harm > 17 || (Q.mode != 1 && Q.mode != 2)) return hipErrorInvalidValue;
-  for (int h = 0; h + 1 < Q.n_harm && h < 16; ++h)
-    if (Q.shift[h] < 0 || Q.shift[h] > 4 * kKP - 9 * 64) return hipErrorInvalidValue;
-  const size_t lds = f0_shared_bytes(Q.N) + kFrameBytes * kW * kWaves;
+// spectra -> Q.shs, 21 values per row). The one-kernel form with every table in LDS: FFT 512 / 1024 (8 .. 16 kHz).
+namespace {
+template <int LOGM>
+hipError_t launch_f0_rows_g(const F0Params &Q, int max_blocks, hipStream_t s) {
+  using G = F0G<LOGM>;
+  if (!f0_shifts_fit<G>(Q)) return hipErrorInvalidValue;
+  const size_t lds = f0_shared_bytes<G>(Q.N) + G::kFrameBytes * kW * kWaves;
   const bool oo = Q.oo.tw != nullptr;
-  const void *fn = oo ? reinterpret_cast<const void *>(&lld_f0_frame<true>) : reinterpret_cast<const void *>(&lld_f0_frame<false>);
+  if (!oo && LOGM != 9) return hipErrorInvalidValue;
+  const void *fn;
+  if constexpr (LOGM == 9) fn = oo ? reinterpret_cast<const void *>(&lld_f0_frame<9, true>) : reinterpret_cast<const void *>(&lld_f0_frame<9, false>);
+  else fn = reinterpret_cast<const void *>(&lld_f0_frame<LOGM, true>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int64_t tiles = (Q.n_rows + kTileFrames - 1) / kTileFrames;
@@ -1439,28 +1553,50 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   if (grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;
   LldParams P;
   std::memset(&P, 0, sizeof(P));
-  if (oo) hipLaunchKernelGGL(lld_f0_frame<true>, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
-  else hipLaunchKernelGGL(lld_f0_frame<false>, dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  if constexpr (LOGM == 9) {
+    if (oo) hipLaunchKernelGGL((lld_f0_frame<9, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+    else hipLaunchKernelGGL((lld_f0_frame<9, false>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  } else {
+    hipLaunchKernelGGL((lld_f0_frame<LOGM, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+  }
   return hipGetLastError();
 }
+}  // namespace
+hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
+  if (Q.n_rows <= 0) return hipSuccess;
+  if (Q.n_harm > 17 || (Q.mode != 1 && Q.mode != 2)) return hipErrorInvalidValue;
+  switch (f0_logm(Q)) {
+    case 8: return launch_f0_rows_g<8>(Q, max_blocks, s);
+    case 9: return launch_f0_rows_g<9>(Q, max_blocks, s);
+    default: return hipErrorInvalidValue;                 // (FFT 2048 / 4096: the tables do not fit LDS; the chain's three kernels cover them)
+  }
+}
+
+namespace {
+hipError_t launch_jitter_kernel(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
+  if (!(Q.jit_Tw > 0.0) || jit_scale(Q.jit_Tw) > 6) return hipErrorInvalidValue;      // up to 96 kHz
+  const bool wide = P.n_utt < 512;
+  const size_t lds = jit_shared_bytes(Q.jit_Tw, wide ? 256 : 64);
+  const void *fn = wide ? reinterpret_cast<const void *>(&lld_f0_jitter<256>) : reinterpret_cast<const void *>(&lld_f0_jitter<64>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if (wide) hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), lds, s, P, Q, d_f0, ld_f0, d_jit4);
+  else hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4);
+  return hipGetLastError();
+}
+}  // namespace
 
 // cPitchJitter alone: F0 contour d_f0 (leading dimension ld_f0, F0final in column 0) -> d_jit4 [frames x 4] (+ Q.jit_shim_db)
 hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
-  if (P.n_utt >= 512) hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_f0, ld_f0, d_jit4);
-  else hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), 0, s, P, Q, d_f0, ld_f0, d_jit4);
-  return hipGetLastError();
+  return launch_jitter_kernel(P, Q, d_f0, ld_f0, d_jit4, s);
 }
 
 // jitter / shimmer / HNR from the wave and the F0 contour (pitch2, T60 x 2), then the F0 group's 12 LLD columns
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s) {
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
-  if (P.n_utt >= 512)
-    hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
-  else
-    hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), 0, s, P, Q, d_pitch2, (int64_t)2, d_jit4);
-  hipError_t e = hipGetLastError();
+  hipError_t e = launch_jitter_kernel(P, Q, d_pitch2, 2, d_jit4, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
                      Q.pending, d_out, ld_out, col_sma, col_de);

@@ -48,7 +48,7 @@ hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int 
 int f0_viterbi_max_buffer();
 int f0_viterbi_states();
 int64_t f0_scratch_rows(int64_t n_tiles);
-int64_t f0_scratch_doubles(int64_t n_tiles);   // rows between the three frame kernels of the F0 chain, one chunk of tiles
+int64_t f0_scratch_doubles(int64_t n_tiles, int K);   // rows between the three frame kernels of the F0 chain, one chunk of tiles
 hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);

@@ -160,7 +160,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 scratch matrices failed");
     }
     b->d_shs.n = nf * 21; b->d_e60.n = nf;
-    const size_t nab = (size_t)std::max<int64_t>(f0_scratch_doubles(b->n_tiles), 1);
+    const size_t nab = (size_t)std::max<int64_t>(f0_scratch_doubles(b->n_tiles, (int)plan->geo.K), 1);
     if (hipMalloc(reinterpret_cast<void **>(&b->d_f0_ab.p), nab * sizeof(double)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 row scratch (%zu MB) failed", nab * sizeof(double) >> 20);

@@ -192,9 +192,9 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
     if (mask != SMILEHIP_STAGE_ALL || p->cfg.preemph || p->cfg.n_delta != 0 || p->cfg.win_offset != 0.0)
       return fail(SMILEHIP_ERR_INVALID, "F0 chain: no pre-emphasis / deltas / window offset");
-    if (p->geo.Nfft != 1024)
-      return fail(SMILEHIP_ERR_INVALID, "F0 chain: the kernels are built for the 1024-point spectrum of 60 ms frames at 16 kHz "
-                  "(this configuration gives %lld points)", (long long)p->geo.Nfft);
+    if (p->geo.Nfft != 512 && p->geo.Nfft != 1024 && p->geo.Nfft != 2048 && p->geo.Nfft != 4096)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: the kernels are instantiated for spectra of 512 .. 4096 points (60 ms frames at 8 .. 48 kHz); "
+                  "this configuration gives %lld points", (long long)p->geo.Nfft);
     if (p->cfg.shs_n_harmonics < 1 || p->cfg.shs_n_harmonics > 17 || !(p->cfg.pitch_max > p->cfg.pitch_min) || p->cfg.pitch_min < 40.0)
       return fail(SMILEHIP_ERR_INVALID, "F0 chain: nHarmonics 1..17, minPitch >= 40 Hz (period search window of the jitter kernel), "
                   "maxPitch > minPitch");

@@ -16,11 +16,17 @@
 
 /* ------------------------------------------------------------------ config */
 
+/* The sample rate of the input the chain functions below work on (cWaveSource reads it from the file; every frame size of
+ * the shipped configs is given in seconds, so the same conf runs at any rate). 16 kHz unless a test sets another one. */
+double g_lldo_rate = 16000.0;
+void lldo_set_sample_rate(double rate) { g_lldo_rate = rate > 0.0 ? rate : 16000.0; }
+double lldo_get_sample_rate(void) { return g_lldo_rate; }
+
 /* config/mfcc/MFCC12_0_D_A.conf:52-131 */
 void lldo_default_mfcc12_cfg(lldo_mfcc_cfg *c)
 {
   memset(c, 0, sizeof(*c));
-  c->sample_rate = 16000.0;
+  c->sample_rate = g_lldo_rate;
   c->frame_size_sec = 0.0250;
   c->frame_step_sec = 0.010;
   c->preemph_enable = 1; c->preemph_k = (float)0.97; c->preemph_de = 0;

@@ -328,7 +328,7 @@ long lldo_compare_ab_chain(const int16_t *pcm, long n_samples, float *out, float
   c.lofreq = 20.0f; c.first_mfcc = 1; c.last_mfcc = 14; c.n_delta = 0;
   lldo_geom g;
   lldo_geometry(&c, &g);
-  const long N60 = 960;
+  const long N60 = lround(0.060 * c.sample_rate);
   long T20 = lldo_num_frames(n_samples, g.N, g.H);
   long T60 = lldo_num_frames(n_samples, N60, g.H);
   if (T60 < 4) return 0;

@@ -737,7 +737,8 @@ void lldo_pitch_jitter_ex(const float *wave, long n, const float *f0, long T, lo
  * Requires T60 >= 4 like the A+B groups (returns 0 rows otherwise). */
 long lldo_compare_f0_lld(const int16_t *pcm, long n_samples, float *out12)
 {
-  const long N = 960, H = 160;
+  const double rate = lldo_get_sample_rate();
+  const long N = lround(0.060 * rate), H = lround(0.010 * rate);
   const long T = lldo_num_frames(n_samples, N, H);
   if (T < 4) return 0;
   const long rows = T + 1;
@@ -756,7 +757,7 @@ long lldo_compare_f0_lld(const int16_t *pcm, long n_samples, float *out12)
     free(tmp); }
   lldo_pcm16_to_float(pcm, n_samples, wave);
   for (long t = 0; t < T; t++) f0[t] = p2[2 * t];
-  lldo_pitch_jitter(wave, n_samples, f0, T, N, H, 16000.0, 0.010, j4);
+  lldo_pitch_jitter(wave, n_samples, f0, T, N, H, rate, 0.010, j4);
   for (long t = 0; t < T; t++) {
     x6[6 * t] = p2[2 * t]; x6[6 * t + 1] = p2[2 * t + 1];
     for (int d = 0; d < 4; d++) x6[6 * t + 2 + d] = j4[4 * t + d];

@@ -927,7 +927,7 @@ void lldo_egemaps_smooth(const lldo_egemaps_lv *L, lldo_egemaps_smo *S)
  * rows = T60 + 1 (the rows both levels hold); 0 if the input has no 60 ms frame. out25 == NULL: query. */
 long lldo_egemaps_lld_chain(const int16_t *pcm, long n_samples, float *out25)
 {
-  const long T60 = lldo_num_frames(n_samples, 960, 160);
+  const long T60 = lldo_num_frames(n_samples, lround(0.060 * lldo_get_sample_rate()), lround(0.010 * lldo_get_sample_rate()));
   if (T60 < 1) return 0;
   if (!out25) return T60 + 1;
   lldo_egemaps_lv L;
@@ -1019,7 +1019,7 @@ int lldo_egemaps_func_from_levels(const lldo_egemaps_lv *L, const lldo_egemaps_s
 
 int lldo_egemaps_func(const int16_t *pcm, long n_samples, float *out88)
 {
-  const long T60 = lldo_num_frames(n_samples, 960, 160);
+  const long T60 = lldo_num_frames(n_samples, lround(0.060 * lldo_get_sample_rate()), lround(0.010 * lldo_get_sample_rate()));
   if (T60 < 1) return 0;
   lldo_egemaps_lv L;
   lldo_egemaps_smo S;

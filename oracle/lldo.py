@@ -427,6 +427,29 @@ def run_reference_func_taps(pcm, fs=16000, is13=False):
         return out
 
 
+def set_sample_rate(rate):
+    """Sample rate of the input of the chain functions (lld_oracle.c: g_lldo_rate; 16000 unless set). Reset it after use."""
+    L = lib()
+    L.lldo_set_sample_rate.argtypes = [C.c_double]
+    L.lldo_set_sample_rate.restype = None
+    L.lldo_set_sample_rate(float(rate))
+
+
+def get_sample_rate():
+    L = lib()
+    L.lldo_get_sample_rate.restype = C.c_double
+    return L.lldo_get_sample_rate()
+
+
+def bins_of(frame_sec):
+    """Number of magnitude bins of a frame of frame_sec seconds at the oracle's current rate (FFT = next power of two)."""
+    n = int(round(frame_sec * get_sample_rate()))
+    nfft = 1
+    while nfft < n:
+        nfft *= 2
+    return nfft // 2 + 1
+
+
 def compare_f0_chain(pcm, taps=False):
     """ComParE_2016 F0 group, level is13_pitchG60: T60 x 2 [F0final, voicingFinalUnclipped];
     taps=True also returns {hps, shs, vit, e60} (the levels of the same names, see lld_oracle_f0.c)."""
@@ -437,7 +460,7 @@ def compare_f0_chain(pcm, taps=False):
     T = L.lldo_compare_f0_chain(pcm.ctypes.data, len(pcm), None, None, None, None, None)
     T = max(T, 0)
     out = np.zeros((T, 2), np.float32)
-    t = {"hps": np.zeros((T, 513), np.float32), "shs": np.zeros((T, 21), np.float32),
+    t = {"hps": np.zeros((T, bins_of(0.060)), np.float32), "shs": np.zeros((T, 21), np.float32),
          "vit": np.zeros((T, 2), np.float32), "e60": np.zeros((T, 1), np.float32)}
     if T > 0:
         r = L.lldo_compare_f0_chain(pcm.ctypes.data, len(pcm), out.ctypes.data, t["hps"].ctypes.data,
