@@ -219,16 +219,21 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int n = ln + 64 * q; pre[q] = (n < P.N) ? xx[n] : (int16_t)0; }
   };
-  if (!xuf) prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
+  const bool ahead = !xuf && P.N <= 512;                 // (longer frames -- 20 ms above 25.6 kHz -- are read at the frame like float input)
+  if (ahead) prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     int lane = lane_in;                                  // opaque per frame (see lld_compare_frame_wave): nothing that depends on
     asm volatile("" : "+v"(lane));                       // the lane only is kept in registers across the frame loop
     const bool warm = t < t0;
     const int16_t *x = xu + (int64_t)t * P.H;
     float *raw = G.raw20 + (f0 + t) * 12;
+    if (ahead) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = xuf ? xuf[(int64_t)t * P.H + n] : pcm16_to_float(pre[q]); }
-    if (!xuf && t + 1 < t_last) prefetch(x + P.H, lane);
+      for (int q = 0; q < 8; ++q) { const int n = lane + 64 * q; if (n < P.N) yv[n] = pcm16_to_float(pre[q]); }
+      if (t + 1 < t_last) prefetch(x + P.H, lane);
+    } else {
+      for (int n = lane; n < P.N; n += 64) yv[n] = xuf ? xuf[(int64_t)t * P.H + n] : pcm16_to_float(x[n]);
+    }
     WaveG::sync();
     // cEnergy energy2 of the raw frame (energy.cpp:152-170): float squares added in double
     double e2 = 0.0;
@@ -347,7 +352,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
     for (int f = 0; f < FW; ++f)
 #pragma unroll
       for (int o = 0; o < 4; ++o)
-        if (o < 3 || o3) xs[fw + f][lane + 64 * o] = acc[f][o] / (float)256;   // /= (FLOAT_DMEM)(K/2), K = 512 inputs
+        if (o < 3 || o3) xs[fw + f][lane + 64 * o] = acc[f][o] / G.rs_norm;   // /= (FLOAT_DMEM)(K/2), K = 512 inputs at 16 kHz
   }
   __syncthreads();
   if (G.op_mode == 1) {                                  // cSpecResample alone: the resampled frames are the output
@@ -685,9 +690,17 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 // LDS: shared win[NP] | twh[256] | twf[260]; per wave z[576 pairs] (later hbin[128] | hfi[128] | hmag[128] | hlr[128]) |
 // mg[516] | acf[516]
 namespace {
-constexpr int kHM = 512, kHK = 513, kHKP = 516;
-constexpr size_t kHarmTwBytes = 6144;                   // twh | twf (4128 B) or the reference-order tables (6016 B, lld_ooura.hpp)
-constexpr int kHarmWaves = 8;                          // 8.7 KB of LDS per wave + 7.9 KB of tables per workgroup: two workgroups = 16 waves per CU
+// Geometry of the 60 ms spectrum by sample rate (as in lld_f0.hip): FFT 512 (8 kHz), 1024 (11.025 / 16 kHz: the tuned case),
+// 2048 (22.05 .. 32 kHz), 4096 (44.1 / 48 kHz)
+template <int LOGM>
+struct HarmG {
+  static constexpr int kHM = 1 << LOGM, kHK = kHM + 1, kHKP = kHM + 4;
+  static constexpr size_t kTwBytes = (size_t)12 * kHM;    // twh | twf (4128 B for M = 512) or the reference-order tables (<= 12 M, lld_ooura.hpp)
+  // M = 512: 8.7 KB of LDS per wave + 7.9 KB of tables per workgroup: two workgroups = 16 waves per CU
+  static constexpr int kWaves = LOGM <= 9 ? 8 : (LOGM == 10 ? 4 : 2);
+  static constexpr int kZ = LOGM == 9 ? WaveFft<9>::kZ : kHM + 64;   // (re, im) pairs of the transform's buffer (>= 256: the harmonics' arrays live there)
+  static constexpr int kMC = LOGM <= 9 ? kHM : -1;        // register-resident transform for M = 256 / 512, in place in LDS above
+};
 __device__ __forceinline__ int harm_is_peak(const float *x, int N, int n) {  // cHarmonics::isPeak, :369-390
   if (n >= N || n < 0) return 0;
   if (n + 1 < N) {
@@ -701,7 +714,7 @@ __device__ __forceinline__ int harm_is_peak(const float *x, int N, int n) {  // 
 // freqToBin (:403-415) on the linear axis frq[i] = Fb * i: the first bin above freq, or its lower neighbour if that one
 // is closer; 0 if there is none. The reference's search start never lies above that bin (see the call sites), so the
 // result does not depend on it.
-__device__ __forceinline__ int harm_freq_to_bin(double Fb, float freq) {
+__device__ __forceinline__ int harm_freq_to_bin(double Fb, float freq, int kHK) {
   const double f = (double)freq;
   int s = (int)(f / Fb);
   while (Fb * (double)s <= f) s++;
@@ -712,7 +725,10 @@ __device__ __forceinline__ int harm_freq_to_bin(double Fb, float freq) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, F0Params Q, GemapsParams G) {
+template <int LOGM>
+__global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldParams P, F0Params Q, GemapsParams G) {
+  using HG = HarmG<LOGM>;
+  constexpr int kHM = HG::kHM, kHK = HG::kHK, kHKP = HG::kHKP, kHarmWaves = HG::kWaves, kMC = HG::kMC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -728,10 +744,10 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
     for (int i = threadIdx.x; i <= kHM / 2; i += blockDim.x) c_twf[i] = Q.tw_full[i];
   }
   __syncthreads();                                       // the only workgroup barrier
-  using Fft = WaveFft<9>;                                // kHM == 512: fused passes on (re, im) pairs, lld_fft.hpp
-  constexpr int per_wave = 2 * Fft::kZ + 2 * kHKP;
-  float2 *z = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(c_twh) + kHarmTwBytes) + (size_t)wave * (per_wave / 2);
-  float *mg = reinterpret_cast<float *>(z + Fft::kZ);
+  using Fft = WaveFft<9>;                                // kHM == 512, own-order A/B build: fused passes on (re, im) pairs, lld_fft.hpp
+  constexpr int per_wave = 2 * HG::kZ + 2 * kHKP;
+  float2 *z = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(c_twh) + HG::kTwBytes) + (size_t)wave * (per_wave / 2);
+  float *mg = reinterpret_cast<float *>(z + HG::kZ);
   float *acf = mg + kHKP;
   int *hbin = reinterpret_cast<int *>(z);                // the harmonics' arrays live in the transform's buffer (dead after the ACF)
   float *hfi = reinterpret_cast<float *>(hbin + 128);
@@ -779,23 +795,28 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
           return make_float2((n0 >= 0 && n0 < Q.N) ? x[n0] * c_win[n0] : 0.0f,
                              (n1 >= 0 && n1 < Q.N) ? x[n1] * c_win[n1] : 0.0f);
         };
-        if (OO.tw) oo_wave_forward<kHM>(z, OO, lane, load_pair);
-        else Fft::forward(z, c_twh, lane, load_pair);
-        for (int k = lane; k <= kHM; k += 64)
-          mg[k] = bin_magnitude(OO.tw ? oo_wave_bin<kHM>(z, OO, k) : fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
+        if constexpr (LOGM == 9) {
+          if (OO.tw) oo_wave_forward<kMC>(z, OO, lane, load_pair);
+          else Fft::forward(z, c_twh, lane, load_pair);
+          for (int k = lane; k <= kHM; k += 64)
+            mg[k] = bin_magnitude(OO.tw ? oo_wave_bin<kMC>(z, OO, k) : fft_untangle<Fft>(z, k, c_twf), k == 0 || k == kHM);
+        } else {
+          oo_wave_forward<kMC>(z, OO, lane, load_pair);
+          for (int k = lane; k <= kHM; k += 64) mg[k] = bin_magnitude(oo_wave_bin<kMC>(z, OO, k), k == 0 || k == kHM);
+        }
       }
       WaveG::sync();
       GPHASE(0);   // load, window, FFT, magnitudes
       // computeAcf (:590-630): inverse real FFT of the squared magnitudes, |.| / nBins, lags 0 .. nBins-1
-      if (OO.tw) {                                       // rdft(N, -1) on the packed squares (harmonics.cpp:609-627)
-        oo_wave_inverse<kHM>(z, OO, lane, [&](int e) {
+      if (LOGM != 9 || OO.tw) {                          // rdft(N, -1) on the packed squares (harmonics.cpp:609-627)
+        oo_wave_inverse<kMC>(z, OO, lane, [&](int e) {
           if (e == 0) { const float m0 = mg[0], m1 = mg[kHM]; return make_float2(m0 * m0, m1 * m1); }
           const float m = mg[e];
           return make_float2(m * m, 0.0f);
         });
-        for (int k = lane; k <= kHM; k += 64) acf[k] = fabsf(oo_wave_inverse_out<kHM>(z, OO, k)) / (float)kHK;
+        for (int k = lane; k <= kHM; k += 64) acf[k] = fabsf(oo_wave_inverse_out<kMC>(z, OO, k)) / (float)kHK;
         WaveG::sync();
-      } else {
+      } else if constexpr (LOGM == 9) {
         const int n = 2 * kHM;
         Fft::forward(z, c_twh, lane, [&](int i) {        // the squared magnitudes, formed as they are asked for
           const int n0 = 2 * i, n1 = 2 * i + 1;
@@ -846,18 +867,18 @@ __global__ void __launch_bounds__(kHarmWaves * 64) lld_gemaps_harm(LldParams P, 
       }
       GPHASE(2);   // HNR peak search
       // findHarmonicPeaks, frequency-axis branch (:478-546): harmonic i = lane, lane + 64
-      const int firstBin = harm_freq_to_bin(Fb, 0.5f * F0);
+      const int firstBin = harm_freq_to_bin(Fb, 0.5f * F0, kHK);
       for (int i = lane; i < 128; i += 64) {
         int bin = -1;
         float fi = 0.0f, mag = 0.0f, mi = 0.0f;
         if (i < kNH) {
-          const int candBin = harm_freq_to_bin(Fb, (float)(i + 1) * F0);
+          const int candBin = harm_freq_to_bin(Fb, (float)(i + 1) * F0, kHK);
           int peakBin = -1;
           if (harm_is_peak(mg, kHK, candBin)) peakBin = candBin;
           else {
             int cl = candBin - 1, cr = candBin + 1;
-            const int lower = harm_freq_to_bin(Fb, ((float)i + 0.5f) * F0);
-            const int upper = harm_freq_to_bin(Fb, ((float)i + 1.5f) * F0);
+            const int lower = harm_freq_to_bin(Fb, ((float)i + 0.5f) * F0, kHK);
+            const int upper = harm_freq_to_bin(Fb, ((float)i + 1.5f) * F0, kHK);
             while ((cl >= lower || cr <= upper) && peakBin == -1) {
               if (cr <= upper) { if (harm_is_peak(mg, kHK, cr)) { peakBin = cr; break; } cr++; }
               if (cl >= lower) { if (harm_is_peak(mg, kHK, cl)) { peakBin = cl; break; } cl--; }
@@ -1126,7 +1147,7 @@ hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s) {
 
 hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s) {
   if (n_runs <= 0) return hipSuccess;
-  if (P.Nfft != 512 || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;
+  if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.N > P.Nfft || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 64 + 96));
@@ -1140,21 +1161,34 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   return launch_formants(G, G.total_frames20, s);
 }
 
+namespace {
+template <int LOGM>
+hipError_t launch_harm_g(const LldParams &P, const F0Params &Q, const GemapsParams &G, int64_t n_tiles, int max_blocks, hipStream_t s) {
+  using HG = HarmG<LOGM>;
+  const int NP = (Q.N + 3) & ~3;
+  if (sizeof(float) * (size_t)oo_table_floats(Q.oo) > HG::kTwBytes) return hipErrorInvalidValue;
+  if (LOGM != 9 && !Q.oo.tw) return hipErrorInvalidValue;             // the own-order A/B build exists for FFT 1024 only
+  const size_t lds = sizeof(float) * (size_t)NP + HG::kTwBytes + sizeof(float) * HG::kWaves * (size_t)(2 * HG::kZ + 2 * HG::kHKP);
+  const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm<LOGM>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  unsigned grid = (unsigned)((n_tiles + HG::kWaves - 1) / HG::kWaves);
+  if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);   // M = 512: 78 KB of LDS per workgroup, two per CU
+  hipLaunchKernelGGL(lld_gemaps_harm<LOGM>, dim3(grid), dim3(HG::kWaves * 64), lds, s, P, Q, G);
+  return hipGetLastError();
+}
+}  // namespace
 hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s) {
   const int64_t n_tiles = G.op_mode == 1 ? (G.op_rows + 7) / 8 : G.n_tiles60;
   if (n_tiles <= 0) return hipSuccess;
-  if (Q.Nfft != 1024 || Q.K != kHK) return hipErrorInvalidValue;
-  const int NP = (Q.N + 3) & ~3;
-  if (sizeof(float) * (size_t)oo_table_floats(Q.oo) > kHarmTwBytes) return hipErrorInvalidValue;
-  const size_t lds = sizeof(float) * (size_t)NP + kHarmTwBytes +
-                     sizeof(float) * kHarmWaves * (size_t)(2 * WaveFft<9>::kZ + 2 * kHKP);
-  const void *fn = reinterpret_cast<const void *>(&lld_gemaps_harm);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  unsigned grid = (unsigned)((n_tiles + kHarmWaves - 1) / kHarmWaves);
-  if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);   // 78 KB of LDS per workgroup: two per CU
-  hipLaunchKernelGGL(lld_gemaps_harm, dim3(grid), dim3(kHarmWaves * 64), lds, s, P, Q, G);
-  return hipGetLastError();
+  if (Q.K != Q.Nfft / 2 + 1) return hipErrorInvalidValue;
+  switch (Q.Nfft) {                                      // 60 ms frames at 8 .. 48 kHz
+    case 512: return launch_harm_g<8>(P, Q, G, n_tiles, max_blocks, s);
+    case 1024: return launch_harm_g<9>(P, Q, G, n_tiles, max_blocks, s);
+    case 2048: return launch_harm_g<10>(P, Q, G, n_tiles, max_blocks, s);
+    case 4096: return launch_harm_g<11>(P, Q, G, n_tiles, max_blocks, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemaps_tail(const int64_t *d_frame_off20, const int64_t *d_row_off, int n_utt, const GemapsParams &G, float *d_out,

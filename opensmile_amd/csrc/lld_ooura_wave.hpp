@@ -161,9 +161,10 @@ __device__ __forceinline__ void oo_wave512(float2 *z, const OouraTab &T, int lan
 }
 
 // ---- the wave-level interface of the chains: register form for M = 256 / 512, the in-place LDS form otherwise.
-// MC: M when the caller knows it at compile time (256 / 512: only that form is generated), 0 = decided at run time
+// MC: M when the caller knows it at compile time (256 / 512: only that form is generated), 0 = decided at run time,
+// -1 = the in-place LDS form only (any other length known at compile time)
 template <int MC = 0>
-__device__ __forceinline__ bool oo_wave_nat(const OouraTab &T) { return MC ? (MC == 256 || MC == 512) : (T.M == 256 || T.M == 512); }
+__device__ __forceinline__ bool oo_wave_nat(const OouraTab &T) { return MC < 0 ? false : (MC ? (MC == 256 || MC == 512) : (T.M == 256 || T.M == 512)); }
 template <int MC = 0>
 __device__ __forceinline__ float2 oo_wave_at(const float2 *z, const OouraTab &T, int F) {
   return oo_wave_nat<MC>(T) ? z[oo_pos(F)] : z[oo_rev(F, T.logM)];
@@ -181,7 +182,8 @@ struct OoWaveG {                                           // the one-wave group
 // forward transform of 2M reals: load(i) = (x[2i], x[2i + 1]); z needs M pairs. Ends with a wave sync.
 template <int MC = 0, class Load>
 __device__ __forceinline__ void oo_wave_forward(float2 *z, const OouraTab &T, int lane, Load load) {
-  if constexpr (MC == 256) { oo_wave256<false>(z, T, lane, load); oo_wave_sync(); }
+  if constexpr (MC < 0) ooura_forward<OoWaveG>(z, T, load);
+  else if constexpr (MC == 256) { oo_wave256<false>(z, T, lane, load); oo_wave_sync(); }
   else if constexpr (MC == 512) { oo_wave512<false>(z, T, lane, load); oo_wave_sync(); }
   else if (T.M == 256) { oo_wave256<false>(z, T, lane, load); oo_wave_sync(); }
   else if (T.M == 512) { oo_wave512<false>(z, T, lane, load); oo_wave_sync(); }
@@ -190,7 +192,7 @@ __device__ __forceinline__ void oo_wave_forward(float2 *z, const OouraTab &T, in
 // bin k (0 <= k <= M) as the standard DFT value (see ooura_bin)
 template <int MC = 0>
 __device__ __forceinline__ float2 oo_wave_bin(const float2 *z, const OouraTab &T, int k) {
-  const int M = MC ? MC : T.M;
+  const int M = MC > 0 ? MC : T.M;
   if (k == 0) { const float2 a = oo_wave_at<MC>(z, T, 0); return make_float2(a.x + a.y, 0.0f); }
   if (k == M) { const float2 a = oo_wave_at<MC>(z, T, 0); return make_float2(a.x - a.y, 0.0f); }
   if (2 * k == M) { const float2 a = oo_wave_at<MC>(z, T, k); return make_float2(a.x, -a.y); }
@@ -206,8 +208,9 @@ __device__ __forceinline__ float2 oo_wave_bin(const float2 *z, const OouraTab &T
 // inverse transform rdft(2M, -1): load(e) = (a[2e], a[2e + 1]) of the packed input. Output sample i: oo_wave_inverse_out.
 template <int MC = 0, class Load>
 __device__ __forceinline__ void oo_wave_inverse(float2 *z, const OouraTab &T, int lane, Load load) {
+  if constexpr (MC < 0) { ooura_inverse<OoWaveG>(z, T, load); return; }
   if constexpr (MC == 0) { if (!oo_wave_nat(T)) { ooura_inverse<OoWaveG>(z, T, load); return; } }
-  const int M = MC ? MC : T.M;
+  const int M = MC > 0 ? MC : T.M;
   // the element of the array after rdft :350-351 and rftbsub :3266-3288, computed where it is needed (the pair's other
   // member is computed by another lane: the same operations on the same operands, the same bits)
   const auto pre = [&](int e) {
@@ -240,7 +243,7 @@ __device__ __forceinline__ float oo_wave_inverse_out(const float2 *z, const Oour
 template <int MC = 0>
 __device__ __forceinline__ void oo_wave_irfft_even(const float *R, float2 *z, const OouraTab &T, float *out, float inv_norm,
                                                    bool take_abs, int lane) {
-  const int M = MC ? MC : T.M;
+  const int M = MC > 0 ? MC : T.M;
   oo_wave_inverse<MC>(z, T, lane, [&](int e) { return e == 0 ? make_float2(R[0], R[M]) : make_float2(R[e], 0.0f); });
   for (int i = lane; i < M; i += 64) {
     const float v = oo_wave_inverse_out<MC>(z, T, i) / inv_norm;

@@ -177,6 +177,7 @@ struct GemapsParams {
   float spec_floor, log_spec_floor, log_spec_factor;
   // ---- cSpecResample -> cLpc -> cFormantLpc ----
   const float *rs_cos, *rs_sin;     // [109 x 220] smileDsp_initIrdft's tables, transposed: [k/2 - 1][i]
+  float rs_norm;                    // smileDsp_irdft's divisor: (FLOAT_DMEM)(K / 2), K = the Nfft values of the complex spectrum (256 at 16 kHz)
   float *lpc;                       // [total_frames20 x 12] 11 LP coefficients + pad
   float *formants;                  // [total_frames20 x 10] 5 frequencies | 5 bandwidths
   int64_t total_frames20;

@@ -590,6 +590,7 @@ void gemaps_plan_consts(const smilehip_plan *plan, GemapsParams &G) {
   G.rng_lo = plan->gm_rng_lo; G.rng_hi = plan->gm_rng_hi;
   G.spec_floor = plan->gm_spec_floor; G.log_spec_floor = plan->gm_log_spec_floor; G.log_spec_factor = plan->gm_log_spec_factor;
   G.rs_cos = plan->d_rs_cos.p; G.rs_sin = plan->d_rs_sin.p;
+  G.rs_norm = (float)(plan->geo.Nfft / 2);
   G.fm_T = 1.0 / plan->gm_target_fs;   // cSpecResample::configureWriter: basePeriod = 1 / targetFs
   G.fm_min = 50.0; G.fm_max = 5450.0;  // [gemapsv01b_formantLpc]
   G.fsSec60 = plan->f0_plan->geo.fft_frame_size_sec;

@@ -180,8 +180,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 4 || p->mel.n_bands != 26 || p->cfg.n_delta != 0 || p->cfg.sma_win != 3 ||
-        !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512 || p->geo.N != 320)
-      return fail(SMILEHIP_ERR_INVALID, "eGeMAPS chain: unsupported parameter set (20 ms frames at 16 kHz, 26 bands, MFCC 1..4)");
+        !p->cfg.use_power || p->cfg.preemph || (p->geo.Nfft != 256 && p->geo.Nfft != 512 && p->geo.Nfft != 1024))
+      return fail(SMILEHIP_ERR_INVALID, "eGeMAPS chain: unsupported parameter set (20 ms frames at 8 .. 48 kHz, 26 bands, MFCC 1..4)");
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_PLP) {
     if (mask != SMILEHIP_STAGE_ALL || p->cfg.plp_lp_order < 1 || p->cfg.plp_lp_order > 15 || !p->cfg.mel_htk_compatible ||
         !p->cfg.use_power || p->mel.n_bands > 30 || p->cfg.plp_compression < 0.0f)

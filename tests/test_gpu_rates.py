@@ -64,3 +64,38 @@ def test_f0_chain_levels_at_rate(fs, oracle, at_rate):
         voiced += int((ref[:, 0] > 0).sum())
     assert voiced > 20, "the test signal should have voiced frames"
     b.close()
+
+
+EG_RATES = [8000, 22050, 32000, 44100, 48000]     # (11 025 Hz: cSpecResample's 20 ms frame gives 221 samples there -- refused)
+
+
+@pytest.mark.parametrize("fs", EG_RATES)
+def test_egemaps_lld_and_functionals_at_rate(fs, oracle, at_rate):
+    """The whole eGeMAPSv02 graph (BASELINE config 5) at another rate: 25-column LLD level and 88 functionals equal the oracle's
+    at that rate bit for bit (20 ms kernels on FFT 256 / 512 / 1024, F0 group / cHarmonics on FFT 512 ... 4096)."""
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    cfg = capi.egemapsv02_config()
+    cfg.sample_rate = float(fs)
+    plan = capi.Plan(ctx, cfg)
+    lens = [int(1.3 * fs) + 5, int(0.06 * fs), int(0.02 * fs) + 1, int(0.5 * fs)]
+    pcms = [synth.utterance(500 + i + fs % 11, n, fs) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, _ = b.run_host_egemaps(np.concatenate(pcms), taps=True)
+    at_rate(fs)
+    oracle.use_reference_fft(False)
+    fi = 0
+    for i, p in enumerate(pcms):
+        ref = oracle.egemaps_lld_chain(p)
+        got = lld[b.frame_offsets[i]:b.frame_offsets[i + 1]]
+        assert got.shape == ref.shape, (fs, i, got.shape, ref.shape)
+        d = bits(got) != bits(ref)
+        assert not d.any(), f"{fs} Hz utt {i}: {d.sum()} of {d.size} LLD cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))}"
+        rf = oracle.egemaps_func(p)
+        if rf.shape[0]:
+            d = bits(func[i]) != bits(rf[0])
+            assert not d.any(), f"{fs} Hz utt {i}: functionals {np.argwhere(d).ravel()[:20]} differ"
+            fi += 1
+    assert fi >= 2
+    b.close()
