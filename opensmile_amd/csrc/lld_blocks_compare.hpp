@@ -208,18 +208,33 @@ __device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot
   }
 }
 
-// spectral_frame for one wave (K = 257): no LDS scratch, no barriers. mg / pw / prev as above; sp[0..14] written by lane 0
-// (roll-off points by the lane that owns the crossing bin).
-// chain: 512 floats of LDS scratch (16-byte aligned) for the two float chains.
+// spectral_frame for one wave, K = 64 W + 1 bins (W = 4: the 512-point spectrum of 20 ms frames at 16 kHz, the tuned case; W = 2 / 8:
+// the 256- / 1024-point spectra of other sample rates): no LDS scratch, no barriers. mg / pw / prev as above; sp[0..14] written
+// by lane 0 (roll-off points by the lane that owns the crossing bin).
+// chain: 128 W floats of LDS scratch (16-byte aligned) for the two float chains.
+template <int NV, int W>
+__device__ __forceinline__ void wave_sumw(const double (&v)[W][NV], double (&tot)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const double sw = wave_first_d(wave_tree_d(v[w][i], [](double a, double b) { return a + b; }));   // the shuffle-down tree, lld_blocks.hpp
+      t = (w == 0) ? sw : t + sw;                        // ((s0 + s1) + s2) + s3 ...
+    }
+    tot[i] = t;
+  }
+}
+template <int W>
 __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float *pw, const float *prev, bool first,
                                                     const SpectralConsts &C, int K, float *chain, float *sp) {
   const double F0 = 1.0 / C.fsSec;
   const int lo = 1, hi = K - 1, nBins = K - 1;
   const int lane = threadIdx.x & 63;
-  float pf[4], tsh[4];
-  double p[4], fj[4], v1[4][6];
+  float pf[W], tsh[W];
+  double p[W], fj[W], v1[W][6];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < W; ++w) {
     const int tid = lane + 64 * w, j = tid + 1;
     pf[w] = pw[j];
     p[w] = (double)pf[w];
@@ -243,15 +258,15 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     }
   }
   double t1v[6];
-  wave_sum4<6>(v1, t1v);
+  wave_sumw<6, W>(v1, t1v);
   const double frameSum = t1v[0], sumA = t1v[1];
   float ctr = 0.0f;
   if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
   // roll-off: inclusive prefix in the block version's order (scan inside each group of 64, then + the earlier groups' totals)
   {
-    double c[4], red[4];
+    double c[W], red[W];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < W; ++w) {
       double x = p[w];
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
@@ -259,12 +274,12 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
       c[w] = x;
     }
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < W; ++w)
 #pragma unroll
       for (int w2 = 0; w2 < w; ++w2) c[w] += red[w2];
     const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < W; ++w) {
       const int tid = lane + 64 * w, j = tid + 1;
       const double up1 = __shfl_up(c[w], 1, 64);
       const double prev63 = __shfl(c[w > 0 ? w - 1 : 0], 63, 64);
@@ -277,15 +292,15 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     }
   }
   // harmonicity: alternating peaks/valleys, distance to the previous one
-  float hc[4];
+  float hc[W];
   {
-    float pk_val[4];
-    bool pk_has[4];
-    bool flag[4];
-    unsigned long long lower[4];
-    float prevw[4];
+    float pk_val[W];
+    bool pk_has[W];
+    bool flag[W];
+    unsigned long long lower[W];
+    float prevw[W];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < W; ++w) {
       const int j = lane + 64 * w + 1;
       flag[w] = false;
       if (j >= lo + 2 && j < hi - 1)
@@ -299,22 +314,22 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
       pk_val[w] = __shfl(pf[w], mask ? 63 - __clzll((long long)mask) : 0, 64);
     }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < W; ++w) {
       hc[w] = 0.0f;
       if (flag[w]) {
         if (lower[w]) hc[w] = fabsf(pf[w] - prevw[w]);
         else {
           bool found = false;
 #pragma unroll
-          for (int w2 = 3; w2 >= 0; --w2)
+          for (int w2 = W - 1; w2 >= 0; --w2)
             if (w2 < w && !found && pk_has[w2]) { hc[w] = fabsf(pf[w] - pk_val[w2]); found = true; }
         }
       }
     }
   }
-  double v2[4][5];
+  double v2[W][5];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < W; ++w) {
     const double entropy_floor = 0.0000001;
     double dn = frameSum;
     if (dn < (float)entropy_floor) dn = (float)entropy_floor;
@@ -328,20 +343,20 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     v2[w][4] = 0.0;
   }
   double t2v[5];
-  wave_sum4<5>(v2, t2v);
+  wave_sumw<5, W>(v2, t2v);
   // sharpness and harmonicity accumulate in FLOAT_DMEM, bin after bin (:1435-1471, :1485-1499): the terms go to LDS, lane 0
   // adds them in order. (Measured alternative: every lane walking the chains with 512 unrolled v_readlane + v_add was 17 %
   // slower for the whole kernel -- issue slots and registers -- than one lane reading float4s one block ahead.)
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < W; ++w) {
     chain[lane + 64 * w] = tsh[w];
-    chain[256 + lane + 64 * w] = hc[w];                 // |srcLP[j] - lastPeak| of a flagged bin, +0 elsewhere (s + 0 = s)
+    chain[64 * W + lane + 64 * w] = hc[w];                 // |srcLP[j] - lastPeak| of a flagged bin, +0 elsewhere (s + 0 = s)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     float sumAA_seq, ptp_seq;
-    seq_sum2_f32(chain, chain + 256, 256, sumAA_seq, ptp_seq);
+    seq_sum2_f32(chain, chain + 64 * W, 64 * W, sumAA_seq, ptp_seq);
     sp[0] = (float)(t1v[4] / (double)nBins);
     sp[1] = (float)(t1v[5] / (double)nBins);
     float c2 = 0.0f;

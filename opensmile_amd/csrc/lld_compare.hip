@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 // keeps the block kernel's order (lld_blocks_compare.hpp), so the two kernels give bit-identical rows.
 // LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave z[fft_pairs(M)] pairs | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // mel[32] | aud[32] | lmel[32]
+template <int W>                                       // K = 64 W + 1 bins: W = 4 at 16 kHz (FFT 512), 2 / 8 for FFT 256 / 1024
 __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, const CompareParams &Q, int n_runs, float *smem) {
   const int M = P.Nfft >> 1, K = P.K;
   const int Kpad = (K + 3) & ~3;
@@ -305,7 +306,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
         if (t < T60) rawA[3] = (float)tot[1] / (float)Q.N60;
       }
     }
-    spectral_frame_wave(mg, pw, prev, t == 0, SC, K, reinterpret_cast<float *>(z), rawB + 26);   // z: free between two transforms
+    spectral_frame_wave<W>(mg, pw, prev, t == 0, SC, K, reinterpret_cast<float *>(z), rawB + 26);   // z: free between two transforms
     WaveG::sync();
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
@@ -318,11 +319,17 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
 // 1000 x 10 s): there the two-wave build runs.
 __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  compare_frame_wave_body(P, Q, n_runs, smem);
+  compare_frame_wave_body<4>(P, Q, n_runs, smem);
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_wave3(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  compare_frame_wave_body(P, Q, n_runs, smem);
+  compare_frame_wave_body<4>(P, Q, n_runs, smem);
+}
+// the other spectrum sizes of 20 ms frames: FFT 256 (8 / 11.025 kHz), FFT 1024 (32 / 44.1 / 48 kHz)
+template <int W>
+__global__ void __launch_bounds__(256) lld_compare_frame_wave_g(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  compare_frame_wave_body<W>(P, Q, n_runs, smem);
 }
 
 // R8 with newRASTA (plp.cpp:434-439, 468-485, 490-497, 512-517): log -> 4-tap FIR + 1-pole IIR
@@ -466,9 +473,17 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if (n_runs <= 0) return hipSuccess;
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  if (P.Nfft != 512) return hipErrorInvalidValue;
-  static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks)
-  if (use_block) {
+  if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.K != M + 1 || P.N > P.Nfft) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
+  static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks, FFT 512)
+  if (P.Nfft != 512) {
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
+    if (!P.oo.tw) return hipErrorInvalidValue;            // (the own-order A/B transform exists for the tuned geometry only)
+    const void *fn = P.Nfft == 256 ? reinterpret_cast<const void *>(&lld_compare_frame_wave_g<2>) : reinterpret_cast<const void *>(&lld_compare_frame_wave_g<8>);
+    hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+    if (P.Nfft == 256) hipLaunchKernelGGL(lld_compare_frame_wave_g<2>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else hipLaunchKernelGGL(lld_compare_frame_wave_g<8>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+  } else if (use_block) {
     const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96) + sizeof(double) * (64 + 256) + 32 +
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);

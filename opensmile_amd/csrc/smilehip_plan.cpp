@@ -176,8 +176,9 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       return fail(SMILEHIP_ERR_INVALID, "IS09 chain needs 12 MFCC, one delta stage and an odd smaWin in 3..9");
   } else if (is_compare_ab_like(p->cfg)) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 14 || p->mel.n_bands != 26 || p->cfg.n_delta != 1 ||
-        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph || p->geo.Nfft != 512)
-      return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set");
+        p->cfg.delta_win != 2 || p->cfg.sma_win != 3 || !p->cfg.use_power || p->cfg.preemph ||
+        (p->geo.Nfft != 256 && p->geo.Nfft != 512 && p->geo.Nfft != 1024))
+      return fail(SMILEHIP_ERR_INVALID, "ComParE A+B chain: unsupported parameter set (20 ms frames at 8 .. 48 kHz)");
   } else if (p->cfg.chain_kind == SMILEHIP_CHAIN_EGEMAPS) {
     if (mask != SMILEHIP_STAGE_ALL || p->dct.n_mfcc != 4 || p->mel.n_bands != 26 || p->cfg.n_delta != 0 || p->cfg.sma_win != 3 ||
         !p->cfg.use_power || p->cfg.preemph || (p->geo.Nfft != 256 && p->geo.Nfft != 512 && p->geo.Nfft != 1024))

@@ -99,3 +99,36 @@ def test_egemaps_lld_and_functionals_at_rate(fs, oracle, at_rate):
             fi += 1
     assert fi >= 2
     b.close()
+
+
+@pytest.mark.parametrize("fs", RATES)
+def test_compare16_lld_and_functionals_at_rate(fs, oracle, at_rate):
+    """The whole ComParE_2016 graph (BASELINE config 4) at another rate: the 130-column LLD level equals the oracle's at that rate
+    bit for bit (A+B frame kernel on FFT 256 / 512 / 1024, F0 group on FFT 512 ... 4096); the 6373 functionals and the LLD level
+    equal the REAL binary's where it travelled to the box."""
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    cfg = capi.compare16_config()
+    cfg.sample_rate = float(fs)
+    plan = capi.Plan(ctx, cfg)
+    lens = [int(1.3 * fs) + 5, int(0.06 * fs), int(0.09 * fs) + 1, int(0.5 * fs), int(0.1 * fs)]
+    pcms = [synth.utterance(600 + i + fs % 11, n, fs) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    lld, func, _ = b.run_host_with_functionals16(np.concatenate(pcms))
+    at_rate(fs)
+    oracle.use_reference_fft(False)
+    for i, p in enumerate(pcms):
+        ref = oracle.compare_lld_chain(p)
+        got = lld[b.frame_offsets[i]:b.frame_offsets[i + 1]]
+        assert got.shape == ref.shape, (fs, i, got.shape, ref.shape)
+        d = bits(got) != bits(ref)
+        assert not d.any(), f"{fs} Hz utt {i}: {d.sum()} of {d.size} LLD cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))}"
+    if oracle.have_ref():
+        for i in (0, 3):
+            rf, rl = oracle.run_reference_func("compare16/ComParE_2016.conf", pcms[i], fs=fs)
+            got = lld[b.frame_offsets[i]:b.frame_offsets[i + 1]]
+            assert got.shape == rl.shape and not (bits(got) != bits(rl)).any(), f"{fs} Hz utt {i}: LLD level differs from the binary's"
+            d = bits(func[i]) != bits(rf[0])
+            assert not d.any(), f"{fs} Hz utt {i}: {d.sum()} of 6373 functionals differ from the binary's, first {np.argwhere(d).ravel()[:10]}"
+    b.close()
