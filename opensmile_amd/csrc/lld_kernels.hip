@@ -416,7 +416,11 @@ hipError_t launch_log_energy(const LldParams &P, const int32_t *d_tile_utt, cons
   if (P.total_frames <= 0 || n_tiles <= 0) return hipSuccess;
   const int span = (kEnFrames - 1) * P.H + P.N;
   const size_t lds = sizeof(float) * (size_t)((span / (P.H > 0 ? P.H : 1) + 2) * (P.H + 1));
-  if (lds > 60 * 1024) return hipErrorInvalidValue;      // frame geometry far outside the speech configs
+  if (lds > 150 * 1024) return hipErrorInvalidValue;     // frame geometry far outside the speech configs (25 ms / 10 ms at 48 kHz: 67 KB)
+  if (lds > 48 * 1024) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_log_energy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
   hipLaunchKernelGGL(lld_log_energy, dim3((unsigned)n_tiles), dim3(64), lds, s, P, d_tile_utt, d_tile_t0, kChainTile, dst, ld, col);
   return hipGetLastError();
 }

@@ -132,3 +132,93 @@ def test_compare16_lld_and_functionals_at_rate(fs, oracle, at_rate):
             d = bits(func[i]) != bits(rf[0])
             assert not d.any(), f"{fs} Hz utt {i}: {d.sum()} of 6373 functionals differ from the binary's, first {np.argwhere(d).ravel()[:10]}"
     b.close()
+
+
+@pytest.mark.parametrize("fs", RATES)
+def test_is09_lld_at_rate(fs, oracle, at_rate):
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    cfg = capi.is09_lld_config()
+    cfg.sample_rate = float(fs)
+    plan = capi.Plan(ctx, cfg)
+    lens = [int(1.1 * fs) + 5, int(0.025 * fs), int(0.3 * fs)]
+    pcms = [synth.utterance(700 + i + fs % 11, n, fs) for i, n in enumerate(lens)]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b = capi.Batch(plan, off)
+    out = b.run_host(np.concatenate(pcms))
+    at_rate(fs)
+    oracle.use_reference_fft(False)
+    for i, p in enumerate(pcms):
+        ref = oracle.is09_chain(p)
+        got = out[b.frame_offsets[i]:b.frame_offsets[i + 1]]
+        assert got.shape == ref.shape, (fs, i, got.shape, ref.shape)
+        d = bits(got) != bits(ref)
+        assert not d.any(), f"{fs} Hz utt {i}: {d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))}"
+    b.close()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
+REF = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
+REF_CONF = os.path.join(ROOT, "oracle", "_ref", "config")
+
+
+@pytest.mark.parametrize("set_name,conf,opts", [
+    ("egemapsv02", "egemaps/v02/eGeMAPSv02.conf", ["-lldhtkoutput", "-htkoutput"]),
+    ("compare16", "compare16/ComParE_2016.conf", ["-lldhtkoutput", "-htkoutput"]),
+    ("is13_compare", "is09-13/IS13_ComParE.conf", ["-lldhtkoutput", "-htkoutput"]),
+    ("is09_emotion", "is09-13/IS09_emotion.conf", ["-lldhtkoutput"]),
+    ("mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf", ["-O"]),
+    ("plp_e_d_a_z", "plp/PLP_E_D_A_Z.conf", ["-O"]),
+])
+def test_smilextract_hip_mixed_rate_list_equals_binary(set_name, conf, opts, tmp_path):
+    """One file list holding 8 / 16 / 22.05 / 44.1 / 48 kHz files (one of them 24-bit stereo): one plan per rate, every output
+    file equal to the real binary's byte for byte."""
+    import subprocess
+    import wave
+    from opensmile_amd import synth
+    from test_gpu_f32_input import write_wav_fmt, _samples
+    if not (os.path.exists(REF) and os.path.exists(EXE) and os.path.isdir(REF_CONF)):
+        pytest.skip("oracle/_ref/SMILExtract (+ config/) or smilextract_hip not built")
+    wavs = []
+    for k, fs in enumerate([44100, 8000, 16000, 48000, 22050, 44100]):
+        w = str(tmp_path / f"r{k}_{fs}.wav")
+        n = int(fs * (1.0 + 0.2 * k)) + k
+        if k == 5:
+            write_wav_fmt(w, _samples(40 + k, n, 2, 3, 24), fs, 3, 24)
+        else:
+            with wave.open(w, "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(fs)
+                f.writeframes(synth.utterance(800 + k, n, fs).astype("<i2").tobytes())
+        wavs.append(w)
+    example = os.path.join(ROOT, "oracle", "_ref", "opensmile.wav")      # the reference's example-audio/opensmile.wav (44.1 kHz; SURVEY 8(c) config 1)
+    if os.path.exists(example):
+        wavs.append(example)
+    for i, w in enumerate(wavs):
+        args = [REF, "-C", os.path.join(REF_CONF, conf), "-I", w, "-l", "0"]
+        for o in opts:
+            args += [o, str(tmp_path / f"ref{i}{o}.htk")]
+        subprocess.run(args, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(w + "\n" for w in wavs))
+    outdir = tmp_path / "own"
+    outdir.mkdir()
+    args = [EXE, "--set", set_name, "-filelist", str(lst), "-outdir", str(outdir)]
+    for o in opts:
+        args += [o, "on"]
+    env = dict(os.environ)
+    if not opts[0].startswith("-lld"):
+        # cepstral sets: 16-bit mono files at 16 kHz normally take the fast 512-point kernel, whose transform has its own order
+        # (within 3e-7 of the reference, tests/test_gpu_mfcc.py); byte identity is the reference-order kernel's property
+        env["SMILEHIP_FORCE_GENERIC"] = "1"
+    r = subprocess.run(args, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lld = set_name in ("is09_emotion", "egemapsv02", "compare16", "is13_compare")
+    ext = {"-O": ".htk", "-lldhtkoutput": ".lld.htk" if lld else ".htk", "-htkoutput": ".func.htk"}
+    for i, w in enumerate(wavs):
+        base = os.path.splitext(os.path.basename(w))[0]
+        for o in opts:
+            ref = open(tmp_path / f"ref{i}{o}.htk", "rb").read()
+            own = open(outdir / (base + ext[o]), "rb").read()
+            assert len(ref) > 12
+            assert own == ref, f"{set_name} {os.path.basename(w)} {o}: files differ ({len(own)} vs {len(ref)} bytes)"

@@ -65,6 +65,11 @@ def test_two_batches_on_two_streams_match_serial_results():
     bb.close()
 
 
+def _rate(cfg, fs):
+    cfg.sample_rate = fs
+    return cfg
+
+
 def test_error_paths_fail_loudly():
     from opensmile_amd import capi
     L = capi.load()
@@ -80,13 +85,18 @@ def test_error_paths_fail_loudly():
     with pytest.raises(capi.SmileHipError):
         capi.Plan(ctx, cfg)
     cfg = capi.compare16_f0_config()
-    cfg.sample_rate = 44100.0                            # 60 ms -> 4096-point spectrum: the F0 kernels are not built for it
-    with pytest.raises(capi.SmileHipError, match="1024-point"):
+    cfg.sample_rate = 96000.0                            # 60 ms -> 8192-point spectrum: the F0 kernels are instantiated up to 4096 (48 kHz)
+    with pytest.raises(capi.SmileHipError, match="512 .. 4096"):
         capi.Plan(ctx, cfg)
     cfg = capi.compare16_config()
-    cfg.sample_rate = 44100.0                            # (the 20 ms part refuses first: 1024 instead of 512 points)
+    cfg.sample_rate = 96000.0                            # (the 20 ms part refuses first: 2048 points)
     with pytest.raises(capi.SmileHipError):
         capi.Plan(ctx, cfg)
+    cfg = capi.egemapsv02_config()
+    cfg.sample_rate = 11025.0                            # cSpecResample would give 221 samples per 20 ms frame: not the kernel's 220
+    with pytest.raises(capi.SmileHipError):
+        capi.Plan(ctx, cfg)
+    capi.Plan(ctx, _rate(capi.compare16_config(), 44100.0)).close()     # the rates of tests/test_gpu_rates.py build
     plan = capi.Plan(ctx)
     with pytest.raises(capi.SmileHipError):
         capi.Batch(plan, np.array([0, 100, 50], np.int64))        # offsets must be non-decreasing

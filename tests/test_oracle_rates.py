@@ -43,3 +43,37 @@ def ref_frame(fs, sec):
     """cFramer's frame size / step in samples (winToVecProcessor.cpp:435-456: round(sec / T), T = 1.0 / fs as a double)."""
     import math
     return int(math.floor(sec / (1.0 / fs) + 0.5))
+
+
+@pytest.mark.parametrize("fs", RATES)
+def test_compare16_lld_level_at_rate(fs, at_rate):
+    from opensmile_amd import synth
+    pcm = synth.utterance(3 + fs % 3, int(1.5 * fs) + 11, fs)
+    ref = lldo.run_reference_lld("compare16/ComParE_2016.conf", pcm, fs=fs)
+    at_rate(fs)
+    lldo.use_reference_fft(False)
+    out = lldo.compare_lld_chain(pcm)
+    assert out.shape == ref.shape == (ref.shape[0], 130) and np.array_equal(bits(out), bits(ref))
+
+
+@pytest.mark.parametrize("fs", [8000, 22050, 32000, 44100, 48000])     # (11 025 Hz: see tests/test_gpu_rates.py)
+def test_egemaps_lld_and_functionals_at_rate(fs, at_rate):
+    from opensmile_amd import synth
+    pcm = synth.utterance(4 + fs % 3, int(1.5 * fs) + 11, fs)
+    ref = lldo.run_reference_egemaps(pcm, fs=fs)
+    at_rate(fs)
+    lldo.use_reference_fft(False)
+    lld, fn = lldo.egemaps_lld_chain(pcm), lldo.egemaps_func(pcm)
+    assert lld.shape == ref["lld"].shape and np.array_equal(bits(lld), bits(ref["lld"]))
+    assert fn.shape == ref["func"].shape == (1, 88) and np.array_equal(bits(fn), bits(ref["func"]))
+
+
+@pytest.mark.parametrize("fs", RATES)
+def test_is09_lld_level_at_rate(fs, at_rate):
+    from opensmile_amd import synth
+    pcm = synth.utterance(5 + fs % 3, int(1.2 * fs) + 3, fs)
+    ref = lldo.run_reference_lld("is09-13/IS09_emotion.conf", pcm, fs=fs)
+    at_rate(fs)
+    lldo.use_reference_fft(False)
+    out = lldo.is09_chain(pcm)
+    assert out.shape == ref.shape and np.array_equal(bits(out), bits(ref))
