@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--sets", default="is09,compare")
     ap.add_argument("--func", action="store_true", help="compare_full / egemaps: also time the set's functionals level")
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length (config 5 of BASELINE.json: 3)")
+    ap.add_argument("--rate", type=int, default=16000, help="sample rate of the synthetic corpus (the big sets run at 8 .. 48 kHz)")
     args = ap.parse_args()
     import torch
     from opensmile_amd import capi, synth
     ctx = capi.Context(0)
-    pcm, off = synth.corpus_tiled(args.utts, int(round(args.seconds * 16000)), n_unique=32)
+    pcm, off = synth.corpus_tiled(args.utts, int(round(args.seconds * args.rate)), n_unique=32, fs=args.rate)
     d_pcm = torch.from_numpy(pcm).cuda()
     for name in args.sets.split(","):
         if name.upper() in ("MFCC12_E_D_A", "MFCC12_0_D_A_Z", "MFCC12_E_D_A_Z", "PLP_E_D_A", "PLP_0_D_A_Z", "PLP_E_D_A_Z"):
@@ -34,6 +35,7 @@ def main():
         cfg = cfg_fn() if cfg_fn else {"is09": capi.is09_lld_config, "compare": capi.compare16_ab_config, "mfcc": capi.mfcc12_0_d_a_config,
                "plp": capi.plp_0_d_a_config, "f0": capi.compare16_f0_config, "compare_full": capi.compare16_config,
                "egemaps": capi.egemapsv02_config}[name]()
+        cfg.sample_rate = float(args.rate)
         plan = capi.Plan(ctx, cfg)
         b = capi.Batch(plan, off)
         n_out = plan.geometry.n_out
@@ -47,7 +49,7 @@ def main():
             b.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, st)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        rec = {"set": name, "utterances": args.utts, "seconds": args.seconds, "frames": b.total_frames, "rows": rows, "cols": n_out,
+        rec = {"set": name, "rate": args.rate, "utterances": args.utts, "seconds": args.seconds, "frames": b.total_frames, "rows": rows, "cols": n_out,
                "ms_per_step": dt * 1e3, "frames_per_s": b.total_frames / dt}
         if name == "compare_full" and args.func:
             # the functionals level on top (6373 values per utterance), LLD matrix resident
