@@ -152,6 +152,9 @@ typedef struct smilehip_lld_config {
    * GeMAPS; <= 40) and cPitchJitter searchRangeRel (src/lld/pitchJitter.cpp:632-637; 0 = 0.25 as in ComParE_2016, 0.1 in GeMAPS) */
   int32_t  vit_buffer_len;
   double   jitter_search_range;
+  /* SMILEHIP_CHAIN_EGEMAPS: cFormantLpc maxF (src/lld/formantLpc.cpp:224-231; 0 = 5450 as in GeMAPSv01b / eGeMAPSv02, 5500 in the
+   * v01a files) */
+  double   formant_max_freq;
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
@@ -228,6 +231,11 @@ void smilehip_config_is13_compare(smilehip_lld_config *c);
 
 /* fills c with the LLD level of config/egemaps/v02/eGeMAPSv02.conf (chain_kind = EGEMAPS, 25 columns) */
 void smilehip_config_egemapsv02(smilehip_lld_config *c);
+/* ... with the option values of the v01a files (config/gemaps/v01a/GeMAPSv01a_core.lld.conf.inc: zeroPadSymmetric = 0 in both
+ * cTransformFFT instances :34,67, useBrokenJitterThresh = 1 :199, cFormantLpc maxF = 5500 :281; everything else is the v01b /
+ * v02 graph): GeMAPSv01a.conf and eGeMAPSv01a.conf write column subsets of this level and of its 88 functionals, the same
+ * subsets GeMAPSv01b.conf / eGeMAPSv01b.conf take of eGeMAPSv02's */
+void smilehip_config_egemapsv01a(smilehip_lld_config *c);
 
 /* F0 group, per component, on an F0 chain plan (smilehip_config_compare16_f0; the plan's spectrum geometry -- n_bins and
  * the level's frameSizeSec, force_fft_frame_size_sec -- must be the input level's):

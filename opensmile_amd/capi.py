@@ -42,7 +42,7 @@ class LldConfig(C.Structure):
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
         ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
-        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double),
+        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double),
     ]
 
 
@@ -113,6 +113,7 @@ SYMBOLS = {
     "smilehip_batch_functionals_is13_compare": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "smilehip_config_is13_compare": (None, [_vp]),
     "smilehip_config_egemapsv02": (None, [C.POINTER(LldConfig)]),
+    "smilehip_config_egemapsv01a": (None, [C.POINTER(LldConfig)]),
     "smilehip_funcspec_egemaps": (C.c_int, [C.c_char_p, _vp]),
     "smilehip_functionals_egemaps_count": (C.c_int, []),
     "smilehip_batch_functionals_egemaps": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -245,6 +246,13 @@ def egemapsv02_config():
     """config/egemaps/v02/eGeMAPSv02.conf (BASELINE config 5): the 25-column LLD level."""
     c = LldConfig()
     load().smilehip_config_egemapsv02(C.byref(c))
+    return c
+
+
+def egemapsv01a_config():
+    """The eGeMAPSv02 graph with the v01a files' option values (GeMAPSv01a.conf / eGeMAPSv01a.conf write column subsets of it)."""
+    c = LldConfig()
+    load().smilehip_config_egemapsv01a(C.byref(c))
     return c
 
 

@@ -592,7 +592,8 @@ void gemaps_plan_consts(const smilehip_plan *plan, GemapsParams &G) {
   G.rs_cos = plan->d_rs_cos.p; G.rs_sin = plan->d_rs_sin.p;
   G.rs_norm = (float)(plan->geo.Nfft / 2);
   G.fm_T = 1.0 / plan->gm_target_fs;   // cSpecResample::configureWriter: basePeriod = 1 / targetFs
-  G.fm_min = 50.0; G.fm_max = 5450.0;  // [gemapsv01b_formantLpc]
+  G.fm_min = 50.0;                     // [gemapsv01b_formantLpc] minF; maxF 5450 (v01b / v02) or 5500 (v01a)
+  G.fm_max = plan->cfg.formant_max_freq > 0.0 ? plan->cfg.formant_max_freq : 5450.0;
   G.fsSec60 = plan->f0_plan->geo.fft_frame_size_sec;
   G.lpc_ld = 12; G.fm_ld = 10;
 }

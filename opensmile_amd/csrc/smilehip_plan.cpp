@@ -144,6 +144,13 @@ extern "C" void smilehip_config_egemapsv02(smilehip_lld_config *c) {
   c->jitter_search_range = 0.1;      // [gemapsv01b_pitchJitter] searchRangeRel
 }
 
+extern "C" void smilehip_config_egemapsv01a(smilehip_lld_config *c) {
+  smilehip_config_egemapsv02(c);
+  c->zero_pad_symmetric = 0;         // [gemapsv01a_fft60] / [gemapsv01a_fft25]: "for compatibility with 2.2.0 and older versions"
+  c->jitter_broken_thresh = 1;       // [gemapsv01a_pitchJitter]
+  c->formant_max_freq = 5500.0;      // [gemapsv01a_formantLpc]
+}
+
 static inline bool is_compare_ab_like(const smilehip_lld_config &c) {
   return c.chain_kind == SMILEHIP_CHAIN_COMPARE_AB || c.chain_kind == SMILEHIP_CHAIN_COMPARE;
 }
@@ -491,6 +498,7 @@ extern "C" int smilehip_plan_create(smilehip_context *ctx, const smilehip_lld_co
     c60.f0_min_energy = cfg->f0_min_energy;
     c60.vit_buffer_len = cfg->vit_buffer_len;
     c60.jitter_search_range = cfg->jitter_search_range;
+    c60.jitter_broken_thresh = cfg->jitter_broken_thresh;
     rc = smilehip_plan_create(ctx, &c60, &p->f0_plan);
     if (rc == SMILEHIP_OK && (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess ||
                               hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -351,6 +351,9 @@ const KnownSet kKnownSets[] = {
     // sub-graphs of eGeMAPSv02.conf: their levels are column subsets of its levels (smilehip_host.hpp, egemaps_subset_columns)
     {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf", 0xd9d453405c7cfe69ull},
     {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf", 0x4bea506faa49e282ull},
+    // the v01a files: the same sub-graphs with zeroPadSymmetric = 0, useBrokenJitterThresh = 1, maxF = 5500 (smilehip_config_egemapsv01a)
+    {0x54c6dceabc3deb6full, "gemapsv01a", "GeMAPSv01a.conf", 0x903089c642c22b56ull},
+    {0x378e8dfc3678ce85ull, "egemapsv01a", "eGeMAPSv01a.conf", 0x554f699baa400cd4ull},
 };
 }  // namespace
 

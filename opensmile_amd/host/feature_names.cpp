@@ -190,12 +190,12 @@ std::vector<std::string> func_names_egemaps() {
 }
 
 std::vector<int> egemaps_subset_columns(const std::string &set, bool func) {
-  if (set == "gemapsv01b") {
+  if (set == "gemapsv01b" || set == "gemapsv01a") {      // (the v01a files: the same columns of the graph run with their option values)
     if (!func) return {0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 24};       // no flux, no MFCC, no F2 / F3 bandwidth
     return {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43,
             44, 45, 46, 47, 50, 51, 52, 53, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 76, 77, 78, 79, 81, 82, 83, 84, 85, 86};
   }
-  if (set == "egemapsv01b") {
+  if (set == "egemapsv01b" || set == "egemapsv01a") {
     std::vector<int> c;
     const int n = func ? 88 : 25;
     for (int i = 0; i < n; ++i)

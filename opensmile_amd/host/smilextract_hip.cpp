@@ -13,6 +13,7 @@
 //   smilextract_hip --set compare16     same options as is09_emotion: the whole ComParE_2016.conf, LLD level + 6373 functionals
 //   smilextract_hip --set is13_compare  the same for config/is09-13/IS13_ComParE.conf
 //   smilextract_hip --set egemapsv02    the whole config/egemaps/v02/eGeMAPSv02.conf: 25-column LLD level + 88 functionals
+//   smilextract_hip --set gemapsv01a | egemapsv01a   the v01a files: the same columns, zeroPadSymmetric = 0, useBrokenJitterThresh = 1, maxF = 5500
 //   smilextract_hip --set gemapsv01b | egemapsv01b   config/gemaps/v01b/GeMAPSv01b.conf (18 LLDs, 62 functionals) / config/egemaps/v01b/
 //                                       eGeMAPSv01b.conf (23, 88): sub-graphs of eGeMAPSv02.conf, written as column subsets of its levels
 //                   [-htkoutput func.htk] [-lldcsvoutput lld.csv] [-lldhtkoutput lld.htk]
@@ -194,7 +195,9 @@ int main(int argc, char **argv) {
   const bool cmp16f = set == "compare16" || is13;              // the whole ComParE_2016.conf: LLD level + 6373 functionals
   const bool cmp16 = set == "compare16_lld" || cmp16f;
   // GeMAPSv01b.conf / eGeMAPSv01b.conf: sub-graphs of eGeMAPSv02.conf -- the v02 chain runs, the set's columns are written
-  const bool egm_subset = set == "gemapsv01b" || set == "egemapsv01b";
+  // GeMAPSv01a.conf / eGeMAPSv01a.conf: the same sub-graphs with three option values of openSMILE 2.2 (smilehip_config_egemapsv01a)
+  const bool egm_v01a = set == "gemapsv01a" || set == "egemapsv01a";
+  const bool egm_subset = set == "gemapsv01b" || set == "egemapsv01b" || egm_v01a;
   const bool egm = set == "egemapsv02" || egm_subset;            // config/egemaps/v02/eGeMAPSv02.conf
   const std::vector<int> sel_lld = egemaps_subset_columns(set, false), sel_func = egemaps_subset_columns(set, true);
   if (egm_subset && gather) die("--gather is not available with --set " + set + " (gather the eGeMAPSv02 vectors and select)");
@@ -207,7 +210,7 @@ int main(int argc, char **argv) {
   const bool htk_variant = free_chain || (!is09 && !cmp16 && !egm && smilehip_config_htk_variant(&vcfg, variant.c_str()) == SMILEHIP_OK);
   const bool plp = htk_variant && vcfg.chain_kind == SMILEHIP_CHAIN_PLP;
   if (!is09 && !cmp16 && !egm && !htk_variant)
-    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare, egemapsv02, gemapsv01b or egemapsv01b (or use -C file.conf)");
+    die("--set must be mfcc12_{0,e}_d_a[_z], plp_{0,e}_d_a[_z], is09_emotion, compare16, compare16_lld, is13_compare, egemapsv02, gemapsv01b, egemapsv01b, gemapsv01a or egemapsv01a (or use -C file.conf)");
   // parmKind of the files' own cHtkSink sections (the _Z files); the others write through standard_data_output_lldonly (9)
   int parm_kind = 9;
   if (variant == "MFCC12_0_D_A_Z") parm_kind = 11014;
@@ -362,6 +365,7 @@ int main(int argc, char **argv) {
         if (is09) smilehip_config_is09_lld(&cfg);
         else if (is13) smilehip_config_is13_compare(&cfg);
         else if (cmp16) smilehip_config_compare16(&cfg);
+        else if (egm_v01a) smilehip_config_egemapsv01a(&cfg);
         else if (egm) smilehip_config_egemapsv02(&cfg);
         else cfg = vcfg;
         if (with_conf) conf_apply_f0_params(conf_plan, cfg);     // an edited big-set file: its own pitch range, harmonics, buffer ...

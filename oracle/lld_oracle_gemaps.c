@@ -674,6 +674,13 @@ void lldo_egemaps_levels_free(lldo_egemaps_lv *L)
 
 /* Every per-frame level of config/gemaps/v01b/GeMAPSv01b_core.lld.conf.inc + config/egemaps/v02/eGeMAPSv02_core.lld.conf.inc
  * for one utterance (16 kHz): 20 ms Hamming frames (T20) and 60 ms Gauss frames (T60), step 10 ms. Returns T60. */
+/* GeMAPSv01a / eGeMAPSv01a instead of v01b / v02: the same graph with three option values of openSMILE 2.2 kept for compatibility
+ * (config/gemaps/v01a/GeMAPSv01a_core.lld.conf.inc:34,67 zeroPadSymmetric = 0 in both cTransformFFT instances, :199
+ * useBrokenJitterThresh = 1, :281 maxF = 5500.0 in cFormantLpc) */
+static int g_lldo_gemaps_v01a = 0;
+void lldo_gemaps_set_v01a(int on) { g_lldo_gemaps_v01a = on ? 1 : 0; }
+extern int g_lldo_is13;     /* lld_oracle_compare.c; read by the jitter restatement for useBrokenJitterThresh */
+
 long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
 {
   memset(L, 0, sizeof(*L));
@@ -723,7 +730,7 @@ long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
     const float *src = x + t * g.H;
     L->energy2[t] = lldo_energy2(src, g.N);                          /* [egemapsv02_energyRMS] on gemapsv01b_frame25 */
     lldo_window_apply(src, fr, g.N, w, 0.0);
-    lldo_rfft_frame(fr, g.N, sp, g.Nfft, 1);
+    lldo_rfft_frame(fr, g.N, sp, g.Nfft, g_lldo_gemaps_v01a ? 0 : 1);
     lldo_fftmag(sp, g.Nfft, mg);
     lldo_melspec(&mel1, mg, mb);
     lldo_plp_audspec(&plp, mb, aud);                                 /* [gemapsv01b_audspec] */
@@ -735,7 +742,7 @@ long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
     lldo_mfcc(&dct, mb, L->mfcc + 4 * t);
     lldo_specresample_frame(&rs, sp, res);                           /* [gemapsv01b_resampLpc] on the complex spectrum */
     lldo_lpc_acf(res, rs.I, 11, lpc);                                /* [gemapsv01b_lpc] p = 11 */
-    lldo_formant_lpc(lpc, 11, 5, 1.0 / rs.target_fs, 50.0, 5450.0, roots, L->formants + 10 * t);
+    lldo_formant_lpc(lpc, 11, 5, 1.0 / rs.target_fs, 50.0, g_lldo_gemaps_v01a ? 5500.0 : 5450.0, roots, L->formants + 10 * t);
   }
   lldo_mel_free(&mel1); lldo_mel_free(&mel2); lldo_mfcc_free(&dct); lldo_plp_free(&plp); lldo_gspec_free(&gs);
   lldo_specresample_free(&rs);
@@ -760,7 +767,7 @@ long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
     for (long t = 0; t < T; t++) {
       lldo_window_apply(x + t * g60.H, fr, g60.N, w, 0.0);
       L->e60[t] = lldo_energy_rms(fr, g60.N);                        /* [gemapsv01b_energy60] on winG60 */
-      lldo_rfft_frame(fr, g60.N, sp, g60.Nfft, 1);
+      lldo_rfft_frame(fr, g60.N, sp, g60.Nfft, g_lldo_gemaps_v01a ? 0 : 1);
       lldo_fftmag(sp, g60.Nfft, mags + t * g60.K);
       lldo_specscale_frame(&ss, mags + t * g60.K, hp);
       lldo_pitch_shs(&sh, hp, L->shs + 21 * t, NULL);
@@ -778,7 +785,10 @@ long lldo_egemaps_levels(const int16_t *pcm, long n_samples, lldo_egemaps_lv *L)
       f0[t] = f;
     }
     float *j4 = (float *)malloc(sizeof(float) * 4 * (size_t)T), *sdb = (float *)malloc(sizeof(float) * (size_t)T);
-    lldo_pitch_jitter_ex(x, n_samples, f0, T, g60.N, g60.H, c.sample_rate, c.frame_step_sec, 0.1, j4, sdb);
+    { const int keep = g_lldo_is13;
+      if (g_lldo_gemaps_v01a) g_lldo_is13 = 1;                        /* useBrokenJitterThresh = 1 */
+      lldo_pitch_jitter_ex(x, n_samples, f0, T, g60.N, g60.H, c.sample_rate, c.frame_step_sec, 0.1, j4, sdb);
+      g_lldo_is13 = keep; }
     for (long t = 0; t < T; t++) {
       L->jitter[2 * t] = j4[4 * t]; L->jitter[2 * t + 1] = sdb[t];
       lldo_harmonics_frame(f0[t], L->formants + 10 * t, 5, mags + t * g60.K, g60.K, g60.frame_size_sec_fft, L->harm + 6 * t);

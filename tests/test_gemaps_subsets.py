@@ -69,3 +69,43 @@ def test_smaller_gemaps_sets_are_column_subsets_of_v02(tmp_path):
             if f.shape[0]:
                 assert fn == [fn2[c] for c in cf]
                 assert np.array_equal(f.view(np.uint32), f2[:, cf].view(np.uint32)), (setname, w)
+
+
+@needs_ref
+def test_v01a_sets_equal_the_oracle_in_v01a_mode(tmp_path):
+    """GeMAPSv01a.conf / eGeMAPSv01a.conf: the v01b sub-graphs with three option values of openSMILE 2.2 (zeroPadSymmetric = 0 in both
+    cTransformFFT instances, useBrokenJitterThresh = 1, cFormantLpc maxF = 5500). The oracle's eGeMAPS chain with those values
+    (lldo_gemaps_set_v01a), cut down to the sets' columns, is the binary's output bit for bit -- LLD level and functionals."""
+    from test_host_io import build_hostlib
+    from opensmile_amd import synth
+    from oracle import lldo
+    L = build_hostlib()
+    L.shim_egemaps_subset.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+
+    def cols(setname, func):
+        out = (C.c_int * 128)()
+        n = L.shim_egemaps_subset(setname.encode(), func, out, 128)
+        return list(out[:n])
+
+    assert cols("gemapsv01a", 0) == cols("gemapsv01b", 0) and cols("egemapsv01a", 1) == list(range(88))
+    lib = lldo.lib()
+    differs = 0
+    for i, n in enumerate((48000, 30000, 9000)):
+        pcm = synth.utterance(60 + i, n)
+        w = str(tmp_path / f"a{i}.wav")
+        lldo.write_wav(w, pcm)
+        lib.lldo_gemaps_set_v01a(1)
+        try:
+            lld, fn = lldo.egemaps_lld_chain(pcm), lldo.egemaps_func(pcm)
+        finally:
+            lib.lldo_gemaps_set_v01a(0)
+        differs += int(not np.array_equal(lld, lldo.egemaps_lld_chain(pcm)))
+        for setname, conf in (("gemapsv01a", "gemaps/v01a/GeMAPSv01a.conf"), ("egemapsv01a", "egemaps/v01a/eGeMAPSv01a.conf")):
+            x, f, names, fnames = run_ref(conf, w, str(tmp_path), setname)
+            cl, cf = cols(setname, 0), cols(setname, 1)
+            assert x.shape == (lld.shape[0], len(cl)), (setname, x.shape, lld.shape)
+            assert np.array_equal(x.view(np.uint32), np.ascontiguousarray(lld[:, cl]).view(np.uint32)), (setname, i)
+            assert f.shape[0] == fn.shape[0]
+            if f.shape[0]:
+                assert np.array_equal(f.view(np.uint32), np.ascontiguousarray(fn[:, cf]).view(np.uint32)), (setname, i)
+    assert differs >= 2            # the option values matter: the v02 chain gives other numbers

@@ -520,3 +520,38 @@ def test_smilextract_hip_gemaps_subsets(tmp_path):
             fn2 = [l.split()[1] for l in open(os.path.join(G, "egemaps_func_u3.arff")).read().split("@data")[0].split("\n") if l.startswith("@attribute")][1:-1]
             fn = [l.split()[1] for l in ref.split("@data")[0].split("\n") if l.startswith("@attribute")][1:-1]
             assert len(fn) == n_f and np.array_equal(f.view(np.uint32), f2[:, [fn2.index(n) for n in fn]].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_gemaps_v01a_sets_equal_binary(tmp_path):
+    """--set gemapsv01a / egemapsv01a and -C <their files>: GeMAPSv01a.conf / eGeMAPSv01a.conf (the v01b sub-graphs with
+    zeroPadSymmetric = 0, useBrokenJitterThresh = 1, maxF = 5500): LLD and functionals HTK files equal the real binary's byte for
+    byte, at 16 kHz and at 44.1 kHz."""
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
+    conf_dir = os.path.join(ROOT, "oracle", "_ref", "config")
+    if not (os.path.exists(ref_exe) and os.path.isdir(conf_dir)):
+        pytest.skip("oracle/_ref/SMILExtract (+ config/) not built")
+    import wave
+    sys.path.insert(0, ROOT)
+    from opensmile_amd import synth
+    wavs = []
+    for k, (fs, n) in enumerate(((16000, 40000), (44100, 70000), (16000, 9000))):
+        w = str(tmp_path / f"a{k}.wav")
+        with wave.open(w, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(fs)
+            f.writeframes(synth.utterance(90 + k, n, fs).astype("<i2").tobytes())
+        wavs.append(w)
+    for setname, conf in (("gemapsv01a", "gemaps/v01a/GeMAPSv01a.conf"), ("egemapsv01a", "egemaps/v01a/eGeMAPSv01a.conf")):
+        for k, w in enumerate(wavs):
+            rl, rf = str(tmp_path / f"ref_{setname}{k}.lld.htk"), str(tmp_path / f"ref_{setname}{k}.func.htk")
+            subprocess.run([ref_exe, "-C", os.path.join(conf_dir, conf), "-I", w, "-lldhtkoutput", rl, "-htkoutput", rf, "-l", "0"],
+                           check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for how in (["--set", setname], ["-C", os.path.join(conf_dir, conf)]):
+                ol, of = str(tmp_path / "own.lld.htk"), str(tmp_path / "own.func.htk")
+                for p in (ol, of):
+                    if os.path.exists(p):
+                        os.remove(p)
+                r = subprocess.run([EXE] + how + ["-I", w, "-lldhtkoutput", ol, "-htkoutput", of], capture_output=True)
+                assert r.returncode == 0, r.stderr.decode()[-1500:]
+                assert open(ol, "rb").read() == open(rl, "rb").read(), (setname, k, how[0], "LLD level")
+                assert open(of, "rb").read() == open(rf, "rb").read(), (setname, k, how[0], "functionals")
