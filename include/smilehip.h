@@ -538,6 +538,29 @@ int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t
  * Full scales: 127, 32767, 32767*256, 2147483647. The fused batch path takes 16-bit mono. */
 int smilehip_pcm_convert(smilehip_context *ctx, const void *d_raw, int n_bps, int n_bits, int n_chan, int mono_mixdown,
                          int64_t n, float *d_out, void *stream);
+/* R4 with inverse = 1 (src/dspcore/transformFft.cpp:196-216): rows of fft_size packed spectrum values (a[0] = X[0], a[1] = X[N/2],
+ * a[2k] = Re, a[2k+1] = -Im, Ooura's packing) -> rdft(N, -1) -> fft_size samples, each times (FLOAT_DMEM)2 / N. The reference's bits. */
+int smilehip_irfft_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_frames,
+                          void *stream);
+/* R5, every output mode of cFFTmagphase::processVector (src/dspcore/fftmagphase.cpp:215-287). flags: 1 magnitude, 2 phase,
+ * 4 normalise, 8 power, 16 dBpsd (with dbp_norm = dBpnorm and min_dbp = mindBp, :129-131). Rows of nfft packed values ->
+ * [magnitude field (nfft/2 + 1) | phase field (nfft/2 + 1)], whichever were asked for (magnitude + phase together = joinMagphase). */
+#define SMILEHIP_MAGPHASE_MAGNITUDE 1
+#define SMILEHIP_MAGPHASE_PHASE 2
+#define SMILEHIP_MAGPHASE_NORMALISE 4
+#define SMILEHIP_MAGPHASE_POWER 8
+#define SMILEHIP_MAGPHASE_DBPSD 16
+int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t nfft, int32_t flags, float dbp_norm,
+                                float min_dbp, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R12, every output of cMZcr::processVector (src/lldcore/mzcr.cpp:108-150). flags: 1 zcr, 2 mcr, 4 amax, 8 maxmin, 16 dc; the row
+ * holds the selected values in that order (maxmin: max, min), as floats. */
+#define SMILEHIP_MZCR_ZCR 1
+#define SMILEHIP_MZCR_MCR 2
+#define SMILEHIP_MZCR_AMAX 4
+#define SMILEHIP_MZCR_MAXMIN 8
+#define SMILEHIP_MZCR_DC 16
+int smilehip_mzcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames, int32_t flags,
+                         float *d_dst, int64_t ld_dst, void *stream);
 /* R2: cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107) */
 int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
                                 int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream);

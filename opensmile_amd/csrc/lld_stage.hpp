@@ -26,6 +26,12 @@ hipError_t stage_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, in
 // second set (lld_stage2_kernels.hip): R9, R10, R12, R13 one component at a time
 hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s);
 hipError_t stage_zcr_count(const float *src, int64_t lds, int64_t N, int64_t nF, int32_t *out, hipStream_t s);
+// lld_stage3_kernels.hip: the components' other option sets
+struct OouraTab;
+hipError_t stage_irfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, const OouraTab &T, hipStream_t s);
+hipError_t stage_fftmagphase(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, int flags, float dBpnorm,
+                             float mindBp, hipStream_t s);
+hipError_t stage_mzcr(const float *src, int64_t lds, int N, int64_t nF, int flags, float *dst, int64_t ldd, hipStream_t s);
 hipError_t stage_valbased(const float *src, int64_t lds, int N, int64_t nF, int idx, float threshold, int invert, int allow_equal,
                           int zerovec, int remove_idx, float output_val, float *dst, int64_t ldd, int32_t *keep, hipStream_t s);
 hipError_t stage_acf(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int K, int n_out, int use_power,

@@ -184,6 +184,35 @@ extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int6
   STAGE_RET(stage_fftmag(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.Nfft, (hipStream_t)stream), "fftmag");
 }
 
+extern "C" int smilehip_irfft_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                     int64_t n_frames, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_irfft_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->geo.Nfft, p->geo.Nfft, "smilehip_irfft_frames");
+  if (rc) return rc;
+  if (!p->oo.d_tw.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_irfft_frames: the reference-order transform is built for 64 .. 8192 points");
+  STAGE_RET(stage_irfft_oo(d_src, ld_src, d_dst, ld_dst, n_frames, (int)p->geo.Nfft, p->oo.tab(), (hipStream_t)stream), "irfft");
+}
+
+extern "C" int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t nfft, int32_t flags,
+                                           float dbp_norm, float min_dbp, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  const int64_t K = nfft / 2 + 1;
+  const int64_t n_out = ((flags & 1) ? K : 0) + ((flags & 2) ? K : 0);
+  if (!ctx || nfft < 4 || (nfft & 1) || !(flags & 3) || (flags & ~31) || n_frames < 0 || ld_src < nfft || ld_dst < n_out ||
+      (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmagphase_frames: bad argument (flags: 1 magnitude, 2 phase, 4 normalise, 8 power, 16 dBpsd)");
+  STAGE_RET(stage_fftmagphase(d_src, ld_src, d_dst, ld_dst, n_frames, (int)nfft, flags, dbp_norm, min_dbp, (hipStream_t)stream), "fftmagphase");
+}
+
+extern "C" int smilehip_mzcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames, int32_t flags,
+                                    float *d_dst, int64_t ld_dst, void *stream) {
+  const int n_out = ((flags & 1) ? 1 : 0) + ((flags & 2) ? 1 : 0) + ((flags & 4) ? 1 : 0) + ((flags & 8) ? 2 : 0) + ((flags & 16) ? 1 : 0);
+  if (!ctx || N < 1 || N > (1 << 15) || !(flags & 31) || (flags & ~31) || n_frames < 0 || ld_src < N || ld_dst < n_out ||
+      (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_mzcr_frames: bad argument (flags: 1 zcr, 2 mcr, 4 amax, 8 maxmin, 16 dc; N <= 32768)");
+  STAGE_RET(stage_mzcr(d_src, ld_src, (int)N, n_frames, flags, d_dst, ld_dst, (hipStream_t)stream), "mzcr");
+}
+
 extern "C" int smilehip_melspec_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
                                        int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_frames: null plan");

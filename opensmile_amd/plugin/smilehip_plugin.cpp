@@ -361,7 +361,23 @@ class cHipTransformFFT : public cTransformFFT {
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
     if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
-    if (getInt("inverse")) { HIP_FALLTHROUGH(2, "cTransformFFT inverse = 1 is not built"); return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (getInt("inverse")) {                             // rdft(N, -1) and the 2 / N scaling (transformFft.cpp:196-216)
+      if (Nsrc != Ndst || Ndst < 64 || Ndst > 8192 || (Ndst & (Ndst - 1))) {
+        HIP_FALLTHROUGH(2, "cTransformFFT inverse = 1: only whole packed spectra of 64 .. 8192 values are built");
+        return cTransformFFT::processVector(src, dst, Nsrc, Ndst, idxi);
+      }
+      smilehip_plan *&pli = plans_.at(getFconf(idxi));
+      if (!pli) {
+        smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
+        check(smilehip_plan_create(context(), &c, &pli));
+      }
+      io_.ensure(Nsrc, Ndst);
+      io_.up(src, Nsrc);
+      check(smilehip_irfft_frames(pli, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+      io_.down(dst, Ndst);
+      g_frames[2]++;
+      return 1;
+    }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
@@ -393,15 +409,39 @@ class cHipFFTmagphase : public cFFTmagphase {
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
-  int plain_ = -1;
+  int plain_ = -1, modes_ = 0;
+  bool other_ok_ = false;
+  float dbp_norm_ = 0.0f, min_dbp_ = 0.0f;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
     if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
-    if (plain_ < 0)
+    if (plain_ < 0) {
       plain_ = (!getInt("inverse") && getInt("magnitude") && !getInt("phase") && !getInt("normalise") &&
                 !getInt("power") && !getInt("dBpsd")) ? 1 : 0;
-    if (!plain_) { HIP_FALLTHROUGH(3, "cFFTmagphase: only the plain magnitude output is built (no phase / normalise / power / dBpsd / inverse)"); return cFFTmagphase::processVector(src, dst, Nsrc, Ndst, idxi); }
+      // every other output mode of :215-287 but the two the reference itself cannot produce properly: inverse = 1 (mag / phase ->
+      // complex) and magnitude + phase as separate fields (:268-276, "this check is wrong" upstream)
+      const int mag = getInt("magnitude"), ph = getInt("phase");
+      modes_ = (mag ? SMILEHIP_MAGPHASE_MAGNITUDE : 0) | (ph ? SMILEHIP_MAGPHASE_PHASE : 0) |
+               (getInt("normalise") ? SMILEHIP_MAGPHASE_NORMALISE : 0) | (getInt("power") ? SMILEHIP_MAGPHASE_POWER : 0) |
+               (getInt("dBpsd") ? SMILEHIP_MAGPHASE_DBPSD : 0);
+      other_ok_ = !getInt("inverse") && (mag || ph) && !(mag && ph && !getInt("joinMagphase"));
+      dbp_norm_ = dBpnorm;                               // the members cFFTmagphase::myFetchConfig filled (:93-98: mindBp >= dBpnorm - 120 enforced)
+      min_dbp_ = mindBp;
+    }
+    if (!plain_ && other_ok_) {
+      const long K = Nsrc / 2 + 1;
+      const long n_out = ((modes_ & 1) ? K : 0) + ((modes_ & 2) ? K : 0);
+      if (n_out <= Ndst && Nsrc >= 4 && !(Nsrc & 1)) {
+        io_.ensure(Nsrc, Ndst);
+        io_.up(src, Nsrc);
+        check(smilehip_fftmagphase_frames(context(), io_.d_in, Nsrc, Nsrc, modes_, dbp_norm_, min_dbp_, io_.d_out, Ndst, 1, nullptr));
+        io_.down(dst, n_out);
+        g_frames[3]++;
+        return 1;
+      }
+    }
+    if (!plain_) { HIP_FALLTHROUGH(3, "cFFTmagphase: inverse = 1 and magnitude + phase as separate fields are not built"); return cFFTmagphase::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(Nsrc, SMILEHIP_STAGE_FFT);
@@ -595,11 +635,25 @@ class cHipMZcr : public cMZcr {
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
-  int plain_ = -1;
+  int plain_ = -1, flags_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (plain_ < 0) plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
-    if (!plain_ || Nsrc == 0) { HIP_FALLTHROUGH(7, "cMZcr: only zcr is built (no mcr / amax / maxmin / dc)"); return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (plain_ < 0) {
+      plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
+      flags_ = (getInt("zcr") ? SMILEHIP_MZCR_ZCR : 0) | (getInt("mcr") ? SMILEHIP_MZCR_MCR : 0) | (getInt("amax") ? SMILEHIP_MZCR_AMAX : 0) |
+               (getInt("maxmin") ? SMILEHIP_MZCR_MAXMIN : 0) | (getInt("dc") ? SMILEHIP_MZCR_DC : 0);
+    }
+    if (Nsrc == 0) return 0;                             // mzcr.cpp:112
+    if (!plain_ && flags_ && Nsrc <= 32768) {            // mcr / amax / maxmin / dc (mzcr.cpp:119-150)
+      const int n_out = ((flags_ & 1) ? 1 : 0) + ((flags_ & 2) ? 1 : 0) + ((flags_ & 4) ? 1 : 0) + ((flags_ & 8) ? 2 : 0) + ((flags_ & 16) ? 1 : 0);
+      io_.ensure(Nsrc, n_out);
+      io_.up(src, Nsrc);
+      check(smilehip_mzcr_frames(context(), io_.d_in, Nsrc, Nsrc, 1, flags_, io_.d_out, n_out, nullptr));
+      io_.down(dst, n_out);
+      g_frames[7]++;
+      return n_out;
+    }
+    if (!plain_) { HIP_FALLTHROUGH(7, "cMZcr: no output selected, or a frame longer than 32768 samples"); return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
     int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t));

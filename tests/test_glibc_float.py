@@ -18,14 +18,14 @@ def lib():
     hdr = os.path.join(ROOT, "opensmile_amd", "csrc", "glibc_float.hpp")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-builtin-logf",
-                        "-fno-builtin-expf", "-fno-builtin-log10f", "-o", so, src, "-lm"], check=True)
+                        "-fno-builtin-expf", "-fno-builtin-log10f", "-fno-builtin-atanf", "-fno-builtin-atan2f", "-o", so, src, "-lm"], check=True)
     L = C.CDLL(so)
     L.glibc_float_sweep.restype = C.c_longlong
     L.glibc_float_sweep.argtypes = [C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_uint)]
     return L
 
 
-@pytest.mark.parametrize("which,name", [(0, "logf"), (1, "expf"), (2, "log10f")])
+@pytest.mark.parametrize("which,name", [(0, "logf"), (1, "expf"), (2, "log10f"), (3, "atanf")])
 def test_bits_equal_libm(lib, which, name):
     if "fma" not in open("/proc/cpuinfo").read():
         pytest.skip("CPU without FMA: the dynamic linker selects glibc's non-FMA build of logf / expf")
@@ -37,3 +37,14 @@ def test_bits_equal_libm(lib, which, name):
     for lo, hi, step in ranges:
         bad = lib.glibc_float_sweep(which, lo, hi, step, C.byref(fb))
         assert bad == 0, f"{name}: {bad} arguments differ from libm in [{lo:#x}, {hi:#x}) step {step}, first {fb.value:#010x}"
+
+
+def test_atan2f_pairs_equal_libm(lib):
+    """glibc_atan2f (fdlibm's float atan2 over glibc_atanf) on pseudo-random pairs, a third with close exponents, special values
+    mixed in (GLIBC_FLOAT_FULL=1: 3e8 pairs)."""
+    lib.glibc_atan2f_pairs.restype = C.c_longlong
+    lib.glibc_atan2f_pairs.argtypes = [C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    by, bx = C.c_uint(0), C.c_uint(0)
+    n = 300_000_000 if os.environ.get("GLIBC_FLOAT_FULL") == "1" else 20_000_000
+    bad = lib.glibc_atan2f_pairs(n, 12345, C.byref(by), C.byref(bx))
+    assert bad == 0, f"atan2f: {bad} of {n} pairs differ from libm, first y = {by.value:#010x}, x = {bx.value:#010x}"
