@@ -552,6 +552,11 @@ int smilehip_irfft_frames(smilehip_plan *plan, const float *d_src, int64_t ld_sr
 #define SMILEHIP_MAGPHASE_DBPSD 16
 int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t nfft, int32_t flags, float dbp_norm,
                                 float min_dbp, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R10, for cPitchACF's voiceQual output: the second result of voicingProb (src/lldcore/pitchACF.cpp:249-283), the zero- or
+ * mean-crossing rate of the ACF (rows of n ACF values; fs_sec / max_pitch as in smilehip_pitchacf_frames), one double per row.
+ * The HNR outputs (computeHNR / _dB / _lin, :310-361) are three scalar expressions on acf[0] and acf[max_idx]. */
+int smilehip_pitchacf_zcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames, double fs_sec,
+                                 double max_pitch, double *d_zcr, void *stream);
 /* R12, every output of cMZcr::processVector (src/lldcore/mzcr.cpp:108-150). flags: 1 zcr, 2 mcr, 4 amax, 8 maxmin, 16 dc; the row
  * holds the selected values in that order (maxmin: max, min), as floats. */
 #define SMILEHIP_MZCR_ZCR 1

@@ -122,6 +122,32 @@ __global__ void __launch_bounds__(64) k_mzcr(const float *src, int64_t lds, int 
   }
 }
 
+// cPitchACF::voicingProb's second result (pitchACF.cpp:249-283): the zero- or mean-crossing rate of the ACF, whichever count is
+// greater, over n -- what the voiceQual output needs. `mean` is a double accumulator in index order, a[skip] counted twice as in
+// the reference (:257-266); lane 0 walks it, the counts are wave-parallel. One wave per frame.
+__global__ void __launch_bounds__(64) k_pitchacf_zcr(const float *src, int64_t lds, int n, int skip, double *zcr_out) {
+  const float *a = src + (int64_t)blockIdx.x * lds;
+  const int lane = threadIdx.x;
+  double mean = 0.0;
+  if (lane == 0) {
+    mean = a[skip];
+    for (int i = (skip > 1 ? skip : 1); i < n; ++i) mean += a[i];
+    mean /= (double)(n - skip + 1);
+  }
+  mean = __shfl(mean, 0);
+  int zc = 0, mc = 0;
+  for (int i = 1 + lane; i < n; i += 64) {
+    if (a[i - 1] * a[i] < 0) zc++;
+    if (((double)a[i - 1] - mean) * ((double)a[i] - mean) < 0) mc++;
+  }
+  for (int of = 32; of > 0; of >>= 1) { zc += __shfl_down(zc, of); mc += __shfl_down(mc, of); }
+  if (lane == 0) zcr_out[blockIdx.x] = (mc > zc) ? (double)mc / (double)n : (double)zc / (double)n;
+}
+hipError_t stage_pitchacf_zcr(const float *src, int64_t lds, int64_t nF, int n, int skip, double *zcr, hipStream_t s) {
+  if (nF > 0) hipLaunchKernelGGL(k_pitchacf_zcr, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n, skip, zcr);
+  return hipGetLastError();
+}
+
 hipError_t stage_irfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, const OouraTab &T, hipStream_t s) {
   if (nF <= 0) return hipSuccess;
   const size_t bytes = sizeof(float) * (size_t)Nfft;

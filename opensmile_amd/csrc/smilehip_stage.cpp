@@ -204,6 +204,17 @@ extern "C" int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d
   STAGE_RET(stage_fftmagphase(d_src, ld_src, d_dst, ld_dst, n_frames, (int)nfft, flags, dbp_norm, min_dbp, (hipStream_t)stream), "fftmagphase");
 }
 
+extern "C" int smilehip_pitchacf_zcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
+                                            double fs_sec, double max_pitch, double *d_zcr, void *stream) {
+  if (!ctx || n < 2 || n > (1 << 20) || n_frames < 0 || ld_src < n || !(fs_sec > 0.0) || (n_frames > 0 && (!d_src || !d_zcr)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_zcr_frames: bad argument");
+  // preskip of cPitchACF::processVector (pitchACF.cpp:151-158): Nd = 2 n values in [acf | cepstrum], Tsamp = fsSec / Nd
+  const double Tsamp = fs_sec / (double)(2 * n);
+  int skip = (max_pitch <= 0.0) ? 0 : (int)(1.0 / (max_pitch * Tsamp));
+  if (skip < 0 || skip >= n) return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_zcr_frames: maxPitch leaves no lag to search (preskip %d of %lld)", skip, (long long)n);
+  STAGE_RET(stage_pitchacf_zcr(d_src, ld_src, n_frames, (int)n, skip, d_zcr, (hipStream_t)stream), "pitchacf_zcr");
+}
+
 extern "C" int smilehip_mzcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames, int32_t flags,
                                     float *d_dst, int64_t ld_dst, void *stream) {
   const int n_out = ((flags & 1) ? 1 : 0) + ((flags & 2) ? 1 : 0) + ((flags & 4) ? 1 : 0) + ((flags & 8) ? 2 : 0) + ((flags & 16) ? 1 : 0);

@@ -721,7 +721,7 @@ class cHipPitchACF : public cPitchACF {
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
-  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, onsFlag_ = 0;
+  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, onsFlag_ = 0, HNR_ = 0, HNRdB_ = 0, linHNR_ = 0, voiceQual_ = 0;
   double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
   FLOAT_DMEM lastPitch_ = 0, lastlastPitch_ = 0, glMeanPitch_ = 0, pitchEnv_ = 0;
   float fsSec_ = -1.0f;
@@ -735,22 +735,47 @@ class cHipPitchACF : public cPitchACF {
       maxPitch_ = getDouble("maxPitch");
       if (maxPitch_ < 0.0) maxPitch_ = 0.0;
       fsSec_ = (float)(reader_->getLevelConfig()->frameSizeSec);          // setupNewNames, :110-114
-      plain_ = (!getInt("HNR") && !getInt("HNRdB") && !getInt("linHNR") && !getInt("voiceQual")) ? 1 : 0;
+      HNR_ = getInt("HNR"); HNRdB_ = getInt("HNRdB"); linHNR_ = getInt("linHNR"); voiceQual_ = getInt("voiceQual");
+      plain_ = 1;
     }
     const long N = (int)floor(Nsrc / 2.0);
-    if (!plain_ || N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: only voiceProb + F0 (+ F0raw) from [acf | cepstrum] are built (no HNR outputs)"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: the input is not [acf | cepstrum] of equal, even size"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
-    unsigned char *r = (unsigned char *)res_.ensure(16);
+    unsigned char *r = (unsigned char *)res_.ensure(24);
     check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)r, (int32_t *)(r + 8), nullptr));
-    struct { double voicing; int32_t idx; int32_t pad; } h;
-    res_.down(&h, 16);
+    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + 16), nullptr));
+    struct { double voicing; int32_t idx; int32_t pad; double acfZcr; } h;
+    h.acfZcr = 0.0;
+    res_.down(&h, voiceQual_ ? 24 : 16);
     const double voicing = h.voicing;
     long maxIdx = h.idx;
     const double Tsamp = fsSec_ / (double)Nsrc;
     int n = 0;
     if (voiceProb_) dst[n++] = (FLOAT_DMEM)voicing;
-    if (F0_ || F0env_ || F0raw_) {
+    // computeHNR / computeHNR_dB / computeHNR_lin (pitchACF.cpp:310-361): scalar expressions on acf[0] and acf[maxIdx]
+    if (HNR_) {
+      double buf;
+      if ((src[0] - src[maxIdx]) == 0.0) buf = 100000000000000000000.0;
+      else buf = src[maxIdx] / (src[0] - src[maxIdx]);
+      dst[n++] = (FLOAT_DMEM)((buf > 0.00000000001) ? 10.0 * log(buf) : 10.0 * log(0.00000000001));
+    }
+    if (HNRdB_) {
+      double buf = src[0] - src[maxIdx];
+      if (buf == 0.0) buf = 10e10; else buf = src[maxIdx] / buf;
+      dst[n++] = (FLOAT_DMEM)((buf <= 10e-10) ? -100.0 : ((buf >= 10e10) ? +100.0 : 10.0 * log(buf) / log(10.0)));
+    }
+    if (linHNR_) {
+      double buf = src[0] - src[maxIdx];
+      if (buf == 0.0) buf = 10e3; else buf = src[maxIdx] / buf;
+      dst[n++] = (FLOAT_DMEM)((buf <= 10e-3) ? 10e-3 : ((buf >= 10e3) ? 10e3 : buf));
+    }
+    if (F0_ || F0env_ || F0raw_ || voiceQual_) {
+      if (voiceQual_) {                                   // :178-181
+        FLOAT_DMEM vq = ((FLOAT_DMEM)maxPitch_ - (FLOAT_DMEM)fabs((h.acfZcr * maxPitch_) - ((FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(maxIdx) * (FLOAT_DMEM)Tsamp)))) * (FLOAT_DMEM)voicing;
+        if (maxIdx == 0.0) vq = 0.0;
+        dst[n++] = vq;
+      }
       FLOAT_DMEM pitch = 0.0, rawF0 = 0.0;
       if (maxIdx > 0) {
         pitch = (FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(maxIdx) * (FLOAT_DMEM)Tsamp);
