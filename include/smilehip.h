@@ -617,7 +617,8 @@ int smilehip_spectral_frames(smilehip_plan *plan, const float *d_mag, int64_t ld
  * equal-loudness weights of the bands (their logs when new_rasta, plp.cpp:335-357), as cPlp::initTables
  * derives them from the input level's band-centre metadata. new_rasta: rasta_coef (host) = {iir, fir[0..4]}
  * (plp.cpp:369-399) and d_state = 4*n_bands + 1 floats, zeroed before a stream's first frame, carries the
- * filter taps and the frame counter across calls. */
+ * filter taps and the frame counter across calls. new_rasta == 2: the older RASTA form (:447-466; same coefficients, d_eql = the
+ * logs as well): d_state = 6*n_bands + 2 floats (a five-frame ring and the IIR value per band, frame counter, ring position). */
 int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
                                 float melfloor, float compression, int new_rasta, const float *rasta_coef, float *d_state,
                                 float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);

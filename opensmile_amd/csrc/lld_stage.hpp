@@ -43,7 +43,7 @@ hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, doub
 struct PlpConsts { float melfloor, compression, iir, fir[5]; };
 hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF, int K,
                           const SpectralConsts &C, hipStream_t s);
-hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, bool rasta, float *state,
+hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,
                      float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,
                         int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s);

@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds,
 
 // R8 cPlp::processVector as auditory spectrum (doAud = 1, no IDFT / LP), with or without newRASTA: the frames of
 // one stream in order, lane = band. state: 4 filter taps per band + the frame counter (as a float) at [4*nB].
+// rasta == 2: the older RASTA form (plp.cpp:447-466): a five-frame ring of the log band values, FIR over it, one IIR value per band;
+// state: [6 x nB] (ring[5] | iir) + the frame counter at [6*nB] + the ring position at [6*nB + 1].
 __global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int nB, const float *eql, PlpConsts Q, int rasta,
                                             float *state, float *dst, int64_t ldd, int64_t nF) {
   const int b = threadIdx.x;
@@ -182,6 +184,30 @@ __global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int n
   const float e = eql[b];
   if (!rasta) {
     for (int64_t f = 0; f < nF; ++f) dst[f * ldd + b] = plp_aud_band(src[f * lds + b], Q.melfloor, e, Q.compression);
+    return;
+  }
+  if (rasta == 2) {
+    float *ring = state + 6 * b;                          // (read and written in place: one frame at a time in the plugin's use)
+    float iirv = ring[5];
+    int init = (int)state[6 * nB], ptr = (int)state[6 * nB + 1];
+    __syncthreads();                                     // every band has read the counters before band 0 rewrites them
+    for (int64_t f = 0; f < nF; ++f) {
+      const float v = src[f * lds + b];
+      const float x = glibc_logf(v < Q.melfloor ? Q.melfloor : v);
+      ring[ptr] = x;
+      float sum = Q.fir[0] * x;
+      for (int m = 1; m < 5; m++) sum += Q.fir[m] * ring[(5 - m + ptr) % 5];
+      sum += Q.iir * iirv;
+      iirv = sum;
+      float y = (init >= 5) ? sum : 0.0f;
+      y += e;                                            // log equal loudness, compression, exp (:490-497, :512-517)
+      y *= Q.compression;
+      dst[f * ldd + b] = glibc_expf(y);
+      if (init < 5) init++;
+      ptr = (ptr + 1) % 5;
+    }
+    ring[5] = iirv;
+    if (b == 0) { state[6 * nB] = (float)init; state[6 * nB + 1] = (float)ptr; }
     return;
   }
   float st[4] = {state[4 * b], state[4 * b + 1], state[4 * b + 2], state[4 * b + 3]};
@@ -286,9 +312,9 @@ hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool firs
   if (nF > 0) hipLaunchKernelGGL(k_spectral, dim3(1), dim3(256), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, C);
   return hipGetLastError();
 }
-hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, bool rasta, float *state,
+hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,
                      float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
-  if (nF > 0) hipLaunchKernelGGL(k_plp, dim3(1), dim3(64), 0, s, src, lds, n_bands, eql, Q, rasta ? 1 : 0, state, dst, ldd, nF);
+  if (nF > 0) hipLaunchKernelGGL(k_plp, dim3(1), dim3(64), 0, s, src, lds, n_bands, eql, Q, rasta, state, dst, ldd, nF);
   return hipGetLastError();
 }
 hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,

@@ -146,7 +146,8 @@ extern "C" int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d
   Q.compression = compression;
   Q.iir = new_rasta ? rasta_coef[0] : 0.0f;
   for (int i = 0; i < 5; ++i) Q.fir[i] = new_rasta ? rasta_coef[1 + i] : 0.0f;
-  STAGE_RET(stage_plp(d_mel, ld_src, n_bands, d_eql, Q, new_rasta != 0, d_state, d_dst, ld_dst, n_frames, (hipStream_t)stream), "plp");
+  if (new_rasta < 0 || new_rasta > 2) return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_audspec_frames: rasta mode must be 0 (none), 1 (newRASTA) or 2 (RASTA)");
+  STAGE_RET(stage_plp(d_mel, ld_src, n_bands, d_eql, Q, new_rasta, d_state, d_dst, ld_dst, n_frames, (hipStream_t)stream), "plp");
 }
 
 extern "C" int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,

@@ -1015,7 +1015,7 @@ class cHipPlp : public cPlp {
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1, newRasta_ = 0, cc_ = 0, lpOrder_ = 0;
+  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
  protected:
@@ -1029,18 +1029,19 @@ class cHipPlp : public cPlp {
       if (doLP) doIDFT = 1;
       newRasta_ = getInt("newRASTA");
       const int rasta = newRasta_ ? 0 : getInt("RASTA");
+      oldRasta_ = rasta;
       compression_ = (FLOAT_DMEM)getDouble("compression");
       if (compression_ < 0.0) compression_ = 0.0;
       melfloor_ = (FLOAT_DMEM)getDouble("melfloor");
-      const bool logs_ok = newRasta_ ? true : (!getInt("doLog") && !getInt("doInvLog"));
-      plain_ = (getInt("doAud") && !doIDFT && !doLP && !rasta && !getInt("htkcompatible") && logs_ok) ? 1 : 0;
+      const bool logs_ok = (newRasta_ || rasta) ? true : (!getInt("doLog") && !getInt("doInvLog"));      // (either RASTA form forces doLog = doInvLog = 1, :168-174)
+      plain_ = (getInt("doAud") && !doIDFT && !doLP && !getInt("htkcompatible") && logs_ok) ? 1 : 0;
       // PLP cepstra in HTK mode (config/plp/*.conf): doAud -> IDFT -> LP -> cepstra, c0 last
       lpOrder_ = getInt("lpOrder");
       const int lastCC = getInt("lastCC"), nCeps = getInt("nCeps");
       cc_ = (getInt("htkcompatible") && doIDFT && doLP && doLpToCeps && !rasta && !newRasta_ && getInt("firstCC") == 0 &&
              lpOrder_ >= 1 && lpOrder_ <= 15 && (lastCC < 0 || lastCC == lpOrder_) && (nCeps < 0 || nCeps == lpOrder_ + 1)) ? 1 : 0;
       if (cc_) { plain_ = 1; melfloor_ = 1.0; }           // htkcompatible forces melfloor = 1, doAud = 1, no logs (plp.cpp:150-160)
-      if (newRasta_) {                                   // initTables, plp.cpp:381-399
+      if (newRasta_ || oldRasta_) {                      // initTables, plp.cpp:361-399 (the same coefficients for both forms)
         const FLOAT_DMEM lo = (FLOAT_DMEM)getDouble("rastaLowerCutoff"), up = (FLOAT_DMEM)getDouble("rastaUpperCutoff");
         coef_[0] = (FLOAT_DMEM)(1.0 - sin(2.0 * M_PI * lo * reader_->getLevelT()));
         const FLOAT_DMEM om = (FLOAT_DMEM)cos(2.0 * M_PI * up * reader_->getLevelT());
@@ -1056,14 +1057,14 @@ class cHipPlp : public cPlp {
     const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
     if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
         (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
-      { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (with / without newRASTA) and the HTK PLP-CC mode are built (no old RASTA, no partial IDFT / LP modes)"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
+      { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (plain, RASTA, newRASTA) and the HTK PLP-CC mode are built (no partial IDFT / LP modes)"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
     if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
       const double *frq = (const double *)(fmeta->field[idxi].info);
-      std::vector<float> e((size_t)Nsrc), st((size_t)(4 * Nsrc + 1), 0.0f);
+      std::vector<float> e((size_t)Nsrc), st((size_t)(6 * Nsrc + 2), 0.0f);
       for (long i = 0; i < Nsrc; ++i) {
         e[(size_t)i] = cc_ ? (FLOAT_DMEM)smileDsp_equalLoudnessWeight_htk((double)frq[i])
                            : (FLOAT_DMEM)smileDsp_equalLoudnessWeight((double)frq[i]);
-        if (newRasta_) e[(size_t)i] = log(e[(size_t)i]);
+        if (newRasta_ || oldRasta_) e[(size_t)i] = log(e[(size_t)i]);
       }
       if (cc_) {                                         // IDFT cosine table and lifter, plp.cpp:288-334
         const int nFreq = (int)Nsrc + 2, nAuto = lpOrder_ + 1;
@@ -1099,7 +1100,7 @@ class cHipPlp : public cPlp {
                                    (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, Ndst, 1, nullptr));
     else
       check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
-                                        newRasta_, coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
+                                        newRasta_ ? 1 : (oldRasta_ ? 2 : 0), coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[13]++;
     return (int)Ndst;

@@ -515,14 +515,14 @@ def test_plugin_option_sets(oracle):
     pcm[2000:2400] = 0                                    # a stretch of exact zeros (zero-crossing rules, dBpsd floor, phase of 0)
     ref, tr0 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
     y, tr = _run(oracle, pcm, None, conf)
-    assert not any(tr0.values()) and ref.shape == y.shape == (ref.shape[0], 2325)
+    assert not any(tr0.values()) and ref.shape == y.shape == (ref.shape[0], 2351)
     T = ref.shape[0]
     assert tr.get("cTransformFFT", 0) == 2 * T and tr.get("cFFTmagphase", 0) == 7 * T and tr.get("cMZcr", 0) == T, tr
-    assert tr.get("cPitchACF", 0) == T and tr.get("cAcf", 0) == 2 * T, tr
+    assert tr.get("cPitchACF", 0) == T and tr.get("cAcf", 0) == 2 * T and tr.get("cPlp", 0) == T and tr.get("cMelspec", 0) == T, tr
     assert not any(k.endswith(".cpu") and v for k, v in tr.items()), tr
     cols = {"ifft": (0, 512), "magN": (512, 769), "magNP": (769, 1026), "magP": (1026, 1283), "magDb": (1283, 1540),
             "join_mag": (1540, 1797), "join_phase": (1797, 2054), "phase": (2054, 2311), "mzcr": (2311, 2317),
-            "pitch [voiceProb HNR HNRdB linHNR voiceQual F0 F0raw F0env]": (2317, 2325)}
+            "pitch [voiceProb HNR HNRdB linHNR voiceQual F0 F0raw F0env]": (2317, 2325), "cPlp RASTA = 1": (2325, 2351)}
     for name, (a, b) in cols.items():
         g, r = np.ascontiguousarray(y[:, a:b]), np.ascontiguousarray(ref[:, a:b])
         d = g.view(np.uint32) != r.view(np.uint32)
