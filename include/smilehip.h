@@ -552,6 +552,14 @@ int smilehip_irfft_frames(smilehip_plan *plan, const float *d_src, int64_t ld_sr
 #define SMILEHIP_MAGPHASE_DBPSD 16
 int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t nfft, int32_t flags, float dbp_norm,
                                 float min_dbp, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R6 with the filter tables given: cMelspec::processVector, forward (src/lldcore/melspec.cpp:519-570) for ANY bank
+ * cMelspec::computeFilters builds (:186-451: spectral scales mel / bark / bark_schroed / bark_speex / semitone / log / lin, bwMethod,
+ * HFCC and custom-bandwidth banks). dense = 0: d_coef[K] rising-slope weights, d_chanmap[K] band of a bin minus 1 (-3 = unused), the
+ * standard bank; dense = 1: d_coef[n_bands x K], d_chanmap[2 n_bands] first / last bin of a band. n_lo / n_hi: nLoF / nHiF (bins).
+ * htk_scale: 1, 32767 or 32767^2 (:556-567). The float sums run bin after bin as in the reference. */
+int smilehip_melspec_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t K, int32_t n_bands, int32_t dense,
+                                  const float *d_coef, const int32_t *d_chanmap, int32_t n_lo, int32_t n_hi, int32_t use_power,
+                                  float htk_scale, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
 /* R10, for cPitchACF's voiceQual output: the second result of voicingProb (src/lldcore/pitchACF.cpp:249-283), the zero- or
  * mean-crossing rate of the ACF (rows of n ACF values; fs_sec / max_pitch as in smilehip_pitchacf_frames), one double per row.
  * The HNR outputs (computeHNR / _dB / _lin, :310-361) are three scalar expressions on acf[0] and acf[max_idx]. */

@@ -143,6 +143,47 @@ __global__ void __launch_bounds__(64) k_pitchacf_zcr(const float *src, int64_t l
   for (int of = 32; of > 0; of >>= 1) { zc += __shfl_down(zc, of); mc += __shfl_down(mc, of); }
   if (lane == 0) zcr_out[blockIdx.x] = (mc > zc) ? (double)mc / (double)n : (double)zc / (double)n;
 }
+// cMelspec::processVector, forward (melspec.cpp:519-570), with the filter tables GIVEN -- whatever spectral scale (mel, bark, bark_schroed,
+// bark_speex, semitone, log, lin), bandwidth method or bank type cMelspec::computeFilters (:186-451) built them for:
+//   dense == 0: the standard bank: coef[K] = the rising-slope weight of bin n, chanmap[K] = its band - 1 (-3: unused). Band m gets
+//               (float)((double)x[n] coef[n]) from the bins mapped to it and x[n] - that from the bins mapped to m - 1, bin after bin;
+//   dense == 1: HFCC / custom-bandwidth banks: coef[n_bands x K], chanmap[2 n_bands] = first / last bin of a band;
+//               dst[m] += (float)((double)x[n] (double)coef[m K + n]).
+// x = src or src^2 (usePower); htk_scale multiplies the band afterwards (32767 or 32767^2, :556-567; 1 = none). Lane = band, every band
+// walks its bins in ascending order: the float sums are the reference's.
+__global__ void __launch_bounds__(64) k_melspec_table(const float *src, int64_t lds, int K, int nB, int dense, const float *coef,
+                                                      const int32_t *chanmap, int nLoF, int nHiF, int use_power, float htk_scale,
+                                                      float *dst, int64_t ldd) {
+  extern __shared__ __attribute__((aligned(16))) float s_p[];
+  const float *a = src + (int64_t)blockIdx.x * lds;
+  for (int n = threadIdx.x; n < K; n += 64) { const float v = a[n]; s_p[n] = use_power ? v * v : v; }
+  __syncthreads();
+  for (int m = threadIdx.x; m < nB; m += 64) {
+    float acc = 0.0f;
+    if (dense) {
+      const int n1 = chanmap[2 * m], n2 = chanmap[2 * m + 1];
+      for (int n = (n1 > nLoF ? n1 : nLoF); n <= n2 && n < nHiF; ++n) acc += (float)((double)s_p[n] * (double)coef[(int64_t)m * K + n]);
+    } else {
+      for (int n = nLoF; n < nHiF; ++n) {
+        const int c = chanmap[n];
+        if (c == m) acc += (float)((double)s_p[n] * (double)coef[n]);
+        else if (c == m - 1 && c > -2) acc += s_p[n] - (float)((double)s_p[n] * (double)coef[n]);
+      }
+    }
+    if (htk_scale != 1.0f) acc *= htk_scale;
+    dst[(int64_t)blockIdx.x * ldd + m] = acc;
+  }
+}
+hipError_t stage_melspec_table(const float *src, int64_t lds, int K, int nB, int dense, const float *coef, const int32_t *chanmap, int nLoF,
+                               int nHiF, int use_power, float htk_scale, float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  const size_t bytes = sizeof(float) * (size_t)((K + 3) & ~3);
+  if (bytes > 48 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_melspec_table, dim3((unsigned)nF), dim3(64), bytes, s, src, lds, K, nB, dense, coef, chanmap, nLoF, nHiF, use_power,
+                     htk_scale, dst, ldd);
+  return hipGetLastError();
+}
+
 hipError_t stage_pitchacf_zcr(const float *src, int64_t lds, int64_t nF, int n, int skip, double *zcr, hipStream_t s) {
   if (nF > 0) hipLaunchKernelGGL(k_pitchacf_zcr, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n, skip, zcr);
   return hipGetLastError();

@@ -266,6 +266,25 @@ int winfunc_id(const char *s) {
 }
 
 // ---------------------------------------------------------------- overrides
+// a small device buffer of raw bytes (results that are not float frames)
+struct DevBytes {
+  void *d = nullptr;
+  uint64_t cap = 0;
+  void *ensure(uint64_t bytes) {
+    if (bytes > cap) {
+      if (d) smilehip_free(context(), d);
+      if (smilehip_alloc(context(), bytes, &d)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap = bytes;
+    }
+    return d;
+  }
+  void down(void *h, uint64_t bytes) {
+    if (smilehip_copy_to_host(context(), h, d, bytes, nullptr) || smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  ~DevBytes() { if (g_ctx && d) smilehip_free(g_ctx, d); }
+};
+
 // R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
 class cHipVectorPreemphasis : public cVectorPreemphasis {
   int fused_ = -1;
@@ -470,6 +489,8 @@ class cHipMelspec : public cMelspec {
   bool cpu_warned_ = false;
   PlanSet<> plans_;
   int plain_ = -1;
+  DevBytes tab_coef_[8], tab_map_[8];
+  bool tab_ready_[8] = {false, false, false, false, false, false, false, false};
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
@@ -480,7 +501,36 @@ class cHipMelspec : public cMelspec {
       const bool mel = getInt("htkcompatible") || (sc && !strcasecmp(sc, "mel"));
       plain_ = (!getInt("inverse") && mel && bw && !strncasecmp(bw, "lr", 2)) ? 1 : 0;
     }
-    if (!plain_) { HIP_FALLTHROUGH(4, "cMelspec: only the mel-scale triangular bank with bwMethod = lr is built (no HFCC / other scales / inverse)"); return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (!plain_ && !getInt("inverse")) {
+      // any other bank cMelspec::computeFilters built (other spectral scales, bwMethod, HFCC, custom bandwidth): the component's own
+      // tables go to the device once, the frames through the table-driven operator
+      const int fc = getFconf(idxi);
+      if (fc >= 0 && fc < 8 && filterCoeffs_ && chanMap_ && filterCoeffs_[fc] && chanMap_[fc] && Ndst == nBands_ && Nsrc <= 8193) {
+        const bool dense = hfcc_ || customBandwidth_;
+        if (!tab_ready_[fc]) {
+          const size_t nc = dense ? (size_t)nBands_ * (size_t)Nsrc : (size_t)Nsrc, nm = dense ? (size_t)2 * nBands_ : (size_t)Nsrc;
+          std::vector<float> cf(filterCoeffs_[fc], filterCoeffs_[fc] + nc);
+          std::vector<int32_t> cm(nm);
+          for (size_t i = 0; i < nm; ++i) cm[i] = (int32_t)chanMap_[fc][i];
+          void *d_c = tab_coef_[fc].ensure(sizeof(float) * nc);
+          void *d_m = tab_map_[fc].ensure(sizeof(int32_t) * nm);
+          if (smilehip_copy_to_device(context(), d_c, cf.data(), sizeof(float) * nc, nullptr) ||
+              smilehip_copy_to_device(context(), d_m, cm.data(), sizeof(int32_t) * nm, nullptr))
+            COMP_ERR("libsmilehip: %s", smilehip_last_error());
+          tab_ready_[fc] = true;
+        }
+        const float scale = htkcompatible_ ? (usePower_ ? (FLOAT_DMEM)(32767.0 * 32767.0) : (FLOAT_DMEM)32767.0) : 1.0f;
+        io_.ensure(Nsrc, Ndst);
+        io_.up(src, Nsrc);
+        check(smilehip_melspec_table_frames(context(), io_.d_in, Nsrc, Nsrc, nBands_, dense ? 1 : 0, (const float *)tab_coef_[fc].d,
+                                            (const int32_t *)tab_map_[fc].d, (int32_t)nLoF_[fc], (int32_t)nHiF_[fc], usePower_, scale,
+                                            io_.d_out, Ndst, 1, nullptr));
+        io_.down(dst, Ndst);
+        g_frames[4]++;
+        return 1;
+      }
+    }
+    if (!plain_) { HIP_FALLTHROUGH(4, "cMelspec: inverse = 1 is not built"); return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       // frame size of the input spectrum, cMelspec::configureField (melspec.cpp:150-173)
@@ -551,25 +601,6 @@ class cHipMfcc : public cMfcc {
     c->setComponentInfo(scname, sdescription);
     return c;
   }
-};
-
-// a small device buffer of raw bytes (results that are not float frames)
-struct DevBytes {
-  void *d = nullptr;
-  uint64_t cap = 0;
-  void *ensure(uint64_t bytes) {
-    if (bytes > cap) {
-      if (d) smilehip_free(context(), d);
-      if (smilehip_alloc(context(), bytes, &d)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
-      cap = bytes;
-    }
-    return d;
-  }
-  void down(void *h, uint64_t bytes) {
-    if (smilehip_copy_to_host(context(), h, d, bytes, nullptr) || smilehip_stream_synchronize(context(), nullptr))
-      COMP_ERR("libsmilehip: %s", smilehip_last_error());
-  }
-  ~DevBytes() { if (g_ctx && d) smilehip_free(g_ctx, d); }
 };
 
 // R12  cEnergy::processVector  (src/lldcore/energy.cpp:152-185): the double-accumulated sum of

@@ -507,7 +507,8 @@ def test_plugin_fused_source_big_set_levels(oracle):
 
 def test_plugin_option_sets(oracle):
     """The components' other option sets (VERDICT r2 missing 3) through the plugin: cTransformFFT inverse = 1, cFFTmagphase normalise /
-    power / dBpsd / phase / joinMagphase, cMZcr mcr / amax / maxmin / dc, cPitchACF's HNR / voiceQual outputs (tests/conf/option_sets.conf). The same binary with and
+    power / dBpsd / phase / joinMagphase, cMZcr mcr / amax / maxmin / dc, cPitchACF's HNR / voiceQual outputs, cPlp RASTA = 1, cMelspec on other
+    spectral scales and with the erb (HFCC) / custom bandwidth banks (tests/conf/option_sets.conf). The same binary with and
     without the overrides: every value the reference's bits (log10f and atan2f follow glibc's algorithms, glibc_float.hpp)."""
     from opensmile_amd import synth
     conf = os.path.join(ROOT, "tests", "conf", "option_sets.conf")
@@ -515,14 +516,16 @@ def test_plugin_option_sets(oracle):
     pcm[2000:2400] = 0                                    # a stretch of exact zeros (zero-crossing rules, dBpsd floor, phase of 0)
     ref, tr0 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
     y, tr = _run(oracle, pcm, None, conf)
-    assert not any(tr0.values()) and ref.shape == y.shape == (ref.shape[0], 2351)
+    assert not any(tr0.values()) and ref.shape == y.shape == (ref.shape[0], 2441)
     T = ref.shape[0]
     assert tr.get("cTransformFFT", 0) == 2 * T and tr.get("cFFTmagphase", 0) == 7 * T and tr.get("cMZcr", 0) == T, tr
-    assert tr.get("cPitchACF", 0) == T and tr.get("cAcf", 0) == 2 * T and tr.get("cPlp", 0) == T and tr.get("cMelspec", 0) == T, tr
+    assert tr.get("cPitchACF", 0) == T and tr.get("cAcf", 0) == 2 * T and tr.get("cPlp", 0) == T and tr.get("cMelspec", 0) == 5 * T, tr
     assert not any(k.endswith(".cpu") and v for k, v in tr.items()), tr
     cols = {"ifft": (0, 512), "magN": (512, 769), "magNP": (769, 1026), "magP": (1026, 1283), "magDb": (1283, 1540),
             "join_mag": (1540, 1797), "join_phase": (1797, 2054), "phase": (2054, 2311), "mzcr": (2311, 2317),
-            "pitch [voiceProb HNR HNRdB linHNR voiceQual F0 F0raw F0env]": (2317, 2325), "cPlp RASTA = 1": (2325, 2351)}
+            "pitch [voiceProb HNR HNRdB linHNR voiceQual F0 F0raw F0env]": (2317, 2325), "cPlp RASTA = 1": (2325, 2351),
+            "cMelspec bark": (2351, 2375), "cMelspec bwMethod erb (HFCC)": (2375, 2395), "cMelspec semitone": (2395, 2425),
+            "cMelspec bark_schroed, custom bandwidth": (2425, 2441)}
     for name, (a, b) in cols.items():
         g, r = np.ascontiguousarray(y[:, a:b]), np.ascontiguousarray(ref[:, a:b])
         d = g.view(np.uint32) != r.view(np.uint32)
