@@ -617,7 +617,7 @@ int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t 
  * 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope, sharpness,
  * harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1): 15 values per frame, in the reference's
  * output order. The frames of ONE stream, in order: d_state (K floats) carries the previous frame's magnitudes
- * across calls (the flux; `first` != 0 marks the stream's first frame, whose flux is 0). Plan: K = 257, built
+ * across calls (the flux; `first` != 0 marks the stream's first frame, whose flux is 0). Plan: K = 129 / 257 / 513, built
  * with SMILEHIP_STAGE_SPECTRAL (or a ComParE chain plan). */
 int smilehip_spectral_frames(smilehip_plan *plan, const float *d_mag, int64_t ld_src, float *d_state, int first,
                              float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);

@@ -785,6 +785,45 @@ __global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_cand(LldPar
   }
   PHASE_FLUSH;
 }
+
+// The per-component operators (mode 1 cSpecScale, mode 2 cPitchShs) for the spectra whose tables do not fit LDS (FFT 2048 / 4096:
+// 22 .. 48 kHz): one wave per row, the same device functions as the chain's three kernels, the spline's sweep as a plain loop on
+// lane 0 (the operators run a frame at a time inside the plugin; the chain has lld_f0_sweep for throughput).
+template <int LOGM>
+__global__ void __launch_bounds__(64) lld_f0_rows_big(F0Params Q) {
+  using G = F0G<LOGM>;
+  F0_GEO;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  if (row >= Q.n_rows) return;
+  double *A = reinterpret_cast<double *>(smem_f0), *B = A + kKP;
+  int *ci = reinterpret_cast<int *>(A + 2 * kKP);
+  F0Tbl T = {};
+  T.d1 = Q.sp_d1; T.d2 = Q.sp_d2; T.audw = Q.audw; T.k = Q.ip_k; T.oo = Q.oo;
+  if (Q.mode == 1) {
+    f0_spectrum<G, true>(T, Q, PcmIn{nullptr, nullptr}, Q.in_rows + row * Q.ld_in, lane, A, B);
+    if (lane == 0) {                                     // smileMath_cspline's two recurrences (see lld_f0_sweep)
+      const double *sp = Q.sp_rec;
+      double up = 0.0;
+      for (int i = 1; i <= kK - 2; ++i) { up = sp[4 * i + 1] * (B[i] - sp[4 * i] * up); B[i] = up; }
+      double yn = 0.0;
+      B[kK - 1] = 0.0;
+      for (int j = kK - 2; j >= 0; --j) { yn = sp[4 * j + 2] * yn + B[j]; B[j] = yn; }
+    }
+    WaveG::sync();
+    (void)f0_shs<G>(T, Q, lane, row, A, B, ci, nullptr, true);
+  } else {
+    double mean = 0.0;
+    const int nf = f0_shs<G>(T, Q, lane, row, A, B, ci, Q.in_rows + row * Q.ld_in, false, &mean);
+    WaveG::sync();
+    if (mean != mean) {
+      if (lane == 0) mean = f0_mean_serial<G>(B);
+      mean = wave_first_d(mean);
+    }
+    f0_candidates<G>(Q, lane, row, A, ci, reinterpret_cast<float *>(ci + 8), nf, mean, 0.0);
+  }
+}
 #undef F0_FOR_BINS
 
 // cSmileViterbi::addFrame / flushTrellis / getNextOutputFrame with cSmileViterbiPitchSmooth's costs
@@ -1568,7 +1607,18 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   switch (f0_logm(Q)) {
     case 8: return launch_f0_rows_g<8>(Q, max_blocks, s);
     case 9: return launch_f0_rows_g<9>(Q, max_blocks, s);
-    default: return hipErrorInvalidValue;                 // (FFT 2048 / 4096: the tables do not fit LDS; the chain's three kernels cover them)
+    case 10: case 11: {                                   // FFT 2048 / 4096: one wave per row, tables through the caches
+      const bool big = f0_logm(Q) == 11;
+      if (!Q.oo.tw || !(big ? f0_shifts_fit<F0G<11>>(Q) : f0_shifts_fit<F0G<10>>(Q))) return hipErrorInvalidValue;
+      const size_t lds = big ? F0G<11>::kFrameBytes : F0G<10>::kFrameBytes;
+      const void *fn = big ? reinterpret_cast<const void *>(&lld_f0_rows_big<11>) : reinterpret_cast<const void *>(&lld_f0_rows_big<10>);
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (big) hipLaunchKernelGGL(lld_f0_rows_big<11>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
+      else hipLaunchKernelGGL(lld_f0_rows_big<10>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
+      return hipGetLastError();
+    }
+    default: return hipErrorInvalidValue;
   }
 }
 

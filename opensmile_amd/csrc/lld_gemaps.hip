@@ -1104,7 +1104,7 @@ __global__ void lld_gemaps_dbp(float *x, int64_t ld, int n_utt, const int64_t *r
 // like smilehip_spectral_frames). One wave.
 __global__ void __launch_bounds__(64) lld_gemaps_spectral_rows(const float *src, int64_t lds, float *state, int first, float *dst,
                                                               int64_t ldd, int64_t nF, int K, GemapsParams G) {
-  __shared__ __attribute__((aligned(16))) float mg[260], pw[260], prev[260], lg[64];
+  __shared__ __attribute__((aligned(16))) float mg[516], pw[516], prev[516], lg[64];     // K <= 513 (20 ms frames up to 48 kHz)
   const int lane = threadIdx.x;
   for (int k = lane; k < K; k += 64) prev[k] = first ? 0.0f : state[k];
   WaveG::sync();
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(64) lld_gemaps_spectral_rows(const float *src,
 hipError_t launch_gemaps_spectral_rows(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF,
                                        int K, const GemapsParams &G, hipStream_t s) {
   if (nF <= 0) return hipSuccess;
-  if (K > 260) return hipErrorInvalidValue;
+  if (K > 516) return hipErrorInvalidValue;
   hipLaunchKernelGGL(lld_gemaps_spectral_rows, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, G);
   return hipGetLastError();
 }

@@ -173,6 +173,27 @@ __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds,
   for (int k = threadIdx.x; k < K; k += blockDim.x) state[k] = prev[k];
 }
 
+// The same operator for the other spectrum sizes of 20 ms frames (K = 129: FFT 256 at 8 / 11.025 kHz, K = 513: FFT 1024 at 32 .. 48 kHz):
+// one wave, the wave form of the descriptors (spectral_frame_wave<W>: the fused ComParE kernel's own code, bit-identical to the block form).
+template <int W>
+__global__ void __launch_bounds__(64) k_spectral_w(const float *src, int64_t lds, float *state, int first, float *dst, int64_t ldd,
+                                                  int64_t nF, SpectralConsts C) {
+  constexpr int K = 64 * W + 1, KP = K + 3;
+  __shared__ __attribute__((aligned(16))) float mg[KP], pw[KP], prev[KP], chain[128 * W];
+  for (int k = threadIdx.x; k < K; k += 64) prev[k] = first ? 0.0f : state[k];
+  WaveG::sync();
+  for (int64_t f = 0; f < nF; ++f) {
+    const float *m = src + f * lds;
+    for (int k = threadIdx.x; k < K; k += 64) { const float v = m[k]; mg[k] = v; pw[k] = v * v; }
+    WaveG::sync();
+    spectral_frame_wave<W>(mg, pw, prev, first && f == 0, C, K, chain, dst + f * ldd);
+    WaveG::sync();
+    for (int k = threadIdx.x; k < K; k += 64) prev[k] = mg[k];
+    WaveG::sync();
+  }
+  for (int k = threadIdx.x; k < K; k += 64) state[k] = prev[k];
+}
+
 // R8 cPlp::processVector as auditory spectrum (doAud = 1, no IDFT / LP), with or without newRASTA: the frames of
 // one stream in order, lane = band. state: 4 filter taps per band + the frame counter (as a float) at [4*nB].
 // rasta == 2: the older RASTA form (plp.cpp:447-466): a five-frame ring of the log band values, FIR over it, one IIR value per band;
@@ -309,7 +330,11 @@ hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, doub
 }
 hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF, int K,
                           const SpectralConsts &C, hipStream_t s) {
-  if (nF > 0) hipLaunchKernelGGL(k_spectral, dim3(1), dim3(256), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, C);
+  if (nF <= 0) return hipSuccess;
+  if (K == 257) hipLaunchKernelGGL(k_spectral, dim3(1), dim3(256), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, C);
+  else if (K == 129) hipLaunchKernelGGL(k_spectral_w<2>, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, C);
+  else if (K == 513) hipLaunchKernelGGL(k_spectral_w<8>, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, C);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,

@@ -117,7 +117,8 @@ extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, in
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null plan");
   if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
   if (!p->d_sharp.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: plan was built without SMILEHIP_STAGE_SPECTRAL");
-  if (p->geo.K != 257) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: K = %lld, the kernel covers K = 257", (long long)p->geo.K);
+  if (p->geo.K != 129 && p->geo.K != 257 && p->geo.K != 513)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: K = %lld, the kernels cover K = 129 / 257 / 513 (20 ms frames at 8 .. 48 kHz)", (long long)p->geo.K);
   if (!d_state && n_frames > 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null state buffer");
   int rc = check_frames(d_mag, d_dst, ld_src, ld_dst, n_frames, p->geo.K, 15, "smilehip_spectral_frames");
   if (rc) return rc;

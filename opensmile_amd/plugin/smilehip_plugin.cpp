@@ -986,13 +986,14 @@ class cHipSpectral : public cSpectral {
       else if (ok && getArraySize("slopes") <= 0 && getInt("alphaRatio") == 0 && getInt("hammarbergIndex") == 0 && getInt("flux") == 1)
         gemaps_ = 2;                                     // 1 output
     }
-    if (gemaps_ > 0 && Nsrc == 257 && Ndst == (gemaps_ == 1 ? 4 : 1) && fc >= 0 && fc < 8) {
+    if (gemaps_ > 0 && (Nsrc == 129 || Nsrc == 257 || Nsrc == 513) && Ndst == (gemaps_ == 1 ? 4 : 1) && fc >= 0 && fc < 8) {
       if (!gm_plan_) {
         const sDmLevelConfig *lc = reader_->getLevelConfig();
         smilehip_lld_config c;
         smilehip_config_egemapsv02(&c);
-        if (!(std::fabs(lc->frameSizeSec - 512.0 / c.sample_rate) < 1e-9))
-          COMP_ERR("libsmilehip plugin: cSpectral (GeMAPS options): the HIP path is built for the 512-point spectrum at 16 kHz");
+        c.sample_rate = std::round(2.0 * (double)(Nsrc - 1) / lc->frameSizeSec);       // the spectrum level's frameSizeSec = Nfft / rate
+        if (!(c.sample_rate >= 7999.0 && c.sample_rate <= 48001.0))
+          COMP_ERR("libsmilehip plugin: cSpectral (GeMAPS options): the HIP path is built for 20 ms frames at 8 .. 48 kHz (this level: %ld bins, %g s)", Nsrc, lc->frameSizeSec);
         check(smilehip_plan_create(context(), &c, &gm_plan_));
       }
       io_.ensure(Nsrc, 5);
@@ -1006,9 +1007,9 @@ class cHipSpectral : public cSpectral {
       g_frames[12]++;
       return (int)Ndst;
     }
-    if (!plain_ || Nsrc != 257 || Ndst != 15 || fc < 0 || fc >= 8) {
+    if (!plain_ || (Nsrc != 129 && Nsrc != 257 && Nsrc != 513) || Ndst != 15 || fc < 0 || fc >= 8) {
       HIP_FALLTHROUGH(12, "cSpectral: only ComParE_2016's option set and the two GeMAPS sets (log-spectrum slopes + alphaRatio + "
-                          "hammarbergIndex; flux over 0-5000 Hz) on a 257-bin spectrum are built");
+                          "hammarbergIndex; flux over 0-5000 Hz) on a 129- / 257- / 513-bin spectrum are built");
       return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     smilehip_plan *&pl = plans_.at(fc);
@@ -1371,6 +1372,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
   smilehip_lld_config c;
   smilehip_config_compare16_f0(&c);
   c.force_fft_frame_size_sec = frame_size_sec;
+  c.force_frame_size = 2 * (K - 1);                      // the spectrum the component sees: K bins of a 2 (K - 1)-point transform
   c.pitch_min = min_pitch;
   c.pitch_max = max_pitch;
   c.voicing_cutoff = cutoff;
@@ -1380,7 +1382,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
   check(smilehip_plan_create(context(), &c, &pl));
   smilehip_geometry g;
   check(smilehip_plan_geometry(pl, &g));
-  if (g.n_bins != K) {                                   // the kernels cover the 1024-point spectrum of 60 ms / 16 kHz frames
+  if (g.n_bins != K) {                                   // (K - 1 not a power of two)
     smilehip_plan_destroy(pl);
     return nullptr;
   }
@@ -1407,7 +1409,7 @@ class cHipSpecScale : public cSpecScale {
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave-scale spline set of the F0 chains on a 1024-point spectrum is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave-scale spline set of the F0 chains on spectra of 512 .. 4096 points is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
     check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
@@ -1467,14 +1469,21 @@ class cHipPitchShs : public cPitchShs {
 // the formant / voice-quality components of GeMAPSv01b_core.lld.conf.inc, per component, on ONE shared
 // eGeMAPS plan (its tables fix the geometry: 16 kHz, 512-point spectrum of 20 ms frames -> 220 samples at 11 kHz, p = 11;
 // 1024-point spectrum of 60 ms frames).
-smilehip_plan *g_gm_plan = nullptr;
-smilehip_plan *gemaps_plan() {
-  if (!g_gm_plan) {
+// Round 3: one plan per sample rate (8 .. 48 kHz). The rate is what the components that see it report (cSpecResample: the level's
+// basePeriod; cSpectral with the GeMAPS options: bins and frameSizeSec of its spectrum); cLpc / cFormantLpc / cHarmonics, which run after
+// them in every tick, use the plan of the rate seen last.
+std::map<long, smilehip_plan *> g_gm_plans;
+long g_gm_rate = 16000;
+smilehip_plan *gemaps_plan(long rate = 0) {
+  if (rate > 0) g_gm_rate = rate;
+  smilehip_plan *&pl = g_gm_plans[g_gm_rate];
+  if (!pl) {
     smilehip_lld_config c;
     smilehip_config_egemapsv02(&c);
-    check(smilehip_plan_create(context(), &c, &g_gm_plan));
+    c.sample_rate = (double)g_gm_rate;
+    check(smilehip_plan_create(context(), &c, &pl));
   }
-  return g_gm_plan;
+  return pl;
 }
 
 // cSpecResample::processVector (src/dsp/specResample.cpp:175-185) for [gemapsv01b_resampLpc]
@@ -1482,20 +1491,23 @@ class cHipSpecResample : public cSpecResample {
   FrameIO io_;
   bool cpu_warned_ = false;
   int usable_ = -1;
+  long rate_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (usable_ < 0) {
       const sDmLevelConfig *c = reader_->getLevelConfig();
-      usable_ = !isSet("resampleRatio") && getDouble("targetFs") == 11000.0 && !getStr("inputFieldPartial") && Nsrc == 512 && Ndst == 220 &&
-                std::fabs(c->basePeriod - 1.0 / 16000.0) < 1e-12 && std::fabs(c->lastFrameSizeSec - 0.020) < 1e-9;
+      rate_ = c->basePeriod > 0.0 ? std::lround(1.0 / c->basePeriod) : 0;
+      usable_ = !isSet("resampleRatio") && getDouble("targetFs") == 11000.0 && !getStr("inputFieldPartial") &&
+                (Nsrc == 256 || Nsrc == 512 || Nsrc == 1024) && Ndst == 220 && rate_ >= 8000 && rate_ <= 48000 &&
+                std::fabs(c->lastFrameSizeSec - 0.020) < 1e-4;
     }
     if (!usable_) {
-      HIP_FALLTHROUGH(17, "cSpecResample: only targetFs = 11000 on the 512-value spectrum of 20 ms frames at 16 kHz is built");
+      HIP_FALLTHROUGH(17, "cSpecResample: only targetFs = 11000 on the spectrum of 20 ms frames at 8 .. 48 kHz (220 samples out) is built");
       return cSpecResample::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_specresample_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_specresample_frames(gemaps_plan(rate_), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[17]++;
     return (int)Ndst;
@@ -1607,25 +1619,32 @@ class cHipHarmonics : public cHarmonics {
           iFf_ = findField(ff, getInt("formantFrequencyFieldNameIsFull"), &nFf_, NULL, -1, NULL);
           iFb_ = findField(fb, getInt("formantBandwidthFieldNameIsFull"), &nFb_, NULL, -1, NULL);
         }
-        // the frequency axis the reference reads from the magnitude field's meta data (harmonics.cpp:753-777): 513 bins of 15.625 Hz
+        // the frequency axis the reference reads from the magnitude field's meta data (harmonics.cpp:753-777): linear, bin 0 at 0 Hz
+        // (513 bins of 15.625 Hz at 16 kHz); the operator's axis is i / fsSec of the plan's 60 ms spectrum
         const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
         bool axis = false;
-        if (fmeta && specField >= 0 && specField < fmeta->N && fmeta->field[specField].info &&
-            fmeta->field[specField].infoSize == 513 * (long)sizeof(double)) {
+        const bool size_ok = nSpec_ == 257 || nSpec_ == 513 || nSpec_ == 1025 || nSpec_ == 2049;
+        if (size_ok && fmeta && specField >= 0 && specField < fmeta->N && fmeta->field[specField].info &&
+            fmeta->field[specField].infoSize == nSpec_ * (long)sizeof(double)) {
           const double *frq = (const double *)fmeta->field[specField].info;
-          axis = frq[0] == 0.0 && frq[1] == 15.625 && frq[512] == 8000.0;
+          smilehip_geometry g;
+          check(smilehip_plan_geometry(gemaps_plan(), &g));
+          // the plan of the rate seen last (cSpecResample / cSpectral run before this component in every tick): its 60 ms
+          // spectrum must be this one -- same number of bins, same axis step
+          const double step = (double)g_gm_rate / (double)(2 * (nSpec_ - 1));
+          axis = frq[0] == 0.0 && frq[1] == step && frq[nSpec_ - 1] == step * (double)(nSpec_ - 1);
         }
-        ok = axis && iF0_ >= 0 && iSpec_ >= 0 && iFf_ >= 0 && iFb_ >= 0 && nSpec_ == 513 && nFf_ == 5 && nFb_ == 5 && iSpec_ + 513 <= Nsrc;
+        ok = axis && iF0_ >= 0 && iSpec_ >= 0 && iFf_ >= 0 && iFb_ >= 0 && size_ok && nFf_ == 5 && nFb_ == 5 && iSpec_ + nSpec_ <= Nsrc;
       }
       usable_ = ok ? 1 : 0;
     }
     if (!usable_) {
-      HIP_FALLTHROUGH(20, "cHarmonics: only GeMAPS' option set (H1-H2, H1-A3, formant amplitudes 1..3, ACF HNR in dB; 5 formants, 513-bin "
-                          "spectrum of 60 ms frames at 16 kHz) is built");
+      HIP_FALLTHROUGH(20, "cHarmonics: only GeMAPS' option set (H1-H2, H1-A3, formant amplitudes 1..3, ACF HNR in dB; 5 formants, the "
+                          "spectrum of 60 ms frames at 8 .. 48 kHz) is built");
       return cHarmonics::processVector(src, dst, Nsrc, Ndst, idxi);
     }
-    io_.ensure(513, 6);
-    io_.up(src + iSpec_, 513);
+    io_.ensure(nSpec_, 6);
+    io_.up(src + iSpec_, nSpec_);
     float fm[10];
     memcpy(fm, src + iFf_, sizeof(float) * 5);
     memcpy(fm + 5, src + iFb_, sizeof(float) * 5);
@@ -1633,7 +1652,7 @@ class cHipHarmonics : public cHarmonics {
     if (smilehip_copy_to_device(context(), d_fm, fm, sizeof(fm), nullptr) ||
         smilehip_copy_to_device(context(), d_f0, src + iF0_, sizeof(float), nullptr))
       COMP_ERR("libsmilehip: %s", smilehip_last_error());
-    check(smilehip_harmonics_frames(gemaps_plan(), d_f0, d_fm, 10, io_.d_in, 513, io_.d_out, 6, 1, nullptr));
+    check(smilehip_harmonics_frames(gemaps_plan(), d_f0, d_fm, 10, io_.d_in, nSpec_, io_.d_out, 6, 1, nullptr));
     io_.down(dst, 6);
     g_frames[20]++;
     return 1;

@@ -17,14 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLUGDIR = os.path.join(ROOT, "opensmile_amd", "plugin")
 
 
-def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf", out_opt="-O"):
+def _run(oracle, pcm, env_extra=None, conf="mfcc/MFCC12_0_D_A.conf", out_opt="-O", fs=16000):
     exe = os.path.join(oracle.REF_DIR, "SMILExtract")
     plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
     if not (os.path.exists(exe) and os.path.exists(plug)):
         pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built (needs /root/reference at build time)")
     with tempfile.TemporaryDirectory() as td:
         wav, out, trace = (os.path.join(td, n) for n in ("in.wav", "out.htk", "trace.txt"))
-        oracle.write_wav(wav, pcm)
+        oracle.write_wav(wav, pcm, fs)
         env = dict(os.environ)
         env["LD_LIBRARY_PATH"] = os.pathsep.join(
             [os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
@@ -530,3 +530,19 @@ def test_plugin_option_sets(oracle):
         g, r = np.ascontiguousarray(y[:, a:b]), np.ascontiguousarray(ref[:, a:b])
         d = g.view(np.uint32) != r.view(np.uint32)
         assert not d.any(), f"{name}: {d.sum()} of {d.size} values differ, first at {np.argwhere(d)[0]}: {g[d][:3]} vs {r[d][:3]}"
+
+
+@pytest.mark.parametrize("fs", [8000, 44100])
+@pytest.mark.parametrize("conf,out_opt", [("egemaps/v02/eGeMAPSv02.conf", "-lldhtkoutput"), ("compare16/ComParE_2016.conf", "-lldhtkoutput")])
+def test_plugin_big_sets_at_other_sample_rates(oracle, conf, out_opt, fs):
+    """The unmodified big-set files inside the unmodified binary on 8 kHz / 44.1 kHz input with every override active: the
+    per-component operators take the spectrum sizes of that rate (cSpectral on 129 / 513 bins, cSpecScale / cPitchShs / cHarmonics on
+    FFT 512 / 4096, cSpecResample from FFT 256 / 1024): the plain binary's LLD file bit for bit, nothing on the CPU code."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(33, int(0.8 * fs), fs)
+    ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, out_opt, fs)
+    y, tr = _run(oracle, pcm, None, conf, out_opt, fs)
+    assert y.shape == ref.shape
+    assert not [n for n, v in tr.items() if n.endswith(".cpu") and v], tr
+    d = y.view(np.uint32) != ref.view(np.uint32)
+    assert not d.any(), f"{d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))[:20]}"
