@@ -324,6 +324,26 @@ uint64_t conf_fingerprint_masked(const ConfFile &f) {
   return h;
 }
 
+static bool conf_is_selection_param(const ConfInstance &i, const std::string &key) {
+  return (i.type == "cMfcc" && key == "lastMfcc") || (i.type == "cFunctionals" && key == "functionalsEnabled");
+}
+uint64_t conf_fingerprint_masked2(const ConfFile &f) {
+  uint64_t h = 1469598103934665603ull;
+  auto eat = [&](const std::string &s) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    h ^= '\n'; h *= 1099511628211ull;
+  };
+  for (const ConfInstance &i : f.inst) {
+    if (is_io_type(i.type)) continue;
+    eat(i.name + ":" + i.type);
+    std::vector<std::pair<std::string, std::string>> o = i.opts;
+    std::sort(o.begin(), o.end());
+    for (const auto &kv : o)
+      if (!conf_is_f0_param(i, kv.first) && !conf_is_selection_param(i, kv.first)) eat(kv.first + "=" + canonical_value(kv.second));
+  }
+  return h;
+}
+
 void conf_apply_f0_params(const ConfPlan &p, smilehip_lld_config &c) {
   for (const auto &kv : p.f0_params) {
     if (kv.first == "pitch_min") c.pitch_min = kv.second;
@@ -339,14 +359,14 @@ void conf_apply_f0_params(const ConfPlan &p, smilehip_lld_config &c) {
 }
 
 namespace {
-struct KnownSet { uint64_t fingerprint; const char *set; const char *file; uint64_t masked; };
+struct KnownSet { uint64_t fingerprint; const char *set; const char *file; uint64_t masked; uint64_t masked2 = 0; };
 // fingerprints of the reference's own files (smilextract_hip -C <file> --fingerprint prints them), computed from
 // config/is09-13/IS09_emotion.conf, config/compare16/ComParE_2016.conf, config/is09-13/IS13_ComParE.conf and
 // config/egemaps/v02/eGeMAPSv02.conf (and its two sub-graphs, GeMAPSv01b.conf / eGeMAPSv01b.conf) with their includes and every command-line option at its default
 const KnownSet kKnownSets[] = {
     {0x84b42d91f07908acull, "is09_emotion", "IS09_emotion.conf", 0},
-    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf", 0x27e03c47ce1ea38aull},
-    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf", 0x7d6ca59726bab51dull},
+    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf", 0x27e03c47ce1ea38aull, 0x99ecb9b8c6a4f3deull},
+    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf", 0x7d6ca59726bab51dull, 0xaf784385ddd585c9ull},
     {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf", 0x0a4014c8c2747c7aull},
     // sub-graphs of eGeMAPSv02.conf: their levels are column subsets of its levels (smilehip_host.hpp, egemaps_subset_columns)
     {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf", 0xd9d453405c7cfe69ull},
@@ -456,6 +476,40 @@ bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
           what += (what.empty() ? "" : ", ") + kv.first + " = " + canonical_value(kv.second);
         }
       p.describe = std::string("the graph of ") + k.file + " with the file's own parameter values (" + what + ")";
+      return true;
+    }
+  // the ComParE graphs with a lower lastMfcc and / or functional families removed: outputs of the shipped graph left out
+  const uint64_t fpm2 = conf_fingerprint_masked2(f);
+  for (const KnownSet &k : kKnownSets)
+    if (k.masked2 != 0 && k.masked2 == fpm2) {
+      if (!conf_check_io(f, {"lld", "lld_de", "func"}, err)) return false;
+      p.preset = k.set;
+      std::string what;
+      for (const ConfInstance &i : f.inst)
+        for (const auto &kv : i.opts) {
+          if (const char *field = conf_is_f0_param(i, kv.first)) {
+            char *end = nullptr;
+            const double v = strtod(kv.second.c_str(), &end);
+            if (end == kv.second.c_str()) { err = "[" + i.name + ":" + i.type + "] " + kv.first + " = " + kv.second + " is not a number"; return false; }
+            p.f0_params[field] = v;
+          } else if (i.type == "cMfcc" && kv.first == "lastMfcc") {
+            p.last_mfcc = atoi(kv.second.c_str());
+            if (p.last_mfcc < 1 || p.last_mfcc > 14) { err = "[" + i.name + ":cMfcc] lastMfcc = " + kv.second + ": the fused ComParE chain computes MFCC 1 .. 14 (a lower lastMfcc drops columns; a higher one is not built)"; return false; }
+            what += (what.empty() ? "" : ", ") + std::string("lastMfcc = ") + kv.second;
+          } else if (i.type == "cFunctionals" && kv.first == "functionalsEnabled") {
+            const size_t at = i.name.find("functionals");
+            const std::string inst = at == std::string::npos ? i.name : i.name.substr(at + 11);
+            std::vector<std::string> fams;
+            std::string tok;
+            for (char ch : kv.second + ";") {
+              if (ch == ';') { if (!tok.empty()) fams.push_back(tok); tok.clear(); }
+              else if (!isspace((unsigned char)ch)) tok += ch;
+            }
+            p.func_enabled[inst] = fams;
+            what += (what.empty() ? "" : ", ") + i.name + ".functionalsEnabled = " + kv.second;
+          }
+        }
+      p.describe = std::string("the graph of ") + k.file + " with outputs left out (" + what + ")";
       return true;
     }
   // ---- a cepstral chain: framer -> [pre-emphasis] -> window -> FFT -> magnitude -> mel -> MFCC | PLP, optional log energy,

@@ -33,6 +33,10 @@ uint64_t conf_fingerprint(const ConfFile &f);
 // the same hash with the options left out that the kernels of the big sets take as parameters (conf_plan.cpp: conf_is_f0_param):
 // a file that differs from a shipped set only in those is the set with other parameter values
 uint64_t conf_fingerprint_masked(const ConfFile &f);
+// ... and with the options left out whose edits only REMOVE outputs of the ComParE graphs (cMfcc lastMfcc, the cFunctionals
+// instances' functionalsEnabled lists): every output of those graphs is computed independently of the others, so a file
+// that lowers lastMfcc or drops functional families writes a column subset of what the shipped file writes
+uint64_t conf_fingerprint_masked2(const ConfFile &f);
 
 struct ConfPlan {
   std::string preset;                    // "is09_emotion", "compare16", "is13_compare", "egemapsv02", or "" = cfg below
@@ -50,6 +54,10 @@ struct ConfPlan {
   // smilehip_lld_config field they map to (pitch_min, pitch_max, voicing_cutoff, shs_n_harmonics, shs_compression,
   // vit_buffer_len, jitter_search_range, jitter_broken_thresh, f0_min_energy)
   std::map<std::string, double> f0_params;
+  // ComParE graphs recognised through the second masked fingerprint: lastMfcc (0 = as shipped: 14) and, per cFunctionals
+  // instance ("A", "B", "F0", "Nz", "LLD", "Delta"), the family names the file enables (absent = as shipped)
+  int last_mfcc = 0;
+  std::map<std::string, std::vector<std::string>> func_enabled;
 };
 void conf_apply_f0_params(const ConfPlan &p, smilehip_lld_config &cfg);
 

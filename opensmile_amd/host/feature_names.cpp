@@ -205,6 +205,61 @@ std::vector<int> egemaps_subset_columns(const std::string &set, bool func) {
   return {};
 }
 
+// ComParE_2016 / IS13_ComParE with outputs left out (conf_plan.hpp: last_mfcc, func_enabled): the columns of the 130-column LLD
+// level and of the 6373-value functionals vector that remain, in order. false + err: a family the shipped instance does not
+// have, or families in another order (cFunctionals writes them in functionalsEnabled order: a reordering is another layout).
+bool compare16_selection(bool is13, int last_mfcc, const std::map<std::string, std::vector<std::string>> &func_enabled,
+                         std::vector<int> &sel_lld, std::vector<int> &sel_func, std::string &err) {
+  static const char *fam_names[SMILEHIP_FAM_COUNT] = {"Extremes", "Means", "Moments", "Regression", "Percentiles", "Times", "Segments", "Lpc", "Peaks2"};
+  sel_lld.clear(); sel_func.clear();
+  const int lm = last_mfcc > 0 ? last_mfcc : 14;
+  auto lld_kept = [&](int c) {                           // [F0 group 6 | A 4 | audSpec 26 | spectral 15 | mfcc 14] + the same _de
+    const int b = c % 65;
+    return !(b >= 51 && b - 51 >= lm);
+  };
+  for (int c = 0; c < 130; ++c) if (lld_kept(c)) sel_lld.push_back(c);
+  struct Part { const char *inst; int c0, n; };
+  static const Part parts[] = {{"A", 6, 4}, {"A", 71, 4}, {"B", 10, 55}, {"B", 75, 55}, {"Nz", 0, 6}, {"Nz", 65, 6}, {"F0", 0, 1}, {"LLD", 6, 59}, {"Delta", 71, 59}};
+  int pos = 0;
+  for (const Part &p : parts) {
+    smilehip_func_spec s;
+    if ((is13 ? smilehip_funcspec_is13_compare(p.inst, &s) : smilehip_funcspec_compare16(p.inst, &s)) != SMILEHIP_OK) { err = "no functionals spec"; return false; }
+    // values per family of this instance
+    std::vector<int> fam_count;
+    std::vector<bool> fam_keep((size_t)s.n_fam, true);
+    for (int i = 0; i < s.n_fam; ++i) {
+      smilehip_func_spec one = s;
+      one.n_fam = 1; one.fam[0] = s.fam[i];
+      fam_count.push_back(smilehip_funcspec_count(&one));
+      if (fam_count.back() < 0) { err = "functionals spec"; return false; }
+    }
+    auto it = func_enabled.find(p.inst);
+    if (it != func_enabled.end()) {
+      size_t next = 0;                                   // the file's list must be an order-preserving subset of the shipped one
+      std::fill(fam_keep.begin(), fam_keep.end(), false);
+      for (const std::string &name : it->second) {
+        bool found = false;
+        for (size_t i = next; i < (size_t)s.n_fam; ++i)
+          if (name == fam_names[s.fam[i]]) { fam_keep[i] = true; next = i + 1; found = true; break; }
+        if (!found) {
+          err = std::string("[is13_functionals") + p.inst + ":cFunctionals] functionalsEnabled: '" + name + "' is not one of the families the shipped "
+                "instance enables, or the families are in another order (only leaving families out is expressible)";
+          return false;
+        }
+      }
+    }
+    for (int c = 0; c < p.n; ++c) {
+      const bool ck = lld_kept(p.c0 + c);
+      for (int i = 0; i < s.n_fam; ++i) {
+        for (int v = 0; v < fam_count[(size_t)i]; ++v, ++pos)
+          if (ck && fam_keep[(size_t)i]) sel_func.push_back(pos);
+      }
+    }
+  }
+  if (pos != 6373) { err = "internal: the functionals layout does not add up"; return false; }
+  return true;
+}
+
 std::vector<std::string> select_names(const std::vector<std::string> &names, const std::vector<int> &cols) {
   std::vector<std::string> out;
   for (int c : cols) out.push_back(names.at((size_t)c));

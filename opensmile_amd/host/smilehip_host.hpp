@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,8 @@ std::vector<std::string> func_names_egemaps();     // 88, its functionals level
 // (func = false) / functionals level (func = true) that `set` ("gemapsv01b" | "egemapsv01b") writes, in its order; empty for
 // any other name.
 std::vector<int> egemaps_subset_columns(const std::string &set, bool func);
+bool compare16_selection(bool is13, int last_mfcc, const std::map<std::string, std::vector<std::string>> &func_enabled,
+                         std::vector<int> &sel_lld, std::vector<int> &sel_func, std::string &err);
 std::vector<std::string> select_names(const std::vector<std::string> &names, const std::vector<int> &cols);
 // rows x cols.size() matrix of the selected columns of x (rows x ld)
 std::vector<float> select_columns(const float *x, int64_t rows, int64_t ld, const std::vector<int> &cols);

@@ -129,7 +129,8 @@ int main(int argc, char **argv) {
     std::string cerr_;
     if (!conf_parse(opt["-C"], conf_cmdline, cf, cerr_)) die("-C " + opt["-C"] + ": " + cerr_);
     if (print_fingerprint) {
-      printf("%016llx %016llx\n", (unsigned long long)conf_fingerprint(cf), (unsigned long long)conf_fingerprint_masked(cf));
+      printf("%016llx %016llx %016llx\n", (unsigned long long)conf_fingerprint(cf), (unsigned long long)conf_fingerprint_masked(cf),
+             (unsigned long long)conf_fingerprint_masked2(cf));
       return 0;
     }
     static const char *builtin[] = {"l", "loglevel", "nologfile", "noconsoleoutput", "logfile", "appendLogfile", "t", "nticks", "d", "debug",
@@ -199,8 +200,17 @@ int main(int argc, char **argv) {
   const bool egm_v01a = set == "gemapsv01a" || set == "egemapsv01a";
   const bool egm_subset = set == "gemapsv01b" || set == "egemapsv01b" || egm_v01a;
   const bool egm = set == "egemapsv02" || egm_subset;            // config/egemaps/v02/eGeMAPSv02.conf
-  const std::vector<int> sel_lld = egemaps_subset_columns(set, false), sel_func = egemaps_subset_columns(set, true);
-  if (egm_subset && gather) die("--gather is not available with --set " + set + " (gather the eGeMAPSv02 vectors and select)");
+  std::vector<int> sel_lld = egemaps_subset_columns(set, false), sel_func = egemaps_subset_columns(set, true);
+  // ComParE_2016 / IS13_ComParE files that lower lastMfcc or leave functional families out (conf_plan.hpp): the shipped graph runs, the
+  // remaining outputs are written
+  bool cmp_subset = false;
+  if (with_conf && cmp16 && (conf_plan.last_mfcc > 0 || !conf_plan.func_enabled.empty())) {
+    std::string e;
+    if (!compare16_selection(is13, conf_plan.last_mfcc, conf_plan.func_enabled, sel_lld, sel_func, e)) die(e);
+    cmp_subset = sel_lld.size() != 130 || sel_func.size() != 6373;
+  }
+  const bool out_subset = egm_subset || cmp_subset;
+  if (out_subset && gather) die("--gather is not available with a set that writes a column selection (" + set + "): gather the whole vectors and select");
   const bool has_func = is09 || cmp16f || egm;
   // the eight files of config/mfcc and config/plp, by their names in lower case
   std::string variant;                             // upper-case config name for smilehip_config_htk_variant
@@ -318,11 +328,11 @@ int main(int argc, char **argv) {
   };
   const std::vector<std::string> lld_names =
       free_chain ? conf_plan.lld_names
-                 : (is09 ? lld_names_is09() : (cmp16 ? lld_names_compare16()
+                 : (is09 ? lld_names_is09() : (cmp16 ? (cmp_subset ? select_names(lld_names_compare16(), sel_lld) : lld_names_compare16())
                     : (egm ? (egm_subset ? select_names(lld_names_egemaps(), sel_lld) : lld_names_egemaps())
                            : lld_names_htk_variant(plp, htk_variant && vcfg.append_log_energy))));
   const std::vector<std::string> fnames =
-      is09 ? func_names_is09() : (cmp16f ? func_names_compare16()
+      is09 ? func_names_is09() : (cmp16f ? (cmp_subset ? select_names(func_names_compare16(), sel_func) : func_names_compare16())
            : (egm ? (egm_subset ? select_names(func_names_egemaps(), sel_func) : func_names_egemaps()) : std::vector<std::string>()));
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
@@ -458,7 +468,7 @@ int main(int argc, char **argv) {
         const int64_t r = row_off[i + 1] - row_off[i];
         int n_w = n_out;                                  // columns written (a subset preset writes its selection)
         std::vector<float> x_sel;
-        if (egm_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
+        if (out_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
         const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
         if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
           if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)) die(err);
@@ -477,7 +487,7 @@ int main(int argc, char **argv) {
           const float *fv = func.data() + i * (size_t)n_func;
           int n_fw = n_func;
           std::vector<float> f_sel;
-          if (egm_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
+          if (out_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
           func_rows[idx[i] - j0].assign(fv, fv + n_fw);
           if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
             if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) die(err);

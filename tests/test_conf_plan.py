@@ -250,3 +250,72 @@ def test_edited_big_set_files_equal_the_binary_on_the_same_file(tmp_path):
             (ha, xa), (hb, xb) = outs["hip"][k], outs["ref"][k]
             assert ha == hb and xa.shape == xb.shape, rel
             assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)), (rel, k, np.abs(xa - xb).max())
+
+
+def _edit_compare16(tmp_path, is13=False):
+    """ComParE_2016.conf (or IS13_ComParE.conf) with maxPitch changed, lastMfcc = 12, Moments removed from is13_functionalsB,
+    Peaks2 removed from is13_functionalsLLD, Regression removed from is13_functionalsNz."""
+    shutil.copytree(CONF, tmp_path / "config")
+    d = "is09-13" if is13 else "compare16"
+    stem = "IS13_ComParE" if is13 else "ComParE_2016"
+    p = tmp_path / "config" / d / (stem + "_core.lld.conf.inc")
+    t = p.read_text()
+    for a, b in (("maxPitch = 620", "maxPitch = 550"), ("lastMfcc  = 14", "lastMfcc  = 12")):
+        assert a in t, a
+        t = t.replace(a, b)
+    p.write_text(t)
+    p = tmp_path / "config" / d / (stem + "_core.func.conf.inc")
+    t = p.read_text()
+    subs = (("functionalsEnabled = Extremes ; Percentiles ; Moments ; Segments ; Times ;  Lpc", "functionalsEnabled = Extremes ; Percentiles ; Segments ; Times ;  Lpc", 1),
+            ("functionalsEnabled = Means ; Peaks2 ; Regression", "functionalsEnabled = Means ; Regression", 0),
+            ("functionalsEnabled = Means ; Extremes ; Regression ; Percentiles ; Moments ; Times ; Lpc", "functionalsEnabled = Means ; Extremes ; Percentiles ; Moments ; Times ; Lpc", 0))
+    for a, b, which in subs:
+        assert a in t, a
+        i = -1
+        for _ in range(which + 1):
+            i = t.index(a, i + 1)
+        t = t[:i] + b + t[i + len(a):]                  # the which-th occurrence (A and B share a line: B is the second)
+    p.write_text(t)
+    return str(tmp_path / "config" / d / (stem + ".conf"))
+
+
+@needs_conf
+def test_output_selection_edits_are_recognised(tmp_path):
+    conf = _edit_compare16(tmp_path)
+    rc, kv, err = describe(conf)
+    assert rc == 0 and kv["preset"] == "compare16", err
+    # a family the shipped instance does not have: refused by name
+    p = tmp_path / "config" / "compare16" / "ComParE_2016_core.func.conf.inc"
+    p.write_text(p.read_text().replace("functionalsEnabled = Means ; Regression", "functionalsEnabled = Means ; Regression ; Onset"))
+    r = subprocess.run([EXE, "-C", conf, "-I", "x.wav", "-lldhtkoutput", "x.htk"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Onset" in r.stderr and "functionalsEnabled" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is13", [False, True])
+def test_output_selection_edits_equal_the_binary(tmp_path, is13):
+    """lastMfcc = 12 and functional families left out (with an F0 parameter changed as well): smilextract_hip -C on the edited file
+    against the REAL binary on the same file -- names, LLD level and functionals bit for bit."""
+    from test_host_io import read_htk
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/SMILExtract not built")
+    import wave
+    from opensmile_amd import synth
+    conf = _edit_compare16(tmp_path, is13)
+    wav = str(tmp_path / "u.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(synth.utterance(9, 50000).tobytes())
+    outs = {}
+    for tag, exe, extra, env in (("hip", EXE, [], None), ("ref", ref_exe, ["-l", "0"], dict(os.environ, SMILEHIP_PLUGIN_COMPONENTS="none"))):
+        lld, fun, csv, fcsv = (str(tmp_path / f"{tag}{e}") for e in (".lld.htk", ".func.htk", ".lld.csv", ".func.csv"))
+        subprocess.run([exe, "-C", conf, "-I", wav, "-lldhtkoutput", lld, "-htkoutput", fun, "-lldcsvoutput", csv, "-csvoutput", fcsv,
+                        "-instname", "u"] + extra, check=True, env=env, cwd=str(tmp_path))
+        outs[tag] = (read_htk(lld), read_htk(fun), open(csv).readline(), open(fcsv).readline())
+    assert outs["hip"][2] == outs["ref"][2] and outs["hip"][3] == outs["ref"][3]         # element names
+    for k in (0, 1):
+        (ha, xa), (hb, xb) = outs["hip"][k], outs["ref"][k]
+        assert ha == hb and xa.shape == xb.shape
+        assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)), (k, np.abs(xa - xb).max())
+    assert outs["ref"][0][1].shape[1] == 126 and outs["ref"][1][1].shape[1] < 6373
