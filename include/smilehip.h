@@ -254,6 +254,10 @@ int smilehip_pitchshs_frames(smilehip_plan *plan, const float *d_hps, int64_t ld
  * candScores[6] | F0raw | voicingClip), energies [total_frames] = level is13_e60 -- and an optional caller-owned
  * destination [total_frames x n_bins] for level is13_hpsG60 (NULL switches the tap off). */
 int smilehip_batch_f0_taps(smilehip_batch *b, float *d_hps_dst, const float **d_shs, const float **d_e60);
+/* Frames per utterance that cPitchSmootherViterbi had not decided when the input ended (they are flushed at the end of input:
+ * src/lld/pitchSmootherViterbi.cpp:451-570), [n_utt] device ints filled by the last smilehip_lld_run of an F0 / ComParE / eGeMAPS
+ * chain batch. Every end-of-input rule of the smoothed levels and the row counts the F0-group functionals see follow from it. */
+int smilehip_batch_f0_pending(smilehip_batch *b, const int32_t **d_pending);
 
 /* ---- functionals over the LLD level ---------------------------------
  * cFunctionals in frameMode=full (src/functionals/functionals.cpp:284-330, one output vector

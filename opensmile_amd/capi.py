@@ -154,6 +154,7 @@ SYMBOLS = {
     "smilehip_plan_get_mel_chanmap": (_i64, [_vp, _vp, _i64]),
     "smilehip_plan_get_dct": (_i64, [_vp, _vp, _i64]),
     "smilehip_plan_get_lifter": (_i64, [_vp, _vp, _i64]),
+    "smilehip_batch_f0_pending": (C.c_int, [_vp, _vp]),
     "smilehip_batch_create": (C.c_int, [_vp, _vp, _i32, C.POINTER(_vp)]),
     "smilehip_batch_destroy": (None, [_vp]),
     "smilehip_batch_total_frames": (_i64, [_vp]),

@@ -671,6 +671,14 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   return timing_mark(plan, 2, s);
 }
 
+extern "C" int smilehip_batch_f0_pending(smilehip_batch *b, const int32_t **d_pending) {
+  if (!b || !d_pending) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_f0_pending: null argument");
+  const smilehip_batch *fb = b->f0_batch ? b->f0_batch : b;
+  if (!fb->d_pending.p) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_f0_pending: not an F0 / ComParE / eGeMAPS chain batch");
+  *d_pending = fb->d_pending.p;
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_batch_egemaps_taps(smilehip_batch *b, const float **d_raw20, const float **d_lpc, const float **d_formants,
                                            const float **d_pitch3, const float **d_jit4, const float **d_shim_db, const float **d_harm6,
                                            const float **d_func_in, const int32_t **d_pending, int64_t *h_frame_off60) {

@@ -447,7 +447,15 @@ bool conf_check_io(const ConfFile &f, const std::set<std::string> &produced, std
   return true;
 }
 
+static bool conf_to_plan_inner(const ConfFile &f, ConfPlan &p, std::string &err);
 bool conf_to_plan(const ConfFile &f, ConfPlan &p, std::string &err) {
+  const bool ok = conf_to_plan_inner(f, p, err);
+  if (ok && p.wave_file.empty())                         // (the big sets return before the cepstral walk that records it)
+    for (const ConfInstance &i : f.inst)
+      if (i.type == "cWaveSource") { const std::string *fn = i.find("filename"); if (fn) p.wave_file = *fn; }
+  return ok;
+}
+static bool conf_to_plan_inner(const ConfFile &f, ConfPlan &p, std::string &err) {
   p = ConfPlan();
   const uint64_t fp = conf_fingerprint(f);
   for (const KnownSet &k : kKnownSets)

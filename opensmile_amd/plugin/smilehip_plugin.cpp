@@ -153,23 +153,173 @@ void check(int rc) {
 // rows out of the batch result: one device round trip per file instead of one per frame and component. Everything
 // downstream (mean normalisation, delta regression, concatenation, sinks) runs the reference's own code on those rows,
 // at the reference's own ticks. Graphs that are not expressible stay on the per-component path (a warning says why).
+long g_fused_stage = 0;
+// a level the fused batch supplies: rows of a host matrix, a column per element of the level (no columns: zeros)
+struct FusedLevel {
+  const std::vector<float> *M = nullptr;
+  int ld = 0;
+  long n_rows = 0;
+  std::vector<int> cols;
+  std::vector<float> extra;      // one more row after the matrix's (ComParE group B's level holds row T60 + 1, which only its functionals read)
+};
 struct FusedChain {
   bool tried = false, active = false;
+  // big = an unmodified big-set file (IS09_emotion, ComParE_2016, IS13_ComParE, eGeMAPSv02 and its sub-graphs): the whole LLD
+  // level comes from ONE fused batch; the components that write the levels the sinks and the cFunctionals instances read
+  // (the final cContourSmoother / cDeltaRegression instances, eGeMAPS' energy level) hand out its rows, every overridden
+  // component upstream of them writes zeros (nobody downstream of the fused levels reads those), the cFunctionals overrides
+  // run as HIP operators on the handed-out levels.
+  bool big = false;
   smilehip_host::ConfPlan plan;
-  std::vector<float> rows;
+  std::vector<float> rows, fin, b_extra;
+  long f0_frames = 0, f0_pending = 0;                     // 60 ms frames of the file, and how many the Viterbi pass left to the end-of-input flush
+  // the functionals vector of the fused batch and where a cFunctionals instance's values start in it (by the instance's writer level);
+  // instances that are not listed run as HIP operators on the handed-out levels
+  std::vector<float> func;
+  struct FuncAt { long base; int count; };
+  std::map<std::string, FuncAt> func_levels;
   long n_rows = 0;
   int n_cols = 0;
   long served = 0;
+  std::map<std::string, FusedLevel> levels;
+  FusedLevel zero_level;
 
   bool stage_level(const char *lvl) const {
     if (!active || !lvl) return false;
+    if (big) return levels.find(lvl) == levels.end();      // everything that is not handed out is a stage
     for (const std::string &l : plan.stage_levels) if (l == lvl) return true;
     return false;
   }
-  const std::vector<int> *static_level(const char *lvl) const {
+  const FusedLevel *static_level(const char *lvl) const {
     if (!active || !lvl) return nullptr;
-    auto it = plan.static_levels.find(lvl);
-    return it == plan.static_levels.end() ? nullptr : &it->second;
+    auto it = levels.find(lvl);
+    if (it != levels.end()) return &it->second;
+    return big ? &zero_level : nullptr;
+  }
+  void add_level(const std::string &name, const std::vector<float> *M, int ld, long nr, int c0, int n) {
+    FusedLevel L;
+    L.M = M; L.ld = ld; L.n_rows = nr;
+    for (int i = 0; i < n; ++i) L.cols.push_back(c0 + i);
+    levels[name] = L;
+  }
+  // the big sets: one batch of the preset's chain over the whole file
+  bool init_big(const smilehip_host::WaveInfo &wi, const std::vector<unsigned char> &raw) {
+    const std::string &ps = plan.preset;
+    smilehip_lld_config c;
+    const bool egm = ps == "egemapsv02";                   // (the GeMAPS sub-graph files have other level names: per-component path)
+    if (ps == "is09_emotion") smilehip_config_is09_lld(&c);
+    else if (ps == "compare16") smilehip_config_compare16(&c);
+    else if (ps == "is13_compare") smilehip_config_is13_compare(&c);
+    else if (egm) smilehip_config_egemapsv02(&c);
+    else return false;
+    smilehip_host::conf_apply_f0_params(plan, c);
+    c.sample_rate = (double)wi.sample_rate;
+    smilehip_plan *pl = nullptr;
+    check(smilehip_plan_create(context(), &c, &pl));
+    smilehip_geometry g;
+    check(smilehip_plan_geometry(pl, &g));
+    const int64_t n = (int64_t)(raw.size() / 2);
+    const int64_t off[2] = {0, n};
+    smilehip_batch *b = nullptr;
+    check(smilehip_batch_create(pl, off, 1, &b));
+    n_rows = (long)smilehip_batch_total_rows(b);
+    n_cols = g.n_out;
+    rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
+    long fin_rows = 0;
+    if (n_rows > 0) {
+      void *d_pcm = nullptr, *d_lld = nullptr;
+      check(smilehip_alloc(context(), (uint64_t)(n > 0 ? n : 1) * 2, &d_pcm));
+      check(smilehip_alloc(context(), (uint64_t)n_rows * n_cols * 4, &d_lld));
+      check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
+      check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, n_cols, nullptr));
+      check(smilehip_copy_to_host(context(), rows.data(), d_lld, (uint64_t)n_rows * n_cols * 4, nullptr));
+      if (ps != "is09_emotion") {
+        const int32_t *d_pend = nullptr;
+        int32_t pend = 0;
+        check(smilehip_batch_f0_pending(b, &d_pend));
+        check(smilehip_copy_to_host(context(), &pend, d_pend, sizeof(pend), nullptr));
+        check(smilehip_stream_synchronize(context(), nullptr));
+        f0_pending = pend;
+        f0_frames = n_rows - 1;                            // rows = T60 + 1
+      }
+      if (ps == "compare16" || ps == "is13_compare") {     // row T60 + 1 of group B's smoothed / delta levels (its functionals read it)
+        const float *d_ex = nullptr;
+        check(smilehip_batch_compare_b_extra(b, &d_ex));
+        b_extra.assign(110, 0.0f);
+        check(smilehip_copy_to_host(context(), b_extra.data(), d_ex, 110 * 4, nullptr));
+      }
+      {                                                    // the set's functionals level, on the device-resident LLD matrix
+        int nf = 0;
+        if (ps == "is09_emotion") nf = 384;
+        else if (ps == "compare16" || ps == "is13_compare") nf = smilehip_functionals_compare16_count();
+        if (nf > 0) {
+          void *d_func = nullptr;
+          check(smilehip_alloc(context(), (uint64_t)nf * 4, &d_func));
+          if (ps == "is09_emotion") check(smilehip_batch_functionals(pl, b, (const float *)d_lld, n_cols, smilehip_functionals_is09_mask(), (float *)d_func, nf, nullptr));
+          else if (ps == "is13_compare") check(smilehip_batch_functionals_is13_compare(pl, b, (const float *)d_lld, n_cols, (float *)d_func, nf, nullptr));
+          else check(smilehip_batch_functionals_compare16(pl, b, (const float *)d_lld, n_cols, (float *)d_func, nf, nullptr));
+          func.assign((size_t)nf, 0.0f);
+          check(smilehip_copy_to_host(context(), func.data(), d_func, (uint64_t)nf * 4, nullptr));
+          check(smilehip_stream_synchronize(context(), nullptr));
+          smilehip_free(context(), d_func);
+          if (ps == "is09_emotion") func_levels["is09_func"] = FuncAt{0, 12};
+          else {
+            static const struct { const char *inst; int elems; } order[] = {{"A", 8}, {"B", 110}, {"Nz", 12}, {"F0", 1}, {"LLD", 59}, {"Delta", 59}};
+            long base = 0;
+            for (const auto &o : order) {
+              smilehip_func_spec fs;
+              check(ps == "is13_compare" ? smilehip_funcspec_is13_compare(o.inst, &fs) : smilehip_funcspec_compare16(o.inst, &fs));
+              const int cnt = smilehip_funcspec_count(&fs);
+              func_levels[std::string("is13_functionals") + o.inst] = FuncAt{base, cnt};
+              base += (long)o.elems * cnt;
+            }
+            if (base != nf) COMP_ERR("libsmilehip plugin: fused mode: the functionals layout does not add up (%ld of %d)", base, nf);
+          }
+        }
+      }
+      if (egm) {                                           // the levels the functionals read (smilehip_batch_egemaps_taps)
+        const float *d_fin = nullptr;
+        check(smilehip_batch_egemaps_taps(b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &d_fin, nullptr, nullptr));
+        fin_rows = (long)smilehip_batch_total_frames(b) + 1;            // T20 + 1
+        fin.assign((size_t)fin_rows * 36, 0.0f);
+        check(smilehip_copy_to_host(context(), fin.data(), d_fin, (uint64_t)fin_rows * 36 * 4, nullptr));
+      }
+      check(smilehip_stream_synchronize(context(), nullptr));
+      smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld);
+    }
+    smilehip_batch_destroy(b);
+    smilehip_plan_destroy(pl);
+    if (ps == "is09_emotion") {
+      add_level("is09_lld", &rows, n_cols, n_rows, 0, 16);
+      add_level("is09_lld_de", &rows, n_cols, n_rows, 16, 16);
+    } else if (ps == "compare16" || ps == "is13_compare") {
+      add_level("is13_lld_nzsmo", &rows, n_cols, n_rows, 0, 6);
+      add_level("is13_lldA_smo", &rows, n_cols, n_rows, 6, 4);
+      add_level("is13_lldB_smo", &rows, n_cols, n_rows, 10, 55);
+      add_level("is13_lld_nzsmo_de", &rows, n_cols, n_rows, 65, 6);
+      add_level("is13_lldA_smo_de", &rows, n_cols, n_rows, 71, 4);
+      add_level("is13_lldB_smo_de", &rows, n_cols, n_rows, 75, 55);
+      if (b_extra.size() == 110) {
+        levels["is13_lldB_smo"].extra.assign(b_extra.begin(), b_extra.begin() + 55);
+        levels["is13_lldB_smo_de"].extra.assign(b_extra.begin() + 55, b_extra.end());
+      }
+    } else {
+      const std::string g1 = "gemapsv01b";               // names of the included core file
+      // the LLD level's two halves, and the levels the functionals read (lld_params.hpp: func_in's 36 columns)
+      add_level("egemapsv02_lldsetE_smo", &rows, n_cols, n_rows, 0, 10);
+      add_level("egemapsv02_lldsetF_smo", &rows, n_cols, n_rows, 10, 15);
+      add_level(g1 + "_loudness_smo", &fin, 36, fin_rows, 0, 1);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessZ_smo", &fin, 36, fin_rows, 1, 5);
+      add_level(g1 + "_lld_single_logF0_smo", &fin, 36, fin_rows, 6, 1);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessNz_smo", &fin, 36, fin_rows, 7, 14);
+      add_level("egemapsv02_lldSetSpectralNz_smo", &fin, 36, fin_rows, 21, 9);
+      add_level("egemapsv02_lldSetSpectralZ_smo", &fin, 36, fin_rows, 30, 5);
+      add_level("egemapsv02_energyRMS", &fin, 36, fin_rows, 35, 1);
+    }
+    big = true;
+    active = true;
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld rows of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+    return true;
   }
   void init() {
     if (tried) return;
@@ -199,15 +349,22 @@ struct FusedChain {
       SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: cannot read the configuration file (%s) -- per-component path", err.c_str());
       return;
     }
-    if (!smilehip_host::conf_to_plan(cf, plan, err) || !plan.preset.empty()) {
-      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: %s -- per-component path",
-                plan.preset.empty() ? err.c_str() : "only the cepstral chains fuse inside the reference process (use smilextract_hip for the big sets)");
+    if (!smilehip_host::conf_to_plan(cf, plan, err)) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: %s -- per-component path", err.c_str());
       return;
     }
     smilehip_host::WaveInfo wi;
     std::vector<unsigned char> raw;
     if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
       SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
+      return;
+    }
+    if (!plan.preset.empty()) {
+      // the big sets fuse only with EVERY override registered: the final smoother / delta instances must be the ones that hand out rows
+      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
+      const bool all = !only || !*only || !strcmp(only, "all");
+      if (!all || plan.last_mfcc > 0 || !plan.func_enabled.empty() || !init_big(wi, raw))
+        SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: this big-set file does not fuse inside the reference process -- per-component path");
       return;
     }
     smilehip_lld_config c = plan.cfg;
@@ -228,19 +385,39 @@ struct FusedChain {
     if (n_rows > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows.data()));
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
+    for (const auto &kv : plan.static_levels) {
+      FusedLevel L;
+      L.M = &rows; L.ld = n_cols; L.n_rows = n_rows; L.cols = kv.second;
+      levels[kv.first] = L;
+    }
     active = true;
     SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld frames of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
   }
-  // row `frame` of the fused static block, the columns of level `cols`
-  void copy(const std::vector<int> &cols, long frame, FLOAT_DMEM *dst, long Ndst) {
-    if (frame >= n_rows) COMP_ERR("libsmilehip plugin: fused mode: the graph asks for frame %ld, the batch has %ld", frame, n_rows);
-    const float *r = rows.data() + (size_t)frame * n_cols;
-    for (long k = 0; k < Ndst && k < (long)cols.size(); ++k) dst[k] = r[cols[k]];
+  // row `frame` of a fused level
+  void copy(const FusedLevel &L, long frame, FLOAT_DMEM *dst, long Ndst) {
+    if (L.cols.empty()) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; return; }
+    if (frame >= L.n_rows) COMP_ERR("libsmilehip plugin: fused mode: the graph asks for frame %ld, the batch has %ld", frame, L.n_rows);
+    const float *r = L.M->data() + (size_t)frame * L.ld;
+    for (long k = 0; k < Ndst && k < (long)L.cols.size(); ++k) dst[k] = r[L.cols[k]];
     ++served;
   }
+  float at(const FusedLevel &L, long frame, int elem) {
+    if (L.cols.empty()) return 0.0f;
+    if (elem >= (int)L.cols.size())
+      COMP_ERR("libsmilehip plugin: fused mode: the graph asks for element %d, the level has %d", elem, (int)L.cols.size());
+    if (frame == L.n_rows && !L.extra.empty()) return L.extra[(size_t)elem];
+    if (frame >= L.n_rows) { ++beyond; return 0.0f; }      // rows a window processor emits at the end of input that no reader of the level uses
+    return (*L.M)[(size_t)frame * L.ld + L.cols[(size_t)elem]];
+  }
+  long beyond = 0;
 };
+// big-set fused mode: an overridden component that does not write a handed-out level fills its output with zeros
+#define FUSED_BIG_STAGE(ret)                                                                                       \
+  do {                                                                                                             \
+    g_fused.init();                                                                                                \
+    if (g_fused.big) { for (long k_ = 0; k_ < Ndst; ++k_) dst[k_] = 0; g_fused_stage++; return (ret); }           \
+  } while (0)
 FusedChain g_fused;
-long g_fused_stage = 0;
 
 smilehip_lld_config base_config(long N, uint32_t stages) {
   smilehip_lld_config c;
@@ -565,7 +742,7 @@ class cHipMelspec : public cMelspec {
 // R7  cMfcc::processVector, forward  (src/lldcore/mfcc.cpp:239-273)
 class cHipMfcc : public cMfcc {
   int fused_ = -1;
-  const std::vector<int> *fcols_ = nullptr;
+  const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -607,7 +784,7 @@ class cHipMfcc : public cMfcc {
 // squares comes from the device, the rms / squared / log expressions are the reference's
 class cHipEnergy : public cEnergy {
   int fused_ = -1;
-  const std::vector<int> *fcols_ = nullptr;
+  const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -669,6 +846,7 @@ class cHipMZcr : public cMZcr {
   int plain_ = -1, flags_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {
       plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
       flags_ = (getInt("zcr") ? SMILEHIP_MZCR_ZCR : 0) | (getInt("mcr") ? SMILEHIP_MZCR_MCR : 0) | (getInt("amax") ? SMILEHIP_MZCR_AMAX : 0) |
@@ -714,6 +892,7 @@ class cHipAcf : public cAcf {
   int plain_ = -1, use_power_ = 0, cepstrum_ = 0, norm_ = 0, abs_ceps_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE(1);
     if (plain_ < 0) {                                    // cAcf::myFetchConfig, acf.cpp:77-110
       cepstrum_ = getInt("cepstrum");
       use_power_ = cepstrum_ ? (isSet("usePower") ? getInt("usePower") : 0) : getInt("usePower");
@@ -758,6 +937,7 @@ class cHipPitchACF : public cPitchACF {
   float fsSec_ = -1.0f;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {                                    // cPitchACF::myFetchConfig, pitchACF.cpp:75-104
       voiceProb_ = getInt("voiceProb"); F0_ = getInt("F0"); F0raw_ = getInt("F0raw"); F0env_ = getInt("F0env");
       voicingCutoff_ = getDouble("voicingCutoff");
@@ -859,6 +1039,26 @@ class cHipPitchACF : public cPitchACF {
 // R13  cWindowProcessor::processBuffer of cDeltaRegression (src/dspcore/deltaRegression.cpp:113-170) and
 // cContourSmoother (src/dspcore/contourSmoother.cpp:85-118): one row of the block the window
 // processor's tick hands over, valid on [-pre, nT+post)
+// big-set fused mode for the window processors (cWindowProcessor::myTick calls processBuffer once per element row of a block,
+// rows 0 .. N-1 in order, windowProcessor.cpp:188-200): the n-th call of a block is element n, the blocks follow each other in time
+struct FusedRows {
+  const FusedLevel *lvl = nullptr;
+  int tried = 0;
+  long call = 0, t_base = 0;
+  // true: `out` has been filled (with the level's rows, or zeros for a level nobody downstream of the fused ones reads)
+  bool serve(const char *writer_level, long n_elems, cMatrix *out) {
+    if (!tried) { tried = 1; g_fused.init(); if (g_fused.big) lvl = g_fused.static_level(writer_level); }
+    if (!g_fused.big || !lvl) return false;
+    const long N = n_elems > 0 ? n_elems : 1;
+    const int e = (int)(call % N);
+    for (long t = 0; t < out->nT; ++t) out->data[t] = g_fused.at(*lvl, t_base + t, e);
+    if (e == N - 1) t_base += out->nT;
+    ++call;
+    if (!lvl->cols.empty()) g_fused.served += out->nT; else g_fused_stage++;
+    return true;
+  }
+};
+
 struct RowIO {
   FrameIO io;
   void run(cMatrix *in, cMatrix *out, int pre, int post, int kind, int W) {
@@ -874,6 +1074,7 @@ struct RowIO {
 
 class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
+  FusedRows frows_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, segs_ = 0;
   DevBytes norm_;
@@ -891,6 +1092,7 @@ class cHipDeltaRegression : public cDeltaRegression {
         check(smilehip_copy_to_device(context(), row_.d_norm, &n0, sizeof(float), nullptr));
       }
     }
+    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
     if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
@@ -908,6 +1110,7 @@ class cHipDeltaRegression : public cDeltaRegression {
 
 class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
+  FusedRows frows_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, nz_ = 0;
  protected:
@@ -918,6 +1121,7 @@ class cHipContourSmoother : public cContourSmoother {
       plain_ = ((smaWin & 1) && W_ >= 1) ? 1 : 0;
       nz_ = getInt("noZeroSma") ? 1 : 0;
     }
+    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: an even smaWin is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);
     g_frames[11] += out->nT;
@@ -951,6 +1155,7 @@ class cHipSpectral : public cSpectral {
   }
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {
       static const char *const bands[2] = {"250-650", "1000-4000"};
       bool ok = array_is("bands", 2, bands) && getArraySize("rollOff") == 4 && getArraySize("slopes") <= 0;
@@ -1041,7 +1246,7 @@ class cHipSpectral : public cSpectral {
 // R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
 class cHipPlp : public cPlp {
   int fused_ = -1;
-  const std::vector<int> *fcols_ = nullptr;
+  const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -1152,6 +1357,8 @@ class cHipPlp : public cPlp {
 // masterTimeNorm, else the family's default; functionalComponent.hpp:68-76) -- is translated into a smilehip_func_spec
 // once; an instance that uses an option the spec cannot express stays on the reference's own code.
 class cHipFunctionals : public cFunctionals {
+  int fused_ = -1;
+  FusedChain::FuncAt fat_{0, 0};
   FrameIO io_;
   bool cpu_warned_ = false;
   int state_ = -1;                                       // -1 = not examined, 0 = not expressible -> reference code, 1 = spec_
@@ -1347,6 +1554,21 @@ class cHipFunctionals : public cFunctionals {
   }
  protected:
   int doProcess(int i, cMatrix *row, FLOAT_DMEM *y) override {
+    if (fused_ < 0) {                                      // big-set fused mode: the instance's values of the fused batch's functionals vector
+      g_fused.init();
+      fused_ = 0;
+      if (g_fused.big) {
+        auto it = g_fused.func_levels.find(getStr("writer.dmLevel"));
+        if (it != g_fused.func_levels.end() && it->second.count == nFunctValues) { fat_ = it->second; fused_ = 1; }
+      }
+    }
+    if (fused_ && row->nT > 0) {
+      const long at = fat_.base + (long)i * fat_.count;
+      if (at + fat_.count > (long)g_fused.func.size()) COMP_ERR("libsmilehip plugin: fused mode: functionals element %d outside the batch's vector", i);
+      for (int k = 0; k < fat_.count; ++k) y[k] = g_fused.func[(size_t)(at + k)];
+      g_fused.served++;
+      return nFunctValues;
+    }
     if (state_ < 0) state_ = build_spec() ? 1 : 0;
     if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Crossings, DCT, Onset, Peaks, Samples, ModulationSpec, pctlquotient, ...)"); return cFunctionals::doProcess(i, row, y); }
     io_.ensure(row->nT, nFunctValues);
@@ -1399,6 +1621,7 @@ class cHipSpecScale : public cSpecScale {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       const char *sc = getStr("scale"), *ss = getStr("sourceScale"), *im = getStr("interpMethod");
       usable_ = sc && !strncasecmp(sc, "oct", 3) && ss && !strncasecmp(ss, "lin", 3) && im && !strncasecmp(im, "spl", 3) &&
@@ -1436,6 +1659,7 @@ class cHipPitchShs : public cPitchShs {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       usable_ = getInt("nCandidates") == 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&
                 getInt("voicingC1") == 0 && getInt("F0raw") == 1 && getInt("voicingClip") == 1 && getInt("octaveCorrection") == 0 &&
@@ -1494,6 +1718,7 @@ class cHipSpecResample : public cSpecResample {
   long rate_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       const sDmLevelConfig *c = reader_->getLevelConfig();
       rate_ = c->basePeriod > 0.0 ? std::lround(1.0 / c->basePeriod) : 0;
@@ -1528,6 +1753,7 @@ class cHipLpc : public cLpc {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       const char *met = getStr("method");
       usable_ = met && !strncasecmp(met, "acf", 3) && getInt("p") == 11 && getInt("saveLPCoeff") == 1 && !getInt("saveRefCoeff") &&
@@ -1560,6 +1786,7 @@ class cHipFormantLpc : public cFormantLpc {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       const sDmLevelConfig *c = reader_->getLevelConfig();
       usable_ = getInt("nFormants") == 5 && getInt("saveFormants") == 1 && getInt("saveBandwidths") == 1 && !getInt("saveIntensity") &&
@@ -1599,6 +1826,7 @@ class cHipHarmonics : public cHarmonics {
   DevBytes fm_, f0_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       static const char *const diffs[2] = {"H1-H2", "H1-A3"};
       bool ok = getInt("nHarmonics") == 100 && getInt("nHarmonicMagnitudes") == 0 && getInt("harmonicDifferencesLog") == 1 &&
@@ -1677,6 +1905,8 @@ class cHipPitchJitter : public cPitchJitter {
   std::vector<int16_t> pcm_;
  protected:
   eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (g_fused.big) return cPitchJitter::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
     if (!ready_) {
       ready_ = true;
       usable_ = !jitterLocalEnv && !jitterDDPEnv && !shimmerLocalEnv && !shimmerLocalDBEnv && !shimmerUseRmsAmplitude && !harmonicERMS &&
@@ -1769,6 +1999,8 @@ class cHipValbasedSelector : public cValbasedSelector {
   cVector *my_ = nullptr;
  protected:
   eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (g_fused.big) return cValbasedSelector::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
     if (!ready_) {
       threshold_ = (FLOAT_DMEM)getDouble("threshold");
       adaptive_ = (int)getInt("adaptiveThreshold");
@@ -1858,13 +2090,34 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
   }
  protected:
   eTickResult myTick(long long t) override {
+    g_fused.init();
     if (!ready_) setup();
     if (!usable_) {
       HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with six candidates and bufferLength <= 40 is built");
       return cPitchSmootherViterbi::myTick(t);
     }
     int32_t n = 0, fr[64], st[64];
-    if (isEOI()) {
+    if (g_fused.big) {
+      // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
+      // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
+      // last P, P as the fused batch's own pass left it
+      const long T = g_fused.f0_frames, P = g_fused.f0_pending;
+      if (isEOI()) {
+        if (!flushed_) {
+          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 64; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
+          flushed_ = true;
+        }
+      } else {
+        cVector *vec = reader_->getNextFrame();
+        if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+        std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+        h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
+        hist_.push_back(h);
+        const long f = (long)hist_.size() - 1;
+        if (f < T - P) { fr[0] = (int32_t)f; st[0] = (int32_t)nCand_; n = 1; }
+        g_fused_stage++;
+      }
+    } else if (isEOI()) {
       if (!flushed_) {
         check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 64));
         flushed_ = true;

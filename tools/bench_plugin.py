@@ -43,8 +43,8 @@ def main():
         for name, conf, opt, extra, frames in cases:
             modes = [("cpu_binary", {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, extra),
                      ("plugin_per_component", {}, conf, extra)]
+            modes.append(("plugin_fused_unmodified_conf", {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, extra))       # (round 3: the big sets too)
             if name == "MFCC12_0_D_A":
-                modes.append(("plugin_fused_unmodified_conf", {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, extra))
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", "mfcc12_0_d_a"]))
             if name in fused_sets:                          # the whole LLD level from ONE source component, the reference's sinks
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "LLD_hip.conf"), ["-featureSet", fused_sets[name]]))
