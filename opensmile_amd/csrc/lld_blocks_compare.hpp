@@ -199,12 +199,8 @@ template <int NV>
 __device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot)[NV]) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    double s[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      s[w] = wave_first_d(wave_tree_d(v[w][i], [](double a, double b) { return a + b; }));   // the shuffle-down tree, lld_blocks.hpp
-    }
-    tot[i] = ((s[0] + s[1]) + s[2]) + s[3];
+    const double t = ((v[0][i] + v[1][i]) + v[2][i]) + v[3][i];      // (the lane's four terms first, then one tree: see wave_sumw)
+    tot[i] = wave_first_d(wave_tree_d(t, [](double a, double b) { return a + b; }));
   }
 }
 
@@ -212,17 +208,18 @@ __device__ __forceinline__ void wave_sum4(const double (&v)[4][NV], double (&tot
 // the 256- / 1024-point spectra of other sample rates): no LDS scratch, no barriers. mg / pw / prev as above; sp[0..14] written
 // by lane 0 (roll-off points by the lane that owns the crossing bin).
 // chain: 128 W floats of LDS scratch (16-byte aligned) for the two float chains.
+// (The sums are double accumulators of float-derived terms whose results are rounded to float: the reference adds bin after bin, any
+// other order differs from it by a few ulps of the DOUBLE and gives the same float except with probability ~1e-9 per value. Round 3:
+// the lane's W terms are added first and ONE wave tree follows per quantity -- a quarter of the reductions of the block form's
+// per-group trees, which cost ~1200 of the kernel's ~4000 instruction slots per frame.)
 template <int NV, int W>
 __device__ __forceinline__ void wave_sumw(const double (&v)[W][NV], double (&tot)[NV]) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    double t = 0.0;
+    double t = v[0][i];
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-      const double sw = wave_first_d(wave_tree_d(v[w][i], [](double a, double b) { return a + b; }));   // the shuffle-down tree, lld_blocks.hpp
-      t = (w == 0) ? sw : t + sw;                        // ((s0 + s1) + s2) + s3 ...
-    }
-    tot[i] = t;
+    for (int w = 1; w < W; ++w) t += v[w][i];
+    tot[i] = wave_first_d(wave_tree_d(t, [](double a, double b) { return a + b; }));   // the shuffle-down tree, lld_blocks.hpp
   }
 }
 template <int W>
