@@ -36,7 +36,7 @@ constexpr int kRun = 8;          // frames per workgroup (the flux needs the pre
 __device__ unsigned long long g_phase_cmp[16];
 #define PHASE_DECL unsigned long long ph_acc[8] = {0}; unsigned long long ph_last = __builtin_amdgcn_s_memtime();
 #define PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
-#define PHASE_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_cmp[i_], ph_acc[i_]); } while (0)
+#define PHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_cmp[i_], ph_acc[i_]); } while (0)
 extern "C" int smilehip_debug_phase_cmp(unsigned long long *out16, int reset) {
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cmp), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) {
@@ -206,7 +206,8 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
-  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 96;
+  const int rawpad = (Q.N60 + 3) & ~3;
+  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 96 + rawpad;
   float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
   float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
@@ -216,6 +217,11 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   float *melv = prev + Kpad;
   float *aud = melv + 32;
   float *lmel = aud + 32;
+  // the frame's raw samples: the 60 ms span the zero-crossing rate covers (its first N samples are the 20 ms frame), staged ONCE per frame
+  // with coalesced loads. (Round 3, phase timing: the energy + ZCR section read every sample three times from global memory through
+  // the int16 / float accessor -- 45 dependent loads per lane and frame, 28 % of the kernel.)
+  float *raw = lmel + 32;
+  (void)yv;
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
@@ -238,7 +244,10 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   SC.slope_S2f = Q.slope_S2f;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
-  for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
+  PHASE_DECL
+  const int t_begin = t0 > 0 ? t0 - 1 : 0;
+  int rbase = 0;
+  for (int t = t_begin; t < t_last; ++t) {
     // an opaque copy of the lane index per frame: otherwise everything below that depends on the lane only (bit-reversed
     // FFT addresses, table addresses, range tests) is hoisted out of the frame loop and kept in ~150 VGPRs across it --
     // two waves per SIMD instead of four
@@ -250,21 +259,37 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
     float *rawB = Q.rawB + (f0 + t) * 55;
     // (asking for frame t + 1's samples here, a frame ahead, was measured: -2 % for this kernel alone, +24 % for the whole
     // ComParE level of a small batch, where the kernel runs beside the jitter pass -- not kept)
-    for (int n = lane; n < P.N; n += 64) yv[n] = x[n];
+    // `raw` is a ring over the 60 ms window: consecutive frames of the run share all but one hop of it, so only the H new samples are
+    // loaded (the whole window at the run's first frame); sample n of THIS frame's window sits at raw[(n + rbase) mod N60]. Samples past
+    // the end of the utterance (the last frames, where only the 20 ms frame still exists) are not read.
+    const int64_t left = utt_len - (int64_t)t * P.H;
+    const int lim = left < (int64_t)Q.N60 ? (int)left : Q.N60;
+    if (t == t_begin) {
+      rbase = 0;
+      for (int n = lane; n < lim; n += 64) raw[n] = x[n];
+    } else {
+      rbase += P.H;
+      if (rbase >= Q.N60) rbase -= Q.N60;
+      for (int n = Q.N60 - P.H + lane; n < lim; n += 64) { int k = n + rbase; if (k >= Q.N60) k -= Q.N60; raw[k] = x[n]; }
+    }
+    const auto R = [&](int n) { int k = n + rbase; if (k >= Q.N60) k -= Q.N60; return raw[k]; };
     WaveG::sync();
+    PHASE(0);
     const auto load_pair = [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-      return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
-                         (n1 >= 0 && n1 < P.N) ? yv[n1] * P.window[n1] + P.win_offset : 0.0f);
+      return make_float2((n0 >= 0 && n0 < P.N) ? R(n0) * P.window[n0] + P.win_offset : 0.0f,
+                         (n1 >= 0 && n1 < P.N) ? R(n1) * P.window[n1] + P.win_offset : 0.0f);
     };
     if (OO.tw) oo_wave_forward(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
     else wave_cfft(z, M, P.tw_half, lane, load_pair);
+    PHASE(1);
     for (int k = lane; k <= M; k += 64) {
       const float m = bin_magnitude(OO.tw ? oo_wave_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;
     }
     WaveG::sync();
+    PHASE(2);
     if (warm) {
       for (int k = lane; k < K; k += 64) prev[k] = mg[k];
       WaveG::sync();
@@ -285,6 +310,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       for (int i = 0; i < P.n_bands; i++) d += aud[i];
       rawA[0] = d / (float)P.n_bands;
     }
+    PHASE(3);
     // R12 in the block kernel's summation order: lane l holds the partial sums of its threads l, l+64, l+128, l+192
     {
       double v0[4][2];
@@ -292,10 +318,10 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       for (int w = 0; w < 4; ++w) {
         const int tid = lane + 64 * w;
         v0[w][0] = 0.0; v0[w][1] = 0.0;
-        for (int n = tid; n < P.N; n += 256) { const float tmp = x[n]; v0[w][0] += tmp * tmp; }   // (yv is gone by now)
+        for (int n = tid; n < P.N; n += 256) { const float tmp = R(n); v0[w][0] += tmp * tmp; }
         if (t < T60)
           for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
-            const float a = x[i - 1], b = x[i], c = x[i + 1];
+            const float a = R(i - 1), b = R(i), c = R(i + 1);
             if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) v0[w][1] += 1.0;
           }
       }
@@ -306,11 +332,14 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
         if (t < T60) rawA[3] = (float)tot[1] / (float)Q.N60;
       }
     }
+    PHASE(4);
     spectral_frame_wave<W>(mg, pw, prev, t == 0, SC, K, reinterpret_cast<float *>(z), rawB + 26);   // z: free between two transforms
     WaveG::sync();
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
+    PHASE(5);
   }
+  PHASE_FLUSH;
 }
 
 // Two builds of the same body. Three waves per SIMD (167 VGPRs, 4 spilled): ComParE A+B alone 12.8 -> 10.1 ms per 1000 x 10 s,
@@ -476,7 +505,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.K != M + 1 || P.N > P.Nfft) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks, FFT 512)
   if (P.Nfft != 512) {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (!P.oo.tw) return hipErrorInvalidValue;            // (the own-order A/B transform exists for the tuned geometry only)
     const void *fn = P.Nfft == 256 ? reinterpret_cast<const void *>(&lld_compare_frame_wave_g<2>) : reinterpret_cast<const void *>(&lld_compare_frame_wave_g<8>);
     hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -488,7 +517,13 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96));
+    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
+    if (P.N > Q.N60) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea != hipSuccess) return ea;
+    }
     static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);

@@ -8,5 +8,6 @@ SRC=../../opensmile_amd/csrc
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$SRC -I../../include"
 mkdir -p build
 /opt/rocm/bin/hipcc $F "$@" -c $SRC/lld_compare.hip -o build/lld_compare_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsmilehip_$NAME.so build/lld_compare_$NAME.o \
-  $SRC/lld_f0.o $SRC/lld_mfcc512.o $SRC/lld_kernels.o $SRC/lld_stage_kernels.o $SRC/lld_stage2_kernels.o $SRC/lld_is09.o $SRC/lld_functionals.o $SRC/smilehip_core.o $SRC/smilehip_plan.o $SRC/smilehip_batch.o $SRC/smilehip_stage.o $SRC/tables.o
+# every other object of the product library as the Makefile built it (make -C opensmile_amd/csrc first)
+OBJS=$(cd $SRC && ls *.o | grep -v '^lld_compare.o$' | sed "s#^#$SRC/#")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsmilehip_$NAME.so build/lld_compare_$NAME.o $OBJS
