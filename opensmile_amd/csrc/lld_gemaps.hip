@@ -39,6 +39,8 @@ __device__ unsigned long long g_phase_gm[16];
 #define GPHASE_DECL unsigned long long gph_acc[8] = {0}; unsigned long long gph_last = __builtin_amdgcn_s_memtime();
 #define GPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gph_acc[i] += t_ - gph_last; gph_last = t_; } while (0)
 #define GPHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_gm[i_], gph_acc[i_]); } while (0)
+// the 20 ms frame kernel's phases go to slots 8 .. 15
+#define GPHASE20_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_gm[8 + i_], gph_acc[i_]); } while (0)
 }  // namespace smilehip
 extern "C" int smilehip_debug_phase_gm(unsigned long long *out16, int reset) {
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(smilehip::g_phase_gm), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
@@ -53,6 +55,7 @@ namespace smilehip {
 #define GPHASE_DECL
 #define GPHASE(i)
 #define GPHASE_FLUSH
+#define GPHASE20_FLUSH
 #endif
 
 namespace {
@@ -133,15 +136,14 @@ __device__ __forceinline__ void gemaps_spectral_wave(const float *mg, const floa
     }
     // sum01 / sum15 are FLOAT_DMEM accumulators (:997-1022): one lane adds the powers bin after bin, the two bands as two
     // interleaved chains (a band that has ended adds +0: s + 0 = s)
+    // (the band edges n1 / n2 come from the plan: finding them with two loops of double products on one lane, every frame, was part of
+    // the 39 % this function took of the 20 ms kernel; the two chains run side by side on lanes 0 and 1)
     float s01 = 0.0f, s15 = 0.0f;
-    if (lane == 0) {
-      int n1 = 0, n2 = 0;                                // bins with f < 1000, bins with f <= 5000
-      while (n1 < K && F0 * (double)n1 < 1000.0) ++n1;
-      n2 = n1;
-      while (n2 < K && !(F0 * (double)n2 > 5000.0)) ++n2;
-      s01 = seq_sum_f32(pw, 0, n1);                      // (measured alternative: every lane walking the bins with v_readlane, 2 % slower)
-      s15 = seq_sum_f32(pw, n1, n2);
+    if (lane < 2) {
+      const float sb = seq_sum_f32(pw, lane == 0 ? 0 : G.ar_n1, lane == 0 ? G.ar_n1 : G.ar_n2);   // (measured alternative: every lane walking the bins with v_readlane, 2 % slower)
+      s01 = sb;
     }
+    s15 = __shfl(s01, 1);
     for (int j = G.rng_lo + lane; j <= G.rng_hi; j += 64) {
       const double myB = (double)mg[j] - (double)prev[j];
       fl += myB * myB;
@@ -221,6 +223,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   };
   const bool ahead = !xuf && P.N <= 512;                 // (longer frames -- 20 ms above 25.6 kHz -- are read at the frame like float input)
   if (ahead) prefetch(xu + (int64_t)(t0 > 0 ? t0 - 1 : 0) * P.H, lane);
+  GPHASE_DECL
   for (int t = (t0 > 0 ? t0 - 1 : 0); t < t_last; ++t) {
     int lane = lane_in;                                  // opaque per frame (see lld_compare_frame_wave): nothing that depends on
     asm volatile("" : "+v"(lane));                       // the lane only is kept in registers across the frame loop
@@ -241,6 +244,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       for (int n = lane; n < P.N; n += 64) { const float tmp = yv[n]; e2 += tmp * tmp; }
       e2 = WaveG::sum(e2, nullptr);
     }
+    GPHASE(0);   // frame into LDS, energy2
     const auto load_pair = [&](int i) {
       const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
       return make_float2((n0 >= 0 && n0 < P.N) ? yv[n0] * P.window[n0] + P.win_offset : 0.0f,
@@ -248,6 +252,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
     };
     if (OO.tw) oo_wave_forward(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
     else wave_cfft(z, M, P.tw_half, lane, load_pair);
+    GPHASE(1);   // FFT
     float *spec = G.spec220 + (f0 + t) * kRsI;
     for (int k = lane; k <= M; k += 64) {
       const float2 X = OO.tw ? oo_wave_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full);
@@ -262,6 +267,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       }
     }
     WaveG::sync();
+    GPHASE(2);   // magnitudes, spectrum rows for cSpecResample
     if (warm) {
       for (int k = lane; k < K; k += 64) prev[k] = mg[k];
       WaveG::sync();
@@ -283,12 +289,15 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       raw[0] = d / (float)P.n_bands;
     }
     if (lane == 0) raw[10] = (float)(e2 / (double)P.N) * 1.0f + 0.0f;
+    GPHASE(3);   // mel, auditory spectrum, MFCC
     gemaps_spectral_wave(mg, pw, prev, t == 0, lg, G, K, lane, raw + 1);
     if (lane == 0) raw[11] = 0.0f;
     WaveG::sync();
     for (int k = lane; k < K; k += 64) prev[k] = mg[k];
     WaveG::sync();
+    GPHASE(4);   // GeMAPS spectral descriptors
   }
+  GPHASE20_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------ cSpecResample + cLpc

@@ -174,6 +174,7 @@ struct GemapsParams {
   int32_t sl_iL[2], sl_iR[2];       // cSpectral slopes 0-500 / 500-1500: edge bins, weights, Nind (spectral.cpp:872-946)
   double sl_wL[2], sl_wR[2], sl_Nind[2];
   int32_t rng_lo, rng_hi;           // freqRange 0-5000 in bins (flux)
+  int32_t ar_n1, ar_n2;             // alpha ratio: bins [0, n1) have f < 1000 Hz, bins [n1, n2) 1000 <= f <= 5000 Hz (f = i / fsSec)
   float spec_floor, log_spec_floor, log_spec_factor;
   // ---- cSpecResample -> cLpc -> cFormantLpc ----
   const float *rs_cos, *rs_sin;     // [109 x 220] smileDsp_initIrdft's tables, transposed: [k/2 - 1][i]

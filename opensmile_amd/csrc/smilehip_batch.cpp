@@ -588,6 +588,7 @@ void gemaps_plan_consts(const smilehip_plan *plan, GemapsParams &G) {
     G.sl_wL[i] = plan->gm_sl_wL[i]; G.sl_wR[i] = plan->gm_sl_wR[i]; G.sl_Nind[i] = plan->gm_sl_Nind[i];
   }
   G.rng_lo = plan->gm_rng_lo; G.rng_hi = plan->gm_rng_hi;
+  G.ar_n1 = plan->gm_ar_n1; G.ar_n2 = plan->gm_ar_n2;
   G.spec_floor = plan->gm_spec_floor; G.log_spec_floor = plan->gm_log_spec_floor; G.log_spec_factor = plan->gm_log_spec_factor;
   G.rs_cos = plan->d_rs_cos.p; G.rs_sin = plan->d_rs_sin.p;
   G.rs_norm = (float)(plan->geo.Nfft / 2);

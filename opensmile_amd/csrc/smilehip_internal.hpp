@@ -134,7 +134,7 @@ struct smilehip_plan {
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
   // eGeMAPS chain: cSpecResample's tables (transposed), cSpectral's band-slope edges and frequency range
   DevBuf<float> d_rs_cos, d_rs_sin;
-  int32_t gm_sl_iL[2] = {0, 0}, gm_sl_iR[2] = {0, 0}, gm_rng_lo = 0, gm_rng_hi = 0;
+  int32_t gm_sl_iL[2] = {0, 0}, gm_sl_iR[2] = {0, 0}, gm_rng_lo = 0, gm_rng_hi = 0, gm_ar_n1 = 0, gm_ar_n2 = 0;
   double gm_sl_wL[2] = {0, 0}, gm_sl_wR[2] = {0, 0}, gm_sl_Nind[2] = {0, 0};
   float gm_spec_floor = 0.f, gm_log_spec_floor = 0.f, gm_log_spec_factor = 0.f;
   double gm_target_fs = 0.0;

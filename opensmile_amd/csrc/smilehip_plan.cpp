@@ -330,6 +330,13 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (hi == -1 || hi >= Nsrc) hi = Nsrc - 1;
     if (lo < 0) lo = 0;
     p->gm_rng_lo = lo; p->gm_rng_hi = hi;
+    {                                                     // the alpha ratio's two bands (spectral.cpp:997-1022), the kernel's own expressions
+      int n1 = 0, n2 = 0;
+      while (n1 < Nsrc && F0 * (double)n1 < 1000.0) ++n1;
+      n2 = n1;
+      while (n2 < Nsrc && !(F0 * (double)n2 > 5000.0)) ++n2;
+      p->gm_ar_n1 = n1; p->gm_ar_n2 = n2;
+    }
     float specFloor = (float)0.0000001;
     specFloor = specFloor * specFloor;
     p->gm_spec_floor = specFloor;

@@ -39,6 +39,11 @@ def main():
     print(f"lld_gemaps_harm: memtime ticks per voiced frame and wave (all frames: {b.total_frames})")
     for nm, x in zip(NAMES, v):
         print(f"  {nm:36s} {x / b.total_frames:8.0f} ticks/frame  {100 * x / v.sum():5.1f} %")
+    names20 = ["frame into LDS, energy2", "FFT", "magnitudes + cSpecResample rows", "mel / auditory spectrum / MFCC", "GeMAPS spectral descriptors"]
+    v = np.array(list(buf)[8:8 + len(names20)], dtype=np.float64)
+    print(f"lld_gemaps_frame20: memtime ticks per frame and wave")
+    for nm, x in zip(names20, v):
+        print(f"  {nm:36s} {x / b.total_frames:8.0f} ticks/frame  {100 * x / v.sum():5.1f} %")
 
 
 if __name__ == "__main__":
