@@ -31,6 +31,13 @@ struct PcmIn {
   __device__ __forceinline__ PcmIn operator+(int64_t o) const { PcmIn r; r.s = s + o; r.f = f ? f + o : nullptr; return r; }
 };
 
+// the same accessor for kernels instantiated for 16-bit input alone (no pointer test at the loads, two registers less)
+struct Pcm16In {
+  const int16_t *s;
+  __device__ __forceinline__ float operator[](int64_t n) const { return pcm16_to_float(s[n]); }
+  __device__ __forceinline__ Pcm16In operator+(int64_t o) const { Pcm16In r; r.s = s + o; return r; }
+};
+
 // R6: one mel band in the reference's accumulation order
 // (cMelspec::processVector, melspec.cpp:544-553): ascending bins, first the
 // rising-slope run (p - p*w), then the falling-slope run (p*w). The reference

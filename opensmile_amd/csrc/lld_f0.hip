@@ -131,8 +131,8 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
-template <class G, bool OO>                            // OO: the reference-order transform (one form per kernel instance: register budget)
-__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const PcmIn x, const float *mag_in, int lane,
+template <class G, bool OO, class XIn = PcmIn>         // OO: the reference-order transform (one form per kernel instance: register budget)
+__device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const XIn x, const float *mag_in, int lane,
                                               double *A, double *B) {
   F0_GEO;
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
@@ -602,7 +602,7 @@ __host__ __device__ inline size_t f0_cand_shared_bytes() {           // a | c | 
   return G::kLdsTables ? (size_t)G::kKP * 8 * 4 + (size_t)G::kKP * 4 : 0;
 }
 
-template <int LOGM, bool OO>
+template <int LOGM, bool OO, bool S16 = false>         // S16: the instance for 16-bit input (the tuned geometry's fast path)
 __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params &Q) {
   using G = F0G<LOGM>;
   F0_GEO;
@@ -635,7 +635,9 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   const int64_t samp0 = P.tile_rec[tile].samp0;
   const int n_fr = P.tile_rec[tile].n_frames;
   for (int w = 0; w < n_fr; ++w) {
-    const double es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
+    double es;
+    if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
+    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     double *row = Q.ab + fr * kKP;
     double *bb = Q.ab + Q.ab_rows * kKP;
@@ -649,9 +651,9 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   }
 }
 // (the register budget of the tuned geometry is pinned; the other geometries take what the compiler gives them)
-template <bool OO>
+template <bool OO, bool S16>
 __global__ void __launch_bounds__(F0G<9>::kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_f0_spec(LldParams P, F0Params Q) {
-  f0_spec_body<9, OO>(P, Q);
+  f0_spec_body<9, OO, S16>(P, Q);
 }
 template <int LOGM>
 __global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_spec_g(LldParams P, F0Params Q) {
@@ -1508,8 +1510,11 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
   const bool oo = Q0.oo.tw != nullptr;
   if (!oo && LOGM != 9) return hipErrorInvalidValue;     // SMILEHIP_FFT=radix2 (the A/B switch) exists for FFT 1024 only
   const void *spec;
-  if constexpr (LOGM == 9) spec = oo ? reinterpret_cast<const void *>(&lld_f0_spec<true>) : reinterpret_cast<const void *>(&lld_f0_spec<false>);
-  else spec = reinterpret_cast<const void *>(&lld_f0_spec_g<LOGM>);
+  const bool s16 = P.pcm_f32 == nullptr;
+  if constexpr (LOGM == 9) {
+    if (oo) spec = s16 ? reinterpret_cast<const void *>(&lld_f0_spec<true, true>) : reinterpret_cast<const void *>(&lld_f0_spec<true, false>);
+    else spec = s16 ? reinterpret_cast<const void *>(&lld_f0_spec<false, true>) : reinterpret_cast<const void *>(&lld_f0_spec<false, false>);
+  } else spec = reinterpret_cast<const void *>(&lld_f0_spec_g<LOGM>);
   hipError_t e = hipFuncSetAttribute(spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand<LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
@@ -1520,8 +1525,10 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
     Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
     const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
     if constexpr (LOGM == 9) {
-      if (oo) hipLaunchKernelGGL(lld_f0_spec<true>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else hipLaunchKernelGGL(lld_f0_spec<false>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      if (oo && s16) hipLaunchKernelGGL((lld_f0_spec<true, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else if (oo) hipLaunchKernelGGL((lld_f0_spec<true, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else if (s16) hipLaunchKernelGGL((lld_f0_spec<false, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else hipLaunchKernelGGL((lld_f0_spec<false, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
     } else {
       hipLaunchKernelGGL(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
     }
