@@ -327,6 +327,15 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   // frame (a few hundred integer operations) and brings the kernel to three waves per SIMD.
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
+#ifdef SMILEHIP_PHASE_TIMING
+  unsigned long long sub_t[5];
+  sub_t[0] = __builtin_amdgcn_s_memtime();
+#define F0_SUB(i) sub_t[i] = __builtin_amdgcn_s_memtime()
+#define F0_SUB_FLUSH do { if (lane_in == 0) for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&g_phase_f0[8 + i_], sub_t[i_ + 1] - sub_t[i_]); } while (0)
+#else
+#define F0_SUB(i)
+#define F0_SUB_FLUSH
+#endif
   float *hps = reinterpret_cast<float *>(A), *SS = hps + kKP;
   float hv[kPer];
   F0_FOR_BINS(m, i) {
@@ -348,6 +357,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   }
   WaveG::sync();
   if (only_scale) return 0;
+  F0_SUB(1);   // spline evaluation + auditory weighting
   F0_FOR_BINS(m, i) if (i < kK) hps[i] = hv[m];
   WaveG::sync();
   // SS[j] = (in[j] + sum_h in[j + shift_h] * scale_h) / nHarmonics, terms in harmonic order
@@ -368,6 +378,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     hv[m] = s;
   }
   F0_FOR_BINS(m, j) if (j < kK) { SS[j] = hv[m]; B[j] = (double)hv[m]; }
+  F0_SUB(2);   // harmonic summation
   if (mean_exact) {
     double part = 0.0;
     float mn = INFINITY;
@@ -380,6 +391,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
     *mean_exact = ok ? S / (double)kK : __longlong_as_double(0x7ff8000000000000ll);
   }
   WaveG::sync();
+  F0_SUB(3);   // exact-mean test
   // local maxima, then the six best: greedy insertion (:262-283) keeps (score descending, bin ascending)
   float lf[kPer], rt[kPer];
   F0_FOR_BINS(m, j) {
@@ -409,6 +421,8 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
       n_found = r + 1;
     }
   }
+  F0_SUB(4);   // local maxima + top six
+  F0_SUB_FLUSH;
   return n_found;
 }
 

@@ -41,6 +41,10 @@ def main():
     print(f"memtime ticks per frame per wave: {tot / b.total_frames:.0f}")
     for nm, x in zip(NAMES, v):
         print(f"  {nm:26s} {x / b.total_frames:8.0f} ticks/frame  {100 * x / tot:5.1f} %")
+    sub = np.array(list(buf)[8:12], dtype=np.float64) / n
+    print("inside 'interp + summation + top six' (f0_shs):")
+    for nm, x in zip(["spline evaluation + auditory weighting", "harmonic summation", "exact-mean test", "local maxima + top six"], sub):
+        print(f"  {nm:40s} {x / b.total_frames:8.0f} ticks/frame  {100 * x / sub.sum():5.1f} %")
 
 
 if __name__ == "__main__":
