@@ -56,10 +56,12 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   int *iscr = reinterpret_cast<int *>(scr + 4);
 
   int lo = 0, hi = P.n_utt;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (P.frame_off[mid] <= row) lo = mid; else hi = mid;
-  }
+  if (P.frame_utt) lo = P.frame_utt[row];                // (one load instead of log2(n_utt) dependent ones per frame)
+  else
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (P.frame_off[mid] <= row) lo = mid; else hi = mid;
+    }
   const int64_t t = row - P.frame_off[lo];
   const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
   float *out = Q.raw16 + row * 16;

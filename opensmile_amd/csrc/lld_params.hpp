@@ -28,6 +28,7 @@ struct LldParams {
   int64_t pcm_total;           // samples in the packed buffer (= samp_off[n_utt])
   const int64_t *samp_off;     // [n_utt+1] sample offsets (device)
   const int64_t *frame_off;    // [n_utt+1] output row offsets (device)
+  const int32_t *frame_utt;    // optional [total_frames]: the utterance of a frame (else: binary search in frame_off)
   const int32_t *tile_utt;     // [n_tiles] utterance of tile
   const int32_t *tile_t0;      // [n_tiles] first frame of tile (within utterance)
   const TileRec *tile_rec;     // [n_tiles] the same tiles, resolved (fast kernel)

@@ -92,6 +92,11 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     delete b;
     return rc;
   }
+  if (plan->cfg.chain_kind == SMILEHIP_CHAIN_IS09 && b->total_frames > 0) {
+    std::vector<int32_t> fu((size_t)b->total_frames);
+    for (int32_t u = 0; u < n_utt; ++u) std::fill(fu.begin() + b->h_frame_off[u], fu.begin() + b->h_frame_off[u + 1], u);
+    if ((rc = b->d_frame_utt.upload(fu))) { delete b; return rc; }
+  }
   if (compare_ab_like(plan)) {
     b->n_runs = (int32_t)run_utt.size();
     if ((rc = b->d_run_utt.upload(run_utt)) || (rc = b->d_run_t0.upload(run_t0))) {
@@ -216,6 +221,7 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.pcm_total = b->h_samp_off.back();
   P.samp_off = b->d_samp_off.p;
   P.frame_off = b->d_frame_off.p;
+  P.frame_utt = b->d_frame_utt.p;
   P.tile_utt = b->d_tile_utt.p;
   P.tile_t0 = b->d_tile_t0.p;
   P.tile_rec = b->d_tile_rec.p;

@@ -191,6 +191,7 @@ struct smilehip_batch {
   int32_t n_runs = 0;
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
+  DevBuf<int32_t> d_frame_utt;     // IS09 chain: utterance of every frame (the frame kernel has one frame per wave and would search frame_off for it)
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
   DevBuf<TileRec> d_tile_rec;
   int32_t n_tiles = 0, n_dtiles = 0;
