@@ -21,6 +21,31 @@
 
 namespace smilehip {
 
+// Development instrumentation (tools/ubench/variant_any.sh is09 phaseis09 -DSMILEHIP_PHASE_TIMING): s_memtime at the phase boundaries of
+// the frame body, summed over all waves by lane 0. Not compiled into the product. (Wave RESIDENCE, not issue slots: with six waves per
+// SIMD a phase that waits for memory shows large here and costs little -- round 3 learnt that by turning the kernel into persistent
+// waves with a register prefetch: 256 VGPRs, one wave per SIMD, 3 x slower.)
+#ifdef SMILEHIP_PHASE_TIMING
+__device__ unsigned long long g_phase_is09[16];
+#define IPHASE_DECL unsigned long long iph_last = __builtin_amdgcn_s_memtime(); unsigned long long iph_acc[8] = {0};
+#define IPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); iph_acc[i] += t_ - iph_last; iph_last = t_; } while (0)
+#define IPHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_is09[i_], iph_acc[i_]); } while (0)
+}  // namespace smilehip
+extern "C" int smilehip_debug_phase_is09(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(smilehip::g_phase_is09), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smilehip::g_phase_is09), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace smilehip {
+#else
+#define IPHASE_DECL
+#define IPHASE(i)
+#define IPHASE_FLUSH
+#endif
+
 // the tables a frame reads: in global memory for the workgroup kernel, staged in LDS once per workgroup for the wave kernel
 // (143 global loads per frame and wave before: the kernel waited on them)
 struct Is09Tbl {
@@ -68,8 +93,10 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   int logM = 0;
   while ((1 << logM) < M) ++logM;
 
+  IPHASE_DECL
   for (int n = G::tid(); n < P.N; n += G::size()) xr[n] = x[n];                      // R0 (or already done: float input)
   G::sync();
+  IPHASE(0);   // utterance lookup + frame load
 
   // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
   {
@@ -79,6 +106,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     const int total = G::sum_i(cnt, iscr);
     if (G::tid() == 0) out[13] = (float)total / (float)P.N;
   }
+  IPHASE(1);   // ZCR
   // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
   double e2 = 0.0;
   for (int n = G::tid(); n < P.N; n += G::size()) {
@@ -93,6 +121,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     const double d = G::sum(e2, scr);
     if (G::tid() == 0) out[0] = (float)sqrt(d / (float)P.N) * 1.0f + 0.0f;
   }
+  IPHASE(2);   // pre-emphasis, window, RMS energy
   // R4 forward real FFT
   if (T.oo.tw) {                                         // the reference's operation order (lld_ooura.hpp / lld_ooura_wave.hpp)
     const auto load_pair = [&](int i) {
@@ -126,6 +155,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
       mg[k] = bin_magnitude(untangle_bin(re, im, M, k, T.tw_full), k == 0 || k == M);     // R5
   }
   G::sync();
+  IPHASE(3);   // forward transform + magnitudes
   // R6 / R7: mel (usePower per config) -> log -> DCT
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = P.use_power ? mg[k] * mg[k] : mg[k];
   G::sync();
@@ -136,6 +166,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     out[1 + r] = dct_coeff(lmel, T.dct_rows + r * P.n_bands, P.n_bands, P.dct_gain[r]);
   G::sync();
 
+  IPHASE(4);   // mel, log, DCT
   // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum, then the cepstrum instance
   for (int k = G::tid(); k <= M; k += G::size()) sp[k] = mg[k] * mg[k];                // usePower=1 (:252-259)
   G::sync();
@@ -151,6 +182,7 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
   else if constexpr (kWave) wave_irfft_even(sp, z, M, T.tw_half, T.tw_full, cep, (float)P.K, false, G::tid());
   else group_irfft_even<G>(sp, re, im, M, logM, T.tw_half, T.tw_full, cep, (float)P.K, false);
 
+  IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
   double voicing, Tsamp;
   int max_idx;
@@ -163,6 +195,8 @@ __device__ __forceinline__ void is09_frame_body(const LldParams &P, const Is09Pa
     out[14] = (float)voicing;
     out[15] = pitch;                                    // smoothed in place by lld_pitch_smooth
   }
+  IPHASE(6);   // cPitchACF
+  IPHASE_FLUSH;
 }
 
 // one workgroup per frame (any FFT size the LDS holds)
