@@ -71,6 +71,8 @@ class FuncSpec(C.Structure):
         ("pk_mask", C.c_uint32), ("pk_norm", C.c_int32), ("pk_ratio_limit", C.c_int32), ("pk_dyn_rel", C.c_int32),
         ("pk_use_abs", C.c_int32), ("reserved5", C.c_int32),
         ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
+        ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
+        ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
     ]
 
 

@@ -178,4 +178,42 @@ GLF_HD float glibc_atan2f(float y, float x) {
   return (z - pi_lo) - pi;
 }
 
+// __ieee754_acosf (sysdeps/ieee754/flt-32/e_acosf.c, fdlibm's float formula, built without FMA). cLsp's `acos(xm)` on a
+// FLOAT_DMEM (lsp.cpp:138, :254) is the C++ float overload, i.e. acosf. Checked against the real libm for all 2^32 arguments.
+GLF_HD float glibc_acosf(float x) {
+  const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f, pS0 = 1.6666667163e-01f,
+              pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f,
+              pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f,
+              qS4 = 7.7038154006e-02f;
+  const int32_t hx = (int32_t)glf::f2u(x), ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + (float)2.0 * pio2_lo;
+  if (ix > 0x3f800000) return (x - x) / (x - x);
+  if (ix < 0x3f000000) {                                  // |x| < 0.5
+    if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+    const float z = x * x;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    return pio2_hi - (x - (pio2_lo - r * x));
+  }
+  if (hx < 0) {                                           // x < -0.5
+    const float z = (one + x) * (float)0.5;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float s = __builtin_sqrtf(z);
+    const float r = p / q;
+    const float w = r * s - pio2_lo;
+    return pi - (float)2.0 * (s + w);
+  }
+  const float z = (one - x) * (float)0.5;                 // x > 0.5
+  const float s = __builtin_sqrtf(z);
+  const float df = glf::u2f(glf::f2u(s) & 0xfffff000u);
+  const float c = (z - df * df) / (s + df);
+  const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const float r = p / q;
+  const float w = r * s + c;
+  return (float)2.0 * (df + w);
+}
+
 }  // namespace smilehip

@@ -38,6 +38,7 @@ static int fam_count(const lldo_func_spec *s, int fam)
     case LLDO_FAM_SEGMENTS: return popc(s->seg_mask & 0x1fu);
     case LLDO_FAM_LPC: return (s->lpc_gain ? 1 : 0) + (s->lpc_coeffs ? s->lpc_order - s->lpc_first : 0);
     case LLDO_FAM_PEAKS2: return popc(s->pk_mask);
+    case LLDO_FAM_ONSET: return popc(s->ons_mask & 0x1fu);
   }
   return -1;
 }
@@ -963,6 +964,44 @@ static int cmp_float(const void *a, const void *b)
   return (x > y) - (x < y);
 }
 
+/* ------------------------------------------------------------------ Onset (functionalOnset.cpp:83-151) */
+static int f_onset(const lldo_func_spec *s, const float *in, float *out, long Nin)
+{
+  long onsetPos = -1, offsetPos = -1, nOnsets = 0, nOffsets = 0;
+  int oo = 0;
+  if (in[0] > s->ons_thr_on) oo = 1;
+  for (long i = 1; i < Nin; i++) {
+    float cur;
+    if (s->ons_use_abs) cur = (float)fabs(in[i]);
+    else cur = in[i];
+    if (cur > s->ons_thr_on) {
+      if (oo == 0) { nOnsets++; if (onsetPos == -1) onsetPos = i; oo = 1; }
+    }
+    if (cur <= s->ons_thr_off) {
+      if (oo == 1) { nOffsets++; offsetPos = i; oo = 0; }
+    }
+  }
+  if (offsetPos == -1) offsetPos = Nin - 1;
+  if (onsetPos == -1) onsetPos = 0;
+  const uint32_t m = s->ons_mask;
+  int n = 0;
+  if (s->ons_norm == LLDO_NORM_SEGMENT) {
+    if (BIT(m, 0)) out[n++] = (float)onsetPos / (float)(Nin);
+    if (BIT(m, 1)) out[n++] = (float)offsetPos / (float)(Nin);
+  } else if (s->ons_norm == LLDO_NORM_SECOND) {
+    const float T = (float)s->period;
+    if (BIT(m, 0)) out[n++] = (float)onsetPos * T;
+    if (BIT(m, 1)) out[n++] = (float)offsetPos * T;
+  } else {
+    if (BIT(m, 0)) out[n++] = (float)onsetPos;
+    if (BIT(m, 1)) out[n++] = (float)offsetPos;
+  }
+  if (BIT(m, 2)) out[n++] = (float)nOnsets;
+  if (BIT(m, 3)) out[n++] = (float)nOffsets;
+  if (BIT(m, 4)) { const float T = (float)s->period; out[n++] = (float)nOnsets / ((float)Nin * T); }
+  return n;
+}
+
 int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int64_t rows, int cols, float *out)
 {
   const int per = lldo_funcspec_count(s);
@@ -1012,6 +1051,7 @@ int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int
         case LLDO_FAM_SEGMENTS: got = f_segments(s, col, min, max, o, NN); break;
         case LLDO_FAM_LPC: got = f_lpc(s, col, o, NN); break;
         case LLDO_FAM_PEAKS2: got = f_peaks2(s, col, min, max, meanf, o, NN); break;
+        case LLDO_FAM_ONSET: got = f_onset(s, col, o, NN); break;
       }
       for (int j = got; j < want; j++) o[j] = 0.0f;
       o += want;

@@ -538,7 +538,7 @@ def htk_variant_chain(name, pcm):
 
 # ---- general functionals engine (lld_oracle_funcspec.c) ---------------------------------------------------------
 FAM = {"Extremes": 0, "Means": 1, "Moments": 2, "Regression": 3, "Percentiles": 4, "Times": 5, "Segments": 6, "Lpc": 7,
-       "Peaks2": 8}
+       "Peaks2": 8, "Onset": 9}
 NORM = {"segment": 0, "second": 1, "frame": 2}
 EXT_NAMES = ["max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"]
 MEANS_NAMES = ["amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness", "posamean",
@@ -549,6 +549,7 @@ REG_NAMES = ["linregc1", "linregc2", "linregerrA", "linregerrQ", "qregc1", "qreg
 PCT_NAMES = ["quartile1", "quartile2", "quartile3", "iqr1-2", "iqr2-3", "iqr1-3"]
 TIMES_NAMES = ["upleveltime25", "downleveltime25", "upleveltime50", "downleveltime50", "upleveltime75", "downleveltime75",
                "upleveltime90", "downleveltime90", "risetime", "falltime", "leftctime", "rightctime", "duration"]
+ONS_NAMES = ["onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"]
 SEG_NAMES = ["numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"]
 PK_NAMES = ["numPeaks", "meanPeakDist", "meanPeakDistDelta", "peakDistStddev", "peakRangeAbs", "peakRangeRel", "peakMeanAbs",
             "peakMeanMeanDist", "peakMeanRel", "ptpAmpMeanAbs", "ptpAmpMeanRel", "ptpAmpStddevAbs", "ptpAmpStddevRel",
@@ -583,6 +584,8 @@ class FuncSpec(C.Structure):
         ("pk_mask", C.c_uint32), ("pk_norm", C.c_int32), ("pk_ratio_limit", C.c_int32), ("pk_dyn_rel", C.c_int32),
         ("pk_use_abs", C.c_int32), ("reserved5", C.c_int32),
         ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
+        ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
+        ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
     ]
 
 
@@ -703,6 +706,8 @@ def funcspec_names(s):
                                                          if s.lpc_coeffs else [])
         elif f == "Peaks2":
             out += [n for k, n in enumerate(PK_NAMES) if s.pk_mask >> k & 1]
+        elif f == "Onset":
+            out += [n for k, n in enumerate(ONS_NAMES) if s.ons_mask >> k & 1]
     return out
 
 
@@ -922,3 +927,106 @@ def frames_cfg(frame_size_sec, win):
     c.lofreq = 20.0
     c.n_delta = 0
     return c
+
+
+# ---------------------------------------------------------------- INTERSPEECH 2010-2012 components (oracle/lld_oracle_is10.c)
+IS10_TAPS_CONF = os.path.join(HERE, "conf", "is10_taps.conf")
+IS10_LEVELS = ["is10_frames", "is10_intens", "is10_fftc", "is10_outpR", "is10_lpc", "is10_lsp", "is10_pitchShs", "is10_pitch",
+               "is10_pitchF", "is10_mspec2", "is10_mspec2log", "is10_jitter", "is10_lld1", "is10_lld2", "is10_lld1_de",
+               "is10_lld2_de", "is10_functOnsets", "is10_funct", "is10_functNz"]
+VOP = {"add": 0, "mul": 1, "log": 2, "lgA": 3, "sqr": 4, "ee": 5, "abs": 6, "dBp": 7, "dBv": 8}
+
+
+def run_reference_is10(pcm, fs=16000, levels=IS10_LEVELS):
+    """Real SMILExtract on the unmodified IS10_paraling.conf (+ HTK taps, oracle/conf/is10_taps.conf): {'lld': T x 76
+    (lld | lld_de as -lldhtkoutput writes them), 'func': 1 x 1582, level name: its rows}."""
+    exe = os.path.join(REF_DIR, "SMILExtract")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = os.path.join(td, "in.wav")
+        write_wav(wav, pcm, fs)
+        subprocess.run([exe, "-C", IS10_TAPS_CONF, "-I", wav, "-lldhtkoutput", "lld.htk", "-htkoutput", "func.htk", "-l", "0"],
+                       check=True, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for k, fn in (("lld", "lld.htk"), ("func", "func.htk")):
+            p = os.path.join(td, fn)
+            out[k] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        for k in levels:
+            p = os.path.join(td, "tap_%s.htk" % k)
+            out[k] = read_htk(p)[0] if os.path.exists(p) else np.zeros((0, 0), np.float32)
+        return out
+
+
+def intensity_rows(frames, intensity=0, loudness=1):
+    """cIntensity over rows of samples: n x N -> n x (intensity + loudness)."""
+    L = lib()
+    frames = np.ascontiguousarray(frames, dtype=np.float32)
+    n, N = frames.shape
+    win = np.zeros(N, np.float64)
+    ws = C.c_double(0.0)
+    L.lldo_intensity_window.argtypes = [C.c_long, C.c_void_p, C.POINTER(C.c_double)]
+    L.lldo_intensity_window(N, win.ctypes.data, C.byref(ws))
+    L.lldo_intensity_frame.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros((n, int(bool(intensity)) + int(bool(loudness))), np.float32)
+    for i in range(n):
+        L.lldo_intensity_frame(frames[i].ctypes.data, N, win.ctypes.data, N, ws, intensity, loudness, out[i].ctypes.data)
+    return out
+
+
+def lsp_rows(lpc):
+    """cLsp over rows of LP coefficients: n x p -> n x p line spectral frequencies."""
+    L = lib()
+    lpc = np.ascontiguousarray(lpc, dtype=np.float32)
+    out = np.zeros_like(lpc)
+    L.lldo_lsp_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for i in range(lpc.shape[0]):
+        L.lldo_lsp_frame(lpc[i].ctypes.data, lpc.shape[1], out[i].ctypes.data)
+    return out
+
+
+class _PitchSmoother(C.Structure):
+    _fields_ = [("n_cand", C.c_int), ("octave_correction", C.c_int), ("post_simple", C.c_int), ("flags", C.c_int),
+                ("voicing_cutoff", C.c_float), ("first_frame", C.c_int), ("ons_flag", C.c_int), ("ons_flag_o", C.c_int),
+                ("last_voice", C.c_float), ("last_final", C.c_float), ("pitch_env", C.c_float)]
+
+
+def pitch_smoother_rows(cands, n_cand=6, voicing_cutoff=0.7, octave_correction=0, post_simple=1, flags=1):
+    """cPitchSmoother over the frames of one stream: rows [F0Cand | candVoicing | candScore] (3 n_cand values each) ->
+    the rows it writes (flags: 1 F0final, 2 F0finEnv, 4 voicingFinalClipped, 8 voicingFinalUnclipped)."""
+    L = lib()
+    cands = np.ascontiguousarray(cands, dtype=np.float32)
+    s = _PitchSmoother()
+    L.lldo_pitch_smoother_init.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.lldo_pitch_smoother_init(C.byref(s), n_cand, voicing_cutoff, octave_correction, post_simple, flags)
+    L.lldo_pitch_smoother_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    w = bin(flags & 15).count("1")
+    out = []
+    row = np.zeros(max(w, 1), np.float32)
+    for i in range(cands.shape[0]):
+        if L.lldo_pitch_smoother_frame(C.byref(s), cands[i].ctypes.data, row.ctypes.data) > 0:
+            out.append(row[:w].copy())
+    return np.array(out, np.float32).reshape(-1, w)
+
+
+def vecop_rows(x, op, param1=1.0, logfloor=1e-12):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    L.lldo_vecop.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_long]
+    assert L.lldo_vecop(VOP[op], param1, logfloor, x.ctypes.data, out.ctypes.data, x.size) == 0
+    return out
+
+
+def specresample_rows(spec, fs_sec, last_fs_sec, base_period, target_fs):
+    """cSpecResample for any geometry: n x Nfft packed spectra -> n x n_out samples."""
+    L = lib()
+    L.lldo_specresample_init.argtypes = [C.POINTER(_SpecRes), C.c_long, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.lldo_specresample_frame.argtypes = [C.POINTER(_SpecRes), C.c_void_p, C.c_void_p]
+    L.lldo_specresample_free.argtypes = [C.POINTER(_SpecRes)]
+    spec = np.ascontiguousarray(spec, dtype=np.float32)
+    r = _SpecRes()
+    L.lldo_specresample_init(C.byref(r), spec.shape[1], fs_sec, last_fs_sec, base_period, target_fs)
+    out = np.zeros((spec.shape[0], r.I), np.float32)
+    for i in range(spec.shape[0]):
+        L.lldo_specresample_frame(C.byref(r), spec[i].ctypes.data, out[i].ctypes.data)
+    L.lldo_specresample_free(C.byref(r))
+    return out

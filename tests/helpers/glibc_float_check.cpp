@@ -12,7 +12,7 @@ static inline bool same(float a, float b) {
   return x == y || (a != a && b != b);
 }
 
-// which: 0 logf, 1 expf, 2 log10f, 3 atanf; arguments = bit patterns lo, lo + step, ... < hi
+// which: 0 logf, 1 expf, 2 log10f, 3 atanf, 4 acosf; arguments = bit patterns lo, lo + step, ... < hi
 extern "C" long long glibc_float_sweep(int which, unsigned long long lo, unsigned long long hi, unsigned long long step,
                                        unsigned int *first_bad) {
   long long bad = 0;
@@ -24,7 +24,8 @@ extern "C" long long glibc_float_sweep(int which, unsigned long long lo, unsigne
     if (which == 0) { r = logf(x); g = smilehip::glibc_logf(x); }
     else if (which == 1) { r = expf(x); g = smilehip::glibc_expf(x); }
     else if (which == 2) { r = log10f(x); g = smilehip::glibc_log10f(x); }
-    else { r = atanf(x); g = smilehip::glibc_atanf(x); }
+    else if (which == 3) { r = atanf(x); g = smilehip::glibc_atanf(x); }
+    else { r = acosf(x); g = smilehip::glibc_acosf(x); }
     if (!same(r, g)) { if (!bad && first_bad) *first_bad = b; ++bad; }
   }
   return bad;

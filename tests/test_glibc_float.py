@@ -18,14 +18,14 @@ def lib():
     hdr = os.path.join(ROOT, "opensmile_amd", "csrc", "glibc_float.hpp")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-builtin-logf",
-                        "-fno-builtin-expf", "-fno-builtin-log10f", "-fno-builtin-atanf", "-fno-builtin-atan2f", "-o", so, src, "-lm"], check=True)
+                        "-fno-builtin-expf", "-fno-builtin-log10f", "-fno-builtin-atanf", "-fno-builtin-atan2f", "-fno-builtin-acosf", "-o", so, src, "-lm"], check=True)
     L = C.CDLL(so)
     L.glibc_float_sweep.restype = C.c_longlong
     L.glibc_float_sweep.argtypes = [C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_uint)]
     return L
 
 
-@pytest.mark.parametrize("which,name", [(0, "logf"), (1, "expf"), (2, "log10f"), (3, "atanf")])
+@pytest.mark.parametrize("which,name", [(0, "logf"), (1, "expf"), (2, "log10f"), (3, "atanf"), (4, "acosf")])
 def test_bits_equal_libm(lib, which, name):
     if "fma" not in open("/proc/cpuinfo").read():
         pytest.skip("CPU without FMA: the dynamic linker selects glibc's non-FMA build of logf / expf")

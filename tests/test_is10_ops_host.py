@@ -1,0 +1,131 @@
+"""opensmile_amd/csrc/lld_is10_ops.hpp -- the per-frame bodies of cIntensity, cLsp, cPitchSmoother and cVectorOperation that the
+kernels of lld_stage4_kernels.hip run one thread per frame -- compiled for the HOST (tests/helpers/is10_ops_check.cpp) and held
+against the oracle on seeded inputs (every option) and against the real binary's own levels, bit for bit. The GPU tests
+(tests/test_gpu_is10.py) then show that the kernels apply the same code to the right rows."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import lldo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def same(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    src = os.path.join(ROOT, "tests", "helpers", "is10_ops_check.cpp")
+    so = os.path.join(ROOT, "tests", "helpers", "_is10_ops_check.so")
+    hdrs = [os.path.join(ROOT, "opensmile_amd", "csrc", h) for h in ("lld_is10_ops.hpp", "glibc_float.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-o", so, src, "-lm"], check=True)
+    return C.CDLL(so)
+
+
+def h_intensity(L, frames, flags):
+    frames = np.ascontiguousarray(frames, np.float32)
+    n, N = frames.shape
+    win = np.zeros(N, np.float64)
+    ws = C.c_double(0.0)
+    ol = lldo.lib()
+    ol.lldo_intensity_window.argtypes = [C.c_long, C.c_void_p, C.POINTER(C.c_double)]
+    ol.lldo_intensity_window(N, win.ctypes.data, C.byref(ws))
+    w = bin(flags).count("1")
+    out = np.zeros((n, w), np.float32)
+    L.is10_intensity_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int64]
+    L.is10_intensity_rows(frames.ctypes.data, N, n, min(w, N), win.ctypes.data, ws, flags, out.ctypes.data, w)
+    return out
+
+
+def h_lsp(L, lpc):
+    lpc = np.ascontiguousarray(lpc, np.float32)
+    out = np.full_like(lpc, 7.0)
+    L.is10_lsp_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
+    L.is10_lsp_rows(lpc.ctypes.data, lpc.shape[1], lpc.shape[0], lpc.shape[1], out.ctypes.data, lpc.shape[1])
+    return out
+
+
+def h_smoother(L, cands, n_cand, cutoff, octc, simple, flags):
+    cands = np.ascontiguousarray(cands, np.float32)
+    w = bin(flags).count("1")
+    out = np.zeros((cands.shape[0], w), np.float32)
+    L.is10_pitch_smoother_rows.restype = C.c_int64
+    L.is10_pitch_smoother_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    rows = L.is10_pitch_smoother_rows(cands.ctypes.data, cands.shape[1], cands.shape[0], n_cand, cutoff, octc, simple, flags, out.ctypes.data, w)
+    return out[:rows]
+
+
+def h_vecop(L, x, op, param1=1.0, logfloor=1e-12):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    aux = {"add": lambda: param1, "mul": lambda: param1, "lgA": lambda: float(np.log(np.float32(param1))),
+           "dBp": lambda: float(np.float32(10.0 / np.log(10.0))), "dBv": lambda: float(np.float32(20.0 / np.log(10.0)))}.get(op, lambda: 0.0)()
+    L.is10_vecop.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64]
+    L.is10_vecop(lldo.VOP[op], aux, logfloor, x.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
+def random_cands(rng, n, c):
+    """rows shaped like cPitchShs' output: candidate 0 the best, octave relatives, unvoiced stretches, empty slots"""
+    f0 = rng.uniform(60, 500, (n, 1)).astype(np.float32)
+    mult = rng.choice(np.array([0.5, 1.0, 2.0, 1.5, 0.33, 3.0], np.float32), (n, c))
+    f = (f0 * mult * rng.uniform(0.97, 1.03, (n, c))).astype(np.float32)
+    f[rng.random((n, c)) < 0.2] = 0.0
+    v = rng.uniform(0.3, 1.0, (n, c)).astype(np.float32)
+    v[:, 0] = np.where(rng.random(n) < 0.35, rng.uniform(0.2, 0.69, n), rng.uniform(0.7, 1.0, n))
+    run = np.cumsum(rng.random(n) < 0.08) % 2 == 1                       # stretches of unvoiced frames
+    v[run, 0] = 0.1
+    s = rng.uniform(0.0, 0.3, (n, c)).astype(np.float32)
+    return np.concatenate([f, v, s], axis=1)
+
+
+def test_ops_equal_oracle_on_seeded_inputs(ops):
+    rng = np.random.default_rng(11)
+    fr = (rng.standard_normal((50, 400)) * 0.2).astype(np.float32)
+    fr[0] = 0.0
+    for fl, (i, l) in ((1, (1, 0)), (2, (0, 1)), (3, (1, 1))):
+        assert same(h_intensity(ops, fr, fl), lldo.intensity_rows(fr, i, l)), fl
+    for p in (8, 10, 16):
+        # LP coefficient sets from random reflection coefficients (stable) plus a few arbitrary ones (roots missing)
+        lpc = []
+        for _ in range(400):
+            k = rng.uniform(-0.95, 0.95, p)
+            a = np.zeros(0)
+            for m in range(p):
+                a = np.concatenate([a + k[m] * a[::-1], [k[m]]])
+            lpc.append(a)
+        lpc = np.array(lpc, np.float32)
+        lpc = np.concatenate([lpc, (rng.standard_normal((40, p)) * 2).astype(np.float32), np.zeros((2, p), np.float32)])
+        assert same(h_lsp(ops, lpc), lldo.lsp_rows(lpc)), p
+    for c in (6, 3):
+        x = random_cands(rng, 3000, c)
+        for octc in (0, 1):
+            for simple in (0, 1):
+                for flags in (1, 2, 3, 8, 2 | 8, 15, 4):
+                    a = h_smoother(ops, x, c, 0.7, octc, simple, flags)
+                    b = lldo.pitch_smoother_rows(x, c, 0.7, octc, simple, flags)
+                    assert same(a, b), (c, octc, simple, flags)
+    v = np.concatenate([rng.standard_normal(5000) * 3, [0.0, -0.0, 1e-13, 1e-12, 1e-30, 88.0, -104.0]]).astype(np.float32)
+    for op, p1 in (("add", 0.37), ("mul", -2.5), ("log", 1), ("lgA", 10.0), ("sqr", 1), ("ee", 1), ("abs", 1), ("dBp", 1), ("dBv", 1)):
+        assert same(h_vecop(ops, v, op, p1), lldo.vecop_rows(v, op, p1)), op
+
+
+@pytest.mark.skipif(not lldo.have_ref(), reason="oracle/_ref not built")
+def test_ops_equal_the_binary_levels(ops):
+    from opensmile_amd import synth
+    for u, n in ((4, 30000), (11, 16000)):
+        r = lldo.run_reference_is10(synth.utterance(u, n))
+        assert same(h_intensity(ops, r["is10_frames"], 2), r["is10_intens"])
+        assert same(h_lsp(ops, r["is10_lpc"]), r["is10_lsp"])
+        assert same(h_vecop(ops, r["is10_mspec2"], "log"), r["is10_mspec2log"])
+        shs = r["is10_pitchShs"]
+        assert same(h_smoother(ops, shs[:, 1:19], 6, 0.7, 0, 1, 2 | 8), r["is10_pitch"])
+        assert same(h_smoother(ops, shs[:, 1:19], 6, 0.7, 0, 1, 1), r["is10_pitchF"].reshape(-1, 1))

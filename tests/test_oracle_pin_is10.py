@@ -1,0 +1,128 @@
+"""Pin oracle/lld_oracle_is10.c (cIntensity, cLsp, cPitchSmoother, cVectorOperation) and the Onset family of
+oracle/lld_oracle_funcspec.c against the REAL reference binary: the unmodified config/is09-13/IS10_paraling.conf with HTK taps
+on its internal levels (oracle/conf/is10_taps.conf); every restated component applied to the binary's own input level must
+reproduce the binary's output level bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import lldo
+
+pytestmark = pytest.mark.skipif(not lldo.have_ref(), reason="oracle/_ref not built")
+
+CASES = [(2, 16000), (10, 32000), (5, 9000), (3, 24000), (12, 40000), (7, 2000)]
+
+
+def same(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))))
+
+
+@pytest.fixture(scope="module")
+def runs():
+    from opensmile_amd import synth
+    return [(u, n, lldo.run_reference_is10(synth.utterance(u, n))) for u, n in CASES]
+
+
+def spec_l1(nz):
+    """[is10_functL1] / [is10_functL1nz] of IS10_paraling_core.func.conf.inc"""
+    s = lldo.FuncSpec()
+    lldo._spec_common(s, ["Extremes", "Regression", "Moments", "Percentiles", "Times"])
+    s.ext_mask = lldo._mask(lldo.EXT_NAMES, ["maxPos", "minPos", "amean"])
+    s.ext_norm = lldo.NORM["frame"]
+    s.reg_mask = lldo._mask(lldo.REG_NAMES, ["linregc1", "linregc2", "linregerrA", "linregerrQ"])
+    s.mom_mask = lldo._mask(lldo.MOM_NAMES, ["stddev", "skewness", "kurtosis"])
+    s.pct_mask = 0x3f
+    s.pct_interp = 1
+    if nz:
+        s.n_pctl, s.n_range = 1, 0
+        s.pctl[0] = 0.99
+        s.non_zero_functs = 1
+    else:
+        s.n_pctl, s.n_range = 2, 1
+        s.pctl[0], s.pctl[1] = 0.01, 0.99
+        s.range_a[0], s.range_b[0] = 0, 1
+    s.times_mask = lldo._mask(lldo.TIMES_NAMES, ["upleveltime75", "upleveltime90"])
+    s.times_norm = lldo.NORM["segment"]
+    return s
+
+
+def spec_onsets():
+    s = lldo.FuncSpec()
+    lldo._spec_common(s, ["Onset", "Times"])
+    s.ons_mask = 1 << 4
+    s.ons_norm = lldo.NORM["segment"]
+    s.times_mask = 1 << 12
+    s.times_norm = lldo.NORM["second"]
+    return s
+
+
+def test_components_bit_exact(runs):
+    for u, n, r in runs:
+        what = f"u{u}_{n}"
+        assert same(lldo.intensity_rows(r["is10_frames"]), r["is10_intens"]), what
+        assert same(lldo.specresample_rows(r["is10_fftc"], 512 / 16000.0, 400 / 16000.0, 1 / 16000.0, 11000.0), r["is10_outpR"]), what
+        assert same(lldo.egemaps_lpc_rows(r["is10_outpR"], 8), r["is10_lpc"]), what
+        assert same(lldo.lsp_rows(r["is10_lpc"]), r["is10_lsp"]), what
+        assert same(lldo.vecop_rows(r["is10_mspec2"], "log"), r["is10_mspec2log"]), what
+        shs = r["is10_pitchShs"]                       # nCandidates | F0Cand[6] | candVoicing[6] | candScores[6]
+        if shs.size:
+            assert shs.shape[1] == 19
+            assert same(lldo.pitch_smoother_rows(shs[:, 1:19], flags=2 | 8), r["is10_pitch"].reshape(-1, 2)), what
+            assert same(lldo.pitch_smoother_rows(shs[:, 1:19], flags=1), r["is10_pitchF"].reshape(-1, 1)), what
+
+
+def test_functionals_bit_exact_and_the_rows_they_read(runs):
+    """The three cFunctionals instances: which rows of their input levels they summarise at the end of the input is the
+    component manager's tick order (measured here: T - 3 of the T rows the smoothed level holds; the onsets instance every row)."""
+    for u, n, r in runs:
+        what = f"u{u}_{n}"
+        T = r["is10_lld1"].shape[0]
+        if T < 4:
+            continue
+        x1 = np.concatenate([r["is10_lld1"][:T - 3], r["is10_lld1_de"][:T - 3]], axis=1)
+        assert same(lldo.funcspec(x1, spec_l1(False)).reshape(1, -1), r["is10_funct"]), what
+        x2 = np.concatenate([r["is10_lld2"][:T - 3], r["is10_lld2_de"][:T - 3]], axis=1)
+        assert same(lldo.funcspec(x2, spec_l1(True)).reshape(1, -1), r["is10_functNz"]), what
+        assert same(lldo.funcspec(r["is10_pitchF"], spec_onsets()).reshape(1, -1), r["is10_functOnsets"]), what
+        assert same(np.concatenate([r["is10_funct"], r["is10_functNz"], r["is10_functOnsets"]], axis=1), r["func"]), what
+
+
+def test_onset_family_options():
+    """thresholds, useAbsVal, every output and norm against a direct restatement of functionalOnset.cpp:83-151"""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((300, 7)) * (rng.random((300, 7)) > 0.4)).astype(np.float32)
+    for norm in ("segment", "second", "frame"):
+        for use_abs, th_on, th_off in ((0, 0.0, 0.0), (1, 0.3, 0.3), (0, 0.5, -0.2), (1, 0.1, 0.6)):
+            s = lldo.FuncSpec()
+            lldo._spec_common(s, ["Onset"])
+            s.ons_mask, s.ons_norm, s.ons_use_abs = 0x1f, lldo.NORM[norm], use_abs
+            s.ons_thr_on, s.ons_thr_off = th_on, th_off
+            got = lldo.funcspec(x, s)
+            for c in range(x.shape[1]):
+                col, N = x[:, c], x.shape[0]
+                on_pos = off_pos = -1
+                n_on = n_off = 0
+                oo = 1 if col[0] > np.float32(th_on) else 0
+                for i in range(1, N):
+                    cur = abs(col[i]) if use_abs else col[i]
+                    if cur > np.float32(th_on) and oo == 0:
+                        n_on += 1
+                        on_pos = i if on_pos == -1 else on_pos
+                        oo = 1
+                    if cur <= np.float32(th_off) and oo == 1:
+                        n_off += 1
+                        off_pos = i
+                        oo = 0
+                off_pos = N - 1 if off_pos == -1 else off_pos
+                on_pos = 0 if on_pos == -1 else on_pos
+                f32 = np.float32
+                T = f32(0.01)
+                if norm == "segment":
+                    pos = [f32(on_pos) / f32(N), f32(off_pos) / f32(N)]
+                elif norm == "second":
+                    pos = [f32(on_pos) * T, f32(off_pos) * T]
+                else:
+                    pos = [f32(on_pos), f32(off_pos)]
+                ref = np.array(pos + [f32(n_on), f32(n_off), f32(n_on) / (f32(N) * T)], np.float32)
+                assert same(got[c], ref), (norm, use_abs, th_on, th_off, c)
