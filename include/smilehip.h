@@ -155,6 +155,8 @@ typedef struct smilehip_lld_config {
   /* SMILEHIP_CHAIN_EGEMAPS: cFormantLpc maxF (src/lld/formantLpc.cpp:224-231; 0 = 5450 as in GeMAPSv01b / eGeMAPSv02, 5500 in the
    * v01a files) */
   double   formant_max_freq;
+  /* F0 chains: cSpecScale minF (src/dsp/specScale.cpp:228-300; 0 = 25 as in ComParE_2016 / GeMAPS, 20 in IS10_paraling .. IS12) */
+  double   specscale_min_f;
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
@@ -322,13 +324,14 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *                                                  minSegLen segLenStddev
  *   Lpc         (functionalLpc.cpp:95-119)         lpgain, lpc[first..order)
  *   Peaks2      (functionalPeaks2.cpp:316-905)     its 32 values in the order of functionalPeaks2.cpp:60-67
+ *   Onset       (functionalOnset.cpp:83-151)       onsetPos offsetPos numOnsets numOffsets onsetRate
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
  * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange, the other
  * segmentation algorithms, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
-  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_COUNT
+  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
 enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2 };
@@ -353,6 +356,8 @@ typedef struct smilehip_func_spec {
   int32_t lpc_gain, lpc_coeffs, lpc_first, lpc_order;      /* order <= 16 */
   uint32_t pk_mask; int32_t pk_norm, pk_ratio_limit, pk_dyn_rel, pk_use_abs, reserved5;
   float pk_rel_thresh, pk_abs_thresh;
+  uint32_t ons_mask; int32_t ons_norm, ons_use_abs, reserved6;   /* Onset: thresholdOnset / thresholdOffset (= threshold unless set) */
+  float ons_thr_on, ons_thr_off;
 } smilehip_func_spec;
 
 /* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */
@@ -670,6 +675,48 @@ int smilehip_specresample_frames(smilehip_plan *plan, const float *d_spec, int64
  * (smileUtil.c:1560-1630) on 220 samples -> 11 coefficients */
 int smilehip_lpc_frames(smilehip_plan *plan, const float *d_x, int64_t ld_src, float *d_lpc, int64_t ld_dst, int64_t n_frames,
                         void *stream);
+/* ---- the components the other INTERSPEECH sets of config/is09-13 add (IS10_paraling, IS11_speaker_state, IS12_speaker_trait) ----
+ * cSpecResample for ANY geometry. smilehip_specresample_geometry: cSpecResample::setupNewNames (src/dsp/specResample.cpp:117-172) for
+ * n_in packed spectrum values of a level with frameSizeSec fs_sec, lastFrameSizeSec last_fs_sec (the frame before zero padding),
+ * basePeriod base_period and the option targetFs -> output samples, kMax (antiAlias = 1) and the tables' denominator nd.
+ * smilehip_specresample_tables: smileDsp_initIrdft (src/smileutil/smileUtil.c:1752-1786), k_max / 2 * n_out floats each (host).
+ * smilehip_specresample_table_frames: smileDsp_irdft (:1800-1820) with those tables on the device. */
+int smilehip_specresample_geometry(int64_t n_in, double fs_sec, double last_fs_sec, double base_period, double target_fs,
+                                   int64_t *n_out, int64_t *k_max, double *nd);
+int smilehip_specresample_tables(int64_t n_in, int64_t n_out, int64_t k_max, double nd, float *cos_table, float *sin_table);
+int smilehip_specresample_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n_in, int64_t n_out,
+                                       int64_t k_max, const float *d_cos, const float *d_sin, float *d_dst, int64_t ld_dst,
+                                       int64_t n_frames, void *stream);
+/* cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, saveLPCoeff only, any frame length n and order p <= 32:
+ * smileDsp_autoCorr + smileDsp_calcLpcAcf (smileUtil.c:1560-1630) */
+int smilehip_lpc_acf_frames(smilehip_context *ctx, const float *d_x, int64_t ld_src, int64_t n, int32_t p, float *d_lpc,
+                            int64_t ld_dst, int64_t n_frames, void *stream);
+/* cLsp::processVector (src/lld/lsp.cpp:289-312): p LP coefficients -> p line spectral frequencies (the Speex-derived lpc_to_lsp,
+ * :144-269, with the C library's acosf) */
+int smilehip_lsp_frames(smilehip_context *ctx, const float *d_lpc, int64_t ld_src, int32_t p, float *d_dst, int64_t ld_dst,
+                        int64_t n_frames, void *stream);
+/* cIntensity::processVector (src/lldcore/intensity.cpp:125-145) on rows of N samples. flags: 1 intensity, 2 loudness, outputs in
+ * that order. As in the reference the Hamming-weighted sum runs over MIN(N, number of outputs) samples (:134). */
+int smilehip_intensity_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int32_t flags, float *d_dst,
+                              int64_t ld_dst, int64_t n_frames, void *stream);
+/* cVectorOperation::processVector, the element-wise operations (src/other/vectorOperation.cpp:360-435, 508-527): add / mul (param1),
+ * log, lgA (base param1), sqr, ee, abs, dBp, dBv; logfloor <= 0 selects the component's default 1e-12 -- and the vector-to-scalar
+ * operations sum, ssm, ll1, ll2 (:461-490: one float accumulation over the row, ONE output value per row). */
+enum { SMILEHIP_VOP_ADD = 0, SMILEHIP_VOP_MUL, SMILEHIP_VOP_LOG, SMILEHIP_VOP_LOGA, SMILEHIP_VOP_SQRT, SMILEHIP_VOP_E, SMILEHIP_VOP_ABS,
+       SMILEHIP_VOP_DB_POW, SMILEHIP_VOP_DB_MAG, SMILEHIP_VOP_X_SUM, SMILEHIP_VOP_X_SUMSQ, SMILEHIP_VOP_X_L1, SMILEHIP_VOP_X_L2 };
+int smilehip_vecop_frames(smilehip_context *ctx, int32_t op, float param1, float logfloor, const float *d_src, int64_t ld_src,
+                          int32_t n_cols, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* cPitchSmoother::processVector (src/lldcore/pitchSmoother.cpp:236-425) over the frames of n_streams streams: medianFilter0 = 0,
+ * postSmoothingMethod none (post_simple = 0) or simple (1), octaveCorrection as given. Rows of d_src = [F0Cand | candVoicing |
+ * candScore] (3 n_cand values: cPitchShs' output without its nCandidates element); stream u = rows [d_row_off[u], d_row_off[u+1])
+ * (d_row_off = NULL: one stream of n_rows_single rows). flags: 1 F0final, 2 F0finEnv, 4 voicingFinalClipped, 8 voicingFinalUnclipped
+ * (output order). The rows the component writes go to d_dst from row d_row_off[u] on -- with simple post smoothing one fewer than it
+ * reads (the first frame yields none, :331); d_written[u] (optional) = that count. d_state (optional, 32 bytes per stream): the
+ * carried state, read when resume != 0 and written back (frame-by-frame callers). */
+int smilehip_pitch_smoother_rows(smilehip_context *ctx, int32_t n_cand, float voicing_cutoff, int32_t octave_correction,
+                                 int32_t post_simple, int32_t flags, const float *d_src, int64_t ld_src, const int64_t *d_row_off,
+                                 int32_t n_streams, int64_t n_rows_single, void *d_state, int32_t resume, float *d_dst, int64_t ld_dst,
+                                 int64_t *d_written, void *stream);
 /* cFormantLpc::processVector (src/lld/formantLpc.cpp:192-290): nFormants = 5, saveFormants = saveBandwidths = 1, minF 50,
  * maxF 5450, no median filter / octave correction; roots of the LP polynomial by the reference's balanced companion-matrix
  * QR iteration (src/smileutil/zerosolve.cpp): 11 coefficients -> [5 frequencies | 5 bandwidths] */
@@ -723,6 +770,9 @@ typedef struct smilehip_jitter_stream smilehip_jitter_stream;
 int smilehip_jitter_stream_create(smilehip_context *ctx, double sample_period, int64_t frame_size, int64_t frame_step,
                                   double frame_step_sec, double search_range_rel, int32_t broken_jitter_thresh,
                                   smilehip_jitter_stream **out);
+/* The first F0 frame's time stamp in frames (tmeta->time / frame_step_sec): 0 behind cPitchSmootherViterbi, 1 behind cPitchSmoother
+ * with simple post smoothing (its first output carries the second frame's time meta data). Before the first push. */
+int smilehip_jitter_stream_set_time_offset(smilehip_jitter_stream *s, int64_t frames);
 int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, const int16_t *h_pcm, int64_t pcm_start, int64_t n_pcm,
                                 float *out5, int64_t *last_idx, int64_t *last_mis);
 int smilehip_jitter_stream_destroy(smilehip_jitter_stream *s);

@@ -42,7 +42,7 @@ class LldConfig(C.Structure):
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
         ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
-        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double),
+        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double), ("specscale_min_f", C.c_double),
     ]
 
 
@@ -128,6 +128,7 @@ SYMBOLS = {
     "smilehip_valbased_select_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp]),
     "smilehip_jitter_stream_create": (C.c_int, [_vp, _dbl, _i64, _i64, _dbl, _dbl, _i32, C.POINTER(_vp)]),
     "smilehip_jitter_stream_push": (C.c_int, [_vp, _f32, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "smilehip_jitter_stream_set_time_offset": (C.c_int, [_vp, _i64]),
     "smilehip_jitter_stream_destroy": (C.c_int, [_vp]),
     "smilehip_viterbi_stream_create": (C.c_int, [_vp, _i32, _f32, _vp, C.POINTER(_vp)]),
     "smilehip_viterbi_stream_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
@@ -190,6 +191,14 @@ SYMBOLS = {
     "smilehip_melspec_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_mfcc_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_delta_chain": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "smilehip_specresample_geometry": (C.c_int, [_i64, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    "smilehip_specresample_tables": (C.c_int, [_i64, _i64, _i64, _dbl, _vp, _vp]),
+    "smilehip_specresample_table_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "smilehip_lpc_acf_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "smilehip_lsp_frames": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "smilehip_intensity_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "smilehip_vecop_frames": (C.c_int, [_vp, _i32, _f32, _f32, _vp, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "smilehip_pitch_smoother_rows": (C.c_int, [_vp, _i32, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -1106,8 +1106,9 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
     int lane = lane_in, tid = tid_in;                      // opaque per frame: lane-only address arithmetic is not kept in registers
     asm volatile("" : "+v"(lane), "+v"(tid));              // across the frame loop (see f0_shs)
     const float F0 = uni(f0[(fo + t) * ld_f0]);
-    const double time = (double)((long)t * H) * Tw;
-    const double lengthSec = ((double)((long)t * H + N - 1) * Tw - (double)((long)t * H) * Tw) + Tw;
+    const long tt = (long)t + (long)Q.jit_t_shift;           // the frame whose time stamp the F0 value carries
+    const double time = (double)(tt * H) * Tw;
+    const double lengthSec = ((double)(tt * H + N - 1) * Tw - (double)(tt * H) * Tw) + Tw;
     const long lenF = uni((long)ceil(lengthSec / Tw));
     const long startVidx = uni((long)round(time / Tw));
     long toRead0 = ppLen + lastMis, toRead = toRead0;

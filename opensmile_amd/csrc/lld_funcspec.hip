@@ -519,6 +519,44 @@ __device__ int f_times(const smilehip_func_spec &s, const Col &in, float min, fl
   return n;
 }
 
+// Onset (functionalOnset.cpp:83-151): a two-state walk over the contour -- an onset when the value rises above thresholdOnset
+// from the "off" state, an offset when it is at or below thresholdOffset in the "on" state (both can fire on one sample)
+__device__ int f_onset(const smilehip_func_spec &s, const Col &in, float *out) {
+  const int64_t Nin = in.N;
+  int64_t onsetPos = -1, offsetPos = -1, nOnsets = 0, nOffsets = 0;
+  int oo = (in[0] > s.ons_thr_on) ? 1 : 0;                       // the first sample is compared as it is, also with useAbsVal
+  const bool use_abs = s.ons_use_abs != 0;
+  const float th_on = s.ons_thr_on, th_off = s.ons_thr_off;
+  for_rows(in, 1, Nin, [&](int64_t i, float v) {
+    const float cur = use_abs ? fabsf(v) : v;
+    if (cur > th_on) {
+      if (oo == 0) { nOnsets++; if (onsetPos == -1) onsetPos = i; oo = 1; }
+    }
+    if (cur <= th_off) {
+      if (oo == 1) { nOffsets++; offsetPos = i; oo = 0; }
+    }
+  });
+  if (offsetPos == -1) offsetPos = Nin - 1;
+  if (onsetPos == -1) onsetPos = 0;
+  const uint32_t m = s.ons_mask;
+  int n = 0;
+  if (s.ons_norm == SMILEHIP_NORM_SEGMENT) {
+    if (FS_BIT(m, 0)) out[n++] = (float)onsetPos / (float)(Nin);
+    if (FS_BIT(m, 1)) out[n++] = (float)offsetPos / (float)(Nin);
+  } else if (s.ons_norm == SMILEHIP_NORM_SECOND) {
+    const float T = (float)s.period;
+    if (FS_BIT(m, 0)) out[n++] = (float)onsetPos * T;
+    if (FS_BIT(m, 1)) out[n++] = (float)offsetPos * T;
+  } else {
+    if (FS_BIT(m, 0)) out[n++] = (float)onsetPos;
+    if (FS_BIT(m, 1)) out[n++] = (float)offsetPos;
+  }
+  if (FS_BIT(m, 2)) out[n++] = (float)nOnsets;
+  if (FS_BIT(m, 3)) out[n++] = (float)nOffsets;
+  if (FS_BIT(m, 4)) { const float T = (float)s.period; out[n++] = (float)nOnsets / ((float)Nin * T); }
+  return n;
+}
+
 // Segments: the segmentation runs twice -- first to get count / sum / extremes of the segment lengths, then again to
 // accumulate the squared deviations from the mean in the same order (instead of keeping the reference's segLens[])
 struct SegAcc {
@@ -1049,6 +1087,7 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_family(FsParams P, int out_o
   if (FAM == SMILEHIP_FAM_TIMES) got = f_times(P.spec, x, mn, mx, o);
   if (FAM == SMILEHIP_FAM_SEGMENTS) got = f_segments(P.spec, x, mn, mx, o);
   if (FAM == SMILEHIP_FAM_LPC) got = f_lpc(P.spec, x, o);
+  if (FAM == SMILEHIP_FAM_ONSET) got = f_onset(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_PEAKS2)
     got = f_peaks2(P.spec, x, mn, mx, mean, P.alive + w.srow0 * P.n_cols + w.c, P.n_cols, o);
   for (int j = got; j < want; ++j) o[j] = 0.0f;
@@ -1265,6 +1304,7 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
       case SMILEHIP_FAM_SEGMENTS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SEGMENTS>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_LPC: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_ONSET: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_ONSET>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PERCENTILES:
         hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
         if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts

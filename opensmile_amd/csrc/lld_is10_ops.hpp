@@ -202,7 +202,8 @@ GLF_HD int pitch_smoother_frame(const PitchSmootherOpts &o, PitchSmootherState &
 // ---- cVectorOperation::processVector, the element-wise operations (src/other/vectorOperation.cpp:360-435, 508-527) ---------
 // std::log / std::exp / std::sqrt on FLOAT_DMEM are the float functions of the C library. `aux` is the operation's constant:
 // param1 (add, mul), logf(param1) (lgA), (float)(10 / log(10)) (dBp), (float)(20 / log(10)) (dBv) -- computed by the host.
-enum { kVopAdd = 0, kVopMul, kVopLog, kVopLogA, kVopSqrt, kVopE, kVopAbs, kVopDbPow, kVopDbMag, kVopCount };
+enum { kVopAdd = 0, kVopMul, kVopLog, kVopLogA, kVopSqrt, kVopE, kVopAbs, kVopDbPow, kVopDbMag, kVopCount,
+       kVopXSum = kVopCount, kVopXSumSq, kVopXL1, kVopXL2, kVopXCount };
 
 GLF_HD float vecop(int op, float aux, float logfloor, float x) {
   switch (op) {
@@ -217,6 +218,20 @@ GLF_HD float vecop(int op, float aux, float logfloor, float x) {
     case kVopDbMag: return aux * (x > logfloor ? glibc_logf(x) : glibc_logf(logfloor));
   }
   return x;
+}
+
+// The vector-to-scalar operations (vectorOperation.cpp:461-490): sum, ssm, ll1, ll2 -- one FLOAT_DMEM accumulation in index order
+// (the reference accumulates in dst[0]); sqrt on FLOAT_DMEM is sqrtf.
+GLF_HD float vecop_reduce(int op, const float *src, int64_t n) {
+  float acc = 0.0f;
+  if (op == kVopXSum || op == kVopXL1) {
+    for (int64_t i = 0; i < n; ++i) acc += src[i];
+  } else {
+    for (int64_t i = 0; i < n; ++i) acc += src[i] * src[i];
+  }
+  if (op == kVopXL2 && acc > 0.0f) acc = __builtin_sqrtf(acc);
+  if ((op == kVopXL1 || op == kVopXL2) && n > 0) acc /= (float)n;
+  return acc;
 }
 
 }  // namespace is10

@@ -156,6 +156,8 @@ struct F0Params {
   int32_t vit_buf;                  // cPitchSmootherViterbi bufferLength (30 ComParE, 40 GeMAPS; <= 40)
   int32_t vit_log_out;              // 1: rows [F0final, F0finalLog, voicingFinalUnclipped] (GeMAPS), 0: [F0final, voicing]
   double jit_search_range;          // cPitchJitter searchRangeRel (0.25 ComParE, 0.1 GeMAPS)
+  int64_t jit_t_shift;              // frames: F0 frame t carries the time stamp of frame t + shift (1 behind cPitchSmoother, which delays its
+                                    // values by one frame but hands on the time meta data of the frame it was called with; 0 otherwise)
   float *jit_shim_db;               // optional [total_frames]: shimmerLocalDB = 20 log10(shimmerLocal + 1)
   double *jit_stream;               // stream mode (one frame per launch, smilehip_jitter_stream_*): [0] lastIdx [1] lastMis [2] next frame
                                     // [3] lastT0 [4] lastDiff [5] lastJitterLocal [6] lastJitterDDP [7] lastShimmerLocal; null = whole utterances

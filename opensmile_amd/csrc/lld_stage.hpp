@@ -26,6 +26,19 @@ hipError_t stage_mfcc(const float *src, int64_t lds, float *dst, int64_t ldd, in
 // second set (lld_stage2_kernels.hip): R9, R10, R12, R13 one component at a time
 hipError_t stage_sumsq(const float *src, int64_t lds, int64_t N, int64_t nF, double *out, hipStream_t s);
 hipError_t stage_zcr_count(const float *src, int64_t lds, int64_t N, int64_t nF, int32_t *out, hipStream_t s);
+// lld_stage4_kernels.hip: the components the other INTERSPEECH sets add (cIntensity, cLsp, cPitchSmoother, cVectorOperation) and
+// cSpecResample / cLpc for any geometry
+hipError_t stage_intensity(const float *src, int64_t lds, int n_sum, double w0, double w1, double win_sum, int flags, float *dst,
+                           int64_t ldd, int64_t nF, hipStream_t s);
+hipError_t stage_lsp(const float *lpc, int64_t lds, int p, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
+hipError_t stage_vecop(int op, float aux, float logfloor, const float *src, int64_t lds, int n_cols, float *dst, int64_t ldd, int64_t nF,
+                       hipStream_t s);
+hipError_t stage_pitch_smoother(int n_cand, float voicing_cutoff, int octave_correction, int post_simple, int flags, const float *src,
+                                int64_t lds, const int64_t *row_off, int n_streams, int64_t n_single, void *state, int resume,
+                                float *dst, int64_t ldd, int64_t *written, hipStream_t s);
+hipError_t stage_specresample_g(const float *src, int64_t lds, int K, int I, int kMax, const float *cost, const float *sint, float *dst,
+                                int64_t ldd, int64_t nF, hipStream_t s);
+hipError_t stage_lpc_g(const float *x, int64_t lds, int n, int p, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 // lld_stage3_kernels.hip: the components' other option sets
 struct OouraTab;
 hipError_t stage_irfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, const OouraTab &T, hipStream_t s);

@@ -206,7 +206,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (p->cfg.shs_n_harmonics < 1 || p->cfg.shs_n_harmonics > 17 || !(p->cfg.pitch_max > p->cfg.pitch_min) || p->cfg.pitch_min < 40.0)
       return fail(SMILEHIP_ERR_INVALID, "F0 chain: nHarmonics 1..17, minPitch >= 40 Hz (period search window of the jitter kernel), "
                   "maxPitch > minPitch");
-    if ((rc = make_f0_tables(p->geo.K, p->geo.fft_frame_size_sec, p->cfg.shs_n_harmonics, p->cfg.shs_compression, p->f0)))
+    if ((rc = make_f0_tables(p->geo.K, p->geo.fft_frame_size_sec, p->cfg.shs_n_harmonics, p->cfg.shs_compression,
+                             p->cfg.specscale_min_f > 0.0 ? p->cfg.specscale_min_f : 25.0, p->f0)))
       return fail(rc, "F0 chain: spectrum geometry / nHarmonics not usable by cSpecScale / cPitchShs");
   } else if (p->cfg.chain_kind != SMILEHIP_CHAIN_MFCC) {
     return fail(SMILEHIP_ERR_INVALID, "unknown chain_kind %d", p->cfg.chain_kind);

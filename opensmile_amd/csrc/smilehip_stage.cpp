@@ -452,6 +452,12 @@ static int grow(T *&p, int64_t &cap, int64_t need, int64_t keep, int width) {
   return SMILEHIP_OK;
 }
 
+extern "C" int smilehip_jitter_stream_set_time_offset(smilehip_jitter_stream *s, int64_t frames) {
+  if (!s || frames < 0 || s->n_frames != 0) return fail(SMILEHIP_ERR_INVALID, "smilehip_jitter_stream_set_time_offset: before the first push, frames >= 0");
+  s->Q.jit_t_shift = frames;
+  return SMILEHIP_OK;
+}
+
 extern "C" int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, const int16_t *h_pcm, int64_t pcm_start, int64_t n_pcm,
                                            float *out5, int64_t *last_idx, int64_t *last_mis) {
   if (!s || !out5 || n_pcm < 0 || pcm_start < 0 || (n_pcm > 0 && !h_pcm)) return fail(SMILEHIP_ERR_INVALID, "smilehip_jitter_stream_push: bad argument");
@@ -489,4 +495,126 @@ extern "C" int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, 
   if (last_mis) *last_mis = (int64_t)st[1];
   s->n_frames = t + 1;
   return SMILEHIP_OK;
+}
+
+// ---------------------------------------------- the components the other INTERSPEECH sets add (lld_stage4_kernels.hip)
+extern "C" int smilehip_intensity_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int32_t flags, float *d_dst,
+                                         int64_t ld_dst, int64_t n_frames, void *stream) {
+  const int n_out = ((flags & 1) ? 1 : 0) + ((flags & 2) ? 1 : 0);
+  if (!ctx || N < 1 || N > (1 << 22) || !(flags & 3) || (flags & ~3) || n_frames < 0 || ld_src < (N < n_out ? N : n_out) || ld_dst < n_out ||
+      (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_intensity_frames: bad argument (flags: 1 intensity, 2 loudness)");
+  // setupNamesForField (intensity.cpp:91-112): the Hamming window as doubles (smileUtil.c:1291-1303) and its sum in index order
+  const double NN = (double)N;
+  double w01[2] = {0.0, 0.0}, sum = 0.0;
+  long j = 0;
+  for (double i = 0.0; i < NN; i += 1.0, ++j) {
+    const double w = 0.54 - 0.46 * std::cos((2.0 * M_PI * i) / (NN - 1.0));
+    if (j < 2) w01[j] = w;
+    sum += w;
+  }
+  if (sum <= 0.0) sum = 1.0;
+  const int n_sum = (int)(N < n_out ? N : n_out);              // MIN(Nsrc, MIN(nWin, Ndst)), :134
+  STAGE_RET(stage_intensity(d_src, ld_src, n_sum, w01[0], w01[1], sum, flags, d_dst, ld_dst, n_frames, (hipStream_t)stream), "intensity");
+}
+
+extern "C" int smilehip_lsp_frames(smilehip_context *ctx, const float *d_lpc, int64_t ld_src, int32_t p, float *d_dst, int64_t ld_dst,
+                                   int64_t n_frames, void *stream) {
+  if (!ctx || p < 2 || p > 32 || n_frames < 0 || ld_src < p || ld_dst < p || (n_frames > 0 && (!d_lpc || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lsp_frames: bad argument (2 <= p <= 32)");
+  STAGE_RET(stage_lsp(d_lpc, ld_src, p, d_dst, ld_dst, n_frames, (hipStream_t)stream), "lsp");
+}
+
+extern "C" int smilehip_vecop_frames(smilehip_context *ctx, int32_t op, float param1, float logfloor, const float *d_src, int64_t ld_src,
+                                     int32_t n_cols, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  const bool reduce = op >= SMILEHIP_VOP_X_SUM && op <= SMILEHIP_VOP_X_L2;
+  if (!ctx || op < 0 || op > SMILEHIP_VOP_X_L2 || n_cols < 1 || n_frames < 0 || ld_src < n_cols || ld_dst < (reduce ? 1 : n_cols) ||
+      (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_vecop_frames: bad argument (op: SMILEHIP_VOP_*)");
+  if (!(logfloor > 0.0f)) logfloor = (float)0.000000000001;            // vectorOperation.cpp:219-223
+  float aux = param1;
+  if (op == SMILEHIP_VOP_LOGA) {                                         // :99-107
+    if (param1 <= 0.0f || param1 == 1.0f) param1 = (float)std::exp(1.0);
+    aux = std::log(param1);
+  }
+  if (op == SMILEHIP_VOP_DB_POW) aux = (float)(10.0 / std::log(10.0));
+  if (op == SMILEHIP_VOP_DB_MAG) aux = (float)(20.0 / std::log(10.0));
+  STAGE_RET(stage_vecop(op, aux, logfloor, d_src, ld_src, n_cols, d_dst, ld_dst, n_frames, (hipStream_t)stream), "vecop");
+}
+
+extern "C" int smilehip_pitch_smoother_rows(smilehip_context *ctx, int32_t n_cand, float voicing_cutoff, int32_t octave_correction,
+                                            int32_t post_simple, int32_t flags, const float *d_src, int64_t ld_src, const int64_t *d_row_off,
+                                            int32_t n_streams, int64_t n_rows_single, void *d_state, int32_t resume, float *d_dst,
+                                            int64_t ld_dst, int64_t *d_written, void *stream) {
+  const int n_out = ((flags & 1) ? 1 : 0) + ((flags & 2) ? 1 : 0) + ((flags & 4) ? 1 : 0) + ((flags & 8) ? 1 : 0);
+  if (!ctx || n_cand < 1 || n_cand > 16 || !(flags & 15) || (flags & ~15) || n_streams < 0 || ld_src < 3 * (int64_t)n_cand || ld_dst < n_out ||
+      (!d_row_off && (n_streams > 1 || n_rows_single < 0)) || (n_streams > 0 && (!d_src || !d_dst)) || (resume && !d_state))
+    return fail(SMILEHIP_ERR_INVALID,
+                "smilehip_pitch_smoother_rows: bad argument (flags: 1 F0final, 2 F0finEnv, 4 voicingFinalClipped, 8 voicingFinalUnclipped; "
+                "rows = [F0Cand | candVoicing | candScore], n_cand <= 16)");
+  STAGE_RET(stage_pitch_smoother(n_cand, voicing_cutoff, octave_correction != 0, post_simple != 0, flags, d_src, ld_src, d_row_off, n_streams,
+                                 n_rows_single, d_state, resume, d_dst, ld_dst, d_written, (hipStream_t)stream), "pitch smoother");
+}
+
+extern "C" int smilehip_specresample_geometry(int64_t n_in, double fs_sec, double last_fs_sec, double base_period, double target_fs,
+                                              int64_t *n_out, int64_t *k_max, double *nd_out) {
+  if (n_in < 2 || !(base_period > 0.0) || !(target_fs > 0.0) || !n_out || !k_max)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_geometry: bad argument");
+  // cSpecResample::setupNewNames (specResample.cpp:117-172), resampleRatio = targetFs / sr (:94-103)
+  const double sr = 1.0 / base_period;
+  double ratio = target_fs / sr, nd;
+  long no;
+  if ((fs_sec != last_fs_sec) && (last_fs_sec != 0.0) && (last_fs_sec != base_period)) {
+    const double nout0 = std::round((double)n_in * ratio * last_fs_sec / fs_sec);
+    const double new_ratio = nout0 / ((double)n_in * (last_fs_sec / fs_sec));
+    no = (long)nout0;
+    if (new_ratio != ratio) ratio = new_ratio;
+    nd = (double)n_in * ratio;
+  } else {
+    const double nout0 = std::round((double)n_in * ratio);
+    no = (long)nout0;
+    nd = nout0;
+  }
+  if (no < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_geometry: no output samples");
+  long km = n_in > no ? no : (long)n_in;                                // antiAlias = 1 (smileDsp_initIrdft, smileUtil.c:1752-1786)
+  if (km & 1) km--;
+  *n_out = no;
+  *k_max = km;
+  if (nd_out) *nd_out = nd;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_specresample_tables(int64_t n_in, int64_t n_out, int64_t k_max, double nd, float *cos_table, float *sin_table) {
+  if (n_in < 2 || n_out < 1 || k_max < 0 || (k_max & 1) || k_max > n_in || !(nd > 0.0) || !cos_table || !sin_table)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_tables: bad argument");
+  const int64_t h = k_max / 2;
+  const double pi2 = 2.0 * M_PI;
+  for (int64_t i = 0; i < h * n_out; ++i) cos_table[i] = sin_table[i] = 0.0f;
+  for (int64_t i = 0; i < n_out; i++) {
+    const int64_t i_n = i * h - 1;
+    if (n_out >= n_in) cos_table[i_n + n_in / 2] = (float)std::cos((pi2 * (double)((n_in / 2) * i)) / nd);
+    for (int64_t k = 2; k < k_max; k += 2) {
+      const double kn = pi2 * (double)(k / 2 * i) / nd;
+      cos_table[i_n + k / 2] = (float)std::cos(kn);
+      sin_table[i_n + k / 2] = (float)std::sin(kn);
+    }
+  }
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_specresample_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n_in, int64_t n_out,
+                                                  int64_t k_max, const float *d_cos, const float *d_sin, float *d_dst, int64_t ld_dst,
+                                                  int64_t n_frames, void *stream) {
+  if (!ctx || n_in < 2 || n_in > 8192 || n_out < 1 || n_out > (1 << 20) || k_max < 2 || (k_max & 1) || k_max > n_in || n_frames < 0 ||
+      ld_src < n_in || ld_dst < n_out || !d_cos || !d_sin || (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_table_frames: bad argument (n_in <= 8192; tables of smilehip_specresample_tables)");
+  STAGE_RET(stage_specresample_g(d_src, ld_src, (int)n_in, (int)n_out, (int)k_max, d_cos, d_sin, d_dst, ld_dst, n_frames, (hipStream_t)stream),
+            "specresample");
+}
+
+extern "C" int smilehip_lpc_acf_frames(smilehip_context *ctx, const float *d_x, int64_t ld_src, int64_t n, int32_t p, float *d_lpc,
+                                       int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!ctx || p < 1 || p > 32 || n <= p || n > 15000 || n_frames < 0 || ld_src < n || ld_dst < p || (n_frames > 0 && (!d_x || !d_lpc)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_lpc_acf_frames: bad argument (1 <= p <= 32 < n <= 15000)");
+  STAGE_RET(stage_lpc_g(d_x, ld_src, (int)n, p, d_lpc, ld_dst, n_frames, (hipStream_t)stream), "lpc");
 }

@@ -233,11 +233,11 @@ namespace smilehip {
 // smileMath_csplint_init (src/smileutil/smileUtilSpline.c:139-155, 296-342), the level meta data cPitchShs reads
 // in setupNewNames (src/lld/pitchShs.cpp:178-204) and its per-harmonic shifts (:235-243). All in double, rounded
 // where the reference rounds (the meta data travels as FLOAT_DMEM).
-int make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, F0Host &h) {
-  if (K < 4 || n_harmonics < 1 || n_harmonics > 17) return SMILEHIP_ERR_INVALID;
+int make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, double min_f, F0Host &h) {
+  if (K < 4 || n_harmonics < 1 || n_harmonics > 17 || !(min_f > 0.0)) return SMILEHIP_ERR_INVALID;
   const double fsSec = (double)(float)fft_frame_size_sec;
   const double deltaF = 1.0 / fsSec;
-  const double minF = 25.0;
+  const double minF = min_f;
   const double maxF = deltaF * (double)(K - 1);
   const double l2 = std::log(2.0);
   const double fmin_t = std::log(minF) / l2, fmax_t = std::log(maxF) / l2;

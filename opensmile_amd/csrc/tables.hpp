@@ -50,7 +50,7 @@ struct F0Host {
   double log_base = 0.0;
 };
 // K bins of a spectrum level whose frameSizeSec is fft_frame_size_sec; 0 on success
-int  make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, F0Host &h);
+int  make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float compression, double min_f, F0Host &h);
 
 int  make_geometry(const smilehip_lld_config &c, Geometry &g);
 int  make_window(const smilehip_lld_config &c, int64_t N, std::vector<float> &w);

@@ -35,6 +35,7 @@
 #include <lld/formantLpc.hpp>
 #include <lld/harmonics.hpp>
 #include <lld/lpc.hpp>
+#include <lld/lsp.hpp>
 #include <lld/pitchShs.hpp>
 #include <lld/pitchSmootherViterbi.hpp>
 // cPitchJitter keeps its second reader, its options and the state it carries from frame to frame private; a tick-level
@@ -43,13 +44,16 @@
 // the header is the library's, token for token -- same layout, same mangled names.
 #include <lld/pitchJitter.hpp>
 #include <lldcore/energy.hpp>
+#include <lldcore/intensity.hpp>
 #include <lldcore/melspec.hpp>
 #include <lldcore/mfcc.hpp>
 #include <lldcore/mzcr.hpp>
 #include <lldcore/pitchACF.hpp>
+#include <lldcore/pitchSmoother.hpp>
 #include <lldcore/plp.hpp>
 #include <lldcore/spectral.hpp>
 #include <other/valbasedSelector.hpp>
+#include <other/vectorOperation.hpp>
 #include <smileutil/smileUtil.h>
 
 #include <cctype>
@@ -73,12 +77,13 @@ namespace {
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-constexpr int kNumOverrides = 24;
+constexpr int kNumOverrides = 28;
 long g_frames[kNumOverrides] = {0};
 long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
 const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
                                             "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
-                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter"};
+                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter",
+                                            "cIntensity", "cLsp", "cPitchSmoother", "cVectorOperation"};
 
 // An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
 // says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
@@ -1400,7 +1405,7 @@ class cHipFunctionals : public cFunctionals {
     s.period = getInputPeriod();
     if (!(s.period > 0.0)) s.period = 1.0;                // only second-normalised values use it
     s.non_zero_functs = (int)getInt("nonZeroFuncts");
-    s.ext_norm = s.means_norm = s.times_norm = s.seg_norm = s.pk_norm = SMILEHIP_NORM_SEGMENT;
+    s.ext_norm = s.means_norm = s.times_norm = s.seg_norm = s.pk_norm = s.ons_norm = SMILEHIP_NORM_SEGMENT;
     s.reg_centroid_norm = SMILEHIP_NORM_SEGMENT;
     s.seg_max_num = 20; s.seg_min_lng = 3; s.seg_pause_min_lng = 2; s.lpc_order = 5;
     const int n = getArraySize("functionalsEnabled");
@@ -1546,8 +1551,17 @@ class cHipFunctionals : public cFunctionals {
           s.pk_abs_thresh = (float)opt_dbl(f, "absThresh");
           s.pk_dyn_rel = 0;
         }
+      } else if (!strcmp(f, "Onset")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_ONSET;
+        static const char *const o[5] = {"onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"};
+        s.ons_mask = mask_of(f, o, 5);
+        s.ons_norm = time_norm(f);
+        s.ons_use_abs = opt_int(f, "useAbsVal");
+        s.ons_thr_on = s.ons_thr_off = (float)opt_dbl(f, "threshold");            // functionalOnset.cpp:72-76
+        if (opt_set(f, "thresholdOnset")) s.ons_thr_on = (float)opt_dbl(f, "thresholdOnset");
+        if (opt_set(f, "thresholdOffset")) s.ons_thr_off = (float)opt_dbl(f, "thresholdOffset");
       } else {
-        return false;                                     // a family that is not built (Crossings, DCT, Onset, Samples, ...)
+        return false;                                     // a family that is not built (Crossings, DCT, Samples, ...)
       }
     }
     return smilehip_funcspec_count(&s) == nFunctValues;
@@ -1590,7 +1604,7 @@ class cHipFunctionals : public cFunctionals {
 // SURVEY 8(f) rank 2, per component. An F0-chain plan carries cSpecScale's spline / weighting tables and cPitchShs'
 // shifts for one spectrum geometry (bins, frameSizeSec of the magnitude level).
 static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double min_pitch, double max_pitch, double cutoff,
-                                        int n_harm, double compression) {
+                                        int n_harm, double compression, double min_f = 25.0) {
   smilehip_lld_config c;
   smilehip_config_compare16_f0(&c);
   c.force_fft_frame_size_sec = frame_size_sec;
@@ -1600,6 +1614,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
   c.voicing_cutoff = cutoff;
   c.shs_n_harmonics = n_harm;
   c.shs_compression = (float)compression;
+  c.specscale_min_f = min_f;
   smilehip_plan *pl = nullptr;
   check(smilehip_plan_create(context(), &c, &pl));
   smilehip_geometry g;
@@ -1625,10 +1640,10 @@ class cHipSpecScale : public cSpecScale {
     if (usable_ < 0) {
       const char *sc = getStr("scale"), *ss = getStr("sourceScale"), *im = getStr("interpMethod");
       usable_ = sc && !strncasecmp(sc, "oct", 3) && ss && !strncasecmp(ss, "lin", 3) && im && !strncasecmp(im, "spl", 3) &&
-                getDouble("minF") == 25.0 && getDouble("maxF") == -1.0 && getInt("nPointsTarget") <= 0 && getInt("specSmooth") == 1 &&
+                getDouble("minF") > 0.0 && getDouble("maxF") == -1.0 && getInt("nPointsTarget") <= 0 && getInt("specSmooth") == 1 &&
                 getInt("specEnhance") == 1 && getInt("auditoryWeighting") == 1 && Nsrc == Ndst;
       if (usable_) {
-        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, 52.0, 620.0, 0.7, 15, 0.85);
+        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, 52.0, 620.0, 0.7, 15, 0.85, getDouble("minF"));
         if (!pl_) usable_ = 0;
       }
     }
@@ -1657,28 +1672,42 @@ class cHipPitchShs : public cPitchShs {
   bool cpu_warned_ = false;
   smilehip_plan *pl_ = nullptr;
   int usable_ = -1;
+  bool raw_ = true, clip_ = true;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       usable_ = getInt("nCandidates") == 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&
-                getInt("voicingC1") == 0 && getInt("F0raw") == 1 && getInt("voicingClip") == 1 && getInt("octaveCorrection") == 0 &&
-                getInt("greedyPeakAlgo") == 1 && getInt("shsSpectrumOutput") == 0 && getDouble("lfCut") <= 0.0 && Ndst == 21 &&
-                reader_->getLevelNf() == 1;
+                getInt("voicingC1") == 0 && getInt("octaveCorrection") == 0 &&
+                getInt("greedyPeakAlgo") == 1 && getInt("shsSpectrumOutput") == 0 && getDouble("lfCut") <= 0.0 &&
+                Ndst == 19 + (getInt("F0raw") ? 1 : 0) + (getInt("voicingClip") ? 1 : 0) && reader_->getLevelNf() == 1;
+      raw_ = getInt("F0raw") != 0;
+      clip_ = getInt("voicingClip") != 0;
+      cVectorMeta *md = reader_->getLevelMetaDataPtr();     // cSpecScale's minF (pitchShs.cpp:166-176): the octave axis' first point
+      const double min_f = md ? (double)md->fData[0] : 25.0;
+      if (!(min_f > 0.0)) usable_ = 0;
       if (usable_) {
         pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, getDouble("minPitch"),
                                 getDouble("maxPitch"), (double)(float)getDouble("voicingCutoff"), getInt("nHarmonics"),
-                                (double)(float)getDouble("compressionFactor"));
+                                (double)(float)getDouble("compressionFactor"), min_f);
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only six candidates with scores / voicing / F0raw / voicingClip and greedyPeakAlgo are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only six candidates with scores and voicing (F0raw / voicingClip optional) and greedyPeakAlgo are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 21);
     io_.up(src, Nsrc);
     check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, 1, nullptr));
-    io_.down(dst, 21);
+    if (raw_ && clip_) io_.down(dst, 21);
+    else {                                                  // [nCandidates | F0Cand | candVoicing | candScores] (+ F0raw) (+ voicingClip)
+      float v[21];
+      io_.down(v, 21);
+      long n = 19;
+      std::memcpy(dst, v, sizeof(float) * 19);
+      if (raw_) dst[n++] = v[19];
+      if (clip_) dst[n++] = v[20];
+    }
     g_frames[16]++;
-    return 21;
+    return (int)Ndst;
   }
  public:
   explicit cHipPitchShs(const char *n) : cPitchShs(n) {}
@@ -1713,8 +1742,9 @@ smilehip_plan *gemaps_plan(long rate = 0) {
 // cSpecResample::processVector (src/dsp/specResample.cpp:175-185) for [gemapsv01b_resampLpc]
 class cHipSpecResample : public cSpecResample {
   FrameIO io_;
+  DevBytes cos_, sin_;
   bool cpu_warned_ = false;
-  int usable_ = -1;
+  int usable_ = -1;                                       // 1: eGeMAPS' fused geometry (plan tables), 2: any geometry (the instance's own tables)
   long rate_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
@@ -1725,14 +1755,25 @@ class cHipSpecResample : public cSpecResample {
       usable_ = !isSet("resampleRatio") && getDouble("targetFs") == 11000.0 && !getStr("inputFieldPartial") &&
                 (Nsrc == 256 || Nsrc == 512 || Nsrc == 1024) && Ndst == 220 && rate_ >= 8000 && rate_ <= 48000 &&
                 std::fabs(c->lastFrameSizeSec - 0.020) < 1e-4;
+      if (!usable_ && dftWork && dftWork->K == Nsrc && dftWork->I == Ndst && Nsrc >= 2 && Nsrc <= 8192 && dftWork->kMax >= 2 &&
+          dftWork->kMax <= Nsrc && !(dftWork->kMax & 1)) {
+        // any other geometry: smileDsp_irdft with the tables smileDsp_initIrdft built for THIS instance (smileUtil.c:1752-1820)
+        const uint64_t bytes = sizeof(float) * (uint64_t)(dftWork->kMax / 2) * (uint64_t)dftWork->I;
+        if (smilehip_copy_to_device(context(), cos_.ensure(bytes), dftWork->costable, bytes, nullptr) ||
+            smilehip_copy_to_device(context(), sin_.ensure(bytes), dftWork->sintable, bytes, nullptr))
+          COMP_ERR("libsmilehip: %s", smilehip_last_error());
+        usable_ = 2;
+      }
     }
     if (!usable_) {
-      HIP_FALLTHROUGH(17, "cSpecResample: only targetFs = 11000 on the spectrum of 20 ms frames at 8 .. 48 kHz (220 samples out) is built");
+      HIP_FALLTHROUGH(17, "cSpecResample: spectra of more than 8192 values are not built");
       return cSpecResample::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_specresample_frames(gemaps_plan(rate_), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    if (usable_ == 1) check(smilehip_specresample_frames(gemaps_plan(rate_), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    else check(smilehip_specresample_table_frames(context(), io_.d_in, Nsrc, Nsrc, Ndst, dftWork->kMax, (const float *)cos_.d,
+                                                  (const float *)sin_.d, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[17]++;
     return (int)Ndst;
@@ -1746,7 +1787,8 @@ class cHipSpecResample : public cSpecResample {
   }
 };
 
-// cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, p = 11, saveLPCoeff only, on 220 samples
+// cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, saveLPCoeff only: p = 11 on 220 samples through the eGeMAPS plan,
+// any other frame length and order p <= 32 through smilehip_lpc_acf_frames
 class cHipLpc : public cLpc {
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -1756,16 +1798,18 @@ class cHipLpc : public cLpc {
     FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       const char *met = getStr("method");
-      usable_ = met && !strncasecmp(met, "acf", 3) && getInt("p") == 11 && getInt("saveLPCoeff") == 1 && !getInt("saveRefCoeff") &&
-                !getInt("lpGain") && !getInt("residual") && !getInt("lpSpectrum") && Nsrc == 220 && Ndst == 11;
+      const bool plain = met && !strncasecmp(met, "acf", 3) && getInt("saveLPCoeff") == 1 && !getInt("saveRefCoeff") && !getInt("lpGain") &&
+                         !getInt("residual") && !getInt("lpSpectrum") && Ndst == p;
+      usable_ = (plain && p == 11 && Nsrc == 220) ? 1 : ((plain && p >= 1 && p <= 32 && Nsrc > p && Nsrc <= 15000) ? 2 : 0);
     }
     if (!usable_) {
-      HIP_FALLTHROUGH(18, "cLpc: only method = acf, p = 11, saveLPCoeff alone on 220-sample frames is built");
+      HIP_FALLTHROUGH(18, "cLpc: only method = acf with saveLPCoeff alone (p <= 32) is built");
       return cLpc::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_lpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    if (usable_ == 1) check(smilehip_lpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    else check(smilehip_lpc_acf_frames(context(), io_.d_in, Nsrc, Nsrc, (int32_t)p, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[18]++;
     return 1;
@@ -1933,6 +1977,9 @@ class cHipPitchJitter : public cPitchJitter {
     if (!js_) {
       const long H = (long)round(pitchT / T), N = (long)round(fvec->tmeta->lengthSec / T);   // (lenF itself is N or N + 1: rounding of the time stamps)
       check(smilehip_jitter_stream_create(context(), T, N, H, pitchT, searchRangeRel, useBrokenJitterThresh_, &js_));
+      // the first F0 frame's time stamp: frame 0 behind the Viterbi smoother, frame 1 behind cPitchSmoother (one frame of delay, the
+      // time meta data of the frame it was called with)
+      check(smilehip_jitter_stream_set_time_offset(js_, std::lround(fvec->tmeta->time / pitchT)));
     }
     const long toRead0 = ppLen + lastMis;
     long toRead = toRead0;
@@ -1981,6 +2028,163 @@ class cHipPitchJitter : public cPitchJitter {
   ~cHipPitchJitter() override { if (js_) smilehip_jitter_stream_destroy(js_); }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPitchJitter(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// ---- the components the other INTERSPEECH sets of config/is09-13 add (IS10_paraling, IS11_speaker_state, IS12_speaker_trait) ----
+// cIntensity::processVector (src/lldcore/intensity.cpp:125-145)
+class cHipIntensity : public cIntensity {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (Nsrc == 0) return 0;
+    const int flags = (intensity ? 1 : 0) | (loudness ? 2 : 0);
+    if (!hamWin || nWin != Nsrc || !flags || Ndst != (intensity ? 1 : 0) + (loudness ? 1 : 0)) {
+      HIP_FALLTHROUGH(24, "cIntensity: a window of another length than the frame is not built");
+      return cIntensity::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_intensity_frames(context(), io_.d_in, Nsrc, Nsrc, flags, io_.d_out, Ndst, 1, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[24]++;
+    return (int)Ndst;
+  }
+ public:
+  explicit cHipIntensity(const char *n) : cIntensity(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipIntensity(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cLsp::processVector (src/lld/lsp.cpp:289-312)
+class cHipLsp : public cLsp {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (Ndst < Nsrc) return 0;
+    if ((lpcIdx == -1) || (nLpc <= 0)) return 0;
+    if (nLpc < 2 || nLpc > 32 || lpcIdx + nLpc > Nsrc) {
+      HIP_FALLTHROUGH(25, "cLsp: more than 32 LP coefficients are not built");
+      return cLsp::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    io_.ensure(nLpc, nLpc);
+    io_.up(src + lpcIdx, nLpc);
+    check(smilehip_lsp_frames(context(), io_.d_in, nLpc, (int32_t)nLpc, io_.d_out, nLpc, 1, nullptr));
+    io_.down(dst, nLpc);
+    g_frames[25]++;
+    return 1;
+  }
+ public:
+  explicit cHipLsp(const char *n) : cLsp(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipLsp(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cPitchSmoother::processVector (src/lldcore/pitchSmoother.cpp:236-425): one input level, medianFilter0 = 0, post smoothing none /
+// simple. The state the component carries from frame to frame lives on the device (32 bytes), the frame is one row of
+// [F0Cand | candVoicing | candScore].
+class cHipPitchSmoother : public cPitchSmoother {
+  FrameIO io_;
+  DevBytes state_, written_;
+  std::vector<float> row_;
+  bool cpu_warned_ = false;
+  int usable_ = -1;
+  bool started_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    const int flags = (F0final ? 1 : 0) | (F0finalEnv ? 2 : 0) | (voicingFinalClipped ? 4 : 0) | (voicingFinalUnclipped ? 8 : 0);
+    if (usable_ < 0) {
+      usable_ = nInputLevels == 1 && medianFilter0 == 0 && postSmoothingMethod != POSTSMOOTHING_MEDIAN && !no0f0 && !F0raw && !voicingC1 &&
+                !voicingClip && flags && nCandidates[0] >= 1 && nCandidates[0] <= 16 && f0candI[0] >= 0 && candVoiceI[0] >= 0 &&
+                candScoreI[0] >= 0;
+    }
+    if (!usable_) {
+      HIP_FALLTHROUGH(26, "cPitchSmoother: several input levels, medianFilter0, median post smoothing, no0f0 and the copied fields are not built");
+      return cPitchSmoother::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    const int c = nCandidates[0];
+    int n_out = 0;
+    for (int b = 0; b < 4; ++b) n_out += (flags >> b) & 1;
+    row_.resize(3 * (size_t)c);
+    for (int j = 0; j < c; ++j) {
+      row_[j] = src[f0candI[0] + j];
+      row_[c + j] = src[candVoiceI[0] + j];
+      row_[2 * c + j] = src[candScoreI[0] + j];
+    }
+    io_.ensure(3 * c, 4);
+    io_.up(row_.data(), 3 * c);
+    const bool simple = postSmoothing && postSmoothingMethod == POSTSMOOTHING_SIMPLE;
+    check(smilehip_pitch_smoother_rows(context(), c, voicingCutoff[0], octaveCorrection, simple ? 1 : 0, flags, io_.d_in, 3 * c, nullptr, 1, 1,
+                                       state_.ensure(32), started_ ? 1 : 0, io_.d_out, 4, (int64_t *)written_.ensure(8), nullptr));
+    started_ = true;
+    int64_t wrote = 0;
+    written_.down(&wrote, 8);
+    g_frames[26]++;
+    if (wrote < 1) return 0;                               // the first frame with simple post smoothing: no output (:331)
+    float out[4];
+    io_.down(out, 4);
+    for (int i = 0; i < n_out && i < Ndst; ++i) dst[i] = out[i];
+    return n_out;
+  }
+ public:
+  explicit cHipPitchSmoother(const char *n) : cPitchSmoother(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchSmoother(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cVectorOperation::processVector, the element-wise operations (src/other/vectorOperation.cpp:360-435, 508-527)
+class cHipVectorOperation : public cVectorOperation {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    int op = -1;
+    switch (operation) {
+      case VOP_ADD: op = SMILEHIP_VOP_ADD; break;
+      case VOP_MUL: op = SMILEHIP_VOP_MUL; break;
+      case VOP_LOG: op = SMILEHIP_VOP_LOG; break;
+      case VOP_LOGA: op = SMILEHIP_VOP_LOGA; break;
+      case VOP_SQRT: op = SMILEHIP_VOP_SQRT; break;
+      case VOP_E: op = SMILEHIP_VOP_E; break;
+      case VOP_ABS: op = SMILEHIP_VOP_ABS; break;
+      case VOP_DB_POW: op = SMILEHIP_VOP_DB_POW; break;
+      case VOP_DB_MAG: op = SMILEHIP_VOP_DB_MAG; break;
+      case VOP_X_SUM: op = SMILEHIP_VOP_X_SUM; break;
+      case VOP_X_SUMSQ: op = SMILEHIP_VOP_X_SUMSQ; break;
+      case VOP_X_L1: op = SMILEHIP_VOP_X_L1; break;
+      case VOP_X_L2: op = SMILEHIP_VOP_X_L2; break;
+    }
+    if (op < 0) {
+      HIP_FALLTHROUGH(27, "cVectorOperation: only add, mul, log, lgA, sqr, ee, abs, dBp, dBv and sum, ssm, ll1, ll2 are built");
+      return cVectorOperation::processVector(src, dst, Nsrc, Ndst, idxi);
+    }
+    const bool reduce = op >= SMILEHIP_VOP_X_SUM;
+    const long n = reduce ? Nsrc : (Nsrc < Ndst ? Nsrc : Ndst);
+    if (n < 1 || Ndst < 1) return 0;
+    io_.ensure(n, n);
+    io_.up(src, n);
+    check(smilehip_vecop_frames(context(), op, param1, logfloor, io_.d_in, n, (int32_t)n, io_.d_out, n, 1, nullptr));
+    io_.down(dst, reduce ? 1 : n);
+    g_frames[27]++;
+    return 1;
+  }
+ public:
+  explicit cHipVectorOperation(const char *n) : cVectorOperation(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipVectorOperation(n);
     c->setComponentInfo(scname, sdescription);
     return c;
   }
@@ -2413,12 +2617,22 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
-  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-four
-  auto want = [&](const char *name) { return !only || strstr(only, name) != nullptr; };
+  const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-eight
+  auto want = [&](const char *name) {                       // whole names of the comma-separated list
+    if (!only) return true;
+    const size_t n = strlen(name);
+    for (const char *p = only; (p = strstr(p, name)) != nullptr; p += n)
+      if ((p == only || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+  };
   if (want("cHipLldSource")) {                             // a NEW type (fused mode), not an override
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cVectorOperation")) head = override_of(&cVectorOperation::registerComponent, &cHipVectorOperation::create, confman, compman, iteration, head);
+  if (want("cPitchSmoother")) head = override_of(&cPitchSmoother::registerComponent, &cHipPitchSmoother::create, confman, compman, iteration, head);
+  if (want("cLsp")) head = override_of(&cLsp::registerComponent, &cHipLsp::create, confman, compman, iteration, head);
+  if (want("cIntensity")) head = override_of(&cIntensity::registerComponent, &cHipIntensity::create, confman, compman, iteration, head);
   if (want("cPitchJitter")) head = override_of(&cPitchJitter::registerComponent, &cHipPitchJitter::create, confman, compman, iteration, head);
   if (want("cValbasedSelector")) head = override_of(&cValbasedSelector::registerComponent, &cHipValbasedSelector::create, confman, compman, iteration, head);
   if (want("cPitchSmootherViterbi")) head = override_of(&cPitchSmootherViterbi::registerComponent, &cHipPitchSmootherViterbi::create, confman, compman, iteration, head);

@@ -267,3 +267,23 @@ int lldo_vecop(int op, float param1, float logfloor, const float *src, float *ds
   }
   return -1;
 }
+
+/* the vector-to-scalar operations (vectorOperation.cpp:461-490): sum, ssm, ll1, ll2 */
+float lldo_vecop_reduce(int op, const float *src, long n)
+{
+  float d = 0.0;
+  switch (op) {
+    case LLDO_VOP_X_SUM: for (long i = 0; i < n; i++) d += src[i]; break;
+    case LLDO_VOP_X_SUMSQ: for (long i = 0; i < n; i++) d += src[i] * src[i]; break;
+    case LLDO_VOP_X_L1:
+      for (long i = 0; i < n; i++) d += src[i];
+      if (n > 0) d /= (float)n;
+      break;
+    case LLDO_VOP_X_L2:
+      for (long i = 0; i < n; i++) d += src[i] * src[i];
+      if (d > 0.0) d = sqrtf(d);
+      if (n > 0) d /= (float)n;
+      break;
+  }
+  return d;
+}

@@ -934,7 +934,7 @@ IS10_TAPS_CONF = os.path.join(HERE, "conf", "is10_taps.conf")
 IS10_LEVELS = ["is10_frames", "is10_intens", "is10_fftc", "is10_outpR", "is10_lpc", "is10_lsp", "is10_pitchShs", "is10_pitch",
                "is10_pitchF", "is10_mspec2", "is10_mspec2log", "is10_jitter", "is10_lld1", "is10_lld2", "is10_lld1_de",
                "is10_lld2_de", "is10_functOnsets", "is10_funct", "is10_functNz"]
-VOP = {"add": 0, "mul": 1, "log": 2, "lgA": 3, "sqr": 4, "ee": 5, "abs": 6, "dBp": 7, "dBv": 8}
+VOP = {"add": 0, "mul": 1, "log": 2, "lgA": 3, "sqr": 4, "ee": 5, "abs": 6, "dBp": 7, "dBv": 8, "sum": 9, "ssm": 10, "ll1": 11, "ll2": 12}
 
 
 def run_reference_is10(pcm, fs=16000, levels=IS10_LEVELS):
@@ -1030,3 +1030,12 @@ def specresample_rows(spec, fs_sec, last_fs_sec, base_period, target_fs):
         L.lldo_specresample_frame(C.byref(r), spec[i].ctypes.data, out[i].ctypes.data)
     L.lldo_specresample_free(C.byref(r))
     return out
+
+
+def vecop_reduce_rows(x, op):
+    """cVectorOperation's vector-to-scalar operations (sum, ssm, ll1, ll2) over rows: n x N -> n."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    L.lldo_vecop_reduce.restype = C.c_float
+    L.lldo_vecop_reduce.argtypes = [C.c_int, C.c_void_p, C.c_long]
+    return np.array([L.lldo_vecop_reduce(VOP[op], x[i].ctypes.data, x.shape[1]) for i in range(x.shape[0])], np.float32)

@@ -28,3 +28,6 @@ extern "C" int64_t is10_pitch_smoother_rows(const float *src, int64_t ld, int64_
 extern "C" void is10_vecop(int op, float aux, float logfloor, const float *src, float *dst, int64_t n) {
   for (int64_t i = 0; i < n; ++i) dst[i] = vecop(op, aux, logfloor, src[i]);
 }
+extern "C" void is10_vecop_reduce(int op, const float *src, int64_t ld, int64_t n_cols, int64_t n, float *dst) {
+  for (int64_t i = 0; i < n; ++i) dst[i] = vecop_reduce(op, src + i * ld, n_cols);
+}

@@ -573,3 +573,31 @@ def test_plugin_fused_mode_unmodified_big_sets(oracle, conf, n_func):
     # no per-frame device work upstream of the fused levels
     for comp in ("cTransformFFT", "cSpecScale", "cPitchShs", "cSpectral", "cHarmonics", "cAcf"):
         assert tr.get(comp, 0) == 0, (comp, tr)
+
+
+def test_plugin_is10_paraling(oracle):
+    """The UNMODIFIED config/is09-13/IS10_paraling.conf (the INTERSPEECH 2010 Paralinguistic Challenge set: 38 LLDs + deltas, 1582
+    functionals) inside the unmodified binary with every override active: the components the five BASELINE configs do not have --
+    cIntensity, cLsp, cPitchSmoother, cVectorOperation, cSpecResample / cLpc on 25 ms frames (512 -> 275 samples, p = 8), cSpecScale with
+    minF = 20, cPitchShs without F0raw / voicingClip, the Onset functionals -- run on the GPU: LLD file and functionals file equal the
+    plain binary's bit for bit, nothing on the reference's CPU code."""
+    from opensmile_amd import synth
+    conf = "is09-13/IS10_paraling.conf"
+    for u, n in ((71, 24000), (5, 9000)):
+        pcm = synth.utterance(u, n)
+        ref_l, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
+        ref_f, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-htkoutput")
+        y_l, tr = _run(oracle, pcm, None, conf, "-lldhtkoutput")
+        y_f, tr2 = _run(oracle, pcm, None, conf, "-htkoutput")
+        assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+        T25 = 1 + (n - 400) // 160
+        for comp, cnt in (("cIntensity", T25), ("cLsp", T25), ("cVectorOperation", T25), ("cSpecResample", T25), ("cLpc", T25)):
+            assert tr.get(comp, 0) == cnt, (comp, tr)
+        assert tr.get("cPitchSmoother", 0) > 0 and tr.get("cPitchShs", 0) > 0 and tr.get("cSpecScale", 0) > 0 and tr.get("cPitchJitter", 0) > 0, tr
+        assert tr.get("cFunctionals", 0) > 0, tr
+        assert ref_l.shape == y_l.shape and ref_l.shape[1] == 76
+        d = y_l.view(np.uint32) != ref_l.view(np.uint32)
+        assert not d.any(), f"LLD: {d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))[:20]}"
+        assert ref_f.shape == y_f.shape == (1, 1582)
+        d = y_f.view(np.uint32) != ref_f.view(np.uint32)
+        assert not d.any(), f"functionals: {d.sum()} of {d.size} differ at {np.argwhere(d)[:10, 1]}: {y_f[d][:5]} vs {ref_f[d][:5]}"

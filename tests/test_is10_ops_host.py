@@ -116,6 +116,13 @@ def test_ops_equal_oracle_on_seeded_inputs(ops):
     v = np.concatenate([rng.standard_normal(5000) * 3, [0.0, -0.0, 1e-13, 1e-12, 1e-30, 88.0, -104.0]]).astype(np.float32)
     for op, p1 in (("add", 0.37), ("mul", -2.5), ("log", 1), ("lgA", 10.0), ("sqr", 1), ("ee", 1), ("abs", 1), ("dBp", 1), ("dBv", 1)):
         assert same(h_vecop(ops, v, op, p1), lldo.vecop_rows(v, op, p1)), op
+    m = (rng.standard_normal((200, 26)) * rng.uniform(0.01, 30, (200, 1))).astype(np.float32)
+    m[0] = 0.0
+    ops.is10_vecop_reduce.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+    for op in ("sum", "ssm", "ll1", "ll2"):
+        out = np.zeros(len(m), np.float32)
+        ops.is10_vecop_reduce(lldo.VOP[op], m.ctypes.data, 26, 26, len(m), out.ctypes.data)
+        assert same(out, lldo.vecop_reduce_rows(m, op)), op
 
 
 @pytest.mark.skipif(not lldo.have_ref(), reason="oracle/_ref not built")
