@@ -157,6 +157,13 @@ typedef struct smilehip_lld_config {
   double   formant_max_freq;
   /* F0 chains: cSpecScale minF (src/dsp/specScale.cpp:228-300; 0 = 25 as in ComParE_2016 / GeMAPS, 20 in IS10_paraling .. IS12) */
   double   specscale_min_f;
+  /* F0 chains: cPitchShs nCandidates (0 = 6 as in ComParE_2016 / GeMAPS; 1 .. 6: the 21-value rows keep six slots per field, the
+   * unused ones zero) and greedyPeakAlgo = 0 (src/lld/pitchShs.cpp:286-302: IS11_speaker_state, IS12_speaker_trait) */
+  int32_t  shs_n_candidates;
+  int32_t  shs_old_peak_algo;
+  /* cSpectral bands[0], bands[1] in Hz (src/lldcore/spectral.cpp:779-853; all four 0 = 250-650 and 1000-4000 as in ComParE_2016;
+   * IS11_speaker_state has 25-650) */
+  int32_t  spectral_band_lo[2], spectral_band_hi[2];
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0
@@ -325,13 +332,15 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *   Lpc         (functionalLpc.cpp:95-119)         lpgain, lpc[first..order)
  *   Peaks2      (functionalPeaks2.cpp:316-905)     its 32 values in the order of functionalPeaks2.cpp:60-67
  *   Onset       (functionalOnset.cpp:83-151)       onsetPos offsetPos numOnsets numOffsets onsetRate
+ *   Peaks       (functionalPeaks.cpp:98-214, the older peak picker; overlapFlag = 1) numPeaks meanPeakDist peakMean
+ *                                                  peakMeanMeanDist peakDistStddev
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
  * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange, the other
  * segmentation algorithms, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
-  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_COUNT
+  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
 enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2 };
@@ -358,6 +367,7 @@ typedef struct smilehip_func_spec {
   float pk_rel_thresh, pk_abs_thresh;
   uint32_t ons_mask; int32_t ons_norm, ons_use_abs, reserved6;   /* Onset: thresholdOnset / thresholdOffset (= threshold unless set) */
   float ons_thr_on, ons_thr_off;
+  uint32_t pko_mask; int32_t pko_norm;                             /* Peaks */
 } smilehip_func_spec;
 
 /* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */
@@ -753,6 +763,8 @@ int smilehip_valbased_select_frames(smilehip_context *ctx, const float *d_src, i
 typedef struct smilehip_viterbi_stream smilehip_viterbi_stream;
 int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buffer_len, float voicing_cutoff, const double *weights6,
                                    smilehip_viterbi_stream **out);
+/* nCandidates of the pitch detector feeding the smoother (default 6; 1 .. 6: states = candidates + "unvoiced"). Before the first push. */
+int smilehip_viterbi_stream_set_candidates(smilehip_viterbi_stream *s, int32_t n_candidates);
 int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing,
                                  int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
 int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);

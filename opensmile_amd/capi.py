@@ -42,7 +42,8 @@ class LldConfig(C.Structure):
         ("stage_mask", C.c_uint32),
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
         ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
-        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double), ("specscale_min_f", C.c_double),
+        ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double), ("specscale_min_f", C.c_double), ("shs_n_candidates", C.c_int32), ("shs_old_peak_algo", C.c_int32),
+        ("spectral_band_lo", C.c_int32 * 2), ("spectral_band_hi", C.c_int32 * 2),
     ]
 
 
@@ -73,6 +74,7 @@ class FuncSpec(C.Structure):
         ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
         ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
         ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
+        ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
     ]
 
 
@@ -132,6 +134,7 @@ SYMBOLS = {
     "smilehip_jitter_stream_destroy": (C.c_int, [_vp]),
     "smilehip_viterbi_stream_create": (C.c_int, [_vp, _i32, _f32, _vp, C.POINTER(_vp)]),
     "smilehip_viterbi_stream_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "smilehip_viterbi_stream_set_candidates": (C.c_int, [_vp, _i32]),
     "smilehip_viterbi_stream_flush": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),
     "smilehip_viterbi_stream_destroy": (C.c_int, [_vp]),
     "smilehip_funcspec_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int32, _vp, _vp]),

@@ -400,9 +400,33 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   }
   unsigned long long open = 0;                           // bit m: this lane's bin lane + 64 m is a local maximum not yet taken (kPer <= 33)
   F0_FOR_BINS(m, j) if (j >= 1 && j < kK - 1 && lf[m] < hv[m] && hv[m] > rt[m]) open |= 1ull << m;
+  if (Q.old_peaks) {
+    // greedyPeakAlgo = 0 (pitchShs.cpp:286-302): a peak enters (at the front) only if it is above the best so far -- the candidates are
+    // the running maxima of the peaks in bin order, the latest nCandidates of them, latest first. Their scores rise with the bin, so
+    // they are the best-scored running maxima: mask the peaks that are not running maxima (exclusive prefix maximum over the
+    // peaks in bin order: a lane scan per row of 64 bins, the rows in sequence) and let the selection below take its pick.
+    float run = -INFINITY;
+    F0_FOR_BINS(m, j) {
+      const bool pk = ((open >> m) & 1ull) != 0;
+      float sc = pk ? hv[m] : -INFINITY;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(sc, d);
+        if (lane >= d) sc = fmaxf(sc, t);
+      }
+      float ex = __shfl_up(sc, 1);
+      if (lane == 0) ex = -INFINITY;
+      const float before = fmaxf(run, ex);
+      if (pk && !(hv[m] > before)) open &= ~(1ull << m);
+      run = fmaxf(run, __shfl(sc, 63));
+      (void)j;
+    }
+  }
+  const int nc = Q.n_cand;
   int n_found = 0;
 #pragma unroll
   for (int r = 0; r < kNC; ++r) {
+    if (r >= nc) break;
     float bv = -1.0f;
     int bi = 1 << 30;
     F0_FOR_BINS(m, j) if (((open >> m) & 1ull) && hv[m] > bv) { bv = hv[m]; bi = j; }     // ascending j: first maximum
@@ -476,13 +500,14 @@ __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64
   WaveG::sync();
   if (lane == 0) {
     float *f0c = cf, *cv = cf + 8, *cs = cf + 16;
+    const int nc = Q.n_cand;
     int n = n_found;
     if (n > 0) {
-      for (int c = 0; c < kNC && n > 0; c++) {
+      for (int c = 0; c < nc && n > 0; c++) {
         if ((double)f0c[c] > Q.max_pitch || (double)f0c[c] < Q.min_pitch) {
           const float orig = f0c[c];
           int j;
-          for (j = c + 1; j < kNC; j++) { f0c[j - 1] = f0c[j]; cv[j - 1] = cv[j]; cs[j - 1] = cs[j]; }
+          for (j = c + 1; j < nc; j++) { f0c[j - 1] = f0c[j]; cv[j - 1] = cv[j]; cs[j - 1] = cs[j]; }
           f0c[j - 1] = 0; cv[j - 1] = 0; cs[j - 1] = 0;
           if (orig > 0.0f) { n--; c--; }
         }
@@ -490,7 +515,7 @@ __device__ __forceinline__ void f0_candidates(const F0Params &Q, int lane, int64
     }
     int best = 0;
     float mx = cs[0];
-    for (int c = 1; c < kNC; c++) if (cs[c] > mx) { mx = cs[c]; best = c; }
+    for (int c = 1; c < nc; c++) if (cs[c] > mx) { mx = cs[c]; best = c; }
     if (best > 0) {
       float tmp;
       tmp = f0c[0]; f0c[0] = f0c[best]; f0c[best] = tmp;
@@ -851,39 +876,40 @@ __global__ void __launch_bounds__(64) lld_f0_rows_big(F0Params Q) {
 // decisions this frame makes possible. `emit(n, s)`: frame n has been decided as state s (called by the lanes that decide;
 // `emit_done(k)` once per frame by every lane with the number of frames decided). State: paths / cost / msel in LDS,
 // the scalars by reference. cur / prev: the frame's and the previous frame's 21 values.
-template <class Emit, class EmitDone>
+template <bool SIX, class Emit, class EmitDone>           // SIX: nCandidates = kNC, the states and lane groups are compile-time constants
 __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, const float *prev, int t, int lane,
                                           int (*paths)[kNS * kVBmax], double *cost, int *msel, double &lastChange, int &pathBuf,
                                           int &pathIdx, int &convIdx, Emit emit, EmitDone emit_done) {
   const int kVB = Q.vit_buf;                               // bufferLength (<= kVBmax, checked by the launcher)
-  const bool valid = lane < kNS * kNS;
-  const int si = valid ? lane / kNS : 0, sj = valid ? lane % kNS : 0;
+  const int nc = SIX ? kNC : Q.n_cand, ns = nc + 1;        // nCandidates (<= kNC; the rows keep kNC slots per field) and the states
+  const bool valid = lane < ns * ns;
+  const int si = valid ? lane / ns : 0, sj = valid ? lane % ns : 0;
   const double wLocal = Q.vit_w[0], wTvv = Q.vit_w[1], wTvvd = Q.vit_w[2], wTvuv = Q.vit_w[3], wThr = Q.vit_w[4],
                wRange = Q.vit_w[5];
   const float thr = Q.voicing_cutoff;
   double lc = 0.0;                                       // localCost of state `lane`
-  if (lane < kNC) {
+  if (lane < nc) {
     double pv = (double)cur[1 + kNC + lane], tc = 0.0;
     if (pv < 0.01) pv = 0.01;
     if (pv > 1.00) pv = 1.00;
     if (pv < thr) tc = wThr;
     lc = (-log(pv) + tc) * wLocal + f_weight(cur[1 + lane]) * wRange;
-  } else if (lane == kNC) {
+  } else if (lane == nc) {
     double flag = 0.0;
-    for (int c = 0; c < kNC; ++c) if (cur[1 + kNC + c] >= thr) { flag = wThr; break; }
+    for (int c = 0; c < nc; ++c) if (cur[1 + kNC + c] >= thr) { flag = wThr; break; }
     if (flag == 0.0 && 0.0f >= thr) flag = wThr;         // frame[13] of the reference's buffer is 0
     lc = wLocal * flag;
   }
   if (t == 0) {
-    if (lane < kNS) { cost[lane] = lc; paths[0][lane * kVB] = lane; }
+    if (lane < ns) { cost[lane] = lc; paths[0][lane * kVB] = lane; }
     __syncthreads();
   } else {
-    const bool vv = valid && si < kNC && sj < kNC;
+    const bool vv = valid && si < nc && sj < nc;
     float fa = 0.0f, fb2 = 0.0f;
     if (vv) { fa = prev[1 + sj]; fb2 = cur[1 + si]; }
     const bool zero = vv && (fa == 0 || fb2 == 0);
     const bool modr = vv && !zero;
-    const bool mod0 = valid && ((si == kNC) != (sj == kNC));
+    const bool mod0 = valid && ((si == nc) != (sj == nc));
     const double r = modr ? log((double)(fb2 / fa)) : 0.0;
     const unsigned long long mask = __ballot(modr || mod0);
     const unsigned long long lower = mask & ((1ull << lane) - 1ull);
@@ -895,25 +921,25 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
     else if (mod0) c = wTvuv;
     if (mask) lastChange = __shfl(r, 63 - __clzll((long long)mask));
     const double tot = valid ? c + cost[sj] : 0.0;
-    const int gb = si * kNS;
+    const int gb = si * ns;
     double mc = __shfl(tot, gb);
     int ms = 0;
 #pragma unroll
     for (int jj = 1; jj < kNS; ++jj) {
       const double v = __shfl(tot, gb + jj);
-      if (v < mc) { mc = v; ms = jj; }
+      if (jj < ns && v < mc) { mc = v; ms = jj; }
     }
     const double lci = __shfl(lc, si);
     __syncthreads();
     if (valid && sj == 0) { cost[si] = mc + lci; msel[si] = ms; }
     __syncthreads();
     const int nb = pathBuf ^ 1;
-    for (int idx = lane; idx < kNS * kVB; idx += 64) {
+    for (int idx = lane; idx < ns * kVB; idx += 64) {
       const int ii = idx / kVB, n = idx - ii * kVB;
       paths[nb][idx] = paths[pathBuf][msel[ii] * kVB + n];
     }
     __syncthreads();
-    if (lane < kNS) paths[nb][lane * kVB + pathIdx % kVB] = lane;
+    if (lane < ns) paths[nb][lane * kVB + pathIdx % kVB] = lane;
     __syncthreads();
     pathBuf = nb;
   }
@@ -921,7 +947,7 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
   const int *Pp = paths[pathBuf];
   if (pathIdx - convIdx > kVB) {                         // forced decision for the oldest open frame
     int ms = 0;
-    for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
+    for (int i = 1; i < ns; i++) if (cost[i] < cost[ms]) ms = i;
     convIdx++;
     if (lane == 0) emit(convIdx, Pp[ms * kVB + convIdx % kVB], 0);
     emit_done(1);
@@ -932,7 +958,7 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
     if (n < pathIdx) {
       xs = Pp[n % kVB];
       match = true;
-      for (int i = 1; i < kNS; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
+      for (int i = 1; i < ns; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
     }
     const unsigned long long mm = __ballot(match);
     const int nlead = __ffsll((long long)~mm) - 1;       // lanes >= 31 never match: ~mm != 0
@@ -962,8 +988,8 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
   auto emit = [&](int n, int s, int) {
     const int64_t row = fo + n;
     const float *fr = S + (int64_t)n * 21;
-    float f = (s < kNC) ? fr[1 + s] : 0.0f;
-    float vp = (s < kNC) ? fr[1 + kNC + s] : fr[1 + kNC];
+    float f = (s < Q.n_cand) ? fr[1 + s] : 0.0f;
+    float vp = (s < Q.n_cand) ? fr[1 + kNC + s] : fr[1 + kNC];
     if (!(Q.e60[row] > Q.min_energy)) { f = 0.0f; vp = 0.0f; }     // cValbasedSelector, zeroVec
     out[row * ld] = f;
     if (Q.vit_log_out) {
@@ -982,13 +1008,14 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
 
   for (int t = 0; t < T; ++t) {
     const float *cur = S + (int64_t)t * 21;
-    vit_frame(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+    if (Q.n_cand == kNC) vit_frame<true>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+    else vit_frame<false>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
   }
   // flushTrellis at end of input
   if (lane == 0 && Q.pending) Q.pending[u] = pathIdx - (convIdx + 1);      // frames only decided by the flush
   {
     int ms = 0;
-    for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
+    for (int i = 1; i <= Q.n_cand; i++) if (cost[i] < cost[ms]) ms = i;
     const int *Pp = paths[pathBuf];
     for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB], 0);
   }
@@ -1016,10 +1043,11 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi_step(F0Params Q, const floa
   if (!flush) {
     const int t = pathIdx;
     const float *cur = frames + (int64_t)t * 21;
-    vit_frame(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+    if (Q.n_cand == kNC) vit_frame<true>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+    else vit_frame<false>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
   } else {                                                 // flushTrellis: everything still open follows the cheapest path
     int ms = 0;
-    for (int i = 1; i < kNS; i++) if (cost[i] < cost[ms]) ms = i;
+    for (int i = 1; i <= Q.n_cand; i++) if (cost[i] < cost[ms]) ms = i;
     const int *Pp = paths[pathBuf];
     for (int n = convIdx + 1 + lane; n < pathIdx; n += 64) emit(n, Pp[ms * kVB + n % kVB], n - (convIdx + 1));
     n_dec = pathIdx - (convIdx + 1);

@@ -557,6 +557,72 @@ __device__ int f_onset(const smilehip_func_spec &s, const Col &in, float *out) {
   return n;
 }
 
+// Peaks (functionalPeaks.cpp:98-214, overlapFlag = 1): the older peak picker. A local maximum arms a peak once it stands more than
+// 0.11 range above the last local minimum (comparisons in double, as written there); the peak is counted when the contour falls more
+// than 0.09 range below it or ends. The walk runs twice -- count / sums first, then the squared deviations of the peak distances from
+// their mean in the same order (instead of the reference's list of distances).
+struct PkoAcc { int64_t nPeaks, nDist; float peakMean, distSum, mean, dev; bool second; };
+__device__ void pko_walk(const Col &in, float range, PkoAcc &r) {
+  const int64_t Nin = in.N;
+  float lastMin = 0.0f, lastMax = 0.0f;
+  int64_t curmaxPos = 0, lastmaxPos = -1;
+  bool peakflag = false;
+  float lastlastVal = in[0], lastVal = Nin > 1 ? in[1] : 0.0f;
+  for_rows(in, 2, Nin, [&](int64_t i, float v) {
+    if ((lastlastVal < lastVal) && (lastVal > v)) {
+      if (!peakflag) lastMax = v;
+      else if (v > lastMax) { lastMax = v; curmaxPos = i; }
+      if ((double)(lastMax - lastMin) > 0.11 * (double)range) { peakflag = true; curmaxPos = i; }
+    } else if ((lastlastVal > lastVal) && (lastVal < v)) {
+      lastMin = v;
+    }
+    if (peakflag && (((double)v < (double)lastMax - 0.09 * (double)range) || (i == Nin - 1))) {
+      if (!r.second) { r.nPeaks++; r.peakMean += lastMax; }
+      if (lastmaxPos >= 0) {
+        const float dist = (float)(curmaxPos - lastmaxPos);
+        if (!r.second) { r.distSum += dist; r.nDist++; }
+        else { const float d = (float)(int64_t)dist - r.mean; r.dev += d * d; }
+      }
+      lastmaxPos = curmaxPos;
+      peakflag = false;
+    }
+    lastlastVal = lastVal;
+    lastVal = v;
+  });
+}
+
+__device__ int f_peaks_old(const smilehip_func_spec &s, const Col &in, float min, float max, float *out) {
+  const int64_t Nin = in.N;
+  float mean = in[0];                                    // the family's own mean: one float chain from in[0] on (:119-124)
+  for_rows(in, 1, Nin, [&](int64_t, float v) { mean += v; });
+  mean /= (float)Nin;
+  const float range = max - min;
+  PkoAcc r{0, 0, 0.0f, 0.0f, 0.0f, 0.0f, false};
+  pko_walk(in, range, r);
+  float peakDist = r.distSum, stddev = 0.0f;
+  if (r.nDist > 0) {
+    peakDist /= (float)r.nDist;
+    r.second = true;
+    r.mean = peakDist;
+    pko_walk(in, range, r);
+    stddev = r.dev / (float)r.nDist;
+    stddev = sqrtf(stddev);
+  } else {
+    peakDist = (float)(Nin + 1);
+  }
+  const uint32_t m = s.pko_mask;
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = (float)r.nPeaks;
+  if (s.pko_norm == SMILEHIP_NORM_SECOND) { peakDist *= (float)s.period; stddev *= (float)s.period; }
+  else if (s.pko_norm == SMILEHIP_NORM_SEGMENT) { peakDist /= (float)Nin; stddev /= (float)Nin; }
+  if (FS_BIT(m, 1)) out[n++] = peakDist;
+  float peakMean = r.nPeaks > 0 ? r.peakMean / (float)r.nPeaks : 0.0f;
+  if (FS_BIT(m, 2)) out[n++] = peakMean;
+  if (FS_BIT(m, 3)) out[n++] = peakMean - mean;
+  if (FS_BIT(m, 4)) out[n++] = stddev;
+  return n;
+}
+
 // Segments: the segmentation runs twice -- first to get count / sum / extremes of the segment lengths, then again to
 // accumulate the squared deviations from the mean in the same order (instead of keeping the reference's segLens[])
 struct SegAcc {
@@ -1088,6 +1154,7 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_family(FsParams P, int out_o
   if (FAM == SMILEHIP_FAM_SEGMENTS) got = f_segments(P.spec, x, mn, mx, o);
   if (FAM == SMILEHIP_FAM_LPC) got = f_lpc(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_ONSET) got = f_onset(P.spec, x, o);
+  if (FAM == SMILEHIP_FAM_PEAKS) got = f_peaks_old(P.spec, x, mn, mx, o);
   if (FAM == SMILEHIP_FAM_PEAKS2)
     got = f_peaks2(P.spec, x, mn, mx, mean, P.alive + w.srow0 * P.n_cols + w.c, P.n_cols, o);
   for (int j = got; j < want; ++j) o[j] = 0.0f;
@@ -1305,6 +1372,7 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
       case SMILEHIP_FAM_LPC: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_ONSET: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_ONSET>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_PEAKS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PERCENTILES:
         hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
         if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts

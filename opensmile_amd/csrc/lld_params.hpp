@@ -156,6 +156,8 @@ struct F0Params {
   int32_t vit_buf;                  // cPitchSmootherViterbi bufferLength (30 ComParE, 40 GeMAPS; <= 40)
   int32_t vit_log_out;              // 1: rows [F0final, F0finalLog, voicingFinalUnclipped] (GeMAPS), 0: [F0final, voicing]
   double jit_search_range;          // cPitchJitter searchRangeRel (0.25 ComParE, 0.1 GeMAPS)
+  int32_t n_cand;                   // cPitchShs nCandidates (1 .. 6; the rows keep six slots, the unused ones are zero)
+  int32_t old_peaks;                // cPitchShs greedyPeakAlgo = 0: only peaks above every earlier peak become candidates (pitchShs.cpp:286-302)
   int64_t jit_t_shift;              // frames: F0 frame t carries the time stamp of frame t + shift (1 behind cPitchSmoother, which delays its
                                     // values by one frame but hands on the time meta data of the frame it was called with; 0 otherwise)
   float *jit_shim_db;               // optional [total_frames]: shimmerLocalDB = 20 log10(shimmerLocal + 1)

@@ -526,6 +526,8 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.vit_w[0] = 2.0; Q.vit_w[1] = 10.0; Q.vit_w[2] = 10.0; Q.vit_w[3] = 10.0; Q.vit_w[4] = 4.0; Q.vit_w[5] = 1.0;
   Q.vit_buf = plan->cfg.vit_buffer_len > 0 ? plan->cfg.vit_buffer_len : 30;
   Q.jit_search_range = plan->cfg.jitter_search_range > 0.0 ? plan->cfg.jitter_search_range : 0.25;
+  Q.n_cand = plan->cfg.shs_n_candidates > 0 ? plan->cfg.shs_n_candidates : 6;
+  Q.old_peaks = plan->cfg.shs_old_peak_algo ? 1 : 0;
 }
 
 // log_out: rows [F0final, F0finalLog, voicingFinalUnclipped] (the eGeMAPS sub-chain, ld_out >= 3) instead of [F0final, voicing]

@@ -58,6 +58,9 @@ int family_count(const smilehip_func_spec &s, int fam) {
     case SMILEHIP_FAM_ONSET:
       if (s.ons_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Onset: unknown bits in mask 0x%x", s.ons_mask);
       return popc(s.ons_mask);
+    case SMILEHIP_FAM_PEAKS:
+      if (s.pko_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Peaks: unknown bits in mask 0x%x", s.pko_mask);
+      return popc(s.pko_mask);
   }
   return fail(SMILEHIP_ERR_INVALID, "unknown functional family %d", fam);
 }
@@ -69,7 +72,7 @@ int spec_layout(const smilehip_func_spec *s, int *fam_off, int *fam_want) {
   if (s->n_fam < 1 || s->n_fam > 12) return fail(SMILEHIP_ERR_INVALID, "functionalsEnabled: %d families (1..12)", s->n_fam);
   if (s->non_zero_functs < 0 || s->non_zero_functs > 2) return fail(SMILEHIP_ERR_INVALID, "nonZeroFuncts %d not in 0..2", s->non_zero_functs);
   if (!norm_ok(s->ext_norm) || !norm_ok(s->means_norm) || !norm_ok(s->times_norm) || !norm_ok(s->seg_norm) || !norm_ok(s->pk_norm) ||
-      !norm_ok(s->reg_centroid_norm) || !norm_ok(s->ons_norm))
+      !norm_ok(s->reg_centroid_norm) || !norm_ok(s->ons_norm) || !norm_ok(s->pko_norm))
     return fail(SMILEHIP_ERR_INVALID, "time norm must be 0 (segment), 1 (second) or 2 (frame)");
   if (!(s->period > 0.0)) return fail(SMILEHIP_ERR_INVALID, "functionals spec: period must be > 0");
   int n = 0;

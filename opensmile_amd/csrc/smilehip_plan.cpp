@@ -206,6 +206,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     if (p->cfg.shs_n_harmonics < 1 || p->cfg.shs_n_harmonics > 17 || !(p->cfg.pitch_max > p->cfg.pitch_min) || p->cfg.pitch_min < 40.0)
       return fail(SMILEHIP_ERR_INVALID, "F0 chain: nHarmonics 1..17, minPitch >= 40 Hz (period search window of the jitter kernel), "
                   "maxPitch > minPitch");
+    if (p->cfg.shs_n_candidates < 0 || p->cfg.shs_n_candidates > 6)
+      return fail(SMILEHIP_ERR_INVALID, "F0 chain: cPitchShs nCandidates 1 .. 6 (0 = 6)");
     if ((rc = make_f0_tables(p->geo.K, p->geo.fft_frame_size_sec, p->cfg.shs_n_harmonics, p->cfg.shs_compression,
                              p->cfg.specscale_min_f > 0.0 ? p->cfg.specscale_min_f : 25.0, p->f0)))
       return fail(rc, "F0 chain: spectrum geometry / nHarmonics not usable by cSpecScale / cPitchShs");
@@ -419,7 +421,13 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
       sw[size_t(j - 1)] = zz * g;
     }
     // band edges of [is13_spectral] bands 250-650 and 1000-4000 (spectral.cpp:779-853)
-    const int band_lo[2] = {250, 1000}, band_hi[2] = {650, 4000};
+    int band_lo[2] = {250, 1000}, band_hi[2] = {650, 4000};
+    if (p->cfg.spectral_band_lo[0] || p->cfg.spectral_band_lo[1] || p->cfg.spectral_band_hi[0] || p->cfg.spectral_band_hi[1])
+      for (int b = 0; b < 2; ++b) {
+        band_lo[b] = p->cfg.spectral_band_lo[b];
+        band_hi[b] = p->cfg.spectral_band_hi[b];
+        if (band_lo[b] < 0 || band_hi[b] <= band_lo[b]) return fail(SMILEHIP_ERR_INVALID, "cSpectral bands[%d] = %d-%d", b, band_lo[b], band_hi[b]);
+      }
     const int Nsrc = (int)p->geo.K;
     for (int b = 0; b < 2; ++b) {
       int ii;

@@ -317,6 +317,7 @@ extern "C" int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buf
   s->ctx = ctx;
   std::memset(&s->Q, 0, sizeof(s->Q));
   s->Q.vit_buf = buffer_len;
+  s->Q.n_cand = 6;
   s->Q.voicing_cutoff = voicing_cutoff;
   for (int i = 0; i < 6; ++i) s->Q.vit_w[i] = weights6[i];
   const int ns = f0_viterbi_states(), np = ns * f0_viterbi_max_buffer();
@@ -334,6 +335,13 @@ extern "C" int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buf
     return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_create: device allocation failed");
   }
   *out = s;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_viterbi_stream_set_candidates(smilehip_viterbi_stream *s, int32_t n_candidates) {
+  if (!s || n_candidates < 1 || n_candidates > 6 || s->n_frames != 0)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_set_candidates: 1 .. 6 candidates, before the first push");
+  s->Q.n_cand = n_candidates;
   return SMILEHIP_OK;
 }
 
@@ -371,7 +379,7 @@ extern "C" int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const fl
     s->cap_frames = ncap;
   }
   float row[21] = {0};
-  for (int c = 0; c < 6; ++c) { row[1 + c] = cand_f0[c]; row[7 + c] = cand_voicing[c]; }
+  for (int c = 0; c < s->Q.n_cand; ++c) { row[1 + c] = cand_f0[c]; row[7 + c] = cand_voicing[c]; }
   if (hipMemcpy(s->d_frames + 21 * s->n_frames, row, sizeof(row), hipMemcpyHostToDevice) != hipSuccess)
     return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push: upload failed");
   s->n_frames++;

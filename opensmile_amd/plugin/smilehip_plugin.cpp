@@ -1150,6 +1150,8 @@ class cHipSpectral : public cSpectral {
   bool seen_[8] = {false, false, false, false, false, false, false, false};
   int plain_ = -1, gemaps_ = -1;
   smilehip_plan *gm_plan_ = nullptr;
+  int band_lo_[2] = {250, 1000}, band_hi_[2] = {650, 4000};
+  bool sel_[3] = {true, true, true};
   bool array_is(const char *name, int n, const char *const *vals) {
     if (getArraySize(name) != n) return false;
     for (int i = 0; i < n; ++i) {
@@ -1162,12 +1164,19 @@ class cHipSpectral : public cSpectral {
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {
-      static const char *const bands[2] = {"250-650", "1000-4000"};
-      bool ok = array_is("bands", 2, bands) && getArraySize("rollOff") == 4 && getArraySize("slopes") <= 0;
+      bool ok = getArraySize("bands") == 2 && getArraySize("rollOff") == 4 && getArraySize("slopes") <= 0;
+      for (int b = 0; ok && b < 2; ++b) {                  // bands[b] = "lo-hi" in Hz, integers (spectral.cpp:163-190)
+        const char *v = getStr_f(myvprint("bands[%i]", b));
+        int lo = -1, hi = -1, used = 0;
+        ok = v && sscanf(v, "%d-%d%n", &lo, &hi, &used) == 2 && v[used] == 0 && lo >= 0 && hi > lo;
+        band_lo_[b] = lo; band_hi_[b] = hi;
+      }
       static const double ro[4] = {0.25, 0.50, 0.75, 0.90};
       for (int i = 0; ok && i < 4; ++i) ok = getDouble_f(myvprint("rollOff[%i]", i)) == ro[i];
-      static const char *const on[] = {"squareInput", "flux", "centroid", "entropy", "variance", "skewness", "kurtosis", "slope",
-                                       "sharpness", "harmonicity", "oldSlopeScale"};
+      // the optional outputs of the fifteen (their values do not enter the others: the centroid is computed whenever a moment or the
+      // slope is on, spectral.cpp:1262): column 7, 13, 14 of the device row
+      sel_[0] = getInt("centroid") != 0; sel_[1] = getInt("sharpness") != 0; sel_[2] = getInt("harmonicity") != 0;
+      static const char *const on[] = {"squareInput", "flux", "entropy", "variance", "skewness", "kurtosis", "slope", "oldSlopeScale"};
       static const char *const off[] = {"normBandEnergies", "specDiff", "specPosDiff", "fluxCentroid", "fluxAtFluxCentroid", "maxPos",
                                         "minPos", "standardDeviation", "alphaRatio", "hammarbergIndex", "tonality", "flatness",
                                         "logFlatness", "buggyRollOff", "useLogSpectrum"};
@@ -1217,8 +1226,8 @@ class cHipSpectral : public cSpectral {
       g_frames[12]++;
       return (int)Ndst;
     }
-    if (!plain_ || (Nsrc != 129 && Nsrc != 257 && Nsrc != 513) || Ndst != 15 || fc < 0 || fc >= 8) {
-      HIP_FALLTHROUGH(12, "cSpectral: only ComParE_2016's option set and the two GeMAPS sets (log-spectrum slopes + alphaRatio + "
+    if (!plain_ || (Nsrc != 129 && Nsrc != 257 && Nsrc != 513) || Ndst != 12 + (int)sel_[0] + (int)sel_[1] + (int)sel_[2] || fc < 0 || fc >= 8) {
+      HIP_FALLTHROUGH(12, "cSpectral: only ComParE_2016's option set (any two bands; centroid / sharpness / harmonicity optional) and the two GeMAPS sets (log-spectrum slopes + alphaRatio + "
                           "hammarbergIndex; flux over 0-5000 Hz) on a 129- / 257- / 513-bin spectrum are built");
       return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);
     }
@@ -1227,14 +1236,22 @@ class cHipSpectral : public cSpectral {
       const sDmLevelConfig *lc = reader_->getLevelConfig();
       smilehip_lld_config c = base_config((Nsrc - 1) * 2, SMILEHIP_STAGE_SPECTRAL);
       c.force_fft_frame_size_sec = lc->frameSizeSec;    // fsSec, spectral.cpp:382-385
+      for (int b = 0; b < 2; ++b) { c.spectral_band_lo[b] = band_lo_[b]; c.spectral_band_hi[b] = band_hi_[b]; }
       check(smilehip_plan_create(context(), &c, &pl));
     }
-    io_.ensure(Nsrc, Ndst);
+    io_.ensure(Nsrc, 15);
     io_.up(src, Nsrc);
     float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
-    check(smilehip_spectral_frames(pl, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_spectral_frames(pl, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 15, 1, nullptr));
     seen_[fc] = true;
-    io_.down(dst, Ndst);
+    if (Ndst == 15) io_.down(dst, 15);
+    else {
+      float v[15];
+      io_.down(v, 15);
+      long n = 0;
+      for (int k = 0; k < 15; ++k)
+        if ((k != 7 || sel_[0]) && (k != 13 || sel_[1]) && (k != 14 || sel_[2])) dst[n++] = v[k];
+    }
     g_frames[12]++;
     return (int)Ndst;
   }
@@ -1405,7 +1422,7 @@ class cHipFunctionals : public cFunctionals {
     s.period = getInputPeriod();
     if (!(s.period > 0.0)) s.period = 1.0;                // only second-normalised values use it
     s.non_zero_functs = (int)getInt("nonZeroFuncts");
-    s.ext_norm = s.means_norm = s.times_norm = s.seg_norm = s.pk_norm = s.ons_norm = SMILEHIP_NORM_SEGMENT;
+    s.ext_norm = s.means_norm = s.times_norm = s.seg_norm = s.pk_norm = s.ons_norm = s.pko_norm = SMILEHIP_NORM_SEGMENT;
     s.reg_centroid_norm = SMILEHIP_NORM_SEGMENT;
     s.seg_max_num = 20; s.seg_min_lng = 3; s.seg_pause_min_lng = 2; s.lpc_order = 5;
     const int n = getArraySize("functionalsEnabled");
@@ -1551,6 +1568,12 @@ class cHipFunctionals : public cFunctionals {
           s.pk_abs_thresh = (float)opt_dbl(f, "absThresh");
           s.pk_dyn_rel = 0;
         }
+      } else if (!strcmp(f, "Peaks")) {
+        if (!opt_int(f, "overlapFlag")) return false;      // overlapFlag = 0 carries the last two values from call to call
+        s.fam[s.n_fam++] = SMILEHIP_FAM_PEAKS;
+        static const char *const o[5] = {"numPeaks", "meanPeakDist", "peakMean", "peakMeanMeanDist", "peakDistStddev"};
+        s.pko_mask = mask_of(f, o, 5);
+        s.pko_norm = time_norm(f);
       } else if (!strcmp(f, "Onset")) {
         s.fam[s.n_fam++] = SMILEHIP_FAM_ONSET;
         static const char *const o[5] = {"onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"};
@@ -1604,7 +1627,7 @@ class cHipFunctionals : public cFunctionals {
 // SURVEY 8(f) rank 2, per component. An F0-chain plan carries cSpecScale's spline / weighting tables and cPitchShs'
 // shifts for one spectrum geometry (bins, frameSizeSec of the magnitude level).
 static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double min_pitch, double max_pitch, double cutoff,
-                                        int n_harm, double compression, double min_f = 25.0) {
+                                        int n_harm, double compression, double min_f = 25.0, int n_cand = 6, int old_peaks = 0) {
   smilehip_lld_config c;
   smilehip_config_compare16_f0(&c);
   c.force_fft_frame_size_sec = frame_size_sec;
@@ -1615,6 +1638,8 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
   c.shs_n_harmonics = n_harm;
   c.shs_compression = (float)compression;
   c.specscale_min_f = min_f;
+  c.shs_n_candidates = n_cand;
+  c.shs_old_peak_algo = old_peaks;
   smilehip_plan *pl = nullptr;
   check(smilehip_plan_create(context(), &c, &pl));
   smilehip_geometry g;
@@ -1673,14 +1698,16 @@ class cHipPitchShs : public cPitchShs {
   smilehip_plan *pl_ = nullptr;
   int usable_ = -1;
   bool raw_ = true, clip_ = true;
+  int nc_ = 6;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
-      usable_ = getInt("nCandidates") == 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&
+      nc_ = (int)getInt("nCandidates");
+      usable_ = nc_ >= 1 && nc_ <= 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&
                 getInt("voicingC1") == 0 && getInt("octaveCorrection") == 0 &&
-                getInt("greedyPeakAlgo") == 1 && getInt("shsSpectrumOutput") == 0 && getDouble("lfCut") <= 0.0 &&
-                Ndst == 19 + (getInt("F0raw") ? 1 : 0) + (getInt("voicingClip") ? 1 : 0) && reader_->getLevelNf() == 1;
+                getInt("shsSpectrumOutput") == 0 && getDouble("lfCut") <= 0.0 &&
+                Ndst == 1 + 3 * nc_ + (getInt("F0raw") ? 1 : 0) + (getInt("voicingClip") ? 1 : 0) && reader_->getLevelNf() == 1;
       raw_ = getInt("F0raw") != 0;
       clip_ = getInt("voicingClip") != 0;
       cVectorMeta *md = reader_->getLevelMetaDataPtr();     // cSpecScale's minF (pitchShs.cpp:166-176): the octave axis' first point
@@ -1689,20 +1716,22 @@ class cHipPitchShs : public cPitchShs {
       if (usable_) {
         pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, getDouble("minPitch"),
                                 getDouble("maxPitch"), (double)(float)getDouble("voicingCutoff"), getInt("nHarmonics"),
-                                (double)(float)getDouble("compressionFactor"), min_f);
+                                (double)(float)getDouble("compressionFactor"), min_f, nc_, getInt("greedyPeakAlgo") ? 0 : 1);
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only six candidates with scores and voicing (F0raw / voicingClip optional) and greedyPeakAlgo are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only up to six candidates with scores and voicing (F0raw / voicingClip optional), no octaveCorrection / lfCut are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 21);
     io_.up(src, Nsrc);
     check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, 1, nullptr));
-    if (raw_ && clip_) io_.down(dst, 21);
+    if (raw_ && clip_ && nc_ == 6) io_.down(dst, 21);
     else {                                                  // [nCandidates | F0Cand | candVoicing | candScores] (+ F0raw) (+ voicingClip)
-      float v[21];
+      float v[21];                                          // (the device rows keep six slots per field)
       io_.down(v, 21);
-      long n = 19;
-      std::memcpy(dst, v, sizeof(float) * 19);
+      long n = 0;
+      dst[n++] = v[0];
+      for (int f = 0; f < 3; ++f)
+        for (int c = 0; c < nc_; ++c) dst[n++] = v[1 + 6 * f + c];
       if (raw_) dst[n++] = v[19];
       if (clip_) dst[n++] = v[20];
     }
@@ -2280,11 +2309,12 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     cVectorMeta *md = reader_->getLevelMetaDataPtr(0);
     if (md != NULL) thresh_ = md->fData[0];                // the voicing cut-off cPitchShs publishes with its level
     const int buflen = getInt("bufferLength");
-    usable_ = f0I_ >= 0 && cvI_ >= 0 && nCand_ == 6 && more == 0 && buflen >= 2 && buflen <= 40 && reader_->getNLevels() == 1;
+    usable_ = f0I_ >= 0 && cvI_ >= 0 && nCand_ >= 1 && nCand_ <= 6 && more == 0 && buflen >= 2 && buflen <= 40 && reader_->getNLevels() == 1;
     if (!usable_) return;
     // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd as well (pitchSmootherViterbi.hpp:291-299)
     const double w[6] = {getDouble("wLocal"), getDouble("wTvv"), getDouble("wTvv"), getDouble("wTvuv"), getDouble("wThr"), getDouble("wRange")};
     check(smilehip_viterbi_stream_create(context(), buflen, thresh_, w, &vs_));
+    check(smilehip_viterbi_stream_set_candidates(vs_, (int32_t)nCand_));
   }
   static FLOAT_DMEM semitone(FLOAT_DMEM f0) {            // :512-519, in the reference's own float arithmetic
     FLOAT_DMEM sc = 0.0;
@@ -2297,7 +2327,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     g_fused.init();
     if (!ready_) setup();
     if (!usable_) {
-      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with six candidates and bufferLength <= 40 is built");
+      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 40 is built");
       return cPitchSmootherViterbi::myTick(t);
     }
     int32_t n = 0, fr[64], st[64];

@@ -161,7 +161,7 @@ void lldo_shs_init(lldo_shs *h, const lldo_specscale *s)
   if (fabs(h->base - 2.0) < 0.00001) h->base = 2.0;
   h->Fmint = fmint;
   h->Fstept = (fmaxt - fmint) / (float)(h->N - 1);
-  h->n_harmonics = 15; h->compression = (float)0.85; h->n_cand = 6;
+  h->n_harmonics = 15; h->compression = (float)0.85; h->n_cand = 6; h->old_peaks = 0;
   h->min_pitch = 52.0; h->max_pitch = 620.0; h->voicing_cutoff = (float)0.7;
 }
 
@@ -213,7 +213,14 @@ void lldo_pitch_shs(const lldo_shs *h, const float *in, float *dst, float *ss_ou
   double mean = (double)SS[0];
   long i;
   for (i = 1; i < N - 1; i++) {
-    if (SS[i - 1] < SS[i] && SS[i] > SS[i + 1]) {
+    if (h->old_peaks) {                                    /* greedyPeakAlgo = 0 (:286-302): only a new maximum enters, at the front */
+      if ((SS[i - 1] < SS[i]) && (SS[i] > SS[i + 1]) && ((SS[i] > cs[0]) || (cs[0] == 0.0))) {
+        for (int j = NC - 1; j > 0; j--) { cs[j] = cs[j - 1]; f0c[j] = f0c[j - 1]; }
+        f0c[0] = (float)i;
+        cs[0] = SS[i];
+        if (n_found < NC) n_found++;
+      }
+    } else if (SS[i - 1] < SS[i] && SS[i] > SS[i + 1]) {
       for (int j = 0; j < NC; j++) {
         if (cs[j] == 0.0 || cs[j] < SS[i]) {
           for (int jj = NC - 1; jj > j; jj--) { cs[jj] = cs[jj - 1]; f0c[jj] = f0c[jj - 1]; }

@@ -39,6 +39,7 @@ static int fam_count(const lldo_func_spec *s, int fam)
     case LLDO_FAM_LPC: return (s->lpc_gain ? 1 : 0) + (s->lpc_coeffs ? s->lpc_order - s->lpc_first : 0);
     case LLDO_FAM_PEAKS2: return popc(s->pk_mask);
     case LLDO_FAM_ONSET: return popc(s->ons_mask & 0x1fu);
+    case LLDO_FAM_PEAKS: return popc(s->pko_mask & 0x1fu);
   }
   return -1;
 }
@@ -1002,6 +1003,73 @@ static int f_onset(const lldo_func_spec *s, const float *in, float *out, long Ni
   return n;
 }
 
+/* ------------------------------------------------------------------ Peaks (functionalPeaks.cpp:98-214), overlapFlag = 1 */
+static int f_peaks_old(const lldo_func_spec *s, const float *in, float *out, long Nin)
+{
+  float max = *in, min = *in, mean = *in;
+  float peakDist = (float)0.0, peakMean = (float)0.0;
+  long nPeakDist = 0, nPeaks = 0;
+  float lastMin = (float)0.0, lastMax = (float)0.0;
+  long curmaxPos = 0, lastmaxPos = -1;
+  int peakflag = 0;
+  long *peakdists = (long *)calloc((size_t)(Nin + 2), sizeof(long));
+  long i;
+  for (i = 1; i < Nin; i++) {
+    if (in[i] < min) min = in[i];
+    if (in[i] > max) max = in[i];
+    mean += in[i];
+  }
+  mean /= (float)Nin;
+  const float range = max - min;
+  float lastlastVal = in[0], lastVal = Nin > 1 ? in[1] : 0.0f;       /* (the reference reads in[1] whatever Nin is) */
+  for (i = 2; i < Nin; i++) {
+    if ((lastlastVal < lastVal) && (lastVal > in[i])) {
+      if (!peakflag) lastMax = in[i];
+      else { if (in[i] > lastMax) { lastMax = in[i]; curmaxPos = i; } }
+      if (lastMax - lastMin > 0.11 * range) { peakflag = 1; curmaxPos = i; }
+    } else {
+      if ((lastlastVal > lastVal) && (lastVal < in[i])) lastMin = in[i];
+    }
+    if ((peakflag) && ((in[i] < lastMax - 0.09 * range) || (i == Nin - 1))) {
+      nPeaks++;
+      peakMean += lastMax;
+      if (lastmaxPos >= 0) {
+        const float dist = (float)(curmaxPos - lastmaxPos);
+        peakDist += dist;
+        peakdists[nPeakDist] = (long)dist;
+        nPeakDist++;
+      }
+      lastmaxPos = curmaxPos;
+      peakflag = 0;
+    }
+    lastlastVal = lastVal;
+    lastVal = in[i];
+  }
+  float stddev = 0.0;
+  if (nPeakDist > 0.0) {
+    peakDist /= (float)nPeakDist;
+    for (i = 0; i < nPeakDist; i++) stddev += (peakdists[i] - peakDist) * (peakdists[i] - peakDist);
+    stddev /= (float)nPeakDist;
+    stddev = sqrtf(stddev);
+  } else {
+    peakDist = (float)(Nin + 1);
+    stddev = 0.0;
+  }
+  free(peakdists);
+  const uint32_t m = s->pko_mask;
+  int n = 0;
+  if (BIT(m, 0)) out[n++] = (float)nPeaks;
+  if (s->pko_norm == LLDO_NORM_SECOND) { peakDist *= (float)s->period; stddev *= (float)s->period; }
+  else if (s->pko_norm == LLDO_NORM_SEGMENT) { peakDist /= (float)Nin; stddev /= (float)Nin; }
+  if (BIT(m, 1)) out[n++] = peakDist;
+  if (nPeaks > 0.0) peakMean /= (float)nPeaks;
+  else peakMean = (float)0.0;
+  if (BIT(m, 2)) out[n++] = peakMean;
+  if (BIT(m, 3)) out[n++] = peakMean - mean;
+  if (BIT(m, 4)) out[n++] = stddev;
+  return n;
+}
+
 int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int64_t rows, int cols, float *out)
 {
   const int per = lldo_funcspec_count(s);
@@ -1052,6 +1120,7 @@ int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int
         case LLDO_FAM_LPC: got = f_lpc(s, col, o, NN); break;
         case LLDO_FAM_PEAKS2: got = f_peaks2(s, col, min, max, meanf, o, NN); break;
         case LLDO_FAM_ONSET: got = f_onset(s, col, o, NN); break;
+        case LLDO_FAM_PEAKS: got = f_peaks_old(s, col, o, NN); break;
       }
       for (int j = got; j < want; j++) o[j] = 0.0f;
       o += want;

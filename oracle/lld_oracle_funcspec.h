@@ -8,7 +8,7 @@
 
 enum {
   LLDO_FAM_EXTREMES = 0, LLDO_FAM_MEANS, LLDO_FAM_MOMENTS, LLDO_FAM_REGRESSION, LLDO_FAM_PERCENTILES,
-  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_COUNT
+  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_COUNT
 };
 enum { LLDO_NORM_SEGMENT = 0, LLDO_NORM_SECOND = 1, LLDO_NORM_FRAME = 2 };   /* functionalComponent.hpp:27-33 */
 enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1, LLDO_SEG_EQX = 2 };
@@ -47,6 +47,9 @@ typedef struct lldo_func_spec {
   /* Onset (functionalOnset.cpp:21-29): onsetPos offsetPos numOnsets numOffsets onsetRate */
   uint32_t ons_mask; int32_t ons_norm, ons_use_abs, reserved6;
   float ons_thr_on, ons_thr_off;
+  /* Peaks (the older peak picker, functionalPeaks.cpp:20-30; overlapFlag = 1): numPeaks meanPeakDist peakMean peakMeanMeanDist
+   * peakDistStddev */
+  uint32_t pko_mask; int32_t pko_norm;
 } lldo_func_spec;
 
 /* values per input column; < 0 for an unusable spec */

@@ -538,7 +538,7 @@ def htk_variant_chain(name, pcm):
 
 # ---- general functionals engine (lld_oracle_funcspec.c) ---------------------------------------------------------
 FAM = {"Extremes": 0, "Means": 1, "Moments": 2, "Regression": 3, "Percentiles": 4, "Times": 5, "Segments": 6, "Lpc": 7,
-       "Peaks2": 8, "Onset": 9}
+       "Peaks2": 8, "Onset": 9, "Peaks": 10}
 NORM = {"segment": 0, "second": 1, "frame": 2}
 EXT_NAMES = ["max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"]
 MEANS_NAMES = ["amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness", "posamean",
@@ -549,6 +549,7 @@ REG_NAMES = ["linregc1", "linregc2", "linregerrA", "linregerrQ", "qregc1", "qreg
 PCT_NAMES = ["quartile1", "quartile2", "quartile3", "iqr1-2", "iqr2-3", "iqr1-3"]
 TIMES_NAMES = ["upleveltime25", "downleveltime25", "upleveltime50", "downleveltime50", "upleveltime75", "downleveltime75",
                "upleveltime90", "downleveltime90", "risetime", "falltime", "leftctime", "rightctime", "duration"]
+PKO_NAMES = ["numPeaks", "meanPeakDist", "peakMean", "peakMeanMeanDist", "peakDistStddev"]
 ONS_NAMES = ["onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"]
 SEG_NAMES = ["numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"]
 PK_NAMES = ["numPeaks", "meanPeakDist", "meanPeakDistDelta", "peakDistStddev", "peakRangeAbs", "peakRangeRel", "peakMeanAbs",
@@ -586,6 +587,7 @@ class FuncSpec(C.Structure):
         ("pk_rel_thresh", C.c_float), ("pk_abs_thresh", C.c_float),
         ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
         ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
+        ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
     ]
 
 
@@ -708,6 +710,8 @@ def funcspec_names(s):
             out += [n for k, n in enumerate(PK_NAMES) if s.pk_mask >> k & 1]
         elif f == "Onset":
             out += [n for k, n in enumerate(ONS_NAMES) if s.ons_mask >> k & 1]
+        elif f == "Peaks":
+            out += [n for k, n in enumerate(PKO_NAMES) if s.pko_mask >> k & 1]
     return out
 
 

@@ -163,3 +163,29 @@ def test_onset_family(env, oracle):
                 ref = oracle.funcspec(x, so)
                 got = out.cpu().numpy().reshape(7, per)
                 assert bits_equal(got, ref), (rows, norm, use_abs, th_on, th_off)
+
+
+def test_peaks_family(env, oracle):
+    """The older peak picker (functionalPeaks.cpp, IS11_speaker_state's "Peaks") on the GPU = the oracle (pinned on the binary)."""
+    torch, capi, ctx = env
+    L = capi.load()
+    rng = np.random.default_rng(9)
+    for rows in (2, 3, 10, 298, 2000):
+        x = np.cumsum(rng.standard_normal((rows, 9)), axis=0).astype(np.float32)
+        x[:, 1] = np.round(x[:, 1])                         # plateaus and ties
+        x[:, 2] = 0.0
+        x[:, 3] = np.sin(np.arange(rows) * 0.3).astype(np.float32) * (1 + 0.3 * rng.standard_normal(rows).astype(np.float32))
+        dx = torch.from_numpy(x).cuda()
+        for norm in ("segment", "second", "frame"):
+            so = oracle.FuncSpec()
+            oracle._spec_common(so, ["Peaks", "Extremes"])
+            so.pko_mask, so.pko_norm = 0x1f, oracle.NORM[norm]
+            so.ext_mask, so.ext_norm = 0x7, oracle.NORM["frame"]
+            s = capi.FuncSpec()
+            C.memmove(C.byref(s), C.byref(so), C.sizeof(s))
+            per = capi.funcspec_count(s)
+            assert per == 8
+            out = torch.full((9 * per,), 9.0, device="cuda")
+            capi._check(L.smilehip_funcspec_matrix(ctx._h, C.byref(s), dx.data_ptr(), 9, rows, 9, out.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert bits_equal(out.cpu().numpy().reshape(9, per), oracle.funcspec(x, so)), (rows, norm)

@@ -601,3 +601,42 @@ def test_plugin_is10_paraling(oracle):
         assert ref_f.shape == y_f.shape == (1, 1582)
         d = y_f.view(np.uint32) != ref_f.view(np.uint32)
         assert not d.any(), f"functionals: {d.sum()} of {d.size} differ at {np.argwhere(d)[:10, 1]}: {y_f[d][:5]} vs {ref_f[d][:5]}"
+
+
+@pytest.mark.parametrize("conf,n_lld,n_func", [("is09-13/IS11_speaker_state.conf", 118, 4368),
+                                               ("is09-13/IS12_speaker_trait.conf", 120, 5757), ("is09-13/IS12_speaker_trait_compat.conf", 128, 6125)])
+def test_plugin_other_interspeech_sets(oracle, conf, n_lld, n_func):
+    """The other INTERSPEECH challenge sets of config/is09-13, unmodified, with every override active: every component and every
+    functional family they use is an operator of the library (IS11 / IS12: cPitchShs with four candidates and the older peak picker
+    (greedyPeakAlgo = 0), cSpectral without centroid / with the band 25-650, the vector sums of cVectorOperation; IS11: the older Peaks
+    functionals; IS12: Peaks2 / Segments / Lpc and the Viterbi smoother on five states) -- nothing runs the reference's CPU code, and the
+    LLD and functionals files equal the plain binary's bit for bit."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(71, 24000)
+    ref_l, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
+    ref_f, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-htkoutput")
+    y_l, tr = _run(oracle, pcm, None, conf, "-lldhtkoutput")
+    y_f, tr2 = _run(oracle, pcm, None, conf, "-htkoutput")
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert tr.get("cFunctionals", 0) > 0 and tr.get("cPitchShs", 0) > 0, tr
+    assert ref_l.shape == y_l.shape and ref_l.shape[1] == n_lld and ref_f.shape == y_f.shape == (1, n_func), (ref_l.shape, y_l.shape, ref_f.shape, y_f.shape)
+    d = y_l.view(np.uint32) != ref_l.view(np.uint32)
+    assert not d.any(), f"LLD: {d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))[:20]}"
+    d = y_f.view(np.uint32) != ref_f.view(np.uint32)
+    assert not d.any(), f"functionals: {d.sum()} of {d.size} differ at {np.argwhere(d)[:10, 1]}: {y_f[d][:5]} vs {ref_f[d][:5]}"
+
+
+def test_plugin_refuses_what_is_not_built(oracle):
+    """IS10_paraling_compat.conf runs cSpecScale on a log2 axis without smoothing / enhancement / auditory weighting -- an option set
+    that is not an operator of the library: the override says so and the process fails (no silent CPU path); with
+    SMILEHIP_PLUGIN_ALLOW_CPU=1 the instance runs the reference's own code, counted, and the file equals the plain binary's."""
+    import subprocess
+    from opensmile_amd import synth
+    pcm = synth.utterance(71, 16000)
+    conf = "is09-13/IS10_paraling_compat.conf"
+    with pytest.raises(AssertionError, match="cSpecScale: only the octave-scale spline set"):
+        _run(oracle, pcm, None, conf, "-lldhtkoutput")
+    ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
+    y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-lldhtkoutput")
+    assert tr.get("cSpecScale.cpu", 0) > 0 and tr.get("cLsp", 0) > 0, tr
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))

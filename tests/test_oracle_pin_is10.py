@@ -126,3 +126,24 @@ def test_onset_family_options():
                     pos = [f32(on_pos), f32(off_pos)]
                 ref = np.array(pos + [f32(n_on), f32(n_off), f32(n_on) / (f32(N) * T)], np.float32)
                 assert same(got[c], ref), (norm, use_abs, th_on, th_off, c)
+
+
+def test_peaks_family_bit_exact(tmp_path):
+    """The older peak picker ("Peaks": IS11_speaker_state's family) of oracle/lld_oracle_funcspec.c against the binary on energy
+    contours (tests/conf/peaks_family.conf: all five values, the three time norms)."""
+    import os
+    import subprocess
+    from opensmile_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for u, n in ((9, 48000), (3, 16000), (12, 8000), (6, 1200)):
+        wav = str(tmp_path / "p.wav")
+        lldo.write_wav(wav, synth.utterance(u, n), 16000)
+        subprocess.run([os.path.join(lldo.REF_DIR, "SMILExtract"), "-C", os.path.join(root, "tests", "conf", "peaks_family.conf"), "-I", wav,
+                        "-T", str(tmp_path), "-l", "0"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        x = lldo.read_htk(str(tmp_path / "tap_energy.htk"))[0]
+        for tag, mask, norm in (("seg", 0x1f, "segment"), ("sec", 0x1e, "second"), ("fra", 0x13, "frame")):
+            ref = lldo.read_htk(str(tmp_path / ("tap_%s.htk" % tag)))[0]
+            s = lldo.FuncSpec()
+            lldo._spec_common(s, ["Peaks"])
+            s.pko_mask, s.pko_norm = mask, lldo.NORM[norm]
+            assert same(lldo.funcspec(x, s).reshape(1, -1), ref), (u, n, tag)
