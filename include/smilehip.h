@@ -334,13 +334,17 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *   Onset       (functionalOnset.cpp:83-151)       onsetPos offsetPos numOnsets numOffsets onsetRate
  *   Peaks       (functionalPeaks.cpp:98-214, the older peak picker; overlapFlag = 1) numPeaks meanPeakDist peakMean
  *                                                  peakMeanMeanDist peakDistStddev
+ *   Crossings   (functionalCrossings.cpp:66-97)    zcr mcr amean
+ *   DCT         (functionalDCT.cpp:84-137)         dct[first .. last]: the table entry (float)cos(pi i / N (m + 0.5)) is formed on the device
+ *   Samples     (functionalSamples.cpp:100-117)    the contour at n_samples (<= 8) relative positions
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
  * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange, the other
  * segmentation algorithms, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
-  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_COUNT
+  SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_CROSSINGS, SMILEHIP_FAM_DCT,
+  SMILEHIP_FAM_SAMPLES, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
 enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2 };
@@ -368,6 +372,8 @@ typedef struct smilehip_func_spec {
   uint32_t ons_mask; int32_t ons_norm, ons_use_abs, reserved6;   /* Onset: thresholdOnset / thresholdOffset (= threshold unless set) */
   float ons_thr_on, ons_thr_off;
   uint32_t pko_mask; int32_t pko_norm;                             /* Peaks */
+  uint32_t crs_mask; int32_t dct_first, dct_last, n_samples;       /* Crossings; DCT firstCoeff .. lastCoeff; Samples */
+  double sample_pos[8];                                            /* Samples.samplepos[], clipped to [0, 1] */
 } smilehip_func_spec;
 
 /* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */

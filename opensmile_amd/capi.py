@@ -75,6 +75,8 @@ class FuncSpec(C.Structure):
         ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
         ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
         ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
+        ("crs_mask", C.c_uint32), ("dct_first", C.c_int32), ("dct_last", C.c_int32), ("n_samples", C.c_int32),
+        ("sample_pos", C.c_double * 8),
     ]
 
 

@@ -623,6 +623,62 @@ __device__ int f_peaks_old(const smilehip_func_spec &s, const Col &in, float min
   return n;
 }
 
+// Crossings (functionalCrossings.cpp:66-97): zero- and mean-crossing rate of the contour; the mean is a double chain in index order,
+// the mean-crossing products are double (float - double)
+__device__ int f_crossings(const smilehip_func_spec &s, const Col &in, float *out) {
+  const int64_t Nin = in.N;
+  const uint32_t m = s.crs_mask;
+  double amean = 0.0;
+  if (FS_BIT(m, 1) || FS_BIT(m, 2)) {
+    amean = (double)in[0];
+    for_rows(in, 1, Nin, [&](int64_t, float v) { amean += (double)v; });
+    amean /= (double)Nin;
+  }
+  int64_t zcr = 0, mcr = 0;
+  const bool want_m = FS_BIT(m, 1) != 0;
+  float pm = in[0], p0 = Nin > 1 ? in[1] : 0.0f;
+  for_rows(in, 2, Nin, [&](int64_t, float pn) {            // sample i = p0 with its neighbours pm, pn (i = 1 .. Nin - 2)
+    if (((pm * pn <= 0.0f) && (p0 == 0.0f)) || (pm * p0 < 0.0f)) zcr++;
+    if (want_m) {
+      const double a = (double)pm - amean, b = (double)p0 - amean, c = (double)pn - amean;
+      if (((a * c <= 0.0) && (b == 0.0)) || (a * b < 0.0)) mcr++;
+    }
+    pm = p0; p0 = pn;
+  });
+  int n = 0;
+  if (FS_BIT(m, 0)) out[n++] = (float)((double)zcr / (double)Nin);
+  if (FS_BIT(m, 1)) out[n++] = (float)((double)mcr / (double)Nin);
+  if (FS_BIT(m, 2)) out[n++] = (float)amean;
+  return n;
+}
+
+// DCT (functionalDCT.cpp:84-137): out[i] = factor * sum over m of in[m] * (FLOAT_DMEM)cos(pi i / N * (m + 0.5)) as ONE float chain per
+// coefficient; the reference keeps the cosines in a table per contour length, here they are formed where they are used (double cos,
+// rounded to float -- the table's values)
+__device__ int f_dct(const smilehip_func_spec &s, const Col &in, float *out) {
+  const int64_t Nin = in.N;
+  const int nCo = s.dct_last - s.dct_first + 1;
+  const float factor = (float)sqrt(2.0 / (double)Nin);
+  for (int i = 0; i < nCo; ++i) {
+    const double w = M_PI * (double)(i + s.dct_first) / (double)Nin;
+    float acc = 0.0f;
+    for_rows(in, 0, Nin, [&](int64_t m, float v) { acc += v * (float)cos(w * ((double)(float)m + 0.5)); });
+    acc *= factor;
+    out[i] = isfinite(acc) ? acc : 0.0f;
+  }
+  return nCo;
+}
+
+// Samples (functionalSamples.cpp:100-117): the contour at relative positions
+__device__ int f_samples(const smilehip_func_spec &s, const Col &in, float *out) {
+  const float Nind = (float)in.N;
+  for (int k = 0; k < s.n_samples; ++k) {
+    const int si = (int)(((double)Nind - 1.0) * s.sample_pos[k]);
+    out[k] = in[si];
+  }
+  return s.n_samples;
+}
+
 // Segments: the segmentation runs twice -- first to get count / sum / extremes of the segment lengths, then again to
 // accumulate the squared deviations from the mean in the same order (instead of keeping the reference's segLens[])
 struct SegAcc {
@@ -1155,6 +1211,9 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_family(FsParams P, int out_o
   if (FAM == SMILEHIP_FAM_LPC) got = f_lpc(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_ONSET) got = f_onset(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_PEAKS) got = f_peaks_old(P.spec, x, mn, mx, o);
+  if (FAM == SMILEHIP_FAM_CROSSINGS) got = f_crossings(P.spec, x, o);
+  if (FAM == SMILEHIP_FAM_DCT) got = f_dct(P.spec, x, o);
+  if (FAM == SMILEHIP_FAM_SAMPLES) got = f_samples(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_PEAKS2)
     got = f_peaks2(P.spec, x, mn, mx, mean, P.alive + w.srow0 * P.n_cols + w.c, P.n_cols, o);
   for (int j = got; j < want; ++j) o[j] = 0.0f;
@@ -1373,6 +1432,9 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
       case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_ONSET: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_ONSET>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PEAKS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_CROSSINGS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_CROSSINGS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_DCT: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_DCT>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_SAMPLES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SAMPLES>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_PERCENTILES:
         hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
         if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts

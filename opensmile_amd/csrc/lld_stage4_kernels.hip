@@ -119,6 +119,48 @@ __global__ void __launch_bounds__(256) k_specresample_g(const float *src, int64_
   }
 }
 
+// The same for FOUR frames per block: a table value is loaded once and used for four accumulations (one per frame, each its own
+// chain in the reference's order); the four spectra sit interleaved in LDS so that one ds_read_b128 broadcasts bin k of all four.
+// Batches; the single-frame form above serves one frame at a time (the plugin) and spectra too long for the LDS budget.
+__global__ void __launch_bounds__(256) k_specresample_g4(const float *src, int64_t lds, int K, int I, int kMax, const float *cost,
+                                                         const float *sint, float *dst, int64_t ldd, int64_t nF) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_in4v[];
+  const int64_t f0 = (int64_t)blockIdx.x * 4;
+  const int nf = (int)((nF - f0) < 4 ? (nF - f0) : 4);
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    v.x = src[f0 * lds + k];
+    if (nf > 1) v.y = src[(f0 + 1) * lds + k];
+    if (nf > 2) v.z = src[(f0 + 2) * lds + k];
+    if (nf > 3) v.w = src[(f0 + 3) * lds + k];
+    s_in4v[k] = v;
+  }
+  __syncthreads();
+  const int h = kMax / 2;
+  const float div = (float)(K / 2);
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    const float *c = cost + (int64_t)i * h - 1, *s = sint + (int64_t)i * h - 1;
+    float4 acc = s_in4v[0];
+    if (I >= K) {
+      const float4 b = s_in4v[1];
+      const float cn = c[K / 2];
+      acc.x += b.x * cn; acc.y += b.y * cn; acc.z += b.z * cn; acc.w += b.w * cn;
+    }
+    for (int k = 2; k < kMax; k += 2) {
+      const float cv = c[k >> 1], sv = s[k >> 1];
+      const float4 a = s_in4v[k], b = s_in4v[k + 1];
+      acc.x += a.x * cv; acc.x += b.x * sv;
+      acc.y += a.y * cv; acc.y += b.y * sv;
+      acc.z += a.z * cv; acc.z += b.z * sv;
+      acc.w += a.w * cv; acc.w += b.w * sv;
+    }
+    dst[f0 * ldd + i] = acc.x / div;
+    if (nf > 1) dst[(f0 + 1) * ldd + i] = acc.y / div;
+    if (nf > 2) dst[(f0 + 2) * ldd + i] = acc.z / div;
+    if (nf > 3) dst[(f0 + 3) * ldd + i] = acc.w / div;
+  }
+}
+
 // cLpc::processVector with method = acf, saveLPCoeff only (lpc.cpp:171-213): smileDsp_autoCorr (smileUtil.c:1560-1570: r[lag] = sum
 // over i = lag .. n-1 of x[i] x[i-lag], a float accumulation in sample order) on lanes 0 .. p, then Durbin's recursion
 // (smileDsp_calcLpcAcf, :1572-1630) on lane 0. One wave per frame, p <= 32.
@@ -206,6 +248,10 @@ hipError_t stage_specresample_g(const float *src, int64_t lds, int K, int I, int
   if (nF <= 0) return hipSuccess;
   const size_t bytes = sizeof(float) * (size_t)((K + 3) & ~3);
   if (bytes > 60 * 1024) return hipErrorInvalidValue;
+  if (nF >= 4 && bytes * 4 <= 48 * 1024) {
+    hipLaunchKernelGGL(k_specresample_g4, dim3((unsigned)((nF + 3) / 4)), dim3(256), bytes * 4, s, src, lds, K, I, kMax, cost, sint, dst, ldd, nF);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_specresample_g, dim3((unsigned)nF), dim3(256), bytes, s, src, lds, K, I, kMax, cost, sint, dst, ldd);
   return hipGetLastError();
 }

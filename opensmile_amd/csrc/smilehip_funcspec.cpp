@@ -61,6 +61,18 @@ int family_count(const smilehip_func_spec &s, int fam) {
     case SMILEHIP_FAM_PEAKS:
       if (s.pko_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Peaks: unknown bits in mask 0x%x", s.pko_mask);
       return popc(s.pko_mask);
+    case SMILEHIP_FAM_CROSSINGS:
+      if (s.crs_mask & ~0x7u) return fail(SMILEHIP_ERR_INVALID, "Crossings: unknown bits in mask 0x%x", s.crs_mask);
+      return popc(s.crs_mask);
+    case SMILEHIP_FAM_DCT:
+      if (s.dct_first < 0 || s.dct_last < s.dct_first || s.dct_last - s.dct_first >= 64)
+        return fail(SMILEHIP_ERR_INVALID, "DCT: coefficients %d .. %d (0 <= first <= last, at most 64)", s.dct_first, s.dct_last);
+      return s.dct_last - s.dct_first + 1;
+    case SMILEHIP_FAM_SAMPLES:
+      if (s.n_samples < 1 || s.n_samples > 8) return fail(SMILEHIP_ERR_INVALID, "Samples: 1 .. 8 positions");
+      for (int i = 0; i < s.n_samples; ++i)
+        if (!(s.sample_pos[i] >= 0.0 && s.sample_pos[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Samples: samplepos[%d] = %g not in [0, 1]", i, s.sample_pos[i]);
+      return s.n_samples;
   }
   return fail(SMILEHIP_ERR_INVALID, "unknown functional family %d", fam);
 }

@@ -1574,6 +1574,31 @@ class cHipFunctionals : public cFunctionals {
         static const char *const o[5] = {"numPeaks", "meanPeakDist", "peakMean", "peakMeanMeanDist", "peakDistStddev"};
         s.pko_mask = mask_of(f, o, 5);
         s.pko_norm = time_norm(f);
+      } else if (!strcmp(f, "Crossings")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_CROSSINGS;
+        static const char *const o[3] = {"zcr", "mcr", "amean"};
+        s.crs_mask = mask_of(f, o, 3);
+      } else if (!strcmp(f, "DCT")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_DCT;
+        s.dct_first = opt_int(f, "firstCoeff");
+        if (s.dct_first < 0) s.dct_first = 0;
+        s.dct_last = opt_set(f, "nCoeffs") ? s.dct_first + opt_int(f, "nCoeffs") - 1 : opt_int(f, "lastCoeff");
+        if (s.dct_last < s.dct_first || s.dct_last - s.dct_first >= 64) return false;
+      } else if (!strcmp(f, "Samples")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_SAMPLES;
+        char *k = myvprint("%s.samplepos", f);
+        const int ns = getArraySize(k); free(k);
+        if (ns > 8) return false;
+        if (ns > 0) {
+          s.n_samples = ns;
+          for (int j = 0; j < ns; ++j) {
+            double v = getDouble_f(myvprint("%s.samplepos[%i]", f, j));
+            s.sample_pos[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+          }
+        } else {                                          // DEFAULT_NR_SAMPLES = 5 (functionalSamples.cpp:27, 78-84)
+          s.n_samples = 5;
+          for (int j = 0; j < 5; ++j) s.sample_pos[j] = (double)j / (5 - 1.0);
+        }
       } else if (!strcmp(f, "Onset")) {
         s.fam[s.n_fam++] = SMILEHIP_FAM_ONSET;
         static const char *const o[5] = {"onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"};
@@ -1584,7 +1609,7 @@ class cHipFunctionals : public cFunctionals {
         if (opt_set(f, "thresholdOnset")) s.ons_thr_on = (float)opt_dbl(f, "thresholdOnset");
         if (opt_set(f, "thresholdOffset")) s.ons_thr_off = (float)opt_dbl(f, "thresholdOffset");
       } else {
-        return false;                                     // a family that is not built (Crossings, DCT, Samples, ...)
+        return false;                                     // a family that is not built (ModulationSpec, ...)
       }
     }
     return smilehip_funcspec_count(&s) == nFunctValues;

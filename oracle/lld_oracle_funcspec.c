@@ -40,6 +40,9 @@ static int fam_count(const lldo_func_spec *s, int fam)
     case LLDO_FAM_PEAKS2: return popc(s->pk_mask);
     case LLDO_FAM_ONSET: return popc(s->ons_mask & 0x1fu);
     case LLDO_FAM_PEAKS: return popc(s->pko_mask & 0x1fu);
+    case LLDO_FAM_CROSSINGS: return popc(s->crs_mask & 0x7u);
+    case LLDO_FAM_DCT: return s->dct_last >= s->dct_first && s->dct_first >= 0 ? s->dct_last - s->dct_first + 1 : -1;
+    case LLDO_FAM_SAMPLES: return s->n_samples >= 1 && s->n_samples <= 8 ? s->n_samples : -1;
   }
   return -1;
 }
@@ -1070,6 +1073,56 @@ static int f_peaks_old(const lldo_func_spec *s, const float *in, float *out, lon
   return n;
 }
 
+/* ------------------------------------------------------------------ Crossings (functionalCrossings.cpp:66-97) */
+static int f_crossings(const lldo_func_spec *s, const float *in, float *out, long Nin)
+{
+  double amean = 0.0;
+  long zcr = 0, mcr = 0, i;
+  const uint32_t m = s->crs_mask;
+  if (BIT(m, 1) || BIT(m, 2)) {
+    amean = (double)*in;
+    for (i = 1; i < Nin; i++) amean += in[i];
+    amean /= (double)Nin;
+  }
+  for (i = 1; i < Nin - 1; i++) {
+    in++;
+    if (((*(in - 1) * *(in + 1) <= 0.0) && (*(in) == 0.0)) || (*(in - 1) * *(in) < 0.0)) zcr++;
+    if (BIT(m, 1))
+      if ((((*(in - 1) - amean) * (*(in + 1) - amean) <= 0.0) && ((*(in) - amean) == 0.0)) || ((*(in - 1) - amean) * (*(in) - amean) < 0.0)) mcr++;
+  }
+  int n = 0;
+  if (BIT(m, 0)) out[n++] = (float)((double)zcr / (double)Nin);
+  if (BIT(m, 1)) out[n++] = (float)((double)mcr / (double)Nin);
+  if (BIT(m, 2)) out[n++] = (float)amean;
+  return n;
+}
+
+/* ------------------------------------------------------------------ DCT (functionalDCT.cpp:84-137): table entry and sum in FLOAT_DMEM */
+static int f_dct(const lldo_func_spec *s, const float *in, float *out, long Nin)
+{
+  const int nCo = s->dct_last - s->dct_first + 1;
+  const float factor = (float)sqrt((double)2.0 / (double)(Nin));
+  for (int i = 0; i < nCo; i++) {
+    out[i] = 0.0;
+    for (long m = 0; m < Nin; m++)
+      out[i] += in[m] * (float)cos(M_PI * (double)(i + s->dct_first) / (double)(Nin) * ((float)(m) + 0.5));
+    out[i] *= factor;
+    if (!isfinite(out[i])) out[i] = 0.0;
+  }
+  return nCo;
+}
+
+/* ------------------------------------------------------------------ Samples (functionalSamples.cpp:100-117) */
+static int f_samples(const lldo_func_spec *s, const float *in, float *out, long Nin)
+{
+  const float Nind = (float)Nin;
+  for (int k = 0; k < s->n_samples; k++) {
+    const int si = (int)((Nind - 1.0) * s->sample_pos[k]);
+    out[k] = in[si];
+  }
+  return s->n_samples;
+}
+
 int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int64_t rows, int cols, float *out)
 {
   const int per = lldo_funcspec_count(s);
@@ -1121,6 +1174,9 @@ int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int
         case LLDO_FAM_PEAKS2: got = f_peaks2(s, col, min, max, meanf, o, NN); break;
         case LLDO_FAM_ONSET: got = f_onset(s, col, o, NN); break;
         case LLDO_FAM_PEAKS: got = f_peaks_old(s, col, o, NN); break;
+        case LLDO_FAM_CROSSINGS: got = f_crossings(s, col, o, NN); break;
+        case LLDO_FAM_DCT: got = f_dct(s, col, o, NN); break;
+        case LLDO_FAM_SAMPLES: got = f_samples(s, col, o, NN); break;
       }
       for (int j = got; j < want; j++) o[j] = 0.0f;
       o += want;

@@ -8,7 +8,7 @@
 
 enum {
   LLDO_FAM_EXTREMES = 0, LLDO_FAM_MEANS, LLDO_FAM_MOMENTS, LLDO_FAM_REGRESSION, LLDO_FAM_PERCENTILES,
-  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_COUNT
+  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_CROSSINGS, LLDO_FAM_DCT, LLDO_FAM_SAMPLES, LLDO_FAM_COUNT
 };
 enum { LLDO_NORM_SEGMENT = 0, LLDO_NORM_SECOND = 1, LLDO_NORM_FRAME = 2 };   /* functionalComponent.hpp:27-33 */
 enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1, LLDO_SEG_EQX = 2 };
@@ -50,6 +50,10 @@ typedef struct lldo_func_spec {
   /* Peaks (the older peak picker, functionalPeaks.cpp:20-30; overlapFlag = 1): numPeaks meanPeakDist peakMean peakMeanMeanDist
    * peakDistStddev */
   uint32_t pko_mask; int32_t pko_norm;
+  /* Crossings (functionalCrossings.cpp:21-28): zcr mcr amean; DCT (functionalDCT.cpp): coefficients first .. last; Samples
+   * (functionalSamples.cpp): the contour's values at n_samples relative positions in [0, 1] */
+  uint32_t crs_mask; int32_t dct_first, dct_last, n_samples;
+  double sample_pos[8];
 } lldo_func_spec;
 
 /* values per input column; < 0 for an unusable spec */

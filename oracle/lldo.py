@@ -538,7 +538,7 @@ def htk_variant_chain(name, pcm):
 
 # ---- general functionals engine (lld_oracle_funcspec.c) ---------------------------------------------------------
 FAM = {"Extremes": 0, "Means": 1, "Moments": 2, "Regression": 3, "Percentiles": 4, "Times": 5, "Segments": 6, "Lpc": 7,
-       "Peaks2": 8, "Onset": 9, "Peaks": 10}
+       "Peaks2": 8, "Onset": 9, "Peaks": 10, "Crossings": 11, "DCT": 12, "Samples": 13}
 NORM = {"segment": 0, "second": 1, "frame": 2}
 EXT_NAMES = ["max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"]
 MEANS_NAMES = ["amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness", "posamean",
@@ -588,6 +588,8 @@ class FuncSpec(C.Structure):
         ("ons_mask", C.c_uint32), ("ons_norm", C.c_int32), ("ons_use_abs", C.c_int32), ("reserved6", C.c_int32),
         ("ons_thr_on", C.c_float), ("ons_thr_off", C.c_float),
         ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
+        ("crs_mask", C.c_uint32), ("dct_first", C.c_int32), ("dct_last", C.c_int32), ("n_samples", C.c_int32),
+        ("sample_pos", C.c_double * 8),
     ]
 
 
@@ -712,6 +714,12 @@ def funcspec_names(s):
             out += [n for k, n in enumerate(ONS_NAMES) if s.ons_mask >> k & 1]
         elif f == "Peaks":
             out += [n for k, n in enumerate(PKO_NAMES) if s.pko_mask >> k & 1]
+        elif f == "Crossings":
+            out += [n for k, n in enumerate(["zcr", "mcr", "amean"]) if s.crs_mask >> k & 1]
+        elif f == "DCT":
+            out += ["dct%d" % k for k in range(s.dct_first, s.dct_last + 1)]
+        elif f == "Samples":
+            out += ["sample%.3f" % s.sample_pos[k] for k in range(s.n_samples)]
     return out
 
 

@@ -115,7 +115,7 @@ def test_specresample_and_lpc_any_geometry(env, oracle, n_in, n_frame, rate, tar
     torch, capi, ctx = env
     L = capi.load()
     rng = np.random.default_rng(n_in + n_frame)
-    spec = (rng.standard_normal((60, n_in)) * 0.5).astype(np.float32)
+    spec = (rng.standard_normal((61, n_in)) * 0.5).astype(np.float32)       # 15 blocks of four frames + one
     spec[0] = 0.0
     fs_sec, last, bp = n_in / rate, n_frame / rate, 1.0 / rate
     n_out, k_max, nd = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
@@ -189,3 +189,33 @@ def test_peaks_family(env, oracle):
             capi._check(L.smilehip_funcspec_matrix(ctx._h, C.byref(s), dx.data_ptr(), 9, rows, 9, out.data_ptr(), None))
             torch.cuda.synchronize()
             assert bits_equal(out.cpu().numpy().reshape(9, per), oracle.funcspec(x, so)), (rows, norm)
+
+
+def test_crossings_dct_samples_families(env, oracle):
+    """The families Crossings, DCT (its cosines formed on the device) and Samples on the GPU = the oracle (pinned on the binary)."""
+    torch, capi, ctx = env
+    L = capi.load()
+    rng = np.random.default_rng(13)
+    for rows in (1, 2, 3, 57, 298, 1000):
+        x = (rng.standard_normal((rows, 6)) * 2).astype(np.float32)
+        x[:, 1] = np.round(x[:, 1])
+        x[:, 2] = 0.0
+        x[:, 3] += 5.0
+        dx = torch.from_numpy(x).cuda()
+        so = oracle.FuncSpec()
+        oracle._spec_common(so, ["Crossings", "DCT", "Samples"])
+        so.crs_mask, so.dct_first, so.dct_last, so.n_samples = 7, 0, 6, 5
+        for i, p in enumerate([0.0, 0.33, 0.5, 0.999, 1.0]):
+            so.sample_pos[i] = p
+        s = capi.FuncSpec()
+        C.memmove(C.byref(s), C.byref(so), C.sizeof(s))
+        per = capi.funcspec_count(s)
+        assert per == 3 + 7 + 5
+        out = torch.full((6 * per,), 9.0, device="cuda")
+        capi._check(L.smilehip_funcspec_matrix(ctx._h, C.byref(s), dx.data_ptr(), 6, rows, 6, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        got, ref = out.cpu().numpy().reshape(6, per), oracle.funcspec(x, so)
+        assert bits_equal(got[:, :3], ref[:, :3]) and bits_equal(got[:, 10:], ref[:, 10:]), rows
+        # DCT: the device's double cosine and libm's agree after the rounding to float but for ~1e-9 of the table entries
+        d = got[:, 3:10].view(np.uint32) != ref[:, 3:10].view(np.uint32)
+        assert d.sum() <= 1 and np.allclose(got[:, 3:10], ref[:, 3:10], rtol=1e-5, atol=1e-6), (rows, d.sum())

@@ -147,3 +147,34 @@ def test_peaks_family_bit_exact(tmp_path):
             lldo._spec_common(s, ["Peaks"])
             s.pko_mask, s.pko_norm = mask, lldo.NORM[norm]
             assert same(lldo.funcspec(x, s).reshape(1, -1), ref), (u, n, tag)
+
+
+def test_crossings_dct_samples_families_bit_exact(tmp_path):
+    """The families Crossings, DCT and Samples of oracle/lld_oracle_funcspec.c against the binary (tests/conf/families_misc.conf)."""
+    import os
+    import subprocess
+    from opensmile_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def spec(fam, **kw):
+        s = lldo.FuncSpec()
+        lldo._spec_common(s, [fam])
+        for k, v in kw.items():
+            if k == "sample_pos":
+                for i, p in enumerate(v):
+                    s.sample_pos[i] = p
+            else:
+                setattr(s, k, v)
+        return s
+    cases = {"f_crs": spec("Crossings", crs_mask=7), "f_crs2": spec("Crossings", crs_mask=2), "f_dct": spec("DCT", dct_first=1, dct_last=6),
+             "f_dct2": spec("DCT", dct_first=0, dct_last=3), "f_smp": spec("Samples", n_samples=5, sample_pos=[0, .25, .5, .75, 1.0]),
+             "f_smp2": spec("Samples", n_samples=5, sample_pos=[0.0, 0.33, 0.5, 0.999, 1.0])}
+    for u, n in ((9, 48000), (3, 16000), (6, 1200)):
+        wav = str(tmp_path / "p.wav")
+        lldo.write_wav(wav, synth.utterance(u, n), 16000)
+        subprocess.run([os.path.join(lldo.REF_DIR, "SMILExtract"), "-C", os.path.join(root, "tests", "conf", "families_misc.conf"), "-I", wav,
+                        "-T", str(tmp_path), "-l", "0"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        x = lldo.read_htk(str(tmp_path / "tap_energy.htk"))[0]
+        for k, s in cases.items():
+            ref = lldo.read_htk(str(tmp_path / ("tap_%s.htk" % k)))[0]
+            assert same(lldo.funcspec(x, s).reshape(1, -1), ref), (u, n, k)

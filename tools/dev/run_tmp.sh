@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/is10
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/is10/pytest_all3.log 2>&1
-grep -n "^FAILED\|passed\|failed" gpurun_out/is10/pytest_all3.log | cut -c1-300 | head -30
-grep -n "^E  .*ERR\|^E  .*Assert\|^E  .*differ" gpurun_out/is10/pytest_all3.log | cut -c1-700 | head -30
-timeout 300 python tools/bench_sets.py --sets f0,compare_full --utts 1000 --steps 10 2>/dev/null | grep set | cut -c1-200
+timeout 600 python -m pytest tests/test_gpu_is10.py tests/test_gpu_funcspec.py tests/test_gpu_plugin.py -q -k "is10 or families or funcspec or other_interspeech or refuses or viterbi" > gpurun_out/is10/pytest_fam.log 2>&1
+grep -n "^FAILED\|passed\|failed" gpurun_out/is10/pytest_fam.log | cut -c1-300 | head
+grep -n "^E  " gpurun_out/is10/pytest_fam.log | cut -c1-400 | head -20
+timeout 300 python tools/bench_stage4.py > gpurun_out/is10/stage4.jsonl 2> gpurun_out/is10/stage4.err; cat gpurun_out/is10/stage4.jsonl; tail -3 gpurun_out/is10/stage4.err
