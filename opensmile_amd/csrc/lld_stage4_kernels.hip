@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_specresample_g(const float *src, int64_
 // The same for FOUR frames per block: a table value is loaded once and used for four accumulations (one per frame, each its own
 // chain in the reference's order); the four spectra sit interleaved in LDS so that one ds_read_b128 broadcasts bin k of all four.
 // Batches; the single-frame form above serves one frame at a time (the plugin) and spectra too long for the LDS budget.
-__global__ void __launch_bounds__(256) k_specresample_g4(const float *src, int64_t lds, int K, int I, int kMax, const float *cost,
+__global__ void __launch_bounds__(1024) k_specresample_g4(const float *src, int64_t lds, int K, int I, int kMax, const float *cost,
                                                          const float *sint, float *dst, int64_t ldd, int64_t nF) {
   extern __shared__ __attribute__((aligned(16))) float4 s_in4v[];
   const int64_t f0 = (int64_t)blockIdx.x * 4;
@@ -249,7 +249,8 @@ hipError_t stage_specresample_g(const float *src, int64_t lds, int K, int I, int
   const size_t bytes = sizeof(float) * (size_t)((K + 3) & ~3);
   if (bytes > 60 * 1024) return hipErrorInvalidValue;
   if (nF >= 4 && bytes * 4 <= 48 * 1024) {
-    hipLaunchKernelGGL(k_specresample_g4, dim3((unsigned)((nF + 3) / 4)), dim3(256), bytes * 4, s, src, lds, K, I, kMax, cost, sint, dst, ldd, nF);
+    const int threads = I >= 1024 ? 1024 : ((I + 63) & ~63);        // one pass over the output samples where a block can hold them (275 -> 320 threads)
+    hipLaunchKernelGGL(k_specresample_g4, dim3((unsigned)((nF + 3) / 4)), dim3(threads), bytes * 4, s, src, lds, K, I, kMax, cost, sint, dst, ldd, nF);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_specresample_g, dim3((unsigned)nF), dim3(256), bytes, s, src, lds, K, I, kMax, cost, sint, dst, ldd);

@@ -640,3 +640,18 @@ def test_plugin_refuses_what_is_not_built(oracle):
     y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-lldhtkoutput")
     assert tr.get("cSpecScale.cpu", 0) > 0 and tr.get("cLsp", 0) > 0, tr
     assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("fs", [8000, 44100])
+def test_plugin_is10_paraling_other_rates(oracle, fs):
+    """IS10_paraling at 8 kHz and 44.1 kHz: the any-geometry operators (cSpecResample from 256 / 2048 spectrum values, cLpc on the
+    resampled frame, cSpecScale / cPitchShs on 512- / 4096-point transforms, the jitter pass at that rate): bit for bit, nothing on the CPU."""
+    from opensmile_amd import synth
+    conf = "is09-13/IS10_paraling.conf"
+    pcm = synth.utterance(33, int(0.8 * fs), fs)
+    ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput", fs)
+    y, tr = _run(oracle, pcm, None, conf, "-lldhtkoutput", fs)
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert y.shape == ref.shape and ref.shape[1] == 76
+    d = y.view(np.uint32) != ref.view(np.uint32)
+    assert not d.any(), f"{d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))[:20]}"
