@@ -1274,7 +1274,7 @@ class cHipPlp : public cPlp {
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0;
+  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0, firstCC_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
  protected:
@@ -1297,8 +1297,9 @@ class cHipPlp : public cPlp {
       // PLP cepstra in HTK mode (config/plp/*.conf): doAud -> IDFT -> LP -> cepstra, c0 last
       lpOrder_ = getInt("lpOrder");
       const int lastCC = getInt("lastCC"), nCeps = getInt("nCeps");
-      cc_ = (getInt("htkcompatible") && doIDFT && doLP && doLpToCeps && !rasta && !newRasta_ && getInt("firstCC") == 0 &&
-             lpOrder_ >= 1 && lpOrder_ <= 15 && (lastCC < 0 || lastCC == lpOrder_) && (nCeps < 0 || nCeps == lpOrder_ + 1)) ? 1 : 0;
+      firstCC_ = (int)getInt("firstCC");                   // 1 (config/plp/PLP_E_*): c1 .. c12 -- the same values without the trailing c0
+      cc_ = (getInt("htkcompatible") && doIDFT && doLP && doLpToCeps && !rasta && !newRasta_ && (firstCC_ == 0 || firstCC_ == 1) &&
+             lpOrder_ >= 1 && lpOrder_ <= 15 && (lastCC < 0 || lastCC == lpOrder_) && (nCeps < 0 || nCeps == lpOrder_ + 1 - firstCC_)) ? 1 : 0;
       if (cc_) { plain_ = 1; melfloor_ = 1.0; }           // htkcompatible forces melfloor = 1, doAud = 1, no logs (plp.cpp:150-160)
       if (newRasta_ || oldRasta_) {                      // initTables, plp.cpp:361-399 (the same coefficients for both forms)
         const FLOAT_DMEM lo = (FLOAT_DMEM)getDouble("rastaLowerCutoff"), up = (FLOAT_DMEM)getDouble("rastaUpperCutoff");
@@ -1314,7 +1315,7 @@ class cHipPlp : public cPlp {
     }
     const int fc = getFconf(idxi);
     const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
-    if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
+    if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 - firstCC_ : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
         (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
       { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (plain, RASTA, newRASTA) and the HTK PLP-CC mode are built (no partial IDFT / LP modes)"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
     if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
@@ -1352,11 +1353,11 @@ class cHipPlp : public cPlp {
         COMP_ERR("libsmilehip: %s", smilehip_last_error());
       ready_[fc] = true;
     }
-    io_.ensure(Nsrc, Ndst);
+    io_.ensure(Nsrc, cc_ ? lpOrder_ + 1 : Ndst);
     io_.up(src, Nsrc);
     if (cc_)
       check(smilehip_plp_cc_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_, lpOrder_,
-                                   (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, Ndst, 1, nullptr));
+                                   (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, lpOrder_ + 1, 1, nullptr));
     else
       check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
                                         newRasta_ ? 1 : (oldRasta_ ? 2 : 0), coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
@@ -1779,15 +1780,17 @@ class cHipPitchShs : public cPitchShs {
 // Round 3: one plan per sample rate (8 .. 48 kHz). The rate is what the components that see it report (cSpecResample: the level's
 // basePeriod; cSpectral with the GeMAPS options: bins and frameSizeSec of its spectrum); cLpc / cFormantLpc / cHarmonics, which run after
 // them in every tick, use the plan of the rate seen last.
-std::map<long, smilehip_plan *> g_gm_plans;
-long g_gm_rate = 16000;
-smilehip_plan *gemaps_plan(long rate = 0) {
+std::map<std::pair<long, long>, smilehip_plan *> g_gm_plans;      // (sample rate, cFormantLpc maxF in Hz)
+long g_gm_rate = 16000, g_gm_maxf = 5450;
+smilehip_plan *gemaps_plan(long rate = 0, long maxf = 0) {
   if (rate > 0) g_gm_rate = rate;
-  smilehip_plan *&pl = g_gm_plans[g_gm_rate];
+  if (maxf > 0) g_gm_maxf = maxf;
+  smilehip_plan *&pl = g_gm_plans[std::make_pair(g_gm_rate, g_gm_maxf)];
   if (!pl) {
     smilehip_lld_config c;
     smilehip_config_egemapsv02(&c);
     c.sample_rate = (double)g_gm_rate;
+    c.formant_max_freq = (double)g_gm_maxf;              // 5450 in GeMAPSv01b / eGeMAPSv02, 5500 in the v01a files (formantLpc.cpp:224-231)
     check(smilehip_plan_create(context(), &c, &pl));
   }
   return pl;
@@ -1889,17 +1892,17 @@ class cHipFormantLpc : public cFormantLpc {
       const sDmLevelConfig *c = reader_->getLevelConfig();
       usable_ = getInt("nFormants") == 5 && getInt("saveFormants") == 1 && getInt("saveBandwidths") == 1 && !getInt("saveIntensity") &&
                 !getInt("saveNumberOfValidFormants") && !getInt("useLpSpec") && !getInt("medianFilter") && !getInt("octaveCorrection") &&
-                getDouble("minF") == 50.0 && getDouble("maxF") == 5450.0 && Nsrc == 11 && Ndst == 10 &&
+                getDouble("minF") == 50.0 && getDouble("maxF") > 50.0 && getDouble("maxF") == std::floor(getDouble("maxF")) && Nsrc == 11 && Ndst == 10 &&
                 std::fabs(c->basePeriod - 1.0 / 11000.0) < 1e-12;
     }
     if (!usable_) {
-      HIP_FALLTHROUGH(19, "cFormantLpc: only nFormants = 5 with bandwidths, minF 50, maxF 5450, no median filter / octave correction on "
+      HIP_FALLTHROUGH(19, "cFormantLpc: only nFormants = 5 with bandwidths, minF 50, no median filter / octave correction on "
                           "11 coefficients at 11 kHz is built");
       return cFormantLpc::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_formantlpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_formantlpc_frames(gemaps_plan(0, (long)getDouble("maxF")), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
     io_.down(dst, Ndst);
     g_frames[19]++;
     return (int)Ndst;
