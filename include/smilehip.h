@@ -149,7 +149,7 @@ typedef struct smilehip_lld_config {
                                            is accepted if its peak correlation exceeds the frame's running minimum (float)
                                            instead of minCC = 0.5 -- IS13_ComParE.conf; 0 in ComParE_2016.conf */
   /* F0 chains: cPitchSmootherViterbi bufferLength (src/lld/pitchSmootherViterbi.cpp:241; 0 = 30 as in ComParE_2016, 40 in
-   * GeMAPS; <= 40) and cPitchJitter searchRangeRel (src/lld/pitchJitter.cpp:632-637; 0 = 0.25 as in ComParE_2016, 0.1 in GeMAPS) */
+   * GeMAPS; <= 128) and cPitchJitter searchRangeRel (src/lld/pitchJitter.cpp:632-637; 0 = 0.25 as in ComParE_2016, 0.1 in GeMAPS) */
   int32_t  vit_buffer_len;
   double   jitter_search_range;
   /* SMILEHIP_CHAIN_EGEMAPS: cFormantLpc maxF (src/lld/formantLpc.cpp:224-231; 0 = 5450 as in GeMAPSv01b / eGeMAPSv02, 5500 in the

@@ -830,9 +830,9 @@ class ViterbiStream:
 
     def _out(self, fn, *head):
         n = C.c_int32(0)
-        fr = (C.c_int32 * 64)()
-        st = (C.c_int32 * 64)()
-        _check(fn(self._h, *head, C.byref(n), fr, st, 64))
+        fr = (C.c_int32 * 128)()
+        st = (C.c_int32 * 128)()
+        _check(fn(self._h, *head, C.byref(n), fr, st, 128))
         return [(fr[i], st[i]) for i in range(n.value)]
 
     def push(self, cand_f0, cand_voicing):

@@ -38,7 +38,7 @@ constexpr int kWaves = 4;        // waves per persistent workgroup
 constexpr int kW = 3;            // frames a wave holds at a time: one lane each in the serial phases
 constexpr int kTileFrames = 8;   // consecutive frames of one utterance per work item
 constexpr int kNC = 6;           // candidates (nCandidates of [is13_shs])
-constexpr int kVBmax = 40;       // largest bufferLength ([is13_pitchSmoothViterbi] 30, [gemapsv01b_pitchSmoothViterbi] 40)
+constexpr int kVBmax = 128;      // largest bufferLength ([is13_pitchSmoothViterbi] 30, [gemapsv01b_pitchSmoothViterbi] 40, avec2011 / smileF0 90)
 constexpr int kNS = kNC + 1;     // Viterbi states: candidates + "unvoiced"
 // Geometry of the 60 ms frame's transform, by sample rate: FFT 512 (8 kHz), 1024 (11.025 / 16 kHz: the geometry the kernels were
 // tuned on -- BASELINE's configs), 2048 (22.05 / 24 / 32 kHz), 4096 (44.1 / 48 kHz). Everything below is written against
@@ -951,20 +951,25 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
     convIdx++;
     if (lane == 0) emit(convIdx, Pp[ms * kVB + convIdx % kVB], 0);
     emit_done(1);
-  } else {                                               // decide up to where all paths agree
-    const int n = convIdx + 1 + lane;
-    bool match = false;
-    int xs = 0;
-    if (n < pathIdx) {
-      xs = Pp[n % kVB];
-      match = true;
-      for (int i = 1; i < ns; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
+  } else {                                               // decide up to where all paths agree: 64 open frames per round
+    int total = 0;
+    for (;;) {
+      const int n = convIdx + 1 + total + lane;
+      bool match = false;
+      int xs = 0;
+      if (n < pathIdx) {
+        xs = Pp[n % kVB];
+        match = true;
+        for (int i = 1; i < ns; i++) if (Pp[i * kVB + n % kVB] != xs) match = false;
+      }
+      const unsigned long long mm = __ballot(match);
+      const int nlead = (~mm) ? __ffsll((long long)~mm) - 1 : 64;
+      if (lane < nlead) emit(n, xs, total + lane);
+      total += nlead;
+      if (nlead < 64) break;                             // (bufferLength > 64: the frames beyond the first 64 open ones)
     }
-    const unsigned long long mm = __ballot(match);
-    const int nlead = __ffsll((long long)~mm) - 1;       // lanes >= 31 never match: ~mm != 0
-    if (lane < nlead) emit(n, xs, lane);
-    emit_done(nlead);
-    convIdx += nlead;
+    emit_done(total);
+    convIdx += total;
   }
   __syncthreads();
 }

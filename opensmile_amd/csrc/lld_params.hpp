@@ -153,7 +153,7 @@ struct F0Params {
   const float *in_rows;
   int64_t ld_in, ld_tap, ld_shs;
   int32_t *pending;                 // optional [n_utt]: frames the Viterbi pass had not decided at the end of input
-  int32_t vit_buf;                  // cPitchSmootherViterbi bufferLength (30 ComParE, 40 GeMAPS; <= 40)
+  int32_t vit_buf;                  // cPitchSmootherViterbi bufferLength (30 ComParE, 40 GeMAPS; <= 128)
   int32_t vit_log_out;              // 1: rows [F0final, F0finalLog, voicingFinalUnclipped] (GeMAPS), 0: [F0final, voicing]
   double jit_search_range;          // cPitchJitter searchRangeRel (0.25 ComParE, 0.1 GeMAPS)
   int32_t n_cand;                   // cPitchShs nCandidates (1 .. 6; the rows keep six slots, the unused ones are zero)

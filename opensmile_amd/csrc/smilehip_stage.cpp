@@ -326,7 +326,7 @@ extern "C" int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buf
   const int st0[4] = {0, -1, 0, 0};
   if (hipMalloc(reinterpret_cast<void **>(&s->d_st), sizeof(st0)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&s->d_paths), sizeof(int) * (size_t)np) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&s->d_decided), sizeof(int) * 2 * 64) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&s->d_decided), sizeof(int) * 2 * 128) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&s->d_dstate), sizeof(double) * ds.size()) != hipSuccess ||
       hipMemcpy(s->d_st, st0, sizeof(st0), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(s->d_paths, 0, sizeof(int) * (size_t)np) != hipSuccess ||
@@ -350,13 +350,13 @@ static int viterbi_step(smilehip_viterbi_stream *s, int flush, int32_t *n_decide
   hipError_t e = launch_f0_viterbi_step(s->Q, s->d_frames, s->d_st, s->d_dstate, s->d_paths, s->d_decided, flush, st);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "viterbi step launch failed: %s", hipGetErrorString(e));
   int h_st[4];
-  int h_dec[2 * 64];
+  int h_dec[2 * 128];
   if (hipMemcpyAsync(h_st, s->d_st, sizeof(h_st), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(h_dec, s->d_decided, sizeof(h_dec), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return fail(SMILEHIP_ERR_HIP, "viterbi step: copy back failed");
   const int n = h_st[3];
-  if (n > cap || n > 64) return fail(SMILEHIP_ERR_INVALID, "viterbi step: %d decisions, room for %d", n, cap);
+  if (n > cap || n > 128) return fail(SMILEHIP_ERR_INVALID, "viterbi step: %d decisions, room for %d", n, cap);
   for (int i = 0; i < n; ++i) { frames[i] = h_dec[2 * i]; states[i] = h_dec[2 * i + 1]; }
   *n_decided = n;
   return SMILEHIP_OK;

@@ -2337,7 +2337,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     cVectorMeta *md = reader_->getLevelMetaDataPtr(0);
     if (md != NULL) thresh_ = md->fData[0];                // the voicing cut-off cPitchShs publishes with its level
     const int buflen = getInt("bufferLength");
-    usable_ = f0I_ >= 0 && cvI_ >= 0 && nCand_ >= 1 && nCand_ <= 6 && more == 0 && buflen >= 2 && buflen <= 40 && reader_->getNLevels() == 1;
+    usable_ = f0I_ >= 0 && cvI_ >= 0 && nCand_ >= 1 && nCand_ <= 6 && more == 0 && buflen >= 2 && buflen <= 128 && reader_->getNLevels() == 1;
     if (!usable_) return;
     // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd as well (pitchSmootherViterbi.hpp:291-299)
     const double w[6] = {getDouble("wLocal"), getDouble("wTvv"), getDouble("wTvv"), getDouble("wTvuv"), getDouble("wThr"), getDouble("wRange")};
@@ -2355,10 +2355,10 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     g_fused.init();
     if (!ready_) setup();
     if (!usable_) {
-      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 40 is built");
+      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 128 is built");
       return cPitchSmootherViterbi::myTick(t);
     }
-    int32_t n = 0, fr[64], st[64];
+    int32_t n = 0, fr[128], st[128];
     if (g_fused.big) {
       // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
       // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
@@ -2366,7 +2366,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
       const long T = g_fused.f0_frames, P = g_fused.f0_pending;
       if (isEOI()) {
         if (!flushed_) {
-          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 64; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
+          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 128; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
           flushed_ = true;
         }
       } else {
@@ -2381,7 +2381,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
       }
     } else if (isEOI()) {
       if (!flushed_) {
-        check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 64));
+        check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 128));
         flushed_ = true;
       }
     } else {
@@ -2398,7 +2398,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
       h[(size_t)(2 * nCand_ + 2)] = c1I_ > 0 ? vec->data[c1I_] : 0.0f;
       h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
       hist_.push_back(h);
-      check(smilehip_viterbi_stream_push(vs_, cf, cv, &n, fr, st, 64));
+      check(smilehip_viterbi_stream_push(vs_, cf, cv, &n, fr, st, 128));
       g_frames[21]++;
     }
     for (int i = 0; i < n; ++i) queue_.push_back(std::make_pair((int)fr[i], (int)st[i]));

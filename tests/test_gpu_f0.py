@@ -115,7 +115,7 @@ def test_viterbi_stream_equals_the_oracle_frame_by_frame(hip, oracle):
     L = oracle.lib()
     L.lldo_pitch_viterbi_ex.restype = None
     L.lldo_pitch_viterbi_ex.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    for buflen, n_samp in ((30, 64000), (40, 48000), (30, 4800)):
+    for buflen, n_samp in ((30, 64000), (40, 48000), (30, 4800), (90, 64000), (128, 96000)):      # > 64: several rounds of the decision scan
         pcm = synth.utterance(70 + buflen, n_samp)
         b = capi.Batch(plan, np.array([0, n_samp], np.int64))
         _, taps = b.f0_run_host_taps(pcm)
