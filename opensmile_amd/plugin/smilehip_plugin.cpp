@@ -1121,13 +1121,13 @@ class cHipContourSmoother : public cContourSmoother {
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
-      const int smaWin = getInt("smaWin");
-      W_ = smaWin / 2;
-      plain_ = ((smaWin & 1) && W_ >= 1) ? 1 : 0;
+      const int w = smaWin;                              // the member: myFetchConfig has made an even value odd (contourSmoother.cpp:64-67)
+      W_ = w / 2;
+      plain_ = ((w & 1) && W_ >= 1) ? 1 : 0;
       nz_ = getInt("noZeroSma") ? 1 : 0;
     }
     if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
-    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: an even smaWin is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: smaWin = 1 (no smoothing) is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);
     g_frames[11] += out->nT;
     return 1;

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 200 python -m pytest tests/test_gpu_f0.py -q -k "viterbi" 2>&1 | tail -8 | cut -c1-300
+timeout 100 python tools/plugin_config_sweep.py --only prosody/ 2>/dev/null | cut -c1-420

@@ -41,6 +41,7 @@ def digest(p):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--probe", action="store_true")
+    ap.add_argument("--only", default="", help="substring of the files to run")
     a = ap.parse_args()
     confs = sorted(glob.glob(os.path.join(lldo.REF_DIR, "config", "**", "*.conf"), recursive=True))
     pcm = synth.utterance(71, 24000)
@@ -64,6 +65,8 @@ def main():
             return
         found = json.load(open(PROBE))
         for rel, opt in sorted(found.items()):
+            if a.only and a.only not in rel:
+                continue
             c = os.path.join(lldo.REF_DIR, "config", rel)
             o1, o2 = os.path.join(td, "plain.bin"), os.path.join(td, "plugin.bin")
             for o in (o1, o2):
