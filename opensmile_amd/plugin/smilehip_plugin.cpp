@@ -1274,7 +1274,7 @@ class cHipPlp : public cPlp {
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0, firstCC_ = 0;
+  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0, firstCC_ = 0, htk_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
  protected:
@@ -1292,8 +1292,10 @@ class cHipPlp : public cPlp {
       compression_ = (FLOAT_DMEM)getDouble("compression");
       if (compression_ < 0.0) compression_ = 0.0;
       melfloor_ = (FLOAT_DMEM)getDouble("melfloor");
-      const bool logs_ok = (newRasta_ || rasta) ? true : (!getInt("doLog") && !getInt("doInvLog"));      // (either RASTA form forces doLog = doInvLog = 1, :168-174)
-      plain_ = (getInt("doAud") && !doIDFT && !doLP && !getInt("htkcompatible") && logs_ok) ? 1 : 0;
+      htk_ = getInt("htkcompatible") ? 1 : 0;              // forces melfloor = 1, doAud = 1, doLog = doInvLog = 0 (plp.cpp:151-161)
+      const bool logs_ok = (newRasta_ || rasta) ? true : (htk_ || (!getInt("doLog") && !getInt("doInvLog")));   // (either RASTA form forces doLog = doInvLog = 1, :168-174)
+      plain_ = ((htk_ || getInt("doAud")) && !doIDFT && !doLP && logs_ok && !(htk_ && (newRasta_ || rasta))) ? 1 : 0;
+      if (htk_) melfloor_ = 1.0;                           // the HTK-style auditory spectrum alone (config/audspec/audspec.conf)
       // PLP cepstra in HTK mode (config/plp/*.conf): doAud -> IDFT -> LP -> cepstra, c0 last
       lpOrder_ = getInt("lpOrder");
       const int lastCC = getInt("lastCC"), nCeps = getInt("nCeps");
@@ -1322,7 +1324,7 @@ class cHipPlp : public cPlp {
       const double *frq = (const double *)(fmeta->field[idxi].info);
       std::vector<float> e((size_t)Nsrc), st((size_t)(6 * Nsrc + 2), 0.0f);
       for (long i = 0; i < Nsrc; ++i) {
-        e[(size_t)i] = cc_ ? (FLOAT_DMEM)smileDsp_equalLoudnessWeight_htk((double)frq[i])
+        e[(size_t)i] = (cc_ || htk_) ? (FLOAT_DMEM)smileDsp_equalLoudnessWeight_htk((double)frq[i])
                            : (FLOAT_DMEM)smileDsp_equalLoudnessWeight((double)frq[i]);
         if (newRasta_ || oldRasta_) e[(size_t)i] = log(e[(size_t)i]);
       }
