@@ -627,7 +627,8 @@ int smilehip_zcr_count_frames(smilehip_context *ctx, const float *d_src, int64_t
                               int32_t *d_out, void *stream);
 /* R9: cAcf::processVector, forward path (acf.cpp:249-349) on a plan whose FFT size is 2*(K-1): input K
  * magnitudes per frame, output the first n_out (<= 2*(K-1)) lags. use_power squares the input (:252-259),
- * cepstrum takes log(x+1) first (:288-305; oldCompatCepstrum and cosLifterCepstrum are not covered),
+ * cepstrum = 1 takes log(x+1) first (:288-305), cepstrum = 2 is oldCompatCepstrum (:275-286: log(x) of the inner bins, DC and
+ * Nyquist as they are); cosLifterCepstrum is not covered,
  * norm_output divides by K (:321-325), abs_cepstrum takes |.| of the cepstrum (:327-331; the ACF is
  * always |.|, :343). */
 int smilehip_acf_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_out,

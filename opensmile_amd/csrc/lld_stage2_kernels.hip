@@ -48,7 +48,8 @@ __global__ void __launch_bounds__(256) k_acf(const float *src, int64_t lds, floa
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float p = m[k];
     if (use_power) p = p * p;                                                              // :252-259
-    if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
+    if (cepstrum == 2) { if (k != 0 && k != K - 1) p = (p > 0.0f) ? (float)log((double)p) : 0.0f; }   // oldCompatCepstrum, :275-286: DC and Nyquist as they are
+    else if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
     sp[k] = p;
   }
   __syncthreads();
@@ -73,7 +74,8 @@ __global__ void __launch_bounds__(256) k_acf_oo_wave(const float *src, int64_t l
   for (int k = lane; k < K; k += 64) {
     float p = m[k];
     if (use_power) p = p * p;                                                              // :252-259
-    if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
+    if (cepstrum == 2) { if (k != 0 && k != K - 1) p = (p > 0.0f) ? (float)log((double)p) : 0.0f; }   // oldCompatCepstrum, :275-286: DC and Nyquist as they are
+    else if (cepstrum) p = (p > 0.0f) ? (float)log((double)p + 1.0) : 0.0f;                     // :288-305
     sp[k] = p;
   }
   oo_wave_sync();

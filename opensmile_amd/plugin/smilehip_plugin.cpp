@@ -903,11 +903,12 @@ class cHipAcf : public cAcf {
       use_power_ = cepstrum_ ? (isSet("usePower") ? getInt("usePower") : 0) : getInt("usePower");
       norm_ = getInt("acfCepsNormOutput");
       abs_ceps_ = getInt("absCepstrum");
-      plain_ = (!getInt("inverse") && !getInt("oldCompatCepstrum") && !getInt("cosLifterCepstrum")) ? 1 : 0;
+      plain_ = (!getInt("inverse") && !getInt("cosLifterCepstrum")) ? 1 : 0;
+      if (cepstrum_ && getInt("oldCompatCepstrum")) cepstrum_ = 2;      // log(x) of the inner bins, DC and Nyquist as they are (acf.cpp:275-286)
     }
     const long N = (Nsrc - 1) * 2;
     if (!plain_ || Nsrc < 5 || (N & (N - 1)) != 0 || Ndst > N / 2)
-      { HIP_FALLTHROUGH(8, "cAcf: inverse / oldCompatCepstrum / cosLifterCepstrum / expBeforeAbs or this field size are not built"); return cAcf::processVector(src, dst, Nsrc, Ndst, idxi); }
+      { HIP_FALLTHROUGH(8, "cAcf: inverse / cosLifterCepstrum / expBeforeAbs or this field size are not built"); return cAcf::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(N, SMILEHIP_STAGE_FFT);

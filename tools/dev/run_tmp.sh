@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 100 python tools/plugin_config_sweep.py --only audspec/ 2>/dev/null | cut -c1-600
-timeout 100 python -m pytest tests/test_gpu_plugin.py -q -k "plp or compare_spectral or option_sets or egemaps_whole" 2>&1 | tail -3
+timeout 60 python tools/plugin_config_sweep.py --only emobase/emobase.conf 2>/dev/null | cut -c1-700
+timeout 60 python tools/plugin_config_sweep.py --only emo_large 2>/dev/null | cut -c1-700
+timeout 100 python -m pytest tests/test_gpu_plugin.py tests/test_gpu_stages.py tests/test_gpu_is09.py -q -k "is09 or acf or option_sets" 2>&1 | tail -3
