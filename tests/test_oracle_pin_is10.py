@@ -178,3 +178,50 @@ def test_crossings_dct_samples_families_bit_exact(tmp_path):
         for k, s in cases.items():
             ref = lldo.read_htk(str(tmp_path / ("tap_%s.htk" % k)))[0]
             assert same(lldo.funcspec(x, s).reshape(1, -1), ref), (u, n, k)
+
+
+def _run_taps(conf, pcm, tmp_path, cwd_taps):
+    import os
+    import subprocess
+    wav = str(tmp_path / "in.wav")
+    lldo.write_wav(wav, pcm, 16000)
+    cmd = [os.path.join(lldo.REF_DIR, "SMILExtract"), "-C", conf, "-I", wav, "-l", "0"] + ([] if cwd_taps else ["-T", str(tmp_path)])
+    subprocess.run(cmd, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return lambda k: lldo.read_htk(str(tmp_path / ("tap_%s.htk" % k)))[0]
+
+
+def test_pitch_smoother_option_paths_bit_exact(tmp_path):
+    """octaveCorrection = 1 (with simple post smoothing and with none; all four outputs): paths no shipped configuration uses, on
+    IS10_paraling's own candidates (oracle/conf/pitch_smoother_options.conf)."""
+    import os
+    from opensmile_amd import synth
+    conf = os.path.join(os.path.dirname(lldo.IS10_TAPS_CONF), "pitch_smoother_options.conf")
+    changed = 0
+    for u, n in ((9, 48000), (71, 24000), (4, 30000)):
+        R = _run_taps(conf, synth.utterance(u, n), tmp_path, True)
+        shs = R("shs")
+        for tag, simple in (("oct", 1), ("none", 0)):
+            got = lldo.pitch_smoother_rows(shs[:, 1:19], 6, 0.7, 1, simple, 15)
+            assert same(got, R(tag)), (u, n, tag)
+            changed += int((lldo.pitch_smoother_rows(shs[:, 1:19], 6, 0.7, 0, simple, 15) != got).any(axis=1).sum())
+    assert changed > 0                                      # the correction did act on some frames
+
+
+def test_operator_option_paths_bit_exact(tmp_path):
+    """Every element-wise and vector-sum operation of cVectorOperation, cIntensity with both outputs, cLsp on 10 and 16 LP
+    coefficients (tests/conf/is10_ops_options.conf)."""
+    import os
+    from opensmile_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = os.path.join(root, "tests", "conf", "is10_ops_options.conf")
+    for u, n in ((9, 48000), (3, 16000)):
+        R = _run_taps(conf, synth.utterance(u, n), tmp_path, False)
+        assert same(lldo.intensity_rows(R("frames"), 1, 1), R("intens"))
+        melc = R("melc")
+        assert same(lldo.vecop_rows(R("mel"), "lgA", 0.5), melc) and melc.min() < 0 < melc.max()
+        for op, p in (("add", 0.37), ("mul", -2.5), ("log", 1), ("lgA", 10), ("sqr", 1), ("ee", 1), ("abs", 1), ("dBp", 1), ("dBv", 1)):
+            assert same(lldo.vecop_rows(melc, op, p), R("vo_" + op)), op
+        for op in ("sum", "ssm", "ll1", "ll2"):
+            assert same(lldo.vecop_reduce_rows(melc, op).reshape(-1, 1), R("vo_" + op)), op
+        for p in (10, 16):
+            assert same(lldo.lsp_rows(R("lpc%d" % p)), R("lsp%d" % p)), p
