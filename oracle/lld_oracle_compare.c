@@ -104,12 +104,11 @@ static double band_energy(const float *srcP, const double *frq, long Nsrc, long 
   return sum / (double)nBins;                                              /* :853 (normBandEnergies=0, lin spectrum) */
 }
 
-/* cSpectral::processVector with [is13_spectral]'s options (ComParE_2016_core.lld.conf.inc):
- * bands 250-650, 1000-4000; rollOff .25 .50 .75 .90; flux, centroid, entropy, variance,
- * skewness, kurtosis, slope, sharpness, harmonicity; defaults squareInput=1,
- * normBandEnergies=0, useLogSpectrum=0, buggyRollOff=0, oldSlopeScale=1, freqRange 0-0.
- * src: magnitude spectrum (K). dst: 15 values in the reference's output order. */
-void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
+/* cSpectral::processVector (spectral.cpp:586-1560) for the descriptor sets of the shipped configurations: any number of bands[]
+ * (<= 16), four rollOff points, and flux, centroid, maxPos, minPos, entropy, variance, skewness, kurtosis, slope, sharpness,
+ * harmonicity each optional, in the reference's output order; defaults squareInput=1, normBandEnergies=0, useLogSpectrum=0,
+ * buggyRollOff=0, oldSlopeScale=1, freqRange 0-0. src: magnitude spectrum (K). Returns the number of values written. */
+int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const float *src, float *dst)
 {
   const long Nsrc = s->K;
   const double *frq = s->frq;
@@ -121,60 +120,71 @@ void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
   const float *srcM = src, *srcLP = srcP;
   double frameSum = 0.0;
   for (i = lo; i <= hi; i++) frameSum += srcP[i];                          /* :762-767 */
-  dst[n++] = (float)band_energy(srcP, frq, Nsrc, 250, 650, nBins);
-  dst[n++] = (float)band_energy(srcP, frq, Nsrc, 1000, 4000, nBins);
+  for (int b = 0; b < o->n_bands; b++) dst[n++] = (float)band_energy(srcP, frq, Nsrc, o->band_lo[b], o->band_hi[b], nBins);
   double sumB = 0.0, sumC = 0.0;
   for (j = lo; j <= hi; j++) sumB += (double)srcLP[j];                     /* :1093-1097 */
-  const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
-  float ro[4] = {0, 0, 0, 0};
+  float ro[16];
+  for (i = 0; i < o->n_rolloff; i++) ro[i] = 0;
   for (j = lo; j <= hi; j++) {                                             /* :1102-1117 */
     sumC += (double)srcP[j];
-    for (i = 0; i < 4; i++)
-      if ((ro[i] == 0.0) && (sumC >= rollOff[i] * frameSum)) ro[i] = (float)frq[j];
+    for (i = 0; i < o->n_rolloff; i++)
+      if ((ro[i] == 0.0) && (sumC >= o->rolloff[i] * frameSum)) ro[i] = (float)frq[j];
   }
-  for (i = 0; i < 4; i++) dst[n++] = ro[i];
-  /* flux, :1124-1254 (first frame of a field: a single 0) */
-  if (!s->have_prev) {
-    dst[n++] = 0.0f;
-    s->have_prev = 1;
-  } else {
-    double myA = 0.0;
-    for (j = lo; j <= hi; j++) {
-      double myB = ((double)srcM[j] / 1.0 - (double)s->prev[j - lo] / 1.0);
-      myA += myB * myB;
+  for (i = 0; i < o->n_rolloff; i++) dst[n++] = ro[i];
+  if (o->flux) {                                                           /* :1124-1254 (first frame of a field: a single 0) */
+    if (!s->have_prev) {
+      dst[n++] = 0.0f;
+      s->have_prev = 1;
+    } else {
+      double myA = 0.0;
+      for (j = lo; j <= hi; j++) {
+        double myB = ((double)srcM[j] / 1.0 - (double)s->prev[j - lo] / 1.0);
+        myA += myB * myB;
+      }
+      double flux = (nBins > 0) ? myA / (double)nBins : 0.0;
+      dst[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
     }
-    double flux = (nBins > 0) ? myA / (double)nBins : 0.0;
-    dst[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+    for (j = lo; j <= hi; j++) s->prev[j - lo] = srcM[j];
   }
-  for (j = lo; j <= hi; j++) s->prev[j - lo] = srcM[j];
-  /* centroid, :1256-1311 */
+  /* centroid, :1256-1311: computed whenever a moment or the slope needs it */
   float ctr = 0.0f;
   double sumA = 0.0;
-  for (j = lo; j <= hi; j++) sumA += (double)frq[j] * (double)srcLP[j];
-  if (sumB != 0.0) ctr = (float)(sumA / sumB);
-  dst[n++] = ctr;
-  dst[n++] = stat_entropy(srcLP + lo, hi - lo + 1);                        /* :1332-1336 */
-  /* moments, :1338-1397 */
-  double u = ctr, m2 = 0.0, m3 = 0.0, m4 = 0.0;
-  for (i = lo; i <= hi; i++) {
-    double t1 = ((double)frq[i] - u);
-    double m = t1 * t1 * (double)srcLP[i];
-    m2 += m; m *= t1; m3 += m; m4 += m * t1;
+  if (o->centroid || o->variance || o->skewness || o->kurtosis || o->slope) {
+    for (j = lo; j <= hi; j++) sumA += (double)frq[j] * (double)srcLP[j];
+    if (sumB != 0.0) ctr = (float)(sumA / sumB);
+    if (o->centroid) dst[n++] = ctr;
   }
-  double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
-  dst[n++] = (float)sigma2;
-  dst[n++] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
-  dst[n++] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
-  /* slope, :1399-1427 (oldSlopeScale = 1) */
-  {
+  if (o->max_pos || o->min_pos) {                                          /* :1314-1330 (the last bin is not looked at) */
+    long maP = lo, miP = lo;
+    float max = srcLP[lo], min = srcLP[lo];
+    for (j = lo + 1; j < hi; j++) {
+      if (srcLP[j] < min) { min = srcLP[j]; miP = j; }
+      if (srcLP[j] > max) { max = srcLP[j]; maP = j; }
+    }
+    if (o->max_pos) dst[n++] = (float)frq[maP];
+    if (o->min_pos) dst[n++] = (float)frq[miP];
+  }
+  if (o->entropy) dst[n++] = stat_entropy(srcLP + lo, hi - lo + 1);        /* :1332-1336 */
+  if (o->variance || o->skewness || o->kurtosis) {                         /* moments, :1338-1397 */
+    double u = ctr, m2 = 0.0, m3 = 0.0, m4 = 0.0;
+    for (i = lo; i <= hi; i++) {
+      double t1 = ((double)frq[i] - u);
+      double m = t1 * t1 * (double)srcLP[i];
+      m2 += m; m *= t1; m3 += m; m4 += m * t1;
+    }
+    double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+    if (o->variance) dst[n++] = (float)sigma2;
+    if (o->skewness) dst[n++] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
+    if (o->kurtosis) dst[n++] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
+  }
+  if (o->slope) {                                                          /* :1399-1427 (oldSlopeScale = 1) */
     double Sf = 0.0, S2f = 0.0, Nind = (double)nBins;
     for (i = lo; i <= hi && i < Nsrc; i++) { S2f += (double)frq[i] * (double)frq[i]; Sf += (double)frq[i]; }
     double deno = (Nind * S2f - Sf * Sf), slope = 0.0;
     if (deno != 0.0) slope = (Nind * sumA - Sf * sumB) / deno;
     dst[n++] = (float)(slope * (Nind - 1.0));
   }
-  /* sharpness, :1429-1482 (frequency axis given, linear scale) */
-  {
+  if (o->sharpness) {                                                      /* :1429-1482 (frequency axis given, linear scale) */
     if (!s->sharp) {
       s->sharp = (double *)malloc(sizeof(double) * (size_t)(hi - lo + 1));
       for (j = lo; j <= hi; j++) {
@@ -187,8 +197,7 @@ void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
     if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
     dst[n++] = (float)(0.11 * c2);
   }
-  /* harmonicity, :1484-1513 */
-  {
+  if (o->harmonicity) {                                                    /* :1484-1513 */
     float ptpSum = 0.0f, lastPeak = -99.0f;
     for (j = lo + 2; j < hi - 1; j++) {
       if ((srcLP[j - 2] < srcLP[j] && srcLP[j - 1] < srcLP[j] && srcLP[j] > srcLP[j + 1] && srcLP[j] > srcLP[j + 2]) ||
@@ -202,6 +211,19 @@ void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
     dst[n++] = ptpSum;
   }
   free(srcP);
+  return (int)n;
+}
+
+/* [is13_spectral]'s options (ComParE_2016_core.lld.conf.inc): bands 250-650, 1000-4000; rollOff .25 .50 .75 .90; flux, centroid,
+ * entropy, variance, skewness, kurtosis, slope, sharpness, harmonicity: 15 values */
+void lldo_spectral_compare(lldo_spectral *s, const float *src, float *dst)
+{
+  lldo_spectral_opts o;
+  memset(&o, 0, sizeof(o));
+  o.n_bands = 2; o.band_lo[0] = 250; o.band_hi[0] = 650; o.band_lo[1] = 1000; o.band_hi[1] = 4000;
+  o.n_rolloff = 4; o.rolloff[0] = 0.25; o.rolloff[1] = 0.50; o.rolloff[2] = 0.75; o.rolloff[3] = 0.90;
+  o.flux = o.centroid = o.entropy = o.variance = o.skewness = o.kurtosis = o.slope = o.sharpness = o.harmonicity = 1;
+  (void)lldo_spectral_general(s, &o, src, dst);
 }
 
 /* ---------------------------------------------------------------------- R8 */

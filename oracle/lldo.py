@@ -1051,3 +1051,43 @@ def vecop_reduce_rows(x, op):
     L.lldo_vecop_reduce.restype = C.c_float
     L.lldo_vecop_reduce.argtypes = [C.c_int, C.c_void_p, C.c_long]
     return np.array([L.lldo_vecop_reduce(VOP[op], x[i].ctypes.data, x.shape[1]) for i in range(x.shape[0])], np.float32)
+
+
+class _Spectral(C.Structure):
+    _fields_ = [("K", C.c_long), ("fsSec", C.c_double), ("prev", C.c_void_p), ("have_prev", C.c_int), ("frq", C.c_void_p),
+                ("sharp", C.c_void_p)]
+
+
+class SpectralOpts(C.Structure):
+    """lldo_spectral_opts (oracle/lld_oracle.h)"""
+    _fields_ = [("n_bands", C.c_int), ("band_lo", C.c_long * 16), ("band_hi", C.c_long * 16), ("n_rolloff", C.c_int),
+                ("rolloff", C.c_double * 16)] + [(k, C.c_int) for k in ("flux", "centroid", "max_pos", "min_pos", "entropy", "variance",
+                                                                        "skewness", "kurtosis", "slope", "sharpness", "harmonicity")]
+
+
+def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 0.9), **flags):
+    """cSpectral over the frames of one stream for any of the shipped descriptor sets: n x K magnitudes -> n x count."""
+    L = lib()
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    o = SpectralOpts()
+    o.n_bands = len(bands)
+    for i, (a, b) in enumerate(bands):
+        o.band_lo[i], o.band_hi[i] = a, b
+    o.n_rolloff = len(rolloff)
+    for i, r in enumerate(rolloff):
+        o.rolloff[i] = r
+    for k, v in flags.items():
+        setattr(o, k, int(v))
+    s = _Spectral()
+    L.lldo_spectral_init.argtypes = [C.c_void_p, C.c_long, C.c_double]
+    L.lldo_spectral_general.restype = C.c_int
+    L.lldo_spectral_general.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lldo_spectral_free.argtypes = [C.c_void_p]
+    L.lldo_spectral_init(C.byref(s), mag.shape[1], frame_size_sec)
+    row = np.zeros(64, np.float32)
+    out = []
+    for i in range(mag.shape[0]):
+        n = L.lldo_spectral_general(C.byref(s), C.byref(o), mag[i].ctypes.data, row.ctypes.data)
+        out.append(row[:n].copy())
+    L.lldo_spectral_free(C.byref(s))
+    return np.array(out, np.float32)
