@@ -26,14 +26,17 @@ static double to_log_scale(double x, double base) { return x > 0 ? log(x) / log(
 /* cSpecScale::dataProcessorCustomFinalise (specScale.cpp:228-300) for scale=octave, sourceScale=lin, minF=25,
  * maxF=-1, nPointsTarget=0 (-> K), auditoryWeighting=1; spline caches: smileMath_cspline_init
  * (smileUtilSpline.c:139-155), smileMath_csplint_init (:296-342) */
-int lldo_specscale_init(lldo_specscale *s, long K, double frame_size_sec_level)
+int lldo_specscale_init(lldo_specscale *s, long K, double frame_size_sec_level) { return lldo_specscale_init_ex(s, K, frame_size_sec_level, 25.0); }
+
+/* the same with cSpecScale.minF given (25 in ComParE_2016 / GeMAPS, 20 in IS10_paraling) */
+int lldo_specscale_init_ex(lldo_specscale *s, long K, double frame_size_sec_level, double min_f)
 {
   memset(s, 0, sizeof(*s));
   s->K = K;
   const double fsSec = (double)(float)frame_size_sec_level;       /* specScale.cpp:186 */
   const double deltaF = 1.0 / fsSec;                              /* :207 */
   const double base = 2.0;
-  double minF = 25.0, maxF = -1.0;
+  double minF = min_f, maxF = -1.0;
   const double samplF = deltaF * (double)(K - 1);                 /* :235-238 */
   if (maxF <= minF || maxF > samplF) maxF = samplF;
   const double fmin_t = to_log_scale(minF, base), fmax_t = to_log_scale(maxF, base);
@@ -118,15 +121,18 @@ static void smooth_121(double *a, long n)
 
 /* cSpecScale::processVector (specScale.cpp:305-357); natural spline by smileMath_cspline
  * (smileUtilSpline.c:157-212), evaluation by smileMath_csplint (:344-357) */
-void lldo_specscale_frame(const lldo_specscale *s, const float *mag, float *dst)
+void lldo_specscale_frame(const lldo_specscale *s, const float *mag, float *dst) { lldo_specscale_frame_ex(s, 7, mag, dst); }
+
+/* flags: 1 specEnhance, 2 specSmooth, 4 auditoryWeighting (without it the spline's values pass as they are, negative ones too) */
+void lldo_specscale_frame_ex(const lldo_specscale *s, int flags, const float *mag, float *dst)
 {
   const long K = s->K;
   double *y = (double *)malloc(sizeof(double) * (size_t)K * 3);
   double *y2 = y + K, *u = y2 + K;
   long *pos = (long *)malloc(sizeof(long) * (size_t)(K / 2 + 3));
   for (long i = 0; i < K; i++) y[i] = (double)mag[i];
-  enhance_peaks(y, K, pos);
-  smooth_121(y, K);
+  if (flags & 1) enhance_peaks(y, K, pos);
+  if (flags & 2) smooth_121(y, K);
   u[0] = 0.0; y2[0] = 0.0;
   for (long i = 1; i < K - 1; i++) {
     const double sg = s->sigma[i];
@@ -142,7 +148,7 @@ void lldo_specscale_frame(const lldo_specscale *s, const float *mag, float *dst)
     const long k = s->k[i];
     const double o = a * y[k] + b * y[k + 1] + c * y2[k] + d * y2[k + 1];
     float v = (float)o;
-    if (v > 0.0) v = (float)((double)v * s->audw[i]); else v = 0.0f;
+    if (flags & 4) { if (v > 0.0) v = (float)((double)v * s->audw[i]); else v = 0.0f; }
     dst[i] = v;
   }
   free(y); free(pos);

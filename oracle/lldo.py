@@ -1091,3 +1091,41 @@ def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 
         out.append(row[:n].copy())
     L.lldo_spectral_free(C.byref(s))
     return np.array(out, np.float32)
+
+
+class _SpecScale(C.Structure):
+    _fields_ = [("K", C.c_long), ("ft", C.c_void_p), ("sigma", C.c_void_p), ("d1", C.c_void_p), ("d2", C.c_void_p), ("k", C.c_void_p),
+                ("co", C.c_void_p), ("audw", C.c_void_p), ("meta", C.c_float * 8)]
+
+
+class _Shs(C.Structure):
+    _fields_ = [("N", C.c_long), ("n_octaves", C.c_float), ("points_per_octave", C.c_float), ("Fmint", C.c_float), ("Fstept", C.c_float),
+                ("base", C.c_double), ("n_harmonics", C.c_int), ("compression", C.c_float), ("n_cand", C.c_int), ("min_pitch", C.c_double),
+                ("max_pitch", C.c_double), ("voicing_cutoff", C.c_float), ("old_peaks", C.c_int)]
+
+
+def specscale_shs_rows(mag, frame_size_sec, min_f=25.0, flags=7, n_cand=6, old_peaks=0, voicing_cutoff=0.7, n_harmonics=15,
+                       compression=0.85, min_pitch=52.0, max_pitch=620.0):
+    """cSpecScale (flags: 1 specEnhance, 2 specSmooth, 4 auditoryWeighting) then cPitchShs over rows of K magnitudes:
+    (n x K octave-scale spectra, n x (3 n_cand + 3) rows [nCandidates | F0Cand | candVoicing | candScores | F0raw | voicingClip])."""
+    L = lib()
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    n, K = mag.shape
+    s, h = _SpecScale(), _Shs()
+    L.lldo_specscale_init_ex.restype = C.c_int
+    L.lldo_specscale_init_ex.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_double]
+    L.lldo_specscale_frame_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lldo_shs_init.argtypes = [C.c_void_p, C.c_void_p]
+    L.lldo_pitch_shs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lldo_specscale_free.argtypes = [C.c_void_p]
+    assert L.lldo_specscale_init_ex(C.byref(s), K, frame_size_sec, min_f) == 1
+    L.lldo_shs_init(C.byref(h), C.byref(s))
+    h.n_cand, h.old_peaks, h.voicing_cutoff, h.n_harmonics, h.compression = n_cand, old_peaks, voicing_cutoff, n_harmonics, compression
+    h.min_pitch, h.max_pitch = min_pitch, max_pitch
+    hps = np.zeros((n, K), np.float32)
+    shs = np.zeros((n, 3 * n_cand + 3), np.float32)
+    for i in range(n):
+        L.lldo_specscale_frame_ex(C.byref(s), flags, mag[i].ctypes.data, hps[i].ctypes.data)
+        L.lldo_pitch_shs(C.byref(h), hps[i].ctypes.data, shs[i].ctypes.data, None)
+    L.lldo_specscale_free(C.byref(s))
+    return hps, shs
