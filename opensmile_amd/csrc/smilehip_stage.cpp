@@ -1,6 +1,10 @@
 // libsmilehip, C ABI part 4: the per-component batched operators (what the plugin's overrides call).
 #include "smilehip_internal.hpp"
 
+#include <array>
+#include <map>
+#include <mutex>
+
 // ---------------------------------------------- per-component entry points
 #include "lld_stage.hpp"
 
@@ -512,16 +516,27 @@ extern "C" int smilehip_intensity_frames(smilehip_context *ctx, const float *d_s
   if (!ctx || N < 1 || N > (1 << 22) || !(flags & 3) || (flags & ~3) || n_frames < 0 || ld_src < (N < n_out ? N : n_out) || ld_dst < n_out ||
       (n_frames > 0 && (!d_src || !d_dst)))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_intensity_frames: bad argument (flags: 1 intensity, 2 loudness)");
-  // setupNamesForField (intensity.cpp:91-112): the Hamming window as doubles (smileUtil.c:1291-1303) and its sum in index order
-  const double NN = (double)N;
+  // setupNamesForField (intensity.cpp:91-112): the Hamming window as doubles (smileUtil.c:1291-1303) and its sum in index order --
+  // once per frame length (the plugin calls with one frame at a time)
+  static std::mutex mu;
+  static std::map<int64_t, std::array<double, 3>> cache;
   double w01[2] = {0.0, 0.0}, sum = 0.0;
-  long j = 0;
-  for (double i = 0.0; i < NN; i += 1.0, ++j) {
-    const double w = 0.54 - 0.46 * std::cos((2.0 * M_PI * i) / (NN - 1.0));
-    if (j < 2) w01[j] = w;
-    sum += w;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(N);
+    if (it == cache.end()) {
+      const double NN = (double)N;
+      long j = 0;
+      for (double i = 0.0; i < NN; i += 1.0, ++j) {
+        const double w = 0.54 - 0.46 * std::cos((2.0 * M_PI * i) / (NN - 1.0));
+        if (j < 2) w01[j] = w;
+        sum += w;
+      }
+      if (sum <= 0.0) sum = 1.0;
+      it = cache.emplace(N, std::array<double, 3>{w01[0], w01[1], sum}).first;
+    }
+    w01[0] = it->second[0]; w01[1] = it->second[1]; sum = it->second[2];
   }
-  if (sum <= 0.0) sum = 1.0;
   const int n_sum = (int)(N < n_out ? N : n_out);              // MIN(Nsrc, MIN(nWin, Ndst)), :134
   STAGE_RET(stage_intensity(d_src, ld_src, n_sum, w01[0], w01[1], sum, flags, d_dst, ld_dst, n_frames, (hipStream_t)stream), "intensity");
 }
