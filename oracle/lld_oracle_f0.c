@@ -539,6 +539,11 @@ static double quad_vertex_y(double x1, double y1, double x2, double y2, double x
 
 /* wave: the utterance as floats (n samples); f0: T values (level is13_pitchG60, column F0final);
  * out: T x 4 [jitterLocal, jitterDDP, shimmerLocal, logHNR]. N, H: frame size / step in samples. */
+/* frames: the F0 value of frame t carries the time stamp of frame t + shift (1 behind cPitchSmoother with simple post smoothing, which
+ * delays its values by one frame and hands on the time meta data of the frame it was called with; 0 behind the Viterbi smoother) */
+static long g_jit_t_shift = 0;
+void lldo_set_jitter_time_shift(long frames) { g_jit_t_shift = frames; }
+
 static void pitch_jitter_impl(const float *wave, long n, const float *f0, long T, long N, long H, double sample_rate,
                               double frame_step_sec, double searchRangeRel, float *out, float *shimmer_db)
 {
@@ -550,8 +555,9 @@ static void pitch_jitter_impl(const float *wave, long n, const float *f0, long T
   float lastT0 = 0.0f, lastDiff = 0.0f, lastJitterLocal = 0.0f, lastJitterDDP = 0.0f, lastShimmerLocal = 0.0f;
   for (long t = 0; t < T; t++) {
     const float F0 = f0[t];
-    const double time = (double)(t * H) * Tw;
-    const double lengthSec = ((double)(t * H + N - 1) * Tw - (double)(t * H) * Tw) + Tw;
+    const long tt = t + g_jit_t_shift;
+    const double time = (double)(tt * H) * Tw;
+    const double lengthSec = ((double)(tt * H + N - 1) * Tw - (double)(tt * H) * Tw) + Tw;
     const long lenF = (long)ceil(lengthSec / Tw);
     const long startVidx = (long)round(time / Tw);
     const long ppLen = (long)ceil(frame_step_sec / Tw);

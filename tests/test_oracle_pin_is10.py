@@ -225,3 +225,28 @@ def test_operator_option_paths_bit_exact(tmp_path):
             assert same(lldo.vecop_reduce_rows(melc, op).reshape(-1, 1), R("vo_" + op)), op
         for p in (10, 16):
             assert same(lldo.lsp_rows(R("lpc%d" % p)), R("lsp%d" % p)), p
+
+
+def test_jitter_behind_pitch_smoother_bit_exact(runs):
+    """cPitchJitter as IS10_paraling configures it (searchRangeRel 0.2, useBrokenJitterThresh's default 1) on F0 frames that come from
+    cPitchSmoother: the value of frame t carries the time stamp of frame t + 1 (lldo_set_jitter_time_shift) -- the binary's level."""
+    import ctypes as C
+    from opensmile_amd import synth
+    L = lldo.lib()
+    L.lldo_pitch_jitter_ex.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_double, C.c_double, C.c_double,
+                                       C.c_void_p, C.c_void_p]
+    L.lldo_set_jitter_time_shift.argtypes = [C.c_long]
+    for u, n, r in runs:
+        f0 = np.ascontiguousarray(r["is10_pitchF"].reshape(-1))
+        if not len(f0):
+            continue
+        x = (synth.utterance(u, n).astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+        out = np.zeros((len(f0), 4), np.float32)
+        lldo.compare_set_is13(True)
+        L.lldo_set_jitter_time_shift(1)
+        try:
+            L.lldo_pitch_jitter_ex(x.ctypes.data, len(x), f0.ctypes.data, len(f0), 960, 160, 16000.0, 0.010, 0.2, out.ctypes.data, None)
+        finally:
+            lldo.compare_set_is13(False)
+            L.lldo_set_jitter_time_shift(0)
+        assert same(out[:, :3], r["is10_jitter"]), (u, n)
