@@ -196,7 +196,7 @@ void lldo_pitch_acf(const float *acf, const float *ceps, long Nhalf, float fsSec
 /* ------------------------------------------------------------- R13 (general) */
 /* Tick-accurate chain of window processors (cWindowProcessor, blocksize 1):
  * stage s has kind[s] (0 = cDeltaRegression with deltawin W, 1 =
- * cContourSmoother with smaWin = 2W+1) and W[s] = pre = post. Same control flow
+ * cContourSmoother with smaWin = 2W+1, 2 = the same with noZeroSma, 3 = cDeltaRegression with onlyInSegments; at most 15 stages) and W[s] = pre = post. Same control flow
  * as lldo_delta_chain (see there for the reference lines). levels_out[s]
  * receives level s+1 (must hold T + sum_{i<=s} W[i] frames of D floats);
  * returns nothing -- frame counts are T + cumulative W. */
@@ -209,6 +209,8 @@ void lldo_window_chain(const float *x, long T, long D, int n_stages, const int *
   float **lv = (float **)calloc((size_t)n_stages + 1, sizeof(float *));
   long *curW = (long *)calloc((size_t)n_stages + 1, sizeof(long));
   char *done = (char *)calloc((size_t)n_stages + 1, 1);
+  float seg_norm[16] = {0};
+  char seg_norm_set[16] = {0};
   for (o = 0; o <= n_stages; o++) lv[o] = (float *)calloc((size_t)cap * (size_t)D, sizeof(float));
   memcpy(lv[0], x, sizeof(float) * (size_t)T * (size_t)D);
   curW[0] = T;
@@ -256,6 +258,40 @@ void lldo_window_chain(const float *x, long T, long D, int n_stages, const int *
             float num = 0.0f;
             for (i = 1; i <= W; i++) num += (float)i * (blk[(W + i) * D + d] - blk[(W - i) * D + d]);
             y[d] = num / norm;
+          }
+        } else if (kind[o - 1] == 3) {     /* cDeltaRegression with onlyInSegments (zero = no value), deltaRegression.cpp:121-137:
+                                              `norm` is a member that grows by i^2 for every pair it uses -- rows in order, columns in order */
+          if (!seg_norm_set[o]) {
+            seg_norm[o] = 0.0f;
+            for (i = 1; i <= W; i++) seg_norm[o] += (float)i * (float)i;
+            seg_norm[o] *= 2.0;
+            seg_norm_set[o] = 1;
+          }
+          for (long d = 0; d < D; d++) {
+            float num = 0.0f;
+            for (i = 1; i <= W; i++) {
+              const float a = blk[(W - i) * D + d], b = blk[(W + i) * D + d];
+              if (!(b == 0.0 || b != b || a == 0.0 || a != a)) {
+                num += (float)i * (b - a);
+                seg_norm[o] += (float)i * (float)i;
+              }
+            }
+            y[d] = (seg_norm[o] != 0.0) ? num / seg_norm[o] : 0.0f;
+          }
+        } else if (kind[o - 1] == 2) {     /* cContourSmoother with noZeroSma, contourSmoother.cpp:91-104 */
+          for (long d = 0; d < D; d++) {
+            const float c0 = blk[W * D + d];
+            if (c0 != 0.0) {
+              long N = 1;
+              float acc = c0;
+              for (i = 1; i <= W; i++) {
+                if (blk[(W - i) * D + d] != 0.0) { acc += blk[(W - i) * D + d]; N++; }
+                if (blk[(W + i) * D + d] != 0.0) { acc += blk[(W + i) * D + d]; N++; }
+              }
+              y[d] = acc / (float)N;
+            } else {
+              y[d] = 0.0f;
+            }
           }
         } else {                           /* cContourSmoother::processBuffer, contourSmoother.cpp:104-111 */
           int smaWin = 2 * W + 1;

@@ -1129,3 +1129,115 @@ def specscale_shs_rows(mag, frame_size_sec, min_f=25.0, flags=7, n_cand=6, old_p
         L.lldo_pitch_shs(C.byref(h), hps[i].ctypes.data, shs[i].ctypes.data, None)
     L.lldo_specscale_free(C.byref(s))
     return hps, shs
+
+
+# ---------------------------------------------------------------- IS10_paraling as a whole chain (the oracle of a future fused chain)
+def window_chain(x, kinds, Ws):
+    """lldo_window_chain: tick-accurate chain of window processors over ONE level (kinds: 0 delta, 1 SMA, 2 SMA with noZeroSma,
+    3 delta with onlyInSegments); returns the levels, stage s with rows + sum(W[:s+1]) rows."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    outs, tot = [], T
+    for w in Ws:
+        tot += w
+        outs.append(np.zeros((tot, D), np.float32))
+    if T <= 0:
+        return [o[:0] for o in outs]
+    ptrs = (C.c_void_p * len(Ws))(*[a.ctypes.data for a in outs])
+    L.lldo_window_chain.restype = None
+    L.lldo_window_chain.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lldo_window_chain(x.ctypes.data, T, D, len(Ws), (C.c_int * len(Ws))(*kinds), (C.c_int * len(Ws))(*Ws), ptrs)
+    return outs
+
+
+def _is10_cfg25(n_bands, hifreq, last):
+    c = default_cfg()
+    c.frame_size_sec, c.preemph_enable, c.preemph_k, c.win_func, c.zero_pad_symmetric = 0.025, 1, 0.97, WIN["ham"], 1
+    c.n_bands, c.lofreq, c.hifreq, c.use_power, c.mel_htk_compatible = n_bands, 20.0, hifreq, 1, 0
+    c.first_mfcc, c.last_mfcc, c.cep_lifter, c.mfcc_htk_compatible, c.n_delta = 0, last, 22.0, 0, 0
+    return c
+
+
+def is10_levels(pcm):
+    """config/is09-13/IS10_paraling.conf from the samples on (16 kHz): every level up to lld1 / lld2 and their deltas, as the binary
+    holds them (pinned by tests/test_oracle_pin_is10.py). Needs at least two 60 ms frames."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    mf, t = mfcc_chain(_is10_cfg25(26, 8000.0, 14), pcm, taps=True)
+    _, t8 = mfcc_chain(_is10_cfg25(8, 6500.0, 7), pcm, taps=True)
+    ml = vecop_rows(t8["mel"], "log")
+    lsp = lsp_rows(egemaps_lpc_rows(specresample_rows(t["fft"], 512 / 16000.0, 400 / 16000.0, 1 / 16000.0, 11000.0), 8))
+    x = (pcm.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    T25 = mf.shape[0]
+    inten = intensity_rows(np.stack([x[i * 160:i * 160 + 400] for i in range(T25)]), 0, 1)
+    c60 = frames_cfg(0.060, "gauss")
+    c60.win_sigma = 0.25
+    _, t60 = mfcc_chain(c60, pcm, taps=True)
+    _, shs = specscale_shs_rows(t60["mag"], 1024 / 16000.0, 20.0, 7, 6, 0, 0.7)
+    pitch = pitch_smoother_rows(shs[:, 1:19], flags=2 | 8)
+    pitchF = pitch_smoother_rows(shs[:, 1:19], flags=1)
+    L = lib()
+    L.lldo_pitch_jitter_ex.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_double, C.c_double, C.c_double,
+                                       C.c_void_p, C.c_void_p]
+    L.lldo_set_jitter_time_shift.argtypes = [C.c_long]
+    f0 = np.ascontiguousarray(pitchF.reshape(-1))
+    jit = np.zeros((len(f0), 4), np.float32)
+    if len(f0):
+        compare_set_is13(True)                               # useBrokenJitterThresh: the option's default, 1
+        L.lldo_set_jitter_time_shift(1)
+        try:
+            L.lldo_pitch_jitter_ex(x.ctypes.data, len(x), f0.ctypes.data, len(f0), 960, 160, 16000.0, 0.010, 0.2, jit.ctypes.data, None)
+        finally:
+            compare_set_is13(False)
+            L.lldo_set_jitter_time_shift(0)
+    Tm = pitch.shape[0]                                      # the shortest input level decides: T60 - 1 rows
+    # [is10_lld]: SMA(3) over five levels of different lengths -- the 25 ms levels hold real frames beyond Tm, the pitch level is padded
+    s25 = window_chain(np.concatenate([inten, mf, ml, lsp], axis=1), [1], [1])[0]
+    sp = window_chain(pitch, [1], [1])[0]
+    lld1 = np.concatenate([s25[:Tm + 1], sp], axis=1)
+    lld1_de = window_chain(lld1, [0], [2])[0]
+    # [is10_lld2] (noZeroSma) and [is10_delta2] (onlyInSegments: its norm grows over the whole file)
+    lld2, lld2_de = window_chain(np.concatenate([pitchF, jit[:, :3]], axis=1), [2, 3], [1, 2])
+    return {"lld1": lld1, "lld1_de": lld1_de, "lld2": lld2, "lld2_de": lld2_de, "pitchF": pitchF}
+
+
+def is10_lld_chain(pcm):
+    """The 76 columns -lldhtkoutput writes for IS10_paraling.conf: [lld1 | lld2 | lld1_de | lld2_de], T60 rows."""
+    d = is10_levels(pcm)
+    n = d["lld1"].shape[0]
+    return np.concatenate([d["lld1"], d["lld2"][:n], d["lld1_de"][:n], d["lld2_de"][:n]], axis=1)
+
+
+def _is10_spec_l1(nz):
+    """[is10_functL1] / [is10_functL1nz] of IS10_paraling_core.func.conf.inc"""
+    s = FuncSpec()
+    _spec_common(s, ["Extremes", "Regression", "Moments", "Percentiles", "Times"])
+    s.ext_mask, s.ext_norm = _mask(EXT_NAMES, ["maxPos", "minPos", "amean"]), NORM["frame"]
+    s.reg_mask = _mask(REG_NAMES, ["linregc1", "linregc2", "linregerrA", "linregerrQ"])
+    s.mom_mask = _mask(MOM_NAMES, ["stddev", "skewness", "kurtosis"])
+    s.pct_mask, s.pct_interp = 0x3f, 1
+    if nz:
+        s.n_pctl, s.n_range, s.non_zero_functs = 1, 0, 1
+        s.pctl[0] = 0.99
+    else:
+        s.n_pctl, s.n_range = 2, 1
+        s.pctl[0], s.pctl[1] = 0.01, 0.99
+        s.range_a[0], s.range_b[0] = 0, 1
+    s.times_mask, s.times_norm = _mask(TIMES_NAMES, ["upleveltime75", "upleveltime90"]), NORM["segment"]
+    return s
+
+
+def is10_func(pcm):
+    """The 1582 functionals of IS10_paraling.conf: [is10_functL1 (34 x 2 x 21) | is10_functL1nz (4 x 2 x 19) | is10_functOnsets (2)].
+    The first two instances summarise the first T - 3 rows of their (smoothed ; delta) levels (T = rows of the smoothed level; measured
+    against the binary), the onsets instance every row of is10_pitchF."""
+    d = is10_levels(pcm)
+    T = d["lld1"].shape[0]
+    n = max(T - 3, 1)
+    f1 = funcspec(np.concatenate([d["lld1"][:n], d["lld1_de"][:n]], axis=1), _is10_spec_l1(False)).reshape(1, -1)
+    f2 = funcspec(np.concatenate([d["lld2"][:n], d["lld2_de"][:n]], axis=1), _is10_spec_l1(True)).reshape(1, -1)
+    so = FuncSpec()
+    _spec_common(so, ["Onset", "Times"])
+    so.ons_mask, so.ons_norm, so.times_mask, so.times_norm = 1 << 4, NORM["segment"], 1 << 12, NORM["second"]
+    f3 = funcspec(d["pitchF"], so).reshape(1, -1)
+    return np.concatenate([f1, f2, f3], axis=1)

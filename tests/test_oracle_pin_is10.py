@@ -250,3 +250,17 @@ def test_jitter_behind_pitch_smoother_bit_exact(runs):
             lldo.compare_set_is13(False)
             L.lldo_set_jitter_time_shift(0)
         assert same(out[:, :3], r["is10_jitter"]), (u, n)
+
+
+@pytest.mark.parametrize("u,n", [(71, 24000), (2, 16000), (10, 32000), (5, 9000), (12, 40000), (7, 2000), (9, 160000)])
+def test_whole_is10_chain_from_the_samples_bit_exact(u, n):
+    """lldo.is10_lld_chain / is10_func: IS10_paraling.conf restated from the PCM samples on -- both framers, every component, the
+    smoothers' and delta instances' end-of-input behaviour over input levels of different lengths, the onlyInSegments delta whose norm
+    grows over the file, the rows the functionals read -- equals the binary's LLD file (76 columns) and functionals (1582) bit for
+    bit. This is the oracle a fused IS10 chain will be held against. Utterances with fewer than four 60 ms frames
+    follow other end-of-input rules and are not covered."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(u, n)
+    r = lldo.run_reference_is10(pcm, levels=[])
+    assert same(lldo.is10_lld_chain(pcm), r["lld"])
+    assert same(lldo.is10_func(pcm), r["func"])
