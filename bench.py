@@ -13,11 +13,19 @@ A "step" is one pass of the fused LLD chain (MFCC12_0_D_A: int16 PCM ->
 10 s, 16 kHz mono, 25 ms / 10 ms => 998 000 frames per GPU (configs[1]). PCM is
 resident in HBM before the timed region starts; outputs stay in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): utterances shard
-embarrassingly, every rank runs its own 1000 x 10 s batch ("weak" scaling, no
-data-path collective); the only collective in the path -- the gather of the
-feature matrices to rank 0 -- is opensmile_amd/gather.py and is reported
-separately (gather_ms) outside the timed region's `value`.
+N > 1, one rank per GPU over RCCL: either the driver launches the ranks (python -m
+torch.distributed.run ... bench.py --gpus N: RANK / WORLD_SIZE are in the environment) or
+`python bench.py --gpus N` launches them itself the same way (launch_ranks below; with fewer
+devices than ranks it says so and falls back to gloo with ranks sharing devices -- a plumbing
+check, not a measurement). WORLD_SIZE must equal --gpus. Utterances shard embarrassingly, every
+rank runs its own 1000 x 10 s batch ("weak" scaling, no data-path collective); the only
+collective in the path -- the gather of the feature matrices to rank 0 -- is
+opensmile_amd/gather.py and is reported next to `value` (gather_ms, value_incl_gather), never in it.
+
+The default N = 1 line also carries (a) "configs": BASELINE.json's configs 3, 4 and 5 at their
+per-GPU sizes, 2-3 timed steps each, each with its own roofline and real-binary CPU baseline
+(--no-configs skips them), (b) "h2d_inclusive" / "to_host": the same chain with the PCM starting
+in pinned host memory / the features ending there (SURVEY 8d's GPU timing protocol).
 
 Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
   roofline     -- dominant kernel (fused MFCC): algorithmic bytes per launch
@@ -73,7 +81,7 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", n_samples=UTT_SAMPLES, frames_per_file=998):
+def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", n_samples=UTT_SAMPLES, frames_per_file=998, max_files=14000):
     """Time the real reference binary (one process per file, HTK output to
     /dev/shm, log level 0) on all host cores; bounded sample, scaled to frames/s."""
     from oracle import lldo
@@ -109,7 +117,7 @@ def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", 
         per_file = (time.perf_counter() - t0) / n_cal
         one_core = frames_per_file / per_file
         # ~10-15 s of wall clock on all cores; outputs reuse 4*cores file names
-        n_files = int(max(cores * 4, min(14000, 12.0 / per_file * cores)))
+        n_files = int(max(cores * 4, min(max_files, min(12.0, max_seconds / 2.0) / per_file * cores)))
         jobs = "\n".join(f"{i % n_unique} {i % (4 * cores)}" for i in range(n_files))
         cmd = (f"xargs -P {cores} -L 1 sh -c '{exe} -C {conf} -I {td}/u$0.wav {opt} {td}/o$1.htk "
                f"-l 0 >/dev/null 2>&1'")
@@ -124,6 +132,84 @@ def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", 
             "one_core_value": one_core}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command under torch.distributed.run, one
+    per GPU (LOCAL_RANK picks the device). Fewer devices than ranks: gloo, ranks share devices (the line then says so)."""
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus:
+        env.setdefault("SMILEHIP_DIST_BACKEND", "gloo")
+        print(f"bench.py: {args.gpus} ranks asked for, {n_dev} device(s) visible: ranks share devices, backend "
+              f"{env['SMILEHIP_DIST_BACKEND']} (plumbing check, not a scaling measurement)", file=sys.stderr, flush=True)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(args):
+    """rank, world, the torch.distributed module (or None) -- one rank per GPU; asserts WORLD_SIZE == --gpus"""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), "
+                         f"or run `python bench.py --gpus {args.gpus}` without a launcher")
+    if world == 1:
+        if not args.plumbing_only:
+            torch.cuda.set_device(0)
+        return rank, world, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # one rank per GPU over RCCL ("nccl" on ROCm). SMILEHIP_DIST_BACKEND=gloo lets ranks share a GPU (launch_ranks on a
+    # box with fewer devices than ranks; tools/smoke_multirank.sh)
+    backend = os.environ.get("SMILEHIP_DIST_BACKEND", "nccl")
+    if args.plumbing_only:
+        dist.init_process_group("gloo")
+        return rank, world, dist
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return rank, world, dist
+
+
+def rank_report(dist, world, plumbing_only=False):
+    """what every rank ran on: backend, RCCL version, device index + bus id per rank"""
+    import torch
+    if plumbing_only:
+        me = "cpu"
+    else:
+        d = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(d)
+        me = f"cuda:{d} {getattr(pr, 'pci_bus_id', '?')}:{getattr(pr, 'pci_device_id', '?')} {pr.name}"
+    devs = [me]
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, me)
+    rep = {"backend": (dist.get_backend() if world > 1 else None), "rank_devices": devs}
+    try:
+        rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rep["rccl_version"] = None
+    if world > 1 and not plumbing_only:
+        rep["distinct_devices"] = len(set(devs))
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,9 +221,24 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the driver's contract): every rank its own 1000 x 10 s; strong: ONE ragged corpus of "
                          "--utts utterances (5..15 s) sharded over the ranks by frame count (gather.shard_utterances)")
+    ap.add_argument("--no-configs", action="store_true", help="leave BASELINE configs 3-5 out of the default line")
+    ap.add_argument("--no-h2d", action="store_true", help="leave the PCIe-inclusive figures out of the default line")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="NO kernel is launched and nothing is measured: only the rank plumbing runs (launcher, rendezvous, barrier, "
+                         "max-over-ranks, frame sum, gather, JSON) on the gloo backend with CPU tensors -- what the CPU test of the "
+                         "N > 1 path uses; the line's metric says so and its value is null")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.plumbing_only:
+        return main_plumbing(args)
     if args.config != 2:
-        return main_other(args)
+        res = run_config(args, args.config, init_ranks(args), with_cpu=not args.no_cpu_baseline)
+        if res is not None:
+            print(json.dumps(res), flush=True)
+        return finish_ranks()
     args.steps = 100 if args.steps is None else args.steps
     args.warmup = 30 if args.warmup is None else args.warmup
     args.utts = N_UTT if args.utts is None else args.utts
@@ -145,23 +246,7 @@ def main():
     import torch
     from opensmile_amd import capi, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one rank per GPU over RCCL ("nccl" on ROCm). SMILEHIP_DIST_BACKEND=gloo lets two ranks share one GPU
-        # for a smoke test of this code path on a single-GPU box (tools/smoke_multirank.sh).
-        backend = os.environ.get("SMILEHIP_DIST_BACKEND", "nccl")
-        local_rank %= max(torch.cuda.device_count(), 1) if backend != "nccl" else 10 ** 9
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
+    rank, world, dist = init_ranks(args)
     dev = torch.cuda.current_device()
 
     ctx = capi.Context(dev)
@@ -219,15 +304,17 @@ def main():
     else:
         total_frames = frames
 
-    # the path's one collective: gather feature matrices to rank 0 (outside `value`)
+    # the path's one collective: gather feature matrices to rank 0 (next to `value`, never in it)
     gather_ms = None
     if world > 1:
         from opensmile_amd import gather
+        gather.gather_features(d_out, dst=0)         # (first call: communicator set-up, receive buffers)
         barrier()
         g0 = time.perf_counter()
         gather.gather_features(d_out, dst=0)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+    ranks = rank_report(dist, world)
 
     if rank == 0:
         value = total_frames * args.steps / dt
@@ -261,57 +348,126 @@ def main():
                        "warmup_note": "clocks ramp over the first ~20 launches: the default is 30 warm-up + 100 timed steps; "
                                       "shorter runs report slower steps",
                        "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fused MFCC (R0-R7)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # The roof that bounds this kernel is FP32 vector issue (+ the per-CU LDS pipe), not HBM -- arithmetic intensity
+            # 41 FLOP/B against a ridge of 20, and the counters agree (profiles/) -- so `bound`,
+            # `achieved`, `peak`, `frac` are the FP32 figures and the HBM figures the north star asks for stand beside them.
+            "roofline": {"bound": "fp32_valu", "kernel": "fused MFCC (R0-R7)",
+                         "achieved": ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3) / 1e12,
+                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3)) / (FP32_PEAK_TFLOPS * 1e12),
+                         "alg_flop_per_frame": ALG_FLOP_PER_FRAME,
+                         "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,      # from profiles/ (a separate --pmc pass), not this run
-                         # the schema offers hbm | mfma and the north star names HBM; the counters say the kernel is limited by
-                         # the per-CU LDS pipe first and FP32 VALU issue second (profiles/): both fractions below
                          "bound_by_counters": "valu+lds",
-                         "limited_by": "lds_pipe+fp32_valu (not HBM: arithmetic intensity 41 FLOP/B vs ridge 20)",
                          "alg_bytes_per_frame": ALG_BYTES_PER_FRAME_MAIN,
-                         "kernel_ms": ms_main, "delta_kernel_ms": ms_delta,
-                         "fp32_valu_frac": (ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3)) / (FP32_PEAK_TFLOPS * 1e12)},
+                         "kernel_ms": ms_main, "delta_kernel_ms": ms_delta},
+            "accuracy_gate": "per-frame-scaled error max_t max_i |d[t,i]| / max_i |ref[t,i]| <= 1e-5 against the reference binary "
+                             "(tests/tolerance.py; measured 3e-7); frame count, index and time stamps compared with ==",
+            "ranks": ranks,
         }
         if gather_ms is not None:
             res["gather_ms"] = gather_ms
+            res["value_incl_gather"] = total_frames * args.steps / (dt + args.steps * gather_ms * 1e-3)
+            res["gather_note"] = "every step's feature matrices (frames x 39 f32 per rank) gathered to rank 0, not overlapped"
+        if world == 1 and not args.no_h2d:
+            try:
+                del d_out, d_pcm
+                res["h2d_inclusive"], res["to_host"] = pcie_figures()
+            except Exception as e:
+                res["h2d_inclusive"] = {"value": None, "note": f"failed: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the bench line down
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {e}"}
+        if world == 1 and not args.no_configs:
+            # BASELINE.json's configs 3-5 at their per-GPU sizes, the same protocol, their own short step counts
+            res["configs"] = {}
+            sub = argparse.Namespace(**vars(args))
+            sub.steps = sub.warmup = sub.utts = None
+            for k in (3, 4, 5):
+                try:
+                    torch.cuda.empty_cache()
+                    res["configs"][str(k)] = run_config(sub, k, (rank, world, dist), with_cpu=not args.no_cpu_baseline, nested=True)
+                except Exception as e:
+                    res["configs"][str(k)] = {"value": None, "error": str(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    finish_ranks()
+
+
+def finish_ranks():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
-def main_other(args):
-    """--config 3 | 4 | 5: the same protocol (warm-up, K timed steps between barrier + synchronize, max over ranks, one JSON
-    line from rank 0) on that config's chain through smilehip_lld_run; weak scaling, every rank its own batch."""
+def pcie_figures(utts=N_UTT, chunks=10, reps=5):
+    """SURVEY 8(d)'s other two figures for the headline workload: PCM starting in pinned host memory (copy of chunk i + 1
+    overlapped with the chain on chunk i), and the same with the features copied back to pinned host memory."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_h2d", os.path.join(ROOT, "tools", "bench_h2d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.measure(utts, chunks, reps, d2h=False)
+    b = mod.measure(utts, chunks, reps, d2h=True)
+    fmt = lambda r: {"value": r["frames_per_s"], "unit": "frames/s", "ms": r["ms"], "h2d_GBps": r["h2d_GBps"], "workload": r["workload"]}
+    return fmt(a), fmt(b)
+
+
+def main_plumbing(args):
+    """--plumbing-only: every step of the N-rank protocol except the device work (see the flag's help)."""
+    import torch
+    rank, world, dist = init_ranks(args)
+    steps = 3 if args.steps is None else args.steps
+    frames = 998 * (10 + rank)                       # ragged on purpose: the gather is a gather-v
+    local = torch.full((frames, 39), float(rank))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        local += 1.0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dts, total = [dt], frames
+    gathered = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        dts = [float(x.item()) for x in all_t]
+        fr = torch.tensor([frames], dtype=torch.int64)
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        total = int(fr.item())
+        from opensmile_amd import gather
+        out = gather.gather_features(local, dst=0)
+        if rank == 0:
+            gathered = [int(o.shape[0]) for o in out]
+            assert all(float(o[0, 0]) == r + steps for r, o in enumerate(out))
+    ranks = rank_report(dist, world, plumbing_only=True)
+    if rank == 0:
+        print(json.dumps({"metric": "PLUMBING ONLY -- no kernel launched, nothing measured", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+                          "config": {"workload": "rank plumbing of bench.py on CPU tensors (gloo)", "ranks_seen": len(dts),
+                                     "frames_total": total, "gathered_rows": gathered},
+                          "ranks": ranks}), flush=True)
+    finish_ranks()
+
+
+def run_config(args, config, ranks, with_cpu=True, nested=False):
+    """config 3 | 4 | 5: the same protocol (warm-up, K timed steps between barrier + synchronize, max over ranks) on that
+    config's chain through smilehip_lld_run; weak scaling, every rank its own batch. Returns rank 0's result object."""
     import ctypes as C
 
     import torch
     from opensmile_amd import capi, synth
-    c = CONFIGS[args.config]
+    c = CONFIGS[config]
     steps = c["steps"] if args.steps is None else args.steps
     warmup = c["warmup"] if args.warmup is None else args.warmup
     utts = c["utts"] if args.utts is None else args.utts
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SMILEHIP_DIST_BACKEND", "nccl")
-        local_rank %= max(torch.cuda.device_count(), 1) if backend != "nccl" else 10 ** 9
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
+    rank, world, dist = ranks
     ctx = capi.Context(torch.cuda.current_device())
     plan = capi.Plan(ctx, getattr(capi, c["cfg"])())
     n_out = plan.geometry.n_out
@@ -323,11 +479,11 @@ def main_other(args):
     d_out = torch.empty((max(rows, 1), n_out), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     L = capi.load()
-    d_func = torch.empty((utts, 88), dtype=torch.float32, device="cuda") if args.config == 5 else None
+    d_func = torch.empty((utts, 88), dtype=torch.float32, device="cuda") if config == 5 else None
 
     def step():
         batch.run_device(d_pcm.data_ptr(), d_out.data_ptr(), n_out, stream)
-        if args.config == 5:     # the functionals level on the smoothed levels the run left in the batch's scratch
+        if config == 5:     # the functionals level on the smoothed levels the run left in the batch's scratch
             capi._check(L.smilehip_batch_functionals_egemaps(plan._h, batch._h, C.c_void_p(d_func.data_ptr()), 88, C.c_void_p(stream)))
 
     def barrier():
@@ -361,11 +517,11 @@ def main_other(args):
         achieved = c["alg_bytes"] * frames / (ms_main * 1e-3) / 1e9
         res = {
             "metric": {3: "IS09_emotion LLD frames/sec (16kHz, 25ms/10ms)", 4: "ComParE_2016 LLD frames/sec (16kHz, 20ms+60ms/10ms)",
-                       5: "eGeMAPSv02 LLD+functionals frames/sec (16kHz, 20ms+60ms/10ms)"}[args.config],
+                       5: "eGeMAPSv02 LLD+functionals frames/sec (16kHz, 20ms+60ms/10ms)"}[config],
             "value": total_frames * steps / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": c["workload"], "baseline_config": args.config, "utterances_per_gpu": utts,
+            "config": {"workload": c["workload"], "baseline_config": config, "utterances_per_gpu": utts,
                        "utterances_total": utts * world, "utterances_per_s": utts * world * steps / dt,
                        "frames_rank0": frames, "rows_rank0": rows, "out_cols": n_out,
                        "ranks_seen": world, "rank_ms_per_step": {"min": min(dts) / steps * 1e3, "max": max(dts) / steps * 1e3},
@@ -374,19 +530,30 @@ def main_other(args):
                        "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "hbm", "bound_by_counters": "valu+lds (latency)", "kernel": c["kernel"], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_source": "not measured in this run; per-kernel FETCH / WRITE tables: profiles/r03_pmc_*.txt",
+                         "traffic_source": None,
                          "alg_bytes_per_frame": c["alg_bytes"], "alg_bytes_note": c["alg_note"], "kernel_ms": ms_main,
                          "rest_of_step_ms": ms_rest},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        # HBM bytes of the roofline kernel(s) per launch: counted by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, each
+        # alone) of this command at a smaller batch, kept per frame in profiles/ and scaled to this batch's frames
+        tfile = os.path.join(ROOT, "profiles", f"pmc_traffic_c{config}.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                res["roofline"]["traffic"] = tj["hbm_bytes_per_frame"] * frames
+                res["roofline"]["traffic_source"] = f"profiles/pmc_traffic_c{config}.json: " + tj.get("source", "")
+                res["roofline"]["traffic_by_kernel_bytes_per_frame"] = tj.get("by_kernel")
+            except Exception:
+                pass
+        if world == 1 and with_cpu:
             try:
                 fpf = plan.num_frames(c["samples"])
-                res["cpu_baseline"] = cpu_baseline(conf_rel=c["conf"], opt=c["opt"], n_samples=c["samples"], frames_per_file=fpf)
+                res["cpu_baseline"] = cpu_baseline(conf_rel=c["conf"], opt=c["opt"], n_samples=c["samples"], frames_per_file=fpf,
+                                                   max_seconds=12.0 if nested else 25.0, max_files=3000 if nested else 14000)
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        return res
+    return None
 
 
 if __name__ == "__main__":

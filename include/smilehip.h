@@ -636,9 +636,16 @@ int smilehip_acf_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src,
 /* R10: the per-frame analysis of cPitchACF::processVector (pitchACF.cpp:137-192, voicingProb :249-284,
  * pitchPeak :286-310). Input per frame: [acf(n) | cepstrum(n)]; output the voicing probability (double) and
  * the index of the cepstral pitch peak (0 = none). F0 = 1/(idx*Tsamp), the voicing cut-off and the causal
- * contour smoother (:189-243) are scalar host code in the caller (the plugin keeps the five state variables). */
+ * contour (:189-243) follow in smilehip_pitchacf_contour_step. */
 int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
                              double fs_sec, double max_pitch, double *d_voicing, int32_t *d_max_idx, void *stream);
+/* R10, the rest of cPitchACF::processVector (pitchACF.cpp:185-243) for ONE stream, one frame per call, on the device:
+ * F0raw = 1 / (idx * t_samp) in float, the voicing cut-off, one step of the causal F0 contour and the F0 envelope -- the device
+ * function the batch chain's lld_pitch_smooth runs over whole utterances (csrc/lld_pitch_contour.hpp). d_voicing / d_max_idx:
+ * what smilehip_pitchacf_frames wrote for this frame; t_samp = fsSec / (2 n); d_state: 8 words, zeroed before the stream's
+ * first frame, carries the contour across calls; d_out4: F0 (contour), F0raw, F0env, 0. */
+int smilehip_pitchacf_contour_step(smilehip_context *ctx, const double *d_voicing, const int32_t *d_max_idx, double t_samp,
+                                   double voicing_cutoff, float *d_state, float *d_out4, void *stream);
 /* R11: cSpectral::processVector with ComParE_2016's option set (spectral.cpp:586-1560; bands 250-650 and
  * 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope, sharpness,
  * harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1): 15 values per frame, in the reference's

@@ -175,6 +175,7 @@ SYMBOLS = {
     "smilehip_zcr_count_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "smilehip_acf_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "smilehip_pitchacf_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
+    "smilehip_pitchacf_contour_step": (C.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     "smilehip_spectral_frames": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp, _i64, _i64, _vp]),
     "smilehip_plp_audspec_frames": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, _i64,
                                              _i64, _vp]),

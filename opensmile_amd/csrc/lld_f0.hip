@@ -46,7 +46,7 @@ constexpr int kNS = kNC + 1;     // Viterbi states: candidates + "unvoiced"
 template <int LOGM>
 struct F0G {
   static constexpr int kLogM = LOGM, kM = 1 << LOGM, kNfft = 2 * kM, kK = kM + 1, kKP = kM + 4, kPer = (kK + 63) / 64;
-  static constexpr int kNBB = (kKP + 7) / 8;               // 8-bin blocks of a row (65 for K = 513)
+  static constexpr int kNB16 = (kK + 15) / 16;             // 16-bin blocks of a row (33 for K = 513): 64-byte lines of floats
   static constexpr bool kRegFft = LOGM <= 9;                // register-resident transform (lld_ooura_wave.hpp: M = 256 / 512)
   static constexpr bool kLdsTables = LOGM <= 9;             // per-bin tables staged in LDS (above: read through the caches)
   static constexpr int kSpecWaves = LOGM <= 9 ? 4 : (LOGM == 10 ? 2 : 1);   // frames (waves) per workgroup of spec / cand
@@ -131,9 +131,11 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 
 // window + energy, FFT, magnitude, cSpecScale's enhancement and smoothing, and the parallel half of the spline:
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
-template <class G, bool OO, class XIn = PcmIn>         // OO: the reference-order transform (one form per kernel instance: register budget)
+// enh_store (optional): a functor (bin, float) that takes the enhanced magnitudes -- they are floats widened, or zero -- and
+// ends the function there (the chain's lld_f0_spec: smoothing and the spline are lld_f0_sweep's work, one frame per lane)
+template <class G, bool OO, class XIn = PcmIn, class EnhStore = std::nullptr_t>   // OO: the reference-order transform (one form per kernel instance: register budget)
 __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const XIn x, const float *mag_in, int lane,
-                                              double *A, double *B) {
+                                              double *A, double *B, EnhStore enh_store = nullptr) {
   F0_GEO;
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
   double esum = 0.0;
@@ -216,8 +218,10 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     if (cnt >= 2) z = (i > first) && (i < last) && !near;
     else if (cnt == 1) z = i >= 3;
     if (z) mg[m] = 0.0;
-    if (i < kK) B[i] = mg[m];
+    if constexpr (!std::is_same<EnhStore, std::nullptr_t>::value) { if (i < kK) enh_store(i, (float)mg[m]); }
+    else if (i < kK) B[i] = mg[m];
   }
+  if constexpr (!std::is_same<EnhStore, std::nullptr_t>::value) return esum;
   WaveG::sync();
   // smileDsp_specSmoothSHS (smileUtil.c:2004-2014); y = A (the FFT buffers are dead)
   F0_FOR_BINS(m, i) {
@@ -317,9 +321,13 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // the smallest non-zero value's last bit 2^(e_min - 23) satisfies exponent(S) - e_min <= 28, every such partial sum is a
 // multiple of that bit below 2^53 of it -- representable: no addition rounds, all orders give the exact S, and the
 // sequential chain (one lane, 512 dependent additions: a fifth of the kernel's instructions) is not needed.
+// hps_blk != null: the chain's lld_f0_cand -- the octave-scale spectrum of chunk frame hps_fr in lld_f0_sweep's blocked layout
+template <class G>
+__host__ __device__ inline int64_t f0_b16_index(int64_t fr, int i);
 template <class G>
 __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane_in, int64_t g, double *A, double *B, int *ci,
-                                      const float *hps_in, bool only_scale, double *mean_exact = nullptr) {
+                                      const float *hps_in, bool only_scale, double *mean_exact = nullptr,
+                                      const float *hps_blk = nullptr, int64_t hps_fr = 0) {
   F0_GEO;
   // Everything below that depends only on the lane (135 clamped addresses and in-range masks of the harmonic shifts, table
   // addresses ...) is loop-invariant over the frames of a wave, and the compiler keeps all of it in registers across the
@@ -340,7 +348,12 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   float hv[kPer];
   F0_FOR_BINS(m, i) {
     hv[m] = 0.0f;
-    if (hps_in) {
+    if (hps_blk) {
+      if (i < kK) {
+        hv[m] = hps_blk[f0_b16_index<G>(hps_fr, i)];
+        if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = hv[m];
+      }
+    } else if (hps_in) {
       if (i < kK) hv[m] = hps_in[i];
     } else if (i < kK) {
       const int k = T.k[i];
@@ -618,27 +631,53 @@ __global__ void __launch_bounds__(kWaves * 64) lld_f0_frame(LldParams P, F0Param
   }
   PHASE_FLUSH;
 }
-// ---- the chain as three kernels (round 2). The old kernel ran the spline's serial sweeps on one lane per frame with
+// ---- the chain as three kernels. Round 1's single kernel ran the spline's serial sweeps on one lane per frame with
 // three frames per wave: 61 idle lanes for 27 % of its time, and the LDS of three frames per wave capped the occupancy.
-// Now: lld_f0_spec (wave per frame: window .. 6*ut, rows of y and 6*ut to a global scratch), lld_f0_sweep (THREAD per
-// frame: 64 recurrences per wave, table operands by scalar loads), lld_f0_cand (wave per frame: evaluation, summation,
-// top six, mean, candidates). Same device functions, same operation order: results are bit-identical to the one-kernel
-// form, which stays for the per-component operators (mode 1 / 2).
-// 6ut / y2 of frame fr (chunk-local), bin i: the 64 frames of a tile keep each 8-bin block side by side, so that the sweep
-// (one frame per lane) streams 4 KB per block and wave while the wave-per-frame kernels still write / read whole 64-byte
-// lines (8 consecutive bins of one frame)
+// Round 2 split it: lld_f0_spec (wave per frame) -> lld_f0_sweep (THREAD per frame: 64 recurrences per wave, table operands
+// by scalar loads) -> lld_f0_cand (wave per frame), with y, 6*ut, u and y2 as rows of doubles in a global scratch:
+// 33 KB of traffic per frame, the sweep HBM-bound on its four passes over the rows.
+// Round 4: only what cannot be recomputed crosses a kernel boundary, and as floats.
+//   lld_f0_spec   window .. peak enhancement; writes the enhanced magnitudes (floats widened, so floats: 2 KB per frame).
+//   lld_f0_sweep  one frame per lane: smoothing, 6*ut (two double divisions per bin -- per wave instruction that is 64
+//                 frames, the same instruction count as one frame per wave had), the forward recurrence keeping only a
+//                 checkpoint per 16-bin block (264 B per frame); then block by block from the top: the block's u
+//                 again from its checkpoint (16 doubles in registers), the backward recurrence, and -- the target points
+//                 above a source bin are consecutive, their constants wave-uniform -- the spline's evaluation and the
+//                 auditory weighting right there. Writes the octave-scale spectrum as floats (2 KB per frame).
+//                 The recurrences run in the reference's operation order (smileUtilSpline.c:156-199); u and y2 never
+//                 leave the registers.
+//   lld_f0_cand   summation, top six, mean, candidates from those rows.
+// Per frame: 2 KB written + 4 KB read (the magnitudes twice) + 0.5 KB of checkpoints + 2 KB written + 2 KB read = 10.5 KB.
+// Same operations in the same order as the one-kernel form (which stays for the per-component operators, mode 1 / 2):
+// results are bit-identical.
+// Blocked rows: the 64 frames of a tile keep each 16-bin block side by side -- the sweep (lane = frame) moves 4 KB of
+// consecutive memory per block and wave, the wave-per-frame kernels still write / read whole 64-byte lines.
 template <class G>
-__device__ __forceinline__ int64_t f0_bb_index(int64_t fr, int i) {
-  return (((fr >> 6) * G::kNBB + (i >> 3)) * 64 + (fr & 63)) * 8 + (i & 7);
+__host__ __device__ inline int64_t f0_b16_index(int64_t fr, int i) {
+  return (((fr >> 6) * G::kNB16 + (i >> 4)) * 64 + (fr & 63)) * 16 + (i & 15);
+}
+struct F0Scratch {
+  float *mg;       // enhanced magnitudes, blocked
+  float *hp;       // octave-scale spectrum, blocked
+  double *cp;      // [tile][block][frame] value of the forward recurrence on entry to the block
+  double *es;      // [frame] sum of squares of the windowed frame
+};
+template <class G>
+__host__ __device__ inline int64_t f0_scratch_doubles_per_row() { return (int64_t)G::kNB16 * 16 + G::kNB16 + 1; }
+template <class G>
+__device__ __forceinline__ F0Scratch f0_scratch(const F0Params &Q) {
+  F0Scratch S;
+  const int64_t blk = Q.ab_rows * G::kNB16;            // 16-bin blocks of the chunk
+  S.mg = reinterpret_cast<float *>(Q.ab);
+  S.hp = S.mg + blk * 16;
+  S.cp = Q.ab + blk * 16;                              // (2 x blk x 16 floats)
+  S.es = S.cp + blk;
+  return S;
 }
 template <class G>
-__host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // [d1 | d2 |] win | twh | twf
+__host__ __device__ inline size_t f0_spec_shared_bytes(int N) {      // win | twh | twf
   const size_t np = (size_t)((N + 3) & ~3);
-  return (G::kLdsTables ? (size_t)G::kKP * 8 * 2 : 0) + np * 4 + G::kTwBytes;
-}
-template <class G>
-__host__ __device__ inline size_t f0_cand_shared_bytes() {           // a | c | d | audw | k
-  return G::kLdsTables ? (size_t)G::kKP * 8 * 4 + (size_t)G::kKP * 4 : 0;
+  return np * 4 + G::kTwBytes;
 }
 
 template <int LOGM, bool OO, bool S16 = false>         // S16: the instance for 16-bit input (the tuned geometry's fast path)
@@ -650,12 +689,9 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NP = (Q.N + 3) & ~3;
-  double *c_d1 = reinterpret_cast<double *>(smem_f0), *c_d2 = c_d1 + kKP;
-  float *c_win = reinterpret_cast<float *>(G::kLdsTables ? c_d2 + kKP : c_d1);
+  float *c_win = reinterpret_cast<float *>(smem_f0);
   float2 *c_twh = reinterpret_cast<float2 *>(c_win + NP);
   float2 *c_twf = c_twh + kM / 2;
-  if constexpr (G::kLdsTables)
-    for (int i = threadIdx.x; i < kK; i += blockDim.x) { c_d1[i] = Q.sp_d1[i]; c_d2[i] = Q.sp_d2[i]; }
   for (int i = threadIdx.x; i < Q.N; i += blockDim.x) c_win[i] = Q.window[i];
   OouraTab c_oo = OouraTab{};
   if (Q.oo.tw) c_oo = oo_stage_tables(Q.oo, reinterpret_cast<float *>(c_twh), threadIdx.x, blockDim.x);
@@ -666,26 +702,20 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   __syncthreads();
   F0Tbl T = {};
   T.oo = c_oo;
-  if constexpr (G::kLdsTables) { T.d1 = c_d1; T.d2 = c_d2; } else { T.d1 = Q.sp_d1; T.d2 = Q.sp_d2; }
   T.win = c_win; T.twh = c_twh; T.twf = c_twf;
   double *A = reinterpret_cast<double *>(smem_f0 + f0_spec_shared_bytes<G>(Q.N)) + (size_t)wave * 2 * kKP;
   const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
   if (tile >= Q.tile0 + Q.n_tiles_chunk) return;
   const int64_t samp0 = P.tile_rec[tile].samp0;
   const int n_fr = P.tile_rec[tile].n_frames;
+  const F0Scratch S = f0_scratch<G>(Q);
   for (int w = 0; w < n_fr; ++w) {
-    double es;
-    if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
-    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP);
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
-    double *row = Q.ab + fr * kKP;
-    double *bb = Q.ab + Q.ab_rows * kKP;
-#pragma unroll
-    for (int m = 0; m < kPer; ++m) {
-      const int i = lane + 64 * m;
-      if (i < kK) { row[i] = A[i]; bb[f0_bb_index<G>(fr, i)] = A[kKP + i]; }
-    }
-    if (lane == 0) row[kK] = es;                       // the frame's sum of squares rides in the row's padding
+    const auto store = [&](int i, float v) { S.mg[f0_b16_index<G>(fr, i)] = v; };
+    double es;
+    if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store);
+    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store);
+    if (lane == 0) S.es[fr] = es;
     WaveG::sync();
   }
 }
@@ -699,73 +729,164 @@ __global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_spec_g(LldP
   f0_spec_body<LOGM, true>(P, Q);
 }
 
-// the spline's two recurrences, one frame per thread, one 64-frame tile per wave. A round is one 8-bin block: the wave
-// reads / writes 4 KB of consecutive memory (lane = frame: its 64-byte line), the next block's operands are loaded before
-// the current block's chain runs (two register sets alternate; the blocks never overlap, which the compiler cannot know).
+// RN(a / b) for a divisor whose correctly rounded reciprocal y = RN(1 / b) is known (host table): q0 = RN(a y) is within two
+// ulps of the quotient, one residual correction makes it a faithful rounding, and a second one -- Markstein's theorem: y
+// correctly rounded, q faithful, the residual a - b q exact in one FMA -- returns the correctly rounded quotient, which is
+// what the division instruction sequence (and the reference's divsd) returns. Five full-rate operations instead of the
+// ~14 of v_div_scale / v_rcp_f64 / refinement / v_div_fmas / v_div_fixup. No overflow / underflow here: the operands are
+// differences of spectrum magnitudes (floats widened) and products of octave-axis distances, 1e-5 .. 2.
+// tests/test_exact_sum_claims.py runs the same sequence against the division on the tables' divisors.
+__device__ __forceinline__ double f0_div_by(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r0 = __builtin_fma(-q0, b, a);
+  const double q1 = __builtin_fma(r0, y, q0);
+  const double r1 = __builtin_fma(-q1, b, a);
+  return __builtin_fma(r1, y, q1);
+}
+
+// One frame per thread, one 64-frame tile per wave (see the overview above). A round is one 16-bin block: the lane's
+// 64-byte line of magnitudes; the next block's line is requested before the current block's arithmetic. The blocks that
+// touch the ends of the spectrum (bin 0; bins K-2, K-1) carry the reference's boundary cases, the blocks in between are
+// straight-line code (32 divisions whose latencies overlap).
 template <int LOGM>
 __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
   using G = F0G<LOGM>;
   F0_GEO;
-  constexpr int kNBB = G::kNBB;
-  double2 *T2 = reinterpret_cast<double2 *>(Q.ab + Q.ab_rows * kKP) + ((int64_t)blockIdx.x * kNBB * 64 + threadIdx.x) * 4;
-  const double *sp = Q.sp_rec;                         // [K x 4]: sigma_i, p_i, dec_i, 0 -- wave-uniform operands
-  auto blk = [&](int bb) { return T2 + (int64_t)bb * 64 * 4; };
-  auto ld = [&](double2 (&c)[4], int bb) {
+  constexpr int NB = G::kNB16;
+  static_assert((kK - 1) % 16 == 0 && NB == (kK - 1) / 16 + 1 && NB >= 4, "bin K-1 opens the last block");
+  __shared__ float stage[16 * 64];                     // lane-private: the 16 target points of an output line, [point][lane]
+  const int lane = threadIdx.x;
+  const F0Scratch S = f0_scratch<G>(Q);
+  const int64_t lane0 = ((int64_t)blockIdx.x * NB * 64 + lane);
+  const float4 *mg4 = reinterpret_cast<const float4 *>(S.mg) + lane0 * 4;     // block bb: + bb * 256
+  float4 *hp4 = reinterpret_cast<float4 *>(S.hp) + lane0 * 4;
+  double *cp = S.cp + lane0;                                                   // block bb: + bb * 64
+  // the tables are read through the constant address space (read-only for the kernel's lifetime): with wave-uniform
+  // addresses they are scalar loads. Through a global pointer they are not -- the kernel stores to global memory, and a load
+  // that a store might have clobbered stays a vector load (64 lanes fetching the same 8 bytes)
+  typedef const __attribute__((address_space(4))) double *ConstD;
+  typedef const __attribute__((address_space(4))) int32_t *ConstI;
+  const ConstD sw = (ConstD)(uintptr_t)Q.sw_rec;       // [bin][8]: sigma, p, dec, d1, 1/d1, d2, 1/d2, 0
+  const ConstD rec = (ConstD)(uintptr_t)Q.ip_rec;      // [target point][4]: a, c, d, auditory weight
+  const ConstI cnt = (ConstI)(uintptr_t)Q.ip_cnt;      // [NB x 16] target points above source bin j
+  using Edge = std::integral_constant<bool, true>;
+  using Inner = std::integral_constant<bool, false>;
+
+  auto ld = [&](float (&c)[16], int bb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) c[q] = blk(bb)[q];
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = mg4[(int64_t)bb * 256 + q];
+      c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+    }
   };
-  auto st = [&](const double2 (&c)[4], int bb) {
+  // smileDsp_specSmoothSHS (smileUtil.c:2004-2014) for bins 16 bb - 1 .. 16 bb + 16: yv[e + 1] = y[16 bb + e].
+  // lo2: the two magnitudes below the block, hi2: the two above it.
+  auto smooth = [&](auto edge, double (&yv)[18], const float (&lo2)[2], const float (&c)[16], const float (&hi2)[2], int bb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) blk(bb)[q] = c[q];
-  };
-  double up = 0.0;
-  auto fw = [&](double2 (&c)[4], int bb) {             // bins 8 bb .. 8 bb + 7, clipped to 1 .. kK-2
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = 8 * bb + e;
-      if (i >= 1 && i <= kK - 2) {
-        double &v = (e & 1) ? c[e >> 1].y : c[e >> 1].x;
-        up = sp[4 * i + 1] * (v - sp[4 * i] * up);
-        v = up;
+    for (int e = -1; e <= 16; ++e) {
+      const int i = 16 * bb + e;
+      const float fa = (e - 1 < 0) ? lo2[e + 1] : c[(e - 1) & 15];
+      const float fb = (e < 0) ? lo2[1] : (e > 15 ? hi2[0] : c[e & 15]);
+      const float fc = (e + 1 > 15) ? hi2[e - 15] : c[(e + 1) & 15];
+      if constexpr (decltype(edge)::value) {
+        const double lf = (i >= 1 && i < kK) ? (double)fa : 0.0;
+        const double rt = (i < kK - 1) ? (double)fc : 0.0;
+        const double mg = (i >= 0 && i < kK) ? (double)fb : 0.0;
+        yv[e + 1] = (i < kK - 1) ? (lf + 2.0 * mg + rt) / 4.0 : mg;
+      } else {
+        yv[e + 1] = ((double)fa + 2.0 * (double)fb + (double)fc) / 4.0;
       }
     }
-    st(c, bb);
   };
-  constexpr int last_fw = (kK - 2) / 8;                // 63
-  double2 ca[4], cb[4];
-  ld(ca, 0);
-  for (int bb = 0; bb <= last_fw; bb += 2) {
-    if (bb + 1 <= last_fw) ld(cb, bb + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fw(ca, bb);
-    __builtin_amdgcn_sched_barrier(0);
-    if (bb + 2 <= last_fw) ld(ca, bb + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (bb + 1 <= last_fw) fw(cb, bb + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  double yn = 0.0;                                       // y2[K-1] of the natural spline
-  auto bw = [&](double2 (&c)[4], int bb) {             // bins 8 bb + 7 .. 8 bb, clipped to kK-1 (set to 0) .. 0
+  // smileMath_cspline (smileUtilSpline.c:157-212): 6*ut of bin i and one step of the forward recurrence
+  auto fw_block = [&](auto edge, double (&u)[17], const double (&yv)[18], double &up, int bb) {
 #pragma unroll
-    for (int e = 7; e >= 0; --e) {
-      const int j = 8 * bb + e;
-      double &v = (e & 1) ? c[e >> 1].y : c[e >> 1].x;
-      if (j == kK - 1) v = 0.0;
-      else if (j <= kK - 2) { yn = sp[4 * j + 2] * yn + v; v = yn; }
+    for (int e = 0; e < 16; ++e) {
+      const int i = 16 * bb + e;
+      if (!decltype(edge)::value || (i >= 1 && i <= kK - 2)) {
+        const ConstD r = sw + 8 * i;
+        const double s6 = 6.0 * (f0_div_by(yv[e + 2] - yv[e + 1], r[3], r[4]) - f0_div_by(yv[e + 1] - yv[e], r[5], r[6]));
+        up = r[1] * (s6 - r[0] * up);
+        u[e] = up;
+      } else {
+        u[e] = 0.0;
+      }
     }
-    st(c, bb);
   };
-  constexpr int first_bw = (kK - 1) / 8;               // 64: holds bin kK-1 only
-  ld(ca, first_bw);
-  for (int bb = first_bw; bb >= 0; bb -= 2) {
-    if (bb - 1 >= 0) ld(cb, bb - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    bw(ca, bb);
-    __builtin_amdgcn_sched_barrier(0);
-    if (bb - 2 >= 0) ld(ca, bb - 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (bb - 1 >= 0) bw(cb, bb - 1);
-    __builtin_amdgcn_sched_barrier(0);
+
+  // ---- pass 1: the forward recurrence, keeping its value on entry to every block
+  {
+    float ca[16], cb[16], lo2[2] = {0.0f, 0.0f}, hi2[2];
+    double yv[18], u[17];
+    double up = 0.0;
+    ld(ca, 0);
+    for (int bb = 0; bb < NB; ++bb) {
+      if (bb + 1 < NB) { ld(cb, bb + 1); hi2[0] = cb[0]; hi2[1] = cb[1]; } else { hi2[0] = 0.0f; hi2[1] = 0.0f; }
+      cp[(int64_t)bb * 64] = up;
+      if (bb == 0 || bb >= NB - 2) { smooth(Edge{}, yv, lo2, ca, hi2, bb); fw_block(Edge{}, u, yv, up, bb); }
+      else { smooth(Inner{}, yv, lo2, ca, hi2, bb); fw_block(Inner{}, u, yv, up, bb); }
+      lo2[0] = ca[14]; lo2[1] = ca[15];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ca[q] = cb[q];
+    }
+  }
+  // ---- pass 2, blocks from the top: u of the block again, the backward recurrence, the target points above its bins
+  {
+    float ca[16], cb[16], lo2[2], hi2[2] = {0.0f, 0.0f};
+    double yv[18], u[17];
+    double yn = 0.0;                                     // y2[K-1] of the natural spline
+    double y2_above = 0.0;                               // y2 of the bin above the block
+    int io = kK - 1;                                     // next target point (they come in descending order)
+    double ra = rec[4 * io], rc = rec[4 * io + 1], rd = rec[4 * io + 2], rw = rec[4 * io + 3];   // its constants, one point ahead
+    ld(ca, NB - 1);
+    double up = cp[(int64_t)(NB - 1) * 64];
+    for (int bb = NB - 1; bb >= 0; --bb) {
+      double up_next = 0.0;
+      if (bb > 0) { ld(cb, bb - 1); lo2[0] = cb[14]; lo2[1] = cb[15]; up_next = cp[(int64_t)(bb - 1) * 64]; }
+      else { lo2[0] = 0.0f; lo2[1] = 0.0f; }
+      int n16[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) n16[e] = cnt[16 * bb + e];
+      const bool edge = bb == 0 || bb >= NB - 2;
+      if (edge) { smooth(Edge{}, yv, lo2, ca, hi2, bb); fw_block(Edge{}, u, yv, up, bb); }
+      else { smooth(Inner{}, yv, lo2, ca, hi2, bb); fw_block(Inner{}, u, yv, up, bb); }
+      u[16] = y2_above;
+#pragma unroll
+      for (int e = 15; e >= 0; --e) {
+        const int j = 16 * bb + e;
+        if (!edge || j <= kK - 2) { yn = sw[8 * j + 2] * yn + u[e]; u[e] = yn; }
+        else u[e] = 0.0;                                 // bin K-1: y2 = 0; the bins above it do not exist
+      }
+      // smileMath_csplint + auditory weighting (specScale.cpp:340-353) of the target points whose lower source bin is j
+#pragma unroll
+      for (int e = 15; e >= 0; --e) {
+        for (int q = 0; q < n16[e]; ++q) {
+          const double a = ra, c = rc, d = rd, aw = rw;
+          const int ip = io > 0 ? io - 1 : 0;
+          ra = rec[4 * ip]; rc = rec[4 * ip + 1]; rd = rec[4 * ip + 2]; rw = rec[4 * ip + 3];
+          const double b = 1.0 - a;
+          const double o = a * yv[e + 1] + b * yv[e + 2] + c * u[e] + d * u[e + 1];
+          float v = (float)o;
+          v = (v > 0.0f) ? (float)((double)v * aw) : 0.0f;
+          stage[(io & 15) * 64 + lane] = v;
+          if ((io & 15) == 0) {                          // the line is complete
+            float4 l4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              l4[r] = make_float4(stage[(4 * r) * 64 + lane], stage[(4 * r + 1) * 64 + lane], stage[(4 * r + 2) * 64 + lane],
+                                  stage[(4 * r + 3) * 64 + lane]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp4[(int64_t)(io >> 4) * 256 + r] = l4[r];
+          }
+          --io;
+        }
+      }
+      y2_above = u[0];
+      hi2[0] = ca[0]; hi2[1] = ca[1];
+      up = up_next;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ca[q] = cb[q];
+    }
   }
 }
 
@@ -778,44 +899,23 @@ __global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_cand(LldPar
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f0[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double *c_a = reinterpret_cast<double *>(smem_f0), *c_c = c_a + kKP, *c_d = c_c + kKP, *c_audw = c_d + kKP;
-  int *c_k = reinterpret_cast<int *>(c_audw + kKP);
-  F0Tbl T = {};
-  if constexpr (G::kLdsTables) {
-    for (int i = threadIdx.x; i < kK; i += blockDim.x) {
-      c_a[i] = Q.ip_co[3 * i]; c_c[i] = Q.ip_co[3 * i + 1]; c_d[i] = Q.ip_co[3 * i + 2];
-      c_audw[i] = Q.audw[i];
-      c_k[i] = Q.ip_k[i];
-    }
-    __syncthreads();
-    T.a = c_a; T.c = c_c; T.d = c_d; T.audw = c_audw; T.k = c_k;
-  } else {                                               // the tables stay in global memory (a | c | d: Q.ip_co, read in f0_shs)
-    T.audw = Q.audw; T.k = Q.ip_k;
-  }
-  unsigned char *base = smem_f0 + f0_cand_shared_bytes<G>() + (size_t)wave * kFrameBytes;
+  const F0Tbl T = {};                                    // (the spline's tables are lld_f0_sweep's business)
+  unsigned char *base = smem_f0 + (size_t)wave * kFrameBytes;
   double *A = reinterpret_cast<double *>(base);
   int *ci = reinterpret_cast<int *>(A + 2 * kKP);
   const int tile = Q.tile0 + blockIdx.x * kSpecWaves + wave;
   if (tile >= Q.tile0 + Q.n_tiles_chunk) return;
   const int64_t row0 = P.tile_rec[tile].row0;
   const int n_fr = P.tile_rec[tile].n_frames;
+  const F0Scratch S = f0_scratch<G>(Q);
   PHASE_DECL
   for (int w = 0; w < n_fr; ++w) {
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
-    const double *row = Q.ab + fr * kKP;
-    const double *bb = Q.ab + Q.ab_rows * kKP;
-#pragma unroll
-    for (int m = 0; m < kPer; ++m) {
-      const int i = lane + 64 * m;
-      if (i < kK) { A[i] = row[i]; A[kKP + i] = bb[f0_bb_index<G>(fr, i)]; }
-    }
-    const double es = row[kK];
-    WaveG::sync();
-    PHASE(0);   // rows from global
+    const double es = S.es[fr];
     double mean = 0.0;
-    const int nf = f0_shs<G>(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean);
+    const int nf = f0_shs<G>(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean, S.hp, fr);
     WaveG::sync();
-    PHASE(2);   // interpolation, summation, top six
+    PHASE(2);   // rows from global, summation, top six
     if (mean != mean) {                                  // (wave-uniform) no exactness guarantee: the reference's chain
       if (lane == 0) mean = f0_mean_serial<G>(A + kKP);
       mean = wave_first_d(mean);
@@ -1554,7 +1654,8 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
   if (!f0_shifts_fit<G>(Q0)) return hipErrorInvalidValue;
   constexpr int kSpecWaves = G::kSpecWaves;
   const size_t lds_spec = f0_spec_shared_bytes<G>(Q0.N) + (size_t)kSpecWaves * 2 * G::kKP * sizeof(double);
-  const size_t lds_cand = f0_cand_shared_bytes<G>() + (size_t)kSpecWaves * G::kFrameBytes;
+  const size_t lds_cand = (size_t)kSpecWaves * G::kFrameBytes;
+  if (!Q0.ip_rec || !Q0.ip_cnt || !Q0.sw_rec) return hipErrorInvalidValue;
   const bool oo = Q0.oo.tw != nullptr;
   if (!oo && LOGM != 9) return hipErrorInvalidValue;     // SMILEHIP_FFT=radix2 (the A/B switch) exists for FFT 1024 only
   const void *spec;
@@ -1621,9 +1722,9 @@ int64_t f0_scratch_rows(int64_t n_tiles) {                // rows of a chunk, a 
   const int64_t t = n_tiles < f0_chunk_tiles() ? n_tiles : f0_chunk_tiles();
   return (t * kTileFrames + 63) / 64 * 64;
 }
-int64_t f0_scratch_doubles(int64_t n_tiles, int K) {      // y rows [K + 3] + the 6ut / y2 blocks [ceil((K + 3) / 8) x 8]
-  const int64_t kp = K + 3;
-  return f0_scratch_rows(n_tiles) * (kp + (kp + 7) / 8 * 8);
+int64_t f0_scratch_doubles(int64_t n_tiles, int K) {      // F0Scratch: two blocked float rows, the checkpoints, the sum of squares
+  const int64_t nb = (K + 15) / 16;
+  return f0_scratch_rows(n_tiles) * (nb * 16 + nb + 1);
 }
 
 

@@ -18,6 +18,7 @@
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
+#include "lld_pitch_contour.hpp"
 
 namespace smilehip {
 
@@ -237,43 +238,40 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
   else is09_frame_body<WaveG>(P, Q, T, row, wave_mem);
 }
 
-// R10, sequential part: cPitchACF's causal contour smoother (pitchACF.cpp:199-243), state
-// per utterance (lastPitch, lastlastPitch, glMeanPitch, onsFlag). One thread per utterance.
+// R10, sequential part: cPitchACF's causal contour (lld_pitch_contour.hpp), state per utterance. One thread per utterance.
 __global__ void __launch_bounds__(64) lld_pitch_smooth(const int64_t *frame_off, int n_utt, float *raw16) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_utt) return;
   const int64_t f0 = frame_off[u];
   const int64_t T = frame_off[u + 1] - f0;
-  float lastPitch = 0.0f, lastlastPitch = 0.0f, glMeanPitch = 0.0f;
-  int onsFlag = 0;
+  PitchContour S = {};
   for (int64_t t = 0; t < T; ++t) {
     float *cell = raw16 + (f0 + t) * 16 + 15;
-    float pitch = *cell;
-    if ((lastPitch == 0.0f) && (pitch > 0.0f)) onsFlag = 1;
-    if ((lastPitch > 0.0f) && (pitch == 0.0f) && (onsFlag == 0)) onsFlag = -1;
-    if ((lastPitch > 0.0f) && (pitch > 0.0f)) onsFlag = 0;
-    if ((lastPitch == 0.0f) && (pitch == 0.0f)) onsFlag = 0;
-    if ((pitch == 0.0f) && (onsFlag == 1)) lastPitch = 0.0f;
-    const float oPitch = pitch;
-    const float tol = 0.4f;
-    float alpha = 0.3f;
-    if (pitch > 0.0f) {
-      if (glMeanPitch == 0.0f) glMeanPitch = pitch;
-      if (!((pitch < (1.0f + tol) * glMeanPitch) && (pitch > (1.0f - tol) * glMeanPitch))) {
-        pitch = glMeanPitch;
-        alpha /= 3.0f;
-      }
-      if (onsFlag && (lastPitch > pitch)) lastPitch *= 0.85f;
-    }
-    if ((pitch > 0.0f) && (onsFlag == -1)) lastPitch = pitch;
-    if (oPitch > 0.0f) glMeanPitch = (1.0f - alpha) * glMeanPitch + alpha * oPitch;
-    float o;
-    if ((lastlastPitch != 0.0f) && (lastPitch != 0.0f)) o = 0.5f * (lastlastPitch + lastPitch);
-    else o = lastPitch;
-    *cell = o;
-    lastlastPitch = lastPitch;
-    lastPitch = pitch;
+    *cell = pitch_contour_step(S, *cell);
   }
+}
+
+// The same contour for ONE stream, a frame per launch (the plugin's cPitchACF override): F0 = 1 / (idx * Tsamp) in float
+// (pitchACF.cpp:185-192), the voicing cut-off, one step of the contour. out4: F0 (contour), F0raw, F0env, 0.
+__global__ void __launch_bounds__(64) lld_pitch_contour_step(const double *voicing, const int32_t *max_idx, double Tsamp, double cutoff,
+                                                             PitchContour *state, float *out4) {
+  if (threadIdx.x != 0) return;
+  PitchContour S = *state;
+  const int idx = *max_idx;
+  float raw = 0.0f;
+  if (idx > 0) raw = 1.0f / ((float)idx * (float)Tsamp);
+  const float p = (*voicing < cutoff) ? 0.0f : raw;
+  out4[0] = pitch_contour_step(S, p);
+  out4[1] = raw;
+  out4[2] = S.env;
+  out4[3] = 0.0f;
+  *state = S;
+}
+hipError_t launch_pitch_contour_step(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
+                                     float *d_out4, hipStream_t s) {
+  hipLaunchKernelGGL(lld_pitch_contour_step, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
+                     reinterpret_cast<PitchContour *>(d_state), d_out4);
+  return hipGetLastError();
 }
 
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {

@@ -53,6 +53,9 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s);
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
+// cPitchACF's F0 contour for one stream, a frame per launch (lld_pitch_contour.hpp); d_state: 8 words, zeroed before the first frame
+hipError_t launch_pitch_contour_step(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
+                                     float *d_out4, hipStream_t s);
 hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s);
 hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n_runs, hipStream_t s);
 hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const GemapsParams &G, int max_blocks, hipStream_t s);

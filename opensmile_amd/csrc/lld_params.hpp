@@ -126,6 +126,9 @@ struct F0Params {
   const int32_t *ip_k;              // [K] lower source bin of target point i (smileMath_csplint_init, :296-342)
   const double *ip_co;              // [K x 3] a, c, d of target point i
   const double *audw;               // [K] auditory weighting (specScale.cpp:279-287)
+  const double *ip_rec;             // [K x 4] a, c, d, audw of target point i as one record (lld_f0_sweep's scalar loads)
+  const int32_t *ip_cnt;            // [ceil(K / 16) x 16] target points whose lower source bin is k (zero beyond K - 2)
+  const double *sw_rec;             // [K x 8] per bin: sigma, p, dec, d1, RN(1 / d1), d2, RN(1 / d2), 0 (lld_f0_sweep: one record)
   // cPitchShs
   int32_t n_harm;
   int32_t shift[16];                // shift[i-2] for harmonic i = 2..n_harm
@@ -145,8 +148,9 @@ struct F0Params {
   float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
   // per-component operators (mode 1: cSpecScale rows -> hps_tap, mode 2: cPitchShs rows -> shs)
   int32_t mode;
-  double *ab;                       // chain mode, between the three frame kernels: y rows [chunk frames x 516] (row-major), then
-                                    // 6ut -> y2 in blocks [64-frame tile][8-bin block (65)][frame (64)][bin in block (8)]
+  double *ab;                       // chain mode, between the three frame kernels (lld_f0.hip, F0Scratch): the enhanced magnitudes
+                                    // and the octave-scale spectrum as floats in blocks [64-frame tile][16-bin block][frame (64)][bin in
+                                    // block (16)], the sweep's checkpoints [tile][block][frame], the frames' sums of squares
   int64_t ab_rows;                  // rows the scratch holds (a multiple of 64)
   int32_t tile0, n_tiles_chunk;     // the tiles [tile0, tile0 + n_tiles_chunk) this launch works on
   int64_t n_rows;

@@ -509,6 +509,7 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.oo = plan->fft_radix2 ? OouraTab{} : plan->oo.tab();
   Q.sp_rec = plan->d_f0_rec.p; Q.sp_d1 = plan->d_f0_d1.p; Q.sp_d2 = plan->d_f0_d2.p;
   Q.ip_k = plan->d_f0_k.p; Q.ip_co = plan->d_f0_co.p; Q.audw = plan->d_f0_audw.p;
+  Q.ip_rec = plan->d_f0_iprec.p; Q.ip_cnt = plan->d_f0_ipcnt.p; Q.sw_rec = plan->d_f0_swrec.p;
   Q.n_harm = plan->f0.n_harm;
   for (int i = 0; i < 16; ++i) { Q.shift[i] = plan->f0.shift[i]; Q.scale[i] = plan->f0.scale[i]; }
   Q.Fmint = plan->f0.Fmint; Q.Fstept = plan->f0.Fstept;

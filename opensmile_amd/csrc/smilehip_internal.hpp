@@ -130,7 +130,8 @@ struct smilehip_plan {
   hipEvent_t ev_bg_fork = nullptr, ev_bg_join = nullptr;   // the 20 ms chain and cHarmonics
   F0Host f0;
   DevBuf<double> d_f0_rec, d_f0_d1, d_f0_d2, d_f0_co, d_f0_audw;
-  DevBuf<int32_t> d_f0_k;
+  DevBuf<double> d_f0_iprec, d_f0_swrec;
+  DevBuf<int32_t> d_f0_k, d_f0_ipcnt;
   float rasta_iir = 0.f, rasta_fir[5] = {0, 0, 0, 0, 0};
   // eGeMAPS chain: cSpecResample's tables (transposed), cSpectral's band-slope edges and frequency range
   DevBuf<float> d_rs_cos, d_rs_sin;

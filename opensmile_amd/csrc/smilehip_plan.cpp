@@ -283,7 +283,8 @@ static int build_tables(smilehip_plan *p, bool upload = true) {
     return rc;
   if (p->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 &&
       ((rc = p->d_f0_rec.upload(p->f0.sp_rec)) || (rc = p->d_f0_d1.upload(p->f0.sp_d1)) || (rc = p->d_f0_d2.upload(p->f0.sp_d2)) ||
-       (rc = p->d_f0_co.upload(p->f0.ip_co)) || (rc = p->d_f0_audw.upload(p->f0.audw)) || (rc = p->d_f0_k.upload(p->f0.ip_k))))
+       (rc = p->d_f0_co.upload(p->f0.ip_co)) || (rc = p->d_f0_audw.upload(p->f0.audw)) || (rc = p->d_f0_k.upload(p->f0.ip_k)) ||
+       (rc = p->d_f0_iprec.upload(p->f0.ip_rec)) || (rc = p->d_f0_swrec.upload(p->f0.sw_rec)) || (rc = p->d_f0_ipcnt.upload(p->f0.ip_cnt))))
     return rc;
   if (p->cfg.vit_buffer_len < 0 || p->cfg.vit_buffer_len == 1 || p->cfg.vit_buffer_len > 128)
     return fail(SMILEHIP_ERR_INVALID, "vit_buffer_len must be 0 (= 30) or 2..128");

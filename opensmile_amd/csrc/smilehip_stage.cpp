@@ -116,6 +116,13 @@ extern "C" int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_sr
   STAGE_RET(stage_pitchacf(d_src, ld_src, n_frames, (int)n, fs_sec, max_pitch, d_voicing, d_max_idx, (hipStream_t)stream), "pitchacf");
 }
 
+extern "C" int smilehip_pitchacf_contour_step(smilehip_context *ctx, const double *d_voicing, const int32_t *d_max_idx, double t_samp,
+                                              double voicing_cutoff, float *d_state, float *d_out4, void *stream) {
+  if (!ctx || !d_voicing || !d_max_idx || !d_state || !d_out4 || !(t_samp > 0.0))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_contour_step: bad argument");
+  STAGE_RET(launch_pitch_contour_step(d_voicing, d_max_idx, t_samp, voicing_cutoff, d_state, d_out4, (hipStream_t)stream), "pitchacf contour");
+}
+
 extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, int64_t ld_src, float *d_state, int first,
                                         float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null plan");

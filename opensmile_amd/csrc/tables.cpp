@@ -282,6 +282,24 @@ int make_f0_tables(int64_t K, double fft_frame_size_sec, int n_harmonics, float 
   const double atan_s = nPPO * (std::log(65.0 / 50.0) / l2) - 1.0;
   h.audw.assign(size_t(K), 0.0);
   for (int64_t i = 0; i < K; ++i) h.audw[i] = 0.5 + std::atan(3.0 * ((double)i + 1 - atan_s) / nPPO) / M_PI;
+  // the same constants as the thread-per-frame sweep reads them: one record per target point, and how many target
+  // points sit above each source bin (the search above only moves `hi` up: ip_k is non-decreasing)
+  h.ip_rec.assign(size_t(K) * 4, 0.0);
+  h.ip_cnt.assign(size_t((K + 15) / 16 * 16), 0);
+  h.sw_rec.assign(size_t(K) * 8, 0.0);
+  for (int64_t i = 0; i < K; ++i) {
+    h.sw_rec[8 * i + 0] = h.sp_rec[4 * i + 0]; h.sw_rec[8 * i + 1] = h.sp_rec[4 * i + 1]; h.sw_rec[8 * i + 2] = h.sp_rec[4 * i + 2];
+    h.sw_rec[8 * i + 3] = h.sp_d1[i]; h.sw_rec[8 * i + 4] = 1.0 / h.sp_d1[i];
+    h.sw_rec[8 * i + 5] = h.sp_d2[i]; h.sw_rec[8 * i + 6] = 1.0 / h.sp_d2[i];
+  }
+  for (int64_t i = 0; i < K; ++i) {
+    h.ip_rec[4 * i + 0] = h.ip_co[3 * i + 0];
+    h.ip_rec[4 * i + 1] = h.ip_co[3 * i + 1];
+    h.ip_rec[4 * i + 2] = h.ip_co[3 * i + 2];
+    h.ip_rec[4 * i + 3] = h.audw[i];
+    if (i > 0 && h.ip_k[i] < h.ip_k[i - 1]) return SMILEHIP_ERR_INVALID;
+    h.ip_cnt[h.ip_k[i]] += 1;
+  }
   // what cPitchShs sees: FLOAT_DMEM meta data
   const float m_fmin = (float)minF, m_ppo = (float)nPPO, m_fmint = (float)fmin_t, m_fmaxt = (float)fmax_t;
   double base = std::exp(std::log((double)m_fmin) / (double)m_fmint);

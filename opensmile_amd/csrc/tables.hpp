@@ -43,6 +43,9 @@ struct DctTables {
 struct F0Host {
   std::vector<double> sp_rec, sp_d1, sp_d2, ip_co, audw;
   std::vector<int32_t> ip_k;
+  std::vector<double> ip_rec;     // [K x 4] a, c, d, auditory weight of target point i: one 32-byte record (lld_f0_sweep)
+  std::vector<int32_t> ip_cnt;    // [ceil(K / 16) x 16] target points whose lower source bin is k (ip_k is non-decreasing: they are consecutive)
+  std::vector<double> sw_rec;     // [K x 8] sigma, p, dec, d1, RN(1 / d1), d2, RN(1 / d2), 0
   int32_t n_harm = 15;
   int32_t shift[16] = {0};
   float scale[16] = {0};

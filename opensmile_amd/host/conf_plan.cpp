@@ -318,8 +318,10 @@ uint64_t conf_fingerprint_masked(const ConfFile &f) {
     eat(i.name + ":" + i.type);
     std::vector<std::pair<std::string, std::string>> o = i.opts;
     std::sort(o.begin(), o.end());
+    // a parameter's VALUE is masked, its presence is not: a file that leaves the line out gets the component's own default
+    // from the reference (pitchJitter.cpp:47/77, pitchSmootherViterbi.cpp:42 ...), not the shipped file's value
     for (const auto &kv : o)
-      if (!conf_is_f0_param(i, kv.first)) eat(kv.first + "=" + canonical_value(kv.second));
+      eat(conf_is_f0_param(i, kv.first) ? kv.first + "=<parameter>" : kv.first + "=" + canonical_value(kv.second));
   }
   return h;
 }
@@ -339,7 +341,8 @@ uint64_t conf_fingerprint_masked2(const ConfFile &f) {
     std::vector<std::pair<std::string, std::string>> o = i.opts;
     std::sort(o.begin(), o.end());
     for (const auto &kv : o)
-      if (!conf_is_f0_param(i, kv.first) && !conf_is_selection_param(i, kv.first)) eat(kv.first + "=" + canonical_value(kv.second));
+      eat((conf_is_f0_param(i, kv.first) || conf_is_selection_param(i, kv.first)) ? kv.first + "=<parameter>"
+                                                                                  : kv.first + "=" + canonical_value(kv.second));
   }
   return h;
 }
@@ -365,15 +368,15 @@ struct KnownSet { uint64_t fingerprint; const char *set; const char *file; uint6
 // config/egemaps/v02/eGeMAPSv02.conf (and its two sub-graphs, GeMAPSv01b.conf / eGeMAPSv01b.conf) with their includes and every command-line option at its default
 const KnownSet kKnownSets[] = {
     {0x84b42d91f07908acull, "is09_emotion", "IS09_emotion.conf", 0},
-    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf", 0x27e03c47ce1ea38aull, 0x99ecb9b8c6a4f3deull},
-    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf", 0x7d6ca59726bab51dull, 0xaf784385ddd585c9ull},
-    {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf", 0x0a4014c8c2747c7aull},
+    {0x9c0cc5d423cf1caeull, "compare16", "ComParE_2016.conf", 0xfae69d014d0dfa60ull, 0x4f1f91fabefddeebull},
+    {0xb409f82a744a62d2ull, "is13_compare", "IS13_ComParE.conf", 0x5a6b988a3b68a67full, 0xfe35c75d8b8a8138ull},
+    {0xcb39106ceca6480cull, "egemapsv02", "eGeMAPSv02.conf", 0xb17c462e03023f64ull},
     // sub-graphs of eGeMAPSv02.conf: their levels are column subsets of its levels (smilehip_host.hpp, egemaps_subset_columns)
-    {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf", 0xd9d453405c7cfe69ull},
-    {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf", 0x4bea506faa49e282ull},
+    {0x07901132e1b570f7ull, "gemapsv01b", "GeMAPSv01b.conf", 0xc9092680fbe30c4full},
+    {0xe0e523408610f510ull, "egemapsv01b", "eGeMAPSv01b.conf", 0x3cde1ce6e1776678ull},
     // the v01a files: the same sub-graphs with zeroPadSymmetric = 0, useBrokenJitterThresh = 1, maxF = 5500 (smilehip_config_egemapsv01a)
-    {0x54c6dceabc3deb6full, "gemapsv01a", "GeMAPSv01a.conf", 0x903089c642c22b56ull},
-    {0x378e8dfc3678ce85ull, "egemapsv01a", "eGeMAPSv01a.conf", 0x554f699baa400cd4ull},
+    {0x54c6dceabc3deb6full, "gemapsv01a", "GeMAPSv01a.conf", 0x20e46a265c0b88beull},
+    {0x378e8dfc3678ce85ull, "egemapsv01a", "eGeMAPSv01a.conf", 0x6956ca30c993252cull},
 };
 }  // namespace
 
@@ -424,19 +427,39 @@ bool conf_check_io(const ConfFile &f, const std::set<std::string> &produced, std
       }
     }
     const bool on_func = lv && *lv == "func";
-    // option -> the one value the writers of opensmile_amd/host/sinks.cpp implement for this kind of sink
-    std::vector<std::pair<std::string, double>> fixed;
-    if (i.type == "cCsvSink") fixed = {{"timestamp", 1}, {"frameTime", 1}, {"printHeader", 1}, {"number", 0}, {"frameIndex", 0}, {"append", on_func ? 1.0 : 0.0}};
-    if (i.type == "cArffSink") fixed = {{"frameIndex", 0}, {"frameTime", on_func ? 0.0 : 1.0}, {"timestamp", on_func ? 0.0 : 1.0}, {"frameTimeAdd", 0}, {"append", 1}};
-    if (i.type == "cHtkSink") fixed = {{"append", 0}};
-    for (const auto &kv : fixed) {
-      const std::string *v = i.find(kv.first);
-      if (v && !num_is(*v, kv.second)) {
-        err = "[" + i.name + ":" + i.type + "] " + kv.first + " = " + *v + " is not implemented by smilextract_hip's writer (only " + kv.first +
-              " = " + canonical_value(std::to_string(kv.second)) + ")";
+    // The values the sink would run with -- the option if the file sets it, else the component's own default (csvSink.cpp:43-51,
+    // 95-104; arffSink.cpp:42-51, 104-120; htkSink.cpp:33-37), `frameIndex` / `frameTime` overriding their synonyms `number` /
+    // `timestamp` when set -- against the one value the writers of opensmile_amd/host/sinks.cpp implement for this kind of sink.
+    auto value_of = [&](const char *key, double dflt, bool &bad) {
+      const std::string *v = i.find(key);
+      if (!v) return dflt;
+      char *end = nullptr;
+      const double d = strtod(v->c_str(), &end);
+      if (end == v->c_str()) { bad = true; return dflt; }
+      return d;
+    };
+    struct Want { const char *what; double has; double implemented; };
+    std::vector<Want> wants;
+    bool bad = false;
+    const double number = i.find("frameIndex") ? value_of("frameIndex", 1, bad) : value_of("number", 1, bad);
+    const double stamp = i.find("frameTime") ? value_of("frameTime", 1, bad) : value_of("timestamp", 1, bad);
+    if (i.type == "cCsvSink")
+      wants = {{"timestamp / frameTime", stamp, 1}, {"printHeader", value_of("printHeader", 1, bad), 1}, {"number / frameIndex", number, 0},
+               {"frameLength", value_of("frameLength", 0, bad), 0}, {"lag", value_of("lag", 0, bad), 0},
+               {"append", value_of("append", 0, bad), on_func ? 1.0 : 0.0}};
+    if (i.type == "cArffSink")
+      wants = {{"number / frameIndex", number, 0}, {"timestamp / frameTime", stamp, on_func ? 0.0 : 1.0},
+               {"frameTimeAdd", value_of("frameTimeAdd", 0, bad), 0}, {"frameLength", value_of("frameLength", 0, bad), 0},
+               {"lag", value_of("lag", 0, bad), 0}, {"append", value_of("append", 0, bad), 1}};
+    if (i.type == "cHtkSink") wants = {{"append", value_of("append", 0, bad), 0}, {"lag", value_of("lag", 0, bad), 0}};
+    if (bad) { err = "[" + i.name + ":" + i.type + "] has a numeric option that does not parse"; return false; }
+    for (const Want &w : wants)
+      if (!((w.has != 0) == (w.implemented != 0)) || (std::string(w.what) == "frameTimeAdd" && w.has != w.implemented) ||
+          (std::string(w.what) == "lag" && w.has != w.implemented)) {
+        err = "[" + i.name + ":" + i.type + "] " + w.what + " = " + canonical_value(std::to_string(w.has)) + (i.find(w.what) ? "" : " (the component's default where the file is silent)") +
+              " is not implemented by smilextract_hip's writer (only " + canonical_value(std::to_string(w.implemented)) + ")";
         return false;
       }
-    }
     if (i.type == "cArffSink" && !on_func) {
       err = "[" + i.name + ":cArffSink] an ARFF file of the LLD level (-lldarffoutput) is not implemented by smilextract_hip";
       return false;

@@ -930,17 +930,20 @@ class cHipAcf : public cAcf {
   }
 };
 
-// R10  cPitchACF::processVector  (src/lldcore/pitchACF.cpp:137-247): voicing probability and the
-// cepstral peak index come from the device; F0, the voicing cut-off and the causal contour
-// smoother are the reference's scalar code on this object's own copy of the five state variables
+// R10  cPitchACF::processVector  (src/lldcore/pitchACF.cpp:137-247), all of it on the device: the voicing probability and the
+// cepstral peak (smilehip_pitchacf_frames), then F0, the voicing cut-off, the causal F0 contour and its envelope
+// (smilehip_pitchacf_contour_step -- the device function the batch chain runs, its state in device memory). The host side
+// only maps the harmonics-to-noise ratio of two ACF values it already holds onto the three HNR scales (:310-361).
 class cHipPitchACF : public cPitchACF {
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
-  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, onsFlag_ = 0, HNR_ = 0, HNRdB_ = 0, linHNR_ = 0, voiceQual_ = 0;
+  bool state_ready_ = false;
+  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, HNR_ = 0, HNRdB_ = 0, linHNR_ = 0, voiceQual_ = 0;
   double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
-  FLOAT_DMEM lastPitch_ = 0, lastlastPitch_ = 0, glMeanPitch_ = 0, pitchEnv_ = 0;
   float fsSec_ = -1.0f;
+  // device result block: voicing | peak index | ACF zero-crossing rate | F0, F0raw, F0env, 0 | contour state (8 words)
+  struct Result { double voicing; int32_t idx; int32_t pad; double acfZcr; float f0[4]; float state[8]; };
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE((int)Ndst);
@@ -959,76 +962,42 @@ class cHipPitchACF : public cPitchACF {
     if (N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: the input is not [acf | cepstrum] of equal, even size"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
-    unsigned char *r = (unsigned char *)res_.ensure(24);
-    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)r, (int32_t *)(r + 8), nullptr));
-    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + 16), nullptr));
-    struct { double voicing; int32_t idx; int32_t pad; double acfZcr; } h;
-    h.acfZcr = 0.0;
-    res_.down(&h, voiceQual_ ? 24 : 16);
-    const double voicing = h.voicing;
-    long maxIdx = h.idx;
+    unsigned char *r = (unsigned char *)res_.ensure(sizeof(Result));
+    if (!state_ready_) {                                 // a stream starts with an all-zero contour
+      const Result zero = {};
+      check(smilehip_copy_to_device(context(), r, &zero, sizeof(Result), nullptr));
+      state_ready_ = true;
+    }
     const double Tsamp = fsSec_ / (double)Nsrc;
+    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, voicing)),
+                                   (int32_t *)(r + offsetof(Result, idx)), nullptr));
+    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, acfZcr)), nullptr));
+    const bool contour = F0_ || F0env_ || F0raw_ || voiceQual_;
+    if (contour)
+      check(smilehip_pitchacf_contour_step(context(), (const double *)(r + offsetof(Result, voicing)), (const int32_t *)(r + offsetof(Result, idx)),
+                                           Tsamp, voicingCutoff_, (float *)(r + offsetof(Result, state)), (float *)(r + offsetof(Result, f0)), nullptr));
+    Result h = {};
+    res_.down(&h, offsetof(Result, state));
+    const long peak = h.idx;
     int n = 0;
-    if (voiceProb_) dst[n++] = (FLOAT_DMEM)voicing;
-    // computeHNR / computeHNR_dB / computeHNR_lin (pitchACF.cpp:310-361): scalar expressions on acf[0] and acf[maxIdx]
-    if (HNR_) {
-      double buf;
-      if ((src[0] - src[maxIdx]) == 0.0) buf = 100000000000000000000.0;
-      else buf = src[maxIdx] / (src[0] - src[maxIdx]);
-      dst[n++] = (FLOAT_DMEM)((buf > 0.00000000001) ? 10.0 * log(buf) : 10.0 * log(0.00000000001));
+    if (voiceProb_) dst[n++] = (FLOAT_DMEM)h.voicing;
+    if (HNR_ || HNRdB_ || linHNR_) {
+      // harmonics-to-noise ratio acf[peak] / (acf[0] - acf[peak]) (float arithmetic), `pure` where the denominator vanishes;
+      // natural-log scale floored at 1e-11, dB scale limited to -100 .. 100, linear scale limited to 1e-2 .. 1e4
+      const FLOAT_DMEM noise = src[0] - src[peak];
+      const auto ratio = [&](double pure) { return noise == 0.0 ? pure : (double)(src[peak] / noise); };
+      if (HNR_) { const double q = ratio(1e20); dst[n++] = (FLOAT_DMEM)(10.0 * log(q > 0.00000000001 ? q : 0.00000000001)); }
+      if (HNRdB_) { const double q = ratio(10e10); dst[n++] = (FLOAT_DMEM)(q <= 10e-10 ? -100.0 : (q >= 10e10 ? 100.0 : 10.0 * log(q) / log(10.0))); }
+      if (linHNR_) { const double q = ratio(10e3); dst[n++] = (FLOAT_DMEM)(q <= 10e-3 ? 10e-3 : (q >= 10e3 ? 10e3 : q)); }
     }
-    if (HNRdB_) {
-      double buf = src[0] - src[maxIdx];
-      if (buf == 0.0) buf = 10e10; else buf = src[maxIdx] / buf;
-      dst[n++] = (FLOAT_DMEM)((buf <= 10e-10) ? -100.0 : ((buf >= 10e10) ? +100.0 : 10.0 * log(buf) / log(10.0)));
-    }
-    if (linHNR_) {
-      double buf = src[0] - src[maxIdx];
-      if (buf == 0.0) buf = 10e3; else buf = src[maxIdx] / buf;
-      dst[n++] = (FLOAT_DMEM)((buf <= 10e-3) ? 10e-3 : ((buf >= 10e3) ? 10e3 : buf));
-    }
-    if (F0_ || F0env_ || F0raw_ || voiceQual_) {
+    if (contour) {
       if (voiceQual_) {                                   // :178-181
-        FLOAT_DMEM vq = ((FLOAT_DMEM)maxPitch_ - (FLOAT_DMEM)fabs((h.acfZcr * maxPitch_) - ((FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(maxIdx) * (FLOAT_DMEM)Tsamp)))) * (FLOAT_DMEM)voicing;
-        if (maxIdx == 0.0) vq = 0.0;
-        dst[n++] = vq;
+        FLOAT_DMEM vq = ((FLOAT_DMEM)maxPitch_ - (FLOAT_DMEM)fabs((h.acfZcr * maxPitch_) - ((FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(peak) * (FLOAT_DMEM)Tsamp)))) * (FLOAT_DMEM)h.voicing;
+        dst[n++] = peak == 0 ? (FLOAT_DMEM)0.0 : vq;
       }
-      FLOAT_DMEM pitch = 0.0, rawF0 = 0.0;
-      if (maxIdx > 0) {
-        pitch = (FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(maxIdx) * (FLOAT_DMEM)Tsamp);
-        rawF0 = pitch;
-      }
-      if (voicing < voicingCutoff_) { maxIdx = 0; pitch = 0.0; }
-      // contour smoothing, pitchACF.cpp:199-243
-      if ((lastPitch_ == 0.0) && (pitch > 0.0)) onsFlag_ = 1;
-      if ((lastPitch_ > 0.0) && (pitch == 0.0) && (onsFlag_ == 0)) onsFlag_ = -1;
-      if ((lastPitch_ > 0.0) && (pitch > 0.0)) onsFlag_ = 0;
-      if ((lastPitch_ == 0.0) && (pitch == 0.0)) onsFlag_ = 0;
-      if ((pitch == 0.0) && (onsFlag_ == 1)) { lastPitch_ = 0.0; }
-      FLOAT_DMEM oPitch = pitch;
-      FLOAT_DMEM tol = (FLOAT_DMEM)0.4;
-      FLOAT_DMEM alpha = (FLOAT_DMEM)0.3;
-      if (pitch > 0.0) {
-        if (glMeanPitch_ == 0.0) glMeanPitch_ = pitch;
-        if (!((pitch < ((FLOAT_DMEM)1.0 + tol) * glMeanPitch_) && (pitch > ((FLOAT_DMEM)1.0 - tol) * glMeanPitch_))) {
-          pitch = glMeanPitch_;
-          alpha /= (FLOAT_DMEM)3.0;
-        }
-        if (onsFlag_ && (lastPitch_ > pitch)) lastPitch_ *= (FLOAT_DMEM)0.85;
-      }
-      if ((pitch > 0.0) && (onsFlag_ == -1)) { lastPitch_ = pitch; }
-      if (oPitch > (FLOAT_DMEM)0.0) glMeanPitch_ = ((FLOAT_DMEM)1.0 - alpha) * glMeanPitch_ + alpha * oPitch;
-      FLOAT_DMEM out;
-      if ((lastlastPitch_ != (FLOAT_DMEM)0.0) && (lastPitch_ != 0.0)) out = (FLOAT_DMEM)0.5 * (lastlastPitch_ + lastPitch_);
-      else out = lastPitch_;
-      if (F0_) dst[n++] = out;
-      if (F0raw_) dst[n++] = rawF0;
-      lastlastPitch_ = lastPitch_;
-      lastPitch_ = pitch;
-      if (F0env_) {
-        if (out > 0.0) pitchEnv_ = (FLOAT_DMEM)0.75 * pitchEnv_ + (FLOAT_DMEM)0.25 * out;
-        dst[n++] = pitchEnv_;
-      }
+      if (F0_) dst[n++] = h.f0[0];
+      if (F0raw_) dst[n++] = h.f0[1];
+      if (F0env_) dst[n++] = h.f0[2];
     }
     g_frames[9]++;
     return n;

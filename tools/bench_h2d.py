@@ -14,13 +14,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--utts", type=int, default=1000)
-    ap.add_argument("--chunks", type=int, default=10)
-    ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--d2h", action="store_true", help="also copy the feature matrix back to pinned host memory")
-    args = ap.parse_args()
+def measure(utts=1000, chunks=10, reps=5, d2h=False):
+    args = argparse.Namespace(utts=utts, chunks=chunks, reps=reps, d2h=d2h)
     import torch
     from opensmile_amd import capi, synth
     ctx = capi.Context(0)
@@ -58,10 +53,20 @@ def main():
         run_once()
     dt = (time.perf_counter() - t0) / args.reps
     total = frames * args.chunks
-    print(json.dumps({"workload": f"{args.chunks} chunks x {per} x 10 s, PCM from pinned host memory, copy/compute overlapped"
-                                  + (", features back to host" if args.d2h else ""),
-                      "frames": total, "ms": dt * 1e3, "frames_per_s": total / dt,
-                      "h2d_GBps": 2.0 * len(pcm) * args.chunks / dt / 1e9}))
+    return {"workload": f"MFCC12_0_D_A, {args.chunks} chunks x {per} x 10 s, PCM from pinned host memory, copy/compute overlapped"
+                        + (", features back to pinned host memory" if args.d2h else ""),
+            "frames": total, "ms": dt * 1e3, "frames_per_s": total / dt,
+            "h2d_GBps": 2.0 * len(pcm) * args.chunks / dt / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=1000)
+    ap.add_argument("--chunks", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--d2h", action="store_true", help="also copy the feature matrix back to pinned host memory")
+    args = ap.parse_args()
+    print(json.dumps(measure(args.utts, args.chunks, args.reps, args.d2h)))
 
 
 if __name__ == "__main__":
