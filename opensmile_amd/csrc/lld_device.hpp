@@ -101,6 +101,26 @@ __device__ __forceinline__ float bin_magnitude(float2 X, bool edge) {
   return edge ? fabsf(X.x) : sqrtf(X.x * X.x + X.y * X.y);
 }
 
+// smileMath_quadFrom3pts (smileUtil.c:1009-1033)
+__device__ __forceinline__ double quad_vertex(double x1, double y1, double x2, double y2, double x3, double y3, double &y) {
+  const double den = x1 * x1 * x2 + x2 * x2 * x3 + x3 * x3 * x1 - x3 * x3 * x2 - x2 * x2 * x1 - x1 * x1 * x3;
+  if (den != 0.0) {
+    const double a = (y1 * x2 + y2 * x3 + y3 * x1 - y3 * x2 - y2 * x1 - y1 * x3) / den;
+    const double b = (x1 * x1 * y2 + x2 * x2 * y3 + x3 * x3 * y1 - x3 * x3 * y2 - x2 * x2 * y1 - x1 * x1 * y3) / den;
+    const double c = (x1 * x1 * x2 * y3 + x2 * x2 * x3 * y1 + x3 * x3 * x1 * y2 - x3 * x3 * x2 * y1 - x2 * x2 * x1 * y3 - x1 * x1 * x3 * y2) / den;
+    if (a != 0.0) {
+      const double x = -b / (2.0 * a);
+      y = c - a * x * x;
+      return x;
+    }
+  }
+  if (y1 > y2 && y1 > y3) { y = y1; return x1; }
+  if (y2 > y1 && y2 > y3) { y = y2; return x2; }
+  if (y3 > y1 && y3 > y2) { y = y3; return x3; }
+  y = y1;
+  return x1;
+}
+
 // Natural logarithm in double for the per-bin / per-band logarithms of the frame kernels (the device library's log is ~95
 // instructions; the cepstrum instance of IS09 takes 257 of them per frame, ComParE's spectral entropy 256). Table + polynomial
 // after the scheme of glibc's log.c (S. Nagy): x = 2^k z, z in [0.6875, 1.375) cut into 128 sub-intervals, z = c (1 + r) with

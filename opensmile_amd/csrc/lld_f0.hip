@@ -73,26 +73,6 @@ __host__ __device__ inline size_t f0_shared_bytes(int N) {
   return (size_t)G::kKP * 16 + (size_t)G::kKP * 8 * 7 + (size_t)G::kKP * 4 + np * 4 + G::kTwBytes;
 }
 
-// smileMath_quadFrom3pts (smileUtil.c:1009-1033)
-__device__ __forceinline__ double quad_vertex(double x1, double y1, double x2, double y2, double x3, double y3, double &y) {
-  const double den = x1 * x1 * x2 + x2 * x2 * x3 + x3 * x3 * x1 - x3 * x3 * x2 - x2 * x2 * x1 - x1 * x1 * x3;
-  if (den != 0.0) {
-    const double a = (y1 * x2 + y2 * x3 + y3 * x1 - y3 * x2 - y2 * x1 - y1 * x3) / den;
-    const double b = (x1 * x1 * y2 + x2 * x2 * y3 + x3 * x3 * y1 - x3 * x3 * y2 - x2 * x2 * y1 - x1 * x1 * y3) / den;
-    const double c = (x1 * x1 * x2 * y3 + x2 * x2 * x3 * y1 + x3 * x3 * x1 * y2 - x3 * x3 * x2 * y1 - x2 * x2 * x1 * y3 - x1 * x1 * x3 * y2) / den;
-    if (a != 0.0) {
-      const double x = -b / (2.0 * a);
-      y = c - a * x * x;
-      return x;
-    }
-  }
-  if (y1 > y2 && y1 > y3) { y = y1; return x1; }
-  if (y2 > y1 && y2 > y3) { y = y2; return x2; }
-  if (y3 > y1 && y3 > y2) { y = y3; return x3; }
-  y = y1;
-  return x1;
-}
-
 // cSmileViterbiPitchSmooth::getFweight (pitchSmootherViterbi.hpp:167-197)
 __device__ __forceinline__ double f_weight(float f) {
   if (f > 0.0 && f < 100.0) return -(1.0 / 100.0) * f + 1.0;
@@ -1164,376 +1144,6 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi_step(F0Params Q, const floa
   if (lane == 0) { dstate[kNS] = lastChange; st[0] = pathIdx; st[1] = convIdx; st[2] = 0; st[3] = n_dec; }
 }
 
-// cPitchJitter::myTick (src/lld/pitchJitter.cpp:591-1064) as [is13_pitchJitter] configures it (searchRangeRel 0.25,
-// minNumPeriods 2, minCC 0.5, useBrokenJitterThresh 0, peak amplitudes, lgHNRfloor -100): jitterLocal, jitterDDP,
-// shimmerLocal, logHNR per F0 frame. One workgroup per utterance, frames in order (the read position in the wave, the
-// left-over samples and the last period / difference / jitter / shimmer values carry over from frame to frame).
-// Per period step every thread cross-correlates one candidate period length (crossCorr, :331-418: two sequential passes
-// in double per candidate, the order the reference sums in); the local-maximum search, the amplitude extremes and the
-// averaged period waveform are wave-parallel, the energy sums run in the reference's float order.
-// Time meta of frame t as the framer derives it from a wave level without stored time stamps
-// (dataMemoryLevel.cpp:617-626,1226-1245): lengthSec = ((tH+N-1)Tw - tH Tw) + Tw, so lenF = ceil(lengthSec/Tw) is N or N+1.
-namespace {
-// Values that are the same in every lane but come out of vector instructions (loads through a vector address, double
-// arithmetic, wave reductions): moved to scalar registers, so that everything derived from them -- loop bounds, sample
-// positions, addresses -- is scalar work and stops occupying a vector register per value.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ long uni(long v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v & 0xffffffffu));
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
-  return (long)(((unsigned long)hi << 32) | lo);
-}
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-// capacities at 16 kHz; every one but the number of periods scales with the sample rate (jit_scale: 1 up to 16 kHz, 3 at 48 kHz)
-constexpr int kJitCap = 2560;      // samples of wave the kernel can hold per frame (frame + left-over of the previous frames)
-constexpr int kJitMaxCand = 192;   // candidate period lengths per step: T0maxF - T0minF + 1 <= 156 for F0 >= 52 Hz
-constexpr int kJitMaxPeriod = 448; // T0f + 1 <= 309
-constexpr int kJitMaxPeriods = 160;
-__host__ __device__ inline int jit_scale(double Tw) {
-  const int r = (int)ceil(1.0 / (Tw * 16000.0) - 1e-9);
-  return r < 1 ? 1 : r;
-}
-inline size_t jit_shared_bytes(double Tw, int threads) {   // ccs (doubles) | wv | avgWf | pbuf | jit_terms
-  const size_t r = (size_t)jit_scale(Tw);
-  return r * kJitMaxCand * 8 + r * kJitCap * 4 + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 + (size_t)threads * 4;
-}
-}
-
-// kJitThreads: 64 (one wave per utterance: best throughput when the batch fills the device) or 256 (four waves, one
-// candidate per thread: lower latency for small batches; the scalar logic then runs redundantly in every wave)
-template <int kJitThreads>
-__global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
-  const int u = blockIdx.x;
-  if (u >= P.n_utt) return;
-  const int64_t fo = P.frame_off[u];
-  const int T = (int)(P.frame_off[u + 1] - fo);
-  if (T <= 0) return;
-  const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_jit[];
-  const int jr = uni(jit_scale(Q.jit_Tw));
-  const int jitCap = jr * kJitCap, jitMaxCand = jr * kJitMaxCand, jitMaxPeriod = jr * kJitMaxPeriod;
-  double *ccs = reinterpret_cast<double *>(smem_jit);                    // [jitMaxCand]
-  float *wv = reinterpret_cast<float *>(ccs + jitMaxCand);               // [jitCap] the frame's wave samples (crossCorr widens them to double as it reads: exact, and half the LDS)
-  float *avgWf = wv + jitCap;                                            // [jitMaxPeriod]
-  int *pbuf = reinterpret_cast<int *>(avgWf + jitMaxPeriod);             // [kJitMaxPeriods]
-  float *jit_terms = reinterpret_cast<float *>(pbuf + kJitMaxPeriods);   // [kJitThreads] one term per lane and wave for the sequential energy sums
-  const int64_t s0 = P.samp_off[u];
-  const int64_t n_samp = P.samp_off[u + 1] - s0;
-  const PcmIn x = pcm_in(P) + s0;
-  const double Tw = Q.jit_Tw;
-  const int N = Q.N, H = Q.H;
-  const long ppLen = uni((long)ceil(Q.jit_step_sec / Tw));
-  PHASE_DECL
-  long lastIdx = 0, lastMis = 0;
-  float lastT0 = 0.0f, lastDiff = 0.0f, lastJL = 0.0f, lastJD = 0.0f, lastSh = 0.0f;
-  int t_first = 0, t_end = T;
-  if (Q.jit_stream) {                                      // stream mode: the state of the frames before, one frame now
-    const double *js = Q.jit_stream;
-    lastIdx = (long)js[0]; lastMis = (long)js[1]; t_first = (int)js[2];
-    lastT0 = (float)js[3]; lastDiff = (float)js[4]; lastJL = (float)js[5]; lastJD = (float)js[6]; lastSh = (float)js[7];
-    t_end = t_first + 1 < T ? t_first + 1 : T;
-    __syncthreads();                                       // every thread has read the state before thread 0 rewrites it
-  }
-  const int lane_in = lane, tid_in = tid;
-  for (int t = t_first; t < t_end; ++t) {
-    int lane = lane_in, tid = tid_in;                      // opaque per frame: lane-only address arithmetic is not kept in registers
-    asm volatile("" : "+v"(lane), "+v"(tid));              // across the frame loop (see f0_shs)
-    const float F0 = uni(f0[(fo + t) * ld_f0]);
-    const long tt = (long)t + (long)Q.jit_t_shift;           // the frame whose time stamp the F0 value carries
-    const double time = (double)(tt * H) * Tw;
-    const double lengthSec = ((double)(tt * H + N - 1) * Tw - (double)(tt * H) * Tw) + Tw;
-    const long lenF = uni((long)ceil(lengthSec / Tw));
-    const long startVidx = uni((long)round(time / Tw));
-    long toRead0 = ppLen + lastMis, toRead = toRead0;
-    double Tf = 0.0;
-    long T0f = 0, T0minF = 0, T0maxF = 0;
-    if (F0 > 0.0f) {
-      const double T0 = 1.0 / F0;
-      Tf = T0 / Tw;
-      T0f = uni((long)round(Tf));
-      T0minF = uni((long)floor((1.0 - Q.jit_search_range) * Tf));
-      T0maxF = uni((long)ceil((1.0 + Q.jit_search_range) * Tf));
-      const long two_pp = 2 * T0maxF + 2;
-      if (toRead < two_pp) toRead = two_pp;
-    }
-    long maxRead = lastMis + lenF;
-    if (toRead > maxRead) toRead = maxRead;
-    if (startVidx - lastMis != lastIdx) {
-      lastIdx = startVidx;
-      if (toRead > lenF) toRead = lenF;
-      if (maxRead > lenF) maxRead = lenF;
-    }
-    float *o = out4 + (fo + t) * 4;
-    const bool fits = toRead + 16 <= jitCap &&         // (+16: the sample loops read ahead by up to two rounds)
-                      (T0maxF - T0minF + 1) <= jitMaxCand && T0f + 1 <= jitMaxPeriod &&
-                      (T0minF <= 0 || maxRead / T0minF + 3 < kJitMaxPeriods);
-    if (lastIdx + toRead > n_samp || !fits) {                  // cannot happen for complete frames / F0 within [52, 620] Hz
-      lastIdx += toRead0;
-      if (tid == 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; if (Q.jit_shim_db) Q.jit_shim_db[fo + t] = 0.0f; }
-      continue;
-    }
-    const long nT = toRead;
-    float nPeriodsLocal = 0, nPeriodsDDP = 0, nPeriods = 0, avgPeriod = 0.0f, JitterDDP = 0.0f, JitterLocal = 0.0f;
-    float avgAmp = 0.0f, avgAmpDiff = 0.0f, lgHNR = 0.0f;
-    long start = 0, lastPeriod = 0;
-    if (F0 > 0.0f) {
-      __syncthreads();
-      for (long i = tid; i < nT; i += kJitThreads) wv[i] = x[lastIdx + i];
-      for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
-      __syncthreads();
-      PHASE(5);   // frame set-up + wave load
-      int numPeriods = 0;
-      long pp = 0;
-      float minCC = -2.0f;
-      const int nc = (int)(T0maxF - T0minF) + 1;
-      while (start < nT - 2 * T0maxF - 1) {
-        for (int k0 = 0; k0 < nc; k0 += kJitThreads) {           // crossCorr of [start, start+tf) with [start+tf, start+2tf)
-          // Candidates in descending length, lane 0 of the first wave the longest (a second round then holds the shortest ones).
-          const int chi = nc - 1 - (k0 + (tid & ~63));             // this wave's candidates: chi - lane, down to clo
-          if (chi < 0) continue;
-          const int clo = chi - 63 > 0 ? chi - 63 : 0;
-          const int c = chi - lane;
-          // The two means (crossCorr :343-352 sums x and y sequentially in double). The samples are floats of magnitude
-          // < 2 (32768 / 32767 at most) and >= 2^-15 (or zero), i.e. multiples of 2^-38, so every partial sum of up to 2^12 of
-          // them is below 2^13 and exact in double in ANY order (tests/test_exact_sum_claims.py): the sums are formed by a wave reduction up to the shortest candidate and a scan over the
-          // candidates instead of one pass over the samples per candidate, with bit-identical results.
-          const long nb = T0minF + clo;
-          double bx = 0.0, bp = 0.0;
-          for (long i = lane; i < nb; i += 64) { bx += (double)wv[start + i]; bp += (double)wv[start + nb + i]; }
-          double ex = 0.0, ep = 0.0;
-          if (c > clo) {
-            const long tfc = T0minF + c;
-            ex = (double)wv[start + tfc - 1];
-            ep = (double)wv[start + 2 * tfc - 2] + (double)wv[start + 2 * tfc - 1];
-          }
-          bx = WaveG::sum(bx, nullptr); bp = WaveG::sum(bp, nullptr);   // (exact sums: any tree)
-          for (int of = 1; of < 64; of <<= 1) {                    // inclusive scan towards the longer candidates (the lower lanes)
-            const double ox = __shfl_down(ex, of), op = __shfl_down(ep, of);
-            if (lane + of < 64) { ex += ox; ep += op; }
-          }
-          if (c < clo) continue;
-          const long tf = T0minF + c;
-          const float *xa = wv + start, *ya = wv + start + tf;
-          const long nr = tf >> 2;
-          const double sx = bx + ex, sy = (bx + bp + ep) - sx;     // sum of x[0..tf), sum of x[tf..2tf)
-          const double mx = sx / (double)tf, my = sy / (double)tf;
-          // one pass in rounds of eight samples, the next round's samples loaded before the current round's sums (the
-          // sums stay sequential in the reference's order)
-          double cc = 0.0, nx = 0.0, ny = 0.0;
-          {
-            float xv[4], yv[4], xn[4], yn[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
-            for (long r = 0; r < nr; ++r) {
-              const long i1 = (r + 1) << 2;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
-                cc += dx * dy;
-                nx += dx * dx;
-                ny += dy * dy;
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if ((nr << 2) + q < tf) {
-                const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
-                cc += dx * dy;
-                nx += dx * dx;
-                ny += dy * dy;
-              }
-          }
-          cc /= sqrt(nx) * sqrt(ny);
-          ccs[c] = cc;
-        }
-        __syncthreads();
-        PHASE(6);   // cross-correlations
-        // the greatest local maximum of cc[1 .. nc-3], the first one among equals (:734-747)
-        double bv = 0.0;
-        int bi = 1 << 30;
-        for (int i = 1 + lane; i < nc - 2; i += 64) {
-          const double v = ccs[i];
-          if (ccs[i - 1] < v && v > ccs[i + 1] && (bi == (1 << 30) || v > bv)) { bv = v; bi = i; }
-        }
-        {   // (commutative selection: any reduction tree gives the same winner; lane 0's tree, then broadcast)
-          auto st = [&](auto tag) {
-            constexpr int OFF = decltype(tag)::value;
-            const double ov = wave_down_d<OFF>(bv);
-            const int oi = wave_down_i<OFF>(bi);
-            if (oi != (1 << 30) && (bi == (1 << 30) || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-          };
-          st(std::integral_constant<int, 32>{}); st(std::integral_constant<int, 16>{}); st(std::integral_constant<int, 8>{});
-          st(std::integral_constant<int, 4>{}); st(std::integral_constant<int, 2>{}); st(std::integral_constant<int, 1>{});
-          bv = wave_first_d(bv);
-          bi = __builtin_amdgcn_readfirstlane(bi);
-        }
-        const long maxI = (bi == (1 << 30)) ? -1 : uni(bi);
-        pp = (maxI == -1) ? T0f : T0minF + maxI;
-        const long os = start;
-        if (maxI >= 0) {
-          start += pp;
-          // amplitudeDiff (:422-459): max - min of x[1 .. pp-2] in both periods
-          float mx0 = wv[os + 1], mn0 = mx0, mx1 = wv[start + 1], mn1 = mx1;
-          for (long i = 1 + lane; i < pp - 1; i += 64) {
-            const float a = wv[os + i], b = wv[start + i];
-            mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
-            mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
-          }
-          {
-            auto fmx = [](int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; };
-            auto fmn = [](int a, int b) { return __int_as_float(b) < __int_as_float(a) ? b : a; };
-            mx0 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mx0), fmx)));
-            mn0 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mn0), fmn)));
-            mx1 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mx1), fmx)));
-            mn1 = __int_as_float(__builtin_amdgcn_readfirstlane(wave_tree_i(__float_as_int(mn1), fmn)));
-          }
-          const float a0 = mx0 - mn0, a1 = mx1 - mn1;
-          const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
-          if (tid == 0) pbuf[numPeriods] = (int)os;
-          numPeriods++;
-          for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += wv[os + i];
-          double ccI = 0.0;
-          const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
-                                                                 (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
-          // :793-809: the accepted-period threshold is minCC = 0.5, or -- useBrokenJitterThresh -- the frame's running
-          // minimum of the peak correlations (which includes this period's own, rounded to float)
-          if (minCC == -2.0f || minCC > (float)ccI) minCC = (float)ccI;
-          const float thresh = Q.jit_broken_thresh ? minCC : (float)0.5;
-          if (ccI > thresh) {
-            const float period = (float)maxId;
-            avgPeriod += period;
-            nPeriods += 1.0f;
-            if (lastT0 > 0.0f) {
-              const float diff = fabsf(lastT0 - period);
-              JitterLocal += diff;
-              nPeriodsLocal += 1.0f;
-              if (lastDiff > 0.0f) { JitterDDP += fabsf(lastDiff - diff); nPeriodsDDP += 1.0f; }
-              lastDiff = diff;
-            }
-            lastT0 = period;
-            avgAmp += (a0 + a1) / (float)2.0;
-            avgAmpDiff += ad;
-          }
-        } else {
-          start += T0f;
-        }
-        if (start < toRead0 - 1) lastPeriod = start;
-        __syncthreads();
-        PHASE(7);   // peak, amplitudes, averaged waveform, jitter sums
-      }
-      if (tid == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
-      numPeriods++;
-      for (long i = tid; i < T0f && start + i < nT; i += kJitThreads) {
-        avgWf[i] += wv[start + i];
-        avgWf[i] /= (float)numPeriods;
-      }
-      __syncthreads();
-      // harmonic / noise energy in the reference's summation order (:843-873). The terms of 64 consecutive samples are
-      // formed one per lane; the sum itself stays one sequential float chain (every lane the same one), fed through
-      // one LDS word per sample (instead of two loads, a conversion, a subtraction and a product per sample in the chain).
-      const int ln = tid & 63;
-      float *tw = jit_terms + (tid & ~63);                        // this wave's 64 terms (LDS ops of one wave stay in order)
-      auto chain_add = [&](float acc, float term, int cnt) {      // acc += term[lane 0], term[lane 1], ... term[lane cnt-1]
-        tw[ln] = term;
-        int q = 0;
-        for (; q + 8 <= cnt; q += 8) {
-          float a[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) a[r] = tw[q + r];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) acc += a[r];
-        }
-        for (; q < cnt; ++q) acc += tw[q];
-        return acc;
-      };
-      float Eh = 0.0f;
-      {
-        long hi = T0f - 2;                                  // i in [3, min(T0f-2, nT-start)): the reference's three conditions
-        if (nT - start < hi) hi = nT - start;
-        for (long i = 3; i < hi; i += 64) {
-          const int cnt = (int)((hi - i < 64) ? (hi - i) : 64);
-          float t = 0.0f;
-          if (ln < cnt) { const float a = avgWf[i + ln]; t = a * a; }
-          Eh = chain_add(Eh, t, cnt);
-        }
-      }
-      if (T0f - 4 > 0) Eh /= (float)(T0f - 4);
-      Eh = sqrtf(Eh);
-      float En = 0.0f;
-      long nEn = 0;
-      for (int i = 0; i < numPeriods; i++) {
-        const long p0 = uni(pbuf[i]), p1 = uni(pbuf[i + 1]);
-        const long lim = (p1 < p0 + T0f ? p1 : p0 + T0f) - 2;
-        long k = 2;
-        for (long j = p0 + 2; j < lim; j += 64, k += 64) {
-          const int cnt = (int)((lim - j < 64) ? (lim - j) : 64);
-          float t = 0.0f;
-          if (ln < cnt) { const float delta = wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
-          En = chain_add(En, t, cnt);
-          nEn += cnt;
-        }
-      }
-      if (nEn > 0) En /= (float)nEn;
-      En = sqrtf(En);
-      if (En > 0.0f) {
-        const float HNR = Eh / En;
-        if (HNR > 0.0f) lgHNR = (float)(20.0 * log((double)HNR) / log(10.0));
-        else lgHNR = -100.0f;
-      }
-      lastMis = toRead0 - lastPeriod;
-      PHASE(8);   // harmonic / noise energies
-    } else {
-      lastPeriod = toRead0;
-      lastMis = 0;
-      lastT0 = 0.0f; lastDiff = 0.0f;
-      lastJD = 0.0f; lastJL = 0.0f; lastSh = 0.0f;
-      lgHNR = -100.0f;
-    }
-    lastIdx += lastPeriod;
-    float o0, o1, o2;
-    const bool voiced = F0 > 0.0f;
-    if (nPeriods > 0.0f && nPeriodsLocal > 0.0f && voiced) {
-      JitterLocal /= nPeriodsLocal;
-      lastJL = JitterLocal / (avgPeriod / nPeriods);
-    }
-    if ((nPeriods > 0.0f && nPeriodsLocal > 0.0f && voiced) || (nPeriods == 0.0f && voiced)) {
-      if (lastJL > 1.0f) lastJL = 1.0f;
-      o0 = lastJL;
-    } else o0 = 0.0f;
-    if (nPeriods > 0.0f && nPeriodsDDP > 0.0f && voiced) {
-      JitterDDP /= nPeriodsDDP;
-      lastJD = JitterDDP / (avgPeriod / nPeriods);
-    }
-    if ((nPeriods > 0.0f && nPeriodsDDP > 0.0f && voiced) || (nPeriods == 0.0f && voiced)) {
-      if (lastJD > 1.0f) lastJD = 1.0f;
-      o1 = lastJD;
-    } else o1 = 0.0f;
-    if (nPeriods > 0.0f && voiced) lastSh = (avgAmp > 0.0f) ? avgAmpDiff / avgAmp : 0.0f;
-    if (voiced) {                                          // nPeriods > 0 or == 0: both branches clip and emit the held value
-      if (lastSh > 1.0f) lastSh = 1.0f;
-      o2 = lastSh;
-    } else o2 = 0.0f;
-    if (lgHNR < -100.0f) lgHNR = -100.0f;
-    if (tid == 0) {
-      o[0] = o0; o[1] = o1; o[2] = o2; o[3] = lgHNR;
-      if (Q.jit_shim_db) {                                 // shimmerLocalDB (:1000-1030): smileDsp_amplitudeRatioToDB(shimmer + 1)
-        const double a = (double)o2 + 1.0;
-        Q.jit_shim_db[fo + t] = voiced ? (float)((a > 10e-50) ? 20.0 * log(a) / log(10.0) : -1000.0) : 0.0f;
-      }
-    }
-    PHASE(9);   // output
-  }
-  if (Q.jit_stream && tid == 0) {
-    double *js = Q.jit_stream;
-    js[0] = (double)lastIdx; js[1] = (double)lastMis; js[2] = (double)t_end;
-    js[3] = lastT0; js[4] = lastDiff; js[5] = lastJL; js[6] = lastJD; js[7] = lastSh;
-  }
-  PHASE_FLUSH;
-}
 
 // [is13_smoNz] + [is13_deNz]: the F0 group's columns of the LLD level, T60+1 rows per utterance:
 // cContourSmoother with noZeroSma (contourSmoother.cpp:85-100) over [F0final, voicing | jitterLocal, jitterDDP,
@@ -1778,31 +1388,12 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
   }
 }
 
-namespace {
-hipError_t launch_jitter_kernel(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
-  if (!(Q.jit_Tw > 0.0) || jit_scale(Q.jit_Tw) > 6) return hipErrorInvalidValue;      // up to 96 kHz
-  const bool wide = P.n_utt < 512;
-  const size_t lds = jit_shared_bytes(Q.jit_Tw, wide ? 256 : 64);
-  const void *fn = wide ? reinterpret_cast<const void *>(&lld_f0_jitter<256>) : reinterpret_cast<const void *>(&lld_f0_jitter<64>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  if (wide) hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), lds, s, P, Q, d_f0, ld_f0, d_jit4);
-  else hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4);
-  return hipGetLastError();
-}
-}  // namespace
-
-// cPitchJitter alone: F0 contour d_f0 (leading dimension ld_f0, F0final in column 0) -> d_jit4 [frames x 4] (+ Q.jit_shim_db)
-hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
-  if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
-  return launch_jitter_kernel(P, Q, d_f0, ld_f0, d_jit4, s);
-}
 
 // jitter / shimmer / HNR from the wave and the F0 contour (pitch2, T60 x 2), then the F0 group's 12 LLD columns
 hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d_row_off, const float *d_pitch2, float *d_jit4,
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s) {
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
-  hipError_t e = launch_jitter_kernel(P, Q, d_pitch2, 2, d_jit4, s);
+  hipError_t e = launch_f0_jitter(P, Q, d_pitch2, 2, d_jit4, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
                      Q.pending, d_out, ld_out, col_sma, col_de);

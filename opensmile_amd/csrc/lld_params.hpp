@@ -167,6 +167,10 @@ struct F0Params {
   float *jit_shim_db;               // optional [total_frames]: shimmerLocalDB = 20 log10(shimmerLocal + 1)
   double *jit_stream;               // stream mode (one frame per launch, smilehip_jitter_stream_*): [0] lastIdx [1] lastMis [2] next frame
                                     // [3] lastT0 [4] lastDiff [5] lastJitterLocal [6] lastJitterDDP [7] lastShimmerLocal; null = whole utterances
+  const int32_t *jit_item_utt, *jit_item_t0;   // lld_jitter_runs' work items (utterance, first frame) of 64 consecutive frames each, ordered
+  int32_t n_jit_items;              //   by first frame, then utterance (smilehip_batch: d_jit_utt / d_jit_t0); null = one workgroup per utterance
+  int32_t *jit_redo;                // [n_utt], zero between runs: utterances lld_jitter_runs hands back to the per-utterance kernel
+  int32_t *jit_ctl;                 // [2], zero between runs: lld_jitter_runs' item counter and count of finished workgroups
 };
 
 // eGeMAPSv02 / GeMAPSv01b LLD level (lld_gemaps.hip): per-frame scratch and constants

@@ -172,7 +172,19 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     }
     b->d_f0_ab.n = nab;
     std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
-    if ((rc = b->d_pending.upload(zp))) {
+    if ((rc = b->d_pending.upload(zp)) || (rc = b->d_jit_redo.upload(zp))) {
+      delete b;
+      return rc;
+    }
+    // cPitchJitter's work items: 64 consecutive frames of one utterance each, all first chunks, then all second chunks, ...
+    // (the chains that begin in a chunk can run to the utterance's end: the longest possible ones are launched first)
+    std::vector<int32_t> ju, jt;
+    int64_t maxT = 0;
+    for (int32_t u = 0; u < n_utt; ++u) maxT = std::max(maxT, b->h_frame_off[u + 1] - b->h_frame_off[u]);
+    for (int64_t t0 = 0; t0 < maxT; t0 += jitter_chunk_frames())
+      for (int32_t u = 0; u < n_utt; ++u)
+        if (t0 < b->h_frame_off[u + 1] - b->h_frame_off[u]) { ju.push_back(u); jt.push_back((int32_t)t0); }
+    if ((rc = b->d_jit_utt.upload(ju)) || (rc = b->d_jit_t0.upload(jt)) || (rc = b->d_jit_ctl.upload(std::vector<int32_t>(2, 0)))) {
       delete b;
       return rc;
     }
@@ -531,6 +543,15 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.old_peaks = plan->cfg.shs_old_peak_algo ? 1 : 0;
 }
 
+// cPitchJitter's work items and redo marks of an F0-group batch (lld_jitter.hip)
+static void set_jitter_items(const smilehip_batch *fb, F0Params &Q) {
+  Q.jit_item_utt = fb->d_jit_utt.p;
+  Q.jit_item_t0 = fb->d_jit_t0.p;
+  Q.n_jit_items = (int32_t)fb->d_jit_utt.n;
+  Q.jit_redo = fb->d_jit_redo.p;
+  Q.jit_ctl = fb->d_jit_ctl.p;
+}
+
 // log_out: rows [F0final, F0finalLog, voicingFinalUnclipped] (the eGeMAPS sub-chain, ld_out >= 3) instead of [F0final, voicing]
 static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, float *d_out, int64_t ld_out, void *stream,
                   bool log_out = false, hipEvent_t frames_done = nullptr) {
@@ -570,14 +591,18 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream, false, plan->ev_fork);
   if (rc) return rc;
   if (fb->total_frames == 0) HIP_TRY(hipEventRecord(plan->ev_fork, s));
-  HIP_TRY(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-  if ((rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, plan->side_stream, 65))) return rc;
-  HIP_TRY(hipEventRecord(plan->ev_join, plan->side_stream));
+  // SMILEHIP_SERIAL=1 (measurement aid): everything on the caller's stream, so that a kernel trace shows each kernel alone
+  static const bool serial = getenv("SMILEHIP_SERIAL") != nullptr;
+  hipStream_t side = serial ? s : plan->side_stream;
+  HIP_TRY(hipStreamWaitEvent(side, plan->ev_fork, 0));
+  if ((rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, side, 65))) return rc;
+  HIP_TRY(hipEventRecord(plan->ev_join, side));
   LldParams P;
   fill_params(plan->f0_plan, fb, d_pcm, d_out, ld_out, P);
   F0Params Q;
   fill_f0_params(plan->f0_plan, Q);
   Q.pending = fb->d_pending.p;
+  set_jitter_items(fb, Q);
   hipError_t e = launch_f0_lld(P, Q, b->d_row_off.p, b->d_pitch2.p, b->d_jit4.p, d_out, ld_out, 0, 65, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 LLD kernel launch failed: %s", hipGetErrorString(e));
   HIP_TRY(hipStreamWaitEvent(s, plan->ev_join, 0));
@@ -661,6 +686,7 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
     F0Params Q;
     fill_f0_params(plan->f0_plan, Q);
     Q.jit_shim_db = b->d_shim.p;
+    set_jitter_items(fb, Q);
     // cPitchJitter is one wave per utterance and latency-bound (a fifth of the VALU issue slots): it runs on the plan's
     // lowest-priority stream beside the 20 ms chain and cHarmonics instead of holding the wave slots they need
     HIP_TRY(hipEventRecord(plan->ev_bg_fork, s));

@@ -178,6 +178,7 @@ struct smilehip_batch {
   DevBuf<double> d_f0_ab;                 // F0 group: rows of (y | 6ut -> y2) between the three frame kernels, one chunk of tiles
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance
+  DevBuf<int32_t> d_jit_utt, d_jit_t0, d_jit_redo, d_jit_ctl;   // F0 group: cPitchJitter's work items (lld_jitter.hip) and its redo marks
   DevBuf<float> d_pitch2, d_jit4;         // whole-level chain: F0final/voicing (T60 x 2) and jitter/shimmer/HNR (T60 x 4)
   smilehip_batch *f0_batch = nullptr;     // whole-level chain: the 60 ms sub-chain's batch
   // eGeMAPS chain scratch (lld_gemaps.hip)
