@@ -90,9 +90,12 @@ __host__ __device__ inline int jit_scale(double Tw) {
   const int r = (int)ceil(1.0 / (Tw * 16000.0) - 1e-9);
   return r < 1 ? 1 : r;
 }
-inline size_t jit_shared_bytes(double Tw, int threads) {   // ccs (doubles) | wv | avgWf | pbuf | jit_terms
-  const size_t r = (size_t)jit_scale(Tw);
-  return r * kJitMaxCand * 8 + r * kJitCap * 4 + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 + (size_t)threads * 4;
+__host__ __device__ inline int jit_wave_cap(const F0Params &Q) {      // samples of wave per frame: the plan's bound, or the general one
+  return Q.jit_cap > 0 ? Q.jit_cap : jit_scale(Q.jit_Tw) * kJitCap;
+}
+inline size_t jit_shared_bytes(const F0Params &Q, int threads) {   // ccs (doubles) | wv | avgWf | pbuf | jit_terms
+  const size_t r = (size_t)jit_scale(Q.jit_Tw);
+  return r * kJitMaxCand * 8 + (size_t)jit_wave_cap(Q) * 4 + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 + (size_t)threads * 4;
 }
 
 // what carries over from frame to frame (cPitchJitter's members lastIdx, lastMis, lastT0, lastDiff, lastJitterLocal,
@@ -113,10 +116,10 @@ struct JitLds {
   float *jit_terms;   // [threads] one term per lane and wave for the sequential energy sums
   int jitCap, jitMaxCand, jitMaxPeriod;
 };
-__device__ __forceinline__ JitLds jit_lds(unsigned char *smem, double Tw) {
+__device__ __forceinline__ JitLds jit_lds(unsigned char *smem, const F0Params &Q) {
   JitLds L;
-  const int jr = uni(jit_scale(Tw));
-  L.jitCap = jr * kJitCap; L.jitMaxCand = jr * kJitMaxCand; L.jitMaxPeriod = jr * kJitMaxPeriod;
+  const int jr = uni(jit_scale(Q.jit_Tw));
+  L.jitCap = uni(jit_wave_cap(Q)); L.jitMaxCand = jr * kJitMaxCand; L.jitMaxPeriod = jr * kJitMaxPeriod;
   L.ccs = reinterpret_cast<double *>(smem);
   L.wv = reinterpret_cast<float *>(L.ccs + L.jitMaxCand);
   L.avgWf = L.wv + L.jitCap;
@@ -352,17 +355,22 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
     // one LDS word per sample (instead of two loads, a conversion, a subtraction and a product per sample in the chain).
     const int ln = tid & 63;
     float *tw = L.jit_terms + (tid & ~63);                      // this wave's 64 terms (LDS ops of one wave stay in order)
+    // The terms of the lanes at and above cnt are +0: the sums are sums of squares starting at +0, never -0, so adding
+    // them changes nothing -- the chain runs in rounds of 16 terms (four 16-byte LDS reads), the next round's terms on their
+    // way while this round's are added.
     auto chain_add = [&](float acc, float term, int cnt) {      // acc += term[lane 0], term[lane 1], ... term[lane cnt-1]
       tw[ln] = term;
-      int q = 0;
-      for (; q + 8 <= cnt; q += 8) {
-        float a[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = tw[q + r];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc += a[r];
+      const float4 *t4 = reinterpret_cast<const float4 *>(tw);
+      float4 c0 = t4[0], c1 = t4[1], c2 = t4[2], c3 = t4[3];
+      for (int q = 0; q < cnt; q += 16) {
+        const int qn = (q + 16 < 64) ? (q >> 2) + 4 : 12;       // (the last round reads its own terms again: unused)
+        const float4 n0 = t4[qn], n1 = t4[qn + 1], n2 = t4[qn + 2], n3 = t4[qn + 3];
+        acc += c0.x; acc += c0.y; acc += c0.z; acc += c0.w;
+        acc += c1.x; acc += c1.y; acc += c1.z; acc += c1.w;
+        acc += c2.x; acc += c2.y; acc += c2.z; acc += c2.w;
+        acc += c3.x; acc += c3.y; acc += c3.z; acc += c3.w;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       }
-      for (; q < cnt; ++q) acc += tw[q];
       return acc;
     };
     float Eh = 0.0f;
@@ -463,7 +471,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, tid = threadIdx.x;   // all waves run the same scalar logic; tid splits the bulk work
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_jit[];
-  const JitLds L = jit_lds(smem_jit, Q.jit_Tw);
+  const JitLds L = jit_lds(smem_jit, Q);
   const int64_t s0 = P.samp_off[u];
   const int64_t n_samp = P.samp_off[u + 1] - s0;
   const PcmIn x = pcm_in(P) + s0;
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
 __global__ void __launch_bounds__(64) lld_jitter_runs(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
   const int lane_in = threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_jit[];
-  const JitLds L = jit_lds(smem_jit, Q.jit_Tw);
+  const JitLds L = jit_lds(smem_jit, Q);
   const long ppLen = uni((long)ceil(Q.jit_step_sec / Q.jit_Tw));
   JitPhase PH;
   for (;;) {
@@ -561,7 +569,7 @@ namespace {
 hipError_t launch_jitter_utt(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, int32_t *redo,
                              hipStream_t s) {
   const bool wide = P.n_utt < 512 && !redo;
-  const size_t lds = jit_shared_bytes(Q.jit_Tw, wide ? 256 : 64);
+  const size_t lds = jit_shared_bytes(Q, wide ? 256 : 64);
   const void *fn = wide ? reinterpret_cast<const void *>(&lld_f0_jitter<256>) : reinterpret_cast<const void *>(&lld_f0_jitter<64>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -572,6 +580,19 @@ hipError_t launch_jitter_utt(const LldParams &P, const F0Params &Q, const float 
 }  // namespace
 
 int jitter_chunk_frames() { return kJitChunk; }
+
+// Samples of wave a frame can need when every F0 value is at least min_pitch: toRead <= lastMis + lenF (:623-640) with
+// lenF <= N + 1 and lastMis <= 2 T0maxF + 1 -- the period walk of the frame before ends within 2 T0maxF + 1 samples of its
+// last sample and the left-over is counted from the last period start in front of that -- plus the 16 samples the loops read
+// ahead and a margin of 64; a multiple of 64, never more than the general capacity.
+int jitter_wave_capacity(double Tw, int64_t N, double min_pitch, double search_range) {
+  const int general = jit_scale(Tw) * kJitCap;
+  if (!(min_pitch > 0.0) || !(Tw > 0.0)) return general;
+  const double t0max = ceil((1.0 + search_range) / (min_pitch * Tw));
+  const double need = 2.0 * t0max + 1.0 + (double)(N + 1) + 16.0 + 64.0;
+  if (!(need < (double)general)) return general;
+  return ((int)need + 63) / 64 * 64;
+}
 
 // cPitchJitter: F0 contour d_f0 (leading dimension ld_f0, F0final in column 0) -> d_jit4 [frames x 4] (+ Q.jit_shim_db).
 // With the batch's work-item table (Q.jit_item_*, Q.jit_redo) the runs of voiced frames are independent work; without it
@@ -587,7 +608,7 @@ hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *
   static const bool by_utt = getenv("SMILEHIP_JITTER_BY_UTT") != nullptr;              // (A/B switch: the round-3 form)
   if (!Q.jit_item_utt || !Q.jit_item_t0 || !Q.jit_redo || !Q.jit_ctl || Q.n_jit_items <= 0 || Q.jit_stream || by_utt)
     return launch_jitter_utt(P, Q, d_f0, ld_f0, d_jit4, nullptr, s);
-  const size_t lds = jit_shared_bytes(Q.jit_Tw, 64);
+  const size_t lds = jit_shared_bytes(Q, 64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_jitter_runs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;

@@ -66,6 +66,7 @@ hipError_t launch_gemaps_spectral_rows(const float *src, int64_t lds, float *sta
 hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s);
 hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s);
 hipError_t launch_gemaps_dbp(float *d_x, int64_t ld, int n_utt, const int64_t *d_row_off, hipStream_t s);
+int jitter_wave_capacity(double Tw, int64_t N, double min_pitch, double search_range);   // F0Params::jit_cap of a chain whose F0 values are >= min_pitch
 int jitter_chunk_frames();          // frames per work item of lld_jitter_runs
 hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s);
 int fs_sort_lds_rows();

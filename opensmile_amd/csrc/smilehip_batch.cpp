@@ -550,6 +550,8 @@ static void set_jitter_items(const smilehip_batch *fb, F0Params &Q) {
   Q.n_jit_items = (int32_t)fb->d_jit_utt.n;
   Q.jit_redo = fb->d_jit_redo.p;
   Q.jit_ctl = fb->d_jit_ctl.p;
+  // (the chain's F0 values are cPitchShs candidates: inside [minPitch, maxPitch], pitchBase.cpp:211-222)
+  Q.jit_cap = jitter_wave_capacity(Q.jit_Tw, Q.N, Q.min_pitch, Q.jit_search_range);
 }
 
 // log_out: rows [F0final, F0finalLog, voicingFinalUnclipped] (the eGeMAPS sub-chain, ld_out >= 3) instead of [F0final, voicing]

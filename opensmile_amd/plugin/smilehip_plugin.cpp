@@ -982,11 +982,13 @@ class cHipPitchACF : public cPitchACF {
     int n = 0;
     if (voiceProb_) dst[n++] = (FLOAT_DMEM)h.voicing;
     if (HNR_ || HNRdB_ || linHNR_) {
-      // harmonics-to-noise ratio acf[peak] / (acf[0] - acf[peak]) (float arithmetic), `pure` where the denominator vanishes;
-      // natural-log scale floored at 1e-11, dB scale limited to -100 .. 100, linear scale limited to 1e-2 .. 1e4
+      // harmonics-to-noise ratio acf[peak] / (acf[0] - acf[peak]), `pure` where the denominator vanishes. The difference is a
+      // float; the natural-log scale divides in float (:315), the dB and linear scales hold the difference in a double and
+      // divide in double (:331-335, :351-355). Natural-log scale floored at 1e-11, dB scale limited to -100 .. 100, linear
+      // scale limited to 1e-2 .. 1e4
       const FLOAT_DMEM noise = src[0] - src[peak];
-      const auto ratio = [&](double pure) { return noise == 0.0 ? pure : (double)(src[peak] / noise); };
-      if (HNR_) { const double q = ratio(1e20); dst[n++] = (FLOAT_DMEM)(10.0 * log(q > 0.00000000001 ? q : 0.00000000001)); }
+      const auto ratio = [&](double pure) { return noise == 0.0 ? pure : (double)src[peak] / (double)noise; };
+      if (HNR_) { const double q = noise == 0.0 ? 1e20 : (double)(src[peak] / noise); dst[n++] = (FLOAT_DMEM)(10.0 * log(q > 0.00000000001 ? q : 0.00000000001)); }
       if (HNRdB_) { const double q = ratio(10e10); dst[n++] = (FLOAT_DMEM)(q <= 10e-10 ? -100.0 : (q >= 10e10 ? 100.0 : 10.0 * log(q) / log(10.0))); }
       if (linHNR_) { const double q = ratio(10e3); dst[n++] = (FLOAT_DMEM)(q <= 10e-3 ? 10e-3 : (q >= 10e3 ? 10e3 : q)); }
     }
