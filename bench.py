@@ -62,20 +62,22 @@ CONFIGS = {
     3: dict(cfg="is09_lld_config", utts=10000, samples=160000, steps=10, warmup=3,
             workload="IS09_emotion LLD (MFCC 1-12, RMS energy, ZCR, voiceProb, F0 via cAcf / cPitchACF; 16 LLD + 16 delta) on "
                      "10 000 x 10 s synthetic 16 kHz mono int16 per GPU, 25 ms / 10 ms, PCM resident in HBM",
-            kernel="lld_is09_frame_wave (+ lld_pitch_smooth)", alg_bytes=2 * 160 + 4 * 16,
+            kernel="lld_is09_frame_wave (+ lld_pitch_smooth)", pmc_kernels=["lld_is09_frame_wave", "lld_pitch_smooth"], alg_bytes=2 * 160 + 4 * 16,
             alg_note="int16 hop in + 16 f32 pre-smoothing columns out per frame (SURVEY 8d counts 448 B for the whole chain incl. deltas)",
             conf="is09-13/IS09_emotion.conf", opt="-lldhtkoutput"),
     4: dict(cfg="compare16_config", utts=12500, samples=160000, steps=4, warmup=1,
             workload="ComParE_2016 whole LLD level (130 columns: F0 group incl. Viterbi + jitter / shimmer, groups A + B, deltas) on "
                      "12 500 x 10 s synthetic 16 kHz mono int16 per GPU (config 4's share of 100 000 utterances over 8 GPUs), "
                      "PCM resident in HBM",
-            kernel="lld_compare_frame_wave3 (+ RASTA scan, group A)", alg_bytes=2 * 160 + 4 * (4 + 55),
+            kernel="lld_compare_frame_wave3 (+ RASTA scan, group A)", pmc_kernels=["lld_compare_frame_wave", "lld_compare_rasta", "lld_compare_groupA"],
+            alg_bytes=2 * 160 + 4 * (4 + 55),
             alg_note="int16 hop in + 59 f32 pre-smoothing columns of groups A + B out per 20 ms frame",
             conf="compare16/ComParE_2016.conf", opt="-lldhtkoutput"),
     5: dict(cfg="egemapsv02_config", utts=125000, samples=48000, steps=3, warmup=1,
             workload="eGeMAPSv02 LLD (25 columns) + 88 functionals per utterance on 125 000 x 3 s synthetic 16 kHz mono int16 per GPU "
                      "(config 5's share of 10^6 utterances over 8 GPUs), PCM resident in HBM",
-            kernel="lld_gemaps_frame20 + lld_gemaps_lpc + lld_gemaps_formants", alg_bytes=2 * 160 + 4 * (12 + 222 + 12 + 10),
+            kernel="lld_gemaps_frame20 + lld_gemaps_lpc + lld_gemaps_formants", pmc_kernels=["lld_gemaps_frame20", "lld_gemaps_lpc", "lld_gemaps_formants"],
+            alg_bytes=2 * 160 + 4 * (12 + 222 + 12 + 10),
             alg_note="int16 hop in + 12 f32 raw descriptors + 222 f32 of cSpecResample's input + 12 LP + 10 formant values out per 20 ms frame",
             conf="egemaps/v02/eGeMAPSv02.conf", opt="-htkoutput"),
 }
@@ -540,9 +542,14 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                res["roofline"]["traffic"] = tj["hbm_bytes_per_frame"] * frames
+                by = tj.get("by_kernel", {})
+                mine = [v for k, v in by.items() if any(k.startswith(n) for n in c["pmc_kernels"])]
+                # the roofline kernel(s)' own HBM bytes per launch (what `achieved` is to be held against), and the whole step's
+                res["roofline"]["traffic"] = sum(v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"] for v in mine) * frames if mine else None
+                res["roofline"]["traffic_step"] = tj["hbm_bytes_per_frame"] * frames
                 res["roofline"]["traffic_source"] = f"profiles/pmc_traffic_c{config}.json: " + tj.get("source", "")
-                res["roofline"]["traffic_by_kernel_bytes_per_frame"] = tj.get("by_kernel")
+                res["roofline"]["traffic_by_kernel_bytes_per_frame"] = {
+                    k: round(v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"], 1) for k, v in by.items()}
             except Exception:
                 pass
         if world == 1 and with_cpu:

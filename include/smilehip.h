@@ -563,6 +563,12 @@ int smilehip_pcm16_to_float(smilehip_context *ctx, const int16_t *d_pcm, int64_t
  * Full scales: 127, 32767, 32767*256, 2147483647. The fused batch path takes 16-bit mono. */
 int smilehip_pcm_convert(smilehip_context *ctx, const void *d_raw, int n_bps, int n_bits, int n_chan, int mono_mixdown,
                          int64_t n, float *d_out, void *stream);
+/* The same for IEEE-float wave files (sample type 3, 32 bit): smilePcm_convertFloatSamples, src/smileutil/smileUtil.c:2629-2690, which
+ * smilePcm_readSamples picks for such files (smileUtil.c:2718-2722; cWaveSource::readData, waveSource.cpp:334-341). d_raw: n * n_chan floats, interleaved. mono_mixdown: the channels are
+ * added to a float zero in channel order and the sum is divided by the channel count (one channel goes through the same two
+ * operations); otherwise the samples are copied. */
+int smilehip_pcm_convert_float(smilehip_context *ctx, const float *d_raw, int n_chan, int mono_mixdown, int64_t n, float *d_out,
+                               void *stream);
 /* R4 with inverse = 1 (src/dspcore/transformFft.cpp:196-216): rows of fft_size packed spectrum values (a[0] = X[0], a[1] = X[N/2],
  * a[2k] = Re, a[2k+1] = -Im, Ooura's packing) -> rdft(N, -1) -> fft_size samples, each times (FLOAT_DMEM)2 / N. The reference's bits. */
 int smilehip_irfft_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_frames,

@@ -184,6 +184,7 @@ SYMBOLS = {
     "smilehip_window_op_row": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "smilehip_window_op_row_ex": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp]),
     "smilehip_pcm_convert": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
+    "smilehip_pcm_convert_float": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, _vp, _vp]),
     "smilehip_pcm16_to_float": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_preemphasis_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, C.c_int, _vp]),
     "smilehip_window_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),

@@ -306,7 +306,13 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
 // tile and all 220 outputs (lane l: outputs l, l+64, l+128, l+192): a table element is loaded once per 8 frames, a spectrum
 // element once per 4 outputs (LDS broadcast).
 __global__ void __launch_bounds__(256) lld_gemaps_lpc(GemapsParams G) {
-  __shared__ __attribute__((aligned(16))) float xs[kLpcTile][kRsI + 4];      // spectra, then the resampled signals
+  // Row stride 236 floats = 12 mod 32 banks: the autocorrelation's lanes are (frame f, lag) pairs reading x[i - lag] of row f, bank
+  // 12 f + i - lag -- the 32 (f, lag) pairs of a half wave then sit on 32 different banks (with the 224 of before every row
+  // started on bank 0 and six rows read the same bank at different addresses: 2.5 conflict cycles per LDS instruction,
+  // profiles/r03_pmc_egemaps.txt)
+  constexpr int kXsRow = kRsI + 16;
+  static_assert(kXsRow % 32 == 12 && kXsRow % 4 == 0, "bank layout of the autocorrelation reads");
+  __shared__ __attribute__((aligned(16))) float xs[kLpcTile][kXsRow];        // spectra, then the resampled signals
   __shared__ float racf[kLpcTile][kLpcP + 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -768,7 +774,18 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
   const int lane_in = lane;
   const bool rows_mode = G.op_mode == 1;                 // per-component operator: F0, formants and magnitudes given per row
   const int n_tiles = rows_mode ? (int)((G.op_rows + 7) / 8) : G.n_tiles60;
-  for (int tile = blockIdx.x * kHarmWaves + wave; tile < n_tiles; tile += tile_stride) {
+  // Tiles cost what their voiced frames cost: with the batch's counter (G.harm_ctl: [0] next tile, [1] waves that have
+  // finished -- the last one zeroes both) the waves take the next tile when they are free; without it (per-component
+  // operator) tile = wave index + k * waves.
+  int tile = blockIdx.x * kHarmWaves + wave;
+  const auto next_tile = [&]() {
+    if (!G.harm_ctl) return tile + tile_stride;
+    int t = 0;
+    if (lane_in == 0) t = atomicAdd(&G.harm_ctl[0], 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  if (G.harm_ctl) tile = next_tile();
+  for (; tile < n_tiles; tile = next_tile()) {
     int64_t samp0 = 0, row0 = (int64_t)tile * 8, r20 = (int64_t)tile * 8;
     int n_fr = (int)((G.op_rows - row0 < 8) ? G.op_rows - row0 : 8);
     if (!rows_mode) {
@@ -975,6 +992,10 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
       WaveG::sync();
       GPHASE(5);   // formant amplitudes + output
     }
+  }
+  if (G.harm_ctl && lane_in == 0 && atomicAdd(&G.harm_ctl[1], 1) == (int)gridDim.x * kHarmWaves - 1) {
+    G.harm_ctl[0] = 0;
+    G.harm_ctl[1] = 0;
   }
   GPHASE_FLUSH;
 }

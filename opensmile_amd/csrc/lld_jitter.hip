@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
 // their shader engines round-robin by index, so items whose cost repeats with a period of 8 or 32 -- a corpus of 32
 // utterances tiled, as the bench's -- pile up on one engine while the others idle: measured 3.6 resident waves per CU of 11.)
 // ctl: [0] next item, [1] workgroups that have finished -- the last one zeroes both for the next launch.
-__global__ void __launch_bounds__(64) lld_jitter_runs(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4) {
+__global__ void __launch_bounds__(64) lld_jitter_runs(LldParams P, F0Params Q, const float *f0, int64_t ld_f0, float *out4, int mark_all) {
   const int lane_in = threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_jit[];
   const JitLds L = jit_lds(smem_jit, Q);
@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(64) lld_jitter_runs(LldParams P, F0Params Q, c
       o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = exit_taken ? 0.0f : -100.0f;
       if (Q.jit_shim_db) Q.jit_shim_db[fo + tl] = 0.0f;
     }
+    if (mark_all && lane_in == 0) Q.jit_redo[u] = 1;       // (test aid: every utterance goes through the redo pass)
     unsigned long long starts = __ballot(v && !pv);        // runs of voiced frames that begin among the 64
     PH(5);   // item set-up + the frames with a known state
     while (starts) {
@@ -605,7 +606,10 @@ hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return n;
   }();
-  static const bool by_utt = getenv("SMILEHIP_JITTER_BY_UTT") != nullptr;              // (A/B switch: the round-3 form)
+  // SMILEHIP_JITTER (read at every launch; A/B switch and test aid): "utt" = one workgroup per utterance (the round-3 form),
+  // "redo" = the runs, every utterance marked, i.e. everything done a second time by the redo pass
+  const char *mode = getenv("SMILEHIP_JITTER");
+  const bool by_utt = mode && !strcmp(mode, "utt"), mark_all = mode && !strcmp(mode, "redo");
   if (!Q.jit_item_utt || !Q.jit_item_t0 || !Q.jit_redo || !Q.jit_ctl || Q.n_jit_items <= 0 || Q.jit_stream || by_utt)
     return launch_jitter_utt(P, Q, d_f0, ld_f0, d_jit4, nullptr, s);
   const size_t lds = jit_shared_bytes(Q, 64);
@@ -617,7 +621,7 @@ hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *
   if (per_cu < 1) per_cu = 1;
   int64_t grid = (int64_t)per_cu * (max_cus > 0 ? max_cus : 256);
   if (grid > Q.n_jit_items) grid = Q.n_jit_items;
-  hipLaunchKernelGGL(lld_jitter_runs, dim3((unsigned)grid), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4);
+  hipLaunchKernelGGL(lld_jitter_runs, dim3((unsigned)grid), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, mark_all ? 1 : 0);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_jitter_utt(P, Q, d_f0, ld_f0, d_jit4, Q.jit_redo, s);
 }

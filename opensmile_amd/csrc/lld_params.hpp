@@ -207,6 +207,7 @@ struct GemapsParams {
   const TileRec *tile60;            // tiles of <= 8 consecutive 60 ms frames
   int32_t n_tiles60;
   const int32_t *pending;           // [n_utt] frames the Viterbi pass had not decided at the end of input
+  int32_t *harm_ctl;                // [2], zero between runs: lld_gemaps_harm's tile counter and count of finished waves (null: static tiles)
   // ---- smoothed levels ----
   float *func_in;                   // [fin_off[n_utt] x 36], T20+1 rows per utterance that has a 60 ms frame:
                                     //   loudness_sma3, flux_sma3, mfcc1..4_sma3 (6) | F0semitone_sma3nz (1) | lldSetNoF0AndLoudnessNz_smo (14) |

@@ -8,6 +8,7 @@
 
 namespace smilehip {
 hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s);
+hipError_t stage_pcm_convert_float(const float *buf, int n_chan, int mixdown, int64_t n, float *out, hipStream_t s);
 hipError_t stage_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan, int mixdown, int64_t n, float *out,
                              hipStream_t s);
 hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,

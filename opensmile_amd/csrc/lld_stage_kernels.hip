@@ -192,6 +192,21 @@ __global__ void k_pcm_convert(const unsigned char *buf, int n_bps, int n_bits, i
   }
 }
 
+// smilePcm_convertFloatSamples (smileUtil.c:2629-2690): 32-bit IEEE float samples; the mono mix-down adds the channels to a
+// float zero in channel order and divides by the channel count (a single channel goes through the same two operations)
+__global__ void k_pcm_convert_float(const float *buf, int n_chan, int mixdown, int64_t n, float *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mixdown) {
+    if (i >= n) return;
+    float tmp = 0.0f;
+    for (int c = 0; c < n_chan; c++) tmp += buf[i * n_chan + c];
+    out[i] = tmp / (float)n_chan;
+  } else {
+    if (i >= n * n_chan) return;
+    out[i] = buf[i];
+  }
+}
+
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s) {
@@ -204,6 +219,11 @@ hipError_t stage_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan,
   if (work > 0)
     hipLaunchKernelGGL(k_pcm_convert, dim3(nblk(work, 256)), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(buf),
                        n_bps, n_bits, n_chan, mixdown, n, out);
+  return hipGetLastError();
+}
+hipError_t stage_pcm_convert_float(const float *buf, int n_chan, int mixdown, int64_t n, float *out, hipStream_t s) {
+  const int64_t work = mixdown ? n : n * n_chan;
+  if (work > 0) hipLaunchKernelGGL(k_pcm_convert_float, dim3(nblk(work, 256)), dim3(256), 0, s, buf, n_chan, mixdown, n, out);
   return hipGetLastError();
 }
 hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,

@@ -143,7 +143,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
                   double(nf * 254 + nf60 * 14 + nfin * 36) * 4e-9);
     }
     std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
-    if ((rc = b->d_pending_j.upload(zp))) {
+    if ((rc = b->d_pending_j.upload(zp)) || (rc = b->d_harm_ctl.upload(std::vector<int32_t>(2, 0)))) {
       delete b;
       return rc;
     }
@@ -647,6 +647,7 @@ static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *
   G.tile60 = fb->d_tile_rec.p;
   G.n_tiles60 = fb->n_tiles;
   G.pending = fb->d_pending.p;
+  G.harm_ctl = b->d_harm_ctl.p;
   G.func_in = b->d_func_in.p;
   G.fin_off = b->d_fin_off.p;
   G.pending_j = b->d_pending_j.p;

@@ -184,6 +184,7 @@ struct smilehip_batch {
   // eGeMAPS chain scratch (lld_gemaps.hip)
   DevBuf<float> d_raw20, d_spec220, d_lpc, d_formants, d_pitch3, d_shim, d_harm6, d_func_in;
   DevBuf<int32_t> d_pending_j;
+  DevBuf<int32_t> d_harm_ctl;             // eGeMAPS chain: lld_gemaps_harm's tile counter
   DevBuf<int64_t> d_fin_off;              // [n_utt+1] rows of func_in: T20 + 1 per utterance with a 60 ms frame
   std::vector<int64_t> h_fin_off;
   bool gm_ran = false;

@@ -36,6 +36,13 @@ extern "C" int smilehip_pcm_convert(smilehip_context *ctx, const void *d_raw, in
   STAGE_RET(stage_pcm_convert(d_raw, n_bps, n_bits, n_chan, mono_mixdown != 0, n, d_out, (hipStream_t)stream), "pcm_convert");
 }
 
+extern "C" int smilehip_pcm_convert_float(smilehip_context *ctx, const float *d_raw, int n_chan, int mono_mixdown, int64_t n,
+                                          float *d_out, void *stream) {
+  if (!ctx || n < 0 || n_chan < 1 || (n > 0 && (!d_raw || !d_out)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pcm_convert_float: bad argument");
+  STAGE_RET(stage_pcm_convert_float(d_raw, n_chan, mono_mixdown != 0, n, d_out, (hipStream_t)stream), "pcm_convert_float");
+}
+
 extern "C" int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
                                            int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream) {
   if (!ctx || N < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_preemphasis_frames: bad argument");

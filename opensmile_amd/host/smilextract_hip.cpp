@@ -350,10 +350,13 @@ int main(int argc, char **argv) {
       std::string e;
       WaveInfo &wi = c.info[k];
       if (!read_wave_file(jobs[c.j0 + k].wav, wi, c.raw[k], e)) { std::lock_guard<std::mutex> g(m); if (c.err.empty()) c.err = e; return; }
-      if (wi.sample_type != 1 || wi.n_chan < 1 || wi.n_bps < 1 || wi.n_bps > 4) {       // integer PCM of any width / channel count
+      // integer PCM of any width, or 32-bit IEEE float (the one float format the reference converts, smileUtil.c:2653-2662)
+      const bool int_ok = wi.sample_type == 1 && wi.n_bps >= 1 && wi.n_bps <= 4;
+      const bool float_ok = wi.sample_type == 3 && wi.n_bps == 4 && wi.n_bits == 32;
+      if (wi.n_chan < 1 || !(int_ok || float_ok)) {
         std::lock_guard<std::mutex> g(m);
-        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': integer PCM (8 / 16 / 24 / 32 bit, any number of channels) is what the fused path reads; "
-                                   "this file's sample type is not (IEEE-float WAV: not built)";
+        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': integer PCM (8 / 16 / 24 / 32 bit) or 32-bit IEEE float, any number of channels, "
+                                   "is what the reference converts (smilePcm_convertSamples / smilePcm_convertFloatSamples); this file is neither";
       }
     });
     return c;
@@ -387,13 +390,13 @@ int main(int argc, char **argv) {
       const std::vector<size_t> &idx = kv.second;
       // exact packing: utterance u = samples [off[u], off[u+1]) of one buffer (the kernels use
       // dword PCM loads when every offset is even, 16-bit loads otherwise). 16-bit mono files go to the device as they are
-      // (the kernels convert at the load); any other integer format / channel count is converted on the device by
-      // smilehip_pcm_convert -- cWaveSource's monoMixdown = 1 of every shipped file (standard_wave_input.conf.inc) -- and the chain
+      // (the kernels convert at the load); any other integer format / channel count and IEEE float are converted on the device by
+      // smilehip_pcm_convert / smilehip_pcm_convert_float -- cWaveSource's monoMixdown = 1 of every shipped file (standard_wave_input.conf.inc) -- and the chain
       // reads floats (smilehip_lld_run_f32)
       bool all_s16_mono = true;
       for (size_t i = 0; i < idx.size(); ++i) {
         const WaveInfo &wi = chunk.info[idx[i] - j0];
-        all_s16_mono = all_s16_mono && wi.n_bps == 2 && wi.n_chan == 1;
+        all_s16_mono = all_s16_mono && wi.sample_type == 1 && wi.n_bps == 2 && wi.n_chan == 1;
       }
       std::vector<int64_t> true_off(idx.size() + 1, 0);
       for (size_t i = 0; i < idx.size(); ++i) {
@@ -431,7 +434,10 @@ int main(int argc, char **argv) {
           const int64_t n = true_off[i + 1] - true_off[i];
           if (n <= 0) continue;
           check(smilehip_copy_to_device(ctx, d_raw, r.data(), (uint64_t)n * wi.n_bps * wi.n_chan, nullptr), "copy_to_device");
-          check(smilehip_pcm_convert(ctx, d_raw, wi.n_bps, wi.n_bits, wi.n_chan, 1, n, (float *)d_f32 + true_off[i], nullptr), "smilehip_pcm_convert");
+          if (wi.sample_type == 3)
+            check(smilehip_pcm_convert_float(ctx, (const float *)d_raw, wi.n_chan, 1, n, (float *)d_f32 + true_off[i], nullptr), "smilehip_pcm_convert_float");
+          else
+            check(smilehip_pcm_convert(ctx, d_raw, wi.n_bps, wi.n_bits, wi.n_chan, 1, n, (float *)d_f32 + true_off[i], nullptr), "smilehip_pcm_convert");
           check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");      // d_raw is reused by the next file
         }
         smilehip_free(ctx, d_raw);

@@ -139,6 +139,32 @@ def test_jitter_and_lld_columns_exact_on_identical_f0(hip, oracle):
     bf.close()
 
 
+def test_jitter_forms_agree_bit_for_bit(hip, monkeypatch):
+    """cPitchJitter's three forms -- runs of voiced frames taken from a counter (the default), one workgroup per utterance
+    (SMILEHIP_JITTER=utt, the form the stream mode and the redo pass use), and the runs with every utterance handed to the
+    redo pass (SMILEHIP_JITTER=redo) -- write the same bits, on ragged lengths incl. utterances without a 60 ms frame, a
+    noise-only one (no voiced frame), the all-zero one and the square wave (one run over the whole utterance); a second
+    run of the default form checks that the counters were left at zero."""
+    capi, ctx, plan = hip
+    from opensmile_amd import synth
+    lens = [160000, 100, 959, 48000, 1760, 160000, 9000, 160000, 0, 21280, 160000]
+    seeds = [0, 3, 4, 5, 6, 1, 7, 10, 8, 9, 12]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(s, n) if n else np.zeros(0, np.int16) for s, n in zip(seeds, lens)])
+    b = capi.Batch(plan, off)
+    monkeypatch.delenv("SMILEHIP_JITTER", raising=False)
+    base = b.run_host(pcm)[:, F0].copy()
+    assert np.isfinite(base).all() and (base[:, 2:6] != 0).any()
+    for mode in ("utt", "redo", None, None):
+        if mode:
+            monkeypatch.setenv("SMILEHIP_JITTER", mode)
+        else:
+            monkeypatch.delenv("SMILEHIP_JITTER", raising=False)
+        o = b.run_host(pcm)[:, F0]
+        assert np.array_equal(o.view(np.uint32), base.view(np.uint32)), f"mode {mode}: rows {sorted(set(np.argwhere(o != base)[:, 0]))[:8]}"
+    b.close()
+
+
 def test_compare_full_large_batch_properties(hip, oracle):
     """A per-GPU share in the direction of config 4 (3000 x 10 s = 3.0 M rows x 130 columns): size-independent
     properties -- row counts, copies of the same utterance give bit-identical rows wherever they sit in the batch,

@@ -1,4 +1,4 @@
-"""Float-sample input of the fused chains (smilehip_lld_run_f32) and every integer sample format through smilextract_hip.
+"""Float-sample input of the fused chains (smilehip_lld_run_f32), every integer sample format and IEEE-float files through smilextract_hip.
 
 cWaveSource hands the graph floats whatever the file held (smilePcm_convertSamples, smileUtil.c:2500-2627, monoMixdown = 1 in
 config/shared/standard_wave_input.conf.inc); the 16-bit mono run converts at the kernels' loads. The two must agree bit for bit:
@@ -143,12 +143,72 @@ def test_smilextract_hip_every_integer_format_equals_binary(set_name, conf, opts
             assert own == ref, f"{set_name} file {i} ({FORMATS[i] if i < len(FORMATS) else 'plain'}) {o}: files differ"
 
 
-def test_smilextract_hip_refuses_float_wav(tmp_path):
+def write_wav_float(path, x, fs):
+    """x: float32 array (n, n_chan): WAVE_FORMAT_IEEE_FLOAT (3), 32 bit"""
+    x = np.asarray(x, "<f4")
+    n, ch = x.shape
+    data = x.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, ch, fs, fs * ch * 4, ch * 4, 32))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+@pytest.mark.parametrize("set_name,conf,opts", [
+    ("mfcc12_0_d_a", "mfcc/MFCC12_0_D_A.conf", ["-O"]),
+    ("egemapsv02", "egemaps/v02/eGeMAPSv02.conf", ["-lldhtkoutput", "-htkoutput"]),
+])
+def test_smilextract_hip_ieee_float_wav_equals_binary(set_name, conf, opts, tmp_path):
+    """32-bit IEEE float files (smilePcm_convertFloatSamples, smileUtil.c:2629-2690): mono, stereo and three channels (the
+    mix-down's float additions in channel order), values beyond +-1 and a negative zero included; in one batch with an
+    integer file."""
+    if not (os.path.exists(REF) and os.path.exists(EXE) and os.path.isdir(REF_CONF)):
+        pytest.skip("oracle/_ref/SMILExtract (+ config/) or smilextract_hip not built")
+    from opensmile_amd import synth
+    wavs = []
+    for k, ch in enumerate([1, 2, 3]):
+        n = 16000 * 2 + 41 * k
+        x = np.stack([synth.utterance(960 + k + 13 * c, n).astype(np.float32) / np.float32(32768.0) * np.float32(1.3 - 0.4 * c)
+                      for c in range(ch)], axis=1)
+        x[5, :] = -0.0
+        w = str(tmp_path / f"fl{k}.wav")
+        write_wav_float(w, x, 16000)
+        wavs.append(w)
+    w = str(tmp_path / "plain.wav")
+    write_wav_fmt(w, _samples(970, 16000 + 5, 1, 2, 16), 16000, 2, 16)
+    wavs.append(w)
+    for i, w in enumerate(wavs):
+        args = [REF, "-C", os.path.join(REF_CONF, conf), "-I", w, "-l", "0"]
+        for o in opts:
+            args += [o, str(tmp_path / f"ref{i}{o}.htk")]
+        subprocess.run(args, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(w + "\n" for w in wavs))
+    outdir = tmp_path / "own"
+    outdir.mkdir()
+    args = [EXE, "--set", set_name, "-filelist", str(lst), "-outdir", str(outdir)]
+    for o in opts:
+        args += [o, "on"]
+    r = subprocess.run(args, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lld = set_name != "mfcc12_0_d_a"
+    ext = {"-O": ".htk", "-lldhtkoutput": ".lld.htk" if lld else ".htk", "-htkoutput": ".func.htk"}
+    for i, w in enumerate(wavs):
+        base = os.path.splitext(os.path.basename(w))[0]
+        for o in opts:
+            ref = open(tmp_path / f"ref{i}{o}.htk", "rb").read()
+            own = open(outdir / (base + ext[o]), "rb").read()
+            assert len(ref) > 12
+            assert own == ref, f"{set_name} file {i} {o}: files differ"
+
+
+def test_smilextract_hip_refuses_other_float_widths(tmp_path):
+    """64-bit float samples: the reference prints 'cannot convert unknown sample format' and delivers nothing; refused by name here"""
     w = str(tmp_path / "f.wav")
-    data = np.zeros(1600, "<f4").tobytes()
+    data = np.zeros(1600, "<f8").tobytes()
     with open(w, "wb") as f:
         f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
-        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32))
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 128000, 8, 64))
         f.write(b"data" + struct.pack("<I", len(data)) + data)
     r = subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-I", w, "-O", str(tmp_path / "o.htk")], capture_output=True)
-    assert r.returncode != 0 and b"IEEE-float" in r.stderr
+    assert r.returncode != 0 and b"IEEE float" in r.stderr

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase wave residence of the jitter kernels (instrumented build: tools/ubench/variant_any.sh jitter phasejit
--DSMILEHIP_PHASE_TIMING). usage: phase_timing_jitter.py [utterances]; SMILEHIP_JITTER_BY_UTT=1 times the per-utterance form."""
+-DSMILEHIP_PHASE_TIMING). usage: phase_timing_jitter.py [utterances]; SMILEHIP_JITTER=utt times the per-utterance form."""
 import ctypes as C
 import os
 import sys
