@@ -115,6 +115,43 @@ struct WaveG {                                           // (all 64 lanes call t
   }
 };
 
+// Sixteen consecutive lanes (a DPP row) work on one frame, four frames per wave: the reductions are butterflies of row
+// rotations (row_ror 8, 4, 2, 1 -- vector-ALU moves), after which every lane of the row holds the row's result. (Sums of doubles:
+// another association than WaveG's tree; like that one it differs from the reference's sequential sum by nothing that
+// survives the rounding to float that follows every use.)
+template <int ROR>
+__device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + ROR, 0xf, 0xf, true); }
+template <int ROR>
+__device__ __forceinline__ double row_ror_d(double x) { return __hiloint2double(row_ror_i<ROR>(__double2hiint(x)), row_ror_i<ROR>(__double2loint(x))); }
+struct QuadG {                                           // (all 64 lanes call these together)
+  __device__ static __forceinline__ int tid() { return threadIdx.x & 15; }
+  __device__ static __forceinline__ int size() { return 16; }
+  __device__ static __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ static __forceinline__ double sum(double v, double *) {
+    v += row_ror_d<8>(v); v += row_ror_d<4>(v); v += row_ror_d<2>(v); v += row_ror_d<1>(v);
+    return v;
+  }
+  __device__ static __forceinline__ double max(double v, double *) {
+    double w;
+    w = row_ror_d<8>(v); v = w > v ? w : v; w = row_ror_d<4>(v); v = w > v ? w : v;
+    w = row_ror_d<2>(v); v = w > v ? w : v; w = row_ror_d<1>(v); v = w > v ? w : v;
+    return v;
+  }
+  __device__ static __forceinline__ int sum_i(int v, int *) {
+    v += row_ror_i<8>(v); v += row_ror_i<4>(v); v += row_ror_i<2>(v); v += row_ror_i<1>(v);
+    return v;
+  }
+  __device__ static __forceinline__ int min_i(int v, int *) {
+    int w;
+    w = row_ror_i<8>(v); v = w < v ? w : v; w = row_ror_i<4>(v); v = w < v ? w : v;
+    w = row_ror_i<2>(v); v = w < v ? w : v; w = row_ror_i<1>(v); v = w < v ? w : v;
+    return v;
+  }
+};
+
 // workgroup-wide shorthands used by the per-component kernels
 __device__ __forceinline__ double block_sum(double v, double *scr) { return BlockG::sum(v, scr); }
 __device__ __forceinline__ double block_max(double v, double *scr) { return BlockG::max(v, scr); }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include <cmath>
 #include <type_traits>
@@ -15,6 +16,7 @@
 
 #include "lld_blocks.hpp"
 #include "lld_fft.hpp"
+#include "lld_ooura_quad.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
@@ -238,6 +240,211 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
   else is09_frame_body<WaveG>(P, Q, T, row, wave_mem);
 }
 
+// ---- SIXTEEN LANES per frame, four frames per wave (16 kHz / 25 ms: M = 256 with the reference-order tables).
+// The wave-per-frame form is bound by the vector ALU's issue rate at 3 455 instructions per frame: the 64 butterflies of a
+// transform level are one per lane and of mixed type / kind (the wave walks every variant), the reductions are six steps
+// deep, and the narrow phases -- 26 mel bands, 12 cepstra, one lane's scalar tail -- leave most of a wave idle. Here a DPP
+// row of 16 lanes owns a frame: the transform is lld_ooura_quad.hpp's schedule of the same network, every reduction a
+// four-step butterfly of row rotations, the narrow phases are shared by four frames, and every loop over samples / bins /
+// lags has a compile-time trip count (16 or 17 per lane; 32 predicated rounds over the frame's samples), so that a phase's
+// LDS reads are in flight together. Same operations on the same operands as the wave form: bit-identical outputs
+// (tests/test_gpu_is09.py::test_is09_quad_form_equals_wave_form_bit_for_bit).
+// LDS per frame: zx[2 x 272] the raw frame, then the transform's transposition / its 256 result pairs | mg[260] the windowed
+// frame (with sp), magnitudes, log spectrum, cepstrum | sp[260] mel input, ACF | lmel[32]: 4.4 KB; workgroups of four waves
+// (16 frames + 8 KB of tables = 78 KB), two per CU, persistent.
+namespace {
+constexpr int kQuadWaves = 4;
+constexpr int kQuadKpad = 260;
+constexpr int kQuadFrameFloats = 2 * kQuadZPairs + 2 * kQuadKpad + 32;
+// the tables the quad form reads: window | mel_coef | mel_rng | dct_rows (the reference-order transform's follow)
+__host__ __device__ inline int is09_quad_table_floats(int N) { return ((N + 3) & ~3) + kQuadKpad + 128 + 16 * 32; }
+
+// group_pitchacf_frame (lld_blocks.hpp) for a row of 16 lanes and n = 256 lags: the same selections, trip counts fixed
+__device__ __forceinline__ void quad_pitchacf_frame(const float *acf, const float *cep, double fsSec, double maxPitch, double &voicing,
+                                                    int &max_idx, double &Tsamp_out) {
+  constexpr int n = 256;
+  const int j = threadIdx.x & 15;
+  const double Tsamp = fsSec / (double)(2 * n);
+  Tsamp_out = Tsamp;
+  const int preskip = (maxPitch <= 0.0) ? 0 : (int)(1.0 / (maxPitch * Tsamp));
+  float a[16], am[16], c[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) { const int i = j + 16 * it; a[it] = acf[i]; am[it] = i > 0 ? acf[i - 1] : 0.0f; c[it] = cep[i]; }
+  double vmax = acf[n - 1];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int i = j + 16 * it;
+    if (i >= 1 && i >= preskip && ((double)a[it] > vmax) && (am[it] < a[it])) vmax = a[it];
+  }
+  vmax = QuadG::max(vmax, nullptr);
+  const float a0 = acf[0];
+  voicing = (a0 > 0.0f) ? vmax / (double)a0 : 0.0;
+  const int skip = preskip + 1;
+  double csum = 0.0, cmax = cep[n - 1];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int i = j + 16 * it;
+    const double b = c[it];
+    csum += fabs(b);
+    if (i >= skip && b > cmax) cmax = b;
+  }
+  csum = QuadG::sum(csum, nullptr) / n;
+  cmax = QuadG::max(cmax, nullptr);
+  const double thr = (cmax + csum) * 0.6;
+  int first = 1 << 30;
+#pragma unroll
+  for (int it = 15; it >= 0; --it) {                       // (descending: the lane's smallest qualifying index stays)
+    const int i = j + 16 * it;
+    if (i >= skip + 1 && i < n - 1) {
+      const float cm = cep[i - 1], cp = cep[i + 1];
+      if ((double)c[it] > thr && (cm < c[it]) && (c[it] > cp)) first = i;
+    }
+  }
+  first = QuadG::min_i(first, nullptr);
+  max_idx = (first == (1 << 30)) ? 0 : first;
+}
+
+__device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *fmem) {
+  constexpr int M = 256;
+  const int lane64 = threadIdx.x & 63, j = lane64 & 15;
+  float *xr = fmem;
+  float2 *z = reinterpret_cast<float2 *>(fmem);
+  float *mg = fmem + 2 * kQuadZPairs;
+  float *sp = mg + kQuadKpad;
+  float *yv = mg;                                          // the windowed frame lives in mg | sp until the transform has read it
+  float *lmel = sp + kQuadKpad;
+  const int N = P.N;
+  const int lo = P.frame_utt[row];
+  const int64_t t = row - P.frame_off[lo];
+  const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
+  float *out = Q.raw16 + row * 16;
+  IPHASE_DECL
+#pragma unroll
+  for (int it = 0; it < 32; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = x[n]; }      // R0 (or already done: float input)
+  QuadG::sync();
+  IPHASE(0);   // utterance lookup + frame load
+  // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
+  {
+    int cnt = 0;
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+      const int i = 1 + j + 16 * it;
+      if (i < N - 1)
+        if (((xr[i - 1] * xr[i + 1] <= 0.0f) && (xr[i] == 0.0f)) || (xr[i - 1] * xr[i] < 0.0f)) ++cnt;
+    }
+    const int total = QuadG::sum_i(cnt, nullptr);
+    if (j == 0) out[13] = (float)total / (float)N;
+  }
+  IPHASE(1);   // ZCR
+  // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
+  double e2 = 0.0;
+#pragma unroll 8
+  for (int it = 0; it < 32; ++it) {
+    const int n = j + 16 * it;
+    if (n < N) {
+      float y = xr[n];
+      if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
+      y = y * T.window[n] + P.win_offset;
+      yv[n] = y;
+      const float sq = y * y;
+      e2 += (double)sq;
+    }
+  }
+  {
+    const double d = QuadG::sum(e2, nullptr);
+    if (j == 0) out[0] = (float)sqrt(d / (float)N) * 1.0f + 0.0f;
+  }
+  QuadG::sync();
+  IPHASE(2);   // pre-emphasis, window, RMS energy
+  // R4 forward real FFT in the reference's operation order, R5 magnitudes
+  oo_quad_forward(z, T.oo, lane64, [&](int i) {
+    const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+    return make_float2((n0 >= 0 && n0 < N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < N) ? yv[n1] : 0.0f);
+  });
+  {
+    float mv[17];
+#pragma unroll
+    for (int m = 0; m < 17; ++m) {
+      const int k = j + 16 * m;
+      mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
+    }
+    QuadG::sync();                                         // (the windowed frame is dead: z holds the spectrum)
+#pragma unroll
+    for (int m = 0; m < 17; ++m) { const int k = j + 16 * m; if (k <= M) { mg[k] = mv[m]; sp[k] = P.use_power ? mv[m] * mv[m] : mv[m]; } }
+  }
+  QuadG::sync();
+  IPHASE(3);   // forward transform + magnitudes
+  // R6 / R7: mel (usePower per config) -> log -> DCT
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int b = j + 16 * h;
+    if (b < P.n_bands) lmel[b] = log_mel(mel_band_exact(sp, T.mel_coef, T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
+  }
+  QuadG::sync();
+  if (j < P.n_mfcc) out[1 + j] = dct_coeff(lmel, T.dct_rows + j * P.n_bands, P.n_bands, P.dct_gain[j]);
+  QuadG::sync();
+  IPHASE(4);   // mel, log, DCT
+  // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum (usePower = 1, :252-259) into sp ...
+  oo_quad_irfft_even(z, T.oo, sp, (float)P.K, true, lane64, [&](int e) {
+    if (e == 0) { const float m0 = mg[0], m1 = mg[M]; return make_float2(m0 * m0, m1 * m1); }
+    const float m = mg[e];
+    return make_float2(m * m, 0.0f);
+  });
+  // ... then the cepstrum instance: log(P + 1) (:288-305) in place of the magnitudes, its lags in their place again
+#pragma unroll
+  for (int m = 0; m < 17; ++m) {
+    const int k = j + 16 * m;
+    if (k <= M) {
+      const float p = mg[k] * mg[k];
+      mg[k] = (p > 0.0f) ? (float)log_d((double)p + 1.0) : 0.0f;
+    }
+  }
+  QuadG::sync();
+  oo_quad_irfft_even(z, T.oo, mg, (float)P.K, false, lane64, [&](int e) { return e == 0 ? make_float2(mg[0], mg[M]) : make_float2(mg[e], 0.0f); });
+  IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
+  // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
+  double voicing, Tsamp;
+  int max_idx;
+  quad_pitchacf_frame(sp, mg, Q.fsSec, Q.maxPitch, voicing, max_idx, Tsamp);
+  if (j == 0) {
+    long maxIdx = max_idx;
+    float pitch = 0.0f;
+    if (maxIdx > 0) pitch = 1.0f / ((float)maxIdx * (float)Tsamp);
+    if (voicing < Q.voicingCutoff) pitch = 0.0f;
+    out[14] = (float)voicing;
+    out[15] = pitch;                                    // smoothed in place by lld_pitch_smooth
+  }
+  QuadG::sync();
+  IPHASE(6);   // cPitchACF
+  IPHASE_FLUSH;
+}
+}  // namespace
+
+// persistent workgroups; rows past the end of the batch repeat the last frame (same values to the same cells)
+__global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Npad = (P.N + 3) & ~3;
+  float *s_win = smem;
+  float *s_coef = s_win + Npad;
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + kQuadKpad);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < P.N; i += kQuadWaves * 64) s_win[i] = P.window[i];
+  for (int i = threadIdx.x; i < P.K; i += kQuadWaves * 64) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * P.n_bands; i += kQuadWaves * 64) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += kQuadWaves * 64) s_dct[i] = P.dct_rows[i];
+  const OouraTab s_oo = oo_stage_tables(P.oo, smem + is09_quad_table_floats(P.N), threadIdx.x, kQuadWaves * 64);
+  __syncthreads();                                       // the only workgroup barrier
+  const Is09Tbl T = {s_win, nullptr, nullptr, s_coef, s_rng, s_dct, s_oo};
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = (threadIdx.x & 63) >> 4;
+  float *fmem = smem + is09_quad_table_floats(P.N) + oo_table_floats(P.oo) + (wave * 4 + g) * kQuadFrameFloats;
+  for (int64_t row0 = ((int64_t)blockIdx.x * kQuadWaves + wave) * 4; row0 < P.total_frames; row0 += (int64_t)gridDim.x * (4 * kQuadWaves)) {
+    int64_t row = row0 + g;
+    if (row >= P.total_frames) row = P.total_frames - 1;
+    is09_quad_body(P, Q, T, row, fmem);
+  }
+}
+
 // R10, sequential part: cPitchACF's causal contour (lld_pitch_contour.hpp), state per utterance. One thread per utterance.
 __global__ void __launch_bounds__(64) lld_pitch_smooth(const int64_t *frame_off, int n_utt, float *raw16) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,8 +490,24 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   const size_t lds_wave = sizeof(float) * (size_t)(Npad + 2 * fft_pairs(M) + 2 * Kpad + M + 32) + 4 * sizeof(double) + 8 * sizeof(int);
   hipError_t e;
   const size_t tbl_floats = (size_t)is09_table_floats(P.N, M, P.K) + (size_t)oo_table_floats(P.oo);
-  if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
-      !getenv("SMILEHIP_IS09_BLOCK")) {                                // a wave per frame: four frames per workgroup
+  const size_t quad_bytes = sizeof(float) * ((size_t)is09_quad_table_floats(P.N) + (size_t)oo_table_floats(P.oo) +
+                                             (size_t)kQuadWaves * 4 * (size_t)kQuadFrameFloats);
+  // SMILEHIP_IS09 (A/B switch): "wave" = one wave per frame, "block" = one workgroup per frame (the forms before the quad one)
+  const char *form = getenv("SMILEHIP_IS09");
+  if (P.oo.tw && M == 256 && P.K == 257 && P.N <= 512 && P.frame_utt && P.n_bands <= 32 && P.n_mfcc <= 16 && quad_bytes <= 160 * 1024 && !form) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess) return e;
+    static const int n_cu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+      return n;
+    }();
+    int64_t grid = (P.total_frames + 4 * kQuadWaves - 1) / (4 * kQuadWaves);
+    const int64_t cap = (int64_t)(n_cu > 0 ? n_cu : 256) * (int64_t)(160 * 1024 / quad_bytes);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(lld_is09_frame_quad, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+  } else if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
+      !(form && !strcmp(form, "block"))) {                             // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds_wave + 15) / 16) * 4;
     const size_t total = sizeof(float) * (tbl_floats + 4 * (size_t)wave_floats);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);

@@ -90,7 +90,7 @@ def test_window_chain_sma_delta_bit_exact(hip, oracle):
 def test_is09_other_sample_rates_wave_equals_workgroup_kernel():
     """Geometries other than 16 kHz / 25 ms: 8 kHz (N = 200, M = 128: the wave kernel's run-time-M path with the generic pair
     transform), 32 kHz (N = 800, M = 512: the fused transform) -- the wave-per-frame kernel against the one-workgroup-per-frame
-    kernel (SMILEHIP_IS09_BLOCK=1), which runs the in-place radix-2 transform and the workgroup reductions: same values within
+    kernel (SMILEHIP_IS09=block), which runs the in-place radix-2 transform and the workgroup reductions: same values within
     the chain's tolerance (the energy sums use different trees)."""
     import os
     from opensmile_amd import capi, synth
@@ -104,11 +104,36 @@ def test_is09_other_sample_rates_wave_equals_workgroup_kernel():
         pcm = np.concatenate([synth.utterance(40 + i, n, fs=fs) for i, n in enumerate(lens)])
         b = capi.Batch(plan, off)
         a = b.run_host(pcm)
-        os.environ["SMILEHIP_IS09_BLOCK"] = "1"
+        os.environ["SMILEHIP_IS09"] = "block"
         try:
             r = b.run_host(pcm)
         finally:
-            del os.environ["SMILEHIP_IS09_BLOCK"]
+            del os.environ["SMILEHIP_IS09"]
         b.close()
         assert a.shape == r.shape and a.shape[0] > 0 and np.isfinite(a).all()
         check_lld(a, r.astype(np.float64), f"fs{fs}")
+
+
+def test_is09_quad_form_equals_wave_form_bit_for_bit(monkeypatch):
+    """16 kHz / 25 ms: the sixteen-lanes-per-frame kernel (four frames per wave, lld_ooura_quad.hpp) against the wave-per-frame
+    kernel (SMILEHIP_IS09=wave) -- the same butterflies on the same operands, the same sequential band / cepstrum sums: every
+    cell but the RMS energy (a double sum whose association differs; rounded to float afterwards) must carry the same bits, and
+    the energy column too on these inputs. Ragged lengths: a batch whose last pass is not full, the all-zero and the clipping
+    utterance."""
+    from opensmile_amd import capi, synth
+    ctx = capi.Context(0)
+    plan = capi.Plan(ctx, capi.is09_lld_config())
+    lens = [48000, 400, 561, 16000, 160000, 24000, 399, 719]
+    seeds = [0, 1, 2, 3, 4, 10, 5, 6]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = np.concatenate([synth.utterance(s, n) for s, n in zip(seeds, lens)])
+    b = capi.Batch(plan, off)
+    monkeypatch.delenv("SMILEHIP_IS09", raising=False)
+    q = b.run_host(pcm)
+    monkeypatch.setenv("SMILEHIP_IS09", "wave")
+    w = b.run_host(pcm)
+    monkeypatch.delenv("SMILEHIP_IS09", raising=False)
+    b.close()
+    assert q.shape == w.shape and q.shape[0] == sum(max(0, (n - 400) // 160 + 1) + (1 if n >= 400 else 0) for n in lens)
+    d = q.view(np.uint32) != w.view(np.uint32)
+    assert not d.any(), f"{d.sum()} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))}, first rows {sorted(set(np.argwhere(d)[:, 0]))[:6]}"
