@@ -261,9 +261,8 @@ __host__ __device__ inline int is09_quad_table_floats(int N) { return ((N + 3) &
 
 // group_pitchacf_frame (lld_blocks.hpp) for a row of 16 lanes and n = 256 lags: the same selections, trip counts fixed
 __device__ __forceinline__ void quad_pitchacf_frame(const float *acf, const float *cep, double fsSec, double maxPitch, double &voicing,
-                                                    int &max_idx, double &Tsamp_out) {
+                                                    int &max_idx, double &Tsamp_out, int j) {
   constexpr int n = 256;
-  const int j = threadIdx.x & 15;
   const double Tsamp = fsSec / (double)(2 * n);
   Tsamp_out = Tsamp;
   const int preskip = (maxPitch <= 0.0) ? 0 : (int)(1.0 / (maxPitch * Tsamp));
@@ -304,9 +303,28 @@ __device__ __forceinline__ void quad_pitchacf_frame(const float *acf, const floa
   max_idx = (first == (1 << 30)) ? 0 : first;
 }
 
-__device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *fmem) {
+// The samples of frame `row` that lane j of the frame's row of lanes keeps: x[j + 16 it], it < NIT (R0 done at the load)
+template <int NIT>
+__device__ __forceinline__ void is09_quad_fetch(const LldParams &P, int64_t row, float (&R)[NIT], int j) {
+  const int lo = P.frame_utt[row];
+  const int64_t t = row - P.frame_off[lo];
+  const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; R[it] = (n < P.N) ? x[n] : 0.0f; }
+}
+
+// One pass: the four frames whose samples R holds. Before the last phase (which needs few registers) the samples of the
+// wave's next pass are requested into R again (next_row < 0: none), so that their latency is the pitch phase's.
+template <int NIT>
+__device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *fmem,
+                                               float (&R)[NIT], int64_t next_row) {
   constexpr int M = 256;
-  const int lane64 = threadIdx.x & 63, j = lane64 & 15;
+  // The thread index is made opaque per pass: what depends on the lane alone (addresses, the masks of the unrolled loops) is
+  // loop-invariant over the wave's passes, and the compiler would carry all of it across the loop (44 registers, see f0_shs)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane64 = tid & 63, j = tid & 15;
+  fmem += ((lane64 >> 4)) * kQuadFrameFloats;              // (fmem: the wave's four frame regions)
   float *xr = fmem;
   float2 *z = reinterpret_cast<float2 *>(fmem);
   float *mg = fmem + 2 * kQuadZPairs;
@@ -314,20 +332,17 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   float *yv = mg;                                          // the windowed frame lives in mg | sp until the transform has read it
   float *lmel = sp + kQuadKpad;
   const int N = P.N;
-  const int lo = P.frame_utt[row];
-  const int64_t t = row - P.frame_off[lo];
-  const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
   float *out = Q.raw16 + row * 16;
   IPHASE_DECL
 #pragma unroll
-  for (int it = 0; it < 32; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = x[n]; }      // R0 (or already done: float input)
+  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = R[it]; }
   QuadG::sync();
   IPHASE(0);   // utterance lookup + frame load
   // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
   {
     int cnt = 0;
 #pragma unroll 8
-    for (int it = 0; it < 32; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int i = 1 + j + 16 * it;
       if (i < N - 1)
         if (((xr[i - 1] * xr[i + 1] <= 0.0f) && (xr[i] == 0.0f)) || (xr[i - 1] * xr[i] < 0.0f)) ++cnt;
@@ -339,7 +354,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
   double e2 = 0.0;
 #pragma unroll 8
-  for (int it = 0; it < 32; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int n = j + 16 * it;
     if (n < N) {
       float y = xr[n];
@@ -367,6 +382,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     for (int m = 0; m < 17; ++m) {
       const int k = j + 16 * m;
       mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
+      if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);   // (six bins' loads in flight at a time: all 17 at once spill)
     }
     QuadG::sync();                                         // (the windowed frame is dead: z holds the spectrum)
 #pragma unroll
@@ -402,10 +418,11 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   QuadG::sync();
   oo_quad_irfft_even(z, T.oo, mg, (float)P.K, false, lane64, [&](int e) { return e == 0 ? make_float2(mg[0], mg[M]) : make_float2(mg[e], 0.0f); });
   IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
+  if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);
   // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
   double voicing, Tsamp;
   int max_idx;
-  quad_pitchacf_frame(sp, mg, Q.fsSec, Q.maxPitch, voicing, max_idx, Tsamp);
+  quad_pitchacf_frame(sp, mg, Q.fsSec, Q.maxPitch, voicing, max_idx, Tsamp, j);
   if (j == 0) {
     long maxIdx = max_idx;
     float pitch = 0.0f;
@@ -421,7 +438,8 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 }  // namespace
 
 // persistent workgroups; rows past the end of the batch repeat the last frame (same values to the same cells)
-__global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
+template <int NIT>                                       // samples per lane: N <= 16 NIT
+__global__ void __launch_bounds__(kQuadWaves * 64) lld_is09_frame_quad(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Npad = (P.N + 3) & ~3;
   float *s_win = smem;
@@ -437,11 +455,15 @@ __global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_p
   const Is09Tbl T = {s_win, nullptr, nullptr, s_coef, s_rng, s_dct, s_oo};
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = (threadIdx.x & 63) >> 4;
-  float *fmem = smem + is09_quad_table_floats(P.N) + oo_table_floats(P.oo) + (wave * 4 + g) * kQuadFrameFloats;
-  for (int64_t row0 = ((int64_t)blockIdx.x * kQuadWaves + wave) * 4; row0 < P.total_frames; row0 += (int64_t)gridDim.x * (4 * kQuadWaves)) {
-    int64_t row = row0 + g;
-    if (row >= P.total_frames) row = P.total_frames - 1;
-    is09_quad_body(P, Q, T, row, fmem);
+  float *fmem = smem + is09_quad_table_floats(P.N) + oo_table_floats(P.oo) + (wave * 4) * kQuadFrameFloats;
+  const int64_t stride = (int64_t)gridDim.x * (4 * kQuadWaves), last = P.total_frames - 1;
+  int64_t row0 = ((int64_t)blockIdx.x * kQuadWaves + wave) * 4;
+  if (row0 > last) return;
+  float R[NIT];
+  is09_quad_fetch<NIT>(P, row0 + g < last ? row0 + g : last, R, (int)(threadIdx.x & 15));
+  for (; row0 <= last; row0 += stride) {
+    const int64_t nxt = row0 + stride;
+    is09_quad_body<NIT>(P, Q, T, row0 + g < last ? row0 + g : last, fmem, R, nxt <= last ? (nxt + g < last ? nxt + g : last) : (int64_t)-1);
   }
 }
 
@@ -495,7 +517,9 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   // SMILEHIP_IS09 (A/B switch): "wave" = one wave per frame, "block" = one workgroup per frame (the forms before the quad one)
   const char *form = getenv("SMILEHIP_IS09");
   if (P.oo.tw && M == 256 && P.K == 257 && P.N <= 512 && P.frame_utt && P.n_bands <= 32 && P.n_mfcc <= 16 && quad_bytes <= 160 * 1024 && !form) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    const bool n25 = P.N <= 400;                           // 25 ms at 16 kHz: 25 samples per lane
+    const void *qfn = n25 ? reinterpret_cast<const void *>(&lld_is09_frame_quad<25>) : reinterpret_cast<const void *>(&lld_is09_frame_quad<32>);
+    e = hipFuncSetAttribute(qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     static const int n_cu = [] {
       int dev = 0, n = 0;
@@ -505,7 +529,8 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
     int64_t grid = (P.total_frames + 4 * kQuadWaves - 1) / (4 * kQuadWaves);
     const int64_t cap = (int64_t)(n_cu > 0 ? n_cu : 256) * (int64_t)(160 * 1024 / quad_bytes);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(lld_is09_frame_quad, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    if (n25) hipLaunchKernelGGL(lld_is09_frame_quad<25>, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    else hipLaunchKernelGGL(lld_is09_frame_quad<32>, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
   } else if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
       !(form && !strcmp(form, "block"))) {                             // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds_wave + 15) / 16) * 4;

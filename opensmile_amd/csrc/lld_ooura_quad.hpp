@@ -106,7 +106,10 @@ __device__ __forceinline__ void oo_quad_inverse(float2 *z, const OouraTab &T, in
   float2 v[16];
   const int j = lane & 15;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = pre(16 * r + j);
+  for (int r = 0; r < 16; ++r) {
+    v[r] = pre(16 * r + j);
+    if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);     // (four elements' loads in flight at a time)
+  }
   oo_quad256<true>(v, T, z, lane);
   oo_quad_store(v, z, lane);
 }
