@@ -62,7 +62,7 @@ CONFIGS = {
     3: dict(cfg="is09_lld_config", utts=10000, samples=160000, steps=10, warmup=3,
             workload="IS09_emotion LLD (MFCC 1-12, RMS energy, ZCR, voiceProb, F0 via cAcf / cPitchACF; 16 LLD + 16 delta) on "
                      "10 000 x 10 s synthetic 16 kHz mono int16 per GPU, 25 ms / 10 ms, PCM resident in HBM",
-            kernel="lld_is09_frame_wave (+ lld_pitch_smooth)", pmc_kernels=["lld_is09_frame_wave", "lld_pitch_smooth"], alg_bytes=2 * 160 + 4 * 16,
+            kernel="lld_is09_frame_quad (+ lld_pitch_smooth)", pmc_kernels=["lld_is09_frame", "lld_pitch_smooth"], alg_bytes=2 * 160 + 4 * 16,
             alg_note="int16 hop in + 16 f32 pre-smoothing columns out per frame (SURVEY 8d counts 448 B for the whole chain incl. deltas)",
             conf="is09-13/IS09_emotion.conf", opt="-lldhtkoutput"),
     4: dict(cfg="compare16_config", utts=12500, samples=160000, steps=4, warmup=1,

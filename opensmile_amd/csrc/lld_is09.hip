@@ -439,7 +439,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 
 // persistent workgroups; rows past the end of the batch repeat the last frame (same values to the same cells)
 template <int NIT>                                       // samples per lane: N <= 16 NIT
-__global__ void __launch_bounds__(kQuadWaves * 64) lld_is09_frame_quad(LldParams P, Is09Params Q) {
+__global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Npad = (P.N + 3) & ~3;
   float *s_win = smem;

@@ -236,29 +236,43 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
         const double sx = bx + ex, sy = (bx + bp + ep) - sx;     // sum of x[0..tf), sum of x[tf..2tf)
         const double mx = sx / (double)tf, my = sy / (double)tf;
         // one pass in rounds of four samples, the next round's samples loaded before the current round's sums (the
-        // sums stay sequential in the reference's order)
+        // sums stay sequential in the reference's order); two rounds per loop iteration on alternating registers
         double cc = 0.0, nx = 0.0, ny = 0.0;
         {
-          float xv[4], yv[4], xn[4], yn[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
-          for (long r = 0; r < nr; ++r) {
-            const long i1 = (r + 1) << 2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+          const auto add4 = [&](const float (&xs)[4], const float (&ys)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
+              const double dx = (double)xs[q] - mx, dy = (double)ys[q] - my;
               cc += dx * dy;
               nx += dx * dx;
               ny += dy * dy;
             }
+          };
+          const int nri = (int)nr;
+          float xv[4], yv[4], xn[4], yn[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
+          int r = 0;
+          for (; r + 2 <= nri; r += 2) {
+            const int i1 = (r + 1) << 2, i2 = (r + 2) << 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+            add4(xv, yv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xv[q] = xa[i2 + q]; yv[q] = ya[i2 + q]; }
+            add4(xn, yn);
+          }
+          if (r < nri) {
+            const int i1 = (r + 1) << 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xn[q] = xa[i1 + q]; yn[q] = ya[i1 + q]; }
+            add4(xv, yv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { xv[q] = xn[q]; yv[q] = yn[q]; }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if ((nr << 2) + q < tf) {
+            if ((nri << 2) + q < (int)tf) {
               const double dx = (double)xv[q] - mx, dy = (double)yv[q] - my;
               cc += dx * dy;
               nx += dx * dx;

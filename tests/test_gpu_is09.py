@@ -123,7 +123,14 @@ def test_is09_quad_form_equals_wave_form_bit_for_bit(monkeypatch):
     from opensmile_amd import capi, synth
     ctx = capi.Context(0)
     plan = capi.Plan(ctx, capi.is09_lld_config())
-    lens = [48000, 400, 561, 16000, 160000, 24000, 399, 719]
+    _quad_vs_wave(capi, synth, plan, 400, monkeypatch)
+    cfg = capi.is09_lld_config()                           # 32 ms frames: 512 samples, still FFT 512 (32 samples per lane)
+    cfg.frame_size_sec = 0.032
+    _quad_vs_wave(capi, synth, capi.Plan(ctx, cfg), 512, monkeypatch)
+
+
+def _quad_vs_wave(capi, synth, plan, N, monkeypatch):
+    lens = [48000, N, N + 161, 16000, 160000, 24000, N - 1, N + 319]
     seeds = [0, 1, 2, 3, 4, 10, 5, 6]
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     pcm = np.concatenate([synth.utterance(s, n) for s, n in zip(seeds, lens)])
@@ -134,6 +141,6 @@ def test_is09_quad_form_equals_wave_form_bit_for_bit(monkeypatch):
     w = b.run_host(pcm)
     monkeypatch.delenv("SMILEHIP_IS09", raising=False)
     b.close()
-    assert q.shape == w.shape and q.shape[0] == sum(max(0, (n - 400) // 160 + 1) + (1 if n >= 400 else 0) for n in lens)
+    assert q.shape == w.shape and q.shape[0] == sum(max(0, (n - N) // 160 + 1) + (1 if n >= N else 0) for n in lens)
     d = q.view(np.uint32) != w.view(np.uint32)
     assert not d.any(), f"{d.sum()} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))}, first rows {sorted(set(np.argwhere(d)[:, 0]))[:6]}"
