@@ -660,6 +660,28 @@ int smilehip_pitchacf_contour_step(smilehip_context *ctx, const double *d_voicin
  * with SMILEHIP_STAGE_SPECTRAL (or a ComParE chain plan). */
 int smilehip_spectral_frames(smilehip_plan *plan, const float *d_mag, int64_t ld_src, float *d_state, int first,
                              float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R11, every option set of the shipped configuration files: cSpectral::processVector (spectral.cpp:586-1560; options :31-63, output
+ * order = the order of the fields below) with squareInput = 1 on a linear magnitude spectrum, freqRange 0-0, normBandEnergies = 0,
+ * useLogSpectrum = 0, buggyRollOff = 0, oldSlopeScale = 1. An operator object holds what follows from the options and the frequency axis
+ * (frq[i] = i / frame_size_sec, i < K: the axis cTransformFFT attaches, transformFft.cpp:102-117). Frames of ONE stream in order:
+ * d_state (K floats; needed when flux is on) carries the last frame's magnitudes from call to call, `first` != 0 marks the stream's
+ * first frame (a single 0 for the flux, :1132-1136). One thread per frame, every sum the reference's own sequential chain. */
+typedef struct smilehip_spectral_opts {
+  int32_t n_bands;              /* bands[]: lo-hi in Hz, <= 16 */
+  int32_t band_lo[16], band_hi[16];
+  int32_t n_rolloff;            /* rollOff[]: <= 16 */
+  double  rolloff[16];
+  int32_t flux, centroid, max_pos, min_pos, entropy, variance, skewness, kurtosis, slope, sharpness, harmonicity;
+  int32_t flatness, log_flatness;      /* flatness: one output; log_flatness: its logarithm instead (:1515-1545) */
+} smilehip_spectral_opts;
+typedef struct smilehip_spectral_op smilehip_spectral_op;
+int smilehip_spectral_opts_count(const smilehip_spectral_opts *opts);      /* outputs per frame, -1 if out of range */
+int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip_spectral_opts *opts, int64_t K, double frame_size_sec,
+                                smilehip_spectral_op **op);
+int smilehip_spectral_op_n_out(const smilehip_spectral_op *op);
+int smilehip_spectral_op_frames(smilehip_spectral_op *op, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                                float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+int smilehip_spectral_op_destroy(smilehip_spectral_op *op);
 /* R8: cPlp::processVector as auditory spectrum (doAud = 1, doIDFT = doLP = 0; plp.cpp:416-593). d_eql: the
  * equal-loudness weights of the bands (their logs when new_rasta, plp.cpp:335-357), as cPlp::initTables
  * derives them from the input level's band-centre metadata. new_rasta: rasta_coef (host) = {iir, fir[0..4]}

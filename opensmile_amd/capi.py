@@ -80,6 +80,27 @@ class FuncSpec(C.Structure):
     ]
 
 
+class SpectralOpts(C.Structure):
+    """smilehip_spectral_opts (include/smilehip.h): cSpectral's general option set"""
+    _fields_ = [("n_bands", C.c_int32), ("band_lo", C.c_int32 * 16), ("band_hi", C.c_int32 * 16), ("n_rolloff", C.c_int32),
+                ("rolloff", C.c_double * 16)] + [(k, C.c_int32) for k in ("flux", "centroid", "max_pos", "min_pos", "entropy", "variance",
+                                                                          "skewness", "kurtosis", "slope", "sharpness", "harmonicity", "flatness",
+                                                                          "log_flatness")]
+
+
+def spectral_opts(bands, rolloff=(0.25, 0.5, 0.75, 0.9), **flags):
+    o = SpectralOpts()
+    o.n_bands = len(bands)
+    for i, (a, b) in enumerate(bands):
+        o.band_lo[i], o.band_hi[i] = a, b
+    o.n_rolloff = len(rolloff)
+    for i, r in enumerate(rolloff):
+        o.rolloff[i] = r
+    for k, v in flags.items():
+        setattr(o, k, int(v))
+    return o
+
+
 class Geometry(C.Structure):
     """smilehip_geometry"""
     _fields_ = [("frame_size", C.c_int64), ("frame_step", C.c_int64), ("fft_size", C.c_int64),
@@ -177,6 +198,11 @@ SYMBOLS = {
     "smilehip_pitchacf_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "smilehip_pitchacf_contour_step": (C.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     "smilehip_spectral_frames": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp, _i64, _i64, _vp]),
+    "smilehip_spectral_opts_count": (C.c_int, [_vp]),
+    "smilehip_spectral_op_create": (C.c_int, [_vp, _vp, _i64, C.c_double, _vp]),
+    "smilehip_spectral_op_n_out": (C.c_int, [_vp]),
+    "smilehip_spectral_op_frames": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp, _i64, _i64, _vp]),
+    "smilehip_spectral_op_destroy": (C.c_int, [_vp]),
     "smilehip_plp_audspec_frames": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, _i64,
                                              _i64, _vp]),
     "smilehip_plp_cc_frames": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, _i64, _i64,

@@ -59,6 +59,20 @@ hipError_t stage_pitchacf(const float *src, int64_t lds, int64_t nF, int n, doub
 struct PlpConsts { float melfloor, compression, iir, fir[5]; };
 hipError_t stage_spectral(const float *src, int64_t lds, float *state, bool first, float *dst, int64_t ldd, int64_t nF, int K,
                           const SpectralConsts &C, hipStream_t s);
+// cSpectral, general option set (lld_spectral_general.hip): what the kernel needs of smilehip_spectral_opts, ready to use
+struct SpectralGeneral {
+  int32_t K;
+  double frame_size_sec;
+  int32_t n_bands, band_iL[16], band_iR[16];            // edge bins and their weights (spectral.cpp:779-826)
+  double band_wL[16], band_wR[16];
+  int32_t n_rolloff;
+  double rolloff[16];
+  int32_t flux, centroid, max_pos, min_pos, entropy, variance, skewness, kurtosis, slope, sharpness, harmonicity, flatness, log_flatness;
+  double slope_Sf, slope_S2f;                           // sums of frq and frq^2 over bins 1 .. K-1 (:1405-1412)
+  const double *sharp_w;                                // [K - 1] sharpness weights of bins 1 .. K-1 (:1440-1455)
+};
+hipError_t stage_spectral_general(const SpectralGeneral &G, const float *mag, int64_t ld_src, float *state, int first, float *dst,
+                                  int64_t ld_dst, int64_t n_frames, hipStream_t s);
 hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,
                      float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,

@@ -43,6 +43,100 @@ extern "C" int smilehip_pcm_convert_float(smilehip_context *ctx, const float *d_
   STAGE_RET(stage_pcm_convert_float(d_raw, n_chan, mono_mixdown != 0, n, d_out, (hipStream_t)stream), "pcm_convert_float");
 }
 
+// ---- R11, general option set: an operator object (the band edges, the slope's sums and the sharpness weights are functions of the
+// options and the frequency axis alone)
+struct smilehip_spectral_op {
+  smilehip_context *ctx = nullptr;
+  SpectralGeneral G;
+  DevBuf<double> d_sharp;
+  int n_out = 0;
+};
+extern "C" int smilehip_spectral_op_destroy(smilehip_spectral_op *op) {
+  delete op;
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_spectral_op_n_out(const smilehip_spectral_op *op) { return op ? op->n_out : -1; }
+extern "C" int smilehip_spectral_opts_count(const smilehip_spectral_opts *o) {
+  if (!o || o->n_bands < 0 || o->n_bands > 16 || o->n_rolloff < 0 || o->n_rolloff > 16) return -1;
+  return o->n_bands + o->n_rolloff + (o->flux != 0) + (o->centroid != 0) + (o->max_pos != 0) + (o->min_pos != 0) + (o->entropy != 0) +
+         (o->variance != 0) + (o->skewness != 0) + (o->kurtosis != 0) + (o->slope != 0) + (o->sharpness != 0) + (o->harmonicity != 0) +
+         (o->flatness != 0);
+}
+extern "C" int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip_spectral_opts *o, int64_t K, double frame_size_sec,
+                                           smilehip_spectral_op **out) {
+  if (!ctx || !o || !out) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_create: null argument");
+  const int n_out = smilehip_spectral_opts_count(o);
+  if (n_out < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_create: 0 .. 16 bands, 0 .. 16 rollOff points, at least one output");
+  if (K < 8 || K > (1 << 20) || !(frame_size_sec > 0.0)) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_create: K %lld, frame size %g s", (long long)K, frame_size_sec);
+  for (int b = 0; b < o->n_bands; ++b)
+    if (o->band_lo[b] < 0 || o->band_hi[b] <= o->band_lo[b]) return fail(SMILEHIP_ERR_INVALID, "cSpectral bands[%d] = %d-%d", b, o->band_lo[b], o->band_hi[b]);
+  for (int i = 0; i < o->n_rolloff; ++i)
+    if (!(o->rolloff[i] >= 0.0 && o->rolloff[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "cSpectral rollOff[%d] = %g", i, o->rolloff[i]);
+  smilehip_spectral_op *op = new smilehip_spectral_op;
+  op->ctx = ctx;
+  op->n_out = n_out;
+  SpectralGeneral &G = op->G;
+  std::memset(&G, 0, sizeof(G));
+  G.K = (int32_t)K;
+  G.frame_size_sec = frame_size_sec;
+  G.n_bands = o->n_bands; G.n_rolloff = o->n_rolloff;
+  for (int i = 0; i < o->n_rolloff; ++i) G.rolloff[i] = o->rolloff[i];
+  G.flux = o->flux != 0; G.centroid = o->centroid != 0; G.max_pos = o->max_pos != 0; G.min_pos = o->min_pos != 0;
+  G.entropy = o->entropy != 0; G.variance = o->variance != 0; G.skewness = o->skewness != 0; G.kurtosis = o->kurtosis != 0;
+  G.slope = o->slope != 0; G.sharpness = o->sharpness != 0; G.harmonicity = o->harmonicity != 0;
+  G.flatness = o->flatness != 0; G.log_flatness = o->log_flatness != 0;
+  const int Nsrc = (int)K;
+  const double F0 = 1.0 / frame_size_sec;                // frq[i] = F0 * i, transformFft.cpp:102-117
+  for (int b = 0; b < o->n_bands; ++b) {                  // the band's edge bins and weights, spectral.cpp:779-826
+    const int lo = o->band_lo[b], hi = o->band_hi[b];
+    int ii;
+    double wghtL, wghtR, idxL, idxR;
+    for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)lo) break;
+    if ((ii < Nsrc) && (ii > 0)) wghtL = (F0 * ii - (double)lo) / (F0 * ii - F0 * (ii - 1)); else wghtL = 1.0;
+    idxL = (double)ii - 1.0;
+    if (idxL < 0) idxL = 0;
+    if (idxL >= Nsrc) idxL = Nsrc;
+    if (wghtL == 0.0) wghtL = 1.0;
+    for (ii = 0; ii < Nsrc; ii++) if (F0 * ii >= (float)hi) break;
+    if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi - F0 * (ii - 1)) / (F0 * ii - F0 * (ii - 1)); else wghtR = 1.0;
+    if ((ii < Nsrc) && (F0 * ii == (float)hi)) idxR = (double)ii; else idxR = (double)ii - 1.0;
+    if (idxR >= Nsrc) idxR = Nsrc - 1;
+    if (wghtR == 0.0) wghtR = 1.0;
+    int iL = (int)std::floor(idxL), iR = (int)std::floor(idxR);
+    if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+    if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+    if (iL < 0) iL = 0;
+    if (iR < 0) iR = 0;
+    if (iR < iL) { delete op; return fail(SMILEHIP_ERR_INVALID, "cSpectral bands[%d] = %d-%d lies between two bins of this spectrum", b, lo, hi); }
+    G.band_iL[b] = iL; G.band_iR[b] = iR; G.band_wL[b] = wghtL; G.band_wR[b] = wghtR;
+  }
+  for (int64_t i = 1; i < K; ++i) { G.slope_S2f += (F0 * i) * (F0 * i); G.slope_Sf += F0 * i; }
+  std::vector<double> sw((size_t)(K - 1));                // sharpness weights bark(f) g(bark(f)), spectral.cpp:1440-1455, smileUtil.c:1063-1078, 1123-1137
+  for (int64_t j = 1; j < K; ++j) {
+    const double x = F0 * double(j);
+    double zz = 0.0;
+    if (x > 0) {
+      zz = (26.81 / (1.0 + 1960.0 / x)) - 0.53;
+      if (zz < 2) zz = 0.85 * zz + 0.3;
+      else if (zz > 20.1) zz = 1.22 * zz - 0.22 * 20.1;
+    }
+    const double g = (zz <= 16.0) ? 1.0 : std::pow((zz - 16.0) / 4.0, 1.5849625) + 1.0;
+    sw[(size_t)(j - 1)] = zz * g;
+  }
+  const int rc = op->d_sharp.upload(sw);
+  if (rc) { delete op; return rc; }
+  G.sharp_w = op->d_sharp.p;
+  *out = op;
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_spectral_op_frames(smilehip_spectral_op *op, const float *d_mag, int64_t ld_src, float *d_state, int first,
+                                           float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!op) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_frames: null operator");
+  if (n_frames < 0 || ld_src < op->G.K || ld_dst < op->n_out || (n_frames > 0 && (!d_mag || !d_dst)) || (op->G.flux && !d_state))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_frames: bad argument (K %d, %d outputs; d_state is needed when flux is on)", op->G.K, op->n_out);
+  STAGE_RET(stage_spectral_general(op->G, d_mag, ld_src, d_state, first, d_dst, ld_dst, n_frames, (hipStream_t)stream), "spectral (general)");
+}
+
 extern "C" int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
                                            int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream) {
   if (!ctx || N < 1) return fail(SMILEHIP_ERR_INVALID, "smilehip_preemphasis_frames: bad argument");

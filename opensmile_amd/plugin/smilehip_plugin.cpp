@@ -1124,6 +1124,10 @@ class cHipSpectral : public cSpectral {
   smilehip_plan *gm_plan_ = nullptr;
   int band_lo_[2] = {250, 1000}, band_hi_[2] = {650, 4000};
   bool sel_[3] = {true, true, true};
+  // the general option set (smilehip_spectral_op_*: any bands / rollOff points, every descriptor optional): one operator per field
+  int general_ = -1, gen_n_out_ = 0;
+  smilehip_spectral_opts gen_opts_;
+  smilehip_spectral_op *gen_op_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool array_is(const char *name, int n, const char *const *vals) {
     if (getArraySize(name) != n) return false;
     for (int i = 0; i < n; ++i) {
@@ -1198,9 +1202,48 @@ class cHipSpectral : public cSpectral {
       g_frames[12]++;
       return (int)Ndst;
     }
-    if (!plain_ || (Nsrc != 129 && Nsrc != 257 && Nsrc != 513) || Ndst != 12 + (int)sel_[0] + (int)sel_[1] + (int)sel_[2] || fc < 0 || fc >= 8) {
-      HIP_FALLTHROUGH(12, "cSpectral: only ComParE_2016's option set (any two bands; centroid / sharpness / harmonicity optional) and the two GeMAPS sets (log-spectrum slopes + alphaRatio + "
-                          "hammarbergIndex; flux over 0-5000 Hz) on a 129- / 257- / 513-bin spectrum are built");
+    const bool compare_set = plain_ && (Nsrc == 129 || Nsrc == 257 || Nsrc == 513) && Ndst == 12 + (int)sel_[0] + (int)sel_[1] + (int)sel_[2];
+    if (!compare_set && general_ < 0) {
+      // everything the linear-spectrum branch of spectral.cpp:586-1560 offers except the slopes[] / alphaRatio / hammarbergIndex /
+      // specDiff / fluxCentroid / standardDeviation / tonality / flatness outputs
+      std::memset(&gen_opts_, 0, sizeof(gen_opts_));
+      const int nb = getArraySize("bands") > 0 ? getArraySize("bands") : 0, nr = getArraySize("rollOff") > 0 ? getArraySize("rollOff") : 0;
+      bool ok = nb <= 16 && nr <= 16 && getArraySize("slopes") <= 0;
+      for (int b = 0; ok && b < nb; ++b) {               // bands[b] = "lo-hi" in Hz, integers (spectral.cpp:163-190)
+        const char *v = getStr_f(myvprint("bands[%i]", b));
+        int lo = -1, hi = -1, used = 0;
+        ok = v && sscanf(v, "%d-%d%n", &lo, &hi, &used) == 2 && v[used] == 0 && lo >= 0 && hi > lo;
+        gen_opts_.band_lo[b] = lo; gen_opts_.band_hi[b] = hi;
+      }
+      for (int i = 0; ok && i < nr; ++i) gen_opts_.rolloff[i] = getDouble_f(myvprint("rollOff[%i]", i));
+      gen_opts_.n_bands = nb; gen_opts_.n_rolloff = nr;
+      gen_opts_.flux = getInt("flux"); gen_opts_.centroid = getInt("centroid"); gen_opts_.max_pos = getInt("maxPos"); gen_opts_.min_pos = getInt("minPos");
+      gen_opts_.entropy = getInt("entropy"); gen_opts_.variance = getInt("variance"); gen_opts_.skewness = getInt("skewness");
+      gen_opts_.kurtosis = getInt("kurtosis"); gen_opts_.slope = getInt("slope"); gen_opts_.sharpness = getInt("sharpness");
+      gen_opts_.harmonicity = getInt("harmonicity"); gen_opts_.flatness = getInt("flatness"); gen_opts_.log_flatness = getInt("logFlatness");
+      static const char *const off[] = {"normBandEnergies", "specDiff", "specPosDiff", "fluxCentroid", "fluxAtFluxCentroid", "standardDeviation",
+                                        "alphaRatio", "hammarbergIndex", "tonality", "buggyRollOff", "useLogSpectrum"};
+      for (const char *o : off) ok = ok && getInt(o) == 0;
+      ok = ok && getInt("squareInput") != 0 && (!gen_opts_.slope || getInt("oldSlopeScale") != 0);
+      const char *fr = getStr("freqRange");
+      ok = ok && fr && !strcmp(fr, "0-0");
+      gen_n_out_ = ok ? smilehip_spectral_opts_count(&gen_opts_) : 0;
+      general_ = (ok && gen_n_out_ > 0) ? 1 : 0;
+    }
+    if (!compare_set && general_ == 1 && Nsrc >= 9 && ((Nsrc - 1) & (Nsrc - 2)) == 0 && Ndst == gen_n_out_ && fc >= 0 && fc < 8) {   // (2^k + 1 bins: an FFT magnitude level, linear axis)
+      if (!gen_op_[fc]) check(smilehip_spectral_op_create(context(), &gen_opts_, Nsrc, reader_->getLevelConfig()->frameSizeSec, &gen_op_[fc]));
+      io_.ensure(Nsrc, gen_n_out_);
+      io_.up(src, Nsrc);
+      float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
+      check(smilehip_spectral_op_frames(gen_op_[fc], io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, gen_n_out_, 1, nullptr));
+      seen_[fc] = true;
+      io_.down(dst, gen_n_out_);
+      g_frames[12]++;
+      return (int)Ndst;
+    }
+    if (!compare_set || fc < 0 || fc >= 8) {
+      HIP_FALLTHROUGH(12, "cSpectral: the linear-spectrum descriptor sets (bands, rollOff points, flux, centroid, maxPos, minPos, entropy, variance, skewness, kurtosis, slope, "
+                          "sharpness, harmonicity, flatness; freqRange 0-0) and the two GeMAPS sets (log-spectrum slopes + alphaRatio + hammarbergIndex; flux over 0-5000 Hz) are built");
       return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     smilehip_plan *&pl = plans_.at(fc);
@@ -1229,7 +1272,10 @@ class cHipSpectral : public cSpectral {
   }
  public:
   explicit cHipSpectral(const char *n) : cSpectral(n) {}
-  ~cHipSpectral() override { if (gm_plan_) smilehip_plan_destroy(gm_plan_); }
+  ~cHipSpectral() override {
+    if (gm_plan_) smilehip_plan_destroy(gm_plan_);
+    for (auto *op : gen_op_) if (op) smilehip_spectral_op_destroy(op);
+  }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipSpectral(n);
     c->setComponentInfo(scname, sdescription);

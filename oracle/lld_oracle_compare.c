@@ -106,7 +106,7 @@ static double band_energy(const float *srcP, const double *frq, long Nsrc, long 
 
 /* cSpectral::processVector (spectral.cpp:586-1560) for the descriptor sets of the shipped configurations: any number of bands[]
  * (<= 16), four rollOff points, and flux, centroid, maxPos, minPos, entropy, variance, skewness, kurtosis, slope, sharpness,
- * harmonicity each optional, in the reference's output order; defaults squareInput=1, normBandEnergies=0, useLogSpectrum=0,
+ * harmonicity, flatness (logFlatness) each optional, in the reference's output order; defaults squareInput=1, normBandEnergies=0, useLogSpectrum=0,
  * buggyRollOff=0, oldSlopeScale=1, freqRange 0-0. src: magnitude spectrum (K). Returns the number of values written. */
 int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const float *src, float *dst)
 {
@@ -209,6 +209,19 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
     ptpSum /= 2.0;
     ptpSum /= (float)nBins;
     dst[n++] = ptpSum;
+  }
+  if (o->flatness) {                                                       /* :1515-1545: FLOAT_DMEM chain of logf, expf of its mean */
+    float sf = 0.0f, gmean = 0.0f;
+    int nGm = 0;
+    if (sumB != 0.0) {
+      for (j = lo; j <= hi; j++)
+        if (srcLP[j] != 0.0) { gmean += logf(fabsf(srcLP[j])); nGm++; }
+      if (nGm > 0) gmean /= (float)nGm;
+      gmean = expf(gmean);
+      sf = gmean / (float)fabs(sumB / (double)nBins);
+    }
+    if (o->log_flatness) dst[n++] = (sf > 0.0) ? (float)logf(sf) : 0.0f;
+    else dst[n++] = sf;
   }
   free(srcP);
   return (int)n;

@@ -1062,7 +1062,8 @@ class SpectralOpts(C.Structure):
     """lldo_spectral_opts (oracle/lld_oracle.h)"""
     _fields_ = [("n_bands", C.c_int), ("band_lo", C.c_long * 16), ("band_hi", C.c_long * 16), ("n_rolloff", C.c_int),
                 ("rolloff", C.c_double * 16)] + [(k, C.c_int) for k in ("flux", "centroid", "max_pos", "min_pos", "entropy", "variance",
-                                                                        "skewness", "kurtosis", "slope", "sharpness", "harmonicity")]
+                                                                        "skewness", "kurtosis", "slope", "sharpness", "harmonicity", "flatness",
+                                                                        "log_flatness")]
 
 
 def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 0.9), **flags):

@@ -655,3 +655,44 @@ def test_plugin_is10_paraling_other_rates(oracle, fs):
     assert y.shape == ref.shape and ref.shape[1] == 76
     d = y.view(np.uint32) != ref.view(np.uint32)
     assert not d.any(), f"{d.sum()} of {d.size} cells differ, columns {sorted(set(np.argwhere(d)[:, 1]))[:20]}"
+
+
+def _run_bytes(oracle, pcm, env_extra, conf, out_opt="-O"):
+    """the output file of one run as bytes (text sinks: ARFF / CSV), and the plugin's frame counters"""
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built (needs /root/reference at build time)")
+    with tempfile.TemporaryDirectory() as td:
+        wav, out, trace = (os.path.join(td, n) for n in ("in.wav", "out.bin", "trace.txt"))
+        oracle.write_wav(wav, pcm, 16000)
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        env.update(env_extra or {})
+        r = subprocess.run([exe, "-C", os.path.join(oracle.REF_DIR, "config", conf), "-I", wav, out_opt, out, "-l", "1"],
+                           cwd=PLUGDIR, env=env, capture_output=True, text=True, errors="replace", timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        data = open(out, "rb").read()
+        tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip()) if os.path.exists(trace) else {}
+    return data, {k: int(v) for k, v in tr.items()}
+
+
+@pytest.mark.parametrize("conf", ["avec11-14/avec2011.conf", "avec11-14/avec2013.conf", "misc/emo_large.conf",
+                                  "mediaeval12/MediaEval_Audio_IS12based_subwin2.conf"])
+def test_plugin_general_spectral_sets(oracle, conf):
+    """The shipped files whose cSpectral instance asks for another descriptor set than ComParE_2016's or GeMAPS' (four bands, maxPos /
+    minPos, no centroid ...): the general operator (smilehip_spectral_op_*) takes them -- the file the plugin run writes equals the
+    plain binary's byte for byte, and nothing ran on the CPU."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(71, 24000)
+    ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+    # every LLD override; these files' cFunctionals instances use families that are not operators of the library (Crossings, DCT,
+    # Peaks, pctlquotient ...: refused by name when overridden) and stay the reference's
+    lld = ("cWindower,cVectorPreemphasis,cTransformFFT,cFFTmagphase,cMelspec,cMfcc,cEnergy,cMZcr,cAcf,cPitchACF,cDeltaRegression,"
+           "cContourSmoother,cSpectral,cPlp,cSpecScale,cPitchShs,cPitchSmootherViterbi,cValbasedSelector,cPitchJitter,cVectorOperation,"
+           "cIntensity,cLsp,cPitchSmoother,cSpecResample,cLpc,cFormantLpc,cHarmonics")
+    own, tr = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": lld}, conf)
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert tr.get("cSpectral", 0) > 0, tr
+    assert len(ref) > 100 and own == ref

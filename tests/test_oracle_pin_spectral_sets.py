@@ -15,6 +15,8 @@ pytestmark = pytest.mark.skipif(not lldo.have_ref(), reason="oracle/_ref not bui
 CASES = {
     "avec11-14/avec2011.conf": ("fftmagH25", [(250, 650), (1000, 4000)],
                                 dict(flux=1, entropy=1, variance=1, skewness=1, kurtosis=1, sharpness=1, harmonicity=1)),
+    "avec11-14/avec2013.conf": ("fftmagH25", [(250, 650), (1000, 4000)],
+                                dict(flux=1, entropy=1, variance=1, skewness=1, kurtosis=1, sharpness=1, harmonicity=1, flatness=1)),
     "misc/emo_large.conf": ("fftmag", [(0, 250), (0, 650), (250, 650), (1000, 4000)], dict(flux=1, centroid=1, max_pos=1, min_pos=1)),
     "mediaeval12/MediaEval_Audio_IS12based_subwin2.conf": ("fftmagH25", [(40, 150), (250, 650), (1000, 4000), (5000, 15000)],
                                                            dict(flux=1, centroid=1, entropy=1, variance=1, skewness=1, kurtosis=1, slope=1,
