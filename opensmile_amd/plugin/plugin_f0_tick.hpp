@@ -1,0 +1,197 @@
+// libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
+// one translation unit: the parts share the state of plugin_shared.hpp): SURVEY 8(f) rank 2, tick level: cValbasedSelector, cPitchSmootherViterbi
+// cValbasedSelector::myTick (src/other/valbasedSelector.cpp:139-247) -- tick-level: a frame may be handed on, replaced by a
+// constant vector, or dropped, so myTick itself is replaced. The decision and the output vector come from the device
+// (smilehip_valbased_select_frames); the adaptive (running-average) threshold is not built.
+class cHipValbasedSelector : public cValbasedSelector {
+  FrameIO io_;
+  DevBytes keep_;
+  bool ready_ = false, cpu_warned_ = false;
+  long idx_ = 0;
+  int removeIdx_ = 0, invert_ = 0, allowEqual_ = 0, zerovec_ = 0, adaptive_ = 0;
+  FLOAT_DMEM outputVal_ = 0, threshold_ = 0;
+  cVector *my_ = nullptr;
+ protected:
+  eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (g_fused.big) return cValbasedSelector::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
+    if (!ready_) {
+      threshold_ = (FLOAT_DMEM)getDouble("threshold");
+      adaptive_ = (int)getInt("adaptiveThreshold");
+      idx_ = getInt("idx"); invert_ = getInt("invert"); allowEqual_ = getInt("allowEqual");
+      removeIdx_ = getInt("removeIdx"); zerovec_ = getInt("zeroVec");
+      outputVal_ = (FLOAT_DMEM)getDouble("outputVal");
+      ready_ = true;
+    }
+    if (adaptive_) { HIP_FALLTHROUGH(22, "cValbasedSelector: adaptiveThreshold = 1 is not built"); return cValbasedSelector::myTick(t); }
+    if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
+    cVector *vec = reader_->getNextFrame();
+    if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+    const long N = vec->N, nOut = removeIdx_ ? N - 1 : N;
+    if (nOut < 1) { HIP_FALLTHROUGH(22, "cValbasedSelector: removeIdx on a one-element vector"); return TICK_INACTIVE; }
+    io_.ensure(N, nOut);
+    io_.up(vec->data, N);
+    int32_t *d_keep = (int32_t *)keep_.ensure(sizeof(int32_t));
+    check(smilehip_valbased_select_frames(context(), io_.d_in, N, N, 1, (int32_t)idx_, threshold_, invert_, allowEqual_, zerovec_, removeIdx_,
+                                          outputVal_, io_.d_out, nOut, d_keep, nullptr));
+    if (my_ == NULL || my_->N != nOut) { delete my_; my_ = new cVector((int)nOut); }
+    io_.down(my_->data, nOut);
+    int32_t keep = 0;
+    keep_.down(&keep, sizeof(keep));
+    g_frames[22]++;
+    if (keep) {
+      my_->setTimeMeta(vec->tmeta);
+      writer_->setNextFrame(my_);
+    }
+    return TICK_SUCCESS;
+  }
+ public:
+  explicit cHipValbasedSelector(const char *n) : cValbasedSelector(n) {}
+  ~cHipValbasedSelector() override { delete my_; }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipValbasedSelector(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cPitchSmootherViterbi::myTick (src/lld/pitchSmootherViterbi.cpp:451-564) -- a TICK-LEVEL override: the component keeps its
+// own buffering (frames are released when all surviving paths agree, or when the path buffer is full, the rest at end of
+// input), so what is replaced is myTick itself. One frame of candidates per tick goes to the device-resident trellis
+// (smilehip_viterbi_stream_push); the frames it reports as decided are written at this very tick, exactly as the
+// reference's incremental scheme does -- the components behind (cPitchJitter does not run during end-of-input ticks, the
+// window processors pad at end of input) see the same frames at the same ticks. Configuration, names, the second reader
+// for the time meta and the writer are the base class's. Six candidates (cPitchShs nCandidates = 6) are built.
+class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
+  smilehip_viterbi_stream *vs_ = nullptr;
+  bool ready_ = false, usable_ = false, cpu_warned_ = false, flushed_ = false;
+  long nCand_ = 0;
+  long f0I_ = -1, cvI_ = -1, rawI_ = -1, clipI_ = -1, c1I_ = -1;
+  int oF0_ = 0, oLog_ = 0, oEnv_ = 0, oEnvLog_ = 0, oVc_ = 0, oVu_ = 0, oRaw_ = 0, oC1_ = 0, oClip_ = 0;
+  FLOAT_DMEM thresh_ = 0, lastValid_ = 0;
+  std::vector<std::vector<FLOAT_DMEM>> hist_;            // what the reference keeps per frame: (F0, voicing) x 6 | F0raw | voicingClip | voicingC1 | vIdx
+  std::vector<std::pair<int, int>> queue_;               // decided (frame, state), not yet written
+  size_t qpos_ = 0;
+  cVector *vec_ = nullptr;
+  long outN_ = 0;
+
+  void setup() {
+    ready_ = true;
+    oF0_ = getInt("F0final"); oLog_ = getInt("F0finalLog"); oEnv_ = getInt("F0finalEnv"); oEnvLog_ = getInt("F0finalEnvLog");
+    oVc_ = getInt("voicingFinalClipped"); oVu_ = getInt("voicingFinalUnclipped");
+    oRaw_ = getInt("F0raw"); oC1_ = getInt("voicingC1"); oClip_ = getInt("voicingClip");
+    outN_ = oF0_ + oLog_ + oEnv_ + oEnvLog_ + oVc_ + oVu_ + oRaw_ + oC1_ + oClip_;
+    int more = 0;
+    f0I_ = findField("F0Cand", 0, &nCand_, NULL, -1, &more);
+    cvI_ = findField("candVoicing");
+    if (oRaw_) rawI_ = findField("F0raw");
+    if (oClip_) clipI_ = findField("voicingClip");
+    if (oC1_) c1I_ = findField("voicingC1");
+    cVectorMeta *md = reader_->getLevelMetaDataPtr(0);
+    if (md != NULL) thresh_ = md->fData[0];                // the voicing cut-off cPitchShs publishes with its level
+    const int buflen = getInt("bufferLength");
+    usable_ = f0I_ >= 0 && cvI_ >= 0 && nCand_ >= 1 && nCand_ <= 6 && more == 0 && buflen >= 2 && buflen <= 128 && reader_->getNLevels() == 1;
+    if (!usable_) return;
+    // cSmileViterbiPitchSmooth::setWeights stores tvv into wTvvd as well (pitchSmootherViterbi.hpp:291-299)
+    const double w[6] = {getDouble("wLocal"), getDouble("wTvv"), getDouble("wTvv"), getDouble("wTvuv"), getDouble("wThr"), getDouble("wRange")};
+    check(smilehip_viterbi_stream_create(context(), buflen, thresh_, w, &vs_));
+    check(smilehip_viterbi_stream_set_candidates(vs_, (int32_t)nCand_));
+  }
+  static FLOAT_DMEM semitone(FLOAT_DMEM f0) {            // :512-519, in the reference's own float arithmetic
+    FLOAT_DMEM sc = 0.0;
+    if (f0 > 29.136) sc = (FLOAT_DMEM)12.0 * log(f0 / (FLOAT_DMEM)27.5) / log((FLOAT_DMEM)2.0);
+    else if (f0 > 0.0) sc = 1.0;
+    return sc;
+  }
+ protected:
+  eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (!ready_) setup();
+    if (!usable_) {
+      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 128 is built");
+      return cPitchSmootherViterbi::myTick(t);
+    }
+    int32_t n = 0, fr[128], st[128];
+    if (g_fused.big) {
+      // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
+      // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
+      // last P, P as the fused batch's own pass left it
+      const long T = g_fused.f0_frames, P = g_fused.f0_pending;
+      if (isEOI()) {
+        if (!flushed_) {
+          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 128; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
+          flushed_ = true;
+        }
+      } else {
+        cVector *vec = reader_->getNextFrame();
+        if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+        std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+        h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
+        hist_.push_back(h);
+        const long f = (long)hist_.size() - 1;
+        if (f < T - P) { fr[0] = (int32_t)f; st[0] = (int32_t)nCand_; n = 1; }
+        g_fused_stage++;
+      }
+    } else if (isEOI()) {
+      if (!flushed_) {
+        check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 128));
+        flushed_ = true;
+      }
+    } else {
+      cVector *vec = reader_->getNextFrame();
+      if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+      std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+      float cf[6], cv[6];
+      for (long i = 0; i < nCand_; i++) {
+        h[(size_t)(2 * i)] = cf[i] = vec->data[f0I_ + i];
+        h[(size_t)(2 * i + 1)] = cv[i] = vec->data[cvI_ + i];
+      }
+      h[(size_t)(2 * nCand_)] = rawI_ >= 0 ? vec->data[rawI_] : 0.0f;
+      h[(size_t)(2 * nCand_ + 1)] = clipI_ > 0 ? vec->data[clipI_] : 0.0f;       // (the reference tests > 0 for these two, :478-482)
+      h[(size_t)(2 * nCand_ + 2)] = c1I_ > 0 ? vec->data[c1I_] : 0.0f;
+      h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
+      hist_.push_back(h);
+      check(smilehip_viterbi_stream_push(vs_, cf, cv, &n, fr, st, 128));
+      g_frames[21]++;
+    }
+    for (int i = 0; i < n; ++i) queue_.push_back(std::make_pair((int)fr[i], (int)st[i]));
+    if (qpos_ >= queue_.size()) return TICK_INACTIVE;
+    if (vec_ == NULL) vec_ = new cVector((int)outN_);
+    const size_t first = qpos_;
+    for (; qpos_ < queue_.size(); ++qpos_) {
+      if (!writer_->checkWrite(1)) return qpos_ == first ? TICK_DEST_NO_SPACE : TICK_SUCCESS;
+      const std::vector<FLOAT_DMEM> &h = hist_[(size_t)queue_[qpos_].first];
+      const int state = queue_[qpos_].second;
+      FLOAT_DMEM f0 = state < nCand_ ? h[(size_t)(2 * state)] : 0.0f;            // getStateValueFromFrame
+      long k = 0;
+      if (oF0_) vec_->data[k++] = f0;
+      if (oLog_) vec_->data[k++] = semitone(f0);
+      if (oEnv_ || oEnvLog_) {
+        if (f0 <= 0.0) f0 = lastValid_; else lastValid_ = f0;
+        if (oEnv_) vec_->data[k++] = f0;
+        if (oEnvLog_) vec_->data[k++] = semitone(f0);
+      }
+      const FLOAT_DMEM vp = state < nCand_ ? h[(size_t)(2 * state + 1)] : h[1];
+      if (oVc_) vec_->data[k++] = vp >= thresh_ ? vp : 0.0f;
+      if (oVu_) vec_->data[k++] = vp;
+      if (oRaw_) vec_->data[k++] = h[(size_t)(2 * nCand_)];
+      if (oC1_) vec_->data[k++] = h[(size_t)(2 * nCand_ + 1)];
+      if (oClip_) vec_->data[k++] = h[(size_t)(2 * nCand_ + 2)];
+      cVector *vin = reader2->getFrame((long)h[(size_t)(2 * nCand_ + 3)]);
+      if (vin != NULL) vec_->setTimeMeta(vin->tmeta);
+      writer_->setNextFrame(vec_);
+    }
+    return TICK_SUCCESS;
+  }
+ public:
+  explicit cHipPitchSmootherViterbi(const char *n) : cPitchSmootherViterbi(n) {}
+  ~cHipPitchSmootherViterbi() override {
+    if (vs_) smilehip_viterbi_stream_destroy(vs_);
+    delete vec_;
+  }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchSmootherViterbi(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};

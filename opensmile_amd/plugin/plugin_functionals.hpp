@@ -1,0 +1,277 @@
+// libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
+// one translation unit: the parts share the state of plugin_shared.hpp): SURVEY 8(f) rank 1: cFunctionals
+// SURVEY 8f rank 1  cFunctionals::doProcess (src/functionals/functionals.cpp:320-389): one input row (one LLD contour)
+// per call through smilehip_funcspec_matrix. The instance's configuration -- functionalsEnabled and the options of the
+// cFunctional* children, time norms resolved with the reference's precedence (the family's own `norm` if set, else
+// masterTimeNorm, else the family's default; functionalComponent.hpp:68-76) -- is translated into a smilehip_func_spec
+// once; an instance that uses an option the spec cannot express stays on the reference's own code.
+class cHipFunctionals : public cFunctionals {
+  int fused_ = -1;
+  FusedChain::FuncAt fat_{0, 0};
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  int state_ = -1;                                       // -1 = not examined, 0 = not expressible -> reference code, 1 = spec_
+  smilehip_func_spec spec_;
+  int opt_int(const char *fam, const char *o) { return (int)getInt_f(myvprint("%s.%s", fam, o)); }
+  double opt_dbl(const char *fam, const char *o) { return getDouble_f(myvprint("%s.%s", fam, o)); }
+  bool opt_set(const char *fam, const char *o) {
+    char *k = myvprint("%s.%s", fam, o);
+    const bool r = isSet(k) != 0;
+    free(k);
+    return r;
+  }
+  static int parse_norm(const char *n, int fallback) {
+    if (!n) return fallback;
+    if (!strncmp(n, "tur", 3) || !strncmp(n, "seg", 3)) return SMILEHIP_NORM_SEGMENT;
+    if (!strncmp(n, "sec", 3)) return SMILEHIP_NORM_SECOND;
+    if (!strncmp(n, "fra", 3)) return SMILEHIP_NORM_FRAME;
+    return fallback;
+  }
+  int time_norm(const char *fam) {                        // parseTimeNormOption + setTimeNorm
+    const int own = parse_norm(getStr_f(myvprint("%s.norm", fam)), SMILEHIP_NORM_SEGMENT);
+    if (opt_set(fam, "norm")) return own;
+    if (isSet("masterTimeNorm")) {
+      const char *m = getStr("masterTimeNorm");
+      if (m && (!strncmp(m, "seg", 3) || !strncmp(m, "tur", 3) || !strncmp(m, "sec", 3) || !strncmp(m, "fra", 3)))
+        return parse_norm(m, own);
+    }
+    return own;
+  }
+  uint32_t mask_of(const char *fam, const char *const *names, int n) {
+    uint32_t m = 0;
+    for (int k = 0; k < n; ++k)
+      if (opt_int(fam, names[k])) m |= 1u << k;
+    return m;
+  }
+  bool build_spec() {
+    smilehip_func_spec &s = spec_;
+    std::memset(&s, 0, sizeof(s));
+    s.period = getInputPeriod();
+    if (!(s.period > 0.0)) s.period = 1.0;                // only second-normalised values use it
+    s.non_zero_functs = (int)getInt("nonZeroFuncts");
+    s.ext_norm = s.means_norm = s.times_norm = s.seg_norm = s.pk_norm = s.ons_norm = s.pko_norm = SMILEHIP_NORM_SEGMENT;
+    s.reg_centroid_norm = SMILEHIP_NORM_SEGMENT;
+    s.seg_max_num = 20; s.seg_min_lng = 3; s.seg_pause_min_lng = 2; s.lpc_order = 5;
+    const int n = getArraySize("functionalsEnabled");
+    if (n < 1 || n > 12) return false;
+    for (int i = 0; i < n; ++i) {
+      const char *f = getStr_f(myvprint("functionalsEnabled[%i]", i));
+      if (!f) return false;
+      if (!strcmp(f, "Extremes")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_EXTREMES;
+        static const char *const o[8] = {"max", "min", "range", "maxpos", "minpos", "amean", "maxameandist", "minameandist"};
+        s.ext_mask = mask_of(f, o, 8);
+        s.ext_norm = time_norm(f);
+      } else if (!strcmp(f, "Means")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_MEANS;
+        static const char *const o[17] = {"amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness",
+                                          "posamean", "negamean", "posqmean", "posrqmean", "negqmean", "negrqmean", "rqmean", "nzrqmean"};
+        s.means_mask = mask_of(f, o, 17);
+        s.means_norm = time_norm(f);
+      } else if (!strcmp(f, "Moments")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_MOMENTS;
+        static const char *const o[5] = {"variance", "stddev", "skewness", "kurtosis", "amean"};
+        s.mom_mask = mask_of(f, o, 5);
+        s.mom_stddev_norm = opt_int(f, "stddevNorm");
+        if (s.mom_stddev_norm == 1 || s.mom_stddev_norm == 2) s.mom_mask |= 1u << 5;
+        s.mom_ratio_limit = opt_int(f, "doRatioLimit");
+      } else if (!strcmp(f, "Regression")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_REGRESSION;
+        static const char *const o[18] = {"linregc1", "linregc2", "linregerrA", "linregerrQ", "qregc1", "qregc2", "qregc3", "qregerrA",
+                                          "qregerrQ", "centroid", "qregls", "qregrs", "qregx0", "qregy0", "qregyr", "qregy0nn",
+                                          "qregc3nn", "qregyrnn"};
+        s.reg_mask = mask_of(f, o, 18);
+        const char *cn = getStr_f(myvprint("%s.centroidNorm", f));
+        if (!cn || (strncmp(cn, "sec", 3) && strncmp(cn, "fra", 3) && strncmp(cn, "seg", 3))) return false;
+        s.reg_centroid_norm = parse_norm(cn, SMILEHIP_NORM_SEGMENT);
+        s.reg_norm_coeff = opt_int(f, "normRegCoeff");
+        s.reg_norm_inputs = opt_int(f, "normInputs");
+        s.reg_centroid_abs = opt_int(f, "centroidUseAbsValues");
+        s.reg_centroid_limit = opt_int(f, "centroidRatioLimit");
+        s.reg_ratio_limit = opt_int(f, "doRatioLimit");
+        s.reg_old_buggy_qerr = opt_int(f, "oldBuggyQerr");
+      } else if (!strcmp(f, "Percentiles")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_PERCENTILES;
+        static const char *const q[3] = {"quartile1", "quartile2", "quartile3"}, *const r[3] = {"iqr12", "iqr23", "iqr13"};
+        uint32_t m = 0;
+        for (int k = 0; k < 3; ++k) if (opt_int(f, q[k])) m |= 1u << k;
+        if (opt_set(f, "quartiles")) m = opt_int(f, "quartiles") ? 7u : 0u;
+        uint32_t mr = 0;
+        for (int k = 0; k < 3; ++k) if (opt_int(f, r[k])) mr |= 1u << (3 + k);
+        if (opt_set(f, "iqr")) mr = opt_int(f, "iqr") ? 0x38u : 0u;
+        s.pct_mask = m | mr;
+        s.pct_interp = opt_int(f, "interp");
+        char *k = myvprint("%s.percentile", f);
+        s.n_pctl = getArraySize(k); free(k);
+        k = myvprint("%s.pctlrange", f);
+        s.n_range = getArraySize(k); free(k);
+        k = myvprint("%s.pctlquotient", f);
+        const int nq = getArraySize(k); free(k);
+        if (s.n_pctl < 0 || s.n_pctl > 8 || s.n_range < 0 || s.n_range > 8) return false;
+        if (s.n_pctl > 0 && nq > 0) return false;         // quotients are not expressible
+        if (s.n_pctl == 0) s.n_range = 0;
+        for (int j = 0; j < s.n_pctl; ++j) {
+          double v = getDouble_f(myvprint("%s.percentile[%i]", f, j));
+          s.pctl[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        }
+        for (int j = 0; j < s.n_range; ++j) {
+          const char *t = getStr_f(myvprint("%s.pctlrange[%i]", f, j));
+          int a = -1, b = -1;
+          if (!t || sscanf(t, "%d-%d", &a, &b) != 2) return false;
+          s.range_a[j] = a; s.range_b[j] = b;
+        }
+      } else if (!strcmp(f, "Times")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_TIMES;
+        static const char *const o[13] = {"upleveltime25", "downleveltime25", "upleveltime50", "downleveltime50", "upleveltime75",
+                                          "downleveltime75", "upleveltime90", "downleveltime90", "risetime", "falltime", "leftctime",
+                                          "rightctime", "duration"};
+        s.times_mask = mask_of(f, o, 13);
+        s.times_norm = time_norm(f);
+        s.times_buggy_sec_norm = opt_int(f, "buggySecNorm");
+        char *k = myvprint("%s.upleveltime", f);
+        const int nu = getArraySize(k); free(k);
+        k = myvprint("%s.downleveltime", f);
+        const int nd = getArraySize(k); free(k);
+        if (nu > 0 || nd > 0 || opt_int(f, "useRobustPercentileRange")) return false;
+      } else if (!strcmp(f, "Segments")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_SEGMENTS;
+        static const char *const o[5] = {"numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"};
+        s.seg_mask = mask_of(f, o, 5);
+        s.seg_norm = time_norm(f);
+        const char *alg = getStr_f(myvprint("%s.segmentationAlgorithm", f));
+        if (!alg) return false;
+        if (!strncmp(alg, "relTh", 5)) s.seg_algo = SMILEHIP_SEG_RELTH;
+        else if (!strncmp(alg, "nonX", 4)) s.seg_algo = SMILEHIP_SEG_NONX;
+        else if (!strncmp(alg, "eqX", 3)) s.seg_algo = SMILEHIP_SEG_EQX;
+        else return false;
+        if (opt_int(f, "growDynSegBuffer") || opt_int(f, "useOldBuggyChX")) return false;
+        s.seg_max_num = opt_int(f, "maxNumSeg");
+        s.seg_min_lng = opt_int(f, "segMinLng");
+        if (s.seg_min_lng < 1) s.seg_min_lng = 1;
+        s.seg_auto_min_lng = opt_set(f, "segMinLng") ? 0 : 1;
+        s.seg_pause_min_lng = opt_int(f, "pauseMinLng");
+        if (s.seg_pause_min_lng < 1) s.seg_pause_min_lng = 1;
+        s.seg_x = (float)opt_dbl(f, "X");
+        s.seg_x_is_rel = opt_int(f, "XisRel");
+        if (s.seg_algo == SMILEHIP_SEG_RELTH) {
+          char *k = myvprint("%s.thresholds", f);
+          s.seg_n_thresholds = getArraySize(k); free(k);
+          if (s.seg_n_thresholds < 0 || s.seg_n_thresholds > 8) return false;
+          for (int j = 0; j < s.seg_n_thresholds; ++j) {
+            float v = (float)getDouble_f(myvprint("%s.thresholds[%i]", f, j));
+            s.seg_thresholds[j] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+          }
+        }
+      } else if (!strcmp(f, "Lpc")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_LPC;
+        s.lpc_first = opt_int(f, "firstCoeff");
+        if (s.lpc_first < 0) s.lpc_first = 0;
+        s.lpc_order = opt_int(f, "order");
+        if (s.lpc_order <= s.lpc_first) return false;
+        s.lpc_gain = opt_int(f, "lpGain") ? 1 : 0;
+        s.lpc_coeffs = opt_int(f, "lpc") ? 1 : 0;
+      } else if (!strcmp(f, "Peaks2")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_PEAKS2;
+        static const char *const o[32] = {"numPeaks", "meanPeakDist", "meanPeakDistDelta", "peakDistStddev", "peakRangeAbs", "peakRangeRel",
+                                          "peakMeanAbs", "peakMeanMeanDist", "peakMeanRel", "ptpAmpMeanAbs", "ptpAmpMeanRel",
+                                          "ptpAmpStddevAbs", "ptpAmpStddevRel", "minRangeAbs", "minRangeRel", "minMeanAbs",
+                                          "minMeanMeanDist", "minMeanRel", "mtmAmpMeanAbs", "mtmAmpMeanRel", "mtmAmpStddevAbs",
+                                          "mtmAmpStddevRel", "meanRisingSlope", "maxRisingSlope", "minRisingSlope",
+                                          "stddevRisingSlope", "meanFallingSlope", "maxFallingSlope", "minFallingSlope",
+                                          "stddevFallingSlope", "covFallingSlope", "covRisingSlope"};
+        s.pk_mask = mask_of(f, o, 32);
+        s.pk_norm = time_norm(f);
+        if (opt_int(f, "noClearPeakList")) return false;
+        const char *dbg = getStr_f(myvprint("%s.posDbgOutp", f));
+        if ((dbg && *dbg) || opt_int(f, "consoleDbg")) return false;
+        s.pk_ratio_limit = opt_int(f, "doRatioLimit");
+        s.pk_dyn_rel = opt_int(f, "dynRelThresh");
+        float rt = (float)opt_dbl(f, "relThresh");
+        if (rt < 0) rt = 0.0f;
+        else if (rt > 1.0f && !s.pk_dyn_rel) rt = 1.0f;
+        s.pk_rel_thresh = rt;
+        if (opt_set(f, "absThresh")) {
+          s.pk_use_abs = 1;
+          s.pk_abs_thresh = (float)opt_dbl(f, "absThresh");
+          s.pk_dyn_rel = 0;
+        }
+      } else if (!strcmp(f, "Peaks")) {
+        if (!opt_int(f, "overlapFlag")) return false;      // overlapFlag = 0 carries the last two values from call to call
+        s.fam[s.n_fam++] = SMILEHIP_FAM_PEAKS;
+        static const char *const o[5] = {"numPeaks", "meanPeakDist", "peakMean", "peakMeanMeanDist", "peakDistStddev"};
+        s.pko_mask = mask_of(f, o, 5);
+        s.pko_norm = time_norm(f);
+      } else if (!strcmp(f, "Crossings")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_CROSSINGS;
+        static const char *const o[3] = {"zcr", "mcr", "amean"};
+        s.crs_mask = mask_of(f, o, 3);
+      } else if (!strcmp(f, "DCT")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_DCT;
+        s.dct_first = opt_int(f, "firstCoeff");
+        if (s.dct_first < 0) s.dct_first = 0;
+        s.dct_last = opt_set(f, "nCoeffs") ? s.dct_first + opt_int(f, "nCoeffs") - 1 : opt_int(f, "lastCoeff");
+        if (s.dct_last < s.dct_first || s.dct_last - s.dct_first >= 64) return false;
+      } else if (!strcmp(f, "Samples")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_SAMPLES;
+        char *k = myvprint("%s.samplepos", f);
+        const int ns = getArraySize(k); free(k);
+        if (ns > 8) return false;
+        if (ns > 0) {
+          s.n_samples = ns;
+          for (int j = 0; j < ns; ++j) {
+            double v = getDouble_f(myvprint("%s.samplepos[%i]", f, j));
+            s.sample_pos[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+          }
+        } else {                                          // DEFAULT_NR_SAMPLES = 5 (functionalSamples.cpp:27, 78-84)
+          s.n_samples = 5;
+          for (int j = 0; j < 5; ++j) s.sample_pos[j] = (double)j / (5 - 1.0);
+        }
+      } else if (!strcmp(f, "Onset")) {
+        s.fam[s.n_fam++] = SMILEHIP_FAM_ONSET;
+        static const char *const o[5] = {"onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"};
+        s.ons_mask = mask_of(f, o, 5);
+        s.ons_norm = time_norm(f);
+        s.ons_use_abs = opt_int(f, "useAbsVal");
+        s.ons_thr_on = s.ons_thr_off = (float)opt_dbl(f, "threshold");            // functionalOnset.cpp:72-76
+        if (opt_set(f, "thresholdOnset")) s.ons_thr_on = (float)opt_dbl(f, "thresholdOnset");
+        if (opt_set(f, "thresholdOffset")) s.ons_thr_off = (float)opt_dbl(f, "thresholdOffset");
+      } else {
+        return false;                                     // a family that is not built (ModulationSpec, ...)
+      }
+    }
+    return smilehip_funcspec_count(&s) == nFunctValues;
+  }
+ protected:
+  int doProcess(int i, cMatrix *row, FLOAT_DMEM *y) override {
+    if (fused_ < 0) {                                      // big-set fused mode: the instance's values of the fused batch's functionals vector
+      g_fused.init();
+      fused_ = 0;
+      if (g_fused.big) {
+        auto it = g_fused.func_levels.find(getStr("writer.dmLevel"));
+        if (it != g_fused.func_levels.end() && it->second.count == nFunctValues) { fat_ = it->second; fused_ = 1; }
+      }
+    }
+    if (fused_ && row->nT > 0) {
+      const long at = fat_.base + (long)i * fat_.count;
+      if (at + fat_.count > (long)g_fused.func.size()) COMP_ERR("libsmilehip plugin: fused mode: functionals element %d outside the batch's vector", i);
+      for (int k = 0; k < fat_.count; ++k) y[k] = g_fused.func[(size_t)(at + k)];
+      g_fused.served++;
+      return nFunctValues;
+    }
+    if (state_ < 0) state_ = build_spec() ? 1 : 0;
+    if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Crossings, DCT, Onset, Peaks, Samples, ModulationSpec, pctlquotient, ...)"); return cFunctionals::doProcess(i, row, y); }
+    io_.ensure(row->nT, nFunctValues);
+    io_.up(row->data, row->nT);
+    check(smilehip_funcspec_matrix(context(), &spec_, io_.d_in, 1, row->nT, 1, io_.d_out, nullptr));
+    io_.down(y, nFunctValues);
+    g_frames[14]++;
+    return nFunctValues;
+  }
+ public:
+  explicit cHipFunctionals(const char *n) : cFunctionals(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipFunctionals(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};

@@ -1,0 +1,229 @@
+// libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
+// one translation unit: the parts share the state of plugin_shared.hpp): R9, R10, R12: cEnergy, cMZcr, cAcf, cPitchACF
+// R12  cEnergy::processVector  (src/lldcore/energy.cpp:152-185): the double-accumulated sum of
+// squares comes from the device, the rms / squared / log expressions are the reference's
+class cHipEnergy : public cEnergy {
+  int fused_ = -1;
+  const FusedLevel *fcols_ = nullptr;
+  long fframe_ = 0, fnext_ = 0;
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  DevBytes res_;
+  int htk_ = 0, erms_ = 0, e2_ = 0, elog_ = 0;
+  FLOAT_DMEM sRms_ = 1, sLog_ = 1, sSq_ = 1, bLog_ = 0, bRms_ = 0, bSq_ = 0;
+  bool ready_ = false;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
+    if (Nsrc == 0) return 0;
+    if (!ready_) {                                       // cEnergy::myFetchConfig, energy.cpp:58-81
+      htk_ = getInt("htkcompatible");
+      erms_ = getInt("rms"); e2_ = getInt("energy2"); elog_ = getInt("log");
+      if (htk_) { elog_ = 1; erms_ = 0; }
+      bLog_ = (FLOAT_DMEM)getDouble("ebiasLog"); bRms_ = (FLOAT_DMEM)getDouble("ebiasRms"); bSq_ = (FLOAT_DMEM)getDouble("ebiasSquare");
+      sRms_ = (FLOAT_DMEM)getDouble("escaleRms"); sSq_ = (FLOAT_DMEM)getDouble("escaleSquare"); sLog_ = (FLOAT_DMEM)getDouble("escaleLog");
+      ready_ = true;
+    }
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    double *d_d = (double *)res_.ensure(sizeof(double));
+    check(smilehip_sumsq_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_d, nullptr));
+    double d = 0.0;
+    res_.down(&d, sizeof(double));
+    int n = 0;
+    if (erms_) dst[n++] = (FLOAT_DMEM)sqrt(d / (FLOAT_DMEM)Nsrc) * sRms_ + bRms_;
+    if (e2_) dst[n++] = (FLOAT_DMEM)(d / (double)Nsrc) * sSq_ + bSq_;
+    if (elog_) {
+      const double minE = 8.674676e-019;
+      if (!htk_) {
+        d /= (FLOAT_DMEM)Nsrc;
+        if (d < minE) d = minE;
+        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+      } else {
+        d *= 32767.0 * 32767.0;
+        if (d <= 1.0) d = 1.0;
+        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+      }
+    }
+    g_frames[6]++;
+    return n;
+  }
+ public:
+  explicit cHipEnergy(const char *n) : cEnergy(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipEnergy(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R12  cMZcr::processVector, zero-crossing rate  (src/lldcore/mzcr.cpp:109-150)
+class cHipMZcr : public cMZcr {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  DevBytes res_;
+  int plain_ = -1, flags_ = 0;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
+    if (plain_ < 0) {
+      plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
+      flags_ = (getInt("zcr") ? SMILEHIP_MZCR_ZCR : 0) | (getInt("mcr") ? SMILEHIP_MZCR_MCR : 0) | (getInt("amax") ? SMILEHIP_MZCR_AMAX : 0) |
+               (getInt("maxmin") ? SMILEHIP_MZCR_MAXMIN : 0) | (getInt("dc") ? SMILEHIP_MZCR_DC : 0);
+    }
+    if (Nsrc == 0) return 0;                             // mzcr.cpp:112
+    if (!plain_ && flags_ && Nsrc <= 32768) {            // mcr / amax / maxmin / dc (mzcr.cpp:119-150)
+      const int n_out = ((flags_ & 1) ? 1 : 0) + ((flags_ & 2) ? 1 : 0) + ((flags_ & 4) ? 1 : 0) + ((flags_ & 8) ? 2 : 0) + ((flags_ & 16) ? 1 : 0);
+      io_.ensure(Nsrc, n_out);
+      io_.up(src, Nsrc);
+      check(smilehip_mzcr_frames(context(), io_.d_in, Nsrc, Nsrc, 1, flags_, io_.d_out, n_out, nullptr));
+      io_.down(dst, n_out);
+      g_frames[7]++;
+      return n_out;
+    }
+    if (!plain_) { HIP_FALLTHROUGH(7, "cMZcr: no output selected, or a frame longer than 32768 samples"); return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi); }
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t));
+    check(smilehip_zcr_count_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_c, nullptr));
+    int32_t c = 0;
+    res_.down(&c, sizeof(c));
+    FLOAT_DMEM nzc = (FLOAT_DMEM)c;
+    nzc /= (FLOAT_DMEM)Nsrc;
+    dst[0] = nzc;
+    g_frames[7]++;
+    return 1;
+  }
+ public:
+  explicit cHipMZcr(const char *n) : cMZcr(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipMZcr(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R9  cAcf::processVector, forward path  (src/dspcore/acf.cpp:249-349)
+class cHipAcf : public cAcf {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  PlanSet<> plans_;
+  int plain_ = -1, use_power_ = 0, cepstrum_ = 0, norm_ = 0, abs_ceps_ = 0;
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE(1);
+    if (plain_ < 0) {                                    // cAcf::myFetchConfig, acf.cpp:77-110
+      cepstrum_ = getInt("cepstrum");
+      use_power_ = cepstrum_ ? (isSet("usePower") ? getInt("usePower") : 0) : getInt("usePower");
+      norm_ = getInt("acfCepsNormOutput");
+      abs_ceps_ = getInt("absCepstrum");
+      plain_ = (!getInt("inverse") && !getInt("cosLifterCepstrum")) ? 1 : 0;
+      if (cepstrum_ && getInt("oldCompatCepstrum")) cepstrum_ = 2;      // log(x) of the inner bins, DC and Nyquist as they are (acf.cpp:275-286)
+    }
+    const long N = (Nsrc - 1) * 2;
+    if (!plain_ || Nsrc < 5 || (N & (N - 1)) != 0 || Ndst > N / 2)
+      { HIP_FALLTHROUGH(8, "cAcf: inverse / cosLifterCepstrum / expBeforeAbs or this field size are not built"); return cAcf::processVector(src, dst, Nsrc, Ndst, idxi); }
+    smilehip_plan *&pl = plans_.at(getFconf(idxi));
+    if (!pl) {
+      smilehip_lld_config c = base_config(N, SMILEHIP_STAGE_FFT);
+      check(smilehip_plan_create(context(), &c, &pl));
+    }
+    io_.ensure(Nsrc, Ndst);
+    io_.up(src, Nsrc);
+    check(smilehip_acf_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, Ndst, 1, use_power_, cepstrum_, norm_, abs_ceps_, nullptr));
+    io_.down(dst, Ndst);
+    g_frames[8]++;
+    return 1;
+  }
+ public:
+  explicit cHipAcf(const char *n) : cAcf(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipAcf(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// R10  cPitchACF::processVector  (src/lldcore/pitchACF.cpp:137-247), all of it on the device: the voicing probability and the
+// cepstral peak (smilehip_pitchacf_frames), then F0, the voicing cut-off, the causal F0 contour and its envelope
+// (smilehip_pitchacf_contour_step -- the device function the batch chain runs, its state in device memory). The host side
+// only maps the harmonics-to-noise ratio of two ACF values it already holds onto the three HNR scales (:310-361).
+class cHipPitchACF : public cPitchACF {
+  FrameIO io_;
+  bool cpu_warned_ = false;
+  DevBytes res_;
+  bool state_ready_ = false;
+  int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, HNR_ = 0, HNRdB_ = 0, linHNR_ = 0, voiceQual_ = 0;
+  double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
+  float fsSec_ = -1.0f;
+  // device result block: voicing | peak index | ACF zero-crossing rate | F0, F0raw, F0env, 0 | contour state (8 words)
+  struct Result { double voicing; int32_t idx; int32_t pad; double acfZcr; float f0[4]; float state[8]; };
+ protected:
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    FUSED_BIG_STAGE((int)Ndst);
+    if (plain_ < 0) {                                    // cPitchACF::myFetchConfig, pitchACF.cpp:75-104
+      voiceProb_ = getInt("voiceProb"); F0_ = getInt("F0"); F0raw_ = getInt("F0raw"); F0env_ = getInt("F0env");
+      voicingCutoff_ = getDouble("voicingCutoff");
+      if (voicingCutoff_ > 1.0) voicingCutoff_ = 1.0;
+      if (voicingCutoff_ < 0.0) voicingCutoff_ = 0.0;
+      maxPitch_ = getDouble("maxPitch");
+      if (maxPitch_ < 0.0) maxPitch_ = 0.0;
+      fsSec_ = (float)(reader_->getLevelConfig()->frameSizeSec);          // setupNewNames, :110-114
+      HNR_ = getInt("HNR"); HNRdB_ = getInt("HNRdB"); linHNR_ = getInt("linHNR"); voiceQual_ = getInt("voiceQual");
+      plain_ = 1;
+    }
+    const long N = (int)floor(Nsrc / 2.0);
+    if (N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: the input is not [acf | cepstrum] of equal, even size"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
+    io_.ensure(Nsrc, 1);
+    io_.up(src, Nsrc);
+    unsigned char *r = (unsigned char *)res_.ensure(sizeof(Result));
+    if (!state_ready_) {                                 // a stream starts with an all-zero contour
+      const Result zero = {};
+      check(smilehip_copy_to_device(context(), r, &zero, sizeof(Result), nullptr));
+      state_ready_ = true;
+    }
+    const double Tsamp = fsSec_ / (double)Nsrc;
+    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, voicing)),
+                                   (int32_t *)(r + offsetof(Result, idx)), nullptr));
+    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, acfZcr)), nullptr));
+    const bool contour = F0_ || F0env_ || F0raw_ || voiceQual_;
+    if (contour)
+      check(smilehip_pitchacf_contour_step(context(), (const double *)(r + offsetof(Result, voicing)), (const int32_t *)(r + offsetof(Result, idx)),
+                                           Tsamp, voicingCutoff_, (float *)(r + offsetof(Result, state)), (float *)(r + offsetof(Result, f0)), nullptr));
+    Result h = {};
+    res_.down(&h, offsetof(Result, state));
+    const long peak = h.idx;
+    int n = 0;
+    if (voiceProb_) dst[n++] = (FLOAT_DMEM)h.voicing;
+    if (HNR_ || HNRdB_ || linHNR_) {
+      // harmonics-to-noise ratio acf[peak] / (acf[0] - acf[peak]), `pure` where the denominator vanishes. The difference is a
+      // float; the natural-log scale divides in float (:315), the dB and linear scales hold the difference in a double and
+      // divide in double (:331-335, :351-355). Natural-log scale floored at 1e-11, dB scale limited to -100 .. 100, linear
+      // scale limited to 1e-2 .. 1e4
+      const FLOAT_DMEM noise = src[0] - src[peak];
+      const auto ratio = [&](double pure) { return noise == 0.0 ? pure : (double)src[peak] / (double)noise; };
+      if (HNR_) { const double q = noise == 0.0 ? 1e20 : (double)(src[peak] / noise); dst[n++] = (FLOAT_DMEM)(10.0 * log(q > 0.00000000001 ? q : 0.00000000001)); }
+      if (HNRdB_) { const double q = ratio(10e10); dst[n++] = (FLOAT_DMEM)(q <= 10e-10 ? -100.0 : (q >= 10e10 ? 100.0 : 10.0 * log(q) / log(10.0))); }
+      if (linHNR_) { const double q = ratio(10e3); dst[n++] = (FLOAT_DMEM)(q <= 10e-3 ? 10e-3 : (q >= 10e3 ? 10e3 : q)); }
+    }
+    if (contour) {
+      if (voiceQual_) {                                   // :178-181
+        FLOAT_DMEM vq = ((FLOAT_DMEM)maxPitch_ - (FLOAT_DMEM)fabs((h.acfZcr * maxPitch_) - ((FLOAT_DMEM)1.0 / ((FLOAT_DMEM)(peak) * (FLOAT_DMEM)Tsamp)))) * (FLOAT_DMEM)h.voicing;
+        dst[n++] = peak == 0 ? (FLOAT_DMEM)0.0 : vq;
+      }
+      if (F0_) dst[n++] = h.f0[0];
+      if (F0raw_) dst[n++] = h.f0[1];
+      if (F0env_) dst[n++] = h.f0[2];
+    }
+    g_frames[9]++;
+    return n;
+  }
+ public:
+  explicit cHipPitchACF(const char *n) : cPitchACF(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipPitchACF(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};

@@ -1,0 +1,374 @@
+// libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
+// one translation unit: the parts share the state of plugin_shared.hpp): shared state of the overrides: context, frame counters, the CPU fall-through rule, frame I/O buffers, fused mode for unmodified configuration files
+
+// ---------------------------------------------------------------- shared state
+smilehip_context *g_ctx = nullptr;
+constexpr int kNumOverrides = 28;
+long g_frames[kNumOverrides] = {0};
+long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
+const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc",
+                                            "cEnergy", "cMZcr", "cAcf", "cPitchACF", "cDeltaRegression", "cContourSmoother", "cSpectral", "cPlp", "cFunctionals", "cSpecScale",
+                                            "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter",
+                                            "cIntensity", "cLsp", "cPitchSmoother", "cVectorOperation"};
+
+// An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
+// says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
+// Round 3: that is opt-in. By default an option set that is not built is an ERROR of the component (COMP_ERR, like any
+// configuration the reference cannot run) -- "the plugin is loaded" then means "the frames were computed on the GPU";
+// SMILEHIP_PLUGIN_ALLOW_CPU=1 brings back the logged and counted fall-through.
+inline bool allow_cpu() {
+  static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_ALLOW_CPU"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+#define HIP_FALLTHROUGH(idx, why)                                                                                  \
+  do {                                                                                                             \
+    if (!allow_cpu())                                                                                              \
+      COMP_ERR("libsmilehip plugin: %s (set SMILEHIP_PLUGIN_ALLOW_CPU=1 to run this instance on the reference's CPU code)", why); \
+    if (!cpu_warned_) {                                                                                            \
+      SMILE_IWRN(1, "libsmilehip plugin: %s -- this instance runs the reference's CPU code", why);                 \
+      cpu_warned_ = true;                                                                                          \
+    }                                                                                                              \
+    g_cpu[idx]++;                                                                                                  \
+  } while (0)
+
+smilehip_context *context() {
+  if (!g_ctx) {
+    const char *dev = getenv("SMILEHIP_DEVICE");
+    if (smilehip_init(dev ? atoi(dev) : 0, &g_ctx) != SMILEHIP_OK)
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  return g_ctx;
+}
+
+// device scratch for one frame in / one frame out
+struct FrameIO {
+  float *d_in = nullptr, *d_out = nullptr;
+  long cap_in = 0, cap_out = 0;
+  void ensure(long n_in, long n_out) {
+    if (n_in > cap_in) {
+      if (d_in) smilehip_free(context(), d_in);
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_in, (void **)&d_in)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_in = n_in;
+    }
+    if (n_out > cap_out) {
+      if (d_out) smilehip_free(context(), d_out);
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_out, (void **)&d_out)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_out = n_out;
+    }
+  }
+  void up(const FLOAT_DMEM *src, long n) {
+    if (smilehip_copy_to_device(context(), d_in, src, sizeof(float) * (uint64_t)n, nullptr)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  void down(FLOAT_DMEM *dst, long n) {
+    if (smilehip_copy_to_host(context(), dst, d_out, sizeof(float) * (uint64_t)n, nullptr) ||
+        smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+  }
+  ~FrameIO() {
+    if (g_ctx) {
+      if (d_in) smilehip_free(g_ctx, d_in);
+      if (d_out) smilehip_free(g_ctx, d_out);
+    }
+  }
+};
+
+void check(int rc) {
+  if (rc != SMILEHIP_OK) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+}
+
+// ---------------------------------------------------------------- fused mode for UNMODIFIED configuration files
+// SMILEHIP_PLUGIN_FUSE=1: the first overridden component that is asked for a frame reads the process's own command line
+// (-C file.conf and the options the file defines), parses the file with the host library's reader (conf_plan.cpp) and, if
+// the graph is a cepstral chain, runs the WHOLE input file through the fused kernels in one batch. From then on the
+// per-frame stages of the chain (pre-emphasis .. mel bank) only mark their frames, and cMfcc / cPlp / cEnergy copy their
+// rows out of the batch result: one device round trip per file instead of one per frame and component. Everything
+// downstream (mean normalisation, delta regression, concatenation, sinks) runs the reference's own code on those rows,
+// at the reference's own ticks. Graphs that are not expressible stay on the per-component path (a warning says why).
+long g_fused_stage = 0;
+// a level the fused batch supplies: rows of a host matrix, a column per element of the level (no columns: zeros)
+struct FusedLevel {
+  const std::vector<float> *M = nullptr;
+  int ld = 0;
+  long n_rows = 0;
+  std::vector<int> cols;
+  std::vector<float> extra;      // one more row after the matrix's (ComParE group B's level holds row T60 + 1, which only its functionals read)
+};
+struct FusedChain {
+  bool tried = false, active = false;
+  // big = an unmodified big-set file (IS09_emotion, ComParE_2016, IS13_ComParE, eGeMAPSv02 and its sub-graphs): the whole LLD
+  // level comes from ONE fused batch; the components that write the levels the sinks and the cFunctionals instances read
+  // (the final cContourSmoother / cDeltaRegression instances, eGeMAPS' energy level) hand out its rows, every overridden
+  // component upstream of them writes zeros (nobody downstream of the fused levels reads those), the cFunctionals overrides
+  // run as HIP operators on the handed-out levels.
+  bool big = false;
+  smilehip_host::ConfPlan plan;
+  std::vector<float> rows, fin, b_extra;
+  long f0_frames = 0, f0_pending = 0;                     // 60 ms frames of the file, and how many the Viterbi pass left to the end-of-input flush
+  // the functionals vector of the fused batch and where a cFunctionals instance's values start in it (by the instance's writer level);
+  // instances that are not listed run as HIP operators on the handed-out levels
+  std::vector<float> func;
+  struct FuncAt { long base; int count; };
+  std::map<std::string, FuncAt> func_levels;
+  long n_rows = 0;
+  int n_cols = 0;
+  long served = 0;
+  std::map<std::string, FusedLevel> levels;
+  FusedLevel zero_level;
+
+  bool stage_level(const char *lvl) const {
+    if (!active || !lvl) return false;
+    if (big) return levels.find(lvl) == levels.end();      // everything that is not handed out is a stage
+    for (const std::string &l : plan.stage_levels) if (l == lvl) return true;
+    return false;
+  }
+  const FusedLevel *static_level(const char *lvl) const {
+    if (!active || !lvl) return nullptr;
+    auto it = levels.find(lvl);
+    if (it != levels.end()) return &it->second;
+    return big ? &zero_level : nullptr;
+  }
+  void add_level(const std::string &name, const std::vector<float> *M, int ld, long nr, int c0, int n) {
+    FusedLevel L;
+    L.M = M; L.ld = ld; L.n_rows = nr;
+    for (int i = 0; i < n; ++i) L.cols.push_back(c0 + i);
+    levels[name] = L;
+  }
+  // the big sets: one batch of the preset's chain over the whole file
+  bool init_big(const smilehip_host::WaveInfo &wi, const std::vector<unsigned char> &raw) {
+    const std::string &ps = plan.preset;
+    smilehip_lld_config c;
+    const bool egm = ps == "egemapsv02";                   // (the GeMAPS sub-graph files have other level names: per-component path)
+    if (ps == "is09_emotion") smilehip_config_is09_lld(&c);
+    else if (ps == "compare16") smilehip_config_compare16(&c);
+    else if (ps == "is13_compare") smilehip_config_is13_compare(&c);
+    else if (egm) smilehip_config_egemapsv02(&c);
+    else return false;
+    smilehip_host::conf_apply_f0_params(plan, c);
+    c.sample_rate = (double)wi.sample_rate;
+    smilehip_plan *pl = nullptr;
+    check(smilehip_plan_create(context(), &c, &pl));
+    smilehip_geometry g;
+    check(smilehip_plan_geometry(pl, &g));
+    const int64_t n = (int64_t)(raw.size() / 2);
+    const int64_t off[2] = {0, n};
+    smilehip_batch *b = nullptr;
+    check(smilehip_batch_create(pl, off, 1, &b));
+    n_rows = (long)smilehip_batch_total_rows(b);
+    n_cols = g.n_out;
+    rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
+    long fin_rows = 0;
+    if (n_rows > 0) {
+      void *d_pcm = nullptr, *d_lld = nullptr;
+      check(smilehip_alloc(context(), (uint64_t)(n > 0 ? n : 1) * 2, &d_pcm));
+      check(smilehip_alloc(context(), (uint64_t)n_rows * n_cols * 4, &d_lld));
+      check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
+      check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, n_cols, nullptr));
+      check(smilehip_copy_to_host(context(), rows.data(), d_lld, (uint64_t)n_rows * n_cols * 4, nullptr));
+      if (ps != "is09_emotion") {
+        const int32_t *d_pend = nullptr;
+        int32_t pend = 0;
+        check(smilehip_batch_f0_pending(b, &d_pend));
+        check(smilehip_copy_to_host(context(), &pend, d_pend, sizeof(pend), nullptr));
+        check(smilehip_stream_synchronize(context(), nullptr));
+        f0_pending = pend;
+        f0_frames = n_rows - 1;                            // rows = T60 + 1
+      }
+      if (ps == "compare16" || ps == "is13_compare") {     // row T60 + 1 of group B's smoothed / delta levels (its functionals read it)
+        const float *d_ex = nullptr;
+        check(smilehip_batch_compare_b_extra(b, &d_ex));
+        b_extra.assign(110, 0.0f);
+        check(smilehip_copy_to_host(context(), b_extra.data(), d_ex, 110 * 4, nullptr));
+      }
+      {                                                    // the set's functionals level, on the device-resident LLD matrix
+        int nf = 0;
+        if (ps == "is09_emotion") nf = 384;
+        else if (ps == "compare16" || ps == "is13_compare") nf = smilehip_functionals_compare16_count();
+        if (nf > 0) {
+          void *d_func = nullptr;
+          check(smilehip_alloc(context(), (uint64_t)nf * 4, &d_func));
+          if (ps == "is09_emotion") check(smilehip_batch_functionals(pl, b, (const float *)d_lld, n_cols, smilehip_functionals_is09_mask(), (float *)d_func, nf, nullptr));
+          else if (ps == "is13_compare") check(smilehip_batch_functionals_is13_compare(pl, b, (const float *)d_lld, n_cols, (float *)d_func, nf, nullptr));
+          else check(smilehip_batch_functionals_compare16(pl, b, (const float *)d_lld, n_cols, (float *)d_func, nf, nullptr));
+          func.assign((size_t)nf, 0.0f);
+          check(smilehip_copy_to_host(context(), func.data(), d_func, (uint64_t)nf * 4, nullptr));
+          check(smilehip_stream_synchronize(context(), nullptr));
+          smilehip_free(context(), d_func);
+          if (ps == "is09_emotion") func_levels["is09_func"] = FuncAt{0, 12};
+          else {
+            static const struct { const char *inst; int elems; } order[] = {{"A", 8}, {"B", 110}, {"Nz", 12}, {"F0", 1}, {"LLD", 59}, {"Delta", 59}};
+            long base = 0;
+            for (const auto &o : order) {
+              smilehip_func_spec fs;
+              check(ps == "is13_compare" ? smilehip_funcspec_is13_compare(o.inst, &fs) : smilehip_funcspec_compare16(o.inst, &fs));
+              const int cnt = smilehip_funcspec_count(&fs);
+              func_levels[std::string("is13_functionals") + o.inst] = FuncAt{base, cnt};
+              base += (long)o.elems * cnt;
+            }
+            if (base != nf) COMP_ERR("libsmilehip plugin: fused mode: the functionals layout does not add up (%ld of %d)", base, nf);
+          }
+        }
+      }
+      if (egm) {                                           // the levels the functionals read (smilehip_batch_egemaps_taps)
+        const float *d_fin = nullptr;
+        check(smilehip_batch_egemaps_taps(b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &d_fin, nullptr, nullptr));
+        fin_rows = (long)smilehip_batch_total_frames(b) + 1;            // T20 + 1
+        fin.assign((size_t)fin_rows * 36, 0.0f);
+        check(smilehip_copy_to_host(context(), fin.data(), d_fin, (uint64_t)fin_rows * 36 * 4, nullptr));
+      }
+      check(smilehip_stream_synchronize(context(), nullptr));
+      smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld);
+    }
+    smilehip_batch_destroy(b);
+    smilehip_plan_destroy(pl);
+    if (ps == "is09_emotion") {
+      add_level("is09_lld", &rows, n_cols, n_rows, 0, 16);
+      add_level("is09_lld_de", &rows, n_cols, n_rows, 16, 16);
+    } else if (ps == "compare16" || ps == "is13_compare") {
+      add_level("is13_lld_nzsmo", &rows, n_cols, n_rows, 0, 6);
+      add_level("is13_lldA_smo", &rows, n_cols, n_rows, 6, 4);
+      add_level("is13_lldB_smo", &rows, n_cols, n_rows, 10, 55);
+      add_level("is13_lld_nzsmo_de", &rows, n_cols, n_rows, 65, 6);
+      add_level("is13_lldA_smo_de", &rows, n_cols, n_rows, 71, 4);
+      add_level("is13_lldB_smo_de", &rows, n_cols, n_rows, 75, 55);
+      if (b_extra.size() == 110) {
+        levels["is13_lldB_smo"].extra.assign(b_extra.begin(), b_extra.begin() + 55);
+        levels["is13_lldB_smo_de"].extra.assign(b_extra.begin() + 55, b_extra.end());
+      }
+    } else {
+      const std::string g1 = "gemapsv01b";               // names of the included core file
+      // the LLD level's two halves, and the levels the functionals read (lld_params.hpp: func_in's 36 columns)
+      add_level("egemapsv02_lldsetE_smo", &rows, n_cols, n_rows, 0, 10);
+      add_level("egemapsv02_lldsetF_smo", &rows, n_cols, n_rows, 10, 15);
+      add_level(g1 + "_loudness_smo", &fin, 36, fin_rows, 0, 1);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessZ_smo", &fin, 36, fin_rows, 1, 5);
+      add_level(g1 + "_lld_single_logF0_smo", &fin, 36, fin_rows, 6, 1);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessNz_smo", &fin, 36, fin_rows, 7, 14);
+      add_level("egemapsv02_lldSetSpectralNz_smo", &fin, 36, fin_rows, 21, 9);
+      add_level("egemapsv02_lldSetSpectralZ_smo", &fin, 36, fin_rows, 30, 5);
+      add_level("egemapsv02_energyRMS", &fin, 36, fin_rows, 35, 1);
+    }
+    big = true;
+    active = true;
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld rows of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+    return true;
+  }
+  void init() {
+    if (tried) return;
+    tried = true;
+    const char *on = getenv("SMILEHIP_PLUGIN_FUSE");
+    if (!on || !*on || !strcmp(on, "0")) return;
+    std::vector<std::string> args;
+    if (FILE *f = fopen("/proc/self/cmdline", "rb")) {
+      std::string cur;
+      int ch;
+      while ((ch = fgetc(f)) != EOF) { if (ch == 0) { args.push_back(cur); cur.clear(); } else cur += (char)ch; }
+      if (!cur.empty()) args.push_back(cur);
+      fclose(f);
+    }
+    std::string conf;
+    std::map<std::string, std::string> cl;
+    for (size_t i = 1; i < args.size(); ++i) {
+      if (args[i].size() < 2 || args[i][0] != '-') continue;
+      const bool has_val = i + 1 < args.size() && (args[i + 1].empty() || args[i + 1][0] != '-' || isdigit((unsigned char)args[i + 1][1]));
+      const std::string key = args[i].substr(1), val = has_val ? args[i + 1] : "1";
+      if (key == "C" || key == "configfile") conf = val; else cl[key] = val;
+      if (has_val) ++i;
+    }
+    std::string err;
+    smilehip_host::ConfFile cf;
+    if (conf.empty() || !smilehip_host::conf_parse(conf, cl, cf, err)) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: cannot read the configuration file (%s) -- per-component path", err.c_str());
+      return;
+    }
+    if (!smilehip_host::conf_to_plan(cf, plan, err)) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: %s -- per-component path", err.c_str());
+      return;
+    }
+    smilehip_host::WaveInfo wi;
+    std::vector<unsigned char> raw;
+    if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
+      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
+      return;
+    }
+    if (!plan.preset.empty()) {
+      // the big sets fuse only with EVERY override registered: the final smoother / delta instances must be the ones that hand out rows
+      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
+      const bool all = !only || !*only || !strcmp(only, "all");
+      if (!all || plan.last_mfcc > 0 || !plan.func_enabled.empty() || !init_big(wi, raw))
+        SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: this big-set file does not fuse inside the reference process -- per-component path");
+      return;
+    }
+    smilehip_lld_config c = plan.cfg;
+    c.sample_rate = (double)wi.sample_rate;
+    c.n_delta = 0;                                        // the static block is all the chain components hand on;
+    c.cms = 0;                                            // mean normalisation and deltas stay with the reference's components
+    smilehip_plan *pl = nullptr;
+    check(smilehip_plan_create(context(), &c, &pl));
+    smilehip_geometry g;
+    check(smilehip_plan_geometry(pl, &g));
+    const int64_t n = (int64_t)(raw.size() / 2);
+    const int64_t off[2] = {0, n};
+    smilehip_batch *b = nullptr;
+    check(smilehip_batch_create(pl, off, 1, &b));
+    n_rows = (long)smilehip_batch_total_rows(b);
+    n_cols = g.n_out;
+    rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
+    if (n_rows > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows.data()));
+    smilehip_batch_destroy(b);
+    smilehip_plan_destroy(pl);
+    for (const auto &kv : plan.static_levels) {
+      FusedLevel L;
+      L.M = &rows; L.ld = n_cols; L.n_rows = n_rows; L.cols = kv.second;
+      levels[kv.first] = L;
+    }
+    active = true;
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld frames of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+  }
+  // row `frame` of a fused level
+  void copy(const FusedLevel &L, long frame, FLOAT_DMEM *dst, long Ndst) {
+    if (L.cols.empty()) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; return; }
+    if (frame >= L.n_rows) COMP_ERR("libsmilehip plugin: fused mode: the graph asks for frame %ld, the batch has %ld", frame, L.n_rows);
+    const float *r = L.M->data() + (size_t)frame * L.ld;
+    for (long k = 0; k < Ndst && k < (long)L.cols.size(); ++k) dst[k] = r[L.cols[k]];
+    ++served;
+  }
+  float at(const FusedLevel &L, long frame, int elem) {
+    if (L.cols.empty()) return 0.0f;
+    if (elem >= (int)L.cols.size())
+      COMP_ERR("libsmilehip plugin: fused mode: the graph asks for element %d, the level has %d", elem, (int)L.cols.size());
+    if (frame == L.n_rows && !L.extra.empty()) return L.extra[(size_t)elem];
+    if (frame >= L.n_rows) { ++beyond; return 0.0f; }      // rows a window processor emits at the end of input that no reader of the level uses
+    return (*L.M)[(size_t)frame * L.ld + L.cols[(size_t)elem]];
+  }
+  long beyond = 0;
+};
+// big-set fused mode: an overridden component that does not write a handed-out level fills its output with zeros
+#define FUSED_BIG_STAGE(ret)                                                                                       \
+  do {                                                                                                             \
+    g_fused.init();                                                                                                \
+    if (g_fused.big) { for (long k_ = 0; k_ < Ndst; ++k_) dst[k_] = 0; g_fused_stage++; return (ret); }           \
+  } while (0)
+FusedChain g_fused;
+
+smilehip_lld_config base_config(long N, uint32_t stages) {
+  smilehip_lld_config c;
+  smilehip_config_mfcc12_0_d_a(&c);
+  c.force_frame_size = N;
+  c.stage_mask = stages;
+  c.n_delta = 0;
+  return c;
+}
+
+int winfunc_id(const char *s) {
+  // same prefixes cWindower accepts (winFuncToInt, smileUtil.c)
+  if (!s) return -1;
+  if (!strncasecmp(s, "han", 3)) return SMILEHIP_WIN_HANN;
+  if (!strncasecmp(s, "ham", 3)) return SMILEHIP_WIN_HAMM;
+  if (!strncasecmp(s, "rec", 3)) return SMILEHIP_WIN_RECT;
+  if (!strncasecmp(s, "gau", 3)) return SMILEHIP_WIN_GAUSS;
+  if (!strncasecmp(s, "sin", 3) || !strncasecmp(s, "cos", 3)) return SMILEHIP_WIN_SINE;
+  if (!strncasecmp(s, "tri", 3)) return SMILEHIP_WIN_TRI;
+  if (!strncasecmp(s, "bar", 3) && strncasecmp(s, "barth", 5)) return SMILEHIP_WIN_BARTLETT;
+  if (!strncasecmp(s, "lac", 3)) return SMILEHIP_WIN_LANCZOS;
+  return -1;
+}

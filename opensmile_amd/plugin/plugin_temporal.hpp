@@ -1,0 +1,101 @@
+// libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
+// one translation unit: the parts share the state of plugin_shared.hpp): R13: cDeltaRegression, cContourSmoother (window processors)
+// R13  cWindowProcessor::processBuffer of cDeltaRegression (src/dspcore/deltaRegression.cpp:113-170) and
+// cContourSmoother (src/dspcore/contourSmoother.cpp:85-118): one row of the block the window
+// processor's tick hands over, valid on [-pre, nT+post)
+// big-set fused mode for the window processors (cWindowProcessor::myTick calls processBuffer once per element row of a block,
+// rows 0 .. N-1 in order, windowProcessor.cpp:188-200): the n-th call of a block is element n, the blocks follow each other in time
+struct FusedRows {
+  const FusedLevel *lvl = nullptr;
+  int tried = 0;
+  long call = 0, t_base = 0;
+  // true: `out` has been filled (with the level's rows, or zeros for a level nobody downstream of the fused ones reads)
+  bool serve(const char *writer_level, long n_elems, cMatrix *out) {
+    if (!tried) { tried = 1; g_fused.init(); if (g_fused.big) lvl = g_fused.static_level(writer_level); }
+    if (!g_fused.big || !lvl) return false;
+    const long N = n_elems > 0 ? n_elems : 1;
+    const int e = (int)(call % N);
+    for (long t = 0; t < out->nT; ++t) out->data[t] = g_fused.at(*lvl, t_base + t, e);
+    if (e == N - 1) t_base += out->nT;
+    ++call;
+    if (!lvl->cols.empty()) g_fused.served += out->nT; else g_fused_stage++;
+    return true;
+  }
+};
+
+struct RowIO {
+  FrameIO io;
+  void run(cMatrix *in, cMatrix *out, int pre, int post, int kind, int W) {
+    const long nT = out->nT;
+    if (nT <= 0) return;
+    io.ensure(nT + pre + post, nT);
+    io.up(in->data - pre, nT + pre + post);
+    check(smilehip_window_op_row_ex(context(), io.d_in + pre, io.d_out, nT, kind, W, d_norm, nullptr));
+    io.down(out->data, nT);
+  }
+  float *d_norm = nullptr;                                 // kind 3: the instance's carried divisor (one device float)
+};
+
+class cHipDeltaRegression : public cDeltaRegression {
+  RowIO row_;
+  FusedRows frows_;
+  bool cpu_warned_ = false;
+  int plain_ = -1, W_ = 0, segs_ = 0;
+  DevBytes norm_;
+ protected:
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    if (plain_ < 0) {
+      W_ = getInt("deltawin");
+      segs_ = getInt("onlyInSegments") ? 1 : 0;
+      plain_ = (W_ > 0 && !getInt("relativeDelta") && !getInt("halfWaveRect") && !getInt("absOutput")) ? 1 : 0;
+      if (plain_ && segs_) {                               // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
+        float n0 = 0.0f;
+        for (int i = 1; i <= W_; i++) n0 += (float)i * (float)i;
+        n0 *= 2.0f;
+        row_.d_norm = (float *)norm_.ensure(sizeof(float));
+        check(smilehip_copy_to_device(context(), row_.d_norm, &n0, sizeof(float), nullptr));
+      }
+    }
+    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
+    if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
+    row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
+    g_frames[10] += out->nT;
+    return 1;
+  }
+ public:
+  explicit cHipDeltaRegression(const char *n) : cDeltaRegression(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipDeltaRegression(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+class cHipContourSmoother : public cContourSmoother {
+  RowIO row_;
+  FusedRows frows_;
+  bool cpu_warned_ = false;
+  int plain_ = -1, W_ = 0, nz_ = 0;
+ protected:
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    if (plain_ < 0) {
+      const int w = smaWin;                              // the member: myFetchConfig has made an even value odd (contourSmoother.cpp:64-67)
+      W_ = w / 2;
+      plain_ = ((w & 1) && W_ >= 1) ? 1 : 0;
+      nz_ = getInt("noZeroSma") ? 1 : 0;
+    }
+    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
+    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: smaWin = 1 (no smoothing) is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
+    row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);
+    g_frames[11] += out->nT;
+    return 1;
+  }
+ public:
+  explicit cHipContourSmoother(const char *n) : cContourSmoother(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipContourSmoother(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
