@@ -718,6 +718,9 @@ extern "C" int smilehip_specresample_geometry(int64_t n_in, double fs_sec, doubl
 extern "C" int smilehip_specresample_tables(int64_t n_in, int64_t n_out, int64_t k_max, double nd, float *cos_table, float *sin_table) {
   if (n_in < 2 || n_out < 1 || k_max < 0 || (k_max & 1) || k_max > n_in || !(nd > 0.0) || !cos_table || !sin_table)
     return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_tables: bad argument");
+  // up-sampling adds the Nyquist term, kept in the last slot of a table row: the row must be the full half spectrum
+  if (n_out >= n_in && k_max != (n_in & ~(int64_t)1))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_tables: n_out >= n_in needs k_max = n_in (even) / n_in - 1 (odd), got %lld", (long long)k_max);
   const int64_t h = k_max / 2;
   const double pi2 = 2.0 * M_PI;
   for (int64_t i = 0; i < h * n_out; ++i) cos_table[i] = sin_table[i] = 0.0f;
@@ -739,6 +742,8 @@ extern "C" int smilehip_specresample_table_frames(smilehip_context *ctx, const f
   if (!ctx || n_in < 2 || n_in > 8192 || n_out < 1 || n_out > (1 << 20) || k_max < 2 || (k_max & 1) || k_max > n_in || n_frames < 0 ||
       ld_src < n_in || ld_dst < n_out || !d_cos || !d_sin || (n_frames > 0 && (!d_src || !d_dst)))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_table_frames: bad argument (n_in <= 8192; tables of smilehip_specresample_tables)");
+  if (n_out >= n_in && k_max != (n_in & ~(int64_t)1))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_specresample_table_frames: n_out >= n_in needs k_max = n_in (even) / n_in - 1 (odd), got %lld", (long long)k_max);
   STAGE_RET(stage_specresample_g(d_src, ld_src, (int)n_in, (int)n_out, (int)k_max, d_cos, d_sin, d_dst, ld_dst, n_frames, (hipStream_t)stream),
             "specresample");
 }

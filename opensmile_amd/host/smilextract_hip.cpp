@@ -287,6 +287,17 @@ int main(int argc, char **argv) {
   auto per_file = [&](const Job &j, const std::string &optname, const char *ext) {
     return list_mode ? outdir + "/" + basename_noext(j.wav) + ext : opt[optname];
   };
+  if (list_mode && !outdir.empty()) {
+    // per-file outputs are written by several threads: two list entries with the same base name (different directories) would
+    // write the same path at the same time -- refused (over the WHOLE list: every rank sees the same answer)
+    std::map<std::string, size_t> seen;
+    for (size_t i = 0; i < all_jobs.size(); ++i) {
+      const auto ins = seen.insert({basename_noext(all_jobs[i].wav), i});
+      if (!ins.second)
+        die("file list entries " + std::to_string(ins.first->second + 1) + " and " + std::to_string(i + 1) + " ('" + all_jobs[i].wav +
+            "') have the same base name: their per-file outputs in -outdir would be the same file");
+    }
+  }
 
   smilehip_context *ctx = nullptr;
   check(smilehip_init(device, &ctx), "smilehip_init");

@@ -555,3 +555,14 @@ def test_smilextract_hip_gemaps_v01a_sets_equal_binary(tmp_path):
                 assert r.returncode == 0, r.stderr.decode()[-1500:]
                 assert open(ol, "rb").read() == open(rl, "rb").read(), (setname, k, how[0], "LLD level")
                 assert open(of, "rb").read() == open(rf, "rb").read(), (setname, k, how[0], "functionals")
+
+
+def test_smilextract_hip_refuses_same_base_name_in_a_list(tmp_path):
+    """per-file outputs of a list are <outdir>/<base name><ext>, written by several threads: two entries with the same base name
+    (different directories) are refused before anything is read or any device is touched"""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    lst = tmp_path / "list.txt"
+    lst.write_text(f"{tmp_path}/a/x.wav\n{tmp_path}/b/y.wav\n{tmp_path}/b/x.wav\n")
+    r = subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-filelist", str(lst), "-outdir", str(tmp_path), "-O", "on"], capture_output=True)
+    assert r.returncode != 0 and b"same base name" in r.stderr and b"entries 1 and 3" in r.stderr, r.stderr
