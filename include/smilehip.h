@@ -709,6 +709,16 @@ int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, 
  * kinds 0 / 1 forward to smilehip_window_op_row. */
 int smilehip_window_op_row_ex(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W, float *d_norm_io,
                               void *stream);
+/* R13, every option of cDeltaRegression::processBuffer (src/dspcore/deltaRegression.cpp:104-170) on one row: deltawin W >= 0 (0: the
+ * simple difference x[n] - x[n-1], :141-153; the row is then valid on [-1, n_t)), flags SMILEHIP_DELTA_RELATIVE (relativeDelta:
+ * delta / |prior|, 0 where prior is 0, :104-111), _HALFWAVE (halfWaveRect), _ABS (absOutput; halfWaveRect wins, :158-166),
+ * _SEGMENTS (onlyInSegments, with d_norm_io as in smilehip_window_op_row_ex). */
+#define SMILEHIP_DELTA_RELATIVE 1
+#define SMILEHIP_DELTA_HALFWAVE 2
+#define SMILEHIP_DELTA_ABS 4
+#define SMILEHIP_DELTA_SEGMENTS 8
+int smilehip_delta_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int W, int flags, float *d_norm_io,
+                          void *stream);
 /* ---- GeMAPS / eGeMAPS components, per component, on an eGeMAPS plan (smilehip_config_egemapsv02: 16 kHz, 20 ms Hamming frames
  * -> 512-point spectrum; 60 ms frames -> 1024-point spectrum). Rows in, rows out, like the operators above. */
 /* cSpectral::processVector (src/lldcore/spectral.cpp:586-1254) with the GeMAPS option sets -- squareInput = 1, useLogSpectrum = 1,

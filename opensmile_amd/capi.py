@@ -209,6 +209,7 @@ SYMBOLS = {
                                         _vp]),
     "smilehip_window_op_row": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "smilehip_window_op_row_ex": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp]),
+    "smilehip_delta_op_row": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp]),
     "smilehip_pcm_convert": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
     "smilehip_pcm_convert_float": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, _vp, _vp]),
     "smilehip_pcm16_to_float": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -154,6 +154,56 @@ __global__ void k_window_op_seq(const float *x, float *y, int64_t nT, int kind, 
   *norm_io = norm;
 }
 
+// cDeltaRegression::processBuffer with its option variants (deltaRegression.cpp:104-170), one row: flags 1 = relativeDelta
+// (computeDelta :104-111: delta / |prior|, 0 where prior is 0), 2 = halfWaveRect, 4 = absOutput (:158-166; halfWaveRect wins),
+// 8 = onlyInSegments (pairs with a zero / NaN member skipped; the norm member grows with every pair used, see k_window_op_seq).
+// W = 0: the simple difference x[n] - x[n-1] (:141-153). Without onlyInSegments every output is independent.
+__device__ __forceinline__ float delta_of(float prior, float later, int relative) {
+  float delta = later - prior;
+  if (relative) delta = (prior != 0.0f) ? delta / fabsf(prior) : 0.0f;
+  return delta;
+}
+__device__ __forceinline__ float delta_post(float y, int flags) {
+  if (flags & 2) return y < 0.0f ? 0.0f : y;
+  if (flags & 4) return y < 0.0f ? -y : y;
+  return y;
+}
+__device__ __forceinline__ bool no_value(float v) { return v == 0.0f || v != v; }    // isNoValue, deltaRegression.hpp
+__global__ void k_delta_op(const float *x, float *y, int64_t nT, int W, float norm, int flags) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nT) return;
+  float v;
+  if (W > 0) {
+    float num = 0.0f;
+    for (int i = 1; i <= W; ++i) num += (float)i * delta_of(x[n - i], x[n + i], flags & 1);
+    v = num / norm;
+  } else {
+    v = delta_of(x[n - 1], x[n], flags & 1);
+  }
+  y[n] = delta_post(v, flags);
+}
+__global__ void k_delta_op_seq(const float *x, float *y, int64_t nT, int W, float *norm_io, int flags) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (W > 0) {
+    float norm = *norm_io;
+    for (int64_t n = 0; n < nT; ++n) {
+      float num = 0.0f;
+      for (int i = 1; i <= W; ++i) {
+        const float a = x[n + i], b = x[n - i];
+        if (!(no_value(a) || no_value(b))) {
+          num += (float)i * delta_of(b, a, flags & 1);
+          norm += (float)i * (float)i;
+        }
+      }
+      y[n] = delta_post((norm != 0.0f) ? num / norm : 0.0f, flags);
+    }
+    *norm_io = norm;
+  } else {
+    for (int64_t n = 0; n < nT; ++n)
+      y[n] = delta_post((no_value(x[n]) || no_value(x[n - 1])) ? 0.0f : delta_of(x[n - 1], x[n], flags & 1), flags);
+  }
+}
+
 // R11 cSpectral::processVector, ComParE option set: the frames of one stream in order (the flux needs the
 // previous frame's magnitudes; `state` carries them across calls). One workgroup, K = 257.
 __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds, float *state, int first, float *dst,
@@ -353,6 +403,12 @@ hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float 
 }
 hipError_t stage_window_op_seq(const float *x, float *y, int64_t nT, int kind, int W, float *d_norm, hipStream_t s) {
   if (nT > 0) hipLaunchKernelGGL(k_window_op_seq, dim3(1), dim3(64), 0, s, x, y, nT, kind, W, d_norm);
+  return hipGetLastError();
+}
+hipError_t stage_delta_op(const float *x, float *y, int64_t nT, int W, float norm, int flags, float *d_norm_io, hipStream_t s) {
+  if (nT <= 0) return hipSuccess;
+  if (flags & 8) hipLaunchKernelGGL(k_delta_op_seq, dim3(1), dim3(64), 0, s, x, y, nT, W, d_norm_io, flags);
+  else hipLaunchKernelGGL(k_delta_op, dim3(nblk2(nT, 256)), dim3(256), 0, s, x, y, nT, W, norm, flags);
   return hipGetLastError();
 }
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {

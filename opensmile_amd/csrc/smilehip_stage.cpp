@@ -289,6 +289,13 @@ extern "C" int smilehip_window_op_row_ex(smilehip_context *ctx, const float *d_x
   STAGE_RET(stage_window_op_seq(d_x, d_y, n_t, kind, W, d_norm_io, (hipStream_t)stream), "window_op_seq");
 }
 
+extern "C" int smilehip_delta_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int W, int flags, float *d_norm_io,
+                                     void *stream) {
+  if (!ctx || n_t < 0 || W < 0 || W > 64 || (flags & ~15) || ((flags & 8) && W > 0 && !d_norm_io) || (n_t > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_op_row: bad argument (deltawin 0 .. 64, flags 1 | 2 | 4 | 8, d_norm_io with onlyInSegments)");
+  STAGE_RET(stage_delta_op(d_x, d_y, n_t, W, W > 0 ? delta_norm(W) : 1.0f, flags, d_norm_io, (hipStream_t)stream), "delta_op");
+}
+
 extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
                                       int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_fftmag_frames: null plan");

@@ -33,6 +33,14 @@ struct RowIO {
     check(smilehip_window_op_row_ex(context(), io.d_in + pre, io.d_out, nT, kind, W, d_norm, nullptr));
     io.down(out->data, nT);
   }
+  void run_delta(cMatrix *in, cMatrix *out, int pre, int post, int W, int flags) {     // cDeltaRegression with option variants
+    const long nT = out->nT;
+    if (nT <= 0) return;
+    io.ensure(nT + pre + post, nT);
+    io.up(in->data - pre, nT + pre + post);
+    check(smilehip_delta_op_row(context(), io.d_in + pre, io.d_out, nT, W, flags, d_norm, nullptr));
+    io.down(out->data, nT);
+  }
   float *d_norm = nullptr;                                 // kind 3: the instance's carried divisor (one device float)
 };
 
@@ -40,15 +48,19 @@ class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
   FusedRows frows_;
   bool cpu_warned_ = false;
-  int plain_ = -1, W_ = 0, segs_ = 0;
+  int plain_ = -1, W_ = 0, segs_ = 0, flags_ = 0;
   DevBytes norm_;
  protected:
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
       W_ = getInt("deltawin");
       segs_ = getInt("onlyInSegments") ? 1 : 0;
-      plain_ = (W_ > 0 && !getInt("relativeDelta") && !getInt("halfWaveRect") && !getInt("absOutput")) ? 1 : 0;
-      if (plain_ && segs_) {                               // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
+      if (W_ < 0) W_ = 0;                                    // :72-75
+      const int hw = getInt("halfWaveRect");
+      flags_ = (getInt("relativeDelta") ? SMILEHIP_DELTA_RELATIVE : 0) | (hw ? SMILEHIP_DELTA_HALFWAVE : 0) |
+               ((!hw && getInt("absOutput")) ? SMILEHIP_DELTA_ABS : 0) | (segs_ ? SMILEHIP_DELTA_SEGMENTS : 0);
+      plain_ = (W_ > 0 && !(flags_ & ~SMILEHIP_DELTA_SEGMENTS)) ? 1 : 0;     // the two forms the window-op kernels have had since round 1 / 2
+      if (segs_ && W_ > 0) {                               // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
         float n0 = 0.0f;
         for (int i = 1; i <= W_; i++) n0 += (float)i * (float)i;
         n0 *= 2.0f;
@@ -58,8 +70,9 @@ class cHipDeltaRegression : public cDeltaRegression {
     }
     if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
-    if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: relativeDelta / absOutput / halfWaveRect are not built"); return cDeltaRegression::processBuffer(in, out, pre, post); }
-    row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
+    if (pre < (W_ > 0 ? W_ : 1) || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: a block without its window's history"); return cDeltaRegression::processBuffer(in, out, pre, post); }
+    if (plain_) row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
+    else row_.run_delta(in, out, pre, post, W_, flags_);   // relativeDelta / halfWaveRect / absOutput / deltawin = 0
     g_frames[10] += out->nT;
     return 1;
   }

@@ -1,5 +1,5 @@
 """The C ABI's operators for the components' other option sets (smilehip_irfft_frames, smilehip_fftmagphase_frames,
-smilehip_mzcr_frames) against numpy restatements of the reference lines they cite (transformFft.cpp:196-216 through the oracle's
+smilehip_mzcr_frames, smilehip_delta_op_row) against numpy restatements of the reference lines they cite (transformFft.cpp:196-216 through the oracle's
 rdft, fftmagphase.cpp:215-287, mzcr.cpp:108-150) on seeded rows, edge cases included. The plugin test
 (tests/test_gpu_plugin.py::test_plugin_option_sets) holds the same operators against the real components."""
 import ctypes as C
@@ -152,3 +152,67 @@ def test_mzcr_every_output(N, flags):
     got, ref = d_o.cpu().numpy(), ref_mzcr(x, flags)
     same = (bits(got) == bits(ref)) | ((got == 0) & (ref == 0))
     assert same.all(), (np.argwhere(~same)[:5], got[~same][:5], ref[~same][:5])
+
+
+def _delta_ref(x, pre, nT, W, flags, norm0):
+    """cDeltaRegression::processBuffer (deltaRegression.cpp:104-170) in float32, the reference's statement order; x[pre + n] = sample n"""
+    f = np.float32
+    rel, half, ab, seg = flags & 1, flags & 2, flags & 4, flags & 8
+    no = lambda v: v == 0.0 or v != v
+
+    def delta(prior, later):
+        d = f(later - prior)
+        if rel:
+            d = f(d / f(abs(prior))) if prior != 0.0 else f(0.0)
+        return d
+    y = np.zeros(nT, np.float32)
+    norm = f(norm0)
+    for n in range(nT):
+        c = pre + n
+        if W > 0:
+            num = f(0.0)
+            for i in range(1, W + 1):
+                if seg and (no(x[c + i]) or no(x[c - i])):
+                    continue
+                num = f(num + f(f(i) * delta(x[c - i], x[c + i])))
+                if seg:
+                    norm = f(norm + f(f(i) * f(i)))
+            y[n] = f(num / norm) if (not seg or norm != 0.0) else f(0.0)
+        else:
+            y[n] = f(0.0) if (seg and (no(x[c]) or no(x[c - 1]))) else delta(x[c - 1], x[c])
+    if half:
+        y[y < 0.0] = 0.0
+    elif ab:
+        y = np.where(y < 0.0, -y, y).astype(np.float32)
+    return y, norm
+
+
+@pytest.mark.parametrize("W", [0, 1, 2, 3])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 6, 5, 8, 9, 13, 11])
+def test_delta_op_row_every_option(W, flags):
+    import torch
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    L = capi.load()
+    rng = np.random.default_rng(100 * W + flags)
+    nT, pre = 97, max(W, 1)
+    x = (rng.standard_normal(nT + pre + W) * 0.5).astype(np.float32)
+    x[rng.random(len(x)) < 0.25] = 0.0                      # "no value" stretches (unvoiced frames of an F0 contour)
+    x[10] = np.nan
+    norm0 = np.float32(2.0) * np.float32(sum(i * i for i in range(1, W + 1)))
+    d_x = torch.from_numpy(x).cuda()
+    d_y = torch.zeros(nT, dtype=torch.float32, device="cuda")
+    d_norm = torch.tensor([norm0], dtype=torch.float32, device="cuda")
+    ref_all, got_all = [], []
+    norm = norm0
+    for rep in range(2):                                    # two rows in the instance's order: onlyInSegments carries its divisor
+        ref, norm = _delta_ref(x, pre, nT, W, flags, norm)
+        capi._check(L.smilehip_delta_op_row(ctx._h, d_x.data_ptr() + 4 * pre, d_y.data_ptr(), nT, W, flags, d_norm.data_ptr(), None))
+        torch.cuda.synchronize()
+        ref_all.append(ref)
+        got_all.append(d_y.cpu().numpy().copy())
+    for ref, got in zip(ref_all, got_all):
+        same = (bits(ref) == bits(got)) | (np.isnan(ref) & np.isnan(got))
+        assert same.all(), f"W={W} flags={flags}: {np.argwhere(~same)[:5].ravel()} {got[~same][:3]} vs {ref[~same][:3]}"
+    if (flags & 8) and W > 0:
+        assert bits(d_norm.cpu().numpy())[0] == bits(np.array([norm]))[0]

@@ -696,3 +696,25 @@ def test_plugin_general_spectral_sets(oracle, conf):
     assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
     assert tr.get("cSpectral", 0) > 0, tr
     assert len(ref) > 100 and own == ref
+
+
+def test_plugin_delta_variants(oracle):
+    """cDeltaRegression's option variants (deltaRegression.cpp:104-170; smilehip_delta_op_row): relativeDelta, halfWaveRect, absOutput
+    (halfWaveRect wins over it), deltawin = 0 (the simple difference), and their combinations with onlyInSegments, on an energy contour
+    and an F0 contour with unvoiced zeros (tests/conf/delta_variants.conf). The same binary with and without the overrides: bit for
+    bit, nothing on the CPU."""
+    from opensmile_amd import synth
+    conf = os.path.join(ROOT, "tests", "conf", "delta_variants.conf")
+    pcm = np.concatenate([synth.utterance(5, 24000), np.zeros(1600, np.int16), synth.utterance(7, 8000)])
+    ref, tr0 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+    y, tr = _run(oracle, pcm, None, conf)
+    assert not any(tr0.values()) and ref.shape == y.shape and ref.shape[1] == 16
+    assert (ref[:, 1] == 0).any() and (ref[:, 1] > 0).any()               # the F0 contour has voiced and unvoiced frames
+    assert tr.get("cDeltaRegression", 0) >= 14 * (ref.shape[0] - 4), tr
+    assert not any(k.endswith(".cpu") and v for k, v in tr.items()), tr
+    names = ["contours", "relativeDelta", "halfWaveRect", "absOutput", "deltawin 0", "deltawin 0 + relative + segments + abs",
+             "relative + segments", "deltawin 3 + relative + halfWave (+ abs)"]
+    for i, name in enumerate(names):
+        g, r = np.ascontiguousarray(y[:, 2 * i:2 * i + 2]), np.ascontiguousarray(ref[:, 2 * i:2 * i + 2])
+        d = g.view(np.uint32) != r.view(np.uint32)
+        assert not d.any(), f"{name}: {d.sum()} of {d.size} values differ, first at {np.argwhere(d)[0]}: {g[d][:3]} vs {r[d][:3]}"
