@@ -164,6 +164,10 @@ typedef struct smilehip_lld_config {
   /* cSpectral bands[0], bands[1] in Hz (src/lldcore/spectral.cpp:779-853; all four 0 = 250-650 and 1000-4000 as in ComParE_2016;
    * IS11_speaker_state has 25-650) */
   int32_t  spectral_band_lo[2], spectral_band_hi[2];
+  /* F0 chains / smilehip_specscale_frames: cSpecScale's three post-processing switches, as "off" bits (0 = all three on, what the
+   * shipped F0 chains set): 1 = specEnhance 0, 2 = specSmooth 0, 4 = auditoryWeighting 0 (src/dsp/specScale.cpp:326-353; without the
+   * weighting the spline's values pass as they are, negative ones too) -- emobase2010, IS10_paraling_compat */
+  int32_t  specscale_off;
 } smilehip_lld_config;
 
 #define SMILEHIP_CHAIN_MFCC 0

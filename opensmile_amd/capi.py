@@ -43,7 +43,7 @@ class LldConfig(C.Structure):
         ("pitch_min", C.c_double), ("shs_n_harmonics", C.c_int32), ("shs_compression", C.c_float),
         ("f0_min_energy", C.c_float), ("append_log_energy", C.c_int32), ("cms", C.c_int32), ("jitter_broken_thresh", C.c_int32),
         ("vit_buffer_len", C.c_int32), ("jitter_search_range", C.c_double), ("formant_max_freq", C.c_double), ("specscale_min_f", C.c_double), ("shs_n_candidates", C.c_int32), ("shs_old_peak_algo", C.c_int32),
-        ("spectral_band_lo", C.c_int32 * 2), ("spectral_band_hi", C.c_int32 * 2),
+        ("spectral_band_lo", C.c_int32 * 2), ("spectral_band_hi", C.c_int32 * 2), ("specscale_off", C.c_int32),
     ]
 
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     bool z = false;
     if (cnt >= 2) z = (i > first) && (i < last) && !near;
     else if (cnt == 1) z = i >= 3;
-    if (z) mg[m] = 0.0;
+    if (z && !(Q.scale_off & 1)) mg[m] = 0.0;            // (specEnhance = 0: the magnitudes pass)
     if constexpr (!std::is_same<EnhStore, std::nullptr_t>::value) { if (i < kK) enh_store(i, (float)mg[m]); }
     else if (i < kK) B[i] = mg[m];
   }
@@ -209,7 +209,7 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     rt[m] = (i < kK - 1) ? B[i + 1] : 0.0;
   }
   F0_FOR_BINS(m, i) {
-    mg[m] = (i < kK - 1) ? (lf[m] + 2.0 * mg[m] + rt[m]) / 4.0 : mg[m];
+    mg[m] = (i < kK - 1 && !(Q.scale_off & 2)) ? (lf[m] + 2.0 * mg[m] + rt[m]) / 4.0 : mg[m];   // (specSmooth = 0: as they are)
     if (i < kK) A[i] = mg[m];
   }
   WaveG::sync();
@@ -343,7 +343,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
       const double b = 1.0 - a;
       const double o = a * A[k] + b * A[k + 1] + c * B[k] + d * B[k + 1];
       float v = (float)o;
-      v = (v > 0.0f) ? (float)((double)v * T.audw[i]) : 0.0f;
+      if (!(Q.scale_off & 4)) v = (v > 0.0f) ? (float)((double)v * T.audw[i]) : 0.0f;     // (auditoryWeighting = 0: the spline's value, negative ones too)
       hv[m] = v;
       if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = v;
     }

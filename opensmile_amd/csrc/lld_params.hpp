@@ -170,6 +170,7 @@ struct F0Params {
   const int32_t *jit_item_utt, *jit_item_t0;   // lld_jitter_runs' work items (utterance, first frame) of 64 consecutive frames each, ordered
   int32_t n_jit_items;              //   by first frame, then utterance (smilehip_batch: d_jit_utt / d_jit_t0); null = one workgroup per utterance
   int32_t *jit_redo;                // [n_utt], zero between runs: utterances lld_jitter_runs hands back to the per-utterance kernel
+  int32_t scale_off;                // cSpecScale: 1 = no peak enhancement, 2 = no smoothing, 4 = no auditory weighting (per-component operator; the chains run with 0)
   int32_t jit_cap;                  // samples of wave per frame the kernels hold in LDS (jitter_wave_capacity; 0 = the general capacity)
   int32_t *jit_ctl;                 // [2], zero between runs: lld_jitter_runs' item counter and count of finished workgroups
 };

@@ -541,6 +541,7 @@ void fill_f0_params(const smilehip_plan *plan, F0Params &Q) {
   Q.jit_search_range = plan->cfg.jitter_search_range > 0.0 ? plan->cfg.jitter_search_range : 0.25;
   Q.n_cand = plan->cfg.shs_n_candidates > 0 ? plan->cfg.shs_n_candidates : 6;
   Q.old_peaks = plan->cfg.shs_old_peak_algo ? 1 : 0;
+  Q.scale_off = plan->cfg.specscale_off & 7;
 }
 
 // cPitchJitter's work items and redo marks of an F0-group batch (lld_jitter.hip)
@@ -560,6 +561,8 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   if (ld_out < (log_out ? 3 : 2)) return fail(SMILEHIP_ERR_INVALID, "ld_out %lld too small", (long long)ld_out);
   if (b->total_frames == 0) return SMILEHIP_OK;
   if (!d_pcm || !d_out) return fail(SMILEHIP_ERR_INVALID, "smilehip_lld_run: null device pointer");
+  if (plan->cfg.specscale_off & 7)
+    return fail(SMILEHIP_ERR_INVALID, "the fused F0 chain runs cSpecScale with enhancement, smoothing and weighting on (specscale_off is for smilehip_specscale_frames)");
   LldParams P;
   fill_params(plan, b, d_pcm, d_out, ld_out, P);
   F0Params Q;

@@ -3,7 +3,8 @@
 // SURVEY 8(f) rank 2, per component. An F0-chain plan carries cSpecScale's spline / weighting tables and cPitchShs'
 // shifts for one spectrum geometry (bins, frameSizeSec of the magnitude level).
 static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double min_pitch, double max_pitch, double cutoff,
-                                        int n_harm, double compression, double min_f = 25.0, int n_cand = 6, int old_peaks = 0) {
+                                        int n_harm, double compression, double min_f = 25.0, int n_cand = 6, int old_peaks = 0,
+                                        int specscale_off = 0) {
   smilehip_lld_config c;
   smilehip_config_compare16_f0(&c);
   c.force_fft_frame_size_sec = frame_size_sec;
@@ -16,6 +17,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
   c.specscale_min_f = min_f;
   c.shs_n_candidates = n_cand;
   c.shs_old_peak_algo = old_peaks;
+  c.specscale_off = specscale_off;
   smilehip_plan *pl = nullptr;
   check(smilehip_plan_create(context(), &c, &pl));
   smilehip_geometry g;
@@ -40,15 +42,17 @@ class cHipSpecScale : public cSpecScale {
     FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       const char *sc = getStr("scale"), *ss = getStr("sourceScale"), *im = getStr("interpMethod");
-      usable_ = sc && !strncasecmp(sc, "oct", 3) && ss && !strncasecmp(ss, "lin", 3) && im && !strncasecmp(im, "spl", 3) &&
-                getDouble("minF") > 0.0 && getDouble("maxF") == -1.0 && getInt("nPointsTarget") <= 0 && getInt("specSmooth") == 1 &&
-                getInt("specEnhance") == 1 && getInt("auditoryWeighting") == 1 && Nsrc == Ndst;
+      // the octave axis: scale = octave, or scale = log with logScaleBase 2 (specScale.cpp:100-111)
+      const bool octave = sc && (!strncasecmp(sc, "oct", 3) || (!strncasecmp(sc, "log", 3) && getDouble("logScaleBase") == 2.0));
+      usable_ = octave && ss && !strncasecmp(ss, "lin", 3) && im && !strncasecmp(im, "spl", 3) &&
+                getDouble("minF") > 0.0 && getDouble("maxF") == -1.0 && getInt("nPointsTarget") <= 0 && Nsrc == Ndst;
       if (usable_) {
-        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, 52.0, 620.0, 0.7, 15, 0.85, getDouble("minF"));
+        const int off = (getInt("specEnhance") ? 0 : 1) | (getInt("specSmooth") ? 0 : 2) | (getInt("auditoryWeighting") ? 0 : 4);
+        pl_ = f0_component_plan(Nsrc, (double)(float)reader_->getLevelConfig()->frameSizeSec, 52.0, 620.0, 0.7, 15, 0.85, getDouble("minF"), 6, 0, off);
         if (!pl_) usable_ = 0;
       }
     }
-    if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave-scale spline set of the F0 chains on spectra of 512 .. 4096 points is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave (log2) target scale from a linear source by spline interpolation, minF > 0, maxF -1, on spectra of 512 .. 4096 points is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
     check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));

@@ -216,3 +216,44 @@ def test_delta_op_row_every_option(W, flags):
         assert same.all(), f"W={W} flags={flags}: {np.argwhere(~same)[:5].ravel()} {got[~same][:3]} vs {ref[~same][:3]}"
     if (flags & 8) and W > 0:
         assert bits(d_norm.cpu().numpy())[0] == bits(np.array([norm]))[0]
+
+
+@pytest.mark.parametrize("K,min_f", [(513, 25.0), (257, 20.0), (2049, 25.0)])
+@pytest.mark.parametrize("off", [0, 1, 2, 4, 7, 5])
+def test_specscale_switches(K, min_f, off, oracle):
+    """cSpecScale with specEnhance / specSmooth / auditoryWeighting switched off one by one and together (emobase2010:
+    all three off; IS10_paraling_compat likewise): smilehip_specscale_frames on a plan with specscale_off against the
+    oracle's lldo_specscale_frame_ex, which tests/test_oracle_pin_f0_variants.py pins on those files' own levels. Without the
+    weighting the spline's negative values pass."""
+    import torch
+    from opensmile_amd import capi
+    ctx = capi.Context(0)
+    cfg = capi.compare16_f0_config()
+    fs = (K - 1) * 2 / 16000.0
+    cfg.force_fft_frame_size_sec = fs
+    cfg.force_frame_size = 2 * (K - 1)
+    cfg.specscale_min_f = min_f
+    cfg.specscale_off = off
+    plan = capi.Plan(ctx, cfg)
+    assert plan.geometry.n_bins == K
+    rng = np.random.default_rng(K + off)
+    mag = np.abs(rng.standard_normal((12, K))).astype(np.float32)
+    mag[0] = 0.0
+    mag[1] = np.linspace(1.0, 0.0, K, dtype=np.float32)
+    mag[2] = 1.0
+    mag[3, ::7] *= 40.0                                      # sharp peaks: the spline overshoots below zero between them
+    ref, _ = oracle.specscale_shs_rows(mag, fs, min_f=min_f, flags=7 & ~off)
+    d_m = torch.from_numpy(mag).cuda()
+    d_h = torch.zeros((12, K), dtype=torch.float32, device="cuda")
+    capi._check(capi.load().smilehip_specscale_frames(plan._h, d_m.data_ptr(), K, d_h.data_ptr(), K, 12, None))
+    torch.cuda.synchronize()
+    got = d_h.cpu().numpy()
+    d = bits(got) != bits(ref)
+    assert not d.any(), f"K={K} off={off}: {d.sum()} cells differ, rows {sorted(set(np.argwhere(d)[:, 0]))}"
+    if off & 4:
+        assert (ref[3] < 0).any()
+    # the fused chain refuses a plan with switches off
+    if off:
+        b = capi.Batch(plan, np.array([0, 16000], np.int64))
+        with pytest.raises(Exception):
+            b.run_host(np.zeros(16000, np.int16))

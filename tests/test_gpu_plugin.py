@@ -627,19 +627,32 @@ def test_plugin_other_interspeech_sets(oracle, conf, n_lld, n_func):
 
 
 def test_plugin_refuses_what_is_not_built(oracle):
-    """IS10_paraling_compat.conf runs cSpecScale on a log2 axis without smoothing / enhancement / auditory weighting -- an option set
-    that is not an operator of the library: the override says so and the process fails (no silent CPU path); with
-    SMILEHIP_PLUGIN_ALLOW_CPU=1 the instance runs the reference's own code, counted, and the file equals the plain binary's."""
-    import subprocess
+    """prosodyShsViterbiLoudness.conf asks cHarmonics for outputs beyond GeMAPS' set -- an option set that is not an operator of the
+    library: the override says so and the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 the instance runs the
+    reference's own code, counted, and the file equals the plain binary's."""
     from opensmile_amd import synth
     pcm = synth.utterance(71, 16000)
-    conf = "is09-13/IS10_paraling_compat.conf"
-    with pytest.raises(AssertionError, match="cSpecScale: only the octave-scale spline set"):
-        _run(oracle, pcm, None, conf, "-lldhtkoutput")
-    ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-lldhtkoutput")
-    y, tr = _run(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-lldhtkoutput")
-    assert tr.get("cSpecScale.cpu", 0) > 0 and tr.get("cLsp", 0) > 0, tr
-    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    conf = "prosody/prosodyShsViterbiLoudness.conf"
+    with pytest.raises(AssertionError, match="cHarmonics: only GeMAPS' option set"):
+        _run_bytes(oracle, pcm, None, conf, "-O")
+    ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-O")
+    y, tr = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-O")
+    assert tr.get("cHarmonics.cpu", 0) > 0 and tr.get("cPitchShs", 0) > 0, tr
+    assert len(ref) > 100 and y == ref
+
+
+@pytest.mark.parametrize("conf,n_lld", [("is09-13/IS10_paraling_compat.conf", 76), ("emobase/emobase2010.conf", None)])
+def test_plugin_specscale_switch_sets(oracle, conf, n_lld):
+    """IS10_paraling_compat.conf and emobase2010.conf run cSpecScale on the log2 axis WITHOUT smoothing / enhancement / auditory
+    weighting (smilehip_lld_config::specscale_off): every override active, nothing on the CPU, the plain binary's file byte for byte."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(71, 24000)
+    opt = "-lldhtkoutput" if n_lld else "-O"
+    ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, opt)
+    y, tr = _run_bytes(oracle, pcm, None, conf, opt)
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert tr.get("cSpecScale", 0) > 0, tr
+    assert len(ref) > 100 and y == ref
 
 
 @pytest.mark.parametrize("fs", [8000, 44100])
