@@ -126,8 +126,8 @@ class cHipFormantLpc : public cFormantLpc {
 class cHipHarmonics : public cHarmonics {
   FrameIO io_;
   bool cpu_warned_ = false;
-  int usable_ = -1;
-  long iF0_ = -1, iSpec_ = -1, iFf_ = -1, iFb_ = -1, nSpec_ = 0, nFf_ = 0, nFb_ = 0;
+  int usable_ = -1;                                        // 1: GeMAPS' six outputs; 2: the ACF harmonics-to-noise ratio alone
+  long iF0_ = -1, iSpec_ = -1, iFf_ = -1, iFb_ = -1, nSpec_ = 0, nFf_ = 0, nFb_ = 0, rate_ = 0;
   DevBytes fm_, f0_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
@@ -143,7 +143,11 @@ class cHipHarmonics : public cHarmonics {
         const char *v = getStr_f(myvprint("harmonicDifferences[%i]", i));
         ok = v && !strcmp(v, diffs[i]);
       }
-      if (ok) {
+      // computeAcfHnrLogdB alone (prosodyShsViterbiLoudness.conf): the ratio comes from the ACF of the squared magnitudes and the F0
+      // lag (harmonics.cpp:590-712) -- no harmonic search, no formants; column 0 of the operator's row
+      const bool hnr_only = !ok && getInt("nHarmonicMagnitudes") == 0 && getArraySize("harmonicDifferences") <= 0 && !getInt("formantAmplitudes") &&
+                            getInt("computeAcfHnrLogdB") == 1 && !getInt("computeAcfHnrLinear") && Ndst == 1 && idxi == 0;
+      if (ok || hnr_only) {
         iF0_ = findElement(getStr("f0ElementName"), getInt("f0ElementNameIsFull"), NULL, NULL, NULL);
         int specField = -1;
         iSpec_ = findField(getStr("magSpecFieldName"), getInt("magSpecFieldNameIsFull"), &nSpec_, NULL, -1, NULL, &specField);
@@ -160,33 +164,40 @@ class cHipHarmonics : public cHarmonics {
         if (size_ok && fmeta && specField >= 0 && specField < fmeta->N && fmeta->field[specField].info &&
             fmeta->field[specField].infoSize == nSpec_ * (long)sizeof(double)) {
           const double *frq = (const double *)fmeta->field[specField].info;
-          smilehip_geometry g;
-          check(smilehip_plan_geometry(gemaps_plan(), &g));
-          // the plan of the rate seen last (cSpecResample / cSpectral run before this component in every tick): its 60 ms
-          // spectrum must be this one -- same number of bins, same axis step
-          const double step = (double)g_gm_rate / (double)(2 * (nSpec_ - 1));
-          axis = frq[0] == 0.0 && frq[1] == step && frq[nSpec_ - 1] == step * (double)(nSpec_ - 1);
+          // GeMAPS' set: the plan of the rate seen last (cSpecResample / cSpectral run before this component in every tick);
+          // alone: the rate the axis itself tells. Its 60 ms spectrum must be this one -- same number of bins, same axis step
+          rate_ = hnr_only ? std::lround(frq[1] * (double)(2 * (nSpec_ - 1))) : g_gm_rate;
+          if (rate_ >= 8000 && rate_ <= 48000) {
+            smilehip_geometry g;
+            check(smilehip_plan_geometry(gemaps_plan(rate_), &g));
+            const double step = (double)rate_ / (double)(2 * (nSpec_ - 1));
+            axis = frq[0] == 0.0 && frq[1] == step && frq[nSpec_ - 1] == step * (double)(nSpec_ - 1);
+          }
         }
-        ok = axis && iF0_ >= 0 && iSpec_ >= 0 && iFf_ >= 0 && iFb_ >= 0 && size_ok && nFf_ == 5 && nFb_ == 5 && iSpec_ + nSpec_ <= Nsrc;
+        const bool common = axis && iF0_ >= 0 && iSpec_ >= 0 && size_ok && iSpec_ + nSpec_ <= Nsrc;
+        if (hnr_only) { usable_ = common ? 2 : 0; ok = false; }
+        else ok = common && iFf_ >= 0 && iFb_ >= 0 && nFf_ == 5 && nFb_ == 5;
       }
-      usable_ = ok ? 1 : 0;
+      if (usable_ < 0) usable_ = ok ? 1 : 0;
     }
     if (!usable_) {
       HIP_FALLTHROUGH(20, "cHarmonics: only GeMAPS' option set (H1-H2, H1-A3, formant amplitudes 1..3, ACF HNR in dB; 5 formants, the "
-                          "spectrum of 60 ms frames at 8 .. 48 kHz) is built");
+                          "spectrum of 60 ms frames at 8 .. 48 kHz) and the ACF HNR in dB alone are built");
       return cHarmonics::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     io_.ensure(nSpec_, 6);
     io_.up(src + iSpec_, nSpec_);
-    float fm[10];
-    memcpy(fm, src + iFf_, sizeof(float) * 5);
-    memcpy(fm + 5, src + iFb_, sizeof(float) * 5);
+    float fm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (usable_ == 1) {
+      memcpy(fm, src + iFf_, sizeof(float) * 5);
+      memcpy(fm + 5, src + iFb_, sizeof(float) * 5);
+    }
     float *d_fm = (float *)fm_.ensure(sizeof(float) * 10), *d_f0 = (float *)f0_.ensure(sizeof(float));
     if (smilehip_copy_to_device(context(), d_fm, fm, sizeof(fm), nullptr) ||
         smilehip_copy_to_device(context(), d_f0, src + iF0_, sizeof(float), nullptr))
       COMP_ERR("libsmilehip: %s", smilehip_last_error());
-    check(smilehip_harmonics_frames(gemaps_plan(), d_f0, d_fm, 10, io_.d_in, nSpec_, io_.d_out, 6, 1, nullptr));
-    io_.down(dst, 6);
+    check(smilehip_harmonics_frames(usable_ == 2 ? gemaps_plan(rate_) : gemaps_plan(), d_f0, d_fm, 10, io_.d_in, nSpec_, io_.d_out, 6, 1, nullptr));
+    io_.down(dst, usable_ == 2 ? 1 : 6);
     g_frames[20]++;
     return 1;
   }

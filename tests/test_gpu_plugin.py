@@ -627,17 +627,30 @@ def test_plugin_other_interspeech_sets(oracle, conf, n_lld, n_func):
 
 
 def test_plugin_refuses_what_is_not_built(oracle):
-    """prosodyShsViterbiLoudness.conf asks cHarmonics for outputs beyond GeMAPS' set -- an option set that is not an operator of the
-    library: the override says so and the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 the instance runs the
-    reference's own code, counted, and the file equals the plain binary's."""
+    """avec2011.conf's cFunctionals instances use families / options that are not operators of the library: the override says so and
+    the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 those instances run the reference's own code, counted,
+    and the file equals the plain binary's."""
     from opensmile_amd import synth
-    pcm = synth.utterance(71, 16000)
-    conf = "prosody/prosodyShsViterbiLoudness.conf"
-    with pytest.raises(AssertionError, match="cHarmonics: only GeMAPS' option set"):
+    pcm = synth.utterance(71, 24000)
+    conf = "avec11-14/avec2011.conf"
+    with pytest.raises(AssertionError, match="cFunctionals: a functional family or option of this instance is not built"):
         _run_bytes(oracle, pcm, None, conf, "-O")
     ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-O")
     y, tr = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-O")
-    assert tr.get("cHarmonics.cpu", 0) > 0 and tr.get("cPitchShs", 0) > 0, tr
+    assert tr.get("cFunctionals.cpu", 0) > 0 and tr.get("cSpectral", 0) > 0, tr
+    assert len(ref) > 100 and y == ref
+
+
+def test_plugin_harmonics_acf_hnr_alone(oracle):
+    """prosodyShsViterbiLoudness.conf asks cHarmonics for the ACF harmonics-to-noise ratio alone (computeAcfHnrLogdB on a 55 ms frame's
+    1024-point spectrum): column 0 of the GeMAPS operator's row. Every override active, nothing on the CPU, byte-identical file."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(71, 24000)
+    conf = "prosody/prosodyShsViterbiLoudness.conf"
+    ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-O")
+    y, tr = _run_bytes(oracle, pcm, None, conf, "-O")
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert tr.get("cHarmonics", 0) > 0 and tr.get("cPitchShs", 0) > 0, tr
     assert len(ref) > 100 and y == ref
 
 
