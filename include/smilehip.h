@@ -343,15 +343,20 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *   Samples     (functionalSamples.cpp:100-117)    the contour at n_samples (<= 8) relative positions
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
- * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange, the other
- * segmentation algorithms, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
+ * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange,
+ * Segments.useOldBuggyChX / growDynSegBuffer, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
   SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_CROSSINGS, SMILEHIP_FAM_DCT,
   SMILEHIP_FAM_SAMPLES, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
-enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2 };
+/* Segments.segmentationAlgorithm (functionalSegments.cpp:118-155). The reference parses ltX / gtX / geqX / leqX but has no
+ * code for them: its switch falls to the delta method (:872-874) -- pass SMILEHIP_SEG_DELTA for those. absTh never reads its
+ * thresholds (:179-180): it finds no segment, here as there. */
+enum { SMILEHIP_SEG_RELTH = 0, SMILEHIP_SEG_NONX = 1, SMILEHIP_SEG_EQX = 2, SMILEHIP_SEG_MRELTH = 3, SMILEHIP_SEG_ABSTH = 4,
+       SMILEHIP_SEG_NARELTH = 5, SMILEHIP_SEG_NAMRELTH = 6, SMILEHIP_SEG_NAABSTH = 7, SMILEHIP_SEG_DELTA = 8,
+       SMILEHIP_SEG_DELTA2 = 9, SMILEHIP_SEG_CHX = 10 };
 
 typedef struct smilehip_func_spec {
   int32_t n_fam;
@@ -368,8 +373,8 @@ typedef struct smilehip_func_spec {
   double pctl[8]; int32_t range_a[8], range_b[8];
   uint32_t times_mask; int32_t times_norm, times_buggy_sec_norm, reserved2;
   uint32_t seg_mask; int32_t seg_norm, seg_algo, seg_max_num, seg_min_lng, seg_auto_min_lng, seg_pause_min_lng,
-      seg_x_is_rel, seg_n_thresholds, reserved3;
-  float seg_x; float seg_thresholds[8]; float reserved4;
+      seg_x_is_rel, seg_n_thresholds, seg_ravg_lng;        /* ravgLng of delta / delt2; <= 0: Nin / (maxNumSeg / 2) */
+  float seg_x; float seg_thresholds[8]; float seg_range_rel_threshold;   /* rangeRelThreshold of delta / delt2 */
   int32_t lpc_gain, lpc_coeffs, lpc_first, lpc_order;      /* order <= 16 */
   uint32_t pk_mask; int32_t pk_norm, pk_ratio_limit, pk_dyn_rel, pk_use_abs, reserved5;
   float pk_rel_thresh, pk_abs_thresh;

@@ -700,30 +700,101 @@ struct SegAcc {
   }
 };
 
-__device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, float range, SegAcc &r) {
+// The walks of functionalSegments.cpp: process_SegDelta :227-264, process_SegDelta2 :266-307, process_SegThresh :309-367,
+// process_SegThreshNoavg :369-413, process_SegChX :560-653, process_SegNonX / process_SegEqX :656-799
+__device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, float range, float amean, SegAcc &r) {
   const int64_t Nin = in.N;
-  if (s.seg_algo == SMILEHIP_SEG_RELTH) {
+  const int algo = s.seg_algo;
+  int64_t segMinLng = s.seg_min_lng;
+  if (algo != SMILEHIP_SEG_NONX && algo != SMILEHIP_SEG_EQX && algo != SMILEHIP_SEG_CHX && s.seg_auto_min_lng) {
+    segMinLng = Nin / s.seg_max_num - 1;
+    if (segMinLng < 2) segMinLng = 2;
+  }
+  if (algo == SMILEHIP_SEG_DELTA || algo == SMILEHIP_SEG_DELTA2) {
+    const float segThresh = range * s.seg_range_rel_threshold;
+    const int64_t L = (s.seg_ravg_lng > 0) ? s.seg_ravg_lng : Nin / (s.seg_max_num / 2);
+    int64_t lastSeg = -segMinLng / 2;
+    const bool d2 = algo == SMILEHIP_SEG_DELTA2;
+    float ravg = 0.0f, raLast = 0.0f, prev = 0.0f;
+    for_rows(in, 0, Nin, [&](int64_t i, float v) {
+      if (d2 && i == 0) { ravg = v; prev = v; return; }    // delt2 starts its average at in[0] and its loop at 1
+      ravg += v;
+      if (i >= L) ravg -= in[i - L];
+      const float ra = ravg / (float)((i + 1 < L) ? (i + 1) : L);
+      const bool hit = d2 ? ((prev - raLast <= segThresh) && (v - ra > segThresh)) : (v - ra > segThresh);
+      if (hit && (i - lastSeg > segMinLng)) { r.add(i, lastSeg); lastSeg = i; }
+      raLast = ra; prev = v;
+    });
+  } else if (algo == SMILEHIP_SEG_RELTH || algo == SMILEHIP_SEG_MRELTH || algo == SMILEHIP_SEG_ABSTH ||
+             algo == SMILEHIP_SEG_NARELTH || algo == SMILEHIP_SEG_NAMRELTH || algo == SMILEHIP_SEG_NAABSTH) {
+    const bool rel = algo == SMILEHIP_SEG_RELTH || algo == SMILEHIP_SEG_NARELTH;
+    const bool mrel = algo == SMILEHIP_SEG_MRELTH || algo == SMILEHIP_SEG_NAMRELTH;
+    const bool avg = algo == SMILEHIP_SEG_RELTH || algo == SMILEHIP_SEG_MRELTH || algo == SMILEHIP_SEG_ABSTH;
+    const int nth = (algo == SMILEHIP_SEG_ABSTH) ? 0 : s.seg_n_thresholds;     // absTh: :179-180 never reads the array
     float th[8];
-    for (int j = 0; j < 8; ++j) th[j] = (j < s.seg_n_thresholds) ? min + range * s.seg_thresholds[j] : 0.0f;
-    int64_t segMinLng = s.seg_min_lng;
-    if (s.seg_auto_min_lng) {
-      segMinLng = Nin / s.seg_max_num - 1;
-      if (segMinLng < 2) segMinLng = 2;
-    }
+    for (int j = 0; j < 8; ++j)
+      th[j] = (j < nth) ? (rel ? min + range * s.seg_thresholds[j] : mrel ? amean * s.seg_thresholds[j] : s.seg_thresholds[j]) : 0.0f;
     int64_t lastSeg = -segMinLng / 2;
     float ravg = 0.0f, raLast = 0.0f;
     float h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;           // in[i-1], in[i-2], in[i-3]
     for_rows(in, 0, Nin, [&](int64_t i, float v) {
-      ravg += v;
-      if (i >= 3) ravg -= h3;
-      const float ra = ravg / (float)((i + 1 < 3) ? (i + 1) : 3);
+      float ra, last;
+      if (avg) {
+        ravg += v;
+        if (i >= 3) ravg -= h3;
+        ra = ravg / (float)((i + 1 < 3) ? (i + 1) : 3);
+        last = raLast;
+        raLast = ra;
+      } else {
+        ra = v; last = h1;
+      }
       bool cross = false;
-      for (int j = 0; j < 8; ++j)
-        if (j < s.seg_n_thresholds && ((ra > th[j] && raLast <= th[j]) || (ra < th[j] && raLast >= th[j]))) cross = true;
-      raLast = ra;
+      if (avg || i >= 1)
+        for (int j = 0; j < 8; ++j)
+          if (j < nth && ((ra > th[j] && last <= th[j]) || (ra < th[j] && last >= th[j]))) cross = true;
       if (cross && (i - lastSeg > segMinLng)) { r.add(i, lastSeg); lastSeg = i; }
       h3 = h2; h2 = h1; h1 = v;
     });
+  } else if (algo == SMILEHIP_SEG_CHX) {
+    const float X = s.seg_x_is_rel ? (min + range * s.seg_x) : s.seg_x;
+    int64_t segStartIndex = 0, segEndIndex = 0;
+    int inSeg = 0, segStart = 0, segEnd = 0;
+    for_rows(in, 0, Nin, [&](int64_t i, float v) {
+      if (v != X) {
+        if (inSeg == 1) {
+          segEnd = 0;
+          segStart++;
+          if (segStart >= s.seg_min_lng) { inSeg = 2; r.add(segStartIndex - 1, segEndIndex); segStart = 0; }
+        } else if (inSeg == 0) {
+          segStart++;
+          segStartIndex = i;
+          inSeg = 1;
+        } else if (inSeg == 2) {
+          segEnd = 0;
+        } else if (inSeg == 3) {
+          segStart++;
+          if (segStart >= s.seg_min_lng) { inSeg = 2; segEnd = 0; segStart = 0; }
+        }
+      }
+      if (v == X) {
+        if (inSeg == 3) {
+          segStart = 0;
+          segEnd++;
+          if (segEnd >= s.seg_min_lng) { inSeg = 0; r.add(segEndIndex - 1, segStartIndex); segEnd = 0; }
+        } else if (inSeg == 2) {
+          segEnd++;
+          segEndIndex = i;
+          inSeg = 3;
+        } else if (inSeg == 0) {
+          segStart = 0;
+        } else if (inSeg == 1) {
+          segEnd++;
+          if (segEnd >= s.seg_pause_min_lng) { inSeg = 0; segEnd = 0; segStart = 0; }
+        }
+      }
+    });
+    if (inSeg == 2) r.add(segEndIndex - 1, segStartIndex);
+    else if (inSeg == 0) r.add(segStartIndex - 1, segEndIndex);
   } else {
     const float X = s.seg_x_is_rel ? (min + range * s.seg_x) : s.seg_x;
     const bool eq = s.seg_algo == SMILEHIP_SEG_EQX;      // eqX (:728-799) is nonX with the two tests swapped
@@ -766,18 +837,18 @@ __device__ void seg_walk(const smilehip_func_spec &s, const Col &in, float min, 
   }
 }
 
-__device__ int f_segments(const smilehip_func_spec &s, const Col &in, float min, float max, float *out) {
+__device__ int f_segments(const smilehip_func_spec &s, const Col &in, float min, float max, float amean, float *out) {
   const int64_t Nin = in.N;
   const float range = max - min;
   SegAcc r;
   r.n = r.sum = r.maxl = r.minl = 0; r.cap = s.seg_max_num; r.second = false; r.mean = r.dev = 0.0f;
-  seg_walk(s, in, min, range, r);
+  seg_walk(s, in, min, range, amean, r);
   const int64_t nSeg = r.n;
   float mean = (nSeg > 1) ? (float)r.sum / ((float)nSeg) : (float)r.sum;
   float lenDev = 0.0f;
   if (nSeg > 1 && FS_BIT(s.seg_mask, 4)) {
     r.second = true; r.n = 0; r.mean = mean; r.dev = 0.0f;
-    seg_walk(s, in, min, range, r);
+    seg_walk(s, in, min, range, amean, r);
     lenDev = r.dev / (float)nSeg;
     lenDev = (float)sqrt((double)lenDev);
   }
@@ -1207,7 +1278,7 @@ __global__ void __launch_bounds__(kColsPerBlock) fs_family(FsParams P, int out_o
   if (FAM == SMILEHIP_FAM_MOMENTS) got = f_moments(P.spec, x, mean, o);
   if (FAM == SMILEHIP_FAM_REGRESSION) got = f_regression(P.spec, x, mn, mx, mean, o);
   if (FAM == SMILEHIP_FAM_TIMES) got = f_times(P.spec, x, mn, mx, o);
-  if (FAM == SMILEHIP_FAM_SEGMENTS) got = f_segments(P.spec, x, mn, mx, o);
+  if (FAM == SMILEHIP_FAM_SEGMENTS) got = f_segments(P.spec, x, mn, mx, mean, o);
   if (FAM == SMILEHIP_FAM_LPC) got = f_lpc(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_ONSET) got = f_onset(P.spec, x, o);
   if (FAM == SMILEHIP_FAM_PEAKS) got = f_peaks_old(P.spec, x, mn, mx, o);

@@ -40,9 +40,11 @@ int family_count(const smilehip_func_spec &s, int fam) {
       return popc(s.times_mask);
     case SMILEHIP_FAM_SEGMENTS:
       if (s.seg_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Segments: unknown bits in mask 0x%x", s.seg_mask);
-      if (s.seg_algo != SMILEHIP_SEG_RELTH && s.seg_algo != SMILEHIP_SEG_NONX && s.seg_algo != SMILEHIP_SEG_EQX)
-        return fail(SMILEHIP_ERR_INVALID, "Segments: segmentationAlgorithm %d is not built (relTh, nonX and eqX are)", s.seg_algo);
+      if (s.seg_algo < SMILEHIP_SEG_RELTH || s.seg_algo > SMILEHIP_SEG_CHX)
+        return fail(SMILEHIP_ERR_INVALID, "Segments: unknown segmentationAlgorithm %d", s.seg_algo);
       if (s.seg_max_num < 1) return fail(SMILEHIP_ERR_INVALID, "Segments.maxNumSeg must be >= 1");
+      if ((s.seg_algo == SMILEHIP_SEG_DELTA || s.seg_algo == SMILEHIP_SEG_DELTA2) && s.seg_ravg_lng <= 0 && s.seg_max_num < 2)
+        return fail(SMILEHIP_ERR_INVALID, "Segments: delta / delt2 without ravgLng need maxNumSeg >= 2 (Nin / (maxNumSeg / 2))");
       if (s.seg_n_thresholds < 0 || s.seg_n_thresholds > 8) return fail(SMILEHIP_ERR_INVALID, "Segments: at most 8 thresholds");
       if (s.seg_min_lng < 1 || s.seg_pause_min_lng < 1) return fail(SMILEHIP_ERR_INVALID, "Segments: segMinLng and pauseMinLng must be >= 1");
       return popc(s.seg_mask);

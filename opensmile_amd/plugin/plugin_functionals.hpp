@@ -140,10 +140,20 @@ class cHipFunctionals : public cFunctionals {
         s.seg_norm = time_norm(f);
         const char *alg = getStr_f(myvprint("%s.segmentationAlgorithm", f));
         if (!alg) return false;
-        if (!strncmp(alg, "relTh", 5)) s.seg_algo = SMILEHIP_SEG_RELTH;
+        // the reference's own prefix tests in its own order (functionalSegments.cpp:120-155); ltX / gtX / geqX / leqX and any
+        // unknown name end in the delta method there (:152-154, :872-874)
+        if (!strncmp(alg, "delta", 5)) s.seg_algo = SMILEHIP_SEG_DELTA;
+        else if (!strncmp(alg, "delt2", 5)) s.seg_algo = SMILEHIP_SEG_DELTA2;
+        else if (!strncmp(alg, "relTh", 5)) s.seg_algo = SMILEHIP_SEG_RELTH;
+        else if (!strncmp(alg, "mrelTh", 6)) s.seg_algo = SMILEHIP_SEG_MRELTH;
+        else if (!strncmp(alg, "absTh", 5)) s.seg_algo = SMILEHIP_SEG_ABSTH;
+        else if (!strncmp(alg, "NArelTh", 7)) s.seg_algo = SMILEHIP_SEG_NARELTH;
+        else if (!strncmp(alg, "mNArelTh", 8) || !strncmp(alg, "NAmrelTh", 8)) s.seg_algo = SMILEHIP_SEG_NAMRELTH;
+        else if (!strncmp(alg, "NAabsTh", 7)) s.seg_algo = SMILEHIP_SEG_NAABSTH;
+        else if (!strncmp(alg, "chX", 3)) s.seg_algo = SMILEHIP_SEG_CHX;
         else if (!strncmp(alg, "nonX", 4)) s.seg_algo = SMILEHIP_SEG_NONX;
         else if (!strncmp(alg, "eqX", 3)) s.seg_algo = SMILEHIP_SEG_EQX;
-        else return false;
+        else s.seg_algo = SMILEHIP_SEG_DELTA;
         if (opt_int(f, "growDynSegBuffer") || opt_int(f, "useOldBuggyChX")) return false;
         s.seg_max_num = opt_int(f, "maxNumSeg");
         s.seg_min_lng = opt_int(f, "segMinLng");
@@ -153,13 +163,19 @@ class cHipFunctionals : public cFunctionals {
         if (s.seg_pause_min_lng < 1) s.seg_pause_min_lng = 1;
         s.seg_x = (float)opt_dbl(f, "X");
         s.seg_x_is_rel = opt_int(f, "XisRel");
-        if (s.seg_algo == SMILEHIP_SEG_RELTH) {
+        s.seg_range_rel_threshold = (float)opt_dbl(f, "rangeRelThreshold");
+        s.seg_ravg_lng = opt_int(f, "ravgLng");
+        if ((s.seg_algo == SMILEHIP_SEG_DELTA || s.seg_algo == SMILEHIP_SEG_DELTA2) && s.seg_ravg_lng <= 0 && s.seg_max_num < 2)
+          return false;                                  // Nin / (maxNumSeg / 2): the reference divides by zero
+        if (s.seg_algo == SMILEHIP_SEG_RELTH || s.seg_algo == SMILEHIP_SEG_NARELTH || s.seg_algo == SMILEHIP_SEG_NAABSTH ||
+            s.seg_algo == SMILEHIP_SEG_MRELTH || s.seg_algo == SMILEHIP_SEG_NAMRELTH) {                           // :179-200
+          const bool clamp = s.seg_algo == SMILEHIP_SEG_RELTH || s.seg_algo == SMILEHIP_SEG_NARELTH;
           char *k = myvprint("%s.thresholds", f);
           s.seg_n_thresholds = getArraySize(k); free(k);
           if (s.seg_n_thresholds < 0 || s.seg_n_thresholds > 8) return false;
           for (int j = 0; j < s.seg_n_thresholds; ++j) {
             float v = (float)getDouble_f(myvprint("%s.thresholds[%i]", f, j));
-            s.seg_thresholds[j] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            s.seg_thresholds[j] = !clamp ? v : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
           }
         }
       } else if (!strcmp(f, "Lpc")) {

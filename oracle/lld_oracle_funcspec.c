@@ -512,33 +512,106 @@ static void seg_add(seg_acc *r, long i, long last)
   }
 }
 
-static int f_segments(const lldo_func_spec *s, const float *in, float min, float max, float *out, long Nin)
+static int f_segments(const lldo_func_spec *s, const float *in, float min, float max, float amean, float *out, long Nin)
 {
   seg_acc r = {0, 0, 0, 0, NULL, s->seg_max_num};
   r.lens = (long *)calloc((size_t)s->seg_max_num + 1, sizeof(long));
   const float range = max - min;
-  if (s->seg_algo == LLDO_SEG_RELTH) {
-    float th[8];
-    for (int j = 0; j < s->seg_n_thresholds; j++) th[j] = min + range * s->seg_thresholds[j];
-    long segMinLng = s->seg_min_lng;
-    if (s->seg_auto_min_lng) {
-      segMinLng = Nin / s->seg_max_num - 1;
-      if (segMinLng < 2) segMinLng = 2;
-    }
-    const long ravgLng = 3;
+  const int algo = s->seg_algo;
+  long segMinLng = s->seg_min_lng;
+  if (algo != LLDO_SEG_NONX && algo != LLDO_SEG_EQX && algo != LLDO_SEG_CHX && s->seg_auto_min_lng) {
+    segMinLng = Nin / s->seg_max_num - 1;                /* :232-235, :328-331, :388-391 */
+    if (segMinLng < 2) segMinLng = 2;
+  }
+  if (algo == LLDO_SEG_DELTA || algo == LLDO_SEG_DELTA2) {          /* process_SegDelta :227-264, process_SegDelta2 :266-307 */
+    const float segThresh = range * s->seg_range_rel_threshold;
+    const long ravgLng = (s->seg_ravg_lng > 0) ? s->seg_ravg_lng : Nin / (s->seg_max_num / 2);
     long lastSeg = -segMinLng / 2;
-    float ravg = 0.0f, raLast = 0.0f;
-    for (long i = 0; i < Nin; i++) {
+    const int d2 = algo == LLDO_SEG_DELTA2;
+    float ravg = d2 ? in[0] : 0.0f, raLast = 0.0f;
+    for (long i = d2 ? 1 : 0; i < Nin; i++) {
       ravg += in[i];
       if (i >= ravgLng) ravg -= in[i - ravgLng];
       const float cur = (float)((i + 1 < ravgLng) ? (i + 1) : ravgLng);
       const float ra = ravg / cur;
-      int cross = 0;
-      for (int j = 0; j < s->seg_n_thresholds; j++)
-        if ((ra > th[j] && raLast <= th[j]) || (ra < th[j] && raLast >= th[j])) cross = 1;
+      const int hit = d2 ? ((in[i - 1] - raLast <= segThresh) && (in[i] - ra > segThresh)) : (in[i] - ra > segThresh);
+      if (hit && (i - lastSeg > segMinLng)) { seg_add(&r, i, lastSeg); lastSeg = i; }
       raLast = ra;
-      if (cross && (i - lastSeg > segMinLng)) { seg_add(&r, i, lastSeg); lastSeg = i; }
     }
+  } else if (algo == LLDO_SEG_RELTH || algo == LLDO_SEG_MRELTH || algo == LLDO_SEG_ABSTH || algo == LLDO_SEG_NARELTH ||
+             algo == LLDO_SEG_NAMRELTH || algo == LLDO_SEG_NAABSTH) {
+    /* process_SegThresh :309-367 (three-frame running average) and process_SegThreshNoavg :369-413 (the contour itself).
+     * absTh never reads its thresholds (:179-180 leaves it out): no crossing, no segment. */
+    float th[8];
+    int nth = (algo == LLDO_SEG_ABSTH) ? 0 : s->seg_n_thresholds;
+    for (int j = 0; j < nth; j++) {
+      if (algo == LLDO_SEG_RELTH || algo == LLDO_SEG_NARELTH) th[j] = min + range * s->seg_thresholds[j];
+      else if (algo == LLDO_SEG_MRELTH || algo == LLDO_SEG_NAMRELTH) th[j] = amean * s->seg_thresholds[j];
+      else th[j] = s->seg_thresholds[j];
+    }
+    long lastSeg = -segMinLng / 2;
+    if (algo == LLDO_SEG_RELTH || algo == LLDO_SEG_MRELTH || algo == LLDO_SEG_ABSTH) {
+      const long ravgLng = 3;
+      float ravg = 0.0f, raLast = 0.0f;
+      for (long i = 0; i < Nin; i++) {
+        ravg += in[i];
+        if (i >= ravgLng) ravg -= in[i - ravgLng];
+        const float cur = (float)((i + 1 < ravgLng) ? (i + 1) : ravgLng);
+        const float ra = ravg / cur;
+        int cross = 0;
+        for (int j = 0; j < nth; j++)
+          if ((ra > th[j] && raLast <= th[j]) || (ra < th[j] && raLast >= th[j])) cross = 1;
+        raLast = ra;
+        if (cross && (i - lastSeg > segMinLng)) { seg_add(&r, i, lastSeg); lastSeg = i; }
+      }
+    } else {
+      for (long i = 1; i < Nin; i++) {
+        int cross = 0;
+        for (int j = 0; j < nth; j++)
+          if ((in[i] > th[j] && in[i - 1] <= th[j]) || (in[i] < th[j] && in[i - 1] >= th[j])) cross = 1;
+        if (cross && (i - lastSeg > segMinLng)) { seg_add(&r, i, lastSeg); lastSeg = i; }
+      }
+    }
+  } else if (algo == LLDO_SEG_CHX) {                     /* process_SegChX :560-653: segments and pauses alike */
+    const float X = s->seg_x_is_rel ? (min + range * s->seg_x) : s->seg_x;
+    long segStartIndex = 0, segEndIndex = 0;
+    int inSeg = 0, segStart = 0, segEnd = 0;
+    for (long i = 0; i < Nin; i++) {
+      if (in[i] != X) {
+        if (inSeg == 1) {
+          segEnd = 0;
+          segStart++;
+          if (segStart >= s->seg_min_lng) { inSeg = 2; seg_add(&r, segStartIndex - 1, segEndIndex); segStart = 0; }
+        } else if (inSeg == 0) {
+          segStart++;
+          segStartIndex = i;
+          inSeg = 1;
+        } else if (inSeg == 2) {
+          segEnd = 0;
+        } else if (inSeg == 3) {
+          segStart++;
+          if (segStart >= s->seg_min_lng) { inSeg = 2; segEnd = 0; segStart = 0; }
+        }
+      }
+      if (in[i] == X) {
+        if (inSeg == 3) {
+          segStart = 0;
+          segEnd++;
+          if (segEnd >= s->seg_min_lng) { inSeg = 0; seg_add(&r, segEndIndex - 1, segStartIndex); segEnd = 0; }
+        } else if (inSeg == 2) {
+          segEnd++;
+          segEndIndex = i;
+          inSeg = 3;
+        } else if (inSeg == 0) {
+          segStart = 0;
+        } else if (inSeg == 1) {
+          segEnd++;
+          if (segEnd >= s->seg_pause_min_lng) { inSeg = 0; segEnd = 0; segStart = 0; }
+        }
+      }
+    }
+    if (inSeg == 2) seg_add(&r, segEndIndex - 1, segStartIndex);
+    else if (inSeg == 0) seg_add(&r, segStartIndex - 1, segEndIndex);
   } else {                                               /* nonX; eqX (:728-799) is its mirror image */
     const float X = s->seg_x_is_rel ? (min + range * s->seg_x) : s->seg_x;
     const int eq = s->seg_algo == LLDO_SEG_EQX;
@@ -1169,7 +1242,7 @@ int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int
         case LLDO_FAM_REGRESSION: got = f_regression(s, col, min, max, meanf, o, NN); break;
         case LLDO_FAM_PERCENTILES: got = f_percentiles(s, sorted, o, NN); break;
         case LLDO_FAM_TIMES: got = f_times(s, col, min, max, o, NN); break;
-        case LLDO_FAM_SEGMENTS: got = f_segments(s, col, min, max, o, NN); break;
+        case LLDO_FAM_SEGMENTS: got = f_segments(s, col, min, max, mean, o, NN); break;
         case LLDO_FAM_LPC: got = f_lpc(s, col, o, NN); break;
         case LLDO_FAM_PEAKS2: got = f_peaks2(s, col, min, max, meanf, o, NN); break;
         case LLDO_FAM_ONSET: got = f_onset(s, col, o, NN); break;

@@ -11,7 +11,9 @@ enum {
   LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_CROSSINGS, LLDO_FAM_DCT, LLDO_FAM_SAMPLES, LLDO_FAM_COUNT
 };
 enum { LLDO_NORM_SEGMENT = 0, LLDO_NORM_SECOND = 1, LLDO_NORM_FRAME = 2 };   /* functionalComponent.hpp:27-33 */
-enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1, LLDO_SEG_EQX = 2 };
+/* functionalSegments.cpp:118-155; ltX / gtX / geqX / leqX are parsed there but fall to the switch's default (:872-874): delta */
+enum { LLDO_SEG_RELTH = 0, LLDO_SEG_NONX = 1, LLDO_SEG_EQX = 2, LLDO_SEG_MRELTH = 3, LLDO_SEG_ABSTH = 4, LLDO_SEG_NARELTH = 5,
+       LLDO_SEG_NAMRELTH = 6, LLDO_SEG_NAABSTH = 7, LLDO_SEG_DELTA = 8, LLDO_SEG_DELTA2 = 9, LLDO_SEG_CHX = 10 };
 
 typedef struct lldo_func_spec {
   int32_t n_fam;
@@ -37,8 +39,8 @@ typedef struct lldo_func_spec {
   uint32_t times_mask; int32_t times_norm, times_buggy_sec_norm, reserved2;
   /* Segments: numSegments meanSegLen maxSegLen minSegLen segLenStddev */
   uint32_t seg_mask; int32_t seg_norm, seg_algo, seg_max_num, seg_min_lng, seg_auto_min_lng, seg_pause_min_lng,
-      seg_x_is_rel, seg_n_thresholds, reserved3;
-  float seg_x; float seg_thresholds[8]; float reserved4;
+      seg_x_is_rel, seg_n_thresholds, seg_ravg_lng;        /* ravgLng (delta, delt2): <= 0 = Nin / (maxNumSeg / 2) */
+  float seg_x; float seg_thresholds[8]; float seg_range_rel_threshold;
   /* Lpc: lpGain, lpc[first..order) */
   int32_t lpc_gain, lpc_coeffs, lpc_first, lpc_order;
   /* Peaks2: the 32 values of functionalPeaks2.cpp:60-67 */

@@ -579,8 +579,8 @@ class FuncSpec(C.Structure):
         ("times_mask", C.c_uint32), ("times_norm", C.c_int32), ("times_buggy_sec_norm", C.c_int32), ("reserved2", C.c_int32),
         ("seg_mask", C.c_uint32), ("seg_norm", C.c_int32), ("seg_algo", C.c_int32), ("seg_max_num", C.c_int32),
         ("seg_min_lng", C.c_int32), ("seg_auto_min_lng", C.c_int32), ("seg_pause_min_lng", C.c_int32),
-        ("seg_x_is_rel", C.c_int32), ("seg_n_thresholds", C.c_int32), ("reserved3", C.c_int32),
-        ("seg_x", C.c_float), ("seg_thresholds", C.c_float * 8), ("reserved4", C.c_float),
+        ("seg_x_is_rel", C.c_int32), ("seg_n_thresholds", C.c_int32), ("seg_ravg_lng", C.c_int32),
+        ("seg_x", C.c_float), ("seg_thresholds", C.c_float * 8), ("seg_range_rel_threshold", C.c_float),
         ("lpc_gain", C.c_int32), ("lpc_coeffs", C.c_int32), ("lpc_first", C.c_int32), ("lpc_order", C.c_int32),
         ("pk_mask", C.c_uint32), ("pk_norm", C.c_int32), ("pk_ratio_limit", C.c_int32), ("pk_dyn_rel", C.c_int32),
         ("pk_use_abs", C.c_int32), ("reserved5", C.c_int32),

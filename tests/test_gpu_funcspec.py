@@ -169,6 +169,44 @@ def test_funcspec_segments_nonx_eqx_seconds(hip, oracle, algo):
     assert (ref[:, 0] > 0).all()
 
 
+SEG_ALGOS = dict(relTh=0, nonX=1, eqX=2, mrelTh=3, absTh=4, NArelTh=5, NAmrelTh=6, NAabsTh=7, delta=8, delt2=9, chX=10)
+
+
+@pytest.mark.parametrize("algo", sorted(SEG_ALGOS))
+def test_funcspec_every_segmentation_algorithm(hip, oracle, algo):
+    """Every segmentationAlgorithm of functionalSegments.cpp:118-155 (the oracle's restatement is pinned on the binary in
+    test_oracle_pin_is10.py::test_segments_every_algorithm_bit_exact): contours with plateaus at 0 and at their minimum, long and
+    short, automatic and explicit minimum lengths, all three time norms, more segments than maxNumSeg."""
+    capi, ctx = hip
+    rng = np.random.default_rng(SEG_ALGOS[algo] + 5)
+    for n_rows, norm, max_num, min_lng, ravg in ((600, 1, 100, None, 0), (77, 2, 4, 2, 3), (1500, 0, 20, None, 0), (9, 2, 20, 1, 0)):
+        s = capi.FuncSpec()
+        s.n_fam, s.period = 1, 0.01
+        s.fam[0] = 6
+        s.seg_mask, s.seg_norm, s.seg_algo, s.seg_max_num = 0x1f, norm, SEG_ALGOS[algo], max_num
+        s.seg_min_lng, s.seg_auto_min_lng = (3, 1) if min_lng is None else (min_lng, 0)
+        s.seg_pause_min_lng, s.seg_x, s.seg_x_is_rel = 2, 0.0, int(n_rows == 1500)
+        s.seg_n_thresholds = 3
+        th = (0.2, 0.5, 0.85) if algo in ("relTh", "NArelTh") else (0.6, 1.0, 1.7) if "mrel" in algo else (-0.4, 0.1, 0.9)
+        for j in range(3):
+            s.seg_thresholds[j] = th[j]
+        s.seg_ravg_lng, s.seg_range_rel_threshold = ravg, 0.15
+        x = np.cumsum(rng.standard_normal((n_rows, 8)), axis=0).astype(np.float32) * 0.3
+        x[:, 4:] = np.abs(x[:, 4:])
+        for c in range(8):
+            pos = 0
+            while pos < n_rows:
+                run = int(rng.integers(1, 30))
+                if rng.random() < 0.4:
+                    x[pos:pos + run, c] = 0.0 if c < 6 else x[:, c].min()
+                pos += run
+        dev = capi.funcspec_matrix_host(ctx, s, x)
+        ref = oracle.funcspec(x, as_oracle_spec(oracle, s))
+        assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32)), (algo, n_rows, dev[:2], ref[:2])
+        if algo != "absTh" and n_rows >= 77:
+            assert (ref[:, 0] > 0).any(), (algo, n_rows)
+
+
 def test_batch_funcspec_ragged_with_cut_and_extra_row(hip, oracle):
     """smilehip_batch_funcspec on a ragged batch: per-utterance rows = max(1, rows - cut) (+ one extra row), column
     sub-ranges, utterances without rows."""
@@ -208,7 +246,7 @@ def test_funcspec_rejects_unusable_specs(hip):
     with pytest.raises(capi.SmileHipError, match="Lpc.order"):
         capi.funcspec_count(s)
     s = capi.funcspec_compare16("A")
-    s.seg_algo = 7
+    s.seg_algo = 11
     with pytest.raises(capi.SmileHipError, match="segmentationAlgorithm"):
         capi.funcspec_count(s)
     s = capi.funcspec_compare16("Nz")

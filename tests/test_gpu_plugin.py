@@ -626,18 +626,81 @@ def test_plugin_other_interspeech_sets(oracle, conf, n_lld, n_func):
     assert not d.any(), f"functionals: {d.sum()} of {d.size} differ at {np.argwhere(d)[:10, 1]}: {y_f[d][:5]} vs {ref_f[d][:5]}"
 
 
+def _run_taps(oracle, pcm, env_extra, conf, expect_fail=None):
+    """a run of a tests/conf file whose only outputs are its HTK taps (-T): {tap name: file bytes}, the plugin's frame counters"""
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built (needs /root/reference at build time)")
+    with tempfile.TemporaryDirectory() as td:
+        wav, trace = os.path.join(td, "in.wav"), os.path.join(td, "trace.txt")
+        oracle.write_wav(wav, pcm, 16000)
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        env.update(env_extra or {})
+        r = subprocess.run([exe, "-C", conf, "-I", wav, "-T", td, "-l", "1"], cwd=PLUGDIR, env=env, capture_output=True, text=True,
+                           errors="replace", timeout=300)
+        if expect_fail is not None:
+            assert r.returncode != 0 and expect_fail in r.stderr + r.stdout, (r.returncode, r.stderr[-2000:])
+            return None, None
+        assert r.returncode == 0, r.stderr[-2000:]
+        taps = {n[4:-4]: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td)) if n.startswith("tap_")}
+        tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip()) if os.path.exists(trace) else {}
+    return taps, {k: int(v) for k, v in tr.items()}
+
+
+def _segments_pcm():
+    from opensmile_amd import synth
+    pcm = synth.utterance(9, 48000).copy()
+    for a, b in ((8000, 12000), (23700, 24200), (30000, 36000)):
+        pcm[a:b] = 0                                     # RMS energy exactly 0, log energy at its floor: plateaus for chX
+    return pcm
+
+
+def test_plugin_segments_every_algorithm(oracle):
+    """tests/conf/segments_family.conf: fifteen cFunctionals instances, one per segmentationAlgorithm / option variant of
+    cFunctionalSegments (delta, delt2, (m)(NA)relTh, (NA)absTh, chX, the names that fall back to delta), behind the plugin: every tap
+    the plain binary's bytes, nothing on the CPU."""
+    conf = os.path.join(ROOT, "tests", "conf", "segments_family.conf")
+    pcm = _segments_pcm()
+    ref, tr0 = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+    own, tr = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, conf)
+    assert not any(tr0.values()) and len(ref) == 16 and sorted(own) == sorted(ref)
+    assert tr.get("cFunctionals", 0) >= 15 and not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    for k in ref:
+        assert len(ref[k]) > 12 and own[k] == ref[k], k
+
+
 def test_plugin_refuses_what_is_not_built(oracle):
-    """avec2011.conf's cFunctionals instances use families / options that are not operators of the library: the override says so and
-    the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 those instances run the reference's own code, counted,
-    and the file equals the plain binary's."""
+    """A cFunctionals instance with an option that is not an operator of the library (Segments.growDynSegBuffer: the segment buffer
+    that grows past maxNumSeg): the override says so and the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 that
+    instance runs the reference's own code, counted, and the taps equal the plain binary's."""
+    pcm = _segments_pcm()
+    with tempfile.TemporaryDirectory() as td:
+        conf = os.path.join(td, "grow.conf")
+        text = open(os.path.join(ROOT, "tests", "conf", "segments_family.conf")).read()
+        key = "Segments.segmentationAlgorithm = delta\n"
+        assert text.count(key) == 2
+        open(conf, "w").write(text.replace(key, key + "Segments.growDynSegBuffer = 1\n", 1))
+        _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, conf,
+                  expect_fail="cFunctionals: a functional family or option of this instance is not built")
+        ref, _ = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+        own, tr = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals", "SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf)
+        assert 0 < tr.get("cFunctionals.cpu", 0) <= 2 and tr.get("cFunctionals", 0) >= 14, tr
+        assert own == ref
+
+
+@pytest.mark.parametrize("conf", ["avec11-14/avec2011.conf", "avec11-14/avec2013.conf"])
+def test_plugin_avec_sets_whole(oracle, conf):
+    """avec2011.conf / avec2013.conf, unmodified, every override active: their functionals use Segments' NArelTh and chX algorithms
+    (functionalSegments.cpp:369-413, :560-653) next to nonX / eqX. Nothing on the CPU; the plain binary's file byte for byte."""
     from opensmile_amd import synth
     pcm = synth.utterance(71, 24000)
-    conf = "avec11-14/avec2011.conf"
-    with pytest.raises(AssertionError, match="cFunctionals: a functional family or option of this instance is not built"):
-        _run_bytes(oracle, pcm, None, conf, "-O")
     ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-O")
-    y, tr = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf, "-O")
-    assert tr.get("cFunctionals.cpu", 0) > 0 and tr.get("cSpectral", 0) > 0, tr
+    y, tr = _run_bytes(oracle, pcm, None, conf, "-O")
+    assert not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+    assert tr.get("cFunctionals", 0) > 0 and tr.get("cSpectral", 0) > 0, tr
     assert len(ref) > 100 and y == ref
 
 

@@ -180,6 +180,59 @@ def test_crossings_dct_samples_families_bit_exact(tmp_path):
             assert same(lldo.funcspec(x, s).reshape(1, -1), ref), (u, n, k)
 
 
+SEG_CASES = {   # instance of tests/conf/segments_family.conf -> (algorithm, norm, keyword options)
+    "delta": ("DELTA", "segment", {}), "deltar": ("DELTA", "frame", dict(ravg=5, rrt=0.1, min_lng=4)),
+    "delt2": ("DELTA2", "second", dict(max_num=50, rrt=0.15)), "rel3": ("RELTH", "frame", dict(th=(0.1, 0.5, 0.9), max_num=40)),
+    "mrel": ("MRELTH", "second", dict(th=(0.5, 1.5), max_num=60)), "abs": ("ABSTH", "frame", dict(th=(0.05,))),
+    "narel": ("NARELTH", "second", dict(th=(0.25,), max_num=100)),
+    "narel2": ("NARELTH", "segment", dict(th=(0.0, 0.4, 1.0), min_lng=1, max_num=8)),         # -0.5 and 1.7 clamped (:190-199)
+    "namrel": ("NAMRELTH", "frame", dict(th=(1.0,), max_num=30)), "namrel2": ("NAMRELTH", "segment", dict(th=(0.8, 1.2))),
+    "naabs": ("NAABSTH", "frame", dict(th=(0.01, 0.05, -3.0), max_num=100)), "chx": ("CHX", "frame", dict(max_num=100)),
+    "chx2": ("CHX", "second", dict(xrel=1, min_lng=2, pause=1, max_num=6)),
+    "ltx": ("DELTA", "frame", {}), "geqx": ("DELTA", "second", dict(max_num=10, rrt=0.05)),   # no code of their own: delta (:872-874)
+}
+SEG_ALGO = dict(RELTH=0, NONX=1, EQX=2, MRELTH=3, ABSTH=4, NARELTH=5, NAMRELTH=6, NAABSTH=7, DELTA=8, DELTA2=9, CHX=10)
+
+
+def segments_spec(algo, norm, th=(), max_num=20, min_lng=None, pause=2, x=0.0, xrel=0, ravg=0, rrt=0.2):
+    s = lldo.FuncSpec()
+    lldo._spec_common(s, ["Segments"])
+    s.period = 0.01
+    s.seg_mask, s.seg_norm, s.seg_algo, s.seg_max_num = 0x1f, lldo.NORM[norm], SEG_ALGO[algo], max_num
+    s.seg_min_lng, s.seg_auto_min_lng = (3, 1) if min_lng is None else (min_lng, 0)
+    s.seg_pause_min_lng, s.seg_x, s.seg_x_is_rel, s.seg_n_thresholds = pause, x, xrel, len(th)
+    for i, v in enumerate(th):
+        s.seg_thresholds[i] = v
+    s.seg_ravg_lng, s.seg_range_rel_threshold = ravg, rrt
+    return s
+
+
+def segments_pcm(u, n):
+    """An utterance with silent stretches: RMS energy exactly 0 and log energy at its floor there (chX needs equal values)."""
+    from opensmile_amd import synth
+    x = synth.utterance(u, n).copy()
+    for a, b in ((n // 6, n // 4), (n // 2 - 300, n // 2 + 200), (5 * n // 8, 3 * n // 4)):
+        x[a:b] = 0
+    return x
+
+
+def test_segments_every_algorithm_bit_exact(tmp_path):
+    """Every segmentationAlgorithm of cFunctionalSegments (functionalSegments.cpp:118-155: delta, delt2, (m)(NA)relTh, (NA)absTh,
+    chX, and the names that fall back to delta) against the binary, on RMS and log energy (tests/conf/segments_family.conf)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = os.path.join(root, "tests", "conf", "segments_family.conf")
+    found = 0
+    for u, n in ((9, 48000), (3, 16000), (6, 1200), (71, 100000)):
+        R = _run_taps(conf, segments_pcm(u, n), tmp_path, False)
+        x = R("energy")
+        for k, (algo, norm, kw) in SEG_CASES.items():
+            ref = R("s_" + k)
+            assert same(lldo.funcspec(x, segments_spec(algo, norm, **kw)).reshape(1, -1), ref), (u, n, k)
+            found += int(ref[0, 0] > 0)
+    assert found > 40
+
+
 def _run_taps(conf, pcm, tmp_path, cwd_taps):
     import os
     import subprocess
