@@ -130,14 +130,21 @@ __device__ __forceinline__ double quad_vertex(double x1, double y1, double x2, d
 // the same one-in-2^28 near-ties. Zero, negative, subnormal, infinite and NaN arguments go to the library function.
 #include "log_table.inc"
 __device__ const double2 kLogTab[128] = {SMILEHIP_LOG_TABLE};
-__device__ __forceinline__ double log_d(double x) {
+// kNormalOrInf: the caller guarantees a positive normal number or +inf (e.g. 1 + a power); tab: the table (kLogTab, or a copy of it
+// in LDS -- the table lookup is the one memory access of a logarithm, 257 of them per IS09 frame)
+template <bool kNormalOrInf = false>
+__device__ __forceinline__ double log_d(double x, const double2 *tab = kLogTab) {
   const unsigned long long ix = (unsigned long long)__double_as_longlong(x);
-  if (!(ix - 0x0010000000000000ull < 0x7fe0000000000000ull)) return log(x);
+  if constexpr (kNormalOrInf) {
+    if (ix == 0x7ff0000000000000ull) return x;           // log(+inf) = +inf
+  } else {
+    if (!(ix - 0x0010000000000000ull < 0x7fe0000000000000ull)) return log(x);
+  }
   const unsigned long long tmp = ix - 0x3fe6000000000000ull;
   const int i = (int)((tmp >> 45) & 127);
   const long long k = (long long)tmp >> 52;
   const double z = __longlong_as_double((long long)(ix - (tmp & (0xfffull << 52))));
-  const double2 t = kLogTab[i];
+  const double2 t = tab[i];
   const double kd = (double)k;
   const double r = fma(z, t.x, -1.0);
   const double w = kd * SMILEHIP_LN2HI + t.y;           // the product is exact (42-bit constant, |k| < 2^11)

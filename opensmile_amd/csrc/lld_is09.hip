@@ -58,6 +58,7 @@ struct Is09Tbl {
   const int32_t *mel_rng;
   const float *dct_rows;
   OouraTab oo;
+  const double2 *log_tab;                                  // kLogTab's copy in LDS (the quad form), else null
 };
 
 // LDS, workgroup form: xr[N] | yv[N] | re[M] | im[M] | mg[K+3] | sp[K+3] | acf[M] | cep[M] | lmel[32] | scr (4 doubles)
@@ -249,37 +250,63 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
 // lags has a compile-time trip count (16 or 17 per lane; 32 predicated rounds over the frame's samples), so that a phase's
 // LDS reads are in flight together. Same operations on the same operands as the wave form: bit-identical outputs
 // (tests/test_gpu_is09.py::test_is09_quad_form_equals_wave_form_bit_for_bit).
-// LDS per frame: zx[2 x 272] the raw frame, then the transform's transposition / its 256 result pairs | mg[260] the windowed
-// frame (with sp), magnitudes, log spectrum, cepstrum | sp[260] mel input, ACF | lmel[32]: 4.4 KB; workgroups of four waves
-// (16 frames + 8 KB of tables = 78 KB), two per CU, persistent.
+// LDS per frame: zx[2 x 272] only -- the raw frame, then the windowed frame, the transform's transposition / its 256 result
+// pairs, the mel input (power spectrum) and the log mel bands, the transposition buffers of the two inverse transforms. The
+// magnitudes, the ACF and the cepstrum stay in registers (17 + 16 + 16 per lane): the inverse transforms take their real input
+// from the registers (lld_ooura_quad.hpp: oo_quad_inverse_real), the pitch phase reads its neighbours with row rotations.
+// 2.2 KB per frame; workgroups of four waves (16 frames + 8 KB of tables = 43 KB), three per CU = three waves per SIMD, persistent.
+#ifndef SMILEHIP_IS09_QUAD_WAVES
+#define SMILEHIP_IS09_QUAD_WAVES 3                         // waves per SIMD the register budget is set for (experiments: 2)
+#endif
+#ifndef SMILEHIP_IS09_PREFETCH_EARLY
+#define SMILEHIP_IS09_PREFETCH_EARLY 0
+#endif
+#ifndef SMILEHIP_IS09_LOG_GROUP
+#define SMILEHIP_IS09_LOG_GROUP 3
+#endif
 namespace {
 constexpr int kQuadWaves = 4;
 constexpr int kQuadKpad = 260;
-constexpr int kQuadFrameFloats = 2 * kQuadZPairs + 2 * kQuadKpad + 32;
+constexpr int kQuadFrameFloats = 2 * kQuadZPairs;
+constexpr int kQuadLmel = 272;                             // the log mel bands' place in the frame's buffer (behind the 257 mel inputs)
 // the tables the quad form reads: window | mel_coef | mel_rng | dct_rows (the reference-order transform's follow)
-__host__ __device__ inline int is09_quad_table_floats(int N) { return ((N + 3) & ~3) + kQuadKpad + 128 + 16 * 32; }
+// log table (128 double2, first: 16-byte aligned) | window | mel_coef | mel_rng | dct_rows
+__host__ __device__ inline int is09_quad_table_floats(int N) { return 512 + ((N + 3) & ~3) + kQuadKpad + 128 + 16 * 32; }
 
-// group_pitchacf_frame (lld_blocks.hpp) for a row of 16 lanes and n = 256 lags: the same selections, trip counts fixed
-__device__ __forceinline__ void quad_pitchacf_frame(const float *acf, const float *cep, double fsSec, double maxPitch, double &voicing,
-                                                    int &max_idx, double &Tsamp_out, int j) {
-  constexpr int n = 256;
-  const double Tsamp = fsSec / (double)(2 * n);
-  Tsamp_out = Tsamp;
-  const int preskip = (maxPitch <= 0.0) ? 0 : (int)(1.0 / (maxPitch * Tsamp));
-  float a[16], am[16], c[16];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) { const int i = j + 16 * it; a[it] = acf[i]; am[it] = i > 0 ? acf[i - 1] : 0.0f; c[it] = cep[i]; }
-  double vmax = acf[n - 1];
+__device__ __forceinline__ float quad_ror1(float x) { return __int_as_float(row_ror_i<1>(__float_as_int(x))); }     // lane j <- j - 1
+__device__ __forceinline__ float quad_rol1(float x) { return __int_as_float(row_ror_i<15>(__float_as_int(x))); }    // lane j <- j + 1
+__device__ __forceinline__ float quad_lane(float x, int lane64, int src) {                                           // lane `src` of the row
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * ((lane64 & 48) | src), __float_as_int(x)));
+}
+
+// group_pitchacf_frame (lld_blocks.hpp) for a row of 16 lanes and n = 256 lags held in registers, in two parts so that the ACF
+// is dead before the cepstrum's transform starts: a[it] = acf[j + 16 it], c[it] = cep[j + 16 it]. The same selections, trip
+// counts fixed.
+__device__ __forceinline__ int quad_pitch_preskip(double fsSec, double maxPitch) {
+  const double Tsamp = fsSec / (double)(2 * 256);
+  return (maxPitch <= 0.0) ? 0 : (int)(1.0 / (maxPitch * Tsamp));
+}
+__device__ __forceinline__ double quad_pitch_voicing(const float (&a)[16], int preskip, int lane64) {
+  const int j = lane64 & 15;
+  double vmax = quad_lane(a[15], lane64, 15);              // acf[n - 1]
+  float prev = 0.0f;                                       // lane 15's acf[16 (it - 1) + 15] as lane 0 sees it
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int i = j + 16 * it;
-    if (i >= 1 && i >= preskip && ((double)a[it] > vmax) && (am[it] < a[it])) vmax = a[it];
+    const float ra = quad_ror1(a[it]);
+    const float am = (j == 0) ? prev : ra;                 // acf[i - 1]
+    prev = ra;
+    if (i >= 1 && i >= preskip && ((double)a[it] > vmax) && (am < a[it])) vmax = a[it];
   }
   vmax = QuadG::max(vmax, nullptr);
-  const float a0 = acf[0];
-  voicing = (a0 > 0.0f) ? vmax / (double)a0 : 0.0;
+  const float a0 = quad_lane(a[0], lane64, 0);
+  return (a0 > 0.0f) ? vmax / (double)a0 : 0.0;
+}
+__device__ __forceinline__ int quad_pitch_cep_peak(const float (&c)[16], int preskip, int lane64) {
+  constexpr int n = 256;
+  const int j = lane64 & 15;
   const int skip = preskip + 1;
-  double csum = 0.0, cmax = cep[n - 1];
+  double csum = 0.0, cmax = quad_lane(c[15], lane64, 15);  // cep[n - 1]
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int i = j + 16 * it;
@@ -291,16 +318,21 @@ __device__ __forceinline__ void quad_pitchacf_frame(const float *acf, const floa
   cmax = QuadG::max(cmax, nullptr);
   const double thr = (cmax + csum) * 0.6;
   int first = 1 << 30;
+  float next = 0.0f;                                       // lane 0's cep[16 (it + 1)] as lane 15 sees it
 #pragma unroll
   for (int it = 15; it >= 0; --it) {                       // (descending: the lane's smallest qualifying index stays)
     const int i = j + 16 * it;
-    if (i >= skip + 1 && i < n - 1) {
-      const float cm = cep[i - 1], cp = cep[i + 1];
+    const float lc = quad_rol1(c[it]);
+    const float cp = (j == 15) ? next : lc;                // cep[i + 1]
+    next = lc;
+    const float rc = quad_ror1(c[it]);
+    const float rcp = (it > 0) ? quad_ror1(c[it > 0 ? it - 1 : 0]) : 0.0f;
+    const float cm = (j == 0) ? rcp : rc;                  // cep[i - 1]
+    if (i >= skip + 1 && i < n - 1)
       if ((double)c[it] > thr && (cm < c[it]) && (c[it] > cp)) first = i;
-    }
   }
   first = QuadG::min_i(first, nullptr);
-  max_idx = (first == (1 << 30)) ? 0 : first;
+  return (first == (1 << 30)) ? 0 : first;
 }
 
 // The samples of frame `row` that lane j of the frame's row of lanes keeps: x[j + 16 it], it < NIT (R0 done at the load)
@@ -324,13 +356,11 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane64 = tid & 63, j = tid & 15;
-  fmem += ((lane64 >> 4)) * kQuadFrameFloats;              // (fmem: the wave's four frame regions)
-  float *xr = fmem;
+  fmem += ((lane64 >> 4)) * kQuadFrameFloats;              // (fmem: the wave's four frame buffers)
+  float *xr = fmem;                                        // raw frame, then the windowed frame
   float2 *z = reinterpret_cast<float2 *>(fmem);
-  float *mg = fmem + 2 * kQuadZPairs;
-  float *sp = mg + kQuadKpad;
-  float *yv = mg;                                          // the windowed frame lives in mg | sp until the transform has read it
-  float *lmel = sp + kQuadKpad;
+  float *sp = fmem;                                        // mel input, once the spectrum has been read out of z
+  float *lmel = fmem + kQuadLmel;
   const int N = P.N;
   float *out = Q.raw16 + row * 16;
   IPHASE_DECL
@@ -351,7 +381,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     if (j == 0) out[13] = (float)total / (float)N;
   }
   IPHASE(1);   // ZCR
-  // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168)
+  // R2 + R3, then R12 cEnergy rms on the WINDOWED frame (energy.cpp:152-168): the lane's samples in R again, then in place
   double e2 = 0.0;
 #pragma unroll 8
   for (int it = 0; it < NIT; ++it) {
@@ -360,7 +390,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
       float y = xr[n];
       if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
       y = y * T.window[n] + P.win_offset;
-      yv[n] = y;
+      R[it] = y;
       const float sq = y * y;
       e2 += (double)sq;
     }
@@ -369,25 +399,27 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     const double d = QuadG::sum(e2, nullptr);
     if (j == 0) out[0] = (float)sqrt(d / (float)N) * 1.0f + 0.0f;
   }
+  QuadG::sync();                                           // (every lane has read its raw samples)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = R[it]; }
   QuadG::sync();
   IPHASE(2);   // pre-emphasis, window, RMS energy
-  // R4 forward real FFT in the reference's operation order, R5 magnitudes
+  // R4 forward real FFT in the reference's operation order (all of the frame is in registers before the transposition writes
+  // z = the same buffer), R5 magnitudes: mv[m] = |X[j + 16 m]|, kept in registers for the two inverse transforms
   oo_quad_forward(z, T.oo, lane64, [&](int i) {
     const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-    return make_float2((n0 >= 0 && n0 < N) ? yv[n0] : 0.0f, (n1 >= 0 && n1 < N) ? yv[n1] : 0.0f);
+    return make_float2((n0 >= 0 && n0 < N) ? xr[n0] : 0.0f, (n1 >= 0 && n1 < N) ? xr[n1] : 0.0f);
   });
-  {
-    float mv[17];
+  float mv[17];
 #pragma unroll
-    for (int m = 0; m < 17; ++m) {
-      const int k = j + 16 * m;
-      mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
-      if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);   // (six bins' loads in flight at a time: all 17 at once spill)
-    }
-    QuadG::sync();                                         // (the windowed frame is dead: z holds the spectrum)
-#pragma unroll
-    for (int m = 0; m < 17; ++m) { const int k = j + 16 * m; if (k <= M) { mg[k] = mv[m]; sp[k] = P.use_power ? mv[m] * mv[m] : mv[m]; } }
+  for (int m = 0; m < 17; ++m) {
+    const int k = j + 16 * m;
+    mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
+    if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);     // (six bins' loads in flight at a time: all 17 at once spill)
   }
+  QuadG::sync();                                           // (z has been read: the mel input takes its place)
+#pragma unroll
+  for (int m = 0; m < 17; ++m) { const int k = j + 16 * m; if (k <= M) sp[k] = P.use_power ? mv[m] * mv[m] : mv[m]; }
   QuadG::sync();
   IPHASE(3);   // forward transform + magnitudes
   // R6 / R7: mel (usePower per config) -> log -> DCT
@@ -400,29 +432,40 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   if (j < P.n_mfcc) out[1 + j] = dct_coeff(lmel, T.dct_rows + j * P.n_bands, P.n_bands, P.dct_gain[j]);
   QuadG::sync();
   IPHASE(4);   // mel, log, DCT
-  // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum (usePower = 1, :252-259) into sp ...
-  oo_quad_irfft_even(z, T.oo, sp, (float)P.K, true, lane64, [&](int e) {
-    if (e == 0) { const float m0 = mg[0], m1 = mg[M]; return make_float2(m0 * m0, m1 * m1); }
-    const float m = mg[e];
-    return make_float2(m * m, 0.0f);
-  });
-  // ... then the cepstrum instance: log(P + 1) (:288-305) in place of the magnitudes, its lags in their place again
+  // R9 cAcf (acf.cpp:249-349): ACF of the power spectrum (usePower = 1, :252-259), and what cPitchACF::processVector
+  // (pitchACF.cpp:137-192) takes from it ...
+  const int preskip = quad_pitch_preskip(Q.fsSec, Q.maxPitch);
+  const double Tsamp = Q.fsSec / (double)(2 * M);
+  double voicing;
+  {
+    float pw[17], acf[16];
 #pragma unroll
-  for (int m = 0; m < 17; ++m) {
-    const int k = j + 16 * m;
-    if (k <= M) {
-      const float p = mg[k] * mg[k];
-      mg[k] = (p > 0.0f) ? (float)log_d((double)p + 1.0) : 0.0f;
-    }
+    for (int m = 0; m < 17; ++m) pw[m] = mv[m] * mv[m];
+    oo_quad_irfft_even_real(z, T.oo, acf, (float)P.K, true, lane64, pw);
+    voicing = quad_pitch_voicing(acf, preskip, lane64);
   }
-  QuadG::sync();
-  oo_quad_irfft_even(z, T.oo, mg, (float)P.K, false, lane64, [&](int e) { return e == 0 ? make_float2(mg[0], mg[M]) : make_float2(mg[e], 0.0f); });
-  IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
-  if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);
-  // R10 cPitchACF::processVector, per-frame part (pitchACF.cpp:137-192)
-  double voicing, Tsamp;
+  __builtin_amdgcn_sched_barrier(0);
+#if SMILEHIP_IS09_PREFETCH_EARLY
+  if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);   // (the next pass's samples: their latency is the logarithms' and the second transform's)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  // ... then the cepstrum instance: log(P + 1) (:288-305)
   int max_idx;
-  quad_pitchacf_frame(sp, mg, Q.fsSec, Q.maxPitch, voicing, max_idx, Tsamp, j);
+  {
+    float pw[17], cep[16];
+#pragma unroll
+    for (int m = 0; m < 17; ++m) {
+      const float p = mv[m] * mv[m];
+      pw[m] = (p > 0.0f) ? (float)log_d<true>((double)p + 1.0, T.log_tab) : 0.0f;   // (1 + p >= 1: never the library's path)
+      if (m % SMILEHIP_IS09_LOG_GROUP == SMILEHIP_IS09_LOG_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // (a few logarithms' intermediates at a time: all 17 at once spill)
+    }
+    oo_quad_irfft_even_real(z, T.oo, cep, (float)P.K, false, lane64, pw);
+    IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
+#if !SMILEHIP_IS09_PREFETCH_EARLY
+    if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);
+#endif
+    max_idx = quad_pitch_cep_peak(cep, preskip, lane64);
+  }
   if (j == 0) {
     long maxIdx = max_idx;
     float pitch = 0.0f;
@@ -439,20 +482,22 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 
 // persistent workgroups; rows past the end of the batch repeat the last frame (same values to the same cells)
 template <int NIT>                                       // samples per lane: N <= 16 NIT
-__global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
+__global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(SMILEHIP_IS09_QUAD_WAVES, SMILEHIP_IS09_QUAD_WAVES))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Npad = (P.N + 3) & ~3;
-  float *s_win = smem;
+  double2 *s_log = reinterpret_cast<double2 *>(smem);
+  float *s_win = smem + 512;
   float *s_coef = s_win + Npad;
   int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + kQuadKpad);
   float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < 128; i += kQuadWaves * 64) s_log[i] = kLogTab[i];
   for (int i = threadIdx.x; i < P.N; i += kQuadWaves * 64) s_win[i] = P.window[i];
   for (int i = threadIdx.x; i < P.K; i += kQuadWaves * 64) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += kQuadWaves * 64) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += kQuadWaves * 64) s_dct[i] = P.dct_rows[i];
   const OouraTab s_oo = oo_stage_tables(P.oo, smem + is09_quad_table_floats(P.N), threadIdx.x, kQuadWaves * 64);
   __syncthreads();                                       // the only workgroup barrier
-  const Is09Tbl T = {s_win, nullptr, nullptr, s_coef, s_rng, s_dct, s_oo};
+  const Is09Tbl T = {s_win, nullptr, nullptr, s_coef, s_rng, s_dct, s_oo, s_log};
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = (threadIdx.x & 63) >> 4;
   float *fmem = smem + is09_quad_table_floats(P.N) + oo_table_floats(P.oo) + (wave * 4) * kQuadFrameFloats;

@@ -22,6 +22,11 @@
 
 #include "lld_ooura_wave.hpp"
 
+// OO_QUAD_BF_FENCE: a scheduling fence behind every butterfly (two butterflies' operands and twiddles in flight instead of four)
+#ifndef OO_QUAD_BF_FENCE
+#define OO_QUAD_BF_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace smilehip {
 
 constexpr int kQuadXRow = 17;                               // pairs per line of a row's 16 x 16 transposition: lane j reads line j --
@@ -37,10 +42,10 @@ __device__ __forceinline__ void oo_quad256(float2 (&v)[16], const OouraTab &T, f
   const int j = lane & 15;
   // L0, q = 64: node 0, butterfly s works on e = c + {0, 64, 128, 192}, c = 16 s + j -> registers s, s + 4, s + 8, s + 12
 #pragma unroll
-  for (int s = 0; s < 4; ++s) oo_level_bf<BWD>(v[s], v[4 + s], v[8 + s], v[12 + s], T, 0, 64, 0, 0u, 16 * s + j);
+  for (int s = 0; s < 4; ++s) { oo_level_bf<BWD>(v[s], v[4 + s], v[8 + s], v[12 + s], T, 0, 64, 0, 0u, 16 * s + j); OO_QUAD_BF_FENCE; }
   // L1, q = 16: node k = (e7 e6), c = j: e = 64 k + j + {0, 16, 32, 48} -> registers 4 k + {0, 1, 2, 3}
 #pragma unroll
-  for (int k = 0; k < 4; ++k) oo_level_bf<false>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], T, 1, 16, 64, (unsigned)k, j);
+  for (int k = 0; k < 4; ++k) { oo_level_bf<false>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], T, 1, 16, 64, (unsigned)k, j); OO_QUAD_BF_FENCE; }
   // 16 x 16 transposition inside the row: element (register r, lane j) -> (register j, lane r): e = 16 j + r
   {
     float2 *xw = zx + j;
@@ -54,21 +59,35 @@ __device__ __forceinline__ void oo_quad256(float2 (&v)[16], const OouraTab &T, f
   }
   // L2, q = 4: node j (e7 .. e4), butterfly c works on e = 16 j + c + {0, 4, 8, 12} -> registers c, c + 4, c + 8, c + 12
 #pragma unroll
-  for (int c = 0; c < 4; ++c) oo_level_bf<false>(v[c], v[4 + c], v[8 + c], v[12 + c], T, 2, 4, 112, (unsigned)j, c);
+  for (int c = 0; c < 4; ++c) { oo_level_bf<false>(v[c], v[4 + c], v[8 + c], v[12 + c], T, 2, 4, 112, (unsigned)j, c); OO_QUAD_BF_FENCE; }
   // L3, q = 1: node 4 j + m, e = 16 j + 4 m + {0, 1, 2, 3} -> registers 4 m + {0, 1, 2, 3}
 #pragma unroll
-  for (int m = 0; m < 4; ++m) oo_level_bf<false>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3], T, 3, 1, 0, (unsigned)(4 * j + m), 0);
+  for (int m = 0; m < 4; ++m) { oo_level_bf<false>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3], T, 3, 1, 0, (unsigned)(4 * j + m), 0); OO_QUAD_BF_FENCE; }
 }
 
 // v[r] (spectrum index 16 bitrev4(r) + bitrev4(j)) -> z[oo_pos(F)], z = the row's buffer. Ends with a wave sync.
 __device__ __forceinline__ void oo_quad_store(const float2 (&v)[16], float2 *z, int lane) {
   const int fj = oo_brev4(lane & 15);
+  // oo_pos(16 R + fj) = 16 R + (fj ^ (R & 3)): four lane-dependent addresses, the rest immediate offsets
+  float2 *zc[4] = {z + fj, z + (fj ^ 1), z + (fj ^ 2), z + (fj ^ 3)};
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     constexpr int kRev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-    z[oo_pos(16 * kRev[r] + fj)] = v[r];
+    zc[kRev[r] & 3][16 * kRev[r]] = v[r];
   }
   oo_wave_sync();
+}
+// output sample j + 16 it of the inverse transform (oo_wave_inverse_out<256>): pair 8 it + (j >> 1) at oo_pos = 8 it + ((j >> 1) ^ c),
+// c = (it >> 1) & 3 -- again four lane-dependent addresses
+__device__ __forceinline__ void oo_quad_inverse_outs(const float2 *z, int lane, float (&o)[16]) {
+  const int jh = (lane & 15) >> 1;
+  const bool odd = lane & 1;
+  const float2 *zc[4] = {z + jh, z + (jh ^ 1), z + (jh ^ 2), z + (jh ^ 3)};
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const float2 a = zc[(it >> 1) & 3][8 * it];
+    o[it] = odd ? -a.y : a.x;
+  }
 }
 
 // forward transform of 512 reals: load(i) = (x[2i], x[2i + 1]); afterwards oo_wave_bin<256>(z, T, k) is bin k
@@ -128,6 +147,60 @@ __device__ __forceinline__ void oo_quad_irfft_even(float2 *z, const OouraTab &T,
   for (int it = 0; it < 16; ++it) {
     const float v = o[it] / inv_norm;
     out[(lane & 15) + 16 * it] = take_abs ? fabsf(v) : v;
+  }
+  oo_wave_sync();
+}
+
+// ---- a REAL packed spectrum held in registers: P[m] = R[j + 16 m] (m <= 16; P[16] = R[256] counts in lane 0 only), the input
+// cAcf gives rdft(512, -1): a[0] = R[0], a[1] = R[M], a[2e] = R[e], a[2e + 1] = 0. The element e = 16 r + j of the array after
+// rdft :350-351 / rftbsub :3266-3288 needs R[e] (the lane's own register r) and R[M - e]: lane (16 - j) & 15's register 15 - r
+// (lane 0: its own register 16 - r) -- two DPP moves instead of a round trip through LDS.
+__device__ __forceinline__ float oo_quad_mirror1(float x) {       // lane j <- lane (16 - j) & 15 of its row
+  int v = __float_as_int(x);
+  v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror: lane j <- 15 - j
+  v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);   // row_ror:1:  lane j <- j - 1
+  return __int_as_float(v);
+}
+__device__ __forceinline__ void oo_quad_inverse_real(float2 *z, const OouraTab &T, int lane, const float (&P)[17]) {
+  constexpr int M = 256;
+  const int j = lane & 15;
+  float2 v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = 16 * r + j;
+    const float own = P[r];
+    const float t = oo_quad_mirror1(P[15 - r]);
+    const float mir = (j == 0) ? P[16 - r] : t;                  // R[M - e]
+    const bool lower = 2 * e < M;
+    const int jj = lower ? e : M - e;
+    const float2 aj = make_float2(lower ? own : mir, 0.0f), ak = make_float2(lower ? mir : own, 0.0f);
+    const float2 wk = T.rft[(2 * e == M) ? 0 : jj];
+    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+    const float yr = wk.x * xr + wk.y * xi, yi = wk.x * xi - wk.y * xr;
+    float2 res = lower ? make_float2(aj.x - yr, aj.y - yi) : make_float2(ak.x + yr, ak.y - yi);
+    if (r == 0) {                                                // e == 0 in lane 0
+      float2 a = make_float2(own, mir);
+      a.y = 0.5f * (a.x - a.y);
+      a.x -= a.y;
+      if (j == 0) res = a;
+    }
+    if (r == 8 && j == 0) res = make_float2(own, 0.0f);          // 2 e == M
+    v[r] = res;
+    if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);           // (four elements' loads in flight at a time)
+  }
+  oo_quad256<true>(v, T, z, lane);
+  oo_quad_store(v, z, lane);
+}
+// cAcf on that input: lags j + 16 it, it < 16, of the lane's row to out[it] (registers)
+__device__ __forceinline__ void oo_quad_irfft_even_real(float2 *z, const OouraTab &T, float (&out)[16], float inv_norm, bool take_abs,
+                                                        int lane, const float (&P)[17]) {
+  constexpr int M = 256;
+  oo_quad_inverse_real(z, T, lane, P);
+  oo_quad_inverse_outs(z, lane, out);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const float v = out[it] / inv_norm;
+    out[it] = take_abs ? fabsf(v) : v;
   }
   oo_wave_sync();
 }

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["SMILEHIP_LIB"] = os.path.join(ROOT, "tools", "ubench", "build", "libsmilehip_phaseis09.so")
+os.environ.setdefault("SMILEHIP_LIB", os.path.join(ROOT, "tools", "ubench", "build", "libsmilehip_phaseis09.so"))
 import torch  # noqa: E402
 from opensmile_amd import capi, synth  # noqa: E402
 
