@@ -340,9 +340,16 @@ template <int NIT>
 __device__ __forceinline__ void is09_quad_fetch(const LldParams &P, int64_t row, float (&R)[NIT], int j) {
   const int lo = P.frame_utt[row];
   const int64_t t = row - P.frame_off[lo];
-  const PcmIn x = pcm_in(P) + (P.samp_off[lo] + t * (int64_t)P.H);
+  const int64_t base = P.samp_off[lo] + t * (int64_t)P.H + j;
+  if (P.pcm_f32) {                                         // (uniform: one kind of load per instance of the loop)
+    const float *x = P.pcm_f32 + base;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; R[it] = (n < P.N) ? x[n] : 0.0f; }
+    for (int it = 0; it < NIT; ++it) R[it] = (j + 16 * it < P.N) ? x[16 * it] : 0.0f;
+  } else {
+    const int16_t *x = P.pcm + base;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) R[it] = (j + 16 * it < P.N) ? pcm16_to_float(x[16 * it]) : 0.0f;
+  }
 }
 
 // One pass: the four frames whose samples R holds. Before the last phase (which needs few registers) the samples of the

@@ -197,10 +197,32 @@ __device__ __forceinline__ void oo_quad_irfft_even_real(float2 *z, const OouraTa
   constexpr int M = 256;
   oo_quad_inverse_real(z, T, lane, P);
   oo_quad_inverse_outs(z, lane, out);
+  // RN(a / b) for the pass's one divisor: y = RN(1 / b) by the division itself, then Markstein's sequence (see f0_div_by in
+  // lld_f0.hip: q0 = RN(a y) within two ulps, one residual step makes it faithful, the second returns the correctly rounded
+  // quotient) -- five operations instead of the division's eleven, for operands well inside the normal range; zeros (whose
+  // sign the sequence would lose), tiny, huge and non-finite values take the division.
+  const float y = 1.0f / inv_norm;
+  bool plain = false;
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const float v = out[it] / inv_norm;
-    out[it] = take_abs ? fabsf(v) : v;
+  for (int it = 0; it < 16; ++it) { const float m = fabsf(out[it]); plain |= !(m > 0x1p-60f && m < 0x1p60f); }
+  const bool norm_ok = inv_norm > 0x1p-30f && inv_norm < 0x1p30f;
+  if (!norm_ok || __builtin_amdgcn_ballot_w64(plain) != 0) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) out[it] = out[it] / inv_norm;
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const float a = out[it];
+      const float q0 = a * y;
+      const float r0 = __builtin_fmaf(-q0, inv_norm, a);
+      const float q1 = __builtin_fmaf(r0, y, q0);
+      const float r1 = __builtin_fmaf(-q1, inv_norm, a);
+      out[it] = __builtin_fmaf(r1, y, q1);
+    }
+  }
+  if (take_abs) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) out[it] = fabsf(out[it]);
   }
   oo_wave_sync();
 }

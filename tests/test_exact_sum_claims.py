@@ -79,3 +79,17 @@ def test_the_condition_is_tight_enough_to_matter():
     assert not cand_condition(vals)
     vals = [np.float32(1.0)] * 512 + [np.float32(2.0 ** -18)]
     assert cand_condition(vals) and seq_sum(vals) == math.fsum(float(v) for v in vals)
+
+
+def test_float_division_by_a_known_divisor_in_five_operations(tmp_path):
+    """oo_quad_irfft_even_real divides the inverse transform's outputs by the frame's one divisor (cAcf: the number of bins) with
+    y = RN(1 / b) and two residual corrections instead of the division instruction sequence. Every dividend significand, three
+    binades, both signs, for the divisors the shipped geometries produce (129 .. 2049) and some hostile ones."""
+    import os
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "markstein_f32.c")
+    exe = str(tmp_path / "markstein_f32")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe, "257", "513", "129", "1025", "2049", "3", "1.9999999", "1.0000001", "16777215"], check=True,
+                         capture_output=True, text=True).stdout
+    assert int(out) == 0
