@@ -331,7 +331,11 @@ def main():
 
     if rank == 0:
         value = total_frames * args.steps / dt
-        alg_bytes = ALG_BYTES_PER_FRAME_MAIN * frames
+        # the frame kernel computes the two regression stages itself (smilehip_batch_delta_fused): its launch then reads the hop and
+        # writes all 39 columns -- 476 B per frame -- and the window-chain kernel is gone from the step
+        fused = bool(getattr(batch, "delta_fused", False)) and ms_delta < 0.2 * ms_main
+        alg_per_frame = ALG_BYTES_PER_FRAME_CHAIN if fused else ALG_BYTES_PER_FRAME_MAIN
+        alg_bytes = alg_per_frame * frames
         achieved = alg_bytes / (ms_main * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel cannot be counted inside this process: the figure is the one the
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command produced (tools/profile_run.sh), kept in profiles/
@@ -365,7 +369,7 @@ def main():
             # The roof that bounds this kernel is FP32 vector issue (+ the per-CU LDS pipe), not HBM -- arithmetic intensity
             # 41 FLOP/B against a ridge of 20, and the counters agree (profiles/) -- so `bound`,
             # `achieved`, `peak`, `frac` are the FP32 figures and the HBM figures the north star asks for stand beside them.
-            "roofline": {"bound": "fp32_valu", "kernel": "fused MFCC (R0-R7)",
+            "roofline": {"bound": "fp32_valu", "kernel": "fused MFCC + delta regression (R0-R7, R13)" if fused else "fused MFCC (R0-R7)",
                          "achieved": ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3) / 1e12,
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ALG_FLOP_PER_FRAME * frames / (ms_main * 1e-3)) / (FP32_PEAK_TFLOPS * 1e12),
@@ -373,7 +377,8 @@ def main():
                          "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,      # from profiles/ (a separate --pmc pass), not this run
                          "bound_by_counters": "valu+lds",
-                         "alg_bytes_per_frame": ALG_BYTES_PER_FRAME_MAIN,
+                         "alg_bytes_per_frame": alg_per_frame,
+                         "alg_flop_note": "SURVEY 8d's count for R0-R7; the two regression stages add ~2e2 per frame, not counted",
                          "kernel_ms": ms_main, "delta_kernel_ms": ms_delta},
             "accuracy_gate": "per-frame-scaled error max_t max_i |d[t,i]| / max_i |ref[t,i]| <= 1e-5 against the reference binary "
                              "(tests/tolerance.py; measured 3e-7); frame count, index and time stamps compared with ==",

@@ -514,6 +514,11 @@ int64_t smilehip_batch_total_frames(const smilehip_batch *batch);
 /* rows of the output matrix (= frames for the MFCC chain; frames + 1 per non-empty
  * utterance for the IS09 chain, whose smoother emits one end-of-input frame) */
 int64_t smilehip_batch_total_rows(const smilehip_batch *batch);
+/* 1 if the batch of an MFCC / PLP chain (fast kernel, two regression stages of window 2, no log energy / mean subtraction)
+ * holds the tiles of the delta-fused frame kernel: smilehip_mfcc_run then computes cDeltaRegression's two stages
+ * (deltaRegression.cpp:144-152) inside the frame kernel whenever the PCM pointer is dword-aligned and every utterance starts
+ * at an even sample, and the window-chain kernel runs only for utterances of <= 16 frames. 0: the window chain runs. */
+int  smilehip_batch_delta_fused(const smilehip_batch *batch);
 /* h_row_offsets[n_utt+1]: row range of utterance u in the output matrix */
 int  smilehip_batch_frame_offsets(const smilehip_batch *batch, int64_t *h_row_offsets);
 

@@ -126,6 +126,7 @@ SYMBOLS = {
     "smilehip_batch_f0_taps": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "smilehip_config_plp_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_batch_total_rows": (_i64, [_vp]),
+    "smilehip_batch_delta_fused": (C.c_int, [_vp]),
     "smilehip_functionals_is09_mask": (C.c_uint32, []),
     "smilehip_functionals_count": (C.c_int, [C.c_uint32]),
     "smilehip_functionals_matrix": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_uint32, _vp, _vp]),
@@ -548,6 +549,7 @@ class Batch:
         _check(load().smilehip_batch_create(plan._h, off.ctypes.data, self.n_utt, C.byref(self._h)))
         self.total_frames = int(load().smilehip_batch_total_frames(self._h))
         self.total_rows = int(load().smilehip_batch_total_rows(self._h))
+        self.delta_fused = bool(load().smilehip_batch_delta_fused(self._h))
         fo = np.zeros(self.n_utt + 1, np.int64)
         _check(load().smilehip_batch_frame_offsets(self._h, fo.ctypes.data))
         self.frame_offsets = fo

@@ -25,7 +25,7 @@ int fast512_tile_frames();
 int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, const std::vector<float> &window,
                        const MelBank &mel, const DctTables &dct, Fast512Host &h);
 // aligned: PCM buffer 4-byte aligned and every utterance starts at an even sample
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s);
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, bool fused_delta, hipStream_t s);
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s);
 hipError_t launch_chain(const ChainParams &P, hipStream_t s);
 hipError_t launch_log_energy(const LldParams &P, const int32_t *d_tile_utt, const int32_t *d_tile_t0, int n_tiles, float *dst,

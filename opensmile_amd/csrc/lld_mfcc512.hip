@@ -49,6 +49,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "lld_device.hpp"
@@ -223,7 +224,13 @@ __device__ unsigned long long g_phase[16];
 //                   melw0 [UC*16 f4] | melw1 [UC*16 f4] | dct [16 x 28] | plp [48]
 //   per wave      : 4 x (log-mel [32] | acf [16] | cepstra [16]) | 4 x power buffer [448];
 //                   the (re,im) transpose buffer [2078] overlays all of it between the two DFT16
-template <int MP, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP, int UC>
+// DELTA: the two regression stages behind the static coefficients (cDeltaRegression, deltaRegression.cpp:144-152, deltawin = 2,
+// twice) computed by the same waves -- a lane keeps its coefficient of the previous pass's frame and the two passes' first-order
+// values in registers, takes its neighbours' through the LDS crossbar (ds_bpermute: no storage), and writes static | delta |
+// acceleration cells of the final rows. The expressions and the index clamps are lld_chain_tiled's (lld_kernels.hip: chain_op,
+// level 1 has T + 2 rows, all of which level 2 reads as data), so the values equal the separate kernel's bit for bit
+// (tests/test_gpu_mfcc.py::test_fused_delta_equals_window_chain). Tiles are FTileRec (lld_params.hpp).
+template <int MP, bool PREEMPH, bool USE_POWER, bool ALIGNED, bool PLP, int UC, bool DELTA = false>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams P, Fast512Tables F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -267,7 +274,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   bool unit_first[UC];
 #pragma unroll
   for (int i = 0; i < UC; ++i) unit_first[i] = ((lane_bands >> i) & 1u) != 0;
-  const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;    // my cell relative to the pass's first output row
+  // my cell relative to the pass's base row: the row of the pass's first frame -- DELTA: of the frame four before it, whose
+  // static | delta | acceleration cells a pass writes together (whole rows: 4 x 156 consecutive bytes per wave and pass.
+  // Writing each value as soon as it exists -- three stores into three different sets of rows -- cost 0.05 ms per 998 000 frames)
+  const uint32_t out_off = (uint32_t)(g * (int)P.ld_out + j) * 4u;
+  const uint32_t out_off_d = out_off + (uint32_t)P.n_mfcc * 4u;
+  const uint32_t out_off_dd = out_off + (uint32_t)P.n_mfcc * 8u;
   const float kpre = P.de ? -P.k : P.k;        // y = x - kpre * x'  (de: y = x + k x')
   const int m0 = P.pad_left >> 5, j0 = (P.pad_left >> 1) & 15;       // where sample 0 of a frame sits
   float *pb_k = s_pb + pb_pos(j);              // my bins k = j + 16 q sit 24 q floats further on
@@ -281,21 +293,33 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   // prefetched PCM, and everything older than those loads was issued a full pass earlier.
   const int tile_stride = __builtin_amdgcn_readfirstlane((int)gridDim.x) * kWavesPerBlock;   // (a vector load otherwise)
   int tile = blockIdx.x * kWavesPerBlock + wave;
-  if (tile >= P.n_tiles) return;                       // wave-uniform; no block barrier below
+  const int n_tiles = DELTA ? P.n_ftiles : P.n_tiles;
+  if (tile >= n_tiles) return;                         // wave-uniform; no block barrier below
   // records are read through the constant address space: read-only for the kernel's lifetime,
   // so wave-uniform addresses become s_load and the values (and every address derived from
   // them) stay in SGPRs
-  typedef const __attribute__((address_space(4))) TileRec *ConstRecPtr;
-  const ConstRecPtr recs = (ConstRecPtr)(uintptr_t)P.tile_rec;
+  typedef typename std::conditional<DELTA, FTileRec, TileRec>::type Rec;
+  typedef const __attribute__((address_space(4))) Rec *ConstRecPtr;
+  const ConstRecPtr recs = DELTA ? (ConstRecPtr)(uintptr_t)P.ftile_rec : (ConstRecPtr)(uintptr_t)P.tile_rec;
   int64_t cur_samp0 = recs[tile].samp0, cur_row0 = recs[tile].row0;
   int cur_n = recs[tile].n_frames;
-  bool has_next = tile + tile_stride < P.n_tiles;
+  // DELTA: frames behind the utterance's end | rows this tile writes | the utterance's first frame | regression stages on
+  int cur_live = 0, cur_e0 = 0, cur_e1 = 0, cur_lo = 0, cur_don = 0;
+  int nxt_live = 0, nxt_e0 = 0, nxt_e1 = 0, nxt_lo = 0, nxt_don = 0;
+  if constexpr (DELTA) {
+    cur_live = recs[tile].live_n; cur_e0 = recs[tile].e0; cur_e1 = recs[tile].e1; cur_lo = recs[tile].lo; cur_don = recs[tile].delta_on;
+  }
+  bool has_next = tile + tile_stride < n_tiles;
   int64_t nxt_samp0 = cur_samp0, nxt_row0 = cur_row0;
   int nxt_n = cur_n;
   if (has_next) {
     nxt_samp0 = recs[tile + tile_stride].samp0;
     nxt_row0 = recs[tile + tile_stride].row0;
     nxt_n = recs[tile + tile_stride].n_frames;
+    if constexpr (DELTA) {
+      nxt_live = recs[tile + tile_stride].live_n; nxt_e0 = recs[tile + tile_stride].e0; nxt_e1 = recs[tile + tile_stride].e1;
+      nxt_lo = recs[tile + tile_stride].lo; nxt_don = recs[tile + tile_stride].delta_on;
+    }
   }
   int tp = 0;                                          // first frame of the pass, relative to the tile
   FrameRegs<MP, ALIGNED> R;
@@ -303,16 +327,80 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   unsigned char *pend_row = nullptr;                   // deferred store of the previous pass (wave-uniform row base)
   float pend_val = 0.0f;
   bool pend_live = false;
+  // DELTA: the previous pass's coefficient (frame tp - 4 + g), this and the previous pass's first-order values (frames
+  // tp - 2 + g, tp - 6 + g); the deferred delta / acceleration cells
+  float s_prev = 0.0f, d_cur = 0.0f;
+  // ... and what the regression stage of the pass that has just ended works on: that pass's tile constants
+  int b_tp = 0, b_lo = 0, b_live = 0, b_e0 = 0, b_e1 = 0, b_don = 0;
+  // The regression stages of one pass: s_cur = the pass's coefficients (frame btp + g), s_prev the previous pass's, dp the previous
+  // pass's first-order values (frame btp - 6 + g). Level 0 is held for the relative frames btp - 4 .. btp + 3 (s_prev of group
+  // f & 3 for f < btp, s_cur behind it), level 1 for btp - 6 .. btp + 1 (dp / dn of group (f - (btp - 2)) & 3). An index is clamped
+  // to its level's rows first: [lo, live_n - 1] for level 0, [lo, live_n + 1] for level 1 (T + deltawin rows, all of them data
+  // for level 2). The expressions are chain_op's (lld_kernels.hip).
+  const auto from_group = [&](int grp, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * ((grp << 4) | j), __float_as_int(v)));
+  };
+  const auto regress = [](float vm2, float vm1, float vp1, float vp2) {
+    float num = 0.0f;
+    num += 1.0f * (vp1 - vm1);
+    num += 2.0f * (vp2 - vm2);
+    return num;
+  };
+  // straight-line form for a pass none of whose indices is clamped: own registers and the two neighbour groups; the quotient by
+  // Markstein's sequence (see lld_ooura_quad.hpp; tests/helpers/markstein_f32.c checks the divisor 10). `plain`: a numerator
+  // outside the range the sequence is safe for (zero keeps its sign only under the division) -> the pass takes delta_exact.
+  const auto div10 = [](float a, bool &plain) {
+    const float y = 0.1f, b = 10.0f;              // y = RN(1 / 10); norm = 2 (1 + 4), deltaRegression.cpp:77-79
+    const float m = fabsf(a);
+    plain |= !(m > 0x1p-60f && m < 0x1p60f);
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-q0, b, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-q1, b, a);
+    return __builtin_fmaf(r1, y, q1);
+  };
+  const auto delta_fast = [&](float s_cur, float dp, float &dn, float &ddn, float &drow, bool &plain) {
+    const float s1 = from_group((g + 1) & 3, g == 0 ? s_cur : s_prev);     // (the SOURCE lane chooses: group 0 holds frame btp, the others btp - 3 ..)
+    const float s3 = from_group((g + 3) & 3, g == 3 ? s_prev : s_cur);
+    dn = div10(regress(s_prev, s1, s3, s_cur), plain);                     // frame btp - 2 + g
+    const float d1 = from_group((g + 1) & 3, g == 0 ? dn : dp);
+    const float d3 = from_group((g + 3) & 3, g == 3 ? dp : dn);
+    ddn = div10(regress(dp, d1, d3, dn), plain);                           // frame btp - 4 + g
+    drow = from_group((g + 2) & 3, g >= 2 ? dp : dn);                      // the first-order value of frame btp - 4 + g
+  };
+  // any pass: clamped indices, the division itself
+  const auto delta_exact = [&](float s_cur, float dp, int btp, int lo, int live_n, float &dn, float &ddn, float &drow) {
+    const auto fetch = [&](int x, int hi_c, int base, float cur, float prev) {   // index x of a level held from `base - 4` on
+      x = x < lo ? lo : (x > hi_c ? hi_c : x);
+      const int dd = x - base;                                                   // -4 .. 3
+      const float c = from_group(dd & 3, cur), p = from_group(dd & 3, prev);
+      return dd >= 0 ? c : p;
+    };
+    const float norm = 10.0f;
+    const int fd = btp - 2 + g, fdd = btp - 4 + g, hi0 = live_n - 1, hi1 = live_n + 1;
+    dn = regress(fetch(fd - 2, hi0, btp, s_cur, s_prev), fetch(fd - 1, hi0, btp, s_cur, s_prev), fetch(fd + 1, hi0, btp, s_cur, s_prev),
+                 fetch(fd + 2, hi0, btp, s_cur, s_prev)) / norm;
+    ddn = regress(fetch(fdd - 2, hi1, btp - 2, dn, dp), fetch(fdd - 1, hi1, btp - 2, dn, dp), fetch(fdd + 1, hi1, btp - 2, dn, dp),
+                  fetch(fdd + 2, hi1, btp - 2, dn, dp)) / norm;
+    drow = from_group((g + 2) & 3, g >= 2 ? dp : dn);
+  };
 
   for (;;) {
-    const bool live = tp + g < cur_n;
+    const bool live = tp + g < (DELTA ? cur_live : cur_n);
     PHASE(0);                                   // loop overhead
     // ------------------------------------------------------------ frame from registers: R0 (scale folded), R2, R3
-    if (pend_row != nullptr && pend_live) {       // previous pass's coefficients
-      uint32_t oo = out_off;
-      asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
-      *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+    if constexpr (!DELTA) {
+      if (pend_row != nullptr && pend_live) {     // previous pass's coefficients
+        uint32_t oo = out_off;
+        asm volatile("" : "+v"(oo));             // keep the 32-bit offset, not a hoisted 64-bit pointer
+        *reinterpret_cast<float *>(pend_row + oo) = pend_val;
+      }
     }
+    // DELTA: the regression stages of the pass that has just ended, in the same basic block as the window arithmetic below (their
+    // five crossbar round trips hide behind it); a pass with a clamped index or an unsafe numerator is redone behind it
+    float st_dn = 0.0f, st_ddn = 0.0f, st_drow = 0.0f;
+    bool st_plain = false;
+    if constexpr (DELTA) delta_fast(pend_val, d_cur, st_dn, st_ddn, st_drow, st_plain);
     float re[16], im[16];
     {
       float tprev = 0.0f;                        // odd sample of pair 15 + 16 (m-1), as lane j = 0 needs it
@@ -345,6 +433,31 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       }
     }
     PHASE(1);                                   // wait for the prefetch, pre-emphasis, window
+    if constexpr (DELTA) {
+      // (first pass of a wave: the tile constants are zero, nothing is written)
+      const bool clamped = !(b_tp - 6 >= b_lo && b_tp + 3 <= b_live - 1);
+      if (clamped || __builtin_amdgcn_ballot_w64(st_plain && j < P.n_mfcc) != 0) delta_exact(pend_val, d_cur, b_tp, b_lo, b_live, st_dn, st_ddn, st_drow);
+      // The row of frame b_tp - 4 + g, complete (static | delta | acceleration: 4 x 156 consecutive bytes per wave and pass). The
+      // stores stand BEHIND the consumption of the prefetched samples: in front of it the compiler waited for them too
+      // (s_waitcnt vmcnt(0) -- the path on which no store was issued decides the count): a store round trip per pass.
+      const int fdd = b_tp - 4 + g;
+      const bool row_live = pend_row != nullptr && j < P.n_mfcc && fdd >= b_e0 && fdd < b_e1;
+      if (row_live) {
+        uint32_t oo = out_off;
+        asm volatile("" : "+v"(oo));               // keep the 32-bit offset, not a hoisted 64-bit pointer
+        *reinterpret_cast<float *>(pend_row + oo) = s_prev;
+      }
+      if (row_live && b_don) {
+        uint32_t oo = out_off_d;
+        asm volatile("" : "+v"(oo));
+        *reinterpret_cast<float *>(pend_row + oo) = st_drow;
+        oo = out_off_dd;
+        asm volatile("" : "+v"(oo));
+        *reinterpret_cast<float *>(pend_row + oo) = st_ddn;
+      }
+      s_prev = pend_val;
+      d_cur = st_dn;
+    }
 
     // ------------------------------------------------------------ 256-point complex FFT
     dft16(re, im);                                           // over m  -> index k1
@@ -496,23 +609,40 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       pend_val = acc * dgain;
     }
     pend_live = live && j < P.n_mfcc;
-    pend_row = reinterpret_cast<unsigned char *>(P.out + (cur_row0 + tp) * P.ld_out);   // wave-uniform
+    pend_row = reinterpret_cast<unsigned char *>(P.out + (cur_row0 + tp - (DELTA ? 4 : 0)) * P.ld_out);   // wave-uniform
+    if constexpr (DELTA) { b_tp = tp; b_lo = cur_lo; b_live = cur_live; b_e0 = cur_e0; b_e1 = cur_e1; b_don = cur_don; }
     wave_lds_fence();   // band vector and power buffer are overwritten by the next pass's transpose
     PHASE(10);                                  // DCT
     if (!more) break;
     if (advance) {
       tile += tile_stride;
       cur_samp0 = nxt_samp0; cur_row0 = nxt_row0; cur_n = nxt_n;
-      has_next = tile + tile_stride < P.n_tiles;
+      if constexpr (DELTA) { cur_live = nxt_live; cur_e0 = nxt_e0; cur_e1 = nxt_e1; cur_lo = nxt_lo; cur_don = nxt_don; }
+      has_next = tile + tile_stride < n_tiles;
       if (has_next) {
         nxt_samp0 = recs[tile + tile_stride].samp0;
         nxt_row0 = recs[tile + tile_stride].row0;
         nxt_n = recs[tile + tile_stride].n_frames;
+        if constexpr (DELTA) {
+          nxt_live = recs[tile + tile_stride].live_n; nxt_e0 = recs[tile + tile_stride].e0; nxt_e1 = recs[tile + tile_stride].e1;
+          nxt_lo = recs[tile + tile_stride].lo; nxt_don = recs[tile + tile_stride].delta_on;
+        }
       }
     }
     tp = ntp;
   }
-  if (pend_live) {
+  if constexpr (DELTA) {                               // the last pass's rows
+    float dn, ddn, drow;
+    delta_exact(pend_val, d_cur, b_tp, b_lo, b_live, dn, ddn, drow);
+    const int fdd = b_tp - 4 + g;
+    if (j < P.n_mfcc && fdd >= b_e0 && fdd < b_e1) {
+      *reinterpret_cast<float *>(pend_row + out_off) = s_prev;
+      if (b_don) {
+        *reinterpret_cast<float *>(pend_row + out_off_d) = drow;
+        *reinterpret_cast<float *>(pend_row + out_off_dd) = ddn;
+      }
+    }
+  } else if (pend_live) {
     uint32_t oo = out_off;
     asm volatile("" : "+v"(oo));
     *reinterpret_cast<float *>(pend_row + oo) = pend_val;
@@ -706,37 +836,50 @@ int fast512_build_host(const smilehip_lld_config &cfg, const Geometry &geo, cons
   return 0;
 }
 
-hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, hipStream_t s) {
+hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast512Host &h, bool aligned, bool fused_delta, hipStream_t s) {
   const int shared_floats = 256 * 2 + h.mp * 16 * 2 + 256 * 2 + h.mel_units * 16 * 8 + 16 * 28 + 48;
   const size_t lds = sizeof(float) * (size_t(shared_floats) + size_t(kWavesPerBlock) * kWaveFloats);
-  unsigned grid = (unsigned)((P.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (fused_delta && (!aligned || !P.ftile_rec || P.n_ftiles <= 0)) return hipErrorInvalidValue;   // (the caller decides; see smilehip_mfcc_run)
+  unsigned grid = (unsigned)(((fused_delta ? P.n_ftiles : P.n_tiles) + kWavesPerBlock - 1) / kWavesPerBlock);
   if (grid > (unsigned)h.max_blocks) grid = (unsigned)h.max_blocks;   // persistent: 2 blocks of 8 waves per CU
 #ifdef SMILEHIP_DEBUG_KNOBS
   if (const char *e = getenv("SMILEHIP_DEBUG_GRID")) grid = (unsigned)atoi(e);
 #endif
   bool launched = false;
-#define SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, UCV)                                                               \
-  if (h.mp == MPV && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL && (P.plp != 0) == PL && \
-      h.mel_units == UCV) {                                                                                     \
-    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<MPV, PE, UP, AL, PL, UCV>);                    \
+#define SMILEHIP_LAUNCH(...)                                                                                    \
+  {                                                                                                             \
+    const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<__VA_ARGS__>);                                 \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((lld_mfcc512<MPV, PE, UP, AL, PL, UCV>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F); \
+    hipLaunchKernelGGL((lld_mfcc512<__VA_ARGS__>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F);        \
     launched = true;                                                                                            \
   }
+#define SMILEHIP_MATCH(MPV, PE, UP, AL, PL, UCV)                                                                \
+  (!launched && h.mp == MPV && (P.preemph != 0) == PE && (P.use_power != 0) == UP && aligned == AL && (P.plp != 0) == PL && h.mel_units == UCV)
+  // the delta-fused instances exist for dword-aligned input (every shipped geometry of the bench and the file front end)
+#define SMILEHIP_PICK_UD(MPV, PE, UP, PL, UCV) \
+  if (fused_delta && SMILEHIP_MATCH(MPV, PE, UP, true, PL, UCV)) SMILEHIP_LAUNCH(MPV, PE, UP, true, PL, UCV, true)
+#define SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, UCV) \
+  if (!fused_delta && SMILEHIP_MATCH(MPV, PE, UP, AL, PL, UCV)) SMILEHIP_LAUNCH(MPV, PE, UP, AL, PL, UCV)
 #define SMILEHIP_PICK(MPV, PE, UP, AL, PL) SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, 6) SMILEHIP_PICK_U(MPV, PE, UP, AL, PL, 8)
-#define SMILEHIP_PICK2(MPV, PE, UP) SMILEHIP_PICK(MPV, PE, UP, true, false) SMILEHIP_PICK(MPV, PE, UP, false, false)
+#define SMILEHIP_PICKD(MPV, PE, UP, PL) SMILEHIP_PICK_UD(MPV, PE, UP, PL, 6) SMILEHIP_PICK_UD(MPV, PE, UP, PL, 8)
+#define SMILEHIP_PICK2(MPV, PE, UP) SMILEHIP_PICK(MPV, PE, UP, true, false) SMILEHIP_PICK(MPV, PE, UP, false, false) SMILEHIP_PICKD(MPV, PE, UP, false)
 #define SMILEHIP_PICK4(MPV) SMILEHIP_PICK2(MPV, true, true) SMILEHIP_PICK2(MPV, true, false) \
                             SMILEHIP_PICK2(MPV, false, true) SMILEHIP_PICK2(MPV, false, false) \
                             /* the PLP chain works on the power spectrum (the plan checks use_power) */ \
                             SMILEHIP_PICK(MPV, true, true, true, true) SMILEHIP_PICK(MPV, true, true, false, true) \
-                            SMILEHIP_PICK(MPV, false, true, true, true) SMILEHIP_PICK(MPV, false, true, false, true)
+                            SMILEHIP_PICK(MPV, false, true, true, true) SMILEHIP_PICK(MPV, false, true, false, true) \
+                            SMILEHIP_PICKD(MPV, true, true, true) SMILEHIP_PICKD(MPV, false, true, true)
   SMILEHIP_PICK4(13)
   SMILEHIP_PICK4(16)
 #undef SMILEHIP_PICK4
 #undef SMILEHIP_PICK2
+#undef SMILEHIP_PICKD
 #undef SMILEHIP_PICK
 #undef SMILEHIP_PICK_U
+#undef SMILEHIP_PICK_UD
+#undef SMILEHIP_MATCH
+#undef SMILEHIP_LAUNCH
   if (!launched) return hipErrorInvalidConfiguration;     // no instantiation for this geometry: fail, never skip
   return hipGetLastError();
 }

@@ -21,6 +21,20 @@ struct TileRec {
   int32_t pad;
 };
 
+// A tile of the fast kernel's delta-fused form (lld_mfcc512<..., DELTA = true>): passes of four frames from frame p0 of its
+// utterance on. The tile's own frames are [t0, t1); p0 = t0 - 4 inside an utterance (one pass ahead: the regression of the tile's
+// first frames reaches four frames back), and one pass follows the tile's last frame (the regression of its last frames
+// reaches four frames ahead; at the utterance's end the same pass drains the two regression stages).
+struct FTileRec {
+  int64_t samp0;       // absolute index (in the packed PCM) of frame p0's first sample
+  int64_t row0;        // output row of frame p0
+  int32_t n_frames;    // 4 x passes
+  int32_t live_n;      // frames p0 + r with r >= live_n lie behind the utterance's last frame (T - p0)
+  int32_t e0, e1;      // the rows of frames p0 + r, e0 <= r < e1, are this tile's to write
+  int32_t lo;          // -p0: the utterance's first frame as a relative index (the lower index clamp)
+  int32_t delta_on;    // 0: static coefficients only (utterances of <= short_T frames: lld_chain_short finishes them)
+};
+
 struct LldParams {
   // batch
   const int16_t *pcm;          // packed utterances
@@ -34,6 +48,8 @@ struct LldParams {
   const TileRec *tile_rec;     // [n_tiles] the same tiles, resolved (fast kernel)
   int32_t n_utt;
   int32_t n_tiles;
+  const FTileRec *ftile_rec;   // [n_ftiles] tiles of the delta-fused fast kernel (null: not built for this batch)
+  int32_t n_ftiles;
   int64_t total_frames;
   float *out;                  // [total_frames x ld_out]
   int64_t ld_out;

@@ -148,8 +148,53 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return rc;
     }
   }
+  // The fast kernel with the two regression stages inside (lld_mfcc512<..., DELTA>): tiles as long as the batch allows -- a tile
+  // pays one pass of four frames before it (inside an utterance) and one behind it. L = the tile length whose estimate
+  // ceil(tiles / wave slots) x (L / 4 + 2) passes is smallest; an utterance is cut into equal parts of at most L frames
+  // (multiples of four: a frame's lane group is its index mod 4).
+  if (plan->use_fast && (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) &&
+      plan->cfg.n_delta == 2 && plan->cfg.delta_win == 2 && !plan->cfg.append_log_energy && !plan->cfg.cms && plan->ctx &&
+      b->total_frames > 0 && !getenv("SMILEHIP_NO_FUSED_DELTA")) {
+    const int64_t slots = std::max<int64_t>(1, plan->fast.max_blocks) * 8;
+    const auto parts_of = [&](int64_t T, int64_t L) { return (T + L - 1) / L; };
+    int64_t bestL = 32;
+    double best = 1e300;
+    for (int64_t L = 32; L <= 2048; L += 4) {
+      int64_t n = 0;
+      for (int32_t u = 0; u < n_utt; ++u) {
+        const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
+        if (T > 0) n += (T <= short_T) ? 1 : parts_of(T, L);
+      }
+      const double cost = double((n + slots - 1) / slots) * double(L / 4 + 2);
+      if (cost <= best) { best = cost; bestL = L; }
+    }
+    std::vector<FTileRec> ft;
+    for (int32_t u = 0; u < n_utt; ++u) {
+      const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
+      if (T <= 0) continue;
+      const int64_t parts = (T <= short_T) ? 1 : parts_of(T, bestL);
+      const int64_t len = (((T + parts - 1) / parts) + 3) & ~int64_t(3);
+      for (int64_t t0 = 0; t0 < T; t0 += len) {
+        const int64_t t1 = std::min<int64_t>(T, t0 + len), p0 = t0 > 0 ? t0 - 4 : 0;
+        FTileRec r;
+        r.samp0 = h_off[u] + p0 * plan->geo.H;
+        r.row0 = b->h_frame_off[u] + p0;
+        const int64_t last = (t1 + 3) & ~int64_t(3);      // first frame of the last pass: the one behind the tile's last frame (rows are written one pass late)
+        r.n_frames = (int32_t)(last - p0 + 4);
+        r.live_n = (int32_t)(T - p0);
+        r.e0 = (int32_t)(t0 - p0);
+        r.e1 = (int32_t)(t1 - p0);
+        r.lo = (int32_t)(-p0);
+        r.delta_on = T > short_T;
+        ft.push_back(r);
+      }
+    }
+    std::stable_sort(ft.begin(), ft.end(), [](const FTileRec &a, const FTileRec &c) { return a.n_frames > c.n_frames; });   // long tiles first
+    b->n_ftiles = (int32_t)ft.size();
+    if ((rc = b->d_ftile_rec.upload(ft))) { delete b; return rc; }
+  }
   if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
-      plan->ctx && b->total_frames > 0) {
+      plan->ctx && b->total_frames > 0 && b->n_ftiles == 0) {
     const size_t n = size_t(b->total_frames) * size_t(plan_n_static(plan));
     if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
       delete b;
@@ -218,6 +263,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
 extern "C" void smilehip_batch_destroy(smilehip_batch *b) { delete b; }
 extern "C" int64_t smilehip_batch_total_frames(const smilehip_batch *b) { return b ? b->total_frames : 0; }
 extern "C" int64_t smilehip_batch_total_rows(const smilehip_batch *b) { return b ? b->total_rows : 0; }
+extern "C" int smilehip_batch_delta_fused(const smilehip_batch *b) { return b && b->n_ftiles > 0 ? 1 : 0; }
 extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o) {
   if (!b || !o) return fail(SMILEHIP_ERR_INVALID, "smilehip_batch_frame_offsets: null argument");
   std::memcpy(o, b->h_row_off.data(), b->h_row_off.size() * sizeof(int64_t));
@@ -237,6 +283,8 @@ static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const i
   P.tile_utt = b->d_tile_utt.p;
   P.tile_t0 = b->d_tile_t0.p;
   P.tile_rec = b->d_tile_rec.p;
+  P.ftile_rec = b->d_ftile_rec.p;
+  P.n_ftiles = b->n_ftiles;
   P.n_utt = b->n_utt;
   P.n_tiles = b->n_tiles;
   P.total_frames = b->total_frames;
@@ -332,7 +380,9 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
   // With deltas to follow, the static block goes to a compact [frames x n_mfcc] scratch: the frame kernel
   // then writes whole lines, the window-chain kernel reads 1/3 of what it would read from 39-float rows,
   // and writes every output row in one piece (static | delta | accel).
-  const bool compact = plan->cfg.n_delta > 0 && b->d_static.p != nullptr;
+  const bool aligned_in = b->all_even && ((reinterpret_cast<uintptr_t>(d_pcm) & 3) == 0);
+  const bool fused_delta = plan->use_fast && !b->run_pcm_f32 && b->n_ftiles > 0 && aligned_in;   // the regression stages inside the frame kernel
+  const bool compact = !fused_delta && plan->cfg.n_delta > 0 && b->d_static.p != nullptr;
   if (compact) {
     P.out = b->d_static.p;
     P.ld_out = n_static;
@@ -357,8 +407,8 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     F.mel_scale = plan->fast.mel_scale;
     F.plp_eql = plan->d_plp_eql.p;
     F.plp_sin = plan->d_plp_sin.p;
-    const bool aligned = b->all_even && ((reinterpret_cast<uintptr_t>(d_pcm) & 3) == 0);
-    e = launch_mfcc512(P, F, plan->fast, aligned, s);
+    const bool aligned = aligned_in;
+    e = launch_mfcc512(P, F, plan->fast, aligned, fused_delta, s);
   } else {
     e = launch_mfcc_generic(P, s);
   }
@@ -368,7 +418,32 @@ extern "C" int smilehip_mfcc_run(smilehip_plan *plan, smilehip_batch *b, const i
     if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "log-energy kernel launch failed: %s", hipGetErrorString(e));
   }
   if (plan->timing) HIP_TRY(hipEventRecord(ev[1], s));
-  if (plan->cfg.n_delta > 0) {
+  if (fused_delta) {                                   // what is left: the tick-accurate path of the very short utterances, in place
+    if (!b->h_short.empty()) {
+      ChainParams Q;
+      std::memset(&Q, 0, sizeof(Q));
+      Q.frame_off = b->d_frame_off.p;
+      Q.row_off = b->d_row_off.p;
+      Q.n_tiles = 0;
+      Q.n_utt = b->n_utt;
+      Q.x = d_out;
+      Q.ld_x = ld_out;
+      Q.copy_col = -1;
+      Q.out = d_out;
+      Q.ld_out = ld_out;
+      Q.D = n_static;
+      Q.n_stages = 2;
+      Q.kind[0] = Q.kind[1] = 0;
+      Q.W[0] = Q.W[1] = plan->cfg.delta_win;
+      Q.out_col[0] = n_static;
+      Q.out_col[1] = 2 * n_static;
+      Q.short_T = chain_short_max();
+      Q.short_utts = b->d_short.p;
+      Q.n_short = (int32_t)b->h_short.size();
+      e = launch_chain(Q, s);
+      if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "window-chain kernel launch failed: %s", hipGetErrorString(e));
+    }
+  } else if (plan->cfg.n_delta > 0) {
     int rc = compact ? delta_chain_from(plan, b, b->d_static.p, n_static, 0, d_out, ld_out, n_static,
                                         plan->cfg.delta_win, plan->cfg.n_delta, stream)
                      : smilehip_delta_chain(plan, b, d_out, ld_out, n_static, plan->cfg.delta_win, plan->cfg.n_delta, stream);

@@ -197,6 +197,8 @@ struct smilehip_batch {
   DevBuf<int32_t> d_frame_utt;     // IS09 chain: utterance of every frame (the frame kernel has one frame per wave and would search frame_off for it)
   DevBuf<int32_t> d_tile_utt, d_tile_t0, d_short, d_dtile_utt, d_dtile_t0;
   DevBuf<TileRec> d_tile_rec;
+  DevBuf<FTileRec> d_ftile_rec;  // tiles of the delta-fused fast kernel (MFCC / PLP chain with two regression stages of window 2)
+  int32_t n_ftiles = 0;
   int32_t n_tiles = 0, n_dtiles = 0;
   bool all_even = true;      // every utterance with frames starts at an even sample offset
 };

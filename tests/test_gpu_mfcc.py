@@ -110,6 +110,54 @@ def test_delta_tail_bit_exact_given_static(hip, plan, oracle):
     b.close()
 
 
+def test_fused_delta_equals_window_chain(hip, oracle):
+    """The fast kernel with the two regression stages inside (lld_mfcc512<..., DELTA>, dword-aligned input) against (a) the same
+    kernel followed by the window-chain kernel (SMILEHIP_NO_FUSED_DELTA=1 at batch creation): every cell the same bits, static
+    coefficients included; (b) the oracle's tick-accurate chain on the GPU's own static columns. Every utterance length from 1 to 40
+    frames (the short path's limit of 16, every residue mod 4), lengths around the tile cuts, one long utterance; then a batch
+    large enough for several tiles per utterance."""
+    capi, ctx = hip
+    from opensmile_amd import synth
+    plan = capi.Plan(ctx)
+    Ts = list(range(1, 41)) + [63, 64, 65, 127, 128, 129, 250, 251, 252, 253, 997, 998, 1000, 1001, 3000]
+    lens = [400 + 160 * (T - 1) + 2 * (i % 3) for i, T in enumerate(Ts)]          # even lengths: even offsets
+    pcm = np.concatenate([synth.utterance(40 + i, n) for i, n in enumerate(lens)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    outs = {}
+    for mode in ("fused", "chain"):
+        if mode == "chain":
+            os.environ["SMILEHIP_NO_FUSED_DELTA"] = "1"
+        try:
+            b = capi.Batch(plan, off)
+        finally:
+            os.environ.pop("SMILEHIP_NO_FUSED_DELTA", None)
+        outs[mode] = b.run_host(pcm)
+        fo = b.frame_offsets
+        b.close()
+    assert outs["fused"].shape == outs["chain"].shape and outs["fused"].shape[1] == 39
+    d = outs["fused"].view(np.uint32) != outs["chain"].view(np.uint32)
+    assert not d.any(), f"{d.sum()} cells differ, first at {np.argwhere(d)[:5]}"
+    for i, T in enumerate(Ts):
+        o = outs["fused"][fo[i]:fo[i + 1]]
+        assert o.shape[0] == T
+        dd = oracle.delta_chain(o[:, :13], 2, 2)
+        assert np.array_equal(o[:, 13:26], dd[0]) and np.array_equal(o[:, 26:39], dd[1]), T
+    # many equal utterances: the tile length comes out near a quarter of an utterance
+    pcm2, off2 = synth.corpus_tiled(6000, 32000, n_unique=8)
+    res = []
+    for mode in ("fused", "chain"):
+        if mode == "chain":
+            os.environ["SMILEHIP_NO_FUSED_DELTA"] = "1"
+        try:
+            b = capi.Batch(plan, off2)
+        finally:
+            os.environ.pop("SMILEHIP_NO_FUSED_DELTA", None)
+        res.append(b.run_host(pcm2))
+        b.close()
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+    plan.close()
+
+
 def test_config1_44k_generic(hip, golden_config1, oracle):
     """Config 1 geometry (44.1 kHz: N=1103, H=441, Nfft=2048) runs on the generic
     kernel; input = the reference's example wav when oracle/_ref ships it,
