@@ -247,6 +247,8 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   PHASE_DECL
   const int t_begin = t0 > 0 ? t0 - 1 : 0;
   int rbase = 0;
+  int zc_count = 0, zc_front = 0;                        // this lane's crossings inside the window / inside its first hop
+  bool zc_have = false;
   for (int t = t_begin; t < t_last; ++t) {
     // an opaque copy of the lane index per frame: otherwise everything below that depends on the lane only (bit-reversed
     // FFT addresses, table addresses, range tests) is hoisted out of the frame loop and kept in ~150 VGPRs across it --
@@ -319,11 +321,28 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
         const int tid = lane + 64 * w;
         v0[w][0] = 0.0; v0[w][1] = 0.0;
         for (int n = tid; n < P.N; n += 256) { const float tmp = R(n); v0[w][0] += tmp * tmp; }
-        if (t < T60)
-          for (int i = 1 + tid; i < Q.N60 - 1; i += 256) {
-            const float a = R(i - 1), b = R(i), c = R(i + 1);
-            if (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) v0[w][1] += 1.0;
-          }
+      }
+      // Zero crossings of the 60 ms window (mzcr.cpp:117-124): a count, so any order of the positions gives the reference's sum.
+      // Consecutive frames of the run share all but one hop of the window: the lane that owns the ABSOLUTE position p (p mod 64)
+      // keeps its count, subtracts the crossings of the hop that leaves (the window's first H positions, counted one frame
+      // earlier from that frame's own window: zc_front) and adds those of the hop that enters (the last H positions).
+      if (t < T60) {
+        const auto cross = [&](int i) {
+          const float a = R(i - 1), b = R(i), c = R(i + 1);
+          return (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) ? 1 : 0;
+        };
+        const auto count = [&](int lo, int hi) {           // positions lo .. hi (relative to the frame) that this lane owns
+          const int off = (int)(((int64_t)t * P.H) & 63);
+          int c = 0;
+          for (int i = lo + ((lane - off - lo) & 63); i <= hi; i += 64) c += cross(i);
+          return c;
+        };
+        const int last = Q.N60 - 2;
+        if (zc_have && 2 * P.H < last) zc_count += count(last - P.H + 1, last) - zc_front;
+        else zc_count = count(1, last);
+        zc_front = count(1, P.H);
+        zc_have = true;
+        v0[0][1] = (double)zc_count;
       }
       double tot[2];
       wave_sum4<2>(v0, tot);
