@@ -65,15 +65,26 @@ bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigne
     }
     bool to_eof = remaining >= 0 && (uint64_t)ch.size > (uint64_t)remaining;
     if (remaining >= 8 && ch.size == 0) {
-      // size 0: a stream written to a pipe (audio until EOF) -- unless what follows is itself a well-formed chunk (an empty
-      // data chunk before LIST / id3 / ... metadata): four printable id bytes and a size that fits the rest of the file
-      unsigned char h[8];
-      const bool got8 = fread(h, 1, 8, f) == 8;
+      // size 0: a stream written to a pipe (audio until EOF) -- unless what follows is a chain of well-formed chunks (an empty
+      // data chunk before LIST / id3 / ... metadata) that walks EXACTLY to the end of the file: four printable id bytes, a size,
+      // the (word-aligned) payload, again. Samples that merely look like one chunk header do not pass that walk.
+      long pos = here;
+      const long end = here + remaining;
+      bool chain = true;
+      int n_chunks = 0;
+      while (chain && pos < end) {
+        unsigned char h[8];
+        if (end - pos < 8 || fseek(f, pos, SEEK_SET) != 0 || fread(h, 1, 8, f) != 8) { chain = false; break; }
+        for (int q = 0; q < 4 && chain; ++q)
+          chain = (h[q] >= 'A' && h[q] <= 'Z') || (h[q] >= 'a' && h[q] <= 'z') || (h[q] >= '0' && h[q] <= '9') || h[q] == ' ';
+        const uint64_t sz = (uint64_t)h[4] | ((uint64_t)h[5] << 8) | ((uint64_t)h[6] << 16) | ((uint64_t)h[7] << 24);
+        const uint64_t adv = 8 + sz + ((sz & 1) && (uint64_t)pos + 8 + sz < (uint64_t)end ? 1 : 0);     // RIFF pads odd chunks
+        if (!chain || adv > (uint64_t)(end - pos)) { chain = false; break; }
+        pos += (long)adv;
+        ++n_chunks;
+      }
       fseek(f, here, SEEK_SET);
-      const uint32_t sz = got8 ? (uint32_t)h[4] | ((uint32_t)h[5] << 8) | ((uint32_t)h[6] << 16) | ((uint32_t)h[7] << 24) : 0;
-      bool printable = got8;
-      for (int q = 0; q < 4 && printable; ++q) printable = (h[q] >= 'A' && h[q] <= 'Z') || (h[q] >= 'a' && h[q] <= 'z') || (h[q] >= '0' && h[q] <= '9') || h[q] == ' ';
-      to_eof = !(printable && (uint64_t)sz + 8 <= (uint64_t)remaining);
+      to_eof = !(chain && n_chunks > 0 && pos == end);
     } else if (remaining >= 0 && remaining < 8 && ch.size == 0) {
       to_eof = remaining > 0;
     }

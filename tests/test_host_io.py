@@ -122,6 +122,15 @@ def test_wave_reader(hostlib, tmp_path):
     assert n == 8 and list(info)[:6] == [8000, 1, 2, 2, 16, 2]
     (tmp_path / "bad.wav").write_bytes(b"RIFX" + b"\0" * 40)
     assert hostlib.shim_read_wave(str(tmp_path / "bad.wav").encode(), info, None, 0) < 0
+    # a data chunk of size 0: audio until the end of the file (a stream written to a pipe) -- also when its first samples
+    # look like a chunk header ("abcd" + a small size) -- unless what follows is a chain of chunks that ends exactly at EOF
+    fmt = b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 16000, 2, 16)
+    looks = b"abcd" + struct.pack("<I", 4) + b"\1\0\2\0" + b"\3\0\4\0\5\0"        # header-like samples, then more audio
+    for name, tail, want in (("pipe.wav", struct.pack("<6h", 5, 6, 7, 8, 9, 10), 12), ("lookalike.wav", looks, len(looks)),
+                             ("meta.wav", b"LIST" + struct.pack("<I", 5) + b"hello\0" + b"id3 " + struct.pack("<I", 2) + b"xy", 0)):
+        body = fmt + b"data" + struct.pack("<I", 0) + tail
+        (tmp_path / name).write_bytes(b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body)
+        assert hostlib.shim_read_wave(str(tmp_path / name).encode(), info, None, 0) == want, name
 
 
 @pytest.mark.gpu
