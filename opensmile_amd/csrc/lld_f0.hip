@@ -870,8 +870,13 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
   }
 }
 
+#ifdef SMILEHIP_F0_CAND_WPE                                 // experiment: a register budget for N waves per SIMD
+#define F0_CAND_ATTR __attribute__((amdgpu_waves_per_eu(SMILEHIP_F0_CAND_WPE, SMILEHIP_F0_CAND_WPE)))
+#else
+#define F0_CAND_ATTR
+#endif
 template <int LOGM>
-__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_cand(LldParams P, F0Params Q) {
+__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) F0_CAND_ATTR lld_f0_cand(LldParams P, F0Params Q) {
   using G = F0G<LOGM>;
   F0_GEO;
   constexpr int kSpecWaves = G::kSpecWaves;
