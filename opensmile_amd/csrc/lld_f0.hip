@@ -870,13 +870,8 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
   }
 }
 
-#ifdef SMILEHIP_F0_CAND_WPE                                 // experiment: a register budget for N waves per SIMD
-#define F0_CAND_ATTR __attribute__((amdgpu_waves_per_eu(SMILEHIP_F0_CAND_WPE, SMILEHIP_F0_CAND_WPE)))
-#else
-#define F0_CAND_ATTR
-#endif
 template <int LOGM>
-__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) F0_CAND_ATTR lld_f0_cand(LldParams P, F0Params Q) {
+__device__ __forceinline__ void f0_cand_body(const LldParams &P, const F0Params &Q) {
   using G = F0G<LOGM>;
   F0_GEO;
   constexpr int kSpecWaves = G::kSpecWaves;
@@ -910,6 +905,16 @@ __global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) F0_CAND_ATTR lld_f
     PHASE(4);   // candidates + output
   }
   PHASE_FLUSH;
+}
+
+// (the tuned geometry at four waves per SIMD: 128 VGPRs, 13 spilled dwords -- 0.97 -> 0.85 ms per 260 k frames; the other
+// geometries take what the compiler gives them)
+__global__ void __launch_bounds__(F0G<9>::kSpecWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) lld_f0_cand9(LldParams P, F0Params Q) {
+  f0_cand_body<9>(P, Q);
+}
+template <int LOGM>
+__global__ void __launch_bounds__(F0G<LOGM>::kSpecWaves * 64) lld_f0_cand(LldParams P, F0Params Q) {
+  f0_cand_body<LOGM>(P, Q);
 }
 
 // The per-component operators (mode 1 cSpecScale, mode 2 cPitchShs) for the spectra whose tables do not fit LDS (FFT 2048 / 4096:
@@ -1281,7 +1286,8 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
   } else spec = reinterpret_cast<const void *>(&lld_f0_spec_g<LOGM>);
   hipError_t e = hipFuncSetAttribute(spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_cand<LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
+  e = hipFuncSetAttribute(LOGM == 9 ? reinterpret_cast<const void *>(&lld_f0_cand9) : reinterpret_cast<const void *>(&lld_f0_cand<LOGM>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
   F0Params Q = Q0;
   for (int t0 = 0; t0 < P.n_tiles; t0 += f0_chunk_tiles()) {
@@ -1298,7 +1304,8 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
     }
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
     hipLaunchKernelGGL(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
-    hipLaunchKernelGGL(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    if constexpr (LOGM == 9) hipLaunchKernelGGL(lld_f0_cand9, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    else hipLaunchKernelGGL(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
