@@ -333,7 +333,8 @@ __device__ __forceinline__ void spectral_frame_wave(const float *mg, const float
     double v = p[w];
     if (v <= entropy_floor) v = entropy_floor;
     const double ln = v / dn;
-    v2[w][0] = (ln > 0.0) ? ln * log_d(ln) / log(2.0) : 0.0;
+    // (ln > 0: a quotient of two values >= 1e-7 that are floats or sums of floats -- a positive normal double, or +inf)
+    v2[w][0] = (ln > 0.0) ? ln * log_d<true>(ln, C.log_tab ? static_cast<const double2 *>(C.log_tab) : kLogTab) / log(2.0) : 0.0;
     const double t1 = fj[w] - (double)ctr;
     double m = t1 * t1 * p[w];
     v2[w][1] = m; m *= t1; v2[w][2] = m; v2[w][3] = m * t1;

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   }
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
+  SC.log_tab = nullptr;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   PHASE_DECL
 
@@ -196,9 +197,11 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   const int Kpad = (K + 3) & ~3;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *s_coef = smem;
+  double2 *s_log = reinterpret_cast<double2 *>(smem);     // the logarithm's table (first: 16-byte aligned), 512 floats
+  float *s_coef = smem + 512;
   int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + Kpad);
   float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) s_log[i] = kLogTab[i];
   for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
@@ -242,6 +245,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   }
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
+  SC.log_tab = s_log;
   const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
   const int lane_in = lane;
   PHASE_DECL
@@ -524,7 +528,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.K != M + 1 || P.N > P.Nfft) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks, FFT 512)
   if (P.Nfft != 512) {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
+    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (!P.oo.tw) return hipErrorInvalidValue;            // (the own-order A/B transform exists for the tuned geometry only)
     const void *fn = P.Nfft == 256 ? reinterpret_cast<const void *>(&lld_compare_frame_wave_g<2>) : reinterpret_cast<const void *>(&lld_compare_frame_wave_g<8>);
     hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -536,7 +540,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
+    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (P.N > Q.N60) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
       hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

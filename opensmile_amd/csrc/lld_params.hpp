@@ -250,6 +250,7 @@ struct SpectralConsts {
   int32_t band_iL[2], band_iR[2];
   double band_wL[2], band_wR[2];
   double slope_Sf, slope_S2f;
+  const void *log_tab;        // kLogTab's copy in LDS (128 double2) where the kernel staged one, else null: the table in global memory
 };
 
 // General functionals (lld_funcspec.hip): one cFunctionals instance over columns [col_first, col_first + n_cols) of

@@ -235,6 +235,7 @@ extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, in
   int rc = check_frames(d_mag, d_dst, ld_src, ld_dst, n_frames, p->geo.K, 15, "smilehip_spectral_frames");
   if (rc) return rc;
   SpectralConsts C;
+  C.log_tab = nullptr;
   C.fsSec = p->geo.fft_frame_size_sec;
   C.sharp_w = p->d_sharp.p;
   for (int i = 0; i < 2; ++i) {
