@@ -191,6 +191,8 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 // keeps the block kernel's order (lld_blocks_compare.hpp), so the two kernels give bit-identical rows.
 // LDS: shared coef[Kpad] | rng[128] | dct[16 x 32]; per wave z[fft_pairs(M)] pairs | mg[Kpad] | pw[Kpad] | prev[Kpad] |
 // mel[32] | aud[32] | lmel[32]
+// the wave's z region: the transform's pairs, then the mel terms (two rows of Kpad floats), then the descriptors' chains
+__host__ __device__ inline int compare_z_floats(int M, int Kpad) { return 2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad; }
 template <int W>                                       // K = 64 W + 1 bins: W = 4 at 16 kHz (FFT 512), 2 / 8 for FFT 256 / 1024
 __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, const CompareParams &Q, int n_runs, float *smem) {
   const int M = P.Nfft >> 1, K = P.K;
@@ -210,10 +212,10 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
   const int rawpad = (Q.N60 + 3) & ~3;
-  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 96 + rawpad;
+  const int per_wave = compare_z_floats(M, Kpad) + 3 * Kpad + 96 + rawpad;
   float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
-  float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
+  float *mg = reinterpret_cast<float *>(z) + compare_z_floats(M, Kpad);
   float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
   float *pw = mg + Kpad;
   float *prev = pw + Kpad;
@@ -301,9 +303,12 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       WaveG::sync();
       continue;
     }
+    float *mt_a = reinterpret_cast<float *>(z), *mt_r = mt_a + Kpad;      // (z: free between the transform and the descriptors' chains)
+    mel_terms_fill<WaveG>(pw, s_coef, K, mt_a, mt_r);
+    WaveG::sync();
     if (lane < P.n_bands) {
       const int b = lane;
-      const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
+      const float acc = mel_band_from_terms(mt_a, mt_r, s_rng, b, 1.0f);
       melv[b] = acc;
       Q.mel1[(f0 + t) * 26 + b] = glibc_logf(acc < Q.plp_melfloor ? Q.plp_melfloor : acc);   // plp.cpp:434-439: logf
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
@@ -528,7 +533,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.K != M + 1 || P.N > P.Nfft) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   static const bool use_block = getenv("SMILEHIP_COMPARE_BLOCK") != nullptr;      // the one-workgroup-per-run kernel (A/B checks, FFT 512)
   if (P.Nfft != 512) {
-    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
+    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (compare_z_floats(M, Kpad) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (!P.oo.tw) return hipErrorInvalidValue;            // (the own-order A/B transform exists for the tuned geometry only)
     const void *fn = P.Nfft == 256 ? reinterpret_cast<const void *>(&lld_compare_frame_wave_g<2>) : reinterpret_cast<const void *>(&lld_compare_frame_wave_g<8>);
     hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -540,7 +545,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
     hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
-    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
+    const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (compare_z_floats(M, Kpad) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (P.N > Q.N60) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
       hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

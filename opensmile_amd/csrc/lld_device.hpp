@@ -58,6 +58,30 @@ __device__ __forceinline__ float mel_band_exact(const float *p, const float *coe
   return acc * scale;
 }
 
+// The same band sum from precomputed terms: every lane of the group forms a[n] = p[n] * coef[n] and r[n] = p[n] - a[n] for its
+// bins (mel_terms_fill), the band's lane then only adds -- four loads in flight per step instead of a load round trip per
+// term (the sums of the widest bands are chains of ~60 dependent additions; with the loads inside the chain the 26 busy lanes
+// kept a wave for a fifth of the ComParE frame kernel's time). Same products, same differences, same order: the same bits.
+template <class G>
+__device__ __forceinline__ void mel_terms_fill(const float *p, const float *coef, int K, float *a, float *r) {
+  for (int n = G::tid(); n < K; n += G::size()) {
+    const float pn = p[n], an = pn * coef[n];
+    a[n] = an;
+    r[n] = pn - an;
+  }
+}
+__device__ __forceinline__ float mel_band_from_terms(const float *a, const float *r, const int32_t *rng, int b, float scale) {
+  const int rl = rng[4 * b + 0], rh = rng[4 * b + 1], fl = rng[4 * b + 2], fh = rng[4 * b + 3];
+  float acc = 0.0f;
+  int n = rl;
+  for (; n + 4 <= rh; n += 4) { const float t0 = r[n], t1 = r[n + 1], t2 = r[n + 2], t3 = r[n + 3]; acc += t0; acc += t1; acc += t2; acc += t3; }
+  for (; n < rh; ++n) acc += r[n];
+  n = fl;
+  for (; n + 4 <= fh; n += 4) { const float t0 = a[n], t1 = a[n + 1], t2 = a[n + 2], t3 = a[n + 3]; acc += t0; acc += t1; acc += t2; acc += t3; }
+  for (; n < fh; ++n) acc += a[n];
+  return acc * scale;
+}
+
 // R4 core: in-place radix-2 DIT complex FFT of length M in LDS (re/im already
 // loaded in bit-reversed order), executed by the whole workgroup.
 __device__ __forceinline__ void block_cfft_radix2(float *re, float *im, int M, const float2 *tw_half) {

@@ -193,10 +193,11 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
-  const int per_wave = 2 * fft_pairs(M) + 3 * Kpad + 64 + 96;
+  const int zf = 2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad;     // the transform's pairs, then the mel terms (two rows of Kpad floats)
+  const int per_wave = zf + 3 * Kpad + 64 + 96;
   float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
-  float *mg = reinterpret_cast<float *>(z) + 2 * fft_pairs(M);
+  float *mg = reinterpret_cast<float *>(z) + zf;
   float *yv = mg;                                        // the raw frame lives in mg | pw (N <= 2 M < 2 Kpad) until the transform has read it
   float *pw = mg + Kpad;
   float *prev = pw + Kpad;
@@ -274,9 +275,12 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
       continue;
     }
     // R6 once, two scalings: [gemapsv01b_melspec1] (htk = 0) feeds cPlp, [egemapsv02_melspecMfcc] (htk = 1) feeds cMfcc
+    float *mt_a = reinterpret_cast<float *>(z), *mt_r = mt_a + Kpad;      // (z: free behind the transform; lld_device.hpp: mel_terms_fill)
+    mel_terms_fill<WaveG>(pw, s_coef, K, mt_a, mt_r);
+    WaveG::sync();
     if (lane < P.n_bands) {
       const int b = lane;
-      const float acc = mel_band_exact(pw, s_coef, s_rng, b, 1.0f);
+      const float acc = mel_band_from_terms(mt_a, mt_r, s_rng, b, 1.0f);
       melv[b] = acc;
       lmel[b] = log_mel(acc * P.mel_scale, P.melfloor, P.log_floor);
       aud[b] = plp_aud_band(acc, G.plp_melfloor, G.eql[b], G.compression);     // [gemapsv01b_audspec], plp.cpp:499-507
@@ -1180,7 +1184,7 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.N > P.Nfft || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (2 * fft_pairs(M) + 3 * Kpad + 64 + 96));
+  const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * ((2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad) + 3 * Kpad + 64 + 96));
   hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

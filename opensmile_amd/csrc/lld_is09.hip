@@ -267,8 +267,9 @@ __global__ void __launch_bounds__(256) lld_is09_frame_wave(LldParams P, Is09Para
 namespace {
 constexpr int kQuadWaves = 4;
 constexpr int kQuadKpad = 260;
-constexpr int kQuadFrameFloats = 2 * kQuadZPairs;
-constexpr int kQuadLmel = 272;                             // the log mel bands' place in the frame's buffer (behind the 257 mel inputs)
+constexpr int kQuadLmel = 2 * 257;                          // the log mel bands' place in the frame's buffer: behind the two rows of 257 mel terms
+constexpr int kQuadFrameFloats = (2 * kQuadZPairs > kQuadLmel + 34 ? 2 * kQuadZPairs : kQuadLmel + 34);      // (548: the transform needs 544)
+static_assert(kQuadFrameFloats % 4 == 0, "16-byte multiples per frame buffer");
 // the tables the quad form reads: window | mel_coef | mel_rng | dct_rows (the reference-order transform's follow)
 // log table (128 double2, first: 16-byte aligned) | window | mel_coef | mel_rng | dct_rows
 __host__ __device__ inline int is09_quad_table_floats(int N) { return 512 + ((N + 3) & ~3) + kQuadKpad + 128 + 16 * 32; }
@@ -424,16 +425,27 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
     if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);     // (six bins' loads in flight at a time: all 17 at once spill)
   }
-  QuadG::sync();                                           // (z has been read: the mel input takes its place)
+  QuadG::sync();                                           // (z has been read: the mel terms take its place)
+  // R6's terms per bin, straight from the registers (lld_device.hpp: mel_band_from_terms): a[k] = p w, r[k] = p - p w
+  {
+    float *mt_a = sp, *mt_r = sp + (M + 1);
 #pragma unroll
-  for (int m = 0; m < 17; ++m) { const int k = j + 16 * m; if (k <= M) sp[k] = P.use_power ? mv[m] * mv[m] : mv[m]; }
+    for (int m = 0; m < 17; ++m) {
+      const int k = j + 16 * m;
+      if (k <= M) {
+        const float pk = P.use_power ? mv[m] * mv[m] : mv[m], ak = pk * T.mel_coef[k];
+        mt_a[k] = ak;
+        mt_r[k] = pk - ak;
+      }
+    }
+  }
   QuadG::sync();
   IPHASE(3);   // forward transform + magnitudes
   // R6 / R7: mel (usePower per config) -> log -> DCT
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int b = j + 16 * h;
-    if (b < P.n_bands) lmel[b] = log_mel(mel_band_exact(sp, T.mel_coef, T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
+    if (b < P.n_bands) lmel[b] = log_mel(mel_band_from_terms(sp, sp + (M + 1), T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
   }
   QuadG::sync();
   if (j < P.n_mfcc) out[1 + j] = dct_coeff(lmel, T.dct_rows + j * P.n_bands, P.n_bands, P.dct_gain[j]);
