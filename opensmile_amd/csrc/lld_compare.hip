@@ -155,8 +155,7 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
     for (int r = threadIdx.x; r < P.n_mfcc; r += blockDim.x)
       rawB[41 + r] = dct_coeff(lmel, s_dct + r * P.n_bands, P.n_bands, P.dct_gain[r]);   // R7
     if (threadIdx.x == 192) {                           // cVectorOperation ll1, vectorOperation.cpp:475-481
-      float d = 0.0f;
-      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      const float d = seq_sum_f32(aud, P.n_bands);
       rawA[0] = d / (float)P.n_bands;
     }
     PHASE(3);   // mel, auditory spectrum, MFCC
@@ -317,8 +316,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
     WaveG::sync();
     if (lane < P.n_mfcc) rawB[41 + lane] = dct_coeff(lmel, s_dct + lane * P.n_bands, P.n_bands, P.dct_gain[lane]);   // R7
     if (lane == 32) {                                    // cVectorOperation ll1, vectorOperation.cpp:475-481
-      float d = 0.0f;
-      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      const float d = seq_sum_f32(aud, P.n_bands);
       rawA[0] = d / (float)P.n_bands;
     }
     PHASE(3);

@@ -194,8 +194,21 @@ __device__ __forceinline__ float log_mel_fast(float v, float melfloor, float log
 // R7: one cepstral coefficient, sequential band order (mfcc.cpp:251-273)
 __device__ __forceinline__ float dct_coeff(const float *lmel, const float *row_c, int n_bands, float gain) {
   float acc = 0.0f;
-  for (int m = 0; m < n_bands; ++m) acc += lmel[m] * row_c[m];
+  int m = 0;
+  for (; m + 4 <= n_bands; m += 4) {                       // (the four products' loads in flight together; the additions in band order)
+    const float t0 = lmel[m] * row_c[m], t1 = lmel[m + 1] * row_c[m + 1], t2 = lmel[m + 2] * row_c[m + 2], t3 = lmel[m + 3] * row_c[m + 3];
+    acc += t0; acc += t1; acc += t2; acc += t3;
+  }
+  for (; m < n_bands; ++m) acc += lmel[m] * row_c[m];
   return acc * gain;
+}
+// a float chain over n values in index order (cVectorOperation's vector sums and the like), four loads in flight per step
+__device__ __forceinline__ float seq_sum_f32(const float *v, int n) {
+  float d = 0.0f;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) { const float t0 = v[i], t1 = v[i + 1], t2 = v[i + 2], t3 = v[i + 3]; d += t0; d += t1; d += t2; d += t3; }
+  for (; i < n; ++i) d += v[i];
+  return d;
 }
 
 // R8, PLP-CC branch of cPlp::processVector (plp.cpp:522-583, htkcompatible = 1, firstCC = 0):

@@ -288,8 +288,7 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
     WaveG::sync();
     if (lane < P.n_mfcc) raw[6 + lane] = dct_coeff(lmel, s_dct + lane * P.n_bands, P.n_bands, P.dct_gain[lane]);   // R7
     if (lane == 32) {                                    // [gemapsv01b_audspecSum] ll1, vectorOperation.cpp:475-481
-      float d = 0.0f;
-      for (int i = 0; i < P.n_bands; i++) d += aud[i];
+      const float d = seq_sum_f32(aud, P.n_bands);
       raw[0] = d / (float)P.n_bands;
     }
     if (lane == 0) raw[10] = (float)(e2 / (double)P.N) * 1.0f + 0.0f;
