@@ -343,8 +343,8 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *   Samples     (functionalSamples.cpp:100-117)    the contour at n_samples (<= 8) relative positions
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
- * Not restated: Percentiles.pctlquotient, Times.upleveltime[]/downleveltime[]/useRobustPercentileRange,
- * Segments.useOldBuggyChX / growDynSegBuffer, Peaks2.noClearPeakList / debug outputs -- a spec cannot express them. */
+ * Not restated: Segments.useOldBuggyChX / growDynSegBuffer, Peaks2.noClearPeakList / debug outputs, the ModulationSpec
+ * family -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
   SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_CROSSINGS, SMILEHIP_FAM_DCT,
@@ -383,6 +383,14 @@ typedef struct smilehip_func_spec {
   uint32_t pko_mask; int32_t pko_norm;                             /* Peaks */
   uint32_t crs_mask; int32_t dct_first, dct_last, n_samples;       /* Crossings; DCT firstCoeff .. lastCoeff; Samples */
   double sample_pos[8];                                            /* Samples.samplepos[], clipped to [0, 1] */
+  /* Percentiles.pctlquotient[] (functionalPercentiles.cpp:179-232, :402-411): percentile quot_a over percentile quot_b through
+   * the soft limiter (50, 100); an index < 0 gives 0. The reference forms the quotients only when pctlrange[] is not empty
+   * (zeros otherwise) and only with n_pctl > 0 -- so does this. */
+  int32_t n_quot, quot_a[8], quot_b[8];
+  /* Times.upleveltime[] / downleveltime[] (functionalTimes.cpp:129-165, :347-364): the share of the contour above / not above
+   * level * range + min, levels clipped to [0, 1]. (Times.useRobustPercentileRange is not built: a spec cannot ask for it.) */
+  int32_t n_ul, n_dl, reserved7;
+  double ul[8], dl[8];
 } smilehip_func_spec;
 
 /* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */

@@ -77,6 +77,9 @@ class FuncSpec(C.Structure):
         ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
         ("crs_mask", C.c_uint32), ("dct_first", C.c_int32), ("dct_last", C.c_int32), ("n_samples", C.c_int32),
         ("sample_pos", C.c_double * 8),
+        ("n_quot", C.c_int32), ("quot_a", C.c_int32 * 8), ("quot_b", C.c_int32 * 8),
+        ("n_ul", C.c_int32), ("n_dl", C.c_int32), ("reserved7", C.c_int32),
+        ("ul", C.c_double * 8), ("dl", C.c_double * 8),
     ]
 
 

@@ -516,6 +516,25 @@ __device__ int f_times(const smilehip_func_spec &s, const Col &in, float min, fl
   if (FS_BIT(m, 10)) out[n++] = (Norm2 != 0.0f) ? ((float)nLC) / Norm2 : 0.0f;
   if (FS_BIT(m, 11)) out[n++] = (Norm2 != 0.0f) ? ((float)nRC) / Norm2 : 0.0f;
   if (FS_BIT(m, 12)) out[n++] = (s.times_norm == SMILEHIP_NORM_SECOND) ? ((float)(Nin) * T) : (float)Nin;
+  // second pass, user defined times (:347-364): one walk for all levels
+  if (s.n_ul + s.n_dl > 0) {
+    float lu[8], ld[8];
+    int64_t cu[8], cd[8];
+    for (int j = 0; j < 8; ++j) {
+      lu[j] = (j < s.n_ul) ? (float)(s.ul[j] * (double)range + (double)min) : 0.0f;
+      ld[j] = (j < s.n_dl) ? (float)(s.dl[j] * (double)range + (double)min) : 0.0f;
+      cu[j] = cd[j] = 0;
+    }
+    for_rows(in, 0, Nin, [&](int64_t, float v) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < s.n_ul && v > lu[j]) cu[j]++;
+        if (j < s.n_dl && v <= ld[j]) cd[j]++;
+      }
+    });
+    for (int j = 0; j < s.n_ul; ++j) out[n++] = ((float)cu[j]) / Norm;
+    for (int j = 0; j < s.n_dl; ++j) out[n++] = ((float)cd[j]) / Norm;
+  }
   return n;
 }
 
@@ -1349,6 +1368,12 @@ __device__ void pctl_readout(const FsParams &P, const Where &w, const float *a, 
     for (int i = 0; i < s.n_pctl; ++i) out[n++] = s.pct_interp ? interp_pctl(s.pctl[i], a, N) : a[pctl_idx(s.pctl[i], N)];
     for (int i = 0; i < s.n_range; ++i) {
       const float v = (float)fabs((double)(out[n0 + s.range_b[i]] - out[n0 + s.range_a[i]]));
+      out[n++] = v;
+    }
+    // pctlquotient (:402-411): under the test of the RANGE switch and of the numerator; without ranges cFunctionals zero-fills
+    for (int i = 0; i < s.n_quot; ++i) {
+      float v = 0.0f;
+      if (s.n_range > 0 && out[n0 + s.quot_a[i]] != 0.0f) v = fs_ratio_limit(out[n0 + s.quot_a[i]] / out[n0 + s.quot_b[i]], 50.0f, 100.0f);
       out[n++] = v;
     }
   }

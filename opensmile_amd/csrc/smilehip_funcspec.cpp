@@ -34,10 +34,20 @@ int family_count(const smilehip_func_spec &s, int fam) {
       for (int i = 0; i < s.n_range; ++i)
         if (s.range_a[i] < 0 || s.range_a[i] >= s.n_pctl || s.range_b[i] < 0 || s.range_b[i] >= s.n_pctl || s.range_a[i] == s.range_b[i])
           return fail(SMILEHIP_ERR_INVALID, "Percentiles: pctlrange[%d] = %d-%d is not a pair of distinct percentile[] indices", i, s.range_a[i], s.range_b[i]);
-      return popc(s.pct_mask) + s.n_pctl + s.n_range;
+      if (s.n_quot < 0 || s.n_quot > 8) return fail(SMILEHIP_ERR_INVALID, "Percentiles: at most 8 pctlquotient[] entries");
+      if (s.n_pctl == 0 && s.n_quot > 0) return fail(SMILEHIP_ERR_INVALID, "Percentiles: pctlquotient[] without percentile[]");
+      for (int i = 0; i < s.n_quot; ++i)
+        if (s.quot_a[i] < 0 || s.quot_a[i] >= s.n_pctl || s.quot_b[i] < 0 || s.quot_b[i] >= s.n_pctl)
+          return fail(SMILEHIP_ERR_INVALID, "Percentiles: pctlquotient[%d] = %d-%d is not a pair of percentile[] indices", i, s.quot_a[i], s.quot_b[i]);
+      return popc(s.pct_mask) + s.n_pctl + s.n_range + s.n_quot;
     case SMILEHIP_FAM_TIMES:
       if (s.times_mask & ~0x1fffu) return fail(SMILEHIP_ERR_INVALID, "Times: unknown bits in mask 0x%x", s.times_mask);
-      return popc(s.times_mask);
+      if (s.n_ul < 0 || s.n_ul > 8 || s.n_dl < 0 || s.n_dl > 8) return fail(SMILEHIP_ERR_INVALID, "Times: at most 8 upleveltime[] and 8 downleveltime[] entries");
+      for (int i = 0; i < s.n_ul; ++i)
+        if (!(s.ul[i] >= 0.0 && s.ul[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Times: upleveltime[%d] = %g not in [0, 1]", i, s.ul[i]);
+      for (int i = 0; i < s.n_dl; ++i)
+        if (!(s.dl[i] >= 0.0 && s.dl[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Times: downleveltime[%d] = %g not in [0, 1]", i, s.dl[i]);
+      return popc(s.times_mask) + s.n_ul + s.n_dl;
     case SMILEHIP_FAM_SEGMENTS:
       if (s.seg_mask & ~0x1fu) return fail(SMILEHIP_ERR_INVALID, "Segments: unknown bits in mask 0x%x", s.seg_mask);
       if (s.seg_algo < SMILEHIP_SEG_RELTH || s.seg_algo > SMILEHIP_SEG_CHX)

@@ -107,9 +107,15 @@ class cHipFunctionals : public cFunctionals {
         s.n_range = getArraySize(k); free(k);
         k = myvprint("%s.pctlquotient", f);
         const int nq = getArraySize(k); free(k);
-        if (s.n_pctl < 0 || s.n_pctl > 8 || s.n_range < 0 || s.n_range > 8) return false;
-        if (s.n_pctl > 0 && nq > 0) return false;         // quotients are not expressible
+        if (s.n_pctl < 0 || s.n_pctl > 8 || s.n_range < 0 || s.n_range > 8 || nq < 0 || nq > 8) return false;
         if (s.n_pctl == 0) s.n_range = 0;
+        s.n_quot = s.n_pctl > 0 ? nq : 0;                 // (read inside `if (nPctl > 0)`, functionalPercentiles.cpp:114-232)
+        for (int j = 0; j < s.n_quot; ++j) {
+          const char *t = getStr_f(myvprint("%s.pctlquotient[%i]", f, j));
+          int a = -1, b = -1;
+          if (!t || sscanf(t, "%d-%d", &a, &b) != 2 || a < 0 || b < 0 || a >= s.n_pctl || b >= s.n_pctl) return false;
+          s.quot_a[j] = a; s.quot_b[j] = b;
+        }
         for (int j = 0; j < s.n_pctl; ++j) {
           double v = getDouble_f(myvprint("%s.percentile[%i]", f, j));
           s.pctl[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
@@ -132,7 +138,10 @@ class cHipFunctionals : public cFunctionals {
         const int nu = getArraySize(k); free(k);
         k = myvprint("%s.downleveltime", f);
         const int nd = getArraySize(k); free(k);
-        if (nu > 0 || nd > 0 || opt_int(f, "useRobustPercentileRange")) return false;
+        if (nu < 0 || nu > 8 || nd < 0 || nd > 8 || opt_int(f, "useRobustPercentileRange")) return false;
+        s.n_ul = nu; s.n_dl = nd;
+        for (int j = 0; j < nu; ++j) { const double v = getDouble_f(myvprint("%s.upleveltime[%i]", f, j)); s.ul[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+        for (int j = 0; j < nd; ++j) { const double v = getDouble_f(myvprint("%s.downleveltime[%i]", f, j)); s.dl[j] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
       } else if (!strcmp(f, "Segments")) {
         s.fam[s.n_fam++] = SMILEHIP_FAM_SEGMENTS;
         static const char *const o[5] = {"numSegments", "meanSegLen", "maxSegLen", "minSegLen", "segLenStddev"};

@@ -33,8 +33,8 @@ static int fam_count(const lldo_func_spec *s, int fam)
     case LLDO_FAM_MEANS: return popc(s->means_mask & 0x1ffffu);
     case LLDO_FAM_MOMENTS: return popc(s->mom_mask & 0x3fu);
     case LLDO_FAM_REGRESSION: return popc(s->reg_mask & 0x3ffffu);
-    case LLDO_FAM_PERCENTILES: return popc(s->pct_mask & 0x3fu) + s->n_pctl + (s->n_pctl > 0 ? s->n_range : 0);
-    case LLDO_FAM_TIMES: return popc(s->times_mask & 0x1fffu);
+    case LLDO_FAM_PERCENTILES: return popc(s->pct_mask & 0x3fu) + s->n_pctl + (s->n_pctl > 0 ? s->n_range + s->n_quot : 0);
+    case LLDO_FAM_TIMES: return popc(s->times_mask & 0x1fffu) + s->n_ul + s->n_dl;
     case LLDO_FAM_SEGMENTS: return popc(s->seg_mask & 0x1fu);
     case LLDO_FAM_LPC: return (s->lpc_gain ? 1 : 0) + (s->lpc_coeffs ? s->lpc_order - s->lpc_first : 0);
     case LLDO_FAM_PEAKS2: return popc(s->pk_mask);
@@ -436,6 +436,14 @@ static int f_percentiles(const lldo_func_spec *s, const float *sorted, float *ou
       const float v = (float)fabs(out[n0 + s->range_b[i]] - out[n0 + s->range_a[i]]);
       out[n++] = v;
     }
+    /* :402-411 -- under the test of the RANGE switch, and on the numerator being non-zero; without ranges cFunctionals zero-fills
+     * the declared values (functionals.cpp:372-375) */
+    for (int i = 0; i < s->n_quot; i++) {
+      float v = 0.0f;
+      if (s->n_range > 0 && s->quot_a[i] >= 0 && s->quot_b[i] >= 0 && out[n0 + s->quot_a[i]] != 0.0)
+        v = ratio_limit(out[n0 + s->quot_a[i]] / out[n0 + s->quot_b[i]], 50.0f, 100.0f);
+      out[n++] = v;
+    }
   }
   return n;
 }
@@ -496,6 +504,18 @@ static int f_times(const lldo_func_spec *s, const float *in, float min, float ma
     if (BIT(m, 11)) out[n++] = 0.0f;
   }
   if (BIT(m, 12)) out[n++] = (s->times_norm == LLDO_NORM_SECOND) ? ((float)(Nin) * T) : (float)Nin;
+  for (int j2 = 0; j2 < s->n_ul; j2++) {                   /* second pass, user defined times :347-364 */
+    const float lX = (float)(s->ul[j2] * range + min);
+    long nX = 0;
+    for (long i = 0; i < Nin; i++) if (in[i] > lX) nX++;
+    out[n++] = ((float)nX) / Norm;
+  }
+  for (int j2 = 0; j2 < s->n_dl; j2++) {
+    const float lX = (float)(s->dl[j2] * range + min);
+    long nX = 0;
+    for (long i = 0; i < Nin; i++) if (in[i] <= lX) nX++;
+    out[n++] = ((float)nX) / Norm;
+  }
   return n;
 }
 

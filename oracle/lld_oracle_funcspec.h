@@ -56,6 +56,13 @@ typedef struct lldo_func_spec {
    * (functionalSamples.cpp): the contour's values at n_samples relative positions in [0, 1] */
   uint32_t crs_mask; int32_t dct_first, dct_last, n_samples;
   double sample_pos[8];
+  /* Percentiles.pctlquotient[] (functionalPercentiles.cpp:179-232, :402-411): percentile a over percentile b through the soft
+   * limiter (50, 100). The reference forms them only when pctlrange[] is not empty -- zeros otherwise -- and only if n_pctl > 0. */
+  int32_t n_quot, quot_a[8], quot_b[8];
+  /* Times.upleveltime[] / downleveltime[] (functionalTimes.cpp:129-165, :347-364): share of the contour above / not above
+   * level * range + min */
+  int32_t n_ul, n_dl, reserved7;
+  double ul[8], dl[8];
 } lldo_func_spec;
 
 /* values per input column; < 0 for an unusable spec */

@@ -590,6 +590,9 @@ class FuncSpec(C.Structure):
         ("pko_mask", C.c_uint32), ("pko_norm", C.c_int32),
         ("crs_mask", C.c_uint32), ("dct_first", C.c_int32), ("dct_last", C.c_int32), ("n_samples", C.c_int32),
         ("sample_pos", C.c_double * 8),
+        ("n_quot", C.c_int32), ("quot_a", C.c_int32 * 8), ("quot_b", C.c_int32 * 8),
+        ("n_ul", C.c_int32), ("n_dl", C.c_int32), ("reserved7", C.c_int32),
+        ("ul", C.c_double * 8), ("dl", C.c_double * 8),
     ]
 
 
@@ -701,8 +704,11 @@ def funcspec_names(s):
             out += [n for k, n in enumerate(PCT_NAMES) if s.pct_mask >> k & 1]
             out += ["percentile%.1f" % (s.pctl[k] * 100.0) for k in range(s.n_pctl)]
             out += ["pctlrange%d-%d" % (s.range_a[k], s.range_b[k]) for k in range(s.n_range)]
+            out += ["pctlquotient%d-%d" % (s.quot_a[k], s.quot_b[k]) for k in range(s.n_quot if s.n_pctl > 0 else 0)]
         elif f == "Times":
             out += [n for k, n in enumerate(TIMES_NAMES) if s.times_mask >> k & 1]
+            out += ["upleveltime%.1f" % (s.ul[k] * 100.0) for k in range(s.n_ul)]
+            out += ["downleveltime%.1f" % (s.dl[k] * 100.0) for k in range(s.n_dl)]
         elif f == "Segments":
             out += [n for k, n in enumerate(SEG_NAMES) if s.seg_mask >> k & 1]
         elif f == "Lpc":

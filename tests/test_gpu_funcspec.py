@@ -207,6 +207,33 @@ def test_funcspec_every_segmentation_algorithm(hip, oracle, algo):
             assert (ref[:, 0] > 0).any(), (algo, n_rows)
 
 
+def test_funcspec_percentile_quotients_and_level_times(hip, oracle):
+    """Percentiles.pctlquotient[] and Times.upleveltime[] / downleveltime[] (the oracle's restatement is pinned on the binary in
+    test_oracle_pin_is10.py::test_percentile_quotients_and_level_times_bit_exact): the pinned specs on contours with zero plateaus
+    (zero numerators and denominators), short and long (the global sort path), both percentile read-outs."""
+    capi, ctx = hip
+    from test_oracle_pin_is10 import quot_time_cases
+    rng = np.random.default_rng(77)
+    for n_rows in (5, 300, 2500):
+        x = np.abs(np.cumsum(rng.standard_normal((n_rows, 6)), axis=0)).astype(np.float32)
+        x[: n_rows // 3, :3] = 0.0
+        x[:, 5] = -x[:, 5]
+        for k, so in quot_time_cases().items():
+            s = capi.FuncSpec()
+            assert C.sizeof(s) == C.sizeof(so)
+            C.memmove(C.byref(s), C.byref(so), C.sizeof(s))
+            dev = capi.funcspec_matrix_host(ctx, s, x)
+            ref = oracle.funcspec(x, so)
+            names = oracle.funcspec_names(so)
+            assert dev.shape == ref.shape == (6, len(names)), (k, dev.shape, ref.shape, len(names))
+            for c, nm in enumerate(names):
+                if nm.startswith("pctlquotient"):                       # the soft limiter goes through exp
+                    err = np.abs(dev[:, c].astype(np.float64) - ref[:, c]) / np.maximum(np.abs(ref[:, c]), 1e-6)
+                    assert err.max() <= 1e-6, (k, nm, dev[:, c], ref[:, c])
+                else:
+                    assert np.array_equal(dev[:, c].view(np.uint32), ref[:, c].view(np.uint32)), (k, n_rows, nm, dev[:, c], ref[:, c])
+
+
 def test_batch_funcspec_ragged_with_cut_and_extra_row(hip, oracle):
     """smilehip_batch_funcspec on a ragged batch: per-utterance rows = max(1, rows - cut) (+ one extra row), column
     sub-ranges, utterances without rows."""

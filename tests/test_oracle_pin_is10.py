@@ -233,6 +233,57 @@ def test_segments_every_algorithm_bit_exact(tmp_path):
     assert found > 40
 
 
+def quot_time_cases():
+    """instance of tests/conf/quotients_leveltimes.conf -> spec"""
+    def pct(mask, interp, pctl, ranges, quots):
+        s = lldo.FuncSpec()
+        lldo._spec_common(s, ["Percentiles"])
+        s.pct_mask, s.pct_interp, s.n_pctl, s.n_range, s.n_quot = mask, interp, len(pctl), len(ranges), len(quots)
+        for i, v in enumerate(pctl):
+            s.pctl[i] = v
+        for i, (a, b) in enumerate(ranges):
+            s.range_a[i], s.range_b[i] = a, b
+        for i, (a, b) in enumerate(quots):
+            s.quot_a[i], s.quot_b[i] = a, b
+        return s
+
+    def tm(mask, norm, ul, dl):
+        s = lldo.FuncSpec()
+        lldo._spec_common(s, ["Times"])
+        s.period = 0.01
+        s.times_mask, s.times_norm, s.n_ul, s.n_dl = mask, lldo.NORM[norm], len(ul), len(dl)
+        s.times_buggy_sec_norm = 1                          # the option's default (functionalTimes.cpp:76)
+        for i, v in enumerate(ul):
+            s.ul[i] = min(1.0, max(0.0, v))
+        for i, v in enumerate(dl):
+            s.dl[i] = min(1.0, max(0.0, v))
+        return s
+    return {"pq": pct(0x07, 1, (0.05, 0.5, 0.95), ((0, 2),), ((0, 2), (2, 0), (1, 1))),
+            "pq_norange": pct(0x38, 1, (0.1, 0.9), (), ((1, 0),)),
+            "pq_nointerp": pct(0, 0, (0.0, 1.0, 0.3), ((0, 1), (2, 1)), ((1, 0), (0, 1))),
+            "tm": tm(0x1fff, "segment", (0.1, 0.6, 1.5), (0.33, -0.2)),
+            "tm_sec": tm(0, "second", (0.5,), (0.5, 0.05)),
+            "tm_frame": tm(0x1fff, "frame", (0.25, 0.75), ())}
+
+
+def test_percentile_quotients_and_level_times_bit_exact(tmp_path):
+    """Percentiles.pctlquotient[] (functionalPercentiles.cpp:402-411: only under the range switch, zero numerators give 0, the soft
+    limiter at 50 / 100) and Times.upleveltime[] / downleveltime[] (functionalTimes.cpp:347-364) against the binary, on RMS and log
+    energy with silent stretches (tests/conf/quotients_leveltimes.conf)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = os.path.join(root, "tests", "conf", "quotients_leveltimes.conf")
+    cases = quot_time_cases()
+    for u, n in ((9, 48000), (3, 16000), (6, 1200), (71, 100000)):
+        R = _run_taps(conf, segments_pcm(u, n), tmp_path, False)
+        x = R("energy")
+        for k, s in cases.items():
+            ref = R("f_" + k)
+            got = lldo.funcspec(x, s).reshape(1, -1)
+            assert got.shape == ref.shape, (k, got.shape, ref.shape)
+            assert same(got, ref), (u, n, k, got, ref)
+
+
 def _run_taps(conf, pcm, tmp_path, cwd_taps):
     import os
     import subprocess
