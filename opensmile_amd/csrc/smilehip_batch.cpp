@@ -271,6 +271,10 @@ extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o)
 }
 
 // -------------------------------------------------------------------- run
+static bool serial_streams(int64_t total_frames) {
+  static const int forced = [] { const char *e = getenv("SMILEHIP_SERIAL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  return forced >= 0 ? forced != 0 : total_frames >= (int64_t)4000000;
+}
 static void fill_params(const smilehip_plan *p, const smilehip_batch *b, const int16_t *d_pcm, float *d_out,
                         int64_t ld, LldParams &P) {
   std::memset(&P, 0, sizeof(P));
@@ -671,8 +675,11 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream, false, plan->ev_fork);
   if (rc) return rc;
   if (fb->total_frames == 0) HIP_TRY(hipEventRecord(plan->ev_fork, s));
-  // SMILEHIP_SERIAL=1 (measurement aid): everything on the caller's stream, so that a kernel trace shows each kernel alone
-  static const bool serial = getenv("SMILEHIP_SERIAL") != nullptr;
+  // One stream for a batch that fills the device on its own (>= 4 M frames: every kernel is then many rounds of workgroups, and
+  // running two of them side by side only makes them share the caches: config 4 315 -> 313 ms, config 5 1266 -> 1239 ms); the
+  // side streams for smaller batches, whose one-wave-per-utterance passes leave most of the device idle (500 x 10 s: 32.8 -> 28.5 ms).
+  // SMILEHIP_SERIAL=1 / =0 forces one or the other (measurement aid: a kernel trace of the serial form shows each kernel alone).
+  const bool serial = serial_streams(b->total_frames);
   hipStream_t side = serial ? s : plan->side_stream;
   HIP_TRY(hipStreamWaitEvent(side, plan->ev_fork, 0));
   if ((rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, side, 65))) return rc;
@@ -745,8 +752,7 @@ static int egemaps_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   // The F0 group's frame kernels fill the device, its Viterbi and jitter passes are one wave per utterance: the 20 ms chain
   // (frame kernel, resampling + LPC, formant roots) starts on the side stream when the frame kernels are done
   hipError_t e = hipSuccess;
-  // SMILEHIP_SERIAL=1 (measurement aid): everything on the caller's stream, so that a kernel trace shows each kernel alone
-  static const bool serial = getenv("SMILEHIP_SERIAL") != nullptr;
+  const bool serial = serial_streams(b->total_frames);  // (see compare_full_run)
   hipStream_t side = serial ? s : plan->side_stream, bg = serial ? s : plan->bg_stream;
   if (fb->total_frames > 0) {
     int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch3.p, 3, stream, true, plan->ev_fork);   // SHS candidates -> Viterbi -> energy gate
