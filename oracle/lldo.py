@@ -729,6 +729,42 @@ def funcspec_names(s):
     return out
 
 
+
+class ModSpecCfg(C.Structure):
+    """lldo_modspec_cfg (oracle/lld_oracle_modspec.h)"""
+    _fields_ = [("period", C.c_double), ("min_freq", C.c_double), ("max_freq", C.c_double), ("win_frames", C.c_int32),
+                ("step_frames", C.c_int32), ("n_bins", C.c_int32), ("win_func", C.c_int32), ("remove_nz_mean", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def modspec_config(period=0.01, win_sec=4.0, step_sec=0.0, win_frames=None, step_frames=None, num_bins=None, resolution=0.5,
+                   min_freq=0.5, max_freq=20.0, win_func=2, remove_nz_mean=0):
+    """cFunctionalModulation's options (defaults as registered, functionalModulation.cpp:68-82) -> ModSpecCfg"""
+    c = ModSpecCfg()
+    L = lib()
+    L.lldo_modspec_config.restype = None
+    L.lldo_modspec_config.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.lldo_modspec_config(C.byref(c), period, win_sec, step_sec, int(win_frames is not None), int(win_frames or 0),
+                          int(step_frames is not None), int(step_frames or 0), int(num_bins is not None), int(num_bins or 0),
+                          resolution, min_freq, max_freq, win_func, remove_nz_mean)
+    return c
+
+
+def modspec(x, cfg):
+    """rows x cols matrix -> cols x n_bins modulation spectra (cFunctionalModulation per column)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    L = lib()
+    L.lldo_modspec_apply.restype = C.c_int
+    L.lldo_modspec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    out = np.zeros((x.shape[1], cfg.n_bins), np.float32)
+    for c in range(x.shape[1]):
+        col = np.ascontiguousarray(x[:, c])
+        if not L.lldo_modspec_apply(C.byref(cfg), col.ctypes.data, col.shape[0], out[c].ctypes.data):
+            raise ValueError("modulation spectrum: input outside what the restatement covers")
+    return out
+
+
 def funcspec(x, spec):
     """rows x cols matrix -> cols x count(spec) functionals."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -284,6 +284,30 @@ def test_percentile_quotients_and_level_times_bit_exact(tmp_path):
             assert same(got, ref), (u, n, k, got, ref)
 
 
+def modulation_cases():
+    """instance of tests/conf/modulation_family.conf -> lldo.ModSpecCfg"""
+    return {"ms": lldo.modspec_config(),
+            "ms_fr": lldo.modspec_config(win_frames=256, step_frames=100, num_bins=20, min_freq=1.0, max_freq=16.0, win_func=1),
+            "ms_nz": lldo.modspec_config(win_sec=2.0, step_sec=1.0, resolution=1.0, remove_nz_mean=1, win_func=0)}
+
+
+def test_modulation_spectrum_bit_exact(tmp_path):
+    """cFunctionalModulation (the Modulation family's ModulationSpec values: windowed STFT magnitudes of the contour, natural cubic
+    spline onto the modulation-frequency axis, average over the windows) against the binary: the default option set, a frame-based
+    set with a Hann window and its own axis, removeNonZeroMean with a rectangular window; contours of 98 .. 998 frames (one short
+    window zero-padded to its own power of two; several windows with a dropped short tail)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = os.path.join(root, "tests", "conf", "modulation_family.conf")
+    for u, n in ((9, 48000), (71, 160000), (3, 16000), (6, 70000)):
+        R = _run_taps(conf, segments_pcm(u, n), tmp_path, False)
+        x = R("energy")
+        for k, c in modulation_cases().items():
+            ref = R("f_" + k)
+            got = lldo.modspec(x, c).reshape(1, -1)
+            assert got.shape == ref.shape and same(got, ref), (u, n, k)
+
+
 def _run_taps(conf, pcm, tmp_path, cwd_taps):
     import os
     import subprocess
