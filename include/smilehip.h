@@ -343,12 +343,12 @@ int smilehip_functionals_matrix(smilehip_context *ctx, const float *d_x, int64_t
  *   Samples     (functionalSamples.cpp:100-117)    the contour at n_samples (<= 8) relative positions
  * Time norms: 0 = segment, 1 = second, 2 = frame (functionalComponent.hpp:27-33) -- the value AFTER the reference's
  * precedence rule (the family's own `norm` if set, else cFunctionals.masterTimeNorm, else the family default).
- * Not restated: Segments.useOldBuggyChX / growDynSegBuffer, Peaks2.noClearPeakList / debug outputs, the ModulationSpec
- * family -- a spec cannot express them. */
+ * Not restated: Segments.useOldBuggyChX / growDynSegBuffer, Peaks2.noClearPeakList / debug outputs, Times.useRobustPercentileRange,
+ * Modulation over the whole contour (stftWinSize 0) -- a spec cannot express them. */
 enum {
   SMILEHIP_FAM_EXTREMES = 0, SMILEHIP_FAM_MEANS, SMILEHIP_FAM_MOMENTS, SMILEHIP_FAM_REGRESSION, SMILEHIP_FAM_PERCENTILES,
   SMILEHIP_FAM_TIMES, SMILEHIP_FAM_SEGMENTS, SMILEHIP_FAM_LPC, SMILEHIP_FAM_PEAKS2, SMILEHIP_FAM_ONSET, SMILEHIP_FAM_PEAKS, SMILEHIP_FAM_CROSSINGS, SMILEHIP_FAM_DCT,
-  SMILEHIP_FAM_SAMPLES, SMILEHIP_FAM_COUNT
+  SMILEHIP_FAM_SAMPLES, SMILEHIP_FAM_MODULATION, SMILEHIP_FAM_COUNT
 };
 enum { SMILEHIP_NORM_SEGMENT = 0, SMILEHIP_NORM_SECOND = 1, SMILEHIP_NORM_FRAME = 2 };
 /* Segments.segmentationAlgorithm (functionalSegments.cpp:118-155). The reference parses ltX / gtX / geqX / leqX but has no
@@ -391,6 +391,13 @@ typedef struct smilehip_func_spec {
    * level * range + min, levels clipped to [0, 1]. (Times.useRobustPercentileRange is not built: a spec cannot ask for it.) */
   int32_t n_ul, n_dl, reserved7;
   double ul[8], dl[8];
+  /* Modulation (cFunctionalModulation, functionalModulation.cpp:452-566): mod_n_bins ModulationSpec values per contour -- the
+   * magnitude spectra of windows of mod_win_frames values every mod_step_frames (window function SMILEHIP_WIN_* of the window's
+   * own length, zero padding to the next power of two, the reference's rdft), mapped by a natural cubic spline onto mod_min_freq +
+   * i (mod_max_freq - mod_min_freq) / mod_n_bins Hz and averaged. Built for windows of 33 .. 1024 values (a contour needs >= 34
+   * rows) and <= 128 bins; stftWinSize 0 (one transform over the whole contour) is not built. */
+  int32_t mod_win_frames, mod_step_frames, mod_n_bins, mod_win_func, mod_remove_nz_mean, reserved8;
+  double mod_min_freq, mod_max_freq;
 } smilehip_func_spec;
 
 /* values per input column; < 0 (and smilehip_last_error) for a spec this library cannot run */

@@ -80,6 +80,9 @@ class FuncSpec(C.Structure):
         ("n_quot", C.c_int32), ("quot_a", C.c_int32 * 8), ("quot_b", C.c_int32 * 8),
         ("n_ul", C.c_int32), ("n_dl", C.c_int32), ("reserved7", C.c_int32),
         ("ul", C.c_double * 8), ("dl", C.c_double * 8),
+        ("mod_win_frames", C.c_int32), ("mod_step_frames", C.c_int32), ("mod_n_bins", C.c_int32), ("mod_win_func", C.c_int32),
+        ("mod_remove_nz_mean", C.c_int32), ("reserved8", C.c_int32),
+        ("mod_min_freq", C.c_double), ("mod_max_freq", C.c_double),
     ]
 
 

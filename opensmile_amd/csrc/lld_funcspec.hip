@@ -22,6 +22,7 @@
 
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
+#include "lld_ooura.hpp"
 
 namespace smilehip {
 
@@ -1510,6 +1511,99 @@ __global__ void __launch_bounds__(256) fs_percentiles_wave(FsParams P, int out_o
 // ------------------------------------------------------------------ launch
 int fs_sort_lds_rows() { return kSortLds; }
 
+// ------------------------------------------------------------------ Modulation (cFunctionalModulation, functionalModulation.cpp)
+// One wave per (utterance, column): the windows of the contour in turn -- window function of the window's own length (host table),
+// zero padding to the next power of two, the reference-order transform (lld_ooura.hpp, the in-place LDS form), magnitudes, the
+// natural cubic spline through them (two sequential recurrences in double on lane 0: smileMath_cspline, smileUtilSpline.c:155-211,
+// with the per-knot constants of mod_prepare), its values at the output bins (smileMath_csplint :344-357), added in window order;
+// the average of the windows that count (computeModSpecSTFTavg :452-478). A contour whose first window has fewer than 33 values,
+// or whose bins lie off a window's frequency axis, gives NaNs (the reference transforms down to 4 points; not built).
+namespace {
+struct ModG {
+  __device__ static __forceinline__ int tid() { return threadIdx.x & 63; }
+  __device__ static __forceinline__ int size() { return 64; }
+  __device__ static __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+}  // namespace
+
+__global__ void __launch_bounds__(64) fs_modulation(FsParams P, int out_off) {
+  __shared__ float2 z[512];
+  __shared__ double yv[516], y2[516], uu[516];
+  __shared__ float acc[128];
+  Where w;
+  w.u = blockIdx.x / P.n_cols;
+  w.c = blockIdx.x % P.n_cols;
+  w.on = true;
+  utt_rows(P, w);
+  const smilehip_func_spec &s = P.spec;
+  const int64_t Nin = P.st_n[(int64_t)w.u * P.n_cols + w.c];
+  if (Nin <= 0) return;
+  const Col x = data_col(P, w);
+  const int lane = threadIdx.x & 63, nb = s.mod_n_bins, W = s.mod_win_frames, step = s.mod_step_frames;
+  float *out = P.out + (int64_t)w.u * P.ld_out + (int64_t)w.c * P.per + out_off;
+  float mean = 0.0f;
+  if (s.mod_remove_nz_mean) {                            // :512-541 -- a FLOAT_DMEM chain; every lane walks it (uniform loads)
+    int64_t n_mean = 0;
+    for_rows(x, 0, Nin, [&](int64_t, float v) { if (v != 0.0f) { mean += v; n_mean++; } });
+    if (n_mean > 0) mean /= (float)n_mean;
+  }
+  const auto val = [&](int64_t t) {
+    const float v = x[t];
+    return s.mod_remove_nz_mean ? ((v != 0.0f) ? v - mean : 0.0f) : v;
+  };
+  for (int i = lane; i < nb; i += 64) acc[i] = 0.0f;
+  ModG::sync();
+  int n_spec = 0;
+  bool bad = false;
+  for (int64_t n = 0; n < Nin; n += step) {
+    const int64_t N = (W < Nin - n - 1) ? W : Nin - n - 1;
+    if (!(N > 2 * W / 3 || n_spec == 0)) continue;
+    if (N < 33) { bad = true; break; }
+    int si = 0;
+    while ((64 << si) < N) ++si;
+    ModSizeTab T;
+    switch (si) { case 0: T = P.mod.size[0]; break; case 1: T = P.mod.size[1]; break; case 2: T = P.mod.size[2]; break;
+                  case 3: T = P.mod.size[3]; break; default: T = P.mod.size[4]; break; }
+    if (!T.ok) { bad = true; break; }
+    const int M = 32 << si, Nmag = M + 1;
+    const float *wN = P.mod.win + N * (N - 1) / 2;
+    ooura_forward<ModG>(z, T.oo, [&](int i) {
+      const int64_t k0 = 2 * (int64_t)i, k1 = k0 + 1;
+      return make_float2(k0 < N ? val(n + k0) * wN[k0] : 0.0f, k1 < N ? val(n + k1) * wN[k1] : 0.0f);
+    });
+    for (int k = lane; k <= M; k += 64) {                // computeMagnitudes :224-232
+      const float2 X = ooura_bin(z, T.oo, k);
+      yv[k] = (double)((k == 0 || k == M) ? fabsf(X.x) : (float)sqrt((double)(X.x * X.x + X.y * X.y)));
+    }
+    ModG::sync();
+    if (lane == 0) {
+      uu[0] = 0.0; y2[0] = 0.0;
+      for (int i = 1; i < Nmag - 1; ++i) {
+        const double sg = T.sigma[i];
+        const double p = 1.0 / (sg * y2[i - 1] + 2.0);
+        y2[i] = (sg - 1.0) * p;
+        const double ut = (yv[i + 1] - yv[i]) / T.d1[i] - (yv[i] - yv[i - 1]) / T.d2[i];
+        uu[i] = p * (6.0 * ut - sg * uu[i - 1]);
+      }
+      y2[Nmag - 1] = (0.0 - 0.0 * uu[Nmag - 2]) / (0.0 * y2[Nmag - 2] + 1.0);
+      for (int j = Nmag - 2; j >= 0; --j) y2[j] = y2[j] * y2[j + 1] + uu[j];
+    }
+    ModG::sync();
+    for (int i = lane; i < nb; i += 64) {
+      const double a = T.co[3 * i], b = 1.0 - a, c = T.co[3 * i + 1], d = T.co[3 * i + 2];
+      const int k = T.k[i];
+      acc[i] += (float)(a * yv[k] + b * yv[k + 1] + c * y2[k] + d * y2[k + 1]);
+    }
+    ModG::sync();
+    n_spec++;
+  }
+  for (int i = lane; i < nb; i += 64)
+    out[i] = bad ? __int_as_float(0x7fc00000) : (n_spec > 0 ? acc[i] / (float)n_spec : acc[i]);
+}
+
 hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s) {
   if (n_utt <= 0 || P.n_cols <= 0) return hipSuccess;
   const int groups = (P.n_cols + kColsPerBlock - 1) / kColsPerBlock;
@@ -1531,6 +1625,9 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
       case SMILEHIP_FAM_CROSSINGS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_CROSSINGS>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_DCT: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_DCT>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_SAMPLES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SAMPLES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_MODULATION:
+        hipLaunchKernelGGL(fs_modulation, dim3((unsigned)(n_utt * P.n_cols)), dim3(64), 0, s, P, off);
+        break;
       case SMILEHIP_FAM_PERCENTILES:
         hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
         if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts

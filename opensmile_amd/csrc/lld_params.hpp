@@ -255,6 +255,21 @@ struct SpectralConsts {
 
 // General functionals (lld_funcspec.hip): one cFunctionals instance over columns [col_first, col_first + n_cols) of
 // the utterances' rows (or of ONE matrix if single_rows >= 0).
+// Tables of the Modulation family (lld_funcspec.hip: fs_modulation; built by smilehip_funcspec.cpp: mod_prepare). size[s] serves
+// the transform length n = 64 << s: the reference-order transform's tables, the spline's per-knot constants over the axis
+// i / (T n) (smileMath_cspline_init, smileUtilSpline.c:138-153) and, per output bin, the knot below it and the three
+// coefficients of smileMath_csplint_init (:295-342); ok = 0: the bins do not lie on that axis.
+struct ModSizeTab {
+  OouraTab oo;
+  const double *sigma, *d1, *d2, *co;
+  const int32_t *k;
+  int32_t ok, pad;
+};
+struct ModTables {
+  const float *win;            // the window function of every length N <= mod_win_frames, length N at N (N - 1) / 2
+  ModSizeTab size[5];
+};
+
 struct FsParams {
   smilehip_func_spec spec;
   const float *x;
@@ -276,6 +291,7 @@ struct FsParams {
   float *out;                // [n_utt x ld_out]
   int64_t ld_out;
   int64_t max_rows;          // upper bound of the rows of any column (host knowledge): decides whether the workgroup sort is launched
+  ModTables mod;             // Modulation family only
 };
 
 // R13: chain of window processors (cDeltaRegression / cContourSmoother) over the

@@ -85,6 +85,15 @@ int family_count(const smilehip_func_spec &s, int fam) {
       for (int i = 0; i < s.n_samples; ++i)
         if (!(s.sample_pos[i] >= 0.0 && s.sample_pos[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Samples: samplepos[%d] = %g not in [0, 1]", i, s.sample_pos[i]);
       return s.n_samples;
+    case SMILEHIP_FAM_MODULATION:
+      if (s.mod_win_frames < 33 || s.mod_win_frames > 1024)
+        return fail(SMILEHIP_ERR_INVALID, "Modulation: windows of 33 .. 1024 values are built (stftWinSize %d; 0 = the whole contour is not)", s.mod_win_frames);
+      if (s.mod_step_frames < 1) return fail(SMILEHIP_ERR_INVALID, "Modulation: stftWinStep must be >= 1");
+      if (s.mod_n_bins < 1 || s.mod_n_bins > 128) return fail(SMILEHIP_ERR_INVALID, "Modulation: 1 .. 128 bins (%d)", s.mod_n_bins);
+      if (s.mod_win_func < SMILEHIP_WIN_RECT || s.mod_win_func > SMILEHIP_WIN_LANCZOS || s.mod_win_func == SMILEHIP_WIN_GAUSS)
+        return fail(SMILEHIP_ERR_INVALID, "Modulation: window function %d (the reference has rectangle, Hann, Hamming, sine, triangle, Bartlett, Lanczos here)", s.mod_win_func);
+      if (!(s.mod_max_freq > s.mod_min_freq) || !(s.mod_min_freq >= 0.0)) return fail(SMILEHIP_ERR_INVALID, "Modulation: frequency axis %g .. %g Hz", s.mod_min_freq, s.mod_max_freq);
+      return s.mod_n_bins;
   }
   return fail(SMILEHIP_ERR_INVALID, "unknown functional family %d", fam);
 }
@@ -171,6 +180,107 @@ int launch_spec(FsParams &P, int n_utt, hipStream_t stream) {
   return SMILEHIP_OK;
 }
 
+// ---- Modulation: the device tables of one option set (ModTables, lld_params.hpp), kept in the context
+}  // namespace
+struct ModCache {
+  int32_t ki[4] = {0, 0, 0, 0};
+  double kd[3] = {0, 0, 0};
+  DevBuf<float> d_win;
+  OouraDev oo[5];
+  DevBuf<double> d_dbl;
+  DevBuf<int32_t> d_k;
+  ModTables tabs{};
+};
+void mod_cache_free(ModCache *m) { delete m; }
+namespace {
+int mod_prepare(smilehip_context *ctx, const smilehip_func_spec &s, ModTables &out) {
+  if (!ctx->mod) ctx->mod = new (std::nothrow) ModCache();
+  ModCache *m = ctx->mod;
+  if (!m) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  const int32_t ki[4] = {s.mod_win_frames, s.mod_n_bins, s.mod_win_func, 0};
+  const double kd[3] = {s.period, s.mod_min_freq, s.mod_max_freq};
+  if (m->tabs.win && !std::memcmp(ki, m->ki, sizeof(ki)) && !std::memcmp(kd, m->kd, sizeof(kd))) { out = m->tabs; return SMILEHIP_OK; }
+  HIP_TRY(hipDeviceSynchronize());                      // (launches that read the previous option set's tables)
+  const int W = s.mod_win_frames, nb = s.mod_n_bins;
+  // the window function of every length a window can have (cSmileUtilWindowedMagnitudeSpectrum::allocateWinFunc: the values of
+  // smileDsp_win* in double, stored as FLOAT_DMEM), lengths below 33 never reach the transform
+  std::vector<float> win(size_t(W) * size_t(W + 1) / 2, 0.0f), w1;
+  smilehip_lld_config wc;
+  std::memset(&wc, 0, sizeof(wc));
+  wc.win_func = s.mod_win_func; wc.win_sigma = 0.4; wc.win_gain = 1.0;
+  for (int N = 33; N <= W; ++N) {
+    int rc = make_window(wc, N, w1);
+    if (rc) return fail(rc, "Modulation: window function %d", s.mod_win_func);
+    std::memcpy(win.data() + size_t(N) * size_t(N - 1) / 2, w1.data(), size_t(N) * sizeof(float));
+  }
+  int rc = m->d_win.upload(win);
+  if (rc) return rc;
+  std::vector<double> dbl;
+  std::vector<int32_t> kk;
+  size_t off_d[5][2] = {}, off_k[5] = {};
+  int ok[5] = {0, 0, 0, 0, 0};
+  const double T = (double)(float)s.period;             // the constructor's T is the FLOAT_DMEM period (functionalModulation.cpp:485)
+  for (int si = 0; si < 5; ++si) {
+    const int n = 64 << si;
+    if (si > 0 && (64 << (si - 1)) >= W) break;                               // no window reaches this length (n / 2 >= W)
+    if ((rc = m->oo[si].build(n, true))) return rc;
+    const int Nmag = n / 2 + 1;
+    const double dfm = (T == 0.0) ? 0.0 : 1.0 / (T * (double)n);
+    std::vector<double> x((size_t)Nmag);
+    for (int i = 0; i < Nmag; ++i) x[i] = (double)i * dfm;
+    off_d[si][0] = dbl.size();
+    dbl.resize(dbl.size() + 3 * (size_t)Nmag, 0.0);
+    double *sigma = dbl.data() + off_d[si][0], *d1 = sigma + Nmag, *d2 = d1 + Nmag;
+    for (int i = 1; i < Nmag - 1; ++i) {                                      // smileMath_cspline_init, smileUtilSpline.c:138-153
+      sigma[i] = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+      d1[i] = (x[i + 1] - x[i]) * (x[i + 1] - x[i - 1]);
+      d2[i] = (x[i] - x[i - 1]) * (x[i + 1] - x[i - 1]);
+    }
+    off_d[si][1] = dbl.size();
+    dbl.resize(dbl.size() + 3 * (size_t)nb, 0.0);
+    off_k[si] = kk.size();
+    kk.resize(kk.size() + (size_t)nb, 0);
+    double *co = dbl.data() + off_d[si][1];
+    int32_t *kp = kk.data() + off_k[si];
+    const double dF = (s.mod_max_freq - s.mod_min_freq) / (double)nb;         // functionalModulation.cpp:311: over Nout
+    bool good = !(s.mod_min_freq < x[0] || s.mod_min_freq + (double)(nb - 1) * dF > x[Nmag - 1]);
+    int hi = 1;
+    for (int i = 0; i < nb && good; ++i) {                                    // smileMath_csplint_init, :295-342
+      const double xt = s.mod_min_freq + (double)i * dF;
+      while (hi < Nmag && x[hi] < xt) hi++;
+      if (hi == Nmag) { good = false; break; }
+      const int lo = hi - 1;
+      const double range = x[hi] - x[lo];
+      if (range == 0.0) { good = false; break; }
+      const double a = (x[hi] - xt) / range, bq = 1.0 - a, r2 = range * range / 6.0;
+      kp[i] = lo;
+      co[3 * i] = a;
+      co[3 * i + 1] = (a * a * a - a) * r2;
+      co[3 * i + 2] = (bq * bq * bq - bq) * r2;
+    }
+    ok[si] = good ? 1 : 0;
+  }
+  if ((rc = m->d_dbl.upload(dbl)) || (rc = m->d_k.upload(kk))) return rc;
+  ModTables tb{};
+  tb.win = m->d_win.p;
+  for (int si = 0; si < 5; ++si) {
+    if (!m->oo[si].d_tw.p) continue;
+    const int Nmag = (64 << si) / 2 + 1;
+    tb.size[si].oo = m->oo[si].tab();
+    tb.size[si].sigma = m->d_dbl.p + off_d[si][0];
+    tb.size[si].d1 = tb.size[si].sigma + Nmag;
+    tb.size[si].d2 = tb.size[si].d1 + Nmag;
+    tb.size[si].co = m->d_dbl.p + off_d[si][1];
+    tb.size[si].k = m->d_k.p + off_k[si];
+    tb.size[si].ok = ok[si];
+  }
+  m->tabs = tb;
+  std::memcpy(m->ki, ki, sizeof(ki));
+  std::memcpy(m->kd, kd, sizeof(kd));
+  out = tb;
+  return SMILEHIP_OK;
+}
+
 int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows, int64_t max_rows, hipStream_t stream) {
   const int per = spec_layout(&P.spec, nullptr, nullptr);
   if (per < 0) return per;
@@ -179,6 +289,8 @@ int run_spec(smilehip_context *ctx, FsParams &P, int n_utt, int64_t scratch_rows
   if (rc) return rc;
   fs_carve(static_cast<char *>(ctx->fs_scratch), P, need);
   P.max_rows = max_rows;
+  std::memset(&P.mod, 0, sizeof(P.mod));
+  if (has_family(P.spec, SMILEHIP_FAM_MODULATION) && (rc = mod_prepare(ctx, P.spec, P.mod))) return rc;
   return launch_spec(P, n_utt, stream);
 }
 

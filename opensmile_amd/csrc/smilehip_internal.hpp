@@ -32,6 +32,8 @@ int fail(int code, const char *fmt, ...);   // records the thread-local message,
   } while (0)
 
 // ----------------------------------------------------------------- objects
+struct ModCache;
+void mod_cache_free(ModCache *m);           // smilehip_funcspec.cpp
 struct smilehip_context {
   int device = 0;
   hipDeviceProp_t prop{};
@@ -43,7 +45,10 @@ struct smilehip_context {
   hipStream_t fs_stream[kFsStreams] = {};
   hipEvent_t fs_done[kFsStreams] = {}, fs_fork = nullptr;
   bool fs_streams_ready = false;
+  // device tables of the Modulation functional family, kept for the last option set used (smilehip_funcspec.cpp)
+  struct ModCache *mod = nullptr;
   ~smilehip_context() {
+    mod_cache_free(mod);
     if (fs_scratch) (void)hipFree(fs_scratch);
     if (fs_streams_ready) {
       for (int k = 0; k < kFsStreams; ++k) { (void)hipStreamDestroy(fs_stream[k]); (void)hipEventDestroy(fs_done[k]); }

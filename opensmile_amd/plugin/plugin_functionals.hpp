@@ -251,6 +251,32 @@ class cHipFunctionals : public cFunctionals {
           s.n_samples = 5;
           for (int j = 0; j < 5; ++j) s.sample_pos[j] = (double)j / (5 - 1.0);
         }
+      } else if (!strcmp(f, "Modulation")) {
+        // cFunctionalModulation::myFetchConfig (functionalModulation.cpp:375-418) and the first call of ::process (:483-496)
+        s.fam[s.n_fam++] = SMILEHIP_FAM_MODULATION;
+        const double per = getInputPeriod();
+        if (!(per > 0.0)) return false;                   // (the reference cannot compute it either: T = 0)
+        double win_sec = opt_dbl(f, "stftWinSizeSec"), step_sec = opt_dbl(f, "stftWinStepSec");
+        if (step_sec == 0.0) step_sec = win_sec;
+        long wf = 0, sf = 0;
+        if (opt_set(f, "stftWinSizeFrames")) { wf = opt_int(f, "stftWinSizeFrames"); win_sec = 0.0; }
+        if (opt_set(f, "stftWinStepFrames")) { sf = opt_int(f, "stftWinStepFrames"); step_sec = 0.0; }
+        if (sf == 0) sf = wf;
+        const float T = (float)per;
+        if (wf == 0) { wf = (long)(win_sec / T); sf = (long)(step_sec / T); }
+        if (wf < 33 || wf > 1024 || sf < 1) return false; // (0: one transform over the whole contour -- not built)
+        s.mod_win_frames = (int32_t)wf;
+        s.mod_step_frames = (int32_t)sf;
+        s.mod_min_freq = opt_dbl(f, "modSpecMinFreq");
+        s.mod_max_freq = opt_dbl(f, "modSpecMaxFreq");
+        if (opt_set(f, "modSpecNumBins")) s.mod_n_bins = opt_int(f, "modSpecNumBins");
+        else s.mod_n_bins = (int)round((s.mod_max_freq - s.mod_min_freq) / opt_dbl(f, "modSpecResolution")) + 1;
+        if (s.mod_n_bins < 1 || s.mod_n_bins > 128) return false;
+        const char *wfn = getStr_f(myvprint("%s.fftWinFunc", f));
+        int wid = winfunc_id(wfn);
+        if (wid < 0 || wid == SMILEHIP_WIN_GAUSS) wid = SMILEHIP_WIN_RECT;      // allocateWinFunc :133-146: any other shape falls back to the rectangle
+        s.mod_win_func = wid;
+        s.mod_remove_nz_mean = opt_int(f, "removeNonZeroMean") ? 1 : 0;
       } else if (!strcmp(f, "Onset")) {
         s.fam[s.n_fam++] = SMILEHIP_FAM_ONSET;
         static const char *const o[5] = {"onsetPos", "offsetPos", "numOnsets", "numOffsets", "onsetRate"};
@@ -261,7 +287,7 @@ class cHipFunctionals : public cFunctionals {
         if (opt_set(f, "thresholdOnset")) s.ons_thr_on = (float)opt_dbl(f, "thresholdOnset");
         if (opt_set(f, "thresholdOffset")) s.ons_thr_off = (float)opt_dbl(f, "thresholdOffset");
       } else {
-        return false;                                     // a family that is not built (ModulationSpec, ...)
+        return false;                                     // a family that is not built
       }
     }
     return smilehip_funcspec_count(&s) == nFunctValues;
@@ -284,7 +310,7 @@ class cHipFunctionals : public cFunctionals {
       return nFunctValues;
     }
     if (state_ < 0) state_ = build_spec() ? 1 : 0;
-    if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Crossings, DCT, Onset, Peaks, Samples, ModulationSpec, pctlquotient, ...)"); return cFunctionals::doProcess(i, row, y); }
+    if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Modulation over the whole contour, Times.useRobustPercentileRange, Segments.growDynSegBuffer, Peaks.overlapFlag = 0, ...)"); return cFunctionals::doProcess(i, row, y); }
     io_.ensure(row->nT, nFunctValues);
     io_.up(row->data, row->nT);
     check(smilehip_funcspec_matrix(context(), &spec_, io_.d_in, 1, row->nT, 1, io_.d_out, nullptr));

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "lld_oracle_funcspec.h"
+#include "lld_oracle_modspec.h"
 
 static int popc(uint32_t v) { int n = 0; while (v) { n += (int)(v & 1u); v >>= 1; } return n; }
 #define BIT(m, i) (((m) >> (i)) & 1u)
@@ -43,6 +44,7 @@ static int fam_count(const lldo_func_spec *s, int fam)
     case LLDO_FAM_CROSSINGS: return popc(s->crs_mask & 0x7u);
     case LLDO_FAM_DCT: return s->dct_last >= s->dct_first && s->dct_first >= 0 ? s->dct_last - s->dct_first + 1 : -1;
     case LLDO_FAM_SAMPLES: return s->n_samples >= 1 && s->n_samples <= 8 ? s->n_samples : -1;
+    case LLDO_FAM_MODULATION: return s->mod_n_bins >= 1 && s->mod_n_bins <= 128 && s->mod_win_frames >= 33 && s->mod_win_frames <= 1024 && s->mod_step_frames >= 1 ? s->mod_n_bins : -1;
   }
   return -1;
 }
@@ -1270,6 +1272,15 @@ int lldo_funcspec_apply(const lldo_func_spec *s, const float *x, int64_t ld, int
         case LLDO_FAM_CROSSINGS: got = f_crossings(s, col, o, NN); break;
         case LLDO_FAM_DCT: got = f_dct(s, col, o, NN); break;
         case LLDO_FAM_SAMPLES: got = f_samples(s, col, o, NN); break;
+        case LLDO_FAM_MODULATION: {                          /* lld_oracle_modspec.c; an input it does not cover gives NaNs */
+          lldo_modspec_cfg mc;
+          memset(&mc, 0, sizeof(mc));
+          mc.period = s->period; mc.min_freq = s->mod_min_freq; mc.max_freq = s->mod_max_freq;
+          mc.win_frames = s->mod_win_frames; mc.step_frames = s->mod_step_frames; mc.n_bins = s->mod_n_bins;
+          mc.win_func = s->mod_win_func; mc.remove_nz_mean = s->mod_remove_nz_mean;
+          if (!lldo_modspec_apply(&mc, col, NN, o)) for (int q = 0; q < s->mod_n_bins; q++) o[q] = NAN;
+          got = s->mod_n_bins;
+          break; }
       }
       for (int j = got; j < want; j++) o[j] = 0.0f;
       o += want;

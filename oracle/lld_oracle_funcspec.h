@@ -8,7 +8,7 @@
 
 enum {
   LLDO_FAM_EXTREMES = 0, LLDO_FAM_MEANS, LLDO_FAM_MOMENTS, LLDO_FAM_REGRESSION, LLDO_FAM_PERCENTILES,
-  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_CROSSINGS, LLDO_FAM_DCT, LLDO_FAM_SAMPLES, LLDO_FAM_COUNT
+  LLDO_FAM_TIMES, LLDO_FAM_SEGMENTS, LLDO_FAM_LPC, LLDO_FAM_PEAKS2, LLDO_FAM_ONSET, LLDO_FAM_PEAKS, LLDO_FAM_CROSSINGS, LLDO_FAM_DCT, LLDO_FAM_SAMPLES, LLDO_FAM_MODULATION, LLDO_FAM_COUNT
 };
 enum { LLDO_NORM_SEGMENT = 0, LLDO_NORM_SECOND = 1, LLDO_NORM_FRAME = 2 };   /* functionalComponent.hpp:27-33 */
 /* functionalSegments.cpp:118-155; ltX / gtX / geqX / leqX are parsed there but fall to the switch's default (:872-874): delta */
@@ -63,6 +63,9 @@ typedef struct lldo_func_spec {
    * level * range + min */
   int32_t n_ul, n_dl, reserved7;
   double ul[8], dl[8];
+  /* Modulation (lld_oracle_modspec.c): window / step in values, number of bins, LLDO_WIN_* window, removeNonZeroMean, axis */
+  int32_t mod_win_frames, mod_step_frames, mod_n_bins, mod_win_func, mod_remove_nz_mean, reserved8;
+  double mod_min_freq, mod_max_freq;
 } lldo_func_spec;
 
 /* values per input column; < 0 for an unusable spec */

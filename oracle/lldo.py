@@ -538,7 +538,7 @@ def htk_variant_chain(name, pcm):
 
 # ---- general functionals engine (lld_oracle_funcspec.c) ---------------------------------------------------------
 FAM = {"Extremes": 0, "Means": 1, "Moments": 2, "Regression": 3, "Percentiles": 4, "Times": 5, "Segments": 6, "Lpc": 7,
-       "Peaks2": 8, "Onset": 9, "Peaks": 10, "Crossings": 11, "DCT": 12, "Samples": 13}
+       "Peaks2": 8, "Onset": 9, "Peaks": 10, "Crossings": 11, "DCT": 12, "Samples": 13, "Modulation": 14}
 NORM = {"segment": 0, "second": 1, "frame": 2}
 EXT_NAMES = ["max", "min", "range", "maxPos", "minPos", "amean", "maxameandist", "minameandist"]
 MEANS_NAMES = ["amean", "absmean", "qmean", "nzamean", "nzabsmean", "nzqmean", "nzgmean", "nnz", "flatness", "posamean",
@@ -593,6 +593,9 @@ class FuncSpec(C.Structure):
         ("n_quot", C.c_int32), ("quot_a", C.c_int32 * 8), ("quot_b", C.c_int32 * 8),
         ("n_ul", C.c_int32), ("n_dl", C.c_int32), ("reserved7", C.c_int32),
         ("ul", C.c_double * 8), ("dl", C.c_double * 8),
+        ("mod_win_frames", C.c_int32), ("mod_step_frames", C.c_int32), ("mod_n_bins", C.c_int32), ("mod_win_func", C.c_int32),
+        ("mod_remove_nz_mean", C.c_int32), ("reserved8", C.c_int32),
+        ("mod_min_freq", C.c_double), ("mod_max_freq", C.c_double),
     ]
 
 
@@ -726,6 +729,8 @@ def funcspec_names(s):
             out += ["dct%d" % k for k in range(s.dct_first, s.dct_last + 1)]
         elif f == "Samples":
             out += ["sample%.3f" % s.sample_pos[k] for k in range(s.n_samples)]
+        elif f == "Modulation":
+            out += ["ModulationSpec%d" % k for k in range(s.mod_n_bins)]
     return out
 
 

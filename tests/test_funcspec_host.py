@@ -12,7 +12,7 @@ EXPECTED = {"A": 31, "B": 31, "F0": 5, "Nz": 39, "LLD": 23, "Delta": 15}
 
 
 def test_spec_layout_matches_oracle(oracle):
-    assert C.sizeof(capi.FuncSpec) == C.sizeof(oracle.FuncSpec) == 744
+    assert C.sizeof(capi.FuncSpec) == C.sizeof(oracle.FuncSpec) == 784
     assert [f for f, _ in capi.FuncSpec._fields_] == [f for f, _ in oracle.FuncSpec._fields_]
 
 

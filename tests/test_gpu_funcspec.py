@@ -234,6 +234,37 @@ def test_funcspec_percentile_quotients_and_level_times(hip, oracle):
                     assert np.array_equal(dev[:, c].view(np.uint32), ref[:, c].view(np.uint32)), (k, n_rows, nm, dev[:, c], ref[:, c])
 
 
+def test_funcspec_modulation_spectrum(hip, oracle):
+    """The Modulation family (cFunctionalModulation's ModulationSpec values; the oracle's restatement is pinned on the binary in
+    test_oracle_pin_is10.py::test_modulation_spectrum_bit_exact): the three pinned option sets on contours of 40 .. 2500 rows (one
+    short window zero-padded to 64 / 128 / 512 points, several windows with a dropped tail), with and without nonZeroFuncts, next
+    to another family in the same instance. Every value the oracle's bits; a contour too short for the 33-value limit gives NaNs
+    on both sides."""
+    capi, ctx = hip
+    from test_oracle_pin_is10 import modulation_cases
+    rng = np.random.default_rng(31)
+    for n_rows in (40, 98, 300, 998, 2500, 20):
+        x = np.abs(np.cumsum(rng.standard_normal((n_rows, 5)), axis=0)).astype(np.float32)
+        x[n_rows // 4: n_rows // 3, :2] = 0.0
+        for k, mc in modulation_cases().items():
+            for nz in (0, 1):
+                s = capi.FuncSpec()
+                s.n_fam, s.period, s.non_zero_functs = 2, 0.01, nz
+                s.fam[0], s.fam[1] = 14, 0
+                s.ext_mask, s.ext_norm = 0x07, 2
+                s.mod_win_frames, s.mod_step_frames, s.mod_n_bins = mc.win_frames, mc.step_frames, mc.n_bins
+                s.mod_win_func, s.mod_remove_nz_mean = mc.win_func, mc.remove_nz_mean
+                s.mod_min_freq, s.mod_max_freq = mc.min_freq, mc.max_freq
+                dev = capi.funcspec_matrix_host(ctx, s, x)
+                ref = oracle.funcspec(x, as_oracle_spec(oracle, s))
+                assert dev.shape == ref.shape == (5, mc.n_bins + 3)
+                assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32)) or \
+                    (np.isnan(ref[:, :mc.n_bins]).all() and np.isnan(dev[:, :mc.n_bins]).all() and
+                     np.array_equal(dev[:, mc.n_bins:].view(np.uint32), ref[:, mc.n_bins:].view(np.uint32))), (k, n_rows, nz, dev[0, :4], ref[0, :4])
+                if n_rows >= 40 and not nz:
+                    assert np.isfinite(ref).all(), (k, n_rows)
+
+
 def test_batch_funcspec_ragged_with_cut_and_extra_row(hip, oracle):
     """smilehip_batch_funcspec on a ragged batch: per-utterance rows = max(1, rows - cut) (+ one extra row), column
     sub-ranges, utterances without rows."""

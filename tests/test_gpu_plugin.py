@@ -685,6 +685,21 @@ def test_plugin_percentile_quotients_and_level_times(oracle):
         assert len(ref[k]) > 12 and own[k] == ref[k], k
 
 
+def test_plugin_modulation_family(oracle):
+    """tests/conf/modulation_family.conf: three cFunctionals instances with the Modulation family (default options; frame-based
+    windows, Hann, its own axis; removeNonZeroMean, rectangle) behind the plugin: every tap the plain binary's bytes, nothing on
+    the CPU."""
+    conf = os.path.join(ROOT, "tests", "conf", "modulation_family.conf")
+    from opensmile_amd import synth
+    for pcm in (_segments_pcm(), synth.utterance(71, 160000)):
+        ref, tr0 = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
+        own, tr = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, conf)
+        assert not any(tr0.values()) and len(ref) == 4 and sorted(own) == sorted(ref)
+        assert tr.get("cFunctionals", 0) >= 3 and not [k for k, v in tr.items() if k.endswith(".cpu") and v], tr
+        for k in ref:
+            assert len(ref[k]) > 12 and own[k] == ref[k], k
+
+
 def test_plugin_refuses_what_is_not_built(oracle):
     """A cFunctionals instance with an option that is not an operator of the library (Segments.growDynSegBuffer: the segment buffer
     that grows past maxNumSeg): the override says so and the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 that
