@@ -154,7 +154,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   // (multiples of four: a frame's lane group is its index mod 4).
   if (plan->use_fast && (plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) &&
       plan->cfg.n_delta == 2 && plan->cfg.delta_win == 2 && !plan->cfg.append_log_energy && !plan->cfg.cms && plan->ctx &&
-      b->total_frames > 0 && !getenv("SMILEHIP_NO_FUSED_DELTA")) {
+      b->total_frames > 0 && b->all_even && !getenv("SMILEHIP_NO_FUSED_DELTA")) {     // (all_even: the dword loads of the aligned instance)
     const int64_t slots = std::max<int64_t>(1, plan->fast.max_blocks) * 8;
     const auto parts_of = [&](int64_t T, int64_t L) { return (T + L - 1) / L; };
     int64_t bestL = 32;
