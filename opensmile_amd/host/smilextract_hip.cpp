@@ -34,6 +34,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <future>
 #include <map>
 #include <mutex>
@@ -52,8 +53,10 @@ namespace {
 
 struct Job { std::string wav, inst; };
 
+std::function<void()> g_before_exit;                    // waits for the ingest thread that reads ahead (exit() under a running thread is a crash at best)
 [[noreturn]] void die(const std::string &m) {
   fprintf(stderr, "smilextract_hip: %s\n", m.c_str());
+  if (g_before_exit) { auto f = g_before_exit; g_before_exit = nullptr; f(); }
   exit(1);
 }
 void check(int rc, const char *what) {
@@ -373,6 +376,7 @@ int main(int argc, char **argv) {
     return c;
   };
   std::future<Chunk> ahead = std::async(std::launch::async, ingest, (size_t)0);
+  g_before_exit = [&] { if (ahead.valid()) ahead.wait(); };
   for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_files) {
     const size_t j1 = std::min(jobs.size(), j0 + chunk_files);
     Chunk chunk = ahead.get();
@@ -479,7 +483,7 @@ int main(int argc, char **argv) {
       std::string sink_err;
       parallel_for(idx.size(), [&](size_t i) {
         std::string err;                                  // (shadows the function's: one per thread)
-        auto die = [&](const std::string &m) { std::lock_guard<std::mutex> g(sink_m); if (sink_err.empty()) sink_err = m; };
+        auto die = [&](const std::string &m) { std::lock_guard<std::mutex> g(sink_m); if (sink_err.empty()) sink_err = m; };   // (the caller returns: no further sink of this file)
         const Job &job = jobs[idx[i]];
         const float *x = lld.data() + (size_t)row_off[i] * n_out;
         const int64_t r = row_off[i + 1] - row_off[i];
@@ -488,7 +492,7 @@ int main(int argc, char **argv) {
         if (out_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
         const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
         if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
-          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)) die(err);
+          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)) { die(err); return; }
         if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
           CsvOptions co;
           co.instance_name = job.inst;
@@ -497,8 +501,10 @@ int main(int argc, char **argv) {
           std::vector<double> times((size_t)r);
           for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
           if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_w, n_w, g.frame_period,
-                         times.data(), co, err))
+                         times.data(), co, err)) {
             die(err);
+            return;
+          }
         }
         if (has_func && r > 0) {                          // no frame -> the reference writes no instance
           const float *fv = func.data() + i * (size_t)n_func;
@@ -507,7 +513,7 @@ int main(int argc, char **argv) {
           if (out_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
           func_rows[idx[i] - j0].assign(fv, fv + n_fw);
           if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
-            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) die(err);
+            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) { die(err); return; }
         }
       });
       if (!sink_err.empty()) die(sink_err);
@@ -597,5 +603,6 @@ int main(int argc, char **argv) {
   if (comm) comm_destroy(comm);
   for (auto &kv : plans) smilehip_plan_destroy(kv.second);
   smilehip_shutdown(ctx);
+  g_before_exit = nullptr;
   return 0;
 }
