@@ -33,6 +33,12 @@ int smilehip_comm_gather_rows(smilehip_comm *c, const float *d_rows, const int64
  * Exported for the CPU tests. */
 int smilehip_comm_bootstrap_bcast(int rank, int world, const char *master_addr, int master_port, void *buf, int32_t len);
 
+/* One grouped ncclSend / ncclRecv pair to the caller's own rank (n floats, device pointers, non-overlapping): the gather's
+ * point-to-point primitives on a single device. Diagnostic / test entry point. */
+int smilehip_comm_self_sendrecv(smilehip_comm *c, const float *d_src, float *d_dst, int64_t n, void *stream);
+/* RCCL's version code (ncclGetVersion) */
+int smilehip_comm_rccl_version(int *version);
+
 const char *smilehip_comm_last_error(void);
 
 #ifdef __cplusplus

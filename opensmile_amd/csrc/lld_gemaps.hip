@@ -1207,6 +1207,8 @@ hipError_t launch_harm_g(const LldParams &P, const F0Params &Q, const GemapsPara
   if (e != hipSuccess) return e;
   unsigned grid = (unsigned)((n_tiles + HG::kWaves - 1) / HG::kWaves);
   if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);   // M = 512: 78 KB of LDS per workgroup, two per CU
+  // (the tile counter starts from zero at every launch, whatever an earlier launch left behind)
+  if (G.harm_ctl && (e = hipMemsetAsync(G.harm_ctl, 0, 2 * sizeof(int32_t), s)) != hipSuccess) return e;
   hipLaunchKernelGGL(lld_gemaps_harm<LOGM>, dim3(grid), dim3(HG::kWaves * 64), lds, s, P, Q, G);
   return hipGetLastError();
 }

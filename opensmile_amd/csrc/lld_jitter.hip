@@ -635,6 +635,10 @@ hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *
   if (per_cu < 1) per_cu = 1;
   int64_t grid = (int64_t)per_cu * (max_cus > 0 ? max_cus : 256);
   if (grid > Q.n_jit_items) grid = Q.n_jit_items;
+  // the counters and the redo marks start from zero at EVERY launch (not only at batch creation): a launch that faulted, or a run
+  // the caller abandoned, must not leave later runs skipping items
+  if ((e = hipMemsetAsync(Q.jit_ctl, 0, 2 * sizeof(int32_t), s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(Q.jit_redo, 0, sizeof(int32_t) * (size_t)P.n_utt, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(lld_jitter_runs, dim3((unsigned)grid), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, mark_all ? 1 : 0);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_jitter_utt(P, Q, d_f0, ld_f0, d_jit4, Q.jit_redo, s);

@@ -159,12 +159,15 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     const auto parts_of = [&](int64_t T, int64_t L) { return (T + L - 1) / L; };
     int64_t bestL = 32;
     double best = 1e300;
+    // (the count of distinct utterance lengths, not the count of utterances, is what the 505 candidate lengths are tried on)
+    std::map<int64_t, int64_t> hist;
+    for (int32_t u = 0; u < n_utt; ++u) {
+      const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
+      if (T > 0) hist[T]++;
+    }
     for (int64_t L = 32; L <= 2048; L += 4) {
       int64_t n = 0;
-      for (int32_t u = 0; u < n_utt; ++u) {
-        const int64_t T = b->h_frame_off[u + 1] - b->h_frame_off[u];
-        if (T > 0) n += (T <= short_T) ? 1 : parts_of(T, L);
-      }
+      for (const auto &h : hist) n += h.second * ((h.first <= short_T) ? 1 : parts_of(h.first, L));
       const double cost = double((n + slots - 1) / slots) * double(L / 4 + 2);
       if (cost <= best) { best = cost; bestL = L; }
     }

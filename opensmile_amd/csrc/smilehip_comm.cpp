@@ -169,3 +169,25 @@ extern "C" int smilehip_comm_gather_rows(smilehip_comm *c, const float *d_rows, 
   if (!s && hipStreamSynchronize(s) != hipSuccess) return fail("gather: synchronize failed");      // null stream: blocking call
   return 0;
 }
+
+// The point-to-point primitives of the gather on ONE device: a grouped ncclSend / ncclRecv pair whose peer is the caller's own
+// rank (RCCL pairs them inside the group). What a box with a single GPU can execute of smilehip_comm_gather_rows' send / receive
+// path -- no xGMI link is crossed; tests/test_gpu_comm.py.
+extern "C" int smilehip_comm_self_sendrecv(smilehip_comm *c, const float *d_src, float *d_dst, int64_t n, void *stream) {
+  if (!c || !d_src || !d_dst || n <= 0) return fail("smilehip_comm_self_sendrecv: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return fail("ncclGroupStart: %s", ncclGetErrorString(r));
+  const ncclResult_t rs = ncclSend(d_src, (size_t)n, ncclFloat, c->rank, c->nccl, s);
+  const ncclResult_t rr = ncclRecv(d_dst, (size_t)n, ncclFloat, c->rank, c->nccl, s);
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (rs != ncclSuccess || rr != ncclSuccess || r2 != ncclSuccess)
+    return fail("self send/recv: %s", ncclGetErrorString(rs != ncclSuccess ? rs : (rr != ncclSuccess ? rr : r2)));
+  if (!s && hipStreamSynchronize(s) != hipSuccess) return fail("self send/recv: synchronize failed");
+  return 0;
+}
+
+extern "C" int smilehip_comm_rccl_version(int *version) {
+  if (!version) return fail("smilehip_comm_rccl_version: null argument");
+  return ncclGetVersion(version) == ncclSuccess ? 0 : fail("ncclGetVersion failed");
+}

@@ -182,7 +182,7 @@ int launch_spec(FsParams &P, int n_utt, hipStream_t stream) {
 
 // ---- Modulation: the device tables of one option set (ModTables, lld_params.hpp), kept in the context
 }  // namespace
-struct ModCache {
+struct ModEntry {                                       // one option set's tables
   int32_t ki[4] = {0, 0, 0, 0};
   double kd[3] = {0, 0, 0};
   DevBuf<float> d_win;
@@ -191,16 +191,41 @@ struct ModCache {
   DevBuf<int32_t> d_k;
   ModTables tabs{};
 };
+// The context's cache: a few option sets side by side (callers alternate between instances: tables of a set in use are never
+// rebuilt under a launch that reads them), most recently used first, behind a lock (a context may be shared by threads).
+struct ModCache {
+  std::mutex mu;
+  std::vector<std::unique_ptr<ModEntry>> sets;
+};
 void mod_cache_free(ModCache *m) { delete m; }
 namespace {
+constexpr size_t kModCacheSets = 8;
 int mod_prepare(smilehip_context *ctx, const smilehip_func_spec &s, ModTables &out) {
-  if (!ctx->mod) ctx->mod = new (std::nothrow) ModCache();
-  ModCache *m = ctx->mod;
-  if (!m) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  static std::mutex create_mu;
+  {
+    std::lock_guard<std::mutex> g(create_mu);
+    if (!ctx->mod) ctx->mod = new (std::nothrow) ModCache();
+  }
+  ModCache *cache = ctx->mod;
+  if (!cache) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
+  std::lock_guard<std::mutex> lock(cache->mu);
   const int32_t ki[4] = {s.mod_win_frames, s.mod_n_bins, s.mod_win_func, 0};
   const double kd[3] = {s.period, s.mod_min_freq, s.mod_max_freq};
-  if (m->tabs.win && !std::memcmp(ki, m->ki, sizeof(ki)) && !std::memcmp(kd, m->kd, sizeof(kd))) { out = m->tabs; return SMILEHIP_OK; }
-  HIP_TRY(hipDeviceSynchronize());                      // (launches that read the previous option set's tables)
+  for (size_t i = 0; i < cache->sets.size(); ++i) {
+    ModEntry *e = cache->sets[i].get();
+    if (e->tabs.win && !std::memcmp(ki, e->ki, sizeof(ki)) && !std::memcmp(kd, e->kd, sizeof(kd))) {
+      out = e->tabs;
+      if (i) std::rotate(cache->sets.begin(), cache->sets.begin() + i, cache->sets.begin() + i + 1);
+      return SMILEHIP_OK;
+    }
+  }
+  if (cache->sets.size() >= kModCacheSets) {             // the least recently used set goes: wait for the launches that may read it
+    HIP_TRY(hipDeviceSynchronize());
+    cache->sets.pop_back();
+  }
+  std::unique_ptr<ModEntry> fresh(new (std::nothrow) ModEntry());
+  ModEntry *m = fresh.get();
+  if (!m) return fail(SMILEHIP_ERR_NOMEM, "out of host memory");
   const int W = s.mod_win_frames, nb = s.mod_n_bins;
   // the window function of every length a window can have (cSmileUtilWindowedMagnitudeSpectrum::allocateWinFunc: the values of
   // smileDsp_win* in double, stored as FLOAT_DMEM), lengths below 33 never reach the transform
@@ -278,6 +303,7 @@ int mod_prepare(smilehip_context *ctx, const smilehip_func_spec &s, ModTables &o
   std::memcpy(m->ki, ki, sizeof(ki));
   std::memcpy(m->kd, kd, sizeof(kd));
   out = tb;
+  cache->sets.insert(cache->sets.begin(), std::move(fresh));
   return SMILEHIP_OK;
 }
 

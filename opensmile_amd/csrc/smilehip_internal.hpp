@@ -7,6 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>

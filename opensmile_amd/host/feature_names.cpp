@@ -211,7 +211,8 @@ std::vector<int> egemaps_subset_columns(const std::string &set, bool func) {
 bool compare16_selection(bool is13, int last_mfcc, const std::map<std::string, std::vector<std::string>> &func_enabled,
                          std::vector<int> &sel_lld, std::vector<int> &sel_func, std::string &err) {
   static const char *fam_names[SMILEHIP_FAM_COUNT] = {"Extremes", "Means", "Moments", "Regression", "Percentiles", "Times", "Segments", "Lpc", "Peaks2",
-                                                      "Onset", "Peaks", "Crossings", "DCT", "Samples"};      // (the enum's order, include/smilehip.h)
+                                                      "Onset", "Peaks", "Crossings", "DCT", "Samples", "Modulation"};      // (the enum's order, include/smilehip.h)
+  static_assert(SMILEHIP_FAM_COUNT == 15 && SMILEHIP_FAM_MODULATION == 14, "fam_names follows the enum of include/smilehip.h");
   sel_lld.clear(); sel_func.clear();
   const int lm = last_mfcc > 0 ? last_mfcc : 14;
   auto lld_kept = [&](int c) {                           // [F0 group 6 | A 4 | audSpec 26 | spectral 15 | mfcc 14] + the same _de
