@@ -337,25 +337,32 @@ __device__ __forceinline__ int quad_pitch_cep_peak(const float (&c)[16], int pre
 }
 
 // The samples of frame `row` that lane j of the frame's row of lanes keeps: x[j + 16 it], it < NIT (R0 done at the load)
-template <int NIT>
-__device__ __forceinline__ void is09_quad_fetch(const LldParams &P, int64_t row, float (&R)[NIT], int j) {
+// FULL: N = 16 NIT exactly and no zero padding in front of the frame (25 ms at 16 kHz, zeroPadSymmetric = 0: the shipped
+// IS09 / emobase files) -- every "n < N" below is then a compile-time fact and the predicated regions around the LDS accesses go
+// (in two steps: the frame's first sample -- two dependent look-ups -- is asked for a whole pass before the samples are)
+__device__ __forceinline__ int64_t is09_quad_base(const LldParams &P, int64_t row) {
   const int lo = P.frame_utt[row];
   const int64_t t = row - P.frame_off[lo];
-  const int64_t base = P.samp_off[lo] + t * (int64_t)P.H + j;
+  return P.samp_off[lo] + t * (int64_t)P.H;
+}
+template <int NIT, bool FULL>
+__device__ __forceinline__ void is09_quad_fetch(const LldParams &P, int64_t base0, float (&R)[NIT], int j) {
+  const int64_t base = base0 + j;
+  const int N = FULL ? 16 * NIT : P.N;
   if (P.pcm_f32) {                                         // (uniform: one kind of load per instance of the loop)
     const float *x = P.pcm_f32 + base;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) R[it] = (j + 16 * it < P.N) ? x[16 * it] : 0.0f;
+    for (int it = 0; it < NIT; ++it) R[it] = (FULL || j + 16 * it < N) ? x[16 * it] : 0.0f;
   } else {
     const int16_t *x = P.pcm + base;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) R[it] = (j + 16 * it < P.N) ? pcm16_to_float(x[16 * it]) : 0.0f;
+    for (int it = 0; it < NIT; ++it) R[it] = (FULL || j + 16 * it < N) ? pcm16_to_float(x[16 * it]) : 0.0f;
   }
 }
 
 // One pass: the four frames whose samples R holds. Before the last phase (which needs few registers) the samples of the
 // wave's next pass are requested into R again (next_row < 0: none), so that their latency is the pitch phase's.
-template <int NIT>
+template <int NIT, bool FULL>
 __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Params &Q, const Is09Tbl &T, int64_t row, float *fmem,
                                                float (&R)[NIT], int64_t next_row) {
   constexpr int M = 256;
@@ -369,11 +376,16 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   float2 *z = reinterpret_cast<float2 *>(fmem);
   float *sp = fmem;                                        // mel input, once the spectrum has been read out of z
   float *lmel = fmem + kQuadLmel;
-  const int N = P.N;
+  const int N = FULL ? 16 * NIT : P.N;
+  const int pad_left = FULL ? 0 : P.pad_left;
   float *out = Q.raw16 + row * 16;
+  // where the NEXT pass's frame starts: requested now, used by the fetch at the end of this pass (two dependent global loads:
+  // asked for at the fetch itself they are two memory round trips during which the wave -- one of three on its SIMD -- waits)
+  // (the FULL instance has the two registers to spare; the general ones ask at the fetch)
+  const int64_t next_base = (FULL && next_row >= 0) ? is09_quad_base(P, next_row) : 0;
   IPHASE_DECL
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = R[it]; }
+  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (FULL || n < N) xr[n] = R[it]; }
   QuadG::sync();
   IPHASE(0);   // utterance lookup + frame load
   // R12 cMZcr::processVector, zcr (mzcr.cpp:117-124): on the RAW frames
@@ -382,7 +394,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 #pragma unroll 8
     for (int it = 0; it < NIT; ++it) {
       const int i = 1 + j + 16 * it;
-      if (i < N - 1)
+      if (i < N - 1)                                       // (FULL: false in lanes 14, 15 of the last round only)
         if (((xr[i - 1] * xr[i + 1] <= 0.0f) && (xr[i] == 0.0f)) || (xr[i - 1] * xr[i] < 0.0f)) ++cnt;
     }
     const int total = QuadG::sum_i(cnt, nullptr);
@@ -394,7 +406,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 #pragma unroll 8
   for (int it = 0; it < NIT; ++it) {
     const int n = j + 16 * it;
-    if (n < N) {
+    if (FULL || n < N) {
       float y = xr[n];
       if (P.preemph) y = (n == 0) ? P.one_minus_k * xr[0] : (P.de ? (xr[n] + P.k * xr[n - 1]) : (xr[n] - P.k * xr[n - 1]));
       y = y * T.window[n] + P.win_offset;
@@ -409,13 +421,13 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   }
   QuadG::sync();                                           // (every lane has read its raw samples)
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (n < N) xr[n] = R[it]; }
+  for (int it = 0; it < NIT; ++it) { const int n = j + 16 * it; if (FULL || n < N) xr[n] = R[it]; }
   QuadG::sync();
   IPHASE(2);   // pre-emphasis, window, RMS energy
   // R4 forward real FFT in the reference's operation order (all of the frame is in registers before the transposition writes
   // z = the same buffer), R5 magnitudes: mv[m] = |X[j + 16 m]|, kept in registers for the two inverse transforms
   oo_quad_forward(z, T.oo, lane64, [&](int i) {
-    const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
+    const int n0 = 2 * i - pad_left, n1 = n0 + 1;
     return make_float2((n0 >= 0 && n0 < N) ? xr[n0] : 0.0f, (n1 >= 0 && n1 < N) ? xr[n1] : 0.0f);
   });
   float mv[17];
@@ -442,10 +454,14 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   QuadG::sync();
   IPHASE(3);   // forward transform + magnitudes
   // R6 / R7: mel (usePower per config) -> log -> DCT
+  // a lane takes band j and band n_bands - 1 - j: the bands widen with their index, and a lane's two sums are walked one after
+  // the other -- narrow + wide is about the same length in every lane (band j and j + 16: lane 9 walked 8 + 60 terms, lane 0 4)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int b = j + 16 * h;
-    if (b < P.n_bands) lmel[b] = log_mel(mel_band_from_terms(sp, sp + (M + 1), T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
+    const int half = P.n_bands >> 1;                       // (n_bands <= 32: launch_is09)
+    const int b = h == 0 ? j : P.n_bands - 1 - j;
+    const bool mine = j < half || (h == 0 && j == half && (P.n_bands & 1));   // (an odd count's middle band: once)
+    if (mine) lmel[b] = log_mel(mel_band_from_terms(sp, sp + (M + 1), T.mel_rng, b, P.mel_scale), P.melfloor, P.log_floor);
   }
   QuadG::sync();
   if (j < P.n_mfcc) out[1 + j] = dct_coeff(lmel, T.dct_rows + j * P.n_bands, P.n_bands, P.dct_gain[j]);
@@ -465,7 +481,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
   }
   __builtin_amdgcn_sched_barrier(0);
 #if SMILEHIP_IS09_PREFETCH_EARLY
-  if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);   // (the next pass's samples: their latency is the logarithms' and the second transform's)
+  if (next_row >= 0) is09_quad_fetch<NIT, FULL>(P, FULL ? next_base : is09_quad_base(P, next_row), R, j);   // (the next pass's samples: their latency is the logarithms' and the second transform's)
   __builtin_amdgcn_sched_barrier(0);
 #endif
   // ... then the cepstrum instance: log(P + 1) (:288-305)
@@ -481,7 +497,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     oo_quad_irfft_even_real(z, T.oo, cep, (float)P.K, false, lane64, pw);
     IPHASE(5);   // ACF + cepstrum: two inverse transforms, 257 double logs
 #if !SMILEHIP_IS09_PREFETCH_EARLY
-    if (next_row >= 0) is09_quad_fetch<NIT>(P, next_row, R, j);
+    if (next_row >= 0) is09_quad_fetch<NIT, FULL>(P, FULL ? next_base : is09_quad_base(P, next_row), R, j);
 #endif
     max_idx = quad_pitch_cep_peak(cep, preskip, lane64);
   }
@@ -500,7 +516,7 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
 }  // namespace
 
 // persistent workgroups; rows past the end of the batch repeat the last frame (same values to the same cells)
-template <int NIT>                                       // samples per lane: N <= 16 NIT
+template <int NIT, bool FULL>                            // samples per lane: N <= 16 NIT (FULL: N = 16 NIT, pad_left = 0)
 __global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(SMILEHIP_IS09_QUAD_WAVES, SMILEHIP_IS09_QUAD_WAVES))) lld_is09_frame_quad(LldParams P, Is09Params Q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Npad = (P.N + 3) & ~3;
@@ -514,7 +530,7 @@ __global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_p
   for (int i = threadIdx.x; i < P.K; i += kQuadWaves * 64) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += kQuadWaves * 64) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += kQuadWaves * 64) s_dct[i] = P.dct_rows[i];
-  const OouraTab s_oo = oo_stage_tables(P.oo, smem + is09_quad_table_floats(P.N), threadIdx.x, kQuadWaves * 64);
+  const OouraTab s_oo = oo_stage_tables<true>(P.oo, smem + is09_quad_table_floats(P.N), threadIdx.x, kQuadWaves * 64);   // (launch_is09: P.oo.tw != null)
   __syncthreads();                                       // the only workgroup barrier
   const Is09Tbl T = {s_win, nullptr, nullptr, s_coef, s_rng, s_dct, s_oo, s_log};
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -524,10 +540,10 @@ __global__ void __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_p
   int64_t row0 = ((int64_t)blockIdx.x * kQuadWaves + wave) * 4;
   if (row0 > last) return;
   float R[NIT];
-  is09_quad_fetch<NIT>(P, row0 + g < last ? row0 + g : last, R, (int)(threadIdx.x & 15));
+  is09_quad_fetch<NIT, FULL>(P, is09_quad_base(P, row0 + g < last ? row0 + g : last), R, (int)(threadIdx.x & 15));
   for (; row0 <= last; row0 += stride) {
     const int64_t nxt = row0 + stride;
-    is09_quad_body<NIT>(P, Q, T, row0 + g < last ? row0 + g : last, fmem, R, nxt <= last ? (nxt + g < last ? nxt + g : last) : (int64_t)-1);
+    is09_quad_body<NIT, FULL>(P, Q, T, row0 + g < last ? row0 + g : last, fmem, R, nxt <= last ? (nxt + g < last ? nxt + g : last) : (int64_t)-1);
   }
 }
 
@@ -582,7 +598,9 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
   const char *form = getenv("SMILEHIP_IS09");
   if (P.oo.tw && M == 256 && P.K == 257 && P.N <= 512 && P.frame_utt && P.n_bands <= 32 && P.n_mfcc <= 16 && quad_bytes <= 160 * 1024 && !form) {
     const bool n25 = P.N <= 400;                           // 25 ms at 16 kHz: 25 samples per lane
-    const void *qfn = n25 ? reinterpret_cast<const void *>(&lld_is09_frame_quad<25>) : reinterpret_cast<const void *>(&lld_is09_frame_quad<32>);
+    const bool full = P.N == 400 && P.pad_left == 0;       // ... exactly 400 and the padding behind the frame: the shipped files
+    const void *qfn = full ? reinterpret_cast<const void *>(&lld_is09_frame_quad<25, true>)
+                           : (n25 ? reinterpret_cast<const void *>(&lld_is09_frame_quad<25, false>) : reinterpret_cast<const void *>(&lld_is09_frame_quad<32, false>));
     e = hipFuncSetAttribute(qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     static const int n_cu = [] {
@@ -593,8 +611,9 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
     int64_t grid = (P.total_frames + 4 * kQuadWaves - 1) / (4 * kQuadWaves);
     const int64_t cap = (int64_t)(n_cu > 0 ? n_cu : 256) * (int64_t)(160 * 1024 / quad_bytes);
     if (grid > cap) grid = cap;
-    if (n25) hipLaunchKernelGGL(lld_is09_frame_quad<25>, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
-    else hipLaunchKernelGGL(lld_is09_frame_quad<32>, dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    if (full) hipLaunchKernelGGL((lld_is09_frame_quad<25, true>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    else if (n25) hipLaunchKernelGGL((lld_is09_frame_quad<25, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    else hipLaunchKernelGGL((lld_is09_frame_quad<32, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
   } else if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
       !(form && !strcmp(form, "block"))) {                             // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds_wave + 15) / 16) * 4;

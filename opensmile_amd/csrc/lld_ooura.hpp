@@ -303,9 +303,13 @@ __device__ __forceinline__ void oo_irfft_even(const float *R, float2 *z, const O
 // floats of LDS a staged copy of the tables takes, and the staging itself (all threads of the workgroup; the caller
 // synchronises): the returned view points into lds
 __host__ __device__ inline int oo_table_floats(const OouraTab &T) { return T.tw ? 4 * T.n_tw + T.M : 0; }
+// ALWAYS: the caller knows the tables exist (its launch condition) -- without the early return both table pointers are LDS
+// pointers on every path, and the compiler addresses them as such (ds_read with immediate offsets); with it, S.rft is "global or
+// LDS" and every read of it becomes a flat load through a 64-bit address
+template <bool ALWAYS = false>
 __device__ __forceinline__ OouraTab oo_stage_tables(const OouraTab &T, float *lds, int tid, int nthreads) {
   OouraTab S = T;
-  if (!T.tw) return S;
+  if (!ALWAYS && !T.tw) return S;
   float4 *tw = reinterpret_cast<float4 *>(lds);
   float2 *rft = reinterpret_cast<float2 *>(lds + 4 * T.n_tw);
   for (int i = tid; i < T.n_tw; i += nthreads) tw[i] = T.tw[i];

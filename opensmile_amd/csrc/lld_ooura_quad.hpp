@@ -66,6 +66,9 @@ __device__ __forceinline__ void oo_quad256(float2 (&v)[16], const OouraTab &T, f
 }
 
 // v[r] (spectrum index 16 bitrev4(r) + bitrev4(j)) -> z[oo_pos(F)], z = the row's buffer. Ends with a wave sync.
+// LOW_HALF: only spectrum indices F < 128 (the even registers) -- all that oo_quad_inverse_outs reads for output samples
+// 0 .. 255; the other half of the last level's results is then dead code
+template <bool LOW_HALF = false>
 __device__ __forceinline__ void oo_quad_store(const float2 (&v)[16], float2 *z, int lane) {
   const int fj = oo_brev4(lane & 15);
   // oo_pos(16 R + fj) = 16 R + (fj ^ (R & 3)): four lane-dependent addresses, the rest immediate offsets
@@ -73,7 +76,7 @@ __device__ __forceinline__ void oo_quad_store(const float2 (&v)[16], float2 *z, 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     constexpr int kRev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-    zc[kRev[r] & 3][16 * kRev[r]] = v[r];
+    if (!LOW_HALF || kRev[r] < 8) zc[kRev[r] & 3][16 * kRev[r]] = v[r];
   }
   oo_wave_sync();
 }
@@ -189,7 +192,7 @@ __device__ __forceinline__ void oo_quad_inverse_real(float2 *z, const OouraTab &
     if (r % 4 == 3) __builtin_amdgcn_sched_barrier(0);           // (four elements' loads in flight at a time)
   }
   oo_quad256<true>(v, T, z, lane);
-  oo_quad_store(v, z, lane);
+  oo_quad_store<true>(v, z, lane);
 }
 // cAcf on that input: lags j + 16 it, it < 16, of the lane's row to out[it] (registers)
 __device__ __forceinline__ void oo_quad_irfft_even_real(float2 *z, const OouraTab &T, float (&out)[16], float inv_norm, bool take_abs,
