@@ -26,7 +26,7 @@
 namespace smilehip {
 
 namespace {
-constexpr int kRun = 8;          // frames per workgroup (the flux needs the previous frame's magnitudes)
+constexpr int kRun = 8;          // frames per run when the caller names none (the flux needs the previous frame's magnitudes)
 
 }  // namespace
 
@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
   SC.log_tab = nullptr;
-  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  const int run_len = Q.run_frames > 0 ? Q.run_frames : kRun;
+  const int t_last = (t0 + run_len < T20) ? t0 + run_len : T20;
   PHASE_DECL
 
   // frames t0-1 (magnitudes only, for the flux) .. t_last-1
@@ -192,9 +193,15 @@ __global__ void __launch_bounds__(256) lld_compare_frame(LldParams P, ComparePar
 // mel[32] | aud[32] | lmel[32]
 // the wave's z region: the transform's pairs, then the mel terms (two rows of Kpad floats), then the descriptors' chains
 __host__ __device__ inline int compare_z_floats(int M, int Kpad) { return 2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad; }
-template <int W>                                       // K = 64 W + 1 bins: W = 4 at 16 kHz (FFT 512), 2 / 8 for FFT 256 / 1024
-__device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, const CompareParams &Q, int n_runs, float *smem) {
-  const int M = P.Nfft >> 1, K = P.K;
+// TUNED: the shipped geometry -- 16 kHz, 20 ms frames (N = 320, hop 160, FFT 512, symmetric padding: 96 zeros in front), the 60 ms
+// window of the zero-crossing rate 960 samples, reference-order transform tables present -- as compile-time facts: the range tests of
+// the loads and the own-order transform's code path go, the staged tables are LDS pointers on every path (no flat loads)
+template <int W, bool TUNED = false>                   // K = 64 W + 1 bins: W = 4 at 16 kHz (FFT 512), 2 / 8 for FFT 256 / 1024
+__device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, const CompareParams &Q_in, int n_runs, float *smem) {
+  struct Geo { int N, H, pad_left, N60; };
+  const Geo Gq = TUNED ? Geo{320, 160, 96, 960} : Geo{P.N, P.H, P.pad_left, Q_in.N60};
+  const CompareParams &Q = Q_in;
+  const int M = TUNED ? 256 : (P.Nfft >> 1), K = TUNED ? 257 : P.K;
   const int Kpad = (K + 3) & ~3;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -206,11 +213,11 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   for (int i = threadIdx.x; i < K; i += blockDim.x) s_coef[i] = P.mel_coef[i];
   for (int i = threadIdx.x; i < 4 * P.n_bands; i += blockDim.x) s_rng[i] = P.mel_rng[i];
   for (int i = threadIdx.x; i < P.n_mfcc * P.n_bands; i += blockDim.x) s_dct[i] = P.dct_rows[i];
-  const OouraTab OO = oo_stage_tables(P.oo, s_dct + 16 * 32, threadIdx.x, blockDim.x);   // reference-order FFT tables (or none)
+  const OouraTab OO = oo_stage_tables<TUNED>(P.oo, s_dct + 16 * 32, threadIdx.x, blockDim.x);   // reference-order FFT tables (or none)
   __syncthreads();                                       // the only workgroup barrier
   const int run = blockIdx.x * 4 + wave;
   if (run >= n_runs) return;
-  const int rawpad = (Q.N60 + 3) & ~3;
+  const int rawpad = (Gq.N60 + 3) & ~3;
   const int per_wave = compare_z_floats(M, Kpad) + 3 * Kpad + 96 + rawpad;
   float2 *z = reinterpret_cast<float2 *>(s_dct + 16 * 32 + oo_table_floats(P.oo) + wave * per_wave);   // the transform's (re, im) pairs
   const int zpad = fft_pad(M);
@@ -235,7 +242,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   const int T20 = (int)(P.frame_off[u + 1] - f0);
   const int64_t s_utt = P.samp_off[u];
   const int64_t utt_len = P.samp_off[u + 1] - s_utt;
-  const int T60 = (utt_len >= Q.N60) ? (int)((utt_len - Q.N60) / P.H + 1) : 0;
+  const int T60 = (utt_len >= Gq.N60) ? (int)((utt_len - Gq.N60) / Gq.H + 1) : 0;
   const PcmIn xu = pcm_in(P) + s_utt;
   SpectralConsts SC;
   SC.fsSec = Q.fsSec;
@@ -247,7 +254,8 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
   SC.slope_Sf = Q.slope_Sf;
   SC.slope_S2f = Q.slope_S2f;
   SC.log_tab = s_log;
-  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  const int run_len = Q.run_frames > 0 ? Q.run_frames : kRun;
+  const int t_last = (t0 + run_len < T20) ? t0 + run_len : T20;
   const int lane_in = lane;
   PHASE_DECL
   const int t_begin = t0 > 0 ? t0 - 1 : 0;
@@ -261,7 +269,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const bool warm = t < t0;
-    const PcmIn x = xu + (int64_t)t * P.H;
+    const PcmIn x = xu + (int64_t)t * Gq.H;
     float *rawA = Q.rawA + (f0 + t) * 4;
     float *rawB = Q.rawB + (f0 + t) * 55;
     // (asking for frame t + 1's samples here, a frame ahead, was measured: -2 % for this kernel alone, +24 % for the whole
@@ -269,29 +277,29 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
     // `raw` is a ring over the 60 ms window: consecutive frames of the run share all but one hop of it, so only the H new samples are
     // loaded (the whole window at the run's first frame); sample n of THIS frame's window sits at raw[(n + rbase) mod N60]. Samples past
     // the end of the utterance (the last frames, where only the 20 ms frame still exists) are not read.
-    const int64_t left = utt_len - (int64_t)t * P.H;
-    const int lim = left < (int64_t)Q.N60 ? (int)left : Q.N60;
+    const int64_t left = utt_len - (int64_t)t * Gq.H;
+    const int lim = left < (int64_t)Gq.N60 ? (int)left : Gq.N60;
     if (t == t_begin) {
       rbase = 0;
       for (int n = lane; n < lim; n += 64) raw[n] = x[n];
     } else {
-      rbase += P.H;
-      if (rbase >= Q.N60) rbase -= Q.N60;
-      for (int n = Q.N60 - P.H + lane; n < lim; n += 64) { int k = n + rbase; if (k >= Q.N60) k -= Q.N60; raw[k] = x[n]; }
+      rbase += Gq.H;
+      if (rbase >= Gq.N60) rbase -= Gq.N60;
+      for (int n = Gq.N60 - Gq.H + lane; n < lim; n += 64) { int k = n + rbase; if (k >= Gq.N60) k -= Gq.N60; raw[k] = x[n]; }
     }
-    const auto R = [&](int n) { int k = n + rbase; if (k >= Q.N60) k -= Q.N60; return raw[k]; };
+    const auto R = [&](int n) { int k = n + rbase; if (k >= Gq.N60) k -= Gq.N60; return raw[k]; };
     WaveG::sync();
     PHASE(0);
     const auto load_pair = [&](int i) {
-      const int n0 = 2 * i - P.pad_left, n1 = n0 + 1;
-      return make_float2((n0 >= 0 && n0 < P.N) ? R(n0) * P.window[n0] + P.win_offset : 0.0f,
-                         (n1 >= 0 && n1 < P.N) ? R(n1) * P.window[n1] + P.win_offset : 0.0f);
+      const int n0 = 2 * i - Gq.pad_left, n1 = n0 + 1;
+      return make_float2((n0 >= 0 && n0 < Gq.N) ? R(n0) * P.window[n0] + P.win_offset : 0.0f,
+                         (n1 >= 0 && n1 < Gq.N) ? R(n1) * P.window[n1] + P.win_offset : 0.0f);
     };
-    if (OO.tw) oo_wave_forward(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
+    if (TUNED || OO.tw) oo_wave_forward<TUNED ? 256 : 0>(z, OO, lane, load_pair);  // the reference's rdft network, register form (lld_ooura_wave.hpp)
     else wave_cfft(z, M, P.tw_half, lane, load_pair);
     PHASE(1);
     for (int k = lane; k <= M; k += 64) {
-      const float m = bin_magnitude(OO.tw ? oo_wave_bin(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
+      const float m = bin_magnitude((TUNED || OO.tw) ? oo_wave_bin<TUNED ? 256 : 0>(z, OO, k) : wave_untangle(z, M, zpad, k, P.tw_full), k == 0 || k == M);
       mg[k] = m;
       pw[k] = m * m;
     }
@@ -327,7 +335,7 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
       for (int w = 0; w < 4; ++w) {
         const int tid = lane + 64 * w;
         v0[w][0] = 0.0; v0[w][1] = 0.0;
-        for (int n = tid; n < P.N; n += 256) { const float tmp = R(n); v0[w][0] += tmp * tmp; }
+        for (int n = tid; n < Gq.N; n += 256) { const float tmp = R(n); v0[w][0] += tmp * tmp; }
       }
       // Zero crossings of the 60 ms window (mzcr.cpp:117-124): a count, so any order of the positions gives the reference's sum.
       // Consecutive frames of the run share all but one hop of the window: the lane that owns the ABSOLUTE position p (p mod 64)
@@ -339,23 +347,23 @@ __device__ __forceinline__ void compare_frame_wave_body(const LldParams &P, cons
           return (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) ? 1 : 0;
         };
         const auto count = [&](int lo, int hi) {           // positions lo .. hi (relative to the frame) that this lane owns
-          const int off = (int)(((int64_t)t * P.H) & 63);
+          const int off = (int)(((int64_t)t * Gq.H) & 63);
           int c = 0;
           for (int i = lo + ((lane - off - lo) & 63); i <= hi; i += 64) c += cross(i);
           return c;
         };
-        const int last = Q.N60 - 2;
-        if (zc_have && 2 * P.H < last) zc_count += count(last - P.H + 1, last) - zc_front;
+        const int last = Gq.N60 - 2;
+        if (zc_have && 2 * Gq.H < last) zc_count += count(last - Gq.H + 1, last) - zc_front;
         else zc_count = count(1, last);
-        zc_front = count(1, P.H);
+        zc_front = count(1, Gq.H);
         zc_have = true;
         v0[0][1] = (double)zc_count;
       }
       double tot[2];
       wave_sum4<2>(v0, tot);
       if (lane == 0) {
-        rawA[2] = (float)sqrt(tot[0] / (float)P.N) * 1.0f + 0.0f;
-        if (t < T60) rawA[3] = (float)tot[1] / (float)Q.N60;
+        rawA[2] = (float)sqrt(tot[0] / (float)Gq.N) * 1.0f + 0.0f;
+        if (t < T60) rawA[3] = (float)tot[1] / (float)Gq.N60;
       }
     }
     PHASE(4);
@@ -379,6 +387,10 @@ __global__ void __launch_bounds__(256) lld_compare_frame_wave(LldParams P, Compa
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_wave3(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   compare_frame_wave_body<4>(P, Q, n_runs, smem);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_wave3t(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  compare_frame_wave_body<4, true>(P, Q, n_runs, smem);
 }
 // the other spectrum sizes of 20 ms frames: FFT 256 (8 / 11.025 kHz), FFT 1024 (32 / 44.1 / 48 kHz)
 template <int W>
@@ -548,11 +560,14 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     if (lds > 48 * 1024) {
       hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_wave3t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (ea != hipSuccess) return ea;
     }
     static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && !getenv("SMILEHIP_COMPARE_GENERAL"))
+      hipLaunchKernelGGL(lld_compare_frame_wave3t, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
     else hipLaunchKernelGGL(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }
   hipError_t e = hipGetLastError();
@@ -566,6 +581,12 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
   return hipGetLastError();
 }
 
-int compare_run_frames() { return kRun; }
+// Frames per run for a batch of `total_frames` 20 ms frames: a run costs one transform more than its frames (the warm-up frame),
+// 12.5 % at 8; the longest of 8 / 16 / 32 / 64 that still leaves >= 65 536 runs (21 per wave slot of the device).
+int compare_run_frames(int64_t total_frames) {
+  int L = kRun;
+  while (L < 64 && total_frames / (2 * L) >= 65536) L *= 2;
+  return L;
+}
 
 }  // namespace smilehip

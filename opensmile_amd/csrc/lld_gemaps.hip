@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
   const int T20 = (int)(P.frame_off[u + 1] - f0);
   const int16_t *xu = P.pcm + P.samp_off[u];
   const float *xuf = P.pcm_f32 ? P.pcm_f32 + P.samp_off[u] : nullptr;    // float input (smilehip_lld_run_f32): read at the frame, no prefetch
-  const int t_last = (t0 + kRun < T20) ? t0 + kRun : T20;
+  const int run_len = G.run_frames > 0 ? G.run_frames : kRun;
+  const int t_last = (t0 + run_len < T20) ? t0 + run_len : T20;
   const int lane_in = lane;
   // the raw samples of frame t + 1 are asked for while frame t is processed (see lld_compare_frame_wave)
   int16_t pre[8];

@@ -34,7 +34,7 @@ hipError_t launch_cms(const int64_t *d_frame_off, int n_utt, const float *x, int
                       hipStream_t s);
 hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs, const int64_t *d_row_off,
                           int64_t total_rows, float *d_out, int64_t ld_out, int de_col, hipStream_t s);
-int compare_run_frames();
+int compare_run_frames(int64_t total_frames);
 hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_row_off, int n_utt, const float *rawB, float *out110,
                                   hipStream_t s);
 // frames_done (optional): recorded on s after the frame kernels, before the Viterbi pass -- what follows (Viterbi, jitter) is

@@ -110,8 +110,9 @@ struct Is09Params {
 
 // Parameters of the ComParE A+B kernels (lld_compare.hip)
 struct CompareParams {
-  const int32_t *run_utt;    // [n_runs] runs of 8 consecutive 20 ms frames: utterance
+  const int32_t *run_utt;    // [n_runs] runs of run_frames consecutive 20 ms frames: utterance
   const int32_t *run_t0;     // [n_runs] first frame
+  int32_t run_frames;        // frames per run (0: 8). A run pays one extra transform (the flux needs the frame before it): the batch picks the longest runs that still fill the device
   float *rawA;               // [total_frames20 x 4]  audspecSum, audspecRastaSum, rms, zcr (zcr valid for t < T60)
   float *rawB;               // [total_frames20 x 55] audSpec_Rfilt[26], spectral[15], mfcc[14]
   float *mel1;               // [total_frames20 x 26] un-filtered mel power spectrum (input of the RASTA pass)
@@ -194,7 +195,8 @@ struct F0Params {
 // eGeMAPSv02 / GeMAPSv01b LLD level (lld_gemaps.hip): per-frame scratch and constants
 struct GemapsParams {
   // ---- 20 ms chain ----
-  const int32_t *run_utt, *run_t0;  // runs of 8 consecutive 20 ms frames (the flux needs the previous frame)
+  const int32_t *run_utt, *run_t0;  // runs of run_frames consecutive 20 ms frames (the flux needs the previous frame)
+  int32_t run_frames;               // frames per run (0: 8), see CompareParams
   float *raw20;                     // [total_frames20 x 12] loudness | slope0-500, slope500-1500, alphaRatio, hammarberg | flux |
                                     //                        mfcc1..4 | energy2 | 0
   float *spec220;                   // [total_frames20 x 220] what cSpecResample reads of the complex spectrum: (Re, Im Ooura) of

@@ -30,6 +30,12 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   const int64_t dtile = chain_tile_rows();
   const int64_t tile_frames = plan->use_fast ? fast512_tile_frames()
                               : (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0 ? f0_tile_frames() : (int64_t(1) << 40));
+  {                                                      // the run length of the 20 ms frame kernels (lld_compare.hip / lld_gemaps.hip)
+    int64_t total_T = 0;
+    for (int32_t u = 0; u < n_utt; ++u) { const int64_t len = h_off[u + 1] - h_off[u]; if (len > 0) total_T += smilehip_num_frames(plan, len); }
+    b->run_frames = compare_run_frames(total_T);
+    if (const char *rf = getenv("SMILEHIP_RUN_FRAMES")) { const int v = atoi(rf); if (v >= 1 && v <= 4096) b->run_frames = v; }   // A/B switch
+  }
   for (int32_t u = 0; u < n_utt; ++u) {
     const int64_t len = h_off[u + 1] - h_off[u];
     if (len < 0) {
@@ -43,7 +49,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       const int64_t N60 = std::lround(0.060 / plan->geo.period);
       const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
       rows = (T60 >= 4) ? T60 + 1 : 0;
-      for (int64_t t0 = 0; t0 < T; t0 += compare_run_frames()) {
+      for (int64_t t0 = 0; t0 < T; t0 += b->run_frames) {
         run_utt.push_back(u);
         run_t0.push_back((int32_t)t0);
       }
@@ -53,7 +59,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       const int64_t N60 = std::lround(0.060 / plan->geo.period);
       const int64_t T60 = (len >= N60) ? (len - N60) / plan->geo.H + 1 : 0;
       rows = (T60 >= 1) ? T60 + 1 : 0;
-      for (int64_t t0 = 0; t0 < T; t0 += compare_run_frames()) {
+      for (int64_t t0 = 0; t0 < T; t0 += b->run_frames) {
         run_utt.push_back(u);
         run_t0.push_back((int32_t)t0);
       }
@@ -541,6 +547,7 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   std::memset(&Q, 0, sizeof(Q));
   Q.run_utt = b->d_run_utt.p;
   Q.run_t0 = b->d_run_t0.p;
+  Q.run_frames = b->run_frames;
   Q.rawA = b->d_rawA.p;
   Q.rawB = b->d_rawB.p;
   Q.mel1 = b->d_mel1.p;
@@ -726,7 +733,7 @@ void gemaps_plan_consts(const smilehip_plan *plan, GemapsParams &G) {
 static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *b, GemapsParams &G) {
   gemaps_plan_consts(plan, G);
   const smilehip_batch *fb = b->f0_batch;
-  G.run_utt = b->d_run_utt.p; G.run_t0 = b->d_run_t0.p;
+  G.run_utt = b->d_run_utt.p; G.run_t0 = b->d_run_t0.p; G.run_frames = b->run_frames;
   G.raw20 = b->d_raw20.p; G.spec220 = b->d_spec220.p;
   G.lpc = b->d_lpc.p; G.formants = b->d_formants.p;
   G.total_frames20 = b->total_frames;

@@ -201,6 +201,7 @@ struct smilehip_batch {
   ~smilehip_batch();
   DevBuf<int32_t> d_run_utt, d_run_t0;
   int32_t n_runs = 0;
+  int32_t run_frames = 8;               // frames per run (compare_run_frames)
   std::vector<int32_t> h_short;
   DevBuf<int64_t> d_samp_off, d_frame_off;
   DevBuf<int32_t> d_frame_utt;     // IS09 chain: utterance of every frame (the frame kernel has one frame per wave and would search frame_off for it)
