@@ -477,6 +477,15 @@ int  smilehip_free(smilehip_context *ctx, void *d_ptr);
 int  smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream);
 int  smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream);
 int  smilehip_stream_synchronize(smilehip_context *ctx, void *stream);
+/* Page-locked host memory for the staging buffers of a file-to-file host (the copies above run at the link's rate only from
+ * such memory; what cWaveSource's read buffer and the sinks' write buffers are to the reference: src/iocore/waveSource.cpp:240-294,
+ * src/iocore/htkSink.cpp:183-202). */
+int  smilehip_alloc_host(smilehip_context *ctx, uint64_t bytes, void **h_ptr);
+int  smilehip_free_host(smilehip_context *ctx, void *h_ptr);
+/* cHtkSink::myTick's byte order (src/iocore/htkSink.cpp:183-202: every value of a vector through smileHtk_SwapFloat on a
+ * little-endian host) done on the device: d_dst[i] = big-endian image of d_src[i], n values; d_dst may equal d_src. The sink
+ * then writes a file's rows with one write(). */
+int  smilehip_htk_rows_be(smilehip_context *ctx, const float *d_src, int64_t n, void *d_dst, void *stream);
 
 /* fills c with config/mfcc/MFCC12_0_D_A.conf's values */
 void smilehip_config_mfcc12_0_d_a(smilehip_lld_config *c);

@@ -174,6 +174,9 @@ SYMBOLS = {
     "smilehip_lld_run_host": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "smilehip_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     "smilehip_free": (C.c_int, [_vp, _vp]),
+    "smilehip_alloc_host": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "smilehip_free_host": (C.c_int, [_vp, _vp]),
+    "smilehip_htk_rows_be": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "smilehip_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "smilehip_stream_synchronize": (C.c_int, [_vp, _vp]),

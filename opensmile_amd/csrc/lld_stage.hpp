@@ -41,6 +41,7 @@ hipError_t stage_specresample_g(const float *src, int64_t lds, int K, int I, int
                                 int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_lpc_g(const float *x, int64_t lds, int n, int p, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 // lld_stage3_kernels.hip: the components' other option sets
+hipError_t stage_htk_rows_be(const float *src, int64_t n, uint32_t *dst, hipStream_t s);
 struct OouraTab;
 hipError_t stage_irfft_oo(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, const OouraTab &T, hipStream_t s);
 hipError_t stage_fftmagphase(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int Nfft, int flags, float dBpnorm,

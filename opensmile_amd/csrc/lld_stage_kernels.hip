@@ -209,6 +209,28 @@ __global__ void k_pcm_convert_float(const float *buf, int n_chan, int mixdown, i
 
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// cHtkSink's byte order (htkSink.cpp:183-202), 16 bytes per thread where the pointers allow
+__global__ void k_htk_rows_be(const uint32_t *src, int64_t n, uint32_t *dst, int vec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    if (4 * i + 3 < n) {
+      uint4 v = reinterpret_cast<const uint4 *>(src)[i];
+      v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+      reinterpret_cast<uint4 *>(dst)[i] = v;
+    } else {
+      for (int64_t k = 4 * i; k < n; ++k) dst[k] = __builtin_bswap32(src[k]);
+    }
+  } else if (i < n) {
+    dst[i] = __builtin_bswap32(src[i]);
+  }
+}
+hipError_t stage_htk_rows_be(const float *src, int64_t n, uint32_t *dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const int64_t work = vec ? (n + 3) / 4 : n;
+  hipLaunchKernelGGL(k_htk_rows_be, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(src), n, dst, vec ? 1 : 0);
+  return hipGetLastError();
+}
 hipError_t stage_pcm16(const int16_t *pcm, int64_t n, float *out, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_pcm16_to_float, dim3(nblk(n, 256)), dim3(256), 0, s, pcm, n, out);
   return hipGetLastError();

@@ -1,5 +1,6 @@
 // libsmilehip, C ABI part 1: errors, context life cycle, device-memory plumbing (include/smilehip.h).
 #include "smilehip_internal.hpp"
+#include "lld_stage.hpp"
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -68,6 +69,23 @@ extern "C" int smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const
 extern "C" int smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
   if (!ctx || (bytes && (!h_dst || !d_src))) return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_host: null argument");
   if (bytes) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_alloc_host(smilehip_context *ctx, uint64_t bytes, void **h_ptr) {
+  if (!ctx || !h_ptr) return fail(SMILEHIP_ERR_INVALID, "smilehip_alloc_host: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_free_host(smilehip_context *ctx, void *h_ptr) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_free_host: null context");
+  if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_htk_rows_be(smilehip_context *ctx, const float *d_src, int64_t n, void *d_dst, void *stream) {
+  if (!ctx || n < 0 || (n && (!d_src || !d_dst))) return fail(SMILEHIP_ERR_INVALID, "smilehip_htk_rows_be: bad argument");
+  const hipError_t e = smilehip::stage_htk_rows_be(d_src, n, static_cast<uint32_t *>(d_dst), (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "smilehip_htk_rows_be: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
 extern "C" int smilehip_stream_synchronize(smilehip_context *ctx, void *stream) {

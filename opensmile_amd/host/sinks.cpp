@@ -1,4 +1,8 @@
 // HTK / CSV / ARFF writers with the reference sinks' byte layouts and printf formats.
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -203,6 +207,41 @@ bool write_htk(const std::string &path, const float *x, int64_t rows, int cols, 
     ok = fwrite(row.data(), 1, row.size(), f) == row.size();
   }
   if (fclose(f) != 0) ok = false;
+  if (!ok) err = "error writing '" + path + "'";
+  return ok;
+}
+
+// The same file from rows that already are big-endian (smilehip_htk_rows_be did cHtkSink's swap on the device), dense
+// (ld = cols): header and rows leave in ONE writev().
+bool write_htk_be(const std::string &path, const void *be_rows, int64_t rows, int cols, double period_sec, int parm_kind,
+                  std::string &err) {
+  const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) { err = "cannot open '" + path + "' for writing"; return false; }
+  unsigned char h[12];
+  be32(h, (uint32_t)rows);
+  be32(h + 4, period_sec <= 0.0 ? 100000u : (uint32_t)std::round(period_sec * 10000000.0));
+  be16(h + 8, (uint16_t)(sizeof(float) * (size_t)cols));
+  be16(h + 10, (uint16_t)parm_kind);
+  const size_t body = (size_t)rows * (size_t)cols * 4;
+  struct iovec iov[2] = {{h, 12}, {const_cast<void *>(be_rows), body}};
+  size_t done = 0;
+  const size_t total = 12 + body;
+  bool ok = true;
+  while (ok && done < total) {
+    struct iovec cur[2];
+    int n = 0;
+    size_t skip = done;
+    for (int i = 0; i < 2; ++i) {
+      if (skip >= iov[i].iov_len) { skip -= iov[i].iov_len; continue; }
+      cur[n].iov_base = static_cast<char *>(iov[i].iov_base) + skip;
+      cur[n].iov_len = iov[i].iov_len - skip;
+      skip = 0;
+      ++n;
+    }
+    const ssize_t k = writev(fd, cur, n);
+    if (k <= 0) ok = false; else done += (size_t)k;
+  }
+  if (close(fd) != 0) ok = false;
   if (!ok) err = "error writing '" + path + "'";
   return ok;
 }

@@ -29,6 +29,11 @@ struct WaveInfo {
 // "data" skipped with their pad byte, fmt size 16/18/40, PCM or IEEE float) and reads the
 // data chunk (clipped to what the file really holds). Returns false + err on failure.
 bool read_wave_file(const std::string &path, WaveInfo &info, std::vector<unsigned char> &data, std::string &err);
+// The same in two steps, for hosts that read the samples straight into a staging buffer of their own: the header walk alone
+// (info.n_blocks clipped to what the file holds), then `bytes` of the data chunk from info.header_offset into dst (pread).
+// read_wave_data returns the sample frames it got (fewer than asked for if the file ended), -1 + err on an I/O error.
+bool probe_wave_file(const std::string &path, WaveInfo &info, std::string &err);
+long read_wave_data(const std::string &path, const WaveInfo &info, void *dst, size_t bytes, std::string &err);
 
 // Element names of a level, as cCsvSink/cArffSink obtain them from the data memory
 // (src/core/dataMemoryLevel.cpp naming: field name + "[index]" for array fields).
@@ -58,6 +63,9 @@ std::vector<std::string> funcspec_value_names(const smilehip_func_spec &spec, co
 // {nSamples u32, samplePeriod u32 [100 ns], sampleSize u16, parmKind u16} + big-endian float32 rows.
 bool write_htk(const std::string &path, const float *x, int64_t rows, int cols, int64_t ld, double period_sec,
                int parm_kind, std::string &err);
+// the same file from dense rows that are big-endian already (smilehip_htk_rows_be): one writev()
+bool write_htk_be(const std::string &path, const void *be_rows, int64_t rows, int cols, double period_sec, int parm_kind,
+                  std::string &err);
 
 // printf("%e", v) / printf("%.0f", v) for a float argument without printf: the decimal digits by exact integer arithmetic
 // (the value is m * 2^e with m < 2^24: 128-bit integers hold every case with |v| in [1e-21, 3.4e38]; round-half-even like

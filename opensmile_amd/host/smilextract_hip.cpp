@@ -31,6 +31,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -70,14 +72,16 @@ std::string basename_noext(const std::string &p) {
 }
 
 
-// f(i) for i in [0, n) on up to 32 threads (file ingest and the per-file sinks: one open / read-or-write / close each, which a
+// f(i) for i in [0, n) on up to 16 threads (SMILEHIP_IO_THREADS; measured on the 256-core host of an MI355X box, 8000 x 320 KB files on tmpfs:
+// 8 threads 60 GB/s, 16 threads 76-108, 32 threads 42-126, 64 threads 25-40, 128 threads 13-28 -- more threads than that only contend) (file ingest and the per-file sinks: one open / read-or-write / close each, which a
 // single thread spends most of its time waiting on); the first error message wins and is reported after the join
 template <class F>
 void parallel_for(size_t n, F f) {
   unsigned hw = std::thread::hardware_concurrency();
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned)CPU_COUNT(&set);      // cgroup / taskset limits
-  const size_t nt = std::min<size_t>(n, std::min<unsigned>(32u, std::max(1u, hw)));
+  static const unsigned cap = [] { const char *e = getenv("SMILEHIP_IO_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
+  const size_t nt = std::min<size_t>(n, std::min<unsigned>(cap, std::max(1u, hw)));
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
   std::atomic<size_t> next{0};
   std::vector<std::thread> th;
@@ -88,8 +92,11 @@ void parallel_for(size_t n, F f) {
 
 struct Chunk {                                             // the files [j0, j1) of the list, read
   size_t j0 = 0, j1 = 0;
-  std::vector<std::vector<unsigned char>> raw;
+  std::vector<std::vector<unsigned char>> raw;             // per file (the general route)
   std::vector<WaveInfo> info;
+  bool fast = false;                                       // every file 16-bit mono PCM at one rate: the samples are in `pcm` already,
+  int16_t *pcm = nullptr;                                  // a page-locked buffer, utterance k = [true_off[k], true_off[k + 1])
+  std::vector<int64_t> true_off;
   std::string err;
 };
 
@@ -302,6 +309,16 @@ int main(int argc, char **argv) {
     }
   }
 
+  // The header walk of EVERY file of the list starts now, beside the device's start-up (a quarter of a second during which the
+  // host would otherwise idle); the chunks' ingest then only lays the samples out and reads them.
+  std::vector<WaveInfo> all_info(jobs.size());
+  std::vector<std::string> all_probe_err(jobs.size());
+  const bool no_pinned = getenv("SMILEHIP_NO_PINNED") != nullptr;   // A/B switch: the pageable, serial route of round 3 (same files)
+  std::shared_future<void> probed = std::async(std::launch::async, [&] {
+    if (no_pinned) return;
+    parallel_for(jobs.size(), [&](size_t k) { probe_wave_file(jobs[k].wav, all_info[k], all_probe_err[k]); });
+  }).share();
+  g_before_exit = [&] { probed.wait(); };
   smilehip_context *ctx = nullptr;
   check(smilehip_init(device, &ctx), "smilehip_init");
   // --gather: the summary rows of every rank travel to rank 0 over RCCL (libsmilehip_comm.so, loaded only here) and rank 0
@@ -329,7 +346,7 @@ int main(int argc, char **argv) {
   std::vector<float> gathered;                              // this rank's summary rows: n_func values + a "has an instance" flag each
   int gathered_cols = 0;
   std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
-  const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 1024;
+  const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 256;
   if (chunk_files_l < 1) die("--chunk-files must be a positive number");
   const size_t chunk_files = (size_t)chunk_files_l;
   // Summary sinks (one row per file appended to ONE file) of several ranks must not share a file: each rank of a
@@ -351,58 +368,168 @@ int main(int argc, char **argv) {
   const uint32_t fmask = smilehip_functionals_is09_mask();
   std::string err;
 
-  // ---- ingest: the files of a chunk are read by up to 32 threads, and chunk k + 1 is read while chunk k is on the device
-  // and in the sinks (16-bit mono PCM is what the fused kernels take)
-  auto ingest = [&](size_t j0) {
+  // ---- staging (round 5). The route is bound by the host, not the device (the MFCC kernel takes 0.4 ms per 1000 x 10 s files,
+  // PCIe 6 ms): the samples are read straight into PAGE-LOCKED memory (probe the headers, lay the chunk out, pread every data
+  // chunk to its place: no per-file vector, no packing copy), the device buffers are kept from chunk to chunk, the feature rows
+  // come back into page-locked memory -- big-endian already when HTK files are all that is written (smilehip_htk_rows_be), so a
+  // file's sink is one writev() -- and the sinks of chunk k run beside the device work of chunk k + 1 and the ingest of chunk
+  // k + 2. SMILEHIP_NO_PINNED=1: the pageable, serial route of round 3 (A/B switch; same files).
+  const bool timing = getenv("SMILEHIP_TIMING") != nullptr;
+  struct HostBuf { void *p = nullptr; size_t cap = 0; };
+  HostBuf pcm_slot[2], out_slot[2];
+  auto host_reserve = [&](HostBuf &hb, size_t bytes) -> void * {
+    if (bytes <= hb.cap) return hb.p;
+    if (hb.p) smilehip_free_host(ctx, hb.p);
+    hb.p = nullptr; hb.cap = 0;
+    const size_t cap = bytes + bytes / 8 + 4096;
+    if (smilehip_alloc_host(ctx, cap, &hb.p) != SMILEHIP_OK) return nullptr;
+    hb.cap = cap;
+    return hb.p;
+  };
+  HostBuf dev_pcm, dev_lld, dev_func;                       // device buffers, kept and grown
+  auto dev_reserve = [&](HostBuf &db, size_t bytes) -> void * {
+    if (bytes <= db.cap && db.p) return db.p;
+    if (db.p) smilehip_free(ctx, db.p);
+    db.p = nullptr; db.cap = 0;
+    const size_t cap = bytes + bytes / 8 + 4096;
+    check(smilehip_alloc(ctx, cap, &db.p), "smilehip_alloc");
+    db.cap = cap;
+    return db.p;
+  };
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  double t_wait_ingest = 0.0, t_device = 0.0, t_wait_sink = 0.0, t_dev_create = 0.0, t_dev_enqueue = 0.0, t_dev_reserve = 0.0, t_dev_sync = 0.0;
+  std::atomic<int64_t> us_probe{0}, us_reserve{0}, us_read{0}, us_sink{0};   // inside the ingest / sink threads (SMILEHIP_TIMING)
+
+  // ---- ingest: chunk k + 1 is read while chunk k is on the device and chunk k - 1 in the sinks (16-bit mono PCM is what the
+  // fused kernels take)
+  auto ingest = [&](size_t j0, size_t slot) {
     Chunk c;
     c.j0 = j0;
     c.j1 = std::min(jobs.size(), j0 + chunk_files);
-    c.raw.resize(c.j1 - c.j0);
-    c.info.resize(c.j1 - c.j0);
+    const size_t n = c.j1 - c.j0;
+    c.raw.resize(n);
+    c.info.resize(n);
     std::mutex m;
-    parallel_for(c.j1 - c.j0, [&](size_t k) {
-      std::string e;
-      WaveInfo &wi = c.info[k];
-      if (!read_wave_file(jobs[c.j0 + k].wav, wi, c.raw[k], e)) { std::lock_guard<std::mutex> g(m); if (c.err.empty()) c.err = e; return; }
+    auto fail1 = [&](const std::string &e) { std::lock_guard<std::mutex> g(m); if (c.err.empty()) c.err = e; };
+    auto format_ok = [&](size_t k) {
+      const WaveInfo &wi = c.info[k];
       // integer PCM of any width, or 32-bit IEEE float (the one float format the reference converts, smileUtil.c:2653-2662)
       const bool int_ok = wi.sample_type == 1 && wi.n_bps >= 1 && wi.n_bps <= 4;
       const bool float_ok = wi.sample_type == 3 && wi.n_bps == 4 && wi.n_bits == 32;
-      if (wi.n_chan < 1 || !(int_ok || float_ok)) {
-        std::lock_guard<std::mutex> g(m);
-        if (c.err.empty()) c.err = "'" + jobs[c.j0 + k].wav + "': integer PCM (8 / 16 / 24 / 32 bit) or 32-bit IEEE float, any number of channels, "
-                                   "is what the reference converts (smilePcm_convertSamples / smilePcm_convertFloatSamples); this file is neither";
+      if (wi.n_chan < 1 || !(int_ok || float_ok))
+        fail1("'" + jobs[c.j0 + k].wav + "': integer PCM (8 / 16 / 24 / 32 bit) or 32-bit IEEE float, any number of channels, "
+              "is what the reference converts (smilePcm_convertSamples / smilePcm_convertFloatSamples); this file is neither");
+    };
+    double ti = now();
+    auto lap = [&](std::atomic<int64_t> &acc) { const double t = now(); acc += (int64_t)((t - ti) * 1e6); ti = t; };
+    if (!no_pinned) {
+      probed.wait();
+      for (size_t k = 0; k < n; ++k) {
+        if (!all_probe_err[c.j0 + k].empty()) { fail1(all_probe_err[c.j0 + k]); break; }
+        c.info[k] = all_info[c.j0 + k];
+        format_ok(k);
       }
+      lap(us_probe);
+      if (!c.err.empty()) return c;
+      c.fast = n > 0;
+      for (size_t k = 0; k < n && c.fast; ++k) {
+        const WaveInfo &wi = c.info[k];
+        c.fast = wi.sample_type == 1 && wi.n_bps == 2 && wi.n_chan == 1 && wi.sample_rate == c.info[0].sample_rate;
+      }
+    }
+    if (c.fast) {
+      c.true_off.assign(n + 1, 0);
+      for (size_t k = 0; k < n; ++k) c.true_off[k + 1] = c.true_off[k] + (int64_t)c.info[k].n_blocks;
+      int16_t *pcm = static_cast<int16_t *>(host_reserve(pcm_slot[slot], ((size_t)c.true_off[n] + 2) * 2));
+      if (!pcm) { c.err = std::string("page-locked staging buffer: ") + smilehip_last_error(); return c; }
+      c.pcm = pcm;
+      pcm[c.true_off[n]] = 0; pcm[c.true_off[n] + 1] = 0;
+      lap(us_reserve);
+      parallel_for(n, [&](size_t k) {
+        std::string e;
+        const long want = c.info[k].n_blocks;
+        if (want <= 0) return;
+        const long got = read_wave_data(jobs[c.j0 + k].wav, c.info[k], pcm + c.true_off[k], (size_t)want * 2, e);
+        if (got < 0) fail1(e);
+        else if (got != want) fail1("'" + jobs[c.j0 + k].wav + "' changed while it was read");
+      });
+      lap(us_read);
+      return c;
+    }
+    parallel_for(n, [&](size_t k) {
+      std::string e;
+      if (!read_wave_file(jobs[c.j0 + k].wav, c.info[k], c.raw[k], e)) { fail1(e); return; }
+      format_ok(k);
     });
     return c;
   };
-  std::future<Chunk> ahead = std::async(std::launch::async, ingest, (size_t)0);
-  g_before_exit = [&] { if (ahead.valid()) ahead.wait(); };
-  for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_files) {
+  // what a chunk's per-file sinks need once the device is done with it (they run beside the next chunk's device work)
+  struct SinkWork {
+    std::vector<size_t> idx;
+    std::vector<int64_t> row_off, true_off;
+    std::vector<float> func, lld_vec;
+    const float *lld = nullptr;
+    int n_out = 0, n_func = 0;
+    bool be = false;
+    smilehip_geometry g;
+    smilehip_plan *plan = nullptr;
+    std::string err;
+  };
+  std::future<std::string> sink_fut[2];
+  auto sink_wait = [&](size_t slot) {
+    if (!sink_fut[slot].valid()) return;
+    const double t0 = now();
+    const std::string e = sink_fut[slot].get();
+    t_wait_sink += now() - t0;
+    if (!e.empty()) die(e);
+  };
+  std::future<Chunk> ahead = std::async(std::launch::async, ingest, (size_t)0, (size_t)0);
+  g_before_exit = [&] {
+    probed.wait();
+    if (ahead.valid()) ahead.wait();
+    for (auto &f : sink_fut) if (f.valid()) f.wait();
+  };
+  auto make_plan = [&](long rate) -> smilehip_plan * {
+    smilehip_plan *&plan = plans[rate];
+    if (!plan) {
+      smilehip_lld_config cfg;
+      if (is09) smilehip_config_is09_lld(&cfg);
+      else if (is13) smilehip_config_is13_compare(&cfg);
+      else if (cmp16) smilehip_config_compare16(&cfg);
+      else if (egm_v01a) smilehip_config_egemapsv01a(&cfg);
+      else if (egm) smilehip_config_egemapsv02(&cfg);
+      else cfg = vcfg;
+      if (with_conf) conf_apply_f0_params(conf_plan, cfg);     // an edited big-set file: its own pitch range, harmonics, buffer ...
+      cfg.sample_rate = (double)rate;
+      check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
+    }
+    return plan;
+  };
+  // (the first file's rate is almost always every file's: its plan -- tables, uploads -- is built while the first chunk is read)
+  if (!no_pinned && !jobs.empty()) { probed.wait(); if (all_probe_err[0].empty() && all_info[0].sample_rate > 0) make_plan(all_info[0].sample_rate); }
+  size_t chunk_no = 0;
+  for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_files, ++chunk_no) {
     const size_t j1 = std::min(jobs.size(), j0 + chunk_files);
+    const size_t slot = chunk_no & 1;
+    double t0 = now();
     Chunk chunk = ahead.get();
-    if (j1 < jobs.size()) ahead = std::async(std::launch::async, ingest, j1);
+    t_wait_ingest += now() - t0;
+    if (j1 < jobs.size()) ahead = std::async(std::launch::async, ingest, j1, slot ^ 1);
     if (!chunk.err.empty()) die(chunk.err);
+    t0 = now();
     std::map<long, std::vector<size_t>> by_rate;
     std::vector<std::vector<unsigned char>> &raw = chunk.raw;
     for (size_t j = j0; j < j1; ++j) by_rate[chunk.info[j - j0].sample_rate].push_back(j);
     std::vector<std::vector<float>> func_rows(j1 - j0);   // per job of the chunk; empty = no instance (no frame)
     for (auto &kv : by_rate) {
-      smilehip_plan *&plan = plans[kv.first];
-      if (!plan) {
-        smilehip_lld_config cfg;
-        if (is09) smilehip_config_is09_lld(&cfg);
-        else if (is13) smilehip_config_is13_compare(&cfg);
-        else if (cmp16) smilehip_config_compare16(&cfg);
-        else if (egm_v01a) smilehip_config_egemapsv01a(&cfg);
-        else if (egm) smilehip_config_egemapsv02(&cfg);
-        else cfg = vcfg;
-        if (with_conf) conf_apply_f0_params(conf_plan, cfg);     // an edited big-set file: its own pitch range, harmonics, buffer ...
-        cfg.sample_rate = (double)kv.first;
-        check(smilehip_plan_create(ctx, &cfg, &plan), "smilehip_plan_create");
-      }
-      smilehip_geometry g;
-      check(smilehip_plan_geometry(plan, &g), "smilehip_plan_geometry");
-      const std::vector<size_t> &idx = kv.second;
+      smilehip_plan *plan = make_plan(kv.first);
+      std::shared_ptr<SinkWork> w = std::make_shared<SinkWork>();
+      check(smilehip_plan_geometry(plan, &w->g), "smilehip_plan_geometry");
+      const smilehip_geometry &g = w->g;
+      w->plan = plan;
+      w->idx = kv.second;
+      const std::vector<size_t> &idx = w->idx;
       // exact packing: utterance u = samples [off[u], off[u+1]) of one buffer (the kernels use
       // dword PCM loads when every offset is even, 16-bit loads otherwise). 16-bit mono files go to the device as they are
       // (the kernels convert at the load); any other integer format / channel count and IEEE float are converted on the device by
@@ -413,29 +540,43 @@ int main(int argc, char **argv) {
         const WaveInfo &wi = chunk.info[idx[i] - j0];
         all_s16_mono = all_s16_mono && wi.sample_type == 1 && wi.n_bps == 2 && wi.n_chan == 1;
       }
-      std::vector<int64_t> true_off(idx.size() + 1, 0);
-      for (size_t i = 0; i < idx.size(); ++i) {
-        const WaveInfo &wi = chunk.info[idx[i] - j0];
-        true_off[i + 1] = true_off[i] + (int64_t)(raw[idx[i] - j0].size() / (size_t)(wi.n_bps * wi.n_chan));
-      }
-      std::vector<int16_t> pcm(all_s16_mono ? (size_t)true_off.back() + 2 : 2, 0);
-      for (size_t i = 0; i < idx.size() && all_s16_mono; ++i) {
-        const auto &r = raw[idx[i] - j0];
-        if (!r.empty()) std::memcpy(&pcm[(size_t)true_off[i]], r.data(), r.size() & ~(size_t)1);
+      std::vector<int64_t> &true_off = w->true_off;
+      std::vector<int16_t> pcm_vec;
+      const int16_t *pcm_host = nullptr;
+      if (chunk.fast) {                                   // (one rate group: the chunk itself, in list order)
+        true_off = chunk.true_off;
+        pcm_host = chunk.pcm;
+      } else {
+        true_off.assign(idx.size() + 1, 0);
+        for (size_t i = 0; i < idx.size(); ++i) {
+          const WaveInfo &wi = chunk.info[idx[i] - j0];
+          true_off[i + 1] = true_off[i] + (int64_t)(raw[idx[i] - j0].size() / (size_t)(wi.n_bps * wi.n_chan));
+        }
+        pcm_vec.assign(all_s16_mono ? (size_t)true_off.back() + 2 : 2, 0);
+        for (size_t i = 0; i < idx.size() && all_s16_mono; ++i) {
+          const auto &r = raw[idx[i] - j0];
+          if (!r.empty()) std::memcpy(&pcm_vec[(size_t)true_off[i]], r.data(), r.size() & ~(size_t)1);
+        }
+        pcm_host = pcm_vec.data();
       }
       smilehip_batch *b = nullptr;
+      double td = now();
+      auto dlap = [&](double &acc) { const double t = now(); acc += t - td; td = t; };
       check(smilehip_batch_create(plan, true_off.data(), (int32_t)idx.size(), &b), "smilehip_batch_create");
+      dlap(t_dev_create);
       const int64_t rows = smilehip_batch_total_rows(b);
-      std::vector<int64_t> row_off(idx.size() + 1, 0);
+      std::vector<int64_t> &row_off = w->row_off;
+      row_off.assign(idx.size() + 1, 0);
       check(smilehip_batch_frame_offsets(b, row_off.data()), "smilehip_batch_frame_offsets");
       const int n_out = g.n_out;
-      void *d_pcm = nullptr, *d_lld = nullptr, *d_func = nullptr;
+      w->n_out = n_out;
+      void *d_func = nullptr;
       const uint64_t pcm_bytes = (uint64_t)std::max<int64_t>(true_off.back(), 2) * 2;
-      check(smilehip_alloc(ctx, pcm_bytes, &d_pcm), "smilehip_alloc");
-      check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4, &d_lld), "smilehip_alloc");
+      void *d_pcm = dev_reserve(dev_pcm, pcm_bytes);
+      void *d_lld = dev_reserve(dev_lld, (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4);
       void *d_f32 = nullptr;
       if (all_s16_mono) {
-        check(smilehip_copy_to_device(ctx, d_pcm, pcm.data(), (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
+        check(smilehip_copy_to_device(ctx, d_pcm, pcm_host, (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
         check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
       } else {
         check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(true_off.back(), 1) * 4, &d_f32), "smilehip_alloc");
@@ -458,11 +599,12 @@ int main(int argc, char **argv) {
         smilehip_free(ctx, d_raw);
         check(smilehip_lld_run_f32(plan, b, (const float *)d_f32, (float *)d_lld, n_out, nullptr), "smilehip_lld_run_f32");
       }
-      std::vector<float> lld((size_t)std::max<int64_t>(rows, 1) * n_out), func;
       const int n_func = is09 ? n_out * smilehip_functionals_count(fmask)
                               : (cmp16f ? smilehip_functionals_compare16_count() : (egm ? smilehip_functionals_egemaps_count() : 0));
+      w->n_func = n_func;
+      std::vector<float> &func = w->func;
       if (has_func) {
-        check(smilehip_alloc(ctx, (uint64_t)idx.size() * n_func * 4, &d_func), "smilehip_alloc");
+        d_func = dev_reserve(dev_func, (uint64_t)idx.size() * n_func * 4);
         if (is09)
           check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
                 "smilehip_batch_functionals");
@@ -475,54 +617,92 @@ int main(int argc, char **argv) {
         func.resize(idx.size() * (size_t)n_func);
         check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, nullptr), "copy_to_host");
       }
-      if (rows > 0) check(smilehip_copy_to_host(ctx, lld.data(), d_lld, (uint64_t)rows * n_out * 4, nullptr), "copy_to_host");
+      const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
+      const bool want_lld_htk = opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?";
+      const bool want_lld_csv = opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?";
+      // the feature rows: into this chunk's page-locked slot (its previous user's sinks are awaited first); big-endian on the
+      // device when HTK files are their only reader
+      dlap(t_dev_enqueue);
+      sink_wait(slot);
+      td = now();
+      const size_t lld_bytes = (size_t)std::max<int64_t>(rows, 1) * n_out * 4;
+      float *lld = nullptr;
+      if (!no_pinned && by_rate.size() == 1) lld = static_cast<float *>(host_reserve(out_slot[slot], lld_bytes));
+      if (!lld) { w->lld_vec.resize(lld_bytes / 4); lld = w->lld_vec.data(); }
+      w->lld = lld;
+      dlap(t_dev_reserve);
+      w->be = !no_pinned && want_lld_htk && !want_lld_csv && !out_subset && rows > 0;
+      if (w->be) check(smilehip_htk_rows_be(ctx, (const float *)d_lld, rows * n_out, d_lld, nullptr), "smilehip_htk_rows_be");
+      if (rows > 0) check(smilehip_copy_to_host(ctx, lld, d_lld, (uint64_t)rows * n_out * 4, nullptr), "copy_to_host");
       check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
-      // ---- sinks: the per-file outputs of the chunk are written by up to 32 threads (different files; the summary rows are
-      // collected here and appended in list order below)
-      std::mutex sink_m;
-      std::string sink_err;
-      parallel_for(idx.size(), [&](size_t i) {
-        std::string err;                                  // (shadows the function's: one per thread)
-        auto die = [&](const std::string &m) { std::lock_guard<std::mutex> g(sink_m); if (sink_err.empty()) sink_err = m; };   // (the caller returns: no further sink of this file)
-        const Job &job = jobs[idx[i]];
-        const float *x = lld.data() + (size_t)row_off[i] * n_out;
-        const int64_t r = row_off[i + 1] - row_off[i];
-        int n_w = n_out;                                  // columns written (a subset preset writes its selection)
-        std::vector<float> x_sel;
-        if (out_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
-        const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
-        if (opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?")
-          if (!write_htk(per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk"), x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)) { die(err); return; }
-        if (opt.count(lld_csv_opt) && opt[lld_csv_opt] != "?") {
-          CsvOptions co;
-          co.instance_name = job.inst;
-          // rows of the ComParE level follow the 60 ms framer: T60 + 1
-          const int64_t n_frames = (cmp16 || egm) ? r - 1 : smilehip_num_frames(plan, true_off[i + 1] - true_off[i]);
-          std::vector<double> times((size_t)r);
-          for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
-          if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_w, n_w, g.frame_period,
-                         times.data(), co, err)) {
-            die(err);
-            return;
-          }
-        }
-        if (has_func && r > 0) {                          // no frame -> the reference writes no instance
-          const float *fv = func.data() + i * (size_t)n_func;
-          int n_fw = n_func;
-          std::vector<float> f_sel;
-          if (out_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
-          func_rows[idx[i] - j0].assign(fv, fv + n_fw);
-          if (opt.count("-htkoutput") && opt["-htkoutput"] != "?")
-            if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) { die(err); return; }
-        }
-      });
-      if (!sink_err.empty()) die(sink_err);
-      smilehip_free(ctx, d_pcm);
+      dlap(t_dev_sync);
       if (d_f32) smilehip_free(ctx, d_f32);
-      smilehip_free(ctx, d_lld);
-      if (d_func) smilehip_free(ctx, d_func);
       smilehip_batch_destroy(b);
+      dlap(t_dev_create);
+      // the summary rows of the chunk (appended in list order below)
+      for (size_t i = 0; i < idx.size() && has_func; ++i) {
+        if (row_off[i + 1] - row_off[i] <= 0) continue;     // no frame -> the reference writes no instance
+        const float *fv = func.data() + i * (size_t)n_func;
+        if (out_subset) func_rows[idx[i] - j0] = select_columns(fv, 1, n_func, sel_func);
+        else func_rows[idx[i] - j0].assign(fv, fv + n_func);
+      }
+      // ---- sinks: the per-file outputs of the chunk on up to 16 threads (different files), beside the next chunk's device work
+      auto sinks = [&, w, want_lld_htk, want_lld_csv, lld_htk_opt, lld_csv_opt]() -> std::string {
+        std::mutex sink_m;
+        std::string sink_err;
+        const double ts0 = now();
+        struct Lap { std::atomic<int64_t> &a; double t0; std::function<double()> nowf; ~Lap() { a += (int64_t)((nowf() - t0) * 1e6); } } lap_sink{us_sink, ts0, now};
+        const std::vector<size_t> &idx = w->idx;
+        const int n_out = w->n_out, n_func = w->n_func;
+        const smilehip_geometry &g = w->g;
+        smilehip_plan *plan = w->plan;
+        parallel_for(idx.size(), [&](size_t i) {
+          std::string err;                                  // (shadows the function's: one per thread)
+          auto die = [&](const std::string &m) { std::lock_guard<std::mutex> gd(sink_m); if (sink_err.empty()) sink_err = m; };   // (the caller returns: no further sink of this file)
+          const Job &job = jobs[idx[i]];
+          const float *x = w->lld + (size_t)w->row_off[i] * n_out;
+          const int64_t r = w->row_off[i + 1] - w->row_off[i];
+          int n_w = n_out;                                  // columns written (a subset preset writes its selection)
+          std::vector<float> x_sel;
+          if (out_subset) { x_sel = select_columns(x, r, n_out, sel_lld); x = x_sel.data(); n_w = (int)sel_lld.size(); }
+          if (want_lld_htk) {
+            const std::string path = per_file(job, lld_htk_opt, lld_opts ? ".lld.htk" : ".htk");
+            const bool ok = w->be ? write_htk_be(path, x, r, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err)
+                                  : write_htk(path, x, r, n_w, n_w, g.frame_period, lld_opts ? 9 : parm_kind, err);
+            if (!ok) { die(err); return; }
+          }
+          if (want_lld_csv) {
+            CsvOptions co;
+            co.instance_name = job.inst;
+            // rows of the ComParE level follow the 60 ms framer: T60 + 1
+            const int64_t n_frames = (cmp16 || egm) ? r - 1 : smilehip_num_frames(plan, w->true_off[i + 1] - w->true_off[i]);
+            std::vector<double> times((size_t)r);
+            for (int64_t t = 0; t < r; ++t) times[(size_t)t] = smilehip_row_time(plan, n_frames, t);
+            if (!write_csv(per_file(job, lld_csv_opt, lld_opts ? ".lld.csv" : ".csv"), lld_names, x, r, n_w, n_w, g.frame_period,
+                           times.data(), co, err)) {
+              die(err);
+              return;
+            }
+          }
+          if (has_func && r > 0) {                          // no frame -> the reference writes no instance
+            const float *fv = w->func.data() + i * (size_t)n_func;
+            int n_fw = n_func;
+            std::vector<float> f_sel;
+            if (out_subset) { f_sel = select_columns(fv, 1, n_func, sel_func); fv = f_sel.data(); n_fw = (int)sel_func.size(); }
+            if (opt.count("-htkoutput") && opt.at("-htkoutput") != "?")
+              if (!write_htk(per_file(job, "-htkoutput", ".func.htk"), fv, 1, n_fw, n_fw, 0.0, 9, err)) { die(err); return; }
+          }
+        });
+        return sink_err;
+      };
+      if (!no_pinned && by_rate.size() == 1) {
+        sink_fut[slot] = std::async(std::launch::async, sinks);
+      } else {
+        const std::string e = sinks();
+        if (!e.empty()) die(e);
+      }
     }
+    t_device += now() - t0;
     // summary sinks in file-list order (the rate groups above may have processed the chunk's files in another order)
     for (size_t j = j0; j < j1 && has_func && gather; ++j) {       // kept for the gather at the end
       const std::vector<float> &fv = func_rows[j - j0];
@@ -550,6 +730,16 @@ int main(int argc, char **argv) {
       }
     }
   }
+  for (size_t s2 = 0; s2 < 2; ++s2) sink_wait(s2);
+  if (timing)
+    fprintf(stderr, "smilextract_hip timing: files %zu, chunks %zu; since the first ingest %.3f s: waiting for ingest %.3f, device stage (pack, copies, "
+            "kernels, summary rows) %.3f, waiting for sinks %.3f; inside the ingest thread: header probes %.3f, staging buffer %.3f, sample reads %.3f; "
+            "inside the sink threads %.3f; of the device stage: batch create / destroy %.3f, enqueue (buffers, copy in, kernels) %.3f, output buffer %.3f, "
+            "copy out + synchronize %.3f\n", jobs.size(), chunk_no, now() - t_start, t_wait_ingest, t_device, t_wait_sink,
+            us_probe.load() * 1e-6, us_reserve.load() * 1e-6, us_read.load() * 1e-6, us_sink.load() * 1e-6, t_dev_create, t_dev_enqueue,
+            t_dev_reserve, t_dev_sync);
+  for (HostBuf *hb : {&pcm_slot[0], &pcm_slot[1], &out_slot[0], &out_slot[1]}) if (hb->p) smilehip_free_host(ctx, hb->p);
+  for (HostBuf *db : {&dev_pcm, &dev_lld, &dev_func}) if (db->p) smilehip_free(ctx, db->p);
   if (gather && has_func) {
     // rank r holds the rows of files r, r + world, ...: counts to everyone, rows to rank 0, rank 0 writes in list order
     std::vector<int64_t> counts((size_t)world, 0);
