@@ -806,6 +806,12 @@ static bool conf_to_plan_inner(const ConfFile &f, ConfPlan &p, std::string &err)
     std::set<std::string> produced;
     for (const std::string &l : split_levels(want)) produced.insert(l);
     if (!conf_check_io(f, produced, err)) return false;
+    p.out_levels = want;
+    if (produced.size() == 1)
+      for (const ConfInstance &i : f.inst) {
+        const std::string *w = i.find("writer.dmLevel");
+        if (w && *w == want) { p.out_writer_name = i.name; p.out_writer_type = i.type; }
+      }
   }
   // must be [cepstra (, energy)] x (1 + n_delta) blocks, the cepstra of block 0 either all normalised or none
   const int n_cep = p.plp ? c.plp_lp_order - c.first_mfcc + 1 : c.last_mfcc - c.first_mfcc + 1;

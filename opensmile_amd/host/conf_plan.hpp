@@ -49,6 +49,9 @@ struct ConfPlan {
   // hold plain static columns of the fused static block (cepstrum j -> j, log energy -> number of cepstra)
   std::vector<std::string> stage_levels;
   std::map<std::string, std::vector<int>> static_levels;
+  // cepstral chains: the level(s) the sinks read ("lld", or "a;b;c" if they read several) and, when it is ONE level, the instance
+  // that writes it (name, type) -- the plugin's fused mode hands the finished rows out there (plugin_shared.hpp)
+  std::string out_levels, out_writer_name, out_writer_type;
   std::string wave_file;                 // the wave source's filename option, command-line options applied
   // big sets recognised through the masked fingerprint: the values of the parameter options the file sets, keyed by the
   // smilehip_lld_config field they map to (pitch_min, pitch_max, voicing_cutoff, shs_n_harmonics, shs_compression,

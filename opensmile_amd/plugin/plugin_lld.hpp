@@ -12,7 +12,18 @@ class cHipEnergy : public cEnergy {
   int htk_ = 0, erms_ = 0, e2_ = 0, elog_ = 0;
   FLOAT_DMEM sRms_ = 1, sLog_ = 1, sSq_ = 1, bLog_ = 0, bRms_ = 0, bSq_ = 0;
   bool ready_ = false;
+  cMatrix *fblock_ = nullptr;
  protected:
+  // fused chain, tick-level hand-out (plugin_shared.hpp: FusedChain::tick_write): this component's level gets its rows a block
+  // per tick, whatever its reader holds (nothing: the wave source idles)
+  eTickResult myTick(long long t) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_ && g_fused.tick_mode) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
+    }
+    return cEnergy::myTick(t);
+  }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
     if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
@@ -51,8 +62,60 @@ class cHipEnergy : public cEnergy {
   }
  public:
   explicit cHipEnergy(const char *n) : cEnergy(n) {}
+  ~cHipEnergy() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipEnergy(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cWaveSource (src/iocore/waveSource.cpp:240-294) inside a fused chain: the batch read the file itself, the components that hand
+// out its rows do so at the tick level (FusedChain::tick_write) -- the source has nothing to feed anybody and idles; every
+// component between it and the chain's last ones then finds no data and idles with it. Outside a tick-level fused chain it is
+// the reference's source, untouched.
+class cHipWaveSource : public cWaveSource {
+ protected:
+  eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (g_fused.active && g_fused.tick_mode) return TICK_INACTIVE;
+    return cWaveSource::myTick(t);
+  }
+ public:
+  explicit cHipWaveSource(const char *n) : cWaveSource(n) {}
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipWaveSource(n);
+    c->setComponentInfo(scname, sdescription);
+    return c;
+  }
+};
+
+// cVectorConcat (src/other/vectorConcat.cpp) as the last component of a fused cepstral chain: the level the sinks read gets the
+// batch's finished rows (static | delta | acceleration, mean-normalised where the file says so) at the tick level. Anywhere
+// else it is the reference's component, untouched.
+class cHipVectorConcat : public cVectorConcat {
+  int fused_ = -1;
+  const FusedLevel *fcols_ = nullptr;
+  long fnext_ = 0;
+  cMatrix *fblock_ = nullptr;
+ protected:
+  eTickResult myTick(long long t) override {
+    if (fused_ < 0) {
+      g_fused.init();
+      fcols_ = (g_fused.active && g_fused.final_level) ? g_fused.static_level(getStr("writer.dmLevel")) : nullptr;
+      fused_ = fcols_ ? 1 : 0;
+    }
+    if (fused_) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
+    }
+    return cVectorConcat::myTick(t);
+  }
+ public:
+  explicit cHipVectorConcat(const char *n) : cVectorConcat(n) {}
+  ~cHipVectorConcat() override { delete fblock_; }
+  static cSmileComponent *create(const char *n) {
+    cSmileComponent *c = new cHipVectorConcat(n);
     c->setComponentInfo(scname, sdescription);
     return c;
   }

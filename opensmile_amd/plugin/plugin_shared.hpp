@@ -255,8 +255,14 @@ struct FusedChain {
   void init() {
     if (tried) return;
     tried = true;
+    // Round 5: fused mode is the DEFAULT whenever the file's graph is one the host library's reader recognises (conf_plan.cpp) and
+    // the input is a 16-bit mono wave file; SMILEHIP_PLUGIN_FUSE=0 keeps every component on its own operator (one device round
+    // trip per frame and component: the parity vehicle, ~100 x slower than the fused batch), =1 asks for it loudly (warnings say
+    // why a file does not fuse; by default those are messages of level 3).
     const char *on = getenv("SMILEHIP_PLUGIN_FUSE");
-    if (!on || !*on || !strcmp(on, "0")) return;
+    if (on && !strcmp(on, "0")) return;
+    const bool loud = on && *on;
+#define FUSE_NOTE(...) do { if (loud) { SMILE_WRN(1, __VA_ARGS__); } else { SMILE_MSG(3, __VA_ARGS__); } } while (0)
     std::vector<std::string> args;
     if (FILE *f = fopen("/proc/self/cmdline", "rb")) {
       std::string cur;
@@ -277,17 +283,17 @@ struct FusedChain {
     std::string err;
     smilehip_host::ConfFile cf;
     if (conf.empty() || !smilehip_host::conf_parse(conf, cl, cf, err)) {
-      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: cannot read the configuration file (%s) -- per-component path", err.c_str());
+      FUSE_NOTE("libsmilehip plugin: fused mode: cannot read the configuration file (%s) -- per-component path", err.c_str());
       return;
     }
     if (!smilehip_host::conf_to_plan(cf, plan, err)) {
-      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: %s -- per-component path", err.c_str());
+      FUSE_NOTE("libsmilehip plugin: fused mode: %s -- per-component path", err.c_str());
       return;
     }
     smilehip_host::WaveInfo wi;
     std::vector<unsigned char> raw;
     if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
-      SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
+      FUSE_NOTE("libsmilehip plugin: fused mode: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
       return;
     }
     if (!plan.preset.empty()) {
@@ -295,13 +301,24 @@ struct FusedChain {
       const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
       const bool all = !only || !*only || !strcmp(only, "all");
       if (!all || plan.last_mfcc > 0 || !plan.func_enabled.empty() || !init_big(wi, raw))
-        SMILE_WRN(1, "libsmilehip plugin: SMILEHIP_PLUGIN_FUSE: this big-set file does not fuse inside the reference process -- per-component path");
+        FUSE_NOTE("libsmilehip plugin: fused mode: this big-set file does not fuse inside the reference process -- per-component path");
       return;
     }
     smilehip_lld_config c = plan.cfg;
     c.sample_rate = (double)wi.sample_rate;
-    c.n_delta = 0;                                        // the static block is all the chain components hand on;
-    c.cms = 0;                                            // mean normalisation and deltas stay with the reference's components
+    // Where the rows are handed out. FINAL (round 5): the sinks read one level written by a cVectorConcat, every override is
+    // registered -> the batch computes the file's whole output level (mean normalisation, regression stages: what smilextract_hip
+    // writes for the same file) and cHipVectorConcat writes it at the tick level; nothing upstream of it ever ticks with data.
+    // Otherwise the static block only: mean normalisation, deltas and concatenation stay with the reference's components.
+    {
+      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS"), *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
+      const bool all = !only || !*only || !strcmp(only, "all");
+      final_level = all && plan.out_writer_type == "cVectorConcat" && !(tm && (!strcmp(tm, "0") || !strcmp(tm, "static")));
+    }
+    if (!final_level) {
+      c.n_delta = 0;                                      // the static block is all the chain components hand on;
+      c.cms = 0;                                          // mean normalisation and deltas stay with the reference's components
+    }
     smilehip_plan *pl = nullptr;
     check(smilehip_plan_create(context(), &c, &pl));
     smilehip_geometry g;
@@ -314,15 +331,61 @@ struct FusedChain {
     n_cols = g.n_out;
     rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
     if (n_rows > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows.data()));
+    {                                                      // tick-level hand-out: needs the wave source's override (it idles) -- every component registered
+      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS"), *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
+      const bool all = !only || !*only || !strcmp(only, "all");
+      tick_mode = all && !(tm && !strcmp(tm, "0"));        // SMILEHIP_PLUGIN_FUSE_TICK=0: the per-frame hand-out of round 3 (A/B switch)
+      const int64_t n_frames = smilehip_num_frames(pl, n);
+      times.assign((size_t)(n_rows > 0 ? n_rows : 1), 0.0);
+      for (long t = 0; t < n_rows; ++t) times[(size_t)t] = smilehip_row_time(pl, n_frames, t);
+      frame_size_sec = c.frame_size_sec;
+      frame_period_sec = c.frame_step_sec;
+    }
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
-    for (const auto &kv : plan.static_levels) {
-      FusedLevel L;
-      L.M = &rows; L.ld = n_cols; L.n_rows = n_rows; L.cols = kv.second;
-      levels[kv.first] = L;
+    if (final_level) {
+      add_level(plan.out_levels, &rows, n_cols, n_rows, 0, n_cols);
+    } else {
+      for (const auto &kv : plan.static_levels) {
+        FusedLevel L;
+        L.M = &rows; L.ld = n_cols; L.n_rows = n_rows; L.cols = kv.second;
+        levels[kv.first] = L;
+      }
     }
     active = true;
     SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld frames of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+  }
+  // ---- tick-level hand-out (round 5; the cepstral chains). The per-frame hand-out above still walks the reference's tick loop
+  // once per frame for every component of the chain (framer, pre-emphasis, window, transform, magnitudes, mel bank: six levels
+  // written and read per frame to carry zeros) -- an hour of audio took LONGER than the CPU binary. Here the wave source idles
+  // (cHipWaveSource: nothing upstream of the chain's last components ever sees data) and those last components write their rows
+  // straight to their levels, a block of frames per tick, with the time stamps the framer would have given them.
+  bool tick_mode = false;
+  bool final_level = false;                               // the rows are the sinks' own level (cHipVectorConcat hands them out)
+  std::vector<double> times;                              // frame time stamps of the batch's rows (smilehip_row_time)
+  double frame_size_sec = 0.0, frame_period_sec = 0.0;
+  // writes the next rows of L to `writer`; next = rows written so far by this component; block: the component's own matrix
+  eTickResult tick_write(const FusedLevel &L, cDataWriter *writer, long &next, cMatrix *&block, long blocksize_w) {
+    long n = L.n_rows - next;
+    if (n <= 0) return TICK_INACTIVE;
+    if (blocksize_w > 0 && n > blocksize_w) n = blocksize_w;
+    if (n > 256) n = 256;
+    while (n > 1 && !writer->checkWrite(n)) n >>= 1;
+    if (!writer->checkWrite(n)) return TICK_DEST_NO_SPACE;
+    const long N = (long)L.cols.size();
+    if (!block || block->nT != n || block->N != N) { delete block; block = new cMatrix((int)N, (int)n); }
+    for (long t = 0; t < n; ++t) {
+      const float *r = L.M->data() + (size_t)(next + t) * L.ld;
+      FLOAT_DMEM *d = block->data + (size_t)t * N;         // data[el + t * N]
+      for (long k = 0; k < N; ++k) d[k] = r[L.cols[(size_t)k]];
+      block->tmeta[t].time = times[(size_t)(next + t)];
+      block->tmeta[t].lengthSec = frame_size_sec;
+      block->tmeta[t].period = frame_period_sec;
+    }
+    writer->setNextMatrix(block);
+    next += n;
+    served += n;
+    return TICK_SUCCESS;
   }
   // row `frame` of a fused level
   void copy(const FusedLevel &L, long frame, FLOAT_DMEM *dst, long Ndst) {

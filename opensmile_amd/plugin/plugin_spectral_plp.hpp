@@ -182,7 +182,18 @@ class cHipPlp : public cPlp {
   int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0, firstCC_ = 0, htk_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
+  cMatrix *fblock_ = nullptr;
  protected:
+  // fused chain, tick-level hand-out (plugin_shared.hpp: FusedChain::tick_write): this component's level gets its rows a block
+  // per tick, whatever its reader holds (nothing: the wave source idles)
+  eTickResult myTick(long long t) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_ && g_fused.tick_mode) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
+    }
+    return cPlp::myTick(t);
+  }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
     if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
@@ -274,6 +285,7 @@ class cHipPlp : public cPlp {
   }
  public:
   explicit cHipPlp(const char *n) : cPlp(n) {}
+  ~cHipPlp() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPlp(n);
     c->setComponentInfo(scname, sdescription);

@@ -305,7 +305,18 @@ class cHipMfcc : public cMfcc {
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
+  cMatrix *fblock_ = nullptr;
  protected:
+  // fused chain, tick-level hand-out (plugin_shared.hpp: FusedChain::tick_write): this component's level gets its rows a block
+  // per tick, whatever its reader holds (nothing: the wave source idles)
+  eTickResult myTick(long long t) override {
+    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
+    if (fused_ && g_fused.tick_mode) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
+    }
+    return cMfcc::myTick(t);
+  }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
     if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
@@ -331,6 +342,7 @@ class cHipMfcc : public cMfcc {
   }
  public:
   explicit cHipMfcc(const char *n) : cMfcc(n) {}
+  ~cHipMfcc() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipMfcc(n);
     c->setComponentInfo(scname, sdescription);

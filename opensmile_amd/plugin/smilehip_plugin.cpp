@@ -22,6 +22,7 @@
 #include <core/componentManager.hpp>
 #include <core/dataSource.hpp>
 #include <core/smileCommon.hpp>
+#include <iocore/waveSource.hpp>
 #include <dsp/specResample.hpp>
 #include <dsp/specScale.hpp>
 #include <dspcore/acf.hpp>
@@ -29,6 +30,7 @@
 #include <dspcore/deltaRegression.hpp>
 #include <dspcore/fftmagphase.hpp>
 #include <dspcore/transformFft.hpp>
+#include <other/vectorConcat.hpp>
 #include <dspcore/vectorPreemphasis.hpp>
 #include <dspcore/windower.hpp>
 #include <functionals/functionals.hpp>
@@ -134,6 +136,8 @@ extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cCom
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cVectorConcat")) head = override_of(&cVectorConcat::registerComponent, &cHipVectorConcat::create, confman, compman, iteration, head);
+  if (want("cWaveSource")) head = override_of(&cWaveSource::registerComponent, &cHipWaveSource::create, confman, compman, iteration, head);
   if (want("cVectorOperation")) head = override_of(&cVectorOperation::registerComponent, &cHipVectorOperation::create, confman, compman, iteration, head);
   if (want("cPitchSmoother")) head = override_of(&cPitchSmoother::registerComponent, &cHipPitchSmoother::create, confman, compman, iteration, head);
   if (want("cLsp")) head = override_of(&cLsp::registerComponent, &cHipLsp::create, confman, compman, iteration, head);

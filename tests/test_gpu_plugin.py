@@ -418,7 +418,12 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
         assert (np.abs(y - ref) / scale).max() <= 1e-5, conf
         frames = ref.shape[0]
         assert tr["fused.batch_frames"] == frames
-        assert tr["fused.rows"] >= frames and tr["fused.stage_frames"] >= 4 * frames
+        # round 5: the chain's last components write their rows at the tick level and the wave source idles -- no stage ever ticks
+        assert tr["fused.rows"] >= frames and tr["fused.stage_frames"] == 0
+        # ... and the per-frame hand-out of round 3 (every stage of the chain still ticks, carrying zeros): the same file
+        y3, tr3 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_FUSE_TICK": "0"}, conf)
+        assert tr3["fused.stage_frames"] >= 4 * frames
+        assert (np.abs(y3 - y) / scale).max() <= 2e-6, conf     # (final-level hand-out: mean normalisation and regression inside the batch)
         # no per-frame kernel launches in the chain: the stage counters stay at zero
         for comp in ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cPlp", "cEnergy", "cDeltaRegression"):
             assert tr.get(comp, 0) == 0, (conf, comp, tr)
@@ -426,6 +431,42 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
     y, tr = _run(oracle, golden_synth["pcm_u3_16000"], {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_COMPONENTS": "cMelspec,cMfcc"},
                  "is09-13/IS09_emotion.conf", "-lldhtkoutput")
     assert tr["fused.batch_frames"] == 0 and tr["cMfcc"] > 0
+
+
+def test_plugin_fused_mode_is_the_default(oracle, golden_synth, monkeypatch):
+    """Round 5: with SMILEHIP_PLUGIN_FUSE unset the unmodified MFCC12_0_D_A.conf runs fused (one batch per file, no per-frame
+    device round trip), quietly; SMILEHIP_PLUGIN_FUSE=0 keeps the components apart; a graph the reader does not recognise
+    stays on the per-component path without a warning."""
+    pcm = golden_synth["pcm_u10_16000"]
+    ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"})
+    monkeypatch.delenv("SMILEHIP_PLUGIN_FUSE", raising=False)
+    y, tr = _run(oracle, pcm)
+    assert tr["fused.batch_frames"] == ref.shape[0] and tr.get("cMfcc", 0) == 0 and tr.get("cTransformFFT", 0) == 0
+    scale = np.abs(ref[:, :13]).max(axis=1, keepdims=True)
+    assert (np.abs(y - ref) / scale).max() <= 1e-5
+    y0, tr0 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "0"})
+    assert tr0["fused.batch_frames"] == 0 and tr0["cMfcc"] == ref.shape[0]
+
+
+def test_plugin_fused_tick_level_text_sink_time_stamps(oracle):
+    """The CSV sink prints every row's frameTime: the rows the fused chain's last components write at the tick level carry the
+    time stamps the framer would have given them -- the file equals the per-frame hand-out's and differs from the CPU binary's
+    only in the values (the fast kernel's 1e-5), never in a name, a row count or a time stamp."""
+    from opensmile_amd import synth
+    pcm = synth.utterance(33, 20000)
+    for conf in ("mfcc/MFCC12_0_D_A.conf",):              # (the one cepstral file with a text sink: standard_data_output_lldonly.conf.inc)
+        ref, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, "-csvoutput")
+        tick, tr = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, "-csvoutput")
+        per_frame, _ = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_FUSE_TICK": "0"}, conf, "-csvoutput")
+        assert tr["fused.stage_frames"] == 0 and tr["fused.batch_frames"] > 0
+        static, trs = _run_bytes(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_FUSE_TICK": "static"}, conf, "-csvoutput")
+        assert trs["fused.stage_frames"] == 0 and static == per_frame, conf     # (the static block at the tick level, the reference's deltas)
+        assert tick == per_frame, conf                     # (the batch's own regression stages: the same bits)
+        rl, tl = ref.decode().splitlines(), tick.decode().splitlines()
+        assert len(rl) == len(tl) and rl[0] == tl[0], conf
+        for a, b in zip(rl[1:], tl[1:]):
+            fa, fb = a.split(";"), b.split(";")
+            assert fa[:2] == fb[:2] and len(fa) == len(fb), (conf, a[:60], b[:60])      # name and frameTime
 
 
 def test_plugin_viterbi_tick_level_override(oracle, golden_f0):

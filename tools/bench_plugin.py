@@ -21,12 +21,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--skip-per-component", action="store_true", help="per-component mode only for MFCC and ComParE (it takes ~25 s per run)")
+    ap.add_argument("--configs", default="", help="comma-separated substrings of the config names to run (default: all)")
+    ap.add_argument("--no-per-component", action="store_true", help="leave the per-component mode out altogether (an hour-long file takes minutes in it)")
     args = ap.parse_args()
     from oracle import lldo
     from opensmile_amd import synth
     exe = os.path.join(lldo.REF_DIR, "SMILExtract")
     plugdir = os.path.join(ROOT, "opensmile_amd", "plugin")
     env0 = dict(os.environ)
+    env0.pop("SMILEHIP_PLUGIN_FUSE", None)
     env0["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), lldo.REF_DIR, env0.get("LD_LIBRARY_PATH", "")])
     n = int(args.seconds * 16000)
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
@@ -41,15 +44,19 @@ def main():
         ]
         fused_sets = {"ComParE_2016 lld": "compare16_lld", "IS09_emotion lld": "is09_lld", "eGeMAPSv02 lld": "egemapsv02_lld"}
         for name, conf, opt, extra, frames in cases:
+            if args.configs and not any(c in name for c in args.configs.split(",")):
+                continue
             modes = [("cpu_binary", {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, extra),
-                     ("plugin_per_component", {}, conf, extra)]
-            modes.append(("plugin_fused_unmodified_conf", {"SMILEHIP_PLUGIN_FUSE": "1"}, conf, extra))       # (round 3: the big sets too)
+                     ("plugin_per_component", {"SMILEHIP_PLUGIN_FUSE": "0"}, conf, extra)]
+            modes.append(("plugin_default_unmodified_conf (fused)", {}, conf, extra))       # (round 5: fused is what an unmodified file gets)
             if name == "MFCC12_0_D_A":
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", "mfcc12_0_d_a"]))
             if name in fused_sets:                          # the whole LLD level from ONE source component, the reference's sinks
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "LLD_hip.conf"), ["-featureSet", fused_sets[name]]))
                 if args.skip_per_component and name != "ComParE_2016 lld":
                     modes = [m for m in modes if m[0] != "plugin_per_component"]
+            if args.no_per_component:
+                modes = [m for m in modes if m[0] != "plugin_per_component"]
             for mode, envx, c, ex in modes:
                 env = dict(env0)
                 env.update(envx)

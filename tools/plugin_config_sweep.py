@@ -25,6 +25,7 @@ OPTS = [["-O"], ["-csvoutput"], ["-lldcsvoutput"], ["-output"], ["-arffout"], ["
 def run(conf, wav, opt, out, env_extra, cwd):
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), lldo.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+    env.setdefault("SMILEHIP_PLUGIN_FUSE", "0")          # (this tool checks the per-component operators; fused mode is the default since round 5)
     env.update(env_extra)
     try:
         r = subprocess.run([os.path.join(lldo.REF_DIR, "SMILExtract"), "-C", conf, "-I", wav] + opt + [out, "-l", "1", "-nologfile"],
