@@ -19,6 +19,7 @@
 #include "lld_blocks.hpp"
 #include "lld_fft.hpp"
 #include "lld_blocks_compare.hpp"
+#include "lld_compare_quad.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
@@ -392,6 +393,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   extern __shared__ __attribute__((aligned(16))) float smem[];
   compare_frame_wave_body<4, true>(P, Q, n_runs, smem);
 }
+// Sixteen lanes per frame, four runs per wave (lld_compare_quad.hpp): the shipped geometry. Workgroups of four waves; LDS:
+// the tables once per workgroup, 2.4 KB per run -- three workgroups per CU.
+namespace {
+constexpr int kCmpQuadWaves = 4;
+inline size_t compare_quad_lds_floats(const OouraTab &oo) {
+  return (size_t)cq::kTableFloats + (size_t)((oo_table_floats(oo) + 3) & ~3) + (size_t)kCmpQuadWaves * 4 * cq::kRowFloats;
+}
+}  // namespace
+__global__ void __launch_bounds__(kCmpQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_quad(LldParams P, CompareParams Q, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double2 *s_log = reinterpret_cast<double2 *>(smem);
+  double *s_sharp = reinterpret_cast<double *>(smem + 512);
+  float *s_win = smem + 1024;
+  float *s_coef = s_win + cq::kN;
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + 260);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  constexpr int NT = kCmpQuadWaves * 64;
+  for (int i = threadIdx.x; i < 128; i += NT) s_log[i] = kLogTab[i];
+  for (int i = threadIdx.x; i < cq::kK - 1; i += NT) s_sharp[i] = Q.sharp_w[i];
+  for (int i = threadIdx.x; i < cq::kN; i += NT) s_win[i] = P.window[i];
+  for (int i = threadIdx.x; i < cq::kK; i += NT) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * cq::kBands; i += NT) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < cq::kMfcc * cq::kBands; i += NT) s_dct[i] = P.dct_rows[i];
+  const OouraTab OO = oo_stage_tables<true>(P.oo, smem + cq::kTableFloats, threadIdx.x, NT);
+  __syncthreads();                                       // the only workgroup barrier
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int first_run = (blockIdx.x * kCmpQuadWaves + wave) * 4;
+  if (first_run >= n_runs) return;
+  float *fmem = smem + cq::kTableFloats + ((oo_table_floats(P.oo) + 3) & ~3) + wave * 4 * cq::kRowFloats;
+  compare_frame_quad_body(P, Q, n_runs, first_run, s_win, s_coef, s_rng, s_dct, s_log, s_sharp, OO, fmem);
+}
+
 // the other spectrum sizes of 20 ms frames: FFT 256 (8 / 11.025 kHz), FFT 1024 (32 / 44.1 / 48 kHz)
 template <int W>
 __global__ void __launch_bounds__(256) lld_compare_frame_wave_g(LldParams P, CompareParams Q, int n_runs) {
@@ -566,7 +599,16 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
-    else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && !getenv("SMILEHIP_COMPARE_GENERAL"))
+    else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
+             P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && Q.max_utt_samples < (int64_t(1) << 31) &&
+             !getenv("SMILEHIP_COMPARE_GENERAL") && !getenv("SMILEHIP_COMPARE_WAVE")) {
+      // sixteen lanes per frame (lld_compare_quad.hpp); SMILEHIP_COMPARE_WAVE=1: the wave-per-frame form (A/B switch)
+      const size_t qlds = sizeof(float) * compare_quad_lds_floats(P.oo);
+      hipError_t eq = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+      if (eq != hipSuccess) return eq;
+      const int per_wg = kCmpQuadWaves * 4;
+      hipLaunchKernelGGL(lld_compare_frame_quad, dim3((unsigned)((n_runs + per_wg - 1) / per_wg)), dim3(kCmpQuadWaves * 64), qlds, s, P, Q, n_runs);
+    } else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && !getenv("SMILEHIP_COMPARE_GENERAL"))
       hipLaunchKernelGGL(lld_compare_frame_wave3t, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
     else hipLaunchKernelGGL(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }

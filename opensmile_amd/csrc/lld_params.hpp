@@ -123,6 +123,7 @@ struct CompareParams {
   float rasta_fir[5];
   double fsSec;              // frameSizeSec of the magnitude level
   int32_t N60;               // samples of a 60 ms frame
+  int64_t max_utt_samples;   // the batch's longest utterance (the quad form keeps 32-bit row state: launch_compare)
   // band-energy edges (spectral.cpp:779-853), resolved on the host: first/last bin and their weights
   int32_t band_iL[2], band_iR[2];
   double band_wL[2], band_wR[2];

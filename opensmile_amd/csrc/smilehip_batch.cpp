@@ -560,6 +560,8 @@ static int compare_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_
   for (int i = 0; i < 5; ++i) Q.rasta_fir[i] = plan->rasta_fir[i];
   Q.fsSec = plan->geo.fft_frame_size_sec;
   Q.N60 = (int32_t)std::lround(0.060 / plan->geo.period);
+  Q.max_utt_samples = 0;
+  for (size_t u2 = 0; u2 + 1 < b->h_samp_off.size(); ++u2) Q.max_utt_samples = std::max<int64_t>(Q.max_utt_samples, b->h_samp_off[u2 + 1] - b->h_samp_off[u2]);
   for (int i = 0; i < 2; ++i) {
     Q.band_iL[i] = plan->band_iL[i]; Q.band_iR[i] = plan->band_iR[i];
     Q.band_wL[i] = plan->band_wL[i]; Q.band_wR[i] = plan->band_wR[i];
