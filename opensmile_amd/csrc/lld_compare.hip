@@ -401,7 +401,7 @@ inline size_t compare_quad_lds_floats(const OouraTab &oo) {
   return (size_t)cq::kTableFloats + (size_t)((oo_table_floats(oo) + 3) & ~3) + (size_t)kCmpQuadWaves * 4 * cq::kRowFloats;
 }
 }  // namespace
-__global__ void __launch_bounds__(kCmpQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_compare_frame_quad(LldParams P, CompareParams Q, int n_runs) {
+__global__ void __launch_bounds__(kCmpQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(CQ_WAVES, CQ_WAVES))) lld_compare_frame_quad(LldParams P, CompareParams Q, int n_runs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   double2 *s_log = reinterpret_cast<double2 *>(smem);
   double *s_sharp = reinterpret_cast<double *>(smem + 512);
@@ -600,7 +600,8 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     if (beside_small_jitter_pass) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
     else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
-             P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && Q.max_utt_samples < (int64_t(1) << 31) &&
+             P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && Q.band_iL[0] >= 0 && Q.band_iL[0] < Q.band_iR[0] && Q.band_iR[0] <= 256 &&
+             Q.band_iL[1] >= 0 && Q.band_iL[1] < Q.band_iR[1] && Q.band_iR[1] <= 256 && Q.max_utt_samples < (int64_t(1) << 31) &&
              !getenv("SMILEHIP_COMPARE_GENERAL") && !getenv("SMILEHIP_COMPARE_WAVE")) {
       // sixteen lanes per frame (lld_compare_quad.hpp); SMILEHIP_COMPARE_WAVE=1: the wave-per-frame form (A/B switch)
       const size_t qlds = sizeof(float) * compare_quad_lds_floats(P.oo);

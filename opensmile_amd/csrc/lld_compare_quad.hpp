@@ -24,9 +24,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lld_blocks.hpp"
 #include "lld_blocks_compare.hpp"
 #include "lld_ooura_quad.hpp"
+
+// (development aid: tools/dev/phase_insts.sh lld_compare.hip <kernel> QPHASE compiles these as assembler comments and counts the
+// instructions between them)
+#ifndef QPHASE
+#define QPHASE(i)
+#endif
+#ifndef CQ_BINS_GROUP
+#define CQ_BINS_GROUP 3                                    // bins of the entropy / moments loop whose operations may interleave
+#endif
+#ifndef CQ_WAVES
+#define CQ_WAVES 3                                         // waves per SIMD the register budget is set for
+#endif
 
 namespace smilehip {
 
@@ -61,6 +75,16 @@ __device__ __forceinline__ double lane_d(double x, int row_base4, int src) {
   const int lo = __builtin_amdgcn_ds_bpermute(row_base4 + 4 * src, __double2loint(x));
   return __hiloint2double(hi, lo);
 }
+// RN(a / b) from y = RN(1 / b) (the division itself, once per divisor): q0 = RN(a y) is within two ulps, one residual step makes
+// it faithful, the second returns the correctly rounded quotient (Markstein; lld_f0.hip: f0_div_by, tests/test_exact_sum_claims.py)
+// -- five full-rate operations instead of the ~25 of the division sequence, for operands well inside the normal range
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r0 = __builtin_fma(-q0, b, a);
+  const double q1 = __builtin_fma(r0, y, q0);
+  const double r1 = __builtin_fma(-q1, b, a);
+  return __builtin_fma(r1, y, q1);
+}
 __device__ __forceinline__ int cross(float a, float b, float c) {               // mzcr.cpp:117-124
   return (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) ? 1 : 0;
 }
@@ -92,14 +116,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
                                                         const float *s_coef, const int32_t *s_rng, const float *s_dct, const double2 *s_log,
                                                         const double *s_sharp, const OouraTab &OO, float *fmem) {
   using namespace cq;
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));                            // (what depends on the lane alone is not to be carried across the frame loop)
-  const int lane64 = tid & 63, j = tid & 15, g = lane64 >> 4, row_base4 = 4 * (lane64 & 48);
-  float *rowm = fmem + g * kRowFloats;
-  float2 *z = reinterpret_cast<float2 *>(rowm);
-  float *zf = rowm;
-  float *lmel = rowm + 2 * kQuadZPairs, *aud = lmel + 32;
-  const int run_raw = first_run + g;
+  const int run_raw = first_run + (int)((threadIdx.x & 63) >> 4);
   const bool have_run = run_raw < n_runs;
   const int run = have_run ? run_raw : n_runs - 1;        // (a row without a run repeats the last one, stores off)
   const int u = Q.run_utt[run], t0 = Q.run_t0[run];
@@ -121,6 +138,16 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
   bool z_have = false;
 
   for (int it = 0; it < n_pass; ++it) {
+    // The thread index is made opaque PER PASS: what depends on the lane alone (LDS addresses of the transform's transposition and
+    // read-out, the masks of the unrolled loops) is loop-invariant over the passes, and the compiler would carry all of it across
+    // the loop (~40 registers, spilled: lld_is09.hip's is09_quad_body)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane64 = tid & 63, j = tid & 15, g = lane64 >> 4, row_base4 = 4 * (lane64 & 48);
+    float *rowm = fmem + g * kRowFloats;
+    float2 *z = reinterpret_cast<float2 *>(rowm);
+    float *zf = rowm;
+    float *lmel = rowm + 2 * kQuadZPairs, *aud = lmel + 32;
     const int t_raw = t_begin + it;
     const bool live = have_run && t_raw < t_last;
     const int t = t_raw < t_last ? t_raw : t_last - 1;
@@ -148,6 +175,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
       const double tot = QuadG::sum(e2, nullptr);
       if (store && j == 0) rawA[2] = (float)sqrt(tot / (float)kN) * 1.0f + 0.0f;
     }
+    QPHASE(0);
     // ---- R12 cMZcr on the 60 ms window (mzcr.cpp:117-124): positions t H + 1 .. t H + 958 = segments S_t .. S_{t+4} (S_m = the
     // positions m H + 1 .. m H + H) + the first 158 positions of S_{t+5}
     if (!warm) {
@@ -172,6 +200,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
         zS0 = zS1; zS1 = zS2; zS2 = zS3; zS3 = S4; zP = rest;
       }
     }
+    QPHASE(1);
     // ---- R4 forward transform in the reference's operation order, R5 magnitudes (registers)
     oo_quad256<false>(v, OO, z, lane64);
     oo_quad_store(v, z, lane64);
@@ -183,6 +212,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
       if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);
     }
     QuadG::sync();                                         // (z has been read)
+    QPHASE(2);
     // spectral flux's sum (:1124-1254) while the previous frame's magnitudes are still here; then this frame's take their place
     double s3 = 0.0;
 #pragma unroll
@@ -221,6 +251,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
       if (j < kMfcc) { const float c = dct_coeff(lmel, s_dct + j * kBands, kBands, P.dct_gain[j]); if (store) rawB[41 + j] = c; }   // R7
       if (j == 15) { const float d = seq_sum_f32(aud, kBands); if (store) rawA[0] = d / (float)kBands; }     // cVectorOperation ll1, vectorOperation.cpp:475-481
       QuadG::sync();                                       // (the terms have been read: the powers take their place)
+      QPHASE(3);
       // ---- R11 cSpectral (spectral.cpp:586-1560, ComParE's option set)
       const bool first = t == 0;
 #pragma unroll
@@ -236,21 +267,17 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
           s0 += p;
           s1 += (F0 * k) * p;
         }
-        if (k <= kM) {
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            double c = 0.0;
-            if (k == Q.band_iL[b]) c += p * Q.band_wL[b];
-            if (k > Q.band_iL[b] && k < Q.band_iR[b]) c += p;
-            if (k == Q.band_iR[b]) c += p * Q.band_wR[b];
-            if (b == 0) s4 += c; else s5 += c;
-          }
-        }
+        // band energies (:779-853): the bins strictly inside a band here, its two edge bins (weighted) once per row below
+        if (k > Q.band_iL[0] && k < Q.band_iR[0]) s4 += p;
+        if (k > Q.band_iL[1] && k < Q.band_iR[1]) s5 += p;
       }
       const double frameSum = QuadG::sum(s0, nullptr), sumA = QuadG::sum(s1, nullptr), fluxS = QuadG::sum(s3, nullptr);
-      const double bandE0 = QuadG::sum(s4, nullptr), bandE1 = QuadG::sum(s5, nullptr);
+      double bandE0 = QuadG::sum(s4, nullptr), bandE1 = QuadG::sum(s5, nullptr);
+      bandE0 += (double)zf[Q.band_iL[0]] * Q.band_wL[0]; bandE0 += (double)zf[Q.band_iR[0]] * Q.band_wR[0];      // (launch_compare: iL < iR <= 256)
+      bandE1 += (double)zf[Q.band_iL[1]] * Q.band_wL[1]; bandE1 += (double)zf[Q.band_iR[1]] * Q.band_wR[1];
       float ctr = 0.0f;
       if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
+      QPHASE(4);
       // roll-off (:1102-1122): inclusive prefix of the powers of bins 1 .. 256, first bin whose prefix reaches the share
       {
         const double rollOff[4] = {0.25, 0.50, 0.75, 0.90};
@@ -280,6 +307,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
           if (store && j == i) rawB[26 + 2 + i] = (float)(F0 * kk);
         }
       }
+      QPHASE(5);
       // harmonicity (:1484-1513): alternating peaks / valleys, distance to the previous flagged bin
       {
         float hc[17];
@@ -311,30 +339,44 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
 #pragma unroll
         for (int m = 0; m < 17; ++m) { const int k = j + 16 * m; if (k >= 1 && k <= kM) zf[256 + k - 1] = hc[m]; }
       }
+      QPHASE(6);
       // the per-bin terms of entropy, variance, skewness, kurtosis, and sharpness' chain terms
       double e0 = 0.0, e1 = 0.0, e2m = 0.0, e3 = 0.0;
       {
         const double entropy_floor = 0.0000001;
         double dn = frameSum;
         if (dn < (float)entropy_floor) dn = (float)entropy_floor;
+        // the frame's two divisors -- its power sum and log 2 -- by their reciprocals (div_by); a power sum beyond 1e150 (or NaN)
+        // keeps the division
+        // (one decision per wave: both forms return the same bits, the quick one only needs its range)
+        const bool quick = __ballot(!(dn < 1e150)) == 0ull;
+        const double inv_dn = 1.0 / dn;
+        constexpr double kLog2 = 0.693147180559945286226764, kInvLog2 = 1.0 / kLog2;
+        const auto bins = [&](auto quick_c) {
+          constexpr bool kQuick = decltype(quick_c)::value;
 #pragma unroll
-        for (int m = 0; m < 17; ++m) {
-          const int k = j + 16 * m;
-          const double p = (double)(mv[m] * mv[m]);
-          if (k >= 1 && k <= kM) {
-            zf[k - 1] = (float)(s_sharp[k - 1] * p);         // :1455 / :1469
-            double vv = p;
-            if (vv <= entropy_floor) vv = entropy_floor;
-            const double ln = vv / dn;
-            e0 += (ln > 0.0) ? ln * log_d<true>(ln, s_log) / log(2.0) : 0.0;
-            const double t1 = F0 * k - (double)ctr;
-            double mm = t1 * t1 * p;
-            e1 += mm; mm *= t1; e2m += mm; e3 += mm * t1;
+          for (int m = 0; m < 17; ++m) {
+            const int k = j + 16 * m;
+            const double p = (double)(mv[m] * mv[m]);
+            if (k >= 1 && k <= kM) {
+              zf[k - 1] = (float)(s_sharp[k - 1] * p);       // :1455 / :1469
+              double vv = p;
+              if (vv <= entropy_floor) vv = entropy_floor;
+              const double ln = kQuick ? div_by(vv, dn, inv_dn) : vv / dn;
+              // (ln > 0: a quotient of two values >= 1e-7 -- a positive normal double; x log x in [-0.37, 1e160): div_by's range)
+              const double xl = ln * log_d<true>(ln, s_log);
+              e0 += (ln > 0.0) ? (kQuick ? div_by(xl, kLog2, kInvLog2) : xl / log(2.0)) : 0.0;
+              const double t1 = F0 * k - (double)ctr;
+              double mm = t1 * t1 * p;
+              e1 += mm; mm *= t1; e2m += mm; e3 += mm * t1;
+            }
+            if (m % CQ_BINS_GROUP == CQ_BINS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
           }
-          if (m % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (quick) bins(std::true_type{}); else bins(std::false_type{});
       }
       const double ent = QuadG::sum(e0, nullptr), mom2 = QuadG::sum(e1, nullptr), mom3 = QuadG::sum(e2m, nullptr), mom4 = QuadG::sum(e3, nullptr);
+      QPHASE(7);
       // the two FLOAT_DMEM chains (:1435-1471 sharpness, :1485-1499 harmonicity): terms of bins 1 .. 256 in order, lane 0 adds the
       // first chain, lane 1 the second
       QuadG::sync();

@@ -5,8 +5,10 @@
 F=$1; K=$2; M=${3:-IPHASE}; shift; shift; [ $# -gt 0 ] && shift
 cd "$(dirname "$0")/../../opensmile_amd/csrc" || exit 1
 sed "s|^#define $M(i)\$|#define $M(i) asm volatile(\"; PHASEMARK \" #i)|" $F > _tmp_mark.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --cuda-device-only -S "$@" -o /tmp/_mark.s _tmp_mark.hip 2>/dev/null
-rm -f _tmp_mark.hip
+# (a marker macro defined in a header the file includes behind an #ifndef: the forced include defines it first)
+printf '#define %s(i) asm volatile("; PHASEMARK " #i)\n' "$M" > _tmp_mark_def.h
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --cuda-device-only -S -include _tmp_mark_def.h "$@" -o /tmp/_mark.s _tmp_mark.hip 2>/dev/null
+rm -f _tmp_mark.hip _tmp_mark_def.h
 awk -v k="$K" 'index($0, k) == 1 && /:/ {p=1} p{print} /s_endpgm/{if(p){exit}}' /tmp/_mark.s > /tmp/_mark_k.s
 python3 - <<'PY'
 import re
