@@ -26,6 +26,7 @@
 #include "lld_blocks.hpp"
 #include "lld_fft.hpp"
 #include "lld_blocks_compare.hpp"
+#include "lld_gemaps_quad.hpp"
 #include "lld_device.hpp"
 #include "lld_launch.hpp"
 #include "lld_params.hpp"
@@ -302,6 +303,34 @@ __global__ void __launch_bounds__(256) lld_gemaps_frame20(LldParams P, GemapsPar
     GPHASE(4);   // GeMAPS spectral descriptors
   }
   GPHASE20_FLUSH;
+}
+
+// Sixteen lanes per frame, four runs per wave (lld_gemaps_quad.hpp): the shipped geometry. Workgroups of four waves, three per CU.
+namespace {
+constexpr int kGmQuadWaves = 4;
+inline size_t gemaps_quad_lds_floats(const OouraTab &oo) {
+  return (size_t)gq::kTableFloats + (size_t)((oo_table_floats(oo) + 3) & ~3) + (size_t)kGmQuadWaves * 4 * gq::kRowFloats;
+}
+}  // namespace
+template <int PAD>
+__global__ void __launch_bounds__(kGmQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) lld_gemaps_frame20_quad(LldParams P, GemapsParams G, int n_runs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_win = smem;
+  float *s_coef = s_win + gq::kN;
+  int32_t *s_rng = reinterpret_cast<int32_t *>(s_coef + 260);
+  float *s_dct = reinterpret_cast<float *>(s_rng + 128);
+  constexpr int NT = kGmQuadWaves * 64;
+  for (int i = threadIdx.x; i < gq::kN; i += NT) s_win[i] = P.window[i];
+  for (int i = threadIdx.x; i < gq::kK; i += NT) s_coef[i] = P.mel_coef[i];
+  for (int i = threadIdx.x; i < 4 * gq::kBands; i += NT) s_rng[i] = P.mel_rng[i];
+  for (int i = threadIdx.x; i < gq::kMfcc * gq::kBands; i += NT) s_dct[i] = P.dct_rows[i];
+  const OouraTab OO = oo_stage_tables<true>(P.oo, smem + gq::kTableFloats, threadIdx.x, NT);
+  __syncthreads();                                       // the only workgroup barrier
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int first_run = (blockIdx.x * kGmQuadWaves + wave) * 4;
+  if (first_run >= n_runs) return;
+  float *fmem = smem + gq::kTableFloats + ((oo_table_floats(P.oo) + 3) & ~3) + wave * 4 * gq::kRowFloats;
+  gemaps_frame20_quad_body<PAD>(P, G, n_runs, first_run, s_win, s_coef, s_rng, s_dct, OO, fmem);
 }
 
 // ------------------------------------------------------------------------------------------------ cSpecResample + cLpc
@@ -1185,7 +1214,22 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   const int M = P.Nfft / 2;
   const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * ((2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad) + 3 * Kpad + 64 + 96));
-  hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
+  // sixteen lanes per frame for the shipped geometry (lld_gemaps_quad.hpp); SMILEHIP_GEMAPS_WAVE=1: the wave-per-frame form (A/B switch)
+  const bool quad_ok = P.oo.tw && P.N == 320 && P.H == 160 && P.Nfft == 512 && (P.pad_left == 0 || P.pad_left == 96) && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 4 &&
+                       P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && G.sl_iL[0] >= 0 && G.sl_iR[0] <= 63 && G.sl_iL[1] >= 0 &&
+                       G.sl_iR[1] <= 63 && G.ar_n1 >= 0 && G.ar_n1 <= G.ar_n2 && G.ar_n2 <= 257 && G.rng_lo >= 0 && !getenv("SMILEHIP_GEMAPS_WAVE");
+  if (quad_ok) {
+    const size_t qlds = sizeof(float) * gemaps_quad_lds_floats(P.oo);
+    const void *qfn = P.pad_left ? reinterpret_cast<const void *>(&lld_gemaps_frame20_quad<96>) : reinterpret_cast<const void *>(&lld_gemaps_frame20_quad<0>);
+    hipError_t eq = hipFuncSetAttribute(qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+    if (eq != hipSuccess) return eq;
+    const int per_wg = kGmQuadWaves * 4;
+    const dim3 qgrid((unsigned)((n_runs + per_wg - 1) / per_wg)), qblock(kGmQuadWaves * 64);
+    if (P.pad_left) hipLaunchKernelGGL(lld_gemaps_frame20_quad<96>, qgrid, qblock, qlds, s, P, G, n_runs);
+    else hipLaunchKernelGGL(lld_gemaps_frame20_quad<0>, qgrid, qblock, qlds, s, P, G, n_runs);
+  } else {
+    hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (G.total_frames20 <= 0) return hipSuccess;
