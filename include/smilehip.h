@@ -396,6 +396,10 @@ typedef struct smilehip_func_spec {
    * own length, zero padding to the next power of two, the reference's rdft), mapped by a natural cubic spline onto mod_min_freq +
    * i (mod_max_freq - mod_min_freq) / mod_n_bins Hz and averaged. Built for windows of 33 .. 1024 values (a contour needs >= 34
    * rows) and <= 128 bins; stftWinSize 0 (one transform over the whole contour) is not built. */
+  /* Limits: 49 <= mod_win_frames <= 1024 (refused otherwise: the reference's transforms of fewer than 64 points -- windows of
+   * fewer than 33 values -- are not built); a contour of fewer than 34 values has no window of 33 values and gets NaN in every
+   * Modulation bin (the reference computes it with a 4 .. 32-point transform): callers that may see such contours check the row
+   * count first, as the plugin's cFunctionals override does. */
   int32_t mod_win_frames, mod_step_frames, mod_n_bins, mod_win_func, mod_remove_nz_mean, reserved8;
   double mod_min_freq, mod_max_freq;
 } smilehip_func_spec;

@@ -86,8 +86,13 @@ int family_count(const smilehip_func_spec &s, int fam) {
         if (!(s.sample_pos[i] >= 0.0 && s.sample_pos[i] <= 1.0)) return fail(SMILEHIP_ERR_INVALID, "Samples: samplepos[%d] = %g not in [0, 1]", i, s.sample_pos[i]);
       return s.n_samples;
     case SMILEHIP_FAM_MODULATION:
-      if (s.mod_win_frames < 33 || s.mod_win_frames > 1024)
-        return fail(SMILEHIP_ERR_INVALID, "Modulation: windows of 33 .. 1024 values are built (stftWinSize %d; 0 = the whole contour is not)", s.mod_win_frames);
+      // A window of W values is followed by tail windows of down to 2 W / 3 + 1 values; the transforms built are those of 33 .. 1024
+      // values (64 .. 1024 points). The reference goes down to 4 points: with W < 49 a tail window would need one of those -- refused
+      // here rather than answered with NaN. (A CONTOUR of fewer than 34 values has no window of 33: its bins are NaN, documented in
+      // include/smilehip.h; the plugin refuses such rows by name.)
+      if (s.mod_win_frames < 49 || s.mod_win_frames > 1024)
+        return fail(SMILEHIP_ERR_INVALID, "Modulation: windows of 49 .. 1024 values are built (stftWinSize %d; 0 = the whole contour is not; below 49 the "
+                    "tail windows need transforms of fewer than 64 points)", s.mod_win_frames);
       if (s.mod_step_frames < 1) return fail(SMILEHIP_ERR_INVALID, "Modulation: stftWinStep must be >= 1");
       if (s.mod_n_bins < 1 || s.mod_n_bins > 128) return fail(SMILEHIP_ERR_INVALID, "Modulation: 1 .. 128 bins (%d)", s.mod_n_bins);
       if (s.mod_win_func < SMILEHIP_WIN_RECT || s.mod_win_func > SMILEHIP_WIN_LANCZOS || s.mod_win_func == SMILEHIP_WIN_GAUSS)

@@ -311,6 +311,14 @@ class cHipFunctionals : public cFunctionals {
     }
     if (state_ < 0) state_ = build_spec() ? 1 : 0;
     if (!state_ || row->nT <= 0) { if (!state_) HIP_FALLTHROUGH(14, "cFunctionals: a functional family or option of this instance is not built (Modulation over the whole contour, Times.useRobustPercentileRange, Segments.growDynSegBuffer, Peaks.overlapFlag = 0, ...)"); return cFunctionals::doProcess(i, row, y); }
+    // The Modulation family on a contour of fewer than 34 values: the reference transforms it with 4 .. 32 points, which the
+    // library does not build (include/smilehip.h) -- refused by name (or the reference's own code under SMILEHIP_PLUGIN_ALLOW_CPU=1),
+    // never answered with NaN
+    if (row->nT < 34) {
+      bool has_mod = false;
+      for (int q = 0; q < spec_.n_fam; ++q) has_mod = has_mod || spec_.fam[q] == SMILEHIP_FAM_MODULATION;
+      if (has_mod) { HIP_FALLTHROUGH(14, "cFunctionals: Modulation on a contour of fewer than 34 values (4 .. 32-point transforms are not built)"); return cFunctionals::doProcess(i, row, y); }
+    }
     io_.ensure(row->nT, nFunctValues);
     io_.up(row->data, row->nT);
     check(smilehip_funcspec_matrix(context(), &spec_, io_.d_in, 1, row->nT, 1, io_.d_out, nullptr));
