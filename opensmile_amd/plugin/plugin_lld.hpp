@@ -18,7 +18,7 @@ class cHipEnergy : public cEnergy {
   // per tick, whatever its reader holds (nothing: the wave source idles)
   eTickResult myTick(long long t) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
-    if (fused_ && g_fused.tick_mode) {
+    if (fused_ && g_fused.tick_mode && !fcols_->cols.empty()) {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
     }

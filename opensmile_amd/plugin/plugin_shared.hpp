@@ -92,6 +92,7 @@ struct FusedLevel {
   long n_rows = 0;
   std::vector<int> cols;
   std::vector<float> extra;      // one more row after the matrix's (ComParE group B's level holds row T60 + 1, which only its functionals read)
+  bool lld_times = true;         // rows carry the LLD level's time stamps (FusedChain::times); false: row index x frame period (levels only functionals read)
 };
 struct FusedChain {
   bool tried = false, active = false;
@@ -218,6 +219,17 @@ struct FusedChain {
       check(smilehip_stream_synchronize(context(), nullptr));
       smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld);
     }
+    {                                                      // tick-level hand-out (round 5): the LLD level's time stamps, as cHipLldSource gives them
+      const char *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
+      // (eGeMAPS keeps the per-frame hand-out: its cFunctionals instances run as operators on the handed-out levels and count the
+      // rows the reference's end-of-input rules leave in them; the other sets' functionals come from the batch's own vector)
+      tick_mode = !egm && !(tm && !strcmp(tm, "0"));
+      const int64_t n_frames = (ps == "is09_emotion") ? smilehip_num_frames(pl, n) : (int64_t)n_rows - 1;
+      times.assign((size_t)(n_rows > 0 ? n_rows : 1), 0.0);
+      for (long t = 0; t < n_rows; ++t) times[(size_t)t] = smilehip_row_time(pl, n_frames, t);
+      frame_size_sec = c.frame_size_sec;
+      frame_period_sec = c.frame_step_sec;
+    }
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
     if (ps == "is09_emotion") {
@@ -246,6 +258,7 @@ struct FusedChain {
       add_level("egemapsv02_lldSetSpectralNz_smo", &fin, 36, fin_rows, 21, 9);
       add_level("egemapsv02_lldSetSpectralZ_smo", &fin, 36, fin_rows, 30, 5);
       add_level("egemapsv02_energyRMS", &fin, 36, fin_rows, 35, 1);
+      for (auto &kv : levels) if (kv.second.M == &fin) kv.second.lld_times = false;
     }
     big = true;
     active = true;
@@ -366,8 +379,9 @@ struct FusedChain {
   double frame_size_sec = 0.0, frame_period_sec = 0.0;
   // writes the next rows of L to `writer`; next = rows written so far by this component; block: the component's own matrix
   eTickResult tick_write(const FusedLevel &L, cDataWriter *writer, long &next, cMatrix *&block, long blocksize_w) {
-    long n = L.n_rows - next;
-    if (n <= 0) return TICK_INACTIVE;
+    const long total = L.n_rows + (L.extra.empty() ? 0 : 1);
+    long n = total - next;
+    if (n <= 0 || L.cols.empty()) return TICK_INACTIVE;
     if (blocksize_w > 0 && n > blocksize_w) n = blocksize_w;
     if (n > 256) n = 256;
     while (n > 1 && !writer->checkWrite(n)) n >>= 1;
@@ -375,10 +389,15 @@ struct FusedChain {
     const long N = (long)L.cols.size();
     if (!block || block->nT != n || block->N != N) { delete block; block = new cMatrix((int)N, (int)n); }
     for (long t = 0; t < n; ++t) {
-      const float *r = L.M->data() + (size_t)(next + t) * L.ld;
+      const long row = next + t;
       FLOAT_DMEM *d = block->data + (size_t)t * N;         // data[el + t * N]
-      for (long k = 0; k < N; ++k) d[k] = r[L.cols[(size_t)k]];
-      block->tmeta[t].time = times[(size_t)(next + t)];
+      if (row < L.n_rows) {
+        const float *r = L.M->data() + (size_t)row * L.ld;
+        for (long k = 0; k < N; ++k) d[k] = r[L.cols[(size_t)k]];
+      } else {
+        for (long k = 0; k < N; ++k) d[k] = L.extra[(size_t)k];
+      }
+      block->tmeta[t].time = (L.lld_times && row < (long)times.size()) ? times[(size_t)row] : (double)row * frame_period_sec;
       block->tmeta[t].lengthSec = frame_size_sec;
       block->tmeta[t].period = frame_period_sec;
     }

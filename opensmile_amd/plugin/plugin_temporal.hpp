@@ -23,6 +23,20 @@ struct FusedRows {
   }
 };
 
+// ... and at the tick level (round 5): the window processor whose writer level the fused batch supplies writes the level's rows
+// in blocks, whatever its reader holds (nothing: the wave source idles, no component upstream ever sees data)
+struct FusedTick {
+  const FusedLevel *lvl = nullptr;
+  int tried = 0;
+  long next = 0;
+  cMatrix *block = nullptr;
+  ~FusedTick() { delete block; }
+  bool mine(const char *writer_level) {
+    if (!tried) { tried = 1; g_fused.init(); if (g_fused.big && g_fused.tick_mode) lvl = g_fused.static_level(writer_level); }
+    return g_fused.big && g_fused.tick_mode && lvl && !lvl->cols.empty();
+  }
+};
+
 struct RowIO {
   FrameIO io;
   void run(cMatrix *in, cMatrix *out, int pre, int post, int kind, int W) {
@@ -47,10 +61,18 @@ struct RowIO {
 class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
   FusedRows frows_;
+  FusedTick ftick_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, segs_ = 0, flags_ = 0;
   DevBytes norm_;
  protected:
+  eTickResult myTick(long long t) override {
+    if (ftick_.mine(getStr("writer.dmLevel"))) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
+    }
+    return cDeltaRegression::myTick(t);
+  }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
       W_ = getInt("deltawin");
@@ -88,9 +110,17 @@ class cHipDeltaRegression : public cDeltaRegression {
 class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
   FusedRows frows_;
+  FusedTick ftick_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, nz_ = 0;
  protected:
+  eTickResult myTick(long long t) override {
+    if (ftick_.mine(getStr("writer.dmLevel"))) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
+    }
+    return cContourSmoother::myTick(t);
+  }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     if (plain_ < 0) {
       const int w = smaWin;                              // the member: myFetchConfig has made an even value odd (contourSmoother.cpp:64-67)
