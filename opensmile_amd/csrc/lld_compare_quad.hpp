@@ -46,7 +46,7 @@ namespace smilehip {
 
 namespace cq {
 constexpr int kN = 320, kH = 160, kPad = 96, kN60 = 960, kM = 256, kK = 257, kBands = 26, kMfcc = 14;
-constexpr int kRowFloats = 2 * kQuadZPairs + 64;           // z (544 floats: transform, then mel terms / powers / chains) | lmel[32] | aud[32]
+constexpr int kRowFloats = 2 * kQuadZPairs + 64 + 16;      // z (544 floats: transform, then mel terms / powers / chains) | lmel[32] | aud[32] | the row's state[16]
 // shared tables: log table (128 double2 = 512 floats, first: 16-byte aligned) | sharpness weights (256 doubles = 512 floats) |
 // window[320] | mel coef[260] | band ranges[128] | DCT rows[16 x 32]
 constexpr int kTableFloats = 512 + 512 + kN + 260 + 128 + 16 * 32;
@@ -85,6 +85,11 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
   const double r1 = __builtin_fma(-q1, b, a);
   return __builtin_fma(r1, y, q1);
 }
+// x, behind a wall the common-subexpression pass does not see through: the bins' powers as doubles are used by three loops a long
+// way apart, and the compiler would rather keep all seventeen (34 registers, spilled) than square and convert again
+__device__ __forceinline__ float fresh(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double fresh(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int fresh(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int cross(float a, float b, float c) {               // mzcr.cpp:117-124
   return (((a * c <= 0.0f) && (b == 0.0f)) || (a * b < 0.0f)) ? 1 : 0;
 }
@@ -131,11 +136,20 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
   const int t_begin = t0 > 0 ? t0 - 1 : 0;
   const int n_pass = __builtin_amdgcn_readfirstlane(wave_tree_i(t_last - t_begin, [](int a, int b) { return b > a ? b : a; }));
   const double F0 = 1.0 / Q.fsSec;
+  // The row's own bookkeeping (its run's frame range, the utterance's samples, the zero-crossing segments) lives in the row's LDS
+  // area between the passes: twelve registers less across the transform (they were spilled)
+  {
+    int *st = reinterpret_cast<int *>(fmem + ((threadIdx.x & 63) >> 4) * kRowFloats + 2 * kQuadZPairs + 64);
+    if ((threadIdx.x & 15) == 0) {
+      st[0] = f0; st[1] = utt_len; st[2] = T60; st[3] = t0; st[4] = t_last; st[5] = t_begin;
+      st[6] = (int)(unsigned)(reinterpret_cast<uintptr_t>(xu) & 0xffffffffu); st[7] = (int)(unsigned)(reinterpret_cast<uintptr_t>(xu) >> 32);
+      st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0; st[12] = 0; st[13] = 0; st[14] = have_run ? 1 : 0;
+    }
+    QuadG::sync();
+  }
   float mvp[17];                                           // the previous frame's magnitudes (flux)
 #pragma unroll
   for (int m = 0; m < 17; ++m) mvp[m] = 0.0f;
-  int zS0 = 0, zS1 = 0, zS2 = 0, zS3 = 0, zP = 0;          // S_t .. S_{t+3} of the frame to come, and the open segment's partial count
-  bool z_have = false;
 
   for (int it = 0; it < n_pass; ++it) {
     // The thread index is made opaque PER PASS: what depends on the lane alone (LDS addresses of the transform's transposition and
@@ -148,6 +162,10 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
     float2 *z = reinterpret_cast<float2 *>(rowm);
     float *zf = rowm;
     float *lmel = rowm + 2 * kQuadZPairs, *aud = lmel + 32;
+    int *st = reinterpret_cast<int *>(aud + 32);
+    const int f0 = st[0], utt_len = st[1], T60 = st[2], t0 = st[3], t_last = st[4], t_begin = st[5];
+    const int16_t *xu = reinterpret_cast<const int16_t *>((uintptr_t)(unsigned)st[6] | ((uintptr_t)(unsigned)st[7] << 32));
+    const bool have_run = st[14] != 0;
     const int t_raw = t_begin + it;
     const bool live = have_run && t_raw < t_last;
     const int t = t_raw < t_last ? t_raw : t_last - 1;
@@ -180,6 +198,8 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
     // positions m H + 1 .. m H + H) + the first 158 positions of S_{t+5}
     if (!warm) {
       const int tH = t * kH;
+      int zS0 = st[8], zS1 = st[9], zS2 = st[10], zS3 = st[11], zP = st[12];     // S_t .. S_{t+3} of this frame, the open segment's partial count
+      const bool z_have = st[13] != 0;
       if (!z_have) {                                       // the run's first frame: the whole window, hop by hop
         int S4 = 0, prev_rest = 0, rest = 0;
 #pragma unroll 1
@@ -191,7 +211,6 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
         }
         if (store && j == 0 && t < T60) rawA[3] = (float)(double)(zS0 + zS1 + zS2 + zS3 + S4 + rest) / (float)kN60;
         zS0 = zS1; zS1 = zS2; zS2 = zS3; zS3 = S4; zP = rest;
-        z_have = true;
       } else {
         int two, rest;
         hop_counts(xu, tH + 5 * kH - 2, utt_len, j, two, rest);
@@ -199,6 +218,7 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
         if (store && j == 0 && t < T60) rawA[3] = (float)(double)(zS0 + zS1 + zS2 + zS3 + S4 + rest) / (float)kN60;
         zS0 = zS1; zS1 = zS2; zS2 = zS3; zS3 = S4; zP = rest;
       }
+      if (j == 0) { st[8] = zS0; st[9] = zS1; st[10] = zS2; st[11] = zS3; st[12] = zP; st[13] = 1; }
     }
     QPHASE(1);
     // ---- R4 forward transform in the reference's operation order, R5 magnitudes (registers)
@@ -277,6 +297,21 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
       bandE1 += (double)zf[Q.band_iL[1]] * Q.band_wL[1]; bandE1 += (double)zf[Q.band_iR[1]] * Q.band_wR[1];
       float ctr = 0.0f;
       if (frameSum != 0.0) ctr = (float)(sumA / frameSum);
+      // (what is final already is written now: the sums it comes from need not live to the end of the pass)
+      if (store && j == 0) {
+        const int nBins = kK - 1;
+        float *sp = rawB + 26;
+        sp[0] = (float)(bandE0 / (double)nBins);
+        sp[1] = (float)(bandE1 / (double)nBins);
+        const double flux = fluxS / (double)nBins;
+        sp[6] = (!first && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+        sp[7] = ctr;
+        const double Nind = (double)nBins;
+        const double deno = (Nind * Q.slope_S2f - Q.slope_Sf * Q.slope_Sf);
+        double slope = 0.0;
+        if (deno != 0.0) slope = (Nind * sumA - Q.slope_Sf * frameSum) / deno;
+        sp[12] = (float)(slope * (Nind - 1.0));
+      }
       QPHASE(4);
       // roll-off (:1102-1122): inclusive prefix of the powers of bins 1 .. 256, first bin whose prefix reaches the share
       {
@@ -286,7 +321,8 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
 #pragma unroll
         for (int m = 0; m < 17; ++m) {
           const int k = j + 16 * m;
-          double c = (k >= 1 && k <= kM) ? (double)(mv[m] * mv[m]) : 0.0;
+          const float mq = fresh(mv[m]);
+          double c = (k >= 1 && k <= kM) ? (double)(mq * mq) : 0.0;
           c += shr0_d<1>(c); c += shr0_d<2>(c); c += shr0_d<4>(c); c += shr0_d<8>(c);
           const double tot = lane_d(c, row_base4, 15);
           c += off;
@@ -346,34 +382,30 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
         const double entropy_floor = 0.0000001;
         double dn = frameSum;
         if (dn < (float)entropy_floor) dn = (float)entropy_floor;
-        // the frame's two divisors -- its power sum and log 2 -- by their reciprocals (div_by); a power sum beyond 1e150 (or NaN)
-        // keeps the division
-        // (one decision per wave: both forms return the same bits, the quick one only needs its range)
-        const bool quick = __ballot(!(dn < 1e150)) == 0ull;
+        // the frame's two divisors -- its power sum and log 2 -- by their reciprocals (div_by). Its range holds by construction:
+        // int16 samples are at most 1 in magnitude, a 320-sample frame's bins at most 320, the power sum at most 2.7e7 (and at
+        // least the floor 1e-7); quotients and x log x stay between 1e-15 and 1e15
         const double inv_dn = 1.0 / dn;
         constexpr double kLog2 = 0.693147180559945286226764, kInvLog2 = 1.0 / kLog2;
-        const auto bins = [&](auto quick_c) {
-          constexpr bool kQuick = decltype(quick_c)::value;
+        const double F0e = fresh(F0);                        // (the bins' frequencies F0 k again, not seventeen doubles kept from the sums' loop)
 #pragma unroll
-          for (int m = 0; m < 17; ++m) {
-            const int k = j + 16 * m;
-            const double p = (double)(mv[m] * mv[m]);
-            if (k >= 1 && k <= kM) {
-              zf[k - 1] = (float)(s_sharp[k - 1] * p);       // :1455 / :1469
-              double vv = p;
-              if (vv <= entropy_floor) vv = entropy_floor;
-              const double ln = kQuick ? div_by(vv, dn, inv_dn) : vv / dn;
-              // (ln > 0: a quotient of two values >= 1e-7 -- a positive normal double; x log x in [-0.37, 1e160): div_by's range)
-              const double xl = ln * log_d<true>(ln, s_log);
-              e0 += (ln > 0.0) ? (kQuick ? div_by(xl, kLog2, kInvLog2) : xl / log(2.0)) : 0.0;
-              const double t1 = F0 * k - (double)ctr;
-              double mm = t1 * t1 * p;
-              e1 += mm; mm *= t1; e2m += mm; e3 += mm * t1;
-            }
-            if (m % CQ_BINS_GROUP == CQ_BINS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < 17; ++m) {
+          const int k = j + 16 * m;
+          const float me = fresh(mv[m]);
+          const double p = (double)(me * me);
+          if (k >= 1 && k <= kM) {
+            zf[k - 1] = (float)(s_sharp[k - 1] * p);         // :1455 / :1469
+            double vv = p;
+            if (vv <= entropy_floor) vv = entropy_floor;
+            const double ln = div_by(vv, dn, inv_dn);
+            const double xl = ln * log_d<true>(ln, s_log);
+            e0 += (ln > 0.0) ? div_by(xl, kLog2, kInvLog2) : 0.0;
+            const double t1 = F0e * fresh(k) - (double)ctr;
+            double mm = t1 * t1 * p;
+            e1 += mm; mm *= t1; e2m += mm; e3 += mm * t1;
           }
-        };
-        if (quick) bins(std::true_type{}); else bins(std::false_type{});
+          if (m % CQ_BINS_GROUP == CQ_BINS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
       const double ent = QuadG::sum(e0, nullptr), mom2 = QuadG::sum(e1, nullptr), mom3 = QuadG::sum(e2m, nullptr), mom4 = QuadG::sum(e3, nullptr);
       QPHASE(7);
@@ -386,25 +418,15 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
       if (store && j == 0) {
         const int nBins = kK - 1;
         float *sp = rawB + 26;
-        sp[0] = (float)(bandE0 / (double)nBins);
-        sp[1] = (float)(bandE1 / (double)nBins);
         float c2 = 0.0f;
         if (frameSum != 0.0) c2 = (float)(sumAA / frameSum);
         sp[13] = (float)(0.11 * c2);
-        const double flux = fluxS / (double)nBins;
-        sp[6] = (!first && flux > 0.0) ? (float)sqrt(flux) : 0.0f;
-        sp[7] = ctr;
         sp[8] = (float)(-ent);
         const double sumB = frameSum;
         const double sigma2 = (sumB != 0.0) ? mom2 / sumB : 0.0;
         sp[9] = (float)sigma2;
         sp[10] = (sigma2 <= 0.0) ? 0.0f : (float)(mom3 / (sumB * sigma2 * sqrt(sigma2)));
         sp[11] = (sigma2 == 0.0) ? 0.0f : (float)(mom4 / (sumB * sigma2 * sigma2));
-        const double Nind = (double)nBins;
-        const double deno = (Nind * Q.slope_S2f - Q.slope_Sf * Q.slope_Sf);
-        double slope = 0.0;
-        if (deno != 0.0) slope = (Nind * sumA - Q.slope_Sf * sumB) / deno;
-        sp[12] = (float)(slope * (Nind - 1.0));
         float ptpSum = ptp;
         ptpSum /= 2.0f;
         ptpSum /= (float)nBins;

@@ -16,7 +16,7 @@ R=$GRAFT_REPO_ROOT
 T=$1; shift
 O=$R/gpurun_out/$T
 mkdir -p $O
-declare -A UTTS=( [2]=1000 [3]=2000 [4]=1000 [5]=6000 )
+declare -A UTTS=( [2]=1000 [3]=2000 [4]=1500 [5]=6000 )
 declare -A STEPS=( [2]=3 [3]=2 [4]=1 [5]=1 )
 n=0
 for sec in "$@"; do
