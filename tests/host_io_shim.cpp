@@ -44,6 +44,28 @@ extern "C" long shim_read_wave(const char *path, long *info, void *buf, int64_t 
   return (long)d.size();
 }
 
+// the two-step reader of the file-to-file route: probe_wave_file (the quick in-memory walk, or the general one) + read_wave_data.
+// Same answer as read_wave_file for every file it accepts; returns the bytes read, -1 on failure.
+extern "C" long shim_probe_read_wave(const char *path, long *info, void *buf, int64_t cap) {
+  WaveInfo w;
+  std::string err;
+  if (!probe_wave_file(path, w, err)) return -1;
+  info[0] = w.sample_rate; info[1] = w.sample_type; info[2] = w.n_chan; info[3] = w.n_bps; info[4] = w.n_bits;
+  info[5] = w.n_blocks; info[6] = w.block_size; info[7] = w.header_offset;
+  const size_t bytes = (size_t)w.n_blocks * (size_t)w.block_size;
+  if (!buf || cap <= 0) return (long)bytes;
+  std::vector<unsigned char> d(bytes ? bytes : 1);
+  const long got = read_wave_data(path, w, d.data(), bytes, err);
+  if (got < 0) return -1;
+  std::memcpy(buf, d.data(), (size_t)std::min<int64_t>(cap, (int64_t)got * w.block_size));
+  return got * w.block_size;
+}
+// write_htk_be on rows the caller has made big-endian (what smilehip_htk_rows_be does on the device)
+extern "C" int shim_write_htk_be(const char *path, const void *be_rows, int64_t rows, int cols, double period) {
+  std::string err;
+  return write_htk_be(path, be_rows, rows, cols, period, 9, err) ? 1 : 0;
+}
+
 // names of a level, '\n'-joined: 3 = ComParE_2016 LLD (130), 4 = ComParE_2016 functionals (6373); returns the byte count
 extern "C" long shim_names(int which, char *buf, long cap) {
   const std::vector<std::string> n = which == 3 ? lld_names_compare16() : func_names_compare16();

@@ -55,6 +55,9 @@ def build_hostlib():
     L.shim_write_arff.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
     L.shim_read_wave.argtypes = [C.c_char_p, C.POINTER(C.c_long), C.c_void_p, C.c_int64]
     L.shim_read_wave.restype = C.c_long
+    L.shim_probe_read_wave.argtypes = [C.c_char_p, C.POINTER(C.c_long), C.c_void_p, C.c_int64]
+    L.shim_probe_read_wave.restype = C.c_long
+    L.shim_write_htk_be.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double]
     return L
 
 
@@ -131,6 +134,105 @@ def test_wave_reader(hostlib, tmp_path):
         body = fmt + b"data" + struct.pack("<I", 0) + tail
         (tmp_path / name).write_bytes(b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body)
         assert hostlib.shim_read_wave(str(tmp_path / name).encode(), info, None, 0) == want, name
+
+
+def test_two_step_wave_reader_equals_the_one_step_reader(hostlib, tmp_path):
+    """probe_wave_file + read_wave_data (the file-to-file route's ingest: one pread + fstat for the common header, the general
+    walk otherwise) give what read_wave_file gives -- parameters, header offset, sample bytes -- on the golden file and on
+    every odd layout of test_wave_reader: chunks before fmt / data, an 18-byte fmt, a data size of 0 (pipe), samples that look
+    like a chunk header, metadata behind an empty data chunk, a data size beyond the file's end, a header beyond the first 4 KB."""
+    fmt = b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 16000, 2, 16)
+    audio = struct.pack("<6h", 5, 6, 7, 8, 9, 10)
+    cases = {
+        "plain.wav": fmt + b"data" + struct.pack("<I", 12) + audio,
+        "odd.wav": (b"LIST" + struct.pack("<I", 3) + b"abc\0" + b"fmt " + struct.pack("<IHHIIHHH", 18, 1, 2, 8000, 32000, 4, 16, 0) +
+                    b"fact" + struct.pack("<I", 4) + b"\0\0\0\0" + b"data" + struct.pack("<I", 8) + struct.pack("<4h", 1, -2, 3, -4)),
+        "pipe.wav": fmt + b"data" + struct.pack("<I", 0) + audio,
+        "lookalike.wav": fmt + b"data" + struct.pack("<I", 0) + b"abcd" + struct.pack("<I", 4) + b"\1\0\2\0" + b"\3\0\4\0\5\0",
+        "meta.wav": fmt + b"data" + struct.pack("<I", 0) + b"LIST" + struct.pack("<I", 5) + b"hello\0" + b"id3 " + struct.pack("<I", 2) + b"xy",
+        "short.wav": fmt + b"data" + struct.pack("<I", 4000) + audio,                    # the header promises more than the file holds
+        "far.wav": b"JUNK" + struct.pack("<I", 5000) + bytes(5000) + fmt + b"data" + struct.pack("<I", 12) + audio,   # header beyond 4 KB
+        "trail.wav": fmt + b"data" + struct.pack("<I", 8) + audio,                       # samples, then bytes the data chunk does not cover
+    }
+    paths = [os.path.join(G, "u2_8000.wav")]
+    for name, body in cases.items():
+        p = tmp_path / name
+        p.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body)
+        paths.append(str(p))
+    for p in paths:
+        ia, ib = (C.c_long * 8)(), (C.c_long * 8)()
+        a, b = np.zeros(20000, np.uint8), np.zeros(20000, np.uint8)
+        na = hostlib.shim_read_wave(p.encode(), ia, a.ctypes.data, a.size)
+        nb = hostlib.shim_probe_read_wave(p.encode(), ib, b.ctypes.data, b.size)
+        assert na == nb and list(ia) == list(ib), (p, na, nb, list(ia), list(ib))
+        assert np.array_equal(a, b), p
+    (tmp_path / "bad.wav").write_bytes(b"RIFX" + b"\0" * 40)
+    assert hostlib.shim_probe_read_wave(str(tmp_path / "bad.wav").encode(), (C.c_long * 8)(), None, 0) < 0
+
+
+def test_htk_writer_from_big_endian_rows_byte_exact(hostlib, tmp_path):
+    """write_htk_be (one writev of rows that are big-endian already) writes the file write_htk writes"""
+    for f, period in (("mfcc_u2_8000.htk", 0.01), ("is09_lld_u3.htk", 0.01)):
+        _, x = read_htk(os.path.join(G, f))
+        be = np.ascontiguousarray(x.astype(">f4"))
+        out = str(tmp_path / f)
+        assert hostlib.shim_write_htk_be(out.encode(), be.ctypes.data, x.shape[0], x.shape[1], period) == 1
+        assert open(out, "rb").read() == open(os.path.join(G, f), "rb").read(), f
+
+
+@pytest.mark.gpu
+def test_htk_rows_be_on_the_device():
+    """smilehip_htk_rows_be: the big-endian image of every value (cHtkSink's swap), aligned and unaligned pointers, in place"""
+    import ctypes as CC
+    from opensmile_amd import capi
+    L = capi.load()
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(3)
+    for n in (1, 3, 4, 5, 39 * 998, 1 << 20):
+        x = rng.standard_normal(n + 1).astype(np.float32)
+        d = CC.c_void_p()
+        capi._check(L.smilehip_alloc(ctx._h, 4 * (n + 1), CC.byref(d)))
+        for shift in (0, 1):                               # (shift 1: a pointer that is not 16-byte aligned)
+            capi._check(L.smilehip_copy_to_device(ctx._h, d, x.ctypes.data, 4 * (n + 1), None))
+            p = CC.c_void_p(d.value + 4 * shift)
+            capi._check(L.smilehip_htk_rows_be(ctx._h, p, n, p, None))
+            y = np.zeros(n + 1, np.float32)
+            capi._check(L.smilehip_copy_to_host(ctx._h, y.ctypes.data, d, 4 * (n + 1), None))
+            capi._check(L.smilehip_stream_synchronize(ctx._h, None))
+            want = x.copy()
+            want[shift:shift + n] = x[shift:shift + n].astype(">f4").view(np.float32)
+            assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), (n, shift)
+        L.smilehip_free(ctx._h, d)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_smilextract_hip_file_list_pipeline_equals_the_serial_route(tmp_path):
+    """The three-stage pipeline (page-locked slots, rows big-endian on the device, one writev per file, chunks in flight) writes
+    byte for byte what the serial, pageable route of round 3 writes (SMILEHIP_NO_PINNED=1) -- a list longer than a chunk, ragged
+    lengths incl. a file too short for a frame, HTK alone and HTK + CSV (the latter keeps the host's swap)."""
+    import wave
+    from opensmile_amd import synth
+    lens = [16000, 400, 399, 8123, 48000, 160, 24000] * 5
+    paths = []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f"f{i:02d}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(synth.utterance(40 + i % 7, n).tobytes())
+        paths.append(p)
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    for opts in (["-O", "1"], ["-O", "1", "-csvoutput", "1"]):
+        outs = {}
+        for tag, env in (("pipeline", {}), ("serial", {"SMILEHIP_NO_PINNED": "1"})):
+            d = tmp_path / (tag + str(len(opts)))
+            d.mkdir()
+            subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-filelist", lst, "-outdir", str(d), "--chunk-files", "8"] + opts,
+                           check=True, env=dict(os.environ, **env))
+            outs[tag] = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))}
+        assert outs["pipeline"].keys() == outs["serial"].keys() and len(outs["pipeline"]) == len(lens) * (len(opts) // 2)
+        assert outs["pipeline"] == outs["serial"]
 
 
 @pytest.mark.gpu
