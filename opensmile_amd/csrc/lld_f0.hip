@@ -113,9 +113,10 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
 // leaves y (smoothed spectrum) in A and 6*ut in B. Returns the frame's sum of squares.
 // enh_store (optional): a functor (bin, float) that takes the enhanced magnitudes -- they are floats widened, or zero -- and
 // ends the function there (the chain's lld_f0_spec: smoothing and the spline are lld_f0_sweep's work, one frame per lane)
-template <class G, bool OO, class XIn = PcmIn, class EnhStore = std::nullptr_t>   // OO: the reference-order transform (one form per kernel instance: register budget)
+// raw_store (optional): a functor (bin, float) that takes the magnitudes as cFFTmagphase writes them (the level's other readers)
+template <class G, bool OO, class XIn = PcmIn, class EnhStore = std::nullptr_t, class RawStore = std::nullptr_t>   // OO: the reference-order transform (one form per kernel instance: register budget)
 __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q, const XIn x, const float *mag_in, int lane,
-                                              double *A, double *B, EnhStore enh_store = nullptr) {
+                                              double *A, double *B, EnhStore enh_store = nullptr, RawStore raw_store = nullptr) {
   F0_GEO;
   float2 *z = reinterpret_cast<float2 *>(A);             // WaveFft<9>::kZ pairs: A and the first 480 bytes of B (B == A + kKP)
   double esum = 0.0;
@@ -153,7 +154,9 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
       if constexpr (OO && !G::kRegFft) X = ooura_bin(z, T.oo, k);
       else if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k);
       else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
-      mg[m] = (double)bin_magnitude(X, k == 0 || k == kM);
+      const float mf = bin_magnitude(X, k == 0 || k == kM);
+      mg[m] = (double)mf;
+      if constexpr (!std::is_same<RawStore, std::nullptr_t>::value) raw_store(k, mf);
     }
   }
   WaveG::sync();                                         // the transform's buffer reaches into B
@@ -304,7 +307,7 @@ __device__ __forceinline__ void f0_spline_serial(const F0Tbl &T, double *B) {
 // hps_blk != null: the chain's lld_f0_cand -- the octave-scale spectrum of chunk frame hps_fr in lld_f0_sweep's blocked layout
 template <class G>
 __host__ __device__ inline int64_t f0_b16_index(int64_t fr, int i);
-template <class G>
+template <class G, bool CHAIN = false>                   // CHAIN: called by lld_f0_cand on lld_f0_sweep's rows (hps_blk)
 __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lane_in, int64_t g, double *A, double *B, int *ci,
                                       const float *hps_in, bool only_scale, double *mean_exact = nullptr,
                                       const float *hps_blk = nullptr, int64_t hps_fr = 0) {
@@ -351,7 +354,13 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   WaveG::sync();
   if (only_scale) return 0;
   F0_SUB(1);   // spline evaluation + auditory weighting
+  // The chain's rows (hps_blk) are weighted spectra, >= +0: a bin past the end of the spectrum may then be read as +0 and ADDED (x + 0 * s
+  // = x bit for bit for x >= +0) instead of selected away -- kK zeros behind the row (where SS will be written afterwards) save a
+  // compare and a select per bin and harmonic, 13 % of lld_f0_cand's vector instructions. Rows of the per-component operators
+  // (any sign, -0 included) keep the select.
+  constexpr bool padded = CHAIN;
   F0_FOR_BINS(m, i) if (i < kK) hps[i] = hv[m];
+  if (padded) { F0_FOR_BINS(m, i) if (i < kK) hps[kK + i] = 0.0f; }
   WaveG::sync();
   // SS[j] = (in[j] + sum_h in[j + shift_h] * scale_h) / nHarmonics, terms in harmonic order
 #pragma unroll
@@ -362,8 +371,14 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
       const int sh = Q.shift[h], lim = kK - sh;
       const float sc = Q.scale[h];
       float v[kPer];
-      F0_FOR_BINS(m, j) v[m] = hps[j + sh];
-      F0_FOR_BINS(m, j) { const float s2 = hv[m] + v[m] * sc; hv[m] = (j < lim) ? s2 : hv[m]; }
+      if (padded) {
+        if (sh >= kK) continue;                          // (wave-uniform: no bin has a partner)
+        F0_FOR_BINS(m, j) v[m] = hps[j + sh];
+        F0_FOR_BINS(m, j) hv[m] = hv[m] + v[m] * sc;     // (bins >= kK collect what lies behind the zeros: never read)
+      } else {
+        F0_FOR_BINS(m, j) v[m] = hps[j + sh];
+        F0_FOR_BINS(m, j) { const float s2 = hv[m] + v[m] * sc; hv[m] = (j < lim) ? s2 : hv[m]; }
+      }
     }
   F0_FOR_BINS(m, j) {
     float s = hv[m] / (float)Q.n_harm;
@@ -692,9 +707,11 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   for (int w = 0; w < n_fr; ++w) {
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     const auto store = [&](int i, float v) { S.mg[f0_b16_index<G>(fr, i)] = v; };
+    float *keep = Q.mag_keep ? Q.mag_keep + (P.tile_rec[tile].row0 + w) * Q.mag_ld : nullptr;      // (wave-uniform)
+    const auto raw = [&](int i, float v) { if (keep) keep[i] = v; };
     double es;
-    if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store);
-    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store);
+    if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
+    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
     if (lane == 0) S.es[fr] = es;
     WaveG::sync();
   }
@@ -893,7 +910,7 @@ __device__ __forceinline__ void f0_cand_body(const LldParams &P, const F0Params 
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
     const double es = S.es[fr];
     double mean = 0.0;
-    const int nf = f0_shs<G>(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean, S.hp, fr);
+    const int nf = f0_shs<G, true>(T, Q, lane, row0 + w, A, A + kKP, ci, nullptr, false, &mean, S.hp, fr);
     WaveG::sync();
     PHASE(2);   // rows from global, summation, top six
     if (mean != mean) {                                  // (wave-uniform) no exactness guarantee: the reference's chain

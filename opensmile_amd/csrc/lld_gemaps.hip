@@ -831,6 +831,21 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
       }
       r20 = row0 - G.frame_off60[lo] + P.frame_off[lo];
     }
+    // The kept spectra (G.mag60): a frame's nine loads per lane are issued one frame ahead -- while the frame before it is worked on --
+    // for voiced frames only.
+    constexpr int kMagPer = (kHM + 64) / 64;
+    float mv[kMagPer];
+    const auto fetch_mag = [&](int tfn) {
+      if (!G.mag60 || rows_mode || tfn >= n_fr) return;
+      const int64_t gn = row0 + tfn;
+      if (!(G.pitch3[gn * 3] > 0.0f)) return;
+      const float *mi = G.mag60 + gn * G.mag60_ld;
+#pragma unroll
+      for (int m = 0; m < kMagPer; ++m) { const int k = lane_in + 64 * m; mv[m] = k <= kHM ? mi[k] : 0.0f; }
+    };
+#pragma unroll
+    for (int m = 0; m < kMagPer; ++m) mv[m] = 0.0f;
+    fetch_mag(0);
     for (int tf = 0; tf < n_fr; ++tf) {
       int lane = lane_in;                                // opaque per frame (see lld_compare_frame_wave)
       asm volatile("" : "+v"(lane));
@@ -842,11 +857,16 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
           o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
           o[3] = (float)-201.0; o[4] = (float)-201.0; o[5] = (float)-201.0;   // logRelValueFloorUnvoiced
         }
+        fetch_mag(tf + 1);
         continue;
       }
       if (rows_mode) {
         const float *mi = G.op_in + g * G.op_ld_in;
         for (int k = lane; k <= kHM; k += 64) mg[k] = mi[k];
+      } else if (G.mag60) {                              // the level as the pitch chain's lld_f0_spec kept it (same frame, window, transform)
+#pragma unroll
+        for (int m = 0; m < kMagPer; ++m) { const int k = lane_in + 64 * m; if (k <= kHM) mg[k] = mv[m]; }
+        fetch_mag(tf + 1);
       } else {
         const PcmIn x = pcm_in(P) + (samp0 + (int64_t)tf * Q.H);
         const auto load_pair = [&](int i) {

@@ -164,6 +164,8 @@ struct F0Params {
   float *shs;                       // [total_frames x 21] nCand | F0Cand[6] | candVoicing[6] | candScores[6] | F0raw | voicingClip
   float *e60;                       // [total_frames] RMS energy of the windowed frame
   float *hps_tap;                   // optional [total_frames x K] level is13_hpsG60, or null
+  float *mag_keep;                  // optional [total_frames x mag_ld]: the magnitude spectra (level fftmagG60) for the readers behind the
+  int64_t mag_ld;                   //   pitch decision (cHarmonics reads the same level: lld_gemaps_harm), or null
   // per-component operators (mode 1: cSpecScale rows -> hps_tap, mode 2: cPitchShs rows -> shs)
   int32_t mode;
   double *ab;                       // chain mode, between the three frame kernels (lld_f0.hip, F0Scratch): the enhanced magnitudes
@@ -223,6 +225,8 @@ struct GemapsParams {
   const float *jit4;                // [total_frames60 x 4] cPitchJitter's outputs, jitterLocal in column 0
   const float *shim_db;             // [total_frames60] shimmerLocalDB
   float *harm6;                     // [total_frames60 x 6] cHarmonics' outputs
+  const float *mag60;               // [total_frames60 x mag60_ld] the 60 ms magnitude spectra as lld_f0_spec kept them (F0Params::mag_keep), or
+  int64_t mag60_ld;                 //   null: lld_gemaps_harm transforms the frames again
   const int64_t *frame_off60;       // [n_utt+1]
   const TileRec *tile60;            // tiles of <= 8 consecutive 60 ms frames
   int32_t n_tiles60;

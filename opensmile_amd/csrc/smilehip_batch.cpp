@@ -153,6 +153,26 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       delete b;
       return rc;
     }
+    // cHarmonics reads gemapsv01b_fftmagG60, the level cSpecScale reads: lld_f0_spec keeps its magnitudes (2 KB per 60 ms frame) and
+    // lld_gemaps_harm starts from them instead of windowing and transforming every voiced frame a second time. Kept only while it
+    // is a modest part of what is free (the caller's output matrices come after this); SMILEHIP_HARM_KEEP_MAG=0 / =1 forces it.
+    if (b->f0_batch->total_frames > 0) {
+      smilehip_batch *fb = b->f0_batch;
+      const int64_t ld = (plan->f0_plan->geo.K + 3) & ~int64_t(3);
+      const size_t need = size_t(fb->total_frames) * size_t(ld) * sizeof(float);
+      size_t free_b = 0, total_b = 0;
+      const char *env = getenv("SMILEHIP_HARM_KEEP_MAG");
+      bool keep = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2;
+      if (env && env[0] == '0') keep = false;
+      if (env && env[0] == '1') keep = true;
+      if (keep && hipMalloc(reinterpret_cast<void **>(&fb->d_mag_keep.p), need) == hipSuccess) {
+        fb->d_mag_keep.n = need / sizeof(float);
+        fb->mag_ld = ld;
+      } else {
+        fb->d_mag_keep.p = nullptr;
+        (void)hipGetLastError();
+      }
+    }
   }
   // The fast kernel with the two regression stages inside (lld_mfcc512<..., DELTA>): tiles as long as the batch allows -- a tile
   // pays one pass of four frames before it (inside an utterance) and one behind it. L = the tile length whose estimate
@@ -663,6 +683,8 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.ab = b->d_f0_ab.p;
   Q.ab_rows = f0_scratch_rows(b->n_tiles);
   Q.hps_tap = b->d_hps_tap;
+  Q.mag_keep = b->d_mag_keep.p;
+  Q.mag_ld = b->mag_ld;
   Q.pending = b->d_pending.p;
   Q.vit_log_out = log_out ? 1 : 0;
   int trc;
@@ -745,6 +767,8 @@ static void fill_gemaps_params(const smilehip_plan *plan, const smilehip_batch *
   G.n_tiles60 = fb->n_tiles;
   G.pending = fb->d_pending.p;
   G.harm_ctl = b->d_harm_ctl.p;
+  G.mag60 = fb->d_mag_keep.p;
+  G.mag60_ld = fb->mag_ld;
   G.func_in = b->d_func_in.p;
   G.fin_off = b->d_fin_off.p;
   G.pending_j = b->d_pending_j.p;

@@ -184,6 +184,8 @@ struct smilehip_batch {
   DevBuf<float> d_rawA, d_rawB, d_mel1;   // ComParE A+B scratch
   DevBuf<float> d_b_extra;                // [n_utt x 110] row T60+1 of group B's sma / delta levels (functionals)
   DevBuf<float> d_shs, d_e60;             // F0 group: candidates (total_frames x 21) and frame energies
+  DevBuf<float> d_mag_keep;               // F0 group inside the eGeMAPS chain: the frames' magnitude spectra (total_frames x mag_ld) for
+  int64_t mag_ld = 0;                     //   cHarmonics, which reads the level the pitch chain reads; empty: cHarmonics transforms again
   DevBuf<double> d_f0_ab;                 // F0 group: rows of (y | 6ut -> y2) between the three frame kernels, one chunk of tiles
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance

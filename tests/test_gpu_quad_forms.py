@@ -69,3 +69,30 @@ def test_gemaps_quad_form_equals_wave_form_bit_for_bit(monkeypatch, run_frames):
             assert not d.any(), (what, int(d.sum()), np.argwhere(d)[:5])
         plan.close()
     ctx.close()
+
+
+def test_harmonics_from_kept_magnitudes_equal_recomputed_ones_bit_for_bit(monkeypatch):
+    """cHarmonics reads the level cSpecScale reads: lld_gemaps_harm on the spectra lld_f0_spec kept (the default when they fit) against
+    lld_gemaps_harm transforming the frames itself (SMILEHIP_HARM_KEEP_MAG=0)."""
+    from opensmile_amd import capi
+    pcm, off = _corpus()
+    ctx = capi.Context(0)
+    for cfg_fn in (capi.egemapsv02_config, capi.egemapsv01a_config):
+        plan = capi.Plan(ctx, cfg_fn())
+        outs = {}
+        for keep in ("1", "0"):
+            monkeypatch.setenv("SMILEHIP_HARM_KEEP_MAG", keep)
+            b = capi.Batch(plan, off)
+            lld, func, taps = b.run_host_egemaps(pcm, taps=True)
+            lld2, func2, taps2 = b.run_host_egemaps(pcm, taps=True)       # (a second run of the same batch: counters and stores reset)
+            assert np.array_equal(lld.view(np.uint32), lld2.view(np.uint32)) and np.array_equal(func.view(np.uint32), func2.view(np.uint32))
+            outs[keep] = (lld.copy(), func.copy(), taps["harm6"].copy())
+            b.close()
+        assert outs["1"][2].shape[1] == 6 and (outs["1"][2][:, 0] != 0).any()            # (voiced frames: an HNR)
+        for i, what in enumerate(("LLD level", "functionals", "cHarmonics' six outputs")):
+            a, w = outs["1"][i], outs["0"][i]
+            assert a.shape == w.shape and a.size > 0, what
+            d = a.view(np.uint32) != w.view(np.uint32)
+            assert not d.any(), (what, int(d.sum()), np.argwhere(d)[:5])
+        plan.close()
+    ctx.close()
