@@ -733,8 +733,9 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
 // ------------------------------------------------------------------------------------------------ cHarmonics
 // cHarmonics::processVector (harmonics.cpp:743-1031) with [gemapsv01b_harmonics]'s options. One wave per tile of <= 8
 // consecutive 60 ms frames; unvoiced frames (F0final == 0) only write the constants the reference emits.
-// The 60 ms magnitude spectrum is recomputed here (window + FFT 1024) rather than kept from the pitch kernel: 2 KB per
-// frame of HBM traffic each way would cost more than the transform.
+// The 60 ms magnitude spectrum is the level cSpecScale reads (gemapsv01b_fftmagG60): the batch keeps lld_f0_spec's magnitudes
+// (G.mag60, 2 KB per frame: 58 ms less here for 14 ms more there per 37 M frames) when they fit; without them -- batches near the
+// memory limit, the per-component operator's rows come in by G.op_in -- the frame is windowed and transformed here.
 // LDS: shared win[NP] | twh[256] | twf[260]; per wave z[576 pairs] (later hbin[128] | hfi[128] | hmag[128] | hlr[128]) |
 // mg[516] | acf[516]
 namespace {

@@ -438,25 +438,29 @@ bool conf_check_io(const ConfFile &f, const std::set<std::string> &produced, std
       if (end == v->c_str()) { bad = true; return dflt; }
       return d;
     };
-    struct Want { const char *what; double has; double implemented; };
+    // what the file asks of a sink option against what smilextract_hip's writers do: `was_set` = the file names the option (under
+    // either of its spellings), `exact` = the value itself must match (offsets), not only its being zero or not (switches)
+    struct Want { const char *what; double has; double implemented; bool was_set; bool exact; };
     std::vector<Want> wants;
     bool bad = false;
+    const auto set = [&](const char *a, const char *b = nullptr) { return i.find(a) != nullptr || (b && i.find(b) != nullptr); };
     const double number = i.find("frameIndex") ? value_of("frameIndex", 1, bad) : value_of("number", 1, bad);
     const double stamp = i.find("frameTime") ? value_of("frameTime", 1, bad) : value_of("timestamp", 1, bad);
+    const bool number_set = set("frameIndex", "number"), stamp_set = set("frameTime", "timestamp");
+    const auto plain = [&](const char *key, double dflt, double implemented, bool exact = false) {
+      return Want{key, value_of(key, dflt, bad), implemented, set(key), exact};
+    };
     if (i.type == "cCsvSink")
-      wants = {{"timestamp / frameTime", stamp, 1}, {"printHeader", value_of("printHeader", 1, bad), 1}, {"number / frameIndex", number, 0},
-               {"frameLength", value_of("frameLength", 0, bad), 0}, {"lag", value_of("lag", 0, bad), 0},
-               {"append", value_of("append", 0, bad), on_func ? 1.0 : 0.0}};
+      wants = {{"timestamp / frameTime", stamp, 1, stamp_set, false}, plain("printHeader", 1, 1), {"number / frameIndex", number, 0, number_set, false},
+               plain("frameLength", 0, 0), plain("lag", 0, 0, true), plain("append", 0, on_func ? 1.0 : 0.0)};
     if (i.type == "cArffSink")
-      wants = {{"number / frameIndex", number, 0}, {"timestamp / frameTime", stamp, on_func ? 0.0 : 1.0},
-               {"frameTimeAdd", value_of("frameTimeAdd", 0, bad), 0}, {"frameLength", value_of("frameLength", 0, bad), 0},
-               {"lag", value_of("lag", 0, bad), 0}, {"append", value_of("append", 0, bad), 1}};
-    if (i.type == "cHtkSink") wants = {{"append", value_of("append", 0, bad), 0}, {"lag", value_of("lag", 0, bad), 0}};
+      wants = {{"number / frameIndex", number, 0, number_set, false}, {"timestamp / frameTime", stamp, on_func ? 0.0 : 1.0, stamp_set, false},
+               plain("frameTimeAdd", 0, 0, true), plain("frameLength", 0, 0), plain("lag", 0, 0, true), plain("append", 0, 1)};
+    if (i.type == "cHtkSink") wants = {plain("append", 0, 0), plain("lag", 0, 0, true)};
     if (bad) { err = "[" + i.name + ":" + i.type + "] has a numeric option that does not parse"; return false; }
     for (const Want &w : wants)
-      if (!((w.has != 0) == (w.implemented != 0)) || (std::string(w.what) == "frameTimeAdd" && w.has != w.implemented) ||
-          (std::string(w.what) == "lag" && w.has != w.implemented)) {
-        err = "[" + i.name + ":" + i.type + "] " + w.what + " = " + canonical_value(std::to_string(w.has)) + (i.find(w.what) ? "" : " (the component's default where the file is silent)") +
+      if (w.exact ? w.has != w.implemented : (w.has != 0) != (w.implemented != 0)) {
+        err = "[" + i.name + ":" + i.type + "] " + w.what + " = " + canonical_value(std::to_string(w.has)) + (w.was_set ? "" : " (the component's default where the file is silent)") +
               " is not implemented by smilextract_hip's writer (only " + canonical_value(std::to_string(w.implemented)) + ")";
         return false;
       }

@@ -116,6 +116,20 @@ def test_option_changes_and_refusals(tmp_path):
     for extra in (("-lldarffoutput", "a.arff"), ("-timestampcsv", "0"), ("-appendarff", "0"), ("-relation", "x"), ("-frameTimeAdd", "1")):
         rc, kv, err = describe(big, *extra)
         assert rc != 0 and extra[0][1:] in err, (extra, err)
+    # the message says whether the refused value is the file's or the component's default: -timestampcsv 0 sets frameTime in
+    # [csvsink] (named by its other spelling in the message); a [csvsink] without its frameIndex line falls back to the default 1
+    bigdir = tmp_path / "is09-13"
+    shutil.copytree(os.path.join(CONF, "is09-13"), bigdir)
+    inc = (tmp_path / "shared" / "standard_data_output.conf.inc")
+    t = inc.read_text()
+    assert "frameIndex=0\n" in t and "frameTime=\\cm[timestampcsv{1}" in t
+    inc.write_text(t.replace("frameTime=\\cm[timestampcsv{1}", "frameTime=0 ;\\cm[timestampcsv{1}", 1))
+    rc, kv, err = describe(str(bigdir / "IS09_emotion.conf"), "-csvoutput", "x.csv")
+    assert rc != 0 and "timestamp / frameTime = 0" in err and "where the file is silent" not in err, err
+    inc.write_text(t.replace("frameIndex=0\n", "", 1))
+    rc, kv, err = describe(str(bigdir / "IS09_emotion.conf"), "-csvoutput", "x.csv")
+    assert rc != 0 and "number / frameIndex = 1" in err and "where the file is silent" in err, err
+    inc.write_text(t)
     # source / sink sections edited in the file itself: a segment, a second sink on a stage level, an unknown sink type
     rc, kv, err = describe(variant("f.conf", ("instance[frame].type=cFramer", "instance[frame].type=cFramer\ninstance[waveIn2].type=cWaveSource"), ("[frame:cFramer]", "[waveIn2:cWaveSource]\nstart = 0.5\n[frame:cFramer]")))
     assert rc != 0 and "start" in err, err
