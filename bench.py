@@ -69,7 +69,7 @@ CONFIGS = {
             workload="ComParE_2016 whole LLD level (130 columns: F0 group incl. Viterbi + jitter / shimmer, groups A + B, deltas) on "
                      "12 500 x 10 s synthetic 16 kHz mono int16 per GPU (config 4's share of 100 000 utterances over 8 GPUs), "
                      "PCM resident in HBM",
-            kernel="lld_compare_frame_wave3 (+ RASTA scan, group A)", pmc_kernels=["lld_compare_frame_wave", "lld_compare_rasta", "lld_compare_groupA"],
+            kernel="lld_compare_frame_quad (+ RASTA scan, group A)", pmc_kernels=["lld_compare_frame", "lld_compare_rasta", "lld_compare_groupA"],
             alg_bytes=2 * 160 + 4 * (4 + 55),
             alg_note="int16 hop in + 59 f32 pre-smoothing columns of groups A + B out per 20 ms frame",
             conf="compare16/ComParE_2016.conf", opt="-lldhtkoutput"),
