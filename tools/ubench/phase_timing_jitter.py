@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase wave residence of the jitter kernels (instrumented build: tools/ubench/variant_any.sh jitter phasejit
--DSMILEHIP_PHASE_TIMING). usage: phase_timing_jitter.py [utterances]; SMILEHIP_JITTER=utt times the per-utterance form."""
+-DSMILEHIP_PHASE_TIMING). usage: phase_timing_jitter.py [utterances] [egemaps]; SMILEHIP_JITTER=utt times the per-utterance form."""
 import ctypes as C
 import os
 import sys
@@ -19,9 +19,10 @@ NAMES = ["frame set-up + wave load", "cross-correlations", "peak / amplitudes / 
 
 def main():
     ctx = capi.Context(0)
-    plan = capi.Plan(ctx, capi.compare16_config())
+    egm = len(sys.argv) > 2 and sys.argv[2] == "egemaps"      # searchRangeRel 0.1 instead of 0.25: a fifth of the period in candidates
+    plan = capi.Plan(ctx, capi.egemapsv02_config() if egm else capi.compare16_config())
     n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    pcm, off = synth.corpus_tiled(n_utt, 160000, n_unique=32)
+    pcm, off = synth.corpus_tiled(n_utt, 48000 if egm else 160000, n_unique=32)
     b = capi.Batch(plan, off)
     d_pcm = torch.from_numpy(pcm).cuda()
     d_out = torch.empty((b.total_rows, 130), dtype=torch.float32, device="cuda")
