@@ -1233,7 +1233,7 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
   if (n_runs <= 0) return hipSuccess;
   if ((P.Nfft != 256 && P.Nfft != 512 && P.Nfft != 1024) || P.N > P.Nfft || P.n_mfcc > 16 || P.n_bands > 32) return hipErrorInvalidValue;   // 20 ms at 8 .. 48 kHz
   const int M = P.Nfft / 2;
-  const int Npad = (P.N + 3) & ~3, Kpad = (P.K + 3) & ~3;
+  const int Kpad = (P.K + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * ((2 * fft_pairs(M) > 2 * Kpad ? 2 * fft_pairs(M) : 2 * Kpad) + 3 * Kpad + 64 + 96));
   // sixteen lanes per frame for the shipped geometry (lld_gemaps_quad.hpp); SMILEHIP_GEMAPS_WAVE=1: the wave-per-frame form (A/B switch)
   const bool quad_ok = P.oo.tw && P.N == 320 && P.H == 160 && P.Nfft == 512 && (P.pad_left == 0 || P.pad_left == 96) && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 4 &&

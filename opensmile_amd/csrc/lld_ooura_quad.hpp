@@ -197,7 +197,7 @@ __device__ __forceinline__ void oo_quad_inverse_real(float2 *z, const OouraTab &
 // cAcf on that input: lags j + 16 it, it < 16, of the lane's row to out[it] (registers)
 __device__ __forceinline__ void oo_quad_irfft_even_real(float2 *z, const OouraTab &T, float (&out)[16], float inv_norm, bool take_abs,
                                                         int lane, const float (&P)[17]) {
-  constexpr int M = 256;
+  // (M = 256: the sizes below are written out)
   oo_quad_inverse_real(z, T, lane, P);
   oo_quad_inverse_outs(z, lane, out);
   // RN(a / b) for the pass's one divisor: y = RN(1 / b) by the division itself, then Markstein's sequence (see f0_div_by in
