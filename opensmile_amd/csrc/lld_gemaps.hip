@@ -705,19 +705,24 @@ __global__ void __launch_bounds__(64) lld_gemaps_formants(GemapsParams G) {
       if (im < 0) continue;
       const double f = fabs(atan2(im, re)) / spPi2;
       if ((f >= G.fm_min) && (f <= fHigh)) {
-        bc[n_found] = -log(sqrt(re * re + im * im)) / spPi;
-        fc[n_found] = f;
+        const double b = -log(sqrt(re * re + im * im)) / spPi;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (k == n_found) { bc[k] = b; fc[k] = f; }   // (compile-time indices: the arrays stay in registers)
         n_found++;
         if (n_found >= 5) break;
       }
     }
-    for (int i = n_found; i < 5; i++) { fc[i] = 0.0; bc[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) if (i >= n_found) { fc[i] = 0.0; bc[i] = 0.0; }
   }
-  int nz = 0;                                                                // ascending order, formantLpc.cpp:270-289
-  for (nz = 0; nz < 5; nz++) if (fc[nz] == 0.0) break;
-  for (int i = 0; i < nz; i++)
-    for (int j = i + 1; j < nz; j++)
-      if (fc[j] < fc[i]) {
+  int nz = 5;                                                                // ascending order, formantLpc.cpp:270-289
+#pragma unroll
+  for (int k = 4; k >= 0; --k) if (fc[k] == 0.0) nz = k;                      // the first zero
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = i + 1; j < 5; j++)
+      if (j < nz && fc[j] < fc[i]) {
         double t = fc[j]; fc[j] = fc[i]; fc[i] = t;
         t = bc[j]; bc[j] = bc[i]; bc[i] = t;
       }
