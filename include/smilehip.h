@@ -481,6 +481,13 @@ int  smilehip_free(smilehip_context *ctx, void *d_ptr);
 int  smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream);
 int  smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream);
 int  smilehip_stream_synchronize(smilehip_context *ctx, void *stream);
+/* The same copies for `rows` rows of `width_bytes` bytes with a row pitch on either side: a block of frames of a dataMemory level
+ * (cMatrix::data, [frames x N] floats: src/core/dataMemoryLevel.cpp:1530-1582 setMatrix / :1651-1740 getMatrix) against a device
+ * block of another width. What the plugin's block-per-tick overrides move per tick (one call per level instead of one per frame). */
+int  smilehip_copy_to_device_2d(smilehip_context *ctx, void *d_dst, uint64_t d_pitch, const void *h_src, uint64_t h_pitch,
+                                uint64_t width_bytes, uint64_t rows, void *stream);
+int  smilehip_copy_to_host_2d(smilehip_context *ctx, void *h_dst, uint64_t h_pitch, const void *d_src, uint64_t d_pitch,
+                              uint64_t width_bytes, uint64_t rows, void *stream);
 /* Page-locked host memory for the staging buffers of a file-to-file host (the copies above run at the link's rate only from
  * such memory; what cWaveSource's read buffer and the sinks' write buffers are to the reference: src/iocore/waveSource.cpp:240-294,
  * src/iocore/htkSink.cpp:183-202). */
@@ -647,6 +654,12 @@ int smilehip_pitchacf_zcr_frames(smilehip_context *ctx, const float *d_src, int6
 #define SMILEHIP_MZCR_DC 16
 int smilehip_mzcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames, int32_t flags,
                          float *d_dst, int64_t ld_dst, void *stream);
+/* R1: the framing cWinToVecProcessor::myTick + cFramer::doProcess do one frame per tick (src/core/winToVecProcessor.cpp:983
+ * getNextMatrix with step / length from setupSequentialMatrixReading, :1037-1052 the row copy; src/dspcore/framer.cpp doProcess),
+ * for n_frames frames of ONE channel at once: d_dst[f * ld_dst + i] = d_samples[f * frame_step + i], i < frame_size. d_samples holds
+ * (n_frames - 1) * frame_step + frame_size floats. */
+int smilehip_frame_rows(smilehip_context *ctx, const float *d_samples, int64_t frame_size, int64_t frame_step, int64_t n_frames,
+                        float *d_dst, int64_t ld_dst, void *stream);
 /* R2: cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107) */
 int smilehip_preemphasis_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, float *d_dst,
                                 int64_t ld_dst, int64_t n_frames, int64_t N, float k, int de, void *stream);
@@ -694,6 +707,10 @@ int smilehip_pitchacf_frames(smilehip_context *ctx, const float *d_src, int64_t 
  * first frame, carries the contour across calls; d_out4: F0 (contour), F0raw, F0env, 0. */
 int smilehip_pitchacf_contour_step(smilehip_context *ctx, const double *d_voicing, const int32_t *d_max_idx, double t_samp,
                                    double voicing_cutoff, float *d_state, float *d_out4, void *stream);
+/* The same for n_frames consecutive frames of the stream in one call (a block tick of the plugin): d_voicing / d_max_idx hold
+ * n_frames values, d_out4 n_frames rows of four. */
+int smilehip_pitchacf_contour_frames(smilehip_context *ctx, const double *d_voicing, const int32_t *d_max_idx, double t_samp,
+                                     double voicing_cutoff, float *d_state, float *d_out4, int64_t n_frames, void *stream);
 /* R11: cSpectral::processVector with ComParE_2016's option set (spectral.cpp:586-1560; bands 250-650 and
  * 1000-4000, roll-off .25/.5/.75/.9, flux, centroid, entropy, variance, skewness, kurtosis, slope, sharpness,
  * harmonicity; squareInput = 1, freqRange 0-0, oldSlopeScale = 1): 15 values per frame, in the reference's
@@ -761,6 +778,15 @@ int smilehip_window_op_row_ex(smilehip_context *ctx, const float *d_x, float *d_
 #define SMILEHIP_DELTA_SEGMENTS 8
 int smilehip_delta_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int W, int flags, float *d_norm_io,
                           void *stream);
+/* R13 on a whole cWindowProcessor block at once (src/core/windowProcessor.cpp:171-236 walks the block's element rows one after the
+ * other; every output depends on its own window only, so the rows and frames of a block are independent): the matrices are
+ * FRAME-major as the data memory holds them (cMatrix::data[el + t * N]). d_x points at frame 0 of the block and is valid on frames
+ * [-max(W,1), n_t + W); d_y gets n_t frames. op 0: cDeltaRegression (deltaRegression.cpp:104-170) with delta_flags
+ * SMILEHIP_DELTA_RELATIVE | _HALFWAVE | _ABS (not _SEGMENTS: its divisor is carried from value to value in processing order, a
+ * block has no such order) and W >= 0; op 1: cContourSmoother (contourSmoother.cpp:106-114), op 2: with noZeroSma (:91-104), W >= 1.
+ * Same expressions as the row operators above: same bits. */
+int smilehip_window_op_block(smilehip_context *ctx, const float *d_x, int64_t ld_x, float *d_y, int64_t ld_y, int64_t n_t,
+                             int32_t n_cols, int op, int W, int delta_flags, void *stream);
 /* ---- GeMAPS / eGeMAPS components, per component, on an eGeMAPS plan (smilehip_config_egemapsv02: 16 kHz, 20 ms Hamming frames
  * -> 512-point spectrum; 60 ms frames -> 1024-point spectrum). Rows in, rows out, like the operators above. */
 /* cSpectral::processVector (src/lldcore/spectral.cpp:586-1254) with the GeMAPS option sets -- squareInput = 1, useLogSpectrum = 1,

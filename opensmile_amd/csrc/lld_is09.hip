@@ -576,6 +576,30 @@ __global__ void __launch_bounds__(64) lld_pitch_contour_step(const double *voici
   out4[3] = 0.0f;
   *state = S;
 }
+// ... and the frames of one stream that a block tick of the plugin hands over at once: the same step, frame after frame, in one launch
+__global__ void __launch_bounds__(64) lld_pitch_contour_frames(const double *voicing, const int32_t *max_idx, double Tsamp, double cutoff,
+                                                               PitchContour *state, float *out4, int64_t n_frames) {
+  if (threadIdx.x != 0) return;
+  PitchContour S = *state;
+  for (int64_t t = 0; t < n_frames; ++t) {
+    const int idx = max_idx[t];
+    float raw = 0.0f;
+    if (idx > 0) raw = 1.0f / ((float)idx * (float)Tsamp);
+    const float p = (voicing[t] < cutoff) ? 0.0f : raw;
+    out4[4 * t + 0] = pitch_contour_step(S, p);
+    out4[4 * t + 1] = raw;
+    out4[4 * t + 2] = S.env;
+    out4[4 * t + 3] = 0.0f;
+  }
+  *state = S;
+}
+hipError_t launch_pitch_contour_frames(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
+                                       float *d_out4, int64_t n_frames, hipStream_t s) {
+  if (n_frames > 0)
+    hipLaunchKernelGGL(lld_pitch_contour_frames, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
+                       reinterpret_cast<PitchContour *>(d_state), d_out4, n_frames);
+  return hipGetLastError();
+}
 hipError_t launch_pitch_contour_step(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
                                      float *d_out4, hipStream_t s) {
   hipLaunchKernelGGL(lld_pitch_contour_step, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,

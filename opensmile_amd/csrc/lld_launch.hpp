@@ -54,6 +54,8 @@ hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d
                          float *d_out, int64_t ld_out, int col_sma, int col_de, hipStream_t s);
 hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s);
 // cPitchACF's F0 contour for one stream, a frame per launch (lld_pitch_contour.hpp); d_state: 8 words, zeroed before the first frame
+hipError_t launch_pitch_contour_frames(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
+                                       float *d_out4, int64_t n_frames, hipStream_t s);
 hipError_t launch_pitch_contour_step(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
                                      float *d_out4, hipStream_t s);
 hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, const int *fam_want, hipStream_t s);

@@ -204,6 +204,48 @@ __global__ void k_delta_op_seq(const float *x, float *y, int64_t nT, int W, floa
   }
 }
 
+// The same three window processors on a whole block, frame-major (x[(n + i) * ldx + c]): one thread per (frame, element). Identical
+// expressions to k_window_op / k_window_op_seq (kind 2) / k_delta_op, value for value.
+__global__ void k_window_op_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t nT, int nC, int op, int W, float norm,
+                                  int flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nT * nC) return;
+  const int64_t n = i / nC;
+  const int c = (int)(i - n * nC);
+  const float *xc = x + c;
+  float out;
+  if (op == 0) {
+    float v;
+    if (W > 0) {
+      float num = 0.0f;
+      for (int k = 1; k <= W; ++k) num += (float)k * delta_of(xc[(n - k) * ldx], xc[(n + k) * ldx], flags & 1);
+      v = num / norm;
+    } else {
+      v = delta_of(xc[(n - 1) * ldx], xc[n * ldx], flags & 1);
+    }
+    out = delta_post(v, flags);
+  } else if (op == 1) {
+    float v = xc[n * ldx];
+    for (int w = 1; w <= W; ++w) { v += xc[(n - w) * ldx]; v += xc[(n + w) * ldx]; }
+    out = v / (float)(2 * W + 1);
+  } else {
+    const float x0 = xc[n * ldx];
+    if (x0 != 0.0f) {
+      long N = 1;
+      float v = x0;
+      for (int w = 1; w <= W; ++w) {
+        const float a = xc[(n - w) * ldx], b = xc[(n + w) * ldx];
+        if (a != 0.0f) { v += a; N++; }
+        if (b != 0.0f) { v += b; N++; }
+      }
+      out = v / (float)N;
+    } else {
+      out = 0.0f;
+    }
+  }
+  y[n * ldy + c] = out;
+}
+
 // R11 cSpectral::processVector, ComParE option set: the frames of one stream in order (the flux needs the
 // previous frame's magnitudes; `state` carries them across calls). One workgroup, K = 257.
 __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds, float *state, int first, float *dst,
@@ -409,6 +451,12 @@ hipError_t stage_delta_op(const float *x, float *y, int64_t nT, int W, float nor
   if (nT <= 0) return hipSuccess;
   if (flags & 8) hipLaunchKernelGGL(k_delta_op_seq, dim3(1), dim3(64), 0, s, x, y, nT, W, d_norm_io, flags);
   else hipLaunchKernelGGL(k_delta_op, dim3(nblk2(nT, 256)), dim3(256), 0, s, x, y, nT, W, norm, flags);
+  return hipGetLastError();
+}
+hipError_t stage_window_op_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t nT, int nC, int op, int W, float norm,
+                                 int flags, hipStream_t s) {
+  if (nT > 0 && nC > 0)
+    hipLaunchKernelGGL(k_window_op_block, dim3(nblk2(nT * nC, 256)), dim3(256), 0, s, x, ldx, y, ldy, nT, nC, op, W, norm, flags);
   return hipGetLastError();
 }
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s) {

@@ -15,6 +15,14 @@ __global__ void k_pcm16_to_float(const int16_t *pcm, int64_t n, float *out) {
   if (i < n) out[i] = pcm16_to_float(pcm[i]);
 }
 
+// cWinToVecProcessor::myTick + cFramer::doProcess (winToVecProcessor.cpp:983, :1037-1052; framer.cpp): frame f = samples [f * step, f * step + N)
+__global__ void k_frame_rows(const float *samples, int64_t N, int64_t step, int64_t nF, float *dst, int64_t ldd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nF * N) return;
+  const int64_t f = i / N, n = i - f * N;
+  dst[f * ldd + n] = samples[f * step + n];
+}
+
 // cVectorPreemphasis::processVector (vectorPreemphasis.cpp:89-107)
 __global__ void k_preemphasis(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N,
                               float k, float omk, int de) {
@@ -246,6 +254,10 @@ hipError_t stage_pcm_convert(const void *buf, int n_bps, int n_bits, int n_chan,
 hipError_t stage_pcm_convert_float(const float *buf, int n_chan, int mixdown, int64_t n, float *out, hipStream_t s) {
   const int64_t work = mixdown ? n : n * n_chan;
   if (work > 0) hipLaunchKernelGGL(k_pcm_convert_float, dim3(nblk(work, 256)), dim3(256), 0, s, buf, n_chan, mixdown, n, out);
+  return hipGetLastError();
+}
+hipError_t stage_frame_rows(const float *samples, int64_t N, int64_t step, int64_t nF, float *dst, int64_t ldd, hipStream_t s) {
+  if (nF * N > 0) hipLaunchKernelGGL(k_frame_rows, dim3(nblk(nF * N, 256)), dim3(256), 0, s, samples, N, step, nF, dst, ldd);
   return hipGetLastError();
 }
 hipError_t stage_preemph(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int64_t N, float k,

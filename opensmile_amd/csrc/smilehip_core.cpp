@@ -71,6 +71,30 @@ extern "C" int smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const v
   if (bytes) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return SMILEHIP_OK;
 }
+// rows x width_bytes between a host matrix and a device matrix with their own row pitches (one level of the data memory is
+// [frames x N] floats; a field of it, or a compact device block, has another pitch)
+extern "C" int smilehip_copy_to_device_2d(smilehip_context *ctx, void *d_dst, uint64_t d_pitch, const void *h_src, uint64_t h_pitch,
+                                          uint64_t width_bytes, uint64_t rows, void *stream) {
+  if (!ctx || d_pitch < width_bytes || h_pitch < width_bytes || (rows && width_bytes && (!d_dst || !h_src)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_device_2d: bad argument");
+  if (!rows || !width_bytes) return SMILEHIP_OK;
+  if (d_pitch == width_bytes && h_pitch == width_bytes)
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, width_bytes * rows, hipMemcpyHostToDevice, (hipStream_t)stream));
+  else
+    HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, width_bytes, rows, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_copy_to_host_2d(smilehip_context *ctx, void *h_dst, uint64_t h_pitch, const void *d_src, uint64_t d_pitch,
+                                        uint64_t width_bytes, uint64_t rows, void *stream) {
+  if (!ctx || d_pitch < width_bytes || h_pitch < width_bytes || (rows && width_bytes && (!h_dst || !d_src)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_copy_to_host_2d: bad argument");
+  if (!rows || !width_bytes) return SMILEHIP_OK;
+  if (d_pitch == width_bytes && h_pitch == width_bytes)
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, width_bytes * rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  else
+    HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
 extern "C" int smilehip_alloc_host(smilehip_context *ctx, uint64_t bytes, void **h_ptr) {
   if (!ctx || !h_ptr) return fail(SMILEHIP_ERR_INVALID, "smilehip_alloc_host: null argument");
   HIP_TRY(hipSetDevice(ctx->device));

@@ -224,6 +224,13 @@ extern "C" int smilehip_pitchacf_contour_step(smilehip_context *ctx, const doubl
   STAGE_RET(launch_pitch_contour_step(d_voicing, d_max_idx, t_samp, voicing_cutoff, d_state, d_out4, (hipStream_t)stream), "pitchacf contour");
 }
 
+extern "C" int smilehip_pitchacf_contour_frames(smilehip_context *ctx, const double *d_voicing, const int32_t *d_max_idx, double t_samp,
+                                                double voicing_cutoff, float *d_state, float *d_out4, int64_t n_frames, void *stream) {
+  if (!ctx || n_frames < 0 || !d_voicing || !d_max_idx || !d_state || !d_out4 || !(t_samp > 0.0))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_pitchacf_contour_frames: bad argument");
+  STAGE_RET(launch_pitch_contour_frames(d_voicing, d_max_idx, t_samp, voicing_cutoff, d_state, d_out4, n_frames, (hipStream_t)stream), "pitchacf contour");
+}
+
 extern "C" int smilehip_spectral_frames(smilehip_plan *p, const float *d_mag, int64_t ld_src, float *d_state, int first,
                                         float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
   if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_frames: null plan");
@@ -295,6 +302,22 @@ extern "C" int smilehip_delta_op_row(smilehip_context *ctx, const float *d_x, fl
   if (!ctx || n_t < 0 || W < 0 || W > 64 || (flags & ~15) || ((flags & 8) && W > 0 && !d_norm_io) || (n_t > 0 && (!d_x || !d_y)))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_op_row: bad argument (deltawin 0 .. 64, flags 1 | 2 | 4 | 8, d_norm_io with onlyInSegments)");
   STAGE_RET(stage_delta_op(d_x, d_y, n_t, W, W > 0 ? delta_norm(W) : 1.0f, flags, d_norm_io, (hipStream_t)stream), "delta_op");
+}
+
+extern "C" int smilehip_window_op_block(smilehip_context *ctx, const float *d_x, int64_t ld_x, float *d_y, int64_t ld_y, int64_t n_t,
+                                        int32_t n_cols, int op, int W, int delta_flags, void *stream) {
+  if (!ctx || n_t < 0 || n_cols < 1 || ld_x < n_cols || ld_y < n_cols || op < 0 || op > 2 || W < (op == 0 ? 0 : 1) || W > 64 ||
+      (delta_flags & ~7) || (n_t > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_window_op_block: bad argument (op 0 | 1 | 2, W <= 64, delta flags 1 | 2 | 4)");
+  STAGE_RET(stage_window_op_block(d_x, ld_x, d_y, ld_y, n_t, n_cols, op, W, (op == 0 && W > 0) ? delta_norm(W) : 1.0f,
+                                  op == 0 ? delta_flags : 0, (hipStream_t)stream), "window_op_block");
+}
+
+extern "C" int smilehip_frame_rows(smilehip_context *ctx, const float *d_samples, int64_t frame_size, int64_t frame_step, int64_t n_frames,
+                                   float *d_dst, int64_t ld_dst, void *stream) {
+  if (!ctx || frame_size < 1 || frame_step < 1 || n_frames < 0 || ld_dst < frame_size || (n_frames > 0 && (!d_samples || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_frame_rows: bad argument");
+  STAGE_RET(stage_frame_rows(d_samples, frame_size, frame_step, n_frames, d_dst, ld_dst, (hipStream_t)stream), "frame_rows");
 }
 
 extern "C" int smilehip_fftmag_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,

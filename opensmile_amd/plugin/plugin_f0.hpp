@@ -32,7 +32,7 @@ static smilehip_plan *f0_component_plan(long K, double frame_size_sec, double mi
 // cSpecScale::processVector (src/dsp/specScale.cpp:305-357) for the option set the F0 chains use (octave target scale,
 // spline interpolation, minF 25, maxF -1, nPointsTarget 0, smoothing + enhancement + auditory weighting); anything else
 // stays on the reference's CPU code. Names, frequency-axis info and the level meta data cPitchShs reads are inherited.
-class cHipSpecScale : public cSpecScale {
+class cHipSpecScale : public BlockVP<cSpecScale> {
   FrameIO io_;
   bool cpu_warned_ = false;
   smilehip_plan *pl_ = nullptr;
@@ -55,13 +55,13 @@ class cHipSpecScale : public cSpecScale {
     if (!usable_) { HIP_FALLTHROUGH(15, "cSpecScale: only the octave (log2) target scale from a linear source by spline interpolation, minF > 0, maxF -1, on spectra of 512 .. 4096 points is built"); return cSpecScale::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_specscale_frames(pl_, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[15]++;
+    g_frames[15] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipSpecScale(const char *n) : cSpecScale(n) {}
+  explicit cHipSpecScale(const char *n) : BlockVP<cSpecScale>(n) {}
   ~cHipSpecScale() override { if (pl_) smilehip_plan_destroy(pl_); }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipSpecScale(n);
@@ -72,7 +72,7 @@ class cHipSpecScale : public cSpecScale {
 
 // cPitchBase::processVector around cPitchShs::pitchDetect (src/lldcore/pitchBase.cpp:187-310, src/lld/pitchShs.cpp:214-347)
 // for six candidates with scores + voicing, F0raw + voicingClip, greedyPeakAlgo, no octave correction / lfCut / SHS dump.
-class cHipPitchShs : public cPitchShs {
+class cHipPitchShs : public BlockVP<cPitchShs> {
   FrameIO io_;
   bool cpu_warned_ = false;
   smilehip_plan *pl_ = nullptr;
@@ -103,23 +103,24 @@ class cHipPitchShs : public cPitchShs {
     if (!usable_) { HIP_FALLTHROUGH(16, "cPitchShs: only up to six candidates with scores and voicing (F0raw / voicingClip optional), no octaveCorrection / lfCut are built"); return cPitchShs::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 21);
     io_.up(src, Nsrc);
-    check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, 1, nullptr));
+    check(smilehip_pitchshs_frames(pl_, io_.d_in, Nsrc, io_.d_out, 21, g_blk.n, nullptr));
     if (raw_ && clip_ && nc_ == 6) io_.down(dst, 21);
     else {                                                  // [nCandidates | F0Cand | candVoicing | candScores] (+ F0raw) (+ voicingClip)
-      float v[21];                                          // (the device rows keep six slots per field)
-      io_.down(v, 21);
-      long n = 0;
-      dst[n++] = v[0];
-      for (int f = 0; f < 3; ++f)
-        for (int c = 0; c < nc_; ++c) dst[n++] = v[1 + 6 * f + c];
-      if (raw_) dst[n++] = v[19];
-      if (clip_) dst[n++] = v[20];
+      const float *v = io_.down_rows();                     // (the device rows keep six slots per field)
+      for (long fr = 0; fr < g_blk.n; ++fr, v += 21, dst += g_blk.ld_dst) {
+        long n = 0;
+        dst[n++] = v[0];
+        for (int f = 0; f < 3; ++f)
+          for (int c = 0; c < nc_; ++c) dst[n++] = v[1 + 6 * f + c];
+        if (raw_) dst[n++] = v[19];
+        if (clip_) dst[n++] = v[20];
+      }
     }
-    g_frames[16]++;
+    g_frames[16] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipPitchShs(const char *n) : cPitchShs(n) {}
+  explicit cHipPitchShs(const char *n) : BlockVP<cPitchShs>(n) {}
   ~cHipPitchShs() override { if (pl_) smilehip_plan_destroy(pl_); }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPitchShs(n);

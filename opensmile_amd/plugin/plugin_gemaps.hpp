@@ -1,7 +1,7 @@
 // libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
 // one translation unit: the parts share the state of plugin_shared.hpp): SURVEY 8(f) rank 3: cSpecResample, cLpc, cFormantLpc, cHarmonics, cPitchJitter
 // cSpecResample::processVector (src/dsp/specResample.cpp:175-185) for [gemapsv01b_resampLpc]
-class cHipSpecResample : public cSpecResample {
+class cHipSpecResample : public BlockVP<cSpecResample> {
   FrameIO io_;
   DevBytes cos_, sin_;
   bool cpu_warned_ = false;
@@ -32,15 +32,15 @@ class cHipSpecResample : public cSpecResample {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    if (usable_ == 1) check(smilehip_specresample_frames(gemaps_plan(rate_), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    if (usable_ == 1) check(smilehip_specresample_frames(gemaps_plan(rate_), io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     else check(smilehip_specresample_table_frames(context(), io_.d_in, Nsrc, Nsrc, Ndst, dftWork->kMax, (const float *)cos_.d,
-                                                  (const float *)sin_.d, io_.d_out, Ndst, 1, nullptr));
+                                                  (const float *)sin_.d, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[17]++;
+    g_frames[17] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipSpecResample(const char *n) : cSpecResample(n) {}
+  explicit cHipSpecResample(const char *n) : BlockVP<cSpecResample>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipSpecResample(n);
     c->setComponentInfo(scname, sdescription);
@@ -50,7 +50,7 @@ class cHipSpecResample : public cSpecResample {
 
 // cLpc::processVector (src/lld/lpc.cpp:171-213) with method = acf, saveLPCoeff only: p = 11 on 220 samples through the eGeMAPS plan,
 // any other frame length and order p <= 32 through smilehip_lpc_acf_frames
-class cHipLpc : public cLpc {
+class cHipLpc : public BlockVP<cLpc> {
   FrameIO io_;
   bool cpu_warned_ = false;
   int usable_ = -1;
@@ -69,14 +69,14 @@ class cHipLpc : public cLpc {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    if (usable_ == 1) check(smilehip_lpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
-    else check(smilehip_lpc_acf_frames(context(), io_.d_in, Nsrc, Nsrc, (int32_t)p, io_.d_out, Ndst, 1, nullptr));
+    if (usable_ == 1) check(smilehip_lpc_frames(gemaps_plan(), io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
+    else check(smilehip_lpc_acf_frames(context(), io_.d_in, Nsrc, Nsrc, (int32_t)p, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[18]++;
+    g_frames[18] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipLpc(const char *n) : cLpc(n) {}
+  explicit cHipLpc(const char *n) : BlockVP<cLpc>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipLpc(n);
     c->setComponentInfo(scname, sdescription);
@@ -85,7 +85,7 @@ class cHipLpc : public cLpc {
 };
 
 // cFormantLpc::processVector (src/lld/formantLpc.cpp:192-290): 5 formants + bandwidths from 11 LP coefficients at 11 kHz
-class cHipFormantLpc : public cFormantLpc {
+class cHipFormantLpc : public BlockVP<cFormantLpc> {
   FrameIO io_;
   bool cpu_warned_ = false;
   int usable_ = -1;
@@ -106,13 +106,13 @@ class cHipFormantLpc : public cFormantLpc {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_formantlpc_frames(gemaps_plan(0, (long)getDouble("maxF")), io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_formantlpc_frames(gemaps_plan(0, (long)getDouble("maxF")), io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[19]++;
+    g_frames[19] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipFormantLpc(const char *n) : cFormantLpc(n) {}
+  explicit cHipFormantLpc(const char *n) : BlockVP<cFormantLpc>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipFormantLpc(n);
     c->setComponentInfo(scname, sdescription);
@@ -123,12 +123,13 @@ class cHipFormantLpc : public cFormantLpc {
 // cHarmonics::processVector (src/lld/harmonics.cpp:743-1031) with [gemapsv01b_harmonics]'s options: the input vector holds the F0
 // element, the formant frequency / bandwidth fields and the 513-bin magnitude field; the positions are looked up by name as the
 // reference does in setupNewNames (:226-307).
-class cHipHarmonics : public cHarmonics {
+class cHipHarmonics : public BlockVP<cHarmonics> {
   FrameIO io_;
   bool cpu_warned_ = false;
   int usable_ = -1;                                        // 1: GeMAPS' six outputs; 2: the ACF harmonics-to-noise ratio alone
   long iF0_ = -1, iSpec_ = -1, iFf_ = -1, iFb_ = -1, nSpec_ = 0, nFf_ = 0, nFb_ = 0, rate_ = 0;
   DevBytes fm_, f0_;
+  std::vector<float> fmh_, f0h_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE(1);
@@ -187,22 +188,29 @@ class cHipHarmonics : public cHarmonics {
     }
     io_.ensure(nSpec_, 6);
     io_.up(src + iSpec_, nSpec_);
-    float fm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (usable_ == 1) {
-      memcpy(fm, src + iFf_, sizeof(float) * 5);
-      memcpy(fm + 5, src + iFb_, sizeof(float) * 5);
+    // the F0 element and the formant fields of the call's frames (1, or the frames of a block tick -- plugin_block.hpp)
+    const long nf = g_blk.n;
+    fmh_.assign((size_t)nf * 10, 0.0f);
+    f0h_.resize((size_t)nf);
+    for (long f = 0; f < nf; ++f) {
+      const FLOAT_DMEM *row = src + (size_t)f * (size_t)g_blk.ld_src;
+      if (usable_ == 1) {
+        memcpy(&fmh_[(size_t)f * 10], row + iFf_, sizeof(float) * 5);
+        memcpy(&fmh_[(size_t)f * 10 + 5], row + iFb_, sizeof(float) * 5);
+      }
+      f0h_[(size_t)f] = row[iF0_];
     }
-    float *d_fm = (float *)fm_.ensure(sizeof(float) * 10), *d_f0 = (float *)f0_.ensure(sizeof(float));
-    if (smilehip_copy_to_device(context(), d_fm, fm, sizeof(fm), nullptr) ||
-        smilehip_copy_to_device(context(), d_f0, src + iF0_, sizeof(float), nullptr))
+    float *d_fm = (float *)fm_.ensure(sizeof(float) * 10 * (uint64_t)nf), *d_f0 = (float *)f0_.ensure(sizeof(float) * (uint64_t)nf);
+    if (smilehip_copy_to_device(context(), d_fm, fmh_.data(), sizeof(float) * fmh_.size(), nullptr) ||
+        smilehip_copy_to_device(context(), d_f0, f0h_.data(), sizeof(float) * f0h_.size(), nullptr))
       COMP_ERR("libsmilehip: %s", smilehip_last_error());
-    check(smilehip_harmonics_frames(usable_ == 2 ? gemaps_plan(rate_) : gemaps_plan(), d_f0, d_fm, 10, io_.d_in, nSpec_, io_.d_out, 6, 1, nullptr));
+    check(smilehip_harmonics_frames(usable_ == 2 ? gemaps_plan(rate_) : gemaps_plan(), d_f0, d_fm, 10, io_.d_in, nSpec_, io_.d_out, 6, nf, nullptr));
     io_.down(dst, usable_ == 2 ? 1 : 6);
-    g_frames[20]++;
+    g_frames[20] += nf;
     return 1;
   }
  public:
-  explicit cHipHarmonics(const char *n) : cHarmonics(n) {}
+  explicit cHipHarmonics(const char *n) : BlockVP<cHarmonics>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipHarmonics(n);
     c->setComponentInfo(scname, sdescription);

@@ -2,7 +2,7 @@
 // one translation unit: the parts share the state of plugin_shared.hpp): the components of IS10_paraling / IS11_speaker_state / IS12_speaker_trait: cIntensity, cLsp, cPitchSmoother, cVectorOperation
 // ---- the components the other INTERSPEECH sets of config/is09-13 add (IS10_paraling, IS11_speaker_state, IS12_speaker_trait) ----
 // cIntensity::processVector (src/lldcore/intensity.cpp:125-145)
-class cHipIntensity : public cIntensity {
+class cHipIntensity : public BlockVP<cIntensity> {
   FrameIO io_;
   bool cpu_warned_ = false;
  protected:
@@ -15,13 +15,13 @@ class cHipIntensity : public cIntensity {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_intensity_frames(context(), io_.d_in, Nsrc, Nsrc, flags, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_intensity_frames(context(), io_.d_in, Nsrc, Nsrc, flags, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[24]++;
+    g_frames[24] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipIntensity(const char *n) : cIntensity(n) {}
+  explicit cHipIntensity(const char *n) : BlockVP<cIntensity>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipIntensity(n);
     c->setComponentInfo(scname, sdescription);
@@ -30,7 +30,7 @@ class cHipIntensity : public cIntensity {
 };
 
 // cLsp::processVector (src/lld/lsp.cpp:289-312)
-class cHipLsp : public cLsp {
+class cHipLsp : public BlockVP<cLsp> {
   FrameIO io_;
   bool cpu_warned_ = false;
  protected:
@@ -43,13 +43,13 @@ class cHipLsp : public cLsp {
     }
     io_.ensure(nLpc, nLpc);
     io_.up(src + lpcIdx, nLpc);
-    check(smilehip_lsp_frames(context(), io_.d_in, nLpc, (int32_t)nLpc, io_.d_out, nLpc, 1, nullptr));
+    check(smilehip_lsp_frames(context(), io_.d_in, nLpc, (int32_t)nLpc, io_.d_out, nLpc, g_blk.n, nullptr));
     io_.down(dst, nLpc);
-    g_frames[25]++;
+    g_frames[25] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipLsp(const char *n) : cLsp(n) {}
+  explicit cHipLsp(const char *n) : BlockVP<cLsp>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipLsp(n);
     c->setComponentInfo(scname, sdescription);
@@ -113,7 +113,7 @@ class cHipPitchSmoother : public cPitchSmoother {
 };
 
 // cVectorOperation::processVector, the element-wise operations (src/other/vectorOperation.cpp:360-435, 508-527)
-class cHipVectorOperation : public cVectorOperation {
+class cHipVectorOperation : public BlockVP<cVectorOperation> {
   FrameIO io_;
   bool cpu_warned_ = false;
  protected:
@@ -143,13 +143,13 @@ class cHipVectorOperation : public cVectorOperation {
     if (n < 1 || Ndst < 1) return 0;
     io_.ensure(n, n);
     io_.up(src, n);
-    check(smilehip_vecop_frames(context(), op, param1, logfloor, io_.d_in, n, (int32_t)n, io_.d_out, n, 1, nullptr));
+    check(smilehip_vecop_frames(context(), op, param1, logfloor, io_.d_in, n, (int32_t)n, io_.d_out, n, g_blk.n, nullptr));
     io_.down(dst, reduce ? 1 : n);
-    g_frames[27]++;
+    g_frames[27] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipVectorOperation(const char *n) : cVectorOperation(n) {}
+  explicit cHipVectorOperation(const char *n) : BlockVP<cVectorOperation>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipVectorOperation(n);
     c->setComponentInfo(scname, sdescription);

@@ -2,13 +2,14 @@
 // one translation unit: the parts share the state of plugin_shared.hpp): R9, R10, R12: cEnergy, cMZcr, cAcf, cPitchACF
 // R12  cEnergy::processVector  (src/lldcore/energy.cpp:152-185): the double-accumulated sum of
 // squares comes from the device, the rms / squared / log expressions are the reference's
-class cHipEnergy : public cEnergy {
+class cHipEnergy : public BlockVP<cEnergy> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
+  std::vector<double> sums_;
   int htk_ = 0, erms_ = 0, e2_ = 0, elog_ = 0;
   FLOAT_DMEM sRms_ = 1, sLog_ = 1, sSq_ = 1, bLog_ = 0, bRms_ = 0, bSq_ = 0;
   bool ready_ = false;
@@ -22,7 +23,7 @@ class cHipEnergy : public cEnergy {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
     }
-    return cEnergy::myTick(t);
+    return BlockVP<cEnergy>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
@@ -38,30 +39,35 @@ class cHipEnergy : public cEnergy {
     }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
-    double *d_d = (double *)res_.ensure(sizeof(double));
-    check(smilehip_sumsq_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_d, nullptr));
-    double d = 0.0;
-    res_.down(&d, sizeof(double));
+    const long nf = g_blk.n;                              // 1, or the frames of a block tick (plugin_block.hpp)
+    double *d_d = (double *)res_.ensure(sizeof(double) * (uint64_t)nf);
+    check(smilehip_sumsq_frames(context(), io_.d_in, Nsrc, Nsrc, nf, d_d, nullptr));
+    sums_.resize((size_t)nf);
+    res_.down(sums_.data(), sizeof(double) * (uint64_t)nf);
     int n = 0;
-    if (erms_) dst[n++] = (FLOAT_DMEM)sqrt(d / (FLOAT_DMEM)Nsrc) * sRms_ + bRms_;
-    if (e2_) dst[n++] = (FLOAT_DMEM)(d / (double)Nsrc) * sSq_ + bSq_;
-    if (elog_) {
-      const double minE = 8.674676e-019;
-      if (!htk_) {
-        d /= (FLOAT_DMEM)Nsrc;
-        if (d < minE) d = minE;
-        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
-      } else {
-        d *= 32767.0 * 32767.0;
-        if (d <= 1.0) d = 1.0;
-        dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+    for (long f = 0; f < nf; ++f, dst += g_blk.ld_dst) {
+      double d = sums_[(size_t)f];
+      n = 0;
+      if (erms_) dst[n++] = (FLOAT_DMEM)sqrt(d / (FLOAT_DMEM)Nsrc) * sRms_ + bRms_;
+      if (e2_) dst[n++] = (FLOAT_DMEM)(d / (double)Nsrc) * sSq_ + bSq_;
+      if (elog_) {
+        const double minE = 8.674676e-019;
+        if (!htk_) {
+          d /= (FLOAT_DMEM)Nsrc;
+          if (d < minE) d = minE;
+          dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+        } else {
+          d *= 32767.0 * 32767.0;
+          if (d <= 1.0) d = 1.0;
+          dst[n++] = (FLOAT_DMEM)log(d) * sLog_ + bLog_;
+        }
       }
     }
-    g_frames[6]++;
+    g_frames[6] += nf;
     return n;
   }
  public:
-  explicit cHipEnergy(const char *n) : cEnergy(n) {}
+  explicit cHipEnergy(const char *n) : BlockVP<cEnergy>(n) {}
   ~cHipEnergy() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipEnergy(n);
@@ -93,7 +99,7 @@ class cHipWaveSource : public cWaveSource {
 // cVectorConcat (src/other/vectorConcat.cpp) as the last component of a fused cepstral chain: the level the sinks read gets the
 // batch's finished rows (static | delta | acceleration, mean-normalised where the file says so) at the tick level. Anywhere
 // else it is the reference's component, untouched.
-class cHipVectorConcat : public cVectorConcat {
+class cHipVectorConcat : public BlockVP<cVectorConcat> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
   long fnext_ = 0;
@@ -109,10 +115,22 @@ class cHipVectorConcat : public cVectorConcat {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
     }
-    return cVectorConcat::myTick(t);
+    return BlockVP<cVectorConcat>::myTick(t);
+  }
+  // cVectorConcat::processVector (src/other/vectorConcat.cpp:48-53: the field's values copied to their place in the output vector) for
+  // the frames of the call -- one on the reference's ticks, every frame the input levels hold on a block tick (plugin_block.hpp);
+  // no arithmetic, the rows stay on the host
+  int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
+    const size_t w = sizeof(FLOAT_DMEM) * (size_t)(Ndst < Nsrc ? Ndst : Nsrc);
+    for (long f = 0; f < g_blk.n; ++f) {
+      const FLOAT_DMEM *a = src + (size_t)f * (size_t)g_blk.ld_src;
+      FLOAT_DMEM *b = dst + (size_t)f * (size_t)g_blk.ld_dst;
+      if (a != b) memcpy(b, a, w);
+    }
+    return 1;
   }
  public:
-  explicit cHipVectorConcat(const char *n) : cVectorConcat(n) {}
+  explicit cHipVectorConcat(const char *n) : BlockVP<cVectorConcat>(n) {}
   ~cHipVectorConcat() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipVectorConcat(n);
@@ -122,10 +140,11 @@ class cHipVectorConcat : public cVectorConcat {
 };
 
 // R12  cMZcr::processVector, zero-crossing rate  (src/lldcore/mzcr.cpp:109-150)
-class cHipMZcr : public cMZcr {
+class cHipMZcr : public BlockVP<cMZcr> {
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
+  std::vector<int32_t> counts_;
   int plain_ = -1, flags_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
@@ -140,26 +159,29 @@ class cHipMZcr : public cMZcr {
       const int n_out = ((flags_ & 1) ? 1 : 0) + ((flags_ & 2) ? 1 : 0) + ((flags_ & 4) ? 1 : 0) + ((flags_ & 8) ? 2 : 0) + ((flags_ & 16) ? 1 : 0);
       io_.ensure(Nsrc, n_out);
       io_.up(src, Nsrc);
-      check(smilehip_mzcr_frames(context(), io_.d_in, Nsrc, Nsrc, 1, flags_, io_.d_out, n_out, nullptr));
+      check(smilehip_mzcr_frames(context(), io_.d_in, Nsrc, Nsrc, g_blk.n, flags_, io_.d_out, n_out, nullptr));
       io_.down(dst, n_out);
-      g_frames[7]++;
+      g_frames[7] += g_blk.n;
       return n_out;
     }
     if (!plain_) { HIP_FALLTHROUGH(7, "cMZcr: no output selected, or a frame longer than 32768 samples"); return cMZcr::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
-    int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t));
-    check(smilehip_zcr_count_frames(context(), io_.d_in, Nsrc, Nsrc, 1, d_c, nullptr));
-    int32_t c = 0;
-    res_.down(&c, sizeof(c));
-    FLOAT_DMEM nzc = (FLOAT_DMEM)c;
-    nzc /= (FLOAT_DMEM)Nsrc;
-    dst[0] = nzc;
-    g_frames[7]++;
+    const long nf = g_blk.n;                              // 1, or the frames of a block tick (plugin_block.hpp)
+    int32_t *d_c = (int32_t *)res_.ensure(sizeof(int32_t) * (uint64_t)nf);
+    check(smilehip_zcr_count_frames(context(), io_.d_in, Nsrc, Nsrc, nf, d_c, nullptr));
+    counts_.resize((size_t)nf);
+    res_.down(counts_.data(), sizeof(int32_t) * (uint64_t)nf);
+    for (long f = 0; f < nf; ++f, dst += g_blk.ld_dst) {
+      FLOAT_DMEM nzc = (FLOAT_DMEM)counts_[(size_t)f];
+      nzc /= (FLOAT_DMEM)Nsrc;
+      dst[0] = nzc;
+    }
+    g_frames[7] += nf;
     return 1;
   }
  public:
-  explicit cHipMZcr(const char *n) : cMZcr(n) {}
+  explicit cHipMZcr(const char *n) : BlockVP<cMZcr>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipMZcr(n);
     c->setComponentInfo(scname, sdescription);
@@ -168,7 +190,7 @@ class cHipMZcr : public cMZcr {
 };
 
 // R9  cAcf::processVector, forward path  (src/dspcore/acf.cpp:249-349)
-class cHipAcf : public cAcf {
+class cHipAcf : public BlockVP<cAcf> {
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
@@ -194,13 +216,13 @@ class cHipAcf : public cAcf {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_acf_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, Ndst, 1, use_power_, cepstrum_, norm_, abs_ceps_, nullptr));
+    check(smilehip_acf_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, Ndst, g_blk.n, use_power_, cepstrum_, norm_, abs_ceps_, nullptr));
     io_.down(dst, Ndst);
-    g_frames[8]++;
+    g_frames[8] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipAcf(const char *n) : cAcf(n) {}
+  explicit cHipAcf(const char *n) : BlockVP<cAcf>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipAcf(n);
     c->setComponentInfo(scname, sdescription);
@@ -212,7 +234,7 @@ class cHipAcf : public cAcf {
 // cepstral peak (smilehip_pitchacf_frames), then F0, the voicing cut-off, the causal F0 contour and its envelope
 // (smilehip_pitchacf_contour_step -- the device function the batch chain runs, its state in device memory). The host side
 // only maps the harmonics-to-noise ratio of two ACF values it already holds onto the three HNR scales (:310-361).
-class cHipPitchACF : public cPitchACF {
+class cHipPitchACF : public BlockVP<cPitchACF> {
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
@@ -220,8 +242,7 @@ class cHipPitchACF : public cPitchACF {
   int plain_ = -1, voiceProb_ = 0, F0_ = 0, F0raw_ = 0, F0env_ = 0, HNR_ = 0, HNRdB_ = 0, linHNR_ = 0, voiceQual_ = 0;
   double maxPitch_ = 0.0, voicingCutoff_ = 0.0;
   float fsSec_ = -1.0f;
-  // device result block: voicing | peak index | ACF zero-crossing rate | F0, F0raw, F0env, 0 | contour state (8 words)
-  struct Result { double voicing; int32_t idx; int32_t pad; double acfZcr; float f0[4]; float state[8]; };
+  std::vector<unsigned char> host_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     FUSED_BIG_STAGE((int)Ndst);
@@ -240,24 +261,38 @@ class cHipPitchACF : public cPitchACF {
     if (N < 4 || 2 * N != Nsrc) { HIP_FALLTHROUGH(9, "cPitchACF: the input is not [acf | cepstrum] of equal, even size"); return cPitchACF::processVector(src, dst, Nsrc, Ndst, idxi); }
     io_.ensure(Nsrc, 1);
     io_.up(src, Nsrc);
-    unsigned char *r = (unsigned char *)res_.ensure(sizeof(Result));
-    if (!state_ready_) {                                 // a stream starts with an all-zero contour
-      const Result zero = {};
-      check(smilehip_copy_to_device(context(), r, &zero, sizeof(Result), nullptr));
+    // device results of the call's frames (1, or the frames of a block tick -- plugin_block.hpp): the contour state (8 words), then
+    // per frame the voicing probability, the peak index, the ACF zero-crossing rate, the four contour outputs
+    const long nf = g_blk.n;
+    const uint64_t o_v = 32, o_i = o_v + 8 * (uint64_t)nf, o_z = (o_i + 4 * (uint64_t)nf + 7) & ~(uint64_t)7, o_f = o_z + 8 * (uint64_t)nf,
+                   total = o_f + 16 * (uint64_t)nf;
+    if (!state_ready_ || total > res_.cap) {               // a stream starts with an all-zero contour; a larger block keeps the state
+      float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (state_ready_) res_.down(st, sizeof(st));
+      res_.ensure(total > 4096 ? total : 4096);
+      check(smilehip_copy_to_device(context(), res_.d, st, sizeof(st), nullptr));
+      check(smilehip_stream_synchronize(context(), nullptr));
       state_ready_ = true;
     }
+    unsigned char *r = (unsigned char *)res_.d;
     const double Tsamp = fsSec_ / (double)Nsrc;
-    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, voicing)),
-                                   (int32_t *)(r + offsetof(Result, idx)), nullptr));
-    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, 1, (double)fsSec_, maxPitch_, (double *)(r + offsetof(Result, acfZcr)), nullptr));
+    check(smilehip_pitchacf_frames(context(), io_.d_in, Nsrc, N, nf, (double)fsSec_, maxPitch_, (double *)(r + o_v), (int32_t *)(r + o_i), nullptr));
+    if (voiceQual_) check(smilehip_pitchacf_zcr_frames(context(), io_.d_in, Nsrc, N, nf, (double)fsSec_, maxPitch_, (double *)(r + o_z), nullptr));
     const bool contour = F0_ || F0env_ || F0raw_ || voiceQual_;
     if (contour)
-      check(smilehip_pitchacf_contour_step(context(), (const double *)(r + offsetof(Result, voicing)), (const int32_t *)(r + offsetof(Result, idx)),
-                                           Tsamp, voicingCutoff_, (float *)(r + offsetof(Result, state)), (float *)(r + offsetof(Result, f0)), nullptr));
-    Result h = {};
-    res_.down(&h, offsetof(Result, state));
-    const long peak = h.idx;
+      check(smilehip_pitchacf_contour_frames(context(), (const double *)(r + o_v), (const int32_t *)(r + o_i), Tsamp, voicingCutoff_, (float *)r,
+                                             (float *)(r + o_f), nf, nullptr));
+    host_.resize((size_t)(total - o_v));
+    check(smilehip_copy_to_host(context(), host_.data(), r + o_v, total - o_v, nullptr));
+    check(smilehip_stream_synchronize(context(), nullptr));
+    const double *h_v = (const double *)host_.data(), *h_z = (const double *)(host_.data() + (o_z - o_v));
+    const int32_t *h_i = (const int32_t *)(host_.data() + (o_i - o_v));
+    const float *h_f = (const float *)(host_.data() + (o_f - o_v));
     int n = 0;
+    for (long f = 0; f < nf; ++f, src += g_blk.ld_src, dst += g_blk.ld_dst) {
+    struct { double voicing; int32_t idx; double acfZcr; float f0[4]; } h = {h_v[f], h_i[f], voiceQual_ ? h_z[f] : 0.0, {h_f[4 * f], h_f[4 * f + 1], h_f[4 * f + 2], h_f[4 * f + 3]}};
+    const long peak = h.idx;
+    n = 0;
     if (voiceProb_) dst[n++] = (FLOAT_DMEM)h.voicing;
     if (HNR_ || HNRdB_ || linHNR_) {
       // harmonics-to-noise ratio acf[peak] / (acf[0] - acf[peak]), `pure` where the denominator vanishes. The difference is a
@@ -279,11 +314,12 @@ class cHipPitchACF : public cPitchACF {
       if (F0raw_) dst[n++] = h.f0[1];
       if (F0env_) dst[n++] = h.f0[2];
     }
-    g_frames[9]++;
+    }
+    g_frames[9] += nf;
     return n;
   }
  public:
-  explicit cHipPitchACF(const char *n) : cPitchACF(n) {}
+  explicit cHipPitchACF(const char *n) : BlockVP<cPitchACF>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPitchACF(n);
     c->setComponentInfo(scname, sdescription);

@@ -11,11 +11,12 @@ const char *const g_names[kNumOverrides] = {"cVectorPreemphasis", "cWindower", "
                                             "cPitchShs", "cSpecResample", "cLpc", "cFormantLpc", "cHarmonics", "cPitchSmootherViterbi", "cValbasedSelector", "cPitchJitter",
                                             "cIntensity", "cLsp", "cPitchSmoother", "cVectorOperation"};
 
-// An override whose option set the HIP path does not cover runs the reference's own code -- never silently: the instance
-// says so once (level-1 warning in the reference's log) and every such frame is counted (trace line "<type>.cpu <n>").
-// Round 3: that is opt-in. By default an option set that is not built is an ERROR of the component (COMP_ERR, like any
-// configuration the reference cannot run) -- "the plugin is loaded" then means "the frames were computed on the GPU";
-// SMILEHIP_PLUGIN_ALLOW_CPU=1 brings back the logged and counted fall-through.
+// An override whose option set the HIP path does not cover is an ERROR of the component (COMP_ERR, like any configuration the
+// reference cannot run): "the plugin is loaded" means "the frames were computed on the GPU". The shipped library has no other
+// behaviour. A DEVELOPMENT build (make DEV_CPU_FALLTHROUGH=1: -DSMILEHIP_DEV_CPU_FALLTHROUGH) can, with SMILEHIP_PLUGIN_ALLOW_CPU=1
+// in the environment, let such an instance run the reference's own code -- logged once (level-1 warning) and counted per frame
+// (trace line "<type>.cpu <n>") -- to find out what ELSE of a new configuration file is not built; it keeps the one-frame ticks.
+#ifdef SMILEHIP_DEV_CPU_FALLTHROUGH
 inline bool allow_cpu() {
   static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_ALLOW_CPU"); return (e && e[0] == '1') ? 1 : 0; }();
   return v != 0;
@@ -23,13 +24,21 @@ inline bool allow_cpu() {
 #define HIP_FALLTHROUGH(idx, why)                                                                                  \
   do {                                                                                                             \
     if (!allow_cpu())                                                                                              \
-      COMP_ERR("libsmilehip plugin: %s (set SMILEHIP_PLUGIN_ALLOW_CPU=1 to run this instance on the reference's CPU code)", why); \
+      COMP_ERR("libsmilehip plugin: %s (development build: SMILEHIP_PLUGIN_ALLOW_CPU=1 runs this instance on the reference's CPU code)", why); \
     if (!cpu_warned_) {                                                                                            \
       SMILE_IWRN(1, "libsmilehip plugin: %s -- this instance runs the reference's CPU code", why);                 \
       cpu_warned_ = true;                                                                                          \
     }                                                                                                              \
     g_cpu[idx]++;                                                                                                  \
   } while (0)
+#else
+inline bool allow_cpu() { return false; }
+#define HIP_FALLTHROUGH(idx, why)                                                                                  \
+  do {                                                                                                             \
+    (void)cpu_warned_;                                                                                             \
+    COMP_ERR("libsmilehip plugin: %s -- this option set is not built for the HIP path", why);                      \
+  } while (0)
+#endif
 
 smilehip_context *context() {
   if (!g_ctx) {
@@ -40,33 +49,105 @@ smilehip_context *context() {
   return g_ctx;
 }
 
-// device scratch for one frame in / one frame out
+// ---------------------------------------------------------------- block-per-tick state (plugin_block.hpp)
+// The reference moves ONE frame per component and tick (cVectorProcessor::myTick, src/core/vectorProcessor.cpp:290-394;
+// cWinToVecProcessor::myTick, src/core/winToVecProcessor.cpp:868-1098). The overrides take every frame their reader's level
+// holds in one tick: ONE getMatrix, one upload (none when the level's rows are still on the device), the component's operator on
+// n frames, one download, ONE setNextMatrix. While such a tick runs, g_blk tells the component's own processVector -- the same
+// code the per-frame path runs -- that its call stands for n frames: FrameIO sizes, uploads and downloads blocks.
+struct BlockCtx {
+  long n = 1;                            // frames the current processVector call stands for (1: the reference's own per-frame call)
+  long ld_src = 0, ld_dst = 0;           // row pitch (floats) of the host matrices the call's src / dst point into
+  const float *d_rows = nullptr;         // the reader level's rows of this block on the device ([n][ld_src]) when its writer left them there
+  int w_level = -1;                      // the writer's level and the index its first row of the block gets: where a device copy of
+  long w_start = 0;                      // the output is registered for the next component
+};
+BlockCtx g_blk;
+long g_block_ticks = 0, g_block_frames = 0, g_block_dev_rows = 0, g_framer_frames = 0;   // trace: block ticks, frames moved by them, frames whose upload was skipped
+
+// rows of a level that are still on the device (written by the override that filled the level, valid until that override's next tick)
+struct DevRows { const float *d = nullptr; long start = 0, n = 0, N = 0; };
+std::map<int, DevRows> g_dev_rows;        // by data-memory level index
+
+inline bool block_mode() {               // SMILEHIP_PLUGIN_BLOCK=0: every override on the reference's own one-frame ticks (the round-3 parity vehicle)
+  static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v != 0 && !allow_cpu();
+}
+inline long block_cap() {                // most frames one block tick takes
+  static const long v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK_MAX"); const long x = e ? atol(e) : 0; return x >= 2 ? x : 4096L; }();
+  return v;
+}
+
+// device scratch for the frames of one processVector call: one frame in / one frame out on the reference's ticks, g_blk.n of each
+// on a block tick
 struct FrameIO {
-  float *d_in = nullptr, *d_out = nullptr;
-  long cap_in = 0, cap_out = 0;
+  float *d_in = nullptr, *d_out = nullptr;               // what the kernels get
+  float *own_in = nullptr;
+  long cap_in = 0, cap_out = 0, w_in = 0, w_out = 0;
+  int dev_level = -1;                                    // the level whose DevRows entry points at d_out
+  void forget() { if (dev_level >= 0) { g_dev_rows.erase(dev_level); dev_level = -1; } }
   void ensure(long n_in, long n_out) {
-    if (n_in > cap_in) {
-      if (d_in) smilehip_free(context(), d_in);
-      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_in, (void **)&d_in)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
-      cap_in = n_in;
+    forget();                                            // d_out is about to be rewritten
+    w_in = n_in; w_out = n_out;
+    const long need_in = n_in * g_blk.n, need_out = n_out * g_blk.n;
+    if (need_in > cap_in) {
+      if (own_in) smilehip_free(context(), own_in);
+      own_in = nullptr;
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)need_in, (void **)&own_in)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_in = need_in;
     }
-    if (n_out > cap_out) {
+    if (need_out > cap_out) {
       if (d_out) smilehip_free(context(), d_out);
-      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)n_out, (void **)&d_out)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
-      cap_out = n_out;
+      d_out = nullptr;
+      if (smilehip_alloc(context(), sizeof(float) * (uint64_t)need_out, (void **)&d_out)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      cap_out = need_out;
     }
+    d_in = own_in;
   }
   void up(const FLOAT_DMEM *src, long n) {
-    if (smilehip_copy_to_device(context(), d_in, src, sizeof(float) * (uint64_t)n, nullptr)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
-  }
-  void down(FLOAT_DMEM *dst, long n) {
-    if (smilehip_copy_to_host(context(), dst, d_out, sizeof(float) * (uint64_t)n, nullptr) ||
-        smilehip_stream_synchronize(context(), nullptr))
+    if (g_blk.n == 1) {
+      if (smilehip_copy_to_device(context(), own_in, src, sizeof(float) * (uint64_t)n, nullptr)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      return;
+    }
+    if (g_blk.d_rows && n == g_blk.ld_src && n == w_in) {   // the field is the level's whole row and the rows never left the device
+      d_in = const_cast<float *>(g_blk.d_rows);
+      g_block_dev_rows += g_blk.n;
+      return;
+    }
+    if (smilehip_copy_to_device_2d(context(), own_in, sizeof(float) * (uint64_t)w_in, src, sizeof(float) * (uint64_t)g_blk.ld_src,
+                                   sizeof(float) * (uint64_t)n, (uint64_t)g_blk.n, nullptr))
       COMP_ERR("libsmilehip: %s", smilehip_last_error());
   }
+  // n floats of every frame's device row (pitch w_out) to the host rows at dst (pitch 1 frame / g_blk.ld_dst)
+  void down(FLOAT_DMEM *dst, long n) {
+    if (g_blk.n == 1) {
+      if (smilehip_copy_to_host(context(), dst, d_out, sizeof(float) * (uint64_t)n, nullptr) || smilehip_stream_synchronize(context(), nullptr))
+        COMP_ERR("libsmilehip: %s", smilehip_last_error());
+      return;
+    }
+    if (smilehip_copy_to_host_2d(context(), dst, sizeof(float) * (uint64_t)g_blk.ld_dst, d_out, sizeof(float) * (uint64_t)w_out,
+                                 sizeof(float) * (uint64_t)n, (uint64_t)g_blk.n, nullptr) ||
+        smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+    if (n == g_blk.ld_dst && n == w_out && g_blk.w_level >= 0) {   // the level's whole rows: the next override may take them from here
+      DevRows r; r.d = d_out; r.start = g_blk.w_start; r.n = g_blk.n; r.N = n;
+      g_dev_rows[g_blk.w_level] = r;
+      dev_level = g_blk.w_level;
+    }
+  }
+  // the device rows of the call's frames on the host as they are ([frames][w_out]), for outputs the component re-orders itself
+  std::vector<float> rows_;
+  const float *down_rows() {
+    rows_.resize((size_t)w_out * (size_t)g_blk.n);
+    if (smilehip_copy_to_host(context(), rows_.data(), d_out, sizeof(float) * (uint64_t)rows_.size(), nullptr) ||
+        smilehip_stream_synchronize(context(), nullptr))
+      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+    return rows_.data();
+  }
   ~FrameIO() {
+    forget();
     if (g_ctx) {
-      if (d_in) smilehip_free(g_ctx, d_in);
+      if (own_in) smilehip_free(g_ctx, own_in);
       if (d_out) smilehip_free(g_ctx, d_out);
     }
   }

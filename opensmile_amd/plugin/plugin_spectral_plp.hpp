@@ -1,7 +1,7 @@
 // libsmilehip_plugin.so, part of smilehip_plugin.cpp (included there, inside its unnamed namespace, in this order;
 // one translation unit: the parts share the state of plugin_shared.hpp): R11, R8: cSpectral, cPlp
 // R11  cSpectral::processVector with ComParE_2016's option set  (src/lldcore/spectral.cpp:586-1560)
-class cHipSpectral : public cSpectral {
+class cHipSpectral : public BlockVP<cSpectral> {
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
@@ -81,12 +81,12 @@ class cHipSpectral : public cSpectral {
       io_.ensure(Nsrc, 5);
       io_.up(src, Nsrc);
       float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
-      check(smilehip_spectral_gemaps_frames(gm_plan_, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 5, 1, nullptr));
+      check(smilehip_spectral_gemaps_frames(gm_plan_, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 5, g_blk.n, nullptr));
       seen_[fc] = true;
-      float five[5];
-      io_.down(five, 5);
-      if (gemaps_ == 1) memcpy(dst, five, sizeof(float) * 4); else dst[0] = five[4];
-      g_frames[12]++;
+      const float *five = io_.down_rows();
+      for (long f = 0; f < g_blk.n; ++f, five += 5, dst += g_blk.ld_dst)
+        if (gemaps_ == 1) memcpy(dst, five, sizeof(float) * 4); else dst[0] = five[4];
+      g_frames[12] += g_blk.n;
       return (int)Ndst;
     }
     const bool compare_set = plain_ && (Nsrc == 129 || Nsrc == 257 || Nsrc == 513) && Ndst == 12 + (int)sel_[0] + (int)sel_[1] + (int)sel_[2];
@@ -122,10 +122,10 @@ class cHipSpectral : public cSpectral {
       io_.ensure(Nsrc, gen_n_out_);
       io_.up(src, Nsrc);
       float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
-      check(smilehip_spectral_op_frames(gen_op_[fc], io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, gen_n_out_, 1, nullptr));
+      check(smilehip_spectral_op_frames(gen_op_[fc], io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, gen_n_out_, g_blk.n, nullptr));
       seen_[fc] = true;
       io_.down(dst, gen_n_out_);
-      g_frames[12]++;
+      g_frames[12] += g_blk.n;
       return (int)Ndst;
     }
     if (!compare_set || fc < 0 || fc >= 8) {
@@ -144,21 +144,22 @@ class cHipSpectral : public cSpectral {
     io_.ensure(Nsrc, 15);
     io_.up(src, Nsrc);
     float *d_prev = (float *)prev_[fc].ensure(sizeof(float) * (uint64_t)Nsrc);
-    check(smilehip_spectral_frames(pl, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 15, 1, nullptr));
+    check(smilehip_spectral_frames(pl, io_.d_in, Nsrc, d_prev, seen_[fc] ? 0 : 1, io_.d_out, 15, g_blk.n, nullptr));
     seen_[fc] = true;
     if (Ndst == 15) io_.down(dst, 15);
     else {
-      float v[15];
-      io_.down(v, 15);
-      long n = 0;
-      for (int k = 0; k < 15; ++k)
-        if ((k != 7 || sel_[0]) && (k != 13 || sel_[1]) && (k != 14 || sel_[2])) dst[n++] = v[k];
+      const float *v = io_.down_rows();
+      for (long f = 0; f < g_blk.n; ++f, v += 15, dst += g_blk.ld_dst) {
+        long n = 0;
+        for (int k = 0; k < 15; ++k)
+          if ((k != 7 || sel_[0]) && (k != 13 || sel_[1]) && (k != 14 || sel_[2])) dst[n++] = v[k];
+      }
     }
-    g_frames[12]++;
+    g_frames[12] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipSpectral(const char *n) : cSpectral(n) {}
+  explicit cHipSpectral(const char *n) : BlockVP<cSpectral>(n) {}
   ~cHipSpectral() override {
     if (gm_plan_) smilehip_plan_destroy(gm_plan_);
     for (auto *op : gen_op_) if (op) smilehip_spectral_op_destroy(op);
@@ -171,7 +172,7 @@ class cHipSpectral : public cSpectral {
 };
 
 // R8  cPlp::processVector as auditory spectrum, with or without newRASTA  (src/lldcore/plp.cpp:416-593)
-class cHipPlp : public cPlp {
+class cHipPlp : public BlockVP<cPlp> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
@@ -192,7 +193,7 @@ class cHipPlp : public cPlp {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
     }
-    return cPlp::myTick(t);
+    return BlockVP<cPlp>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
@@ -275,16 +276,16 @@ class cHipPlp : public cPlp {
     io_.up(src, Nsrc);
     if (cc_)
       check(smilehip_plp_cc_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_, lpOrder_,
-                                   (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, lpOrder_ + 1, 1, nullptr));
+                                   (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, lpOrder_ + 1, g_blk.n, nullptr));
     else
       check(smilehip_plp_audspec_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_,
-                                        newRasta_ ? 1 : (oldRasta_ ? 2 : 0), coef_, (float *)state_[fc].d, io_.d_out, Ndst, 1, nullptr));
+                                        newRasta_ ? 1 : (oldRasta_ ? 2 : 0), coef_, (float *)state_[fc].d, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[13]++;
+    g_frames[13] += g_blk.n;
     return (int)Ndst;
   }
  public:
-  explicit cHipPlp(const char *n) : cPlp(n) {}
+  explicit cHipPlp(const char *n) : BlockVP<cPlp>(n) {}
   ~cHipPlp() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipPlp(n);

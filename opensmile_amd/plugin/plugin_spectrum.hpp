@@ -21,7 +21,7 @@ struct DevBytes {
 };
 
 // R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
-class cHipVectorPreemphasis : public cVectorPreemphasis {
+class cHipVectorPreemphasis : public BlockVP<cVectorPreemphasis> {
   int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -41,13 +41,13 @@ class cHipVectorPreemphasis : public cVectorPreemphasis {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_preemphasis_frames(context(), io_.d_in, Nsrc, io_.d_out, Ndst, 1, Ndst, k_, de_, nullptr));
+    check(smilehip_preemphasis_frames(context(), io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, Ndst, k_, de_, nullptr));
     io_.down(dst, Ndst);
-    g_frames[0]++;
+    g_frames[0] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipVectorPreemphasis(const char *n) : cVectorPreemphasis(n) {}
+  explicit cHipVectorPreemphasis(const char *n) : BlockVP<cVectorPreemphasis>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipVectorPreemphasis(n);
     c->setComponentInfo(scname, sdescription);
@@ -68,7 +68,7 @@ struct PlanSet {
 };
 
 // R3  cWindower::processVector  (src/dspcore/windower.cpp:221-229)
-class cHipWindower : public cWindower {
+class cHipWindower : public BlockVP<cWindower> {
   int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -91,13 +91,13 @@ class cHipWindower : public cWindower {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_window_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_window_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[1]++;
+    g_frames[1] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipWindower(const char *n) : cWindower(n) {}
+  explicit cHipWindower(const char *n) : BlockVP<cWindower>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipWindower(n);
     c->setComponentInfo(scname, sdescription);
@@ -106,7 +106,7 @@ class cHipWindower : public cWindower {
 };
 
 // R4  cTransformFFT::processVector, forward  (src/dspcore/transformFft.cpp:165-223)
-class cHipTransformFFT : public cTransformFFT {
+class cHipTransformFFT : public BlockVP<cTransformFFT> {
   int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -127,9 +127,9 @@ class cHipTransformFFT : public cTransformFFT {
       }
       io_.ensure(Nsrc, Ndst);
       io_.up(src, Nsrc);
-      check(smilehip_irfft_frames(pli, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+      check(smilehip_irfft_frames(pli, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
       io_.down(dst, Ndst);
-      g_frames[2]++;
+      g_frames[2] += g_blk.n;
       return 1;
     }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
@@ -143,13 +143,13 @@ class cHipTransformFFT : public cTransformFFT {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_rfft_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_rfft_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[2]++;
+    g_frames[2] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipTransformFFT(const char *n) : cTransformFFT(n) {}
+  explicit cHipTransformFFT(const char *n) : BlockVP<cTransformFFT>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipTransformFFT(n);
     c->setComponentInfo(scname, sdescription);
@@ -158,7 +158,7 @@ class cHipTransformFFT : public cTransformFFT {
 };
 
 // R5  cFFTmagphase::processVector, magnitude branch  (src/dspcore/fftmagphase.cpp:215-221)
-class cHipFFTmagphase : public cFFTmagphase {
+class cHipFFTmagphase : public BlockVP<cFFTmagphase> {
   int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -189,9 +189,9 @@ class cHipFFTmagphase : public cFFTmagphase {
       if (n_out <= Ndst && Nsrc >= 4 && !(Nsrc & 1)) {
         io_.ensure(Nsrc, Ndst);
         io_.up(src, Nsrc);
-        check(smilehip_fftmagphase_frames(context(), io_.d_in, Nsrc, Nsrc, modes_, dbp_norm_, min_dbp_, io_.d_out, Ndst, 1, nullptr));
+        check(smilehip_fftmagphase_frames(context(), io_.d_in, Nsrc, Nsrc, modes_, dbp_norm_, min_dbp_, io_.d_out, Ndst, g_blk.n, nullptr));
         io_.down(dst, n_out);
-        g_frames[3]++;
+        g_frames[3] += g_blk.n;
         return 1;
       }
     }
@@ -203,13 +203,13 @@ class cHipFFTmagphase : public cFFTmagphase {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_fftmag_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_fftmag_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[3]++;
+    g_frames[3] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipFFTmagphase(const char *n) : cFFTmagphase(n) {}
+  explicit cHipFFTmagphase(const char *n) : BlockVP<cFFTmagphase>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipFFTmagphase(n);
     c->setComponentInfo(scname, sdescription);
@@ -218,7 +218,7 @@ class cHipFFTmagphase : public cFFTmagphase {
 };
 
 // R6  cMelspec::processVector  (src/lldcore/melspec.cpp:519-570)
-class cHipMelspec : public cMelspec {
+class cHipMelspec : public BlockVP<cMelspec> {
   int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
@@ -259,9 +259,9 @@ class cHipMelspec : public cMelspec {
         io_.up(src, Nsrc);
         check(smilehip_melspec_table_frames(context(), io_.d_in, Nsrc, Nsrc, nBands_, dense ? 1 : 0, (const float *)tab_coef_[fc].d,
                                             (const int32_t *)tab_map_[fc].d, (int32_t)nLoF_[fc], (int32_t)nHiF_[fc], usePower_, scale,
-                                            io_.d_out, Ndst, 1, nullptr));
+                                            io_.d_out, Ndst, g_blk.n, nullptr));
         io_.down(dst, Ndst);
-        g_frames[4]++;
+        g_frames[4] += g_blk.n;
         return 1;
       }
     }
@@ -283,13 +283,13 @@ class cHipMelspec : public cMelspec {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_melspec_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_melspec_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[4]++;
+    g_frames[4] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipMelspec(const char *n) : cMelspec(n) {}
+  explicit cHipMelspec(const char *n) : BlockVP<cMelspec>(n) {}
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipMelspec(n);
     c->setComponentInfo(scname, sdescription);
@@ -298,7 +298,7 @@ class cHipMelspec : public cMelspec {
 };
 
 // R7  cMfcc::processVector, forward  (src/lldcore/mfcc.cpp:239-273)
-class cHipMfcc : public cMfcc {
+class cHipMfcc : public BlockVP<cMfcc> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
   long fframe_ = 0, fnext_ = 0;
@@ -315,7 +315,7 @@ class cHipMfcc : public cMfcc {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*fcols_, writer_, fnext_, fblock_, blocksizeW_);
     }
-    return cMfcc::myTick(t);
+    return BlockVP<cMfcc>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
     if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
@@ -335,13 +335,13 @@ class cHipMfcc : public cMfcc {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
-    check(smilehip_mfcc_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, 1, nullptr));
+    check(smilehip_mfcc_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
-    g_frames[5]++;
+    g_frames[5] += g_blk.n;
     return 1;
   }
  public:
-  explicit cHipMfcc(const char *n) : cMfcc(n) {}
+  explicit cHipMfcc(const char *n) : BlockVP<cMfcc>(n) {}
   ~cHipMfcc() override { delete fblock_; }
   static cSmileComponent *create(const char *n) {
     cSmileComponent *c = new cHipMfcc(n);

@@ -62,18 +62,11 @@ class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
   FusedRows frows_;
   FusedTick ftick_;
+  WinBlock wblock_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, segs_ = 0, flags_ = 0;
   DevBytes norm_;
- protected:
-  eTickResult myTick(long long t) override {
-    if (ftick_.mine(getStr("writer.dmLevel"))) {
-      if (isEOI()) return TICK_INACTIVE;
-      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
-    }
-    return cDeltaRegression::myTick(t);
-  }
-  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+  void options() {
     if (plain_ < 0) {
       W_ = getInt("deltawin");
       segs_ = getInt("onlyInSegments") ? 1 : 0;
@@ -90,6 +83,21 @@ class cHipDeltaRegression : public cDeltaRegression {
         check(smilehip_copy_to_device(context(), row_.d_norm, &n0, sizeof(float), nullptr));
       }
     }
+  }
+ protected:
+  eTickResult myTick(long long t) override {
+    if (ftick_.mine(getStr("writer.dmLevel"))) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
+    }
+    // every block between the padded ones at the two ends of the input in one tick (plugin_block.hpp); onlyInSegments carries its
+    // divisor from value to value in processing order and keeps the reference's ticks
+    options();
+    if (!segs_ && wblock_.tick(this, 0, W_, flags_ & ~SMILEHIP_DELTA_SEGMENTS, &g_frames[10])) return TICK_SUCCESS;
+    return cDeltaRegression::myTick(t);
+  }
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    options();
     if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
     if (pre < (W_ > 0 ? W_ : 1) || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: a block without its window's history"); return cDeltaRegression::processBuffer(in, out, pre, post); }
@@ -111,23 +119,29 @@ class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
   FusedRows frows_;
   FusedTick ftick_;
+  WinBlock wblock_;
   bool cpu_warned_ = false;
   int plain_ = -1, W_ = 0, nz_ = 0;
- protected:
-  eTickResult myTick(long long t) override {
-    if (ftick_.mine(getStr("writer.dmLevel"))) {
-      if (isEOI()) return TICK_INACTIVE;
-      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
-    }
-    return cContourSmoother::myTick(t);
-  }
-  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+  void options() {
     if (plain_ < 0) {
       const int w = smaWin;                              // the member: myFetchConfig has made an even value odd (contourSmoother.cpp:64-67)
       W_ = w / 2;
       plain_ = ((w & 1) && W_ >= 1) ? 1 : 0;
       nz_ = getInt("noZeroSma") ? 1 : 0;
     }
+  }
+ protected:
+  eTickResult myTick(long long t) override {
+    if (ftick_.mine(getStr("writer.dmLevel"))) {
+      if (isEOI()) return TICK_INACTIVE;
+      return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
+    }
+    options();
+    if (plain_ && wblock_.tick(this, nz_ ? 2 : 1, W_, 0, &g_frames[11])) return TICK_SUCCESS;   // (plugin_block.hpp)
+    return cContourSmoother::myTick(t);
+  }
+  int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
+    options();
     if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: smaWin = 1 (no smoothing) is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);

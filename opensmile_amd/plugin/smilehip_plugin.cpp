@@ -29,6 +29,8 @@
 #include <dspcore/contourSmoother.hpp>
 #include <dspcore/deltaRegression.hpp>
 #include <dspcore/fftmagphase.hpp>
+#include <dspcore/framer.hpp>
+#include <dspcore/framer.hpp>
 #include <dspcore/transformFft.hpp>
 #include <other/vectorConcat.hpp>
 #include <dspcore/vectorPreemphasis.hpp>
@@ -78,6 +80,7 @@
 namespace {
 // the overrides, by component family (one translation unit; see the header of each part)
 #include "plugin_shared.hpp"
+#include "plugin_block.hpp"
 #include "plugin_spectrum.hpp"
 #include "plugin_lld.hpp"
 #include "plugin_temporal.hpp"
@@ -99,6 +102,7 @@ struct TraceAtExit {
     if (!f) return;
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s.cpu %ld\n", g_names[i], g_cpu[i]);
+    fprintf(f, "cFramer %ld\nblock.ticks %ld\nblock.frames %ld\nblock.dev_rows %ld\n", g_framer_frames, g_block_ticks, g_block_frames, g_block_dev_rows);
     fprintf(f, "fused.rows %ld\nfused.stage_frames %ld\nfused.batch_frames %ld\n", g_fused.served, g_fused_stage, g_fused.active ? g_fused.n_rows : 0L);
     fclose(f);
   }
@@ -136,6 +140,7 @@ extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cCom
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cFramer")) head = override_of(&cFramer::registerComponent, &cHipFramer::create, confman, compman, iteration, head);
   if (want("cVectorConcat")) head = override_of(&cVectorConcat::registerComponent, &cHipVectorConcat::create, confman, compman, iteration, head);
   if (want("cWaveSource")) head = override_of(&cWaveSource::registerComponent, &cHipWaveSource::create, confman, compman, iteration, head);
   if (want("cVectorOperation")) head = override_of(&cVectorOperation::registerComponent, &cHipVectorOperation::create, confman, compman, iteration, head);

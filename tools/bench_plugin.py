@@ -47,7 +47,8 @@ def main():
             if args.configs and not any(c in name for c in args.configs.split(",")):
                 continue
             modes = [("cpu_binary", {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf, extra),
-                     ("plugin_per_component", {"SMILEHIP_PLUGIN_FUSE": "0"}, conf, extra)]
+                     ("plugin_per_component", {"SMILEHIP_PLUGIN_FUSE": "0", "SMILEHIP_PLUGIN_BLOCK": "0"}, conf, extra),
+                     ("plugin_block_per_tick", {"SMILEHIP_PLUGIN_FUSE": "0"}, conf, extra)]
             modes.append(("plugin_default_unmodified_conf (fused)", {}, conf, extra))       # (round 5: fused is what an unmodified file gets)
             if name == "MFCC12_0_D_A":
                 modes.append(("plugin_fused_source", {}, os.path.join(plugdir, "conf", "MFCC12_0_D_A_hip.conf"), ["-featureSet", "mfcc12_0_d_a"]))
