@@ -787,6 +787,12 @@ int smilehip_delta_op_row(smilehip_context *ctx, const float *d_x, float *d_y, i
  * Same expressions as the row operators above: same bits. */
 int smilehip_window_op_block(smilehip_context *ctx, const float *d_x, int64_t ld_x, float *d_y, int64_t ld_y, int64_t n_t,
                              int32_t n_cols, int op, int W, int delta_flags, void *stream);
+/* cDeltaRegression with onlyInSegments (deltaRegression.cpp:121-137) on the same kind of block: n_ticks ticks of tick_frames frames
+ * (the component's blocksize) each. Its divisor grows with every pair of values it uses, in the order the reference's ticks visit
+ * them (tick, then element, then the tick's frames): the block is walked in that order by one thread; d_norm_io as in
+ * smilehip_window_op_row_ex. */
+int smilehip_delta_segments_block(smilehip_context *ctx, const float *d_x, int64_t ld_x, float *d_y, int64_t ld_y, int64_t n_ticks,
+                                  int32_t tick_frames, int32_t n_cols, int W, int delta_flags, float *d_norm_io, void *stream);
 /* ---- GeMAPS / eGeMAPS components, per component, on an eGeMAPS plan (smilehip_config_egemapsv02: 16 kHz, 20 ms Hamming frames
  * -> 512-point spectrum; 60 ms frames -> 1024-point spectrum). Rows in, rows out, like the operators above. */
 /* cSpectral::processVector (src/lldcore/spectral.cpp:586-1254) with the GeMAPS option sets -- squareInput = 1, useLogSpectrum = 1,
@@ -887,6 +893,11 @@ int smilehip_viterbi_stream_create(smilehip_context *ctx, int32_t buffer_len, fl
 int smilehip_viterbi_stream_set_candidates(smilehip_viterbi_stream *s, int32_t n_candidates);
 int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing,
                                  int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
+/* n_frames consecutive frames in one call (a block tick of the plugin): cand_f0 / cand_voicing are n_frames rows of `ld` floats
+ * (the first n_candidates of a row are read); the decisions of all the steps come back in the order the single pushes would have
+ * reported them. */
+int smilehip_viterbi_stream_push_frames(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing, int64_t ld,
+                                        int32_t n_frames, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
 int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap);
 int smilehip_viterbi_stream_destroy(smilehip_viterbi_stream *s);
 
@@ -907,6 +918,11 @@ int smilehip_jitter_stream_create(smilehip_context *ctx, double sample_period, i
 int smilehip_jitter_stream_set_time_offset(smilehip_jitter_stream *s, int64_t frames);
 int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, const int16_t *h_pcm, int64_t pcm_start, int64_t n_pcm,
                                 float *out5, int64_t *last_idx, int64_t *last_mis);
+/* n_frames consecutive F0 frames in one call (a block tick of the plugin). h_pcm / pcm_start / n_pcm: the samples that arrived since
+ * the last call (every sample of the stream is kept on the device); pcm_start + n_pcm is what exists of the stream now -- a frame
+ * whose periods reach beyond it is the reference's "no matrix" case (pitchJitter.cpp:660-665). out5: n_frames rows of five. */
+int smilehip_jitter_stream_push_frames(smilehip_jitter_stream *s, const float *f0, int32_t n_frames, const int16_t *h_pcm,
+                                       int64_t pcm_start, int64_t n_pcm, float *out5, int64_t *last_idx, int64_t *last_mis);
 int smilehip_jitter_stream_destroy(smilehip_jitter_stream *s);
 
 #ifdef __cplusplus

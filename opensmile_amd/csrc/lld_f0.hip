@@ -1172,6 +1172,35 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi_step(F0Params Q, const floa
 }
 
 
+// ... and n_steps frames per launch (a block tick of the plugin hands the stream every frame its input level holds): the same step,
+// frame after frame, the decisions of all of them appended to `decided` in order (room for n_steps + kVBmax pairs).
+__global__ void __launch_bounds__(64) lld_f0_viterbi_steps(F0Params Q, const float *frames, int *st, double *dstate, int *spaths,
+                                                           int *decided, int n_steps) {
+  __shared__ int paths[2][kNS * kVBmax];
+  __shared__ double cost[kNS];
+  __shared__ int msel[kNS];
+  const int lane = threadIdx.x;
+  const int kVB = Q.vit_buf;
+  int pathIdx = st[0], convIdx = st[1], pathBuf = 0;
+  double lastChange = dstate[kNS];
+  for (int i = lane; i < kNS * kVB; i += 64) paths[0][i] = spaths[i];
+  if (lane < kNS) cost[lane] = dstate[lane];
+  __syncthreads();
+  int n_dec = 0;
+  auto emit = [&](int n, int s, int slot) { decided[2 * (n_dec + slot)] = n; decided[2 * (n_dec + slot) + 1] = s; };
+  auto emit_done = [&](int k) { n_dec += k; };
+  for (int step = 0; step < n_steps; ++step) {
+    const int t = pathIdx;
+    const float *cur = frames + (int64_t)t * 21;
+    if (Q.n_cand == kNC) vit_frame<true>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+    else vit_frame<false>(Q, cur, cur - 21, t, lane, paths, cost, msel, lastChange, pathBuf, pathIdx, convIdx, emit, emit_done);
+  }
+  __syncthreads();
+  for (int i = lane; i < kNS * kVB; i += 64) spaths[i] = paths[pathBuf][i];
+  if (lane < kNS) dstate[lane] = cost[lane];
+  if (lane == 0) { dstate[kNS] = lastChange; st[0] = pathIdx; st[1] = convIdx; st[2] = 0; st[3] = n_dec; }
+}
+
 // [is13_smoNz] + [is13_deNz]: the F0 group's columns of the LLD level, T60+1 rows per utterance:
 // cContourSmoother with noZeroSma (contourSmoother.cpp:85-100) over [F0final, voicing | jitterLocal, jitterDDP,
 // shimmerLocal, logHNR], then cDeltaRegression with onlyInSegments (deltaRegression.cpp:113-135) whose `norm` grows by
@@ -1352,6 +1381,12 @@ hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int 
                                   int flush, hipStream_t s) {
   if (Q.vit_buf < 2 || Q.vit_buf > kVBmax) return hipErrorInvalidValue;
   hipLaunchKernelGGL(lld_f0_viterbi_step, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, flush);
+  return hipGetLastError();
+}
+hipError_t launch_f0_viterbi_steps(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
+                                   int n_steps, hipStream_t s) {
+  if (Q.vit_buf < 2 || Q.vit_buf > kVBmax || n_steps < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lld_f0_viterbi_steps, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, n_steps);
   return hipGetLastError();
 }
 int f0_viterbi_max_buffer() { return kVBmax; }

@@ -493,11 +493,11 @@ __global__ void __launch_bounds__(kJitThreads) lld_f0_jitter(LldParams P, F0Para
   JitPhase PH;
   JitState S{0, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   int t_first = 0, t_end = T;
-  if (Q.jit_stream) {                                      // stream mode: the state of the frames before, one frame now
+  if (Q.jit_stream) {                                      // stream mode: the state of the frames before, the new frames now
     const double *js = Q.jit_stream;
     S.lastIdx = (long)js[0]; S.lastMis = (long)js[1]; t_first = (int)js[2];
     S.lastT0 = (float)js[3]; S.lastDiff = (float)js[4]; S.lastJL = (float)js[5]; S.lastJD = (float)js[6]; S.lastSh = (float)js[7];
-    t_end = t_first + 1 < T ? t_first + 1 : T;
+    t_end = T;                                             // every frame pushed since (one per launch, or a block of them)
     __syncthreads();                                       // every thread has read the state before thread 0 rewrites it
   }
   PH(5);   // workgroup set-up

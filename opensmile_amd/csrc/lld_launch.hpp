@@ -43,6 +43,8 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, floa
                      hipEvent_t frames_done = nullptr);
 int f0_tile_frames();
 // cPitchSmootherViterbi as a stream: one frame (or the flush) per launch, state in global memory
+hipError_t launch_f0_viterbi_steps(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
+                                   int n_steps, hipStream_t s);
 hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
                                   int flush, hipStream_t s);
 int f0_viterbi_max_buffer();

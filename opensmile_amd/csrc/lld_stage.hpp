@@ -81,6 +81,8 @@ hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float 
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s);
 hipError_t stage_window_op_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t nT, int nC, int op, int W, float norm,
                                  int flags, hipStream_t s);
+hipError_t stage_delta_seg_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_ticks, int bs, int nC, int W, float *d_norm,
+                                 int flags, hipStream_t s);
 hipError_t stage_frame_rows(const float *samples, int64_t N, int64_t step, int64_t nF, float *dst, int64_t ldd, hipStream_t s);
 hipError_t stage_delta_op(const float *x, float *y, int64_t nT, int W, float norm, int flags, float *d_norm_io, hipStream_t s);
 hipError_t stage_window_op_seq(const float *x, float *y, int64_t nT, int kind, int W, float *d_norm, hipStream_t s);

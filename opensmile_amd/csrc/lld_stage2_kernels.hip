@@ -246,6 +246,38 @@ __global__ void k_window_op_block(const float *x, int64_t ldx, float *y, int64_t
   y[n * ldy + c] = out;
 }
 
+// cDeltaRegression with onlyInSegments on a block of n_ticks * bs frames: the divisor is carried from value to value in the order the
+// reference's ticks visit them -- tick after tick (bs frames each), within a tick element after element, within an element the
+// tick's frames (windowProcessor.cpp:188-200) -- so ONE thread walks the block in exactly that order (k_delta_op_seq's expressions).
+__global__ void k_delta_seg_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_ticks, int bs, int nC, int W,
+                                  float *norm_io, int flags) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float norm = *norm_io;
+  for (int64_t j = 0; j < n_ticks; ++j)
+    for (int c = 0; c < nC; ++c)
+      for (int t = 0; t < bs; ++t) {
+        const int64_t n = j * bs + t;
+        const float *xc = x + c;
+        float out;
+        if (W > 0) {
+          float num = 0.0f;
+          for (int i = 1; i <= W; ++i) {
+            const float a = xc[(n + i) * ldx], b = xc[(n - i) * ldx];
+            if (!(no_value(a) || no_value(b))) {
+              num += (float)i * delta_of(b, a, flags & 1);
+              norm += (float)i * (float)i;
+            }
+          }
+          out = delta_post((norm != 0.0f) ? num / norm : 0.0f, flags);
+        } else {
+          const float a = xc[n * ldx], b = xc[(n - 1) * ldx];
+          out = delta_post((no_value(a) || no_value(b)) ? 0.0f : delta_of(b, a, flags & 1), flags);
+        }
+        y[n * ldy + c] = out;
+      }
+  *norm_io = norm;
+}
+
 // R11 cSpectral::processVector, ComParE option set: the frames of one stream in order (the flux needs the
 // previous frame's magnitudes; `state` carries them across calls). One workgroup, K = 257.
 __global__ void __launch_bounds__(256) k_spectral(const float *src, int64_t lds, float *state, int first, float *dst,
@@ -451,6 +483,11 @@ hipError_t stage_delta_op(const float *x, float *y, int64_t nT, int W, float nor
   if (nT <= 0) return hipSuccess;
   if (flags & 8) hipLaunchKernelGGL(k_delta_op_seq, dim3(1), dim3(64), 0, s, x, y, nT, W, d_norm_io, flags);
   else hipLaunchKernelGGL(k_delta_op, dim3(nblk2(nT, 256)), dim3(256), 0, s, x, y, nT, W, norm, flags);
+  return hipGetLastError();
+}
+hipError_t stage_delta_seg_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_ticks, int bs, int nC, int W, float *d_norm,
+                                 int flags, hipStream_t s) {
+  if (n_ticks > 0 && nC > 0) hipLaunchKernelGGL(k_delta_seg_block, dim3(1), dim3(64), 0, s, x, ldx, y, ldy, n_ticks, bs, nC, W, d_norm, flags);
   return hipGetLastError();
 }
 hipError_t stage_window_op_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t nT, int nC, int op, int W, float norm,

@@ -313,6 +313,14 @@ extern "C" int smilehip_window_op_block(smilehip_context *ctx, const float *d_x,
                                   op == 0 ? delta_flags : 0, (hipStream_t)stream), "window_op_block");
 }
 
+extern "C" int smilehip_delta_segments_block(smilehip_context *ctx, const float *d_x, int64_t ld_x, float *d_y, int64_t ld_y, int64_t n_ticks,
+                                             int32_t tick_frames, int32_t n_cols, int W, int delta_flags, float *d_norm_io, void *stream) {
+  if (!ctx || n_ticks < 0 || tick_frames < 1 || n_cols < 1 || ld_x < n_cols || ld_y < n_cols || W < 0 || W > 64 || (delta_flags & ~7) || !d_norm_io ||
+      (n_ticks > 0 && (!d_x || !d_y)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_delta_segments_block: bad argument");
+  STAGE_RET(stage_delta_seg_block(d_x, ld_x, d_y, ld_y, n_ticks, tick_frames, n_cols, W, d_norm_io, delta_flags | 8, (hipStream_t)stream), "delta_seg_block");
+}
+
 extern "C" int smilehip_frame_rows(smilehip_context *ctx, const float *d_samples, int64_t frame_size, int64_t frame_step, int64_t n_frames,
                                    float *d_dst, int64_t ld_dst, void *stream) {
   if (!ctx || frame_size < 1 || frame_step < 1 || n_frames < 0 || ld_dst < frame_size || (n_frames > 0 && (!d_samples || !d_dst)))
@@ -437,6 +445,7 @@ struct smilehip_viterbi_stream {
   float *d_frames = nullptr;
   int64_t cap_frames = 0, n_frames = 0;
   int *d_st = nullptr, *d_paths = nullptr, *d_decided = nullptr;
+  int64_t cap_decided = 128;                               // (frame, state) pairs d_decided holds
   double *d_dstate = nullptr;
 };
 
@@ -527,6 +536,62 @@ extern "C" int smilehip_viterbi_stream_push(smilehip_viterbi_stream *s, const fl
     return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push: upload failed");
   s->n_frames++;
   return viterbi_step(s, 0, n_decided, frames, states, cap);
+}
+
+static int viterbi_reserve(smilehip_viterbi_stream *s, int64_t more) {     // the device keeps every frame: transitions and decisions look back
+  if (s->n_frames + more <= s->cap_frames) return SMILEHIP_OK;
+  int64_t ncap = s->cap_frames ? s->cap_frames * 2 : 4096;
+  while (ncap < s->n_frames + more) ncap *= 2;
+  float *nf = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&nf), sizeof(float) * 21 * (size_t)ncap) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "viterbi stream: device allocation failed");
+  if (s->n_frames && hipMemcpy(nf, s->d_frames, sizeof(float) * 21 * (size_t)s->n_frames, hipMemcpyDeviceToDevice) != hipSuccess) {
+    (void)hipFree(nf);
+    return fail(SMILEHIP_ERR_HIP, "viterbi stream: copy failed");
+  }
+  if (s->d_frames) (void)hipFree(s->d_frames);
+  s->d_frames = nf;
+  s->cap_frames = ncap;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_viterbi_stream_push_frames(smilehip_viterbi_stream *s, const float *cand_f0, const float *cand_voicing, int64_t ld,
+                                                   int32_t n_frames, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap) {
+  if (!s || !cand_f0 || !cand_voicing || !n_decided || !frames || !states || n_frames < 1 || ld < s->Q.n_cand)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_viterbi_stream_push_frames: bad argument");
+  int rc = viterbi_reserve(s, n_frames);
+  if (rc) return rc;
+  const int64_t need = (int64_t)n_frames + f0_viterbi_max_buffer();
+  if (need > s->cap_decided) {
+    int *nd = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&nd), sizeof(int) * 2 * (size_t)need) != hipSuccess)
+      return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push_frames: device allocation failed");
+    (void)hipFree(s->d_decided);
+    s->d_decided = nd;
+    s->cap_decided = need;
+  }
+  std::vector<float> rows((size_t)n_frames * 21, 0.0f);
+  for (int32_t f = 0; f < n_frames; ++f)
+    for (int c = 0; c < s->Q.n_cand; ++c) {
+      rows[(size_t)f * 21 + 1 + c] = cand_f0[(size_t)f * (size_t)ld + c];
+      rows[(size_t)f * 21 + 7 + c] = cand_voicing[(size_t)f * (size_t)ld + c];
+    }
+  if (hipMemcpy(s->d_frames + 21 * s->n_frames, rows.data(), sizeof(float) * rows.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_viterbi_stream_push_frames: upload failed");
+  s->n_frames += n_frames;
+  hipStream_t st = nullptr;
+  hipError_t e = launch_f0_viterbi_steps(s->Q, s->d_frames, s->d_st, s->d_dstate, s->d_paths, s->d_decided, n_frames, st);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "viterbi steps launch failed: %s", hipGetErrorString(e));
+  int h_st[4];
+  if (hipMemcpy(h_st, s->d_st, sizeof(h_st), hipMemcpyDeviceToHost) != hipSuccess) return fail(SMILEHIP_ERR_HIP, "viterbi steps: copy back failed");
+  const int n = h_st[3];
+  if (n > cap || n > need) return fail(SMILEHIP_ERR_INVALID, "viterbi steps: %d decisions, room for %d", n, cap);
+  std::vector<int> h_dec((size_t)2 * (size_t)(n > 0 ? n : 1));
+  if (n > 0 && hipMemcpy(h_dec.data(), s->d_decided, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "viterbi steps: copy back failed");
+  for (int i = 0; i < n; ++i) { frames[i] = h_dec[2 * (size_t)i]; states[i] = h_dec[2 * (size_t)i + 1]; }
+  *n_decided = n;
+  return SMILEHIP_OK;
 }
 
 extern "C" int smilehip_viterbi_stream_flush(smilehip_viterbi_stream *s, int32_t *n_decided, int32_t *frames, int32_t *states, int32_t cap) {
@@ -645,6 +710,49 @@ extern "C" int smilehip_jitter_stream_push(smilehip_jitter_stream *s, float f0, 
   if (last_idx) *last_idx = (int64_t)st[0];
   if (last_mis) *last_mis = (int64_t)st[1];
   s->n_frames = t + 1;
+  return SMILEHIP_OK;
+}
+
+extern "C" int smilehip_jitter_stream_push_frames(smilehip_jitter_stream *s, const float *f0, int32_t n_frames, const int16_t *h_pcm,
+                                                  int64_t pcm_start, int64_t n_pcm, float *out5, int64_t *last_idx, int64_t *last_mis) {
+  if (!s || !f0 || !out5 || n_frames < 1 || n_pcm < 0 || pcm_start < 0 || (n_pcm > 0 && !h_pcm))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_jitter_stream_push_frames: bad argument");
+  int rc;
+  const int64_t t = s->n_frames;
+  {
+    int64_t c1 = s->cap_frames, c2 = s->cap_frames, c3 = s->cap_frames;
+    if ((rc = grow(s->d_f0, c1, t + n_frames, t, 1)) || (rc = grow(s->d_out4, c2, t + n_frames, t, 4)) || (rc = grow(s->d_shim, c3, t + n_frames, t, 1))) return rc;
+    s->cap_frames = c1;
+  }
+  const int64_t n_samp = pcm_start + n_pcm;                 // samples [0, n_samp) of the stream exist (the earlier ones are on the device)
+  if ((rc = grow(s->d_pcm, s->cap_pcm, n_samp + 2, s->cap_pcm, 1))) return rc;
+  if (n_pcm > 0 && hipMemcpy(s->d_pcm + pcm_start, h_pcm, sizeof(int16_t) * (size_t)n_pcm, hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push_frames: upload failed");
+  const int64_t off[4] = {0, t + n_frames, 0, n_samp};
+  if (hipMemcpy(s->d_off, off, sizeof(off), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->d_f0 + t, f0, sizeof(float) * (size_t)n_frames, hipMemcpyHostToDevice) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push_frames: upload failed");
+  s->P.frame_off = s->d_off;
+  s->P.samp_off = s->d_off + 2;
+  s->P.pcm = s->d_pcm;
+  s->P.total_frames = t + n_frames;
+  s->Q.jit_shim_db = s->d_shim;
+  s->Q.jit_stream = s->d_state;
+  hipError_t e = launch_f0_jitter(s->P, s->Q, s->d_f0, 1, s->d_out4, nullptr);
+  if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "jitter steps launch failed: %s", hipGetErrorString(e));
+  std::vector<float> o4((size_t)n_frames * 4), sh((size_t)n_frames);
+  double st[8];
+  if (hipMemcpy(o4.data(), s->d_out4 + 4 * t, sizeof(float) * o4.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(sh.data(), s->d_shim + t, sizeof(float) * sh.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(st, s->d_state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(SMILEHIP_ERR_HIP, "smilehip_jitter_stream_push_frames: copy back failed");
+  for (int32_t f = 0; f < n_frames; ++f) {
+    for (int k = 0; k < 4; ++k) out5[(size_t)f * 5 + k] = o4[(size_t)f * 4 + k];
+    out5[(size_t)f * 5 + 4] = sh[(size_t)f];
+  }
+  if (last_idx) *last_idx = (int64_t)st[0];
+  if (last_mis) *last_mis = (int64_t)st[1];
+  s->n_frames = t + n_frames;
   return SMILEHIP_OK;
 }
 

@@ -49,6 +49,7 @@ struct Parser {
   std::string top_dir, err;
   int depth = 0;
   std::string cur_name, cur_type;      // the open section: an include is textual, it continues (and may change) the section
+  const ConfCmValue *cm_value = nullptr;   // conf_from_sections: the host's own command-line parser answers (effective value of an option)
 
   // "\cm[long(short){dflt}:descr]trailing" -> value of the option (command line, else default) + trailing
   bool resolve_cm(const std::string &v, std::string &res) {
@@ -77,6 +78,8 @@ struct Parser {
     }
     if (!short_name.empty()) out.cm_short[name] = short_name;
     if (has_dflt && !out.cm_defaults.count(name)) out.cm_defaults[name] = dflt;
+    std::string host_val;
+    if (cm_value && *cm_value && (*cm_value)(name, host_val)) { res = host_val + trailing; out.cm_used.insert(name); return true; }
     auto it = cmdline.find(name);
     if (it == cmdline.end() && out.cm_short.count(name)) it = cmdline.find(out.cm_short[name]);
     if (it != cmdline.end()) res = it->second + trailing;
@@ -94,6 +97,41 @@ struct Parser {
       }
     out.inst.push_back(ConfInstance{name, type, {}, false});
     return out.inst.back();
+  }
+
+  // one line of a section body or a section header (comments at the start of the line and includes are the caller's business)
+  bool body_line(std::string l, const std::string &real) {
+      const size_t eol = l.find("//");
+      if (eol != std::string::npos) l = trim(l.substr(0, eol));
+      if (l.empty()) return true;
+      if (l[0] == '[') {
+        const size_t c = l.find(':'), e = l.find(']');
+        if (c == std::string::npos || e == std::string::npos || c > e) { err = "bad section header '" + l + "' in " + real; return false; }
+        cur_name = trim(l.substr(1, c - 1));
+        cur_type = trim(l.substr(c + 1, e - c - 1));
+        if (cur_type != "cComponentManager") instance(cur_name, cur_type).has_section = true;
+        return true;
+      }
+      const size_t eq = l.find('=');
+      if (eq == std::string::npos) { err = "missing '=' in line '" + l + "' of " + real; return false; }
+      std::string key = trim(l.substr(0, eq)), val;
+      if (!resolve_cm(trim(l.substr(eq + 1)), val)) return false;
+      val = trim(val);
+      if (cur_name.empty()) { err = "field '" + key + "' outside a section in " + real; return false; }
+      if (key.compare(0, cur_name.size() + 1, cur_name + ".") == 0) key = key.substr(cur_name.size() + 1);
+      if (cur_type == "cComponentManager") {
+        if (key.compare(0, 9, "instance[") == 0) {
+          const size_t e = key.find(']');
+          if (e != std::string::npos && key.substr(e + 1) == ".type") instance(key.substr(9, e - 9), val);
+        }
+        return true;                                       // nThreads, printLevelStats ...: the manager's own business
+      }
+      ConfInstance &ci = instance(cur_name, cur_type);
+      bool replaced = false;
+      for (auto &kv : ci.opts)
+        if (kv.first == key) { kv.second = val; replaced = true; }
+      if (!replaced) ci.opts.push_back({key, val});
+        return true;
   }
 
   bool parse_file(const std::string &path, const std::string &parent) {
@@ -124,36 +162,7 @@ struct Parser {
         if (!parse_file(inc, real)) return false;
         continue;
       }
-      const size_t eol = l.find("//");
-      if (eol != std::string::npos) l = trim(l.substr(0, eol));
-      if (l.empty()) continue;
-      if (l[0] == '[') {
-        const size_t c = l.find(':'), e = l.find(']');
-        if (c == std::string::npos || e == std::string::npos || c > e) { err = "bad section header '" + l + "' in " + real; return false; }
-        cur_name = trim(l.substr(1, c - 1));
-        cur_type = trim(l.substr(c + 1, e - c - 1));
-        if (cur_type != "cComponentManager") instance(cur_name, cur_type).has_section = true;
-        continue;
-      }
-      const size_t eq = l.find('=');
-      if (eq == std::string::npos) { err = "missing '=' in line '" + l + "' of " + real; return false; }
-      std::string key = trim(l.substr(0, eq)), val;
-      if (!resolve_cm(trim(l.substr(eq + 1)), val)) return false;
-      val = trim(val);
-      if (cur_name.empty()) { err = "field '" + key + "' outside a section in " + real; return false; }
-      if (key.compare(0, cur_name.size() + 1, cur_name + ".") == 0) key = key.substr(cur_name.size() + 1);
-      if (cur_type == "cComponentManager") {
-        if (key.compare(0, 9, "instance[") == 0) {
-          const size_t e = key.find(']');
-          if (e != std::string::npos && key.substr(e + 1) == ".type") instance(key.substr(9, e - 9), val);
-        }
-        continue;                                       // nThreads, printLevelStats ...: the manager's own business
-      }
-      ConfInstance &ci = instance(cur_name, cur_type);
-      bool replaced = false;
-      for (auto &kv : ci.opts)
-        if (kv.first == key) { kv.second = val; replaced = true; }
-      if (!replaced) ci.opts.push_back({key, val});
+      if (!body_line(l, real)) return false;
     }
     --depth;
     return true;
@@ -263,6 +272,26 @@ bool conf_parse(const std::string &path, const std::map<std::string, std::string
   out = ConfFile();
   Parser p{out, cmdline, dir_of(path), "", 0, "", ""};
   if (!p.parse_file(path, path)) { err = p.err; return false; }
+  for (const ConfInstance &i : out.inst)
+    if (i.type.empty()) { err = "instance '" + i.name + "' has no type"; return false; }
+  return true;
+}
+
+bool conf_from_sections(const std::vector<ConfRawSection> &sections, const ConfCmValue &cm_value, ConfFile &out, std::string &err) {
+  out = ConfFile();
+  static const std::map<std::string, std::string> none;
+  Parser p{out, none, ".", "", 0, "", ""};
+  p.cm_value = &cm_value;
+  for (const ConfRawSection &sec : sections) {
+    p.cur_name = sec.name;
+    p.cur_type = sec.type;
+    if (sec.type != "cComponentManager") p.instance(sec.name, sec.type).has_section = true;
+    for (const std::string &raw : sec.lines) {
+      const std::string l = trim(raw);
+      if (l.empty() || l[0] == ';' || l[0] == '#' || l[0] == '%' || l.compare(0, 2, "//") == 0) continue;
+      if (!p.body_line(l, "(configuration manager)")) { err = p.err; return false; }
+    }
+  }
   for (const ConfInstance &i : out.inst)
     if (i.type.empty()) { err = "instance '" + i.name + "' has no type"; return false; }
   return true;

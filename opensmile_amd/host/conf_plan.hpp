@@ -2,6 +2,7 @@
 // of the fused path (see conf_plan.cpp). No reference code is linked.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -27,6 +28,15 @@ struct ConfFile {
 
 // cmdline: values for the file's \cm[...] options, keyed by the long or the one-letter name (no dash)
 bool conf_parse(const std::string &path, const std::map<std::string, std::string> &cmdline, ConfFile &out, std::string &err);
+
+// The same ConfFile from sections a host has ALREADY read: the reference's own cFileConfigReader keeps every section of the file
+// (includes expanded, block comments removed) as its raw "field = value" lines (src/include/core/configManager.hpp:475-482
+// fileInstance; src/core/configManager.cpp:1684-1699 addLine, :1747-2110 openInput) -- what the plugin hands over from the
+// cConfigManager the component loader gave it. cm_value: the effective value of a \cm[...] option (command line, else default)
+// from the host's own command-line parser; false = not known there (the default the placeholder itself names is used).
+struct ConfRawSection { std::string name, type; std::vector<std::string> lines; };
+typedef std::function<bool(const std::string &name, std::string &value)> ConfCmValue;
+bool conf_from_sections(const std::vector<ConfRawSection> &sections, const ConfCmValue &cm_value, ConfFile &out, std::string &err);
 
 // hash of every processing component (name, type, options; sources / sinks / data memory excluded)
 uint64_t conf_fingerprint(const ConfFile &f);

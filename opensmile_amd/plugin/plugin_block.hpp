@@ -20,6 +20,49 @@ long block_room(W *writer, long n) {
   return f < n ? (f > 0 ? f : 0) : n;
 }
 
+// How many of `avail` frames a block tick moves. A sink takes one frame per tick (cDataSink::myTick), so once the level in front of
+// it is full every level upstream fills up too and room appears one frame at a time: taking it as it comes would put the whole graph
+// back on one-frame ticks. A component whose writer's level is being drained therefore WAITS (its tick reports success and moves
+// nothing) until a block's worth of room is there -- a quarter of the level, at most 256 frames -- and takes what there is as soon
+// as a tick passes without the room growing (nobody drains: waiting longer could stall the graph). Returns the frames to move
+// (>= 1), 0 = wait, -1 = nothing to do here (the reference's own tick reports why).
+struct BlockGate {
+  long last_room = -1, last_avail = -1;
+  // true: fewer than block_min() frames (ticks' worth: units of `unit` frames) are there and more arrived since the last tick -- wait
+  // for a block; false: take what is there (enough, or the input has stopped growing)
+  bool input(long avail, long unit = 1) {
+    if (avail >= block_min() * unit || avail <= last_avail) { last_avail = -1; return false; }
+    last_avail = avail;
+    return true;
+  }
+  template <class W>
+  long frames(W *writer, long avail, long unit = 1) {
+    long n = avail < block_cap() ? avail : block_cap();
+    n -= n % unit;
+    if (n < 1) return -1;
+    long room = block_room(writer, n);
+    room -= room % unit;
+    if (room >= n) { last_room = -1; return n; }
+    const sDmLevelConfig *c = writer->getLevelConfig();
+    long target = c ? c->nT / 4 : 64;
+    target = target > 256 ? 256 : (target < 2 ? 2 : target);
+    target -= target % unit;
+    if (target < unit) target = unit;
+    if (target > n) target = n;
+    if (room >= target) { last_room = -1; return room; }
+    if (room > last_room) { last_room = room; return 0; }
+    last_room = -1;
+    return room >= 1 ? room : -1;
+  }
+};
+
+// frames written so far to every level a reader reads (the slowest of them)
+inline long reader_cur_w(cDataReader *r) {
+  long w = r->dm->getCurW(r->level[0]);
+  for (int i = 1; i < r->nLevels; ++i) { const long x = r->dm->getCurW(r->level[i]); if (x < w) w = x; }
+  return w;
+}
+
 // rows [start, start + n) of a reader's level, if the override that wrote them left them on the device
 inline const float *block_dev_rows(cDataReader *r, long start, long n, long N) {
   if (r->nLevels != 1) return nullptr;
@@ -52,17 +95,29 @@ template <class B>
 class BlockVP : public B {
  protected:
   BlockMat bout_;
+  BlockGate gate_;
   // may this instance's processVector stand for a block (every operator call in it takes g_blk.n frames, its host-side
   // arithmetic loops over them)? Overrides whose option set has no such form return false and keep the one-frame ticks.
   virtual bool blockCapable() { return true; }
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = B::configureWriter(c);
+    if (r && block_mode()) {                               // room for blocks in the levels either side (plugin_shared.hpp: block_frames)
+      this->reader_->updateBlocksize(block_frames());
+      if (c.blocksizeWriter < block_frames()) c.blocksizeWriter = block_frames();
+    }
+    return r;
+  }
   eTickResult myTick(long long t) override {
     g_fused.init();
     if (!block_mode() || g_fused.active || this->isEOI() || this->processArrayFields == 2 || !blockCapable()) return B::myTick(t);
     cDataReader *rd = this->reader_;
-    long n = rd->getNAvail();
-    if (n > block_cap()) n = block_cap();
-    if (n < 2 || rd->curR < 0) return B::myTick(t);
-    n = block_room(this->writer_, n);
+    const long avail = rd->getNAvail();
+    if (avail < 1 || rd->curR < 0) return B::myTick(t);
+    if (gate_.input(avail)) return TICK_SUCCESS;           // a block is still arriving (BlockGate::input)
+    if (avail < 2) return B::myTick(t);
+    long n = gate_.frames(this->writer_, avail);
+    BLOCK_DBG("%s: vector tick: curR %ld avail %ld n %ld", this->getInstName(), rd->curR, avail, n);
+    if (n == 0) return TICK_SUCCESS;                       // waiting for a block's worth of room (BlockGate)
     if (n < 2) return B::myTick(t);
     const long s = rd->curR;
     cMatrix *mat = rd->getMatrix(s, n);
@@ -109,8 +164,14 @@ class BlockVP : public B {
 // (winToVecProcessor.cpp:983 getNextMatrix with stepM / lengthM, :1037-1052 the row copy, :1064-1072 the frame's time stamp)
 class cHipFramer : public cFramer {
   BlockMat bout_;
+  BlockGate gate_;
   FrameIO io_;
  protected:
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cFramer::configureWriter(c);
+    if (r && block_mode() && c.blocksizeWriter < block_frames()) c.blocksizeWriter = block_frames();   // (plugin_shared.hpp: block_frames)
+    return r;
+  }
   eTickResult myTick(long long t) override {
     cDataReader *rd = reader_;
     g_fused.init();
@@ -119,9 +180,11 @@ class cHipFramer : public cFramer {
       return cFramer::myTick(t);
     const long s = rd->curR, step = rd->stepM, len = rd->lengthM;
     const long have = rd->dm->getCurW(rd->level[0]) - s;
-    long n = have >= len ? (have - len) / step + 1 : 0;
-    if (n > block_cap()) n = block_cap();
-    n = block_room(writer_, n);
+    const long avail = have >= len ? (have - len) / step + 1 : 0;
+    if (avail < 2) return cFramer::myTick(t);
+    const long n = gate_.frames(writer_, avail);
+    BLOCK_DBG("%s: framer tick: curR %ld have %ld n %ld", getInstName(), s, have, n);
+    if (n == 0) return TICK_SUCCESS;                       // waiting for a block's worth of room (BlockGate)
     if (n < 2) return cFramer::myTick(t);
     const long span = (n - 1) * step + len;
     cMatrix *mat = rd->getMatrix(s, span);
@@ -169,22 +232,45 @@ class cHipFramer : public cFramer {
 // input (padded, the R13 end-of-input rule) stay with the reference's tick.
 struct WinBlock {
   BlockMat out;
+  BlockGate gate;
   FrameIO io;
-  // op: 0 cDeltaRegression, 1 cContourSmoother, 2 with noZeroSma. Returns false when this tick is not a block tick.
+  bool waiting = false;                                    // the last tick() was a wait: the caller's tick reports success
+  // room for blocks in the levels either side (plugin_shared.hpp: block_frames). cDataProcessor::myConfigureInstance copies the
+  // writer's block size into blocksizeW_, which cWindowProcessor::myTick asks its level for before it writes ONE block
+  // (windowProcessor.cpp:176): restore() puts the component's own value back.
   template <class C>
-  bool tick(C *c, int op, int W, int delta_flags, long *counter) {
+  void configure(C *c, sDmLevelConfig &cfg) {
+    if (!block_mode()) return;
+    own_bs_w = cfg.blocksizeWriter;
+    c->reader_->updateBlocksize(block_frames() + c->winsize);
+    if (cfg.blocksizeWriter < block_frames()) cfg.blocksizeWriter = block_frames();
+  }
+  long own_bs_w = -1;
+  template <class C>
+  void restore(C *c) { if (own_bs_w > 0) { c->blocksizeW_ = own_bs_w; own_bs_w = -1; } }
+  // op: 0 cDeltaRegression, 1 cContourSmoother, 2 with noZeroSma, 3 cDeltaRegression with onlyInSegments (d_norm: its carried
+  // divisor). Returns false when this tick is not a block tick. One device round trip for the block, whatever its size: a single
+  // tick's worth too (the reference's own tick calls processBuffer once per ELEMENT -- a round trip each on the per-row path).
+  template <class C>
+  bool tick(C *c, int op, int W, int delta_flags, long *counter, float *d_norm = nullptr) {
     cDataReader *rd = c->reader_;
     const long bs = rd->stepM, win = c->winsize, pre = c->pre, post = c->post;
-    if (!block_mode() || g_fused.active || c->isEOI() || rd->nLevels != 1 || bs < 1 || rd->lengthM != bs + win || rd->curR < 0 || c->multiplier != 1 ||
-        win != pre + post || pre < (W > 0 ? W : 1) || post < W)
+    if (!block_mode() || g_fused.active || c->isEOI() || rd->nLevels < 1 || bs < 1 || rd->lengthM != bs + win || rd->curR < 0 || c->multiplier != 1 ||
+        win != pre + post || pre < (W > 0 ? W : 1) || post < W) {
+      BLOCK_DBG("%s: window tick refused: eoi %d levels %d bs %ld lengthM %ld win %ld curR %ld mult %d pre %ld post %ld W %d", c->getInstName(), (int)c->isEOI(),
+                rd->nLevels, bs, rd->lengthM, win, rd->curR, (int)c->multiplier, pre, post, W);
       return false;
+    }
     const long s = rd->curR;
-    const long have = rd->dm->getCurW(rd->level[0]) - s;
-    long k = have >= bs + win ? (have - win) / bs : 0;
-    if (k * bs > block_cap()) k = block_cap() / bs;
-    long n = block_room(c->writer_, k * bs);
-    n -= n % bs;
-    if (n < 2 || n < 2 * bs) return false;
+    const long have = reader_cur_w(rd) - s;
+    const long k = have >= bs + win ? (have - win) / bs : 0;
+    waiting = false;
+    if (k < 1) return false;
+    if (gate.input(k * bs, bs)) { waiting = true; return true; }   // a block is still arriving (BlockGate::input)
+    const long n = gate.frames(c->writer_, k * bs, bs);
+    BLOCK_DBG("%s: window tick: curR %ld have %ld k %ld n %ld", c->getInstName(), s, have, k, n);
+    if (n == 0) { waiting = true; return true; }           // waiting for a block's worth of room (BlockGate)
+    if (n < bs) return false;
     cMatrix *mat = rd->getMatrix(s, n + win);
     if (!mat) return false;
     const long N = mat->N;
@@ -194,7 +280,11 @@ struct WinBlock {
     cMatrix *o = out.get(N, n);
     io.ensure((n + win) * N, n * N);
     check(smilehip_copy_to_device(context(), io.own_in, mat->data, sizeof(float) * (uint64_t)((n + win) * N), nullptr));
-    check(smilehip_window_op_block(context(), io.own_in + (size_t)pre * (size_t)N, N, io.d_out, N, n, (int32_t)N, op, W, delta_flags, nullptr));
+    if (op == 3)
+      check(smilehip_delta_segments_block(context(), io.own_in + (size_t)pre * (size_t)N, N, io.d_out, N, n / bs, (int32_t)bs, (int32_t)N, W, delta_flags,
+                                          d_norm, nullptr));
+    else
+      check(smilehip_window_op_block(context(), io.own_in + (size_t)pre * (size_t)N, N, io.d_out, N, n, (int32_t)N, op, W, delta_flags, nullptr));
     check(smilehip_copy_to_host(context(), o->data, io.d_out, sizeof(float) * (uint64_t)(n * N), nullptr));
     check(smilehip_stream_synchronize(context(), nullptr));
     o->setTimeMeta(mat->tmeta + pre);                      // matnew->setTimeMeta(mat->tmeta + pre), windowProcessor.cpp:222-224

@@ -11,7 +11,62 @@ class cHipValbasedSelector : public cValbasedSelector {
   int removeIdx_ = 0, invert_ = 0, allowEqual_ = 0, zerovec_ = 0, adaptive_ = 0;
   FLOAT_DMEM outputVal_ = 0, threshold_ = 0;
   cVector *my_ = nullptr;
+  BlockGate gate_;
+  BlockMat bout_;
+  std::vector<int32_t> keeps_;
+  std::vector<float> rows_;
+  // every frame the reader's level holds in one tick (plugin_block.hpp): the decisions and the rows of the block from one operator
+  // call, the frames that are handed on written as one matrix, each with its own time stamp. Returns false: not a block tick.
+  bool blockTick(eTickResult &res) {
+    cDataReader *rd = reader_;
+    if (!block_mode() || isEOI() || rd->curR < 0) return false;
+    const long avail = rd->getNAvail();
+    if (avail < 1) return false;
+    if (gate_.input(avail)) { res = TICK_SUCCESS; return true; }
+    if (avail < 2) return false;
+    const long n = gate_.frames(writer_, avail);
+    if (n == 0) { res = TICK_SUCCESS; return true; }
+    if (n < 2) return false;
+    const long s = rd->curR;
+    cMatrix *mat = rd->getMatrix(s, n);
+    if (!mat || mat->nT != n) return false;
+    const long N = mat->N, nOut = removeIdx_ ? N - 1 : N;
+    if (nOut < 1) return false;
+    rd->curR = s + n;
+    rd->catchupCurR(s + n);
+    io_.ensure(n * N, n * nOut);
+    check(smilehip_copy_to_device(context(), io_.own_in, mat->data, sizeof(float) * (uint64_t)(n * N), nullptr));
+    int32_t *d_keep = (int32_t *)keep_.ensure(sizeof(int32_t) * (uint64_t)n);
+    check(smilehip_valbased_select_frames(context(), io_.own_in, N, N, n, (int32_t)idx_, threshold_, invert_, allowEqual_, zerovec_, removeIdx_,
+                                          outputVal_, io_.d_out, nOut, d_keep, nullptr));
+    rows_.resize((size_t)(n * nOut));
+    keeps_.resize((size_t)n);
+    check(smilehip_copy_to_host(context(), rows_.data(), io_.d_out, sizeof(float) * rows_.size(), nullptr));
+    keep_.down(keeps_.data(), sizeof(int32_t) * (uint64_t)n);
+    cMatrix *out = bout_.get(nOut, n);
+    long m = 0;
+    for (long f = 0; f < n; ++f) {
+      if (!keeps_[(size_t)f]) continue;
+      memcpy(out->data + (size_t)m * (size_t)nOut, rows_.data() + (size_t)f * (size_t)nOut, sizeof(float) * (size_t)nOut);
+      out->tmeta[m] = mat->tmeta[f];                       // my_->setTimeMeta(vec->tmeta)
+      ++m;
+    }
+    g_frames[22] += n;
+    g_block_ticks++;
+    g_block_frames += n;
+    if (m > 0) { out->nT = m; writer_->setNextMatrix(out); }
+    res = TICK_SUCCESS;
+    return true;
+  }
  protected:
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cValbasedSelector::configureWriter(c);
+    if (r && block_mode()) {                               // room for blocks in the levels either side (plugin_shared.hpp: block_frames)
+      reader_->updateBlocksize(block_frames());
+      if (c.blocksizeWriter < block_frames()) c.blocksizeWriter = block_frames();
+    }
+    return r;
+  }
   eTickResult myTick(long long t) override {
     g_fused.init();
     if (g_fused.big) return cValbasedSelector::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
@@ -24,6 +79,7 @@ class cHipValbasedSelector : public cValbasedSelector {
       ready_ = true;
     }
     if (adaptive_) { HIP_FALLTHROUGH(22, "cValbasedSelector: adaptiveThreshold = 1 is not built"); return cValbasedSelector::myTick(t); }
+    { eTickResult r; if (blockTick(r)) return r; }
     if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
     cVector *vec = reader_->getNextFrame();
     if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
@@ -32,7 +88,7 @@ class cHipValbasedSelector : public cValbasedSelector {
     io_.ensure(N, nOut);
     io_.up(vec->data, N);
     int32_t *d_keep = (int32_t *)keep_.ensure(sizeof(int32_t));
-    check(smilehip_valbased_select_frames(context(), io_.d_in, N, N, 1, (int32_t)idx_, threshold_, invert_, allowEqual_, zerovec_, removeIdx_,
+    check(smilehip_valbased_select_frames(context(), io_.own_in, N, N, 1, (int32_t)idx_, threshold_, invert_, allowEqual_, zerovec_, removeIdx_,
                                           outputVal_, io_.d_out, nOut, d_keep, nullptr));
     if (my_ == NULL || my_->N != nOut) { delete my_; my_ = new cVector((int)nOut); }
     io_.down(my_->data, nOut);
@@ -103,58 +159,8 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     else if (f0 > 0.0) sc = 1.0;
     return sc;
   }
- protected:
-  eTickResult myTick(long long t) override {
-    g_fused.init();
-    if (!ready_) setup();
-    if (!usable_) {
-      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 128 is built");
-      return cPitchSmootherViterbi::myTick(t);
-    }
-    int32_t n = 0, fr[128], st[128];
-    if (g_fused.big) {
-      // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
-      // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
-      // last P, P as the fused batch's own pass left it
-      const long T = g_fused.f0_frames, P = g_fused.f0_pending;
-      if (isEOI()) {
-        if (!flushed_) {
-          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 128; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
-          flushed_ = true;
-        }
-      } else {
-        cVector *vec = reader_->getNextFrame();
-        if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
-        std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
-        h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
-        hist_.push_back(h);
-        const long f = (long)hist_.size() - 1;
-        if (f < T - P) { fr[0] = (int32_t)f; st[0] = (int32_t)nCand_; n = 1; }
-        g_fused_stage++;
-      }
-    } else if (isEOI()) {
-      if (!flushed_) {
-        check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 128));
-        flushed_ = true;
-      }
-    } else {
-      cVector *vec = reader_->getNextFrame();
-      if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
-      std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
-      float cf[6], cv[6];
-      for (long i = 0; i < nCand_; i++) {
-        h[(size_t)(2 * i)] = cf[i] = vec->data[f0I_ + i];
-        h[(size_t)(2 * i + 1)] = cv[i] = vec->data[cvI_ + i];
-      }
-      h[(size_t)(2 * nCand_)] = rawI_ >= 0 ? vec->data[rawI_] : 0.0f;
-      h[(size_t)(2 * nCand_ + 1)] = clipI_ > 0 ? vec->data[clipI_] : 0.0f;       // (the reference tests > 0 for these two, :478-482)
-      h[(size_t)(2 * nCand_ + 2)] = c1I_ > 0 ? vec->data[c1I_] : 0.0f;
-      h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
-      hist_.push_back(h);
-      check(smilehip_viterbi_stream_push(vs_, cf, cv, &n, fr, st, 128));
-      g_frames[21]++;
-    }
-    for (int i = 0; i < n; ++i) queue_.push_back(std::make_pair((int)fr[i], (int)st[i]));
+  // the decided frames that are not written yet, as many as the writer's level takes (pitchSmootherViterbi.cpp:497-560)
+  eTickResult write_decided() {
     if (qpos_ >= queue_.size()) return TICK_INACTIVE;
     if (vec_ == NULL) vec_ = new cVector((int)outN_);
     const size_t first = qpos_;
@@ -182,6 +188,106 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
       writer_->setNextFrame(vec_);
     }
     return TICK_SUCCESS;
+  }
+  BlockGate gate_;
+  std::vector<int32_t> fr_, st_;
+  std::vector<float> cf_, cv_;
+ protected:
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cPitchSmootherViterbi::configureWriter(c);
+    if (r && block_mode()) {                               // room for blocks in the levels either side (plugin_shared.hpp: block_frames)
+      reader_->updateBlocksize(block_frames());
+      if (c.blocksizeWriter < block_frames()) c.blocksizeWriter = block_frames();
+    }
+    return r;
+  }
+  eTickResult myTick(long long t) override {
+    g_fused.init();
+    if (!ready_) setup();
+    if (!usable_) {
+      HIP_FALLTHROUGH(21, "cPitchSmootherViterbi: only one input level with up to six candidates and bufferLength <= 128 is built");
+      return cPitchSmootherViterbi::myTick(t);
+    }
+    int32_t n = 0;
+    fr_.resize(128); st_.resize(128);
+    int32_t *fr = fr_.data(), *st = st_.data();
+    if (g_fused.big) {
+      // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
+      // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
+      // last P, P as the fused batch's own pass left it
+      const long T = g_fused.f0_frames, P = g_fused.f0_pending;
+      if (isEOI()) {
+        if (!flushed_) {
+          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 128; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
+          flushed_ = true;
+        }
+      } else {
+        cVector *vec = reader_->getNextFrame();
+        if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
+        std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+        h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
+        hist_.push_back(h);
+        const long f = (long)hist_.size() - 1;
+        if (f < T - P) { fr[0] = (int32_t)f; st[0] = (int32_t)nCand_; n = 1; }
+        g_fused_stage++;
+      }
+    } else if (isEOI()) {
+      if (!flushed_) {
+        check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 128));
+        flushed_ = true;
+      }
+    } else {
+      // every frame of candidates the input level holds goes to the trellis in ONE call (plugin_block.hpp; one frame: the reference's
+      // own pace); what becomes decided is written below, in order, as the single pushes would have reported it
+      cDataReader *rd = reader_;
+      long avail = block_mode() ? rd->getNAvail() : 1;
+      if (avail >= 1 && block_mode() && qpos_ >= queue_.size() && gate_.input(avail)) return TICK_SUCCESS;   // a block is still arriving (BlockGate::input)
+      if (avail > block_cap()) avail = block_cap();
+      cMatrix *mat = (avail >= 2 && rd->curR >= 0) ? rd->getMatrix(rd->curR, avail) : nullptr;
+      if (mat != NULL && mat->nT == avail) {
+        const long nf = avail, N = mat->N;
+        rd->curR += nf;
+        rd->catchupCurR(rd->curR);
+        cf_.assign((size_t)nf * 6, 0.0f); cv_.assign((size_t)nf * 6, 0.0f);
+        for (long f = 0; f < nf; ++f) {
+          const FLOAT_DMEM *row = mat->data + (size_t)f * (size_t)N;
+          std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+          for (long i = 0; i < nCand_; i++) {
+            h[(size_t)(2 * i)] = cf_[(size_t)f * 6 + (size_t)i] = row[f0I_ + i];
+            h[(size_t)(2 * i + 1)] = cv_[(size_t)f * 6 + (size_t)i] = row[cvI_ + i];
+          }
+          h[(size_t)(2 * nCand_)] = rawI_ >= 0 ? row[rawI_] : 0.0f;
+          h[(size_t)(2 * nCand_ + 1)] = clipI_ > 0 ? row[clipI_] : 0.0f;
+          h[(size_t)(2 * nCand_ + 2)] = c1I_ > 0 ? row[c1I_] : 0.0f;
+          h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)mat->tmeta[f].vIdx;
+          hist_.push_back(h);
+        }
+        fr_.resize((size_t)nf + 128); st_.resize((size_t)nf + 128);
+        fr = fr_.data(); st = st_.data();
+        check(smilehip_viterbi_stream_push_frames(vs_, cf_.data(), cv_.data(), 6, (int32_t)nf, &n, fr, st, (int32_t)nf + 128));
+        g_frames[21] += nf;
+        g_block_ticks++;
+        g_block_frames += nf;
+      } else {
+      cVector *vec = reader_->getNextFrame();
+      if (vec == NULL) return qpos_ < queue_.size() ? write_decided() : TICK_SOURCE_NOT_AVAIL;
+      std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
+      float cf[6], cv[6];
+      for (long i = 0; i < nCand_; i++) {
+        h[(size_t)(2 * i)] = cf[i] = vec->data[f0I_ + i];
+        h[(size_t)(2 * i + 1)] = cv[i] = vec->data[cvI_ + i];
+      }
+      h[(size_t)(2 * nCand_)] = rawI_ >= 0 ? vec->data[rawI_] : 0.0f;
+      h[(size_t)(2 * nCand_ + 1)] = clipI_ > 0 ? vec->data[clipI_] : 0.0f;       // (the reference tests > 0 for these two, :478-482)
+      h[(size_t)(2 * nCand_ + 2)] = c1I_ > 0 ? vec->data[c1I_] : 0.0f;
+      h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
+      hist_.push_back(h);
+      check(smilehip_viterbi_stream_push(vs_, cf, cv, &n, fr, st, 128));
+      g_frames[21]++;
+      }
+    }
+    for (int i = 0; i < n; ++i) queue_.push_back(std::make_pair((int)fr[i], (int)st[i]));
+    return write_decided();
   }
  public:
   explicit cHipPitchSmootherViterbi(const char *n) : cPitchSmootherViterbi(n) {}

@@ -227,14 +227,97 @@ class cHipPitchJitter : public cPitchJitter {
   smilehip_jitter_stream *js_ = nullptr;
   bool ready_ = false, usable_ = false, cpu_warned_ = false;
   std::vector<int16_t> pcm_;
+  // block ticks (plugin_block.hpp): the samples of the wave level go to the device-resident stream as they arrive (pend_: what has been
+  // read from the level and not pushed yet, samples [dev_upto_, dev_upto_ + pend_.size())), every F0 frame the pitch level holds in one
+  // smilehip_jitter_stream_push_frames call; the read positions are the stream's own (the device function the batch path runs)
+  BlockGate gate_;
+  BlockMat bout_;
+  std::vector<int16_t> pend_;
+  std::vector<float> f0s_, outs_;
+  long dev_upto_ = 0;
+  bool block_started_ = false;
+  void make_stream(const TimeMetaInfo *tm) {
+    const double T = reader_->getLevelT();
+    const double pitchT = tm->period;
+    const long H = (long)round(pitchT / T), N = (long)round(tm->lengthSec / T);   // (lenF itself is N or N + 1: rounding of the time stamps)
+    check(smilehip_jitter_stream_create(context(), T, N, H, pitchT, searchRangeRel, useBrokenJitterThresh_, &js_));
+    // the first F0 frame's time stamp: frame 0 behind the Viterbi smoother, frame 1 behind cPitchSmoother (one frame of delay, the
+    // time meta data of the frame it was called with)
+    check(smilehip_jitter_stream_set_time_offset(js_, std::lround(tm->time / pitchT)));
+  }
+  bool blockTick(eTickResult &res) {
+    if (!block_mode() || reader_->getNLevels() != 1) return false;
+    // the wave level's new samples (the level holds s / 32767: exact as 16-bit values)
+    const long curW = reader_->dm->getCurW(reader_->level[0]);
+    const long have = dev_upto_ + (long)pend_.size();
+    if (curW > have) {
+      cMatrix *mat = reader_->getMatrix(have, curW - have);
+      if (mat == NULL || mat->nT != curW - have || mat->N != 1) {
+        if (block_started_) COMP_ERR("libsmilehip plugin: cPitchJitter: samples %ld .. %ld of the wave level are not readable any more", have, curW);
+        return false;
+      }
+      const size_t o = pend_.size();
+      pend_.resize(o + (size_t)mat->nT);
+      for (long i = 0; i < mat->nT; ++i) pend_[o + (size_t)i] = (int16_t)lrintf(mat->data[i] * 32767.0f);
+      reader_->catchupCurR(curW);
+      block_started_ = true;
+    }
+    cDataReader *fr = F0reader;
+    const long avail = fr->getNAvail();
+    if (avail < 1 || fr->curR < 0) { res = TICK_SOURCE_NOT_AVAIL; return true; }
+    if (gate_.input(avail)) { res = TICK_SUCCESS; return true; }
+    const long n = gate_.frames(writer_, avail);
+    if (n == 0) { res = TICK_SUCCESS; return true; }
+    if (n < 1) { res = TICK_DEST_NO_SPACE; return true; }
+    cMatrix *fm = fr->getMatrix(fr->curR, n);
+    if (fm == NULL || fm->nT != n) { res = TICK_SOURCE_NOT_AVAIL; return true; }
+    fr->curR += n;
+    fr->catchupCurR(fr->curR);
+    if (!js_) make_stream(fm->tmeta);
+    f0s_.resize((size_t)n);
+    for (long f = 0; f < n; ++f) f0s_[(size_t)f] = F0fieldIdx < fm->N ? fm->data[(size_t)f * (size_t)fm->N + (size_t)F0fieldIdx] : 0.0f;
+    outs_.resize((size_t)n * 5);
+    int64_t li = 0, lm = 0;
+    check(smilehip_jitter_stream_push_frames(js_, f0s_.data(), (int32_t)n, pend_.data(), dev_upto_, (int64_t)pend_.size(), outs_.data(), &li, &lm));
+    dev_upto_ += (long)pend_.size();
+    pend_.clear();
+    lastIdx = (long)li; lastMis = (long)lm;
+    g_frames[23] += n;
+    g_block_ticks++;
+    g_block_frames += n;
+    res = TICK_SUCCESS;
+    if (Nout == 0) { res = TICK_INACTIVE; return true; }   // (:941-947)
+    cMatrix *o = bout_.get(Nout, n);
+    long m = 0;
+    for (long f = 0; f < n; ++f) {
+      if (onlyVoiced && (f0s_[(size_t)f] == 0.0)) continue;
+      const float *out5 = &outs_[(size_t)f * 5];
+      FLOAT_DMEM *d = o->data + (size_t)m * (size_t)Nout;
+      long k = 0;
+      if (jitterLocal) d[k++] = out5[0];
+      if (jitterDDP) d[k++] = out5[1];
+      if (shimmerLocal) d[k++] = out5[2];
+      if (shimmerLocalDB) d[k++] = out5[4];
+      if (logHNR) d[k++] = out5[3];
+      o->tmeta[m] = fm->tmeta[f];
+      ++m;
+    }
+    if (m > 0) { o->nT = m; writer_->setNextMatrix(o); }
+    return true;
+  }
  protected:
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cPitchJitter::configureWriter(c);
+    if (r && block_mode() && c.blocksizeWriter < block_frames()) c.blocksizeWriter = block_frames();   // (plugin_shared.hpp: block_frames)
+    return r;
+  }
   eTickResult myTick(long long t) override {
     g_fused.init();
     if (g_fused.big) return cPitchJitter::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
     if (!ready_) {
       ready_ = true;
       usable_ = !jitterLocalEnv && !jitterDDPEnv && !shimmerLocalEnv && !shimmerLocalDBEnv && !shimmerUseRmsAmplitude && !harmonicERMS &&
-                !noiseERMS && !linearHNR && !sourceQualityRange && !sourceQualityMean && !periodLengths && !periodStarts && !refinedF0 &&
+                !noiseERMS && !linearHNR && !sourceQualityRange && !sourceQualityMean && !refinedF0 &&   // (periodLengths / periodStarts: members the reference never sets or reads)
                 !usePeakToPeakPeriodLength_ && minNumPeriods == 2 && filehandle == NULL &&
                 (useBrokenJitterThresh_ || threshCC_ == (FLOAT_DMEM)0.5) && lgHNRfloor == (FLOAT_DMEM)-100.0 && reader_->getLevelN() == 1;
     }
@@ -244,6 +327,7 @@ class cHipPitchJitter : public cPitchJitter {
       return cPitchJitter::myTick(t);
     }
     if (isEOI()) return TICK_INACTIVE;
+    { eTickResult r; if (blockTick(r)) return r; }
     if (!writer_->checkWrite(1)) return TICK_DEST_NO_SPACE;
     cVector *fvec = F0reader->getNextFrame();
     if (fvec == NULL) return TICK_SOURCE_NOT_AVAIL;

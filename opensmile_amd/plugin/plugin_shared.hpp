@@ -3,6 +3,7 @@
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
+cConfigManager *g_confman = nullptr;     // the loader's configuration manager (registerPluginComponent's first argument)
 constexpr int kNumOverrides = 28;
 long g_frames[kNumOverrides] = {0};
 long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
@@ -73,10 +74,33 @@ inline bool block_mode() {               // SMILEHIP_PLUGIN_BLOCK=0: every overr
   static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK"); return (e && e[0] == '0') ? 0 : 1; }();
   return v != 0 && !allow_cpu();
 }
+// The shipped files of the big sets give most levels a ring buffer of FIVE frames (config/shared/BufferModeRb.conf.inc: one-frame
+// ticks need no more). A block-capable override announces block_frames() as its read and write block size while the levels are
+// configured (cDataReader::updateBlocksize, sDmLevelConfig::blocksizeWriter): the data memory then sizes the level for it
+// (cDataMemoryLevel::finaliseLevel, src/core/dataMemoryLevel.cpp:1343-1356: nT >= blocksizeReader + 2 blocksizeWriter). Capacity
+// only: what is written to and read from a level does not change.
+inline long block_frames() {
+  static const long v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK_FRAMES"); const long x = e ? atol(e) : 0; return x >= 1 ? x : 256L; }();
+  return v;
+}
+// A component behind one that still moves a frame per tick (a component the plugin does not override, a tick-level override) would
+// see one new frame per tick: it waits while its input keeps growing, until block_min() frames are there (BlockGate::input).
+inline long block_min() {
+  static const long v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK_MIN"); const long x = e ? atol(e) : 0; return x >= 1 ? x : 32L; }();
+  return v;
+}
 inline long block_cap() {                // most frames one block tick takes
   static const long v = [] { const char *e = getenv("SMILEHIP_PLUGIN_BLOCK_MAX"); const long x = e ? atol(e) : 0; return x >= 2 ? x : 4096L; }();
   return v;
 }
+
+// SMILEHIP_PLUGIN_DEBUG=1: why a tick was (not) a block tick, the first 200 decisions on stderr
+inline bool block_debug() {
+  static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_DEBUG"); return (e && e[0] == '1') ? 1 : 0; }();
+  static int left = 200;
+  return v != 0 && left-- > 0;
+}
+#define BLOCK_DBG(...) do { if (block_debug()) { fprintf(stderr, "[smilehip block] " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 // device scratch for the frames of one processVector call: one frame in / one frame out on the reference's ticks, g_blk.n of each
 // on a block tick
@@ -357,37 +381,47 @@ struct FusedChain {
     if (on && !strcmp(on, "0")) return;
     const bool loud = on && *on;
 #define FUSE_NOTE(...) do { if (loud) { SMILE_WRN(1, __VA_ARGS__); } else { SMILE_MSG(3, __VA_ARGS__); } } while (0)
-    std::vector<std::string> args;
-    if (FILE *f = fopen("/proc/self/cmdline", "rb")) {
-      std::string cur;
-      int ch;
-      while ((ch = fgetc(f)) != EOF) { if (ch == 0) { args.push_back(cur); cur.clear(); } else cur += (char)ch; }
-      if (!cur.empty()) args.push_back(cur);
-      fclose(f);
-    }
-    std::string conf;
-    std::map<std::string, std::string> cl;
-    for (size_t i = 1; i < args.size(); ++i) {
-      if (args[i].size() < 2 || args[i][0] != '-') continue;
-      const bool has_val = i + 1 < args.size() && (args[i + 1].empty() || args[i + 1][0] != '-' || isdigit((unsigned char)args[i + 1][1]));
-      const std::string key = args[i].substr(1), val = has_val ? args[i + 1] : "1";
-      if (key == "C" || key == "configfile") conf = val; else cl[key] = val;
-      if (has_val) ++i;
-    }
+    // The graph is the one the loader's cConfigManager holds (registerPluginComponent stored the pointer): its file reader keeps
+    // every section of the configuration file as raw "field = value" lines, includes expanded (configManager.hpp:475-482, :567-610),
+    // and its command-line parser knows the effective value of every \\cm[...] option the file defines -- whether the host is
+    // SMILExtract (-C file -I wav ...) or a program that called smile_initialize with a file and an option list.
     std::string err;
     smilehip_host::ConfFile cf;
-    if (conf.empty() || !smilehip_host::conf_parse(conf, cl, cf, err)) {
-      FUSE_NOTE("libsmilehip plugin: fused mode: cannot read the configuration file (%s) -- per-component path", err.c_str());
-      return;
+    {
+      std::vector<smilehip_host::ConfRawSection> sections;
+      cConfigManager *cm = g_confman;
+      for (int r = 0; cm && r < cm->nReaders; ++r) {
+        cFileConfigReader *fr = dynamic_cast<cFileConfigReader *>(cm->reader[r]);
+        for (int i = 0; fr && i < fr->nInst_; ++i) {
+          const fileInstance &fi = fr->inst_[i];
+          smilehip_host::ConfRawSection sec;
+          sec.name = fi.name ? fi.name : "";
+          sec.type = fi.type ? fi.type : "";
+          for (int l = 0; l < fi.N; ++l) if (fi.lines[l]) sec.lines.push_back(fi.lines[l]);
+          sections.push_back(sec);
+        }
+      }
+      cCommandlineParser *cp = cm ? cm->cmdparser : nullptr;
+      const smilehip_host::ConfCmValue cm_value = [cp](const std::string &name, std::string &value) {
+        if (!cp || !cp->optionExists(name.c_str())) return false;
+        const char *v = cp->getStr(name.c_str());
+        if (!v) return false;
+        value = v;
+        return true;
+      };
+      if (sections.empty() || !smilehip_host::conf_from_sections(sections, cm_value, cf, err)) {
+        FUSE_NOTE("libsmilehip plugin: fused mode: the configuration manager holds no file the host library's reader understands (%s) -- block-per-tick path", err.c_str());
+        return;
+      }
     }
     if (!smilehip_host::conf_to_plan(cf, plan, err)) {
-      FUSE_NOTE("libsmilehip plugin: fused mode: %s -- per-component path", err.c_str());
+      FUSE_NOTE("libsmilehip plugin: fused mode: %s -- block-per-tick path", err.c_str());
       return;
     }
     smilehip_host::WaveInfo wi;
     std::vector<unsigned char> raw;
     if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
-      FUSE_NOTE("libsmilehip plugin: fused mode: '%s' is not a 16-bit mono PCM file (%s) -- per-component path", plan.wave_file.c_str(), err.c_str());
+      FUSE_NOTE("libsmilehip plugin: fused mode: '%s' is not a 16-bit mono PCM file (%s) -- block-per-tick path", plan.wave_file.c_str(), err.c_str());
       return;
     }
     if (!plan.preset.empty()) {
@@ -395,7 +429,7 @@ struct FusedChain {
       const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
       const bool all = !only || !*only || !strcmp(only, "all");
       if (!all || plan.last_mfcc > 0 || !plan.func_enabled.empty() || !init_big(wi, raw))
-        FUSE_NOTE("libsmilehip plugin: fused mode: this big-set file does not fuse inside the reference process -- per-component path");
+        FUSE_NOTE("libsmilehip plugin: fused mode: this big-set file does not fuse inside the reference process -- block-per-tick path");
       return;
     }
     smilehip_lld_config c = plan.cfg;

@@ -75,7 +75,7 @@ class cHipDeltaRegression : public cDeltaRegression {
       flags_ = (getInt("relativeDelta") ? SMILEHIP_DELTA_RELATIVE : 0) | (hw ? SMILEHIP_DELTA_HALFWAVE : 0) |
                ((!hw && getInt("absOutput")) ? SMILEHIP_DELTA_ABS : 0) | (segs_ ? SMILEHIP_DELTA_SEGMENTS : 0);
       plain_ = (W_ > 0 && !(flags_ & ~SMILEHIP_DELTA_SEGMENTS)) ? 1 : 0;     // the two forms the window-op kernels have had since round 1 / 2
-      if (segs_ && W_ > 0) {                               // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
+      if (segs_) {                                         // the norm member the onlyInSegments branch keeps adding to (:77-79, :129)
         float n0 = 0.0f;
         for (int i = 1; i <= W_; i++) n0 += (float)i * (float)i;
         n0 *= 2.0f;
@@ -91,10 +91,16 @@ class cHipDeltaRegression : public cDeltaRegression {
       return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
     }
     // every block between the padded ones at the two ends of the input in one tick (plugin_block.hpp); onlyInSegments carries its
-    // divisor from value to value in processing order and keeps the reference's ticks
+    // divisor from value to value in the order of the reference's ticks: its block operator walks the block in that order
+    wblock_.restore(this);
     options();
-    if (!segs_ && wblock_.tick(this, 0, W_, flags_ & ~SMILEHIP_DELTA_SEGMENTS, &g_frames[10])) return TICK_SUCCESS;
+    if (wblock_.tick(this, segs_ ? 3 : 0, W_, flags_ & ~SMILEHIP_DELTA_SEGMENTS, &g_frames[10], row_.d_norm)) return TICK_SUCCESS;
     return cDeltaRegression::myTick(t);
+  }
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cDeltaRegression::configureWriter(c);
+    if (r) wblock_.configure(this, c);
+    return r;
   }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     options();
@@ -136,9 +142,15 @@ class cHipContourSmoother : public cContourSmoother {
       if (isEOI()) return TICK_INACTIVE;
       return g_fused.tick_write(*ftick_.lvl, writer_, ftick_.next, ftick_.block, blocksizeW_);
     }
+    wblock_.restore(this);
     options();
     if (plain_ && wblock_.tick(this, nz_ ? 2 : 1, W_, 0, &g_frames[11])) return TICK_SUCCESS;   // (plugin_block.hpp)
     return cContourSmoother::myTick(t);
+  }
+  int configureWriter(sDmLevelConfig &c) override {
+    const int r = cContourSmoother::configureWriter(c);
+    if (r) wblock_.configure(this, c);
+    return r;
   }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     options();

@@ -20,6 +20,8 @@
 // This file is compiled with the HOST g++ against the reference's headers
 // (ABI-coupled to libopensmile.so); it contains no HIP code.
 #include <core/componentManager.hpp>
+#include <core/configManager.hpp>
+#include <core/commandlineParser.hpp>
 #include <core/dataSource.hpp>
 #include <core/smileCommon.hpp>
 #include <iocore/waveSource.hpp>
@@ -128,6 +130,7 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 // The loader's entry point: type registerFunction, src/include/core/componentManager.hpp:23
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
+  g_confman = confman;                                      // the parsed graph lives there (plugin_shared.hpp: FusedChain::init)
   const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-eight
   auto want = [&](const char *name) {                       // whole names of the comma-separated list
     if (!only) return true;

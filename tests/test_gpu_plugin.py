@@ -370,14 +370,16 @@ def test_plugin_egemaps_whole_graph(oracle):
         assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (k, np.abs(y[0].astype(np.float64) - ref[0]).max())
 
 
-def test_plugin_logs_cpu_fallthrough(oracle, golden_synth):
-    """An option set the HIP path does not cover runs the reference's code, with a warning in the log and a counter in the
-    trace -- never silently: config/mfcc/MFCC12_0_D_A.conf with cMfcc doLog = 0 is not built."""
+def test_plugin_option_set_not_built_is_an_error(oracle, golden_synth):
+    """An option set the HIP path does not cover is an ERROR of the component, named in the log -- the shipped library has no CPU
+    fall-through at all (round 6: the development switch is a compile-time flag, -DSMILEHIP_DEV_CPU_FALLTHROUGH; the environment
+    variable of earlier rounds does nothing): config/mfcc/MFCC12_0_D_A.conf with cMfcc doLog = 0 is not built."""
     import tempfile
     exe = os.path.join(oracle.REF_DIR, "SMILExtract")
     plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
     if not (os.path.exists(exe) and os.path.exists(plug)):
         pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    assert b"SMILEHIP_PLUGIN_ALLOW_CPU" not in open(plug, "rb").read()
     with tempfile.TemporaryDirectory() as td:
         conf = os.path.join(td, "m.conf")
         base = os.path.join(oracle.REF_DIR, "config", "mfcc", "MFCC12_0_D_A.conf")
@@ -389,18 +391,12 @@ def test_plugin_logs_cpu_fallthrough(oracle, golden_synth):
         env = dict(os.environ)
         env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
         env["SMILEHIP_PLUGIN_TRACE"] = trace
-        # default (round 3): an option set that is not built is an error of the component, named in the log
-        r = subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "2"], cwd=PLUGDIR, env=env, capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode != 0 and "SMILEHIP_PLUGIN_ALLOW_CPU" in (r.stderr + r.stdout), (r.returncode, (r.stderr + r.stdout)[-1500:])
-        # opt-in: the reference's own code runs, logged and counted
-        env["SMILEHIP_PLUGIN_ALLOW_CPU"] = "1"
-        r = subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "2"], cwd=PLUGDIR, env=env, capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        tr = dict(l.split() for l in open(trace).read().split("\n") if l.strip())
-        assert int(tr["cMfcc.cpu"]) == 98 and int(tr["cMfcc"]) == 0
-        assert "runs the reference's CPU code" in (r.stderr + r.stdout)
+        for extra in ({}, {"SMILEHIP_PLUGIN_ALLOW_CPU": "1"}):
+            e = dict(env)
+            e.update(extra)
+            r = subprocess.run([exe, "-C", conf, "-I", wav, "-O", out, "-l", "2"], cwd=PLUGDIR, env=e, capture_output=True, text=True,
+                               timeout=300)
+            assert r.returncode != 0 and "not built for the HIP path" in (r.stderr + r.stdout), (r.returncode, (r.stderr + r.stdout)[-1500:])
 
 
 def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
@@ -743,8 +739,8 @@ def test_plugin_modulation_family(oracle):
 
 def test_plugin_refuses_what_is_not_built(oracle):
     """A cFunctionals instance with an option that is not an operator of the library (Segments.growDynSegBuffer: the segment buffer
-    that grows past maxNumSeg): the override says so and the process fails (no silent CPU path); with SMILEHIP_PLUGIN_ALLOW_CPU=1 that
-    instance runs the reference's own code, counted, and the taps equal the plain binary's."""
+    that grows past maxNumSeg): the override says so and the process fails -- no CPU path, silent or otherwise, in the shipped library
+    (the environment variable of earlier rounds changes nothing)."""
     pcm = _segments_pcm()
     with tempfile.TemporaryDirectory() as td:
         conf = os.path.join(td, "grow.conf")
@@ -754,10 +750,8 @@ def test_plugin_refuses_what_is_not_built(oracle):
         open(conf, "w").write(text.replace(key, key + "Segments.growDynSegBuffer = 1\n", 1))
         _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals"}, conf,
                   expect_fail="cFunctionals: a functional family or option of this instance is not built")
-        ref, _ = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
-        own, tr = _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals", "SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf)
-        assert 0 < tr.get("cFunctionals.cpu", 0) <= 2 and tr.get("cFunctionals", 0) >= 14, tr
-        assert own == ref
+        _run_taps(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "cFunctionals", "SMILEHIP_PLUGIN_ALLOW_CPU": "1"}, conf,
+                  expect_fail="cFunctionals: a functional family or option of this instance is not built")
 
 
 @pytest.mark.parametrize("conf", ["avec11-14/avec2011.conf", "avec11-14/avec2013.conf"])
