@@ -403,11 +403,15 @@ struct FusedChain {
       }
       cCommandlineParser *cp = cm ? cm->cmdparser : nullptr;
       const smilehip_host::ConfCmValue cm_value = [cp](const std::string &name, std::string &value) {
-        if (!cp || !cp->optionExists(name.c_str())) return false;
-        const char *v = cp->getStr(name.c_str());
-        if (!v) return false;
-        value = v;
-        return true;
+        const sCmdlineOpt *o = cp ? cp->findOpt(name.c_str()) : nullptr;
+        if (!o) return false;
+        char buf[64];
+        switch (o->type) {                                 // (the host program may have registered an option with a type of its own: SMILExtract's -start / -end are doubles)
+          case eCmdlineOptType::Str: value = o->getStr(); return true;
+          case eCmdlineOptType::Int: if (!o->isSet) return false; snprintf(buf, sizeof(buf), "%d", o->getInt()); value = buf; return true;
+          case eCmdlineOptType::Double: if (!o->isSet) return false; snprintf(buf, sizeof(buf), "%.17g", o->getDouble()); value = buf; return true;
+          default: if (!o->isSet) return false; value = o->getBoolean() ? "1" : "0"; return true;
+        }
       };
       if (sections.empty() || !smilehip_host::conf_from_sections(sections, cm_value, cf, err)) {
         FUSE_NOTE("libsmilehip plugin: fused mode: the configuration manager holds no file the host library's reader understands (%s) -- block-per-tick path", err.c_str());
