@@ -108,8 +108,7 @@ class BlockVP : public B {
     return r;
   }
   eTickResult myTick(long long t) override {
-    g_fused.init();
-    if (!block_mode() || g_fused.active || this->isEOI() || this->processArrayFields == 2 || !blockCapable()) return B::myTick(t);
+    if (!block_mode() || this->isEOI() || this->processArrayFields == 2 || !blockCapable()) return B::myTick(t);
     cDataReader *rd = this->reader_;
     const long avail = rd->getNAvail();
     if (avail < 1 || rd->curR < 0) return B::myTick(t);
@@ -175,7 +174,9 @@ class cHipFramer : public cFramer {
   eTickResult myTick(long long t) override {
     cDataReader *rd = reader_;
     g_fused.init();
-    if (!block_mode() || g_fused.active || isEOI() || frameMode != FRAMEMODE_FIXED || allow_last_frame_incomplete_ || wholeMatrixMode || Ni != 1 ||
+    // fused mode (plugin_shared.hpp): the samples of the wave level go to the batch, the frame level stays empty
+    if (g_fused.active && rd->nLevels == 1 && Ni == 1) return isEOI() ? TICK_INACTIVE : g_fused.feed_tick(rd, this);
+    if (!block_mode() || isEOI() || frameMode != FRAMEMODE_FIXED || allow_last_frame_incomplete_ || wholeMatrixMode || Ni != 1 ||
         rd->nLevels != 1 || rd->stepM <= 0 || rd->lengthM <= 0 || rd->curR < 0 || No != rd->lengthM)
       return cFramer::myTick(t);
     const long s = rd->curR, step = rd->stepM, len = rd->lengthM;
@@ -255,7 +256,7 @@ struct WinBlock {
   bool tick(C *c, int op, int W, int delta_flags, long *counter, float *d_norm = nullptr) {
     cDataReader *rd = c->reader_;
     const long bs = rd->stepM, win = c->winsize, pre = c->pre, post = c->post;
-    if (!block_mode() || g_fused.active || c->isEOI() || rd->nLevels < 1 || bs < 1 || rd->lengthM != bs + win || rd->curR < 0 || c->multiplier != 1 ||
+    if (!block_mode() || c->isEOI() || rd->nLevels < 1 || bs < 1 || rd->lengthM != bs + win || rd->curR < 0 || c->multiplier != 1 ||
         win != pre + post || pre < (W > 0 ? W : 1) || post < W) {
       BLOCK_DBG("%s: window tick refused: eoi %d levels %d bs %ld lengthM %ld win %ld curR %ld mult %d pre %ld post %ld W %d", c->getInstName(), (int)c->isEOI(),
                 rd->nLevels, bs, rd->lengthM, win, rd->curR, (int)c->multiplier, pre, post, W);

@@ -313,7 +313,10 @@ class cHipPitchJitter : public cPitchJitter {
   }
   eTickResult myTick(long long t) override {
     g_fused.init();
-    if (g_fused.big) return cPitchJitter::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
+    if (g_fused.big) {                                     // big-set fused mode: the jitter columns come from the batch; the wave level's samples are only passed by
+      reader_->catchupCurR();
+      return TICK_INACTIVE;
+    }
     if (!ready_) {
       ready_ = true;
       usable_ = !jitterLocalEnv && !jitterDDPEnv && !shimmerLocalEnv && !shimmerLocalDBEnv && !shimmerUseRmsAmplitude && !harmonicERMS &&

@@ -76,16 +76,15 @@ class cHipEnergy : public BlockVP<cEnergy> {
   }
 };
 
-// cWaveSource (src/iocore/waveSource.cpp:240-294) inside a fused chain: the batch read the file itself, the components that hand
-// out its rows do so at the tick level (FusedChain::tick_write) -- the source has nothing to feed anybody and idles; every
-// component between it and the chain's last ones then finds no data and idles with it. Outside a tick-level fused chain it is
-// the reference's source, untouched.
+// cWaveSource (src/iocore/waveSource.cpp:240-294): the reference's source, untouched -- it reads the file and writes its level block
+// after block. The override only tells the fused chain (plugin_shared.hpp) when the last block has been written: the batch over the
+// whole input starts then.
 class cHipWaveSource : public cWaveSource {
  protected:
   eTickResult myTick(long long t) override {
-    g_fused.init();
-    if (g_fused.active && g_fused.tick_mode) return TICK_INACTIVE;
-    return cWaveSource::myTick(t);
+    const eTickResult r = cWaveSource::myTick(t);
+    if (eof) g_fused.source_eof = true;
+    return r;
   }
  public:
   explicit cHipWaveSource(const char *n) : cWaveSource(n) {}

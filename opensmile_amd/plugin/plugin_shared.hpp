@@ -3,7 +3,8 @@
 
 // ---------------------------------------------------------------- shared state
 smilehip_context *g_ctx = nullptr;
-cConfigManager *g_confman = nullptr;     // the loader's configuration manager (registerPluginComponent's first argument)
+cConfigManager *g_confman = nullptr;     // the loader's configuration manager and component manager (registerPluginComponent's arguments)
+cComponentManager *g_compman = nullptr;
 constexpr int kNumOverrides = 28;
 long g_frames[kNumOverrides] = {0};
 long g_cpu[kNumOverrides] = {0};       // frames an overridden component handed to the reference's own CPU code (option set not built)
@@ -182,15 +183,23 @@ void check(int rc) {
 }
 
 // ---------------------------------------------------------------- fused mode for UNMODIFIED configuration files
-// SMILEHIP_PLUGIN_FUSE=1: the first overridden component that is asked for a frame reads the process's own command line
-// (-C file.conf and the options the file defines), parses the file with the host library's reader (conf_plan.cpp) and, if
-// the graph is a cepstral chain, runs the WHOLE input file through the fused kernels in one batch. From then on the
-// per-frame stages of the chain (pre-emphasis .. mel bank) only mark their frames, and cMfcc / cPlp / cEnergy copy their
-// rows out of the batch result: one device round trip per file instead of one per frame and component. Everything
-// downstream (mean normalisation, delta regression, concatenation, sinks) runs the reference's own code on those rows,
-// at the reference's own ticks. Graphs that are not expressible stay on the per-component path (a warning says why).
+// A graph the host library's reader recognises (a cepstral chain of config/mfcc / config/plp, or one of the big sets:
+// IS09_emotion, ComParE_2016, IS13_ComParE, eGeMAPSv02) whose audio comes from a cWaveSource -- a FINITE input -- runs through the
+// fused kernels as ONE batch, behind the data memory on both sides:
+//   * the graph is the one the loader's cConfigManager holds (no second look at the command line, no second reading of the file);
+//   * the samples are the ones the reference's own cWaveSource writes to its level: the framer overrides (cHipFramer) take them
+//     from the level with their readers, block after block, and keep them; nothing else of the chain sees data (the levels between
+//     the framers and the chain's last components stay empty -- not zero-filled);
+//   * when the source has delivered its last block, the batch runs once (smilehip_lld_run on the int16 image of the samples when
+//     every sample is one -- a 16-bit file --, smilehip_lld_run_f32 otherwise: any sample format / channel mix-down), and the
+//     chain's LAST components write the finished rows to their own levels with setNextMatrix, a block per tick, with the time
+//     stamps the framer would have given them (FusedChain::tick_write). Sinks, cFunctionals instances and everything else
+//     downstream read them as they read the reference's rows.
+// An input that is not a cWaveSource (cExternalAudioSource, a live source: no end to wait for), a graph the reader does not
+// recognise, or a run with only some overrides registered takes the block-per-tick path (plugin_block.hpp) instead.
+// SMILEHIP_PLUGIN_FUSE=0: block-per-tick everywhere; =1: say loudly why a graph does not fuse.
 long g_fused_stage = 0;
-// a level the fused batch supplies: rows of a host matrix, a column per element of the level (no columns: zeros)
+// a level the fused batch supplies: rows of a host matrix, a column per element of the level
 struct FusedLevel {
   const std::vector<float> *M = nullptr;
   int ld = 0;
@@ -201,11 +210,15 @@ struct FusedLevel {
 };
 struct FusedChain {
   bool tried = false, active = false;
-  // big = an unmodified big-set file (IS09_emotion, ComParE_2016, IS13_ComParE, eGeMAPSv02 and its sub-graphs): the whole LLD
-  // level comes from ONE fused batch; the components that write the levels the sinks and the cFunctionals instances read
-  // (the final cContourSmoother / cDeltaRegression instances, eGeMAPS' energy level) hand out its rows, every overridden
-  // component upstream of them writes zeros (nobody downstream of the fused levels reads those), the cFunctionals overrides
-  // run as HIP operators on the handed-out levels.
+  bool ran = false;                                       // the batch has run: the rows exist
+  bool source_eof = false;                                // the wave source has written its last block (cHipWaveSource)
+  std::vector<float> pcm;                                 // the wave level's samples, as the framer overrides took them from it
+  const void *feeder = nullptr;                           // the framer instance that keeps the samples (the others only drain their readers)
+  double sample_rate = 16000.0;
+  // big = an unmodified big-set file (IS09_emotion, ComParE_2016, IS13_ComParE, eGeMAPSv02): the whole LLD level comes from ONE
+  // fused batch; the components that write the levels the sinks and the cFunctionals instances read (the final cContourSmoother /
+  // cDeltaRegression instances, eGeMAPS' energy level) hand out its rows; the functionals of IS09 / ComParE / IS13 are the batch's
+  // own vector, eGeMAPS' cFunctionals instances run as HIP operators on the handed-out levels.
   bool big = false;
   smilehip_host::ConfPlan plan;
   std::vector<float> rows, fin, b_extra;
@@ -233,29 +246,80 @@ struct FusedChain {
     if (it != levels.end()) return &it->second;
     return big ? &zero_level : nullptr;
   }
-  void add_level(const std::string &name, const std::vector<float> *M, int ld, long nr, int c0, int n) {
+  void add_level(const std::string &name, const std::vector<float> *M, int ld, int c0, int n, bool lld_t = true) {
     FusedLevel L;
-    L.M = M; L.ld = ld; L.n_rows = nr;
+    L.M = M; L.ld = ld; L.n_rows = 0; L.lld_times = lld_t;
     for (int i = 0; i < n; ++i) L.cols.push_back(c0 + i);
     levels[name] = L;
   }
-  // the big sets: one batch of the preset's chain over the whole file
-  bool init_big(const smilehip_host::WaveInfo &wi, const std::vector<unsigned char> &raw) {
+  void config_big(smilehip_lld_config &c) const {
     const std::string &ps = plan.preset;
-    smilehip_lld_config c;
-    const bool egm = ps == "egemapsv02";                   // (the GeMAPS sub-graph files have other level names: per-component path)
     if (ps == "is09_emotion") smilehip_config_is09_lld(&c);
     else if (ps == "compare16") smilehip_config_compare16(&c);
     else if (ps == "is13_compare") smilehip_config_is13_compare(&c);
-    else if (egm) smilehip_config_egemapsv02(&c);
-    else return false;
+    else smilehip_config_egemapsv02(&c);
     smilehip_host::conf_apply_f0_params(plan, c);
-    c.sample_rate = (double)wi.sample_rate;
+    c.sample_rate = sample_rate;
+  }
+  // the levels the batch will supply, by name (the overrides look theirs up at their first tick; the rows arrive with run())
+  void declare_levels() {
+    const std::string &ps = plan.preset;
+    if (ps.empty()) {
+      if (final_level) add_level(plan.out_levels, &rows, 0, 0, 0);
+      else for (const auto &kv : plan.static_levels) { FusedLevel L; L.M = &rows; L.cols = kv.second; levels[kv.first] = L; }
+    } else if (ps == "is09_emotion") {
+      add_level("is09_lld", &rows, 32, 0, 16);
+      add_level("is09_lld_de", &rows, 32, 16, 16);
+    } else if (ps == "compare16" || ps == "is13_compare") {
+      add_level("is13_lld_nzsmo", &rows, 130, 0, 6);
+      add_level("is13_lldA_smo", &rows, 130, 6, 4);
+      add_level("is13_lldB_smo", &rows, 130, 10, 55);
+      add_level("is13_lld_nzsmo_de", &rows, 130, 65, 6);
+      add_level("is13_lldA_smo_de", &rows, 130, 71, 4);
+      add_level("is13_lldB_smo_de", &rows, 130, 75, 55);
+    } else {
+      const std::string g1 = "gemapsv01b";               // names of the included core file
+      // the LLD level's two halves, and the levels the functionals read (lld_params.hpp: func_in's 36 columns)
+      add_level("egemapsv02_lldsetE_smo", &rows, 25, 0, 10);
+      add_level("egemapsv02_lldsetF_smo", &rows, 25, 10, 15);
+      add_level(g1 + "_loudness_smo", &fin, 36, 0, 1, false);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessZ_smo", &fin, 36, 1, 5, false);
+      add_level(g1 + "_lld_single_logF0_smo", &fin, 36, 6, 1, false);
+      add_level("egemapsv02_lldSetNoF0AndLoudnessNz_smo", &fin, 36, 7, 14, false);
+      add_level("egemapsv02_lldSetSpectralNz_smo", &fin, 36, 21, 9, false);
+      add_level("egemapsv02_lldSetSpectralZ_smo", &fin, 36, 30, 5, false);
+      add_level("egemapsv02_energyRMS", &fin, 36, 35, 1, false);
+    }
+  }
+  void set_rows(const std::vector<float> *M, long nr, int ld) {
+    for (auto &kv : levels) if (kv.second.M == M) { kv.second.n_rows = nr; kv.second.ld = ld; }
+  }
+  // The batch, once: every sample the wave source wrote is in `pcm`.
+  void run() {
+    if (ran) return;
+    ran = true;
+    const int64_t n = (int64_t)pcm.size();
+    // the int16 image of the samples, when every sample is one (cWaveSource's 16-bit conversion is s / 32767.0f, smileUtil.c:2527-2535)
+    std::vector<int16_t> s16((size_t)(n > 0 ? n : 1));
+    bool is16 = true;
+    for (int64_t i = 0; i < n && is16; ++i) {
+      const float r = nearbyintf(pcm[(size_t)i] * 32767.0f);
+      is16 = r >= -32768.0f && r <= 32767.0f && (float)(int16_t)r / 32767.0f == pcm[(size_t)i];
+      s16[(size_t)i] = (int16_t)r;
+    }
+    smilehip_lld_config c;
+    const std::string &ps = plan.preset;
+    const bool egm = ps == "egemapsv02";
+    if (!ps.empty()) config_big(c);
+    else {
+      c = plan.cfg;
+      c.sample_rate = sample_rate;
+      if (!final_level) { c.n_delta = 0; c.cms = 0; }    // the static block only: mean normalisation and deltas stay with the reference's components
+    }
     smilehip_plan *pl = nullptr;
     check(smilehip_plan_create(context(), &c, &pl));
     smilehip_geometry g;
     check(smilehip_plan_geometry(pl, &g));
-    const int64_t n = (int64_t)(raw.size() / 2);
     const int64_t off[2] = {0, n};
     smilehip_batch *b = nullptr;
     check(smilehip_batch_create(pl, off, 1, &b));
@@ -265,12 +329,17 @@ struct FusedChain {
     long fin_rows = 0;
     if (n_rows > 0) {
       void *d_pcm = nullptr, *d_lld = nullptr;
-      check(smilehip_alloc(context(), (uint64_t)(n > 0 ? n : 1) * 2, &d_pcm));
+      check(smilehip_alloc(context(), (uint64_t)(n > 0 ? n : 1) * (is16 ? 2 : 4), &d_pcm));
       check(smilehip_alloc(context(), (uint64_t)n_rows * n_cols * 4, &d_lld));
-      check(smilehip_copy_to_device(context(), d_pcm, raw.data(), (uint64_t)n * 2, nullptr));
-      check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, n_cols, nullptr));
+      if (is16) {
+        check(smilehip_copy_to_device(context(), d_pcm, s16.data(), (uint64_t)n * 2, nullptr));
+        check(smilehip_lld_run(pl, b, (const int16_t *)d_pcm, (float *)d_lld, n_cols, nullptr));
+      } else {
+        check(smilehip_copy_to_device(context(), d_pcm, pcm.data(), (uint64_t)n * 4, nullptr));
+        check(smilehip_lld_run_f32(pl, b, (const float *)d_pcm, (float *)d_lld, n_cols, nullptr));
+      }
       check(smilehip_copy_to_host(context(), rows.data(), d_lld, (uint64_t)n_rows * n_cols * 4, nullptr));
-      if (ps != "is09_emotion") {
+      if (big && ps != "is09_emotion") {
         const int32_t *d_pend = nullptr;
         int32_t pend = 0;
         check(smilehip_batch_f0_pending(b, &d_pend));
@@ -285,7 +354,7 @@ struct FusedChain {
         b_extra.assign(110, 0.0f);
         check(smilehip_copy_to_host(context(), b_extra.data(), d_ex, 110 * 4, nullptr));
       }
-      {                                                    // the set's functionals level, on the device-resident LLD matrix
+      if (big) {                                           // the set's functionals level, on the device-resident LLD matrix
         int nf = 0;
         if (ps == "is09_emotion") nf = 384;
         else if (ps == "compare16" || ps == "is13_compare") nf = smilehip_functionals_compare16_count();
@@ -324,12 +393,8 @@ struct FusedChain {
       check(smilehip_stream_synchronize(context(), nullptr));
       smilehip_free(context(), d_pcm); smilehip_free(context(), d_lld);
     }
-    {                                                      // tick-level hand-out (round 5): the LLD level's time stamps, as cHipLldSource gives them
-      const char *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
-      // (eGeMAPS keeps the per-frame hand-out: its cFunctionals instances run as operators on the handed-out levels and count the
-      // rows the reference's end-of-input rules leave in them; the other sets' functionals come from the batch's own vector)
-      tick_mode = !egm && !(tm && !strcmp(tm, "0"));
-      const int64_t n_frames = (ps == "is09_emotion") ? smilehip_num_frames(pl, n) : (int64_t)n_rows - 1;
+    {                                                      // the rows' time stamps, as the framer and the window processors give them
+      const int64_t n_frames = (!big || ps == "is09_emotion") ? smilehip_num_frames(pl, n) : (int64_t)n_rows - 1;
       times.assign((size_t)(n_rows > 0 ? n_rows : 1), 0.0);
       for (long t = 0; t < n_rows; ++t) times[(size_t)t] = smilehip_row_time(pl, n_frames, t);
       frame_size_sec = c.frame_size_sec;
@@ -337,50 +402,45 @@ struct FusedChain {
     }
     smilehip_batch_destroy(b);
     smilehip_plan_destroy(pl);
-    if (ps == "is09_emotion") {
-      add_level("is09_lld", &rows, n_cols, n_rows, 0, 16);
-      add_level("is09_lld_de", &rows, n_cols, n_rows, 16, 16);
-    } else if (ps == "compare16" || ps == "is13_compare") {
-      add_level("is13_lld_nzsmo", &rows, n_cols, n_rows, 0, 6);
-      add_level("is13_lldA_smo", &rows, n_cols, n_rows, 6, 4);
-      add_level("is13_lldB_smo", &rows, n_cols, n_rows, 10, 55);
-      add_level("is13_lld_nzsmo_de", &rows, n_cols, n_rows, 65, 6);
-      add_level("is13_lldA_smo_de", &rows, n_cols, n_rows, 71, 4);
-      add_level("is13_lldB_smo_de", &rows, n_cols, n_rows, 75, 55);
-      if (b_extra.size() == 110) {
-        levels["is13_lldB_smo"].extra.assign(b_extra.begin(), b_extra.begin() + 55);
-        levels["is13_lldB_smo_de"].extra.assign(b_extra.begin() + 55, b_extra.end());
-      }
-    } else {
-      const std::string g1 = "gemapsv01b";               // names of the included core file
-      // the LLD level's two halves, and the levels the functionals read (lld_params.hpp: func_in's 36 columns)
-      add_level("egemapsv02_lldsetE_smo", &rows, n_cols, n_rows, 0, 10);
-      add_level("egemapsv02_lldsetF_smo", &rows, n_cols, n_rows, 10, 15);
-      add_level(g1 + "_loudness_smo", &fin, 36, fin_rows, 0, 1);
-      add_level("egemapsv02_lldSetNoF0AndLoudnessZ_smo", &fin, 36, fin_rows, 1, 5);
-      add_level(g1 + "_lld_single_logF0_smo", &fin, 36, fin_rows, 6, 1);
-      add_level("egemapsv02_lldSetNoF0AndLoudnessNz_smo", &fin, 36, fin_rows, 7, 14);
-      add_level("egemapsv02_lldSetSpectralNz_smo", &fin, 36, fin_rows, 21, 9);
-      add_level("egemapsv02_lldSetSpectralZ_smo", &fin, 36, fin_rows, 30, 5);
-      add_level("egemapsv02_energyRMS", &fin, 36, fin_rows, 35, 1);
-      for (auto &kv : levels) if (kv.second.M == &fin) kv.second.lld_times = false;
+    set_rows(&rows, n_rows, n_cols);
+    if (final_level) { FusedLevel &L = levels[plan.out_levels]; L.cols.clear(); for (int i = 0; i < n_cols; ++i) L.cols.push_back(i); }
+    if (b_extra.size() == 110) {
+      levels["is13_lldB_smo"].extra.assign(b_extra.begin(), b_extra.begin() + 55);
+      levels["is13_lldB_smo_de"].extra.assign(b_extra.begin() + 55, b_extra.end());
     }
-    big = true;
-    active = true;
-    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld rows of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
-    return true;
+    if (egm && n_rows > 0) {
+      // The rows a cFunctionals instance of the eGeMAPS files summarises are the ones its input level holds at its first
+      // end-of-input tick (csrc/smilehip_funcspec.cpp: kEgemapsParts, measured against the binary): with T20 / T60 the frames of
+      // the 20 ms / 60 ms framers and P the frames the Viterbi pass had not decided at the end of input -- 20 ms levels T20; the
+      // levels behind the Viterbi smoother max(1, T60 - P); the voiced-only levels, which also wait for cPitchJitter, T60 - P, or
+      // T60 when P = T60. Those rows are handed out; what the window processors would add afterwards nobody reads.
+      const long T20 = fin_rows - 1, T60 = n_rows - 1, P = f0_pending;
+      const long behind = T60 - P > 1 ? T60 - P : 1, voiced = P < T60 ? T60 - P : T60;
+      set_rows(&fin, 0, 36);
+      const std::string g1 = "gemapsv01b";
+      levels[g1 + "_loudness_smo"].n_rows = T20;
+      levels["egemapsv02_lldSetNoF0AndLoudnessZ_smo"].n_rows = T20;
+      levels["egemapsv02_energyRMS"].n_rows = T20;
+      levels[g1 + "_lld_single_logF0_smo"].n_rows = behind;
+      levels["egemapsv02_lldSetSpectralZ_smo"].n_rows = behind;
+      levels["egemapsv02_lldSetNoF0AndLoudnessNz_smo"].n_rows = voiced;
+      levels["egemapsv02_lldSetSpectralNz_smo"].n_rows = voiced;
+    }
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld rows from %ld samples of the wave level in one batch (%s samples)", plan.describe.c_str(), n_rows,
+              (long)n, is16 ? "16-bit" : "float");
+    std::vector<float>().swap(pcm);
   }
   void init() {
     if (tried) return;
     tried = true;
-    // Round 5: fused mode is the DEFAULT whenever the file's graph is one the host library's reader recognises (conf_plan.cpp) and
-    // the input is a 16-bit mono wave file; SMILEHIP_PLUGIN_FUSE=0 keeps every component on its own operator (one device round
-    // trip per frame and component: the parity vehicle, ~100 x slower than the fused batch), =1 asks for it loudly (warnings say
-    // why a file does not fuse; by default those are messages of level 3).
     const char *on = getenv("SMILEHIP_PLUGIN_FUSE");
     if (on && !strcmp(on, "0")) return;
     const bool loud = on && *on;
 #define FUSE_NOTE(...) do { if (loud) { SMILE_WRN(1, __VA_ARGS__); } else { SMILE_MSG(3, __VA_ARGS__); } } while (0)
+    {                                                      // every override registered: the chain's last components must be the ones that hand out rows
+      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
+      if (only && *only && strcmp(only, "all")) { FUSE_NOTE("libsmilehip plugin: fused mode needs every override registered -- block-per-tick path"); return; }
+    }
     // The graph is the one the loader's cConfigManager holds (registerPluginComponent stored the pointer): its file reader keeps
     // every section of the configuration file as raw "field = value" lines, includes expanded (configManager.hpp:475-482, :567-610),
     // and its command-line parser knows the effective value of every \\cm[...] option the file defines -- whether the host is
@@ -422,70 +482,56 @@ struct FusedChain {
       FUSE_NOTE("libsmilehip plugin: fused mode: %s -- block-per-tick path", err.c_str());
       return;
     }
-    smilehip_host::WaveInfo wi;
-    std::vector<unsigned char> raw;
-    if (!smilehip_host::read_wave_file(plan.wave_file, wi, raw, err) || wi.sample_type != 1 || wi.n_bps != 2 || wi.n_chan != 1) {
-      FUSE_NOTE("libsmilehip plugin: fused mode: '%s' is not a 16-bit mono PCM file (%s) -- block-per-tick path", plan.wave_file.c_str(), err.c_str());
+    if (!plan.preset.empty() && (plan.last_mfcc > 0 || !plan.func_enabled.empty())) {
+      FUSE_NOTE("libsmilehip plugin: fused mode: an edited big-set file (lastMfcc / functionalsEnabled) -- block-per-tick path");
       return;
     }
-    if (!plan.preset.empty()) {
-      // the big sets fuse only with EVERY override registered: the final smoother / delta instances must be the ones that hand out rows
-      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");
-      const bool all = !only || !*only || !strcmp(only, "all");
-      if (!all || plan.last_mfcc > 0 || !plan.func_enabled.empty() || !init_big(wi, raw))
-        FUSE_NOTE("libsmilehip plugin: fused mode: this big-set file does not fuse inside the reference process -- block-per-tick path");
-      return;
-    }
-    smilehip_lld_config c = plan.cfg;
-    c.sample_rate = (double)wi.sample_rate;
-    // Where the rows are handed out. FINAL (round 5): the sinks read one level written by a cVectorConcat, every override is
-    // registered -> the batch computes the file's whole output level (mean normalisation, regression stages: what smilextract_hip
-    // writes for the same file) and cHipVectorConcat writes it at the tick level; nothing upstream of it ever ticks with data.
-    // Otherwise the static block only: mean normalisation, deltas and concatenation stay with the reference's components.
+    // The input must end: ONE cWaveSource writes the level every cFramer reads, one channel (a file of one, or monoMixdown).
     {
-      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS"), *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
-      const bool all = !only || !*only || !strcmp(only, "all");
-      final_level = all && plan.out_writer_type == "cVectorConcat" && !(tm && (!strcmp(tm, "0") || !strcmp(tm, "static")));
-    }
-    if (!final_level) {
-      c.n_delta = 0;                                      // the static block is all the chain components hand on;
-      c.cms = 0;                                          // mean normalisation and deltas stay with the reference's components
-    }
-    smilehip_plan *pl = nullptr;
-    check(smilehip_plan_create(context(), &c, &pl));
-    smilehip_geometry g;
-    check(smilehip_plan_geometry(pl, &g));
-    const int64_t n = (int64_t)(raw.size() / 2);
-    const int64_t off[2] = {0, n};
-    smilehip_batch *b = nullptr;
-    check(smilehip_batch_create(pl, off, 1, &b));
-    n_rows = (long)smilehip_batch_total_rows(b);
-    n_cols = g.n_out;
-    rows.assign((size_t)(n_rows > 0 ? n_rows : 1) * n_cols, 0.0f);
-    if (n_rows > 0) check(smilehip_lld_run_host(pl, b, reinterpret_cast<const int16_t *>(raw.data()), n, rows.data()));
-    {                                                      // tick-level hand-out: needs the wave source's override (it idles) -- every component registered
-      const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS"), *tm = getenv("SMILEHIP_PLUGIN_FUSE_TICK");
-      const bool all = !only || !*only || !strcmp(only, "all");
-      tick_mode = all && !(tm && !strcmp(tm, "0"));        // SMILEHIP_PLUGIN_FUSE_TICK=0: the per-frame hand-out of round 3 (A/B switch)
-      const int64_t n_frames = smilehip_num_frames(pl, n);
-      times.assign((size_t)(n_rows > 0 ? n_rows : 1), 0.0);
-      for (long t = 0; t < n_rows; ++t) times[(size_t)t] = smilehip_row_time(pl, n_frames, t);
-      frame_size_sec = c.frame_size_sec;
-      frame_period_sec = c.frame_step_sec;
-    }
-    smilehip_batch_destroy(b);
-    smilehip_plan_destroy(pl);
-    if (final_level) {
-      add_level(plan.out_levels, &rows, n_cols, n_rows, 0, n_cols);
-    } else {
-      for (const auto &kv : plan.static_levels) {
-        FusedLevel L;
-        L.M = &rows; L.ld = n_cols; L.n_rows = n_rows; L.cols = kv.second;
-        levels[kv.first] = L;
+      std::string src_name, src_level;
+      int n_src = 0;
+      for (const smilehip_host::ConfInstance &i : cf.inst) {
+        if (i.type == "cWaveSource") { ++n_src; src_name = i.name; const std::string *l = i.find("writer.dmLevel"); src_level = l ? *l : ""; }
+        else if (i.type.size() > 6 && i.type.compare(i.type.size() - 6, 6, "Source") == 0 && i.type != "cHipLldSource") n_src += 2;
       }
+      bool ok = n_src == 1 && !src_level.empty();
+      for (const smilehip_host::ConfInstance &i : cf.inst)
+        if (ok && i.type == "cFramer") { const std::string *l = i.find("reader.dmLevel"); ok = l && *l == src_level; }
+      cWaveSource *ws = ok && g_compman ? dynamic_cast<cWaveSource *>(g_compman->getComponentInstance(src_name.c_str())) : nullptr;
+      if (!ws || !(ws->monoMixdown || ws->pcmParam.nChan == 1) || ws->pcmParam.sampleRate <= 0) {
+        FUSE_NOTE("libsmilehip plugin: fused mode: the audio does not come from one cWaveSource with one (mixed-down) channel -- block-per-tick path");
+        return;
+      }
+      sample_rate = (double)ws->pcmParam.sampleRate;
     }
+    big = !plan.preset.empty();
+    // Where the rows of a cepstral chain are handed out. FINAL: the sinks read one level written by a cVectorConcat -> the batch computes
+    // the file's whole output level (mean normalisation, regression stages) and cHipVectorConcat writes it; otherwise the static block
+    // only: mean normalisation, deltas and concatenation stay with the reference's components (block-per-tick).
+    final_level = !big && plan.out_writer_type == "cVectorConcat";
+    declare_levels();
+    tick_mode = true;
     active = true;
-    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: %ld frames of '%s' in one batch", plan.describe.c_str(), n_rows, plan.wave_file.c_str());
+    SMILE_MSG(2, "libsmilehip plugin: fused mode -- %s: the samples of the wave level go through the fused kernels in one batch (SMILEHIP_PLUGIN_FUSE=0: block-per-tick)",
+              plan.describe.c_str());
+  }
+  // A framer override's tick in fused mode: every sample its reader's level holds is taken (and kept, by the first framer that asks);
+  // when the source is done and the level is drained, the batch runs.
+  eTickResult feed_tick(cDataReader *rd, const void *who) {
+    if (ran) return TICK_INACTIVE;
+    if (!feeder) feeder = who;
+    if (rd->curR < 0) rd->curR = 0;
+    const long have = rd->dm->getCurW(rd->level[0]) - rd->curR;
+    if (have > 0) {
+      cMatrix *mat = rd->getMatrix(rd->curR, have);
+      if (!mat || mat->nT != have || mat->N != 1) COMP_ERR("libsmilehip plugin: fused mode: cannot read %ld samples of the wave level at %ld", have, rd->curR);
+      if (feeder == who) pcm.insert(pcm.end(), mat->data, mat->data + have);
+      rd->curR += have;
+      rd->catchupCurR(rd->curR);
+      return TICK_SUCCESS;
+    }
+    if (feeder == who && source_eof) { run(); return TICK_SUCCESS; }
+    return TICK_INACTIVE;
   }
   // ---- tick-level hand-out (round 5; the cepstral chains). The per-frame hand-out above still walks the reference's tick loop
   // once per frame for every component of the chain (framer, pre-emphasis, window, transform, magnitudes, mel bank: six levels
@@ -498,6 +544,7 @@ struct FusedChain {
   double frame_size_sec = 0.0, frame_period_sec = 0.0;
   // writes the next rows of L to `writer`; next = rows written so far by this component; block: the component's own matrix
   eTickResult tick_write(const FusedLevel &L, cDataWriter *writer, long &next, cMatrix *&block, long blocksize_w) {
+    if (!ran) return TICK_INACTIVE;                        // the source is still writing: the batch has not run yet
     const long total = L.n_rows + (L.extra.empty() ? 0 : 1);
     long n = total - next;
     if (n <= 0 || L.cols.empty()) return TICK_INACTIVE;

@@ -105,7 +105,6 @@ class cHipDeltaRegression : public cDeltaRegression {
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     options();
     if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
-    if (g_fused.active) return cDeltaRegression::processBuffer(in, out, pre, post);   // fused mode: the rows are already on the host, the reference's own regression is cheaper than a device round trip per block
     if (pre < (W_ > 0 ? W_ : 1) || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: a block without its window's history"); return cDeltaRegression::processBuffer(in, out, pre, post); }
     if (plain_) row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
     else row_.run_delta(in, out, pre, post, W_, flags_);   // relativeDelta / halfWaveRect / absOutput / deltawin = 0

@@ -131,6 +131,7 @@ sComponentInfo *override_of(regfn builtin, createfn mine, cConfigManager *c, cCo
 extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cComponentManager *compman, int iteration) {
   sComponentInfo *head = nullptr;
   g_confman = confman;                                      // the parsed graph lives there (plugin_shared.hpp: FusedChain::init)
+  g_compman = compman;
   const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-eight
   auto want = [&](const char *name) {                       // whole names of the comma-separated list
     if (!only) return true;

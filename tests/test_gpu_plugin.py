@@ -400,10 +400,9 @@ def test_plugin_option_set_not_built_is_an_error(oracle, golden_synth):
 
 
 def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
-    """SMILEHIP_PLUGIN_FUSE=1 with UNMODIFIED files of config/mfcc and config/plp: the plugin reads the configuration file
-    named on the process's own command line, runs the whole input through the fused kernels in one batch, and the chain's
-    components hand out its rows (no device round trip per frame); mean normalisation, deltas, concatenation and the sinks
-    stay the reference's. Same file as the plain CPU binary within the chain's tolerance."""
+    """SMILEHIP_PLUGIN_FUSE=1 with UNMODIFIED files of config/mfcc and config/plp: the plugin recognises the graph the loader's configuration
+    manager holds, takes the samples the reference's wave source writes from its level, runs the whole input through the fused
+    kernels in one batch, and the chain's last components hand out its rows through their own levels. Same file as the plain CPU binary within the chain's tolerance."""
     pcm = golden_synth["pcm_u10_16000"]
     for conf in ("mfcc/MFCC12_0_D_A.conf", "mfcc/MFCC12_E_D_A_Z.conf", "plp/PLP_0_D_A.conf", "plp/PLP_E_D_A.conf"):
         ref, _ = _run(oracle, pcm, {"SMILEHIP_PLUGIN_COMPONENTS": "none"}, conf)
@@ -416,10 +415,11 @@ def test_plugin_fused_mode_unmodified_confs(oracle, golden_synth):
         assert tr["fused.batch_frames"] == frames
         # round 5: the chain's last components write their rows at the tick level and the wave source idles -- no stage ever ticks
         assert tr["fused.rows"] >= frames and tr["fused.stage_frames"] == 0
-        # ... and the per-frame hand-out of round 3 (every stage of the chain still ticks, carrying zeros): the same file
-        y3, tr3 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "1", "SMILEHIP_PLUGIN_FUSE_TICK": "0"}, conf)
-        assert tr3["fused.stage_frames"] >= 4 * frames
-        assert (np.abs(y3 - y) / scale).max() <= 2e-6, conf     # (final-level hand-out: mean normalisation and regression inside the batch)
+        # ... and the block-per-tick path (round 6: every component keeps its own level and moves a block of frames per tick, on the
+        # reference-order kernels): the same file within the chain's tolerance, no batch
+        y3, tr3 = _run(oracle, pcm, {"SMILEHIP_PLUGIN_FUSE": "0"}, conf)
+        assert tr3["fused.batch_frames"] == 0 and tr3["block.ticks"] > 0 and tr3["cFramer"] == frames, tr3
+        assert (np.abs(y3 - ref) / scale).max() <= 1e-5, conf
         # no per-frame kernel launches in the chain: the stage counters stay at zero
         for comp in ("cVectorPreemphasis", "cWindower", "cTransformFFT", "cFFTmagphase", "cMelspec", "cMfcc", "cPlp", "cEnergy", "cDeltaRegression"):
             assert tr.get(comp, 0) == 0, (conf, comp, tr)
