@@ -493,6 +493,10 @@ int  smilehip_copy_to_host_2d(smilehip_context *ctx, void *h_dst, uint64_t h_pit
  * src/iocore/htkSink.cpp:183-202). */
 int  smilehip_alloc_host(smilehip_context *ctx, uint64_t bytes, void **h_ptr);
 int  smilehip_free_host(smilehip_context *ctx, void *h_ptr);
+/* ... and page-locking of memory the caller owns already (the plugin's block matrices are cMatrix objects of the data memory,
+ * src/core/dataMemoryLevel.cpp:459-472: their storage is the reference's own allocation). */
+int  smilehip_host_register(smilehip_context *ctx, void *h_ptr, uint64_t bytes);
+int  smilehip_host_unregister(smilehip_context *ctx, void *h_ptr);
 /* cHtkSink::myTick's byte order (src/iocore/htkSink.cpp:183-202: every value of a vector through smileHtk_SwapFloat on a
  * little-endian host) done on the device: d_dst[i] = big-endian image of d_src[i], n values; d_dst may equal d_src. The sink
  * then writes a file's rows with one write(). */

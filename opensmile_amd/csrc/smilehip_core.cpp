@@ -106,6 +106,18 @@ extern "C" int smilehip_free_host(smilehip_context *ctx, void *h_ptr) {
   if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
   return SMILEHIP_OK;
 }
+// page-locks host memory the caller owns (a block matrix of the plugin): copies to and from it then run at the link's rate
+extern "C" int smilehip_host_register(smilehip_context *ctx, void *h_ptr, uint64_t bytes) {
+  if (!ctx || !h_ptr || !bytes) return fail(SMILEHIP_ERR_INVALID, "smilehip_host_register: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_host_unregister(smilehip_context *ctx, void *h_ptr) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_host_unregister: null context");
+  if (h_ptr) HIP_TRY(hipHostUnregister(h_ptr));
+  return SMILEHIP_OK;
+}
 extern "C" int smilehip_htk_rows_be(smilehip_context *ctx, const float *d_src, int64_t n, void *d_dst, void *stream) {
   if (!ctx || n < 0 || (n && (!d_src || !d_dst))) return fail(SMILEHIP_ERR_INVALID, "smilehip_htk_rows_be: bad argument");
   const hipError_t e = smilehip::stage_htk_rows_be(d_src, n, static_cast<uint32_t *>(d_dst), (hipStream_t)stream);

@@ -12,6 +12,9 @@ class cHipFunctionals : public cFunctionals {
   bool cpu_warned_ = false;
   int state_ = -1;                                       // -1 = not examined, 0 = not expressible -> reference code, 1 = spec_
   smilehip_func_spec spec_;
+  std::vector<float> all_;                               // the values of every contour of the current tick's matrix ([contour][functional])
+  const cMatrix *all_of_ = nullptr;
+  long all_nT_ = 0, all_n_ = 0;
   int opt_int(const char *fam, const char *o) { return (int)getInt_f(myvprint("%s.%s", fam, o)); }
   double opt_dbl(const char *fam, const char *o) { return getDouble_f(myvprint("%s.%s", fam, o)); }
   bool opt_set(const char *fam, const char *o) {
@@ -318,6 +321,32 @@ class cHipFunctionals : public cFunctionals {
       bool has_mod = false;
       for (int q = 0; q < spec_.n_fam; ++q) has_mod = has_mod || spec_.fam[q] == SMILEHIP_FAM_MODULATION;
       if (has_mod) { HIP_FALLTHROUGH(14, "cFunctionals: Modulation on a contour of fewer than 34 values (4 .. 32-point transforms are not built)"); return cFunctionals::doProcess(i, row, y); }
+    }
+    // Every contour of the tick in ONE operator call (round 6): cWinToVecProcessor::myTick hands doProcess the rows of ONE matrix one
+    // after the other (winToVecProcessor.cpp:1037-1052), and that matrix is still the reader's (cDataReader::m, dataReader.cpp:446-536).
+    // At the tick's first row the whole matrix goes to the device and the operator runs over all its columns -- a thread per contour
+    // instead of one thread in all --, the later rows take their values from that result. (A row that is not the matrix's -- checked
+    // on its first and last value -- takes the single-contour call below.)
+    {
+      cMatrix *whole = reader_->m;
+      const long nT = row->nT;
+      if (block_mode() && whole && whole->nT == nT && whole->N > 1 && i >= 0 && i < whole->N && whole->N <= 4096 &&
+          !memcmp(&whole->data[i], &row->data[0], sizeof(FLOAT_DMEM)) &&
+          !memcmp(&whole->data[(size_t)(nT - 1) * (size_t)whole->N + (size_t)i], &row->data[nT - 1], sizeof(FLOAT_DMEM))) {
+        if (i == 0 || all_of_ != whole || all_nT_ != nT || all_n_ != whole->N) {
+          const long N = whole->N;
+          io_.ensure(nT * N, N * nFunctValues);
+          check(smilehip_copy_to_device(context(), io_.own_in, whole->data, sizeof(float) * (uint64_t)(nT * N), nullptr));
+          check(smilehip_funcspec_matrix(context(), &spec_, io_.own_in, N, nT, (int32_t)N, io_.d_out, nullptr));
+          all_.resize((size_t)(N * nFunctValues));
+          check(smilehip_copy_to_host(context(), all_.data(), io_.d_out, sizeof(float) * all_.size(), nullptr));
+          check(smilehip_stream_synchronize(context(), nullptr));
+          all_of_ = whole; all_nT_ = nT; all_n_ = N;
+        }
+        memcpy(y, &all_[(size_t)i * (size_t)nFunctValues], sizeof(float) * (size_t)nFunctValues);
+        g_frames[14]++;
+        return nFunctValues;
+      }
     }
     io_.ensure(row->nT, nFunctValues);
     io_.up(row->data, row->nT);

@@ -103,6 +103,19 @@ inline bool block_debug() {
 }
 #define BLOCK_DBG(...) do { if (block_debug()) { fprintf(stderr, "[smilehip block] " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
+// SMILEHIP_PLUGIN_TIMING=1: where a block tick's time goes (seconds, summed over the run; trace lines "time.<phase>")
+double g_t_read = 0, g_t_op = 0, g_t_write = 0, g_t_win = 0, g_t_framer = 0, g_t_up = 0, g_t_down = 0;
+inline bool block_timing() {
+  static const int v = [] { const char *e = getenv("SMILEHIP_PLUGIN_TIMING"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+inline double now_sec() {
+  if (!block_timing()) return 0.0;
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 // device scratch for the frames of one processVector call: one frame in / one frame out on the reference's ticks, g_blk.n of each
 // on a block tick
 struct FrameIO {
@@ -130,6 +143,16 @@ struct FrameIO {
     d_in = own_in;
   }
   void up(const FLOAT_DMEM *src, long n) {
+    const double t0 = now_sec();
+    up_(src, n);
+    g_t_up += now_sec() - t0;
+  }
+  void down(FLOAT_DMEM *dst, long n) {
+    const double t0 = now_sec();
+    down_(dst, n);
+    g_t_down += now_sec() - t0;
+  }
+  void up_(const FLOAT_DMEM *src, long n) {
     if (g_blk.n == 1) {
       if (smilehip_copy_to_device(context(), own_in, src, sizeof(float) * (uint64_t)n, nullptr)) COMP_ERR("libsmilehip: %s", smilehip_last_error());
       return;
@@ -144,7 +167,7 @@ struct FrameIO {
       COMP_ERR("libsmilehip: %s", smilehip_last_error());
   }
   // n floats of every frame's device row (pitch w_out) to the host rows at dst (pitch 1 frame / g_blk.ld_dst)
-  void down(FLOAT_DMEM *dst, long n) {
+  void down_(FLOAT_DMEM *dst, long n) {
     if (g_blk.n == 1) {
       if (smilehip_copy_to_host(context(), dst, d_out, sizeof(float) * (uint64_t)n, nullptr) || smilehip_stream_synchronize(context(), nullptr))
         COMP_ERR("libsmilehip: %s", smilehip_last_error());

@@ -25,6 +25,10 @@
 #include <core/dataSource.hpp>
 #include <core/smileCommon.hpp>
 #include <iocore/waveSource.hpp>
+#include <iocore/htkSink.hpp>
+#include <iocore/csvSink.hpp>
+#include <iocore/arffSink.hpp>
+#include <iocore/externalSink.hpp>
 #include <dsp/specResample.hpp>
 #include <dsp/specScale.hpp>
 #include <dspcore/acf.hpp>
@@ -105,6 +109,7 @@ struct TraceAtExit {
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s %ld\n", g_names[i], g_frames[i]);
     for (int i = 0; i < kNumOverrides; ++i) fprintf(f, "%s.cpu %ld\n", g_names[i], g_cpu[i]);
     fprintf(f, "cFramer %ld\nblock.ticks %ld\nblock.frames %ld\nblock.dev_rows %ld\n", g_framer_frames, g_block_ticks, g_block_frames, g_block_dev_rows);
+    if (block_timing()) fprintf(f, "time.read %.4f\ntime.op %.4f\ntime.up %.4f\ntime.down %.4f\ntime.write %.4f\n", g_t_read, g_t_op, g_t_up, g_t_down, g_t_write);
     fprintf(f, "fused.rows %ld\nfused.stage_frames %ld\nfused.batch_frames %ld\n", g_fused.served, g_fused_stage, g_fused.active ? g_fused.n_rows : 0L);
     fclose(f);
   }
@@ -144,6 +149,10 @@ extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cCom
     sComponentInfo *ci = cHipLldSource::registerComponent(confman, compman, iteration);
     if (ci) { ci->builtIn = 0; ci->next = head; head = ci; }
   }
+  if (want("cHtkSink")) head = override_of(&cHtkSink::registerComponent, &cHipHtkSink::create, confman, compman, iteration, head);
+  if (want("cCsvSink")) head = override_of(&cCsvSink::registerComponent, &cHipCsvSink::create, confman, compman, iteration, head);
+  if (want("cArffSink")) head = override_of(&cArffSink::registerComponent, &cHipArffSink::create, confman, compman, iteration, head);
+  if (want("cExternalSink")) head = override_of(&cExternalSink::registerComponent, &cHipExternalSink::create, confman, compman, iteration, head);
   if (want("cFramer")) head = override_of(&cFramer::registerComponent, &cHipFramer::create, confman, compman, iteration, head);
   if (want("cVectorConcat")) head = override_of(&cVectorConcat::registerComponent, &cHipVectorConcat::create, confman, compman, iteration, head);
   if (want("cWaveSource")) head = override_of(&cWaveSource::registerComponent, &cHipWaveSource::create, confman, compman, iteration, head);

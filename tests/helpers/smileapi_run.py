@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage: smileapi_run.py <libSMILEapi.so> <conf> <pcm.npy> <out.npy>
+"""usage: smileapi_run.py <libSMILEapi.so> <conf> <pcm.npy> <out.npy> [--block SAMPLES] [--timing]
 Feeds 16-bit PCM into a running openSMILE instance through the reference's C API (progsrc/include/smileapi/SMILEapi.h:
 smile_new / smile_initialize / smile_run on a second thread, smile_extaudiosource_write_data in 50 ms pieces, then
 smile_extaudiosource_set_external_eoi) and collects what the cExternalSink instance `extsink` hands to its callback.
@@ -18,6 +18,9 @@ class Opt(C.Structure):
 
 def main():
     lib, conf, pcm_path, out_path = sys.argv[1:5]
+    extra = sys.argv[5:]
+    step = int(extra[extra.index("--block") + 1]) if "--block" in extra else 800      # samples per write (default 50 ms)
+    timing = "--timing" in extra
     L = C.CDLL(lib)
     L.smile_new.restype = C.c_void_p
     L.smile_initialize.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
@@ -33,9 +36,10 @@ def main():
     rows = []
 
     def on_vector(data, n, _param):
-        rows.append(np.ctypeslib.as_array(data, shape=(n,)).copy())
+        rows.append(C.string_at(data, 4 * n))
         return True
     cb = CB(on_vector)
+    t_init = time.time()
     obj = L.smile_new()
     rc = L.smile_initialize(obj, conf.encode(), 0, None, 1, 0, 0, None)
     if rc != 0:
@@ -46,7 +50,7 @@ def main():
     res = {}
     th = threading.Thread(target=lambda: res.setdefault("rc", L.smile_run(obj)))
     th.start()
-    step, pos = 800, 0
+    pos = 0
     t0 = time.time()
     while pos < len(pcm):
         chunk = np.ascontiguousarray(pcm[pos:pos + step])
@@ -61,9 +65,14 @@ def main():
     th.join(240)
     if res.get("rc", -1) != 0:
         raise SystemExit(f"smile_run: {res.get('rc')}: {L.smile_error_msg(obj)}")
+    t_end = time.time()
     L.smile_free(obj)
-    np.save(out_path, np.array(rows, np.float32))
+    out = np.frombuffer(b"".join(rows), np.float32).reshape(len(rows), -1) if rows else np.zeros((0, 0), np.float32)
+    np.save(out_path, out)
     print(len(rows), "vectors")
+    if timing:
+        import json
+        print(json.dumps({"vectors": len(rows), "feed_to_end_s": t_end - t0, "init_s": t0 - t_init}))
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ export LD_LIBRARY_PATH=$R/opensmile_amd:$R/oracle/_ref:${LD_LIBRARY_PATH:-}
 export TMPDIR=/tmp
 cd $R/opensmile_amd/plugin
 tag=$(basename $conf .conf)
-SMILEHIP_PLUGIN_FUSE=${FUSE:-0} SMILEHIP_PLUGIN_TRACE=$O/trace_$tag.txt rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$tag -- $R/oracle/_ref/SMILExtract -C $R/oracle/_ref/config/$conf -I /tmp/in.wav $opt /tmp/o.htk -l 1 > $O/run_$tag.log 2>&1
+SMILEHIP_PLUGIN_TRACE=$O/trace_$tag.txt rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$tag -- $R/oracle/_ref/SMILExtract -C $R/oracle/_ref/config/$conf -I /tmp/in.wav $opt /tmp/o.htk -l 1 > $O/run_$tag.log 2>&1
 cp $(find $O/p_$tag -name '*kernel_stats.csv' | head -1) $O/${tag}_kernel_stats.csv; rm -rf $O/p_$tag
 cut -d, -f1-4,7 $O/${tag}_kernel_stats.csv | cut -c1-150 | head -25
 grep -v "\.cpu\| 0$" $O/trace_$tag.txt | tr '\n' ' '
