@@ -179,6 +179,16 @@ SYMBOLS = {
     "smilehip_htk_rows_be": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "smilehip_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "smilehip_copy_to_device_2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "smilehip_copy_to_host_2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "smilehip_host_register": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "smilehip_host_unregister": (C.c_int, [_vp, _vp]),
+    "smilehip_frame_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "smilehip_window_op_block": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, C.c_int, C.c_int, C.c_int, _vp]),
+    "smilehip_delta_segments_block": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, C.c_int, C.c_int, _vp, _vp]),
+    "smilehip_pitchacf_contour_frames": (C.c_int, [_vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp]),
+    "smilehip_viterbi_stream_push_frames": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32]),
+    "smilehip_jitter_stream_push_frames": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp]),
     "smilehip_stream_synchronize": (C.c_int, [_vp, _vp]),
     "smilehip_config_mfcc12_0_d_a": (None, [C.POINTER(LldConfig)]),
     "smilehip_plan_create": (C.c_int, [_vp, C.POINTER(LldConfig), C.POINTER(_vp)]),

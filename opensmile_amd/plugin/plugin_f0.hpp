@@ -39,7 +39,6 @@ class cHipSpecScale : public BlockVP<cSpecScale> {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       const char *sc = getStr("scale"), *ss = getStr("sourceScale"), *im = getStr("interpMethod");
       // the octave axis: scale = octave, or scale = log with logScaleBase 2 (specScale.cpp:100-111)
@@ -81,7 +80,6 @@ class cHipPitchShs : public BlockVP<cPitchShs> {
   int nc_ = 6;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       nc_ = (int)getInt("nCandidates");
       usable_ = nc_ >= 1 && nc_ <= 6 && getInt("scores") == 1 && getInt("voicing") == 1 && getInt("F0C1") == 0 &&

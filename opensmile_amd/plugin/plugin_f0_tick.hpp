@@ -69,7 +69,7 @@ class cHipValbasedSelector : public cValbasedSelector {
   }
   eTickResult myTick(long long t) override {
     g_fused.init();
-    if (g_fused.big) return cValbasedSelector::myTick(t);            // big-set fused mode: a stage on zero-filled levels (the reference's own tick code keeps the frame bookkeeping)
+    if (g_fused.big) return TICK_INACTIVE;                 // big-set fused mode: the selected levels come from the batch; no frame ever arrives here
     if (!ready_) {
       threshold_ = (FLOAT_DMEM)getDouble("threshold");
       adaptive_ = (int)getInt("adaptiveThreshold");
@@ -212,25 +212,7 @@ class cHipPitchSmootherViterbi : public cPitchSmootherViterbi {
     fr_.resize(128); st_.resize(128);
     int32_t *fr = fr_.data(), *st = st_.data();
     if (g_fused.big) {
-      // big-set fused mode: this level is a stage (zeros), but WHEN its frames appear shapes every end-of-input rule downstream (the
-      // frames the Viterbi pass has not decided when the input ends arrive in the flush): frames are "decided" at once except the
-      // last P, P as the fused batch's own pass left it
-      const long T = g_fused.f0_frames, P = g_fused.f0_pending;
-      if (isEOI()) {
-        if (!flushed_) {
-          for (long f = (T - P > 0 ? T - P : 0); f < (long)hist_.size() && n < 128; ++f) { fr[n] = (int32_t)f; st[n] = (int32_t)nCand_; ++n; }
-          flushed_ = true;
-        }
-      } else {
-        cVector *vec = reader_->getNextFrame();
-        if (vec == NULL) return TICK_SOURCE_NOT_AVAIL;
-        std::vector<FLOAT_DMEM> h((size_t)(2 * nCand_ + 4), 0.0f);
-        h[(size_t)(2 * nCand_ + 3)] = (FLOAT_DMEM)vec->tmeta->vIdx;
-        hist_.push_back(h);
-        const long f = (long)hist_.size() - 1;
-        if (f < T - P) { fr[0] = (int32_t)f; st[0] = (int32_t)nCand_; n = 1; }
-        g_fused_stage++;
-      }
+      return TICK_INACTIVE;                                // big-set fused mode: the pitch contour comes from the batch; no candidates ever arrive here
     } else if (isEOI()) {
       if (!flushed_) {
         check(smilehip_viterbi_stream_flush(vs_, &n, fr, st, 128));

@@ -9,7 +9,6 @@ class cHipSpecResample : public BlockVP<cSpecResample> {
   long rate_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       const sDmLevelConfig *c = reader_->getLevelConfig();
       rate_ = c->basePeriod > 0.0 ? std::lround(1.0 / c->basePeriod) : 0;
@@ -56,7 +55,6 @@ class cHipLpc : public BlockVP<cLpc> {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       const char *met = getStr("method");
       const bool plain = met && !strncasecmp(met, "acf", 3) && getInt("saveLPCoeff") == 1 && !getInt("saveRefCoeff") && !getInt("lpGain") &&
@@ -91,7 +89,6 @@ class cHipFormantLpc : public BlockVP<cFormantLpc> {
   int usable_ = -1;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (usable_ < 0) {
       const sDmLevelConfig *c = reader_->getLevelConfig();
       usable_ = getInt("nFormants") == 5 && getInt("saveFormants") == 1 && getInt("saveBandwidths") == 1 && !getInt("saveIntensity") &&
@@ -132,7 +129,6 @@ class cHipHarmonics : public BlockVP<cHarmonics> {
   std::vector<float> fmh_, f0h_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE(1);
     if (usable_ < 0) {
       static const char *const diffs[2] = {"H1-H2", "H1-A3"};
       bool ok = getInt("nHarmonics") == 100 && getInt("nHarmonicMagnitudes") == 0 && getInt("harmonicDifferencesLog") == 1 &&

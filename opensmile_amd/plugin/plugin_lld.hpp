@@ -5,7 +5,7 @@
 class cHipEnergy : public BlockVP<cEnergy> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
-  long fframe_ = 0, fnext_ = 0;
+  long fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes res_;
@@ -26,8 +26,6 @@ class cHipEnergy : public BlockVP<cEnergy> {
     return BlockVP<cEnergy>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
-    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (Nsrc == 0) return 0;
     if (!ready_) {                                       // cEnergy::myFetchConfig, energy.cpp:58-81
       htk_ = getInt("htkcompatible");
@@ -147,7 +145,6 @@ class cHipMZcr : public BlockVP<cMZcr> {
   int plain_ = -1, flags_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {
       plain_ = (getInt("zcr") && !getInt("mcr") && !getInt("amax") && !getInt("maxmin") && !getInt("dc")) ? 1 : 0;
       flags_ = (getInt("zcr") ? SMILEHIP_MZCR_ZCR : 0) | (getInt("mcr") ? SMILEHIP_MZCR_MCR : 0) | (getInt("amax") ? SMILEHIP_MZCR_AMAX : 0) |
@@ -196,7 +193,6 @@ class cHipAcf : public BlockVP<cAcf> {
   int plain_ = -1, use_power_ = 0, cepstrum_ = 0, norm_ = 0, abs_ceps_ = 0;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE(1);
     if (plain_ < 0) {                                    // cAcf::myFetchConfig, acf.cpp:77-110
       cepstrum_ = getInt("cepstrum");
       use_power_ = cepstrum_ ? (isSet("usePower") ? getInt("usePower") : 0) : getInt("usePower");
@@ -244,7 +240,6 @@ class cHipPitchACF : public BlockVP<cPitchACF> {
   std::vector<unsigned char> host_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {                                    // cPitchACF::myFetchConfig, pitchACF.cpp:75-104
       voiceProb_ = getInt("voiceProb"); F0_ = getInt("F0"); F0raw_ = getInt("F0raw"); F0env_ = getInt("F0env");
       voicingCutoff_ = getDouble("voicingCutoff");

@@ -556,11 +556,8 @@ struct FusedChain {
     if (feeder == who && source_eof) { run(); return TICK_SUCCESS; }
     return TICK_INACTIVE;
   }
-  // ---- tick-level hand-out (round 5; the cepstral chains). The per-frame hand-out above still walks the reference's tick loop
-  // once per frame for every component of the chain (framer, pre-emphasis, window, transform, magnitudes, mel bank: six levels
-  // written and read per frame to carry zeros) -- an hour of audio took LONGER than the CPU binary. Here the wave source idles
-  // (cHipWaveSource: nothing upstream of the chain's last components ever sees data) and those last components write their rows
-  // straight to their levels, a block of frames per tick, with the time stamps the framer would have given them.
+  // ---- the hand-out: the chain's last components write their rows straight to their own levels, a block of frames per tick, with
+  // the time stamps the framer would have given them (nothing between the framers and them ever sees data).
   bool tick_mode = false;
   bool final_level = false;                               // the rows are the sinks' own level (cHipVectorConcat hands them out)
   std::vector<double> times;                              // frame time stamps of the batch's rows (smilehip_row_time)
@@ -595,30 +592,7 @@ struct FusedChain {
     served += n;
     return TICK_SUCCESS;
   }
-  // row `frame` of a fused level
-  void copy(const FusedLevel &L, long frame, FLOAT_DMEM *dst, long Ndst) {
-    if (L.cols.empty()) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; return; }
-    if (frame >= L.n_rows) COMP_ERR("libsmilehip plugin: fused mode: the graph asks for frame %ld, the batch has %ld", frame, L.n_rows);
-    const float *r = L.M->data() + (size_t)frame * L.ld;
-    for (long k = 0; k < Ndst && k < (long)L.cols.size(); ++k) dst[k] = r[L.cols[k]];
-    ++served;
-  }
-  float at(const FusedLevel &L, long frame, int elem) {
-    if (L.cols.empty()) return 0.0f;
-    if (elem >= (int)L.cols.size())
-      COMP_ERR("libsmilehip plugin: fused mode: the graph asks for element %d, the level has %d", elem, (int)L.cols.size());
-    if (frame == L.n_rows && !L.extra.empty()) return L.extra[(size_t)elem];
-    if (frame >= L.n_rows) { ++beyond; return 0.0f; }      // rows a window processor emits at the end of input that no reader of the level uses
-    return (*L.M)[(size_t)frame * L.ld + L.cols[(size_t)elem]];
-  }
-  long beyond = 0;
 };
-// big-set fused mode: an overridden component that does not write a handed-out level fills its output with zeros
-#define FUSED_BIG_STAGE(ret)                                                                                       \
-  do {                                                                                                             \
-    g_fused.init();                                                                                                \
-    if (g_fused.big) { for (long k_ = 0; k_ < Ndst; ++k_) dst[k_] = 0; g_fused_stage++; return (ret); }           \
-  } while (0)
 FusedChain g_fused;
 
 smilehip_lld_config base_config(long N, uint32_t stages) {

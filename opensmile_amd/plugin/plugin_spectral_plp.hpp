@@ -25,7 +25,6 @@ class cHipSpectral : public BlockVP<cSpectral> {
   }
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    FUSED_BIG_STAGE((int)Ndst);
     if (plain_ < 0) {
       bool ok = getArraySize("bands") == 2 && getArraySize("rollOff") == 4 && getArraySize("slopes") <= 0;
       for (int b = 0; ok && b < 2; ++b) {                  // bands[b] = "lo-hi" in Hz, integers (spectral.cpp:163-190)
@@ -175,7 +174,7 @@ class cHipSpectral : public BlockVP<cSpectral> {
 class cHipPlp : public BlockVP<cPlp> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
-  long fframe_ = 0, fnext_ = 0;
+  long fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
@@ -196,8 +195,6 @@ class cHipPlp : public BlockVP<cPlp> {
     return BlockVP<cPlp>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
-    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (plain_ < 0) {                                    // cPlp::myFetchConfig, plp.cpp:90-176
       int doLP = getInt("doLP"), doLpToCeps = getInt("doLpToCeps"), doIDFT = getInt("doIDFT");
       if (getInt("lpOrder") <= 0) { doLP = 0; doLpToCeps = 0; }

@@ -22,7 +22,6 @@ struct DevBytes {
 
 // R2  cVectorPreemphasis::processVector  (src/dspcore/vectorPreemphasis.cpp:89-107)
 class cHipVectorPreemphasis : public BlockVP<cVectorPreemphasis> {
-  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   float k_ = 0.f;
@@ -30,8 +29,6 @@ class cHipVectorPreemphasis : public BlockVP<cVectorPreemphasis> {
   bool ready_ = false;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
-    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (!ready_) {
       double f = isSet("f") ? getDouble("f") : -1.0;
       k_ = (FLOAT_DMEM)getDouble("k");
@@ -69,14 +66,11 @@ struct PlanSet {
 
 // R3  cWindower::processVector  (src/dspcore/windower.cpp:221-229)
 class cHipWindower : public BlockVP<cWindower> {
-  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
-    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       if (getDouble("fade") > 0.0 || getInt("squareRoot") || getDouble("xshift") != 0.0)
@@ -107,14 +101,11 @@ class cHipWindower : public BlockVP<cWindower> {
 
 // R4  cTransformFFT::processVector, forward  (src/dspcore/transformFft.cpp:165-223)
 class cHipTransformFFT : public BlockVP<cTransformFFT> {
-  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
-    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (getInt("inverse")) {                             // rdft(N, -1) and the 2 / N scaling (transformFft.cpp:196-216)
       if (Nsrc != Ndst || Ndst < 64 || Ndst > 8192 || (Ndst & (Ndst - 1))) {
         HIP_FALLTHROUGH(2, "cTransformFFT inverse = 1: only whole packed spectra of 64 .. 8192 values are built");
@@ -159,7 +150,6 @@ class cHipTransformFFT : public BlockVP<cTransformFFT> {
 
 // R5  cFFTmagphase::processVector, magnitude branch  (src/dspcore/fftmagphase.cpp:215-221)
 class cHipFFTmagphase : public BlockVP<cFFTmagphase> {
-  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
@@ -168,8 +158,6 @@ class cHipFFTmagphase : public BlockVP<cFFTmagphase> {
   float dbp_norm_ = 0.0f, min_dbp_ = 0.0f;
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
-    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (plain_ < 0) {
       plain_ = (!getInt("inverse") && getInt("magnitude") && !getInt("phase") && !getInt("normalise") &&
                 !getInt("power") && !getInt("dBpsd")) ? 1 : 0;
@@ -219,7 +207,6 @@ class cHipFFTmagphase : public BlockVP<cFFTmagphase> {
 
 // R6  cMelspec::processVector  (src/lldcore/melspec.cpp:519-570)
 class cHipMelspec : public BlockVP<cMelspec> {
-  int fused_ = -1;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
@@ -228,8 +215,6 @@ class cHipMelspec : public BlockVP<cMelspec> {
   bool tab_ready_[8] = {false, false, false, false, false, false, false, false};
  protected:
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fused_ = g_fused.stage_level(getStr("writer.dmLevel")) ? 1 : 0; }
-    if (fused_) { for (long k = 0; k < Ndst; ++k) dst[k] = 0; g_fused_stage++; return 1; }   // fused mode: cMfcc / cPlp hand out the batch's rows
     if (plain_ < 0) {
       const char *bw = getStr("bwMethod");
       const char *sc = getStr("specScale");
@@ -301,7 +286,7 @@ class cHipMelspec : public BlockVP<cMelspec> {
 class cHipMfcc : public BlockVP<cMfcc> {
   int fused_ = -1;
   const FusedLevel *fcols_ = nullptr;
-  long fframe_ = 0, fnext_ = 0;
+  long fnext_ = 0;
   FrameIO io_;
   bool cpu_warned_ = false;
   PlanSet<> plans_;
@@ -318,8 +303,6 @@ class cHipMfcc : public BlockVP<cMfcc> {
     return BlockVP<cMfcc>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (fused_ < 0) { g_fused.init(); fcols_ = g_fused.static_level(getStr("writer.dmLevel")); fused_ = fcols_ ? 1 : 0; }
-    if (fused_) { if (idxi == 0) fframe_ = fnext_++; g_fused.copy(*fcols_, fframe_, dst, Ndst); return 1; }   // fused mode: rows of the whole-file batch
     if (getInt("inverse") || !getInt("doLog")) { HIP_FALLTHROUGH(5, "cMfcc: inverse = 1 / doLog = 0 are not built"); return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {

@@ -3,27 +3,7 @@
 // R13  cWindowProcessor::processBuffer of cDeltaRegression (src/dspcore/deltaRegression.cpp:113-170) and
 // cContourSmoother (src/dspcore/contourSmoother.cpp:85-118): one row of the block the window
 // processor's tick hands over, valid on [-pre, nT+post)
-// big-set fused mode for the window processors (cWindowProcessor::myTick calls processBuffer once per element row of a block,
-// rows 0 .. N-1 in order, windowProcessor.cpp:188-200): the n-th call of a block is element n, the blocks follow each other in time
-struct FusedRows {
-  const FusedLevel *lvl = nullptr;
-  int tried = 0;
-  long call = 0, t_base = 0;
-  // true: `out` has been filled (with the level's rows, or zeros for a level nobody downstream of the fused ones reads)
-  bool serve(const char *writer_level, long n_elems, cMatrix *out) {
-    if (!tried) { tried = 1; g_fused.init(); if (g_fused.big) lvl = g_fused.static_level(writer_level); }
-    if (!g_fused.big || !lvl) return false;
-    const long N = n_elems > 0 ? n_elems : 1;
-    const int e = (int)(call % N);
-    for (long t = 0; t < out->nT; ++t) out->data[t] = g_fused.at(*lvl, t_base + t, e);
-    if (e == N - 1) t_base += out->nT;
-    ++call;
-    if (!lvl->cols.empty()) g_fused.served += out->nT; else g_fused_stage++;
-    return true;
-  }
-};
-
-// ... and at the tick level (round 5): the window processor whose writer level the fused batch supplies writes the level's rows
+// fused mode (plugin_shared.hpp): the window processor whose writer level the fused batch supplies writes the level's rows
 // in blocks, whatever its reader holds (nothing: the wave source idles, no component upstream ever sees data)
 struct FusedTick {
   const FusedLevel *lvl = nullptr;
@@ -60,7 +40,6 @@ struct RowIO {
 
 class cHipDeltaRegression : public cDeltaRegression {
   RowIO row_;
-  FusedRows frows_;
   FusedTick ftick_;
   WinBlock wblock_;
   bool cpu_warned_ = false;
@@ -104,7 +83,6 @@ class cHipDeltaRegression : public cDeltaRegression {
   }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     options();
-    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (pre < (W_ > 0 ? W_ : 1) || post < W_) { HIP_FALLTHROUGH(10, "cDeltaRegression: a block without its window's history"); return cDeltaRegression::processBuffer(in, out, pre, post); }
     if (plain_) row_.run(in, out, pre, post, segs_ ? 3 : 0, W_);
     else row_.run_delta(in, out, pre, post, W_, flags_);   // relativeDelta / halfWaveRect / absOutput / deltawin = 0
@@ -122,7 +100,6 @@ class cHipDeltaRegression : public cDeltaRegression {
 
 class cHipContourSmoother : public cContourSmoother {
   RowIO row_;
-  FusedRows frows_;
   FusedTick ftick_;
   WinBlock wblock_;
   bool cpu_warned_ = false;
@@ -153,7 +130,6 @@ class cHipContourSmoother : public cContourSmoother {
   }
   int processBuffer(cMatrix *in, cMatrix *out, int pre, int post) override {
     options();
-    if (frows_.serve(getStr("writer.dmLevel"), Ni, out)) return 1;                    // big-set fused mode: rows of the whole-file batch
     if (!plain_ || pre < W_ || post < W_) { HIP_FALLTHROUGH(11, "cContourSmoother: smaWin = 1 (no smoothing) is not built as a per-component operator"); return cContourSmoother::processBuffer(in, out, pre, post); }
     row_.run(in, out, pre, post, nz_ ? 2 : 1, W_);
     g_frames[11] += out->nT;
