@@ -14,6 +14,15 @@ EXE = os.path.join(ROOT, "opensmile_amd", "smilextract_hip")
 CONF = os.path.join(ROOT, "oracle", "_ref", "config")
 G = os.path.join(ROOT, "tests", "golden", "files")
 
+def _copytree(src, dst):
+    """a writable copy (the reference tree, and with it oracle/_ref/config, may be read-only; the tests edit their copies)"""
+    _copytree(src, dst)
+    for d, _dirs, files in os.walk(dst):
+        os.chmod(d, 0o755)
+        for f in files:
+            os.chmod(os.path.join(d, f), 0o644)
+
+
 needs_conf = pytest.mark.skipif(not (os.path.isdir(CONF) and os.path.exists(EXE)), reason="oracle/_ref/config or smilextract_hip not built")
 
 
@@ -71,7 +80,7 @@ def test_big_sets_are_recognised_by_their_graph():
 @needs_conf
 def test_option_changes_and_refusals(tmp_path):
     src = os.path.join(CONF, "mfcc", "MFCC12_0_D_A.conf")
-    shutil.copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
+    _copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
     os.makedirs(tmp_path / "mfcc")
     txt = open(src).read()
 
@@ -119,7 +128,7 @@ def test_option_changes_and_refusals(tmp_path):
     # the message says whether the refused value is the file's or the component's default: -timestampcsv 0 sets frameTime in
     # [csvsink] (named by its other spelling in the message); a [csvsink] without its frameIndex line falls back to the default 1
     bigdir = tmp_path / "is09-13"
-    shutil.copytree(os.path.join(CONF, "is09-13"), bigdir)
+    _copytree(os.path.join(CONF, "is09-13"), bigdir)
     inc = (tmp_path / "shared" / "standard_data_output.conf.inc")
     t = inc.read_text()
     assert "frameIndex=0\n" in t and "frameTime=\\cm[timestampcsv{1}" in t
@@ -154,7 +163,7 @@ def test_conf_front_end_equals_set(tmp_path):
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "SMILExtract")
     if not os.path.exists(ref_exe):
         pytest.skip("oracle/_ref/SMILExtract not built")
-    shutil.copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
+    _copytree(os.path.join(CONF, "shared"), tmp_path / "shared")
     os.makedirs(tmp_path / "mfcc")
     t = open(os.path.join(CONF, "mfcc", "MFCC12_0_D_A.conf")).read()
     for x, y in (("frameSize = 0.0250", "frameSize = 0.032"), ("nBands = 26", "nBands = 40"), ("lastMfcc  = 12", "lastMfcc  = 19"),
@@ -205,7 +214,7 @@ def test_edited_big_set_files_are_the_set_with_other_parameters(tmp_path):
     """ComParE_2016.conf / eGeMAPSv02.conf with other values of the F0 group's options are recognised through the masked
     fingerprint (the graph is the shipped one, only parameter options differ) and --describe lists the values it will run
     with; an edit of any other option is still refused."""
-    shutil.copytree(CONF, tmp_path / "config")
+    _copytree(CONF, tmp_path / "config")
     inc = tmp_path / "config" / "compare16" / "ComParE_2016_core.lld.conf.inc"
     t = inc.read_text()
     for a, b in (("maxPitch = 620", "maxPitch = 500"), ("minPitch = 52", "minPitch = 60"), ("nHarmonics = 15", "nHarmonics = 12"),
@@ -239,7 +248,7 @@ def test_edited_big_set_files_equal_the_binary_on_the_same_file(tmp_path):
     with wave.open(wav, "wb") as w:
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
         w.writeframes(synth.utterance(7, 64000).tobytes())
-    shutil.copytree(CONF, tmp_path / "config")
+    _copytree(CONF, tmp_path / "config")
     edits = {
         "compare16/ComParE_2016_core.lld.conf.inc": (("maxPitch = 620", "maxPitch = 500"), ("minPitch = 52", "minPitch = 60"),
                                                     ("nHarmonics = 15", "nHarmonics = 12"), ("bufferLength=30", "bufferLength=20"),
@@ -269,7 +278,7 @@ def test_edited_big_set_files_equal_the_binary_on_the_same_file(tmp_path):
 def _edit_compare16(tmp_path, is13=False):
     """ComParE_2016.conf (or IS13_ComParE.conf) with maxPitch changed, lastMfcc = 12, Moments removed from is13_functionalsB,
     Peaks2 removed from is13_functionalsLLD, Regression removed from is13_functionalsNz."""
-    shutil.copytree(CONF, tmp_path / "config")
+    _copytree(CONF, tmp_path / "config")
     d = "is09-13" if is13 else "compare16"
     stem = "IS13_ComParE" if is13 else "ComParE_2016"
     p = tmp_path / "config" / d / (stem + "_core.lld.conf.inc")
