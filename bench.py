@@ -83,6 +83,33 @@ CONFIGS = {
 }
 
 
+# Algorithmic bytes per 10 ms frame of the kernels that can dominate a step of configs 3-5: what that STAGE of the chain has to
+# read and write if nothing is wasted -- the int16 hop where the kernel reads the samples, the values it takes from the stage in
+# front of it and the values it hands on. The three kernels of the F0 front end (spec -> sweep -> cand) are one stage (the rows they
+# pass each other are not algorithmic: SURVEY 8d): each is priced with the stage's bytes, 320 in + 6 candidates x (f0, score) + 3
+# frame values out.
+KERNEL_ALG_BYTES = {
+    "lld_jitter_runs": (2 * 160 + 4 + 4 * 3, "int16 hop + final F0 in, jitterLocal / jitterDDP / shimmerLocal out"),
+    "lld_f0_jitter": (2 * 160 + 4 + 4 * 3, "int16 hop + final F0 in, jitterLocal / jitterDDP / shimmerLocal out"),
+    "lld_f0_spec": (2 * 160 + 4 * 15, "F0 front end (spec + sweep + cand are one stage): int16 hop in, 6 x (f0, score) + 3 frame values out"),
+    "lld_f0_sweep": (2 * 160 + 4 * 15, "F0 front end (one stage with spec and cand), as lld_f0_spec"),
+    "lld_f0_cand9": (2 * 160 + 4 * 15, "F0 front end (one stage with spec and sweep), as lld_f0_spec"),
+    "lld_f0_cand": (2 * 160 + 4 * 15, "F0 front end (one stage with spec and sweep), as lld_f0_spec"),
+    "lld_f0_viterbi": (4 * 12 + 4 * 3, "6 x (f0, score) in, final F0 + voicing + score out"),
+    "lld_compare_frame_quad": (2 * 160 + 4 * (4 + 55), "int16 hop in + 59 f32 pre-smoothing columns of groups A + B out"),
+    "lld_compare_frame_wave3t": (2 * 160 + 4 * (4 + 55), "int16 hop in + 59 f32 pre-smoothing columns of groups A + B out"),
+    "lld_is09_frame_quad": (2 * 160 + 4 * 16, "int16 hop in + 16 f32 pre-smoothing columns out"),
+    "lld_chain_tiled": (None, "smoothing / delta chain: every column of the level read once and written once (8 B per output cell)"),
+    "lld_gemaps_harm": (2 * 160 + 4 + 4 * 9, "int16 hop (60 ms frames) + final F0 in, 9 harmonic / formant-amplitude values out"),
+    "lld_gemaps_frame20_quad": (2 * 160 + 4 * (12 + 222), "int16 hop in + 12 raw descriptors + 222 f32 of cSpecResample's input out"),
+    "lld_gemaps_frame20": (2 * 160 + 4 * (12 + 222), "int16 hop in + 12 raw descriptors + 222 f32 of cSpecResample's input out"),
+    "lld_gemaps_lpc": (4 * 222 + 4 * 12, "222 f32 resampled spectrum in, 12 LP values out"),
+    "lld_gemaps_formants": (4 * 12 + 4 * 10, "12 LP values in, 10 formant values out"),
+}
+# SURVEY 8(d)'s per-frame figure of the WHOLE chain of a config: the int16 hop in, every column of the output level out
+CHAIN_ALG_BYTES = {3: 2 * 160 + 4 * 32, 4: 2 * 160 + 4 * 130, 5: 2 * 160 + 4 * 25}
+
+
 def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", n_samples=UTT_SAMPLES, frames_per_file=998, max_files=14000):
     """Time the real reference binary (one process per file, HTK output to
     /dev/shm, log level 0) on all host cores; bounded sample, scaled to frames/s."""
@@ -135,13 +162,15 @@ def cpu_baseline(max_seconds=25.0, conf_rel="mfcc/MFCC12_0_D_A.conf", opt="-O", 
 
 
 def _counters(config):
-    """Counter evidence of the round's --pmc passes (tools/pmc_counters_json.py -> profiles/r05_pmc_c<N>.json): what bounds the
+    """Counter evidence of the latest round's --pmc passes (tools/pmc_counters_json.py -> profiles/r06_pmc_c<N>.json): what bounds the
     config's kernels by the SQ counters, and the VALU issue fraction of the roofline kernel(s). None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", f"r05_pmc_c{config}.json")
-    try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for rnd in ("r06", "r05"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_c{config}.json")
+        try:
+            return json.load(open(path)), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def _counter_fields(config, kernels):
@@ -158,6 +187,33 @@ def _counter_fields(config, kernels):
     return {"bound_by_counters": top.get("bound"), "valu_issue_frac": avg("valu_issue_frac"), "valu_busy_frac": avg("valu_busy_frac"),
             "lds_pipe_frac": avg("lds_pipe_frac"), "lds_bank_conflict_frac": avg("lds_bank_conflict_frac"),
             "wait_inst_frac": avg("wait_inst_frac"), "counters_source": src}
+
+
+def _issue_roofline(config, kernel, kernel_ms_per_step, launches_per_step):
+    """The instruction-issue roofline of the dominant kernel: VALU wave-instructions per launch (SQ_INSTS_VALU of the --pmc pass at
+    this batch size) x the calibrated issue cycles per instruction of a saturated SIMD (profiles/r06_valu_issue_calibration.json:
+    tools/ubench/valu_mix.hip, the 4-waves-per-SIMD rate of the kernel class's own instruction mix) / 1024 SIMDs = the cycles the
+    launch needs if every SIMD issued back to back; over the launch's measured duration at the calibration's clock = frac."""
+    cj, src = _counters(config)
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_issue_calibration.json")))
+    except Exception:
+        cal = None
+    if not cj or not cal or not kernel:
+        return None
+    mine = [v for k, v in cj.get("kernels", {}).items() if k.split("(")[0].split("<")[0].split("::")[-1].strip() == kernel and v.get("valu_insts")]
+    if not mine:
+        return None
+    insts = sum(v["valu_insts"] * (v.get("dispatches") or 1) for v in mine) / sum((v.get("dispatches") or 1) for v in mine)   # per launch
+    cpi = cal.get("cycles_per_valu_inst", {}).get(kernel, cal.get("cycles_per_valu_inst", {}).get("default"))
+    ghz = cal.get("clock_ghz", 2.4)
+    if not cpi:
+        return None
+    floor_ms = insts * cpi / 1024.0 / (ghz * 1e6)
+    per_launch_ms = kernel_ms_per_step / max(launches_per_step, 1)
+    return {"valu_wave_insts_per_launch": insts, "cycles_per_inst_saturated": cpi, "clock_ghz": ghz, "floor_ms_per_launch": floor_ms,
+            "measured_ms_per_launch": per_launch_ms, "frac": floor_ms / per_launch_ms if per_launch_ms else None,
+            "source": f"{src} (SQ_INSTS_VALU) x profiles/r06_valu_issue_calibration.json"}
 
 
 def measured_accuracy(config, host_rows, frame_offsets, pcm, sample_offsets, func_rows=None, n_check=32):
@@ -337,7 +393,8 @@ def main():
         if res is not None:
             print(json.dumps(res), flush=True)
         return finish_ranks()
-    args.steps = 100 if args.steps is None else args.steps
+    # N > 1: >= 200 steps, so that the timed region (one barrier on each side) is >= 80 ms of kernels
+    args.steps = (200 if args.gpus > 1 else 100) if args.steps is None else args.steps
     args.warmup = 30 if args.warmup is None else args.warmup
     args.utts = N_UTT if args.utts is None else args.utts
 
@@ -675,6 +732,7 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
     for _ in range(warmup):
         step()
     plan.set_timing(True)
+    capi.kernel_timing(True)                     # two HIP events around EVERY launch of the step, on the launch's own stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -682,6 +740,8 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
     barrier()
     dt = time.perf_counter() - t0
     ms_main, ms_rest = plan.last_timing()
+    by_kernel = capi.kernel_timing_report()      # {name: (launches, summed ms)} over the timed region
+    capi.kernel_timing(False)
     plan.set_timing(False)
     dts = [dt]
     total_frames = frames
@@ -709,7 +769,17 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
         gather_ms = (time.perf_counter() - g0) * 1e3
         gathered = "88 functionals per utterance" if config == 5 else "LLD matrix (rows x 32)"
     if rank == 0:
-        achieved = c["alg_bytes"] * frames / (ms_main * 1e-3) / 1e9
+        # the dominant kernel = the largest share of the step's summed kernel time (kernels on side streams overlap: the shares
+        # are of the SUM, which exceeds the step's wall time where streams run beside each other)
+        k_sum = sum(v[1] for v in by_kernel.values()) or 1.0
+        dom = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else None
+        dom_ms = by_kernel[dom][1] / steps if dom else ms_main           # per step (a kernel launched per chunk: all its launches)
+        dom_alg, dom_note = KERNEL_ALG_BYTES.get(dom, (None, None)) if dom else (None, None)
+        if dom_alg is None:                                              # not in the table: the whole chain's bytes
+            dom_alg, dom_note = CHAIN_ALG_BYTES[config], dom_note or "the whole chain's bytes per frame (SURVEY 8d): int16 hop in, every output column out"
+        achieved = dom_alg * frames / (dom_ms * 1e-3) / 1e9
+        achieved_step = CHAIN_ALG_BYTES[config] * frames / (dt / steps) / 1e9
+        cf = _counter_fields(config, [dom] if dom else c["pmc_kernels"])
         try:
             accuracy = measured_accuracy(config, lambda a, b: d_out[a:b].cpu().numpy(), batch.frame_offsets, pcm, off,
                                          func_rows=(lambda u: d_func[u].cpu().numpy()) if config == 5 else None)
@@ -730,11 +800,20 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
                        "corpus": "32 seeded utterances of the SURVEY 8(d) contract tiled (work per frame is data-independent except "
                                  "for the voiced / unvoiced pattern, which the 32 cover)",
                        "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "hbm", **_counter_fields(config, c["pmc_kernels"]), "kernel": c["kernel"], "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_source": None,
-                         "alg_bytes_per_frame": c["alg_bytes"], "alg_bytes_note": c["alg_note"], "kernel_ms": ms_main,
-                         "rest_of_step_ms": ms_rest},
+            # `bound` is what the counters of the dominant kernel say (profiles/r06_pmc_c<N>.json, collected at this batch size by
+            # separate --pmc passes), never a literal; the HBM figures (achieved / peak / frac) are the contract's ruler and stand
+            # beside the instruction-issue figures below, which are the ruler that fits these kernels
+            "roofline": {"bound": cf.get("bound_by_counters") or "unknown (no counter file for this kernel)", **cf,
+                         "kernel": dom, "kernel_share_of_summed_kernel_time": (by_kernel[dom][1] / k_sum) if dom else None,
+                         "kernel_launches_per_step": (by_kernel[dom][0] / steps) if dom else None,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_step": achieved_step / HBM_PEAK_GBS, "achieved_step": achieved_step,
+                         "alg_bytes_per_frame_step": CHAIN_ALG_BYTES[config],
+                         "traffic": None, "traffic_source": None,
+                         "alg_bytes_per_frame": dom_alg, "alg_bytes_note": dom_note, "kernel_ms": dom_ms,
+                         "frame_kernels": c["kernel"], "frame_kernels_ms": ms_main, "rest_of_step_ms": ms_rest,
+                         "issue": _issue_roofline(config, dom, dom_ms, by_kernel[dom][0] / steps if dom else 1),
+                         "kernels_ms_per_step": {k: round(v[1] / steps, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])}},
         }
         if gather_ms is not None:
             res["gather_ms"], res["gathered"] = gather_ms, gathered
@@ -746,7 +825,7 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
             try:
                 tj = json.load(open(tfile))
                 by = tj.get("by_kernel", {})
-                mine = [v for k, v in by.items() if any(k.startswith(n) for n in c["pmc_kernels"])]
+                mine = [v for k, v in by.items() if k.split("<")[0] == dom]
                 # the roofline kernel(s)' own HBM bytes per launch (what `achieved` is to be held against), and the whole step's
                 res["roofline"]["traffic"] = sum(v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"] for v in mine) * frames if mine else None
                 res["roofline"]["traffic_step"] = tj["hbm_bytes_per_frame"] * frames

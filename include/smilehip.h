@@ -601,6 +601,13 @@ int  smilehip_mfcc_run_host(smilehip_plan *plan, smilehip_batch *batch, const in
  * recorded since (at most the last 128) -- call it after synchronising. */
 int  smilehip_plan_set_timing(smilehip_plan *plan, int enable);
 int  smilehip_plan_last_timing(smilehip_plan *plan, float *ms_main, float *ms_delta);
+/* Live timing of EVERY kernel the batch chains launch (bench.py's roofline objects of configs 3-5 name the kernel with the largest
+ * share of a step from it): smilehip_kernel_timing(1) clears the records and brackets every launch from then on with two HIP events
+ * on the stream the kernel is launched on; after the caller has synchronised, smilehip_kernel_timing_report writes one line per
+ * kernel name -- "name<TAB>launches<TAB>summed ms" -- into buf and returns the text's length (negative: buflen too small, the
+ * length needed negated). smilehip_kernel_timing(0) switches it off. Process-wide. */
+int  smilehip_kernel_timing(int enable);
+int64_t smilehip_kernel_timing_report(char *buf, int64_t buflen);
 
 /* ------------------------------------- per-component batched entry points */
 /* Same arithmetic, one reference component at a time, over n_frames frames;

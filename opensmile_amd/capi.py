@@ -179,6 +179,8 @@ SYMBOLS = {
     "smilehip_htk_rows_be": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "smilehip_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "smilehip_kernel_timing": (C.c_int, [C.c_int]),
+    "smilehip_kernel_timing_report": (C.c_int64, [_vp, _i64]),
     "smilehip_copy_to_device_2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "smilehip_copy_to_host_2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "smilehip_host_register": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -834,6 +836,31 @@ def pcm_convert_host(ctx, raw, n_bps, n_bits, n_chan, mixdown=True):
     finally:
         L.smilehip_free(ctx._h, d_in)
         L.smilehip_free(ctx._h, d_out)
+    return out
+
+
+def kernel_timing(enable=True):
+    """HIP events around every batch-chain launch from now on (records cleared); process-wide (smilehip_kernel_timing)"""
+    _check(load().smilehip_kernel_timing(1 if enable else 0))
+
+
+def kernel_timing_report():
+    """{kernel name (template arguments stripped): (launches, summed ms)} of the launches since kernel_timing(True); call after
+    synchronising (smilehip_kernel_timing_report)"""
+    L = load()
+    n = 1 << 16
+    while True:
+        buf = C.create_string_buffer(n)
+        got = L.smilehip_kernel_timing_report(buf, n)
+        if got >= 0:
+            break
+        n = -got + 1
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, launches, ms = line.split("\t")
+        name = name.split("<")[0].strip()
+        a = out.get(name, (0, 0.0))
+        out[name] = (a[0] + int(launches), a[1] + float(ms))
     return out
 
 

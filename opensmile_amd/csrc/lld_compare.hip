@@ -13,6 +13,7 @@
 //   lld_compare_groupA  SMA + delta of group A, whose levels have different lengths
 // Group B's SMA + delta run through the generic window chain (lld_kernels.hip).
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cstdlib>
 
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(64) lld_compare_b_extra(const int64_t *frame_o
 hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_row_off, int n_utt, const float *rawB, float *out110,
                                   hipStream_t s) {
   if (n_utt <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_compare_b_extra, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, d_row_off, n_utt, rawB, out110);
+  SMILEHIP_KLAUNCH(lld_compare_b_extra, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, d_row_off, n_utt, rawB, out110);
   return hipGetLastError();
 }
 
@@ -581,12 +582,12 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     const void *fn = P.Nfft == 256 ? reinterpret_cast<const void *>(&lld_compare_frame_wave_g<2>) : reinterpret_cast<const void *>(&lld_compare_frame_wave_g<8>);
     hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
-    if (P.Nfft == 256) hipLaunchKernelGGL(lld_compare_frame_wave_g<2>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
-    else hipLaunchKernelGGL(lld_compare_frame_wave_g<8>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    if (P.Nfft == 256) SMILEHIP_KLAUNCH(lld_compare_frame_wave_g<2>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else SMILEHIP_KLAUNCH(lld_compare_frame_wave_g<8>, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   } else if (use_block) {
     const size_t lds = sizeof(float) * (size_t)(Npad + 2 * M + 3 * Kpad + 96) + sizeof(double) * (64 + 256) + 32 +
                        sizeof(float) * (size_t)(Kpad + 128 + 16 * 32);
-    hipLaunchKernelGGL(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
+    SMILEHIP_KLAUNCH(lld_compare_frame, dim3((unsigned)n_runs), dim3(256), lds, s, P, Q);
   } else {
     const size_t lds = sizeof(float) * (size_t)(512 + Kpad + 128 + 16 * 32 + oo_table_floats(P.oo) + 4 * (compare_z_floats(M, Kpad) + 3 * Kpad + 96 + ((Q.N60 + 3) & ~3)));
     if (P.N > Q.N60) return hipErrorInvalidValue;
@@ -601,7 +602,7 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     // (the quad form first: it is short enough not to crowd out a small batch's jitter pass, the reason for the two-wave build below)
     const bool quad_ok = P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
                          P.pcm && !P.pcm_f32 && !(force && force[0] == '2');
-    if (beside_small_jitter_pass && !quad_ok) hipLaunchKernelGGL(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    if (beside_small_jitter_pass && !quad_ok) SMILEHIP_KLAUNCH(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
     else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
              P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && Q.band_iL[0] >= 0 && Q.band_iL[0] < Q.band_iR[0] && Q.band_iR[0] <= 256 &&
              Q.band_iL[1] >= 0 && Q.band_iL[1] < Q.band_iR[1] && Q.band_iR[1] <= 256 && Q.max_utt_samples < (int64_t(1) << 31) &&
@@ -611,18 +612,18 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
       hipError_t eq = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
       if (eq != hipSuccess) return eq;
       const int per_wg = kCmpQuadWaves * 4;
-      hipLaunchKernelGGL(lld_compare_frame_quad, dim3((unsigned)((n_runs + per_wg - 1) / per_wg)), dim3(kCmpQuadWaves * 64), qlds, s, P, Q, n_runs);
+      SMILEHIP_KLAUNCH(lld_compare_frame_quad, dim3((unsigned)((n_runs + per_wg - 1) / per_wg)), dim3(kCmpQuadWaves * 64), qlds, s, P, Q, n_runs);
     } else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && !getenv("SMILEHIP_COMPARE_GENERAL"))
-      hipLaunchKernelGGL(lld_compare_frame_wave3t, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
-    else hipLaunchKernelGGL(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+      SMILEHIP_KLAUNCH(lld_compare_frame_wave3t, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else SMILEHIP_KLAUNCH(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_compare_rasta, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q);
+  SMILEHIP_KLAUNCH(lld_compare_rasta, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (total_rows > 0)
-    hipLaunchKernelGGL(lld_compare_groupA, dim3((unsigned)((total_rows * 4 + 255) / 256)), dim3(256), 0, s, P.frame_off,
+    SMILEHIP_KLAUNCH(lld_compare_groupA, dim3((unsigned)((total_rows * 4 + 255) / 256)), dim3(256), 0, s, P.frame_off,
                        d_row_off, P.n_utt, total_rows, Q, d_out, ld_out, de_col);
   return hipGetLastError();
 }

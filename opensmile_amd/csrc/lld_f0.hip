@@ -21,6 +21,7 @@
 //                   path buffer, decisions emitted where all paths agree or forced when the buffer is full),
 //                   lane = (state now, state before) pair; then cValbasedSelector's energy gate. 2.6 ms.
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cstring>
 #include <type_traits>
@@ -1341,17 +1342,17 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
     Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
     const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
     if constexpr (LOGM == 9) {
-      if (oo && s16) hipLaunchKernelGGL((lld_f0_spec<true, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else if (oo) hipLaunchKernelGGL((lld_f0_spec<true, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else if (s16) hipLaunchKernelGGL((lld_f0_spec<false, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else hipLaunchKernelGGL((lld_f0_spec<false, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      if (oo && s16) SMILEHIP_KLAUNCH((lld_f0_spec<true, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else if (oo) SMILEHIP_KLAUNCH((lld_f0_spec<true, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else if (s16) SMILEHIP_KLAUNCH((lld_f0_spec<false, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      else SMILEHIP_KLAUNCH((lld_f0_spec<false, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
     } else {
-      hipLaunchKernelGGL(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      SMILEHIP_KLAUNCH(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
     }
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
-    hipLaunchKernelGGL(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
-    if constexpr (LOGM == 9) hipLaunchKernelGGL(lld_f0_cand9, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
-    else hipLaunchKernelGGL(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    SMILEHIP_KLAUNCH(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
+    if constexpr (LOGM == 9) SMILEHIP_KLAUNCH(lld_f0_cand9, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    else SMILEHIP_KLAUNCH(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1374,19 +1375,19 @@ hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, flo
   }
   if (e != hipSuccess) return e;
   if (frames_done && (e = hipEventRecord(frames_done, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q0, d_out, ld_out);
+  SMILEHIP_KLAUNCH(lld_f0_viterbi, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, P.n_utt, Q0, d_out, ld_out);
   return hipGetLastError();
 }
 hipError_t launch_f0_viterbi_step(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
                                   int flush, hipStream_t s) {
   if (Q.vit_buf < 2 || Q.vit_buf > kVBmax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lld_f0_viterbi_step, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, flush);
+  SMILEHIP_KLAUNCH(lld_f0_viterbi_step, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, flush);
   return hipGetLastError();
 }
 hipError_t launch_f0_viterbi_steps(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,
                                    int n_steps, hipStream_t s) {
   if (Q.vit_buf < 2 || Q.vit_buf > kVBmax || n_steps < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lld_f0_viterbi_steps, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, n_steps);
+  SMILEHIP_KLAUNCH(lld_f0_viterbi_steps, dim3(1), dim3(64), 0, s, Q, d_frames, d_st, d_dstate, d_paths, d_decided, n_steps);
   return hipGetLastError();
 }
 int f0_viterbi_max_buffer() { return kVBmax; }
@@ -1423,10 +1424,10 @@ hipError_t launch_f0_rows_g(const F0Params &Q, int max_blocks, hipStream_t s) {
   LldParams P;
   std::memset(&P, 0, sizeof(P));
   if constexpr (LOGM == 9) {
-    if (oo) hipLaunchKernelGGL((lld_f0_frame<9, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
-    else hipLaunchKernelGGL((lld_f0_frame<9, false>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+    if (oo) SMILEHIP_KLAUNCH((lld_f0_frame<9, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+    else SMILEHIP_KLAUNCH((lld_f0_frame<9, false>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
   } else {
-    hipLaunchKernelGGL((lld_f0_frame<LOGM, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
+    SMILEHIP_KLAUNCH((lld_f0_frame<LOGM, true>), dim3(grid), dim3(kWaves * 64), lds, s, P, Q);
   }
   return hipGetLastError();
 }
@@ -1444,8 +1445,8 @@ hipError_t launch_f0_rows(const F0Params &Q, int max_blocks, hipStream_t s) {
       const void *fn = big ? reinterpret_cast<const void *>(&lld_f0_rows_big<11>) : reinterpret_cast<const void *>(&lld_f0_rows_big<10>);
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      if (big) hipLaunchKernelGGL(lld_f0_rows_big<11>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
-      else hipLaunchKernelGGL(lld_f0_rows_big<10>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
+      if (big) SMILEHIP_KLAUNCH(lld_f0_rows_big<11>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
+      else SMILEHIP_KLAUNCH(lld_f0_rows_big<10>, dim3((unsigned)Q.n_rows), dim3(64), lds, s, Q);
       return hipGetLastError();
     }
     default: return hipErrorInvalidValue;
@@ -1459,7 +1460,7 @@ hipError_t launch_f0_lld(const LldParams &P, const F0Params &Q, const int64_t *d
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
   hipError_t e = launch_f0_jitter(P, Q, d_pitch2, 2, d_jit4, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
+  SMILEHIP_KLAUNCH(lld_f0_lld, dim3((unsigned)P.n_utt), dim3(64), 0, s, P.frame_off, d_row_off, P.n_utt, d_pitch2, d_jit4,
                      Q.pending, d_out, ld_out, col_sma, col_de);
   return hipGetLastError();
 }

@@ -16,6 +16,7 @@
 // Peaks2's list of local extrema is not materialised: an element is identified by its row index and only an
 // "alive" byte per row is kept; each pruning pass re-derives the extrema from three neighbouring samples.
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -1608,30 +1609,30 @@ hipError_t launch_funcspec(const FsParams &P, int n_utt, const int *fam_off, con
   if (n_utt <= 0 || P.n_cols <= 0) return hipSuccess;
   const int groups = (P.n_cols + kColsPerBlock - 1) / kColsPerBlock;
   const dim3 grid((unsigned)(n_utt * groups)), block(kColsPerBlock);
-  hipLaunchKernelGGL(fs_stats, grid, block, 0, s, P);
+  SMILEHIP_KLAUNCH(fs_stats, grid, block, 0, s, P);
   for (int i = 0; i < P.spec.n_fam; ++i) {
     const int off = fam_off[i], want = fam_want[i];
     switch (P.spec.fam[i]) {
-      case SMILEHIP_FAM_EXTREMES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_EXTREMES>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_MEANS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_MEANS>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_MOMENTS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_MOMENTS>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_REGRESSION: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_REGRESSION>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_TIMES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_TIMES>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_SEGMENTS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SEGMENTS>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_LPC: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_PEAKS2: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_ONSET: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_ONSET>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_PEAKS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_PEAKS>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_CROSSINGS: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_CROSSINGS>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_DCT: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_DCT>, grid, block, 0, s, P, off, want); break;
-      case SMILEHIP_FAM_SAMPLES: hipLaunchKernelGGL(fs_family<SMILEHIP_FAM_SAMPLES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_EXTREMES: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_EXTREMES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_MEANS: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_MEANS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_MOMENTS: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_MOMENTS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_REGRESSION: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_REGRESSION>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_TIMES: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_TIMES>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_SEGMENTS: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_SEGMENTS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_LPC: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_LPC>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_PEAKS2: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_PEAKS2>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_ONSET: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_ONSET>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_PEAKS: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_PEAKS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_CROSSINGS: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_CROSSINGS>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_DCT: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_DCT>, grid, block, 0, s, P, off, want); break;
+      case SMILEHIP_FAM_SAMPLES: SMILEHIP_KLAUNCH(fs_family<SMILEHIP_FAM_SAMPLES>, grid, block, 0, s, P, off, want); break;
       case SMILEHIP_FAM_MODULATION:
-        hipLaunchKernelGGL(fs_modulation, dim3((unsigned)(n_utt * P.n_cols)), dim3(64), 0, s, P, off);
+        SMILEHIP_KLAUNCH(fs_modulation, dim3((unsigned)(n_utt * P.n_cols)), dim3(64), 0, s, P, off);
         break;
       case SMILEHIP_FAM_PERCENTILES:
-        hipLaunchKernelGGL(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
+        SMILEHIP_KLAUNCH(fs_percentiles_wave, dim3((unsigned)((n_utt * P.n_cols + 3) / 4)), dim3(256), 0, s, P, off, n_utt * P.n_cols);
         if (P.max_rows > kWaveSortMax)                   // some contour may be longer than one wave sorts
-          hipLaunchKernelGGL(fs_percentiles, dim3((unsigned)(n_utt * P.n_cols)), dim3(kSortThreads), 0, s, P, off);
+          SMILEHIP_KLAUNCH(fs_percentiles, dim3((unsigned)(n_utt * P.n_cols)), dim3(kSortThreads), 0, s, P, off);
         break;
       default: return hipErrorInvalidValue;
     }

@@ -20,6 +20,7 @@
 // Reference-order arithmetic where the result is order-sensitive (float sums of cSpecResample / cLpc, the QR iteration);
 // sums the reference keeps in double are formed as double tree sums. Parity first; bounds in DESIGN.md.
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cstring>
 
@@ -1214,19 +1215,19 @@ hipError_t launch_gemaps_spectral_rows(const float *src, int64_t lds, float *sta
                                        int K, const GemapsParams &G, hipStream_t s) {
   if (nF <= 0) return hipSuccess;
   if (K > 516) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lld_gemaps_spectral_rows, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, G);
+  SMILEHIP_KLAUNCH(lld_gemaps_spectral_rows, dim3(1), dim3(64), 0, s, src, lds, state, first ? 1 : 0, dst, ldd, nF, K, G);
   return hipGetLastError();
 }
 
 // op_mode 1 (cSpecResample rows) / 2 (cLpc rows) of the resampling kernel; cFormantLpc rows
 hipError_t launch_gemaps_lpc_rows(const GemapsParams &G, hipStream_t s) {
   if (G.op_rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.op_rows + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
+  SMILEHIP_KLAUNCH(lld_gemaps_lpc, dim3((unsigned)((G.op_rows + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
   return hipGetLastError();
 }
 static hipError_t launch_formants(const GemapsParams &G, int64_t rows, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_formants, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, G);
+  SMILEHIP_KLAUNCH(lld_gemaps_formants, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, G);
   return hipGetLastError();
 }
 hipError_t launch_gemaps_formant_rows(const GemapsParams &G, hipStream_t s) {
@@ -1251,15 +1252,15 @@ hipError_t launch_gemaps_frames(const LldParams &P, const GemapsParams &G, int n
     if (eq != hipSuccess) return eq;
     const int per_wg = kGmQuadWaves * 4;
     const dim3 qgrid((unsigned)((n_runs + per_wg - 1) / per_wg)), qblock(kGmQuadWaves * 64);
-    if (P.pad_left) hipLaunchKernelGGL(lld_gemaps_frame20_quad<96>, qgrid, qblock, qlds, s, P, G, n_runs);
-    else hipLaunchKernelGGL(lld_gemaps_frame20_quad<0>, qgrid, qblock, qlds, s, P, G, n_runs);
+    if (P.pad_left) SMILEHIP_KLAUNCH(lld_gemaps_frame20_quad<96>, qgrid, qblock, qlds, s, P, G, n_runs);
+    else SMILEHIP_KLAUNCH(lld_gemaps_frame20_quad<0>, qgrid, qblock, qlds, s, P, G, n_runs);
   } else {
-    hipLaunchKernelGGL(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
+    SMILEHIP_KLAUNCH(lld_gemaps_frame20, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, G, n_runs);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (G.total_frames20 <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_lpc, dim3((unsigned)((G.total_frames20 + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
+  SMILEHIP_KLAUNCH(lld_gemaps_lpc, dim3((unsigned)((G.total_frames20 + kLpcTile - 1) / kLpcTile)), dim3(256), 0, s, G);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_formants(G, G.total_frames20, s);
@@ -1280,7 +1281,7 @@ hipError_t launch_harm_g(const LldParams &P, const F0Params &Q, const GemapsPara
   if (grid > (unsigned)(2 * max_blocks)) grid = (unsigned)(2 * max_blocks);   // M = 512: 78 KB of LDS per workgroup, two per CU
   // (the tile counter starts from zero at every launch, whatever an earlier launch left behind)
   if (G.harm_ctl && (e = hipMemsetAsync(G.harm_ctl, 0, 2 * sizeof(int32_t), s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_gemaps_harm<LOGM>, dim3(grid), dim3(HG::kWaves * 64), lds, s, P, Q, G);
+  SMILEHIP_KLAUNCH(lld_gemaps_harm<LOGM>, dim3(grid), dim3(HG::kWaves * 64), lds, s, P, Q, G);
   return hipGetLastError();
 }
 }  // namespace
@@ -1300,13 +1301,13 @@ hipError_t launch_gemaps_harm(const LldParams &P, const F0Params &Q, const Gemap
 hipError_t launch_gemaps_tail(const int64_t *d_frame_off20, const int64_t *d_row_off, int n_utt, const GemapsParams &G, float *d_out,
                               int64_t ld_out, hipStream_t s) {
   if (n_utt <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_tail, dim3((unsigned)n_utt), dim3(256), 0, s, d_frame_off20, d_row_off, n_utt, G, d_out, ld_out);
+  SMILEHIP_KLAUNCH(lld_gemaps_tail, dim3((unsigned)n_utt), dim3(256), 0, s, d_frame_off20, d_row_off, n_utt, G, d_out, ld_out);
   return hipGetLastError();
 }
 
 hipError_t launch_gemaps_dbp(float *d_x, int64_t ld, int n_utt, const int64_t *d_row_off, hipStream_t s) {
   if (n_utt <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lld_gemaps_dbp, dim3((unsigned)((n_utt + 255) / 256)), dim3(256), 0, s, d_x, ld, n_utt, d_row_off);
+  SMILEHIP_KLAUNCH(lld_gemaps_dbp, dim3((unsigned)((n_utt + 255) / 256)), dim3(256), 0, s, d_x, ld, n_utt, d_row_off);
   return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 // window chain (lld_kernels.hip) adds SMA + delta. Correctness first: this path is
 // not yet tuned (three LDS FFTs per frame).
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -596,13 +597,13 @@ __global__ void __launch_bounds__(64) lld_pitch_contour_frames(const double *voi
 hipError_t launch_pitch_contour_frames(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
                                        float *d_out4, int64_t n_frames, hipStream_t s) {
   if (n_frames > 0)
-    hipLaunchKernelGGL(lld_pitch_contour_frames, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
+    SMILEHIP_KLAUNCH(lld_pitch_contour_frames, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
                        reinterpret_cast<PitchContour *>(d_state), d_out4, n_frames);
   return hipGetLastError();
 }
 hipError_t launch_pitch_contour_step(const double *d_voicing, const int32_t *d_max_idx, double Tsamp, double cutoff, float *d_state,
                                      float *d_out4, hipStream_t s) {
-  hipLaunchKernelGGL(lld_pitch_contour_step, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
+  SMILEHIP_KLAUNCH(lld_pitch_contour_step, dim3(1), dim3(64), 0, s, d_voicing, d_max_idx, Tsamp, cutoff,
                      reinterpret_cast<PitchContour *>(d_state), d_out4);
   return hipGetLastError();
 }
@@ -635,24 +636,24 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
     int64_t grid = (P.total_frames + 4 * kQuadWaves - 1) / (4 * kQuadWaves);
     const int64_t cap = (int64_t)(n_cu > 0 ? n_cu : 256) * (int64_t)(160 * 1024 / quad_bytes);
     if (grid > cap) grid = cap;
-    if (full) hipLaunchKernelGGL((lld_is09_frame_quad<25, true>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
-    else if (n25) hipLaunchKernelGGL((lld_is09_frame_quad<25, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
-    else hipLaunchKernelGGL((lld_is09_frame_quad<32, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    if (full) SMILEHIP_KLAUNCH((lld_is09_frame_quad<25, true>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    else if (n25) SMILEHIP_KLAUNCH((lld_is09_frame_quad<25, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
+    else SMILEHIP_KLAUNCH((lld_is09_frame_quad<32, false>), dim3((unsigned)grid), dim3(kQuadWaves * 64), quad_bytes, s, P, Q);
   } else if (P.n_bands <= 32 && P.n_mfcc <= 16 && 4 * lds_wave + 4 * tbl_floats <= 64 * 1024 &&
       !(form && !strcmp(form, "block"))) {                             // a wave per frame: four frames per workgroup
     const int wave_floats = (int)((lds_wave + 15) / 16) * 4;
     const size_t total = sizeof(float) * (tbl_floats + 4 * (size_t)wave_floats);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), total, s, P, Q, wave_floats);
+    SMILEHIP_KLAUNCH(lld_is09_frame_wave, dim3((unsigned)((P.total_frames + 3) / 4)), dim3(256), total, s, P, Q, wave_floats);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_is09_frame), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lld_is09_frame, dim3((unsigned)P.total_frames), dim3(256), lds, s, P, Q);
+    SMILEHIP_KLAUNCH(lld_is09_frame, dim3((unsigned)P.total_frames), dim3(256), lds, s, P, Q);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_pitch_smooth, dim3((unsigned)((P.n_utt + 63) / 64)), dim3(64), 0, s, P.frame_off, P.n_utt, Q.raw16);
+  SMILEHIP_KLAUNCH(lld_pitch_smooth, dim3((unsigned)((P.n_utt + 63) / 64)), dim3(64), 0, s, P.frame_off, P.n_utt, Q.raw16);
   return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@
 // Time meta of frame t as the framer derives it from a wave level without stored time stamps
 // (dataMemoryLevel.cpp:617-626,1226-1245): lengthSec = ((tH+N-1)Tw - tH Tw) + Tw, so lenF = ceil(lengthSec/Tw) is N or N+1.
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -588,8 +589,8 @@ hipError_t launch_jitter_utt(const LldParams &P, const F0Params &Q, const float 
   const void *fn = wide ? reinterpret_cast<const void *>(&lld_f0_jitter<256>) : reinterpret_cast<const void *>(&lld_f0_jitter<64>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  if (wide) hipLaunchKernelGGL(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), lds, s, P, Q, d_f0, ld_f0, d_jit4, redo);
-  else hipLaunchKernelGGL(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, redo);
+  if (wide) SMILEHIP_KLAUNCH(lld_f0_jitter<256>, dim3((unsigned)P.n_utt), dim3(256), lds, s, P, Q, d_f0, ld_f0, d_jit4, redo);
+  else SMILEHIP_KLAUNCH(lld_f0_jitter<64>, dim3((unsigned)P.n_utt), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, redo);
   return hipGetLastError();
 }
 }  // namespace
@@ -639,7 +640,7 @@ hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *
   // the caller abandoned, must not leave later runs skipping items
   if ((e = hipMemsetAsync(Q.jit_ctl, 0, 2 * sizeof(int32_t), s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(Q.jit_redo, 0, sizeof(int32_t) * (size_t)P.n_utt, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(lld_jitter_runs, dim3((unsigned)grid), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, mark_all ? 1 : 0);
+  SMILEHIP_KLAUNCH(lld_jitter_runs, dim3((unsigned)grid), dim3(64), lds, s, P, Q, d_f0, ld_f0, d_jit4, mark_all ? 1 : 0);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_jitter_utt(P, Q, d_f0, ld_f0, d_jit4, Q.jit_redo, s);
 }

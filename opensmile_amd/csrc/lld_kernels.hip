@@ -13,6 +13,7 @@
 //   lld_delta_*        R13 delta/accel tail incl. the end-of-input rules.
 // The fast fused kernel for Nfft = 512 lives in lld_mfcc512.hip.
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include "lld_device.hpp"
 #include "lld_blocks.hpp"
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(64) lld_chain_short(ChainParams P) {
 hipError_t launch_mfcc_generic(const LldParams &P, hipStream_t s) {
   const int M = P.Nfft / 2;
   const size_t lds = sizeof(float) * (size_t)(2 * M + P.K + 1 + P.n_bands + 24);
-  hipLaunchKernelGGL(lld_mfcc_generic, dim3((unsigned)P.total_frames), dim3(256), lds, s, P);
+  SMILEHIP_KLAUNCH(lld_mfcc_generic, dim3((unsigned)P.total_frames), dim3(256), lds, s, P);
   return hipGetLastError();
 }
 
@@ -421,7 +422,7 @@ hipError_t launch_log_energy(const LldParams &P, const int32_t *d_tile_utt, cons
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_log_energy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
   }
-  hipLaunchKernelGGL(lld_log_energy, dim3((unsigned)n_tiles), dim3(64), lds, s, P, d_tile_utt, d_tile_t0, kChainTile, dst, ld, col);
+  SMILEHIP_KLAUNCH(lld_log_energy, dim3((unsigned)n_tiles), dim3(64), lds, s, P, d_tile_utt, d_tile_t0, kChainTile, dst, ld, col);
   return hipGetLastError();
 }
 
@@ -429,7 +430,7 @@ hipError_t launch_cms(const int64_t *d_frame_off, int n_utt, const float *x, int
                       hipStream_t s) {
   if (n_utt <= 0 || n_cols <= 0) return hipSuccess;
   if (n_cols > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lld_cms, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, n_utt, x, ld_x, out, ld_out, n_cols);
+  SMILEHIP_KLAUNCH(lld_cms, dim3((unsigned)n_utt), dim3(64), 0, s, d_frame_off, n_utt, x, ld_x, out, ld_out, n_cols);
   return hipGetLastError();
 }
 
@@ -442,12 +443,12 @@ hipError_t launch_chain(const ChainParams &P, hipStream_t s) {
     if (P.W[i] < 1 || P.W[i] > kChainMaxW) return hipErrorInvalidValue;
   if (P.short_T > kShortMaxT) return hipErrorInvalidValue;
   if (P.n_tiles > 0)
-    hipLaunchKernelGGL(lld_chain_tiled, dim3((unsigned)P.n_tiles, (unsigned)((P.D + kChainMaxD - 1) / kChainMaxD)), dim3(256), 0, s, P);
+    SMILEHIP_KLAUNCH(lld_chain_tiled, dim3((unsigned)P.n_tiles, (unsigned)((P.D + kChainMaxD - 1) / kChainMaxD)), dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (P.n_short > 0) {
     const int m = P.n_short * P.D;
-    hipLaunchKernelGGL(lld_chain_short, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, P);
+    SMILEHIP_KLAUNCH(lld_chain_short, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, P);
     e = hipGetLastError();
   }
   return e;

@@ -43,6 +43,7 @@
 // measured in tests/test_gpu_mfcc.py; the reference-order path is
 // lld_mfcc_generic (SMILEHIP_FORCE_GENERIC=1).
 #include <hip/hip_runtime.h>
+#include "kernel_timing.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -851,7 +852,7 @@ hipError_t launch_mfcc512(const LldParams &P, const Fast512Tables &F, const Fast
     const void *fn = reinterpret_cast<const void *>(&lld_mfcc512<__VA_ARGS__>);                                 \
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((lld_mfcc512<__VA_ARGS__>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F);        \
+    SMILEHIP_KLAUNCH((lld_mfcc512<__VA_ARGS__>), dim3(grid), dim3(kWavesPerBlock * 64), lds, s, P, F);        \
     launched = true;                                                                                            \
   }
 #define SMILEHIP_MATCH(MPV, PE, UP, AL, PL, UCV)                                                                \

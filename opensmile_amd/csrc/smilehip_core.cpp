@@ -1,6 +1,11 @@
 // libsmilehip, C ABI part 1: errors, context life cycle, device-memory plumbing (include/smilehip.h).
 #include "smilehip_internal.hpp"
 #include "lld_stage.hpp"
+#include "kernel_timing.hpp"
+
+#include <map>
+#include <mutex>
+#include <vector>
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -128,4 +133,69 @@ extern "C" int smilehip_stream_synchronize(smilehip_context *ctx, void *stream) 
   if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_synchronize: null context");
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return SMILEHIP_OK;
+}
+
+// ------------------------------------------------------------------ live per-kernel timing (kernel_timing.hpp)
+namespace smilehip {
+bool g_kernel_timing_on = false;
+namespace {
+struct KRec { const char *name; hipEvent_t a, b; };
+std::mutex g_kt_mu;
+std::vector<KRec> g_kt_recs;
+std::vector<hipEvent_t> g_kt_pool;
+thread_local std::vector<size_t> g_kt_open;               // records begun on this thread and not ended yet (launches do not nest across threads)
+hipEvent_t kt_event() {
+  if (!g_kt_pool.empty()) { hipEvent_t e = g_kt_pool.back(); g_kt_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+void kernel_mark_begin(const char *name, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_kt_mu);
+  KRec r{name, kt_event(), kt_event()};
+  if (r.a) (void)hipEventRecord(r.a, s);
+  g_kt_recs.push_back(r);
+  g_kt_open.push_back(g_kt_recs.size() - 1);
+}
+void kernel_mark_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_kt_mu);
+  if (g_kt_open.empty()) return;
+  const size_t i = g_kt_open.back();
+  g_kt_open.pop_back();
+  if (i < g_kt_recs.size() && g_kt_recs[i].b) (void)hipEventRecord(g_kt_recs[i].b, s);
+}
+}  // namespace smilehip
+
+extern "C" int smilehip_kernel_timing(int enable) {
+  std::lock_guard<std::mutex> lock(smilehip::g_kt_mu);
+  for (auto &r : smilehip::g_kt_recs) { if (r.a) smilehip::g_kt_pool.push_back(r.a); if (r.b) smilehip::g_kt_pool.push_back(r.b); }
+  smilehip::g_kt_recs.clear();
+  smilehip::g_kernel_timing_on = enable != 0;
+  return SMILEHIP_OK;
+}
+
+extern "C" int64_t smilehip_kernel_timing_report(char *buf, int64_t buflen) {
+  if (!buf || buflen < 1) return -1;
+  std::lock_guard<std::mutex> lock(smilehip::g_kt_mu);
+  std::map<std::string, std::pair<double, long>> sum;
+  for (auto &r : smilehip::g_kt_recs) {
+    float ms = 0.0f;
+    if (!r.a || !r.b || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    std::string n = r.name;
+    while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
+    while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
+    auto &e = sum[n];
+    e.first += ms;
+    e.second += 1;
+  }
+  std::string out;
+  char line[256];
+  for (auto &kv : sum) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.second, kv.second.first);
+    out += line;
+  }
+  if ((int64_t)out.size() + 1 > buflen) return -(int64_t)out.size() - 1;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int64_t)out.size();
 }

@@ -42,11 +42,44 @@ inline bool allow_cpu() { return false; }
   } while (0)
 #endif
 
+// The device is opened (runtime start-up, code objects, a first launch: ~0.3 s) on a thread of its own as soon as the loader asks the
+// plugin for its components, beside the host's own start-up -- reading the configuration, creating the instances, the wave source's
+// first blocks. The first override that needs the device waits for it here.
+struct DeviceStart {
+  std::thread th;
+  smilehip_context *ctx = nullptr;
+  int rc = 0;
+  std::string err;
+  bool started = false;
+  void start() {
+    if (started) return;
+    started = true;
+    th = std::thread([this] {
+      const char *dev = getenv("SMILEHIP_DEVICE");
+      rc = smilehip_init(dev ? atoi(dev) : 0, &ctx);
+      if (rc != SMILEHIP_OK) { err = smilehip_last_error(); return; }
+      void *d = nullptr;                                   // the library's code objects load with the first launch
+      if (smilehip_alloc(ctx, 16, &d) == SMILEHIP_OK) {
+        smilehip_pcm16_to_float(ctx, (const int16_t *)d, 1, (float *)((char *)d + 8), nullptr);
+        smilehip_stream_synchronize(ctx, nullptr);
+        smilehip_free(ctx, d);
+      }
+    });
+  }
+  ~DeviceStart() { if (th.joinable()) th.join(); }
+} g_device_start;
+
 smilehip_context *context() {
   if (!g_ctx) {
-    const char *dev = getenv("SMILEHIP_DEVICE");
-    if (smilehip_init(dev ? atoi(dev) : 0, &g_ctx) != SMILEHIP_OK)
-      COMP_ERR("libsmilehip: %s", smilehip_last_error());
+    if (g_device_start.started) {
+      if (g_device_start.th.joinable()) g_device_start.th.join();
+      if (g_device_start.rc != SMILEHIP_OK) COMP_ERR("libsmilehip: %s", g_device_start.err.c_str());
+      g_ctx = g_device_start.ctx;
+    } else {
+      const char *dev = getenv("SMILEHIP_DEVICE");
+      if (smilehip_init(dev ? atoi(dev) : 0, &g_ctx) != SMILEHIP_OK)
+        COMP_ERR("libsmilehip: %s", smilehip_last_error());
+    }
   }
   return g_ctx;
 }

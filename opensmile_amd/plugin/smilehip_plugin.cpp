@@ -71,6 +71,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <map>
@@ -138,6 +139,10 @@ extern "C" sComponentInfo *registerPluginComponent(cConfigManager *confman, cCom
   g_confman = confman;                                      // the parsed graph lives there (plugin_shared.hpp: FusedChain::init)
   g_compman = compman;
   const char *only = getenv("SMILEHIP_PLUGIN_COMPONENTS");   // e.g. "cMelspec,cMfcc"; default: all twenty-eight
+  {                                                         // open the device beside the host's own start-up (plugin_shared.hpp: DeviceStart)
+    const char *lazy = getenv("SMILEHIP_PLUGIN_LAZY_DEVICE");
+    if (!(only && !strcmp(only, "none")) && !(lazy && lazy[0] == '1')) g_device_start.start();
+  }
   auto want = [&](const char *name) {                       // whole names of the comma-separated list
     if (!only) return true;
     const size_t n = strlen(name);

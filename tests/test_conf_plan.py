@@ -16,7 +16,7 @@ G = os.path.join(ROOT, "tests", "golden", "files")
 
 def _copytree(src, dst):
     """a writable copy (the reference tree, and with it oracle/_ref/config, may be read-only; the tests edit their copies)"""
-    _copytree(src, dst)
+    shutil.copytree(src, dst)
     for d, _dirs, files in os.walk(dst):
         os.chmod(d, 0o755)
         for f in files:

@@ -63,7 +63,7 @@ PY
     pmc:*)
       c=${sec#pmc:}
       if [ $c = 2 ]; then X="--no-configs --no-h2d"; else X="--config $c"; fi
-      BENCH="python $R/bench.py $X --utts ${UTTS[$c]} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline"
+      BENCH="python $R/bench.py $X --utts ${PMC_UTTS:-${UTTS[$c]}} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline"      # PMC_UTTS=12500: the bench's own batch size
       cd /tmp && export TMPDIR=/tmp
       i=0
       for set in \
