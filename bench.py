@@ -364,6 +364,33 @@ def rank_report(dist, world, plumbing_only=False):
     return rep
 
 
+def open_comm(dist, world):
+    """The product's own gather library (include/smilehip_comm.h) for the path's one collective: an RCCL communicator joined through
+    the launcher's process group (rank 0's unique id is broadcast; torch.distributed moves nothing else). -> (Comm or None, text).
+    Ranks that share a device (the gloo plumbing fallback of launch_ranks) cannot form an RCCL communicator: torch.distributed P2P then."""
+    import torch
+    if world > 1 and dist.get_backend() != "nccl":
+        return None, f"torch.distributed point-to-point ({dist.get_backend()}: ranks share devices, no RCCL communicator)"
+    try:
+        from opensmile_amd import comm as smcomm
+        cm = smcomm.Comm.from_process_group(dist if world > 1 else None, torch.cuda.current_device())
+        return cm, "libsmilehip_comm.so (smilehip_comm_allgather_count + smilehip_comm_gather_rows: one grouped ncclSend / ncclRecv per gather)"
+    except Exception as e:
+        return None, f"torch.distributed point-to-point (libsmilehip_comm.so failed: {type(e).__name__}: {e})"
+
+
+def gather_rows(cm, dist, local, stream):
+    """every rank's rows to rank 0 (stream-ordered on `stream`): through the library, or torch.distributed when there is no communicator"""
+    import torch
+    if cm is None:
+        from opensmile_amd import gather
+        return gather.gather_features(local, dst=0)
+    counts = cm.allgather_count(local.shape[0], stream)
+    out = torch.empty((int(counts.sum()), local.shape[1]), dtype=torch.float32, device="cuda") if cm.rank == 0 else None
+    cm.gather_rows(local.data_ptr() if local.numel() else None, counts, int(local.shape[1]), out.data_ptr() if out is not None else None, stream)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +404,8 @@ def main():
                          "--utts utterances (5..15 s) sharded over the ranks by frame count (gather.shard_utterances)")
     ap.add_argument("--no-configs", action="store_true", help="leave BASELINE configs 3-5 out of the default line")
     ap.add_argument("--no-h2d", action="store_true", help="leave the PCIe-inclusive figures out of the default line")
+    ap.add_argument("--with-gather", action="store_true",
+                    help="run the gather section at N = 1 too (a world-size-1 communicator: rank 0's own block, the same calls)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="NO kernel is launched and nothing is measured: only the rank plumbing runs (launcher, rendezvous, barrier, "
                          "max-over-ranks, frame sum, gather, JSON) on the gloo backend with CPU tensors -- what the CPU test of the "
@@ -471,15 +500,18 @@ def main():
         total_frames = frames
 
     # the path's one collective: gather feature matrices to rank 0 (next to `value`, never in it)
-    gather_ms = None
-    if world > 1:
-        from opensmile_amd import gather
-        gather.gather_features(d_out, dst=0)         # (first call: communicator set-up, receive buffers)
+    gather_ms, gather_via = None, None
+    if world > 1 or args.with_gather:
+        cm, gather_via = open_comm(dist, world)
+        gather_rows(cm, dist, d_out, stream)         # (first call: communicator set-up, receive buffers)
         barrier()
         g0 = time.perf_counter()
-        gather.gather_features(d_out, dst=0)
+        gathered = gather_rows(cm, dist, d_out, stream)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        del gathered
+        if cm is not None:
+            cm.close()
     ranks = rank_report(dist, world)
 
     if rank == 0:
@@ -547,6 +579,7 @@ def main():
             res["gather_ms"] = gather_ms
             res["value_incl_gather"] = total_frames * args.steps / (dt + args.steps * gather_ms * 1e-3)
             res["gather_note"] = "every step's feature matrices (frames x 39 f32 per rank) gathered to rank 0, not overlapped"
+            res["gather_via"] = gather_via
         if world == 1 and not args.no_h2d:
             try:
                 del d_out, d_pcm
@@ -670,7 +703,7 @@ def main_plumbing(args):
         dist.barrier()
     dt = time.perf_counter() - t0
     dts, total = [dt], frames
-    gathered = None
+    gathered, pieces = None, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         all_t = [torch.zeros_like(t) for _ in range(world)]
@@ -684,13 +717,23 @@ def main_plumbing(args):
         if rank == 0:
             gathered = [int(o.shape[0]) for o in out]
             assert all(float(o[0, 0]) == r + steps for r, o in enumerate(out))
+        # ... and in pieces: the call order of config 4's gather (opensmile_amd/comm.py: PieceGather; on devices the pieces travel
+        # through libsmilehip_comm.so, here through gloo -- the rows of each piece are the library's own arithmetic either way)
+        from opensmile_amd import comm as smcomm
+        pg = smcomm.PieceGather(local, dist, piece_rows=4096)
+        for k in range(pg.pieces):
+            pg.piece(k)
+        whole = pg.finish()
+        if rank == 0:
+            pieces = {"pieces": pg.pieces, "rows": int(whole.shape[0]),
+                      "equal": bool(torch.equal(whole, torch.cat(out)))}
     ranks = rank_report(dist, world, plumbing_only=True)
     if rank == 0:
         print(json.dumps({"metric": "PLUMBING ONLY -- no kernel launched, nothing measured", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
                           "config": {"workload": "rank plumbing of bench.py on CPU tensors (gloo)", "ranks_seen": len(dts),
-                                     "frames_total": total, "gathered_rows": gathered},
+                                     "frames_total": total, "gathered_rows": gathered, "gathered_in_pieces": pieces},
                           "ranks": ranks}), flush=True)
     finish_ranks()
 
@@ -754,20 +797,60 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
         fr = torch.tensor([frames], dtype=torch.int64, device="cuda")
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         total_frames = int(fr.item())
-    # the path's one collective: what a caller wants in one place goes to rank 0 -- config 5's 88 functionals per
-    # utterance (44 MB per rank), config 3's LLD matrix; config 4's LLD level (6.5 GB per rank) stays per rank (its functionals
-    # are not part of this step). Next to `value`, never in it.
-    gather_ms, gathered = None, None
-    if world > 1 and config in (3, 5):
-        from opensmile_amd import gather
-        g_src = d_func if config == 5 else d_out
-        gather.gather_features(g_src, dst=0)             # (first call: communicator set-up, receive buffers)
-        barrier()
-        g0 = time.perf_counter()
-        gather.gather_features(g_src, dst=0)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        gathered = "88 functionals per utterance" if config == 5 else "LLD matrix (rows x 32)"
+    # the path's one collective: what a caller wants in one place goes to rank 0, through the product's own library
+    # (include/smilehip_comm.h) -- config 5's 88 functionals per utterance (44 MB per rank) and config 3's LLD matrix in one grouped
+    # send / receive; config 4's LLD level (6.5 GB per rank) in pieces on the communicator's own stream BESIDE the next step's
+    # kernels (two output buffers). Next to `value`, never in it.
+    gather_ms, gathered, gather_via, overlap = None, None, None, None
+    if world > 1 or args.with_gather:
+        cm, gather_via = open_comm(dist, world)
+        if config in (3, 5) or cm is None:
+            g_src = d_func if config == 5 else d_out
+            gather_rows(cm, dist, g_src, stream)             # (first call: communicator set-up, receive buffers)
+            barrier()
+            g0 = time.perf_counter()
+            got = gather_rows(cm, dist, g_src, stream)
+            barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            gathered = "88 functionals per utterance" if config == 5 else f"LLD matrix (rows x {n_out})"
+            if rank == 0 and cm is not None:
+                overlap = {"rank0_block_equal": bool(torch.equal(got[:g_src.shape[0]], g_src))}
+            del got
+        else:
+            from opensmile_amd import comm as smcomm
+            piece_rows = 1 << 18                             # 136 MB of 130-column rows per rank and piece
+            bufs = [d_out, torch.empty_like(d_out)]
+            pg = smcomm.PieceGather(bufs[0], cm, piece_rows=piece_rows)      # counts exchanged once; rank 0 holds the gathered level
+            def issue(buf):
+                pg.rebind(buf)
+                for k in range(pg.pieces):
+                    pg.piece(k, after_stream=stream)
+            barrier()
+            g0 = time.perf_counter()
+            for i in range(steps):
+                cm.wait(stream)                              # the gathers issued so far (steps <= i - 2) are done before step i overwrites their buffer
+                if i > 0:
+                    issue(bufs[(i - 1) % 2])                 # step i - 1's rows travel while step i's kernels run
+                batch.run_device(d_pcm.data_ptr(), bufs[i % 2].data_ptr(), n_out, stream)
+            issue(bufs[(steps - 1) % 2])
+            cm.wait(stream)
+            barrier()
+            dt_ov = time.perf_counter() - g0
+            dts_ov = [dt_ov]
+            if world > 1:
+                t = torch.tensor([dt_ov], dtype=torch.float64, device="cuda")
+                all_t = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(all_t, t)
+                dts_ov = [float(x.item()) for x in all_t]
+            gathered = f"LLD level (rows x {n_out}) of every step, in pieces of {piece_rows} rows per rank on the communicator's stream beside the next step's kernels"
+            overlap = {"ms_per_step_with_overlapped_gather": max(dts_ov) / steps * 1e3, "pieces_per_step": pg.pieces, "piece_rows": piece_rows,
+                       "value_incl_gather_overlapped": total_frames * steps / max(dts_ov)}
+            if rank == 0:
+                last = bufs[(steps - 1) % 2]
+                overlap["rank0_block_equal"] = bool(torch.equal(pg.out[:last.shape[0]], last))
+            del pg, bufs
+        if cm is not None:
+            cm.close()
     if rank == 0:
         # the dominant kernel = the largest share of the step's summed kernel time (kernels on side streams overlap: the shares
         # are of the SUM, which exceeds the step's wall time where streams run beside each other)
@@ -815,9 +898,13 @@ def run_config(args, config, ranks, with_cpu=True, nested=False):
                          "issue": _issue_roofline(config, dom, dom_ms, by_kernel[dom][0] / steps if dom else 1),
                          "kernels_ms_per_step": {k: round(v[1] / steps, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])}},
         }
+        if gather_via is not None:
+            res["gathered"], res["gather_via"] = gathered, gather_via
         if gather_ms is not None:
-            res["gather_ms"], res["gathered"] = gather_ms, gathered
+            res["gather_ms"] = gather_ms
             res["value_incl_gather"] = total_frames * steps / (dt + steps * gather_ms * 1e-3)
+        if overlap is not None:
+            res["gather_check"] = overlap
         # HBM bytes of the roofline kernel(s) per launch: counted by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, each
         # alone) of this command at a smaller batch, kept per frame in profiles/ and scaled to this batch's frames
         tfile = os.path.join(ROOT, "profiles", f"pmc_traffic_c{config}.json")

@@ -628,11 +628,7 @@ hipError_t launch_is09(const LldParams &P, const Is09Params &Q, hipStream_t s) {
                            : (n25 ? reinterpret_cast<const void *>(&lld_is09_frame_quad<25, false>) : reinterpret_cast<const void *>(&lld_is09_frame_quad<32, false>));
     e = hipFuncSetAttribute(qfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
-    static const int n_cu = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-      return n;
-    }();
+    const int n_cu = current_device_cus();
     int64_t grid = (P.total_frames + 4 * kQuadWaves - 1) / (4 * kQuadWaves);
     const int64_t cap = (int64_t)(n_cu > 0 ? n_cu : 256) * (int64_t)(160 * 1024 / quad_bytes);
     if (grid > cap) grid = cap;

@@ -616,11 +616,7 @@ int jitter_wave_capacity(double Tw, int64_t N, double min_pitch, double search_r
 hipError_t launch_f0_jitter(const LldParams &P, const F0Params &Q, const float *d_f0, int64_t ld_f0, float *d_jit4, hipStream_t s) {
   if (P.n_utt <= 0 || P.total_frames <= 0) return hipSuccess;
   if (!(Q.jit_Tw > 0.0) || jit_scale(Q.jit_Tw) > 6) return hipErrorInvalidValue;      // up to 96 kHz
-  static const int max_cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-  }();
+  const int max_cus = current_device_cus();
   // SMILEHIP_JITTER (read at every launch; A/B switch and test aid): "utt" = one workgroup per utterance (the round-3 form),
   // "redo" = the runs, every utterance marked, i.e. everything done a second time by the redo pass
   const char *mode = getenv("SMILEHIP_JITTER");

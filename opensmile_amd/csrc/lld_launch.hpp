@@ -8,6 +8,19 @@
 #include "tables.hpp"
 
 namespace smilehip {
+// compute units of the device that is current on the calling thread, looked up once PER DEVICE (one process may drive several
+// devices; a function-static would keep the count of whichever device launched first)
+inline int current_device_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64 && __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) > 0) return __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+  return n;
+}
+
 struct Fast512Host {
   std::vector<float2> tw256, tw512, win;
   std::vector<float4> melw;

@@ -49,6 +49,8 @@ struct smilehip_comm {
   ncclComm_t nccl = nullptr;
   int rank = 0, world = 1, device = 0;
   int64_t *d_counts = nullptr;       // [world + 1] device scratch of the count exchange
+  hipStream_t piece_stream = nullptr; // the pieces of a chunked gather travel here, beside the caller's kernels
+  hipEvent_t piece_ready = nullptr, piece_done = nullptr;
 };
 
 extern "C" const char *smilehip_comm_last_error(void) { return g_err; }
@@ -102,6 +104,22 @@ extern "C" int smilehip_comm_bootstrap_bcast(int rank, int world, const char *ma
   return fail("bootstrap: rank 0 not reachable at %s:%d", master_addr, master_port);
 }
 
+static int comm_join(int device, int rank, int world, const ncclUniqueId &id, smilehip_comm **out) {
+  smilehip_comm *c = new smilehip_comm;
+  c->rank = rank; c->world = world; c->device = device;
+  const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank: %s", ncclGetErrorString(r)); }
+  if (hipMalloc(&c->d_counts, sizeof(int64_t) * (size_t)(world + 1)) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->piece_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->piece_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->piece_done, hipEventDisableTiming) != hipSuccess) {
+    smilehip_comm_destroy(c);
+    return fail("smilehip_comm_create: device resources (count scratch, piece stream, events) failed");
+  }
+  *out = c;
+  return 0;
+}
+
 extern "C" int smilehip_comm_create(int device, int rank, int world, const char *master_addr, int master_port, smilehip_comm **out) {
   if (!out || world < 1 || rank < 0 || rank >= world) return fail("smilehip_comm_create: bad argument");
   if (hipSetDevice(device) != hipSuccess) return fail("smilehip_comm_create: hipSetDevice(%d) failed", device);
@@ -109,21 +127,32 @@ extern "C" int smilehip_comm_create(int device, int rank, int world, const char 
   memset(&id, 0, sizeof(id));
   if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
   if (smilehip_comm_bootstrap_bcast(rank, world, master_addr, master_port, &id, (int32_t)sizeof(id)) != 0) return -1;
-  smilehip_comm *c = new smilehip_comm;
-  c->rank = rank; c->world = world; c->device = device;
-  const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
-  if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank: %s", ncclGetErrorString(r)); }
-  if (hipMalloc(&c->d_counts, sizeof(int64_t) * (size_t)(world + 1)) != hipSuccess) {
-    ncclCommDestroy(c->nccl);
-    delete c;
-    return fail("smilehip_comm_create: hipMalloc failed");
-  }
-  *out = c;
+  return comm_join(device, rank, world, id, out);
+}
+
+static_assert(sizeof(ncclUniqueId) == SMILEHIP_COMM_ID_BYTES, "SMILEHIP_COMM_ID_BYTES");
+
+extern "C" int smilehip_comm_unique_id(void *id) {
+  if (!id) return fail("smilehip_comm_unique_id: null argument");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return fail("ncclGetUniqueId failed");
+  memcpy(id, &u, sizeof(u));
   return 0;
+}
+
+extern "C" int smilehip_comm_create_from_id(int device, int rank, int world, const void *id, smilehip_comm **out) {
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail("smilehip_comm_create_from_id: bad argument");
+  if (hipSetDevice(device) != hipSuccess) return fail("smilehip_comm_create_from_id: hipSetDevice(%d) failed", device);
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  return comm_join(device, rank, world, u, out);
 }
 
 extern "C" int smilehip_comm_destroy(smilehip_comm *c) {
   if (!c) return 0;
+  if (c->piece_stream) { (void)hipStreamSynchronize(c->piece_stream); (void)hipStreamDestroy(c->piece_stream); }
+  if (c->piece_ready) (void)hipEventDestroy(c->piece_ready);
+  if (c->piece_done) (void)hipEventDestroy(c->piece_done);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->nccl) ncclCommDestroy(c->nccl);
   delete c;
@@ -167,6 +196,68 @@ extern "C" int smilehip_comm_gather_rows(smilehip_comm *c, const float *d_rows, 
   if (c->rank == 0 && mine && hipMemcpyAsync(d_all, d_rows, mine * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return fail("gather: local copy failed");
   if (!s && hipStreamSynchronize(s) != hipSuccess) return fail("gather: synchronize failed");      // null stream: blocking call
+  return 0;
+}
+
+extern "C" int64_t smilehip_comm_gather_pieces(const int64_t *counts, int world, int64_t piece_rows) {
+  if (!counts || world < 1 || piece_rows <= 0) return -1;
+  int64_t mx = 0;
+  for (int r = 0; r < world; ++r) mx = counts[r] > mx ? counts[r] : mx;
+  return (mx + piece_rows - 1) / piece_rows;
+}
+
+extern "C" int smilehip_comm_piece_rows(const int64_t *counts, int world, int64_t piece_rows, int64_t k, int rank, int64_t *first, int64_t *n,
+                                        int64_t *dst_row) {
+  if (!counts || world < 1 || piece_rows <= 0 || k < 0 || rank < 0 || rank >= world || !first || !n || !dst_row)
+    return fail("smilehip_comm_piece_rows: bad argument");
+  int64_t block0 = 0;
+  for (int r = 0; r < rank; ++r) block0 += counts[r];
+  *first = k * piece_rows;
+  int64_t m = counts[rank] - *first;
+  *n = m < 0 ? 0 : (m > piece_rows ? piece_rows : m);
+  *dst_row = block0 + *first;
+  return 0;
+}
+
+extern "C" int smilehip_comm_gather_rows_piece(smilehip_comm *c, const float *d_rows, const int64_t *counts, int32_t cols, float *d_all,
+                                               int64_t piece_rows, int64_t k, void *after_stream) {
+  if (!c || !counts || cols <= 0 || piece_rows <= 0 || k < 0) return fail("smilehip_comm_gather_rows_piece: bad argument");
+  if (c->rank == 0 && !d_all) return fail("smilehip_comm_gather_rows_piece: rank 0 needs d_all");
+  int64_t my_first = 0, my_n = 0, my_dst = 0;
+  if (smilehip_comm_piece_rows(counts, c->world, piece_rows, k, c->rank, &my_first, &my_n, &my_dst) != 0) return -1;
+  if (my_n && !d_rows) return fail("smilehip_comm_gather_rows_piece: rank %d has rows in piece %lld but no d_rows", c->rank, (long long)k);
+  hipStream_t ps = c->piece_stream;
+  if (after_stream) {                                                  // the piece's rows are written by work enqueued there
+    if (hipEventRecord(c->piece_ready, static_cast<hipStream_t>(after_stream)) != hipSuccess ||
+        hipStreamWaitEvent(ps, c->piece_ready, 0) != hipSuccess)
+      return fail("smilehip_comm_gather_rows_piece: event hand-over failed");
+  }
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return fail("ncclGroupStart: %s", ncclGetErrorString(r));
+  if (c->rank == 0) {
+    for (int p = 1; p < c->world; ++p) {
+      int64_t first = 0, n = 0, dst = 0;
+      (void)smilehip_comm_piece_rows(counts, c->world, piece_rows, k, p, &first, &n, &dst);
+      if (n && (r = ncclRecv(d_all + (size_t)dst * (size_t)cols, (size_t)n * (size_t)cols, ncclFloat, p, c->nccl, ps)) != ncclSuccess) break;
+    }
+  } else if (my_n) {
+    r = ncclSend(d_rows + (size_t)my_first * (size_t)cols, (size_t)my_n * (size_t)cols, ncclFloat, 0, c->nccl, ps);
+  }
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess || r2 != ncclSuccess) return fail("gather piece: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+  if (c->rank == 0 && my_n &&
+      hipMemcpyAsync(d_all + (size_t)my_dst * (size_t)cols, d_rows + (size_t)my_first * (size_t)cols, (size_t)my_n * (size_t)cols * sizeof(float),
+                     hipMemcpyDeviceToDevice, ps) != hipSuccess)
+    return fail("gather piece: local copy failed");
+  return 0;
+}
+
+extern "C" int smilehip_comm_gather_wait(smilehip_comm *c, void *stream) {
+  if (!c) return fail("smilehip_comm_gather_wait: null argument");
+  if (!stream) return hipStreamSynchronize(c->piece_stream) == hipSuccess ? 0 : fail("gather wait: synchronize failed");
+  if (hipEventRecord(c->piece_done, c->piece_stream) != hipSuccess ||
+      hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->piece_done, 0) != hipSuccess)
+    return fail("gather wait: event hand-over failed");
   return 0;
 }
 

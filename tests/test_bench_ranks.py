@@ -30,6 +30,7 @@ def test_bench_gpus2_launches_its_own_ranks_plumbing_only():
     assert r["config"]["ranks_seen"] == 2
     assert r["config"]["frames_total"] == 998 * 10 + 998 * 11
     assert r["config"]["gathered_rows"] == [998 * 10, 998 * 11]
+    assert r["config"]["gathered_in_pieces"] == {"pieces": 3, "rows": 998 * 21, "equal": True}      # ceil(998 * 11 / 4096) pieces
     assert r["ranks"]["backend"] == "gloo" and len(r["ranks"]["rank_devices"]) == 2
 
 
@@ -47,3 +48,19 @@ def test_bench_gpus2_real_line():
     assert r["config"]["frames_rank0"] == 998000 and r["value"] > 1e8
     assert r["gather_ms"] > 0 and 0 < r["value_incl_gather"] < r["value"]
     assert len(r["ranks"]["rank_devices"]) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_bench_gather_through_the_comm_library_world1(config):
+    """--with-gather at N = 1: the gather section of the N > 1 line with a world-size-1 RCCL communicator -- the same calls into
+    libsmilehip_comm.so (config 4: the LLD level in pieces on the communicator's stream beside the next step's kernels)"""
+    extra = ["--no-configs", "--no-h2d"] if config == 2 else ["--config", str(config)]
+    r = _run(extra + ["--utts", "96", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--with-gather"], 600)
+    assert r["n_gpus"] == 1 and r["gather_via"].startswith("libsmilehip_comm.so")
+    if config == 2:
+        assert r["gather_ms"] > 0
+    else:
+        assert r["gather_check"]["rank0_block_equal"] is True
+    if config == 4:
+        assert r["gather_check"]["pieces_per_step"] >= 1 and r["gather_check"]["value_incl_gather_overlapped"] > 0

@@ -61,3 +61,25 @@ def test_self_send_recv_pair(comm):
     assert L.smilehip_comm_self_sendrecv(h, src.data_ptr(), dst.data_ptr(), n, None) == 0, L.smilehip_comm_last_error()
     torch.cuda.synchronize()
     assert torch.equal(src, dst)
+
+
+def test_world1_gather_in_pieces():
+    """smilehip_comm_gather_rows_piece / _wait on the one device: rank 0's block travels piece by piece on the communicator's own
+    stream behind the caller's stream (the event hand-over), the gathered matrix equals the block; rendezvous by unique id"""
+    import torch
+    from opensmile_amd import comm
+    c = comm.Comm.from_process_group(None, 0)                 # smilehip_comm_unique_id + smilehip_comm_create_from_id, world 1
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = torch.zeros((12500, 130), dtype=torch.float32, device="cuda")
+    g = comm.PieceGather(rows, c, piece_rows=3000)
+    assert g.pieces == 5 and g.counts.tolist() == [12500]
+    rows.copy_(torch.arange(12500 * 130, dtype=torch.float32, device="cuda").reshape(12500, 130))    # enqueued on the caller's stream
+    for k in range(g.pieces):
+        g.piece(k, after_stream=stream)
+    out = g.finish(stream)                                   # the caller's stream waits for the pieces
+    torch.cuda.synchronize()
+    assert torch.equal(out, rows)
+    # an empty block, and finish on the host
+    g2 = comm.PieceGather(rows[:0], c, piece_rows=3000)
+    assert g2.pieces == 0 and g2.finish(None).shape == (0, 130)
+    c.close()

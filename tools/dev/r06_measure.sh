@@ -11,6 +11,7 @@
 #   e2e        tools/bench_e2e.py (file-to-file route)        plugin   tools/bench_plugin.py (60 s and 600 s files)
 #   smileapi   tools/bench_smileapi.py (10 min pushed in 1 s pieces through cExternalAudioSource)
 #   sweep      tools/plugin_config_sweep.py (the 40 runnable shipped files through the plugin)
+#   pmc64:N    only the FP64 / INT64 instruction-class pass of config N (-> pmc64_c<N>.txt)
 #   sh:<cmd>   any command (quoted), output to sh_<n>.log
 set -u
 R=$GRAFT_REPO_ROOT
@@ -18,6 +19,7 @@ T=$1; shift
 O=$R/gpurun_out/$T
 mkdir -p $O
 declare -A UTTS=( [2]=1000 [3]=2000 [4]=1500 [5]=6000 )
+[ "${PMC_FULL:-0}" = 1 ] && UTTS=( [2]=1000 [3]=10000 [4]=12500 [5]=125000 )     # the bench's own batch sizes
 declare -A STEPS=( [2]=3 [3]=2 [4]=1 [5]=1 )
 n=0
 for sec in "$@"; do
@@ -63,7 +65,7 @@ PY
     pmc:*)
       c=${sec#pmc:}
       if [ $c = 2 ]; then X="--no-configs --no-h2d"; else X="--config $c"; fi
-      BENCH="python $R/bench.py $X --utts ${PMC_UTTS:-${UTTS[$c]}} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline"      # PMC_UTTS=12500: the bench's own batch size
+      BENCH="python $R/bench.py $X --utts ${UTTS[$c]} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline"
       cd /tmp && export TMPDIR=/tmp
       i=0
       for set in \
@@ -71,6 +73,7 @@ PY
        "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR" \
        "GRBM_GUI_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM" \
        "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH SQ_IFETCH" \
+       "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64" \
        "FETCH_SIZE" "WRITE_SIZE" ; do
         i=$((i+1))
         timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_c$c/p$i -- $BENCH > $O/pmc_c${c}_p$i.log 2>&1
@@ -85,6 +88,14 @@ for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:12]:
     print("%-46s %8.2f ms  valu %.2f lds %.2f wait %.2f hbm %.3f" % (k[:46], v["ms"], v["valu_busy_frac"], v["lds_pipe_frac"], v["wait_inst_frac"] or 0, v["hbm_frac"] or 0))
 PY
       ;;
+    pmc64:*)
+      c=${sec#pmc64:}
+      if [ $c = 2 ]; then X="--no-configs --no-h2d"; else X="--config $c"; fi
+      cd /tmp && export TMPDIR=/tmp
+      timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU --output-format csv -d $O/pmc64_c$c/p1 -- python $R/bench.py $X --utts ${UTTS[$c]} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline > $O/pmc64_c${c}.log 2>&1
+      python $R/tools/pmc_summary.py $O/pmc64_c$c $O/pmc64_c$c.txt > /dev/null 2>&1
+      rm -rf $O/pmc64_c$c
+      grep -c "^==" $O/pmc64_c$c.txt ;;
     traffic) bash tools/pmc_traffic_configs.sh $T/traffic > $O/traffic.log 2>&1; cp $O/traffic/pmc_traffic_c*.json $O/ 2>/dev/null; tail -3 $O/traffic.log | cut -c1-300 ;;
     e2e) timeout 900 python tools/bench_e2e.py > $O/e2e.jsonl 2> $O/e2e.err; cut -c1-400 $O/e2e.jsonl; tail -3 $O/e2e.err ;;
     plugin) ( timeout 900 python tools/bench_plugin.py --seconds 60 --skip-per-component; echo '{"note": "ten-minute files (one hour for MFCC12_0_D_A is 6 x this): CPU binary, the block-per-tick path, the default (fused batch fed from the wave level), the fused source component"}'; timeout 1200 python tools/bench_plugin.py --seconds 600 --no-per-component ) > $O/plugin_throughput.jsonl 2> $O/plugin.err; cut -c1-260 $O/plugin_throughput.jsonl | grep -v fused_source; tail -3 $O/plugin.err ;;
