@@ -184,7 +184,8 @@ def _counter_fields(config, kernels):
     w = sum(v["ms"] for v in mine) or 1.0
     avg = lambda key: sum(v.get(key, 0.0) * v["ms"] for v in mine) / w
     top = max(mine, key=lambda v: v["ms"])
-    return {"bound_by_counters": top.get("bound"), "valu_issue_frac": avg("valu_issue_frac"), "valu_busy_frac": avg("valu_busy_frac"),
+    return {"bound_by_counters": top.get("bound"), "valu_issue_floor_frac": avg("valu_issue_floor_frac") if all(v.get("valu_issue_floor_frac") is not None for v in mine) else None,
+            "valu_issue_frac": avg("valu_issue_frac"), "valu_busy_frac": avg("valu_busy_frac"),
             "lds_pipe_frac": avg("lds_pipe_frac"), "lds_bank_conflict_frac": avg("lds_bank_conflict_frac"),
             "wait_inst_frac": avg("wait_inst_frac"), "counters_source": src}
 
