@@ -35,9 +35,9 @@
 //           quads at each step (fast512_build_host)
 //   cep     DCT-II rows + lifter (R7): one lane per coefficient, b128 reads
 //
-// Numerics: R2/R3 keep the reference's rounding sequence on integer-valued
-// samples (the 1/32767 of R0 is folded into the window table, <= 1 ulp per
-// sample); the FFT uses FMA and its own butterfly order (cannot match Ooura's
+// Numerics: R3 keeps the reference's rounding on integer-valued samples (the
+// 1/32767 of R0 is folded into the window table, <= 1 ulp per sample); R2 is
+// one fused multiply-add per sample since round 6 (one rounding, not two); the FFT uses FMA and its own butterfly order (cannot match Ooura's
 // split radix anyway); power skips the reference's sqrt-then-square; mel/DCT
 // sums use FMA in a fixed deterministic order. Deviation from the reference is
 // measured in tests/test_gpu_mfcc.py; the reference-order path is
@@ -107,25 +107,42 @@ __device__ __forceinline__ void cmul(float &r, float &i, float c, float s) {   /
   const float ni = fmaf(r, s, i * c);
   r = nr; i = ni;
 }
+// the same with -s handed in as a value of its own: i * (-s) = -(i * s) exactly, and the product needs no negated operand
+// (which only the 64-bit VOP3 form has)
+__device__ __forceinline__ void cmul_ns(float &r, float &i, float c, float s, float ns) {
+  const float nr = fmaf(r, c, i * ns);
+  const float ni = fmaf(r, s, i * c);
+  r = nr; i = ni;
+}
+
+// The constants of a DFT16 as wave-uniform register values (SGPRs): a literal makes a VOP2 instruction 64 bits long, and the
+// 64-bit encoded forms issue every ~4.2 cycles where the 32-bit ones take ~2.8 (profiles/r06_valu_classes.json). The negatives
+// are constants of their own: a negated operand would need the (64-bit) VOP3 form.
+struct Dft16K {
+  float c1, s1, r2, nc1, ns1, nr2;
+  __device__ __forceinline__ Dft16K() : c1(C1), s1(S1), r2(R2), nc1(-C1), ns1(-S1), nr2(-R2) {
+    asm volatile("" : "+s"(c1), "+s"(s1), "+s"(r2), "+s"(nc1), "+s"(ns1), "+s"(nr2));
+  }
+};
 
 // forward DFT16, natural order in and out (registers, static indexing only).
 // x[m], m = m0 + 4 m1:  y[m0][q] = DFT4 over m1; y *= w16^(m0 q);
 // X[q + 4p] = DFT4 over m0.
-__device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
+__device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16], const Dft16K &K) {
 #pragma unroll
   for (int m0 = 0; m0 < 4; ++m0)
     dft4(re[m0], im[m0], re[m0 + 4], im[m0 + 4], re[m0 + 8], im[m0 + 8], re[m0 + 12], im[m0 + 12]);
   // y[m0][q] now sits at index m0 + 4q. Twiddles w16^(m0*q), w16 = e^{-2 pi i/16}:
   // (1,1)->e1 (1,2)->e2 (1,3)->e3 (2,1)->e2 (2,2)->e4 (2,3)->e6 (3,1)->e3 (3,2)->e6 (3,3)->e9
-  cmul(re[1 + 4], im[1 + 4], C1, -S1);                                    // e1
-  { const float a = re[1 + 8], b = im[1 + 8]; re[1 + 8] = R2 * (a + b); im[1 + 8] = R2 * (b - a); }    // e2
-  cmul(re[1 + 12], im[1 + 12], S1, -C1);                                  // e3
-  { const float a = re[2 + 4], b = im[2 + 4]; re[2 + 4] = R2 * (a + b); im[2 + 4] = R2 * (b - a); }    // e2
-  { const float a = re[2 + 8], b = im[2 + 8]; re[2 + 8] = b; im[2 + 8] = -a; }                         // e4 = -i
-  { const float a = re[2 + 12], b = im[2 + 12]; re[2 + 12] = R2 * (b - a); im[2 + 12] = -R2 * (a + b); }  // e6
-  cmul(re[3 + 4], im[3 + 4], S1, -C1);                                    // e3
-  { const float a = re[3 + 8], b = im[3 + 8]; re[3 + 8] = R2 * (b - a); im[3 + 8] = -R2 * (a + b); }   // e6
-  cmul(re[3 + 12], im[3 + 12], -C1, S1);                                  // e9
+  cmul_ns(re[1 + 4], im[1 + 4], K.c1, K.ns1, K.s1);                       // e1
+  { const float a = re[1 + 8], b = im[1 + 8]; re[1 + 8] = K.r2 * (a + b); im[1 + 8] = K.r2 * (b - a); }    // e2
+  cmul_ns(re[1 + 12], im[1 + 12], K.s1, K.nc1, K.c1);                     // e3
+  { const float a = re[2 + 4], b = im[2 + 4]; re[2 + 4] = K.r2 * (a + b); im[2 + 4] = K.r2 * (b - a); }    // e2
+  { const float a = re[2 + 8], b = im[2 + 8]; re[2 + 8] = b; im[2 + 8] = -a; }                             // e4 = -i
+  { const float a = re[2 + 12], b = im[2 + 12]; re[2 + 12] = K.r2 * (b - a); im[2 + 12] = K.nr2 * (a + b); }  // e6
+  cmul_ns(re[3 + 4], im[3 + 4], K.s1, K.nc1, K.c1);                       // e3
+  { const float a = re[3 + 8], b = im[3 + 8]; re[3 + 8] = K.r2 * (b - a); im[3 + 8] = K.nr2 * (a + b); }   // e6
+  cmul_ns(re[3 + 12], im[3 + 12], K.nc1, K.s1, K.ns1);                    // e9
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     dft4(re[4 * q], im[4 * q], re[4 * q + 1], im[4 * q + 1], re[4 * q + 2], im[4 * q + 2], re[4 * q + 3],
@@ -160,9 +177,32 @@ struct FrameRegs {
   uint32_t v[ALIGNED ? MP : 2 * MP];
 };
 
+// (round 6) The loads are BUFFER loads: a wave-uniform resource descriptor (base = the pass's first sample, size = what is left of the
+// PCM buffer behind it) in four SGPRs, ONE VGPR of per-lane byte offset and the immediate 64 m -- no 64-bit address arithmetic on the
+// vector ALU (the global-load form spent 13 v_lshl_add_u64 and 26 address VGPRs per pass on it), and the hardware's range check
+// replaces the clamped-address branch: a read behind the end of the buffer (or in front of it: the offset wraps to a huge unsigned
+// value) returns zero, which is as good as the clamped sample -- such samples meet a zero of the window table or belong to a frame
+// that is not stored. -DSMILEHIP_MFCC512_GLOBAL_LOADS builds the round-5 form (A/B aid).
 template <int MP, bool ALIGNED>
 __device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_total, int64_t base, int H, int lane,
                                              FrameRegs<MP, ALIGNED> &R) {
+#ifndef SMILEHIP_MFCC512_GLOBAL_LOADS
+  const int64_t b0 = base < 0 ? 0 : base;                // (negative only for the buffer's first frames under symmetric zero padding)
+  int64_t left = (pcm_total - b0) * 2;                   // bytes behind the descriptor's base
+  left = left < 0 ? 0 : (left > 0xfffffffcLL ? 0xfffffffcLL : left);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t *>(pcm + b0), 0, (int)(uint32_t)left, 0x00020000);
+  uint32_t lo = ((uint32_t)(lane >> 4) * (uint32_t)H + 2u * (uint32_t)(lane & 15)) * 2u + (uint32_t)((base - b0) * 2);
+  asm volatile("" : "+v"(lo));                           // opaque per call: no hoisted per-m offset registers
+#pragma unroll
+  for (int m = 0; m < MP; ++m) {
+    if (ALIGNED) {
+      R.v[m] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lo + 64 * m, 0, 0);
+    } else {
+      R.v[2 * m] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)lo + 64 * m, 0, 0);
+      R.v[2 * m + 1] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)lo + 64 * m + 2, 0, 0);
+    }
+  }
+#else
 #ifdef SMILEHIP_DEBUG_SAME_SPAN
   base &= 0xfffff;                                       // experiment: every span inside the first 2 MB (L2 resident)
 #endif
@@ -204,6 +244,7 @@ __device__ __forceinline__ void pcm_prefetch(const int16_t *pcm, int64_t pcm_tot
       }
     }
   }
+#endif
 }
 
 // Developer instrumentation (tools/ubench/variant.sh builds a private copy of the library
@@ -272,9 +313,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   // which of my units belong to my first band (bit i) | first band << 8 | second band << 16 (0xff: none)
   const uint32_t lane_bands = (uint32_t)F.lane_bands[j];
   const int band0 = (int)((lane_bands >> 8) & 0xffu), band1 = (int)((lane_bands >> 16) & 0xffu);
-  bool unit_first[UC];
+  // 1.0f / 0.0f per unit: the unit's sum goes to the lane's first / second band as a0 = fma(acc, uf0, a0), a1 = fma(acc, uf1, a1) --
+  // acc x 1 is exact and acc x 0 = 0 (the sums are finite and >= 0), so the two band sums are the ones a select + add produced, bit
+  // for bit, for two 32-bit encoded v_fmac instead of two selects (64-bit encoded, a lane mask in an SGPR pair each) + two adds
+  float uf0[UC], uf1[UC];
 #pragma unroll
-  for (int i = 0; i < UC; ++i) unit_first[i] = ((lane_bands >> i) & 1u) != 0;
+  for (int i = 0; i < UC; ++i) { uf0[i] = ((lane_bands >> i) & 1u) ? 1.0f : 0.0f; uf1[i] = 1.0f - uf0[i]; }
   // my cell relative to the pass's base row: the row of the pass's first frame -- DELTA: of the frame four before it, whose
   // static | delta | acceleration cells a pass writes together (whole rows: 4 x 156 consecutive bytes per wave and pass.
   // Writing each value as soon as it exists -- three stores into three different sets of rows -- cost 0.05 ms per 998 000 frames)
@@ -286,6 +330,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   float *pb_k = s_pb + pb_pos(j);              // my bins k = j + 16 q sit 24 q floats further on
   float *pb_m = s_pb + pb_pos(256 - j);        // their mirror images 256 - k sit 24 q floats back
 
+  const Dft16K dk;
   PHASE_DECL
   // Persistent waves walk tiles tile, tile + #waves, ... as ONE flat stream of passes: the
   // next pass's PCM (same tile or the first pass of the next tile) is always in flight, tile
@@ -306,22 +351,14 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
   int cur_n = recs[tile].n_frames;
   // DELTA: frames behind the utterance's end | rows this tile writes | the utterance's first frame | regression stages on
   int cur_live = 0, cur_e0 = 0, cur_e1 = 0, cur_lo = 0, cur_don = 0;
-  int nxt_live = 0, nxt_e0 = 0, nxt_e1 = 0, nxt_lo = 0, nxt_don = 0;
   if constexpr (DELTA) {
     cur_live = recs[tile].live_n; cur_e0 = recs[tile].e0; cur_e1 = recs[tile].e1; cur_lo = recs[tile].lo; cur_don = recs[tile].delta_on;
   }
+  // of the next tile's record only the first sample is held ahead (the prefetch of its first pass needs it a pass early); the
+  // other fields are read when the wave moves on to the tile -- an s_load once per eight passes instead of ten SGPRs across the loop
   bool has_next = tile + tile_stride < n_tiles;
-  int64_t nxt_samp0 = cur_samp0, nxt_row0 = cur_row0;
-  int nxt_n = cur_n;
-  if (has_next) {
-    nxt_samp0 = recs[tile + tile_stride].samp0;
-    nxt_row0 = recs[tile + tile_stride].row0;
-    nxt_n = recs[tile + tile_stride].n_frames;
-    if constexpr (DELTA) {
-      nxt_live = recs[tile + tile_stride].live_n; nxt_e0 = recs[tile + tile_stride].e0; nxt_e1 = recs[tile + tile_stride].e1;
-      nxt_lo = recs[tile + tile_stride].lo; nxt_don = recs[tile + tile_stride].delta_on;
-    }
-  }
+  int64_t nxt_samp0 = cur_samp0;
+  if (has_next) nxt_samp0 = recs[tile + tile_stride].samp0;
   int tp = 0;                                          // first frame of the pass, relative to the tile
   FrameRegs<MP, ALIGNED> R;
   pcm_prefetch<MP, ALIGNED>(P.pcm, P.pcm_total, cur_samp0 - P.pad_left, P.H, lane, R);
@@ -421,8 +458,17 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
             const float t = dpp_f<0x121>(b);     // row_ror:1 -- lane j sees the odd sample of pair j-1 (lane 0: of lane 15)
             const float pa = (j == 0) ? tprev : t;
             tprev = t;
+#ifndef SMILEHIP_MFCC512_PREEMPH_TWO_ROUNDINGS
+            // (round 6) one rounding where the reference has two (preemphasis.cpp: x - k x' as a product and a difference): 26 vector
+            // instructions fewer per pass, 0.3745 -> 0.3665 ms per 998 000 frames, and the distance to the reference went DOWN
+            // (per-frame-scaled 1.048e-6 -> 1.041e-6, max abs 1.56e-4 -> 1.49e-4: the fused form is the exact difference rounded once).
+            // This kernel's contract is the 1e-5 gate; the reference's own rounding sequence is lld_mfcc_generic's.
+            ya = fmaf(-kpre, pa, a);
+            yb = fmaf(-kpre, a, b);
+#else
             ya = a - kpre * pa;
             yb = b - kpre * a;
+#endif
             if (m == m0 && j == j0) ya = P.one_minus_k * a;      // y[0] = (1-k) x[0]
           }
           const float2 w = s_win[m * 16 + j];
@@ -461,7 +507,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
 
     // ------------------------------------------------------------ 256-point complex FFT
-    dft16(re, im);                                           // over m  -> index k1
+    dft16(re, im, dk);                                       // over m  -> index k1
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
       const float2 w = s_tw256[k1 * 16 + j];
@@ -490,7 +536,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     }
     PHASE(4);                                   // transposes
 #ifndef SMILEHIP_DEBUG_SKIP_DFT2
-    dft16(re, im);                                           // over j -> k2 ; Z[j + 16 k2]
+    dft16(re, im, dk);                                       // over j -> k2 ; Z[j + 16 k2]
 #endif
     PHASE(5);                                   // second dft16
 
@@ -500,6 +546,22 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     // register up (bin 256 - 16 q = 0 + 16 (16 - q)): its value is parked in lane 15 first (row_ror:15), where the shift
     // has no source and leaves it. q = 0 of lane 0 is the DC/Nyquist pair, handled below.
     float zr[8], zi[8];
+#ifdef SMILEHIP_MFCC512_BPERMUTE_PARTNER
+    // (round 6, measured and NOT taken) ... through the LDS crossbar instead (ds_bpermute: no storage): one crossbar read + one
+    // select (lane 0 is its own partner one register up) where the DPP route takes three vector instructions per value -- 33 fewer
+    // VALU instructions per pass (905 -> 872; replayed VALU stream 0.343 -> 0.314 ms per 998 000 frames), but the launch got SLOWER,
+    // 0.3773 -> 0.3830 ms: sixteen more LDS-pipe instructions per pass cost more than the vector instructions they replace.
+    {
+      const int paddr = 4 * ((lane & 48) | ((16 - j) & 15));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float c = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(re[15 - q])));
+        float d = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(im[15 - q])));
+        if (q > 0) { c = (j == 0) ? re[16 - q] : c; d = (j == 0) ? im[16 - q] : d; }
+        zr[q] = c; zi[q] = d;
+      }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float pr = q > 0 ? dpp_f<0x12f>(re[(16 - q) & 15]) : re[15];
@@ -509,6 +571,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
       zr[q] = dpp_f<0x140>(tr);
       zi[q] = dpp_f<0x140>(ti);
     }
+#endif
     float2 tw5[8];                                // e^{-2 pi i k/512} of my eight bins, all read before the first store to the
 #pragma unroll                                    // power buffer (the compiler cannot tell the two LDS regions apart)
     for (int q = 0; q < 8; ++q) tw5[q] = s_tw512[j + 16 * q];
@@ -562,8 +625,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
         float acc = p0.x * w0.x;
         acc = fmaf(p0.y, w0.y, acc); acc = fmaf(p0.z, w0.z, acc); acc = fmaf(p0.w, w0.w, acc);
         acc = fmaf(p1.x, w1.x, acc); acc = fmaf(p1.y, w1.y, acc); acc = fmaf(p1.z, w1.z, acc); acc = fmaf(p1.w, w1.w, acc);
-        a0 += unit_first[i] ? acc : 0.0f;         // x + 0 is exact
-        a1 += unit_first[i] ? 0.0f : acc;
+        a0 = fmaf(acc, uf0[i], a0);
+        a1 = fmaf(acc, uf1[i], a1);
       }
       PHASE(8);                                   // mel units
 #pragma unroll
@@ -617,18 +680,12 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64, 4) lld_mfcc512(LldParams 
     if (!more) break;
     if (advance) {
       tile += tile_stride;
-      cur_samp0 = nxt_samp0; cur_row0 = nxt_row0; cur_n = nxt_n;
-      if constexpr (DELTA) { cur_live = nxt_live; cur_e0 = nxt_e0; cur_e1 = nxt_e1; cur_lo = nxt_lo; cur_don = nxt_don; }
-      has_next = tile + tile_stride < n_tiles;
-      if (has_next) {
-        nxt_samp0 = recs[tile + tile_stride].samp0;
-        nxt_row0 = recs[tile + tile_stride].row0;
-        nxt_n = recs[tile + tile_stride].n_frames;
-        if constexpr (DELTA) {
-          nxt_live = recs[tile + tile_stride].live_n; nxt_e0 = recs[tile + tile_stride].e0; nxt_e1 = recs[tile + tile_stride].e1;
-          nxt_lo = recs[tile + tile_stride].lo; nxt_don = recs[tile + tile_stride].delta_on;
-        }
+      cur_samp0 = nxt_samp0; cur_row0 = recs[tile].row0; cur_n = recs[tile].n_frames;
+      if constexpr (DELTA) {
+        cur_live = recs[tile].live_n; cur_e0 = recs[tile].e0; cur_e1 = recs[tile].e1; cur_lo = recs[tile].lo; cur_don = recs[tile].delta_on;
       }
+      has_next = tile + tile_stride < n_tiles;
+      if (has_next) nxt_samp0 = recs[tile + tile_stride].samp0;
     }
     tp = ntp;
   }
