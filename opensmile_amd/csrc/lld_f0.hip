@@ -1316,7 +1316,7 @@ bool f0_shifts_fit(const F0Params &Q) {                  // f0_shs reads bin j +
   return true;
 }
 template <int LOGM>
-hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t s) {
+hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t s, const F0Pipe *pipe) {
   using G = F0G<LOGM>;
   if (!f0_shifts_fit<G>(Q0)) return hipErrorInvalidValue;
   constexpr int kSpecWaves = G::kSpecWaves;
@@ -1337,22 +1337,46 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
   F0Params Q = Q0;
-  for (int t0 = 0; t0 < P.n_tiles; t0 += f0_chunk_tiles()) {
+  // the chunk pipeline (F0Pipe, lld_launch.hpp): spectra on pipe->spec, sweeps on pipe->sweep, candidates on the caller's stream;
+  // chunk i works on scratch set i & 1, whose previous user is chunk i - 2
+  const bool piped = pipe && pipe->spec && pipe->sweep && pipe->ab2 && P.n_tiles > f0_chunk_tiles();
+  hipStream_t s_spec = piped ? pipe->spec : s, s_sweep = piped ? pipe->sweep : s;
+  if (piped) {
+    if ((e = hipEventRecord(pipe->start, s)) != hipSuccess) return e;               // what the caller's stream did before (the scratch rows' last readers)
+    if ((e = hipStreamWaitEvent(s_spec, pipe->start, 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s_sweep, pipe->start, 0)) != hipSuccess) return e;
+  }
+  int ci = 0;
+  for (int t0 = 0; t0 < P.n_tiles; t0 += f0_chunk_tiles(), ++ci) {
+    const int set = ci & 1;
     Q.tile0 = t0;
     Q.n_tiles_chunk = (P.n_tiles - t0 < f0_chunk_tiles()) ? P.n_tiles - t0 : f0_chunk_tiles();
+    if (piped) {
+      Q.ab = set ? pipe->ab2 : Q0.ab;
+      if (ci >= 2 && (e = hipStreamWaitEvent(s_spec, pipe->cand_done[set], 0)) != hipSuccess) return e;   // chunk i - 2 has read its rows
+    }
     const unsigned grid = (unsigned)((Q.n_tiles_chunk + kSpecWaves - 1) / kSpecWaves);
     if constexpr (LOGM == 9) {
-      if (oo && s16) SMILEHIP_KLAUNCH((lld_f0_spec<true, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else if (oo) SMILEHIP_KLAUNCH((lld_f0_spec<true, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else if (s16) SMILEHIP_KLAUNCH((lld_f0_spec<false, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
-      else SMILEHIP_KLAUNCH((lld_f0_spec<false, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      if (oo && s16) SMILEHIP_KLAUNCH((lld_f0_spec<true, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s_spec, P, Q);
+      else if (oo) SMILEHIP_KLAUNCH((lld_f0_spec<true, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s_spec, P, Q);
+      else if (s16) SMILEHIP_KLAUNCH((lld_f0_spec<false, true>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s_spec, P, Q);
+      else SMILEHIP_KLAUNCH((lld_f0_spec<false, false>), dim3(grid), dim3(kSpecWaves * 64), lds_spec, s_spec, P, Q);
     } else {
-      SMILEHIP_KLAUNCH(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s, P, Q);
+      SMILEHIP_KLAUNCH(lld_f0_spec_g<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_spec, s_spec, P, Q);
+    }
+    if (piped) {
+      if ((e = hipEventRecord(pipe->spec_done[set], s_spec)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(s_sweep, pipe->spec_done[set], 0)) != hipSuccess) return e;
     }
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
-    SMILEHIP_KLAUNCH(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, Q);
+    SMILEHIP_KLAUNCH(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s_sweep, Q);
+    if (piped) {
+      if ((e = hipEventRecord(pipe->sweep_done[set], s_sweep)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(s, pipe->sweep_done[set], 0)) != hipSuccess) return e;
+    }
     if constexpr (LOGM == 9) SMILEHIP_KLAUNCH(lld_f0_cand9, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
     else SMILEHIP_KLAUNCH(lld_f0_cand<LOGM>, dim3(grid), dim3(kSpecWaves * 64), lds_cand, s, P, Q);
+    if (piped && (e = hipEventRecord(pipe->cand_done[set], s)) != hipSuccess) return e;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1361,16 +1385,16 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
 }  // namespace
 
 hipError_t launch_f0(const LldParams &P, const F0Params &Q0, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
-                     hipEvent_t frames_done) {
+                     hipEvent_t frames_done, const F0Pipe *pipe) {
   if (P.total_frames <= 0) return hipSuccess;
   if (Q0.n_harm > 17 || Q0.vit_buf < 2 || Q0.vit_buf > kVBmax || !Q0.ab) return hipErrorInvalidValue;
   (void)max_blocks;
   hipError_t e;
   switch (f0_logm(Q0)) {
-    case 8: e = launch_f0_chunks<8>(P, Q0, s); break;
-    case 9: e = launch_f0_chunks<9>(P, Q0, s); break;
-    case 10: e = launch_f0_chunks<10>(P, Q0, s); break;
-    case 11: e = launch_f0_chunks<11>(P, Q0, s); break;
+    case 8: e = launch_f0_chunks<8>(P, Q0, s, pipe); break;
+    case 9: e = launch_f0_chunks<9>(P, Q0, s, pipe); break;
+    case 10: e = launch_f0_chunks<10>(P, Q0, s, pipe); break;
+    case 11: e = launch_f0_chunks<11>(P, Q0, s, pipe); break;
     default: return hipErrorInvalidValue;                 // 60 ms frames of 8 .. 48 kHz
   }
   if (e != hipSuccess) return e;

@@ -52,8 +52,19 @@ hipError_t launch_compare_b_extra(const int64_t *d_frame_off, const int64_t *d_r
                                   hipStream_t s);
 // frames_done (optional): recorded on s after the frame kernels, before the Viterbi pass -- what follows (Viterbi, jitter) is
 // one wave per utterance and leaves the device to whatever a side stream starts then
+// F0Pipe (optional, host side; round 6): the three frame kernels of the chunk loop -- lld_f0_spec (70 % VALU, LDS), lld_f0_sweep
+// (one frame per lane: memory latency, 41 % VALU) and lld_f0_cand (98 % VALU) -- as a PIPELINE over the chunks: chunk i's
+// candidates on the caller's stream beside chunk i + 1's sweep and chunk i + 2's spectra on two streams of their own, two sets of
+// scratch rows taken in turn. The idea: each kernel alone leaves issue slots idle for its own reason, side by side they would fill one
+// another's. Measured (SMILEHIP_F0_PIPE=1): bit-identical, not faster (config 4: 243.4 against 241.0 ms) -- off by default.
+struct F0Pipe {
+  hipStream_t spec = nullptr, sweep = nullptr;
+  hipEvent_t start = nullptr, spec_done[2] = {nullptr, nullptr}, sweep_done[2] = {nullptr, nullptr}, cand_done[2] = {nullptr, nullptr};
+  double *ab2 = nullptr;                                  // the second set of scratch rows (the first is F0Params::ab)
+};
 hipError_t launch_f0(const LldParams &P, const F0Params &Q, int max_blocks, float *d_out, int64_t ld_out, hipStream_t s,
-                     hipEvent_t frames_done = nullptr);
+                     hipEvent_t frames_done = nullptr, const F0Pipe *pipe = nullptr);
+int f0_chunk_tiles();
 int f0_tile_frames();
 // cPitchSmootherViterbi as a stream: one frame (or the flush) per launch, state in global memory
 hipError_t launch_f0_viterbi_steps(const F0Params &Q, const float *d_frames, int *d_st, double *d_dstate, int *d_paths, int *d_decided,

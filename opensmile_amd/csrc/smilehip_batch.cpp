@@ -245,6 +245,21 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 row scratch (%zu MB) failed", nab * sizeof(double) >> 20);
     }
     b->d_f0_ab.n = nab;
+    // SMILEHIP_F0_PIPE=1 (round 6, measured and NOT the default): a second set of rows for the chunk pipeline (F0Pipe). Bit-identical
+    // (tests/test_gpu_f0_pipe.py) and no faster: config 4 243.4 ms piped against 241.0 ms chunk after chunk, config 5 1087 against
+    // 1081 -- side by side the three kernels stretch (spec 39 -> 102 ms, cand 36 -> 45, sweep 26 -> 38 summed) by what they gain;
+    // the idle issue slots their counters show are not slots another kernel's waves can use.
+    {
+      static const bool pipe_on = [] { const char *e = getenv("SMILEHIP_F0_PIPE"); return e && e[0] == '1'; }();
+      if (pipe_on && b->n_tiles > f0_chunk_tiles()) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 > nab * sizeof(double) &&
+            hipMalloc(reinterpret_cast<void **>(&b->d_f0_ab2.p), nab * sizeof(double)) == hipSuccess)
+          b->d_f0_ab2.n = nab;
+        else
+          (void)hipGetLastError();
+      }
+    }
     std::vector<int32_t> zp(size_t(n_utt ? n_utt : 1), 0);
     if ((rc = b->d_pending.upload(zp)) || (rc = b->d_jit_redo.upload(zp))) {
       delete b;
@@ -300,6 +315,10 @@ extern "C" int smilehip_batch_frame_offsets(const smilehip_batch *b, int64_t *o)
 }
 
 // -------------------------------------------------------------------- run
+static bool serial_forced() {                              // SMILEHIP_SERIAL=1: every kernel alone on the device (kernel tables)
+  static const bool v = [] { const char *e = getenv("SMILEHIP_SERIAL"); return e && e[0] != '0'; }();
+  return v;
+}
 static bool serial_streams(int64_t total_frames) {
   static const int forced = [] { const char *e = getenv("SMILEHIP_SERIAL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
   return forced >= 0 ? forced != 0 : total_frames >= (int64_t)4000000;
@@ -689,7 +708,19 @@ static int f0_run(smilehip_plan *plan, smilehip_batch *b, const int16_t *d_pcm, 
   Q.vit_log_out = log_out ? 1 : 0;
   int trc;
   if ((trc = timing_mark(plan, 0, (hipStream_t)stream))) return trc;       // (a sub-chain's plan never has timing switched on)
-  hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream, frames_done);
+  const F0Pipe *pipe = nullptr;
+  if (b->d_f0_ab2.p && !serial_forced()) {
+    F0Pipe &fp = plan->f0_pipe;
+    if (!fp.spec) {
+      HIP_TRY(hipStreamCreateWithFlags(&fp.spec, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&fp.sweep, hipStreamNonBlocking));
+      for (hipEvent_t *ev_ : {&fp.start, &fp.spec_done[0], &fp.spec_done[1], &fp.sweep_done[0], &fp.sweep_done[1], &fp.cand_done[0], &fp.cand_done[1]})
+        HIP_TRY(hipEventCreateWithFlags(ev_, hipEventDisableTiming));
+    }
+    fp.ab2 = b->d_f0_ab2.p;
+    pipe = &fp;
+  }
+  hipError_t e = launch_f0(P, Q, plan->ctx->prop.multiProcessorCount, d_out, ld_out, (hipStream_t)stream, frames_done, pipe);
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "F0 kernel launch failed: %s", hipGetErrorString(e));
   if ((trc = timing_mark(plan, 1, (hipStream_t)stream))) return trc;
   return timing_mark(plan, 2, (hipStream_t)stream);

@@ -135,6 +135,7 @@ struct smilehip_plan {
   smilehip_plan *f0_plan = nullptr;
   hipStream_t side_stream = nullptr;      // whole-level chain: groups A+B run here, concurrently with the F0 group
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  F0Pipe f0_pipe;                         // the F0 chunk pipeline's streams and events (created by the first run that uses them)
   hipStream_t bg_stream = nullptr;        // eGeMAPS: cPitchJitter (one wave per utterance, latency-bound) at the lowest priority, beside
   hipEvent_t ev_bg_fork = nullptr, ev_bg_join = nullptr;   // the 20 ms chain and cHarmonics
   F0Host f0;
@@ -163,6 +164,11 @@ struct smilehip_plan {
     if (side_stream) (void)hipStreamDestroy(side_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (f0_pipe.spec) (void)hipStreamDestroy(f0_pipe.spec);
+    if (f0_pipe.sweep) (void)hipStreamDestroy(f0_pipe.sweep);
+    for (hipEvent_t ev_ : {f0_pipe.start, f0_pipe.spec_done[0], f0_pipe.spec_done[1], f0_pipe.sweep_done[0], f0_pipe.sweep_done[1],
+                           f0_pipe.cand_done[0], f0_pipe.cand_done[1]})
+      if (ev_) (void)hipEventDestroy(ev_);
     if (bg_stream) (void)hipStreamDestroy(bg_stream);
     if (ev_bg_fork) (void)hipEventDestroy(ev_bg_fork);
     if (ev_bg_join) (void)hipEventDestroy(ev_bg_join);
@@ -187,6 +193,7 @@ struct smilehip_batch {
   DevBuf<float> d_mag_keep;               // F0 group inside the eGeMAPS chain: the frames' magnitude spectra (total_frames x mag_ld) for
   int64_t mag_ld = 0;                     //   cHarmonics, which reads the level the pitch chain reads; empty: cHarmonics transforms again
   DevBuf<double> d_f0_ab;                 // F0 group: rows of (y | 6ut -> y2) between the three frame kernels, one chunk of tiles
+  DevBuf<double> d_f0_ab2;                // ... the second set of the chunk pipeline (batches of more than one chunk)
   float *d_hps_tap = nullptr;             // F0 group: caller-owned destination of the is13_hpsG60 tap (or null)
   DevBuf<int32_t> d_pending;              // F0 group: frames the Viterbi pass left undecided at the end, per utterance
   DevBuf<int32_t> d_jit_utt, d_jit_t0, d_jit_redo, d_jit_ctl;   // F0 group: cPitchJitter's work items (lld_jitter.hip) and its redo marks
