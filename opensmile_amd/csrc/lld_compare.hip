@@ -600,20 +600,24 @@ hipError_t launch_compare(const LldParams &P, const CompareParams &Q, int n_runs
     static const char *force = getenv("SMILEHIP_COMPARE_WAVES");              // "2" / "3": A/B checks
     const bool beside_small_jitter_pass = force ? force[0] == '2' : (de_col == 65 && P.n_utt < 2048);   // (65: the whole ComParE level, see above)
     // (the quad form first: it is short enough not to crowd out a small batch's jitter pass, the reason for the two-wave build below)
-    const bool quad_ok = P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
-                         P.pcm && !P.pcm_f32 && !(force && force[0] == '2');
-    if (beside_small_jitter_pass && !quad_ok) SMILEHIP_KLAUNCH(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
-    else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && P.n_bands == 26 && P.n_mfcc == 14 &&
-             P.pcm && !P.pcm_f32 && P.total_frames < (int64_t(1) << 31) && Q.band_iL[0] >= 0 && Q.band_iL[0] < Q.band_iR[0] && Q.band_iR[0] <= 256 &&
-             Q.band_iL[1] >= 0 && Q.band_iL[1] < Q.band_iR[1] && Q.band_iR[1] <= 256 && Q.max_utt_samples < (int64_t(1) << 31) &&
-             !getenv("SMILEHIP_COMPARE_GENERAL") && !getenv("SMILEHIP_COMPARE_WAVE")) {
+    // ONE statement of when the sixteen-lanes-per-frame form runs (the condition used to be written twice and the two
+    // copies differed -- with SMILEHIP_COMPARE_WAVE=1 on a small batch the launch went to wave3t instead of the two-wave kernel)
+    const bool tuned_geo = P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257;
+    const bool use_quad = tuned_geo && P.n_bands == 26 && P.n_mfcc == 14 && P.pcm && !P.pcm_f32 && !(force && force[0] == '2') &&
+                          P.total_frames < (int64_t(1) << 31) && Q.max_utt_samples < (int64_t(1) << 31) &&
+                          Q.band_iL[0] >= 0 && Q.band_iL[0] < Q.band_iR[0] && Q.band_iR[0] <= 256 &&
+                          Q.band_iL[1] >= 0 && Q.band_iL[1] < Q.band_iR[1] && Q.band_iR[1] <= 256 &&
+                          !getenv("SMILEHIP_COMPARE_GENERAL") && !getenv("SMILEHIP_COMPARE_WAVE");
+    // (the quad form first: it is short enough not to crowd out a small batch's jitter pass, the reason for the two-wave build)
+    if (beside_small_jitter_pass && !use_quad) SMILEHIP_KLAUNCH(lld_compare_frame_wave, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
+    else if (use_quad) {
       // sixteen lanes per frame (lld_compare_quad.hpp); SMILEHIP_COMPARE_WAVE=1: the wave-per-frame form (A/B switch)
       const size_t qlds = sizeof(float) * compare_quad_lds_floats(P.oo);
       hipError_t eq = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_compare_frame_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
       if (eq != hipSuccess) return eq;
       const int per_wg = kCmpQuadWaves * 4;
       SMILEHIP_KLAUNCH(lld_compare_frame_quad, dim3((unsigned)((n_runs + per_wg - 1) / per_wg)), dim3(kCmpQuadWaves * 64), qlds, s, P, Q, n_runs);
-    } else if (P.oo.tw && P.N == 320 && P.H == 160 && P.pad_left == 96 && Q.N60 == 960 && P.K == 257 && !getenv("SMILEHIP_COMPARE_GENERAL"))
+    } else if (tuned_geo && !getenv("SMILEHIP_COMPARE_GENERAL"))
       SMILEHIP_KLAUNCH(lld_compare_frame_wave3t, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
     else SMILEHIP_KLAUNCH(lld_compare_frame_wave3, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), lds, s, P, Q, n_runs);
   }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemaps_frame20_quad_body(const LldParams &P, con
     const bool warm = t < t0;
     const bool store = live && !warm;
     float *raw = G.raw20 + (int64_t)(f0 + t) * 12;
-    const int16_t *x = xu + t * kH;
+    const int16_t *x = xu + (int64_t)t * kH;      // (64-bit: t * kH in int overflows on an utterance of more than 2^31 samples)
     // ---- samples: element i = 16 r + j holds samples 2 i - PAD, 2 i - PAD + 1 (ten registers of the sixteen)
     static_assert(PAD % 32 == 0 && PAD >= 0 && PAD <= 192, "whole registers of padding");
     float2 v[16];

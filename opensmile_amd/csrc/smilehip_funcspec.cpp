@@ -201,6 +201,10 @@ struct ModEntry {                                       // one option set's tabl
 struct ModCache {
   std::mutex mu;
   std::vector<std::unique_ptr<ModEntry>> sets;
+  // sets that left the cache: their tables may still be read by a launch another thread has not enqueued yet (it copied the
+  // pointers out under the lock and launches after releasing it), so they are kept until many of them have piled up -- by then
+  // every launch that could name them is long enqueued -- and freed behind a device synchronisation
+  std::vector<std::unique_ptr<ModEntry>> retired;
 };
 void mod_cache_free(ModCache *m) { delete m; }
 namespace {
@@ -224,9 +228,13 @@ int mod_prepare(smilehip_context *ctx, const smilehip_func_spec &s, ModTables &o
       return SMILEHIP_OK;
     }
   }
-  if (cache->sets.size() >= kModCacheSets) {             // the least recently used set goes: wait for the launches that may read it
-    HIP_TRY(hipDeviceSynchronize());
+  if (cache->sets.size() >= kModCacheSets) {             // the least recently used set leaves the cache (ModCache::retired)
+    cache->retired.push_back(std::move(cache->sets.back()));
     cache->sets.pop_back();
+    if (cache->retired.size() > 64) {
+      HIP_TRY(hipDeviceSynchronize());
+      cache->retired.clear();
+    }
   }
   std::unique_ptr<ModEntry> fresh(new (std::nothrow) ModEntry());
   ModEntry *m = fresh.get();
