@@ -481,6 +481,24 @@ int  smilehip_free(smilehip_context *ctx, void *d_ptr);
 int  smilehip_copy_to_device(smilehip_context *ctx, void *d_dst, const void *h_src, uint64_t bytes, void *stream);
 int  smilehip_copy_to_host(smilehip_context *ctx, void *h_dst, const void *d_src, uint64_t bytes, void *stream);
 int  smilehip_stream_synchronize(smilehip_context *ctx, void *stream);
+/* Block cache for the device memory of batches and plans: up to `bytes` of the blocks the library frees are kept and handed out
+ * again for allocations of exactly their size (0, the default: off, and the kept blocks are freed). For hosts that create and
+ * destroy one batch per chunk of files while the next chunk's copies and kernels are already enqueued on another stream:
+ * hipFree synchronises the whole device, i.e. would wait for them. With the cache on, smilehip_batch_destroy no longer implies
+ * that synchronisation -- the caller destroys a batch only after the stream its work ran on has drained. Process-wide. */
+int  smilehip_alloc_cache(smilehip_context *ctx, uint64_t bytes);
+/* A stream of the caller's own (non-blocking with respect to the null stream): what a host that overlaps the copies and kernels of
+ * consecutive chunks needs and cannot create without linking the HIP runtime (smilextract_hip: chunk k's copy-out beside chunk
+ * k + 1's copy-in and kernels). Every entry point with a `stream` argument takes it. */
+int  smilehip_stream_create(smilehip_context *ctx, void **stream);
+int  smilehip_stream_destroy(smilehip_context *ctx, void *stream);
+/* ... and the ordering between two such streams: an event (no timing) recorded on one, awaited by the other -- "chunk k + 1's
+ * kernels start when chunk k's kernels are done" (the library's context-wide scratch, e.g. the functionals', serves one run at a
+ * time) while the copies either side run on. */
+int  smilehip_event_create(smilehip_context *ctx, void **event);
+int  smilehip_event_destroy(smilehip_context *ctx, void *event);
+int  smilehip_event_record(smilehip_context *ctx, void *event, void *stream);
+int  smilehip_stream_wait_event(smilehip_context *ctx, void *stream, void *event);
 /* The same copies for `rows` rows of `width_bytes` bytes with a row pitch on either side: a block of frames of a dataMemory level
  * (cMatrix::data, [frames x N] floats: src/core/dataMemoryLevel.cpp:1530-1582 setMatrix / :1651-1740 getMatrix) against a device
  * block of another width. What the plugin's block-per-tick overrides move per tick (one call per level instead of one per frame). */

@@ -179,6 +179,13 @@ SYMBOLS = {
     "smilehip_htk_rows_be": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "smilehip_copy_to_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "smilehip_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "smilehip_alloc_cache": (C.c_int, [_vp, C.c_uint64]),
+    "smilehip_stream_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "smilehip_stream_destroy": (C.c_int, [_vp, _vp]),
+    "smilehip_event_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "smilehip_event_destroy": (C.c_int, [_vp, _vp]),
+    "smilehip_event_record": (C.c_int, [_vp, _vp, _vp]),
+    "smilehip_stream_wait_event": (C.c_int, [_vp, _vp, _vp]),
     "smilehip_kernel_timing": (C.c_int, [C.c_int]),
     "smilehip_kernel_timing_report": (C.c_int64, [_vp, _i64]),
     "smilehip_copy_to_device_2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),

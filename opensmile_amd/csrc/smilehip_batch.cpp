@@ -110,15 +110,15 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return rc;
     }
     const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_rawA.p), nf * 4 * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&b->d_rawB.p), nf * 55 * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&b->d_mel1.p), nf * 26 * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_rawA.p), nf * 4 * sizeof(float)) != hipSuccess ||
+        smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_rawB.p), nf * 55 * sizeof(float)) != hipSuccess ||
+        smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_mel1.p), nf * 26 * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
     }
     b->d_rawA.n = nf * 4; b->d_rawB.n = nf * 55; b->d_mel1.n = nf * 26;
     b->d_b_extra.n = size_t(n_utt ? n_utt : 1) * 110;
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_b_extra.p), b->d_b_extra.n * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_b_extra.p), b->d_b_extra.n * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the ComParE scratch matrices failed");
     }
@@ -137,7 +137,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     const size_t nfin = size_t(b->h_fin_off[n_utt] ? b->h_fin_off[n_utt] : 1);
     auto alloc = [&](DevBuf<float> &d, size_t n) {
       d.release();
-      if (hipMalloc(reinterpret_cast<void **>(&d.p), n * sizeof(float)) != hipSuccess) return false;
+      if (smilehip::dev_malloc(reinterpret_cast<void **>(&d.p), n * sizeof(float)) != hipSuccess) return false;
       d.n = n;
       return true;
     };
@@ -165,7 +165,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       bool keep = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2;
       if (env && env[0] == '0') keep = false;
       if (env && env[0] == '1') keep = true;
-      if (keep && hipMalloc(reinterpret_cast<void **>(&fb->d_mag_keep.p), need) == hipSuccess) {
+      if (keep && smilehip::dev_malloc(reinterpret_cast<void **>(&fb->d_mag_keep.p), need) == hipSuccess) {
         fb->d_mag_keep.n = need / sizeof(float);
         fb->mag_ld = ld;
       } else {
@@ -225,7 +225,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   if ((plan->cfg.chain_kind == SMILEHIP_CHAIN_MFCC || plan->cfg.chain_kind == SMILEHIP_CHAIN_PLP) && plan->cfg.n_delta > 0 &&
       plan->ctx && b->total_frames > 0 && b->n_ftiles == 0) {
     const size_t n = size_t(b->total_frames) * size_t(plan_n_static(plan));
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_static.p), n * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the static-block scratch failed");
     }
@@ -233,14 +233,14 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
   }
   if (plan->cfg.chain_kind == SMILEHIP_CHAIN_COMPARE_F0) {
     const size_t nf = size_t(b->total_frames ? b->total_frames : 1);
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_shs.p), nf * 21 * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&b->d_e60.p), nf * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_shs.p), nf * 21 * sizeof(float)) != hipSuccess ||
+        smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_e60.p), nf * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 scratch matrices failed");
     }
     b->d_shs.n = nf * 21; b->d_e60.n = nf;
     const size_t nab = (size_t)std::max<int64_t>(f0_scratch_doubles(b->n_tiles, (int)plan->geo.K), 1);
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_f0_ab.p), nab * sizeof(double)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_f0_ab.p), nab * sizeof(double)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 row scratch (%zu MB) failed", nab * sizeof(double) >> 20);
     }
@@ -254,7 +254,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       if (pipe_on && b->n_tiles > f0_chunk_tiles()) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 > nab * sizeof(double) &&
-            hipMalloc(reinterpret_cast<void **>(&b->d_f0_ab2.p), nab * sizeof(double)) == hipSuccess)
+            smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_f0_ab2.p), nab * sizeof(double)) == hipSuccess)
           b->d_f0_ab2.n = nab;
         else
           (void)hipGetLastError();
@@ -284,8 +284,8 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
       return rc;
     }
     const size_t nf = size_t(b->f0_batch->total_frames ? b->f0_batch->total_frames : 1);
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_pitch2.p), nf * 2 * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&b->d_jit4.p), nf * 4 * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_pitch2.p), nf * 2 * sizeof(float)) != hipSuccess ||
+        smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_jit4.p), nf * 4 * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the F0 group's scratch matrices failed");
     }
@@ -295,7 +295,7 @@ extern "C" int smilehip_batch_create(smilehip_plan *plan, const int64_t *h_off, 
     std::vector<float> zero;   // allocate only
     b->d_raw16.release();
     b->d_raw16.n = size_t(b->total_frames) * 16;
-    if (hipMalloc(reinterpret_cast<void **>(&b->d_raw16.p), (b->d_raw16.n ? b->d_raw16.n : 1) * sizeof(float)) != hipSuccess) {
+    if (smilehip::dev_malloc(reinterpret_cast<void **>(&b->d_raw16.p), (b->d_raw16.n ? b->d_raw16.n : 1) * sizeof(float)) != hipSuccess) {
       delete b;
       return fail(SMILEHIP_ERR_HIP, "hipMalloc of the IS09 scratch matrix failed");
     }

@@ -129,9 +129,143 @@ extern "C" int smilehip_htk_rows_be(smilehip_context *ctx, const float *d_src, i
   if (e != hipSuccess) return fail(SMILEHIP_ERR_HIP, "smilehip_htk_rows_be: %s", hipGetErrorString(e));
   return SMILEHIP_OK;
 }
+extern "C" int smilehip_stream_create(smilehip_context *ctx, void **stream) {
+  if (!ctx || !stream) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_create: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_stream_destroy(smilehip_context *ctx, void *stream) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_destroy: null context");
+  if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_event_create(smilehip_context *ctx, void **event) {
+  if (!ctx || !event) return fail(SMILEHIP_ERR_INVALID, "smilehip_event_create: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipEvent_t e = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = e;
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_event_destroy(smilehip_context *ctx, void *event) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_event_destroy: null context");
+  if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_event_record(smilehip_context *ctx, void *event, void *stream) {
+  if (!ctx || !event) return fail(SMILEHIP_ERR_INVALID, "smilehip_event_record: null argument");
+  HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+extern "C" int smilehip_stream_wait_event(smilehip_context *ctx, void *stream, void *event) {
+  if (!ctx || !event) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_wait_event: null argument");
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return SMILEHIP_OK;
+}
 extern "C" int smilehip_stream_synchronize(smilehip_context *ctx, void *stream) {
   if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_stream_synchronize: null context");
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SMILEHIP_OK;
+}
+
+// ------------------------------------------------------------------ block cache of the batches' and plans' device memory
+#include <unordered_map>
+namespace smilehip {
+namespace {
+std::mutex g_dc_mu;
+size_t g_dc_limit = 0, g_dc_held = 0;
+std::unordered_map<void *, size_t> g_dc_size;             // blocks handed out while the cache is on
+std::multimap<size_t, void *> g_dc_free;                  // blocks kept, by size
+}  // namespace
+hipError_t dev_malloc(void **p, size_t bytes) {
+  bytes = bytes ? bytes : 1;
+  {
+    std::lock_guard<std::mutex> lock(g_dc_mu);
+    if (g_dc_limit) {
+      auto it = g_dc_free.find(bytes);
+      if (it != g_dc_free.end()) {
+        *p = it->second;
+        g_dc_free.erase(it);
+        g_dc_held -= bytes;
+        g_dc_size[*p] = bytes;
+        return hipSuccess;
+      }
+    }
+  }
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(g_dc_mu);
+    if (g_dc_limit) g_dc_size[*p] = bytes;
+  }
+  return e;
+}
+void dev_free(void *p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_dc_mu);
+    auto it = g_dc_size.find(p);
+    if (it != g_dc_size.end()) {
+      const size_t b = it->second;
+      g_dc_size.erase(it);
+      if (g_dc_limit && g_dc_held + b <= g_dc_limit) {
+        g_dc_free.emplace(b, p);
+        g_dc_held += b;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+namespace {
+constexpr size_t kStageBytes = (size_t)4 << 20;
+std::mutex g_up_mu;
+void *g_up_stage = nullptr;
+hipStream_t g_up_stream = nullptr;
+__global__ void k_upload_words(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+hipError_t dev_upload(void *d_dst, const void *h_src, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  bool fast;
+  {
+    std::lock_guard<std::mutex> lock(g_dc_mu);
+    fast = g_dc_limit != 0;
+  }
+  if (!fast || bytes > kStageBytes || (bytes & 3)) return hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice);
+  std::lock_guard<std::mutex> lock(g_up_mu);
+  hipError_t e;
+  if (!g_up_stage) {
+    if ((e = hipHostMalloc(&g_up_stage, kStageBytes, hipHostMallocDefault)) != hipSuccess) { g_up_stage = nullptr; return hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice); }
+    if ((e = hipStreamCreateWithFlags(&g_up_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+  }
+  memcpy(g_up_stage, h_src, bytes);
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_upload_words, dim3(grid), dim3(256), 0, g_up_stream, static_cast<const uint32_t *>(g_up_stage), static_cast<uint32_t *>(d_dst), n);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipStreamSynchronize(g_up_stream);
+}
+}  // namespace smilehip
+
+extern "C" int smilehip_alloc_cache(smilehip_context *ctx, uint64_t bytes) {
+  if (!ctx) return fail(SMILEHIP_ERR_INVALID, "smilehip_alloc_cache: null context");
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> lock(smilehip::g_dc_mu);
+    smilehip::g_dc_limit = (size_t)bytes;
+    while (!smilehip::g_dc_free.empty() && smilehip::g_dc_held > smilehip::g_dc_limit) {
+      auto it = std::prev(smilehip::g_dc_free.end());
+      smilehip::g_dc_held -= it->first;
+      drop.push_back(it->second);
+      smilehip::g_dc_free.erase(it);
+    }
+    if (!bytes) smilehip::g_dc_size.clear();
+  }
+  for (void *p : drop) (void)hipFree(p);
   return SMILEHIP_OK;
 }
 

@@ -376,7 +376,7 @@ int main(int argc, char **argv) {
   // k + 2. SMILEHIP_NO_PINNED=1: the pageable, serial route of round 3 (A/B switch; same files).
   const bool timing = getenv("SMILEHIP_TIMING") != nullptr;
   struct HostBuf { void *p = nullptr; size_t cap = 0; };
-  HostBuf pcm_slot[2], out_slot[2];
+  HostBuf pcm_slot[3], out_slot[2];                          // (three sample slots: chunk k + 2 is read while chunk k's copy-in may still be under way)
   auto host_reserve = [&](HostBuf &hb, size_t bytes) -> void * {
     if (bytes <= hb.cap) return hb.p;
     if (hb.p) smilehip_free_host(ctx, hb.p);
@@ -386,7 +386,21 @@ int main(int argc, char **argv) {
     hb.cap = cap;
     return hb.p;
   };
-  HostBuf dev_pcm, dev_lld, dev_func;                       // device buffers, kept and grown
+  HostBuf dev_pcm[2], dev_lld[2], dev_func[2];              // device buffers, kept and grown; two sets taken in turn by the chunks
+  // (round 6) Chunk k's copy-in, kernels and copy-out go to stream k & 1 and the host does NOT wait for them: it reads and enqueues
+  // chunk k + 1 first -- whose copy-in and kernels then run beside chunk k's copy-out, the link's two directions at once -- and only
+  // then finishes chunk k (synchronise its stream, destroy its batch, start its sinks, write its summary rows). Chunks that are not
+  // the plain case (one sample rate, 16-bit mono, page-locked slots) are finished at once, as before.
+  // The KERNELS of consecutive chunks stay in order (the library's context-wide scratch -- the functionals' -- serves one run at
+  // a time): chunk k + 1's first kernel waits for the event behind chunk k's last one; the copies either side do not.
+  void *chunk_stream[2] = {nullptr, nullptr}, *chunk_computed[2] = {nullptr, nullptr};
+  bool computed_recorded[2] = {false, false};
+  if (!no_pinned && !getenv("SMILEHIP_E2E_SERIAL")) {
+    for (void *&cs : chunk_stream) check(smilehip_stream_create(ctx, &cs), "smilehip_stream_create");
+    for (void *&ce : chunk_computed) check(smilehip_event_create(ctx, &ce), "smilehip_event_create");
+    check(smilehip_alloc_cache(ctx, (uint64_t)1 << 30), "smilehip_alloc_cache");   // a batch's blocks go to the next batch: no hipFree (= device-wide wait) per chunk
+  }
+  std::function<void()> pending;                            // what the previous chunk still has to do
   auto dev_reserve = [&](HostBuf &db, size_t bytes) -> void * {
     if (bytes <= db.cap && db.p) return db.p;
     if (db.p) smilehip_free(ctx, db.p);
@@ -515,13 +529,19 @@ int main(int argc, char **argv) {
     double t0 = now();
     Chunk chunk = ahead.get();
     t_wait_ingest += now() - t0;
-    if (j1 < jobs.size()) ahead = std::async(std::launch::async, ingest, j1, slot ^ 1);
+    if (j1 < jobs.size()) ahead = std::async(std::launch::async, ingest, j1, (chunk_no + 1) % 3);
     if (!chunk.err.empty()) die(chunk.err);
     t0 = now();
     std::map<long, std::vector<size_t>> by_rate;
     std::vector<std::vector<unsigned char>> &raw = chunk.raw;
     for (size_t j = j0; j < j1; ++j) by_rate[chunk.info[j - j0].sample_rate].push_back(j);
-    std::vector<std::vector<float>> func_rows(j1 - j0);   // per job of the chunk; empty = no instance (no frame)
+    // per job of the chunk; empty = no instance (no frame). On the heap: the chunk may be finished an iteration later.
+    std::shared_ptr<std::vector<std::vector<float>>> func_rows_p = std::make_shared<std::vector<std::vector<float>>>(j1 - j0);
+    std::vector<std::vector<float>> &func_rows = *func_rows_p;
+    std::vector<std::function<void()>> finish_groups;       // one per rate group
+    const bool defer = chunk_stream[0] != nullptr && chunk.fast && by_rate.size() == 1;
+    void *const st = defer ? chunk_stream[slot] : nullptr;
+    if (!defer && pending) { pending(); pending = nullptr; }   // (a chunk on the null stream: the one before it is finished first)
     for (auto &kv : by_rate) {
       smilehip_plan *plan = make_plan(kv.first);
       std::shared_ptr<SinkWork> w = std::make_shared<SinkWork>();
@@ -572,12 +592,13 @@ int main(int argc, char **argv) {
       w->n_out = n_out;
       void *d_func = nullptr;
       const uint64_t pcm_bytes = (uint64_t)std::max<int64_t>(true_off.back(), 2) * 2;
-      void *d_pcm = dev_reserve(dev_pcm, pcm_bytes);
-      void *d_lld = dev_reserve(dev_lld, (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4);
+      void *d_pcm = dev_reserve(dev_pcm[slot], pcm_bytes);
+      void *d_lld = dev_reserve(dev_lld[slot], (uint64_t)std::max<int64_t>(rows, 1) * n_out * 4);
       void *d_f32 = nullptr;
       if (all_s16_mono) {
-        check(smilehip_copy_to_device(ctx, d_pcm, pcm_host, (uint64_t)true_off.back() * 2, nullptr), "copy_to_device");
-        check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, nullptr), "smilehip_lld_run");
+        check(smilehip_copy_to_device(ctx, d_pcm, pcm_host, (uint64_t)true_off.back() * 2, st), "copy_to_device");
+        if (defer && computed_recorded[slot ^ 1]) check(smilehip_stream_wait_event(ctx, st, chunk_computed[slot ^ 1]), "stream_wait_event");
+        check(smilehip_lld_run(plan, b, (const int16_t *)d_pcm, (float *)d_lld, n_out, st), "smilehip_lld_run");
       } else {
         check(smilehip_alloc(ctx, (uint64_t)std::max<int64_t>(true_off.back(), 1) * 4, &d_f32), "smilehip_alloc");
         size_t biggest = 1;
@@ -604,18 +625,18 @@ int main(int argc, char **argv) {
       w->n_func = n_func;
       std::vector<float> &func = w->func;
       if (has_func) {
-        d_func = dev_reserve(dev_func, (uint64_t)idx.size() * n_func * 4);
+        d_func = dev_reserve(dev_func[slot], (uint64_t)idx.size() * n_func * 4);
         if (is09)
-          check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, nullptr),
+          check(smilehip_batch_functionals(plan, b, (const float *)d_lld, n_out, fmask, (float *)d_func, n_func, st),
                 "smilehip_batch_functionals");
         else if (egm)
-          check(smilehip_batch_functionals_egemaps(plan, b, (float *)d_func, n_func, nullptr), "smilehip_batch_functionals_egemaps");
+          check(smilehip_batch_functionals_egemaps(plan, b, (float *)d_func, n_func, st), "smilehip_batch_functionals_egemaps");
         else
           check((is13 ? smilehip_batch_functionals_is13_compare : smilehip_batch_functionals_compare16)(
-                    plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, nullptr),
+                    plan, b, (const float *)d_lld, n_out, (float *)d_func, n_func, st),
                 "smilehip_batch_functionals_compare16");
         func.resize(idx.size() * (size_t)n_func);
-        check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, nullptr), "copy_to_host");
+        check(smilehip_copy_to_host(ctx, func.data(), d_func, (uint64_t)func.size() * 4, st), "copy_to_host");
       }
       const std::string lld_htk_opt = lld_opts ? "-lldhtkoutput" : "-O", lld_csv_opt = lld_opts ? "-lldcsvoutput" : "-csvoutput";
       const bool want_lld_htk = opt.count(lld_htk_opt) && opt[lld_htk_opt] != "?";
@@ -632,9 +653,21 @@ int main(int argc, char **argv) {
       w->lld = lld;
       dlap(t_dev_reserve);
       w->be = !no_pinned && want_lld_htk && !want_lld_csv && !out_subset && rows > 0;
-      if (w->be) check(smilehip_htk_rows_be(ctx, (const float *)d_lld, rows * n_out, d_lld, nullptr), "smilehip_htk_rows_be");
-      if (rows > 0) check(smilehip_copy_to_host(ctx, lld, d_lld, (uint64_t)rows * n_out * 4, nullptr), "copy_to_host");
-      check(smilehip_stream_synchronize(ctx, nullptr), "stream_synchronize");
+      if (w->be) check(smilehip_htk_rows_be(ctx, (const float *)d_lld, rows * n_out, d_lld, st), "smilehip_htk_rows_be");
+      if (defer) { check(smilehip_event_record(ctx, chunk_computed[slot], st), "event_record"); computed_recorded[slot] = true; }
+      if (rows > 0) check(smilehip_copy_to_host(ctx, lld, d_lld, (uint64_t)rows * n_out * 4, st), "copy_to_host");
+      dlap(t_dev_enqueue);
+      // ---- from here on: what the chunk does once its stream has drained (at once, or after the next chunk has been enqueued).
+      // Everything of this iteration it needs is taken by value.
+      const bool one_group = by_rate.size() == 1;
+      finish_groups.push_back([&, w, b, st, d_f32, n_func, j0, slot, func_rows_p, want_lld_htk, want_lld_csv, lld_htk_opt, lld_csv_opt, one_group]() {
+      std::vector<std::vector<float>> &func_rows = *func_rows_p;
+      const std::vector<size_t> &idx = w->idx;
+      const std::vector<int64_t> &row_off = w->row_off;
+      const std::vector<float> &func = w->func;
+      double td = now();
+      auto dlap = [&](double &acc) { const double t = now(); acc += t - td; td = t; };
+      check(smilehip_stream_synchronize(ctx, st), "stream_synchronize");
       dlap(t_dev_sync);
       if (d_f32) smilehip_free(ctx, d_f32);
       smilehip_batch_destroy(b);
@@ -695,14 +728,20 @@ int main(int argc, char **argv) {
         });
         return sink_err;
       };
-      if (!no_pinned && by_rate.size() == 1) {
+      if (!no_pinned && one_group) {
         sink_fut[slot] = std::async(std::launch::async, sinks);
       } else {
         const std::string e = sinks();
         if (!e.empty()) die(e);
       }
+      });
+      if (!defer) finish_groups.back()();
     }
     t_device += now() - t0;
+    auto finish_chunk = [&, j0, j1, func_rows_p, finish_groups, defer]() {
+    std::vector<std::vector<float>> &func_rows = *func_rows_p;
+    const double tf0 = now();
+    if (defer) for (const auto &fg : finish_groups) fg();
     // summary sinks in file-list order (the rate groups above may have processed the chunk's files in another order)
     for (size_t j = j0; j < j1 && has_func && gather; ++j) {       // kept for the gather at the end
       const std::vector<float> &fv = func_rows[j - j0];
@@ -729,7 +768,14 @@ int main(int argc, char **argv) {
         if (!write_csv(summary_path(opt["-csvoutput"]), fnames, fv.data(), 1, n_func, n_func, 0.0, nullptr, co, err)) die(err);
       }
     }
+    t_device += now() - tf0;
+    };
+    // the chunk before this one is finished now that this one's work is enqueued behind it; this one waits for the next
+    if (pending) { pending(); pending = nullptr; }
+    if (defer) pending = finish_chunk;
+    else finish_chunk();
   }
+  if (pending) { pending(); pending = nullptr; }
   for (size_t s2 = 0; s2 < 2; ++s2) sink_wait(s2);
   if (timing)
     fprintf(stderr, "smilextract_hip timing: files %zu, chunks %zu; since the first ingest %.3f s: waiting for ingest %.3f, device stage (pack, copies, "
@@ -738,8 +784,10 @@ int main(int argc, char **argv) {
             "copy out + synchronize %.3f\n", jobs.size(), chunk_no, now() - t_start, t_wait_ingest, t_device, t_wait_sink,
             us_probe.load() * 1e-6, us_reserve.load() * 1e-6, us_read.load() * 1e-6, us_sink.load() * 1e-6, t_dev_create, t_dev_enqueue,
             t_dev_reserve, t_dev_sync);
-  for (HostBuf *hb : {&pcm_slot[0], &pcm_slot[1], &out_slot[0], &out_slot[1]}) if (hb->p) smilehip_free_host(ctx, hb->p);
-  for (HostBuf *db : {&dev_pcm, &dev_lld, &dev_func}) if (db->p) smilehip_free(ctx, db->p);
+  for (HostBuf *hb : {&pcm_slot[0], &pcm_slot[1], &pcm_slot[2], &out_slot[0], &out_slot[1]}) if (hb->p) smilehip_free_host(ctx, hb->p);
+  for (HostBuf *db : {&dev_pcm[0], &dev_pcm[1], &dev_lld[0], &dev_lld[1], &dev_func[0], &dev_func[1]}) if (db->p) smilehip_free(ctx, db->p);
+  for (void *cs : chunk_stream) if (cs) smilehip_stream_destroy(ctx, cs);
+  for (void *ce : chunk_computed) if (ce) smilehip_event_destroy(ctx, ce);
   if (gather && has_func) {
     // rank r holds the rows of files r, r + world, ...: counts to everyone, rows to rank 0, rank 0 writes in list order
     std::vector<int64_t> counts((size_t)world, 0);

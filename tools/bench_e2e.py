@@ -43,6 +43,16 @@ def main():
     for name in args.sets.split(","):
         hset, conf_rel, secs, hip_out, ref_opt, ext = SETS[name]
         d = args.dir
+        # the files live in memory (/dev/shm): inputs + both outputs must fit with room to spare, or the box dies under the run
+        need = args.files * (secs * 32000 + 2 * secs * 100 * 4 * 140) * 1.3
+        try:
+            avail = {l.split(":")[0]: int(l.split()[1]) * 1024 for l in open("/proc/meminfo")}["MemAvailable"]
+            shm = shutil.disk_usage(os.path.dirname(d.rstrip("/")) or "/dev/shm").free
+        except Exception:
+            avail = shm = 0
+        if need > 0.5 * min(avail, shm):
+            print(json.dumps({"set": name, "files": args.files, "skipped": f"needs {need / 1e9:.1f} GB of /dev/shm, {min(avail, shm) / 1e9:.1f} GB available"}), flush=True)
+            continue
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d + "/in"); os.makedirs(d + "/hip"); os.makedirs(d + "/ref")
         n_samp = int(secs * 16000)
@@ -71,10 +81,18 @@ def main():
         import re
         m = re.search(r"since the first ingest ([0-9.]+) s", stages[-1]) if stages else None
         t_net = float(m.group(1)) if m else None
-        # the route of round 3 (pageable buffers, serial stages) on the same list: A/B
-        t0 = time.perf_counter()
-        subprocess.run(cmd_hip, env=dict(env, SMILEHIP_NO_PINNED="1"), capture_output=True, text=True)
-        t_old = time.perf_counter() - t0
+        # A/B on the same list: the device stage of round 5 (every chunk's copies and kernels on the null stream, the host waiting for
+        # each: SMILEHIP_E2E_SERIAL=1) and the route of round 3 (pageable buffers, serial stages; not at the large file counts)
+        t_r5 = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.run(cmd_hip, env=dict(env, SMILEHIP_E2E_SERIAL="1"), capture_output=True, text=True)
+            t_r5 = min(t_r5 or 1e9, time.perf_counter() - t0)
+        t_old = None
+        if args.files <= 10000:
+            t0 = time.perf_counter()
+            subprocess.run(cmd_hip, env=dict(env, SMILEHIP_NO_PINNED="1"), capture_output=True, text=True)
+            t_old = time.perf_counter() - t0
         # the reference-order kernel (SMILEHIP_FORCE_GENERIC=1: the binary's bits) for the byte comparison of the HTK files
         generic_same = generic_cmp = None
         if name == "mfcc12_0_d_a":
@@ -108,7 +126,7 @@ def main():
                           "frames_per_s_gross": args.files * frames_per_file / t_hip if frames_per_file else None,
                           "frames_per_s_net_of_startup": args.files * frames_per_file / t_net if (frames_per_file and t_net) else None,
                           "net_s_first_ingest_to_last_sink": t_net, "stages": stages[-1] if stages else None,
-                          "round3_route_wall_s": t_old,
+                          "round5_serial_device_stage_wall_s": t_r5, "round3_route_wall_s": t_old,
                           "force_generic_outputs_compared": generic_cmp, "force_generic_outputs_byte_identical": generic_same,
                           "smilextract_hip_files_per_s": args.files / t_hip, "smilextract_hip_audio_s_per_s": args.files * secs / t_hip,
                           "reference_files": n_ref, "reference_cores": cores, "reference_wall_s": t_ref,
