@@ -761,6 +761,14 @@ typedef struct smilehip_spectral_opts {
   double  rolloff[16];
   int32_t flux, centroid, max_pos, min_pos, entropy, variance, skewness, kurtosis, slope, sharpness, harmonicity;
   int32_t flatness, log_flatness;      /* flatness: one output; log_flatness: its logarithm instead (:1515-1545) */
+  /* round 6 -- the rest of the linear-spectrum branch (no shipped file uses them): specDiff, specPosDiff, fluxCentroid,
+   * fluxAtFluxCentroid (:1124-1254: with flux they share ONE zero on a field's first frame, the values behind it move up and the
+   * vector's last slots stay zero, as in the reference), standardDeviation (:1370-1376), slopes[] on the linear axis (:872-985,
+   * oldSlopeScale = 1). Output order: bands, slopes, rollOff, specDiff, specPosDiff, flux, fluxCentroid, fluxAtFluxCentroid,
+   * centroid, maxPos, minPos, entropy, standardDeviation, variance, skewness, kurtosis, slope, sharpness, harmonicity, flatness. */
+  int32_t spec_diff, spec_pos_diff, flux_centroid, flux_at_flux_centroid, standard_deviation;
+  int32_t n_slopes;             /* slopes[]: lo-hi in Hz, <= 16 */
+  int32_t slope_lo[16], slope_hi[16];
 } smilehip_spectral_opts;
 typedef struct smilehip_spectral_op smilehip_spectral_op;
 int smilehip_spectral_opts_count(const smilehip_spectral_opts *opts);      /* outputs per frame, -1 if out of range */

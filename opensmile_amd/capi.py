@@ -91,11 +91,16 @@ class SpectralOpts(C.Structure):
     _fields_ = [("n_bands", C.c_int32), ("band_lo", C.c_int32 * 16), ("band_hi", C.c_int32 * 16), ("n_rolloff", C.c_int32),
                 ("rolloff", C.c_double * 16)] + [(k, C.c_int32) for k in ("flux", "centroid", "max_pos", "min_pos", "entropy", "variance",
                                                                           "skewness", "kurtosis", "slope", "sharpness", "harmonicity", "flatness",
-                                                                          "log_flatness")]
+                                                                          "log_flatness", "spec_diff", "spec_pos_diff", "flux_centroid",
+                                                                          "flux_at_flux_centroid", "standard_deviation", "n_slopes")] + [
+                   ("slope_lo", C.c_int32 * 16), ("slope_hi", C.c_int32 * 16)]
 
 
-def spectral_opts(bands, rolloff=(0.25, 0.5, 0.75, 0.9), **flags):
+def spectral_opts(bands, rolloff=(0.25, 0.5, 0.75, 0.9), slopes=(), **flags):
     o = SpectralOpts()
+    o.n_slopes = len(slopes)
+    for i, (a, b) in enumerate(slopes):
+        o.slope_lo[i], o.slope_hi[i] = a, b
     o.n_bands = len(bands)
     for i, (a, b) in enumerate(bands):
         o.band_lo[i], o.band_hi[i] = a, b

@@ -1,6 +1,7 @@
 // R11, the whole option space of the shipped configuration files: cSpectral::processVector (src/lldcore/spectral.cpp:586-1560)
-// with any number of bands[] (<= 16) and rollOff[] points (<= 16) and flux, centroid, maxPos, minPos, entropy, variance, skewness,
-// kurtosis, slope, sharpness, harmonicity, flatness (or its logarithm) each optional, in the reference's output order; squareInput = 1, a linear magnitude
+// with any number of bands[] (<= 16), slopes[] (<= 16) and rollOff[] points (<= 16) and specDiff, specPosDiff, flux, fluxCentroid,
+// fluxAtFluxCentroid, centroid, maxPos, minPos, entropy, standardDeviation, variance, skewness, kurtosis, slope, sharpness, harmonicity,
+// flatness (or its logarithm) each optional, in the reference's output order; squareInput = 1, a linear magnitude
 // spectrum with the frequency axis cTransformFFT attaches (frq[i] = i / frameSizeSec), freqRange 0-0, normBandEnergies = 0,
 // useLogSpectrum = 0, buggyRollOff = 0, oldSlopeScale = 1 -- what avec2011 / avec2013, emo_large and the MediaEval files ask for
 // (ComParE_2016's and GeMAPS' sets have their own wave-parallel kernels, lld_blocks_compare.hpp / lld_gemaps.hip).
@@ -29,8 +30,12 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
   const double F0 = 1.0 / G.frame_size_sec;                      // frq[i] = F0 * i (transformFft.cpp:102-117)
   // ---- first walk
   double frameSum = 0.0, sumA = 0.0, fluxA = 0.0;                // :762-767 (== sumB, :1093-1097, == the entropy's dn), :1262-1266, :1196-1203
+  double fluxAf = 0.0, sdiff = 0.0, spdiff = 0.0;                // :1177-1190 (sum of myB^2 frq), :1143-1168 (specDiff / specPosDiff)
+  const bool flux_family = G.spec_pos_diff || G.spec_diff || G.flux || G.flux_centroid || G.flux_at_flux_centroid;
   double band[16];
   for (int b = 0; b < 16; ++b) band[b] = 0.0;
+  double sl_Sf[16], sl_S2f[16], sl_A[16], sl_B[16];              // slopes[]: :944-962
+  for (int b = 0; b < 16; ++b) { sl_Sf[b] = 0.0; sl_S2f[b] = 0.0; sl_A[b] = 0.0; sl_B[b] = 0.0; }
   int maP = lo, miP = lo;
   float vmax = 0.0f, vmin = 0.0f;
   for (int j = 0; j < Nsrc; ++j) {
@@ -41,10 +46,39 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
       else if (j > G.band_iL[b] && j < G.band_iR[b]) band[b] += (double)p;
       if (j == G.band_iR[b]) band[b] += (double)p * G.band_wR[b];
     }
+    for (int b = 0; b < G.n_slopes; ++b) {                       // :944-962: the same three-part walk, four sums
+      const double fj = F0 * (double)j;
+      if (j == G.sl_iL[b]) {
+        sl_Sf[b] = fj * G.sl_wL[b];
+        sl_S2f[b] = sl_Sf[b] * sl_Sf[b];
+        sl_A[b] = fj * G.sl_wL[b] * (double)p;
+        sl_B[b] = G.sl_wL[b] * (double)p;
+      } else if (j > G.sl_iL[b] && j < G.sl_iR[b]) {
+        sl_S2f[b] += fj * fj;
+        sl_Sf[b] += fj;
+        sl_A[b] += fj * (double)p;
+        sl_B[b] += (double)p;
+      }
+      if (j == G.sl_iR[b]) {
+        sl_S2f[b] += fj * G.sl_wR[b] * fj * G.sl_wR[b];
+        sl_Sf[b] += fj * G.sl_wR[b];
+        sl_A[b] += fj * G.sl_wR[b] * (double)p;
+        sl_B[b] += G.sl_wR[b] * (double)p;
+      }
+    }
     if (j >= lo) {
       frameSum += p;
       sumA += (F0 * (double)j) * (double)p;
-      if (have_prev) { const double d = ((double)m / 1.0 - (double)prev[j] / 1.0); fluxA += d * d; }
+      if (have_prev && flux_family) {
+        const double d = ((double)m / 1.0 - (double)prev[j] / 1.0);
+        if (G.flux || G.flux_centroid) fluxA += d * d;
+        if (G.flux_centroid) fluxAf += d * d * (F0 * (double)j);
+        if (G.spec_diff || G.spec_pos_diff) {                    // (the reference subtracts the two FLOAT_DMEM values as floats here)
+          const double myd = (double)(m - prev[j]);
+          if (G.spec_diff) sdiff += myd * myd;
+          if (G.spec_pos_diff && myd > 0.0) spdiff += myd * myd;
+        }
+      }
       if (j == lo) { vmax = p; vmin = p; }                       // :1314-1330 (the last bin is not looked at)
       else if (j < hi) {
         if (p < vmin) { vmin = p; miP = j; }
@@ -54,9 +88,16 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
   }
   int n = 0;
   for (int b = 0; b < G.n_bands; ++b) o[n++] = (float)(band[b] / (double)nBins);     // :853 (normBandEnergies = 0)
+  for (int b = 0; b < G.n_slopes; ++b) {                         // :963-980 (oldSlopeScale = 1)
+    const double Nind = G.sl_Nind[b];
+    const double deno = (Nind * sl_S2f[b] - sl_Sf[b] * sl_Sf[b]);
+    double slope = 0.0;
+    if (deno != 0.0) slope = (Nind * sl_A[b] - sl_Sf[b] * sl_B[b]) / deno;
+    o[n++] = (float)(slope * (Nind - 1.0));
+  }
   const double sumB = frameSum;
   float ctr = 0.0f;
-  const bool need_ctr = G.centroid || G.variance || G.skewness || G.kurtosis || G.slope;
+  const bool need_ctr = G.centroid || G.standard_deviation || G.variance || G.skewness || G.kurtosis || G.slope;
   if (need_ctr && sumB != 0.0) ctr = (float)(sumA / sumB);       // :1256-1311
   // ---- second walk
   float ro[16];
@@ -84,7 +125,7 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
       const double ln = v / dn;
       if (ln > 0.0) ent += ln * log_d(ln) / l2;
     }
-    if (G.variance || G.skewness || G.kurtosis) {                // :1338-1397
+    if (G.standard_deviation || G.variance || G.skewness || G.kurtosis) {   // :1338-1397
       const double t1 = (F0 * (double)j - u);
       double m = t1 * t1 * (double)p;
       m2 += m; m *= t1; m3 += m; m4 += m * t1;
@@ -100,19 +141,40 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
     w0 = w1; w1 = w2; w2 = w3; w3 = w4;
   }
   for (int i = 0; i < G.n_rolloff; ++i) o[n++] = ro[i];
-  if (G.flux) {                                                  // :1124-1254 (first frame of a field: a single 0)
-    if (!have_prev) o[n++] = 0.0f;
+  if (flux_family) {                                             // :1124-1254
+    if (!have_prev) o[n++] = 0.0f;                               // a field's first frame: ONE zero for the whole family (:1136)
     else {
-      const double flux = (nBins > 0) ? fluxA / (double)nBins : 0.0;
-      o[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+      const double nR = (double)(hi - lo + 1);
+      if (G.spec_diff) { const double d = sdiff / nR; o[n++] = (d > 0.0) ? (float)sqrt(d) : 0.0f; }
+      if (G.spec_pos_diff) { const double d = spdiff / nR; o[n++] = (d > 0.0) ? (float)sqrt(d) : 0.0f; }
+      if (G.flux) {
+        const double flux = (nBins > 0) ? fluxA / (double)nBins : 0.0;
+        o[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+      }
+      if (G.flux_centroid || G.flux_at_flux_centroid) {
+        const double fluxCentr = (fluxA > 0.0) ? fluxAf / fluxA : 0.0;
+        if (G.flux_centroid) o[n++] = (float)fluxCentr;
+        if (G.flux_at_flux_centroid) {                           // :1209-1247: the flux of the five bins around the centroid's bin
+          int bin = hi;
+          for (int j = lo; j <= hi; ++j) if (F0 * (double)j >= fluxCentr) { bin = j; break; }
+          int start = bin - 2, end = bin + 2;
+          if (start < lo) start = lo;
+          if (end > hi) end = hi;
+          double myF = 0.0;
+          for (int j = start; j <= end; ++j) { const double d = ((double)src[j] / 1.0 - (double)prev[j] / 1.0); myF += d * d; }
+          if (end - start + 1 > 0) myF /= (double)(end - start + 1); else myF = 0.0;
+          o[n++] = (float)myF;
+        }
+      }
     }
   }
   if (G.centroid) o[n++] = ctr;
   if (G.max_pos) o[n++] = (float)(F0 * (double)maP);
   if (G.min_pos) o[n++] = (float)(F0 * (double)miP);
   if (G.entropy) o[n++] = (float)(-ent);
-  if (G.variance || G.skewness || G.kurtosis) {
+  if (G.standard_deviation || G.variance || G.skewness || G.kurtosis) {
     const double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+    if (G.standard_deviation) o[n++] = (sigma2 > 0.0) ? (float)sqrt(sigma2) : 0.0f;
     if (G.variance) o[n++] = (float)sigma2;
     if (G.skewness) o[n++] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
     if (G.kurtosis) o[n++] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
@@ -143,6 +205,8 @@ __global__ void __launch_bounds__(64) lld_spectral_general(SpectralGeneral G, co
     }
     o[n++] = G.log_flatness ? ((sf > 0.0f) ? glibc_logf(sf) : 0.0f) : sf;
   }
+  while (n < G.n_out) o[n++] = 0.0f;                             // (a field's first frame with more than one of the flux family on: the
+                                                                 // reference's vector keeps its calloc'd zeros in the last slots)
 }
 
 // the last frame's magnitudes become the stream's state (the next launch's flux)
@@ -156,7 +220,7 @@ hipError_t stage_spectral_general(const SpectralGeneral &G, const float *mag, in
   if (n_frames <= 0) return hipSuccess;
   hipLaunchKernelGGL(lld_spectral_general, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, G, mag, ld_src, state, first, dst, ld_dst,
                      n_frames);
-  if (G.flux && state)
+  if ((G.flux || G.spec_diff || G.spec_pos_diff || G.flux_centroid || G.flux_at_flux_centroid) && state)
     hipLaunchKernelGGL(lld_spectral_keep, dim3((unsigned)((G.K + 255) / 256)), dim3(256), 0, s, mag + (n_frames - 1) * ld_src, state, G.K);
   return hipGetLastError();
 }

@@ -71,6 +71,10 @@ struct SpectralGeneral {
   int32_t flux, centroid, max_pos, min_pos, entropy, variance, skewness, kurtosis, slope, sharpness, harmonicity, flatness, log_flatness;
   double slope_Sf, slope_S2f;                           // sums of frq and frq^2 over bins 1 .. K-1 (:1405-1412)
   const double *sharp_w;                                // [K - 1] sharpness weights of bins 1 .. K-1 (:1440-1455)
+  // round 6: the rest of the linear-spectrum branch
+  int32_t spec_diff, spec_pos_diff, flux_centroid, flux_at_flux_centroid, standard_deviation, n_out;
+  int32_t n_slopes, sl_iL[16], sl_iR[16];               // slopes[]: edge bins, their weights, idxR - idxL (:872-943)
+  double sl_wL[16], sl_wR[16], sl_Nind[16];
 };
 hipError_t stage_spectral_general(const SpectralGeneral &G, const float *mag, int64_t ld_src, float *state, int first, float *dst,
                                   int64_t ld_dst, int64_t n_frames, hipStream_t s);

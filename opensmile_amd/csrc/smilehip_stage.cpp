@@ -57,10 +57,11 @@ extern "C" int smilehip_spectral_op_destroy(smilehip_spectral_op *op) {
 }
 extern "C" int smilehip_spectral_op_n_out(const smilehip_spectral_op *op) { return op ? op->n_out : -1; }
 extern "C" int smilehip_spectral_opts_count(const smilehip_spectral_opts *o) {
-  if (!o || o->n_bands < 0 || o->n_bands > 16 || o->n_rolloff < 0 || o->n_rolloff > 16) return -1;
-  return o->n_bands + o->n_rolloff + (o->flux != 0) + (o->centroid != 0) + (o->max_pos != 0) + (o->min_pos != 0) + (o->entropy != 0) +
-         (o->variance != 0) + (o->skewness != 0) + (o->kurtosis != 0) + (o->slope != 0) + (o->sharpness != 0) + (o->harmonicity != 0) +
-         (o->flatness != 0);
+  if (!o || o->n_bands < 0 || o->n_bands > 16 || o->n_rolloff < 0 || o->n_rolloff > 16 || o->n_slopes < 0 || o->n_slopes > 16) return -1;
+  return o->n_bands + o->n_slopes + o->n_rolloff + (o->spec_diff != 0) + (o->spec_pos_diff != 0) + (o->flux != 0) + (o->flux_centroid != 0) +
+         (o->flux_at_flux_centroid != 0) + (o->centroid != 0) + (o->max_pos != 0) + (o->min_pos != 0) + (o->entropy != 0) +
+         (o->standard_deviation != 0) + (o->variance != 0) + (o->skewness != 0) + (o->kurtosis != 0) + (o->slope != 0) +
+         (o->sharpness != 0) + (o->harmonicity != 0) + (o->flatness != 0);
 }
 extern "C" int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip_spectral_opts *o, int64_t K, double frame_size_sec,
                                            smilehip_spectral_op **out) {
@@ -85,10 +86,15 @@ extern "C" int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip
   G.entropy = o->entropy != 0; G.variance = o->variance != 0; G.skewness = o->skewness != 0; G.kurtosis = o->kurtosis != 0;
   G.slope = o->slope != 0; G.sharpness = o->sharpness != 0; G.harmonicity = o->harmonicity != 0;
   G.flatness = o->flatness != 0; G.log_flatness = o->log_flatness != 0;
+  G.spec_diff = o->spec_diff != 0; G.spec_pos_diff = o->spec_pos_diff != 0; G.flux_centroid = o->flux_centroid != 0;
+  G.flux_at_flux_centroid = o->flux_at_flux_centroid != 0; G.standard_deviation = o->standard_deviation != 0;
+  G.n_out = n_out; G.n_slopes = o->n_slopes;
   const int Nsrc = (int)K;
   const double F0 = 1.0 / frame_size_sec;                // frq[i] = F0 * i, transformFft.cpp:102-117
-  for (int b = 0; b < o->n_bands; ++b) {                  // the band's edge bins and weights, spectral.cpp:779-826
-    const int lo = o->band_lo[b], hi = o->band_hi[b];
+  for (int b = 0; b < o->n_bands + o->n_slopes; ++b) {    // a band's (spectral.cpp:779-826) or a slope band's (:872-943: the same mapping) edge bins and weights
+    const bool is_slope = b >= o->n_bands;
+    const int lo = is_slope ? o->slope_lo[b - o->n_bands] : o->band_lo[b], hi = is_slope ? o->slope_hi[b - o->n_bands] : o->band_hi[b];
+    if (is_slope && (lo < 0 || hi <= lo)) { delete op; return fail(SMILEHIP_ERR_INVALID, "cSpectral slopes[%d] = %d-%d", b - o->n_bands, lo, hi); }
     int ii;
     double wghtL, wghtR, idxL, idxR;
     for (ii = 0; ii < Nsrc; ii++) if (F0 * ii > (double)lo) break;
@@ -107,8 +113,13 @@ extern "C" int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip
     if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
     if (iL < 0) iL = 0;
     if (iR < 0) iR = 0;
-    if (iR < iL) { delete op; return fail(SMILEHIP_ERR_INVALID, "cSpectral bands[%d] = %d-%d lies between two bins of this spectrum", b, lo, hi); }
-    G.band_iL[b] = iL; G.band_iR[b] = iR; G.band_wL[b] = wghtL; G.band_wR[b] = wghtR;
+    if (iR < iL) { delete op; return fail(SMILEHIP_ERR_INVALID, "cSpectral %s[%d] = %d-%d lies between two bins of this spectrum", is_slope ? "slopes" : "bands", is_slope ? b - o->n_bands : b, lo, hi); }
+    if (is_slope) {
+      const int k = b - o->n_bands;
+      G.sl_iL[k] = iL; G.sl_iR[k] = iR; G.sl_wL[k] = wghtL; G.sl_wR[k] = wghtR; G.sl_Nind[k] = idxR - idxL;
+    } else {
+      G.band_iL[b] = iL; G.band_iR[b] = iR; G.band_wL[b] = wghtL; G.band_wR[b] = wghtR;
+    }
   }
   for (int64_t i = 1; i < K; ++i) { G.slope_S2f += (F0 * i) * (F0 * i); G.slope_Sf += F0 * i; }
   std::vector<double> sw((size_t)(K - 1));                // sharpness weights bark(f) g(bark(f)), spectral.cpp:1440-1455, smileUtil.c:1063-1078, 1123-1137
@@ -132,7 +143,8 @@ extern "C" int smilehip_spectral_op_create(smilehip_context *ctx, const smilehip
 extern "C" int smilehip_spectral_op_frames(smilehip_spectral_op *op, const float *d_mag, int64_t ld_src, float *d_state, int first,
                                            float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
   if (!op) return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_frames: null operator");
-  if (n_frames < 0 || ld_src < op->G.K || ld_dst < op->n_out || (n_frames > 0 && (!d_mag || !d_dst)) || (op->G.flux && !d_state))
+  if (n_frames < 0 || ld_src < op->G.K || ld_dst < op->n_out || (n_frames > 0 && (!d_mag || !d_dst)) ||
+      ((op->G.flux || op->G.spec_diff || op->G.spec_pos_diff || op->G.flux_centroid || op->G.flux_at_flux_centroid) && !d_state))
     return fail(SMILEHIP_ERR_INVALID, "smilehip_spectral_op_frames: bad argument (K %d, %d outputs; d_state is needed when flux is on)", op->G.K, op->n_out);
   STAGE_RET(stage_spectral_general(op->G, d_mag, ld_src, d_state, first, d_dst, ld_dst, n_frames, (hipStream_t)stream), "spectral (general)");
 }

@@ -90,11 +90,21 @@ class cHipSpectral : public BlockVP<cSpectral> {
     }
     const bool compare_set = plain_ && (Nsrc == 129 || Nsrc == 257 || Nsrc == 513) && Ndst == 12 + (int)sel_[0] + (int)sel_[1] + (int)sel_[2];
     if (!compare_set && general_ < 0) {
-      // everything the linear-spectrum branch of spectral.cpp:586-1560 offers except the slopes[] / alphaRatio / hammarbergIndex /
-      // specDiff / fluxCentroid / standardDeviation / tonality / flatness outputs
+      // everything the linear-spectrum branch of spectral.cpp:586-1560 offers except the alphaRatio / hammarbergIndex / tonality outputs
+      // (round 6: + slopes[], specDiff, specPosDiff, fluxCentroid, fluxAtFluxCentroid, standardDeviation)
       std::memset(&gen_opts_, 0, sizeof(gen_opts_));
       const int nb = getArraySize("bands") > 0 ? getArraySize("bands") : 0, nr = getArraySize("rollOff") > 0 ? getArraySize("rollOff") : 0;
-      bool ok = nb <= 16 && nr <= 16 && getArraySize("slopes") <= 0;
+      const int nsl = getArraySize("slopes") > 0 ? getArraySize("slopes") : 0;
+      bool ok = nb <= 16 && nr <= 16 && nsl <= 16;
+      for (int b = 0; ok && b < nsl; ++b) {              // slopes[b] = "lo-hi" in Hz, integers (spectral.cpp:327-338)
+        const char *v = getStr_f(myvprint("slopes[%i]", b));
+        int lo = -1, hi = -1, used = 0;
+        ok = v && sscanf(v, "%d-%d%n", &lo, &hi, &used) == 2 && v[used] == 0 && lo >= 0 && hi > lo;
+        gen_opts_.slope_lo[b] = lo; gen_opts_.slope_hi[b] = hi;
+      }
+      gen_opts_.n_slopes = nsl;
+      gen_opts_.spec_diff = getInt("specDiff"); gen_opts_.spec_pos_diff = getInt("specPosDiff"); gen_opts_.flux_centroid = getInt("fluxCentroid");
+      gen_opts_.flux_at_flux_centroid = getInt("fluxAtFluxCentroid"); gen_opts_.standard_deviation = getInt("standardDeviation");
       for (int b = 0; ok && b < nb; ++b) {               // bands[b] = "lo-hi" in Hz, integers (spectral.cpp:163-190)
         const char *v = getStr_f(myvprint("bands[%i]", b));
         int lo = -1, hi = -1, used = 0;
@@ -107,10 +117,9 @@ class cHipSpectral : public BlockVP<cSpectral> {
       gen_opts_.entropy = getInt("entropy"); gen_opts_.variance = getInt("variance"); gen_opts_.skewness = getInt("skewness");
       gen_opts_.kurtosis = getInt("kurtosis"); gen_opts_.slope = getInt("slope"); gen_opts_.sharpness = getInt("sharpness");
       gen_opts_.harmonicity = getInt("harmonicity"); gen_opts_.flatness = getInt("flatness"); gen_opts_.log_flatness = getInt("logFlatness");
-      static const char *const off[] = {"normBandEnergies", "specDiff", "specPosDiff", "fluxCentroid", "fluxAtFluxCentroid", "standardDeviation",
-                                        "alphaRatio", "hammarbergIndex", "tonality", "buggyRollOff", "useLogSpectrum"};
+      static const char *const off[] = {"normBandEnergies", "alphaRatio", "hammarbergIndex", "tonality", "buggyRollOff", "useLogSpectrum"};
       for (const char *o : off) ok = ok && getInt(o) == 0;
-      ok = ok && getInt("squareInput") != 0 && (!gen_opts_.slope || getInt("oldSlopeScale") != 0);
+      ok = ok && getInt("squareInput") != 0 && ((!gen_opts_.slope && !nsl) || getInt("oldSlopeScale") != 0);
       const char *fr = getStr("freqRange");
       ok = ok && fr && !strcmp(fr, "0-0");
       gen_n_out_ = ok ? smilehip_spectral_opts_count(&gen_opts_) : 0;
@@ -128,8 +137,8 @@ class cHipSpectral : public BlockVP<cSpectral> {
       return (int)Ndst;
     }
     if (!compare_set || fc < 0 || fc >= 8) {
-      HIP_FALLTHROUGH(12, "cSpectral: the linear-spectrum descriptor sets (bands, rollOff points, flux, centroid, maxPos, minPos, entropy, variance, skewness, kurtosis, slope, "
-                          "sharpness, harmonicity, flatness; freqRange 0-0) and the two GeMAPS sets (log-spectrum slopes + alphaRatio + hammarbergIndex; flux over 0-5000 Hz) are built");
+      HIP_FALLTHROUGH(12, "cSpectral: the linear-spectrum descriptor sets (bands, slopes, rollOff points, specDiff, specPosDiff, flux, fluxCentroid, fluxAtFluxCentroid, centroid, "
+                          "maxPos, minPos, entropy, standardDeviation, variance, skewness, kurtosis, slope, sharpness, harmonicity, flatness; freqRange 0-0) and the two GeMAPS sets (log-spectrum slopes + alphaRatio + hammarbergIndex; flux over 0-5000 Hz) are built");
       return cSpectral::processVector(src, dst, Nsrc, Ndst, idxi);
     }
     smilehip_plan *&pl = plans_.at(fc);

@@ -104,6 +104,57 @@ static double band_energy(const float *srcP, const double *frq, long Nsrc, long 
   return sum / (double)nBins;                                              /* :853 (normBandEnergies=0, lin spectrum) */
 }
 
+/* outputs per frame of an option set, in the order cSpectral::processVector writes them (spectral.cpp:770-1545) */
+int lldo_spectral_count(const lldo_spectral_opts *o)
+{
+  return o->n_bands + o->n_slopes + o->n_rolloff + (o->spec_diff != 0) + (o->spec_pos_diff != 0) + (o->flux != 0) + (o->flux_centroid != 0) +
+         (o->flux_at_flux_centroid != 0) + (o->centroid != 0) + (o->max_pos != 0) + (o->min_pos != 0) + (o->entropy != 0) +
+         (o->standard_deviation != 0) + (o->variance != 0) + (o->skewness != 0) + (o->kurtosis != 0) + (o->slope != 0) +
+         (o->sharpness != 0) + (o->harmonicity != 0) + (o->flatness != 0);
+}
+
+/* slopes[i] = lo-hi: the slope of the (linear power) spectrum over the band, spectral.cpp:872-985, frequency axis given
+ * (nScale >= Nsrc), oldSlopeScale = 1 */
+static float band_slope(const float *srcLP, const double *frq, long Nsrc, long lo, long hi)
+{
+  long ii;
+  double wghtL, wghtR, idxL, idxR;
+  for (ii = 0; ii < Nsrc; ii++) if (frq[ii] > (double)lo) break;                             /* :886-896 */
+  if ((ii < Nsrc) && (ii > 0)) wghtL = (frq[ii] - (double)lo) / (frq[ii] - frq[ii - 1]); else wghtL = 1.0;
+  idxL = (double)ii - 1.0;
+  if (idxL < 0) idxL = 0;
+  if (idxL >= Nsrc) idxL = Nsrc;
+  if (wghtL == 0.0) wghtL = 1.0;
+  for (ii = 0; ii < Nsrc; ii++) if (frq[ii] >= (float)hi) break;                             /* :912-926 */
+  if ((ii < Nsrc) && (ii > 0)) wghtR = ((double)hi - frq[ii - 1]) / (frq[ii] - frq[ii - 1]); else wghtR = 1.0;
+  if ((ii < Nsrc) && (frq[ii] == (float)hi)) idxR = (double)ii; else idxR = (double)ii - 1.0;
+  if (idxR >= Nsrc) idxR = Nsrc - 1;
+  if (wghtR == 0.0) wghtR = 1.0;
+  long iL = (long)floor(idxL), iR = (long)floor(idxR);
+  if (iL >= Nsrc) { iL = iR = Nsrc - 1; wghtR = 0.0; wghtL = 0.0; }
+  if (iR >= Nsrc) { iR = Nsrc - 1; wghtR = 1.0; }
+  if (iL < 0) iL = 0;
+  if (iR < 0) iR = 0;
+  double Sf, S2f, sumA, sumB, Nind = idxR - idxL;                                           /* :944-962 */
+  Sf = (double)frq[iL] * wghtL;
+  S2f = Sf * Sf;
+  sumA = (double)frq[iL] * wghtL * (double)srcLP[iL];
+  sumB = wghtL * srcLP[iL];
+  for (ii = iL + 1; ii < iR && ii < Nsrc; ii++) {
+    S2f += (double)frq[ii] * (double)frq[ii];
+    Sf += (double)frq[ii];
+    sumA += (double)frq[ii] * (double)srcLP[ii];
+    sumB += (double)srcLP[ii];
+  }
+  S2f += (double)frq[iR] * wghtR * (double)frq[iR] * wghtR;
+  Sf += (double)frq[iR] * wghtR;
+  sumA += (double)frq[iR] * wghtR * (double)srcLP[iR];
+  sumB += wghtR * (double)srcLP[iR];
+  double deno = (Nind * S2f - Sf * Sf), slope = 0.0;
+  if (deno != 0.0) slope = (Nind * sumA - Sf * sumB) / deno;
+  return (float)(slope * (Nind - 1.0));                                                     /* oldSlopeScale = 1 (:979) */
+}
+
 /* cSpectral::processVector (spectral.cpp:586-1560) for the descriptor sets of the shipped configurations: any number of bands[]
  * (<= 16), four rollOff points, and flux, centroid, maxPos, minPos, entropy, variance, skewness, kurtosis, slope, sharpness,
  * harmonicity, flatness (logFlatness) each optional, in the reference's output order; defaults squareInput=1, normBandEnergies=0, useLogSpectrum=0,
@@ -121,6 +172,7 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
   double frameSum = 0.0;
   for (i = lo; i <= hi; i++) frameSum += srcP[i];                          /* :762-767 */
   for (int b = 0; b < o->n_bands; b++) dst[n++] = (float)band_energy(srcP, frq, Nsrc, o->band_lo[b], o->band_hi[b], nBins);
+  for (int b = 0; b < o->n_slopes; b++) dst[n++] = band_slope(srcLP, frq, Nsrc, o->slope_lo[b], o->slope_hi[b]);
   double sumB = 0.0, sumC = 0.0;
   for (j = lo; j <= hi; j++) sumB += (double)srcLP[j];                     /* :1093-1097 */
   float ro[16];
@@ -131,25 +183,62 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
       if ((ro[i] == 0.0) && (sumC >= o->rolloff[i] * frameSum)) ro[i] = (float)frq[j];
   }
   for (i = 0; i < o->n_rolloff; i++) dst[n++] = ro[i];
-  if (o->flux) {                                                           /* :1124-1254 (first frame of a field: a single 0) */
+  if (o->spec_pos_diff || o->spec_diff || o->flux || o->flux_centroid || o->flux_at_flux_centroid) {   /* :1124-1254 */
     if (!s->have_prev) {
-      dst[n++] = 0.0f;
+      dst[n++] = 0.0f;                               /* first frame of a field: ONE zero, however many of the five are on (:1136) */
       s->have_prev = 1;
     } else {
-      double myA = 0.0;
-      for (j = lo; j <= hi; j++) {
-        double myB = ((double)srcM[j] / 1.0 - (double)s->prev[j - lo] / 1.0);
-        myA += myB * myB;
+      const float *magP = s->prev;
+      double myA = 0.0, myAf = 0.0, d = 0.0, dp = 0.0;
+      if (o->spec_diff) {
+        for (j = lo; j <= hi; j++) { double myd = (srcM[j] - magP[j - lo]); d += myd * myd; }
+        d /= (double)(hi - lo + 1);
+        dst[n++] = (d > 0.0) ? (float)sqrt(d) : 0.0f;
       }
-      double flux = (nBins > 0) ? myA / (double)nBins : 0.0;
-      dst[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+      if (o->spec_pos_diff) {
+        for (j = lo; j <= hi; j++) { double myd = (srcM[j] - magP[j - lo]); if (myd > 0.0) dp += myd * myd; }
+        dp /= (double)(hi - lo + 1);
+        dst[n++] = (dp > 0.0) ? (float)sqrt(dp) : 0.0f;
+      }
+      if (o->flux || o->flux_centroid)
+        for (j = lo; j <= hi; j++) {
+          double myB = ((double)srcM[j] / 1.0 - (double)magP[j - lo] / 1.0);
+          myA += myB * myB;
+        }
+      if (o->flux_centroid)                          /* (nScale > specRangeUpperBin, frq given: :1178-1182) */
+        for (j = lo; j <= hi; j++) {
+          double myB = ((double)srcM[j] / 1.0 - (double)magP[j - lo] / 1.0);
+          myAf += myB * myB * frq[j];
+        }
+      if (o->flux) {
+        double flux = (nBins > 0) ? myA / (double)nBins : 0.0;
+        dst[n++] = (flux > 0.0) ? (float)sqrt(flux) : 0.0f;
+      }
+      if (o->flux_centroid || o->flux_at_flux_centroid) {
+        double fluxCentr = (myA > 0.0) ? myAf / myA : 0.0;
+        if (o->flux_centroid) dst[n++] = (float)fluxCentr;
+        if (o->flux_at_flux_centroid) {              /* :1209-1247 */
+          long bin = hi;
+          for (j = lo; j <= hi; j++) if (frq[j] >= fluxCentr) { bin = j; break; }
+          long start = bin - 2, end = bin + 2;
+          if (start < lo) start = lo;
+          if (end > hi) end = hi;
+          double myF = 0.0;
+          for (j = start; j <= end; j++) {
+            double myB = ((double)srcM[j] / 1.0 - (double)magP[j - lo] / 1.0);
+            myF += myB * myB;
+          }
+          if (end - start + 1 > 0) myF /= (double)(end - start + 1); else myF = 0.0;
+          dst[n++] = (float)myF;
+        }
+      }
     }
     for (j = lo; j <= hi; j++) s->prev[j - lo] = srcM[j];
   }
   /* centroid, :1256-1311: computed whenever a moment or the slope needs it */
   float ctr = 0.0f;
   double sumA = 0.0;
-  if (o->centroid || o->variance || o->skewness || o->kurtosis || o->slope) {
+  if (o->centroid || o->standard_deviation || o->variance || o->skewness || o->kurtosis || o->slope) {
     for (j = lo; j <= hi; j++) sumA += (double)frq[j] * (double)srcLP[j];
     if (sumB != 0.0) ctr = (float)(sumA / sumB);
     if (o->centroid) dst[n++] = ctr;
@@ -165,7 +254,7 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
     if (o->min_pos) dst[n++] = (float)frq[miP];
   }
   if (o->entropy) dst[n++] = stat_entropy(srcLP + lo, hi - lo + 1);        /* :1332-1336 */
-  if (o->variance || o->skewness || o->kurtosis) {                         /* moments, :1338-1397 */
+  if (o->standard_deviation || o->variance || o->skewness || o->kurtosis) { /* moments, :1338-1397 */
     double u = ctr, m2 = 0.0, m3 = 0.0, m4 = 0.0;
     for (i = lo; i <= hi; i++) {
       double t1 = ((double)frq[i] - u);
@@ -173,6 +262,7 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
       m2 += m; m *= t1; m3 += m; m4 += m * t1;
     }
     double sigma2 = (sumB != 0.0) ? m2 / sumB : 0.0;
+    if (o->standard_deviation) dst[n++] = (sigma2 > 0.0) ? (float)(sqrt(sigma2)) : 0.0f;
     if (o->variance) dst[n++] = (float)sigma2;
     if (o->skewness) dst[n++] = (sigma2 <= 0.0) ? 0.0f : (float)(m3 / (sumB * sigma2 * sqrt(sigma2)));
     if (o->kurtosis) dst[n++] = (sigma2 == 0.0) ? 0.0f : (float)(m4 / (sumB * sigma2 * sigma2));
@@ -224,6 +314,10 @@ int lldo_spectral_general(lldo_spectral *s, const lldo_spectral_opts *o, const f
     else dst[n++] = sf;
   }
   free(srcP);
+  /* a field's first frame writes one value for the whole flux family: the values behind it move up and the vector's last slots keep
+   * what cVector's calloc put there (dataMemoryLevel.cpp:386-398) */
+  const long total = lldo_spectral_count(o);
+  while (n < total) dst[n++] = 0.0f;
   return (int)n;
 }
 

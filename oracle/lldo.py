@@ -1110,10 +1110,12 @@ class SpectralOpts(C.Structure):
     _fields_ = [("n_bands", C.c_int), ("band_lo", C.c_long * 16), ("band_hi", C.c_long * 16), ("n_rolloff", C.c_int),
                 ("rolloff", C.c_double * 16)] + [(k, C.c_int) for k in ("flux", "centroid", "max_pos", "min_pos", "entropy", "variance",
                                                                         "skewness", "kurtosis", "slope", "sharpness", "harmonicity", "flatness",
-                                                                        "log_flatness")]
+                                                                        "log_flatness", "spec_diff", "spec_pos_diff", "flux_centroid",
+                                                                        "flux_at_flux_centroid", "standard_deviation", "n_slopes")] + [
+                   ("slope_lo", C.c_long * 16), ("slope_hi", C.c_long * 16)]
 
 
-def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 0.9), **flags):
+def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 0.9), slopes=(), **flags):
     """cSpectral over the frames of one stream for any of the shipped descriptor sets: n x K magnitudes -> n x count."""
     L = lib()
     mag = np.ascontiguousarray(mag, dtype=np.float32)
@@ -1124,6 +1126,9 @@ def spectral_general_rows(mag, frame_size_sec, bands, rolloff=(0.25, 0.5, 0.75, 
     o.n_rolloff = len(rolloff)
     for i, r in enumerate(rolloff):
         o.rolloff[i] = r
+    o.n_slopes = len(slopes)
+    for i, (a, b) in enumerate(slopes):
+        o.slope_lo[i], o.slope_hi[i] = a, b
     for k, v in flags.items():
         setattr(o, k, int(v))
     s = _Spectral()

@@ -872,3 +872,39 @@ def test_plugin_delta_variants(oracle):
         g, r = np.ascontiguousarray(y[:, 2 * i:2 * i + 2]), np.ascontiguousarray(ref[:, 2 * i:2 * i + 2])
         d = g.view(np.uint32) != r.view(np.uint32)
         assert not d.any(), f"{name}: {d.sum()} of {d.size} values differ, first at {np.argwhere(d)[0]}: {g[d][:3]} vs {r[d][:3]}"
+
+
+@pytest.mark.parametrize("case", ["all", "noflux", "posdiff_only"])
+def test_plugin_spectral_round6_options(oracle, case, tmp_path):
+    """cSpectral option sets no shipped file uses (specDiff, specPosDiff, fluxCentroid, fluxAtFluxCentroid, standardDeviation, slopes[];
+    round 6): a second cSpectral instance behind avec2011's magnitude level -- the plugin's output level equals the plain binary's
+    byte for byte (incl. the reference's single zero for the whole flux family on the first frame), every frame through the override."""
+    from test_oracle_pin_spectral_sets import EXTRA, spectral_section
+    from opensmile_amd import synth
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    bands, slopes, flags = EXTRA[case]
+    td = str(tmp_path)
+    wav = os.path.join(td, "in.wav")
+    oracle.write_wav(wav, synth.utterance(9, 32000), 16000)
+    outs = {}
+    for mode in ("plain", "plugin"):
+        c = os.path.join(td, f"{mode}.conf")
+        open(c, "w").write("\\{%s}\n[componentInstances:cComponentManager]\ninstance[spec2].type=cSpectral\ninstance[tap_out].type=cHtkSink\n"
+                           "%s[tap_out:cHtkSink]\nreader.dmLevel=spectral2\nfilename=%s/tap_%s.htk\n"
+                           % (os.path.join(oracle.REF_DIR, "config", "avec11-14/avec2011.conf"),
+                              spectral_section("spec2", "fftmagH25", "spectral2", bands, slopes, flags), td, mode))
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        trace = os.path.join(td, "trace.txt")
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        r = subprocess.run([exe, "-C", c, "-I", wav, "-O", os.path.join(td, "o.bin"), "-l", "1"], cwd=PLUGDIR if mode == "plugin" else td, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stderr + r.stdout)[-1500:]
+        outs[mode] = open(os.path.join(td, f"tap_{mode}.htk"), "rb").read()
+        if mode == "plugin":
+            tr = dict(l.split() for l in open(trace) if len(l.split()) == 2)
+            assert int(tr["cSpectral"]) > 0 and int(tr.get("cSpectral.cpu", 0)) == 0
+    assert len(outs["plain"]) > 1000 and outs["plain"] == outs["plugin"]

@@ -22,7 +22,14 @@ SETS = {
     "no_band_slope": ([], dict(slope=1)),
     "sixteen": ([(100 * i, 100 * i + 450) for i in range(16)], dict(kurtosis=1)),
     "flux_only": ([], dict(flux=1)),
+    # round 6: the options no shipped file uses (pinned on the real binary by tests/test_oracle_pin_spectral_sets.py::test_spectral_round6_options_bit_exact)
+    "r6_all": ([(250, 650), (1000, 4000)], dict(spec_diff=1, spec_pos_diff=1, flux=1, flux_centroid=1, flux_at_flux_centroid=1, centroid=1,
+                                               standard_deviation=1, variance=1, skewness=1)),
+    "r6_noflux": ([(0, 250)], dict(spec_diff=1, flux_centroid=1, standard_deviation=1)),
+    "r6_posdiff": ([], dict(spec_pos_diff=1, flux_at_flux_centroid=1, kurtosis=1, entropy=1)),
+    "r6_slopes": ([], dict(slope=1)),
 }
+SLOPES = {"r6_all": [(0, 500), (500, 1500), (1500, 8000)], "r6_noflux": [(300, 3400)], "r6_slopes": [(0, 8000), (100, 101), (7000, 7999)]}
 
 
 def _spectra(K, n, seed):
@@ -43,17 +50,18 @@ def test_spectral_general_equals_oracle(name, K, oracle):
     import torch
     from opensmile_amd import capi
     bands, flags = SETS[name]
+    slopes = SLOPES.get(name, [])
     rolloff = (0.25, 0.5, 0.75, 0.9) if name != "flux_only" else ()
     ctx = capi.Context(0)
     L = capi.load()
-    o = capi.spectral_opts(bands, rolloff, **flags)
+    o = capi.spectral_opts(bands, rolloff, slopes, **flags)
     fs = (K - 1) * 2 / 16000.0
     op = C.c_void_p()
     capi._check(L.smilehip_spectral_op_create(ctx._h, C.byref(o), K, fs, C.byref(op)))
     n_out = L.smilehip_spectral_op_n_out(op)
-    assert n_out == L.smilehip_spectral_opts_count(C.byref(o)) == len(bands) + len(rolloff) + sum(v for k, v in flags.items() if k != "log_flatness")
+    assert n_out == L.smilehip_spectral_opts_count(C.byref(o)) == len(bands) + len(slopes) + len(rolloff) + sum(v for k, v in flags.items() if k != "log_flatness")
     mag = _spectra(K, 24, 11 if K == 257 else 12)
-    ref = oracle.spectral_general_rows(mag, fs, bands, rolloff, **flags)
+    ref = oracle.spectral_general_rows(mag, fs, bands, rolloff, slopes=slopes, **flags)
     assert ref.shape == (24, n_out)
     d_mag = torch.from_numpy(mag).cuda()
     d_state = torch.zeros(K, dtype=torch.float32, device="cuda")

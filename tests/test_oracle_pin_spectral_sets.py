@@ -42,3 +42,54 @@ def test_spectral_descriptor_sets_bit_exact(conf, tmp_path):
         ref = lldo.read_htk(os.path.join(td, "tap_out.htk"))[0]
         got = lldo.spectral_general_rows(mag, (mag.shape[1] - 1) * 2 / 16000.0, bands, **flags)
         assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (conf, u, n)
+
+
+# Round 6: the options of the linear-spectrum branch no shipped file uses (specDiff, specPosDiff, fluxCentroid, fluxAtFluxCentroid,
+# standardDeviation, slopes[]): a second cSpectral instance behind avec2011's magnitude level, its own output level tapped.
+EXTRA = {
+    "all": ([(250, 650), (1000, 4000)], [(0, 500), (500, 1500), (1500, 8000)],
+            dict(spec_diff=1, spec_pos_diff=1, flux=1, flux_centroid=1, flux_at_flux_centroid=1, centroid=1, standard_deviation=1, variance=1,
+                 skewness=1)),
+    "noflux": ([(0, 250)], [(300, 3400)], dict(spec_diff=1, flux_centroid=1, standard_deviation=1)),
+    "posdiff_only": ([], [], dict(spec_pos_diff=1, flux_at_flux_centroid=1, kurtosis=1, entropy=1)),
+}
+CONF_NAMES = {"spec_diff": "specDiff", "spec_pos_diff": "specPosDiff", "flux": "flux", "flux_centroid": "fluxCentroid",
+              "flux_at_flux_centroid": "fluxAtFluxCentroid", "centroid": "centroid", "standard_deviation": "standardDeviation",
+              "variance": "variance", "skewness": "skewness", "kurtosis": "kurtosis", "entropy": "entropy", "max_pos": "maxPos",
+              "min_pos": "minPos", "slope": "slope", "sharpness": "sharpness", "harmonicity": "harmonicity", "flatness": "flatness"}
+
+
+def spectral_section(name, reader, writer, bands, slopes, flags, rolloff=(0.25, 0.5, 0.75, 0.9)):
+    """a cSpectral section with exactly these options on (the component's defaults switch flux, centroid, maxPos, minPos on)"""
+    lines = [f"[{name}:cSpectral]", f"reader.dmLevel={reader}", f"writer.dmLevel={writer}", "copyInputName=1", "processArrayFields=1",
+             "squareInput=1"]
+    lines += [f"bands[{i}]={a}-{b}" for i, (a, b) in enumerate(bands)]
+    lines += [f"slopes[{i}]={a}-{b}" for i, (a, b) in enumerate(slopes)]
+    lines += [f"rollOff[{i}]={r}" for i, r in enumerate(rolloff)]
+    for key, conf in CONF_NAMES.items():
+        lines.append(f"{conf}={int(bool(flags.get(key, 0)))}")
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA))
+def test_spectral_round6_options_bit_exact(case, tmp_path):
+    from opensmile_amd import synth
+    bands, slopes, flags = EXTRA[case]
+    td = str(tmp_path)
+    for u, n in ((9, 32000), (3, 12000)):
+        wav = os.path.join(td, "in.wav")
+        lldo.write_wav(wav, synth.utterance(u, n), 16000)
+        c = os.path.join(td, "t.conf")
+        open(c, "w").write("\\{%s}\n[componentInstances:cComponentManager]\ninstance[spec2].type=cSpectral\ninstance[tap_in].type=cHtkSink\n"
+                           "instance[tap_out].type=cHtkSink\n%s[tap_in:cHtkSink]\nreader.dmLevel=fftmagH25\nfilename=%s/tap_in.htk\n"
+                           "[tap_out:cHtkSink]\nreader.dmLevel=spectral2\nfilename=%s/tap_out.htk\n"
+                           % (os.path.join(lldo.REF_DIR, "config", "avec11-14/avec2011.conf"),
+                              spectral_section("spec2", "fftmagH25", "spectral2", bands, slopes, flags), td, td))
+        subprocess.run([os.path.join(lldo.REF_DIR, "SMILExtract"), "-C", c, "-I", wav, "-O", os.path.join(td, "o.bin"), "-l", "0"], cwd=td,
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        mag = lldo.read_htk(os.path.join(td, "tap_in.htk"))[0]
+        ref = lldo.read_htk(os.path.join(td, "tap_out.htk"))[0]
+        got = lldo.spectral_general_rows(mag, (mag.shape[1] - 1) * 2 / 16000.0, bands, slopes=slopes, **flags)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
+        assert bad.size == 0, (case, u, n, bad[:8].tolist(), got[bad[0][0]].tolist(), ref[bad[0][0]].tolist())
