@@ -794,6 +794,12 @@ int smilehip_plp_audspec_frames(smilehip_context *ctx, const float *d_mel, int64
 int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
                            float melfloor, float compression, int lp_order, const float *d_cos, const float *d_sin,
                            float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R8: cPlp's partial modes in HTK mode (plp.cpp:573-583): the same chain cut short -- out_stage 1: the autocorrelation the IDFT leaves
+ * (doIDFT = 1, doLP = 0: lp_order + 1 values per frame), out_stage 2: the LP coefficients of the Durbin recursion (doLP = 1,
+ * doLpToCeps = 0: lp_order values). d_cos as for smilehip_plp_cc_frames. */
+int smilehip_plp_stage_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                              float melfloor, float compression, int lp_order, const float *d_cos, int out_stage,
+                              float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
 /* R13: cDeltaRegression::processBuffer (kind 0, deltaRegression.cpp:144-152, norm = 2*sum i^2) and
  * cContourSmoother::processBuffer (kind 1, contourSmoother.cpp:106-114, smaWin = 2W+1) on one row of a
  * cWindowProcessor block: d_x points at sample 0 of the row and is valid on [-W, n_t + W). */

@@ -223,7 +223,8 @@ __device__ __forceinline__ float plp_acf_lag(const float *aud, const float *cosr
 }
 // ... then Durbin (smileDsp_calcLpcAcf, smileUtil.c:1572-1630), LP -> cepstra (smileDsp_lpToCeps, :1532-1556) and the
 // lifter, all in the reference's float sequence; p <= 15. out: c1..cp, c0 (HTK order).
-__device__ __forceinline__ void plp_cc_serial(const float *r, int p, const float *sintable, float *out) {
+// lp_only: stop behind the Durbin recursion and hand out the p LP coefficients (cPlp with doLP = 1, doLpToCeps = 0: plp.cpp:573-577)
+__device__ __forceinline__ void plp_cc_serial(const float *r, int p, const float *sintable, float *out, bool lp_only = false) {
   float a[16], ceps[16];
   for (int i = 0; i < 16; ++i) { a[i] = 0.0f; ceps[i] = 0.0f; }
   float gain = 0.0f;
@@ -243,6 +244,10 @@ __device__ __forceinline__ void plp_cc_serial(const float *r, int p, const float
       if (e == 0.0f) { for (int i = m; i < p; i++) a[i] = 0.0f; break; }
     }
     gain = e;
+  }
+  if (lp_only) {
+    for (int i = 0; i < p; i++) out[i] = a[i];
+    return;
   }
   if (gain <= 0) gain = (float)1.0;
   for (int n = 1; n <= p; n++) {

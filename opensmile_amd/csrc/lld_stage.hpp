@@ -81,7 +81,8 @@ hipError_t stage_spectral_general(const SpectralGeneral &G, const float *mag, in
 hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,
                      float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,
-                        int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
+                        int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s,
+                        int out_stage = 3);               // 3: cepstra, 2: LP coefficients, 1: autocorrelation (cPlp's partial modes)
 hipError_t stage_window_op(const float *x, float *y, int64_t nT, int kind, int W, float norm, hipStream_t s);
 hipError_t stage_window_op_block(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t nT, int nC, int op, int W, float norm,
                                  int flags, hipStream_t s);

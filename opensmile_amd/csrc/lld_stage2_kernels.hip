@@ -371,9 +371,10 @@ __global__ void __launch_bounds__(64) k_plp(const float *src, int64_t lds, int n
 
 // R8 cPlp::processVector with doAud = doIDFT = doLP = doLpToCeps = 1, htkcompatible = 1 (PLP cepstra, plp.cpp:499-583):
 // one 64-thread workgroup per frame. LDS: aud[n_bands] | acf[16]
+// out_stage: 3 = cepstra (order + 1 values), 2 = LP coefficients (order), 1 = the autocorrelation (order + 1)
 __global__ void __launch_bounds__(64) k_plp_cc(const float *src, int64_t lds, int nB, const float *eql, float melfloor,
                                                float compression, int order, const float *costab, const float *sintab,
-                                               float *dst, int64_t ldd) {
+                                               float *dst, int64_t ldd, int out_stage) {
   __shared__ float aud[64], acf[16];
   const float *m = src + (int64_t)blockIdx.x * lds;
   const int b = threadIdx.x;
@@ -386,10 +387,15 @@ __global__ void __launch_bounds__(64) k_plp_cc(const float *src, int64_t lds, in
   __syncthreads();
   if (b <= order) acf[b] = plp_acf_lag(aud, costab + b * (nB + 2), nB);
   __syncthreads();
+  if (out_stage == 1) {
+    if (b <= order) dst[(int64_t)blockIdx.x * ldd + b] = acf[b];
+    return;
+  }
   if (b == 0) {
     float o[16];
-    plp_cc_serial(acf, order, sintab, o);
-    for (int r = 0; r <= order; ++r) dst[(int64_t)blockIdx.x * ldd + r] = o[r];
+    plp_cc_serial(acf, order, sintab, o, out_stage == 2);
+    const int n = out_stage == 2 ? order : order + 1;
+    for (int r = 0; r < n; ++r) dst[(int64_t)blockIdx.x * ldd + r] = o[r];
   }
 }
 
@@ -469,10 +475,10 @@ hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eq
   return hipGetLastError();
 }
 hipError_t stage_plp_cc(const float *src, int64_t lds, int n_bands, const float *eql, float melfloor, float compression,
-                        int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
+                        int order, const float *costab, const float *sintab, float *dst, int64_t ldd, int64_t nF, hipStream_t s, int out_stage) {
   if (nF > 0)
     hipLaunchKernelGGL(k_plp_cc, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n_bands, eql, melfloor, compression, order, costab,
-                       sintab, dst, ldd);
+                       sintab, dst, ldd, out_stage);
   return hipGetLastError();
 }
 hipError_t stage_window_op_seq(const float *x, float *y, int64_t nT, int kind, int W, float *d_norm, hipStream_t s) {

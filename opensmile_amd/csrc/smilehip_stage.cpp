@@ -294,6 +294,17 @@ extern "C" int smilehip_plp_cc_frames(smilehip_context *ctx, const float *d_mel,
                          (hipStream_t)stream), "plp_cc");
 }
 
+extern "C" int smilehip_plp_stage_frames(smilehip_context *ctx, const float *d_mel, int64_t ld_src, int n_bands, const float *d_eql,
+                                         float melfloor, float compression, int lp_order, const float *d_cos, int out_stage,
+                                         float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream) {
+  if (!ctx || n_bands < 2 || n_bands > 64 || lp_order < 1 || lp_order > 15 || !d_eql || !d_cos || (out_stage != 1 && out_stage != 2))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_plp_stage_frames: bad argument (2..64 bands, lpOrder 1..15, stage 1 | 2)");
+  int rc = check_frames(d_mel, d_dst, ld_src, ld_dst, n_frames, n_bands, out_stage == 1 ? lp_order + 1 : lp_order, "smilehip_plp_stage_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_plp_cc(d_mel, ld_src, n_bands, d_eql, melfloor, compression, lp_order, d_cos, d_cos /* no lifter here */, d_dst, ld_dst,
+                         n_frames, (hipStream_t)stream, out_stage), "plp_stage");
+}
+
 extern "C" int smilehip_window_op_row(smilehip_context *ctx, const float *d_x, float *d_y, int64_t n_t, int kind, int W,
                                       void *stream) {
   if (!ctx || n_t < 0 || W < 1 || (kind != 0 && kind != 1) || (n_t > 0 && (!d_x || !d_y)))

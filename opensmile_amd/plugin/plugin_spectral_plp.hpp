@@ -188,7 +188,7 @@ class cHipPlp : public BlockVP<cPlp> {
   bool cpu_warned_ = false;
   DevBytes eql_[8], state_[8], cos_[8], sin_[8];
   bool ready_[8] = {false, false, false, false, false, false, false, false};
-  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, lpOrder_ = 0, firstCC_ = 0, htk_ = 0;
+  int plain_ = -1, newRasta_ = 0, oldRasta_ = 0, cc_ = 0, part_ = 0, lpOrder_ = 0, firstCC_ = 0, htk_ = 0;
   FLOAT_DMEM compression_ = 0, melfloor_ = 0;
   float coef_[6] = {0, 0, 0, 0, 0, 0};
   cMatrix *fblock_ = nullptr;
@@ -225,6 +225,11 @@ class cHipPlp : public BlockVP<cPlp> {
       firstCC_ = (int)getInt("firstCC");                   // 1 (config/plp/PLP_E_*): c1 .. c12 -- the same values without the trailing c0
       cc_ = (getInt("htkcompatible") && doIDFT && doLP && doLpToCeps && !rasta && !newRasta_ && (firstCC_ == 0 || firstCC_ == 1) &&
              lpOrder_ >= 1 && lpOrder_ <= 15 && (lastCC < 0 || lastCC == lpOrder_) && (nCeps < 0 || nCeps == lpOrder_ + 1 - firstCC_)) ? 1 : 0;
+      // round 6: the same chain cut short (plp.cpp:573-583) -- the autocorrelation (doIDFT = 1, doLP = 0) or the LP coefficients
+      // (doLP = 1, doLpToCeps = 0) as the component's output
+      part_ = 0;
+      if (getInt("htkcompatible") && doIDFT && !doLpToCeps && !rasta && !newRasta_ && lpOrder_ >= 1 && lpOrder_ <= 15) part_ = doLP ? 2 : 1;
+      if (part_) cc_ = 1;                                 // (the tables and the equal-loudness weights are the cepstral mode's)
       if (cc_) { plain_ = 1; melfloor_ = 1.0; }           // htkcompatible forces melfloor = 1, doAud = 1, no logs (plp.cpp:150-160)
       if (newRasta_ || oldRasta_) {                      // initTables, plp.cpp:361-399 (the same coefficients for both forms)
         const FLOAT_DMEM lo = (FLOAT_DMEM)getDouble("rastaLowerCutoff"), up = (FLOAT_DMEM)getDouble("rastaUpperCutoff");
@@ -240,9 +245,10 @@ class cHipPlp : public BlockVP<cPlp> {
     }
     const int fc = getFconf(idxi);
     const FrameMetaInfo *fmeta = reader_->getFrameMetaInfo();
-    if (!plain_ || (cc_ ? Ndst != lpOrder_ + 1 - firstCC_ : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
+    const long n_cc = part_ == 1 ? lpOrder_ + 1 : (part_ == 2 ? lpOrder_ : lpOrder_ + 1 - firstCC_);
+    if (!plain_ || (cc_ ? Ndst != n_cc : Nsrc != Ndst) || Nsrc > 64 || fc < 0 || fc >= 8 || !fmeta || idxi >= fmeta->N ||
         (long)(fmeta->field[idxi].infoSize / sizeof(double)) != Nsrc)
-      { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (plain, RASTA, newRASTA) and the HTK PLP-CC mode are built (no partial IDFT / LP modes)"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
+      { HIP_FALLTHROUGH(13, "cPlp: only the auditory spectrum (plain, RASTA, newRASTA) and the HTK modes (PLP-CC, or the chain cut behind the IDFT / the LP analysis) are built"); return cPlp::processVector(src, dst, Nsrc, Ndst, idxi); }
     if (!ready_[fc]) {                                   // equal-loudness curve at the band centres, plp.cpp:335-357
       const double *frq = (const double *)(fmeta->field[idxi].info);
       std::vector<float> e((size_t)Nsrc), st((size_t)(6 * Nsrc + 2), 0.0f);
@@ -280,7 +286,10 @@ class cHipPlp : public BlockVP<cPlp> {
     }
     io_.ensure(Nsrc, cc_ ? lpOrder_ + 1 : Ndst);
     io_.up(src, Nsrc);
-    if (cc_)
+    if (part_)
+      check(smilehip_plp_stage_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_, lpOrder_,
+                                      (const float *)cos_[fc].d, part_, io_.d_out, lpOrder_ + 1, g_blk.n, nullptr));
+    else if (cc_)
       check(smilehip_plp_cc_frames(context(), io_.d_in, Nsrc, (int)Nsrc, (const float *)eql_[fc].d, melfloor_, compression_, lpOrder_,
                                    (const float *)cos_[fc].d, (const float *)sin_[fc].d, io_.d_out, lpOrder_ + 1, g_blk.n, nullptr));
     else

@@ -598,8 +598,17 @@ static float lp_to_ceps(const float *lp, int nLp, float lpGain, float *ceps, int
 }
 
 /* band_hz: the band-centre metadata of the mel level; mel: n_bands values; out: lp_order + 1 values */
+/* stage 1: the autocorrelation (doIDFT = 1, doLP = 0: lp_order + 1 values, plp.cpp:579-583); stage 2: the LP coefficients (doLP = 1,
+ * doLpToCeps = 0: lp_order values, :573-577); stage 3: the cepstra (the HTK PLP-CC mode) */
+void lldo_plp_stage(const float *mel, int n_bands, const double *band_hz, int lp_order, float compression, int cep_lifter_i, int stage,
+                    float *out);
 void lldo_plp_cc(const float *mel, int n_bands, const double *band_hz, int lp_order, float compression, int cep_lifter_i,
                  float *out)
+{
+  lldo_plp_stage(mel, n_bands, band_hz, lp_order, compression, cep_lifter_i, 3, out);
+}
+void lldo_plp_stage(const float *mel, int n_bands, const double *band_hz, int lp_order, float compression, int cep_lifter_i, int stage,
+                    float *out)
 {
   const float melfloor = 1.0f;                            /* htkcompatible forces melfloor = 1.0, plp.cpp:150-160 */
   const int nFreq = n_bands + 2, nAuto = lp_order + 1, nCeps = lp_order + 1, firstCC = 0, lastCC = lp_order;
@@ -634,9 +643,11 @@ void lldo_plp_cc(const float *mel, int n_bands, const double *band_hz, int lp_or
     tmp += (double)costable[m + i * nFreq] * (double)src[nFreq - 3];
     acf[i] = (float)(tmp / (2.0 * (nFreq - 1)));
   }
+  if (stage == 1) { for (i = 0; i < nAuto; i++) out[i] = acf[i]; free(src); free(costable); return; }
   float lpGain = 0.0f;
   for (i = 0; i < 32; i++) { lpc[i] = 0.0f; ceps[i] = 0.0f; }
   calc_lpc_acf(acf, lpc, lp_order, &lpGain);
+  if (stage == 2) { for (i = 0; i < lp_order; i++) out[i] = lpc[i]; free(src); free(costable); return; }
   if (lpGain <= 0) lpGain = (float)1.0;
   float zeroth = lp_to_ceps(lpc, lp_order, lpGain, ceps, firstCC, lastCC);
   ceps[nCeps - 1] = zeroth;                               /* htkcompatible && firstCC == 0 */
@@ -676,6 +687,31 @@ long lldo_plp_chain(const int16_t *pcm, long n_samples, float *out)
   }
   lldo_mel_free(&mb);
   free(mfcc); free(mel); free(st); free(tmp);
+  return T;
+}
+
+/* the [plp:cPlp] level of config/plp/PLP_0_D_A.conf with the chain cut after `stage` (doLP = 0 | doLpToCeps = 0 | as shipped):
+ * T x (6 | 5 | 6) */
+long lldo_plp_static_stage(const int16_t *pcm, long n_samples, int stage, float *out)
+{
+  lldo_mfcc_cfg c;
+  lldo_default_mfcc12_cfg(&c);
+  lldo_geom g;
+  lldo_geometry(&c, &g);
+  const long T = lldo_num_frames(n_samples, g.N, g.H);
+  if (!out || T <= 0) return T;
+  const int D = stage == 2 ? 5 : 6;
+  c.n_delta = 0;
+  float *mfcc = (float *)malloc(sizeof(float) * (size_t)T * 13);
+  float *mel = (float *)malloc(sizeof(float) * (size_t)T * 26);
+  lldo_mfcc_chain(&c, pcm, n_samples, mfcc, NULL, NULL, NULL, mel);
+  lldo_mel mb;
+  lldo_mel_init(&mb, g.K, g.frame_size_sec_fft, 26, c.lofreq, c.hifreq, c.use_power, c.mel_htk_compatible);
+  double band_hz[26];
+  for (int m = 1; m <= 26; m++) band_hz[m - 1] = 700.0 * (exp((double)mb.cfs[m] / 1127.0) - 1.0);   /* melspec.cpp:408-412 */
+  for (long t = 0; t < T; t++) lldo_plp_stage(mel + t * 26, 26, band_hz, 5, (float)0.33, 22, stage, out + t * D);
+  lldo_mel_free(&mb);
+  free(mfcc); free(mel);
   return T;
 }
 

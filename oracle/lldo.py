@@ -1100,6 +1100,35 @@ def vecop_reduce_rows(x, op):
     return np.array([L.lldo_vecop_reduce(VOP[op], x[i].ctypes.data, x.shape[1]) for i in range(x.shape[0])], np.float32)
 
 
+def plp_static_stage(pcm, stage):
+    """[plp:cPlp]'s level of config/plp/PLP_0_D_A.conf cut after a stage: 1 = autocorrelation (doLP = 0), 2 = LP coefficients
+    (doLpToCeps = 0), 3 = cepstra (as shipped)"""
+    L = lib()
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    L.lldo_plp_static_stage.restype = C.c_long
+    L.lldo_plp_static_stage.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    T = L.lldo_plp_static_stage(pcm.ctypes.data, len(pcm), stage, None)
+    out = np.zeros((max(T, 0), 5 if stage == 2 else 6), np.float32)
+    if T > 0:
+        L.lldo_plp_static_stage(pcm.ctypes.data, len(pcm), stage, out.ctypes.data)
+    return out
+
+
+def plp_stage_rows(mel, band_hz, lp_order, compression, stage, cep_lifter=22):
+    """cPlp in HTK mode up to a stage (oracle/lld_oracle_compare.c::lldo_plp_stage): 1 = autocorrelation (doLP = 0), 2 = LP coefficients
+    (doLpToCeps = 0), 3 = cepstra. mel: n x n_bands; band_hz: the bands' centre frequencies (the level's meta data)."""
+    L = lib()
+    mel = np.ascontiguousarray(mel, dtype=np.float32)
+    hz = np.ascontiguousarray(band_hz, dtype=np.float64)
+    n_out = {1: lp_order + 1, 2: lp_order, 3: lp_order + 1}[stage]
+    L.lldo_plp_stage.restype = None
+    L.lldo_plp_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros((mel.shape[0], n_out), np.float32)
+    for i in range(mel.shape[0]):
+        L.lldo_plp_stage(mel[i].ctypes.data, mel.shape[1], hz.ctypes.data, lp_order, compression, cep_lifter, stage, out[i].ctypes.data)
+    return out
+
+
 class _Spectral(C.Structure):
     _fields_ = [("K", C.c_long), ("fsSec", C.c_double), ("prev", C.c_void_p), ("have_prev", C.c_int), ("frq", C.c_void_p),
                 ("sharp", C.c_void_p)]

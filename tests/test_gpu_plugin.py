@@ -908,3 +908,38 @@ def test_plugin_spectral_round6_options(oracle, case, tmp_path):
             tr = dict(l.split() for l in open(trace) if len(l.split()) == 2)
             assert int(tr["cSpectral"]) > 0 and int(tr.get("cSpectral.cpu", 0)) == 0
     assert len(outs["plain"]) > 1000 and outs["plain"] == outs["plugin"]
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_plugin_plp_partial_modes(oracle, stage, tmp_path):
+    """cPlp cut behind the IDFT (doLP = 0: the autocorrelation) or behind the LP analysis (doLpToCeps = 0: the LP coefficients) --
+    round 6, smilehip_plp_stage_frames: config/plp/PLP_0_D_A.conf with those options changed; the plugin's [plp] level and its HTK
+    output equal the plain binary's byte for byte, every frame through the override."""
+    from test_oracle_pin_plp import plp_conf_cut
+    from opensmile_amd import synth
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    td = str(tmp_path)
+    wav = os.path.join(td, "in.wav")
+    oracle.write_wav(wav, synth.utterance(5, 48000), 16000)
+    c = plp_conf_cut(oracle, stage, td)
+    outs = {}
+    for mode in ("plain", "plugin"):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        trace = os.path.join(td, "trace.txt")
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        out = os.path.join(td, f"o_{mode}.htk")
+        r = subprocess.run([exe, "-C", c, "-I", wav, "-O", out, "-l", "1"], cwd=PLUGDIR if mode == "plugin" else td, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stderr + r.stdout)[-1500:]
+        outs[mode] = (open(os.path.join(td, "tap_plp.htk"), "rb").read(), open(out, "rb").read())
+        if mode == "plugin":
+            tr = dict(l.split() for l in open(trace) if len(l.split()) == 2)
+            assert int(tr["cPlp"]) > 0 and int(tr.get("cPlp.cpu", 0)) == 0
+    assert len(outs["plain"][0]) > 1000 and outs["plain"] == outs["plugin"]
+    got = oracle.read_htk(os.path.join(td, "tap_plp.htk"))[0]
+    ref = oracle.plp_static_stage(synth.utterance(5, 48000), stage)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
