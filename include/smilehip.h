@@ -708,6 +708,12 @@ int smilehip_melspec_frames(smilehip_plan *plan, const float *d_src, int64_t ld_
 /* R7: cMfcc::processVector (mfcc.cpp:239-273) */
 int smilehip_mfcc_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst,
                          int64_t ld_dst, int64_t n_frames, void *stream);
+/* cMfcc::processVector with inverse = 1 (src/lldcore/mfcc.cpp:184-235): cepstra back to a mel spectrum -- inverse liftering, the
+ * transposed cosine table with c0 halved, sqrt(2 / nBands), exp() when do_log. The plan is one whose n_bands is the component's
+ * nBands option (the bands to CREATE) and whose first_mfcc / last_mfcc / cep_lifter / mfcc_htk_compatible are the instance's; the
+ * input rows hold last - first + 1 coefficients in the forward component's output order. */
+int  smilehip_mfcc_inverse_frames(smilehip_plan *plan, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                  int64_t n_frames, int do_log, void *stream);
 /* R12: the accumulation of cEnergy::processVector (energy.cpp:152-161): d_out[f] = sum_n x[n]*x[n] with the
  * float product added to a double; rms / squared / log variants are one host expression on d. */
 int smilehip_sumsq_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t N, int64_t n_frames,

@@ -241,6 +241,7 @@ SYMBOLS = {
                                              _i64, _vp]),
     "smilehip_plp_cc_frames": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, _i64, _i64,
                                         _vp]),
+    "smilehip_mfcc_inverse_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "smilehip_plp_stage_frames": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_float, C.c_float, C.c_int, _vp, C.c_int, _vp, _i64, _i64,
                                            _vp]),
     "smilehip_window_op_row": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp]),

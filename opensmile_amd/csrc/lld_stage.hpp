@@ -76,6 +76,8 @@ struct SpectralGeneral {
   int32_t n_slopes, sl_iL[16], sl_iR[16];               // slopes[]: edge bins, their weights, idxR - idxL (:872-943)
   double sl_wL[16], sl_wR[16], sl_Nind[16];
 };
+hipError_t stage_mfcc_inverse(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int n_bands, int first, int last, int htk,
+                              int do_log, const float *rows, const float *lifter, hipStream_t s);
 hipError_t stage_spectral_general(const SpectralGeneral &G, const float *mag, int64_t ld_src, float *state, int first, float *dst,
                                   int64_t ld_dst, int64_t n_frames, hipStream_t s);
 hipError_t stage_plp(const float *src, int64_t lds, int n_bands, const float *eql, const PlpConsts &Q, int rasta, float *state,

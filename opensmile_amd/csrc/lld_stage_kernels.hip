@@ -159,6 +159,36 @@ __global__ void __launch_bounds__(64) k_mfcc(const float *src, int64_t lds, floa
     dst[(int64_t)blockIdx.x * ldd + r] = dct_coeff(smem, rows + r * n_bands, n_bands, gain[r]);
 }
 
+// cMfcc::processVector with inverse = 1 (mfcc.cpp:184-235): one thread per (frame, band). Coefficient i = first + i0 sits at input
+// position pos(i) -- HTK mode with firstMfcc = 0: c0 last -- which is also its row of `rows` (rows are by OUTPUT position of the
+// forward transform); lifter[i0] is the reference's sintable. The sum runs over i in ascending order, a float chain, every product
+// ((c x cos) x correction) x factor as written there.
+struct MfccInverse { int first, last, n_bands, htk, do_log; float factor; float lifter[64]; };
+__global__ void __launch_bounds__(64) k_mfcc_inverse(const float *src, int64_t lds, float *dst, int64_t ldd, const float *rows, MfccInverse Q) {
+  const float *c = src + (int64_t)blockIdx.x * lds;
+  for (int m = threadIdx.x; m < Q.n_bands; m += blockDim.x) {
+    float acc = 0.0f;
+    for (int i = Q.first; i <= Q.last; ++i) {
+      const int i0 = i - Q.first;
+      const int pos = (Q.htk && Q.first == 0) ? (i == 0 ? Q.last : i0 - 1) : i0;
+      const float v = c[pos] / Q.lifter[i0];
+      const float corr = (i == 0) ? 0.5f : 1.0f;
+      acc += v * rows[pos * Q.n_bands + m] * corr * Q.factor;
+    }
+    dst[(int64_t)blockIdx.x * ldd + m] = Q.do_log ? glibc_expf(acc) : acc;
+  }
+}
+hipError_t stage_mfcc_inverse(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t nF, int n_bands, int first, int last, int htk,
+                              int do_log, const float *rows, const float *lifter, hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  MfccInverse Q;
+  Q.first = first; Q.last = last; Q.n_bands = n_bands; Q.htk = htk; Q.do_log = do_log;
+  Q.factor = (float)sqrt((double)2.0 / (double)(n_bands));
+  for (int i = 0; i < 64; ++i) Q.lifter[i] = (i <= last - first) ? lifter[i] : 1.0f;
+  hipLaunchKernelGGL(k_mfcc_inverse, dim3((unsigned)nF), dim3(64), 0, s, src, lds, dst, ldd, rows, Q);
+  return hipGetLastError();
+}
+
 // R0, every sample format of smilePcm_convertSamples (smileUtil.c:2500-2627): one thread per
 // output sample (mixdown) or per (sample, channel). The divisions are IEEE float divisions in
 // the reference's order: (sum / nChan) / full-scale.

@@ -432,6 +432,19 @@ extern "C" int smilehip_mfcc_frames(smilehip_plan *p, const float *d_src, int64_
                        p->d_dct_gain.p, p->dct.melfloor, p->dct.log_floor, (hipStream_t)stream), "mfcc");
 }
 
+extern "C" int smilehip_mfcc_inverse_frames(smilehip_plan *p, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst,
+                                            int64_t n_frames, int do_log, void *stream) {
+  if (!p) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_inverse_frames: null plan");
+  if (!p->ctx) return fail(SMILEHIP_ERR_NO_DEVICE, "host-only plan: no device attached");
+  if (!(p->stage_mask & SMILEHIP_STAGE_MFCC)) return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_inverse_frames: plan was built without this stage's tables");
+  if (p->dct.n_mfcc < 1 || p->dct.n_mfcc > 64 || (int)p->dct.lifter.size() < p->dct.n_mfcc)
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_mfcc_inverse_frames: 1 .. 64 coefficients");
+  int rc = check_frames(d_src, d_dst, ld_src, ld_dst, n_frames, p->dct.n_mfcc, p->mel.n_bands, "smilehip_mfcc_inverse_frames");
+  if (rc) return rc;
+  STAGE_RET(stage_mfcc_inverse(d_src, ld_src, d_dst, ld_dst, n_frames, p->mel.n_bands, p->dct.first, p->dct.last, p->cfg.mfcc_htk_compatible != 0,
+                               do_log != 0, p->d_dct_rows.p, p->dct.lifter.data(), (hipStream_t)stream), "mfcc_inverse");
+}
+
 // ---------------------------------------------- F0 group, per-component
 static int f0_rows(smilehip_plan *p, int mode, const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_frames,
                    void *stream, const char *fn) {

@@ -303,11 +303,13 @@ class cHipMfcc : public BlockVP<cMfcc> {
     return BlockVP<cMfcc>::myTick(t);
   }
   int processVector(const FLOAT_DMEM *src, FLOAT_DMEM *dst, long Nsrc, long Ndst, int idxi) override {
-    if (getInt("inverse") || !getInt("doLog")) { HIP_FALLTHROUGH(5, "cMfcc: inverse = 1 / doLog = 0 are not built"); return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi); }
+    const bool inv = getInt("inverse") != 0;               // round 6: cepstra back to nBands mel bands (mfcc.cpp:184-235)
+    if ((!inv && !getInt("doLog")) || (inv && (Ndst < 2 || Ndst > 64 || Nsrc > 64)))
+      { HIP_FALLTHROUGH(5, "cMfcc: doLog = 0 (forward) is not built"); return cMfcc::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       smilehip_lld_config c = base_config(512, SMILEHIP_STAGE_MFCC);
-      c.n_bands = (int)Nsrc;
+      c.n_bands = inv ? (int)Ndst : (int)Nsrc;
       c.first_mfcc = getInt("firstMfcc");
       c.last_mfcc = getInt("lastMfcc");
       if (!isSet("lastMfcc") && isSet("nMfcc")) c.last_mfcc = c.first_mfcc + getInt("nMfcc") - 1;   // mfcc.cpp:77-82
@@ -318,6 +320,8 @@ class cHipMfcc : public BlockVP<cMfcc> {
     }
     io_.ensure(Nsrc, Ndst);
     io_.up(src, Nsrc);
+    if (inv) check(smilehip_mfcc_inverse_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, getInt("doLog") ? 1 : 0, nullptr));
+    else
     check(smilehip_mfcc_frames(pl, io_.d_in, Nsrc, io_.d_out, Ndst, g_blk.n, nullptr));
     io_.down(dst, Ndst);
     g_frames[5] += g_blk.n;

@@ -715,6 +715,42 @@ long lldo_plp_static_stage(const int16_t *pcm, long n_samples, int stage, float 
   return T;
 }
 
+/* cMfcc with inverse = 1 (mfcc.cpp:184-235): cepstra back to a (log) mel spectrum -- inverse liftering, the transposed cosine table
+ * (initTables with blocksize = nBands, :142-170) with the 0th coefficient halved, sqrt(2 / nBands), exp() when doLog. src: the
+ * lastMfcc - firstMfcc + 1 coefficients in the forward component's output order (HTK mode with firstMfcc = 0: c1 .. cN, c0). */
+void lldo_mfcc_inverse(const float *src, int first, int last, int n_bands, float cep_lifter, int htk, int do_log, float *dst)
+{
+  const int nMfcc = last - first + 1;
+  float costable[64 * 64], sintable[64], tmp[64];
+  int i, m;
+  double fnM = (double)n_bands;
+  for (i = first; i <= last; i++) {
+    double fi = (double)i;
+    for (m = 0; m < n_bands; m++) costable[m + (i - first) * n_bands] = (float)cos((double)M_PI * (fi / fnM) * ((double)(m) + (double)0.5));
+  }
+  for (i = first; i <= last; i++)
+    sintable[i - first] = (cep_lifter > 0.0) ? ((float)1.0 + cep_lifter / (float)2.0 * sinf((float)M_PI * ((float)(i)) / cep_lifter)) : (float)1.0;   /* sin() on a FLOAT_DMEM in C++ is the float overload */
+  float factor = (float)sqrt((double)2.0 / (double)(n_bands));
+  for (i = first; i <= last; i++) {
+    int i0 = i - first, srcIdx = i0;
+    if (htk && (first == 0)) srcIdx = (i == 0) ? last : i0 - 1;
+    tmp[srcIdx] = src[srcIdx] / (sintable[i0]);
+  }
+  for (m = 0; m < n_bands; m++) {
+    float *outc = dst + m;
+    *outc = 0.0;
+    for (i = first; i <= last; i++) {
+      int i0 = i - first, srcIdx = i0;
+      if (htk && (first == 0)) srcIdx = (i == 0) ? last : i0 - 1;
+      float correctionfactor = 1.0;
+      if (i == 0) correctionfactor = (float)(0.5f);
+      *outc += tmp[srcIdx] * costable[m + i0 * n_bands] * correctionfactor * factor;
+    }
+    if (do_log) *outc = (float)(expf(*outc));            /* exp() on a FLOAT_DMEM in C++ is the float overload */
+  }
+  (void)nMfcc;
+}
+
 /* ------------------------------------------------------------- the other configs of config/mfcc and config/plp */
 /* MFCC12_E_D_A, MFCC12_0_D_A_Z, MFCC12_E_D_A_Z, PLP_E_D_A, PLP_0_D_A_Z, PLP_E_D_A_Z next to the _0_D_A pair:
  *   E: cMfcc firstMfcc = 1 (cPlp firstCC = 1) and a cEnergy column appended to the static block -- log energy of the RAW

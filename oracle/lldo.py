@@ -1100,6 +1100,19 @@ def vecop_reduce_rows(x, op):
     return np.array([L.lldo_vecop_reduce(VOP[op], x[i].ctypes.data, x.shape[1]) for i in range(x.shape[0])], np.float32)
 
 
+def mfcc_inverse_rows(mfcc, first, last, n_bands, cep_lifter, htk=1, do_log=1):
+    """cMfcc with inverse = 1 (oracle/lld_oracle_compare.c::lldo_mfcc_inverse): n x (last - first + 1) cepstra -> n x n_bands"""
+    L = lib()
+    x = np.ascontiguousarray(mfcc, dtype=np.float32)
+    assert x.shape[1] == last - first + 1
+    L.lldo_mfcc_inverse.restype = None
+    L.lldo_mfcc_inverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros((x.shape[0], n_bands), np.float32)
+    for i in range(x.shape[0]):
+        L.lldo_mfcc_inverse(x[i].ctypes.data, first, last, n_bands, cep_lifter, htk, do_log, out[i].ctypes.data)
+    return out
+
+
 def plp_static_stage(pcm, stage):
     """[plp:cPlp]'s level of config/plp/PLP_0_D_A.conf cut after a stage: 1 = autocorrelation (doLP = 0), 2 = LP coefficients
     (doLpToCeps = 0), 3 = cepstra (as shipped)"""

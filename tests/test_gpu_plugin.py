@@ -943,3 +943,38 @@ def test_plugin_plp_partial_modes(oracle, stage, tmp_path):
     got = oracle.read_htk(os.path.join(td, "tap_plp.htk"))[0]
     ref = oracle.plp_static_stage(synth.utterance(5, 48000), stage)
     assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["htk_c0", "htk_first1", "htk_nolog"])
+def test_plugin_mfcc_inverse(oracle, case, tmp_path):
+    """cMfcc with inverse = 1 (round 6, smilehip_mfcc_inverse_frames): a second cMfcc instance turns the cepstral level of an MFCC file
+    back into 26 mel bands; the plugin's level equals the plain binary's byte for byte and the oracle's bit for bit."""
+    from test_oracle_pin_mfcc_inverse import CASES, inverse_conf
+    from opensmile_amd import synth
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    td = str(tmp_path)
+    wav = os.path.join(td, "in.wav")
+    oracle.write_wav(wav, synth.utterance(5, 48000), 16000)
+    c = inverse_conf(case, td)
+    outs = {}
+    for mode in ("plain", "plugin"):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        trace = os.path.join(td, "trace.txt")
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        r = subprocess.run([exe, "-C", c, "-I", wav, "-O", os.path.join(td, "o.htk"), "-l", "1"], cwd=PLUGDIR if mode == "plugin" else td, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stderr + r.stdout)[-1500:]
+        outs[mode] = open(os.path.join(td, "tap_m.htk"), "rb").read()
+        if mode == "plugin":
+            tr = dict(l.split() for l in open(trace) if len(l.split()) == 2)
+            assert int(tr["cMfcc"]) > 0 and int(tr.get("cMfcc.cpu", 0)) == 0
+    assert len(outs["plain"]) > 1000 and outs["plain"] == outs["plugin"]
+    _f, _level, first, last, lifter, htk, dolog = CASES[case]
+    cep = oracle.read_htk(os.path.join(td, "tap_c.htk"))[0]
+    got = oracle.read_htk(os.path.join(td, "tap_m.htk"))[0]
+    ref = oracle.mfcc_inverse_rows(cep, first, last, 26, lifter, htk, dolog)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

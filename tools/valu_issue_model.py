@@ -49,7 +49,10 @@ def main():
            "class_cost_source": "profiles/r06_valu_classes.json (tools/ubench/valu_classes.hip, 4 waves per SIMD; the cheapest form of each class; "
                                 "v_cndmask_b32's 23.6 there is an artefact of the VOP2 form's implicit vcc in a tight loop and is not used)",
            "kernels": {}, "cycles_per_valu_inst": {}}
-    rep = json.load(open(os.path.join(P, "r06_valu_replay.json")))["variants"]
+    # the replay of the round's FINAL kernel when it is there (r06_valu_replay_tuned.json), else of the kernel the round started with
+    rep_file = "r06_valu_replay_tuned.json" if os.path.exists(os.path.join(P, "r06_valu_replay_tuned.json")) else "r06_valu_replay.json"
+    rep = json.load(open(os.path.join(P, rep_file)))["variants"]
+    out["replay_source"] = "profiles/" + rep_file
     for c in (2, 3, 4, 5):
         a, b = parse(os.path.join(P, f"r06_pmc_c{c}.txt")), parse(os.path.join(P, f"r06_pmc64_c{c}.txt"))
         for k, v in a.items():
@@ -82,12 +85,12 @@ def main():
             out["kernels"].setdefault(f"c{c}:{k}", r)
     out["mfma_beside_valu"] = {
         "question": "does v_mfma_f32_32x32x2_f32 run beside the vector ALU of the same SIMD (VERDICT r05 item 2b)?",
-        "answer": "no: the times ADD. In one stream (16 MFMA spread over the 937-instruction pass) each MFMA costs its full ~75 cycles on top of the VALU "
+        "answer": "no: the times ADD. In one stream (16 MFMA spread over the %d-instruction pass) each MFMA costs its full ~75 cycles on top of the VALU "
                   "time; wave-specialised (waves 0-3 of a block VALU only, waves 4-7 MFMA only) the two halves take %.2f ms and %.2f ms alone and %.2f ms "
                   "together. A radix-16 stage as a dense 32 x 32 real product (16 MFMA per pass = 1024 matrix-pipe cycles) would replace 138-144 VALU "
-                  "instructions (~530 cycles): slower on either schedule." % (rep["split_valu_only"]["ms_run"], rep["split_mfma_only"]["ms_run"], rep["split_both"]["ms_run"]),
+                  "instructions (~520 cycles): slower on either schedule." % (rep["base"]["valu_per_pass"], rep["split_valu_only"]["ms_run"], rep["split_mfma_only"]["ms_run"], rep["split_both"]["ms_run"]),
         "ms_per_bench_launch": {k: v["ms_per_bench_launch"] for k, v in rep.items() if not k.startswith("split")},
-        "source": "profiles/r06_valu_replay.json, counters (SQ_VALU_MFMA_BUSY_CYCLES beside SQ_ACTIVE_INST_VALU) profiles/r06_valu_replay_pmc.txt"}
+        "source": "profiles/" + rep_file + " (the round-5 kernel's: r06_valu_replay.json), counters (SQ_VALU_MFMA_BUSY_CYCLES beside SQ_ACTIVE_INST_VALU) profiles/r06_valu_replay_tuned_pmc.txt / r06_valu_replay_pmc.txt"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
