@@ -102,7 +102,14 @@ struct Chunk {                                             // the files [j0, j1)
 
 }  // namespace
 
-int main(int argc, char **argv) {
+// what --serve keeps from list to list: the device context (0.3 s of runtime start-up, code objects, first launch) and the plans
+struct Persist {
+  smilehip_context *ctx = nullptr;
+  std::map<long, smilehip_plan *> plans;
+  std::string key;                                         // the options the plans were built for
+};
+
+static int run_main(int argc, char **argv, Persist *ps) {
   std::map<std::string, std::string> opt, conf_cmdline;
   const char *with_value[] = {"--set", "-C", "-I", "-filelist", "-O", "-csvoutput", "-htkoutput", "-lldcsvoutput", "-lldhtkoutput",
                               "-instname", "-N", "-outdir", "--device", "--rank", "--world", "--chunk-files", "--master-addr", "--master-port"};
@@ -320,7 +327,9 @@ int main(int argc, char **argv) {
   }).share();
   g_before_exit = [&] { probed.wait(); };
   smilehip_context *ctx = nullptr;
-  check(smilehip_init(device, &ctx), "smilehip_init");
+  if (ps && ps->ctx) ctx = ps->ctx;
+  else check(smilehip_init(device, &ctx), "smilehip_init");
+  if (ps) ps->ctx = ctx;
   // --gather: the summary rows of every rank travel to rank 0 over RCCL (libsmilehip_comm.so, loaded only here) and rank 0
   // writes ONE file in list order; without it every rank writes <name>.rank<r><ext>
   smilehip_comm *comm = nullptr;
@@ -345,7 +354,16 @@ int main(int argc, char **argv) {
   }
   std::vector<float> gathered;                              // this rank's summary rows: n_func values + a "has an instance" flag each
   int gathered_cols = 0;
-  std::map<long, smilehip_plan *> plans;                  // one plan per sample rate
+  std::map<long, smilehip_plan *> own_plans;
+  if (ps) {                                                // (--serve: the plans of the list before, if it asked for the same set / file)
+    const std::string key = (opt.count("--set") ? opt["--set"] : "") + "|" + (opt.count("-C") ? opt["-C"] : "");
+    if (key != ps->key) {
+      for (auto &kv : ps->plans) smilehip_plan_destroy(kv.second);
+      ps->plans.clear();
+      ps->key = key;
+    }
+  }
+  std::map<long, smilehip_plan *> &plans = ps ? ps->plans : own_plans;   // one plan per sample rate
   const long chunk_files_l = opt.count("--chunk-files") ? atol(opt["--chunk-files"].c_str()) : 256;
   if (chunk_files_l < 1) die("--chunk-files must be a positive number");
   const size_t chunk_files = (size_t)chunk_files_l;
@@ -839,8 +857,48 @@ int main(int argc, char **argv) {
     smilehip_free(ctx, d_mine);
   }
   if (comm) comm_destroy(comm);
-  for (auto &kv : plans) smilehip_plan_destroy(kv.second);
-  smilehip_shutdown(ctx);
+  if (!ps) {
+    for (auto &kv : plans) smilehip_plan_destroy(kv.second);
+    smilehip_shutdown(ctx);
+  }
   g_before_exit = nullptr;
+  return 0;
+}
+
+// smilextract_hip [options] --serve: the options on the command line are every list's; then one line per list on standard input --
+// more options, blank-separated (typically `-filelist <file> -outdir <dir>`; no blanks inside a value) -- each run like a command of
+// its own, on the SAME process, device context and plans: what a list costs is its files, not the 0.3 s of start-up. After a list:
+// one line `done <files' exit status> <seconds>` on standard output. An error in a list ends the server (as it ends the command).
+int main(int argc, char **argv) {
+  bool serve = false;
+  std::vector<char *> base;
+  for (int i = 0; i < argc; ++i) {
+    if (i > 0 && !strcmp(argv[i], "--serve")) { serve = true; continue; }
+    base.push_back(argv[i]);
+  }
+  if (!serve) return run_main(argc, argv, nullptr);
+  Persist ps;
+  char *line = nullptr;
+  size_t cap = 0;
+  while (getline(&line, &cap, stdin) > 0) {
+    std::vector<std::string> tok;
+    std::string cur;
+    for (const char *c = line; *c; ++c) {
+      if (*c == ' ' || *c == '\t' || *c == '\n' || *c == '\r') { if (!cur.empty()) { tok.push_back(cur); cur.clear(); } }
+      else cur += *c;
+    }
+    if (!cur.empty()) tok.push_back(cur);
+    if (tok.empty()) continue;
+    if (tok[0] == "quit") break;
+    std::vector<char *> av = base;
+    for (std::string &t : tok) av.push_back(&t[0]);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = run_main((int)av.size(), av.data(), &ps);
+    printf("done %d %.4f\n", rc, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    fflush(stdout);
+  }
+  free(line);
+  for (auto &kv : ps.plans) smilehip_plan_destroy(kv.second);
+  if (ps.ctx) smilehip_shutdown(ps.ctx);
   return 0;
 }

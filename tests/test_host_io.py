@@ -207,6 +207,44 @@ def test_htk_rows_be_on_the_device():
 
 
 @pytest.mark.gpu
+def test_smilextract_hip_serve_mode(tmp_path):
+    """--serve: lists arrive as lines on standard input and run on ONE process, context and plan set; every list's files equal what a
+    command of its own writes, a `done 0 <seconds>` line follows each, and a list of another sample rate gets its own plan."""
+    import wave
+    from opensmile_amd import synth
+    def make(tag, lens, rate=16000):
+        paths = []
+        for i, n in enumerate(lens):
+            p = str(tmp_path / f"{tag}{i:02d}.wav")
+            with wave.open(p, "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate)
+                w.writeframes(synth.utterance(50 + i % 5, n).tobytes())
+            paths.append(p)
+        lst = str(tmp_path / f"{tag}.txt")
+        open(lst, "w").write("\n".join(paths) + "\n")
+        return lst
+    lists = {"a": make("a", [16000, 8123, 48000, 400] * 4), "b": make("b", [24000, 399, 16000] * 3), "c": make("c", [22050, 11025], rate=22050)}
+    want = {}
+    for tag, lst in lists.items():
+        d = tmp_path / ("single_" + tag); d.mkdir()
+        subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-filelist", lst, "-outdir", str(d), "-O", "1", "--chunk-files", "5"], check=True)
+        want[tag] = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))}
+    lines = ""
+    for tag, lst in lists.items():
+        d = tmp_path / ("serve_" + tag); d.mkdir()
+        lines += f"-filelist {lst} -outdir {d}\n"
+    r = subprocess.run([EXE, "--set", "mfcc12_0_d_a", "-O", "1", "--chunk-files", "5", "--serve"], input=lines + "quit\n", capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    done = [l.split() for l in r.stdout.splitlines() if l.startswith("done ")]
+    assert len(done) == 3 and all(d[1] == "0" and float(d[2]) > 0 for d in done), r.stdout
+    for tag in lists:
+        d = tmp_path / ("serve_" + tag)
+        got = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))}
+        assert got.keys() == want[tag].keys() and len(got) > 0 and got == want[tag], tag
+
+
+@pytest.mark.gpu
 def test_smilextract_hip_file_list_pipeline_equals_the_serial_route(tmp_path):
     """The three-stage pipeline (page-locked slots, rows big-endian on the device, one writev per file, chunks in flight) writes
     byte for byte what the serial, pageable route of round 3 writes (SMILEHIP_NO_PINNED=1) -- a list longer than a chunk, ragged

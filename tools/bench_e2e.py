@@ -81,6 +81,17 @@ def main():
         import re
         m = re.search(r"since the first ingest ([0-9.]+) s", stages[-1]) if stages else None
         t_net = float(m.group(1)) if m else None
+        # --serve: the same list as the second list of a running server (process, context and plans already there)
+        t_serve = None
+        try:
+            os.makedirs(d + "/hips", exist_ok=True)
+            line = f"-filelist {lst} -outdir {d}/hips\n"
+            r2 = subprocess.run(cmd_hip[:3] + hip_out + ["--serve"], input=line + line + "quit\n", env=env, capture_output=True, text=True)
+            dl = [l.split() for l in r2.stdout.splitlines() if l.startswith("done ")]
+            if r2.returncode == 0 and len(dl) == 2 and dl[1][1] == "0":
+                t_serve = float(dl[1][2])
+        except Exception:
+            t_serve = None
         # A/B on the same list: the device stage of round 5 (every chunk's copies and kernels on the null stream, the host waiting for
         # each: SMILEHIP_E2E_SERIAL=1) and the route of round 3 (pageable buffers, serial stages; not at the large file counts)
         t_r5 = None
@@ -126,6 +137,8 @@ def main():
                           "frames_per_s_gross": args.files * frames_per_file / t_hip if frames_per_file else None,
                           "frames_per_s_net_of_startup": args.files * frames_per_file / t_net if (frames_per_file and t_net) else None,
                           "net_s_first_ingest_to_last_sink": t_net, "stages": stages[-1] if stages else None,
+                          "serve_second_list_wall_s": t_serve,
+                          "frames_per_s_served": args.files * frames_per_file / t_serve if (frames_per_file and t_serve) else None,
                           "round5_serial_device_stage_wall_s": t_r5, "round3_route_wall_s": t_old,
                           "force_generic_outputs_compared": generic_cmp, "force_generic_outputs_byte_identical": generic_same,
                           "smilextract_hip_files_per_s": args.files / t_hip, "smilextract_hip_audio_s_per_s": args.files * secs / t_hip,
