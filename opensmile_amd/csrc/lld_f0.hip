@@ -100,10 +100,25 @@ extern "C" int smilehip_debug_phase_f0(unsigned long long *out16, int reset) {
   }
   return 0;
 }
+// (lld_f0_sweep: 0 pass 1, a block's first 14 bins | 1 pass 1, the wait for the next block | 2 pass 1, the last two bins + the next
+//  block's line from LDS | 3 pass 2, the wait for the block | 4 pass 2, the recurrences | 5 pass 2, target points + output)
+__device__ unsigned long long g_phase_sweep[8];
+#define SWEEP_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SWEEP_PHASE_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_sweep[i_], ph_acc[i_]); } while (0)
+extern "C" int smilehip_debug_phase_sweep(unsigned long long *out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_sweep), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_sweep), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 #else
 #define PHASE_DECL
 #define PHASE(i)
 #define PHASE_FLUSH
+#define SWEEP_WAIT_VM
+#define SWEEP_PHASE_FLUSH
 #endif
 
 // ---- per-frame phases. Lane l owns bins i = l + 64 m, m = 0..8 (bin 512: lane 0); all loops over m are unrolled
@@ -655,11 +670,11 @@ __host__ __device__ inline int64_t f0_b16_index(int64_t fr, int i) {
 struct F0Scratch {
   float *mg;       // enhanced magnitudes, blocked
   float *hp;       // octave-scale spectrum, blocked
-  double *cp;      // [tile][block][frame] value of the forward recurrence on entry to the block
+  double *cp;      // [tile][block][frame] pairs: value of the forward recurrence on entry to the block | the two magnitudes below the block (floats)
   double *es;      // [frame] sum of squares of the windowed frame
 };
 template <class G>
-__host__ __device__ inline int64_t f0_scratch_doubles_per_row() { return (int64_t)G::kNB16 * 16 + G::kNB16 + 1; }
+__host__ __device__ inline int64_t f0_scratch_doubles_per_row() { return (int64_t)G::kNB16 * 16 + 2 * G::kNB16 + 1; }
 template <class G>
 __device__ __forceinline__ F0Scratch f0_scratch(const F0Params &Q) {
   F0Scratch S;
@@ -667,7 +682,7 @@ __device__ __forceinline__ F0Scratch f0_scratch(const F0Params &Q) {
   S.mg = reinterpret_cast<float *>(Q.ab);
   S.hp = S.mg + blk * 16;
   S.cp = Q.ab + blk * 16;                              // (2 x blk x 16 floats)
-  S.es = S.cp + blk;
+  S.es = S.cp + 2 * blk;
   return S;
 }
 template <class G>
@@ -746,19 +761,59 @@ __device__ __forceinline__ double f0_div_by(double a, double b, double y) {
 // 64-byte line of magnitudes; the next block's line is requested before the current block's arithmetic. The blocks that
 // touch the ends of the spectrum (bin 0; bins K-2, K-1) carry the reference's boundary cases, the blocks in between are
 // straight-line code (32 divisions whose latencies overlap).
+constexpr int kSweepWaves = 16;                        // tiles (waves) per workgroup: one workgroup per CU, four waves per SIMD
+constexpr size_t kSweepWaveLds = 16 * 65 * 4;          // stage (dynamic; tp is a static array: see the kernel)
 template <int LOGM>
-__global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
+__global__ void __launch_bounds__(kSweepWaves * 64) lld_f0_sweep(F0Params Q) {
   using G = F0G<LOGM>;
   F0_GEO;
   constexpr int NB = G::kNB16;
   static_assert((kK - 1) % 16 == 0 && NB == (kK - 1) / 16 + 1 && NB >= 4, "bin K-1 opens the last block");
-  __shared__ float stage[16 * 64];                     // lane-private: the 16 target points of an output line, [point][lane]
-  const int lane = threadIdx.x;
+  // Every global access of the wave is one contiguous kilobyte. A block's 4 KB -- 64 lines of 64 bytes, line f being frame f's
+  // 16 bins -- come in as four direct-to-LDS loads of 64 consecutive 16-byte pieces (no registers hold data in flight) and
+  // are handed to their frames by LDS reads: piece (f, j) lies in slot 4 f + (j ^ ((f >> 2) & 3)) -- the load writes LDS lane by
+  // lane, so it is the lane's SOURCE piece that is permuted (within its 64-byte line), and the 16-lane groups of the 16-byte read
+  // each cover their bank rows once. The target points leave the same way, from the staged lines.
+  // The two magnitudes a block needs from its neighbour: pass 1 reads the next block's first two once that block has landed
+  // (before its last two bins); pass 2 finds the previous block's last two beside the checkpoint pass 1 wrote.
+  //
+  // The tables (51 KB: a 64-byte record per bin, 32 bytes per target point) are scalar loads, and the scalar cache holds 16 KB.
+  // With every wave at its own place in the tables nearly every one of a wave's 3 100 loads missed: 52 % of the wave cycles were
+  // s_waitcnt (the counters), a replay of the loop's instruction stream runs at 4.6 cycles per vector instruction with a table
+  // window that fits the cache and 6.4 - 11 without (tools/ubench/stream_replay_gen.py). So the 16 waves of a workgroup (= of a
+  // CU) walk the blocks TOGETHER (see `pace` below; nothing is exchanged), and at the top of a block each wave touches one line of
+  // the NEXT block's records (16 waves = its 16 bins), every 32 target points its share of the points 32 .. 63 ahead: what the
+  // waves then load is in the cache, the misses happen once per line and CU, ahead of their use.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_sweep[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (two objects, so that the compiler can tell them apart: with both in one array every read of a staged line waited for the
+  //  direct-to-LDS load of the next block that was in flight)
+  __shared__ float4 tp_all[kSweepWaves * 4 * 64];
+  float *stage = reinterpret_cast<float *>(smem_sweep + (size_t)wave * kSweepWaveLds);   // the 16 target points of an output line, [point][lane] (+1: the read-out)
+  float4 *tp = tp_all + wave * 256;
+  // Walking together: every wave posts the step (block of pass 1, then of pass 2) it enters and goes on once no wave is more than
+  // one step behind -- not a barrier: 4 096 waves in lock step all store their 4 KB output lines in the same microsecond, 16 MB at
+  // once, and wait for the burst to drain (measured: two thirds of the target-point phase). The waves start a few hundred cycles
+  // apart (one target point or so each) and, nobody having to wait for anybody, stay that way.
+  __shared__ volatile int progress[kSweepWaves];
+  if (threadIdx.x < kSweepWaves) progress[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(6);
+  auto pace = [&](int step) {
+    if (lane == 0) progress[wave] = step;
+    while (__ballot(progress[lane & (kSweepWaves - 1)] < step - 1) != 0) __builtin_amdgcn_s_sleep(4);
+  };
+  int tile = blockIdx.x * kSweepWaves + wave;            // 64 rows of the chunk (a last workgroup's spare waves repeat the last 64: same values to the same places)
+  const int n_sweep = (Q.n_tiles_chunk * kTileFrames + 63) / 64;
+  if (tile >= n_sweep) tile = n_sweep - 1;
   const F0Scratch S = f0_scratch<G>(Q);
-  const int64_t lane0 = ((int64_t)blockIdx.x * NB * 64 + lane);
-  const float4 *mg4 = reinterpret_cast<const float4 *>(S.mg) + lane0 * 4;     // block bb: + bb * 256
-  float4 *hp4 = reinterpret_cast<float4 *>(S.hp) + lane0 * 4;
-  double *cp = S.cp + lane0;                                                   // block bb: + bb * 64
+  const int64_t lane0 = ((int64_t)tile * NB * 64 + lane);
+  const float4 *mg4 = reinterpret_cast<const float4 *>(S.mg) + (int64_t)tile * NB * 256 + (lane ^ ((lane >> 4) & 3));
+  float4 *hp4 = reinterpret_cast<float4 *>(S.hp) + (int64_t)tile * NB * 256 + lane;   // block bb, piece q: + bb * 256 + q * 64
+  double2 *cp = reinterpret_cast<double2 *>(S.cp) + lane0;                     // block bb: + bb * 64
+  const int tp_r = 4 * lane, tp_x = (lane >> 2) & 3;   // this lane's frame: its piece j is in slot tp_r + (j ^ tp_x)
+  PHASE_DECL
   // the tables are read through the constant address space (read-only for the kernel's lifetime): with wave-uniform
   // addresses they are scalar loads. Through a global pointer they are not -- the kernel stores to global memory, and a load
   // that a store might have clobbered stays a vector load (64 lanes fetching the same 8 bytes)
@@ -769,19 +824,46 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
   const ConstI cnt = (ConstI)(uintptr_t)Q.ip_cnt;      // [NB x 16] target points above source bin j
   using Edge = std::integral_constant<bool, true>;
   using Inner = std::integral_constant<bool, false>;
+  // one word of a table line, loaded for the line's sake. The compiler waits for every scalar load of its own before it issues the
+  // next one here, so the touches of a block top are issued by hand, all in flight together, and waited for once (the words live in
+  // scalar registers of their own from the load to the wait; nothing reads them)
+  auto touch = [&](ConstD table, int index) -> int {     // (the index is wave-uniform; said so, for the places where the compiler keeps it in a vector register)
+    const ConstD line = table + __builtin_amdgcn_readfirstlane(index);
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(line));
+    return v;
+  };
+  // (addresses are clamped into the tables instead of guarded: a branch around a load would bring its wait with it)
+  auto touch_records = [&](int bb) -> int {              // this wave's line of block bb's records
+    int j = 16 * (bb < 0 ? 0 : bb) + wave;
+    if (j > kK - 1) j = kK - 1;
+    return touch(sw, 8 * j);
+  };
 
-  auto ld = [&](float (&c)[16], int bb) {
+  typedef const __attribute__((address_space(1))) void *GlobalPtr;
+  typedef __attribute__((address_space(3))) void *LdsPtr;
+  auto ld_async = [&](int bb) {                          // block bb -> tp (one wave per workgroup: nothing else touches tp)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = mg4[(int64_t)bb * 256 + q];
-      c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((GlobalPtr)(mg4 + (int64_t)bb * 256 + q * 64), (LdsPtr)(tp + 64 * q), 16, 0, 0);
+  };
+  auto ld_get = [&](float (&c)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = tp[tp_r + (j ^ tp_x)];
+      c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
     }
   };
   // smileDsp_specSmoothSHS (smileUtil.c:2004-2014) for bins 16 bb - 1 .. 16 bb + 16: yv[e + 1] = y[16 bb + e].
   // lo2: the two magnitudes below the block, hi2: the two above it.
-  auto smooth = [&](auto edge, double (&yv)[18], const float (&lo2)[2], const float (&c)[16], const float (&hi2)[2], int bb) {
+  // (part: all 16 bins of the block, or -- pass 1 -- the first 14, which do not need hi2, and then the last two)
+  using PAll = std::integral_constant<int, 0>;
+  using P14 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  auto smooth = [&](auto edge, auto part, double (&yv)[18], const float (&lo2)[2], const float (&c)[16], const float (&hi2)[2], int bb) {
+    constexpr int e_lo = decltype(part)::value == 2 ? 15 : -1, e_hi = decltype(part)::value == 1 ? 14 : 16;
 #pragma unroll
-    for (int e = -1; e <= 16; ++e) {
+    for (int e = e_lo; e <= e_hi; ++e) {
       const int i = 16 * bb + e;
       const float fa = (e - 1 < 0) ? lo2[e + 1] : c[(e - 1) & 15];
       const float fb = (e < 0) ? lo2[1] : (e > 15 ? hi2[0] : c[e & 15]);
@@ -797,9 +879,10 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
     }
   };
   // smileMath_cspline (smileUtilSpline.c:157-212): 6*ut of bin i and one step of the forward recurrence
-  auto fw_block = [&](auto edge, double (&u)[17], const double (&yv)[18], double &up, int bb) {
+  auto fw_block = [&](auto edge, auto part, double (&u)[17], const double (&yv)[18], double &up, int bb) {
+    constexpr int e_lo = decltype(part)::value == 2 ? 14 : 0, e_hi = decltype(part)::value == 1 ? 14 : 16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = e_lo; e < e_hi; ++e) {
       const int i = 16 * bb + e;
       if (!decltype(edge)::value || (i >= 1 && i <= kK - 2)) {
         const ConstD r = sw + 8 * i;
@@ -814,40 +897,67 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
 
   // ---- pass 1: the forward recurrence, keeping its value on entry to every block
   {
-    float ca[16], cb[16], lo2[2] = {0.0f, 0.0f}, hi2[2];
+    float ca[16], lo2[2] = {0.0f, 0.0f}, hi2[2];
     double yv[18], u[17];
     double up = 0.0;
-    ld(ca, 0);
+    ld_async(0);
+    { int t0 = touch_records(0); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0)); }
+    ld_get(ca);
+    PHASE(7);
     for (int bb = 0; bb < NB; ++bb) {
-      if (bb + 1 < NB) { ld(cb, bb + 1); hi2[0] = cb[0]; hi2[1] = cb[1]; } else { hi2[0] = 0.0f; hi2[1] = 0.0f; }
-      cp[(int64_t)bb * 64] = up;
-      if (bb == 0 || bb >= NB - 2) { smooth(Edge{}, yv, lo2, ca, hi2, bb); fw_block(Edge{}, u, yv, up, bb); }
-      else { smooth(Inner{}, yv, lo2, ca, hi2, bb); fw_block(Inner{}, u, yv, up, bb); }
+      pace(bb);
+      if (bb + 1 < NB) ld_async(bb + 1);                 // (tp is free: this block is in registers)
+      { int t0 = touch_records(bb + 1); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0)); }
+      cp[(int64_t)bb * 64] = make_double2(up, __hiloint2double(__float_as_int(lo2[1]), __float_as_int(lo2[0])));
+      const bool edge = bb == 0 || bb >= NB - 2;
+      hi2[0] = 0.0f; hi2[1] = 0.0f;
+      if (edge) smooth(Edge{}, P14{}, yv, lo2, ca, hi2, bb); else smooth(Inner{}, P14{}, yv, lo2, ca, hi2, bb);
+      if (edge) fw_block(Edge{}, P14{}, u, yv, up, bb); else fw_block(Inner{}, P14{}, u, yv, up, bb);
+      __builtin_amdgcn_sched_barrier(0);                 // (the wait for the next block stays behind the first 14 bins)
+      PHASE(0);
+      SWEEP_WAIT_VM;
+      PHASE(1);
+      if (bb + 1 < NB) { const float4 h = tp[tp_r + tp_x]; hi2[0] = h.x; hi2[1] = h.y; }
+      if (edge) smooth(Edge{}, P2{}, yv, lo2, ca, hi2, bb); else smooth(Inner{}, P2{}, yv, lo2, ca, hi2, bb);
+      if (edge) fw_block(Edge{}, P2{}, u, yv, up, bb); else fw_block(Inner{}, P2{}, u, yv, up, bb);
       lo2[0] = ca[14]; lo2[1] = ca[15];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ca[q] = cb[q];
+      if (bb + 1 < NB) ld_get(ca);
+      PHASE(2);
     }
   }
   // ---- pass 2, blocks from the top: u of the block again, the backward recurrence, the target points above its bins
   {
-    float ca[16], cb[16], lo2[2], hi2[2] = {0.0f, 0.0f};
+    float ca[16], lo2[2], hi2[2] = {0.0f, 0.0f};
     double yv[18], u[17];
     double yn = 0.0;                                     // y2[K-1] of the natural spline
     double y2_above = 0.0;                               // y2 of the bin above the block
     int io = kK - 1;                                     // next target point (they come in descending order)
     double ra = rec[4 * io], rc = rec[4 * io + 1], rd = rec[4 * io + 2], rw = rec[4 * io + 3];   // its constants, one point ahead
-    ld(ca, NB - 1);
-    double up = cp[(int64_t)(NB - 1) * 64];
+    ld_async(NB - 1);
+    {                                                    // the first 64 target points, the first block's records and counts
+      int t0 = touch(rec, 4 * ((kK - 1 - 2 * wave) & ~1)), t1 = touch(rec, 4 * ((kK - 33 - 2 * wave) & ~1));
+      int t2 = touch_records(NB - 1), t3 = touch((ConstD)(uintptr_t)Q.ip_cnt, 8 * (NB - 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3));
+    }
+    double2 rec_cp = cp[(int64_t)(NB - 1) * 64];         // the value of the forward recurrence on entry to the block | the two magnitudes below it
+    ld_get(ca);
     for (int bb = NB - 1; bb >= 0; --bb) {
-      double up_next = 0.0;
-      if (bb > 0) { ld(cb, bb - 1); lo2[0] = cb[14]; lo2[1] = cb[15]; up_next = cp[(int64_t)(bb - 1) * 64]; }
-      else { lo2[0] = 0.0f; lo2[1] = 0.0f; }
+      double up = rec_cp.x;
+      lo2[0] = __int_as_float(__double2loint(rec_cp.y)); lo2[1] = __int_as_float(__double2hiint(rec_cp.y));
+      PHASE(3);
+      pace(2 * NB - 1 - bb);
+      if (bb > 0) { ld_async(bb - 1); rec_cp = cp[(int64_t)(bb - 1) * 64]; }
+      {
+        int t0 = touch_records(bb - 1);
+        int t1 = touch((ConstD)(uintptr_t)Q.ip_cnt, 8 * (bb > 0 ? bb - 1 : 0));   // (16 counts = 8 doubles)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0), "+s"(t1));
+      }
       int n16[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) n16[e] = cnt[16 * bb + e];
       const bool edge = bb == 0 || bb >= NB - 2;
-      if (edge) { smooth(Edge{}, yv, lo2, ca, hi2, bb); fw_block(Edge{}, u, yv, up, bb); }
-      else { smooth(Inner{}, yv, lo2, ca, hi2, bb); fw_block(Inner{}, u, yv, up, bb); }
+      if (edge) { smooth(Edge{}, PAll{}, yv, lo2, ca, hi2, bb); fw_block(Edge{}, PAll{}, u, yv, up, bb); }
+      else { smooth(Inner{}, PAll{}, yv, lo2, ca, hi2, bb); fw_block(Inner{}, PAll{}, u, yv, up, bb); }
       u[16] = y2_above;
 #pragma unroll
       for (int e = 15; e >= 0; --e) {
@@ -855,10 +965,17 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
         if (!edge || j <= kK - 2) { yn = sw[8 * j + 2] * yn + u[e]; u[e] = yn; }
         else u[e] = 0.0;                                 // bin K-1: y2 = 0; the bins above it do not exist
       }
+      PHASE(4);
       // smileMath_csplint + auditory weighting (specScale.cpp:340-353) of the target points whose lower source bin is j
 #pragma unroll
       for (int e = 15; e >= 0; --e) {
         for (int q = 0; q < n16[e]; ++q) {
+          if ((io & 31) == 0) {                          // the target points 32 .. 63 ahead (two to a line, a line per wave: the low blocks hold
+            int pt = io - 32 - 2 * wave;                 //  half of all points, a touch at the block's top would not reach)
+            if (pt < 0) pt = 0;
+            int tr = touch(rec, 4 * (pt & ~1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tr));
+          }
           const double a = ra, c = rc, d = rd, aw = rw;
           const int ip = io > 0 ? io - 1 : 0;
           ra = rec[4 * ip]; rc = rec[4 * ip + 1]; rd = rec[4 * ip + 2]; rw = rec[4 * ip + 3];
@@ -866,26 +983,27 @@ __global__ void __launch_bounds__(64) lld_f0_sweep(F0Params Q) {
           const double o = a * yv[e + 1] + b * yv[e + 2] + c * u[e] + d * u[e + 1];
           float v = (float)o;
           v = (v > 0.0f) ? (float)((double)v * aw) : 0.0f;
-          stage[(io & 15) * 64 + lane] = v;
-          if ((io & 15) == 0) {                          // the line is complete
+          stage[(io & 15) * 65 + lane] = v;
+          if ((io & 15) == 0) {                          // the line is complete: piece (lane & 3) of frames 16 r + (lane >> 2)
             float4 l4[4];
+            const int p0 = 4 * (lane & 3) * 65 + (lane >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              l4[r] = make_float4(stage[(4 * r) * 64 + lane], stage[(4 * r + 1) * 64 + lane], stage[(4 * r + 2) * 64 + lane],
-                                  stage[(4 * r + 3) * 64 + lane]);
+              l4[r] = make_float4(stage[p0 + 16 * r], stage[p0 + 65 + 16 * r], stage[p0 + 130 + 16 * r], stage[p0 + 195 + 16 * r]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp4[(int64_t)(io >> 4) * 256 + r] = l4[r];
+            for (int r = 0; r < 4; ++r) hp4[(int64_t)(io >> 4) * 256 + 64 * r] = l4[r];
           }
           --io;
         }
       }
       y2_above = u[0];
       hi2[0] = ca[0]; hi2[1] = ca[1];
-      up = up_next;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ca[q] = cb[q];
+      PHASE(5);
+      SWEEP_WAIT_VM;
+      if (bb > 0) ld_get(ca);
     }
   }
+  SWEEP_PHASE_FLUSH;
 }
 
 template <int LOGM>
@@ -1336,6 +1454,9 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
   e = hipFuncSetAttribute(LOGM == 9 ? reinterpret_cast<const void *>(&lld_f0_cand9) : reinterpret_cast<const void *>(&lld_f0_cand<LOGM>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cand);
   if (e != hipSuccess) return e;
+  const size_t lds_sweep = kSweepWaves * kSweepWaveLds;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lld_f0_sweep<LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sweep);
+  if (e != hipSuccess) return e;
   F0Params Q = Q0;
   // the chunk pipeline (F0Pipe, lld_launch.hpp): spectra on pipe->spec, sweeps on pipe->sweep, candidates on the caller's stream;
   // chunk i works on scratch set i & 1, whose previous user is chunk i - 2
@@ -1369,7 +1490,7 @@ hipError_t launch_f0_chunks(const LldParams &P, const F0Params &Q0, hipStream_t 
       if ((e = hipStreamWaitEvent(s_sweep, pipe->spec_done[set], 0)) != hipSuccess) return e;
     }
     const int64_t rows = (int64_t)Q.n_tiles_chunk * kTileFrames;          // unused rows of short tiles are swept too (harmless)
-    SMILEHIP_KLAUNCH(lld_f0_sweep<LOGM>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s_sweep, Q);
+    SMILEHIP_KLAUNCH(lld_f0_sweep<LOGM>, dim3((unsigned)(((rows + 63) / 64 + kSweepWaves - 1) / kSweepWaves)), dim3(kSweepWaves * 64), lds_sweep, s_sweep, Q);
     if (piped) {
       if ((e = hipEventRecord(pipe->sweep_done[set], s_sweep)) != hipSuccess) return e;
       if ((e = hipStreamWaitEvent(s, pipe->sweep_done[set], 0)) != hipSuccess) return e;
@@ -1423,7 +1544,7 @@ int64_t f0_scratch_rows(int64_t n_tiles) {                // rows of a chunk, a 
 }
 int64_t f0_scratch_doubles(int64_t n_tiles, int K) {      // F0Scratch: two blocked float rows, the checkpoints, the sum of squares
   const int64_t nb = (K + 15) / 16;
-  return f0_scratch_rows(n_tiles) * (nb * 16 + nb + 1);
+  return f0_scratch_rows(n_tiles) * (nb * 16 + 2 * nb + 1);
 }
 
 

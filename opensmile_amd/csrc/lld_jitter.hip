@@ -94,9 +94,20 @@ __host__ __device__ inline int jit_scale(double Tw) {
 __host__ __device__ inline int jit_wave_cap(const F0Params &Q) {      // samples of wave per frame: the plan's bound, or the general one
   return Q.jit_cap > 0 ? Q.jit_cap : jit_scale(Q.jit_Tw) * kJitCap;
 }
+// The frame's wave samples in LDS: floats, widened by crossCorr as it reads them (exact). -DSMILEHIP_JITTER_WAVE_DOUBLE keeps them as
+// doubles (widened once, when the frame is loaded; the few float readers narrow them back, exactly): crossCorr's loop drops its two
+// conversions per sample and candidate, 10 -> 8 vector instructions -- and is SLOWER, 93 ms against 80 per 12 500 x 10 s (round 6,
+// profiles/r06_jitter_wave_double.txt): every lane reads its own samples, a wave then moves 1 KB per read instruction through the
+// LDS pipe (128 B per clock and CU, twelve waves), and the pipe, not the issue slots, becomes the limit.
+#ifdef SMILEHIP_JITTER_WAVE_DOUBLE
+typedef double JitSample;
+#else
+typedef float JitSample;
+#endif
 inline size_t jit_shared_bytes(const F0Params &Q, int threads) {   // ccs (doubles) | wv | avgWf | pbuf | jit_terms
   const size_t r = (size_t)jit_scale(Q.jit_Tw);
-  return r * kJitMaxCand * 8 + (size_t)jit_wave_cap(Q) * 4 + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 + (size_t)threads * 4;
+  return r * kJitMaxCand * 8 + (size_t)jit_wave_cap(Q) * sizeof(JitSample) + r * kJitMaxPeriod * 4 + (size_t)kJitMaxPeriods * 4 +
+         (size_t)threads * 4;
 }
 
 // what carries over from frame to frame (cPitchJitter's members lastIdx, lastMis, lastT0, lastDiff, lastJitterLocal,
@@ -111,7 +122,7 @@ __device__ __forceinline__ JitState jit_reset_state() { return JitState{-1, 0, 0
 
 struct JitLds {
   double *ccs;        // [jitMaxCand]
-  float *wv;          // [jitCap] the frame's wave samples (crossCorr widens them to double as it reads: exact, and half the LDS)
+  JitSample *wv;      // [jitCap] the frame's wave samples
   float *avgWf;       // [jitMaxPeriod]
   int *pbuf;          // [kJitMaxPeriods]
   float *jit_terms;   // [threads] one term per lane and wave for the sequential energy sums
@@ -122,8 +133,8 @@ __device__ __forceinline__ JitLds jit_lds(unsigned char *smem, const F0Params &Q
   const int jr = uni(jit_scale(Q.jit_Tw));
   L.jitCap = uni(jit_wave_cap(Q)); L.jitMaxCand = jr * kJitMaxCand; L.jitMaxPeriod = jr * kJitMaxPeriod;
   L.ccs = reinterpret_cast<double *>(smem);
-  L.wv = reinterpret_cast<float *>(L.ccs + L.jitMaxCand);
-  L.avgWf = L.wv + L.jitCap;
+  L.wv = reinterpret_cast<JitSample *>(L.ccs + L.jitMaxCand);
+  L.avgWf = reinterpret_cast<float *>(L.wv + L.jitCap);
   L.pbuf = reinterpret_cast<int *>(L.avgWf + L.jitMaxPeriod);
   L.jit_terms = reinterpret_cast<float *>(L.pbuf + kJitMaxPeriods);
   return L;
@@ -155,7 +166,8 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
   asm volatile("" : "+v"(lane), "+v"(tid));              // opaque per frame: lane-only address arithmetic is not kept in
                                                          // registers across the frame loop (see f0_shs)
   double *ccs = L.ccs;
-  float *wv = L.wv, *avgWf = L.avgWf;
+  JitSample *wv = L.wv;
+  float *avgWf = L.avgWf;
   int *pbuf = L.pbuf;
   const double Tw = Q.jit_Tw;
   const JitFrameTime ft = jit_frame_time(Q, t);
@@ -195,7 +207,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
   long start = 0, lastPeriod = 0;
   if (F0 > 0.0f) {
     __syncthreads();
-    for (long i = tid; i < nT; i += kJitThreads) wv[i] = x[lastIdx + i];
+    for (long i = tid; i < nT; i += kJitThreads) wv[i] = (JitSample)x[lastIdx + i];
     for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
     __syncthreads();
     PH(0);   // frame set-up + wave load
@@ -232,7 +244,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
         }
         if (c < clo) continue;
         const long tf = T0minF + c;
-        const float *xa = wv + start, *ya = wv + start + tf;
+        const JitSample *xa = wv + start, *ya = wv + start + tf;
         const long nr = tf >> 2;
         const double sx = bx + ex, sy = (bx + bp + ep) - sx;     // sum of x[0..tf), sum of x[tf..2tf)
         const double mx = sx / (double)tf, my = sy / (double)tf;
@@ -240,7 +252,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
         // sums stay sequential in the reference's order); two rounds per loop iteration on alternating registers
         double cc = 0.0, nx = 0.0, ny = 0.0;
         {
-          const auto add4 = [&](const float (&xs)[4], const float (&ys)[4]) {
+          const auto add4 = [&](const JitSample (&xs)[4], const JitSample (&ys)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const double dx = (double)xs[q] - mx, dy = (double)ys[q] - my;
@@ -250,7 +262,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
             }
           };
           const int nri = (int)nr;
-          float xv[4], yv[4], xn[4], yn[4];
+          JitSample xv[4], yv[4], xn[4], yn[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { xv[q] = xa[q]; yv[q] = ya[q]; }
           int r = 0;
@@ -310,9 +322,9 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
       if (maxI >= 0) {
         start += pp;
         // amplitudeDiff (:422-459): max - min of x[1 .. pp-2] in both periods
-        float mx0 = wv[os + 1], mn0 = mx0, mx1 = wv[start + 1], mn1 = mx1;
+        float mx0 = (float)wv[os + 1], mn0 = mx0, mx1 = (float)wv[start + 1], mn1 = mx1;
         for (long i = 1 + lane; i < pp - 1; i += 64) {
-          const float a = wv[os + i], b = wv[start + i];
+          const float a = (float)wv[os + i], b = (float)wv[start + i];
           mx0 = a > mx0 ? a : mx0; mn0 = a < mn0 ? a : mn0;
           mx1 = b > mx1 ? b : mx1; mn1 = b < mn1 ? b : mn1;
         }
@@ -328,7 +340,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
         const float ad = fabsf((mx0 - mn0) - (mx1 - mn1));
         if (tid == 0) pbuf[numPeriods] = (int)os;
         numPeriods++;
-        for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += wv[os + i];
+        for (long i = tid; i < T0f; i += kJitThreads) avgWf[i] += (float)wv[os + i];
         double ccI = 0.0;
         const double maxId = fabs((double)T0minF + quad_vertex((double)(maxI - 1), ccs[maxI - 1], (double)maxI, ccs[maxI],
                                                                (double)(maxI + 1), ccs[maxI + 1], ccI)) * Tw;
@@ -361,7 +373,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
     if (tid == 0) { pbuf[numPeriods] = (int)start; pbuf[numPeriods + 1] = (pp > 0) ? (int)(start + pp) : 0; }
     numPeriods++;
     for (long i = tid; i < T0f && start + i < nT; i += kJitThreads) {
-      avgWf[i] += wv[start + i];
+      avgWf[i] += (float)wv[start + i];
       avgWf[i] /= (float)numPeriods;
     }
     __syncthreads();
@@ -410,7 +422,7 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
       for (long j = p0 + 2; j < lim; j += 64, k += 64) {
         const int cnt = (int)((lim - j < 64) ? (lim - j) : 64);
         float t = 0.0f;
-        if (ln < cnt) { const float delta = wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
+        if (ln < cnt) { const float delta = (float)wv[j + ln] - avgWf[k + ln]; t = delta * delta; }
         En = chain_add(En, t, cnt);
         nEn += cnt;
       }

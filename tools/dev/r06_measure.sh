@@ -12,6 +12,7 @@
 #   smileapi   tools/bench_smileapi.py (10 min pushed in 1 s pieces through cExternalAudioSource)
 #   sweep      tools/plugin_config_sweep.py (the 40 runnable shipped files through the plugin)
 #   pmc64:N    only the FP64 / INT64 instruction-class pass of config N (-> pmc64_c<N>.txt)
+#   pmcx:N     counter sets of the caller's choice, PMCX_SETS="A B C;D E" (one pass per ';' part) -> pmcx_c<N>.txt
 #   sh:<cmd>   any command (quoted), output to sh_<n>.log
 set -u
 R=$GRAFT_REPO_ROOT
@@ -88,6 +89,19 @@ for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:12]:
     print("%-46s %8.2f ms  valu %.2f lds %.2f wait %.2f hbm %.3f" % (k[:46], v["ms"], v["valu_busy_frac"], v["lds_pipe_frac"], v["wait_inst_frac"] or 0, v["hbm_frac"] or 0))
 PY
       ;;
+    pmcx:*)                                              # pmcx:N  counter sets of the caller's choice: PMCX_SETS="A B C;D E" (one pass per ';' part) -> pmcx_c<N>.txt
+      c=${sec#pmcx:}
+      if [ $c = 2 ]; then X="--no-configs --no-h2d"; else X="--config $c"; fi
+      cd /tmp && export TMPDIR=/tmp
+      i=0
+      IFS=';' read -ra SETS <<< "${PMCX_SETS:-SQ_WAVES SQ_WAVE_CYCLES}"
+      for set in "${SETS[@]}"; do
+        i=$((i+1))
+        timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmcx_c$c/p$i -- python $R/bench.py $X --utts ${UTTS[$c]} --steps ${STEPS[$c]} --warmup 1 --no-cpu-baseline > $O/pmcx_c${c}_p$i.log 2>&1
+      done
+      python $R/tools/pmc_summary.py $O/pmcx_c$c $O/pmcx_c$c.txt > /dev/null 2>&1
+      rm -rf $O/pmcx_c$c
+      grep -c "^==" $O/pmcx_c$c.txt ;;
     pmc64:*)
       c=${sec#pmc64:}
       if [ $c = 2 ]; then X="--no-configs --no-h2d"; else X="--config $c"; fi
