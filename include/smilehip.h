@@ -669,6 +669,14 @@ int smilehip_fftmagphase_frames(smilehip_context *ctx, const float *d_src, int64
 int smilehip_melspec_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t K, int32_t n_bands, int32_t dense,
                                   const float *d_coef, const int32_t *d_chanmap, int32_t n_lo, int32_t n_hi, int32_t use_power,
                                   float htk_scale, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
+/* R6 inverse: cMelspec::processVector with inverse = 1 (src/lldcore/melspec.cpp:466-516): rows of n_src mel bands -> rows of K spectrum
+ * bins ("nBands" of an inverse instance is K, :38,191-194) through the standard bank's tables as cMelspec::computeFilters builds them
+ * with the roles swapped (d_coef[K], d_chanmap[K], n_lo / n_hi = nLoF / nHiF). htk_div: 1, 32767 or 32767^2 -- the bands are DIVIDED by
+ * it first (:468-479). use_power: the square root of the positive sums, 0 otherwise (:508-514). The HFCC / custom-bandwidth banks are
+ * refused by the reference itself in this direction (:487-490). */
+int smilehip_melspec_inverse_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int32_t n_src, int64_t K,
+                                          const float *d_coef, const int32_t *d_chanmap, int32_t n_lo, int32_t n_hi, int32_t use_power,
+                                          float htk_div, float *d_dst, int64_t ld_dst, int64_t n_frames, void *stream);
 /* R10, for cPitchACF's voiceQual output: the second result of voicingProb (src/lldcore/pitchACF.cpp:249-283), the zero- or
  * mean-crossing rate of the ACF (rows of n ACF values; fs_sec / max_pitch as in smilehip_pitchacf_frames), one double per row.
  * The HNR outputs (computeHNR / _dB / _lin, :310-361) are three scalar expressions on acf[0] and acf[max_idx]. */

@@ -257,6 +257,7 @@ SYMBOLS = {
     "smilehip_irfft_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "smilehip_fftmagphase_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp, _i64, _i64, _vp]),
     "smilehip_melspec_table_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
+    "smilehip_melspec_inverse_table_frames": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
     "smilehip_pitchacf_zcr_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "smilehip_mzcr_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "smilehip_melspec_frames": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),

@@ -48,6 +48,8 @@ hipError_t stage_fftmagphase(const float *src, int64_t lds, float *dst, int64_t 
                              float mindBp, hipStream_t s);
 hipError_t stage_melspec_table(const float *src, int64_t lds, int K, int nB, int dense, const float *coef, const int32_t *chanmap, int nLoF,
                                int nHiF, int use_power, float htk_scale, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
+hipError_t stage_melspec_inverse_table(const float *src, int64_t lds, int n_src, int K, const float *coef, const int32_t *chanmap, int nLoF,
+                                       int nHiF, int use_power, float htk_div, float *dst, int64_t ldd, int64_t nF, hipStream_t s);
 hipError_t stage_pitchacf_zcr(const float *src, int64_t lds, int64_t nF, int n, int skip, double *zcr, hipStream_t s);
 hipError_t stage_mzcr(const float *src, int64_t lds, int N, int64_t nF, int flags, float *dst, int64_t ldd, hipStream_t s);
 hipError_t stage_valbased(const float *src, int64_t lds, int N, int64_t nF, int idx, float threshold, int invert, int allow_equal,

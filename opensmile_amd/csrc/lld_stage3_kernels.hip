@@ -184,6 +184,42 @@ hipError_t stage_melspec_table(const float *src, int64_t lds, int K, int nB, int
   return hipGetLastError();
 }
 
+// cMelspec::processVector, inverse = 1 (src/lldcore/melspec.cpp:466-516): n_src bands -> K spectrum bins through the standard bank's
+// tables (coef[K], chanmap[K] as computeFilters builds them with the roles swapped, :186-199). Lane = bin:
+//   x[m] = src[m] / htk_div (32767 or 32767^2, :468-479; 1 = none);  m = chanmap[n]
+//   dst[n] = x[m] coef[n] (+ x[m + 1] (1 - coef[n]) unless m is the last band) for nLoF <= n < min(K, nHiF) and m >= 0, else 0
+//   usePower: dst[n] = dst[n] > 0 ? sqrt(dst[n]) : 0
+__global__ void __launch_bounds__(64) k_melspec_inverse_table(const float *src, int64_t lds, int n_src, int K, const float *coef,
+                                                              const int32_t *chanmap, int nLoF, int nHiF, int use_power, float htk_div,
+                                                              float *dst, int64_t ldd) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];
+  const float *a = src + (int64_t)blockIdx.x * lds;
+  for (int m = threadIdx.x; m < n_src; m += 64) s_x[m] = (htk_div != 1.0f) ? a[m] / htk_div : a[m];
+  __syncthreads();
+  const int hi = K < nHiF ? K : nHiF;
+  for (int n = threadIdx.x; n < K; n += 64) {
+    float acc = 0.0f;
+    if (n >= nLoF && n < hi) {
+      const int m = chanmap[n];
+      if (m > -1 && m < n_src) {
+        acc += s_x[m] * coef[n];
+        if (m < n_src - 1) acc += s_x[m + 1] * (1.0f - coef[n]);
+      }
+    }
+    if (use_power) acc = (acc > 0.0f) ? sqrtf(acc) : 0.0f;
+    dst[(int64_t)blockIdx.x * ldd + n] = acc;
+  }
+}
+hipError_t stage_melspec_inverse_table(const float *src, int64_t lds, int n_src, int K, const float *coef, const int32_t *chanmap, int nLoF,
+                                       int nHiF, int use_power, float htk_div, float *dst, int64_t ldd, int64_t nF, hipStream_t s) {
+  if (nF <= 0) return hipSuccess;
+  const size_t bytes = sizeof(float) * (size_t)((n_src + 3) & ~3);
+  if (bytes > 48 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_melspec_inverse_table, dim3((unsigned)nF), dim3(64), bytes, s, src, lds, n_src, K, coef, chanmap, nLoF, nHiF,
+                     use_power, htk_div, dst, ldd);
+  return hipGetLastError();
+}
+
 hipError_t stage_pitchacf_zcr(const float *src, int64_t lds, int64_t nF, int n, int skip, double *zcr, hipStream_t s) {
   if (nF > 0) hipLaunchKernelGGL(k_pitchacf_zcr, dim3((unsigned)nF), dim3(64), 0, s, src, lds, n, skip, zcr);
   return hipGetLastError();

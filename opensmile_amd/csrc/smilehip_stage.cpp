@@ -390,6 +390,17 @@ extern "C" int smilehip_melspec_table_frames(smilehip_context *ctx, const float 
                                 n_frames, (hipStream_t)stream), "melspec_table");
 }
 
+extern "C" int smilehip_melspec_inverse_table_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int32_t n_src, int64_t K,
+                                                     const float *d_coef, const int32_t *d_chanmap, int32_t n_lo, int32_t n_hi,
+                                                     int32_t use_power, float htk_div, float *d_dst, int64_t ld_dst, int64_t n_frames,
+                                                     void *stream) {
+  if (!ctx || K < 2 || K > 8193 || n_src < 1 || n_src > 4096 || !d_coef || !d_chanmap || n_lo < 0 || n_hi < 0 || n_frames < 0 ||
+      ld_src < n_src || ld_dst < K || !(htk_div > 0.0f) || (n_frames > 0 && (!d_src || !d_dst)))
+    return fail(SMILEHIP_ERR_INVALID, "smilehip_melspec_inverse_table_frames: bad argument");
+  STAGE_RET(stage_melspec_inverse_table(d_src, ld_src, n_src, (int)K, d_coef, d_chanmap, n_lo, n_hi, use_power, htk_div, d_dst, ld_dst,
+                                        n_frames, (hipStream_t)stream), "melspec_inverse_table");
+}
+
 extern "C" int smilehip_pitchacf_zcr_frames(smilehip_context *ctx, const float *d_src, int64_t ld_src, int64_t n, int64_t n_frames,
                                             double fs_sec, double max_pitch, double *d_zcr, void *stream) {
   if (!ctx || n < 2 || n > (1 << 20) || n_frames < 0 || ld_src < n || !(fs_sec > 0.0) || (n_frames > 0 && (!d_src || !d_zcr)))

@@ -250,7 +250,37 @@ class cHipMelspec : public BlockVP<cMelspec> {
         return 1;
       }
     }
-    if (!plain_) { HIP_FALLTHROUGH(4, "cMelspec: inverse = 1 is not built"); return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi); }
+    if (getInt("inverse")) {
+      // inverse = 1 (melspec.cpp:466-516): Nsrc bands -> nBands_ spectrum bins through the component's own tables (computeFilters with the
+      // roles swapped, :191-194). The HFCC / custom-bandwidth banks have no inverse in the reference either (:487-490): its own message.
+      const int fc = getFconf(idxi);
+      const bool dense = hfcc_ || customBandwidth_;
+      if (!dense && fc >= 0 && fc < 8 && filterCoeffs_ && chanMap_ && filterCoeffs_[fc] && chanMap_[fc] && Ndst == nBands_ && Ndst >= 2 &&
+          Ndst <= 8193 && Nsrc <= 4096) {
+        if (!tab_ready_[fc]) {
+          const size_t nc = (size_t)Ndst;
+          std::vector<float> cf(filterCoeffs_[fc], filterCoeffs_[fc] + nc);
+          std::vector<int32_t> cm(nc);
+          for (size_t i = 0; i < nc; ++i) cm[i] = (int32_t)chanMap_[fc][i];
+          void *d_c = tab_coef_[fc].ensure(sizeof(float) * nc);
+          void *d_m = tab_map_[fc].ensure(sizeof(int32_t) * nc);
+          if (smilehip_copy_to_device(context(), d_c, cf.data(), sizeof(float) * nc, nullptr) ||
+              smilehip_copy_to_device(context(), d_m, cm.data(), sizeof(int32_t) * nc, nullptr))
+            COMP_ERR("libsmilehip: %s", smilehip_last_error());
+          tab_ready_[fc] = true;
+        }
+        const float div = htkcompatible_ ? (usePower_ ? (FLOAT_DMEM)(32767.0 * 32767.0) : (FLOAT_DMEM)32767.0) : 1.0f;
+        io_.ensure(Nsrc, Ndst);
+        io_.up(src, Nsrc);
+        check(smilehip_melspec_inverse_table_frames(context(), io_.d_in, Nsrc, (int32_t)Nsrc, Ndst, (const float *)tab_coef_[fc].d,
+                                                    (const int32_t *)tab_map_[fc].d, (int32_t)nLoF_[fc], (int32_t)nHiF_[fc], usePower_, div,
+                                                    io_.d_out, Ndst, g_blk.n, nullptr));
+        io_.down(dst, Ndst);
+        g_frames[4] += g_blk.n;
+        return 1;
+      }
+    }
+    if (!plain_) { HIP_FALLTHROUGH(4, "cMelspec: a bank without an inverse (HFCC / custom bandwidth)"); return cMelspec::processVector(src, dst, Nsrc, Ndst, idxi); }
     smilehip_plan *&pl = plans_.at(getFconf(idxi));
     if (!pl) {
       // frame size of the input spectrum, cMelspec::configureField (melspec.cpp:150-173)

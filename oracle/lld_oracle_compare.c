@@ -826,3 +826,40 @@ long lldo_htk_variant_chain(int plp, int energy, int cms, const int16_t *pcm, lo
   free(st); free(x); free(tmp);
   return T;
 }
+
+/* cMelspec with inverse = 1 (src/lldcore/melspec.cpp:466-516; the bank's tables :186-199,217-239,393-447 with the roles swapped:
+ * `n_out` spectrum bins to create -- the option nBands --, `n_src` mel bands coming in). Standard (mel, bwMethod lr) bank only: the
+ * reference refuses the HFCC / custom-bandwidth banks here (:487-490). tab (optional, 2 + 2 n_out floats' worth): receives nLoF, nHiF,
+ * then the n_out weights and the n_out channel numbers (as floats), i.e. what the table-driven device entry is fed with. */
+void lldo_melspec_inverse(const float *src, int n_src, int n_out, double frame_size_sec, float lofreq, float hifreq, int use_power, int htk,
+                          float *dst, float *tab)
+{
+  lldo_mel m;
+  long n;
+  float *s = (float *)malloc(sizeof(float) * (size_t)n_src);
+  memset(dst, 0, sizeof(float) * (size_t)n_out);
+  if (!lldo_mel_init(&m, n_out, frame_size_sec, n_src, lofreq, hifreq, use_power, htk)) { free(s); return; }
+  for (n = 0; n < n_src; n++) {                                  /* :468-479 */
+    if (htk) s[n] = use_power ? src[n] / (float)(32767.0 * 32767.0) : src[n] / (float)32767.0;
+    else s[n] = src[n];
+  }
+  for (n = m.nLo; n < (n_out < m.nHi ? n_out : m.nHi); n++) {    /* :492-505 */
+    const long mm = m.chan_map[n];
+    if (mm > -1) {
+      float a = s[mm] * m.coef[n];
+      dst[n] += a;
+      if (mm < n_src - 1) {
+        a = s[mm + 1] * ((float)1.0 - m.coef[n]);
+        dst[n] += a;
+      }
+    }
+  }
+  if (use_power)                                                 /* :508-514 (sqrt of a float: the C++ overload) */
+    for (n = 0; n < n_out; n++) dst[n] = (dst[n] > 0.0) ? sqrtf(dst[n]) : (float)0.0;
+  if (tab) {
+    tab[0] = (float)m.nLo; tab[1] = (float)m.nHi;
+    for (n = 0; n < n_out; n++) { tab[2 + n] = m.coef[n]; tab[2 + n_out + n] = (float)m.chan_map[n]; }
+  }
+  lldo_mel_free(&m);
+  free(s);
+}

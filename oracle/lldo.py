@@ -1113,6 +1113,26 @@ def mfcc_inverse_rows(mfcc, first, last, n_bands, cep_lifter, htk=1, do_log=1):
     return out
 
 
+def melspec_inverse_rows(mel, n_out, frame_size_sec, lofreq=0.0, hifreq=8000.0, use_power=1, htk=1, tables=False):
+    """cMelspec with inverse = 1 (oracle/lld_oracle_compare.c::lldo_melspec_inverse): n x n_src mel bands -> n x n_out spectrum bins;
+    tables = True: also (nLoF, nHiF, weights[n_out], channels[n_out] as int32), the tables of the bank"""
+    L = lib()
+    x = np.ascontiguousarray(mel, dtype=np.float32)
+    L.lldo_melspec_inverse.restype = None
+    L.lldo_melspec_inverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    out = np.zeros((x.shape[0], n_out), np.float32)
+    tab = np.zeros(2 + 2 * n_out, np.float32)
+    for i in range(x.shape[0]):
+        L.lldo_melspec_inverse(x[i].ctypes.data, x.shape[1], n_out, frame_size_sec, lofreq, hifreq, use_power, htk, out[i].ctypes.data,
+                               tab.ctypes.data if i == 0 else None)
+    if not tables:
+        return out
+    if x.shape[0] == 0:
+        L.lldo_melspec_inverse(np.zeros(x.shape[1], np.float32).ctypes.data, x.shape[1], n_out, frame_size_sec, lofreq, hifreq, use_power, htk,
+                               np.zeros(n_out, np.float32).ctypes.data, tab.ctypes.data)
+    return out, (int(tab[0]), int(tab[1]), tab[2:2 + n_out].copy(), tab[2 + n_out:].astype(np.int32))
+
+
 def plp_static_stage(pcm, stage):
     """[plp:cPlp]'s level of config/plp/PLP_0_D_A.conf cut after a stage: 1 = autocorrelation (doLP = 0), 2 = LP coefficients
     (doLpToCeps = 0), 3 = cepstra (as shipped)"""

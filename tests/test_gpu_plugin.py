@@ -978,3 +978,38 @@ def test_plugin_mfcc_inverse(oracle, case, tmp_path):
     got = oracle.read_htk(os.path.join(td, "tap_m.htk"))[0]
     ref = oracle.mfcc_inverse_rows(cep, first, last, 26, lifter, htk, dolog)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["power_htk_257", "mag_257", "power_nohtk_129", "power_htk_band"])
+def test_plugin_melspec_inverse(oracle, case, tmp_path):
+    """cMelspec with inverse = 1 (round 6, smilehip_melspec_inverse_table_frames): a second cMelspec instance turns the mel level of
+    MFCC12_0_D_A.conf back into a magnitude spectrum; the plugin's level equals the plain binary's byte for byte and the oracle's bit for bit."""
+    from test_oracle_pin_melspec_inverse import CASES, inverse_conf
+    from opensmile_amd import synth
+    exe = os.path.join(oracle.REF_DIR, "SMILExtract")
+    plug = os.path.join(PLUGDIR, "plugins", "libsmilehip_plugin.so")
+    if not (os.path.exists(exe) and os.path.exists(plug)):
+        pytest.skip("oracle/_ref/SMILExtract or the plugin .so not built")
+    td = str(tmp_path)
+    wav = os.path.join(td, "in.wav")
+    oracle.write_wav(wav, synth.utterance(5, 48000), 16000)
+    c = inverse_conf(case, td)
+    outs = {}
+    for mode in ("plain", "plugin"):
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "opensmile_amd"), oracle.REF_DIR, env.get("LD_LIBRARY_PATH", "")])
+        trace = os.path.join(td, "trace.txt")
+        env["SMILEHIP_PLUGIN_TRACE"] = trace
+        r = subprocess.run([exe, "-C", c, "-I", wav, "-O", os.path.join(td, "o.htk"), "-l", "1"], cwd=PLUGDIR if mode == "plugin" else td, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stderr + r.stdout)[-1500:]
+        outs[mode] = open(os.path.join(td, "tap_s.htk"), "rb").read()
+        if mode == "plugin":
+            tr = dict(l.split() for l in open(trace) if len(l.split()) == 2)
+            assert int(tr["cMelspec"]) > 0 and int(tr.get("cMelspec.cpu", 0)) == 0
+    assert len(outs["plain"]) > 1000 and outs["plain"] == outs["plugin"]
+    n_out, power, htk, lo, hi = CASES[case]
+    mel = oracle.read_htk(os.path.join(td, "tap_m.htk"))[0]
+    got = oracle.read_htk(os.path.join(td, "tap_s.htk"))[0]
+    ref = oracle.melspec_inverse_rows(mel, n_out, 512 / 16000.0, lo, hi, power, htk)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
