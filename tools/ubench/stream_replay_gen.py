@@ -11,7 +11,8 @@ Compiles opensmile_amd/csrc/lld_<stem>.hip with the Makefile's flags to assembly
   <name>_valu   only the v_* instructions and s_nop, in a counted loop
   <name>_scal   + the scalar ALU instructions, scalar loads and s_waitcnt lgkmcnt (vector memory, LDS, branches, barriers and
                 anything that writes EXEC stay out); --init lines run once per iteration before the stretch (set up the scalar
-                registers the stretch's addresses are built from: s[2:3] holds the pointer argument (1 MB of zeros), s4 the iteration count down, s5 the workgroup index)
+                registers the stretch's addresses are built from; {PTR} = the pointer argument (1 MB of zeros), {CTR} = the iteration
+                count down, {WG} = the workgroup index: registers the stretch leaves alone)
 tools/ubench/stream_replay_run.hip runs them at a given grid / block and prints cycles per vector instruction per SIMD."""
 import json
 import os
@@ -69,6 +70,20 @@ def main():
                 scal.append(f"s_waitcnt lgkmcnt({m.group(1)})")
         elif op.startswith("s_") and not re.match(r"s_(c?branch|barrier|endpgm|setpc|swappc|getpc|call|sleep|sethalt|trap|setprio|memtime|memrealtime|dcache)", op):
             scal.append(t)
+    # housekeeping registers the stretch does not touch: the pointer argument (a pair), the iteration counter, the workgroup index
+    used = set()
+    for t in scal + inits:
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", t):
+            if m.group(3):
+                used.add(int(m.group(3)))
+            else:
+                used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    free = [k for k in range(96, 5, -1) if k not in used]
+    ptr = next(k for k in free if k % 2 == 0 and k + 1 not in used)
+    ctr = next(k for k in free if k not in (ptr, ptr + 1))
+    wg = next(k for k in free if k not in (ptr, ptr + 1, ctr))
+    sub = lambda t: t.replace("{PTR}", f"s[{ptr}:{ptr + 1}]").replace("{CTR}", f"s{ctr}").replace("{WG}", f"s{wg}")
+    inits = [sub(t) for t in inits]
     n_valu = sum(1 for t in valu if t.startswith("v_"))
     info = {"kernel": kernel, "first": first, "last": last, "valu": n_valu, "scalar_alu": sum(1 for t in scal if t.startswith("s_") and not t.startswith("s_load") and not t.startswith("s_waitcnt") and not t.startswith("s_nop")),
             "smem": sum(1 for t in scal if t.startswith("s_load")), "waits": sum(1 for t in scal if t.startswith("s_waitcnt")),
@@ -82,9 +97,9 @@ def main():
 \t.p2align\t8
 \t.type\t{kn},@function
 {kn}:
-\ts_mov_b32 s5, s2
-\ts_load_dword s4, s[0:1], 0x0
-\ts_load_dwordx2 s[2:3], s[0:1], 0x8
+\ts_mov_b32 s{wg}, s2
+\ts_load_dword s{ctr}, s[0:1], 0x0
+\ts_load_dwordx2 s[{ptr}:{ptr + 1}], s[0:1], 0x8
 \ts_waitcnt lgkmcnt(0)
 .Lloop_{kn}:
 ''')
@@ -93,8 +108,8 @@ def main():
                     f.write("\t" + t + "\n")
             for t in ins:
                 f.write("\t" + t + "\n")
-            f.write(f'''\ts_sub_u32 s4, s4, 1
-\ts_cmp_lg_u32 s4, 0
+            f.write(f'''\ts_sub_u32 s{ctr}, s{ctr}, 1
+\ts_cmp_lg_u32 s{ctr}, 0
 \ts_cbranch_scc1 .Lloop_{kn}
 \ts_endpgm
 .Lfunc_end_{kn}:
