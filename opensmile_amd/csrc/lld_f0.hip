@@ -722,7 +722,10 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
   const F0Scratch S = f0_scratch<G>(Q);
   for (int w = 0; w < n_fr; ++w) {
     const int64_t fr = (int64_t)(tile - Q.tile0) * kTileFrames + w;
-    const auto store = [&](int i, float v) { S.mg[f0_b16_index<G>(fr, i)] = v; };
+    // f0_b16_index(fr, i) = the frame's place (wave-uniform: scalar arithmetic) + (i >> 4) * 1024 + (i & 15): 32-bit lane arithmetic
+    // per store instead of the 64-bit index expression per bin
+    float *mg_row = S.mg + (((fr >> 6) * G::kNB16) * 64 + (fr & 63)) * 16;
+    const auto store = [&](int i, float v) { mg_row[((i >> 4) << 10) + (i & 15)] = v; };
     float *keep = Q.mag_keep ? Q.mag_keep + (P.tile_rec[tile].row0 + w) * Q.mag_ld : nullptr;      // (wave-uniform)
     const auto raw = [&](int i, float v) { if (keep) keep[i] = v; };
     double es;
