@@ -829,7 +829,8 @@ __global__ void __launch_bounds__(kSweepWaves * 64) lld_f0_sweep(F0Params Q) {
   using Inner = std::integral_constant<bool, false>;
   // one word of a table line, loaded for the line's sake. The compiler waits for every scalar load of its own before it issues the
   // next one here, so the touches of a block top are issued by hand, all in flight together, and waited for once (the words live in
-  // scalar registers of their own from the load to the wait; nothing reads them)
+  // scalar registers of their own from the load to the wait; nothing reads them -- and nothing may move them in between: the few
+  // instructions between a touch and its wait are address arithmetic only, so the register allocator has no reason to)
   auto touch = [&](ConstD table, int index) -> int {     // (the index is wave-uniform; said so, for the places where the compiler keeps it in a vector register)
     const ConstD line = table + __builtin_amdgcn_readfirstlane(index);
     int v;
