@@ -212,9 +212,16 @@ def _issue_roofline(config, kernel, kernel_ms_per_step, launches_per_step):
         return None
     floor_ms = insts * cpi / 1024.0 / (ghz * 1e6)
     per_launch_ms = kernel_ms_per_step / max(launches_per_step, 1)
-    return {"valu_wave_insts_per_launch": insts, "cycles_per_inst_saturated": cpi, "clock_ghz": ghz, "floor_ms_per_launch": floor_ms,
-            "measured_ms_per_launch": per_launch_ms, "frac": floor_ms / per_launch_ms if per_launch_ms else None,
-            "source": f"{src} (SQ_INSTS_VALU) x profiles/r06_valu_issue_calibration.json"}
+    out = {"valu_wave_insts_per_launch": insts, "cycles_per_inst_saturated": cpi, "clock_ghz": ghz, "floor_ms_per_launch": floor_ms,
+           "measured_ms_per_launch": per_launch_ms, "frac": floor_ms / per_launch_ms if per_launch_ms else None,
+           "source": f"{src} (SQ_INSTS_VALU) x profiles/r06_valu_issue_calibration.json"}
+    # the kernel's OWN instruction stream replayed alone (tools/ubench/stream_replay_gen.py), where it has been: the tight floor
+    rcpi = cal.get("replay_cycles_per_valu_inst", {}).get(kernel)
+    if rcpi:
+        out["replay_cycles_per_inst"] = rcpi
+        out["replay_floor_ms_per_launch"] = insts * rcpi / 1024.0 / (ghz * 1e6)
+        out["replay_frac"] = out["replay_floor_ms_per_launch"] / per_launch_ms if per_launch_ms else None
+    return out
 
 
 def measured_accuracy(config, host_rows, frame_offsets, pcm, sample_offsets, func_rows=None, n_check=32):

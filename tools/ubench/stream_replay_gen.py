@@ -4,7 +4,7 @@ specific to lld_mfcc512, made general): what does the stretch cost when only its
 scalar instructions, scalar loads and their waits come back?
 
     tools/ubench/stream_replay_gen.py <file stem, e.g. f0> <mangled kernel name> <first label> <last label> <outdir> <name>
-                                      [--block N] [--lds BYTES] [--vgprs N] [--init 'asm line' ...]
+                                      [--block N] [--lds BYTES] [--vgprs N] [--valu-only 1] [--init 'asm line' ...]
 
 Compiles opensmile_amd/csrc/lld_<stem>.hip with the Makefile's flags to assembly, takes the kernel's lines from <first label> up to
 (not including) <last label> and writes two code objects (registers as the compiler allocated them: every dependency is the kernel's own):
@@ -88,7 +88,8 @@ def main():
     info = {"kernel": kernel, "first": first, "last": last, "valu": n_valu, "scalar_alu": sum(1 for t in scal if t.startswith("s_") and not t.startswith("s_load") and not t.startswith("s_waitcnt") and not t.startswith("s_nop")),
             "smem": sum(1 for t in scal if t.startswith("s_load")), "waits": sum(1 for t in scal if t.startswith("s_waitcnt")),
             "block": int(opt["--block"]), "lds": int(opt["--lds"]), "vgprs": int(opt["--vgprs"])}
-    for variant, ins in (("valu", valu), ("scal", scal)):
+    variants = (("valu", valu),) if "--valu-only" in opt else (("valu", valu), ("scal", scal))
+    for variant, ins in variants:
         kn = f"{name}_{variant}"
         with open(os.path.join(out, kn + ".s"), "w") as f:
             f.write(f'''\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"

@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
   void *buf;
   CK(hipMalloc(&buf, 1 << 20));
   CK(hipMemset(buf, 0, 1 << 20));
-  for (const char *v : {"valu", "scal"}) {
+  for (const char *v : {"valu", "scal"}) {   // (a missing code object is skipped)
     hipModule_t mod;
     hipFunction_t fn;
     const std::string kn = name + "_" + v;

@@ -53,6 +53,15 @@ def main():
     rep_file = "r06_valu_replay_tuned.json" if os.path.exists(os.path.join(P, "r06_valu_replay_tuned.json")) else "r06_valu_replay.json"
     rep = json.load(open(os.path.join(P, rep_file)))["variants"]
     out["replay_source"] = "profiles/" + rep_file
+    quad_rep = {}
+    qf = os.path.join(P, "r06_stream_replay_quads.json")
+    if os.path.exists(qf):
+        names = {"is09_quad_valu": "lld_is09_frame_quad", "compare_quad_valu": "lld_compare_frame_quad", "frame20_quad_valu": "lld_gemaps_frame20_quad"}
+        for l in open(qf):
+            if l.strip().startswith("{"):
+                j = json.loads(l)
+                if j.get("kernel") in names:
+                    quad_rep[names[j["kernel"]]] = j
     for c in (2, 3, 4, 5):
         a, b = parse(os.path.join(P, f"r06_pmc_c{c}.txt")), parse(os.path.join(P, f"r06_pmc64_c{c}.txt"))
         for k, v in a.items():
@@ -80,6 +89,15 @@ def main():
                 r["replay_note"] = ("tools/ubench/valu_replay_gen.py: the pass loop's own 937 VALU instructions (steady-state path) with the compiler's "
                                     "registers, nothing else, 4 waves per SIMD: %.4f ms per 249 500 passes against the launch's measured time" % rep["base"]["ms_per_bench_launch"])
                 out["cycles_per_valu_inst"][name] = cpi
+            elif name in quad_rep:
+                # the frame loop of a sixteen-lanes-per-frame kernel replayed (tools/ubench/run_stream_replay_quads.sh): its own stream's cost
+                cpi = quad_rep[name]["cycles_per_valu_per_simd"]
+                r["replay_floor_cycles_per_inst"] = cpi
+                r["issue_frac_replay_floor"] = cpi * n / (cycles * N_SIMD)
+                r["replay_note"] = ("tools/ubench/stream_replay_gen.py: the frame loop's %d vector instructions (every block, file order) alone at the "
+                                    "kernel's 3 waves per SIMD; profiles/r06_stream_replay_quads.json" % quad_rep[name]["valu_per_iter"])
+                out["cycles_per_valu_inst"].setdefault(name, floor / n)
+                out.setdefault("replay_cycles_per_valu_inst", {})[name] = cpi
             else:
                 out["cycles_per_valu_inst"].setdefault(name, floor / n)
             out["kernels"].setdefault(f"c{c}:{k}", r)
