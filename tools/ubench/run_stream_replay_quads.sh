@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, via gpurun): tools/ubench/run_stream_replay_quads.sh <tag>  -> gpurun_out/<tag>/stream_replay_quads.json
-# The frame loops of the three sixteen-lanes-per-frame kernels (IS09, ComParE groups A+B, eGeMAPS 20 ms) replayed: their vector
+# The frame loops of the three sixteen-lanes-per-frame kernels (IS09, ComParE groups A+B, eGeMAPS 20 ms) and of lld_f0_spec replayed: their vector
 # instructions alone (every block of the loop in file order; the static count is within 2 - 8 % of the counters' dynamic count per
 # pass), at the kernels' own 3 waves per SIMD -- the issue time their instruction streams need.
 set -u
@@ -20,5 +20,6 @@ done <<'L'
 is09 _ZN8smilehip19lld_is09_frame_quadILi25ELb1EEEvNS_9LldParamsENS_10Is09ParamsE is09_quad
 compare _ZN8smilehip22lld_compare_frame_quadENS_9LldParamsENS_13CompareParamsEi compare_quad
 gemaps _ZN8smilehip23lld_gemaps_frame20_quadILi96EEEvNS_9LldParamsENS_12GemapsParamsEi frame20_quad
+f0 _ZN8smilehip11lld_f0_specILb1ELb1EEEvNS_9LldParamsENS_8F0ParamsE f0_spec
 L
 cat $O/stream_replay_quads.json

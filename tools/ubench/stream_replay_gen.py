@@ -72,13 +72,13 @@ def main():
             scal.append(t)
     # housekeeping registers the stretch does not touch: the pointer argument (a pair), the iteration counter, the workgroup index
     used = set()
-    for t in scal + inits:
+    for t in (valu if "--valu-only" in opt else scal) + inits:
         for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", t):
             if m.group(3):
                 used.add(int(m.group(3)))
             else:
                 used.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    free = [k for k in range(96, 5, -1) if k not in used]
+    free = [k for k in range(100, 5, -1) if k not in used]
     ptr = next(k for k in free if k % 2 == 0 and k + 1 not in used)
     ctr = next(k for k in free if k not in (ptr, ptr + 1))
     wg = next(k for k in free if k not in (ptr, ptr + 1, ctr))

@@ -56,7 +56,7 @@ def main():
     quad_rep = {}
     qf = os.path.join(P, "r06_stream_replay_quads.json")
     if os.path.exists(qf):
-        names = {"is09_quad_valu": "lld_is09_frame_quad", "compare_quad_valu": "lld_compare_frame_quad", "frame20_quad_valu": "lld_gemaps_frame20_quad"}
+        names = {"is09_quad_valu": "lld_is09_frame_quad", "compare_quad_valu": "lld_compare_frame_quad", "frame20_quad_valu": "lld_gemaps_frame20_quad", "f0_spec_valu": "lld_f0_spec"}
         for l in open(qf):
             if l.strip().startswith("{"):
                 j = json.loads(l)
@@ -90,7 +90,7 @@ def main():
                                     "registers, nothing else, 4 waves per SIMD: %.4f ms per 249 500 passes against the launch's measured time" % rep["base"]["ms_per_bench_launch"])
                 out["cycles_per_valu_inst"][name] = cpi
             elif name in quad_rep:
-                # the frame loop of a sixteen-lanes-per-frame kernel replayed (tools/ubench/run_stream_replay_quads.sh): its own stream's cost
+                # the frame loop of a sixteen-lanes-per-frame kernel (or of lld_f0_spec) replayed (tools/ubench/run_stream_replay_quads.sh): its own stream's cost
                 cpi = quad_rep[name]["cycles_per_valu_per_simd"]
                 r["replay_floor_cycles_per_inst"] = cpi
                 r["issue_frac_replay_floor"] = cpi * n / (cycles * N_SIMD)
