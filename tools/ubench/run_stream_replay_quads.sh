@@ -22,4 +22,12 @@ compare _ZN8smilehip22lld_compare_frame_quadENS_9LldParamsENS_13CompareParamsEi 
 gemaps _ZN8smilehip23lld_gemaps_frame20_quadILi96EEEvNS_9LldParamsENS_12GemapsParamsEi frame20_quad
 f0 _ZN8smilehip11lld_f0_specILb1ELb1EEEvNS_9LldParamsENS_8F0ParamsE f0_spec
 L
+# lld_f0_cand9's frame loop without the blocks of the paths the chain does not take (greedyPeakAlgo = 0's scan, the serial mean), 4 waves per SIMD
+asm=$B/stream_co/lld_f0.s
+K9=_ZN8smilehip12lld_f0_cand9ENS_9LldParamsENS_8F0ParamsE
+read first last nv < <(python $R/tools/ubench/find_main_loop.py $asm $K9)
+python $R/tools/ubench/stream_replay_gen.py f0 $K9 $first $last $B/stream_co f0_cand9 --block 64 --lds 0 --vgprs 128 --valu-only 1 \
+    --skip ${CAND9_SKIP:-.LBB0_158,.LBB0_162,.LBB0_166,.LBB0_170,.LBB0_174,.LBB0_178,.LBB0_182,.LBB0_186,.LBB0_284,.LBB0_286} > $O/gen_f0_cand9.log 2>&1
+nvr=$(python -c "import json; print(json.load(open('$B/stream_co/f0_cand9_info.json'))['valu'])")
+$B/stream_replay_run $B/stream_co f0_cand9 4096 64 1000 $nvr | grep "_valu" | sed "s/^{/{\"loop\": \"$first .. $last\", /" >> $O/stream_replay_quads.json
 cat $O/stream_replay_quads.json

@@ -4,7 +4,7 @@ specific to lld_mfcc512, made general): what does the stretch cost when only its
 scalar instructions, scalar loads and their waits come back?
 
     tools/ubench/stream_replay_gen.py <file stem, e.g. f0> <mangled kernel name> <first label> <last label> <outdir> <name>
-                                      [--block N] [--lds BYTES] [--vgprs N] [--valu-only 1] [--init 'asm line' ...]
+                                      [--block N] [--lds BYTES] [--vgprs N] [--valu-only 1] [--skip .LBBa,.LBBb] [--init 'asm line' ...]
 
 Compiles opensmile_amd/csrc/lld_<stem>.hip with the Makefile's flags to assembly, takes the kernel's lines from <first label> up to
 (not including) <last label> and writes two code objects (registers as the compiler allocated them: every dependency is the kernel's own):
@@ -51,7 +51,14 @@ def main():
     i0 = next(i for i, l in enumerate(body) if l.startswith(first + ":"))
     i1 = next(i for i, l in enumerate(body) if l.startswith(last + ":")) if last != "end" else len(body)
     valu, scal = [], []
+    skip = set(x for x in opt.get("--skip", "").split(",") if x)      # labels of blocks the steady state does not execute
+    skipping = False
     for l in body[i0:i1]:
+        ml = re.match(r"^(\.LBB\d+_\d+):", l)
+        if ml:
+            skipping = ml.group(1) in skip
+        if skipping:
+            continue
         t = l.split(";")[0].strip()
         if not t or t.startswith(".") or t.endswith(":"):
             continue

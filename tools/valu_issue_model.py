@@ -56,7 +56,7 @@ def main():
     quad_rep = {}
     qf = os.path.join(P, "r06_stream_replay_quads.json")
     if os.path.exists(qf):
-        names = {"is09_quad_valu": "lld_is09_frame_quad", "compare_quad_valu": "lld_compare_frame_quad", "frame20_quad_valu": "lld_gemaps_frame20_quad", "f0_spec_valu": "lld_f0_spec"}
+        names = {"is09_quad_valu": "lld_is09_frame_quad", "compare_quad_valu": "lld_compare_frame_quad", "frame20_quad_valu": "lld_gemaps_frame20_quad", "f0_spec_valu": "lld_f0_spec", "f0_cand9_valu": "lld_f0_cand9"}
         for l in open(qf):
             if l.strip().startswith("{"):
                 j = json.loads(l)
