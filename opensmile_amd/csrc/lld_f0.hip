@@ -396,12 +396,39 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
         F0_FOR_BINS(m, j) { const float s2 = hv[m] + v[m] * sc; hv[m] = (j < lim) ? s2 : hv[m]; }
       }
     }
-  F0_FOR_BINS(m, j) {
-    float s = hv[m] / (float)Q.n_harm;
-    if (s < 0) s = 0.0f;
-    hv[m] = s;
+  // sum / nHarmonics (pitchShs.cpp:255). The chain's rows are >= +0: there the quotient is formed from the divisor's correctly rounded
+  // reciprocal (one division per frame) by a product and two residual corrections -- five full-rate operations per bin instead of the
+  // division sequence's eleven (one of them a reciprocal) --, the correctly rounded quotient for every mantissa and every divisor
+  // 1 .. 32 (tools/ubench/div_f32_by_const_check.hip: all 2^23 x 32 x 10 exponents equal the division's bits) as long as the
+  // residuals do not underflow: a frame with a value in (0, 2^-100) takes the division (wave-uniform choice).
+  const float nh = (float)Q.n_harm;
+  bool fast_div = false;
+  if constexpr (CHAIN) {
+    bool tiny = false;
+    F0_FOR_BINS(m, j) tiny |= (__float_as_uint(hv[m]) - 1u) < (0x0d800000u - 1u);     // 0 < hv < 2^-100 (hv is never negative here)
+    fast_div = !__any(tiny);
   }
-  F0_FOR_BINS(m, j) if (j < kK) { SS[j] = hv[m]; B[j] = (double)hv[m]; }
+  if (fast_div) {
+    const float y = 1.0f / nh;
+    F0_FOR_BINS(m, j) {
+      const float a = hv[m];
+      const float q0 = a * y;
+      const float r0 = __builtin_fmaf(-q0, nh, a);
+      const float q1 = __builtin_fmaf(r0, y, q0);
+      const float r1 = __builtin_fmaf(-q1, nh, a);
+      float s = __builtin_fmaf(r1, y, q1);
+      if (s < 0) s = 0.0f;
+      hv[m] = s;
+    }
+  } else {
+    F0_FOR_BINS(m, j) {
+      float s = hv[m] / nh;
+      if (s < 0) s = 0.0f;
+      hv[m] = s;
+    }
+  }
+  // (B: the values widened, for the serial mean -- the chain forms it from SS when it needs it, f0_cand_body)
+  F0_FOR_BINS(m, j) if (j < kK) { SS[j] = hv[m]; if constexpr (!CHAIN) B[j] = (double)hv[m]; }
   F0_SUB(2);   // harmonic summation
   if (mean_exact) {
     double part = 0.0;
@@ -1037,6 +1064,9 @@ __device__ __forceinline__ void f0_cand_body(const LldParams &P, const F0Params 
     WaveG::sync();
     PHASE(2);   // rows from global, summation, top six
     if (mean != mean) {                                  // (wave-uniform) no exactness guarantee: the reference's chain
+      const float *SSf = reinterpret_cast<const float *>(A) + kKP;
+      F0_FOR_BINS(m, j) if (j < kK) (A + kKP)[j] = (double)SSf[j];     // (the summation spectrum widened: f0_shs<CHAIN> leaves only the floats)
+      WaveG::sync();
       if (lane == 0) mean = f0_mean_serial<G>(A + kKP);
       mean = wave_first_d(mean);
     }

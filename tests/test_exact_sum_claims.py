@@ -93,3 +93,18 @@ def test_float_division_by_a_known_divisor_in_five_operations(tmp_path):
     out = subprocess.run([exe, "257", "513", "129", "1025", "2049", "3", "1.9999999", "1.0000001", "16777215"], check=True,
                          capture_output=True, text=True).stdout
     assert int(out) == 0
+
+
+def test_float_division_by_the_number_of_harmonics_in_five_operations(tmp_path):
+    """lld_f0_cand's f0_shs (round 6) divides the summation spectrum by nHarmonics the same way -- y = RN(1 / b), a product, two residual
+    corrections -- when no value of the frame lies in (0, 2^-100). Every dividend significand for every divisor 1 .. 32 (the same
+    statement on the device's own instructions, with ten exponents of the dividend: tools/ubench/div_f32_by_const_check.hip,
+    profiles/r06_div_f32_by_const_check.json)."""
+    import os
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "markstein_f32.c")
+    exe = str(tmp_path / "markstein_f32")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe] + [str(b) for b in range(1, 33)], check=True, capture_output=True, text=True).stdout
+    assert int(out) == 0
+
