@@ -224,13 +224,20 @@ __device__ __forceinline__ void compare_frame_quad_body(const LldParams &P, cons
     // ---- R4 forward transform in the reference's operation order, R5 magnitudes (registers)
     oo_quad256<false>(v, OO, z, lane64);
     oo_quad_store(v, z, lane64);
+    // (bins j + 16 m, m < 16: sqrt(re^2 + im^2) through sqrt_rn_batch (lld_device.hpp), bin 0 (j = 0, m = 0) and bin M (j = 0, m = 16): |re|)
     float mv[17];
+    float edge0 = 0.0f;
 #pragma unroll
     for (int m = 0; m < 17; ++m) {
       const int k = j + 16 * m;
-      mv[m] = (k <= kM) ? bin_magnitude(oo_wave_bin<256>(z, OO, k <= kM ? k : 0), k == 0 || k == kM) : 0.0f;
+      const float2 X = oo_wave_bin<256>(z, OO, k <= kM ? k : 0);
+      mv[m] = (m < 16) ? X.x * X.x + X.y * X.y : ((k <= kM) ? fabsf(X.x) : 0.0f);
+      if (m == 0) edge0 = fabsf(X.x);
       if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);
     }
+    if (j == 0) mv[0] = 1.0f;
+    sqrt_rn_batch(reinterpret_cast<float (&)[16]>(mv));
+    if (j == 0) mv[0] = edge0;
     QuadG::sync();                                         // (z has been read)
     QPHASE(2);
     // spectral flux's sum (:1124-1254) while the previous frame's magnitudes are still here; then this frame's take their place

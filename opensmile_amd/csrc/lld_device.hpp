@@ -124,6 +124,33 @@ __device__ __forceinline__ float2 untangle_bin(const float *re, const float *im,
 __device__ __forceinline__ float bin_magnitude(float2 X, bool edge) {
   return edge ? fabsf(X.x) : sqrtf(X.x * X.x + X.y * X.y);
 }
+// sqrtf for an argument in [2^-96, infinity): v_sqrt_f32 and the library sequence's two residual tests, without its scaling of small
+// arguments and its zero / infinity test (16 -> 9 instructions). Equal to sqrtf for every such float
+// (tools/ubench/sqrt_f32_normal_check.hip: all 1.88e9 of them on the device).
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = (0.0f >= rm) ? sm : s;
+  s = (0.0f < rp) ? sp : s;
+  return s;
+}
+// v[m] = sqrtf(v[m]) for a lane's batch: the lean form when every value of every lane of the wave lies in [2^-96, infinity), the
+// library's otherwise (a zero, a tiny or a non-finite value anywhere: one wave-uniform test per batch). Callers put 1.0f where they
+// have no value.
+template <int N>
+__device__ __forceinline__ void sqrt_rn_batch(float (&v)[N]) {
+  bool odd = false;
+#pragma unroll
+  for (int m = 0; m < N; ++m) odd |= (__float_as_uint(v[m]) - 0x0f800000u) >= (0x7f800000u - 0x0f800000u);
+  if (__builtin_amdgcn_ballot_w64(odd) != 0) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) v[m] = sqrtf(v[m]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < N; ++m) v[m] = sqrt_rn_normal(v[m]);
+  }
+}
 
 // smileMath_quadFrom3pts (smileUtil.c:1009-1033)
 __device__ __forceinline__ double quad_vertex(double x1, double y1, double x2, double y2, double x3, double y3, double &y) {

@@ -163,16 +163,27 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
     esum += wave_down_d<8>(esum); esum += wave_down_d<16>(esum); esum += wave_down_d<32>(esum);  //  butterfly, lld_blocks.hpp)
     esum = wave_first_d(esum);
   }
-  F0_FOR_BINS(m, k) {
-    mg[m] = 0.0;
-    if (k < kK) {
-      float2 X;
-      if constexpr (OO && !G::kRegFft) X = ooura_bin(z, T.oo, k);
-      else if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k);
-      else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
-      const float mf = bin_magnitude(X, k == 0 || k == kM);
-      mg[m] = (double)mf;
-      if constexpr (!std::is_same<RawStore, std::nullptr_t>::value) raw_store(k, mf);
+  {
+    // rows m < kPer - 1 are inner bins (sqrt(re^2 + im^2): sqrt_rn_batch, lld_device.hpp) except bin 0 (lane 0, m = 0); the last row
+    // is bin kM for lane 0 alone: |re|
+    float mf[kPer];
+    float edge0 = 0.0f;
+    F0_FOR_BINS(m, k) {
+      float2 X = make_float2(0.0f, 0.0f);
+      if (k < kK) {
+        if constexpr (OO && !G::kRegFft) X = ooura_bin(z, T.oo, k);
+        else if constexpr (OO) X = oo_wave_bin<kM>(z, T.oo, k);
+        else X = fft_untangle<WaveFft<9>>(z, k, T.twf);
+      }
+      mf[m] = (m < kPer - 1) ? X.x * X.x + X.y * X.y : ((k < kK) ? fabsf(X.x) : 0.0f);
+      if (m == 0) edge0 = fabsf(X.x);
+    }
+    if (lane == 0) mf[0] = 1.0f;
+    sqrt_rn_batch(reinterpret_cast<float (&)[kPer - 1]>(mf));
+    if (lane == 0) mf[0] = edge0;
+    F0_FOR_BINS(m, k) {
+      mg[m] = (k < kK) ? (double)mf[m] : 0.0;
+      if constexpr (!std::is_same<RawStore, std::nullptr_t>::value) { if (k < kK) raw_store(k, mf[m]); }
     }
   }
   WaveG::sync();                                         // the transform's buffer reaches into B

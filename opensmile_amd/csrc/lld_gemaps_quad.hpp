@@ -75,12 +75,14 @@ __device__ __forceinline__ void gemaps_frame20_quad_body(const LldParams &P, con
     oo_quad256<false>(v, OO, z, lane64);
     oo_quad_store(v, z, lane64);
     float mv[17];
+    float edge0 = 0.0f;
     float *spec = G.spec220 + (int64_t)(f0 + t) * kRsI;
 #pragma unroll
     for (int m = 0; m < 17; ++m) {
       const int k = j + 16 * m;
       const float2 X = (k <= kM) ? oo_wave_bin<256>(z, OO, k <= kM ? k : 0) : make_float2(0.0f, 0.0f);
-      mv[m] = (k <= kM) ? bin_magnitude(X, k == 0 || k == kM) : 0.0f;
+      mv[m] = (m < 16) ? X.x * X.x + X.y * X.y : ((k <= kM) ? fabsf(X.x) : 0.0f);     // (the roots: sqrt_rn_batch below)
+      if (m == 0) edge0 = fabsf(X.x);
       // what cSpecResample reads of the complex level (Ooura packing, fftsg.c:103-135): (Re, -Im) of bins 1 .. 109, then a[0], one pad
       if (m < 7 && store) {
         if (k == 0) *reinterpret_cast<float2 *>(spec + 2 * kRsB) = make_float2(X.x, 0.0f);
@@ -88,6 +90,9 @@ __device__ __forceinline__ void gemaps_frame20_quad_body(const LldParams &P, con
       }
       if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);
     }
+    if (j == 0) mv[0] = 1.0f;                              // (bin 0 and bin M take |re|; k > M is lanes j > 0 at m = 16 only)
+    sqrt_rn_batch(reinterpret_cast<float (&)[16]>(mv));
+    if (j == 0) mv[0] = edge0;
     QuadG::sync();
     // flux (:1124-1254) over freqRange's bins while the previous frame's magnitudes are here
     double fl = 0.0;

@@ -431,13 +431,21 @@ __device__ __forceinline__ void is09_quad_body(const LldParams &P, const Is09Par
     const int n0 = 2 * i - pad_left, n1 = n0 + 1;
     return make_float2((n0 >= 0 && n0 < N) ? xr[n0] : 0.0f, (n1 >= 0 && n1 < N) ? xr[n1] : 0.0f);
   });
+  // (bins j + 16 m, m < 16, are inner bins -- sqrt(re^2 + im^2) -- except bin 0 (lane row j = 0, m = 0); m = 16 exists for j = 0 only
+  //  and is the edge bin M: |re|. The sixteen square roots go through sqrt_rn_batch, lld_device.hpp.)
   float mv[17];
+  float edge0 = 0.0f;
 #pragma unroll
   for (int m = 0; m < 17; ++m) {
     const int k = j + 16 * m;
-    mv[m] = (k <= M) ? bin_magnitude(oo_wave_bin<256>(z, T.oo, k <= M ? k : 0), k == 0 || k == M) : 0.0f;
+    const float2 X = oo_wave_bin<256>(z, T.oo, k <= M ? k : 0);
+    mv[m] = (m < 16) ? X.x * X.x + X.y * X.y : ((k <= M) ? fabsf(X.x) : 0.0f);
+    if (m == 0) edge0 = fabsf(X.x);
     if (m % 6 == 5) __builtin_amdgcn_sched_barrier(0);     // (six bins' loads in flight at a time: all 17 at once spill)
   }
+  if (j == 0) mv[0] = 1.0f;                                // (bin 0 takes |re|: no root of it is used)
+  sqrt_rn_batch(reinterpret_cast<float (&)[16]>(mv));
+  if (j == 0) mv[0] = edge0;
   QuadG::sync();                                           // (z has been read: the mel terms take its place)
   // R6's terms per bin, straight from the registers (lld_device.hpp: mel_band_from_terms): a[k] = p w, r[k] = p - p w
   {
