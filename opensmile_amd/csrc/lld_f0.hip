@@ -355,12 +355,13 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
 #define F0_SUB_FLUSH
 #endif
   float *hps = reinterpret_cast<float *>(A), *SS = hps + kKP;
+  const float *hps_row = hps_blk ? hps_blk + (((hps_fr >> 6) * G::kNB16) * 64 + (hps_fr & 63)) * 16 : nullptr;
   float hv[kPer];
   F0_FOR_BINS(m, i) {
     hv[m] = 0.0f;
     if (hps_blk) {
       if (i < kK) {
-        hv[m] = hps_blk[f0_b16_index<G>(hps_fr, i)];
+        hv[m] = hps_row[((i >> 4) << 10) + (i & 15)];    // = hps_blk[f0_b16_index(hps_fr, i)]: the frame's (scalar) place + 32-bit lane arithmetic
         if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = hv[m];
       }
     } else if (hps_in) {
