@@ -142,11 +142,17 @@ __device__ __forceinline__ double f0_spectrum(const F0Tbl &T, const F0Params &Q,
   } else {
   // R0 + R3 (gauss) + R12 energy of the windowed frame ([is13_energy60], energy.cpp:152-168); the transform's first pass
   // asks for the inputs it needs (lld_fft.hpp)
+  // (branch-free: a sample outside the frame is read at index 0 and replaced by +0 -- its square adds +0.0 to the sum, which changes
+  //  nothing --, so that the transform's sixteen loads per lane are in flight together instead of each behind its own branch and wait)
   const auto load_pair = [&](int i) {
     const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
-    float a = 0.0f, b = 0.0f;
-    if (n0 >= 0 && n0 < Q.N) { a = x[n0] * T.win[n0]; const float sq = a * a; esum += (double)sq; }
-    if (n1 >= 0 && n1 < Q.N) { b = x[n1] * T.win[n1]; const float sq = b * b; esum += (double)sq; }
+    const bool v0 = n0 >= 0 && n0 < Q.N, v1 = n1 >= 0 && n1 < Q.N;
+    const int c0 = v0 ? n0 : 0, c1 = v1 ? n1 : 0;
+    float a = x[c0] * T.win[c0], b = x[c1] * T.win[c1];
+    a = v0 ? a : 0.0f;
+    b = v1 ? b : 0.0f;
+    { const float sq = a * a; esum += (double)sq; }
+    { const float sq = b * b; esum += (double)sq; }
     return make_float2(a, b);
   };
   if constexpr (OO && !G::kRegFft) {                     // the reference's rdft network in place in LDS (lld_ooura.hpp): any length
