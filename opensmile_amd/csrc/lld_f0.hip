@@ -363,13 +363,21 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
   float *hps = reinterpret_cast<float *>(A), *SS = hps + kKP;
   const float *hps_row = hps_blk ? hps_blk + (((hps_fr >> 6) * G::kNB16) * 64 + (hps_fr & 63)) * 16 : nullptr;
   float hv[kPer];
+  if constexpr (CHAIN) {                                 // (the chain: the row's loads in ONE straight stretch, nothing between them)
+    F0_FOR_BINS(m, i) {
+      const int ic = (i < kK) ? i : 0;
+      const float v = hps_row[((ic >> 4) << 10) + (ic & 15)];
+      hv[m] = (i < kK) ? v : 0.0f;
+    }
+  } else
   F0_FOR_BINS(m, i) {
     hv[m] = 0.0f;
     if (hps_blk) {
-      if (i < kK) {
-        hv[m] = hps_row[((i >> 4) << 10) + (i & 15)];    // = hps_blk[f0_b16_index(hps_fr, i)]: the frame's (scalar) place + 32-bit lane arithmetic
-        if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = hv[m];
-      }
+      // (= hps_blk[f0_b16_index(hps_fr, i)]: the frame's scalar place + 32-bit lane arithmetic; branch-free -- a lane beyond the row reads
+      //  bin 0 and keeps +0 --, so that the row's loads are in flight together instead of each behind its own branch and wait)
+      const int ic = (i < kK) ? i : 0;
+      const float v = hps_row[((ic >> 4) << 10) + (ic & 15)];
+      hv[m] = (i < kK) ? v : 0.0f;               // (the tap's stores: a loop of their own below -- between the loads each would wait for its load)
     } else if (hps_in) {
       if (i < kK) hv[m] = hps_in[i];
     } else if (i < kK) {
@@ -385,6 +393,7 @@ __device__ __forceinline__ int f0_shs(const F0Tbl &T, const F0Params &Q, int lan
       if (Q.hps_tap) Q.hps_tap[g * Q.ld_tap + i] = v;
     }
   }
+  if (hps_blk && Q.hps_tap) { F0_FOR_BINS(m, i) if (i < kK) Q.hps_tap[g * Q.ld_tap + i] = hv[m]; }
   WaveG::sync();
   if (only_scale) return 0;
   F0_SUB(1);   // spline evaluation + auditory weighting
