@@ -848,7 +848,11 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
       if (!(G.pitch3[gn * 3] > 0.0f)) return;
       const float *mi = G.mag60 + gn * G.mag60_ld;
 #pragma unroll
-      for (int m = 0; m < kMagPer; ++m) { const int k = lane_in + 64 * m; mv[m] = k <= kHM ? mi[k] : 0.0f; }
+      for (int m = 0; m < kMagPer; ++m) {                // (branch-free: a load behind a lane condition brings its own branch and wait with it)
+        const int k = lane_in + 64 * m;
+        const float v = mi[k <= kHM ? k : 0];
+        mv[m] = k <= kHM ? v : 0.0f;
+      }
     };
 #pragma unroll
     for (int m = 0; m < kMagPer; ++m) mv[m] = 0.0f;
