@@ -1087,9 +1087,10 @@ __device__ __forceinline__ float sma3(const Sma &s, bool nz, F X) {
   int c = s.clip();
   if (c < 0) c = 0;
   auto I = [&](int i) { return i < 0 ? 0 : (i > c ? c : i); };
-  const float a = X(I(s.n));
+  // (the three values asked for together -- the clamped indices are always rows of the level --, then the cases: a load behind a
+  //  condition brings its own branch and wait with it)
+  const float a = X(I(s.n)), l = X(I(s.n - 1)), r = X(I(s.n + 1));
   if (s.first_exact()) return a;
-  const float l = X(I(s.n - 1)), r = X(I(s.n + 1));
   if (nz) {
     if (a != 0.0f) {
       int N = 1;
@@ -1137,15 +1138,23 @@ __global__ void __launch_bounds__(256) lld_gemaps_tail(const int64_t *frame_off2
   }
   for (int64_t it = threadIdx.x; it < (int64_t)rowsF * 44; it += 256) {
     const int n = (int)(it / 44), c = (int)(it - (int64_t)n * 44);
+    // (a column's source as one pointer and one stride, picked once per item: the three rows' loads are then plain and together)
+    const auto src_of = [&](int q, const float *&ptr, int &stride) {     // q: 0 F0finalLog | 1 jitter | 2 shimmer dB | 3..5 harm6[0..2] | 6.. F(k+1) f, bw, amp
+      if (q == 0) { ptr = p3 + 1; stride = 3; }
+      else if (q == 1) { ptr = j4; stride = 4; }
+      else if (q == 2) { ptr = sdb; stride = 1; }
+      else if (q < 6) { ptr = h6 + (q - 3); stride = 6; }
+      else {
+        const int k = (q - 6) / 3, w = (q - 6) - 3 * k;
+        if (w == 2) { ptr = h6 + 3 + k; stride = 6; }
+        else { ptr = fm + (w == 0 ? k : 5 + k); stride = 10; }
+      }
+    };
     if (c < 15) {                                        // [egemapsv02_lldSetSelectorF] -> [egemapsv02_smoFnz]
       Sma s{T, P, kEoiJitter, n};
-      const float v = sma3(s, true, [&](int i) -> float {
-        if (c == 0) return p3[(int64_t)i * 3 + 1];
-        if (c < 3) return c == 1 ? j4[(int64_t)i * 4] : sdb[i];
-        if (c < 6) return h6[(int64_t)i * 6 + (c - 3)];
-        const int k = (c - 6) / 3, w = (c - 6) - 3 * k;  // F(k+1): frequency, bandwidth, amplitude
-        return w == 0 ? fm[(int64_t)i * 10 + k] : (w == 1 ? fm[(int64_t)i * 10 + 5 + k] : h6[(int64_t)i * 6 + 3 + k]);
-      });
+      const float *ptr; int stride;
+      src_of(c, ptr, stride);
+      const float v = sma3(s, true, [&](int i) -> float { return ptr[(int64_t)i * stride]; });
       o[(int64_t)n * ld + 10 + c] = v;
     } else if (c == 15) {                                // [gemapsv01b_lldSetSelectorLogF0] -> [gemapsv01b_smoF0]
       Sma s{T, P, kEoiLockstep, n};
@@ -1153,25 +1162,26 @@ __global__ void __launch_bounds__(256) lld_gemaps_tail(const int64_t *frame_off2
     } else if (c < 30) {                                 // [gemapsv01b_formantVoiced] + [egemapsv02_lldSetSelectorNoF0LoudnNz]
       const int d = c - 16;
       Sma s{T, P, kEoiJitter, n};
+      const float *ptr; int stride;
+      src_of(d + 1, ptr, stride);                        // (d = 0 jitter ... = the selector F's column d + 1)
+      const bool gated = d >= 5 && ((d - 5) % 3) != 2;   // formant frequency / bandwidth: zero in unvoiced frames
       fin[(int64_t)n * 36 + 7 + d] = sma3(s, true, [&](int i) -> float {
-        if (d < 2) return d == 0 ? j4[(int64_t)i * 4] : sdb[i];
-        if (d < 5) return h6[(int64_t)i * 6 + (d - 2)];
-        const int k = (d - 5) / 3, w = (d - 5) - 3 * k;
-        if (w == 2) return h6[(int64_t)i * 6 + 3 + k];
-        const bool voiced = p3[(int64_t)i * 3 + 1] > (float)0.000001;
-        return voiced ? fm[(int64_t)i * 10 + (w == 0 ? k : 5 + k)] : 0.0f;
+        const float x = ptr[(int64_t)i * stride], f0l = p3[(int64_t)i * 3 + 1];
+        return (!gated || f0l > (float)0.000001) ? x : 0.0f;
       });
     } else if (c < 39) {                                 // [egemapsv02_logSpectralVoiced] + SelectorSpectralNz
       const int d = c - 30;
       Sma s{T, P, kEoiLockstep, n};
       fin[(int64_t)n * 36 + 21 + d] = sma3(s, true, [&](int i) -> float {
-        return (p3[(int64_t)i * 3 + 1] > (float)0.000001) ? raw[(int64_t)i * 12 + spRaw[d]] : 0.0f;
+        const float x = raw[(int64_t)i * 12 + spRaw[d]], f0l = p3[(int64_t)i * 3 + 1];
+        return (f0l > (float)0.000001) ? x : 0.0f;
       });
     } else {                                             // [egemapsv02_logSpectralUnvoiced] + SelectorSpectralZ
       const int d = c - 39;
       Sma s{T, P, kEoiLockstep, n};
       fin[(int64_t)n * 36 + 30 + d] = sma3(s, true, [&](int i) -> float {
-        return (p3[(int64_t)i * 3 + 1] < (float)0.000001) ? raw[(int64_t)i * 12 + spRaw[d]] : 0.0f;
+        const float x = raw[(int64_t)i * 12 + spRaw[d]], f0l = p3[(int64_t)i * 3 + 1];
+        return (f0l < (float)0.000001) ? x : 0.0f;
       });
     }
   }
