@@ -1174,16 +1174,23 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
   const double wLocal = Q.vit_w[0], wTvv = Q.vit_w[1], wTvvd = Q.vit_w[2], wTvuv = Q.vit_w[3], wThr = Q.vit_w[4],
                wRange = Q.vit_w[5];
   const float thr = Q.voicing_cutoff;
+  // Every value of the two rows (21 floats each) this frame reads, asked for at once and without conditions -- clamped indices,
+  // the unused ones ignored: behind their lane conditions the loads were four round trips one after the other, per frame of a
+  // pass that is one dependent chain per utterance.
+  const int lc_i = lane < kNC ? lane : 0;
+  const float my_voice = cur[1 + kNC + lc_i], my_freq = cur[1 + lc_i];   // state `lane`'s voicing probability and frequency (lane < nc)
+  const float to_freq = cur[1 + (si < kNC ? si : 0)];                      // the transition's end (state si of this frame)
+  const float from_freq = (t > 0 ? prev : cur)[1 + (sj < kNC ? sj : 0)];   // and its start (state sj of the frame before)
+  const unsigned long long voiced_mask = __ballot(lane < nc && my_voice >= thr);
   double lc = 0.0;                                       // localCost of state `lane`
   if (lane < nc) {
-    double pv = (double)cur[1 + kNC + lane], tc = 0.0;
+    double pv = (double)my_voice, tc = 0.0;
     if (pv < 0.01) pv = 0.01;
     if (pv > 1.00) pv = 1.00;
     if (pv < thr) tc = wThr;
-    lc = (-log(pv) + tc) * wLocal + f_weight(cur[1 + lane]) * wRange;
+    lc = (-log(pv) + tc) * wLocal + f_weight(my_freq) * wRange;
   } else if (lane == nc) {
-    double flag = 0.0;
-    for (int c = 0; c < nc; ++c) if (cur[1 + kNC + c] >= thr) { flag = wThr; break; }
+    double flag = voiced_mask ? wThr : 0.0;              // (any candidate's voicing probability at or above the threshold)
     if (flag == 0.0 && 0.0f >= thr) flag = wThr;         // frame[13] of the reference's buffer is 0
     lc = wLocal * flag;
   }
@@ -1192,8 +1199,7 @@ __device__ __forceinline__ void vit_frame(const F0Params &Q, const float *cur, c
     __syncthreads();
   } else {
     const bool vv = valid && si < nc && sj < nc;
-    float fa = 0.0f, fb2 = 0.0f;
-    if (vv) { fa = prev[1 + sj]; fb2 = cur[1 + si]; }
+    const float fa = vv ? from_freq : 0.0f, fb2 = vv ? to_freq : 0.0f;
     const bool zero = vv && (fa == 0 || fb2 == 0);
     const bool modr = vv && !zero;
     const bool mod0 = valid && ((si == nc) != (sj == nc));
