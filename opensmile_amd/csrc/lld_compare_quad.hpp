@@ -101,7 +101,9 @@ __device__ __forceinline__ void hop_counts(const int16_t *xu, int base, int len,
 #pragma unroll
   for (int m = 0; m < 11; ++m) {
     const int i = base + j + 16 * m;
-    b[m] = (i >= 0 && i < len) ? pcm16_to_float(xu[i]) : 0.0f;
+    const bool in = i >= 0 && i < len;                     // (branch-free: a load behind the condition waits alone, eleven times per hop)
+    const float v = pcm16_to_float(xu[in ? i : 0]);
+    b[m] = in ? v : 0.0f;
   }
   int c2 = 0, cr = 0;
 #pragma unroll

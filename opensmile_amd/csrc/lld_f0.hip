@@ -1286,9 +1286,11 @@ __global__ void __launch_bounds__(64) lld_f0_viterbi(const int64_t *frame_off, i
   auto emit = [&](int n, int s, int) {
     const int64_t row = fo + n;
     const float *fr = S + (int64_t)n * 21;
-    float f = (s < Q.n_cand) ? fr[1 + s] : 0.0f;
-    float vp = (s < Q.n_cand) ? fr[1 + kNC + s] : fr[1 + kNC];
-    if (!(Q.e60[row] > Q.min_energy)) { f = 0.0f; vp = 0.0f; }     // cValbasedSelector, zeroVec
+    const int sc = (s < Q.n_cand) ? s : 0;               // (the unvoiced state reads candidate 0's voicing probability; its frequency is 0)
+    const float f_in = fr[1 + sc], vp_in = fr[1 + kNC + sc], e_in = Q.e60[row];   // (three loads together, no conditions)
+    float f = (s < Q.n_cand) ? f_in : 0.0f;
+    float vp = vp_in;
+    if (!(e_in > Q.min_energy)) { f = 0.0f; vp = 0.0f; }     // cValbasedSelector, zeroVec
     out[row * ld] = f;
     if (Q.vit_log_out) {
       // F0finalLog (pitchSmootherViterbi.cpp:497-505): semitones above 27.5 Hz, float arithmetic throughout; the

@@ -882,8 +882,10 @@ __global__ void __launch_bounds__(HarmG<LOGM>::kWaves * 64) lld_gemaps_harm(LldP
         const PcmIn x = pcm_in(P) + (samp0 + (int64_t)tf * Q.H);
         const auto load_pair = [&](int i) {
           const int n0 = 2 * i - Q.pad_left, n1 = n0 + 1;
-          return make_float2((n0 >= 0 && n0 < Q.N) ? x[n0] * c_win[n0] : 0.0f,
-                             (n1 >= 0 && n1 < Q.N) ? x[n1] * c_win[n1] : 0.0f);
+          const bool v0 = n0 >= 0 && n0 < Q.N, v1 = n1 >= 0 && n1 < Q.N;      // (branch-free: see lld_f0.hip's load_pair)
+          const int c0 = v0 ? n0 : 0, c1 = v1 ? n1 : 0;
+          const float a = x[c0] * c_win[c0], b = x[c1] * c_win[c1];
+          return make_float2(v0 ? a : 0.0f, v1 ? b : 0.0f);
         };
         if constexpr (LOGM == 9) {
           if (OO.tw) oo_wave_forward<kMC>(z, OO, lane, load_pair);
