@@ -207,7 +207,21 @@ __device__ __forceinline__ bool jit_frame(const F0Params &Q, const JitLds &L, co
   long start = 0, lastPeriod = 0;
   if (F0 > 0.0f) {
     __syncthreads();
-    for (long i = tid; i < nT; i += kJitThreads) wv[i] = (JitSample)x[lastIdx + i];
+    // (eight strides' loads in flight together -- indices clamped into the frame, the surplus not written --: one at a time each
+    //  load was a round trip of its own, twenty per voiced frame)
+    {
+      const auto fill = [&](auto sample) {
+        for (long i0 = tid; i0 < nT; i0 += 8 * kJitThreads) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const long i = i0 + (long)q * kJitThreads; v[q] = sample(lastIdx + (i < nT ? i : nT - 1)); }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const long i = i0 + (long)q * kJitThreads; if (i < nT) wv[i] = (JitSample)v[q]; }
+        }
+      };
+      if (x.f) fill([&](long n) { return x.f[n]; });
+      else fill([&](long n) { return pcm16_to_float(x.s[n]); });
+    }
     for (long i = tid; i <= T0f; i += kJitThreads) avgWf[i] = 0.0f;
     __syncthreads();
     PH(0);   // frame set-up + wave load
