@@ -32,6 +32,12 @@ struct PcmIn {
 };
 
 // the same accessor for kernels instantiated for 16-bit input alone (no pointer test at the loads, two registers less)
+// (and for 32-bit float input alone: the generic accessor's pointer test sits in front of EVERY load, and a load behind a branch waits alone)
+struct PcmF32In {
+  const float *f;
+  __device__ __forceinline__ float operator[](int64_t n) const { return f[n]; }
+  __device__ __forceinline__ PcmF32In operator+(int64_t o) const { PcmF32In r; r.f = f + o; return r; }
+};
 struct Pcm16In {
   const int16_t *s;
   __device__ __forceinline__ float operator[](int64_t n) const { return pcm16_to_float(s[n]); }

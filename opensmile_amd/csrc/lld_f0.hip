@@ -784,7 +784,8 @@ __device__ __forceinline__ void f0_spec_body(const LldParams &P, const F0Params 
     const auto raw = [&](int i, float v) { if (keep) keep[i] = v; };
     double es;
     if constexpr (S16) es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
-    else es = f0_spectrum<G, OO>(T, Q, pcm_in(P) + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
+    else if (P.pcm_f32) es = f0_spectrum<G, OO, PcmF32In>(T, Q, PcmF32In{P.pcm_f32} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
+    else es = f0_spectrum<G, OO, Pcm16In>(T, Q, Pcm16In{P.pcm} + (samp0 + (int64_t)w * Q.H), nullptr, lane, A, A + kKP, store, raw);
     if (lane == 0) S.es[fr] = es;
     WaveG::sync();
   }
