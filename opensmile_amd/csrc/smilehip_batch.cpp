@@ -740,11 +740,12 @@ static int compare_full_run(smilehip_plan *plan, smilehip_batch *b, const int16_
   int rc = f0_run(plan->f0_plan, fb, d_pcm, b->d_pitch2.p, 2, stream, false, plan->ev_fork);
   if (rc) return rc;
   if (fb->total_frames == 0) HIP_TRY(hipEventRecord(plan->ev_fork, s));
-  // One stream for a batch that fills the device on its own (>= 4 M frames: every kernel is then many rounds of workgroups, and
-  // running two of them side by side only makes them share the caches: config 4 315 -> 313 ms, config 5 1266 -> 1239 ms); the
-  // side streams for smaller batches, whose one-wave-per-utterance passes leave most of the device idle (500 x 10 s: 32.8 -> 28.5 ms).
-  // SMILEHIP_SERIAL=1 / =0 forces one or the other (measurement aid: a kernel trace of the serial form shows each kernel alone).
-  const bool serial = serial_streams(b->total_frames);
+  // Small batches: the one-wave-per-utterance passes leave most of the device idle (500 x 10 s: 32.8 -> 28.5 ms with the side stream).
+  // Batches that fill the device on their own: rounds 3-5 measured one stream a hair faster (config 4 315 -> 313 ms); with round 6's
+  // kernels the side stream is (217.5 / 218.1 / 218.9 ms on one stream, 216.6 / 217.7 / 217.5 beside: groups A+B fill the tails of the
+  // Viterbi and jitter passes), so this chain always forks. The eGeMAPS chain keeps the threshold (config 5: 1012.5 on one stream, 1028.9
+  // forked, 1029 with the 20 ms chain alone forked beside the Viterbi pass: profiles/r06_streams_ab.txt). SMILEHIP_SERIAL=1 forces one stream (a kernel trace then shows each kernel alone).
+  const bool serial = serial_forced();
   hipStream_t side = serial ? s : plan->side_stream;
   HIP_TRY(hipStreamWaitEvent(side, plan->ev_fork, 0));
   if ((rc = compare_run(plan, b, d_pcm, d_out + 6, ld_out, side, 65))) return rc;
